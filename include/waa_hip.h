@@ -1,0 +1,240 @@
+/*
+ * waa_hip.h — C ABI of the MI355X batched offline render engine.
+ *
+ * One `waa_batch` = N independent, identically-shaped OfflineAudioContexts
+ * ("instances") rendered together on one GPU.  The entry points replace, for the
+ * per-quantum DSP path only, what a Rust FFI shim would bind behind these
+ * reference interfaces (paths relative to the reference crate web-audio-api 1.6.0):
+ *
+ *   waa_batch_create            OfflineAudioContext::new                     src/context/offline.rs:78-143
+ *                               + ConcreteBaseAudioContext::register          src/context/concrete_base.rs:232-270
+ *                               + AudioNode::connect (ControlMessage::ConnectNode) src/node/audio_node.rs:247-289
+ *   waa_source_set_buffer*      AudioBufferSourceNode::set_buffer             src/node/audio_buffer_source.rs:853-866 (onmessage)
+ *   waa_source_start/stop/loop  AudioBufferSourceNode::start_at_with_offset_and_duration / stop_at / set_loop*
+ *                                                                             src/node/audio_buffer_source.rs:388-398
+ *   waa_convolver_set_buffer    ConvolverNode::set_buffer                     src/node/convolver.rs:259-317
+ *   waa_waveshaper_set_curve    WaveShaperNode::set_curve                     src/node/waveshaper.rs:489-509 (onmessage)
+ *   waa_set_param_const/block   AudioParamValues::get (len 1 / len 128)       src/render/processor.rs:186-229
+ *                               (the automation timeline itself stays on the host: src/param.rs:685-797)
+ *   waa_render                  OfflineAudioContext::start_rendering_sync     src/context/offline.rs:157-185
+ *                               -> RenderThread::render_audiobuffer_sync      src/render/thread.rs:260-302
+ *                               -> Graph::render                              src/render/graph.rs:490-591
+ *                               -> every AudioProcessor::process              src/render/processor.rs:113-139
+ *   waa_download*               AudioBuffer returned by start_rendering_sync  src/render/thread.rs:384-395
+ *   waa_analyser_*              AnalyserNode::get_*_data                      src/node/analyser.rs:228-258, src/analysis.rs:261-401
+ *
+ * Conventions: plain pointers and sizes only; every pointer argument is caller-owned
+ * and copied before the call returns (except *_adopt_device, documented below); every
+ * call returns a waa_status (0 = ok) and leaves a message readable with
+ * waa_last_error() (thread-local).  A batch is single-threaded; different batches are
+ * independent (one per GPU for multi-GPU sharding, no collectives).
+ *
+ * The oracle (oracle/waa_oracle.c, test infrastructure only) exports the same entry
+ * points with the prefix orc_ so the parity tests can drive both with one harness.
+ */
+#ifndef WAA_HIP_H
+#define WAA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WAA_RENDER_QUANTUM_SIZE 128 /* src/lib.rs:18 */
+#define WAA_MAX_CHANNELS 32         /* src/lib.rs:21 */
+#define WAA_ALL_INSTANCES 0xFFFFFFFFu
+
+typedef struct waa_batch waa_batch;
+typedef int32_t waa_status;
+
+enum {
+  WAA_OK = 0,
+  WAA_ERR_INVALID_ARGUMENT = 1, /* reference: assert!/panic with "…Error - …" message */
+  WAA_ERR_NOT_SUPPORTED = 2,    /* reference: "NotSupportedError - …"                 */
+  WAA_ERR_INVALID_STATE = 3,    /* reference: "InvalidStateError - …"                 */
+  WAA_ERR_OUT_OF_SCOPE = 4,     /* legal in the reference, not on this hot path (HRTF, oversampling, cycles, …) */
+  WAA_ERR_DEVICE = 5            /* HIP runtime failure                                 */
+};
+
+/* Node kinds: one per *Renderer on the path. */
+enum {
+  WAA_NODE_DESTINATION = 0,     /* src/node/destination.rs:140-163   */
+  WAA_NODE_BUFFER_SOURCE = 1,   /* src/node/audio_buffer_source.rs:422-845 */
+  WAA_NODE_BIQUAD = 2,          /* src/node/biquad_filter.rs:764-899 */
+  WAA_NODE_GAIN = 3,            /* src/node/gain.rs:143-199          */
+  WAA_NODE_CONVOLVER = 4,       /* src/node/convolver.rs:343-490     */
+  WAA_NODE_STEREO_PANNER = 5,   /* src/node/stereo_panner.rs:218-317 */
+  WAA_NODE_PANNER = 6,          /* src/node/panner.rs:685-904 (equal-power only) */
+  WAA_NODE_ANALYSER = 7,        /* src/node/analyser.rs:265-290      */
+  WAA_NODE_WAVESHAPER = 8,      /* src/node/waveshaper.rs:383-487 (oversample None only) */
+  WAA_NODE_CONSTANT_SOURCE = 9, /* src/node/constant_source.rs:190-275 */
+  WAA_NODE_KIND_COUNT = 10
+};
+
+/* src/node/audio_node.rs ChannelCountMode / ChannelInterpretation */
+enum { WAA_COUNT_MODE_MAX = 0, WAA_COUNT_MODE_CLAMPED_MAX = 1, WAA_COUNT_MODE_EXPLICIT = 2 };
+enum { WAA_INTERP_SPEAKERS = 0, WAA_INTERP_DISCRETE = 1 };
+
+/* src/node/biquad_filter.rs:376-404 BiquadFilterType (same order) */
+enum {
+  WAA_BIQUAD_LOWPASS = 0, WAA_BIQUAD_HIGHPASS = 1, WAA_BIQUAD_BANDPASS = 2, WAA_BIQUAD_NOTCH = 3,
+  WAA_BIQUAD_ALLPASS = 4, WAA_BIQUAD_PEAKING = 5, WAA_BIQUAD_LOWSHELF = 6, WAA_BIQUAD_HIGHSHELF = 7
+};
+/* src/node/panner.rs PanningModelType / DistanceModelType */
+enum { WAA_PANNING_EQUALPOWER = 0, WAA_PANNING_HRTF = 1 };
+enum { WAA_DISTANCE_LINEAR = 0, WAA_DISTANCE_INVERSE = 1, WAA_DISTANCE_EXPONENTIAL = 2 };
+/* src/node/waveshaper.rs OverSampleType */
+enum { WAA_OVERSAMPLE_NONE = 0, WAA_OVERSAMPLE_X2 = 1, WAA_OVERSAMPLE_X4 = 2 };
+
+/* AudioParam ids, per node kind (the reference has one AudioParamId per param node). */
+enum { WAA_PARAM_BIQUAD_FREQUENCY = 0, WAA_PARAM_BIQUAD_DETUNE = 1, WAA_PARAM_BIQUAD_Q = 2, WAA_PARAM_BIQUAD_GAIN = 3 };
+enum { WAA_PARAM_GAIN_GAIN = 0 };
+enum { WAA_PARAM_SOURCE_PLAYBACK_RATE = 0, WAA_PARAM_SOURCE_DETUNE = 1 };
+enum { WAA_PARAM_STEREO_PANNER_PAN = 0 };
+enum { WAA_PARAM_CONSTANT_OFFSET = 0 };
+enum {
+  WAA_PARAM_PANNER_POSITION_X = 0, WAA_PARAM_PANNER_POSITION_Y = 1, WAA_PARAM_PANNER_POSITION_Z = 2,
+  WAA_PARAM_PANNER_ORIENTATION_X = 3, WAA_PARAM_PANNER_ORIENTATION_Y = 4, WAA_PARAM_PANNER_ORIENTATION_Z = 5,
+  /* the AudioListener's 9 params (src/spatial.rs:127-144) are addressed through any panner node */
+  WAA_PARAM_LISTENER_POSITION_X = 6, WAA_PARAM_LISTENER_POSITION_Y = 7, WAA_PARAM_LISTENER_POSITION_Z = 8,
+  WAA_PARAM_LISTENER_FORWARD_X = 9, WAA_PARAM_LISTENER_FORWARD_Y = 10, WAA_PARAM_LISTENER_FORWARD_Z = 11,
+  WAA_PARAM_LISTENER_UP_X = 12, WAA_PARAM_LISTENER_UP_Y = 13, WAA_PARAM_LISTENER_UP_Z = 14
+};
+#define WAA_MAX_PARAMS 15
+
+/*
+ * Static per-node configuration (the *Options structs of the reference).
+ *   channel_count / _mode / _interpretation : AudioNodeOptions (0 in channel_count = kind default)
+ *   i[] / d[] by kind:
+ *     BIQUAD      i[0] = filter type
+ *     PANNER      i[0] = panning model, i[1] = distance model,
+ *                 d[0] ref_distance, d[1] max_distance, d[2] rolloff_factor,
+ *                 d[3] cone_inner_angle, d[4] cone_outer_angle, d[5] cone_outer_gain
+ *     ANALYSER    i[0] = fft_size, d[0] smoothing_time_constant, d[1] min_decibels, d[2] max_decibels
+ *     WAVESHAPER  i[0] = oversample
+ *     CONVOLVER   i[0] = disable_normalization (0/1)
+ */
+typedef struct {
+  uint32_t kind;
+  uint32_t channel_count;
+  uint32_t channel_count_mode;
+  uint32_t channel_interpretation;
+  int32_t i[4];
+  double d[8];
+} waa_node_desc;
+
+/* AudioNode::connect_from_output_to_input(from, output, to, input); mirrors graph.rs Edge. */
+typedef struct {
+  uint32_t from;
+  uint32_t from_output;
+  uint32_t to;
+  uint32_t to_input;
+} waa_edge_desc;
+
+/* Node 0 must be the destination (DESTINATION_NODE_ID, src/context/mod.rs:24). */
+typedef struct {
+  uint32_t n_nodes;
+  const waa_node_desc* nodes;
+  uint32_t n_edges;
+  const waa_edge_desc* edges;
+} waa_graph_desc;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+
+/* device < 0: current HIP device.  length_frames / sample_rate / n_channels_out as in
+ * OfflineAudioContext::new(number_of_channels, length, sample_rate). */
+waa_status waa_batch_create(const waa_graph_desc* graph, uint32_t n_instances, uint32_t n_channels_out,
+                            uint64_t length_frames, float sample_rate, int32_t device, waa_batch** out);
+void waa_batch_destroy(waa_batch* batch);
+const char* waa_last_error(void);
+/* number of visible HIP devices (0 if none / runtime unavailable) */
+int32_t waa_device_count(void);
+
+/* ---- node payloads --------------------------------------------------------------------- */
+
+/* AudioBuffer for one instance (or WAA_ALL_INSTANCES: the same buffer shared by all, like a
+ * cloned Arc<Vec<f32>>). channels[c] points at `frames` f32. */
+waa_status waa_source_set_buffer(waa_batch* batch, uint32_t node, uint32_t instance, const float* const* channels,
+                                 uint32_t n_channels, uint64_t frames, float buffer_sample_rate);
+/* Whole batch at once: data laid out [instance][channel][frame], distinct per instance. */
+waa_status waa_source_set_buffer_batch(waa_batch* batch, uint32_t node, const float* data, uint32_t n_channels,
+                                       uint64_t frames, float buffer_sample_rate);
+/* Zero-copy: `device_data` is a device pointer with the same [instance][channel][frame] layout that
+ * must stay valid until the batch is destroyed (bench: inputs resident in HBM). */
+waa_status waa_source_adopt_device(waa_batch* batch, uint32_t node, const float* device_data, uint32_t n_channels,
+                                   uint64_t frames, float buffer_sample_rate);
+/* AudioScheduledSourceNode::start_at_with_offset_and_duration(when, offset, duration);
+ * duration = DBL_MAX for "none" (the reference stores f64::MAX). */
+waa_status waa_source_start(waa_batch* batch, uint32_t node, uint32_t instance, double when, double offset,
+                            double duration);
+waa_status waa_source_stop(waa_batch* batch, uint32_t node, uint32_t instance, double when);
+waa_status waa_source_set_loop(waa_batch* batch, uint32_t node, uint32_t instance, int32_t is_looping,
+                               double loop_start, double loop_end);
+
+/* Impulse response shared by all instances. sample_rate must equal the context's
+ * (NotSupportedError otherwise), n_channels in {1,2,4}. */
+waa_status waa_convolver_set_buffer(waa_batch* batch, uint32_t node, const float* const* channels,
+                                    uint32_t n_channels, uint64_t frames, float sample_rate);
+waa_status waa_waveshaper_set_curve(waa_batch* batch, uint32_t node, const float* curve, uint32_t n);
+
+/* ---- AudioParam values (computed by the host-side automation) -------------------------- */
+
+waa_status waa_set_param_const(waa_batch* batch, uint32_t node, uint32_t param, uint32_t instance, float value);
+/* values: n_quanta * values_per_quantum f32, values_per_quantum in {1, 128}; applies to quanta
+ * [quantum0, quantum0 + n_quanta); quanta not covered keep the constant value. */
+waa_status waa_set_param_block(waa_batch* batch, uint32_t node, uint32_t param, uint32_t instance,
+                               uint64_t quantum0, uint32_t n_quanta, uint32_t values_per_quantum,
+                               const float* values);
+
+/* ---- render ---------------------------------------------------------------------------- */
+
+/* start_rendering_sync for every instance: renders all ceil(length/128) quanta. Asynchronous on the
+ * batch's stream; waa_download / waa_download_all / waa_sync wait for it. */
+waa_status waa_render(waa_batch* batch);
+waa_status waa_sync(waa_batch* batch);
+/* rendered AudioBuffer channel of one instance -> dst[frames] (frames <= length) */
+waa_status waa_download(waa_batch* batch, uint32_t instance, uint32_t channel, float* dst, uint64_t frames);
+/* all instances: dst laid out [instance][channel][length_frames] */
+waa_status waa_download_all(waa_batch* batch, float* dst);
+/* device pointer + strides (in floats) of the rendered output, valid until destroy */
+waa_status waa_output_device(waa_batch* batch, const float** device_ptr, uint64_t* instance_stride,
+                             uint64_t* channel_stride);
+
+/* ---- analyser (control-side pulls after the render; current_time = end of render) ------ */
+waa_status waa_analyser_get_float_frequency_data(waa_batch* batch, uint32_t node, uint32_t instance, float* dst,
+                                                 uint32_t n);
+waa_status waa_analyser_get_byte_frequency_data(waa_batch* batch, uint32_t node, uint32_t instance, uint8_t* dst,
+                                                uint32_t n);
+waa_status waa_analyser_get_float_time_domain_data(waa_batch* batch, uint32_t node, uint32_t instance, float* dst,
+                                                   uint32_t n);
+waa_status waa_analyser_get_byte_time_domain_data(waa_batch* batch, uint32_t node, uint32_t instance, uint8_t* dst,
+                                                  uint32_t n);
+
+/* ---- input prep + pure helpers (no batch) ---------------------------------------------- */
+
+/* AudioBuffer::resample (src/buffer.rs:311-363): returns the target length; writes at most dst_capacity
+ * frames to dst (call with dst = NULL to query the length). */
+uint64_t waa_buffer_resample(const float* src, uint64_t frames, float source_sample_rate, float target_sample_rate,
+                             float* dst, uint64_t dst_capacity);
+/* BiquadFilterNode::get_frequency_response (src/node/biquad_filter.rs:670-735) */
+waa_status waa_biquad_frequency_response(int32_t type, float sample_rate, float frequency, float detune, float q,
+                                         float gain, const float* frequency_hz, float* mag, float* phase,
+                                         uint32_t n);
+
+/* ---- measurement ----------------------------------------------------------------------- */
+
+/* When enabled, every kernel launch of waa_render is bracketed by HIP events on the batch's
+ * stream; after waa_sync the per-kernel totals can be read back. */
+waa_status waa_profile_enable(waa_batch* batch, int32_t on);
+int32_t waa_profile_count(waa_batch* batch);
+/* name: kernel label, launches: number of launches since the last reset, total_ms: sum of durations */
+waa_status waa_profile_get(waa_batch* batch, int32_t index, const char** name, uint64_t* launches,
+                           double* total_ms);
+waa_status waa_profile_reset(waa_batch* batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAA_HIP_H */

@@ -1,0 +1,755 @@
+"""Host-side mirror of the reference's control API for the offline render path.
+
+The names follow the reference crate (web-audio-api 1.6.0):
+
+* ``OfflineAudioContext(number_of_channels, length, sample_rate)``  src/context/offline.rs:78
+* ``create_buffer_source / create_biquad_filter / create_gain / create_convolver /
+  create_stereo_panner / create_panner / create_analyser / create_wave_shaper /
+  create_constant_source``                                         src/context/base.rs:23-367
+* ``AudioNode.connect``                                            src/node/audio_node.rs:247-289
+* ``AudioScheduledSourceNode.start/start_at/stop/stop_at``         src/node/scheduled_source.rs:6-44
+* ``AudioParam.value / set_value``                                 src/param.rs:268-662
+* ``start_rendering_sync``                                         src/context/offline.rs:157-185
+
+The one extension is ``n_instances``: a context object stands for a *batch* of N
+identically shaped OfflineAudioContexts rendered together by one ``waa_batch``
+(include/waa_hip.h).  Per-instance payloads are addressed with ``instance=k``.
+
+This module only talks to a C-ABI library through ctypes.  Which library is decided by
+the caller (``bind(lib, prefix)``): the product binds ``libwaa_hip.so`` with prefix
+``waa_`` (see __init__.py); the tests may bind the CPU oracle with prefix ``orc_``.
+Nothing in this package imports or loads the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+RENDER_QUANTUM_SIZE = 128
+ALL = 0xFFFFFFFF
+F64_MAX = 1.7976931348623157e308
+
+# node kinds / enums (include/waa_hip.h)
+NODE_DESTINATION, NODE_BUFFER_SOURCE, NODE_BIQUAD, NODE_GAIN, NODE_CONVOLVER = 0, 1, 2, 3, 4
+NODE_STEREO_PANNER, NODE_PANNER, NODE_ANALYSER, NODE_WAVESHAPER, NODE_CONSTANT_SOURCE = 5, 6, 7, 8, 9
+COUNT_MODE = {"max": 0, "clamped-max": 1, "explicit": 2}
+INTERPRETATION = {"speakers": 0, "discrete": 1}
+BIQUAD_TYPE = {"lowpass": 0, "highpass": 1, "bandpass": 2, "notch": 3, "allpass": 4, "peaking": 5,
+               "lowshelf": 6, "highshelf": 7}
+PANNING_MODEL = {"equalpower": 0, "HRTF": 1}
+DISTANCE_MODEL = {"linear": 0, "inverse": 1, "exponential": 2}
+OVERSAMPLE = {"none": 0, "2x": 1, "4x": 2}
+
+
+class WaaError(RuntimeError):
+    """Raised where the reference panics (the message keeps the W3C error name)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+class NodeDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("channel_count", C.c_uint32), ("channel_count_mode", C.c_uint32),
+                ("channel_interpretation", C.c_uint32), ("i", C.c_int32 * 4), ("d", C.c_double * 8)]
+
+
+class EdgeDesc(C.Structure):
+    _fields_ = [("from_", C.c_uint32), ("from_output", C.c_uint32), ("to", C.c_uint32), ("to_input", C.c_uint32)]
+
+
+class GraphDesc(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("nodes", C.POINTER(NodeDesc)), ("n_edges", C.c_uint32),
+                ("edges", C.POINTER(EdgeDesc))]
+
+
+_FP = C.POINTER(C.c_float)
+_FPP = C.POINTER(_FP)
+_VP = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/waa_hip.h declares
+ABI = {
+    "batch_create": (C.c_int32, [C.POINTER(GraphDesc), C.c_uint32, C.c_uint32, C.c_uint64, C.c_float, C.c_int32,
+                                 C.POINTER(_VP)]),
+    "batch_destroy": (None, [_VP]),
+    "last_error": (C.c_char_p, []),
+    "device_count": (C.c_int32, []),
+    "source_set_buffer": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FPP, C.c_uint32, C.c_uint64, C.c_float]),
+    "source_set_buffer_batch": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32, C.c_uint64, C.c_float]),
+    "source_adopt_device": (C.c_int32, [_VP, C.c_uint32, _VP, C.c_uint32, C.c_uint64, C.c_float]),
+    "source_start": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]),
+    "source_stop": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_double]),
+    "source_set_loop": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_int32, C.c_double, C.c_double]),
+    "convolver_set_buffer": (C.c_int32, [_VP, C.c_uint32, _FPP, C.c_uint32, C.c_uint64, C.c_float]),
+    "waveshaper_set_curve": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32]),
+    "set_param_const": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
+    "set_param_block": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
+    "render": (C.c_int32, [_VP]),
+    "sync": (C.c_int32, [_VP]),
+    "download": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FP, C.c_uint64]),
+    "download_all": (C.c_int32, [_VP, _FP]),
+    "output_device": (C.c_int32, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "analyser_get_float_frequency_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FP, C.c_uint32]),
+    "analyser_get_byte_frequency_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32]),
+    "analyser_get_float_time_domain_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FP, C.c_uint32]),
+    "analyser_get_byte_time_domain_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32]),
+    "buffer_resample": (C.c_uint64, [_FP, C.c_uint64, C.c_float, C.c_float, _FP, C.c_uint64]),
+    "biquad_frequency_response": (C.c_int32, [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _FP,
+                                              _FP, _FP, C.c_uint32]),
+    "profile_enable": (C.c_int32, [_VP, C.c_int32]),
+    "profile_count": (C.c_int32, [_VP]),
+    "profile_get": (C.c_int32, [_VP, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "profile_reset": (C.c_int32, [_VP]),
+}
+
+
+class Binding:
+    """ctypes view of one C-ABI library (prefix ``waa_`` for the product)."""
+
+    def __init__(self, lib: C.CDLL, prefix: str):
+        self.lib = lib
+        self.prefix = prefix
+        for name, (restype, argtypes) in ABI.items():
+            fn = getattr(lib, prefix + name)  # AttributeError if the symbol is missing: fail loudly
+            fn.restype = restype
+            fn.argtypes = argtypes
+            setattr(self, name, fn)
+
+    def check(self, status: int):
+        if status != 0:
+            msg = self.last_error()
+            raise WaaError(status, msg.decode() if msg else f"status {status}")
+
+
+def bind(lib: C.CDLL, prefix: str = "waa_") -> Binding:
+    return Binding(lib, prefix)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(_FP)
+
+
+def _chan_ptrs(arr2d: np.ndarray):
+    ptrs = (_FP * arr2d.shape[0])()
+    for c in range(arr2d.shape[0]):
+        ptrs[c] = arr2d[c].ctypes.data_as(_FP)
+    return ptrs
+
+
+class AudioBuffer:
+    """src/buffer.rs:69 — channels x frames of f32 plus a sample rate."""
+
+    def __init__(self, data, sample_rate: float):
+        data = _f32(data)
+        if data.ndim == 1:
+            data = data[None, :]
+        self.data = data
+        self.sample_rate = float(np.float32(sample_rate))
+
+    @property
+    def number_of_channels(self) -> int:
+        return self.data.shape[0]
+
+    @property
+    def length(self) -> int:
+        return self.data.shape[1]
+
+    @property
+    def duration(self) -> float:
+        return self.length / self.sample_rate
+
+    def get_channel_data(self, c: int) -> np.ndarray:
+        return self.data[c]
+
+
+class AudioParam:
+    """Value source for one AudioParam of one node (src/param.rs:268).
+
+    The automation timeline is host-side work; this mirror supports the
+    constant value and explicit per-quantum blocks, which is what crosses the C ABI."""
+
+    def __init__(self, node: "AudioNode", pid: int, default: float):
+        self._node, self._pid = node, pid
+        self._const = {ALL: float(default)}
+        self._blocks = []
+
+    @property
+    def value(self) -> float:
+        return self._const[ALL]
+
+    @value.setter
+    def value(self, v: float):
+        self.set_value(v)
+
+    def set_value(self, v: float, instance: int = ALL):
+        self._const[instance] = float(v)
+        if instance == ALL:
+            self._const = {ALL: float(v)}
+        return self
+
+    def set_block(self, quantum0: int, values, instance: int = ALL):
+        """values: [n_quanta] (k-rate, len-1 slices) or [n_quanta, 128] (a-rate slices)."""
+        v = _f32(values)
+        if v.ndim == 1:
+            v = v[:, None]
+        assert v.shape[1] in (1, RENDER_QUANTUM_SIZE)
+        self._blocks.append((int(quantum0), v, instance))
+        return self
+
+    def _apply(self, ctx: "OfflineAudioContext"):
+        b, h = ctx._b, ctx._handle
+        for inst, v in sorted(self._const.items(), key=lambda kv: kv[0] != ALL):
+            b.check(b.set_param_const(h, self._node.id, self._pid, inst, v))
+        for q0, v, inst in self._blocks:
+            b.check(b.set_param_block(h, self._node.id, self._pid, inst, q0, v.shape[0], v.shape[1], _fp(v)))
+
+
+class AudioNode:
+    kind = -1
+    default_channel_config = (2, "max", "speakers")
+
+    def __init__(self, ctx: "OfflineAudioContext", channel_count=None, channel_count_mode=None,
+                 channel_interpretation=None):
+        self.context = ctx
+        cc, mode, interp = self.default_channel_config
+        self.channel_count = cc if channel_count is None else channel_count
+        self.channel_count_mode = mode if channel_count_mode is None else channel_count_mode
+        self.channel_interpretation = interp if channel_interpretation is None else channel_interpretation
+        self._explicit_config = not (channel_count is None and channel_count_mode is None and
+                                     channel_interpretation is None)
+        self.params: List[AudioParam] = []
+        self.id = ctx._register(self)
+
+    # AudioNode channel config setters (audio_node.rs:296-340)
+    def set_channel_count(self, v: int):
+        self.channel_count = int(v)
+        self._explicit_config = True
+
+    def set_channel_count_mode(self, v: str):
+        self.channel_count_mode = v
+        self._explicit_config = True
+
+    def set_channel_interpretation(self, v: str):
+        self.channel_interpretation = v
+        self._explicit_config = True
+
+    # AudioNode::connect (audio_node.rs:247): returns the destination node for chaining
+    def connect(self, dest: "AudioNode", output: int = 0, input: int = 0) -> "AudioNode":
+        if dest.context is not self.context:
+            raise WaaError(1, "InvalidAccessError - Attempting to connect nodes from different contexts")
+        self.context._edges.append((self.id, output, dest.id, input))
+        return dest
+
+    def _desc(self) -> NodeDesc:
+        d = NodeDesc()
+        d.kind = self.kind
+        if self._explicit_config:
+            d.channel_count = self.channel_count
+            d.channel_count_mode = COUNT_MODE[self.channel_count_mode]
+            d.channel_interpretation = INTERPRETATION[self.channel_interpretation]
+        self._fill_desc(d)
+        return d
+
+    def _fill_desc(self, d: NodeDesc):
+        pass
+
+    def _apply(self, ctx: "OfflineAudioContext"):
+        for p in self.params:
+            p._apply(ctx)
+
+
+class AudioDestinationNode(AudioNode):
+    kind = NODE_DESTINATION
+
+    def __init__(self, ctx):
+        # destination.rs:103-107: count = context channels, Explicit, Speakers
+        self.default_channel_config = (ctx.number_of_channels, "explicit", "speakers")
+        super().__init__(ctx)
+
+
+class _ScheduledSource(AudioNode):
+    def __init__(self, ctx, **kw):
+        super().__init__(ctx, **kw)
+        self._starts = {}
+        self._stops = {}
+
+    def start(self):
+        return self.start_at(0.0)
+
+    def start_at(self, when: float, instance: int = ALL):
+        return self.start_at_with_offset_and_duration(when, 0.0, F64_MAX, instance)
+
+    def start_at_with_offset(self, when: float, offset: float, instance: int = ALL):
+        return self.start_at_with_offset_and_duration(when, offset, F64_MAX, instance)
+
+    def start_at_with_offset_and_duration(self, when: float, offset: float, duration: float, instance: int = ALL):
+        if instance in self._starts or ALL in self._starts:
+            raise WaaError(3, "InvalidStateError - Cannot call `start` twice")
+        self._starts[instance] = (float(when), float(offset), float(duration))
+        return self
+
+    def stop(self):
+        return self.stop_at(0.0)
+
+    def stop_at(self, when: float, instance: int = ALL):
+        if instance not in self._starts and ALL not in self._starts:
+            raise WaaError(3, "InvalidStateError - cannot stop before start")
+        self._stops[instance] = float(when)
+        return self
+
+    def _apply(self, ctx):
+        super()._apply(ctx)
+        b, h = ctx._b, ctx._handle
+        for inst, (w, o, d) in self._starts.items():
+            b.check(b.source_start(h, self.id, inst, w, o, d))
+        for inst, w in self._stops.items():
+            b.check(b.source_stop(h, self.id, inst, w))
+
+
+class AudioBufferSourceNode(_ScheduledSource):
+    kind = NODE_BUFFER_SOURCE
+
+    def __init__(self, ctx, **kw):
+        super().__init__(ctx, **kw)
+        self.playback_rate = AudioParam(self, 0, 1.0)
+        self.detune = AudioParam(self, 1, 0.0)
+        self.params = [self.playback_rate, self.detune]
+        self._buffers = {}
+        self._batch = None
+        self._device = None
+        self._loop = {}
+
+    def set_buffer(self, buffer: AudioBuffer, instance: int = ALL):
+        self._buffers[instance] = buffer
+        return self
+
+    def set_buffer_batch(self, data, sample_rate: float):
+        """data: [n_instances, channels, frames], distinct per instance."""
+        self._batch = (_f32(data), float(np.float32(sample_rate)))
+        return self
+
+    def adopt_device_buffer(self, device_ptr: int, n_channels: int, frames: int, sample_rate: float):
+        """device_ptr: address of a resident [n_instances, channels, frames] f32 device array."""
+        self._device = (int(device_ptr), int(n_channels), int(frames), float(np.float32(sample_rate)))
+        return self
+
+    def set_loop(self, value: bool, instance: int = ALL):
+        self._loop.setdefault(instance, [False, 0.0, 0.0])[0] = bool(value)
+        return self
+
+    def set_loop_start(self, value: float, instance: int = ALL):
+        self._loop.setdefault(instance, [False, 0.0, 0.0])[1] = float(value)
+        return self
+
+    def set_loop_end(self, value: float, instance: int = ALL):
+        self._loop.setdefault(instance, [False, 0.0, 0.0])[2] = float(value)
+        return self
+
+    def _apply(self, ctx):
+        b, h = ctx._b, ctx._handle
+        if self._device is not None:
+            p, nch, frames, sr = self._device
+            b.check(b.source_adopt_device(h, self.id, p, nch, frames, sr))
+        if self._batch is not None:
+            data, sr = self._batch
+            assert data.ndim == 3 and data.shape[0] == ctx.n_instances
+            b.check(b.source_set_buffer_batch(h, self.id, _fp(data), data.shape[1], data.shape[2], sr))
+        for inst, buf in sorted(self._buffers.items(), key=lambda kv: kv[0] != ALL):
+            b.check(b.source_set_buffer(h, self.id, inst, _chan_ptrs(buf.data), buf.number_of_channels, buf.length,
+                                        buf.sample_rate))
+        for inst, (lp, ls, le) in sorted(self._loop.items(), key=lambda kv: kv[0] != ALL):
+            b.check(b.source_set_loop(h, self.id, inst, int(lp), ls, le))
+        super()._apply(ctx)
+
+
+class ConstantSourceNode(_ScheduledSource):
+    kind = NODE_CONSTANT_SOURCE
+
+    def __init__(self, ctx, offset: float = 1.0, **kw):
+        super().__init__(ctx, **kw)
+        self.offset = AudioParam(self, 0, offset)
+        self.params = [self.offset]
+
+
+class BiquadFilterNode(AudioNode):
+    kind = NODE_BIQUAD
+
+    def __init__(self, ctx, type_="lowpass", frequency=350.0, detune=0.0, q=1.0, gain=0.0, **kw):
+        super().__init__(ctx, **kw)
+        self.type_ = type_
+        self.frequency = AudioParam(self, 0, frequency)
+        self.detune = AudioParam(self, 1, detune)
+        self.q = AudioParam(self, 2, q)
+        self.gain = AudioParam(self, 3, gain)
+        self.params = [self.frequency, self.detune, self.q, self.gain]
+
+    def set_type(self, type_: str):
+        self.type_ = type_
+        return self
+
+    def _fill_desc(self, d):
+        d.i[0] = BIQUAD_TYPE[self.type_]
+
+    def get_frequency_response(self, frequency_hz) -> tuple:
+        hz = _f32(frequency_hz)
+        mag = np.empty_like(hz)
+        phase = np.empty_like(hz)
+        b = self.context._b
+        b.check(b.biquad_frequency_response(BIQUAD_TYPE[self.type_], self.context.sample_rate, self.frequency.value,
+                                            self.detune.value, self.q.value, self.gain.value, _fp(hz), _fp(mag),
+                                            _fp(phase), hz.size))
+        return mag, phase
+
+
+class GainNode(AudioNode):
+    kind = NODE_GAIN
+
+    def __init__(self, ctx, gain: float = 1.0, **kw):
+        super().__init__(ctx, **kw)
+        self.gain = AudioParam(self, 0, gain)
+        self.params = [self.gain]
+
+
+class ConvolverNode(AudioNode):
+    kind = NODE_CONVOLVER
+    default_channel_config = (2, "clamped-max", "speakers")
+
+    def __init__(self, ctx, buffer: Optional[AudioBuffer] = None, disable_normalization: bool = False, **kw):
+        super().__init__(ctx, **kw)
+        self.normalize = not disable_normalization
+        self.buffer = None
+        self._normalize_at_set = self.normalize
+        if buffer is not None:
+            self.set_buffer(buffer)
+
+    def set_normalize(self, value: bool):
+        self.normalize = bool(value)
+
+    def set_buffer(self, buffer: AudioBuffer):
+        if buffer.sample_rate != self.context.sample_rate:
+            raise WaaError(2, "NotSupportedError - sample rate of the convolution buffer must match the audio context")
+        if buffer.number_of_channels not in (1, 2, 4):
+            raise WaaError(2, "NotSupportedError - the convolution buffer must consist of 1, 2 or 4 channels")
+        self.buffer = buffer
+        self._normalize_at_set = self.normalize
+        return self
+
+    def _fill_desc(self, d):
+        d.i[0] = 0 if self._normalize_at_set else 1
+
+    def _apply(self, ctx):
+        if self.buffer is not None:
+            b, h = ctx._b, ctx._handle
+            buf = self.buffer
+            b.check(b.convolver_set_buffer(h, self.id, _chan_ptrs(buf.data), buf.number_of_channels, buf.length,
+                                           buf.sample_rate))
+
+
+class StereoPannerNode(AudioNode):
+    kind = NODE_STEREO_PANNER
+    default_channel_config = (2, "clamped-max", "speakers")
+
+    def __init__(self, ctx, pan: float = 0.0, **kw):
+        super().__init__(ctx, **kw)
+        self.pan = AudioParam(self, 0, pan)
+        self.params = [self.pan]
+
+
+class AudioListener:
+    """src/spatial.rs:127-144 — shared by every PannerNode of the context."""
+
+    def __init__(self):
+        self.values = [0.0, 0.0, 0.0, 0.0, 0.0, -1.0, 0.0, 1.0, 0.0]
+
+    def set_position(self, x, y, z):
+        self.values[0:3] = [float(x), float(y), float(z)]
+
+    def set_orientation(self, fx, fy, fz, ux, uy, uz):
+        self.values[3:9] = [float(v) for v in (fx, fy, fz, ux, uy, uz)]
+
+
+class PannerNode(AudioNode):
+    kind = NODE_PANNER
+    default_channel_config = (2, "clamped-max", "speakers")
+
+    def __init__(self, ctx, panning_model="equalpower", distance_model="inverse", position=(0.0, 0.0, 0.0),
+                 orientation=(1.0, 0.0, 0.0), ref_distance=1.0, max_distance=10000.0, rolloff_factor=1.0,
+                 cone_inner_angle=360.0, cone_outer_angle=360.0, cone_outer_gain=0.0, **kw):
+        super().__init__(ctx, **kw)
+        self.panning_model, self.distance_model = panning_model, distance_model
+        self.ref_distance, self.max_distance, self.rolloff_factor = ref_distance, max_distance, rolloff_factor
+        self.cone_inner_angle, self.cone_outer_angle, self.cone_outer_gain = (cone_inner_angle, cone_outer_angle,
+                                                                              cone_outer_gain)
+        self.position_x = AudioParam(self, 0, position[0])
+        self.position_y = AudioParam(self, 1, position[1])
+        self.position_z = AudioParam(self, 2, position[2])
+        self.orientation_x = AudioParam(self, 3, orientation[0])
+        self.orientation_y = AudioParam(self, 4, orientation[1])
+        self.orientation_z = AudioParam(self, 5, orientation[2])
+        self.params = [self.position_x, self.position_y, self.position_z, self.orientation_x, self.orientation_y,
+                       self.orientation_z]
+
+    def set_position(self, x, y, z):
+        self.position_x.set_value(x)
+        self.position_y.set_value(y)
+        self.position_z.set_value(z)
+
+    def set_orientation(self, x, y, z):
+        self.orientation_x.set_value(x)
+        self.orientation_y.set_value(y)
+        self.orientation_z.set_value(z)
+
+    def _fill_desc(self, d):
+        d.i[0] = PANNING_MODEL[self.panning_model]
+        d.i[1] = DISTANCE_MODEL[self.distance_model]
+        d.d[0], d.d[1], d.d[2] = self.ref_distance, self.max_distance, self.rolloff_factor
+        d.d[3], d.d[4], d.d[5] = self.cone_inner_angle, self.cone_outer_angle, self.cone_outer_gain
+
+    def _apply(self, ctx):
+        super()._apply(ctx)
+        b, h = ctx._b, ctx._handle
+        for i, v in enumerate(ctx.listener().values):
+            b.check(b.set_param_const(h, self.id, 6 + i, ALL, v))
+
+
+class AnalyserNode(AudioNode):
+    kind = NODE_ANALYSER
+
+    def __init__(self, ctx, fft_size=2048, smoothing_time_constant=0.8, min_decibels=-100.0, max_decibels=-30.0,
+                 **kw):
+        super().__init__(ctx, **kw)
+        self.fft_size, self.smoothing_time_constant = fft_size, smoothing_time_constant
+        self.min_decibels, self.max_decibels = min_decibels, max_decibels
+
+    @property
+    def frequency_bin_count(self) -> int:
+        return self.fft_size // 2
+
+    def _fill_desc(self, d):
+        d.i[0] = self.fft_size
+        d.d[0], d.d[1], d.d[2] = self.smoothing_time_constant, self.min_decibels, self.max_decibels
+
+    def _pull(self, fn_name: str, n: int, instance: int, dtype):
+        ctx = self.context
+        if ctx._handle is None:
+            raise WaaError(3, "InvalidStateError - analyser data is only available after start_rendering_sync")
+        out = np.zeros(n, dtype=dtype)
+        ptr = out.ctypes.data_as(_FP if dtype == np.float32 else C.POINTER(C.c_uint8))
+        ctx._b.check(getattr(ctx._b, fn_name)(ctx._handle, self.id, instance, ptr, n))
+        return out
+
+    def get_float_frequency_data(self, n: Optional[int] = None, instance: int = 0) -> np.ndarray:
+        return self._pull("analyser_get_float_frequency_data", n or self.frequency_bin_count, instance, np.float32)
+
+    def get_byte_frequency_data(self, n: Optional[int] = None, instance: int = 0) -> np.ndarray:
+        return self._pull("analyser_get_byte_frequency_data", n or self.frequency_bin_count, instance, np.uint8)
+
+    def get_float_time_domain_data(self, n: Optional[int] = None, instance: int = 0) -> np.ndarray:
+        return self._pull("analyser_get_float_time_domain_data", n or self.fft_size, instance, np.float32)
+
+    def get_byte_time_domain_data(self, n: Optional[int] = None, instance: int = 0) -> np.ndarray:
+        return self._pull("analyser_get_byte_time_domain_data", n or self.fft_size, instance, np.uint8)
+
+
+class WaveShaperNode(AudioNode):
+    kind = NODE_WAVESHAPER
+
+    def __init__(self, ctx, curve=None, oversample="none", **kw):
+        super().__init__(ctx, **kw)
+        self.oversample = oversample
+        self.curve = None
+        if curve is not None:
+            self.set_curve(curve)
+
+    def set_curve(self, curve):
+        if self.curve is not None:
+            raise WaaError(3, "InvalidStateError - cannot assign curve twice")
+        self.curve = _f32(curve)
+        return self
+
+    def set_oversample(self, oversample: str):
+        self.oversample = oversample
+
+    def _fill_desc(self, d):
+        d.i[0] = OVERSAMPLE[self.oversample]
+
+    def _apply(self, ctx):
+        if self.curve is not None:
+            b, h = ctx._b, ctx._handle
+            b.check(b.waveshaper_set_curve(h, self.id, _fp(self.curve), self.curve.size))
+
+
+class RenderedBatch:
+    """What start_rendering_sync returns: one AudioBuffer per instance (array [inst, ch, frames])."""
+
+    def __init__(self, data: np.ndarray, sample_rate: float):
+        self.data = data
+        self.sample_rate = sample_rate
+
+    def buffer(self, instance: int = 0) -> AudioBuffer:
+        return AudioBuffer(self.data[instance], self.sample_rate)
+
+    def get_channel_data(self, c: int, instance: int = 0) -> np.ndarray:
+        return self.data[instance, c]
+
+    @property
+    def length(self):
+        return self.data.shape[2]
+
+    @property
+    def number_of_channels(self):
+        return self.data.shape[1]
+
+
+class OfflineAudioContext:
+    """A batch of ``n_instances`` identically shaped OfflineAudioContexts (offline.rs:68)."""
+
+    def __init__(self, number_of_channels: int, length: int, sample_rate: float, n_instances: int = 1,
+                 binding: Optional[Binding] = None, device: int = -1):
+        if binding is None:
+            from . import default_binding  # loads libwaa_hip.so; raises if it is not built
+            binding = default_binding()
+        self._b = binding
+        self.number_of_channels = int(number_of_channels)
+        self.length = int(length)
+        self.sample_rate = float(np.float32(sample_rate))
+        self.n_instances = int(n_instances)
+        self.device = device
+        self._nodes: List[AudioNode] = []
+        self._edges = []
+        self._handle = None
+        self._rendered = False
+        self._listener = AudioListener()
+        self._destination = AudioDestinationNode(self)
+
+    def _register(self, node: AudioNode) -> int:
+        if self._handle is not None:
+            raise WaaError(3, "InvalidStateError - graph is frozen once rendering has started")
+        self._nodes.append(node)
+        return len(self._nodes) - 1
+
+    # BaseAudioContext
+    def destination(self) -> AudioDestinationNode:
+        return self._destination
+
+    def listener(self) -> AudioListener:
+        return self._listener
+
+    def create_buffer(self, number_of_channels: int, length: int, sample_rate: float) -> AudioBuffer:
+        return AudioBuffer(np.zeros((number_of_channels, length), np.float32), sample_rate)
+
+    def create_buffer_source(self, **kw):
+        return AudioBufferSourceNode(self, **kw)
+
+    def create_constant_source(self, **kw):
+        return ConstantSourceNode(self, **kw)
+
+    def create_biquad_filter(self, **kw):
+        return BiquadFilterNode(self, **kw)
+
+    def create_gain(self, **kw):
+        return GainNode(self, **kw)
+
+    def create_convolver(self, **kw):
+        return ConvolverNode(self, **kw)
+
+    def create_stereo_panner(self, **kw):
+        return StereoPannerNode(self, **kw)
+
+    def create_panner(self, **kw):
+        return PannerNode(self, **kw)
+
+    def create_analyser(self, **kw):
+        return AnalyserNode(self, **kw)
+
+    def create_wave_shaper(self, **kw):
+        return WaveShaperNode(self, **kw)
+
+    # -- render -------------------------------------------------------------------------
+    def _build(self):
+        n = len(self._nodes)
+        nodes = (NodeDesc * n)(*[nd._desc() for nd in self._nodes])
+        m = len(self._edges)
+        edges = (EdgeDesc * max(m, 1))()
+        for k, (f, fo, t, ti) in enumerate(self._edges):
+            edges[k].from_, edges[k].from_output, edges[k].to, edges[k].to_input = f, fo, t, ti
+        g = GraphDesc(n, nodes, m, edges)
+        h = _VP()
+        self._b.check(self._b.batch_create(C.byref(g), self.n_instances, self.number_of_channels, self.length,
+                                           self.sample_rate, self.device, C.byref(h)))
+        self._handle = h
+        for nd in self._nodes:
+            nd._apply(self)
+
+    def prepare(self):
+        """Create the batch and upload every payload (outside any timed region)."""
+        if self._handle is None:
+            self._build()
+        return self
+
+    def render_async(self):
+        """Launch the render on the batch's stream without waiting (bench inner loop)."""
+        self.prepare()
+        self._b.check(self._b.render(self._handle))
+        self._rendered = True
+
+    def sync(self):
+        self._b.check(self._b.sync(self._handle))
+
+    def start_rendering_sync(self) -> RenderedBatch:
+        if self._rendered:
+            raise WaaError(3, "InvalidStateError - Cannot call `startRendering` twice")
+        self.render_async()
+        out = np.empty((self.n_instances, self.number_of_channels, self.length), np.float32)
+        self._b.check(self._b.download_all(self._handle, _fp(out)))
+        return RenderedBatch(out, self.sample_rate)
+
+    def output_device(self):
+        p, s_i, s_c = _VP(), C.c_uint64(), C.c_uint64()
+        self._b.check(self._b.output_device(self._handle, C.byref(p), C.byref(s_i), C.byref(s_c)))
+        return p.value, s_i.value, s_c.value
+
+    def profile(self, enable=True):
+        self.prepare()
+        self._b.check(self._b.profile_enable(self._handle, int(enable)))
+
+    def profile_entries(self):
+        out = []
+        for i in range(self._b.profile_count(self._handle)):
+            name, launches, ms = C.c_char_p(), C.c_uint64(), C.c_double()
+            self._b.check(self._b.profile_get(self._handle, i, C.byref(name), C.byref(launches), C.byref(ms)))
+            out.append((name.value.decode(), launches.value, ms.value))
+        return out
+
+    def profile_reset(self):
+        self._b.check(self._b.profile_reset(self._handle))
+
+    def close(self):
+        if self._handle is not None:
+            self._b.batch_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def resample(binding: Binding, data, source_sample_rate: float, target_sample_rate: float) -> np.ndarray:
+    """AudioBuffer::resample (src/buffer.rs:311-363) for a [channels, frames] array."""
+    data = _f32(data)
+    if data.ndim == 1:
+        data = data[None, :]
+    n = binding.buffer_resample(_fp(data[0]), data.shape[1], source_sample_rate, target_sample_rate, None, 0)
+    out = np.empty((data.shape[0], n), np.float32)
+    for c in range(data.shape[0]):
+        binding.buffer_resample(_fp(data[c]), data.shape[1], source_sample_rate, target_sample_rate, _fp(out[c]), n)
+    return out
