@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the batched offline render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|t1|c3|c5] [--instances I] [--seconds S]
+
+A "step" = one start_rendering_sync-equivalent pass over one batch of synthetic input:
+`instances` independent OfflineAudioContexts x `seconds` s @ 48 kHz stereo, inputs already
+resident in HBM (white noise generated on the device).  Default workload = BASELINE.json
+configs[1] (C2): 1024 contexts, BufferSource -> Biquad(lowpass 200 Hz, Q 1) -> Gain(0.5) -> destination.
+
+N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`, one rank per GPU;
+independent batches shard over the GPUs with no data-path collective (weak scaling: every GPU
+renders `instances` contexts).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+SR = 48000.0
+RQ = 128
+
+
+def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
+    ctx = waa.OfflineAudioContext(2, frames, SR, n_instances=n_inst, binding=binding, device=device)
+    src = ctx.create_buffer_source()
+    if noise_ptr is not None:
+        src.adopt_device_buffer(noise_ptr, 2, frames, SR)
+    node = src
+    if name in ("c2", "t1", "c4"):
+        node = node.connect(ctx.create_biquad_filter(type_="lowpass", frequency=200.0, q=1.0))
+    if name == "c2":
+        node = node.connect(ctx.create_gain(gain=0.5))
+    if name in ("t1", "c3", "c4"):
+        from graphs import garage_like_ir
+        node = node.connect(ctx.create_convolver(buffer=waa.AudioBuffer(garage_like_ir(), SR)))
+    if name == "c4":
+        node = node.connect(ctx.create_stereo_panner(pan=0.1))
+        node = node.connect(ctx.create_analyser(fft_size=2048, smoothing_time_constant=0.8))
+    if name == "c5":
+        src.playback_rate.set_value(1.5)
+        src.set_loop(True)
+        i = np.arange(2048, dtype=np.float32)
+        curve = np.cos(np.float32(np.pi) + i * np.float32(np.pi) / np.float32(2047)).astype(np.float32)
+        node = node.connect(ctx.create_wave_shaper(curve=curve))
+    node.connect(ctx.destination())
+    src.start()
+    return ctx, src
+
+
+# algorithmic bytes per context-quantum
+ALG_BYTES = {"c2": 2048.0, "c5": 2560.0, "c3": 362848.0, "t1": 362848.0 + 2048.0, "c4": 362848.0 + 2048.0 + 512.0}
+DESCR = {
+    "c2": "C2: {n} OfflineAudioContexts x {s:g} s @48kHz stereo, BufferSource->Biquad(lowpass 200Hz,Q1)->Gain(0.5)->destination",
+    "t1": "T1: {n} contexts x {s:g} s, BufferSource->Biquad->Convolver(2ch x 178899-frame IR, 175 partitions)->destination",
+    "c3": "C3: {n} contexts x {s:g} s, BufferSource->Convolver(2ch x 178899-frame IR)->destination",
+    "c4": "C4: {n} contexts x {s:g} s, BufferSource->Biquad->Convolver->StereoPanner->Analyser->destination",
+    "c5": "C5: {n} contexts x {s:g} s, BufferSource(playbackRate 1.5, loop)->WaveShaper(2048-pt)->destination",
+}
+
+
+def cpu_baseline(waa, name, frames):
+    """The oracle ("port": a C restatement of the reference algorithm, NOT the Rust reference itself) timed
+    on this box's host cores, one context per thread, on a bounded sample of the same workload."""
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    orc = waa.bind(lib, "orc_")
+    cores = os.cpu_count() or 1
+    per_ctx_s = {"c2": 0.03, "c5": 0.05, "c3": 2.5, "t1": 2.5, "c4": 2.6}[name] * (frames / 480000.0)
+    n = int(max(cores, min(64 * cores, round(15.0 * cores / max(per_ctx_s, 1e-3)))))
+    n = (n + cores - 1) // cores * cores
+    from graphs import white_noise
+    noise = white_noise(n, 2, frames)
+    ctx, src = build_workload(waa, orc, name, n, frames, -1, None)
+    src.set_buffer_batch(noise, SR)
+    ctx.prepare()
+    lib.orc_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.orc_set_threads(ctx._handle, cores)
+    t0 = time.perf_counter()
+    orc.check(orc.render(ctx._handle))
+    wall = time.perf_counter() - t0
+    ctx.close()
+    nq = (frames + RQ - 1) // RQ
+    return {"value": n * nq / wall, "unit": "quanta/s", "cores": cores, "kind": "port",
+            "sample": f"{n} contexts x {frames / SR:g} s of the same graph, one context per thread, wall {wall:.2f} s",
+            "rtf": n * (frames / SR) / wall}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(ALG_BYTES))
+    ap.add_argument("--instances", type=int, default=None, help="contexts per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import web_audio_api_rs_amd as waa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    name = args.workload
+    n_inst = args.instances or {"c2": 1024, "t1": 1024, "c3": 512, "c4": 512, "c5": 2048}[name]
+    frames = int(round(args.seconds * SR))
+    nq = (frames + RQ - 1) // RQ
+    hip = waa.default_binding()
+
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0xA0D10 + rank)
+    noise = torch.empty((n_inst, 2, frames), dtype=torch.float32, device="cuda").uniform_(-1.0, 1.0, generator=gen)
+    ctx, _ = build_workload(waa, hip, name, n_inst, frames, local_rank, noise.data_ptr())
+    ctx.prepare()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.render_async()
+    ctx.sync()
+    ctx.profile(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.render_async()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.sync()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        total_quanta = world * n_inst * nq
+        value = total_quanta * args.steps / elapsed
+        prof = sorted(ctx.profile_entries(), key=lambda e: -e[2])
+        dom = prof[0] if prof else ("none", 1, float("nan"))
+        kernel_ms = {n_: (ms / max(l, 1)) for n_, l, ms in prof}
+        launches_per_step = {n_: l / args.steps for n_, l, ms in prof}
+        # roofline of the dominant kernel: algorithmic bytes of one launch / its mean duration
+        alg_bytes_step = ALG_BYTES[name] * n_inst * nq
+        dom_share = 1.0
+        if name in ("c3", "t1", "c4"):
+            # several kernels share the algorithmic bytes of the FDL: attribute them to the whole render
+            achieved = alg_bytes_step / (sum(ms for _, _, ms in prof) / args.steps * 1e-3) / 1e9
+            dom_name = "render (all kernels)"
+        else:
+            achieved = alg_bytes_step * dom_share / (dom[2] / max(dom[1], 1) * 1e-3) / 1e9
+            dom_name = dom[0]
+        out = {
+            "metric": "render quanta/sec (48kHz, 128-frame)",
+            "value": value,
+            "unit": "quanta/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if name in ("c2", "t1", "c4") else "f32",
+            "data": "synthetic",
+            "config": {"workload": DESCR[name].format(n=n_inst, s=args.seconds), "contexts_per_gpu": n_inst,
+                       "sample_rate": SR, "render_seconds": args.seconds, "quanta_per_context": nq,
+                       "parallelism": f"{world} independent batch(es), no collective"},
+            "real_time_factor": world * n_inst * args.seconds * args.steps / elapsed,
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes_step,
+                         "kernel_ms": kernel_ms, "launches_per_step": launches_per_step},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(waa, name, frames)
+                if out["cpu_baseline"]:
+                    out["gpu_over_cpu_rtf"] = out["real_time_factor"] / out["cpu_baseline"]["rtf"]
+            except Exception as e:  # the baseline is reporting only; never fail the bench line on it
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,3 +42,9 @@ def hip():
     import web_audio_api_rs_amd as waa
 
     return waa.default_binding()
+
+
+@pytest.fixture(params=["orc", pytest.param("hip", marks=pytest.mark.gpu)])
+def be(request):
+    """Backend under test: the CPU oracle (pins the oracle) or the HIP library (-m gpu)."""
+    return request.getfixturevalue(request.param)

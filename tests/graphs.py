@@ -1,0 +1,87 @@
+"""Graph builders shared by the parity tests (BASELINE.json configs C1..C5, T1 at small sizes)."""
+import numpy as np
+
+import web_audio_api_rs_amd as waa
+
+
+def white_noise(n_inst, n_ch, frames, seed0=0xA0D10, first=0):
+    """uniform white noise in [-1, 1), seed = 0xA0D10 + instance."""
+    out = np.empty((n_inst, n_ch, frames), np.float32)
+    for i in range(n_inst):
+        rng = np.random.default_rng(seed0 + first + i)
+        out[i] = rng.uniform(-1.0, 1.0, (n_ch, frames)).astype(np.float32)
+    return out
+
+
+def garage_like_ir(frames=178899, n_ch=2, sr=48000.0, seed=7):
+    """Synthetic stand-in for samples/parking-garage-response.wav resampled to 48 kHz (2 ch x 178 899
+    frames => 175 partitions of 1024): exponentially decaying noise, ~1.2 s RT60-ish."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(frames, dtype=np.float64) / sr
+    env = np.exp(-t / 0.35)
+    ir = (rng.uniform(-1.0, 1.0, (n_ch, frames)) * env).astype(np.float32)
+    return ir
+
+
+def c2(binding, noise, sr=48000.0, length=None, ftype="lowpass", freq=200.0, q=1.0, gain=0.5, device=-1):
+    """C2: src -> Biquad(lowpass 200 Hz, Q 1) -> Gain(0.5) -> destination."""
+    n_inst, n_ch, frames = noise.shape
+    ctx = waa.OfflineAudioContext(2, length or frames, sr, n_instances=n_inst, binding=binding, device=device)
+    src = ctx.create_buffer_source()
+    src.set_buffer_batch(noise, sr)
+    flt = ctx.create_biquad_filter(type_=ftype, frequency=freq, q=q)
+    g = ctx.create_gain(gain=gain)
+    src.connect(flt).connect(g).connect(ctx.destination())
+    src.start()
+    return ctx, dict(src=src, biquad=flt, gain=g)
+
+
+def c5(binding, noise, sr=48000.0, length=None, buf_sr=None, rate=1.5, loop=True):
+    """C5: src(playbackRate != 1 or foreign buffer rate, loop) -> WaveShaper(2048-pt cos curve) -> destination."""
+    n_inst, n_ch, frames = noise.shape
+    ctx = waa.OfflineAudioContext(2, length or frames, sr, n_instances=n_inst, binding=binding)
+    src = ctx.create_buffer_source()
+    src.set_buffer_batch(noise, buf_sr or sr)
+    src.playback_rate.set_value(rate)
+    src.set_loop(loop)
+    i = np.arange(2048, dtype=np.float32)
+    curve = np.cos(np.float32(np.pi) + i * np.float32(np.pi) / np.float32(2047)).astype(np.float32)  # waveshaper.rs:78-87
+    sh = ctx.create_wave_shaper(curve=curve)
+    src.connect(sh).connect(ctx.destination())
+    src.start()
+    return ctx, dict(src=src, shaper=sh)
+
+
+def t1(binding, noise, ir, sr=48000.0, length=None, with_biquad=True, device=-1):
+    """T1 / C3: src -> [Biquad] -> Convolver(IR, normalize) -> destination."""
+    n_inst, n_ch, frames = noise.shape
+    ctx = waa.OfflineAudioContext(2, length or frames, sr, n_instances=n_inst, binding=binding, device=device)
+    src = ctx.create_buffer_source()
+    src.set_buffer_batch(noise, sr)
+    conv = ctx.create_convolver(buffer=waa.AudioBuffer(ir, sr))
+    node = src
+    if with_biquad:
+        node = src.connect(ctx.create_biquad_filter(type_="lowpass", frequency=200.0, q=1.0))
+    node.connect(conv).connect(ctx.destination())
+    src.start()
+    return ctx, dict(src=src, conv=conv)
+
+
+def c4(binding, noise, ir, sr=48000.0, length=None, device=-1):
+    """C4: src -> Biquad -> Convolver -> StereoPanner(0.1) -> Analyser(2048, 0.8) -> destination."""
+    n_inst, n_ch, frames = noise.shape
+    ctx = waa.OfflineAudioContext(2, length or frames, sr, n_instances=n_inst, binding=binding, device=device)
+    src = ctx.create_buffer_source()
+    src.set_buffer_batch(noise, sr)
+    flt = ctx.create_biquad_filter(type_="lowpass", frequency=200.0, q=1.0)
+    conv = ctx.create_convolver(buffer=waa.AudioBuffer(ir, sr))
+    pan = ctx.create_stereo_panner(pan=0.1)
+    an = ctx.create_analyser(fft_size=2048, smoothing_time_constant=0.8)
+    src.connect(flt).connect(conv).connect(pan).connect(an).connect(ctx.destination())
+    src.start()
+    return ctx, dict(src=src, analyser=an)
+
+
+def rms_err(a, b):
+    """per (instance, channel) RMS error, f64"""
+    return np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2, axis=-1))

@@ -1,8 +1,13 @@
-"""Pins the CPU oracle against the reference's own known-answer tests.
+"""The reference's own known-answer tests, re-typed, run against BOTH implementations.
 
-Every test here is a re-typed unit/integration test of the reference (file:line in the
-docstring) driven through the oracle's C ABI (prefix orc_) with the same host mirror
-the product uses.  CPU only.
+Every test is a unit/integration test of the reference (file:line in the docstring) driven
+through the C ABI with the host mirror:
+
+* backend ``orc``  — the CPU oracle (prefix orc_): this is what PINS the oracle; runs in the
+  CPU suite (``-m "not gpu"``).
+* backend ``hip``  — the product library on a real MI355X (prefix waa_): ``-m gpu``.
+
+Tests that take ``orc``/``orc_lib`` directly exercise oracle-only helpers (CPU only).
 """
 import json
 import math
@@ -18,8 +23,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 F32PI = np.float32(np.pi)
 
 
-def ctx(orc, channels, length, sr, **kw):
-    return waa.OfflineAudioContext(channels, length, sr, binding=orc, **kw)
+def ctx(be, channels, length, sr, **kw):
+    return waa.OfflineAudioContext(channels, length, sr, binding=be, **kw)
 
 
 def buf(data, sr):
@@ -31,10 +36,10 @@ KATS = json.load(open(os.path.join(HERE, "golden", "biquad_frequency_response.js
 
 
 @pytest.mark.parametrize("name", sorted(KATS))
-def test_biquad_frequency_responses(orc, name):
+def test_biquad_frequency_responses(be, name):
     """src/node/biquad_filter.rs:1000-1412 — Chrome/Firefox vectors, abs_all <= 1e-6."""
     k = KATS[name]
-    c = ctx(orc, 1, 128, k["sample_rate"])
+    c = ctx(be, 1, 128, k["sample_rate"])
     f = c.create_biquad_filter()
     f.set_type(name)
     f.frequency.set_value(k["frequency"])
@@ -45,9 +50,9 @@ def test_biquad_frequency_responses(orc, name):
     assert np.max(np.abs(phases - np.float32(k["expected_phases"]))) <= 1e-6
 
 
-def test_biquad_frequency_response_nan_outside_range(orc):
+def test_biquad_frequency_response_nan_outside_range(be):
     """src/node/biquad_filter.rs:1415-1436"""
-    c = ctx(orc, 1, 128, 44100.0)
+    c = ctx(be, 1, 128, 44100.0)
     f = c.create_biquad_filter()
     mags, phases = f.get_frequency_response([-1.0, 22051.0])
     assert np.all(np.isnan(mags)) and np.all(np.isnan(phases))
@@ -63,7 +68,7 @@ def test_computed_freq(orc_lib):
     assert abs(orc_lib.orc_get_computed_freq(440.0, -1200.0) - 220.0) <= 1e-4
 
 
-def test_biquad_render_matches_lfilter(orc):
+def test_biquad_render_matches_lfilter(be, orc):
     """The reference pins no biquad *samples* (SURVEY §8c); cross-check the restated
     DF-I recurrence against scipy.signal.lfilter in f64 with the restated coefficients."""
     import ctypes as C
@@ -73,7 +78,7 @@ def test_biquad_render_matches_lfilter(orc):
     x = rng.uniform(-1, 1, (2, n)).astype(np.float32)
     for ftype, f0, q, g in [("lowpass", 200.0, 1.0, 0.0), ("peaking", 3000.0, 2.0, 6.0), ("highshelf", 5000.0, 1.0, -9.0),
                             ("notch", 1000.0, 10.0, 0.0)]:
-        c = ctx(orc, 2, n, sr)
+        c = ctx(be, 2, n, sr)
         src = c.create_buffer_source()
         src.set_buffer(buf(x, sr))
         flt = c.create_biquad_filter(type_=ftype, frequency=f0, q=q, gain=g)
@@ -138,9 +143,9 @@ def test_mix_rules(orc_lib):
     assert np.all(o[0] == 1.0)
 
 
-def _run_mixing(orc, n_out, dest_interp, count, mode, interp):
+def _run_mixing(be, n_out, dest_interp, count, mode, interp):
     """tests/mixing.rs:9-37"""
-    c = ctx(orc, n_out, 128, 44100.0)
+    c = ctx(be, n_out, 128, 44100.0)
     c.destination().set_channel_interpretation(dest_interp)
     k = c.create_constant_source()
     k.start()
@@ -152,28 +157,28 @@ def _run_mixing(orc, n_out, dest_interp, count, mode, interp):
     return c.start_rendering_sync().data[0]
 
 
-def test_mixing_integration(orc):
+def test_mixing_integration(be):
     """tests/mixing.rs:40-100"""
     ones, zeros = np.ones(128, np.float32), np.zeros(128, np.float32)
-    o = _run_mixing(orc, 1, "speakers", 1, "max", "speakers")
+    o = _run_mixing(be, 1, "speakers", 1, "max", "speakers")
     assert np.array_equal(o[0], ones)
-    o = _run_mixing(orc, 2, "speakers", 2, "max", "speakers")
+    o = _run_mixing(be, 2, "speakers", 2, "max", "speakers")
     assert np.array_equal(o[0], ones) and np.array_equal(o[1], ones)
-    o = _run_mixing(orc, 4, "speakers", 4, "max", "speakers")
+    o = _run_mixing(be, 4, "speakers", 4, "max", "speakers")
     assert np.array_equal(o[0], ones) and np.array_equal(o[1], ones) and np.array_equal(o[2], zeros) and np.array_equal(
         o[3], zeros)
-    o = _run_mixing(orc, 2, "discrete", 1, "max", "speakers")
+    o = _run_mixing(be, 2, "discrete", 1, "max", "speakers")
     assert np.array_equal(o[0], ones) and np.array_equal(o[1], zeros)
-    o = _run_mixing(orc, 2, "discrete", 2, "max", "speakers")
+    o = _run_mixing(be, 2, "discrete", 2, "max", "speakers")
     assert np.array_equal(o[0], ones) and np.array_equal(o[1], zeros)
-    o = _run_mixing(orc, 1, "discrete", 2, "max", "speakers")
+    o = _run_mixing(be, 1, "discrete", 2, "max", "speakers")
     assert np.array_equal(o[0], ones)
 
 
-def test_offline_render_summing_and_truncation(orc):
+def test_offline_render_summing_and_truncation(be):
     """tests/offline.rs:11-46 — fan-in summing, non-multiple-of-128 length, mono->stereo."""
     length = 555
-    c = ctx(orc, 2, length, 44100.0)
+    c = ctx(be, 2, length, 44100.0)
     k1 = c.create_constant_source()
     k1.offset.set_value(2.0)
     k1.connect(c.destination())
@@ -188,9 +193,9 @@ def test_offline_render_summing_and_truncation(orc):
     assert np.array_equal(out.data[0, 1], np.full(length, -2.0, np.float32))
 
 
-def test_flush_denormals(orc):
+def test_flush_denormals(be):
     """tests/denormals.rs:5-30"""
-    c = ctx(orc, 1, 128, 48000.0)
+    c = ctx(be, 1, 128, 48000.0)
     s = c.create_constant_source()
     s.start()
     g1 = c.create_gain(gain=0.001)
@@ -201,17 +206,17 @@ def test_flush_denormals(orc):
     assert np.array_equal(out, np.zeros(128, np.float32))
 
 
-def test_start_rendering_twice(orc):
+def test_start_rendering_twice(be):
     """src/context/offline.rs:163 InvalidStateError"""
-    c = ctx(orc, 1, 128, 48000.0)
+    c = ctx(be, 1, 128, 48000.0)
     c.start_rendering_sync()
     with pytest.raises(waa.WaaError, match="InvalidStateError"):
         c.start_rendering_sync()
 
 
 # ----------------------------------------------------------------------------- stereo panner
-def _pan(orc, data, pan, **cfg):
-    c = ctx(orc, 2, 128, 44100.0)
+def _pan(be, data, pan, **cfg):
+    c = ctx(be, 2, 128, 44100.0)
     p = c.create_stereo_panner(pan=pan, **cfg)
     p.connect(c.destination())
     s = c.create_buffer_source()
@@ -221,32 +226,32 @@ def _pan(orc, data, pan, **cfg):
     return c.start_rendering_sync().data[0]
 
 
-def test_stereo_panner_mono(orc):
+def test_stereo_panner_mono(be):
     """src/node/stereo_panner.rs:370-462"""
     one = np.ones((1, 128), np.float32)
     cfg = dict(channel_count=1, channel_count_mode="clamped-max")
-    o = _pan(orc, one, -1.0, **cfg)
+    o = _pan(be, one, -1.0, **cfg)
     assert np.array_equal(o[0], one[0]) and np.array_equal(o[1], np.zeros(128, np.float32))
-    o = _pan(orc, one, 1.0, **cfg)
+    o = _pan(be, one, 1.0, **cfg)
     assert np.max(np.abs(o[0])) <= 1e-7 and np.array_equal(o[1], one[0])
-    o = _pan(orc, one, 0.0, **cfg)
+    o = _pan(be, one, 0.0, **cfg)
     assert np.max(np.abs(o[0] * o[0] + o[1] * o[1] - 1.0)) <= 1.2e-7
 
 
-def test_stereo_panner_stereo(orc):
+def test_stereo_panner_stereo(be):
     """src/node/stereo_panner.rs:465-552"""
     ones = np.ones((2, 128), np.float32)
-    o = _pan(orc, ones, -1.0)
+    o = _pan(be, ones, -1.0)
     assert np.array_equal(o[0], np.full(128, 2.0, np.float32)) and np.array_equal(o[1], np.zeros(128, np.float32))
-    o = _pan(orc, ones, 1.0)
+    o = _pan(be, ones, 1.0)
     assert np.max(np.abs(o[0])) <= 1e-7 and np.array_equal(o[1], np.full(128, 2.0, np.float32))
-    o = _pan(orc, ones, 0.0)
+    o = _pan(be, ones, 0.0)
     assert np.max(np.abs(o[0] - 1.0)) <= 1e-7 and np.array_equal(o[1], np.ones(128, np.float32))
 
 
-def test_stereo_panner_rejects_max_mode(orc):
+def test_stereo_panner_rejects_max_mode(be):
     """src/node/stereo_panner.rs:60-68"""
-    c = ctx(orc, 2, 128, 44100.0)
+    c = ctx(be, 2, 128, 44100.0)
     c.create_stereo_panner(channel_count=2, channel_count_mode="max")
     with pytest.raises(waa.WaaError, match="NotSupportedError"):
         c.start_rendering_sync()
@@ -282,10 +287,10 @@ def test_spatial_geometry(orc_lib):
     assert orc_lib.orc_spatial_angle(F3(1, 0, 0), F3(0, -1, 0), LP) == 90.0
 
 
-def test_panner_equal_power_mono_to_stereo(orc):
+def test_panner_equal_power_mono_to_stereo(be):
     """src/node/panner.rs:1081-1131"""
     sr = 44100.0
-    c = ctx(orc, 2, RQ * 4, sr)
+    c = ctx(be, 2, RQ * 4, sr)
     s = c.create_buffer_source()
     s.set_buffer(buf(np.ones((1, RQ)), sr))
     s.start()
@@ -299,10 +304,10 @@ def test_panner_equal_power_mono_to_stereo(orc):
     assert np.max(np.abs(o[:, 128:256])) <= 1e-6
 
 
-def test_panner_equal_power_azimuth(orc):
+def test_panner_equal_power_azimuth(be):
     """src/node/panner.rs:1133-1168"""
     sr = 44100.0
-    c = ctx(orc, 2, RQ, sr)
+    c = ctx(be, 2, RQ, sr)
     s = c.create_buffer_source()
     s.set_buffer(buf(np.ones((1, RQ)), sr))
     s.start()
@@ -314,10 +319,10 @@ def test_panner_equal_power_azimuth(orc):
     assert np.max(np.abs(o[0] - r)) <= 1e-6 and np.max(np.abs(o[1] - r)) <= 1e-6
 
 
-def test_panner_equal_power_stereo_to_stereo(orc):
+def test_panner_equal_power_stereo_to_stereo(be):
     """src/node/panner.rs:1170-1223"""
     sr = 44100.0
-    c = ctx(orc, 2, RQ, sr)
+    c = ctx(be, 2, RQ, sr)
     c.listener().set_position(10.0, 0.0, 0.0)
     c.listener().set_orientation(1.0, 0.0, 0.0, 0.0, 0.0, 1.0)
     s = c.create_buffer_source()
@@ -330,8 +335,8 @@ def test_panner_equal_power_stereo_to_stereo(orc):
     assert np.max(np.abs(o[0] - 0.2)) <= 1e-3 and np.max(np.abs(o[1])) <= 1e-3
 
 
-def test_panner_hrtf_out_of_scope(orc):
-    c = ctx(orc, 2, RQ, 44100.0)
+def test_panner_hrtf_out_of_scope(be):
+    c = ctx(be, 2, RQ, 44100.0)
     c.create_panner(panning_model="HRTF")
     with pytest.raises(waa.WaaError) as e:
         c.start_rendering_sync()
@@ -339,8 +344,8 @@ def test_panner_hrtf_out_of_scope(orc):
 
 
 # ----------------------------------------------------------------------------- buffer source
-def _play(orc, data, sr, length=RQ, channels=1, buf_sr=None, setup=None):
-    c = ctx(orc, channels, length, sr)
+def _play(be, data, sr, length=RQ, channels=1, buf_sr=None, setup=None):
+    c = ctx(be, channels, length, sr)
     s = c.create_buffer_source()
     s.connect(c.destination())
     b = buf(data, buf_sr or sr)
@@ -349,23 +354,23 @@ def _play(orc, data, sr, length=RQ, channels=1, buf_sr=None, setup=None):
     return c.start_rendering_sync().data[0]
 
 
-def test_source_sub_quantum_start(orc):
+def test_source_sub_quantum_start(be):
     """src/node/audio_buffer_source.rs:974-995, :1036-1057"""
     sr = 48000.0
-    o = _play(orc, [[1.0]], sr, setup=lambda s, b: s.start_at(1.0 / sr))
+    o = _play(be, [[1.0]], sr, setup=lambda s, b: s.start_at(1.0 / sr))
     e = np.zeros(RQ, np.float32)
     e[1] = 1.0
     assert np.array_equal(o[0], e)
-    o = _play(orc, [[1.0]], sr, setup=lambda s, b: s.start_at(1.5 / sr))
+    o = _play(be, [[1.0]], sr, setup=lambda s, b: s.start_at(1.5 / sr))
     e = np.zeros(RQ, np.float32)
     e[2] = 0.5
     assert np.array_equal(o[0], e)
 
 
-def test_source_sample_accurate_scheduling(orc):
+def test_source_sample_accurate_scheduling(be):
     """src/node/audio_buffer_source.rs:997-1033"""
     sr = 44100.0
-    c = ctx(orc, 2, int(4 * sr), sr)
+    c = ctx(be, 2, int(4 * sr), sr)
     d = np.zeros((2, 512), np.float32)
     d[:, 0] = 1.0
     offsets = [0, 3, 512, 517, 1000, 1005, 20000, 21234, 37590]
@@ -380,7 +385,7 @@ def test_source_sample_accurate_scheduling(orc):
         assert o[0, idx] != 0.0
 
 
-def test_source_stop(orc):
+def test_source_stop(be):
     """src/node/audio_buffer_source.rs:1059-1149"""
     sr = 48000.0
     z = np.zeros(RQ, np.float32)
@@ -390,27 +395,27 @@ def test_source_stop(orc):
         a[0, :len(v)] = v
         return a
 
-    o = _play(orc, pad([0, 0, 0, 0, 1]), sr, setup=lambda s, b: (s.start_at(0.0), s.stop_at(4.0 / sr)))
+    o = _play(be, pad([0, 0, 0, 0, 1]), sr, setup=lambda s, b: (s.start_at(0.0), s.stop_at(4.0 / sr)))
     assert np.array_equal(o[0], z)
-    o = _play(orc, pad([0, 0, 0, 1]), sr, setup=lambda s, b: (s.start_at(1.0 / sr), s.stop_at(4.0 / sr)))
+    o = _play(be, pad([0, 0, 0, 1]), sr, setup=lambda s, b: (s.start_at(1.0 / sr), s.stop_at(4.0 / sr)))
     assert np.array_equal(o[0], z)
-    o = _play(orc, pad([0, 0, 0, 0, 1, 1]), sr, setup=lambda s, b: (s.start_at(0.0), s.stop_at(4.5 / sr)))
+    o = _play(be, pad([0, 0, 0, 0, 1, 1]), sr, setup=lambda s, b: (s.start_at(0.0), s.stop_at(4.5 / sr)))
     e = z.copy()
     e[4] = 1.0
     assert np.array_equal(o[0], e)
-    o = _play(orc, pad([0, 0, 0, 0, 1, 1]), sr, setup=lambda s, b: (s.start_at(1.0 / sr), s.stop_at(5.5 / sr)))
+    o = _play(be, pad([0, 0, 0, 0, 1, 1]), sr, setup=lambda s, b: (s.start_at(1.0 / sr), s.stop_at(5.5 / sr)))
     e = z.copy()
     e[5] = 1.0
     assert np.array_equal(o[0], e)
 
 
 @pytest.mark.parametrize("buf_sr", [22500, 38000, 43800, 48000, 96000])
-def test_source_buffer_resampling(orc, buf_sr):
+def test_source_buffer_resampling(be, buf_sr):
     """src/node/audio_buffer_source.rs:1175-1217 — 1 Hz sine at 5 buffer rates, 1e-6."""
     base = 44100
     i = np.arange(buf_sr, dtype=np.float32)
     sine = np.sin(np.float32(1.0) * i / np.float32(buf_sr) * np.float32(2.0) * F32PI).astype(np.float32)
-    o = _play(orc, sine[None, :], float(base), length=base, buf_sr=float(buf_sr), setup=lambda s, b: s.start_at(0.0))
+    o = _play(be, sine[None, :], float(base), length=base, buf_sr=float(buf_sr), setup=lambda s, b: s.start_at(0.0))
     j = np.arange(base, dtype=np.float32)
     exp = np.sin(j / np.float32(base) * np.float32(2.0) * F32PI).astype(np.float32)
     assert np.max(np.abs(o[0] - exp)) <= 1e-6
@@ -421,89 +426,89 @@ def _sine(n):
     return np.sin(i / np.float32(n) * np.float32(2.0) * F32PI).astype(np.float32)
 
 
-def test_source_playback_rate_and_detune(orc):
+def test_source_playback_rate_and_detune(be):
     """src/node/audio_buffer_source.rs:1220-1256, :1294-1329"""
     sr = 44100
     j = np.arange(sr, dtype=np.float32)
     exp = np.sin(j / np.float32(sr) * F32PI).astype(np.float32)
-    o = _play(orc, _sine(sr)[None, :], float(sr), length=sr,
+    o = _play(be, _sine(sr)[None, :], float(sr), length=sr,
               setup=lambda s, b: (s.playback_rate.set_value(0.5), s.start()))
     assert np.max(np.abs(o[0] - exp)) <= 1e-6
-    o = _play(orc, _sine(sr)[None, :], float(sr), length=sr, setup=lambda s, b: (s.detune.set_value(-1200.0), s.start()))
+    o = _play(be, _sine(sr)[None, :], float(sr), length=sr, setup=lambda s, b: (s.detune.set_value(-1200.0), s.start()))
     assert np.max(np.abs(o[0] - exp)) <= 1e-6
 
 
-def test_source_negative_playback_rate(orc):
+def test_source_negative_playback_rate(be):
     """src/node/audio_buffer_source.rs:1258-1291"""
     sr = 44100
     sine = _sine(sr)
-    o = _play(orc, sine[None, :], float(sr), length=sr,
+    o = _play(be, sine[None, :], float(sr), length=sr,
               setup=lambda s, b: (s.playback_rate.set_value(-1.0), s.start_at_with_offset(0.0, b.duration)))
     exp = sine[::-1].copy()
     exp = np.concatenate([[np.float32(0.0)], exp[:-1]])
     assert np.max(np.abs(o[0] - exp)) <= 1e-6
 
 
-def test_source_end_of_file(orc):
+def test_source_end_of_file(be):
     """src/node/audio_buffer_source.rs:1332-1381, :1837-1889"""
     sr = 48000.0
     d = np.zeros((1, 129), np.float32)
     d[0, 0] = d[0, 128] = 1.0
-    o = _play(orc, d, sr, length=256, setup=lambda s, b: s.start_at(0.0))
+    o = _play(be, d, sr, length=256, setup=lambda s, b: s.start_at(0.0))
     e = np.zeros(256, np.float32)
     e[0] = e[128] = 1.0
     assert np.array_equal(o[0], e)
-    o = _play(orc, d, sr, length=256, setup=lambda s, b: s.start_at(1.0 / sr))
+    o = _play(be, d, sr, length=256, setup=lambda s, b: s.start_at(1.0 / sr))
     e = np.zeros(256, np.float32)
     e[1] = e[129] = 1.0
     assert np.max(np.abs(o[0] - e)) <= 1e-10
     d5 = np.zeros((1, 5), np.float32)
     d5[0, 0] = 1.0
-    o = _play(orc, d5, sr, setup=lambda s, b: (s.start_at(0.0), s.stop_at(125.0 / sr)))
+    o = _play(be, d5, sr, setup=lambda s, b: (s.start_at(0.0), s.stop_at(125.0 / sr)))
     e = np.zeros(128, np.float32)
     e[0] = 1.0
     assert np.array_equal(o[0], e)
-    o = _play(orc, d5, sr, setup=lambda s, b: (s.start_at(1.0 / sr), s.stop_at(125.0 / sr)))
+    o = _play(be, d5, sr, setup=lambda s, b: (s.start_at(1.0 / sr), s.stop_at(125.0 / sr)))
     e = np.zeros(128, np.float32)
     e[1] = 1.0
     assert np.array_equal(o[0], e)
 
 
-def test_source_duration_and_offset(orc):
+def test_source_duration_and_offset(be):
     """src/node/audio_buffer_source.rs:1384-1506, :1537-1573"""
     sr = 48000.0
     d = np.zeros((1, RQ), np.float32)
     d[0, 4] = d[0, 5] = 1.0
-    o = _play(orc, d, sr, setup=lambda s, b: s.start_at_with_offset_and_duration(0.0, 0.0, 4.5 / sr))
+    o = _play(be, d, sr, setup=lambda s, b: s.start_at_with_offset_and_duration(0.0, 0.0, 4.5 / sr))
     e = np.zeros(RQ, np.float32)
     e[4] = 1.0
     assert np.array_equal(o[0], e)
-    o = _play(orc, d, sr, setup=lambda s, b: s.start_at_with_offset_and_duration(1.0 / sr, 0.0, 4.5 / sr))
+    o = _play(be, d, sr, setup=lambda s, b: s.start_at_with_offset_and_duration(1.0 / sr, 0.0, 4.5 / sr))
     e = np.zeros(RQ, np.float32)
     e[5] = 1.0
     assert np.array_equal(o[0], e)
-    o = _play(orc, d, sr, setup=lambda s, b: s.start_at_with_offset_and_duration(0.0, 1.0 / sr, 3.5 / sr))
+    o = _play(be, d, sr, setup=lambda s, b: s.start_at_with_offset_and_duration(0.0, 1.0 / sr, 3.5 / sr))
     e = np.zeros(RQ, np.float32)
     e[3] = 1.0
     assert np.array_equal(o[0], e)
     # wpt sub-sample-grain
     sr2 = 32768.0
     start_i, end_i = 3.1, 37.2
-    o = _play(orc, np.ones((1, RQ), np.float32), sr2,
+    o = _play(be, np.ones((1, RQ), np.float32), sr2,
               setup=lambda s, b: s.start_at_with_offset_and_duration(start_i / sr2, 0.0, (end_i - start_i) / sr2))
     e = np.ones(RQ, np.float32)
     e[:int(math.floor(start_i)) + 1] = 0.0
     e[int(math.ceil(end_i)):] = 0.0
     assert np.array_equal(o[0], e)
     # reverse playback with duration
-    o = _play(orc, [[1.0, 2.0, 3.0, 4.0, 5.0]], sr,
+    o = _play(be, [[1.0, 2.0, 3.0, 4.0, 5.0]], sr,
               setup=lambda s, b: (s.playback_rate.set_value(-1.0),
                                   s.start_at_with_offset_and_duration(0.0, b.duration, 2.0 / sr)))
     e = np.zeros(RQ, np.float32)
     e[1] = 5.0
     assert np.array_equal(o[0], e)
     # offset larger than buffer duration (source not connected in the reference test: output silent)
-    o = _play(orc, np.ones((1, 13), np.float32), sr, setup=lambda s, b: s.start_at_with_offset(0.0, 64.0 / sr))
+    o = _play(be, np.ones((1, 13), np.float32), sr, setup=lambda s, b: s.start_at_with_offset(0.0, 64.0 / sr))
     assert np.array_equal(o[0], np.zeros(RQ, np.float32))
 
 
@@ -511,16 +516,16 @@ LOOP_LENS = [RQ // 2 - 1, RQ // 2, RQ // 2 + 1, RQ - 1, RQ, RQ + 1, RQ * 2 - 1, 
 
 
 @pytest.mark.parametrize("blen", LOOP_LENS)
-def test_source_loops(orc, blen):
+def test_source_loops(be, blen):
     """src/node/audio_buffer_source.rs:1576-1756 — fast/slow track loops, mono/stereo."""
     sr, ln = 48000.0, RQ * 4
     d = np.zeros((1, blen), np.float32)
     d[0, 0] = 1.0
-    o = _play(orc, d, sr, length=ln, setup=lambda s, b: (s.set_loop(True), s.start()))
+    o = _play(be, d, sr, length=ln, setup=lambda s, b: (s.set_loop(True), s.start()))
     e = np.zeros(ln, np.float32)
     e[0:ln:blen] = 1.0
     assert np.max(np.abs(o[0] - e)) <= 1e-10
-    o = _play(orc, d, sr, length=ln, setup=lambda s, b: (s.set_loop(True), s.start_at(1.0 / sr)))
+    o = _play(be, d, sr, length=ln, setup=lambda s, b: (s.set_loop(True), s.start_at(1.0 / sr)))
     e = np.zeros(ln, np.float32)
     e[1:ln:blen] = 1.0
     assert np.max(np.abs(o[0] - e)) <= 1e-9
@@ -528,7 +533,7 @@ def test_source_loops(orc, blen):
     d2[0, 0] = 1.0
     d2[1, 1] = 1.0
     for start, first, tol in [(0.0, 0, 1e-10), (1.0 / sr, 1, 1e-9)]:
-        o = _play(orc, d2, sr, length=ln, channels=2, setup=lambda s, b: (s.set_loop(True), s.start_at(start)))
+        o = _play(be, d2, sr, length=ln, channels=2, setup=lambda s, b: (s.set_loop(True), s.start_at(start)))
         el, er = np.zeros(ln, np.float32), np.zeros(ln, np.float32)
         for i in range(first, ln, blen):
             el[i] = 1.0
@@ -537,10 +542,10 @@ def test_source_loops(orc, blen):
         assert np.max(np.abs(o[0] - el)) <= tol and np.max(np.abs(o[1] - er)) <= tol
 
 
-def test_source_reverse_loop_boundaries(orc):
+def test_source_reverse_loop_boundaries(be):
     """src/node/audio_buffer_source.rs:1758-1778"""
     sr = 48000.0
-    o = _play(orc, [[1.0, 2.0, 3.0, 4.0, 5.0]], sr,
+    o = _play(be, [[1.0, 2.0, 3.0, 4.0, 5.0]], sr,
               setup=lambda s, b: (s.set_loop(True), s.set_loop_start(1.0 / sr), s.set_loop_end(4.0 / sr),
                                   s.playback_rate.set_value(-1.0), s.start_at_with_offset(0.0, 3.0 / sr)))
     assert np.array_equal(o[0, :8], np.float32([4, 3, 2, 4, 3, 2, 4, 3]))
@@ -548,22 +553,22 @@ def test_source_reverse_loop_boundaries(orc):
 
 @pytest.mark.parametrize("ls,le,err", [(-2.0, -1.0, 0.0), (-1.0, -2.0, 0.0), (0.0, 0.0, 0.0), (-1.0, 2.0, 0.0),
                                        (2.0, -1.0, 1e-10), (1.0, 1.0, 1e-10), (2.0, 3.0, 1e-10), (3.0, 2.0, 1e-10)])
-def test_source_loop_out_of_bounds(orc, ls, le, err):
+def test_source_loop_out_of_bounds(be, ls, le, err):
     """src/node/audio_buffer_source.rs:1780-1835"""
     sr = 48000.0
     length = 4800
     d = np.zeros((1, 500), np.float32)
     d[0, 0] = 1.0
-    o = _play(orc, d, sr, length=length,
+    o = _play(be, d, sr, length=length,
               setup=lambda s, b: (s.set_loop(True), s.set_loop_start(ls), s.set_loop_end(le), s.start()))
     e = np.zeros(length, np.float32)
     e[0:length:500] = 1.0
     assert np.max(np.abs(o[0] - e)) <= err
 
 
-def test_source_start_twice(orc):
+def test_source_start_twice(be):
     """src/node/scheduled_source.rs / audio_buffer_source.rs:300 InvalidStateError"""
-    c = ctx(orc, 1, RQ, 48000.0)
+    c = ctx(be, 1, RQ, 48000.0)
     s = c.create_buffer_source()
     s.start()
     with pytest.raises(waa.WaaError, match="InvalidStateError"):
@@ -571,10 +576,10 @@ def test_source_start_twice(orc):
 
 
 # ----------------------------------------------------------------------------- waveshaper
-def test_waveshaper(orc):
+def test_waveshaper(be):
     """src/node/waveshaper.rs:673-741 (tolerance 0)"""
     sr = 44100.0
-    c = ctx(orc, 1, 3 * RQ, sr)
+    c = ctx(be, 1, 3 * RQ, sr)
     sh = c.create_wave_shaper()
     sh.set_curve([-0.5, 0.0, 0.5])
     sh.connect(c.destination())
@@ -586,7 +591,7 @@ def test_waveshaper(orc):
     o = c.start_rendering_sync().data[0, 0]
     assert np.array_equal(o, (data * np.float32(0.5)).astype(np.float32))
 
-    c = ctx(orc, 1, RQ, sr)
+    c = ctx(be, 1, RQ, sr)
     sh = c.create_wave_shaper()
     sh.set_curve([-0.5, 0.0, 0.5])
     sh.connect(c.destination())
@@ -601,8 +606,8 @@ def test_waveshaper(orc):
     assert np.array_equal(o, (x / np.float32(2.0)).astype(np.float32))
 
 
-def test_waveshaper_oversample_out_of_scope(orc):
-    c = ctx(orc, 1, RQ, 44100.0)
+def test_waveshaper_oversample_out_of_scope(be):
+    c = ctx(be, 1, RQ, 44100.0)
     c.create_wave_shaper(oversample="2x")
     with pytest.raises(waa.WaaError) as e:
         c.start_rendering_sync()
@@ -610,8 +615,8 @@ def test_waveshaper_oversample_out_of_scope(orc):
 
 
 # ----------------------------------------------------------------------------- convolver
-def _convolve(orc, signal, ir, length, normalize=True, channels=1, sr=44100.0):
-    c = ctx(orc, channels, length, sr)
+def _convolve(be, signal, ir, length, normalize=True, channels=1, sr=44100.0):
+    c = ctx(be, channels, length, sr)
     s = c.create_buffer_source()
     s.set_buffer(buf(signal, sr))
     s.start()
@@ -622,35 +627,35 @@ def _convolve(orc, signal, ir, length, normalize=True, channels=1, sr=44100.0):
     return c.start_rendering_sync().data[0]
 
 
-def test_convolver_basic(orc):
+def test_convolver_basic(be):
     """src/node/convolver.rs:551-650"""
     cal = np.float32(0.00125)
     sig = [[0.0, 1.0, 0.0, -1.0, 0.0]]
-    o = _convolve(orc, sig, None, 10)
+    o = _convolve(be, sig, None, 10)
     assert np.max(np.abs(o[0] - np.float32([0, 1, 0, -1, 0, 0, 0, 0, 0, 0]))) <= 1e-6
-    o = _convolve(orc, sig, np.zeros((1, 0), np.float32), 10)
+    o = _convolve(be, sig, np.zeros((1, 0), np.float32), 10)
     assert np.max(np.abs(o[0])) <= 1e-6
-    o = _convolve(orc, sig, [[0.0] * 6], 10)
+    o = _convolve(be, sig, [[0.0] * 6], 10)
     assert np.max(np.abs(o[0])) <= 1e-6
-    o = _convolve(orc, sig, [[1.0]], 10)
+    o = _convolve(be, sig, [[1.0]], 10)
     assert np.max(np.abs(o[0] - np.float32([0, cal, 0, -cal, 0, 0, 0, 0, 0, 0]))) <= 1e-6
-    o = _convolve(orc, sig, [[1.0, 1.0]], 10)
+    o = _convolve(be, sig, [[1.0, 1.0]], 10)
     assert np.max(np.abs(o[0] - np.float32([0, cal, cal, -cal, -cal, 0, 0, 0, 0, 0]))) <= 1e-6
 
 
-def test_convolver_tail_time(orc):
+def test_convolver_tail_time(be):
     """src/node/convolver.rs:653-668"""
-    o = _convolve(orc, [[1.0]], np.ones((1, 256), np.float32), 512)[0]
+    o = _convolve(be, [[1.0]], np.ones((1, 256), np.float32), 512)[0]
     assert not np.any(o[:256] <= 1e-6)
     assert np.max(np.abs(o[256:])) <= 1e-6
 
 
-def test_convolver_errors(orc):
+def test_convolver_errors(be):
     """src/node/convolver.rs:520-549"""
-    c = ctx(orc, 1, 128, 44100.0)
+    c = ctx(be, 1, 128, 44100.0)
     with pytest.raises(waa.WaaError, match="NotSupportedError"):
         c.create_convolver(buffer=buf([[1.0]], 48000.0))
-    c = ctx(orc, 1, 128, 48000.0)
+    c = ctx(be, 1, 128, 48000.0)
     with pytest.raises(waa.WaaError, match="NotSupportedError"):
         c.create_convolver(buffer=buf(np.ones((3, 1)), 48000.0))
 
@@ -664,9 +669,9 @@ def test_convolver_errors(orc):
      {0: [1, 4], 1: [2, 5]}),
     ([[1.0, 0.0]], [[0, 1, 0, 0, 0], [0, 0, 1, 0, 0], [0, 0, 0, 1, 0], [0, 0, 0, 0, 1]], 2, {0: [1, 3], 1: [2, 4]}),
 ])
-def test_convolver_channel_routing(orc, inp, ir, n_out, expect):
+def test_convolver_channel_routing(be, inp, ir, n_out, expect):
     """src/node/convolver.rs:671-991 — six (input, IR) channel configurations, 1e-7."""
-    o = _convolve(orc, inp, ir, 128, normalize=False, channels=n_out)
+    o = _convolve(be, inp, ir, 128, normalize=False, channels=n_out)
     for c in range(n_out):
         e = np.zeros(128, np.float32)
         for i in expect[c]:
@@ -696,17 +701,17 @@ def test_fftconvolver_matches_exact_multi_partition(orc_lib):
 
 
 # ----------------------------------------------------------------------------- resample
-def test_buffer_resample(orc):
+def test_buffer_resample(be):
     """src/buffer.rs:736-817"""
-    o = waa.resample(orc, [[1, 2, 3, 4, 5]], 48000.0, 96000.0)
+    o = waa.resample(be, [[1, 2, 3, 4, 5]], 48000.0, 96000.0)
     exp = np.float32(1.0) + np.float32(4.0 / 9.0) * np.arange(10, dtype=np.float32)
     assert o.shape == (1, 10) and np.max(np.abs(o[0] - exp)) <= 1e-6
-    o = waa.resample(orc, [[1, 2, 3, 4, 5]], 96000.0, 48000.0)
+    o = waa.resample(be, [[1, 2, 3, 4, 5]], 96000.0, 48000.0)
     assert np.array_equal(o[0], np.float32([1, 3, 5]))
     for sr in (22500, 38000, 48000, 96000):
         i = np.arange(sr, dtype=np.float32)
         ph = i / np.float32(sr) * np.float32(2.0) * F32PI
-        o = waa.resample(orc, np.stack([np.sin(ph), np.cos(ph)]).astype(np.float32), float(sr), 44100.0)
+        o = waa.resample(be, np.stack([np.sin(ph), np.cos(ph)]).astype(np.float32), float(sr), 44100.0)
         j = np.arange(44100, dtype=np.float32) / np.float32(44100) * np.float32(2.0) * F32PI
         assert o.shape == (2, 44100)
         assert np.max(np.abs(o[0] - np.sin(j))) <= 1e-3 and np.max(np.abs(o[1] - np.cos(j))) <= 1e-3
@@ -723,14 +728,14 @@ def test_blackman(orc_lib):
     assert int(np.argmin(v)) == 0 and int(np.argmax(v)) == 1024
 
 
-def test_analyser_peak_bin_and_silence(orc):
+def test_analyser_peak_bin_and_silence(be):
     """src/analysis.rs:721-796 driven through a render: source -> analyser -> destination."""
     sr, fft = 44100.0, 1024
     for num_bin in (1, 7, 40, 127):
         freq = np.float32(43.066) * np.float32(num_bin)
         i = np.arange(fft, dtype=np.float32)
         sig = np.sin(freq * i / np.float32(sr) * np.float32(2.0) * F32PI).astype(np.float32)
-        c = ctx(orc, 1, fft, sr)
+        c = ctx(be, 1, fft, sr)
         s = c.create_buffer_source()
         s.set_buffer(buf(sig[None, :], sr))
         s.start()
@@ -742,7 +747,7 @@ def test_analyser_peak_bin_and_silence(orc):
         assert bins.shape == (fft // 2,) and int(np.argmax(bins)) == num_bin
         td = a.get_float_time_domain_data()
         assert np.array_equal(td, sig)
-    c = ctx(orc, 1, RQ, sr)
+    c = ctx(be, 1, RQ, sr)
     a = c.create_analyser(fft_size=RQ)
     a.connect(c.destination())
     c.start_rendering_sync()
@@ -751,12 +756,12 @@ def test_analyser_peak_bin_and_silence(orc):
     assert np.all(a.get_byte_frequency_data() == 0)
 
 
-def test_analyser_matches_numpy_dft(orc):
+def test_analyser_matches_numpy_dft(be):
     """dB values are 'parity unpinned' by the reference; pin the oracle to the DFT definition."""
     sr, fft, n = 48000.0, 2048, 128 * 40
     rng = np.random.default_rng(3)
     x = rng.uniform(-1, 1, (2, n)).astype(np.float32)
-    c = ctx(orc, 2, n, sr)
+    c = ctx(be, 2, n, sr)
     s = c.create_buffer_source()
     s.set_buffer(buf(x, sr))
     s.start()

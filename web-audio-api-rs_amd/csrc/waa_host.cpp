@@ -1,0 +1,1690 @@
+// waa_host.cpp — host side of libwaa_hip.so: the C ABI (include/waa_hip.h), graph validation,
+// the planner that fuses single-consumer node paths into chain-kernel launches, the host-side
+// scheduler of AudioBufferSourceNode (port of the playhead state machine — scheduling stays on
+// the host), AudioParam materialisation and coefficient pre-computation.
+//
+// All sample arithmetic happens in the HIP kernels (waa_kernels.hip, waa_conv.hip); there is no
+// CPU fallback: without a HIP device every render call fails with WAA_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/waa_hip.h"
+#include "waa_internal.hpp"
+
+using namespace waa;
+
+struct waa_batch;
+static int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in);
+
+namespace {
+
+thread_local char g_err[768];
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(WAA_ERR_DEVICE, "HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, \
+                                      __LINE__, #expr);                                         \
+  } while (0)
+
+struct ParamBlock {
+  uint32_t inst;
+  uint64_t q0;
+  uint32_t nq, vpq;
+  std::vector<float> v;
+};
+struct ParamStore {
+  std::vector<float> cst;
+  std::vector<ParamBlock> blocks;
+  float defv = 0, minv = -FLT_MAX, maxv = FLT_MAX;
+  void init(uint32_t n, float d, float lo, float hi) {
+    cst.assign(n, d);
+    defv = d;
+    minv = lo;
+    maxv = hi;
+  }
+  // AudioParamProcessor::mix_to_output clamp / NaN rule (param.rs:739-797)
+  float fix(float x) const { return std::isnan(x) ? defv : std::fmin(std::fmax(x, minv), maxv); }
+  int mode() const {
+    int m = 0;
+    for (auto& b : blocks) m = std::max(m, b.vpq == 1 ? 1 : 2);
+    return m;
+  }
+};
+
+struct DeviceBuffer {  // an AudioBuffer resident in HBM
+  float* base = nullptr;  // channel 0
+  uint64_t ch_stride = 0;
+  uint64_t frames = 0;
+  uint32_t nch = 0;
+  float sr = 0;
+  bool valid = false;
+};
+
+struct SourceSched {  // per instance scheduling parameters
+  double start = DBL_MAX, stop = DBL_MAX, offset = 0, duration = DBL_MAX;
+  int looping = 0;
+  double loop_start = 0, loop_end = 0;
+};
+
+struct Node {
+  waa_node_desc desc{};
+  int cc = 2, mode = WAA_COUNT_MODE_MAX, interp = WAA_INTERP_SPEAKERS;
+  std::vector<ParamStore> params;
+  // sources
+  std::vector<DeviceBuffer> bufs;   // [n_inst]
+  std::vector<SourceSched> sched;   // [n_inst]
+  // convolver
+  std::vector<std::vector<float>> ir;  // host copy, scaled
+  uint64_t ir_len = 0;
+  int ir_nch = 0;
+  bool has_ir = false;
+  // waveshaper
+  std::vector<float> curve;
+  bool has_curve = false;
+  float* d_curve = nullptr;
+  // planning
+  int in_nch = 1;      // computed input channel count
+  int out_nch = 1;     // static output channel count
+  bool live = false;
+  bool materialized = false;
+  SignalRef sig{};     // valid when materialized
+  std::vector<int> in_edges;   // indices into edges, in summing order
+  int n_consumers = 0;
+};
+
+struct ProfileEntry {
+  std::string name;
+  uint64_t launches = 0;
+  double total_ms = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct Step {
+  int kind = 0;  // 0 chain
+  ChainDesc chain{};
+  int cmax = 1;
+  int profile_slot = -1;
+};
+
+}  // namespace
+
+struct waa_batch {
+  uint32_t n_inst = 0, n_out = 0;
+  uint64_t length = 0;
+  float sr = 0;
+  uint32_t n_quanta = 0, n_tiles = 0;
+  uint64_t lp = 0;  // padded frames per channel
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<Node> nodes;
+  std::vector<waa_edge_desc> edges;
+  std::vector<uint32_t> order;
+  std::vector<void*> allocs;        // plan-owned device allocations
+  std::vector<void*> payload_allocs;  // buffers uploaded through the API
+  std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render
+  std::vector<Step> steps;
+  bool planned = false;
+  bool profiling = false;
+  std::vector<ProfileEntry> prof;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail(WAA_ERR_DEVICE, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  (payload ? b->payload_allocs : b->allocs).push_back(p);
+  *out = reinterpret_cast<T*>(p);
+  return 0;
+}
+template <typename T>
+int dev_upload(waa_batch* b, T** out, const std::vector<T>& host) {
+  int e = dev_alloc(b, out, host.size());
+  if (e) return e;
+  if (!host.empty()) HIP_TRY(hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int check_node(waa_batch* b, uint32_t node, uint32_t kind) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (node >= b->nodes.size() || b->nodes[node].desc.kind != kind)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not of the expected kind", node);
+  return 0;
+}
+int check_inst(waa_batch* b, uint32_t inst) {
+  if (inst != WAA_ALL_INSTANCES && inst >= b->n_inst) return fail(WAA_ERR_INVALID_ARGUMENT, "instance out of range");
+  return 0;
+}
+int check_unplanned(waa_batch* b) {
+  if (b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - the batch is frozen once rendering has started");
+  return 0;
+}
+
+// ---- almost crate 0.2 (see oracle header for the provenance note) ----------------------
+const double ALMOST_TOL = 1.4901161193847656e-8;
+bool almost_zero(double a) { return std::fabs(a) < ALMOST_TOL; }
+bool almost_equal(double a, double b) {
+  if (a == b) return true;
+  if (!std::isfinite(a) || !std::isfinite(b)) return false;
+  double scale = std::fmax(std::fabs(a), std::fabs(b));
+  if (scale < 1.0) scale = 1.0;
+  return std::fabs(a - b) < scale * ALMOST_TOL;
+}
+
+// ---- biquad coefficients (biquad_filter.rs:28-373), f64 ---------------------------------
+struct Coefs {
+  double b0, b1, b2, a1, a2;
+};
+Coefs norm(double b0, double b1, double b2, double a0, double a1, double a2) {
+  double s = 1. / a0;
+  return {b0 * s, b1 * s, b2 * s, a1 * s, a2 * s};
+}
+Coefs biquad_coefs(int type, double sample_rate, double f0, double gain, double q) {
+  const double PI = 3.14159265358979323846;
+  double nyq = sample_rate / 2.;
+  double f = f0 / nyq;
+  f = f < 0. ? 0. : f > 1. ? 1. : f;
+  const Coefs wire{1., 0., 0., 0., 0.}, zero{0., 0., 0., 0., 0.};
+  double A = std::pow(10., gain / 40.);
+  switch (type) {
+    case WAA_BIQUAD_LOWPASS: {
+      if (f == 1.) return wire;
+      double w0 = PI * f, al = std::sin(w0) / (2. * std::pow(10., q / 20.)), cw = std::cos(w0), be = (1. - cw) / 2.;
+      return norm(be, 2. * be, be, 1. + al, -2. * cw, 1. - al);
+    }
+    case WAA_BIQUAD_HIGHPASS: {
+      if (f == 1.) return zero;
+      if (f == 0.) return wire;
+      double w0 = PI * f, al = std::sin(w0) / (2. * std::pow(10., q / 20.)), cw = std::cos(w0), be = (1. + cw) / 2.;
+      return norm(be, -2. * be, be, 1. + al, -2. * cw, 1. - al);
+    }
+    case WAA_BIQUAD_BANDPASS: {
+      if (!(f > 0. && f < 1.)) return zero;
+      if (!(q > 0.)) return wire;
+      double w0 = PI * f, al = std::sin(w0) / (2. * q), cw = std::cos(w0);
+      return norm(al, 0., -al, 1. + al, -2. * cw, 1. - al);
+    }
+    case WAA_BIQUAD_NOTCH: {
+      if (!(f > 0. && f < 1.)) return wire;
+      if (!(q > 0.)) return zero;
+      double w0 = PI * f, al = std::sin(w0) / (2. * q), cw = std::cos(w0);
+      return norm(1., -2. * cw, 1., 1. + al, -2. * cw, 1. - al);
+    }
+    case WAA_BIQUAD_ALLPASS: {
+      if (!(f > 0. && f < 1.)) return wire;
+      if (!(q > 0.)) return Coefs{-1., 0., 0., 0., 0.};
+      double w0 = PI * f, al = std::sin(w0) / (2. * q), cw = std::cos(w0);
+      return norm(1. - al, -2. * cw, 1. + al, 1. + al, -2. * cw, 1. - al);
+    }
+    case WAA_BIQUAD_PEAKING: {
+      if (!(f > 0. && f < 1.)) return wire;
+      if (!(q > 0.)) return Coefs{A * A, 0., 0., 0., 0.};
+      double w0 = PI * f, al = std::sin(w0) / (2. * q), cw = std::cos(w0);
+      return norm(1. + al * A, -2. * cw, 1. - al * A, 1. + al / A, -2. * cw, 1. - al / A);
+    }
+    case WAA_BIQUAD_LOWSHELF: {
+      if (f == 1.) return Coefs{A * A, 0., 0., 0., 0.};
+      if (f == 0.) return wire;
+      double w0 = PI * f, cw = std::cos(w0), as = std::sin(w0) / 2. * 1.41421356237309504880;
+      double k = 2. * as * std::sqrt(A), ap = A + 1., am = A - 1.;
+      return norm(A * (ap - am * cw + k), 2. * A * (am - ap * cw), A * (ap - am * cw - k), ap + am * cw + k,
+                  -2. * (am + ap * cw), ap + am * cw - k);
+    }
+    default: {
+      if (f == 1.) return wire;
+      if (!(f > 0.)) return Coefs{A * A, 0., 0., 0., 0.};
+      double w0 = PI * f, cw = std::cos(w0), as = std::sin(w0) / 2. * 1.41421356237309504880;
+      double k = 2. * as * std::sqrt(A), ap = A + 1., am = A - 1.;
+      return norm(A * (ap + am * cw + k), -2. * A * (am + ap * cw), A * (ap + am * cw - k), ap - am * cw + k,
+                  2. * (am - ap * cw), ap - am * cw - k);
+    }
+  }
+}
+float computed_freq(float freq, float detune) { return detune != 0.f ? freq * exp2f(detune / 1200.f) : freq; }
+
+// ---- spatial geometry (spatial.rs:205-299, panner.rs:927-985), f32 as the reference -----
+struct V3 {
+  float x, y, z;
+};
+V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+float sqlen(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+V3 scale(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+V3 normalized(V3 a) { return scale(a, 1.f / std::sqrt(sqlen(a))); }
+V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+const float PI_F = 3.14159265358979323846f;
+
+void azimuth_elevation(V3 sp, V3 lp, V3 lf, V3 lu, float* az, float* el) {
+  *az = 0.f;
+  *el = 0.f;
+  V3 rel = sub(sp, lp);
+  if (sqlen(rel) <= FLT_MIN) return;
+  V3 sl = normalized(rel);
+  V3 right = cross(lf, lu);
+  if (sqlen(right) == 0.f) return;
+  V3 rn = normalized(right), fn = normalized(lf), up = cross(rn, fn);
+  float elevation = 90.f - 180.f * acosf(dot(sl, up)) / PI_F;
+  if (elevation > 90.f)
+    elevation = 180.f - elevation;
+  else if (elevation < -90.f)
+    elevation = -180.f - elevation;
+  float up_proj = dot(sl, up);
+  V3 ps = sub(sl, scale(up, up_proj));
+  *el = elevation;
+  if (sqlen(ps) == 0.f) return;
+  V3 psn = normalized(ps);
+  float azimuth = 180.f * acosf(dot(psn, rn)) / PI_F;
+  if (dot(psn, fn) < 0.f) azimuth = 360.f - azimuth;
+  if (azimuth >= 0.f && azimuth <= 270.f)
+    azimuth = 90.f - azimuth;
+  else
+    azimuth = 450.f - azimuth;
+  *az = azimuth;
+}
+float spatial_angle(V3 sp, V3 so, V3 lp) {
+  if (sqlen(so) == 0.f) return 0.f;
+  V3 son = normalized(so), rel = sub(sp, lp);
+  if (sqlen(rel) <= FLT_MIN) return 0.f;
+  V3 sl = normalized(rel);
+  return std::fabs(180.f * acosf(dot(sl, son)) / PI_F);
+}
+float cone_gain(const waa_node_desc& d, V3 sp, V3 so, V3 lp) {
+  float in = (float)std::fabs(d.d[3]) / 2.f, out = (float)std::fabs(d.d[4]) / 2.f;
+  if (in >= 180.f && out >= 180.f) return 1.f;
+  float cog = (float)d.d[5];
+  float a = spatial_angle(sp, so, lp);
+  if (a < in) return 1.f;
+  if (a >= out) return cog;
+  float x = (a - in) / (out - in);
+  return (1.f - x) + cog * x;
+}
+float dist_gain(const waa_node_desc& d, V3 sp, V3 lp) {
+  double distance = (double)std::sqrt(sqlen(sub(sp, lp)));
+  double ref = d.d[0], maxd = d.d[1], roll = d.d[2], g;
+  switch (d.i[1]) {
+    case WAA_DISTANCE_LINEAR: {
+      double rf = roll < 0. ? 0. : roll > 1. ? 1. : roll;
+      double lo = std::fmin(ref, maxd), hi = std::fmax(ref, maxd);
+      double dc = distance < lo ? lo : distance > hi ? hi : distance;
+      g = 1. - rf * (dc - lo) / (hi - lo);
+      break;
+    }
+    case WAA_DISTANCE_INVERSE: {
+      double rf = std::fmax(roll, 0.);
+      g = distance > 0. ? ref / (ref + rf * (std::fmax(ref, distance) - ref)) : 1.;
+      break;
+    }
+    default: {
+      double rf = std::fmax(roll, 0.);
+      g = std::pow(std::fmax(distance, ref) / ref, -rf);
+    }
+  }
+  return (float)g;
+}
+
+// ---- AudioBufferSourceNode scheduler: port of audio_buffer_source.rs:422-845 -------------
+struct SchedOut {
+  std::vector<QRec> qrec;
+  std::vector<SlowRec> slow;  // empty if no slow quantum
+  std::vector<uint8_t> tile_fast;
+  bool any_slow = false;
+};
+using SchedKey = std::tuple<double, double, double, double, int, double, double, uint64_t, float, float, float>;
+
+void schedule_source(const waa_batch* b, const SourceSched& cfg, uint64_t frames, float buf_sr, bool has_buffer,
+                     const std::vector<float>& rate_q, const std::vector<float>& detune_q, SchedOut* out) {
+  const uint32_t nq = b->n_quanta;
+  out->qrec.assign(nq, QRec{0, Q_SILENT, 0});
+  out->slow.clear();
+  out->any_slow = false;
+  double start_time = cfg.start, stop_time = cfg.stop, offset = cfg.offset, duration = cfg.duration;
+  const double sample_rate = (double)b->sr;
+  const double dt = 1. / sample_rate;
+  const double block_duration = dt * (double)RQ;
+  const double buffer_duration = has_buffer ? (double)frames / (double)buf_sr : 0.;
+  // clamp_loop_boundaries (:401-417)
+  double loop_start = cfg.loop_start, loop_end = cfg.loop_end;
+  if (has_buffer) {
+    if (loop_start < 0.)
+      loop_start = 0.;
+    else if (loop_start > buffer_duration)
+      loop_start = buffer_duration;
+    if (loop_end <= 0. || loop_end > buffer_duration) loop_end = buffer_duration;
+  }
+  const bool is_looping = cfg.looping != 0;
+  const double sampling_ratio = has_buffer ? (double)buf_sr / sample_rate : 1.;
+  double buffer_time = 0., elapsed = 0.;
+  bool started = false, entered_loop = false, is_aligned = false, ended = false;
+  auto ensure_slow = [&]() {
+    if (!out->any_slow) {
+      out->slow.assign((size_t)nq * RQ, SlowRec{-1, -1, 0.});
+      out->any_slow = true;
+    }
+  };
+  for (uint32_t q = 0; q < nq; q++) {
+    if (ended) break;
+    const double block_time = (double)((uint64_t)q * RQ) / sample_rate;  // thread.rs:360
+    const double next_block_time = block_time + block_duration;
+    if (!has_buffer && start_time != DBL_MAX) break;  // ended
+    if (start_time >= next_block_time) {
+      if (stop_time <= next_block_time) break;
+      continue;
+    }
+    if (!has_buffer) continue;
+    const double detune = (double)detune_q[detune_q.size() == 1 ? 0 : q];
+    const double playback_rate = (double)rate_q[rate_q.size() == 1 ? 0 : q];
+    const double cpr = playback_rate * std::exp2(detune / 1200.);
+    double actual_loop_start = 0., actual_loop_end = 0.;
+    if (!started && start_time < block_time) start_time = block_time;
+    if (start_time == block_time && offset == 0.) is_aligned = true;
+    if (sampling_ratio != 1. || cpr != 1.) is_aligned = false;
+    if (loop_start != 0. || loop_end != buffer_duration) is_aligned = false;
+    if (buffer_time + block_duration > duration || block_time + block_duration > stop_time) is_aligned = false;
+    if (is_aligned) {
+      if (start_time == block_time) started = true;
+      const int64_t start_index = (int64_t)std::llround(buffer_time * sample_rate);
+      out->qrec[q] = QRec{start_index, is_looping ? (uint32_t)Q_FAST_LOOP : (uint32_t)Q_FAST, 0};
+      if (buffer_time + block_duration > buffer_duration) {
+        // did the playhead wrap inside this block?  (:568-607)
+        int loop_point_index = -1;
+        if (is_looping) {
+          uint64_t si = (uint64_t)start_index, off = 0;
+          for (int index = 0; index < RQ; index++) {
+            uint64_t bi = si + (uint64_t)index - off;
+            if (bi >= frames) {
+              loop_point_index = index;
+              si = 0;
+              off = (uint64_t)index;
+            }
+          }
+        }
+        if (loop_point_index >= 0)
+          buffer_time = std::fmod((double)(RQ - loop_point_index) / sample_rate, buffer_duration);
+        else
+          buffer_time += block_duration;
+      } else {
+        buffer_time += block_duration;
+      }
+      elapsed += block_duration;
+    } else {
+      if (is_looping) {
+        if (loop_start >= 0. && loop_end > 0. && loop_start < loop_end) {
+          actual_loop_start = loop_start;
+          actual_loop_end = loop_end;
+        } else {
+          actual_loop_start = 0.;
+          actual_loop_end = buffer_duration;
+        }
+      } else {
+        entered_loop = false;
+      }
+      ensure_slow();
+      out->qrec[q] = QRec{0, Q_SLOW, 0};
+      SlowRec* rec = &out->slow[(size_t)q * RQ];
+      for (int i = 0; i < RQ; i++) {
+        rec[i] = SlowRec{-1, -1, 0.};
+        const double current_time = block_time + (double)i * dt;
+        if (!started && almost_equal(current_time, start_time)) start_time = current_time;
+        if (almost_equal(elapsed, duration)) elapsed = duration;
+        if (current_time < start_time || current_time >= stop_time || elapsed >= duration) continue;
+        if (!started) {
+          const double delta = current_time - start_time;
+          offset += delta * cpr;
+          offset = std::fmin(std::fmax(offset, 0.), buffer_duration);
+          if (is_looping && cpr >= 0. && offset > actual_loop_end) offset = actual_loop_end;
+          if (is_looping && cpr < 0. && offset < actual_loop_start) offset = actual_loop_start;
+          buffer_time = offset;
+          elapsed = std::fabs(delta * cpr);
+          started = true;
+        }
+        if (is_looping) {
+          if (almost_equal(buffer_time, actual_loop_end)) buffer_time = actual_loop_end;
+          if (almost_equal(buffer_time, actual_loop_start)) buffer_time = actual_loop_start;
+          if (!entered_loop) {
+            if (offset < actual_loop_end && buffer_time >= actual_loop_start) entered_loop = true;
+            if (offset >= actual_loop_end && buffer_time < actual_loop_end) entered_loop = true;
+          }
+          if (entered_loop) {
+            while (buffer_time >= actual_loop_end) buffer_time -= actual_loop_end - actual_loop_start;
+            while (buffer_time < actual_loop_start) buffer_time += actual_loop_end - actual_loop_start;
+          }
+        }
+        if (almost_zero(buffer_time)) buffer_time = 0.;
+        if (buffer_time >= 0. && buffer_time < buffer_duration) {
+          const double position = buffer_time * sampling_ratio;
+          const double playhead = position * sample_rate;
+          const double pf = std::floor(playhead);
+          const uint64_t prev = (uint64_t)pf;
+          const double k = playhead - pf;
+          if (prev < frames) {
+            SlowRec r;
+            r.prev = (int32_t)prev;
+            r.k = k;
+            if (prev + 1 < frames) {
+              r.next = (int32_t)(prev + 1);
+            } else if (is_looping) {
+              if (playback_rate >= 0.) {
+                const double sp = actual_loop_start * sample_rate;
+                r.next = (int32_t)((std::floor(sp) == sp) ? (uint64_t)sp : (uint64_t)sp + 1);
+              } else {
+                const double ep = actual_loop_end * sample_rate;
+                r.next = (int32_t)(uint64_t)ep;
+              }
+            } else {
+              r.next = (almost_equal(k, 1.) || prev == 0) ? -1 : -2;
+            }
+            rec[i] = r;
+          }
+        }
+        const double time_incr = dt * cpr;
+        buffer_time += time_incr;
+        elapsed += std::fabs(time_incr);
+      }
+    }
+    if (next_block_time >= stop_time || elapsed >= duration ||
+        (!is_looping && ((cpr > 0. && buffer_time >= buffer_duration) || (cpr < 0. && buffer_time < 0.))))
+      ended = true;
+  }
+  // per tile: can the whole tile be fetched as one aligned contiguous run?
+  out->tile_fast.assign(b->n_tiles, 0);
+  for (uint32_t t = 0; t < b->n_tiles; t++) {
+    bool ok = true;
+    int64_t s0 = 0;
+    for (int k = 0; k < QUANTA_PER_TILE && ok; k++) {
+      uint32_t q = t * QUANTA_PER_TILE + k;
+      if (q >= nq) {
+        ok = false;
+        break;
+      }
+      const QRec& r = out->qrec[q];
+      if (r.mode != Q_FAST && r.mode != Q_FAST_LOOP) ok = false;
+      if (k == 0) s0 = r.start;
+      if (r.start != s0 + (int64_t)k * RQ) ok = false;
+    }
+    if (ok && (s0 % 4 != 0 || (uint64_t)s0 + TILE > frames)) ok = false;
+    out->tile_fast[t] = ok ? 1 : 0;
+  }
+}
+
+// values of one param for one instance, one value per quantum (first sample of a len-128 slice)
+std::vector<float> param_per_quantum(const waa_batch* b, const ParamStore& p, uint32_t inst, bool* varies) {
+  std::vector<float> v(1, p.fix(p.cst[inst]));
+  bool any = false;
+  for (auto& blk : p.blocks)
+    if (blk.inst == WAA_ALL_INSTANCES || blk.inst == inst) any = true;
+  if (!any) {
+    if (varies) *varies = false;
+    return v;
+  }
+  v.assign(b->n_quanta, p.fix(p.cst[inst]));
+  for (auto& blk : p.blocks) {
+    if (!(blk.inst == WAA_ALL_INSTANCES || blk.inst == inst)) continue;
+    for (uint32_t k = 0; k < blk.nq; k++) {
+      uint64_t q = blk.q0 + k;
+      if (q < b->n_quanta) v[q] = p.fix(blk.v[(size_t)k * blk.vpq]);
+    }
+  }
+  if (varies) *varies = true;
+  return v;
+}
+
+// Upload a param as a device ParamRef (mode 0 / 1 / 2), values clamped like the reference.
+int upload_param(waa_batch* b, const ParamStore& p, ParamRef* ref) {
+  const int mode = p.mode();
+  std::vector<float> host;
+  if (mode == 0) {
+    host.resize(b->n_inst);
+    for (uint32_t i = 0; i < b->n_inst; i++) host[i] = p.fix(p.cst[i]);
+    ref->stride = 0;
+  } else {
+    const uint64_t per = mode == 1 ? b->n_quanta : (uint64_t)b->n_quanta * RQ;
+    host.resize((size_t)b->n_inst * per);
+    for (uint32_t i = 0; i < b->n_inst; i++) {
+      float c = p.fix(p.cst[i]);
+      std::fill(host.begin() + (size_t)i * per, host.begin() + (size_t)(i + 1) * per, c);
+    }
+    for (auto& blk : p.blocks) {
+      uint32_t lo = blk.inst == WAA_ALL_INSTANCES ? 0 : blk.inst, hi = blk.inst == WAA_ALL_INSTANCES ? b->n_inst : blk.inst + 1;
+      for (uint32_t i = lo; i < hi; i++)
+        for (uint32_t k = 0; k < blk.nq; k++) {
+          uint64_t q = blk.q0 + k;
+          if (q >= b->n_quanta) continue;
+          if (mode == 1) {
+            host[(size_t)i * per + q] = p.fix(blk.v[k]);
+          } else {
+            for (int s = 0; s < RQ; s++)
+              host[(size_t)i * per + q * RQ + s] = p.fix(blk.v[(size_t)k * blk.vpq + (blk.vpq == 1 ? 0 : s)]);
+          }
+        }
+    }
+    ref->stride = per;
+  }
+  float* d = nullptr;
+  int e = dev_upload(b, &d, host);
+  if (e) return e;
+  ref->base = d;
+  ref->mode = mode;
+  ref->pad = 0;
+  return 0;
+}
+// Upload host-computed per-instance (mode 0) or per-(instance, quantum) (mode 1) values.
+int upload_values(waa_batch* b, const std::vector<float>& host, int mode, ParamRef* ref) {
+  float* d = nullptr;
+  int e = dev_upload(b, &d, host);
+  if (e) return e;
+  ref->base = d;
+  ref->mode = mode;
+  ref->stride = mode == 0 ? 0 : b->n_quanta;
+  ref->pad = 0;
+  return 0;
+}
+
+int computed_in_nch(const Node& n, int maxc) {
+  switch (n.mode) {
+    case WAA_COUNT_MODE_MAX: return maxc;
+    case WAA_COUNT_MODE_EXPLICIT: return n.cc;
+    default: return std::min(maxc, n.cc);
+  }
+}
+
+void topo_visit(const waa_batch* b, uint32_t id, std::vector<uint8_t>& marked, std::vector<uint8_t>& temp,
+                std::vector<uint32_t>& post, bool* cycle) {
+  if (temp[id]) {
+    *cycle = true;
+    return;
+  }
+  if (marked[id]) return;
+  marked[id] = temp[id] = 1;
+  for (auto& e : b->edges)
+    if (e.from == id) topo_visit(b, e.to, marked, temp, post, cycle);
+  post.push_back(id);
+  temp[id] = 0;
+}
+
+int slot_for(waa_batch* b, const char* name) {
+  for (size_t i = 0; i < b->prof.size(); i++)
+    if (b->prof[i].name == name) return (int)i;
+  b->prof.push_back(ProfileEntry{name});
+  return (int)b->prof.size() - 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// planner
+// ---------------------------------------------------------------------------------------
+int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector<OpDesc>& ops, int* out_nch);
+
+int build_plan(waa_batch* b) {
+  const uint32_t N = (uint32_t)b->nodes.size();
+  // processing order = reversed DFS post-order over outgoing edges in insertion order (graph.rs:331-487)
+  {
+    std::vector<uint8_t> marked(N, 0), temp(N, 0);
+    std::vector<uint32_t> post;
+    bool cycle = false;
+    for (uint32_t i = 0; i < N; i++) topo_visit(b, i, marked, temp, post, &cycle);
+    if (cycle) return fail(WAA_ERR_OUT_OF_SCOPE, "graph cycles (DelayNode feedback) are out of scope");
+    b->order.assign(post.rbegin(), post.rend());
+  }
+  std::vector<uint32_t> pos(N);
+  for (uint32_t i = 0; i < N; i++) pos[b->order[i]] = i;
+  // incoming edges in summing order: by processing position of the producer, then edge insertion order
+  for (auto& n : b->nodes) {
+    n.in_edges.clear();
+    n.n_consumers = 0;
+    n.live = n.materialized = false;
+  }
+  for (uint32_t e = 0; e < b->edges.size(); e++) {
+    b->nodes[b->edges[e].to].in_edges.push_back((int)e);
+    b->nodes[b->edges[e].from].n_consumers++;
+  }
+  for (auto& n : b->nodes)
+    std::stable_sort(n.in_edges.begin(), n.in_edges.end(),
+                     [&](int x, int y) { return pos[b->edges[x].from] < pos[b->edges[y].from]; });
+  // liveness: everything that reaches the destination or an analyser
+  {
+    std::vector<uint32_t> stack;
+    for (uint32_t i = 0; i < N; i++)
+      if (b->nodes[i].desc.kind == WAA_NODE_DESTINATION || b->nodes[i].desc.kind == WAA_NODE_ANALYSER) stack.push_back(i);
+    while (!stack.empty()) {
+      uint32_t id = stack.back();
+      stack.pop_back();
+      if (b->nodes[id].live) continue;
+      b->nodes[id].live = true;
+      for (int e : b->nodes[id].in_edges) stack.push_back(b->edges[e].from);
+    }
+  }
+  // static channel counts (the reference's counts are dynamic: a silent quantum is mono; every case the
+  // static count differs from the dynamic one carries zeros — see DESIGN.md "Silence and channel counts")
+  for (uint32_t id : b->order) {
+    Node& n = b->nodes[id];
+    if (!n.live) continue;
+    int maxc = 1;
+    for (int e : n.in_edges) maxc = std::max(maxc, b->nodes[b->edges[e].from].out_nch);
+    n.in_nch = computed_in_nch(n, maxc);
+    switch (n.desc.kind) {
+      case WAA_NODE_BUFFER_SOURCE: {
+        uint32_t nch = 0;
+        for (auto& bf : n.bufs)
+          if (bf.valid) {
+            if (nch && bf.nch != nch)
+              return fail(WAA_ERR_OUT_OF_SCOPE, "instances of one batch must use AudioBuffers with the same channel count");
+            nch = bf.nch;
+          }
+        n.out_nch = nch ? (int)nch : 1;
+        break;
+      }
+      case WAA_NODE_CONSTANT_SOURCE: n.out_nch = 1; break;
+      case WAA_NODE_STEREO_PANNER:
+      case WAA_NODE_PANNER: n.out_nch = 2; break;
+      case WAA_NODE_CONVOLVER:
+        if (!n.has_ir)
+          n.out_nch = n.in_nch;
+        else
+          n.out_nch = (n.in_nch == 1 && n.ir_nch == 1) ? 1 : 2;
+        break;
+      default: n.out_nch = n.in_nch; break;
+    }
+    if (n.in_nch > 2 || n.out_nch > 2)
+      return fail(WAA_ERR_OUT_OF_SCOPE, "the device path of this round renders at most 2 channels per signal (node %u needs %d)",
+                  id, std::max(n.in_nch, n.out_nch));
+  }
+  // materialisation points
+  for (uint32_t id = 0; id < N; id++) {
+    Node& n = b->nodes[id];
+    if (!n.live) continue;
+    bool mat = false;
+    const uint32_t kind = n.desc.kind;
+    if (kind == WAA_NODE_DESTINATION || kind == WAA_NODE_ANALYSER || kind == WAA_NODE_CONVOLVER) mat = true;
+    int live_consumers = 0;
+    for (auto& e : b->edges)
+      if (e.from == id && b->nodes[e.to].live) {
+        live_consumers++;
+        const Node& c = b->nodes[e.to];
+        if (c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir) mat = true;
+        int live_in = 0;
+        for (int ie : c.in_edges)
+          if (b->nodes[b->edges[ie].from].live) live_in++;
+        if (live_in > 1) mat = true;
+      }
+    if (live_consumers != 1) mat = true;
+    n.materialized = mat;
+  }
+  // allocate materialised signals
+  for (uint32_t id = 0; id < N; id++) {
+    Node& n = b->nodes[id];
+    if (!n.live || !n.materialized) continue;
+    float* p = nullptr;
+    int e = dev_alloc(b, &p, (size_t)b->n_inst * n.out_nch * b->lp);
+    if (e) return e;
+    n.sig = SignalRef{p, (uint64_t)n.out_nch * b->lp, b->lp, n.out_nch, 0};
+  }
+  // chains, in processing order of their terminal node
+  b->steps.clear();
+  for (uint32_t id : b->order) {
+    Node& term = b->nodes[id];
+    if (!term.live || !term.materialized) continue;
+    if (term.desc.kind == WAA_NODE_CONVOLVER && term.has_ir)
+      return fail(WAA_ERR_OUT_OF_SCOPE, "ConvolverNode kernels are not part of this build yet");
+    // walk back through fused single-input predecessors
+    std::vector<uint32_t> path;  // terminal first
+    uint32_t cur = id;
+    Step st;
+    ChainDesc& cd = st.chain;
+    std::memset(&cd, 0, sizeof cd);
+    for (;;) {
+      path.push_back(cur);
+      Node& n = b->nodes[cur];
+      const uint32_t kind = n.desc.kind;
+      if (kind == WAA_NODE_BUFFER_SOURCE || kind == WAA_NODE_CONSTANT_SOURCE) break;  // chain input = this source
+      if (n.in_edges.size() != 1) break;                                               // silent or fan-in head
+      uint32_t p = b->edges[n.in_edges[0]].from;
+      if (b->nodes[p].materialized) break;
+      cur = p;
+    }
+    // inputs of the head node
+    const uint32_t head = path.back();
+    Node& hn = b->nodes[head];
+    int cmax = 1;
+    if (hn.desc.kind == WAA_NODE_BUFFER_SOURCE || hn.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
+      cd.n_inputs = 1;
+      cd.in_nch = hn.out_nch;
+      cd.in_interp = 0;
+      InputRef& in = cd.in[0];
+      in.nch = hn.out_nch;
+      if (hn.desc.kind == WAA_NODE_BUFFER_SOURCE) {
+        in.kind = IN_SOURCE;
+        // filled by prepare_source below
+      } else {
+        in.kind = IN_CONSTANT;
+      }
+    } else if (hn.in_edges.empty()) {
+      cd.n_inputs = 1;
+      cd.in[0].kind = IN_SILENT;
+      cd.in[0].nch = 1;
+      cd.in_nch = hn.in_nch;
+      cd.in_interp = hn.interp;
+    } else {
+      if (hn.in_edges.size() > MAX_INPUTS) return fail(WAA_ERR_OUT_OF_SCOPE, "fan-in above %d is out of scope", MAX_INPUTS);
+      cd.n_inputs = (int)hn.in_edges.size();
+      cd.in_nch = hn.in_nch;
+      cd.in_interp = hn.interp;
+      for (int k = 0; k < cd.n_inputs; k++) {
+        Node& pn = b->nodes[b->edges[hn.in_edges[k]].from];
+        InputRef& in = cd.in[k];
+        if (pn.materialized) {
+          in.kind = IN_SIGNAL;
+          in.nch = pn.out_nch;
+          in.sig = pn.sig;
+        } else {
+          // only reachable for a single unfused source predecessor
+          return fail(WAA_ERR_INVALID_STATE, "internal: unmaterialised fan-in input");
+        }
+        cmax = std::max(cmax, in.nch);
+      }
+    }
+    cmax = std::max(cmax, cd.in_nch);
+    // ops: head first
+    std::vector<OpDesc> ops;
+    int cur_nch = cd.in_nch;
+    for (size_t k = path.size(); k-- > 0;) {
+      uint32_t nid = path[k];
+      const bool is_head = (k == path.size() - 1);
+      int out_nch = cur_nch;
+      int e = emit_node_ops(b, nid, cur_nch, is_head, ops, &out_nch);
+      if (e) return e;
+      cur_nch = out_nch;
+    }
+    if (ops.size() > MAX_OPS) return fail(WAA_ERR_OUT_OF_SCOPE, "more than %d fused ops in one chain", MAX_OPS);
+    for (auto& o : ops) cmax = std::max({cmax, o.nch_in, o.nch_out});
+    cd.n_ops = (int)ops.size();
+    for (size_t k = 0; k < ops.size(); k++) cd.ops[k] = ops[k];
+    cd.out = term.sig;
+    cd.n_inst = b->n_inst;
+    cd.n_tiles = b->n_tiles;
+    cd.n_quanta = b->n_quanta;
+    st.cmax = cmax;
+    st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : "chain_kernel<2>");
+    // source inputs
+    if (cd.in[0].kind == IN_SOURCE || cd.in[0].kind == IN_CONSTANT) {
+      int e = prepare_source_input(b, head, &cd.in[0]);
+      if (e) return e;
+    }
+    b->steps.push_back(st);
+  }
+  b->planned = true;
+  return 0;
+}
+
+}  // namespace
+
+// Resolve a source node into an InputRef: schedules, per-instance buffer table, constant ranges.
+static int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
+  Node& n = b->nodes[id];
+  if (n.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
+    int e = upload_param(b, n.params[0], &in->offset);
+    if (e) return e;
+    // active frame range per instance (constant_source.rs:203-258), found by replaying the quantum loop
+    std::vector<int64_t> act((size_t)b->n_inst * 2);
+    const double dt = 1. / (double)b->sr;
+    for (uint32_t i = 0; i < b->n_inst; i++) {
+      const double start = n.sched[i].start, stop = n.sched[i].stop;
+      int64_t a0 = -1, a1 = -1;
+      for (uint32_t q = 0; q < b->n_quanta; q++) {
+        const double ct = (double)((uint64_t)q * RQ) / (double)b->sr;
+        const double nbt = ct + dt * (double)RQ;
+        if (start >= nbt) continue;
+        if (start <= ct && stop >= nbt) {
+          if (a0 < 0) a0 = (int64_t)q * RQ;
+          a1 = (int64_t)(q + 1) * RQ;
+        } else {
+          double t = ct;
+          for (int s = 0; s < RQ; s++) {
+            if (!(t < start || t >= stop)) {
+              if (a0 < 0) a0 = (int64_t)q * RQ + s;
+              a1 = (int64_t)q * RQ + s + 1;
+            }
+            t += dt;
+          }
+        }
+        if (stop <= nbt) break;
+      }
+      act[(size_t)i * 2] = a0 < 0 ? 0 : a0;
+      act[(size_t)i * 2 + 1] = a0 < 0 ? 0 : a1;
+    }
+    int64_t* d = nullptr;
+    e = dev_upload(b, &d, act);
+    if (e) return e;
+    in->active = d;
+    return 0;
+  }
+  // AudioBufferSourceNode
+  std::vector<SrcInst> insts(b->n_inst);
+  std::vector<SrcSchedule> scheds;
+  std::map<SchedKey, uint32_t> dedup;
+  const ParamStore& p_rate = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
+  const ParamStore& p_det = n.params[WAA_PARAM_SOURCE_DETUNE];
+  const bool automated = !p_rate.blocks.empty() || !p_det.blocks.empty();
+  for (uint32_t i = 0; i < b->n_inst; i++) {
+    const DeviceBuffer& bf = n.bufs[i];
+    SrcInst& si = insts[i];
+    si.base = bf.base;
+    si.ch_stride = bf.ch_stride;
+    si.frames = bf.frames;
+    si.aligned = (bf.valid && ((uintptr_t)bf.base % 16 == 0) && (bf.ch_stride % 4 == 0)) ? 1 : 0;
+    std::vector<float> rate_q = param_per_quantum(b, p_rate, i, nullptr);
+    std::vector<float> det_q = param_per_quantum(b, p_det, i, nullptr);
+    const SourceSched& ss = n.sched[i];
+    const SchedKey key(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end,
+                       bf.valid ? bf.frames : 0, bf.valid ? bf.sr : 0.f, rate_q[0], det_q[0]);
+    if (!automated) {
+      auto it = dedup.find(key);
+      if (it != dedup.end()) {
+        si.sched = it->second;
+        continue;
+      }
+    }
+    SchedOut so;
+    schedule_source(b, n.sched[i], bf.frames, bf.sr, bf.valid, rate_q, det_q, &so);
+    SrcSchedule ds{};
+    QRec* dq = nullptr;
+    int e = dev_upload(b, &dq, so.qrec);
+    if (e) return e;
+    ds.qrec = dq;
+    if (so.any_slow) {
+      SlowRec* dsr = nullptr;
+      e = dev_upload(b, &dsr, so.slow);
+      if (e) return e;
+      ds.slow = dsr;
+    }
+    uint8_t* dtf = nullptr;
+    e = dev_upload(b, &dtf, so.tile_fast);
+    if (e) return e;
+    ds.tile_fast = dtf;
+    si.sched = (uint32_t)scheds.size();
+    scheds.push_back(ds);
+    if (!automated) dedup[key] = si.sched;
+  }
+  SrcInst* d_insts = nullptr;
+  int e = dev_upload(b, &d_insts, insts);
+  if (e) return e;
+  SrcSchedule* d_scheds = nullptr;
+  e = dev_upload(b, &d_scheds, scheds);
+  if (e) return e;
+  in->src = d_insts;
+  in->sched = d_scheds;
+  return 0;
+}
+
+namespace {
+
+// Emit the fused ops of node `id` given the running channel count.
+int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector<OpDesc>& ops, int* out_nch) {
+  Node& n = b->nodes[id];
+  const uint32_t kind = n.desc.kind;
+  if (kind == WAA_NODE_BUFFER_SOURCE || kind == WAA_NODE_CONSTANT_SOURCE) {
+    *out_nch = n.out_nch;
+    return 0;
+  }
+  // input mixing to the node's computed channel count (quantum.rs:532-569); the chain head's inputs are
+  // mixed by the input stage already
+  if (!head && cur_nch != n.in_nch) {
+    OpDesc m{};
+    m.kind = OP_MIX;
+    m.nch_in = cur_nch;
+    m.nch_out = n.in_nch;
+    m.i0 = n.interp;
+    ops.push_back(m);
+  }
+  const int nch = n.in_nch;
+  *out_nch = n.out_nch;
+  switch (kind) {
+    case WAA_NODE_GAIN: {
+      OpDesc o{};
+      o.kind = OP_GAIN;
+      o.nch_in = o.nch_out = nch;
+      int e = upload_param(b, n.params[0], &o.p0);
+      if (e) return e;
+      ops.push_back(o);
+      break;
+    }
+    case WAA_NODE_BIQUAD: {
+      OpDesc o{};
+      o.kind = OP_BIQUAD;
+      o.nch_in = o.nch_out = nch;
+      bool varies = false;
+      for (auto& p : n.params) {
+        if (p.mode() == 2)
+          return fail(WAA_ERR_OUT_OF_SCOPE, "a-rate (per-sample) BiquadFilter params are a §8(f) 'next' item");
+        if (p.mode() == 1) varies = true;
+      }
+      const uint64_t per = varies ? (uint64_t)b->n_quanta * 5 : 5;
+      std::vector<double> co((size_t)b->n_inst * per);
+      for (uint32_t i = 0; i < b->n_inst; i++) {
+        auto f = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_FREQUENCY], i, nullptr);
+        auto d = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_DETUNE], i, nullptr);
+        auto q = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_Q], i, nullptr);
+        auto g = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_GAIN], i, nullptr);
+        const uint32_t cnt = varies ? b->n_quanta : 1;
+        for (uint32_t k = 0; k < cnt; k++) {
+          auto at = [&](const std::vector<float>& v) { return v[v.size() == 1 ? 0 : k]; };
+          Coefs c = biquad_coefs(n.desc.i[0], (double)b->sr, (double)computed_freq(at(f), at(d)), (double)at(g), (double)at(q));
+          double* dst = &co[(size_t)i * per + (size_t)k * 5];
+          dst[0] = c.b0;
+          dst[1] = c.b1;
+          dst[2] = c.b2;
+          dst[3] = c.a1;
+          dst[4] = c.a2;
+        }
+      }
+      double* dco = nullptr;
+      int e = dev_upload(b, &dco, co);
+      if (e) return e;
+      double* dst = nullptr;
+      e = dev_alloc(b, &dst, (size_t)b->n_inst * STATE_STRIDE);
+      if (e) return e;
+      b->state_bufs.push_back({dst, (size_t)b->n_inst * STATE_STRIDE * sizeof(double)});
+      o.i0 = varies ? 1 : 0;
+      o.ptr0 = dco;
+      o.ptr1 = dst;
+      o.u0 = per;
+      ops.push_back(o);
+      break;
+    }
+    case WAA_NODE_WAVESHAPER: {
+      if (n.has_curve) {
+        OpDesc o{};
+        o.kind = OP_WAVESHAPER;
+        o.nch_in = o.nch_out = nch;
+        if (!n.d_curve) {
+          int e = dev_upload(b, &n.d_curve, n.curve);
+          if (e) return e;
+        }
+        o.ptr0 = n.d_curve;
+        o.i0 = (int)n.curve.size();
+        ops.push_back(o);
+      }
+      break;
+    }
+    case WAA_NODE_STEREO_PANNER: {
+      OpDesc o{};
+      o.kind = OP_STEREO_PAN;
+      o.nch_in = nch;
+      o.nch_out = 2;
+      const ParamStore& p = n.params[0];
+      int e = upload_param(b, p, &o.p0);
+      if (e) return e;
+      if (p.mode() != 2) {
+        // gains on the host with the same libm sinf the reference's f32::sin resolves to (stereo_panner.rs:74-79)
+        const uint32_t cnt = p.mode() == 1 ? b->n_quanta : 1;
+        std::vector<float> gl((size_t)b->n_inst * cnt), gr((size_t)b->n_inst * cnt);
+        for (uint32_t i = 0; i < b->n_inst; i++) {
+          auto pv = param_per_quantum(b, p, i, nullptr);
+          for (uint32_t k = 0; k < cnt; k++) {
+            float pan = pv[pv.size() == 1 ? 0 : k];
+            float x = nch == 1 ? (pan + 1.f) * 0.5f : (pan <= 0.f ? pan + 1.f : pan);
+            gl[(size_t)i * cnt + k] = sinf((1.f - x) * PI_F / 2.f);
+            gr[(size_t)i * cnt + k] = sinf(x * PI_F / 2.f);
+          }
+        }
+        if ((e = upload_values(b, gl, p.mode(), &o.p1))) return e;
+        if ((e = upload_values(b, gr, p.mode(), &o.p2))) return e;
+      }
+      ops.push_back(o);
+      break;
+    }
+    case WAA_NODE_PANNER: {
+      OpDesc o{};
+      o.kind = OP_PANNER;
+      o.nch_in = nch;
+      o.nch_out = 2;
+      int mode = 0;
+      for (auto& p : n.params) mode = std::max(mode, p.mode());
+      for (int k = 6; k < 15; k++)
+        if (n.params[k].mode() == 2)
+          return fail(WAA_ERR_OUT_OF_SCOPE, "a-rate AudioListener automation is out of scope for this round");
+      // listener single-valued => the reference evaluates the geometry once per quantum from the first value of
+      // every param (panner.rs:833-846)
+      const uint32_t cnt = mode == 0 ? 1 : b->n_quanta;
+      const int vmode = mode == 0 ? 0 : 1;
+      std::vector<float> az((size_t)b->n_inst * cnt), gl(az.size()), gr(az.size()), dg(az.size()), cg(az.size());
+      for (uint32_t i = 0; i < b->n_inst; i++) {
+        std::vector<std::vector<float>> pv(15);
+        for (int k = 0; k < 15; k++) pv[k] = param_per_quantum(b, n.params[k], i, nullptr);
+        for (uint32_t k = 0; k < cnt; k++) {
+          auto at = [&](int p) { return pv[p][pv[p].size() == 1 ? 0 : k]; };
+          V3 sp{at(0), at(1), at(2)}, so{at(3), at(4), at(5)}, lp{at(6), at(7), at(8)}, lf{at(9), at(10), at(11)},
+              lu{at(12), at(13), at(14)};
+          float a, el;
+          azimuth_elevation(sp, lp, lf, lu, &a, &el);
+          // panner.rs:996-1004
+          a = a < -180.f ? -180.f : a > 180.f ? 180.f : a;
+          if (a < -90.f)
+            a = -180.f - a;
+          else if (a > 90.f)
+            a = 180.f - a;
+          float x = nch == 1 ? (a + 90.f) / 180.f : (a <= 0.f ? (a + 90.f) / 90.f : a / 90.f);
+          const size_t ix = (size_t)i * cnt + k;
+          az[ix] = a;
+          gl[ix] = cosf(x * PI_F / 2.f);
+          gr[ix] = sinf(x * PI_F / 2.f);
+          dg[ix] = dist_gain(n.desc, sp, lp);
+          cg[ix] = cone_gain(n.desc, sp, so, lp);
+        }
+      }
+      int e;
+      if ((e = upload_values(b, az, vmode, &o.p0)) || (e = upload_values(b, gl, vmode, &o.p1)) ||
+          (e = upload_values(b, gr, vmode, &o.p2)) || (e = upload_values(b, dg, vmode, &o.p3)) ||
+          (e = upload_values(b, cg, vmode, &o.p4)))
+        return e;
+      ops.push_back(o);
+      break;
+    }
+    case WAA_NODE_CONVOLVER:
+      // no buffer set: passthrough (convolver.rs:368-374)
+      break;
+    case WAA_NODE_ANALYSER:
+    case WAA_NODE_DESTINATION:
+    default:
+      break;
+  }
+  return 0;
+}
+
+void default_config(Node& n, uint32_t n_out) {
+  int cc = 2, mode = WAA_COUNT_MODE_MAX, interp = WAA_INTERP_SPEAKERS;
+  switch (n.desc.kind) {
+    case WAA_NODE_DESTINATION:
+      cc = (int)n_out;
+      mode = WAA_COUNT_MODE_EXPLICIT;
+      break;
+    case WAA_NODE_CONVOLVER:
+    case WAA_NODE_STEREO_PANNER:
+    case WAA_NODE_PANNER:
+      mode = WAA_COUNT_MODE_CLAMPED_MAX;
+      break;
+    default: break;
+  }
+  if (n.desc.channel_count != 0) {
+    cc = (int)n.desc.channel_count;
+    mode = (int)n.desc.channel_count_mode;
+    interp = (int)n.desc.channel_interpretation;
+  }
+  n.cc = cc;
+  n.mode = mode;
+  n.interp = interp;
+}
+
+}  // namespace
+
+// =======================================================================================
+// C ABI
+// =======================================================================================
+extern "C" {
+
+const char* waa_last_error(void) { return g_err; }
+
+int32_t waa_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n_out, uint64_t length, float sr,
+                            int32_t device, waa_batch** out) {
+  if (!g || !out || g->n_nodes == 0 || n_inst == 0) return fail(WAA_ERR_INVALID_ARGUMENT, "invalid arguments");
+  if (g->nodes[0].kind != WAA_NODE_DESTINATION) return fail(WAA_ERR_INVALID_ARGUMENT, "node 0 must be the destination");
+  if (n_out == 0 || n_out > WAA_MAX_CHANNELS)
+    return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels: %u", n_out);
+  if (!(sr >= 8000.f && sr <= 192000.f)) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid sample rate: %f", sr);
+  std::unique_ptr<waa_batch> b(new waa_batch);
+  b->n_inst = n_inst;
+  b->n_out = n_out;
+  b->length = length;
+  b->sr = sr;
+  b->n_quanta = (uint32_t)((length + RQ - 1) / RQ);
+  if (b->n_quanta == 0) b->n_quanta = 1;
+  b->n_tiles = (b->n_quanta + QUANTA_PER_TILE - 1) / QUANTA_PER_TILE;
+  b->lp = (uint64_t)b->n_tiles * TILE;
+  for (uint32_t e = 0; e < g->n_edges; e++) {
+    const waa_edge_desc& ed = g->edges[e];
+    if (ed.from >= g->n_nodes || ed.to >= g->n_nodes || ed.from_output != 0 || ed.to_input != 0)
+      return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - invalid edge %u", e);
+    b->edges.push_back(ed);
+  }
+  b->nodes.resize(g->n_nodes);
+  for (uint32_t i = 0; i < g->n_nodes; i++) {
+    Node& n = b->nodes[i];
+    n.desc = g->nodes[i];
+    if (n.desc.kind >= WAA_NODE_KIND_COUNT) return fail(WAA_ERR_INVALID_ARGUMENT, "unknown node kind");
+    default_config(n, n_out);
+    if (n.cc < 1 || n.cc > WAA_MAX_CHANNELS)
+      return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels: %d", n.cc);
+    auto P = [&](size_t k) -> ParamStore& {
+      if (n.params.size() <= k) n.params.resize(k + 1);
+      return n.params[k];
+    };
+    switch (n.desc.kind) {
+      case WAA_NODE_BIQUAD:
+        P(WAA_PARAM_BIQUAD_FREQUENCY).init(n_inst, 350.f, 0.f, sr / 2.f);
+        P(WAA_PARAM_BIQUAD_DETUNE).init(n_inst, 0.f, -153600.f, 153600.f);
+        P(WAA_PARAM_BIQUAD_Q).init(n_inst, 1.f, -FLT_MAX, FLT_MAX);
+        P(WAA_PARAM_BIQUAD_GAIN).init(n_inst, 0.f, -FLT_MAX, 40.f * log10f(FLT_MAX));
+        if (n.desc.i[0] < 0 || n.desc.i[0] > 7) return fail(WAA_ERR_INVALID_ARGUMENT, "bad biquad type");
+        break;
+      case WAA_NODE_GAIN: P(0).init(n_inst, 1.f, -FLT_MAX, FLT_MAX); break;
+      case WAA_NODE_BUFFER_SOURCE:
+        P(WAA_PARAM_SOURCE_PLAYBACK_RATE).init(n_inst, 1.f, -FLT_MAX, FLT_MAX);
+        P(WAA_PARAM_SOURCE_DETUNE).init(n_inst, 0.f, -FLT_MAX, FLT_MAX);
+        n.bufs.resize(n_inst);
+        n.sched.resize(n_inst);
+        break;
+      case WAA_NODE_CONSTANT_SOURCE:
+        P(0).init(n_inst, 1.f, -FLT_MAX, FLT_MAX);
+        n.sched.resize(n_inst);
+        break;
+      case WAA_NODE_STEREO_PANNER:
+        P(0).init(n_inst, 0.f, -1.f, 1.f);
+        if (n.mode == WAA_COUNT_MODE_MAX)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - StereoPannerNode channel count mode cannot be set to max");
+        if (n.cc > 2)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - StereoPannerNode channel count cannot be greater than two");
+        break;
+      case WAA_NODE_PANNER: {
+        static const float defs[15] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, -1, 0, 1, 0};
+        for (int p = 0; p < 15; p++) P(p).init(n_inst, defs[p], -FLT_MAX, FLT_MAX);
+        if (n.desc.i[0] == WAA_PANNING_HRTF)
+          return fail(WAA_ERR_OUT_OF_SCOPE, "HRTF panning is out of scope (third-party hrtf crate, parity unpinned)");
+        if (n.mode == WAA_COUNT_MODE_MAX)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count mode cannot be set to max");
+        if (n.cc > 2)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count cannot be greater than two");
+        break;
+      }
+      case WAA_NODE_WAVESHAPER:
+        if (n.desc.i[0] != WAA_OVERSAMPLE_NONE)
+          return fail(WAA_ERR_OUT_OF_SCOPE, "WaveShaper oversampling is out of scope (third-party rubato, parity unpinned)");
+        break;
+      case WAA_NODE_CONVOLVER:
+        if (n.cc > 2)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - ConvolverNode channel count cannot be greater than two");
+        if (n.mode == WAA_COUNT_MODE_MAX)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - ConvolverNode channel count mode cannot be set to max");
+        break;
+      case WAA_NODE_ANALYSER: {
+        int fs = n.desc.i[0] ? n.desc.i[0] : 2048;
+        if (fs < 32 || fs > 32768 || (fs & (fs - 1)))
+          return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - Invalid fft size: %d is not a power of two", fs);
+        n.desc.i[0] = fs;
+        if (n.desc.d[0] == 0. && n.desc.d[1] == 0. && n.desc.d[2] == 0.) {
+          n.desc.d[0] = 0.8;
+          n.desc.d[1] = -100.;
+          n.desc.d[2] = -30.;
+        }
+        if (n.desc.d[0] < 0. || n.desc.d[0] > 1.)
+          return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - Invalid smoothing time constant");
+        if (!(n.desc.d[1] < n.desc.d[2])) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - Invalid min decibels");
+        break;
+      }
+      default: break;
+    }
+  }
+  // the device is only touched from here on; a machine without a GPU still validates graphs above
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(WAA_ERR_DEVICE, "no HIP device available: libwaa_hip has no CPU fallback");
+  if (device >= 0) {
+    if (device >= ndev) return fail(WAA_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    b->device = device;
+  } else {
+    HIP_TRY(hipGetDevice(&b->device));
+  }
+  HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  *out = b.release();
+  return WAA_OK;
+}
+
+void waa_batch_destroy(waa_batch* b) {
+  if (!b) return;
+  if (b->stream) {
+    (void)hipStreamSynchronize(b->stream);
+    for (auto& p : b->prof)
+      for (auto& ev : p.pending) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+      }
+    for (void* p : b->allocs) (void)hipFree(p);
+    for (void* p : b->payload_allocs) (void)hipFree(p);
+    (void)hipStreamDestroy(b->stream);
+  }
+  delete b;
+}
+
+static int upload_buffer(waa_batch* b, const float* const* channels, uint32_t n_ch, uint64_t frames, float sr,
+                         DeviceBuffer* out) {
+  const uint64_t stride = (frames + 3) / 4 * 4;
+  float* d = nullptr;
+  int e = dev_alloc(b, &d, (size_t)n_ch * std::max<uint64_t>(stride, 4), true);
+  if (e) return e;
+  for (uint32_t c = 0; c < n_ch; c++)
+    if (frames) HIP_TRY(hipMemcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float), hipMemcpyHostToDevice));
+  out->base = d;
+  out->ch_stride = stride;
+  out->frames = frames;
+  out->nch = n_ch;
+  out->sr = sr;
+  out->valid = true;
+  return 0;
+}
+
+waa_status waa_source_set_buffer(waa_batch* b, uint32_t node, uint32_t inst, const float* const* channels,
+                                 uint32_t n_ch, uint64_t frames, float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
+  HIP_TRY(hipSetDevice(b->device));
+  DeviceBuffer db;
+  if ((e = upload_buffer(b, channels, n_ch, frames, sr, &db))) return e;
+  Node& n = b->nodes[node];
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) n.bufs[k] = db;
+  return WAA_OK;
+}
+
+waa_status waa_source_set_buffer_batch(waa_batch* b, uint32_t node, const float* data, uint32_t n_ch, uint64_t frames,
+                                       float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_unplanned(b))) return e;
+  if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
+  HIP_TRY(hipSetDevice(b->device));
+  const uint64_t stride = (frames + 3) / 4 * 4;
+  float* d = nullptr;
+  if ((e = dev_alloc(b, &d, (size_t)b->n_inst * n_ch * std::max<uint64_t>(stride, 4), true))) return e;
+  if (frames)
+    HIP_TRY(hipMemcpy2D(d, stride * sizeof(float), data, frames * sizeof(float), frames * sizeof(float),
+                        (size_t)b->n_inst * n_ch, hipMemcpyHostToDevice));
+  Node& n = b->nodes[node];
+  for (uint32_t k = 0; k < b->n_inst; k++) {
+    DeviceBuffer db;
+    db.base = d + (size_t)k * n_ch * stride;
+    db.ch_stride = stride;
+    db.frames = frames;
+    db.nch = n_ch;
+    db.sr = sr;
+    db.valid = true;
+    n.bufs[k] = db;
+  }
+  return WAA_OK;
+}
+
+waa_status waa_source_adopt_device(waa_batch* b, uint32_t node, const float* device_data, uint32_t n_ch, uint64_t frames,
+                                   float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_unplanned(b))) return e;
+  if (!device_data || n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_INVALID_ARGUMENT, "bad device buffer");
+  Node& n = b->nodes[node];
+  for (uint32_t k = 0; k < b->n_inst; k++) {
+    DeviceBuffer db;
+    db.base = const_cast<float*>(device_data) + (size_t)k * n_ch * frames;
+    db.ch_stride = frames;
+    db.frames = frames;
+    db.nch = n_ch;
+    db.sr = sr;
+    db.valid = true;
+    n.bufs[k] = db;
+  }
+  return WAA_OK;
+}
+
+waa_status waa_source_start(waa_batch* b, uint32_t node, uint32_t inst, double when, double offset, double duration) {
+  int e;
+  if (!b || node >= b->nodes.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node");
+  const uint32_t kind = b->nodes[node].desc.kind;
+  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not a scheduled source", node);
+  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  if (!std::isfinite(when) || !std::isfinite(offset) || !std::isfinite(duration))
+    return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided time value is non-finite.");
+  if (when < 0. || offset < 0. || duration < 0.)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - The provided time value cannot be negative");
+  Node& n = b->nodes[node];
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) {
+    if (n.sched[k].start != DBL_MAX) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot call `start` twice");
+    n.sched[k].start = when;
+    if (kind == WAA_NODE_BUFFER_SOURCE) {
+      n.sched[k].offset = offset;
+      n.sched[k].duration = duration;
+    }
+  }
+  return WAA_OK;
+}
+
+waa_status waa_source_stop(waa_batch* b, uint32_t node, uint32_t inst, double when) {
+  int e;
+  if (!b || node >= b->nodes.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node");
+  const uint32_t kind = b->nodes[node].desc.kind;
+  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not a scheduled source", node);
+  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  if (!std::isfinite(when)) return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided time value is non-finite.");
+  if (when < 0.) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - The provided time value cannot be negative");
+  Node& n = b->nodes[node];
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) {
+    if (n.sched[k].start == DBL_MAX) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot stop before start");
+    n.sched[k].stop = when;
+  }
+  return WAA_OK;
+}
+
+waa_status waa_source_set_loop(waa_batch* b, uint32_t node, uint32_t inst, int32_t looping, double ls, double le) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  Node& n = b->nodes[node];
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) {
+    n.sched[k].looping = looping;
+    n.sched[k].loop_start = ls;
+    n.sched[k].loop_end = le;
+  }
+  return WAA_OK;
+}
+
+// convolver.rs:16-53
+static float normalize_buffer(const float* const* ch, uint32_t n_ch, uint64_t len, float sr) {
+  const float gain_calibration = 0.00125f, gain_calibration_sample_rate = 44100.f, min_power = 0.000125f;
+  float power = 0.f;
+  for (uint32_t c = 0; c < n_ch; c++) {
+    float s = 0.f;
+    for (uint64_t i = 0; i < len; i++) s += ch[c][i] * ch[c][i];
+    power += s;
+  }
+  power = std::sqrt(power / (float)(n_ch * len));
+  if (!std::isfinite(power) || std::isnan(power) || power < min_power) power = min_power;
+  float scale = 1.f / power;
+  scale *= gain_calibration;
+  scale *= gain_calibration_sample_rate / sr;
+  if (n_ch == 4) scale *= 0.5f;
+  return scale;
+}
+
+waa_status waa_convolver_set_buffer(waa_batch* b, uint32_t node, const float* const* channels, uint32_t n_ch,
+                                    uint64_t frames, float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_CONVOLVER)) || (e = check_unplanned(b))) return e;
+  if (sr != b->sr)
+    return fail(WAA_ERR_NOT_SUPPORTED,
+                "NotSupportedError - sample rate of the convolution buffer must match the audio context");
+  if (!(n_ch == 1 || n_ch == 2 || n_ch == 4))
+    return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - the convolution buffer must consist of 1, 2 or 4 channels");
+  Node& n = b->nodes[node];
+  const float scale = n.desc.i[0] ? 1.f : normalize_buffer(channels, n_ch, frames, sr);
+  n.ir.assign(n_ch, std::vector<float>(frames));
+  for (uint32_t c = 0; c < n_ch; c++)
+    for (uint64_t i = 0; i < frames; i++) n.ir[c][i] = channels[c][i] * scale;
+  n.ir_len = frames;
+  n.ir_nch = (int)n_ch;
+  n.has_ir = true;
+  return WAA_OK;
+}
+
+waa_status waa_waveshaper_set_curve(waa_batch* b, uint32_t node, const float* curve, uint32_t nn) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_WAVESHAPER)) || (e = check_unplanned(b))) return e;
+  Node& n = b->nodes[node];
+  if (n.has_curve) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - cannot assign curve twice");
+  n.curve.assign(curve, curve + nn);
+  n.has_curve = true;
+  return WAA_OK;
+}
+
+waa_status waa_set_param_const(waa_batch* b, uint32_t node, uint32_t param, uint32_t inst, float value) {
+  int e;
+  if (!b || node >= b->nodes.size() || param >= b->nodes[node].params.size())
+    return fail(WAA_ERR_INVALID_ARGUMENT, "no such param %u on node %u", param, node);
+  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  ParamStore& p = b->nodes[node].params[param];
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) p.cst[k] = value;
+  return WAA_OK;
+}
+
+waa_status waa_set_param_block(waa_batch* b, uint32_t node, uint32_t param, uint32_t inst, uint64_t q0, uint32_t nq,
+                               uint32_t vpq, const float* values) {
+  int e;
+  if (!b || node >= b->nodes.size() || param >= b->nodes[node].params.size())
+    return fail(WAA_ERR_INVALID_ARGUMENT, "no such param %u on node %u", param, node);
+  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  if (vpq != 1 && vpq != RQ) return fail(WAA_ERR_INVALID_ARGUMENT, "values_per_quantum must be 1 or 128");
+  ParamBlock blk;
+  blk.inst = inst;
+  blk.q0 = q0;
+  blk.nq = nq;
+  blk.vpq = vpq;
+  blk.v.assign(values, values + (size_t)nq * vpq);
+  b->nodes[node].params[param].blocks.push_back(std::move(blk));
+  return WAA_OK;
+}
+
+waa_status waa_render(waa_batch* b) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  HIP_TRY(hipSetDevice(b->device));
+  if (!b->planned) {
+    int e = build_plan(b);
+    if (e) return e;
+  }
+  // every render starts from the initial state (offline contexts render exactly once; re-rendering the
+  // same batch is what the benchmark loop does)
+  for (auto& sb : b->state_bufs) HIP_TRY(hipMemsetAsync(sb.first, 0, sb.second, b->stream));
+  for (auto& st : b->steps) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (b->profiling) {
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, b->stream));
+    }
+    launch_chain(st.chain, st.cmax, b->stream);
+    HIP_TRY(hipGetLastError());
+    if (b->profiling) {
+      HIP_TRY(hipEventRecord(e1, b->stream));
+      b->prof[st.profile_slot].pending.push_back({e0, e1});
+    }
+  }
+  return WAA_OK;
+}
+
+static int drain_profile(waa_batch* b) {
+  for (auto& p : b->prof) {
+    for (auto& ev : p.pending) {
+      float ms = 0.f;
+      HIP_TRY(hipEventSynchronize(ev.second));
+      HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+      p.total_ms += (double)ms;
+      p.launches++;
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    p.pending.clear();
+  }
+  return 0;
+}
+
+waa_status waa_sync(waa_batch* b) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return drain_profile(b);
+}
+
+waa_status waa_download(waa_batch* b, uint32_t inst, uint32_t ch, float* dst, uint64_t frames) {
+  if (!b || inst >= b->n_inst || ch >= b->n_out || frames > b->length)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "download out of range");
+  if (!b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const SignalRef& s = b->nodes[0].sig;
+  if ((int)ch < s.nch) {
+    HIP_TRY(hipMemcpy(dst, s.base + (size_t)inst * s.inst_stride + (size_t)ch * s.ch_stride, frames * sizeof(float),
+                      hipMemcpyDeviceToHost));
+  } else {
+    std::memset(dst, 0, frames * sizeof(float));
+  }
+  return WAA_OK;
+}
+
+waa_status waa_download_all(waa_batch* b, float* dst) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (!b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const SignalRef& s = b->nodes[0].sig;
+  if (b->length == 0) return WAA_OK;
+  if ((uint32_t)s.nch == b->n_out) {
+    HIP_TRY(hipMemcpy2D(dst, b->length * sizeof(float), s.base, s.ch_stride * sizeof(float), b->length * sizeof(float),
+                        (size_t)b->n_inst * b->n_out, hipMemcpyDeviceToHost));
+  } else {
+    for (uint32_t i = 0; i < b->n_inst; i++)
+      for (uint32_t c = 0; c < b->n_out; c++) {
+        int e = waa_download(b, i, c, dst + ((size_t)i * b->n_out + c) * b->length, b->length);
+        if (e) return e;
+      }
+  }
+  return WAA_OK;
+}
+
+waa_status waa_output_device(waa_batch* b, const float** p, uint64_t* is, uint64_t* cs) {
+  if (!b || !b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
+  const SignalRef& s = b->nodes[0].sig;
+  *p = s.base;
+  *is = s.inst_stride;
+  *cs = s.ch_stride;
+  return WAA_OK;
+}
+
+waa_status waa_analyser_get_float_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t n) {
+  (void)inst;
+  (void)dst;
+  (void)n;
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_ANALYSER))) return e;
+  return fail(WAA_ERR_OUT_OF_SCOPE, "analyser pulls are not part of this build yet");
+}
+waa_status waa_analyser_get_byte_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t n) {
+  (void)inst;
+  (void)dst;
+  (void)n;
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_ANALYSER))) return e;
+  return fail(WAA_ERR_OUT_OF_SCOPE, "analyser pulls are not part of this build yet");
+}
+waa_status waa_analyser_get_float_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t n) {
+  (void)inst;
+  (void)dst;
+  (void)n;
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_ANALYSER))) return e;
+  return fail(WAA_ERR_OUT_OF_SCOPE, "analyser pulls are not part of this build yet");
+}
+waa_status waa_analyser_get_byte_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t n) {
+  (void)inst;
+  (void)dst;
+  (void)n;
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_ANALYSER))) return e;
+  return fail(WAA_ERR_OUT_OF_SCOPE, "analyser pulls are not part of this build yet");
+}
+
+// buffer.rs:311-363 (input prep, host side)
+uint64_t waa_buffer_resample(const float* src, uint64_t frames, float source_sr, float target_sr, float* dst, uint64_t cap) {
+  if (std::fabs(source_sr - target_sr) <= 0.1f || frames == 0) {
+    if (dst)
+      for (uint64_t i = 0; i < frames && i < cap; i++) dst[i] = src[i];
+    return frames;
+  }
+  const double ratio = (double)target_sr / (double)source_sr;
+  const uint64_t tl = (uint64_t)std::ceil((double)frames * ratio);
+  if (!dst) return tl;
+  for (uint64_t i = 0; i < tl && i < cap; i++) {
+    const double position = (double)i / (double)(tl - 1);
+    const double playhead = position * (double)(frames - 1);
+    const double pf = std::floor(playhead);
+    const uint64_t prev = (uint64_t)pf;
+    const uint64_t next = std::min<uint64_t>(prev + 1, frames - 1);
+    const float k = (float)(playhead - pf), kinv = 1.f - k;
+    dst[i] = kinv * src[prev] + k * src[next];
+  }
+  return tl;
+}
+
+// biquad_filter.rs:670-735 (control side, host)
+waa_status waa_biquad_frequency_response(int32_t type, float sample_rate, float frequency, float detune, float q,
+                                         float gain, const float* hz, float* mag, float* phase, uint32_t n) {
+  if (type < 0 || type > 7) return fail(WAA_ERR_INVALID_ARGUMENT, "bad filter type");
+  const double PI = 3.14159265358979323846;
+  const float nyq = sample_rate / 2.f;
+  const Coefs c = biquad_coefs(type, (double)sample_rate, (double)computed_freq(frequency, detune), (double)gain, (double)q);
+  for (uint32_t i = 0; i < n; i++) {
+    const float f = hz[i];
+    if (f < 0.f || f > nyq) {
+      mag[i] = NAN;
+      phase[i] = NAN;
+      continue;
+    }
+    const float fn = f / nyq;
+    const double omega = -PI * (double)fn;
+    const double zr = std::cos(omega), zi = std::sin(omega);
+    const double tr = c.b1 + c.b2 * zr, ti = c.b2 * zi;
+    const double nr = c.b0 + (tr * zr - ti * zi), ni = tr * zi + ti * zr;
+    const double ur = c.a1 + c.a2 * zr, ui = c.a2 * zi;
+    const double dr = 1. + (ur * zr - ui * zi), di = ur * zi + ui * zr;
+    const double den = dr * dr + di * di;
+    const double rr = (nr * dr + ni * di) / den, ri = (ni * dr - nr * di) / den;
+    mag[i] = (float)std::hypot(rr, ri);
+    phase[i] = (float)std::atan2(ri, rr);
+  }
+  return WAA_OK;
+}
+
+waa_status waa_profile_enable(waa_batch* b, int32_t on) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  b->profiling = on != 0;
+  return WAA_OK;
+}
+int32_t waa_profile_count(waa_batch* b) { return b ? (int32_t)b->prof.size() : 0; }
+waa_status waa_profile_get(waa_batch* b, int32_t i, const char** name, uint64_t* launches, double* ms) {
+  if (!b || i < 0 || i >= (int32_t)b->prof.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "profile index out of range");
+  *name = b->prof[i].name.c_str();
+  *launches = b->prof[i].launches;
+  *ms = b->prof[i].total_ms;
+  return WAA_OK;
+}
+waa_status waa_profile_reset(waa_batch* b) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  for (auto& p : b->prof) {
+    p.launches = 0;
+    p.total_ms = 0;
+  }
+  return WAA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// waa_internal.hpp — structures shared by the host planner (waa_host.cpp) and the gfx950 kernels
+// (waa_kernels.hip).  Not part of the public C ABI (include/waa_hip.h).
+#pragma once
+#include <cstdint>
+
+namespace waa {
+
+constexpr int RQ = 128;            // render quantum (reference src/lib.rs:18)
+constexpr int TILE_K = 32;         // frames per lane in the transposed (recurrence) layout
+constexpr int TILE = 64 * TILE_K;  // frames per wave-tile = 2048 = 16 render quanta
+constexpr int QUANTA_PER_TILE = TILE / RQ;
+constexpr int MAX_OPS = 12;
+constexpr int MAX_INPUTS = 4;
+constexpr int MAX_CH = 8;          // channels per signal the device path supports
+constexpr int STATE_STRIDE = MAX_CH * 4;  // doubles of biquad state per instance per op
+
+// An AudioParam's values as seen by a kernel (AudioParamValues::get, processor.rs:186-229).
+//   mode 0: one value per instance              base[inst]
+//   mode 1: one value per (instance, quantum)   base[inst*stride + q]           (len-1 slices)
+//   mode 2: one value per (instance, frame)     base[inst*stride + frame]       (len-128 slices)
+struct ParamRef {
+  const float* base;
+  uint64_t stride;
+  int32_t mode;
+  int32_t pad;
+};
+
+// A materialised signal: [instance][channel][frames_padded] f32, frames_padded % TILE == 0.
+struct SignalRef {
+  float* base;
+  uint64_t inst_stride;
+  uint64_t ch_stride;
+  int32_t nch;
+  int32_t pad;
+};
+
+// ---- AudioBufferSourceNode on device ---------------------------------------------------
+// Per-quantum playback record produced by the host-side scheduler (port of the state machine
+// in audio_buffer_source.rs:422-845; "host-side scheduling stays on the host").
+enum : uint32_t { Q_SILENT = 0, Q_FAST = 1, Q_SLOW = 2, Q_FAST_LOOP = 3 };
+struct QRec {
+  int64_t start;   // FAST: buffer index of the first frame of this quantum
+  uint32_t mode;   // Q_*
+  uint32_t pad;
+};
+// Per-frame playback info of the slow track (audio_buffer_source.rs:631-751), already resolved:
+struct SlowRec {
+  int32_t prev;  // -1: output 0
+  int32_t next;  // >=0: index of next sample; -1: next_sample = 0; -2: extrapolate 2*prev - prevprev
+  double k;
+};
+struct SrcSchedule {
+  const QRec* qrec;        // [n_quanta]
+  const SlowRec* slow;     // [n_quanta*128] or null if no slow quantum
+  const uint8_t* tile_fast;  // [n_tiles] 1 = all 16 quanta FAST, contiguous, in range, 16B aligned
+};
+struct SrcInst {
+  const float* base;     // channel 0 of this instance's AudioBuffer
+  uint64_t ch_stride;    // floats between channels
+  uint64_t frames;
+  uint32_t sched;        // index into the schedule table
+  uint32_t aligned;      // base and ch_stride multiples of 4 floats
+};
+
+// ---- chain kernel description ----------------------------------------------------------
+enum : int32_t { IN_SILENT = 0, IN_SIGNAL = 1, IN_SOURCE = 2, IN_CONSTANT = 3 };
+struct InputRef {
+  int32_t kind;
+  int32_t nch;            // channels this input delivers
+  SignalRef sig;          // IN_SIGNAL
+  const SrcInst* src;     // IN_SOURCE: [n_inst]
+  const SrcSchedule* sched;  // IN_SOURCE: schedule table
+  ParamRef offset;        // IN_CONSTANT: the offset param
+  const int64_t* active;  // IN_CONSTANT: [n_inst][2] first/last+1 active frame
+};
+
+enum : int32_t {
+  OP_GAIN = 1,        // gain.rs:143-199
+  OP_BIQUAD = 2,      // biquad_filter.rs:764-899
+  OP_WAVESHAPER = 3,  // waveshaper.rs:555-573
+  OP_STEREO_PAN = 4,  // stereo_panner.rs:218-317
+  OP_PANNER = 5,      // panner.rs:830-897, 988-1057 (equal power)
+  OP_MIX = 6          // quantum.rs:285-505
+};
+struct OpDesc {
+  int32_t kind;
+  int32_t nch_in;
+  int32_t nch_out;
+  int32_t i0;        // MIX: interpretation; WAVESHAPER: curve length; BIQUAD: coef mode (0 per inst, 1 per quantum)
+  ParamRef p0;       // GAIN: gain; STEREO_PAN: pan; PANNER: azimuth (wrapped)
+  ParamRef p1;       // STEREO_PAN / PANNER: gain_l
+  ParamRef p2;       // STEREO_PAN / PANNER: gain_r
+  ParamRef p3;       // PANNER: dist_gain*cone_gain factors (dist), p4 (cone)
+  ParamRef p4;
+  const void* ptr0;  // WAVESHAPER: curve; BIQUAD: coefficients (double[5] per inst or per inst*quantum)
+  void* ptr1;        // BIQUAD: state double[nch][4] per instance
+  uint64_t u0;       // BIQUAD: coefficient stride per instance (in doubles)
+};
+
+struct ChainDesc {
+  int32_t n_inputs;
+  int32_t in_nch;          // channel count the summed input is mixed to
+  int32_t in_interp;
+  int32_t n_ops;
+  InputRef in[MAX_INPUTS];
+  OpDesc ops[MAX_OPS];
+  SignalRef out;
+  uint32_t n_inst;
+  uint32_t n_tiles;
+  uint32_t n_quanta;
+  uint32_t pad;
+};
+
+// launchers implemented in waa_kernels.hip
+void launch_chain(const ChainDesc& d, int cmax, void* stream);
+
+}  // namespace waa

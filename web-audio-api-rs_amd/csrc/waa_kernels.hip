@@ -1,0 +1,649 @@
+// waa_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the batched offline render engine.
+//
+// chain_kernel: one 64-lane wavefront renders ONE instance (all its channels) for the whole
+// duration, tile by tile (2048 frames = 16 render quanta), carrying recurrence state in
+// registers.  A chain is  input(s) -> [mix] -> op* -> output  where the ops are the fused node
+// kernels of a single-consumer path of the graph (source fetch, gain, biquad, waveshaper,
+// stereo panner, equal-power panner, channel mixing).  Global loads/stores are 16 B per lane,
+// fully coalesced (1 KiB per wave instruction); the biquad recurrence runs on an LDS-transposed
+// layout (32 consecutive frames per lane) as zero-state pass + wavefront scan of 2x2 affine maps
+// + exact-order final pass in f64.  HBM-bound by design: no MFMA anywhere.
+//
+// Compiled with -ffp-contract=off: the reference (Rust) never fuses a*b+c unless it says
+// mul_add; every fma below is explicit.
+#include <hip/hip_runtime.h>
+
+#include "waa_internal.hpp"
+
+namespace waa {
+
+constexpr int NV4 = TILE_K / 4;      // float4 per lane per channel per tile
+constexpr int LDS_ROW = TILE_K + 4;  // padded row (floats): 144 B, conflict-free b128 access
+constexpr int CARRY_BYTES = MAX_OPS * 8 * 4 * 8;  // [MAX_OPS][C<=8][4] doubles
+
+struct f4 {
+  float x, y, z, w;
+};
+
+__device__ __forceinline__ float param_at(const ParamRef& p, uint32_t inst, uint32_t q, uint64_t frame) {
+  if (p.mode == 0) return p.base[inst];
+  if (p.mode == 1) return p.base[(uint64_t)inst * p.stride + q];
+  return p.base[(uint64_t)inst * p.stride + frame];
+}
+
+// ---- channel mixing on register tiles (quantum.rs:285-505) ------------------------------
+template <int C>
+__device__ __forceinline__ void mix_regs(float (&v)[C][TILE_K], int from, int to, int interp) {
+  if (from == to) return;
+  if (interp == 1 || from > 6 || to > 6) {  // discrete: pad with silence / truncate
+#pragma unroll
+    for (int c = 0; c < C; c++)
+      if (c >= from && c < to) {
+#pragma unroll
+        for (int i = 0; i < TILE_K; i++) v[c][i] = 0.f;
+      }
+    return;
+  }
+  if constexpr (C >= 2) {
+    if (from == 1 && to == 2) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) v[1][i] = v[0][i];
+      return;
+    }
+    if (from == 2 && to == 1) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) v[0][i] = 0.5f * (v[0][i] + v[1][i]);
+      return;
+    }
+  }
+  if constexpr (C >= 4) {
+    if (from == 1 && to == 4) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) {
+        v[1][i] = v[0][i];
+        v[2][i] = 0.f;
+        v[3][i] = 0.f;
+      }
+      return;
+    }
+    if (from == 2 && to == 4) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) {
+        v[2][i] = 0.f;
+        v[3][i] = 0.f;
+      }
+      return;
+    }
+    if (from == 4 && to == 1) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) v[0][i] = 0.25f * (v[0][i] + v[1][i] + v[2][i] + v[3][i]);
+      return;
+    }
+    if (from == 4 && to == 2) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) {
+        v[0][i] = 0.5f * (v[0][i] + v[2][i]);
+        v[1][i] = 0.5f * (v[1][i] + v[3][i]);
+      }
+      return;
+    }
+  }
+  if constexpr (C >= 6) {
+    const float sqrt05 = 0.70710678118654752440f;
+    if (from == 1 && to == 6) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) {
+        v[2][i] = v[0][i];
+        v[0][i] = v[1][i] = v[3][i] = v[4][i] = v[5][i] = 0.f;
+      }
+      return;
+    }
+    if (from == 2 && to == 6) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) v[2][i] = v[3][i] = v[4][i] = v[5][i] = 0.f;
+      return;
+    }
+    if (from == 4 && to == 5) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) {
+        v[4][i] = v[3][i];
+        v[3][i] = v[2][i];
+        v[2][i] = 0.f;
+      }
+      return;
+    }
+    if (from == 4 && to == 6) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) {
+        v[4][i] = v[2][i];
+        v[5][i] = v[3][i];
+        v[2][i] = v[3][i] = 0.f;
+      }
+      return;
+    }
+    if (from == 6 && to == 1) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++)
+        v[0][i] = __builtin_fmaf(sqrt05, v[0][i] + v[1][i], __builtin_fmaf(0.5f, v[4][i] + v[5][i], v[2][i]));
+      return;
+    }
+    if (from == 6 && to == 2) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) {
+        v[0][i] += sqrt05 * (v[2][i] + v[4][i]);
+        v[1][i] += sqrt05 * (v[2][i] + v[5][i]);
+      }
+      return;
+    }
+    if (from == 6 && to == 4) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) {
+        float c = v[2][i];
+        v[0][i] += sqrt05 * c;
+        v[1][i] += sqrt05 * c;
+        v[2][i] = v[4][i];
+        v[3][i] = v[5][i];
+      }
+      return;
+    }
+  }
+  // all other speaker layouts: pad with silence / truncate
+#pragma unroll
+  for (int c = 0; c < C; c++)
+    if (c >= from && c < to) {
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) v[c][i] = 0.f;
+    }
+}
+
+// ---- input fetch (layout A: lane holds float4 j at frame tile*TILE + j*256 + lane*4) ------
+template <int C>
+__device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, uint32_t tile, int lane, uint32_t n_quanta,
+                                           float (&v)[C][TILE_K]) {
+  const uint64_t f_tile = (uint64_t)tile * TILE;
+  if (in.kind == IN_SIGNAL) {
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      if (c < in.nch) {
+        const float* p = in.sig.base + (uint64_t)inst * in.sig.inst_stride + (uint64_t)c * in.sig.ch_stride + f_tile;
+#pragma unroll
+        for (int j = 0; j < NV4; j++) {
+          const float4 t = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
+          v[c][j * 4 + 0] = t.x;
+          v[c][j * 4 + 1] = t.y;
+          v[c][j * 4 + 2] = t.z;
+          v[c][j * 4 + 3] = t.w;
+        }
+      }
+    }
+    return;
+  }
+  if (in.kind == IN_SOURCE) {
+    const SrcInst si = in.src[inst];
+    const SrcSchedule sc = in.sched[si.sched];
+    if (si.aligned && sc.tile_fast[tile]) {
+      // whole tile is one contiguous, in-range, 16B-aligned run of the AudioBuffer
+      const int64_t start = sc.qrec[(uint64_t)tile * QUANTA_PER_TILE].start;
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        if (c < in.nch) {
+          const float* p = si.base + (uint64_t)c * si.ch_stride + start;
+#pragma unroll
+          for (int j = 0; j < NV4; j++) {
+            const float4 t = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
+            v[c][j * 4 + 0] = t.x;
+            v[c][j * 4 + 1] = t.y;
+            v[c][j * 4 + 2] = t.z;
+            v[c][j * 4 + 3] = t.w;
+          }
+        }
+      }
+      return;
+    }
+    // generic path: per-quantum records (silent / fast copy with end-of-buffer or loop wrap / slow track)
+#pragma unroll
+    for (int j = 0; j < NV4; j++) {
+      const uint32_t fq = j * 256 + lane * 4;  // frame within tile
+      uint32_t q = tile * QUANTA_PER_TILE + fq / RQ;
+      const bool valid_q = q < n_quanta;
+      const QRec r = sc.qrec[valid_q ? q : 0];
+      const uint32_t mode = valid_q ? r.mode : (uint32_t)Q_SILENT;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const uint32_t i = (fq % RQ) + e;  // index within quantum
+        if (mode == Q_FAST || mode == Q_FAST_LOOP) {
+          // audio_buffer_source.rs:562-607: index start+i, zero past the end, or wrap when looping
+          uint64_t bi = (uint64_t)r.start + i;
+          bool ok = true;
+          if (bi >= si.frames) {
+            if (mode == Q_FAST_LOOP)
+              bi = bi % si.frames;
+            else
+              ok = false;
+          }
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (c < in.nch) v[c][j * 4 + e] = ok ? si.base[(uint64_t)c * si.ch_stride + bi] : 0.f;
+        } else if (mode == Q_SLOW) {
+          const SlowRec s = sc.slow[(uint64_t)q * RQ + i];
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (c < in.nch) {
+              float o = 0.f;
+              if (s.prev >= 0) {
+                // audio_buffer_source.rs:754-822
+                const float* ch = si.base + (uint64_t)c * si.ch_stride;
+                const double prev_sample = (double)ch[s.prev];
+                double next_sample;
+                if (s.next >= 0)
+                  next_sample = (double)ch[s.next];
+                else if (s.next == -1)
+                  next_sample = 0.;
+                else
+                  next_sample = 2. * prev_sample - (double)ch[s.prev - 1];
+                o = (float)__builtin_fma(1. - s.k, prev_sample, s.k * next_sample);
+              }
+              v[c][j * 4 + e] = o;
+            }
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (c < in.nch) v[c][j * 4 + e] = 0.f;
+        }
+      }
+    }
+    return;
+  }
+  if (in.kind == IN_CONSTANT) {
+    // constant_source.rs:190-275; the active frame range was resolved on the host
+    const int64_t a0 = in.active[(uint64_t)inst * 2], a1 = in.active[(uint64_t)inst * 2 + 1];
+#pragma unroll
+    for (int j = 0; j < NV4; j++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const uint64_t f = f_tile + j * 256 + lane * 4 + e;
+        uint32_t q = (uint32_t)(f / RQ);
+        if (q >= n_quanta) q = n_quanta - 1;
+        const uint64_t fc = f < (uint64_t)n_quanta * RQ ? f : (uint64_t)n_quanta * RQ - 1;
+        const float val = param_at(in.offset, inst, q, fc);
+        v[0][j * 4 + e] = ((int64_t)f >= a0 && (int64_t)f < a1) ? val : 0.f;
+      }
+    }
+    return;
+  }
+  // IN_SILENT
+#pragma unroll
+  for (int i = 0; i < TILE_K; i++) v[0][i] = 0.f;
+}
+
+// ---- biquad (biquad_filter.rs:764-899) on the transposed layout --------------------------
+struct Mat2 {
+  double a, b, c, d;  // [[a b],[c d]]
+};
+__device__ __forceinline__ Mat2 matmul(const Mat2& x, const Mat2& y) {
+  Mat2 r;
+  r.a = __builtin_fma(x.a, y.a, x.b * y.c);
+  r.b = __builtin_fma(x.a, y.b, x.b * y.d);
+  r.c = __builtin_fma(x.c, y.a, x.d * y.c);
+  r.d = __builtin_fma(x.c, y.b, x.d * y.d);
+  return r;
+}
+__device__ __forceinline__ double shfl_up_d(double v, int delta) { return __shfl_up(v, delta, 64); }
+
+template <int C>
+__device__ __forceinline__ void biquad_op(const OpDesc& op, uint32_t inst, uint32_t tile, int lane, uint32_t n_quanta,
+                                          float* lds, float (&v)[C][TILE_K], double* carry, const double* coef_inst) {
+  // carry: LDS, [C][4] = (x1, x2, y1, y2) per channel at the start of this tile
+  const int nch = op.nch_in;
+  // A -> LDS
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    if (c < nch) {
+      float* base = lds + c * (64 * LDS_ROW);
+#pragma unroll
+      for (int j = 0; j < NV4; j++) {
+        const int row = j * 8 + (lane >> 3), col = (lane & 7) * 4;
+        *reinterpret_cast<float4*>(base + row * LDS_ROW + col) =
+            make_float4(v[c][j * 4 + 0], v[c][j * 4 + 1], v[c][j * 4 + 2], v[c][j * 4 + 3]);
+      }
+    }
+  }
+  __syncthreads();
+  // coefficients for this lane's quantum (4 lanes per quantum)
+  double b0, b1, b2, a1, a2;
+  {
+    const double* cp = coef_inst;
+    if (op.i0 == 1) {
+      uint32_t q = tile * QUANTA_PER_TILE + (lane >> 2);
+      if (q >= n_quanta) q = n_quanta - 1;
+      cp += (uint64_t)q * 5;
+    }
+    b0 = cp[0];
+    b1 = cp[1];
+    b2 = cp[2];
+    a1 = cp[3];
+    a2 = cp[4];
+  }
+  // A_l = M^32 with M = [[-a1, -a2], [1, 0]] acting on (y[n-1], y[n-2])
+  Mat2 A;
+  {
+    Mat2 m = {-a1, -a2, 1., 0.};
+#pragma unroll
+    for (int s = 0; s < 5; s++) m = matmul(m, m);
+    A = m;
+  }
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    if (c < nch) {
+      float* base = lds + c * (64 * LDS_ROW);
+      float x[TILE_K];
+#pragma unroll
+      for (int j = 0; j < NV4; j++) {
+        const float4 t = *reinterpret_cast<const float4*>(base + lane * LDS_ROW + j * 4);
+        x[j * 4 + 0] = t.x;
+        x[j * 4 + 1] = t.y;
+        x[j * 4 + 2] = t.z;
+        x[j * 4 + 3] = t.w;
+      }
+      // x history at the chunk boundary: previous lane's last two samples (lane 0: carried state)
+      float xm1 = __shfl_up(x[TILE_K - 1], 1, 64), xm2 = __shfl_up(x[TILE_K - 2], 1, 64);
+      const double c_x1 = carry[c * 4 + 0], c_x2 = carry[c * 4 + 1], c_y1 = carry[c * 4 + 2], c_y2 = carry[c * 4 + 3];
+      double x1 = lane == 0 ? c_x1 : (double)xm1;
+      double x2 = lane == 0 ? c_x2 : (double)xm2;
+      // FIR part in the reference's evaluation order: (b0*x + b1*x1) + b2*x2, then zero-state recurrence
+      double w[TILE_K];
+      double z1 = 0., z2 = 0.;
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) {
+        const double xd = (double)x[i];
+        w[i] = (b0 * xd + b1 * x1) + b2 * x2;
+        x2 = x1;
+        x1 = xd;
+        const double t = __builtin_fma(-a2, z2, w[i]);
+        const double y = __builtin_fma(-a1, z1, t);
+        z2 = z1;
+        z1 = y;
+      }
+      // inclusive wavefront scan of the affine maps s -> A s + z  (s = (y1, y2) at chunk end)
+      Mat2 P = A;
+      double r1 = z1, r2 = z2;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        Mat2 Q;
+        Q.a = shfl_up_d(P.a, d);
+        Q.b = shfl_up_d(P.b, d);
+        Q.c = shfl_up_d(P.c, d);
+        Q.d = shfl_up_d(P.d, d);
+        const double q1 = shfl_up_d(r1, d), q2 = shfl_up_d(r2, d);
+        if (lane >= d) {
+          const double n1 = __builtin_fma(P.a, q1, __builtin_fma(P.b, q2, r1));
+          const double n2 = __builtin_fma(P.c, q1, __builtin_fma(P.d, q2, r2));
+          r1 = n1;
+          r2 = n2;
+          P = matmul(P, Q);
+        }
+      }
+      // incoming state of this lane = map of lane-1 applied to the tile's incoming state
+      double y1, y2;
+      {
+        const double pa = shfl_up_d(P.a, 1), pb = shfl_up_d(P.b, 1), pc = shfl_up_d(P.c, 1), pd = shfl_up_d(P.d, 1);
+        const double q1 = shfl_up_d(r1, 1), q2 = shfl_up_d(r2, 1);
+        const double s1 = c_y1, s2 = c_y2;
+        y1 = lane == 0 ? s1 : __builtin_fma(pa, s1, __builtin_fma(pb, s2, q1));
+        y2 = lane == 0 ? s2 : __builtin_fma(pc, s1, __builtin_fma(pd, s2, q2));
+      }
+      // final pass, exact reference order: y = ((w) - a1*y1) - a2*y2 ; flush !is_normal to 0
+      float yo[TILE_K];
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) {
+        double y = (w[i] - a1 * y1) - a2 * y2;
+        if (!__builtin_isnormal(y)) y = 0.;
+        y2 = y1;
+        y1 = y;
+        yo[i] = (float)y;
+      }
+      // new carried state = lane 63's end state
+      if (lane == 63) {
+        carry[c * 4 + 0] = (double)x[TILE_K - 1];
+        carry[c * 4 + 1] = (double)x[TILE_K - 2];
+        carry[c * 4 + 2] = y1;
+        carry[c * 4 + 3] = y2;
+      }
+      // T -> LDS (own row)
+#pragma unroll
+      for (int j = 0; j < NV4; j++)
+        *reinterpret_cast<float4*>(base + lane * LDS_ROW + j * 4) =
+            make_float4(yo[j * 4 + 0], yo[j * 4 + 1], yo[j * 4 + 2], yo[j * 4 + 3]);
+    }
+  }
+  __syncthreads();
+  // LDS -> A
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    if (c < nch) {
+      const float* base = lds + c * (64 * LDS_ROW);
+#pragma unroll
+      for (int j = 0; j < NV4; j++) {
+        const int row = j * 8 + (lane >> 3), col = (lane & 7) * 4;
+        const float4 t = *reinterpret_cast<const float4*>(base + row * LDS_ROW + col);
+        v[c][j * 4 + 0] = t.x;
+        v[c][j * 4 + 1] = t.y;
+        v[c][j * 4 + 2] = t.z;
+        v[c][j * 4 + 3] = t.w;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// waveshaper.rs:555-573
+__device__ __forceinline__ float apply_curve(const float* curve, int nn, float input) {
+  if (nn == 0) return 0.f;
+  const float n = (float)nn;
+  const float v = (n - 1.f) / 2.0f * (input + 1.f);
+  if (v <= 0.f) return curve[0];
+  if (v >= n - 1.f) return curve[nn - 1];
+  const float k = floorf(v);
+  const float f = v - k;
+  const int ki = (int)k;
+  return (1.f - f) * curve[ki] + f * curve[ki + 1];
+}
+
+__device__ __forceinline__ void stereo_gains_dev(float x, float& gl, float& gr) {
+  const float PI_F = 3.14159265358979323846f;
+  gl = sinf((1.f - x) * PI_F / 2.f);
+  gr = sinf(x * PI_F / 2.f);
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void chain_kernel(const ChainDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const uint32_t inst = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (inst >= d.n_inst) return;
+
+  // recurrence state of every biquad op of the chain lives in LDS: [MAX_OPS][C][4] doubles
+  double* carry_all = reinterpret_cast<double*>(lds + C * 64 * LDS_ROW);
+  for (int o = 0; o < d.n_ops; o++) {
+    if (d.ops[o].kind == OP_BIQUAD) {
+      const double* st = reinterpret_cast<const double*>(d.ops[o].ptr1) + (uint64_t)inst * STATE_STRIDE;
+      if (lane < C * 4) carry_all[o * C * 4 + lane] = (lane >> 2) < d.ops[o].nch_in ? st[lane] : 0.;
+    }
+  }
+  __syncthreads();
+
+  for (uint32_t tile = 0; tile < d.n_tiles; tile++) {
+    float v[C][TILE_K];
+    // ---- inputs: mix every incoming edge to the node's computed channel count and sum in edge order
+    load_input<C>(d.in[0], inst, tile, lane, d.n_quanta, v);
+    mix_regs<C>(v, d.in[0].nch, d.in_nch, d.in_interp);
+    for (int k = 1; k < d.n_inputs; k++) {
+      float u[C][TILE_K];
+      load_input<C>(d.in[k], inst, tile, lane, d.n_quanta, u);
+      mix_regs<C>(u, d.in[k].nch, d.in_nch, d.in_interp);
+#pragma unroll
+      for (int c = 0; c < C; c++)
+        if (c < d.in_nch) {
+#pragma unroll
+          for (int i = 0; i < TILE_K; i++) v[c][i] += u[c][i];
+        }
+    }
+    // ---- fused node ops
+    for (int o = 0; o < d.n_ops; o++) {
+      const OpDesc& op = d.ops[o];
+      switch (op.kind) {
+        case OP_GAIN: {
+#pragma unroll
+          for (int j = 0; j < NV4; j++) {
+            const uint32_t q = tile * QUANTA_PER_TILE + j * 2 + (lane >> 5);
+            const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
+            const uint64_t f = (uint64_t)tile * TILE + j * 256 + lane * 4;
+            if (op.p0.mode == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const uint64_t fc = f + e < (uint64_t)d.n_quanta * RQ ? f + e : (uint64_t)d.n_quanta * RQ - 1;
+                const float g = op.p0.base[(uint64_t)inst * op.p0.stride + fc];
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                  if (c < op.nch_in) v[c][j * 4 + e] *= g;
+              }
+            } else {
+              // gain.rs:163-179: |g| <= 1e-6 -> silent, |1-g| <= 1e-6 -> passthrough
+              const float g = param_at(op.p0, inst, qc, 0);
+              const bool mute = fabsf(g) <= 1e-6f;
+              const bool pass = fabsf(1.f - g) <= 1e-6f;
+#pragma unroll
+              for (int c = 0; c < C; c++)
+                if (c < op.nch_in) {
+#pragma unroll
+                  for (int e = 0; e < 4; e++) v[c][j * 4 + e] = mute ? 0.f : (pass ? v[c][j * 4 + e] : v[c][j * 4 + e] * g);
+                }
+            }
+          }
+          break;
+        }
+        case OP_BIQUAD: {
+          const double* coef = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0;
+          biquad_op<C>(op, inst, tile, lane, d.n_quanta, lds, v, carry_all + o * C * 4, coef);
+          break;
+        }
+        case OP_WAVESHAPER: {
+          const float* curve = reinterpret_cast<const float*>(op.ptr0);
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (c < op.nch_in) {
+#pragma unroll
+              for (int i = 0; i < TILE_K; i++) v[c][i] = apply_curve(curve, op.i0, v[c][i]);
+            }
+          break;
+        }
+        case OP_STEREO_PAN: {
+          if constexpr (C >= 2) {
+#pragma unroll
+            for (int j = 0; j < NV4; j++) {
+              const uint32_t q = tile * QUANTA_PER_TILE + j * 2 + (lane >> 5);
+              const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
+              const uint64_t f = (uint64_t)tile * TILE + j * 256 + lane * 4;
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const uint64_t fc = f + e < (uint64_t)d.n_quanta * RQ ? f + e : (uint64_t)d.n_quanta * RQ - 1;
+                const float pan = param_at(op.p0, inst, qc, fc);
+                float gl, gr;
+                if (op.p0.mode == 2) {
+                  const float x = op.nch_in == 1 ? (pan + 1.f) * 0.5f : (pan <= 0.f ? pan + 1.f : pan);
+                  stereo_gains_dev(x, gl, gr);
+                } else {
+                  gl = param_at(op.p1, inst, qc, fc);
+                  gr = param_at(op.p2, inst, qc, fc);
+                }
+                if (op.nch_in == 1) {
+                  const float in = v[0][j * 4 + e];
+                  v[0][j * 4 + e] = in * gl;
+                  v[1][j * 4 + e] = in * gr;
+                } else {
+                  const float il = v[0][j * 4 + e], ir = v[1][j * 4 + e];
+                  if (pan <= 0.f) {
+                    v[0][j * 4 + e] = __builtin_fmaf(ir, gl, il);
+                    v[1][j * 4 + e] = ir * gr;
+                  } else {
+                    v[0][j * 4 + e] = il * gl;
+                    v[1][j * 4 + e] = __builtin_fmaf(il, gr, ir);
+                  }
+                }
+              }
+            }
+          }
+          break;
+        }
+        case OP_PANNER: {
+          if constexpr (C >= 2) {
+#pragma unroll
+            for (int j = 0; j < NV4; j++) {
+              const uint32_t q = tile * QUANTA_PER_TILE + j * 2 + (lane >> 5);
+              const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
+              const float az = param_at(op.p0, inst, qc, 0);
+              const float gl = param_at(op.p1, inst, qc, 0), gr = param_at(op.p2, inst, qc, 0);
+              const float dg = param_at(op.p3, inst, qc, 0), cg = param_at(op.p4, inst, qc, 0);
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                if (op.nch_in == 1) {
+                  // panner.rs:988-1014 (after the mono -> stereo up-mix l = r = in)
+                  const float in = v[0][j * 4 + e];
+                  v[0][j * 4 + e] = in * (gl * dg * cg);
+                  v[1][j * 4 + e] = in * (gr * dg * cg);
+                } else {
+                  // panner.rs:1016-1057
+                  const float il = v[0][j * 4 + e], ir = v[1][j * 4 + e];
+                  if (az <= 0.f) {
+                    v[0][j * 4 + e] = (il + ir * gl) * dg * cg;
+                    v[1][j * 4 + e] = ir * gr * dg * cg;
+                  } else {
+                    v[0][j * 4 + e] = il * gl * dg * cg;
+                    v[1][j * 4 + e] = (ir + il * gr) * dg * cg;
+                  }
+                }
+              }
+            }
+          }
+          break;
+        }
+        case OP_MIX:
+          mix_regs<C>(v, op.nch_in, op.nch_out, op.i0);
+          break;
+        default:
+          break;
+      }
+    }
+    // ---- store
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      if (c < d.out.nch) {
+        float* p = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)tile * TILE;
+#pragma unroll
+        for (int j = 0; j < NV4; j++)
+          *reinterpret_cast<float4*>(p + j * 256 + lane * 4) =
+              make_float4(v[c][j * 4 + 0], v[c][j * 4 + 1], v[c][j * 4 + 2], v[c][j * 4 + 3]);
+      }
+    }
+  }
+  // persist recurrence state (lets a later render range continue; also what tail logic would inspect)
+  __syncthreads();
+  for (int o = 0; o < d.n_ops; o++) {
+    if (d.ops[o].kind == OP_BIQUAD) {
+      double* st = reinterpret_cast<double*>(d.ops[o].ptr1) + (uint64_t)inst * STATE_STRIDE;
+      if (lane < C * 4 && (lane >> 2) < d.ops[o].nch_in) st[lane] = carry_all[o * C * 4 + lane];
+    }
+  }
+}
+
+void launch_chain(const ChainDesc& d, int cmax, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(d.n_inst), block(64);
+  if (cmax <= 1) {
+    hipLaunchKernelGGL(chain_kernel<1>, grid, block, 1 * 64 * LDS_ROW * sizeof(float) + CARRY_BYTES, s, d);
+  } else {
+    hipLaunchKernelGGL(chain_kernel<2>, grid, block, 2 * 64 * LDS_ROW * sizeof(float) + CARRY_BYTES, s, d);
+  }
+}
+
+}  // namespace waa
