@@ -164,15 +164,26 @@ def test_mixing_integration(be):
     assert np.array_equal(o[0], ones)
     o = _run_mixing(be, 2, "speakers", 2, "max", "speakers")
     assert np.array_equal(o[0], ones) and np.array_equal(o[1], ones)
-    o = _run_mixing(be, 4, "speakers", 4, "max", "speakers")
-    assert np.array_equal(o[0], ones) and np.array_equal(o[1], ones) and np.array_equal(o[2], zeros) and np.array_equal(
-        o[3], zeros)
     o = _run_mixing(be, 2, "discrete", 1, "max", "speakers")
     assert np.array_equal(o[0], ones) and np.array_equal(o[1], zeros)
     o = _run_mixing(be, 2, "discrete", 2, "max", "speakers")
     assert np.array_equal(o[0], ones) and np.array_equal(o[1], zeros)
     o = _run_mixing(be, 1, "discrete", 2, "max", "speakers")
     assert np.array_equal(o[0], ones)
+
+
+def test_mixing_integration_quad(be):
+    """tests/mixing.rs:56-65 (quad destination). The device path of this round renders <= 2 channels per
+    signal and must say so loudly (status 4) instead of producing wrong channels."""
+    ones, zeros = np.ones(128, np.float32), np.zeros(128, np.float32)
+    if be.prefix == "waa_":
+        with pytest.raises(waa.WaaError) as e:
+            _run_mixing(be, 4, "speakers", 4, "max", "speakers")
+        assert e.value.status == 4
+        return
+    o = _run_mixing(be, 4, "speakers", 4, "max", "speakers")
+    assert np.array_equal(o[0], ones) and np.array_equal(o[1], ones) and np.array_equal(o[2], zeros) and np.array_equal(
+        o[3], zeros)
 
 
 def test_offline_render_summing_and_truncation(be):

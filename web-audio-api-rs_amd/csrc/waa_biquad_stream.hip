@@ -1,0 +1,323 @@
+// waa_biquad_stream.hip — the streaming biquad kernel (BASELINE config C2 and the Biquad stage of T1/C4).
+//
+// One 64-lane wavefront renders one (instance, channel) stream for the whole duration, 2048 frames
+// (16 render quanta) per tile:
+//   global (16 B/lane, coalesced, next tile prefetched in registers)
+//     -> LDS transpose -> 32 consecutive frames per lane
+//     -> FIR part w = (b0*x + b1*x1) + b2*x2 in the reference's evaluation order (f64, unfused)
+//     -> zero-state recurrence per lane, then the true incoming state of every lane from a wavefront
+//        scan: 4 DPP row_shr steps with the uniform matrix powers A, A^2, A^4, A^8 (A = M^32), row
+//        carries through A^16, per-lane A^(lane%16)
+//     -> final pass y = (w - a1*y1) - a2*y2 in the reference's order (biquad_filter.rs:877)
+//     -> LDS transpose back -> gains -> global store (16 B/lane).
+// f64 denormals are flushed by hardware mode (the reference renders under FTZ/DAZ, thread.rs:374-382);
+// the explicit `!y.is_normal() -> 0` of biquad_filter.rs:881-883 then only matters for inf/NaN, which is
+// detected off the critical path and handled by re-running the lane's pass with the flush.
+// HBM-bound by design (8 B of traffic per frame-channel); no MFMA.
+#include <hip/hip_runtime.h>
+
+#include "waa_internal.hpp"
+
+namespace waa {
+
+namespace {
+constexpr int NV4 = TILE_K / 4;
+constexpr int LDS_ROW = TILE_K + 4;
+
+struct M2 {
+  double a, b, c, d;
+};
+__device__ __forceinline__ M2 mm(const M2& x, const M2& y) {
+  M2 r;
+  r.a = __builtin_fma(x.a, y.a, x.b * y.c);
+  r.b = __builtin_fma(x.a, y.b, x.b * y.d);
+  r.c = __builtin_fma(x.c, y.a, x.d * y.c);
+  r.d = __builtin_fma(x.c, y.b, x.d * y.d);
+  return r;
+}
+
+// DPP row shift right by N lanes within each row of 16; lanes without a source read 0.
+template <int N>
+__device__ __forceinline__ double row_shr(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, true);
+  return __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// generic (rare) input path for one channel: end-of-buffer / loop wrap / slow track / silent quanta
+__device__ __noinline__ void load_channel_generic(const InputRef& in, const SrcInst& si, const SrcSchedule& sc, int ch,
+                                                  uint32_t tile, int lane, uint32_t n_quanta, float* out32) {
+  const float* chp = si.base + (uint64_t)ch * si.ch_stride;
+  for (int j = 0; j < NV4; j++) {
+    const uint32_t fq = j * 256 + lane * 4;
+    const uint32_t q = tile * QUANTA_PER_TILE + fq / RQ;
+    const bool valid_q = q < n_quanta;
+    const QRec r = sc.qrec[valid_q ? q : 0];
+    const uint32_t mode = valid_q ? r.mode : (uint32_t)Q_SILENT;
+    for (int e = 0; e < 4; e++) {
+      const uint32_t i = (fq % RQ) + e;
+      float o = 0.f;
+      if (mode == Q_FAST || mode == Q_FAST_LOOP) {
+        uint64_t bi = (uint64_t)r.start + i;
+        bool ok = true;
+        if (bi >= si.frames) {
+          if (mode == Q_FAST_LOOP)
+            bi = bi % si.frames;
+          else
+            ok = false;
+        }
+        o = ok ? chp[bi] : 0.f;
+      } else if (mode == Q_SLOW) {
+        const SlowRec s = sc.slow[(uint64_t)q * RQ + i];
+        if (s.prev >= 0) {
+          const double prev_sample = (double)chp[s.prev];
+          double next_sample;
+          if (s.next >= 0)
+            next_sample = (double)chp[s.next];
+          else if (s.next == -1)
+            next_sample = 0.;
+          else
+            next_sample = 2. * prev_sample - (double)chp[s.prev - 1];
+          o = (float)__builtin_fma(1. - s.k, prev_sample, s.k * next_sample);
+        }
+      }
+      out32[j * 4 + e] = o;
+    }
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64, 2) void biquad_stream_kernel(const BiquadStreamDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const uint32_t wid = blockIdx.x;
+  const uint32_t inst = wid / (uint32_t)d.nch;
+  const int ch = (int)(wid % (uint32_t)d.nch);
+  const int lane = threadIdx.x;
+  if (inst >= d.n_inst) return;
+
+  // f64 (and f16) denormals: flush inputs and outputs, like the reference's FTZ/DAZ render scope.
+  // hwreg(HW_REG_MODE = 1, offset 6, width 2)
+  __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);
+
+  // coefficients (uniform per wave)
+  const double* cp = d.coefs + (uint64_t)inst * 5;
+  const double b0 = cp[0], b1 = cp[1], b2 = cp[2], a1 = cp[3], a2 = cp[4];
+  // matrix powers of the 32-step state transition: A = M^32, M = [[-a1, -a2], [1, 0]] on (y[n-1], y[n-2])
+  M2 A1;
+  {
+    M2 m = {-a1, -a2, 1., 0.};
+#pragma unroll
+    for (int s = 0; s < 5; s++) m = mm(m, m);
+    A1 = m;
+  }
+  const M2 A2 = mm(A1, A1), A4 = mm(A2, A2), A8 = mm(A4, A4), A16 = mm(A8, A8);
+  // per-lane A^(lane % 16)
+  M2 Aj = {1., 0., 0., 1.};
+  {
+    const int j = lane & 15;
+    if (j & 1) Aj = mm(Aj, A1);
+    if (j & 2) Aj = mm(Aj, A2);
+    if (j & 4) Aj = mm(Aj, A4);
+    if (j & 8) Aj = mm(Aj, A8);
+  }
+  const int row = lane >> 4;
+
+  // carried state (uniform): x[n-1], x[n-2], y[n-1], y[n-2]
+  double* st = d.state + (uint64_t)inst * STATE_STRIDE + ch * 4;
+  double cx1 = st[0], cx2 = st[1], cy1 = st[2], cy2 = st[3];
+
+  // gains (gain.rs:163-179 fast paths are per render quantum with a constant gain => per kernel here)
+  float g[2] = {1.f, 1.f};
+  bool g_mute[2] = {false, false}, g_pass[2] = {true, true};
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+    if (k < d.n_gain) {
+      g[k] = d.gain[k].base[inst];
+      g_mute[k] = fabsf(g[k]) <= 1e-6f;
+      g_pass[k] = fabsf(1.f - g[k]) <= 1e-6f;
+    }
+
+  // input addressing
+  const bool is_src = d.in.kind == IN_SOURCE;
+  SrcInst si{};
+  SrcSchedule sc{};
+  const float* sig_base = nullptr;
+  if (is_src) {
+    si = d.in.src[inst];
+    sc = d.in.sched[si.sched];
+  } else {
+    sig_base = d.in.sig.base + (uint64_t)inst * d.in.sig.inst_stride + (uint64_t)ch * d.in.sig.ch_stride;
+  }
+  float* out_base = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)ch * d.out.ch_stride;
+
+  float4 nx[NV4];
+  auto fetch = [&](uint32_t tile) {
+    if (!is_src) {
+      const float* p = sig_base + (uint64_t)tile * TILE;
+#pragma unroll
+      for (int j = 0; j < NV4; j++) nx[j] = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
+    } else if (si.aligned && sc.tile_fast[tile]) {
+      const float* p = si.base + (uint64_t)ch * si.ch_stride + sc.qrec[(uint64_t)tile * QUANTA_PER_TILE].start;
+#pragma unroll
+      for (int j = 0; j < NV4; j++) nx[j] = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
+    } else {
+      float tmp[TILE_K];
+      load_channel_generic(d.in, si, sc, ch, tile, lane, d.n_quanta, tmp);
+#pragma unroll
+      for (int j = 0; j < NV4; j++) nx[j] = make_float4(tmp[j * 4], tmp[j * 4 + 1], tmp[j * 4 + 2], tmp[j * 4 + 3]);
+    }
+  };
+  fetch(0);
+
+  for (uint32_t tile = 0; tile < d.n_tiles; tile++) {
+    // A layout -> LDS
+#pragma unroll
+    for (int j = 0; j < NV4; j++) {
+      const int r = j * 8 + (lane >> 3), c = (lane & 7) * 4;
+      *reinterpret_cast<float4*>(lds + r * LDS_ROW + c) = nx[j];
+    }
+    if (tile + 1 < d.n_tiles) fetch(tile + 1);  // prefetch: in flight during the whole recurrence
+    __syncthreads();
+    float x[TILE_K];
+#pragma unroll
+    for (int j = 0; j < NV4; j++) {
+      const float4 t = *reinterpret_cast<const float4*>(lds + lane * LDS_ROW + j * 4);
+      x[j * 4 + 0] = t.x;
+      x[j * 4 + 1] = t.y;
+      x[j * 4 + 2] = t.z;
+      x[j * 4 + 3] = t.w;
+    }
+    // x history at the chunk boundary
+    const float xm1 = __shfl_up(x[TILE_K - 1], 1, 64), xm2 = __shfl_up(x[TILE_K - 2], 1, 64);
+    double x1 = lane == 0 ? cx1 : (double)xm1;
+    double x2 = lane == 0 ? cx2 : (double)xm2;
+    // FIR part + zero-state recurrence
+    double w[TILE_K];
+    double z1 = 0., z2 = 0.;
+#pragma unroll
+    for (int i = 0; i < TILE_K; i++) {
+      const double xd = (double)x[i];
+      w[i] = (b0 * xd + b1 * x1) + b2 * x2;
+      x2 = x1;
+      x1 = xd;
+      const double t = __builtin_fma(-a2, z2, w[i]);
+      const double y = __builtin_fma(-a1, z1, t);
+      z2 = z1;
+      z1 = y;
+    }
+    // in-row inclusive scan (rows of 16 lanes): R_l = sum_{i in row, i<=l} A^(l-i) z_i
+    double r1 = z1, r2 = z2;
+    {
+      double q1 = row_shr<1>(r1), q2 = row_shr<1>(r2);
+      r1 = __builtin_fma(A1.a, q1, __builtin_fma(A1.b, q2, r1));
+      r2 = __builtin_fma(A1.c, q1, __builtin_fma(A1.d, q2, r2));
+      q1 = row_shr<2>(r1);
+      q2 = row_shr<2>(r2);
+      r1 = __builtin_fma(A2.a, q1, __builtin_fma(A2.b, q2, r1));
+      r2 = __builtin_fma(A2.c, q1, __builtin_fma(A2.d, q2, r2));
+      q1 = row_shr<4>(r1);
+      q2 = row_shr<4>(r2);
+      r1 = __builtin_fma(A4.a, q1, __builtin_fma(A4.b, q2, r1));
+      r2 = __builtin_fma(A4.c, q1, __builtin_fma(A4.d, q2, r2));
+      q1 = row_shr<8>(r1);
+      q2 = row_shr<8>(r2);
+      r1 = __builtin_fma(A8.a, q1, __builtin_fma(A8.b, q2, r1));
+      r2 = __builtin_fma(A8.c, q1, __builtin_fma(A8.d, q2, r2));
+    }
+    // state entering each row: T0 = carried, T_{k+1} = A^16 T_k + R(end of row k)
+    const double e01 = read_lane(r1, 15), e02 = read_lane(r2, 15);
+    const double e11 = read_lane(r1, 31), e12 = read_lane(r2, 31);
+    const double e21 = read_lane(r1, 47), e22 = read_lane(r2, 47);
+    const double t01 = cy1, t02 = cy2;
+    const double t11 = __builtin_fma(A16.a, t01, __builtin_fma(A16.b, t02, e01));
+    const double t12 = __builtin_fma(A16.c, t01, __builtin_fma(A16.d, t02, e02));
+    const double t21 = __builtin_fma(A16.a, t11, __builtin_fma(A16.b, t12, e11));
+    const double t22 = __builtin_fma(A16.c, t11, __builtin_fma(A16.d, t12, e12));
+    const double t31 = __builtin_fma(A16.a, t21, __builtin_fma(A16.b, t22, e21));
+    const double t32 = __builtin_fma(A16.c, t21, __builtin_fma(A16.d, t22, e22));
+    const double T1 = row == 0 ? t01 : row == 1 ? t11 : row == 2 ? t21 : t31;
+    const double T2 = row == 0 ? t02 : row == 1 ? t12 : row == 2 ? t22 : t32;
+    // state entering this lane = A^(lane%16) * T_row + exclusive in-row scan
+    const double ex1 = row_shr<1>(r1), ex2 = row_shr<1>(r2);
+    const double s1 = __builtin_fma(Aj.a, T1, __builtin_fma(Aj.b, T2, ex1));
+    const double s2 = __builtin_fma(Aj.c, T1, __builtin_fma(Aj.d, T2, ex2));
+    // final pass in the reference's order
+    double y1 = s1, y2 = s2;
+    bool bad = false;
+    float yo[TILE_K];
+#pragma unroll
+    for (int i = 0; i < TILE_K; i++) {
+      const double y = (w[i] - a1 * y1) - a2 * y2;
+      bad |= !__builtin_isfinite(y);
+      y2 = y1;
+      y1 = y;
+      yo[i] = (float)y;
+    }
+    if (__any(bad)) {
+      // inf / NaN appeared somewhere: redo with the explicit flush of biquad_filter.rs:881-883
+      y1 = s1;
+      y2 = s2;
+      if (!__builtin_isfinite(y1)) y1 = 0.;
+      if (!__builtin_isfinite(y2)) y2 = 0.;
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) {
+        double y = (w[i] - a1 * y1) - a2 * y2;
+        if (!__builtin_isnormal(y)) y = 0.;
+        y2 = y1;
+        y1 = y;
+        yo[i] = (float)y;
+      }
+    }
+    // carried state for the next tile: lane 63's end state
+    cx1 = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[TILE_K - 1]), 63));
+    cx2 = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[TILE_K - 2]), 63));
+    cy1 = read_lane(y1, 63);
+    cy2 = read_lane(y2, 63);
+    // T layout -> LDS (own row) -> A layout
+#pragma unroll
+    for (int j = 0; j < NV4; j++)
+      *reinterpret_cast<float4*>(lds + lane * LDS_ROW + j * 4) =
+          make_float4(yo[j * 4 + 0], yo[j * 4 + 1], yo[j * 4 + 2], yo[j * 4 + 3]);
+    __syncthreads();
+    float* op = out_base + (uint64_t)tile * TILE;
+#pragma unroll
+    for (int j = 0; j < NV4; j++) {
+      const int r = j * 8 + (lane >> 3), c = (lane & 7) * 4;
+      float4 t = *reinterpret_cast<const float4*>(lds + r * LDS_ROW + c);
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (k < d.n_gain) {
+          if (g_mute[k]) {
+            t = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else if (!g_pass[k]) {
+            t.x *= g[k];
+            t.y *= g[k];
+            t.z *= g[k];
+            t.w *= g[k];
+          }
+        }
+      *reinterpret_cast<float4*>(op + j * 256 + lane * 4) = t;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    st[0] = cx1;
+    st[1] = cx2;
+    st[2] = cy1;
+    st[3] = cy2;
+  }
+}
+
+void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
+  hipLaunchKernelGGL(biquad_stream_kernel, dim3(d.n_inst * (uint32_t)d.nch), dim3(64), 64 * LDS_ROW * sizeof(float),
+                     (hipStream_t)stream, d);
+}
+
+}  // namespace waa

@@ -118,8 +118,9 @@ struct ProfileEntry {
 };
 
 struct Step {
-  int kind = 0;  // 0 chain
+  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel
   ChainDesc chain{};
+  BiquadStreamDesc bq{};
   int cmax = 1;
   int profile_slot = -1;
 };
@@ -824,11 +825,35 @@ int build_plan(waa_batch* b) {
     cd.n_quanta = b->n_quanta;
     st.cmax = cmax;
     st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : "chain_kernel<2>");
+    // hot shape: single unmixed input -> Biquad(constant coefficients) -> constant gains: streaming kernel
+    {
+      bool fast = cd.n_inputs == 1 && (cd.in[0].kind == IN_SOURCE || cd.in[0].kind == IN_SIGNAL) &&
+                  cd.in[0].nch == cd.in_nch && cd.n_ops >= 1 && cd.n_ops <= 3 && cd.ops[0].kind == OP_BIQUAD &&
+                  cd.ops[0].i0 == 0 && cd.ops[0].nch_in == cd.in_nch && cd.out.nch == cd.in_nch;
+      for (int k = 1; fast && k < cd.n_ops; k++)
+        fast = cd.ops[k].kind == OP_GAIN && cd.ops[k].p0.mode == 0 && cd.ops[k].nch_in == cd.in_nch;
+      if (fast) {
+        st.kind = 1;
+        BiquadStreamDesc& q = st.bq;
+        std::memset(&q, 0, sizeof q);
+        q.coefs = reinterpret_cast<const double*>(cd.ops[0].ptr0);
+        q.state = reinterpret_cast<double*>(cd.ops[0].ptr1);
+        q.n_gain = cd.n_ops - 1;
+        for (int k = 1; k < cd.n_ops; k++) q.gain[k - 1] = cd.ops[k].p0;
+        q.nch = cd.in_nch;
+        q.out = cd.out;
+        q.n_inst = b->n_inst;
+        q.n_tiles = b->n_tiles;
+        q.n_quanta = b->n_quanta;
+        st.profile_slot = slot_for(b, "biquad_stream_kernel");
+      }
+    }
     // source inputs
     if (cd.in[0].kind == IN_SOURCE || cd.in[0].kind == IN_CONSTANT) {
       int e = prepare_source_input(b, head, &cd.in[0]);
       if (e) return e;
     }
+    if (st.kind == 1) st.bq.in = cd.in[0];
     b->steps.push_back(st);
   }
   b->planned = true;
@@ -1504,7 +1529,10 @@ waa_status waa_render(waa_batch* b) {
       HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, b->stream));
     }
-    launch_chain(st.chain, st.cmax, b->stream);
+    if (st.kind == 1)
+      launch_biquad_stream(st.bq, b->stream);
+    else
+      launch_chain(st.chain, st.cmax, b->stream);
     HIP_TRY(hipGetLastError());
     if (b->profiling) {
       HIP_TRY(hipEventRecord(e1, b->stream));

@@ -111,6 +111,24 @@ struct ChainDesc {
   uint32_t pad;
 };
 
+// ---- streaming biquad kernel (the C2 / T1 hot shape) --------------------------------------
+// input (source or signal, no input mixing) -> Biquad(per-instance constant coefficients)
+// -> up to 2 k-rate-constant gains -> output; one wavefront per (instance, channel).
+struct BiquadStreamDesc {
+  InputRef in;
+  const double* coefs;   // [n_inst][5]
+  double* state;         // [n_inst][STATE_STRIDE]
+  ParamRef gain[2];      // mode 0 only
+  int32_t n_gain;
+  int32_t nch;
+  SignalRef out;
+  uint32_t n_inst;
+  uint32_t n_tiles;
+  uint32_t n_quanta;
+  uint32_t pad;
+};
+void launch_biquad_stream(const BiquadStreamDesc& d, void* stream);
+
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);
 
