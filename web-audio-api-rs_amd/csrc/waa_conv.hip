@@ -1,0 +1,335 @@
+// waa_conv.hip — ConvolverNode on gfx950: node-major partitioned overlap-save convolution.
+//
+// The reference (convolver.rs:343-490 -> crate fft-convolver) runs, per 128-frame quantum and per
+// convolver, a 2048-point real FFT, a complex MAC against P = ceil(len/1024) IR partitions held in
+// a frequency-domain delay line, and an inverse FFT (overlap-add).  That arithmetic is the linear
+// convolution of the input with the (normalised, scaled) impulse response.  Because a whole offline
+// render is available node-major, the same linear convolution is evaluated here time-tiled:
+//
+//   conv_fft_kernel<FWD>  one workgroup per (block k, input channel, instance pair): the two
+//                         instances' real streams are packed as z = a + i b (the IR spectra are shared
+//                         by every instance, so (a + i b) * h = a*h + i b*h), window [(k-1)B, (k+1)B),
+//                         in-place radix-4 DIF FFT in LDS, spectrum stored in bit-reversed order.
+//   conv_mac_kernel       Y_k[pos] = sum_p H_p[pos] * X_{k-p}[pos], register-tiled over 16 output
+//                         blocks so every input spectrum is read ~2.4x instead of P times.
+//   conv_fft_kernel<INV>  radix-4 DIT inverse straight from the bit-reversed spectrum, last B samples
+//                         (overlap-save), real part -> instance a, imaginary part -> instance b.
+//
+// f32 throughout (the reference convolver is f32).  No MFMA: the FFTs are LDS/HBM bound and the MAC is
+// a streaming f32 FMA kernel.
+#include <hip/hip_runtime.h>
+
+#include "waa_internal.hpp"
+
+namespace waa {
+
+namespace {
+
+__device__ __forceinline__ Cplx cmul(Cplx a, Cplx b) {
+  Cplx r;
+  r.re = __builtin_fmaf(a.re, b.re, -(a.im * b.im));
+  r.im = __builtin_fmaf(a.re, b.im, a.im * b.re);
+  return r;
+}
+__device__ __forceinline__ Cplx cadd(Cplx a, Cplx b) { return Cplx{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ Cplx csub(Cplx a, Cplx b) { return Cplx{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ Cplx mul_negi(Cplx a) { return Cplx{a.im, -a.re}; }  // a * (-i)
+__device__ __forceinline__ Cplx mul_posi(Cplx a) { return Cplx{-a.im, a.re}; }  // a * (+i)
+__device__ __forceinline__ Cplx conj(Cplx a) { return Cplx{a.re, -a.im}; }
+
+// in-place radix-4 decimation-in-frequency FFT: natural order in, bit-reversed order out. n = 4^m.
+// n = 4^m or 2 * 4^m (a trailing radix-2 stage on adjacent pairs)
+__device__ __forceinline__ void fft_dif(Cplx* a, const Cplx* tw, int n, int tid, int nthreads) {
+  int L = n;
+  for (; L >= 4; L >>= 2) {
+    const int q = L >> 2;
+    const int tstep = n / (4 * q);
+    for (int b = tid; b < (n >> 2); b += nthreads) {
+      const int j = b % q, base = (b / q) * 4 * q + j;
+      const Cplx x0 = a[base], x1 = a[base + q], x2 = a[base + 2 * q], x3 = a[base + 3 * q];
+      const Cplx s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = mul_negi(csub(x1, x3));
+      const Cplx w1 = tw[j * tstep];
+      const Cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+      a[base] = cadd(s02, s13);
+      a[base + q] = cmul(csub(s02, s13), w2);
+      a[base + 2 * q] = cmul(cadd(d02, d13), w1);
+      a[base + 3 * q] = cmul(csub(d02, d13), w3);
+    }
+    __syncthreads();
+  }
+  if (L == 2) {
+    for (int b = tid; b < (n >> 1); b += nthreads) {
+      const Cplx u = a[2 * b], v = a[2 * b + 1];
+      a[2 * b] = cadd(u, v);
+      a[2 * b + 1] = csub(u, v);
+    }
+    __syncthreads();
+  }
+}
+// in-place radix-4 decimation-in-time inverse FFT: bit-reversed order in, natural order out (unscaled).
+__device__ __forceinline__ void fft_dit_inv(Cplx* a, const Cplx* tw, int n, int tid, int nthreads) {
+  int q0 = 1;
+  if (__builtin_ctz(n) & 1) {  // n = 2 * 4^m: leading radix-2 stage on adjacent pairs
+    for (int b = tid; b < (n >> 1); b += nthreads) {
+      const Cplx u = a[2 * b], v = a[2 * b + 1];
+      a[2 * b] = cadd(u, v);
+      a[2 * b + 1] = csub(u, v);
+    }
+    __syncthreads();
+    q0 = 2;
+  }
+  for (int q = q0; q <= (n >> 2); q <<= 2) {
+    const int tstep = n / (4 * q);
+    for (int b = tid; b < (n >> 2); b += nthreads) {
+      const int j = b % q, base = (b / q) * 4 * q + j;
+      const Cplx w1 = conj(tw[j * tstep]);
+      const Cplx w2 = cmul(w1, w1);
+      const Cplx x0 = a[base], x1 = cmul(a[base + q], w2), x2 = a[base + 2 * q], x3 = cmul(a[base + 3 * q], w2);
+      const Cplx a0 = cadd(x0, x1), a1 = csub(x0, x1);
+      const Cplx a2 = cmul(cadd(x2, x3), w1), a3 = mul_posi(cmul(csub(x2, x3), w1));
+      a[base] = cadd(a0, a2);
+      a[base + 2 * q] = csub(a0, a2);
+      a[base + q] = cadd(a1, a3);
+      a[base + 3 * q] = csub(a1, a3);
+    }
+    __syncthreads();
+  }
+}
+
+enum { MODE_FWD = 0, MODE_INV = 1, MODE_IR = 2 };
+
+template <int MODE>
+__global__ void conv_fft_kernel(const ConvDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  Cplx* a = reinterpret_cast<Cplx*>(lds_raw);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int n = d.n, B = d.block;
+  const int k = blockIdx.x;  // output block (FWD/INV) or partition (IR)
+  const int c = blockIdx.y;  // channel
+  const uint32_t pair = blockIdx.z;
+  if (MODE == MODE_IR) {
+    // spectrum of IR partition k of IR channel c: h[kB .. (k+1)B) zero-padded to 2B
+    const float* h = d.ir + (uint64_t)c * d.ir_len;
+    for (int i = tid; i < n; i += nt) {
+      const uint64_t idx = (uint64_t)k * B + i;
+      a[i] = Cplx{(i < B && idx < d.ir_len) ? h[idx] : 0.f, 0.f};
+    }
+    __syncthreads();
+    fft_dif(a, d.tw, n, tid, nt);
+    Cplx* dst = const_cast<Cplx*>(d.H) + ((uint64_t)c * d.parts + k) * n;
+    for (int i = tid; i < n; i += nt) dst[i] = a[i];
+    return;
+  }
+  const uint32_t ia = pair * 2, ib = pair * 2 + 1;
+  const bool has_b = ib < d.n_inst;
+  if (MODE == MODE_FWD) {
+    const float* pa = d.in.base + (uint64_t)ia * d.in.inst_stride + (uint64_t)c * d.in.ch_stride;
+    const float* pb = d.in.base + (uint64_t)(has_b ? ib : ia) * d.in.inst_stride + (uint64_t)c * d.in.ch_stride;
+    const int64_t f0 = ((int64_t)k - 1) * B;
+    for (int i = tid; i < n; i += nt) {
+      const int64_t f = f0 + i;
+      const bool ok = f >= 0 && (uint64_t)f < d.frames;
+      a[i] = Cplx{ok ? pa[f] : 0.f, (ok && has_b) ? pb[f] : 0.f};
+    }
+    __syncthreads();
+    fft_dif(a, d.tw, n, tid, nt);
+    Cplx* dst = d.X + (((uint64_t)pair * d.cin + c) * d.nb + k) * n;
+    for (int i = tid; i < n; i += nt) dst[i] = a[i];
+  } else {
+    const Cplx* src = d.Y + (((uint64_t)pair * d.cout + c) * d.nb + k) * n;
+    for (int i = tid; i < n; i += nt) a[i] = src[i];
+    __syncthreads();
+    fft_dit_inv(a, d.tw, n, tid, nt);
+    float* pa = d.out.base + (uint64_t)ia * d.out.inst_stride + (uint64_t)c * d.out.ch_stride;
+    float* pb = d.out.base + (uint64_t)(has_b ? ib : ia) * d.out.inst_stride + (uint64_t)c * d.out.ch_stride;
+    const float scale = 1.f / (float)n;
+    for (int i = tid; i < B; i += nt) {
+      const uint64_t f = (uint64_t)k * B + i;
+      if (f < d.frames) {
+        const Cplx v = a[B + i];  // overlap-save: the last B samples are the linear convolution
+        pa[f] = v.re * scale;
+        if (has_b) pb[f] = v.im * scale;
+      }
+    }
+  }
+}
+
+// Y_k = sum_terms sum_p H_p X_{k-p}, KT output blocks per thread, partitions in chunks of PC.
+template <int KT, int PC>
+__global__ __launch_bounds__(256) void conv_mac_kernel(const ConvDesc d) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  const int k0 = blockIdx.y * KT;
+  const uint32_t pair = blockIdx.z / (uint32_t)d.cout;
+  const int co = (int)(blockIdx.z % (uint32_t)d.cout);
+  const int n = d.n, nb = d.nb, P = d.parts;
+  Cplx acc[KT];
+#pragma unroll
+  for (int i = 0; i < KT; i++) acc[i] = Cplx{0.f, 0.f};
+  for (int t = 0; t < d.n_terms; t++) {
+    if (d.terms[t].out_ch != co) continue;
+    const Cplx* Hc = d.H + (uint64_t)d.terms[t].ir_ch * P * n + pos;
+    const Cplx* Xc = d.X + ((uint64_t)pair * d.cin + d.terms[t].in_ch) * nb * n + pos;
+    for (int pc0 = 0; pc0 < P; pc0 += PC) {
+      Cplx h[PC];
+#pragma unroll
+      for (int i = 0; i < PC; i++) h[i] = (pc0 + i < P) ? Hc[(uint64_t)(pc0 + i) * n] : Cplx{0.f, 0.f};
+#pragma unroll
+      for (int jj = 0; jj < KT + PC - 1; jj++) {
+        const int j = k0 - pc0 - (PC - 1) + jj;
+        Cplx x = Cplx{0.f, 0.f};
+        if (j >= 0 && j < nb) x = Xc[(uint64_t)j * n];
+#pragma unroll
+        for (int i = 0; i < KT; i++) {
+          const int pl = i + (PC - 1) - jj;  // local partition index, compile-time after unrolling
+          if (pl >= 0 && pl < PC) {
+            acc[i].re = __builtin_fmaf(h[pl].re, x.re, acc[i].re);
+            acc[i].re = __builtin_fmaf(-h[pl].im, x.im, acc[i].re);
+            acc[i].im = __builtin_fmaf(h[pl].re, x.im, acc[i].im);
+            acc[i].im = __builtin_fmaf(h[pl].im, x.re, acc[i].im);
+          }
+        }
+      }
+    }
+  }
+  Cplx* Yc = d.Y + ((uint64_t)pair * d.cout + co) * nb * n + pos;
+#pragma unroll
+  for (int i = 0; i < KT; i++)
+    if (k0 + i < nb) Yc[(uint64_t)(k0 + i) * n] = acc[i];
+}
+
+// Short impulse responses (<= DIRECT_MAX_TAPS after trimming): direct time-domain FIR with f64 accumulation.
+// This is the linear convolution itself, so it is at least as close to the exact result as the reference's
+// f32 FFT convolver (the reference's own delta-IR tests ask for 1e-7).  Per term the f64 sum is rounded to f32
+// and the terms are added in f32, like `o_left += o_2` in convolver.rs:430-441.
+constexpr int DIRECT_TILE = 1024;
+__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvDesc d) {
+  __shared__ float xs[2][DIRECT_TILE + DIRECT_MAX_TAPS];
+  __shared__ float hs[4][DIRECT_MAX_TAPS];
+  const int tid = threadIdx.x;
+  const uint64_t f0 = (uint64_t)blockIdx.x * DIRECT_TILE;
+  const int co = blockIdx.y;
+  const uint32_t inst = blockIdx.z;
+  const int taps = (int)d.ir_len;
+  for (int c = 0; c < d.cin; c++) {
+    const float* p = d.in.base + (uint64_t)inst * d.in.inst_stride + (uint64_t)c * d.in.ch_stride;
+    for (int i = tid; i < DIRECT_TILE + DIRECT_MAX_TAPS; i += 256) {
+      const int64_t f = (int64_t)f0 - DIRECT_MAX_TAPS + i;
+      xs[c][i] = (f >= 0 && (uint64_t)f < d.frames) ? p[f] : 0.f;
+    }
+  }
+  for (int t = 0; t < d.n_terms; t++)
+    for (int i = tid; i < DIRECT_MAX_TAPS; i += 256) hs[t][i] = i < taps ? d.ir[(uint64_t)d.terms[t].ir_ch * d.ir_len + i] : 0.f;
+  __syncthreads();
+  float* o = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)co * d.out.ch_stride;
+  for (int i = tid; i < DIRECT_TILE; i += 256) {
+    float sum = 0.f;
+    bool first = true;
+    for (int t = 0; t < d.n_terms; t++) {
+      if (d.terms[t].out_ch != co) continue;
+      const float* x = xs[d.terms[t].in_ch] + DIRECT_MAX_TAPS + i;
+      double acc = 0.;
+      for (int k = 0; k < taps; k++) acc = __builtin_fma((double)hs[t][k], (double)x[-k], acc);
+      sum = first ? (float)acc : sum + (float)acc;
+      first = false;
+    }
+    const uint64_t f = f0 + i;
+    if (f < d.frames) o[f] = sum;
+  }
+}
+
+// AnalyserNode control side (analysis.rs:261-345): most recent fft_size frames of the mono down-mix,
+// Blackman window, real FFT via a packed complex FFT of half the size, |X[k]| / N, smoothing against the
+// previous (zero) spectrum.  One workgroup per pull.
+__global__ void analyser_kernel(const AnalyserDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  Cplx* a = reinterpret_cast<Cplx*>(lds_raw);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int N = d.fft_size, M = N >> 1;
+  const float* p0 = d.sig.base + (uint64_t)d.inst * d.sig.inst_stride;
+  const int64_t first = (int64_t)d.frames_written - N;  // ring_buffer.read: the last N frames written
+  for (int i = tid; i < N; i += nt) {
+    const int64_t f = first + i;
+    float v = 0.f;
+    if (f >= 0) {
+      // mono down-mix of the analyser input (analyser.rs:277-280, quantum.rs:387-397)
+      v = d.sig.nch == 1 ? p0[f] : 0.5f * (p0[f] + p0[d.sig.ch_stride + f]);
+    }
+    d.time_out[i] = v;
+    const float wv = v * d.window[i];
+    reinterpret_cast<float*>(a)[i] = wv;  // z[n] = x[2n] + i x[2n+1]
+  }
+  __syncthreads();
+  fft_dif(a, d.tw, M, tid, nt);
+  const int lg = 31 - __builtin_clz(M);
+  const float nf = 1.f / (float)N;
+  const float tau = d.smoothing;
+  for (int k = tid; k < M; k += nt) {
+    const int k2 = (M - k) & (M - 1);
+    const Cplx z = a[__brev((unsigned)k) >> (32 - lg)];
+    const Cplx zc = conj(a[__brev((unsigned)k2) >> (32 - lg)]);
+    const Cplx e = Cplx{0.5f * (z.re + zc.re), 0.5f * (z.im + zc.im)};
+    const Cplx o = mul_negi(Cplx{0.5f * (z.re - zc.re), 0.5f * (z.im - zc.im)});
+    const Cplx w = d.tw_full[k];  // exp(-2 pi i k / N)
+    const Cplx x = cadd(e, cmul(o, w));
+    const float norm = hypotf(x.re, x.im) * nf;
+    const float value = tau * d.prev[k] + (1.f - tau) * norm;
+    d.spec_out[k] = isfinite(value) ? value : 0.f;
+  }
+}
+
+int fft_threads(int n) {
+  int t = n / 16;
+  if (t < 64) t = 64;
+  if (t > 1024) t = 1024;
+  return t;
+}
+
+}  // namespace
+
+static void allow_big_lds(size_t bytes) {
+  static bool done = false;
+  if (done || bytes <= 64 * 1024) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_IR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done = true;
+}
+
+void launch_conv_ir_spectra(const ConvDesc& d, void* stream) {
+  allow_big_lds((size_t)d.n * sizeof(Cplx));
+  hipLaunchKernelGGL(conv_fft_kernel<MODE_IR>, dim3(d.parts, d.ir_nch, 1), dim3(fft_threads(d.n)), (size_t)d.n * sizeof(Cplx),
+                     (hipStream_t)stream, d);
+}
+void launch_conv_forward(const ConvDesc& d, void* stream) {
+  allow_big_lds((size_t)d.n * sizeof(Cplx));
+  hipLaunchKernelGGL(conv_fft_kernel<MODE_FWD>, dim3(d.nb, d.cin, d.n_pairs), dim3(fft_threads(d.n)), (size_t)d.n * sizeof(Cplx),
+                     (hipStream_t)stream, d);
+}
+void launch_conv_inverse(const ConvDesc& d, void* stream) {
+  allow_big_lds((size_t)d.n * sizeof(Cplx));
+  hipLaunchKernelGGL(conv_fft_kernel<MODE_INV>, dim3(d.nb, d.cout, d.n_pairs), dim3(fft_threads(d.n)), (size_t)d.n * sizeof(Cplx),
+                     (hipStream_t)stream, d);
+}
+void launch_conv_direct(const ConvDesc& d, void* stream) {
+  dim3 grid((unsigned)((d.frames + DIRECT_TILE - 1) / DIRECT_TILE), d.cout, d.n_inst);
+  hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
+}
+void launch_analyser(const AnalyserDesc& d, void* stream) {
+  const int M = d.fft_size / 2;
+  static bool big = false;
+  if (!big) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(analyser_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    big = true;
+  }
+  hipLaunchKernelGGL(analyser_kernel, dim3(1), dim3(fft_threads(M)), (size_t)M * sizeof(Cplx), (hipStream_t)stream, d);
+}
+void launch_conv_mac(const ConvDesc& d, void* stream) {
+  constexpr int KT = 16;
+  dim3 grid(d.n / 256, (d.nb + KT - 1) / KT, d.n_pairs * (uint32_t)d.cout);
+  if (d.parts <= 8)
+    hipLaunchKernelGGL((conv_mac_kernel<KT, 8>), grid, dim3(256), 0, (hipStream_t)stream, d);
+  else
+    hipLaunchKernelGGL((conv_mac_kernel<KT, 24>), grid, dim3(256), 0, (hipStream_t)stream, d);
+}
+
+}  // namespace waa

@@ -100,6 +100,14 @@ struct Node {
   std::vector<float> curve;
   bool has_curve = false;
   float* d_curve = nullptr;
+  // analyser (control side state)
+  struct AnCache {
+    std::vector<float> spec, time;
+  };
+  std::map<uint32_t, AnCache> an_cache;
+  float* d_window = nullptr;
+  Cplx *d_an_tw = nullptr, *d_an_twfull = nullptr;
+  float *d_an_prev = nullptr, *d_an_spec = nullptr, *d_an_time = nullptr;
   // planning
   int in_nch = 1;      // computed input channel count
   int out_nch = 1;     // static output channel count
@@ -118,9 +126,13 @@ struct ProfileEntry {
 };
 
 struct Step {
-  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel
+  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR
   ChainDesc chain{};
   BiquadStreamDesc bq{};
+  ConvDesc conv{};
+  int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
+  void* zero_ptr = nullptr;
+  size_t zero_bytes = 0;
   int cmax = 1;
   int profile_slot = -1;
 };
@@ -143,6 +155,7 @@ struct waa_batch {
   std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render
   std::vector<Step> steps;
   bool planned = false;
+  bool rendered = false;
   bool profiling = false;
   std::vector<ProfileEntry> prof;
 };
@@ -623,6 +636,9 @@ void topo_visit(const waa_batch* b, uint32_t id, std::vector<uint8_t>& marked, s
   temp[id] = 0;
 }
 
+int plan_convolver(waa_batch* b, uint32_t id);
+int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int interp);
+
 int slot_for(waa_batch* b, const char* name) {
   for (size_t i = 0; i < b->prof.size(); i++)
     if (b->prof[i].name == name) return (int)i;
@@ -730,22 +746,40 @@ int build_plan(waa_batch* b) {
     if (live_consumers != 1) mat = true;
     n.materialized = mat;
   }
-  // allocate materialised signals
-  for (uint32_t id = 0; id < N; id++) {
-    Node& n = b->nodes[id];
-    if (!n.live || !n.materialized) continue;
+  auto alloc_signal = [&](Node& n) -> int {
     float* p = nullptr;
     int e = dev_alloc(b, &p, (size_t)b->n_inst * n.out_nch * b->lp);
     if (e) return e;
     n.sig = SignalRef{p, (uint64_t)n.out_nch * b->lp, b->lp, n.out_nch, 0};
-  }
+    return 0;
+  };
   // chains, in processing order of their terminal node
   b->steps.clear();
   for (uint32_t id : b->order) {
     Node& term = b->nodes[id];
     if (!term.live || !term.materialized) continue;
-    if (term.desc.kind == WAA_NODE_CONVOLVER && term.has_ir)
-      return fail(WAA_ERR_OUT_OF_SCOPE, "ConvolverNode kernels are not part of this build yet");
+    if (term.desc.kind == WAA_NODE_CONVOLVER && term.has_ir) {
+      int e = alloc_signal(term);
+      if (e) return e;
+      if ((e = plan_convolver(b, id))) return e;
+      continue;
+    }
+    // identity node on a materialised signal of the same layout (destination / analyser / passthrough right
+    // behind a materialised producer): alias instead of copying 8 B per frame-channel through HBM
+    if (term.in_edges.size() == 1) {
+      Node& p = b->nodes[b->edges[term.in_edges[0]].from];
+      const uint32_t k = term.desc.kind;
+      const bool identity = k == WAA_NODE_DESTINATION || k == WAA_NODE_ANALYSER ||
+                            (k == WAA_NODE_CONVOLVER && !term.has_ir) || (k == WAA_NODE_WAVESHAPER && !term.has_curve);
+      if (identity && p.materialized && p.out_nch == term.in_nch && term.in_nch == term.out_nch) {
+        term.sig = p.sig;
+        continue;
+      }
+    }
+    {
+      int e = alloc_signal(term);
+      if (e) return e;
+    }
     // walk back through fused single-input predecessors
     std::vector<uint32_t> path;  // terminal first
     uint32_t cur = id;
@@ -785,22 +819,24 @@ int build_plan(waa_batch* b) {
       cd.in_nch = hn.in_nch;
       cd.in_interp = hn.interp;
     } else {
-      if (hn.in_edges.size() > MAX_INPUTS) return fail(WAA_ERR_OUT_OF_SCOPE, "fan-in above %d is out of scope", MAX_INPUTS);
-      cd.n_inputs = (int)hn.in_edges.size();
       cd.in_nch = hn.in_nch;
       cd.in_interp = hn.interp;
+      std::vector<InputRef> ins;
+      for (int ie : hn.in_edges) {
+        Node& pn = b->nodes[b->edges[ie].from];
+        if (!pn.materialized) return fail(WAA_ERR_INVALID_STATE, "internal: unmaterialised fan-in input");
+        InputRef in{};
+        in.kind = IN_SIGNAL;
+        in.nch = pn.out_nch;
+        in.sig = pn.sig;
+        ins.push_back(in);
+      }
+      int e = reduce_fan_in(b, ins, hn.in_nch, hn.interp);
+      if (e) return e;
+      cd.n_inputs = (int)ins.size();
       for (int k = 0; k < cd.n_inputs; k++) {
-        Node& pn = b->nodes[b->edges[hn.in_edges[k]].from];
-        InputRef& in = cd.in[k];
-        if (pn.materialized) {
-          in.kind = IN_SIGNAL;
-          in.nch = pn.out_nch;
-          in.sig = pn.sig;
-        } else {
-          // only reachable for a single unfused source predecessor
-          return fail(WAA_ERR_INVALID_STATE, "internal: unmaterialised fan-in input");
-        }
-        cmax = std::max(cmax, in.nch);
+        cd.in[k] = ins[k];
+        cmax = std::max(cmax, ins[k].nch);
       }
     }
     cmax = std::max(cmax, cd.in_nch);
@@ -961,6 +997,199 @@ static int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
 }
 
 namespace {
+
+// Fan-in above MAX_INPUTS: sum the first MAX_INPUTS inputs (mixed to the receiver's channel count) into a
+// temporary signal and continue; the left-to-right order of the f32 additions (graph.rs:524-535) is kept.
+int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int interp) {
+  while (ins.size() > (size_t)MAX_INPUTS) {
+    float* ptr = nullptr;
+    int e = dev_alloc(b, &ptr, (size_t)b->n_inst * in_nch * b->lp);
+    if (e) return e;
+    Step st;
+    ChainDesc& cd = st.chain;
+    std::memset(&cd, 0, sizeof cd);
+    cd.n_inputs = MAX_INPUTS;
+    for (int k = 0; k < MAX_INPUTS; k++) cd.in[k] = ins[k];
+    cd.in_nch = in_nch;
+    cd.in_interp = interp;
+    cd.out = SignalRef{ptr, (uint64_t)in_nch * b->lp, b->lp, in_nch, 0};
+    cd.n_inst = b->n_inst;
+    cd.n_tiles = b->n_tiles;
+    cd.n_quanta = b->n_quanta;
+    int cmax = in_nch;
+    for (int k = 0; k < MAX_INPUTS; k++) cmax = std::max(cmax, ins[k].nch);
+    st.cmax = cmax;
+    st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : "chain_kernel<2>");
+    b->steps.push_back(st);
+    InputRef partial{};
+    partial.kind = IN_SIGNAL;
+    partial.nch = in_nch;
+    partial.sig = cd.out;
+    ins.erase(ins.begin(), ins.begin() + MAX_INPUTS);
+    ins.insert(ins.begin(), partial);
+  }
+  return 0;
+}
+
+// ConvolverNode with an impulse response (convolver.rs:259-317, 343-490): input mix chain (if needed)
+// + forward FFT / spectral MAC / inverse FFT steps.
+int plan_convolver(waa_batch* b, uint32_t id) {
+  Node& n = b->nodes[id];
+  // input signal: the single producer if its channel count already matches, else a mixing chain
+  SignalRef in_sig{};
+  bool direct = false;
+  if (n.in_edges.size() == 1) {
+    Node& p = b->nodes[b->edges[n.in_edges[0]].from];
+    if (p.materialized && p.out_nch == n.in_nch) {
+      in_sig = p.sig;
+      direct = true;
+    }
+  }
+  if (!direct) {
+    float* ptr = nullptr;
+    int e = dev_alloc(b, &ptr, (size_t)b->n_inst * n.in_nch * b->lp);
+    if (e) return e;
+    in_sig = SignalRef{ptr, (uint64_t)n.in_nch * b->lp, b->lp, n.in_nch, 0};
+    Step st;
+    ChainDesc& cd = st.chain;
+    std::memset(&cd, 0, sizeof cd);
+    if (n.in_edges.empty()) {
+      cd.n_inputs = 1;
+      cd.in[0].kind = IN_SILENT;
+      cd.in[0].nch = 1;
+    } else {
+      std::vector<InputRef> ins;
+      for (int ie : n.in_edges) {
+        Node& pn = b->nodes[b->edges[ie].from];
+        if (!pn.materialized) return fail(WAA_ERR_INVALID_STATE, "internal: unmaterialised convolver input");
+        InputRef in{};
+        in.kind = IN_SIGNAL;
+        in.nch = pn.out_nch;
+        in.sig = pn.sig;
+        ins.push_back(in);
+      }
+      int e2 = reduce_fan_in(b, ins, n.in_nch, n.interp);
+      if (e2) return e2;
+      cd.n_inputs = (int)ins.size();
+      for (int k = 0; k < cd.n_inputs; k++) cd.in[k] = ins[k];
+    }
+    cd.in_nch = n.in_nch;
+    cd.in_interp = n.interp;
+    cd.n_ops = 0;
+    cd.out = in_sig;
+    cd.n_inst = b->n_inst;
+    cd.n_tiles = b->n_tiles;
+    cd.n_quanta = b->n_quanta;
+    st.cmax = 2;
+    st.profile_slot = slot_for(b, "chain_kernel<2>");
+    b->steps.push_back(st);
+  }
+  // one FFTConvolver per IR channel, at least two (convolver.rs:291-306); each trims its own trailing
+  // |h| < 1e-6 samples (fft-convolver init) — only the longest trimmed length matters here
+  const int ir_nch = n.ir_nch;
+  uint64_t len = 0;
+  for (int c = 0; c < ir_nch; c++) {
+    uint64_t l = n.ir_len;
+    while (l > 0 && std::fabs(n.ir[c][l - 1]) < 0.000001f) l--;
+    len = std::max(len, l);
+  }
+  Step st;
+  st.kind = 2;
+  ConvDesc& cv = st.conv;
+  std::memset(&cv, 0, sizeof cv);
+  if (len == 0) {
+    // all-zero impulse response: FFTConvolver::process outputs zeros
+    Step z;
+    z.kind = 3;
+    z.zero_ptr = n.sig.base;
+    z.zero_bytes = (size_t)b->n_inst * n.out_nch * b->lp * sizeof(float);
+    b->steps.push_back(z);
+    return 0;
+  }
+  const bool direct_fir = len <= (uint64_t)DIRECT_MAX_TAPS;
+  int B = 8192;
+  for (int cand : {128, 512, 2048, 8192})
+    if ((len + cand - 1) / cand <= 24) {
+      B = cand;
+      break;
+    }
+  cv.block = B;
+  cv.n = 2 * B;
+  cv.parts = (int)((len + B - 1) / B);
+  cv.nb = (int)((b->lp + B - 1) / B);
+  cv.cin = n.in_nch;
+  cv.cout = n.out_nch;
+  cv.in = in_sig;
+  cv.out = n.sig;
+  cv.frames = b->lp;
+  cv.n_inst = b->n_inst;
+  cv.n_pairs = (b->n_inst + 1) / 2;
+  cv.ir_nch = ir_nch;
+  cv.ir_len = len;
+  // routing (convolver.rs:384-466)
+  auto term = [&](int in_ch, int ir_ch, int out_ch) { cv.terms[cv.n_terms++] = ConvTerm{in_ch, ir_ch, out_ch, 0}; };
+  if (n.in_nch == 1 && ir_nch == 1) {
+    term(0, 0, 0);
+  } else if (n.in_nch == 1 && ir_nch == 2) {
+    term(0, 0, 0);
+    term(0, 1, 1);
+  } else if (n.in_nch == 2 && ir_nch == 1) {
+    term(0, 0, 0);
+    term(1, 0, 1);
+  } else if (n.in_nch == 2 && ir_nch == 2) {
+    term(0, 0, 0);
+    term(1, 1, 1);
+  } else if (n.in_nch == 2 && ir_nch == 4) {
+    term(0, 0, 0);
+    term(0, 1, 1);
+    term(1, 2, 0);
+    term(1, 3, 1);
+  } else {
+    term(0, 0, 0);
+    term(0, 1, 1);
+    term(0, 2, 0);
+    term(0, 3, 1);
+  }
+  // device resources
+  std::vector<float> irflat((size_t)ir_nch * len);
+  for (int c = 0; c < ir_nch; c++) {
+    uint64_t l = n.ir_len;
+    while (l > 0 && std::fabs(n.ir[c][l - 1]) < 0.000001f) l--;  // samples past a channel's own trim are dropped
+    for (uint64_t i = 0; i < len; i++) irflat[(size_t)c * len + i] = i < l ? n.ir[c][i] : 0.f;
+  }
+  float* d_ir = nullptr;
+  int e = dev_upload(b, &d_ir, irflat);
+  if (e) return e;
+  cv.ir = d_ir;
+  if (direct_fir) {
+    st.kind = 4;
+    st.slot_mac = slot_for(b, "conv_direct_kernel");
+    b->steps.push_back(st);
+    return 0;
+  }
+  std::vector<Cplx> tw(cv.n);
+  for (int t = 0; t < cv.n; t++) {
+    const double a = -2.0 * 3.14159265358979323846 * (double)t / (double)cv.n;
+    tw[t] = Cplx{(float)std::cos(a), (float)std::sin(a)};
+  }
+  Cplx* d_tw = nullptr;
+  if ((e = dev_upload(b, &d_tw, tw))) return e;
+  cv.tw = d_tw;
+  Cplx *dH = nullptr, *dX = nullptr, *dY = nullptr;
+  if ((e = dev_alloc(b, &dH, (size_t)ir_nch * cv.parts * cv.n))) return e;
+  if ((e = dev_alloc(b, &dX, (size_t)cv.n_pairs * cv.cin * cv.nb * cv.n))) return e;
+  if ((e = dev_alloc(b, &dY, (size_t)cv.n_pairs * cv.cout * cv.nb * cv.n))) return e;
+  cv.H = dH;
+  cv.X = dX;
+  cv.Y = dY;
+  launch_conv_ir_spectra(cv, b->stream);  // control-side work of ConvolverNode::set_buffer, once
+  HIP_TRY(hipGetLastError());
+  st.slot_fwd = slot_for(b, "conv_fft_kernel<fwd>");
+  st.slot_mac = slot_for(b, "conv_mac_kernel");
+  st.slot_inv = slot_for(b, "conv_fft_kernel<inv>");
+  b->steps.push_back(st);
+  return 0;
+}
 
 // Emit the fused ops of node `id` given the running channel count.
 int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector<OpDesc>& ops, int* out_nch) {
@@ -1522,22 +1751,37 @@ waa_status waa_render(waa_batch* b) {
   // every render starts from the initial state (offline contexts render exactly once; re-rendering the
   // same batch is what the benchmark loop does)
   for (auto& sb : b->state_bufs) HIP_TRY(hipMemsetAsync(sb.first, 0, sb.second, b->stream));
-  for (auto& st : b->steps) {
+  for (auto& n : b->nodes) n.an_cache.clear();
+  b->rendered = true;
+  auto timed = [&](int slot, auto&& launch) -> int {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (b->profiling) {
+    if (b->profiling && slot >= 0) {
       HIP_TRY(hipEventCreate(&e0));
       HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, b->stream));
     }
-    if (st.kind == 1)
-      launch_biquad_stream(st.bq, b->stream);
-    else
-      launch_chain(st.chain, st.cmax, b->stream);
+    launch();
     HIP_TRY(hipGetLastError());
-    if (b->profiling) {
+    if (b->profiling && slot >= 0) {
       HIP_TRY(hipEventRecord(e1, b->stream));
-      b->prof[st.profile_slot].pending.push_back({e0, e1});
+      b->prof[slot].pending.push_back({e0, e1});
     }
+    return 0;
+  };
+  for (auto& st : b->steps) {
+    int e = 0;
+    switch (st.kind) {
+      case 1: e = timed(st.profile_slot, [&] { launch_biquad_stream(st.bq, b->stream); }); break;
+      case 2:
+        if ((e = timed(st.slot_fwd, [&] { launch_conv_forward(st.conv, b->stream); }))) break;
+        if ((e = timed(st.slot_mac, [&] { launch_conv_mac(st.conv, b->stream); }))) break;
+        e = timed(st.slot_inv, [&] { launch_conv_inverse(st.conv, b->stream); });
+        break;
+      case 3: HIP_TRY(hipMemsetAsync(st.zero_ptr, 0, st.zero_bytes, b->stream)); break;
+      case 4: e = timed(st.slot_mac, [&] { launch_conv_direct(st.conv, b->stream); }); break;
+      default: e = timed(st.profile_slot, [&] { launch_chain(st.chain, st.cmax, b->stream); }); break;
+    }
+    if (e) return e;
   }
   return WAA_OK;
 }
@@ -1609,37 +1853,111 @@ waa_status waa_output_device(waa_batch* b, const float** p, uint64_t* is, uint64
   return WAA_OK;
 }
 
-waa_status waa_analyser_get_float_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t n) {
-  (void)inst;
-  (void)dst;
-  (void)n;
+// AnalyserNode pulls (analysis.rs:261-401).  current_time after an offline render never changes, so the
+// spectrum is computed once per (node, instance) and repeated pulls return the same data (analysis.rs:354-357).
+static int analyser_compute(waa_batch* b, uint32_t node, uint32_t inst, Node::AnCache** out) {
   int e;
   if ((e = check_node(b, node, WAA_NODE_ANALYSER))) return e;
-  return fail(WAA_ERR_OUT_OF_SCOPE, "analyser pulls are not part of this build yet");
+  if (inst >= b->n_inst) return fail(WAA_ERR_INVALID_ARGUMENT, "instance out of range");
+  Node& n = b->nodes[node];
+  const int N = n.desc.i[0], M = N / 2;
+  auto it = n.an_cache.find(inst);
+  if (it != n.an_cache.end()) {
+    *out = &it->second;
+    return 0;
+  }
+  Node::AnCache cache;
+  cache.spec.assign(M, 0.f);
+  cache.time.assign(N, 0.f);
+  if (b->planned && b->rendered && n.live) {
+    HIP_TRY(hipSetDevice(b->device));
+    if (!n.d_window) {
+      // generate_blackman (analysis.rs:14-24), f32 with the host libm the reference's f32::cos resolves to
+      std::vector<float> win(N);
+      const float alpha = 0.16f, a0 = (1.f - alpha) / 2.f, a1 = 1.f / 2.f, a2 = alpha / 2.f;
+      for (int i = 0; i < N; i++)
+        win[i] = a0 - a1 * cosf(2.f * PI_F * (float)i / (float)N) + a2 * cosf(4.f * PI_F * (float)i / (float)N);
+      std::vector<Cplx> tw(M), twf(M);
+      for (int t = 0; t < M; t++) {
+        const double x = -2.0 * 3.14159265358979323846 * (double)t / (double)M;
+        const double y = -2.0 * 3.14159265358979323846 * (double)t / (double)N;
+        tw[t] = Cplx{(float)std::cos(x), (float)std::sin(x)};
+        twf[t] = Cplx{(float)std::cos(y), (float)std::sin(y)};
+      }
+      std::vector<float> zeros(M, 0.f);
+      if ((e = dev_upload(b, &n.d_window, win)) || (e = dev_upload(b, &n.d_an_tw, tw)) ||
+          (e = dev_upload(b, &n.d_an_twfull, twf)) || (e = dev_upload(b, &n.d_an_prev, zeros)) ||
+          (e = dev_alloc(b, &n.d_an_spec, (size_t)M)) || (e = dev_alloc(b, &n.d_an_time, (size_t)N)))
+        return e;
+    }
+    AnalyserDesc ad{};
+    ad.sig = n.sig;
+    ad.inst = inst;
+    ad.fft_size = N;
+    ad.frames_written = (uint64_t)b->n_quanta * RQ;
+    ad.smoothing = (float)n.desc.d[0];
+    ad.window = n.d_window;
+    ad.tw = n.d_an_tw;
+    ad.tw_full = n.d_an_twfull;
+    ad.prev = n.d_an_prev;
+    ad.spec_out = n.d_an_spec;
+    ad.time_out = n.d_an_time;
+    launch_analyser(ad, b->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(cache.spec.data(), n.d_an_spec, (size_t)M * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cache.time.data(), n.d_an_time, (size_t)N * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  auto ins = n.an_cache.emplace(inst, std::move(cache));
+  *out = &ins.first->second;
+  return 0;
 }
-waa_status waa_analyser_get_byte_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t n) {
-  (void)inst;
-  (void)dst;
-  (void)n;
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_ANALYSER))) return e;
-  return fail(WAA_ERR_OUT_OF_SCOPE, "analyser pulls are not part of this build yet");
+
+waa_status waa_analyser_get_float_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t nn) {
+  Node::AnCache* c;
+  int e = analyser_compute(b, node, inst, &c);
+  if (e) return e;
+  const uint32_t len = std::min<uint32_t>(nn, (uint32_t)c->spec.size());
+  for (uint32_t k = 0; k < len; k++) dst[k] = 20.f * log10f(c->spec[k]);  // analysis.rs:365-368
+  return WAA_OK;
 }
-waa_status waa_analyser_get_float_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t n) {
-  (void)inst;
-  (void)dst;
-  (void)n;
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_ANALYSER))) return e;
-  return fail(WAA_ERR_OUT_OF_SCOPE, "analyser pulls are not part of this build yet");
+waa_status waa_analyser_get_byte_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t nn) {
+  Node::AnCache* c;
+  int e = analyser_compute(b, node, inst, &c);
+  if (e) return e;
+  const Node& n = b->nodes[node];
+  const float mind = (float)n.desc.d[1], maxd = (float)n.desc.d[2];
+  const uint32_t len = std::min<uint32_t>(nn, (uint32_t)c->spec.size());
+  for (uint32_t k = 0; k < len; k++) {  // analysis.rs:388-400
+    const float db = 20.f * log10f(c->spec[k]);
+    const float scaled = 255.f / (maxd - mind) * (db - mind);
+    const float clamped = scaled < 0.f ? 0.f : scaled > 255.f ? 255.f : scaled;
+    dst[k] = std::isnan(scaled) ? 0 : (uint8_t)clamped;
+  }
+  return WAA_OK;
 }
-waa_status waa_analyser_get_byte_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t n) {
-  (void)inst;
-  (void)dst;
-  (void)n;
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_ANALYSER))) return e;
-  return fail(WAA_ERR_OUT_OF_SCOPE, "analyser pulls are not part of this build yet");
+waa_status waa_analyser_get_float_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t nn) {
+  Node::AnCache* c;
+  int e = analyser_compute(b, node, inst, &c);
+  if (e) return e;
+  const uint32_t N = (uint32_t)c->time.size();
+  const uint32_t len = std::min(nn, N);  // ring_buffer.read: the most recent `len` frames (analysis.rs:114-127)
+  for (uint32_t i = 0; i < len; i++) dst[i] = c->time[N - len + i];
+  return WAA_OK;
+}
+waa_status waa_analyser_get_byte_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t nn) {
+  Node::AnCache* c;
+  int e = analyser_compute(b, node, inst, &c);
+  if (e) return e;
+  const uint32_t N = (uint32_t)c->time.size();
+  const uint32_t len = std::min(nn, N);
+  for (uint32_t i = 0; i < nn; i++) {  // analysis.rs:268-276 (elements past fft_size read a zeroed tmp)
+    const float v = i < len ? c->time[N - len + i] : 0.f;
+    const float scaled = 128.f * (1.f + v);
+    const float clamped = scaled < 0.f ? 0.f : scaled > 255.f ? 255.f : scaled;
+    dst[i] = (uint8_t)clamped;
+  }
+  return WAA_OK;
 }
 
 // buffer.rs:311-363 (input prep, host side)

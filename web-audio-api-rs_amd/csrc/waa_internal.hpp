@@ -129,6 +129,56 @@ struct BiquadStreamDesc {
 };
 void launch_biquad_stream(const BiquadStreamDesc& d, void* stream);
 
+// ---- ConvolverNode (convolver.rs:343-490 + fft-convolver), node-major overlap-save ------------
+// out[co] = sum over terms t with t.out_ch == co of  IR[t.ir_ch] * in[t.in_ch]   (linear convolution)
+struct ConvTerm {
+  int32_t in_ch, ir_ch, out_ch, pad;
+};
+struct Cplx {
+  float re, im;
+};
+struct ConvDesc {
+  SignalRef in, out;
+  int32_t n_terms;
+  int32_t cin, cout;
+  int32_t n;        // complex FFT size = 2 * block
+  int32_t block;    // partition size B
+  int32_t parts;    // P = ceil(trimmed IR length / B)
+  int32_t nb;       // number of output blocks = ceil(frames / B)
+  int32_t pad0;
+  ConvTerm terms[4];
+  const Cplx* H;    // [ir_nch][P][n] spectra of the IR partitions (bit-reversed order)
+  Cplx* X;          // [n_pairs][cin][nb][n] input spectra of instance pairs (a + i b)
+  Cplx* Y;          // [n_pairs][cout][nb][n]
+  const Cplx* tw;   // [n] exp(-2 pi i t / n)
+  const float* ir;  // [ir_nch][ir_len] scaled, trimmed IR (device) for the IR-spectrum pass
+  uint64_t ir_len;
+  uint64_t frames;  // valid frames per channel in `in` / `out` (padded length)
+  uint32_t n_inst, n_pairs;
+  int32_t ir_nch, pad1;
+};
+struct AnalyserDesc {
+  SignalRef sig;         // the analyser's (passthrough) signal
+  uint32_t inst;
+  int32_t fft_size;
+  uint64_t frames_written;  // n_quanta * 128
+  float smoothing;
+  int32_t pad;
+  const float* window;   // [fft_size] Blackman
+  const Cplx* tw;        // [fft_size/2] exp(-2 pi i t / (fft_size/2))
+  const Cplx* tw_full;   // [fft_size/2] exp(-2 pi i k / fft_size)
+  const float* prev;     // [fft_size/2] previous smoothed spectrum
+  float* spec_out;       // [fft_size/2]
+  float* time_out;       // [fft_size]
+};
+void launch_analyser(const AnalyserDesc& d, void* stream);
+constexpr int DIRECT_MAX_TAPS = 128;  // trimmed IRs up to this length use the direct FIR kernel
+void launch_conv_direct(const ConvDesc& d, void* stream);
+void launch_conv_ir_spectra(const ConvDesc& d, void* stream);
+void launch_conv_forward(const ConvDesc& d, void* stream);
+void launch_conv_mac(const ConvDesc& d, void* stream);
+void launch_conv_inverse(const ConvDesc& d, void* stream);
+
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);
 
