@@ -134,29 +134,16 @@ def main():
     ctx, _ = build_workload(waa, hip, name, n_inst, frames, local_rank, noise.data_ptr())
     ctx.prepare()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    from web_audio_api_rs_amd.sharding import timed_steps
 
-    for _ in range(args.warmup):
-        ctx.render_async()
+    ctx.render_async()  # first launch builds the plan (uploads schedules / coefficients) outside any timing
     ctx.sync()
     ctx.profile(True)
     ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.render_async()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_steps(ctx.render_async, torch.cuda.synchronize, args.steps, args.warmup, dist=dist,
+                          device_tensor=lambda v: torch.tensor([v], dtype=torch.float64, device="cuda"))
     ctx.sync()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # the warmup launches were also event-timed: normalise per launch below
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -164,14 +151,15 @@ def main():
         value = total_quanta * args.steps / elapsed
         prof = sorted(ctx.profile_entries(), key=lambda e: -e[2])
         dom = prof[0] if prof else ("none", 1, float("nan"))
+        total_launch_steps = args.steps + args.warmup
         kernel_ms = {n_: (ms / max(l, 1)) for n_, l, ms in prof}
-        launches_per_step = {n_: l / args.steps for n_, l, ms in prof}
+        launches_per_step = {n_: l / total_launch_steps for n_, l, ms in prof}
         # roofline of the dominant kernel: algorithmic bytes of one launch / its mean duration
         alg_bytes_step = ALG_BYTES[name] * n_inst * nq
         dom_share = 1.0
         if name in ("c3", "t1", "c4"):
             # several kernels share the algorithmic bytes of the FDL: attribute them to the whole render
-            achieved = alg_bytes_step / (sum(ms for _, _, ms in prof) / args.steps * 1e-3) / 1e9
+            achieved = alg_bytes_step / (sum(ms for _, _, ms in prof) / total_launch_steps * 1e-3) / 1e9
             dom_name = "render (all kernels)"
         else:
             achieved = alg_bytes_step * dom_share / (dom[2] / max(dom[1], 1) * 1e-3) / 1e9
