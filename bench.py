@@ -67,33 +67,45 @@ DESCR = {
 }
 
 
-def cpu_baseline(waa, name, frames):
+def cpu_baseline(waa, name, frames, target_wall=12.0):
     """The oracle ("port": a C restatement of the reference algorithm, NOT the Rust reference itself) timed
-    on this box's host cores, one context per thread, on a bounded sample of the same workload."""
+    on this box's host cores, one context per thread, on a BOUNDED sample of the same workload: a short
+    single-thread calibration render fixes the sample duration so the timed run takes ~target_wall seconds."""
     path = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(path):
         return None
     lib = ctypes.CDLL(path)
     orc = waa.bind(lib, "orc_")
-    cores = os.cpu_count() or 1
-    per_ctx_s = {"c2": 0.03, "c5": 0.05, "c3": 2.5, "t1": 2.5, "c4": 2.6}[name] * (frames / 480000.0)
-    n = int(max(cores, min(64 * cores, round(15.0 * cores / max(per_ctx_s, 1e-3)))))
-    n = (n + cores - 1) // cores * cores
-    from graphs import white_noise
-    noise = white_noise(n, 2, frames)
-    ctx, src = build_workload(waa, orc, name, n, frames, -1, None)
-    src.set_buffer_batch(noise, SR)
-    ctx.prepare()
     lib.orc_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int32]
-    lib.orc_set_threads(ctx._handle, cores)
-    t0 = time.perf_counter()
-    orc.check(orc.render(ctx._handle))
-    wall = time.perf_counter() - t0
-    ctx.close()
-    nq = (frames + RQ - 1) // RQ
+    cores = os.cpu_count() or 1
+    from graphs import white_noise
+
+    def run(n, fr, threads):
+        noise = white_noise(n, 2, fr)
+        ctx, src = build_workload(waa, orc, name, n, fr, -1, None)
+        src.set_buffer_batch(noise, SR)
+        ctx.prepare()
+        lib.orc_set_threads(ctx._handle, threads)
+        t0 = time.perf_counter()
+        orc.check(orc.render(ctx._handle))
+        wall = time.perf_counter() - t0
+        ctx.close()
+        return wall
+
+    cal_frames = min(frames, 128 * 150)  # 0.4 s of audio, one context, one thread
+    t_cal = max(run(1, cal_frames, 1), 1e-4)
+    sec_per_ctx_sec = t_cal / (cal_frames / SR)
+    sample_frames = int(min(frames, max(128 * 150, (target_wall / sec_per_ctx_sec) * SR)))
+    sample_frames = (sample_frames // RQ) * RQ
+    per_thread = max(1, int(target_wall / max(sec_per_ctx_sec * sample_frames / SR, 1e-6)))
+    per_thread = min(per_thread, 64, max(1, int(2e9 / (sample_frames * 8.0) / cores)))  # <= 2 GB of host noise
+    n = cores * per_thread
+    wall = run(n, sample_frames, cores)
+    nq = sample_frames // RQ
     return {"value": n * nq / wall, "unit": "quanta/s", "cores": cores, "kind": "port",
-            "sample": f"{n} contexts x {frames / SR:g} s of the same graph, one context per thread, wall {wall:.2f} s",
-            "rtf": n * (frames / SR) / wall}
+            "sample": f"{n} contexts x {sample_frames / SR:.2f} s of the same graph, one context per thread on {cores} "
+                      f"threads, wall {wall:.2f} s (single-thread calibration {t_cal:.2f} s for {cal_frames / SR:.2f} s)",
+            "rtf": n * (sample_frames / SR) / wall}
 
 
 def main():

@@ -157,24 +157,27 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel(const BiquadStream
   }
   float* out_base = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)ch * d.out.ch_stride;
 
-  float4 nx[NV4];
-  auto fetch = [&](uint32_t tile) {
+  // two tiles of input are kept in flight in registers (16 KiB per wave): with 8 waves per CU that is
+  // 32 MiB on the chip, what Little's law asks for at ~3 TB/s of reads and several microseconds of loaded latency
+  float4 nx[NV4], nx2[NV4];
+  auto fetch = [&](uint32_t tile, float4 (&dst)[NV4]) {
     if (!is_src) {
       const float* p = sig_base + (uint64_t)tile * TILE;
 #pragma unroll
-      for (int j = 0; j < NV4; j++) nx[j] = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
+      for (int j = 0; j < NV4; j++) dst[j] = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
     } else if (si.aligned && sc.tile_fast[tile]) {
       const float* p = si.base + (uint64_t)ch * si.ch_stride + sc.qrec[(uint64_t)tile * QUANTA_PER_TILE].start;
 #pragma unroll
-      for (int j = 0; j < NV4; j++) nx[j] = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
+      for (int j = 0; j < NV4; j++) dst[j] = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
     } else {
       float tmp[TILE_K];
       load_channel_generic(d.in, si, sc, ch, tile, lane, d.n_quanta, tmp);
 #pragma unroll
-      for (int j = 0; j < NV4; j++) nx[j] = make_float4(tmp[j * 4], tmp[j * 4 + 1], tmp[j * 4 + 2], tmp[j * 4 + 3]);
+      for (int j = 0; j < NV4; j++) dst[j] = make_float4(tmp[j * 4], tmp[j * 4 + 1], tmp[j * 4 + 2], tmp[j * 4 + 3]);
     }
   };
-  fetch(0);
+  fetch(0, nx);
+  if (d.n_tiles > 1) fetch(1, nx2);
 
   for (uint32_t tile = 0; tile < d.n_tiles; tile++) {
     // A layout -> LDS
@@ -183,7 +186,9 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel(const BiquadStream
       const int r = j * 8 + (lane >> 3), c = (lane & 7) * 4;
       *reinterpret_cast<float4*>(lds + r * LDS_ROW + c) = nx[j];
     }
-    if (tile + 1 < d.n_tiles) fetch(tile + 1);  // prefetch: in flight during the whole recurrence
+#pragma unroll
+    for (int j = 0; j < NV4; j++) nx[j] = nx2[j];
+    if (tile + 2 < d.n_tiles) fetch(tile + 2, nx2);  // prefetch distance 2 tiles
     __syncthreads();
     float x[TILE_K];
 #pragma unroll
@@ -250,17 +255,17 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel(const BiquadStream
     const double s2 = __builtin_fma(Aj.c, T1, __builtin_fma(Aj.d, T2, ex2));
     // final pass in the reference's order
     double y1 = s1, y2 = s2;
-    bool bad = false;
+    float badacc = 0.f;  // becomes NaN as soon as one output is inf/NaN (x * 0 + acc), off the critical path
     float yo[TILE_K];
 #pragma unroll
     for (int i = 0; i < TILE_K; i++) {
       const double y = (w[i] - a1 * y1) - a2 * y2;
-      bad |= !__builtin_isfinite(y);
       y2 = y1;
       y1 = y;
       yo[i] = (float)y;
+      badacc = __builtin_fmaf(yo[i], 0.f, badacc);
     }
-    if (__any(bad)) {
+    if (__any(badacc != badacc)) {
       // inf / NaN appeared somewhere: redo with the explicit flush of biquad_filter.rs:881-883
       y1 = s1;
       y2 = s2;

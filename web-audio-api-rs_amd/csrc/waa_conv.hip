@@ -126,29 +126,38 @@ __global__ void conv_fft_kernel(const ConvDesc d) {
     const float* pa = d.in.base + (uint64_t)ia * d.in.inst_stride + (uint64_t)c * d.in.ch_stride;
     const float* pb = d.in.base + (uint64_t)(has_b ? ib : ia) * d.in.inst_stride + (uint64_t)c * d.in.ch_stride;
     const int64_t f0 = ((int64_t)k - 1) * B;
-    for (int i = tid; i < n; i += nt) {
-      const int64_t f = f0 + i;
-      const bool ok = f >= 0 && (uint64_t)f < d.frames;
-      a[i] = Cplx{ok ? pa[f] : 0.f, (ok && has_b) ? pb[f] : 0.f};
+    // 16 B per lane per stream: 4 consecutive frames of instance a and of instance b -> 4 complex samples
+    for (int i4 = tid; i4 < (n >> 2); i4 += nt) {
+      const int64_t f = f0 + 4 * (int64_t)i4;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (f >= 0 && (uint64_t)f + 3 < d.frames) {
+        va = *reinterpret_cast<const float4*>(pa + f);
+        if (has_b) vb = *reinterpret_cast<const float4*>(pb + f);
+      }
+      float4* dst4 = reinterpret_cast<float4*>(a + 4 * i4);
+      dst4[0] = make_float4(va.x, vb.x, va.y, vb.y);
+      dst4[1] = make_float4(va.z, vb.z, va.w, vb.w);
     }
     __syncthreads();
     fft_dif(a, d.tw, n, tid, nt);
-    Cplx* dst = d.X + (((uint64_t)pair * d.cin + c) * d.nb + k) * n;
-    for (int i = tid; i < n; i += nt) dst[i] = a[i];
+    float4* dst = reinterpret_cast<float4*>(d.X + (((uint64_t)pair * d.cin + c) * d.nb + k) * n);
+    for (int i = tid; i < (n >> 1); i += nt) dst[i] = reinterpret_cast<const float4*>(a)[i];
   } else {
-    const Cplx* src = d.Y + (((uint64_t)pair * d.cout + c) * d.nb + k) * n;
-    for (int i = tid; i < n; i += nt) a[i] = src[i];
+    const float4* src = reinterpret_cast<const float4*>(d.Y + (((uint64_t)pair * d.cout + c) * d.nb + k) * n);
+    for (int i = tid; i < (n >> 1); i += nt) reinterpret_cast<float4*>(a)[i] = src[i];
     __syncthreads();
     fft_dit_inv(a, d.tw, n, tid, nt);
     float* pa = d.out.base + (uint64_t)ia * d.out.inst_stride + (uint64_t)c * d.out.ch_stride;
     float* pb = d.out.base + (uint64_t)(has_b ? ib : ia) * d.out.inst_stride + (uint64_t)c * d.out.ch_stride;
     const float scale = 1.f / (float)n;
-    for (int i = tid; i < B; i += nt) {
-      const uint64_t f = (uint64_t)k * B + i;
-      if (f < d.frames) {
-        const Cplx v = a[B + i];  // overlap-save: the last B samples are the linear convolution
-        pa[f] = v.re * scale;
-        if (has_b) pb[f] = v.im * scale;
+    for (int i4 = tid; i4 < (B >> 2); i4 += nt) {
+      const uint64_t f = (uint64_t)k * B + 4 * (uint64_t)i4;
+      if (f + 3 < d.frames) {
+        // overlap-save: the last B samples are the linear convolution; re -> instance a, im -> instance b
+        const float4 p0 = reinterpret_cast<const float4*>(a + B + 4 * i4)[0];
+        const float4 p1 = reinterpret_cast<const float4*>(a + B + 4 * i4)[1];
+        *reinterpret_cast<float4*>(pa + f) = make_float4(p0.x * scale, p0.z * scale, p1.x * scale, p1.z * scale);
+        if (has_b) *reinterpret_cast<float4*>(pb + f) = make_float4(p0.y * scale, p0.w * scale, p1.y * scale, p1.w * scale);
       }
     }
   }

@@ -17,7 +17,6 @@
 
 namespace waa {
 
-constexpr int NV4 = TILE_K / 4;      // float4 per lane per channel per tile
 constexpr int LDS_ROW = TILE_K + 4;  // padded row (floats): 144 B, conflict-free b128 access
 constexpr int CARRY_BYTES = MAX_OPS * 8 * 4 * 8;  // [MAX_OPS][C<=8][4] doubles
 
@@ -32,8 +31,9 @@ __device__ __forceinline__ float param_at(const ParamRef& p, uint32_t inst, uint
 }
 
 // ---- channel mixing on register tiles (quantum.rs:285-505) ------------------------------
-template <int C>
-__device__ __forceinline__ void mix_regs(float (&v)[C][TILE_K], int from, int to, int interp) {
+template <int C, int K>
+__device__ __forceinline__ void mix_regs(float (&v)[C][K], int from, int to, int interp) {
+  constexpr int TILE_K = K;
   if (from == to) return;
   if (interp == 1 || from > 6 || to > 6) {  // discrete: pad with silence / truncate
 #pragma unroll
@@ -157,10 +157,15 @@ __device__ __forceinline__ void mix_regs(float (&v)[C][TILE_K], int from, int to
 }
 
 // ---- input fetch (layout A: lane holds float4 j at frame tile*TILE + j*256 + lane*4) ------
-template <int C>
+// K = frames per lane: a tile is 64*K frames = K/2 render quanta (K = 32: the serial 2048-frame tiles of chains
+// with a recurrence; K = 4: the 256-frame sub-tiles of tile-parallel element-wise chains)
+template <int C, int K>
 __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, uint32_t tile, int lane, uint32_t n_quanta,
-                                           float (&v)[C][TILE_K]) {
-  const uint64_t f_tile = (uint64_t)tile * TILE;
+                                           float (&v)[C][K]) {
+  constexpr int NV4 = K / 4;
+  constexpr int TILE_FR = 64 * K;
+  constexpr int QPT = K / 2;
+  const uint64_t f_tile = (uint64_t)tile * TILE_FR;
   if (in.kind == IN_SIGNAL) {
 #pragma unroll
     for (int c = 0; c < C; c++) {
@@ -181,9 +186,9 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
   if (in.kind == IN_SOURCE) {
     const SrcInst si = in.src[inst];
     const SrcSchedule sc = in.sched[si.sched];
-    if (si.aligned && sc.tile_fast[tile]) {
-      // whole tile is one contiguous, in-range, 16B-aligned run of the AudioBuffer
-      const int64_t start = sc.qrec[(uint64_t)tile * QUANTA_PER_TILE].start;
+    if (si.aligned && sc.tile_fast[f_tile / TILE]) {
+      // the enclosing 2048-frame tile is one contiguous, in-range, 16B-aligned run of the AudioBuffer
+      const int64_t start = sc.qrec[(uint64_t)tile * QPT].start;
 #pragma unroll
       for (int c = 0; c < C; c++) {
         if (c < in.nch) {
@@ -204,7 +209,7 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
 #pragma unroll
     for (int j = 0; j < NV4; j++) {
       const uint32_t fq = j * 256 + lane * 4;  // frame within tile
-      uint32_t q = tile * QUANTA_PER_TILE + fq / RQ;
+      uint32_t q = tile * QPT + fq / RQ;
       const bool valid_q = q < n_quanta;
       const QRec r = sc.qrec[valid_q ? q : 0];
       const uint32_t mode = valid_q ? r.mode : (uint32_t)Q_SILENT;
@@ -273,7 +278,7 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
   }
   // IN_SILENT
 #pragma unroll
-  for (int i = 0; i < TILE_K; i++) v[0][i] = 0.f;
+  for (int i = 0; i < K; i++) v[0][i] = 0.f;
 }
 
 // ---- biquad (biquad_filter.rs:764-899) on the transposed layout --------------------------
@@ -294,6 +299,7 @@ template <int C>
 __device__ __forceinline__ void biquad_op(const OpDesc& op, uint32_t inst, uint32_t tile, int lane, uint32_t n_quanta,
                                           float* lds, float (&v)[C][TILE_K], double* carry, const double* coef_inst) {
   // carry: LDS, [C][4] = (x1, x2, y1, y2) per channel at the start of this tile
+  constexpr int NV4 = TILE_K / 4;
   const int nch = op.nch_in;
   // A -> LDS
 #pragma unroll
@@ -455,37 +461,56 @@ __device__ __forceinline__ void stereo_gains_dev(float x, float& gl, float& gr) 
   gr = sinf(x * PI_F / 2.f);
 }
 
-template <int C>
-__global__ __launch_bounds__(64) void chain_kernel(const ChainDesc d) {
+// SERIAL = true : chains with a recurrence (OP_BIQUAD): one wave per instance walks the 2048-frame tiles in order.
+// SERIAL = false: element-wise chains: one wave per (instance, 256-frame sub-tile), 4 waves per workgroup.
+template <int C, int K, bool SERIAL>
+__global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const uint32_t inst = blockIdx.x;
-  const int lane = threadIdx.x;
+  constexpr int NV4 = K / 4;
+  constexpr int TILE_FR = 64 * K;
+  constexpr int QPT = K / 2;
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_tiles_k = d.n_tiles * (TILE / TILE_FR);
+  uint32_t inst, tile_first, tile_last;
+  if (SERIAL) {
+    inst = blockIdx.x;
+    tile_first = 0;
+    tile_last = n_tiles_k;
+  } else {
+    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    inst = (uint32_t)(wid / n_tiles_k);
+    tile_first = (uint32_t)(wid % n_tiles_k);
+    tile_last = tile_first + 1;
+  }
   if (inst >= d.n_inst) return;
+  __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);  // f64 denormals flushed (FTZ/DAZ render scope)
 
   // recurrence state of every biquad op of the chain lives in LDS: [MAX_OPS][C][4] doubles
   double* carry_all = reinterpret_cast<double*>(lds + C * 64 * LDS_ROW);
-  for (int o = 0; o < d.n_ops; o++) {
-    if (d.ops[o].kind == OP_BIQUAD) {
-      const double* st = reinterpret_cast<const double*>(d.ops[o].ptr1) + (uint64_t)inst * STATE_STRIDE;
-      if (lane < C * 4) carry_all[o * C * 4 + lane] = (lane >> 2) < d.ops[o].nch_in ? st[lane] : 0.;
+  if constexpr (SERIAL) {
+    for (int o = 0; o < d.n_ops; o++) {
+      if (d.ops[o].kind == OP_BIQUAD) {
+        const double* st = reinterpret_cast<const double*>(d.ops[o].ptr1) + (uint64_t)inst * STATE_STRIDE;
+        if (lane < C * 4) carry_all[o * C * 4 + lane] = (lane >> 2) < d.ops[o].nch_in ? st[lane] : 0.;
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
 
-  for (uint32_t tile = 0; tile < d.n_tiles; tile++) {
-    float v[C][TILE_K];
+  for (uint32_t tile = tile_first; tile < tile_last; tile++) {
+    float v[C][K];
     // ---- inputs: mix every incoming edge to the node's computed channel count and sum in edge order
-    load_input<C>(d.in[0], inst, tile, lane, d.n_quanta, v);
-    mix_regs<C>(v, d.in[0].nch, d.in_nch, d.in_interp);
+    load_input<C, K>(d.in[0], inst, tile, lane, d.n_quanta, v);
+    mix_regs<C, K>(v, d.in[0].nch, d.in_nch, d.in_interp);
     for (int k = 1; k < d.n_inputs; k++) {
-      float u[C][TILE_K];
-      load_input<C>(d.in[k], inst, tile, lane, d.n_quanta, u);
-      mix_regs<C>(u, d.in[k].nch, d.in_nch, d.in_interp);
+      float u[C][K];
+      load_input<C, K>(d.in[k], inst, tile, lane, d.n_quanta, u);
+      mix_regs<C, K>(u, d.in[k].nch, d.in_nch, d.in_interp);
 #pragma unroll
       for (int c = 0; c < C; c++)
         if (c < d.in_nch) {
 #pragma unroll
-          for (int i = 0; i < TILE_K; i++) v[c][i] += u[c][i];
+          for (int i = 0; i < K; i++) v[c][i] += u[c][i];
         }
     }
     // ---- fused node ops
@@ -495,9 +520,9 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainDesc d) {
         case OP_GAIN: {
 #pragma unroll
           for (int j = 0; j < NV4; j++) {
-            const uint32_t q = tile * QUANTA_PER_TILE + j * 2 + (lane >> 5);
+            const uint32_t q = tile * QPT + j * 2 + (lane >> 5);
             const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
-            const uint64_t f = (uint64_t)tile * TILE + j * 256 + lane * 4;
+            const uint64_t f = (uint64_t)tile * TILE_FR + j * 256 + lane * 4;
             if (op.p0.mode == 2) {
 #pragma unroll
               for (int e = 0; e < 4; e++) {
@@ -523,8 +548,10 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainDesc d) {
           break;
         }
         case OP_BIQUAD: {
-          const double* coef = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0;
-          biquad_op<C>(op, inst, tile, lane, d.n_quanta, lds, v, carry_all + o * C * 4, coef);
+          if constexpr (SERIAL) {
+            const double* coef = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0;
+            biquad_op<C>(op, inst, tile, lane, d.n_quanta, lds, v, carry_all + o * C * 4, coef);
+          }
           break;
         }
         case OP_WAVESHAPER: {
@@ -533,7 +560,7 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainDesc d) {
           for (int c = 0; c < C; c++)
             if (c < op.nch_in) {
 #pragma unroll
-              for (int i = 0; i < TILE_K; i++) v[c][i] = apply_curve(curve, op.i0, v[c][i]);
+              for (int i = 0; i < K; i++) v[c][i] = apply_curve(curve, op.i0, v[c][i]);
             }
           break;
         }
@@ -541,9 +568,9 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainDesc d) {
           if constexpr (C >= 2) {
 #pragma unroll
             for (int j = 0; j < NV4; j++) {
-              const uint32_t q = tile * QUANTA_PER_TILE + j * 2 + (lane >> 5);
+              const uint32_t q = tile * QPT + j * 2 + (lane >> 5);
               const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
-              const uint64_t f = (uint64_t)tile * TILE + j * 256 + lane * 4;
+              const uint64_t f = (uint64_t)tile * TILE_FR + j * 256 + lane * 4;
 #pragma unroll
               for (int e = 0; e < 4; e++) {
                 const uint64_t fc = f + e < (uint64_t)d.n_quanta * RQ ? f + e : (uint64_t)d.n_quanta * RQ - 1;
@@ -579,7 +606,7 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainDesc d) {
           if constexpr (C >= 2) {
 #pragma unroll
             for (int j = 0; j < NV4; j++) {
-              const uint32_t q = tile * QUANTA_PER_TILE + j * 2 + (lane >> 5);
+              const uint32_t q = tile * QPT + j * 2 + (lane >> 5);
               const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
               const float az = param_at(op.p0, inst, qc, 0);
               const float gl = param_at(op.p1, inst, qc, 0), gr = param_at(op.p2, inst, qc, 0);
@@ -608,7 +635,7 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainDesc d) {
           break;
         }
         case OP_MIX:
-          mix_regs<C>(v, op.nch_in, op.nch_out, op.i0);
+          mix_regs<C, K>(v, op.nch_in, op.nch_out, op.i0);
           break;
         default:
           break;
@@ -618,7 +645,7 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainDesc d) {
 #pragma unroll
     for (int c = 0; c < C; c++) {
       if (c < d.out.nch) {
-        float* p = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)tile * TILE;
+        float* p = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)tile * TILE_FR;
 #pragma unroll
         for (int j = 0; j < NV4; j++)
           *reinterpret_cast<float4*>(p + j * 256 + lane * 4) =
@@ -627,6 +654,7 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainDesc d) {
     }
   }
   // persist recurrence state (lets a later render range continue; also what tail logic would inspect)
+  if constexpr (!SERIAL) return;
   __syncthreads();
   for (int o = 0; o < d.n_ops; o++) {
     if (d.ops[o].kind == OP_BIQUAD) {
@@ -638,11 +666,21 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainDesc d) {
 
 void launch_chain(const ChainDesc& d, int cmax, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(d.n_inst), block(64);
-  if (cmax <= 1) {
-    hipLaunchKernelGGL(chain_kernel<1>, grid, block, 1 * 64 * LDS_ROW * sizeof(float) + CARRY_BYTES, s, d);
+  bool serial = false;
+  for (int o = 0; o < d.n_ops; o++) serial |= d.ops[o].kind == OP_BIQUAD;
+  if (serial) {
+    dim3 grid(d.n_inst), block(64);
+    if (cmax <= 1)
+      hipLaunchKernelGGL((chain_kernel<1, TILE_K, true>), grid, block, 1 * 64 * LDS_ROW * sizeof(float) + CARRY_BYTES, s, d);
+    else
+      hipLaunchKernelGGL((chain_kernel<2, TILE_K, true>), grid, block, 2 * 64 * LDS_ROW * sizeof(float) + CARRY_BYTES, s, d);
   } else {
-    hipLaunchKernelGGL(chain_kernel<2>, grid, block, 2 * 64 * LDS_ROW * sizeof(float) + CARRY_BYTES, s, d);
+    const uint64_t waves = (uint64_t)d.n_inst * d.n_tiles * (TILE / 256);
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (cmax <= 1)
+      hipLaunchKernelGGL((chain_kernel<1, 4, false>), grid, block, 0, s, d);
+    else
+      hipLaunchKernelGGL((chain_kernel<2, 4, false>), grid, block, 0, s, d);
   }
 }
 
