@@ -92,19 +92,20 @@ def cpu_baseline(waa, name, frames, target_wall=12.0):
         ctx.close()
         return wall
 
-    cal_frames = min(frames, 128 * 150)  # 0.4 s of audio, one context, one thread
-    t_cal = max(run(1, cal_frames, 1), 1e-4)
-    sec_per_ctx_sec = t_cal / (cal_frames / SR)
-    sample_frames = int(min(frames, max(128 * 150, (target_wall / sec_per_ctx_sec) * SR)))
+    # calibration under the same contention as the timed run: every thread renders one short context
+    cal_frames = min(frames, 128 * 160)
+    t_cal = max(run(cores, cal_frames, cores), 1e-4)
+    sec_per_ctx_sec = t_cal / (cal_frames / SR)  # wall seconds per rendered second with all threads busy
+    sample_frames = int(min(frames, max(cal_frames, (target_wall / sec_per_ctx_sec) * SR)))
     sample_frames = (sample_frames // RQ) * RQ
     per_thread = max(1, int(target_wall / max(sec_per_ctx_sec * sample_frames / SR, 1e-6)))
-    per_thread = min(per_thread, 64, max(1, int(2e9 / (sample_frames * 8.0) / cores)))  # <= 2 GB of host noise
+    per_thread = min(per_thread, 16, max(1, int(2e9 / (sample_frames * 8.0) / cores)))  # <= 2 GB of host noise
     n = cores * per_thread
     wall = run(n, sample_frames, cores)
     nq = sample_frames // RQ
     return {"value": n * nq / wall, "unit": "quanta/s", "cores": cores, "kind": "port",
             "sample": f"{n} contexts x {sample_frames / SR:.2f} s of the same graph, one context per thread on {cores} "
-                      f"threads, wall {wall:.2f} s (single-thread calibration {t_cal:.2f} s for {cal_frames / SR:.2f} s)",
+                      f"threads, wall {wall:.2f} s (all-thread calibration {t_cal:.2f} s for {cal_frames / SR:.2f} s)",
             "rtf": n * (sample_frames / SR) / wall}
 
 

@@ -409,6 +409,13 @@ static void convir_free(ConvIR* c) {
   free(c->ir_im);
   free(c);
 }
+/* touch every page once so that a timed render does not measure first-touch page faults */
+static void prefault(void* p, size_t bytes) {
+  volatile unsigned char* c = (volatile unsigned char*)p;
+  for (size_t i = 0; i < bytes; i += 4096) c[i] = c[i];
+  if (bytes) c[bytes - 1] = c[bytes - 1];
+}
+
 static ConvState* convstate_new(const ConvIR* ir) {
   ConvState* s = (ConvState*)calloc(1, sizeof *s);
   s->ir = ir;
@@ -422,6 +429,8 @@ static ConvState* convstate_new(const ConvIR* ir) {
   s->fftbuf = (float*)calloc(ir->seg, sizeof(float));
   s->overlap = (float*)calloc(ir->block, sizeof(float));
   s->inbuf = (float*)calloc(ir->block, sizeof(float));
+  prefault(s->seg_re, (size_t)ir->seg_count * ir->csize * sizeof(float));
+  prefault(s->seg_im, (size_t)ir->seg_count * ir->csize * sizeof(float));
   return s;
 }
 static void convstate_free(ConvState* s) {
@@ -798,6 +807,7 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
   b->st = (NodeState**)calloc(n_inst, sizeof(NodeState*));
   for (uint32_t k = 0; k < n_inst; k++) b->st[k] = (NodeState*)calloc(g->n_nodes, sizeof(NodeState));
   b->out = (float*)calloc((size_t)n_inst * n_out * (length ? length : 1), sizeof(float));
+  prefault(b->out, (size_t)n_inst * n_out * (length ? length : 1) * sizeof(float));
   *out = b;
   return WAA_OK;
 }

@@ -355,3 +355,24 @@ def test_many_sources_fan_in(hip, orc):
         outs.append(ctx.start_rendering_sync().data)
         ctx.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("ftype", ["lowpass", "peaking", "highshelf", "bandpass"])
+def test_c1_a_rate_biquad(hip, orc, ftype):
+    """BASELINE config C1, a-rate variant (examples/biquad.rs:39-42): frequency exponential ramp 10 Hz -> 10 kHz
+    over the render => per-sample coefficients (biquad_filter.rs:837-855). Coefficients come from device
+    sin/cos/pow (<= 1-2 ulp from the host libm the oracle uses)."""
+    n, frames, sr = 3, RQ * 150 + 9, 48000.0
+    noise = white_noise(n, 2, frames)
+    outs = []
+    for b in (hip, orc):
+        ctx, nodes = c2(b, noise, ftype=ftype)
+        f = nodes["biquad"].frequency
+        f.set_value_at_time(10.0, 0.0)
+        f.exponential_ramp_to_value_at_time(10000.0, frames / sr)
+        nodes["biquad"].gain.set_value(6.0)
+        nodes["biquad"].detune.set_block(20, np.linspace(-600, 600, 30 * RQ).astype(np.float32).reshape(30, RQ), instance=1)
+        outs.append(ctx.start_rendering_sync().data)
+        ctx.close()
+    assert rms_err(*outs).max() <= TOL
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-6

@@ -179,6 +179,7 @@ class AudioParam:
         self._node, self._pid = node, pid
         self._const = {ALL: float(default)}
         self._blocks = []
+        self._events = []
 
     @property
     def value(self) -> float:
@@ -203,8 +204,49 @@ class AudioParam:
         self._blocks.append((int(quantum0), v, instance))
         return self
 
+    # -- a small automation timeline (host side, like src/param.rs; a convenience of this mirror, the ABI only
+    #    sees the resulting value blocks).  Supported: set_value_at_time, linear_ramp_to_value_at_time,
+    #    exponential_ramp_to_value_at_time (formulas of param.rs:63-86, f32 like the reference).
+    def set_value_at_time(self, value: float, time: float):
+        self._events.append(("set", float(value), float(time)))
+        return self
+
+    def linear_ramp_to_value_at_time(self, value: float, time: float):
+        self._events.append(("lin", float(value), float(time)))
+        return self
+
+    def exponential_ramp_to_value_at_time(self, value: float, time: float):
+        if value == 0.0:
+            raise WaaError(1, "RangeError - exponential ramp to zero is not allowed")
+        self._events.append(("exp", float(value), float(time)))
+        return self
+
+    def _render_events(self, ctx: "OfflineAudioContext"):
+        """Evaluate the timeline for every frame of the render -> [n_quanta, 128] block (a-rate)."""
+        nq = (ctx.length + RENDER_QUANTUM_SIZE - 1) // RENDER_QUANTUM_SIZE
+        t = np.arange(nq * RENDER_QUANTUM_SIZE, dtype=np.float64) / np.float64(ctx.sample_rate)
+        out = np.full(t.shape, np.float32(self._const[ALL]), np.float32)
+        prev_v, prev_t = np.float32(self._const[ALL]), 0.0
+        for kind, v, te in sorted(self._events, key=lambda e: e[2]):
+            v = np.float32(v)
+            if kind == "set":
+                out[t >= te] = v
+            else:
+                m = (t >= prev_t) & (t < te)
+                phase = ((t[m] - prev_t) / (te - prev_t)).astype(np.float32)
+                if kind == "lin":
+                    out[m] = (v - prev_v) * phase + prev_v
+                else:
+                    out[m] = prev_v * np.power(np.float32(v / prev_v), phase, dtype=np.float32)
+                out[t >= te] = v
+            prev_v, prev_t = v, te
+        return out.reshape(nq, RENDER_QUANTUM_SIZE)
+
     def _apply(self, ctx: "OfflineAudioContext"):
         b, h = ctx._b, ctx._handle
+        if self._events:
+            self.set_block(0, self._render_events(ctx))
+            self._events = []
         for inst, v in sorted(self._const.items(), key=lambda kv: kv[0] != ALL):
             b.check(b.set_param_const(h, self._node.id, self._pid, inst, v))
         for q0, v, inst in self._blocks:

@@ -157,39 +157,62 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel(const BiquadStream
   }
   float* out_base = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)ch * d.out.ch_stride;
 
-  // two tiles of input are kept in flight in registers (16 KiB per wave): with 8 waves per CU that is
-  // 32 MiB on the chip, what Little's law asks for at ~3 TB/s of reads and several microseconds of loaded latency
-  float4 nx[NV4], nx2[NV4];
-  auto fetch = [&](uint32_t tile, float4 (&dst)[NV4]) {
-    if (!is_src) {
-      const float* p = sig_base + (uint64_t)tile * TILE;
+  // One workgroup = one wavefront: LDS hand-offs between lanes only need program order (DS operations of a
+  // wave execute in order), so a compiler-level wave barrier replaces __syncthreads() — whose fences would
+  // drain every outstanding global load/store (s_waitcnt vmcnt(0)) and serialise the software pipeline.
+  auto lds_sync = []() __attribute__((always_inline)) { __builtin_amdgcn_wave_barrier(); };
+
+  auto fetch_fast = [&](uint32_t tile, float (&dst)[TILE_K]) __attribute__((always_inline)) {
+    const float* p = is_src ? si.base + (uint64_t)ch * si.ch_stride + sc.qrec[(uint64_t)tile * QUANTA_PER_TILE].start
+                            : sig_base + (uint64_t)tile * TILE;
 #pragma unroll
-      for (int j = 0; j < NV4; j++) dst[j] = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
-    } else if (si.aligned && sc.tile_fast[tile]) {
-      const float* p = si.base + (uint64_t)ch * si.ch_stride + sc.qrec[(uint64_t)tile * QUANTA_PER_TILE].start;
-#pragma unroll
-      for (int j = 0; j < NV4; j++) dst[j] = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
-    } else {
-      float tmp[TILE_K];
-      load_channel_generic(d.in, si, sc, ch, tile, lane, d.n_quanta, tmp);
-#pragma unroll
-      for (int j = 0; j < NV4; j++) dst[j] = make_float4(tmp[j * 4], tmp[j * 4 + 1], tmp[j * 4 + 2], tmp[j * 4 + 3]);
+    for (int j = 0; j < NV4; j++) {
+      const float4 t = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
+      dst[j * 4 + 0] = t.x;
+      dst[j * 4 + 1] = t.y;
+      dst[j * 4 + 2] = t.z;
+      dst[j * 4 + 3] = t.w;
     }
   };
-  fetch(0, nx);
-  if (d.n_tiles > 1) fetch(1, nx2);
+  auto tile_is_fast = [&](uint32_t tile) __attribute__((always_inline)) -> bool { return !is_src || (si.aligned && sc.tile_fast[tile]); };
 
-  for (uint32_t tile = 0; tile < d.n_tiles; tile++) {
-    // A layout -> LDS
+  // everything after the input fetch: transposes, recurrence, gains, store
+  // stage the tile (A layout registers) into LDS
+  auto stage = [&](const float (&cur)[TILE_K]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NV4; j++) {
       const int r = j * 8 + (lane >> 3), c = (lane & 7) * 4;
-      *reinterpret_cast<float4*>(lds + r * LDS_ROW + c) = nx[j];
+      *reinterpret_cast<float4*>(lds + r * LDS_ROW + c) =
+          make_float4(cur[j * 4 + 0], cur[j * 4 + 1], cur[j * 4 + 2], cur[j * 4 + 3]);
     }
+  };
+  float* lds_out = lds + 64 * LDS_ROW;  // second buffer: results of the previous tile, stored one iteration later
+  // store the tile whose results sit in lds_out (T layout rows) — gains applied on the way out
+  auto flush = [&](uint32_t tile) __attribute__((always_inline)) {
+    lds_sync();
+    float* op = out_base + (uint64_t)tile * TILE;
 #pragma unroll
-    for (int j = 0; j < NV4; j++) nx[j] = nx2[j];
-    if (tile + 2 < d.n_tiles) fetch(tile + 2, nx2);  // prefetch distance 2 tiles
-    __syncthreads();
+    for (int j = 0; j < NV4; j++) {
+      const int r = j * 8 + (lane >> 3), c = (lane & 7) * 4;
+      float4 t = *reinterpret_cast<const float4*>(lds_out + r * LDS_ROW + c);
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (k < d.n_gain) {
+          if (g_mute[k]) {
+            t = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else if (!g_pass[k]) {
+            t.x *= g[k];
+            t.y *= g[k];
+            t.z *= g[k];
+            t.w *= g[k];
+          }
+        }
+      *reinterpret_cast<float4*>(op + j * 256 + lane * 4) = t;
+    }
+    lds_sync();
+  };
+  auto process = [&](uint32_t tile) __attribute__((always_inline)) {
+    lds_sync();
     float x[TILE_K];
 #pragma unroll
     for (int j = 0; j < NV4; j++) {
@@ -285,33 +308,53 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel(const BiquadStream
     cx2 = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[TILE_K - 2]), 63));
     cy1 = read_lane(y1, 63);
     cy2 = read_lane(y2, 63);
-    // T layout -> LDS (own row) -> A layout
+    // T layout -> second LDS buffer (own row); stored to HBM by flush() during the next iteration
+    lds_sync();
 #pragma unroll
     for (int j = 0; j < NV4; j++)
-      *reinterpret_cast<float4*>(lds + lane * LDS_ROW + j * 4) =
+      *reinterpret_cast<float4*>(lds_out + lane * LDS_ROW + j * 4) =
           make_float4(yo[j * 4 + 0], yo[j * 4 + 1], yo[j * 4 + 2], yo[j * 4 + 3]);
-    __syncthreads();
-    float* op = out_base + (uint64_t)tile * TILE;
+    lds_sync();
+  };
+
+  // Tiles are visited in order (the recurrence is serial).  Software pipeline per iteration:
+  //   wait for tile t's input (requested one iteration ago) -> stage it into LDS -> request tile t+1
+  //   -> store tile t-1's results (kept in the second LDS buffer) -> recurrence of tile t.
+  // The compiler drains the whole VMEM queue (vmcnt(0)) before the staged registers are read because loads and
+  // stores share one counter on gfx9; with this order everything still outstanding at that point was issued a
+  // full iteration earlier, so the wait is (almost) free and stores never sit on the critical path.
+  bool pending = false;   // a finished tile waits in lds_out
+  uint32_t pending_tile = 0;
+  uint32_t tile = 0;
+  while (tile < d.n_tiles) {
+    if (!tile_is_fast(tile)) {
+      float tmp[TILE_K];
+      load_channel_generic(d.in, si, sc, ch, tile, lane, d.n_quanta, tmp);
+      float cur[TILE_K];
 #pragma unroll
-    for (int j = 0; j < NV4; j++) {
-      const int r = j * 8 + (lane >> 3), c = (lane & 7) * 4;
-      float4 t = *reinterpret_cast<const float4*>(lds + r * LDS_ROW + c);
-#pragma unroll
-      for (int k = 0; k < 2; k++)
-        if (k < d.n_gain) {
-          if (g_mute[k]) {
-            t = make_float4(0.f, 0.f, 0.f, 0.f);
-          } else if (!g_pass[k]) {
-            t.x *= g[k];
-            t.y *= g[k];
-            t.z *= g[k];
-            t.w *= g[k];
-          }
-        }
-      *reinterpret_cast<float4*>(op + j * 256 + lane * 4) = t;
+      for (int i = 0; i < TILE_K; i++) cur[i] = tmp[i];
+      stage(cur);
+      if (pending) flush(pending_tile);
+      process(tile);
+      pending = true;
+      pending_tile = tile;
+      tile++;
+      continue;
     }
-    __syncthreads();
+    uint32_t end = tile + 1;  // [tile, end) = maximal run of fast tiles
+    while (end < d.n_tiles && tile_is_fast(end)) end++;
+    float nx[TILE_K];
+    fetch_fast(tile, nx);
+    for (; tile < end; tile++) {
+      stage(nx);
+      fetch_fast(tile + 1 < end ? tile + 1 : tile, nx);  // clamped: the last iteration re-reads its own tile (L2 hit)
+      if (pending) flush(pending_tile);
+      process(tile);
+      pending = true;
+      pending_tile = tile;
+    }
   }
+  if (pending) flush(pending_tile);
   if (lane == 0) {
     st[0] = cx1;
     st[1] = cx2;
@@ -321,7 +364,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel(const BiquadStream
 }
 
 void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
-  hipLaunchKernelGGL(biquad_stream_kernel, dim3(d.n_inst * (uint32_t)d.nch), dim3(64), 64 * LDS_ROW * sizeof(float),
+  hipLaunchKernelGGL(biquad_stream_kernel, dim3(d.n_inst * (uint32_t)d.nch), dim3(64), 2 * 64 * LDS_ROW * sizeof(float),
                      (hipStream_t)stream, d);
 }
 

@@ -126,10 +126,11 @@ struct ProfileEntry {
 };
 
 struct Step {
-  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR
+  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients
   ChainDesc chain{};
   BiquadStreamDesc bq{};
   ConvDesc conv{};
+  BiquadCoefDesc coef{};
   int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
   void* zero_ptr = nullptr;
   size_t zero_bytes = 0;
@@ -1225,11 +1226,42 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
       OpDesc o{};
       o.kind = OP_BIQUAD;
       o.nch_in = o.nch_out = nch;
-      bool varies = false;
+      bool varies = false, a_rate = false;
       for (auto& p : n.params) {
-        if (p.mode() == 2)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "a-rate (per-sample) BiquadFilter params are a §8(f) 'next' item");
+        if (p.mode() == 2) a_rate = true;
         if (p.mode() == 1) varies = true;
+      }
+      if (a_rate) {
+        // a-rate params: coefficients per frame (biquad_filter.rs:837-855), computed on the device in f64 from
+        // the per-frame param values into a table the chain kernel streams
+        Step cs;
+        cs.kind = 5;
+        BiquadCoefDesc& cdsc = cs.coef;
+        std::memset(&cdsc, 0, sizeof cdsc);
+        int e;
+        if ((e = upload_param(b, n.params[WAA_PARAM_BIQUAD_FREQUENCY], &cdsc.frequency)) ||
+            (e = upload_param(b, n.params[WAA_PARAM_BIQUAD_DETUNE], &cdsc.detune)) ||
+            (e = upload_param(b, n.params[WAA_PARAM_BIQUAD_Q], &cdsc.q)) ||
+            (e = upload_param(b, n.params[WAA_PARAM_BIQUAD_GAIN], &cdsc.gain)))
+          return e;
+        cdsc.n_frames = (uint64_t)b->n_quanta * RQ;
+        cdsc.n_inst = b->n_inst;
+        cdsc.type = n.desc.i[0];
+        cdsc.sample_rate = b->sr;
+        double* dco = nullptr;
+        if ((e = dev_alloc(b, &dco, (size_t)b->n_inst * cdsc.n_frames * 5))) return e;
+        cdsc.coefs = dco;
+        cs.profile_slot = slot_for(b, "biquad_coef_kernel");
+        b->steps.push_back(cs);
+        double* dst = nullptr;
+        if ((e = dev_alloc(b, &dst, (size_t)b->n_inst * STATE_STRIDE))) return e;
+        b->state_bufs.push_back({dst, (size_t)b->n_inst * STATE_STRIDE * sizeof(double)});
+        o.i0 = 2;
+        o.ptr0 = dco;
+        o.ptr1 = dst;
+        o.u0 = cdsc.n_frames * 5;
+        ops.push_back(o);
+        break;
       }
       const uint64_t per = varies ? (uint64_t)b->n_quanta * 5 : 5;
       std::vector<double> co((size_t)b->n_inst * per);
@@ -1779,6 +1811,7 @@ waa_status waa_render(waa_batch* b) {
         break;
       case 3: HIP_TRY(hipMemsetAsync(st.zero_ptr, 0, st.zero_bytes, b->stream)); break;
       case 4: e = timed(st.slot_mac, [&] { launch_conv_direct(st.conv, b->stream); }); break;
+      case 5: e = timed(st.profile_slot, [&] { launch_biquad_coefs(st.coef, b->stream); }); break;
       default: e = timed(st.profile_slot, [&] { launch_chain(st.chain, st.cmax, b->stream); }); break;
     }
     if (e) return e;

@@ -86,7 +86,7 @@ struct OpDesc {
   int32_t kind;
   int32_t nch_in;
   int32_t nch_out;
-  int32_t i0;        // MIX: interpretation; WAVESHAPER: curve length; BIQUAD: coef mode (0 per inst, 1 per quantum)
+  int32_t i0;        // MIX: interpretation; WAVESHAPER: curve length; BIQUAD: coef mode (0 per inst, 1 per quantum, 2 per frame)
   ParamRef p0;       // GAIN: gain; STEREO_PAN: pan; PANNER: azimuth (wrapped)
   ParamRef p1;       // STEREO_PAN / PANNER: gain_l
   ParamRef p2;       // STEREO_PAN / PANNER: gain_r
@@ -178,6 +178,18 @@ void launch_conv_ir_spectra(const ConvDesc& d, void* stream);
 void launch_conv_forward(const ConvDesc& d, void* stream);
 void launch_conv_mac(const ConvDesc& d, void* stream);
 void launch_conv_inverse(const ConvDesc& d, void* stream);
+
+// ---- per-frame biquad coefficients for a-rate params (biquad_filter.rs:837-855) -------------
+struct BiquadCoefDesc {
+  ParamRef frequency, detune, q, gain;
+  double* coefs;        // [n_inst][n_frames][5]
+  uint64_t n_frames;    // n_quanta * 128
+  uint32_t n_inst;
+  int32_t type;
+  float sample_rate;
+  int32_t pad;
+};
+void launch_biquad_coefs(const BiquadCoefDesc& d, void* stream);
 
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);

@@ -315,9 +315,14 @@ __device__ __forceinline__ void biquad_op(const OpDesc& op, uint32_t inst, uint3
     }
   }
   __syncthreads();
-  // coefficients for this lane's quantum (4 lanes per quantum)
-  double b0, b1, b2, a1, a2;
-  {
+  // coefficients: per instance (mode 0), per quantum (mode 1: 4 lanes per quantum) or per frame (mode 2:
+  // a-rate params, biquad_filter.rs:837-855 — streamed from the table written by biquad_coef_kernel)
+  const bool per_frame = op.i0 == 2;
+  const uint64_t f_lane = (uint64_t)tile * TILE + (uint64_t)lane * TILE_K;  // first frame of this lane's chunk
+  const uint64_t f_max = (uint64_t)n_quanta * RQ - 1;
+  double b0 = 0., b1 = 0., b2 = 0., a1 = 0., a2 = 0.;
+  Mat2 A;
+  if (!per_frame) {
     const double* cp = coef_inst;
     if (op.i0 == 1) {
       uint32_t q = tile * QUANTA_PER_TILE + (lane >> 2);
@@ -329,14 +334,25 @@ __device__ __forceinline__ void biquad_op(const OpDesc& op, uint32_t inst, uint3
     b2 = cp[2];
     a1 = cp[3];
     a2 = cp[4];
-  }
-  // A_l = M^32 with M = [[-a1, -a2], [1, 0]] acting on (y[n-1], y[n-2])
-  Mat2 A;
-  {
+    // A_l = M^32 with M = [[-a1, -a2], [1, 0]] acting on (y[n-1], y[n-2])
     Mat2 m = {-a1, -a2, 1., 0.};
 #pragma unroll
     for (int s = 0; s < 5; s++) m = matmul(m, m);
     A = m;
+  } else {
+    // A_l = M_31 * ... * M_0 ; left-multiplying by M_i = [[-a1_i, -a2_i], [1, 0]] costs 4 flops
+    Mat2 pm = {1., 0., 0., 1.};
+#pragma unroll
+    for (int i = 0; i < TILE_K; i++) {
+      const uint64_t f = f_lane + i < f_max ? f_lane + i : f_max;
+      const double ca1 = coef_inst[f * 5 + 3], ca2 = coef_inst[f * 5 + 4];
+      const double na = __builtin_fma(-ca1, pm.a, -(ca2 * pm.c)), nb = __builtin_fma(-ca1, pm.b, -(ca2 * pm.d));
+      pm.c = pm.a;
+      pm.d = pm.b;
+      pm.a = na;
+      pm.b = nb;
+    }
+    A = pm;
   }
 #pragma unroll
   for (int c = 0; c < C; c++) {
@@ -361,6 +377,15 @@ __device__ __forceinline__ void biquad_op(const OpDesc& op, uint32_t inst, uint3
       double z1 = 0., z2 = 0.;
 #pragma unroll
       for (int i = 0; i < TILE_K; i++) {
+        if (per_frame) {
+          const uint64_t f = f_lane + i < f_max ? f_lane + i : f_max;
+          const double* cp = coef_inst + f * 5;
+          b0 = cp[0];
+          b1 = cp[1];
+          b2 = cp[2];
+          a1 = cp[3];
+          a2 = cp[4];
+        }
         const double xd = (double)x[i];
         w[i] = (b0 * xd + b1 * x1) + b2 * x2;
         x2 = x1;
@@ -402,6 +427,11 @@ __device__ __forceinline__ void biquad_op(const OpDesc& op, uint32_t inst, uint3
       float yo[TILE_K];
 #pragma unroll
       for (int i = 0; i < TILE_K; i++) {
+        if (per_frame) {
+          const uint64_t f = f_lane + i < f_max ? f_lane + i : f_max;
+          a1 = coef_inst[f * 5 + 3];
+          a2 = coef_inst[f * 5 + 4];
+        }
         double y = (w[i] - a1 * y1) - a2 * y2;
         if (!__builtin_isnormal(y)) y = 0.;
         y2 = y1;
@@ -662,6 +692,100 @@ __global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDes
       if (lane < C * 4 && (lane >> 2) < d.ops[o].nch_in) st[lane] = carry_all[o * C * 4 + lane];
     }
   }
+}
+
+// ---- per-frame biquad coefficients (biquad_filter.rs:28-373 calculate_coefs, get_computed_freq) in f64 ----
+__device__ __forceinline__ void norm_coefs(double b0, double b1, double b2, double a0, double a1, double a2, double* o) {
+  const double s = 1. / a0;
+  o[0] = b0 * s;
+  o[1] = b1 * s;
+  o[2] = b2 * s;
+  o[3] = a1 * s;
+  o[4] = a2 * s;
+}
+__device__ __forceinline__ void raw_coefs(double b0, double* o) {
+  o[0] = b0;
+  o[1] = o[2] = o[3] = o[4] = 0.;
+}
+__global__ __launch_bounds__(256) void biquad_coef_kernel(const BiquadCoefDesc d) {
+  const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (uint64_t)d.n_inst * d.n_frames) return;
+  const uint32_t inst = (uint32_t)(idx / d.n_frames);
+  const uint64_t frame = idx % d.n_frames;
+  const uint32_t q = (uint32_t)(frame / RQ);
+  const float freq = param_at(d.frequency, inst, q, frame), det = param_at(d.detune, inst, q, frame);
+  const double Q = (double)param_at(d.q, inst, q, frame), gain = (double)param_at(d.gain, inst, q, frame);
+  const float cf = det != 0.f ? freq * exp2f(det / 1200.f) : freq;  // get_computed_freq: f32
+  const double PI = 3.14159265358979323846;
+  const double nyq = (double)d.sample_rate / 2.;
+  double f = (double)cf / nyq;
+  f = f < 0. ? 0. : f > 1. ? 1. : f;
+  double* o = d.coefs + idx * 5;
+  const double A = pow(10., gain / 40.);
+  const double w0 = PI * f, sw = sin(w0), cw = cos(w0);
+  switch (d.type) {
+    case 0: {  // lowpass
+      if (f == 1.) { raw_coefs(1., o); break; }
+      const double al = sw / (2. * pow(10., Q / 20.)), be = (1. - cw) / 2.;
+      norm_coefs(be, 2. * be, be, 1. + al, -2. * cw, 1. - al, o);
+      break;
+    }
+    case 1: {  // highpass
+      if (f == 1.) { raw_coefs(0., o); break; }
+      if (f == 0.) { raw_coefs(1., o); break; }
+      const double al = sw / (2. * pow(10., Q / 20.)), be = (1. + cw) / 2.;
+      norm_coefs(be, -2. * be, be, 1. + al, -2. * cw, 1. - al, o);
+      break;
+    }
+    case 2: {  // bandpass
+      if (!(f > 0. && f < 1.)) { raw_coefs(0., o); break; }
+      if (!(Q > 0.)) { raw_coefs(1., o); break; }
+      const double al = sw / (2. * Q);
+      norm_coefs(al, 0., -al, 1. + al, -2. * cw, 1. - al, o);
+      break;
+    }
+    case 3: {  // notch
+      if (!(f > 0. && f < 1.)) { raw_coefs(1., o); break; }
+      if (!(Q > 0.)) { raw_coefs(0., o); break; }
+      const double al = sw / (2. * Q);
+      norm_coefs(1., -2. * cw, 1., 1. + al, -2. * cw, 1. - al, o);
+      break;
+    }
+    case 4: {  // allpass
+      if (!(f > 0. && f < 1.)) { raw_coefs(1., o); break; }
+      if (!(Q > 0.)) { raw_coefs(-1., o); break; }
+      const double al = sw / (2. * Q);
+      norm_coefs(1. - al, -2. * cw, 1. + al, 1. + al, -2. * cw, 1. - al, o);
+      break;
+    }
+    case 5: {  // peaking
+      if (!(f > 0. && f < 1.)) { raw_coefs(1., o); break; }
+      if (!(Q > 0.)) { raw_coefs(A * A, o); break; }
+      const double al = sw / (2. * Q);
+      norm_coefs(1. + al * A, -2. * cw, 1. - al * A, 1. + al / A, -2. * cw, 1. - al / A, o);
+      break;
+    }
+    case 6: {  // lowshelf
+      if (f == 1.) { raw_coefs(A * A, o); break; }
+      if (f == 0.) { raw_coefs(1., o); break; }
+      const double as = sw / 2. * 1.41421356237309504880, k = 2. * as * sqrt(A), ap = A + 1., am = A - 1.;
+      norm_coefs(A * (ap - am * cw + k), 2. * A * (am - ap * cw), A * (ap - am * cw - k), ap + am * cw + k,
+                 -2. * (am + ap * cw), ap + am * cw - k, o);
+      break;
+    }
+    default: {  // highshelf
+      if (f == 1.) { raw_coefs(1., o); break; }
+      if (!(f > 0.)) { raw_coefs(A * A, o); break; }
+      const double as = sw / 2. * 1.41421356237309504880, k = 2. * as * sqrt(A), ap = A + 1., am = A - 1.;
+      norm_coefs(A * (ap + am * cw + k), -2. * A * (am + ap * cw), A * (ap + am * cw - k), ap - am * cw + k,
+                 2. * (am - ap * cw), ap - am * cw - k, o);
+      break;
+    }
+  }
+}
+void launch_biquad_coefs(const BiquadCoefDesc& d, void* stream) {
+  const uint64_t total = (uint64_t)d.n_inst * d.n_frames;
+  hipLaunchKernelGGL(biquad_coef_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d);
 }
 
 void launch_chain(const ChainDesc& d, int cmax, void* stream) {
