@@ -1439,10 +1439,13 @@ static void process_buffer_source(orc_batch* b, NodeCfg* n, NodeState* s, uint32
           if (playback_rate >= 0.) {
             double sp = actual_loop_start * sample_rate;
             uint64_t si = (floor(sp) == sp) ? (uint64_t)sp : (uint64_t)sp + 1;
-            next_sample = (double)ch[si];
+            next_sample = si < buffer_length ? (double)ch[si] : 0.;
           } else {
             double ep = actual_loop_end * sample_rate;
-            next_sample = (double)ch[(uint64_t)ep];
+            uint64_t ei = (uint64_t)ep;
+            /* the reference indexes buffer_channel[end_index] here (audio_buffer_source.rs:795-797), which is one
+             * past the end when loop_end == duration: a Rust panic (the node is muted).  Defined here as 0. */
+            next_sample = ei < buffer_length ? (double)ch[ei] : 0.;
           }
         } else {
           if (almost_equal(k, 1.) || prev == 0)

@@ -173,17 +173,31 @@ def test_mixing_integration(be):
 
 
 def test_mixing_integration_quad(be):
-    """tests/mixing.rs:56-65 (quad destination). The device path of this round renders <= 2 channels per
-    signal and must say so loudly (status 4) instead of producing wrong channels."""
+    """tests/mixing.rs:56-65 (quad destination)."""
     ones, zeros = np.ones(128, np.float32), np.zeros(128, np.float32)
-    if be.prefix == "waa_":
-        with pytest.raises(waa.WaaError) as e:
-            _run_mixing(be, 4, "speakers", 4, "max", "speakers")
-        assert e.value.status == 4
-        return
     o = _run_mixing(be, 4, "speakers", 4, "max", "speakers")
     assert np.array_equal(o[0], ones) and np.array_equal(o[1], ones) and np.array_equal(o[2], zeros) and np.array_equal(
         o[3], zeros)
+
+
+def test_wide_channel_mixing_chain(be, orc):
+    """quantum.rs:285-505 end to end: stereo source -> gain(6, explicit) -> gain(4, explicit) -> 5.1 destination
+    and a 6 -> 1 down-mix, against the oracle (the oracle's matrices are pinned by test_mix_rules)."""
+    sr = 44100.0
+    rng = np.random.default_rng(2)
+    data = rng.uniform(-1, 1, (2, 128 * 6)).astype(np.float32)
+    outs = []
+    for b in (be, orc):
+        for n_out in (6, 1):
+            c = ctx(b, n_out, 128 * 6, sr)
+            s = c.create_buffer_source()
+            s.set_buffer(buf(data, sr))
+            g6 = c.create_gain(gain=0.5, channel_count=6, channel_count_mode="explicit", channel_interpretation="speakers")
+            g4 = c.create_gain(gain=0.8, channel_count=4, channel_count_mode="explicit", channel_interpretation="speakers")
+            s.connect(g6).connect(g4).connect(c.destination())
+            s.start()
+            outs.append(c.start_rendering_sync().data)
+    assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[3])
 
 
 def test_offline_render_summing_and_truncation(be):

@@ -261,7 +261,17 @@ __global__ void analyser_kernel(const AnalyserDesc d) {
     float v = 0.f;
     if (f >= 0) {
       // mono down-mix of the analyser input (analyser.rs:277-280, quantum.rs:387-397)
-      v = d.sig.nch == 1 ? p0[f] : 0.5f * (p0[f] + p0[d.sig.ch_stride + f]);
+      const uint64_t cs = d.sig.ch_stride;
+      switch (d.sig.nch) {  // quantum.rs:387-429 speaker down-mix to mono
+        case 1: v = p0[f]; break;
+        case 2: v = 0.5f * (p0[f] + p0[cs + f]); break;
+        case 4: v = 0.25f * (p0[f] + p0[cs + f] + p0[2 * cs + f] + p0[3 * cs + f]); break;
+        case 6:
+          v = __builtin_fmaf(0.70710678118654752440f, p0[f] + p0[cs + f],
+                             __builtin_fmaf(0.5f, p0[4 * cs + f] + p0[5 * cs + f], p0[2 * cs + f]));
+          break;
+        default: v = p0[f]; break;  // other layouts: truncate
+      }
     }
     d.time_out[i] = v;
     const float wv = v * d.window[i];

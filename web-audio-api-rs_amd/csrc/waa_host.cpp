@@ -501,10 +501,14 @@ void schedule_source(const waa_batch* b, const SourceSched& cfg, uint64_t frames
             } else if (is_looping) {
               if (playback_rate >= 0.) {
                 const double sp = actual_loop_start * sample_rate;
-                r.next = (int32_t)((std::floor(sp) == sp) ? (uint64_t)sp : (uint64_t)sp + 1);
+                const uint64_t si = (std::floor(sp) == sp) ? (uint64_t)sp : (uint64_t)sp + 1;
+                r.next = si < frames ? (int32_t)si : -1;
               } else {
+                // the reference reads buffer_channel[end_index] (audio_buffer_source.rs:795-797): one past the
+                // end when loop_end == duration (a Rust panic there); defined as a 0 sample here
                 const double ep = actual_loop_end * sample_rate;
-                r.next = (int32_t)(uint64_t)ep;
+                const uint64_t ei = (uint64_t)ep;
+                r.next = ei < frames ? (int32_t)ei : -1;
               }
             } else {
               r.next = (almost_equal(k, 1.) || prev == 0) ? -1 : -2;
@@ -722,9 +726,9 @@ int build_plan(waa_batch* b) {
         break;
       default: n.out_nch = n.in_nch; break;
     }
-    if (n.in_nch > 2 || n.out_nch > 2)
-      return fail(WAA_ERR_OUT_OF_SCOPE, "the device path of this round renders at most 2 channels per signal (node %u needs %d)",
-                  id, std::max(n.in_nch, n.out_nch));
+    if (n.in_nch > 6 || n.out_nch > 6)
+      return fail(WAA_ERR_OUT_OF_SCOPE, "the device path renders at most 6 channels per signal (node %u needs %d)", id,
+                  std::max(n.in_nch, n.out_nch));
   }
   // materialisation points
   for (uint32_t id = 0; id < N; id++) {
@@ -854,6 +858,11 @@ int build_plan(waa_batch* b) {
     }
     if (ops.size() > MAX_OPS) return fail(WAA_ERR_OUT_OF_SCOPE, "more than %d fused ops in one chain", MAX_OPS);
     for (auto& o : ops) cmax = std::max({cmax, o.nch_in, o.nch_out});
+    for (auto& o : ops)
+      if (o.kind == OP_BIQUAD && cmax > 2)
+        return fail(WAA_ERR_OUT_OF_SCOPE,
+                    "chains with a BiquadFilter are limited to 2 channels per signal on the device path of this round (needs %d)",
+                    cmax);
     cd.n_ops = (int)ops.size();
     for (size_t k = 0; k < ops.size(); k++) cd.ops[k] = ops[k];
     cd.out = term.sig;
@@ -861,7 +870,7 @@ int build_plan(waa_batch* b) {
     cd.n_tiles = b->n_tiles;
     cd.n_quanta = b->n_quanta;
     st.cmax = cmax;
-    st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : "chain_kernel<2>");
+    st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : cmax <= 2 ? "chain_kernel<2>" : "chain_kernel<4+>");
     // hot shape: single unmixed input -> Biquad(constant coefficients) -> constant gains: streaming kernel
     {
       bool fast = cd.n_inputs == 1 && (cd.in[0].kind == IN_SOURCE || cd.in[0].kind == IN_SIGNAL) &&

@@ -803,8 +803,12 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     if (cmax <= 1)
       hipLaunchKernelGGL((chain_kernel<1, 4, false>), grid, block, 0, s, d);
-    else
+    else if (cmax <= 2)
       hipLaunchKernelGGL((chain_kernel<2, 4, false>), grid, block, 0, s, d);
+    else if (cmax <= 4)
+      hipLaunchKernelGGL((chain_kernel<4, 4, false>), grid, block, 0, s, d);
+    else
+      hipLaunchKernelGGL((chain_kernel<6, 4, false>), grid, block, 0, s, d);
   }
 }
 
