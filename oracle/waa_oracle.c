@@ -280,9 +280,7 @@ typedef struct {
   FftPlan* half;
   float* tre; /* n/2 twiddles e^{-2 pi i k / n}, k < n/2 */
   float* tim;
-  float* sre; /* scratch n/2 */
-  float* sim;
-} RfftPlan;
+} RfftPlan; /* read-only after creation: shared by all instances / threads; scratch is the caller's */
 
 static RfftPlan* rfft_plan_new(int n) {
   RfftPlan* p = (RfftPlan*)calloc(1, sizeof *p);
@@ -290,8 +288,6 @@ static RfftPlan* rfft_plan_new(int n) {
   p->half = fft_plan_new(n / 2);
   p->tre = (float*)malloc(sizeof(float) * (n / 2 + 1));
   p->tim = (float*)malloc(sizeof(float) * (n / 2 + 1));
-  p->sre = (float*)malloc(sizeof(float) * (n / 2 + 1));
-  p->sim = (float*)malloc(sizeof(float) * (n / 2 + 1));
   for (int k = 0; k <= n / 2; k++) {
     double a = -2.0 * M_PI * (double)k / (double)n;
     p->tre[k] = (float)cos(a);
@@ -304,22 +300,20 @@ static void rfft_plan_free(RfftPlan* p) {
   fft_plan_free(p->half);
   free(p->tre);
   free(p->tim);
-  free(p->sre);
-  free(p->sim);
   free(p);
 }
-/* real -> n/2+1 complex bins (unnormalised) */
-static void rfft_forward(RfftPlan* p, const float* x, float* ore, float* oim) {
+/* real -> n/2+1 complex bins (unnormalised); sre/sim: caller-owned scratch of n/2+1 floats each */
+static void rfft_forward(const RfftPlan* p, float* sre, float* sim, const float* x, float* ore, float* oim) {
   int n = p->n, h = n / 2;
   for (int i = 0; i < h; i++) {
-    p->sre[i] = x[2 * i];
-    p->sim[i] = x[2 * i + 1];
+    sre[i] = x[2 * i];
+    sim[i] = x[2 * i + 1];
   }
-  fft_c2c(p->half, p->sre, p->sim, 0);
+  fft_c2c(p->half, sre, sim, 0);
   for (int k = 0; k <= h; k++) {
     int k1 = k % h, k2 = (h - k) % h;
-    float zr = p->sre[k1], zi = p->sim[k1];
-    float cr = p->sre[k2], ci = -p->sim[k2]; /* conj(Z[h-k]) */
+    float zr = sre[k1], zi = sim[k1];
+    float cr = sre[k2], ci = -sim[k2]; /* conj(Z[h-k]) */
     float er = 0.5f * (zr + cr), ei = 0.5f * (zi + ci);
     float dr = 0.5f * (zr - cr), di = 0.5f * (zi - ci);
     /* odd = -i * d ; X = e + w^k * odd */
@@ -330,7 +324,7 @@ static void rfft_forward(RfftPlan* p, const float* x, float* ore, float* oim) {
   }
 }
 /* n/2+1 complex bins -> real, scaled by 1/n (true inverse) */
-static void rfft_inverse(RfftPlan* p, const float* ire, const float* iim, float* x) {
+static void rfft_inverse(const RfftPlan* p, float* sre, float* sim, const float* ire, const float* iim, float* x) {
   int n = p->n, h = n / 2;
   for (int k = 0; k < h; k++) {
     float ar = ire[k], ai = iim[k];
@@ -340,14 +334,14 @@ static void rfft_inverse(RfftPlan* p, const float* ire, const float* iim, float*
     /* odd = d * conj(w^k); Z = e + i * odd */
     float wr = p->tre[k], wi = -p->tim[k];
     float odr = dr * wr - di * wi, odi = dr * wi + di * wr;
-    p->sre[k] = er - odi;
-    p->sim[k] = ei + odr;
+    sre[k] = er - odi;
+    sim[k] = ei + odr;
   }
-  fft_c2c(p->half, p->sre, p->sim, 1);
+  fft_c2c(p->half, sre, sim, 1);
   float s = 1.0f / (float)h;
   for (int i = 0; i < h; i++) {
-    x[2 * i] = p->sre[i] * s;
-    x[2 * i + 1] = p->sim[i] * s;
+    x[2 * i] = sre[i] * s;
+    x[2 * i + 1] = sim[i] * s;
   }
 }
 
@@ -373,6 +367,8 @@ typedef struct {
   float* fftbuf;   /* seg */
   float* overlap;  /* block */
   float* inbuf;    /* block */
+  float* sre;      /* FFT scratch, seg/2+1 each (per state: states render on different threads) */
+  float* sim;
   int inbuf_fill;
   int current;
 } ConvState;
@@ -392,14 +388,18 @@ static ConvIR* convir_new(int block_size, const float* ir, size_t len) {
   c->ir_re = (float*)calloc((size_t)c->seg_count * c->csize, sizeof(float));
   c->ir_im = (float*)calloc((size_t)c->seg_count * c->csize, sizeof(float));
   float* buf = (float*)calloc(c->seg, sizeof(float));
+  float* sre = (float*)calloc(c->seg / 2 + 1, sizeof(float));
+  float* sim = (float*)calloc(c->seg / 2 + 1, sizeof(float));
   for (int s = 0; s < c->seg_count; s++) {
     size_t remaining = len - (size_t)s * b;
     size_t cp = remaining < (size_t)b ? remaining : (size_t)b;
     memset(buf, 0, sizeof(float) * c->seg);
     memcpy(buf, ir + (size_t)s * b, cp * sizeof(float));
-    rfft_forward(c->plan, buf, c->ir_re + (size_t)s * c->csize, c->ir_im + (size_t)s * c->csize);
+    rfft_forward(c->plan, sre, sim, buf, c->ir_re + (size_t)s * c->csize, c->ir_im + (size_t)s * c->csize);
   }
   free(buf);
+  free(sre);
+  free(sim);
   return c;
 }
 static void convir_free(ConvIR* c) {
@@ -429,6 +429,8 @@ static ConvState* convstate_new(const ConvIR* ir) {
   s->fftbuf = (float*)calloc(ir->seg, sizeof(float));
   s->overlap = (float*)calloc(ir->block, sizeof(float));
   s->inbuf = (float*)calloc(ir->block, sizeof(float));
+  s->sre = (float*)calloc(ir->seg / 2 + 1, sizeof(float));
+  s->sim = (float*)calloc(ir->seg / 2 + 1, sizeof(float));
   prefault(s->seg_re, (size_t)ir->seg_count * ir->csize * sizeof(float));
   prefault(s->seg_im, (size_t)ir->seg_count * ir->csize * sizeof(float));
   return s;
@@ -444,6 +446,8 @@ static void convstate_free(ConvState* s) {
   free(s->fftbuf);
   free(s->overlap);
   free(s->inbuf);
+  free(s->sre);
+  free(s->sim);
   free(s);
 }
 static void cmac(float* __restrict__ rre, float* __restrict__ rim, const float* __restrict__ are,
@@ -470,7 +474,7 @@ static void conv_process(ConvState* s, const float* input, float* output, int le
     /* forward FFT of the zero-padded input block */
     memcpy(s->fftbuf, s->inbuf, sizeof(float) * ir->block);
     memset(s->fftbuf + ir->block, 0, sizeof(float) * ir->block);
-    rfft_forward(ir->plan, s->fftbuf, s->seg_re + (size_t)s->current * cs, s->seg_im + (size_t)s->current * cs);
+    rfft_forward(ir->plan, s->sre, s->sim, s->fftbuf, s->seg_re + (size_t)s->current * cs, s->seg_im + (size_t)s->current * cs);
     /* complex multiplication */
     if (was_empty) {
       memset(s->pre_re, 0, sizeof(float) * cs);
@@ -486,7 +490,7 @@ static void conv_process(ConvState* s, const float* input, float* output, int le
     cmac(s->conv_re, s->conv_im, s->seg_re + (size_t)s->current * cs, s->seg_im + (size_t)s->current * cs,
          ir->ir_re, ir->ir_im, cs);
     /* backward FFT */
-    rfft_inverse(ir->plan, s->conv_re, s->conv_im, s->fftbuf);
+    rfft_inverse(ir->plan, s->sre, s->sim, s->conv_re, s->conv_im, s->fftbuf);
     /* add overlap */
     for (int i = 0; i < processing; i++) output[processed + i] = s->fftbuf[pos + i] + s->overlap[pos + i];
     s->inbuf_fill += processing;
@@ -2132,7 +2136,11 @@ static void analyser_compute_fft(NodeCfg* n, NodeState* s) {
   RfftPlan* plan = rfft_plan_new(fft_size);
   float* re = (float*)malloc(sizeof(float) * (fft_size / 2 + 1));
   float* im = (float*)malloc(sizeof(float) * (fft_size / 2 + 1));
-  rfft_forward(plan, input, re, im);
+  float* sre = (float*)malloc(sizeof(float) * (fft_size / 2 + 1));
+  float* sim = (float*)malloc(sizeof(float) * (fft_size / 2 + 1));
+  rfft_forward(plan, sre, sim, input, re, im);
+  free(sre);
+  free(sim);
   if (!s->last_fft_output) s->last_fft_output = (float*)calloc(MAX_FFT_SIZE / 2 + 1, sizeof(float));
   float nf = 1.f / (float)fft_size;
   for (int k = 0; k < fft_size / 2; k++) {

@@ -800,3 +800,27 @@ def test_analyser_matches_numpy_dft(be):
     mag = np.abs(np.fft.rfft(mono.astype(np.float64) * w))[:fft // 2] / fft * (1 - 0.8)
     ref = 20 * np.log10(mag)
     assert np.max(np.abs(db - ref)) <= 1e-3
+
+
+def test_oracle_threaded_render_is_identical(orc, orc_lib):
+    """The oracle's multi-threaded mode (used by bench.py's cpu_baseline leg) must equal its serial mode."""
+    import ctypes as C
+    rng = np.random.default_rng(4)
+    n, frames, sr = 6, 128 * 40, 48000.0
+    noise = rng.uniform(-1, 1, (n, 2, frames)).astype(np.float32)
+    ir = (rng.uniform(-1, 1, (2, 3000)) * np.exp(-np.arange(3000) / 600.0)).astype(np.float32)
+    outs = []
+    for threads in (1, 4):
+        c = ctx(orc, 2, frames, sr, n_instances=n)
+        s = c.create_buffer_source()
+        s.set_buffer_batch(noise, sr)
+        f = c.create_biquad_filter(type_="lowpass", frequency=200.0)
+        cv = c.create_convolver(buffer=buf(ir, sr))
+        an = c.create_analyser()
+        s.connect(f).connect(cv).connect(an).connect(c.destination())
+        s.start()
+        c.prepare()
+        orc_lib.orc_set_threads.argtypes = [C.c_void_p, C.c_int32]
+        orc_lib.orc_set_threads(c._handle, threads)
+        outs.append(c.start_rendering_sync().data)
+    assert np.array_equal(outs[0], outs[1])
