@@ -96,6 +96,120 @@ __device__ __forceinline__ void fft_dit_inv(Cplx* a, const Cplx* tw, int n, int 
   }
 }
 
+
+// ---- convolver FFTs (n = 4^m >= 256): padded LDS layout + register radix-16 tail ---------------------------
+// Element i lives at pad(i) = i + 2*(i/16) complex slots (16 B of padding per 128 B), so a thread can read or
+// write 16 consecutive elements with eight conflict-free ds_*_b128 (lane stride 144 B).  The two innermost
+// radix-4 stages (strides 4 and 1) then run on registers instead of taking 4- and 8-way bank conflicts in LDS.
+__device__ __forceinline__ int pad(int i) { return i + ((i >> 4) << 1); }
+
+__device__ __forceinline__ void radix4_dif(Cplx& x0, Cplx& x1, Cplx& x2, Cplx& x3, Cplx w1, bool use_tw) {
+  const Cplx s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = mul_negi(csub(x1, x3));
+  const Cplx y0 = cadd(s02, s13), y1 = csub(s02, s13), y2 = cadd(d02, d13), y3 = csub(d02, d13);
+  if (use_tw) {
+    const Cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+    x0 = y0;
+    x1 = cmul(y1, w2);
+    x2 = cmul(y2, w1);
+    x3 = cmul(y3, w3);
+  } else {
+    x0 = y0;
+    x1 = y1;
+    x2 = y2;
+    x3 = y3;
+  }
+}
+__device__ __forceinline__ void radix4_dit(Cplx& x0, Cplx& x1, Cplx& x2, Cplx& x3, Cplx w1c, bool use_tw) {
+  Cplx t1 = x1, t2 = x2, t3 = x3;
+  if (use_tw) {
+    const Cplx w2 = cmul(w1c, w1c);
+    t1 = cmul(x1, w2);
+    t3 = cmul(x3, w2);
+  }
+  const Cplx a0 = cadd(x0, t1), a1 = csub(x0, t1);
+  Cplx a2 = cadd(t2, t3), a3 = csub(t2, t3);
+  if (use_tw) {
+    a2 = cmul(a2, w1c);
+    a3 = cmul(a3, w1c);
+  }
+  a3 = mul_posi(a3);
+  x0 = cadd(a0, a2);
+  x2 = csub(a0, a2);
+  x1 = cadd(a1, a3);
+  x3 = csub(a1, a3);
+}
+
+__device__ __forceinline__ void fft_dif_padded(Cplx* a, const Cplx* tw, int n, int tid, int nthreads) {
+  for (int L = n; L >= 64; L >>= 2) {  // LDS stages with stride q >= 16
+    const int q = L >> 2;
+    const int tstep = n / (4 * q);
+    for (int b = tid; b < (n >> 2); b += nthreads) {
+      const int j = b % q, base = (b / q) * 4 * q + j;
+      const int i0 = pad(base), i1 = pad(base + q), i2 = pad(base + 2 * q), i3 = pad(base + 3 * q);
+      Cplx x0 = a[i0], x1 = a[i1], x2 = a[i2], x3 = a[i3];
+      radix4_dif(x0, x1, x2, x3, tw[j * tstep], true);
+      a[i0] = x0;
+      a[i1] = x1;
+      a[i2] = x2;
+      a[i3] = x3;
+    }
+    __syncthreads();
+  }
+  // strides 4 and 1 on registers: thread t owns elements [16t, 16t+16)
+  for (int t = tid; t < (n >> 4); t += nthreads) {
+    float4* row = reinterpret_cast<float4*>(a + 18 * t);
+    Cplx x[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float4 v = row[k];
+      x[2 * k] = Cplx{v.x, v.y};
+      x[2 * k + 1] = Cplx{v.z, v.w};
+    }
+    const int tstep = n >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) radix4_dif(x[j], x[j + 4], x[j + 8], x[j + 12], tw[j * tstep], true);
+#pragma unroll
+    for (int g = 0; g < 4; g++) radix4_dif(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], Cplx{1.f, 0.f}, false);
+#pragma unroll
+    for (int k = 0; k < 8; k++) row[k] = make_float4(x[2 * k].re, x[2 * k].im, x[2 * k + 1].re, x[2 * k + 1].im);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void fft_dit_inv_padded(Cplx* a, const Cplx* tw, int n, int tid, int nthreads) {
+  for (int t = tid; t < (n >> 4); t += nthreads) {
+    float4* row = reinterpret_cast<float4*>(a + 18 * t);
+    Cplx x[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float4 v = row[k];
+      x[2 * k] = Cplx{v.x, v.y};
+      x[2 * k + 1] = Cplx{v.z, v.w};
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) radix4_dit(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], Cplx{1.f, 0.f}, false);
+    const int tstep = n >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) radix4_dit(x[j], x[j + 4], x[j + 8], x[j + 12], conj(tw[j * tstep]), true);
+#pragma unroll
+    for (int k = 0; k < 8; k++) row[k] = make_float4(x[2 * k].re, x[2 * k].im, x[2 * k + 1].re, x[2 * k + 1].im);
+  }
+  __syncthreads();
+  for (int q = 16; q <= (n >> 2); q <<= 2) {
+    const int tstep = n / (4 * q);
+    for (int b = tid; b < (n >> 2); b += nthreads) {
+      const int j = b % q, base = (b / q) * 4 * q + j;
+      const int i0 = pad(base), i1 = pad(base + q), i2 = pad(base + 2 * q), i3 = pad(base + 3 * q);
+      Cplx x0 = a[i0], x1 = a[i1], x2 = a[i2], x3 = a[i3];
+      radix4_dit(x0, x1, x2, x3, conj(tw[j * tstep]), true);
+      a[i0] = x0;
+      a[i1] = x1;
+      a[i2] = x2;
+      a[i3] = x3;
+    }
+    __syncthreads();
+  }
+}
+
 enum { MODE_FWD = 0, MODE_INV = 1, MODE_IR = 2 };
 
 template <int MODE>
@@ -112,12 +226,12 @@ __global__ void conv_fft_kernel(const ConvDesc d) {
     const float* h = d.ir + (uint64_t)c * d.ir_len;
     for (int i = tid; i < n; i += nt) {
       const uint64_t idx = (uint64_t)k * B + i;
-      a[i] = Cplx{(i < B && idx < d.ir_len) ? h[idx] : 0.f, 0.f};
+      a[pad(i)] = Cplx{(i < B && idx < d.ir_len) ? h[idx] : 0.f, 0.f};
     }
     __syncthreads();
-    fft_dif(a, d.tw, n, tid, nt);
+    fft_dif_padded(a, d.tw, n, tid, nt);
     Cplx* dst = const_cast<Cplx*>(d.H) + ((uint64_t)c * d.parts + k) * n;
-    for (int i = tid; i < n; i += nt) dst[i] = a[i];
+    for (int i = tid; i < n; i += nt) dst[i] = a[pad(i)];
     return;
   }
   const uint32_t ia = pair * 2, ib = pair * 2 + 1;
@@ -134,19 +248,19 @@ __global__ void conv_fft_kernel(const ConvDesc d) {
         va = *reinterpret_cast<const float4*>(pa + f);
         if (has_b) vb = *reinterpret_cast<const float4*>(pb + f);
       }
-      float4* dst4 = reinterpret_cast<float4*>(a + 4 * i4);
+      float4* dst4 = reinterpret_cast<float4*>(a + pad(4 * i4));
       dst4[0] = make_float4(va.x, vb.x, va.y, vb.y);
       dst4[1] = make_float4(va.z, vb.z, va.w, vb.w);
     }
     __syncthreads();
-    fft_dif(a, d.tw, n, tid, nt);
+    fft_dif_padded(a, d.tw, n, tid, nt);
     float4* dst = reinterpret_cast<float4*>(d.X + (((uint64_t)pair * d.cin + c) * d.nb + k) * n);
-    for (int i = tid; i < (n >> 1); i += nt) dst[i] = reinterpret_cast<const float4*>(a)[i];
+    for (int i = tid; i < (n >> 1); i += nt) dst[i] = *reinterpret_cast<const float4*>(a + pad(2 * i));
   } else {
     const float4* src = reinterpret_cast<const float4*>(d.Y + (((uint64_t)pair * d.cout + c) * d.nb + k) * n);
-    for (int i = tid; i < (n >> 1); i += nt) reinterpret_cast<float4*>(a)[i] = src[i];
+    for (int i = tid; i < (n >> 1); i += nt) *reinterpret_cast<float4*>(a + pad(2 * i)) = src[i];
     __syncthreads();
-    fft_dit_inv(a, d.tw, n, tid, nt);
+    fft_dit_inv_padded(a, d.tw, n, tid, nt);
     float* pa = d.out.base + (uint64_t)ia * d.out.inst_stride + (uint64_t)c * d.out.ch_stride;
     float* pb = d.out.base + (uint64_t)(has_b ? ib : ia) * d.out.inst_stride + (uint64_t)c * d.out.ch_stride;
     const float scale = 1.f / (float)n;
@@ -154,8 +268,8 @@ __global__ void conv_fft_kernel(const ConvDesc d) {
       const uint64_t f = (uint64_t)k * B + 4 * (uint64_t)i4;
       if (f + 3 < d.frames) {
         // overlap-save: the last B samples are the linear convolution; re -> instance a, im -> instance b
-        const float4 p0 = reinterpret_cast<const float4*>(a + B + 4 * i4)[0];
-        const float4 p1 = reinterpret_cast<const float4*>(a + B + 4 * i4)[1];
+        const float4 p0 = reinterpret_cast<const float4*>(a + pad(B + 4 * i4))[0];
+        const float4 p1 = reinterpret_cast<const float4*>(a + pad(B + 4 * i4))[1];
         *reinterpret_cast<float4*>(pa + f) = make_float4(p0.x * scale, p0.z * scale, p1.x * scale, p1.z * scale);
         if (has_b) *reinterpret_cast<float4*>(pb + f) = make_float4(p0.y * scale, p0.w * scale, p1.y * scale, p1.w * scale);
       }
@@ -316,17 +430,17 @@ static void allow_big_lds(size_t bytes) {
 
 void launch_conv_ir_spectra(const ConvDesc& d, void* stream) {
   allow_big_lds((size_t)d.n * sizeof(Cplx));
-  hipLaunchKernelGGL(conv_fft_kernel<MODE_IR>, dim3(d.parts, d.ir_nch, 1), dim3(fft_threads(d.n)), (size_t)d.n * sizeof(Cplx),
+  hipLaunchKernelGGL(conv_fft_kernel<MODE_IR>, dim3(d.parts, d.ir_nch, 1), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
                      (hipStream_t)stream, d);
 }
 void launch_conv_forward(const ConvDesc& d, void* stream) {
   allow_big_lds((size_t)d.n * sizeof(Cplx));
-  hipLaunchKernelGGL(conv_fft_kernel<MODE_FWD>, dim3(d.nb, d.cin, d.n_pairs), dim3(fft_threads(d.n)), (size_t)d.n * sizeof(Cplx),
+  hipLaunchKernelGGL(conv_fft_kernel<MODE_FWD>, dim3(d.nb, d.cin, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
                      (hipStream_t)stream, d);
 }
 void launch_conv_inverse(const ConvDesc& d, void* stream) {
   allow_big_lds((size_t)d.n * sizeof(Cplx));
-  hipLaunchKernelGGL(conv_fft_kernel<MODE_INV>, dim3(d.nb, d.cout, d.n_pairs), dim3(fft_threads(d.n)), (size_t)d.n * sizeof(Cplx),
+  hipLaunchKernelGGL(conv_fft_kernel<MODE_INV>, dim3(d.nb, d.cout, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
                      (hipStream_t)stream, d);
 }
 void launch_conv_direct(const ConvDesc& d, void* stream) {
