@@ -376,3 +376,27 @@ def test_c1_a_rate_biquad(hip, orc, ftype):
         ctx.close()
     assert rms_err(*outs).max() <= TOL
     assert np.abs(outs[0] - outs[1]).max() <= 2e-6
+
+
+def test_t1_full_length_sampled_instances(hip, orc):
+    """North-star headline graph (T1: src -> Biquad -> Convolver(garage-sized IR) -> destination) at the full
+    10 s render length (59 blocks of 8192, 22 partitions); the oracle renders a sample of the instances."""
+    n_inst, frames = 33, 480000  # odd count: the last instance pair is half empty
+    noise = white_noise(n_inst, 2, frames)
+    ir = garage_like_ir()
+    ctx, _ = t1(hip, noise, ir)
+    out = ctx.start_rendering_sync().data
+    ctx.close()
+    pick = [0, 17, 32]
+    octx, _ = t1(orc, noise[pick], ir)
+    ref = octx.start_rendering_sync().data
+    octx.close()
+    err = rms_err(out[pick], ref)
+    assert err.max() <= TOL, err
+    # size-independent property: time invariance / causality — the first 100 ms do not depend on later input
+    noise2 = noise[:2].copy()
+    noise2[:, :, 4800:] = 0.0
+    ctx, _ = t1(hip, noise2, ir)
+    out2 = ctx.start_rendering_sync().data
+    ctx.close()
+    assert np.abs(out2[:, :, :4800] - out[:2, :, :4800]).max() <= 1e-6
