@@ -400,3 +400,31 @@ def test_t1_full_length_sampled_instances(hip, orc):
     out2 = ctx.start_rendering_sync().data
     ctx.close()
     assert np.abs(out2[:, :, :4800] - out[:2, :, :4800]).max() <= 1e-6
+
+
+def test_split_chains_biquads_with_elementwise_ops(hip, orc):
+    """Planner: constant-coefficient biquads go to the streaming kernel, the ops around them to the element-wise
+    kernel (src -> gain -> biquad -> gain -> stereo panner -> biquad -> waveshaper -> destination, mono source)."""
+    sr, n = 48000.0, 5
+    for nch in (1, 2):
+        noise = white_noise(n, nch, RQ * 70 + 3)
+        outs = []
+        for b in (hip, orc):
+            ctx = waa.OfflineAudioContext(2, RQ * 80, sr, n_instances=n, binding=b)
+            src = ctx.create_buffer_source()
+            src.set_buffer_batch(noise, sr)
+            g0 = ctx.create_gain(gain=0.9)
+            b1 = ctx.create_biquad_filter(type_="peaking", frequency=1200.0, q=2.0, gain=5.0)
+            g1 = ctx.create_gain(gain=0.7)
+            pan = ctx.create_stereo_panner(pan=-0.35)
+            b2 = ctx.create_biquad_filter(type_="highpass", frequency=90.0, q=0.7)
+            i = np.arange(257, dtype=np.float32)
+            sh = ctx.create_wave_shaper(curve=np.tanh((i - 128) / 64).astype(np.float32))
+            src.connect(g0).connect(b1).connect(g1).connect(pan).connect(b2).connect(sh).connect(ctx.destination())
+            for k in range(n):
+                b1.frequency.set_value(300.0 + 400.0 * k, instance=k)
+            src.start_at(RQ * 2 / sr)
+            outs.append(ctx.start_rendering_sync().data)
+            ctx.close()
+        assert rms_err(*outs).max() <= TOL, nch
+        assert np.abs(outs[0] - outs[1]).max() <= 1e-6

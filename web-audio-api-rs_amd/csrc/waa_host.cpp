@@ -656,6 +656,120 @@ int slot_for(waa_batch* b, const char* name) {
 // ---------------------------------------------------------------------------------------
 int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector<OpDesc>& ops, int* out_nch);
 
+// One interpreter-kernel step: input(s) -> [mix to in_nch] -> ops -> out
+int push_chain_step(waa_batch* b, const std::vector<InputRef>& inputs, int in_nch, int in_interp,
+                    const std::vector<OpDesc>& ops, const SignalRef& out) {
+  if (ops.size() > (size_t)MAX_OPS) return fail(WAA_ERR_OUT_OF_SCOPE, "more than %d fused ops in one chain", MAX_OPS);
+  Step st;
+  ChainDesc& cd = st.chain;
+  std::memset(&cd, 0, sizeof cd);
+  int cmax = std::max(in_nch, out.nch);
+  cd.n_inputs = (int)inputs.size();
+  for (size_t k = 0; k < inputs.size(); k++) {
+    cd.in[k] = inputs[k];
+    cmax = std::max(cmax, inputs[k].nch);
+  }
+  cd.in_nch = in_nch;
+  cd.in_interp = in_interp;
+  for (auto& o : ops) cmax = std::max({cmax, o.nch_in, o.nch_out});
+  for (auto& o : ops)
+    if (o.kind == OP_BIQUAD && cmax > 2)
+      return fail(WAA_ERR_OUT_OF_SCOPE,
+                  "chains with a BiquadFilter are limited to 2 channels per signal on the device path of this round (needs %d)",
+                  cmax);
+  cd.n_ops = (int)ops.size();
+  for (size_t k = 0; k < ops.size(); k++) cd.ops[k] = ops[k];
+  cd.out = out;
+  cd.n_inst = b->n_inst;
+  cd.n_tiles = b->n_tiles;
+  cd.n_quanta = b->n_quanta;
+  st.cmax = cmax;
+  st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : cmax <= 2 ? "chain_kernel<2>" : "chain_kernel<4+>");
+  b->steps.push_back(st);
+  return 0;
+}
+
+int temp_signal(waa_batch* b, int nch, SignalRef* out) {
+  float* p = nullptr;
+  int e = dev_alloc(b, &p, (size_t)b->n_inst * nch * b->lp);
+  if (e) return e;
+  *out = SignalRef{p, (uint64_t)nch * b->lp, b->lp, nch, 0};
+  return 0;
+}
+
+// Turn one fused chain into kernel launches.  A Biquad with constant coefficients (plus up to two constant
+// gains right behind it) goes to the streaming kernel (one wave per instance-channel, ~60 % of HBM peak); the
+// ops around it run on the tile-parallel element-wise kernel.  Splitting costs one extra pass through HBM
+// per cut but keeps every segment on a kernel that is 3-6x closer to the roofline than the serial interpreter,
+// which remains the path for per-quantum / per-frame coefficient biquads.
+int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in_interp, const std::vector<OpDesc>& ops,
+                  const SignalRef& out) {
+  bool any_stream = false;
+  for (auto& o : ops) any_stream |= (o.kind == OP_BIQUAD && o.i0 == 0 && o.nch_in <= 2);
+  if (!any_stream) return push_chain_step(b, inputs, in_nch, in_interp, ops, out);
+  std::vector<OpDesc> pending;
+  int cur_nch = in_nch;
+  size_t i = 0;
+  while (i < ops.size()) {
+    const OpDesc& o = ops[i];
+    if (!(o.kind == OP_BIQUAD && o.i0 == 0 && o.nch_in <= 2)) {
+      pending.push_back(o);
+      cur_nch = o.nch_out;
+      i++;
+      continue;
+    }
+    // the streaming kernel wants ONE plain input (signal or source) of exactly the biquad's channel count
+    const bool plain = pending.empty() && inputs.size() == 1 && (inputs[0].kind == IN_SOURCE || inputs[0].kind == IN_SIGNAL) &&
+                       inputs[0].nch == cur_nch;
+    if (!plain) {
+      SignalRef tmp;
+      int e = temp_signal(b, cur_nch, &tmp);
+      if (e) return e;
+      if ((e = push_chain_step(b, inputs, in_nch, in_interp, pending, tmp))) return e;
+      pending.clear();
+      InputRef in{};
+      in.kind = IN_SIGNAL;
+      in.nch = cur_nch;
+      in.sig = tmp;
+      inputs.assign(1, in);
+      in_nch = cur_nch;
+    }
+    size_t j = i + 1;
+    while (j < ops.size() && j - i <= 2 && ops[j].kind == OP_GAIN && ops[j].p0.mode == 0 && ops[j].nch_in == cur_nch) j++;
+    SignalRef seg_out = out;
+    if (j < ops.size() || out.nch != cur_nch) {
+      int e = temp_signal(b, cur_nch, &seg_out);
+      if (e) return e;
+    }
+    Step st;
+    st.kind = 1;
+    BiquadStreamDesc& q = st.bq;
+    std::memset(&q, 0, sizeof q);
+    q.in = inputs[0];
+    q.coefs = reinterpret_cast<const double*>(o.ptr0);
+    q.state = reinterpret_cast<double*>(o.ptr1);
+    q.n_gain = (int)(j - i - 1);
+    for (size_t k = i + 1; k < j; k++) q.gain[k - i - 1] = ops[k].p0;
+    q.nch = cur_nch;
+    q.out = seg_out;
+    q.n_inst = b->n_inst;
+    q.n_tiles = b->n_tiles;
+    q.n_quanta = b->n_quanta;
+    st.profile_slot = slot_for(b, "biquad_stream_kernel");
+    b->steps.push_back(st);
+    InputRef in{};
+    in.kind = IN_SIGNAL;
+    in.nch = cur_nch;
+    in.sig = seg_out;
+    inputs.assign(1, in);
+    in_nch = cur_nch;
+    i = j;
+    if (i == ops.size() && seg_out.base == out.base) return 0;  // the streaming kernel wrote the final output
+  }
+  // trailing element-wise ops (or a pure channel-count change into `out`)
+  return push_chain_step(b, inputs, in_nch, in_interp, pending, out);
+}
+
 int build_plan(waa_batch* b) {
   const uint32_t N = (uint32_t)b->nodes.size();
   // processing order = reversed DFS post-order over outgoing edges in insertion order (graph.rs:331-487)
@@ -856,51 +970,14 @@ int build_plan(waa_batch* b) {
       if (e) return e;
       cur_nch = out_nch;
     }
-    if (ops.size() > MAX_OPS) return fail(WAA_ERR_OUT_OF_SCOPE, "more than %d fused ops in one chain", MAX_OPS);
-    for (auto& o : ops) cmax = std::max({cmax, o.nch_in, o.nch_out});
-    for (auto& o : ops)
-      if (o.kind == OP_BIQUAD && cmax > 2)
-        return fail(WAA_ERR_OUT_OF_SCOPE,
-                    "chains with a BiquadFilter are limited to 2 channels per signal on the device path of this round (needs %d)",
-                    cmax);
-    cd.n_ops = (int)ops.size();
-    for (size_t k = 0; k < ops.size(); k++) cd.ops[k] = ops[k];
-    cd.out = term.sig;
-    cd.n_inst = b->n_inst;
-    cd.n_tiles = b->n_tiles;
-    cd.n_quanta = b->n_quanta;
-    st.cmax = cmax;
-    st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : cmax <= 2 ? "chain_kernel<2>" : "chain_kernel<4+>");
-    // hot shape: single unmixed input -> Biquad(constant coefficients) -> constant gains: streaming kernel
-    {
-      bool fast = cd.n_inputs == 1 && (cd.in[0].kind == IN_SOURCE || cd.in[0].kind == IN_SIGNAL) &&
-                  cd.in[0].nch == cd.in_nch && cd.n_ops >= 1 && cd.n_ops <= 3 && cd.ops[0].kind == OP_BIQUAD &&
-                  cd.ops[0].i0 == 0 && cd.ops[0].nch_in == cd.in_nch && cd.out.nch == cd.in_nch;
-      for (int k = 1; fast && k < cd.n_ops; k++)
-        fast = cd.ops[k].kind == OP_GAIN && cd.ops[k].p0.mode == 0 && cd.ops[k].nch_in == cd.in_nch;
-      if (fast) {
-        st.kind = 1;
-        BiquadStreamDesc& q = st.bq;
-        std::memset(&q, 0, sizeof q);
-        q.coefs = reinterpret_cast<const double*>(cd.ops[0].ptr0);
-        q.state = reinterpret_cast<double*>(cd.ops[0].ptr1);
-        q.n_gain = cd.n_ops - 1;
-        for (int k = 1; k < cd.n_ops; k++) q.gain[k - 1] = cd.ops[k].p0;
-        q.nch = cd.in_nch;
-        q.out = cd.out;
-        q.n_inst = b->n_inst;
-        q.n_tiles = b->n_tiles;
-        q.n_quanta = b->n_quanta;
-        st.profile_slot = slot_for(b, "biquad_stream_kernel");
-      }
-    }
-    // source inputs
+    // source inputs: schedules / buffer tables / constant ranges
     if (cd.in[0].kind == IN_SOURCE || cd.in[0].kind == IN_CONSTANT) {
       int e = prepare_source_input(b, head, &cd.in[0]);
       if (e) return e;
     }
-    if (st.kind == 1) st.bq.in = cd.in[0];
-    b->steps.push_back(st);
+    std::vector<InputRef> inputs(cd.in, cd.in + cd.n_inputs);
+    int e = emit_segments(b, inputs, cd.in_nch, cd.in_interp, ops, term.sig);
+    if (e) return e;
   }
   b->planned = true;
   return 0;
