@@ -109,6 +109,20 @@ def cpu_baseline(waa, name, frames, target_wall=12.0):
             "rtf": n * (sample_frames / SR) / wall}
 
 
+def pmc_traffic(name, n_inst, frames):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes:
+    profiles/pmc_traffic.json records the numbers and their provenance).  null when no PMC data matches."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path)).get(name)
+        if rec and rec["contexts"] == n_inst and rec["frames"] == frames:
+            return rec["bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,12 +142,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    # one rank per GPU.  WAA_BENCH_BACKEND=gloo + WAA_BENCH_SHARE_GPU=1 let the N > 1 plumbing be exercised on a
+    # single-GPU box (ranks share device 0; RCCL refuses two ranks on one device) — never used for reported numbers.
+    backend = os.environ.get("WAA_BENCH_BACKEND", "nccl")
+    if os.environ.get("WAA_BENCH_SHARE_GPU") == "1":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     name = args.workload
     n_inst = args.instances or {"c2": 1024, "t1": 1024, "c3": 512, "c4": 512, "c5": 2048}[name]
@@ -154,7 +176,8 @@ def main():
     ctx.profile(True)
     ctx.profile_reset()
     elapsed = timed_steps(ctx.render_async, torch.cuda.synchronize, args.steps, args.warmup, dist=dist,
-                          device_tensor=lambda v: torch.tensor([v], dtype=torch.float64, device="cuda"))
+                          device_tensor=lambda v: torch.tensor([v], dtype=torch.float64,
+                                                               device="cuda" if backend == "nccl" else "cpu"))
     ctx.sync()
     # the warmup launches were also event-timed: normalise per launch below
 
@@ -195,7 +218,7 @@ def main():
                        "parallelism": f"{world} independent batch(es), no collective"},
             "real_time_factor": world * n_inst * args.seconds * args.steps / elapsed,
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": pmc_traffic(name, n_inst, frames),
                          "algorithmic_bytes_per_launch": alg_bytes_step,
                          "kernel_ms": kernel_ms, "launches_per_step": launches_per_step},
         }

@@ -143,8 +143,11 @@ typedef struct {
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
 
-/* device < 0: current HIP device.  length_frames / sample_rate / n_channels_out as in
- * OfflineAudioContext::new(number_of_channels, length, sample_rate). */
+/* device >= 0: that HIP device; -1: the current HIP device; WAA_DEVICE_PLAN_ONLY (-2): no device at all —
+ * the batch can be configured and planned (waa_plan_describe) but never rendered (host-logic tests, tooling).
+ * length_frames / sample_rate / n_channels_out as in OfflineAudioContext::new(number_of_channels, length,
+ * sample_rate). */
+#define WAA_DEVICE_PLAN_ONLY (-2)
 waa_status waa_batch_create(const waa_graph_desc* graph, uint32_t n_instances, uint32_t n_channels_out,
                             uint64_t length_frames, float sample_rate, int32_t device, waa_batch** out);
 void waa_batch_destroy(waa_batch* batch);
@@ -211,6 +214,14 @@ waa_status waa_analyser_get_float_time_domain_data(waa_batch* batch, uint32_t no
                                                    uint32_t n);
 waa_status waa_analyser_get_byte_time_domain_data(waa_batch* batch, uint32_t node, uint32_t instance, uint8_t* dst,
                                                   uint32_t n);
+
+/* ---- introspection --------------------------------------------------------------------- */
+
+/* Human-readable description of the launch plan the engine derived from the graph (one line per kernel
+ * launch / alias / resource: chain fusion, streaming-biquad segments, convolver block size and partitions,
+ * source schedules).  Builds the plan if necessary.  Writes at most cap-1 bytes + NUL; returns the full
+ * length through *needed (may be NULL). */
+waa_status waa_plan_describe(waa_batch* batch, char* buf, size_t cap, size_t* needed);
 
 /* ---- input prep + pure helpers (no batch) ---------------------------------------------- */
 

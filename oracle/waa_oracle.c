@@ -2295,6 +2295,17 @@ void orc_mix(const float* in, uint32_t from, uint32_t to, int32_t interp, float*
   for (uint32_t c = 0; c < to; c++) memcpy(out + (size_t)c * RQ, q.d[c], sizeof(float) * RQ);
 }
 
+waa_status orc_plan_describe(orc_batch* b, char* buf, size_t cap, size_t* needed) {
+  const char* text = "oracle: quantum-major interpreter (no launch plan)\n";
+  (void)b;
+  if (needed) *needed = strlen(text);
+  if (buf && cap) {
+    strncpy(buf, text, cap - 1);
+    buf[cap - 1] = 0;
+  }
+  return WAA_OK;
+}
+
 /* measurement API parity with the product (no-ops) */
 waa_status orc_profile_enable(orc_batch* b, int32_t on) {
   (void)b;

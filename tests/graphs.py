@@ -18,8 +18,12 @@ def garage_like_ir(frames=178899, n_ch=2, sr=48000.0, seed=7):
     frames => 175 partitions of 1024): exponentially decaying noise, ~1.2 s RT60-ish."""
     rng = np.random.default_rng(seed)
     t = np.arange(frames, dtype=np.float64) / sr
-    env = np.exp(-t / 0.35)
+    # decaying reverb tail over a noise floor (a recorded IR never decays to digital silence): after the
+    # reference's normalisation the last samples stay above FFTConvolver's 1e-6 trim threshold, so all 175
+    # reference partitions (22 device blocks of 8192) are exercised
+    env = np.exp(-t / 0.35) + 2e-3
     ir = (rng.uniform(-1.0, 1.0, (n_ch, frames)) * env).astype(np.float32)
+    ir[:, -1] = np.float32(0.5 * 2e-3)
     return ir
 
 

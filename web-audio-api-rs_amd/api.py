@@ -29,6 +29,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 RENDER_QUANTUM_SIZE = 128
+PLAN_ONLY = -2  # WAA_DEVICE_PLAN_ONLY: configure + plan without a device (never renders)
 ALL = 0xFFFFFFFF
 F64_MAX = 1.7976931348623157e308
 
@@ -99,6 +100,7 @@ ABI = {
     "buffer_resample": (C.c_uint64, [_FP, C.c_uint64, C.c_float, C.c_float, _FP, C.c_uint64]),
     "biquad_frequency_response": (C.c_int32, [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _FP,
                                               _FP, _FP, C.c_uint32]),
+    "plan_describe": (C.c_int32, [_VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "profile_enable": (C.c_int32, [_VP, C.c_int32]),
     "profile_count": (C.c_int32, [_VP]),
     "profile_get": (C.c_int32, [_VP, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
@@ -752,6 +754,15 @@ class OfflineAudioContext:
         out = np.empty((self.n_instances, self.number_of_channels, self.length), np.float32)
         self._b.check(self._b.download_all(self._handle, _fp(out)))
         return RenderedBatch(out, self.sample_rate)
+
+    def plan_describe(self) -> str:
+        """The launch plan derived from the graph (works on a plan-only context: device=PLAN_ONLY)."""
+        self.prepare()
+        need = C.c_size_t()
+        self._b.check(self._b.plan_describe(self._handle, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value + 1)
+        self._b.check(self._b.plan_describe(self._handle, buf, need.value + 1, None))
+        return buf.value.decode()
 
     def output_device(self):
         p, s_i, s_c = _VP(), C.c_uint64(), C.c_uint64()

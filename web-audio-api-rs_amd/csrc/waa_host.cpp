@@ -26,6 +26,9 @@ using namespace waa;
 
 struct waa_batch;
 static int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in);
+namespace {
+void plan_note(waa_batch* b, const char* fmt, ...);
+}
 
 namespace {
 
@@ -157,6 +160,8 @@ struct waa_batch {
   std::vector<Step> steps;
   bool planned = false;
   bool rendered = false;
+  bool dry = false;                  // WAA_DEVICE_PLAN_ONLY: allocations are host memory, nothing is launched
+  std::vector<std::string> plan_log;  // waa_plan_describe
   bool profiling = false;
   std::vector<ProfileEntry> prof;
 };
@@ -167,6 +172,15 @@ template <typename T>
 int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
   void* p = nullptr;
   size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  if (b->dry) {
+    // plan-only: big signal / spectrum buffers are never touched, so reserve address space lazily (calloc of a
+    // huge block is not committed until written) — small tables are really filled by dev_upload
+    p = std::calloc(1, bytes);
+    if (!p) return fail(WAA_ERR_DEVICE, "plan-only allocation of %zu bytes failed", bytes);
+    (payload ? b->payload_allocs : b->allocs).push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return 0;
+  }
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) return fail(WAA_ERR_DEVICE, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
   (payload ? b->payload_allocs : b->allocs).push_back(p);
@@ -177,7 +191,12 @@ template <typename T>
 int dev_upload(waa_batch* b, T** out, const std::vector<T>& host) {
   int e = dev_alloc(b, out, host.size());
   if (e) return e;
-  if (!host.empty()) HIP_TRY(hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (!host.empty()) {
+    if (b->dry)
+      std::memcpy(*out, host.data(), host.size() * sizeof(T));
+    else
+      HIP_TRY(hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -644,6 +663,34 @@ void topo_visit(const waa_batch* b, uint32_t id, std::vector<uint8_t>& marked, s
 int plan_convolver(waa_batch* b, uint32_t id);
 int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int interp);
 
+void plan_note(waa_batch* b, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  b->plan_log.emplace_back(buf);
+}
+const char* input_kind_name(int k) {
+  switch (k) {
+    case IN_SIGNAL: return "signal";
+    case IN_SOURCE: return "source";
+    case IN_CONSTANT: return "constant";
+    default: return "silent";
+  }
+}
+const char* op_name(int k) {
+  switch (k) {
+    case OP_GAIN: return "GAIN";
+    case OP_BIQUAD: return "BIQUAD";
+    case OP_WAVESHAPER: return "WAVESHAPER";
+    case OP_STEREO_PAN: return "STEREO_PAN";
+    case OP_PANNER: return "PANNER";
+    case OP_MIX: return "MIX";
+    default: return "?";
+  }
+}
+
 int slot_for(waa_batch* b, const char* name) {
   for (size_t i = 0; i < b->prof.size(); i++)
     if (b->prof[i].name == name) return (int)i;
@@ -686,6 +733,29 @@ int push_chain_step(waa_batch* b, const std::vector<InputRef>& inputs, int in_nc
   st.cmax = cmax;
   st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : cmax <= 2 ? "chain_kernel<2>" : "chain_kernel<4+>");
   b->steps.push_back(st);
+  {
+    bool serial = false;
+    std::string desc;
+    for (auto& o : ops) {
+      serial |= o.kind == OP_BIQUAD;
+      char t[64];
+      if (o.kind == OP_MIX)
+        snprintf(t, sizeof t, "MIX(%d->%d)", o.nch_in, o.nch_out);
+      else if (o.kind == OP_BIQUAD)
+        snprintf(t, sizeof t, "BIQUAD(%s)", o.i0 == 0 ? "const" : o.i0 == 1 ? "k-rate" : "a-rate");
+      else
+        snprintf(t, sizeof t, "%s", op_name(o.kind));
+      desc += desc.empty() ? t : std::string(",") + t;
+    }
+    std::string ins;
+    for (auto& in : inputs) {
+      char t[48];
+      snprintf(t, sizeof t, "%s:%dch", input_kind_name(in.kind), in.nch);
+      ins += ins.empty() ? t : std::string("+") + t;
+    }
+    plan_note(b, "chain %s C=%d in=[%s]->%dch ops=[%s] out=%dch", serial ? "serial" : "parallel", cmax, ins.c_str(), in_nch,
+              desc.c_str(), out.nch);
+  }
   return 0;
 }
 
@@ -757,6 +827,8 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     q.n_quanta = b->n_quanta;
     st.profile_slot = slot_for(b, "biquad_stream_kernel");
     b->steps.push_back(st);
+    plan_note(b, "biquad_stream in=%s:%dch gains=%d out=%s", input_kind_name(inputs[0].kind), cur_nch, q.n_gain,
+              seg_out.base == out.base ? "final" : "temp");
     InputRef in{};
     in.kind = IN_SIGNAL;
     in.nch = cur_nch;
@@ -892,6 +964,7 @@ int build_plan(waa_batch* b) {
                             (k == WAA_NODE_CONVOLVER && !term.has_ir) || (k == WAA_NODE_WAVESHAPER && !term.has_curve);
       if (identity && p.materialized && p.out_nch == term.in_nch && term.in_nch == term.out_nch) {
         term.sig = p.sig;
+        plan_note(b, "alias node %u -> output of node %u", id, b->edges[term.in_edges[0]].from);
         continue;
       }
     }
@@ -1023,6 +1096,7 @@ static int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
     e = dev_upload(b, &d, act);
     if (e) return e;
     in->active = d;
+    plan_note(b, "constant source node %u: active frames [%lld, %lld) for instance 0", id, (long long)act[0], (long long)act[1]);
     return 0;
   }
   // AudioBufferSourceNode
@@ -1053,6 +1127,17 @@ static int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
     }
     SchedOut so;
     schedule_source(b, n.sched[i], bf.frames, bf.sr, bf.valid, rate_q, det_q, &so);
+    {
+      uint32_t nf = 0, nl = 0, ns = 0, nt = 0;
+      for (auto& r : so.qrec) {
+        nf += r.mode == Q_FAST;
+        nl += r.mode == Q_FAST_LOOP;
+        ns += r.mode == Q_SLOW;
+      }
+      for (auto t : so.tile_fast) nt += t;
+      plan_note(b, "source node %u schedule %zu: quanta fast=%u fast_loop=%u slow=%u silent=%u fast_tiles=%u/%u", id,
+                scheds.size(), nf, nl, ns, (uint32_t)so.qrec.size() - nf - nl - ns, nt, b->n_tiles);
+    }
     SrcSchedule ds{};
     QRec* dq = nullptr;
     int e = dev_upload(b, &dq, so.qrec);
@@ -1080,6 +1165,7 @@ static int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   if (e) return e;
   in->src = d_insts;
   in->sched = d_scheds;
+  plan_note(b, "source node %u: %zu distinct schedule(s) for %u instance(s)", id, scheds.size(), b->n_inst);
   return 0;
 }
 
@@ -1114,6 +1200,7 @@ int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int inte
     partial.sig = cd.out;
     ins.erase(ins.begin(), ins.begin() + MAX_INPUTS);
     ins.insert(ins.begin(), partial);
+    plan_note(b, "fan-in partial sum of %d inputs -> %dch", MAX_INPUTS, in_nch);
   }
   return 0;
 }
@@ -1191,6 +1278,7 @@ int plan_convolver(waa_batch* b, uint32_t id) {
     z.zero_ptr = n.sig.base;
     z.zero_bytes = (size_t)b->n_inst * n.out_nch * b->lp * sizeof(float);
     b->steps.push_back(z);
+    plan_note(b, "convolver node %u: all-zero impulse response -> zero fill", id);
     return 0;
   }
   const bool direct_fir = len <= (uint64_t)DIRECT_MAX_TAPS;
@@ -1252,6 +1340,8 @@ int plan_convolver(waa_batch* b, uint32_t id) {
     st.kind = 4;
     st.slot_mac = slot_for(b, "conv_direct_kernel");
     b->steps.push_back(st);
+    plan_note(b, "convolver node %u: direct FIR taps=%llu cin=%d cout=%d terms=%d", id, (unsigned long long)len, cv.cin,
+              cv.cout, cv.n_terms);
     return 0;
   }
   std::vector<Cplx> tw(cv.n);
@@ -1269,8 +1359,12 @@ int plan_convolver(waa_batch* b, uint32_t id) {
   cv.H = dH;
   cv.X = dX;
   cv.Y = dY;
-  launch_conv_ir_spectra(cv, b->stream);  // control-side work of ConvolverNode::set_buffer, once
-  HIP_TRY(hipGetLastError());
+  if (!b->dry) {
+    launch_conv_ir_spectra(cv, b->stream);  // control-side work of ConvolverNode::set_buffer, once
+    HIP_TRY(hipGetLastError());
+  }
+  plan_note(b, "convolver node %u: fft B=%d N=%d P=%d blocks=%d pairs=%u cin=%d cout=%d terms=%d ir_len=%llu", id, cv.block,
+            cv.n, cv.parts, cv.nb, cv.n_pairs, cv.cin, cv.cout, cv.n_terms, (unsigned long long)len);
   st.slot_fwd = slot_for(b, "conv_fft_kernel<fwd>");
   st.slot_mac = slot_for(b, "conv_mac_kernel");
   st.slot_inv = slot_for(b, "conv_fft_kernel<inv>");
@@ -1620,6 +1714,12 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
       default: break;
     }
   }
+  if (device == WAA_DEVICE_PLAN_ONLY) {
+    b->dry = true;
+    b->device = -1;
+    *out = b.release();
+    return WAA_OK;
+  }
   // the device is only touched from here on; a machine without a GPU still validates graphs above
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1638,6 +1738,12 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
 
 void waa_batch_destroy(waa_batch* b) {
   if (!b) return;
+  if (b->dry) {
+    for (void* p : b->allocs) std::free(p);
+    for (void* p : b->payload_allocs) std::free(p);
+    delete b;
+    return;
+  }
   if (b->stream) {
     (void)hipStreamSynchronize(b->stream);
     for (auto& p : b->prof)
@@ -1659,7 +1765,12 @@ static int upload_buffer(waa_batch* b, const float* const* channels, uint32_t n_
   int e = dev_alloc(b, &d, (size_t)n_ch * std::max<uint64_t>(stride, 4), true);
   if (e) return e;
   for (uint32_t c = 0; c < n_ch; c++)
-    if (frames) HIP_TRY(hipMemcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float), hipMemcpyHostToDevice));
+    if (frames) {
+      if (b->dry)
+        std::memcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float));
+      else
+        HIP_TRY(hipMemcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float), hipMemcpyHostToDevice));
+    }
   out->base = d;
   out->ch_stride = stride;
   out->frames = frames;
@@ -1674,7 +1785,7 @@ waa_status waa_source_set_buffer(waa_batch* b, uint32_t node, uint32_t inst, con
   int e;
   if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
   if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
-  HIP_TRY(hipSetDevice(b->device));
+  if (!b->dry) HIP_TRY(hipSetDevice(b->device));
   DeviceBuffer db;
   if ((e = upload_buffer(b, channels, n_ch, frames, sr, &db))) return e;
   Node& n = b->nodes[node];
@@ -1688,11 +1799,11 @@ waa_status waa_source_set_buffer_batch(waa_batch* b, uint32_t node, const float*
   int e;
   if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_unplanned(b))) return e;
   if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
-  HIP_TRY(hipSetDevice(b->device));
+  if (!b->dry) HIP_TRY(hipSetDevice(b->device));
   const uint64_t stride = (frames + 3) / 4 * 4;
   float* d = nullptr;
   if ((e = dev_alloc(b, &d, (size_t)b->n_inst * n_ch * std::max<uint64_t>(stride, 4), true))) return e;
-  if (frames)
+  if (frames && !b->dry)
     HIP_TRY(hipMemcpy2D(d, stride * sizeof(float), data, frames * sizeof(float), frames * sizeof(float),
                         (size_t)b->n_inst * n_ch, hipMemcpyHostToDevice));
   Node& n = b->nodes[node];
@@ -1859,8 +1970,31 @@ waa_status waa_set_param_block(waa_batch* b, uint32_t node, uint32_t param, uint
   return WAA_OK;
 }
 
+waa_status waa_plan_describe(waa_batch* b, char* buf, size_t cap, size_t* needed) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (!b->planned) {
+    if (!b->dry) HIP_TRY(hipSetDevice(b->device));
+    int e = build_plan(b);
+    if (e) return e;
+  }
+  std::string text;
+  char head[256];
+  snprintf(head, sizeof head, "batch: %u instance(s) x %llu frames (%u quanta, %u tiles of %d) @ %g Hz, %u output channel(s)\n",
+           b->n_inst, (unsigned long long)b->length, b->n_quanta, b->n_tiles, TILE, (double)b->sr, b->n_out);
+  text += head;
+  for (auto& l : b->plan_log) text += l + "\n";
+  if (needed) *needed = text.size();
+  if (buf && cap) {
+    const size_t n = std::min(cap - 1, text.size());
+    std::memcpy(buf, text.data(), n);
+    buf[n] = 0;
+  }
+  return WAA_OK;
+}
+
 waa_status waa_render(waa_batch* b) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch (WAA_DEVICE_PLAN_ONLY) cannot render: there is no CPU fallback");
   HIP_TRY(hipSetDevice(b->device));
   if (!b->planned) {
     int e = build_plan(b);
@@ -1923,6 +2057,7 @@ static int drain_profile(waa_batch* b) {
 
 waa_status waa_sync(waa_batch* b) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch has no device");
   HIP_TRY(hipStreamSynchronize(b->stream));
   return drain_profile(b);
 }
@@ -1930,7 +2065,7 @@ waa_status waa_sync(waa_batch* b) {
 waa_status waa_download(waa_batch* b, uint32_t inst, uint32_t ch, float* dst, uint64_t frames) {
   if (!b || inst >= b->n_inst || ch >= b->n_out || frames > b->length)
     return fail(WAA_ERR_INVALID_ARGUMENT, "download out of range");
-  if (!b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
+  if (!b->planned || !b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   const SignalRef& s = b->nodes[0].sig;
@@ -1945,7 +2080,7 @@ waa_status waa_download(waa_batch* b, uint32_t inst, uint32_t ch, float* dst, ui
 
 waa_status waa_download_all(waa_batch* b, float* dst) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
-  if (!b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
+  if (!b->planned || !b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   const SignalRef& s = b->nodes[0].sig;
