@@ -277,47 +277,51 @@ __global__ void conv_fft_kernel(const ConvDesc d) {
   }
 }
 
-// Y_k = sum_terms sum_p H_p X_{k-p}, KT output blocks per thread, partitions in chunks of PC.
+// Y_k = sum_terms sum_p H_p X_{k-p}, KT output blocks per register tile, partitions in chunks of PC.
+// A thread owns one spectral position and walks ALL k-tiles of its (pair, output channel) in order, so the
+// (PC - 1) input spectra a tile shares with its predecessor were read by the same CU a moment ago (L2 / MALL
+// hits instead of HBM re-reads).
 template <int KT, int PC>
 __global__ __launch_bounds__(256) void conv_mac_kernel(const ConvDesc d) {
   const int pos = blockIdx.x * 256 + threadIdx.x;
-  const int k0 = blockIdx.y * KT;
-  const uint32_t pair = blockIdx.z / (uint32_t)d.cout;
-  const int co = (int)(blockIdx.z % (uint32_t)d.cout);
+  const uint32_t pair = blockIdx.y / (uint32_t)d.cout;
+  const int co = (int)(blockIdx.y % (uint32_t)d.cout);
   const int n = d.n, nb = d.nb, P = d.parts;
-  Cplx acc[KT];
+  Cplx* Yc = d.Y + ((uint64_t)pair * d.cout + co) * nb * n + pos;
+  for (int k0 = 0; k0 < nb; k0 += KT) {
+    Cplx acc[KT];
 #pragma unroll
-  for (int i = 0; i < KT; i++) acc[i] = Cplx{0.f, 0.f};
-  for (int t = 0; t < d.n_terms; t++) {
-    if (d.terms[t].out_ch != co) continue;
-    const Cplx* Hc = d.H + (uint64_t)d.terms[t].ir_ch * P * n + pos;
-    const Cplx* Xc = d.X + ((uint64_t)pair * d.cin + d.terms[t].in_ch) * nb * n + pos;
-    for (int pc0 = 0; pc0 < P; pc0 += PC) {
-      Cplx h[PC];
+    for (int i = 0; i < KT; i++) acc[i] = Cplx{0.f, 0.f};
+    for (int t = 0; t < d.n_terms; t++) {
+      if (d.terms[t].out_ch != co) continue;
+      const Cplx* Hc = d.H + (uint64_t)d.terms[t].ir_ch * P * n + pos;
+      const Cplx* Xc = d.X + ((uint64_t)pair * d.cin + d.terms[t].in_ch) * nb * n + pos;
+      for (int pc0 = 0; pc0 < P; pc0 += PC) {
+        Cplx h[PC];
 #pragma unroll
-      for (int i = 0; i < PC; i++) h[i] = (pc0 + i < P) ? Hc[(uint64_t)(pc0 + i) * n] : Cplx{0.f, 0.f};
-#pragma unroll
-      for (int jj = 0; jj < KT + PC - 1; jj++) {
-        const int j = k0 - pc0 - (PC - 1) + jj;
-        Cplx x = Cplx{0.f, 0.f};
-        if (j >= 0 && j < nb) x = Xc[(uint64_t)j * n];
-#pragma unroll
-        for (int i = 0; i < KT; i++) {
-          const int pl = i + (PC - 1) - jj;  // local partition index, compile-time after unrolling
-          if (pl >= 0 && pl < PC) {
-            acc[i].re = __builtin_fmaf(h[pl].re, x.re, acc[i].re);
-            acc[i].re = __builtin_fmaf(-h[pl].im, x.im, acc[i].re);
-            acc[i].im = __builtin_fmaf(h[pl].re, x.im, acc[i].im);
-            acc[i].im = __builtin_fmaf(h[pl].im, x.re, acc[i].im);
+        for (int i = 0; i < PC; i++) h[i] = (pc0 + i < P) ? Hc[(uint64_t)(pc0 + i) * n] : Cplx{0.f, 0.f};
+#pragma clang loop unroll(full)
+        for (int jj = 0; jj < KT + PC - 1; jj++) {
+          const int j = k0 - pc0 - (PC - 1) + jj;
+          Cplx x = Cplx{0.f, 0.f};
+          if (j >= 0 && j < nb) x = Xc[(uint64_t)j * n];
+#pragma clang loop unroll(full)
+          for (int i = 0; i < KT; i++) {
+            const int pl = i + (PC - 1) - jj;  // local partition index, compile-time after unrolling
+            if (pl >= 0 && pl < PC) {
+              acc[i].re = __builtin_fmaf(h[pl].re, x.re, acc[i].re);
+              acc[i].re = __builtin_fmaf(-h[pl].im, x.im, acc[i].re);
+              acc[i].im = __builtin_fmaf(h[pl].re, x.im, acc[i].im);
+              acc[i].im = __builtin_fmaf(h[pl].im, x.re, acc[i].im);
+            }
           }
         }
       }
     }
-  }
-  Cplx* Yc = d.Y + ((uint64_t)pair * d.cout + co) * nb * n + pos;
 #pragma unroll
-  for (int i = 0; i < KT; i++)
-    if (k0 + i < nb) Yc[(uint64_t)(k0 + i) * n] = acc[i];
+    for (int i = 0; i < KT; i++)
+      if (k0 + i < nb) Yc[(uint64_t)(k0 + i) * n] = acc[i];
+  }
 }
 
 // Short impulse responses (<= DIRECT_MAX_TAPS after trimming): direct time-domain FIR with f64 accumulation.
@@ -457,12 +461,11 @@ void launch_analyser(const AnalyserDesc& d, void* stream) {
   hipLaunchKernelGGL(analyser_kernel, dim3(1), dim3(fft_threads(M)), (size_t)M * sizeof(Cplx), (hipStream_t)stream, d);
 }
 void launch_conv_mac(const ConvDesc& d, void* stream) {
-  constexpr int KT = 16;
-  dim3 grid(d.n / 256, (d.nb + KT - 1) / KT, d.n_pairs * (uint32_t)d.cout);
+  dim3 grid(d.n / 256, d.n_pairs * (uint32_t)d.cout);
   if (d.parts <= 8)
-    hipLaunchKernelGGL((conv_mac_kernel<KT, 8>), grid, dim3(256), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL((conv_mac_kernel<16, 8>), grid, dim3(256), 0, (hipStream_t)stream, d);
   else
-    hipLaunchKernelGGL((conv_mac_kernel<KT, 24>), grid, dim3(256), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL((conv_mac_kernel<16, 24>), grid, dim3(256), 0, (hipStream_t)stream, d);
 }
 
 }  // namespace waa
