@@ -16,6 +16,8 @@
 // HBM-bound by design (8 B of traffic per frame-channel); no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "waa_internal.hpp"
 
 namespace waa {
@@ -94,7 +96,10 @@ __device__ __noinline__ void load_channel_generic(const InputRef& in, const SrcI
 
 }  // namespace
 
-__global__ __launch_bounds__(64, 2) void biquad_stream_kernel(const BiquadStreamDesc d) {
+// DBG is a measurement aid (WAA_STREAM_DEBUG): 0 = product kernel, 1 = same memory pattern without the recurrence,
+// 2 = recurrence without the stores (results are wrong by construction in modes 1 and 2)
+template <int DBG>
+__global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStreamDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const uint32_t wid = blockIdx.x;
   const uint32_t inst = wid / (uint32_t)d.nch;
@@ -207,7 +212,11 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel(const BiquadStream
             t.w *= g[k];
           }
         }
-      *reinterpret_cast<float4*>(op + j * 256 + lane * 4) = t;
+      if constexpr (DBG == 2) {
+        asm volatile("" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+      } else {
+        *reinterpret_cast<float4*>(op + j * 256 + lane * 4) = t;
+      }
     }
     lds_sync();
   };
@@ -221,6 +230,15 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel(const BiquadStream
       x[j * 4 + 1] = t.y;
       x[j * 4 + 2] = t.z;
       x[j * 4 + 3] = t.w;
+    }
+    if constexpr (DBG == 1) {
+      lds_sync();
+#pragma unroll
+      for (int j = 0; j < NV4; j++)
+        *reinterpret_cast<float4*>(lds_out + lane * LDS_ROW + j * 4) =
+            make_float4(x[j * 4 + 0], x[j * 4 + 1], x[j * 4 + 2], x[j * 4 + 3]);
+      lds_sync();
+      return;
     }
     // x history at the chunk boundary
     const float xm1 = __shfl_up(x[TILE_K - 1], 1, 64), xm2 = __shfl_up(x[TILE_K - 2], 1, 64);
@@ -364,8 +382,15 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel(const BiquadStream
 }
 
 void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
-  hipLaunchKernelGGL(biquad_stream_kernel, dim3(d.n_inst * (uint32_t)d.nch), dim3(64), 2 * 64 * LDS_ROW * sizeof(float),
-                     (hipStream_t)stream, d);
+  const dim3 grid(d.n_inst * (uint32_t)d.nch), block(64);
+  const size_t lds = 2 * 64 * LDS_ROW * sizeof(float);
+  const char* dbg = getenv("WAA_STREAM_DEBUG");  // measurement aid only, see profiles/r01_c2_memory_pattern.txt
+  if (dbg && dbg[0] == '1')
+    hipLaunchKernelGGL(biquad_stream_kernel_t<1>, grid, block, lds, (hipStream_t)stream, d);
+  else if (dbg && dbg[0] == '2')
+    hipLaunchKernelGGL(biquad_stream_kernel_t<2>, grid, block, lds, (hipStream_t)stream, d);
+  else
+    hipLaunchKernelGGL(biquad_stream_kernel_t<0>, grid, block, lds, (hipStream_t)stream, d);
 }
 
 }  // namespace waa
