@@ -428,3 +428,27 @@ def test_split_chains_biquads_with_elementwise_ops(hip, orc):
             ctx.close()
         assert rms_err(*outs).max() <= TOL, nch
         assert np.abs(outs[0] - outs[1]).max() <= 1e-6
+
+
+def test_k_rate_biquad_streaming_kernel(hip, orc):
+    """Per-quantum coefficient changes (k-rate automation of all four params, distinct per instance) on the
+    streaming kernel: per-lane matrices + general scan; includes degenerate coefficient sets mid-render."""
+    n, nq = 6, 70
+    noise = white_noise(n, 2, RQ * nq + 5)
+    rng = np.random.default_rng(21)
+    for ftype in ("lowpass", "peaking", "notch", "highshelf"):
+        outs = []
+        for b in (hip, orc):
+            ctx, nodes = c2(b, noise, ftype=ftype)
+            bq = nodes["biquad"]
+            for i in range(n):
+                f = np.geomspace(40.0 + 30 * i, 15000.0, nq).astype(np.float32)
+                f[nq // 2] = 24000.0 if i % 2 else 0.0  # degenerate sets (f == nyquist / 0) in the middle
+                bq.frequency.set_block(0, f, instance=i)
+                bq.q.set_block(5, rng.uniform(0.3, 8.0, nq - 10).astype(np.float32), instance=i)
+                bq.gain.set_block(0, rng.uniform(-12, 12, nq).astype(np.float32), instance=i)
+                bq.detune.set_block(20, rng.uniform(-300, 300, 20).astype(np.float32), instance=i)
+            outs.append(ctx.start_rendering_sync().data)
+            ctx.close()
+        assert rms_err(*outs).max() <= TOL, ftype
+        assert np.abs(outs[0] - outs[1]).max() <= 1e-6, ftype

@@ -46,6 +46,14 @@ __device__ __forceinline__ double row_shr(double v) {
   const int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, true);
   return __hiloint2double(hi2, lo2);
 }
+// same shift, but a lane without a source keeps `fallback` (used to compose with the identity map)
+template <int N>
+__device__ __forceinline__ double row_shr_keep(double v, double fallback) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(__double2loint(fallback), lo, 0x110 + N, 0xf, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(__double2hiint(fallback), hi, 0x110 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi2, lo2);
+}
 __device__ __forceinline__ double read_lane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -98,7 +106,9 @@ __device__ __noinline__ void load_channel_generic(const InputRef& in, const SrcI
 
 // DBG is a measurement aid (WAA_STREAM_DEBUG): 0 = product kernel, 1 = same memory pattern without the recurrence,
 // 2 = recurrence without the stores (results are wrong by construction in modes 1 and 2)
-template <int DBG>
+// VARY: coefficients change per render quantum (k-rate automation; d.coefs holds n_quanta sets per instance):
+// per-lane coefficients (4 lanes share a quantum), per-lane A = M^32, general scan of the affine maps.
+template <int DBG, bool VARY>
 __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStreamDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const uint32_t wid = blockIdx.x;
@@ -111,9 +121,9 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
   // hwreg(HW_REG_MODE = 1, offset 6, width 2)
   __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);
 
-  // coefficients (uniform per wave)
-  const double* cp = d.coefs + (uint64_t)inst * 5;
-  const double b0 = cp[0], b1 = cp[1], b2 = cp[2], a1 = cp[3], a2 = cp[4];
+  // coefficients: uniform per wave (constant params) or reloaded per tile and lane (VARY)
+  const double* cp = d.coefs + (uint64_t)inst * d.coef_stride;
+  double b0 = cp[0], b1 = cp[1], b2 = cp[2], a1 = cp[3], a2 = cp[4];
   // matrix powers of the 32-step state transition: A = M^32, M = [[-a1, -a2], [1, 0]] on (y[n-1], y[n-2])
   M2 A1;
   {
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
   const M2 A2 = mm(A1, A1), A4 = mm(A2, A2), A8 = mm(A4, A4), A16 = mm(A8, A8);
   // per-lane A^(lane % 16)
   M2 Aj = {1., 0., 0., 1.};
-  {
+  if constexpr (!VARY) {
     const int j = lane & 15;
     if (j & 1) Aj = mm(Aj, A1);
     if (j & 2) Aj = mm(Aj, A2);
@@ -240,6 +250,21 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
       lds_sync();
       return;
     }
+    M2 Al = A1;  // this lane's 32-step transition
+    if constexpr (VARY) {
+      uint32_t q = tile * QUANTA_PER_TILE + (lane >> 2);
+      if (q >= d.n_quanta) q = d.n_quanta - 1;
+      const double* cq = cp + (uint64_t)q * 5;
+      b0 = cq[0];
+      b1 = cq[1];
+      b2 = cq[2];
+      a1 = cq[3];
+      a2 = cq[4];
+      M2 m = {-a1, -a2, 1., 0.};
+#pragma unroll
+      for (int s = 0; s < 5; s++) m = mm(m, m);
+      Al = m;
+    }
     // x history at the chunk boundary
     const float xm1 = __shfl_up(x[TILE_K - 1], 1, 64), xm2 = __shfl_up(x[TILE_K - 2], 1, 64);
     double x1 = lane == 0 ? cx1 : (double)xm1;
@@ -258,42 +283,85 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
       z2 = z1;
       z1 = y;
     }
-    // in-row inclusive scan (rows of 16 lanes): R_l = sum_{i in row, i<=l} A^(l-i) z_i
-    double r1 = z1, r2 = z2;
-    {
-      double q1 = row_shr<1>(r1), q2 = row_shr<1>(r2);
-      r1 = __builtin_fma(A1.a, q1, __builtin_fma(A1.b, q2, r1));
-      r2 = __builtin_fma(A1.c, q1, __builtin_fma(A1.d, q2, r2));
-      q1 = row_shr<2>(r1);
-      q2 = row_shr<2>(r2);
-      r1 = __builtin_fma(A2.a, q1, __builtin_fma(A2.b, q2, r1));
-      r2 = __builtin_fma(A2.c, q1, __builtin_fma(A2.d, q2, r2));
-      q1 = row_shr<4>(r1);
-      q2 = row_shr<4>(r2);
-      r1 = __builtin_fma(A4.a, q1, __builtin_fma(A4.b, q2, r1));
-      r2 = __builtin_fma(A4.c, q1, __builtin_fma(A4.d, q2, r2));
-      q1 = row_shr<8>(r1);
-      q2 = row_shr<8>(r2);
-      r1 = __builtin_fma(A8.a, q1, __builtin_fma(A8.b, q2, r1));
-      r2 = __builtin_fma(A8.c, q1, __builtin_fma(A8.d, q2, r2));
+    double s1, s2;  // state entering this lane's chunk
+    if constexpr (!VARY) {
+      // in-row inclusive scan (rows of 16 lanes): R_l = sum_{i in row, i<=l} A^(l-i) z_i
+      double r1 = z1, r2 = z2;
+      {
+        double q1 = row_shr<1>(r1), q2 = row_shr<1>(r2);
+        r1 = __builtin_fma(A1.a, q1, __builtin_fma(A1.b, q2, r1));
+        r2 = __builtin_fma(A1.c, q1, __builtin_fma(A1.d, q2, r2));
+        q1 = row_shr<2>(r1);
+        q2 = row_shr<2>(r2);
+        r1 = __builtin_fma(A2.a, q1, __builtin_fma(A2.b, q2, r1));
+        r2 = __builtin_fma(A2.c, q1, __builtin_fma(A2.d, q2, r2));
+        q1 = row_shr<4>(r1);
+        q2 = row_shr<4>(r2);
+        r1 = __builtin_fma(A4.a, q1, __builtin_fma(A4.b, q2, r1));
+        r2 = __builtin_fma(A4.c, q1, __builtin_fma(A4.d, q2, r2));
+        q1 = row_shr<8>(r1);
+        q2 = row_shr<8>(r2);
+        r1 = __builtin_fma(A8.a, q1, __builtin_fma(A8.b, q2, r1));
+        r2 = __builtin_fma(A8.c, q1, __builtin_fma(A8.d, q2, r2));
+      }
+      // state entering each row: T0 = carried, T_{k+1} = A^16 T_k + R(end of row k)
+      const double e01 = read_lane(r1, 15), e02 = read_lane(r2, 15);
+      const double e11 = read_lane(r1, 31), e12 = read_lane(r2, 31);
+      const double e21 = read_lane(r1, 47), e22 = read_lane(r2, 47);
+      const double t01 = cy1, t02 = cy2;
+      const double t11 = __builtin_fma(A16.a, t01, __builtin_fma(A16.b, t02, e01));
+      const double t12 = __builtin_fma(A16.c, t01, __builtin_fma(A16.d, t02, e02));
+      const double t21 = __builtin_fma(A16.a, t11, __builtin_fma(A16.b, t12, e11));
+      const double t22 = __builtin_fma(A16.c, t11, __builtin_fma(A16.d, t12, e12));
+      const double t31 = __builtin_fma(A16.a, t21, __builtin_fma(A16.b, t22, e21));
+      const double t32 = __builtin_fma(A16.c, t21, __builtin_fma(A16.d, t22, e22));
+      const double T1 = row == 0 ? t01 : row == 1 ? t11 : row == 2 ? t21 : t31;
+      const double T2 = row == 0 ? t02 : row == 1 ? t12 : row == 2 ? t22 : t32;
+      // state entering this lane = A^(lane%16) * T_row + exclusive in-row scan
+      const double ex1 = row_shr<1>(r1), ex2 = row_shr<1>(r2);
+      s1 = __builtin_fma(Aj.a, T1, __builtin_fma(Aj.b, T2, ex1));
+      s2 = __builtin_fma(Aj.c, T1, __builtin_fma(Aj.d, T2, ex2));
+    } else {
+      // general case: every lane has its own map s -> Al s + z.  Inclusive in-row scan of the composed maps
+      // (P, r) with DPP row shifts (a lane without a source composes with the identity), then the row carries.
+      M2 P = Al;
+      double r1 = z1, r2 = z2;
+      auto step = [&](auto shr) __attribute__((always_inline)) {
+        M2 Q;
+        Q.a = shr(P.a, 1.);
+        Q.b = shr(P.b, 0.);
+        Q.c = shr(P.c, 0.);
+        Q.d = shr(P.d, 1.);
+        const double q1 = shr(r1, 0.), q2 = shr(r2, 0.);
+        r1 = __builtin_fma(P.a, q1, __builtin_fma(P.b, q2, r1));
+        r2 = __builtin_fma(P.c, q1, __builtin_fma(P.d, q2, r2));
+        P = mm(P, Q);
+      };
+      step([](double v, double idv) __attribute__((always_inline)) { return row_shr_keep<1>(v, idv); });
+      step([](double v, double idv) __attribute__((always_inline)) { return row_shr_keep<2>(v, idv); });
+      step([](double v, double idv) __attribute__((always_inline)) { return row_shr_keep<4>(v, idv); });
+      step([](double v, double idv) __attribute__((always_inline)) { return row_shr_keep<8>(v, idv); });
+      // state entering each row: T0 = carried, T_{k+1} = P(end of row k) T_k + r(end of row k)
+      double t1[4], t2[4];
+      t1[0] = cy1;
+      t2[0] = cy2;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int e = 16 * k + 15;
+        const double pa = read_lane(P.a, e), pb = read_lane(P.b, e), pc = read_lane(P.c, e), pd = read_lane(P.d, e);
+        const double e1 = read_lane(r1, e), e2 = read_lane(r2, e);
+        t1[k + 1] = __builtin_fma(pa, t1[k], __builtin_fma(pb, t2[k], e1));
+        t2[k + 1] = __builtin_fma(pc, t1[k], __builtin_fma(pd, t2[k], e2));
+      }
+      const double T1 = row == 0 ? t1[0] : row == 1 ? t1[1] : row == 2 ? t1[2] : t1[3];
+      const double T2 = row == 0 ? t2[0] : row == 1 ? t2[1] : row == 2 ? t2[2] : t2[3];
+      // exclusive composite of this lane within its row (identity for the first lane of a row)
+      const double xa = row_shr_keep<1>(P.a, 1.), xb = row_shr_keep<1>(P.b, 0.), xc = row_shr_keep<1>(P.c, 0.),
+                   xd = row_shr_keep<1>(P.d, 1.);
+      const double x1r = row_shr_keep<1>(r1, 0.), x2r = row_shr_keep<1>(r2, 0.);
+      s1 = __builtin_fma(xa, T1, __builtin_fma(xb, T2, x1r));
+      s2 = __builtin_fma(xc, T1, __builtin_fma(xd, T2, x2r));
     }
-    // state entering each row: T0 = carried, T_{k+1} = A^16 T_k + R(end of row k)
-    const double e01 = read_lane(r1, 15), e02 = read_lane(r2, 15);
-    const double e11 = read_lane(r1, 31), e12 = read_lane(r2, 31);
-    const double e21 = read_lane(r1, 47), e22 = read_lane(r2, 47);
-    const double t01 = cy1, t02 = cy2;
-    const double t11 = __builtin_fma(A16.a, t01, __builtin_fma(A16.b, t02, e01));
-    const double t12 = __builtin_fma(A16.c, t01, __builtin_fma(A16.d, t02, e02));
-    const double t21 = __builtin_fma(A16.a, t11, __builtin_fma(A16.b, t12, e11));
-    const double t22 = __builtin_fma(A16.c, t11, __builtin_fma(A16.d, t12, e12));
-    const double t31 = __builtin_fma(A16.a, t21, __builtin_fma(A16.b, t22, e21));
-    const double t32 = __builtin_fma(A16.c, t21, __builtin_fma(A16.d, t22, e22));
-    const double T1 = row == 0 ? t01 : row == 1 ? t11 : row == 2 ? t21 : t31;
-    const double T2 = row == 0 ? t02 : row == 1 ? t12 : row == 2 ? t22 : t32;
-    // state entering this lane = A^(lane%16) * T_row + exclusive in-row scan
-    const double ex1 = row_shr<1>(r1), ex2 = row_shr<1>(r2);
-    const double s1 = __builtin_fma(Aj.a, T1, __builtin_fma(Aj.b, T2, ex1));
-    const double s2 = __builtin_fma(Aj.c, T1, __builtin_fma(Aj.d, T2, ex2));
     // final pass in the reference's order
     double y1 = s1, y2 = s2;
     float badacc = 0.f;  // becomes NaN as soon as one output is inf/NaN (x * 0 + acc), off the critical path
@@ -385,12 +453,14 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
   const dim3 grid(d.n_inst * (uint32_t)d.nch), block(64);
   const size_t lds = 2 * 64 * LDS_ROW * sizeof(float);
   const char* dbg = getenv("WAA_STREAM_DEBUG");  // measurement aid only, see profiles/r01_c2_memory_pattern.txt
-  if (dbg && dbg[0] == '1')
-    hipLaunchKernelGGL(biquad_stream_kernel_t<1>, grid, block, lds, (hipStream_t)stream, d);
+  if (d.vary)
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, true>), grid, block, lds, (hipStream_t)stream, d);
+  else if (dbg && dbg[0] == '1')
+    hipLaunchKernelGGL((biquad_stream_kernel_t<1, false>), grid, block, lds, (hipStream_t)stream, d);
   else if (dbg && dbg[0] == '2')
-    hipLaunchKernelGGL(biquad_stream_kernel_t<2>, grid, block, lds, (hipStream_t)stream, d);
+    hipLaunchKernelGGL((biquad_stream_kernel_t<2, false>), grid, block, lds, (hipStream_t)stream, d);
   else
-    hipLaunchKernelGGL(biquad_stream_kernel_t<0>, grid, block, lds, (hipStream_t)stream, d);
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, false>), grid, block, lds, (hipStream_t)stream, d);
 }
 
 }  // namespace waa

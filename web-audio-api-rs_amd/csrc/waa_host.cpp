@@ -775,14 +775,14 @@ int temp_signal(waa_batch* b, int nch, SignalRef* out) {
 int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in_interp, const std::vector<OpDesc>& ops,
                   const SignalRef& out) {
   bool any_stream = false;
-  for (auto& o : ops) any_stream |= (o.kind == OP_BIQUAD && o.i0 == 0 && o.nch_in <= 2);
+  for (auto& o : ops) any_stream |= (o.kind == OP_BIQUAD && o.i0 <= 1 && o.nch_in <= 2);
   if (!any_stream) return push_chain_step(b, inputs, in_nch, in_interp, ops, out);
   std::vector<OpDesc> pending;
   int cur_nch = in_nch;
   size_t i = 0;
   while (i < ops.size()) {
     const OpDesc& o = ops[i];
-    if (!(o.kind == OP_BIQUAD && o.i0 == 0 && o.nch_in <= 2)) {
+    if (!(o.kind == OP_BIQUAD && o.i0 <= 1 && o.nch_in <= 2)) {
       pending.push_back(o);
       cur_nch = o.nch_out;
       i++;
@@ -817,6 +817,8 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     std::memset(&q, 0, sizeof q);
     q.in = inputs[0];
     q.coefs = reinterpret_cast<const double*>(o.ptr0);
+    q.coef_stride = o.u0;
+    q.vary = o.i0 == 1;
     q.state = reinterpret_cast<double*>(o.ptr1);
     q.n_gain = (int)(j - i - 1);
     for (size_t k = i + 1; k < j; k++) q.gain[k - i - 1] = ops[k].p0;
@@ -827,8 +829,8 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     q.n_quanta = b->n_quanta;
     st.profile_slot = slot_for(b, "biquad_stream_kernel");
     b->steps.push_back(st);
-    plan_note(b, "biquad_stream in=%s:%dch gains=%d out=%s", input_kind_name(inputs[0].kind), cur_nch, q.n_gain,
-              seg_out.base == out.base ? "final" : "temp");
+    plan_note(b, "biquad_stream%s in=%s:%dch gains=%d out=%s", q.vary ? "(k-rate)" : "", input_kind_name(inputs[0].kind),
+              cur_nch, q.n_gain, seg_out.base == out.base ? "final" : "temp");
     InputRef in{};
     in.kind = IN_SIGNAL;
     in.nch = cur_nch;

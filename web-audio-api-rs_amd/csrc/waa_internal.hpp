@@ -116,7 +116,10 @@ struct ChainDesc {
 // -> up to 2 k-rate-constant gains -> output; one wavefront per (instance, channel).
 struct BiquadStreamDesc {
   InputRef in;
-  const double* coefs;   // [n_inst][5]
+  const double* coefs;   // [n_inst][coef_stride]: 5 per instance, or 5 per (instance, quantum) when vary
+  uint64_t coef_stride;  // doubles per instance
+  int32_t vary;          // 1: per-quantum coefficients (k-rate automation)
+  int32_t pad0;
   double* state;         // [n_inst][STATE_STRIDE]
   ParamRef gain[2];      // mode 0 only
   int32_t n_gain;
