@@ -35,9 +35,13 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
     if noise_ptr is not None:
         src.adopt_device_buffer(noise_ptr, 2, frames, SR)
     node = src
-    if name in ("c2", "t1", "c4"):
-        node = node.connect(ctx.create_biquad_filter(type_="lowpass", frequency=200.0, q=1.0))
-    if name == "c2":
+    if name in ("c2", "c2k", "t1", "c4"):
+        bq = ctx.create_biquad_filter(type_="lowpass", frequency=200.0, q=1.0)
+        if name == "c2k":  # k-rate automation: the cutoff sweeps 100 Hz -> 8 kHz, one value per render quantum
+            nq = (frames + RQ - 1) // RQ
+            bq.frequency.set_block(0, np.geomspace(100.0, 8000.0, nq).astype(np.float32))
+        node = node.connect(bq)
+    if name in ("c2", "c2k"):
         node = node.connect(ctx.create_gain(gain=0.5))
     if name in ("t1", "c3", "c4"):
         from graphs import garage_like_ir
@@ -57,8 +61,9 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
 
 
 # algorithmic bytes per context-quantum
-ALG_BYTES = {"c2": 2048.0, "c5": 2560.0, "c3": 362848.0, "t1": 362848.0 + 2048.0, "c4": 362848.0 + 2048.0 + 512.0}
+ALG_BYTES = {"c2": 2048.0, "c2k": 2048.0, "c5": 2560.0, "c3": 362848.0, "t1": 362848.0 + 2048.0, "c4": 362848.0 + 2048.0 + 512.0}
 DESCR = {
+    "c2k": "C2 with k-rate automation: {n} contexts x {s:g} s, Biquad cutoff swept per render quantum ->Gain(0.5)->destination",
     "c2": "C2: {n} OfflineAudioContexts x {s:g} s @48kHz stereo, BufferSource->Biquad(lowpass 200Hz,Q1)->Gain(0.5)->destination",
     "t1": "T1: {n} contexts x {s:g} s, BufferSource->Biquad->Convolver(2ch x 178899-frame IR, 175 partitions)->destination",
     "c3": "C3: {n} contexts x {s:g} s, BufferSource->Convolver(2ch x 178899-frame IR)->destination",
@@ -158,7 +163,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     name = args.workload
-    n_inst = args.instances or {"c2": 1024, "t1": 1024, "c3": 512, "c4": 512, "c5": 2048}[name]
+    n_inst = args.instances or {"c2": 1024, "c2k": 1024, "t1": 1024, "c3": 512, "c4": 512, "c5": 2048}[name]
     frames = int(round(args.seconds * SR))
     nq = (frames + RQ - 1) // RQ
     hip = waa.default_binding()
@@ -211,7 +216,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if name in ("c2", "t1", "c4") else "f32",
+            "dtype": "f64" if name in ("c2", "c2k", "t1", "c4") else "f32",
             "data": "synthetic",
             "config": {"workload": DESCR[name].format(n=n_inst, s=args.seconds), "contexts_per_gpu": n_inst,
                        "sample_rate": SR, "render_seconds": args.seconds, "quanta_per_context": nq,

@@ -436,6 +436,9 @@ def test_k_rate_biquad_streaming_kernel(hip, orc):
     n, nq = 6, 70
     noise = white_noise(n, 2, RQ * nq + 5)
     rng = np.random.default_rng(21)
+    qv = rng.uniform(0.3, 8.0, (n, nq - 10)).astype(np.float32)
+    gv = rng.uniform(-12, 12, (n, nq)).astype(np.float32)
+    dv = rng.uniform(-300, 300, (n, 20)).astype(np.float32)
     for ftype in ("lowpass", "peaking", "notch", "highshelf"):
         outs = []
         for b in (hip, orc):
@@ -445,9 +448,9 @@ def test_k_rate_biquad_streaming_kernel(hip, orc):
                 f = np.geomspace(40.0 + 30 * i, 15000.0, nq).astype(np.float32)
                 f[nq // 2] = 24000.0 if i % 2 else 0.0  # degenerate sets (f == nyquist / 0) in the middle
                 bq.frequency.set_block(0, f, instance=i)
-                bq.q.set_block(5, rng.uniform(0.3, 8.0, nq - 10).astype(np.float32), instance=i)
-                bq.gain.set_block(0, rng.uniform(-12, 12, nq).astype(np.float32), instance=i)
-                bq.detune.set_block(20, rng.uniform(-300, 300, 20).astype(np.float32), instance=i)
+                bq.q.set_block(5, qv[i], instance=i)
+                bq.gain.set_block(0, gv[i], instance=i)
+                bq.detune.set_block(20, dv[i], instance=i)
             outs.append(ctx.start_rendering_sync().data)
             ctx.close()
         assert rms_err(*outs).max() <= TOL, ftype

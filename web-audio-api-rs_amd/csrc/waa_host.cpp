@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -775,14 +776,15 @@ int temp_signal(waa_batch* b, int nch, SignalRef* out) {
 int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in_interp, const std::vector<OpDesc>& ops,
                   const SignalRef& out) {
   bool any_stream = false;
-  for (auto& o : ops) any_stream |= (o.kind == OP_BIQUAD && o.i0 <= 1 && o.nch_in <= 2);
+  const int max_mode = getenv("WAA_NO_KRATE_STREAM") ? 0 : 1;  // debugging aid: force k-rate biquads onto the interpreter
+  for (auto& o : ops) any_stream |= (o.kind == OP_BIQUAD && o.i0 <= max_mode && o.nch_in <= 2);
   if (!any_stream) return push_chain_step(b, inputs, in_nch, in_interp, ops, out);
   std::vector<OpDesc> pending;
   int cur_nch = in_nch;
   size_t i = 0;
   while (i < ops.size()) {
     const OpDesc& o = ops[i];
-    if (!(o.kind == OP_BIQUAD && o.i0 <= 1 && o.nch_in <= 2)) {
+    if (!(o.kind == OP_BIQUAD && o.i0 <= max_mode && o.nch_in <= 2)) {
       pending.push_back(o);
       cur_nch = o.nch_out;
       i++;
