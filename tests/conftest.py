@@ -38,9 +38,16 @@ def orc_lib(orc):
 
 @pytest.fixture(scope="session")
 def hip():
-    """ctypes binding of the product library; fails loudly if it is not built."""
+    """ctypes binding of the product library.  Built in-tree with hipcc (cross-compiles without a GPU) if the
+    shared object is missing or older than its sources; there is no fallback if that fails."""
     import web_audio_api_rs_amd as waa
 
+    csrc = os.path.join(ROOT, "web-audio-api-rs_amd", "csrc")
+    lib = waa.LIB_PATH
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".hpp"))]
+    srcs.append(os.path.join(ROOT, "include", "waa_hip.h"))
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", csrc, "-j4"])
     return waa.default_binding()
 
 

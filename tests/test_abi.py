@@ -19,7 +19,7 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(waa_[a-z_0-9]+)\s*\(", text)))
 
 
-def test_header_symbols_exported_by_product_library():
+def test_header_symbols_exported_by_product_library(hip):
     lib = ctypes.CDLL(waa.LIB_PATH)
     syms = declared_symbols()
     assert len(syms) >= 29
