@@ -49,6 +49,10 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
     if name == "c4":
         node = node.connect(ctx.create_stereo_panner(pan=0.1))
         node = node.connect(ctx.create_analyser(fft_size=2048, smoothing_time_constant=0.8))
+    if name.startswith("iir"):  # IIRFilterNode, Butterworth low-pass of the given order
+        from scipy import signal
+        b, a = signal.butter(int(name[3:]), 0.25)
+        node = node.connect(ctx.create_iir_filter(b, a))
     if name == "c5":
         src.playback_rate.set_value(1.5)
         src.set_loop(True)
@@ -62,6 +66,9 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
 
 # algorithmic bytes per context-quantum
 ALG_BYTES = {"c2": 2048.0, "c2k": 2048.0, "c5": 2560.0, "c3": 362848.0, "t1": 362848.0 + 2048.0, "c4": 362848.0 + 2048.0 + 512.0}
+IIR_ORDERS = (2, 4, 8, 12, 19)
+for _o in IIR_ORDERS:
+    ALG_BYTES[f"iir{_o}"] = 2048.0
 DESCR = {
     "c2k": "C2 with k-rate automation: {n} contexts x {s:g} s, Biquad cutoff swept per render quantum ->Gain(0.5)->destination",
     "c2": "C2: {n} OfflineAudioContexts x {s:g} s @48kHz stereo, BufferSource->Biquad(lowpass 200Hz,Q1)->Gain(0.5)->destination",
@@ -70,6 +77,8 @@ DESCR = {
     "c4": "C4: {n} contexts x {s:g} s, BufferSource->Biquad->Convolver->StereoPanner->Analyser->destination",
     "c5": "C5: {n} contexts x {s:g} s, BufferSource(playbackRate 1.5, loop)->WaveShaper(2048-pt)->destination",
 }
+for _o in IIR_ORDERS:
+    DESCR[f"iir{_o}"] = "IIR: {n} contexts x {s:g} s, BufferSource->IIRFilter(Butterworth order %d)->destination" % _o
 
 
 def cpu_baseline(waa, name, frames, target_wall=12.0):
@@ -163,7 +172,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     name = args.workload
-    n_inst = args.instances or {"c2": 1024, "c2k": 1024, "t1": 1024, "c3": 512, "c4": 512, "c5": 2048}[name]
+    n_inst = args.instances or {"c2": 1024, "c2k": 1024, "t1": 1024, "c3": 512, "c4": 512, "c5": 2048}.get(name, 1024)
     frames = int(round(args.seconds * SR))
     nq = (frames + RQ - 1) // RQ
     hip = waa.default_binding()
@@ -216,7 +225,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if name in ("c2", "c2k", "t1", "c4") else "f32",
+            "dtype": "f64" if name in ("c2", "c2k", "t1", "c4") or name.startswith("iir") else "f32",
             "data": "synthetic",
             "config": {"workload": DESCR[name].format(n=n_inst, s=args.seconds), "contexts_per_gpu": n_inst,
                        "sample_rate": SR, "render_seconds": args.seconds, "quanta_per_context": nq,

@@ -14,6 +14,8 @@
  *                                                                             src/node/audio_buffer_source.rs:388-398
  *   waa_convolver_set_buffer    ConvolverNode::set_buffer                     src/node/convolver.rs:259-317
  *   waa_waveshaper_set_curve    WaveShaperNode::set_curve                     src/node/waveshaper.rs:489-509 (onmessage)
+ *   waa_iir_set_coefficients    IIRFilterNode::new(IIRFilterOptions)          src/node/iir_filter.rs:163-189
+ *   waa_iir_frequency_response  IIRFilterNode::get_frequency_response         src/node/iir_filter.rs:218-262
  *   waa_set_param_const/block   AudioParamValues::get (len 1 / len 128)       src/render/processor.rs:186-229
  *                               (the automation timeline itself stays on the host: src/param.rs:685-797)
  *   waa_render                  OfflineAudioContext::start_rendering_sync     src/context/offline.rs:157-185
@@ -70,7 +72,8 @@ enum {
   WAA_NODE_ANALYSER = 7,        /* src/node/analyser.rs:265-290      */
   WAA_NODE_WAVESHAPER = 8,      /* src/node/waveshaper.rs:383-487 (oversample None only) */
   WAA_NODE_CONSTANT_SOURCE = 9, /* src/node/constant_source.rs:190-275 */
-  WAA_NODE_KIND_COUNT = 10
+  WAA_NODE_IIR_FILTER = 10,     /* src/node/iir_filter.rs:323-405 */
+  WAA_NODE_KIND_COUNT = 11
 };
 
 /* src/node/audio_node.rs ChannelCountMode / ChannelInterpretation */
@@ -181,6 +184,12 @@ waa_status waa_source_set_loop(waa_batch* batch, uint32_t node, uint32_t instanc
 waa_status waa_convolver_set_buffer(waa_batch* batch, uint32_t node, const float* const* channels,
                                     uint32_t n_channels, uint64_t frames, float sample_rate);
 waa_status waa_waveshaper_set_curve(waa_batch* batch, uint32_t node, const float* curve, uint32_t n);
+/* IIRFilterOptions{feedforward, feedback} (src/node/iir_filter.rs:63-72), shared by all instances; required
+ * before waa_render.  1..20 coefficients each (NotSupportedError otherwise), feedforward not all zero and
+ * feedback[0] != 0 (InvalidStateError), iir_filter.rs:17-46. */
+#define WAA_MAX_IIR_COEFFS 20
+waa_status waa_iir_set_coefficients(waa_batch* batch, uint32_t node, const double* feedforward, uint32_t n_feedforward,
+                                    const double* feedback, uint32_t n_feedback);
 
 /* ---- AudioParam values (computed by the host-side automation) -------------------------- */
 
@@ -233,6 +242,11 @@ uint64_t waa_buffer_resample(const float* src, uint64_t frames, float source_sam
 waa_status waa_biquad_frequency_response(int32_t type, float sample_rate, float frequency, float detune, float q,
                                          float gain, const float* frequency_hz, float* mag, float* phase,
                                          uint32_t n);
+/* IIRFilterNode::get_frequency_response (src/node/iir_filter.rs:218-262); frequencies outside
+ * [0, sample_rate/2] give NaN. */
+waa_status waa_iir_frequency_response(const double* feedforward, uint32_t n_feedforward, const double* feedback,
+                                      uint32_t n_feedback, float sample_rate, const float* frequency_hz, float* mag,
+                                      float* phase, uint32_t n);
 
 /* ---- measurement ----------------------------------------------------------------------- */
 

@@ -549,6 +549,9 @@ typedef struct {
   uint32_t curve_n;
   int has_curve;
   int can_propagate_silence;
+  /* iir filter (shared): normalised (b, a) pairs, iir_filter.rs:273-311 */
+  double iir_b[WAA_MAX_IIR_COEFFS], iir_a[WAA_MAX_IIR_COEFFS];
+  int iir_len;
 } NodeCfg;
 
 typedef struct {
@@ -556,6 +559,9 @@ typedef struct {
   /* biquad */
   double xy[ORC_MAXC][4];
   int xy_len;
+  /* iir filter: per-channel state, iir_filter.rs:269 */
+  double iir_state[ORC_MAXC][WAA_MAX_IIR_COEFFS];
+  int iir_nch;
   /* buffer source render state (audio_buffer_source.rs:352-370) */
   double buffer_time, buffer_time_elapsed;
   double start_time, stop_time, offset, duration;
@@ -1055,6 +1061,32 @@ waa_status orc_waveshaper_set_curve(orc_batch* b, uint32_t node, const float* cu
   return WAA_OK;
 }
 
+/* iir_filter.rs:17-46 (validation), :273-311 (IirFilterRenderer::new: pad to equal length, normalise by a0) */
+waa_status orc_iir_set_coefficients(orc_batch* b, uint32_t node, const double* ff, uint32_t nff, const double* fb,
+                                    uint32_t nfb) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_IIR_FILTER))) return e;
+  if (!ff || nff == 0 || nff > WAA_MAX_IIR_COEFFS)
+    return fail(WAA_ERR_NOT_SUPPORTED,
+                "NotSupportedError - IIR Filter feedforward coefficients should have length >= 0 and <= %d", WAA_MAX_IIR_COEFFS);
+  int all_zero = 1;
+  for (uint32_t i = 0; i < nff; i++) all_zero &= ff[i] == 0.;
+  if (all_zero) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIR Filter feedforward coefficients cannot be all zeros");
+  if (!fb || nfb == 0 || nfb > WAA_MAX_IIR_COEFFS)
+    return fail(WAA_ERR_NOT_SUPPORTED,
+                "NotSupportedError - IIR Filter feedback coefficients should have length >= 0 and <= %d", WAA_MAX_IIR_COEFFS);
+  if (fb[0] == 0.) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIR Filter feedback first coefficient cannot be zero");
+  NodeCfg* n = &b->nodes[node];
+  uint32_t len = nff > nfb ? nff : nfb;
+  double a0 = fb[0];
+  for (uint32_t i = 0; i < len; i++) {
+    n->iir_b[i] = (i < nff ? ff[i] : 0.) / a0;
+    n->iir_a[i] = (i < nfb ? fb[i] : 0.) / a0;
+  }
+  n->iir_len = (int)len;
+  return WAA_OK;
+}
+
 waa_status orc_set_param_const(orc_batch* b, uint32_t node, uint32_t param, uint32_t inst, float value) {
   int e;
   if (!b || node >= b->n_nodes || (int)param >= b->nodes[node].n_params)
@@ -1237,6 +1269,37 @@ waa_status orc_biquad_frequency_response(int32_t type, float sample_rate, float 
     double nr = c.b0 + (tr * zr - ti * zi), ni = tr * zi + ti * zr;
     double ur = c.a1 + c.a2 * zr, ui = c.a2 * zi;
     double dr = 1. + (ur * zr - ui * zi), di = ur * zi + ui * zr;
+    double den = dr * dr + di * di;
+    double rr = (nr * dr + ni * di) / den, ri = (ni * dr - nr * di) / den;
+    mag[i] = (float)hypot(rr, ri);
+    phase[i] = (float)atan2(ri, rr);
+  }
+  return WAA_OK;
+}
+
+/* iir_filter.rs:218-262 */
+waa_status orc_iir_frequency_response(const double* ff, uint32_t nff, const double* fb, uint32_t nfb, float sample_rate,
+                                      const float* hz, float* mag, float* phase, uint32_t n) {
+  if (!ff || !fb || nff == 0 || nfb == 0 || nff > WAA_MAX_IIR_COEFFS || nfb > WAA_MAX_IIR_COEFFS)
+    return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - invalid IIR coefficient arrays");
+  double sr = (double)sample_rate, nyq = sr / 2.;
+  for (uint32_t i = 0; i < n; i++) {
+    double freq = (double)hz[i];
+    if (freq < 0. || freq > nyq) {
+      mag[i] = NAN;
+      phase[i] = NAN;
+      continue;
+    }
+    double z = -2.0 * M_PI * freq / sr;
+    double nr = 0., ni = 0., dr = 0., di = 0.;
+    for (uint32_t k = 0; k < nff; k++) {
+      nr += ff[k] * cos((double)k * z);
+      ni += ff[k] * sin((double)k * z);
+    }
+    for (uint32_t k = 0; k < nfb; k++) {
+      dr += fb[k] * cos((double)k * z);
+      di += fb[k] * sin((double)k * z);
+    }
     double den = dr * dr + di * di;
     double rr = (nr * dr + ni * di) / den, ri = (ni * dr - nr * di) / den;
     mag[i] = (float)hypot(rr, ri);
@@ -1560,6 +1623,53 @@ static void process_biquad(NodeCfg* n, NodeState* s, uint32_t inst, const Scope*
     s->xy[c][1] = x2;
     s->xy[c][2] = y1;
     s->xy[c][3] = y2;
+  }
+}
+
+/* src/node/iir_filter.rs:323-405 (f64 transposed direct form II) */
+static void process_iir(NodeCfg* n, NodeState* s) {
+  const Quantum* input = &s->in;
+  Quantum* output = &s->out;
+  const int len = n->iir_len;
+  int in_silent = q_is_silent(input);
+  if (s->iir_nch == 0) s->iir_nch = 2; /* "eagerly assume stereo input", :303-306 */
+  if (in_silent) {
+    int ended = 1;
+    for (int c = 0; c < s->iir_nch && ended; c++)
+      for (int j = 0; j < len; j++)
+        if (isnormal(s->iir_state[c][j])) {
+          ended = 0;
+          break;
+        }
+    if (ended) {
+      q_make_silent(output);
+      return;
+    }
+  }
+  if (!in_silent) {
+    int nc = input->n;
+    if (nc != s->iir_nch) {
+      for (int c = s->iir_nch; c < nc; c++) memset(s->iir_state[c], 0, sizeof s->iir_state[c]);
+      s->iir_nch = nc;
+    }
+    q_set_number_of_channels(output, nc);
+  } else {
+    q_set_number_of_channels(output, s->iir_nch);
+  }
+  for (int c = 0; c < output->n; c++) {
+    const float* in = in_silent ? input->d[0] : input->d[c];
+    double* st = s->iir_state[c];
+    for (int i = 0; i < RQ; i++) {
+      double x = (double)in[i];
+      double y = fma(n->iir_b[0], x, st[0]);
+      if (!isnormal(y)) y = 0.;
+      for (int k = 1; k < len; k++) {
+        double next = k < WAA_MAX_IIR_COEFFS ? st[k] : 0.;
+        st[k - 1] = n->iir_b[k] * x - n->iir_a[k] * y + next;
+      }
+      output->d[c][i] = (float)y;
+    }
+    output->silent[c] = 0;
   }
 }
 
@@ -1962,6 +2072,7 @@ static void process_node(orc_batch* b, uint32_t id, uint32_t inst, const Scope* 
     case WAA_NODE_BUFFER_SOURCE: process_buffer_source(b, n, s, inst, sc); break;
     case WAA_NODE_CONSTANT_SOURCE: process_constant_source(n, s, inst, sc); break;
     case WAA_NODE_BIQUAD: process_biquad(n, s, inst, sc); break;
+    case WAA_NODE_IIR_FILTER: process_iir(n, s); break;
     case WAA_NODE_GAIN: process_gain(n, s, inst, sc); break;
     case WAA_NODE_STEREO_PANNER: process_stereo_panner(n, s, inst, sc); break;
     case WAA_NODE_PANNER: process_panner(n, s, inst, sc); break;
@@ -2067,6 +2178,9 @@ waa_status orc_render(orc_batch* b) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
   if (b->rendered) /* offline.rs:163 */
     return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot call `startRendering` twice");
+  for (uint32_t i = 0; i < b->n_nodes; i++) /* the reference takes the coefficients in the constructor */
+    if (b->nodes[i].desc.kind == WAA_NODE_IIR_FILTER && b->nodes[i].iir_len == 0)
+      return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIRFilterNode %u has no coefficients", i);
   b->rendered = 1;
   int nt = b->n_threads;
   if ((uint32_t)nt > b->n_inst) nt = (int)b->n_inst;

@@ -36,6 +36,8 @@ F64_MAX = 1.7976931348623157e308
 # node kinds / enums (include/waa_hip.h)
 NODE_DESTINATION, NODE_BUFFER_SOURCE, NODE_BIQUAD, NODE_GAIN, NODE_CONVOLVER = 0, 1, 2, 3, 4
 NODE_STEREO_PANNER, NODE_PANNER, NODE_ANALYSER, NODE_WAVESHAPER, NODE_CONSTANT_SOURCE = 5, 6, 7, 8, 9
+NODE_IIR_FILTER = 10
+MAX_IIR_COEFFS = 20
 COUNT_MODE = {"max": 0, "clamped-max": 1, "explicit": 2}
 INTERPRETATION = {"speakers": 0, "discrete": 1}
 BIQUAD_TYPE = {"lowpass": 0, "highpass": 1, "bandpass": 2, "notch": 3, "allpass": 4, "peaking": 5,
@@ -68,6 +70,7 @@ class GraphDesc(C.Structure):
 
 
 _FP = C.POINTER(C.c_float)
+_DP = C.POINTER(C.c_double)
 _FPP = C.POINTER(_FP)
 _VP = C.c_void_p
 
@@ -86,6 +89,8 @@ ABI = {
     "source_set_loop": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_int32, C.c_double, C.c_double]),
     "convolver_set_buffer": (C.c_int32, [_VP, C.c_uint32, _FPP, C.c_uint32, C.c_uint64, C.c_float]),
     "waveshaper_set_curve": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32]),
+    "iir_set_coefficients": (C.c_int32, [_VP, C.c_uint32, _DP, C.c_uint32, _DP, C.c_uint32]),
+    "iir_frequency_response": (C.c_int32, [_DP, C.c_uint32, _DP, C.c_uint32, C.c_float, _FP, _FP, _FP, C.c_uint32]),
     "set_param_const": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
     "set_param_block": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
     "render": (C.c_int32, [_VP]),
@@ -630,6 +635,46 @@ class WaveShaperNode(AudioNode):
             b.check(b.waveshaper_set_curve(h, self.id, _fp(self.curve), self.curve.size))
 
 
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(_DP)
+
+
+class IIRFilterNode(AudioNode):
+    """src/node/iir_filter.rs:140-263.  Coefficients are fixed at construction (IIRFilterOptions)."""
+
+    kind = NODE_IIR_FILTER
+
+    def __init__(self, ctx, feedforward, feedback, **kw):
+        ff = np.ascontiguousarray(feedforward, dtype=np.float64).reshape(-1)
+        fb = np.ascontiguousarray(feedback, dtype=np.float64).reshape(-1)
+        # iir_filter.rs:17-46
+        if not 1 <= ff.size <= MAX_IIR_COEFFS:
+            raise WaaError(2, "NotSupportedError - IIR Filter feedforward coefficients should have length >= 0 and <= 20")
+        if not np.any(ff != 0.0):
+            raise WaaError(3, "InvalidStateError - IIR Filter feedforward coefficients cannot be all zeros")
+        if not 1 <= fb.size <= MAX_IIR_COEFFS:
+            raise WaaError(2, "NotSupportedError - IIR Filter feedback coefficients should have length >= 0 and <= 20")
+        if fb[0] == 0.0:
+            raise WaaError(3, "InvalidStateError - IIR Filter feedback first coefficient cannot be zero")
+        super().__init__(ctx, **kw)
+        self.feedforward, self.feedback = ff, fb
+
+    def _apply(self, ctx):
+        b, h = ctx._b, ctx._handle
+        b.check(b.iir_set_coefficients(h, self.id, _dp(self.feedforward), self.feedforward.size, _dp(self.feedback),
+                                       self.feedback.size))
+
+    def get_frequency_response(self, frequency_hz) -> tuple:
+        hz = _f32(frequency_hz)
+        mag = np.empty_like(hz)
+        phase = np.empty_like(hz)
+        b = self.context._b
+        b.check(b.iir_frequency_response(_dp(self.feedforward), self.feedforward.size, _dp(self.feedback),
+                                         self.feedback.size, self.context.sample_rate, _fp(hz), _fp(mag), _fp(phase),
+                                         hz.size))
+        return mag, phase
+
+
 class RenderedBatch:
     """What start_rendering_sync returns: one AudioBuffer per instance (array [inst, ch, frames])."""
 
@@ -715,6 +760,9 @@ class OfflineAudioContext:
 
     def create_wave_shaper(self, **kw):
         return WaveShaperNode(self, **kw)
+
+    def create_iir_filter(self, feedforward, feedback, **kw):
+        return IIRFilterNode(self, feedforward, feedback, **kw)
 
     # -- render -------------------------------------------------------------------------
     def _build(self):

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <complex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -104,6 +105,8 @@ struct Node {
   std::vector<float> curve;
   bool has_curve = false;
   float* d_curve = nullptr;
+  // iir filter: normalised coefficient pairs (iir_filter.rs:273-311)
+  std::vector<double> iir_b, iir_a;
   // analyser (control side state)
   struct AnCache {
     std::vector<float> spec, time;
@@ -130,11 +133,12 @@ struct ProfileEntry {
 };
 
 struct Step {
-  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients
+  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel
   ChainDesc chain{};
   BiquadStreamDesc bq{};
   ConvDesc conv{};
   BiquadCoefDesc coef{};
+  IirStreamDesc iir{};
   int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
   void* zero_ptr = nullptr;
   size_t zero_bytes = 0;
@@ -688,6 +692,7 @@ const char* op_name(int k) {
     case OP_STEREO_PAN: return "STEREO_PAN";
     case OP_PANNER: return "PANNER";
     case OP_MIX: return "MIX";
+    case OP_IIR: return "IIR";
     default: return "?";
   }
 }
@@ -720,6 +725,8 @@ int push_chain_step(waa_batch* b, const std::vector<InputRef>& inputs, int in_nc
   cd.in_nch = in_nch;
   cd.in_interp = in_interp;
   for (auto& o : ops) cmax = std::max({cmax, o.nch_in, o.nch_out});
+  for (auto& o : ops)
+    if (o.kind == OP_IIR) return fail(WAA_ERR_DEVICE, "internal: IIR op reached the interpreter kernel");
   for (auto& o : ops)
     if (o.kind == OP_BIQUAD && cmax > 2)
       return fail(WAA_ERR_OUT_OF_SCOPE,
@@ -777,22 +784,24 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
                   const SignalRef& out) {
   bool any_stream = false;
   const int max_mode = getenv("WAA_NO_KRATE_STREAM") ? 0 : 1;  // debugging aid: force k-rate biquads onto the interpreter
-  for (auto& o : ops) any_stream |= (o.kind == OP_BIQUAD && o.i0 <= max_mode && o.nch_in <= 2);
+  auto streams = [&](const OpDesc& o) { return o.kind == OP_IIR || (o.kind == OP_BIQUAD && o.i0 <= max_mode && o.nch_in <= 2); };
+  for (auto& o : ops) any_stream |= streams(o);
   if (!any_stream) return push_chain_step(b, inputs, in_nch, in_interp, ops, out);
   std::vector<OpDesc> pending;
   int cur_nch = in_nch;
   size_t i = 0;
   while (i < ops.size()) {
     const OpDesc& o = ops[i];
-    if (!(o.kind == OP_BIQUAD && o.i0 <= max_mode && o.nch_in <= 2)) {
+    if (!streams(o)) {
       pending.push_back(o);
       cur_nch = o.nch_out;
       i++;
       continue;
     }
     // the streaming kernel wants ONE plain input (signal or source) of exactly the biquad's channel count
-    const bool plain = pending.empty() && inputs.size() == 1 && (inputs[0].kind == IN_SOURCE || inputs[0].kind == IN_SIGNAL) &&
-                       inputs[0].nch == cur_nch;
+    const bool iir_exact = o.kind == OP_IIR && o.i0 < 0;  // the lane-per-stream kernel reads a materialised signal
+    const bool plain = pending.empty() && inputs.size() == 1 &&
+                       ((inputs[0].kind == IN_SOURCE && !iir_exact) || inputs[0].kind == IN_SIGNAL) && inputs[0].nch == cur_nch;
     if (!plain) {
       SignalRef tmp;
       int e = temp_signal(b, cur_nch, &tmp);
@@ -807,11 +816,44 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
       in_nch = cur_nch;
     }
     size_t j = i + 1;
-    while (j < ops.size() && j - i <= 2 && ops[j].kind == OP_GAIN && ops[j].p0.mode == 0 && ops[j].nch_in == cur_nch) j++;
+    if (o.kind == OP_BIQUAD)  // the biquad kernel applies up to two constant gains on the way out
+      while (j < ops.size() && j - i <= 2 && ops[j].kind == OP_GAIN && ops[j].p0.mode == 0 && ops[j].nch_in == cur_nch) j++;
     SignalRef seg_out = out;
     if (j < ops.size() || out.nch != cur_nch) {
       int e = temp_signal(b, cur_nch, &seg_out);
       if (e) return e;
+    }
+    if (o.kind == OP_IIR) {
+      Step st;
+      st.kind = 6;
+      IirStreamDesc& q = st.iir;
+      std::memset(&q, 0, sizeof q);
+      q.in = inputs[0];
+      q.coef = reinterpret_cast<const double*>(o.ptr0);
+      q.pow = reinterpret_cast<const double*>(o.ptr2);
+      q.state = reinterpret_cast<double*>(o.ptr1);
+      q.ns = std::abs(o.i0);
+      q.exact = iir_exact ? 1u : 0u;
+      q.nch = cur_nch;
+      q.out = seg_out;
+      q.n_inst = b->n_inst;
+      q.n_tiles = b->n_tiles;
+      q.n_quanta = b->n_quanta;
+      char name[32];
+      snprintf(name, sizeof name, "%s<%d>", iir_exact ? "iir_lane_kernel" : "iir_stream_kernel", q.ns);
+      st.profile_slot = slot_for(b, name);
+      b->steps.push_back(st);
+      plan_note(b, "%s states=%d in=%s:%dch out=%s", iir_exact ? "iir_exact" : "iir_stream", q.ns,
+                input_kind_name(inputs[0].kind), cur_nch, seg_out.base == out.base ? "final" : "temp");
+      InputRef in{};
+      in.kind = IN_SIGNAL;
+      in.nch = cur_nch;
+      in.sig = seg_out;
+      inputs.assign(1, in);
+      in_nch = cur_nch;
+      i = j;
+      if (i == ops.size() && seg_out.base == out.base) return 0;
+      continue;
     }
     Step st;
     st.kind = 1;
@@ -848,6 +890,9 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
 
 int build_plan(waa_batch* b) {
   const uint32_t N = (uint32_t)b->nodes.size();
+  for (uint32_t i = 0; i < N; i++)  // the reference takes the coefficients in the constructor
+    if (b->nodes[i].desc.kind == WAA_NODE_IIR_FILTER && b->nodes[i].iir_b.empty())
+      return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIRFilterNode %u has no coefficients", i);
   // processing order = reversed DFS post-order over outgoing edges in insertion order (graph.rs:331-487)
   {
     std::vector<uint8_t> marked(N, 0), temp(N, 0);
@@ -1480,6 +1525,76 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
       ops.push_back(o);
       break;
     }
+    case WAA_NODE_IIR_FILTER: {
+      // iir_filter.rs:323-405.  N = len - 1 state variables, padded with zero coefficients to a kernel size.
+      OpDesc o{};
+      o.kind = OP_IIR;
+      o.nch_in = o.nch_out = nch;
+      const int len = (int)n.iir_b.size();
+      const int ns = iir_padded_states(len - 1);
+      if (ns < 0) return fail(WAA_ERR_DEVICE, "internal: IIR order");
+      std::vector<double> co(2 * (size_t)(ns + 1), 0.);
+      for (int k = 0; k < len; k++) {
+        co[k] = n.iir_b[k];
+        co[ns + 1 + k] = n.iir_a[k];
+      }
+      // zero-input state transition M: s_i' = -a_{i+1} s_0 + s_{i+1}; powers M^(32 * 2^k), k = 0..5, for the
+      // lane scan of the kernel (long double on the host, rounded once).  `growth` = largest entry of any power
+      // the scan can form (intermediate squarings and all A^j, j <= 64): the scan's rounding error relative to
+      // the state is about ns * growth * 2^-53, so ill-conditioned direct forms (clustered poles, high order)
+      // and unstable filters go to the exact lane-per-stream kernel instead.
+      std::vector<long double> m((size_t)ns * ns, 0.L), t((size_t)ns * ns);
+      for (int i = 0; i < ns; i++) {
+        m[(size_t)i * ns] = -(long double)co[ns + 1 + i + 1];
+        if (i + 1 < ns) m[(size_t)i * ns + i + 1] += 1.L;
+      }
+      long double growth = 0.L;
+      auto note = [&](const std::vector<long double>& a) {
+        for (long double v : a) growth = std::isfinite((double)v) ? std::max(growth, fabsl(v)) : INFINITY;
+      };
+      auto mul = [&](const std::vector<long double>& x, const std::vector<long double>& y, std::vector<long double>& out) {
+        for (int r = 0; r < ns; r++)
+          for (int c = 0; c < ns; c++) {
+            long double acc = 0.L;
+            for (int k = 0; k < ns; k++) acc += x[(size_t)r * ns + k] * y[(size_t)k * ns + c];
+            out[(size_t)r * ns + c] = acc;
+          }
+      };
+      for (int k = 0; k < 5; k++) {  // M^32
+        mul(m, m, t);
+        m.swap(t);
+        note(m);
+      }
+      const std::vector<long double> A = m;
+      std::vector<double> pw(6 * (size_t)ns * ns);
+      for (int lvl = 0; lvl < 6; lvl++) {
+        for (size_t k = 0; k < (size_t)ns * ns; k++) pw[lvl * (size_t)ns * ns + k] = (double)m[k];
+        mul(m, m, t);
+        m.swap(t);
+        note(m);
+      }
+      m = A;
+      for (int j = 2; j <= 64 && std::isfinite((double)growth); j++) {  // every A^j a lane can see
+        mul(m, A, t);
+        m.swap(t);
+        note(m);
+      }
+      const bool exact = !(growth <= 1e4L) || getenv("WAA_IIR_EXACT") != nullptr;  // env: debugging aid
+      if (exact)
+        for (auto& v : pw) v = 0.;  // unused
+      double *dco = nullptr, *dpw = nullptr, *dst = nullptr;
+      int e;
+      if ((e = dev_upload(b, &dco, co)) || (e = dev_upload(b, &dpw, pw))) return e;
+      const size_t n_state = (size_t)b->n_inst * nch * ns;
+      if ((e = dev_alloc(b, &dst, n_state))) return e;
+      b->state_bufs.push_back({dst, n_state * sizeof(double)});
+      o.i0 = exact ? -ns : ns;
+      o.ptr0 = dco;
+      o.ptr1 = dst;
+      o.ptr2 = dpw;
+      ops.push_back(o);
+      break;
+    }
     case WAA_NODE_WAVESHAPER: {
       if (n.has_curve) {
         OpDesc o{};
@@ -1946,6 +2061,38 @@ waa_status waa_waveshaper_set_curve(waa_batch* b, uint32_t node, const float* cu
   return WAA_OK;
 }
 
+// iir_filter.rs:17-46 (validation) and :273-311 (pad to equal length, normalise by a0)
+static int check_iir_coefs(const double* ff, uint32_t nff, const double* fb, uint32_t nfb) {
+  if (!ff || nff == 0 || nff > WAA_MAX_IIR_COEFFS)
+    return fail(WAA_ERR_NOT_SUPPORTED,
+                "NotSupportedError - IIR Filter feedforward coefficients should have length >= 0 and <= %d", WAA_MAX_IIR_COEFFS);
+  bool all_zero = true;
+  for (uint32_t i = 0; i < nff; i++) all_zero &= ff[i] == 0.;
+  if (all_zero) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIR Filter feedforward coefficients cannot be all zeros");
+  if (!fb || nfb == 0 || nfb > WAA_MAX_IIR_COEFFS)
+    return fail(WAA_ERR_NOT_SUPPORTED,
+                "NotSupportedError - IIR Filter feedback coefficients should have length >= 0 and <= %d", WAA_MAX_IIR_COEFFS);
+  if (fb[0] == 0.) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIR Filter feedback first coefficient cannot be zero");
+  return 0;
+}
+
+waa_status waa_iir_set_coefficients(waa_batch* b, uint32_t node, const double* ff, uint32_t nff, const double* fb,
+                                    uint32_t nfb) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_IIR_FILTER)) || (e = check_unplanned(b))) return e;
+  if ((e = check_iir_coefs(ff, nff, fb, nfb))) return e;
+  Node& n = b->nodes[node];
+  const uint32_t len = std::max(nff, nfb);
+  const double a0 = fb[0];
+  n.iir_b.assign(len, 0.);
+  n.iir_a.assign(len, 0.);
+  for (uint32_t i = 0; i < len; i++) {
+    n.iir_b[i] = (i < nff ? ff[i] : 0.) / a0;
+    n.iir_a[i] = (i < nfb ? fb[i] : 0.) / a0;
+  }
+  return WAA_OK;
+}
+
 waa_status waa_set_param_const(waa_batch* b, uint32_t node, uint32_t param, uint32_t inst, float value) {
   int e;
   if (!b || node >= b->nodes.size() || param >= b->nodes[node].params.size())
@@ -2036,6 +2183,7 @@ waa_status waa_render(waa_batch* b) {
       case 3: HIP_TRY(hipMemsetAsync(st.zero_ptr, 0, st.zero_bytes, b->stream)); break;
       case 4: e = timed(st.slot_mac, [&] { launch_conv_direct(st.conv, b->stream); }); break;
       case 5: e = timed(st.profile_slot, [&] { launch_biquad_coefs(st.coef, b->stream); }); break;
+      case 6: e = timed(st.profile_slot, [&] { launch_iir_stream(st.iir, b->stream); }); break;
       default: e = timed(st.profile_slot, [&] { launch_chain(st.chain, st.cmax, b->stream); }); break;
     }
     if (e) return e;
@@ -2238,6 +2386,32 @@ uint64_t waa_buffer_resample(const float* src, uint64_t frames, float source_sr,
     dst[i] = kinv * src[prev] + k * src[next];
   }
   return tl;
+}
+
+// iir_filter.rs:218-262 (control side, host)
+waa_status waa_iir_frequency_response(const double* ff, uint32_t nff, const double* fb, uint32_t nfb, float sample_rate,
+                                      const float* hz, float* mag, float* phase, uint32_t n) {
+  if (int e = check_iir_coefs(ff, nff, fb, nfb)) return e;
+  if (n && (!hz || !mag || !phase)) return fail(WAA_ERR_INVALID_ARGUMENT, "null array");
+  const double sr = (double)sample_rate, nyquist = sr / 2.;
+  for (uint32_t i = 0; i < n; i++) {
+    const double freq = (double)hz[i];
+    if (freq < 0. || freq > nyquist) {
+      mag[i] = std::nanf("");
+      phase[i] = std::nanf("");
+      continue;
+    }
+    const double z = -2.0 * 3.14159265358979323846 * freq / sr;
+    std::complex<double> num(0., 0.), den(0., 0.);
+    for (uint32_t k = 0; k < nff; k++) num += std::complex<double>(ff[k] * std::cos((double)k * z), ff[k] * std::sin((double)k * z));
+    for (uint32_t k = 0; k < nfb; k++) den += std::complex<double>(fb[k] * std::cos((double)k * z), fb[k] * std::sin((double)k * z));
+    const double ns = den.real() * den.real() + den.imag() * den.imag();
+    const double rr = (num.real() * den.real() + num.imag() * den.imag()) / ns;
+    const double ri = (num.imag() * den.real() - num.real() * den.imag()) / ns;
+    mag[i] = (float)std::hypot(rr, ri);
+    phase[i] = (float)std::atan2(ri, rr);
+  }
+  return WAA_OK;
 }
 
 // biquad_filter.rs:670-735 (control side, host)

@@ -80,20 +80,22 @@ enum : int32_t {
   OP_WAVESHAPER = 3,  // waveshaper.rs:555-573
   OP_STEREO_PAN = 4,  // stereo_panner.rs:218-317
   OP_PANNER = 5,      // panner.rs:830-897, 988-1057 (equal power)
-  OP_MIX = 6          // quantum.rs:285-505
+  OP_MIX = 6,         // quantum.rs:285-505
+  OP_IIR = 7          // iir_filter.rs:323-405 (always cut out of the chain into the streaming IIR kernel)
 };
 struct OpDesc {
   int32_t kind;
   int32_t nch_in;
   int32_t nch_out;
-  int32_t i0;        // MIX: interpretation; WAVESHAPER: curve length; BIQUAD: coef mode (0 per inst, 1 per quantum, 2 per frame)
+  int32_t i0;        // MIX: interpretation; WAVESHAPER: curve length; BIQUAD: coef mode (0 per inst, 1 per quantum, 2 per frame); IIR: padded state count, negative = exact lane kernel
   ParamRef p0;       // GAIN: gain; STEREO_PAN: pan; PANNER: azimuth (wrapped)
   ParamRef p1;       // STEREO_PAN / PANNER: gain_l
   ParamRef p2;       // STEREO_PAN / PANNER: gain_r
   ParamRef p3;       // PANNER: dist_gain*cone_gain factors (dist), p4 (cone)
   ParamRef p4;
-  const void* ptr0;  // WAVESHAPER: curve; BIQUAD: coefficients (double[5] per inst or per inst*quantum)
-  void* ptr1;        // BIQUAD: state double[nch][4] per instance
+  const void* ptr0;  // WAVESHAPER: curve; BIQUAD: coefficients (double[5] per inst or per inst*quantum); IIR: coef block
+  void* ptr1;        // BIQUAD: state double[nch][4] per instance; IIR: state double[nch][ns] per instance
+  const void* ptr2;  // IIR: matrix powers
   uint64_t u0;       // BIQUAD: coefficient stride per instance (in doubles)
 };
 
@@ -131,6 +133,25 @@ struct BiquadStreamDesc {
   uint32_t pad;
 };
 void launch_biquad_stream(const BiquadStreamDesc& d, void* stream);
+
+// ---- streaming IIR kernel (IIRFilterNode, iir_filter.rs:323-405) -----------------------------
+// input (source or signal) -> transposed direct form II with ns state variables -> output; coefficients are
+// shared by all instances (they are constructor arguments of the node).
+struct IirStreamDesc {
+  InputRef in;
+  const double* coef;  // [2][ns+1]: normalised feedforward b[0..ns], then feedback a[0..ns], zero padded
+  const double* pow;   // [6][ns][ns]: M^(32 * 2^k), M = zero-input state transition
+  double* state;       // [n_inst][nch][ns]
+  int32_t ns;          // padded state count, one of the instantiated kernel sizes
+  int32_t nch;
+  SignalRef out;
+  uint32_t n_inst;
+  uint32_t n_tiles;
+  uint32_t n_quanta;
+  uint32_t exact;      // 1: lane-per-stream kernel (input must be IN_SIGNAL), see waa_iir_stream.hip
+};
+int iir_padded_states(int n_states);  // smallest instantiated ns >= n_states
+void launch_iir_stream(const IirStreamDesc& d, void* stream);
 
 // ---- ConvolverNode (convolver.rs:343-490 + fft-convolver), node-major overlap-save ------------
 // out[co] = sum over terms t with t.out_ch == co of  IR[t.ir_ch] * in[t.in_ch]   (linear convolution)
