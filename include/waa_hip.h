@@ -73,7 +73,8 @@ enum {
   WAA_NODE_WAVESHAPER = 8,      /* src/node/waveshaper.rs:383-487 (oversample None only) */
   WAA_NODE_CONSTANT_SOURCE = 9, /* src/node/constant_source.rs:190-275 */
   WAA_NODE_IIR_FILTER = 10,     /* src/node/iir_filter.rs:323-405 */
-  WAA_NODE_KIND_COUNT = 11
+  WAA_NODE_DELAY = 11,          /* src/node/delay.rs:428-745, writer + reader outside a cycle */
+  WAA_NODE_KIND_COUNT = 12
 };
 
 /* src/node/audio_node.rs ChannelCountMode / ChannelInterpretation */
@@ -97,6 +98,7 @@ enum { WAA_PARAM_GAIN_GAIN = 0 };
 enum { WAA_PARAM_SOURCE_PLAYBACK_RATE = 0, WAA_PARAM_SOURCE_DETUNE = 1 };
 enum { WAA_PARAM_STEREO_PANNER_PAN = 0 };
 enum { WAA_PARAM_CONSTANT_OFFSET = 0 };
+enum { WAA_PARAM_DELAY_DELAY_TIME = 0 };
 enum {
   WAA_PARAM_PANNER_POSITION_X = 0, WAA_PARAM_PANNER_POSITION_Y = 1, WAA_PARAM_PANNER_POSITION_Z = 2,
   WAA_PARAM_PANNER_ORIENTATION_X = 3, WAA_PARAM_PANNER_ORIENTATION_Y = 4, WAA_PARAM_PANNER_ORIENTATION_Z = 5,
@@ -118,6 +120,8 @@ enum {
  *     ANALYSER    i[0] = fft_size, d[0] smoothing_time_constant, d[1] min_decibels, d[2] max_decibels
  *     WAVESHAPER  i[0] = oversample
  *     CONVOLVER   i[0] = disable_normalization (0/1)
+ *     DELAY       d[0] = max_delay_time in seconds (0 = the default, 1 s); must be > 0 and < 180
+ *                 (NotSupportedError, delay.rs:290-293).  Feedback loops through a DelayNode are out of scope.
  */
 typedef struct {
   uint32_t kind;

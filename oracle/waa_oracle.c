@@ -559,6 +559,9 @@ typedef struct {
   /* biquad */
   double xy[ORC_MAXC][4];
   int xy_len;
+  /* delay line (delay.rs:297-303): ring of num_quanta + 1 render quanta shared by writer and reader */
+  Quantum* dl_ring;
+  int dl_cap, dl_windex, dl_rindex;
   /* iir filter: per-channel state, iir_filter.rs:269 */
   double iir_state[ORC_MAXC][WAA_MAX_IIR_COEFFS];
   int iir_nch;
@@ -764,6 +767,15 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
           return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count cannot be greater than two");
         break;
       }
+      case WAA_NODE_DELAY: { /* delay.rs:283-335 */
+        if (n->desc.d[0] == 0.) n->desc.d[0] = 1.;
+        if (!(n->desc.d[0] > 0. && n->desc.d[0] < 180.))
+          return fail(WAA_ERR_NOT_SUPPORTED,
+                      "NotSupportedError - maxDelayTime MUST be greater than zero and less than three minutes");
+        n->n_params = 1;
+        param_init(&n->params[0], n_inst, 0.f, 0.f, (float)n->desc.d[0]);
+        break;
+      }
       case WAA_NODE_WAVESHAPER:
         if (n->desc.i[0] != WAA_OVERSAMPLE_NONE)
           return fail(WAA_ERR_OUT_OF_SCOPE, "WaveShaper oversampling is out of scope (third-party rubato, parity unpinned)");
@@ -839,6 +851,7 @@ void orc_batch_destroy(orc_batch* b) {
       NodeState* s = &b->st[k][i];
       for (int c = 0; c < 4; c++) convstate_free(s->conv[c]);
       free(s->ring);
+      free(s->dl_ring);
       free(s->last_fft_output);
     }
     free(b->st[k]);
@@ -1673,6 +1686,90 @@ static void process_iir(NodeCfg* n, NodeState* s) {
   }
 }
 
+/* src/node/delay.rs: DelayWriter::process :428-466 followed by DelayReader::process :515-680 (the node outside a
+ * cycle: the writer->reader edge of delay.rs:361 makes the writer render first, so in_cycle stays false) */
+typedef struct {
+  int prev_block_index, prev_frame_index;
+  float k;
+} PlaybackInfo;
+
+/* delay.rs:682-745 */
+static PlaybackInfo delay_playback_infos(double delay, double sample_index, double sample_rate, int ring_size,
+                                         int ring_index) {
+  double num_samples = delay * sample_rate; /* in_cycle == false: no clamp */
+  double position = sample_index - num_samples;
+  double position_floored = floor(position);
+  int num_frames = RQ;
+  double block_offset = floor(position_floored / (double)num_frames);
+  int prev_block_index = ring_index + (int)block_offset;
+  if (prev_block_index < 0) prev_block_index += ring_size;
+  int frame_offset = (int)position_floored % num_frames; /* C and Rust: sign of the dividend */
+  if (frame_offset == 0) frame_offset = -num_frames;
+  int prev_frame_index = frame_offset <= 0 ? num_frames + frame_offset : frame_offset;
+  PlaybackInfo r = {prev_block_index, prev_frame_index, (float)(position - position_floored)};
+  return r;
+}
+
+static void process_delay(NodeCfg* n, NodeState* s, uint32_t inst, const Scope* sc) {
+  const Quantum* input = &s->in;
+  Quantum* output = &s->out;
+  double sample_rate = (double)sc->sample_rate;
+  if (!s->dl_ring) { /* delay.rs:297-303 + check_ring_buffer_size :386-397: filled with silent quanta */
+    int num_quanta = (int)ceil(n->desc.d[0] * sample_rate / (double)RQ);
+    s->dl_cap = num_quanta + 1;
+    s->dl_ring = (Quantum*)malloc(sizeof(Quantum) * (size_t)s->dl_cap);
+    for (int i = 0; i < s->dl_cap; i++) q_make_silent(&s->dl_ring[i]);
+  }
+  /* ---- writer ---- */
+  if (s->dl_ring[0].n != input->n) /* check_ring_buffer_up_down_mix :469-489 */
+    for (int i = 0; i < s->dl_cap; i++) q_mix(&s->dl_ring[i], input->n, WAA_INTERP_SPEAKERS);
+  q_copy(&s->dl_ring[s->dl_windex], input);
+  s->dl_windex = (s->dl_windex + 1) % s->dl_cap;
+  /* ---- reader ---- */
+  const Quantum* ring = s->dl_ring;
+  int nch = ring[0].n;
+  q_set_number_of_channels(output, nch);
+  float tmp[RQ];
+  int len;
+  const float* delay = param_get(&n->params[0], inst, sc->quantum, &len, tmp);
+  int ring_size = s->dl_cap, ring_index = s->dl_rindex;
+  PlaybackInfo infos[RQ];
+  if (len == 1) {
+    infos[0] = delay_playback_infos((double)delay[0], 0., sample_rate, ring_size, ring_index);
+    for (int i = 1; i < RQ; i++) {
+      PlaybackInfo p = infos[i - 1];
+      p.prev_frame_index += 1;
+      if (p.prev_frame_index >= RQ) {
+        p.prev_block_index = (p.prev_block_index + 1) % ring_size;
+        p.prev_frame_index = 0;
+      }
+      infos[i] = p;
+    }
+  } else {
+    for (int i = 0; i < RQ; i++)
+      infos[i] = delay_playback_infos((double)delay[i], (double)i, sample_rate, ring_size, ring_index);
+  }
+  int active = 0;
+  for (int c = 0; c < nch; c++) {
+    for (int i = 0; i < RQ; i++) {
+      PlaybackInfo p = infos[i];
+      int next_block_index = p.prev_block_index, next_frame_index = p.prev_frame_index + 1;
+      if (next_frame_index >= RQ) {
+        next_block_index = (next_block_index + 1) % ring_size;
+        next_frame_index = 0;
+      }
+      float prev_sample = ring[p.prev_block_index].d[c][p.prev_frame_index];
+      float next_sample = ring[next_block_index].d[c][next_frame_index];
+      float value = fmaf(1.f - p.k, prev_sample, p.k * next_sample);
+      if (isnormal(value)) active = 1;
+      output->d[c][i] = value;
+    }
+    output->silent[c] = 0;
+  }
+  if (!active) q_make_silent(output);
+  s->dl_rindex = (s->dl_rindex + 1) % s->dl_cap;
+}
+
 /* src/node/gain.rs:143-199 */
 static void process_gain(NodeCfg* n, NodeState* s, uint32_t inst, const Scope* sc) {
   const Quantum* input = &s->in;
@@ -2073,6 +2170,7 @@ static void process_node(orc_batch* b, uint32_t id, uint32_t inst, const Scope* 
     case WAA_NODE_CONSTANT_SOURCE: process_constant_source(n, s, inst, sc); break;
     case WAA_NODE_BIQUAD: process_biquad(n, s, inst, sc); break;
     case WAA_NODE_IIR_FILTER: process_iir(n, s); break;
+    case WAA_NODE_DELAY: process_delay(n, s, inst, sc); break;
     case WAA_NODE_GAIN: process_gain(n, s, inst, sc); break;
     case WAA_NODE_STEREO_PANNER: process_stereo_panner(n, s, inst, sc); break;
     case WAA_NODE_PANNER: process_panner(n, s, inst, sc); break;

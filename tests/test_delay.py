@@ -1,0 +1,277 @@
+"""DelayNode outside a feedback loop: the reference's own tests re-typed
+(src/node/delay.rs:750-1206) on both backends, plus GPU-vs-oracle parity on seeded inputs.  The oracle keeps
+the reference's ring of render quanta; the device path gathers from the node's input in absolute time —
+the KATs below pin both."""
+import numpy as np
+import pytest
+
+import web_audio_api_rs_amd as waa
+from graphs import rms_err, white_noise
+
+RQ = 128
+
+
+def ctx(be, channels, length, sr, **kw):
+    return waa.OfflineAudioContext(channels, length, sr, binding=be, **kw)
+
+
+def dirac_through_delay(be, delay_frames, length, sr=48000.0, max_delay=2.0, start=0.0):
+    c = ctx(be, 1, length, sr)
+    delay = c.create_delay(max_delay)
+    delay.delay_time.set_value(np.float32(delay_frames) / np.float32(sr))
+    delay.connect(c.destination())
+    src = c.create_buffer_source()
+    src.connect(delay)
+    src.set_buffer(waa.AudioBuffer(np.array([[1.0]], np.float32), sr))
+    src.start_at(start)
+    return c.start_rendering_sync().data[0, 0]
+
+
+# --------------------------------------------------------------------------- reference KATs
+def test_constructor_validation(be):
+    """delay.rs:290-293"""
+    c = ctx(be, 1, 128, 48000.0)
+    for bad in (0.0, -1.0, 180.0, 200.0):
+        with pytest.raises(waa.WaaError, match="NotSupportedError"):
+            c.create_delay(bad)
+    d = c.create_delay(1.0, delay_time=0.12)
+    assert d.delay_time.value == pytest.approx(0.12)  # delay.rs:755-764
+
+
+def test_c_abi_rejects_bad_max_delay(be):
+    c = ctx(be, 1, 128, 48000.0)
+    d = c.create_delay(1.0)
+    d.max_delay_time = 500.0  # past the Python mirror: the C entry point must refuse
+    d.connect(c.destination())
+    with pytest.raises(waa.WaaError, match="NotSupportedError"):
+        c.prepare()
+
+
+@pytest.mark.parametrize("frames", [128.0, 131.0, 197.0])
+def test_sample_accurate(be, frames):
+    """delay.rs:766-792, abs_all <= 1e-5"""
+    out = dirac_through_delay(be, frames, 256)
+    expected = np.zeros(256, np.float32)
+    expected[int(frames)] = 1.0
+    assert np.max(np.abs(out - expected)) <= 1e-5
+
+
+@pytest.mark.parametrize("frames,e128,e129", [(128.5, 0.5, 0.5), (128.8, 0.2, 0.8)])
+def test_sub_sample_accurate(be, frames, e128, e129):
+    """delay.rs:794-848"""
+    out = dirac_through_delay(be, frames, 256)
+    expected = np.zeros(256, np.float32)
+    expected[128], expected[129] = e128, e129
+    assert np.max(np.abs(out - expected)) <= 1e-5
+
+
+def test_multichannel(be):
+    """delay.rs:850-881"""
+    sr = 48000.0
+    c = ctx(be, 2, 256, sr)
+    delay = c.create_delay(2.0)
+    delay.delay_time.set_value(128.0 / sr)
+    delay.connect(c.destination())
+    buf = np.zeros((2, 256), np.float32)
+    buf[0, 0] = 1.0
+    buf[1, 1] = 1.0
+    src = c.create_buffer_source()
+    src.connect(delay)
+    src.set_buffer(waa.AudioBuffer(buf, sr))
+    src.start_at(0.0)
+    out = c.start_rendering_sync().data[0]
+    exp = np.zeros((2, 256), np.float32)
+    exp[0, 128] = 1.0
+    exp[1, 129] = 1.0
+    assert np.max(np.abs(out - exp)) <= 1e-5
+
+
+def test_input_number_of_channels_change(be):
+    """delay.rs:883-924: a mono source, then a stereo one a quantum later; the delay line is up-mixed"""
+    sr = 48000.0
+    c = ctx(be, 2, 3 * 128, sr)
+    delay = c.create_delay(2.0)
+    delay.delay_time.set_value(128.0 / sr)
+    delay.connect(c.destination())
+    one = np.zeros((1, 128), np.float32)
+    one[0, 0] = 1.0
+    src1 = c.create_buffer_source()
+    src1.connect(delay)
+    src1.set_buffer(waa.AudioBuffer(one, sr))
+    src1.start_at(0.0)
+    two = np.zeros((2, 256), np.float32)
+    two[0, 0] = 1.0
+    two[1, 1] = 1.0
+    src2 = c.create_buffer_source()
+    src2.connect(delay)
+    src2.set_buffer(waa.AudioBuffer(two, sr))
+    src2.start_at(128.0 / sr)
+    out = c.start_rendering_sync().data[0]
+    exp = np.zeros((2, 384), np.float32)
+    exp[0, 128] = exp[0, 256] = 1.0
+    exp[1, 128] = exp[1, 257] = 1.0
+    assert np.max(np.abs(out - exp)) <= 1e-5
+
+
+def test_node_stays_alive_long_enough(be):
+    """delay.rs:926-960: the source starts in the 4th quantum"""
+    sr = 48000.0
+    out = dirac_through_delay(be, 128.0, 5 * 128, max_delay=1.0, start=128.0 * 3.0 / sr)
+    exp = np.zeros(5 * 128, np.float32)
+    exp[4 * 128] = 1.0
+    assert np.max(np.abs(out - exp)) <= 1e-5
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 63, 64, 100, 126, 127])
+def test_subquantum_delay(be, i):
+    """delay.rs:962-988 (all of 0..128 there; a spread here)"""
+    out = dirac_through_delay(be, float(i), 128, max_delay=1.0)
+    exp = np.zeros(128, np.float32)
+    exp[i] = 1.0
+    assert np.max(np.abs(out - exp)) <= 1e-5
+
+
+@pytest.mark.parametrize("seconds", [1.0, 1.5])
+def test_max_delay(be, seconds):
+    """delay.rs:1022-1074 (wpt delaynode-max-default-delay / -nondefault-delay): delay == maxDelay, exact copy.
+    Shortened tone (0.5 s) and render (seconds + 1 s) to keep the CPU suite quick."""
+    sr = 44100.0
+    tone_len = int(0.5 * sr)
+    length = int((seconds + 1.0) * sr)
+    i = np.arange(tone_len, dtype=np.float32)
+    tone = np.sin(np.float32(20.0) * np.float32(2.0) * np.float32(np.pi) * i / np.float32(sr)).astype(np.float32)
+    c = ctx(be, 1, length, sr)
+    src = c.create_buffer_source()
+    src.set_buffer(waa.AudioBuffer(tone[None, :], sr))
+    delay = c.create_delay(seconds)
+    delay.delay_time.set_value(seconds)
+    src.connect(delay)
+    delay.connect(c.destination())
+    src.start_at(0.0)
+    out = c.start_rendering_sync().data[0, 0]
+    d = int(seconds * sr)
+    exp = np.zeros(length, np.float32)
+    exp[d:d + tone_len] = tone
+    assert np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("quanta", [1, 2])
+def test_max_delay_multiple_of_quantum_size(be, quanta):
+    """delay.rs:1116-1172: delay == maxDelay == 1 or 2 render quanta"""
+    sr = 48000.0
+    out = dirac_through_delay(be, 128.0 * quanta, (quanta + 1) * 128, max_delay=128.0 * quanta / sr)
+    exp = np.zeros((quanta + 1) * 128, np.float32)
+    exp[128 * quanta] = 1.0
+    assert np.max(np.abs(out - exp)) <= 1e-5
+
+
+def test_subquantum_delay_dynamic_lifetime(be):
+    """delay.rs:1174-1204: constant source for 120 frames, delayed by 64"""
+    sr = 48000.0
+    c = ctx(be, 1, 3 * 128, sr)
+    delay = c.create_delay(1.0)
+    delay.delay_time.set_value(np.float32(64.0) / np.float32(sr))
+    delay.connect(c.destination())
+    src = c.create_constant_source()
+    src.connect(delay)
+    src.start_at(0.0)
+    src.stop_at(120.0 / sr)
+    out = c.start_rendering_sync().data[0, 0]
+    exp = np.zeros(3 * 128, np.float32)
+    exp[64:64 + 120] = 1.0
+    assert np.max(np.abs(out - exp)) <= 1e-5
+
+
+def test_feedback_loop_is_out_of_scope(be):
+    """delay.rs:990-1019 needs the cycle breaker (graph.rs:302-304): refused, not mis-rendered"""
+    c = ctx(be, 1, 256, 48000.0)
+    delay = c.create_delay(1.0)
+    delay.connect(c.destination())
+    gain = c.create_gain(gain=0.0)
+    delay.connect(gain)
+    gain.connect(delay)
+    with pytest.raises(waa.WaaError) as ei:
+        c.start_rendering_sync()
+    assert ei.value.status == 4
+
+
+def test_plan_delay_is_node_major(hip):
+    c = waa.OfflineAudioContext(2, RQ * 64, 48000.0, n_instances=4, binding=hip, device=waa.PLAN_ONLY)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(white_noise(4, 2, RQ * 64), 48000.0)
+    d = c.create_delay(0.5, delay_time=0.01)
+    src.connect(c.create_gain(gain=0.5)).connect(d).connect(c.create_gain(gain=2.0)).connect(c.destination())
+    src.start()
+    plan = c.plan_describe()
+    assert "delay node" in plan and "ring=189 quanta" in plan and "delayTime=const" in plan
+    c.close()
+
+
+# --------------------------------------------------------------------------- GPU parity on seeded inputs
+def _echo(binding, noise, delay_s, max_delay=1.0, blocks=None, length=None, sr=48000.0):
+    """src -> [dry] + [delay -> gain 0.5] -> destination (a feed-forward echo)"""
+    n_inst, n_ch, frames = noise.shape
+    c = waa.OfflineAudioContext(2, length or frames, sr, n_instances=n_inst, binding=binding)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, sr)
+    d = c.create_delay(max_delay)
+    if blocks is None:
+        for i in range(n_inst):
+            d.delay_time.set_value(delay_s[i], instance=i)
+    else:
+        d.delay_time.set_block(0, blocks)
+    wet = c.create_gain(gain=0.5)
+    src.connect(c.destination())
+    src.connect(d).connect(wet).connect(c.destination())
+    src.start()
+    out = c.start_rendering_sync().data
+    c.close()
+    return out
+
+
+@pytest.mark.gpu
+def test_delay_parity_constant_per_instance(hip, orc):
+    n = 8
+    noise = white_noise(n, 2, 2048 * 2 + 333, seed0=3)
+    delays = np.float32([0.0, 1.0 / 48000.0, 0.5 / 48000.0, 127.0 / 48000.0, 128.0 / 48000.0, 0.0123, 0.05, 0.08])
+    g = _echo(hip, noise, delays, max_delay=0.08)
+    o = _echo(orc, noise, delays, max_delay=0.08)
+    assert np.array_equal(g, o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate", ["k", "a"])
+def test_delay_parity_automated(hip, orc, rate):
+    """k-rate: one delayTime per quantum (the len-1 path of delay.rs:560-590); a-rate: 128 values per quantum
+    (a chorus-like sweep, delay.rs:591-606)"""
+    n, frames = 3, 2048 * 2
+    nq = frames // RQ
+    noise = white_noise(n, 2, frames, seed0=8)
+    if rate == "k":
+        blocks = (0.002 + 0.0015 * np.sin(np.arange(nq) * 0.3)).astype(np.float32)
+    else:
+        t = np.arange(nq * RQ, dtype=np.float64) / 48000.0
+        blocks = (0.003 + 0.002 * np.sin(2 * np.pi * 3.0 * t)).astype(np.float32).reshape(nq, RQ)
+    g = _echo(hip, noise, None, max_delay=0.01, blocks=blocks)
+    o = _echo(orc, noise, None, max_delay=0.01, blocks=blocks)
+    assert rms_err(g, o).max() <= 1e-7
+    assert np.abs(g - o).max() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_delay_parity_mono_six_channel_inputs(hip, orc):
+    """channel counts other than stereo, delay behind a biquad"""
+    for nch in (1, 4):
+        noise = white_noise(2, nch, 2048 + 100, seed0=nch)
+        outs = []
+        for be_ in (hip, orc):
+            c = waa.OfflineAudioContext(nch, 2048 + 100, 48000.0, n_instances=2, binding=be_)
+            src = c.create_buffer_source()
+            src.set_buffer_batch(noise, 48000.0)
+            d = c.create_delay(0.02, delay_time=0.0071, channel_count=nch, channel_count_mode="explicit",
+                               channel_interpretation="discrete")
+            src.connect(d).connect(c.destination())
+            src.start()
+            outs.append(c.start_rendering_sync().data)
+            c.close()
+        assert np.array_equal(*outs)

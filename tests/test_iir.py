@@ -182,14 +182,14 @@ def test_plan_routes_iir_to_the_streaming_kernel(hip):
     src.connect(g0).connect(iir).connect(g1).connect(c.destination())
     src.start()
     plan = c.plan_describe()
-    assert "iir_stream states=8" in plan
+    assert "iir_stream states=5" in plan
     assert "IIR" not in plan.replace("iir_stream", "")  # never on the interpreter
     c.close()
 
 
 @pytest.mark.parametrize("order,wn,kernel", [(2, 0.25, "iir_stream states=2"), (4, 0.25, "iir_stream states=4"),
-                                             (11, 0.1, "iir_exact states=12"), (19, 0.1, "iir_exact states=19"),
-                                             (6, 0.02, "iir_exact states=8")])
+                                             (11, 0.1, "iir_exact(row) states=11"), (19, 0.1, "iir_exact(row) states=19"),
+                                             (6, 0.02, "iir_exact(row) states=6")])
 def test_plan_sends_ill_conditioned_filters_to_the_exact_kernel(hip, order, wn, kernel):
     """the lane scan multiplies by powers of the 32-step transition; where those are large (clustered poles)
     the planner picks the lane-per-stream kernel, which needs a materialised input signal"""
@@ -212,7 +212,7 @@ def test_plan_unstable_filter_is_exact(hip):
     src.set_buffer_batch(white_noise(2, 1, RQ * 64), 48000.0)
     src.connect(c.create_iir_filter([1.0, 0.3], [1.0, -2.5, 1.2])).connect(c.destination())
     src.start()
-    assert "iir_exact states=2" in c.plan_describe()
+    assert "iir_exact(lane) states=2" in c.plan_describe()  # low order: one lane per stream
     c.close()
 
 
@@ -250,10 +250,13 @@ def test_iir_parity_butterworth(hip, orc, order, wn):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("order", [2, 5, 10])
-def test_iir_exact_kernel_is_bit_identical(hip, orc, order, monkeypatch):
-    """WAA_IIR_EXACT forces the lane-per-stream kernel: same operations in the same order as the oracle"""
+@pytest.mark.parametrize("kernel", ["WAA_IIR_LANE", "WAA_IIR_ROW"])
+@pytest.mark.parametrize("order", [1, 2, 5, 10, 16, 17, 19])
+def test_iir_exact_kernels_are_bit_identical(hip, orc, order, kernel, monkeypatch):
+    """WAA_IIR_EXACT forces an exact kernel (lane per stream / DPP row per stream): the same operations in the
+    same order as the oracle"""
     monkeypatch.setenv("WAA_IIR_EXACT", "1")
+    monkeypatch.setenv(kernel, "1")
     b, a = signal.butter(order, 0.3)
     noise = white_noise(70, 2, 2048 + 300, seed0=order)  # 140 streams: more than two waves, last one partial
     g = _render_iir(hip, noise, b, a)

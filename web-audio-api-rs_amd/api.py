@@ -37,6 +37,7 @@ F64_MAX = 1.7976931348623157e308
 NODE_DESTINATION, NODE_BUFFER_SOURCE, NODE_BIQUAD, NODE_GAIN, NODE_CONVOLVER = 0, 1, 2, 3, 4
 NODE_STEREO_PANNER, NODE_PANNER, NODE_ANALYSER, NODE_WAVESHAPER, NODE_CONSTANT_SOURCE = 5, 6, 7, 8, 9
 NODE_IIR_FILTER = 10
+NODE_DELAY = 11
 MAX_IIR_COEFFS = 20
 COUNT_MODE = {"max": 0, "clamped-max": 1, "explicit": 2}
 INTERPRETATION = {"speakers": 0, "discrete": 1}
@@ -675,6 +676,24 @@ class IIRFilterNode(AudioNode):
         return mag, phase
 
 
+class DelayNode(AudioNode):
+    """src/node/delay.rs:127-376 (DelayOptions{max_delay_time = 1, delay_time = 0}).  Feedback loops through
+    the node (the reference's cycle breaker) are out of scope of the device path."""
+
+    kind = NODE_DELAY
+
+    def __init__(self, ctx, max_delay_time: float = 1.0, delay_time: float = 0.0, **kw):
+        if not (0.0 < max_delay_time < 180.0):  # delay.rs:290-293
+            raise WaaError(2, "NotSupportedError - maxDelayTime MUST be greater than zero and less than three minutes")
+        super().__init__(ctx, **kw)
+        self.max_delay_time = float(max_delay_time)
+        self.delay_time = AudioParam(self, 0, delay_time)
+        self.params = [self.delay_time]
+
+    def _fill_desc(self, d):
+        d.d[0] = self.max_delay_time
+
+
 class RenderedBatch:
     """What start_rendering_sync returns: one AudioBuffer per instance (array [inst, ch, frames])."""
 
@@ -760,6 +779,9 @@ class OfflineAudioContext:
 
     def create_wave_shaper(self, **kw):
         return WaveShaperNode(self, **kw)
+
+    def create_delay(self, max_delay_time: float = 1.0, **kw):
+        return DelayNode(self, max_delay_time=max_delay_time, **kw)
 
     def create_iir_filter(self, feedforward, feedback, **kw):
         return IIRFilterNode(self, feedforward, feedback, **kw)

@@ -133,12 +133,13 @@ struct ProfileEntry {
 };
 
 struct Step {
-  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel
+  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather
   ChainDesc chain{};
   BiquadStreamDesc bq{};
   ConvDesc conv{};
   BiquadCoefDesc coef{};
   IirStreamDesc iir{};
+  DelayDesc delay{};
   int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
   void* zero_ptr = nullptr;
   size_t zero_bytes = 0;
@@ -666,6 +667,7 @@ void topo_visit(const waa_batch* b, uint32_t id, std::vector<uint8_t>& marked, s
 }
 
 int plan_convolver(waa_batch* b, uint32_t id);
+int plan_delay(waa_batch* b, uint32_t id);
 int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int interp);
 
 void plan_note(waa_batch* b, const char* fmt, ...) {
@@ -833,17 +835,25 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
       q.pow = reinterpret_cast<const double*>(o.ptr2);
       q.state = reinterpret_cast<double*>(o.ptr1);
       q.ns = std::abs(o.i0);
-      q.exact = iir_exact ? 1u : 0u;
+      // exact kernels: one lane per stream pays off for low orders or very many streams, one DPP row per
+      // stream otherwise (issue cycles per frame: ~12 ns + 32 per 64 streams vs ~64 per 4 streams, on 1024 SIMDs)
+      q.exact = 0u;
+      if (iir_exact) {
+        const double streams = (double)b->n_inst * cur_nch;
+        const double lane_cost = std::ceil(streams / 64. / 1024.) * (12. * q.ns + 32.);
+        const double row_cost = std::ceil(streams / 4. / 1024.) * 64.;
+        q.exact = (row_cost < lane_cost && !getenv("WAA_IIR_LANE")) || getenv("WAA_IIR_ROW") ? 2u : 1u;
+      }
       q.nch = cur_nch;
       q.out = seg_out;
       q.n_inst = b->n_inst;
       q.n_tiles = b->n_tiles;
       q.n_quanta = b->n_quanta;
       char name[32];
-      snprintf(name, sizeof name, "%s<%d>", iir_exact ? "iir_lane_kernel" : "iir_stream_kernel", q.ns);
+      snprintf(name, sizeof name, "%s<%d>", q.exact == 2 ? "iir_row_kernel" : q.exact == 1 ? "iir_lane_kernel" : "iir_stream_kernel", q.ns);
       st.profile_slot = slot_for(b, name);
       b->steps.push_back(st);
-      plan_note(b, "%s states=%d in=%s:%dch out=%s", iir_exact ? "iir_exact" : "iir_stream", q.ns,
+      plan_note(b, "%s states=%d in=%s:%dch out=%s", q.exact == 2 ? "iir_exact(row)" : q.exact == 1 ? "iir_exact(lane)" : "iir_stream", q.ns,
                 input_kind_name(inputs[0].kind), cur_nch, seg_out.base == out.base ? "final" : "temp");
       InputRef in{};
       in.kind = IN_SIGNAL;
@@ -971,13 +981,13 @@ int build_plan(waa_batch* b) {
     if (!n.live) continue;
     bool mat = false;
     const uint32_t kind = n.desc.kind;
-    if (kind == WAA_NODE_DESTINATION || kind == WAA_NODE_ANALYSER || kind == WAA_NODE_CONVOLVER) mat = true;
+    if (kind == WAA_NODE_DESTINATION || kind == WAA_NODE_ANALYSER || kind == WAA_NODE_CONVOLVER || kind == WAA_NODE_DELAY) mat = true;
     int live_consumers = 0;
     for (auto& e : b->edges)
       if (e.from == id && b->nodes[e.to].live) {
         live_consumers++;
         const Node& c = b->nodes[e.to];
-        if (c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir) mat = true;
+        if ((c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir) || c.desc.kind == WAA_NODE_DELAY) mat = true;
         int live_in = 0;
         for (int ie : c.in_edges)
           if (b->nodes[b->edges[ie].from].live) live_in++;
@@ -1002,6 +1012,12 @@ int build_plan(waa_batch* b) {
       int e = alloc_signal(term);
       if (e) return e;
       if ((e = plan_convolver(b, id))) return e;
+      continue;
+    }
+    if (term.desc.kind == WAA_NODE_DELAY) {
+      int e = alloc_signal(term);
+      if (e) return e;
+      if ((e = plan_delay(b, id))) return e;
       continue;
     }
     // identity node on a materialised signal of the same layout (destination / analyser / passthrough right
@@ -1256,56 +1272,73 @@ int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int inte
 
 // ConvolverNode with an impulse response (convolver.rs:259-317, 343-490): input mix chain (if needed)
 // + forward FFT / spectral MAC / inverse FFT steps.
-int plan_convolver(waa_batch* b, uint32_t id) {
+// Input of a node-major step (convolver, delay): the single producer's signal if its channel count already
+// matches, else a mixing chain into a temporary.
+int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig) {
   Node& n = b->nodes[id];
-  // input signal: the single producer if its channel count already matches, else a mixing chain
-  SignalRef in_sig{};
-  bool direct = false;
   if (n.in_edges.size() == 1) {
     Node& p = b->nodes[b->edges[n.in_edges[0]].from];
     if (p.materialized && p.out_nch == n.in_nch) {
-      in_sig = p.sig;
-      direct = true;
+      *out_sig = p.sig;
+      return 0;
     }
   }
-  if (!direct) {
-    float* ptr = nullptr;
-    int e = dev_alloc(b, &ptr, (size_t)b->n_inst * n.in_nch * b->lp);
-    if (e) return e;
-    in_sig = SignalRef{ptr, (uint64_t)n.in_nch * b->lp, b->lp, n.in_nch, 0};
-    Step st;
-    ChainDesc& cd = st.chain;
-    std::memset(&cd, 0, sizeof cd);
-    if (n.in_edges.empty()) {
-      cd.n_inputs = 1;
-      cd.in[0].kind = IN_SILENT;
-      cd.in[0].nch = 1;
-    } else {
-      std::vector<InputRef> ins;
-      for (int ie : n.in_edges) {
-        Node& pn = b->nodes[b->edges[ie].from];
-        if (!pn.materialized) return fail(WAA_ERR_INVALID_STATE, "internal: unmaterialised convolver input");
-        InputRef in{};
-        in.kind = IN_SIGNAL;
-        in.nch = pn.out_nch;
-        in.sig = pn.sig;
-        ins.push_back(in);
-      }
-      int e2 = reduce_fan_in(b, ins, n.in_nch, n.interp);
-      if (e2) return e2;
-      cd.n_inputs = (int)ins.size();
-      for (int k = 0; k < cd.n_inputs; k++) cd.in[k] = ins[k];
+  SignalRef in_sig;
+  int e = temp_signal(b, n.in_nch, &in_sig);
+  if (e) return e;
+  std::vector<InputRef> ins;
+  if (n.in_edges.empty()) {
+    InputRef in{};
+    in.kind = IN_SILENT;
+    in.nch = 1;
+    ins.push_back(in);
+  } else {
+    for (int ie : n.in_edges) {
+      Node& pn = b->nodes[b->edges[ie].from];
+      if (!pn.materialized) return fail(WAA_ERR_INVALID_STATE, "internal: unmaterialised input of a node-major step");
+      InputRef in{};
+      in.kind = IN_SIGNAL;
+      in.nch = pn.out_nch;
+      in.sig = pn.sig;
+      ins.push_back(in);
     }
-    cd.in_nch = n.in_nch;
-    cd.in_interp = n.interp;
-    cd.n_ops = 0;
-    cd.out = in_sig;
-    cd.n_inst = b->n_inst;
-    cd.n_tiles = b->n_tiles;
-    cd.n_quanta = b->n_quanta;
-    st.cmax = 2;
-    st.profile_slot = slot_for(b, "chain_kernel<2>");
-    b->steps.push_back(st);
+    if ((e = reduce_fan_in(b, ins, n.in_nch, n.interp))) return e;
+  }
+  if ((e = push_chain_step(b, ins, n.in_nch, n.interp, {}, in_sig))) return e;
+  *out_sig = in_sig;
+  return 0;
+}
+
+// DelayNode outside a cycle (delay.rs:428-745): one gather kernel from the materialised input
+int plan_delay(waa_batch* b, uint32_t id) {
+  Node& n = b->nodes[id];
+  Step st;
+  st.kind = 7;
+  DelayDesc& d = st.delay;
+  std::memset(&d, 0, sizeof d);
+  int e = node_input_signal(b, id, &d.in);
+  if (e) return e;
+  d.out = n.sig;
+  if ((e = upload_param(b, n.params[WAA_PARAM_DELAY_DELAY_TIME], &d.delay))) return e;
+  d.sample_rate = (double)b->sr;
+  d.frames = b->lp;
+  d.num_quanta = (int32_t)std::ceil(n.desc.d[0] * (double)b->sr / (double)RQ);
+  d.nch = n.in_nch;
+  d.n_inst = b->n_inst;
+  d.n_quanta = b->n_quanta;
+  st.profile_slot = slot_for(b, "delay_kernel");
+  b->steps.push_back(st);
+  plan_note(b, "delay node %u: %dch delayTime=%s ring=%d quanta", id, d.nch,
+            d.delay.mode == 0 ? "const" : d.delay.mode == 1 ? "k-rate" : "a-rate", d.num_quanta + 1);
+  return 0;
+}
+
+int plan_convolver(waa_batch* b, uint32_t id) {
+  Node& n = b->nodes[id];
+  SignalRef in_sig{};
+  {
+    int e = node_input_signal(b, id, &in_sig);
+    if (e) return e;
   }
   // one FFTConvolver per IR channel, at least two (convolver.rs:291-306); each trims its own trailing
   // |h| < 1e-6 samples (fft-convolver init) — only the longest trimmed length matters here
@@ -1805,6 +1838,13 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
           return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count cannot be greater than two");
         break;
       }
+      case WAA_NODE_DELAY:  // delay.rs:283-335
+        if (n.desc.d[0] == 0.) n.desc.d[0] = 1.;
+        if (!(n.desc.d[0] > 0. && n.desc.d[0] < 180.))
+          return fail(WAA_ERR_NOT_SUPPORTED,
+                      "NotSupportedError - maxDelayTime MUST be greater than zero and less than three minutes");
+        P(WAA_PARAM_DELAY_DELAY_TIME).init(n_inst, 0.f, 0.f, (float)n.desc.d[0]);
+        break;
       case WAA_NODE_WAVESHAPER:
         if (n.desc.i[0] != WAA_OVERSAMPLE_NONE)
           return fail(WAA_ERR_OUT_OF_SCOPE, "WaveShaper oversampling is out of scope (third-party rubato, parity unpinned)");
@@ -2184,6 +2224,7 @@ waa_status waa_render(waa_batch* b) {
       case 4: e = timed(st.slot_mac, [&] { launch_conv_direct(st.conv, b->stream); }); break;
       case 5: e = timed(st.profile_slot, [&] { launch_biquad_coefs(st.coef, b->stream); }); break;
       case 6: e = timed(st.profile_slot, [&] { launch_iir_stream(st.iir, b->stream); }); break;
+      case 7: e = timed(st.profile_slot, [&] { launch_delay(st.delay, b->stream); }); break;
       default: e = timed(st.profile_slot, [&] { launch_chain(st.chain, st.cmax, b->stream); }); break;
     }
     if (e) return e;

@@ -13,7 +13,7 @@
 //           order; only this pass produces output.
 // Inf/NaN anywhere (unstable filters; the reference flushes such outputs to 0, iir_filter.rs:383-385, which is
 // not affine) is detected off the critical path and that tile is redone lane after lane, exactly.
-// NS (template) = number of state variables, padded with zero coefficients to the next instantiated size.
+// NS (template) = number of state variables; every order 1..19 has its own instantiation.
 // Roofline: HBM for small orders (8 B per frame-channel, like the biquad kernel); the f64 vector rate takes over
 // around NS >= 8 (about 6 NS^2 + 4 NS * 32 DFMA per lane and tile).  No MFMA: the matrices are tiny and per
 // lane-vector, the scan is latency-, not throughput-shaped.
@@ -341,35 +341,122 @@ __global__ __launch_bounds__(64) void iir_lane_kernel(const IirStreamDesc d) {
   for (int k = 0; k < NS; k++) st[k] = s[k];
 }
 
-int iir_padded_states(int n_states) {
-  const int sizes[] = {2, 4, 8, 12, 19};
-  for (int s : sizes)
-    if (n_states <= s) return s;
-  return -1;
+// Exact kernel for higher orders: one DPP row (16 lanes) per stream, lane j owns states j*M .. j*M+M-1, four
+// streams per wave.  Per frame every lane forms y from lane 0's s_0 (row broadcast), takes s_{k+1} of its last
+// state from its right neighbour (row shift) and updates its own states: the dependent chain per frame is the
+// same handful of operations as in the scalar loop, but the NS-wide part runs across lanes instead of in time,
+// and 16x more wavefronts are in flight than with one lane per stream.  Arithmetic identical to the reference.
+template <int M>
+__global__ __launch_bounds__(64) void iir_row_kernel(const IirStreamDesc d) {
+  const int lane = threadIdx.x, j = lane & 15;
+  const uint32_t n_streams = d.n_inst * (uint32_t)d.nch;
+  uint32_t sid = blockIdx.x * 4 + (lane >> 4);
+  const bool valid = sid < n_streams;
+  if (!valid) sid = n_streams - 1;  // keep the row busy (whole-wave DPP), never store
+  const uint32_t inst = sid / (uint32_t)d.nch;
+  const int ch = (int)(sid % (uint32_t)d.nch);
+  __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);
+  const int ns = d.ns;
+  const double b0 = d.coef[0];
+  double bk[M], ak[M], s[M];
+  double* st = d.state + ((uint64_t)inst * d.nch + ch) * ns;
+  bool last = false;  // this lane owns s_{ns-1}: its successor is the constant 0 (iir_filter.rs:389-392)
+#pragma unroll
+  for (int t = 0; t < M; t++) {
+    const int k = j * M + t;
+    bk[t] = k < ns ? d.coef[k + 1] : 0.;
+    ak[t] = k < ns ? d.coef[ns + 1 + k + 1] : 0.;
+    s[t] = k < ns ? st[k] : 0.;
+    if (t == M - 1) last = k >= ns - 1;
+  }
+  const float* ip = d.in.sig.base + (uint64_t)inst * d.in.sig.inst_stride + (uint64_t)ch * d.in.sig.ch_stride;
+  float* op = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)ch * d.out.ch_stride;
+  constexpr int BLK = 16;
+  const uint64_t n_blocks = (uint64_t)d.n_tiles * TILE / BLK;
+  float4 nx[BLK / 4];
+#pragma unroll
+  for (int q = 0; q < BLK / 4; q++) nx[q] = reinterpret_cast<const float4*>(ip)[q];
+  auto dpp64 = [](double v, auto ctrl, auto bound) __attribute__((always_inline)) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), decltype(ctrl)::value, 0xf, 0xf, decltype(bound)::value);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), decltype(ctrl)::value, 0xf, 0xf, decltype(bound)::value);
+    return __hiloint2double(hi, lo);
+  };
+  for (uint64_t blk = 0; blk < n_blocks; blk++) {
+    float x[BLK];
+#pragma unroll
+    for (int q = 0; q < BLK / 4; q++) {
+      x[q * 4 + 0] = nx[q].x;
+      x[q * 4 + 1] = nx[q].y;
+      x[q * 4 + 2] = nx[q].z;
+      x[q * 4 + 3] = nx[q].w;
+    }
+    const uint64_t nb = blk + 1 < n_blocks ? blk + 1 : blk;
+#pragma unroll
+    for (int q = 0; q < BLK / 4; q++) nx[q] = reinterpret_cast<const float4*>(ip + nb * BLK)[q];
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < BLK; i++) {
+      const double xd = (double)x[i];
+      const double s0 = dpp64(s[0], std::integral_constant<int, 0x150>{}, std::false_type{});   // row_share:0
+      double y = __builtin_fma(b0, xd, s0);
+      if (!__builtin_isnormal(y)) y = 0.;
+      double nxt = dpp64(s[0], std::integral_constant<int, 0x101>{}, std::true_type{});         // row_shl:1, lane 15 <- 0
+      if (last) nxt = 0.;
+#pragma unroll
+      for (int t = 0; t < M; t++) {
+        const double next = t + 1 < M ? s[t + 1] : nxt;
+        s[t] = (bk[t] * xd - ak[t] * y) + next;
+      }
+      mine = i == j ? (float)y : mine;
+    }
+    if (valid) op[blk * BLK + j] = mine;
+  }
+  if (valid) {
+#pragma unroll
+    for (int t = 0; t < M; t++)
+      if (j * M + t < ns) st[j * M + t] = s[t];
+  }
 }
+
+int iir_padded_states(int n_states) {  // every order has its own instantiation: no zero-padded states
+  if (n_states < 1) return 1;  // a pure gain b0 still runs as a one-state filter with zero coefficients
+  return n_states <= 19 ? n_states : -1;
+}
+
+namespace {
+template <int NS>
+void launch_ns(const IirStreamDesc& d, hipStream_t s) {
+  if (d.exact == 1) {
+    const dim3 grid((d.n_inst * (uint32_t)d.nch + 63) / 64), block(64);
+    hipLaunchKernelGGL((iir_lane_kernel<NS>), grid, block, 0, s, d);
+  } else {
+    const dim3 grid(d.n_inst * (uint32_t)d.nch), block(64);
+    const size_t lds = 2 * 64 * LDS_ROW * sizeof(float);
+    hipLaunchKernelGGL((iir_stream_kernel<NS>), grid, block, lds, s, d);
+  }
+}
+template <int NS>
+void dispatch_ns(const IirStreamDesc& d, hipStream_t s) {
+  if constexpr (NS >= 1) {
+    if (d.ns == NS)
+      launch_ns<NS>(d, s);
+    else
+      dispatch_ns<NS - 1>(d, s);
+  }
+}
+}  // namespace
 
 void launch_iir_stream(const IirStreamDesc& d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (d.exact) {
-    const dim3 grid((d.n_inst * (uint32_t)d.nch + 63) / 64), block(64);
-    switch (d.ns) {
-      case 2: hipLaunchKernelGGL((iir_lane_kernel<2>), grid, block, 0, s, d); break;
-      case 4: hipLaunchKernelGGL((iir_lane_kernel<4>), grid, block, 0, s, d); break;
-      case 8: hipLaunchKernelGGL((iir_lane_kernel<8>), grid, block, 0, s, d); break;
-      case 12: hipLaunchKernelGGL((iir_lane_kernel<12>), grid, block, 0, s, d); break;
-      default: hipLaunchKernelGGL((iir_lane_kernel<19>), grid, block, 0, s, d); break;
-    }
+  if (d.exact == 2) {
+    const dim3 grid((d.n_inst * (uint32_t)d.nch + 3) / 4), block(64);
+    if (d.ns <= 16)
+      hipLaunchKernelGGL((iir_row_kernel<1>), grid, block, 0, s, d);
+    else
+      hipLaunchKernelGGL((iir_row_kernel<2>), grid, block, 0, s, d);
     return;
   }
-  const dim3 grid(d.n_inst * (uint32_t)d.nch), block(64);
-  const size_t lds = 2 * 64 * LDS_ROW * sizeof(float);
-  switch (d.ns) {
-    case 2: hipLaunchKernelGGL((iir_stream_kernel<2>), grid, block, lds, s, d); break;
-    case 4: hipLaunchKernelGGL((iir_stream_kernel<4>), grid, block, lds, s, d); break;
-    case 8: hipLaunchKernelGGL((iir_stream_kernel<8>), grid, block, lds, s, d); break;
-    case 12: hipLaunchKernelGGL((iir_stream_kernel<12>), grid, block, lds, s, d); break;
-    default: hipLaunchKernelGGL((iir_stream_kernel<19>), grid, block, lds, s, d); break;
-  }
+  dispatch_ns<19>(d, s);
 }
 
 }  // namespace waa

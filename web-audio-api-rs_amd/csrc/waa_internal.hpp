@@ -142,15 +142,15 @@ struct IirStreamDesc {
   const double* coef;  // [2][ns+1]: normalised feedforward b[0..ns], then feedback a[0..ns], zero padded
   const double* pow;   // [6][ns][ns]: M^(32 * 2^k), M = zero-input state transition
   double* state;       // [n_inst][nch][ns]
-  int32_t ns;          // padded state count, one of the instantiated kernel sizes
+  int32_t ns;          // state count (1..19)
   int32_t nch;
   SignalRef out;
   uint32_t n_inst;
   uint32_t n_tiles;
   uint32_t n_quanta;
-  uint32_t exact;      // 1: lane-per-stream kernel (input must be IN_SIGNAL), see waa_iir_stream.hip
+  uint32_t exact;      // 0: scan kernel; exact kernels (input must be IN_SIGNAL): 1 lane per stream, 2 DPP row per stream
 };
-int iir_padded_states(int n_states);  // smallest instantiated ns >= n_states
+int iir_padded_states(int n_states);  // kernel state count for a filter with n_states state variables
 void launch_iir_stream(const IirStreamDesc& d, void* stream);
 
 // ---- ConvolverNode (convolver.rs:343-490 + fft-convolver), node-major overlap-save ------------
@@ -202,6 +202,19 @@ void launch_conv_ir_spectra(const ConvDesc& d, void* stream);
 void launch_conv_forward(const ConvDesc& d, void* stream);
 void launch_conv_mac(const ConvDesc& d, void* stream);
 void launch_conv_inverse(const ConvDesc& d, void* stream);
+
+// ---- DelayNode outside a cycle (delay.rs:428-745) as a gather from its materialised input ---------
+struct DelayDesc {
+  SignalRef in, out;
+  ParamRef delay;        // delayTime, clamped to [0, maxDelayTime] by the host
+  double sample_rate;
+  uint64_t frames;       // padded frames per channel (multiple of TILE)
+  int32_t num_quanta;    // ring capacity - 1 = ceil(maxDelayTime * sample_rate / 128), delay.rs:300-302
+  int32_t nch;
+  uint32_t n_inst;
+  uint32_t n_quanta;
+};
+void launch_delay(const DelayDesc& d, void* stream);
 
 // ---- per-frame biquad coefficients for a-rate params (biquad_filter.rs:837-855) -------------
 struct BiquadCoefDesc {
