@@ -132,7 +132,14 @@ typedef struct {
   double d[8];
 } waa_node_desc;
 
-/* AudioNode::connect_from_output_to_input(from, output, to, input); mirrors graph.rs Edge. */
+/* AudioNode::connect_from_output_to_input(from, output, to, input); mirrors graph.rs Edge.
+ * `node.connect(&audio_param)` (audio-rate modulation, src/param.rs:686-795: the param is a graph node with
+ * channel count 1 / explicit / discrete whose summed input is added to the intrinsic value) is expressed as an
+ * edge into the OWNING node with to_input = WAA_PARAM_INPUT(param id).  Supported on the device for a-rate
+ * params rendered there (Gain gain, Biquad frequency/detune/Q/gain, Delay delayTime, StereoPanner pan,
+ * ConstantSource offset); params evaluated by the host (source playbackRate/detune, panner geometry) report
+ * WAA_ERR_OUT_OF_SCOPE when modulated. */
+#define WAA_PARAM_INPUT(param) (0x80000000u | (uint32_t)(param))
 typedef struct {
   uint32_t from;
   uint32_t from_output;

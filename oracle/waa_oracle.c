@@ -559,6 +559,8 @@ typedef struct {
   /* biquad */
   double xy[ORC_MAXC][4];
   int xy_len;
+  /* audio-rate inputs of this node's AudioParams (param.rs:686-699), allocated for modulated params only */
+  Quantum* pin[WAA_MAX_PARAMS];
   /* delay line (delay.rs:297-303): ring of num_quanta + 1 render quanta shared by writer and reader */
   Quantum* dl_ring;
   int dl_cap, dl_windex, dl_rindex;
@@ -614,21 +616,40 @@ static void param_init(Param* p, uint32_t n_inst, float defv, float minv, float 
 /* AudioParamValues::get (src/render/processor.rs:186-229): slice of len 1 or 128.
  * Values handed in by the host already went through the timeline; the clamp / NaN rule of
  * AudioParamProcessor::mix_to_output (src/param.rs:739-797) is applied here. */
-static const float* param_get(const Param* p, uint32_t inst, uint64_t q, int* len, float* tmp) {
+static float param_fix(const Param* p, float x) { /* param.rs:755-761: NaN -> default, max then min */
+  return isnan(x) ? p->defv : fminf(fmaxf(x, p->minv), p->maxv);
+}
+/* AudioParamValues::get of one param for this quantum = AudioParamProcessor::process (param.rs:686-795):
+ * intrinsic values (a constant or a caller-computed block: the timeline of param.rs:1050-1600 stays on the
+ * host) mixed with the param's audio-rate input `in` (NULL when nothing is connected).  All params the device
+ * path modulates are a-rate. */
+static const float* param_get_in(const Param* p, const Quantum* in, uint32_t inst, uint64_t q, int* len, float* tmp) {
   const ParamBlock* b = &p->blk[inst];
+  float one;
+  const float* v = &one;
+  int vlen = 1;
+  one = p->cst[inst];
   if (b->v && q >= b->q0 && q < b->q0 + b->nq) {
-    const float* v = b->v + (size_t)(q - b->q0) * b->vpq;
-    *len = (int)b->vpq;
-    for (int i = 0; i < *len; i++) {
-      float x = v[i];
-      tmp[i] = isnan(x) ? p->defv : fminf(fmaxf(x, p->minv), p->maxv);
-    }
-    return tmp;
+    v = b->v + (size_t)(q - b->q0) * b->vpq;
+    vlen = (int)b->vpq;
   }
-  float x = p->cst[inst];
-  tmp[0] = isnan(x) ? p->defv : fminf(fmaxf(x, p->minv), p->maxv);
-  *len = 1;
+  int in_silent = !in || q_is_silent(in);
+  if (vlen == 1) {
+    if (in_silent) { /* single-valued output */
+      tmp[0] = param_fix(p, v[0] + (in ? in->d[0][0] : 0.f));
+      *len = 1;
+    } else {
+      for (int i = 0; i < RQ; i++) tmp[i] = param_fix(p, in->d[0][i] + v[0]);
+      *len = RQ;
+    }
+  } else {
+    for (int i = 0; i < RQ; i++) tmp[i] = param_fix(p, (in ? in->d[0][i] : 0.f) + v[i]);
+    *len = RQ;
+  }
   return tmp;
+}
+static const float* param_get(const Param* p, uint32_t inst, uint64_t q, int* len, float* tmp) {
+  return param_get_in(p, NULL, inst, q, len, tmp);
 }
 
 /* graph.rs:331-487: DFS post-order over outgoing edges in insertion order, reversed. */
@@ -697,7 +718,7 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
   memcpy(b->edges, g->edges, sizeof(waa_edge_desc) * g->n_edges);
   for (uint32_t e = 0; e < g->n_edges; e++) {
     if (g->edges[e].from >= g->n_nodes || g->edges[e].to >= g->n_nodes || g->edges[e].from_output != 0 ||
-        g->edges[e].to_input != 0)
+        (g->edges[e].to_input != 0 && !(g->edges[e].to_input & 0x80000000u)))
       return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - invalid edge %u", e);
   }
   for (uint32_t i = 0; i < g->n_nodes; i++) {
@@ -828,6 +849,22 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
   /* state */
   b->st = (NodeState**)calloc(n_inst, sizeof(NodeState*));
   for (uint32_t k = 0; k < n_inst; k++) b->st[k] = (NodeState*)calloc(g->n_nodes, sizeof(NodeState));
+  for (uint32_t e = 0; e < g->n_edges; e++) { /* node.connect(&param): src/param.rs:300-320 */
+    uint32_t ti = g->edges[e].to_input;
+    if (!(ti & 0x80000000u)) continue;
+    uint32_t pid = ti & 0x7fffffffu, to = g->edges[e].to;
+    NodeCfg* dn = &b->nodes[to];
+    if ((int)pid >= dn->n_params) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - node %u has no param %u", to, pid);
+    uint32_t kind = dn->desc.kind;
+    if (!(kind == WAA_NODE_GAIN || kind == WAA_NODE_BIQUAD || kind == WAA_NODE_DELAY || kind == WAA_NODE_STEREO_PANNER ||
+          kind == WAA_NODE_CONSTANT_SOURCE))
+      return fail(WAA_ERR_OUT_OF_SCOPE, "audio-rate modulation of a host-evaluated param (node %u) is out of scope", to);
+    for (uint32_t k = 0; k < n_inst; k++)
+      if (!b->st[k][to].pin[pid]) {
+        b->st[k][to].pin[pid] = (Quantum*)malloc(sizeof(Quantum));
+        q_make_silent(b->st[k][to].pin[pid]);
+      }
+  }
   b->out = (float*)calloc((size_t)n_inst * n_out * (length ? length : 1), sizeof(float));
   prefault(b->out, (size_t)n_inst * n_out * (length ? length : 1) * sizeof(float));
   *out = b;
@@ -852,6 +889,7 @@ void orc_batch_destroy(orc_batch* b) {
       for (int c = 0; c < 4; c++) convstate_free(s->conv[c]);
       free(s->ring);
       free(s->dl_ring);
+      for (int p = 0; p < WAA_MAX_PARAMS; p++) free(s->pin[p]);
       free(s->last_fft_output);
     }
     free(b->st[k]);
@@ -1558,7 +1596,7 @@ static void process_constant_source(NodeCfg* n, NodeState* s, uint32_t inst, con
   output->silent[0] = 0;
   float tmp[RQ];
   int len;
-  const float* offset = param_get(&n->params[0], inst, sc->quantum, &len, tmp);
+  const float* offset = param_get_in(&n->params[0], s->pin[0], inst, sc->quantum, &len, tmp);
   if (len == 1 && s->start_time <= sc->current_time && s->stop_time >= next_block_time) {
     for (int i = 0; i < RQ; i++) output->d[0][i] = offset[0];
   } else {
@@ -1602,10 +1640,10 @@ static void process_biquad(NodeCfg* n, NodeState* s, uint32_t inst, const Scope*
   }
   float tf[RQ], td[RQ], tq[RQ], tg[RQ];
   int lf, ld, lq, lg;
-  const float* frequency = param_get(&n->params[WAA_PARAM_BIQUAD_FREQUENCY], inst, sc->quantum, &lf, tf);
-  const float* detune = param_get(&n->params[WAA_PARAM_BIQUAD_DETUNE], inst, sc->quantum, &ld, td);
-  const float* q = param_get(&n->params[WAA_PARAM_BIQUAD_Q], inst, sc->quantum, &lq, tq);
-  const float* gain = param_get(&n->params[WAA_PARAM_BIQUAD_GAIN], inst, sc->quantum, &lg, tg);
+  const float* frequency = param_get_in(&n->params[WAA_PARAM_BIQUAD_FREQUENCY], s->pin[WAA_PARAM_BIQUAD_FREQUENCY], inst, sc->quantum, &lf, tf);
+  const float* detune = param_get_in(&n->params[WAA_PARAM_BIQUAD_DETUNE], s->pin[WAA_PARAM_BIQUAD_DETUNE], inst, sc->quantum, &ld, td);
+  const float* q = param_get_in(&n->params[WAA_PARAM_BIQUAD_Q], s->pin[WAA_PARAM_BIQUAD_Q], inst, sc->quantum, &lq, tq);
+  const float* gain = param_get_in(&n->params[WAA_PARAM_BIQUAD_GAIN], s->pin[WAA_PARAM_BIQUAD_GAIN], inst, sc->quantum, &lg, tg);
   double srd = (double)sc->sample_rate;
   int type = n->desc.i[0];
   Coefs coefs[RQ];
@@ -1731,7 +1769,7 @@ static void process_delay(NodeCfg* n, NodeState* s, uint32_t inst, const Scope* 
   q_set_number_of_channels(output, nch);
   float tmp[RQ];
   int len;
-  const float* delay = param_get(&n->params[0], inst, sc->quantum, &len, tmp);
+  const float* delay = param_get_in(&n->params[0], s->pin[0], inst, sc->quantum, &len, tmp);
   int ring_size = s->dl_cap, ring_index = s->dl_rindex;
   PlaybackInfo infos[RQ];
   if (len == 1) {
@@ -1780,7 +1818,7 @@ static void process_gain(NodeCfg* n, NodeState* s, uint32_t inst, const Scope* s
   }
   float tmp[RQ];
   int len;
-  const float* gain = param_get(&n->params[0], inst, sc->quantum, &len, tmp);
+  const float* gain = param_get_in(&n->params[0], s->pin[0], inst, sc->quantum, &len, tmp);
   if (len == 1) {
     float threshold = 1e-6f;
     if (fabsf(gain[0]) <= threshold) {
@@ -1821,7 +1859,7 @@ static void process_stereo_panner(NodeCfg* n, NodeState* s, uint32_t inst, const
   }
   float tmp[RQ];
   int len;
-  const float* pan_values = param_get(&n->params[0], inst, sc->quantum, &len, tmp);
+  const float* pan_values = param_get_in(&n->params[0], s->pin[0], inst, sc->quantum, &len, tmp);
   float (*L) = output->d[0], (*R) = output->d[1];
   if (input->n == 1) {
     const float* in = input->d[0];
@@ -2233,9 +2271,15 @@ static void render_instance(orc_batch* b, uint32_t inst) {
         if (b->edges[e].from != id) continue;
         NodeCfg* dn = &b->nodes[b->edges[e].to];
         NodeState* ds = &st[b->edges[e].to];
-        q_add(&ds->in, &s->out, dn->cc, dn->ccmode, dn->ccinterp);
+        uint32_t ti = b->edges[e].to_input;
+        if (ti & 0x80000000u) /* AudioParam node: channel count 1, explicit, discrete (param.rs:309-311) */
+          q_add(ds->pin[ti & 0x7fffffffu], &s->out, 1, WAA_COUNT_MODE_EXPLICIT, WAA_INTERP_DISCRETE);
+        else
+          q_add(&ds->in, &s->out, dn->cc, dn->ccmode, dn->ccinterp);
       }
       q_make_silent(&s->in);
+      for (int p = 0; p < WAA_MAX_PARAMS; p++)
+        if (s->pin[p]) q_make_silent(s->pin[p]);
     }
     const Quantum* rendered = &st[0].out;
     uint64_t remaining = b->length - written;

@@ -39,6 +39,7 @@ NODE_STEREO_PANNER, NODE_PANNER, NODE_ANALYSER, NODE_WAVESHAPER, NODE_CONSTANT_S
 NODE_IIR_FILTER = 10
 NODE_DELAY = 11
 MAX_IIR_COEFFS = 20
+PARAM_INPUT = 0x80000000  # WAA_PARAM_INPUT(param): edge into an AudioParam of the target node
 COUNT_MODE = {"max": 0, "clamped-max": 1, "explicit": 2}
 INTERPRETATION = {"speakers": 0, "discrete": 1}
 BIQUAD_TYPE = {"lowpass": 0, "highpass": 1, "bandpass": 2, "notch": 3, "allpass": 4, "peaking": 5,
@@ -291,7 +292,13 @@ class AudioNode:
         self._explicit_config = True
 
     # AudioNode::connect (audio_node.rs:247): returns the destination node for chaining
-    def connect(self, dest: "AudioNode", output: int = 0, input: int = 0) -> "AudioNode":
+    def connect(self, dest, output: int = 0, input: int = 0):
+        """AudioNode::connect; `dest` may be an AudioParam (audio-rate modulation, src/param.rs:300-320)."""
+        if isinstance(dest, AudioParam):
+            if dest._node.context is not self.context:
+                raise WaaError(1, "InvalidAccessError - Attempting to connect nodes from different contexts")
+            self.context._edges.append((self.id, output, dest._node.id, PARAM_INPUT | dest._pid))
+            return dest
         if dest.context is not self.context:
             raise WaaError(1, "InvalidAccessError - Attempting to connect nodes from different contexts")
         self.context._edges.append((self.id, output, dest.id, input))

@@ -122,6 +122,11 @@ struct Node {
   bool materialized = false;
   SignalRef sig{};     // valid when materialized
   std::vector<int> in_edges;   // indices into edges, in summing order
+  // audio-rate inputs of this node's AudioParams (edges with to_input = WAA_PARAM_INPUT(k)), in summing order,
+  // and the per-frame value signal planned for them (param.rs:686-795)
+  std::vector<std::vector<int>> pin_edges;
+  std::vector<ParamRef> pin_ref;
+  std::vector<char> pin_ready;
   int n_consumers = 0;
 };
 
@@ -632,6 +637,65 @@ int upload_param(waa_batch* b, const ParamStore& p, ParamRef* ref) {
   ref->pad = 0;
   return 0;
 }
+// Value mode of param k of node `id` as the kernels will see it: a param with an audio-rate input is per-frame.
+int param_mode(const Node& n, size_t k) {
+  if (k < n.pin_edges.size() && !n.pin_edges[k].empty()) return 2;
+  return n.params[k].mode();
+}
+int push_chain_step(waa_batch* b, const std::vector<InputRef>& inputs, int in_nch, int in_interp,
+                    const std::vector<OpDesc>& ops, const SignalRef& out);
+int temp_signal(waa_batch* b, int nch, SignalRef* out);
+int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int interp);
+// ParamRef of param k of node `id`.  Without an audio-rate input: the uploaded constants / value blocks.  With one
+// (param.rs:686-795): a chain that sums the connected outputs mixed to ONE channel (count 1, explicit, discrete,
+// param.rs:309-311), adds the intrinsic value and clamps, written to a one-channel signal the consumer reads
+// as per-frame values.  Planned once, right before the first consumer (its producers are materialised and
+// precede the owner in processing order).
+int node_param(waa_batch* b, uint32_t id, size_t k, ParamRef* ref) {
+  Node& n = b->nodes[id];
+  if (k >= n.pin_edges.size() || n.pin_edges[k].empty()) return upload_param(b, n.params[k], ref);
+  if (n.pin_ready[k]) {
+    *ref = n.pin_ref[k];
+    return 0;
+  }
+  std::vector<InputRef> ins;
+  for (int ie : n.pin_edges[k]) {
+    Node& pn = b->nodes[b->edges[ie].from];
+    if (!pn.materialized || !pn.sig.base)
+      return fail(WAA_ERR_INVALID_STATE, "internal: AudioParam input of node %u is not materialised yet", id);
+    InputRef in{};
+    in.kind = IN_SIGNAL;
+    in.nch = pn.out_nch;
+    in.sig = pn.sig;
+    ins.push_back(in);
+  }
+  int e = reduce_fan_in(b, ins, 1, WAA_INTERP_DISCRETE);
+  if (e) return e;
+  OpDesc o{};
+  o.kind = OP_PARAM_ADD;
+  o.nch_in = o.nch_out = 1;
+  if ((e = upload_param(b, n.params[k], &o.p0))) return e;
+  auto bits = [](float f) {
+    int32_t i;
+    std::memcpy(&i, &f, 4);
+    return i;
+  };
+  o.i0 = bits(n.params[k].minv);
+  o.i1 = bits(n.params[k].maxv);
+  o.i2 = bits(n.params[k].defv);
+  SignalRef sig;
+  if ((e = temp_signal(b, 1, &sig))) return e;
+  if ((e = push_chain_step(b, ins, 1, WAA_INTERP_DISCRETE, {o}, sig))) return e;
+  ParamRef r{};
+  r.base = sig.base;
+  r.stride = sig.inst_stride;
+  r.mode = 2;
+  n.pin_ref[k] = r;
+  n.pin_ready[k] = 1;
+  *ref = r;
+  return 0;
+}
+
 // Upload host-computed per-instance (mode 0) or per-(instance, quantum) (mode 1) values.
 int upload_values(waa_batch* b, const std::vector<float>& host, int mode, ParamRef* ref) {
   float* d = nullptr;
@@ -695,6 +759,7 @@ const char* op_name(int k) {
     case OP_PANNER: return "PANNER";
     case OP_MIX: return "MIX";
     case OP_IIR: return "IIR";
+    case OP_PARAM_ADD: return "PARAM_ADD";
     default: return "?";
   }
 }
@@ -917,16 +982,33 @@ int build_plan(waa_batch* b) {
   // incoming edges in summing order: by processing position of the producer, then edge insertion order
   for (auto& n : b->nodes) {
     n.in_edges.clear();
+    n.pin_edges.assign(n.params.size(), {});
+    n.pin_ref.assign(n.params.size(), ParamRef{});
+    n.pin_ready.assign(n.params.size(), 0);
     n.n_consumers = 0;
     n.live = n.materialized = false;
   }
   for (uint32_t e = 0; e < b->edges.size(); e++) {
-    b->nodes[b->edges[e].to].in_edges.push_back((int)e);
-    b->nodes[b->edges[e].from].n_consumers++;
+    const waa_edge_desc& ed = b->edges[e];
+    Node& to = b->nodes[ed.to];
+    if (ed.to_input & 0x80000000u) {
+      const uint32_t pid = ed.to_input & 0x7fffffffu;
+      if (pid >= to.params.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - node %u has no param %u", ed.to, pid);
+      const uint32_t k = to.desc.kind;
+      if (!(k == WAA_NODE_GAIN || k == WAA_NODE_BIQUAD || k == WAA_NODE_DELAY || k == WAA_NODE_STEREO_PANNER ||
+            k == WAA_NODE_CONSTANT_SOURCE))
+        return fail(WAA_ERR_OUT_OF_SCOPE, "audio-rate modulation of a host-evaluated param (node %u) is out of scope", ed.to);
+      to.pin_edges[pid].push_back((int)e);
+    } else {
+      to.in_edges.push_back((int)e);
+    }
+    b->nodes[ed.from].n_consumers++;
   }
-  for (auto& n : b->nodes)
-    std::stable_sort(n.in_edges.begin(), n.in_edges.end(),
-                     [&](int x, int y) { return pos[b->edges[x].from] < pos[b->edges[y].from]; });
+  auto by_position = [&](int x, int y) { return pos[b->edges[x].from] < pos[b->edges[y].from]; };
+  for (auto& n : b->nodes) {
+    std::stable_sort(n.in_edges.begin(), n.in_edges.end(), by_position);
+    for (auto& pe : n.pin_edges) std::stable_sort(pe.begin(), pe.end(), by_position);
+  }
   // liveness: everything that reaches the destination or an analyser
   {
     std::vector<uint32_t> stack;
@@ -938,6 +1020,8 @@ int build_plan(waa_batch* b) {
       if (b->nodes[id].live) continue;
       b->nodes[id].live = true;
       for (int e : b->nodes[id].in_edges) stack.push_back(b->edges[e].from);
+      for (auto& pe : b->nodes[id].pin_edges)
+        for (int e : pe) stack.push_back(b->edges[e].from);
     }
   }
   // static channel counts (the reference's counts are dynamic: a silent quantum is mono; every case the
@@ -988,6 +1072,7 @@ int build_plan(waa_batch* b) {
         live_consumers++;
         const Node& c = b->nodes[e.to];
         if ((c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir) || c.desc.kind == WAA_NODE_DELAY) mat = true;
+        if (e.to_input & 0x80000000u) mat = true;  // feeds an AudioParam: read back as a per-frame value signal
         int live_in = 0;
         for (int ie : c.in_edges)
           if (b->nodes[b->edges[ie].from].live) live_in++;
@@ -1127,7 +1212,7 @@ int build_plan(waa_batch* b) {
 static int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   Node& n = b->nodes[id];
   if (n.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
-    int e = upload_param(b, n.params[0], &in->offset);
+    int e = node_param(b, id, 0, &in->offset);
     if (e) return e;
     // active frame range per instance (constant_source.rs:203-258), found by replaying the quantum loop
     std::vector<int64_t> act((size_t)b->n_inst * 2);
@@ -1319,7 +1404,7 @@ int plan_delay(waa_batch* b, uint32_t id) {
   int e = node_input_signal(b, id, &d.in);
   if (e) return e;
   d.out = n.sig;
-  if ((e = upload_param(b, n.params[WAA_PARAM_DELAY_DELAY_TIME], &d.delay))) return e;
+  if ((e = node_param(b, id, WAA_PARAM_DELAY_DELAY_TIME, &d.delay))) return e;
   d.sample_rate = (double)b->sr;
   d.frames = b->lp;
   d.num_quanta = (int32_t)std::ceil(n.desc.d[0] * (double)b->sr / (double)RQ);
@@ -1479,7 +1564,7 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
       OpDesc o{};
       o.kind = OP_GAIN;
       o.nch_in = o.nch_out = nch;
-      int e = upload_param(b, n.params[0], &o.p0);
+      int e = node_param(b, id, 0, &o.p0);
       if (e) return e;
       ops.push_back(o);
       break;
@@ -1489,9 +1574,9 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
       o.kind = OP_BIQUAD;
       o.nch_in = o.nch_out = nch;
       bool varies = false, a_rate = false;
-      for (auto& p : n.params) {
-        if (p.mode() == 2) a_rate = true;
-        if (p.mode() == 1) varies = true;
+      for (size_t k = 0; k < n.params.size(); k++) {
+        if (param_mode(n, k) == 2) a_rate = true;
+        if (param_mode(n, k) == 1) varies = true;
       }
       if (a_rate) {
         // a-rate params: coefficients per frame (biquad_filter.rs:837-855), computed on the device in f64 from
@@ -1501,10 +1586,10 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
         BiquadCoefDesc& cdsc = cs.coef;
         std::memset(&cdsc, 0, sizeof cdsc);
         int e;
-        if ((e = upload_param(b, n.params[WAA_PARAM_BIQUAD_FREQUENCY], &cdsc.frequency)) ||
-            (e = upload_param(b, n.params[WAA_PARAM_BIQUAD_DETUNE], &cdsc.detune)) ||
-            (e = upload_param(b, n.params[WAA_PARAM_BIQUAD_Q], &cdsc.q)) ||
-            (e = upload_param(b, n.params[WAA_PARAM_BIQUAD_GAIN], &cdsc.gain)))
+        if ((e = node_param(b, id, WAA_PARAM_BIQUAD_FREQUENCY, &cdsc.frequency)) ||
+            (e = node_param(b, id, WAA_PARAM_BIQUAD_DETUNE, &cdsc.detune)) ||
+            (e = node_param(b, id, WAA_PARAM_BIQUAD_Q, &cdsc.q)) ||
+            (e = node_param(b, id, WAA_PARAM_BIQUAD_GAIN, &cdsc.gain)))
           return e;
         cdsc.n_frames = (uint64_t)b->n_quanta * RQ;
         cdsc.n_inst = b->n_inst;
@@ -1649,9 +1734,9 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
       o.nch_in = nch;
       o.nch_out = 2;
       const ParamStore& p = n.params[0];
-      int e = upload_param(b, p, &o.p0);
+      int e = node_param(b, id, 0, &o.p0);
       if (e) return e;
-      if (p.mode() != 2) {
+      if (param_mode(n, 0) != 2) {
         // gains on the host with the same libm sinf the reference's f32::sin resolves to (stereo_panner.rs:74-79)
         const uint32_t cnt = p.mode() == 1 ? b->n_quanta : 1;
         std::vector<float> gl((size_t)b->n_inst * cnt), gr((size_t)b->n_inst * cnt);
@@ -1785,7 +1870,8 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
   b->lp = (uint64_t)b->n_tiles * TILE;
   for (uint32_t e = 0; e < g->n_edges; e++) {
     const waa_edge_desc& ed = g->edges[e];
-    if (ed.from >= g->n_nodes || ed.to >= g->n_nodes || ed.from_output != 0 || ed.to_input != 0)
+    if (ed.from >= g->n_nodes || ed.to >= g->n_nodes || ed.from_output != 0 ||
+        (ed.to_input != 0 && !(ed.to_input & 0x80000000u)))
       return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - invalid edge %u", e);
     b->edges.push_back(ed);
   }

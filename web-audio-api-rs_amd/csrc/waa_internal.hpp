@@ -81,13 +81,16 @@ enum : int32_t {
   OP_STEREO_PAN = 4,  // stereo_panner.rs:218-317
   OP_PANNER = 5,      // panner.rs:830-897, 988-1057 (equal power)
   OP_MIX = 6,         // quantum.rs:285-505
-  OP_IIR = 7          // iir_filter.rs:323-405 (always cut out of the chain into the streaming IIR kernel)
+  OP_IIR = 7,         // iir_filter.rs:323-405 (always cut out of the chain into the streaming IIR kernel)
+  OP_PARAM_ADD = 8    // param.rs:737-795: audio-rate input of an AudioParam + intrinsic value, clamped
 };
 struct OpDesc {
   int32_t kind;
   int32_t nch_in;
   int32_t nch_out;
-  int32_t i0;        // MIX: interpretation; WAVESHAPER: curve length; BIQUAD: coef mode (0 per inst, 1 per quantum, 2 per frame); IIR: padded state count, negative = exact lane kernel
+  int32_t i1;        // PARAM_ADD: max value (float bits)
+  int32_t i2;        // PARAM_ADD: default value (float bits)
+  int32_t i0;        // MIX: interpretation; WAVESHAPER: curve length; BIQUAD: coef mode (0 per inst, 1 per quantum, 2 per frame); IIR: padded state count, negative = exact lane kernel; PARAM_ADD: min value (float bits)
   ParamRef p0;       // GAIN: gain; STEREO_PAN: pan; PANNER: azimuth (wrapped)
   ParamRef p1;       // STEREO_PAN / PANNER: gain_l
   ParamRef p2;       // STEREO_PAN / PANNER: gain_r

@@ -577,6 +577,25 @@ __global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDes
           }
           break;
         }
+        case OP_PARAM_ADD: {
+          // AudioParamProcessor::mix_to_output (param.rs:737-795): input (already mixed to one channel) + intrinsic
+          // value, NaN -> default, clamp with max/min (not `clamp`: no NaN branch)
+          const float pmin = __int_as_float(op.i0), pmax = __int_as_float(op.i1), pdef = __int_as_float(op.i2);
+#pragma unroll
+          for (int j = 0; j < NV4; j++) {
+            const uint32_t q = tile * QPT + j * 2 + (lane >> 5);
+            const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
+            const uint64_t f = (uint64_t)tile * TILE_FR + j * 256 + lane * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const uint64_t fc = f + e < (uint64_t)d.n_quanta * RQ ? f + e : (uint64_t)d.n_quanta * RQ - 1;
+              float o1 = v[0][j * 4 + e] + param_at(op.p0, inst, qc, fc);
+              o1 = o1 != o1 ? pdef : fminf(fmaxf(o1, pmin), pmax);
+              v[0][j * 4 + e] = o1;
+            }
+          }
+          break;
+        }
         case OP_BIQUAD: {
           if constexpr (SERIAL) {
             const double* coef = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0;
