@@ -564,6 +564,8 @@ typedef struct {
   /* delay line (delay.rs:297-303): ring of num_quanta + 1 render quanta shared by writer and reader */
   Quantum* dl_ring;
   int dl_cap, dl_windex, dl_rindex;
+  uint64_t dl_latest_frame_written;
+  int dl_written_once, dl_in_cycle;
   /* iir filter: per-channel state, iir_filter.rs:269 */
   double iir_state[ORC_MAXC][WAA_MAX_IIR_COEFFS];
   int iir_nch;
@@ -652,20 +654,89 @@ static const float* param_get(const Param* p, uint32_t inst, uint64_t q, int* le
   return param_get_in(p, NULL, inst, q, len, tmp);
 }
 
-/* graph.rs:331-487: DFS post-order over outgoing edges in insertion order, reversed. */
-static void visit(const orc_batch* b, uint32_t id, unsigned char* marked, unsigned char* temp, uint32_t* ordered,
-                  uint32_t* n_ordered, int* cycle) {
-  if (temp[id]) {
-    *cycle = 1;
-    return;
+/* graph.rs:323-487 order_nodes/visit: DFS post-order over outgoing edges in insertion order, reversed; cycles
+ * are broken at the first cycle breaker on the detected loop (a DelayNode's WRITER half: its writer->reader edge
+ * is cleared and the ordering restarts, graph.rs:340-361,440-452); nodes of a cycle without a breaker are
+ * dropped from the ordering (muted, graph.rs:362-368,455-458).  A DelayNode is two graph nodes in the reference
+ * (delay.rs:283-366: writer registered first, reader second, edge writer->reader); here the node id is the
+ * writer and id | ORC_READER the reader. */
+#define ORC_READER 0x80000000u
+typedef struct {
+  const orc_batch* b;
+  const unsigned char* cut; /* [n_nodes] writer->reader edge cleared */
+  uint32_t *marked, n_marked, *temp, n_temp, *ordered, n_ordered, *in_cycle, n_in_cycle;
+  uint32_t breaker;
+} OrderCtx;
+static int vtx_in(const uint32_t* a, uint32_t n, uint32_t v) {
+  for (uint32_t i = 0; i < n; i++)
+    if (a[i] == v) return (int)i;
+  return -1;
+}
+static int order_visit(OrderCtx* c, uint32_t v) {
+  const orc_batch* b = c->b;
+  int pos = vtx_in(c->temp, c->n_temp, v);
+  if (pos >= 0) {
+    for (uint32_t i = (uint32_t)pos; i < c->n_temp; i++) {
+      uint32_t t = c->temp[i];
+      if (!(t & ORC_READER) && b->nodes[t].desc.kind == WAA_NODE_DELAY) { /* cycle_breaker == true */
+        c->breaker = t;
+        return 1;
+      }
+    }
+    for (uint32_t i = (uint32_t)pos; i < c->n_temp; i++) c->in_cycle[c->n_in_cycle++] = c->temp[i];
+    return 0;
   }
-  if (marked[id]) return;
-  marked[id] = 1;
-  temp[id] = 1;
-  for (uint32_t e = 0; e < b->n_edges; e++)
-    if (b->edges[e].from == id) visit(b, b->edges[e].to, marked, temp, ordered, n_ordered, cycle);
-  ordered[(*n_ordered)++] = id;
-  temp[id] = 0;
+  if (vtx_in(c->marked, c->n_marked, v) >= 0) return 0;
+  c->marked[c->n_marked++] = v;
+  c->temp[c->n_temp++] = v;
+  uint32_t id = v & ~ORC_READER;
+  if (!(v & ORC_READER) && b->nodes[id].desc.kind == WAA_NODE_DELAY) {
+    if (!c->cut[id] && order_visit(c, id | ORC_READER)) return 1;
+  } else {
+    for (uint32_t e = 0; e < b->n_edges; e++) {
+      if (b->edges[e].from != id) continue;
+      uint32_t to = b->edges[e].to;
+      /* inputs go to the writer; a param edge goes to the param's owner: delayTime belongs to the reader */
+      if (b->nodes[to].desc.kind == WAA_NODE_DELAY && (b->edges[e].to_input & 0x80000000u)) to |= ORC_READER;
+      if (order_visit(c, to)) return 1;
+    }
+  }
+  c->ordered[c->n_ordered++] = v;
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < c->n_temp; i++)
+    if (c->temp[i] != v) c->temp[k++] = c->temp[i];
+  c->n_temp = k;
+  return 0;
+}
+/* fills b->order (render order) and b->n_order */
+static void order_nodes(orc_batch* b) {
+  uint32_t cap = 2 * b->n_nodes + 2;
+  unsigned char* cut = (unsigned char*)calloc(b->n_nodes, 1);
+  OrderCtx c;
+  c.b = b;
+  c.cut = cut;
+  c.marked = (uint32_t*)malloc(sizeof(uint32_t) * cap);
+  c.temp = (uint32_t*)malloc(sizeof(uint32_t) * cap);
+  c.ordered = (uint32_t*)malloc(sizeof(uint32_t) * cap);
+  c.in_cycle = (uint32_t*)malloc(sizeof(uint32_t) * cap * 4);
+  for (;;) {
+    c.n_marked = c.n_temp = c.n_ordered = c.n_in_cycle = 0;
+    int applied = 0;
+    for (uint32_t i = 0; i < b->n_nodes && !applied; i++) {
+      applied = order_visit(&c, i);
+      if (!applied && b->nodes[i].desc.kind == WAA_NODE_DELAY) applied = order_visit(&c, i | ORC_READER);
+    }
+    if (!applied) break;
+    cut[c.breaker] = 1;
+  }
+  b->n_order = 0;
+  for (uint32_t i = c.n_ordered; i-- > 0;)
+    if (vtx_in(c.in_cycle, c.n_in_cycle, c.ordered[i]) < 0) b->order[b->n_order++] = c.ordered[i];
+  free(cut);
+  free(c.marked);
+  free(c.temp);
+  free(c.ordered);
+  free(c.in_cycle);
 }
 
 static int default_channel_config(NodeCfg* n, uint32_t n_out) {
@@ -828,24 +899,8 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
     }
   }
   /* ordering */
-  b->order = (uint32_t*)malloc(sizeof(uint32_t) * g->n_nodes);
-  {
-    unsigned char* marked = (unsigned char*)calloc(g->n_nodes, 1);
-    unsigned char* temp = (unsigned char*)calloc(g->n_nodes, 1);
-    uint32_t* post = (uint32_t*)malloc(sizeof(uint32_t) * g->n_nodes);
-    uint32_t np = 0;
-    int cycle = 0;
-    for (uint32_t i = 0; i < g->n_nodes; i++) visit(b, i, marked, temp, post, &np, &cycle);
-    free(marked);
-    free(temp);
-    if (cycle) {
-      free(post);
-      return fail(WAA_ERR_OUT_OF_SCOPE, "graph cycles (DelayNode feedback) are out of scope");
-    }
-    for (uint32_t i = 0; i < np; i++) b->order[i] = post[np - 1 - i];
-    b->n_order = np;
-    free(post);
-  }
+  b->order = (uint32_t*)malloc(sizeof(uint32_t) * (2 * g->n_nodes + 2));
+  order_nodes(b);
   /* state */
   b->st = (NodeState**)calloc(n_inst, sizeof(NodeState*));
   for (uint32_t k = 0; k < n_inst; k++) b->st[k] = (NodeState*)calloc(g->n_nodes, sizeof(NodeState));
@@ -1724,17 +1779,19 @@ static void process_iir(NodeCfg* n, NodeState* s) {
   }
 }
 
-/* src/node/delay.rs: DelayWriter::process :428-466 followed by DelayReader::process :515-680 (the node outside a
- * cycle: the writer->reader edge of delay.rs:361 makes the writer render first, so in_cycle stays false) */
+/* src/node/delay.rs: DelayWriter::process :428-466 and DelayReader::process :515-680.  Outside a cycle the
+ * writer->reader edge of delay.rs:361 makes the writer render first (sub-quantum delays work); inside one the
+ * cycle breaker removes that edge, the reader renders first and clamps the delay to one render quantum. */
 typedef struct {
   int prev_block_index, prev_frame_index;
   float k;
 } PlaybackInfo;
 
 /* delay.rs:682-745 */
-static PlaybackInfo delay_playback_infos(double delay, double sample_index, double sample_rate, int ring_size,
-                                         int ring_index) {
-  double num_samples = delay * sample_rate; /* in_cycle == false: no clamp */
+static PlaybackInfo delay_playback_infos(double delay, int in_cycle, double sample_index, double quantum_duration,
+                                         double sample_rate, int ring_size, int ring_index) {
+  double clamped_delay = in_cycle ? fmax(delay, quantum_duration) : delay; /* :693-701 */
+  double num_samples = clamped_delay * sample_rate;
   double position = sample_index - num_samples;
   double position_floored = floor(position);
   int num_frames = RQ;
@@ -1748,32 +1805,46 @@ static PlaybackInfo delay_playback_infos(double delay, double sample_index, doub
   return r;
 }
 
-static void process_delay(NodeCfg* n, NodeState* s, uint32_t inst, const Scope* sc) {
+static void delay_check_ring(NodeCfg* n, NodeState* s, double sample_rate) {
+  if (s->dl_ring) return; /* delay.rs:297-303 + check_ring_buffer_size :386-397: filled with silent quanta */
+  int num_quanta = (int)ceil(n->desc.d[0] * sample_rate / (double)RQ);
+  s->dl_cap = num_quanta + 1;
+  s->dl_ring = (Quantum*)malloc(sizeof(Quantum) * (size_t)s->dl_cap);
+  for (int i = 0; i < s->dl_cap; i++) q_make_silent(&s->dl_ring[i]);
+}
+
+/* DelayWriter::process, delay.rs:428-466 */
+static void process_delay_writer(NodeCfg* n, NodeState* s, const Scope* sc) {
   const Quantum* input = &s->in;
-  Quantum* output = &s->out;
-  double sample_rate = (double)sc->sample_rate;
-  if (!s->dl_ring) { /* delay.rs:297-303 + check_ring_buffer_size :386-397: filled with silent quanta */
-    int num_quanta = (int)ceil(n->desc.d[0] * sample_rate / (double)RQ);
-    s->dl_cap = num_quanta + 1;
-    s->dl_ring = (Quantum*)malloc(sizeof(Quantum) * (size_t)s->dl_cap);
-    for (int i = 0; i < s->dl_cap; i++) q_make_silent(&s->dl_ring[i]);
-  }
-  /* ---- writer ---- */
+  delay_check_ring(n, s, (double)sc->sample_rate);
   if (s->dl_ring[0].n != input->n) /* check_ring_buffer_up_down_mix :469-489 */
     for (int i = 0; i < s->dl_cap; i++) q_mix(&s->dl_ring[i], input->n, WAA_INTERP_SPEAKERS);
   q_copy(&s->dl_ring[s->dl_windex], input);
   s->dl_windex = (s->dl_windex + 1) % s->dl_cap;
-  /* ---- reader ---- */
+  s->dl_latest_frame_written = sc->current_frame;
+  s->dl_written_once = 1;
+}
+
+/* DelayReader::process, delay.rs:515-680 */
+static void process_delay_reader(NodeCfg* n, NodeState* s, uint32_t inst, const Scope* sc) {
+  Quantum* output = &s->out;
+  double sample_rate = (double)sc->sample_rate;
+  delay_check_ring(n, s, sample_rate);
   const Quantum* ring = s->dl_ring;
   int nch = ring[0].n;
+  q_make_silent(output);
   q_set_number_of_channels(output, nch);
+  if (!s->dl_in_cycle) /* :535-541: the writer has not rendered this quantum => the cycle breaker was applied */
+    s->dl_in_cycle = !(s->dl_written_once && s->dl_latest_frame_written == sc->current_frame);
   float tmp[RQ];
   int len;
   const float* delay = param_get_in(&n->params[0], s->pin[0], inst, sc->quantum, &len, tmp);
+  double dt = 1. / sample_rate;
+  double quantum_duration = (double)RQ * dt;
   int ring_size = s->dl_cap, ring_index = s->dl_rindex;
   PlaybackInfo infos[RQ];
   if (len == 1) {
-    infos[0] = delay_playback_infos((double)delay[0], 0., sample_rate, ring_size, ring_index);
+    infos[0] = delay_playback_infos((double)delay[0], s->dl_in_cycle, 0., quantum_duration, sample_rate, ring_size, ring_index);
     for (int i = 1; i < RQ; i++) {
       PlaybackInfo p = infos[i - 1];
       p.prev_frame_index += 1;
@@ -1785,7 +1856,8 @@ static void process_delay(NodeCfg* n, NodeState* s, uint32_t inst, const Scope* 
     }
   } else {
     for (int i = 0; i < RQ; i++)
-      infos[i] = delay_playback_infos((double)delay[i], (double)i, sample_rate, ring_size, ring_index);
+      infos[i] = delay_playback_infos((double)delay[i], s->dl_in_cycle, (double)i, quantum_duration, sample_rate, ring_size,
+                                      ring_index);
   }
   int active = 0;
   for (int c = 0; c < nch; c++) {
@@ -2208,7 +2280,6 @@ static void process_node(orc_batch* b, uint32_t id, uint32_t inst, const Scope* 
     case WAA_NODE_CONSTANT_SOURCE: process_constant_source(n, s, inst, sc); break;
     case WAA_NODE_BIQUAD: process_biquad(n, s, inst, sc); break;
     case WAA_NODE_IIR_FILTER: process_iir(n, s); break;
-    case WAA_NODE_DELAY: process_delay(n, s, inst, sc); break;
     case WAA_NODE_GAIN: process_gain(n, s, inst, sc); break;
     case WAA_NODE_STEREO_PANNER: process_stereo_panner(n, s, inst, sc); break;
     case WAA_NODE_PANNER: process_panner(n, s, inst, sc); break;
@@ -2264,9 +2335,18 @@ static void render_instance(orc_batch* b, uint32_t inst) {
     sc.sample_rate = b->sr;
     sc.quantum = q;
     for (uint32_t oi = 0; oi < b->n_order; oi++) {
-      uint32_t id = b->order[oi];
-      process_node(b, id, inst, &sc);
+      uint32_t item = b->order[oi], id = item & ~ORC_READER;
       NodeState* s = &st[id];
+      if (b->nodes[id].desc.kind == WAA_NODE_DELAY) {
+        if (!(item & ORC_READER)) { /* writer half: consumes the input, produces nothing */
+          process_delay_writer(&b->nodes[id], s, &sc);
+          q_make_silent(&s->in);
+          continue;
+        }
+        process_delay_reader(&b->nodes[id], s, inst, &sc);
+      } else {
+        process_node(b, id, inst, &sc);
+      }
       for (uint32_t e = 0; e < b->n_edges; e++) {
         if (b->edges[e].from != id) continue;
         NodeCfg* dn = &b->nodes[b->edges[e].to];
@@ -2277,7 +2357,7 @@ static void render_instance(orc_batch* b, uint32_t inst) {
         else
           q_add(&ds->in, &s->out, dn->cc, dn->ccmode, dn->ccinterp);
       }
-      q_make_silent(&s->in);
+      if (b->nodes[id].desc.kind != WAA_NODE_DELAY) q_make_silent(&s->in);
       for (int p = 0; p < WAA_MAX_PARAMS; p++)
         if (s->pin[p]) q_make_silent(s->pin[p]);
     }

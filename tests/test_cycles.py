@@ -1,0 +1,147 @@
+"""Graph cycles: the cycle breaker of a DelayNode (src/render/graph.rs:323-487,
+src/node/delay.rs:361,535-541,693-701) and muted cycles.  Reference tests re-typed: tests/offline.rs:170-244,
+src/node/delay.rs:990-1019,1076-1113, src/render/graph.rs:708-742."""
+import numpy as np
+import pytest
+
+import web_audio_api_rs_amd as waa
+from graphs import rms_err, white_noise
+
+RQ = 128
+
+
+def ctx(be, channels, length, sr=48000.0, **kw):
+    return waa.OfflineAudioContext(channels, length, sr, binding=be, **kw)
+
+
+def test_cycle_without_delay_is_muted(be):
+    """tests/offline.rs:170-202: gain <-> gain cycle is muted, the other source still renders"""
+    c = ctx(be, 1, RQ)
+    cycle1 = c.create_gain()
+    cycle1.connect(c.destination())
+    cycle2 = c.create_gain()
+    cycle2.connect(cycle1)
+    cycle1.connect(cycle2)
+    source_cycle = c.create_constant_source(offset=1.0)
+    source_cycle.connect(cycle1)
+    other = c.create_constant_source(offset=2.0)
+    other.connect(c.destination())
+    source_cycle.start()
+    other.start()
+    out = c.start_rendering_sync().data[0, 0]
+    assert np.array_equal(out, np.full(RQ, 2.0, np.float32))
+
+
+def test_cycle_breaker(be):
+    """tests/offline.rs:204-244: delay.connect(&delay), positive feedback: 1, 2, 3 per quantum"""
+    sr = 48000.0
+    c = ctx(be, 1, RQ * 3, sr)
+    delay = c.create_delay(1.0 / sr)
+    delay.delay_time.set_value(np.float32(1.0) / np.float32(sr))
+    delay.connect(c.destination())
+    delay.connect(delay)
+    source = c.create_constant_source(offset=1.0)
+    source.connect(delay)
+    source.connect(c.destination())
+    source.start()
+    out = c.start_rendering_sync().data[0, 0]
+    assert np.array_equal(out[:RQ], np.full(RQ, 1.0, np.float32))
+    assert np.array_equal(out[RQ:2 * RQ], np.full(RQ, 2.0, np.float32))
+    assert np.array_equal(out[2 * RQ:], np.full(RQ, 3.0, np.float32))
+
+
+@pytest.mark.parametrize("max_delay_frames,delay_frames", [(48000.0, 1.0), (64.0, 64.0)])
+def test_min_delay_when_in_loop(be, max_delay_frames, delay_frames):
+    """delay.rs:990-1019 and :1076-1113: inside a loop the delay is clamped to one render quantum, abs_all <= 0"""
+    sr = 48000.0
+    c = ctx(be, 1, 256, sr)
+    delay = c.create_delay(max_delay_frames / sr)
+    delay.delay_time.set_value(np.float32(delay_frames) / np.float32(sr))
+    delay.connect(c.destination())
+    gain = c.create_gain(gain=0.0)  # a loop without feedback
+    delay.connect(gain)
+    gain.connect(delay)
+    src = c.create_buffer_source()
+    src.connect(delay)
+    src.set_buffer(waa.AudioBuffer(np.array([[1.0]], np.float32), sr))
+    src.start_at(0.0)
+    out = c.start_rendering_sync().data[0, 0]
+    exp = np.zeros(256, np.float32)
+    exp[128] = 1.0
+    assert np.array_equal(out, exp)
+
+
+def test_detached_leg_of_a_muted_cycle_still_renders(be):
+    """graph.rs:708-742: 4->2, 2->1, 1->0, 1->2, 3->0: nodes 1 and 2 are dropped, 3 renders"""
+    c = ctx(be, 1, RQ)
+    n1, n2 = c.create_gain(), c.create_gain()
+    n3 = c.create_constant_source(offset=0.5)
+    n4 = c.create_constant_source(offset=4.0)
+    n4.connect(n2)
+    n2.connect(n1)
+    n1.connect(c.destination())
+    n1.connect(n2)
+    n3.connect(c.destination())
+    n3.start()
+    n4.start()
+    out = c.start_rendering_sync().data[0, 0]
+    assert np.array_equal(out, np.full(RQ, 0.5, np.float32))
+
+
+def test_feedback_echo_matches_closed_form(be):
+    """src -> (+) -> delay(D) -> gain(g) -> back to (+); output = the delay's output: y[n] = x[n-D] + g y[n-D]
+    (sample rate 2^15 so that D / sr is exact in f32 and the delay interpolates with k == 0)"""
+    sr, n, D, g = 32768.0, RQ * 12, 300, np.float32(0.5)
+    x = white_noise(1, 1, n, seed0=4)[0, 0]
+    c = ctx(be, 1, n, sr)
+    src = c.create_buffer_source()
+    src.set_buffer(waa.AudioBuffer(x[None, :], sr))
+    delay = c.create_delay(0.1)
+    delay.delay_time.set_value(np.float32(D) / np.float32(sr))
+    fb = c.create_gain(gain=float(g))
+    src.connect(delay)
+    delay.connect(fb).connect(delay)
+    delay.connect(c.destination())
+    src.start()
+    out = c.start_rendering_sync().data[0, 0]
+    y = np.zeros(n, np.float32)
+    for i in range(D, n):
+        y[i] = np.float32(x[i - D] + np.float32(g * y[i - D]))
+    assert np.max(np.abs(out - y)) <= 1e-6
+
+
+# --------------------------------------------------------------------------- GPU parity on seeded inputs
+def _feedback_graph(binding, noise, delays, gains, with_filter):
+    n = noise.shape[0]
+    c = waa.OfflineAudioContext(2, noise.shape[2], 48000.0, n_instances=n, binding=binding)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    delay = c.create_delay(0.05)
+    fb = c.create_gain()
+    for i in range(n):
+        delay.delay_time.set_value(delays[i], instance=i)
+        fb.gain.set_value(gains[i], instance=i)
+    src.connect(delay)
+    tail = delay
+    if with_filter:
+        tail = delay.connect(c.create_biquad_filter(type_="lowpass", frequency=3000.0))
+    tail.connect(fb).connect(delay)
+    src.connect(c.destination())
+    tail.connect(c.destination())
+    src.start()
+    out = c.start_rendering_sync().data
+    c.close()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_filter", [False, True])
+def test_parity_feedback_delay(hip, orc, with_filter):
+    n, frames = 6, RQ * 40 + 17
+    noise = white_noise(n, 2, frames, seed0=6)
+    delays = np.float32([0.0, 0.001, 128.0 / 48000.0, 0.004, 0.0123, 0.05])
+    gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, 0.8])
+    g = _feedback_graph(hip, noise, delays, gains, with_filter)
+    o = _feedback_graph(orc, noise, delays, gains, with_filter)
+    assert rms_err(g, o).max() <= 1e-6
+    assert np.abs(g - o).max() <= (1e-6 if with_filter else 0.0)

@@ -182,19 +182,6 @@ def test_subquantum_delay_dynamic_lifetime(be):
     assert np.max(np.abs(out - exp)) <= 1e-5
 
 
-def test_feedback_loop_is_out_of_scope(be):
-    """delay.rs:990-1019 needs the cycle breaker (graph.rs:302-304): refused, not mis-rendered"""
-    c = ctx(be, 1, 256, 48000.0)
-    delay = c.create_delay(1.0)
-    delay.connect(c.destination())
-    gain = c.create_gain(gain=0.0)
-    delay.connect(gain)
-    gain.connect(delay)
-    with pytest.raises(waa.WaaError) as ei:
-        c.start_rendering_sync()
-    assert ei.value.status == 4
-
-
 def test_plan_delay_is_node_major(hip):
     c = waa.OfflineAudioContext(2, RQ * 64, 48000.0, n_instances=4, binding=hip, device=waa.PLAN_ONLY)
     src = c.create_buffer_source()
