@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -138,13 +139,14 @@ struct ProfileEntry {
 };
 
 struct Step {
-  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather
+  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop
   ChainDesc chain{};
   BiquadStreamDesc bq{};
   ConvDesc conv{};
   BiquadCoefDesc coef{};
   IirStreamDesc iir{};
   DelayDesc delay{};
+  LoopDesc loop{};
   int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
   void* zero_ptr = nullptr;
   size_t zero_bytes = 0;
@@ -165,6 +167,7 @@ struct waa_batch {
   std::vector<Node> nodes;
   std::vector<waa_edge_desc> edges;
   std::vector<uint32_t> order;
+  std::vector<uint8_t> cut;         // per DelayNode: writer->reader edge removed by the cycle breaker
   std::vector<void*> allocs;        // plan-owned device allocations
   std::vector<void*> payload_allocs;  // buffers uploaded through the API
   std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render
@@ -716,18 +719,40 @@ int computed_in_nch(const Node& n, int maxc) {
   }
 }
 
-void topo_visit(const waa_batch* b, uint32_t id, std::vector<uint8_t>& marked, std::vector<uint8_t>& temp,
-                std::vector<uint32_t>& post, bool* cycle) {
-  if (temp[id]) {
-    *cycle = true;
-    return;
+// graph.rs:323-487 order_nodes / visit.  A DelayNode is two graph nodes in the reference (delay.rs:283-366:
+// writer, then reader, edge writer->reader); vertex `id` is the writer (or a plain node), `id | VTX_READER` the
+// reader.  Cycles are broken at the first DelayNode writer on the detected loop (its writer->reader edge is
+// cleared and the ordering restarts); nodes of a loop without one are dropped from the ordering (muted).
+constexpr uint32_t VTX_READER = 0x80000000u;
+struct OrderCtx {
+  const waa_batch* b;
+  std::vector<uint8_t> cut;
+  std::vector<uint32_t> marked, temp, ordered, in_cycle;
+  uint32_t breaker = 0;
+};
+bool is_delay(const waa_batch* b, uint32_t id);
+void vertex_targets(const waa_batch* b, uint32_t v, const std::vector<uint8_t>& cut, std::vector<uint32_t>& out);
+bool order_visit(OrderCtx& c, uint32_t v) {
+  auto pos = std::find(c.temp.begin(), c.temp.end(), v);
+  if (pos != c.temp.end()) {
+    for (auto it = pos; it != c.temp.end(); ++it)
+      if (!(*it & VTX_READER) && is_delay(c.b, *it)) {
+        c.breaker = *it;
+        return true;
+      }
+    c.in_cycle.insert(c.in_cycle.end(), pos, c.temp.end());
+    return false;
   }
-  if (marked[id]) return;
-  marked[id] = temp[id] = 1;
-  for (auto& e : b->edges)
-    if (e.from == id) topo_visit(b, e.to, marked, temp, post, cycle);
-  post.push_back(id);
-  temp[id] = 0;
+  if (std::find(c.marked.begin(), c.marked.end(), v) != c.marked.end()) return false;
+  c.marked.push_back(v);
+  c.temp.push_back(v);
+  std::vector<uint32_t> targets;
+  vertex_targets(c.b, v, c.cut, targets);
+  for (uint32_t t : targets)
+    if (order_visit(c, t)) return true;
+  c.ordered.push_back(v);
+  c.temp.erase(std::remove(c.temp.begin(), c.temp.end(), v), c.temp.end());
+  return false;
 }
 
 int plan_convolver(waa_batch* b, uint32_t id);
@@ -963,22 +988,119 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
   return push_chain_step(b, inputs, in_nch, in_interp, pending, out);
 }
 
+bool is_delay(const waa_batch* b, uint32_t id) { return b->nodes[id].desc.kind == WAA_NODE_DELAY; }
+// outgoing edges of a vertex of the expanded graph, in insertion order
+void vertex_targets(const waa_batch* b, uint32_t v, const std::vector<uint8_t>& cut, std::vector<uint32_t>& out) {
+  const uint32_t id = v & ~VTX_READER;
+  if (!(v & VTX_READER) && is_delay(b, id)) {
+    if (!cut[id]) out.push_back(id | VTX_READER);
+    return;
+  }
+  for (auto& e : b->edges) {
+    if (e.from != id) continue;
+    // inputs go to the writer half; delayTime belongs to the reader half (delay.rs:316-318)
+    out.push_back(is_delay(b, e.to) && (e.to_input & 0x80000000u) ? (e.to | VTX_READER) : e.to);
+  }
+}
+
+int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items);
+
 int build_plan(waa_batch* b) {
   const uint32_t N = (uint32_t)b->nodes.size();
   for (uint32_t i = 0; i < N; i++)  // the reference takes the coefficients in the constructor
     if (b->nodes[i].desc.kind == WAA_NODE_IIR_FILTER && b->nodes[i].iir_b.empty())
       return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIRFilterNode %u has no coefficients", i);
-  // processing order = reversed DFS post-order over outgoing edges in insertion order (graph.rs:331-487)
+  // processing order = reversed DFS post-order over outgoing edges in insertion order, cycle breakers applied
+  // (graph.rs:323-487); `items` has two entries per DelayNode (writer, reader), none for muted nodes
+  std::vector<uint32_t> items;
+  std::vector<uint8_t> muted(N, 0);
   {
-    std::vector<uint8_t> marked(N, 0), temp(N, 0);
-    std::vector<uint32_t> post;
-    bool cycle = false;
-    for (uint32_t i = 0; i < N; i++) topo_visit(b, i, marked, temp, post, &cycle);
-    if (cycle) return fail(WAA_ERR_OUT_OF_SCOPE, "graph cycles (DelayNode feedback) are out of scope");
-    b->order.assign(post.rbegin(), post.rend());
+    OrderCtx c;
+    c.b = b;
+    c.cut.assign(N, 0);
+    for (;;) {
+      c.marked.clear();
+      c.temp.clear();
+      c.ordered.clear();
+      c.in_cycle.clear();
+      bool applied = false;
+      for (uint32_t i = 0; i < N && !applied; i++) {
+        applied = order_visit(c, i);
+        if (!applied && is_delay(b, i)) applied = order_visit(c, i | VTX_READER);
+      }
+      if (!applied) break;
+      c.cut[c.breaker] = 1;
+    }
+    for (uint32_t v : c.in_cycle) muted[v & ~VTX_READER] = 1;
+    for (auto it = c.ordered.rbegin(); it != c.ordered.rend(); ++it)
+      if (!muted[*it & ~VTX_READER]) items.push_back(*it);
+    b->cut = c.cut;
   }
-  std::vector<uint32_t> pos(N);
-  for (uint32_t i = 0; i < N; i++) pos[b->order[i]] = i;
+  // one entry per node, at the position where its OUTPUT is produced (the reader half of a DelayNode)
+  b->order.clear();
+  for (uint32_t v : items)
+    if (!is_delay(b, v & ~VTX_READER) || (v & VTX_READER)) b->order.push_back(v & ~VTX_READER);
+  for (uint32_t i = 0; i < N; i++)
+    if (muted[i]) plan_note(b, "node %u is part of a cycle without a DelayNode: muted (graph.rs:362-368)", i);
+  // feedback loops: strongly connected components of the graph with the writer->reader edges in place
+  // (Tarjan); their members are rendered quantum by quantum by the loop kernel
+  std::vector<int> scc_of(N, -1);
+  int n_scc = 0;
+  {
+    const uint32_t V = 2 * N;
+    auto vidx = [&](uint32_t v) { return (v & VTX_READER) ? N + (v & ~VTX_READER) : v; };
+    std::vector<int> index(V, -1), low(V, 0), comp(V, -1);
+    std::vector<uint8_t> on(V, 0);
+    std::vector<uint32_t> stk;
+    int counter = 0, n_comp = 0;
+    const std::vector<uint8_t> no_cut(N, 0);
+    std::vector<int> comp_size;
+    std::function<void(uint32_t)> strong = [&](uint32_t v) {
+      const uint32_t vi = vidx(v);
+      index[vi] = low[vi] = counter++;
+      stk.push_back(v);
+      on[vi] = 1;
+      std::vector<uint32_t> ts;
+      vertex_targets(b, v, no_cut, ts);
+      for (uint32_t t : ts) {
+        if (muted[t & ~VTX_READER]) continue;
+        const uint32_t ti = vidx(t);
+        if (index[ti] < 0) {
+          strong(t);
+          low[vi] = std::min(low[vi], low[ti]);
+        } else if (on[ti]) {
+          low[vi] = std::min(low[vi], index[ti]);
+        }
+      }
+      if (low[vi] == index[vi]) {
+        int size = 0;
+        for (;;) {
+          const uint32_t w = stk.back();
+          stk.pop_back();
+          on[vidx(w)] = 0;
+          comp[vidx(w)] = n_comp;
+          size++;
+          if (w == v) break;
+        }
+        comp_size.push_back(size);
+        n_comp++;
+      }
+    };
+    for (uint32_t i = 0; i < N; i++) {
+      if (muted[i]) continue;
+      if (index[i] < 0) strong(i);
+      if (is_delay(b, i) && index[N + i] < 0) strong(i | VTX_READER);
+    }
+    std::map<int, int> renum;
+    for (uint32_t i = 0; i < N; i++) {
+      if (muted[i] || comp[i] < 0 || comp_size[comp[i]] < 2) continue;
+      auto it = renum.find(comp[i]);
+      if (it == renum.end()) it = renum.emplace(comp[i], n_scc++).first;
+      scc_of[i] = it->second;
+    }
+  }
+  std::vector<uint32_t> pos(N, 0xffffffffu);
+  for (uint32_t i = 0; i < b->order.size(); i++) pos[b->order[i]] = i;
   // incoming edges in summing order: by processing position of the producer, then edge insertion order
   for (auto& n : b->nodes) {
     n.in_edges.clear();
@@ -991,6 +1113,7 @@ int build_plan(waa_batch* b) {
   for (uint32_t e = 0; e < b->edges.size(); e++) {
     const waa_edge_desc& ed = b->edges[e];
     Node& to = b->nodes[ed.to];
+    if (muted[ed.from] || muted[ed.to]) continue;  // a muted node renders nothing and contributes nothing
     if (ed.to_input & 0x80000000u) {
       const uint32_t pid = ed.to_input & 0x7fffffffu;
       if (pid >= to.params.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - node %u has no param %u", ed.to, pid);
@@ -1026,9 +1149,14 @@ int build_plan(waa_batch* b) {
   }
   // static channel counts (the reference's counts are dynamic: a silent quantum is mono; every case the
   // static count differs from the dynamic one carries zeros — see DESIGN.md "Silence and channel counts")
+  // (inside a feedback loop a producer can come later in the order: iterate to the fixed point; counts only grow)
+  for (auto& n : b->nodes) n.in_nch = n.out_nch = 1;
+  for (int pass = 0; pass < 16; pass++) {
+  bool changed = false;
   for (uint32_t id : b->order) {
     Node& n = b->nodes[id];
     if (!n.live) continue;
+    const int old_in = n.in_nch, old_out = n.out_nch;
     int maxc = 1;
     for (int e : n.in_edges) maxc = std::max(maxc, b->nodes[b->edges[e].from].out_nch);
     n.in_nch = computed_in_nch(n, maxc);
@@ -1058,6 +1186,9 @@ int build_plan(waa_batch* b) {
     if (n.in_nch > 6 || n.out_nch > 6)
       return fail(WAA_ERR_OUT_OF_SCOPE, "the device path renders at most 6 channels per signal (node %u needs %d)", id,
                   std::max(n.in_nch, n.out_nch));
+    changed |= n.in_nch != old_in || n.out_nch != old_out;
+  }
+  if (!changed || n_scc == 0) break;
   }
   // materialisation points
   for (uint32_t id = 0; id < N; id++) {
@@ -1066,6 +1197,7 @@ int build_plan(waa_batch* b) {
     bool mat = false;
     const uint32_t kind = n.desc.kind;
     if (kind == WAA_NODE_DESTINATION || kind == WAA_NODE_ANALYSER || kind == WAA_NODE_CONVOLVER || kind == WAA_NODE_DELAY) mat = true;
+    if (scc_of[id] >= 0) mat = true;  // loop members publish their own signal
     int live_consumers = 0;
     for (auto& e : b->edges)
       if (e.from == id && b->nodes[e.to].live) {
@@ -1073,6 +1205,7 @@ int build_plan(waa_batch* b) {
         const Node& c = b->nodes[e.to];
         if ((c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir) || c.desc.kind == WAA_NODE_DELAY) mat = true;
         if (e.to_input & 0x80000000u) mat = true;  // feeds an AudioParam: read back as a per-frame value signal
+        if (scc_of[e.to] >= 0) mat = true;         // feeds a feedback loop
         int live_in = 0;
         for (int ie : c.in_edges)
           if (b->nodes[b->edges[ie].from].live) live_in++;
@@ -1088,9 +1221,62 @@ int build_plan(waa_batch* b) {
     n.sig = SignalRef{p, (uint64_t)n.out_nch * b->lp, b->lp, n.out_nch, 0};
     return 0;
   };
+  // planning units: single nodes and whole feedback loops, producers first (the condensed graph is acyclic),
+  // otherwise in processing order
+  struct Unit {
+    int scc;
+    uint32_t id;
+  };
+  std::vector<Unit> units;
+  {
+    std::vector<uint8_t> node_done(N, 0), scc_done(n_scc, 0);
+    std::function<void(uint32_t)> visit_unit = [&](uint32_t id) {
+      const int sc = scc_of[id];
+      if (sc >= 0 ? scc_done[sc] : node_done[id]) return;
+      std::vector<uint32_t> members;
+      if (sc >= 0) {
+        scc_done[sc] = 1;
+        for (uint32_t m : b->order)
+          if (scc_of[m] == sc) members.push_back(m);
+      } else {
+        node_done[id] = 1;
+        members.push_back(id);
+      }
+      for (uint32_t m : members) {
+        for (int e : b->nodes[m].in_edges)
+          if (sc < 0 || scc_of[b->edges[e].from] != sc) visit_unit(b->edges[e].from);
+        for (auto& pe : b->nodes[m].pin_edges)
+          for (int e : pe)
+            if (sc < 0 || scc_of[b->edges[e].from] != sc) visit_unit(b->edges[e].from);
+      }
+      units.push_back(Unit{sc, id});
+    };
+    for (uint32_t id : b->order) visit_unit(id);
+  }
   // chains, in processing order of their terminal node
   b->steps.clear();
-  for (uint32_t id : b->order) {
+  for (const Unit& unit : units) {
+    const uint32_t id = unit.id;
+    if (unit.scc >= 0) {
+      std::vector<uint32_t> loop_items;
+      bool any_live = false;
+      for (uint32_t v : items)
+        if (scc_of[v & ~VTX_READER] == unit.scc) {
+          loop_items.push_back(v);
+          any_live |= b->nodes[v & ~VTX_READER].live;
+        }
+      if (!any_live) continue;
+      for (uint32_t v : loop_items) {
+        Node& m = b->nodes[v & ~VTX_READER];
+        if (!m.sig.base) {
+          int e = alloc_signal(m);
+          if (e) return e;
+        }
+      }
+      int e = plan_loop(b, loop_items);
+      if (e) return e;
+      continue;
+    }
     Node& term = b->nodes[id];
     if (!term.live || !term.materialized) continue;
     if (term.desc.kind == WAA_NODE_CONVOLVER && term.has_ir) {
@@ -1415,6 +1601,121 @@ int plan_delay(waa_batch* b, uint32_t id) {
   b->steps.push_back(st);
   plan_note(b, "delay node %u: %dch delayTime=%s ring=%d quanta", id, d.nch,
             d.delay.mode == 0 ? "const" : d.delay.mode == 1 ? "k-rate" : "a-rate", d.num_quanta + 1);
+  return 0;
+}
+
+// A feedback loop (strongly connected group around at least one DelayNode): one loop_kernel launch renders all
+// members quantum by quantum in the reference's processing order.  `loop_items` = that order, two entries per
+// DelayNode (writer / reader halves).
+int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items) {
+  if (loop_items.size() > (size_t)LOOP_MAX_ITEMS)
+    return fail(WAA_ERR_OUT_OF_SCOPE, "feedback loop with more than %d members", LOOP_MAX_ITEMS);
+  std::map<uint32_t, int> out_item;  // node id -> item that produces its output
+  std::map<uint32_t, int> writer_item;
+  for (size_t k = 0; k < loop_items.size(); k++) {
+    const uint32_t v = loop_items[k], id = v & ~VTX_READER;
+    if (is_delay(b, id)) {
+      if (v & VTX_READER)
+        out_item[id] = (int)k;
+      else
+        writer_item[id] = (int)k;
+    } else {
+      out_item[id] = (int)k;
+    }
+  }
+  std::vector<LoopItem> host(loop_items.size());
+  std::string desc;
+  for (size_t k = 0; k < loop_items.size(); k++) {
+    const uint32_t v = loop_items[k], id = v & ~VTX_READER;
+    Node& n = b->nodes[id];
+    LoopItem& li = host[k];
+    std::memset(&li, 0, sizeof li);
+    if (n.in_nch > 2 || n.out_nch > 2)
+      return fail(WAA_ERR_OUT_OF_SCOPE, "feedback loops render at most 2 channels per signal (node %u)", id);
+    for (auto& pe : n.pin_edges)
+      for (int e : pe)
+        if (out_item.count(b->edges[e].from))
+          return fail(WAA_ERR_OUT_OF_SCOPE, "an AudioParam of node %u is modulated from inside its own feedback loop", id);
+    const bool reader = is_delay(b, id) && (v & VTX_READER);
+    li.nch_in = n.in_nch;
+    li.nch_out = n.out_nch;
+    li.interp = n.interp;
+    if (!reader) {
+      // inputs of the node (of the writer half for a DelayNode), in summing order
+      if (n.in_edges.size() > (size_t)MAX_INPUTS)
+        return fail(WAA_ERR_OUT_OF_SCOPE, "more than %d inputs on node %u inside a feedback loop", MAX_INPUTS, id);
+      li.n_in = (int)n.in_edges.size();
+      for (int j = 0; j < li.n_in; j++) {
+        const uint32_t pid = b->edges[n.in_edges[j]].from;
+        Node& pn = b->nodes[pid];
+        li.in_nch[j] = pn.out_nch;
+        auto it = out_item.find(pid);
+        if (it != out_item.end()) {
+          if (it->second >= (int)k) return fail(WAA_ERR_INVALID_STATE, "internal: loop member order");
+          li.in_item[j] = it->second;
+        } else {
+          if (!pn.materialized || !pn.sig.base) return fail(WAA_ERR_INVALID_STATE, "internal: loop input not planned");
+          li.in_item[j] = -1;
+          li.in_sig[j] = pn.sig;
+        }
+      }
+    }
+    char t[96];
+    if (is_delay(b, id)) {
+      if (!reader) {
+        li.kind = LI_DELAY_W;
+        int e = temp_signal(b, n.in_nch, &li.out);  // the delay line, in absolute time
+        if (e) return e;
+        snprintf(t, sizeof t, "delayW%u", id);
+      } else {
+        li.kind = LI_DELAY_R;
+        li.out = n.sig;
+        li.writer_item = writer_item.at(id);
+        li.in_cycle = li.writer_item > (int)k ? 1 : 0;  // delay.rs:535-541: the writer has not rendered yet
+        li.num_quanta = (int32_t)std::ceil(n.desc.d[0] * (double)b->sr / (double)RQ);
+        int e = node_param(b, id, WAA_PARAM_DELAY_DELAY_TIME, &li.op.p0);
+        if (e) return e;
+        snprintf(t, sizeof t, "delayR%u%s", id, li.in_cycle ? "(clamped)" : "");
+      }
+    } else {
+      li.kind = LI_NODE;
+      li.out = n.sig;
+      std::vector<OpDesc> ops;
+      int out_nch = 0;
+      int e = emit_node_ops(b, id, n.in_nch, true, ops, &out_nch);
+      if (e) return e;
+      if (ops.size() > 1) return fail(WAA_ERR_OUT_OF_SCOPE, "node %u cannot be rendered inside a feedback loop", id);
+      if (!ops.empty()) {
+        const OpDesc& o = ops[0];
+        const bool ok = o.kind == OP_GAIN || o.kind == OP_BIQUAD || o.kind == OP_WAVESHAPER ||
+                        (o.kind == OP_STEREO_PAN && o.p0.mode != 2);
+        if (!ok)
+          return fail(WAA_ERR_OUT_OF_SCOPE, "node %u (%s) cannot be rendered inside a feedback loop on the device path", id,
+                      op_name(o.kind));
+        li.op = o;
+      }
+      snprintf(t, sizeof t, "%s%u", ops.empty() ? "pass" : op_name(ops[0].kind), id);
+    }
+    desc += desc.empty() ? t : std::string(",") + t;
+  }
+  // fix up the reader items' writer outputs are read through host[writer_item].out on the device: same array
+  LoopItem* dev = nullptr;
+  int e = dev_upload(b, &dev, host);
+  if (e) return e;
+  Step st;
+  st.kind = 8;
+  LoopDesc& d = st.loop;
+  std::memset(&d, 0, sizeof d);
+  d.items = dev;
+  d.n_items = (int32_t)host.size();
+  d.n_inst = b->n_inst;
+  d.n_quanta = b->n_quanta;
+  d.sample_rate = (double)b->sr;
+  const double dt = 1. / (double)b->sr;
+  d.quantum_duration = (double)RQ * dt;  // delay.rs:546-548
+  st.profile_slot = slot_for(b, "loop_kernel");
+  b->steps.push_back(st);
+  plan_note(b, "feedback loop: %d item(s) per quantum [%s]", d.n_items, desc.c_str());
   return 0;
 }
 
@@ -2311,6 +2612,7 @@ waa_status waa_render(waa_batch* b) {
       case 5: e = timed(st.profile_slot, [&] { launch_biquad_coefs(st.coef, b->stream); }); break;
       case 6: e = timed(st.profile_slot, [&] { launch_iir_stream(st.iir, b->stream); }); break;
       case 7: e = timed(st.profile_slot, [&] { launch_delay(st.delay, b->stream); }); break;
+      case 8: e = timed(st.profile_slot, [&] { launch_loop(st.loop, b->stream); }); break;
       default: e = timed(st.profile_slot, [&] { launch_chain(st.chain, st.cmax, b->stream); }); break;
     }
     if (e) return e;

@@ -219,6 +219,39 @@ struct DelayDesc {
 };
 void launch_delay(const DelayDesc& d, void* stream);
 
+// ---- feedback loops (graph.rs:323-487 cycle breaker): quantum-serial rendering of a strongly connected group ----
+// The members of a loop are rendered render quantum by render quantum, in the reference's processing order, by
+// one wavefront per instance; every member writes its own output signal.  A DelayNode contributes two items
+// (delay.rs:283-366): the writer stores the node's mixed input ("history"), the reader gathers from it.
+enum : int32_t { LI_NODE = 0, LI_DELAY_W = 1, LI_DELAY_R = 2 };
+constexpr int LOOP_MAX_ITEMS = 24;
+struct LoopItem {
+  int32_t kind;
+  int32_t nch_in;       // channel count the summed input is mixed to
+  int32_t nch_out;
+  int32_t interp;
+  int32_t n_in;
+  int32_t in_item[MAX_INPUTS];  // >= 0: output of that item of the same quantum (LDS); -1: external signal
+  int32_t in_nch[MAX_INPUTS];
+  SignalRef in_sig[MAX_INPUTS];
+  SignalRef out;        // LI_NODE / LI_DELAY_R: the node's output; LI_DELAY_W: the delay line (absolute time)
+  OpDesc op;            // LI_NODE: kind 0 = pass-through; LI_DELAY_R: p0 = delayTime
+  int32_t writer_item;  // LI_DELAY_R: item whose `out` is the delay line
+  int32_t in_cycle;     // LI_DELAY_R: the reader renders before its writer: delay clamped to one quantum
+  int32_t num_quanta;   // LI_DELAY_R: ring capacity - 1
+  int32_t pad;
+};
+struct LoopDesc {
+  const LoopItem* items;  // device memory
+  int32_t n_items;
+  uint32_t n_inst;
+  uint32_t n_quanta;
+  uint32_t pad;
+  double sample_rate;
+  double quantum_duration;  // 128 * (1 / sample_rate), delay.rs:546-548
+};
+void launch_loop(const LoopDesc& d, void* stream);
+
 // ---- per-frame biquad coefficients for a-rate params (biquad_filter.rs:837-855) -------------
 struct BiquadCoefDesc {
   ParamRef frequency, detune, q, gain;
