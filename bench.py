@@ -53,6 +53,14 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
         from scipy import signal
         b, a = signal.butter(int(name[3:]), 0.25)
         node = node.connect(ctx.create_iir_filter(b, a))
+    if name in ("fb", "fbq"):  # feedback echo, DelayNode (0.25 s) <-> Gain(0.5) [-> Biquad]
+        delay = ctx.create_delay(1.0, delay_time=0.25)
+        src.connect(delay)
+        tail = delay
+        if name == "fbq":
+            tail = delay.connect(ctx.create_biquad_filter(type_="lowpass", frequency=4000.0))
+        tail.connect(ctx.create_gain(gain=0.5)).connect(delay)
+        tail.connect(ctx.destination())
     if name == "c5":
         src.playback_rate.set_value(1.5)
         src.set_loop(True)
@@ -66,6 +74,7 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
 
 # algorithmic bytes per context-quantum
 ALG_BYTES = {"c2": 2048.0, "c2k": 2048.0, "c5": 2560.0, "c3": 362848.0, "t1": 362848.0 + 2048.0, "c4": 362848.0 + 2048.0 + 512.0}
+ALG_BYTES["fb"] = ALG_BYTES["fbq"] = 2048.0
 IIR_ORDERS = (2, 4, 8, 12, 19)
 for _o in IIR_ORDERS:
     ALG_BYTES[f"iir{_o}"] = 2048.0
@@ -77,6 +86,8 @@ DESCR = {
     "c4": "C4: {n} contexts x {s:g} s, BufferSource->Biquad->Convolver->StereoPanner->Analyser->destination",
     "c5": "C5: {n} contexts x {s:g} s, BufferSource(playbackRate 1.5, loop)->WaveShaper(2048-pt)->destination",
 }
+DESCR["fb"] = "feedback echo: {n} contexts x {s:g} s, BufferSource->[Delay(0.25s)<->Gain(0.5)]->destination (+dry)"
+DESCR["fbq"] = "filtered feedback echo: {n} contexts x {s:g} s, BufferSource->[Delay(0.25s)->Biquad->Gain(0.5)->back]->destination (+dry)"
 for _o in IIR_ORDERS:
     DESCR[f"iir{_o}"] = "IIR: {n} contexts x {s:g} s, BufferSource->IIRFilter(Butterworth order %d)->destination" % _o
 

@@ -145,3 +145,68 @@ def test_parity_feedback_delay(hip, orc, with_filter):
     o = _feedback_graph(orc, noise, delays, gains, with_filter)
     assert rms_err(g, o).max() <= 1e-6
     assert np.abs(g - o).max() <= (1e-6 if with_filter else 0.0)
+
+
+def _ping_pong(binding, noise, lfo=None):
+    """stereo ping-pong: two DelayNodes in ONE loop (only the first one found is cut, the second keeps its
+    writer->reader edge and may use a sub-quantum delay), a WaveShaper and a StereoPanner inside the loop, a
+    k-rate swept Biquad, delayTime of the first delay modulated from OUTSIDE the loop."""
+    n, _, frames = noise.shape
+    nq = (frames + RQ - 1) // RQ
+    c = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n, binding=binding)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    d1 = c.create_delay(0.02, delay_time=0.006)
+    d2 = c.create_delay(0.02, delay_time=0.0005)  # 24 frames: sub-quantum, legal for the uncut delay
+    ws = c.create_wave_shaper(curve=np.tanh(np.linspace(-2.0, 2.0, 257)).astype(np.float32))
+    pan = c.create_stereo_panner(pan=-0.3)
+    bq = c.create_biquad_filter(type_="bandpass", frequency=1500.0, q=0.8)
+    bq.frequency.set_block(0, np.geomspace(500.0, 4000.0, nq).astype(np.float32))
+    fb = c.create_gain(gain=0.6)
+    src.connect(d1)
+    d1.connect(ws).connect(pan).connect(d2).connect(bq).connect(fb).connect(d1)
+    if lfo is not None:
+        mod = c.create_buffer_source()
+        mod.set_buffer_batch(lfo, 48000.0)
+        depth = c.create_gain(gain=0.002)
+        mod.connect(depth).connect(d1.delay_time)
+        mod.start()
+    src.connect(c.destination())
+    d2.connect(c.destination())
+    src.start()
+    plan = c.plan_describe() if binding.prefix == "waa_" else ""
+    out = c.start_rendering_sync().data
+    c.close()
+    return out, plan
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("modulated", [False, True])
+def test_parity_ping_pong_loop(hip, orc, modulated):
+    n, frames = 3, RQ * 48
+    noise = (white_noise(n, 2, frames, seed0=12) * 0.5).astype(np.float32)
+    lfo = None
+    if modulated:
+        t = np.arange(frames) / 48000.0
+        lfo = np.stack([np.sin(2 * np.pi * (2.0 + i) * t) for i in range(n)]).astype(np.float32)[:, None, :]
+    g, plan = _ping_pong(hip, noise, lfo)
+    o, _ = _ping_pong(orc, noise, lfo)
+    assert "feedback loop: 8 item(s)" in plan and "(clamped)" in plan
+    assert np.isfinite(o).all()
+    assert rms_err(g, o).max() <= 1e-6
+    assert np.abs(g - o).max() <= 5e-6
+
+
+@pytest.mark.gpu
+def test_unsupported_node_in_loop_is_refused(hip):
+    c = waa.OfflineAudioContext(2, RQ * 4, 48000.0, n_instances=1, binding=hip)
+    src = c.create_constant_source()
+    d = c.create_delay(0.1, delay_time=0.01)
+    iir = c.create_iir_filter([0.5, 0.5], [1.0, -0.2])
+    src.connect(d)
+    d.connect(iir).connect(d)
+    d.connect(c.destination())
+    src.start()
+    with pytest.raises(waa.WaaError) as ei:
+        c.start_rendering_sync()
+    assert ei.value.status == 4
