@@ -218,7 +218,7 @@ def main():
         # roofline of the dominant kernel: algorithmic bytes of one launch / its mean duration
         alg_bytes_step = ALG_BYTES[name] * n_inst * nq
         dom_share = 1.0
-        if name in ("c3", "t1", "c4"):
+        if name in ("c3", "t1", "c4") or len(prof) > 1 or max(launches_per_step.values(), default=1) > 1.5:
             # several kernels share the algorithmic bytes of the FDL: attribute them to the whole render
             achieved = alg_bytes_step / (sum(ms for _, _, ms in prof) / total_launch_steps * 1e-3) / 1e9
             dom_name = "render (all kernels)"

@@ -210,3 +210,38 @@ def test_unsupported_node_in_loop_is_refused(hip):
     with pytest.raises(waa.WaaError) as ei:
         c.start_rendering_sync()
     assert ei.value.status == 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("forced_loop_kernel", [False, True])
+@pytest.mark.parametrize("with_filter", [False, True])
+def test_parity_long_feedback_delay_block_scheduled(hip, orc, with_filter, forced_loop_kernel, monkeypatch):
+    """every loop delay is longer than a 2048-frame tile: the loop is rendered block by block with the ordinary
+    node-major kernels (streaming biquad included); WAA_LOOP_KERNEL forces the quantum-serial kernel instead"""
+    if forced_loop_kernel:
+        monkeypatch.setenv("WAA_LOOP_KERNEL", "1")
+    n, frames = 5, 2048 * 7 + 300
+    noise = white_noise(n, 2, frames, seed0=31)
+    delays = np.float32([0.0430, 0.05, 0.0861, 0.1, 0.0999])   # 2064 .. 4800 frames
+    gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6])
+    g = _feedback_graph(hip, noise, delays, gains, with_filter)
+    o = _feedback_graph(orc, noise, delays, gains, with_filter)
+    assert rms_err(g, o).max() <= 1e-6
+    assert np.abs(g - o).max() <= (2e-6 if with_filter else 0.0)
+
+
+def test_plan_block_scheduled_loop(hip):
+    c = waa.OfflineAudioContext(2, 2048 * 8, 48000.0, n_instances=2, binding=hip, device=waa.PLAN_ONLY)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(white_noise(2, 2, 2048 * 8), 48000.0)
+    delay = c.create_delay(1.0, delay_time=0.25)          # 12000 frames -> blocks of 5 tiles
+    bq = c.create_biquad_filter(type_="lowpass", frequency=3000.0)
+    fb = c.create_gain(gain=0.5)
+    src.connect(delay)
+    delay.connect(bq).connect(fb).connect(delay)
+    bq.connect(c.destination())
+    src.start()
+    plan = c.plan_describe()
+    assert "block-scheduled, 5 tile(s) = 10240 frames per block" in plan
+    assert "biquad_stream" in plan and "in a loop: clamped" in plan
+    c.close()

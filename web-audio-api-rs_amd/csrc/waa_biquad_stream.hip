@@ -345,8 +345,8 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
   // full iteration earlier, so the wait is (almost) free and stores never sit on the critical path.
   bool pending = false;   // a finished tile waits in lds_out
   uint32_t pending_tile = 0;
-  uint32_t tile = 0;
-  while (tile < d.n_tiles) {
+  uint32_t tile = d.tile0;
+  while (tile < d.tile1) {
     if (!tile_is_fast(tile)) {
       float tmp[TILE_K];
       load_channel_generic(d.in, si, sc, ch, tile, lane, d.n_quanta, tmp);
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
       continue;
     }
     uint32_t end = tile + 1;  // [tile, end) = maximal run of fast tiles
-    while (end < d.n_tiles && tile_is_fast(end)) end++;
+    while (end < d.tile1 && tile_is_fast(end)) end++;
     float nx[TILE_K];
     fetch_fast(tile, nx);
     for (; tile < end; tile++) {

@@ -16,8 +16,8 @@ __global__ __launch_bounds__(256) void delay_kernel(const DelayDesc d) {
   const uint32_t sid = blockIdx.y;  // instance * nch + channel
   const uint32_t inst = sid / (uint32_t)d.nch;
   const int ch = (int)(sid % (uint32_t)d.nch);
-  const uint64_t f0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (f0 >= d.frames) return;
+  const uint64_t f0 = (uint64_t)d.tile0 * TILE + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (f0 >= (uint64_t)d.tile1 * TILE) return;
   const float* in = d.in.base + (uint64_t)inst * d.in.inst_stride + (uint64_t)ch * d.in.ch_stride;
   float* out = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)ch * d.out.ch_stride;
   const uint32_t q = (uint32_t)(f0 / RQ);
@@ -31,7 +31,9 @@ __global__ __launch_bounds__(256) void delay_kernel(const DelayDesc d) {
     float k0 = 0.f;
     if (d.delay.mode != 2) {
       const float dv = d.delay.mode == 0 ? d.delay.base[inst] : d.delay.base[(uint64_t)inst * d.delay.stride + q];
-      const double position = 0. - (double)dv * d.sample_rate;
+      double dd = (double)dv;
+      if (d.in_cycle) dd = fmax(dd, d.quantum_duration);  // delay.rs:693-701
+      const double position = 0. - dd * d.sample_rate;
       const double fl = floor(position);
       pf0 = (int64_t)fl;
       k0 = (float)(position - fl);
@@ -46,7 +48,9 @@ __global__ __launch_bounds__(256) void delay_kernel(const DelayDesc d) {
         k = k0;
       } else {
         const float dv = d.delay.base[(uint64_t)inst * d.delay.stride + (uint64_t)q * RQ + i];
-        const double position = (double)i - (double)dv * d.sample_rate;
+        double dd = (double)dv;
+        if (d.in_cycle) dd = fmax(dd, d.quantum_duration);
+        const double position = (double)i - dd * d.sample_rate;
         const double fl = floor(position);
         pf = (int64_t)fl;
         k = (float)(position - fl);
@@ -54,7 +58,10 @@ __global__ __launch_bounds__(256) void delay_kernel(const DelayDesc d) {
       const int64_t prev = qstart + pf;
       // the sample after frame 127 of the newest block is frame 0 of the OLDEST ring block (delay.rs:622-626);
       // only reachable with a zero delay, where k == 0
-      const int64_t next = pf == RQ - 1 ? (int64_t)(q - (int64_t)d.num_quanta) * RQ : prev + 1;
+      int64_t next = pf == RQ - 1 ? (int64_t)(q - (int64_t)d.num_quanta) * RQ : prev + 1;
+      // a reader that renders before its writer finds, in the slot of the current quantum, the block written
+      // ring-capacity quanta ago (only reachable with k == 0)
+      if (d.in_cycle && next >= qstart) next -= ((int64_t)d.num_quanta + 1) * RQ;
       const float ps = prev >= 0 ? in[prev] : 0.f;
       const float nsamp = next >= 0 ? in[next] : 0.f;
       r[e] = __builtin_fmaf(1.f - k, ps, k * nsamp);
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(256) void delay_kernel(const DelayDesc d) {
 }
 
 void launch_delay(const DelayDesc& d, void* stream) {
-  const dim3 grid((uint32_t)((d.frames + 1023) / 1024), d.n_inst * (uint32_t)d.nch), block(256);
+  const dim3 grid((uint32_t)(((uint64_t)(d.tile1 - d.tile0) * TILE + 1023) / 1024), d.n_inst * (uint32_t)d.nch), block(256);
   hipLaunchKernelGGL(delay_kernel, grid, block, 0, (hipStream_t)stream, d);
 }
 

@@ -122,6 +122,8 @@ struct Node {
   bool live = false;
   bool materialized = false;
   SignalRef sig{};     // valid when materialized
+  SignalRef hist{};    // DelayNode: the delay line (the node's mixed input, absolute time)
+  bool hist_is_temp = false;
   std::vector<int> in_edges;   // indices into edges, in summing order
   // audio-rate inputs of this node's AudioParams (edges with to_input = WAA_PARAM_INPUT(k)), in summing order,
   // and the per-frame value signal planned for them (param.rs:686-795)
@@ -152,6 +154,8 @@ struct Step {
   size_t zero_bytes = 0;
   int cmax = 1;
   int profile_slot = -1;
+  int group = -1;         // >= 0: member of a block-scheduled feedback loop (launched block by block)
+  bool prologue = false;  // inside a group: runs once over the full range before the blocks
 };
 
 }  // namespace
@@ -168,6 +172,7 @@ struct waa_batch {
   std::vector<waa_edge_desc> edges;
   std::vector<uint32_t> order;
   std::vector<uint8_t> cut;         // per DelayNode: writer->reader edge removed by the cycle breaker
+  std::vector<uint32_t> group_tiles;  // block size (tiles) of every block-scheduled feedback loop
   std::vector<void*> allocs;        // plan-owned device allocations
   std::vector<void*> payload_allocs;  // buffers uploaded through the API
   std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render
@@ -756,7 +761,6 @@ bool order_visit(OrderCtx& c, uint32_t v) {
 }
 
 int plan_convolver(waa_batch* b, uint32_t id);
-int plan_delay(waa_batch* b, uint32_t id);
 int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int interp);
 
 void plan_note(waa_batch* b, const char* fmt, ...) {
@@ -829,6 +833,8 @@ int push_chain_step(waa_batch* b, const std::vector<InputRef>& inputs, int in_nc
   cd.out = out;
   cd.n_inst = b->n_inst;
   cd.n_tiles = b->n_tiles;
+  cd.tile0 = 0;
+  cd.tile1 = b->n_tiles;
   cd.n_quanta = b->n_quanta;
   st.cmax = cmax;
   st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : cmax <= 2 ? "chain_kernel<2>" : "chain_kernel<4+>");
@@ -938,6 +944,10 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
       q.out = seg_out;
       q.n_inst = b->n_inst;
       q.n_tiles = b->n_tiles;
+    q.tile0 = 0;
+    q.tile1 = b->n_tiles;
+      q.tile0 = 0;
+      q.tile1 = b->n_tiles;
       q.n_quanta = b->n_quanta;
       char name[32];
       snprintf(name, sizeof name, "%s<%d>", q.exact == 2 ? "iir_row_kernel" : q.exact == 1 ? "iir_lane_kernel" : "iir_stream_kernel", q.ns);
@@ -970,6 +980,8 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     q.out = seg_out;
     q.n_inst = b->n_inst;
     q.n_tiles = b->n_tiles;
+    q.tile0 = 0;
+    q.tile1 = b->n_tiles;
     q.n_quanta = b->n_quanta;
     st.profile_slot = slot_for(b, "biquad_stream_kernel");
     b->steps.push_back(st);
@@ -1004,6 +1016,9 @@ void vertex_targets(const waa_batch* b, uint32_t v, const std::vector<uint8_t>& 
 }
 
 int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items);
+int plan_delay_writer(waa_batch* b, uint32_t id);
+int plan_delay_reader(waa_batch* b, uint32_t id);
+uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items);
 
 int build_plan(waa_batch* b) {
   const uint32_t N = (uint32_t)b->nodes.size();
@@ -1253,43 +1268,23 @@ int build_plan(waa_batch* b) {
     };
     for (uint32_t id : b->order) visit_unit(id);
   }
-  // chains, in processing order of their terminal node
   b->steps.clear();
-  for (const Unit& unit : units) {
-    const uint32_t id = unit.id;
-    if (unit.scc >= 0) {
-      std::vector<uint32_t> loop_items;
-      bool any_live = false;
-      for (uint32_t v : items)
-        if (scc_of[v & ~VTX_READER] == unit.scc) {
-          loop_items.push_back(v);
-          any_live |= b->nodes[v & ~VTX_READER].live;
-        }
-      if (!any_live) continue;
-      for (uint32_t v : loop_items) {
-        Node& m = b->nodes[v & ~VTX_READER];
-        if (!m.sig.base) {
-          int e = alloc_signal(m);
-          if (e) return e;
-        }
-      }
-      int e = plan_loop(b, loop_items);
-      if (e) return e;
-      continue;
-    }
+  std::function<int(uint32_t)> plan_single = [&](uint32_t id) -> int {
     Node& term = b->nodes[id];
-    if (!term.live || !term.materialized) continue;
+    if (!term.live || !term.materialized) return 0;
     if (term.desc.kind == WAA_NODE_CONVOLVER && term.has_ir) {
+      if (scc_of[id] >= 0) return fail(WAA_ERR_OUT_OF_SCOPE, "a ConvolverNode inside a feedback loop is out of scope (node %u)", id);
       int e = alloc_signal(term);
       if (e) return e;
       if ((e = plan_convolver(b, id))) return e;
-      continue;
+      return 0;
     }
-    if (term.desc.kind == WAA_NODE_DELAY) {
+    if (term.desc.kind == WAA_NODE_DELAY) {  // outside a loop: writer and reader halves back to back
       int e = alloc_signal(term);
       if (e) return e;
-      if ((e = plan_delay(b, id))) return e;
-      continue;
+      if ((e = plan_delay_writer(b, id))) return e;
+      if ((e = plan_delay_reader(b, id))) return e;
+      return 0;
     }
     // identity node on a materialised signal of the same layout (destination / analyser / passthrough right
     // behind a materialised producer): alias instead of copying 8 B per frame-channel through HBM
@@ -1298,13 +1293,13 @@ int build_plan(waa_batch* b) {
       const uint32_t k = term.desc.kind;
       const bool identity = k == WAA_NODE_DESTINATION || k == WAA_NODE_ANALYSER ||
                             (k == WAA_NODE_CONVOLVER && !term.has_ir) || (k == WAA_NODE_WAVESHAPER && !term.has_curve);
-      if (identity && p.materialized && p.out_nch == term.in_nch && term.in_nch == term.out_nch) {
+      if (identity && scc_of[id] < 0 && p.materialized && p.out_nch == term.in_nch && term.in_nch == term.out_nch) {
         term.sig = p.sig;
         plan_note(b, "alias node %u -> output of node %u", id, b->edges[term.in_edges[0]].from);
-        continue;
+        return 0;
       }
     }
-    {
+    if (!term.sig.base) {  // (members of a feedback loop are allocated up front)
       int e = alloc_signal(term);
       if (e) return e;
     }
@@ -1386,6 +1381,62 @@ int build_plan(waa_batch* b) {
     }
     std::vector<InputRef> inputs(cd.in, cd.in + cd.n_inputs);
     int e = emit_segments(b, inputs, cd.in_nch, cd.in_interp, ops, term.sig);
+    if (e) return e;
+    return 0;
+  };
+  // chains, in processing order of their terminal node
+  for (const Unit& unit : units) {
+    const uint32_t id = unit.id;
+    if (unit.scc >= 0) {
+      std::vector<uint32_t> loop_items;
+      bool any_live = false;
+      for (uint32_t v : items)
+        if (scc_of[v & ~VTX_READER] == unit.scc) {
+          loop_items.push_back(v);
+          any_live |= b->nodes[v & ~VTX_READER].live;
+        }
+      if (!any_live) continue;
+      for (uint32_t v : loop_items) {
+        Node& m = b->nodes[v & ~VTX_READER];
+        if (!m.sig.base) {
+          int e = alloc_signal(m);
+          if (e) return e;
+        }
+      }
+      const uint32_t bt = loop_block_tiles(b, loop_items);
+      if (bt == 0) {  // short or modulated loop delay: quantum-serial loop kernel
+        int e = plan_loop(b, loop_items);
+        if (e) return e;
+        continue;
+      }
+      // Block-scheduled loop: every delay that breaks the loop is longer than `bt` tiles, so a block of bt tiles
+      // only reads loop history from earlier blocks: the members are planned as ordinary node-major steps (same
+      // kernels as outside a loop) in the reference's processing order and launched block by block.
+      const size_t first_step = b->steps.size();
+      for (uint32_t v : loop_items) {
+        const uint32_t mid = v & ~VTX_READER;
+        int e = 0;
+        if (is_delay(b, mid))
+          e = (v & VTX_READER) ? plan_delay_reader(b, mid) : plan_delay_writer(b, mid);
+        else
+          e = plan_single(mid);
+        if (e) return e;
+      }
+      const int group = (int)b->group_tiles.size();
+      b->group_tiles.push_back(bt);
+      for (size_t k = first_step; k < b->steps.size(); k++) {
+        Step& st = b->steps[k];
+        st.group = group;
+        // steps that only depend on data from outside the loop run once, over the full range, before the blocks
+        st.prologue = st.kind == 5 || st.kind == 3 || (st.kind == 0 && st.chain.n_ops == 1 && st.chain.ops[0].kind == OP_PARAM_ADD);
+        if (st.kind == 2 || st.kind == 4)
+          return fail(WAA_ERR_OUT_OF_SCOPE, "this node kind cannot be rendered inside a feedback loop");
+      }
+      plan_note(b, "feedback loop: block-scheduled, %u tile(s) = %u frames per block, %zu step(s) per block", bt, bt * TILE,
+                b->steps.size() - first_step);
+      continue;
+    }
+    int e = plan_single(id);
     if (e) return e;
   }
   b->planned = true;
@@ -1524,6 +1575,10 @@ int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int inte
     cd.out = SignalRef{ptr, (uint64_t)in_nch * b->lp, b->lp, in_nch, 0};
     cd.n_inst = b->n_inst;
     cd.n_tiles = b->n_tiles;
+    cd.tile0 = 0;
+    cd.tile1 = b->n_tiles;
+  cd.tile0 = 0;
+  cd.tile1 = b->n_tiles;
     cd.n_quanta = b->n_quanta;
     int cmax = in_nch;
     for (int k = 0; k < MAX_INPUTS; k++) cmax = std::max(cmax, ins[k].nch);
@@ -1545,9 +1600,9 @@ int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int inte
 // + forward FFT / spectral MAC / inverse FFT steps.
 // Input of a node-major step (convolver, delay): the single producer's signal if its channel count already
 // matches, else a mixing chain into a temporary.
-int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig) {
+int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr) {
   Node& n = b->nodes[id];
-  if (n.in_edges.size() == 1) {
+  if (!target && n.in_edges.size() == 1) {
     Node& p = b->nodes[b->edges[n.in_edges[0]].from];
     if (p.materialized && p.out_nch == n.in_nch) {
       *out_sig = p.sig;
@@ -1555,7 +1610,11 @@ int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig) {
     }
   }
   SignalRef in_sig;
-  int e = temp_signal(b, n.in_nch, &in_sig);
+  int e = 0;
+  if (target)
+    in_sig = *target;  // mix into a signal somebody already reads from
+  else
+    e = temp_signal(b, n.in_nch, &in_sig);
   if (e) return e;
   std::vector<InputRef> ins;
   if (n.in_edges.empty()) {
@@ -1580,28 +1639,90 @@ int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig) {
   return 0;
 }
 
-// DelayNode outside a cycle (delay.rs:428-745): one gather kernel from the materialised input
-int plan_delay(waa_batch* b, uint32_t id) {
+// DelayNode (delay.rs:428-745).  Writer half: the node's mixed input becomes the delay line `hist` (an alias of the
+// producer's signal when nothing has to be mixed).  Reader half: one gather kernel from the delay line.  Outside a
+// loop the two are planned back to back; inside a block-scheduled loop each at its own place in the order.
+int plan_delay_writer(waa_batch* b, uint32_t id) {
+  Node& n = b->nodes[id];
+  if (n.hist.base) {  // the reader half was planned first (inside a loop) and chose the delay line
+    if (!n.hist_is_temp) return 0;
+    SignalRef same;
+    return node_input_signal(b, id, &same, &n.hist);
+  }
+  return node_input_signal(b, id, &n.hist);
+}
+int plan_delay_reader(waa_batch* b, uint32_t id) {
   Node& n = b->nodes[id];
   Step st;
   st.kind = 7;
   DelayDesc& d = st.delay;
   std::memset(&d, 0, sizeof d);
-  int e = node_input_signal(b, id, &d.in);
-  if (e) return e;
+  const bool in_cycle = id < b->cut.size() && b->cut[id];
+  if (in_cycle && !n.hist.base) {
+    // the reader renders before its writer: the delay line is not planned yet.  It is the producer's signal when
+    // there is exactly one materialised producer of the right layout, else a temporary the writer half fills.
+    bool direct = false;
+    if (n.in_edges.size() == 1) {
+      Node& p = b->nodes[b->edges[n.in_edges[0]].from];
+      direct = p.materialized && p.out_nch == n.in_nch && p.sig.base;
+      if (direct) n.hist = p.sig;
+    }
+    if (!direct) {
+      int e = temp_signal(b, n.in_nch, &n.hist);
+      if (e) return e;
+      n.hist_is_temp = true;
+    }
+  }
+  if (!n.hist.base) return fail(WAA_ERR_INVALID_STATE, "internal: delay line of node %u not planned", id);
+  d.in = n.hist;
   d.out = n.sig;
-  if ((e = node_param(b, id, WAA_PARAM_DELAY_DELAY_TIME, &d.delay))) return e;
+  int e = node_param(b, id, WAA_PARAM_DELAY_DELAY_TIME, &d.delay);
+  if (e) return e;
   d.sample_rate = (double)b->sr;
   d.frames = b->lp;
   d.num_quanta = (int32_t)std::ceil(n.desc.d[0] * (double)b->sr / (double)RQ);
   d.nch = n.in_nch;
   d.n_inst = b->n_inst;
   d.n_quanta = b->n_quanta;
+  d.tile0 = 0;
+  d.tile1 = b->n_tiles;
+  d.in_cycle = in_cycle ? 1 : 0;
+  const double dt = 1. / (double)b->sr;
+  d.quantum_duration = (double)RQ * dt;  // delay.rs:546-548
   st.profile_slot = slot_for(b, "delay_kernel");
   b->steps.push_back(st);
-  plan_note(b, "delay node %u: %dch delayTime=%s ring=%d quanta", id, d.nch,
-            d.delay.mode == 0 ? "const" : d.delay.mode == 1 ? "k-rate" : "a-rate", d.num_quanta + 1);
+  plan_note(b, "delay node %u: %dch delayTime=%s ring=%d quanta%s", id, d.nch,
+            d.delay.mode == 0 ? "const" : d.delay.mode == 1 ? "k-rate" : "a-rate", d.num_quanta + 1,
+            in_cycle ? " (in a loop: clamped to one quantum)" : "");
   return 0;
+}
+
+// Block size (in 2048-frame tiles) for a block-scheduled feedback loop, 0 if the loop needs the quantum-serial
+// kernel.  Every DelayNode whose writer->reader edge the cycle breaker removed must have a host-known delay
+// (constant or k-rate blocks, not modulated from the graph) strictly longer than the block: then no frame of a
+// block depends on loop history of the same block.
+uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items) {
+  if (getenv("WAA_LOOP_KERNEL")) return 0;  // debugging aid: force the quantum-serial kernel
+  const double dt = 1. / (double)b->sr;
+  const double quantum_duration = (double)RQ * dt;
+  double dmin = 1e300;
+  for (uint32_t v : loop_items) {
+    const uint32_t id = v & ~VTX_READER;
+    Node& n = b->nodes[id];
+    if (!(v & VTX_READER)) {
+      if (n.desc.kind == WAA_NODE_CONVOLVER && n.has_ir) return 0;
+      continue;
+    }
+    if (!b->cut[id]) continue;  // keeps its writer->reader edge: reads the current block like any other node
+    if (param_mode(n, WAA_PARAM_DELAY_DELAY_TIME) == 2) return 0;
+    for (uint32_t i = 0; i < b->n_inst; i++)
+      for (float dv : param_per_quantum(b, n.params[WAA_PARAM_DELAY_DELAY_TIME], i, nullptr))
+        dmin = std::min(dmin, std::max((double)dv, quantum_duration) * (double)b->sr);
+  }
+  if (!(dmin < 1e300)) return 0;
+  const double tiles = std::ceil(dmin / (double)TILE) - 1.;  // block < delay, strictly
+  if (tiles < 1.) return 0;
+  return (uint32_t)std::min(tiles, 64.);
 }
 
 // A feedback loop (strongly connected group around at least one DelayNode): one loop_kernel launch renders all
@@ -2598,10 +2719,17 @@ waa_status waa_render(waa_batch* b) {
     }
     return 0;
   };
-  for (auto& st : b->steps) {
+  // one step over the tile range [t0, t1)
+  auto run_step = [&](const Step& st, uint32_t t0, uint32_t t1) -> int {
     int e = 0;
     switch (st.kind) {
-      case 1: e = timed(st.profile_slot, [&] { launch_biquad_stream(st.bq, b->stream); }); break;
+      case 1: {
+        BiquadStreamDesc d = st.bq;
+        d.tile0 = t0;
+        d.tile1 = t1;
+        e = timed(st.profile_slot, [&] { launch_biquad_stream(d, b->stream); });
+        break;
+      }
       case 2:
         if ((e = timed(st.slot_fwd, [&] { launch_conv_forward(st.conv, b->stream); }))) break;
         if ((e = timed(st.slot_mac, [&] { launch_conv_mac(st.conv, b->stream); }))) break;
@@ -2610,12 +2738,57 @@ waa_status waa_render(waa_batch* b) {
       case 3: HIP_TRY(hipMemsetAsync(st.zero_ptr, 0, st.zero_bytes, b->stream)); break;
       case 4: e = timed(st.slot_mac, [&] { launch_conv_direct(st.conv, b->stream); }); break;
       case 5: e = timed(st.profile_slot, [&] { launch_biquad_coefs(st.coef, b->stream); }); break;
-      case 6: e = timed(st.profile_slot, [&] { launch_iir_stream(st.iir, b->stream); }); break;
-      case 7: e = timed(st.profile_slot, [&] { launch_delay(st.delay, b->stream); }); break;
+      case 6: {
+        IirStreamDesc d = st.iir;
+        d.tile0 = t0;
+        d.tile1 = t1;
+        e = timed(st.profile_slot, [&] { launch_iir_stream(d, b->stream); });
+        break;
+      }
+      case 7: {
+        DelayDesc d = st.delay;
+        d.tile0 = t0;
+        d.tile1 = t1;
+        e = timed(st.profile_slot, [&] { launch_delay(d, b->stream); });
+        break;
+      }
       case 8: e = timed(st.profile_slot, [&] { launch_loop(st.loop, b->stream); }); break;
-      default: e = timed(st.profile_slot, [&] { launch_chain(st.chain, st.cmax, b->stream); }); break;
+      default: {
+        ChainDesc d = st.chain;
+        d.tile0 = t0;
+        d.tile1 = t1;
+        e = timed(st.profile_slot, [&] { launch_chain(d, st.cmax, b->stream); });
+        break;
+      }
     }
-    if (e) return e;
+    return e;
+  };
+  for (size_t i = 0; i < b->steps.size();) {
+    const Step& st = b->steps[i];
+    if (st.group < 0) {
+      int e = run_step(st, 0, b->n_tiles);
+      if (e) return e;
+      i++;
+      continue;
+    }
+    // block-scheduled feedback loop: steps [i, j) block by block (graph.rs cycle breaker, see build_plan)
+    size_t j = i;
+    while (j < b->steps.size() && b->steps[j].group == st.group) j++;
+    for (size_t k = i; k < j; k++)
+      if (b->steps[k].prologue) {
+        int e = run_step(b->steps[k], 0, b->n_tiles);
+        if (e) return e;
+      }
+    const uint32_t bt = b->group_tiles[st.group];
+    for (uint32_t t0 = 0; t0 < b->n_tiles; t0 += bt) {
+      const uint32_t t1 = std::min(b->n_tiles, t0 + bt);
+      for (size_t k = i; k < j; k++)
+        if (!b->steps[k].prologue) {
+          int e = run_step(b->steps[k], t0, t1);
+          if (e) return e;
+        }
+    }
+    i = j;
   }
   return WAA_OK;
 }

@@ -243,8 +243,8 @@ __global__ __launch_bounds__(64, 2) void iir_stream_kernel(const IirStreamDesc d
   // same software pipeline as the biquad kernel: next tile's input in flight, previous tile's store deferred
   bool pending = false;
   uint32_t pending_tile = 0;
-  uint32_t tile = 0;
-  while (tile < d.n_tiles) {
+  uint32_t tile = d.tile0;
+  while (tile < d.tile1) {
     if (!tile_is_fast(tile)) {
       float tmp[TILE_K];
       load_channel_generic(d.in, si, sc, ch, tile, lane, d.n_quanta, tmp);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64, 2) void iir_stream_kernel(const IirStreamDesc d
       continue;
     }
     uint32_t end = tile + 1;
-    while (end < d.n_tiles && tile_is_fast(end)) end++;
+    while (end < d.tile1 && tile_is_fast(end)) end++;
     float nx[TILE_K];
     fetch_fast(tile, nx);
     for (; tile < end; tile++) {
@@ -298,11 +298,11 @@ __global__ __launch_bounds__(64) void iir_lane_kernel(const IirStreamDesc d) {
 #pragma unroll
   for (int k = 0; k < NS; k++) s[k] = st[k];
   constexpr int BLK = 16;
-  const uint64_t n_blocks = (uint64_t)d.n_tiles * TILE / BLK;
+  const uint64_t blk0 = (uint64_t)d.tile0 * TILE / BLK, n_blocks = (uint64_t)d.tile1 * TILE / BLK;
   float4 nx[BLK / 4];
 #pragma unroll
-  for (int j = 0; j < BLK / 4; j++) nx[j] = reinterpret_cast<const float4*>(ip)[j];
-  for (uint64_t blk = 0; blk < n_blocks; blk++) {
+  for (int j = 0; j < BLK / 4; j++) nx[j] = reinterpret_cast<const float4*>(ip + blk0 * BLK)[j];
+  for (uint64_t blk = blk0; blk < n_blocks; blk++) {
     float x[BLK];
 #pragma unroll
     for (int j = 0; j < BLK / 4; j++) {
@@ -372,16 +372,16 @@ __global__ __launch_bounds__(64) void iir_row_kernel(const IirStreamDesc d) {
   const float* ip = d.in.sig.base + (uint64_t)inst * d.in.sig.inst_stride + (uint64_t)ch * d.in.sig.ch_stride;
   float* op = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)ch * d.out.ch_stride;
   constexpr int BLK = 16;
-  const uint64_t n_blocks = (uint64_t)d.n_tiles * TILE / BLK;
+  const uint64_t blk0 = (uint64_t)d.tile0 * TILE / BLK, n_blocks = (uint64_t)d.tile1 * TILE / BLK;
   float4 nx[BLK / 4];
 #pragma unroll
-  for (int q = 0; q < BLK / 4; q++) nx[q] = reinterpret_cast<const float4*>(ip)[q];
+  for (int q = 0; q < BLK / 4; q++) nx[q] = reinterpret_cast<const float4*>(ip + blk0 * BLK)[q];
   auto dpp64 = [](double v, auto ctrl, auto bound) __attribute__((always_inline)) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), decltype(ctrl)::value, 0xf, 0xf, decltype(bound)::value);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), decltype(ctrl)::value, 0xf, 0xf, decltype(bound)::value);
     return __hiloint2double(hi, lo);
   };
-  for (uint64_t blk = 0; blk < n_blocks; blk++) {
+  for (uint64_t blk = blk0; blk < n_blocks; blk++) {
     float x[BLK];
 #pragma unroll
     for (int q = 0; q < BLK / 4; q++) {

@@ -114,6 +114,7 @@ struct ChainDesc {
   uint32_t n_tiles;
   uint32_t n_quanta;
   uint32_t pad;
+  uint32_t tile0, tile1;   // tiles [tile0, tile1) of this launch (block-scheduled feedback loops); full range otherwise
 };
 
 // ---- streaming biquad kernel (the C2 / T1 hot shape) --------------------------------------
@@ -134,6 +135,7 @@ struct BiquadStreamDesc {
   uint32_t n_tiles;
   uint32_t n_quanta;
   uint32_t pad;
+  uint32_t tile0, tile1;
 };
 void launch_biquad_stream(const BiquadStreamDesc& d, void* stream);
 
@@ -152,6 +154,7 @@ struct IirStreamDesc {
   uint32_t n_tiles;
   uint32_t n_quanta;
   uint32_t exact;      // 0: scan kernel; exact kernels (input must be IN_SIGNAL): 1 lane per stream, 2 DPP row per stream
+  uint32_t tile0, tile1;
 };
 int iir_padded_states(int n_states);  // kernel state count for a filter with n_states state variables
 void launch_iir_stream(const IirStreamDesc& d, void* stream);
@@ -216,6 +219,10 @@ struct DelayDesc {
   int32_t nch;
   uint32_t n_inst;
   uint32_t n_quanta;
+  uint32_t tile0, tile1;
+  int32_t in_cycle;      // the cycle breaker removed this node's writer->reader edge: delay clamped to one quantum
+  int32_t pad;
+  double quantum_duration;
 };
 void launch_delay(const DelayDesc& d, void* stream);
 

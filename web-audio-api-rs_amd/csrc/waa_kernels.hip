@@ -500,16 +500,16 @@ __global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDes
   constexpr int TILE_FR = 64 * K;
   constexpr int QPT = K / 2;
   const int lane = threadIdx.x & 63;
-  const uint32_t n_tiles_k = d.n_tiles * (TILE / TILE_FR);
+  const uint32_t n_tiles_k = (d.tile1 - d.tile0) * (TILE / TILE_FR);  // sub-tiles of this launch
   uint32_t inst, tile_first, tile_last;
   if (SERIAL) {
     inst = blockIdx.x;
-    tile_first = 0;
-    tile_last = n_tiles_k;
+    tile_first = d.tile0 * (TILE / TILE_FR);
+    tile_last = d.tile1 * (TILE / TILE_FR);
   } else {
     const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     inst = (uint32_t)(wid / n_tiles_k);
-    tile_first = (uint32_t)(wid % n_tiles_k);
+    tile_first = d.tile0 * (TILE / TILE_FR) + (uint32_t)(wid % n_tiles_k);
     tile_last = tile_first + 1;
   }
   if (inst >= d.n_inst) return;
@@ -818,7 +818,7 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
     else
       hipLaunchKernelGGL((chain_kernel<2, TILE_K, true>), grid, block, 2 * 64 * LDS_ROW * sizeof(float) + CARRY_BYTES, s, d);
   } else {
-    const uint64_t waves = (uint64_t)d.n_inst * d.n_tiles * (TILE / 256);
+    const uint64_t waves = (uint64_t)d.n_inst * (d.tile1 - d.tile0) * (TILE / 256);
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     if (cmax <= 1)
       hipLaunchKernelGGL((chain_kernel<1, 4, false>), grid, block, 0, s, d);
