@@ -73,7 +73,7 @@ enum {
   WAA_NODE_WAVESHAPER = 8,      /* src/node/waveshaper.rs:383-487 (oversample None only) */
   WAA_NODE_CONSTANT_SOURCE = 9, /* src/node/constant_source.rs:190-275 */
   WAA_NODE_IIR_FILTER = 10,     /* src/node/iir_filter.rs:323-405 */
-  WAA_NODE_DELAY = 11,          /* src/node/delay.rs:428-745, writer + reader outside a cycle */
+  WAA_NODE_DELAY = 11,          /* src/node/delay.rs:428-745 incl. the cycle breaker of graph.rs:323-487 */
   WAA_NODE_KIND_COUNT = 12
 };
 
@@ -121,7 +121,8 @@ enum {
  *     WAVESHAPER  i[0] = oversample
  *     CONVOLVER   i[0] = disable_normalization (0/1)
  *     DELAY       d[0] = max_delay_time in seconds (0 = the default, 1 s); must be > 0 and < 180
- *                 (NotSupportedError, delay.rs:290-293).  Feedback loops through a DelayNode are out of scope.
+ *                 (NotSupportedError, delay.rs:290-293).  Graph cycles through a DelayNode are rendered (the delay
+ *                 is clamped to one render quantum inside a loop, delay.rs:693-701); cycles without one are muted.
  */
 typedef struct {
   uint32_t kind;

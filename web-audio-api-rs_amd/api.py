@@ -684,8 +684,8 @@ class IIRFilterNode(AudioNode):
 
 
 class DelayNode(AudioNode):
-    """src/node/delay.rs:127-376 (DelayOptions{max_delay_time = 1, delay_time = 0}).  Feedback loops through
-    the node (the reference's cycle breaker) are out of scope of the device path."""
+    """src/node/delay.rs:127-376 (DelayOptions{max_delay_time = 1, delay_time = 0}).  Inside a graph cycle the
+    node acts as the reference's cycle breaker (delay clamped to one render quantum)."""
 
     kind = NODE_DELAY
 
