@@ -14,6 +14,7 @@
  *                                                                             src/node/audio_buffer_source.rs:388-398
  *   waa_convolver_set_buffer    ConvolverNode::set_buffer                     src/node/convolver.rs:259-317
  *   waa_waveshaper_set_curve    WaveShaperNode::set_curve                     src/node/waveshaper.rs:489-509 (onmessage)
+ *   waa_oscillator_set_periodic_wave  OscillatorNode::set_periodic_wave     src/node/oscillator.rs:318-321
  *   waa_iir_set_coefficients    IIRFilterNode::new(IIRFilterOptions)          src/node/iir_filter.rs:163-189
  *   waa_iir_frequency_response  IIRFilterNode::get_frequency_response         src/node/iir_filter.rs:218-262
  *   waa_set_param_const/block   AudioParamValues::get (len 1 / len 128)       src/render/processor.rs:186-229
@@ -74,7 +75,8 @@ enum {
   WAA_NODE_CONSTANT_SOURCE = 9, /* src/node/constant_source.rs:190-275 */
   WAA_NODE_IIR_FILTER = 10,     /* src/node/iir_filter.rs:323-405 */
   WAA_NODE_DELAY = 11,          /* src/node/delay.rs:428-745 incl. the cycle breaker of graph.rs:323-487 */
-  WAA_NODE_KIND_COUNT = 12
+  WAA_NODE_OSCILLATOR = 12,     /* src/node/oscillator.rs:323-660 (on-device source) */
+  WAA_NODE_KIND_COUNT = 13
 };
 
 /* src/node/audio_node.rs ChannelCountMode / ChannelInterpretation */
@@ -99,6 +101,9 @@ enum { WAA_PARAM_SOURCE_PLAYBACK_RATE = 0, WAA_PARAM_SOURCE_DETUNE = 1 };
 enum { WAA_PARAM_STEREO_PANNER_PAN = 0 };
 enum { WAA_PARAM_CONSTANT_OFFSET = 0 };
 enum { WAA_PARAM_DELAY_DELAY_TIME = 0 };
+enum { WAA_PARAM_OSCILLATOR_FREQUENCY = 0, WAA_PARAM_OSCILLATOR_DETUNE = 1 };
+/* src/node/oscillator.rs OscillatorType */
+enum { WAA_OSC_SINE = 0, WAA_OSC_SQUARE = 1, WAA_OSC_SAWTOOTH = 2, WAA_OSC_TRIANGLE = 3, WAA_OSC_CUSTOM = 4 };
 enum {
   WAA_PARAM_PANNER_POSITION_X = 0, WAA_PARAM_PANNER_POSITION_Y = 1, WAA_PARAM_PANNER_POSITION_Z = 2,
   WAA_PARAM_PANNER_ORIENTATION_X = 3, WAA_PARAM_PANNER_ORIENTATION_Y = 4, WAA_PARAM_PANNER_ORIENTATION_Z = 5,
@@ -120,6 +125,8 @@ enum {
  *     ANALYSER    i[0] = fft_size, d[0] smoothing_time_constant, d[1] min_decibels, d[2] max_decibels
  *     WAVESHAPER  i[0] = oversample
  *     CONVOLVER   i[0] = disable_normalization (0/1)
+ *     OSCILLATOR  i[0] = type (WAA_OSC_*; CUSTOM needs waa_oscillator_set_periodic_wave); scheduled with
+ *                 waa_source_start / waa_source_stop like the other AudioScheduledSourceNodes
  *     DELAY       d[0] = max_delay_time in seconds (0 = the default, 1 s); must be > 0 and < 180
  *                 (NotSupportedError, delay.rs:290-293).  Graph cycles through a DelayNode are rendered (the delay
  *                 is clamped to one render quantum inside a loop, delay.rs:693-701); cycles without one are muted.
@@ -196,6 +203,11 @@ waa_status waa_source_set_loop(waa_batch* batch, uint32_t node, uint32_t instanc
 waa_status waa_convolver_set_buffer(waa_batch* batch, uint32_t node, const float* const* channels,
                                     uint32_t n_channels, uint64_t frames, float sample_rate);
 waa_status waa_waveshaper_set_curve(waa_batch* batch, uint32_t node, const float* curve, uint32_t n);
+/* OscillatorNode::set_periodic_wave(PeriodicWave::new(real, imag, disable_normalization))
+ * (src/periodic_wave.rs:88-190, src/node/oscillator.rs:318-321): the 8192-point wavetable is generated on the
+ * host; n >= 2 (IndexSizeError); real or imag may be NULL (zeros).  Switches the node to the custom type. */
+waa_status waa_oscillator_set_periodic_wave(waa_batch* batch, uint32_t node, const float* real, const float* imag,
+                                            uint32_t n, int32_t disable_normalization);
 /* IIRFilterOptions{feedforward, feedback} (src/node/iir_filter.rs:63-72), shared by all instances; required
  * before waa_render.  1..20 coefficients each (NotSupportedError otherwise), feedforward not all zero and
  * feedback[0] != 0 (InvalidStateError), iir_filter.rs:17-46. */

@@ -549,6 +549,8 @@ typedef struct {
   uint32_t curve_n;
   int has_curve;
   int can_propagate_silence;
+  /* oscillator: custom wavetable (periodic_wave.rs:76, 8192 points), shared */
+  float* osc_wave;
   /* iir filter (shared): normalised (b, a) pairs, iir_filter.rs:273-311 */
   double iir_b[WAA_MAX_IIR_COEFFS], iir_a[WAA_MAX_IIR_COEFFS];
   int iir_len;
@@ -559,6 +561,9 @@ typedef struct {
   /* biquad */
   double xy[ORC_MAXC][4];
   int xy_len;
+  /* oscillator render state (oscillator.rs:323-334) */
+  double osc_phase;
+  int osc_started;
   /* audio-rate inputs of this node's AudioParams (param.rs:686-699), allocated for modulated params only */
   Quantum* pin[WAA_MAX_PARAMS];
   /* delay line (delay.rs:297-303): ring of num_quanta + 1 render quanta shared by writer and reader */
@@ -859,6 +864,19 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
           return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count cannot be greater than two");
         break;
       }
+      case WAA_NODE_OSCILLATOR: { /* oscillator.rs:210-262 */
+        if (n->desc.i[0] < WAA_OSC_SINE || n->desc.i[0] > WAA_OSC_CUSTOM) return fail(WAA_ERR_INVALID_ARGUMENT, "bad oscillator type");
+        n->n_params = 2;
+        param_init(&n->params[WAA_PARAM_OSCILLATOR_FREQUENCY], n_inst, 440.f, -sr / 2.f, sr / 2.f);
+        param_init(&n->params[WAA_PARAM_OSCILLATOR_DETUNE], n_inst, 0.f, -153600.f, 153600.f);
+        n->start_time = (double*)malloc(sizeof(double) * n_inst);
+        n->stop_time = (double*)malloc(sizeof(double) * n_inst);
+        for (uint32_t k = 0; k < n_inst; k++) {
+          n->start_time[k] = DBL_MAX;
+          n->stop_time[k] = DBL_MAX;
+        }
+        break;
+      }
       case WAA_NODE_DELAY: { /* delay.rs:283-335 */
         if (n->desc.d[0] == 0.) n->desc.d[0] = 1.;
         if (!(n->desc.d[0] > 0. && n->desc.d[0] < 180.))
@@ -912,7 +930,7 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
     if ((int)pid >= dn->n_params) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - node %u has no param %u", to, pid);
     uint32_t kind = dn->desc.kind;
     if (!(kind == WAA_NODE_GAIN || kind == WAA_NODE_BIQUAD || kind == WAA_NODE_DELAY || kind == WAA_NODE_STEREO_PANNER ||
-          kind == WAA_NODE_CONSTANT_SOURCE))
+          kind == WAA_NODE_CONSTANT_SOURCE || kind == WAA_NODE_OSCILLATOR))
       return fail(WAA_ERR_OUT_OF_SCOPE, "audio-rate modulation of a host-evaluated param (node %u) is out of scope", to);
     for (uint32_t k = 0; k < n_inst; k++)
       if (!b->st[k][to].pin[pid]) {
@@ -971,6 +989,7 @@ void orc_batch_destroy(orc_batch* b) {
     free(n->loop_end);
     for (int c = 0; c < 4; c++) convir_free(n->conv_ir[c]);
     free(n->curve);
+    free(n->osc_wave);
   }
   free(b->nodes);
   free(b->edges);
@@ -1039,7 +1058,7 @@ waa_status orc_source_start(orc_batch* b, uint32_t node, uint32_t inst, double w
   int e;
   if (!b || node >= b->n_nodes) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node");
   uint32_t kind = b->nodes[node].desc.kind;
-  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE)
+  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE && kind != WAA_NODE_OSCILLATOR)
     return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not a scheduled source", node);
   if ((e = check_inst(b, inst))) return e;
   if (!(when >= 0.) || !(offset >= 0.) || !(duration >= 0.)) /* scheduled_source.rs assert_valid_time_value */
@@ -1060,7 +1079,7 @@ waa_status orc_source_stop(orc_batch* b, uint32_t node, uint32_t inst, double wh
   int e;
   if (!b || node >= b->n_nodes) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node");
   uint32_t kind = b->nodes[node].desc.kind;
-  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE)
+  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE && kind != WAA_NODE_OSCILLATOR)
     return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not a scheduled source", node);
   if ((e = check_inst(b, inst))) return e;
   if (!(when >= 0.)) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - timing value should be finite and positive");
@@ -1190,6 +1209,44 @@ waa_status orc_iir_set_coefficients(orc_batch* b, uint32_t node, const double* f
     n->iir_a[i] = (i < nfb ? fb[i] : 0.) / a0;
   }
   n->iir_len = (int)len;
+  return WAA_OK;
+}
+
+/* periodic_wave.rs:88-190 + oscillator.rs:318-321 */
+waa_status orc_oscillator_set_periodic_wave(orc_batch* b, uint32_t node, const float* real, const float* imag, uint32_t nn,
+                                            int32_t disable_normalization) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_OSCILLATOR))) return e;
+  if ((!real && !imag) || nn < 2) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - `real` and `imag` length should at least 2");
+  NodeCfg* n = &b->nodes[node];
+  const int size = 8192;
+  float* wavetable = (float*)malloc(sizeof(float) * size);
+  const float pi_2 = 2.f * 3.14159265358979323846f;
+  for (int i = 0; i < size; i++) {
+    float sample = 0.f;
+    float phase = pi_2 * (float)i / (float)size;
+    for (uint32_t j = 1; j < nn; j++) {
+      float freq = (float)j;
+      float re = real ? real[j] : 0.f, im = imag ? imag[j] : 0.f;
+      float rad = phase * freq;
+      float contrib = re * cosf(rad) + im * sinf(rad);
+      sample += contrib;
+    }
+    wavetable[i] = sample;
+  }
+  if (!disable_normalization) {
+    float max = 0.f;
+    for (int i = 0; i < size; i++) {
+      float a = fabsf(wavetable[i]);
+      if (a > max) max = a;
+    }
+    if (max > 0.f) {
+      float norm_factor = 1.f / max;
+      for (int i = 0; i < size; i++) wavetable[i] *= norm_factor;
+    }
+  }
+  free(n->osc_wave);
+  n->osc_wave = wavetable;
   return WAA_OK;
 }
 
@@ -1880,6 +1937,134 @@ static void process_delay_reader(NodeCfg* n, NodeState* s, uint32_t inst, const 
   s->dl_rindex = (s->dl_rindex + 1) % s->dl_cap;
 }
 
+/* src/node/oscillator.rs:323-660 */
+#define OSC_SINE_TABLE_LEN 2048
+static const float* osc_sine_table(void) { /* oscillator.rs:16-28 */
+  static float table[OSC_SINE_TABLE_LEN];
+  static int ready = 0;
+  if (!ready) {
+    const float pi = 3.14159265358979323846f;
+    for (int x = 0; x < OSC_SINE_TABLE_LEN; x++) table[x] = sinf(((float)x) * 2.0f * pi * (1.f / (float)OSC_SINE_TABLE_LEN));
+    ready = 1;
+  }
+  return table;
+}
+static double osc_unroll_phase(double phase) { /* :646-654 */
+  if (phase >= 1.) return phase - 1.;
+  if (phase < 0.) return phase + 1.;
+  return phase;
+}
+static double osc_unroll_phase_unbounded(double phase) { /* :656-659 rem_euclid(1.) */
+  double r = fmod(phase, 1.);
+  return r < 0. ? r + 1. : r;
+}
+static double osc_poly_blep(double t, double dt) { /* :630-643 (production: cfg!(test) == false) */
+  if (t < dt) {
+    t /= dt;
+    return t + t - t * t - 1.0;
+  } else if (t > 1.0 - dt) {
+    t = (t - 1.0) / dt;
+    return fma(t, t, t) + t + 1.0;
+  }
+  return 0.0;
+}
+static float osc_table_sample(const float* table, int len, double phase) { /* :571-586, :604-619 */
+  double position = phase * (double)len;
+  double floored = floor(position);
+  int prev_index = (int)floored;
+  int next_index = prev_index + 1;
+  if (next_index == len) next_index = 0;
+  float k = (float)(position - floored);
+  return fmaf(table[prev_index], 1.f - k, table[next_index] * k);
+}
+static float osc_waveform_sample(const NodeCfg* n, double phase, double phase_incr) { /* :561-602 */
+  switch (n->osc_wave ? WAA_OSC_CUSTOM : n->desc.i[0]) {
+    case WAA_OSC_SINE: return osc_table_sample(osc_sine_table(), OSC_SINE_TABLE_LEN, phase);
+    case WAA_OSC_SAWTOOTH: {
+      double ph = osc_unroll_phase(phase + 0.5);
+      double sample = 2.0 * ph - 1.0;
+      sample -= osc_poly_blep(ph, phase_incr);
+      return (float)sample;
+    }
+    case WAA_OSC_SQUARE: {
+      double sample = phase < 0.5 ? 1.0 : -1.0;
+      sample += osc_poly_blep(phase, phase_incr);
+      double shift_phase = osc_unroll_phase(phase + 0.5);
+      sample -= osc_poly_blep(shift_phase, phase_incr);
+      return (float)sample;
+    }
+    case WAA_OSC_TRIANGLE: {
+      double sample = -4. * phase + 2.;
+      if (sample > 1.)
+        sample = 2. - sample;
+      else if (sample < -1.)
+        sample = -2. - sample;
+      return (float)sample;
+    }
+    default: return osc_table_sample(n->osc_wave, 8192, phase);
+  }
+}
+/* generate_sample, :505-553 */
+static double osc_generate_sample(const NodeCfg* n, NodeState* s, float* output, int outside_nyquist, double phase_incr,
+                                  double current_time, double dt) {
+  if (current_time < s->start_time || current_time >= s->stop_time) {
+    *output = 0.f;
+    return current_time + dt;
+  }
+  if (!s->osc_started) {
+    if (current_time > s->start_time) {
+      double ratio = (current_time - s->start_time) / dt;
+      s->osc_phase = outside_nyquist ? osc_unroll_phase_unbounded(phase_incr * ratio) : osc_unroll_phase(phase_incr * ratio);
+    }
+    s->osc_started = 1;
+  }
+  *output = outside_nyquist ? 0.f : osc_waveform_sample(n, s->osc_phase, phase_incr);
+  s->osc_phase = outside_nyquist ? osc_unroll_phase_unbounded(s->osc_phase + phase_incr) : osc_unroll_phase(s->osc_phase + phase_incr);
+  return current_time + dt;
+}
+static void process_oscillator(NodeCfg* n, NodeState* s, uint32_t inst, const Scope* sc) {
+  Quantum* output = &s->out;
+  q_make_silent(output); /* 1 channel */
+  double sample_rate = (double)sc->sample_rate;
+  double dt = 1. / sample_rate;
+  double next_block_time = sc->current_time + dt * (double)RQ;
+  if (s->stop_time <= sc->current_time) return;
+  if (s->start_time >= next_block_time) return;
+  float tf[RQ], td[RQ];
+  int lf, ld;
+  const float* frequency_values = param_get_in(&n->params[WAA_PARAM_OSCILLATOR_FREQUENCY], s->pin[WAA_PARAM_OSCILLATOR_FREQUENCY],
+                                               inst, sc->quantum, &lf, tf);
+  const float* detune_values = param_get_in(&n->params[WAA_PARAM_OSCILLATOR_DETUNE], s->pin[WAA_PARAM_OSCILLATOR_DETUNE], inst,
+                                            sc->quantum, &ld, td);
+  double current_time = sc->current_time;
+  if (!s->osc_started && s->start_time < current_time) s->start_time = current_time;
+  double nyquist = sample_rate / 2.;
+  float* channel_data = output->d[0];
+  output->silent[0] = 0;
+  if (lf == 1 && ld == 1) {
+    double computed_freq = (double)frequency_values[0] * exp2((double)detune_values[0] / 1200.);
+    double phase_incr = computed_freq / sample_rate;
+    int outside_nyquist = fabs(computed_freq) >= nyquist;
+    int fully_active = s->osc_started && s->start_time <= sc->current_time && s->stop_time >= next_block_time;
+    if (fully_active && !outside_nyquist) {
+      for (int i = 0; i < RQ; i++) {
+        channel_data[i] = osc_waveform_sample(n, s->osc_phase, phase_incr);
+        s->osc_phase = osc_unroll_phase(s->osc_phase + phase_incr);
+      }
+    } else {
+      for (int i = 0; i < RQ; i++)
+        current_time = osc_generate_sample(n, s, &channel_data[i], outside_nyquist, phase_incr, current_time, dt);
+    }
+  } else {
+    for (int i = 0; i < RQ; i++) {
+      double computed_freq = (double)frequency_values[i % lf] * exp2((double)detune_values[i % ld] / 1200.);
+      double phase_incr = computed_freq / sample_rate;
+      int outside_nyquist = fabs(computed_freq) >= nyquist;
+      current_time = osc_generate_sample(n, s, &channel_data[i], outside_nyquist, phase_incr, current_time, dt);
+    }
+  }
+}
+
 /* src/node/gain.rs:143-199 */
 static void process_gain(NodeCfg* n, NodeState* s, uint32_t inst, const Scope* sc) {
   const Quantum* input = &s->in;
@@ -2278,6 +2463,7 @@ static void process_node(orc_batch* b, uint32_t id, uint32_t inst, const Scope* 
     case WAA_NODE_DESTINATION: q_copy(&s->out, &s->in); break; /* destination.rs:142-158 */
     case WAA_NODE_BUFFER_SOURCE: process_buffer_source(b, n, s, inst, sc); break;
     case WAA_NODE_CONSTANT_SOURCE: process_constant_source(n, s, inst, sc); break;
+    case WAA_NODE_OSCILLATOR: process_oscillator(n, s, inst, sc); break;
     case WAA_NODE_BIQUAD: process_biquad(n, s, inst, sc); break;
     case WAA_NODE_IIR_FILTER: process_iir(n, s); break;
     case WAA_NODE_GAIN: process_gain(n, s, inst, sc); break;

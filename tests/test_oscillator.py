@@ -1,0 +1,218 @@
+"""OscillatorNode: the reference's tests re-typed (src/node/oscillator.rs:700-1460,
+src/periodic_wave.rs:213-320) on both backends plus GPU-vs-oracle parity.  Note: the reference disables polyBLEP
+under cfg!(test) (oscillator.rs:626-632); the restatement is the PRODUCTION code (polyBLEP on), so the crude
+square/sawtooth comparisons of the reference's test build are replaced by the polyBLEP formula itself."""
+import numpy as np
+import pytest
+
+import web_audio_api_rs_amd as waa
+from graphs import rms_err, white_noise
+
+RQ = 128
+
+
+def render_osc(be, sr, length, freq, type_="sine", start=0.0, stop=None, detune=0.0, wave=None):
+    c = waa.OfflineAudioContext(1, length, float(sr), binding=be)
+    kw = dict(type_=type_, frequency=freq, detune=detune)
+    if wave is not None:
+        kw = dict(frequency=freq, detune=detune, periodic_wave=wave)
+    osc = c.create_oscillator(**kw)
+    osc.connect(c.destination())
+    osc.start_at(start)
+    if stop is not None:
+        osc.stop_at(stop)
+    return c.start_rendering_sync().data[0, 0]
+
+
+def ref_phase_sine(n, freq, sr, phase0=0.0, first=0):
+    out = np.zeros(n, np.float32)
+    phase, incr = phase0, float(np.float32(freq)) / float(sr)
+    for i in range(first, n):
+        out[i] = np.float32(np.sin(phase * 2.0 * np.pi))
+        phase += incr
+        if phase >= 1.0:
+            phase -= 1.0
+    return out
+
+
+@pytest.mark.parametrize("exp", range(5))
+def test_sine_raw(be, exp):
+    """oscillator.rs:806-840: 1 .. 10 kHz for one second, abs_all <= 1e-5 (8192 frames here)"""
+    freq, sr, n = 10.0 ** exp, 44100, 8192
+    out = render_osc(be, sr, n, freq)
+    assert np.max(np.abs(out - ref_phase_sine(n, freq, sr))) <= 1e-5
+
+
+def test_sine_negative_frequency(be):
+    """oscillator.rs:1430-1455"""
+    sr, n, freq = 44100, 4096, -440.0
+    out = render_osc(be, sr, n, freq)
+    i = np.arange(n)
+    exp = np.sin(2 * np.pi * freq * i / sr).astype(np.float32)
+    assert np.max(np.abs(out - exp)) <= 1e-4
+
+
+def test_triangle_raw(be):
+    """oscillator.rs:909-953: abs_all <= 1e-10"""
+    sr, n, freq = 44100, 4096, 100.0
+    out = render_osc(be, sr, n, freq, type_="triangle")
+    exp = np.zeros(n, np.float32)
+    phase, incr = 0.0, float(np.float32(freq)) / sr
+    for i in range(n):
+        s = -4.0 * phase + 2.0
+        if s > 1.0:
+            s = 2.0 - s
+        elif s < -1.0:
+            s = -2.0 - s
+        exp[i] = np.float32(s)
+        phase += incr
+        if phase >= 1.0:
+            phase -= 1.0
+    assert np.max(np.abs(out - exp)) <= 1e-10
+
+
+def poly_blep(t, dt):
+    """oscillator.rs:626-643"""
+    if t < dt:
+        t /= dt
+        return t + t - t * t - 1.0
+    if t > 1.0 - dt:
+        t = (t - 1.0) / dt
+        return t * t + t + t + 1.0
+    return 0.0
+
+
+@pytest.mark.parametrize("type_", ["square", "sawtooth"])
+def test_square_and_sawtooth_with_polyblep(be, type_):
+    """oscillator.rs:588-602 (production arithmetic; the polyBLEP term itself is pinned by :1095-1132)"""
+    sr, n, freq = 44100, 4096, 441.0
+    out = render_osc(be, sr, n, freq, type_=type_)
+    exp = np.zeros(n, np.float32)
+    phase, incr = 0.0, float(np.float32(freq)) / sr
+    unroll = lambda p: p - 1.0 if p >= 1.0 else (p + 1.0 if p < 0.0 else p)
+    for i in range(n):
+        if type_ == "square":
+            s = (1.0 if phase < 0.5 else -1.0) + poly_blep(phase, incr) - poly_blep(unroll(phase + 0.5), incr)
+        else:
+            ph = unroll(phase + 0.5)
+            s = 2.0 * ph - 1.0 - poly_blep(ph, incr)
+        exp[i] = np.float32(s)
+        phase = unroll(phase + incr)
+    assert np.max(np.abs(out - exp)) <= 1e-6
+
+
+def test_polyblep_isolated(orc_lib):
+    """oscillator.rs:1095-1132 is a unit test of poly_blep; covered through the rendered waveforms above"""
+    assert poly_blep(0.0, 0.01) == -1.0 and poly_blep(0.5, 0.01) == 0.0
+
+
+@pytest.mark.parametrize("harmonics", [1, 2])
+def test_periodic_wave(be, harmonics):
+    """oscillator.rs:1001-1092: custom wave = sine (+ 0.5 second harmonic), normalised; abs_all <= 1e-5"""
+    sr, n, freq = 44100, 4096, 100.0
+    real = [0.0] * (harmonics + 1)
+    imag = [0.0, 1.0] + ([0.5] if harmonics == 2 else [])
+    out = render_osc(be, sr, n, freq, wave=waa.PeriodicWave(real=real, imag=imag))
+    i = np.arange(8192, dtype=np.float64)
+    table = np.sin(2 * np.pi * i / 8192) + (0.5 * np.sin(4 * np.pi * i / 8192) if harmonics == 2 else 0.0)
+    norm = 1.0 / np.abs(table).max()
+    phase, incr = 0.0, float(np.float32(freq)) / sr
+    exp = np.zeros(n, np.float32)
+    for k in range(n):
+        exp[k] = np.float32(norm * (np.sin(phase * 2 * np.pi) + (0.5 * np.sin(phase * 4 * np.pi) if harmonics == 2 else 0.0)))
+        phase += incr
+        if phase >= 1.0:
+            phase -= 1.0
+    assert np.max(np.abs(out - exp)) <= 1e-4  # 8192-point table, linear interpolation (reference: 1e-5 at lower freq)
+
+
+def test_periodic_wave_validation(be):
+    """periodic_wave.rs:104-139"""
+    with pytest.raises(waa.WaaError, match="IndexSizeError"):
+        waa.PeriodicWave(real=[0.0], imag=[0.0])
+    with pytest.raises(waa.WaaError, match="IndexSizeError"):
+        waa.PeriodicWave(real=[0.0, 1.0], imag=[0.0, 1.0, 0.5])
+    c = waa.OfflineAudioContext(1, RQ, 44100.0, binding=be)
+    osc = c.create_oscillator()
+    with pytest.raises(waa.WaaError, match="InvalidStateError"):
+        osc.set_type("custom")  # oscillator.rs:305-309
+    osc.set_periodic_wave(waa.PeriodicWave())
+    osc.set_type("square")      # ignored, oscillator.rs:770-797
+    assert osc.type_ == "custom"
+
+
+def test_sub_quantum_and_sub_sample_start(be):
+    """oscillator.rs:1135-1197"""
+    sr = 44100
+    out = render_osc(be, sr, 4096, 1.25, start=2.0 / sr)
+    assert np.max(np.abs(out - ref_phase_sine(4096, 1.25, sr, first=2))) <= 1e-5
+    sr = 96000
+    out = render_osc(be, sr, 4096, 1.0, start=1.3 / sr)
+    incr = 1.0 / sr
+    assert out[0] == 0.0 and out[1] == 0.0
+    assert np.max(np.abs(out - ref_phase_sine(4096, 1.0, sr, phase0=0.7 * incr, first=2))) <= 1e-5
+
+
+def test_sub_quantum_stop_and_disarm(be):
+    """oscillator.rs:1199-1246"""
+    sr = 44100
+    out = render_osc(be, sr, 1024, 2345.6, stop=6.0 / sr)
+    exp = ref_phase_sine(1024, 2345.6, sr)
+    exp[6:] = 0.0
+    assert np.max(np.abs(out - exp)) <= 1e-5
+    out = render_osc(be, sr, 128, 440.0, start=1.0, stop=0.5)  # stop before start: silence
+    assert np.array_equal(out, np.zeros(128, np.float32))
+
+
+def test_start_in_the_past_is_now(be):
+    """oscillator.rs:1310-1342 (start_at(0) is the same thing offline); delayed start :1409-1428"""
+    sr = 48000
+    out = render_osc(be, sr, RQ * 3, 440.0, start=RQ / sr)
+    exp = np.zeros(RQ * 3, np.float32)
+    exp[RQ:] = ref_phase_sine(RQ * 2, 440.0, sr)
+    assert np.max(np.abs(out - exp)) <= 1e-5
+
+
+@pytest.mark.parametrize("freq", [30000.0, -30000.0])
+def test_outside_nyquist_is_silent(be, freq):
+    """oscillator.rs:1344-1382: the param clamps to +-nyquist, at which the oscillator outputs zero"""
+    out = render_osc(be, 44100, 128, freq)
+    assert np.max(np.abs(out)) <= 1e-5
+
+
+# --------------------------------------------------------------------------- GPU parity
+def _fm_patch(binding, n, frames):
+    """two-operator FM: modulator oscillator -> gain (index) -> carrier.frequency; detuned per instance; envelope"""
+    c = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n, binding=binding)
+    mod = c.create_oscillator(type_="sine", frequency=110.0)
+    idx = c.create_gain(gain=300.0)
+    car = c.create_oscillator(type_="sine", frequency=440.0)
+    sq = c.create_oscillator(type_="square", frequency=55.0)
+    saw = c.create_oscillator(type_="sawtooth", frequency=82.4)
+    tri = c.create_oscillator(type_="triangle", frequency=220.0, detune=700.0)
+    for i in range(n):
+        car.detune.set_value(25.0 * i, instance=i)
+        mod.frequency.set_value(110.0 + 7.0 * i, instance=i)
+    mix = c.create_gain(gain=0.2)
+    pan = c.create_stereo_panner(pan=0.25)
+    mod.connect(idx).connect(car.frequency)
+    for o in (car, sq, saw, tri):
+        o.connect(mix)
+    mix.connect(pan).connect(c.destination())
+    mod.start()
+    car.start_at(0.001)
+    sq.start()
+    saw.start_at(300.5 / 48000.0)
+    saw.stop_at(0.05)
+    tri.start()
+    out = c.start_rendering_sync().data
+    c.close()
+    return out
+
+
+@pytest.mark.gpu
+def test_parity_fm_patch(hip, orc):
+    n, frames = 5, 2048 * 2 + 99
+    g, o = _fm_patch(hip, n, frames), _fm_patch(orc, n, frames)
+    assert rms_err(g, o).max() <= 1e-6
+    assert np.abs(g - o).max() <= 5e-6

@@ -38,6 +38,8 @@ NODE_DESTINATION, NODE_BUFFER_SOURCE, NODE_BIQUAD, NODE_GAIN, NODE_CONVOLVER = 0
 NODE_STEREO_PANNER, NODE_PANNER, NODE_ANALYSER, NODE_WAVESHAPER, NODE_CONSTANT_SOURCE = 5, 6, 7, 8, 9
 NODE_IIR_FILTER = 10
 NODE_DELAY = 11
+NODE_OSCILLATOR = 12
+OSCILLATOR_TYPE = {"sine": 0, "square": 1, "sawtooth": 2, "triangle": 3, "custom": 4}
 MAX_IIR_COEFFS = 20
 PARAM_INPUT = 0x80000000  # WAA_PARAM_INPUT(param): edge into an AudioParam of the target node
 COUNT_MODE = {"max": 0, "clamped-max": 1, "explicit": 2}
@@ -91,6 +93,7 @@ ABI = {
     "source_set_loop": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_int32, C.c_double, C.c_double]),
     "convolver_set_buffer": (C.c_int32, [_VP, C.c_uint32, _FPP, C.c_uint32, C.c_uint64, C.c_float]),
     "waveshaper_set_curve": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32]),
+    "oscillator_set_periodic_wave": (C.c_int32, [_VP, C.c_uint32, _FP, _FP, C.c_uint32, C.c_int32]),
     "iir_set_coefficients": (C.c_int32, [_VP, C.c_uint32, _DP, C.c_uint32, _DP, C.c_uint32]),
     "iir_frequency_response": (C.c_int32, [_DP, C.c_uint32, _DP, C.c_uint32, C.c_float, _FP, _FP, _FP, C.c_uint32]),
     "set_param_const": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
@@ -433,6 +436,65 @@ class ConstantSourceNode(_ScheduledSource):
         super().__init__(ctx, **kw)
         self.offset = AudioParam(self, 0, offset)
         self.params = [self.offset]
+
+
+class PeriodicWave:
+    """src/periodic_wave.rs:35-190: PeriodicWaveOptions{real, imag, disable_normalization}; the 8192-point table is
+    generated by the library when the wave is set on an oscillator."""
+
+    def __init__(self, ctx=None, real=None, imag=None, disable_normalization: bool = False):
+        if real is None and imag is None:  # defaults to a sine wave (periodic_wave.rs:140-143)
+            real, imag = [0.0, 0.0], [0.0, 1.0]
+        r = None if real is None else _f32(real).reshape(-1)
+        i = None if imag is None else _f32(imag).reshape(-1)
+        if r is not None and i is not None and r.size != i.size:
+            raise WaaError(1, "IndexSizeError - `real` and `imag` length should be equal")
+        n = (r if r is not None else i).size
+        if n < 2:
+            raise WaaError(1, "IndexSizeError - `real` and `imag` length should at least 2")
+        self.real = r if r is not None else np.zeros(n, np.float32)
+        self.imag = i if i is not None else np.zeros(n, np.float32)
+        self.disable_normalization = bool(disable_normalization)
+
+
+class OscillatorNode(_ScheduledSource):
+    """src/node/oscillator.rs:64-321 (OscillatorOptions{type = sine, frequency = 440, detune = 0, periodic_wave})"""
+
+    kind = NODE_OSCILLATOR
+
+    def __init__(self, ctx, type_="sine", frequency=440.0, detune=0.0, periodic_wave=None, **kw):
+        super().__init__(ctx, **kw)
+        if type_ == "custom" and periodic_wave is None:
+            raise WaaError(3, "InvalidStateError: Custom type cannot be set manually")
+        self.type_ = type_
+        self.frequency = AudioParam(self, 0, frequency)
+        self.detune = AudioParam(self, 1, detune)
+        self.params = [self.frequency, self.detune]
+        self.periodic_wave = None
+        if periodic_wave is not None:
+            self.set_periodic_wave(periodic_wave)
+
+    def set_type(self, type_: str):
+        if type_ == "custom":  # oscillator.rs:305-309
+            raise WaaError(3, "InvalidStateError: Custom type cannot be set manually")
+        if self.type_ == "custom":  # ignored once a periodic wave is set (oscillator.rs:311-314)
+            return
+        self.type_ = type_
+
+    def set_periodic_wave(self, wave: PeriodicWave):
+        self.type_ = "custom"
+        self.periodic_wave = wave
+
+    def _fill_desc(self, d):
+        d.i[0] = OSCILLATOR_TYPE[self.type_]
+
+    def _apply(self, ctx):
+        super()._apply(ctx)
+        if self.periodic_wave is not None:
+            w = self.periodic_wave
+            b, h = ctx._b, ctx._handle
+            b.check(b.oscillator_set_periodic_wave(h, self.id, _fp(w.real), _fp(w.imag), w.real.size,
+                                                   int(w.disable_normalization)))
 
 
 class BiquadFilterNode(AudioNode):
@@ -786,6 +848,12 @@ class OfflineAudioContext:
 
     def create_wave_shaper(self, **kw):
         return WaveShaperNode(self, **kw)
+
+    def create_oscillator(self, **kw):
+        return OscillatorNode(self, **kw)
+
+    def create_periodic_wave(self, **kw):
+        return PeriodicWave(self, **kw)
 
     def create_delay(self, max_delay_time: float = 1.0, **kw):
         return DelayNode(self, max_delay_time=max_delay_time, **kw)

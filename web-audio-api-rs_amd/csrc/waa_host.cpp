@@ -106,6 +106,8 @@ struct Node {
   std::vector<float> curve;
   bool has_curve = false;
   float* d_curve = nullptr;
+  // oscillator: custom PeriodicWave table (8192 points, periodic_wave.rs:76)
+  std::vector<float> osc_wave;
   // iir filter: normalised coefficient pairs (iir_filter.rs:273-311)
   std::vector<double> iir_b, iir_a;
   // analyser (control side state)
@@ -141,7 +143,7 @@ struct ProfileEntry {
 };
 
 struct Step {
-  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop
+  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator
   ChainDesc chain{};
   BiquadStreamDesc bq{};
   ConvDesc conv{};
@@ -149,6 +151,7 @@ struct Step {
   IirStreamDesc iir{};
   DelayDesc delay{};
   LoopDesc loop{};
+  OscDesc osc{};
   int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
   void* zero_ptr = nullptr;
   size_t zero_bytes = 0;
@@ -1017,6 +1020,7 @@ void vertex_targets(const waa_batch* b, uint32_t v, const std::vector<uint8_t>& 
 
 int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items);
 int plan_delay_writer(waa_batch* b, uint32_t id);
+int plan_oscillator(waa_batch* b, uint32_t id);
 int plan_delay_reader(waa_batch* b, uint32_t id);
 uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items);
 
@@ -1134,7 +1138,7 @@ int build_plan(waa_batch* b) {
       if (pid >= to.params.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - node %u has no param %u", ed.to, pid);
       const uint32_t k = to.desc.kind;
       if (!(k == WAA_NODE_GAIN || k == WAA_NODE_BIQUAD || k == WAA_NODE_DELAY || k == WAA_NODE_STEREO_PANNER ||
-            k == WAA_NODE_CONSTANT_SOURCE))
+            k == WAA_NODE_CONSTANT_SOURCE || k == WAA_NODE_OSCILLATOR))
         return fail(WAA_ERR_OUT_OF_SCOPE, "audio-rate modulation of a host-evaluated param (node %u) is out of scope", ed.to);
       to.pin_edges[pid].push_back((int)e);
     } else {
@@ -1187,7 +1191,8 @@ int build_plan(waa_batch* b) {
         n.out_nch = nch ? (int)nch : 1;
         break;
       }
-      case WAA_NODE_CONSTANT_SOURCE: n.out_nch = 1; break;
+      case WAA_NODE_CONSTANT_SOURCE:
+      case WAA_NODE_OSCILLATOR: n.out_nch = 1; break;
       case WAA_NODE_STEREO_PANNER:
       case WAA_NODE_PANNER: n.out_nch = 2; break;
       case WAA_NODE_CONVOLVER:
@@ -1213,6 +1218,7 @@ int build_plan(waa_batch* b) {
     const uint32_t kind = n.desc.kind;
     if (kind == WAA_NODE_DESTINATION || kind == WAA_NODE_ANALYSER || kind == WAA_NODE_CONVOLVER || kind == WAA_NODE_DELAY) mat = true;
     if (scc_of[id] >= 0) mat = true;  // loop members publish their own signal
+    if (kind == WAA_NODE_OSCILLATOR) mat = true;  // rendered by its own (lane-per-instance) kernel
     int live_consumers = 0;
     for (auto& e : b->edges)
       if (e.from == id && b->nodes[e.to].live) {
@@ -1278,6 +1284,11 @@ int build_plan(waa_batch* b) {
       if (e) return e;
       if ((e = plan_convolver(b, id))) return e;
       return 0;
+    }
+    if (term.desc.kind == WAA_NODE_OSCILLATOR) {
+      int e = alloc_signal(term);
+      if (e) return e;
+      return plan_oscillator(b, id);
     }
     if (term.desc.kind == WAA_NODE_DELAY) {  // outside a loop: writer and reader halves back to back
       int e = alloc_signal(term);
@@ -1636,6 +1647,55 @@ int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const Signa
   }
   if ((e = push_chain_step(b, ins, n.in_nch, n.interp, {}, in_sig))) return e;
   *out_sig = in_sig;
+  return 0;
+}
+
+// OscillatorNode (oscillator.rs:323-660): one kernel, one lane per instance (the phase accumulator is serial)
+int plan_oscillator(waa_batch* b, uint32_t id) {
+  Node& n = b->nodes[id];
+  Step st;
+  st.kind = 9;
+  OscDesc& d = st.osc;
+  std::memset(&d, 0, sizeof d);
+  int e;
+  if ((e = node_param(b, id, WAA_PARAM_OSCILLATOR_FREQUENCY, &d.frequency)) ||
+      (e = node_param(b, id, WAA_PARAM_OSCILLATOR_DETUNE, &d.detune)))
+    return e;
+  std::vector<double> start(b->n_inst), stop(b->n_inst);
+  for (uint32_t i = 0; i < b->n_inst; i++) {
+    start[i] = n.sched[i].start;
+    stop[i] = n.sched[i].stop;
+  }
+  double *d_start = nullptr, *d_stop = nullptr;
+  if ((e = dev_upload(b, &d_start, start)) || (e = dev_upload(b, &d_stop, stop))) return e;
+  d.start = d_start;
+  d.stop = d_stop;
+  d.type = n.osc_wave.empty() ? n.desc.i[0] : WAA_OSC_CUSTOM;
+  if (d.type == WAA_OSC_CUSTOM && n.osc_wave.empty())
+    return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - custom oscillator %u has no PeriodicWave", id);
+  std::vector<float> table;
+  if (d.type == WAA_OSC_CUSTOM) {
+    table = n.osc_wave;
+  } else {  // oscillator.rs:16-28 (same libm sinf as the reference's f32::sin)
+    table.resize(2048);
+    const float pi = 3.14159265358979323846f;
+    for (int x = 0; x < 2048; x++) table[x] = std::sin(((float)x) * 2.0f * pi * (1.f / 2048.f));
+  }
+  float* d_table = nullptr;
+  if ((e = dev_upload(b, &d_table, table))) return e;
+  d.table = d_table;
+  d.table_len = (int32_t)table.size();
+  d.out = n.sig;
+  d.frames = b->lp;
+  d.n_inst = b->n_inst;
+  d.n_quanta = b->n_quanta;
+  d.sample_rate = (double)b->sr;
+  st.profile_slot = slot_for(b, "osc_kernel");
+  b->steps.push_back(st);
+  static const char* names[] = {"sine", "square", "sawtooth", "triangle", "custom"};
+  plan_note(b, "oscillator node %u: %s frequency=%s detune=%s", id, names[d.type],
+            d.frequency.mode == 0 ? "const" : d.frequency.mode == 1 ? "k-rate" : "a-rate",
+            d.detune.mode == 0 ? "const" : d.detune.mode == 1 ? "k-rate" : "a-rate");
   return 0;
 }
 
@@ -2328,6 +2388,12 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
         P(0).init(n_inst, 1.f, -FLT_MAX, FLT_MAX);
         n.sched.resize(n_inst);
         break;
+      case WAA_NODE_OSCILLATOR:  // oscillator.rs:210-262
+        if (n.desc.i[0] < WAA_OSC_SINE || n.desc.i[0] > WAA_OSC_CUSTOM) return fail(WAA_ERR_INVALID_ARGUMENT, "bad oscillator type");
+        P(WAA_PARAM_OSCILLATOR_FREQUENCY).init(n_inst, 440.f, -sr / 2.f, sr / 2.f);
+        P(WAA_PARAM_OSCILLATOR_DETUNE).init(n_inst, 0.f, -153600.f, 153600.f);
+        n.sched.resize(n_inst);
+        break;
       case WAA_NODE_STEREO_PANNER:
         P(0).init(n_inst, 0.f, -1.f, 1.f);
         if (n.mode == WAA_COUNT_MODE_MAX)
@@ -2510,7 +2576,7 @@ waa_status waa_source_start(waa_batch* b, uint32_t node, uint32_t inst, double w
   int e;
   if (!b || node >= b->nodes.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node");
   const uint32_t kind = b->nodes[node].desc.kind;
-  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE)
+  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE && kind != WAA_NODE_OSCILLATOR)
     return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not a scheduled source", node);
   if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
   if (!std::isfinite(when) || !std::isfinite(offset) || !std::isfinite(duration))
@@ -2534,7 +2600,7 @@ waa_status waa_source_stop(waa_batch* b, uint32_t node, uint32_t inst, double wh
   int e;
   if (!b || node >= b->nodes.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node");
   const uint32_t kind = b->nodes[node].desc.kind;
-  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE)
+  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE && kind != WAA_NODE_OSCILLATOR)
     return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not a scheduled source", node);
   if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
   if (!std::isfinite(when)) return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided time value is non-finite.");
@@ -2606,6 +2672,39 @@ waa_status waa_waveshaper_set_curve(waa_batch* b, uint32_t node, const float* cu
   if (n.has_curve) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - cannot assign curve twice");
   n.curve.assign(curve, curve + nn);
   n.has_curve = true;
+  return WAA_OK;
+}
+
+// periodic_wave.rs:88-190 + oscillator.rs:318-321 (control side: the wavetable is generated on the host)
+waa_status waa_oscillator_set_periodic_wave(waa_batch* b, uint32_t node, const float* real, const float* imag, uint32_t nn,
+                                            int32_t disable_normalization) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_OSCILLATOR)) || (e = check_unplanned(b))) return e;
+  if ((!real && !imag) || nn < 2) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - `real` and `imag` length should at least 2");
+  const int size = 8192;
+  std::vector<float> wavetable(size);
+  const float pi_2 = 2.f * 3.14159265358979323846f;
+  for (int i = 0; i < size; i++) {
+    float sample = 0.f;
+    const float phase = pi_2 * (float)i / (float)size;
+    for (uint32_t j = 1; j < nn; j++) {
+      const float freq = (float)j;
+      const float re = real ? real[j] : 0.f, im = imag ? imag[j] : 0.f;
+      const float rad = phase * freq;
+      const float contrib = re * std::cos(rad) + im * std::sin(rad);
+      sample += contrib;
+    }
+    wavetable[i] = sample;
+  }
+  if (!disable_normalization) {
+    float max = 0.f;
+    for (float v : wavetable) max = std::fabs(v) > max ? std::fabs(v) : max;
+    if (max > 0.f) {
+      const float norm_factor = 1.f / max;
+      for (float& v : wavetable) v *= norm_factor;
+    }
+  }
+  b->nodes[node].osc_wave.swap(wavetable);
   return WAA_OK;
 }
 
@@ -2753,6 +2852,7 @@ waa_status waa_render(waa_batch* b) {
         break;
       }
       case 8: e = timed(st.profile_slot, [&] { launch_loop(st.loop, b->stream); }); break;
+      case 9: e = timed(st.profile_slot, [&] { launch_osc(st.osc, b->stream); }); break;
       default: {
         ChainDesc d = st.chain;
         d.tile0 = t0;

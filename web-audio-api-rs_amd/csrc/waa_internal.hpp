@@ -226,6 +226,22 @@ struct DelayDesc {
 };
 void launch_delay(const DelayDesc& d, void* stream);
 
+// ---- OscillatorNode (oscillator.rs:323-660): one lane per instance, frames in order ----------------
+struct OscDesc {
+  ParamRef frequency, detune;
+  const double* start;   // [n_inst] start_time (DBL_MAX = never started)
+  const double* stop;    // [n_inst]
+  const float* table;    // sine (2048 points) or the custom PeriodicWave (8192 points)
+  int32_t table_len;
+  int32_t type;          // WAA_OSC_*; sine and custom read `table`
+  SignalRef out;         // 1 channel
+  uint64_t frames;       // padded frames
+  uint32_t n_inst;
+  uint32_t n_quanta;
+  double sample_rate;
+};
+void launch_osc(const OscDesc& d, void* stream);
+
 // ---- feedback loops (graph.rs:323-487 cycle breaker): quantum-serial rendering of a strongly connected group ----
 // The members of a loop are rendered render quantum by render quantum, in the reference's processing order, by
 // one wavefront per instance; every member writes its own output signal.  A DelayNode contributes two items

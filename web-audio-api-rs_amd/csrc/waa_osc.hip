@@ -1,0 +1,162 @@
+// waa_osc.hip — OscillatorNode (src/node/oscillator.rs:323-660) as an on-device source.
+// The oscillator is a serial f64 phase accumulator with a conditional wrap per sample (`unroll_phase`), so its
+// samples cannot be produced out of order without changing the rounding.  One LANE renders one instance, frame
+// after frame, with the reference's arithmetic (table interpolation in f32 with mul_add, polyBLEP in f64,
+// computed frequency in f64); 1024 contexts are 16 wavefronts.  Frequency and detune come as ParamRefs, so
+// automation blocks and audio-rate modulation from the graph (FM) are the same code path.
+// Latency-bound (about 100 cycles per frame and lane); stores are packed to 16 B per lane.
+#include <hip/hip_runtime.h>
+
+#include "waa_internal.hpp"
+
+namespace waa {
+
+namespace {
+__device__ __forceinline__ double unroll_phase(double phase) {  // oscillator.rs:646-654
+  if (phase >= 1.) return phase - 1.;
+  if (phase < 0.) return phase + 1.;
+  return phase;
+}
+__device__ __forceinline__ double unroll_phase_unbounded(double phase) {  // rem_euclid(1.), :656-659
+  const double r = fmod(phase, 1.);
+  return r < 0. ? r + 1. : r;
+}
+__device__ __forceinline__ double poly_blep(double t, double dt) {  // :626-643 (production path)
+  if (t < dt) {
+    t /= dt;
+    return t + t - t * t - 1.0;
+  } else if (t > 1.0 - dt) {
+    t = (t - 1.0) / dt;
+    return __builtin_fma(t, t, t) + t + 1.0;
+  }
+  return 0.0;
+}
+__device__ __forceinline__ float table_sample(const float* table, int len, double phase) {  // :571-586, :604-619
+  const double position = phase * (double)len;
+  const double floored = floor(position);
+  const int prev_index = (int)floored;
+  int next_index = prev_index + 1;
+  if (next_index == len) next_index = 0;
+  const float k = (float)(position - floored);
+  return __builtin_fmaf(table[prev_index], 1.f - k, table[next_index] * k);
+}
+__device__ __forceinline__ float waveform_sample(const OscDesc& d, double phase, double phase_incr) {  // :561-602
+  switch (d.type) {
+    case 1: {  // square
+      double sample = phase < 0.5 ? 1.0 : -1.0;
+      sample += poly_blep(phase, phase_incr);
+      sample -= poly_blep(unroll_phase(phase + 0.5), phase_incr);
+      return (float)sample;
+    }
+    case 2: {  // sawtooth
+      const double ph = unroll_phase(phase + 0.5);
+      double sample = 2.0 * ph - 1.0;
+      sample -= poly_blep(ph, phase_incr);
+      return (float)sample;
+    }
+    case 3: {  // triangle
+      double sample = -4. * phase + 2.;
+      if (sample > 1.)
+        sample = 2. - sample;
+      else if (sample < -1.)
+        sample = -2. - sample;
+      return (float)sample;
+    }
+    default: return table_sample(d.table, d.table_len, phase);  // sine (2048) or custom (8192)
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void osc_kernel(const OscDesc d) {
+  const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
+  if (inst >= d.n_inst) return;
+  __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);
+  float* out = d.out.base + (uint64_t)inst * d.out.inst_stride;
+  double start_time = d.start[inst];
+  const double stop_time = d.stop[inst];
+  const double sample_rate = d.sample_rate, dt = 1. / sample_rate, nyquist = sample_rate / 2.;
+  double phase = 0.;
+  bool started = false;
+  const bool per_frame = d.frequency.mode == 2 || d.detune.mode == 2;
+  for (uint32_t q = 0; q < d.n_quanta; q++) {
+    const uint64_t f0 = (uint64_t)q * RQ;
+    const double block_time = (double)f0 / sample_rate;
+    const double next_block_time = block_time + dt * (double)RQ;
+    float4* o4 = reinterpret_cast<float4*>(out + f0);
+    if (stop_time <= block_time || start_time >= next_block_time) {  // :349-375
+      for (int j = 0; j < RQ / 4; j++) o4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    double current_time = block_time;
+    if (!started && start_time < current_time) start_time = current_time;  // :386-393
+    // the per-sample body of generate_sample, :505-553
+    auto generate = [&](bool outside_nyquist, double phase_incr) __attribute__((always_inline)) -> float {
+      float v = 0.f;
+      if (!(current_time < start_time || current_time >= stop_time)) {
+        if (!started) {
+          if (current_time > start_time) {
+            const double ratio = (current_time - start_time) / dt;
+            phase = outside_nyquist ? unroll_phase_unbounded(phase_incr * ratio) : unroll_phase(phase_incr * ratio);
+          }
+          started = true;
+        }
+        v = outside_nyquist ? 0.f : waveform_sample(d, phase, phase_incr);
+        phase = outside_nyquist ? unroll_phase_unbounded(phase + phase_incr) : unroll_phase(phase + phase_incr);
+      }
+      current_time += dt;
+      return v;
+    };
+    if (!per_frame) {
+      const float freq = d.frequency.mode == 0 ? d.frequency.base[inst] : d.frequency.base[(uint64_t)inst * d.frequency.stride + q];
+      const float detune = d.detune.mode == 0 ? d.detune.base[inst] : d.detune.base[(uint64_t)inst * d.detune.stride + q];
+      const double computed_freq = (double)freq * exp2((double)detune / 1200.);  // :30-32
+      const double phase_incr = computed_freq / sample_rate;
+      const bool outside_nyquist = fabs(computed_freq) >= nyquist;
+      const bool fully_active = started && start_time <= block_time && stop_time >= next_block_time;
+      if (fully_active && !outside_nyquist) {
+        for (int j = 0; j < RQ / 4; j++) {
+          float r[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            r[e] = waveform_sample(d, phase, phase_incr);
+            phase = unroll_phase(phase + phase_incr);
+          }
+          o4[j] = make_float4(r[0], r[1], r[2], r[3]);
+        }
+      } else {
+        for (int j = 0; j < RQ / 4; j++) {
+          float r[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) r[e] = generate(outside_nyquist, phase_incr);
+          o4[j] = make_float4(r[0], r[1], r[2], r[3]);
+        }
+      }
+    } else {
+      for (int j = 0; j < RQ / 4; j++) {
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint64_t f = f0 + j * 4 + e;
+          const float freq = d.frequency.mode == 0   ? d.frequency.base[inst]
+                             : d.frequency.mode == 1 ? d.frequency.base[(uint64_t)inst * d.frequency.stride + q]
+                                                     : d.frequency.base[(uint64_t)inst * d.frequency.stride + f];
+          const float detune = d.detune.mode == 0   ? d.detune.base[inst]
+                               : d.detune.mode == 1 ? d.detune.base[(uint64_t)inst * d.detune.stride + q]
+                                                    : d.detune.base[(uint64_t)inst * d.detune.stride + f];
+          const double computed_freq = (double)freq * exp2((double)detune / 1200.);
+          const double phase_incr = computed_freq / sample_rate;
+          r[e] = generate(fabs(computed_freq) >= nyquist, phase_incr);
+        }
+        o4[j] = make_float4(r[0], r[1], r[2], r[3]);
+      }
+    }
+  }
+  // frames past the last quantum of the padded signal
+  for (uint64_t f = (uint64_t)d.n_quanta * RQ; f < d.frames; f += 4) *reinterpret_cast<float4*>(out + f) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+void launch_osc(const OscDesc& d, void* stream) {
+  hipLaunchKernelGGL(osc_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
+}
+
+}  // namespace waa
