@@ -31,6 +31,14 @@ RQ = 128
 
 def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
     ctx = waa.OfflineAudioContext(2, frames, SR, n_instances=n_inst, binding=binding, device=device)
+    if name == "osc":  # subtractive voice, Oscillator(sawtooth) -> Biquad(lowpass) -> Gain
+        osc = ctx.create_oscillator(type_="sawtooth", frequency=110.0)
+        for i in range(0, n_inst, max(1, n_inst // 64)):
+            osc.detune.set_value(float(i % 1200), instance=i)
+        osc.connect(ctx.create_biquad_filter(type_="lowpass", frequency=1200.0, q=2.0)).connect(
+            ctx.create_gain(gain=0.5)).connect(ctx.destination())
+        osc.start()
+        return ctx, osc
     src = ctx.create_buffer_source()
     if noise_ptr is not None:
         src.adopt_device_buffer(noise_ptr, 2, frames, SR)
@@ -53,6 +61,9 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
         from scipy import signal
         b, a = signal.butter(int(name[3:]), 0.25)
         node = node.connect(ctx.create_iir_filter(b, a))
+    if name == "echo":
+        node.connect(ctx.destination())
+        node = node.connect(ctx.create_delay(1.0, delay_time=0.25)).connect(ctx.create_gain(gain=0.5))
     if name in ("fb", "fbq"):  # feedback echo, DelayNode (0.25 s) <-> Gain(0.5) [-> Biquad]
         delay = ctx.create_delay(1.0, delay_time=0.25)
         src.connect(delay)
@@ -75,6 +86,8 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
 # algorithmic bytes per context-quantum
 ALG_BYTES = {"c2": 2048.0, "c2k": 2048.0, "c5": 2560.0, "c3": 362848.0, "t1": 362848.0 + 2048.0, "c4": 362848.0 + 2048.0 + 512.0}
 ALG_BYTES["fb"] = ALG_BYTES["fbq"] = 2048.0
+ALG_BYTES["osc"] = 1024.0   # no input; 2 output channels x 128 frames x 4 B
+ALG_BYTES["echo"] = 2048.0
 IIR_ORDERS = (2, 4, 8, 12, 19)
 for _o in IIR_ORDERS:
     ALG_BYTES[f"iir{_o}"] = 2048.0
@@ -86,6 +99,8 @@ DESCR = {
     "c4": "C4: {n} contexts x {s:g} s, BufferSource->Biquad->Convolver->StereoPanner->Analyser->destination",
     "c5": "C5: {n} contexts x {s:g} s, BufferSource(playbackRate 1.5, loop)->WaveShaper(2048-pt)->destination",
 }
+DESCR["osc"] = "subtractive voice: {n} contexts x {s:g} s, Oscillator(sawtooth 110 Hz, detuned)->Biquad(lowpass)->Gain->destination"
+DESCR["echo"] = "feed-forward echo: {n} contexts x {s:g} s, BufferSource->destination + BufferSource->Delay(0.25s)->Gain(0.5)->destination"
 DESCR["fb"] = "feedback echo: {n} contexts x {s:g} s, BufferSource->[Delay(0.25s)<->Gain(0.5)]->destination (+dry)"
 DESCR["fbq"] = "filtered feedback echo: {n} contexts x {s:g} s, BufferSource->[Delay(0.25s)->Biquad->Gain(0.5)->back]->destination (+dry)"
 for _o in IIR_ORDERS:
@@ -108,7 +123,8 @@ def cpu_baseline(waa, name, frames, target_wall=12.0):
     def run(n, fr, threads):
         noise = white_noise(n, 2, fr)
         ctx, src = build_workload(waa, orc, name, n, fr, -1, None)
-        src.set_buffer_batch(noise, SR)
+        if hasattr(src, "set_buffer_batch"):  # (the oscillator workload has no input buffer)
+            src.set_buffer_batch(noise, SR)
         ctx.prepare()
         lib.orc_set_threads(ctx._handle, threads)
         t0 = time.perf_counter()
@@ -236,7 +252,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if name in ("c2", "c2k", "t1", "c4") or name.startswith("iir") else "f32",
+            "dtype": "f64" if name in ("c2", "c2k", "t1", "c4", "fbq", "osc") or name.startswith("iir") else "f32",
             "data": "synthetic",
             "config": {"workload": DESCR[name].format(n=n_inst, s=args.seconds), "contexts_per_gpu": n_inst,
                        "sample_rate": SR, "render_seconds": args.seconds, "quanta_per_context": nq,

@@ -211,8 +211,40 @@ def _fm_patch(binding, n, frames):
 
 
 @pytest.mark.gpu
-def test_parity_fm_patch(hip, orc):
+@pytest.mark.parametrize("exact", [False, True])
+def test_parity_fm_patch(hip, orc, exact, monkeypatch):
+    """unmodulated oscillators use the time-parallel kernel (closed-form phase) unless WAA_OSC_EXACT forces the
+    lane-per-instance kernel; the FM carrier always runs on the latter"""
+    if exact:
+        monkeypatch.setenv("WAA_OSC_EXACT", "1")
     n, frames = 5, 2048 * 2 + 99
     g, o = _fm_patch(hip, n, frames), _fm_patch(orc, n, frames)
     assert rms_err(g, o).max() <= 1e-6
     assert np.abs(g - o).max() <= 5e-6
+
+
+@pytest.mark.gpu
+def test_parity_long_render_closed_form_phase(hip, orc):
+    """10 s: the closed-form phase of the time-parallel kernel against 480 000 rounded additions of the reference;
+    k-rate frequency sweep, start and stop inside quanta"""
+    sr, frames = 48000.0, 480000
+    nq = (frames + RQ - 1) // RQ
+    outs = []
+    for be_ in (hip, orc):
+        c = waa.OfflineAudioContext(1, frames, sr, n_instances=3, binding=be_)
+        o1 = c.create_oscillator(type_="sawtooth", frequency=97.3)
+        o2 = c.create_oscillator(type_="sine", frequency=440.0)
+        o2.frequency.set_block(0, np.geomspace(100.0, 6000.0, nq).astype(np.float32))
+        o3 = c.create_oscillator(type_="square", frequency=-333.3, detune=50.0)
+        mix = c.create_gain(gain=0.3)
+        for o_ in (o1, o2, o3):
+            o_.connect(mix)
+        mix.connect(c.destination())
+        o1.start_at(0.01234)
+        o1.stop_at(9.4321)
+        o2.start()
+        o3.start_at(1.0)
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    assert rms_err(*outs).max() <= 1e-6
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-5  # isolated samples on a square edge may land on the other side

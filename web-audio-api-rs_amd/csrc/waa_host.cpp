@@ -1690,10 +1690,69 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
   d.n_inst = b->n_inst;
   d.n_quanta = b->n_quanta;
   d.sample_rate = (double)b->sr;
-  st.profile_slot = slot_for(b, "osc_kernel");
+  const bool parallel = d.frequency.mode != 2 && d.detune.mode != 2 && !getenv("WAA_OSC_EXACT");
+  if (parallel) {
+    // host-known frequency: replay the per-quantum decisions of OscillatorRenderer::process (oscillator.rs:336-452)
+    // and record the phase at the first active frame of every quantum
+    std::vector<OscQuantum> tq((size_t)b->n_inst * b->n_quanta);
+    const double sample_rate = (double)b->sr, dt = 1. / sample_rate, nyquist = sample_rate / 2.;
+    auto frac = [](long double x) {
+      long double r = x - floorl(x);
+      return (double)(r >= 1.L ? r - 1.L : r);
+    };
+    for (uint32_t i = 0; i < b->n_inst; i++) {
+      const auto fq = param_per_quantum(b, n.params[WAA_PARAM_OSCILLATOR_FREQUENCY], i, nullptr);
+      const auto dq = param_per_quantum(b, n.params[WAA_PARAM_OSCILLATOR_DETUNE], i, nullptr);
+      double start_time = start[i];
+      const double stop_time = stop[i];
+      long double phase = 0.L;
+      bool started = false;
+      for (uint32_t q = 0; q < b->n_quanta; q++) {
+        OscQuantum& oq = tq[(size_t)i * b->n_quanta + q];
+        oq = OscQuantum{0., 0., 0, 0, 0};
+        const double block_time = (double)((uint64_t)q * RQ) / sample_rate;
+        const double next_block_time = block_time + dt * (double)RQ;
+        if (stop_time <= block_time || start_time >= next_block_time) continue;
+        if (!started && start_time < block_time) start_time = block_time;
+        const float f = fq[fq.size() == 1 ? 0 : q], det = dq[dq.size() == 1 ? 0 : q];
+        const double computed_freq = (double)f * std::exp2((double)det / 1200.);
+        const double incr = computed_freq / sample_rate;
+        oq.incr = incr;
+        oq.outside_nyquist = std::fabs(computed_freq) >= nyquist ? 1 : 0;
+        // the reference advances current_time by repeated addition: replay it to find the active frame range
+        double current_time = block_time;
+        int first = -1, end = RQ;
+        for (int k = 0; k < RQ; k++) {
+          const bool active = !(current_time < start_time || current_time >= stop_time);
+          if (active && first < 0) {
+            first = k;
+            if (!started) {
+              if (current_time > start_time) phase = frac((long double)incr * (long double)((current_time - start_time) / dt));
+              started = true;
+            }
+          }
+          if (!active && first >= 0) {
+            end = k;
+            break;
+          }
+          current_time += dt;
+        }
+        if (first < 0) continue;
+        oq.first = (int16_t)first;
+        oq.end = (int16_t)end;
+        oq.phase = (double)phase;
+        phase = frac(phase + (long double)(end - first) * (long double)incr);
+      }
+    }
+    OscQuantum* d_tq = nullptr;
+    if ((e = dev_upload(b, &d_tq, tq))) return e;
+    d.table_q = d_tq;
+  }
+  st.profile_slot = slot_for(b, parallel ? "osc_par_kernel" : "osc_kernel");
   b->steps.push_back(st);
   static const char* names[] = {"sine", "square", "sawtooth", "triangle", "custom"};
-  plan_note(b, "oscillator node %u: %s frequency=%s detune=%s", id, names[d.type],
+  plan_note(b, "oscillator node %u: %s (%s) frequency=%s detune=%s", id, names[d.type],
+            parallel ? "time-parallel, closed-form phase" : "lane per instance, serial phase",
             d.frequency.mode == 0 ? "const" : d.frequency.mode == 1 ? "k-rate" : "a-rate",
             d.detune.mode == 0 ? "const" : d.detune.mode == 1 ? "k-rate" : "a-rate");
   return 0;

@@ -239,6 +239,15 @@ struct OscDesc {
   uint32_t n_inst;
   uint32_t n_quanta;
   double sample_rate;
+  const struct OscQuantum* table_q;  // non-null: time-parallel kernel (host-known frequency), [n_inst][n_quanta]
+};
+// Per-(instance, quantum) record of the time-parallel oscillator: frames [first, end) of the quantum are active,
+// the phase of frame `first` is `phase`, every further frame advances by `incr` (oscillator.rs:395-440).
+struct OscQuantum {
+  double phase;
+  double incr;
+  int16_t first, end;
+  int32_t outside_nyquist;
 };
 void launch_osc(const OscDesc& d, void* stream);
 

@@ -155,7 +155,42 @@ __global__ __launch_bounds__(64) void osc_kernel(const OscDesc d) {
   for (uint64_t f = (uint64_t)d.n_quanta * RQ; f < d.frames; f += 4) *reinterpret_cast<float4*>(out + f) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Time-parallel variant for host-known frequencies (constants or one value per quantum, no graph modulation):
+// the host replays the scheduling decisions of the reference per quantum (start/stop inside a quantum, sub-sample
+// start phase, Nyquist muting) and hands over the phase at the first active frame of every quantum; inside the
+// quantum the phase is phase + i * incr in closed form instead of i rounded additions.  The two differ by the
+// accumulated rounding of the reference's running sum (~1e-14 after 10 s), far below one f32 ulp of the output;
+// the waveform arithmetic is the reference's.  HBM-bound: 4 B written per frame.
+__global__ __launch_bounds__(256) void osc_par_kernel(const OscDesc d) {
+  const uint32_t inst = blockIdx.y;
+  const uint64_t f0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (f0 >= d.frames) return;
+  __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);
+  float* out = d.out.base + (uint64_t)inst * d.out.inst_stride;
+  const uint32_t q = (uint32_t)(f0 / RQ);
+  float r[4] = {0.f, 0.f, 0.f, 0.f};
+  if (q < d.n_quanta) {
+    const OscQuantum oq = d.table_q[(uint64_t)inst * d.n_quanta + q];
+    const int i0 = (int)(f0 % RQ);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int i = i0 + e;
+      if (i >= oq.first && i < oq.end && !oq.outside_nyquist) {
+        const double x = __builtin_fma((double)(i - oq.first), oq.incr, oq.phase);
+        double ph = x - floor(x);
+        if (ph >= 1.) ph -= 1.;
+        r[e] = waveform_sample(d, ph, oq.incr);
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(out + f0) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
 void launch_osc(const OscDesc& d, void* stream) {
+  if (d.table_q) {
+    hipLaunchKernelGGL(osc_par_kernel, dim3((unsigned)((d.frames + 1023) / 1024), d.n_inst), dim3(256), 0, (hipStream_t)stream, d);
+    return;
+  }
   hipLaunchKernelGGL(osc_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
 }
 
