@@ -13,6 +13,8 @@
 // mul_add; every fma below is explicit.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "waa_internal.hpp"
 
 namespace waa {
@@ -485,6 +487,19 @@ __device__ __forceinline__ float apply_curve(const float* curve, int nn, float i
   return (1.f - f) * curve[ki] + f * curve[ki + 1];
 }
 
+// the same lookup on a curve staged in LDS
+__device__ __forceinline__ float apply_curve_lds(const __attribute__((address_space(3))) float* curve, int nn, float input) {
+  if (nn == 0) return 0.f;
+  const float n = (float)nn;
+  const float v = (n - 1.f) / 2.0f * (input + 1.f);
+  if (v <= 0.f) return curve[0];
+  if (v >= n - 1.f) return curve[nn - 1];
+  const float k = floorf(v);
+  const float f = v - k;
+  const int ki = (int)k;
+  return (1.f - f) * curve[ki] + f * curve[ki + 1];
+}
+
 __device__ __forceinline__ void stereo_gains_dev(float x, float& gl, float& gr) {
   const float PI_F = 3.14159265358979323846f;
   gl = sinf((1.f - x) * PI_F / 2.f);
@@ -508,9 +523,29 @@ __global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDes
     tile_last = d.tile1 * (TILE / TILE_FR);
   } else {
     const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    inst = (uint32_t)(wid / n_tiles_k);
-    tile_first = d.tile0 * (TILE / TILE_FR) + (uint32_t)(wid % n_tiles_k);
+    if (d.tile_major) {
+      // neighbouring waves render the SAME sub-tile of different instances: the per-frame playback table of a
+      // resampling source (16 B per frame, shared by all instances of a schedule) is then reused out of L2 instead
+      // of being re-fetched once per instance (C5: 15.7 GB of the 35 GB the kernel moved)
+      inst = (uint32_t)(wid % d.n_inst);
+      tile_first = d.tile0 * (TILE / TILE_FR) + (uint32_t)(wid / d.n_inst);
+      if (wid / d.n_inst >= n_tiles_k) inst = d.n_inst;  // past the end: retire below
+    } else {
+      inst = (uint32_t)(wid / n_tiles_k);
+      tile_first = d.tile0 * (TILE / TILE_FR) + (uint32_t)(wid % n_tiles_k);
+    }
     tile_last = tile_first + 1;
+  }
+  // tile-parallel variant: the WaveShaper curve is staged in LDS once per workgroup; per-sample lookups are then
+  // LDS gathers instead of global gathers that cost one L1 line access per distinct line (C5: the curve lookups
+  // were 16 of the 36 vector-memory instructions per lane and sub-tile)
+  if constexpr (!SERIAL) {
+    if (d.lds_curve_op >= 0) {
+      const int nn = d.ops[d.lds_curve_op].i0;
+      const float* src = reinterpret_cast<const float*>(d.ops[d.lds_curve_op].ptr0);
+      for (int i = threadIdx.x; i < nn; i += 256) lds[i] = src[i];
+      __syncthreads();
+    }
   }
   if (inst >= d.n_inst) return;
   __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);  // f64 denormals flushed (FTZ/DAZ render scope)
@@ -604,13 +639,24 @@ __global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDes
           break;
         }
         case OP_WAVESHAPER: {
-          const float* curve = reinterpret_cast<const float*>(op.ptr0);
+          if (!SERIAL && o == d.lds_curve_op) {
+            // (indexing `lds` directly keeps the LDS address space: ds_read, not flat loads)
 #pragma unroll
-          for (int c = 0; c < C; c++)
-            if (c < op.nch_in) {
+            for (int c = 0; c < C; c++)
+              if (c < op.nch_in) {
 #pragma unroll
-              for (int i = 0; i < K; i++) v[c][i] = apply_curve(curve, op.i0, v[c][i]);
-            }
+                for (int i = 0; i < K; i++)
+                  v[c][i] = apply_curve_lds((const __attribute__((address_space(3))) float*)lds, op.i0, v[c][i]);
+              }
+          } else {
+            const float* curve = reinterpret_cast<const float*>(op.ptr0);
+#pragma unroll
+            for (int c = 0; c < C; c++)
+              if (c < op.nch_in) {
+#pragma unroll
+                for (int i = 0; i < K; i++) v[c][i] = apply_curve(curve, op.i0, v[c][i]);
+              }
+          }
           break;
         }
         case OP_STEREO_PAN: {
@@ -818,16 +864,28 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
     else
       hipLaunchKernelGGL((chain_kernel<2, TILE_K, true>), grid, block, 2 * 64 * LDS_ROW * sizeof(float) + CARRY_BYTES, s, d);
   } else {
+    ChainDesc dd = d;
+    dd.lds_curve_op = -1;
+    dd.tile_major = 0;
+    for (int k = 0; k < d.n_inputs; k++) dd.tile_major |= d.in[k].kind == IN_SOURCE;
+    if (getenv("WAA_NO_TILE_MAJOR")) dd.tile_major = 0;  // measurement aid
+    for (int o = 0; o < d.n_ops; o++)
+      if (d.ops[o].kind == OP_WAVESHAPER && d.ops[o].i0 > 0 && d.ops[o].i0 <= 8192) {
+        dd.lds_curve_op = o;
+        break;
+      }
+    const size_t lds = dd.lds_curve_op >= 0 ? (size_t)d.ops[dd.lds_curve_op].i0 * sizeof(float) : 0;
+    // (8 frames per lane instead of 4 was measured: fewer waves fit per SIMD and every workload got slower)
     const uint64_t waves = (uint64_t)d.n_inst * (d.tile1 - d.tile0) * (TILE / 256);
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     if (cmax <= 1)
-      hipLaunchKernelGGL((chain_kernel<1, 4, false>), grid, block, 0, s, d);
+      hipLaunchKernelGGL((chain_kernel<1, 4, false>), grid, block, lds, s, dd);
     else if (cmax <= 2)
-      hipLaunchKernelGGL((chain_kernel<2, 4, false>), grid, block, 0, s, d);
+      hipLaunchKernelGGL((chain_kernel<2, 4, false>), grid, block, lds, s, dd);
     else if (cmax <= 4)
-      hipLaunchKernelGGL((chain_kernel<4, 4, false>), grid, block, 0, s, d);
+      hipLaunchKernelGGL((chain_kernel<4, 4, false>), grid, block, lds, s, dd);
     else
-      hipLaunchKernelGGL((chain_kernel<6, 4, false>), grid, block, 0, s, d);
+      hipLaunchKernelGGL((chain_kernel<6, 4, false>), grid, block, lds, s, dd);
   }
 }
 
