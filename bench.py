@@ -31,6 +31,15 @@ RQ = 128
 
 def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
     ctx = waa.OfflineAudioContext(2, frames, SR, n_instances=n_inst, binding=binding, device=device)
+    if name == "fm":  # two-operator FM: Oscillator -> Gain(index) -> carrier.frequency; carrier -> Gain -> destination
+        mod = ctx.create_oscillator(type_="sine", frequency=110.0)
+        idx = ctx.create_gain(gain=300.0)
+        car = ctx.create_oscillator(type_="sine", frequency=440.0)
+        mod.connect(idx).connect(car.frequency)
+        car.connect(ctx.create_gain(gain=0.5)).connect(ctx.destination())
+        mod.start()
+        car.start()
+        return ctx, car
     if name == "osc":  # subtractive voice, Oscillator(sawtooth) -> Biquad(lowpass) -> Gain
         osc = ctx.create_oscillator(type_="sawtooth", frequency=110.0)
         for i in range(0, n_inst, max(1, n_inst // 64)):
@@ -86,6 +95,7 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
 # algorithmic bytes per context-quantum
 ALG_BYTES = {"c2": 2048.0, "c2k": 2048.0, "c5": 2560.0, "c3": 362848.0, "t1": 362848.0 + 2048.0, "c4": 362848.0 + 2048.0 + 512.0}
 ALG_BYTES["fb"] = ALG_BYTES["fbq"] = 2048.0
+ALG_BYTES["fm"] = 1024.0
 ALG_BYTES["osc"] = 1024.0   # no input; 2 output channels x 128 frames x 4 B
 ALG_BYTES["echo"] = 2048.0
 IIR_ORDERS = (2, 4, 8, 12, 19)
@@ -99,6 +109,7 @@ DESCR = {
     "c4": "C4: {n} contexts x {s:g} s, BufferSource->Biquad->Convolver->StereoPanner->Analyser->destination",
     "c5": "C5: {n} contexts x {s:g} s, BufferSource(playbackRate 1.5, loop)->WaveShaper(2048-pt)->destination",
 }
+DESCR["fm"] = "two-operator FM: {n} contexts x {s:g} s, Oscillator->Gain(300)->carrier.frequency, carrier->Gain->destination"
 DESCR["osc"] = "subtractive voice: {n} contexts x {s:g} s, Oscillator(sawtooth 110 Hz, detuned)->Biquad(lowpass)->Gain->destination"
 DESCR["echo"] = "feed-forward echo: {n} contexts x {s:g} s, BufferSource->destination + BufferSource->Delay(0.25s)->Gain(0.5)->destination"
 DESCR["fb"] = "feedback echo: {n} contexts x {s:g} s, BufferSource->[Delay(0.25s)<->Gain(0.5)]->destination (+dry)"

@@ -213,8 +213,8 @@ def _fm_patch(binding, n, frames):
 @pytest.mark.gpu
 @pytest.mark.parametrize("exact", [False, True])
 def test_parity_fm_patch(hip, orc, exact, monkeypatch):
-    """unmodulated oscillators use the time-parallel kernel (closed-form phase) unless WAA_OSC_EXACT forces the
-    lane-per-instance kernel; the FM carrier always runs on the latter"""
+    """unmodulated oscillators use the time-parallel kernel (closed-form phase), the FM carrier the prefix-sum
+    kernel; WAA_OSC_EXACT forces the serial lane-per-instance kernel for both"""
     if exact:
         monkeypatch.setenv("WAA_OSC_EXACT", "1")
     n, frames = 5, 2048 * 2 + 99
@@ -248,3 +248,26 @@ def test_parity_long_render_closed_form_phase(hip, orc):
         c.close()
     assert rms_err(*outs).max() <= 1e-6
     assert np.abs(outs[0] - outs[1]).max() <= 2e-5  # isolated samples on a square edge may land on the other side
+
+
+@pytest.mark.gpu
+def test_parity_fm_long_render(hip, orc):
+    """4 s of two-operator FM with a sub-sample start and a stop: prefix-sum phase vs the reference's running sum"""
+    sr, frames = 48000.0, 48000 * 4
+    outs = []
+    for be_ in (hip, orc):
+        c = waa.OfflineAudioContext(1, frames, sr, n_instances=2, binding=be_)
+        mod = c.create_oscillator(type_="sine", frequency=3.0)
+        idx = c.create_gain(gain=200.0)
+        car = c.create_oscillator(type_="sawtooth", frequency=220.0)
+        car.detune.set_value(300.0, instance=1)
+        mod.connect(idx).connect(car.frequency)
+        car.connect(c.destination())
+        mod.start()
+        car.start_at(0.2500071)
+        car.stop_at(3.5)
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    assert np.abs(outs[1]).max() > 0.5
+    assert rms_err(*outs).max() <= 1e-6
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-4  # isolated samples next to a sawtooth edge

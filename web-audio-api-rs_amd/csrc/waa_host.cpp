@@ -1748,11 +1748,52 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
     if ((e = dev_upload(b, &d_tq, tq))) return e;
     d.table_q = d_tq;
   }
-  st.profile_slot = slot_for(b, parallel ? "osc_par_kernel" : "osc_kernel");
+  const bool scan = !parallel && !getenv("WAA_OSC_EXACT");
+  if (scan) {
+    // a-rate / graph-modulated frequency: the device forms the phase as a prefix sum of per-frame increments; the
+    // host replays only the reference's clock (current_time += dt per frame, oscillator.rs:505-552) to find the
+    // active frame range and the sub-sample start offset of every instance
+    std::vector<int64_t> act((size_t)b->n_inst * 2, 0);
+    std::vector<double> ratio(b->n_inst, 0.);
+    const double sample_rate = (double)b->sr, dt = 1. / sample_rate;
+    for (uint32_t i = 0; i < b->n_inst; i++) {
+      double start_time = start[i];
+      const double stop_time = stop[i];
+      int64_t first = -1, end = -1;
+      bool started = false;
+      for (uint32_t q = 0; q < b->n_quanta; q++) {
+        const double block_time = (double)((uint64_t)q * RQ) / sample_rate;
+        const double next_block_time = block_time + dt * (double)RQ;
+        if (stop_time <= block_time || start_time >= next_block_time) continue;
+        if (!started && start_time < block_time) start_time = block_time;
+        double current_time = block_time;
+        for (int k = 0; k < RQ; k++) {
+          const bool active = !(current_time < start_time || current_time >= stop_time);
+          if (active) {
+            if (first < 0) {
+              first = (int64_t)q * RQ + k;
+              if (current_time > start_time) ratio[i] = (current_time - start_time) / dt;
+              started = true;
+            }
+            end = (int64_t)q * RQ + k + 1;
+          }
+          current_time += dt;
+        }
+      }
+      act[(size_t)i * 2] = first < 0 ? 0 : first;
+      act[(size_t)i * 2 + 1] = first < 0 ? 0 : end;
+    }
+    int64_t* d_act = nullptr;
+    double* d_ratio = nullptr;
+    if ((e = dev_upload(b, &d_act, act)) || (e = dev_upload(b, &d_ratio, ratio))) return e;
+    d.active = d_act;
+    d.start_ratio = d_ratio;
+  }
+  st.profile_slot = slot_for(b, parallel ? "osc_par_kernel" : scan ? "osc_scan_kernel" : "osc_kernel");
   b->steps.push_back(st);
   static const char* names[] = {"sine", "square", "sawtooth", "triangle", "custom"};
   plan_note(b, "oscillator node %u: %s (%s) frequency=%s detune=%s", id, names[d.type],
-            parallel ? "time-parallel, closed-form phase" : "lane per instance, serial phase",
+            parallel ? "time-parallel, closed-form phase" : scan ? "prefix-sum phase" : "lane per instance, serial phase",
             d.frequency.mode == 0 ? "const" : d.frequency.mode == 1 ? "k-rate" : "a-rate",
             d.detune.mode == 0 ? "const" : d.detune.mode == 1 ? "k-rate" : "a-rate");
   return 0;

@@ -186,9 +186,82 @@ __global__ __launch_bounds__(256) void osc_par_kernel(const OscDesc d) {
   *reinterpret_cast<float4*>(out + f0) = make_float4(r[0], r[1], r[2], r[3]);
 }
 
+// a-rate / graph-modulated frequency (FM): the phase is the running sum of per-frame increments.  One wavefront per
+// instance walks 256-frame groups: every lane owns 4 consecutive frames (coalesced 16 B accesses), sums its four
+// increments, a 6-step wavefront scan gives every lane the sum of everything before it in the group, and the group
+// total is carried on (mod 1).  The order of the f64 additions differs from the reference's frame-by-frame sum —
+// same ~1e-14 phase difference as the closed form above, far below one f32 ulp of the output; the per-frame
+// decisions (active range from the host replay of the reference's clock, Nyquist muting, sub-sample start phase)
+// and the waveform arithmetic are the reference's.
+__global__ __launch_bounds__(64) void osc_scan_kernel(const OscDesc d) {
+  const uint32_t inst = blockIdx.x;
+  const int lane = threadIdx.x;
+  __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);
+  float* out = d.out.base + (uint64_t)inst * d.out.inst_stride;
+  const int64_t first = d.active[(uint64_t)inst * 2], end = d.active[(uint64_t)inst * 2 + 1];
+  const double ratio = d.start_ratio[inst];  // (time of frame `first` - start_time) / dt, 0 when it starts on a frame
+  const double sample_rate = d.sample_rate, nyquist = sample_rate / 2.;
+  double carry = 0.;  // phase at the first frame of the group
+  for (uint64_t g0 = 0; g0 < d.frames; g0 += 256) {
+    const uint64_t f0 = g0 + (uint64_t)lane * 4;
+    double incr[4];
+    bool outside[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint64_t f = f0 + e;
+      const uint64_t fc = f < (uint64_t)d.n_quanta * RQ ? f : (uint64_t)d.n_quanta * RQ - 1;
+      const uint32_t q = (uint32_t)(fc / RQ);
+      const float freq = d.frequency.mode == 0   ? d.frequency.base[inst]
+                         : d.frequency.mode == 1 ? d.frequency.base[(uint64_t)inst * d.frequency.stride + q]
+                                                 : d.frequency.base[(uint64_t)inst * d.frequency.stride + fc];
+      const float detune = d.detune.mode == 0   ? d.detune.base[inst]
+                           : d.detune.mode == 1 ? d.detune.base[(uint64_t)inst * d.detune.stride + q]
+                                                : d.detune.base[(uint64_t)inst * d.detune.stride + fc];
+      const double computed_freq = (double)freq * exp2((double)detune / 1200.);
+      incr[e] = computed_freq / sample_rate;
+      outside[e] = fabs(computed_freq) >= nyquist;
+    }
+    // contribution of each frame to the phase of LATER frames: inactive frames do not advance the phase
+    double adv[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int64_t f = (int64_t)(f0 + e);
+      adv[e] = (f >= first && f < end) ? incr[e] : 0.;
+      if (f == first) adv[e] += incr[e] * ratio;  // sub-sample start: the first frame starts at incr * ratio (:516-528)
+    }
+    const double local = ((adv[0] + adv[1]) + adv[2]) + adv[3];
+    double incl = local;  // inclusive scan over lanes
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const double t = __shfl_up(incl, sft, 64);
+      if (lane >= sft) incl += t;
+    }
+    double ph = carry + (incl - local);  // phase before this lane's first frame (may exceed 1: reduced per frame)
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int64_t f = (int64_t)(f0 + e);
+      double p = ph;
+      if (f == first) p += incr[e] * ratio;
+      p -= floor(p);
+      if (p >= 1.) p -= 1.;
+      r[e] = (f >= first && f < end && !outside[e]) ? waveform_sample(d, p, incr[e]) : 0.f;
+      ph += adv[e];
+    }
+    *reinterpret_cast<float4*>(out + f0) = make_float4(r[0], r[1], r[2], r[3]);
+    double total = __shfl(incl, 63, 64) + carry;
+    total -= floor(total);
+    carry = total;
+  }
+}
+
 void launch_osc(const OscDesc& d, void* stream) {
   if (d.table_q) {
     hipLaunchKernelGGL(osc_par_kernel, dim3((unsigned)((d.frames + 1023) / 1024), d.n_inst), dim3(256), 0, (hipStream_t)stream, d);
+    return;
+  }
+  if (d.active) {
+    hipLaunchKernelGGL(osc_scan_kernel, dim3(d.n_inst), dim3(64), 0, (hipStream_t)stream, d);
     return;
   }
   hipLaunchKernelGGL(osc_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
