@@ -75,6 +75,25 @@ struct ParamStore {
   }
 };
 
+// double-double (unevaluated sum hi + lo, ~106 bits) for the IIR transition-matrix powers
+struct DD {
+  double hi = 0., lo = 0.;
+};
+inline DD dd_add(DD a, DD b) {
+  const double s = a.hi + b.hi, bb = s - a.hi;
+  double e = (a.hi - (s - bb)) + (b.hi - bb);
+  e += a.lo + b.lo;
+  const double hi = s + e;
+  return DD{hi, e - (hi - s)};
+}
+inline DD dd_mul(DD a, DD b) {
+  const double p = a.hi * b.hi;
+  double e = std::fma(a.hi, b.hi, -p);
+  e += a.hi * b.lo + a.lo * b.hi;
+  const double hi = p + e;
+  return DD{hi, e - (hi - p)};
+}
+
 struct DeviceBuffer {  // an AudioBuffer resident in HBM
   float* base = nullptr;  // channel 0
   uint64_t ch_stride = 0;
@@ -2239,24 +2258,26 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
         co[ns + 1 + k] = n.iir_a[k];
       }
       // zero-input state transition M: s_i' = -a_{i+1} s_0 + s_{i+1}; powers M^(32 * 2^k), k = 0..5, for the
-      // lane scan of the kernel (long double on the host, rounded once).  `growth` = largest entry of any power
+      // lane scan of the kernel (double-double on the host, rounded once).  `growth` = largest entry of any power
       // the scan can form (intermediate squarings and all A^j, j <= 64): the scan's rounding error relative to
       // the state is about ns * growth * 2^-53, so ill-conditioned direct forms (clustered poles, high order)
       // and unstable filters go to the exact lane-per-stream kernel instead.
-      std::vector<long double> m((size_t)ns * ns, 0.L), t((size_t)ns * ns);
+      // (double-double arithmetic, ~106 bits: repeated squaring of a matrix with large transient entries loses
+      // growth^2 * eps per step, which long double cannot absorb for the filters that are still worth scanning)
+      std::vector<DD> m((size_t)ns * ns), t((size_t)ns * ns);
       for (int i = 0; i < ns; i++) {
-        m[(size_t)i * ns] = -(long double)co[ns + 1 + i + 1];
-        if (i + 1 < ns) m[(size_t)i * ns + i + 1] += 1.L;
+        m[(size_t)i * ns] = DD{-co[ns + 1 + i + 1], 0.};
+        if (i + 1 < ns) m[(size_t)i * ns + i + 1] = dd_add(m[(size_t)i * ns + i + 1], DD{1., 0.});
       }
-      long double growth = 0.L;
-      auto note = [&](const std::vector<long double>& a) {
-        for (long double v : a) growth = std::isfinite((double)v) ? std::max(growth, fabsl(v)) : INFINITY;
+      double growth = 0.;
+      auto note = [&](const std::vector<DD>& a) {
+        for (const DD& v : a) growth = std::isfinite(v.hi) ? std::max(growth, std::fabs(v.hi)) : INFINITY;
       };
-      auto mul = [&](const std::vector<long double>& x, const std::vector<long double>& y, std::vector<long double>& out) {
+      auto mul = [&](const std::vector<DD>& x, const std::vector<DD>& y, std::vector<DD>& out) {
         for (int r = 0; r < ns; r++)
           for (int c = 0; c < ns; c++) {
-            long double acc = 0.L;
-            for (int k = 0; k < ns; k++) acc += x[(size_t)r * ns + k] * y[(size_t)k * ns + c];
+            DD acc{0., 0.};
+            for (int k = 0; k < ns; k++) acc = dd_add(acc, dd_mul(x[(size_t)r * ns + k], y[(size_t)k * ns + c]));
             out[(size_t)r * ns + c] = acc;
           }
       };
@@ -2265,21 +2286,23 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
         m.swap(t);
         note(m);
       }
-      const std::vector<long double> A = m;
+      const std::vector<DD> A = m;
       std::vector<double> pw(6 * (size_t)ns * ns);
       for (int lvl = 0; lvl < 6; lvl++) {
-        for (size_t k = 0; k < (size_t)ns * ns; k++) pw[lvl * (size_t)ns * ns + k] = (double)m[k];
+        for (size_t k = 0; k < (size_t)ns * ns; k++) pw[lvl * (size_t)ns * ns + k] = m[k].hi + m[k].lo;
         mul(m, m, t);
         m.swap(t);
         note(m);
       }
       m = A;
-      for (int j = 2; j <= 64 && std::isfinite((double)growth); j++) {  // every A^j a lane can see
+      for (int j = 2; j <= 64 && std::isfinite(growth); j++) {  // every A^j a lane can see
         mul(m, A, t);
         m.swap(t);
         note(m);
       }
-      const bool exact = !(growth <= 1e4L) || getenv("WAA_IIR_EXACT") != nullptr;  // env: debugging aid
+      const char* genv = getenv("WAA_IIR_GROWTH");  // experiments only
+      const double growth_limit = genv ? atof(genv) : 1e4;
+      const bool exact = !(growth <= growth_limit) || getenv("WAA_IIR_EXACT") != nullptr;  // env: debugging aid
       if (exact)
         for (auto& v : pw) v = 0.;  // unused
       double *dco = nullptr, *dpw = nullptr, *dst = nullptr;
