@@ -1,0 +1,869 @@
+// waa_abi.cpp — the C ABI of libwaa_hip.so (include/waa_hip.h): batch construction and validation (the reference's
+// panics become status codes with the same message text), payload uploads, render, download, analyser pulls,
+// control-side helpers, profiling.  All sample arithmetic happens in the HIP kernels; there is no CPU fallback:
+// without a HIP device every render call fails with WAA_ERR_DEVICE.
+#include "waa_host.hpp"
+
+namespace waa {
+namespace host {
+thread_local char g_err[768];
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+}  // namespace host
+}  // namespace waa
+
+using namespace waa;
+using namespace waa::host;
+
+// =======================================================================================
+// C ABI
+// =======================================================================================
+extern "C" {
+
+const char* waa_last_error(void) { return g_err; }
+
+int32_t waa_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n_out, uint64_t length, float sr,
+                            int32_t device, waa_batch** out) {
+  if (!g || !out || g->n_nodes == 0 || n_inst == 0) return fail(WAA_ERR_INVALID_ARGUMENT, "invalid arguments");
+  if (g->nodes[0].kind != WAA_NODE_DESTINATION) return fail(WAA_ERR_INVALID_ARGUMENT, "node 0 must be the destination");
+  if (n_out == 0 || n_out > WAA_MAX_CHANNELS)
+    return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels: %u", n_out);
+  if (!(sr >= 8000.f && sr <= 192000.f)) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid sample rate: %f", sr);
+  std::unique_ptr<waa_batch> b(new waa_batch);
+  b->n_inst = n_inst;
+  b->n_out = n_out;
+  b->length = length;
+  b->sr = sr;
+  b->n_quanta = (uint32_t)((length + RQ - 1) / RQ);
+  if (b->n_quanta == 0) b->n_quanta = 1;
+  b->n_tiles = (b->n_quanta + QUANTA_PER_TILE - 1) / QUANTA_PER_TILE;
+  b->lp = (uint64_t)b->n_tiles * TILE;
+  for (uint32_t e = 0; e < g->n_edges; e++) {
+    const waa_edge_desc& ed = g->edges[e];
+    if (ed.from >= g->n_nodes || ed.to >= g->n_nodes || ed.from_output != 0 ||
+        (ed.to_input != 0 && !(ed.to_input & 0x80000000u)))
+      return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - invalid edge %u", e);
+    b->edges.push_back(ed);
+  }
+  b->nodes.resize(g->n_nodes);
+  for (uint32_t i = 0; i < g->n_nodes; i++) {
+    Node& n = b->nodes[i];
+    n.desc = g->nodes[i];
+    if (n.desc.kind >= WAA_NODE_KIND_COUNT) return fail(WAA_ERR_INVALID_ARGUMENT, "unknown node kind");
+    default_channel_config(n, n_out);
+    if (n.cc < 1 || n.cc > WAA_MAX_CHANNELS)
+      return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels: %d", n.cc);
+    auto P = [&](size_t k) -> ParamStore& {
+      if (n.params.size() <= k) n.params.resize(k + 1);
+      return n.params[k];
+    };
+    switch (n.desc.kind) {
+      case WAA_NODE_BIQUAD:
+        P(WAA_PARAM_BIQUAD_FREQUENCY).init(n_inst, 350.f, 0.f, sr / 2.f);
+        P(WAA_PARAM_BIQUAD_DETUNE).init(n_inst, 0.f, -153600.f, 153600.f);
+        P(WAA_PARAM_BIQUAD_Q).init(n_inst, 1.f, -FLT_MAX, FLT_MAX);
+        P(WAA_PARAM_BIQUAD_GAIN).init(n_inst, 0.f, -FLT_MAX, 40.f * log10f(FLT_MAX));
+        if (n.desc.i[0] < 0 || n.desc.i[0] > 7) return fail(WAA_ERR_INVALID_ARGUMENT, "bad biquad type");
+        break;
+      case WAA_NODE_GAIN: P(0).init(n_inst, 1.f, -FLT_MAX, FLT_MAX); break;
+      case WAA_NODE_BUFFER_SOURCE:
+        P(WAA_PARAM_SOURCE_PLAYBACK_RATE).init(n_inst, 1.f, -FLT_MAX, FLT_MAX);
+        P(WAA_PARAM_SOURCE_DETUNE).init(n_inst, 0.f, -FLT_MAX, FLT_MAX);
+        n.bufs.resize(n_inst);
+        n.sched.resize(n_inst);
+        break;
+      case WAA_NODE_CONSTANT_SOURCE:
+        P(0).init(n_inst, 1.f, -FLT_MAX, FLT_MAX);
+        n.sched.resize(n_inst);
+        break;
+      case WAA_NODE_OSCILLATOR:  // oscillator.rs:210-262
+        if (n.desc.i[0] < WAA_OSC_SINE || n.desc.i[0] > WAA_OSC_CUSTOM) return fail(WAA_ERR_INVALID_ARGUMENT, "bad oscillator type");
+        P(WAA_PARAM_OSCILLATOR_FREQUENCY).init(n_inst, 440.f, -sr / 2.f, sr / 2.f);
+        P(WAA_PARAM_OSCILLATOR_DETUNE).init(n_inst, 0.f, -153600.f, 153600.f);
+        n.sched.resize(n_inst);
+        break;
+      case WAA_NODE_STEREO_PANNER:
+        P(0).init(n_inst, 0.f, -1.f, 1.f);
+        if (n.mode == WAA_COUNT_MODE_MAX)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - StereoPannerNode channel count mode cannot be set to max");
+        if (n.cc > 2)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - StereoPannerNode channel count cannot be greater than two");
+        break;
+      case WAA_NODE_PANNER: {
+        static const float defs[15] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, -1, 0, 1, 0};
+        for (int p = 0; p < 15; p++) P(p).init(n_inst, defs[p], -FLT_MAX, FLT_MAX);
+        if (n.desc.i[0] == WAA_PANNING_HRTF)
+          return fail(WAA_ERR_OUT_OF_SCOPE, "HRTF panning is out of scope (third-party hrtf crate, parity unpinned)");
+        if (n.mode == WAA_COUNT_MODE_MAX)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count mode cannot be set to max");
+        if (n.cc > 2)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count cannot be greater than two");
+        break;
+      }
+      case WAA_NODE_DELAY:  // delay.rs:283-335
+        if (n.desc.d[0] == 0.) n.desc.d[0] = 1.;
+        if (!(n.desc.d[0] > 0. && n.desc.d[0] < 180.))
+          return fail(WAA_ERR_NOT_SUPPORTED,
+                      "NotSupportedError - maxDelayTime MUST be greater than zero and less than three minutes");
+        P(WAA_PARAM_DELAY_DELAY_TIME).init(n_inst, 0.f, 0.f, (float)n.desc.d[0]);
+        break;
+      case WAA_NODE_WAVESHAPER:
+        if (n.desc.i[0] != WAA_OVERSAMPLE_NONE)
+          return fail(WAA_ERR_OUT_OF_SCOPE, "WaveShaper oversampling is out of scope (third-party rubato, parity unpinned)");
+        break;
+      case WAA_NODE_CONVOLVER:
+        if (n.cc > 2)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - ConvolverNode channel count cannot be greater than two");
+        if (n.mode == WAA_COUNT_MODE_MAX)
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - ConvolverNode channel count mode cannot be set to max");
+        break;
+      case WAA_NODE_ANALYSER: {
+        int fs = n.desc.i[0] ? n.desc.i[0] : 2048;
+        if (fs < 32 || fs > 32768 || (fs & (fs - 1)))
+          return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - Invalid fft size: %d is not a power of two", fs);
+        n.desc.i[0] = fs;
+        if (n.desc.d[0] == 0. && n.desc.d[1] == 0. && n.desc.d[2] == 0.) {
+          n.desc.d[0] = 0.8;
+          n.desc.d[1] = -100.;
+          n.desc.d[2] = -30.;
+        }
+        if (n.desc.d[0] < 0. || n.desc.d[0] > 1.)
+          return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - Invalid smoothing time constant");
+        if (!(n.desc.d[1] < n.desc.d[2])) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - Invalid min decibels");
+        break;
+      }
+      default: break;
+    }
+  }
+  if (device == WAA_DEVICE_PLAN_ONLY) {
+    b->dry = true;
+    b->device = -1;
+    *out = b.release();
+    return WAA_OK;
+  }
+  // the device is only touched from here on; a machine without a GPU still validates graphs above
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(WAA_ERR_DEVICE, "no HIP device available: libwaa_hip has no CPU fallback");
+  if (device >= 0) {
+    if (device >= ndev) return fail(WAA_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    b->device = device;
+  } else {
+    HIP_TRY(hipGetDevice(&b->device));
+  }
+  HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  *out = b.release();
+  return WAA_OK;
+}
+
+void waa_batch_destroy(waa_batch* b) {
+  if (!b) return;
+  if (b->dry) {
+    for (void* p : b->allocs) std::free(p);
+    for (void* p : b->payload_allocs) std::free(p);
+    delete b;
+    return;
+  }
+  if (b->stream) {
+    (void)hipStreamSynchronize(b->stream);
+    for (auto& p : b->prof)
+      for (auto& ev : p.pending) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+      }
+    for (void* p : b->allocs) (void)hipFree(p);
+    for (void* p : b->payload_allocs) (void)hipFree(p);
+    (void)hipStreamDestroy(b->stream);
+  }
+  delete b;
+}
+
+static int upload_buffer(waa_batch* b, const float* const* channels, uint32_t n_ch, uint64_t frames, float sr,
+                         DeviceBuffer* out) {
+  const uint64_t stride = (frames + 3) / 4 * 4;
+  float* d = nullptr;
+  int e = dev_alloc(b, &d, (size_t)n_ch * std::max<uint64_t>(stride, 4), true);
+  if (e) return e;
+  for (uint32_t c = 0; c < n_ch; c++)
+    if (frames) {
+      if (b->dry)
+        std::memcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float));
+      else
+        HIP_TRY(hipMemcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float), hipMemcpyHostToDevice));
+    }
+  out->base = d;
+  out->ch_stride = stride;
+  out->frames = frames;
+  out->nch = n_ch;
+  out->sr = sr;
+  out->valid = true;
+  return 0;
+}
+
+waa_status waa_source_set_buffer(waa_batch* b, uint32_t node, uint32_t inst, const float* const* channels,
+                                 uint32_t n_ch, uint64_t frames, float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
+  if (!b->dry) HIP_TRY(hipSetDevice(b->device));
+  DeviceBuffer db;
+  if ((e = upload_buffer(b, channels, n_ch, frames, sr, &db))) return e;
+  Node& n = b->nodes[node];
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) n.bufs[k] = db;
+  return WAA_OK;
+}
+
+waa_status waa_source_set_buffer_batch(waa_batch* b, uint32_t node, const float* data, uint32_t n_ch, uint64_t frames,
+                                       float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_unplanned(b))) return e;
+  if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
+  if (!b->dry) HIP_TRY(hipSetDevice(b->device));
+  const uint64_t stride = (frames + 3) / 4 * 4;
+  float* d = nullptr;
+  if ((e = dev_alloc(b, &d, (size_t)b->n_inst * n_ch * std::max<uint64_t>(stride, 4), true))) return e;
+  if (frames && !b->dry)
+    HIP_TRY(hipMemcpy2D(d, stride * sizeof(float), data, frames * sizeof(float), frames * sizeof(float),
+                        (size_t)b->n_inst * n_ch, hipMemcpyHostToDevice));
+  Node& n = b->nodes[node];
+  for (uint32_t k = 0; k < b->n_inst; k++) {
+    DeviceBuffer db;
+    db.base = d + (size_t)k * n_ch * stride;
+    db.ch_stride = stride;
+    db.frames = frames;
+    db.nch = n_ch;
+    db.sr = sr;
+    db.valid = true;
+    n.bufs[k] = db;
+  }
+  return WAA_OK;
+}
+
+waa_status waa_source_adopt_device(waa_batch* b, uint32_t node, const float* device_data, uint32_t n_ch, uint64_t frames,
+                                   float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_unplanned(b))) return e;
+  if (!device_data || n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_INVALID_ARGUMENT, "bad device buffer");
+  Node& n = b->nodes[node];
+  for (uint32_t k = 0; k < b->n_inst; k++) {
+    DeviceBuffer db;
+    db.base = const_cast<float*>(device_data) + (size_t)k * n_ch * frames;
+    db.ch_stride = frames;
+    db.frames = frames;
+    db.nch = n_ch;
+    db.sr = sr;
+    db.valid = true;
+    n.bufs[k] = db;
+  }
+  return WAA_OK;
+}
+
+waa_status waa_source_start(waa_batch* b, uint32_t node, uint32_t inst, double when, double offset, double duration) {
+  int e;
+  if (!b || node >= b->nodes.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node");
+  const uint32_t kind = b->nodes[node].desc.kind;
+  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE && kind != WAA_NODE_OSCILLATOR)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not a scheduled source", node);
+  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  if (!std::isfinite(when) || !std::isfinite(offset) || !std::isfinite(duration))
+    return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided time value is non-finite.");
+  if (when < 0. || offset < 0. || duration < 0.)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - The provided time value cannot be negative");
+  Node& n = b->nodes[node];
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) {
+    if (n.sched[k].start != DBL_MAX) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot call `start` twice");
+    n.sched[k].start = when;
+    if (kind == WAA_NODE_BUFFER_SOURCE) {
+      n.sched[k].offset = offset;
+      n.sched[k].duration = duration;
+    }
+  }
+  return WAA_OK;
+}
+
+waa_status waa_source_stop(waa_batch* b, uint32_t node, uint32_t inst, double when) {
+  int e;
+  if (!b || node >= b->nodes.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node");
+  const uint32_t kind = b->nodes[node].desc.kind;
+  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE && kind != WAA_NODE_OSCILLATOR)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not a scheduled source", node);
+  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  if (!std::isfinite(when)) return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided time value is non-finite.");
+  if (when < 0.) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - The provided time value cannot be negative");
+  Node& n = b->nodes[node];
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) {
+    if (n.sched[k].start == DBL_MAX) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot stop before start");
+    n.sched[k].stop = when;
+  }
+  return WAA_OK;
+}
+
+waa_status waa_source_set_loop(waa_batch* b, uint32_t node, uint32_t inst, int32_t looping, double ls, double le) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  Node& n = b->nodes[node];
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) {
+    n.sched[k].looping = looping;
+    n.sched[k].loop_start = ls;
+    n.sched[k].loop_end = le;
+  }
+  return WAA_OK;
+}
+
+// convolver.rs:16-53
+static float normalize_buffer(const float* const* ch, uint32_t n_ch, uint64_t len, float sr) {
+  const float gain_calibration = 0.00125f, gain_calibration_sample_rate = 44100.f, min_power = 0.000125f;
+  float power = 0.f;
+  for (uint32_t c = 0; c < n_ch; c++) {
+    float s = 0.f;
+    for (uint64_t i = 0; i < len; i++) s += ch[c][i] * ch[c][i];
+    power += s;
+  }
+  power = std::sqrt(power / (float)(n_ch * len));
+  if (!std::isfinite(power) || std::isnan(power) || power < min_power) power = min_power;
+  float scale = 1.f / power;
+  scale *= gain_calibration;
+  scale *= gain_calibration_sample_rate / sr;
+  if (n_ch == 4) scale *= 0.5f;
+  return scale;
+}
+
+waa_status waa_convolver_set_buffer(waa_batch* b, uint32_t node, const float* const* channels, uint32_t n_ch,
+                                    uint64_t frames, float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_CONVOLVER)) || (e = check_unplanned(b))) return e;
+  if (sr != b->sr)
+    return fail(WAA_ERR_NOT_SUPPORTED,
+                "NotSupportedError - sample rate of the convolution buffer must match the audio context");
+  if (!(n_ch == 1 || n_ch == 2 || n_ch == 4))
+    return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - the convolution buffer must consist of 1, 2 or 4 channels");
+  Node& n = b->nodes[node];
+  const float scale = n.desc.i[0] ? 1.f : normalize_buffer(channels, n_ch, frames, sr);
+  n.ir.assign(n_ch, std::vector<float>(frames));
+  for (uint32_t c = 0; c < n_ch; c++)
+    for (uint64_t i = 0; i < frames; i++) n.ir[c][i] = channels[c][i] * scale;
+  n.ir_len = frames;
+  n.ir_nch = (int)n_ch;
+  n.has_ir = true;
+  return WAA_OK;
+}
+
+waa_status waa_waveshaper_set_curve(waa_batch* b, uint32_t node, const float* curve, uint32_t nn) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_WAVESHAPER)) || (e = check_unplanned(b))) return e;
+  Node& n = b->nodes[node];
+  if (n.has_curve) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - cannot assign curve twice");
+  n.curve.assign(curve, curve + nn);
+  n.has_curve = true;
+  return WAA_OK;
+}
+
+// periodic_wave.rs:88-190 + oscillator.rs:318-321 (control side: the wavetable is generated on the host)
+waa_status waa_oscillator_set_periodic_wave(waa_batch* b, uint32_t node, const float* real, const float* imag, uint32_t nn,
+                                            int32_t disable_normalization) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_OSCILLATOR)) || (e = check_unplanned(b))) return e;
+  if ((!real && !imag) || nn < 2) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - `real` and `imag` length should at least 2");
+  const int size = 8192;
+  std::vector<float> wavetable(size);
+  const float pi_2 = 2.f * 3.14159265358979323846f;
+  for (int i = 0; i < size; i++) {
+    float sample = 0.f;
+    const float phase = pi_2 * (float)i / (float)size;
+    for (uint32_t j = 1; j < nn; j++) {
+      const float freq = (float)j;
+      const float re = real ? real[j] : 0.f, im = imag ? imag[j] : 0.f;
+      const float rad = phase * freq;
+      const float contrib = re * std::cos(rad) + im * std::sin(rad);
+      sample += contrib;
+    }
+    wavetable[i] = sample;
+  }
+  if (!disable_normalization) {
+    float max = 0.f;
+    for (float v : wavetable) max = std::fabs(v) > max ? std::fabs(v) : max;
+    if (max > 0.f) {
+      const float norm_factor = 1.f / max;
+      for (float& v : wavetable) v *= norm_factor;
+    }
+  }
+  b->nodes[node].osc_wave.swap(wavetable);
+  return WAA_OK;
+}
+
+// iir_filter.rs:17-46 (validation) and :273-311 (pad to equal length, normalise by a0)
+static int check_iir_coefs(const double* ff, uint32_t nff, const double* fb, uint32_t nfb) {
+  if (!ff || nff == 0 || nff > WAA_MAX_IIR_COEFFS)
+    return fail(WAA_ERR_NOT_SUPPORTED,
+                "NotSupportedError - IIR Filter feedforward coefficients should have length >= 0 and <= %d", WAA_MAX_IIR_COEFFS);
+  bool all_zero = true;
+  for (uint32_t i = 0; i < nff; i++) all_zero &= ff[i] == 0.;
+  if (all_zero) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIR Filter feedforward coefficients cannot be all zeros");
+  if (!fb || nfb == 0 || nfb > WAA_MAX_IIR_COEFFS)
+    return fail(WAA_ERR_NOT_SUPPORTED,
+                "NotSupportedError - IIR Filter feedback coefficients should have length >= 0 and <= %d", WAA_MAX_IIR_COEFFS);
+  if (fb[0] == 0.) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIR Filter feedback first coefficient cannot be zero");
+  return 0;
+}
+
+waa_status waa_iir_set_coefficients(waa_batch* b, uint32_t node, const double* ff, uint32_t nff, const double* fb,
+                                    uint32_t nfb) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_IIR_FILTER)) || (e = check_unplanned(b))) return e;
+  if ((e = check_iir_coefs(ff, nff, fb, nfb))) return e;
+  Node& n = b->nodes[node];
+  const uint32_t len = std::max(nff, nfb);
+  const double a0 = fb[0];
+  n.iir_b.assign(len, 0.);
+  n.iir_a.assign(len, 0.);
+  for (uint32_t i = 0; i < len; i++) {
+    n.iir_b[i] = (i < nff ? ff[i] : 0.) / a0;
+    n.iir_a[i] = (i < nfb ? fb[i] : 0.) / a0;
+  }
+  return WAA_OK;
+}
+
+waa_status waa_set_param_const(waa_batch* b, uint32_t node, uint32_t param, uint32_t inst, float value) {
+  int e;
+  if (!b || node >= b->nodes.size() || param >= b->nodes[node].params.size())
+    return fail(WAA_ERR_INVALID_ARGUMENT, "no such param %u on node %u", param, node);
+  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  ParamStore& p = b->nodes[node].params[param];
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) p.cst[k] = value;
+  return WAA_OK;
+}
+
+waa_status waa_set_param_block(waa_batch* b, uint32_t node, uint32_t param, uint32_t inst, uint64_t q0, uint32_t nq,
+                               uint32_t vpq, const float* values) {
+  int e;
+  if (!b || node >= b->nodes.size() || param >= b->nodes[node].params.size())
+    return fail(WAA_ERR_INVALID_ARGUMENT, "no such param %u on node %u", param, node);
+  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  if (vpq != 1 && vpq != RQ) return fail(WAA_ERR_INVALID_ARGUMENT, "values_per_quantum must be 1 or 128");
+  ParamBlock blk;
+  blk.inst = inst;
+  blk.q0 = q0;
+  blk.nq = nq;
+  blk.vpq = vpq;
+  blk.v.assign(values, values + (size_t)nq * vpq);
+  b->nodes[node].params[param].blocks.push_back(std::move(blk));
+  return WAA_OK;
+}
+
+waa_status waa_plan_describe(waa_batch* b, char* buf, size_t cap, size_t* needed) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (!b->planned) {
+    if (!b->dry) HIP_TRY(hipSetDevice(b->device));
+    int e = build_plan(b);
+    if (e) return e;
+  }
+  std::string text;
+  char head[256];
+  snprintf(head, sizeof head, "batch: %u instance(s) x %llu frames (%u quanta, %u tiles of %d) @ %g Hz, %u output channel(s)\n",
+           b->n_inst, (unsigned long long)b->length, b->n_quanta, b->n_tiles, TILE, (double)b->sr, b->n_out);
+  text += head;
+  for (auto& l : b->plan_log) text += l + "\n";
+  if (needed) *needed = text.size();
+  if (buf && cap) {
+    const size_t n = std::min(cap - 1, text.size());
+    std::memcpy(buf, text.data(), n);
+    buf[n] = 0;
+  }
+  return WAA_OK;
+}
+
+waa_status waa_render(waa_batch* b) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch (WAA_DEVICE_PLAN_ONLY) cannot render: there is no CPU fallback");
+  HIP_TRY(hipSetDevice(b->device));
+  if (!b->planned) {
+    int e = build_plan(b);
+    if (e) return e;
+  }
+  // every render starts from the initial state (offline contexts render exactly once; re-rendering the
+  // same batch is what the benchmark loop does)
+  for (auto& sb : b->state_bufs) HIP_TRY(hipMemsetAsync(sb.first, 0, sb.second, b->stream));
+  for (auto& n : b->nodes) n.an_cache.clear();
+  b->rendered = true;
+  auto timed = [&](int slot, auto&& launch) -> int {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (b->profiling && slot >= 0) {
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, b->stream));
+    }
+    launch();
+    HIP_TRY(hipGetLastError());
+    if (b->profiling && slot >= 0) {
+      HIP_TRY(hipEventRecord(e1, b->stream));
+      b->prof[slot].pending.push_back({e0, e1});
+    }
+    return 0;
+  };
+  // one step over the tile range [t0, t1)
+  auto run_step = [&](const Step& st, uint32_t t0, uint32_t t1) -> int {
+    int e = 0;
+    switch (st.kind) {
+      case 1: {
+        BiquadStreamDesc d = st.bq;
+        d.tile0 = t0;
+        d.tile1 = t1;
+        e = timed(st.profile_slot, [&] { launch_biquad_stream(d, b->stream); });
+        break;
+      }
+      case 2:
+        if ((e = timed(st.slot_fwd, [&] { launch_conv_forward(st.conv, b->stream); }))) break;
+        if ((e = timed(st.slot_mac, [&] { launch_conv_mac(st.conv, b->stream); }))) break;
+        e = timed(st.slot_inv, [&] { launch_conv_inverse(st.conv, b->stream); });
+        break;
+      case 3: HIP_TRY(hipMemsetAsync(st.zero_ptr, 0, st.zero_bytes, b->stream)); break;
+      case 4: e = timed(st.slot_mac, [&] { launch_conv_direct(st.conv, b->stream); }); break;
+      case 5: e = timed(st.profile_slot, [&] { launch_biquad_coefs(st.coef, b->stream); }); break;
+      case 6: {
+        IirStreamDesc d = st.iir;
+        d.tile0 = t0;
+        d.tile1 = t1;
+        e = timed(st.profile_slot, [&] { launch_iir_stream(d, b->stream); });
+        break;
+      }
+      case 7: {
+        DelayDesc d = st.delay;
+        d.tile0 = t0;
+        d.tile1 = t1;
+        e = timed(st.profile_slot, [&] { launch_delay(d, b->stream); });
+        break;
+      }
+      case 8: e = timed(st.profile_slot, [&] { launch_loop(st.loop, b->stream); }); break;
+      case 9: e = timed(st.profile_slot, [&] { launch_osc(st.osc, b->stream); }); break;
+      default: {
+        ChainDesc d = st.chain;
+        d.tile0 = t0;
+        d.tile1 = t1;
+        e = timed(st.profile_slot, [&] { launch_chain(d, st.cmax, b->stream); });
+        break;
+      }
+    }
+    return e;
+  };
+  for (size_t i = 0; i < b->steps.size();) {
+    const Step& st = b->steps[i];
+    if (st.group < 0) {
+      int e = run_step(st, 0, b->n_tiles);
+      if (e) return e;
+      i++;
+      continue;
+    }
+    // block-scheduled feedback loop: steps [i, j) block by block (graph.rs cycle breaker, see build_plan)
+    size_t j = i;
+    while (j < b->steps.size() && b->steps[j].group == st.group) j++;
+    for (size_t k = i; k < j; k++)
+      if (b->steps[k].prologue) {
+        int e = run_step(b->steps[k], 0, b->n_tiles);
+        if (e) return e;
+      }
+    const uint32_t bt = b->group_tiles[st.group];
+    for (uint32_t t0 = 0; t0 < b->n_tiles; t0 += bt) {
+      const uint32_t t1 = std::min(b->n_tiles, t0 + bt);
+      for (size_t k = i; k < j; k++)
+        if (!b->steps[k].prologue) {
+          int e = run_step(b->steps[k], t0, t1);
+          if (e) return e;
+        }
+    }
+    i = j;
+  }
+  return WAA_OK;
+}
+
+static int drain_profile(waa_batch* b) {
+  for (auto& p : b->prof) {
+    for (auto& ev : p.pending) {
+      float ms = 0.f;
+      HIP_TRY(hipEventSynchronize(ev.second));
+      HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+      p.total_ms += (double)ms;
+      p.launches++;
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    p.pending.clear();
+  }
+  return 0;
+}
+
+waa_status waa_sync(waa_batch* b) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch has no device");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return drain_profile(b);
+}
+
+waa_status waa_download(waa_batch* b, uint32_t inst, uint32_t ch, float* dst, uint64_t frames) {
+  if (!b || inst >= b->n_inst || ch >= b->n_out || frames > b->length)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "download out of range");
+  if (!b->planned || !b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const SignalRef& s = b->nodes[0].sig;
+  if ((int)ch < s.nch) {
+    HIP_TRY(hipMemcpy(dst, s.base + (size_t)inst * s.inst_stride + (size_t)ch * s.ch_stride, frames * sizeof(float),
+                      hipMemcpyDeviceToHost));
+  } else {
+    std::memset(dst, 0, frames * sizeof(float));
+  }
+  return WAA_OK;
+}
+
+waa_status waa_download_all(waa_batch* b, float* dst) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (!b->planned || !b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const SignalRef& s = b->nodes[0].sig;
+  if (b->length == 0) return WAA_OK;
+  if ((uint32_t)s.nch == b->n_out) {
+    HIP_TRY(hipMemcpy2D(dst, b->length * sizeof(float), s.base, s.ch_stride * sizeof(float), b->length * sizeof(float),
+                        (size_t)b->n_inst * b->n_out, hipMemcpyDeviceToHost));
+  } else {
+    for (uint32_t i = 0; i < b->n_inst; i++)
+      for (uint32_t c = 0; c < b->n_out; c++) {
+        int e = waa_download(b, i, c, dst + ((size_t)i * b->n_out + c) * b->length, b->length);
+        if (e) return e;
+      }
+  }
+  return WAA_OK;
+}
+
+waa_status waa_output_device(waa_batch* b, const float** p, uint64_t* is, uint64_t* cs) {
+  if (!b || !b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
+  const SignalRef& s = b->nodes[0].sig;
+  *p = s.base;
+  *is = s.inst_stride;
+  *cs = s.ch_stride;
+  return WAA_OK;
+}
+
+// AnalyserNode pulls (analysis.rs:261-401).  current_time after an offline render never changes, so the
+// spectrum is computed once per (node, instance) and repeated pulls return the same data (analysis.rs:354-357).
+static int analyser_compute(waa_batch* b, uint32_t node, uint32_t inst, Node::AnCache** out) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_ANALYSER))) return e;
+  if (inst >= b->n_inst) return fail(WAA_ERR_INVALID_ARGUMENT, "instance out of range");
+  Node& n = b->nodes[node];
+  const int N = n.desc.i[0], M = N / 2;
+  auto it = n.an_cache.find(inst);
+  if (it != n.an_cache.end()) {
+    *out = &it->second;
+    return 0;
+  }
+  Node::AnCache cache;
+  cache.spec.assign(M, 0.f);
+  cache.time.assign(N, 0.f);
+  if (b->planned && b->rendered && n.live) {
+    HIP_TRY(hipSetDevice(b->device));
+    if (!n.d_window) {
+      // generate_blackman (analysis.rs:14-24), f32 with the host libm the reference's f32::cos resolves to
+      std::vector<float> win(N);
+      const float alpha = 0.16f, a0 = (1.f - alpha) / 2.f, a1 = 1.f / 2.f, a2 = alpha / 2.f;
+      for (int i = 0; i < N; i++)
+        win[i] = a0 - a1 * cosf(2.f * PI_F * (float)i / (float)N) + a2 * cosf(4.f * PI_F * (float)i / (float)N);
+      std::vector<Cplx> tw(M), twf(M);
+      for (int t = 0; t < M; t++) {
+        const double x = -2.0 * 3.14159265358979323846 * (double)t / (double)M;
+        const double y = -2.0 * 3.14159265358979323846 * (double)t / (double)N;
+        tw[t] = Cplx{(float)std::cos(x), (float)std::sin(x)};
+        twf[t] = Cplx{(float)std::cos(y), (float)std::sin(y)};
+      }
+      std::vector<float> zeros(M, 0.f);
+      if ((e = dev_upload(b, &n.d_window, win)) || (e = dev_upload(b, &n.d_an_tw, tw)) ||
+          (e = dev_upload(b, &n.d_an_twfull, twf)) || (e = dev_upload(b, &n.d_an_prev, zeros)) ||
+          (e = dev_alloc(b, &n.d_an_spec, (size_t)M)) || (e = dev_alloc(b, &n.d_an_time, (size_t)N)))
+        return e;
+    }
+    AnalyserDesc ad{};
+    ad.sig = n.sig;
+    ad.inst = inst;
+    ad.fft_size = N;
+    ad.frames_written = (uint64_t)b->n_quanta * RQ;
+    ad.smoothing = (float)n.desc.d[0];
+    ad.window = n.d_window;
+    ad.tw = n.d_an_tw;
+    ad.tw_full = n.d_an_twfull;
+    ad.prev = n.d_an_prev;
+    ad.spec_out = n.d_an_spec;
+    ad.time_out = n.d_an_time;
+    launch_analyser(ad, b->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(cache.spec.data(), n.d_an_spec, (size_t)M * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cache.time.data(), n.d_an_time, (size_t)N * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  auto ins = n.an_cache.emplace(inst, std::move(cache));
+  *out = &ins.first->second;
+  return 0;
+}
+
+waa_status waa_analyser_get_float_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t nn) {
+  Node::AnCache* c;
+  int e = analyser_compute(b, node, inst, &c);
+  if (e) return e;
+  const uint32_t len = std::min<uint32_t>(nn, (uint32_t)c->spec.size());
+  for (uint32_t k = 0; k < len; k++) dst[k] = 20.f * log10f(c->spec[k]);  // analysis.rs:365-368
+  return WAA_OK;
+}
+waa_status waa_analyser_get_byte_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t nn) {
+  Node::AnCache* c;
+  int e = analyser_compute(b, node, inst, &c);
+  if (e) return e;
+  const Node& n = b->nodes[node];
+  const float mind = (float)n.desc.d[1], maxd = (float)n.desc.d[2];
+  const uint32_t len = std::min<uint32_t>(nn, (uint32_t)c->spec.size());
+  for (uint32_t k = 0; k < len; k++) {  // analysis.rs:388-400
+    const float db = 20.f * log10f(c->spec[k]);
+    const float scaled = 255.f / (maxd - mind) * (db - mind);
+    const float clamped = scaled < 0.f ? 0.f : scaled > 255.f ? 255.f : scaled;
+    dst[k] = std::isnan(scaled) ? 0 : (uint8_t)clamped;
+  }
+  return WAA_OK;
+}
+waa_status waa_analyser_get_float_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t nn) {
+  Node::AnCache* c;
+  int e = analyser_compute(b, node, inst, &c);
+  if (e) return e;
+  const uint32_t N = (uint32_t)c->time.size();
+  const uint32_t len = std::min(nn, N);  // ring_buffer.read: the most recent `len` frames (analysis.rs:114-127)
+  for (uint32_t i = 0; i < len; i++) dst[i] = c->time[N - len + i];
+  return WAA_OK;
+}
+waa_status waa_analyser_get_byte_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t nn) {
+  Node::AnCache* c;
+  int e = analyser_compute(b, node, inst, &c);
+  if (e) return e;
+  const uint32_t N = (uint32_t)c->time.size();
+  const uint32_t len = std::min(nn, N);
+  for (uint32_t i = 0; i < nn; i++) {  // analysis.rs:268-276 (elements past fft_size read a zeroed tmp)
+    const float v = i < len ? c->time[N - len + i] : 0.f;
+    const float scaled = 128.f * (1.f + v);
+    const float clamped = scaled < 0.f ? 0.f : scaled > 255.f ? 255.f : scaled;
+    dst[i] = (uint8_t)clamped;
+  }
+  return WAA_OK;
+}
+
+// buffer.rs:311-363 (input prep, host side)
+uint64_t waa_buffer_resample(const float* src, uint64_t frames, float source_sr, float target_sr, float* dst, uint64_t cap) {
+  if (std::fabs(source_sr - target_sr) <= 0.1f || frames == 0) {
+    if (dst)
+      for (uint64_t i = 0; i < frames && i < cap; i++) dst[i] = src[i];
+    return frames;
+  }
+  const double ratio = (double)target_sr / (double)source_sr;
+  const uint64_t tl = (uint64_t)std::ceil((double)frames * ratio);
+  if (!dst) return tl;
+  for (uint64_t i = 0; i < tl && i < cap; i++) {
+    const double position = (double)i / (double)(tl - 1);
+    const double playhead = position * (double)(frames - 1);
+    const double pf = std::floor(playhead);
+    const uint64_t prev = (uint64_t)pf;
+    const uint64_t next = std::min<uint64_t>(prev + 1, frames - 1);
+    const float k = (float)(playhead - pf), kinv = 1.f - k;
+    dst[i] = kinv * src[prev] + k * src[next];
+  }
+  return tl;
+}
+
+// iir_filter.rs:218-262 (control side, host)
+waa_status waa_iir_frequency_response(const double* ff, uint32_t nff, const double* fb, uint32_t nfb, float sample_rate,
+                                      const float* hz, float* mag, float* phase, uint32_t n) {
+  if (int e = check_iir_coefs(ff, nff, fb, nfb)) return e;
+  if (n && (!hz || !mag || !phase)) return fail(WAA_ERR_INVALID_ARGUMENT, "null array");
+  const double sr = (double)sample_rate, nyquist = sr / 2.;
+  for (uint32_t i = 0; i < n; i++) {
+    const double freq = (double)hz[i];
+    if (freq < 0. || freq > nyquist) {
+      mag[i] = std::nanf("");
+      phase[i] = std::nanf("");
+      continue;
+    }
+    const double z = -2.0 * 3.14159265358979323846 * freq / sr;
+    std::complex<double> num(0., 0.), den(0., 0.);
+    for (uint32_t k = 0; k < nff; k++) num += std::complex<double>(ff[k] * std::cos((double)k * z), ff[k] * std::sin((double)k * z));
+    for (uint32_t k = 0; k < nfb; k++) den += std::complex<double>(fb[k] * std::cos((double)k * z), fb[k] * std::sin((double)k * z));
+    const double ns = den.real() * den.real() + den.imag() * den.imag();
+    const double rr = (num.real() * den.real() + num.imag() * den.imag()) / ns;
+    const double ri = (num.imag() * den.real() - num.real() * den.imag()) / ns;
+    mag[i] = (float)std::hypot(rr, ri);
+    phase[i] = (float)std::atan2(ri, rr);
+  }
+  return WAA_OK;
+}
+
+// biquad_filter.rs:670-735 (control side, host)
+waa_status waa_biquad_frequency_response(int32_t type, float sample_rate, float frequency, float detune, float q,
+                                         float gain, const float* hz, float* mag, float* phase, uint32_t n) {
+  if (type < 0 || type > 7) return fail(WAA_ERR_INVALID_ARGUMENT, "bad filter type");
+  const double PI = 3.14159265358979323846;
+  const float nyq = sample_rate / 2.f;
+  const Coefs c = biquad_coefs(type, (double)sample_rate, (double)computed_freq(frequency, detune), (double)gain, (double)q);
+  for (uint32_t i = 0; i < n; i++) {
+    const float f = hz[i];
+    if (f < 0.f || f > nyq) {
+      mag[i] = NAN;
+      phase[i] = NAN;
+      continue;
+    }
+    const float fn = f / nyq;
+    const double omega = -PI * (double)fn;
+    const double zr = std::cos(omega), zi = std::sin(omega);
+    const double tr = c.b1 + c.b2 * zr, ti = c.b2 * zi;
+    const double nr = c.b0 + (tr * zr - ti * zi), ni = tr * zi + ti * zr;
+    const double ur = c.a1 + c.a2 * zr, ui = c.a2 * zi;
+    const double dr = 1. + (ur * zr - ui * zi), di = ur * zi + ui * zr;
+    const double den = dr * dr + di * di;
+    const double rr = (nr * dr + ni * di) / den, ri = (ni * dr - nr * di) / den;
+    mag[i] = (float)std::hypot(rr, ri);
+    phase[i] = (float)std::atan2(ri, rr);
+  }
+  return WAA_OK;
+}
+
+waa_status waa_profile_enable(waa_batch* b, int32_t on) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  b->profiling = on != 0;
+  return WAA_OK;
+}
+int32_t waa_profile_count(waa_batch* b) { return b ? (int32_t)b->prof.size() : 0; }
+waa_status waa_profile_get(waa_batch* b, int32_t i, const char** name, uint64_t* launches, double* ms) {
+  if (!b || i < 0 || i >= (int32_t)b->prof.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "profile index out of range");
+  *name = b->prof[i].name.c_str();
+  *launches = b->prof[i].launches;
+  *ms = b->prof[i].total_ms;
+  return WAA_OK;
+}
+waa_status waa_profile_reset(waa_batch* b) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  for (auto& p : b->prof) {
+    p.launches = 0;
+    p.total_ms = 0;
+  }
+  return WAA_OK;
+}
+
+}  // extern "C"

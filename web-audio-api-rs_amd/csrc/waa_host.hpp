@@ -1,0 +1,288 @@
+// waa_host.hpp — host-side data model of libwaa_hip.so shared by the scheduler (waa_schedule.cpp), the planner
+// (waa_plan.cpp) and the C ABI (waa_abi.cpp).  Not part of the public interface (include/waa_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <complex>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/waa_hip.h"
+#include "waa_internal.hpp"
+
+struct waa_batch;
+
+namespace waa {
+namespace host {
+
+// last error of the calling thread (waa_last_error); returns `code`
+int fail(int code, const char* fmt, ...);
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(WAA_ERR_DEVICE, "HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, \
+                                      __LINE__, #expr);                                         \
+  } while (0)
+
+struct ParamBlock {
+  uint32_t inst;
+  uint64_t q0;
+  uint32_t nq, vpq;
+  std::vector<float> v;
+};
+struct ParamStore {
+  std::vector<float> cst;
+  std::vector<ParamBlock> blocks;
+  float defv = 0, minv = -FLT_MAX, maxv = FLT_MAX;
+  void init(uint32_t n, float d, float lo, float hi) {
+    cst.assign(n, d);
+    defv = d;
+    minv = lo;
+    maxv = hi;
+  }
+  // AudioParamProcessor::mix_to_output clamp / NaN rule (param.rs:739-797)
+  float fix(float x) const { return std::isnan(x) ? defv : std::fmin(std::fmax(x, minv), maxv); }
+  int mode() const {
+    int m = 0;
+    for (auto& b : blocks) m = std::max(m, b.vpq == 1 ? 1 : 2);
+    return m;
+  }
+};
+
+// double-double (unevaluated sum hi + lo, ~106 bits) for the IIR transition-matrix powers
+struct DD {
+  double hi = 0., lo = 0.;
+};
+inline DD dd_add(DD a, DD b) {
+  const double s = a.hi + b.hi, bb = s - a.hi;
+  double e = (a.hi - (s - bb)) + (b.hi - bb);
+  e += a.lo + b.lo;
+  const double hi = s + e;
+  return DD{hi, e - (hi - s)};
+}
+inline DD dd_mul(DD a, DD b) {
+  const double p = a.hi * b.hi;
+  double e = std::fma(a.hi, b.hi, -p);
+  e += a.hi * b.lo + a.lo * b.hi;
+  const double hi = p + e;
+  return DD{hi, e - (hi - p)};
+}
+
+struct DeviceBuffer {  // an AudioBuffer resident in HBM
+  float* base = nullptr;  // channel 0
+  uint64_t ch_stride = 0;
+  uint64_t frames = 0;
+  uint32_t nch = 0;
+  float sr = 0;
+  bool valid = false;
+};
+
+struct SourceSched {  // per instance scheduling parameters
+  double start = DBL_MAX, stop = DBL_MAX, offset = 0, duration = DBL_MAX;
+  int looping = 0;
+  double loop_start = 0, loop_end = 0;
+};
+
+struct Node {
+  waa_node_desc desc{};
+  int cc = 2, mode = WAA_COUNT_MODE_MAX, interp = WAA_INTERP_SPEAKERS;
+  std::vector<ParamStore> params;
+  // sources
+  std::vector<DeviceBuffer> bufs;   // [n_inst]
+  std::vector<SourceSched> sched;   // [n_inst]
+  // convolver
+  std::vector<std::vector<float>> ir;  // host copy, scaled
+  uint64_t ir_len = 0;
+  int ir_nch = 0;
+  bool has_ir = false;
+  // waveshaper
+  std::vector<float> curve;
+  bool has_curve = false;
+  float* d_curve = nullptr;
+  // oscillator: custom PeriodicWave table (8192 points, periodic_wave.rs:76)
+  std::vector<float> osc_wave;
+  // iir filter: normalised coefficient pairs (iir_filter.rs:273-311)
+  std::vector<double> iir_b, iir_a;
+  // analyser (control side state)
+  struct AnCache {
+    std::vector<float> spec, time;
+  };
+  std::map<uint32_t, AnCache> an_cache;
+  float* d_window = nullptr;
+  Cplx *d_an_tw = nullptr, *d_an_twfull = nullptr;
+  float *d_an_prev = nullptr, *d_an_spec = nullptr, *d_an_time = nullptr;
+  // planning
+  int in_nch = 1;      // computed input channel count
+  int out_nch = 1;     // static output channel count
+  bool live = false;
+  bool materialized = false;
+  SignalRef sig{};     // valid when materialized
+  SignalRef hist{};    // DelayNode: the delay line (the node's mixed input, absolute time)
+  bool hist_is_temp = false;
+  std::vector<int> in_edges;   // indices into edges, in summing order
+  // audio-rate inputs of this node's AudioParams (edges with to_input = WAA_PARAM_INPUT(k)), in summing order,
+  // and the per-frame value signal planned for them (param.rs:686-795)
+  std::vector<std::vector<int>> pin_edges;
+  std::vector<ParamRef> pin_ref;
+  std::vector<char> pin_ready;
+  int n_consumers = 0;
+};
+
+struct ProfileEntry {
+  std::string name;
+  uint64_t launches = 0;
+  double total_ms = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct Step {
+  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator
+  ChainDesc chain{};
+  BiquadStreamDesc bq{};
+  ConvDesc conv{};
+  BiquadCoefDesc coef{};
+  IirStreamDesc iir{};
+  DelayDesc delay{};
+  LoopDesc loop{};
+  OscDesc osc{};
+  int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
+  void* zero_ptr = nullptr;
+  size_t zero_bytes = 0;
+  int cmax = 1;
+  int profile_slot = -1;
+  int group = -1;         // >= 0: member of a block-scheduled feedback loop (launched block by block)
+  bool prologue = false;  // inside a group: runs once over the full range before the blocks
+};
+
+}  // namespace host
+}  // namespace waa
+
+using namespace waa::host;  // (the opaque C handle lives in the global namespace)
+
+struct waa_batch {
+  uint32_t n_inst = 0, n_out = 0;
+  uint64_t length = 0;
+  float sr = 0;
+  uint32_t n_quanta = 0, n_tiles = 0;
+  uint64_t lp = 0;  // padded frames per channel
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<Node> nodes;
+  std::vector<waa_edge_desc> edges;
+  std::vector<uint32_t> order;
+  std::vector<uint8_t> cut;         // per DelayNode: writer->reader edge removed by the cycle breaker
+  std::vector<uint32_t> group_tiles;  // block size (tiles) of every block-scheduled feedback loop
+  std::vector<void*> allocs;        // plan-owned device allocations
+  std::vector<void*> payload_allocs;  // buffers uploaded through the API
+  std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render
+  std::vector<Step> steps;
+  bool planned = false;
+  bool rendered = false;
+  bool dry = false;                  // WAA_DEVICE_PLAN_ONLY: allocations are host memory, nothing is launched
+  std::vector<std::string> plan_log;  // waa_plan_describe
+  bool profiling = false;
+  std::vector<ProfileEntry> prof;
+};
+
+namespace waa {
+namespace host {
+
+template <typename T>
+int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  if (b->dry) {
+    // plan-only: big signal / spectrum buffers are never touched, so reserve address space lazily (calloc of a
+    // huge block is not committed until written) — small tables are really filled by dev_upload
+    p = std::calloc(1, bytes);
+    if (!p) return fail(WAA_ERR_DEVICE, "plan-only allocation of %zu bytes failed", bytes);
+    (payload ? b->payload_allocs : b->allocs).push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return 0;
+  }
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail(WAA_ERR_DEVICE, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  (payload ? b->payload_allocs : b->allocs).push_back(p);
+  *out = reinterpret_cast<T*>(p);
+  return 0;
+}
+template <typename T>
+int dev_upload(waa_batch* b, T** out, const std::vector<T>& host) {
+  int e = dev_alloc(b, out, host.size());
+  if (e) return e;
+  if (!host.empty()) {
+    if (b->dry)
+      std::memcpy(*out, host.data(), host.size() * sizeof(T));
+    else
+      HIP_TRY(hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+inline int check_node(waa_batch* b, uint32_t node, uint32_t kind) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (node >= b->nodes.size() || b->nodes[node].desc.kind != kind)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not of the expected kind", node);
+  return 0;
+}
+inline int check_inst(waa_batch* b, uint32_t inst) {
+  if (inst != WAA_ALL_INSTANCES && inst >= b->n_inst) return fail(WAA_ERR_INVALID_ARGUMENT, "instance out of range");
+  return 0;
+}
+inline int check_unplanned(waa_batch* b) {
+  if (b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - the batch is frozen once rendering has started");
+  return 0;
+}
+
+}  // namespace host
+}  // namespace waa
+
+namespace waa {
+namespace host {
+
+// ---- waa_schedule.cpp: host-side arithmetic of the reference's control/render split ---------------------
+struct Coefs {
+  double b0, b1, b2, a1, a2;
+};
+Coefs biquad_coefs(int type, double sample_rate, double f0, double gain, double q);   // biquad_filter.rs:28-373
+float computed_freq(float freq, float detune);                                          // biquad_filter.rs:367-373
+struct V3 {
+  float x, y, z;
+};
+constexpr float PI_F = 3.14159265358979323846f;
+void azimuth_elevation(V3 sp, V3 lp, V3 lf, V3 lu, float* az, float* el);               // spatial.rs / panner.rs
+float spatial_angle(V3 sp, V3 so, V3 lp);
+float cone_gain(const waa_node_desc& d, V3 sp, V3 so, V3 lp);
+float dist_gain(const waa_node_desc& d, V3 sp, V3 lp);
+// AudioBufferSourceNode scheduler: port of audio_buffer_source.rs:422-845
+struct SchedOut {
+  std::vector<QRec> qrec;
+  std::vector<SlowRec> slow;  // empty if no slow quantum
+  std::vector<uint8_t> tile_fast;
+  bool any_slow = false;
+};
+using SchedKey = std::tuple<double, double, double, double, int, double, double, uint64_t, float, float, float>;
+void schedule_source(const waa_batch* b, const SourceSched& cfg, uint64_t frames, float buf_sr, bool has_buffer,
+                     const std::vector<float>& rate_q, const std::vector<float>& detune_q, SchedOut* out);
+// one value per quantum (or a single one) of a host-evaluated param, clamped like the reference
+std::vector<float> param_per_quantum(const waa_batch* b, const ParamStore& p, uint32_t inst, bool* varies);
+
+// ---- waa_plan.cpp: graph -> launch plan -----------------------------------------------------------------
+int build_plan(waa_batch* b);
+void plan_note(waa_batch* b, const char* fmt, ...);
+int slot_for(waa_batch* b, const char* name);
+void default_channel_config(Node& n, uint32_t n_out);
+
+}  // namespace host
+}  // namespace waa

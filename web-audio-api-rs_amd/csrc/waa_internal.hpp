@@ -1,4 +1,4 @@
-// waa_internal.hpp — structures shared by the host planner (waa_host.cpp) and the gfx950 kernels
+// waa_internal.hpp — structures shared by the host planner (waa_plan.cpp) and the gfx950 kernels
 // (waa_kernels.hip).  Not part of the public C ABI (include/waa_hip.h).
 #pragma once
 #include <cstdint>

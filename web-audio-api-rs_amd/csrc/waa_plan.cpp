@@ -1,632 +1,12 @@
-// waa_host.cpp — host side of libwaa_hip.so: the C ABI (include/waa_hip.h), graph validation,
-// the planner that fuses single-consumer node paths into chain-kernel launches, the host-side
-// scheduler of AudioBufferSourceNode (port of the playhead state machine — scheduling stays on
-// the host), AudioParam materialisation and coefficient pre-computation.
-//
-// All sample arithmetic happens in the HIP kernels (waa_kernels.hip, waa_conv.hip); there is no
-// CPU fallback: without a HIP device every render call fails with WAA_ERR_DEVICE.
-#include <hip/hip_runtime.h>
+// waa_plan.cpp — the planner: processing order with the reference's cycle breaker, liveness, static channel
+// counts, materialisation points, fusion of single-consumer paths into chain launches, node-major steps
+// (convolver, delay, oscillator, IIR), feedback loops (block-scheduled or quantum-serial), AudioParam chains.
+#include "waa_host.hpp"
 
-#include <algorithm>
-#include <cfloat>
-#include <cmath>
-#include <complex>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <map>
-#include <memory>
-#include <string>
-#include <tuple>
-#include <vector>
+namespace waa {
+namespace host {
 
-#include "../../include/waa_hip.h"
-#include "waa_internal.hpp"
-
-using namespace waa;
-
-struct waa_batch;
-static int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in);
-namespace {
-void plan_note(waa_batch* b, const char* fmt, ...);
-}
-
-namespace {
-
-thread_local char g_err[768];
-int fail(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof g_err, fmt, ap);
-  va_end(ap);
-  return code;
-}
-#define HIP_TRY(expr)                                                                           \
-  do {                                                                                          \
-    hipError_t e_ = (expr);                                                                     \
-    if (e_ != hipSuccess) return fail(WAA_ERR_DEVICE, "HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, \
-                                      __LINE__, #expr);                                         \
-  } while (0)
-
-struct ParamBlock {
-  uint32_t inst;
-  uint64_t q0;
-  uint32_t nq, vpq;
-  std::vector<float> v;
-};
-struct ParamStore {
-  std::vector<float> cst;
-  std::vector<ParamBlock> blocks;
-  float defv = 0, minv = -FLT_MAX, maxv = FLT_MAX;
-  void init(uint32_t n, float d, float lo, float hi) {
-    cst.assign(n, d);
-    defv = d;
-    minv = lo;
-    maxv = hi;
-  }
-  // AudioParamProcessor::mix_to_output clamp / NaN rule (param.rs:739-797)
-  float fix(float x) const { return std::isnan(x) ? defv : std::fmin(std::fmax(x, minv), maxv); }
-  int mode() const {
-    int m = 0;
-    for (auto& b : blocks) m = std::max(m, b.vpq == 1 ? 1 : 2);
-    return m;
-  }
-};
-
-// double-double (unevaluated sum hi + lo, ~106 bits) for the IIR transition-matrix powers
-struct DD {
-  double hi = 0., lo = 0.;
-};
-inline DD dd_add(DD a, DD b) {
-  const double s = a.hi + b.hi, bb = s - a.hi;
-  double e = (a.hi - (s - bb)) + (b.hi - bb);
-  e += a.lo + b.lo;
-  const double hi = s + e;
-  return DD{hi, e - (hi - s)};
-}
-inline DD dd_mul(DD a, DD b) {
-  const double p = a.hi * b.hi;
-  double e = std::fma(a.hi, b.hi, -p);
-  e += a.hi * b.lo + a.lo * b.hi;
-  const double hi = p + e;
-  return DD{hi, e - (hi - p)};
-}
-
-struct DeviceBuffer {  // an AudioBuffer resident in HBM
-  float* base = nullptr;  // channel 0
-  uint64_t ch_stride = 0;
-  uint64_t frames = 0;
-  uint32_t nch = 0;
-  float sr = 0;
-  bool valid = false;
-};
-
-struct SourceSched {  // per instance scheduling parameters
-  double start = DBL_MAX, stop = DBL_MAX, offset = 0, duration = DBL_MAX;
-  int looping = 0;
-  double loop_start = 0, loop_end = 0;
-};
-
-struct Node {
-  waa_node_desc desc{};
-  int cc = 2, mode = WAA_COUNT_MODE_MAX, interp = WAA_INTERP_SPEAKERS;
-  std::vector<ParamStore> params;
-  // sources
-  std::vector<DeviceBuffer> bufs;   // [n_inst]
-  std::vector<SourceSched> sched;   // [n_inst]
-  // convolver
-  std::vector<std::vector<float>> ir;  // host copy, scaled
-  uint64_t ir_len = 0;
-  int ir_nch = 0;
-  bool has_ir = false;
-  // waveshaper
-  std::vector<float> curve;
-  bool has_curve = false;
-  float* d_curve = nullptr;
-  // oscillator: custom PeriodicWave table (8192 points, periodic_wave.rs:76)
-  std::vector<float> osc_wave;
-  // iir filter: normalised coefficient pairs (iir_filter.rs:273-311)
-  std::vector<double> iir_b, iir_a;
-  // analyser (control side state)
-  struct AnCache {
-    std::vector<float> spec, time;
-  };
-  std::map<uint32_t, AnCache> an_cache;
-  float* d_window = nullptr;
-  Cplx *d_an_tw = nullptr, *d_an_twfull = nullptr;
-  float *d_an_prev = nullptr, *d_an_spec = nullptr, *d_an_time = nullptr;
-  // planning
-  int in_nch = 1;      // computed input channel count
-  int out_nch = 1;     // static output channel count
-  bool live = false;
-  bool materialized = false;
-  SignalRef sig{};     // valid when materialized
-  SignalRef hist{};    // DelayNode: the delay line (the node's mixed input, absolute time)
-  bool hist_is_temp = false;
-  std::vector<int> in_edges;   // indices into edges, in summing order
-  // audio-rate inputs of this node's AudioParams (edges with to_input = WAA_PARAM_INPUT(k)), in summing order,
-  // and the per-frame value signal planned for them (param.rs:686-795)
-  std::vector<std::vector<int>> pin_edges;
-  std::vector<ParamRef> pin_ref;
-  std::vector<char> pin_ready;
-  int n_consumers = 0;
-};
-
-struct ProfileEntry {
-  std::string name;
-  uint64_t launches = 0;
-  double total_ms = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-};
-
-struct Step {
-  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator
-  ChainDesc chain{};
-  BiquadStreamDesc bq{};
-  ConvDesc conv{};
-  BiquadCoefDesc coef{};
-  IirStreamDesc iir{};
-  DelayDesc delay{};
-  LoopDesc loop{};
-  OscDesc osc{};
-  int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
-  void* zero_ptr = nullptr;
-  size_t zero_bytes = 0;
-  int cmax = 1;
-  int profile_slot = -1;
-  int group = -1;         // >= 0: member of a block-scheduled feedback loop (launched block by block)
-  bool prologue = false;  // inside a group: runs once over the full range before the blocks
-};
-
-}  // namespace
-
-struct waa_batch {
-  uint32_t n_inst = 0, n_out = 0;
-  uint64_t length = 0;
-  float sr = 0;
-  uint32_t n_quanta = 0, n_tiles = 0;
-  uint64_t lp = 0;  // padded frames per channel
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::vector<Node> nodes;
-  std::vector<waa_edge_desc> edges;
-  std::vector<uint32_t> order;
-  std::vector<uint8_t> cut;         // per DelayNode: writer->reader edge removed by the cycle breaker
-  std::vector<uint32_t> group_tiles;  // block size (tiles) of every block-scheduled feedback loop
-  std::vector<void*> allocs;        // plan-owned device allocations
-  std::vector<void*> payload_allocs;  // buffers uploaded through the API
-  std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render
-  std::vector<Step> steps;
-  bool planned = false;
-  bool rendered = false;
-  bool dry = false;                  // WAA_DEVICE_PLAN_ONLY: allocations are host memory, nothing is launched
-  std::vector<std::string> plan_log;  // waa_plan_describe
-  bool profiling = false;
-  std::vector<ProfileEntry> prof;
-};
-
-namespace {
-
-template <typename T>
-int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
-  void* p = nullptr;
-  size_t bytes = std::max<size_t>(count * sizeof(T), 16);
-  if (b->dry) {
-    // plan-only: big signal / spectrum buffers are never touched, so reserve address space lazily (calloc of a
-    // huge block is not committed until written) — small tables are really filled by dev_upload
-    p = std::calloc(1, bytes);
-    if (!p) return fail(WAA_ERR_DEVICE, "plan-only allocation of %zu bytes failed", bytes);
-    (payload ? b->payload_allocs : b->allocs).push_back(p);
-    *out = reinterpret_cast<T*>(p);
-    return 0;
-  }
-  hipError_t e = hipMalloc(&p, bytes);
-  if (e != hipSuccess) return fail(WAA_ERR_DEVICE, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-  (payload ? b->payload_allocs : b->allocs).push_back(p);
-  *out = reinterpret_cast<T*>(p);
-  return 0;
-}
-template <typename T>
-int dev_upload(waa_batch* b, T** out, const std::vector<T>& host) {
-  int e = dev_alloc(b, out, host.size());
-  if (e) return e;
-  if (!host.empty()) {
-    if (b->dry)
-      std::memcpy(*out, host.data(), host.size() * sizeof(T));
-    else
-      HIP_TRY(hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
-  }
-  return 0;
-}
-
-int check_node(waa_batch* b, uint32_t node, uint32_t kind) {
-  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
-  if (node >= b->nodes.size() || b->nodes[node].desc.kind != kind)
-    return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not of the expected kind", node);
-  return 0;
-}
-int check_inst(waa_batch* b, uint32_t inst) {
-  if (inst != WAA_ALL_INSTANCES && inst >= b->n_inst) return fail(WAA_ERR_INVALID_ARGUMENT, "instance out of range");
-  return 0;
-}
-int check_unplanned(waa_batch* b) {
-  if (b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - the batch is frozen once rendering has started");
-  return 0;
-}
-
-// ---- almost crate 0.2 (see oracle header for the provenance note) ----------------------
-const double ALMOST_TOL = 1.4901161193847656e-8;
-bool almost_zero(double a) { return std::fabs(a) < ALMOST_TOL; }
-bool almost_equal(double a, double b) {
-  if (a == b) return true;
-  if (!std::isfinite(a) || !std::isfinite(b)) return false;
-  double scale = std::fmax(std::fabs(a), std::fabs(b));
-  if (scale < 1.0) scale = 1.0;
-  return std::fabs(a - b) < scale * ALMOST_TOL;
-}
-
-// ---- biquad coefficients (biquad_filter.rs:28-373), f64 ---------------------------------
-struct Coefs {
-  double b0, b1, b2, a1, a2;
-};
-Coefs norm(double b0, double b1, double b2, double a0, double a1, double a2) {
-  double s = 1. / a0;
-  return {b0 * s, b1 * s, b2 * s, a1 * s, a2 * s};
-}
-Coefs biquad_coefs(int type, double sample_rate, double f0, double gain, double q) {
-  const double PI = 3.14159265358979323846;
-  double nyq = sample_rate / 2.;
-  double f = f0 / nyq;
-  f = f < 0. ? 0. : f > 1. ? 1. : f;
-  const Coefs wire{1., 0., 0., 0., 0.}, zero{0., 0., 0., 0., 0.};
-  double A = std::pow(10., gain / 40.);
-  switch (type) {
-    case WAA_BIQUAD_LOWPASS: {
-      if (f == 1.) return wire;
-      double w0 = PI * f, al = std::sin(w0) / (2. * std::pow(10., q / 20.)), cw = std::cos(w0), be = (1. - cw) / 2.;
-      return norm(be, 2. * be, be, 1. + al, -2. * cw, 1. - al);
-    }
-    case WAA_BIQUAD_HIGHPASS: {
-      if (f == 1.) return zero;
-      if (f == 0.) return wire;
-      double w0 = PI * f, al = std::sin(w0) / (2. * std::pow(10., q / 20.)), cw = std::cos(w0), be = (1. + cw) / 2.;
-      return norm(be, -2. * be, be, 1. + al, -2. * cw, 1. - al);
-    }
-    case WAA_BIQUAD_BANDPASS: {
-      if (!(f > 0. && f < 1.)) return zero;
-      if (!(q > 0.)) return wire;
-      double w0 = PI * f, al = std::sin(w0) / (2. * q), cw = std::cos(w0);
-      return norm(al, 0., -al, 1. + al, -2. * cw, 1. - al);
-    }
-    case WAA_BIQUAD_NOTCH: {
-      if (!(f > 0. && f < 1.)) return wire;
-      if (!(q > 0.)) return zero;
-      double w0 = PI * f, al = std::sin(w0) / (2. * q), cw = std::cos(w0);
-      return norm(1., -2. * cw, 1., 1. + al, -2. * cw, 1. - al);
-    }
-    case WAA_BIQUAD_ALLPASS: {
-      if (!(f > 0. && f < 1.)) return wire;
-      if (!(q > 0.)) return Coefs{-1., 0., 0., 0., 0.};
-      double w0 = PI * f, al = std::sin(w0) / (2. * q), cw = std::cos(w0);
-      return norm(1. - al, -2. * cw, 1. + al, 1. + al, -2. * cw, 1. - al);
-    }
-    case WAA_BIQUAD_PEAKING: {
-      if (!(f > 0. && f < 1.)) return wire;
-      if (!(q > 0.)) return Coefs{A * A, 0., 0., 0., 0.};
-      double w0 = PI * f, al = std::sin(w0) / (2. * q), cw = std::cos(w0);
-      return norm(1. + al * A, -2. * cw, 1. - al * A, 1. + al / A, -2. * cw, 1. - al / A);
-    }
-    case WAA_BIQUAD_LOWSHELF: {
-      if (f == 1.) return Coefs{A * A, 0., 0., 0., 0.};
-      if (f == 0.) return wire;
-      double w0 = PI * f, cw = std::cos(w0), as = std::sin(w0) / 2. * 1.41421356237309504880;
-      double k = 2. * as * std::sqrt(A), ap = A + 1., am = A - 1.;
-      return norm(A * (ap - am * cw + k), 2. * A * (am - ap * cw), A * (ap - am * cw - k), ap + am * cw + k,
-                  -2. * (am + ap * cw), ap + am * cw - k);
-    }
-    default: {
-      if (f == 1.) return wire;
-      if (!(f > 0.)) return Coefs{A * A, 0., 0., 0., 0.};
-      double w0 = PI * f, cw = std::cos(w0), as = std::sin(w0) / 2. * 1.41421356237309504880;
-      double k = 2. * as * std::sqrt(A), ap = A + 1., am = A - 1.;
-      return norm(A * (ap + am * cw + k), -2. * A * (am + ap * cw), A * (ap + am * cw - k), ap - am * cw + k,
-                  2. * (am - ap * cw), ap - am * cw - k);
-    }
-  }
-}
-float computed_freq(float freq, float detune) { return detune != 0.f ? freq * exp2f(detune / 1200.f) : freq; }
-
-// ---- spatial geometry (spatial.rs:205-299, panner.rs:927-985), f32 as the reference -----
-struct V3 {
-  float x, y, z;
-};
-V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-float sqlen(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-V3 scale(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-V3 normalized(V3 a) { return scale(a, 1.f / std::sqrt(sqlen(a))); }
-V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-const float PI_F = 3.14159265358979323846f;
-
-void azimuth_elevation(V3 sp, V3 lp, V3 lf, V3 lu, float* az, float* el) {
-  *az = 0.f;
-  *el = 0.f;
-  V3 rel = sub(sp, lp);
-  if (sqlen(rel) <= FLT_MIN) return;
-  V3 sl = normalized(rel);
-  V3 right = cross(lf, lu);
-  if (sqlen(right) == 0.f) return;
-  V3 rn = normalized(right), fn = normalized(lf), up = cross(rn, fn);
-  float elevation = 90.f - 180.f * acosf(dot(sl, up)) / PI_F;
-  if (elevation > 90.f)
-    elevation = 180.f - elevation;
-  else if (elevation < -90.f)
-    elevation = -180.f - elevation;
-  float up_proj = dot(sl, up);
-  V3 ps = sub(sl, scale(up, up_proj));
-  *el = elevation;
-  if (sqlen(ps) == 0.f) return;
-  V3 psn = normalized(ps);
-  float azimuth = 180.f * acosf(dot(psn, rn)) / PI_F;
-  if (dot(psn, fn) < 0.f) azimuth = 360.f - azimuth;
-  if (azimuth >= 0.f && azimuth <= 270.f)
-    azimuth = 90.f - azimuth;
-  else
-    azimuth = 450.f - azimuth;
-  *az = azimuth;
-}
-float spatial_angle(V3 sp, V3 so, V3 lp) {
-  if (sqlen(so) == 0.f) return 0.f;
-  V3 son = normalized(so), rel = sub(sp, lp);
-  if (sqlen(rel) <= FLT_MIN) return 0.f;
-  V3 sl = normalized(rel);
-  return std::fabs(180.f * acosf(dot(sl, son)) / PI_F);
-}
-float cone_gain(const waa_node_desc& d, V3 sp, V3 so, V3 lp) {
-  float in = (float)std::fabs(d.d[3]) / 2.f, out = (float)std::fabs(d.d[4]) / 2.f;
-  if (in >= 180.f && out >= 180.f) return 1.f;
-  float cog = (float)d.d[5];
-  float a = spatial_angle(sp, so, lp);
-  if (a < in) return 1.f;
-  if (a >= out) return cog;
-  float x = (a - in) / (out - in);
-  return (1.f - x) + cog * x;
-}
-float dist_gain(const waa_node_desc& d, V3 sp, V3 lp) {
-  double distance = (double)std::sqrt(sqlen(sub(sp, lp)));
-  double ref = d.d[0], maxd = d.d[1], roll = d.d[2], g;
-  switch (d.i[1]) {
-    case WAA_DISTANCE_LINEAR: {
-      double rf = roll < 0. ? 0. : roll > 1. ? 1. : roll;
-      double lo = std::fmin(ref, maxd), hi = std::fmax(ref, maxd);
-      double dc = distance < lo ? lo : distance > hi ? hi : distance;
-      g = 1. - rf * (dc - lo) / (hi - lo);
-      break;
-    }
-    case WAA_DISTANCE_INVERSE: {
-      double rf = std::fmax(roll, 0.);
-      g = distance > 0. ? ref / (ref + rf * (std::fmax(ref, distance) - ref)) : 1.;
-      break;
-    }
-    default: {
-      double rf = std::fmax(roll, 0.);
-      g = std::pow(std::fmax(distance, ref) / ref, -rf);
-    }
-  }
-  return (float)g;
-}
-
-// ---- AudioBufferSourceNode scheduler: port of audio_buffer_source.rs:422-845 -------------
-struct SchedOut {
-  std::vector<QRec> qrec;
-  std::vector<SlowRec> slow;  // empty if no slow quantum
-  std::vector<uint8_t> tile_fast;
-  bool any_slow = false;
-};
-using SchedKey = std::tuple<double, double, double, double, int, double, double, uint64_t, float, float, float>;
-
-void schedule_source(const waa_batch* b, const SourceSched& cfg, uint64_t frames, float buf_sr, bool has_buffer,
-                     const std::vector<float>& rate_q, const std::vector<float>& detune_q, SchedOut* out) {
-  const uint32_t nq = b->n_quanta;
-  out->qrec.assign(nq, QRec{0, Q_SILENT, 0});
-  out->slow.clear();
-  out->any_slow = false;
-  double start_time = cfg.start, stop_time = cfg.stop, offset = cfg.offset, duration = cfg.duration;
-  const double sample_rate = (double)b->sr;
-  const double dt = 1. / sample_rate;
-  const double block_duration = dt * (double)RQ;
-  const double buffer_duration = has_buffer ? (double)frames / (double)buf_sr : 0.;
-  // clamp_loop_boundaries (:401-417)
-  double loop_start = cfg.loop_start, loop_end = cfg.loop_end;
-  if (has_buffer) {
-    if (loop_start < 0.)
-      loop_start = 0.;
-    else if (loop_start > buffer_duration)
-      loop_start = buffer_duration;
-    if (loop_end <= 0. || loop_end > buffer_duration) loop_end = buffer_duration;
-  }
-  const bool is_looping = cfg.looping != 0;
-  const double sampling_ratio = has_buffer ? (double)buf_sr / sample_rate : 1.;
-  double buffer_time = 0., elapsed = 0.;
-  bool started = false, entered_loop = false, is_aligned = false, ended = false;
-  auto ensure_slow = [&]() {
-    if (!out->any_slow) {
-      out->slow.assign((size_t)nq * RQ, SlowRec{-1, -1, 0.});
-      out->any_slow = true;
-    }
-  };
-  for (uint32_t q = 0; q < nq; q++) {
-    if (ended) break;
-    const double block_time = (double)((uint64_t)q * RQ) / sample_rate;  // thread.rs:360
-    const double next_block_time = block_time + block_duration;
-    if (!has_buffer && start_time != DBL_MAX) break;  // ended
-    if (start_time >= next_block_time) {
-      if (stop_time <= next_block_time) break;
-      continue;
-    }
-    if (!has_buffer) continue;
-    const double detune = (double)detune_q[detune_q.size() == 1 ? 0 : q];
-    const double playback_rate = (double)rate_q[rate_q.size() == 1 ? 0 : q];
-    const double cpr = playback_rate * std::exp2(detune / 1200.);
-    double actual_loop_start = 0., actual_loop_end = 0.;
-    if (!started && start_time < block_time) start_time = block_time;
-    if (start_time == block_time && offset == 0.) is_aligned = true;
-    if (sampling_ratio != 1. || cpr != 1.) is_aligned = false;
-    if (loop_start != 0. || loop_end != buffer_duration) is_aligned = false;
-    if (buffer_time + block_duration > duration || block_time + block_duration > stop_time) is_aligned = false;
-    if (is_aligned) {
-      if (start_time == block_time) started = true;
-      const int64_t start_index = (int64_t)std::llround(buffer_time * sample_rate);
-      out->qrec[q] = QRec{start_index, is_looping ? (uint32_t)Q_FAST_LOOP : (uint32_t)Q_FAST, 0};
-      if (buffer_time + block_duration > buffer_duration) {
-        // did the playhead wrap inside this block?  (:568-607)
-        int loop_point_index = -1;
-        if (is_looping) {
-          uint64_t si = (uint64_t)start_index, off = 0;
-          for (int index = 0; index < RQ; index++) {
-            uint64_t bi = si + (uint64_t)index - off;
-            if (bi >= frames) {
-              loop_point_index = index;
-              si = 0;
-              off = (uint64_t)index;
-            }
-          }
-        }
-        if (loop_point_index >= 0)
-          buffer_time = std::fmod((double)(RQ - loop_point_index) / sample_rate, buffer_duration);
-        else
-          buffer_time += block_duration;
-      } else {
-        buffer_time += block_duration;
-      }
-      elapsed += block_duration;
-    } else {
-      if (is_looping) {
-        if (loop_start >= 0. && loop_end > 0. && loop_start < loop_end) {
-          actual_loop_start = loop_start;
-          actual_loop_end = loop_end;
-        } else {
-          actual_loop_start = 0.;
-          actual_loop_end = buffer_duration;
-        }
-      } else {
-        entered_loop = false;
-      }
-      ensure_slow();
-      out->qrec[q] = QRec{0, Q_SLOW, 0};
-      SlowRec* rec = &out->slow[(size_t)q * RQ];
-      for (int i = 0; i < RQ; i++) {
-        rec[i] = SlowRec{-1, -1, 0.};
-        const double current_time = block_time + (double)i * dt;
-        if (!started && almost_equal(current_time, start_time)) start_time = current_time;
-        if (almost_equal(elapsed, duration)) elapsed = duration;
-        if (current_time < start_time || current_time >= stop_time || elapsed >= duration) continue;
-        if (!started) {
-          const double delta = current_time - start_time;
-          offset += delta * cpr;
-          offset = std::fmin(std::fmax(offset, 0.), buffer_duration);
-          if (is_looping && cpr >= 0. && offset > actual_loop_end) offset = actual_loop_end;
-          if (is_looping && cpr < 0. && offset < actual_loop_start) offset = actual_loop_start;
-          buffer_time = offset;
-          elapsed = std::fabs(delta * cpr);
-          started = true;
-        }
-        if (is_looping) {
-          if (almost_equal(buffer_time, actual_loop_end)) buffer_time = actual_loop_end;
-          if (almost_equal(buffer_time, actual_loop_start)) buffer_time = actual_loop_start;
-          if (!entered_loop) {
-            if (offset < actual_loop_end && buffer_time >= actual_loop_start) entered_loop = true;
-            if (offset >= actual_loop_end && buffer_time < actual_loop_end) entered_loop = true;
-          }
-          if (entered_loop) {
-            while (buffer_time >= actual_loop_end) buffer_time -= actual_loop_end - actual_loop_start;
-            while (buffer_time < actual_loop_start) buffer_time += actual_loop_end - actual_loop_start;
-          }
-        }
-        if (almost_zero(buffer_time)) buffer_time = 0.;
-        if (buffer_time >= 0. && buffer_time < buffer_duration) {
-          const double position = buffer_time * sampling_ratio;
-          const double playhead = position * sample_rate;
-          const double pf = std::floor(playhead);
-          const uint64_t prev = (uint64_t)pf;
-          const double k = playhead - pf;
-          if (prev < frames) {
-            SlowRec r;
-            r.prev = (int32_t)prev;
-            r.k = k;
-            if (prev + 1 < frames) {
-              r.next = (int32_t)(prev + 1);
-            } else if (is_looping) {
-              if (playback_rate >= 0.) {
-                const double sp = actual_loop_start * sample_rate;
-                const uint64_t si = (std::floor(sp) == sp) ? (uint64_t)sp : (uint64_t)sp + 1;
-                r.next = si < frames ? (int32_t)si : -1;
-              } else {
-                // the reference reads buffer_channel[end_index] (audio_buffer_source.rs:795-797): one past the
-                // end when loop_end == duration (a Rust panic there); defined as a 0 sample here
-                const double ep = actual_loop_end * sample_rate;
-                const uint64_t ei = (uint64_t)ep;
-                r.next = ei < frames ? (int32_t)ei : -1;
-              }
-            } else {
-              r.next = (almost_equal(k, 1.) || prev == 0) ? -1 : -2;
-            }
-            rec[i] = r;
-          }
-        }
-        const double time_incr = dt * cpr;
-        buffer_time += time_incr;
-        elapsed += std::fabs(time_incr);
-      }
-    }
-    if (next_block_time >= stop_time || elapsed >= duration ||
-        (!is_looping && ((cpr > 0. && buffer_time >= buffer_duration) || (cpr < 0. && buffer_time < 0.))))
-      ended = true;
-  }
-  // per tile: can the whole tile be fetched as one aligned contiguous run?
-  out->tile_fast.assign(b->n_tiles, 0);
-  for (uint32_t t = 0; t < b->n_tiles; t++) {
-    bool ok = true;
-    int64_t s0 = 0;
-    for (int k = 0; k < QUANTA_PER_TILE && ok; k++) {
-      uint32_t q = t * QUANTA_PER_TILE + k;
-      if (q >= nq) {
-        ok = false;
-        break;
-      }
-      const QRec& r = out->qrec[q];
-      if (r.mode != Q_FAST && r.mode != Q_FAST_LOOP) ok = false;
-      if (k == 0) s0 = r.start;
-      if (r.start != s0 + (int64_t)k * RQ) ok = false;
-    }
-    if (ok && (s0 % 4 != 0 || (uint64_t)s0 + TILE > frames)) ok = false;
-    out->tile_fast[t] = ok ? 1 : 0;
-  }
-}
-
-// values of one param for one instance, one value per quantum (first sample of a len-128 slice)
-std::vector<float> param_per_quantum(const waa_batch* b, const ParamStore& p, uint32_t inst, bool* varies) {
-  std::vector<float> v(1, p.fix(p.cst[inst]));
-  bool any = false;
-  for (auto& blk : p.blocks)
-    if (blk.inst == WAA_ALL_INSTANCES || blk.inst == inst) any = true;
-  if (!any) {
-    if (varies) *varies = false;
-    return v;
-  }
-  v.assign(b->n_quanta, p.fix(p.cst[inst]));
-  for (auto& blk : p.blocks) {
-    if (!(blk.inst == WAA_ALL_INSTANCES || blk.inst == inst)) continue;
-    for (uint32_t k = 0; k < blk.nq; k++) {
-      uint64_t q = blk.q0 + k;
-      if (q < b->n_quanta) v[q] = p.fix(blk.v[(size_t)k * blk.vpq]);
-    }
-  }
-  if (varies) *varies = true;
-  return v;
-}
+int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in);
 
 // Upload a param as a device ParamRef (mode 0 / 1 / 2), values clamped like the reference.
 int upload_param(waa_batch* b, const ParamStore& p, ParamRef* ref) {
@@ -1473,10 +853,8 @@ int build_plan(waa_batch* b) {
   return 0;
 }
 
-}  // namespace
-
 // Resolve a source node into an InputRef: schedules, per-instance buffer table, constant ranges.
-static int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
+int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   Node& n = b->nodes[id];
   if (n.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
     int e = node_param(b, id, 0, &in->offset);
@@ -1585,8 +963,6 @@ static int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   plan_note(b, "source node %u: %zu distinct schedule(s) for %u instance(s)", id, scheds.size(), b->n_inst);
   return 0;
 }
-
-namespace {
 
 // Fan-in above MAX_INPUTS: sum the first MAX_INPUTS inputs (mixed to the receiver's channel count) into a
 // temporary signal and continue; the left-to-right order of the f32 additions (graph.rs:524-535) is kept.
@@ -2418,7 +1794,7 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
   return 0;
 }
 
-void default_config(Node& n, uint32_t n_out) {
+void default_channel_config(Node& n, uint32_t n_out) {
   int cc = 2, mode = WAA_COUNT_MODE_MAX, interp = WAA_INTERP_SPEAKERS;
   switch (n.desc.kind) {
     case WAA_NODE_DESTINATION:
@@ -2442,852 +1818,5 @@ void default_config(Node& n, uint32_t n_out) {
   n.interp = interp;
 }
 
-}  // namespace
-
-// =======================================================================================
-// C ABI
-// =======================================================================================
-extern "C" {
-
-const char* waa_last_error(void) { return g_err; }
-
-int32_t waa_device_count(void) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-  return n;
-}
-
-waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n_out, uint64_t length, float sr,
-                            int32_t device, waa_batch** out) {
-  if (!g || !out || g->n_nodes == 0 || n_inst == 0) return fail(WAA_ERR_INVALID_ARGUMENT, "invalid arguments");
-  if (g->nodes[0].kind != WAA_NODE_DESTINATION) return fail(WAA_ERR_INVALID_ARGUMENT, "node 0 must be the destination");
-  if (n_out == 0 || n_out > WAA_MAX_CHANNELS)
-    return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels: %u", n_out);
-  if (!(sr >= 8000.f && sr <= 192000.f)) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid sample rate: %f", sr);
-  std::unique_ptr<waa_batch> b(new waa_batch);
-  b->n_inst = n_inst;
-  b->n_out = n_out;
-  b->length = length;
-  b->sr = sr;
-  b->n_quanta = (uint32_t)((length + RQ - 1) / RQ);
-  if (b->n_quanta == 0) b->n_quanta = 1;
-  b->n_tiles = (b->n_quanta + QUANTA_PER_TILE - 1) / QUANTA_PER_TILE;
-  b->lp = (uint64_t)b->n_tiles * TILE;
-  for (uint32_t e = 0; e < g->n_edges; e++) {
-    const waa_edge_desc& ed = g->edges[e];
-    if (ed.from >= g->n_nodes || ed.to >= g->n_nodes || ed.from_output != 0 ||
-        (ed.to_input != 0 && !(ed.to_input & 0x80000000u)))
-      return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - invalid edge %u", e);
-    b->edges.push_back(ed);
-  }
-  b->nodes.resize(g->n_nodes);
-  for (uint32_t i = 0; i < g->n_nodes; i++) {
-    Node& n = b->nodes[i];
-    n.desc = g->nodes[i];
-    if (n.desc.kind >= WAA_NODE_KIND_COUNT) return fail(WAA_ERR_INVALID_ARGUMENT, "unknown node kind");
-    default_config(n, n_out);
-    if (n.cc < 1 || n.cc > WAA_MAX_CHANNELS)
-      return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels: %d", n.cc);
-    auto P = [&](size_t k) -> ParamStore& {
-      if (n.params.size() <= k) n.params.resize(k + 1);
-      return n.params[k];
-    };
-    switch (n.desc.kind) {
-      case WAA_NODE_BIQUAD:
-        P(WAA_PARAM_BIQUAD_FREQUENCY).init(n_inst, 350.f, 0.f, sr / 2.f);
-        P(WAA_PARAM_BIQUAD_DETUNE).init(n_inst, 0.f, -153600.f, 153600.f);
-        P(WAA_PARAM_BIQUAD_Q).init(n_inst, 1.f, -FLT_MAX, FLT_MAX);
-        P(WAA_PARAM_BIQUAD_GAIN).init(n_inst, 0.f, -FLT_MAX, 40.f * log10f(FLT_MAX));
-        if (n.desc.i[0] < 0 || n.desc.i[0] > 7) return fail(WAA_ERR_INVALID_ARGUMENT, "bad biquad type");
-        break;
-      case WAA_NODE_GAIN: P(0).init(n_inst, 1.f, -FLT_MAX, FLT_MAX); break;
-      case WAA_NODE_BUFFER_SOURCE:
-        P(WAA_PARAM_SOURCE_PLAYBACK_RATE).init(n_inst, 1.f, -FLT_MAX, FLT_MAX);
-        P(WAA_PARAM_SOURCE_DETUNE).init(n_inst, 0.f, -FLT_MAX, FLT_MAX);
-        n.bufs.resize(n_inst);
-        n.sched.resize(n_inst);
-        break;
-      case WAA_NODE_CONSTANT_SOURCE:
-        P(0).init(n_inst, 1.f, -FLT_MAX, FLT_MAX);
-        n.sched.resize(n_inst);
-        break;
-      case WAA_NODE_OSCILLATOR:  // oscillator.rs:210-262
-        if (n.desc.i[0] < WAA_OSC_SINE || n.desc.i[0] > WAA_OSC_CUSTOM) return fail(WAA_ERR_INVALID_ARGUMENT, "bad oscillator type");
-        P(WAA_PARAM_OSCILLATOR_FREQUENCY).init(n_inst, 440.f, -sr / 2.f, sr / 2.f);
-        P(WAA_PARAM_OSCILLATOR_DETUNE).init(n_inst, 0.f, -153600.f, 153600.f);
-        n.sched.resize(n_inst);
-        break;
-      case WAA_NODE_STEREO_PANNER:
-        P(0).init(n_inst, 0.f, -1.f, 1.f);
-        if (n.mode == WAA_COUNT_MODE_MAX)
-          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - StereoPannerNode channel count mode cannot be set to max");
-        if (n.cc > 2)
-          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - StereoPannerNode channel count cannot be greater than two");
-        break;
-      case WAA_NODE_PANNER: {
-        static const float defs[15] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, -1, 0, 1, 0};
-        for (int p = 0; p < 15; p++) P(p).init(n_inst, defs[p], -FLT_MAX, FLT_MAX);
-        if (n.desc.i[0] == WAA_PANNING_HRTF)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "HRTF panning is out of scope (third-party hrtf crate, parity unpinned)");
-        if (n.mode == WAA_COUNT_MODE_MAX)
-          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count mode cannot be set to max");
-        if (n.cc > 2)
-          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count cannot be greater than two");
-        break;
-      }
-      case WAA_NODE_DELAY:  // delay.rs:283-335
-        if (n.desc.d[0] == 0.) n.desc.d[0] = 1.;
-        if (!(n.desc.d[0] > 0. && n.desc.d[0] < 180.))
-          return fail(WAA_ERR_NOT_SUPPORTED,
-                      "NotSupportedError - maxDelayTime MUST be greater than zero and less than three minutes");
-        P(WAA_PARAM_DELAY_DELAY_TIME).init(n_inst, 0.f, 0.f, (float)n.desc.d[0]);
-        break;
-      case WAA_NODE_WAVESHAPER:
-        if (n.desc.i[0] != WAA_OVERSAMPLE_NONE)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "WaveShaper oversampling is out of scope (third-party rubato, parity unpinned)");
-        break;
-      case WAA_NODE_CONVOLVER:
-        if (n.cc > 2)
-          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - ConvolverNode channel count cannot be greater than two");
-        if (n.mode == WAA_COUNT_MODE_MAX)
-          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - ConvolverNode channel count mode cannot be set to max");
-        break;
-      case WAA_NODE_ANALYSER: {
-        int fs = n.desc.i[0] ? n.desc.i[0] : 2048;
-        if (fs < 32 || fs > 32768 || (fs & (fs - 1)))
-          return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - Invalid fft size: %d is not a power of two", fs);
-        n.desc.i[0] = fs;
-        if (n.desc.d[0] == 0. && n.desc.d[1] == 0. && n.desc.d[2] == 0.) {
-          n.desc.d[0] = 0.8;
-          n.desc.d[1] = -100.;
-          n.desc.d[2] = -30.;
-        }
-        if (n.desc.d[0] < 0. || n.desc.d[0] > 1.)
-          return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - Invalid smoothing time constant");
-        if (!(n.desc.d[1] < n.desc.d[2])) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - Invalid min decibels");
-        break;
-      }
-      default: break;
-    }
-  }
-  if (device == WAA_DEVICE_PLAN_ONLY) {
-    b->dry = true;
-    b->device = -1;
-    *out = b.release();
-    return WAA_OK;
-  }
-  // the device is only touched from here on; a machine without a GPU still validates graphs above
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-    return fail(WAA_ERR_DEVICE, "no HIP device available: libwaa_hip has no CPU fallback");
-  if (device >= 0) {
-    if (device >= ndev) return fail(WAA_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
-    b->device = device;
-  } else {
-    HIP_TRY(hipGetDevice(&b->device));
-  }
-  HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-  *out = b.release();
-  return WAA_OK;
-}
-
-void waa_batch_destroy(waa_batch* b) {
-  if (!b) return;
-  if (b->dry) {
-    for (void* p : b->allocs) std::free(p);
-    for (void* p : b->payload_allocs) std::free(p);
-    delete b;
-    return;
-  }
-  if (b->stream) {
-    (void)hipStreamSynchronize(b->stream);
-    for (auto& p : b->prof)
-      for (auto& ev : p.pending) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
-      }
-    for (void* p : b->allocs) (void)hipFree(p);
-    for (void* p : b->payload_allocs) (void)hipFree(p);
-    (void)hipStreamDestroy(b->stream);
-  }
-  delete b;
-}
-
-static int upload_buffer(waa_batch* b, const float* const* channels, uint32_t n_ch, uint64_t frames, float sr,
-                         DeviceBuffer* out) {
-  const uint64_t stride = (frames + 3) / 4 * 4;
-  float* d = nullptr;
-  int e = dev_alloc(b, &d, (size_t)n_ch * std::max<uint64_t>(stride, 4), true);
-  if (e) return e;
-  for (uint32_t c = 0; c < n_ch; c++)
-    if (frames) {
-      if (b->dry)
-        std::memcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float));
-      else
-        HIP_TRY(hipMemcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float), hipMemcpyHostToDevice));
-    }
-  out->base = d;
-  out->ch_stride = stride;
-  out->frames = frames;
-  out->nch = n_ch;
-  out->sr = sr;
-  out->valid = true;
-  return 0;
-}
-
-waa_status waa_source_set_buffer(waa_batch* b, uint32_t node, uint32_t inst, const float* const* channels,
-                                 uint32_t n_ch, uint64_t frames, float sr) {
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
-  if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
-  if (!b->dry) HIP_TRY(hipSetDevice(b->device));
-  DeviceBuffer db;
-  if ((e = upload_buffer(b, channels, n_ch, frames, sr, &db))) return e;
-  Node& n = b->nodes[node];
-  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
-  for (uint32_t k = lo; k < hi; k++) n.bufs[k] = db;
-  return WAA_OK;
-}
-
-waa_status waa_source_set_buffer_batch(waa_batch* b, uint32_t node, const float* data, uint32_t n_ch, uint64_t frames,
-                                       float sr) {
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_unplanned(b))) return e;
-  if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
-  if (!b->dry) HIP_TRY(hipSetDevice(b->device));
-  const uint64_t stride = (frames + 3) / 4 * 4;
-  float* d = nullptr;
-  if ((e = dev_alloc(b, &d, (size_t)b->n_inst * n_ch * std::max<uint64_t>(stride, 4), true))) return e;
-  if (frames && !b->dry)
-    HIP_TRY(hipMemcpy2D(d, stride * sizeof(float), data, frames * sizeof(float), frames * sizeof(float),
-                        (size_t)b->n_inst * n_ch, hipMemcpyHostToDevice));
-  Node& n = b->nodes[node];
-  for (uint32_t k = 0; k < b->n_inst; k++) {
-    DeviceBuffer db;
-    db.base = d + (size_t)k * n_ch * stride;
-    db.ch_stride = stride;
-    db.frames = frames;
-    db.nch = n_ch;
-    db.sr = sr;
-    db.valid = true;
-    n.bufs[k] = db;
-  }
-  return WAA_OK;
-}
-
-waa_status waa_source_adopt_device(waa_batch* b, uint32_t node, const float* device_data, uint32_t n_ch, uint64_t frames,
-                                   float sr) {
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_unplanned(b))) return e;
-  if (!device_data || n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_INVALID_ARGUMENT, "bad device buffer");
-  Node& n = b->nodes[node];
-  for (uint32_t k = 0; k < b->n_inst; k++) {
-    DeviceBuffer db;
-    db.base = const_cast<float*>(device_data) + (size_t)k * n_ch * frames;
-    db.ch_stride = frames;
-    db.frames = frames;
-    db.nch = n_ch;
-    db.sr = sr;
-    db.valid = true;
-    n.bufs[k] = db;
-  }
-  return WAA_OK;
-}
-
-waa_status waa_source_start(waa_batch* b, uint32_t node, uint32_t inst, double when, double offset, double duration) {
-  int e;
-  if (!b || node >= b->nodes.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node");
-  const uint32_t kind = b->nodes[node].desc.kind;
-  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE && kind != WAA_NODE_OSCILLATOR)
-    return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not a scheduled source", node);
-  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
-  if (!std::isfinite(when) || !std::isfinite(offset) || !std::isfinite(duration))
-    return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided time value is non-finite.");
-  if (when < 0. || offset < 0. || duration < 0.)
-    return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - The provided time value cannot be negative");
-  Node& n = b->nodes[node];
-  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
-  for (uint32_t k = lo; k < hi; k++) {
-    if (n.sched[k].start != DBL_MAX) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot call `start` twice");
-    n.sched[k].start = when;
-    if (kind == WAA_NODE_BUFFER_SOURCE) {
-      n.sched[k].offset = offset;
-      n.sched[k].duration = duration;
-    }
-  }
-  return WAA_OK;
-}
-
-waa_status waa_source_stop(waa_batch* b, uint32_t node, uint32_t inst, double when) {
-  int e;
-  if (!b || node >= b->nodes.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node");
-  const uint32_t kind = b->nodes[node].desc.kind;
-  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE && kind != WAA_NODE_OSCILLATOR)
-    return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not a scheduled source", node);
-  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
-  if (!std::isfinite(when)) return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided time value is non-finite.");
-  if (when < 0.) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - The provided time value cannot be negative");
-  Node& n = b->nodes[node];
-  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
-  for (uint32_t k = lo; k < hi; k++) {
-    if (n.sched[k].start == DBL_MAX) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot stop before start");
-    n.sched[k].stop = when;
-  }
-  return WAA_OK;
-}
-
-waa_status waa_source_set_loop(waa_batch* b, uint32_t node, uint32_t inst, int32_t looping, double ls, double le) {
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
-  Node& n = b->nodes[node];
-  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
-  for (uint32_t k = lo; k < hi; k++) {
-    n.sched[k].looping = looping;
-    n.sched[k].loop_start = ls;
-    n.sched[k].loop_end = le;
-  }
-  return WAA_OK;
-}
-
-// convolver.rs:16-53
-static float normalize_buffer(const float* const* ch, uint32_t n_ch, uint64_t len, float sr) {
-  const float gain_calibration = 0.00125f, gain_calibration_sample_rate = 44100.f, min_power = 0.000125f;
-  float power = 0.f;
-  for (uint32_t c = 0; c < n_ch; c++) {
-    float s = 0.f;
-    for (uint64_t i = 0; i < len; i++) s += ch[c][i] * ch[c][i];
-    power += s;
-  }
-  power = std::sqrt(power / (float)(n_ch * len));
-  if (!std::isfinite(power) || std::isnan(power) || power < min_power) power = min_power;
-  float scale = 1.f / power;
-  scale *= gain_calibration;
-  scale *= gain_calibration_sample_rate / sr;
-  if (n_ch == 4) scale *= 0.5f;
-  return scale;
-}
-
-waa_status waa_convolver_set_buffer(waa_batch* b, uint32_t node, const float* const* channels, uint32_t n_ch,
-                                    uint64_t frames, float sr) {
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_CONVOLVER)) || (e = check_unplanned(b))) return e;
-  if (sr != b->sr)
-    return fail(WAA_ERR_NOT_SUPPORTED,
-                "NotSupportedError - sample rate of the convolution buffer must match the audio context");
-  if (!(n_ch == 1 || n_ch == 2 || n_ch == 4))
-    return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - the convolution buffer must consist of 1, 2 or 4 channels");
-  Node& n = b->nodes[node];
-  const float scale = n.desc.i[0] ? 1.f : normalize_buffer(channels, n_ch, frames, sr);
-  n.ir.assign(n_ch, std::vector<float>(frames));
-  for (uint32_t c = 0; c < n_ch; c++)
-    for (uint64_t i = 0; i < frames; i++) n.ir[c][i] = channels[c][i] * scale;
-  n.ir_len = frames;
-  n.ir_nch = (int)n_ch;
-  n.has_ir = true;
-  return WAA_OK;
-}
-
-waa_status waa_waveshaper_set_curve(waa_batch* b, uint32_t node, const float* curve, uint32_t nn) {
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_WAVESHAPER)) || (e = check_unplanned(b))) return e;
-  Node& n = b->nodes[node];
-  if (n.has_curve) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - cannot assign curve twice");
-  n.curve.assign(curve, curve + nn);
-  n.has_curve = true;
-  return WAA_OK;
-}
-
-// periodic_wave.rs:88-190 + oscillator.rs:318-321 (control side: the wavetable is generated on the host)
-waa_status waa_oscillator_set_periodic_wave(waa_batch* b, uint32_t node, const float* real, const float* imag, uint32_t nn,
-                                            int32_t disable_normalization) {
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_OSCILLATOR)) || (e = check_unplanned(b))) return e;
-  if ((!real && !imag) || nn < 2) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - `real` and `imag` length should at least 2");
-  const int size = 8192;
-  std::vector<float> wavetable(size);
-  const float pi_2 = 2.f * 3.14159265358979323846f;
-  for (int i = 0; i < size; i++) {
-    float sample = 0.f;
-    const float phase = pi_2 * (float)i / (float)size;
-    for (uint32_t j = 1; j < nn; j++) {
-      const float freq = (float)j;
-      const float re = real ? real[j] : 0.f, im = imag ? imag[j] : 0.f;
-      const float rad = phase * freq;
-      const float contrib = re * std::cos(rad) + im * std::sin(rad);
-      sample += contrib;
-    }
-    wavetable[i] = sample;
-  }
-  if (!disable_normalization) {
-    float max = 0.f;
-    for (float v : wavetable) max = std::fabs(v) > max ? std::fabs(v) : max;
-    if (max > 0.f) {
-      const float norm_factor = 1.f / max;
-      for (float& v : wavetable) v *= norm_factor;
-    }
-  }
-  b->nodes[node].osc_wave.swap(wavetable);
-  return WAA_OK;
-}
-
-// iir_filter.rs:17-46 (validation) and :273-311 (pad to equal length, normalise by a0)
-static int check_iir_coefs(const double* ff, uint32_t nff, const double* fb, uint32_t nfb) {
-  if (!ff || nff == 0 || nff > WAA_MAX_IIR_COEFFS)
-    return fail(WAA_ERR_NOT_SUPPORTED,
-                "NotSupportedError - IIR Filter feedforward coefficients should have length >= 0 and <= %d", WAA_MAX_IIR_COEFFS);
-  bool all_zero = true;
-  for (uint32_t i = 0; i < nff; i++) all_zero &= ff[i] == 0.;
-  if (all_zero) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIR Filter feedforward coefficients cannot be all zeros");
-  if (!fb || nfb == 0 || nfb > WAA_MAX_IIR_COEFFS)
-    return fail(WAA_ERR_NOT_SUPPORTED,
-                "NotSupportedError - IIR Filter feedback coefficients should have length >= 0 and <= %d", WAA_MAX_IIR_COEFFS);
-  if (fb[0] == 0.) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIR Filter feedback first coefficient cannot be zero");
-  return 0;
-}
-
-waa_status waa_iir_set_coefficients(waa_batch* b, uint32_t node, const double* ff, uint32_t nff, const double* fb,
-                                    uint32_t nfb) {
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_IIR_FILTER)) || (e = check_unplanned(b))) return e;
-  if ((e = check_iir_coefs(ff, nff, fb, nfb))) return e;
-  Node& n = b->nodes[node];
-  const uint32_t len = std::max(nff, nfb);
-  const double a0 = fb[0];
-  n.iir_b.assign(len, 0.);
-  n.iir_a.assign(len, 0.);
-  for (uint32_t i = 0; i < len; i++) {
-    n.iir_b[i] = (i < nff ? ff[i] : 0.) / a0;
-    n.iir_a[i] = (i < nfb ? fb[i] : 0.) / a0;
-  }
-  return WAA_OK;
-}
-
-waa_status waa_set_param_const(waa_batch* b, uint32_t node, uint32_t param, uint32_t inst, float value) {
-  int e;
-  if (!b || node >= b->nodes.size() || param >= b->nodes[node].params.size())
-    return fail(WAA_ERR_INVALID_ARGUMENT, "no such param %u on node %u", param, node);
-  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
-  ParamStore& p = b->nodes[node].params[param];
-  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
-  for (uint32_t k = lo; k < hi; k++) p.cst[k] = value;
-  return WAA_OK;
-}
-
-waa_status waa_set_param_block(waa_batch* b, uint32_t node, uint32_t param, uint32_t inst, uint64_t q0, uint32_t nq,
-                               uint32_t vpq, const float* values) {
-  int e;
-  if (!b || node >= b->nodes.size() || param >= b->nodes[node].params.size())
-    return fail(WAA_ERR_INVALID_ARGUMENT, "no such param %u on node %u", param, node);
-  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
-  if (vpq != 1 && vpq != RQ) return fail(WAA_ERR_INVALID_ARGUMENT, "values_per_quantum must be 1 or 128");
-  ParamBlock blk;
-  blk.inst = inst;
-  blk.q0 = q0;
-  blk.nq = nq;
-  blk.vpq = vpq;
-  blk.v.assign(values, values + (size_t)nq * vpq);
-  b->nodes[node].params[param].blocks.push_back(std::move(blk));
-  return WAA_OK;
-}
-
-waa_status waa_plan_describe(waa_batch* b, char* buf, size_t cap, size_t* needed) {
-  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
-  if (!b->planned) {
-    if (!b->dry) HIP_TRY(hipSetDevice(b->device));
-    int e = build_plan(b);
-    if (e) return e;
-  }
-  std::string text;
-  char head[256];
-  snprintf(head, sizeof head, "batch: %u instance(s) x %llu frames (%u quanta, %u tiles of %d) @ %g Hz, %u output channel(s)\n",
-           b->n_inst, (unsigned long long)b->length, b->n_quanta, b->n_tiles, TILE, (double)b->sr, b->n_out);
-  text += head;
-  for (auto& l : b->plan_log) text += l + "\n";
-  if (needed) *needed = text.size();
-  if (buf && cap) {
-    const size_t n = std::min(cap - 1, text.size());
-    std::memcpy(buf, text.data(), n);
-    buf[n] = 0;
-  }
-  return WAA_OK;
-}
-
-waa_status waa_render(waa_batch* b) {
-  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
-  if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch (WAA_DEVICE_PLAN_ONLY) cannot render: there is no CPU fallback");
-  HIP_TRY(hipSetDevice(b->device));
-  if (!b->planned) {
-    int e = build_plan(b);
-    if (e) return e;
-  }
-  // every render starts from the initial state (offline contexts render exactly once; re-rendering the
-  // same batch is what the benchmark loop does)
-  for (auto& sb : b->state_bufs) HIP_TRY(hipMemsetAsync(sb.first, 0, sb.second, b->stream));
-  for (auto& n : b->nodes) n.an_cache.clear();
-  b->rendered = true;
-  auto timed = [&](int slot, auto&& launch) -> int {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (b->profiling && slot >= 0) {
-      HIP_TRY(hipEventCreate(&e0));
-      HIP_TRY(hipEventCreate(&e1));
-      HIP_TRY(hipEventRecord(e0, b->stream));
-    }
-    launch();
-    HIP_TRY(hipGetLastError());
-    if (b->profiling && slot >= 0) {
-      HIP_TRY(hipEventRecord(e1, b->stream));
-      b->prof[slot].pending.push_back({e0, e1});
-    }
-    return 0;
-  };
-  // one step over the tile range [t0, t1)
-  auto run_step = [&](const Step& st, uint32_t t0, uint32_t t1) -> int {
-    int e = 0;
-    switch (st.kind) {
-      case 1: {
-        BiquadStreamDesc d = st.bq;
-        d.tile0 = t0;
-        d.tile1 = t1;
-        e = timed(st.profile_slot, [&] { launch_biquad_stream(d, b->stream); });
-        break;
-      }
-      case 2:
-        if ((e = timed(st.slot_fwd, [&] { launch_conv_forward(st.conv, b->stream); }))) break;
-        if ((e = timed(st.slot_mac, [&] { launch_conv_mac(st.conv, b->stream); }))) break;
-        e = timed(st.slot_inv, [&] { launch_conv_inverse(st.conv, b->stream); });
-        break;
-      case 3: HIP_TRY(hipMemsetAsync(st.zero_ptr, 0, st.zero_bytes, b->stream)); break;
-      case 4: e = timed(st.slot_mac, [&] { launch_conv_direct(st.conv, b->stream); }); break;
-      case 5: e = timed(st.profile_slot, [&] { launch_biquad_coefs(st.coef, b->stream); }); break;
-      case 6: {
-        IirStreamDesc d = st.iir;
-        d.tile0 = t0;
-        d.tile1 = t1;
-        e = timed(st.profile_slot, [&] { launch_iir_stream(d, b->stream); });
-        break;
-      }
-      case 7: {
-        DelayDesc d = st.delay;
-        d.tile0 = t0;
-        d.tile1 = t1;
-        e = timed(st.profile_slot, [&] { launch_delay(d, b->stream); });
-        break;
-      }
-      case 8: e = timed(st.profile_slot, [&] { launch_loop(st.loop, b->stream); }); break;
-      case 9: e = timed(st.profile_slot, [&] { launch_osc(st.osc, b->stream); }); break;
-      default: {
-        ChainDesc d = st.chain;
-        d.tile0 = t0;
-        d.tile1 = t1;
-        e = timed(st.profile_slot, [&] { launch_chain(d, st.cmax, b->stream); });
-        break;
-      }
-    }
-    return e;
-  };
-  for (size_t i = 0; i < b->steps.size();) {
-    const Step& st = b->steps[i];
-    if (st.group < 0) {
-      int e = run_step(st, 0, b->n_tiles);
-      if (e) return e;
-      i++;
-      continue;
-    }
-    // block-scheduled feedback loop: steps [i, j) block by block (graph.rs cycle breaker, see build_plan)
-    size_t j = i;
-    while (j < b->steps.size() && b->steps[j].group == st.group) j++;
-    for (size_t k = i; k < j; k++)
-      if (b->steps[k].prologue) {
-        int e = run_step(b->steps[k], 0, b->n_tiles);
-        if (e) return e;
-      }
-    const uint32_t bt = b->group_tiles[st.group];
-    for (uint32_t t0 = 0; t0 < b->n_tiles; t0 += bt) {
-      const uint32_t t1 = std::min(b->n_tiles, t0 + bt);
-      for (size_t k = i; k < j; k++)
-        if (!b->steps[k].prologue) {
-          int e = run_step(b->steps[k], t0, t1);
-          if (e) return e;
-        }
-    }
-    i = j;
-  }
-  return WAA_OK;
-}
-
-static int drain_profile(waa_batch* b) {
-  for (auto& p : b->prof) {
-    for (auto& ev : p.pending) {
-      float ms = 0.f;
-      HIP_TRY(hipEventSynchronize(ev.second));
-      HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
-      p.total_ms += (double)ms;
-      p.launches++;
-      (void)hipEventDestroy(ev.first);
-      (void)hipEventDestroy(ev.second);
-    }
-    p.pending.clear();
-  }
-  return 0;
-}
-
-waa_status waa_sync(waa_batch* b) {
-  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
-  if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch has no device");
-  HIP_TRY(hipStreamSynchronize(b->stream));
-  return drain_profile(b);
-}
-
-waa_status waa_download(waa_batch* b, uint32_t inst, uint32_t ch, float* dst, uint64_t frames) {
-  if (!b || inst >= b->n_inst || ch >= b->n_out || frames > b->length)
-    return fail(WAA_ERR_INVALID_ARGUMENT, "download out of range");
-  if (!b->planned || !b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
-  HIP_TRY(hipSetDevice(b->device));
-  HIP_TRY(hipStreamSynchronize(b->stream));
-  const SignalRef& s = b->nodes[0].sig;
-  if ((int)ch < s.nch) {
-    HIP_TRY(hipMemcpy(dst, s.base + (size_t)inst * s.inst_stride + (size_t)ch * s.ch_stride, frames * sizeof(float),
-                      hipMemcpyDeviceToHost));
-  } else {
-    std::memset(dst, 0, frames * sizeof(float));
-  }
-  return WAA_OK;
-}
-
-waa_status waa_download_all(waa_batch* b, float* dst) {
-  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
-  if (!b->planned || !b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
-  HIP_TRY(hipSetDevice(b->device));
-  HIP_TRY(hipStreamSynchronize(b->stream));
-  const SignalRef& s = b->nodes[0].sig;
-  if (b->length == 0) return WAA_OK;
-  if ((uint32_t)s.nch == b->n_out) {
-    HIP_TRY(hipMemcpy2D(dst, b->length * sizeof(float), s.base, s.ch_stride * sizeof(float), b->length * sizeof(float),
-                        (size_t)b->n_inst * b->n_out, hipMemcpyDeviceToHost));
-  } else {
-    for (uint32_t i = 0; i < b->n_inst; i++)
-      for (uint32_t c = 0; c < b->n_out; c++) {
-        int e = waa_download(b, i, c, dst + ((size_t)i * b->n_out + c) * b->length, b->length);
-        if (e) return e;
-      }
-  }
-  return WAA_OK;
-}
-
-waa_status waa_output_device(waa_batch* b, const float** p, uint64_t* is, uint64_t* cs) {
-  if (!b || !b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
-  const SignalRef& s = b->nodes[0].sig;
-  *p = s.base;
-  *is = s.inst_stride;
-  *cs = s.ch_stride;
-  return WAA_OK;
-}
-
-// AnalyserNode pulls (analysis.rs:261-401).  current_time after an offline render never changes, so the
-// spectrum is computed once per (node, instance) and repeated pulls return the same data (analysis.rs:354-357).
-static int analyser_compute(waa_batch* b, uint32_t node, uint32_t inst, Node::AnCache** out) {
-  int e;
-  if ((e = check_node(b, node, WAA_NODE_ANALYSER))) return e;
-  if (inst >= b->n_inst) return fail(WAA_ERR_INVALID_ARGUMENT, "instance out of range");
-  Node& n = b->nodes[node];
-  const int N = n.desc.i[0], M = N / 2;
-  auto it = n.an_cache.find(inst);
-  if (it != n.an_cache.end()) {
-    *out = &it->second;
-    return 0;
-  }
-  Node::AnCache cache;
-  cache.spec.assign(M, 0.f);
-  cache.time.assign(N, 0.f);
-  if (b->planned && b->rendered && n.live) {
-    HIP_TRY(hipSetDevice(b->device));
-    if (!n.d_window) {
-      // generate_blackman (analysis.rs:14-24), f32 with the host libm the reference's f32::cos resolves to
-      std::vector<float> win(N);
-      const float alpha = 0.16f, a0 = (1.f - alpha) / 2.f, a1 = 1.f / 2.f, a2 = alpha / 2.f;
-      for (int i = 0; i < N; i++)
-        win[i] = a0 - a1 * cosf(2.f * PI_F * (float)i / (float)N) + a2 * cosf(4.f * PI_F * (float)i / (float)N);
-      std::vector<Cplx> tw(M), twf(M);
-      for (int t = 0; t < M; t++) {
-        const double x = -2.0 * 3.14159265358979323846 * (double)t / (double)M;
-        const double y = -2.0 * 3.14159265358979323846 * (double)t / (double)N;
-        tw[t] = Cplx{(float)std::cos(x), (float)std::sin(x)};
-        twf[t] = Cplx{(float)std::cos(y), (float)std::sin(y)};
-      }
-      std::vector<float> zeros(M, 0.f);
-      if ((e = dev_upload(b, &n.d_window, win)) || (e = dev_upload(b, &n.d_an_tw, tw)) ||
-          (e = dev_upload(b, &n.d_an_twfull, twf)) || (e = dev_upload(b, &n.d_an_prev, zeros)) ||
-          (e = dev_alloc(b, &n.d_an_spec, (size_t)M)) || (e = dev_alloc(b, &n.d_an_time, (size_t)N)))
-        return e;
-    }
-    AnalyserDesc ad{};
-    ad.sig = n.sig;
-    ad.inst = inst;
-    ad.fft_size = N;
-    ad.frames_written = (uint64_t)b->n_quanta * RQ;
-    ad.smoothing = (float)n.desc.d[0];
-    ad.window = n.d_window;
-    ad.tw = n.d_an_tw;
-    ad.tw_full = n.d_an_twfull;
-    ad.prev = n.d_an_prev;
-    ad.spec_out = n.d_an_spec;
-    ad.time_out = n.d_an_time;
-    launch_analyser(ad, b->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    HIP_TRY(hipMemcpy(cache.spec.data(), n.d_an_spec, (size_t)M * sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cache.time.data(), n.d_an_time, (size_t)N * sizeof(float), hipMemcpyDeviceToHost));
-  }
-  auto ins = n.an_cache.emplace(inst, std::move(cache));
-  *out = &ins.first->second;
-  return 0;
-}
-
-waa_status waa_analyser_get_float_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t nn) {
-  Node::AnCache* c;
-  int e = analyser_compute(b, node, inst, &c);
-  if (e) return e;
-  const uint32_t len = std::min<uint32_t>(nn, (uint32_t)c->spec.size());
-  for (uint32_t k = 0; k < len; k++) dst[k] = 20.f * log10f(c->spec[k]);  // analysis.rs:365-368
-  return WAA_OK;
-}
-waa_status waa_analyser_get_byte_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t nn) {
-  Node::AnCache* c;
-  int e = analyser_compute(b, node, inst, &c);
-  if (e) return e;
-  const Node& n = b->nodes[node];
-  const float mind = (float)n.desc.d[1], maxd = (float)n.desc.d[2];
-  const uint32_t len = std::min<uint32_t>(nn, (uint32_t)c->spec.size());
-  for (uint32_t k = 0; k < len; k++) {  // analysis.rs:388-400
-    const float db = 20.f * log10f(c->spec[k]);
-    const float scaled = 255.f / (maxd - mind) * (db - mind);
-    const float clamped = scaled < 0.f ? 0.f : scaled > 255.f ? 255.f : scaled;
-    dst[k] = std::isnan(scaled) ? 0 : (uint8_t)clamped;
-  }
-  return WAA_OK;
-}
-waa_status waa_analyser_get_float_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t nn) {
-  Node::AnCache* c;
-  int e = analyser_compute(b, node, inst, &c);
-  if (e) return e;
-  const uint32_t N = (uint32_t)c->time.size();
-  const uint32_t len = std::min(nn, N);  // ring_buffer.read: the most recent `len` frames (analysis.rs:114-127)
-  for (uint32_t i = 0; i < len; i++) dst[i] = c->time[N - len + i];
-  return WAA_OK;
-}
-waa_status waa_analyser_get_byte_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t nn) {
-  Node::AnCache* c;
-  int e = analyser_compute(b, node, inst, &c);
-  if (e) return e;
-  const uint32_t N = (uint32_t)c->time.size();
-  const uint32_t len = std::min(nn, N);
-  for (uint32_t i = 0; i < nn; i++) {  // analysis.rs:268-276 (elements past fft_size read a zeroed tmp)
-    const float v = i < len ? c->time[N - len + i] : 0.f;
-    const float scaled = 128.f * (1.f + v);
-    const float clamped = scaled < 0.f ? 0.f : scaled > 255.f ? 255.f : scaled;
-    dst[i] = (uint8_t)clamped;
-  }
-  return WAA_OK;
-}
-
-// buffer.rs:311-363 (input prep, host side)
-uint64_t waa_buffer_resample(const float* src, uint64_t frames, float source_sr, float target_sr, float* dst, uint64_t cap) {
-  if (std::fabs(source_sr - target_sr) <= 0.1f || frames == 0) {
-    if (dst)
-      for (uint64_t i = 0; i < frames && i < cap; i++) dst[i] = src[i];
-    return frames;
-  }
-  const double ratio = (double)target_sr / (double)source_sr;
-  const uint64_t tl = (uint64_t)std::ceil((double)frames * ratio);
-  if (!dst) return tl;
-  for (uint64_t i = 0; i < tl && i < cap; i++) {
-    const double position = (double)i / (double)(tl - 1);
-    const double playhead = position * (double)(frames - 1);
-    const double pf = std::floor(playhead);
-    const uint64_t prev = (uint64_t)pf;
-    const uint64_t next = std::min<uint64_t>(prev + 1, frames - 1);
-    const float k = (float)(playhead - pf), kinv = 1.f - k;
-    dst[i] = kinv * src[prev] + k * src[next];
-  }
-  return tl;
-}
-
-// iir_filter.rs:218-262 (control side, host)
-waa_status waa_iir_frequency_response(const double* ff, uint32_t nff, const double* fb, uint32_t nfb, float sample_rate,
-                                      const float* hz, float* mag, float* phase, uint32_t n) {
-  if (int e = check_iir_coefs(ff, nff, fb, nfb)) return e;
-  if (n && (!hz || !mag || !phase)) return fail(WAA_ERR_INVALID_ARGUMENT, "null array");
-  const double sr = (double)sample_rate, nyquist = sr / 2.;
-  for (uint32_t i = 0; i < n; i++) {
-    const double freq = (double)hz[i];
-    if (freq < 0. || freq > nyquist) {
-      mag[i] = std::nanf("");
-      phase[i] = std::nanf("");
-      continue;
-    }
-    const double z = -2.0 * 3.14159265358979323846 * freq / sr;
-    std::complex<double> num(0., 0.), den(0., 0.);
-    for (uint32_t k = 0; k < nff; k++) num += std::complex<double>(ff[k] * std::cos((double)k * z), ff[k] * std::sin((double)k * z));
-    for (uint32_t k = 0; k < nfb; k++) den += std::complex<double>(fb[k] * std::cos((double)k * z), fb[k] * std::sin((double)k * z));
-    const double ns = den.real() * den.real() + den.imag() * den.imag();
-    const double rr = (num.real() * den.real() + num.imag() * den.imag()) / ns;
-    const double ri = (num.imag() * den.real() - num.real() * den.imag()) / ns;
-    mag[i] = (float)std::hypot(rr, ri);
-    phase[i] = (float)std::atan2(ri, rr);
-  }
-  return WAA_OK;
-}
-
-// biquad_filter.rs:670-735 (control side, host)
-waa_status waa_biquad_frequency_response(int32_t type, float sample_rate, float frequency, float detune, float q,
-                                         float gain, const float* hz, float* mag, float* phase, uint32_t n) {
-  if (type < 0 || type > 7) return fail(WAA_ERR_INVALID_ARGUMENT, "bad filter type");
-  const double PI = 3.14159265358979323846;
-  const float nyq = sample_rate / 2.f;
-  const Coefs c = biquad_coefs(type, (double)sample_rate, (double)computed_freq(frequency, detune), (double)gain, (double)q);
-  for (uint32_t i = 0; i < n; i++) {
-    const float f = hz[i];
-    if (f < 0.f || f > nyq) {
-      mag[i] = NAN;
-      phase[i] = NAN;
-      continue;
-    }
-    const float fn = f / nyq;
-    const double omega = -PI * (double)fn;
-    const double zr = std::cos(omega), zi = std::sin(omega);
-    const double tr = c.b1 + c.b2 * zr, ti = c.b2 * zi;
-    const double nr = c.b0 + (tr * zr - ti * zi), ni = tr * zi + ti * zr;
-    const double ur = c.a1 + c.a2 * zr, ui = c.a2 * zi;
-    const double dr = 1. + (ur * zr - ui * zi), di = ur * zi + ui * zr;
-    const double den = dr * dr + di * di;
-    const double rr = (nr * dr + ni * di) / den, ri = (ni * dr - nr * di) / den;
-    mag[i] = (float)std::hypot(rr, ri);
-    phase[i] = (float)std::atan2(ri, rr);
-  }
-  return WAA_OK;
-}
-
-waa_status waa_profile_enable(waa_batch* b, int32_t on) {
-  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
-  b->profiling = on != 0;
-  return WAA_OK;
-}
-int32_t waa_profile_count(waa_batch* b) { return b ? (int32_t)b->prof.size() : 0; }
-waa_status waa_profile_get(waa_batch* b, int32_t i, const char** name, uint64_t* launches, double* ms) {
-  if (!b || i < 0 || i >= (int32_t)b->prof.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "profile index out of range");
-  *name = b->prof[i].name.c_str();
-  *launches = b->prof[i].launches;
-  *ms = b->prof[i].total_ms;
-  return WAA_OK;
-}
-waa_status waa_profile_reset(waa_batch* b) {
-  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
-  for (auto& p : b->prof) {
-    p.launches = 0;
-    p.total_ms = 0;
-  }
-  return WAA_OK;
-}
-
-}  // extern "C"
+}  // namespace host
+}  // namespace waa
