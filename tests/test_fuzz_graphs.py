@@ -1,0 +1,192 @@
+"""Randomised graph parity: seeded random Web Audio graphs (sources, filters, panners, delays, fan-in / fan-out,
+AudioParam modulation, feedback loops through DelayNodes) rendered by the HIP path and by the oracle.
+This is the planner's safety net: processing order, summing order, channel-count propagation, materialisation,
+chain fusion, loop scheduling and param chains all have to agree with the reference's per-quantum graph walk.
+
+A graph the device path refuses with status 4 (out of scope, e.g. a biquad on a 4-channel signal) is skipped —
+refusing loudly is the contract; mis-rendering is the failure."""
+import os
+
+import numpy as np
+import pytest
+from scipy import signal
+
+import web_audio_api_rs_amd as waa
+from graphs import rms_err, white_noise
+
+RQ = 128
+SR = 48000.0
+N_INST = 2
+# Sources that start late change the reference's DYNAMIC channel counts mid-render (a silent input is mono); the
+# device plan uses static counts and says so in the plan; such graphs are skipped below.
+LATE_STARTS = True
+FRAMES = 2048 * 5 + 200
+
+
+def build_random_graph(be, seed):
+    rng = np.random.default_rng(seed)
+    c = waa.OfflineAudioContext(2, FRAMES, SR, n_instances=N_INST, binding=be)
+    outputs = []      # nodes that can feed others
+    descr = []
+
+    def add_source():
+        kind = rng.choice(["buffer1", "buffer2", "buffer2", "constant", "osc"])
+        if os.environ.get("FUZZ_STEREO_ONLY"):
+            kind = "buffer2"
+        if kind.startswith("buffer"):
+            nch = int(kind[-1])
+            n = c.create_buffer_source()
+            n.set_buffer_batch(white_noise(N_INST, nch, FRAMES, seed0=int(rng.integers(1, 1 << 20))) * 0.5, SR)
+            if LATE_STARTS and rng.random() < 0.3:
+                n.start_at(float(rng.integers(0, 600)) / SR)
+            else:
+                n.start()
+        elif kind == "constant":
+            n = c.create_constant_source(offset=float(rng.uniform(-0.5, 0.5)))
+            n.start_at(float(rng.integers(0, 300)) / SR if LATE_STARTS else 0.0)
+        else:
+            n = c.create_oscillator(type_=str(rng.choice(["sine", "triangle", "sawtooth", "square"])),
+                                    frequency=float(rng.uniform(50.0, 2000.0)))
+            n.start()
+        outputs.append(n)
+        descr.append(kind)
+        return n
+
+    def add_processor():
+        kind = str(rng.choice(["gain", "gain", "biquad", "biquad", "iir", "shaper", "pan", "delay", "delay", "conv"]))
+        if kind == "gain":
+            n = c.create_gain(gain=float(rng.uniform(-1.0, 1.0)))
+        elif kind == "biquad":
+            n = c.create_biquad_filter(type_=str(rng.choice(["lowpass", "highpass", "bandpass", "peaking", "notch"])),
+                                       frequency=float(rng.uniform(100.0, 8000.0)), q=float(rng.uniform(0.3, 4.0)),
+                                       gain=float(rng.uniform(-6.0, 6.0)))
+        elif kind == "iir":
+            b, a = signal.butter(int(rng.integers(1, 5)), float(rng.uniform(0.1, 0.6)))
+            n = c.create_iir_filter(b, a)
+        elif kind == "shaper":
+            n = c.create_wave_shaper(curve=np.tanh(np.linspace(-2.0, 2.0, int(rng.choice([3, 64, 257])))).astype(np.float32))
+        elif kind == "pan":
+            n = c.create_stereo_panner(pan=float(rng.uniform(-1.0, 1.0)))
+        elif kind == "delay":
+            n = c.create_delay(0.1, delay_time=float(rng.choice([0.0, 0.0007, 0.003, 0.01, 0.05, 0.09])))
+        else:
+            ir = (rng.uniform(-1, 1, (int(rng.choice([1, 2])), int(rng.choice([16, 100, 700])))) *
+                  np.exp(-np.arange(1)[None, :])).astype(np.float32)
+            n = c.create_convolver(buffer=waa.AudioBuffer(ir, SR))
+        descr.append(kind)
+        return n
+
+    for _ in range(int(rng.integers(1, 4))):
+        add_source()
+    procs = []
+    for _ in range(int(rng.integers(2, 8))):
+        n = add_processor()
+        # 1..3 inputs from anything created so far (forward edges only: a DAG)
+        for src in rng.choice(len(outputs), size=min(len(outputs), int(rng.integers(1, 4))), replace=False):
+            outputs[int(src)].connect(n)
+        outputs.append(n)
+        procs.append(n)
+    # feedback: a later node back into an earlier DelayNode (the delay breaks the cycle), attenuated
+    delays = [p for p in procs if isinstance(p, waa.DelayNode)]
+    if delays and rng.random() < 0.6:
+        d = delays[int(rng.integers(0, len(delays)))]
+        later = [p for p in procs[procs.index(d):] if not isinstance(p, (waa.ConvolverNode, waa.IIRFilterNode))]
+        tail = later[int(rng.integers(0, len(later)))]
+        fb = c.create_gain(gain=float(rng.uniform(-0.5, 0.5)))
+        tail.connect(fb).connect(d)
+        descr.append("feedback")
+    # audio-rate modulation of a param from a source
+    gains = [p for p in procs if isinstance(p, waa.GainNode)]
+    if gains and rng.random() < 0.5:
+        lfo = c.create_oscillator(type_="sine", frequency=float(rng.uniform(1.0, 20.0)))
+        depth = c.create_gain(gain=float(rng.uniform(0.05, 0.4)))
+        lfo.connect(depth).connect(gains[0].gain)
+        lfo.start()
+        descr.append("param-mod")
+    # everything without a consumer goes to the destination, plus one random extra tap
+    fed = {e[0] for e in c._edges}
+    for n in outputs:
+        if n.id not in fed:
+            n.connect(c.destination())
+    outputs[int(rng.integers(0, len(outputs)))].connect(c.destination())
+    return c, "+".join(descr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", "60"))))
+def test_random_graph_parity(hip, orc, seed):
+    ch, descr = build_random_graph(hip, seed)
+    try:
+        plan = ch.plan_describe()
+        g = ch.start_rendering_sync().data
+    except waa.WaaError as e:
+        if e.status == 4:
+            pytest.skip(f"out of scope on the device path: {e} [{descr}]")
+        raise
+    ch.close()
+    if "dynamic channel count" in plan:
+        # the planner itself reports that this graph changes its channel count mid-render (a narrow input is
+        # active while a wider one is still silent): the documented static-count divergence, DESIGN.md section 5
+        pytest.skip(f"planner note: dynamic channel count [{descr}]")
+    co, _ = build_random_graph(orc, seed)
+    o = co.start_rendering_sync().data
+    co.close()
+    assert np.isfinite(o).all(), descr
+    scale = max(1.0, float(np.abs(o).max()))
+    err = np.abs(g - o).max()
+    assert rms_err(g, o).max() <= 1e-6 * scale, f"{descr}: rms {rms_err(g, o).max():.3g}"
+    assert err <= 2e-5 * scale, f"{descr}: max |d| {err:.3g}"
+
+
+def test_random_graphs_plan_on_cpu(hip):
+    """the same graphs go through the planner without a device (plan-only batches): no crash, a plan or status 4"""
+    planned = 0
+    for seed in range(60):
+        rng_state = seed
+
+        def mk(be):
+            return build_random_graph(be, rng_state)
+
+        c, descr = mk(hip)
+        c.device = waa.PLAN_ONLY
+        try:
+            text = c.plan_describe()
+            planned += 1
+            assert "batch:" in text
+        except waa.WaaError as e:
+            assert e.status == 4, f"{descr}: {e}"
+        c.close()
+    assert planned >= 40
+
+
+@pytest.mark.gpu
+def test_dynamic_channel_count_divergence_is_reported(hip, orc, monkeypatch):
+    """A mono oscillator from t = 0 plus a stereo buffer that starts later, into a BiquadFilter: the reference
+    filters ONE channel until the stereo source starts and then starts channel 1 from a zero state
+    (biquad_filter.rs:800-815); the device plan filters two channels throughout.  The planner reports it, and
+    WAA_STRICT_CHANNEL_COUNTS turns the report into a refusal."""
+    def build(be):
+        c = waa.OfflineAudioContext(2, FRAMES, SR, n_instances=1, binding=be)
+        osc = c.create_oscillator(frequency=220.0)
+        buf = c.create_buffer_source()
+        buf.set_buffer_batch(white_noise(1, 2, FRAMES, seed0=3), SR)
+        bq = c.create_biquad_filter(type_="lowpass", frequency=300.0)
+        osc.connect(bq)
+        buf.connect(bq)
+        bq.connect(c.destination())
+        osc.start()
+        buf.start_at(1000.0 / SR)
+        return c
+    c = build(hip)
+    assert "dynamic channel count" in c.plan_describe()
+    g = c.start_rendering_sync().data
+    c.close()
+    o = build(orc).start_rendering_sync().data
+    # identical until the stereo source starts, different afterwards (channel 1's filter state)
+    assert np.abs(g[:, :, :896] - o[:, :, :896]).max() <= 1e-6
+    assert np.abs(g[:, 1, 1024:] - o[:, 1, 1024:]).max() > 1e-4
+    monkeypatch.setenv("WAA_STRICT_CHANNEL_COUNTS", "1")
+    c = build(hip)
+    with pytest.raises(waa.WaaError) as ei:
+        c.start_rendering_sync()
+    assert ei.value.status == 4

@@ -609,6 +609,102 @@ int build_plan(waa_batch* b) {
   }
   if (!changed || n_scc == 0) break;
   }
+  // Static vs dynamic channel counts.  The reference counts a silent input as mono, so a node fed by a narrow and a
+  // wide producer changes its channel count when the wide one starts later or ends earlier; count-sensitive nodes
+  // (filters keep per-channel state, the panners use a different law for mono input, the convolver routes by
+  // count) then differ from this plan, which renders the static (maximal) count throughout.  Detected here from
+  // the host-known activity windows of the sources (start/stop/duration; a node with memory stays active once
+  // started) and reported in the plan; WAA_STRICT_CHANNEL_COUNTS turns the note into status 4.
+  {
+    const double qsec = (double)RQ / (double)b->sr;
+    const double render_end = (double)b->n_quanta, inf = 1e300;
+    // per node: [act_lo, act_hi) = quanta with a non-silent output, [wide_lo, wide_hi) = quanta where that output
+    // carries the static (maximal) channel count
+    std::vector<double> act_lo(N), act_hi(N), wide_lo(N), wide_hi(N);
+    bool reported = false;
+    const int passes = n_scc > 0 ? 4 : 1;  // windows travel once around a feedback loop per pass
+    for (uint32_t inst = 0; inst < b->n_inst && !reported; inst++) {
+      std::fill(act_lo.begin(), act_lo.end(), inf);
+      std::fill(wide_lo.begin(), wide_lo.end(), inf);
+      std::fill(act_hi.begin(), act_hi.end(), -1.);
+      std::fill(wide_hi.begin(), wide_hi.end(), -1.);
+      for (int pass = 0; pass < passes && !reported; pass++)
+      for (uint32_t id : b->order) {
+        Node& n = b->nodes[id];
+        if (!n.live) continue;
+        const uint32_t kind = n.desc.kind;
+        if (kind == WAA_NODE_BUFFER_SOURCE || kind == WAA_NODE_CONSTANT_SOURCE || kind == WAA_NODE_OSCILLATOR) {
+          const SourceSched& ss = n.sched[inst];
+          double lo = ss.start == DBL_MAX ? inf : std::floor(ss.start / qsec), hi = inf;
+          if (ss.stop != DBL_MAX) hi = std::ceil(ss.stop / qsec);
+          if (kind == WAA_NODE_BUFFER_SOURCE && !ss.looping && n.bufs[inst].valid) {
+            const auto rate = param_per_quantum(b, n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE], inst, nullptr);
+            double rmin = inf;
+            for (float r : rate) rmin = std::min(rmin, (double)std::fabs(r));
+            const double dur = std::min(ss.duration, (double)n.bufs[inst].frames / (double)n.bufs[inst].sr) / std::max(rmin, 1e-9);
+            hi = std::min(hi, std::ceil((ss.start + dur) / qsec) + 1.);
+          }
+          act_lo[id] = wide_lo[id] = lo;
+          act_hi[id] = wide_hi[id] = hi;
+          continue;
+        }
+        double alo = inf, ahi = -1., wlo = inf, whi = -1., nhi = -1.;
+        for (int e : n.in_edges) {
+          const uint32_t p = b->edges[e].from;
+          alo = std::min(alo, act_lo[p]);
+          ahi = std::max(ahi, act_hi[p]);
+          const bool wide = n.in_nch <= 1 || std::min(b->nodes[p].out_nch, std::max(n.cc, 1)) >= n.in_nch ||
+                            b->nodes[p].out_nch >= n.in_nch;
+          if (wide) {
+            wlo = std::min(wlo, n.in_nch <= 1 ? act_lo[p] : wide_lo[p]);
+            whi = std::max(whi, n.in_nch <= 1 ? act_hi[p] : wide_hi[p]);
+          } else {
+            nhi = std::max(nhi, act_hi[p]);
+          }
+        }
+        const bool memory = kind == WAA_NODE_BIQUAD || kind == WAA_NODE_IIR_FILTER || kind == WAA_NODE_CONVOLVER || kind == WAA_NODE_DELAY;
+        const bool sensitive = kind == WAA_NODE_BIQUAD || kind == WAA_NODE_IIR_FILTER || kind == WAA_NODE_STEREO_PANNER ||
+                               kind == WAA_NODE_PANNER || (kind == WAA_NODE_CONVOLVER && n.has_ir);
+        if (pass == passes - 1 && sensitive && n.in_nch > 1 && !n.in_edges.empty() && !reported) {
+          const bool late = wlo > alo && alo < render_end;                      // narrower signal first
+          const bool early_end = whi < std::min(ahi, render_end) && whi >= 0.;  // the wide part ends first
+          if (late || early_end) {
+            plan_note(b,
+                      "note: the input of node %u does not carry its static channel count over all active quanta (instance %u): "
+                      "the reference's dynamic channel count changes mid-render, the device renders %d channel(s) throughout "
+                      "(DESIGN.md section 5)",
+                      id, inst, n.in_nch);
+            reported = true;
+            if (getenv("WAA_STRICT_CHANNEL_COUNTS"))
+              return fail(WAA_ERR_OUT_OF_SCOPE,
+                          "node %u: dynamic channel-count change (a narrower signal is active while the wider one is silent) "
+                          "is not rendered exactly on the device path",
+                          id);
+          }
+        }
+        // output windows
+        double shift = 0.;
+        if (kind == WAA_NODE_DELAY && param_mode(n, WAA_PARAM_DELAY_DELAY_TIME) != 2) {
+          // the reader's output stays silent (mono) until the first delayed block arrives (delay.rs:646-662)
+          double dmin = inf;
+          for (float dv : param_per_quantum(b, n.params[WAA_PARAM_DELAY_DELAY_TIME], inst, nullptr)) dmin = std::min(dmin, (double)dv);
+          shift = std::floor(dmin / qsec);
+          if (id < b->cut.size() && b->cut[id]) shift = std::max(shift, 1.);  // inside a loop: at least one quantum
+        }
+        act_lo[id] = alo + shift;
+        act_hi[id] = memory ? inf : ahi;
+        const bool fixed_out = kind == WAA_NODE_STEREO_PANNER || kind == WAA_NODE_PANNER ||
+                               (kind == WAA_NODE_CONVOLVER && n.has_ir && n.ir_nch >= 2);
+        if (fixed_out || n.out_nch <= 1) {
+          wide_lo[id] = act_lo[id];
+          wide_hi[id] = act_hi[id];
+        } else {
+          wide_lo[id] = wlo + shift;
+          wide_hi[id] = (nhi > whi) ? whi : (memory ? inf : whi);  // a narrower input outlives the wide one
+        }
+      }
+    }
+  }
   // materialisation points
   for (uint32_t id = 0; id < N; id++) {
     Node& n = b->nodes[id];
@@ -1361,6 +1457,13 @@ int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items) {
       int e = emit_node_ops(b, id, n.in_nch, true, ops, &out_nch);
       if (e) return e;
       if (ops.size() > 1) return fail(WAA_ERR_OUT_OF_SCOPE, "node %u cannot be rendered inside a feedback loop", id);
+      if (ops.empty()) {  // only true pass-through nodes may render nothing
+        const uint32_t k = n.desc.kind;
+        const bool pass = k == WAA_NODE_ANALYSER || (k == WAA_NODE_WAVESHAPER && !n.has_curve) ||
+                          (k == WAA_NODE_CONVOLVER && !n.has_ir);
+        if (!pass)
+          return fail(WAA_ERR_OUT_OF_SCOPE, "node %u (kind %u) cannot be rendered inside a feedback loop on the device path", id, k);
+      }
       if (!ops.empty()) {
         const OpDesc& o = ops[0];
         const bool ok = o.kind == OP_GAIN || o.kind == OP_BIQUAD || o.kind == OP_WAVESHAPER ||
