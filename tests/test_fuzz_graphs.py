@@ -53,9 +53,32 @@ def build_random_graph(be, seed):
         return n
 
     def add_processor():
-        kind = str(rng.choice(["gain", "gain", "biquad", "biquad", "iir", "shaper", "pan", "delay", "delay", "conv"]))
+        kind = str(rng.choice(["gain", "gain", "biquad", "biquad", "iir", "shaper", "pan", "delay", "delay", "conv",
+                               "panner", "analyser", "cfg-gain", "krate-gain", "krate-biquad"]))
+        nq = (FRAMES + RQ - 1) // RQ
         if kind == "gain":
             n = c.create_gain(gain=float(rng.uniform(-1.0, 1.0)))
+        elif kind == "cfg-gain":  # explicit / clamped-max channel configs, discrete interpretation
+            cc, mode, interp = [(1, "explicit", "speakers"), (2, "explicit", "speakers"), (1, "clamped-max", "speakers"),
+                                (2, "explicit", "discrete"), (4, "explicit", "discrete")][int(rng.integers(0, 5))]
+            n = c.create_gain(gain=float(rng.uniform(0.2, 1.0)), channel_count=cc, channel_count_mode=mode,
+                              channel_interpretation=interp)
+        elif kind == "krate-gain":  # one value per render quantum (includes exact 0 and 1: gain.rs fast paths)
+            n = c.create_gain(gain=0.5)
+            vals = rng.uniform(-1.0, 1.0, nq).astype(np.float32)
+            vals[3::11] = 1.0
+            if rng.random() < 0.25:
+                vals[::7] = 0.0  # a zero gain emits a SILENT (mono) quantum: the planner must flag it
+            n.gain.set_block(0, vals)
+        elif kind == "krate-biquad":
+            n = c.create_biquad_filter(type_="lowpass", frequency=1000.0, q=1.0)
+            n.frequency.set_block(0, np.geomspace(200.0, 6000.0, nq).astype(np.float32))
+        elif kind == "panner":
+            n = c.create_panner(position=tuple(float(v) for v in rng.uniform(-3.0, 3.0, 3)),
+                                distance_model=str(rng.choice(["inverse", "linear", "exponential"])),
+                                ref_distance=float(rng.uniform(0.5, 2.0)))
+        elif kind == "analyser":
+            n = c.create_analyser(fft_size=256)
         elif kind == "biquad":
             n = c.create_biquad_filter(type_=str(rng.choice(["lowpass", "highpass", "bandpass", "peaking", "notch"])),
                                        frequency=float(rng.uniform(100.0, 8000.0)), q=float(rng.uniform(0.3, 4.0)),

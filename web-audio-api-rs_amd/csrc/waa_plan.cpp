@@ -665,7 +665,10 @@ int build_plan(waa_batch* b) {
         const bool memory = kind == WAA_NODE_BIQUAD || kind == WAA_NODE_IIR_FILTER || kind == WAA_NODE_CONVOLVER || kind == WAA_NODE_DELAY;
         const bool sensitive = kind == WAA_NODE_BIQUAD || kind == WAA_NODE_IIR_FILTER || kind == WAA_NODE_STEREO_PANNER ||
                                kind == WAA_NODE_PANNER || (kind == WAA_NODE_CONVOLVER && n.has_ir);
-        if (pass == passes - 1 && sensitive && n.in_nch > 1 && !n.in_edges.empty() && !reported) {
+        // (layouts above stereo and the discrete interpretation are count-sensitive for every node: mono -> quad ->
+        // stereo is not mono -> stereo, and a discrete [m, 0] is not the speakers up-mix [m, m] made upstream)
+        if (pass == passes - 1 && (sensitive || n.in_nch > 2 || n.interp == WAA_INTERP_DISCRETE) && n.in_nch > 1 &&
+            !n.in_edges.empty() && !reported) {
           const bool late = wlo > alo && alo < render_end;                      // narrower signal first
           const bool early_end = whi < std::min(ahi, render_end) && whi >= 0.;  // the wide part ends first
           if (late || early_end) {
@@ -682,6 +685,21 @@ int build_plan(waa_batch* b) {
                           id);
           }
         }
+        // a Gain whose (host-known) value is within 1e-6 of zero emits a SILENT, i.e. mono, quantum (gain.rs:163-170)
+        if (pass == passes - 1 && kind == WAA_NODE_GAIN && !reported && param_mode(n, 0) != 2) {
+          bool zero = false;
+          for (float gv : param_per_quantum(b, n.params[0], inst, nullptr)) zero |= std::fabs(gv) <= 1e-6f;
+          if (zero) {
+            plan_note(b,
+                      "note: Gain node %u is (at times) zero: the reference then emits a silent mono quantum (and so does every "
+                      "widening node behind it), a dynamic channel count change the device does not reproduce (it renders %d "
+                      "channel(s) of zeros; DESIGN.md section 5)",
+                      id, n.out_nch);
+            reported = true;
+            if (getenv("WAA_STRICT_CHANNEL_COUNTS"))
+              return fail(WAA_ERR_OUT_OF_SCOPE, "node %u: a zero gain changes the dynamic channel count", id);
+          }
+        }
         // output windows
         double shift = 0.;
         if (kind == WAA_NODE_DELAY && param_mode(n, WAA_PARAM_DELAY_DELAY_TIME) != 2) {
@@ -694,7 +712,8 @@ int build_plan(waa_batch* b) {
         act_lo[id] = alo + shift;
         act_hi[id] = memory ? inf : ahi;
         const bool fixed_out = kind == WAA_NODE_STEREO_PANNER || kind == WAA_NODE_PANNER ||
-                               (kind == WAA_NODE_CONVOLVER && n.has_ir && n.ir_nch >= 2);
+                               (kind == WAA_NODE_CONVOLVER && n.has_ir && n.ir_nch >= 2) ||
+                               (n.mode == WAA_COUNT_MODE_EXPLICIT && kind != WAA_NODE_DESTINATION);
         if (fixed_out || n.out_nch <= 1) {
           wide_lo[id] = act_lo[id];
           wide_hi[id] = act_hi[id];
