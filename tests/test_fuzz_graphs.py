@@ -36,7 +36,8 @@ def build_random_graph(be, seed):
         if kind.startswith("buffer"):
             nch = int(kind[-1])
             n = c.create_buffer_source()
-            n.set_buffer_batch(white_noise(N_INST, nch, FRAMES, seed0=int(rng.integers(1, 1 << 20))) * 0.5, SR)
+            length = FRAMES if rng.random() < 0.7 else int(rng.integers(300, FRAMES // 2))  # some end early
+            n.set_buffer_batch(white_noise(N_INST, nch, length, seed0=int(rng.integers(1, 1 << 20))) * 0.5, SR)
             if LATE_STARTS and rng.random() < 0.3:
                 n.start_at(float(rng.integers(0, 600)) / SR)
             else:
@@ -44,6 +45,8 @@ def build_random_graph(be, seed):
         elif kind == "constant":
             n = c.create_constant_source(offset=float(rng.uniform(-0.5, 0.5)))
             n.start_at(float(rng.integers(0, 300)) / SR if LATE_STARTS else 0.0)
+            if rng.random() < 0.3:
+                n.stop_at(float(rng.integers(2000, FRAMES)) / SR)
         else:
             n = c.create_oscillator(type_=str(rng.choice(["sine", "triangle", "sawtooth", "square"])),
                                     frequency=float(rng.uniform(50.0, 2000.0)))
@@ -136,7 +139,8 @@ def build_random_graph(be, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEEDS", "60"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_FIRST", "0")),
+                                        int(os.environ.get("FUZZ_FIRST", "0")) + int(os.environ.get("FUZZ_SEEDS", "60"))))
 def test_random_graph_parity(hip, orc, seed):
     ch, descr = build_random_graph(hip, seed)
     try:

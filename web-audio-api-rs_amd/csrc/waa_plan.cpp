@@ -609,119 +609,196 @@ int build_plan(waa_batch* b) {
   }
   if (!changed || n_scc == 0) break;
   }
-  // Static vs dynamic channel counts.  The reference counts a silent input as mono, so a node fed by a narrow and a
-  // wide producer changes its channel count when the wide one starts later or ends earlier; count-sensitive nodes
-  // (filters keep per-channel state, the panners use a different law for mono input, the convolver routes by
-  // count) then differ from this plan, which renders the static (maximal) count throughout.  Detected here from
-  // the host-known activity windows of the sources (start/stop/duration; a node with memory stays active once
-  // started) and reported in the plan; WAA_STRICT_CHANNEL_COUNTS turns the note into status 4.
+  // Static vs dynamic channel counts.  The reference counts a silent input as mono, so the channel count of a
+  // signal changes mid-render when a narrow and a wide producer are not active over the same quanta, when a source
+  // ends, when a Gain is (at times) zero.  Count-sensitive nodes then differ from this plan, which renders the
+  // static (maximal) count throughout: filters keep per-channel state, the panners use another law for mono input,
+  // the convolver routes by count, a DelayNode re-mixes its whole line to the count of the current input, layouts
+  // above stereo and the discrete interpretation do not commute with an earlier speakers up-mix.  The planner
+  // replays the reference's silence / count propagation per quantum from what the host knows (source windows,
+  // delay times, zero gains; data-dependent filter tails are bounded from both sides) and reports the
+  // first affected node in the plan; WAA_STRICT_CHANNEL_COUNTS turns the note into status 4.
   {
+    const uint32_t nq = b->n_quanta;
     const double qsec = (double)RQ / (double)b->sr;
-    const double render_end = (double)b->n_quanta, inf = 1e300;
-    // per node: [act_lo, act_hi) = quanta with a non-silent output, [wide_lo, wide_hi) = quanta where that output
-    // carries the static (maximal) channel count
-    std::vector<double> act_lo(N), act_hi(N), wide_lo(N), wide_hi(N);
+    std::vector<std::vector<uint8_t>> act(N, std::vector<uint8_t>(nq)), cnt(N, std::vector<uint8_t>(nq));
+    std::vector<std::vector<uint8_t>> in_act(N, std::vector<uint8_t>(nq)), in_cnt(N, std::vector<uint8_t>(nq));
+    std::map<std::string, bool> seen;  // instances with identical host-known inputs are simulated once
     bool reported = false;
-    const int passes = n_scc > 0 ? 4 : 1;  // windows travel once around a feedback loop per pass
     for (uint32_t inst = 0; inst < b->n_inst && !reported; inst++) {
-      std::fill(act_lo.begin(), act_lo.end(), inf);
-      std::fill(wide_lo.begin(), wide_lo.end(), inf);
-      std::fill(act_hi.begin(), act_hi.end(), -1.);
-      std::fill(wide_hi.begin(), wide_hi.end(), -1.);
-      for (int pass = 0; pass < passes && !reported; pass++)
+      // per-instance inputs of the simulation
+      std::vector<double> lo(N, 1e300), hi(N, -1.), shift(N, 0.);
+      std::vector<std::vector<uint8_t>> zero_gain(N);
+      std::string sig;
+      auto add_sig = [&](double v) { sig.append(reinterpret_cast<const char*>(&v), sizeof v); };
       for (uint32_t id : b->order) {
         Node& n = b->nodes[id];
         if (!n.live) continue;
         const uint32_t kind = n.desc.kind;
         if (kind == WAA_NODE_BUFFER_SOURCE || kind == WAA_NODE_CONSTANT_SOURCE || kind == WAA_NODE_OSCILLATOR) {
           const SourceSched& ss = n.sched[inst];
-          double lo = ss.start == DBL_MAX ? inf : std::floor(ss.start / qsec), hi = inf;
-          if (ss.stop != DBL_MAX) hi = std::ceil(ss.stop / qsec);
+          lo[id] = ss.start == DBL_MAX ? 1e300 : std::floor(ss.start / qsec);
+          hi[id] = ss.stop != DBL_MAX ? std::ceil(ss.stop / qsec) : 1e300;
           if (kind == WAA_NODE_BUFFER_SOURCE && !ss.looping && n.bufs[inst].valid) {
-            const auto rate = param_per_quantum(b, n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE], inst, nullptr);
-            double rmin = inf;
-            for (float r : rate) rmin = std::min(rmin, (double)std::fabs(r));
+            double rmin = 1e300;
+            for (float r : param_per_quantum(b, n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE], inst, nullptr))
+              rmin = std::min(rmin, (double)std::fabs(r));
             const double dur = std::min(ss.duration, (double)n.bufs[inst].frames / (double)n.bufs[inst].sr) / std::max(rmin, 1e-9);
-            hi = std::min(hi, std::ceil((ss.start + dur) / qsec) + 1.);
+            hi[id] = std::min(hi[id], std::ceil((ss.start + dur) / qsec));
           }
-          act_lo[id] = wide_lo[id] = lo;
-          act_hi[id] = wide_hi[id] = hi;
-          continue;
-        }
-        double alo = inf, ahi = -1., wlo = inf, whi = -1., nhi = -1.;
-        for (int e : n.in_edges) {
-          const uint32_t p = b->edges[e].from;
-          alo = std::min(alo, act_lo[p]);
-          ahi = std::max(ahi, act_hi[p]);
-          const bool wide = n.in_nch <= 1 || std::min(b->nodes[p].out_nch, std::max(n.cc, 1)) >= n.in_nch ||
-                            b->nodes[p].out_nch >= n.in_nch;
-          if (wide) {
-            wlo = std::min(wlo, n.in_nch <= 1 ? act_lo[p] : wide_lo[p]);
-            whi = std::max(whi, n.in_nch <= 1 ? act_hi[p] : wide_hi[p]);
-          } else {
-            nhi = std::max(nhi, act_hi[p]);
+          if (kind == WAA_NODE_BUFFER_SOURCE && !n.bufs[inst].valid) lo[id] = 1e300;
+          add_sig(lo[id]);
+          add_sig(hi[id]);
+        } else if (kind == WAA_NODE_DELAY) {
+          if (param_mode(n, WAA_PARAM_DELAY_DELAY_TIME) != 2) {
+            double dmin = 1e300;
+            for (float dv : param_per_quantum(b, n.params[WAA_PARAM_DELAY_DELAY_TIME], inst, nullptr)) dmin = std::min(dmin, (double)dv);
+            shift[id] = std::floor(dmin / qsec);
           }
-        }
-        const bool memory = kind == WAA_NODE_BIQUAD || kind == WAA_NODE_IIR_FILTER || kind == WAA_NODE_CONVOLVER || kind == WAA_NODE_DELAY;
-        const bool sensitive = kind == WAA_NODE_BIQUAD || kind == WAA_NODE_IIR_FILTER || kind == WAA_NODE_STEREO_PANNER ||
-                               kind == WAA_NODE_PANNER || (kind == WAA_NODE_CONVOLVER && n.has_ir);
-        // (layouts above stereo and the discrete interpretation are count-sensitive for every node: mono -> quad ->
-        // stereo is not mono -> stereo, and a discrete [m, 0] is not the speakers up-mix [m, m] made upstream)
-        if (pass == passes - 1 && (sensitive || n.in_nch > 2 || n.interp == WAA_INTERP_DISCRETE) && n.in_nch > 1 &&
-            !n.in_edges.empty() && !reported) {
-          const bool late = wlo > alo && alo < render_end;                      // narrower signal first
-          const bool early_end = whi < std::min(ahi, render_end) && whi >= 0.;  // the wide part ends first
-          if (late || early_end) {
-            plan_note(b,
-                      "note: the input of node %u does not carry its static channel count over all active quanta (instance %u): "
-                      "the reference's dynamic channel count changes mid-render, the device renders %d channel(s) throughout "
-                      "(DESIGN.md section 5)",
-                      id, inst, n.in_nch);
-            reported = true;
-            if (getenv("WAA_STRICT_CHANNEL_COUNTS"))
-              return fail(WAA_ERR_OUT_OF_SCOPE,
-                          "node %u: dynamic channel-count change (a narrower signal is active while the wider one is silent) "
-                          "is not rendered exactly on the device path",
-                          id);
+          if (id < b->cut.size() && b->cut[id]) shift[id] = std::max(shift[id], 1.);  // inside a loop: >= one quantum
+          add_sig(shift[id]);
+        } else if (kind == WAA_NODE_GAIN && param_mode(n, 0) != 2) {
+          const auto gv = param_per_quantum(b, n.params[0], inst, nullptr);
+          zero_gain[id].assign(nq, 0);
+          bool any = false;
+          for (uint32_t q = 0; q < nq; q++) {
+            zero_gain[id][q] = std::fabs(gv[gv.size() == 1 ? 0 : q]) <= 1e-6f;
+            any |= zero_gain[id][q] != 0;
           }
-        }
-        // a Gain whose (host-known) value is within 1e-6 of zero emits a SILENT, i.e. mono, quantum (gain.rs:163-170)
-        if (pass == passes - 1 && kind == WAA_NODE_GAIN && !reported && param_mode(n, 0) != 2) {
-          bool zero = false;
-          for (float gv : param_per_quantum(b, n.params[0], inst, nullptr)) zero |= std::fabs(gv) <= 1e-6f;
-          if (zero) {
-            plan_note(b,
-                      "note: Gain node %u is (at times) zero: the reference then emits a silent mono quantum (and so does every "
-                      "widening node behind it), a dynamic channel count change the device does not reproduce (it renders %d "
-                      "channel(s) of zeros; DESIGN.md section 5)",
-                      id, n.out_nch);
-            reported = true;
-            if (getenv("WAA_STRICT_CHANNEL_COUNTS"))
-              return fail(WAA_ERR_OUT_OF_SCOPE, "node %u: a zero gain changes the dynamic channel count", id);
-          }
-        }
-        // output windows
-        double shift = 0.;
-        if (kind == WAA_NODE_DELAY && param_mode(n, WAA_PARAM_DELAY_DELAY_TIME) != 2) {
-          // the reader's output stays silent (mono) until the first delayed block arrives (delay.rs:646-662)
-          double dmin = inf;
-          for (float dv : param_per_quantum(b, n.params[WAA_PARAM_DELAY_DELAY_TIME], inst, nullptr)) dmin = std::min(dmin, (double)dv);
-          shift = std::floor(dmin / qsec);
-          if (id < b->cut.size() && b->cut[id]) shift = std::max(shift, 1.);  // inside a loop: at least one quantum
-        }
-        act_lo[id] = alo + shift;
-        act_hi[id] = memory ? inf : ahi;
-        const bool fixed_out = kind == WAA_NODE_STEREO_PANNER || kind == WAA_NODE_PANNER ||
-                               (kind == WAA_NODE_CONVOLVER && n.has_ir && n.ir_nch >= 2) ||
-                               (n.mode == WAA_COUNT_MODE_EXPLICIT && kind != WAA_NODE_DESTINATION);
-        if (fixed_out || n.out_nch <= 1) {
-          wide_lo[id] = act_lo[id];
-          wide_hi[id] = act_hi[id];
-        } else {
-          wide_lo[id] = wlo + shift;
-          wide_hi[id] = (nhi > whi) ? whi : (memory ? inf : whi);  // a narrower input outlives the wide one
+          if (!any) zero_gain[id].clear();
+          for (uint8_t z : zero_gain[id]) sig.push_back((char)z);
+          sig.push_back('|');
         }
       }
+      if (seen.count(sig)) continue;
+      seen[sig] = true;
+      // Tails are data dependent (a filter renders until its state has decayed).  Both bounds are simulated per node
+      // with memory: it falls silent with its input (tail 0), or never again once it was active (tail infinite); a
+      // finding under any combination is reported.
+      std::vector<uint32_t> mem_nodes;
+      for (uint32_t id : b->order) {
+        const Node& n = b->nodes[id];
+        const uint32_t k = n.desc.kind;
+        if (n.live && (k == WAA_NODE_BIQUAD || k == WAA_NODE_IIR_FILTER || k == WAA_NODE_DELAY || (k == WAA_NODE_CONVOLVER && n.has_ir)))
+          mem_nodes.push_back(id);
+      }
+      // every combination of short / long tails for up to 8 nodes with memory, the two uniform bounds beyond that
+      const uint32_t n_modes = mem_nodes.size() <= 8 ? (1u << mem_nodes.size()) : 2u;
+      std::vector<uint8_t> long_tail(N, 0);
+      for (uint32_t tail_mode = 0; tail_mode < n_modes && !reported; tail_mode++) {
+      for (size_t k = 0; k < mem_nodes.size(); k++)
+        long_tail[mem_nodes[k]] = mem_nodes.size() <= 8 ? ((tail_mode >> k) & 1u) : (uint8_t)tail_mode;
+      for (uint32_t id = 0; id < N; id++) {
+        std::fill(act[id].begin(), act[id].end(), 0);
+        std::fill(cnt[id].begin(), cnt[id].end(), 1);
+      }
+      const int passes = n_scc > 0 ? 4 : 1;  // activity travels once around a feedback loop per pass
+      for (int pass = 0; pass < passes; pass++)
+        for (uint32_t id : b->order) {
+          Node& n = b->nodes[id];
+          if (!n.live) continue;
+          const uint32_t kind = n.desc.kind;
+          if (kind == WAA_NODE_BUFFER_SOURCE || kind == WAA_NODE_CONSTANT_SOURCE || kind == WAA_NODE_OSCILLATOR) {
+            for (uint32_t q = 0; q < nq; q++) {
+              act[id][q] = (double)q >= lo[id] && (double)q < hi[id];
+              cnt[id][q] = act[id][q] ? (uint8_t)n.out_nch : 1;
+            }
+            continue;
+          }
+          for (uint32_t q = 0; q < nq; q++) {
+            uint8_t a = 0, c = 1;
+            for (int e : n.in_edges) {
+              const uint32_t p = b->edges[e].from;
+              a |= act[p][q];
+              c = std::max(c, cnt[p][q]);
+            }
+            in_act[id][q] = a;
+            in_cnt[id][q] = (uint8_t)computed_in_nch(n, c);
+          }
+          for (uint32_t q = 0; q < nq; q++) {
+            uint8_t a = in_act[id][q], c = in_cnt[id][q];
+            if (kind == WAA_NODE_DELAY) {
+              // the data is `shift` quanta old; the channel count is the line's, which follows the writer's CURRENT
+              // input (delay.rs:469-489) — of the previous quantum when the reader renders first (inside a loop)
+              const int64_t qs = (int64_t)q - (int64_t)shift[id];
+              a = qs >= 0 ? in_act[id][qs] : 0;
+              const bool in_loop = id < b->cut.size() && b->cut[id];
+              const int64_t qc = in_loop ? (int64_t)q - 1 : (int64_t)q;
+              c = qc >= 0 ? in_cnt[id][qc] : 1;
+            } else if (kind == WAA_NODE_GAIN && !zero_gain[id].empty() && zero_gain[id][q]) {
+              a = 0;
+            }
+            if (a) {
+              if (kind == WAA_NODE_STEREO_PANNER || kind == WAA_NODE_PANNER) c = 2;
+              if (kind == WAA_NODE_CONVOLVER && n.has_ir) c = (c == 1 && n.ir_nch == 1) ? 1 : 2;
+            }
+            const bool has_memory = kind == WAA_NODE_BIQUAD || kind == WAA_NODE_IIR_FILTER || kind == WAA_NODE_DELAY ||
+                                    (kind == WAA_NODE_CONVOLVER && n.has_ir);
+            if (has_memory && long_tail[id] && !a && q > 0 && act[id][q - 1]) {  // still ringing, with the old layout
+              a = 1;
+              c = cnt[id][q - 1];
+            }
+            act[id][q] = a;
+            cnt[id][q] = a ? c : 1;
+          }
+        }
+      // findings
+      for (uint32_t id : b->order) {
+        Node& n = b->nodes[id];
+        if (!n.live || n.in_nch <= 1 || n.in_edges.empty()) continue;
+        const uint32_t kind = n.desc.kind;
+        const bool line = kind == WAA_NODE_DELAY || (kind == WAA_NODE_CONVOLVER && n.has_ir);
+        const bool sensitive = kind == WAA_NODE_BIQUAD || kind == WAA_NODE_IIR_FILTER || kind == WAA_NODE_STEREO_PANNER ||
+                               kind == WAA_NODE_PANNER || line || n.in_nch > 2 || n.interp == WAA_INTERP_DISCRETE;
+        if (!sensitive) continue;
+        // a DelayNode up-mixes its line by copying when the wide signal arrives (= the static plan) but collapses it
+        // when the input narrows or falls silent while the line still holds wide material
+        const bool narrowing_only = kind == WAA_NODE_DELAY && n.in_nch <= 2 && n.interp != WAA_INTERP_DISCRETE;
+        int64_t last_wide = -1;
+        const int64_t memory_q = kind == WAA_NODE_DELAY ? (int64_t)std::ceil(n.desc.d[0] / qsec) + 1
+                                 : kind == WAA_NODE_CONVOLVER ? (int64_t)(n.ir_len / RQ) + 2 : 0;
+        const char* what = nullptr;
+        uint32_t at = 0;
+        for (uint32_t q = 0; q < nq && !what; q++) {
+          const bool wide_now = in_act[id][q] && in_cnt[id][q] >= n.in_nch;
+          if (in_act[id][q] && !wide_now && !(narrowing_only && last_wide < 0)) {
+            if (!narrowing_only || (int64_t)q - last_wide <= memory_q) {
+              what = "is narrower than its static channel count";
+              at = q;
+            }
+          }
+          if (line && !in_act[id][q] && last_wide >= 0 && (int64_t)q - last_wide <= memory_q && (int64_t)q - last_wide >= 1) {
+            what = "falls silent (= mono) while the node still holds multi-channel material";
+            at = q;
+          }
+          if (wide_now) last_wide = q;
+        }
+        // mixing rules that do not commute with the speakers up-mix the static plan applied upstream: an input that
+        // is active but narrower than its static width, into a discrete or wider-than-stereo mix
+        if (!what)
+          for (int e : n.in_edges) {
+            const uint32_t p = b->edges[e].from;
+            const int pw = b->nodes[p].out_nch;
+            if (!(n.interp == WAA_INTERP_DISCRETE || n.in_nch > 2 || pw > 2)) continue;
+            for (uint32_t q = 0; q < nq && !what; q++)
+              if (act[p][q] && cnt[p][q] < pw) {
+                what = "mixes a signal that is narrower than its static width with a rule that does not commute with the "
+                       "speakers up-mix made upstream (discrete interpretation or more than two channels);";
+                at = q;
+              }
+          }
+        if (what) {
+          plan_note(b,
+                    "note: the input of node %u %s at quantum %u (instance %u): the reference's dynamic channel count changes "
+                    "mid-render, the device renders %d channel(s) throughout (DESIGN.md section 5)",
+                    id, what, at, inst, n.in_nch);
+          reported = true;
+          if (getenv("WAA_STRICT_CHANNEL_COUNTS"))
+            return fail(WAA_ERR_OUT_OF_SCOPE, "node %u: a dynamic channel-count change is not rendered exactly on the device path", id);
+          break;
+        }
+      }
+      }  // tail_mode
     }
   }
   // materialisation points
