@@ -143,3 +143,90 @@ def test_channel_limits_are_reported_loudly(hip):
     with pytest.raises(waa.WaaError) as e:
         ctx.plan_describe()
     assert e.value.status == 4 and "limited to 2 channels" in str(e.value)
+
+
+# --------------------------------------------------------------------------- dynamic channel-count notes
+def _plan_only(n_ch=2, frames=RQ * 40):
+    return waa.OfflineAudioContext(n_ch, frames, 48000.0, n_instances=2, binding=waa.default_binding(), device=waa.PLAN_ONLY)
+
+
+def _buffer(c, nch, frames, start=0.0):
+    s = c.create_buffer_source()
+    s.set_buffer_batch(np.zeros((2, nch, frames), np.float32), 48000.0)
+    s.start_at(start)
+    return s
+
+
+def test_note_mono_first_then_stereo_into_a_filter():
+    """the reference filters one channel until the stereo source starts (biquad_filter.rs:800-815)"""
+    c = _plan_only()
+    mono, stereo = _buffer(c, 1, RQ * 40), _buffer(c, 2, RQ * 40, start=RQ * 5 / 48000.0)
+    bq = c.create_biquad_filter()
+    mono.connect(bq)
+    stereo.connect(bq)
+    bq.connect(c.destination())
+    plan = c.plan_describe()
+    assert "dynamic channel count" in plan and "narrower than its static channel count at quantum 0" in plan
+    c.close()
+
+
+def test_no_note_when_widths_agree_over_time():
+    """same graph, both sources from t = 0: the count never changes; a lone stereo source that ends early keeps the
+    filter's count while it rings (biquad_filter.rs:786-798)"""
+    c = _plan_only()
+    mono, stereo = _buffer(c, 1, RQ * 40), _buffer(c, 2, RQ * 40)
+    bq = c.create_biquad_filter()
+    mono.connect(bq)
+    stereo.connect(bq)
+    bq.connect(c.destination())
+    assert "dynamic channel count" not in c.plan_describe()
+    c.close()
+    c = _plan_only()
+    short = _buffer(c, 2, RQ * 3)
+    bq = c.create_biquad_filter()
+    short.connect(bq).connect(c.destination())
+    assert "dynamic channel count" not in c.plan_describe()
+    c.close()
+
+
+def test_note_delay_line_collapses_when_its_stereo_input_ends():
+    """delay.rs:469-489: the line is re-mixed to the channel count of the current (silent = mono) input"""
+    c = _plan_only()
+    short = _buffer(c, 2, RQ * 3)
+    d = c.create_delay(0.1, delay_time=0.05)
+    short.connect(d).connect(c.destination())
+    plan = c.plan_describe()
+    assert "falls silent (= mono) while the node still holds multi-channel material" in plan
+    c.close()
+    # a mono input into the same delay never changes the count
+    c = _plan_only()
+    short = _buffer(c, 1, RQ * 3)
+    d = c.create_delay(0.1, delay_time=0.05)
+    short.connect(d).connect(c.destination())
+    assert "dynamic channel count" not in c.plan_describe()
+    c.close()
+
+
+def test_note_zero_gain_in_front_of_a_panner_and_strict_mode(monkeypatch):
+    """gain.rs:163-170: |g| <= 1e-6 emits a silent (mono) quantum; the StereoPanner behind it then sees mono"""
+    def build():
+        c = _plan_only()
+        a, b2 = _buffer(c, 2, RQ * 40), _buffer(c, 1, RQ * 40)
+        g = c.create_gain(gain=1.0)
+        vals = np.ones(40, np.float32)
+        vals[10:20] = 0.0
+        g.gain.set_block(0, vals)
+        pan = c.create_stereo_panner(pan=0.3)
+        a.connect(g).connect(pan)
+        b2.connect(pan)
+        pan.connect(c.destination())
+        return c
+    c = build()
+    assert "narrower than its static channel count at quantum 10" in c.plan_describe()
+    c.close()
+    monkeypatch.setenv("WAA_STRICT_CHANNEL_COUNTS", "1")
+    c = build()
+    with pytest.raises(waa.WaaError) as ei:
+        c.plan_describe()
+    assert ei.value.status == 4
+    c.close()
