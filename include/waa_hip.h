@@ -224,6 +224,42 @@ waa_status waa_set_param_block(waa_batch* batch, uint32_t node, uint32_t param, 
                                uint64_t quantum0, uint32_t n_quanta, uint32_t values_per_quantum,
                                const float* values);
 
+/* ---- AudioParam automation (src/param.rs:386-600 control side, :796-1584 timeline) ---------------- */
+
+/* AudioParamEventType, same order as src/param.rs:151-160 */
+enum {
+  WAA_EVENT_SET_VALUE = 0,                /* AudioParam::set_value                                      */
+  WAA_EVENT_SET_VALUE_AT_TIME = 1,        /* set_value_at_time(value, start_time)                      */
+  WAA_EVENT_LINEAR_RAMP = 2,              /* linear_ramp_to_value_at_time(value, end_time)             */
+  WAA_EVENT_EXPONENTIAL_RAMP = 3,         /* exponential_ramp_to_value_at_time(value, end_time)        */
+  WAA_EVENT_CANCEL_SCHEDULED_VALUES = 4,  /* cancel_scheduled_values(cancel_time)                      */
+  WAA_EVENT_SET_TARGET = 5,               /* set_target_at_time(value, start_time, aux = time_constant) */
+  WAA_EVENT_CANCEL_AND_HOLD = 6,          /* cancel_and_hold_at_time(cancel_time)                      */
+  WAA_EVENT_SET_VALUE_CURVE = 7           /* set_value_curve_at_time(curve, start_time, aux = duration) */
+};
+
+/* Schedule an automation event on a param of a node (instance or WAA_ALL_INSTANCES), before waa_render.  The
+ * events of a param are applied in call order, exactly like the reference's render thread receives them
+ * (handle_incoming_event, param.rs:796-1047), and the timeline is evaluated per render quantum with the
+ * reference's arithmetic (compute_buffer, param.rs:1483-1584) on the HOST (automation is control-side work);
+ * the resulting per-quantum / per-frame values take the place of waa_set_param_block for that param.
+ * Errors mirror the reference's panics: RangeError / TypeError for bad values and times, InvalidStateError for a
+ * curve shorter than 2, NotSupportedError for events overlapping a value curve. */
+waa_status waa_param_schedule_event(waa_batch* batch, uint32_t node, uint32_t param, uint32_t instance, int32_t type,
+                                    float value, double time, double aux, const float* curve, uint32_t n_curve);
+
+/* The same timeline as a stand-alone object (no batch, no device): what AudioParamProcessor::
+ * compute_intrinsic_values (param.rs:730-735) is to the reference's unit tests. */
+typedef struct waa_timeline waa_timeline;
+waa_timeline* waa_timeline_create(float default_value, float min_value, float max_value, int32_t a_rate);
+void waa_timeline_destroy(waa_timeline* timeline);
+waa_status waa_timeline_event(waa_timeline* timeline, int32_t type, float value, double time, double aux,
+                              const float* curve, uint32_t n_curve);
+/* one block: writes 1 or `count` values to out (capacity >= count), returns how many */
+uint32_t waa_timeline_compute(waa_timeline* timeline, double block_time, double dt, uint32_t count, float* out);
+/* AudioParam::value(): the clamped intrinsic value at the beginning of the last computed block */
+float waa_timeline_value(const waa_timeline* timeline);
+
 /* ---- render ---------------------------------------------------------------------------- */
 
 /* start_rendering_sync for every instance: renders all ceil(length/128) quanta. Asynchronous on the

@@ -505,6 +505,492 @@ static void conv_process(ConvState* s, const float* input, float* output, int le
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* AudioParam automation timeline (src/param.rs:151-235 events + queue, :796-1047          */
+/* handle_incoming_event, :1049-1584 compute_*_automation + compute_buffer)                */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+  int type;
+  float value;
+  double time;
+  int has_time_constant, has_cancel_time, has_duration;
+  double time_constant, cancel_time, duration;
+  float* values; /* owned */
+  int n_values;
+} TlEvent;
+
+struct orc_timeline {
+  float default_value, min_value, max_value;
+  float intrinsic_value;
+  float current_value;
+  int a_rate;
+  TlEvent* ev; /* the event queue, sorted by time (stable) unless `dirty` */
+  int n, cap;
+  int has_last;
+  TlEvent last_event; /* values pointer not owned here (never read) */
+  float buffer[1024];
+  int blen;
+};
+typedef struct orc_timeline orc_timeline;
+
+#define SNAP_TO_TARGET 1e-10f /* param.rs:22 */
+
+static float tl_linear_ramp_sample(double start_time, double duration, float start_value, float diff, double time) {
+  double phase = (time - start_time) / duration; /* :66-76 */
+  return fmaf(diff, (float)phase, start_value);
+}
+static float tl_exponential_ramp_sample(double start_time, double duration, float start_value, float ratio, double time) {
+  double phase = (time - start_time) / duration; /* :79-90 */
+  return start_value * powf(ratio, (float)phase);
+}
+static float tl_set_target_sample(double start_time, double time_constant, float end_value, float diff, double time) {
+  double exponent = -((time - start_time) / time_constant); /* :93-103 */
+  return fmaf(diff, (float)exp(exponent), end_value);
+}
+static float tl_set_value_curve_sample(double start_time, double duration, const float* values, int n, double time) {
+  if (time - start_time >= duration) return values[n - 1]; /* :107-121 */
+  double position = (double)(n - 1) * (time - start_time) / duration;
+  int k = (int)position;
+  float phase = (float)(position - floor(position));
+  return fmaf(values[k + 1] - values[k], phase, values[k]);
+}
+
+orc_timeline* orc_timeline_create(float default_value, float min_value, float max_value, int32_t a_rate) {
+  orc_timeline* t = (orc_timeline*)calloc(1, sizeof *t);
+  t->default_value = default_value;
+  t->min_value = min_value;
+  t->max_value = max_value;
+  t->intrinsic_value = default_value;
+  t->current_value = default_value;
+  t->a_rate = a_rate != 0;
+  return t;
+}
+void orc_timeline_destroy(orc_timeline* t) {
+  if (!t) return;
+  for (int i = 0; i < t->n; i++) free(t->ev[i].values);
+  free(t->ev);
+  free(t);
+}
+float orc_timeline_value(const orc_timeline* t) { return t->current_value; }
+
+static void tl_push(orc_timeline* t, TlEvent e) {
+  if (t->n == t->cap) {
+    t->cap = t->cap ? t->cap * 2 : 32;
+    t->ev = (TlEvent*)realloc(t->ev, sizeof(TlEvent) * (size_t)t->cap);
+  }
+  t->ev[t->n++] = e;
+}
+static void tl_sort(orc_timeline* t) { /* stable sort by time (Vec::sort_by is stable), :222-226 */
+  for (int i = 1; i < t->n; i++) {
+    TlEvent e = t->ev[i];
+    int j = i - 1;
+    while (j >= 0 && t->ev[j].time > e.time) {
+      t->ev[j + 1] = t->ev[j];
+      j--;
+    }
+    t->ev[j + 1] = e;
+  }
+}
+static TlEvent tl_pop(orc_timeline* t) { /* remove(0), :186-192 */
+  TlEvent e = t->ev[0];
+  memmove(t->ev, t->ev + 1, sizeof(TlEvent) * (size_t)(t->n - 1));
+  t->n--;
+  return e;
+}
+static void tl_set_last(orc_timeline* t, TlEvent e) {
+  free(e.values); /* the curve of a finished SetValueCurve is never read again */
+  e.values = NULL;
+  t->last_event = e;
+  t->has_last = 1;
+}
+static TlEvent tl_plain(int type, float value, double time) {
+  TlEvent e;
+  memset(&e, 0, sizeof e);
+  e.type = type;
+  e.value = value;
+  e.time = time;
+  return e;
+}
+
+/* control side: the *_raw constructors (param.rs:399-596) + render side: handle_incoming_event (:796-1047) */
+waa_status orc_timeline_event(orc_timeline* t, int32_t type, float value, double time, double aux, const float* curve,
+                              uint32_t n_curve) {
+  if (!t) return fail(WAA_ERR_INVALID_ARGUMENT, "null timeline");
+  TlEvent event = tl_plain(type, value, time);
+  switch (type) {
+    case WAA_EVENT_SET_VALUE:
+      if (!isfinite(value)) return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided value is non-finite.");
+      t->current_value = fminf(fmaxf(value, t->min_value), t->max_value);
+      event.time = 0.;
+      break;
+    case WAA_EVENT_SET_VALUE_AT_TIME:
+    case WAA_EVENT_LINEAR_RAMP:
+      if (!isfinite(value)) return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided value is non-finite.");
+      break;
+    case WAA_EVENT_EXPONENTIAL_RAMP:
+      if (!isfinite(value)) return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided value is non-finite.");
+      if (value == 0.f) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - value (0.0) should not be equal to zero");
+      break;
+    case WAA_EVENT_SET_TARGET:
+      if (!isfinite(value)) return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided value is non-finite.");
+      if (!isfinite(aux)) return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided time value is non-finite.");
+      if (aux < 0.) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - The provided time value cannot be negative");
+      if (aux == 0.) { /* "the output value jumps immediately to the final value", :497-507 */
+        event.type = WAA_EVENT_SET_VALUE_AT_TIME;
+      } else {
+        event.has_time_constant = 1;
+        event.time_constant = aux;
+      }
+      break;
+    case WAA_EVENT_CANCEL_SCHEDULED_VALUES:
+    case WAA_EVENT_CANCEL_AND_HOLD: event.value = 0.f; break;
+    case WAA_EVENT_SET_VALUE_CURVE:
+      if (!curve || n_curve < 2)
+        return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - sequence length (%u) should not be less than 2", n_curve);
+      if (!isfinite(aux)) return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided value is non-finite.");
+      if (!(aux > 0.)) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - duration (%g) should be strictly positive", aux);
+      event.value = 0.f;
+      event.has_duration = 1;
+      event.duration = aux;
+      break;
+    default: return fail(WAA_ERR_INVALID_ARGUMENT, "unknown automation event type %d", type);
+  }
+  if (type != WAA_EVENT_SET_VALUE) { /* assert_valid_time_value */
+    if (!isfinite(time)) return fail(WAA_ERR_INVALID_ARGUMENT, "TypeError - The provided time value is non-finite.");
+    if (time < 0.) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - The provided time value cannot be negative");
+  }
+
+  /* ---- handle_incoming_event ---- */
+  if (event.type == WAA_EVENT_CANCEL_SCHEDULED_VALUES) { /* :808-864 */
+    if (t->n > 0) {
+      const TlEvent* cur = &t->ev[0];
+      if ((cur->type == WAA_EVENT_LINEAR_RAMP || cur->type == WAA_EVENT_EXPONENTIAL_RAMP) && cur->time >= event.time && t->has_last)
+        t->intrinsic_value = t->last_event.value;
+    }
+    int k = 0;
+    for (int i = 0; i < t->n; i++) {
+      if (t->ev[i].time < event.time)
+        t->ev[k++] = t->ev[i];
+      else
+        free(t->ev[i].values);
+    }
+    t->n = k;
+    return WAA_OK;
+  }
+  if (event.type == WAA_EVENT_CANCEL_AND_HOLD) { /* :866-945 */
+    int e1 = -1, e2 = -1;
+    double t1 = -DBL_MAX, t2 = DBL_MAX;
+    tl_sort(t);
+    for (int i = 0; i < t->n; i++) {
+      if (t->ev[i].time >= t1 && t->ev[i].time <= event.time) {
+        t1 = t->ev[i].time;
+        e1 = i;
+      } else if (t->ev[i].time < t2 && t->ev[i].time > event.time) {
+        t2 = t->ev[i].time;
+        e2 = i;
+      }
+    }
+    if (e2 >= 0) {
+      if (t->ev[e2].type == WAA_EVENT_LINEAR_RAMP || t->ev[e2].type == WAA_EVENT_EXPONENTIAL_RAMP) {
+        t->ev[e2].has_cancel_time = 1;
+        t->ev[e2].cancel_time = event.time;
+      }
+    } else if (e1 >= 0) {
+      if (t->ev[e1].type == WAA_EVENT_SET_TARGET) {
+        t->ev[e1].has_cancel_time = 1;
+        t->ev[e1].cancel_time = event.time;
+      } else if (t->ev[e1].type == WAA_EVENT_SET_VALUE_CURVE) {
+        if (event.time <= t->ev[e1].time + t->ev[e1].duration) {
+          t->ev[e1].has_cancel_time = 1;
+          t->ev[e1].cancel_time = event.time;
+        }
+      }
+    }
+    int k = 0;
+    for (int i = 0; i < t->n; i++) {
+      double tt = t->ev[i].has_cancel_time ? t->ev[i].cancel_time : t->ev[i].time;
+      if (tt <= event.time)
+        t->ev[k++] = t->ev[i];
+      else
+        free(t->ev[i].values);
+    }
+    t->n = k;
+    return WAA_OK;
+  }
+  if (event.type == WAA_EVENT_SET_VALUE_CURVE) { /* :947-968 */
+    double start_time = event.time, end_time = start_time + event.duration;
+    for (int i = 0; i < t->n; i++)
+      if (!(t->ev[i].time <= start_time || t->ev[i].time >= end_time))
+        return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - scheduling SetValueCurveAtTime at time of another automation event");
+  }
+  if (event.type == WAA_EVENT_SET_VALUE_AT_TIME || event.type == WAA_EVENT_SET_VALUE || event.type == WAA_EVENT_LINEAR_RAMP ||
+      event.type == WAA_EVENT_EXPONENTIAL_RAMP || event.type == WAA_EVENT_SET_TARGET) { /* :970-993 */
+    for (int i = 0; i < t->n; i++)
+      if (t->ev[i].type == WAA_EVENT_SET_VALUE_CURVE) {
+        double start_time = t->ev[i].time, end_time = start_time + t->ev[i].duration;
+        if (!(event.time <= start_time || event.time >= end_time))
+          return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - scheduling automation event during SetValueCurveAtTime");
+      }
+  }
+  if (event.type == WAA_EVENT_SET_VALUE) t->intrinsic_value = event.value; /* :995-998 */
+  if (t->n == 0 && !t->has_last && (event.type == WAA_EVENT_LINEAR_RAMP || event.type == WAA_EVENT_EXPONENTIAL_RAMP))
+    tl_push(t, tl_plain(WAA_EVENT_SET_VALUE, t->intrinsic_value, 0.)); /* :1000-1022 */
+  if (t->n == 0 && event.type == WAA_EVENT_SET_TARGET) tl_push(t, tl_plain(WAA_EVENT_SET_VALUE, t->intrinsic_value, 0.)); /* :1024-1043 */
+  if (event.type == WAA_EVENT_SET_VALUE_CURVE) {
+    event.values = (float*)malloc(sizeof(float) * n_curve);
+    memcpy(event.values, curve, sizeof(float) * n_curve);
+    event.n_values = (int)n_curve;
+  }
+  tl_push(t, event);
+  tl_sort(t);
+  return WAA_OK;
+}
+
+typedef struct {
+  double block_time, dt, next_block_time;
+  int count, is_a_rate;
+} TlBlock;
+
+static int tl_end_index(const TlBlock* b, double end_time) { /* ((end_time - block_time).max(0.) / dt).round() as usize, clipped */
+  double v = round(fmax(end_time - b->block_time, 0.) / b->dt);
+  if (v > (double)b->count) return b->count;
+  return (int)v;
+}
+
+/* :1049-1096 */
+static int tl_compute_set_value(orc_timeline* t, const TlBlock* b) {
+  TlEvent* event = &t->ev[0];
+  double time = event->time;
+  if (time == 0.) time = b->block_time;
+  if (b->is_a_rate) {
+    int end_index_clipped = tl_end_index(b, time);
+    for (int i = t->blen; i < end_index_clipped; i++) t->buffer[t->blen++] = t->intrinsic_value;
+  }
+  if (time > b->next_block_time) return 1;
+  t->intrinsic_value = event->value;
+  TlEvent e = tl_pop(t);
+  e.time = time;
+  tl_set_last(t, e);
+  return 0;
+}
+/* :1100-1170 */
+static int tl_compute_linear_ramp(orc_timeline* t, const TlBlock* b) {
+  TlEvent* event = &t->ev[0];
+  double start_time = t->last_event.time, end_time = event->time;
+  double duration = end_time - start_time;
+  if (event->has_cancel_time) end_time = event->cancel_time;
+  float start_value = t->last_event.value, end_value = event->value, diff = end_value - start_value;
+  if (b->is_a_rate) {
+    int start_index = t->blen, end_index_clipped = tl_end_index(b, end_time);
+    if (end_index_clipped > start_index) {
+      double time = fma((double)start_index, b->dt, b->block_time);
+      float value = 0.f;
+      for (int i = start_index; i < end_index_clipped; i++) {
+        value = tl_linear_ramp_sample(start_time, duration, start_value, diff, time);
+        t->buffer[t->blen++] = value;
+        time += b->dt;
+      }
+      t->intrinsic_value = value;
+    }
+  }
+  if (end_time >= b->next_block_time) {
+    t->intrinsic_value = tl_linear_ramp_sample(start_time, duration, start_value, diff, b->next_block_time);
+    return 1;
+  }
+  if (event->has_cancel_time) {
+    float value = tl_linear_ramp_sample(start_time, duration, start_value, diff, end_time);
+    t->intrinsic_value = value;
+    TlEvent e = tl_pop(t);
+    e.time = end_time;
+    e.value = value;
+    tl_set_last(t, e);
+  } else {
+    t->intrinsic_value = end_value;
+    tl_set_last(t, tl_pop(t));
+  }
+  return 0;
+}
+/* :1174-1278 */
+static int tl_compute_exponential_ramp(orc_timeline* t, const TlBlock* b) {
+  TlEvent* event = &t->ev[0];
+  double start_time = t->last_event.time, end_time = event->time;
+  double duration = end_time - start_time;
+  if (event->has_cancel_time) end_time = event->cancel_time;
+  float start_value = t->last_event.value, end_value = event->value, ratio = end_value / start_value;
+  if (start_value == 0.f || start_value * end_value < 0.f) {
+    free(t->ev[0].values);
+    t->ev[0] = tl_plain(WAA_EVENT_SET_VALUE_AT_TIME, end_value, end_time); /* replace_peek */
+    return 0;
+  }
+  if (b->is_a_rate) {
+    int start_index = t->blen, end_index_clipped = tl_end_index(b, end_time);
+    if (end_index_clipped > start_index) {
+      double time = fma((double)start_index, b->dt, b->block_time);
+      float value = 0.f;
+      for (int i = start_index; i < end_index_clipped; i++) {
+        value = tl_exponential_ramp_sample(start_time, duration, start_value, ratio, time);
+        t->buffer[t->blen++] = value;
+        time += b->dt;
+      }
+      t->intrinsic_value = value;
+    }
+  }
+  if (end_time >= b->next_block_time) {
+    t->intrinsic_value = tl_exponential_ramp_sample(start_time, duration, start_value, ratio, b->next_block_time);
+    return 1;
+  }
+  if (event->has_cancel_time) {
+    float value = tl_exponential_ramp_sample(start_time, duration, start_value, ratio, end_time);
+    t->intrinsic_value = value;
+    TlEvent e = tl_pop(t);
+    e.time = end_time;
+    e.value = value;
+    tl_set_last(t, e);
+  } else {
+    t->intrinsic_value = end_value;
+    tl_set_last(t, tl_pop(t));
+  }
+  return 0;
+}
+/* :1286-1420 */
+static int tl_compute_set_target(orc_timeline* t, const TlBlock* b) {
+  TlEvent* event = &t->ev[0];
+  double end_time = b->next_block_time;
+  int ended = 0;
+  if (t->n > 1) {
+    const TlEvent* next_event = &t->ev[1];
+    if (next_event->type == WAA_EVENT_LINEAR_RAMP || next_event->type == WAA_EVENT_EXPONENTIAL_RAMP) {
+      end_time = b->block_time;
+      ended = 1;
+    } else if (next_event->time < b->next_block_time) {
+      end_time = next_event->time;
+      ended = 1;
+    }
+  }
+  if (event->has_cancel_time && event->cancel_time < b->next_block_time) {
+    end_time = event->cancel_time;
+    ended = 1;
+  }
+  double start_time = event->time;
+  float start_value = t->last_event.value, end_value = event->value, diff = start_value - end_value;
+  double time_constant = event->time_constant;
+  if (b->is_a_rate) {
+    int start_index = t->blen, end_index_clipped = tl_end_index(b, end_time);
+    if (end_index_clipped > start_index) {
+      double time = fma((double)start_index, b->dt, b->block_time);
+      float value = 0.f;
+      for (int i = start_index; i < end_index_clipped; i++) {
+        value = (time - start_time < 0.) ? t->intrinsic_value : tl_set_target_sample(start_time, time_constant, end_value, diff, time);
+        t->buffer[t->blen++] = value;
+        time += b->dt;
+      }
+      t->intrinsic_value = value;
+    }
+  }
+  if (!ended) {
+    float value = tl_set_target_sample(start_time, time_constant, end_value, diff, b->next_block_time);
+    float d = fabsf(end_value - value);
+    if (d < SNAP_TO_TARGET) {
+      t->intrinsic_value = end_value;
+      if (end_value == 0.f)
+        for (int i = 0; i < t->blen; i++)
+          if (fpclassify(t->buffer[i]) == FP_SUBNORMAL) t->buffer[i] = 0.f;
+      free(t->ev[0].values);
+      t->ev[0] = tl_plain(WAA_EVENT_SET_VALUE_AT_TIME, end_value, b->next_block_time); /* replace_peek */
+    } else {
+      t->intrinsic_value = value;
+    }
+    return 1;
+  }
+  float value = tl_set_target_sample(start_time, time_constant, end_value, diff, end_time);
+  t->intrinsic_value = value;
+  TlEvent e = tl_pop(t);
+  e.time = end_time;
+  e.value = value;
+  tl_set_last(t, e);
+  return 0;
+}
+/* :1422-1496 */
+static int tl_compute_set_value_curve(orc_timeline* t, const TlBlock* b) {
+  TlEvent* event = &t->ev[0];
+  double start_time = event->time, duration = event->duration;
+  const float* values = event->values;
+  int n = event->n_values;
+  double end_time = start_time + duration;
+  if (event->has_cancel_time) end_time = event->cancel_time;
+  if (b->is_a_rate) {
+    int start_index = t->blen, end_index_clipped = tl_end_index(b, end_time);
+    if (end_index_clipped > start_index) {
+      double time = fma((double)start_index, b->dt, b->block_time);
+      float value = 0.f;
+      for (int i = start_index; i < end_index_clipped; i++) {
+        value = time < start_time ? t->intrinsic_value : tl_set_value_curve_sample(start_time, duration, values, n, time);
+        t->buffer[t->blen++] = value;
+        time += b->dt;
+      }
+      t->intrinsic_value = value;
+    }
+  }
+  if (end_time >= b->next_block_time) {
+    t->intrinsic_value = tl_set_value_curve_sample(start_time, duration, values, n, b->next_block_time);
+    return 1;
+  }
+  float value = event->has_cancel_time ? tl_set_value_curve_sample(start_time, duration, values, n, end_time) : values[n - 1];
+  t->intrinsic_value = value;
+  TlEvent e = tl_pop(t);
+  e.time = end_time;
+  e.value = value;
+  tl_set_last(t, e);
+  return 0;
+}
+
+/* compute_buffer, :1498-1584; returns the number of values (1 or count) */
+uint32_t orc_timeline_compute(orc_timeline* t, double block_time, double dt, uint32_t count, float* out) {
+  if (count > 1024) count = 1024;
+  t->current_value = fminf(fmaxf(t->intrinsic_value, t->min_value), t->max_value);
+  t->blen = 0;
+  TlBlock b;
+  b.block_time = block_time;
+  b.dt = dt;
+  b.count = (int)count;
+  b.is_a_rate = t->a_rate;
+  b.next_block_time = fma(dt, (double)count, block_time);
+  int is_constant_block = 1;
+  if (t->n > 0) {
+    const TlEvent* e = &t->ev[0];
+    if (e->type != WAA_EVENT_LINEAR_RAMP && e->type != WAA_EVENT_EXPONENTIAL_RAMP)
+      is_constant_block = e->time >= b.next_block_time;
+    else
+      is_constant_block = 0;
+  }
+  if (!b.is_a_rate || is_constant_block) {
+    t->buffer[t->blen++] = t->intrinsic_value;
+    if (is_constant_block) goto done;
+  }
+  for (;;) {
+    int exit_loop;
+    if (t->n == 0) {
+      if (b.is_a_rate)
+        for (int i = t->blen; i < b.count; i++) t->buffer[t->blen++] = t->intrinsic_value;
+      exit_loop = 1;
+    } else {
+      switch (t->ev[0].type) {
+        case WAA_EVENT_SET_VALUE:
+        case WAA_EVENT_SET_VALUE_AT_TIME: exit_loop = tl_compute_set_value(t, &b); break;
+        case WAA_EVENT_LINEAR_RAMP: exit_loop = tl_compute_linear_ramp(t, &b); break;
+        case WAA_EVENT_EXPONENTIAL_RAMP: exit_loop = tl_compute_exponential_ramp(t, &b); break;
+        case WAA_EVENT_SET_TARGET: exit_loop = tl_compute_set_target(t, &b); break;
+        case WAA_EVENT_SET_VALUE_CURVE: exit_loop = tl_compute_set_value_curve(t, &b); break;
+        default: exit_loop = 1; break;
+      }
+    }
+    if (exit_loop) break;
+  }
+done:
+  memcpy(out, t->buffer, sizeof(float) * (size_t)t->blen);
+  return (uint32_t)t->blen;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* context / nodes                                                                        */
 /* ------------------------------------------------------------------------------------ */
 typedef struct {
@@ -518,6 +1004,9 @@ typedef struct {
   float* cst;          /* [n_inst] */
   ParamBlock* blk;     /* [n_inst] */
   float defv, minv, maxv;
+  orc_timeline** tl;   /* [n_inst] automation timelines (NULL until an event is scheduled) */
+  int k_rate;          /* AutomationRate::K (source playbackRate / detune) */
+  double sample_rate;
 } Param;
 
 typedef struct {
@@ -633,10 +1122,15 @@ static float param_fix(const Param* p, float x) { /* param.rs:755-761: NaN -> de
 static const float* param_get_in(const Param* p, const Quantum* in, uint32_t inst, uint64_t q, int* len, float* tmp) {
   const ParamBlock* b = &p->blk[inst];
   float one;
+  float tlbuf[RQ];
   const float* v = &one;
   int vlen = 1;
   one = p->cst[inst];
-  if (b->v && q >= b->q0 && q < b->q0 + b->nq) {
+  if (p->tl && p->tl[inst]) { /* AudioParamProcessor::process: compute_intrinsic_values(current_time, 1/sr, 128), param.rs:686-699 */
+    double block_time = (double)(q * RQ) / p->sample_rate;
+    vlen = (int)orc_timeline_compute(p->tl[inst], block_time, 1. / p->sample_rate, RQ, tlbuf);
+    v = tlbuf;
+  } else if (b->v && q >= b->q0 && q < b->q0 + b->nq) {
     v = b->v + (size_t)(q - b->q0) * b->vpq;
     vlen = (int)b->vpq;
   }
@@ -820,6 +1314,8 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
         n->n_params = 2;
         param_init(&n->params[WAA_PARAM_SOURCE_PLAYBACK_RATE], n_inst, 1.f, -FLT_MAX, FLT_MAX);
         param_init(&n->params[WAA_PARAM_SOURCE_DETUNE], n_inst, 0.f, -FLT_MAX, FLT_MAX);
+        n->params[WAA_PARAM_SOURCE_PLAYBACK_RATE].k_rate = 1; /* audio_buffer_source.rs:157,168 */
+        n->params[WAA_PARAM_SOURCE_DETUNE].k_rate = 1;
         n->bufs = (Buf*)calloc(n_inst, sizeof(Buf));
         n->start_time = (double*)malloc(sizeof(double) * n_inst);
         n->stop_time = (double*)malloc(sizeof(double) * n_inst);
@@ -975,6 +1471,10 @@ void orc_batch_destroy(orc_batch* b) {
         if (n->params[p].blk[k].owned) free(n->params[p].blk[k].v);
       free(n->params[p].cst);
       free(n->params[p].blk);
+      if (n->params[p].tl) {
+        for (uint32_t k = 0; k < b->n_inst; k++) orc_timeline_destroy(n->params[p].tl[k]);
+        free(n->params[p].tl);
+      }
     }
     if (n->bufs) {
       for (uint32_t k = 0; k < b->n_inst; k++) buf_release(&n->bufs[k]);
@@ -1247,6 +1747,28 @@ waa_status orc_oscillator_set_periodic_wave(orc_batch* b, uint32_t node, const f
   }
   free(n->osc_wave);
   n->osc_wave = wavetable;
+  return WAA_OK;
+}
+
+/* AudioParam::set_value_at_time & co. (param.rs:428-596) on a param of the batch */
+waa_status orc_param_schedule_event(orc_batch* b, uint32_t node, uint32_t param, uint32_t inst, int32_t type, float value,
+                                    double time, double aux, const float* curve, uint32_t n_curve) {
+  int e;
+  if (!b || node >= b->n_nodes || (int)param >= b->nodes[node].n_params)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "no such param %u on node %u", param, node);
+  if ((e = check_inst(b, inst))) return e;
+  Param* p = &b->nodes[node].params[param];
+  if (!p->tl) p->tl = (orc_timeline**)calloc(b->n_inst, sizeof(orc_timeline*));
+  p->sample_rate = (double)b->sr;
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) {
+    if (!p->tl[k]) {
+      p->tl[k] = orc_timeline_create(p->defv, p->minv, p->maxv, !p->k_rate);
+      /* the node constructor's `param.set_value(options.x)` (e.g. gain.rs:117) */
+      if ((e = orc_timeline_event(p->tl[k], WAA_EVENT_SET_VALUE, p->cst[k], 0., 0., NULL, 0))) return e;
+    }
+    if ((e = orc_timeline_event(p->tl[k], type, value, time, aux, curve, n_curve))) return e;
+  }
   return WAA_OK;
 }
 

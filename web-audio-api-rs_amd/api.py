@@ -42,6 +42,8 @@ NODE_OSCILLATOR = 12
 OSCILLATOR_TYPE = {"sine": 0, "square": 1, "sawtooth": 2, "triangle": 3, "custom": 4}
 MAX_IIR_COEFFS = 20
 PARAM_INPUT = 0x80000000  # WAA_PARAM_INPUT(param): edge into an AudioParam of the target node
+(EVENT_SET_VALUE, EVENT_SET_VALUE_AT_TIME, EVENT_LINEAR_RAMP, EVENT_EXPONENTIAL_RAMP, EVENT_CANCEL_SCHEDULED_VALUES,
+ EVENT_SET_TARGET, EVENT_CANCEL_AND_HOLD, EVENT_SET_VALUE_CURVE) = range(8)  # WAA_EVENT_* (src/param.rs:151-160)
 COUNT_MODE = {"max": 0, "clamped-max": 1, "explicit": 2}
 INTERPRETATION = {"speakers": 0, "discrete": 1}
 BIQUAD_TYPE = {"lowpass": 0, "highpass": 1, "bandpass": 2, "notch": 3, "allpass": 4, "peaking": 5,
@@ -96,6 +98,13 @@ ABI = {
     "oscillator_set_periodic_wave": (C.c_int32, [_VP, C.c_uint32, _FP, _FP, C.c_uint32, C.c_int32]),
     "iir_set_coefficients": (C.c_int32, [_VP, C.c_uint32, _DP, C.c_uint32, _DP, C.c_uint32]),
     "iir_frequency_response": (C.c_int32, [_DP, C.c_uint32, _DP, C.c_uint32, C.c_float, _FP, _FP, _FP, C.c_uint32]),
+    "param_schedule_event": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_float, C.c_double, C.c_double,
+                                         _FP, C.c_uint32]),
+    "timeline_create": (_VP, [C.c_float, C.c_float, C.c_float, C.c_int32]),
+    "timeline_destroy": (None, [_VP]),
+    "timeline_event": (C.c_int32, [_VP, C.c_int32, C.c_float, C.c_double, C.c_double, _FP, C.c_uint32]),
+    "timeline_compute": (C.c_uint32, [_VP, C.c_double, C.c_double, C.c_uint32, _FP]),
+    "timeline_value": (C.c_float, [_VP]),
     "set_param_const": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
     "set_param_block": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
     "render": (C.c_int32, [_VP]),
@@ -184,8 +193,8 @@ class AudioBuffer:
 class AudioParam:
     """Value source for one AudioParam of one node (src/param.rs:268).
 
-    The automation timeline is host-side work; this mirror supports the
-    constant value and explicit per-quantum blocks, which is what crosses the C ABI."""
+    Constants, explicit per-quantum value blocks and automation events all cross the C ABI; the timeline itself is
+    evaluated by the library on the host (automation is control-side work)."""
 
     def __init__(self, node: "AudioNode", pid: int, default: float):
         self._node, self._pid = node, pid
@@ -216,53 +225,42 @@ class AudioParam:
         self._blocks.append((int(quantum0), v, instance))
         return self
 
-    # -- a small automation timeline (host side, like src/param.rs; a convenience of this mirror, the ABI only
-    #    sees the resulting value blocks).  Supported: set_value_at_time, linear_ramp_to_value_at_time,
-    #    exponential_ramp_to_value_at_time (formulas of param.rs:63-86, f32 like the reference).
-    def set_value_at_time(self, value: float, time: float):
-        self._events.append(("set", float(value), float(time)))
+    # -- automation methods (src/param.rs:428-596).  The events cross the ABI (waa_param_schedule_event) and are
+    #    evaluated by the library's restatement of AudioParamProcessor; nothing is computed in this mirror.
+    def _event(self, kind: int, value: float, time: float, aux: float = 0.0, curve=None):
+        self._events.append((kind, float(value), float(time), float(aux), None if curve is None else _f32(curve)))
         return self
 
-    def linear_ramp_to_value_at_time(self, value: float, time: float):
-        self._events.append(("lin", float(value), float(time)))
-        return self
+    def set_value_at_time(self, value: float, start_time: float):
+        return self._event(EVENT_SET_VALUE_AT_TIME, value, start_time)
 
-    def exponential_ramp_to_value_at_time(self, value: float, time: float):
-        if value == 0.0:
-            raise WaaError(1, "RangeError - exponential ramp to zero is not allowed")
-        self._events.append(("exp", float(value), float(time)))
-        return self
+    def linear_ramp_to_value_at_time(self, value: float, end_time: float):
+        return self._event(EVENT_LINEAR_RAMP, value, end_time)
 
-    def _render_events(self, ctx: "OfflineAudioContext"):
-        """Evaluate the timeline for every frame of the render -> [n_quanta, 128] block (a-rate)."""
-        nq = (ctx.length + RENDER_QUANTUM_SIZE - 1) // RENDER_QUANTUM_SIZE
-        t = np.arange(nq * RENDER_QUANTUM_SIZE, dtype=np.float64) / np.float64(ctx.sample_rate)
-        out = np.full(t.shape, np.float32(self._const[ALL]), np.float32)
-        prev_v, prev_t = np.float32(self._const[ALL]), 0.0
-        for kind, v, te in sorted(self._events, key=lambda e: e[2]):
-            v = np.float32(v)
-            if kind == "set":
-                out[t >= te] = v
-            else:
-                m = (t >= prev_t) & (t < te)
-                phase = ((t[m] - prev_t) / (te - prev_t)).astype(np.float32)
-                if kind == "lin":
-                    out[m] = (v - prev_v) * phase + prev_v
-                else:
-                    out[m] = prev_v * np.power(np.float32(v / prev_v), phase, dtype=np.float32)
-                out[t >= te] = v
-            prev_v, prev_t = v, te
-        return out.reshape(nq, RENDER_QUANTUM_SIZE)
+    def exponential_ramp_to_value_at_time(self, value: float, end_time: float):
+        return self._event(EVENT_EXPONENTIAL_RAMP, value, end_time)
+
+    def set_target_at_time(self, value: float, start_time: float, time_constant: float):
+        return self._event(EVENT_SET_TARGET, value, start_time, time_constant)
+
+    def cancel_scheduled_values(self, cancel_time: float):
+        return self._event(EVENT_CANCEL_SCHEDULED_VALUES, 0.0, cancel_time)
+
+    def cancel_and_hold_at_time(self, cancel_time: float):
+        return self._event(EVENT_CANCEL_AND_HOLD, 0.0, cancel_time)
+
+    def set_value_curve_at_time(self, values, start_time: float, duration: float):
+        return self._event(EVENT_SET_VALUE_CURVE, 0.0, start_time, duration, values)
 
     def _apply(self, ctx: "OfflineAudioContext"):
         b, h = ctx._b, ctx._handle
-        if self._events:
-            self.set_block(0, self._render_events(ctx))
-            self._events = []
         for inst, v in sorted(self._const.items(), key=lambda kv: kv[0] != ALL):
             b.check(b.set_param_const(h, self._node.id, self._pid, inst, v))
         for q0, v, inst in self._blocks:
             b.check(b.set_param_block(h, self._node.id, self._pid, inst, q0, v.shape[0], v.shape[1], _fp(v)))
+        for kind, value, time, aux, curve in self._events:  # in call order, like the reference's message queue
+            b.check(b.param_schedule_event(h, self._node.id, self._pid, ALL, kind, value, time, aux,
+                                           None if curve is None else _fp(curve), 0 if curve is None else curve.size))
 
 
 class AudioNode:

@@ -80,6 +80,7 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
       case WAA_NODE_BUFFER_SOURCE:
         P(WAA_PARAM_SOURCE_PLAYBACK_RATE).init(n_inst, 1.f, -FLT_MAX, FLT_MAX);
         P(WAA_PARAM_SOURCE_DETUNE).init(n_inst, 0.f, -FLT_MAX, FLT_MAX);
+        P(WAA_PARAM_SOURCE_PLAYBACK_RATE).k_rate = P(WAA_PARAM_SOURCE_DETUNE).k_rate = true;  // audio_buffer_source.rs:157,168
         n.bufs.resize(n_inst);
         n.sched.resize(n_inst);
         break;
@@ -435,6 +436,27 @@ waa_status waa_iir_set_coefficients(waa_batch* b, uint32_t node, const double* f
   for (uint32_t i = 0; i < len; i++) {
     n.iir_b[i] = (i < nff ? ff[i] : 0.) / a0;
     n.iir_a[i] = (i < nfb ? fb[i] : 0.) / a0;
+  }
+  return WAA_OK;
+}
+
+// AudioParam::set_value_at_time & co. (param.rs:428-596) on a param of the batch; evaluated at plan time
+waa_status waa_param_schedule_event(waa_batch* b, uint32_t node, uint32_t param, uint32_t inst, int32_t type, float value,
+                                    double time, double aux, const float* curve, uint32_t n_curve) {
+  int e;
+  if (!b || node >= b->nodes.size() || param >= b->nodes[node].params.size())
+    return fail(WAA_ERR_INVALID_ARGUMENT, "no such param %u on node %u", param, node);
+  if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  ParamStore& p = b->nodes[node].params[param];
+  if (p.timelines.empty()) p.timelines.resize(b->n_inst);
+  const uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) {
+    if (!p.timelines[k]) {
+      p.timelines[k] = std::make_shared<Timeline>(p.defv, p.minv, p.maxv, !p.k_rate);
+      // the node constructor's `param.set_value(options.x)` (e.g. gain.rs:117)
+      if ((e = p.timelines[k]->schedule(WAA_EVENT_SET_VALUE, p.cst[k], 0., 0., nullptr, 0))) return e;
+    }
+    if ((e = p.timelines[k]->schedule(type, value, time, aux, curve, n_curve))) return e;
   }
   return WAA_OK;
 }

@@ -35,6 +35,26 @@ int fail(int code, const char* fmt, ...);
                                       __LINE__, #expr);                                         \
   } while (0)
 
+// AudioParam automation timeline (waa_automation.cpp): the reference's AudioParamProcessor on the host
+class Timeline {
+ public:
+  Timeline(float default_value, float min_value, float max_value, bool a_rate);
+  ~Timeline();
+  // one automation method call (WAA_EVENT_*); returns a waa_status (the reference's panics)
+  int schedule(int type, float value, double time, double aux, const float* curve, uint32_t n_curve);
+  // one block: 1 or `count` values into out (capacity >= count); returns how many
+  uint32_t compute(double block_time, double dt, uint32_t count, float* out);
+  float value() const;  // AudioParam::value()
+
+ private:
+  struct Event;
+  int insert(Event ev);
+  float min_, max_, intrinsic_, current_;
+  bool a_rate_;
+  std::vector<Event> queue_;     // sorted by time (stable)
+  std::unique_ptr<Event> last_;  // the last event that was consumed (start point of ramps and targets)
+};
+
 struct ParamBlock {
   uint32_t inst;
   uint64_t q0;
@@ -44,6 +64,8 @@ struct ParamBlock {
 struct ParamStore {
   std::vector<float> cst;
   std::vector<ParamBlock> blocks;
+  std::vector<std::shared_ptr<Timeline>> timelines;  // [n_inst] or empty: scheduled automation (waa_param_schedule_event)
+  bool k_rate = false;                               // AutomationRate::K (source playbackRate / detune)
   float defv = 0, minv = -FLT_MAX, maxv = FLT_MAX;
   void init(uint32_t n, float d, float lo, float hi) {
     cst.assign(n, d);

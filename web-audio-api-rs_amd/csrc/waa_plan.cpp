@@ -423,8 +423,49 @@ int plan_oscillator(waa_batch* b, uint32_t id);
 int plan_delay_reader(waa_batch* b, uint32_t id);
 uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items);
 
+// Scheduled automation -> value blocks: every timeline is evaluated for all quanta of the render, in order
+// (AudioParamProcessor::process calls compute_intrinsic_values(current_time, 1 / sample_rate, 128) once per
+// quantum, param.rs:686-699), and stored like caller-provided blocks: runs of single-valued quanta as k-rate
+// blocks, runs of 128-valued quanta as a-rate blocks.
+int materialise_automation(waa_batch* b) {
+  const double sample_rate = (double)b->sr, dt = 1. / sample_rate;
+  for (Node& n : b->nodes)
+    for (ParamStore& p : n.params) {
+      if (p.timelines.empty()) continue;
+      for (uint32_t inst = 0; inst < b->n_inst; inst++) {
+        Timeline* tl = p.timelines[inst].get();
+        if (!tl) continue;
+        // (appended after caller-provided blocks: the scheduled automation wins where both exist)
+        float buf[RQ];
+        ParamBlock run;
+        run.inst = inst;
+        run.nq = 0;
+        auto flush = [&] {
+          if (run.nq) p.blocks.push_back(run);
+          run.nq = 0;
+          run.v.clear();
+        };
+        for (uint32_t q = 0; q < b->n_quanta; q++) {
+          const double block_time = (double)((uint64_t)q * RQ) / sample_rate;
+          const uint32_t len = tl->compute(block_time, dt, RQ, buf);
+          if (run.nq && run.vpq != len) flush();
+          if (!run.nq) {
+            run.q0 = q;
+            run.vpq = len;
+          }
+          run.v.insert(run.v.end(), buf, buf + len);
+          run.nq++;
+        }
+        flush();
+      }
+      p.timelines.clear();  // consumed (a batch renders one timeline once, like an OfflineAudioContext)
+    }
+  return 0;
+}
+
 int build_plan(waa_batch* b) {
   const uint32_t N = (uint32_t)b->nodes.size();
+  if (int e = materialise_automation(b)) return e;
   for (uint32_t i = 0; i < N; i++)  // the reference takes the coefficients in the constructor
     if (b->nodes[i].desc.kind == WAA_NODE_IIR_FILTER && b->nodes[i].iir_b.empty())
       return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIRFilterNode %u has no coefficients", i);
