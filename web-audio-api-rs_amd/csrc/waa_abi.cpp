@@ -449,6 +449,7 @@ waa_status waa_param_schedule_event(waa_batch* b, uint32_t node, uint32_t param,
   if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
   ParamStore& p = b->nodes[node].params[param];
   if (p.timelines.empty()) p.timelines.resize(b->n_inst);
+  if (inst != WAA_ALL_INSTANCES) p.timelines_shared = false;
   const uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
   for (uint32_t k = lo; k < hi; k++) {
     if (!p.timelines[k]) {

@@ -66,6 +66,7 @@ struct ParamStore {
   std::vector<ParamBlock> blocks;
   std::vector<std::shared_ptr<Timeline>> timelines;  // [n_inst] or empty: scheduled automation (waa_param_schedule_event)
   bool k_rate = false;                               // AutomationRate::K (source playbackRate / detune)
+  bool timelines_shared = true;                      // every event was scheduled for WAA_ALL_INSTANCES
   float defv = 0, minv = -FLT_MAX, maxv = FLT_MAX;
   void init(uint32_t n, float d, float lo, float hi) {
     cst.assign(n, d);

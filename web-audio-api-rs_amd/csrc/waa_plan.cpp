@@ -18,13 +18,18 @@ int upload_param(waa_batch* b, const ParamStore& p, ParamRef* ref) {
     ref->stride = 0;
   } else {
     const uint64_t per = mode == 1 ? b->n_quanta : (uint64_t)b->n_quanta * RQ;
-    host.resize((size_t)b->n_inst * per);
-    for (uint32_t i = 0; i < b->n_inst; i++) {
+    // the same values for every instance (constants equal, every block for all instances): one row, stride 0
+    bool same = true;
+    for (uint32_t i = 1; i < b->n_inst && same; i++) same = p.cst[i] == p.cst[0];
+    for (auto& blk : p.blocks) same &= blk.inst == WAA_ALL_INSTANCES;
+    const uint32_t rows = same ? 1u : b->n_inst;
+    host.resize((size_t)rows * per);
+    for (uint32_t i = 0; i < rows; i++) {
       float c = p.fix(p.cst[i]);
       std::fill(host.begin() + (size_t)i * per, host.begin() + (size_t)(i + 1) * per, c);
     }
     for (auto& blk : p.blocks) {
-      uint32_t lo = blk.inst == WAA_ALL_INSTANCES ? 0 : blk.inst, hi = blk.inst == WAA_ALL_INSTANCES ? b->n_inst : blk.inst + 1;
+      uint32_t lo = blk.inst == WAA_ALL_INSTANCES ? 0 : blk.inst, hi = blk.inst == WAA_ALL_INSTANCES ? rows : blk.inst + 1;
       for (uint32_t i = lo; i < hi; i++)
         for (uint32_t k = 0; k < blk.nq; k++) {
           uint64_t q = blk.q0 + k;
@@ -37,7 +42,7 @@ int upload_param(waa_batch* b, const ParamStore& p, ParamRef* ref) {
           }
         }
     }
-    ref->stride = per;
+    ref->stride = same ? 0 : per;
   }
   float* d = nullptr;
   int e = dev_upload(b, &d, host);
@@ -432,13 +437,16 @@ int materialise_automation(waa_batch* b) {
   for (Node& n : b->nodes)
     for (ParamStore& p : n.params) {
       if (p.timelines.empty()) continue;
-      for (uint32_t inst = 0; inst < b->n_inst; inst++) {
+      // identical timelines (every event scheduled for all instances, same initial value): evaluate once
+      bool shared = p.timelines_shared && p.timelines[0];
+      for (uint32_t i = 1; i < b->n_inst && shared; i++) shared = p.cst[i] == p.cst[0] && p.timelines[i];
+      for (uint32_t inst = 0; inst < (shared ? 1u : b->n_inst); inst++) {
         Timeline* tl = p.timelines[inst].get();
         if (!tl) continue;
         // (appended after caller-provided blocks: the scheduled automation wins where both exist)
         float buf[RQ];
         ParamBlock run;
-        run.inst = inst;
+        run.inst = shared ? WAA_ALL_INSTANCES : inst;
         run.nq = 0;
         auto flush = [&] {
           if (run.nq) p.blocks.push_back(run);
