@@ -16,7 +16,7 @@ from graphs import rms_err, white_noise
 
 RQ = 128
 SR = 48000.0
-N_INST = 2
+N_INST = 3
 # Sources that start late change the reference's DYNAMIC channel counts mid-render (a silent input is mono); the
 # device plan uses static counts and says so in the plan; such graphs are skipped below.
 LATE_STARTS = True
@@ -38,8 +38,12 @@ def build_random_graph(be, seed):
             n = c.create_buffer_source()
             length = FRAMES if rng.random() < 0.7 else int(rng.integers(300, FRAMES // 2))  # some end early
             n.set_buffer_batch(white_noise(N_INST, nch, length, seed0=int(rng.integers(1, 1 << 20))) * 0.5, SR)
-            if LATE_STARTS and rng.random() < 0.3:
+            r = rng.random()
+            if LATE_STARTS and r < 0.2:
                 n.start_at(float(rng.integers(0, 600)) / SR)
+            elif LATE_STARTS and r < 0.3:  # per-instance start times
+                for i in range(N_INST):
+                    n.start_at(float(rng.integers(0, 600)) / SR, instance=i)
             else:
                 n.start()
         elif kind == "constant":
@@ -61,6 +65,9 @@ def build_random_graph(be, seed):
         nq = (FRAMES + RQ - 1) // RQ
         if kind == "gain":
             n = c.create_gain(gain=float(rng.uniform(-1.0, 1.0)))
+            if rng.random() < 0.3:  # per-instance values
+                for i in range(N_INST):
+                    n.gain.set_value(float(rng.uniform(-1.0, 1.0)), instance=i)
         elif kind == "cfg-gain":  # explicit / clamped-max channel configs, discrete interpretation
             cc, mode, interp = [(1, "explicit", "speakers"), (2, "explicit", "speakers"), (1, "clamped-max", "speakers"),
                                 (2, "explicit", "discrete"), (4, "explicit", "discrete")][int(rng.integers(0, 5))]
@@ -95,6 +102,9 @@ def build_random_graph(be, seed):
             n = c.create_stereo_panner(pan=float(rng.uniform(-1.0, 1.0)))
         elif kind == "delay":
             n = c.create_delay(0.1, delay_time=float(rng.choice([0.0, 0.0007, 0.003, 0.01, 0.05, 0.09])))
+            if rng.random() < 0.3:  # per-instance delay times (different loop strategies per batch are not possible:
+                for i in range(N_INST):  # the planner must take the most restrictive one)
+                    n.delay_time.set_value(float(rng.choice([0.0, 0.002, 0.03, 0.06])), instance=i)
         else:
             ir = (rng.uniform(-1, 1, (int(rng.choice([1, 2])), int(rng.choice([16, 100, 700])))) *
                   np.exp(-np.arange(1)[None, :])).astype(np.float32)

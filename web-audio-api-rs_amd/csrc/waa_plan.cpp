@@ -676,7 +676,7 @@ int build_plan(waa_batch* b) {
     bool reported = false;
     for (uint32_t inst = 0; inst < b->n_inst && !reported; inst++) {
       // per-instance inputs of the simulation
-      std::vector<double> lo(N, 1e300), hi(N, -1.), shift(N, 0.);
+      std::vector<double> lo(N, 1e300), hi(N, -1.), shift(N, 0.), shift_hi(N, 0.);
       std::vector<std::vector<uint8_t>> zero_gain(N);
       std::string sig;
       auto add_sig = [&](double v) { sig.append(reinterpret_cast<const char*>(&v), sizeof v); };
@@ -703,9 +703,16 @@ int build_plan(waa_batch* b) {
             double dmin = 1e300;
             for (float dv : param_per_quantum(b, n.params[WAA_PARAM_DELAY_DELAY_TIME], inst, nullptr)) dmin = std::min(dmin, (double)dv);
             shift[id] = std::floor(dmin / qsec);
+            // a delay that is not a whole number of quanta: whether the first delayed samples land in this quantum or
+            // the next depends on where inside its quantum the input started — both are simulated
+            shift_hi[id] = std::ceil(dmin / qsec);
           }
-          if (id < b->cut.size() && b->cut[id]) shift[id] = std::max(shift[id], 1.);  // inside a loop: >= one quantum
+          if (id < b->cut.size() && b->cut[id]) {  // inside a loop: >= one quantum
+            shift[id] = std::max(shift[id], 1.);
+            shift_hi[id] = std::max(shift_hi[id], 1.);
+          }
           add_sig(shift[id]);
+          add_sig(shift_hi[id]);
         } else if (kind == WAA_NODE_GAIN && param_mode(n, 0) != 2) {
           const auto gv = param_per_quantum(b, n.params[0], inst, nullptr);
           zero_gain[id].assign(nq, 0);
@@ -734,7 +741,10 @@ int build_plan(waa_batch* b) {
       // every combination of short / long tails for up to 8 nodes with memory, the two uniform bounds beyond that
       const uint32_t n_modes = mem_nodes.size() <= 8 ? (1u << mem_nodes.size()) : 2u;
       std::vector<uint8_t> long_tail(N, 0);
-      for (uint32_t tail_mode = 0; tail_mode < n_modes && !reported; tail_mode++) {
+      for (uint32_t mode_index = 0; mode_index < 2 * n_modes && !reported; mode_index++) {
+      const uint32_t tail_mode = mode_index >> 1;
+      const std::vector<double>& dshift = (mode_index & 1) ? shift_hi : shift;
+      if ((mode_index & 1) && shift_hi == shift) continue;
       for (size_t k = 0; k < mem_nodes.size(); k++)
         long_tail[mem_nodes[k]] = mem_nodes.size() <= 8 ? ((tail_mode >> k) & 1u) : (uint8_t)tail_mode;
       for (uint32_t id = 0; id < N; id++) {
@@ -769,7 +779,7 @@ int build_plan(waa_batch* b) {
             if (kind == WAA_NODE_DELAY) {
               // the data is `shift` quanta old; the channel count is the line's, which follows the writer's CURRENT
               // input (delay.rs:469-489) — of the previous quantum when the reader renders first (inside a loop)
-              const int64_t qs = (int64_t)q - (int64_t)shift[id];
+              const int64_t qs = (int64_t)q - (int64_t)dshift[id];
               a = qs >= 0 ? in_act[id][qs] : 0;
               const bool in_loop = id < b->cut.size() && b->cut[id];
               const int64_t qc = in_loop ? (int64_t)q - 1 : (int64_t)q;
