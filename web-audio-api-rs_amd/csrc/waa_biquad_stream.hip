@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
   const float* sig_base = nullptr;
   if (is_src) {
     si = d.in.src[inst];
-    sc = d.in.sched[si.sched];
+    sc = si.sc;
   } else {
     sig_base = d.in.sig.base + (uint64_t)inst * d.in.sig.inst_stride + (uint64_t)ch * d.in.sig.ch_stride;
   }

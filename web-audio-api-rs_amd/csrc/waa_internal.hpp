@@ -60,6 +60,7 @@ struct SrcInst {
   uint64_t frames;
   uint32_t sched;        // index into the schedule table
   uint32_t aligned;      // base and ch_stride multiples of 4 floats
+  SrcSchedule sc;        // copy of the schedule entry: saves the kernels one dependent load per wave
 };
 
 // ---- chain kernel description ----------------------------------------------------------

@@ -187,7 +187,7 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
   }
   if (in.kind == IN_SOURCE) {
     const SrcInst si = in.src[inst];
-    const SrcSchedule sc = in.sched[si.sched];
+    const SrcSchedule sc = si.sc;
     if (si.aligned && sc.tile_fast[f_tile / TILE]) {
       // the enclosing 2048-frame tile is one contiguous, in-range, 16B-aligned run of the AudioBuffer
       const int64_t start = sc.qrec[(uint64_t)tile * QPT].start;
@@ -208,6 +208,78 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
       return;
     }
     // generic path: per-quantum records (silent / fast copy with end-of-buffer or loop wrap / slow track)
+    if constexpr (K == 4) {
+      // tile-parallel chains run one 256-frame sub-tile per wave, so a wave's time is the latency of its chain of
+      // dependent loads (instance record -> quantum record -> playback records -> samples) and not bandwidth:
+      // the playback records are requested together with the quantum record, before the mode is known, and the
+      // interpolating track is straight-line code so that all its gathers are in flight at once
+      const uint32_t q = tile * 2 + (lane >> 5);
+      const bool valid_q = q < n_quanta;
+      const uint32_t qc = valid_q ? q : 0;
+      const uint32_t i0 = (lane & 31) * 4;  // index of this lane's first frame within the quantum
+      const QRec r = sc.qrec[qc];
+      SlowRec s[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) s[e] = SlowRec{-1, -1, 0.};
+      if (sc.slow) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) s[e] = sc.slow[(uint64_t)qc * RQ + i0 + e];
+      }
+      const uint32_t mode = valid_q ? r.mode : (uint32_t)Q_SILENT;
+      if (mode == Q_SLOW) {
+        // audio_buffer_source.rs:754-822
+        float g0[C][4], g1[C][4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int32_t ip = s[e].prev >= 0 ? s[e].prev : 0;
+          // next >= 0: the next frame; -1: silence after the end; -2: extrapolate from the frame BEFORE prev
+          const int32_t in2 = s[e].prev < 0 ? 0 : (s[e].next >= 0 ? s[e].next : (s[e].next == -1 ? 0 : s[e].prev - 1));
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (c < in.nch) {
+              const float* ch = si.base + (uint64_t)c * si.ch_stride;
+              g0[c][e] = ch[ip];
+              g1[c][e] = ch[in2];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (c < in.nch) {
+              const double prev_sample = (double)g0[c][e];
+              const double other = (double)g1[c][e];
+              const double next_sample = s[e].next >= 0 ? other : (s[e].next == -1 ? 0. : 2. * prev_sample - other);
+              const float o = (float)__builtin_fma(1. - s[e].k, prev_sample, s[e].k * next_sample);
+              v[c][e] = s[e].prev >= 0 ? o : 0.f;
+            }
+        }
+      } else if (mode == Q_FAST || mode == Q_FAST_LOOP) {
+        // audio_buffer_source.rs:562-607: index start+i, zero past the end, or wrap when looping
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          uint64_t bi = (uint64_t)r.start + i0 + e;
+          bool ok = true;
+          if (bi >= si.frames) {
+            if (mode == Q_FAST_LOOP)
+              bi = bi % si.frames;
+            else
+              ok = false;
+          }
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (c < in.nch) v[c][e] = ok ? si.base[(uint64_t)c * si.ch_stride + bi] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; c++)
+          if (c < in.nch) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[c][e] = 0.f;
+          }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NV4; j++) {
       const uint32_t fq = j * 256 + lane * 4;  // frame within tile
@@ -508,7 +580,10 @@ __device__ __forceinline__ void stereo_gains_dev(float x, float& gl, float& gr) 
 
 // SERIAL = true : chains with a recurrence (OP_BIQUAD): one wave per instance walks the 2048-frame tiles in order.
 // SERIAL = false: element-wise chains: one wave per (instance, 256-frame sub-tile), 4 waves per workgroup.
-template <int C, int K, bool SERIAL>
+// FANIN = false: single-input chains skip the summing loop; the second inlined copy of the input fetch is what
+// doubles the kernel's VGPR count (57 -> 110 for C = 2), i.e. halves the waves per SIMD of kernels that are bound
+// by the latency of their dependent loads.
+template <int C, int K, bool SERIAL, bool FANIN = true>
 __global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NV4 = K / 4;
@@ -522,7 +597,8 @@ __global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDes
     tile_first = d.tile0 * (TILE / TILE_FR);
     tile_last = d.tile1 * (TILE / TILE_FR);
   } else {
-    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (readfirstlane: the wave index is uniform; telling the compiler keeps instance / tile addressing in SGPRs)
+    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (d.tile_major) {
       // neighbouring waves render the SAME sub-tile of different instances: the per-frame playback table of a
       // resampling source (16 B per frame, shared by all instances of a schedule) is then reused out of L2 instead
@@ -565,18 +641,30 @@ __global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDes
   for (uint32_t tile = tile_first; tile < tile_last; tile++) {
     float v[C][K];
     // ---- inputs: mix every incoming edge to the node's computed channel count and sum in edge order
-    load_input<C, K>(d.in[0], inst, tile, lane, d.n_quanta, v);
-    mix_regs<C, K>(v, d.in[0].nch, d.in_nch, d.in_interp);
-    for (int k = 1; k < d.n_inputs; k++) {
-      float u[C][K];
-      load_input<C, K>(d.in[k], inst, tile, lane, d.n_quanta, u);
-      mix_regs<C, K>(u, d.in[k].nch, d.in_nch, d.in_interp);
+    if constexpr (!FANIN) {
+      load_input<C, K>(d.in[0], inst, tile, lane, d.n_quanta, v);
+      mix_regs<C, K>(v, d.in[0].nch, d.in_nch, d.in_interp);
+    } else {
+      // one copy of the input fetch for all edges (not an unrolled first edge + loop): half the registers
 #pragma unroll
-      for (int c = 0; c < C; c++)
-        if (c < d.in_nch) {
+      for (int c = 0; c < C; c++) {
 #pragma unroll
-          for (int i = 0; i < K; i++) v[c][i] += u[c][i];
-        }
+        for (int i = 0; i < K; i++) v[c][i] = 0.f;
+      }
+#pragma nounroll
+      for (int k = 0; k < d.n_inputs; k++) {
+        float u[C][K];
+        int lane_k = lane;  // opaque per iteration: per-lane address terms are recomputed, not kept live (LICM)
+        asm volatile("" : "+v"(lane_k));
+        load_input<C, K>(d.in[k], inst, tile, lane_k, d.n_quanta, u);
+        mix_regs<C, K>(u, d.in[k].nch, d.in_nch, d.in_interp);
+#pragma unroll
+        for (int c = 0; c < C; c++)
+          if (c < d.in_nch) {
+#pragma unroll
+            for (int i = 0; i < K; i++) v[c][i] = k == 0 ? u[c][i] : v[c][i] + u[c][i];
+          }
+      }
     }
     // ---- fused node ops
     for (int o = 0; o < d.n_ops; o++) {
@@ -878,7 +966,16 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
     // (8 frames per lane instead of 4 was measured: fewer waves fit per SIMD and every workload got slower)
     const uint64_t waves = (uint64_t)d.n_inst * (d.tile1 - d.tile0) * (TILE / 256);
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    if (cmax <= 1)
+    if (d.n_inputs <= 1) {
+      if (cmax <= 1)
+        hipLaunchKernelGGL((chain_kernel<1, 4, false, false>), grid, block, lds, s, dd);
+      else if (cmax <= 2)
+        hipLaunchKernelGGL((chain_kernel<2, 4, false, false>), grid, block, lds, s, dd);
+      else if (cmax <= 4)
+        hipLaunchKernelGGL((chain_kernel<4, 4, false, false>), grid, block, lds, s, dd);
+      else
+        hipLaunchKernelGGL((chain_kernel<6, 4, false, false>), grid, block, lds, s, dd);
+    } else if (cmax <= 1)
       hipLaunchKernelGGL((chain_kernel<1, 4, false>), grid, block, lds, s, dd);
     else if (cmax <= 2)
       hipLaunchKernelGGL((chain_kernel<2, 4, false>), grid, block, lds, s, dd);

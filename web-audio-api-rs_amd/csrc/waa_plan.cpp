@@ -1203,6 +1203,7 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
     scheds.push_back(ds);
     if (!automated) dedup[key] = si.sched;
   }
+  for (auto& si : insts) si.sc = scheds[si.sched];
   SrcInst* d_insts = nullptr;
   int e = dev_upload(b, &d_insts, insts);
   if (e) return e;
