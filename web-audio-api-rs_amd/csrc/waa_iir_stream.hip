@@ -78,18 +78,18 @@ __global__ __launch_bounds__(64, 2) void iir_stream_kernel(const IirStreamDesc d
   constexpr int AHEAD = NS <= 4 ? 4 : 2;
   auto lds_sync = []() __attribute__((always_inline)) { __builtin_amdgcn_wave_barrier(); };
   auto fetch_fast = [&](uint32_t tile, float (&dst)[TILE_K]) __attribute__((always_inline)) {
-    const float* p = is_src ? si.base + (uint64_t)ch * si.ch_stride + sc.qrec[(uint64_t)tile * QUANTA_PER_TILE].start
+    const float* p = is_src ? si.base + (uint64_t)ch * si.ch_stride + load_global(&sc.qrec[(uint64_t)tile * QUANTA_PER_TILE].start)
                             : sig_base + (uint64_t)tile * TILE;
 #pragma unroll
     for (int j = 0; j < NV4; j++) {
-      const float4 t = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
+      const f4v t = load_global_f4(p + j * 256 + lane * 4);
       dst[j * 4 + 0] = t.x;
       dst[j * 4 + 1] = t.y;
       dst[j * 4 + 2] = t.z;
       dst[j * 4 + 3] = t.w;
     }
   };
-  auto tile_is_fast = [&](uint32_t tile) __attribute__((always_inline)) -> bool { return !is_src || (si.aligned && sc.tile_fast[tile]); };
+  auto tile_is_fast = [&](uint32_t tile) __attribute__((always_inline)) -> bool { return !is_src || (si.aligned && load_global(sc.tile_fast + tile)); };
   auto stage = [&](const float (&cur)[TILE_K]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NV4; j++) {

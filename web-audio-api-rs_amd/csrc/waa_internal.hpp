@@ -304,4 +304,42 @@ void launch_biquad_coefs(const BiquadCoefDesc& d, void* stream);
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);
 
+#ifdef __HIPCC__
+// A pointer LOADED from memory (the per-instance source records) is a generic pointer to the compiler: every access
+// through it becomes a flat_load, which counts on lgkmcnt as well as vmcnt — so the next wait on an LDS read also
+// waits for the prefetched tile, and the software pipeline of the streaming kernels collapses.  The loads below go
+// through explicit global-address-space pointers instead.
+typedef float f4v __attribute__((ext_vector_type(4)));
+#define WAA_GLOBAL_AS __attribute__((address_space(1)))
+__device__ __forceinline__ f4v load_global_f4(const float* p) { return *(const WAA_GLOBAL_AS f4v*)p; }
+template <class T>
+__device__ __forceinline__ T load_global(const T* p) {
+  static_assert(sizeof(T) <= 8, "scalar types only");
+  return *(const WAA_GLOBAL_AS T*)p;
+}
+template <class T>
+__device__ __forceinline__ void store_global(T* p, T v) {
+  static_assert(sizeof(T) <= 8, "scalar types only");
+  *(WAA_GLOBAL_AS T*)p = v;
+}
+typedef int i4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ QRec load_global(const QRec* p) {
+  const i4v t = *(const WAA_GLOBAL_AS i4v*)p;
+  QRec r;
+  r.start = (int64_t)(((uint64_t)(uint32_t)t.y << 32) | (uint32_t)t.x);
+  r.mode = (uint32_t)t.z;
+  r.pad = 0;
+  return r;
+}
+__device__ __forceinline__ SlowRec load_global(const SlowRec* p) {
+  const i4v t = *(const WAA_GLOBAL_AS i4v*)p;
+  SlowRec r;
+  r.prev = t.x;
+  r.next = t.y;
+  r.k = __longlong_as_double((long long)(((uint64_t)(uint32_t)t.w << 32) | (uint32_t)t.z));
+  return r;
+}
+
+#endif
+
 }  // namespace waa

@@ -188,16 +188,16 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
   if (in.kind == IN_SOURCE) {
     const SrcInst si = in.src[inst];
     const SrcSchedule sc = si.sc;
-    if (si.aligned && sc.tile_fast[f_tile / TILE]) {
+    if (si.aligned && load_global(sc.tile_fast + f_tile / TILE)) {
       // the enclosing 2048-frame tile is one contiguous, in-range, 16B-aligned run of the AudioBuffer
-      const int64_t start = sc.qrec[(uint64_t)tile * QPT].start;
+      const int64_t start = load_global(&sc.qrec[(uint64_t)tile * QPT].start);
 #pragma unroll
       for (int c = 0; c < C; c++) {
         if (c < in.nch) {
           const float* p = si.base + (uint64_t)c * si.ch_stride + start;
 #pragma unroll
           for (int j = 0; j < NV4; j++) {
-            const float4 t = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
+            const f4v t = load_global_f4(p + j * 256 + lane * 4);
             v[c][j * 4 + 0] = t.x;
             v[c][j * 4 + 1] = t.y;
             v[c][j * 4 + 2] = t.z;
@@ -217,13 +217,13 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
       const bool valid_q = q < n_quanta;
       const uint32_t qc = valid_q ? q : 0;
       const uint32_t i0 = (lane & 31) * 4;  // index of this lane's first frame within the quantum
-      const QRec r = sc.qrec[qc];
+      const QRec r = load_global(sc.qrec + qc);
       SlowRec s[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) s[e] = SlowRec{-1, -1, 0.};
       if (sc.slow) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) s[e] = sc.slow[(uint64_t)qc * RQ + i0 + e];
+        for (int e = 0; e < 4; e++) s[e] = load_global(sc.slow + (uint64_t)qc * RQ + i0 + e);
       }
       const uint32_t mode = valid_q ? r.mode : (uint32_t)Q_SILENT;
       if (mode == Q_SLOW) {
@@ -238,8 +238,8 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
           for (int c = 0; c < C; c++)
             if (c < in.nch) {
               const float* ch = si.base + (uint64_t)c * si.ch_stride;
-              g0[c][e] = ch[ip];
-              g1[c][e] = ch[in2];
+              g0[c][e] = load_global(ch + ip);
+              g1[c][e] = load_global(ch + in2);
             }
         }
 #pragma unroll
@@ -268,7 +268,7 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
           }
 #pragma unroll
           for (int c = 0; c < C; c++)
-            if (c < in.nch) v[c][e] = ok ? si.base[(uint64_t)c * si.ch_stride + bi] : 0.f;
+            if (c < in.nch) v[c][e] = ok ? load_global(si.base + (uint64_t)c * si.ch_stride + bi) : 0.f;
         }
       } else {
 #pragma unroll
@@ -285,7 +285,7 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
       const uint32_t fq = j * 256 + lane * 4;  // frame within tile
       uint32_t q = tile * QPT + fq / RQ;
       const bool valid_q = q < n_quanta;
-      const QRec r = sc.qrec[valid_q ? q : 0];
+      const QRec r = load_global(sc.qrec + (valid_q ? q : 0));
       const uint32_t mode = valid_q ? r.mode : (uint32_t)Q_SILENT;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -302,9 +302,9 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
           }
 #pragma unroll
           for (int c = 0; c < C; c++)
-            if (c < in.nch) v[c][j * 4 + e] = ok ? si.base[(uint64_t)c * si.ch_stride + bi] : 0.f;
+            if (c < in.nch) v[c][j * 4 + e] = ok ? load_global(si.base + (uint64_t)c * si.ch_stride + bi) : 0.f;
         } else if (mode == Q_SLOW) {
-          const SlowRec s = sc.slow[(uint64_t)q * RQ + i];
+          const SlowRec s = load_global(sc.slow + (uint64_t)q * RQ + i);
 #pragma unroll
           for (int c = 0; c < C; c++)
             if (c < in.nch) {
@@ -312,14 +312,14 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
               if (s.prev >= 0) {
                 // audio_buffer_source.rs:754-822
                 const float* ch = si.base + (uint64_t)c * si.ch_stride;
-                const double prev_sample = (double)ch[s.prev];
+                const double prev_sample = (double)load_global(ch + s.prev);
                 double next_sample;
                 if (s.next >= 0)
-                  next_sample = (double)ch[s.next];
+                  next_sample = (double)load_global(ch + s.next);
                 else if (s.next == -1)
                   next_sample = 0.;
                 else
-                  next_sample = 2. * prev_sample - (double)ch[s.prev - 1];
+                  next_sample = 2. * prev_sample - (double)load_global(ch + s.prev - 1);
                 o = (float)__builtin_fma(1. - s.k, prev_sample, s.k * next_sample);
               }
               v[c][j * 4 + e] = o;

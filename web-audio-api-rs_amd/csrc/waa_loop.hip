@@ -18,24 +18,24 @@ namespace waa {
 
 namespace {
 __device__ __forceinline__ float param_val(const ParamRef& p, uint32_t inst, uint32_t q, uint64_t frame) {
-  if (p.mode == 0) return p.base[inst];
-  if (p.mode == 1) return p.base[(uint64_t)inst * p.stride + q];
-  return p.base[(uint64_t)inst * p.stride + frame];
+  if (p.mode == 0) return load_global(p.base + inst);
+  if (p.mode == 1) return load_global(p.base + (uint64_t)inst * p.stride + q);
+  return load_global(p.base + (uint64_t)inst * p.stride + frame);
 }
 __device__ __forceinline__ float coherent_load(const float* p) {
-  return __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return __int_as_float(__hip_atomic_load((const WAA_GLOBAL_AS int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 // waveshaper.rs:555-573
 __device__ __forceinline__ float shape(const float* curve, int nn, float input) {
   if (nn == 0) return 0.f;
   const float n = (float)nn;
   const float v = (n - 1.f) / 2.0f * (input + 1.f);
-  if (v <= 0.f) return curve[0];
-  if (v >= n - 1.f) return curve[nn - 1];
+  if (v <= 0.f) return load_global(curve);
+  if (v >= n - 1.f) return load_global(curve + nn - 1);
   const float k = floorf(v);
   const float f = v - k;
   const int ki = (int)k;
-  return (1.f - f) * curve[ki] + f * curve[ki + 1];
+  return (1.f - f) * load_global(curve + ki) + f * load_global(curve + ki + 1);
 }
 // quantum.rs:285-505 for the layouts a loop may carry (mono / stereo)
 __device__ __forceinline__ void mix12(float (&u)[2][2], int from, int to, int interp) {
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(64) void loop_kernel(const LoopDesc d) {
 #pragma unroll
             for (int c = 0; c < 2; c++)
               if (c < nc) {
-                u[c][0] = src[(uint64_t)c * sg.ch_stride + lane];
-                u[c][1] = src[(uint64_t)c * sg.ch_stride + 64 + lane];
+                u[c][0] = load_global(src + (uint64_t)c * sg.ch_stride + lane);
+                u[c][1] = load_global(src + (uint64_t)c * sg.ch_stride + 64 + lane);
               }
           }
           mix12(u, nc, li.nch_in, li.interp);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const LoopDesc d) {
             if (op.p0.mode == 2) {
 #pragma unroll
               for (int e = 0; e < 2; e++) {
-                const float g = op.p0.base[(uint64_t)inst * op.p0.stride + f0 + e * 64 + lane];
+                const float g = load_global(op.p0.base + (uint64_t)inst * op.p0.stride + f0 + e * 64 + lane);
                 v[0][e] *= g;
                 v[1][e] *= g;
               }
@@ -167,7 +167,8 @@ __global__ __launch_bounds__(64) void loop_kernel(const LoopDesc d) {
               for (int i = 0; i < RQ; i++) {
                 const double* cf = op.i0 == 0 ? cbase : op.i0 == 1 ? cbase + (uint64_t)q * 5 : cbase + (f0 + i) * 5;
                 const double x = (double)row[i];
-                double y = cf[0] * x + cf[1] * x1 + cf[2] * x2 - cf[3] * y1 - cf[4] * y2;
+                double y = load_global(cf) * x + load_global(cf + 1) * x1 + load_global(cf + 2) * x2 - load_global(cf + 3) * y1 -
+                           load_global(cf + 4) * y2;
                 if (!__builtin_isnormal(y)) y = 0.;
                 x2 = x1;
                 x1 = x;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const LoopDesc d) {
             pf = pf0 + i;
             k = k0;
           } else {
-            double dv = (double)op.p0.base[(uint64_t)inst * op.p0.stride + f0 + i];
+            double dv = (double)load_global(op.p0.base + (uint64_t)inst * op.p0.stride + f0 + i);
             if (li.in_cycle) dv = fmax(dv, d.quantum_duration);
             const double position = (double)i - dv * d.sample_rate;
             const double fl = floor(position);
@@ -246,8 +247,8 @@ __global__ __launch_bounds__(64) void loop_kernel(const LoopDesc d) {
         if (c < nco) {
           dst[c * RQ + lane] = v[c][0];
           dst[c * RQ + 64 + lane] = v[c][1];
-          gout[(uint64_t)c * li.out.ch_stride + lane] = v[c][0];
-          gout[(uint64_t)c * li.out.ch_stride + 64 + lane] = v[c][1];
+          store_global(gout + (uint64_t)c * li.out.ch_stride + lane, v[c][0]);
+          store_global(gout + (uint64_t)c * li.out.ch_stride + 64 + lane, v[c][1]);
         }
       __syncthreads();
     }

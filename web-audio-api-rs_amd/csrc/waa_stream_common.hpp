@@ -41,7 +41,7 @@ __device__ __noinline__ void load_channel_generic(const InputRef& in, const SrcI
     const uint32_t fq = j * 256 + lane * 4;
     const uint32_t q = tile * QUANTA_PER_TILE + fq / RQ;
     const bool valid_q = q < n_quanta;
-    const QRec r = sc.qrec[valid_q ? q : 0];
+    const QRec r = load_global(sc.qrec + (valid_q ? q : 0));
     const uint32_t mode = valid_q ? r.mode : (uint32_t)Q_SILENT;
     for (int e = 0; e < 4; e++) {
       const uint32_t i = (fq % RQ) + e;
@@ -55,18 +55,18 @@ __device__ __noinline__ void load_channel_generic(const InputRef& in, const SrcI
           else
             ok = false;
         }
-        o = ok ? chp[bi] : 0.f;
+        o = ok ? load_global(chp + bi) : 0.f;
       } else if (mode == Q_SLOW) {
-        const SlowRec s = sc.slow[(uint64_t)q * RQ + i];
+        const SlowRec s = load_global(sc.slow + (uint64_t)q * RQ + i);
         if (s.prev >= 0) {
-          const double prev_sample = (double)chp[s.prev];
+          const double prev_sample = (double)load_global(chp + s.prev);
           double next_sample;
           if (s.next >= 0)
-            next_sample = (double)chp[s.next];
+            next_sample = (double)load_global(chp + s.next);
           else if (s.next == -1)
             next_sample = 0.;
           else
-            next_sample = 2. * prev_sample - (double)chp[s.prev - 1];
+            next_sample = 2. * prev_sample - (double)load_global(chp + s.prev - 1);
           o = (float)__builtin_fma(1. - s.k, prev_sample, s.k * next_sample);
         }
       }
