@@ -73,6 +73,9 @@ struct InputRef {
   const SrcSchedule* sched;  // IN_SOURCE: schedule table
   ParamRef offset;        // IN_CONSTANT: the offset param
   const int64_t* active;  // IN_CONSTANT: [n_inst][2] first/last+1 active frame
+  ParamRef gain;          // has_gain: a GainNode folded into this edge (applied before the mix to the receiver's count)
+  int32_t has_gain;
+  int32_t pad;
 };
 
 enum : int32_t {

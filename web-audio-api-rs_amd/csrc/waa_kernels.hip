@@ -355,6 +355,42 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
   for (int i = 0; i < K; i++) v[0][i] = 0.f;
 }
 
+// ---- GainNode (gain.rs:143-199) on a register tile; also the gain folded into an input edge ----------------
+template <int C, int K>
+__device__ __forceinline__ void gain_regs(float (&v)[C][K], int nch, const ParamRef& p0, uint32_t inst, uint32_t tile, int lane,
+                                          uint32_t n_quanta) {
+  constexpr int NV4 = K / 4;
+  constexpr int TILE_FR = 64 * K;
+  constexpr int QPT = K / 2;
+#pragma unroll
+  for (int j = 0; j < NV4; j++) {
+    const uint32_t q = tile * QPT + j * 2 + (lane >> 5);
+    const uint32_t qc = q < n_quanta ? q : n_quanta - 1;
+    const uint64_t f = (uint64_t)tile * TILE_FR + j * 256 + lane * 4;
+    if (p0.mode == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const uint64_t fc = f + e < (uint64_t)n_quanta * RQ ? f + e : (uint64_t)n_quanta * RQ - 1;
+        const float g = p0.base[(uint64_t)inst * p0.stride + fc];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+          if (c < nch) v[c][j * 4 + e] *= g;
+      }
+    } else {
+      // gain.rs:163-179: |g| <= 1e-6 -> silent, |1-g| <= 1e-6 -> passthrough
+      const float g = param_at(p0, inst, qc, 0);
+      const bool mute = fabsf(g) <= 1e-6f;
+      const bool pass = fabsf(1.f - g) <= 1e-6f;
+#pragma unroll
+      for (int c = 0; c < C; c++)
+        if (c < nch) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[c][j * 4 + e] = mute ? 0.f : (pass ? v[c][j * 4 + e] : v[c][j * 4 + e] * g);
+        }
+    }
+  }
+}
+
 // ---- biquad (biquad_filter.rs:764-899) on the transposed layout --------------------------
 struct Mat2 {
   double a, b, c, d;  // [[a b],[c d]]
@@ -584,7 +620,8 @@ __device__ __forceinline__ void stereo_gains_dev(float x, float& gl, float& gr) 
 // doubles the kernel's VGPR count (57 -> 110 for C = 2), i.e. halves the waves per SIMD of kernels that are bound
 // by the latency of their dependent loads.
 template <int C, int K, bool SERIAL, bool FANIN = true>
-__global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDesc d) {
+__global__ __launch_bounds__(SERIAL ? 64 : 256) __attribute__((amdgpu_waves_per_eu((!SERIAL && FANIN && C == 2) ? 6 : 1)))
+void chain_kernel(const ChainDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NV4 = K / 4;
   constexpr int TILE_FR = 64 * K;
@@ -643,6 +680,7 @@ __global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDes
     // ---- inputs: mix every incoming edge to the node's computed channel count and sum in edge order
     if constexpr (!FANIN) {
       load_input<C, K>(d.in[0], inst, tile, lane, d.n_quanta, v);
+      if (d.in[0].has_gain) gain_regs<C, K>(v, d.in[0].nch, d.in[0].gain, inst, tile, lane, d.n_quanta);
       mix_regs<C, K>(v, d.in[0].nch, d.in_nch, d.in_interp);
     } else {
       // one copy of the input fetch for all edges (not an unrolled first edge + loop): half the registers
@@ -657,6 +695,7 @@ __global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDes
         int lane_k = lane;  // opaque per iteration: per-lane address terms are recomputed, not kept live (LICM)
         asm volatile("" : "+v"(lane_k));
         load_input<C, K>(d.in[k], inst, tile, lane_k, d.n_quanta, u);
+        if (d.in[k].has_gain) gain_regs<C, K>(u, d.in[k].nch, d.in[k].gain, inst, tile, lane_k, d.n_quanta);
         mix_regs<C, K>(u, d.in[k].nch, d.in_nch, d.in_interp);
 #pragma unroll
         for (int c = 0; c < C; c++)
@@ -670,36 +709,9 @@ __global__ __launch_bounds__(SERIAL ? 64 : 256) void chain_kernel(const ChainDes
     for (int o = 0; o < d.n_ops; o++) {
       const OpDesc& op = d.ops[o];
       switch (op.kind) {
-        case OP_GAIN: {
-#pragma unroll
-          for (int j = 0; j < NV4; j++) {
-            const uint32_t q = tile * QPT + j * 2 + (lane >> 5);
-            const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
-            const uint64_t f = (uint64_t)tile * TILE_FR + j * 256 + lane * 4;
-            if (op.p0.mode == 2) {
-#pragma unroll
-              for (int e = 0; e < 4; e++) {
-                const uint64_t fc = f + e < (uint64_t)d.n_quanta * RQ ? f + e : (uint64_t)d.n_quanta * RQ - 1;
-                const float g = op.p0.base[(uint64_t)inst * op.p0.stride + fc];
-#pragma unroll
-                for (int c = 0; c < C; c++)
-                  if (c < op.nch_in) v[c][j * 4 + e] *= g;
-              }
-            } else {
-              // gain.rs:163-179: |g| <= 1e-6 -> silent, |1-g| <= 1e-6 -> passthrough
-              const float g = param_at(op.p0, inst, qc, 0);
-              const bool mute = fabsf(g) <= 1e-6f;
-              const bool pass = fabsf(1.f - g) <= 1e-6f;
-#pragma unroll
-              for (int c = 0; c < C; c++)
-                if (c < op.nch_in) {
-#pragma unroll
-                  for (int e = 0; e < 4; e++) v[c][j * 4 + e] = mute ? 0.f : (pass ? v[c][j * 4 + e] : v[c][j * 4 + e] * g);
-                }
-            }
-          }
+        case OP_GAIN:
+          gain_regs<C, K>(v, op.nch_in, op.p0, inst, tile, lane, d.n_quanta);
           break;
-        }
         case OP_PARAM_ADD: {
           // AudioParamProcessor::mix_to_output (param.rs:737-795): input (already mixed to one channel) + intrinsic
           // value, NaN -> default, clamp with max/min (not `clamp`: no NaN branch)

@@ -263,7 +263,7 @@ int push_chain_step(waa_batch* b, const std::vector<InputRef>& inputs, int in_nc
     std::string ins;
     for (auto& in : inputs) {
       char t[48];
-      snprintf(t, sizeof t, "%s:%dch", input_kind_name(in.kind), in.nch);
+      snprintf(t, sizeof t, "%s%s:%dch", in.has_gain ? "gain*" : "", input_kind_name(in.kind), in.nch);
       ins += ins.empty() ? t : std::string("+") + t;
     }
     plan_note(b, "chain %s C=%d in=[%s]->%dch ops=[%s] out=%dch", serial ? "serial" : "parallel", cmax, ins.c_str(), in_nch,
@@ -305,7 +305,7 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     }
     // the streaming kernel wants ONE plain input (signal or source) of exactly the biquad's channel count
     const bool iir_exact = o.kind == OP_IIR && o.i0 < 0;  // the lane-per-stream kernel reads a materialised signal
-    const bool plain = pending.empty() && inputs.size() == 1 &&
+    const bool plain = pending.empty() && inputs.size() == 1 && !inputs[0].has_gain &&
                        ((inputs[0].kind == IN_SOURCE && !iir_exact) || inputs[0].kind == IN_SIGNAL) && inputs[0].nch == cur_nch;
     if (!plain) {
       SignalRef tmp;
@@ -861,10 +861,11 @@ int build_plan(waa_batch* b) {
     }
   }
   // materialisation points
+  std::vector<uint8_t> mat_hard(N, 0), fan_in_only(N, 0);
   for (uint32_t id = 0; id < N; id++) {
     Node& n = b->nodes[id];
     if (!n.live) continue;
-    bool mat = false;
+    bool mat = false, fan = false;
     const uint32_t kind = n.desc.kind;
     if (kind == WAA_NODE_DESTINATION || kind == WAA_NODE_ANALYSER || kind == WAA_NODE_CONVOLVER || kind == WAA_NODE_DELAY) mat = true;
     if (scc_of[id] >= 0) mat = true;  // loop members publish their own signal
@@ -880,11 +881,36 @@ int build_plan(waa_batch* b) {
         int live_in = 0;
         for (int ie : c.in_edges)
           if (b->nodes[b->edges[ie].from].live) live_in++;
-        if (live_in > 1) mat = true;
+        if (live_in > 1) fan = true;
       }
     if (live_consumers != 1) mat = true;
-    n.materialized = mat;
+    mat_hard[id] = mat;
+    fan_in_only[id] = !mat && fan;
+    n.materialized = mat || fan;
   }
+  // A producer that is materialised ONLY because its single consumer sums several inputs can instead be folded
+  // into that consumer's input stage: a source is fetched by the summing kernel itself, and a GainNode on a
+  // materialised signal (or on a source) becomes a per-edge gain — the mixer pattern source->Gain->bus costs no
+  // pass through HBM of its own.
+  auto is_source_kind = [&](uint32_t k) { return k == WAA_NODE_BUFFER_SOURCE || k == WAA_NODE_CONSTANT_SOURCE; };
+  if (!getenv("WAA_NO_EDGE_FOLD"))
+    for (uint32_t id = 0; id < N; id++) {
+      Node& n = b->nodes[id];
+      if (!n.live || !fan_in_only[id]) continue;
+      if (is_source_kind(n.desc.kind)) {
+        n.materialized = false;
+        continue;
+      }
+      if (n.desc.kind != WAA_NODE_GAIN || n.in_edges.size() != 1 || n.in_nch != n.out_nch) continue;
+      bool modulated = false;
+      for (auto& pe : n.pin_edges) modulated |= !pe.empty();
+      if (modulated) continue;
+      const uint32_t x = b->edges[n.in_edges[0]].from;
+      const Node& xn = b->nodes[x];
+      if (!xn.live || xn.out_nch != n.in_nch) continue;
+      // x is either materialised for its own reasons, or a source whose only consumer is this gain
+      if (mat_hard[x] || (is_source_kind(xn.desc.kind) && !fan_in_only[x])) n.materialized = false;
+    }
   auto alloc_signal = [&](Node& n) -> int {
     float* p = nullptr;
     int e = dev_alloc(b, &p, (size_t)b->n_inst * n.out_nch * b->lp);
@@ -1007,12 +1033,28 @@ int build_plan(waa_batch* b) {
       cd.in_interp = hn.interp;
       std::vector<InputRef> ins;
       for (int ie : hn.in_edges) {
-        Node& pn = b->nodes[b->edges[ie].from];
-        if (!pn.materialized) return fail(WAA_ERR_INVALID_STATE, "internal: unmaterialised fan-in input");
+        uint32_t pid = b->edges[ie].from;
         InputRef in{};
-        in.kind = IN_SIGNAL;
+        if (!b->nodes[pid].materialized && b->nodes[pid].desc.kind == WAA_NODE_GAIN) {
+          // a GainNode folded into the edge (see the materialisation pass)
+          int e = node_param(b, pid, 0, &in.gain);
+          if (e) return e;
+          in.has_gain = 1;
+          plan_note(b, "gain node %u folded into an input edge of node %u", pid, head);
+          pid = b->edges[b->nodes[pid].in_edges[0]].from;
+        }
+        Node& pn = b->nodes[pid];
         in.nch = pn.out_nch;
-        in.sig = pn.sig;
+        if (pn.materialized) {
+          in.kind = IN_SIGNAL;
+          in.sig = pn.sig;
+        } else if (pn.desc.kind == WAA_NODE_BUFFER_SOURCE || pn.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
+          in.kind = pn.desc.kind == WAA_NODE_BUFFER_SOURCE ? IN_SOURCE : IN_CONSTANT;
+          int e = prepare_source_input(b, pid, &in);
+          if (e) return e;
+        } else {
+          return fail(WAA_ERR_INVALID_STATE, "internal: unmaterialised fan-in input");
+        }
         ins.push_back(in);
       }
       int e = reduce_fan_in(b, ins, hn.in_nch, hn.interp);
@@ -1036,7 +1078,7 @@ int build_plan(waa_batch* b) {
       cur_nch = out_nch;
     }
     // source inputs: schedules / buffer tables / constant ranges
-    if (cd.in[0].kind == IN_SOURCE || cd.in[0].kind == IN_CONSTANT) {
+    if (hn.desc.kind == WAA_NODE_BUFFER_SOURCE || hn.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
       int e = prepare_source_input(b, head, &cd.in[0]);
       if (e) return e;
     }
