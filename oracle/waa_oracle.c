@@ -549,7 +549,7 @@ static float tl_set_target_sample(double start_time, double time_constant, float
 static float tl_set_value_curve_sample(double start_time, double duration, const float* values, int n, double time) {
   if (time - start_time >= duration) return values[n - 1]; /* :107-121 */
   double position = (double)(n - 1) * (time - start_time) / duration;
-  int k = (int)position;
+  int k = position > 0. ? (int)position : 0; /* `as usize` saturates: negative (sample time before the start) -> 0 */
   float phase = (float)(position - floor(position));
   return fmaf(values[k + 1] - values[k], phase, values[k]);
 }

@@ -452,3 +452,73 @@ def test_scheduling_errors_reach_the_caller(be):
     g.connect(c.destination())
     with pytest.raises(waa.WaaError, match="RangeError"):
         c.prepare()
+
+
+
+def test_value_curve_sampled_before_its_start_follows_the_reference_arithmetic(mk):
+    """param.rs:1470-1478 with :116-119: when a SetValueCurve is reached in a block that ends BEFORE the curve starts
+    (an earlier event of the same block was consumed first), the intrinsic value kept for the next block is the
+    curve sampled at next_block_time < start_time.  `position as usize` saturates to 0 in Rust and the phase is the
+    fractional part of the NEGATIVE position: (3 - 1) * 0.5 + 1 = 2, not the 0.5 the SetValueAtTime left behind.
+    A quirk of the reference, reproduced (both restatements used to index the curve at -3 here)."""
+    p = mk(0.0, -10.0, 10.0)
+    p.ok(SET_AT, 0.5, 2.0)
+    p.ok(CURVE, 0.0, 20.0, 4.0, curve=[1.0, 3.0])
+    eq(p.compute(0.0), [0.0, 0.0, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5])
+    eq(p.compute(10.0), [2.0])  # constant block (the curve starts at next_block_time): the intrinsic value
+    eq(p.compute(20.0)[:5], [1.0, 1.5, 2.0, 2.5, 3.0])
+
+
+def test_ramp_without_a_consumed_event_does_not_crash(mk):
+    """A ramp inserted BEFORE an already queued first event has no last event to start from; the reference panics on
+    `last_event.unwrap()` (param.rs:1107).  Both restatements read a zero event instead and keep rendering."""
+    p = mk(0.25, -10.0, 10.0)
+    p.ok(CURVE, 0.0, 20.0, 1.0, curve=[0.5, -0.5])
+    p.ok(LIN, 4.0, 8.0)  # queue not empty: no implicit SetValue in front of the ramp
+    eq(p.compute(0.0), [0.0, 0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0, 4.0])
+
+
+# --------------------------------------------------------------------------- differential fuzz (CPU only)
+def _random_schedule(rng, tls, horizon):
+    """the same random automation calls on every timeline in `tls`; returns the list of status codes"""
+    statuses = []
+    t = 0.0
+    for _ in range(int(rng.integers(1, 9))):
+        kind = int(rng.choice([SET, SET_AT, LIN, EXP, TARGET, CURVE, CANCEL, HOLD], p=[.08, .2, .2, .14, .14, .1, .07, .07]))
+        t += float(rng.choice([0.0, 0.25, 1.0, 3.0, 7.5, 20.0]))
+        value = float(rng.choice([-2.0, -0.5, 0.0, 1e-3, 0.5, 1.0, 3.0]))  # EXP to/from 0 and opposite signs included
+        aux, curve = 0.0, None
+        if kind == TARGET:
+            aux = float(rng.choice([0.0, 0.5, 4.0, 30.0]))  # time constant (0: jump)
+        if kind == CURVE:
+            curve = rng.uniform(-1.0, 1.0, int(rng.integers(2, 7))).astype(np.float32)
+            aux = float(rng.choice([1.0, 4.0, 10.5]))  # duration
+        when = t if rng.random() < 0.85 else max(0.0, t - float(rng.uniform(0.0, 6.0)))  # sometimes out of order
+        statuses.append(tuple(tl.event(kind, value, when, aux, curve) for tl in tls))
+    return statuses
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_random_schedules_agree_between_the_two_restatements(orc_lib, hip, seed):
+    """The oracle's timeline (plain C) and the product's (C++) are written independently from src/param.rs:796-1584;
+    random event lists — ramps to and from zero, out-of-order insertion, overlapping curves (refused), cancels and
+    holds in the middle of ramps — have to give the same status codes and bit-identical blocks, a-rate and k-rate,
+    including the intrinsic value after every block."""
+    rng = np.random.default_rng(seed)
+    a_rate = bool(rng.integers(0, 2))
+    lo, hi = (-1.5, 2.5) if rng.random() < 0.5 else (-3.4028235e38, 3.4028235e38)
+    tls = [TL(orc_lib, "orc_", 0.25, lo, hi, a_rate), TL(hip.lib, "waa_", 0.25, lo, hi, a_rate)]
+    horizon = 80
+    done = 0
+    while done < horizon:
+        st = _random_schedule(rng, tls, horizon)
+        for s in st:
+            assert s[0] == s[1], (seed, st)
+        n = int(rng.choice([8, 16]))
+        o = tls[0].compute(float(done), count=n)
+        p = tls[1].compute(float(done), count=n)
+        assert o.shape == p.shape, (seed, done)
+        assert np.array_equal(o, p, equal_nan=True), (seed, done, o, p)
+        vo, vp = tls[0].value(), tls[1].value()
+        assert vo == vp or (np.isnan(vo) and np.isnan(vp)), (seed, done)
+        done += n

@@ -29,7 +29,10 @@ float target_sample(double t0, double time_constant, float v1, float diff, doubl
 float curve_sample(double t0, double duration, const std::vector<float>& values, double t) {
   if (t - t0 >= duration) return values.back();
   const double position = (double)(values.size() - 1) * (t - t0) / duration;
-  const size_t k = (size_t)position;
+  // `position as usize` saturates in Rust: a sample time before the curve's start (the intrinsic value kept for
+  // the NEXT block while the curve has not started yet, param.rs:1470-1478) reads segment 0 with the fractional
+  // part of the negative position — reproduced, not repaired
+  const size_t k = position > 0. ? (size_t)position : 0;
   const float phase = (float)(position - std::floor(position));
   return std::fma(values[k + 1] - values[k], phase, values[k]);
 }
@@ -219,10 +222,15 @@ uint32_t Timeline::compute(double block_time, double dt, uint32_t count, float* 
       case WAA_EVENT_LINEAR_RAMP:
       case WAA_EVENT_EXPONENTIAL_RAMP: {  // param.rs:1100-1278
         const bool linear = ev.type == WAA_EVENT_LINEAR_RAMP;
-        const double t0 = last_->time;
+        // (a ramp or target at the head of the queue with no consumed event before it — possible when later calls
+        // insert events EARLIER than an already queued first ramp — makes the reference panic, param.rs:1107 `unwrap`;
+        // here the missing event reads as time 0 / value 0, like the oracle, instead of crashing the caller)
+        const Event no_event{};
+        const Event& last = last_ ? *last_ : no_event;
+        const double t0 = last.time;
         const double duration = ev.time - t0;  // the declared slope survives a CancelAndHold
         const double t1 = ev.cancelled ? ev.cancel_time : ev.time;
-        const float v0 = last_->value, v1 = ev.value;
+        const float v0 = last.value, v1 = ev.value;
         const float k = linear ? v1 - v0 : v1 / v0;
         if (!linear && (v0 == 0.f || v0 * v1 < 0.f)) {  // v(t) = V0 until T1: behaves as a SetValueAtTime(T1)
           Event rep;
@@ -279,7 +287,7 @@ uint32_t Timeline::compute(double block_time, double dt, uint32_t count, float* 
           ended = true;
         }
         const double t0 = ev.time, tau = ev.time_constant;
-        const float v0 = last_->value, v1 = ev.value, diff = v0 - v1;
+        const float v0 = last_ ? last_->value : 0.f, v1 = ev.value, diff = v0 - v1;  // (no consumed event: see the ramps)
         if (a_rate_) {
           const uint32_t end = end_index(t1);
           if (end > len) {
