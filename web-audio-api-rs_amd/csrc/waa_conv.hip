@@ -19,6 +19,8 @@
 // a streaming f32 FMA kernel.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "waa_internal.hpp"
 
 namespace waa {
@@ -277,6 +279,222 @@ __global__ void conv_fft_kernel(const ConvDesc d) {
   }
 }
 
+// ---- N = 16384 (B = 8192, long IRs): persistent, software-pipelined FFT workgroups ------------------------------
+// One 16384-point complex FFT fills 144 KB of LDS, so only ONE workgroup fits on a CU and the plain kernel above
+// runs load -> FFT -> store strictly one after the other: the memory system idles while the CU computes and vice
+// versa (it reached ~2.5 TB/s).  Here a workgroup walks a run of consecutive blocks of one (pair, channel):
+//   * the NEXT block's input is requested into registers before the current FFT starts, so its HBM latency is
+//     hidden behind the butterflies; the spectrum / output stores of the current block are fire-and-forget;
+//   * forward: consecutive overlap-save windows share half their samples — the shared half stays in registers and
+//     the input is read once instead of twice;
+//   * every twiddle a thread needs (13 complex values: thread t always meets the same twiddle in stages 2..4) is
+//     loaded once per workgroup and lives in registers: no global loads inside the butterfly stages.
+// The arithmetic and its order are those of fft_dif_padded / fft_dit_inv_padded for n = 16384 (which butterfly a thread
+// executes does not change any value): results are bit-identical to the plain kernel (WAA_CONV_FFT_PLAIN=1 selects it; tests compare the two).
+constexpr int PIPE_N = 16384, PIPE_NT = 512, PIPE_B = PIPE_N / 2;
+constexpr int PIPE_IT = PIPE_N / 4 / PIPE_NT;     // radix-4 butterflies per thread and stage (8)
+constexpr int PIPE_ROWS = PIPE_N / 16 / PIPE_NT;  // 16-element register rows per thread in the tail (2)
+struct PipeTw {
+  Cplx s0[PIPE_IT];  // stage 0 (q = 4096): one per butterfly of this thread
+  Cplx s1[2];        // stage 1 (q = 1024 = 2 x threads): even / odd butterflies
+  Cplx s[3];         // stages 2..4 (q = 256, 64, 16 <= threads): the same twiddle for every butterfly
+  Cplx t[4];         // register tail: exp(-2 pi i j / 16), j = 0..3 (uniform)
+};
+template <bool KEEP0>
+__device__ __forceinline__ PipeTw pipe_twiddles(const Cplx* tw, int tid) {
+  PipeTw r;
+#pragma unroll
+  for (int it = 0; it < PIPE_IT; it++) r.s0[it] = KEEP0 ? tw[tid + it * PIPE_NT] : Cplx{0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < 2; h++) r.s1[h] = tw[((tid + h * PIPE_NT) % 1024) * 4];
+#pragma unroll
+  for (int st = 2; st <= 4; st++) {
+    const int q = PIPE_N >> (2 * (st + 1));
+    r.s[st - 2] = tw[(tid % q) * (PIPE_N / (4 * q))];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) r.t[j] = tw[j * (PIPE_N >> 4)];
+  return r;
+}
+// one radix-4 pass over this thread's butterflies of stage `st` (same index arithmetic as fft_dif_padded)
+// KEEP0 = false: the stage-0 twiddles (8 per thread) are re-read from the table (L2 hits, all eight requests go
+// out before the first butterfly) instead of living in 16 registers — the forward kernel needs those for its two
+// half windows
+template <bool INVERSE, bool KEEP0>
+__device__ __forceinline__ void pipe_stage(Cplx* a, int st, const PipeTw& w, const Cplx* twg, int tid) {
+  const int q = PIPE_N >> (2 * (st + 1));
+#pragma unroll
+  for (int it = 0; it < PIPE_IT; it++) {
+    const int b = tid + it * PIPE_NT;
+    const int j = b % q, base = (b / q) * 4 * q + j;
+    const int i0 = pad(base), i1 = pad(base + q), i2 = pad(base + 2 * q), i3 = pad(base + 3 * q);
+    const Cplx tw = st == 0 ? (KEEP0 ? w.s0[it] : twg[tid + it * PIPE_NT]) : st == 1 ? w.s1[it & 1] : w.s[st - 2];
+    Cplx x0 = a[i0], x1 = a[i1], x2 = a[i2], x3 = a[i3];
+    if (INVERSE)
+      radix4_dit(x0, x1, x2, x3, conj(tw), true);
+    else
+      radix4_dif(x0, x1, x2, x3, tw, true);
+    a[i0] = x0;
+    a[i1] = x1;
+    a[i2] = x2;
+    a[i3] = x3;
+  }
+}
+__device__ __forceinline__ void pipe_fft_dif(Cplx* a, const PipeTw& w, const Cplx* twg, int tid) {
+#pragma unroll
+  for (int st = 0; st <= 4; st++) {
+    pipe_stage<false, false>(a, st, w, twg, tid);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int rr = 0; rr < PIPE_ROWS; rr++) {
+    float4* row = reinterpret_cast<float4*>(a + 18 * (tid + rr * PIPE_NT));  // elements [16t, 16t+16)
+    Cplx x[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float4 v = row[k];
+      x[2 * k] = Cplx{v.x, v.y};
+      x[2 * k + 1] = Cplx{v.z, v.w};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) radix4_dif(x[j], x[j + 4], x[j + 8], x[j + 12], w.t[j], true);
+#pragma unroll
+    for (int g = 0; g < 4; g++) radix4_dif(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], Cplx{1.f, 0.f}, false);
+#pragma unroll
+    for (int k = 0; k < 8; k++) row[k] = make_float4(x[2 * k].re, x[2 * k].im, x[2 * k + 1].re, x[2 * k + 1].im);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void pipe_fft_dit_inv(Cplx* a, const PipeTw& w, int tid) {
+#pragma unroll
+  for (int rr = 0; rr < PIPE_ROWS; rr++) {
+    float4* row = reinterpret_cast<float4*>(a + 18 * (tid + rr * PIPE_NT));
+    Cplx x[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float4 v = row[k];
+      x[2 * k] = Cplx{v.x, v.y};
+      x[2 * k + 1] = Cplx{v.z, v.w};
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) radix4_dit(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], Cplx{1.f, 0.f}, false);
+#pragma unroll
+    for (int j = 0; j < 4; j++) radix4_dit(x[j], x[j + 4], x[j + 8], x[j + 12], conj(w.t[j]), true);
+#pragma unroll
+    for (int k = 0; k < 8; k++) row[k] = make_float4(x[2 * k].re, x[2 * k].im, x[2 * k + 1].re, x[2 * k + 1].im);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int st = 4; st >= 0; st--) {
+    pipe_stage<true, true>(a, st, w, nullptr, tid);
+    __syncthreads();
+  }
+}
+
+constexpr int PIPE_H = PIPE_B / 4 / PIPE_NT;  // float4 groups per thread in half a window (4)
+constexpr int PIPE_S = PIPE_N / 2 / PIPE_NT;  // float4 (two complex bins) per thread in a spectrum (16)
+// half a window = B frames of both instances: PIPE_H x (16 B of a, 16 B of b) per thread
+__device__ __forceinline__ void pipe_load_half(const float* pa, const float* pb, bool has_b, int64_t f0, uint64_t frames, int tid,
+                                               f4v (&va)[PIPE_H], f4v (&vb)[PIPE_H]) {
+#pragma unroll
+  for (int r = 0; r < PIPE_H; r++) {
+    const int64_t f = f0 + 4 * (int64_t)(tid + r * PIPE_NT);
+    va[r] = f4v{0.f, 0.f, 0.f, 0.f};
+    vb[r] = f4v{0.f, 0.f, 0.f, 0.f};
+    if (f >= 0 && (uint64_t)f + 3 < frames) {
+      va[r] = *reinterpret_cast<const f4v*>(pa + f);
+      if (has_b) vb[r] = *reinterpret_cast<const f4v*>(pb + f);
+    }
+  }
+}
+__device__ __forceinline__ void pipe_stage_half(Cplx* a, int e0, int tid, const f4v (&va)[PIPE_H], const f4v (&vb)[PIPE_H]) {
+#pragma unroll
+  for (int r = 0; r < PIPE_H; r++) {
+    f4v* dst4 = reinterpret_cast<f4v*>(a + pad(e0 + 4 * (tid + r * PIPE_NT)));
+    dst4[0] = f4v{va[r].x, vb[r].x, va[r].y, vb[r].y};
+    dst4[1] = f4v{va[r].z, vb[r].z, va[r].w, vb[r].w};
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d, int blocks_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  Cplx* a = reinterpret_cast<Cplx*>(lds_raw);
+  const int tid = threadIdx.x;
+  const int c = blockIdx.y;
+  const uint32_t pair = blockIdx.z;
+  const int k0 = blockIdx.x * blocks_per_wg;
+  const int k1 = k0 + blocks_per_wg < d.nb ? k0 + blocks_per_wg : d.nb;
+  if (k0 >= k1) return;
+  const PipeTw w = pipe_twiddles<MODE == MODE_INV>(d.tw, tid);
+  const uint32_t ia = pair * 2, ib = pair * 2 + 1;
+  const bool has_b = ib < d.n_inst;
+  if (MODE == MODE_FWD) {
+    const float* pa = d.in.base + (uint64_t)ia * d.in.inst_stride + (uint64_t)c * d.in.ch_stride;
+    const float* pb = d.in.base + (uint64_t)(has_b ? ib : ia) * d.in.inst_stride + (uint64_t)c * d.in.ch_stride;
+    f4v oa[PIPE_H], ob[PIPE_H], na[PIPE_H], nb[PIPE_H];
+    pipe_load_half(pa, pb, has_b, ((int64_t)k0 - 1) * PIPE_B, d.frames, tid, oa, ob);
+    pipe_load_half(pa, pb, has_b, (int64_t)k0 * PIPE_B, d.frames, tid, na, nb);
+    for (int k = k0; k < k1; k++) {
+      // (opaque copy of the thread index: otherwise every LDS address of all five stages is loop-invariant, gets
+      // hoisted out of the block loop and ~160 address registers stay live across it)
+      int tid_k = tid;
+      asm volatile("" : "+v"(tid_k));
+      pipe_stage_half(a, 0, tid_k, oa, ob);  // window [(k-1)B, (k+1)B)
+      pipe_stage_half(a, PIPE_B, tid_k, na, nb);
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < PIPE_H; r++) {
+        oa[r] = na[r];
+        ob[r] = nb[r];
+      }
+      // the next block's new half: in flight during the FFT below (all-zero past the end of the stream)
+      pipe_load_half(pa, pb, has_b, k + 1 < k1 ? ((int64_t)k + 1) * PIPE_B : (int64_t)d.frames, d.frames, tid_k, na, nb);
+      pipe_fft_dif(a, w, d.tw, tid_k);
+      f4v* dst = reinterpret_cast<f4v*>(d.X + (((uint64_t)pair * d.cin + c) * d.nb + k) * PIPE_N);
+#pragma unroll
+      for (int r = 0; r < PIPE_S; r++) {
+        const int i = tid_k + r * PIPE_NT;
+        dst[i] = *reinterpret_cast<const f4v*>(a + pad(2 * i));
+      }
+      __syncthreads();  // LDS is rewritten by the next window
+    }
+  } else {
+    float* pa = d.out.base + (uint64_t)ia * d.out.inst_stride + (uint64_t)c * d.out.ch_stride;
+    float* pb = d.out.base + (uint64_t)(has_b ? ib : ia) * d.out.inst_stride + (uint64_t)c * d.out.ch_stride;
+    const float scale = 1.f / (float)PIPE_N;
+    const f4v* ybase = reinterpret_cast<const f4v*>(d.Y + ((uint64_t)pair * d.cout + c) * d.nb * PIPE_N);
+    f4v y[PIPE_S];
+#pragma unroll
+    for (int r = 0; r < PIPE_S; r++) y[r] = ybase[(uint64_t)k0 * (PIPE_N / 2) + tid + r * PIPE_NT];
+    for (int k = k0; k < k1; k++) {
+      int tid_k = tid;
+      asm volatile("" : "+v"(tid_k));
+#pragma unroll
+      for (int r = 0; r < PIPE_S; r++) *reinterpret_cast<f4v*>(a + pad(2 * (tid_k + r * PIPE_NT))) = y[r];
+      __syncthreads();
+      // the next spectrum: in flight during the inverse FFT below (the last block re-reads itself: harmless)
+      const int kn = k + 1 < k1 ? k + 1 : k;
+#pragma unroll
+      for (int r = 0; r < PIPE_S; r++) y[r] = ybase[(uint64_t)kn * (PIPE_N / 2) + tid_k + r * PIPE_NT];
+      pipe_fft_dit_inv(a, w, tid_k);
+#pragma unroll
+      for (int r = 0; r < PIPE_H; r++) {
+        const int i4 = tid_k + r * PIPE_NT;
+        const uint64_t f = (uint64_t)k * PIPE_B + 4 * (uint64_t)i4;
+        if (f + 3 < d.frames) {
+          // overlap-save: the last B samples are the linear convolution; re -> instance a, im -> instance b
+          const f4v p0 = reinterpret_cast<const f4v*>(a + pad(PIPE_B + 4 * i4))[0];
+          const f4v p1 = reinterpret_cast<const f4v*>(a + pad(PIPE_B + 4 * i4))[1];
+          *reinterpret_cast<f4v*>(pa + f) = f4v{p0.x * scale, p0.z * scale, p1.x * scale, p1.z * scale};
+          if (has_b) *reinterpret_cast<f4v*>(pb + f) = f4v{p0.y * scale, p0.w * scale, p1.y * scale, p1.w * scale};
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // Y_k = sum_terms sum_p H_p X_{k-p}, KT output blocks per register tile, partitions in chunks of PC.
 // A thread owns one spectral position and walks ALL k-tiles of its (pair, output channel) in order, so the
 // (PC - 1) input spectra a tile shares with its predecessor were read by the same CU a moment ago (L2 / MALL
@@ -429,6 +647,8 @@ static void allow_big_lds(size_t bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_IR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   done = true;
 }
 
@@ -437,13 +657,35 @@ void launch_conv_ir_spectra(const ConvDesc& d, void* stream) {
   hipLaunchKernelGGL(conv_fft_kernel<MODE_IR>, dim3(d.parts, d.ir_nch, 1), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
                      (hipStream_t)stream, d);
 }
+// blocks per persistent workgroup: whole (pair, channel) streams when there are enough of them to fill the chip,
+// shorter runs otherwise
+static int pipe_blocks_per_wg(const ConvDesc& d, int channels) {
+  const int streams = (int)d.n_pairs * channels;
+  int segs = streams >= 512 ? 1 : (512 + streams - 1) / streams;
+  if (segs > d.nb) segs = d.nb;
+  return (d.nb + segs - 1) / segs;
+}
+static bool use_pipe(const ConvDesc& d) { return d.n == PIPE_N && !getenv("WAA_CONV_FFT_PLAIN"); }
+
 void launch_conv_forward(const ConvDesc& d, void* stream) {
   allow_big_lds((size_t)d.n * sizeof(Cplx));
+  if (use_pipe(d)) {
+    const int bpw = pipe_blocks_per_wg(d, d.cin);
+    hipLaunchKernelGGL(conv_fft_pipe_kernel<MODE_FWD>, dim3((d.nb + bpw - 1) / bpw, d.cin, d.n_pairs), dim3(PIPE_NT),
+                       (size_t)(d.n + d.n / 8) * sizeof(Cplx), (hipStream_t)stream, d, bpw);
+    return;
+  }
   hipLaunchKernelGGL(conv_fft_kernel<MODE_FWD>, dim3(d.nb, d.cin, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
                      (hipStream_t)stream, d);
 }
 void launch_conv_inverse(const ConvDesc& d, void* stream) {
   allow_big_lds((size_t)d.n * sizeof(Cplx));
+  if (use_pipe(d)) {
+    const int bpw = pipe_blocks_per_wg(d, d.cout);
+    hipLaunchKernelGGL(conv_fft_pipe_kernel<MODE_INV>, dim3((d.nb + bpw - 1) / bpw, d.cout, d.n_pairs), dim3(PIPE_NT),
+                       (size_t)(d.n + d.n / 8) * sizeof(Cplx), (hipStream_t)stream, d, bpw);
+    return;
+  }
   hipLaunchKernelGGL(conv_fft_kernel<MODE_INV>, dim3(d.nb, d.cout, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
                      (hipStream_t)stream, d);
 }
