@@ -707,6 +707,9 @@ void launch_conv_mac(const ConvDesc& d, void* stream) {
   if (d.parts <= 8)
     hipLaunchKernelGGL((conv_mac_kernel<16, 8>), grid, dim3(256), 0, (hipStream_t)stream, d);
   else
+    // (32 and 30 output blocks per register tile were measured: fewer re-reads of X on paper, but 280 registers
+    // leave one wave per SIMD (5.5 ms) and capping at 256 spills (4.7 ms) against 4.6 ms for this one — the
+    // re-reads are L2 / MALL hits already)
     hipLaunchKernelGGL((conv_mac_kernel<16, 24>), grid, dim3(256), 0, (hipStream_t)stream, d);
 }
 
