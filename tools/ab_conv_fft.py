@@ -28,21 +28,13 @@ def render_small(mode, name, n_small=6):
 
 
 for name in ("t1",):
-    os.environ["WAA_CONV_MAC_KT16"] = "1"
-    a = render_small("plain", name)
-    os.environ.pop("WAA_CONV_MAC_KT16", None)
-    b = render_small("pipe", name)
+    a, b = render_small("plain", name), render_small("pipe", name)
     print(name, "plain vs pipelined bit-identical:", bool(np.array_equal(a, b)), "max |d|", float(np.abs(a - b).max()), flush=True)
 for name in ("t1", "c3"):
-    for mode in ("plain", "pipe", "pipe+kt32", "pipe+kt30"):
+    for mode in ("plain", "pipe"):
         os.environ.pop("WAA_CONV_FFT_PLAIN", None)
-        os.environ.pop("WAA_CONV_MAC_KT", None)
-        os.environ["WAA_CONV_MAC_KT16"] = "1"
         if mode == "plain":
             os.environ["WAA_CONV_FFT_PLAIN"] = "1"
-        if "+kt" in mode:
-            os.environ.pop("WAA_CONV_MAC_KT16", None)
-            os.environ["WAA_CONV_MAC_KT"] = mode[-2:]
         ctx, _ = bench.build_workload(waa, hip, name, n_inst, frames, 0, noise.data_ptr())
         ctx.prepare()
         ctx.render_async()
