@@ -287,53 +287,107 @@ __global__ void conv_fft_kernel(const ConvDesc d) {
 //     hidden behind the butterflies; the spectrum / output stores of the current block are fire-and-forget;
 //   * forward: consecutive overlap-save windows share half their samples — the shared half stays in registers and
 //     the input is read once instead of twice;
-//   * every twiddle a thread needs (13 complex values: thread t always meets the same twiddle in stages 2..4) is
+//   * every twiddle a thread needs (the forward kernel re-reads the eight q = 4096 ones per block) is
 //     loaded once per workgroup and lives in registers: no global loads inside the butterfly stages.
 // The arithmetic and its order are those of fft_dif_padded / fft_dit_inv_padded for n = 16384 (which butterfly a thread
 // executes does not change any value): results are bit-identical to the plain kernel (WAA_CONV_FFT_PLAIN=1 selects it; tests compare the two).
 constexpr int PIPE_N = 16384, PIPE_NT = 512, PIPE_B = PIPE_N / 2;
-constexpr int PIPE_IT = PIPE_N / 4 / PIPE_NT;     // radix-4 butterflies per thread and stage (8)
+constexpr int PIPE_IT = PIPE_N / 4 / PIPE_NT;     // radix-4 butterflies per thread in the q = 16 stage (8)
 constexpr int PIPE_ROWS = PIPE_N / 16 / PIPE_NT;  // 16-element register rows per thread in the tail (2)
+// Two radix-4 stages per LDS round trip: the 16 elements e0 + m * stride (m = 0..15) are closed under the stage
+// with q = 4 * stride (butterflies over m, m+4, m+8, m+12) and under the stage with q = stride (butterflies over
+// 4g .. 4g+3), so a thread runs both on registers — the values and their order of operations are exactly those
+// of two separate passes of fft_dif_padded, one barrier and 256 KB of LDS traffic less per pair of stages.
+// Stages (q = 4096, 1024) and (256, 64) are paired; q = 16 stays a radix-4 pass; strides 4 and 1 are the register
+// tail on 16 contiguous elements.  Four LDS round trips per FFT instead of six.
 struct PipeTw {
-  Cplx s0[PIPE_IT];  // stage 0 (q = 4096): one per butterfly of this thread
-  Cplx s1[2];        // stage 1 (q = 1024 = 2 x threads): even / odd butterflies
-  Cplx s[3];         // stages 2..4 (q = 256, 64, 16 <= threads): the same twiddle for every butterfly
-  Cplx t[4];         // register tail: exp(-2 pi i j / 16), j = 0..3 (uniform)
+  Cplx a0[2][4];  // pass 1, q = 4096: tw[j' + r * 1024], j' = tid + set * 512
+  Cplx b0[2];     // pass 1, q = 1024: tw[4 j']
+  Cplx a1[4];     // pass 2, q = 256: tw[16 (j'' + r * 64)], j'' = tid % 64 (the same for both sets)
+  Cplx b1;        // pass 2, q = 64: tw[64 j'']
+  Cplx s16;       // q = 16: tw[256 (tid % 16)]
+  Cplx t[4];      // register tail: exp(-2 pi i j / 16), j = 0..3 (uniform)
 };
+// KEEP0 = false: the q = 4096 twiddles (8 per thread) are re-read from the table in every block (L2 hits)
+// instead of living in 16 registers — the forward kernel needs those for its two half windows
 template <bool KEEP0>
 __device__ __forceinline__ PipeTw pipe_twiddles(const Cplx* tw, int tid) {
   PipeTw r;
 #pragma unroll
-  for (int it = 0; it < PIPE_IT; it++) r.s0[it] = KEEP0 ? tw[tid + it * PIPE_NT] : Cplx{0.f, 0.f};
+  for (int set = 0; set < 2; set++) {
+    const int jp = tid + set * PIPE_NT;
 #pragma unroll
-  for (int h = 0; h < 2; h++) r.s1[h] = tw[((tid + h * PIPE_NT) % 1024) * 4];
-#pragma unroll
-  for (int st = 2; st <= 4; st++) {
-    const int q = PIPE_N >> (2 * (st + 1));
-    r.s[st - 2] = tw[(tid % q) * (PIPE_N / (4 * q))];
+    for (int q4 = 0; q4 < 4; q4++) r.a0[set][q4] = KEEP0 ? tw[jp + q4 * 1024] : Cplx{0.f, 0.f};
+    r.b0[set] = tw[jp * 4];
   }
+#pragma unroll
+  for (int q4 = 0; q4 < 4; q4++) r.a1[q4] = tw[((tid % 64) + q4 * 64) * 16];
+  r.b1 = tw[(tid % 64) * 64];
+  r.s16 = tw[(tid % 16) * 256];
 #pragma unroll
   for (int j = 0; j < 4; j++) r.t[j] = tw[j * (PIPE_N >> 4)];
   return r;
 }
-// one radix-4 pass over this thread's butterflies of stage `st` (same index arithmetic as fft_dif_padded)
-// KEEP0 = false: the stage-0 twiddles (8 per thread) are re-read from the table (L2 hits, all eight requests go
-// out before the first butterfly) instead of living in 16 registers — the forward kernel needs those for its two
-// half windows
+// (keeps the LDS address arithmetic of a pass from being hoisted above the previous pass, where it would only
+// occupy registers: everything below is pure arithmetic on the thread index)
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+template <bool INVERSE>
+__device__ __forceinline__ void pipe_radix16(Cplx* a, int e0, int stride, const Cplx (&twa)[4], Cplx twb) {
+  Cplx x[16];
+#pragma unroll
+  for (int m = 0; m < 16; m++) x[m] = a[pad(e0 + m * stride)];
+  if (!INVERSE) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) radix4_dif(x[r], x[r + 4], x[r + 8], x[r + 12], twa[r], true);
+#pragma unroll
+    for (int g = 0; g < 4; g++) radix4_dif(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], twb, true);
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; g++) radix4_dit(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], conj(twb), true);
+#pragma unroll
+    for (int r = 0; r < 4; r++) radix4_dit(x[r], x[r + 4], x[r + 8], x[r + 12], conj(twa[r]), true);
+  }
+#pragma unroll
+  for (int m = 0; m < 16; m++) a[pad(e0 + m * stride)] = x[m];
+}
 template <bool INVERSE, bool KEEP0>
-__device__ __forceinline__ void pipe_stage(Cplx* a, int st, const PipeTw& w, const Cplx* twg, int tid) {
-  const int q = PIPE_N >> (2 * (st + 1));
+__device__ __forceinline__ void pipe_pass1(Cplx* a, const PipeTw& w, const Cplx* twg, int tid) {
+#pragma unroll
+  for (int set = 0; set < 2; set++) {
+    const int jp = opaque(tid) + set * PIPE_NT;
+    Cplx twa[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) twa[r] = KEEP0 ? w.a0[set][r] : twg[jp + r * 1024];
+    pipe_radix16<INVERSE>(a, jp, 1024, twa, w.b0[set]);
+    __builtin_amdgcn_sched_barrier(0);  // one 16-element set at a time: the registers hold the prefetched block
+  }
+}
+template <bool INVERSE>
+__device__ __forceinline__ void pipe_pass2(Cplx* a, const PipeTw& w, int tid) {
+#pragma unroll
+  for (int set = 0; set < 2; set++) {
+    const int t2 = opaque(tid) + set * PIPE_NT;
+    pipe_radix16<INVERSE>(a, (t2 / 64) * 1024 + (t2 % 64), 64, w.a1, w.b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// the q = 16 stage: eight radix-4 butterflies per thread (index arithmetic of fft_dif_padded)
+template <bool INVERSE>
+__device__ __forceinline__ void pipe_stage16(Cplx* a, const PipeTw& w, int tid) {
+  constexpr int q = 16;
 #pragma unroll
   for (int it = 0; it < PIPE_IT; it++) {
     const int b = tid + it * PIPE_NT;
     const int j = b % q, base = (b / q) * 4 * q + j;
     const int i0 = pad(base), i1 = pad(base + q), i2 = pad(base + 2 * q), i3 = pad(base + 3 * q);
-    const Cplx tw = st == 0 ? (KEEP0 ? w.s0[it] : twg[tid + it * PIPE_NT]) : st == 1 ? w.s1[it & 1] : w.s[st - 2];
     Cplx x0 = a[i0], x1 = a[i1], x2 = a[i2], x3 = a[i3];
     if (INVERSE)
-      radix4_dit(x0, x1, x2, x3, conj(tw), true);
+      radix4_dit(x0, x1, x2, x3, conj(w.s16), true);
     else
-      radix4_dif(x0, x1, x2, x3, tw, true);
+      radix4_dif(x0, x1, x2, x3, w.s16, true);
     a[i0] = x0;
     a[i1] = x1;
     a[i2] = x2;
@@ -341,14 +395,15 @@ __device__ __forceinline__ void pipe_stage(Cplx* a, int st, const PipeTw& w, con
   }
 }
 __device__ __forceinline__ void pipe_fft_dif(Cplx* a, const PipeTw& w, const Cplx* twg, int tid) {
-#pragma unroll
-  for (int st = 0; st <= 4; st++) {
-    pipe_stage<false, false>(a, st, w, twg, tid);
-    __syncthreads();
-  }
+  pipe_pass1<false, false>(a, w, twg, opaque(tid));
+  __syncthreads();
+  pipe_pass2<false>(a, w, opaque(tid));
+  __syncthreads();
+  pipe_stage16<false>(a, w, opaque(tid));
+  __syncthreads();
 #pragma unroll
   for (int rr = 0; rr < PIPE_ROWS; rr++) {
-    float4* row = reinterpret_cast<float4*>(a + 18 * (tid + rr * PIPE_NT));  // elements [16t, 16t+16)
+    float4* row = reinterpret_cast<float4*>(a + 18 * (opaque(tid) + rr * PIPE_NT));  // elements [16t, 16t+16)
     Cplx x[16];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -365,10 +420,10 @@ __device__ __forceinline__ void pipe_fft_dif(Cplx* a, const PipeTw& w, const Cpl
   }
   __syncthreads();
 }
-__device__ __forceinline__ void pipe_fft_dit_inv(Cplx* a, const PipeTw& w, int tid) {
+__device__ __forceinline__ void pipe_fft_dit_inv(Cplx* a, const PipeTw& w, const Cplx* twg, int tid) {
 #pragma unroll
   for (int rr = 0; rr < PIPE_ROWS; rr++) {
-    float4* row = reinterpret_cast<float4*>(a + 18 * (tid + rr * PIPE_NT));
+    float4* row = reinterpret_cast<float4*>(a + 18 * (opaque(tid) + rr * PIPE_NT));
     Cplx x[16];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -384,11 +439,12 @@ __device__ __forceinline__ void pipe_fft_dit_inv(Cplx* a, const PipeTw& w, int t
     for (int k = 0; k < 8; k++) row[k] = make_float4(x[2 * k].re, x[2 * k].im, x[2 * k + 1].re, x[2 * k + 1].im);
   }
   __syncthreads();
-#pragma unroll
-  for (int st = 4; st >= 0; st--) {
-    pipe_stage<true, true>(a, st, w, nullptr, tid);
-    __syncthreads();
-  }
+  pipe_stage16<true>(a, w, opaque(tid));
+  __syncthreads();
+  pipe_pass2<true>(a, w, opaque(tid));
+  __syncthreads();
+  pipe_pass1<true, false>(a, w, twg, opaque(tid));
+  __syncthreads();
 }
 
 constexpr int PIPE_H = PIPE_B / 4 / PIPE_NT;  // float4 groups per thread in half a window (4)
@@ -426,7 +482,7 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
   const int k0 = blockIdx.x * blocks_per_wg;
   const int k1 = k0 + blocks_per_wg < d.nb ? k0 + blocks_per_wg : d.nb;
   if (k0 >= k1) return;
-  const PipeTw w = pipe_twiddles<MODE == MODE_INV>(d.tw, tid);
+  const PipeTw w = pipe_twiddles<false>(d.tw, tid);
   const uint32_t ia = pair * 2, ib = pair * 2 + 1;
   const bool has_b = ib < d.n_inst;
   if (MODE == MODE_FWD) {
@@ -477,7 +533,7 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
       const int kn = k + 1 < k1 ? k + 1 : k;
 #pragma unroll
       for (int r = 0; r < PIPE_S; r++) y[r] = ybase[(uint64_t)kn * (PIPE_N / 2) + tid_k + r * PIPE_NT];
-      pipe_fft_dit_inv(a, w, tid_k);
+      pipe_fft_dit_inv(a, w, d.tw, tid_k);
 #pragma unroll
       for (int r = 0; r < PIPE_H; r++) {
         const int i4 = tid_k + r * PIPE_NT;
