@@ -583,6 +583,8 @@ __global__ __launch_bounds__(256) void conv_mac_kernel(const ConvDesc d) {
           for (int i = 0; i < KT; i++) {
             const int pl = i + (PC - 1) - jj;  // local partition index, compile-time after unrolling
             if (pl >= 0 && pl < PC) {
+              // (two v_pk_fma_f32 per complex multiply-add instead of these four scalar FMAs were measured: 5.9 ms
+              // against 4.5 ms — the swapped (im, re) operand costs extra moves and the packed op is not faster)
               acc[i].re = __builtin_fmaf(h[pl].re, x.re, acc[i].re);
               acc[i].re = __builtin_fmaf(-h[pl].im, x.im, acc[i].re);
               acc[i].im = __builtin_fmaf(h[pl].re, x.im, acc[i].im);
