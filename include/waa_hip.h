@@ -10,6 +10,7 @@
  *                               + ConcreteBaseAudioContext::register          src/context/concrete_base.rs:232-270
  *                               + AudioNode::connect (ControlMessage::ConnectNode) src/node/audio_node.rs:247-289
  *   waa_source_set_buffer*      AudioBufferSourceNode::set_buffer             src/node/audio_buffer_source.rs:853-866 (onmessage)
+ *   waa_source_ended            AudioScheduledSourceNode `ended` event        src/render/processor.rs:53-58, src/render/thread.rs:398-411
  *   waa_source_start/stop/loop  AudioBufferSourceNode::start_at_with_offset_and_duration / stop_at / set_loop*
  *                                                                             src/node/audio_buffer_source.rs:388-398
  *   waa_convolver_set_buffer    ConvolverNode::set_buffer                     src/node/convolver.rs:259-317
@@ -302,6 +303,18 @@ uint64_t waa_buffer_resample(const float* src, uint64_t frames, float source_sam
 waa_status waa_biquad_frequency_response(int32_t type, float sample_rate, float frequency, float detune, float q,
                                          float gain, const float* frequency_hz, float* mag, float* phase,
                                          uint32_t n);
+/* AudioScheduledSourceNode `ended` (src/node/scheduled_source.rs:44, src/render/processor.rs:53-58): WHEN the
+ * reference dispatches the event for source `node` (AudioBufferSource, ConstantSource, Oscillator) of `instance`.
+ *   *quantum >= 0        after rendering that render quantum (the renderer called send_ended_event() in it:
+ *                        audio_buffer_source.rs:446-461,834-842, constant_source.rs:204-262, oscillator.rs:382-465);
+ *   WAA_ENDED_AT_UNLOAD  when the graph is unloaded after the last quantum (render/thread.rs:398-411 -> before_drop:
+ *                        the source had started, or its stop time had passed, but it never finished);
+ *   WAA_ENDED_NEVER      not at all (never started).
+ * Host-side scheduling only: valid before or after the render. */
+#define WAA_ENDED_NEVER (-1)
+#define WAA_ENDED_AT_UNLOAD (-2)
+waa_status waa_source_ended(waa_batch* batch, uint32_t node, uint32_t instance, int64_t* quantum);
+
 /* IIRFilterNode::get_frequency_response (src/node/iir_filter.rs:218-262); frequencies outside
  * [0, sample_rate/2] give NaN. */
 waa_status waa_iir_frequency_response(const double* feedforward, uint32_t n_feedforward, const double* feedback,

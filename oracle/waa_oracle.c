@@ -1069,8 +1069,11 @@ typedef struct {
   int started, entered_loop, is_aligned, ended;
   int is_looping;
   double loop_start, loop_end;
-  /* constant source */
+  /* constant source / oscillator */
   int ended_triggered;
+  /* quantum in which the renderer called send_ended_event() (processor.rs:53-58); -1: not yet; after the last quantum
+   * WAA_ENDED_AT_UNLOAD if before_drop sends it (thread.rs:398-411) */
+  int64_t ended_q;
   /* convolver */
   ConvState* conv[4];
   uint64_t tail_count;
@@ -1962,6 +1965,17 @@ waa_status orc_biquad_frequency_response(int32_t type, float sample_rate, float 
   return WAA_OK;
 }
 
+
+/* when `ended` was dispatched for a scheduled source (after orc_render) */
+waa_status orc_source_ended(orc_batch* b, uint32_t node, uint32_t inst, int64_t* quantum) {
+  if (!b || node >= b->n_nodes || inst >= b->n_inst || !quantum) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node / instance");
+  uint32_t kind = b->nodes[node].desc.kind;
+  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE && kind != WAA_NODE_OSCILLATOR)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "not a scheduled source");
+  if (!b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
+  *quantum = b->st[inst][node].ended_q;
+  return WAA_OK;
+}
 /* iir_filter.rs:218-262 */
 waa_status orc_iir_frequency_response(const double* ff, uint32_t nff, const double* fb, uint32_t nfb, float sample_rate,
                                       const float* hz, float* mag, float* phase, uint32_t n) {
@@ -2043,11 +2057,15 @@ static void process_buffer_source(orc_batch* b, NodeCfg* n, NodeState* s, uint32
   if (!buffer && s->start_time != DBL_MAX) {
     q_make_silent(output);
     s->ended = 1;
+    s->ended_q = (int64_t)sc->quantum;
     return;
   }
   if (s->start_time >= next_block_time) {
     q_make_silent(output);
-    if (s->stop_time <= next_block_time) s->ended = 1;
+    if (s->stop_time <= next_block_time) {
+      s->ended = 1;
+      s->ended_q = (int64_t)sc->quantum;
+    }
     return;
   }
   if (!buffer) {
@@ -2212,8 +2230,10 @@ static void process_buffer_source(orc_batch* b, NodeCfg* n, NodeState* s, uint32
   s->buffer_time = buffer_time;
   if (next_block_time >= s->stop_time || s->buffer_time_elapsed >= s->duration ||
       (!is_looping && ((computed_playback_rate > 0. && buffer_time >= buffer_duration) ||
-                       (computed_playback_rate < 0. && buffer_time < 0.))))
+                       (computed_playback_rate < 0. && buffer_time < 0.)))) {
     s->ended = 1;
+    s->ended_q = (int64_t)sc->quantum;
+  }
   (void)b;
 }
 
@@ -2224,7 +2244,15 @@ static void process_constant_source(NodeCfg* n, NodeState* s, uint32_t inst, con
   double next_block_time = sc->current_time + dt * (double)RQ;
   if (s->start_time >= next_block_time) {
     q_make_silent(output);
+    if (s->stop_time <= next_block_time && !s->ended_triggered) { /* :207-212 */
+      s->ended_triggered = 1;
+      s->ended_q = (int64_t)sc->quantum;
+    }
     return;
+  }
+  if (!(s->stop_time > next_block_time) && !s->ended_triggered) { /* :254-262, `still_running` */
+    s->ended_triggered = 1;
+    s->ended_q = (int64_t)sc->quantum;
   }
   output->n = 1;
   output->silent[0] = 0;
@@ -2550,7 +2578,17 @@ static void process_oscillator(NodeCfg* n, NodeState* s, uint32_t inst, const Sc
   double sample_rate = (double)sc->sample_rate;
   double dt = 1. / sample_rate;
   double next_block_time = sc->current_time + dt * (double)RQ;
-  if (s->stop_time <= sc->current_time) return;
+  if (s->stop_time <= sc->current_time) { /* :382-390 */
+    if (!s->ended_triggered) {
+      s->ended_triggered = 1;
+      s->ended_q = (int64_t)sc->quantum;
+    }
+    return;
+  }
+  if (s->stop_time <= next_block_time && !s->ended_triggered) { /* :394-399 and :461-466: both branches test this */
+    s->ended_triggered = 1;
+    s->ended_q = (int64_t)sc->quantum;
+  }
   if (s->start_time >= next_block_time) return;
   float tf[RQ], td[RQ];
   int lf, ld;
@@ -3011,6 +3049,7 @@ static void render_instance(orc_batch* b, uint32_t inst) {
     NodeState* s = &st[i];
     q_make_silent(&s->in);
     q_make_silent(&s->out);
+    s->ended_q = WAA_ENDED_NEVER;
     if (n->start_time) {
       s->start_time = n->start_time[inst];
       s->stop_time = n->stop_time[inst];
@@ -3080,6 +3119,16 @@ static void render_instance(orc_batch* b, uint32_t inst) {
         memset(dst, 0, sizeof(float) * remaining);
     }
     written += remaining;
+  }
+  { /* unload_graph -> before_drop (thread.rs:398-411; audio_buffer_source.rs:872-878, constant_source.rs:280-286,
+     * oscillator.rs:502-508) with the time after the last quantum */
+    double end_time = (double)(num_quanta * RQ) / (double)b->sr;
+    for (uint32_t i = 0; i < b->n_nodes; i++) {
+      uint32_t kind = b->nodes[i].desc.kind;
+      if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE && kind != WAA_NODE_OSCILLATOR) continue;
+      NodeState* s = &st[i];
+      if (s->ended_q < 0 && (end_time >= s->start_time || end_time >= s->stop_time)) s->ended_q = WAA_ENDED_AT_UNLOAD;
+    }
   }
 #if defined(__x86_64__)
   _mm_setcsr(saved);

@@ -31,6 +31,7 @@ import numpy as np
 RENDER_QUANTUM_SIZE = 128
 PLAN_ONLY = -2  # WAA_DEVICE_PLAN_ONLY: configure + plan without a device (never renders)
 ALL = 0xFFFFFFFF
+ENDED_NEVER, ENDED_AT_UNLOAD = -1, -2
 F64_MAX = 1.7976931348623157e308
 
 # node kinds / enums (include/waa_hip.h)
@@ -93,6 +94,7 @@ ABI = {
     "source_start": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]),
     "source_stop": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_double]),
     "source_set_loop": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_int32, C.c_double, C.c_double]),
+    "source_ended": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_int64)]),
     "convolver_set_buffer": (C.c_int32, [_VP, C.c_uint32, _FPP, C.c_uint32, C.c_uint64, C.c_float]),
     "waveshaper_set_curve": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32]),
     "oscillator_set_periodic_wave": (C.c_int32, [_VP, C.c_uint32, _FP, _FP, C.c_uint32, C.c_int32]),
@@ -361,6 +363,15 @@ class _ScheduledSource(AudioNode):
             raise WaaError(3, "InvalidStateError - cannot stop before start")
         self._stops[instance] = float(when)
         return self
+
+    def ended_quantum(self, instance: int = 0) -> int:
+        """When the reference fires `onended` (scheduled_source.rs:44) for this source of `instance`: the index of
+        the render quantum after which the event is dispatched, ENDED_AT_UNLOAD (after the last quantum, from
+        before_drop) or ENDED_NEVER.  Call after the render."""
+        ctx = self.context
+        q = C.c_int64()
+        ctx._b.check(ctx._b.source_ended(ctx._handle, self.id, instance, C.byref(q)))
+        return q.value
 
     def _apply(self, ctx):
         super()._apply(ctx)

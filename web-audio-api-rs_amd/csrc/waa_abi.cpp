@@ -812,6 +812,48 @@ uint64_t waa_buffer_resample(const float* src, uint64_t frames, float source_sr,
   return tl;
 }
 
+// When the reference dispatches `ended` for a scheduled source (host-side replay of the renderers' scheduling;
+// processor.rs:53-58, thread.rs:398-411)
+waa_status waa_source_ended(waa_batch* b, uint32_t node, uint32_t inst, int64_t* quantum) {
+  if (!b || node >= b->nodes.size() || !quantum) return fail(WAA_ERR_INVALID_ARGUMENT, "bad node");
+  Node& n = b->nodes[node];
+  const uint32_t kind = n.desc.kind;
+  if (kind != WAA_NODE_BUFFER_SOURCE && kind != WAA_NODE_CONSTANT_SOURCE && kind != WAA_NODE_OSCILLATOR)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "node %u is not a scheduled source", node);
+  if (inst >= b->n_inst) return fail(WAA_ERR_INVALID_ARGUMENT, "instance %u out of range", inst);
+  if (!b->planned) {  // automation of playbackRate / detune is evaluated by the planner
+    if (!b->dry) HIP_TRY(hipSetDevice(b->device));
+    int e = build_plan(b);
+    if (e) return e;
+  }
+  const SourceSched& ss = n.sched[inst];
+  const double sr = (double)b->sr, dt = 1. / sr;
+  const double end_time = (double)((uint64_t)b->n_quanta * RQ) / sr;
+  *quantum = WAA_ENDED_NEVER;
+  if (kind == WAA_NODE_BUFFER_SOURCE) {
+    const DeviceBuffer& bf = n.bufs[inst];
+    SchedOut so;
+    schedule_source(b, ss, bf.frames, bf.sr, bf.valid, param_per_quantum(b, n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE], inst, nullptr),
+                    param_per_quantum(b, n.params[WAA_PARAM_SOURCE_DETUNE], inst, nullptr), &so);
+    if (so.ended_quantum >= 0)
+      *quantum = so.ended_quantum;
+    else if (so.ended_at_unload)
+      *quantum = WAA_ENDED_AT_UNLOAD;
+    return WAA_OK;
+  }
+  // ConstantSource (constant_source.rs:204-262) and Oscillator (oscillator.rs:382-465): the first quantum whose end
+  // reaches the stop time (the oscillator also tests the start of the quantum)
+  for (uint32_t q = 0; q < b->n_quanta; q++) {
+    const double ct = (double)((uint64_t)q * RQ) / sr, nbt = ct + dt * (double)RQ;
+    if ((kind == WAA_NODE_OSCILLATOR && ss.stop <= ct) || ss.stop <= nbt) {
+      *quantum = q;
+      return WAA_OK;
+    }
+  }
+  if (end_time >= ss.start || end_time >= ss.stop) *quantum = WAA_ENDED_AT_UNLOAD;
+  return WAA_OK;
+}
+
 // iir_filter.rs:218-262 (control side, host)
 waa_status waa_iir_frequency_response(const double* ff, uint32_t nff, const double* fb, uint32_t nfb, float sample_rate,
                                       const float* hz, float* mag, float* phase, uint32_t n) {

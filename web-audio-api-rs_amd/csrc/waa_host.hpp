@@ -294,6 +294,8 @@ struct SchedOut {
   std::vector<SlowRec> slow;  // empty if no slow quantum
   std::vector<uint8_t> tile_fast;
   bool any_slow = false;
+  int64_t ended_quantum = -1;  // quantum in which the renderer sends `ended` (-1: not during the render)
+  bool ended_at_unload = false;  // ... or before_drop sends it after the last quantum
 };
 using SchedKey = std::tuple<double, double, double, double, int, double, double, uint64_t, float, float, float>;
 void schedule_source(const waa_batch* b, const SourceSched& cfg, uint64_t frames, float buf_sr, bool has_buffer,

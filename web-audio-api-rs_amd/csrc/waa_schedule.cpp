@@ -198,9 +198,15 @@ void schedule_source(const waa_batch* b, const SourceSched& cfg, uint64_t frames
     if (ended) break;
     const double block_time = (double)((uint64_t)q * RQ) / sample_rate;  // thread.rs:360
     const double next_block_time = block_time + block_duration;
-    if (!has_buffer && start_time != DBL_MAX) break;  // ended
+    if (!has_buffer && start_time != DBL_MAX) {  // ended (start with a null buffer, :446-451)
+      out->ended_quantum = q;
+      break;
+    }
     if (start_time >= next_block_time) {
-      if (stop_time <= next_block_time) break;
+      if (stop_time <= next_block_time) {  // stopped before it started (:457-461)
+        out->ended_quantum = q;
+        break;
+      }
       continue;
     }
     if (!has_buffer) continue;
@@ -319,8 +325,14 @@ void schedule_source(const waa_batch* b, const SourceSched& cfg, uint64_t frames
       }
     }
     if (next_block_time >= stop_time || elapsed >= duration ||
-        (!is_looping && ((cpr > 0. && buffer_time >= buffer_duration) || (cpr < 0. && buffer_time < 0.))))
+        (!is_looping && ((cpr > 0. && buffer_time >= buffer_duration) || (cpr < 0. && buffer_time < 0.)))) {
       ended = true;
+      out->ended_quantum = q;
+    }
+  }
+  if (out->ended_quantum < 0) {  // before_drop (:872-878) with the time after the last quantum (thread.rs:399-401)
+    const double end_time = (double)((uint64_t)nq * RQ) / sample_rate;
+    out->ended_at_unload = end_time >= start_time || end_time >= stop_time;
   }
   // per tile: can the whole tile be fetched as one aligned contiguous run?
   out->tile_fast.assign(b->n_tiles, 0);
