@@ -1005,6 +1005,9 @@ typedef struct {
   ParamBlock* blk;     /* [n_inst] */
   float defv, minv, maxv;
   orc_timeline** tl;   /* [n_inst] automation timelines (NULL until an event is scheduled) */
+  float* tl_vals;      /* [n_inst][RQ] this quantum's intrinsic values: the AudioParam is its own graph node and runs
+                        * ONCE in EVERY quantum (param.rs:686-699), whether or not its owner processes */
+  int* tl_vlen;        /* [n_inst] 1 or RQ */
   int k_rate;          /* AutomationRate::K (source playbackRate / detune) */
   double sample_rate;
 } Param;
@@ -1129,10 +1132,10 @@ static const float* param_get_in(const Param* p, const Quantum* in, uint32_t ins
   const float* v = &one;
   int vlen = 1;
   one = p->cst[inst];
-  if (p->tl && p->tl[inst]) { /* AudioParamProcessor::process: compute_intrinsic_values(current_time, 1/sr, 128), param.rs:686-699 */
-    double block_time = (double)(q * RQ) / p->sample_rate;
-    vlen = (int)orc_timeline_compute(p->tl[inst], block_time, 1. / p->sample_rate, RQ, tlbuf);
-    v = tlbuf;
+  if (p->tl && p->tl[inst]) { /* evaluated by params_advance() at the start of the quantum */
+    (void)tlbuf;
+    v = p->tl_vals + (size_t)inst * RQ;
+    vlen = p->tl_vlen[inst];
   } else if (b->v && q >= b->q0 && q < b->q0 + b->nq) {
     v = b->v + (size_t)(q - b->q0) * b->vpq;
     vlen = (int)b->vpq;
@@ -1151,6 +1154,15 @@ static const float* param_get_in(const Param* p, const Quantum* in, uint32_t ins
     *len = RQ;
   }
   return tmp;
+}
+/* AudioParamProcessor::process of every automated param for quantum q: compute_intrinsic_values(current_time, 1/sr,
+ * 128) (param.rs:686-699).  The timeline is stateful (events are consumed, a SetValue at time 0 takes the time of the
+ * block that consumes it, param.rs:1060-1062), so it has to run exactly once per quantum from quantum 0 on — not
+ * only in the quanta in which the owning node happens to read it (a node with a silent input returns early). */
+static void param_advance(Param* p, uint32_t inst, uint64_t q) {
+  if (!p->tl || !p->tl[inst]) return;
+  double block_time = (double)(q * RQ) / p->sample_rate;
+  p->tl_vlen[inst] = (int)orc_timeline_compute(p->tl[inst], block_time, 1. / p->sample_rate, RQ, p->tl_vals + (size_t)inst * RQ);
 }
 static const float* param_get(const Param* p, uint32_t inst, uint64_t q, int* len, float* tmp) {
   return param_get_in(p, NULL, inst, q, len, tmp);
@@ -1477,6 +1489,8 @@ void orc_batch_destroy(orc_batch* b) {
       if (n->params[p].tl) {
         for (uint32_t k = 0; k < b->n_inst; k++) orc_timeline_destroy(n->params[p].tl[k]);
         free(n->params[p].tl);
+        free(n->params[p].tl_vals);
+        free(n->params[p].tl_vlen);
       }
     }
     if (n->bufs) {
@@ -1761,7 +1775,11 @@ waa_status orc_param_schedule_event(orc_batch* b, uint32_t node, uint32_t param,
     return fail(WAA_ERR_INVALID_ARGUMENT, "no such param %u on node %u", param, node);
   if ((e = check_inst(b, inst))) return e;
   Param* p = &b->nodes[node].params[param];
-  if (!p->tl) p->tl = (orc_timeline**)calloc(b->n_inst, sizeof(orc_timeline*));
+  if (!p->tl) {
+    p->tl = (orc_timeline**)calloc(b->n_inst, sizeof(orc_timeline*));
+    p->tl_vals = (float*)calloc((size_t)b->n_inst * RQ, sizeof(float));
+    p->tl_vlen = (int*)calloc(b->n_inst, sizeof(int));
+  }
   p->sample_rate = (double)b->sr;
   uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
   for (uint32_t k = lo; k < hi; k++) {
@@ -3081,6 +3099,8 @@ static void render_instance(orc_batch* b, uint32_t inst) {
     sc.current_time = (double)sc.current_frame / (double)b->sr;
     sc.sample_rate = b->sr;
     sc.quantum = q;
+    for (uint32_t i = 0; i < b->n_nodes; i++)
+      for (int p = 0; p < b->nodes[i].n_params; p++) param_advance(&b->nodes[i].params[p], inst, q);
     for (uint32_t oi = 0; oi < b->n_order; oi++) {
       uint32_t item = b->order[oi], id = item & ~ORC_READER;
       NodeState* s = &st[id];

@@ -522,3 +522,27 @@ def test_random_schedules_agree_between_the_two_restatements(orc_lib, hip, seed)
         vo, vp = tls[0].value(), tls[1].value()
         assert vo == vp or (np.isnan(vo) and np.isnan(vp)), (seed, done)
         done += n
+
+
+def test_automated_param_advances_while_its_owner_is_idle(be):
+    """An AudioParam is its own graph node and is processed in EVERY quantum (param.rs:686-699), also while the node
+    that owns it sees a silent input and returns early (stereo_panner.rs:229-232).  The timeline is stateful — a
+    SetValueAtTime at time 0 takes the time of the block that consumes it (param.rs:1060-1062) — so evaluating it
+    only when the owner reads it shifts the whole automation by the idle quanta (the oracle used to do that; the
+    randomised graphs with automation found it).  A constant 1 that starts at frame 300 into a StereoPanner whose pan
+    ramps -1 -> 1 over the render: the output IS the gain pair of the pan value at absolute time t."""
+    sr, frames, start = 48000.0, 128 * 40, 300
+    c = waa.OfflineAudioContext(2, frames, sr, binding=be)
+    k = c.create_constant_source(offset=1.0)
+    pan = c.create_stereo_panner(pan=0.0)
+    t_end = frames / sr
+    pan.pan.set_value_at_time(-1.0, 0.0).linear_ramp_to_value_at_time(1.0, t_end)
+    k.connect(pan).connect(c.destination())
+    k.start_at(start / sr)
+    out = c.start_rendering_sync().data[0]
+    t = np.arange(frames) / sr
+    x = (np.clip(-1.0 + 2.0 * t / t_end, -1.0, 1.0) + 1.0) / 2.0
+    exp_l, exp_r = np.sin((1.0 - x) * np.pi / 2.0), np.sin(x * np.pi / 2.0)
+    assert np.all(out[:, :start] == 0.0)
+    assert np.max(np.abs(out[0, start:] - exp_l[start:])) <= 2e-6
+    assert np.max(np.abs(out[1, start:] - exp_r[start:])) <= 2e-6

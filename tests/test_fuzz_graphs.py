@@ -61,7 +61,8 @@ def build_random_graph(be, seed):
 
     def add_processor():
         kind = str(rng.choice(["gain", "gain", "biquad", "biquad", "iir", "shaper", "pan", "delay", "delay", "conv",
-                               "panner", "analyser", "cfg-gain", "krate-gain", "krate-biquad"]))
+                               "panner", "analyser", "cfg-gain", "krate-gain", "krate-biquad", "auto-gain", "auto-biquad",
+                               "auto-pan"]))
         nq = (FRAMES + RQ - 1) // RQ
         if kind == "gain":
             n = c.create_gain(gain=float(rng.uniform(-1.0, 1.0)))
@@ -80,6 +81,28 @@ def build_random_graph(be, seed):
             if rng.random() < 0.25:
                 vals[::7] = 0.0  # a zero gain emits a SILENT (mono) quantum: the planner must flag it
             n.gain.set_block(0, vals)
+        elif kind == "auto-gain":  # AudioParam automation methods (param.rs:796-1584), evaluated by the timeline
+            n = c.create_gain(gain=float(rng.uniform(0.1, 0.9)))
+            t_end = FRAMES / SR
+            style = int(rng.integers(0, 4))
+            if style == 0:
+                n.gain.set_value_at_time(0.1, 0.0).linear_ramp_to_value_at_time(float(rng.uniform(0.3, 1.0)), t_end * 0.7)
+            elif style == 1:
+                n.gain.set_value_at_time(0.8, t_end * 0.1).exponential_ramp_to_value_at_time(0.05, t_end * 0.9)
+            elif style == 2:
+                n.gain.set_target_at_time(float(rng.uniform(0.0, 1.0)), t_end * 0.2, float(rng.uniform(0.005, 0.05)))
+                n.gain.cancel_and_hold_at_time(t_end * 0.6)
+            else:
+                n.gain.set_value_curve_at_time(rng.uniform(0.0, 1.0, int(rng.integers(2, 9))).astype(np.float32), t_end * 0.15,
+                                               t_end * 0.5)
+        elif kind == "auto-biquad":  # a-rate frequency: per-frame coefficients (biquad_filter.rs:837-855)
+            n = c.create_biquad_filter(type_=str(rng.choice(["lowpass", "bandpass", "highshelf"])), frequency=300.0,
+                                       q=float(rng.uniform(0.5, 3.0)), gain=float(rng.uniform(-6.0, 6.0)))
+            n.frequency.set_value_at_time(200.0, 0.0).exponential_ramp_to_value_at_time(float(rng.uniform(1000.0, 9000.0)),
+                                                                                        FRAMES / SR)
+        elif kind == "auto-pan":
+            n = c.create_stereo_panner(pan=0.0)
+            n.pan.set_value_at_time(-1.0, 0.0).linear_ramp_to_value_at_time(1.0, FRAMES / SR * float(rng.uniform(0.5, 1.0)))
         elif kind == "krate-biquad":
             n = c.create_biquad_filter(type_="lowpass", frequency=1000.0, q=1.0)
             n.frequency.set_block(0, np.geomspace(200.0, 6000.0, nq).astype(np.float32))
