@@ -46,15 +46,26 @@ def build_random_graph(be, seed):
                     n.start_at(float(rng.integers(0, 600)) / SR, instance=i)
             else:
                 n.start()
+            if rng.random() < 0.15:  # k-rate playbackRate / detune automation: the slow track with a changing rate
+                n.playback_rate.set_value_at_time(1.0, 0.0).linear_ramp_to_value_at_time(float(rng.uniform(0.5, 1.8)),
+                                                                                          FRAMES / SR * 0.8)
+            elif rng.random() < 0.1:
+                n.detune.set_value_at_time(float(rng.uniform(-700.0, 700.0)), FRAMES / SR * float(rng.uniform(0.1, 0.6)))
         elif kind == "constant":
             n = c.create_constant_source(offset=float(rng.uniform(-0.5, 0.5)))
             n.start_at(float(rng.integers(0, 300)) / SR if LATE_STARTS else 0.0)
             if rng.random() < 0.3:
                 n.stop_at(float(rng.integers(2000, FRAMES)) / SR)
+            if rng.random() < 0.3:  # automated offset (a-rate)
+                n.offset.set_target_at_time(float(rng.uniform(-0.5, 0.5)), FRAMES / SR * 0.25, float(rng.uniform(0.005, 0.05)))
         else:
             n = c.create_oscillator(type_=str(rng.choice(["sine", "triangle", "sawtooth", "square"])),
                                     frequency=float(rng.uniform(50.0, 2000.0)))
             n.start()
+            if rng.random() < 0.3:  # a glide: a-rate frequency (prefix-sum phase kernel)
+                n.frequency.exponential_ramp_to_value_at_time(float(rng.uniform(100.0, 3000.0)), FRAMES / SR * 0.9)
+            elif rng.random() < 0.15:
+                n.detune.set_value_at_time(0.0, 0.0).linear_ramp_to_value_at_time(float(rng.uniform(-1200.0, 1200.0)), FRAMES / SR)
         outputs.append(n)
         descr.append(kind)
         return n
@@ -62,7 +73,7 @@ def build_random_graph(be, seed):
     def add_processor():
         kind = str(rng.choice(["gain", "gain", "biquad", "biquad", "iir", "shaper", "pan", "delay", "delay", "conv",
                                "panner", "analyser", "cfg-gain", "krate-gain", "krate-biquad", "auto-gain", "auto-biquad",
-                               "auto-pan"]))
+                               "auto-pan", "auto-delay"]))
         nq = (FRAMES + RQ - 1) // RQ
         if kind == "gain":
             n = c.create_gain(gain=float(rng.uniform(-1.0, 1.0)))
@@ -100,6 +111,9 @@ def build_random_graph(be, seed):
                                        q=float(rng.uniform(0.5, 3.0)), gain=float(rng.uniform(-6.0, 6.0)))
             n.frequency.set_value_at_time(200.0, 0.0).exponential_ramp_to_value_at_time(float(rng.uniform(1000.0, 9000.0)),
                                                                                         FRAMES / SR)
+        elif kind == "auto-delay":  # a chorus-like sweep of delayTime (a-rate, delay.rs:591-606)
+            n = c.create_delay(0.05, delay_time=0.01)
+            n.delay_time.set_value_at_time(0.004, 0.0).linear_ramp_to_value_at_time(float(rng.uniform(0.01, 0.04)), FRAMES / SR)
         elif kind == "auto-pan":
             n = c.create_stereo_panner(pan=0.0)
             n.pan.set_value_at_time(-1.0, 0.0).linear_ramp_to_value_at_time(1.0, FRAMES / SR * float(rng.uniform(0.5, 1.0)))

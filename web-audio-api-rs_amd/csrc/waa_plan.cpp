@@ -674,6 +674,7 @@ int build_plan(waa_batch* b) {
     std::vector<std::vector<uint8_t>> in_act(N, std::vector<uint8_t>(nq)), in_cnt(N, std::vector<uint8_t>(nq));
     std::map<std::string, bool> seen;  // instances with identical host-known inputs are simulated once
     bool reported = false;
+    std::map<std::pair<uint32_t, SchedKey>, int64_t> end_cache;  // (source node, schedule) -> quantum of its end
     for (uint32_t inst = 0; inst < b->n_inst && !reported; inst++) {
       // per-instance inputs of the simulation
       std::vector<double> lo(N, 1e300), hi(N, -1.), shift(N, 0.), shift_hi(N, 0.);
@@ -688,24 +689,58 @@ int build_plan(waa_batch* b) {
           const SourceSched& ss = n.sched[inst];
           lo[id] = ss.start == DBL_MAX ? 1e300 : std::floor(ss.start / qsec);
           hi[id] = ss.stop != DBL_MAX ? std::ceil(ss.stop / qsec) : 1e300;
-          if (kind == WAA_NODE_BUFFER_SOURCE && !ss.looping && n.bufs[inst].valid) {
-            double rmin = 1e300;
-            for (float r : param_per_quantum(b, n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE], inst, nullptr))
-              rmin = std::min(rmin, (double)std::fabs(r));
-            const double dur = std::min(ss.duration, (double)n.bufs[inst].frames / (double)n.bufs[inst].sr) / std::max(rmin, 1e-9);
-            hi[id] = std::min(hi[id], std::ceil((ss.start + dur) / qsec));
+          if (kind == WAA_NODE_BUFFER_SOURCE && n.bufs[inst].valid) {
+            // the quantum in which the source really ends: the scheduling replay with this instance's playbackRate
+            // and detune per quantum (an automated rate moves the end; an estimate from the slowest rate claimed the
+            // source active — and the signal stereo — for longer than the reference renders it)
+            const DeviceBuffer& bf = n.bufs[inst];
+            const ParamStore& p_rate = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
+            const ParamStore& p_det = n.params[WAA_PARAM_SOURCE_DETUNE];
+            std::vector<float> rate_q = param_per_quantum(b, p_rate, inst, nullptr);
+            std::vector<float> det_q = param_per_quantum(b, p_det, inst, nullptr);
+            const bool automated = !p_rate.blocks.empty() || !p_det.blocks.empty();
+            const SchedKey key(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end, bf.frames, bf.sr,
+                               rate_q[0], det_q[0]);
+            int64_t endq;
+            auto it = automated ? end_cache.end() : end_cache.find(std::make_pair(id, key));
+            if (it != end_cache.end()) {
+              endq = it->second;
+            } else {
+              SchedOut so;
+              schedule_source(b, ss, bf.frames, bf.sr, true, rate_q, det_q, &so);
+              endq = so.ended_quantum;
+              if (!automated) end_cache[std::make_pair(id, key)] = endq;
+            }
+            if (endq >= 0) hi[id] = std::min(hi[id], (double)endq + 1.);
           }
           if (kind == WAA_NODE_BUFFER_SOURCE && !n.bufs[inst].valid) lo[id] = 1e300;
           add_sig(lo[id]);
           add_sig(hi[id]);
         } else if (kind == WAA_NODE_DELAY) {
-          if (param_mode(n, WAA_PARAM_DELAY_DELAY_TIME) != 2) {
-            double dmin = 1e300;
-            for (float dv : param_per_quantum(b, n.params[WAA_PARAM_DELAY_DELAY_TIME], inst, nullptr)) dmin = std::min(dmin, (double)dv);
-            shift[id] = std::floor(dmin / qsec);
+          {
             // a delay that is not a whole number of quanta: whether the first delayed samples land in this quantum or
-            // the next depends on where inside its quantum the input started — both are simulated
-            shift_hi[id] = std::ceil(dmin / qsec);
+            // the next depends on where inside its quantum the input started — both are simulated.  A delayTime that
+            // varies (k-rate or a-rate automation) is simulated at its shortest and at its longest value; one that is
+            // modulated by the graph is only known to lie in [0, maxDelayTime].
+            const ParamStore& pd = n.params[WAA_PARAM_DELAY_DELAY_TIME];
+            double dmin = (double)pd.fix(pd.cst[inst]), dmax = dmin;
+            bool covered_all = false;
+            for (auto& blk : pd.blocks) {
+              if (!(blk.inst == WAA_ALL_INSTANCES || blk.inst == inst)) continue;
+              for (float dv : blk.v) {
+                dmin = std::min(dmin, (double)pd.fix(dv));
+                dmax = std::max(dmax, (double)pd.fix(dv));
+              }
+              covered_all |= blk.q0 == 0 && blk.nq >= nq;
+            }
+            (void)covered_all;
+            const bool modulated = WAA_PARAM_DELAY_DELAY_TIME < n.pin_edges.size() && !n.pin_edges[WAA_PARAM_DELAY_DELAY_TIME].empty();
+            if (modulated) {
+              dmin = 0.;
+              dmax = n.desc.d[0];
+            }
+            shift[id] = std::floor(dmin / qsec);
+            shift_hi[id] = std::ceil(dmax / qsec);
           }
           if (id < b->cut.size() && b->cut[id]) {  // inside a loop: >= one quantum
             shift[id] = std::max(shift[id], 1.);
