@@ -61,7 +61,17 @@ def build_random_graph(be, seed):
         else:
             n = c.create_oscillator(type_=str(rng.choice(["sine", "triangle", "sawtooth", "square"])),
                                     frequency=float(rng.uniform(50.0, 2000.0)))
-            n.start()
+            if rng.random() < 0.2:  # custom PeriodicWave (periodic_wave.rs:35-190)
+                k = int(rng.integers(2, 9))
+                n.set_periodic_wave(c.create_periodic_wave(real=rng.uniform(-1, 1, k).astype(np.float32),
+                                                           imag=rng.uniform(-1, 1, k).astype(np.float32),
+                                                           disable_normalization=bool(rng.integers(0, 2))))
+            r = rng.random()
+            if LATE_STARTS and r < 0.2:  # sub-quantum start, stop before the end
+                n.start_at(float(rng.integers(0, 700)) / SR)
+                n.stop_at(float(rng.integers(3000, FRAMES)) / SR)
+            else:
+                n.start()
             if rng.random() < 0.3:  # a glide: a-rate frequency (prefix-sum phase kernel)
                 n.frequency.exponential_ramp_to_value_at_time(float(rng.uniform(100.0, 3000.0)), FRAMES / SR * 0.9)
             elif rng.random() < 0.15:
