@@ -209,8 +209,10 @@ uint32_t Timeline::compute(double block_time, double dt, uint32_t count, float* 
       case WAA_EVENT_SET_VALUE:
       case WAA_EVENT_SET_VALUE_AT_TIME: {  // param.rs:1049-1096
         const double time = ev.time == 0. ? block_time : ev.time;
-        if (a_rate_)
-          for (const uint32_t end = end_index(time); len < end;) push(intrinsic_);
+        if (a_rate_) {
+          const uint32_t end = end_index(time);
+          while (len < end) push(intrinsic_);  // (push advances len)
+        }
         if (time > next_block_time) {
           block_done = true;
           break;

@@ -351,8 +351,6 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
       q.out = seg_out;
       q.n_inst = b->n_inst;
       q.n_tiles = b->n_tiles;
-    q.tile0 = 0;
-    q.tile1 = b->n_tiles;
       q.tile0 = 0;
       q.tile1 = b->n_tiles;
       q.n_quanta = b->n_quanta;
