@@ -232,3 +232,24 @@ def test_note_zero_gain_in_front_of_a_panner_and_strict_mode(monkeypatch):
         c.plan_describe()
     assert ei.value.status == 4
     c.close()
+
+
+def test_plan_validator_refuses_a_misordered_launch_list(hip, monkeypatch):
+    """build_plan ends with a read-before-write check over the launch list (a consumer launched before its producer
+    would render stale data silently).  WAA_DEBUG_REVERSE_PLAN reverses the list before the check: the dependent
+    launches of a Biquad -> Convolver -> StereoPanner graph must not get past it."""
+    def build():
+        ctx = waa.OfflineAudioContext(2, RQ * 40, 48000.0, n_instances=2, binding=hip, device=waa.PLAN_ONLY)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(white_noise(2, 2, RQ * 40), 48000.0)
+        bq = ctx.create_biquad_filter(type_="lowpass", frequency=500.0)
+        conv = ctx.create_convolver(buffer=waa.AudioBuffer(white_noise(1, 2, 300)[0], 48000.0))
+        pan = ctx.create_stereo_panner(pan=0.3)
+        src.connect(bq).connect(conv).connect(pan).connect(ctx.destination())
+        src.start()
+        return ctx
+    assert len(plan(build())) >= 3
+    monkeypatch.setenv("WAA_DEBUG_REVERSE_PLAN", "1")
+    with pytest.raises(waa.WaaError, match="reads a buffer that a later launch produces") as ei:
+        build().plan_describe()
+    assert ei.value.status == 3

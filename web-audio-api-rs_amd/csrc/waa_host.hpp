@@ -184,6 +184,9 @@ struct Step {
   size_t zero_bytes = 0;
   int cmax = 1;
   int profile_slot = -1;
+  // plan validation (host only): signals and per-frame param tables this step reads / writes; a quantum-serial loop
+  // step lists the external signals its items read and the signals they publish
+  std::vector<const void*> loop_reads, loop_writes;
   int group = -1;         // >= 0: member of a block-scheduled feedback loop (launched block by block)
   bool prologue = false;  // inside a group: runs once over the full range before the blocks
 };

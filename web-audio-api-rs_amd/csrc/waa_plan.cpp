@@ -1,12 +1,15 @@
 // waa_plan.cpp — the planner: processing order with the reference's cycle breaker, liveness, static channel
 // counts, materialisation points, fusion of single-consumer paths into chain launches, node-major steps
 // (convolver, delay, oscillator, IIR), feedback loops (block-scheduled or quantum-serial), AudioParam chains.
+#include <set>
+
 #include "waa_host.hpp"
 
 namespace waa {
 namespace host {
 
 int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in);
+int validate_plan(waa_batch* b);
 
 // Upload a param as a device ParamRef (mode 0 / 1 / 2), values clamped like the reference.
 int upload_param(waa_batch* b, const ParamStore& p, ParamRef* ref) {
@@ -1175,7 +1178,117 @@ int build_plan(waa_batch* b) {
     int e = plan_single(id);
     if (e) return e;
   }
+  // (self-test of the check below: a reversed launch list must not get past it, tests/test_plan.py)
+  if (getenv("WAA_DEBUG_REVERSE_PLAN")) std::reverse(b->steps.begin(), b->steps.end());
+  if (int e = validate_plan(b)) return e;
   b->planned = true;
+  return 0;
+}
+
+// ---- plan validation -----------------------------------------------------------------------------------------
+// The plan is a linear list of launches over shared device buffers; nothing but their order makes a consumer see
+// its producer's data.  This check walks the list once and refuses a plan in which a launch reads a buffer that
+// some launch of the plan writes, but none has written yet — an ordering bug of the planner would otherwise
+// render stale or zero data silently.  The only legal read-before-write is a DelayNode reader inside a feedback
+// loop (it reads the PREVIOUS quanta of a line that is filled later in the same pass).
+namespace {
+struct StepIo {
+  std::vector<const void*> reads, writes;
+  bool feedback_reader = false;
+};
+void io_param(const ParamRef& p, StepIo& io) {
+  if (p.base && p.mode == 2) io.reads.push_back(p.base);  // per-frame values: possibly produced by a param chain
+}
+void io_input(const InputRef& in, StepIo& io) {
+  if (in.kind == IN_SIGNAL) io.reads.push_back(in.sig.base);
+  if (in.kind == IN_CONSTANT) io_param(in.offset, io);
+  if (in.has_gain) io_param(in.gain, io);
+}
+StepIo step_io(const Step& st) {
+  StepIo io;
+  switch (st.kind) {
+    case 0: {
+      const ChainDesc& c = st.chain;
+      for (int k = 0; k < c.n_inputs; k++) io_input(c.in[k], io);
+      for (int o = 0; o < c.n_ops; o++) {
+        const OpDesc& op = c.ops[o];
+        io_param(op.p0, io);
+        io_param(op.p1, io);
+        io_param(op.p2, io);
+        io_param(op.p3, io);
+        io_param(op.p4, io);
+        if (op.kind == OP_BIQUAD && op.i0 == 2) io.reads.push_back(op.ptr0);  // per-frame coefficient table
+      }
+      io.writes.push_back(c.out.base);
+      break;
+    }
+    case 1:
+      io_input(st.bq.in, io);
+      io.writes.push_back(st.bq.out.base);
+      break;
+    case 2:
+    case 4:
+      io.reads.push_back(st.conv.in.base);
+      io.writes.push_back(st.conv.out.base);
+      break;
+    case 3:
+      io.writes.push_back(st.zero_ptr);
+      break;
+    case 5:
+      io_param(st.coef.frequency, io);
+      io_param(st.coef.detune, io);
+      io_param(st.coef.q, io);
+      io_param(st.coef.gain, io);
+      io.writes.push_back(st.coef.coefs);
+      break;
+    case 6:
+      io_input(st.iir.in, io);
+      io.writes.push_back(st.iir.out.base);
+      break;
+    case 7:
+      io.reads.push_back(st.delay.in.base);
+      io_param(st.delay.delay, io);
+      io.writes.push_back(st.delay.out.base);
+      io.feedback_reader = st.delay.in_cycle != 0;
+      break;
+    case 8:
+      io.reads = st.loop_reads;
+      io.writes = st.loop_writes;
+      break;
+    case 9:
+      io_param(st.osc.frequency, io);
+      io_param(st.osc.detune, io);
+      io.writes.push_back(st.osc.out.base);
+      break;
+    default:
+      break;
+  }
+  return io;
+}
+}  // namespace
+
+int validate_plan(waa_batch* b) {
+  std::vector<StepIo> ios;
+  std::set<const void*> produced, written;
+  for (const Step& st : b->steps) {
+    ios.push_back(step_io(st));
+    for (const void* w : ios.back().writes)
+      if (w) produced.insert(w);
+  }
+  for (size_t k = 0; k < b->steps.size(); k++) {
+    const StepIo& io = ios[k];
+    if (b->steps[k].kind == 8) {  // the items of a quantum-serial loop hand over inside the kernel
+      for (const void* w : io.writes) written.insert(w);
+    }
+    for (const void* r : io.reads) {
+      if (!r || !produced.count(r) || written.count(r)) continue;
+      if (io.feedback_reader && r == b->steps[k].delay.in.base) continue;
+      return fail(WAA_ERR_INVALID_STATE, "internal: launch %zu of the plan (kind %d) reads a buffer that a later launch produces", k,
+                  b->steps[k].kind);
+    }
+    for (const void* w : io.writes)
+      if (w) written.insert(w);
+  }
   return 0;
 }
 
@@ -1724,6 +1837,11 @@ int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items) {
   const double dt = 1. / (double)b->sr;
   d.quantum_duration = (double)RQ * dt;  // delay.rs:546-548
   st.profile_slot = slot_for(b, "loop_kernel");
+  for (const LoopItem& li : host) {
+    for (int j = 0; j < li.n_in; j++)
+      if (li.in_item[j] < 0) st.loop_reads.push_back(li.in_sig[j].base);
+    st.loop_writes.push_back(li.out.base);
+  }
   b->steps.push_back(st);
   plan_note(b, "feedback loop: %d item(s) per quantum [%s]", d.n_items, desc.c_str());
   return 0;
