@@ -274,7 +274,9 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_step,
                          "kernel_ms": kernel_ms, "launches_per_step": launches_per_step},
         }
-        if not args.no_cpu_baseline:
+        if world > 1:
+            out["cpu_baseline"] = None  # timed at N = 1 only: the host cores are shared by the ranks
+        elif not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(waa, name, frames)
                 if out["cpu_baseline"]:
