@@ -1,0 +1,128 @@
+// stream_probe — what bounds a "one wave per stream" copy on MI355X?  (measurement tool, not part of the product)
+//
+// The streaming biquad kernel of C2 gives every (instance, channel) stream to one wave that walks it in 2048-frame
+// tiles; with its recurrence removed it still only reaches ~4.9 TB/s where a linear copy reaches ~6.3 TB/s
+// (profiles/r01_c2_memory_pattern.txt).  This probe times copies of the same 2 x 3.9 GB with different shapes:
+//   linear        grid-stride float4 copy (the reference point)
+//   stream T      one wave per stream, tile of T floats, next tile prefetched into registers before the stores
+//   stream+lds    the same with the two LDS transposes of the real kernel
+//   split S       every stream cut into S contiguous segments, one wave each (S x more waves, same bytes)
+// build: hipcc --offload-arch=gfx950 -O3 -o stream_probe tools/stream_probe.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x)                                                                  \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e_));              \
+      exit(1);                                                                    \
+    }                                                                             \
+  } while (0)
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void linear_copy(const f4v* __restrict__ in, f4v* __restrict__ out, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = in[i] * 0.5f;
+}
+
+// one wave per (stream, segment): tiles of NV4 float4 per lane, software-pipelined like biquad_stream_kernel
+template <int NV4, bool LDS>
+__global__ __launch_bounds__(64) void stream_copy(const float* __restrict__ in, float* __restrict__ out, size_t stream_len,
+                                                  int segments) {
+  __shared__ float lds[LDS ? 2 * 64 * (NV4 * 4 + 4) : 1];
+  const int lane = threadIdx.x;
+  const size_t stream = blockIdx.x / segments, seg = blockIdx.x % segments;
+  constexpr int TILE = 64 * NV4 * 4;
+  const size_t tiles_total = stream_len / TILE, per = tiles_total / segments;
+  const size_t t0 = seg * per, t1 = seg + 1 == (size_t)segments ? tiles_total : t0 + per;
+  const float* ip = in + stream * stream_len;
+  float* op = out + stream * stream_len;
+  f4v cur[NV4], nxt[NV4];
+#pragma unroll
+  for (int j = 0; j < NV4; j++) cur[j] = *(const f4v*)(ip + t0 * TILE + j * 256 + lane * 4);
+  for (size_t t = t0; t < t1; t++) {
+    if (t + 1 < t1) {
+#pragma unroll
+      for (int j = 0; j < NV4; j++) nxt[j] = *(const f4v*)(ip + (t + 1) * TILE + j * 256 + lane * 4);
+    }
+    if (LDS) {
+      // A layout -> LDS, read back transposed (lane owns NV4*4 consecutive frames), write, read A layout again
+      constexpr int ROW = NV4 * 4 + 4;
+      float* a = lds;
+      float* b = lds + 64 * ROW;
+#pragma unroll
+      for (int j = 0; j < NV4; j++) {
+        const int fr = j * 256 + lane * 4;  // frame within tile
+        *(f4v*)(a + (fr / (NV4 * 4)) * ROW + fr % (NV4 * 4)) = cur[j];
+      }
+      __builtin_amdgcn_wave_barrier();
+      f4v x[NV4];
+#pragma unroll
+      for (int j = 0; j < NV4; j++) x[j] = *(const f4v*)(a + lane * ROW + j * 4);
+#pragma unroll
+      for (int j = 0; j < NV4; j++) *(f4v*)(b + lane * ROW + j * 4) = x[j] * 0.5f;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < NV4; j++) {
+        const int fr = j * 256 + lane * 4;
+        cur[j] = *(const f4v*)(b + (fr / (NV4 * 4)) * ROW + fr % (NV4 * 4));
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV4; j++) cur[j] = cur[j] * 0.5f;
+    }
+#pragma unroll
+    for (int j = 0; j < NV4; j++) *(f4v*)(op + t * TILE + j * 256 + lane * 4) = cur[j];
+#pragma unroll
+    for (int j = 0; j < NV4; j++) cur[j] = nxt[j];
+  }
+}
+
+template <class F>
+static void timeit(const char* name, double bytes, F launch) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  launch();
+  CHECK(hipDeviceSynchronize());
+  const int reps = 5;
+  CHECK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++) launch();
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  printf("%-28s %8.3f ms  %7.1f GB/s\n", name, ms, bytes / (ms * 1e-3) / 1e9);
+  fflush(stdout);
+}
+
+int main() {
+  const size_t n_streams = 2048, stream_len = 235 * 2048;  // C2: 1024 contexts x 2 channels x 481280 padded frames
+  const size_t n = n_streams * stream_len;
+  float *in = nullptr, *out = nullptr;
+  CHECK(hipMalloc(&in, n * sizeof(float)));
+  CHECK(hipMalloc(&out, n * sizeof(float)));
+  CHECK(hipMemset(in, 0, n * sizeof(float)));
+  const double bytes = 2.0 * n * sizeof(float);
+  timeit("linear 256x4096", bytes, [&] { hipLaunchKernelGGL(linear_copy, dim3(4096), dim3(256), 0, 0, (const f4v*)in, (f4v*)out, n / 4); });
+  timeit("linear 256x65536", bytes, [&] { hipLaunchKernelGGL(linear_copy, dim3(65536), dim3(256), 0, 0, (const f4v*)in, (f4v*)out, n / 4); });
+  timeit("stream tile 2048", bytes, [&] { hipLaunchKernelGGL((stream_copy<8, false>), dim3(n_streams), dim3(64), 0, 0, in, out, stream_len, 1); });
+  timeit("stream tile 1024", bytes, [&] { hipLaunchKernelGGL((stream_copy<4, false>), dim3(n_streams), dim3(64), 0, 0, in, out, stream_len, 1); });
+  timeit("stream tile 4096", bytes, [&] { hipLaunchKernelGGL((stream_copy<16, false>), dim3(n_streams), dim3(64), 0, 0, in, out, stream_len, 1); });
+  timeit("stream tile 2048 + lds", bytes, [&] { hipLaunchKernelGGL((stream_copy<8, true>), dim3(n_streams), dim3(64), 0, 0, in, out, stream_len, 1); });
+  for (int s : {2, 4, 8, 16}) {
+    char name[64];
+    snprintf(name, sizeof name, "stream 2048, split %d", s);
+    timeit(name, bytes, [&] { hipLaunchKernelGGL((stream_copy<8, false>), dim3(n_streams * s), dim3(64), 0, 0, in, out, stream_len, s); });
+  }
+  timeit("stream 2048+lds, split 4", bytes, [&] { hipLaunchKernelGGL((stream_copy<8, true>), dim3(n_streams * 4), dim3(64), 0, 0, in, out, stream_len, 4); });
+  timeit("stream 1024, split 4", bytes, [&] { hipLaunchKernelGGL((stream_copy<4, false>), dim3(n_streams * 4), dim3(64), 0, 0, in, out, stream_len, 4); });
+  CHECK(hipFree(in));
+  CHECK(hipFree(out));
+  return 0;
+}

@@ -78,7 +78,10 @@ __global__ __launch_bounds__(64, 2) void iir_stream_kernel(const IirStreamDesc d
   constexpr int AHEAD = NS <= 4 ? 4 : 2;
   auto lds_sync = []() __attribute__((always_inline)) { __builtin_amdgcn_wave_barrier(); };
   auto fetch_fast = [&](uint32_t tile, float (&dst)[TILE_K]) __attribute__((always_inline)) {
-    const float* p = is_src ? si.base + (uint64_t)ch * si.ch_stride + load_global(&sc.qrec[(uint64_t)tile * QUANTA_PER_TILE].start)
+    // (inside the linear prefix the start of a tile is arithmetic; behind it, it comes from the schedule table)
+    const float* p = is_src ? si.base + (uint64_t)ch * si.ch_stride +
+                                  (tile < si.fast_prefix ? si.linear_start + (int64_t)tile * TILE
+                                                         : load_global(&sc.qrec[(uint64_t)tile * QUANTA_PER_TILE].start))
                             : sig_base + (uint64_t)tile * TILE;
 #pragma unroll
     for (int j = 0; j < NV4; j++) {
@@ -89,7 +92,9 @@ __global__ __launch_bounds__(64, 2) void iir_stream_kernel(const IirStreamDesc d
       dst[j * 4 + 3] = t.w;
     }
   };
-  auto tile_is_fast = [&](uint32_t tile) __attribute__((always_inline)) -> bool { return !is_src || (si.aligned && load_global(sc.tile_fast + tile)); };
+  auto tile_is_fast = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
+    return !is_src || tile < si.fast_prefix || (si.aligned && load_global(sc.tile_fast + tile));
+  };
   auto stage = [&](const float (&cur)[TILE_K]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NV4; j++) {
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(64, 2) void iir_stream_kernel(const IirStreamDesc d
       continue;
     }
     uint32_t end = tile + 1;
+    if (is_src && end < si.fast_prefix) end = si.fast_prefix < d.tile1 ? si.fast_prefix : d.tile1;  // no table walk
     while (end < d.tile1 && tile_is_fast(end)) end++;
     float nx[TILE_K];
     fetch_fast(tile, nx);

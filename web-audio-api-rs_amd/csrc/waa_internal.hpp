@@ -61,6 +61,13 @@ struct SrcInst {
   uint32_t sched;        // index into the schedule table
   uint32_t aligned;      // base and ch_stride multiples of 4 floats
   SrcSchedule sc;        // copy of the schedule entry: saves the kernels one dependent load per wave
+  // tiles [0, fast_prefix) are fast AND one linear run: tile t starts at buffer frame linear_start + t * 2048.  The
+  // streaming kernels then need neither the per-tile flag nor the per-tile start from the tables — two dependent
+  // loads in front of every prefetch (tools/stream_probe.hip: the same copy without them runs at 6.0 TB/s, with
+  // them the kernel's copy floor was 4.9 TB/s)
+  int64_t linear_start;
+  uint32_t fast_prefix;
+  uint32_t pad;
 };
 
 // ---- chain kernel description ----------------------------------------------------------

@@ -1336,6 +1336,7 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   // AudioBufferSourceNode
   std::vector<SrcInst> insts(b->n_inst);
   std::vector<SrcSchedule> scheds;
+  std::vector<std::pair<int64_t, uint32_t>> linear;  // per schedule: (linear_start, fast_prefix)
   std::map<SchedKey, uint32_t> dedup;
   const ParamStore& p_rate = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
   const ParamStore& p_det = n.params[WAA_PARAM_SOURCE_DETUNE];
@@ -1372,6 +1373,20 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
       plan_note(b, "source node %u schedule %zu: quanta fast=%u fast_loop=%u slow=%u silent=%u fast_tiles=%u/%u", id,
                 scheds.size(), nf, nl, ns, (uint32_t)so.qrec.size() - nf - nl - ns, nt, b->n_tiles);
     }
+    {
+      // leading tiles that are fast and form one linear run of the buffer
+      int64_t start0 = 0;
+      uint32_t prefix = 0;
+      if (!so.tile_fast.empty() && so.tile_fast[0]) {
+        start0 = so.qrec[0].start;
+        while (prefix < b->n_tiles && so.tile_fast[prefix] &&
+               so.qrec[(size_t)prefix * QUANTA_PER_TILE].start == start0 + (int64_t)prefix * TILE)
+          prefix++;
+      }
+      linear.push_back({start0, prefix});
+      plan_note(b, "source node %u schedule %zu: tiles [0, %u) are one linear run from buffer frame %lld", id, scheds.size(), prefix,
+                (long long)start0);
+    }
     SrcSchedule ds{};
     QRec* dq = nullptr;
     int e = dev_upload(b, &dq, so.qrec);
@@ -1391,7 +1406,11 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
     scheds.push_back(ds);
     if (!automated) dedup[key] = si.sched;
   }
-  for (auto& si : insts) si.sc = scheds[si.sched];
+  for (auto& si : insts) {
+    si.sc = scheds[si.sched];
+    si.linear_start = linear[si.sched].first;
+    si.fast_prefix = si.aligned ? linear[si.sched].second : 0;
+  }
   SrcInst* d_insts = nullptr;
   int e = dev_upload(b, &d_insts, insts);
   if (e) return e;
