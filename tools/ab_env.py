@@ -1,0 +1,44 @@
+"""Same-process A/B of a library switch: python tools/ab_env.py VAR[=VALUE] workload [workload ...]
+Renders each bench.py workload with the environment variable unset and then set (plan-time switches are read when
+the batch is planned, launch-time ones at every launch), alternating twice (A B A B) so that drift shows, and prints
+the per-kernel HIP-event means.  Example — the linear-prefix fetch of the streaming kernels:
+    python tools/ab_env.py WAA_NO_LINEAR_PREFIX c2 iir2 t1"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import web_audio_api_rs_amd as waa  # noqa: E402
+
+
+def main(argv):
+    var, _, value = argv[0].partition("=")
+    value = value or "1"
+    n_inst, frames = 1024, 480000
+    hip = waa.default_binding()
+    noise = torch.empty((n_inst, 2, frames), dtype=torch.float32, device="cuda").uniform_(-1, 1)
+    for name in argv[1:]:
+        for rep in range(2):
+            for on in (False, True):
+                os.environ.pop(var, None)
+                if on:
+                    os.environ[var] = value
+                ctx, _ = bench.build_workload(waa, hip, name, n_inst, frames, 0, noise.data_ptr())
+                ctx.prepare()
+                ctx.render_async()
+                ctx.sync()
+                ctx.profile(True)
+                ctx.profile_reset()
+                for _ in range(5):
+                    ctx.render_async()
+                ctx.sync()
+                print(name, f"{var}={'%s' % value if on else '(unset)'}", {n: round(ms / 5, 3) for n, l, ms in ctx.profile_entries()},
+                      flush=True)
+                ctx.close()
+    os.environ.pop(var, None)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1409,7 +1409,7 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   for (auto& si : insts) {
     si.sc = scheds[si.sched];
     si.linear_start = linear[si.sched].first;
-    si.fast_prefix = si.aligned ? linear[si.sched].second : 0;
+    si.fast_prefix = si.aligned && !getenv("WAA_NO_LINEAR_PREFIX") ? linear[si.sched].second : 0;  // (switch: A/B aid)
   }
   SrcInst* d_insts = nullptr;
   int e = dev_upload(b, &d_insts, insts);
