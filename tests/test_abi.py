@@ -48,6 +48,12 @@ def test_product_never_references_oracle():
     assert "oracle" not in out
 
 
+@pytest.fixture(params=["orc", "hip-plan-only"])
+def be_plan(request, orc, hip):
+    """(binding, context kwargs): the oracle, or the product on a plan-only batch (no GPU needed)"""
+    return (orc, {}) if request.param == "orc" else (hip, {"device": waa.PLAN_ONLY})
+
+
 def test_validation_without_gpu(hip):
     """Graph validation happens before the device is touched and mirrors the reference's panics."""
     c = waa.OfflineAudioContext(2, 128, 44100.0, binding=hip)
@@ -62,6 +68,38 @@ def test_validation_without_gpu(hip):
     c = waa.OfflineAudioContext(2, 128, 1000.0, binding=hip)
     with pytest.raises(waa.WaaError, match="NotSupportedError"):
         c.start_rendering_sync()
+
+
+def test_context_construction_limits(be_plan):
+    """OfflineAudioContext::new (offline.rs:78-81): assert_valid_number_of_channels / _buffer_length / _sample_rate
+    (src/lib.rs:165-228), same messages, on both libraries; a destination wider than the device path renders is
+    refused with status 4 by the product (never truncated)."""
+    be, kw = be_plan
+
+    def attempt(ch, length, sr, n_inst=1):
+        c = waa.OfflineAudioContext(ch, length, sr, n_instances=n_inst, binding=be, **kw)
+        s = c.create_buffer_source()
+        s.set_buffer(waa.AudioBuffer(np.ones((1, 4), np.float32), 48000.0))
+        s.connect(c.destination())
+        s.start()
+        c.prepare()
+        return c
+
+    for ch in (0, 33):
+        with pytest.raises(waa.WaaError, match="NotSupportedError - Invalid number of channels") as e:
+            attempt(ch, 128, 48000.0)
+        assert e.value.status == 2
+    with pytest.raises(waa.WaaError, match="NotSupportedError - Invalid length: 0") as e:
+        attempt(2, 0, 48000.0)
+    assert e.value.status == 2
+    for sr in (2999.0, 768001.0, float("nan")):
+        with pytest.raises(waa.WaaError, match="NotSupportedError - Invalid sample rate"):
+            attempt(2, 128, sr)
+    with pytest.raises(waa.WaaError) as e:
+        attempt(2, 128, 48000.0, n_inst=0)
+    assert e.value.status == 1
+    attempt(2, 1, 3000.0).close()  # the smallest legal context
+    attempt(6, 129, 768000.0).close()
 
 
 def test_host_helpers_match_oracle(hip, orc):

@@ -39,7 +39,10 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
   if (g->nodes[0].kind != WAA_NODE_DESTINATION) return fail(WAA_ERR_INVALID_ARGUMENT, "node 0 must be the destination");
   if (n_out == 0 || n_out > WAA_MAX_CHANNELS)
     return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels: %u", n_out);
-  if (!(sr >= 8000.f && sr <= 192000.f)) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid sample rate: %f", sr);
+  if (length == 0)  // assert_valid_buffer_length, src/lib.rs:222-228
+    return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid length: 0 is less than or equal to minimum bound (0)");
+  if (!(sr >= 3000.f && sr <= 768000.f))  // MIN/MAX_SAMPLE_RATE, src/lib.rs:149-160
+    return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid sample rate: %f", sr);
   std::unique_ptr<waa_batch> b(new waa_batch);
   b->n_inst = n_inst;
   b->n_out = n_out;
