@@ -118,3 +118,28 @@ def test_host_helpers_match_oracle(hip, orc):
                                                 hz.size))
             outs.append((mag, ph))
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_panner_option_limits(be_plan):
+    """PannerOptions validation (panner.rs:408-428, assert_valid_cone_outer_gain :20-33): same messages and error
+    classes on both libraries, before anything is rendered."""
+    be, kw = be_plan
+
+    def attempt(**opts):
+        c = waa.OfflineAudioContext(2, 128, 48000.0, binding=be, **kw)
+        s = c.create_constant_source()
+        s.connect(c.create_panner(**opts)).connect(c.destination())
+        s.start()
+        c.prepare()
+        c.close()
+
+    attempt()  # defaults
+    attempt(ref_distance=0.0, rolloff_factor=0.0, cone_outer_gain=1.0)  # the boundaries are legal
+    for opts, msg, status in ((dict(ref_distance=-0.1), "RangeError - refDistance cannot be negative", 1),
+                              (dict(max_distance=0.0), "RangeError - maxDistance must be strictly positive", 1),
+                              (dict(rolloff_factor=-1.0), "RangeError - rolloffFactor cannot be negative", 1),
+                              (dict(cone_outer_gain=1.5), "InvalidStateError - coneOuterGain must be in the range", 3),
+                              (dict(cone_outer_gain=-0.1), "InvalidStateError - coneOuterGain must be in the range", 3)):
+        with pytest.raises(waa.WaaError, match=msg) as e:
+            attempt(**opts)
+        assert e.value.status == status

@@ -113,6 +113,19 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
           return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count mode cannot be set to max");
         if (n.cc > 2)
           return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count cannot be greater than two");
+        // PannerOptions (panner.rs:408-428, 20-33); an all-zero d[] block means "the defaults" (panner.rs:146-166)
+        if (n.desc.d[0] == 0. && n.desc.d[1] == 0. && n.desc.d[2] == 0. && n.desc.d[3] == 0. && n.desc.d[4] == 0. && n.desc.d[5] == 0.) {
+          n.desc.d[0] = 1.;
+          n.desc.d[1] = 10000.;
+          n.desc.d[2] = 1.;
+          n.desc.d[3] = 360.;
+          n.desc.d[4] = 360.;
+        }
+        if (!(n.desc.d[0] >= 0.)) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - refDistance cannot be negative");
+        if (!(n.desc.d[1] > 0.)) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - maxDistance must be strictly positive");
+        if (!(n.desc.d[2] >= 0.)) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - rolloffFactor cannot be negative");
+        if (!(n.desc.d[5] >= 0. && n.desc.d[5] <= 1.))
+          return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - coneOuterGain must be in the range [0, 1]");
         break;
       }
       case WAA_NODE_DELAY:  // delay.rs:283-335
