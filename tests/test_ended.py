@@ -200,3 +200,84 @@ def test_block_boundary_stop_times_follow_the_f64_arithmetic(orc, hip):
     # sanity: always quantum i or i + 1, never anything else
     for per_node in results[0]:
         assert all(q in (i, i + 1, ENDED_AT_UNLOAD) for i, q in enumerate(per_node))
+
+
+# --------------------------------------------------------------------------- the reference's own onended tests
+def _kat_ctx(mk, length=44100, sr=44100.0, channels=2):
+    be, is_orc, device = mk
+    kw = {} if device is None else {"device": device}
+    return waa.OfflineAudioContext(channels, length, sr, binding=be, **kw), is_orc
+
+
+def _make(c, kind):
+    return {"constant": c.create_constant_source, "buffer": c.create_buffer_source, "oscillator": c.create_oscillator}[kind]()
+
+
+@pytest.mark.parametrize("kind", ["constant", "buffer", "oscillator"])
+def test_reference_ended_event_kats(mk, kind):
+    """scheduled_source.rs:135-263 (run_ended_event, run_no_ended_event, run_exact_ended_event,
+    run_implicit_ended_event), each for ConstantSource, AudioBufferSource (WITHOUT a buffer, as there) and Oscillator:
+    the reference only asserts whether `onended` fired by the end of start_rendering_sync."""
+    fired = {}
+    for name, start, stop in (("ended", 0.0, 0.5), ("never started", None, None), ("exact", 0.0, 1.0), ("implicit", 0.0, None)):
+        c, is_orc = _kat_ctx(mk)
+        src = _make(c, kind)
+        src.connect(c.destination())
+        if start is not None:
+            src.start_at(start)
+        if stop is not None:
+            src.stop_at(stop)
+        run(c, is_orc)
+        fired[name] = src.ended_quantum() != ENDED_NEVER
+        c.close()
+    assert fired == {"ended": True, "never started": False, "exact": True, "implicit": True}
+
+
+def test_reference_onended_before_drop(mk):
+    """audio_buffer_source.rs:2042-2071: the buffer is longer than the render, the event still fires (before_drop)"""
+    c, is_orc = _kat_ctx(mk, length=RQ, sr=48000.0, channels=1)
+    src = c.create_buffer_source()
+    buf = np.zeros((1, RQ * 2), np.float32)
+    buf[0, 0] = 1.0
+    src.set_buffer(waa.AudioBuffer(buf, 48000.0))
+    src.connect(c.destination())
+    src.start()
+    run(c, is_orc)
+    assert src.ended_quantum() == ENDED_AT_UNLOAD
+
+
+def test_reference_null_buffer_start_ends_before_start_time(mk):
+    """audio_buffer_source.rs:1508-1534: start_at(0.75) with no buffer; `ended` is already set when the context is
+    suspended at 0.5 s"""
+    c, is_orc = _kat_ctx(mk, length=48000, sr=48000.0, channels=1)
+    src = c.create_buffer_source()
+    src.connect(c.destination())
+    src.start_at(0.75)
+    run(c, is_orc)
+    q = src.ended_quantum()
+    assert 0 <= q < int(0.5 * 48000.0) // RQ
+
+
+def test_reference_osc_stop_before_start_ends_without_waiting(mk):
+    """oscillator.rs:1248-1276: start two quanta ahead, stop() now: `ended` has fired when the context is suspended
+    at the start of quantum 1"""
+    c, is_orc = _kat_ctx(mk, length=RQ * 4, sr=44100.0, channels=1)
+    osc = c.create_oscillator()
+    osc.connect(c.destination())
+    osc.start_at(2.0 * RQ / 44100.0)
+    osc.stop()
+    run(c, is_orc)
+    assert osc.ended_quantum() == 0
+
+
+@pytest.mark.parametrize("start_frame", [0, 1])
+def test_reference_one_sample_buffer_ends_in_the_first_quantum(mk, start_frame):
+    """audio_buffer_source.rs:1919-1983 (fast track / slow track): a one-sample buffer; the handler of `ended` runs
+    before the second quantum is rendered (it switches looping on and the output must not restart)"""
+    c, is_orc = _kat_ctx(mk, length=RQ * 4, sr=48000.0, channels=1)
+    src = c.create_buffer_source()
+    src.set_buffer(waa.AudioBuffer(np.ones((1, 1), np.float32), 48000.0))
+    src.connect(c.destination())
+    src.start_at(start_frame / 48000.0)
+    run(c, is_orc)
+    assert src.ended_quantum() == 0
