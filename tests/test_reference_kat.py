@@ -824,3 +824,31 @@ def test_oracle_threaded_render_is_identical(orc, orc_lib):
         orc_lib.orc_set_threads(c._handle, threads)
         outs.append(c.start_rendering_sync().data)
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_constant_source_start_stop(orc):
+    """src/node/constant_source.rs test_start_stop (:308-340): start in the 2nd block at frame 129, stop in the 3rd at
+    frame 257, tolerance 0.  (Oracle pin; the HIP path renders constant sources with sub-quantum starts and stops
+    in tests/test_delay.py::test_subquantum_delay_dynamic_lifetime and in the randomised graphs.)"""
+    sr = 48000.0
+    c = waa.OfflineAudioContext(1, 128 * 4, sr, binding=orc)
+    src = c.create_constant_source()
+    src.connect(c.destination())
+    src.start_at(129.0 / sr)
+    src.stop_at(257.0 / sr)
+    out = c.start_rendering_sync().data[0, 0]
+    exp = np.zeros(512, np.float32)
+    exp[129:257] = 1.0
+    assert np.array_equal(out, exp)
+
+
+def test_gain_audioparam_value_applies_immediately(orc):
+    """src/node/gain.rs test_audioparam_value_applies_immediately (:209-229): a value set before rendering is in
+    effect from the first frame"""
+    c = waa.OfflineAudioContext(1, 128, 48000.0, binding=orc)
+    g = c.create_gain(gain=0.5)
+    src = c.create_constant_source()
+    src.connect(g).connect(c.destination())
+    src.start()
+    out = c.start_rendering_sync().data[0, 0]
+    assert np.array_equal(out, np.full(128, 0.5, np.float32))
