@@ -852,3 +852,31 @@ def test_gain_audioparam_value_applies_immediately(orc):
     src.start()
     out = c.start_rendering_sync().data[0, 0]
     assert np.array_equal(out, np.full(128, 0.5, np.float32))
+
+
+def _analyser_of_constant(orc, value, fft_size):
+    c = waa.OfflineAudioContext(1, 128, 48000.0, binding=orc)
+    src = c.create_constant_source(offset=value)
+    an = c.create_analyser(fft_size=fft_size)
+    src.connect(an).connect(c.destination())
+    src.start()
+    c.start_rendering_sync()
+    return an
+
+
+def test_analyser_time_domain_data_vs_fft_size(orc):
+    """src/analysis.rs:656-691: a destination longer than fftSize only gets fftSize values (the rest is untouched),
+    a shorter one is filled completely; tolerance 0"""
+    an = _analyser_of_constant(orc, 1.0, 32)
+    got = an.get_float_time_domain_data(n=128)
+    exp = np.zeros(128, np.float32)
+    exp[:32] = 1.0
+    assert np.array_equal(got, exp)
+    an = _analyser_of_constant(orc, 1.0, 128)
+    assert np.array_equal(an.get_float_time_domain_data(n=16), np.ones(16, np.float32))
+
+
+def test_analyser_byte_time_domain_data(orc):
+    """src/analysis.rs:694-718: +1 -> 255, -1 -> 0"""
+    assert np.array_equal(_analyser_of_constant(orc, 1.0, 128).get_byte_time_domain_data(n=128), np.full(128, 255, np.uint8))
+    assert np.array_equal(_analyser_of_constant(orc, -1.0, 128).get_byte_time_domain_data(n=128), np.zeros(128, np.uint8))
