@@ -880,3 +880,35 @@ def test_analyser_byte_time_domain_data(orc):
     """src/analysis.rs:694-718: +1 -> 255, -1 -> 0"""
     assert np.array_equal(_analyser_of_constant(orc, 1.0, 128).get_byte_time_domain_data(n=128), np.full(128, 255, np.uint8))
     assert np.array_equal(_analyser_of_constant(orc, -1.0, 128).get_byte_time_domain_data(n=128), np.zeros(128, np.uint8))
+
+
+def test_offline_start_stop_square_dc(orc):
+    """tests/offline.rs:48-81: a square oscillator at 0 Hz is a constant 1; started at quantum 1, stopped at quantum 3;
+    tolerance 0"""
+    sr = 48000.0
+    c = waa.OfflineAudioContext(1, 128 * 4, sr, binding=orc)
+    osc = c.create_oscillator(type_="square", frequency=0.0)
+    osc.connect(c.destination())
+    osc.start_at(128.0 / sr)
+    osc.stop_at(128.0 * 3.0 / sr)
+    out = c.start_rendering_sync().data
+    assert out.shape == (1, 1, 512)
+    exp = np.zeros(512, np.float32)
+    exp[128:384] = 1.0
+    assert np.array_equal(out[0, 0], exp)
+
+
+def test_offline_delayed_constant_source(orc):
+    """tests/offline.rs:83-112: constant source through a 2-quantum delay, abs_all <= 1e-5"""
+    sr = 48000.0
+    c = waa.OfflineAudioContext(1, 128 * 4, sr, binding=orc)
+    delay = c.create_delay(1.0)
+    delay.delay_time.set_value(np.float32(128.0 * 2.0) / np.float32(sr))
+    delay.connect(c.destination())
+    src = c.create_constant_source()
+    src.connect(delay)
+    src.start()
+    out = c.start_rendering_sync().data[0, 0]
+    exp = np.zeros(512, np.float32)
+    exp[256:] = 1.0
+    assert np.max(np.abs(out - exp)) <= 1e-5
