@@ -271,3 +271,39 @@ def test_parity_fm_long_render(hip, orc):
     assert np.abs(outs[1]).max() > 0.5
     assert rms_err(*outs).max() <= 1e-6
     assert np.abs(outs[0] - outs[1]).max() <= 1e-4  # isolated samples next to a sawtooth edge
+
+
+# --------------------------------------------------------------------------- more of the reference's tests (oracle pins)
+@pytest.mark.parametrize("exp", range(5))
+def test_sine_raw_exact_phase(orc, exp):
+    """oscillator.rs:842-869: the expected phase is freq * i / sr computed per sample (no accumulation), one second,
+    abs_all <= 1e-5 — bounds the drift of the running phase"""
+    sr = 44100
+    freq = float(np.float32(10.0) ** np.float32(exp))
+    out = render_osc(orc, sr, sr, freq)
+    i = np.arange(sr, dtype=np.float64)
+    want = np.sin(freq * i / sr * 2.0 * np.pi).astype(np.float32)
+    assert np.max(np.abs(out - want)) <= 1e-5
+
+
+def test_sub_sample_stop(orc):
+    """oscillator.rs:1278-1308: stop_at(19.4 / sr): frames 0..19 sound, the rest is silent"""
+    sr = 44100
+    out = render_osc(orc, sr, 2048, 8910.1, stop=19.4 / sr)
+    want = ref_phase_sine(2048, 8910.1, sr)
+    want[20:] = 0.0
+    assert np.max(np.abs(out - want)) <= 1e-5
+
+
+def test_reenters_the_audible_range_after_large_phase_increments(orc):
+    """oscillator.rs:1384-1407: 20 kHz detuned by +2400 cents is 80 kHz (>= nyquist: silence); the detune drops to 0 at
+    the second quantum and the oscillator must come back with finite, non-zero samples"""
+    sr = 44100
+    c = waa.OfflineAudioContext(1, 256, float(sr), binding=orc)
+    osc = c.create_oscillator(frequency=20000.0, detune=2400.0)
+    osc.detune.set_value_at_time(0.0, RQ / sr)
+    osc.connect(c.destination())
+    osc.start_at(0.0)
+    out = c.start_rendering_sync().data[0, 0]
+    assert np.max(np.abs(out[:RQ])) <= 1e-5
+    assert np.all(np.isfinite(out[RQ:])) and np.any(out[RQ:] != 0.0)
