@@ -3217,6 +3217,50 @@ waa_status orc_render(orc_batch* b) {
   }
   return WAA_OK;
 }
+/* oracle-only TIMING aid (bench.py cpu_baseline): puts a rendered batch back into its pre-render state (every
+ * renderer's state zeroed, convolver and delay lines cleared) so that the same batch can be rendered again under the
+ * stopwatch; the rewind itself is outside the timed region.  Refused for batches with scheduled automation (the
+ * timelines are consumed by the first render). */
+waa_status orc_rewind(orc_batch* b) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  for (uint32_t i = 0; i < b->n_nodes; i++)
+    for (int p = 0; p < b->nodes[i].n_params; p++)
+      if (b->nodes[i].params[p].tl) return fail(WAA_ERR_INVALID_STATE, "orc_rewind: batch has automation timelines");
+  for (uint32_t k = 0; k < b->n_inst; k++)
+    for (uint32_t i = 0; i < b->n_nodes; i++) {
+      NodeState* s = &b->st[k][i];
+      Quantum* pin[WAA_MAX_PARAMS];
+      ConvState* conv[4];
+      memcpy(pin, s->pin, sizeof pin);
+      memcpy(conv, s->conv, sizeof conv);
+      free(s->ring);
+      free(s->dl_ring);
+      free(s->last_fft_output);
+      memset(s, 0, sizeof *s);
+      memcpy(s->pin, pin, sizeof pin);
+      for (int p = 0; p < WAA_MAX_PARAMS; p++)
+        if (s->pin[p]) q_make_silent(s->pin[p]);
+      for (int c = 0; c < 4; c++) {
+        ConvState* cs = conv[c];
+        s->conv[c] = cs;
+        if (!cs || cs->ir->seg_count == 0) continue;
+        const ConvIR* ir = cs->ir;
+        memset(cs->seg_re, 0, (size_t)ir->seg_count * ir->csize * sizeof(float));
+        memset(cs->seg_im, 0, (size_t)ir->seg_count * ir->csize * sizeof(float));
+        memset(cs->pre_re, 0, ir->csize * sizeof(float));
+        memset(cs->pre_im, 0, ir->csize * sizeof(float));
+        memset(cs->conv_re, 0, ir->csize * sizeof(float));
+        memset(cs->conv_im, 0, ir->csize * sizeof(float));
+        memset(cs->fftbuf, 0, ir->seg * sizeof(float));
+        memset(cs->overlap, 0, ir->block * sizeof(float));
+        memset(cs->inbuf, 0, ir->block * sizeof(float));
+        cs->inbuf_fill = 0;
+        cs->current = 0;
+      }
+    }
+  b->rendered = 0;
+  return WAA_OK;
+}
 waa_status orc_sync(orc_batch* b) {
   (void)b;
   return WAA_OK;

@@ -13,6 +13,34 @@ def white_noise(n_inst, n_ch, frames, seed0=0xA0D10, first=0):
     return out
 
 
+_GARAGE_CACHE = {}
+
+
+def garage_ir(binding=None, sr=48000.0):
+    """The impulse response BASELINE.json config 3 names: samples/parking-garage-response.wav of the reference
+    (2 ch, 44.1 kHz, 16-bit PCM, 164 363 frames; committed as tests/golden/parking-garage-response.wav), decoded the
+    way the reference's decoder does (symphonia's i16 -> f32 conversion, third party, restated: sample / 32768) and
+    resampled to the context rate by AudioBuffer::resample (decoding.rs:51 -> buffer.rs:311-363): 44 100 -> 48 000 Hz
+    gives 178 899 frames = 175 reference partitions of 1024.  `binding` selects whose
+    resampler runs (the product's waa_buffer_resample by default; tests check it against the oracle's bit for bit)."""
+    import os
+    import wave
+    if binding is None:
+        binding = waa.default_binding()
+    key = (binding.prefix if hasattr(binding, "prefix") else id(binding), float(sr))
+    if key not in _GARAGE_CACHE:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parking-garage-response.wav")
+        with wave.open(path) as w:
+            assert (w.getnchannels(), w.getframerate(), w.getsampwidth(), w.getnframes()) == (2, 44100, 2, 164363)
+            raw = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, 2).T
+        pcm = np.ascontiguousarray(raw.astype(np.float32) / np.float32(32768.0))
+        ir = pcm if float(sr) == 44100.0 else waa.resample(binding, pcm, 44100.0, sr)
+        if float(sr) == 48000.0:
+            assert ir.shape == (2, 178899), ir.shape
+        _GARAGE_CACHE[key] = ir
+    return _GARAGE_CACHE[key]
+
+
 def garage_like_ir(frames=178899, n_ch=2, sr=48000.0, seed=7):
     """Synthetic stand-in for samples/parking-garage-response.wav resampled to 48 kHz (2 ch x 178 899
     frames => 175 partitions of 1024): exponentially decaying noise, ~1.2 s RT60-ish."""

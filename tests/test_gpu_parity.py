@@ -211,7 +211,7 @@ def test_c2_full_size_sampled_instances(hip, orc):
 
 
 # ----------------------------------------------------------------------------- convolver / analyser
-from graphs import c4, garage_like_ir, t1  # noqa: E402
+from graphs import c4, garage_ir, garage_like_ir, t1  # noqa: E402
 
 
 def _decaying_ir(n_ch, frames, seed=3, tau=0.3):
@@ -279,7 +279,7 @@ def test_garage_sized_ir_sampled(hip, orc):
     """C3/T1 IR shape (2 ch x 178 899 frames = 175 reference partitions; 22 blocks of 8192 on the device)."""
     n_inst, frames = 6, RQ * 300
     noise = white_noise(n_inst, 2, frames)
-    ir = garage_like_ir()
+    ir = garage_like_ir()  # (synthetic stand-in with a hand-set noise floor; the real IR is used by the tests below)
     ctx, _ = t1(hip, noise, ir)
     out = ctx.start_rendering_sync().data
     ctx.close()
@@ -383,7 +383,7 @@ def test_t1_full_length_sampled_instances(hip, orc):
     10 s render length (59 blocks of 8192, 22 partitions); the oracle renders a sample of the instances."""
     n_inst, frames = 33, 480000  # odd count: the last instance pair is half empty
     noise = white_noise(n_inst, 2, frames)
-    ir = garage_like_ir()
+    ir = garage_ir(hip)  # the reference's parking-garage response, decoded + resampled to 48 kHz: 2 x 178 899
     ctx, _ = t1(hip, noise, ir)
     out = ctx.start_rendering_sync().data
     ctx.close()
@@ -455,3 +455,77 @@ def test_k_rate_biquad_streaming_kernel(hip, orc):
             ctx.close()
         assert rms_err(*outs).max() <= TOL, ftype
         assert np.abs(outs[0] - outs[1]).max() <= 1e-6, ftype
+
+
+# ----------------------------------------------------------------------------- BASELINE configs at FULL size
+def _noise_fast(n_inst, n_ch, frames, seed):
+    """uniform white noise in [-1, 1) for a whole batch from one generator (fast enough for GBs)"""
+    rng = np.random.default_rng(seed)
+    out = rng.random((n_inst, n_ch, frames), dtype=np.float32)
+    out *= 2.0
+    out -= 1.0
+    return out
+
+
+def test_c3_full_size_real_ir_sampled(hip, orc):
+    """BASELINE config 3 at full size: 512 contexts x 10 s, BufferSource -> Convolver(parking-garage IR, normalised)
+    -> destination; the oracle (restated fft-convolver, 175 partitions of 1024) renders a sample of the instances."""
+    n_inst, frames = 512, 480000
+    noise = _noise_fast(n_inst, 2, frames, 31)
+    ir = garage_ir(hip)
+    assert ir.shape == (2, 178899)
+    pick = [0, 1, 255, 510, 511]
+    ctx, _ = t1(hip, noise, ir, with_biquad=False)
+    assert "P=22 blocks=59" in ctx.plan_describe()
+    out = ctx.render_instances(pick)
+    ctx.close()
+    octx, _ = t1(orc, noise[pick], garage_ir(orc), with_biquad=False)
+    ref = octx.start_rendering_sync().data
+    octx.close()
+    err = rms_err(out, ref)
+    assert err.max() <= TOL, err
+    assert float(np.abs(ref).max()) > 1e-2
+
+
+def test_c4_full_size_real_ir_sampled(hip, orc):
+    """BASELINE config 4, one GPU's shard at full size: 512 contexts x 10 s, BufferSource -> Biquad -> Convolver(garage
+    IR) -> StereoPanner(0.1) -> Analyser(2048, 0.8) -> destination, one get_float_frequency_data pull per sampled
+    context after the render."""
+    n_inst, frames = 512, 480000
+    noise = _noise_fast(n_inst, 2, frames, 32)
+    pick = [0, 3, 256, 511]
+    ctx, nodes = c4(hip, noise, garage_ir(hip))
+    out = ctx.render_instances(pick)
+    gf = [nodes["analyser"].get_float_frequency_data(instance=i) for i in pick]
+    gt = [nodes["analyser"].get_float_time_domain_data(instance=i) for i in pick]
+    ctx.close()
+    octx, onodes = c4(orc, noise[pick], garage_ir(orc))
+    ref = octx.start_rendering_sync().data
+    of = [onodes["analyser"].get_float_frequency_data(instance=i) for i in range(len(pick))]
+    ot = [onodes["analyser"].get_float_time_domain_data(instance=i) for i in range(len(pick))]
+    octx.close()
+    err = rms_err(out, ref)
+    assert err.max() <= TOL, err
+    for k in range(len(pick)):
+        assert np.abs(gt[k] - ot[k]).max() <= 2e-6
+        gl, ol = 10.0 ** (gf[k].astype(np.float64) / 20), 10.0 ** (of[k].astype(np.float64) / 20)
+        assert np.abs(gl - ol).max() <= 1e-8 + 1e-3 * np.abs(ol).max()
+
+
+@pytest.mark.parametrize("rate,buf_sr,n_ch", [(1.5, None, 2), (1.0, 38000.0, 2), (1.5, None, 1)])
+def test_c5_full_size_sampled(hip, orc, rate, buf_sr, n_ch):
+    """BASELINE config 5 at full size: 2048 contexts x 10 s, looping BufferSource with playbackRate 1.5 (or a 38 kHz
+    buffer in a 48 kHz context) -> WaveShaper(2048-point curve) -> destination; 1e-6 RMS per channel against the
+    oracle for a sample of the instances (the 10 s render wraps the 65 536-frame loop 7-11 times)."""
+    n_inst, frames, buf_frames = 2048, 480000, 65536
+    noise = _noise_fast(n_inst, n_ch, buf_frames, 33)
+    pick = [0, 1, 1023, 2046, 2047]
+    ctx, _ = c5(hip, noise, length=frames, rate=rate, buf_sr=buf_sr, loop=True)
+    out = ctx.render_instances(pick)
+    ctx.close()
+    octx, _ = c5(orc, noise[pick], length=frames, rate=rate, buf_sr=buf_sr, loop=True)
+    ref = octx.start_rendering_sync().data
+    octx.close()
+    err = rms_err(out, ref)
+    assert err.max() <= TOL, err
+    assert np.abs(out - ref).max() <= 1e-6

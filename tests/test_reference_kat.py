@@ -742,6 +742,21 @@ def test_buffer_resample(be):
         assert np.max(np.abs(o[0] - np.sin(j))) <= 1e-3 and np.max(np.abs(o[1] - np.cos(j))) <= 1e-3
 
 
+
+def test_parking_garage_ir_fixture(hip, orc):
+    """BASELINE.json config 3's impulse response: samples/parking-garage-response.wav (2 ch, 44.1 kHz, 16-bit,
+    164 363 frames) -> AudioBuffer::resample to 48 kHz (decoding.rs:51, buffer.rs:311-363) = 2 x 178 899 frames,
+    i.e. 175 partitions of 1024.  The product's host resampler and the oracle's agree bit for bit
+    (waa_buffer_resample is host code: no device needed), first and last samples are kept (buffer.rs:330-347)."""
+    from graphs import garage_ir
+    a, b = garage_ir(hip), garage_ir(orc)
+    raw = garage_ir(hip, sr=44100.0)
+    assert raw.shape == (2, 164363) and a.shape == b.shape == (2, 178899)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[:, 0], raw[:, 0]) and np.array_equal(a[:, -1], raw[:, -1])
+    assert (a.shape[1] + 1023) // 1024 == 175
+    assert float(np.abs(raw).max()) == 1.0  # a full-scale (-32768) sample: i16 / 32768
+
 # ----------------------------------------------------------------------------- analyser
 def test_blackman(orc_lib):
     """src/analysis.rs:415-437"""

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""tools/pmc_merge.py <workload> <contexts> <frames> <tag> — fold gpurun_out/<tag>_{stats,fetch,write}.txt (tools/pmc_pass.sh)
+into profiles/pmc_traffic.json: HBM bytes per launch of every product kernel (FETCH_SIZE x 2, the gfx950 correction of
+MI355X_MICROARCH.md for wide coalesced reads, + WRITE_SIZE; both counters are in KiB... rocprofv3 reports them in KB of
+1024 B) and per render step (sum over kernels x launches per step)."""
+import json
+import os
+import re
+import sys
+
+name, contexts, frames, tag = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse(path):
+    calls, pmc = {}, {}
+    mode = None
+    for line in open(path):
+        if line.startswith("-- kernel stats"):
+            mode = "k"
+        elif line.startswith("-- PMC"):
+            mode = "p"
+        elif mode and "|" in line:
+            f = [x.strip() for x in line.split("|")]
+            if mode == "k":
+                calls[f[0]] = (int(f[1]), float(f[3]))
+            else:
+                pmc[f[0]] = (f[1], int(f[2]), float(f[3]))
+    return calls, pmc
+
+
+def short(k):
+    m = re.search(r"(waa::(?:\(anonymous namespace\)::)?)([A-Za-z_0-9]+(?:<[^(]*>)?)", k)
+    return m.group(2) if m else k
+
+
+stats, _ = parse(os.path.join(root, "gpurun_out", f"{tag}_stats.txt"))
+_, fetch = parse(os.path.join(root, "gpurun_out", f"{tag}_fetch.txt"))
+_, write = parse(os.path.join(root, "gpurun_out", f"{tag}_write.txt"))
+steps = 4  # --steps 3 --warmup 1 (+ the planning render: 5 launches of every per-step kernel)
+kernels, total = {}, 0.0
+for k, (n_calls, avg_us) in stats.items():
+    if "waa::" not in k or k not in fetch or k not in write:
+        continue
+    rd = fetch[k][2] * 1024.0 * 2.0
+    wr = write[k][2] * 1024.0
+    per_step = round(n_calls / 5.0)
+    if per_step < 1:
+        continue  # one-off kernels (IR spectra)
+    kernels[short(k)] = {"launches_per_step": per_step, "avg_us": avg_us, "read_bytes": rd, "write_bytes": wr,
+                         "bytes_per_launch": rd + wr, "GBps": (rd + wr) / avg_us / 1e3}
+    total += (rd + wr) * per_step
+path = os.path.join(root, "profiles", "pmc_traffic.json")
+data = json.load(open(path))
+rec = {"contexts": contexts, "frames": frames, "kernels": kernels, "bytes_per_step": total,
+       "note": f"tools/pmc_pass.sh {name} {tag}: rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE in "
+               "separate passes of `python bench.py --workload %s --steps 3 --warmup 1 --no-cpu-baseline --no-extra`; "
+               "gfx950 correction FETCH_SIZE x 2; summaries: profiles/%s_*.txt" % (name, tag)}
+if len(kernels) == 1:
+    k = next(iter(kernels.values()))
+    rec["kernel"] = next(iter(kernels))
+    rec["bytes_per_launch"] = k["bytes_per_launch"]
+data[name] = rec
+json.dump(data, open(path, "w"), indent=1)
+print(json.dumps(rec, indent=1))

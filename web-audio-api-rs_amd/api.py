@@ -909,6 +909,18 @@ class OfflineAudioContext:
         self._b.check(self._b.download_all(self._handle, _fp(out)))
         return RenderedBatch(out, self.sample_rate)
 
+    def render_instances(self, instances) -> np.ndarray:
+        """start_rendering_sync for the whole batch, but only the AudioBuffers of `instances` are downloaded
+        (waa_download per channel): full-size batches whose result would not fit a test's host memory budget."""
+        if self._rendered:
+            raise WaaError(3, "InvalidStateError - Cannot call `startRendering` twice")
+        self.render_async()
+        out = np.empty((len(instances), self.number_of_channels, self.length), np.float32)
+        for k, inst in enumerate(instances):
+            for c in range(self.number_of_channels):
+                self._b.check(self._b.download(self._handle, int(inst), c, _fp(out[k, c]), self.length))
+        return out
+
     def plan_describe(self) -> str:
         """The launch plan derived from the graph (works on a plan-only context: device=PLAN_ONLY)."""
         self.prepare()
