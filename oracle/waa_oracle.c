@@ -1239,6 +1239,13 @@ static void order_nodes(orc_batch* b) {
     for (uint32_t i = 0; i < b->n_nodes && !applied; i++) {
       applied = order_visit(&c, i);
       if (!applied && b->nodes[i].desc.kind == WAA_NODE_DELAY) applied = order_visit(&c, i | ORC_READER);
+      /* The AudioListener is graph node 1 (LISTENER_NODE_ID, context/mod.rs:26), right behind the destination, with one
+       * outgoing edge per PannerNode in creation order (concrete_base.rs:511-534 connect_listener_to_panner): as a DFS
+       * root it pulls every panner branch to the front of the traversal, which moves those branches BACK in the
+       * reversed post-order and thereby fixes the f32 summing order of fan-ins of three or more signals. */
+      if (i == 0)
+        for (uint32_t pn = 0; pn < b->n_nodes && !applied; pn++)
+          if (b->nodes[pn].desc.kind == WAA_NODE_PANNER) applied = order_visit(&c, pn);
     }
     if (!applied) break;
     cut[c.breaker] = 1;
@@ -1816,7 +1823,11 @@ waa_status orc_set_param_const(orc_batch* b, uint32_t node, uint32_t param, uint
   if ((e = check_inst(b, inst))) return e;
   Param* p = &b->nodes[node].params[param];
   uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
-  for (uint32_t k = lo; k < hi; k++) p->cst[k] = value;
+  for (uint32_t k = lo; k < hi; k++) {
+    p->cst[k] = value;
+    /* AudioParam::set_value after automation methods is one more SetValue event (param.rs:392-415) */
+    if (p->tl && p->tl[k] && (e = orc_timeline_event(p->tl[k], WAA_EVENT_SET_VALUE, value, 0., 0., NULL, 0))) return e;
+  }
   return WAA_OK;
 }
 waa_status orc_set_param_block(orc_batch* b, uint32_t node, uint32_t param, uint32_t inst, uint64_t q0, uint32_t nq,

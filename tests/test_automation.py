@@ -410,6 +410,8 @@ def test_argument_validation(mk):  # :24-62, :1666-1697
 # --------------------------------------------------------------------------- through a render (GPU vs oracle)
 from graphs import rms_err, white_noise  # noqa: E402
 
+RQ = 128
+
 
 def _automated_graph(binding, noise):
     n, _, frames = noise.shape
@@ -443,6 +445,31 @@ def test_render_with_scheduled_automation(hip, orc):
     g, o = _automated_graph(hip, noise), _automated_graph(orc, noise)
     assert rms_err(g, o).max() <= 1e-6
     assert np.abs(g - o).max() <= 5e-6
+
+
+@pytest.mark.gpu
+def test_set_value_after_scheduled_events_is_one_more_event(hip, orc):
+    """AudioParam::set_value (param.rs:402-425) AFTER automation methods enqueues a SetValue event; through the C ABI
+    that is waa_set_param_const following waa_param_schedule_event: the new constant must reach the timeline that
+    already exists (it used to be dropped: the timeline kept the constant it was seeded with)."""
+    noise = white_noise(2, 1, RQ * 12, seed0=5)
+    outs = []
+    for b in (hip, orc):
+        c = waa.OfflineAudioContext(1, RQ * 12, 48000.0, n_instances=2, binding=b)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(noise, 48000.0)
+        g = c.create_gain(gain=0.25)
+        g.gain.set_value_at_time(0.5, RQ * 6 / 48000.0)
+        src.connect(g).connect(c.destination())
+        src.start()
+        c.prepare()
+        b.check(b.set_param_const(c._handle, g.id, 0, 1, 0.75))  # instance 1 only, after the event above
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    assert np.array_equal(outs[0], outs[1])
+    g_ = outs[0]
+    assert np.allclose(g_[0, 0, :RQ * 6], 0.25 * noise[0, 0, :RQ * 6]) and np.allclose(g_[1, 0, :RQ * 6], 0.75 * noise[1, 0, :RQ * 6])
+    assert np.allclose(g_[1, 0, RQ * 6:], 0.5 * noise[1, 0, RQ * 6:])
 
 
 def test_scheduling_errors_reach_the_caller(be):

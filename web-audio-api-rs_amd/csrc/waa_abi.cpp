@@ -485,7 +485,16 @@ waa_status waa_set_param_const(waa_batch* b, uint32_t node, uint32_t param, uint
   if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
   ParamStore& p = b->nodes[node].params[param];
   uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
-  for (uint32_t k = lo; k < hi; k++) p.cst[k] = value;
+  for (uint32_t k = lo; k < hi; k++) {
+    p.cst[k] = value;
+    // AudioParam::set_value after automation methods enqueues a SetValue event (param.rs:386-400): a timeline that
+    // already exists was seeded with the OLD constant, so the new value has to go through it as well
+    if (k < p.timelines.size() && p.timelines[k]) {
+      if (inst != WAA_ALL_INSTANCES) p.timelines_shared = false;
+      int st = p.timelines[k]->schedule(WAA_EVENT_SET_VALUE, value, 0., 0., nullptr, 0);
+      if (st) return st;
+    }
+  }
   return WAA_OK;
 }
 

@@ -495,6 +495,13 @@ int build_plan(waa_batch* b) {
       for (uint32_t i = 0; i < N && !applied; i++) {
         applied = order_visit(c, i);
         if (!applied && is_delay(b, i)) applied = order_visit(c, i | VTX_READER);
+        // the AudioListener is the reference's graph node 1, right behind the destination, with an edge to every
+        // PannerNode in creation order (concrete_base.rs:511-534): visited as a DFS root it pulls the panner branches
+        // to the front of the traversal, i.e. to the back of the reversed post-order — which decides the f32 summing
+        // order wherever three or more signals meet
+        if (i == 0)
+          for (uint32_t pn = 0; pn < N && !applied; pn++)
+            if (b->nodes[pn].desc.kind == WAA_NODE_PANNER) applied = order_visit(c, pn);
       }
       if (!applied) break;
       c.cut[c.breaker] = 1;
