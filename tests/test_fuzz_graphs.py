@@ -208,10 +208,7 @@ def test_random_graph_parity(hip, orc, seed):
             pytest.skip(f"out of scope on the device path: {e} [{descr}]")
         raise
     ch.close()
-    if "dynamic channel count" in plan:
-        # the planner itself reports that this graph changes its channel count mid-render (a narrow input is
-        # active while a wider one is still silent): the documented static-count divergence, DESIGN.md section 5
-        pytest.skip(f"planner note: dynamic channel count [{descr}]")
+    assert "dynamic channel count" not in plan  # (the round-1 note of the static plan; WAA_STATIC_CHANNEL_COUNTS only)
     co, _ = build_random_graph(orc, seed)
     o = co.start_rendering_sync().data
     co.close()
@@ -244,11 +241,12 @@ def test_random_graphs_plan_on_cpu(hip):
 
 
 @pytest.mark.gpu
-def test_dynamic_channel_count_divergence_is_reported(hip, orc, monkeypatch):
+def test_dynamic_channel_count_is_rendered(hip, orc, monkeypatch):
     """A mono oscillator from t = 0 plus a stereo buffer that starts later, into a BiquadFilter: the reference
     filters ONE channel until the stereo source starts and then starts channel 1 from a zero state
-    (biquad_filter.rs:800-815); the device plan filters two channels throughout.  The planner reports it, and
-    WAA_STRICT_CHANNEL_COUNTS turns the report into a refusal."""
+    (biquad_filter.rs:800-815).  The planner's replay finds the count change and renders the graph with exact
+    per-quantum channel counts (waa_dyn.hip); WAA_STATIC_CHANNEL_COUNTS=1 brings back the static plan of round 1, which
+    filters two channels throughout, says so in the plan, and is refused under WAA_STRICT_CHANNEL_COUNTS."""
     def build(be):
         c = waa.OfflineAudioContext(2, FRAMES, SR, n_instances=1, binding=be)
         osc = c.create_oscillator(frequency=220.0)
@@ -261,12 +259,19 @@ def test_dynamic_channel_count_divergence_is_reported(hip, orc, monkeypatch):
         osc.start()
         buf.start_at(1000.0 / SR)
         return c
+    o = build(orc).start_rendering_sync().data
+    c = build(hip)
+    plan = c.plan_describe()
+    assert "dynamic-count group" in plan and "dynamic channel count" not in plan
+    g = c.start_rendering_sync().data
+    c.close()
+    assert rms_err(g, o).max() <= 1e-6 and np.abs(g - o).max() <= 2e-6
+    monkeypatch.setenv("WAA_STATIC_CHANNEL_COUNTS", "1")
     c = build(hip)
     assert "dynamic channel count" in c.plan_describe()
     g = c.start_rendering_sync().data
     c.close()
-    o = build(orc).start_rendering_sync().data
-    # identical until the stereo source starts, different afterwards (channel 1's filter state)
+    # the static plan: identical until the stereo source starts, different afterwards (channel 1's filter state)
     assert np.abs(g[:, :, :896] - o[:, :, :896]).max() <= 1e-6
     assert np.abs(g[:, 1, 1024:] - o[:, 1, 1024:]).max() > 1e-4
     monkeypatch.setenv("WAA_STRICT_CHANNEL_COUNTS", "1")

@@ -234,11 +234,8 @@ def test_t1_small_multi_partition(hip, orc, ir_len, n_inst):
 
 @pytest.mark.parametrize("in_ch,ir_ch", [
     (1, 1), (1, 2), (2, 2), (2, 4), (1, 4),
-    pytest.param(2, 1, marks=pytest.mark.xfail(strict=True, reason=(
-        "KNOWN DIVERGENCE (DESIGN.md 'Silence and channel counts'): once a stereo source has ended, the reference's "
-        "convolver sees a 1-channel silent quantum and, with a mono IR, switches to the (1,1) routing: only "
-        "convolver 0 keeps running and its tail is up-mixed into BOTH channels (convolver.rs:343-392). The device "
-        "path keeps the static stereo routing, so the right-channel tail differs after the source ends."))),
+    (2, 1),  # after the stereo source has ended the reference falls back to the (1,1) routing: convolver 0's tail in
+             # both channels (convolver.rs:343-392) — rendered by the dynamic-count path (waa_dyn.hip), was a strict xfail
 ])
 def test_convolver_channel_configs_random(hip, orc, in_ch, ir_ch):
     """convolver.rs:384-466 routing with random data, normalisation on, plus a tail after the source ends."""

@@ -168,7 +168,23 @@ def test_note_mono_first_then_stereo_into_a_filter():
     stereo.connect(bq)
     bq.connect(c.destination())
     plan = c.plan_describe()
-    assert "dynamic channel count" in plan and "narrower than its static channel count at quantum 0" in plan
+    assert "narrower than its static channel count at quantum 0" in plan
+    # the planner answers with the exact per-quantum channel counts of waa_dyn.hip: filter + destination in one group
+    assert "dynamic-count group: 2 item(s) per quantum [BIQUAD3,pass0]" in plan and "dynamic channel count" not in plan
+    c.close()
+
+
+def test_static_plan_switch_keeps_the_round1_note(monkeypatch):
+    """WAA_STATIC_CHANNEL_COUNTS=1 (A/B aid): the static plan of round 1 with its 'dynamic channel count' note"""
+    monkeypatch.setenv("WAA_STATIC_CHANNEL_COUNTS", "1")
+    c = _plan_only()
+    mono, stereo = _buffer(c, 1, RQ * 40), _buffer(c, 2, RQ * 40, start=RQ * 5 / 48000.0)
+    bq = c.create_biquad_filter()
+    mono.connect(bq)
+    stereo.connect(bq)
+    bq.connect(c.destination())
+    plan = c.plan_describe()
+    assert "dynamic channel count" in plan and "dynamic-count group" not in plan and "biquad_stream" in plan
     c.close()
 
 
@@ -181,13 +197,13 @@ def test_no_note_when_widths_agree_over_time():
     mono.connect(bq)
     stereo.connect(bq)
     bq.connect(c.destination())
-    assert "dynamic channel count" not in c.plan_describe()
+    assert "dynamic-count group" not in c.plan_describe()
     c.close()
     c = _plan_only()
     short = _buffer(c, 2, RQ * 3)
     bq = c.create_biquad_filter()
     short.connect(bq).connect(c.destination())
-    assert "dynamic channel count" not in c.plan_describe()
+    assert "dynamic-count group" not in c.plan_describe()
     c.close()
 
 
@@ -199,13 +215,14 @@ def test_note_delay_line_collapses_when_its_stereo_input_ends():
     short.connect(d).connect(c.destination())
     plan = c.plan_describe()
     assert "falls silent (= mono) while the node still holds multi-channel material" in plan
+    assert "dynamic-count group: 3 item(s) per quantum [delayW2,delayR2,pass0]" in plan
     c.close()
     # a mono input into the same delay never changes the count
     c = _plan_only()
     short = _buffer(c, 1, RQ * 3)
     d = c.create_delay(0.1, delay_time=0.05)
     short.connect(d).connect(c.destination())
-    assert "dynamic channel count" not in c.plan_describe()
+    assert "dynamic-count group" not in c.plan_describe()
     c.close()
 
 
@@ -224,8 +241,10 @@ def test_note_zero_gain_in_front_of_a_panner_and_strict_mode(monkeypatch):
         pan.connect(c.destination())
         return c
     c = build()
-    assert "narrower than its static channel count at quantum 10" in c.plan_describe()
+    plan = c.plan_describe()
+    assert "narrower than its static channel count at quantum 10" in plan and "dynamic-count group" in plan
     c.close()
+    monkeypatch.setenv("WAA_STATIC_CHANNEL_COUNTS", "1")
     monkeypatch.setenv("WAA_STRICT_CHANNEL_COUNTS", "1")
     c = build()
     with pytest.raises(waa.WaaError) as ei:

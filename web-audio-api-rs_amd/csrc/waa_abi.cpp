@@ -600,6 +600,8 @@ waa_status waa_render(waa_batch* b) {
       }
       case 8: e = timed(st.profile_slot, [&] { launch_loop(st.loop, b->stream); }); break;
       case 9: e = timed(st.profile_slot, [&] { launch_osc(st.osc, b->stream); }); break;
+      case 10: e = timed(st.profile_slot, [&] { launch_dyn(st.dyn, b->stream); }); break;
+      case 11: e = timed(st.profile_slot, [&] { launch_conv_codes(st.ccode, b->stream); }); break;
       default: {
         ChainDesc d = st.chain;
         d.tile0 = t0;

@@ -1,0 +1,529 @@
+// waa_dyn.hip — exact dynamic channel counts.  The reference's AudioRenderQuantum (quantum.rs:178-586) carries a
+// channel count and a "silent" flag that change from render quantum to render quantum: a silent quantum is mono,
+// `add` mixes both operands to the count computed from the receiver's channel config and the CURRENT counts
+// (quantum.rs:532-569), and count-sensitive processors follow that count — the Biquad / IIR filters keep state per
+// channel and start a new channel from zero (biquad_filter.rs:778-815, iir_filter.rs:323-360), the StereoPanner and
+// the Panner have a mono and a stereo law (stereo_panner.rs:218-317, panner.rs:988-1057), the DelayNode re-mixes its
+// whole line to the count of its current input (delay.rs:469-489) and reports silence from the DATA it read
+// (delay.rs:660-668), the filters' tails end when their state leaves the normal range.  The node-major kernels render
+// static counts; that is exact as long as the planner's replay finds no count change at a count-sensitive node
+// (DESIGN.md section 5).  When it does, the graph (everything but sources and FFT convolvers) is rendered here:
+// one wavefront per instance, render quantum by render quantum, items in the reference's processing order, every
+// signal accompanied by a per-quantum code = count | CODE_SILENT.  Feedback loops need nothing extra in this form
+// (the loop kernel of waa_loop.hip is the static-count special case).  Latency-bound by construction; throughput
+// comes from the batch (1024 instances = 1024 wavefronts).
+#include <hip/hip_runtime.h>
+
+#include "waa_internal.hpp"
+
+namespace waa {
+
+namespace {
+__device__ __forceinline__ float pval(const ParamRef& p, uint32_t inst, uint32_t q, uint64_t frame) {
+  if (p.mode == 0) return load_global(p.base + inst);
+  if (p.mode == 1) return load_global(p.base + (uint64_t)inst * p.stride + q);
+  return load_global(p.base + (uint64_t)inst * p.stride + frame);
+}
+__device__ __forceinline__ float coherent_f(const float* p) {
+  return __int_as_float(__hip_atomic_load((const WAA_GLOBAL_AS int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ uint32_t coherent_u(const uint32_t* p) {
+  return (uint32_t)__hip_atomic_load((const WAA_GLOBAL_AS int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// waveshaper.rs:555-573
+__device__ __forceinline__ float shape(const float* curve, int nn, float input) {
+  if (nn == 0) return 0.f;
+  const float n = (float)nn;
+  const float v = (n - 1.f) / 2.0f * (input + 1.f);
+  if (v <= 0.f) return load_global(curve);
+  if (v >= n - 1.f) return load_global(curve + nn - 1);
+  const float k = floorf(v);
+  const float f = v - k;
+  const int ki = (int)k;
+  return (1.f - f) * load_global(curve + ki) + f * load_global(curve + ki + 1);
+}
+// quantum.rs:285-505 mix_inner for mono / stereo; `sil` = every channel is the allocator's zero block.  A computed
+// down-mix goes through make_mut, so its result is no longer silent by pointer identity (quantum.rs:96-104).
+__device__ __forceinline__ void mix12(float (&u)[2][2], int from, int to, int interp, bool& sil) {
+  if (from == to) return;
+  if (from == 1 && to == 2) {
+#pragma unroll
+    for (int e = 0; e < 2; e++) u[1][e] = interp == 1 ? 0.f : u[0][e];
+  } else if (from == 2 && to == 1) {
+    if (interp != 1) {
+#pragma unroll
+      for (int e = 0; e < 2; e++) u[0][e] = 0.5f * (u[0][e] + u[1][e]);
+      sil = false;
+    }
+  }
+}
+__device__ __forceinline__ void stereo_gains(float x, float& gl, float& gr) {  // stereo_panner.rs:74-79
+  const float PI_F = 3.14159265358979323846f;
+  gl = sinf((1.f - x) * PI_F / 2.f);
+  gr = sinf(x * PI_F / 2.f);
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* cur = lds;                                                          // [n_items][2][128] outputs of this quantum
+  float* scratch = cur + (size_t)d.n_items * 2 * RQ;                          // [2][128]
+  double* fst = reinterpret_cast<double*>(scratch + 2 * RQ);                  // [n_items][2][DYN_STATE] filter state
+  int* ist = reinterpret_cast<int*>(fst + (size_t)d.n_items * 2 * DYN_STATE);  // [n_items][4] integer state
+  int* codes = ist + (size_t)d.n_items * 4;                                   // [n_items] codes of this quantum
+  const uint32_t inst = blockIdx.x;
+  const int lane = threadIdx.x;
+  __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);  // f64 denormals flushed (FTZ/DAZ render scope, thread.rs:374-382)
+  for (int i = lane; i < d.n_items * 2 * DYN_STATE; i += 64) fst[i] = 0.;
+  for (int i = lane; i < d.n_items; i += 64) {
+    const DynItem& li = d.items[i];
+    // ist[0]: channels of the filter state (xy_len = 0, iir_filter.rs:303-306 "eagerly assume stereo" = 2) /
+    //         delay writer: the line's channel count (ring of silent = mono quanta, delay.rs:386-397)
+    ist[i * 4 + 0] = (li.kind == DI_NODE && li.dk == DK_IIR) ? 2 : (li.kind == DI_DELAY_W ? 1 : 0);
+    ist[i * 4 + 1] = -1;  // delay writer: last quantum in which the line was (re-)mixed to mono
+    ist[i * 4 + 2] = 0;   // DK_CONV_IN: compacted quantum slots used by channel 1
+    ist[i * 4 + 3] = 0;
+    codes[i] = (int)(1u | CODE_SILENT);
+  }
+  __syncthreads();
+
+  for (uint32_t q = 0; q < d.n_quanta; q++) {
+    const uint64_t f0 = (uint64_t)q * RQ;
+    for (int it = 0; it < d.n_items; it++) {
+      const DynItem& li = d.items[it];
+      float v[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+      int sn = 1;       // number_of_channels of the mixed input
+      bool ss = true;   // is_silent
+      if (li.kind != DI_DELAY_R) {
+        // ---- graph.rs:524-535: the input starts silent (mono); every incoming edge is `add`ed in order
+        for (int k = 0; k < li.n_in; k++) {
+          const DynInput& in = li.in[k];
+          float u[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+          uint32_t oc;
+          if (in.item >= 0) {
+            oc = (uint32_t)codes[in.item];
+            const float* src = cur + (size_t)in.item * 2 * RQ;
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+              if (c < (int)(oc & 7u)) {
+                u[c][0] = src[c * RQ + lane];
+                u[c][1] = src[c * RQ + 64 + lane];
+              }
+          } else {
+            oc = in.code ? (uint32_t)load_global(in.code + (uint64_t)inst * in.code_stride + q) : (uint32_t)in.nch;
+            const float* src = in.sig.base + (uint64_t)inst * in.sig.inst_stride;
+            const int on = (int)(oc & 7u);
+            if (!(oc & CODE_SILENT)) {
+              u[0][0] = load_global(src + f0 + lane);
+              u[0][1] = load_global(src + f0 + 64 + lane);
+              if (on >= 2) {
+                const uint64_t f1 = in.remap ? (uint64_t)load_global(in.remap + (uint64_t)inst * in.code_stride + q) * RQ : f0;
+                u[1][0] = load_global(src + in.sig.ch_stride + f1 + lane);
+                u[1][1] = load_global(src + in.sig.ch_stride + f1 + 64 + lane);
+              }
+            }
+          }
+          int on = (int)(oc & 7u);
+          bool os = (oc & CODE_SILENT) != 0;
+          if (on > 2) on = 2;  // (the planner refuses wider layouts in dynamic plans)
+          // quantum.rs:532-569
+          const int maxc = sn > on ? sn : on;
+          int newc = li.mode == 0 ? maxc : (li.mode == 2 ? li.cc : (maxc < li.cc ? maxc : li.cc));
+          if (newc > 2) newc = 2;
+          if (newc < 1) newc = 1;
+          mix12(v, sn, newc, li.interp, ss);
+          mix12(u, on, newc, li.interp, os);
+          if (ss) {  // quantum.rs:114-120: a silent channel takes the other operand (and its flag)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+              for (int e = 0; e < 2; e++) v[c][e] = u[c][e];
+            ss = os;
+          } else if (!os) {
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+              for (int e = 0; e < 2; e++) v[c][e] = v[c][e] + u[c][e];
+          }
+          sn = newc;
+        }
+        if (ss) {  // silent data is the zero block
+#pragma unroll
+          for (int c = 0; c < 2; c++) v[c][0] = v[c][1] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+          if (c >= sn) v[c][0] = v[c][1] = 0.f;
+      }
+      int outn = sn;
+      bool outs = ss;
+      if (li.kind == DI_NODE) {
+        const OpDesc& op = li.op;
+        switch (li.dk) {
+          case DK_GAIN: {  // gain.rs:143-199
+            if (ss) {
+              outn = 1;
+              break;
+            }
+            if (op.p0.mode == 2) {
+#pragma unroll
+              for (int e = 0; e < 2; e++) {
+                const float g = load_global(op.p0.base + (uint64_t)inst * op.p0.stride + f0 + e * 64 + lane);
+                v[0][e] *= g;
+                v[1][e] *= g;
+              }
+            } else {
+              const float g = pval(op.p0, inst, q, 0);
+              if (fabsf(g) <= 1e-6f) {  // :163-171 silent output
+                outs = true;
+                outn = 1;
+#pragma unroll
+                for (int c = 0; c < 2; c++) v[c][0] = v[c][1] = 0.f;
+              } else if (!(fabsf(1.f - g) <= 1e-6f)) {
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                  for (int e = 0; e < 2; e++) v[c][e] *= g;
+              }
+            }
+            break;
+          }
+          case DK_BIQUAD:
+          case DK_IIR: {
+            // biquad_filter.rs:764-899 / iir_filter.rs:323-405: per-channel state, tail until the state is denormal
+            const bool iir = li.dk == DK_IIR;
+            const int ns = iir ? (op.i0 < 0 ? -op.i0 : op.i0) : 4;  // state doubles that decide the tail
+            double* st = fst + (size_t)it * 2 * DYN_STATE;
+            int nst = ist[it * 4 + 0];
+            if (ss) {
+              bool normal = false;
+              for (int j = lane; j < nst * DYN_STATE; j += 64) {
+                const int c = j / DYN_STATE, jj = j % DYN_STATE;
+                if (jj < (iir ? ns + 1 : 4)) normal |= __builtin_isnormal(st[c * DYN_STATE + jj]);
+              }
+              if (!__any(normal)) {
+                outs = true;
+                outn = 1;
+                break;
+              }
+              outn = nst;
+            } else {
+              if (sn != nst) {
+                __syncthreads();
+                for (int j = lane; j < 2 * DYN_STATE; j += 64)
+                  if (j / DYN_STATE >= nst && j / DYN_STATE < sn) st[j] = 0.;
+                if (lane == 0) ist[it * 4 + 0] = sn;
+                nst = sn;
+              }
+              outn = sn;
+            }
+            outs = false;
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+              // (a silent input reads its single zero channel for every state channel, :858-862)
+              scratch[c * RQ + lane] = ss ? 0.f : v[c][0];
+              scratch[c * RQ + 64 + lane] = ss ? 0.f : v[c][1];
+            }
+            __syncthreads();
+            if (lane < outn) {
+              double* s = st + lane * DYN_STATE;
+              float* row = scratch + lane * RQ;
+              if (!iir) {
+                double x1 = s[0], x2 = s[1], y1 = s[2], y2 = s[3];
+                const double* cbase = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0;
+                for (int i = 0; i < RQ; i++) {
+                  const double* cf = op.i0 == 0 ? cbase : op.i0 == 1 ? cbase + (uint64_t)q * 5 : cbase + (f0 + i) * 5;
+                  const double x = (double)row[i];
+                  double y = load_global(cf) * x + load_global(cf + 1) * x1 + load_global(cf + 2) * x2 - load_global(cf + 3) * y1 -
+                             load_global(cf + 4) * y2;
+                  if (!__builtin_isnormal(y)) y = 0.;
+                  x2 = x1;
+                  x1 = x;
+                  y2 = y1;
+                  y1 = y;
+                  row[i] = (float)y;
+                }
+                s[0] = x1;
+                s[1] = x2;
+                s[2] = y1;
+                s[3] = y2;
+              } else {
+                const double* cb = reinterpret_cast<const double*>(op.ptr0);  // [2][ns + 1]: b then a, zero padded
+                const double* ca = cb + (ns + 1);
+                const double b0 = load_global(cb);
+                for (int i = 0; i < RQ; i++) {
+                  const double x = (double)row[i];
+                  double y = __builtin_fma(b0, x, s[0]);
+                  if (!__builtin_isnormal(y)) y = 0.;
+                  for (int k = 1; k <= ns; k++) {
+                    const double next = k < DYN_STATE ? s[k] : 0.;
+                    s[k - 1] = load_global(cb + k) * x - load_global(ca + k) * y + next;
+                  }
+                  row[i] = (float)y;
+                }
+              }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+              v[c][0] = c < outn ? scratch[c * RQ + lane] : 0.f;
+              v[c][1] = c < outn ? scratch[c * RQ + 64 + lane] : 0.f;
+            }
+            break;
+          }
+          case DK_WAVESHAPER: {  // waveshaper.rs:383-487 (oversample none)
+            if (ss && (li.flags & 1)) {
+              outn = 1;
+              break;
+            }
+            if (op.ptr0) {
+              const float* curve = reinterpret_cast<const float*>(op.ptr0);
+#pragma unroll
+              for (int c = 0; c < 2; c++)
+                if (c < sn) {
+#pragma unroll
+                  for (int e = 0; e < 2; e++) v[c][e] = shape(curve, op.i0, v[c][e]);
+                }
+              outs = false;
+            }
+            break;
+          }
+          case DK_STEREO_PAN: {  // stereo_panner.rs:218-317
+            if (ss) {
+              outn = 1;
+              break;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+              const uint64_t f = f0 + e * 64 + lane;
+              const float pan = pval(op.p0, inst, q, f);
+              float gl, gr;
+              if (sn == 1) {
+                if (op.p0.mode == 2) {
+                  stereo_gains((pan + 1.f) * 0.5f, gl, gr);
+                } else {
+                  gl = pval(li.alt1, inst, q, 0);
+                  gr = pval(li.alt2, inst, q, 0);
+                }
+                const float x = v[0][e];
+                v[0][e] = x * gl;
+                v[1][e] = x * gr;
+              } else {
+                if (op.p0.mode == 2) {
+                  stereo_gains(pan <= 0.f ? pan + 1.f : pan, gl, gr);
+                } else {
+                  gl = pval(op.p1, inst, q, 0);
+                  gr = pval(op.p2, inst, q, 0);
+                }
+                const float il = v[0][e], ir = v[1][e];
+                if (pan <= 0.f) {
+                  v[0][e] = __builtin_fmaf(ir, gl, il);
+                  v[1][e] = ir * gr;
+                } else {
+                  v[0][e] = il * gl;
+                  v[1][e] = __builtin_fmaf(il, gr, ir);
+                }
+              }
+            }
+            outn = 2;
+            outs = false;
+            break;
+          }
+          case DK_PANNER: {  // panner.rs:830-897, 988-1057 (equal power)
+            if (ss) {
+              outn = 1;
+              break;
+            }
+            const float az = pval(op.p0, inst, q, 0);
+            const float dg = pval(op.p3, inst, q, 0), cg = pval(op.p4, inst, q, 0);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+              if (sn == 1) {
+                const float gl = pval(li.alt1, inst, q, 0), gr = pval(li.alt2, inst, q, 0);
+                const float x = v[0][e];
+                v[0][e] = x * (gl * dg * cg);
+                v[1][e] = x * (gr * dg * cg);
+              } else {
+                const float gl = pval(op.p1, inst, q, 0), gr = pval(op.p2, inst, q, 0);
+                const float il = v[0][e], ir = v[1][e];
+                if (az <= 0.f) {
+                  v[0][e] = (il + ir * gl) * dg * cg;
+                  v[1][e] = ir * gr * dg * cg;
+                } else {
+                  v[0][e] = il * gl * dg * cg;
+                  v[1][e] = (ir + il * gr) * dg * cg;
+                }
+              }
+            }
+            outn = 2;
+            outs = false;
+            break;
+          }
+          case DK_PASS:
+            if (li.flags & 2) {  // ConvolverNode without a buffer (convolver.rs:357-374): no tail, then passthrough
+              if (ss) outn = 1;
+            }
+            break;
+          default: break;  // DK_CONV_IN: the mixed input as it is
+        }
+      } else if (li.kind == DI_DELAY_W) {
+        // delay.rs:428-489: the ring is re-mixed to the count of the current input, then the input is stored
+        if (lane == 0) {
+          ist[it * 4 + 0] = sn;
+          if (sn == 1) ist[it * 4 + 1] = (int)q;
+        }
+      } else {
+        // ---- DelayReader::process, delay.rs:515-745, on the writer's line in absolute time
+        __syncthreads();  // the writer's stores of this quantum (if it rendered first) have reached L2
+        const DynItem& wi = d.items[li.writer_item];
+        const SignalRef& hs = wi.out;
+        const int nch = ist[li.writer_item * 4 + 0];         // ring[0].number_of_channels() right now
+        const int last_mono = ist[li.writer_item * 4 + 1];   // entries written before it were collapsed to mono
+        const uint32_t* wcode = wi.aux32 + (uint64_t)inst * wi.code_stride;
+        const OpDesc& op = li.op;
+        int64_t pf0 = 0;
+        float k0 = 0.f;
+        if (op.p0.mode != 2) {
+          double dv = (double)pval(op.p0, inst, q, 0);
+          if (li.in_cycle) dv = fmax(dv, d.quantum_duration);
+          const double position = 0. - dv * d.sample_rate;
+          const double fl = floor(position);
+          pf0 = (int64_t)fl;
+          k0 = (float)(position - fl);
+        }
+        bool active = false;
+        const float* hb = hs.base + (uint64_t)inst * hs.inst_stride;
+        // one sample of the line as the reader sees it NOW: entries written with two channels were averaged when the
+        // line was re-mixed to mono after they were written, and duplicated again if it went back to stereo
+        auto sample = [&](int c, int64_t idx) -> float {
+          if (idx < 0) return 0.f;
+          const int p = (int)(idx >> 7);
+          const uint32_t pc = coherent_u(wcode + p);
+          if (pc & CODE_SILENT) return 0.f;
+          const int np = (int)(pc & 7u);
+          if (np <= 1) return coherent_f(hb + idx);
+          if (last_mono > p) return 0.5f * (coherent_f(hb + idx) + coherent_f(hb + hs.ch_stride + idx));
+          return coherent_f(hb + (uint64_t)c * hs.ch_stride + idx);
+        };
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int i = e * 64 + lane;
+          int64_t pf;
+          float k;
+          if (op.p0.mode != 2) {
+            pf = pf0 + i;
+            k = k0;
+          } else {
+            double dv = (double)load_global(op.p0.base + (uint64_t)inst * op.p0.stride + f0 + i);
+            if (li.in_cycle) dv = fmax(dv, d.quantum_duration);
+            const double position = (double)i - dv * d.sample_rate;
+            const double fl = floor(position);
+            pf = (int64_t)fl;
+            k = (float)(position - fl);
+          }
+          const int64_t prev = (int64_t)f0 + pf;
+          // frame 128 of the newest block wraps to the OLDEST ring block (delay.rs:622-626); a reader that renders
+          // before its writer sees, in the slot of the current quantum, the block written ring-capacity quanta ago
+          int64_t next = prev + 1;
+          if (!li.in_cycle && pf == RQ - 1) next = ((int64_t)q - li.num_quanta) * RQ;
+          if (li.in_cycle && next >= (int64_t)f0) next -= ((int64_t)li.num_quanta + 1) * RQ;
+#pragma unroll
+          for (int c = 0; c < 2; c++)
+            if (c < nch) {
+              const float ps = sample(c, prev), nsv = sample(c, next);
+              const float val = __builtin_fmaf(1.f - k, ps, k * nsv);
+              active |= __builtin_isnormal(val);
+              v[c][e] = val;
+            }
+        }
+        if (__any(active)) {
+          outn = nch;
+          outs = false;
+        } else {  // delay.rs:660-668: nothing but zeros / denormals came out: the output is silent
+          outn = 1;
+          outs = true;
+#pragma unroll
+          for (int c = 0; c < 2; c++) v[c][0] = v[c][1] = 0.f;
+        }
+      }
+      if (outs) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) v[c][0] = v[c][1] = 0.f;
+      }
+      // ---- hand over (LDS) and publish (HBM)
+      float* dst = cur + (size_t)it * 2 * RQ;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        dst[c * RQ + lane] = c < outn ? v[c][0] : 0.f;
+        dst[c * RQ + 64 + lane] = c < outn ? v[c][1] : 0.f;
+      }
+      const uint32_t code = (uint32_t)outn | (outs ? CODE_SILENT : 0u);
+      if (lane == 0) codes[it] = (int)code;
+      if (li.out.base) {
+        float* gout = li.out.base + (uint64_t)inst * li.out.inst_stride;
+        uint64_t f1 = f0;
+        if (li.compact_ch1) {  // mono impulse response: convolver 1 only runs (= its time only advances) on stereo quanta
+          const int slot = ist[it * 4 + 2];
+          f1 = (uint64_t)slot * RQ;
+          if (lane == 0) {
+            store_global(li.aux32 + (uint64_t)inst * li.code_stride + q, (uint32_t)slot);
+            if (outn >= 2) ist[it * 4 + 2] = slot + 1;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+          if (c < li.nch_pub) {
+            const bool have = c < outn;
+            const bool dup = !have && li.publish_upmix && !outs;
+            if (c == 1 && li.compact_ch1 && !have) continue;  // nothing enters convolver 1 in this quantum
+            const uint64_t fc = c == 1 ? f1 : f0;
+            store_global(gout + (uint64_t)c * li.out.ch_stride + fc + lane, have ? v[c][0] : (dup ? v[0][0] : 0.f));
+            store_global(gout + (uint64_t)c * li.out.ch_stride + fc + 64 + lane, have ? v[c][1] : (dup ? v[0][1] : 0.f));
+          }
+        if (lane == 0) {
+          if (li.out_code) li.out_code[(uint64_t)inst * li.code_stride + q] = (uint8_t)code;
+          if (li.kind == DI_DELAY_W) store_global(li.aux32 + (uint64_t)inst * li.code_stride + q, code);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+void launch_dyn(const DynDesc& d, void* stream) {
+  const size_t lds = ((size_t)d.n_items * 2 * RQ + 2 * RQ) * sizeof(float) + (size_t)d.n_items * 2 * DYN_STATE * sizeof(double) +
+                     (size_t)d.n_items * 5 * sizeof(int);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dyn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(dyn_kernel, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, d);
+}
+
+// ConvolverRenderer::process on codes (convolver.rs:343-392): the tail counter cuts the output off once a silent input
+// has lasted for the length of the impulse response; the output count follows the routing table (:384-466).
+__global__ void conv_code_kernel(const ConvCodeDesc d) {
+  const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= d.n_inst) return;
+  const uint8_t* in = d.in_code + (uint64_t)inst * d.code_stride;
+  uint8_t* out = d.out_code + (uint64_t)inst * d.code_stride;
+  uint64_t tail = 0;
+  for (uint32_t q = 0; q < d.n_quanta; q++) {
+    const uint32_t c = in[q];
+    if (c & CODE_SILENT) {
+      if (tail >= d.impulse_length) {
+        out[q] = (uint8_t)(1u | CODE_SILENT);
+        continue;
+      }
+      tail += RQ;
+    } else {
+      tail = 0;
+    }
+    const int ic = (int)(c & 7u);
+    out[q] = (uint8_t)((ic == 1 && d.ir_nch == 1) ? 1u : 2u);
+  }
+}
+void launch_conv_codes(const ConvCodeDesc& d, void* stream) {
+  hipLaunchKernelGGL(conv_code_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
+}
+
+}  // namespace waa

@@ -160,6 +160,11 @@ struct Node {
   std::vector<ParamRef> pin_ref;
   std::vector<char> pin_ready;
   int n_consumers = 0;
+  // dynamic plans (waa_dyn.hip): per-quantum codes of the published signal, and the quantum slot of channel 1 when the
+  // signal feeds a mono-IR convolver whose second FFTConvolver only advances on stereo quanta
+  uint8_t* code = nullptr;
+  uint8_t* in_code = nullptr;  // ConvolverNode: codes of its mixed input
+  uint32_t* remap = nullptr;
 };
 
 struct ProfileEntry {
@@ -170,7 +175,7 @@ struct ProfileEntry {
 };
 
 struct Step {
-  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator
+  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator, 10 dynamic-count group (dyn_kernel), 11 convolver codes
   ChainDesc chain{};
   BiquadStreamDesc bq{};
   ConvDesc conv{};
@@ -179,6 +184,8 @@ struct Step {
   DelayDesc delay{};
   LoopDesc loop{};
   OscDesc osc{};
+  DynDesc dyn{};
+  ConvCodeDesc ccode{};
   int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
   void* zero_ptr = nullptr;
   size_t zero_bytes = 0;
@@ -214,6 +221,8 @@ struct waa_batch {
   std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render
   std::vector<Step> steps;
   bool planned = false;
+  bool dynamic = false;              // the plan renders the reference's dynamic channel counts (dyn_kernel)
+  uint64_t code_stride = 0;          // bytes per instance of a code table (n_quanta rounded up)
   bool rendered = false;
   bool dry = false;                  // WAA_DEVICE_PLAN_ONLY: allocations are host memory, nothing is launched
   std::vector<std::string> plan_log;  // waa_plan_describe

@@ -299,6 +299,77 @@ struct LoopDesc {
 };
 void launch_loop(const LoopDesc& d, void* stream);
 
+// ---- exact dynamic channel counts (quantum.rs:109-120,532-569): quantum-serial rendering with per-quantum codes ----
+// The reference's AudioRenderQuantum carries a channel count and a silent flag that change from quantum to quantum
+// (a silent quantum is mono); count-sensitive nodes (filters with per-channel state, the panners' mono / stereo laws,
+// the delay line's re-mix, the convolver's routing) render differently depending on it.  When the planner's replay
+// finds such a change, every node that is not a source or a convolver is rendered by dyn_kernel: one wavefront per
+// instance walks the render quanta in order, processes the items (nodes) in the reference's processing order and
+// carries, next to every signal, a per-quantum CODE = channel count | CODE_SILENT.  Signals are published to HBM in
+// their native layout (the first `count` channels) together with their code table, so that later launches (a
+// second dyn group behind a convolver) consume them with the same rules.
+constexpr int DYN_MAX_IN = 8;
+constexpr int DYN_MAX_ITEMS = 48;
+constexpr int DYN_STATE = 20;             // doubles of filter state per channel (biquad 4, IIR <= 20)
+constexpr uint32_t CODE_SILENT = 0x80u;   // quantum.rs:254-256 is_silent; low bits = number_of_channels
+enum : int32_t { DI_NODE = 0, DI_DELAY_W = 1, DI_DELAY_R = 2 };
+enum : int32_t {
+  DK_PASS = 0,        // destination / analyser / convolver or waveshaper without payload: output = input
+  DK_GAIN = 1, DK_BIQUAD = 2, DK_IIR = 3, DK_WAVESHAPER = 4, DK_STEREO_PAN = 5, DK_PANNER = 6,
+  DK_CONV_IN = 7      // the mixed input of a ConvolverNode with an impulse response (rendered node-major)
+};
+struct DynInput {
+  int32_t item;             // >= 0: output of that item of this launch (same quantum, through LDS); -1: external
+  int32_t nch;              // external: static width of the signal
+  SignalRef sig;            // external
+  const uint8_t* code;      // external: [n_inst][code_stride] per-quantum codes; null: always active, `nch` channels
+  const uint32_t* remap;    // external: channel 1 of quantum q lives in quantum slot remap[inst][q] (mono-IR convolver)
+  uint64_t code_stride;
+};
+struct DynItem {
+  int32_t kind;             // DI_*
+  int32_t dk;               // DK_* (DI_NODE)
+  int32_t cc, mode, interp; // channel config: computed number of channels of the mixed input (quantum.rs:543-547)
+  int32_t n_in;
+  int32_t nch_pub;          // static width of the published signal
+  int32_t publish_upmix;    // published mono quanta are duplicated into channel 1 (consumers outside dyn_kernel)
+  int32_t compact_ch1;      // DK_CONV_IN with a mono impulse response: channel 1 is published in compacted time
+  int32_t flags;            // DK_WAVESHAPER: bit 0 = can_propagate_silence (waveshaper.rs:498-509)
+  int32_t writer_item;      // DI_DELAY_R
+  int32_t in_cycle;         // DI_DELAY_R: renders before its writer (delay clamped to one quantum, delay.rs:693-701)
+  int32_t num_quanta;       // DI_DELAY_R: ring capacity - 1
+  int32_t pad;
+  DynInput in[DYN_MAX_IN];
+  OpDesc op;                // coefficients / params of the node (same meaning as in ChainDesc)
+  ParamRef alt1, alt2;      // DK_STEREO_PAN / DK_PANNER: left / right gain of the MONO law (op.p1 / op.p2: stereo law)
+  SignalRef out;            // published signal (DI_DELAY_W: the delay line, absolute time)
+  uint8_t* out_code;        // [n_inst][code_stride]
+  uint32_t* aux32;          // DI_DELAY_W: line codes as 32-bit words (read back by the reader of the same launch);
+                            // DK_CONV_IN + compact_ch1: remap table [n_inst][code_stride]
+  uint64_t code_stride;
+};
+struct DynDesc {
+  const DynItem* items;     // device memory
+  int32_t n_items;
+  uint32_t n_inst;
+  uint32_t n_quanta;
+  uint32_t pad;
+  double sample_rate;
+  double quantum_duration;
+};
+void launch_dyn(const DynDesc& d, void* stream);
+// ConvolverNode tail / routing on codes (convolver.rs:343-392): input codes -> output codes
+struct ConvCodeDesc {
+  const uint8_t* in_code;
+  uint8_t* out_code;
+  uint64_t code_stride;
+  uint64_t impulse_length;  // frames of the AudioBuffer (untrimmed), convolver.rs:357-366
+  int32_t ir_nch;
+  uint32_t n_inst, n_quanta;
+  int32_t pad;
+};
+void launch_conv_codes(const ConvCodeDesc& d, void* stream);
+
 // ---- per-frame biquad coefficients for a-rate params (biquad_filter.rs:837-855) -------------
 struct BiquadCoefDesc {
   ParamRef frequency, detune, q, gain;
