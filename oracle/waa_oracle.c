@@ -1104,6 +1104,7 @@ struct orc_batch {
   int rendered;
   int n_threads;
   int exact_conv;
+  unsigned char* dbg_codes; /* [n_inst][n_nodes][n_quanta], ORC_DUMP_CODES only */
 };
 typedef struct orc_batch orc_batch;
 
@@ -1535,6 +1536,7 @@ void orc_batch_destroy(orc_batch* b) {
   free(b->edges);
   free(b->order);
   free(b->out);
+  free(b->dbg_codes);
   free(b);
 }
 
@@ -3141,6 +3143,8 @@ static void render_instance(orc_batch* b, uint32_t inst) {
       } else {
         process_node(b, id, inst, &sc);
       }
+      if (b->dbg_codes) /* debugging aid (ORC_DUMP_CODES): number_of_channels | 0x80 if silent, per node and quantum */
+        b->dbg_codes[((size_t)inst * b->n_nodes + id) * num_quanta + q] = (unsigned char)(s->out.n | (q_is_silent(&s->out) ? 0x80 : 0));
       for (uint32_t e = 0; e < b->n_edges; e++) {
         if (b->edges[e].from != id) continue;
         NodeCfg* dn = &b->nodes[b->edges[e].to];
@@ -3208,6 +3212,13 @@ waa_status orc_render(orc_batch* b) {
     if (b->nodes[i].desc.kind == WAA_NODE_IIR_FILTER && b->nodes[i].iir_len == 0)
       return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIRFilterNode %u has no coefficients", i);
   b->rendered = 1;
+  const char* dump = getenv("ORC_DUMP_CODES");
+  uint64_t dbg_nq = (b->length + RQ - 1) / RQ;
+  if (dump) {
+    free(b->dbg_codes);
+    b->dbg_codes = (unsigned char*)malloc((size_t)b->n_inst * b->n_nodes * (dbg_nq ? dbg_nq : 1));
+    memset(b->dbg_codes, 0xFF, (size_t)b->n_inst * b->n_nodes * (dbg_nq ? dbg_nq : 1));
+  }
   int nt = b->n_threads;
   if ((uint32_t)nt > b->n_inst) nt = (int)b->n_inst;
   if (nt <= 1) {
@@ -3225,6 +3236,15 @@ waa_status orc_render(orc_batch* b) {
     for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
     free(th);
     free(w);
+  }
+  if (dump && b->dbg_codes) {
+    FILE* f = fopen(dump, "wb");
+    if (f) {
+      uint32_t hdr[3] = {b->n_inst, b->n_nodes, (uint32_t)dbg_nq};
+      fwrite(hdr, sizeof hdr, 1, f);
+      fwrite(b->dbg_codes, 1, (size_t)b->n_inst * b->n_nodes * dbg_nq, f);
+      fclose(f);
+    }
   }
   return WAA_OK;
 }

@@ -658,10 +658,33 @@ static int drain_profile(waa_batch* b) {
   return 0;
 }
 
+// Debugging aid of the dynamic-count path (WAA_DUMP_CODES=<file>): the per-quantum codes (count | 0x80 if silent) of every
+// node's published signal, [n_inst][n_nodes][n_quanta] behind a 3-word header; 0xFF where a node has no code table.
+static int dump_codes(waa_batch* b) {
+  const char* path = getenv("WAA_DUMP_CODES");
+  if (!path || !b->dynamic) return 0;
+  const uint32_t N = (uint32_t)b->nodes.size(), nq = b->n_quanta;
+  std::vector<uint8_t> all((size_t)b->n_inst * N * nq, 0xFF), tab((size_t)b->n_inst * b->code_stride);
+  for (uint32_t id = 0; id < N; id++) {
+    if (!b->nodes[id].code) continue;
+    HIP_TRY(hipMemcpy(tab.data(), b->nodes[id].code, tab.size(), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < b->n_inst; i++)
+      std::memcpy(&all[((size_t)i * N + id) * nq], &tab[(size_t)i * b->code_stride], nq);
+  }
+  if (FILE* f = fopen(path, "wb")) {
+    const uint32_t hdr[3] = {b->n_inst, N, nq};
+    fwrite(hdr, sizeof hdr, 1, f);
+    fwrite(all.data(), 1, all.size(), f);
+    fclose(f);
+  }
+  return 0;
+}
+
 waa_status waa_sync(waa_batch* b) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
   if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch has no device");
   HIP_TRY(hipStreamSynchronize(b->stream));
+  if (int e = dump_codes(b)) return e;
   return drain_profile(b);
 }
 

@@ -221,6 +221,7 @@ struct waa_batch {
   std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render
   std::vector<Step> steps;
   bool planned = false;
+  bool force_dynamic = false;        // second planning pass: a loop member the static loop kernel cannot render
   bool dynamic = false;              // the plan renders the reference's dynamic channel counts (dyn_kernel)
   uint64_t code_stride = 0;          // bytes per instance of a code table (n_quanta rounded up)
   bool rendered = false;

@@ -1150,7 +1150,9 @@ int build_plan(waa_batch* b) {
   // other live node becomes an item of a quantum-serial dyn_kernel launch that carries per-quantum codes
   // (count | silent) with every signal.  A convolver splits the items into groups (its input is produced by the
   // group in front of it, its output consumed by the group behind it).
-  if (count_change_found) {
+  if (count_change_found || b->force_dynamic) {
+    if (!count_change_found)
+      plan_note(b, "a feedback loop needs quantum-serial rendering with node kinds the loop kernel does not cover -> dyn_kernel");
     b->dynamic = true;
     b->code_stride = ((uint64_t)b->n_quanta + 15) & ~(uint64_t)15;
     const uint64_t cs = b->code_stride;
@@ -1405,6 +1407,12 @@ int build_plan(waa_batch* b) {
       bool any_live = false;
       for (uint32_t v : verts) any_live |= b->nodes[v & ~VTX_READER].live;
       if (!any_live) continue;
+      if (unit.scc >= 0)
+        for (uint32_t v : verts) {
+          const Node& m = b->nodes[v & ~VTX_READER];
+          if (m.desc.kind == WAA_NODE_CONVOLVER && m.has_ir)
+            return fail(WAA_ERR_OUT_OF_SCOPE, "a ConvolverNode inside a feedback loop is out of scope (node %u)", v & ~VTX_READER);
+        }
       // AudioParam inputs are summed by a node-major chain in front of the group: their producers must be complete
       bool param_dep = false;
       for (uint32_t v : verts)
@@ -1492,6 +1500,21 @@ int build_plan(waa_batch* b) {
       const uint32_t bt = loop_block_tiles(b, loop_items);
       if (bt == 0) {  // short or modulated loop delay: quantum-serial loop kernel
         int e = plan_loop(b, loop_items);
+        if (e == WAA_ERR_OUT_OF_SCOPE && !b->force_dynamic && !getenv("WAA_STATIC_CHANNEL_COUNTS")) {
+          // the static loop kernel covers Gain / Biquad / WaveShaper / k-rate StereoPanner / Delay members only; the
+          // dynamic-count kernel renders every node kind quantum by quantum (waa_dyn.hip): plan the graph again with it
+          b->force_dynamic = true;
+          b->steps.clear();
+          b->group_tiles.clear();
+          b->state_bufs.clear();
+          b->plan_log.clear();
+          for (auto& nd : b->nodes) {
+            nd.sig = SignalRef{};
+            nd.hist = SignalRef{};
+            nd.hist_is_temp = false;
+          }
+          return build_plan(b);
+        }
         if (e) return e;
         continue;
       }
@@ -2131,6 +2154,8 @@ int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items) {
       for (int j = 0; j < li.n_in; j++) {
         const uint32_t pid = b->edges[n.in_edges[j]].from;
         Node& pn = b->nodes[pid];
+        if (pn.out_nch > 2)  // (the loop kernel loads and mixes mono / stereo inputs only)
+          return fail(WAA_ERR_OUT_OF_SCOPE, "feedback loops render at most 2 channels per signal (input %u of node %u)", pid, id);
         li.in_nch[j] = pn.out_nch;
         auto it = out_item.find(pid);
         if (it != out_item.end()) {
