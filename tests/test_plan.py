@@ -102,7 +102,8 @@ def test_automated_biquads(hip):
     assert "biquad_stream(k-rate) in=source:2ch gains=1 out=final" in plan(ctx)  # per-quantum coefficients: streaming too
     ctx, nodes = c2(hip, noise, device=waa.PLAN_ONLY)
     nodes["biquad"].frequency.set_value_at_time(10.0, 0.0).exponential_ramp_to_value_at_time(10000.0, 0.05)
-    assert any("chain serial C=2" in l and "BIQUAD(a-rate)" in l for l in plan(ctx))  # per-frame: serial interpreter
+    # per-frame coefficients (a-rate automation, the same for every instance): one shared lane-major table + streaming
+    assert "biquad_stream(a-rate, shared table) in=source:2ch gains=1 out=final" in plan(ctx)
 
 
 def test_fan_in_above_four_inputs_is_reduced_in_order(hip):

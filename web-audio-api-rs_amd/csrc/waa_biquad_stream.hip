@@ -40,9 +40,14 @@ __device__ __forceinline__ M2 mm(const M2& x, const M2& y) {
 
 // DBG is a measurement aid (WAA_STREAM_DEBUG): 0 = product kernel, 1 = same memory pattern without the recurrence,
 // 2 = recurrence without the stores (results are wrong by construction in modes 1 and 2)
-// VARY: coefficients change per render quantum (k-rate automation; d.coefs holds n_quanta sets per instance):
+// VARY = 1: coefficients change per render quantum (k-rate automation; d.coefs holds n_quanta sets per instance):
 // per-lane coefficients (4 lanes share a quantum), per-lane A = M^32, general scan of the affine maps.
-template <int DBG, bool VARY>
+// VARY = 2: coefficients change per FRAME (a-rate params, biquad_filter.rs:837-855).  The table of biquad_coef_kernel is
+// lane-major — element (tile, k, coef, lane) — so step k of all 64 lanes reads 64 consecutive doubles.  A lane streams
+// its 32 coefficient sets twice (zero-state pass with the transition product P = M_31 ... M_0, then the exact-order
+// pass from the true incoming state) instead of holding 160 doubles in registers; the table is one per batch when the
+// automation is the same for every instance (then it lives in L2 / Infinity Cache and HBM only carries the samples).
+template <int DBG, int VARY, int NBUF = 2>
 __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStreamDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const uint32_t wid = blockIdx.x;
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
   const M2 A2 = mm(A1, A1), A4 = mm(A2, A2), A8 = mm(A4, A4), A16 = mm(A8, A8);
   // per-lane A^(lane % 16)
   M2 Aj = {1., 0., 0., 1.};
-  if constexpr (!VARY) {
+  if constexpr (VARY == 0) {
     const int j = lane & 15;
     if (j & 1) Aj = mm(Aj, A1);
     if (j & 2) Aj = mm(Aj, A2);
@@ -169,6 +174,183 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
     }
     lds_sync();
   };
+  // ---- a-rate params: per-frame coefficient sets streamed from the lane-major table, two sweeps per tile
+  auto process_arate = [&](uint32_t tile) __attribute__((always_inline)) {
+    lds_sync();
+    const float* xrow = lds + lane * LDS_ROW;     // this lane's 32 frames (T layout), stable during the tile
+    float* yrow = lds_out + lane * LDS_ROW;
+    const double* ct = cp + (uint64_t)tile * (TILE_K * 5 * 64) + lane;  // element (k, coef) at ct[(k * 5 + coef) * 64]
+    auto load_chunk = [&](double (&c)[20], int chunk) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 20; j++) c[j] = load_global(ct + (chunk * 20 + j) * 64);
+    };
+    // x history at the chunk boundary
+    const float xl1 = xrow[TILE_K - 1], xl2 = xrow[TILE_K - 2];
+    const float xm1 = __shfl_up(xl1, 1, 64), xm2 = __shfl_up(xl2, 1, 64);
+    const double xs1 = lane == 0 ? cx1 : (double)xm1, xs2 = lane == 0 ? cx2 : (double)xm2;
+    // sweep 1: zero-state response of the chunk and its transition P = M_31 ... M_0, M_i = [[-a1, -a2], [1, 0]]
+    double x1 = xs1, x2 = xs2, z1 = 0., z2 = 0.;
+    M2 P = {1., 0., 0., 1.};
+    double ca[20], cb[20], cc[NBUF == 3 ? 20 : 1];
+    if constexpr (VARY == 3) {
+      // shared table: the end state is a 34-tap dot product with the digest of biquad_hp_kernel (BiquadHpDesc)
+      const double* hp = d.hp + (uint64_t)tile * (HP_WORDS * 64) + lane;
+      load_chunk(ca, 0);  // sweep 2's first coefficient sets are requested before the dot product starts
+      load_chunk(cb, 1);
+      double za = load_global(hp + 64 * 64) * xs1, zb = load_global(hp + 65 * 64) * xs1;
+      double zc = load_global(hp + 66 * 64) * xs2, zd = load_global(hp + 67 * 64) * xs2;
+#pragma unroll 2
+      for (int chunk = 0; chunk < TILE_K / 4; chunk++) {
+        const float4 xv = *reinterpret_cast<const float4*>(xrow + chunk * 4);
+        const double* hc = hp + chunk * 8 * 64;
+        const double h0 = load_global(hc), h1 = load_global(hc + 64), h2 = load_global(hc + 128), h3 = load_global(hc + 192),
+                     h4 = load_global(hc + 256), h5 = load_global(hc + 320), h6 = load_global(hc + 384), h7 = load_global(hc + 448);
+        za = __builtin_fma(h0, (double)xv.x, za);
+        zb = __builtin_fma(h1, (double)xv.x, zb);
+        zc = __builtin_fma(h2, (double)xv.y, zc);
+        zd = __builtin_fma(h3, (double)xv.y, zd);
+        za = __builtin_fma(h4, (double)xv.z, za);
+        zb = __builtin_fma(h5, (double)xv.z, zb);
+        zc = __builtin_fma(h6, (double)xv.w, zc);
+        zd = __builtin_fma(h7, (double)xv.w, zd);
+      }
+      z1 = za + zc;
+      z2 = zb + zd;
+      P.a = load_global(hp + 68 * 64);
+      P.b = load_global(hp + 69 * 64);
+      P.c = load_global(hp + 70 * 64);
+      P.d = load_global(hp + 71 * 64);
+    }
+    auto step_a = [&](const double (&c)[20], int chunk) __attribute__((always_inline)) {
+      const float4 xv = *reinterpret_cast<const float4*>(xrow + chunk * 4);
+      const float xf[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const double cb0 = c[j * 5], cb1 = c[j * 5 + 1], cb2 = c[j * 5 + 2], ca1 = c[j * 5 + 3], ca2 = c[j * 5 + 4];
+        const double xd = (double)xf[j];
+        const double wi = (cb0 * xd + cb1 * x1) + cb2 * x2;
+        x2 = x1;
+        x1 = xd;
+        const double t = __builtin_fma(-ca2, z2, wi);
+        const double y = __builtin_fma(-ca1, z1, t);
+        z2 = z1;
+        z1 = y;
+        const double na = __builtin_fma(-ca1, P.a, -(ca2 * P.c)), nb = __builtin_fma(-ca1, P.b, -(ca2 * P.d));
+        P.c = P.a;
+        P.d = P.b;
+        P.a = na;
+        P.b = nb;
+      }
+    };
+    {
+      if constexpr (VARY == 2) {
+        load_chunk(ca, 0);
+#pragma unroll 1
+        for (int chunk = 0; chunk < TILE_K / 4; chunk += 2) {
+          load_chunk(cb, chunk + 1);
+          step_a(ca, chunk);
+          load_chunk(ca, chunk + 2 < TILE_K / 4 ? chunk + 2 : 0);  // (the last one is the prefetch of sweep 2)
+          step_a(cb, chunk + 1);
+        }
+        load_chunk(cb, 1);
+      }
+      // inclusive in-row scan of the composed maps (P, r), row carries, exclusive composite: as in the k-rate path
+      double r1 = z1, r2 = z2;
+      auto step = [&](auto shr) __attribute__((always_inline)) {
+        M2 Q;
+        Q.a = shr(P.a, 1.);
+        Q.b = shr(P.b, 0.);
+        Q.c = shr(P.c, 0.);
+        Q.d = shr(P.d, 1.);
+        const double q1 = shr(r1, 0.), q2 = shr(r2, 0.);
+        r1 = __builtin_fma(P.a, q1, __builtin_fma(P.b, q2, r1));
+        r2 = __builtin_fma(P.c, q1, __builtin_fma(P.d, q2, r2));
+        P = mm(P, Q);
+      };
+      step([](double v, double idv) __attribute__((always_inline)) { return row_shr_keep<1>(v, idv); });
+      step([](double v, double idv) __attribute__((always_inline)) { return row_shr_keep<2>(v, idv); });
+      step([](double v, double idv) __attribute__((always_inline)) { return row_shr_keep<4>(v, idv); });
+      step([](double v, double idv) __attribute__((always_inline)) { return row_shr_keep<8>(v, idv); });
+      double t1[4], t2[4];
+      t1[0] = cy1;
+      t2[0] = cy2;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int e = 16 * k + 15;
+        const double pa = read_lane(P.a, e), pb = read_lane(P.b, e), pc = read_lane(P.c, e), pd = read_lane(P.d, e);
+        const double e1 = read_lane(r1, e), e2 = read_lane(r2, e);
+        t1[k + 1] = __builtin_fma(pa, t1[k], __builtin_fma(pb, t2[k], e1));
+        t2[k + 1] = __builtin_fma(pc, t1[k], __builtin_fma(pd, t2[k], e2));
+      }
+      const double T1 = row == 0 ? t1[0] : row == 1 ? t1[1] : row == 2 ? t1[2] : t1[3];
+      const double T2 = row == 0 ? t2[0] : row == 1 ? t2[1] : row == 2 ? t2[2] : t2[3];
+      const double xa = row_shr_keep<1>(P.a, 1.), xb = row_shr_keep<1>(P.b, 0.), xc = row_shr_keep<1>(P.c, 0.),
+                   xd = row_shr_keep<1>(P.d, 1.);
+      const double x1r = row_shr_keep<1>(r1, 0.), x2r = row_shr_keep<1>(r2, 0.);
+      const double s1 = __builtin_fma(xa, T1, __builtin_fma(xb, T2, x1r));
+      const double s2 = __builtin_fma(xc, T1, __builtin_fma(xd, T2, x2r));
+      // sweep 2: the reference's evaluation order from the true incoming state (biquad_filter.rs:877-883)
+      double y1 = s1, y2 = s2;
+      float badacc = 0.f;
+      auto sweep = [&](bool flush_bad) __attribute__((always_inline)) {
+        double p1 = xs1, p2 = xs2;
+        auto step_b = [&](const double (&c)[20], int chunk) __attribute__((always_inline)) {
+          const float4 xv = *reinterpret_cast<const float4*>(xrow + chunk * 4);
+          const float xf[4] = {xv.x, xv.y, xv.z, xv.w};
+          float yo[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const double xd2 = (double)xf[j];
+            const double wi = (c[j * 5] * xd2 + c[j * 5 + 1] * p1) + c[j * 5 + 2] * p2;
+            p2 = p1;
+            p1 = xd2;
+            double y = (wi - c[j * 5 + 3] * y1) - c[j * 5 + 4] * y2;
+            if (flush_bad && !__builtin_isnormal(y)) y = 0.;
+            y2 = y1;
+            y1 = y;
+            yo[j] = (float)y;
+            badacc = __builtin_fmaf(yo[j], 0.f, badacc);
+          }
+          *reinterpret_cast<float4*>(yrow + chunk * 4) = make_float4(yo[0], yo[1], yo[2], yo[3]);
+        };
+        if constexpr (NBUF == 3) {
+          // three rotating buffers: a coefficient set is requested two chunks (8 frames of recurrence) before its use
+#pragma unroll 1
+          for (int chunk = 0; chunk < 6; chunk += 3) {
+            load_chunk(cc, chunk + 2);
+            step_b(ca, chunk);
+            load_chunk(ca, chunk + 3);
+            step_b(cb, chunk + 1);
+            load_chunk(cb, chunk + 4);
+            step_b(cc, chunk + 2);
+          }
+          step_b(ca, 6);
+          step_b(cb, 7);
+        } else {
+#pragma unroll 1
+          for (int chunk = 0; chunk < TILE_K / 4; chunk += 2) {
+            step_b(ca, chunk);
+            if (chunk + 2 < TILE_K / 4) load_chunk(ca, chunk + 2);
+            step_b(cb, chunk + 1);
+            if (chunk + 3 < TILE_K / 4) load_chunk(cb, chunk + 3);
+          }
+        }
+      };
+      sweep(false);
+      if (__any(badacc != badacc)) {  // inf / NaN somewhere: redo with the explicit flush
+        y1 = __builtin_isfinite(s1) ? s1 : 0.;
+        y2 = __builtin_isfinite(s2) ? s2 : 0.;
+        load_chunk(ca, 0);
+        load_chunk(cb, 1);
+        sweep(true);
+      }
+      cx1 = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xl1), 63));
+      cx2 = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xl2), 63));
+      cy1 = read_lane(y1, 63);
+      cy2 = read_lane(y2, 63);
+    }
+    lds_sync();
+  };
   auto process = [&](uint32_t tile) __attribute__((always_inline)) {
     lds_sync();
     float x[TILE_K];
@@ -190,7 +372,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
       return;
     }
     M2 Al = A1;  // this lane's 32-step transition
-    if constexpr (VARY) {
+    if constexpr (VARY == 1) {
       uint32_t q = tile * QUANTA_PER_TILE + (lane >> 2);
       if (q >= d.n_quanta) q = d.n_quanta - 1;
       const double* cq = cp + (uint64_t)q * 5;
@@ -223,7 +405,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
       z1 = y;
     }
     double s1, s2;  // state entering this lane's chunk
-    if constexpr (!VARY) {
+    if constexpr (VARY == 0) {
       // in-row inclusive scan (rows of 16 lanes): R_l = sum_{i in row, i<=l} A^(l-i) z_i
       double r1 = z1, r2 = z2;
       {
@@ -360,7 +542,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
       for (int i = 0; i < TILE_K; i++) cur[i] = tmp[i];
       stage(cur);
       if (pending) flush(pending_tile);
-      process(tile);
+      if constexpr (VARY >= 2) process_arate(tile); else process(tile);
       pending = true;
       pending_tile = tile;
       tile++;
@@ -375,7 +557,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
       stage(nx);
       fetch_fast(tile + 1 < end ? tile + 1 : tile, nx);  // clamped: the last iteration re-reads its own tile (L2 hit)
       if (pending) flush(pending_tile);
-      process(tile);
+      if constexpr (VARY >= 2) process_arate(tile); else process(tile);
       pending = true;
       pending_tile = tile;
     }
@@ -393,14 +575,20 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
   const dim3 grid(d.n_inst * (uint32_t)d.nch), block(64);
   const size_t lds = 2 * 64 * LDS_ROW * sizeof(float);
   const char* dbg = getenv("WAA_STREAM_DEBUG");  // measurement aid only, see profiles/r01_c2_memory_pattern.txt
-  if (d.vary)
-    hipLaunchKernelGGL((biquad_stream_kernel_t<0, true>), grid, block, lds, (hipStream_t)stream, d);
+  if (d.vary == 3 && getenv("WAA_ARATE_BUFS3"))  // experiment: deeper coefficient prefetch (spills a few registers)
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 3, 3>), grid, block, lds, (hipStream_t)stream, d);
+  else if (d.vary == 3)
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 3>), grid, block, lds, (hipStream_t)stream, d);
+  else if (d.vary == 2)
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 2>), grid, block, lds, (hipStream_t)stream, d);
+  else if (d.vary)
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 1>), grid, block, lds, (hipStream_t)stream, d);
   else if (dbg && dbg[0] == '1')
-    hipLaunchKernelGGL((biquad_stream_kernel_t<1, false>), grid, block, lds, (hipStream_t)stream, d);
+    hipLaunchKernelGGL((biquad_stream_kernel_t<1, 0>), grid, block, lds, (hipStream_t)stream, d);
   else if (dbg && dbg[0] == '2')
-    hipLaunchKernelGGL((biquad_stream_kernel_t<2, false>), grid, block, lds, (hipStream_t)stream, d);
+    hipLaunchKernelGGL((biquad_stream_kernel_t<2, 0>), grid, block, lds, (hipStream_t)stream, d);
   else
-    hipLaunchKernelGGL((biquad_stream_kernel_t<0, false>), grid, block, lds, (hipStream_t)stream, d);
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0>), grid, block, lds, (hipStream_t)stream, d);
 }
 
 }  // namespace waa

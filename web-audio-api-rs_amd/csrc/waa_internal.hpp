@@ -135,11 +135,14 @@ struct ChainDesc {
 // -> up to 2 k-rate-constant gains -> output; one wavefront per (instance, channel).
 struct BiquadStreamDesc {
   InputRef in;
-  const double* coefs;   // [n_inst][coef_stride]: 5 per instance, or 5 per (instance, quantum) when vary
+  const double* coefs;   // [n_inst][coef_stride]: 5 per instance, 5 per (instance, quantum) when vary == 1, the lane-major
+                         // per-frame table of biquad_coef_kernel when vary == 2 (coef_stride 0: one table for all instances)
   uint64_t coef_stride;  // doubles per instance
-  int32_t vary;          // 1: per-quantum coefficients (k-rate automation)
+  int32_t vary;          // 1: per-quantum coefficients (k-rate automation); 2: per-frame coefficients (a-rate params);
+                         // 3: per-frame coefficients shared by all instances, with the precomputed `hp` table
   int32_t pad0;
   double* state;         // [n_inst][STATE_STRIDE]
+  const double* hp;      // vary == 3: [n_tiles][HP_WORDS][64], see BiquadHpDesc
   ParamRef gain[2];      // mode 0 only
   int32_t n_gain;
   int32_t nch;
@@ -373,14 +376,29 @@ void launch_conv_codes(const ConvCodeDesc& d, void* stream);
 // ---- per-frame biquad coefficients for a-rate params (biquad_filter.rs:837-855) -------------
 struct BiquadCoefDesc {
   ParamRef frequency, detune, q, gain;
-  double* coefs;        // [n_inst][n_frames][5]
-  uint64_t n_frames;    // n_quanta * 128
-  uint32_t n_inst;
+  double* coefs;        // frame-major [rows][frames_padded][5], or lane-major [rows][n_tiles][32][5][64] (streaming kernel)
+  uint64_t n_frames;    // n_quanta * 128 (params are read clamped to it)
+  uint64_t frames_padded;  // n_tiles * 2048: frames of one table row
+  uint32_t rows;        // n_inst, or 1 when the four params are the same for every instance (one shared table)
   int32_t type;
   float sample_rate;
-  int32_t pad;
+  int32_t lane_major;   // element (tile, k, coef, lane) of frame tile * 2048 + lane * 32 + k
 };
 void launch_biquad_coefs(const BiquadCoefDesc& d, void* stream);
+// A per-frame coefficient table that is the same for every instance is digested once per plan: for the 32 frames a
+// lane of the streaming kernel owns in a tile, the zero-state end state is LINEAR in the lane's samples,
+//   (y_31, y_30) = sum_i H_i x_i + Hm1 x_{-1} + Hm2 x_{-2},   H_i = G_i b0_i + G_{i+1} b1_{i+1} + G_{i+2} b2_{i+2},
+// G_i = first column of M_31 ... M_{i+1}, and the transition is P = M_31 ... M_0 (M_i = [[-a1_i, -a2_i], [1, 0]]).
+// The streaming kernel then forms every lane's end state as a 34-tap dot product (no dependent chain, 16 B per frame
+// instead of 40 B) before the exact-order pass.  hp[tile][e][lane]: e = 2i, 2i+1: H_i; 64, 65: Hm1; 66, 67: Hm2; 68..71: P.
+constexpr int HP_WORDS = 72;
+struct BiquadHpDesc {
+  const double* coefs;  // lane-major per-frame table, one row
+  double* hp;
+  uint32_t n_tiles;
+  uint32_t pad;
+};
+void launch_biquad_hp(const BiquadHpDesc& d, void* stream);
 
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);

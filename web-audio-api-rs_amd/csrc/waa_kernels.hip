@@ -874,9 +874,19 @@ __device__ __forceinline__ void raw_coefs(double b0, double* o) {
 }
 __global__ __launch_bounds__(256) void biquad_coef_kernel(const BiquadCoefDesc d) {
   const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (uint64_t)d.n_inst * d.n_frames) return;
-  const uint32_t inst = (uint32_t)(idx / d.n_frames);
-  const uint64_t frame = idx % d.n_frames;
+  if (idx >= (uint64_t)d.rows * d.frames_padded) return;
+  const uint32_t inst = (uint32_t)(idx / d.frames_padded);
+  const uint64_t r = idx % d.frames_padded;
+  uint64_t frame = r, slot = r * 5, cstep = 1;
+  if (d.lane_major) {
+    // a wave covers the 64 lanes of one (tile, k): the streaming kernel's lane l owns frames tile*2048 + l*32 + k, and
+    // its loads of coefficient c for step k are 64 consecutive doubles
+    const uint64_t tile = r / TILE, in = r % TILE, k = in / 64, lane = in % 64;
+    frame = tile * TILE + lane * TILE_K + k;
+    slot = ((tile * TILE_K + k) * 5) * 64 + lane;
+    cstep = 64;
+  }
+  if (frame >= d.n_frames) frame = d.n_frames - 1;  // padded tail of the last tile: any finite set will do
   const uint32_t q = (uint32_t)(frame / RQ);
   const float freq = param_at(d.frequency, inst, q, frame), det = param_at(d.detune, inst, q, frame);
   const double Q = (double)param_at(d.q, inst, q, frame), gain = (double)param_at(d.gain, inst, q, frame);
@@ -885,7 +895,7 @@ __global__ __launch_bounds__(256) void biquad_coef_kernel(const BiquadCoefDesc d
   const double nyq = (double)d.sample_rate / 2.;
   double f = (double)cf / nyq;
   f = f < 0. ? 0. : f > 1. ? 1. : f;
-  double* o = d.coefs + idx * 5;
+  double o[5];
   const double A = pow(10., gain / 40.);
   const double w0 = PI * f, sw = sin(w0), cw = cos(w0);
   switch (d.type) {
@@ -947,10 +957,58 @@ __global__ __launch_bounds__(256) void biquad_coef_kernel(const BiquadCoefDesc d
       break;
     }
   }
+  double* out = d.coefs + (uint64_t)inst * d.frames_padded * 5 + slot;
+#pragma unroll
+  for (int c = 0; c < 5; c++) out[(uint64_t)c * cstep] = o[c];
 }
 void launch_biquad_coefs(const BiquadCoefDesc& d, void* stream) {
-  const uint64_t total = (uint64_t)d.n_inst * d.n_frames;
+  const uint64_t total = (uint64_t)d.rows * d.frames_padded;
   hipLaunchKernelGGL(biquad_coef_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d);
+}
+
+// digest of a shared per-frame coefficient table (see BiquadHpDesc): one thread per (tile, lane), 32 frames backwards
+__global__ __launch_bounds__(64) void biquad_hp_kernel(const BiquadHpDesc d) {
+  const uint32_t tile = blockIdx.x;
+  const int lane = threadIdx.x;
+  const double* ct = d.coefs + (uint64_t)tile * (TILE_K * 5 * 64) + lane;  // element (k, coef) at ct[(k * 5 + coef) * 64]
+  double* out = d.hp + (uint64_t)tile * (HP_WORDS * 64) + lane;
+  // Phi_i = M_31 ... M_{i+1}; G_i = its first column; Phi_{i-1} = Phi_i M_i with M_i = [[-a1, -a2], [1, 0]]
+  double pa = 1., pb = 0., pc = 0., pd = 1.;
+  double g1a = 0., g1c = 0., g2a = 0., g2c = 0.;  // G_{i+1}, G_{i+2}
+  double b1n = 0., b2n = 0., b2nn = 0.;           // b1_{i+1}, b2_{i+1}, b2_{i+2}
+  for (int i = TILE_K - 1; i >= 0; i--) {
+    const double b0 = ct[(i * 5 + 0) * 64], b1 = ct[(i * 5 + 1) * 64], b2 = ct[(i * 5 + 2) * 64], a1 = ct[(i * 5 + 3) * 64],
+                 a2 = ct[(i * 5 + 4) * 64];
+    // H_i = G_i b0_i + G_{i+1} b1_{i+1} + G_{i+2} b2_{i+2}
+    out[(2 * i) * 64] = pa * b0 + g1a * b1n + g2a * b2nn;
+    out[(2 * i + 1) * 64] = pc * b0 + g1c * b1n + g2c * b2nn;
+    if (i == 0) {
+      out[64 * 64] = pa * b1 + g1a * b2n;  // Hm1 = G_0 b1_0 + G_1 b2_1
+      out[65 * 64] = pc * b1 + g1c * b2n;
+      out[66 * 64] = pa * b2;              // Hm2 = G_0 b2_0
+      out[67 * 64] = pc * b2;
+    }
+    g2a = g1a;
+    g2c = g1c;
+    g1a = pa;
+    g1c = pc;
+    b2nn = b2n;
+    b1n = b1;
+    b2n = b2;
+    // Phi <- Phi M_i: columns (a, c | b, d): new first column = -a1 * col1 + col2, new second column = -a2 * col1
+    const double na = __builtin_fma(-a1, pa, pb), nc = __builtin_fma(-a1, pc, pd);
+    pb = -a2 * pa;
+    pd = -a2 * pc;
+    pa = na;
+    pc = nc;
+  }
+  out[68 * 64] = pa;
+  out[69 * 64] = pb;
+  out[70 * 64] = pc;
+  out[71 * 64] = pd;
+}
+void launch_biquad_hp(const BiquadHpDesc& d, void* stream) {
+  hipLaunchKernelGGL(biquad_hp_kernel, dim3(d.n_tiles), dim3(64), 0, (hipStream_t)stream, d);
 }
 
 void launch_chain(const ChainDesc& d, int cmax, void* stream) {

@@ -291,7 +291,8 @@ int temp_signal(waa_batch* b, int nch, SignalRef* out) {
 int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in_interp, const std::vector<OpDesc>& ops,
                   const SignalRef& out) {
   bool any_stream = false;
-  const int max_mode = getenv("WAA_NO_KRATE_STREAM") ? 0 : 1;  // debugging aid: force k-rate biquads onto the interpreter
+  // debugging aids: force k-rate / a-rate biquads onto the serial interpreter
+  const int max_mode = getenv("WAA_NO_KRATE_STREAM") ? 0 : (getenv("WAA_NO_ARATE_STREAM") ? 1 : 2);
   auto streams = [&](const OpDesc& o) { return o.kind == OP_IIR || (o.kind == OP_BIQUAD && o.i0 <= max_mode && o.nch_in <= 2); };
   for (auto& o : ops) any_stream |= streams(o);
   if (!any_stream) return push_chain_step(b, inputs, in_nch, in_interp, ops, out);
@@ -380,7 +381,24 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     q.in = inputs[0];
     q.coefs = reinterpret_cast<const double*>(o.ptr0);
     q.coef_stride = o.u0;
-    q.vary = o.i0 == 1;
+    q.vary = o.i0;
+    if (o.i0 == 2) {
+      Step& cstep = b->steps[(size_t)o.i1];
+      cstep.coef.lane_major = 1;  // the table is read lane by lane (waa_biquad_stream.hip)
+      if (cstep.coef.rows == 1 && !getenv("WAA_NO_ARATE_DIGEST")) {
+        // one table for all instances: digest it once (zero-state end state as a dot product, BiquadHpDesc); the
+        // digest step was reserved right behind the coefficient step by emit_node_ops
+        Step& hstep = b->steps[(size_t)o.i1 + 1];
+        double* dhp = nullptr;
+        int e = dev_alloc(b, &dhp, (size_t)b->n_tiles * HP_WORDS * 64);
+        if (e) return e;
+        hstep.hp.coefs = cstep.coef.coefs;
+        hstep.hp.hp = dhp;
+        hstep.hp.n_tiles = b->n_tiles;
+        q.hp = dhp;
+        q.vary = 3;
+      }
+    }
     q.state = reinterpret_cast<double*>(o.ptr1);
     q.n_gain = (int)(j - i - 1);
     for (size_t k = i + 1; k < j; k++) q.gain[k - i - 1] = ops[k].p0;
@@ -393,7 +411,9 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     q.n_quanta = b->n_quanta;
     st.profile_slot = slot_for(b, "biquad_stream_kernel");
     b->steps.push_back(st);
-    plan_note(b, "biquad_stream%s in=%s:%dch gains=%d out=%s", q.vary ? "(k-rate)" : "", input_kind_name(inputs[0].kind),
+    plan_note(b, "biquad_stream%s in=%s:%dch gains=%d out=%s",
+              q.vary == 3 ? "(a-rate, shared table)" : q.vary == 2 ? "(a-rate, per-instance table)" : q.vary ? "(k-rate)" : "",
+              input_kind_name(inputs[0].kind),
               cur_nch, q.n_gain, seg_out.base == out.base ? "final" : "temp");
     InputRef in{};
     in.kind = IN_SIGNAL;
@@ -1537,7 +1557,7 @@ int build_plan(waa_batch* b) {
         Step& st = b->steps[k];
         st.group = group;
         // steps that only depend on data from outside the loop run once, over the full range, before the blocks
-        st.prologue = st.kind == 5 || st.kind == 3 || (st.kind == 0 && st.chain.n_ops == 1 && st.chain.ops[0].kind == OP_PARAM_ADD);
+        st.prologue = st.kind == 5 || st.kind == 12 || st.kind == 3 || (st.kind == 0 && st.chain.n_ops == 1 && st.chain.ops[0].kind == OP_PARAM_ADD);
         if (st.kind == 2 || st.kind == 4)
           return fail(WAA_ERR_OUT_OF_SCOPE, "this node kind cannot be rendered inside a feedback loop");
       }
@@ -1594,6 +1614,8 @@ StepIo step_io(const Step& st) {
     }
     case 1:
       io_input(st.bq.in, io);
+      if (st.bq.vary >= 2) io.reads.push_back(st.bq.coefs);
+      if (st.bq.vary == 3) io.reads.push_back(st.bq.hp);
       io.writes.push_back(st.bq.out.base);
       break;
     case 2:
@@ -1610,6 +1632,12 @@ StepIo step_io(const Step& st) {
       io_param(st.coef.q, io);
       io_param(st.coef.gain, io);
       io.writes.push_back(st.coef.coefs);
+      break;
+    case 12:
+      if (st.hp.coefs) {
+        io.reads.push_back(st.hp.coefs);
+        io.writes.push_back(st.hp.hp);
+      }
       break;
     case 6:
       io_input(st.iir.in, io);
@@ -2415,11 +2443,22 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
             (e = node_param(b, id, WAA_PARAM_BIQUAD_GAIN, &cdsc.gain)))
           return e;
         cdsc.n_frames = (uint64_t)b->n_quanta * RQ;
-        cdsc.n_inst = b->n_inst;
+        cdsc.frames_padded = b->lp;
+        // one table for all instances when the four params do not depend on the instance (the usual automation:
+        // the same timeline scheduled on every context): 40 B per frame instead of 40 B per frame-instance
+        bool shared = true;
+        for (size_t k = 0; k < 4; k++) {
+          const bool modulated = k < n.pin_edges.size() && !n.pin_edges[k].empty();
+          const ParamStore& ps = n.params[k];
+          if (modulated) shared = false;
+          for (uint32_t i = 1; i < b->n_inst && shared; i++) shared = ps.cst[i] == ps.cst[0];
+          for (auto& blk : ps.blocks) shared &= blk.inst == WAA_ALL_INSTANCES;
+        }
+        cdsc.rows = shared ? 1u : b->n_inst;
         cdsc.type = n.desc.i[0];
         cdsc.sample_rate = b->sr;
         double* dco = nullptr;
-        if ((e = dev_alloc(b, &dco, (size_t)b->n_inst * cdsc.n_frames * 5))) return e;
+        if ((e = dev_alloc(b, &dco, (size_t)cdsc.rows * cdsc.frames_padded * 5))) return e;
         cdsc.coefs = dco;
         cs.profile_slot = slot_for(b, "biquad_coef_kernel");
         b->steps.push_back(cs);
@@ -2427,9 +2466,17 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
         if ((e = dev_alloc(b, &dst, (size_t)b->n_inst * STATE_STRIDE))) return e;
         b->state_bufs.push_back({dst, (size_t)b->n_inst * STATE_STRIDE * sizeof(double)});
         o.i0 = 2;
+        o.i1 = (int32_t)b->steps.size() - 1;  // the coefficient step: emit_segments may switch it to the lane-major layout
+        {
+          Step hs;  // placeholder for the digest of a shared table (a no-op unless emit_segments fills it in)
+          hs.kind = 12;
+          std::memset(&hs.hp, 0, sizeof hs.hp);
+          hs.profile_slot = slot_for(b, "biquad_hp_kernel");
+          b->steps.push_back(hs);
+        }
         o.ptr0 = dco;
         o.ptr1 = dst;
-        o.u0 = cdsc.n_frames * 5;
+        o.u0 = shared ? 0 : cdsc.frames_padded * 5;
         ops.push_back(o);
         break;
       }
