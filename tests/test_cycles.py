@@ -198,13 +198,31 @@ def test_parity_ping_pong_loop(hip, orc, modulated):
 
 
 @pytest.mark.gpu
-def test_unsupported_node_in_loop_is_refused(hip):
+def test_node_kinds_outside_the_static_loop_kernel_go_to_the_dynamic_path(hip, orc):
+    """An IIRFilter inside a short feedback loop: the static loop kernel does not cover it (status 4 in round 1); the
+    planner now renders the whole graph quantum by quantum with dyn_kernel.  A ConvolverNode inside a loop is still
+    refused (FFT convolvers are node-major launches)."""
+    outs = []
+    for be in (hip, orc):
+        c = waa.OfflineAudioContext(2, RQ * 40, 48000.0, n_instances=2, binding=be)
+        src = c.create_constant_source()
+        d = c.create_delay(0.1, delay_time=0.01)
+        iir = c.create_iir_filter([0.5, 0.5], [1.0, -0.2])
+        src.connect(d)
+        d.connect(iir).connect(d)
+        d.connect(c.destination())
+        src.start()
+        if be is hip:
+            assert "dynamic-count group" in c.plan_describe()
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-6
     c = waa.OfflineAudioContext(2, RQ * 4, 48000.0, n_instances=1, binding=hip)
     src = c.create_constant_source()
     d = c.create_delay(0.1, delay_time=0.01)
-    iir = c.create_iir_filter([0.5, 0.5], [1.0, -0.2])
+    conv = c.create_convolver(buffer=waa.AudioBuffer(np.ones((1, 300), np.float32), 48000.0))
     src.connect(d)
-    d.connect(iir).connect(d)
+    d.connect(conv).connect(d)
     d.connect(c.destination())
     src.start()
     with pytest.raises(waa.WaaError) as ei:

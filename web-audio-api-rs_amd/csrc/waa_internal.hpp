@@ -402,6 +402,9 @@ void launch_biquad_hp(const BiquadHpDesc& d, void* stream);
 
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);
+// waa_resample.hip: AudioBufferSource [-> WaveShaper] -> signal without the op interpreter (the C5 shape)
+bool resample_shape(const ChainDesc& d, int* curve_op);
+void launch_resample(const ChainDesc& d, int curve_op, void* stream);
 
 #ifdef __HIPCC__
 // A pointer LOADED from memory (the per-instance source records) is a generic pointer to the compiler: every access

@@ -1022,6 +1022,11 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
     else
       hipLaunchKernelGGL((chain_kernel<2, TILE_K, true>), grid, block, 2 * 64 * LDS_ROW * sizeof(float) + CARRY_BYTES, s, d);
   } else {
+    int curve_op = -1;
+    if (resample_shape(d, &curve_op)) {  // source [-> WaveShaper] -> signal: the specialised kernel of waa_resample.hip
+      launch_resample(d, curve_op, stream);
+      return;
+    }
     ChainDesc dd = d;
     dd.lds_curve_op = -1;
     dd.tile_major = 0;

@@ -248,6 +248,12 @@ int push_chain_step(waa_batch* b, const std::vector<InputRef>& inputs, int in_nc
   cd.n_quanta = b->n_quanta;
   st.cmax = cmax;
   st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : cmax <= 2 ? "chain_kernel<2>" : "chain_kernel<4+>");
+  {
+    int curve_op = -1;
+    bool has_biquad = false;
+    for (auto& o : ops) has_biquad |= o.kind == OP_BIQUAD;
+    if (!has_biquad && resample_shape(cd, &curve_op)) st.profile_slot = slot_for(b, "resample_kernel");
+  }
   b->steps.push_back(st);
   {
     bool serial = false;
