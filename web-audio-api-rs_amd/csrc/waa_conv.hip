@@ -600,6 +600,61 @@ __global__ __launch_bounds__(256) void conv_mac_kernel(const ConvDesc d) {
   }
 }
 
+// The same product with a SLIDING register window: consecutive k-tiles of one spectral position share PC - 1 input
+// spectra; conv_mac_kernel re-reads them (2.2x the X bytes from HBM, profiles/r02a_t1_fetch.txt), here they stay in
+// registers, the IR column h[0..PC) is loaded once per thread, and every X value is read exactly once.  One term per
+// output channel and P <= PC (every routing but the true-stereo 4-channel IR; the launcher picks).
+template <int KT, int PC>
+__global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t pair = blockIdx.y / (uint32_t)d.cout;
+  const int co = (int)(blockIdx.y % (uint32_t)d.cout);
+  const int n = d.n, nb = d.nb, P = d.parts;
+  int term = 0;
+  for (int t = 0; t < d.n_terms; t++)
+    if (d.terms[t].out_ch == co) term = t;
+  Cplx* Yc = d.Y + ((uint64_t)pair * d.cout + co) * nb * n + pos;
+  const Cplx* Hc = d.H + (uint64_t)d.terms[term].ir_ch * P * n + pos;
+  const Cplx* Xc = d.X + ((uint64_t)pair * d.cin + d.terms[term].in_ch) * nb * n + pos;
+  Cplx h[PC];
+#pragma unroll
+  for (int i = 0; i < PC; i++) h[i] = i < P ? Hc[(uint64_t)i * n] : Cplx{0.f, 0.f};
+  Cplx win[PC - 1];  // X_{k0 - (PC-1)} .. X_{k0 - 1}
+#pragma unroll
+  for (int i = 0; i < PC - 1; i++) win[i] = Cplx{0.f, 0.f};
+  for (int k0 = 0; k0 < nb; k0 += KT) {
+    Cplx xn[KT];  // X_{k0} .. X_{k0 + KT - 1}
+#pragma unroll
+    for (int i = 0; i < KT; i++) xn[i] = k0 + i < nb ? Xc[(uint64_t)(k0 + i) * n] : Cplx{0.f, 0.f};
+    Cplx acc[KT];
+#pragma unroll
+    for (int i = 0; i < KT; i++) acc[i] = Cplx{0.f, 0.f};
+#pragma clang loop unroll(full)
+    for (int jj = 0; jj < KT + PC - 1; jj++) {
+      const Cplx x = jj < PC - 1 ? win[jj < PC - 1 ? jj : 0] : xn[jj >= PC - 1 ? jj - (PC - 1) : 0];
+#pragma clang loop unroll(full)
+      for (int i = 0; i < KT; i++) {
+        const int pl = i + (PC - 1) - jj;  // partition index, compile-time after unrolling
+        if (pl >= 0 && pl < PC) {
+          acc[i].re = __builtin_fmaf(h[pl].re, x.re, acc[i].re);
+          acc[i].re = __builtin_fmaf(-h[pl].im, x.im, acc[i].re);
+          acc[i].im = __builtin_fmaf(h[pl].re, x.im, acc[i].im);
+          acc[i].im = __builtin_fmaf(h[pl].im, x.re, acc[i].im);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < KT; i++)
+      if (k0 + i < nb) Yc[(uint64_t)(k0 + i) * n] = acc[i];
+    // slide the window by KT blocks
+#pragma unroll
+    for (int w = 0; w < PC - 1; w++) {
+      const int src = w + KT;  // index into the concatenation [win | xn]
+      win[w] = src < PC - 1 ? win[src < PC - 1 ? src : 0] : xn[src >= PC - 1 ? src - (PC - 1) : 0];
+    }
+  }
+}
+
 // Short impulse responses (<= DIRECT_MAX_TAPS after trimming): direct time-domain FIR with f64 accumulation.
 // This is the linear convolution itself, so it is at least as close to the exact result as the reference's
 // f32 FFT convolver (the reference's own delta-IR tests ask for 1e-7).  Per term the f64 sum is rounded to f32
@@ -762,6 +817,23 @@ void launch_analyser(const AnalyserDesc& d, void* stream) {
 }
 void launch_conv_mac(const ConvDesc& d, void* stream) {
   dim3 grid(d.n / 256, d.n_pairs * (uint32_t)d.cout);
+  bool one_term = true;
+  for (int co = 0; co < d.cout; co++) {
+    int cnt = 0;
+    for (int t = 0; t < d.n_terms; t++) cnt += d.terms[t].out_ch == co;
+    one_term &= cnt == 1;
+  }
+  if (one_term && d.parts > 8 && d.parts <= 24 && !getenv("WAA_CONV_MAC_REREAD")) {  // (switch: A/B against conv_mac_kernel)
+    if (d.parts <= 12)
+      hipLaunchKernelGGL((conv_mac_win_kernel<16, 12>), grid, dim3(256), 0, (hipStream_t)stream, d);
+    else if (d.parts <= 16)
+      hipLaunchKernelGGL((conv_mac_win_kernel<16, 16>), grid, dim3(256), 0, (hipStream_t)stream, d);
+    else if (d.parts <= 22)  // (8 output blocks per tile were measured: 220 registers all the same, 3.78 ms against 3.59)
+      hipLaunchKernelGGL((conv_mac_win_kernel<16, 22>), grid, dim3(256), 0, (hipStream_t)stream, d);
+    else
+      hipLaunchKernelGGL((conv_mac_win_kernel<16, 24>), grid, dim3(256), 0, (hipStream_t)stream, d);
+    return;
+  }
   if (d.parts <= 8)
     hipLaunchKernelGGL((conv_mac_kernel<16, 8>), grid, dim3(256), 0, (hipStream_t)stream, d);
   else
