@@ -526,3 +526,34 @@ def test_c5_full_size_sampled(hip, orc, rate, buf_sr, n_ch):
     err = rms_err(out, ref)
     assert err.max() <= TOL, err
     assert np.abs(out - ref).max() <= 1e-6
+
+
+@pytest.mark.parametrize("nch", [1, 2])
+def test_audio_rate_listener_automation(hip, orc, nch):
+    """panner.rs:830-897, the branch taken when a listener param is a 128-value slice: every frame has its own
+    geometry (a-rate listener positionX ramp, a-rate panner positionZ, a k-rate forward vector change halfway); quanta
+    in which the listener is single-valued (before the ramp starts) keep the once-per-quantum rule.  Geometry runs on
+    the device (waa_panner.hip: device acosf / sinf / cosf, <= 1-2 ulp from the host libm of the oracle)."""
+    sr, n, frames = 48000.0, 3, RQ * 60 + 11
+    noise = white_noise(n, nch, frames, seed0=17)
+    outs = []
+    for b in (hip, orc):
+        ctx = waa.OfflineAudioContext(2, frames, sr, n_instances=n, binding=b)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(noise, sr)
+        pn = ctx.create_panner(distance_model="inverse", ref_distance=1.0, rolloff_factor=1.5, position=(1.0, 0.5, -2.0),
+                               cone_inner_angle=40.0, cone_outer_angle=100.0, cone_outer_gain=0.2)
+        li = ctx.listener()
+        li.position_x.set_value_at_time(-3.0, RQ * 10 / sr).linear_ramp_to_value_at_time(4.0, RQ * 50 / sr)
+        li.forward_x.set_value_at_time(0.5, RQ * 30 / sr)
+        pn.position_z.set_value_at_time(-2.0, 0.0).linear_ramp_to_value_at_time(1.5, frames / sr)
+        for i in range(n):
+            pn.position_y.set_value(0.5 - 0.4 * i, instance=i)
+        src.connect(pn).connect(ctx.destination())
+        src.start()
+        if b is hip:
+            assert "audio-rate AudioListener automation" in ctx.plan_describe()
+        outs.append(ctx.start_rendering_sync().data)
+        ctx.close()
+    assert rms_err(*outs).max() <= TOL
+    assert np.abs(outs[0] - outs[1]).max() <= 5e-6

@@ -254,14 +254,16 @@ class AudioParam:
     def set_value_curve_at_time(self, values, start_time: float, duration: float):
         return self._event(EVENT_SET_VALUE_CURVE, 0.0, start_time, duration, values)
 
-    def _apply(self, ctx: "OfflineAudioContext"):
+    def _apply(self, ctx: "OfflineAudioContext", node_id=None, pid=None):
         b, h = ctx._b, ctx._handle
+        node_id = self._node.id if node_id is None else node_id
+        pid = self._pid if pid is None else pid
         for inst, v in sorted(self._const.items(), key=lambda kv: kv[0] != ALL):
-            b.check(b.set_param_const(h, self._node.id, self._pid, inst, v))
+            b.check(b.set_param_const(h, node_id, pid, inst, v))
         for q0, v, inst in self._blocks:
-            b.check(b.set_param_block(h, self._node.id, self._pid, inst, q0, v.shape[0], v.shape[1], _fp(v)))
+            b.check(b.set_param_block(h, node_id, pid, inst, q0, v.shape[0], v.shape[1], _fp(v)))
         for kind, value, time, aux, curve in self._events:  # in call order, like the reference's message queue
-            b.check(b.param_schedule_event(h, self._node.id, self._pid, ALL, kind, value, time, aux,
+            b.check(b.param_schedule_event(h, node_id, pid, ALL, kind, value, time, aux,
                                            None if curve is None else _fp(curve), 0 if curve is None else curve.size))
 
 
@@ -594,13 +596,23 @@ class AudioListener:
     """src/spatial.rs:127-144 — shared by every PannerNode of the context."""
 
     def __init__(self):
-        self.values = [0.0, 0.0, 0.0, 0.0, 0.0, -1.0, 0.0, 1.0, 0.0]
+        # nine a-rate AudioParams (spatial.rs:18-24 defaults); they cross the ABI through every PannerNode (params 6..14)
+        names = ["position_x", "position_y", "position_z", "forward_x", "forward_y", "forward_z", "up_x", "up_y", "up_z"]
+        self.params = [AudioParam(None, 6 + i, v) for i, v in enumerate([0.0, 0.0, 0.0, 0.0, 0.0, -1.0, 0.0, 1.0, 0.0])]
+        for name, prm in zip(names, self.params):
+            setattr(self, name, prm)
+
+    @property
+    def values(self):
+        return [p.value for p in self.params]
 
     def set_position(self, x, y, z):
-        self.values[0:3] = [float(x), float(y), float(z)]
+        for p, v in zip(self.params[0:3], (x, y, z)):
+            p.set_value(v)
 
     def set_orientation(self, fx, fy, fz, ux, uy, uz):
-        self.values[3:9] = [float(v) for v in (fx, fy, fz, ux, uy, uz)]
+        for p, v in zip(self.params[3:9], (fx, fy, fz, ux, uy, uz)):
+            p.set_value(v)
 
 
 class PannerNode(AudioNode):
@@ -642,9 +654,8 @@ class PannerNode(AudioNode):
 
     def _apply(self, ctx):
         super()._apply(ctx)
-        b, h = ctx._b, ctx._handle
-        for i, v in enumerate(ctx.listener().values):
-            b.check(b.set_param_const(h, self.id, 6 + i, ALL, v))
+        for i, prm in enumerate(ctx.listener().params):  # the AudioListener's params, addressed through this panner
+            prm._apply(ctx, node_id=self.id, pid=6 + i)
 
 
 class AnalyserNode(AudioNode):

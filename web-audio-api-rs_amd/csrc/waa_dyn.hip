@@ -335,17 +335,18 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
               outn = 1;
               break;
             }
-            const float az = pval(op.p0, inst, q, 0);
-            const float dg = pval(op.p3, inst, q, 0), cg = pval(op.p4, inst, q, 0);
 #pragma unroll
             for (int e = 0; e < 2; e++) {
+              const uint64_t f = f0 + e * 64 + lane;  // (per-frame tables with an audio-rate AudioListener)
+              const float az = pval(op.p0, inst, q, f);
+              const float dg = pval(op.p3, inst, q, f), cg = pval(op.p4, inst, q, f);
               if (sn == 1) {
-                const float gl = pval(li.alt1, inst, q, 0), gr = pval(li.alt2, inst, q, 0);
+                const float gl = pval(li.alt1, inst, q, f), gr = pval(li.alt2, inst, q, f);
                 const float x = v[0][e];
                 v[0][e] = x * (gl * dg * cg);
                 v[1][e] = x * (gr * dg * cg);
               } else {
-                const float gl = pval(op.p1, inst, q, 0), gr = pval(op.p2, inst, q, 0);
+                const float gl = pval(op.p1, inst, q, f), gr = pval(op.p2, inst, q, f);
                 const float il = v[0][e], ir = v[1][e];
                 if (az <= 0.f) {
                   v[0][e] = (il + ir * gl) * dg * cg;

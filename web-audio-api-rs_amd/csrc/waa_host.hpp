@@ -175,7 +175,7 @@ struct ProfileEntry {
 };
 
 struct Step {
-  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator, 10 dynamic-count group (dyn_kernel), 11 convolver codes, 12 digest of a shared per-frame coefficient table
+  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator, 10 dynamic-count group (dyn_kernel), 11 convolver codes, 12 digest of a shared per-frame coefficient table, 13 per-frame panner geometry
   ChainDesc chain{};
   BiquadStreamDesc bq{};
   ConvDesc conv{};
@@ -187,6 +187,7 @@ struct Step {
   DynDesc dyn{};
   ConvCodeDesc ccode{};
   BiquadHpDesc hp{};
+  PannerGeomDesc geom{};
   int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
   void* zero_ptr = nullptr;
   size_t zero_bytes = 0;

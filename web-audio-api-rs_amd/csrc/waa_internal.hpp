@@ -400,6 +400,21 @@ struct BiquadHpDesc {
 };
 void launch_biquad_hp(const BiquadHpDesc& d, void* stream);
 
+// ---- per-frame panner geometry for an audio-rate AudioListener (waa_panner.hip; panner.rs:720-897) ----
+struct PannerGeomDesc {
+  ParamRef p[15];          // WAA_PARAM_PANNER_* / WAA_PARAM_LISTENER_* in id order
+  const uint8_t* single;   // [rows][single_stride]: 1 = all nine listener params are single-valued in this quantum
+  uint64_t single_stride;
+  float *az, *gl_mono, *gr_mono, *gl_stereo, *gr_stereo, *dg, *cg;  // [rows][n_frames]
+  uint64_t n_frames;       // n_quanta * 128
+  uint32_t rows;           // n_inst, or 1 when nothing depends on the instance
+  int32_t distance_model;
+  double ref_distance, max_distance, rolloff;
+  float cone_inner, cone_outer, cone_outer_gain;
+  int32_t pad;
+};
+void launch_panner_geom(const PannerGeomDesc& d, void* stream);
+
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);
 // waa_resample.hip: AudioBufferSource [-> WaveShaper] -> signal without the op interpreter (the C5 shape)

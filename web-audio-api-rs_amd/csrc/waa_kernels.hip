@@ -803,11 +803,21 @@ void chain_kernel(const ChainDesc d) {
             for (int j = 0; j < NV4; j++) {
               const uint32_t q = tile * QPT + j * 2 + (lane >> 5);
               const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
-              const float az = param_at(op.p0, inst, qc, 0);
-              const float gl = param_at(op.p1, inst, qc, 0), gr = param_at(op.p2, inst, qc, 0);
-              const float dg = param_at(op.p3, inst, qc, 0), cg = param_at(op.p4, inst, qc, 0);
+              float az = param_at(op.p0, inst, qc, 0);
+              float gl = param_at(op.p1, inst, qc, 0), gr = param_at(op.p2, inst, qc, 0);
+              float dg = param_at(op.p3, inst, qc, 0), cg = param_at(op.p4, inst, qc, 0);
+              const bool per_frame = op.p0.mode == 2;  // audio-rate AudioListener: tables of waa_panner.hip
+              const uint64_t f = (uint64_t)tile * TILE_FR + j * 256 + lane * 4;
 #pragma unroll
               for (int e = 0; e < 4; e++) {
+                if (per_frame) {
+                  const uint64_t fc = f + e < (uint64_t)d.n_quanta * RQ ? f + e : (uint64_t)d.n_quanta * RQ - 1;
+                  az = param_at(op.p0, inst, qc, fc);
+                  gl = param_at(op.p1, inst, qc, fc);
+                  gr = param_at(op.p2, inst, qc, fc);
+                  dg = param_at(op.p3, inst, qc, fc);
+                  cg = param_at(op.p4, inst, qc, fc);
+                }
                 if (op.nch_in == 1) {
                   // panner.rs:988-1014 (after the mono -> stereo up-mix l = r = in)
                   const float in = v[0][j * 4 + e];

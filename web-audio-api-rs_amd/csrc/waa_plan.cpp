@@ -1563,7 +1563,7 @@ int build_plan(waa_batch* b) {
         Step& st = b->steps[k];
         st.group = group;
         // steps that only depend on data from outside the loop run once, over the full range, before the blocks
-        st.prologue = st.kind == 5 || st.kind == 12 || st.kind == 3 || (st.kind == 0 && st.chain.n_ops == 1 && st.chain.ops[0].kind == OP_PARAM_ADD);
+        st.prologue = st.kind == 5 || st.kind == 12 || st.kind == 13 || st.kind == 3 || (st.kind == 0 && st.chain.n_ops == 1 && st.chain.ops[0].kind == OP_PARAM_ADD);
         if (st.kind == 2 || st.kind == 4)
           return fail(WAA_ERR_OUT_OF_SCOPE, "this node kind cannot be rendered inside a feedback loop");
       }
@@ -1638,6 +1638,16 @@ StepIo step_io(const Step& st) {
       io_param(st.coef.q, io);
       io_param(st.coef.gain, io);
       io.writes.push_back(st.coef.coefs);
+      break;
+    case 13:
+      for (int k = 0; k < 15; k++) io_param(st.geom.p[k], io);
+      io.writes.push_back(st.geom.az);
+      io.writes.push_back(st.geom.gl_mono);
+      io.writes.push_back(st.geom.gr_mono);
+      io.writes.push_back(st.geom.gl_stereo);
+      io.writes.push_back(st.geom.gr_stereo);
+      io.writes.push_back(st.geom.dg);
+      io.writes.push_back(st.geom.cg);
       break;
     case 12:
       if (st.hp.coefs) {
@@ -2642,9 +2652,80 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
       o.nch_out = 2;
       int mode = 0;
       for (auto& p : n.params) mode = std::max(mode, p.mode());
-      for (int k = 6; k < 15; k++)
-        if (n.params[k].mode() == 2)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "a-rate AudioListener automation is out of scope for this round");
+      bool listener_a_rate = false;
+      for (int k = 6; k < 15; k++) listener_a_rate |= n.params[k].mode() == 2;
+      if (listener_a_rate) {
+        // audio-rate AudioListener automation (panner.rs:830-897, the `else` of `single_valued`): per-frame geometry on
+        // the device (waa_panner.hip).  Quanta in which all nine listener params happen to be single-valued keep the
+        // once-per-quantum rule (first value of every param), flagged per quantum from the value blocks.
+        Step gs;
+        gs.kind = 13;
+        PannerGeomDesc& g = gs.geom;
+        std::memset(&g, 0, sizeof g);
+        bool shared = true;
+        for (int k = 0; k < 15; k++) {
+          const ParamStore& ps = n.params[k];
+          for (uint32_t i = 1; i < b->n_inst && shared; i++) shared = ps.cst[i] == ps.cst[0];
+          for (auto& blk : ps.blocks) shared &= blk.inst == WAA_ALL_INSTANCES;
+          int e = upload_param(b, ps, &g.p[k]);
+          if (e) return e;
+        }
+        g.rows = shared ? 1u : b->n_inst;
+        g.n_frames = (uint64_t)b->n_quanta * RQ;
+        std::vector<uint8_t> single((size_t)g.rows * b->n_quanta, 1);
+        for (uint32_t r = 0; r < g.rows; r++)
+          for (int k = 6; k < 15; k++) {
+            // length of the slice param k delivers in quantum q: the LAST block that covers (instance, q) decides
+            std::vector<uint8_t> len128(b->n_quanta, 0);
+            for (auto& blk : n.params[k].blocks) {
+              if (!(blk.inst == WAA_ALL_INSTANCES || blk.inst == r)) continue;
+              for (uint32_t j = 0; j < blk.nq; j++)
+                if (blk.q0 + j < b->n_quanta) len128[blk.q0 + j] = blk.vpq == 1 ? 0 : 1;
+            }
+            for (uint32_t q = 0; q < b->n_quanta; q++)
+              if (len128[q]) single[(size_t)r * b->n_quanta + q] = 0;
+          }
+        uint8_t* d_single = nullptr;
+        int e = dev_upload(b, &d_single, single);
+        if (e) return e;
+        g.single = d_single;
+        g.single_stride = b->n_quanta;
+        float* tabs[7];
+        for (auto& t : tabs)
+          if ((e = dev_alloc(b, &t, (size_t)g.rows * g.n_frames))) return e;
+        g.az = tabs[0];
+        g.gl_mono = tabs[1];
+        g.gr_mono = tabs[2];
+        g.gl_stereo = tabs[3];
+        g.gr_stereo = tabs[4];
+        g.dg = tabs[5];
+        g.cg = tabs[6];
+        g.distance_model = n.desc.i[1];
+        g.ref_distance = n.desc.d[0];
+        g.max_distance = n.desc.d[1];
+        g.rolloff = n.desc.d[2];
+        g.cone_inner = (float)n.desc.d[3];
+        g.cone_outer = (float)n.desc.d[4];
+        g.cone_outer_gain = (float)n.desc.d[5];
+        gs.profile_slot = slot_for(b, "panner_geom_kernel");
+        b->steps.push_back(gs);
+        auto ref = [&](float* base) {
+          ParamRef r{};
+          r.base = base;
+          r.stride = g.rows == 1 ? 0 : g.n_frames;
+          r.mode = 2;
+          return r;
+        };
+        o.p0 = ref(g.az);
+        o.p1 = ref(nch == 1 ? g.gl_mono : g.gl_stereo);
+        o.p2 = ref(nch == 1 ? g.gr_mono : g.gr_stereo);
+        o.p3 = ref(g.dg);
+        o.p4 = ref(g.cg);
+        plan_note(b, "panner node %u: audio-rate AudioListener automation -> per-frame geometry on the device (%u table row(s))", id,
+                  g.rows);
+        ops.push_back(o);
+        break;
+      }
       // listener single-valued => the reference evaluates the geometry once per quantum from the first value of
       // every param (panner.rs:833-846)
       const uint32_t cnt = mode == 0 ? 1 : b->n_quanta;
