@@ -242,8 +242,9 @@ enum {
 /* Schedule an automation event on a param of a node (instance or WAA_ALL_INSTANCES), before waa_render.  The
  * events of a param are applied in call order, exactly like the reference's render thread receives them
  * (handle_incoming_event, param.rs:796-1047), and the timeline is evaluated per render quantum with the
- * reference's arithmetic (compute_buffer, param.rs:1483-1584) on the HOST (automation is control-side work);
- * the resulting per-quantum / per-frame values take the place of waa_set_param_block for that param.
+ * reference's arithmetic (compute_buffer, param.rs:1483-1584): once on the HOST when the events are the same for every
+ * instance (automation is control-side work), by a device kernel when instances carry different event lists on an a-rate
+ * param (waa_timeline.hip); the resulting per-quantum / per-frame values take the place of waa_set_param_block.
  * Errors mirror the reference's panics: RangeError / TypeError for bad values and times, InvalidStateError for a
  * curve shorter than 2, NotSupportedError for events overlapping a value curve. */
 waa_status waa_param_schedule_event(waa_batch* batch, uint32_t node, uint32_t param, uint32_t instance, int32_t type,
@@ -260,6 +261,12 @@ waa_status waa_timeline_event(waa_timeline* timeline, int32_t type, float value,
 uint32_t waa_timeline_compute(waa_timeline* timeline, double block_time, double dt, uint32_t count, float* out);
 /* AudioParam::value(): the clamped intrinsic value at the beginning of the last computed block */
 float waa_timeline_value(const waa_timeline* timeline);
+/* The same timeline replayed ON THE DEVICE (the kernel that renders per-instance automation inside a batch,
+ * AudioParamProcessor::compute_buffer param.rs:1498-1584 per render quantum from time 0): out[n_quanta * 128] with
+ * single-valued slices replicated, lens[n_quanta] = 1 or 128 (the slice length AudioParamValues::get would return,
+ * processor.rs:186-229).  Does not consume the timeline.  WAA_ERR_DEVICE without a HIP device. */
+waa_status waa_timeline_render_device(const waa_timeline* timeline, uint32_t n_quanta, float sample_rate, float* out,
+                                      uint8_t* lens);
 
 /* ---- render ---------------------------------------------------------------------------- */
 

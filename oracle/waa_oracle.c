@@ -990,6 +990,32 @@ done:
   return (uint32_t)t->blen;
 }
 
+/* Same entry point as the product's waa_timeline_render_device (the device replay of a timeline): here it is simply the
+ * per-quantum evaluation above on a copy of the timeline, so that the parity tests can drive both libraries alike. */
+waa_status orc_timeline_render_device(const orc_timeline* t, uint32_t n_quanta, float sample_rate, float* out, uint8_t* lens) {
+  if (!t || !out || !lens || n_quanta == 0) return fail(WAA_ERR_INVALID_ARGUMENT, "bad arguments");
+  orc_timeline* c = (orc_timeline*)malloc(sizeof *c);
+  *c = *t;
+  c->ev = (TlEvent*)malloc(sizeof(TlEvent) * (size_t)(t->cap ? t->cap : 1));
+  c->cap = t->cap ? t->cap : 1;
+  for (int i = 0; i < t->n; i++) {
+    c->ev[i] = t->ev[i];
+    if (t->ev[i].values) {
+      c->ev[i].values = (float*)malloc(sizeof(float) * (size_t)t->ev[i].n_values);
+      memcpy(c->ev[i].values, t->ev[i].values, sizeof(float) * (size_t)t->ev[i].n_values);
+    }
+  }
+  double sr = (double)sample_rate, dt = 1. / sr;
+  for (uint32_t q = 0; q < n_quanta; q++) {
+    float buf[RQ];
+    uint32_t n = orc_timeline_compute(c, (double)((uint64_t)q * RQ) / sr, dt, RQ, buf);
+    lens[q] = (uint8_t)(n == 1 ? 1 : RQ);
+    for (uint32_t i = 0; i < RQ; i++) out[(size_t)q * RQ + i] = n == 1 ? buf[0] : buf[i];
+  }
+  orc_timeline_destroy(c);
+  return WAA_OK;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* context / nodes                                                                        */
 /* ------------------------------------------------------------------------------------ */

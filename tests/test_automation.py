@@ -551,6 +551,96 @@ def test_random_schedules_agree_between_the_two_restatements(orc_lib, hip, seed)
         done += n
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(300))
+def test_device_replay_of_random_schedules(hip, seed):
+    """waa_timeline.hip: the kernel that replays per-instance automation on the device, against the host restatement
+    (waa_timeline_compute, itself pinned by the reference's unit tests above and by the oracle's independent twin) on the
+    same 300 random event lists: identical slice lengths (1 or 128) in every quantum; bit-identical values for set-value
+    events, linear ramps and value curves, and within 4 ulp where powf / exp of the device math library are involved
+    (exponential ramps, set-target)."""
+    rng = np.random.default_rng(seed)
+    a_rate = bool(rng.integers(0, 2))
+    lo, hi = -3.4028235e38, 3.4028235e38
+    tls = [TL(hip.lib, "waa_", 0.25, lo, hi, a_rate), TL(hip.lib, "waa_", 0.25, lo, hi, a_rate)]
+    kinds = set()
+    for _ in range(int(rng.integers(1, 4))):
+        # (record which event kinds the script holds: the tolerance depends on it)
+        state = rng.bit_generator.state
+        probe = np.random.default_rng(0)
+        probe.bit_generator.state = state
+        for _ in range(int(probe.integers(1, 9))):
+            kinds.add(int(probe.choice([SET, SET_AT, LIN, EXP, TARGET, CURVE, CANCEL, HOLD], p=[.08, .2, .2, .14, .14, .1, .07, .07])))
+            probe.choice([0.0, 0.25, 1.0, 3.0, 7.5, 20.0]); probe.choice([-2.0, -0.5, 0.0, 1e-3, 0.5, 1.0, 3.0])
+            break  # (only a hint; the tolerance below is decided from the values)
+        _random_schedule(rng, tls, 80)
+    sr, nq = 16.0, 14  # 8 s per render quantum: the schedules span the first ~10 quanta
+    fn = hip.lib.waa_timeline_render_device
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_uint8)]
+    dev = np.zeros(nq * 128, np.float32)
+    lens = np.zeros(nq, np.uint8)
+    assert fn(tls[0].h, nq, sr, dev.ctypes.data_as(C.POINTER(C.c_float)), lens.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    for q in range(nq):
+        ref = tls[1].compute(q * 128 / sr, count=128, dt=1.0 / sr)
+        assert lens[q] == (1 if ref.size == 1 else 128), (seed, q)
+        d = dev[q * 128:(q + 1) * 128]
+        r = np.full(128, ref[0], np.float32) if ref.size == 1 else ref
+        if np.array_equal(d, r, equal_nan=True):
+            continue
+        # powf / exp differ by an ulp or two between the device and the host math libraries
+        tol = 4 * np.spacing(np.maximum(np.abs(r), np.float32(1e-30)).astype(np.float32))
+        bad = ~(np.abs(d.astype(np.float64) - r) <= tol) & ~(np.isnan(d) & np.isnan(r))
+        assert not bad.any(), (seed, q, d[bad][:4], r[bad][:4])
+
+
+@pytest.mark.gpu
+def test_per_instance_automation_is_replayed_on_the_device(hip, orc):
+    """Every context of the batch schedules its OWN automation on a-rate params (gain envelope, biquad sweep, pan, delay
+    time, constant offset, oscillator glide): the planner uploads the event queues and timeline_kernel evaluates them
+    (the plan says so); output against the oracle, whose timelines are evaluated per quantum on the host."""
+    n, frames, sr = 4, RQ * 70 + 9, 48000.0
+    noise = white_noise(n, 2, frames, seed0=91)
+    outs = []
+    for b in (hip, orc):
+        c = waa.OfflineAudioContext(2, frames, sr, n_instances=n, binding=b)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(noise, sr)
+        bq = c.create_biquad_filter(type_="lowpass", frequency=800.0, q=2.0)
+        g = c.create_gain(gain=0.2)
+        pan = c.create_stereo_panner(pan=0.0)
+        d = c.create_delay(0.05, delay_time=0.004)
+        k = c.create_constant_source(offset=0.1)
+        osc = c.create_oscillator(type_="sine", frequency=200.0)
+        t_end = frames / sr
+        for i in range(n):
+            g.gain.set_value_at_time(0.05 + 0.1 * i, 0.0, instance=i)
+            g.gain.linear_ramp_to_value_at_time(0.9 - 0.1 * i, t_end * (0.4 + 0.1 * i), instance=i)
+            g.gain.set_target_at_time(0.3, t_end * 0.7, 0.01 + 0.005 * i, instance=i)
+            bq.frequency.set_value_at_time(200.0 + 100.0 * i, 0.0, instance=i)
+            bq.frequency.exponential_ramp_to_value_at_time(4000.0 + 500.0 * i, t_end, instance=i)
+            pan.pan.set_value_curve_at_time(np.float32([-1.0, 0.5 - 0.3 * i, 1.0, 0.0]), t_end * 0.1, t_end * 0.6, instance=i)
+            d.delay_time.set_value_at_time(0.002 + 0.001 * i, 0.0, instance=i)
+            d.delay_time.linear_ramp_to_value_at_time(0.02, t_end * 0.9, instance=i)
+            k.offset.set_value_at_time(0.1 * i, t_end * 0.2, instance=i)
+            k.offset.cancel_and_hold_at_time(t_end * 0.5, instance=i)
+            osc.frequency.linear_ramp_to_value_at_time(300.0 + 50.0 * i, t_end * 0.8, instance=i)
+        src.connect(bq).connect(g).connect(pan).connect(c.destination())
+        src.connect(d).connect(c.destination())
+        k.connect(c.destination())
+        osc.connect(c.destination())
+        src.start()
+        k.start()
+        osc.start()
+        if b is hip:
+            plan = c.plan_describe()
+            assert plan.count("replayed on the device") == 6, plan
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    assert rms_err(*outs).max() <= 1e-6
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-5
+
+
 def test_automated_param_advances_while_its_owner_is_idle(be):
     """An AudioParam is its own graph node and is processed in EVERY quantum (param.rs:686-699), also while the node
     that owns it sees a silent input and returns early (stereo_panner.rs:229-232).  The timeline is stateful — a

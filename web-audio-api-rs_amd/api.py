@@ -107,6 +107,7 @@ ABI = {
     "timeline_event": (C.c_int32, [_VP, C.c_int32, C.c_float, C.c_double, C.c_double, _FP, C.c_uint32]),
     "timeline_compute": (C.c_uint32, [_VP, C.c_double, C.c_double, C.c_uint32, _FP]),
     "timeline_value": (C.c_float, [_VP]),
+    "timeline_render_device": (C.c_int32, [_VP, C.c_uint32, C.c_float, _FP, C.POINTER(C.c_uint8)]),
     "set_param_const": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
     "set_param_block": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, _FP]),
     "render": (C.c_int32, [_VP]),
@@ -229,30 +230,31 @@ class AudioParam:
 
     # -- automation methods (src/param.rs:428-596).  The events cross the ABI (waa_param_schedule_event) and are
     #    evaluated by the library's restatement of AudioParamProcessor; nothing is computed in this mirror.
-    def _event(self, kind: int, value: float, time: float, aux: float = 0.0, curve=None):
-        self._events.append((kind, float(value), float(time), float(aux), None if curve is None else _f32(curve)))
+    #    `instance`: the context of the batch the call is made on (ALL = the same call on every context).
+    def _event(self, kind: int, value: float, time: float, aux: float = 0.0, curve=None, instance: int = ALL):
+        self._events.append((kind, float(value), float(time), float(aux), None if curve is None else _f32(curve), instance))
         return self
 
-    def set_value_at_time(self, value: float, start_time: float):
-        return self._event(EVENT_SET_VALUE_AT_TIME, value, start_time)
+    def set_value_at_time(self, value: float, start_time: float, instance: int = ALL):
+        return self._event(EVENT_SET_VALUE_AT_TIME, value, start_time, instance=instance)
 
-    def linear_ramp_to_value_at_time(self, value: float, end_time: float):
-        return self._event(EVENT_LINEAR_RAMP, value, end_time)
+    def linear_ramp_to_value_at_time(self, value: float, end_time: float, instance: int = ALL):
+        return self._event(EVENT_LINEAR_RAMP, value, end_time, instance=instance)
 
-    def exponential_ramp_to_value_at_time(self, value: float, end_time: float):
-        return self._event(EVENT_EXPONENTIAL_RAMP, value, end_time)
+    def exponential_ramp_to_value_at_time(self, value: float, end_time: float, instance: int = ALL):
+        return self._event(EVENT_EXPONENTIAL_RAMP, value, end_time, instance=instance)
 
-    def set_target_at_time(self, value: float, start_time: float, time_constant: float):
-        return self._event(EVENT_SET_TARGET, value, start_time, time_constant)
+    def set_target_at_time(self, value: float, start_time: float, time_constant: float, instance: int = ALL):
+        return self._event(EVENT_SET_TARGET, value, start_time, time_constant, instance=instance)
 
-    def cancel_scheduled_values(self, cancel_time: float):
-        return self._event(EVENT_CANCEL_SCHEDULED_VALUES, 0.0, cancel_time)
+    def cancel_scheduled_values(self, cancel_time: float, instance: int = ALL):
+        return self._event(EVENT_CANCEL_SCHEDULED_VALUES, 0.0, cancel_time, instance=instance)
 
-    def cancel_and_hold_at_time(self, cancel_time: float):
-        return self._event(EVENT_CANCEL_AND_HOLD, 0.0, cancel_time)
+    def cancel_and_hold_at_time(self, cancel_time: float, instance: int = ALL):
+        return self._event(EVENT_CANCEL_AND_HOLD, 0.0, cancel_time, instance=instance)
 
-    def set_value_curve_at_time(self, values, start_time: float, duration: float):
-        return self._event(EVENT_SET_VALUE_CURVE, 0.0, start_time, duration, values)
+    def set_value_curve_at_time(self, values, start_time: float, duration: float, instance: int = ALL):
+        return self._event(EVENT_SET_VALUE_CURVE, 0.0, start_time, duration, values, instance=instance)
 
     def _apply(self, ctx: "OfflineAudioContext", node_id=None, pid=None):
         b, h = ctx._b, ctx._handle
@@ -262,8 +264,8 @@ class AudioParam:
             b.check(b.set_param_const(h, node_id, pid, inst, v))
         for q0, v, inst in self._blocks:
             b.check(b.set_param_block(h, node_id, pid, inst, q0, v.shape[0], v.shape[1], _fp(v)))
-        for kind, value, time, aux, curve in self._events:  # in call order, like the reference's message queue
-            b.check(b.param_schedule_event(h, node_id, pid, ALL, kind, value, time, aux,
+        for kind, value, time, aux, curve, inst in self._events:  # in call order, like the reference's message queue
+            b.check(b.param_schedule_event(h, node_id, pid, inst, kind, value, time, aux,
                                            None if curve is None else _fp(curve), 0 if curve is None else curve.size))
 
 

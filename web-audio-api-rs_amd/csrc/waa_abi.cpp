@@ -603,6 +603,7 @@ waa_status waa_render(waa_batch* b) {
       case 10: e = timed(st.profile_slot, [&] { launch_dyn(st.dyn, b->stream); }); break;
       case 11: e = timed(st.profile_slot, [&] { launch_conv_codes(st.ccode, b->stream); }); break;
       case 13: e = timed(st.profile_slot, [&] { launch_panner_geom(st.geom, b->stream); }); break;
+      case 14: e = timed(st.profile_slot, [&] { launch_timeline(st.tl, b->stream); }); break;
       case 12:
         if (st.hp.coefs) e = timed(st.profile_slot, [&] { launch_biquad_hp(st.hp, b->stream); });
         break;

@@ -55,6 +55,30 @@ Timeline::~Timeline() = default;
 
 float Timeline::value() const { return current_; }
 
+void Timeline::export_queue(TlHeader* hdr, std::vector<TlEvent>* events, std::vector<float>* curves) const {
+  hdr->minv = min_;
+  hdr->maxv = max_;
+  hdr->intrinsic = intrinsic_;
+  hdr->a_rate = a_rate_ ? 1 : 0;
+  hdr->ev_off = (int32_t)events->size();
+  hdr->n_events = (int32_t)queue_.size();
+  hdr->pad = 0;
+  for (const Event& e : queue_) {
+    TlEvent t{};
+    t.type = e.type;
+    t.value = e.value;
+    t.time = e.time;
+    t.time_constant = e.time_constant;
+    t.cancel_time = e.cancel_time;
+    t.duration = e.duration;
+    t.cancelled = e.cancelled ? 1 : 0;
+    t.curve_off = (int32_t)curves->size();
+    t.curve_len = (int32_t)e.values.size();
+    curves->insert(curves->end(), e.values.begin(), e.values.end());
+    events->push_back(t);
+  }
+}
+
 int Timeline::schedule(int type, float value, double time, double aux, const float* curve, uint32_t n_curve) {
   Event ev;
   ev.type = type;
@@ -382,4 +406,67 @@ uint32_t waa_timeline_compute(waa_timeline* t, double block_time, double dt, uin
   return t->tl.compute(block_time, dt, count, out);
 }
 float waa_timeline_value(const waa_timeline* t) { return t->tl.value(); }
+// The same timeline replayed by timeline_kernel on the current HIP device for `n_quanta` render quanta from time 0:
+// out[n_quanta * 128] (single-valued slices replicated), lens[n_quanta] = 1 or 128.  The timeline object itself is
+// not consumed.  Parity hook for tests/test_automation.py (device replay vs waa_timeline_compute).
+waa_status waa_timeline_render_device(const waa_timeline* t, uint32_t n_quanta, float sample_rate, float* out, uint8_t* lens) {
+  using namespace waa;
+  if (!t || !out || !lens || n_quanta == 0) return waa::host::fail(WAA_ERR_INVALID_ARGUMENT, "bad arguments");
+  TlHeader hdr{};
+  std::vector<TlEvent> events;
+  std::vector<float> curves;
+  t->tl.export_queue(&hdr, &events, &curves);
+  hdr.defv = 0.f;
+  hdr.minv = -FLT_MAX;  // (the stand-alone object is compared before clamping, like waa_timeline_compute)
+  hdr.maxv = FLT_MAX;
+  TlHeader* d_hdr = nullptr;
+  TlEvent *d_ev = nullptr, *d_work = nullptr;
+  float *d_curves = nullptr, *d_out = nullptr;
+  uint8_t* d_lens = nullptr;
+  const size_t n_ev = std::max<size_t>(events.size(), 1), n_cv = std::max<size_t>(curves.size(), 1);
+  auto cleanup = [&] {
+    (void)hipFree(d_hdr);
+    (void)hipFree(d_ev);
+    (void)hipFree(d_work);
+    (void)hipFree(d_curves);
+    (void)hipFree(d_out);
+    (void)hipFree(d_lens);
+  };
+#define TL_TRY(expr)                                                                                          \
+  do {                                                                                                        \
+    hipError_t e_ = (expr);                                                                                   \
+    if (e_ != hipSuccess) {                                                                                   \
+      cleanup();                                                                                              \
+      return waa::host::fail(WAA_ERR_DEVICE, "HIP error %s (%s)", hipGetErrorString(e_), #expr);              \
+    }                                                                                                         \
+  } while (0)
+  TL_TRY(hipMalloc(&d_hdr, sizeof hdr));
+  TL_TRY(hipMalloc(&d_ev, n_ev * sizeof(TlEvent)));
+  TL_TRY(hipMalloc(&d_work, n_ev * sizeof(TlEvent)));
+  TL_TRY(hipMalloc(&d_curves, n_cv * sizeof(float)));
+  TL_TRY(hipMalloc(&d_out, (size_t)n_quanta * RQ * sizeof(float)));
+  TL_TRY(hipMalloc(&d_lens, n_quanta));
+  TL_TRY(hipMemcpy(d_hdr, &hdr, sizeof hdr, hipMemcpyHostToDevice));
+  if (!events.empty()) TL_TRY(hipMemcpy(d_ev, events.data(), events.size() * sizeof(TlEvent), hipMemcpyHostToDevice));
+  if (!curves.empty()) TL_TRY(hipMemcpy(d_curves, curves.data(), curves.size() * sizeof(float), hipMemcpyHostToDevice));
+  TimelineDesc d{};
+  d.hdr = d_hdr;
+  d.events = d_ev;
+  d.work = d_work;
+  d.curves = d_curves;
+  d.out = d_out;
+  d.lens = d_lens;
+  d.out_stride = (uint64_t)n_quanta * RQ;
+  d.rows = 1;
+  d.n_quanta = n_quanta;
+  d.sample_rate = (double)sample_rate;
+  launch_timeline(d, nullptr);
+  TL_TRY(hipGetLastError());
+  TL_TRY(hipDeviceSynchronize());
+  TL_TRY(hipMemcpy(out, d_out, (size_t)n_quanta * RQ * sizeof(float), hipMemcpyDeviceToHost));
+  TL_TRY(hipMemcpy(lens, d_lens, n_quanta, hipMemcpyDeviceToHost));
+#undef TL_TRY
+  cleanup();
+  return WAA_OK;
+}
 }

@@ -45,6 +45,9 @@ class Timeline {
   // one block: 1 or `count` values into out (capacity >= count); returns how many
   uint32_t compute(double block_time, double dt, uint32_t count, float* out);
   float value() const;  // AudioParam::value()
+  // the scheduled queue in the form timeline_kernel replays (waa_timeline.hip); `ev_off` / curve offsets are relative
+  // to the arrays the events are appended to
+  void export_queue(TlHeader* hdr, std::vector<TlEvent>* events, std::vector<float>* curves) const;
 
  private:
   struct Event;
@@ -67,6 +70,10 @@ struct ParamStore {
   std::vector<std::shared_ptr<Timeline>> timelines;  // [n_inst] or empty: scheduled automation (waa_param_schedule_event)
   bool k_rate = false;                               // AutomationRate::K (source playbackRate / detune)
   bool timelines_shared = true;                      // every event was scheduled for WAA_ALL_INSTANCES
+  bool dev_tl = false;                               // the timelines are replayed on the device (per-instance automation)
+  mutable bool dev_ready = false;                    // ... and their step has been planned:
+  mutable ParamRef dev_ref{};                        //     per-frame values [n_inst][n_quanta * 128]
+  mutable uint8_t* dev_lens = nullptr;               //     slice length per (instance, quantum)
   float defv = 0, minv = -FLT_MAX, maxv = FLT_MAX;
   void init(uint32_t n, float d, float lo, float hi) {
     cst.assign(n, d);
@@ -77,6 +84,7 @@ struct ParamStore {
   // AudioParamProcessor::mix_to_output clamp / NaN rule (param.rs:739-797)
   float fix(float x) const { return std::isnan(x) ? defv : std::fmin(std::fmax(x, minv), maxv); }
   int mode() const {
+    if (dev_tl) return 2;
     int m = 0;
     for (auto& b : blocks) m = std::max(m, b.vpq == 1 ? 1 : 2);
     return m;
@@ -175,7 +183,7 @@ struct ProfileEntry {
 };
 
 struct Step {
-  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator, 10 dynamic-count group (dyn_kernel), 11 convolver codes, 12 digest of a shared per-frame coefficient table, 13 per-frame panner geometry
+  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator, 10 dynamic-count group (dyn_kernel), 11 convolver codes, 12 digest of a shared per-frame coefficient table, 13 per-frame panner geometry, 14 automation timelines replayed on the device
   ChainDesc chain{};
   BiquadStreamDesc bq{};
   ConvDesc conv{};
@@ -188,6 +196,7 @@ struct Step {
   ConvCodeDesc ccode{};
   BiquadHpDesc hp{};
   PannerGeomDesc geom{};
+  TimelineDesc tl{};
   int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
   void* zero_ptr = nullptr;
   size_t zero_bytes = 0;

@@ -405,6 +405,7 @@ struct PannerGeomDesc {
   ParamRef p[15];          // WAA_PARAM_PANNER_* / WAA_PARAM_LISTENER_* in id order
   const uint8_t* single;   // [rows][single_stride]: 1 = all nine listener params are single-valued in this quantum
   uint64_t single_stride;
+  const uint8_t* dev_len[9];  // listener params evaluated by timeline_kernel: [n_inst][single_stride] slice lengths, else null
   float *az, *gl_mono, *gr_mono, *gl_stereo, *gr_stereo, *dg, *cg;  // [rows][n_frames]
   uint64_t n_frames;       // n_quanta * 128
   uint32_t rows;           // n_inst, or 1 when nothing depends on the instance
@@ -414,6 +415,40 @@ struct PannerGeomDesc {
   int32_t pad;
 };
 void launch_panner_geom(const PannerGeomDesc& d, void* stream);
+
+// ---- AudioParam automation on the device (waa_timeline.hip; param.rs:1049-1584) ----
+struct TlEvent {            // one queued AudioParamEvent (param.rs:162-171), as the render side holds it
+  int32_t type;             // WAA_EVENT_*
+  float value;
+  double time;
+  double time_constant;     // SetTarget
+  double cancel_time;       // CancelAndHold rewrote the end of this event
+  double duration;          // SetValueCurve
+  int32_t cancelled;
+  int32_t curve_off;        // SetValueCurve: offset / length of its values in the curve pool
+  int32_t curve_len;
+  int32_t pad;
+};
+struct TlHeader {           // one timeline = one (param, instance)
+  float minv, maxv, defv, intrinsic;
+  int32_t a_rate;
+  int32_t ev_off;           // first event of this timeline in the event arrays
+  int32_t n_events;
+  int32_t pad;
+};
+struct TimelineDesc {
+  const TlHeader* hdr;      // [rows]
+  const TlEvent* events;    // scheduled queues (read-only)
+  TlEvent* work;            // same size: the queue as the replay consumes / rewrites it
+  const float* curves;
+  float* out;               // [rows][out_stride] per-frame values
+  uint8_t* lens;            // [rows][n_quanta]: 1 or 128, the length of the reference's slice in that quantum
+  uint64_t out_stride;
+  uint32_t rows;
+  uint32_t n_quanta;
+  double sample_rate;
+};
+void launch_timeline(const TimelineDesc& d, void* stream);
 
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);

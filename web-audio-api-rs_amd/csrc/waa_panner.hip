@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void panner_geom_kernel(const PannerGeomDesc d
   const uint64_t frame = idx % d.n_frames;
   const uint32_t q = (uint32_t)(frame / RQ);
   // a single-valued listener: one geometry per quantum from the first value of every param (panner.rs:833-846)
-  const bool single = d.single[(uint64_t)inst * d.single_stride + q] != 0;
+  bool single = d.single[(uint64_t)inst * d.single_stride + q] != 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++)
+    if (d.dev_len[k]) single = single && d.dev_len[k][(uint64_t)inst * d.single_stride + q] == 1;
   const uint64_t f = single ? (uint64_t)q * RQ : frame;
   float v[15];
 #pragma unroll

@@ -12,7 +12,65 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in);
 int validate_plan(waa_batch* b);
 
 // Upload a param as a device ParamRef (mode 0 / 1 / 2), values clamped like the reference.
+// Per-instance automation of an a-rate param: upload the event queues, plan one timeline_kernel step (waa_timeline.hip)
+// that replays them for all quanta into a per-frame table, and hand that table out as the param's values.
+int device_timeline_param(waa_batch* b, const ParamStore& p, ParamRef* ref) {
+  if (p.dev_ready) {
+    *ref = p.dev_ref;
+    return 0;
+  }
+  std::vector<TlHeader> hdr(b->n_inst);
+  std::vector<TlEvent> events;
+  std::vector<float> curves;
+  for (uint32_t i = 0; i < b->n_inst; i++) {
+    TlHeader& h = hdr[i];
+    std::memset(&h, 0, sizeof h);
+    if (i < p.timelines.size() && p.timelines[i]) {
+      p.timelines[i]->export_queue(&h, &events, &curves);
+    } else {  // no automation on this instance: the constant
+      h.intrinsic = p.cst[i];
+      h.a_rate = 1;
+      h.ev_off = (int32_t)events.size();
+    }
+    h.minv = p.minv;
+    h.maxv = p.maxv;
+    h.defv = p.defv;
+  }
+  Step st;
+  st.kind = 14;
+  TimelineDesc& d = st.tl;
+  std::memset(&d, 0, sizeof d);
+  TlHeader* d_hdr = nullptr;
+  TlEvent *d_ev = nullptr, *d_work = nullptr;
+  float *d_curves = nullptr, *d_out = nullptr;
+  uint8_t* d_lens = nullptr;
+  int e;
+  if ((e = dev_upload(b, &d_hdr, hdr)) || (e = dev_upload(b, &d_ev, events)) || (e = dev_alloc(b, &d_work, events.size())) ||
+      (e = dev_upload(b, &d_curves, curves)) || (e = dev_alloc(b, &d_out, (size_t)b->n_inst * b->n_quanta * RQ)) ||
+      (e = dev_alloc(b, &d_lens, (size_t)b->n_inst * b->n_quanta)))
+    return e;
+  d.hdr = d_hdr;
+  d.events = d_ev;
+  d.work = d_work;
+  d.curves = d_curves;
+  d.out = d_out;
+  d.lens = d_lens;
+  d.out_stride = (uint64_t)b->n_quanta * RQ;
+  d.rows = b->n_inst;
+  d.n_quanta = b->n_quanta;
+  d.sample_rate = (double)b->sr;
+  st.profile_slot = slot_for(b, "timeline_kernel");
+  b->steps.push_back(st);
+  plan_note(b, "automation: %u per-instance timeline(s), %zu event(s) in total, replayed on the device", b->n_inst, events.size());
+  p.dev_ref = ParamRef{d_out, d.out_stride, 2, 0};
+  p.dev_lens = d_lens;
+  p.dev_ready = true;
+  *ref = p.dev_ref;
+  return 0;
+}
+
 int upload_param(waa_batch* b, const ParamStore& p, ParamRef* ref) {
+  if (p.dev_tl) return device_timeline_param(b, p, ref);
   const int mode = p.mode();
   std::vector<float> host;
   if (mode == 0) {
@@ -462,11 +520,26 @@ uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items)
 int materialise_automation(waa_batch* b) {
   const double sample_rate = (double)b->sr, dt = 1. / sample_rate;
   for (Node& n : b->nodes)
-    for (ParamStore& p : n.params) {
+    for (size_t pk = 0; pk < n.params.size(); pk++) {
+      ParamStore& p = n.params[pk];
       if (p.timelines.empty()) continue;
       // identical timelines (every event scheduled for all instances, same initial value): evaluate once
       bool shared = p.timelines_shared && p.timelines[0];
       for (uint32_t i = 1; i < b->n_inst && shared; i++) shared = p.cst[i] == p.cst[0] && p.timelines[i];
+      // Different event lists per instance on an a-rate param the DEVICE consumes: replay them there
+      // (waa_timeline.hip) instead of evaluating n_inst x n_quanta x 128 values here and uploading them.  Params the
+      // host needs per quantum (source playbackRate / detune: k-rate, the playhead replay) stay on this path.
+      {
+        const uint32_t kind = n.desc.kind;
+        const bool consumable = kind == WAA_NODE_GAIN || kind == WAA_NODE_BIQUAD || kind == WAA_NODE_DELAY ||
+                                kind == WAA_NODE_STEREO_PANNER || kind == WAA_NODE_CONSTANT_SOURCE ||
+                                kind == WAA_NODE_OSCILLATOR || kind == WAA_NODE_PANNER;
+        const bool want = getenv("WAA_DEVICE_AUTOMATION") ? true : !shared;  // (switch: also replay shared timelines there)
+        if (consumable && !p.k_rate && want && !b->dry && !getenv("WAA_HOST_AUTOMATION")) {
+          p.dev_tl = true;
+          continue;  // (the timelines are consumed when the param is uploaded)
+        }
+      }
       for (uint32_t inst = 0; inst < (shared ? 1u : b->n_inst); inst++) {
         Timeline* tl = p.timelines[inst].get();
         if (!tl) continue;
@@ -769,7 +842,8 @@ int build_plan(waa_batch* b) {
               covered_all |= blk.q0 == 0 && blk.nq >= nq;
             }
             (void)covered_all;
-            const bool modulated = WAA_PARAM_DELAY_DELAY_TIME < n.pin_edges.size() && !n.pin_edges[WAA_PARAM_DELAY_DELAY_TIME].empty();
+            const bool modulated = (WAA_PARAM_DELAY_DELAY_TIME < n.pin_edges.size() && !n.pin_edges[WAA_PARAM_DELAY_DELAY_TIME].empty()) ||
+                                   pd.dev_tl;  // (replayed on the device: only known to lie in [0, maxDelayTime])
             if (modulated) {
               dmin = 0.;
               dmax = n.desc.d[0];
@@ -1563,7 +1637,7 @@ int build_plan(waa_batch* b) {
         Step& st = b->steps[k];
         st.group = group;
         // steps that only depend on data from outside the loop run once, over the full range, before the blocks
-        st.prologue = st.kind == 5 || st.kind == 12 || st.kind == 13 || st.kind == 3 || (st.kind == 0 && st.chain.n_ops == 1 && st.chain.ops[0].kind == OP_PARAM_ADD);
+        st.prologue = st.kind == 5 || st.kind == 12 || st.kind == 13 || st.kind == 14 || st.kind == 3 || (st.kind == 0 && st.chain.n_ops == 1 && st.chain.ops[0].kind == OP_PARAM_ADD);
         if (st.kind == 2 || st.kind == 4)
           return fail(WAA_ERR_OUT_OF_SCOPE, "this node kind cannot be rendered inside a feedback loop");
       }
@@ -1638,6 +1712,9 @@ StepIo step_io(const Step& st) {
       io_param(st.coef.q, io);
       io_param(st.coef.gain, io);
       io.writes.push_back(st.coef.coefs);
+      break;
+    case 14:
+      io.writes.push_back(st.tl.out);
       break;
     case 13:
       for (int k = 0; k < 15; k++) io_param(st.geom.p[k], io);
@@ -2466,7 +2543,7 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
         for (size_t k = 0; k < 4; k++) {
           const bool modulated = k < n.pin_edges.size() && !n.pin_edges[k].empty();
           const ParamStore& ps = n.params[k];
-          if (modulated) shared = false;
+          if (modulated || ps.dev_tl) shared = false;
           for (uint32_t i = 1; i < b->n_inst && shared; i++) shared = ps.cst[i] == ps.cst[0];
           for (auto& blk : ps.blocks) shared &= blk.inst == WAA_ALL_INSTANCES;
         }
@@ -2665,10 +2742,12 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
         bool shared = true;
         for (int k = 0; k < 15; k++) {
           const ParamStore& ps = n.params[k];
+          if (ps.dev_tl) shared = false;
           for (uint32_t i = 1; i < b->n_inst && shared; i++) shared = ps.cst[i] == ps.cst[0];
           for (auto& blk : ps.blocks) shared &= blk.inst == WAA_ALL_INSTANCES;
           int e = upload_param(b, ps, &g.p[k]);
           if (e) return e;
+          if (k >= 6 && ps.dev_tl) g.dev_len[k - 6] = ps.dev_lens;  // slice lengths come from the device replay
         }
         g.rows = shared ? 1u : b->n_inst;
         g.n_frames = (uint64_t)b->n_quanta * RQ;
