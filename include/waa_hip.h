@@ -15,6 +15,10 @@
  *                                                                             src/node/audio_buffer_source.rs:388-398
  *   waa_convolver_set_buffer    ConvolverNode::set_buffer                     src/node/convolver.rs:259-317
  *   waa_waveshaper_set_curve    WaveShaperNode::set_curve                     src/node/waveshaper.rs:489-509 (onmessage)
+ *   waa_hrtf_load_sphere        load_hrtf_processor (include_bytes!(IRC_1003_C.bin) -> hrtf::HrirSphere::new)
+ *                                                                             src/node/panner.rs:39-68
+ *   waa_hrtf_hrir_length        HrirSphere::len (the HRTF panner's tail time)  src/node/panner.rs:56,270-272
+ *   waa_hrtf_sample             hrtf::HrirSphere::sample_bilinear (test hook)  src/node/panner.rs:261 (process_samples)
  *   waa_oscillator_set_periodic_wave  OscillatorNode::set_periodic_wave     src/node/oscillator.rs:318-321
  *   waa_iir_set_coefficients    IIRFilterNode::new(IIRFilterOptions)          src/node/iir_filter.rs:163-189
  *   waa_iir_frequency_response  IIRFilterNode::get_frequency_response         src/node/iir_filter.rs:218-262
@@ -58,7 +62,7 @@ enum {
   WAA_ERR_INVALID_ARGUMENT = 1, /* reference: assert!/panic with "…Error - …" message */
   WAA_ERR_NOT_SUPPORTED = 2,    /* reference: "NotSupportedError - …"                 */
   WAA_ERR_INVALID_STATE = 3,    /* reference: "InvalidStateError - …"                 */
-  WAA_ERR_OUT_OF_SCOPE = 4,     /* legal in the reference, not on this hot path (HRTF, oversampling, cycles, …) */
+  WAA_ERR_OUT_OF_SCOPE = 4,     /* legal in the reference, not on this hot path (worklets, >6 channels, …) */
   WAA_ERR_DEVICE = 5            /* HIP runtime failure                                 */
 };
 
@@ -72,7 +76,7 @@ enum {
   WAA_NODE_STEREO_PANNER = 5,   /* src/node/stereo_panner.rs:218-317 */
   WAA_NODE_PANNER = 6,          /* src/node/panner.rs:685-904 (equal-power only) */
   WAA_NODE_ANALYSER = 7,        /* src/node/analyser.rs:265-290      */
-  WAA_NODE_WAVESHAPER = 8,      /* src/node/waveshaper.rs:383-487 (oversample None only) */
+  WAA_NODE_WAVESHAPER = 8,      /* src/node/waveshaper.rs:383-487 (oversample None, 2x, 4x) */
   WAA_NODE_CONSTANT_SOURCE = 9, /* src/node/constant_source.rs:190-275 */
   WAA_NODE_IIR_FILTER = 10,     /* src/node/iir_filter.rs:323-405 */
   WAA_NODE_DELAY = 11,          /* src/node/delay.rs:428-745 incl. the cycle breaker of graph.rs:323-487 */
@@ -301,6 +305,19 @@ waa_status waa_analyser_get_byte_time_domain_data(waa_batch* batch, uint32_t nod
 waa_status waa_plan_describe(waa_batch* batch, char* buf, size_t cap, size_t* needed);
 
 /* ---- input prep + pure helpers (no batch) ---------------------------------------------- */
+
+/* The HRIR database of the HRTF panning model.  The reference embeds resources/IRC_1003_C.bin in the crate
+ * (`include_bytes!`, src/node/panner.rs:55) and hands it to hrtf::HrirSphere::new; a shim passes the same bytes
+ * here ONCE per process, before the first batch with an HRTF PannerNode is created (InvalidStateError otherwise).
+ * Format (crate hrtf): "HRIR", then u32 LE sample rate, HRIR length, vertex count, index count; the triangle
+ * indices (u32); per vertex x, y, z (f32) and the left and right HRIR (f32 each).  The bytes are copied.  HRIRs
+ * for other context sample rates are derived on first use and cached per rate (panner.rs:39-60). */
+waa_status waa_hrtf_load_sphere(const void* data, uint64_t size);
+/* HrirSphere::len() at a context sample rate (= PannerRenderer's HRTF tail in frames); 0 without a database */
+uint32_t waa_hrtf_hrir_length(float sample_rate);
+/* HrirSphere::sample_bilinear: the interpolated left / right HRIR (waa_hrtf_hrir_length(sample_rate) taps each) for
+ * a direction in the sphere's coordinates (x, y, z).  Test hook; the render path does this per render quantum. */
+void waa_hrtf_sample(float sample_rate, const float* dir, float* left, float* right);
 
 /* AudioBuffer::resample (src/buffer.rs:311-363): returns the target length; writes at most dst_capacity
  * frames to dst (call with dst = NULL to query the length). */

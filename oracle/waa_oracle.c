@@ -26,6 +26,18 @@
  *     reference tests (peak bin, -inf on silence) => "parity unpinned" beyond DFT maths.
  *   - almost::equal/zero (crate almost "0.2", not vendored): restated from its published
  *     behaviour (tolerance sqrt(f64::EPSILON)); edge cases unverifiable here.
+ *   - WaveShaper 2x/4x oversampling: the resamplers are rubato "0.16" FftFixedInOut (third
+ *     party, not vendored).  orc restates its synchronous FFT resampler (windowed-sinc
+ *     anti-alias filter applied in the frequency domain, spectrum zero-padded / truncated,
+ *     overlap-add) from the crate's published source as remembered; the reference's tests
+ *     only construct such nodes (waveshaper.rs:608-670) => PARITY UNPINNED, the written
+ *     definition is DESIGN.md section 3.5.
+ *   - HRTF panning: crate hrtf "0.8.1" (third party, not vendored).  orc restates its
+ *     published algorithm (HRIR sphere file format, barycentric interpolation of the three
+ *     HRIRs of the triangle the direction pierces, linear convolution of the block with the
+ *     previous input samples as history, distance gain) with an exact f64 direct
+ *     convolution; the reference only asserts "differs from the input, non-zero tail"
+ *     (panner.rs:1226-1269) => PARITY UNPINNED, definition in DESIGN.md section 3.6.
  *
  * Exports the same entry points as include/waa_hip.h with the prefix orc_.
  */
@@ -343,6 +355,88 @@ static void rfft_inverse(const RfftPlan* p, float* sre, float* sim, const float*
     x[2 * i] = sre[i] * s;
     x[2 * i + 1] = sim[i] * s;
   }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* rubato 0.16 FftFixedInOut / FftResampler (synchro.rs), restated from the crate's        */
+/* published source: the WaveShaper's oversamplers.  Call sites: waveshaper.rs:290-347      */
+/* (Resampler::new / process), :232-287 (chunk sizes and rates).  With fs_out = R * fs_in   */
+/* (or fs_in = R * fs_out) and chunk_size_in = 128 (128 * R) rubato picks                   */
+/* fft_size_in = chunk_size_in and fft_size_out = chunk_size_in * fs_out / fs_in.           */
+/* PARITY UNPINNED by the reference (its tests only construct such nodes).                  */
+/* ------------------------------------------------------------------------------------ */
+typedef struct OsResampler {
+  int fi, fo;        /* fft_size_in, fft_size_out */
+  float *fre, *fim;  /* filter_f: fi + 1 bins */
+  RfftPlan *fwd, *inv; /* real FFTs of 2 * fi and 2 * fo points */
+} OsResampler;
+
+static float os_sinc(float value) { /* rubato sinc(): sin(pi x) / (pi x) in the sample type */
+  const float pi = 3.14159265358979323846f;
+  if (value == 0.f) return 1.f;
+  return sinf(value * pi) / (value * pi);
+}
+/* FftResampler::new: anti-alias cutoff, make_sincs(fft_size_in, 1, cutoff, BlackmanHarris2), filter / (2 fi), FFT */
+static OsResampler* os_resampler_new(int fi, int fo) {
+  OsResampler* r = (OsResampler*)calloc(1, sizeof *r);
+  r->fi = fi;
+  r->fo = fo;
+  float cutoff = fi > fo ? powf(0.4f, 16.0f / (float)fi) * (float)fo / (float)fi : powf(0.4f, 16.0f / (float)fi);
+  const float pi = 3.14159265358979323846f;
+  const float pi2 = 2.f * pi, pi4 = 4.f * pi, pi6 = 6.f * pi, np = (float)fi;
+  float* y = (float*)malloc(sizeof(float) * (size_t)fi);
+  float sum = 0.f;
+  for (int x = 0; x < fi; x++) {
+    float xf = (float)x;
+    float bh = 0.35875f - 0.48829f * cosf(pi2 * xf / np) + 0.14128f * cosf(pi4 * xf / np) - 0.01168f * cosf(pi6 * xf / np);
+    float w = bh * bh; /* WindowFunction::BlackmanHarris2 */
+    float val = w * os_sinc((xf - (float)(fi / 2)) * cutoff / 1.f);
+    sum += val;
+    y[x] = val;
+  }
+  float* ft = (float*)calloc((size_t)2 * fi, sizeof(float));
+  for (int n = 0; n < fi; n++) ft[n] = (y[n] / sum) / (float)(2 * fi);
+  free(y);
+  r->fwd = rfft_plan_new(2 * fi);
+  r->inv = rfft_plan_new(2 * fo);
+  r->fre = (float*)calloc((size_t)fi + 1, sizeof(float));
+  r->fim = (float*)calloc((size_t)fi + 1, sizeof(float));
+  float* sre = (float*)malloc(sizeof(float) * ((size_t)fi + 1));
+  float* sim = (float*)malloc(sizeof(float) * ((size_t)fi + 1));
+  rfft_forward(r->fwd, sre, sim, ft, r->fre, r->fim);
+  free(sre);
+  free(sim);
+  free(ft);
+  return r;
+}
+static void os_resampler_free(OsResampler* r) {
+  if (!r) return;
+  rfft_plan_free(r->fwd);
+  rfft_plan_free(r->inv);
+  free(r->fre);
+  free(r->fim);
+  free(r);
+}
+/* FftResampler::resample_unit: wave_in (fi frames) -> wave_out (fo frames), overlap (fo frames) carried */
+static void os_resample_unit(const OsResampler* r, const float* in, float* out, float* overlap) {
+  const int fi = r->fi, fo = r->fo;
+  float inbuf[2 * 512], ire[513], iim[513], ore[513] = {0}, oim[513] = {0}, sre[513], sim[513], obuf[2 * 512];
+  memcpy(inbuf, in, sizeof(float) * (size_t)fi);
+  memset(inbuf + fi, 0, sizeof(float) * (size_t)fi);
+  rfft_forward(r->fwd, sre, sim, inbuf, ire, iim);
+  const int new_len = fi < fo ? fi + 1 : fo;
+  for (int k = 0; k <= fo; k++) {
+    if (k < new_len) { /* spec *= filt */
+      ore[k] = ire[k] * r->fre[k] - iim[k] * r->fim[k];
+      oim[k] = ire[k] * r->fim[k] + iim[k] * r->fre[k];
+    } else {
+      ore[k] = oim[k] = 0.f;
+    }
+  }
+  rfft_inverse(r->inv, sre, sim, ore, oim, obuf);
+  const float unnorm = (float)(2 * fo); /* realfft's inverse is unnormalised; rfft_inverse divides by its length */
+  for (int n = 0; n < fo; n++) out[n] = obuf[n] * unnorm + overlap[n];
+  for (int n = 0; n < fo; n++) overlap[n] = obuf[fo + n] * unnorm;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1072,6 +1166,11 @@ typedef struct {
   /* iir filter (shared): normalised (b, a) pairs, iir_filter.rs:273-311 */
   double iir_b[WAA_MAX_IIR_COEFFS], iir_a[WAA_MAX_IIR_COEFFS];
   int iir_len;
+  /* waveshaper oversampling (shared, read-only): the up / down resamplers of waveshaper.rs:232-287 */
+  struct OsResampler *os_up, *os_dn;
+  int os_factor; /* 1 (none), 2, 4 */
+  /* HRTF panner (shared, read-only): the HRIR sphere at the context's sample rate (panner.rs:39-68) */
+  const struct HrirSphere* hrtf;
 } NodeCfg;
 
 typedef struct {
@@ -1112,10 +1211,20 @@ typedef struct {
   float* last_fft_output;
   double last_fft_time;
   int has_inputs;
+  /* waveshaper oversampling: overlap of the up / down resampler per channel; channel count they were built for
+   * minus one (zero-initialised = the renderer's initial channels_x2 = channels_x4 = 1, waveshaper.rs:526-527) */
+  float *os_up_ovl, *os_dn_ovl;
+  int os_channels_m1;
+  /* HRTF panner: the last hrir_len - 1 input samples (HrtfState::prev_left_samples; left == right for a mono
+   * source), tail counter (panner.rs:682) */
+  float* hrtf_prev;
+  uint64_t hrtf_tail_counter;
 } NodeState;
 
 #define MAX_FFT_SIZE 32768
 #define RING_BUFFER_SIZE (MAX_FFT_SIZE + RQ)
+
+static const struct HrirSphere* hrir_for_rate(uint32_t sample_rate); /* HRTF panner, below */
 
 struct orc_batch {
   uint32_t n_nodes, n_edges, n_inst, n_out;
@@ -1403,8 +1512,11 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
         n->n_params = 15;
         static const float defs[15] = {0, 0, 0, 1, 0, 0, /* listener */ 0, 0, 0, 0, 0, -1, 0, 1, 0};
         for (int p = 0; p < 15; p++) param_init(&n->params[p], n_inst, defs[p], -FLT_MAX, FLT_MAX);
-        if (n->desc.i[0] == WAA_PANNING_HRTF)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "HRTF panning is out of scope (third-party hrtf crate, parity unpinned)");
+        if (n->desc.i[0] == WAA_PANNING_HRTF) {
+          n->hrtf = hrir_for_rate((uint32_t)sr);
+          if (!n->hrtf)
+            return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - HRTF panning needs the HRIR sphere (waa_hrtf_load_sphere)");
+        }
         if (n->ccmode == WAA_COUNT_MODE_MAX)
           return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count mode cannot be set to max");
         if (n->cc > 2)
@@ -1448,8 +1560,11 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
         break;
       }
       case WAA_NODE_WAVESHAPER:
-        if (n->desc.i[0] != WAA_OVERSAMPLE_NONE)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "WaveShaper oversampling is out of scope (third-party rubato, parity unpinned)");
+        n->os_factor = n->desc.i[0] == WAA_OVERSAMPLE_X2 ? 2 : n->desc.i[0] == WAA_OVERSAMPLE_X4 ? 4 : 1;
+        if (n->os_factor > 1) { /* waveshaper.rs:232-287: chunk 128 up, 128 * R down */
+          n->os_up = os_resampler_new(RQ, RQ * n->os_factor);
+          n->os_dn = os_resampler_new(RQ * n->os_factor, RQ);
+        }
         n->can_propagate_silence = 1;
         break;
       case WAA_NODE_CONVOLVER: /* convolver.rs:195-215 */
@@ -1525,6 +1640,9 @@ void orc_batch_destroy(orc_batch* b) {
       free(s->dl_ring);
       for (int p = 0; p < WAA_MAX_PARAMS; p++) free(s->pin[p]);
       free(s->last_fft_output);
+      free(s->os_up_ovl);
+      free(s->os_dn_ovl);
+      free(s->hrtf_prev);
     }
     free(b->st[k]);
   }
@@ -1557,6 +1675,8 @@ void orc_batch_destroy(orc_batch* b) {
     for (int c = 0; c < 4; c++) convir_free(n->conv_ir[c]);
     free(n->curve);
     free(n->osc_wave);
+    os_resampler_free(n->os_up);
+    os_resampler_free(n->os_dn);
   }
   free(b->nodes);
   free(b->edges);
@@ -2947,13 +3067,243 @@ static void apply_stereo_to_stereo_gain(SpatialParams p, float il, float ir, flo
     *orr = (ir + il * gr) * p.dist_gain * p.cone_gain;
   }
 }
+/* ---- HRTF panning: crate hrtf 0.8.1 restated (HrirSphere::new, sample_bilinear, HrtfProcessor::process_samples);
+ * call sites panner.rs:39-68 (load_hrtf_processor: resources/IRC_1003_C.bin, interpolation_steps = 1, block 128),
+ * :225-275 (HrtfState::process), :781-829.  PARITY UNPINNED by the reference (see the header). ---- */
+typedef struct HrirSphere {
+  uint32_t sr;  /* sample rate the HRIRs are stored at */
+  int len;      /* taps per HRIR */
+  int nv, nf;
+  uint32_t* faces; /* [nf][3] */
+  float* pos;      /* [nv][3] */
+  float *left, *right; /* [nv][len] */
+} HrirSphere;
+static HrirSphere* g_hrir_file;          /* as loaded (orc_hrtf_load_sphere) */
+static HrirSphere* g_hrir_cache[16];     /* resampled, one per sample rate (panner.rs:39-60 caches the same way) */
+static pthread_mutex_t g_hrir_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void hrir_free(HrirSphere* h) {
+  if (!h) return;
+  free(h->faces);
+  free(h->pos);
+  free(h->left);
+  free(h->right);
+  free(h);
+}
+/* The file format of the hrtf crate ("HRIR", sample rate, length, vertex count, index count : u32 LE; indices u32;
+ * per vertex x y z f32, left[length] f32, right[length] f32). */
+waa_status orc_hrtf_load_sphere(const void* data, uint64_t size) {
+  const unsigned char* d = (const unsigned char*)data;
+  if (!d || size < 20 || memcmp(d, "HRIR", 4) != 0) return fail(WAA_ERR_INVALID_ARGUMENT, "HRIR sphere: bad magic");
+  uint32_t hdr[4];
+  memcpy(hdr, d + 4, 16);
+  const uint64_t len = hdr[1], nv = hdr[2], ni = hdr[3];
+  if (len == 0 || ni % 3 != 0 || size != 20 + 4 * ni + nv * (12 + 8 * len))
+    return fail(WAA_ERR_INVALID_ARGUMENT, "HRIR sphere: inconsistent sizes");
+  HrirSphere* h = (HrirSphere*)calloc(1, sizeof *h);
+  h->sr = hdr[0];
+  h->len = (int)len;
+  h->nv = (int)nv;
+  h->nf = (int)(ni / 3);
+  h->faces = (uint32_t*)malloc(4 * ni);
+  memcpy(h->faces, d + 20, 4 * ni);
+  for (uint64_t i = 0; i < ni; i++)
+    if (h->faces[i] >= nv) {
+      hrir_free(h);
+      return fail(WAA_ERR_INVALID_ARGUMENT, "HRIR sphere: face index out of range");
+    }
+  h->pos = (float*)malloc(12 * nv);
+  h->left = (float*)malloc(4 * nv * len);
+  h->right = (float*)malloc(4 * nv * len);
+  const unsigned char* p = d + 20 + 4 * ni;
+  for (uint64_t v = 0; v < nv; v++) {
+    memcpy(h->pos + 3 * v, p, 12);
+    memcpy(h->left + v * len, p + 12, 4 * len);
+    memcpy(h->right + v * len, p + 12 + 4 * len, 4 * len);
+    p += 12 + 8 * len;
+  }
+  pthread_mutex_lock(&g_hrir_lock);
+  hrir_free(g_hrir_file);
+  g_hrir_file = h;
+  for (int i = 0; i < 16; i++) {
+    hrir_free(g_hrir_cache[i]);
+    g_hrir_cache[i] = NULL;
+  }
+  pthread_mutex_unlock(&g_hrir_lock);
+  return WAA_OK;
+}
+/* HRIRs at another sample rate.  The crate resamples every HRIR once with rubato's asynchronous sinc resampler
+ * (sinc_len 256, f_cutoff 0.95, BlackmanHarris2, 160x oversampled table + cubic interpolation), one 512-frame chunk;
+ * neither crate is available, so this is OUR definition of that step: output n is the band-limited
+ * signal at input position t_n = (n + 1) / ratio - 128 (the resampler starts half a filter length before the chunk),
+ * kernel = sinc(fc * x) * BH2(x) evaluated directly (no table), fc = 0.95 * min(1, ratio), gain fc; output n exists
+ * while t_n < len - 257 - 1/ratio (the chunk-end rule). */
+static double hrir_kernel(double x, double fc) {
+  if (fabs(x) >= 128.) return 0.;
+  const double u = (x + 128.) / 256.;
+  const double bh = 0.35875 - 0.48829 * cos(2. * M_PI * u) + 0.14128 * cos(4. * M_PI * u) - 0.01168 * cos(6. * M_PI * u);
+  const double a = M_PI * x * fc;
+  return bh * bh * (x == 0. ? 1. : sin(a) / a) * fc;
+}
+static int hrir_resampled_len(int len, double ratio) {
+  int n = 0;
+  while ((double)(n + 1) / ratio - 128. < (double)len - 257. - 1. / ratio) n++;
+  return n;
+}
+static void hrir_resample(const float* in, int len, double ratio, float* out, int out_len) {
+  const double fc = 0.95 * (ratio < 1. ? ratio : 1.);
+  for (int n = 0; n < out_len; n++) {
+    const double t = (double)(n + 1) / ratio - 128.;
+    int m0 = (int)ceil(t - 128.), m1 = (int)floor(t + 128.);
+    if (m0 < 0) m0 = 0;
+    if (m1 > len - 1) m1 = len - 1;
+    double acc = 0.;
+    for (int m = m0; m <= m1; m++) acc += (double)in[m] * hrir_kernel(t - (double)m, fc);
+    out[n] = (float)acc;
+  }
+}
+static const HrirSphere* hrir_for_rate(uint32_t sample_rate) {
+  if (sample_rate < 27000) sample_rate = 27000; /* panner.rs:46-49 */
+  pthread_mutex_lock(&g_hrir_lock);
+  const HrirSphere* res = NULL;
+  if (g_hrir_file) {
+    if (g_hrir_file->sr == sample_rate) res = g_hrir_file;
+    int slot = -1;
+    for (int i = 0; i < 16 && !res; i++) {
+      if (g_hrir_cache[i] && g_hrir_cache[i]->sr == sample_rate) res = g_hrir_cache[i];
+      if (!g_hrir_cache[i] && slot < 0) slot = i;
+    }
+    if (!res && slot >= 0) {
+      const HrirSphere* f = g_hrir_file;
+      const double ratio = (double)sample_rate / (double)f->sr;
+      HrirSphere* h = (HrirSphere*)calloc(1, sizeof *h);
+      h->sr = sample_rate;
+      h->len = hrir_resampled_len(f->len, ratio);
+      h->nv = f->nv;
+      h->nf = f->nf;
+      h->faces = (uint32_t*)malloc(12 * (size_t)f->nf);
+      memcpy(h->faces, f->faces, 12 * (size_t)f->nf);
+      h->pos = (float*)malloc(12 * (size_t)f->nv);
+      memcpy(h->pos, f->pos, 12 * (size_t)f->nv);
+      h->left = (float*)malloc(4 * (size_t)f->nv * h->len);
+      h->right = (float*)malloc(4 * (size_t)f->nv * h->len);
+      for (int v = 0; v < f->nv; v++) {
+        hrir_resample(f->left + (size_t)v * f->len, f->len, ratio, h->left + (size_t)v * h->len, h->len);
+        hrir_resample(f->right + (size_t)v * f->len, f->len, ratio, h->right + (size_t)v * h->len, h->len);
+      }
+      g_hrir_cache[slot] = h;
+      res = h;
+    }
+  }
+  pthread_mutex_unlock(&g_hrir_lock);
+  return res;
+}
+uint32_t orc_hrtf_hrir_length(float sample_rate) {
+  const HrirSphere* h = hrir_for_rate((uint32_t)sample_rate);
+  return h ? (uint32_t)h->len : 0;
+}
+/* HrirSphere::sample_bilinear: the triangle the ray from the origin along `dir` pierces, barycentric weights of the
+ * piercing point (u, v, w for the face's vertices a, b, c); out = a*u + b*v + c*w per tap, f32.  Of the faces whose
+ * plane the ray meets in front of the origin the one with the largest smallest weight is taken (= the face that
+ * contains the point; on an edge both candidates interpolate to the same HRIR). */
+static void hrir_locate(const HrirSphere* h, const float dir[3], int vtx[3], float wgt[3]) {
+  float best = -1e30f;
+  vtx[0] = vtx[1] = vtx[2] = 0;
+  wgt[0] = 1.f;
+  wgt[1] = wgt[2] = 0.f;
+  for (int f = 0; f < h->nf; f++) {
+    const float* a = h->pos + 3 * h->faces[3 * f];
+    const float* b = h->pos + 3 * h->faces[3 * f + 1];
+    const float* c = h->pos + 3 * h->faces[3 * f + 2];
+    float ba[3], ca[3], nrm[3];
+    v3_sub(b, a, ba);
+    v3_sub(c, a, ca);
+    v3_cross(ba, ca, nrm);
+    const float denom = v3_dot(dir, nrm);
+    const float num = v3_dot(a, nrm);
+    if (denom == 0.f) continue;
+    const float t = num / denom;
+    if (!(t > 0.f)) continue;
+    float pnt[3] = {dir[0] * t, dir[1] * t, dir[2] * t}, v2[3];
+    v3_sub(pnt, a, v2);
+    const float d00 = v3_dot(ba, ba), d01 = v3_dot(ba, ca), d11 = v3_dot(ca, ca), d20 = v3_dot(v2, ba), d21 = v3_dot(v2, ca);
+    const float den = d00 * d11 - d01 * d01;
+    const float v = (d11 * d20 - d01 * d21) / den;
+    const float w = (d00 * d21 - d01 * d20) / den;
+    const float u = 1.0f - v - w;
+    float m = u < v ? u : v;
+    if (w < m) m = w;
+    if (m > best) {
+      best = m;
+      for (int k = 0; k < 3; k++) vtx[k] = (int)h->faces[3 * f + k];
+      wgt[0] = u;
+      wgt[1] = v;
+      wgt[2] = w;
+    }
+  }
+}
+void orc_hrtf_sample(float sample_rate, const float* dir, float* left, float* right) {
+  const HrirSphere* h = hrir_for_rate((uint32_t)sample_rate);
+  if (!h) return;
+  int vtx[3];
+  float wgt[3];
+  hrir_locate(h, dir, vtx, wgt);
+  for (int i = 0; i < h->len; i++) {
+    left[i] = h->left[(size_t)vtx[0] * h->len + i] * wgt[0] + h->left[(size_t)vtx[1] * h->len + i] * wgt[1] +
+              h->left[(size_t)vtx[2] * h->len + i] * wgt[2];
+    right[i] = h->right[(size_t)vtx[0] * h->len + i] * wgt[0] + h->right[(size_t)vtx[1] * h->len + i] * wgt[1] +
+               h->right[(size_t)vtx[2] * h->len + i] * wgt[2];
+  }
+}
+/* HrtfProcessor::process_samples with interpolation_steps = 1 (t = 1: the HRIR and the distance gain of THIS block):
+ * out[i] = gain * sum_j hrir[j] * x[i - j], x continued into the previous blocks by prev (hrir_len - 1 samples, the
+ * raw input: overlap-save).  The crate evaluates the convolution with an FFT of block + hrir_len - 1 points (639, not
+ * a power of two; k = gain / pad_length is the inverse transform's normalisation); here: exact f64 sum, rounded once. */
+static void hrtf_process(const HrirSphere* h, float* prev, const float* source, float gain, const float dir[3], float* out_l,
+                         float* out_r) {
+  const int L = h->len;
+  float* hl = (float*)malloc(sizeof(float) * 2 * (size_t)L);
+  float* hr = hl + L;
+  int vtx[3];
+  float wgt[3];
+  hrir_locate(h, dir, vtx, wgt);
+  for (int i = 0; i < L; i++) {
+    hl[i] = h->left[(size_t)vtx[0] * L + i] * wgt[0] + h->left[(size_t)vtx[1] * L + i] * wgt[1] + h->left[(size_t)vtx[2] * L + i] * wgt[2];
+    hr[i] = h->right[(size_t)vtx[0] * L + i] * wgt[0] + h->right[(size_t)vtx[1] * L + i] * wgt[1] + h->right[(size_t)vtx[2] * L + i] * wgt[2];
+  }
+  for (int i = 0; i < RQ; i++) {
+    double al = 0., ar = 0.;
+    for (int j = 0; j < L; j++) {
+      const int k = i - j;
+      const double x = k >= 0 ? (double)source[k] : (double)prev[L - 1 + k];
+      al += (double)hl[j] * x;
+      ar += (double)hr[j] * x;
+    }
+    out_l[i] = (float)al * gain;
+    out_r[i] = (float)ar * gain;
+  }
+  /* the last hrir_len - 1 raw input samples become the history of the next block */
+  if (L - 1 <= RQ) {
+    memcpy(prev, source + RQ - (L - 1), sizeof(float) * (size_t)(L - 1));
+  } else {
+    memmove(prev, prev + RQ, sizeof(float) * (size_t)(L - 1 - RQ));
+    memcpy(prev + (L - 1 - RQ), source, sizeof(float) * RQ);
+  }
+  free(hl);
+}
+
 /* src/node/panner.rs:685-904 (equal-power branch :830-897) */
 static void process_panner(NodeCfg* n, NodeState* s, uint32_t inst, const Scope* sc) {
   const Quantum* input = &s->in;
   Quantum* output = &s->out;
   if (q_is_silent(input)) {
-    q_make_silent(output);
-    return;
+    /* the HRTF panner has a tail as long as the impulse responses; the counter is never reset (:697-711) */
+    int tail = n->hrtf && (uint64_t)n->hrtf->len > s->hrtf_tail_counter;
+    if (!tail) {
+      q_make_silent(output);
+      return;
+    }
+    s->hrtf_tail_counter += RQ;
   }
   float tmp[15][RQ];
   const float* pv[15];
@@ -2977,7 +3327,31 @@ static void process_panner(NodeCfg* n, NodeState* s, uint32_t inst, const Scope*
     sp_arr[i].cone_gain = cone_gain(n, spos, sori, lpos);
     azimuth_and_elevation(spos, lpos, lfw, lup, &sp_arr[i].azimuth, &sp_arr[i].elevation);
   }
-  if (input->n == 1) {
+  if (n->hrtf) { /* :781-829: always k-rate, the first value of every param */
+    const SpatialParams p0 = sp_arr[0];
+    const float new_distance_gain = p0.cone_gain * p0.dist_gain;
+    const float az_rad = p0.azimuth * PI_F32 / 180.f, el_rad = p0.elevation * PI_F32 / 180.f;
+    float ps[3] = {sinf(az_rad) * cosf(el_rad), sinf(el_rad), cosf(az_rad) * cosf(el_rad)}; /* x, y, z */
+    if (fabsf(ps[0]) <= 1e-6f && fabsf(ps[1]) <= 1e-6f && fabsf(ps[2]) <= 1e-6f) {
+      ps[0] = ps[1] = 0.f;
+      ps[2] = 1.f;
+    }
+    const float dir[3] = {ps[0], ps[2], ps[1]}; /* Vec3 { x: p[0], z: p[1], y: p[2] }, :246-250 */
+    q_copy(output, input);
+    float correction = 1.f;
+    if (output->n == 2) { /* stereo input: mixed down, doubled afterwards (:800-810) */
+      correction *= 2.f;
+      q_mix(output, 1, WAA_INTERP_SPEAKERS);
+    }
+    if (!s->hrtf_prev) s->hrtf_prev = (float*)calloc((size_t)n->hrtf->len, sizeof(float));
+    float ol[RQ], orr[RQ];
+    hrtf_process(n->hrtf, s->hrtf_prev, output->d[0], new_distance_gain, dir, ol, orr);
+    q_set_number_of_channels(output, 2);
+    for (int i = 0; i < RQ; i++) {
+      output->d[0][i] = correction * ol[i];
+      output->d[1][i] = correction * orr[i];
+    }
+  } else if (input->n == 1) {
     q_copy(output, input);
     q_mix(output, 2, WAA_INTERP_SPEAKERS);
     for (int i = 0; i < RQ; i++)
@@ -3002,7 +3376,7 @@ static float apply_curve(const float* curve, uint32_t nn, float input) {
   float f = v - k;
   return (1.f - f) * curve[(size_t)k] + f * curve[(size_t)(k + 1.f)];
 }
-/* src/node/waveshaper.rs:383-487 (OverSampleType::None) */
+/* src/node/waveshaper.rs:383-487 */
 static void process_waveshaper(NodeCfg* n, NodeState* s) {
   const Quantum* input = &s->in;
   Quantum* output = &s->out;
@@ -3011,11 +3385,32 @@ static void process_waveshaper(NodeCfg* n, NodeState* s) {
     return;
   }
   q_copy(output, input);
-  if (n->has_curve) {
+  if (!n->has_curve) return;
+  if (n->os_factor <= 1) { /* OverSampleType::None, :402-407 */
     for (int c = 0; c < output->n; c++) {
       output->silent[c] = 0;
       for (int i = 0; i < RQ; i++) output->d[c][i] = apply_curve(n->curve, n->curve_n, output->d[c][i]);
     }
+    return;
+  }
+  /* X2 / X4 (:408-481): up-sample, shape, down-sample; the resamplers are re-created (= their overlap is lost) when
+   * the channel count of the quantum differs from the count they were built for */
+  const int up_len = RQ * n->os_factor;
+  if (!s->os_up_ovl) {
+    s->os_up_ovl = (float*)calloc((size_t)ORC_MAXC * up_len, sizeof(float));
+    s->os_dn_ovl = (float*)calloc((size_t)ORC_MAXC * RQ, sizeof(float));
+  }
+  if (output->n != s->os_channels_m1 + 1) {
+    s->os_channels_m1 = output->n - 1;
+    memset(s->os_up_ovl, 0, sizeof(float) * (size_t)ORC_MAXC * up_len);
+    memset(s->os_dn_ovl, 0, sizeof(float) * (size_t)ORC_MAXC * RQ);
+  }
+  float up[512];
+  for (int c = 0; c < output->n; c++) {
+    os_resample_unit(n->os_up, output->d[c], up, s->os_up_ovl + (size_t)c * up_len);
+    for (int i = 0; i < up_len; i++) up[i] = apply_curve(n->curve, n->curve_n, up[i]);
+    os_resample_unit(n->os_dn, up, output->d[c], s->os_dn_ovl + (size_t)c * RQ);
+    output->silent[c] = 0;
   }
 }
 
@@ -3293,6 +3688,9 @@ waa_status orc_rewind(orc_batch* b) {
       free(s->ring);
       free(s->dl_ring);
       free(s->last_fft_output);
+      free(s->os_up_ovl);
+      free(s->os_dn_ovl);
+      free(s->hrtf_prev);
       memset(s, 0, sizeof *s);
       memcpy(s->pin, pin, sizeof pin);
       for (int p = 0; p < WAA_MAX_PARAMS; p++)

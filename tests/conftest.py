@@ -12,6 +12,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the HRIR database of the HRTF panning model: the reference embeds resources/IRC_1003_C.bin in the crate
+    # (src/node/panner.rs:55); the copy under tests/golden/ is handed to whichever library a test binds
+    import web_audio_api_rs_amd as waa
+    waa.set_hrtf_database(os.path.join(ROOT, "tests", "golden", "IRC_1003_C.bin"))
 
 
 def _oracle_path():

@@ -1,0 +1,262 @@
+"""WaveShaperNode with 2x / 4x oversampling (src/node/waveshaper.rs:290-347,409-481).
+
+The resamplers are rubato 0.16 `FftFixedInOut` (third party, not vendored): the reference's own tests only construct such
+nodes (waveshaper.rs:608-670), so sample values are PARITY UNPINNED by the reference.  What pins them here:
+
+* the written definition restated a third time, independently, in numpy f64 (`RubatoStage`
+  below) — the oracle (f32 FFTs, like the crate) and the device (matrix products) both have to match it;
+* the reference's control flow around the resamplers, which IS in the reference: a silent input with a curve that maps
+  0 to 0 skips the block and freezes the overlap (:395-400), a change of the channel count re-creates the resamplers
+  (:413-425), a curve that does not map 0 to 0 keeps processing silence (:498-509).
+"""
+import numpy as np
+import pytest
+
+import web_audio_api_rs_amd as waa
+
+SR = 44100.0
+RQ = 128
+
+
+class RubatoStage:
+    """One FftResampler stage (rubato synchro.rs), f64 except the filter taps, which the crate computes in f32."""
+
+    def __init__(self, fi, fo):
+        f32 = np.float32
+        self.fi, self.fo = fi, fo
+        cutoff = f32(0.4) ** f32(16.0 / fi) * (f32(fo) / f32(fi) if fi > fo else f32(1))
+        x = np.arange(fi, dtype=np.float32)
+        pi = f32(np.pi)
+        bh = (f32(0.35875) - f32(0.48829) * np.cos(f32(2) * pi * x / f32(fi)) + f32(0.14128) * np.cos(f32(4) * pi * x / f32(fi))
+              - f32(0.01168) * np.cos(f32(6) * pi * x / f32(fi))).astype(np.float32)
+        arg = ((x - f32(fi // 2)) * cutoff).astype(np.float32)
+        sinc = np.where(arg == 0, f32(1), np.sin(arg * pi) / np.where(arg == 0, f32(1), arg * pi)).astype(np.float32)
+        y = (bh * bh * sinc).astype(np.float32)
+        y = (y / y.sum(dtype=np.float32) / f32(2 * fi)).astype(np.float32)
+        ft = np.zeros(2 * fi)
+        ft[:fi] = y
+        self.F = np.fft.rfft(ft)
+        self.reset()
+
+    def reset(self):
+        self.overlap = np.zeros(self.fo)
+
+    def process(self, x):
+        fi, fo = self.fi, self.fo
+        X = np.fft.rfft(np.concatenate([np.asarray(x, np.float64), np.zeros(fi)]))
+        new_len = fi + 1 if fi < fo else fo
+        Z = np.zeros(fo + 1, complex)
+        Z[:new_len] = X[:new_len] * self.F[:new_len]
+        ob = np.fft.irfft(Z, 2 * fo) * (2 * fo)
+        out = ob[:fo] + self.overlap
+        self.overlap = ob[fo:].copy()
+        return out
+
+
+def apply_curve(curve, x):
+    """waveshaper.rs:555-573 in f64."""
+    n = len(curve)
+    v = (n - 1) / 2.0 * (np.asarray(x, np.float64) + 1.0)
+    k = np.clip(np.floor(v), 0, n - 2).astype(int)
+    f = v - k
+    out = (1 - f) * curve[k] + f * curve[k + 1]
+    out = np.where(v <= 0, curve[0], out)
+    return np.where(v >= n - 1, curve[n - 1], out)
+
+
+def definition_render(x, curve, factor, active=None, can_propagate=True):
+    """One channel through up -> curve -> down, quantum by quantum; `active[q]` False = silent input quantum."""
+    nq = len(x) // RQ
+    up, dn = RubatoStage(RQ, RQ * factor), RubatoStage(RQ * factor, RQ)
+    out = np.zeros(nq * RQ)
+    c = np.asarray(curve, np.float64)
+    for q in range(nq):
+        if active is not None and not active[q] and can_propagate:
+            continue
+        blk = x[q * RQ:(q + 1) * RQ] if (active is None or active[q]) else np.zeros(RQ)
+        out[q * RQ:(q + 1) * RQ] = dn.process(apply_curve(c, up.process(blk)))
+    return out
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+TANH = np.tanh(np.linspace(-3, 3, 257)).astype(np.float32)
+
+
+def shaper_graph(be, noise, curve, oversample, length, start=0.0, stop=None, sr=SR, n_out=None):
+    n_inst, n_ch, _ = noise.shape
+    ctx = waa.OfflineAudioContext(n_out or n_ch, length, sr, n_instances=n_inst, binding=be)
+    src = ctx.create_buffer_source()
+    src.set_buffer_batch(noise, sr)
+    ws = ctx.create_wave_shaper(curve=curve, oversample=oversample)
+    src.connect(ws).connect(ctx.destination())
+    src.start_at(start)
+    if stop is not None:
+        src.stop_at(stop)
+    return ctx
+
+
+# ---- the reference's own tests (construct + render, waveshaper.rs:608-670) -----------------------------------
+def test_user_defined_options(be):
+    ctx = waa.OfflineAudioContext(2, 555, SR, binding=be)
+    shaper = ctx.create_wave_shaper(curve=[1.0], oversample="2x")
+    out = ctx.start_rendering_sync()
+    assert shaper.oversample == "2x" and list(shaper.curve) == [1.0]
+    assert out.data.shape == (1, 2, 555)
+
+
+def test_change_none_for_curve_after_build(be):
+    ctx = waa.OfflineAudioContext(2, 555, SR, binding=be)
+    shaper = ctx.create_wave_shaper(oversample="2x")
+    shaper.set_curve([2.0])
+    shaper.set_oversample("4x")
+    ctx.start_rendering_sync()
+    assert shaper.oversample == "4x" and list(shaper.curve) == [2.0]
+
+
+def test_curve_twice_is_an_error(be):
+    ctx = waa.OfflineAudioContext(2, 555, SR, binding=be)
+    shaper = ctx.create_wave_shaper(curve=[1.0], oversample="2x")
+    with pytest.raises(waa.WaaError):
+        shaper.set_curve([2.0])
+
+
+# ---- the definition ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("oversample,factor", [("2x", 2), ("4x", 4)])
+@pytest.mark.parametrize("n_ch", [1, 2])
+def test_matches_the_written_definition(be, oversample, factor, n_ch):
+    nq = 12
+    length = nq * RQ - 37  # (a truncated last quantum)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (2, n_ch, nq * RQ)).astype(np.float32)
+    out = shaper_graph(be, x, TANH, oversample, length).start_rendering_sync().data
+    for i in range(2):
+        for c in range(n_ch):
+            ref = definition_render(x[i, c], TANH, factor)[:length]
+            assert rms(out[i, c], ref) <= 1e-6, (i, c, rms(out[i, c], ref))
+
+
+@pytest.mark.parametrize("oversample,factor", [("2x", 2), ("4x", 4)])
+def test_latency_is_one_render_quantum(be, oversample, factor):
+    """Both stages are linear-phase FIRs of fft_size_in taps: together 128 frames at the context rate — a 440 Hz tone
+    through a straight-line curve comes back one render quantum late (the comment at waveshaper.rs:483 says otherwise)."""
+    n = 20 * RQ
+    t = np.arange(n) / SR
+    x = (0.5 * np.sin(2 * np.pi * 440.0 * t)).astype(np.float32)[None, None, :]
+    line = np.linspace(-1.0, 1.0, 1025).astype(np.float32)
+    out = shaper_graph(be, x, line, oversample, n).start_rendering_sync().data[0, 0]
+    assert np.abs(out[3 * RQ:] - x[0, 0, 2 * RQ:-RQ]).max() < 1e-3
+    assert np.abs(out[3 * RQ:] - x[0, 0, 3 * RQ:]).max() > 1e-2  # (not un-delayed)
+
+
+# ---- the control flow the reference wraps around the resamplers ------------------------------------------------
+def test_silent_input_freezes_the_overlap(be):
+    """Start late and stop early: the blocks before / after are skipped (waveshaper.rs:395-400) — the tail the two
+    overlap-add stages still hold when the source stops is never flushed."""
+    nq = 16
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, (1, 1, 6 * RQ)).astype(np.float32)
+    start, stop = 3 * RQ / SR, 9 * RQ / SR - 1e-9
+    out = shaper_graph(be, x, TANH, "2x", nq * RQ, start=start, stop=stop).start_rendering_sync().data[0, 0]
+    active = [3 <= q < 9 for q in range(nq)]
+    xin = np.zeros(nq * RQ)
+    xin[3 * RQ:9 * RQ] = x[0, 0]
+    ref = definition_render(xin, TANH, 2, active=active)
+    assert rms(out, ref) <= 1e-6
+    assert np.all(out[9 * RQ:] == 0.0) and np.all(out[:3 * RQ] == 0.0)
+    # ... whereas a flushed tail would be far above the tolerance:
+    assert rms(definition_render(xin, TANH, 2), ref) > 1e-3
+
+
+def test_curve_that_does_not_map_zero_to_zero_keeps_processing(be):
+    curve = (TANH + np.float32(0.25)).astype(np.float32)
+    nq = 10
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (1, 1, 4 * RQ)).astype(np.float32)
+    out = shaper_graph(be, x, curve, "4x", nq * RQ, start=2 * RQ / SR).start_rendering_sync().data[0, 0]
+    xin = np.zeros(nq * RQ)
+    xin[2 * RQ:6 * RQ] = x[0, 0]
+    ref = definition_render(xin, curve, 4, active=[2 <= q < 6 for q in range(nq)], can_propagate=False)
+    assert rms(out, ref) <= 1e-6
+    assert abs(out[-1] - 0.25) < 1e-3
+
+
+def _two_source_graph(be, a, b_, curve, oversample, length, start_b):
+    ctx = waa.OfflineAudioContext(2, length, SR, n_instances=a.shape[0], binding=be)
+    sa, sb = ctx.create_buffer_source(), ctx.create_buffer_source()
+    sa.set_buffer_batch(a, SR)
+    sb.set_buffer_batch(b_, SR)
+    ws = ctx.create_wave_shaper(curve=curve, oversample=oversample)
+    sa.connect(ws)
+    sb.connect(ws)
+    ws.connect(ctx.destination())
+    sa.start()
+    sb.start_at(start_b)
+    return ctx
+
+
+@pytest.mark.parametrize("oversample,factor", [("2x", 2), ("4x", 4)])
+def test_gap_between_two_sources(be, oversample, factor):
+    """Two sources into one shaper with a silent gap in between (not a single source: the device takes its exact
+    per-quantum codes path): the first source's tail is added to the first block of the second."""
+    nq = 14
+    rng = np.random.default_rng(13)
+    a = rng.uniform(-1, 1, (2, 1, 4 * RQ)).astype(np.float32)
+    b_ = rng.uniform(-1, 1, (2, 1, 3 * RQ)).astype(np.float32)
+    out = _two_source_graph(be, a, b_, TANH, oversample, nq * RQ, 8 * RQ / SR).start_rendering_sync().data
+    for i in range(2):
+        xin = np.zeros(nq * RQ)
+        xin[:4 * RQ] = a[i, 0]
+        xin[8 * RQ:11 * RQ] = b_[i, 0]
+        active = [q < 4 or 8 <= q < 11 for q in range(nq)]
+        ref = definition_render(xin, TANH, factor, active=active)
+        for c in range(2):  # (mono graph, up-mixed by the destination)
+            assert rms(out[i, c], ref) <= 1e-6
+
+
+def test_channel_count_change_recreates_the_resamplers(be):
+    """A mono source from t = 0 and a stereo source that starts later: when the quantum turns stereo the resamplers are
+    built anew (waveshaper.rs:413-425) — channel 0 loses its overlap at that quantum."""
+    nq = 12
+    rng = np.random.default_rng(17)
+    a = rng.uniform(-1, 1, (1, 1, nq * RQ)).astype(np.float32)
+    b_ = rng.uniform(-1, 1, (1, 2, 4 * RQ)).astype(np.float32)
+    out = _two_source_graph(be, a, b_, TANH, "2x", nq * RQ, 5 * RQ / SR).start_rendering_sync().data[0]
+    # mono quanta 0..4, stereo 5..8 (mono a up-mixed + b), mono again from 9
+    segs = [(0, 5), (5, 9), (9, nq)]
+    ref = np.zeros((2, nq * RQ))
+    for (q0, q1) in segs:
+        stereo = q0 == 5
+        for c in range(2):
+            xin = a[0, 0, q0 * RQ:q1 * RQ].astype(np.float64)
+            if stereo:
+                xin = (a[0, 0, q0 * RQ:q1 * RQ] + b_[0, c, :(q1 - q0) * RQ]).astype(np.float32).astype(np.float64)
+            ref[c, q0 * RQ:q1 * RQ] = definition_render(xin, TANH, 2)
+    assert rms(out[0], ref[0]) <= 1e-6 and rms(out[1], ref[1]) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_oversample_many_instances_sampled(hip, orc):
+    """C5-shaped batch (256 contexts x 2 s, stereo, per-instance start times) on the device, sampled instances against
+    the oracle."""
+    n_inst, nq = 256, 750
+    rng = np.random.default_rng(23)
+    x = rng.uniform(-1, 1, (n_inst, 2, nq * RQ)).astype(np.float32)
+    sample = [0, 1, 77, 255]
+    outs = []
+    for be, idx in ((hip, None), (orc, sample)):
+        noise = x if idx is None else x[idx]
+        ctx = waa.OfflineAudioContext(2, nq * RQ, 48000.0, n_instances=noise.shape[0], binding=be)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(noise, 48000.0)
+        ws = ctx.create_wave_shaper(curve=TANH, oversample="2x")
+        src.connect(ws).connect(ctx.destination())
+        for k in range(noise.shape[0]):
+            inst = k if idx is None else idx[k]
+            src.start_at((inst % 7) * 0.01, instance=k)
+        outs.append(ctx.start_rendering_sync().data)
+    for k, inst in enumerate(sample):
+        for c in range(2):
+            assert rms(outs[0][inst, c], outs[1][k, c]) <= 1e-6

@@ -360,9 +360,17 @@ def test_panner_equal_power_stereo_to_stereo(be):
     assert np.max(np.abs(o[0] - 0.2)) <= 1e-3 and np.max(np.abs(o[1])) <= 1e-3
 
 
-def test_panner_hrtf_out_of_scope(be):
-    c = ctx(be, 2, RQ, 44100.0)
-    c.create_panner(panning_model="HRTF")
+def test_panner_hrtf_in_a_feedback_loop_is_out_of_scope(be):
+    """HRTF panning itself is rendered (tests/test_hrtf.py); inside a feedback loop the product refuses it (status 4)."""
+    if be.prefix == "orc_":
+        pytest.skip("the oracle renders quantum by quantum and has no such limit")
+    c = ctx(be, 2, 8 * RQ, 44100.0)
+    s = c.create_constant_source()
+    s.start()
+    p = c.create_panner(panning_model="HRTF")
+    d = c.create_delay(1.0, delay_time=0.01)
+    s.connect(p).connect(d).connect(p)
+    d.connect(c.destination())
     with pytest.raises(waa.WaaError) as e:
         c.start_rendering_sync()
     assert e.value.status == 4
@@ -629,14 +637,6 @@ def test_waveshaper(be):
     s.start_at(0.0)
     o = c.start_rendering_sync().data[0, 0]
     assert np.array_equal(o, (x / np.float32(2.0)).astype(np.float32))
-
-
-def test_waveshaper_oversample_out_of_scope(be):
-    c = ctx(be, 1, RQ, 44100.0)
-    c.create_wave_shaper(oversample="2x")
-    with pytest.raises(waa.WaaError) as e:
-        c.start_rendering_sync()
-    assert e.value.status == 4
 
 
 # ----------------------------------------------------------------------------- convolver

@@ -119,6 +119,9 @@ ABI = {
     "analyser_get_byte_frequency_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32]),
     "analyser_get_float_time_domain_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FP, C.c_uint32]),
     "analyser_get_byte_time_domain_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32]),
+    "hrtf_load_sphere": (C.c_int32, [C.c_char_p, C.c_uint64]),
+    "hrtf_hrir_length": (C.c_uint32, [C.c_float]),
+    "hrtf_sample": (None, [C.c_float, _FP, _FP, _FP]),
     "buffer_resample": (C.c_uint64, [_FP, C.c_uint64, C.c_float, C.c_float, _FP, C.c_uint64]),
     "biquad_frequency_response": (C.c_int32, [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _FP,
                                               _FP, _FP, C.c_uint32]),
@@ -893,6 +896,8 @@ class OfflineAudioContext:
             edges[k].from_, edges[k].from_output, edges[k].to, edges[k].to_input = f, fo, t, ti
         g = GraphDesc(n, nodes, m, edges)
         h = _VP()
+        if any(getattr(nd, "panning_model", None) == "HRTF" for nd in self._nodes):
+            ensure_hrtf_database(self._b)
         self._b.check(self._b.batch_create(C.byref(g), self.n_instances, self.number_of_channels, self.length,
                                            self.sample_rate, self.device, C.byref(h)))
         self._handle = h
@@ -984,4 +989,41 @@ def resample(binding: Binding, data, source_sample_rate: float, target_sample_ra
     out = np.empty((data.shape[0], n), np.float32)
     for c in range(data.shape[0]):
         binding.buffer_resample(_fp(data[c]), data.shape[1], source_sample_rate, target_sample_rate, _fp(out[c]), n)
+    return out
+
+
+# ---- HRTF database (src/node/panner.rs:39-68) --------------------------------------------------------------
+# The reference embeds resources/IRC_1003_C.bin in the crate (`include_bytes!`); a library behind the C ABI gets the
+# same bytes through waa_hrtf_load_sphere, once per process.  `set_hrtf_database` names the file (or the bytes) this
+# mirror hands over the first time a context with an HRTF PannerNode is built.
+_HRTF_DATABASE = None
+_HRTF_LOADED = set()
+
+
+def set_hrtf_database(path_or_bytes):
+    global _HRTF_DATABASE
+    if isinstance(path_or_bytes, (bytes, bytearray)):
+        _HRTF_DATABASE = bytes(path_or_bytes)
+    else:
+        with open(path_or_bytes, "rb") as f:
+            _HRTF_DATABASE = f.read()
+    _HRTF_LOADED.clear()
+
+
+def ensure_hrtf_database(binding: Binding):
+    if id(binding.lib) in _HRTF_LOADED:
+        return
+    if _HRTF_DATABASE is None:
+        raise WaaError(3, "InvalidStateError - HRTF panning needs the HRIR sphere: call set_hrtf_database(path) first")
+    binding.check(binding.hrtf_load_sphere(_HRTF_DATABASE, len(_HRTF_DATABASE)))
+    _HRTF_LOADED.add(id(binding.lib))
+
+
+def hrtf_sample(binding: Binding, sample_rate: float, direction) -> np.ndarray:
+    """hrtf::HrirSphere::sample_bilinear (test hook): [2, taps] left / right HRIR for a direction (sphere coordinates)."""
+    ensure_hrtf_database(binding)
+    n = int(binding.hrtf_hrir_length(sample_rate))
+    out = np.zeros((2, n), np.float32)
+    d = _f32(direction)
+    binding.hrtf_sample(sample_rate, _fp(d), _fp(out[0]), _fp(out[1]))
     return out

@@ -107,8 +107,8 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
       case WAA_NODE_PANNER: {
         static const float defs[15] = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, -1, 0, 1, 0};
         for (int p = 0; p < 15; p++) P(p).init(n_inst, defs[p], -FLT_MAX, FLT_MAX);
-        if (n.desc.i[0] == WAA_PANNING_HRTF)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "HRTF panning is out of scope (third-party hrtf crate, parity unpinned)");
+        if (n.desc.i[0] == WAA_PANNING_HRTF && !hrtf_sphere_loaded())  // (the reference embeds the database in the crate)
+          return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - HRTF panning needs the HRIR sphere (waa_hrtf_load_sphere)");
         if (n.mode == WAA_COUNT_MODE_MAX)
           return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - PannerNode channel count mode cannot be set to max");
         if (n.cc > 2)
@@ -136,8 +136,7 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
         P(WAA_PARAM_DELAY_DELAY_TIME).init(n_inst, 0.f, 0.f, (float)n.desc.d[0]);
         break;
       case WAA_NODE_WAVESHAPER:
-        if (n.desc.i[0] != WAA_OVERSAMPLE_NONE)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "WaveShaper oversampling is out of scope (third-party rubato, parity unpinned)");
+        if (n.desc.i[0] < WAA_OVERSAMPLE_NONE || n.desc.i[0] > WAA_OVERSAMPLE_X4) return fail(WAA_ERR_INVALID_ARGUMENT, "bad oversample type");
         break;
       case WAA_NODE_CONVOLVER:
         if (n.cc > 2)
@@ -604,6 +603,9 @@ waa_status waa_render(waa_batch* b) {
       case 11: e = timed(st.profile_slot, [&] { launch_conv_codes(st.ccode, b->stream); }); break;
       case 13: e = timed(st.profile_slot, [&] { launch_panner_geom(st.geom, b->stream); }); break;
       case 14: e = timed(st.profile_slot, [&] { launch_timeline(st.tl, b->stream); }); break;
+      case 15: e = timed(st.profile_slot, [&] { launch_link(st.link, b->stream); }); break;
+      case 16: e = timed(st.profile_slot, [&] { launch_qgemm(st.qgemm, b->stream); }); break;
+      case 17: e = timed(st.profile_slot, [&] { launch_hrtf(st.hrtf, b->stream); }); break;
       case 12:
         if (st.hp.coefs) e = timed(st.profile_slot, [&] { launch_biquad_hp(st.hp, b->stream); });
         break;

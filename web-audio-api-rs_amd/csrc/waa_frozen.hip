@@ -1,0 +1,295 @@
+// waa_frozen.hip — the two node kinds whose render state FREEZES while they do not process, rendered node-major:
+//
+//   * WaveShaperNode with 2x / 4x oversampling (waveshaper.rs:395-481): up-sample the quantum (rubato FftFixedInOut,
+//     third party), apply the curve, down-sample.  A silent input (with a curve that maps 0 to 0) skips the whole
+//     block — the resamplers' overlap is NOT flushed, it is added to the next block that is processed; a change of the
+//     quantum's channel count re-creates the resamplers (overlap lost).
+//   * PannerNode with the HRTF panning model (panner.rs:697-711,781-829): an FIR with a per-quantum impulse response
+//     whose history is the input of the quanta the node PROCESSED (silent quanta after the tail counter ran out are
+//     skipped and leave no trace in the history).
+//
+// link_kernel replays that control flow once per instance over the per-quantum codes of the node's input and leaves
+// a `prev` table; everything else is parallel over (instance, quantum):
+//   qgemm_kernel — both resampling stages are LINEAR maps of (this block, previous processed block), i.e. matrix
+//                  products over render quanta: f32 FMA GEMM, 128 x 128 tile, register-blocked 8 x 8.
+//   hrtf_kernel  — direct-form FIR, one wavefront per (instance, quantum), sliding register window.
+// No MFMA: the matrices are f32 and the reference's tolerance (1e-6 RMS) rules out the reduced-precision matrix
+// formats; f32 MFMA has the same peak as the vector FMA pipe on this part.
+#include <hip/hip_runtime.h>
+
+#include "waa_internal.hpp"
+
+namespace waa {
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void link_kernel(const LinkDesc d) {
+  const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= d.n_inst) return;
+  const uint8_t* in = d.in_code + (uint64_t)inst * d.code_stride;
+  uint8_t* out = d.out_code ? d.out_code + (uint64_t)inst * d.code_stride : nullptr;
+  int32_t* prev = d.prev + (uint64_t)inst * d.prev_stride;
+  int32_t last = LINK_FRESH;
+  if (d.kind == 0) {
+    // WaveShaperRenderer::process, X2 / X4 (waveshaper.rs:395-400, 409-425): channels_x2 starts at 1 (:526-527)
+    int cur_ch = 1;
+    for (uint32_t q = 0; q < d.n_quanta; q++) {
+      const uint32_t c = in[q];
+      const bool silent = (c & CODE_SILENT) != 0;
+      if (silent && d.can_propagate_silence) {
+        prev[q] = LINK_SKIP;
+        if (out) out[q] = (uint8_t)(1u | CODE_SILENT);
+        continue;
+      }
+      const int nch = silent ? 1 : (int)(c & 7u);
+      if (nch != cur_ch) {  // the resamplers are re-created for the new channel count: their overlap is gone
+        cur_ch = nch;
+        last = LINK_FRESH;
+      }
+      prev[q] = last;
+      last = (int32_t)q;
+      if (out) out[q] = (uint8_t)nch;
+    }
+  } else {
+    // PannerRenderer::process, HRTF (panner.rs:697-711): the tail counter only ever grows
+    uint64_t tail_counter = 0;
+    for (uint32_t q = 0; q < d.n_quanta; q++) {
+      const uint32_t c = in[q];
+      if (c & CODE_SILENT) {
+        if (!((uint64_t)d.tail_frames > tail_counter)) {
+          prev[q] = LINK_SKIP;
+          if (out) out[q] = (uint8_t)(1u | CODE_SILENT);
+          continue;
+        }
+        tail_counter += RQ;
+      }
+      prev[q] = last;
+      last = (int32_t)q;
+      if (out) out[q] = (uint8_t)2u;
+    }
+  }
+}
+void launch_link(const LinkDesc& d, void* stream) {
+  hipLaunchKernelGGL(link_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDA = BM + 4, LDB = BN + 4;  // padded LDS rows (bank spread of the transposing stores)
+
+__device__ __forceinline__ float shape_curve(const float* curve, int nn, float input) {  // waveshaper.rs:555-573
+  if (nn == 0) return 0.f;
+  const float n = (float)nn;
+  const float v = (n - 1.f) / 2.0f * (input + 1.f);
+  if (v <= 0.f) return load_global(curve);
+  if (v >= n - 1.f) return load_global(curve + nn - 1);
+  const float k = floorf(v);
+  const float f = v - k;
+  const int ki = (int)k;
+  return (1.f - f) * load_global(curve + ki) + f * load_global(curve + ki + 1);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void qgemm_kernel(const QGemmDesc d) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+  __shared__ int32_t prev_s[BN];
+  const int tid = threadIdx.x;
+  const int ty = tid & 15;   // row group: rows ty * 4 + {0..3} and 64 + ty * 4 + {0..3} of the tile
+  const int tx = tid >> 4;   // column group: columns tx * 4 + {0..3} and 64 + tx * 4 + {0..3}
+  const uint32_t q0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const uint32_t inst = blockIdx.z / (uint32_t)d.nch, ch = blockIdx.z % (uint32_t)d.nch;
+  const float* src = d.src + (uint64_t)inst * d.src_inst + (uint64_t)ch * d.src_ch;
+  if (tid < BN) {
+    const uint32_t q = q0 + tid;
+    prev_s[tid] = q < d.n_quanta ? load_global(d.prev + (uint64_t)inst * d.prev_stride + q) : LINK_SKIP;
+  }
+  __syncthreads();
+  const int K = 2 * d.Kh;
+  // global -> register staging: A tile BK x BM = 512 float4 (2 per thread), B tile BN columns x 4 float4 (2 per thread)
+  f4v ra[2], rb[2];
+  auto fetch = [&](int kk) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int idx = tid + i * 256;
+      const int ak = idx >> 5, am = (idx & 31) * 4;  // 32 float4 per A row
+      ra[i] = load_global_f4(d.A + (uint64_t)(kk + ak) * d.M + m0 + am);
+      const int col = idx >> 2, part = idx & 3;
+      const uint32_t q = q0 + col;
+      const int32_t p = prev_s[col];
+      const bool second = kk >= d.Kh;
+      const int32_t sq = second ? p : (int32_t)q;
+      f4v v = {0.f, 0.f, 0.f, 0.f};
+      if (p != LINK_SKIP && sq >= 0)
+        v = load_global_f4(src + (uint64_t)sq * d.src_q + (uint64_t)((second ? kk - d.Kh : kk) + part * 4));
+      rb[i] = v;
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int idx = tid + i * 256;
+      const int ak = idx >> 5, am = (idx & 31) * 4;
+      *reinterpret_cast<f4v*>(&As[buf][ak][am]) = ra[i];
+      const int col = idx >> 2, part = idx & 3;
+      Bs[buf][part * 4 + 0][col] = rb[i].x;
+      Bs[buf][part * 4 + 1][col] = rb[i].y;
+      Bs[buf][part * 4 + 2][col] = rb[i].z;
+      Bs[buf][part * 4 + 3][col] = rb[i].w;
+    }
+  };
+  float acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[i][j] = 0.f;
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kk = 0; kk < K; kk += BK) {
+    const bool more = kk + BK < K;
+    if (more) fetch(kk + BK);
+#pragma unroll
+    for (int k = 0; k < BK; k++) {
+      const f4v a0 = *reinterpret_cast<const f4v*>(&As[buf][k][ty * 4]);
+      const f4v a1 = *reinterpret_cast<const f4v*>(&As[buf][k][64 + ty * 4]);
+      const f4v b0 = *reinterpret_cast<const f4v*>(&Bs[buf][k][tx * 4]);
+      const f4v b1 = *reinterpret_cast<const f4v*>(&Bs[buf][k][64 + tx * 4]);
+      const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = __builtin_fmaf(a[i], bb[j], acc[i][j]);
+    }
+    if (more) {
+      stage(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  // epilogue: column j of the thread = quantum q0 + (j < 4 ? tx * 4 + j : 64 + tx * 4 + j - 4); rows in two float4
+  float* dst = d.dst + (uint64_t)inst * d.dst_inst + (uint64_t)ch * d.dst_ch;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int col = (j < 4 ? tx * 4 + j : 64 + tx * 4 + (j - 4));
+    const uint32_t q = q0 + col;
+    if (q >= d.n_quanta) continue;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      f4v v = {acc[h * 4 + 0][j], acc[h * 4 + 1][j], acc[h * 4 + 2][j], acc[h * 4 + 3][j]};
+      if (d.curve) {
+        v.x = shape_curve(d.curve, d.curve_n, v.x);
+        v.y = shape_curve(d.curve, d.curve_n, v.y);
+        v.z = shape_curve(d.curve, d.curve_n, v.z);
+        v.w = shape_curve(d.curve, d.curve_n, v.w);
+      }
+      *(WAA_GLOBAL_AS f4v*)(dst + (uint64_t)q * d.dst_q + m0 + h * 64 + ty * 4) = v;
+    }
+  }
+}
+void launch_qgemm(const QGemmDesc& d, void* stream) {
+  dim3 grid((d.n_quanta + BN - 1) / BN, d.M / BM, d.n_inst * (uint32_t)d.nch);
+  hipLaunchKernelGGL(qgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// HRTF FIR.  Workgroup = 4 wavefronts, each renders one (instance, quantum): lanes 0..31 the left ear, 32..63 the
+// right ear, four consecutive output frames per lane.  LDS per wavefront: the mono input window xw[O + 128] (O = taps
+// rounded up to 4: positions -O .. 127 relative to the quantum) and the interpolated HRIR pair h[2][O].
+__global__ __launch_bounds__(256) void hrtf_kernel(const HrtfDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int O = (d.taps + 3) & ~3;
+  float* xw = lds + (size_t)wave * (size_t)(3 * O + RQ);
+  float* hh = xw + O + RQ;  // [2][O]
+  const uint32_t inst = blockIdx.y;
+  const uint32_t q = blockIdx.x * 4 + wave;
+  const bool in_range = q < d.n_quanta;
+  const int32_t* prev = d.prev + (uint64_t)inst * d.prev_stride;
+  const uint8_t* code = d.in_code + (uint64_t)inst * d.code_stride;
+  const int32_t link = in_range ? load_global(prev + q) : LINK_SKIP;
+  const bool process = link != LINK_SKIP;
+  float gain = 0.f, corr = 1.f;
+  if (process) {
+    const HrtfQ* rec = d.table + (uint64_t)(d.rows == 1 ? 0 : inst) * d.per_row + (d.per_row == 1 ? 0 : q);
+    const int v0 = load_global(&rec->v[0]), v1 = load_global(&rec->v[1]), v2 = load_global(&rec->v[2]);
+    const float w0 = load_global(&rec->w[0]), w1 = load_global(&rec->w[1]), w2 = load_global(&rec->w[2]);
+    gain = load_global(&rec->gain);
+    // HrirSphere::sample_bilinear: a * u + b * v + c * w per tap, f32, in this order
+    const float* pa = d.hrir + (uint64_t)v0 * 2 * d.taps;
+    const float* pb = d.hrir + (uint64_t)v1 * 2 * d.taps;
+    const float* pc = d.hrir + (uint64_t)v2 * 2 * d.taps;
+    for (int i = lane; i < 2 * O; i += 64) {
+      const int ear = i >= O, t = ear ? i - O : i;
+      float v = 0.f;
+      if (t < d.taps) {
+        const int o = ear * d.taps + t;
+        v = load_global(pa + o) * w0 + load_global(pb + o) * w1 + load_global(pc + o) * w2;
+      }
+      hh[i] = v;
+    }
+    // input window: this quantum and, through the prev links, the quanta processed before it
+    const float* src = d.in.base + (uint64_t)inst * d.in.inst_stride;
+    int32_t qe = (int32_t)q;
+    for (int e = 0; e * RQ < O + RQ; e++) {  // element e covers positions [-e * 128, -e * 128 + 128)
+      float m0 = 0.f, m1 = 0.f;
+      if (qe >= 0) {
+        const uint32_t c = load_global(code + qe);
+        if (!(c & CODE_SILENT)) {
+          const uint64_t f = (uint64_t)qe * RQ;
+          m0 = load_global(src + f + lane);
+          m1 = load_global(src + f + 64 + lane);
+          if ((c & 7u) >= 2) {  // stereo input: mixed down (quantum.rs:387-397), doubled after the convolution
+            m0 = 0.5f * (m0 + load_global(src + d.in.ch_stride + f + lane));
+            m1 = 0.5f * (m1 + load_global(src + d.in.ch_stride + f + 64 + lane));
+          }
+        }
+        if (e == 0) corr = (!(c & CODE_SILENT) && (c & 7u) >= 2) ? 2.f : 1.f;
+      }
+      const int p0 = O - e * RQ + lane, p1 = p0 + 64;
+      if (p0 >= 0) xw[p0] = m0;
+      if (p1 >= 0) xw[p1] = m1;
+      if (qe >= 0) qe = load_global(prev + qe);  // LINK_FRESH (-1): nothing before it -> zeros
+    }
+  }
+  __syncthreads();
+  float* out = d.out.base + (uint64_t)inst * d.out.inst_stride;
+  const int ear = lane >> 5, n0 = (lane & 31) * 4;
+  if (!in_range) return;
+  f4v res = {0.f, 0.f, 0.f, 0.f};
+  if (process) {
+    const float* h = hh + ear * O;
+    const int b = O + n0;  // xw index of output frame n0 at tap 0
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    f4v cur = *reinterpret_cast<const f4v*>(xw + b);  // x[b .. b + 3]
+    for (int g = 0; g < O / 4; g++) {
+      const f4v nxt = *reinterpret_cast<const f4v*>(xw + b - 4 * g - 4);  // x[b - 4g - 4 .. b - 4g - 1]
+      const f4v hv = *reinterpret_cast<const f4v*>(h + 4 * g);
+      const float win[7] = {nxt.y, nxt.z, nxt.w, cur.x, cur.y, cur.z, cur.w};  // x[b - 4g - 3 .. b - 4g + 3]
+      const float ht[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = __builtin_fmaf(ht[t], win[3 + r - t], acc[r]);
+      cur = nxt;
+    }
+    res.x = acc[0] * gain * corr;
+    res.y = acc[1] * gain * corr;
+    res.z = acc[2] * gain * corr;
+    res.w = acc[3] * gain * corr;
+  }
+  *(WAA_GLOBAL_AS f4v*)(out + (uint64_t)ear * d.out.ch_stride + (uint64_t)q * RQ + n0) = res;
+}
+void launch_hrtf(const HrtfDesc& d, void* stream) {
+  const int O = (d.taps + 3) & ~3;
+  const size_t lds = (size_t)4 * (size_t)(3 * O + RQ) * sizeof(float);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hrtf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  dim3 grid((d.n_quanta + 3) / 4, d.n_inst);
+  hipLaunchKernelGGL(hrtf_kernel, grid, dim3(256), lds, (hipStream_t)stream, d);
+}
+
+}  // namespace waa

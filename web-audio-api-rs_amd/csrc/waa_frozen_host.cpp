@@ -1,0 +1,470 @@
+// waa_frozen_host.cpp — host side of the WaveShaper's 2x / 4x oversampling and of the HRTF panning model: the written
+// definitions of the two third-party algorithms (rubato 0.16 FftFixedInOut, hrtf 0.8.1) turned
+// into the tables the kernels of waa_frozen.hip consume, and the planning of their steps.
+#include <array>
+#include <mutex>
+
+#include "waa_host.hpp"
+
+namespace waa {
+namespace host {
+
+int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr);
+
+// ===============================================================================================================
+// WaveShaper oversampling.  One rubato FftResampler stage (synchro.rs), fft_size_in = fi, fft_size_out = fo:
+//   x[0..fi) zero-padded to 2 fi -> real FFT -> bins [0, new_len) times the filter spectrum F, the rest zero
+//   (new_len = fi + 1 when up-sampling, fo when down-sampling) -> inverse real FFT of 2 fo points (unnormalised; F
+//   carries the 1 / (2 fi)) -> the first fo samples plus the overlap kept from the previous call are the output, the
+//   last fo samples the new overlap.
+// F is the spectrum of a windowed sinc of fi taps: cutoff 0.4^(16 / fi) (times fo / fi when down-sampling), window
+// BlackmanHarris squared, normalised to unit sum — evaluated in f32 like the crate does (that IS the filter), then
+// everything downstream in f64.  The stage is linear and time-invariant per block:
+//   out_buf[m] = sum_j x[j] * phi[(m * fm / fo - j * fm / fi) mod 2 fm],   fm = max(fi, fo),
+//   phi[p] = sum_{k < new_len} c_k Re(F[k] exp(2 pi i k p / (2 fm))),  c_0 = 1, c_k = 2,
+// which is what the device multiplies with: A[k][m] (k < fi) = the response of output frame m to input frame k of the
+// SAME block, A[fi + k][m] = the response of frame m to input frame k of the PREVIOUS processed block (its overlap).
+static std::vector<float> rubato_filter_taps(int fi, int fo) {
+  const float cutoff = fi > fo ? std::pow(0.4f, 16.0f / (float)fi) * (float)fo / (float)fi : std::pow(0.4f, 16.0f / (float)fi);
+  const float pi = 3.14159265358979323846f;
+  const float pi2 = 2.f * pi, pi4 = 4.f * pi, pi6 = 6.f * pi, np = (float)fi;
+  std::vector<float> y((size_t)fi);
+  float sum = 0.f;
+  for (int x = 0; x < fi; x++) {
+    const float xf = (float)x;
+    const float bh = 0.35875f - 0.48829f * std::cos(pi2 * xf / np) + 0.14128f * std::cos(pi4 * xf / np) - 0.01168f * std::cos(pi6 * xf / np);
+    const float arg = (xf - (float)(fi / 2)) * cutoff / 1.f;
+    const float sinc = arg == 0.f ? 1.f : std::sin(arg * pi) / (arg * pi);
+    const float val = bh * bh * sinc;
+    sum += val;
+    y[(size_t)x] = val;
+  }
+  for (int n = 0; n < fi; n++) y[(size_t)n] = (y[(size_t)n] / sum) / (float)(2 * fi);
+  return y;
+}
+static std::vector<float> resampler_matrix(int fi, int fo) {
+  const std::vector<float> g = rubato_filter_taps(fi, fo);
+  const int new_len = fi < fo ? fi + 1 : fo;
+  const int fm = std::max(fi, fo);
+  const double two_pi = 6.283185307179586476925286766559;
+  std::vector<double> fre((size_t)new_len), fim((size_t)new_len);
+  for (int k = 0; k < new_len; k++) {
+    double re = 0., im = 0.;
+    for (int n = 0; n < fi; n++) {
+      const double a = -two_pi * (double)((int64_t)k * n % (2 * fi)) / (double)(2 * fi);
+      re += (double)g[(size_t)n] * std::cos(a);
+      im += (double)g[(size_t)n] * std::sin(a);
+    }
+    fre[(size_t)k] = re;
+    fim[(size_t)k] = im;
+  }
+  // (the inverse real transform ignores the imaginary part of bin 0; F[0] is real anyway)
+  std::vector<double> phi((size_t)2 * fm);
+  for (int p = 0; p < 2 * fm; p++) {
+    double acc = fre[0];
+    for (int k = 1; k < new_len; k++) {
+      const double a = two_pi * (double)((int64_t)k * p % (2 * fm)) / (double)(2 * fm);
+      acc += 2. * (fre[(size_t)k] * std::cos(a) - fim[(size_t)k] * std::sin(a));
+    }
+    phi[(size_t)p] = acc;
+  }
+  const int so = fm / fo, si = fm / fi;
+  std::vector<float> A((size_t)2 * fi * fo);
+  for (int k = 0; k < fi; k++)
+    for (int m = 0; m < 2 * fo; m++) {
+      int p = (m * so - k * si) % (2 * fm);
+      if (p < 0) p += 2 * fm;
+      const float v = (float)phi[(size_t)p];
+      if (m < fo)
+        A[(size_t)k * fo + m] = v;
+      else
+        A[(size_t)(fi + k) * fo + (m - fo)] = v;
+    }
+  return A;
+}
+
+// host-known codes (count | CODE_SILENT per quantum) of a source node: waa_plan.cpp
+int source_code_rows(waa_batch* b, uint32_t id, uint64_t cs, std::vector<uint8_t>* host);
+
+// codes of the node's mixed input and the prev table; `src_id` >= 0: static plan, the input is that source
+static int plan_link(waa_batch* b, uint32_t id, int kind, int src_id, uint32_t tail_frames, int can_propagate, const uint8_t** in_code,
+                     int32_t** prev_out) {
+  Node& n = b->nodes[id];
+  const uint64_t cs = b->code_stride ? b->code_stride : (((uint64_t)b->n_quanta + 15) & ~(uint64_t)15);
+  const uint8_t* d_in = n.in_code;
+  if (src_id >= 0) {
+    std::vector<uint8_t> host;
+    int e = source_code_rows(b, (uint32_t)src_id, cs, &host);
+    if (e) return e;
+    uint8_t* up = nullptr;
+    if ((e = dev_upload(b, &up, host))) return e;
+    d_in = up;
+  }
+  if (!d_in) return fail(WAA_ERR_INVALID_STATE, "internal: node %u has no input codes", id);
+  int32_t* d_prev = nullptr;
+  int e = dev_alloc(b, &d_prev, (size_t)b->n_inst * b->n_quanta);
+  if (e) return e;
+  uint8_t* d_out = nullptr;
+  if (b->dynamic) {
+    if ((e = dev_alloc(b, &d_out, (size_t)b->n_inst * cs))) return e;
+    n.code = d_out;
+  }
+  Step st;
+  st.kind = 15;
+  LinkDesc& d = st.link;
+  std::memset(&d, 0, sizeof d);
+  d.in_code = d_in;
+  d.out_code = d_out;
+  d.prev = d_prev;
+  d.code_stride = cs;
+  d.prev_stride = b->n_quanta;
+  d.n_inst = b->n_inst;
+  d.n_quanta = b->n_quanta;
+  d.kind = kind;
+  d.can_propagate_silence = can_propagate;
+  d.tail_frames = tail_frames;
+  st.profile_slot = slot_for(b, "link_kernel");
+  b->steps.push_back(st);
+  *in_code = d_in;
+  *prev_out = d_prev;
+  return 0;
+}
+
+int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
+  Node& n = b->nodes[id];
+  const int R = n.desc.i[0] == WAA_OVERSAMPLE_X2 ? 2 : 4;
+  SignalRef in_sig{};
+  if (b->dynamic && n.hist.base) {
+    in_sig = n.hist;  // dynamic plans: the mixed input was published by the group in front (waa_dyn.hip)
+  } else {
+    int e = node_input_signal(b, id, &in_sig);
+    if (e) return e;
+  }
+  const size_t cn = n.curve.size();
+  const float mid = cn == 0 ? 0.f : (cn % 2 ? n.curve[cn / 2] : (n.curve[cn / 2 - 1] + n.curve[cn / 2]) / 2.f);
+  const int can_propagate = (cn == 0 || std::fabs(mid) < 1e-9f) ? 1 : 0;  // waveshaper.rs:498-509
+  const uint8_t* in_code = nullptr;
+  int32_t* prev = nullptr;
+  int e = plan_link(b, id, 0, src_id, 0, can_propagate, &in_code, &prev);
+  if (e) return e;
+  if (!n.d_curve && (e = dev_upload(b, &n.d_curve, n.curve))) return e;
+  const int up_len = RQ * R;
+  const int nch = n.in_nch;
+  float *d_up = nullptr, *d_dn = nullptr, *sbuf = nullptr;
+  if ((e = dev_upload(b, &d_up, resampler_matrix(RQ, up_len))) || (e = dev_upload(b, &d_dn, resampler_matrix(up_len, RQ))) ||
+      (e = dev_alloc(b, &sbuf, (size_t)b->n_inst * nch * b->n_quanta * up_len)))
+    return e;
+  Step up;
+  up.kind = 16;
+  QGemmDesc& g = up.qgemm;
+  std::memset(&g, 0, sizeof g);
+  g.A = d_up;
+  g.M = up_len;
+  g.Kh = RQ;
+  g.src = in_sig.base;
+  g.src_inst = in_sig.inst_stride;
+  g.src_ch = in_sig.ch_stride;
+  g.src_q = RQ;
+  g.dst = sbuf;
+  g.dst_ch = (uint64_t)b->n_quanta * up_len;
+  g.dst_inst = g.dst_ch * nch;
+  g.dst_q = up_len;
+  g.prev = prev;
+  g.prev_stride = b->n_quanta;
+  g.curve = n.d_curve;
+  g.curve_n = (int32_t)cn;
+  g.nch = nch;
+  g.n_inst = b->n_inst;
+  g.n_quanta = b->n_quanta;
+  up.profile_slot = slot_for(b, "qgemm_kernel<up+curve>");
+  up.loop_reads.push_back(in_sig.base);
+  up.loop_writes.push_back(sbuf);
+  b->steps.push_back(up);
+  Step dn;
+  dn.kind = 16;
+  QGemmDesc& h = dn.qgemm;
+  std::memset(&h, 0, sizeof h);
+  h.A = d_dn;
+  h.M = RQ;
+  h.Kh = up_len;
+  h.src = sbuf;
+  h.src_inst = g.dst_inst;
+  h.src_ch = g.dst_ch;
+  h.src_q = up_len;
+  h.dst = n.sig.base;
+  h.dst_inst = n.sig.inst_stride;
+  h.dst_ch = n.sig.ch_stride;
+  h.dst_q = RQ;
+  h.prev = prev;
+  h.prev_stride = b->n_quanta;
+  h.nch = nch;
+  h.n_inst = b->n_inst;
+  h.n_quanta = b->n_quanta;
+  dn.profile_slot = slot_for(b, "qgemm_kernel<down>");
+  dn.loop_reads.push_back(sbuf);
+  dn.loop_writes.push_back(n.sig.base);
+  b->steps.push_back(dn);
+  plan_note(b, "waveshaper node %u: %dx oversampling as two matrix products over render quanta (%d x %d and %d x %d), %d channel(s)%s", id,
+            R, up_len, 2 * RQ, RQ, 2 * up_len, nch, can_propagate ? ", silent input skips the block" : "");
+  return 0;
+}
+
+// ===============================================================================================================
+// HRTF panning: the HRIR sphere (crate hrtf 0.8.1 file format and algorithm, restated)
+struct Sphere {
+  uint32_t sr = 0;
+  int taps = 0;
+  std::vector<uint32_t> faces;  // [nf][3]
+  std::vector<float> pos;       // [nv][3]
+  std::vector<float> left, right;  // [nv][taps]
+  int nv() const { return (int)(pos.size() / 3); }
+  int nf() const { return (int)(faces.size() / 3); }
+};
+static std::mutex g_sphere_lock;
+static std::shared_ptr<Sphere> g_sphere_file;
+static std::map<uint32_t, std::shared_ptr<Sphere>> g_sphere_cache;  // per sample rate, like panner.rs:39-60
+
+static double resample_kernel_value(double x, double fc) {
+  if (std::fabs(x) >= 128.) return 0.;
+  const double pi = 3.14159265358979323846;
+  const double u = (x + 128.) / 256.;
+  const double bh = 0.35875 - 0.48829 * std::cos(2. * pi * u) + 0.14128 * std::cos(4. * pi * u) - 0.01168 * std::cos(6. * pi * u);
+  const double a = pi * x * fc;
+  return bh * bh * (x == 0. ? 1. : std::sin(a) / a) * fc;
+}
+// HRIRs at another rate — OUR definition of the crate's one-chunk rubato SincFixedIn pass (sinc_len 256, f_cutoff 0.95,
+// BlackmanHarris2): output n is the band-limited signal at input position t_n = (n + 1) / ratio - 128, while
+// t_n < taps - 257 - 1 / ratio; kernel evaluated directly instead of through the oversampled cubic table.
+static void resample_hrir(const float* in, int len, double ratio, std::vector<float>* out) {
+  int n_out = 0;
+  while ((double)(n_out + 1) / ratio - 128. < (double)len - 257. - 1. / ratio) n_out++;
+  const double fc = 0.95 * (ratio < 1. ? ratio : 1.);
+  for (int n = 0; n < n_out; n++) {
+    const double t = (double)(n + 1) / ratio - 128.;
+    int m0 = (int)std::ceil(t - 128.), m1 = (int)std::floor(t + 128.);
+    m0 = std::max(m0, 0);
+    m1 = std::min(m1, len - 1);
+    double acc = 0.;
+    for (int m = m0; m <= m1; m++) acc += (double)in[m] * resample_kernel_value(t - (double)m, fc);
+    out->push_back((float)acc);
+  }
+}
+static std::shared_ptr<Sphere> sphere_for_rate(uint32_t sample_rate) {
+  if (sample_rate < 27000) sample_rate = 27000;  // panner.rs:46-49
+  std::lock_guard<std::mutex> lock(g_sphere_lock);
+  if (!g_sphere_file) return nullptr;
+  if (g_sphere_file->sr == sample_rate) return g_sphere_file;
+  auto it = g_sphere_cache.find(sample_rate);
+  if (it != g_sphere_cache.end()) return it->second;
+  const Sphere& f = *g_sphere_file;
+  auto s = std::make_shared<Sphere>();
+  s->sr = sample_rate;
+  s->faces = f.faces;
+  s->pos = f.pos;
+  const double ratio = (double)sample_rate / (double)f.sr;
+  for (int v = 0; v < f.nv(); v++) {
+    resample_hrir(f.left.data() + (size_t)v * f.taps, f.taps, ratio, &s->left);
+    resample_hrir(f.right.data() + (size_t)v * f.taps, f.taps, ratio, &s->right);
+  }
+  s->taps = f.nv() ? (int)(s->left.size() / (size_t)f.nv()) : 0;
+  g_sphere_cache[sample_rate] = s;
+  return s;
+}
+// HrirSphere::sample_bilinear: the face the ray origin -> dir pierces, barycentric weights of the piercing point.  Of
+// all faces whose plane lies in front, the one in which the point sits deepest (largest smallest weight) is the face
+// that contains it; on an edge either neighbour interpolates to the same HRIR.  f32, like the crate.
+static void sphere_locate(const Sphere& s, const float dir[3], int vtx[3], float wgt[3]) {
+  float best = -1e30f;
+  vtx[0] = vtx[1] = vtx[2] = 0;
+  wgt[0] = 1.f;
+  wgt[1] = wgt[2] = 0.f;
+  auto dot = [](const float* a, const float* c) { return a[0] * c[0] + a[1] * c[1] + a[2] * c[2]; };
+  for (int f = 0; f < s.nf(); f++) {
+    const float* a = &s.pos[3 * (size_t)s.faces[3 * (size_t)f]];
+    const float* bb = &s.pos[3 * (size_t)s.faces[3 * (size_t)f + 1]];
+    const float* c = &s.pos[3 * (size_t)s.faces[3 * (size_t)f + 2]];
+    const float ba[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]}, ca[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    const float nrm[3] = {ba[1] * ca[2] - ba[2] * ca[1], ba[2] * ca[0] - ba[0] * ca[2], ba[0] * ca[1] - ba[1] * ca[0]};
+    const float denom = dot(dir, nrm), num = dot(a, nrm);
+    if (denom == 0.f) continue;
+    const float t = num / denom;
+    if (!(t > 0.f)) continue;
+    const float pnt[3] = {dir[0] * t, dir[1] * t, dir[2] * t};
+    const float v2[3] = {pnt[0] - a[0], pnt[1] - a[1], pnt[2] - a[2]};
+    const float d00 = dot(ba, ba), d01 = dot(ba, ca), d11 = dot(ca, ca), d20 = dot(v2, ba), d21 = dot(v2, ca);
+    const float den = d00 * d11 - d01 * d01;
+    const float v = (d11 * d20 - d01 * d21) / den;
+    const float w = (d00 * d21 - d01 * d20) / den;
+    const float u = 1.0f - v - w;
+    const float m = std::min(u, std::min(v, w));
+    if (m > best) {
+      best = m;
+      for (int k = 0; k < 3; k++) vtx[k] = (int)s.faces[3 * (size_t)f + k];
+      wgt[0] = u;
+      wgt[1] = v;
+      wgt[2] = w;
+    }
+  }
+}
+
+int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
+  Node& n = b->nodes[id];
+  std::shared_ptr<Sphere> sp = sphere_for_rate((uint32_t)b->sr);
+  if (!sp) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - HRTF panning needs the HRIR sphere (waa_hrtf_load_sphere)");
+  if (sp->taps > HRTF_MAX_TAPS || sp->taps < 1)
+    return fail(WAA_ERR_OUT_OF_SCOPE, "HRTF panning at %g Hz needs %d-tap impulse responses; the device kernel holds at most %d", (double)b->sr,
+                sp->taps, HRTF_MAX_TAPS);
+  SignalRef in_sig{};
+  if (b->dynamic && n.hist.base) {
+    in_sig = n.hist;
+  } else {
+    int e = node_input_signal(b, id, &in_sig);
+    if (e) return e;
+  }
+  const uint8_t* in_code = nullptr;
+  int32_t* prev = nullptr;
+  int e = plan_link(b, id, 1, src_id, (uint32_t)sp->taps, 0, &in_code, &prev);
+  if (e) return e;
+  // geometry per (instance, quantum) on the host, always k-rate: the first value of every param (panner.rs:781-799)
+  bool shared = true, varies = false;
+  for (int k = 0; k < 15; k++) {
+    const ParamStore& ps = n.params[k];
+    for (uint32_t i = 1; i < b->n_inst && shared; i++) shared = ps.cst[i] == ps.cst[0];
+    for (auto& blk : ps.blocks) shared &= blk.inst == WAA_ALL_INSTANCES;
+    varies |= !ps.blocks.empty();
+    if (ps.dev_tl) return fail(WAA_ERR_INVALID_STATE, "internal: device-side automation on an HRTF panner param");
+  }
+  const uint32_t rows = shared ? 1u : b->n_inst, per_row = varies ? b->n_quanta : 1u;
+  std::vector<HrtfQ> table((size_t)rows * per_row);
+  std::map<std::tuple<float, float, float>, std::pair<std::array<int, 3>, std::array<float, 3>>> located;
+  for (uint32_t i = 0; i < rows; i++) {
+    std::vector<std::vector<float>> pv(15);
+    for (int k = 0; k < 15; k++) pv[k] = param_per_quantum(b, n.params[k], i, nullptr);
+    for (uint32_t q = 0; q < per_row; q++) {
+      auto at = [&](int p) { return pv[p][pv[p].size() == 1 ? 0 : q]; };
+      V3 spos{at(0), at(1), at(2)}, so{at(3), at(4), at(5)}, lp{at(6), at(7), at(8)}, lf{at(9), at(10), at(11)}, lu{at(12), at(13), at(14)};
+      float az, el;
+      azimuth_elevation(spos, lp, lf, lu, &az, &el);
+      const float az_rad = az * PI_F / 180.f, el_rad = el * PI_F / 180.f;
+      float ps[3] = {sinf(az_rad) * cosf(el_rad), sinf(el_rad), cosf(az_rad) * cosf(el_rad)};
+      if (std::fabs(ps[0]) <= 1e-6f && std::fabs(ps[1]) <= 1e-6f && std::fabs(ps[2]) <= 1e-6f) {
+        ps[0] = ps[1] = 0.f;
+        ps[2] = 1.f;
+      }
+      const float dir[3] = {ps[0], ps[2], ps[1]};  // Vec3 { x: p[0], z: p[1], y: p[2] } (panner.rs:246-250)
+      HrtfQ& r = table[(size_t)i * per_row + q];
+      auto key = std::make_tuple(dir[0], dir[1], dir[2]);
+      auto it = located.find(key);
+      if (it == located.end()) {
+        int vtx[3];
+        float wgt[3];
+        sphere_locate(*sp, dir, vtx, wgt);
+        it = located.emplace(key, std::make_pair(std::array<int, 3>{vtx[0], vtx[1], vtx[2]}, std::array<float, 3>{wgt[0], wgt[1], wgt[2]})).first;
+      }
+      for (int k = 0; k < 3; k++) {
+        r.v[k] = it->second.first[(size_t)k];
+        r.w[k] = it->second.second[(size_t)k];
+      }
+      r.gain = cone_gain(n.desc, spos, so, lp) * dist_gain(n.desc, spos, lp);
+      r.pad = 0;
+    }
+  }
+  std::vector<float> hr((size_t)sp->nv() * 2 * sp->taps);
+  for (int v = 0; v < sp->nv(); v++) {
+    std::copy(sp->left.begin() + (size_t)v * sp->taps, sp->left.begin() + (size_t)(v + 1) * sp->taps, hr.begin() + (size_t)v * 2 * sp->taps);
+    std::copy(sp->right.begin() + (size_t)v * sp->taps, sp->right.begin() + (size_t)(v + 1) * sp->taps,
+              hr.begin() + (size_t)v * 2 * sp->taps + sp->taps);
+  }
+  float* d_hr = nullptr;
+  HrtfQ* d_table = nullptr;
+  if ((e = dev_upload(b, &d_hr, hr)) || (e = dev_upload(b, &d_table, table))) return e;
+  Step st;
+  st.kind = 17;
+  HrtfDesc& d = st.hrtf;
+  std::memset(&d, 0, sizeof d);
+  d.in = in_sig;
+  d.out = n.sig;
+  d.in_code = in_code;
+  d.code_stride = b->code_stride ? b->code_stride : (((uint64_t)b->n_quanta + 15) & ~(uint64_t)15);
+  d.prev = prev;
+  d.prev_stride = b->n_quanta;
+  d.hrir = d_hr;
+  d.table = d_table;
+  d.rows = rows;
+  d.per_row = per_row;
+  d.taps = sp->taps;
+  d.n_inst = b->n_inst;
+  d.n_quanta = b->n_quanta;
+  st.profile_slot = slot_for(b, "hrtf_kernel");
+  st.loop_reads.push_back(in_sig.base);
+  st.loop_writes.push_back(n.sig.base);
+  b->steps.push_back(st);
+  plan_note(b, "panner node %u: HRTF, %d-tap impulse responses at %u Hz, geometry table %u row(s) x %u, direct FIR per render quantum", id,
+            sp->taps, sp->sr, rows, per_row);
+  return 0;
+}
+
+}  // namespace host
+}  // namespace waa
+
+// ---- C ABI (include/waa_hip.h) ---------------------------------------------------------------------------------
+using namespace waa::host;
+
+extern "C" waa_status waa_hrtf_load_sphere(const void* data, uint64_t size) {
+  const unsigned char* d = static_cast<const unsigned char*>(data);
+  if (!d || size < 20 || std::memcmp(d, "HRIR", 4) != 0) return fail(WAA_ERR_INVALID_ARGUMENT, "HRIR sphere: bad magic");
+  uint32_t hdr[4];
+  std::memcpy(hdr, d + 4, 16);
+  const uint64_t len = hdr[1], nv = hdr[2], ni = hdr[3];
+  if (len == 0 || ni % 3 != 0 || size != 20 + 4 * ni + nv * (12 + 8 * len))
+    return fail(WAA_ERR_INVALID_ARGUMENT, "HRIR sphere: inconsistent sizes");
+  auto s = std::make_shared<Sphere>();
+  s->sr = hdr[0];
+  s->taps = (int)len;
+  s->faces.resize(ni);
+  std::memcpy(s->faces.data(), d + 20, 4 * ni);
+  for (uint32_t f : s->faces)
+    if (f >= nv) return fail(WAA_ERR_INVALID_ARGUMENT, "HRIR sphere: face index out of range");
+  s->pos.resize(3 * nv);
+  s->left.resize(nv * len);
+  s->right.resize(nv * len);
+  const unsigned char* p = d + 20 + 4 * ni;
+  for (uint64_t v = 0; v < nv; v++) {
+    std::memcpy(&s->pos[3 * v], p, 12);
+    std::memcpy(&s->left[v * len], p + 12, 4 * len);
+    std::memcpy(&s->right[v * len], p + 12 + 4 * len, 4 * len);
+    p += 12 + 8 * len;
+  }
+  std::lock_guard<std::mutex> lock(g_sphere_lock);
+  g_sphere_file = s;
+  g_sphere_cache.clear();
+  return WAA_OK;
+}
+
+extern "C" uint32_t waa_hrtf_hrir_length(float sample_rate) {
+  auto s = sphere_for_rate((uint32_t)sample_rate);
+  return s ? (uint32_t)s->taps : 0u;
+}
+
+extern "C" void waa_hrtf_sample(float sample_rate, const float* dir, float* left, float* right) {
+  auto s = sphere_for_rate((uint32_t)sample_rate);
+  if (!s) return;
+  int vtx[3];
+  float wgt[3];
+  sphere_locate(*s, dir, vtx, wgt);
+  for (int i = 0; i < s->taps; i++) {
+    left[i] = s->left[(size_t)vtx[0] * s->taps + i] * wgt[0] + s->left[(size_t)vtx[1] * s->taps + i] * wgt[1] +
+              s->left[(size_t)vtx[2] * s->taps + i] * wgt[2];
+    right[i] = s->right[(size_t)vtx[0] * s->taps + i] * wgt[0] + s->right[(size_t)vtx[1] * s->taps + i] * wgt[1] +
+               s->right[(size_t)vtx[2] * s->taps + i] * wgt[2];
+  }
+}
+
+namespace waa {
+namespace host {
+bool hrtf_sphere_loaded() {
+  std::lock_guard<std::mutex> lock(g_sphere_lock);
+  return (bool)g_sphere_file;
+}
+}  // namespace host
+}  // namespace waa

@@ -183,7 +183,7 @@ struct ProfileEntry {
 };
 
 struct Step {
-  int kind = 0;  // 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator, 10 dynamic-count group (dyn_kernel), 11 convolver codes, 12 digest of a shared per-frame coefficient table, 13 per-frame panner geometry, 14 automation timelines replayed on the device
+  int kind = 0;  // 15 link table of a frozen-state node, 16 one resampling stage of an oversampled WaveShaper (qgemm_kernel), 17 HRTF FIR; 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator, 10 dynamic-count group (dyn_kernel), 11 convolver codes, 12 digest of a shared per-frame coefficient table, 13 per-frame panner geometry, 14 automation timelines replayed on the device
   ChainDesc chain{};
   BiquadStreamDesc bq{};
   ConvDesc conv{};
@@ -197,6 +197,9 @@ struct Step {
   BiquadHpDesc hp{};
   PannerGeomDesc geom{};
   TimelineDesc tl{};
+  LinkDesc link{};
+  QGemmDesc qgemm{};
+  HrtfDesc hrtf{};
   int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
   void* zero_ptr = nullptr;
   size_t zero_bytes = 0;
@@ -277,6 +280,12 @@ int dev_upload(waa_batch* b, T** out, const std::vector<T>& host) {
   return 0;
 }
 
+// nodes whose render state freezes while they do not process (waa_frozen.hip): rendered node-major behind a link table
+inline bool is_frozen_node(const Node& n) {
+  return (n.desc.kind == WAA_NODE_WAVESHAPER && n.has_curve && n.desc.i[0] != WAA_OVERSAMPLE_NONE) ||
+         (n.desc.kind == WAA_NODE_PANNER && n.desc.i[0] == WAA_PANNING_HRTF);
+}
+
 inline int check_node(waa_batch* b, uint32_t node, uint32_t kind) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
   if (node >= b->nodes.size() || b->nodes[node].desc.kind != kind)
@@ -329,6 +338,11 @@ std::vector<float> param_per_quantum(const waa_batch* b, const ParamStore& p, ui
 
 // ---- waa_plan.cpp: graph -> launch plan -----------------------------------------------------------------
 int build_plan(waa_batch* b);
+// waa_frozen_host.cpp: WaveShaper 2x / 4x and the HRTF panner as node-major steps; src_id >= 0: static plan, the node's
+// only input is that source node (its host-known codes stand in for the codes a dynamic plan computes on the device)
+int plan_oversampler(waa_batch* b, uint32_t id, int src_id);
+int plan_hrtf(waa_batch* b, uint32_t id, int src_id);
+bool hrtf_sphere_loaded();
 void plan_note(waa_batch* b, const char* fmt, ...);
 int slot_for(waa_batch* b, const char* name);
 void default_channel_config(Node& n, uint32_t n_out);

@@ -450,6 +450,71 @@ struct TimelineDesc {
 };
 void launch_timeline(const TimelineDesc& d, void* stream);
 
+// ---- nodes whose state FREEZES while they do not process: WaveShaper 2x / 4x (waveshaper.rs:395-400: silent input and a
+// curve that maps 0 to 0 -> the resamplers are not run) and the HRTF panner (panner.rs:697-711: silent input after the
+// tail counter ran out).  Rendered node-major; a serial pass over the per-quantum codes of the node's mixed input
+// (link_kernel, one thread per instance) turns the reference's control flow into a table the time-parallel kernels
+// follow: prev[inst][q] = LINK_SKIP (the node does not process quantum q: silent output), LINK_FRESH (it processes q
+// with fresh state) or the previous quantum it processed (where its state comes from).
+constexpr int32_t LINK_SKIP = -2, LINK_FRESH = -1;
+struct LinkDesc {
+  const uint8_t* in_code;   // [n_inst][code_stride] count | CODE_SILENT of the node's mixed input per quantum
+  uint8_t* out_code;        // [n_inst][code_stride] codes of the node's output (null in static plans)
+  int32_t* prev;            // [n_inst][prev_stride]
+  uint64_t code_stride, prev_stride;
+  uint32_t n_inst, n_quanta;
+  int32_t kind;             // 0: oversampled WaveShaper, 1: HRTF panner
+  int32_t can_propagate_silence;  // kind 0 (waveshaper.rs:498-509)
+  uint32_t tail_frames;     // kind 1: HRIR length (panner.rs:270-272)
+  int32_t pad;
+};
+void launch_link(const LinkDesc& d, void* stream);
+
+// One resampling stage of the oversampled WaveShaper as a matrix product over render quanta: column (inst, ch, q) of
+// the result = A[:, 0:Kh] * src(inst, ch, q) + A[:, Kh:2Kh] * src(inst, ch, prev(q)) — the block's own response plus
+// the overlap the previous processed block left behind (rubato FftFixedInOut's overlap-add) — followed
+// by the WaveShaper curve when `curve` is set (the up-sampling stage).
+struct QGemmDesc {
+  const float* A;           // [2 * Kh][M], k-major: row k holds the M coefficients that multiply source element k
+  int32_t M, Kh;
+  const float* src;         // element k of column (inst, ch, q): src[inst * src_inst + ch * src_ch + q * src_q + k]
+  uint64_t src_inst, src_ch, src_q;
+  float* dst;               // M contiguous floats per column
+  uint64_t dst_inst, dst_ch, dst_q;
+  const int32_t* prev;
+  uint64_t prev_stride;
+  const float* curve;       // epilogue: waveshaper.rs:555-573 (null: none)
+  int32_t curve_n;
+  int32_t nch;
+  uint32_t n_inst, n_quanta;
+};
+void launch_qgemm(const QGemmDesc& d, void* stream);
+
+// HRTF panner (panner.rs:781-829 + crate hrtf): per render quantum the HRIR pair of the direction
+// (barycentric mix of three measured HRIRs) is convolved with the mono input continued into the previously processed
+// quanta; direct-form FIR, one wavefront per (instance, quantum).
+struct HrtfQ {              // host-evaluated geometry of one (instance, quantum) — or one per instance when static
+  int32_t v[3];             // vertices of the triangle the direction pierces
+  float w[3];               // barycentric weights
+  float gain;               // cone_gain * dist_gain
+  int32_t pad;
+};
+constexpr int HRTF_MAX_TAPS = 1280;
+struct HrtfDesc {
+  SignalRef in, out;        // in: the node's mixed input (1 or 2 channels); out: 2 channels
+  const uint8_t* in_code;   // [n_inst][code_stride]
+  uint64_t code_stride;
+  const int32_t* prev;
+  uint64_t prev_stride;
+  const float* hrir;        // [n_vertices][2][taps]: left, right
+  const HrtfQ* table;       // [rows][per_row]
+  uint32_t rows, per_row;   // rows: n_inst or 1 (nothing depends on the instance); per_row: n_quanta or 1 (static)
+  int32_t taps;
+  uint32_t n_inst, n_quanta;
+  int32_t pad;
+};
+void launch_hrtf(const HrtfDesc& d, void* stream);
+
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);
 // waa_resample.hip: AudioBufferSource [-> WaveShaper] -> signal without the op interpreter (the C5 shape)

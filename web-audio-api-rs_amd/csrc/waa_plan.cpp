@@ -531,9 +531,12 @@ int materialise_automation(waa_batch* b) {
       // host needs per quantum (source playbackRate / detune: k-rate, the playhead replay) stay on this path.
       {
         const uint32_t kind = n.desc.kind;
+        // (PannerNode: only the AudioListener's params of an equal-power panner go through the per-frame geometry
+        // kernel; its own position / orientation and everything of an HRTF panner is geometry the host evaluates)
         const bool consumable = kind == WAA_NODE_GAIN || kind == WAA_NODE_BIQUAD || kind == WAA_NODE_DELAY ||
                                 kind == WAA_NODE_STEREO_PANNER || kind == WAA_NODE_CONSTANT_SOURCE ||
-                                kind == WAA_NODE_OSCILLATOR || kind == WAA_NODE_PANNER;
+                                kind == WAA_NODE_OSCILLATOR ||
+                                (kind == WAA_NODE_PANNER && pk >= 6 && n.desc.i[0] != WAA_PANNING_HRTF);
         const bool want = getenv("WAA_DEVICE_AUTOMATION") ? true : !shared;  // (switch: also replay shared timelines there)
         if (consumable && !p.k_rate && want && !b->dry && !getenv("WAA_HOST_AUTOMATION")) {
           p.dev_tl = true;
@@ -568,6 +571,54 @@ int materialise_automation(waa_batch* b) {
       }
       p.timelines.clear();  // consumed (a batch renders one timeline once, like an OfflineAudioContext)
     }
+  return 0;
+}
+
+// Host-known codes (count | CODE_SILENT per quantum, [n_inst][cs]) of a source node: active quanta carry the source's
+// channel count (the buffer source's active quanta come from the scheduling replay).
+int source_code_rows(waa_batch* b, uint32_t id, uint64_t cs, std::vector<uint8_t>* out) {
+  Node& n = b->nodes[id];
+  std::vector<uint8_t>& host = *out;
+  host.assign((size_t)b->n_inst * cs, (uint8_t)(1u | CODE_SILENT));
+  const double sample_rate = (double)b->sr, dt = 1. / sample_rate;
+  std::map<SchedKey, std::vector<uint8_t>> cache;
+  for (uint32_t i = 0; i < b->n_inst; i++) {
+    uint8_t* row = host.data() + (size_t)i * cs;
+    const SourceSched& ss = n.sched[i];
+    if (n.desc.kind == WAA_NODE_BUFFER_SOURCE) {
+      const DeviceBuffer& bf = n.bufs[i];
+      const ParamStore& p_rate = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
+      const ParamStore& p_det = n.params[WAA_PARAM_SOURCE_DETUNE];
+      const bool automated = !p_rate.blocks.empty() || !p_det.blocks.empty();
+      std::vector<float> rate_q = param_per_quantum(b, p_rate, i, nullptr);
+      std::vector<float> det_q = param_per_quantum(b, p_det, i, nullptr);
+      const SchedKey key(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end,
+                         bf.valid ? bf.frames : 0, bf.valid ? bf.sr : 0.f, rate_q[0], det_q[0]);
+      auto itc = automated ? cache.end() : cache.find(key);
+      if (itc == cache.end()) {
+        SchedOut so;
+        schedule_source(b, ss, bf.frames, bf.sr, bf.valid, rate_q, det_q, &so);
+        std::vector<uint8_t> r(b->n_quanta);
+        for (uint32_t q = 0; q < b->n_quanta; q++)
+          r[q] = so.qrec[q].mode == Q_SILENT ? (uint8_t)(1u | CODE_SILENT) : (uint8_t)n.out_nch;
+        itc = cache.emplace(automated ? SchedKey(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end,
+                                                 (uint64_t)i, -1.f, 0.f, 0.f)
+                                      : key,
+                            std::move(r)).first;
+      }
+      std::copy(itc->second.begin(), itc->second.end(), row);
+    } else {
+      for (uint32_t q = 0; q < b->n_quanta; q++) {
+        const double ct = (double)((uint64_t)q * RQ) / sample_rate, nbt = ct + dt * (double)RQ;
+        bool silent;
+        if (n.desc.kind == WAA_NODE_CONSTANT_SOURCE)
+          silent = ss.start >= nbt;                    // constant_source.rs:203-216: silent until it starts, never again
+        else
+          silent = ss.stop <= ct || ss.start >= nbt;   // oscillator.rs:382-404
+        row[q] = silent ? (uint8_t)(1u | CODE_SILENT) : (uint8_t)1u;
+      }
+    }
+  }
   return 0;
 }
 
@@ -879,7 +930,8 @@ int build_plan(waa_batch* b) {
       for (uint32_t id : b->order) {
         const Node& n = b->nodes[id];
         const uint32_t k = n.desc.kind;
-        if (n.live && (k == WAA_NODE_BIQUAD || k == WAA_NODE_IIR_FILTER || k == WAA_NODE_DELAY || (k == WAA_NODE_CONVOLVER && n.has_ir)))
+        if (n.live && (k == WAA_NODE_BIQUAD || k == WAA_NODE_IIR_FILTER || k == WAA_NODE_DELAY || (k == WAA_NODE_CONVOLVER && n.has_ir) ||
+                       (k == WAA_NODE_PANNER && n.desc.i[0] == WAA_PANNING_HRTF)))
           mem_nodes.push_back(id);
       }
       // every combination of short / long tails for up to 8 nodes with memory, the two uniform bounds beyond that
@@ -941,7 +993,8 @@ int build_plan(waa_batch* b) {
               if (kind == WAA_NODE_CONVOLVER && n.has_ir) c = (c == 1 && n.ir_nch == 1) ? 1 : 2;
             }
             const bool has_memory = kind == WAA_NODE_BIQUAD || kind == WAA_NODE_IIR_FILTER || kind == WAA_NODE_DELAY ||
-                                    (kind == WAA_NODE_CONVOLVER && n.has_ir);
+                                    (kind == WAA_NODE_CONVOLVER && n.has_ir) ||
+                                    (kind == WAA_NODE_PANNER && n.desc.i[0] == WAA_PANNING_HRTF);  // (HRIR tail)
             if (has_memory && long_tail[id] && !a && q > 0 && act[id][q - 1]) {  // still ringing, with the old layout
               a = 1;
               c = cnt[id][q - 1];
@@ -1017,6 +1070,26 @@ int build_plan(waa_batch* b) {
       }  // tail_mode
     }
   }
+  // Nodes whose state freezes while they do not process (WaveShaper 2x / 4x, HRTF panner; waa_frozen.hip) follow the
+  // per-quantum silence / count codes of their input EXACTLY.  Directly behind one source those codes are host-known
+  // (the scheduling replay); behind anything else they come out of the dynamic-count rendering.
+  std::vector<int> frozen_src(N, -1);
+  for (uint32_t id = 0; id < N && !count_change_found && !b->force_dynamic; id++) {
+    Node& n = b->nodes[id];
+    if (!n.live || !is_frozen_node(n)) continue;
+    bool simple = n.in_edges.size() == 1 && scc_of[id] < 0 && !getenv("WAA_FROZEN_DYNAMIC");
+    if (simple) {
+      const uint32_t p = b->edges[n.in_edges[0]].from;
+      const uint32_t pk = b->nodes[p].desc.kind;
+      simple = (pk == WAA_NODE_BUFFER_SOURCE || pk == WAA_NODE_CONSTANT_SOURCE || pk == WAA_NODE_OSCILLATOR) &&
+               b->nodes[p].out_nch == n.in_nch && n.in_nch <= 2;
+      if (simple) frozen_src[id] = (int)p;
+    }
+    if (!simple && !getenv("WAA_STATIC_CHANNEL_COUNTS")) {
+      plan_note(b, "node %u keeps frozen state over silent quanta and is not fed by a single source -> exact per-quantum codes (dyn_kernel)", id);
+      count_change_found = true;
+    }
+  }
   // materialisation points
   std::vector<uint8_t> mat_hard(N, 0), fan_in_only(N, 0);
   for (uint32_t id = 0; id < N; id++) {
@@ -1025,6 +1098,7 @@ int build_plan(waa_batch* b) {
     bool mat = false, fan = false;
     const uint32_t kind = n.desc.kind;
     if (kind == WAA_NODE_DESTINATION || kind == WAA_NODE_ANALYSER || kind == WAA_NODE_CONVOLVER || kind == WAA_NODE_DELAY) mat = true;
+    if (is_frozen_node(n)) mat = true;  // rendered node-major (waa_frozen.hip)
     if (scc_of[id] >= 0) mat = true;  // loop members publish their own signal
     if (kind == WAA_NODE_OSCILLATOR) mat = true;  // rendered by its own (lane-per-instance) kernel
     int live_consumers = 0;
@@ -1032,7 +1106,7 @@ int build_plan(waa_batch* b) {
       if (e.from == id && b->nodes[e.to].live) {
         live_consumers++;
         const Node& c = b->nodes[e.to];
-        if ((c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir) || c.desc.kind == WAA_NODE_DELAY) mat = true;
+        if ((c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir) || c.desc.kind == WAA_NODE_DELAY || is_frozen_node(c)) mat = true;
         if (e.to_input & 0x80000000u) mat = true;  // feeds an AudioParam: read back as a per-frame value signal
         if (scc_of[e.to] >= 0) mat = true;         // feeds a feedback loop
         int live_in = 0;
@@ -1122,6 +1196,13 @@ int build_plan(waa_batch* b) {
       int e = alloc_signal(term);
       if (e) return e;
       return plan_oscillator(b, id);
+    }
+    if (is_frozen_node(term)) {
+      if (scc_of[id] >= 0)
+        return fail(WAA_ERR_OUT_OF_SCOPE, "an oversampled WaveShaperNode / HRTF PannerNode inside a feedback loop is out of scope (node %u)", id);
+      int e = alloc_signal(term);
+      if (e) return e;
+      return term.desc.kind == WAA_NODE_PANNER ? plan_hrtf(b, id, frozen_src[id]) : plan_oversampler(b, id, frozen_src[id]);
     }
     if (term.desc.kind == WAA_NODE_DELAY) {  // outside a loop: writer and reader halves back to back
       int e = alloc_signal(term);
@@ -1276,51 +1357,12 @@ int build_plan(waa_batch* b) {
     auto in_pending = [&](uint32_t node) { return pending_nodes.count(node) != 0; };
     // ---- host-known codes of a source: active quanta carry the source's channel count
     auto source_codes = [&](uint32_t id) -> int {
-      Node& n = b->nodes[id];
-      std::vector<uint8_t> host((size_t)b->n_inst * cs, (uint8_t)(1u | CODE_SILENT));
-      const double sample_rate = (double)b->sr, dt = 1. / sample_rate;
-      std::map<SchedKey, std::vector<uint8_t>> cache;
-      for (uint32_t i = 0; i < b->n_inst; i++) {
-        uint8_t* row = host.data() + (size_t)i * cs;
-        const SourceSched& ss = n.sched[i];
-        if (n.desc.kind == WAA_NODE_BUFFER_SOURCE) {
-          const DeviceBuffer& bf = n.bufs[i];
-          const ParamStore& p_rate = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
-          const ParamStore& p_det = n.params[WAA_PARAM_SOURCE_DETUNE];
-          const bool automated = !p_rate.blocks.empty() || !p_det.blocks.empty();
-          std::vector<float> rate_q = param_per_quantum(b, p_rate, i, nullptr);
-          std::vector<float> det_q = param_per_quantum(b, p_det, i, nullptr);
-          const SchedKey key(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end,
-                             bf.valid ? bf.frames : 0, bf.valid ? bf.sr : 0.f, rate_q[0], det_q[0]);
-          auto itc = automated ? cache.end() : cache.find(key);
-          if (itc == cache.end()) {
-            SchedOut so;
-            schedule_source(b, ss, bf.frames, bf.sr, bf.valid, rate_q, det_q, &so);
-            std::vector<uint8_t> r(b->n_quanta);
-            for (uint32_t q = 0; q < b->n_quanta; q++)
-              r[q] = so.qrec[q].mode == Q_SILENT ? (uint8_t)(1u | CODE_SILENT) : (uint8_t)n.out_nch;
-            itc = cache.emplace(automated ? SchedKey(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end,
-                                                     (uint64_t)i, -1.f, 0.f, 0.f)
-                                          : key,
-                                std::move(r)).first;
-          }
-          std::copy(itc->second.begin(), itc->second.end(), row);
-        } else {
-          for (uint32_t q = 0; q < b->n_quanta; q++) {
-            const double ct = (double)((uint64_t)q * RQ) / sample_rate, nbt = ct + dt * (double)RQ;
-            bool silent;
-            if (n.desc.kind == WAA_NODE_CONSTANT_SOURCE)
-              silent = ss.start >= nbt;                    // constant_source.rs:203-216: silent until it starts, never again
-            else
-              silent = ss.stop <= ct || ss.start >= nbt;   // oscillator.rs:382-404
-            row[q] = silent ? (uint8_t)(1u | CODE_SILENT) : (uint8_t)1u;
-          }
-        }
-      }
-      uint8_t* dcode = nullptr;
-      int e = dev_upload(b, &dcode, host);
+      std::vector<uint8_t> host;
+      int e = source_code_rows(b, id, cs, &host);
       if (e) return e;
-      n.code = dcode;
+      uint8_t* dcode = nullptr;
+      if ((e = dev_upload(b, &dcode, host))) return e;
+      b->nodes[id].code = dcode;
       return 0;
     };
     // ---- one dyn_kernel launch for the pending vertices
@@ -1411,7 +1453,7 @@ int build_plan(waa_batch* b) {
           li.out_code = n.code;
           std::vector<OpDesc> ops;
           int out_nch = 0;
-          if (kind == WAA_NODE_STEREO_PANNER || kind == WAA_NODE_PANNER) {
+          if ((kind == WAA_NODE_STEREO_PANNER || kind == WAA_NODE_PANNER) && !is_frozen_node(n)) {
             // both laws: the gains for a mono input (alt) and for a stereo input (op)
             const int keep = n.in_nch;
             n.in_nch = 1;
@@ -1425,8 +1467,8 @@ int build_plan(waa_batch* b) {
             }
             n.in_nch = keep;
             if (e) return e;
-          } else if (kind == WAA_NODE_CONVOLVER && n.has_ir) {
-            // (the mixed input of the convolver; the FFT steps follow the launch)
+          } else if ((kind == WAA_NODE_CONVOLVER && n.has_ir) || is_frozen_node(n)) {
+            // (the mixed input of the node; its node-major steps follow the launch)
           } else {
             if ((e = emit_node_ops(b, id, n.in_nch, true, ops, &out_nch))) return e;
           }
@@ -1444,7 +1486,7 @@ int build_plan(waa_batch* b) {
               default: return fail(WAA_ERR_DEVICE, "internal: op %d in a dynamic-count group", ops[0].kind);
             }
           }
-          if (kind == WAA_NODE_WAVESHAPER) {
+          if (kind == WAA_NODE_WAVESHAPER && !is_frozen_node(n)) {
             li.dk = DK_WAVESHAPER;  // (without a curve: ptr0 == null, output = input)
             const size_t cn = n.curve.size();
             const float mid = cn == 0 ? 0.f : (cn % 2 ? n.curve[cn / 2] : (n.curve[cn / 2 - 1] + n.curve[cn / 2]) / 2.f);
@@ -1452,6 +1494,17 @@ int build_plan(waa_batch* b) {
           }
           if (kind == WAA_NODE_CONVOLVER && !n.has_ir) li.flags |= 2;
           if (kind == WAA_NODE_ANALYSER) li.publish_upmix = 1;  // the analyser FFT reads a static stereo signal
+          if (is_frozen_node(n)) {
+            // the item publishes the node's INPUT (n.hist) and its codes; n.sig is written by the node-major steps
+            li.dk = DK_CONV_IN;
+            int e2 = temp_signal(b, n.in_nch, &n.hist);
+            if (e2) return e2;
+            li.out = n.hist;
+            li.nch_pub = n.in_nch;
+            if ((e2 = alloc_codes(&n.in_code))) return e2;
+            li.out_code = n.in_code;
+            li.publish_upmix = 1;
+          }
           if (kind == WAA_NODE_CONVOLVER && n.has_ir) {
             li.dk = DK_CONV_IN;
             // the item publishes the convolver's INPUT (n.hist); its output signal n.sig is written by the FFT steps
@@ -1512,6 +1565,9 @@ int build_plan(waa_batch* b) {
           const Node& m = b->nodes[v & ~VTX_READER];
           if (m.desc.kind == WAA_NODE_CONVOLVER && m.has_ir)
             return fail(WAA_ERR_OUT_OF_SCOPE, "a ConvolverNode inside a feedback loop is out of scope (node %u)", v & ~VTX_READER);
+          if (is_frozen_node(m))
+            return fail(WAA_ERR_OUT_OF_SCOPE, "an oversampled WaveShaperNode / HRTF PannerNode inside a feedback loop is out of scope (node %u)",
+                        v & ~VTX_READER);
         }
       // AudioParam inputs are summed by a node-major chain in front of the group: their producers must be complete
       bool param_dep = false;
@@ -1548,6 +1604,14 @@ int build_plan(waa_batch* b) {
         }
         if (std::find(pending.begin(), pending.end(), v) == pending.end()) pending.push_back(v);
         pending_nodes.insert(v & ~VTX_READER);
+      }
+      if (unit.scc < 0 && is_frozen_node(n)) {
+        // the group ends with the node's mixed input and its codes; then the link table (which also writes the node's
+        // output codes) and the node-major steps
+        if (int e = flush()) return e;
+        if (!n.in_code) return fail(WAA_ERR_INVALID_STATE, "internal: input codes of node %u", id);
+        int e = n.desc.kind == WAA_NODE_PANNER ? plan_hrtf(b, id, -1) : plan_oversampler(b, id, -1);
+        if (e) return e;
       }
       if (unit.scc < 0 && n.desc.kind == WAA_NODE_CONVOLVER && n.has_ir) {
         // the group ends with the convolver's mixed input; then the node-major FFT steps and the code kernel
@@ -1638,7 +1702,7 @@ int build_plan(waa_batch* b) {
         st.group = group;
         // steps that only depend on data from outside the loop run once, over the full range, before the blocks
         st.prologue = st.kind == 5 || st.kind == 12 || st.kind == 13 || st.kind == 14 || st.kind == 3 || (st.kind == 0 && st.chain.n_ops == 1 && st.chain.ops[0].kind == OP_PARAM_ADD);
-        if (st.kind == 2 || st.kind == 4)
+        if (st.kind == 2 || st.kind == 4 || st.kind == 15 || st.kind == 16 || st.kind == 17)
           return fail(WAA_ERR_OUT_OF_SCOPE, "this node kind cannot be rendered inside a feedback loop");
       }
       plan_note(b, "feedback loop: block-scheduled, %u tile(s) = %u frames per block, %zu step(s) per block", bt, bt * TILE,
@@ -1744,6 +1808,8 @@ StepIo step_io(const Step& st) {
       break;
     case 8:
     case 10:
+    case 16:
+    case 17:
       io.reads = st.loop_reads;
       io.writes = st.loop_writes;
       break;
@@ -2259,6 +2325,8 @@ int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items) {
     std::memset(&li, 0, sizeof li);
     if (n.in_nch > 2 || n.out_nch > 2)
       return fail(WAA_ERR_OUT_OF_SCOPE, "feedback loops render at most 2 channels per signal (node %u)", id);
+    if (is_frozen_node(n))
+      return fail(WAA_ERR_OUT_OF_SCOPE, "an oversampled WaveShaperNode / HRTF PannerNode inside a feedback loop is out of scope (node %u)", id);
     for (auto& pe : n.pin_edges)
       for (int e : pe)
         if (out_item.count(b->edges[e].from))
