@@ -84,6 +84,12 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
             tail = delay.connect(ctx.create_biquad_filter(type_="lowpass", frequency=4000.0))
         tail.connect(ctx.create_gain(gain=0.5)).connect(delay)
         tail.connect(ctx.destination())
+    if name in ("os2", "os4"):  # WaveShaper with 2x / 4x oversampling (waveshaper.rs:409-481)
+        node = node.connect(ctx.create_wave_shaper(curve=np.tanh(np.linspace(-3.0, 3.0, 2049)).astype(np.float32),
+                                                   oversample="2x" if name == "os2" else "4x"))
+    if name == "hrtf":  # PannerNode, HRTF panning model (panner.rs:781-829), static geometry
+        waa.set_hrtf_database(os.path.join(ROOT, "tests", "golden", "IRC_1003_C.bin"))
+        node = node.connect(ctx.create_panner(panning_model="HRTF", position=(1.0, 0.5, -0.5)))
     if name == "c5":
         src.playback_rate.set_value(1.5)
         src.set_loop(True)
@@ -102,6 +108,12 @@ ALG_BYTES["fb"] = ALG_BYTES["fbq"] = 2048.0
 ALG_BYTES["fm"] = 1024.0
 ALG_BYTES["osc"] = 1024.0   # no input; 2 output channels x 128 frames x 4 B
 ALG_BYTES["echo"] = 2048.0
+ALG_BYTES["os2"] = ALG_BYTES["os4"] = 2048.0
+ALG_BYTES["hrtf"] = 2048.0
+# f32 FMA work per context-quantum of the compute-bound workloads (2 flops per multiply-add): both resampling stages of
+# the oversampled WaveShaper as matrix products (2 channels x (128R x 256 + 128 x 256R)), the HRTF FIR (128 frames x 2 ears
+# x 512 taps at 44.1 / 48 kHz -> 415 taps at 48 kHz)
+ALG_FLOPS = {"os2": 2 * 2.0 * (256 * 256 + 128 * 512), "os4": 2 * 2.0 * (512 * 256 + 128 * 1024), "hrtf": 2.0 * 128 * 2 * 415}
 IIR_ORDERS = (2, 4, 8, 12, 19)
 for _o in IIR_ORDERS:
     ALG_BYTES[f"iir{_o}"] = 2048.0
@@ -115,6 +127,9 @@ DESCR = {
 }
 DESCR["c1a"] = ("C1 a-rate variant x {n}: {s:g} s, BufferSource->Biquad(lowpass, frequency exponential ramp 10 Hz->10 kHz, "
                 "per-sample coefficients)->destination")
+DESCR["os2"] = "WaveShaper 2x: {n} contexts x {s:g} s, BufferSource(stereo)->WaveShaper(tanh 2049-pt, oversample 2x)->destination"
+DESCR["os4"] = "WaveShaper 4x: {n} contexts x {s:g} s, BufferSource(stereo)->WaveShaper(tanh 2049-pt, oversample 4x)->destination"
+DESCR["hrtf"] = "HRTF panner: {n} contexts x {s:g} s, BufferSource(stereo)->PannerNode(HRTF, static position)->destination"
 DESCR["fm"] = "two-operator FM: {n} contexts x {s:g} s, Oscillator->Gain(300)->carrier.frequency, carrier->Gain->destination"
 DESCR["osc"] = "subtractive voice: {n} contexts x {s:g} s, Oscillator(sawtooth 110 Hz, detuned)->Biquad(lowpass)->Gain->destination"
 DESCR["echo"] = "feed-forward echo: {n} contexts x {s:g} s, BufferSource->destination + BufferSource->Delay(0.25s)->Gain(0.5)->destination"
@@ -262,6 +277,14 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
         if pmc and "kernels" in pmc:
             roof["traffic_per_kernel"] = pmc["kernels"]
     roof["frac"] = roof["achieved"] / 8000.0
+    if name in ALG_FLOPS:
+        # compute-bound rows (f32 FMA; no MFMA format with enough mantissa except the f32 one, same peak): flops of the
+        # dominant kernels / their time against the 157.3 TFLOP/s f32 peak of MI355X_MICROARCH.md
+        flops = ALG_FLOPS[name] * n_inst * nq
+        comp_ms = sum(ms / max(l, 1) * (l / total_launch_steps) for n_, l, ms in prof if n_.startswith(("qgemm", "hrtf")))
+        roof.update({"bound": "valu_f32", "peak": 157.3, "unit": "TFLOP/s", "achieved": flops / (comp_ms * 1e-3) / 1e12,
+                     "algorithmic_flops_per_step": flops, "compute_kernel_ms_per_step": comp_ms})
+        roof["frac"] = roof["achieved"] / 157.3
     return {
         "value": world * n_inst * nq * steps / elapsed,
         "ms_per_step": ms_per_step,

@@ -14,6 +14,8 @@
  *   waa_source_start/stop/loop  AudioBufferSourceNode::start_at_with_offset_and_duration / stop_at / set_loop*
  *                                                                             src/node/audio_buffer_source.rs:388-398
  *   waa_convolver_set_buffer    ConvolverNode::set_buffer                     src/node/convolver.rs:259-317
+ *   waa_*_set_buffer_pcm16*     BaseAudioContext::decode_audio_data_sync      src/context/base.rs:68-73, src/decoding.rs:15-54
+ *                               (+ AudioBuffer::resample src/buffer.rs:311-363) feeding the two set_buffer calls above
  *   waa_waveshaper_set_curve    WaveShaperNode::set_curve                     src/node/waveshaper.rs:489-509 (onmessage)
  *   waa_hrtf_load_sphere        load_hrtf_processor (include_bytes!(IRC_1003_C.bin) -> hrtf::HrirSphere::new)
  *                                                                             src/node/panner.rs:39-68
@@ -202,6 +204,19 @@ waa_status waa_source_start(waa_batch* batch, uint32_t node, uint32_t instance, 
 waa_status waa_source_stop(waa_batch* batch, uint32_t node, uint32_t instance, double when);
 waa_status waa_source_set_loop(waa_batch* batch, uint32_t node, uint32_t instance, int32_t is_looping,
                                double loop_start, double loop_end);
+
+/* BaseAudioContext::decode_audio_data_sync (src/context/base.rs:68-73 -> src/decoding.rs:15-54) for input the decoder
+ * delivers as 16-bit PCM (WAV): interleaved i16 frames in, the sample conversion (sample / 32768) and
+ * AudioBuffer::resample to the context's sample rate (src/buffer.rs:311-363) run on the device.  The resulting
+ * AudioBuffer has the context's rate.  Half the host-to-device bytes of the f32 entry points; bit-identical to
+ * converting and calling waa_buffer_resample on the host.  `_batch`: data = [n_instances][frames][n_channels]. */
+waa_status waa_source_set_buffer_pcm16(waa_batch* batch, uint32_t node, uint32_t instance, const int16_t* interleaved,
+                                       uint32_t n_channels, uint64_t frames, float sample_rate);
+waa_status waa_source_set_buffer_pcm16_batch(waa_batch* batch, uint32_t node, const int16_t* data, uint32_t n_channels,
+                                             uint64_t frames, float sample_rate);
+/* ... followed by ConvolverNode::set_buffer with the decoded buffer (src/node/convolver.rs:259-317) */
+waa_status waa_convolver_set_buffer_pcm16(waa_batch* batch, uint32_t node, const int16_t* interleaved, uint32_t n_channels,
+                                          uint64_t frames, float sample_rate);
 
 /* Impulse response shared by all instances. sample_rate must equal the context's
  * (NotSupportedError otherwise), n_channels in {1,2,4}. */

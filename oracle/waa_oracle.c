@@ -1854,6 +1854,61 @@ waa_status orc_convolver_set_buffer(orc_batch* b, uint32_t node, const float* co
 }
 
 /* waveshaper.rs:489-509 */
+/* BaseAudioContext::decode_audio_data_sync (context/base.rs:68-73 -> decoding.rs:15-54) for input that decodes to
+ * 16-bit PCM: symphonia's i16 -> f32 conversion (third party; restated: sample / 32768), then AudioBuffer::resample to
+ * the context's rate (buffer.rs:311-363).  Returns planes [n_ch][*target] (malloc). */
+uint64_t orc_buffer_resample(const float* src, uint64_t frames, float source_sr, float target_sr, float* dst, uint64_t cap);
+static float* decode_pcm16(const int16_t* pcm, uint32_t n_ch, uint64_t frames, float src_sr, float ctx_sr, uint64_t* target) {
+  float* plane = (float*)calloc(frames ? frames : 1, sizeof(float));
+  *target = orc_buffer_resample(plane, frames, src_sr, ctx_sr, NULL, 0);
+  float* out = (float*)malloc(sizeof(float) * (size_t)n_ch * (*target ? *target : 1));
+  for (uint32_t c = 0; c < n_ch; c++) {
+    for (uint64_t i = 0; i < frames; i++) plane[i] = (float)pcm[i * n_ch + c] / 32768.f;
+    orc_buffer_resample(plane, frames, src_sr, ctx_sr, out + (size_t)c * *target, *target);
+  }
+  free(plane);
+  return out;
+}
+waa_status orc_source_set_buffer_pcm16(orc_batch* b, uint32_t node, uint32_t inst, const int16_t* interleaved, uint32_t n_ch,
+                                       uint64_t frames, float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_inst(b, inst))) return e;
+  if (n_ch == 0 || n_ch > ORC_MAXC) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
+  if (!(sr >= 3000.f && sr <= 768000.f)) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid sample rate: %f", sr);
+  uint64_t target = 0;
+  float* planes = decode_pcm16(interleaved, n_ch, frames, sr, b->sr, &target);
+  const float* chans[ORC_MAXC];
+  for (uint32_t c = 0; c < n_ch; c++) chans[c] = planes + (size_t)c * target;
+  e = orc_source_set_buffer(b, node, inst, chans, n_ch, target, b->sr);
+  free(planes);
+  return e;
+}
+waa_status orc_source_set_buffer_pcm16_batch(orc_batch* b, uint32_t node, const int16_t* data, uint32_t n_ch, uint64_t frames,
+                                             float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE))) return e;
+  for (uint32_t k = 0; k < b->n_inst; k++)
+    if ((e = orc_source_set_buffer_pcm16(b, node, k, data + (size_t)k * frames * n_ch, n_ch, frames, sr))) return e;
+  return WAA_OK;
+}
+waa_status orc_convolver_set_buffer(orc_batch* b, uint32_t node, const float* const* channels, uint32_t n_ch, uint64_t frames,
+                                    float sr);
+waa_status orc_convolver_set_buffer_pcm16(orc_batch* b, uint32_t node, const int16_t* interleaved, uint32_t n_ch, uint64_t frames,
+                                          float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_CONVOLVER))) return e;
+  if (!(n_ch == 1 || n_ch == 2 || n_ch == 4))
+    return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - the convolution buffer must consist of 1, 2 or 4 channels");
+  if (!(sr >= 3000.f && sr <= 768000.f)) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid sample rate: %f", sr);
+  uint64_t target = 0;
+  float* planes = decode_pcm16(interleaved, n_ch, frames, sr, b->sr, &target);
+  const float* chans[4];
+  for (uint32_t c = 0; c < n_ch; c++) chans[c] = planes + (size_t)c * target;
+  e = orc_convolver_set_buffer(b, node, chans, n_ch, target, b->sr);
+  free(planes);
+  return e;
+}
+
 waa_status orc_waveshaper_set_curve(orc_batch* b, uint32_t node, const float* curve, uint32_t nn) {
   int e;
   if ((e = check_node(b, node, WAA_NODE_WAVESHAPER))) return e;

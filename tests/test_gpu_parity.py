@@ -557,3 +557,31 @@ def test_audio_rate_listener_automation(hip, orc, nch):
         ctx.close()
     assert rms_err(*outs).max() <= TOL
     assert np.abs(outs[0] - outs[1]).max() <= 5e-6
+
+
+@pytest.mark.parametrize("listener_too", [False, True])
+def test_per_instance_panner_automation(hip, orc, listener_too):
+    """Per-instance event lists on an equal-power PannerNode's OWN params with a single-valued listener: the geometry is
+    evaluated once per quantum from the first value of every param (panner.rs:833-846) — host work; only AudioListener
+    params are replayed on the device.  With `listener_too` a listener param is automated per instance as well (then
+    the per-frame geometry kernel consumes the device replay of the listener and the value blocks of the panner)."""
+    sr, n, frames = 48000.0, 4, RQ * 40 + 3
+    noise = white_noise(n, 1, frames, seed0=31)
+    outs = []
+    for b in (hip, orc):
+        ctx = waa.OfflineAudioContext(2, frames, sr, n_instances=n, binding=b)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(noise, sr)
+        pn = ctx.create_panner(distance_model="inverse", rolloff_factor=1.2, position=(0.5, 0.2, -1.0))
+        for i in range(n):
+            pn.position_x.set_value_at_time(-2.0 + i, 0.0, instance=i)
+            pn.position_x.linear_ramp_to_value_at_time(3.0 - 0.5 * i, frames / sr * (0.5 + 0.1 * i), instance=i)
+            if listener_too:
+                ctx.listener().position_z.set_value_at_time(0.5 * i, RQ * 5 / sr, instance=i)
+                ctx.listener().position_z.linear_ramp_to_value_at_time(-1.0 - i, RQ * 30 / sr, instance=i)
+        src.connect(pn).connect(ctx.destination())
+        src.start()
+        outs.append(ctx.start_rendering_sync().data)
+        ctx.close()
+    assert rms_err(*outs).max() <= TOL
+    assert np.abs(outs[0] - outs[1]).max() <= 5e-6

@@ -90,6 +90,9 @@ ABI = {
     "device_count": (C.c_int32, []),
     "source_set_buffer": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FPP, C.c_uint32, C.c_uint64, C.c_float]),
     "source_set_buffer_batch": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32, C.c_uint64, C.c_float]),
+    "source_set_buffer_pcm16": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_int16), C.c_uint32, C.c_uint64, C.c_float]),
+    "source_set_buffer_pcm16_batch": (C.c_int32, [_VP, C.c_uint32, C.POINTER(C.c_int16), C.c_uint32, C.c_uint64, C.c_float]),
+    "convolver_set_buffer_pcm16": (C.c_int32, [_VP, C.c_uint32, C.POINTER(C.c_int16), C.c_uint32, C.c_uint64, C.c_float]),
     "source_adopt_device": (C.c_int32, [_VP, C.c_uint32, _VP, C.c_uint32, C.c_uint64, C.c_float]),
     "source_start": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]),
     "source_stop": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_double]),
@@ -399,6 +402,8 @@ class AudioBufferSourceNode(_ScheduledSource):
         self.params = [self.playback_rate, self.detune]
         self._buffers = {}
         self._batch = None
+        self._pcm = None
+        self._pcm_one = {}
         self._device = None
         self._loop = {}
 
@@ -409,6 +414,17 @@ class AudioBufferSourceNode(_ScheduledSource):
     def set_buffer_batch(self, data, sample_rate: float):
         """data: [n_instances, channels, frames], distinct per instance."""
         self._batch = (_f32(data), float(np.float32(sample_rate)))
+        return self
+
+    def set_buffer_pcm16_batch(self, pcm, sample_rate: float):
+        """decode_audio_data_sync for decoded 16-bit PCM: pcm = [n_instances, frames, channels] int16 (interleaved); the
+        sample conversion and the resampling to the context's rate run in the library (on the device)."""
+        self._pcm = (np.ascontiguousarray(pcm, dtype=np.int16), float(np.float32(sample_rate)))
+        return self
+
+    def set_buffer_pcm16(self, pcm, sample_rate: float, instance: int = ALL):
+        """pcm = [frames, channels] int16 for one instance (or all)."""
+        self._pcm_one[instance] = (np.ascontiguousarray(pcm, dtype=np.int16), float(np.float32(sample_rate)))
         return self
 
     def adopt_device_buffer(self, device_ptr: int, n_channels: int, frames: int, sample_rate: float):
@@ -437,6 +453,13 @@ class AudioBufferSourceNode(_ScheduledSource):
             data, sr = self._batch
             assert data.ndim == 3 and data.shape[0] == ctx.n_instances
             b.check(b.source_set_buffer_batch(h, self.id, _fp(data), data.shape[1], data.shape[2], sr))
+        _I16 = C.POINTER(C.c_int16)
+        if self._pcm is not None:
+            pcm, sr = self._pcm
+            assert pcm.ndim == 3 and pcm.shape[0] == ctx.n_instances
+            b.check(b.source_set_buffer_pcm16_batch(h, self.id, pcm.ctypes.data_as(_I16), pcm.shape[2], pcm.shape[1], sr))
+        for inst, (pcm, sr) in sorted(self._pcm_one.items(), key=lambda kv: kv[0] != ALL):
+            b.check(b.source_set_buffer_pcm16(h, self.id, inst, pcm.ctypes.data_as(_I16), pcm.shape[1], pcm.shape[0], sr))
         for inst, buf in sorted(self._buffers.items(), key=lambda kv: kv[0] != ALL):
             b.check(b.source_set_buffer(h, self.id, inst, _chan_ptrs(buf.data), buf.number_of_channels, buf.length,
                                         buf.sample_rate))
@@ -576,10 +599,24 @@ class ConvolverNode(AudioNode):
         self._normalize_at_set = self.normalize
         return self
 
+    def set_buffer_pcm16(self, pcm, sample_rate: float):
+        """decode_audio_data_sync + set_buffer: pcm = [frames, channels] int16 at `sample_rate`; decoded and resampled to
+        the context's rate by the library (on the device)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        if pcm.shape[1] not in (1, 2, 4):
+            raise WaaError(2, "NotSupportedError - the convolution buffer must consist of 1, 2 or 4 channels")
+        self._pcm = (pcm, float(np.float32(sample_rate)))
+        self._normalize_at_set = self.normalize
+        return self
+
     def _fill_desc(self, d):
         d.i[0] = 0 if self._normalize_at_set else 1
 
     def _apply(self, ctx):
+        if getattr(self, "_pcm", None) is not None:
+            pcm, sr = self._pcm
+            ctx._b.check(ctx._b.convolver_set_buffer_pcm16(ctx._handle, self.id, pcm.ctypes.data_as(C.POINTER(C.c_int16)),
+                                                           pcm.shape[1], pcm.shape[0], sr))
         if self.buffer is not None:
             b, h = ctx._b, ctx._handle
             buf = self.buffer

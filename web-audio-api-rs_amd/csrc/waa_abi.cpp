@@ -268,6 +268,101 @@ waa_status waa_source_set_buffer_batch(waa_batch* b, uint32_t node, const float*
   return WAA_OK;
 }
 
+// BaseAudioContext::decode_audio_data_sync for decoded 16-bit PCM (decoding.rs:15-54): sample conversion and
+// AudioBuffer::resample to the context's rate run on the device (waa_decode.hip); `planes` = [n_items][n_ch][stride]
+static int decode_pcm16(waa_batch* b, const int16_t* pcm, uint32_t n_items, uint32_t n_ch, uint64_t frames, float src_sr,
+                        float** planes, uint64_t* stride_out, uint64_t* target_out) {
+  const bool same = std::fabs(src_sr - b->sr) <= 0.1f || frames == 0;  // buffer.rs:315-324
+  const uint64_t target = same ? frames : (uint64_t)std::ceil((double)frames * ((double)b->sr / (double)src_sr));
+  const uint64_t stride = (target + 3) / 4 * 4;
+  float* d = nullptr;
+  int e = dev_alloc(b, &d, (size_t)n_items * n_ch * std::max<uint64_t>(stride, 4), true);
+  if (e) return e;
+  *planes = d;
+  *stride_out = stride;
+  *target_out = target;
+  if (frames == 0) return 0;
+  if (b->dry) {  // plan-only batches have no device: the same arithmetic on the host
+    std::vector<float> plane(frames);
+    for (uint32_t it = 0; it < n_items; it++)
+      for (uint32_t c = 0; c < n_ch; c++) {
+        for (uint64_t i = 0; i < frames; i++) plane[i] = (float)pcm[((uint64_t)it * frames + i) * n_ch + c] / 32768.f;
+        waa_buffer_resample(plane.data(), frames, src_sr, b->sr, d + ((size_t)it * n_ch + c) * stride, target);
+      }
+    return 0;
+  }
+  int16_t* d_pcm = nullptr;
+  const size_t bytes = (size_t)n_items * frames * n_ch * sizeof(int16_t);
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_pcm), bytes));
+  hipError_t he = hipMemcpyAsync(d_pcm, pcm, bytes, hipMemcpyHostToDevice, b->stream);
+  if (he == hipSuccess) {
+    waa::DecodeDesc dd{};
+    dd.pcm = d_pcm;
+    dd.out = d;
+    dd.frames = frames;
+    dd.target_frames = target;
+    dd.out_item_stride = (uint64_t)n_ch * stride;
+    dd.out_ch_stride = stride;
+    dd.nch = n_ch;
+    dd.n_items = n_items;
+    dd.resample = same ? 0 : 1;
+    dd.scale = 1.f;
+    waa::launch_pcm16_resample(dd, b->stream);
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = hipStreamSynchronize(b->stream);
+  (void)hipFree(d_pcm);
+  if (he != hipSuccess) return fail(WAA_ERR_DEVICE, "HIP error %s in the PCM decode path", hipGetErrorString(he));
+  return 0;
+}
+
+waa_status waa_source_set_buffer_pcm16(waa_batch* b, uint32_t node, uint32_t inst, const int16_t* interleaved, uint32_t n_ch,
+                                       uint64_t frames, float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
+  if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
+  if (!(sr >= 3000.f && sr <= 768000.f)) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid sample rate: %f", sr);
+  if (!b->dry) HIP_TRY(hipSetDevice(b->device));
+  float* d = nullptr;
+  uint64_t stride = 0, target = 0;
+  if ((e = decode_pcm16(b, interleaved, 1, n_ch, frames, sr, &d, &stride, &target))) return e;
+  DeviceBuffer db;
+  db.base = d;
+  db.ch_stride = stride;
+  db.frames = target;
+  db.nch = n_ch;
+  db.sr = b->sr;
+  db.valid = true;
+  Node& n = b->nodes[node];
+  uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  for (uint32_t k = lo; k < hi; k++) n.bufs[k] = db;
+  return WAA_OK;
+}
+
+waa_status waa_source_set_buffer_pcm16_batch(waa_batch* b, uint32_t node, const int16_t* data, uint32_t n_ch, uint64_t frames,
+                                             float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_unplanned(b))) return e;
+  if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
+  if (!(sr >= 3000.f && sr <= 768000.f)) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid sample rate: %f", sr);
+  if (!b->dry) HIP_TRY(hipSetDevice(b->device));
+  float* d = nullptr;
+  uint64_t stride = 0, target = 0;
+  if ((e = decode_pcm16(b, data, b->n_inst, n_ch, frames, sr, &d, &stride, &target))) return e;
+  Node& n = b->nodes[node];
+  for (uint32_t k = 0; k < b->n_inst; k++) {
+    DeviceBuffer db;
+    db.base = d + (size_t)k * n_ch * stride;
+    db.ch_stride = stride;
+    db.frames = target;
+    db.nch = n_ch;
+    db.sr = b->sr;
+    db.valid = true;
+    n.bufs[k] = db;
+  }
+  return WAA_OK;
+}
+
 waa_status waa_source_adopt_device(waa_batch* b, uint32_t node, const float* device_data, uint32_t n_ch, uint64_t frames,
                                    float sr) {
   int e;
@@ -378,6 +473,33 @@ waa_status waa_convolver_set_buffer(waa_batch* b, uint32_t node, const float* co
   n.ir_nch = (int)n_ch;
   n.has_ir = true;
   return WAA_OK;
+}
+
+// decode_audio_data_sync + ConvolverNode::set_buffer: the impulse response is decoded and resampled on the device, the
+// normalisation (convolver.rs:16-53: a sequential f32 sum, order-dependent) stays where set_buffer does it
+waa_status waa_convolver_set_buffer_pcm16(waa_batch* b, uint32_t node, const int16_t* interleaved, uint32_t n_ch, uint64_t frames,
+                                          float sr) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_CONVOLVER)) || (e = check_unplanned(b))) return e;
+  if (!(n_ch == 1 || n_ch == 2 || n_ch == 4))
+    return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - the convolution buffer must consist of 1, 2 or 4 channels");
+  if (!(sr >= 3000.f && sr <= 768000.f)) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid sample rate: %f", sr);
+  if (!b->dry) HIP_TRY(hipSetDevice(b->device));
+  float* d = nullptr;
+  uint64_t stride = 0, target = 0;
+  if ((e = decode_pcm16(b, interleaved, 1, n_ch, frames, sr, &d, &stride, &target))) return e;
+  std::vector<std::vector<float>> host(n_ch, std::vector<float>(target));
+  std::vector<const float*> ptrs(n_ch);
+  for (uint32_t c = 0; c < n_ch; c++) {
+    if (target) {
+      if (b->dry)
+        std::memcpy(host[c].data(), d + (size_t)c * stride, target * sizeof(float));
+      else
+        HIP_TRY(hipMemcpy(host[c].data(), d + (size_t)c * stride, target * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    ptrs[c] = host[c].data();
+  }
+  return waa_convolver_set_buffer(b, node, ptrs.data(), n_ch, target, b->sr);
 }
 
 waa_status waa_waveshaper_set_curve(waa_batch* b, uint32_t node, const float* curve, uint32_t nn) {

@@ -515,6 +515,19 @@ struct HrtfDesc {
 };
 void launch_hrtf(const HrtfDesc& d, void* stream);
 
+// ---- input preparation on the device (waa_decode.hip): decoded 16-bit PCM -> f32 planes at the context rate ----
+struct DecodeDesc {
+  const int16_t* pcm;        // [n_items][frames][nch] interleaved
+  float* out;                // planes: out[item * out_item_stride + ch * out_ch_stride + frame]
+  uint64_t frames;           // source frames per item
+  uint64_t target_frames;    // ceil(frames * ratio), or frames when the rates match (buffer.rs:315-318)
+  uint64_t out_item_stride, out_ch_stride;
+  uint32_t nch, n_items;
+  int32_t resample;
+  float scale;               // 1 (kept for callers that fold a constant gain in)
+};
+void launch_pcm16_resample(const DecodeDesc& d, void* stream);
+
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);
 // waa_resample.hip: AudioBufferSource [-> WaveShaper] -> signal without the op interpreter (the C5 shape)
