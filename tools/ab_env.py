@@ -20,7 +20,7 @@ def main(argv):
     hip = waa.default_binding()
     noise = torch.empty((n_inst, 2, frames), dtype=torch.float32, device="cuda").uniform_(-1, 1)
     for name in argv[1:]:
-        for rep in range(2):
+        for rep in range(int(os.environ.get("AB_REPS", "2"))):
             for on in (False, True):
                 os.environ.pop(var, None)
                 if on:
@@ -31,10 +31,11 @@ def main(argv):
                 ctx.sync()
                 ctx.profile(True)
                 ctx.profile_reset()
-                for _ in range(5):
+                iters = int(os.environ.get("AB_ITERS", "5"))
+                for _ in range(iters):
                     ctx.render_async()
                 ctx.sync()
-                print(name, f"{var}={'%s' % value if on else '(unset)'}", {n: round(ms / 5, 3) for n, l, ms in ctx.profile_entries()},
+                print(name, f"{var}={'%s' % value if on else '(unset)'}", {n: round(ms / iters, 3) for n, l, ms in ctx.profile_entries()},
                       flush=True)
                 ctx.close()
     os.environ.pop(var, None)

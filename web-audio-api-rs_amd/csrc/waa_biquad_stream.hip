@@ -551,6 +551,36 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
     uint32_t end = tile + 1;  // [tile, end) = maximal run of fast tiles
     if (is_src && end < si.fast_prefix) end = si.fast_prefix < d.tile1 ? si.fast_prefix : d.tile1;  // no table walk
     while (end < d.tile1 && tile_is_fast(end)) end++;
+    if constexpr (VARY == 0 && NBUF == 4) {
+      // prefetch distance 2: a wave's loads are in flight for two iterations instead of one — the recurrence keeps a
+      // wave busy for ~6 us per tile while its next tile arrives in ~2 us, so with distance 1 most waves have nothing
+      // in flight most of the time and HBM runs below what the same access pattern reaches as a plain copy
+      float na[TILE_K], nb[TILE_K];
+      fetch_fast(tile, na);
+      fetch_fast(tile + 1 < end ? tile + 1 : tile, nb);
+      for (; tile + 1 < end; tile += 2) {
+        stage(na);
+        fetch_fast(tile + 2 < end ? tile + 2 : tile, na);
+        if (pending) flush(pending_tile);
+        process(tile);
+        pending = true;
+        pending_tile = tile;
+        stage(nb);
+        fetch_fast(tile + 3 < end ? tile + 3 : tile + 1, nb);
+        flush(pending_tile);
+        process(tile + 1);
+        pending_tile = tile + 1;
+      }
+      if (tile < end) {
+        stage(na);
+        if (pending) flush(pending_tile);
+        process(tile);
+        pending = true;
+        pending_tile = tile;
+        tile++;
+      }
+      continue;
+    }
     float nx[TILE_K];
     fetch_fast(tile, nx);
     for (; tile < end; tile++) {
@@ -587,6 +617,8 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
     hipLaunchKernelGGL((biquad_stream_kernel_t<1, 0>), grid, block, lds, (hipStream_t)stream, d);
   else if (dbg && dbg[0] == '2')
     hipLaunchKernelGGL((biquad_stream_kernel_t<2, 0>), grid, block, lds, (hipStream_t)stream, d);
+  else if (getenv("WAA_STREAM_PREFETCH2"))  // experiment (A/B with tools/ab_env.py)
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 4>), grid, block, lds, (hipStream_t)stream, d);
   else
     hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0>), grid, block, lds, (hipStream_t)stream, d);
 }

@@ -246,7 +246,7 @@ __global__ void conv_fft_kernel(const ConvDesc d) {
     for (int i4 = tid; i4 < (n >> 2); i4 += nt) {
       const int64_t f = f0 + 4 * (int64_t)i4;
       float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-      if (f >= 0 && (uint64_t)f + 3 < d.frames) {
+      if (f >= 0 && (uint64_t)f + 3 < d.in_valid) {
         va = *reinterpret_cast<const float4*>(pa + f);
         if (has_b) vb = *reinterpret_cast<const float4*>(pb + f);
       }
@@ -489,8 +489,8 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
     const float* pa = d.in.base + (uint64_t)ia * d.in.inst_stride + (uint64_t)c * d.in.ch_stride;
     const float* pb = d.in.base + (uint64_t)(has_b ? ib : ia) * d.in.inst_stride + (uint64_t)c * d.in.ch_stride;
     f4v oa[PIPE_H], ob[PIPE_H], na[PIPE_H], nb[PIPE_H];
-    pipe_load_half(pa, pb, has_b, ((int64_t)k0 - 1) * PIPE_B, d.frames, tid, oa, ob);
-    pipe_load_half(pa, pb, has_b, (int64_t)k0 * PIPE_B, d.frames, tid, na, nb);
+    pipe_load_half(pa, pb, has_b, ((int64_t)k0 - 1) * PIPE_B, d.in_valid, tid, oa, ob);
+    pipe_load_half(pa, pb, has_b, (int64_t)k0 * PIPE_B, d.in_valid, tid, na, nb);
     for (int k = k0; k < k1; k++) {
       // (opaque copy of the thread index: otherwise every LDS address of all five stages is loop-invariant, gets
       // hoisted out of the block loop and ~160 address registers stay live across it)
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
         ob[r] = nb[r];
       }
       // the next block's new half: in flight during the FFT below (all-zero past the end of the stream)
-      pipe_load_half(pa, pb, has_b, k + 1 < k1 ? ((int64_t)k + 1) * PIPE_B : (int64_t)d.frames, d.frames, tid_k, na, nb);
+      pipe_load_half(pa, pb, has_b, k + 1 < k1 ? ((int64_t)k + 1) * PIPE_B : (int64_t)d.in_valid, d.in_valid, tid_k, na, nb);
       pipe_fft_dif(a, w, d.tw, tid_k);
       f4v* dst = reinterpret_cast<f4v*>(d.X + (((uint64_t)pair * d.cin + c) * d.nb + k) * PIPE_N);
 #pragma unroll
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvDesc d) {
     const float* p = d.in.base + (uint64_t)inst * d.in.inst_stride + (uint64_t)c * d.in.ch_stride;
     for (int i = tid; i < DIRECT_TILE + DIRECT_MAX_TAPS; i += 256) {
       const int64_t f = (int64_t)f0 - DIRECT_MAX_TAPS + i;
-      xs[c][i] = (f >= 0 && (uint64_t)f < d.frames) ? p[f] : 0.f;
+      xs[c][i] = (f >= 0 && (uint64_t)f < d.in_valid) ? p[f] : 0.f;
     }
   }
   for (int t = 0; t < d.n_terms; t++)

@@ -9,7 +9,7 @@
 namespace waa {
 namespace host {
 
-int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr);
+int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr);
 
 // ===============================================================================================================
 // WaveShaper oversampling.  One rubato FftResampler stage (synchro.rs), fft_size_in = fi, fft_size_out = fo:
@@ -137,7 +137,8 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
   if (b->dynamic && n.hist.base) {
     in_sig = n.hist;  // dynamic plans: the mixed input was published by the group in front (waa_dyn.hip)
   } else {
-    int e = node_input_signal(b, id, &in_sig);
+    uint64_t valid = 0;  // (a source read in place: whole quanta only, and quanta past its end are skipped, never read)
+    int e = node_input_signal(b, id, &in_sig, nullptr, &valid);
     if (e) return e;
   }
   const size_t cn = n.curve.size();
@@ -318,7 +319,8 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
   if (b->dynamic && n.hist.base) {
     in_sig = n.hist;
   } else {
-    int e = node_input_signal(b, id, &in_sig);
+    uint64_t valid = 0;  // (a source read in place: silent quanta are recognised by their code, never read)
+    int e = node_input_signal(b, id, &in_sig, nullptr, &valid);
     if (e) return e;
   }
   const uint8_t* in_code = nullptr;

@@ -168,6 +168,12 @@ struct Node {
   std::vector<ParamRef> pin_ref;
   std::vector<char> pin_ready;
   int n_consumers = 0;
+  // a BufferSource that renders its AudioBuffer unchanged from frame 0 (fast track, rate 1, no loop, same layout for
+  // every instance) and whose only consumer is a node-major step that takes a bounded view: it is not materialised,
+  // the consumer reads the buffer in place (view_valid frames per channel, zeros beyond)
+  bool is_view = false;
+  SignalRef view_sig{};
+  uint64_t view_valid = 0;
   // dynamic plans (waa_dyn.hip): per-quantum codes of the published signal, and the quantum slot of channel 1 when the
   // signal feeds a mono-IR convolver whose second FFTConvolver only advances on stereo quanta
   uint8_t* code = nullptr;

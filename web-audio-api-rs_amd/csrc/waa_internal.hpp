@@ -199,7 +199,9 @@ struct ConvDesc {
   const Cplx* tw;   // [n] exp(-2 pi i t / n)
   const float* ir;  // [ir_nch][ir_len] scaled, trimmed IR (device) for the IR-spectrum pass
   uint64_t ir_len;
-  uint64_t frames;  // valid frames per channel in `in` / `out` (padded length)
+  uint64_t frames;  // valid frames per channel in `out` (padded length)
+  uint64_t in_valid;  // frames of `in` that may be read (zeros beyond): the padded length, or the AudioBuffer's length when
+                      // `in` is a view of a source's buffer (the source renders its buffer unchanged from frame 0)
   uint32_t n_inst, n_pairs;
   int32_t ir_nch, pad1;
 };

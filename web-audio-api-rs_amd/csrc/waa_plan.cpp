@@ -1142,6 +1142,55 @@ int build_plan(waa_batch* b) {
       // x is either materialised for its own reasons, or a source whose only consumer is this gain
       if (mat_hard[x] || (is_source_kind(xn.desc.kind) && !fan_in_only[x])) n.materialized = false;
     }
+  // A BufferSource whose output IS its AudioBuffer (fast track from frame 0: start 0, no offset / duration / stop /
+  // loop, playbackRate 1, detune 0, buffer at the context's rate, one layout for all instances) and whose single
+  // consumer is a node-major step that accepts a bounded view: read in place, no copy through HBM.
+  for (uint32_t id = 0; id < N && !getenv("WAA_NO_SOURCE_VIEW"); id++) {
+    Node& n = b->nodes[id];
+    n.is_view = false;
+    if (!n.live || n.desc.kind != WAA_NODE_BUFFER_SOURCE || !n.materialized || count_change_found || b->force_dynamic) continue;
+    int consumer = -1, n_live = 0;
+    for (auto& e : b->edges)
+      if (e.from == id && b->nodes[e.to].live) {
+        n_live++;
+        consumer = (e.to_input & 0x80000000u) ? -1 : (int)e.to;
+      }
+    if (n_live != 1 || consumer < 0) continue;
+    const Node& c = b->nodes[(uint32_t)consumer];
+    const bool conv = c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir;
+    bool frozen_ok = false;
+    if (is_frozen_node(c) && frozen_src[(uint32_t)consumer] == (int)id) {
+      if (c.desc.kind == WAA_NODE_PANNER) {
+        frozen_ok = true;
+      } else {  // (a shaper that processes silent quanta would read them from the view: copy instead)
+        const size_t cn = c.curve.size();
+        const float mid = cn == 0 ? 0.f : (cn % 2 ? c.curve[cn / 2] : (c.curve[cn / 2 - 1] + c.curve[cn / 2]) / 2.f);
+        frozen_ok = cn == 0 || std::fabs(mid) < 1e-9f;
+      }
+    }
+    if (!(conv || frozen_ok) || c.in_edges.size() != 1 || c.in_nch != n.out_nch || scc_of[(uint32_t)consumer] >= 0) continue;
+    const ParamStore& pr = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
+    const ParamStore& pd = n.params[WAA_PARAM_SOURCE_DETUNE];
+    bool ok = pr.blocks.empty() && pd.blocks.empty() && pr.timelines.empty() && pd.timelines.empty() && !pr.dev_tl && !pd.dev_tl;
+    const DeviceBuffer& b0 = n.bufs[0];
+    ok = ok && b0.valid && b0.sr == b->sr && (uintptr_t)b0.base % 16 == 0 && b0.ch_stride % 4 == 0 && b0.frames % RQ == 0 && b0.frames > 0;
+    const int64_t inst_stride = b->n_inst > 1 && n.bufs[1].valid ? n.bufs[1].base - b0.base : (int64_t)b0.ch_stride * b0.nch;
+    ok = ok && inst_stride > 0 && inst_stride % 4 == 0;
+    for (uint32_t i = 0; i < b->n_inst && ok; i++) {
+      const DeviceBuffer& bf = n.bufs[i];
+      const SourceSched& ss = n.sched[i];
+      ok = bf.valid && bf.base == b0.base + (int64_t)i * inst_stride && bf.ch_stride == b0.ch_stride && bf.frames == b0.frames &&
+           bf.nch == b0.nch && bf.sr == b0.sr && pr.cst[i] == 1.f && pd.cst[i] == 0.f && ss.start == 0. && ss.stop == DBL_MAX &&
+           ss.offset == 0. && ss.duration == DBL_MAX && !ss.looping;
+    }
+    if (!ok) continue;
+    n.is_view = true;
+    n.materialized = false;
+    n.view_sig = SignalRef{b0.base, (uint64_t)inst_stride, b0.ch_stride, (int32_t)b0.nch, 0};
+    n.view_valid = b0.frames;
+    plan_note(b, "source node %u renders its AudioBuffer unchanged: node %d reads it in place (%llu frames per channel)", id, consumer,
+              (unsigned long long)b0.frames);
+  }
   auto alloc_signal = [&](Node& n) -> int {
     float* p = nullptr;
     int e = dev_alloc(b, &p, (size_t)b->n_inst * n.out_nch * b->lp);
@@ -2023,10 +2072,16 @@ int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int inte
 // + forward FFT / spectral MAC / inverse FFT steps.
 // Input of a node-major step (convolver, delay): the single producer's signal if its channel count already
 // matches, else a mixing chain into a temporary.
-int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr) {
+int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr) {
   Node& n = b->nodes[id];
+  if (valid) *valid = b->lp;
   if (!target && n.in_edges.size() == 1) {
     Node& p = b->nodes[b->edges[n.in_edges[0]].from];
+    if (p.is_view && valid) {  // a source read in place (see build_plan)
+      *out_sig = p.view_sig;
+      *valid = p.view_valid;
+      return 0;
+    }
     if (p.materialized && p.out_nch == n.in_nch) {
       *out_sig = p.sig;
       return 0;
@@ -2431,10 +2486,11 @@ int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items) {
 int plan_convolver(waa_batch* b, uint32_t id) {
   Node& n = b->nodes[id];
   SignalRef in_sig{};
+  uint64_t in_valid = b->lp;
   if (b->dynamic && n.hist.base) {
     in_sig = n.hist;  // dynamic plans: the mixed input was published by the DK_CONV_IN item (waa_dyn.hip)
   } else {
-    int e = node_input_signal(b, id, &in_sig);
+    int e = node_input_signal(b, id, &in_sig, nullptr, &in_valid);
     if (e) return e;
   }
   // one FFTConvolver per IR channel, at least two (convolver.rs:291-306); each trims its own trailing
@@ -2476,6 +2532,7 @@ int plan_convolver(waa_batch* b, uint32_t id) {
   cv.in = in_sig;
   cv.out = n.sig;
   cv.frames = b->lp;
+  cv.in_valid = in_valid;
   cv.n_inst = b->n_inst;
   cv.n_pairs = (b->n_inst + 1) / 2;
   cv.ir_nch = ir_nch;
