@@ -17,6 +17,8 @@
 // formats; f32 MFMA has the same peak as the vector FMA pipe on this part.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "waa_internal.hpp"
 
 namespace waa {
@@ -87,6 +89,18 @@ __device__ __forceinline__ float shape_curve(const float* curve, int nn, float i
   const float f = v - k;
   const int ki = (int)k;
   return (1.f - f) * load_global(curve + ki) + f * load_global(curve + ki + 1);
+}
+constexpr int CURVE_LDS = 4100;
+__device__ __forceinline__ float shape_curve_lds(const float* curve, int nn, float input) {  // waveshaper.rs:555-573
+  if (nn == 0) return 0.f;
+  const float n = (float)nn;
+  const float v = (n - 1.f) / 2.0f * (input + 1.f);
+  if (v <= 0.f) return curve[0];
+  if (v >= n - 1.f) return curve[nn - 1];
+  const float k = floorf(v);
+  const float f = v - k;
+  const int ki = (int)k;
+  return (1.f - f) * curve[ki] + f * curve[ki + 1];
 }
 }  // namespace
 
@@ -190,9 +204,166 @@ __global__ __launch_bounds__(256) void qgemm_kernel(const QGemmDesc d) {
     }
   }
 }
+// The same product on the matrix cores: v_mfma_f32_32x32x2_f32 multiplies f32 by f32 into f32 (exact products, the
+// same peak as the vector FMA pipe — 64 flop / clk / SIMD — but reachable: the FMA form above spends a third of its
+// issue slots on LDS reads and register shuffles).  Operand roles are swapped with respect to the maths: the SOURCE
+// tile (render quanta x k) is the MFMA's A operand and the matrix tile (k x output frames) its B operand, so a lane of
+// the 32 x 32 result block holds 16 quanta of ONE output frame and the 32 lanes of a half-wave hold 32 consecutive
+// frames of one quantum — the epilogue stores are 128-byte runs.  Workgroup tile 128 x 128, one 64 x 64 quadrant (2 x 2
+// result blocks, 64 accumulator registers) per wavefront; staging through LDS exactly as in qgemm_kernel.
+// DBG (WAA_QGEMM_DEBUG, measurement aid; results are wrong by construction): 1 = no stores, 2 = no source loads,
+// 3 = no matrix loads, 4 = no MFMAs
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int DBG>
+__global__ __launch_bounds__(256) void qgemm_mfma_kernel(const QGemmDesc d) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+  __shared__ int32_t prev_s[BN];
+  __shared__ float curve_s[CURVE_LDS];  // the WaveShaper curve (two gathers per output element in the epilogue)
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const bool curve_in_lds = d.curve && d.curve_n <= CURVE_LDS;
+  if (curve_in_lds)
+    for (int i = tid; i < d.curve_n; i += 256) curve_s[i] = load_global(d.curve + i);
+  const int wq = (wave >> 1) * 64, wm = (wave & 1) * 64;  // this wave's quadrant: quanta [wq, wq + 64), frames [wm, wm + 64)
+  const int l32 = lane & 31, kh = lane >> 5;
+  const uint32_t q0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const uint32_t inst = blockIdx.z / (uint32_t)d.nch, ch = blockIdx.z % (uint32_t)d.nch;
+  const float* src = d.src + (uint64_t)inst * d.src_inst + (uint64_t)ch * d.src_ch;
+  if (tid < BN) {
+    const uint32_t q = q0 + tid;
+    prev_s[tid] = q < d.n_quanta ? load_global(d.prev + (uint64_t)inst * d.prev_stride + q) : LINK_SKIP;
+  }
+  __syncthreads();
+  const int K = 2 * d.Kh;
+  // two register sets: a tile is requested TWO k-tiles (two MFMA phases, ~1.7 us) before it is staged into LDS — one
+  // phase (0.85 us) is shorter than the HBM latency under load, and every k-tile then ended in a wait for its loads
+  f4v ra0[2], rb0[2], ra1[2], rb1[2];
+  auto fetch = [&](int kk, f4v (&ra)[2], f4v (&rb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int idx = tid + i * 256;
+      const int ak = idx >> 5, am = (idx & 31) * 4;
+      if constexpr (DBG == 3)
+        ra[i] = f4v{1.f, 1.f, 1.f, 1.f};
+      else
+        ra[i] = load_global_f4(d.A + (uint64_t)(kk + ak) * d.M + m0 + am);
+      const int col = idx >> 2, part = idx & 3;
+      const uint32_t q = q0 + col;
+      const int32_t p = prev_s[col];
+      const bool second = kk >= d.Kh;
+      const int32_t sq = second ? p : (int32_t)q;
+      f4v v = {0.f, 0.f, 0.f, 0.f};
+      if (DBG != 2 && p != LINK_SKIP && sq >= 0)
+        v = load_global_f4(src + (uint64_t)sq * d.src_q + (uint64_t)((second ? kk - d.Kh : kk) + part * 4));
+      rb[i] = v;
+    }
+  };
+  auto stage = [&](int buf, const f4v (&ra)[2], const f4v (&rb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int idx = tid + i * 256;
+      const int ak = idx >> 5, am = (idx & 31) * 4;
+      *reinterpret_cast<f4v*>(&As[buf][ak][am]) = ra[i];
+      const int col = idx >> 2, part = idx & 3;
+      Bs[buf][part * 4 + 0][col] = rb[i].x;
+      Bs[buf][part * 4 + 1][col] = rb[i].y;
+      Bs[buf][part * 4 + 2][col] = rb[i].z;
+      Bs[buf][part * 4 + 3][col] = rb[i].w;
+    }
+  };
+  f16v acc[2][2];  // [quanta block][frame block]
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  auto mfma_tile = [&](int buf) __attribute__((always_inline)) {
+    // all operands of the k-tile first (32 registers), then 32 MFMAs back to back: with the operands read step by step
+    // into the same four registers every group of four MFMAs waited for its LDS reads
+    // A operand (32 x 2): row = quantum l32, k = kh;  B operand (2 x 32): k = kh, column = output frame l32
+    float sv[BK / 2][2], cv[BK / 2][2];
+#pragma unroll
+    for (int k = 0; k < BK; k += 2) {
+      sv[k / 2][0] = Bs[buf][k + kh][wq + l32];
+      sv[k / 2][1] = Bs[buf][k + kh][wq + 32 + l32];
+      cv[k / 2][0] = As[buf][k + kh][wm + l32];
+      cv[k / 2][1] = As[buf][k + kh][wm + 32 + l32];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the reads back between the MFMA groups)
+#pragma unroll
+    for (int k = 0; k < BK / 2; k++) {
+      if constexpr (DBG == 4) {
+        acc[0][0][k] += sv[k][0] * cv[k][0];
+        acc[1][1][k] += sv[k][1] * cv[k][1];
+        continue;
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[k][0], cv[k][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[k][0], cv[k][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[k][1], cv[k][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[k][1], cv[k][1], acc[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  fetch(0, ra0, rb0);
+  stage(0, ra0, rb0);
+  __syncthreads();
+  fetch(BK, ra0, rb0);  // (K >= 2 * BK always: K = 2 * Kh, Kh a multiple of 128)
+  int buf = 0;
+  for (int kk = 0; kk < K; kk += 2 * BK) {
+    // tile kk is in LDS[buf], tile kk + BK in flight in set 0
+    if (kk + 2 * BK < K) fetch(kk + 2 * BK, ra1, rb1);
+    mfma_tile(buf);
+    stage(buf ^ 1, ra0, rb0);
+    __syncthreads();
+    buf ^= 1;
+    // tile kk + BK is in LDS[buf], tile kk + 2 BK in flight in set 1
+    if (kk + 3 * BK < K) fetch(kk + 3 * BK, ra0, rb0);
+    mfma_tile(buf);
+    if (kk + 2 * BK < K) {
+      stage(buf ^ 1, ra1, rb1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  // result block layout: element e of a lane = row (e / 4) * 8 + kh * 4 + e % 4 (quantum), column l32 (output frame)
+  float* dst = d.dst + (uint64_t)inst * d.dst_inst + (uint64_t)ch * d.dst_ch;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const uint32_t q = q0 + (uint32_t)(wq + i * 32 + (e >> 2) * 8 + kh * 4 + (e & 3));
+      if (q >= d.n_quanta) continue;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        float v = acc[i][j][e];
+        if (curve_in_lds)
+          v = shape_curve_lds(curve_s, d.curve_n, v);
+        else if (d.curve)
+          v = shape_curve(d.curve, d.curve_n, v);
+        if constexpr (DBG == 1) {
+          asm volatile("" ::"v"(v));
+        } else {
+          store_global(dst + (uint64_t)q * d.dst_q + m0 + wm + j * 32 + l32, v);
+        }
+      }
+    }
+}
 void launch_qgemm(const QGemmDesc& d, void* stream) {
   dim3 grid((d.n_quanta + BN - 1) / BN, d.M / BM, d.n_inst * (uint32_t)d.nch);
-  hipLaunchKernelGGL(qgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
+  if (getenv("WAA_QGEMM_FMA"))  // (switch: the vector-FMA form, same-box A/B with tools/ab_env.py)
+    hipLaunchKernelGGL(qgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
+  else if (const char* dbg = getenv("WAA_QGEMM_DEBUG")) {
+    switch (dbg[0]) {
+      case '1': hipLaunchKernelGGL(qgemm_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, d); break;
+      case '2': hipLaunchKernelGGL(qgemm_mfma_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, d); break;
+      case '3': hipLaunchKernelGGL(qgemm_mfma_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, d); break;
+      default: hipLaunchKernelGGL(qgemm_mfma_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, d); break;
+    }
+  } else
+    hipLaunchKernelGGL(qgemm_mfma_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
