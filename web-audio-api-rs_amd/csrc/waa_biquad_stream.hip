@@ -601,6 +601,340 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Constant coefficients, second form ("digest"): the same arithmetic seen by the samples, restructured for occupancy.
+// biquad_stream_kernel_t<0, 0> keeps a tile's FIR part w[32] (64 registers) between its two sweeps and owns two LDS
+// buffers: 230 registers and 18 KB per wave = 2 waves per SIMD, and a wave that is inside its ~6 us recurrence has
+// nothing but one prefetched tile in flight.  Here
+//   * sweep 1 does not run the recurrence at all: with constant coefficients the zero-state end state of a lane's 32
+//     frames is LINEAR in them, (y31, y30) = sum_i H_i x_i + Hm1 x[-1] + Hm2 x[-2] with
+//     H_i = b0 g(31-i) + b1 g(30-i) + b2 g(29-i), g(n) = first column of M^n (0 for n < 0) — 68 uniform doubles per
+//     wave, computed once and kept in LDS (broadcast reads); two independent 34-tap dot products instead of a serial
+//     chain of 64 FMAs, and no w[] to keep;
+//   * sweep 2 re-reads x from the lane's LDS row, evaluates the reference's expression in the reference's order
+//     (biquad_filter.rs:877, exactly as the first form) and writes y back IN PLACE;
+//   * one LDS buffer: at the top of the next iteration every lane swaps, chunk by chunk, the finished tile out of LDS
+//     (-> gains -> global store) and the prefetched tile in — same addresses in both directions.
+// 9.2 KB of LDS and < 128 registers per wave: 4 waves per SIMD.  Outputs: the incoming state of a lane is the only
+// thing that is computed differently from the serial reference (as in the first form), f64-accurate either way.
+__global__ __launch_bounds__(64, 4) void biquad_stream_digest_kernel(const BiquadStreamDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  double* htab = reinterpret_cast<double*>(lds + 64 * LDS_ROW);  // [34][2]: H_0..H_31, Hm1, Hm2
+  const uint32_t wid = blockIdx.x;
+  const uint32_t inst = wid / (uint32_t)d.nch;
+  const int ch = (int)(wid % (uint32_t)d.nch);
+  const int lane = threadIdx.x;
+  if (inst >= d.n_inst) return;
+  __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);  // f64 denormals flushed (thread.rs:374-382)
+
+  // wave-uniform values live in SGPRs (one scalar operand per f64 FMA is free): the compiler cannot prove that a value
+  // COMPUTED on the vector unit is uniform and would keep the 25 doubles below in 50 VGPRs
+  auto uni = [](double v) __attribute__((always_inline)) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  };
+  auto uni_m = [&](const M2& m) __attribute__((always_inline)) { return M2{uni(m.a), uni(m.b), uni(m.c), uni(m.d)}; };
+  const double* cp = d.coefs + (uint64_t)inst * d.coef_stride;
+  const double b0 = uni(cp[0]), b1 = uni(cp[1]), b2 = uni(cp[2]), a1 = uni(cp[3]), a2 = uni(cp[4]);
+  M2 A1;
+  {
+    M2 m = {-a1, -a2, 1., 0.};
+#pragma unroll
+    for (int s = 0; s < 5; s++) m = mm(m, m);
+    A1 = uni_m(m);
+  }
+  const M2 A2 = uni_m(mm(A1, A1)), A4 = uni_m(mm(A2, A2)), A8 = uni_m(mm(A4, A4)), A16 = uni_m(mm(A8, A8));
+  M2 Aj = {1., 0., 0., 1.};
+  {
+    const int j = lane & 15;
+    if (j & 1) Aj = mm(Aj, A1);
+    if (j & 2) Aj = mm(Aj, A2);
+    if (j & 4) Aj = mm(Aj, A4);
+    if (j & 8) Aj = mm(Aj, A8);
+  }
+  const int row = lane >> 4;
+  {
+    // g(n) = M^n e1, n = 0..31; lane i < 32 keeps H_i, lanes 32 / 33 keep Hm1 / Hm2
+    double g1 = 1., g2 = 0.;          // g(n)
+    double p1 = 0., p2 = 0.;          // g(n - 1)
+    double q1 = 0., q2 = 0.;          // g(n - 2)
+    double h1 = 0., h2 = 0.;
+    for (int n = 0; n < TILE_K; n++) {
+      // H_{31-n} = b0 g(n) + b1 g(n-1) + b2 g(n-2)
+      if (lane == TILE_K - 1 - n) {
+        h1 = __builtin_fma(b0, g1, __builtin_fma(b1, p1, b2 * q1));
+        h2 = __builtin_fma(b0, g2, __builtin_fma(b1, p2, b2 * q2));
+      }
+      if (n == TILE_K - 1) {
+        if (lane == 32) {  // Hm1 = b1 g(31) + b2 g(30)
+          h1 = __builtin_fma(b1, g1, b2 * p1);
+          h2 = __builtin_fma(b1, g2, b2 * p2);
+        }
+        if (lane == 33) {  // Hm2 = b2 g(31)
+          h1 = b2 * g1;
+          h2 = b2 * g2;
+        }
+      }
+      const double n1 = __builtin_fma(-a1, g1, -(a2 * g2)), n2 = g1;
+      q1 = p1;
+      q2 = p2;
+      p1 = g1;
+      p2 = g2;
+      g1 = n1;
+      g2 = n2;
+    }
+    if (lane < 34) {
+      htab[lane * 2] = h1;
+      htab[lane * 2 + 1] = h2;
+    }
+  }
+  double* st = d.state + (uint64_t)inst * STATE_STRIDE + ch * 4;
+  double cx1 = st[0], cx2 = st[1], cy1 = st[2], cy2 = st[3];
+  float g[2] = {1.f, 1.f};
+  bool g_mute[2] = {false, false}, g_pass[2] = {true, true};
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+    if (k < d.n_gain) {
+      g[k] = d.gain[k].base[inst];
+      g_mute[k] = fabsf(g[k]) <= 1e-6f;
+      g_pass[k] = fabsf(1.f - g[k]) <= 1e-6f;
+    }
+  const bool is_src = d.in.kind == IN_SOURCE;
+  SrcInst si{};
+  SrcSchedule sc{};
+  const float* sig_base = nullptr;
+  if (is_src) {
+    si = d.in.src[inst];
+    sc = si.sc;
+  } else {
+    sig_base = d.in.sig.base + (uint64_t)inst * d.in.sig.inst_stride + (uint64_t)ch * d.in.sig.ch_stride;
+  }
+  float* out_base = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)ch * d.out.ch_stride;
+  auto lds_sync = []() __attribute__((always_inline)) { __builtin_amdgcn_wave_barrier(); };
+  auto fetch_fast = [&](uint32_t tile, float (&dst)[TILE_K]) __attribute__((always_inline)) {
+    const float* p = is_src ? si.base + (uint64_t)ch * si.ch_stride +
+                                  (tile < si.fast_prefix ? si.linear_start + (int64_t)tile * TILE
+                                                         : load_global(&sc.qrec[(uint64_t)tile * QUANTA_PER_TILE].start))
+                            : sig_base + (uint64_t)tile * TILE;
+#pragma unroll
+    for (int j = 0; j < NV4; j++) {
+      const f4v t = load_global_f4(p + j * 256 + lane * 4);
+      dst[j * 4 + 0] = t.x;
+      dst[j * 4 + 1] = t.y;
+      dst[j * 4 + 2] = t.z;
+      dst[j * 4 + 3] = t.w;
+    }
+  };
+  auto tile_is_fast = [&](uint32_t tile) __attribute__((always_inline)) -> bool {
+    return !is_src || tile < si.fast_prefix || (si.aligned && load_global(sc.tile_fast + tile));
+  };
+  // swap: the finished tile `done` (if any) leaves LDS for HBM, the staged registers take its place
+  auto swap_in = [&](const float (&cur)[TILE_K], bool have_done, uint32_t done) __attribute__((always_inline)) {
+    lds_sync();
+    float* op = out_base + (uint64_t)done * TILE;
+#pragma unroll
+    for (int j = 0; j < NV4; j++) {
+      const int r = j * 8 + (lane >> 3), c = (lane & 7) * 4;
+      float4* cell = reinterpret_cast<float4*>(lds + r * LDS_ROW + c);
+      float4 t = *cell;
+      *cell = make_float4(cur[j * 4 + 0], cur[j * 4 + 1], cur[j * 4 + 2], cur[j * 4 + 3]);
+      if (have_done) {
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+          if (k < d.n_gain) {
+            if (g_mute[k]) {
+              t = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (!g_pass[k]) {
+              t.x *= g[k];
+              t.y *= g[k];
+              t.z *= g[k];
+              t.w *= g[k];
+            }
+          }
+        *reinterpret_cast<float4*>(op + j * 256 + lane * 4) = t;
+      }
+    }
+    lds_sync();
+  };
+  auto flush_last = [&](uint32_t done) __attribute__((always_inline)) {
+    lds_sync();
+    float* op = out_base + (uint64_t)done * TILE;
+#pragma unroll
+    for (int j = 0; j < NV4; j++) {
+      const int r = j * 8 + (lane >> 3), c = (lane & 7) * 4;
+      float4 t = *reinterpret_cast<const float4*>(lds + r * LDS_ROW + c);
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (k < d.n_gain) {
+          if (g_mute[k]) {
+            t = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else if (!g_pass[k]) {
+            t.x *= g[k];
+            t.y *= g[k];
+            t.z *= g[k];
+            t.w *= g[k];
+          }
+        }
+      *reinterpret_cast<float4*>(op + j * 256 + lane * 4) = t;
+    }
+  };
+  auto process = [&]() __attribute__((always_inline)) {
+    float* xrow = lds + lane * LDS_ROW;  // this lane's 32 frames; y replaces x chunk by chunk
+    const float4 xlast = *reinterpret_cast<const float4*>(xrow + TILE_K - 4);
+    const float xl1 = xlast.w, xl2 = xlast.z;
+    const float xm1 = __shfl_up(xl1, 1, 64), xm2 = __shfl_up(xl2, 1, 64);
+    const double xs1 = lane == 0 ? cx1 : (double)xm1, xs2 = lane == 0 ? cx2 : (double)xm2;
+    // sweep 1: zero-state end state as two dot products
+    double za, zb, zc, zd;
+    {
+      const double2 hm1 = *reinterpret_cast<const double2*>(htab + 64), hm2 = *reinterpret_cast<const double2*>(htab + 66);
+      za = hm1.x * xs1;
+      zb = hm1.y * xs1;
+      zc = hm2.x * xs2;
+      zd = hm2.y * xs2;
+    }
+#pragma unroll 2
+    for (int c = 0; c < NV4; c++) {
+      const float4 xv = *reinterpret_cast<const float4*>(xrow + c * 4);
+      const double2 h0 = *reinterpret_cast<const double2*>(htab + (c * 4 + 0) * 2);
+      const double2 h1 = *reinterpret_cast<const double2*>(htab + (c * 4 + 1) * 2);
+      const double2 h2 = *reinterpret_cast<const double2*>(htab + (c * 4 + 2) * 2);
+      const double2 h3 = *reinterpret_cast<const double2*>(htab + (c * 4 + 3) * 2);
+      za = __builtin_fma(h0.x, (double)xv.x, za);
+      zb = __builtin_fma(h0.y, (double)xv.x, zb);
+      zc = __builtin_fma(h1.x, (double)xv.y, zc);
+      zd = __builtin_fma(h1.y, (double)xv.y, zd);
+      za = __builtin_fma(h2.x, (double)xv.z, za);
+      zb = __builtin_fma(h2.y, (double)xv.z, zb);
+      zc = __builtin_fma(h3.x, (double)xv.w, zc);
+      zd = __builtin_fma(h3.y, (double)xv.w, zd);
+    }
+    const double z1 = za + zc, z2 = zb + zd;
+    // wavefront scan of the affine maps s -> A s + z (as in the first form)
+    double s1, s2;
+    {
+      double r1 = z1, r2 = z2;
+      double q1 = row_shr<1>(r1), q2 = row_shr<1>(r2);
+      r1 = __builtin_fma(A1.a, q1, __builtin_fma(A1.b, q2, r1));
+      r2 = __builtin_fma(A1.c, q1, __builtin_fma(A1.d, q2, r2));
+      q1 = row_shr<2>(r1);
+      q2 = row_shr<2>(r2);
+      r1 = __builtin_fma(A2.a, q1, __builtin_fma(A2.b, q2, r1));
+      r2 = __builtin_fma(A2.c, q1, __builtin_fma(A2.d, q2, r2));
+      q1 = row_shr<4>(r1);
+      q2 = row_shr<4>(r2);
+      r1 = __builtin_fma(A4.a, q1, __builtin_fma(A4.b, q2, r1));
+      r2 = __builtin_fma(A4.c, q1, __builtin_fma(A4.d, q2, r2));
+      q1 = row_shr<8>(r1);
+      q2 = row_shr<8>(r2);
+      r1 = __builtin_fma(A8.a, q1, __builtin_fma(A8.b, q2, r1));
+      r2 = __builtin_fma(A8.c, q1, __builtin_fma(A8.d, q2, r2));
+      const double e01 = read_lane(r1, 15), e02 = read_lane(r2, 15);
+      const double e11 = read_lane(r1, 31), e12 = read_lane(r2, 31);
+      const double e21 = read_lane(r1, 47), e22 = read_lane(r2, 47);
+      const double t01 = cy1, t02 = cy2;
+      const double t11 = __builtin_fma(A16.a, t01, __builtin_fma(A16.b, t02, e01));
+      const double t12 = __builtin_fma(A16.c, t01, __builtin_fma(A16.d, t02, e02));
+      const double t21 = __builtin_fma(A16.a, t11, __builtin_fma(A16.b, t12, e11));
+      const double t22 = __builtin_fma(A16.c, t11, __builtin_fma(A16.d, t12, e12));
+      const double t31 = __builtin_fma(A16.a, t21, __builtin_fma(A16.b, t22, e21));
+      const double t32 = __builtin_fma(A16.c, t21, __builtin_fma(A16.d, t22, e22));
+      const double T1 = row == 0 ? t01 : row == 1 ? t11 : row == 2 ? t21 : t31;
+      const double T2 = row == 0 ? t02 : row == 1 ? t12 : row == 2 ? t22 : t32;
+      const double ex1 = row_shr<1>(r1), ex2 = row_shr<1>(r2);
+      s1 = __builtin_fma(Aj.a, T1, __builtin_fma(Aj.b, T2, ex1));
+      s2 = __builtin_fma(Aj.c, T1, __builtin_fma(Aj.d, T2, ex2));
+    }
+    // sweep 2: the reference's expression in the reference's order (biquad_filter.rs:877-883), from the true incoming
+    // state; y replaces x in place, 4 frames at a time.  `!y.is_normal() -> 0` only matters for inf / NaN (denormals are
+    // flushed by the hardware mode): a chunk in which one shows up anywhere in the wave is redone with the explicit test
+    double y1 = __builtin_isfinite(s1) ? s1 : 0., y2 = __builtin_isfinite(s2) ? s2 : 0.;
+    double p1 = xs1, p2 = xs2;
+#pragma unroll 1
+    for (int c = 0; c < NV4; c++) {
+      const float4 xv = *reinterpret_cast<const float4*>(xrow + c * 4);
+      const float xf[4] = {xv.x, xv.y, xv.z, xv.w};
+      const double sy1 = y1, sy2 = y2, sp1 = p1, sp2 = p2;
+      float yo[4];
+      float badacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const double xd = (double)xf[j];
+        const double wi = (b0 * xd + b1 * p1) + b2 * p2;
+        p2 = p1;
+        p1 = xd;
+        const double y = (wi - a1 * y1) - a2 * y2;
+        y2 = y1;
+        y1 = y;
+        yo[j] = (float)y;
+        badacc = __builtin_fmaf(yo[j], 0.f, badacc);  // NaN as soon as one output is inf / NaN
+      }
+      if (__any(badacc != badacc)) {
+        y1 = sy1;
+        y2 = sy2;
+        p1 = sp1;
+        p2 = sp2;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const double xd = (double)xf[j];
+          const double wi = (b0 * xd + b1 * p1) + b2 * p2;
+          p2 = p1;
+          p1 = xd;
+          double y = (wi - a1 * y1) - a2 * y2;
+          if (!__builtin_isnormal(y)) y = 0.;
+          y2 = y1;
+          y1 = y;
+          yo[j] = (float)y;
+        }
+      }
+      *reinterpret_cast<float4*>(xrow + c * 4) = make_float4(yo[0], yo[1], yo[2], yo[3]);
+    }
+    cx1 = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xl1), 63));
+    cx2 = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xl2), 63));
+    cy1 = read_lane(y1, 63);
+    cy2 = read_lane(y2, 63);
+  };
+  // Software pipeline per iteration: wait for tile t (requested one iteration ago) -> swap it into LDS while tile t-1
+  // leaves for HBM -> request tile t+1 -> both sweeps of tile t.  Stores and loads are issued back to back, one whole
+  // process() before the next wait: neither sits on the critical path.
+  bool have = false;
+  uint32_t done = 0;
+  uint32_t tile = d.tile0;
+  while (tile < d.tile1) {
+    if (!tile_is_fast(tile)) {
+      float tmp[TILE_K];
+      load_channel_generic(d.in, si, sc, ch, tile, lane, d.n_quanta, tmp);
+      float cur[TILE_K];
+#pragma unroll
+      for (int i = 0; i < TILE_K; i++) cur[i] = tmp[i];
+      swap_in(cur, have, done);
+      process();
+      have = true;
+      done = tile;
+      tile++;
+      continue;
+    }
+    uint32_t end = tile + 1;
+    if (is_src && end < si.fast_prefix) end = si.fast_prefix < d.tile1 ? si.fast_prefix : d.tile1;
+    while (end < d.tile1 && tile_is_fast(end)) end++;
+    float nx[TILE_K];
+    fetch_fast(tile, nx);
+    for (; tile < end; tile++) {
+      swap_in(nx, have, done);
+      fetch_fast(tile + 1 < end ? tile + 1 : tile, nx);
+      process();
+      have = true;
+      done = tile;
+    }
+  }
+  if (have) flush_last(done);
+  if (lane == 0) {
+    st[0] = cx1;
+    st[1] = cx2;
+    st[2] = cy1;
+    st[3] = cy2;
+  }
+}
+
 void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
   const dim3 grid(d.n_inst * (uint32_t)d.nch), block(64);
   const size_t lds = 2 * 64 * LDS_ROW * sizeof(float);
@@ -619,6 +953,11 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
     hipLaunchKernelGGL((biquad_stream_kernel_t<2, 0>), grid, block, lds, (hipStream_t)stream, d);
   else if (getenv("WAA_STREAM_PREFETCH2"))  // experiment (A/B with tools/ab_env.py)
     hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 4>), grid, block, lds, (hipStream_t)stream, d);
+  else if (getenv("WAA_BIQUAD_DIGEST"))  // experiment, bit-identical output; same-box A/B (tools/ab_env.py): no gain — with 4
+                                         // instead of 2 waves per SIMD the kernel runs at the same 1.5-1.65 ms, i.e. what bounds
+                                         // C2 is the memory side of 2048 concurrent streams, not the wave's latency hiding
+    hipLaunchKernelGGL(biquad_stream_digest_kernel, grid, block, 64 * LDS_ROW * sizeof(float) + 34 * 2 * sizeof(double),
+                       (hipStream_t)stream, d);
   else
     hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0>), grid, block, lds, (hipStream_t)stream, d);
 }
