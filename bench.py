@@ -334,11 +334,37 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, n_sub=4):
     one = min(timed(1) for _ in range(2))
     split = min(timed(n_sub) for _ in range(2))
     nbytes = 2.0 * n_inst * 2 * frames * 4
-    return {"workload": "c2", "contexts": n_inst, "single_batch_ms": one, f"split_{n_sub}_batches_ms": split,
-            "host_bytes_moved": nbytes, "effective_GBps_single": nbytes / one / 1e6,
-            "effective_GBps_split": nbytes / split / 1e6,
-            "note": "host (pinned) -> set_buffer_batch -> render -> download_all, batch creation and planning included; "
-                    "PCIe-bound, reported for the boundary only"}
+    rec = {"workload": "c2", "contexts": n_inst, "single_batch_ms": one, f"split_{n_sub}_batches_ms": split,
+           "host_bytes_moved": nbytes, "effective_GBps_single": nbytes / one / 1e6,
+           "effective_GBps_split": nbytes / split / 1e6,
+           "note": "host (pinned) -> set_buffer_batch -> render -> download_all, batch creation and planning included; "
+                   "PCIe-bound, reported for the boundary only"}
+    # the same with the input handed over as decoded 16-bit PCM (waa_source_set_buffer_pcm16_batch: half the upload,
+    # sample conversion on the device) — what a caller that holds WAV data would do
+    try:
+        pcm = torch.empty((n_inst, frames, 2), dtype=torch.int16, pin_memory=True).random_(-32768, 32767)
+        I16 = C.POINTER(C.c_int16)
+
+        def run_pcm(lo, hi):
+            ctx, src = build_workload(waa, hip, "c2", hi - lo, frames, local_rank, None)
+            ctx.prepare()
+            hip.check(hip.source_set_buffer_pcm16_batch(ctx._handle, src.id, C.cast(pcm[lo:hi].data_ptr(), I16), 2, frames, SR))
+            hip.check(hip.render(ctx._handle))
+            hip.check(hip.download_all(ctx._handle, C.cast(host_out[lo:hi].data_ptr(), FP)))
+            ctx.close()
+
+        def timed_pcm():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_pcm(0, n_inst)
+            return (time.perf_counter() - t0) * 1e3
+
+        timed_pcm()
+        rec["pcm16_single_batch_ms"] = min(timed_pcm() for _ in range(2))
+        rec["pcm16_host_bytes_moved"] = n_inst * 2 * frames * (2 + 4.0)
+    except Exception as e:  # reporting only
+        rec["pcm16_error"] = repr(e)
+    return rec
 
 
 def main():
@@ -386,9 +412,9 @@ def main():
     extra = {}
     default_run = name == "c2" and args.instances is None and args.seconds == 10.0 and not args.no_extra
     if default_run:
-        for sub in ("t1", "c3", "c5", "c1a"):
+        for sub in ("t1", "c3", "c5", "c1a", "os2", "hrtf"):
             try:
-                extra[sub] = measure(torch, waa, hip, sub, DEFAULT_INSTANCES[sub], args.seconds, max(3, args.steps // 2),
+                extra[sub] = measure(torch, waa, hip, sub, DEFAULT_INSTANCES.get(sub, 1024), args.seconds, max(3, args.steps // 2),
                                      min(args.warmup, 2) or 1, rank, world, local_rank, dist, backend)
                 extra[sub]["steps"] = max(3, args.steps // 2)
             except Exception as e:  # a sub-record never takes the headline line down

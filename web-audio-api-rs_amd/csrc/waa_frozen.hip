@@ -24,50 +24,103 @@
 namespace waa {
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void link_kernel(const LinkDesc d) {
-  const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
-  if (inst >= d.n_inst) return;
-  const uint8_t* in = d.in_code + (uint64_t)inst * d.code_stride;
-  uint8_t* out = d.out_code ? d.out_code + (uint64_t)inst * d.code_stride : nullptr;
-  int32_t* prev = d.prev + (uint64_t)inst * d.prev_stride;
+// One thread per instance walks its row of codes in order; the rows of the 64 instances of a workgroup are moved
+// through LDS in chunks of 128 quanta, so that global loads and stores are 16-byte pieces of contiguous rows instead of
+// one byte / one word per lane at a stride of a whole row.
+namespace {
+constexpr int LCH = 128;               // quanta per chunk
+constexpr int LCP = LCH + 4;           // row pitch of the byte tiles
+constexpr int LPP = LCH + 1;           // row pitch (words) of the prev tile
+}  // namespace
+__global__ __launch_bounds__(64) void link_kernel(const LinkDesc d) {
+  __shared__ __attribute__((aligned(16))) uint8_t cin[64 * LCP];
+  __shared__ __attribute__((aligned(16))) uint8_t cout[64 * LCP];
+  __shared__ int32_t pv[64 * LPP];
+  const int t = threadIdx.x;
+  const uint32_t inst0 = blockIdx.x * 64, inst = inst0 + t;
+  const bool live = inst < d.n_inst;
   int32_t last = LINK_FRESH;
-  if (d.kind == 0) {
-    // WaveShaperRenderer::process, X2 / X4 (waveshaper.rs:395-400, 409-425): channels_x2 starts at 1 (:526-527)
-    int cur_ch = 1;
-    for (uint32_t q = 0; q < d.n_quanta; q++) {
-      const uint32_t c = in[q];
-      const bool silent = (c & CODE_SILENT) != 0;
-      if (silent && d.can_propagate_silence) {
-        prev[q] = LINK_SKIP;
-        if (out) out[q] = (uint8_t)(1u | CODE_SILENT);
-        continue;
-      }
-      const int nch = silent ? 1 : (int)(c & 7u);
-      if (nch != cur_ch) {  // the resamplers are re-created for the new channel count: their overlap is gone
-        cur_ch = nch;
-        last = LINK_FRESH;
-      }
-      prev[q] = last;
-      last = (int32_t)q;
-      if (out) out[q] = (uint8_t)nch;
+  int cur_ch = 1;               // kind 0: channels_x2 / channels_x4 start at 1 (waveshaper.rs:526-527)
+  uint64_t tail_counter = 0;    // kind 1: only ever grows (panner.rs:697-711)
+  for (uint32_t q0 = 0; q0 < d.n_quanta; q0 += LCH) {
+    // rows in: 64 x 128 B as 512 pieces of 16 B (code_stride is a multiple of 16, rows are 16-byte aligned)
+    for (int p = t; p < 64 * (LCH / 16); p += 64) {
+      const int r = p / (LCH / 16), off = (p % (LCH / 16)) * 16;
+      uint4 v = make_uint4(0x81818181u, 0x81818181u, 0x81818181u, 0x81818181u);
+      if (inst0 + r < d.n_inst && q0 + off < d.code_stride)
+        v = *reinterpret_cast<const uint4*>(d.in_code + (uint64_t)(inst0 + r) * d.code_stride + q0 + off);
+      *reinterpret_cast<uint32_t*>(cin + r * LCP + off + 0) = v.x;
+      *reinterpret_cast<uint32_t*>(cin + r * LCP + off + 4) = v.y;
+      *reinterpret_cast<uint32_t*>(cin + r * LCP + off + 8) = v.z;
+      *reinterpret_cast<uint32_t*>(cin + r * LCP + off + 12) = v.w;
     }
-  } else {
-    // PannerRenderer::process, HRTF (panner.rs:697-711): the tail counter only ever grows
-    uint64_t tail_counter = 0;
-    for (uint32_t q = 0; q < d.n_quanta; q++) {
-      const uint32_t c = in[q];
-      if (c & CODE_SILENT) {
-        if (!((uint64_t)d.tail_frames > tail_counter)) {
-          prev[q] = LINK_SKIP;
-          if (out) out[q] = (uint8_t)(1u | CODE_SILENT);
-          continue;
+    __syncthreads();
+    if (live) {
+      const uint32_t n = d.n_quanta - q0 < (uint32_t)LCH ? d.n_quanta - q0 : (uint32_t)LCH;
+      for (uint32_t i = 0; i < n; i++) {
+        const uint32_t c = cin[t * LCP + i];
+        const bool silent = (c & CODE_SILENT) != 0;
+        int32_t link;
+        uint8_t oc;
+        if (d.kind == 0) {
+          // WaveShaperRenderer::process, X2 / X4 (waveshaper.rs:395-400, 409-425)
+          if (silent && d.can_propagate_silence) {
+            link = LINK_SKIP;
+            oc = (uint8_t)(1u | CODE_SILENT);
+          } else {
+            const int nch = silent ? 1 : (int)(c & 7u);
+            if (nch != cur_ch) {  // the resamplers are re-created for the new channel count: their overlap is gone
+              cur_ch = nch;
+              last = LINK_FRESH;
+            }
+            link = last;
+            last = (int32_t)(q0 + i);
+            oc = (uint8_t)nch;
+          }
+        } else {
+          // PannerRenderer::process, HRTF (panner.rs:697-711)
+          bool skip = false;
+          if (silent) {
+            if (!((uint64_t)d.tail_frames > tail_counter))
+              skip = true;
+            else
+              tail_counter += RQ;
+          }
+          if (skip) {
+            link = LINK_SKIP;
+            oc = (uint8_t)(1u | CODE_SILENT);
+          } else {
+            link = last;
+            last = (int32_t)(q0 + i);
+            oc = (uint8_t)2u;
+          }
         }
-        tail_counter += RQ;
+        pv[t * LPP + i] = link;
+        cout[t * LCP + i] = oc;
       }
-      prev[q] = last;
-      last = (int32_t)q;
-      if (out) out[q] = (uint8_t)2u;
     }
+    __syncthreads();
+    // rows out: prev as 16-byte pieces (4 words), codes as 16-byte pieces
+    for (int p = t; p < 64 * (LCH / 4); p += 64) {
+      const int r = p / (LCH / 4), off = (p % (LCH / 4)) * 4;
+      if (inst0 + r >= d.n_inst) continue;
+      int32_t* dst = d.prev + (uint64_t)(inst0 + r) * d.prev_stride + q0 + off;
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (q0 + off + e < d.n_quanta) dst[e] = pv[r * LPP + off + e];
+    }
+    if (d.out_code)
+      for (int p = t; p < 64 * (LCH / 16); p += 64) {
+        const int r = p / (LCH / 16), off = (p % (LCH / 16)) * 16;
+        if (inst0 + r >= d.n_inst || q0 + off >= d.code_stride) continue;
+        uint4 v;
+        v.x = *reinterpret_cast<const uint32_t*>(cout + r * LCP + off + 0);
+        v.y = *reinterpret_cast<const uint32_t*>(cout + r * LCP + off + 4);
+        v.z = *reinterpret_cast<const uint32_t*>(cout + r * LCP + off + 8);
+        v.w = *reinterpret_cast<const uint32_t*>(cout + r * LCP + off + 12);
+        *reinterpret_cast<uint4*>(d.out_code + (uint64_t)(inst0 + r) * d.code_stride + q0 + off) = v;
+      }
+    __syncthreads();
   }
 }
 void launch_link(const LinkDesc& d, void* stream) {
