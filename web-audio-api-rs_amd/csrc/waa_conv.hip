@@ -306,8 +306,13 @@ struct PipeTw {
   Cplx a1[4];     // pass 2, q = 256: tw[16 (j'' + r * 64)], j'' = tid % 64 (the same for both sets)
   Cplx b1;        // pass 2, q = 64: tw[64 j'']
   Cplx s16;       // q = 16: tw[256 (tid % 16)]
-  Cplx t[4];      // register tail: exp(-2 pi i j / 16), j = 0..3 (uniform)
 };
+// register tail: exp(-2 pi i j / 16), j = 0..3 — the table's entries tw[j * 1024] ((float)cos / (float)sin of the f64 angle)
+// as literals: uniform constants cost no vector registers (the forward kernel was 21 registers over its budget)
+#define PIPE_T(j)                                                                                                          \
+  ((j) == 0 ? Cplx{0x1p+0f, -0x0p+0f}                                                                                       \
+            : (j) == 1 ? Cplx{0x1.d906bcp-1f, -0x1.87de2ap-2f}                                                             \
+                       : (j) == 2 ? Cplx{0x1.6a09e6p-1f, -0x1.6a09e6p-1f} : Cplx{0x1.87de2ap-2f, -0x1.d906bcp-1f})
 // KEEP0 = false: the q = 4096 twiddles (8 per thread) are re-read from the table in every block (L2 hits)
 // instead of living in 16 registers — the forward kernel needs those for its two half windows
 template <bool KEEP0>
@@ -324,8 +329,6 @@ __device__ __forceinline__ PipeTw pipe_twiddles(const Cplx* tw, int tid) {
   for (int q4 = 0; q4 < 4; q4++) r.a1[q4] = tw[((tid % 64) + q4 * 64) * 16];
   r.b1 = tw[(tid % 64) * 64];
   r.s16 = tw[(tid % 16) * 256];
-#pragma unroll
-  for (int j = 0; j < 4; j++) r.t[j] = tw[j * (PIPE_N >> 4)];
   return r;
 }
 // (keeps the LDS address arithmetic of a pass from being hoisted above the previous pass, where it would only
@@ -412,7 +415,7 @@ __device__ __forceinline__ void pipe_fft_dif(Cplx* a, const PipeTw& w, const Cpl
       x[2 * k + 1] = Cplx{v.z, v.w};
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) radix4_dif(x[j], x[j + 4], x[j + 8], x[j + 12], w.t[j], true);
+    for (int j = 0; j < 4; j++) radix4_dif(x[j], x[j + 4], x[j + 8], x[j + 12], PIPE_T(j), true);
 #pragma unroll
     for (int g = 0; g < 4; g++) radix4_dif(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], Cplx{1.f, 0.f}, false);
 #pragma unroll
@@ -434,7 +437,7 @@ __device__ __forceinline__ void pipe_fft_dit_inv(Cplx* a, const PipeTw& w, const
 #pragma unroll
     for (int g = 0; g < 4; g++) radix4_dit(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], Cplx{1.f, 0.f}, false);
 #pragma unroll
-    for (int j = 0; j < 4; j++) radix4_dit(x[j], x[j + 4], x[j + 8], x[j + 12], conj(w.t[j]), true);
+    for (int j = 0; j < 4; j++) radix4_dit(x[j], x[j + 4], x[j + 8], x[j + 12], conj(PIPE_T(j)), true);
 #pragma unroll
     for (int k = 0; k < 8; k++) row[k] = make_float4(x[2 * k].re, x[2 * k].im, x[2 * k + 1].re, x[2 * k + 1].im);
   }
