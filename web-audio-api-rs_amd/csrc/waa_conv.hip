@@ -301,7 +301,7 @@ constexpr int PIPE_ROWS = PIPE_N / 16 / PIPE_NT;  // 16-element register rows pe
 // Stages (q = 4096, 1024) and (256, 64) are paired; q = 16 stays a radix-4 pass; strides 4 and 1 are the register
 // tail on 16 contiguous elements.  Four LDS round trips per FFT instead of six.
 struct PipeTw {
-  Cplx a0[2][4];  // pass 1, q = 4096: tw[j' + r * 1024], j' = tid + set * 512
+                  // pass 1, q = 4096: tw[j' + r * 1024], j' = tid + set * 512: parked in LDS (pipe_park_tw0)
   Cplx b0[2];     // pass 1, q = 1024: tw[4 j']
   Cplx a1[4];     // pass 2, q = 256: tw[16 (j'' + r * 64)], j'' = tid % 64 (the same for both sets)
   Cplx b1;        // pass 2, q = 64: tw[64 j'']
@@ -313,16 +313,12 @@ struct PipeTw {
   ((j) == 0 ? Cplx{0x1p+0f, -0x0p+0f}                                                                                       \
             : (j) == 1 ? Cplx{0x1.d906bcp-1f, -0x1.87de2ap-2f}                                                             \
                        : (j) == 2 ? Cplx{0x1.6a09e6p-1f, -0x1.6a09e6p-1f} : Cplx{0x1.87de2ap-2f, -0x1.d906bcp-1f})
-// KEEP0 = false: the q = 4096 twiddles (8 per thread) are re-read from the table in every block (L2 hits)
-// instead of living in 16 registers — the forward kernel needs those for its two half windows
 template <bool KEEP0>
 __device__ __forceinline__ PipeTw pipe_twiddles(const Cplx* tw, int tid) {
   PipeTw r;
 #pragma unroll
   for (int set = 0; set < 2; set++) {
     const int jp = tid + set * PIPE_NT;
-#pragma unroll
-    for (int q4 = 0; q4 < 4; q4++) r.a0[set][q4] = KEEP0 ? tw[jp + q4 * 1024] : Cplx{0.f, 0.f};
     r.b0[set] = tw[jp * 4];
   }
 #pragma unroll
@@ -356,14 +352,21 @@ __device__ __forceinline__ void pipe_radix16(Cplx* a, int e0, int stride, const 
 #pragma unroll
   for (int m = 0; m < 16; m++) a[pad(e0 + m * stride)] = x[m];
 }
+// KEEP0: the q = 4096 twiddles come from w.a0 or, when `tws` is given, from LDS — set 0 from the 16 KB behind the
+// transform buffer (tws[r * 512 + tid]), set 1 from the two padding slots of rows 2 tid and 2 tid + 1 of the buffer itself
+// (pad() never maps an element there and the register tail touches 16 of a row's 18 slots): 2 x 16 KB that the
+// 16384-point transform leaves unused, exactly 8 twiddles for each of the 512 threads
 template <bool INVERSE, bool KEEP0>
-__device__ __forceinline__ void pipe_pass1(Cplx* a, const PipeTw& w, const Cplx* twg, int tid) {
+__device__ __forceinline__ void pipe_pass1(Cplx* a, const PipeTw& w, const Cplx* twg, int tid, const Cplx* tws = nullptr) {
 #pragma unroll
   for (int set = 0; set < 2; set++) {
     const int jp = opaque(tid) + set * PIPE_NT;
     Cplx twa[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) twa[r] = KEEP0 ? w.a0[set][r] : twg[jp + r * 1024];
+    for (int r = 0; r < 4; r++)
+      twa[r] = !KEEP0 ? twg[jp + r * 1024]
+                      : set == 0 ? tws[r * PIPE_NT + opaque(tid)]
+                                 : a[18 * (2 * opaque(tid) + (r >> 1)) + 16 + (r & 1)];  // (the rows' two padding slots)
     pipe_radix16<INVERSE>(a, jp, 1024, twa, w.b0[set]);
     __builtin_amdgcn_sched_barrier(0);  // one 16-element set at a time: the registers hold the prefetched block
   }
@@ -397,8 +400,23 @@ __device__ __forceinline__ void pipe_stage16(Cplx* a, const PipeTw& w, int tid) 
     a[i3] = x3;
   }
 }
-__device__ __forceinline__ void pipe_fft_dif(Cplx* a, const PipeTw& w, const Cplx* twg, int tid) {
-  pipe_pass1<false, false>(a, w, twg, opaque(tid));
+// The q = 4096 twiddles of a block (8 per thread, L2 hits).  They are requested BEFORE the next block's input: the
+// hardware counts returning loads in order, so the wait for the twiddles inside pass 1 then leaves the younger input
+// prefetch in flight.  Requested inside pass 1 (behind the prefetch) they fenced it: every block waited for its
+// successor's input a few hundred cycles after asking for it.
+// The q = 4096 twiddles (8 per thread) of the persistent kernels are parked in LDS once per workgroup.  Re-read from
+// the table in every block (round 1: L2 hits, "free") they were loads that sit BEHIND the next block's input prefetch in
+// the in-order return queue: the wait for them inside pass 1 of the forward transform was a wait for the prefetch, a few
+// hundred cycles after it had been issued — the prefetch overlapped nothing.
+__device__ __forceinline__ void pipe_park_tw0(Cplx* a, Cplx* tws, const Cplx* twg, int tid) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    tws[r * PIPE_NT + tid] = twg[tid + r * 1024];
+    a[18 * (2 * tid + (r >> 1)) + 16 + (r & 1)] = twg[tid + PIPE_NT + r * 1024];
+  }
+}
+__device__ __forceinline__ void pipe_fft_dif(Cplx* a, const PipeTw& w, const Cplx* twg, int tid, const Cplx* tws) {
+  pipe_pass1<false, true>(a, w, twg, opaque(tid), tws);
   __syncthreads();
   pipe_pass2<false>(a, w, opaque(tid));
   __syncthreads();
@@ -423,7 +441,7 @@ __device__ __forceinline__ void pipe_fft_dif(Cplx* a, const PipeTw& w, const Cpl
   }
   __syncthreads();
 }
-__device__ __forceinline__ void pipe_fft_dit_inv(Cplx* a, const PipeTw& w, const Cplx* twg, int tid) {
+__device__ __forceinline__ void pipe_fft_dit_inv(Cplx* a, const PipeTw& w, const Cplx* twg, int tid, const Cplx* tws) {
 #pragma unroll
   for (int rr = 0; rr < PIPE_ROWS; rr++) {
     float4* row = reinterpret_cast<float4*>(a + 18 * (opaque(tid) + rr * PIPE_NT));
@@ -446,33 +464,51 @@ __device__ __forceinline__ void pipe_fft_dit_inv(Cplx* a, const PipeTw& w, const
   __syncthreads();
   pipe_pass2<true>(a, w, opaque(tid));
   __syncthreads();
-  pipe_pass1<true, false>(a, w, twg, opaque(tid));
+  pipe_pass1<true, true>(a, w, twg, opaque(tid), tws);
   __syncthreads();
 }
 
 constexpr int PIPE_H = PIPE_B / 4 / PIPE_NT;  // float4 groups per thread in half a window (4)
 constexpr int PIPE_S = PIPE_N / 2 / PIPE_NT;  // float4 (two complex bins) per thread in a spectrum (16)
 // half a window = B frames of both instances: PIPE_H x (16 B of a, 16 B of b) per thread
+// The loads are UNCONDITIONAL (a frame group outside [0, frames) reads frame 0 instead and is zeroed when it is staged):
+// with the load inside an `if` the compiler merged the loaded value and the zero default in copy instructions right
+// behind the load — i.e. waited for every prefetch the moment it was issued, and the "prefetch" overlapped nothing.
 __device__ __forceinline__ void pipe_load_half(const float* pa, const float* pb, bool has_b, int64_t f0, uint64_t frames, int tid,
                                                f4v (&va)[PIPE_H], f4v (&vb)[PIPE_H]) {
+  (void)has_b;  // (pb == pa without a second instance)
 #pragma unroll
   for (int r = 0; r < PIPE_H; r++) {
     const int64_t f = f0 + 4 * (int64_t)(tid + r * PIPE_NT);
-    va[r] = f4v{0.f, 0.f, 0.f, 0.f};
-    vb[r] = f4v{0.f, 0.f, 0.f, 0.f};
-    if (f >= 0 && (uint64_t)f + 3 < frames) {
-      va[r] = *reinterpret_cast<const f4v*>(pa + f);
-      if (has_b) vb[r] = *reinterpret_cast<const f4v*>(pb + f);
-    }
+    const bool ok = f >= 0 && (uint64_t)f + 3 < frames;
+    const int64_t fc = ok ? f : 0;
+    va[r] = *reinterpret_cast<const f4v*>(pa + fc);
+    vb[r] = *reinterpret_cast<const f4v*>(pb + fc);
   }
 }
-__device__ __forceinline__ void pipe_stage_half(Cplx* a, int e0, int tid, const f4v (&va)[PIPE_H], const f4v (&vb)[PIPE_H]) {
+__device__ __forceinline__ void pipe_stage_half(Cplx* a, int e0, int tid, const f4v (&va)[PIPE_H], const f4v (&vb)[PIPE_H], bool has_b,
+                                                int64_t f0, uint64_t frames) {
 #pragma unroll
   for (int r = 0; r < PIPE_H; r++) {
+    const int64_t f = f0 + 4 * (int64_t)(tid + r * PIPE_NT);
+    const bool ok = f >= 0 && (uint64_t)f + 3 < frames;
+    const f4v z = {0.f, 0.f, 0.f, 0.f};
+    const f4v xa = ok ? va[r] : z, xb = ok && has_b ? vb[r] : z;
     f4v* dst4 = reinterpret_cast<f4v*>(a + pad(e0 + 4 * (tid + r * PIPE_NT)));
-    dst4[0] = f4v{va[r].x, vb[r].x, va[r].y, vb[r].y};
-    dst4[1] = f4v{va[r].z, vb[r].z, va[r].w, vb[r].w};
+    dst4[0] = f4v{xa.x, xb.x, xa.y, xb.y};
+    dst4[1] = f4v{xa.z, xb.z, xa.w, xb.w};
   }
+}
+// Forces the wait for a prefetch to sit HERE.  gfx9 counts loads and stores in one counter and the compiler has to
+// assume they complete out of order, so a wait for loads that is placed behind newer stores becomes "wait for
+// everything": placed in front of the stores of a block, it costs nothing (the loads are a whole FFT old) and the
+// stores then drain behind the next block's work.
+template <int N>
+__device__ __forceinline__ void pipe_settle(f4v (&v)[N]) {
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < N; r++) asm volatile("" : "+v"(v[r])::"memory");
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int MODE>
@@ -486,6 +522,8 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
   const int k1 = k0 + blocks_per_wg < d.nb ? k0 + blocks_per_wg : d.nb;
   if (k0 >= k1) return;
   const PipeTw w = pipe_twiddles<false>(d.tw, tid);
+  Cplx* tws = a + (PIPE_N + PIPE_N / 8);  // behind the padded transform buffer
+  pipe_park_tw0(a, tws, d.tw, tid);
   const uint32_t ia = pair * 2, ib = pair * 2 + 1;
   const bool has_b = ib < d.n_inst;
   if (MODE == MODE_FWD) {
@@ -499,8 +537,8 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
       // hoisted out of the block loop and ~160 address registers stay live across it)
       int tid_k = tid;
       asm volatile("" : "+v"(tid_k));
-      pipe_stage_half(a, 0, tid_k, oa, ob);  // window [(k-1)B, (k+1)B)
-      pipe_stage_half(a, PIPE_B, tid_k, na, nb);
+      pipe_stage_half(a, 0, tid_k, oa, ob, has_b, ((int64_t)k - 1) * PIPE_B, d.in_valid);  // window [(k-1)B, (k+1)B)
+      pipe_stage_half(a, PIPE_B, tid_k, na, nb, has_b, (int64_t)k * PIPE_B, d.in_valid);
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < PIPE_H; r++) {
@@ -509,7 +547,9 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
       }
       // the next block's new half: in flight during the FFT below (all-zero past the end of the stream)
       pipe_load_half(pa, pb, has_b, k + 1 < k1 ? ((int64_t)k + 1) * PIPE_B : (int64_t)d.in_valid, d.in_valid, tid_k, na, nb);
-      pipe_fft_dif(a, w, d.tw, tid_k);
+      pipe_fft_dif(a, w, d.tw, tid_k, tws);
+      pipe_settle(na);
+      pipe_settle(nb);
       f4v* dst = reinterpret_cast<f4v*>(d.X + (((uint64_t)pair * d.cin + c) * d.nb + k) * PIPE_N);
 #pragma unroll
       for (int r = 0; r < PIPE_S; r++) {
@@ -536,7 +576,8 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
       const int kn = k + 1 < k1 ? k + 1 : k;
 #pragma unroll
       for (int r = 0; r < PIPE_S; r++) y[r] = ybase[(uint64_t)kn * (PIPE_N / 2) + tid_k + r * PIPE_NT];
-      pipe_fft_dit_inv(a, w, d.tw, tid_k);
+      pipe_fft_dit_inv(a, w, d.tw, tid_k, tws);
+      pipe_settle(y);
 #pragma unroll
       for (int r = 0; r < PIPE_H; r++) {
         const int i4 = tid_k + r * PIPE_NT;
@@ -788,7 +829,7 @@ void launch_conv_forward(const ConvDesc& d, void* stream) {
   if (use_pipe(d)) {
     const int bpw = pipe_blocks_per_wg(d, d.cin);
     hipLaunchKernelGGL(conv_fft_pipe_kernel<MODE_FWD>, dim3((d.nb + bpw - 1) / bpw, d.cin, d.n_pairs), dim3(PIPE_NT),
-                       (size_t)(d.n + d.n / 8) * sizeof(Cplx), (hipStream_t)stream, d, bpw);
+                       (size_t)(d.n + d.n / 8) * sizeof(Cplx) + (size_t)PIPE_NT * 4 * sizeof(Cplx), (hipStream_t)stream, d, bpw);
     return;
   }
   hipLaunchKernelGGL(conv_fft_kernel<MODE_FWD>, dim3(d.nb, d.cin, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
@@ -799,7 +840,7 @@ void launch_conv_inverse(const ConvDesc& d, void* stream) {
   if (use_pipe(d)) {
     const int bpw = pipe_blocks_per_wg(d, d.cout);
     hipLaunchKernelGGL(conv_fft_pipe_kernel<MODE_INV>, dim3((d.nb + bpw - 1) / bpw, d.cout, d.n_pairs), dim3(PIPE_NT),
-                       (size_t)(d.n + d.n / 8) * sizeof(Cplx), (hipStream_t)stream, d, bpw);
+                       (size_t)(d.n + d.n / 8) * sizeof(Cplx) + (size_t)PIPE_NT * 4 * sizeof(Cplx), (hipStream_t)stream, d, bpw);
     return;
   }
   hipLaunchKernelGGL(conv_fft_kernel<MODE_INV>, dim3(d.nb, d.cout, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
