@@ -660,16 +660,25 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
   Cplx* Yc = d.Y + ((uint64_t)pair * d.cout + co) * nb * n + pos;
   const Cplx* Hc = d.H + (uint64_t)d.terms[term].ir_ch * P * n + pos;
   const Cplx* Xc = d.X + ((uint64_t)pair * d.cin + d.terms[term].in_ch) * nb * n + pos;
+  // Loads are unconditional (clamped index, the zero selected afterwards): behind `i < P ? load : 0` the compiler
+  // branched around every load and waited for it on the spot — 22 memory latencies in a row before the first product
+  // (about half of a workgroup's life), and again one full latency per k-tile before any of its arithmetic.
   Cplx h[PC];
 #pragma unroll
-  for (int i = 0; i < PC; i++) h[i] = i < P ? Hc[(uint64_t)i * n] : Cplx{0.f, 0.f};
+  for (int i = 0; i < PC; i++) h[i] = Hc[(uint64_t)(i < P ? i : 0) * n];
+#pragma unroll
+  for (int i = 0; i < PC; i++)
+    if (i >= P) h[i] = Cplx{0.f, 0.f};
   Cplx win[PC - 1];  // X_{k0 - (PC-1)} .. X_{k0 - 1}
 #pragma unroll
   for (int i = 0; i < PC - 1; i++) win[i] = Cplx{0.f, 0.f};
   for (int k0 = 0; k0 < nb; k0 += KT) {
     Cplx xn[KT];  // X_{k0} .. X_{k0 + KT - 1}
 #pragma unroll
-    for (int i = 0; i < KT; i++) xn[i] = k0 + i < nb ? Xc[(uint64_t)(k0 + i) * n] : Cplx{0.f, 0.f};
+    for (int i = 0; i < KT; i++) xn[i] = Xc[(uint64_t)(k0 + i < nb ? k0 + i : nb - 1) * n];
+#pragma unroll
+    for (int i = 0; i < KT; i++)
+      if (k0 + i >= nb) xn[i] = Cplx{0.f, 0.f};
     Cplx acc[KT];
 #pragma unroll
     for (int i = 0; i < KT; i++) acc[i] = Cplx{0.f, 0.f};
