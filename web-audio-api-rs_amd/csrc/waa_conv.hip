@@ -408,6 +408,11 @@ __device__ __forceinline__ void pipe_stage16(Cplx* a, const PipeTw& w, int tid) 
 // the table in every block (round 1: L2 hits, "free") they were loads that sit BEHIND the next block's input prefetch in
 // the in-order return queue: the wait for them inside pass 1 of the forward transform was a wait for the prefetch, a few
 // hundred cycles after it had been issued — the prefetch overlapped nothing.
+// Workgroup barrier for LDS hand-offs.  __syncthreads() is a workgroup-scope fence plus s_barrier, and the release half
+// of that fence waits for every outstanding GLOBAL store (vmcnt(0)): inside these persistent loops each barrier behind
+// a block's 128 KB of spectrum / output stores stalled until they had reached memory, i.e. the stores overlapped
+// nothing.  Here: this wave's LDS traffic has completed (DS operations of a wave finish in order), then the barrier.
+__device__ __forceinline__ void pipe_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void pipe_park_tw0(Cplx* a, Cplx* tws, const Cplx* twg, int tid) {
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -417,11 +422,11 @@ __device__ __forceinline__ void pipe_park_tw0(Cplx* a, Cplx* tws, const Cplx* tw
 }
 __device__ __forceinline__ void pipe_fft_dif(Cplx* a, const PipeTw& w, const Cplx* twg, int tid, const Cplx* tws) {
   pipe_pass1<false, true>(a, w, twg, opaque(tid), tws);
-  __syncthreads();
+  pipe_barrier();
   pipe_pass2<false>(a, w, opaque(tid));
-  __syncthreads();
+  pipe_barrier();
   pipe_stage16<false>(a, w, opaque(tid));
-  __syncthreads();
+  pipe_barrier();
 #pragma unroll
   for (int rr = 0; rr < PIPE_ROWS; rr++) {
     float4* row = reinterpret_cast<float4*>(a + 18 * (opaque(tid) + rr * PIPE_NT));  // elements [16t, 16t+16)
@@ -439,7 +444,7 @@ __device__ __forceinline__ void pipe_fft_dif(Cplx* a, const PipeTw& w, const Cpl
 #pragma unroll
     for (int k = 0; k < 8; k++) row[k] = make_float4(x[2 * k].re, x[2 * k].im, x[2 * k + 1].re, x[2 * k + 1].im);
   }
-  __syncthreads();
+  pipe_barrier();
 }
 __device__ __forceinline__ void pipe_fft_dit_inv(Cplx* a, const PipeTw& w, const Cplx* twg, int tid, const Cplx* tws) {
 #pragma unroll
@@ -459,13 +464,13 @@ __device__ __forceinline__ void pipe_fft_dit_inv(Cplx* a, const PipeTw& w, const
 #pragma unroll
     for (int k = 0; k < 8; k++) row[k] = make_float4(x[2 * k].re, x[2 * k].im, x[2 * k + 1].re, x[2 * k + 1].im);
   }
-  __syncthreads();
+  pipe_barrier();
   pipe_stage16<true>(a, w, opaque(tid));
-  __syncthreads();
+  pipe_barrier();
   pipe_pass2<true>(a, w, opaque(tid));
-  __syncthreads();
+  pipe_barrier();
   pipe_pass1<true, true>(a, w, twg, opaque(tid), tws);
-  __syncthreads();
+  pipe_barrier();
 }
 
 constexpr int PIPE_H = PIPE_B / 4 / PIPE_NT;  // float4 groups per thread in half a window (4)
@@ -511,7 +516,8 @@ __device__ __forceinline__ void pipe_settle(f4v (&v)[N]) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MODE>
+// DBG (WAA_CONV_PIPE_DEBUG, measurement aid, results wrong by construction): 1 = no global stores, 2 = no global loads
+template <int MODE, int DBG = 0>
 __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d, int blocks_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   Cplx* a = reinterpret_cast<Cplx*>(lds_raw);
@@ -532,6 +538,13 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
     f4v oa[PIPE_H], ob[PIPE_H], na[PIPE_H], nb[PIPE_H];
     pipe_load_half(pa, pb, has_b, ((int64_t)k0 - 1) * PIPE_B, d.in_valid, tid, oa, ob);
     pipe_load_half(pa, pb, has_b, (int64_t)k0 * PIPE_B, d.in_valid, tid, na, nb);
+    // (no load may be pending on loop entry: the wait counts the compiler computes for the loop header are the merge of
+    // this path and the back edge, where the previous block's stores are in flight — a count that is right for loads
+    // pending from here is a wait for those stores on every later iteration)
+    pipe_settle(oa);
+    pipe_settle(ob);
+    pipe_settle(na);
+    pipe_settle(nb);
     for (int k = k0; k < k1; k++) {
       // (opaque copy of the thread index: otherwise every LDS address of all five stages is loop-invariant, gets
       // hoisted out of the block loop and ~160 address registers stay live across it)
@@ -539,14 +552,15 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
       asm volatile("" : "+v"(tid_k));
       pipe_stage_half(a, 0, tid_k, oa, ob, has_b, ((int64_t)k - 1) * PIPE_B, d.in_valid);  // window [(k-1)B, (k+1)B)
       pipe_stage_half(a, PIPE_B, tid_k, na, nb, has_b, (int64_t)k * PIPE_B, d.in_valid);
-      __syncthreads();
+      pipe_barrier();
 #pragma unroll
       for (int r = 0; r < PIPE_H; r++) {
         oa[r] = na[r];
         ob[r] = nb[r];
       }
       // the next block's new half: in flight during the FFT below (all-zero past the end of the stream)
-      pipe_load_half(pa, pb, has_b, k + 1 < k1 ? ((int64_t)k + 1) * PIPE_B : (int64_t)d.in_valid, d.in_valid, tid_k, na, nb);
+      if (DBG != 2)
+        pipe_load_half(pa, pb, has_b, k + 1 < k1 ? ((int64_t)k + 1) * PIPE_B : (int64_t)d.in_valid, d.in_valid, tid_k, na, nb);
       pipe_fft_dif(a, w, d.tw, tid_k, tws);
       pipe_settle(na);
       pipe_settle(nb);
@@ -554,9 +568,13 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
 #pragma unroll
       for (int r = 0; r < PIPE_S; r++) {
         const int i = tid_k + r * PIPE_NT;
-        dst[i] = *reinterpret_cast<const f4v*>(a + pad(2 * i));
+        const f4v v = *reinterpret_cast<const f4v*>(a + pad(2 * i));
+        if (DBG == 1)
+          asm volatile("" ::"v"(v));
+        else
+          dst[i] = v;
       }
-      __syncthreads();  // LDS is rewritten by the next window
+      pipe_barrier();  // LDS is rewritten by the next window
     }
   } else {
     float* pa = d.out.base + (uint64_t)ia * d.out.inst_stride + (uint64_t)c * d.out.ch_stride;
@@ -566,16 +584,18 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
     f4v y[PIPE_S];
 #pragma unroll
     for (int r = 0; r < PIPE_S; r++) y[r] = ybase[(uint64_t)k0 * (PIPE_N / 2) + tid + r * PIPE_NT];
+    pipe_settle(y);  // (as in the forward kernel)
     for (int k = k0; k < k1; k++) {
       int tid_k = tid;
       asm volatile("" : "+v"(tid_k));
 #pragma unroll
       for (int r = 0; r < PIPE_S; r++) *reinterpret_cast<f4v*>(a + pad(2 * (tid_k + r * PIPE_NT))) = y[r];
-      __syncthreads();
+      pipe_barrier();
       // the next spectrum: in flight during the inverse FFT below (the last block re-reads itself: harmless)
       const int kn = k + 1 < k1 ? k + 1 : k;
 #pragma unroll
-      for (int r = 0; r < PIPE_S; r++) y[r] = ybase[(uint64_t)kn * (PIPE_N / 2) + tid_k + r * PIPE_NT];
+      for (int r = 0; r < PIPE_S; r++)
+        if (DBG != 2) y[r] = ybase[(uint64_t)kn * (PIPE_N / 2) + tid_k + r * PIPE_NT];
       pipe_fft_dit_inv(a, w, d.tw, tid_k, tws);
       pipe_settle(y);
 #pragma unroll
@@ -586,11 +606,17 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
           // overlap-save: the last B samples are the linear convolution; re -> instance a, im -> instance b
           const f4v p0 = reinterpret_cast<const f4v*>(a + pad(PIPE_B + 4 * i4))[0];
           const f4v p1 = reinterpret_cast<const f4v*>(a + pad(PIPE_B + 4 * i4))[1];
-          *reinterpret_cast<f4v*>(pa + f) = f4v{p0.x * scale, p0.z * scale, p1.x * scale, p1.z * scale};
-          if (has_b) *reinterpret_cast<f4v*>(pb + f) = f4v{p0.y * scale, p0.w * scale, p1.y * scale, p1.w * scale};
+          const f4v va = f4v{p0.x * scale, p0.z * scale, p1.x * scale, p1.z * scale};
+          const f4v vb = f4v{p0.y * scale, p0.w * scale, p1.y * scale, p1.w * scale};
+          if (DBG == 1) {
+            asm volatile("" ::"v"(va), "v"(vb));
+          } else {
+            *reinterpret_cast<f4v*>(pa + f) = va;
+            if (has_b) *reinterpret_cast<f4v*>(pb + f) = vb;
+          }
         }
       }
-      __syncthreads();
+      pipe_barrier();
     }
   }
 }
@@ -813,8 +839,12 @@ static void allow_big_lds(size_t bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_IR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_FWD, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_INV, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_FWD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_INV, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_FWD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_INV, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   done = true;
 }
 
@@ -837,8 +867,15 @@ void launch_conv_forward(const ConvDesc& d, void* stream) {
   allow_big_lds((size_t)d.n * sizeof(Cplx));
   if (use_pipe(d)) {
     const int bpw = pipe_blocks_per_wg(d, d.cin);
-    hipLaunchKernelGGL(conv_fft_pipe_kernel<MODE_FWD>, dim3((d.nb + bpw - 1) / bpw, d.cin, d.n_pairs), dim3(PIPE_NT),
-                       (size_t)(d.n + d.n / 8) * sizeof(Cplx) + (size_t)PIPE_NT * 4 * sizeof(Cplx), (hipStream_t)stream, d, bpw);
+    const dim3 grid((d.nb + bpw - 1) / bpw, d.cin, d.n_pairs);
+    const size_t lds = (size_t)(d.n + d.n / 8) * sizeof(Cplx) + (size_t)PIPE_NT * 4 * sizeof(Cplx);
+    const char* dbg = getenv("WAA_CONV_PIPE_DEBUG");
+    if (dbg && dbg[0] == '1')
+      hipLaunchKernelGGL((conv_fft_pipe_kernel<MODE_FWD, 1>), grid, dim3(PIPE_NT), lds, (hipStream_t)stream, d, bpw);
+    else if (dbg && dbg[0] == '2')
+      hipLaunchKernelGGL((conv_fft_pipe_kernel<MODE_FWD, 2>), grid, dim3(PIPE_NT), lds, (hipStream_t)stream, d, bpw);
+    else
+      hipLaunchKernelGGL((conv_fft_pipe_kernel<MODE_FWD, 0>), grid, dim3(PIPE_NT), lds, (hipStream_t)stream, d, bpw);
     return;
   }
   hipLaunchKernelGGL(conv_fft_kernel<MODE_FWD>, dim3(d.nb, d.cin, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
@@ -848,8 +885,15 @@ void launch_conv_inverse(const ConvDesc& d, void* stream) {
   allow_big_lds((size_t)d.n * sizeof(Cplx));
   if (use_pipe(d)) {
     const int bpw = pipe_blocks_per_wg(d, d.cout);
-    hipLaunchKernelGGL(conv_fft_pipe_kernel<MODE_INV>, dim3((d.nb + bpw - 1) / bpw, d.cout, d.n_pairs), dim3(PIPE_NT),
-                       (size_t)(d.n + d.n / 8) * sizeof(Cplx) + (size_t)PIPE_NT * 4 * sizeof(Cplx), (hipStream_t)stream, d, bpw);
+    const dim3 grid((d.nb + bpw - 1) / bpw, d.cout, d.n_pairs);
+    const size_t lds = (size_t)(d.n + d.n / 8) * sizeof(Cplx) + (size_t)PIPE_NT * 4 * sizeof(Cplx);
+    const char* dbg = getenv("WAA_CONV_PIPE_DEBUG");
+    if (dbg && dbg[0] == '1')
+      hipLaunchKernelGGL((conv_fft_pipe_kernel<MODE_INV, 1>), grid, dim3(PIPE_NT), lds, (hipStream_t)stream, d, bpw);
+    else if (dbg && dbg[0] == '2')
+      hipLaunchKernelGGL((conv_fft_pipe_kernel<MODE_INV, 2>), grid, dim3(PIPE_NT), lds, (hipStream_t)stream, d, bpw);
+    else
+      hipLaunchKernelGGL((conv_fft_pipe_kernel<MODE_INV, 0>), grid, dim3(PIPE_NT), lds, (hipStream_t)stream, d, bpw);
     return;
   }
   hipLaunchKernelGGL(conv_fft_kernel<MODE_INV>, dim3(d.nb, d.cout, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
