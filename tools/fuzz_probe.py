@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""tools/fuzz_probe.py <seed> [--probe] — render one graph of tests/test_fuzz_graphs.py on the HIP path and on the oracle and
+"""tools/fuzz_probe.py <seed> [--probe] [--frozen] [--live] — render one graph of tests/test_fuzz_graphs.py on the HIP path and on the oracle and
 report where they differ; with --probe every node is tapped in turn (its output alone connected to the destination), which
 localises a divergence to the first node whose output differs.  Debugging aid for the planner / dyn_kernel (GPU box)."""
 import ctypes
@@ -12,7 +12,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 import web_audio_api_rs_amd as waa  # noqa: E402
-from test_fuzz_graphs import build_random_graph  # noqa: E402
+from test_fuzz_graphs import build_random_graph as _build  # noqa: E402
+
+waa.set_hrtf_database(os.path.join(ROOT, "tests", "golden", "IRC_1003_C.bin"))
+
+
+def build_random_graph(be, seed):
+    return _build(be, seed, frozen="--frozen" in sys.argv)  # (the generator with oversampled shapers / HRTF panners)
 
 
 def render(be, seed, probe=None, want_plan=False, count_probe=False):

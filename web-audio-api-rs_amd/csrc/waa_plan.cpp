@@ -848,6 +848,10 @@ int build_plan(waa_batch* b) {
           const SourceSched& ss = n.sched[inst];
           lo[id] = ss.start == DBL_MAX ? 1e300 : std::floor(ss.start / qsec);
           hi[id] = ss.stop != DBL_MAX ? std::ceil(ss.stop / qsec) : 1e300;
+          // a ConstantSourceNode is silent until it starts and NEVER again: past its stop time it keeps rendering zeros
+          // into a non-silent mono quantum (constant_source.rs:203-258) — a narrower-than-static input for whatever
+          // count-sensitive node it feeds together with a wider source that has ended (found by fuzz seed 1579)
+          if (kind == WAA_NODE_CONSTANT_SOURCE) hi[id] = 1e300;
           if (kind == WAA_NODE_BUFFER_SOURCE && n.bufs[inst].valid) {
             // the quantum in which the source really ends: the scheduling replay with this instance's playbackRate
             // and detune per quantum (an automated rate moves the end; an estimate from the slowest rate claimed the
@@ -2516,7 +2520,13 @@ int plan_convolver(waa_batch* b, uint32_t id) {
     plan_note(b, "convolver node %u: all-zero impulse response -> zero fill", id);
     return 0;
   }
-  const bool direct_fir = len <= (uint64_t)DIRECT_MAX_TAPS;
+  // Short impulse responses: the direct FIR is exact where the reference's FFT convolver leaves roundoff noise (its
+  // delta-IR tests ask for 1e-7).  In a dynamic-count plan that difference is audible further down: silence is DATA
+  // dependent there (a DelayNode reports silence when it read nothing but zeros, delay.rs:660-668; filter tails end
+  // when their state leaves the normal range), and exact zeros behind a convolver that has seen input turn "still
+  // ringing with noise, stereo" into "silent, mono" for every count-sensitive node behind it.  Dynamic plans therefore
+  // take the FFT form for every length, like the reference (fuzz seeds 1658, 1340 of the 1500-seed runs).
+  const bool direct_fir = len <= (uint64_t)DIRECT_MAX_TAPS && !b->dynamic && !getenv("WAA_NO_DIRECT_FIR");
   int B = 8192;
   for (int cand : {128, 512, 2048, 8192})
     if ((len + cand - 1) / cand <= 24) {
