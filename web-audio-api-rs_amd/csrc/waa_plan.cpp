@@ -850,8 +850,9 @@ int build_plan(waa_batch* b) {
           hi[id] = ss.stop != DBL_MAX ? std::ceil(ss.stop / qsec) : 1e300;
           // a ConstantSourceNode is silent until it starts and NEVER again: past its stop time it keeps rendering zeros
           // into a non-silent mono quantum (constant_source.rs:203-258) — a narrower-than-static input for whatever
-          // count-sensitive node it feeds together with a wider source that has ended (found by fuzz seed 1579)
-          if (kind == WAA_NODE_CONSTANT_SOURCE) hi[id] = 1e300;
+          // count-sensitive node it feeds together with a wider source that has ended (fuzz seed 1579), yet nothing
+          // but zeros for the nodes whose silence is data dependent (a DelayNode behind it falls silent: seed 3071).
+          // Both readings are simulated (const_forever below).
           if (kind == WAA_NODE_BUFFER_SOURCE && n.bufs[inst].valid) {
             // the quantum in which the source really ends: the scheduling replay with this instance's playbackRate
             // and detune per quantum (an automated rate moves the end; an estimate from the slowest rate claimed the
@@ -941,6 +942,10 @@ int build_plan(waa_batch* b) {
       // every combination of short / long tails for up to 8 nodes with memory, the two uniform bounds beyond that
       const uint32_t n_modes = mem_nodes.size() <= 8 ? (1u << mem_nodes.size()) : 2u;
       std::vector<uint8_t> long_tail(N, 0);
+      bool stopped_constant = false;
+      for (uint32_t id : b->order)
+        stopped_constant |= b->nodes[id].live && b->nodes[id].desc.kind == WAA_NODE_CONSTANT_SOURCE && hi[id] < 1e299;
+      for (int const_forever = 0; const_forever < (stopped_constant ? 2 : 1) && !reported; const_forever++)
       for (uint32_t mode_index = 0; mode_index < 2 * n_modes && !reported; mode_index++) {
       const uint32_t tail_mode = mode_index >> 1;
       const std::vector<double>& dshift = (mode_index & 1) ? shift_hi : shift;
@@ -959,7 +964,7 @@ int build_plan(waa_batch* b) {
           const uint32_t kind = n.desc.kind;
           if (kind == WAA_NODE_BUFFER_SOURCE || kind == WAA_NODE_CONSTANT_SOURCE || kind == WAA_NODE_OSCILLATOR) {
             for (uint32_t q = 0; q < nq; q++) {
-              act[id][q] = (double)q >= lo[id] && (double)q < hi[id];
+              act[id][q] = (double)q >= lo[id] && ((double)q < hi[id] || (const_forever && kind == WAA_NODE_CONSTANT_SOURCE));
               cnt[id][q] = act[id][q] ? (uint8_t)n.out_nch : 1;
             }
             continue;
