@@ -285,6 +285,13 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
         roof.update({"bound": "valu_f32", "peak": 157.3, "unit": "TFLOP/s", "achieved": flops / (comp_ms * 1e-3) / 1e12,
                      "algorithmic_flops_per_step": flops, "compute_kernel_ms_per_step": comp_ms})
         roof["frac"] = roof["achieved"] / 157.3
+        if name in ("os2", "os4") and not any(os.environ.get(k) for k in ("WAA_QGEMM_FMA", "WAA_QGEMM_F32")):
+            # the resampling products run on the bf16 matrix cores as SIX bf16 products per f32 product (exact three-way
+            # split of both operands, f32-grade result: DESIGN.md 3.5): the ceiling of that method is the dense bf16 MFMA
+            # peak / 6, in f32-equivalent flops; `mfma_flops_per_step` is what the matrix cores really execute
+            roof.update({"bound": "mfma", "peak": 2500.0 / 6.0, "peak_basis": "2.5 PFLOP/s dense bf16 MFMA / 6 products per f32 product",
+                         "mfma_flops_per_step": 6.0 * flops, "vs_f32_vector_peak": roof["achieved"] / 157.3})
+            roof["frac"] = roof["achieved"] / (2500.0 / 6.0)
     return {
         "value": world * n_inst * nq * steps / elapsed,
         "ms_per_step": ms_per_step,

@@ -260,3 +260,82 @@ def test_oversample_many_instances_sampled(hip, orc):
     for k, inst in enumerate(sample):
         for c in range(2):
             assert rms(outs[0][inst, c], outs[1][k, c]) <= 1e-6
+
+
+# ---- the three forms of the resampling products (waa_frozen.hip) -------------------------------------------------
+def _render_with_env(hip, x, oversample, env):
+    import os
+    keys = ("WAA_QGEMM_FMA", "WAA_QGEMM_F32", "WAA_QGEMM_W4")
+    saved = {k: os.environ.pop(k, None) for k in keys}
+    try:
+        os.environ.update(env)
+        return shaper_graph(hip, x, TANH, oversample, x.shape[2]).start_rendering_sync().data
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("oversample,factor", [("2x", 2), ("4x", 4)])
+def test_product_forms_agree(hip, oversample, factor):
+    """vector FMA, f32 MFMA, six bf16 MFMA products per f32 product (eight and four wavefronts): one result, the written
+    definition in f64 as the judge; the bf16 form is not allowed to be worse than the f32 forms"""
+    nq = 140  # (two workgroup tiles of 128 quanta, the second one ragged)
+    rng = np.random.default_rng(31)
+    x = rng.uniform(-1, 1, (3, 2, nq * RQ)).astype(np.float32)
+    ref = np.stack([[definition_render(x[i, c], TANH, factor) for c in range(2)] for i in range(3)])
+    err = {}
+    for name, env in (("bf16x6", {}), ("bf16x6_w4", {"WAA_QGEMM_W4": "1"}), ("f32_mfma", {"WAA_QGEMM_F32": "1"}),
+                      ("f32_fma", {"WAA_QGEMM_FMA": "1"})):
+        out = _render_with_env(hip, x, oversample, env)
+        err[name] = max(rms(out[i, c], ref[i, c]) for i in range(3) for c in range(2))
+        assert err[name] <= 1e-6, (name, err)
+    assert err["bf16x6"] <= 2.0 * err["f32_fma"] + 1e-9, err
+
+
+@pytest.mark.gpu
+def test_bf16_split_keeps_the_dynamic_range(hip, orc):
+    """the exact three-way bf16 split has f32's exponent range and 24 significant bits: quiet quanta between loud ones come
+    out as accurately as in the oracle.  (Through the node only absolute accuracy can be asked for: the curve lookup
+    computes input + 1 in f32, waveshaper.rs:558-560, which quantises a 1e-6 signal to two digits in the reference too.)"""
+    nq = 24
+    rng = np.random.default_rng(37)
+    x = rng.uniform(-1, 1, (2, 1, nq * RQ)).astype(np.float32)
+    scale = np.ones(nq, np.float32)
+    scale[4:8] = 1e-6
+    scale[14:17] = 1e-3
+    x *= np.repeat(scale, RQ)[None, None, :]
+    ident = np.linspace(-1, 1, 4097).astype(np.float32)  # identity on [-1, 1]
+    outs = []
+    for be in (hip, orc):
+        ctx = waa.OfflineAudioContext(1, nq * RQ, SR, n_instances=2, binding=be)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(x, SR)
+        src.connect(ctx.create_wave_shaper(curve=ident, oversample="2x")).connect(ctx.destination())
+        src.start()
+        outs.append(ctx.start_rendering_sync().data)
+    for q0, q1, level in ((6, 8, 1e-6), (16, 17, 1e-3), (19, 24, 1.0)):  # (inside a stretch of one scale: one-quantum latency)
+        a, b_ = outs[0][:, 0, q0 * RQ:q1 * RQ].astype(np.float64), outs[1][:, 0, q0 * RQ:q1 * RQ].astype(np.float64)
+        assert np.sqrt(np.mean(b_ ** 2)) > 0.2 * level
+        assert np.sqrt(np.mean((a - b_) ** 2)) <= max(1e-6 * level, 1.5e-7), (q0, q1)
+
+
+@pytest.mark.gpu
+def test_non_finite_block_stays_local(hip):
+    """an inf / NaN sample poisons the blocks whose window holds it (the reference's FFT does the same) and nothing else"""
+    nq = 12
+    rng = np.random.default_rng(41)
+    x = rng.uniform(-1, 1, (1, 1, nq * RQ)).astype(np.float32)
+    y = x.copy()
+    y[0, 0, 5 * RQ + 17] = np.inf
+    y[0, 0, 5 * RQ + 90] = np.nan
+    clean = shaper_graph(hip, x, TANH, "2x", nq * RQ).start_rendering_sync().data
+    dirty = shaper_graph(hip, y, TANH, "2x", nq * RQ).start_rendering_sync().data
+    # quantum 5 enters the up-sampler's window of quanta 5 and 6, whose outputs enter the down-sampler's of 5..7
+    for q in range(nq):
+        blk = dirty[0, 0, q * RQ:(q + 1) * RQ]
+        if q < 5 or q > 7:
+            assert np.array_equal(blk, clean[0, 0, q * RQ:(q + 1) * RQ]), q
+    assert not np.all(np.isfinite(dirty[0, 0, 5 * RQ:8 * RQ]))

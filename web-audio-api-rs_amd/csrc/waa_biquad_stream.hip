@@ -181,6 +181,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
     float* yrow = lds_out + lane * LDS_ROW;
     const double* ct = cp + (uint64_t)tile * (TILE_K * 5 * 64) + lane;  // element (k, coef) at ct[(k * 5 + coef) * 64]
     auto load_chunk = [&](double (&c)[20], int chunk) __attribute__((always_inline)) {
+      if (DBG >= 3 && tile != d.tile0) return;  // (measurement aid: the coefficient sets of the first tile for all tiles)
 #pragma unroll
       for (int j = 0; j < 20; j++) c[j] = load_global(ct + (chunk * 20 + j) * 64);
     };
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
     double ca[20], cb[20], cc[NBUF == 3 ? 20 : 1];
     if constexpr (VARY == 3) {
       // shared table: the end state is a 34-tap dot product with the digest of biquad_hp_kernel (BiquadHpDesc)
-      const double* hp = d.hp + (uint64_t)tile * (HP_WORDS * 64) + lane;
+      const double* hp = d.hp + (uint64_t)(DBG == 4 ? d.tile0 : tile) * (HP_WORDS * 64) + lane;
       load_chunk(ca, 0);  // sweep 2's first coefficient sets are requested before the dot product starts
       load_chunk(cb, 1);
       double za = load_global(hp + 64 * 64) * xs1, zb = load_global(hp + 65 * 64) * xs1;
@@ -939,7 +940,11 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
   const dim3 grid(d.n_inst * (uint32_t)d.nch), block(64);
   const size_t lds = 2 * 64 * LDS_ROW * sizeof(float);
   const char* dbg = getenv("WAA_STREAM_DEBUG");  // measurement aid only, see profiles/r01_c2_memory_pattern.txt
-  if (d.vary == 3 && getenv("WAA_ARATE_BUFS3"))  // experiment: deeper coefficient prefetch (spills a few registers)
+  if (d.vary == 3 && dbg && dbg[0] == '3')
+    hipLaunchKernelGGL((biquad_stream_kernel_t<3, 3>), grid, block, lds, (hipStream_t)stream, d);
+  else if (d.vary == 3 && dbg && dbg[0] == '4')
+    hipLaunchKernelGGL((biquad_stream_kernel_t<4, 3>), grid, block, lds, (hipStream_t)stream, d);
+  else if (d.vary == 3 && getenv("WAA_ARATE_BUFS3"))  // experiment: deeper coefficient prefetch (spills a few registers)
     hipLaunchKernelGGL((biquad_stream_kernel_t<0, 3, 3>), grid, block, lds, (hipStream_t)stream, d);
   else if (d.vary == 3)
     hipLaunchKernelGGL((biquad_stream_kernel_t<0, 3>), grid, block, lds, (hipStream_t)stream, d);

@@ -404,9 +404,386 @@ __global__ __launch_bounds__(256) void qgemm_mfma_kernel(const QGemmDesc d) {
       }
     }
 }
+// The same product on the bf16 matrix cores, at f32 accuracy.  Every f32 value is the EXACT sum of three bf16 values
+// (hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid: 8 + 8 + 8 significant bits), so
+//     s * a = (sh + sm + sl) * (ah + am + al)
+// and the six products of weight >= 2^-16 — sh ah, sh am, sm ah, sh al, sl ah, sm am — carry it to 2^-24 relative (the
+// three dropped ones are below the rounding of an f32 product); each bf16 x bf16 product is exact in the f32 accumulator.
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the f32 MFMA / vector FMA, six of them per f32 product leave 2.7x.
+// Measured against the f64 product on resampler-shaped data: 2.0e-7 relative RMS (a chain of f32 FMAs: 2.9e-7).
+// Tile: 128 quanta x 128 output frames per workgroup, one 64 x 64 quadrant per wavefront, k in steps of 16.  The matrix
+// comes pre-split and pre-tiled from the host (QGemmDesc::A16); the source tile is split on the fly while it is staged.
+// LDS image of a plane of a tile: fragment (block of 32 rows, k half h, row) = 16 B at slot (block * 2 + h) * 32 + row, so
+// the 64 lanes of a fragment read (lane & 31 = row, lane >> 5 = h) touch 64 consecutive slots: conflict-free ds_read_b128.
+namespace {
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+constexpr int XK = 16;
+struct XSet {          // one k-tile in flight: 2 x 4 source floats, 3 x 8 matrix bf16 per thread
+  f4v s[2];
+  u4v m[3];
+};
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+// (x0, x1) = hi + mid + lo, each a pair of bf16 in one word: v_cvt_pk_bf16_f32 rounds to nearest even, the residuals
+// x - hi and (x - hi) - mid are exact in f32 and the last one has at most 8 significant bits.  inf / NaN: hi keeps the
+// class, the residuals are NaN — the products are NaN either way.
+__device__ __forceinline__ void split_bf16x3(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  const bf2v h = {(__bf16)x0, (__bf16)x1};
+  hi = __builtin_bit_cast(uint32_t, h);
+  const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  const bf2v m = {(__bf16)r0, (__bf16)r1};
+  mid = __builtin_bit_cast(uint32_t, m);
+  const float l0 = r0 - __uint_as_float(mid << 16), l1 = r1 - __uint_as_float(mid & 0xffff0000u);
+  const bf2v l = {(__bf16)l0, (__bf16)l1};
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+// LDS slot (16 B) of fragment (block of 32 rows, k half h, row): the two halves of a block 40 slots apart, so that the
+// staging writes (8 rows x both halves per 32 lanes) spread over all banks like the fragment reads do
+__device__ __forceinline__ int xslot(int blk, int h, int row) { return blk * 72 + h * 40 + row; }
+constexpr int XSLOTS = 4 * 72;
+}  // namespace
+// DBG (WAA_QGEMM_DEBUG=a|b|c, measurement aid, results wrong by construction): 1 = no global loads after the first four
+// tiles, 2 = no MFMAs, 3 = nothing staged after the first tile (no split, no LDS writes)
+template <int DBG>
+__global__ __launch_bounds__(256, 2) void qgemm_bf16x6_kernel(const QGemmDesc d) {
+  __shared__ u4v Ss[2][3][XSLOTS];  // [buffer][plane][slot]: source tile, 128 quanta x 16 k
+  __shared__ u4v Ms[2][3][XSLOTS];  // matrix tile, 128 output frames x 16 k
+  __shared__ int32_t prev_s[BN];
+  __shared__ float curve_s[CURVE_LDS];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const bool curve_in_lds = d.curve && d.curve_n <= CURVE_LDS;
+  if (curve_in_lds)
+    for (int i = tid; i < d.curve_n; i += 256) curve_s[i] = load_global(d.curve + i);
+  const int wq = (wave >> 1) * 64, wm = (wave & 1) * 64;
+  const int l32 = lane & 31, kh = lane >> 5;
+  const uint32_t q0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const uint32_t inst = blockIdx.z / (uint32_t)d.nch, ch = blockIdx.z % (uint32_t)d.nch;
+  const float* src = d.src + (uint64_t)inst * d.src_inst + (uint64_t)ch * d.src_ch;
+  if (tid < BN) {
+    const uint32_t q = q0 + tid;
+    prev_s[tid] = q < d.n_quanta ? load_global(d.prev + (uint64_t)inst * d.prev_stride + q) : LINK_SKIP;
+  }
+  __syncthreads();
+  const int KT = 2 * d.Kh / XK;  // (a multiple of 16: Kh is a multiple of 128)
+  // this thread's two source pieces: quantum row `col`, 4 consecutive k; its three matrix pieces: 16 B of plane p
+  int32_t srow[2][2];  // [piece][first / second half of k]: source quantum or -1
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int col = (tid + i * 256) >> 2;
+    const int32_t p = prev_s[col];
+    srow[i][0] = p != LINK_SKIP ? (int32_t)(q0 + col) : -1;
+    srow[i][1] = p != LINK_SKIP ? p : -1;  // (LINK_FRESH = -1: no previous block)
+  }
+  const u4v* a16 = reinterpret_cast<const u4v*>(d.A16);  // tile kt, plane p, column m, half h: ((kt * 3 + p) * M + m) * 2 + h
+  bool warm = false;  // (DBG 1 / 3)
+  auto fetch = [&](int kt, XSet& x) __attribute__((always_inline)) {
+    if (DBG == 1 && warm) return;
+    // tile order: (k-tile p of this block, k-tile p of the previous block), p = 0, 1, ...: the two read the same source
+    // columns of neighbouring quanta (the previous processed block is almost always quantum q - 1), i.e. the same cache
+    // lines one phase apart.  In plain k order the second pass over the rows came half a workgroup lifetime later, after
+    // the 128 KB panel had left the L2 (64 workgroups per XCD): the source was fetched from HBM several times.
+    const bool second = kt & 1;
+    const int koff = (kt >> 1) * XK;
+    const int mt = (kt >> 1) + (second ? d.Kh / XK : 0);  // matrix tile (rows mt * 16 ... of the k-major matrix)
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int part = (tid + i * 256) & 3;
+      const int32_t sq = srow[i][second ? 1 : 0];
+      // (unconditional load, row 0 instead of a skipped row, zeroed when staged: a load inside a branch is waited for at once)
+      x.s[i] = load_global_f4(src + (uint64_t)(sq < 0 ? 0 : sq) * d.src_q + (uint64_t)(koff + part * 4));
+    }
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+      x.m[p] = *(const WAA_GLOBAL_AS u4v*)(a16 + ((uint64_t)(mt * 3 + p) * d.M + m0) * 2 + tid);
+  };
+  auto stage = [&](int kt, int buf, const XSet& x) __attribute__((always_inline)) {
+    if (DBG == 3 && warm) {
+      asm volatile("" ::"v"(x.s[0]), "v"(x.s[1]), "v"(x.m[0]), "v"(x.m[1]), "v"(x.m[2]));
+      return;
+    }
+    const bool second = kt & 1;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int idx = tid + i * 256;
+      const int col = idx >> 2, part = idx & 3;
+      const bool live = srow[i][second ? 1 : 0] >= 0;
+      uint32_t h[2], m[2], l[2];
+      split_bf16x3(x.s[i].x, x.s[i].y, h[0], m[0], l[0]);
+      split_bf16x3(x.s[i].z, x.s[i].w, h[1], m[1], l[1]);
+      const int slot = xslot(col >> 5, part >> 1, col & 31);
+      const u2v z = {0u, 0u};
+      *(reinterpret_cast<u2v*>(&Ss[buf][0][slot]) + (part & 1)) = live ? u2v{h[0], h[1]} : z;
+      *(reinterpret_cast<u2v*>(&Ss[buf][1][slot]) + (part & 1)) = live ? u2v{m[0], m[1]} : z;
+      *(reinterpret_cast<u2v*>(&Ss[buf][2][slot]) + (part & 1)) = live ? u2v{l[0], l[1]} : z;
+    }
+    // matrix piece tid of a plane = column tid >> 1, half tid & 1
+    const int mslot = xslot((tid >> 1) >> 5, tid & 1, (tid >> 1) & 31);
+#pragma unroll
+    for (int p = 0; p < 3; p++) Ms[buf][p][mslot] = x.m[p];
+  };
+  f16v acc[2][2];  // [quanta block][frame block]
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    bf8v sf[2][3], mf[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+        sf[i][p] = __builtin_bit_cast(bf8v, Ss[buf][p][xslot((wq >> 5) + i, kh, l32)]);
+        mf[i][p] = __builtin_bit_cast(bf8v, Ms[buf][p][xslot((wm >> 5) + i, kh, l32)]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    // smallest products first; the four result blocks interleaved, so that consecutive MFMAs are independent
+    constexpr int PS[6] = {2, 0, 1, 1, 0, 0}, PM[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; t++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          if (DBG == 2)
+            asm volatile("" : "+v"(acc[i][j]) : "v"(sf[i][PS[t]]), "v"(mf[j][PM[t]]));
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf[i][PS[t]], mf[j][PM[t]], acc[i][j], 0, 0, 0);
+        }
+  };
+  // four register sets by tile index mod 4: a tile is requested four compute phases (~1.3 us) before it is staged
+  XSet x0, x1, x2, x3;
+  fetch(0, x0);
+  fetch(1, x1);
+  fetch(2, x2);
+  fetch(3, x3);
+  stage(0, 0, x0);
+  __syncthreads();
+  warm = true;
+  int buf = 0;
+  // Every fetch and every stage is UNCONDITIONAL (past the last tile: the last tile again, staged into the buffer nobody
+  // reads): the wait counts of the loads are static, and a fetch inside an `if` makes the compiler assume it did not
+  // happen — the stage of the oldest set then waited for the fetch issued a few instructions earlier (measured: 3x).
+  const int KL = KT - 1;
+  for (int kt = 0; kt < KT; kt += 4) {
+    // tile kt in LDS[buf]; kt + 1, kt + 2, kt + 3 in flight in x1, x2, x3; x0 free
+    fetch(kt + 4 < KL ? kt + 4 : KL, x0);
+    compute(buf);
+    stage(kt + 1, buf ^ 1, x1);
+    __syncthreads();
+    buf ^= 1;
+    fetch(kt + 5 < KL ? kt + 5 : KL, x1);
+    compute(buf);
+    stage(kt + 2, buf ^ 1, x2);
+    __syncthreads();
+    buf ^= 1;
+    fetch(kt + 6 < KL ? kt + 6 : KL, x2);
+    compute(buf);
+    stage(kt + 3, buf ^ 1, x3);
+    __syncthreads();
+    buf ^= 1;
+    fetch(kt + 7 < KL ? kt + 7 : KL, x3);
+    compute(buf);
+    stage(kt + 4 < KL ? kt + 4 : KL, buf ^ 1, x0);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // result block layout: element e of a lane = row (e / 4) * 8 + kh * 4 + e % 4 (quantum), column l32 (output frame)
+  float* dst = d.dst + (uint64_t)inst * d.dst_inst + (uint64_t)ch * d.dst_ch;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const uint32_t q = q0 + (uint32_t)(wq + i * 32 + (e >> 2) * 8 + kh * 4 + (e & 3));
+      if (q >= d.n_quanta) continue;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        float v = acc[i][j][e];
+        if (curve_in_lds)
+          v = shape_curve_lds(curve_s, d.curve_n, v);
+        else if (d.curve)
+          v = shape_curve(d.curve, d.curve_n, v);
+        store_global(dst + (uint64_t)q * d.dst_q + m0 + wm + j * 32 + l32, v);
+      }
+    }
+}
+// The same tile with EIGHT wavefronts (64 quanta x 32 frames each, 32 accumulator registers): four waves per SIMD
+// with two workgroups per CU.  The four-wave form ran as the plain SUM of its parts (MFMA time + staging + loads + LDS
+// hand-offs: removing any one of them removed exactly its own time) — two waves per SIMD do not overlap them.
+struct XSet8 {  // one k-tile in flight: 4 source floats, 2 x 8 matrix bf16 per thread
+  f4v s[1];
+  u4v m[2];
+};
+template <int DBG>
+__global__ __launch_bounds__(512, 4) void qgemm_bf16x6_w8_kernel(const QGemmDesc d) {
+  __shared__ u4v Ss[2][3][XSLOTS];  // [buffer][plane][slot]: source tile, 128 quanta x 16 k
+  __shared__ u4v Ms[2][3][XSLOTS];  // matrix tile, 128 output frames x 16 k
+  __shared__ int32_t prev_s[BN];
+  __shared__ float curve_s[CURVE_LDS];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const bool curve_in_lds = d.curve && d.curve_n <= CURVE_LDS;
+  if (curve_in_lds)
+    for (int i = tid; i < d.curve_n; i += 512) curve_s[i] = load_global(d.curve + i);
+  const int wq = (wave >> 2) * 64, wm = (wave & 3) * 32;
+  const int l32 = lane & 31, kh = lane >> 5;
+  const uint32_t q0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const uint32_t inst = blockIdx.z / (uint32_t)d.nch, ch = blockIdx.z % (uint32_t)d.nch;
+  const float* src = d.src + (uint64_t)inst * d.src_inst + (uint64_t)ch * d.src_ch;
+  if (tid < BN) {
+    const uint32_t q = q0 + tid;
+    prev_s[tid] = q < d.n_quanta ? load_global(d.prev + (uint64_t)inst * d.prev_stride + q) : LINK_SKIP;
+  }
+  __syncthreads();
+  const int KT = 2 * d.Kh / XK;  // (a multiple of 16: Kh is a multiple of 128)
+  // this thread's two source pieces: quantum row `col`, 4 consecutive k; its three matrix pieces: 16 B of plane p
+  int32_t srow[1][2];  // [piece][first / second half of k]: source quantum or -1
+#pragma unroll
+  for (int i = 0; i < 1; i++) {
+    const int col = tid >> 2;
+    const int32_t p = prev_s[col];
+    srow[i][0] = p != LINK_SKIP ? (int32_t)(q0 + col) : -1;
+    srow[i][1] = p != LINK_SKIP ? p : -1;  // (LINK_FRESH = -1: no previous block)
+  }
+  const u4v* a16 = reinterpret_cast<const u4v*>(d.A16);  // tile kt, plane p, column m, half h: ((kt * 3 + p) * M + m) * 2 + h
+  bool warm = false;  // (DBG 1 / 3)
+  auto fetch = [&](int kt, XSet8& x) __attribute__((always_inline)) {
+    if (DBG == 1 && warm) return;
+    // tile order: (k-tile p of this block, k-tile p of the previous block), p = 0, 1, ...: the two read the same source
+    // columns of neighbouring quanta (the previous processed block is almost always quantum q - 1), i.e. the same cache
+    // lines one phase apart.  In plain k order the second pass over the rows came half a workgroup lifetime later, after
+    // the 128 KB panel had left the L2 (64 workgroups per XCD): the source was fetched from HBM several times.
+    const bool second = kt & 1;
+    const int koff = (kt >> 1) * XK;
+    const int mt = (kt >> 1) + (second ? d.Kh / XK : 0);  // matrix tile (rows mt * 16 ... of the k-major matrix)
+#pragma unroll
+    for (int i = 0; i < 1; i++) {
+      const int part = tid & 3;
+      const int32_t sq = srow[i][second ? 1 : 0];
+      // (unconditional load, row 0 instead of a skipped row, zeroed when staged: a load inside a branch is waited for at once)
+      x.s[i] = load_global_f4(src + (uint64_t)(sq < 0 ? 0 : sq) * d.src_q + (uint64_t)(koff + part * 4));
+    }
+    // 768 matrix pieces for 512 threads: piece tid & 255 of plane tid >> 8, and of plane 2 (both halves of the workgroup:
+    // the same load and the same LDS store twice, instead of a branch around a load)
+    x.m[0] = *(const WAA_GLOBAL_AS u4v*)(a16 + ((uint64_t)(mt * 3 + (tid >> 8)) * d.M + m0) * 2 + (tid & 255));
+    x.m[1] = *(const WAA_GLOBAL_AS u4v*)(a16 + ((uint64_t)(mt * 3 + 2) * d.M + m0) * 2 + (tid & 255));
+  };
+  auto stage = [&](int kt, int buf, const XSet8& x) __attribute__((always_inline)) {
+    if (DBG == 3 && warm) {
+      asm volatile("" ::"v"(x.s[0]), "v"(x.m[0]), "v"(x.m[1]));
+      return;
+    }
+    const bool second = kt & 1;
+#pragma unroll
+    for (int i = 0; i < 1; i++) {
+      const int idx = tid;
+      const int col = idx >> 2, part = idx & 3;
+      const bool live = srow[i][second ? 1 : 0] >= 0;
+      uint32_t h[2], m[2], l[2];
+      split_bf16x3(x.s[i].x, x.s[i].y, h[0], m[0], l[0]);
+      split_bf16x3(x.s[i].z, x.s[i].w, h[1], m[1], l[1]);
+      const int slot = xslot(col >> 5, part >> 1, col & 31);
+      const u2v z = {0u, 0u};
+      *(reinterpret_cast<u2v*>(&Ss[buf][0][slot]) + (part & 1)) = live ? u2v{h[0], h[1]} : z;
+      *(reinterpret_cast<u2v*>(&Ss[buf][1][slot]) + (part & 1)) = live ? u2v{m[0], m[1]} : z;
+      *(reinterpret_cast<u2v*>(&Ss[buf][2][slot]) + (part & 1)) = live ? u2v{l[0], l[1]} : z;
+    }
+    // matrix piece tid of a plane = column tid >> 1, half tid & 1
+    const int mslot = xslot(((tid & 255) >> 1) >> 5, tid & 1, ((tid & 255) >> 1) & 31);
+    Ms[buf][tid >> 8][mslot] = x.m[0];
+    Ms[buf][2][mslot] = x.m[1];
+  };
+  f16v acc[2][1];  // [quanta block][frame block]
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[i][0][e] = 0.f;
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    bf8v sf[2][3], mf[1][3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      sf[0][p] = __builtin_bit_cast(bf8v, Ss[buf][p][xslot((wq >> 5), kh, l32)]);
+      sf[1][p] = __builtin_bit_cast(bf8v, Ss[buf][p][xslot((wq >> 5) + 1, kh, l32)]);
+      mf[0][p] = __builtin_bit_cast(bf8v, Ms[buf][p][xslot(wm >> 5, kh, l32)]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // smallest products first; the four result blocks interleaved, so that consecutive MFMAs are independent
+    constexpr int PS[6] = {2, 0, 1, 1, 0, 0}, PM[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; t++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 1; j++) {
+          if (DBG == 2)
+            asm volatile("" : "+v"(acc[i][j]) : "v"(sf[i][PS[t]]), "v"(mf[j][PM[t]]));
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf[i][PS[t]], mf[j][PM[t]], acc[i][j], 0, 0, 0);
+        }
+  };
+  // two register sets by tile parity: a tile is requested two compute phases before it is staged (four waves per SIMD hide
+  // the rest; four sets as in the four-wave form spill at 128 registers)
+  XSet8 x0, x1;
+  fetch(0, x0);
+  fetch(1, x1);
+  stage(0, 0, x0);
+  __syncthreads();
+  warm = true;
+  int buf = 0;
+  // (every fetch and every stage unconditional, see the four-wave form)
+  const int KL = KT - 1;
+  for (int kt = 0; kt < KT; kt += 2) {
+    fetch(kt + 2 < KL ? kt + 2 : KL, x0);
+    compute(buf);
+    stage(kt + 1, buf ^ 1, x1);
+    __syncthreads();
+    buf ^= 1;
+    fetch(kt + 3 < KL ? kt + 3 : KL, x1);
+    compute(buf);
+    stage(kt + 2 < KL ? kt + 2 : KL, buf ^ 1, x0);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // result block layout: element e of a lane = row (e / 4) * 8 + kh * 4 + e % 4 (quantum), column l32 (output frame)
+  float* dst = d.dst + (uint64_t)inst * d.dst_inst + (uint64_t)ch * d.dst_ch;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const uint32_t q = q0 + (uint32_t)(wq + i * 32 + (e >> 2) * 8 + kh * 4 + (e & 3));
+      if (q >= d.n_quanta) continue;
+#pragma unroll
+      for (int j = 0; j < 1; j++) {
+        float v = acc[i][j][e];
+        if (curve_in_lds)
+          v = shape_curve_lds(curve_s, d.curve_n, v);
+        else if (d.curve)
+          v = shape_curve(d.curve, d.curve_n, v);
+        store_global(dst + (uint64_t)q * d.dst_q + m0 + wm + j * 32 + l32, v);
+      }
+    }
+}
 void launch_qgemm(const QGemmDesc& d, void* stream) {
   dim3 grid((d.n_quanta + BN - 1) / BN, d.M / BM, d.n_inst * (uint32_t)d.nch);
-  if (getenv("WAA_QGEMM_FMA"))  // (switch: the vector-FMA form, same-box A/B with tools/ab_env.py)
+  const char* xdbg = getenv("WAA_QGEMM_DEBUG");
+  if (d.A16 && xdbg && xdbg[0] >= 'a' && xdbg[0] <= 'c') {
+    if (xdbg[0] == 'a') hipLaunchKernelGGL(qgemm_bf16x6_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, d);
+    if (xdbg[0] == 'b') hipLaunchKernelGGL(qgemm_bf16x6_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, d);
+    if (xdbg[0] == 'c') hipLaunchKernelGGL(qgemm_bf16x6_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, d);
+  } else if (d.A16 && xdbg && xdbg[0] >= 'd' && xdbg[0] <= 'f') {
+    if (xdbg[0] == 'd') hipLaunchKernelGGL(qgemm_bf16x6_w8_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, d);
+    if (xdbg[0] == 'e') hipLaunchKernelGGL(qgemm_bf16x6_w8_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, d);
+    if (xdbg[0] == 'f') hipLaunchKernelGGL(qgemm_bf16x6_w8_kernel<3>, grid, dim3(512), 0, (hipStream_t)stream, d);
+  } else if (d.A16 && !getenv("WAA_QGEMM_FMA") && !getenv("WAA_QGEMM_F32") && !xdbg && getenv("WAA_QGEMM_W4"))
+    hipLaunchKernelGGL(qgemm_bf16x6_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d);
+  else if (d.A16 && !getenv("WAA_QGEMM_FMA") && !getenv("WAA_QGEMM_F32") && !xdbg)
+    hipLaunchKernelGGL(qgemm_bf16x6_w8_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, d);
+  else if (getenv("WAA_QGEMM_FMA"))  // (switch: the vector-FMA form, same-box A/B with tools/ab_env.py)
     hipLaunchKernelGGL(qgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
   else if (const char* dbg = getenv("WAA_QGEMM_DEBUG")) {
     switch (dbg[0]) {

@@ -83,6 +83,35 @@ static std::vector<float> resampler_matrix(int fi, int fo) {
   return A;
 }
 
+// The matrix as three bf16 planes, A = hi + mid + lo exactly (round to nearest even at each step), in the tile order
+// of qgemm_bf16x6_kernel: [k / 16][plane][M][16].  A is [K][M], k-major.
+static std::vector<uint16_t> split_matrix_bf16x3(const std::vector<float>& A, int K, int M) {
+  auto rne = [](float x) -> uint32_t {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+  };
+  auto as_float = [](uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+  };
+  std::vector<uint16_t> out((size_t)3 * K * M);
+  for (int k = 0; k < K; k++)
+    for (int m = 0; m < M; m++) {
+      const float x = A[(size_t)k * M + m];
+      const uint32_t hi = rne(x);
+      const float r = x - as_float(hi);
+      const uint32_t mid = rne(r);
+      const float l = r - as_float(mid);
+      uint32_t lo;
+      std::memcpy(&lo, &l, 4);
+      const uint32_t plane[3] = {hi, mid, lo};
+      for (int p = 0; p < 3; p++) out[(((size_t)(k / 16) * 3 + p) * M + m) * 16 + (size_t)(k % 16)] = (uint16_t)(plane[p] >> 16);
+    }
+  return out;
+}
+
 // host-known codes (count | CODE_SILENT per quantum) of a source node: waa_plan.cpp
 int source_code_rows(waa_batch* b, uint32_t id, uint64_t cs, std::vector<uint8_t>* host);
 
@@ -152,7 +181,11 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
   const int up_len = RQ * R;
   const int nch = n.in_nch;
   float *d_up = nullptr, *d_dn = nullptr, *sbuf = nullptr;
-  if ((e = dev_upload(b, &d_up, resampler_matrix(RQ, up_len))) || (e = dev_upload(b, &d_dn, resampler_matrix(up_len, RQ))) ||
+  uint16_t *d_up16 = nullptr, *d_dn16 = nullptr;
+  const std::vector<float> m_up = resampler_matrix(RQ, up_len), m_dn = resampler_matrix(up_len, RQ);
+  if ((e = dev_upload(b, &d_up, m_up)) || (e = dev_upload(b, &d_dn, m_dn)) ||
+      (e = dev_upload(b, &d_up16, split_matrix_bf16x3(m_up, 2 * RQ, up_len))) ||
+      (e = dev_upload(b, &d_dn16, split_matrix_bf16x3(m_dn, 2 * up_len, RQ))) ||
       (e = dev_alloc(b, &sbuf, (size_t)b->n_inst * nch * b->n_quanta * up_len)))
     return e;
   Step up;
@@ -160,6 +193,7 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
   QGemmDesc& g = up.qgemm;
   std::memset(&g, 0, sizeof g);
   g.A = d_up;
+  g.A16 = d_up16;
   g.M = up_len;
   g.Kh = RQ;
   g.src = in_sig.base;
@@ -186,6 +220,7 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
   QGemmDesc& h = dn.qgemm;
   std::memset(&h, 0, sizeof h);
   h.A = d_dn;
+  h.A16 = d_dn16;
   h.M = RQ;
   h.Kh = up_len;
   h.src = sbuf;
@@ -236,20 +271,34 @@ static double resample_kernel_value(double x, double fc) {
 // HRIRs at another rate — OUR definition of the crate's one-chunk rubato SincFixedIn pass (sinc_len 256, f_cutoff 0.95,
 // BlackmanHarris2): output n is the band-limited signal at input position t_n = (n + 1) / ratio - 128, while
 // t_n < taps - 257 - 1 / ratio; kernel evaluated directly instead of through the oversampled cubic table.
-static void resample_hrir(const float* in, int len, double ratio, std::vector<float>* out) {
-  int n_out = 0;
-  while ((double)(n_out + 1) / ratio - 128. < (double)len - 257. - 1. / ratio) n_out++;
-  const double fc = 0.95 * (ratio < 1. ? ratio : 1.);
-  for (int n = 0; n < n_out; n++) {
-    const double t = (double)(n + 1) / ratio - 128.;
-    int m0 = (int)std::ceil(t - 128.), m1 = (int)std::floor(t + 128.);
-    m0 = std::max(m0, 0);
-    m1 = std::min(m1, len - 1);
-    double acc = 0.;
-    for (int m = m0; m <= m1; m++) acc += (double)in[m] * resample_kernel_value(t - (double)m, fc);
-    out->push_back((float)acc);
+// The kernel weights depend on the output index and the tap offset only — one table for all 2 x 187 impulse responses
+// (evaluating the window per product made the first plan of a process take 0.7 s).
+struct HrirResampler {
+  int len = 0, n_out = 0;
+  std::vector<int> m0, m1;
+  std::vector<double> w;  // [n_out][257]
+  HrirResampler(int len_, double ratio) : len(len_) {
+    while ((double)(n_out + 1) / ratio - 128. < (double)len - 257. - 1. / ratio) n_out++;
+    const double fc = 0.95 * (ratio < 1. ? ratio : 1.);
+    m0.resize((size_t)n_out);
+    m1.resize((size_t)n_out);
+    w.assign((size_t)n_out * 257, 0.);
+    for (int n = 0; n < n_out; n++) {
+      const double t = (double)(n + 1) / ratio - 128.;
+      m0[(size_t)n] = std::max((int)std::ceil(t - 128.), 0);
+      m1[(size_t)n] = std::min((int)std::floor(t + 128.), len - 1);
+      for (int m = m0[(size_t)n]; m <= m1[(size_t)n]; m++) w[(size_t)n * 257 + (size_t)(m - m0[(size_t)n])] = resample_kernel_value(t - (double)m, fc);
+    }
   }
-}
+  void run(const float* in, std::vector<float>* out) const {
+    for (int n = 0; n < n_out; n++) {
+      double acc = 0.;
+      const double* wn = &w[(size_t)n * 257];
+      for (int m = m0[(size_t)n]; m <= m1[(size_t)n]; m++) acc += (double)in[m] * wn[m - m0[(size_t)n]];
+      out->push_back((float)acc);
+    }
+  }
+};
 static std::shared_ptr<Sphere> sphere_for_rate(uint32_t sample_rate) {
   if (sample_rate < 27000) sample_rate = 27000;  // panner.rs:46-49
   std::lock_guard<std::mutex> lock(g_sphere_lock);
@@ -263,9 +312,10 @@ static std::shared_ptr<Sphere> sphere_for_rate(uint32_t sample_rate) {
   s->faces = f.faces;
   s->pos = f.pos;
   const double ratio = (double)sample_rate / (double)f.sr;
+  const HrirResampler rs(f.taps, ratio);
   for (int v = 0; v < f.nv(); v++) {
-    resample_hrir(f.left.data() + (size_t)v * f.taps, f.taps, ratio, &s->left);
-    resample_hrir(f.right.data() + (size_t)v * f.taps, f.taps, ratio, &s->right);
+    rs.run(f.left.data() + (size_t)v * f.taps, &s->left);
+    rs.run(f.right.data() + (size_t)v * f.taps, &s->right);
   }
   s->taps = f.nv() ? (int)(s->left.size() / (size_t)f.nv()) : 0;
   g_sphere_cache[sample_rate] = s;

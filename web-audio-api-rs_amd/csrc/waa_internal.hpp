@@ -478,6 +478,7 @@ void launch_link(const LinkDesc& d, void* stream);
 // by the WaveShaper curve when `curve` is set (the up-sampling stage).
 struct QGemmDesc {
   const float* A;           // [2 * Kh][M], k-major: row k holds the M coefficients that multiply source element k
+  const uint16_t* A16;      // the same matrix as three bf16 planes (A = hi + mid + lo exactly), tiled [k / 16][plane][M][16]
   int32_t M, Kh;
   const float* src;         // element k of column (inst, ch, q): src[inst * src_inst + ch * src_ch + q * src_q + k]
   uint64_t src_inst, src_ch, src_q;
