@@ -10,11 +10,11 @@
 //
 // link_kernel replays that control flow once per instance over the per-quantum codes of the node's input and leaves
 // a `prev` table; everything else is parallel over (instance, quantum):
-//   qgemm_kernel — both resampling stages are LINEAR maps of (this block, previous processed block), i.e. matrix
-//                  products over render quanta: f32 FMA GEMM, 128 x 128 tile, register-blocked 8 x 8.
+//   qgemm_*      — both resampling stages are LINEAR maps of (this block, previous processed block), i.e. matrix
+//                  products over render quanta.  Product path: qgemm_bf16x6_w8_kernel, the bf16 matrix
+//                  cores at f32 accuracy (exact three-way bf16 split of both operands, six MFMA products per f32
+//                  product); cross-checks: qgemm_mfma_kernel (f32 MFMA) and qgemm_kernel (f32 vector FMA).
 //   hrtf_kernel  — direct-form FIR, one wavefront per (instance, quantum), sliding register window.
-// No MFMA: the matrices are f32 and the reference's tolerance (1e-6 RMS) rules out the reduced-precision matrix
-// formats; f32 MFMA has the same peak as the vector FMA pipe on this part.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
