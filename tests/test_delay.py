@@ -182,16 +182,38 @@ def test_subquantum_delay_dynamic_lifetime(be):
     assert np.max(np.abs(out - exp)) <= 1e-5
 
 
-def test_plan_delay_is_node_major(hip):
+def _plan_of_delay_graph(hip, a_rate=False, second_consumer=None):
     c = waa.OfflineAudioContext(2, RQ * 64, 48000.0, n_instances=4, binding=hip, device=waa.PLAN_ONLY)
     src = c.create_buffer_source()
     src.set_buffer_batch(white_noise(4, 2, RQ * 64), 48000.0)
     d = c.create_delay(0.5, delay_time=0.01)
+    if a_rate:
+        d.delay_time.set_block(0, np.full((64, RQ), 0.01, np.float32))
     src.connect(c.create_gain(gain=0.5)).connect(d).connect(c.create_gain(gain=2.0)).connect(c.destination())
+    if second_consumer == "delay":
+        d.connect(c.create_delay(0.5, delay_time=0.02)).connect(c.destination())
     src.start()
     plan = c.plan_describe()
-    assert "delay node" in plan and "ring=189 quanta" in plan and "delayTime=const" in plan
     c.close()
+    return plan
+
+
+def test_plan_constant_delay_is_folded_into_its_consumer(hip):
+    """constant delayTime, consumed by a chain: no pass of its own, the consumer gathers from the delay line"""
+    plan = _plan_of_delay_graph(hip)
+    assert "read by its consumers from the delay line" in plan and "delayed:2ch" in plan and "ring=" not in plan
+
+
+def test_plan_delay_is_node_major(hip, monkeypatch):
+    """per-frame delayTime, a node-major consumer, or the switch: the gather kernel (waa_delay.hip)"""
+    plan = _plan_of_delay_graph(hip, a_rate=True)
+    assert "delay node" in plan and "ring=189 quanta" in plan and "delayTime=a-rate" in plan
+    plan = _plan_of_delay_graph(hip, second_consumer="delay")
+    # (the first delay feeds another DelayNode: node-major; the second one only feeds the destination: folded)
+    assert plan.count("ring=189 quanta") == 1 and "delayTime=const" in plan and "delayed:2ch" in plan
+    monkeypatch.setenv("WAA_NO_DELAY_FOLD", "1")
+    plan = _plan_of_delay_graph(hip)
+    assert "delay node" in plan and "ring=189 quanta" in plan and "delayTime=const" in plan
 
 
 # --------------------------------------------------------------------------- GPU parity on seeded inputs

@@ -24,43 +24,26 @@ __global__ __launch_bounds__(256) void delay_kernel(const DelayDesc d) {
   const int i0 = (int)(f0 % RQ);
   const int64_t qstart = (int64_t)q * RQ;
   float r[4] = {0.f, 0.f, 0.f, 0.f};
-  if (q < d.n_quanta) {
-    // delay.len() == 1 (constant or one value per quantum): infos[0] from the value, then one frame per frame
-    // (delay.rs:560-590); a-rate: every frame from its own value (delay.rs:591-606)
-    int64_t pf0 = 0;
-    float k0 = 0.f;
-    if (d.delay.mode != 2) {
-      const float dv = d.delay.mode == 0 ? d.delay.base[inst] : d.delay.base[(uint64_t)inst * d.delay.stride + q];
-      double dd = (double)dv;
-      if (d.in_cycle) dd = fmax(dd, d.quantum_duration);  // delay.rs:693-701
-      const double position = 0. - dd * d.sample_rate;
-      const double fl = floor(position);
-      pf0 = (int64_t)fl;
-      k0 = (float)(position - fl);
-    }
+  if (q < d.n_quanta && d.delay.mode != 2) {
+    // one value per quantum (constant or k-rate)
+    const float dv = d.delay.mode == 0 ? d.delay.base[inst] : d.delay.base[(uint64_t)inst * d.delay.stride + q];
+    delay_read4(in, d.frames, dv, d.sample_rate, d.num_quanta, d.in_cycle != 0, d.quantum_duration, q, i0, r);
+  } else if (q < d.n_quanta) {
+    // a-rate: every frame from its own value (delay.rs:591-606)
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int i = i0 + e;
-      int64_t pf;
-      float k;
-      if (d.delay.mode != 2) {
-        pf = pf0 + i;
-        k = k0;
-      } else {
-        const float dv = d.delay.base[(uint64_t)inst * d.delay.stride + (uint64_t)q * RQ + i];
-        double dd = (double)dv;
-        if (d.in_cycle) dd = fmax(dd, d.quantum_duration);
-        const double position = (double)i - dd * d.sample_rate;
-        const double fl = floor(position);
-        pf = (int64_t)fl;
-        k = (float)(position - fl);
-      }
+      const float dv = d.delay.base[(uint64_t)inst * d.delay.stride + (uint64_t)q * RQ + i];
+      double dd = (double)dv;
+      if (d.in_cycle) dd = fmax(dd, d.quantum_duration);
+      const double position = (double)i - dd * d.sample_rate;
+      const double fl = floor(position);
+      const int64_t pf = (int64_t)fl;
+      const float k = (float)(position - fl);
       const int64_t prev = qstart + pf;
       // the sample after frame 127 of the newest block is frame 0 of the OLDEST ring block (delay.rs:622-626);
       // only reachable with a zero delay, where k == 0
       int64_t next = pf == RQ - 1 ? (int64_t)(q - (int64_t)d.num_quanta) * RQ : prev + 1;
-      // a reader that renders before its writer finds, in the slot of the current quantum, the block written
-      // ring-capacity quanta ago (only reachable with k == 0)
       if (d.in_cycle && next >= qstart) next -= ((int64_t)d.num_quanta + 1) * RQ;
       const float ps = prev >= 0 ? in[prev] : 0.f;
       const float nsamp = next >= 0 ? in[next] : 0.f;

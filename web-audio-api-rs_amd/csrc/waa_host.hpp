@@ -172,6 +172,10 @@ struct Node {
   // every instance) and whose only consumer is a node-major step that takes a bounded view: it is not materialised,
   // the consumer reads the buffer in place (view_valid frames per channel, zeros beyond)
   bool is_view = false;
+  // DelayNode outside a loop, constant / k-rate delayTime, consumed by chain input stages only: no reader pass, the
+  // consumers gather from the delay line themselves (IN_DELAYED)
+  bool delay_folded = false;
+  uint64_t hist_valid = 0;  // frames of the delay line that may be read (zeros beyond): the padded length, or a source view's
   SignalRef view_sig{};
   uint64_t view_valid = 0;
   // dynamic plans (waa_dyn.hip): per-quantum codes of the published signal, and the quantum slot of channel 1 when the

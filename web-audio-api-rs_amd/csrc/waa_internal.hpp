@@ -71,15 +71,22 @@ struct SrcInst {
 };
 
 // ---- chain kernel description ----------------------------------------------------------
-enum : int32_t { IN_SILENT = 0, IN_SIGNAL = 1, IN_SOURCE = 2, IN_CONSTANT = 3 };
+// IN_DELAYED: the output of a DelayNode outside a feedback loop with a constant / k-rate delayTime, read by its
+// consumer straight from the delay line (`sig` = the DelayNode's mixed input in absolute time) — the gather of
+// waa_delay.hip folded into the consumer's input stage instead of a pass through HBM of its own
+enum : int32_t { IN_SILENT = 0, IN_SIGNAL = 1, IN_SOURCE = 2, IN_CONSTANT = 3, IN_DELAYED = 4 };
 struct InputRef {
   int32_t kind;
   int32_t nch;            // channels this input delivers
-  SignalRef sig;          // IN_SIGNAL
+  SignalRef sig;          // IN_SIGNAL; IN_DELAYED: the delay line
   const SrcInst* src;     // IN_SOURCE: [n_inst]
   const SrcSchedule* sched;  // IN_SOURCE: schedule table
-  ParamRef offset;        // IN_CONSTANT: the offset param
+  ParamRef offset;        // IN_CONSTANT: the offset param; IN_DELAYED: delayTime (mode 0 or 1), clamped by the host
   const int64_t* active;  // IN_CONSTANT: [n_inst][2] first/last+1 active frame
+  double sample_rate;     // IN_DELAYED
+  int32_t num_quanta;     // IN_DELAYED: ring capacity - 1 (delay.rs:300-302)
+  int32_t pad1;
+  uint64_t valid;         // IN_DELAYED: frames of the delay line that may be read (zeros beyond: a source's buffer read in place)
   ParamRef gain;          // has_gain: a GainNode folded into this edge (applied before the mix to the receiver's count)
   int32_t has_gain;
   int32_t pad;
@@ -243,6 +250,7 @@ struct DelayDesc {
   double quantum_duration;
 };
 void launch_delay(const DelayDesc& d, void* stream);
+
 
 // ---- OscillatorNode (oscillator.rs:323-660): one lane per instance, frames in order ----------------
 struct OscDesc {
@@ -575,4 +583,50 @@ __device__ __forceinline__ SlowRec load_global(const SlowRec* p) {
 
 #endif
 
+#ifdef __HIPCC__
+// Four consecutive frames (i0 .. i0 + 3 of quantum q) of a DelayNode's output for a delay that is ONE value in this
+// quantum (constant or k-rate): delay.rs:560-590 (infos[0] from the value, then one frame per frame), :642 (the f32 fma),
+// :622-626 (the sample after frame 127 of the newest block is frame 0 of the oldest ring block).  `in` is the delay line
+// of this (instance, channel) in absolute time; frames before 0 read silence.
+__device__ __forceinline__ void delay_read4(const float* in, uint64_t valid, float dv, double sample_rate, int32_t num_quanta,
+                                            bool in_cycle, double quantum_duration, uint32_t q, int i0, float (&r)[4]) {
+  double dd = (double)dv;
+  if (in_cycle) dd = fmax(dd, quantum_duration);  // delay.rs:693-701
+  const double position = 0. - dd * sample_rate;
+  const double fl = floor(position);
+  const int64_t pf0 = (int64_t)fl;
+  const float k = (float)(position - fl);
+  const int64_t qstart = (int64_t)q * RQ;
+  {
+    // fast path: the five samples in[first .. first + 4] out of two aligned 16-byte loads (instead of eight scattered
+    // 4-byte ones); taken when no frame of the group is frame 127 of the newest block (the wrap rule below) and the
+    // aligned window lies inside the line
+    const int64_t first = qstart + pf0 + i0;
+    const int64_t a = first & ~(int64_t)3;
+    if (pf0 + i0 + 3 < RQ - 1 && !in_cycle && a >= 0 && (uint64_t)a + 8 <= valid && ((uintptr_t)in & 15) == 0) {
+      const f4v v0 = load_global_f4(in + a), v1 = load_global_f4(in + a + 4);
+      const float w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      const int sh = (int)(first - a);
+      float x[5];
+#pragma unroll
+      for (int e = 0; e < 5; e++) x[e] = sh == 0 ? w[e] : sh == 1 ? w[e + 1] : sh == 2 ? w[e + 2] : w[e + 3];
+#pragma unroll
+      for (int e = 0; e < 4; e++) r[e] = __builtin_fmaf(1.f - k, x[e], k * x[e + 1]);
+      return;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int64_t pf = pf0 + i0 + e;
+    const int64_t prev = qstart + pf;
+    int64_t next = pf == RQ - 1 ? (int64_t)((int64_t)q - (int64_t)num_quanta) * RQ : prev + 1;
+    // a reader that renders before its writer finds, in the slot of the current quantum, the block written
+    // ring-capacity quanta ago (only reachable with k == 0)
+    if (in_cycle && next >= qstart) next -= ((int64_t)num_quanta + 1) * RQ;
+    const float ps = prev >= 0 && (uint64_t)prev < valid ? in[prev] : 0.f;
+    const float nsamp = next >= 0 && (uint64_t)next < valid ? in[next] : 0.f;
+    r[e] = __builtin_fmaf(1.f - k, ps, k * nsamp);
+  }
+}
+#endif
 }  // namespace waa

@@ -185,6 +185,28 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
     }
     return;
   }
+  if (in.kind == IN_DELAYED) {
+    // the gather of waa_delay.hip in the input stage (delay.rs:560-590, 622-642); 4 | 128: a float4 group sits in one quantum
+#pragma unroll
+    for (int j = 0; j < NV4; j++) {
+      const uint64_t f = f_tile + (uint64_t)(j * 256 + lane * 4);
+      const uint32_t q = (uint32_t)(f / RQ);
+      const bool live = q < n_quanta;
+      const float dv = in.offset.mode == 0 ? load_global(in.offset.base + inst)
+                                           : load_global(in.offset.base + (uint64_t)inst * in.offset.stride + (live ? q : 0));
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        if (c < in.nch) {
+          const float* p = in.sig.base + (uint64_t)inst * in.sig.inst_stride + (uint64_t)c * in.sig.ch_stride;
+          float r[4] = {0.f, 0.f, 0.f, 0.f};
+          if (live) delay_read4(p, in.valid, dv, in.sample_rate, in.num_quanta, false, 0., q, (int)(f % RQ), r);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[c][j * 4 + e] = r[e];
+        }
+      }
+    }
+    return;
+  }
   if (in.kind == IN_SOURCE) {
     const SrcInst si = in.src[inst];
     const SrcSchedule sc = si.sc;

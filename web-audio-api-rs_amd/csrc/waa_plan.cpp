@@ -244,6 +244,7 @@ const char* input_kind_name(int k) {
     case IN_SIGNAL: return "signal";
     case IN_SOURCE: return "source";
     case IN_CONSTANT: return "constant";
+    case IN_DELAYED: return "delayed";
     default: return "silent";
   }
 }
@@ -509,6 +510,7 @@ void vertex_targets(const waa_batch* b, uint32_t v, const std::vector<uint8_t>& 
 
 int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items);
 int plan_delay_writer(waa_batch* b, uint32_t id);
+int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr);
 int plan_oscillator(waa_batch* b, uint32_t id);
 int plan_delay_reader(waa_batch* b, uint32_t id);
 uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items);
@@ -1099,11 +1101,40 @@ int build_plan(waa_batch* b) {
       count_change_found = true;
     }
   }
+  // A DelayNode outside a feedback loop whose delayTime is one value per quantum and whose consumers are all input
+  // stages of chain kernels is not rendered by a pass of its own: the consumers gather from the delay line (IN_DELAYED).
+  // (Static plans only; an echo — source -> Delay -> Gain -> bus — then costs one pass instead of three.)
+  std::vector<uint8_t> folded_delay(N, 0);
+  for (uint32_t id = 0; id < N; id++) {
+    Node& n = b->nodes[id];
+    n.delay_folded = false;
+    if (!n.live || n.desc.kind != WAA_NODE_DELAY || count_change_found || b->force_dynamic || getenv("WAA_NO_DELAY_FOLD")) continue;
+    if (scc_of[id] >= 0 || (id < b->cut.size() && b->cut[id])) continue;
+    const ParamStore& dt = n.params[WAA_PARAM_DELAY_DELAY_TIME];
+    bool ok = dt.mode() != 2 && n.in_edges.size() >= 1;
+    if ((size_t)WAA_PARAM_DELAY_DELAY_TIME < n.pin_edges.size() && !n.pin_edges[WAA_PARAM_DELAY_DELAY_TIME].empty()) ok = false;
+    int consumers = 0;
+    for (auto& e : b->edges) {
+      if (e.from != id || !b->nodes[e.to].live) continue;
+      consumers++;
+      const Node& c = b->nodes[e.to];
+      const uint32_t ck = c.desc.kind;
+      if ((e.to_input & 0x80000000u) || scc_of[e.to] >= 0 || (ck == WAA_NODE_CONVOLVER && c.has_ir) || ck == WAA_NODE_DELAY ||
+          is_frozen_node(c) || c.in_nch > 2 || n.out_nch > 2)
+        ok = false;
+    }
+    if (ok && consumers > 0) folded_delay[id] = 1;
+  }
   // materialisation points
   std::vector<uint8_t> mat_hard(N, 0), fan_in_only(N, 0);
   for (uint32_t id = 0; id < N; id++) {
     Node& n = b->nodes[id];
     if (!n.live) continue;
+    if (folded_delay[id]) {
+      n.delay_folded = true;
+      n.materialized = false;
+      continue;
+    }
     bool mat = false, fan = false;
     const uint32_t kind = n.desc.kind;
     if (kind == WAA_NODE_DESTINATION || kind == WAA_NODE_ANALYSER || kind == WAA_NODE_CONVOLVER || kind == WAA_NODE_DELAY) mat = true;
@@ -1149,7 +1180,7 @@ int build_plan(waa_batch* b) {
       const Node& xn = b->nodes[x];
       if (!xn.live || xn.out_nch != n.in_nch) continue;
       // x is either materialised for its own reasons, or a source whose only consumer is this gain
-      if (mat_hard[x] || (is_source_kind(xn.desc.kind) && !fan_in_only[x])) n.materialized = false;
+      if (mat_hard[x] || folded_delay[x] || (is_source_kind(xn.desc.kind) && !fan_in_only[x])) n.materialized = false;
     }
   // A BufferSource whose output IS its AudioBuffer (fast track from frame 0: start 0, no offset / duration / stop /
   // loop, playbackRate 1, detune 0, buffer at the context's rate, one layout for all instances) and whose single
@@ -1164,11 +1195,28 @@ int build_plan(waa_batch* b) {
         n_live++;
         consumer = (e.to_input & 0x80000000u) ? -1 : (int)e.to;
       }
-    if (n_live != 1 || consumer < 0) continue;
-    const Node& c = b->nodes[(uint32_t)consumer];
-    const bool conv = c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir;
-    bool frozen_ok = false;
-    if (is_frozen_node(c) && frozen_src[(uint32_t)consumer] == (int)id) {
+    // ... or whose consumers are all input stages of chain kernels (which fetch a source themselves) and folded
+    // DelayNodes (whose delay line the source's buffer then IS): no copy either
+    bool shared_ok = n_live >= 2;
+    int n_delay = 0;
+    for (auto& e : b->edges) {
+      if (e.from != id || !b->nodes[e.to].live || !shared_ok) continue;
+      const Node& c = b->nodes[e.to];
+      const uint32_t ck = c.desc.kind;
+      if (c.delay_folded) {
+        n_delay++;
+        shared_ok = c.in_edges.size() == 1 && c.in_nch == n.out_nch;
+      } else if ((e.to_input & 0x80000000u) || scc_of[e.to] >= 0 || (ck == WAA_NODE_CONVOLVER && c.has_ir) || ck == WAA_NODE_DELAY ||
+                 is_frozen_node(c) || ck == WAA_NODE_IIR_FILTER) {
+        shared_ok = false;
+      }
+    }
+    shared_ok = shared_ok && n_delay > 0;
+    if (!shared_ok && (n_live != 1 || consumer < 0)) continue;
+    const Node& c = b->nodes[(uint32_t)(shared_ok ? 0 : consumer)];
+    const bool conv = !shared_ok && c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir;
+    bool frozen_ok = shared_ok;
+    if (!shared_ok && is_frozen_node(c) && frozen_src[(uint32_t)consumer] == (int)id) {
       if (c.desc.kind == WAA_NODE_PANNER) {
         frozen_ok = true;
       } else {  // (a shaper that processes silent quanta would read them from the view: copy instead)
@@ -1177,7 +1225,8 @@ int build_plan(waa_batch* b) {
         frozen_ok = cn == 0 || std::fabs(mid) < 1e-9f;
       }
     }
-    if (!(conv || frozen_ok) || c.in_edges.size() != 1 || c.in_nch != n.out_nch || scc_of[(uint32_t)consumer] >= 0) continue;
+    if (!(conv || frozen_ok)) continue;
+    if (!shared_ok && (c.in_edges.size() != 1 || c.in_nch != n.out_nch || scc_of[(uint32_t)consumer] >= 0)) continue;
     const ParamStore& pr = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
     const ParamStore& pd = n.params[WAA_PARAM_SOURCE_DETUNE];
     bool ok = pr.blocks.empty() && pd.blocks.empty() && pr.timelines.empty() && pd.timelines.empty() && !pr.dev_tl && !pd.dev_tl;
@@ -1197,8 +1246,12 @@ int build_plan(waa_batch* b) {
     n.materialized = false;
     n.view_sig = SignalRef{b0.base, (uint64_t)inst_stride, b0.ch_stride, (int32_t)b0.nch, 0};
     n.view_valid = b0.frames;
-    plan_note(b, "source node %u renders its AudioBuffer unchanged: node %d reads it in place (%llu frames per channel)", id, consumer,
-              (unsigned long long)b0.frames);
+    if (shared_ok)
+      plan_note(b, "source node %u renders its AudioBuffer unchanged: its %d consumers read it in place (%llu frames per channel)", id, n_live,
+                (unsigned long long)b0.frames);
+    else
+      plan_note(b, "source node %u renders its AudioBuffer unchanged: node %d reads it in place (%llu frames per channel)", id, consumer,
+                (unsigned long long)b0.frames);
   }
   auto alloc_signal = [&](Node& n) -> int {
     float* p = nullptr;
@@ -1242,6 +1295,10 @@ int build_plan(waa_batch* b) {
   b->steps.clear();
   std::function<int(uint32_t)> plan_single = [&](uint32_t id) -> int {
     Node& term = b->nodes[id];
+    if (term.live && term.delay_folded) {
+      plan_note(b, "delay node %u: %dch, read by its consumers from the delay line (no pass of its own)", id, term.in_nch);
+      return node_input_signal(b, id, &term.hist, nullptr, &term.hist_valid);  // the delay line = the node's mixed input
+    }
     if (!term.live || !term.materialized) return 0;
     if (term.desc.kind == WAA_NODE_CONVOLVER && term.has_ir) {
       if (scc_of[id] >= 0) return fail(WAA_ERR_OUT_OF_SCOPE, "a ConvolverNode inside a feedback loop is out of scope (node %u)", id);
@@ -1299,7 +1356,7 @@ int build_plan(waa_batch* b) {
       if (kind == WAA_NODE_BUFFER_SOURCE || kind == WAA_NODE_CONSTANT_SOURCE) break;  // chain input = this source
       if (n.in_edges.size() != 1) break;                                               // silent or fan-in head
       uint32_t p = b->edges[n.in_edges[0]].from;
-      if (b->nodes[p].materialized) break;
+      if (b->nodes[p].materialized || b->nodes[p].delay_folded) break;
       cur = p;
     }
     // inputs of the head node
@@ -1344,6 +1401,16 @@ int build_plan(waa_batch* b) {
         if (pn.materialized) {
           in.kind = IN_SIGNAL;
           in.sig = pn.sig;
+        } else if (pn.delay_folded) {
+          if (!pn.hist.base) return fail(WAA_ERR_INVALID_STATE, "internal: delay line of node %u not planned", pid);
+          in.kind = IN_DELAYED;
+          in.sig = pn.hist;
+          in.nch = pn.in_nch;
+          int e = node_param(b, pid, WAA_PARAM_DELAY_DELAY_TIME, &in.offset);
+          if (e) return e;
+          in.sample_rate = (double)b->sr;
+          in.num_quanta = (int32_t)std::ceil(pn.desc.d[0] * (double)b->sr / (double)RQ);
+          in.valid = pn.hist_valid;
         } else if (pn.desc.kind == WAA_NODE_BUFFER_SOURCE || pn.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
           in.kind = pn.desc.kind == WAA_NODE_BUFFER_SOURCE ? IN_SOURCE : IN_CONSTANT;
           int e = prepare_source_input(b, pid, &in);
@@ -1792,7 +1859,7 @@ void io_param(const ParamRef& p, StepIo& io) {
   if (p.base && p.mode == 2) io.reads.push_back(p.base);  // per-frame values: possibly produced by a param chain
 }
 void io_input(const InputRef& in, StepIo& io) {
-  if (in.kind == IN_SIGNAL) io.reads.push_back(in.sig.base);
+  if (in.kind == IN_SIGNAL || in.kind == IN_DELAYED) io.reads.push_back(in.sig.base);
   if (in.kind == IN_CONSTANT) io_param(in.offset, io);
   if (in.has_gain) io_param(in.gain, io);
 }
@@ -2081,7 +2148,7 @@ int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int inte
 // + forward FFT / spectral MAC / inverse FFT steps.
 // Input of a node-major step (convolver, delay): the single producer's signal if its channel count already
 // matches, else a mixing chain into a temporary.
-int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr) {
+int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target, uint64_t* valid) {
   Node& n = b->nodes[id];
   if (valid) *valid = b->lp;
   if (!target && n.in_edges.size() == 1) {
