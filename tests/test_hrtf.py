@@ -357,3 +357,46 @@ def test_hrtf_many_instances_sampled(hip, orc):
     for k, inst in enumerate(sample):
         for c in range(2):
             assert rms(outs[0][inst, c], outs[1][k, c]) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("positions", ["batch", "instance"])
+def test_fir_forms_are_bit_identical(hip, positions):
+    """hrtf8_kernel (eight frames per lane, both ears packed, HRIR pair from the scalar cache) against hrtf_kernel (four
+    frames per lane, HRIR pair interpolated per unit into LDS): same products, same summation order, same bits — with one
+    direction for the batch, one per instance, stereo input, gaps and a ragged end"""
+    import os
+    n_inst, nq = 5, 37  # (37: the last wavefront of hrtf8_kernel holds one unit)
+    rng = np.random.default_rng(43)
+    x = rng.uniform(-1, 1, (n_inst, 2, 20 * RQ)).astype(np.float32)
+
+    def render():
+        ctx = waa.OfflineAudioContext(2, nq * RQ - 3, SR, n_instances=n_inst, binding=hip)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(x, SR)
+        pan = ctx.create_panner(panning_model="HRTF", position=(1.0, 0.5, -0.5))
+        src.connect(pan).connect(ctx.destination())
+        for k in range(n_inst):
+            src.start_at(0.004 * k, instance=k)
+            if positions == "instance":
+                pan.position_x.set_value(1.0 + 0.3 * k, instance=k)
+                pan.position_y.set_value(0.2 * k - 0.4, instance=k)
+        return ctx.start_rendering_sync().data
+
+    saved = {k: os.environ.pop(k, None) for k in ("WAA_HRTF_V1", "WAA_HRTF_V8", "WAA_HRTF_DYNAMIC")}
+    try:
+        new = render()
+        os.environ["WAA_HRTF_V1"] = "1"
+        old = render()
+        os.environ.pop("WAA_HRTF_V1")
+        os.environ["WAA_HRTF_DYNAMIC"] = "1"
+        os.environ["WAA_HRTF_V8"] = "1"
+        lds = render()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert np.any(new != 0)
+    assert np.array_equal(new, old)
+    assert np.array_equal(lds, old)

@@ -884,7 +884,154 @@ __global__ __launch_bounds__(256) void hrtf_kernel(const HrtfDesc d) {
   }
   *(WAA_GLOBAL_AS f4v*)(out + (uint64_t)ear * d.out.ch_stride + (uint64_t)q * RQ + n0) = res;
 }
+// The same FIR with EIGHT output frames per lane and both ears in one packed operation.  One wavefront renders four
+// (instance, quantum) units, 16 lanes each.  acc[r] = (left, right) of frame n0 + r; a tap is one v_pk_fma_f32 per frame:
+// (hL[j], hR[j]) * (x, x) + acc — the packed pipe is the only way past half of the f32 peak, and with eight frames per
+// lane one 16-byte LDS read of new input feeds 64 multiply-adds (the four-frame form: 16, and it was LDS-bound).
+// Summation order per output (taps in order, one fma each) is that of hrtf_kernel: the results are bit-identical
+// (WAA_HRTF_V1=1 selects the old form; tests compare the two).
+// STATIC: one HRIR pair per instance (or for the whole batch) — nothing automated: interpolated once on the host
+// (HrtfDesc::hstatic, [row][tap][ear]) and read through the scalar cache — no per-unit interpolation, no LDS traffic for h.
+// Directions that change per quantum keep the four-frame form (one wavefront per unit: its prologue interpolates the
+// unit's HRIR pair, and four units per wavefront would serialise four of those).
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <bool STATIC>
+__global__ __launch_bounds__(64) void hrtf8_kernel(const HrtfDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const int O = (d.taps + 3) & ~3;
+  const int per_unit = (STATIC ? O : 3 * O) + RQ;  // xw[O + 128] (+ hh[O][2])
+  __shared__ float meta[4][2];                     // gain * corr, process flag
+  const uint32_t inst = blockIdx.y;
+  const int32_t* prev = d.prev + (uint64_t)inst * d.prev_stride;
+  const uint8_t* code = d.in_code + (uint64_t)inst * d.code_stride;
+  const float* src = d.in.base + (uint64_t)inst * d.in.inst_stride;
+  for (int u = 0; u < 4; u++) {
+    float* xw = lds + (size_t)u * (size_t)per_unit;
+    float* hh = xw + O + RQ;  // [O][2]
+    const uint32_t q = blockIdx.x * 4 + u;
+    const int32_t link = q < d.n_quanta ? load_global(prev + q) : LINK_SKIP;
+    const bool process = link != LINK_SKIP;
+    float gain = 0.f, corr = 1.f;
+    if (process) {
+      const HrtfQ* rec = d.table + (uint64_t)(d.rows == 1 ? 0 : inst) * d.per_row + (d.per_row == 1 ? 0 : q);
+      gain = load_global(&rec->gain);
+      if (!STATIC) {
+        const int v0 = load_global(&rec->v[0]), v1 = load_global(&rec->v[1]), v2 = load_global(&rec->v[2]);
+        const float w0 = load_global(&rec->w[0]), w1 = load_global(&rec->w[1]), w2 = load_global(&rec->w[2]);
+        // HrirSphere::sample_bilinear: a * u + b * v + c * w per tap, f32, in this order
+        const float* pa = d.hrir + (uint64_t)v0 * 2 * d.taps;
+        const float* pb = d.hrir + (uint64_t)v1 * 2 * d.taps;
+        const float* pc = d.hrir + (uint64_t)v2 * 2 * d.taps;
+        for (int i = lane; i < 2 * O; i += 64) {
+          const int ear = i >= O, t = ear ? i - O : i;
+          float v = 0.f;
+          if (t < d.taps) {
+            const int o = ear * d.taps + t;
+            v = load_global(pa + o) * w0 + load_global(pb + o) * w1 + load_global(pc + o) * w2;
+          }
+          hh[2 * t + ear] = v;
+        }
+      }
+      // input window: this quantum and, through the prev links, the quanta processed before it
+      int32_t qe = (int32_t)q;
+      for (int e = 0; e * RQ < O + RQ; e++) {  // element e covers positions [-e * 128, -e * 128 + 128)
+        float m0 = 0.f, m1 = 0.f;
+        if (qe >= 0) {
+          const uint32_t c = load_global(code + qe);
+          if (!(c & CODE_SILENT)) {
+            const uint64_t f = (uint64_t)qe * RQ;
+            m0 = load_global(src + f + lane);
+            m1 = load_global(src + f + 64 + lane);
+            if ((c & 7u) >= 2) {  // stereo input: mixed down (quantum.rs:387-397), doubled after the convolution
+              m0 = 0.5f * (m0 + load_global(src + d.in.ch_stride + f + lane));
+              m1 = 0.5f * (m1 + load_global(src + d.in.ch_stride + f + 64 + lane));
+            }
+          }
+          if (e == 0) corr = (!(c & CODE_SILENT) && (c & 7u) >= 2) ? 2.f : 1.f;
+        }
+        const int p0 = O - e * RQ + lane, p1 = p0 + 64;
+        if (p0 >= 0) xw[p0] = m0;
+        if (p1 >= 0) xw[p1] = m1;
+        if (qe >= 0) qe = load_global(prev + qe);  // LINK_FRESH (-1): nothing before it -> zeros
+      }
+    }
+    if (lane == 0) {
+      meta[u][0] = gain;
+      meta[u][1] = process ? corr : 0.f;  // (corr is 1 or 2: 0 marks a skipped unit)
+    }
+  }
+  __syncthreads();
+  const int u = lane >> 4, n0 = (lane & 15) * 8;
+  const uint32_t q = blockIdx.x * 4 + u;
+  if (q >= d.n_quanta) return;
+  const float gain = meta[u][0], corr = meta[u][1];
+  f2v acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) acc[r] = f2v{0.f, 0.f};
+  if (corr != 0.f) {
+    const float* xw = lds + (size_t)u * (size_t)per_unit;
+    const float* hh = xw + O + RQ;
+    const int b = O + n0;  // xw index of output frame n0 at tap 0
+    f4v c0 = *reinterpret_cast<const f4v*>(xw + b), c1 = *reinterpret_cast<const f4v*>(xw + b + 4);  // x[b .. b + 7]
+    for (int g = 0; g < O / 4; g++) {
+      const f4v nx = *reinterpret_cast<const f4v*>(xw + b - 4 * g - 4);  // x[b - 4g - 4 .. b - 4g - 1]
+      const float w[12] = {nx.x, nx.y, nx.z, nx.w, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};  // x[b - 4g - 4 + i]
+      f2v h[4];
+      if (STATIC) {
+        const f2v* hs = reinterpret_cast<const f2v*>(d.hstatic) + (size_t)(d.rows == 1 ? 0 : inst) * O + 4 * g;  // (uniform address: scalar loads)
+#pragma unroll
+        for (int t = 0; t < 4; t++) h[t] = hs[t];
+      } else {
+        const f4v h01 = *reinterpret_cast<const f4v*>(hh + 8 * g), h23 = *reinterpret_cast<const f4v*>(hh + 8 * g + 4);
+        h[0] = f2v{h01.x, h01.y};
+        h[1] = f2v{h01.z, h01.w};
+        h[2] = f2v{h23.x, h23.y};
+        h[3] = f2v{h23.z, h23.w};
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const float x = w[4 - t + r];
+          acc[r] = __builtin_elementwise_fma(h[t], f2v{x, x}, acc[r]);
+        }
+      c1 = c0;
+      c0 = nx;
+    }
+  }
+  float* out = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)q * RQ + n0;
+  const float gc = gain * corr;
+  // (acc * gain * corr in the old form: (acc * gain) * corr — keep that order)
+  f4v l0, l1, r0, r1;
+  l0.x = acc[0].x * gain * corr; l0.y = acc[1].x * gain * corr; l0.z = acc[2].x * gain * corr; l0.w = acc[3].x * gain * corr;
+  l1.x = acc[4].x * gain * corr; l1.y = acc[5].x * gain * corr; l1.z = acc[6].x * gain * corr; l1.w = acc[7].x * gain * corr;
+  r0.x = acc[0].y * gain * corr; r0.y = acc[1].y * gain * corr; r0.z = acc[2].y * gain * corr; r0.w = acc[3].y * gain * corr;
+  r1.x = acc[4].y * gain * corr; r1.y = acc[5].y * gain * corr; r1.z = acc[6].y * gain * corr; r1.w = acc[7].y * gain * corr;
+  (void)gc;
+  if (corr == 0.f) l0 = l1 = r0 = r1 = f4v{0.f, 0.f, 0.f, 0.f};
+  *(WAA_GLOBAL_AS f4v*)(out) = l0;
+  *(WAA_GLOBAL_AS f4v*)(out + 4) = l1;
+  *(WAA_GLOBAL_AS f4v*)(out + d.out.ch_stride) = r0;
+  *(WAA_GLOBAL_AS f4v*)(out + d.out.ch_stride + 4) = r1;
+}
 void launch_hrtf(const HrtfDesc& d, void* stream) {
+  if (!getenv("WAA_HRTF_V1")) {
+    const int O = (d.taps + 3) & ~3;
+    const bool stat = d.hstatic != nullptr && !getenv("WAA_HRTF_DYNAMIC");
+    const size_t lds = (size_t)4 * (size_t)((stat ? O : 3 * O) + RQ) * sizeof(float);
+    dim3 grid((d.n_quanta + 3) / 4, d.n_inst);
+    if (stat) {
+      hipLaunchKernelGGL(hrtf8_kernel<true>, grid, dim3(64), lds, (hipStream_t)stream, d);
+      return;
+    }
+    if (getenv("WAA_HRTF_V8")) {  // (experiment: the eight-frame form with per-unit HRIR pairs in LDS — slower, see above)
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hrtf8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(hrtf8_kernel<false>, grid, dim3(64), lds, (hipStream_t)stream, d);
+      return;
+    }
+  }
   const int O = (d.taps + 3) & ~3;
   const size_t lds = (size_t)4 * (size_t)(3 * O + RQ) * sizeof(float);
   if (lds > 64 * 1024)

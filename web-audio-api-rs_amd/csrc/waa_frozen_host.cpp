@@ -430,6 +430,24 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
   float* d_hr = nullptr;
   HrtfQ* d_table = nullptr;
   if ((e = dev_upload(b, &d_hr, hr)) || (e = dev_upload(b, &d_table, table))) return e;
+  // one direction for the whole batch: the HRIR pair once, in the device kernel's arithmetic (a * u + b * v + c * w, f32)
+  float* d_hstatic = nullptr;
+  if (per_row == 1) {  // (one direction per instance, or one for the batch)
+    const int O = (sp->taps + 3) & ~3;
+    std::vector<float> hs((size_t)rows * 2 * O, 0.f);
+    for (uint32_t i = 0; i < rows; i++) {
+      const HrtfQ& r = table[i];
+      for (int ear = 0; ear < 2; ear++)
+        for (int t = 0; t < sp->taps; t++) {
+          const size_t o = (size_t)ear * sp->taps + t;
+          const float a = hr[(size_t)r.v[0] * 2 * sp->taps + o], bb = hr[(size_t)r.v[1] * 2 * sp->taps + o], c = hr[(size_t)r.v[2] * 2 * sp->taps + o];
+          volatile float p0 = a * r.w[0], p1 = bb * r.w[1], p2 = c * r.w[2];  // (no contraction: the device code is built with -ffp-contract=off)
+          volatile float s01 = p0 + p1;
+          hs[((size_t)i * O + t) * 2 + ear] = s01 + p2;
+        }
+    }
+    if ((e = dev_upload(b, &d_hstatic, hs))) return e;
+  }
   Step st;
   st.kind = 17;
   HrtfDesc& d = st.hrtf;
@@ -441,6 +459,7 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
   d.prev = prev;
   d.prev_stride = b->n_quanta;
   d.hrir = d_hr;
+  d.hstatic = d_hstatic;
   d.table = d_table;
   d.rows = rows;
   d.per_row = per_row;

@@ -518,6 +518,7 @@ struct HrtfDesc {
   const int32_t* prev;
   uint64_t prev_stride;
   const float* hrir;        // [n_vertices][2][taps]: left, right
+  const float* hstatic;     // one HRIR pair for the whole batch, interpolated on the host: [taps rounded up to 4][2]; or null
   const HrtfQ* table;       // [rows][per_row]
   uint32_t rows, per_row;   // rows: n_inst or 1 (nothing depends on the instance); per_row: n_quanta or 1 (static)
   int32_t taps;
