@@ -260,6 +260,26 @@ def test_plan_block_scheduled_loop(hip):
     bq.connect(c.destination())
     src.start()
     plan = c.plan_describe()
-    assert "block-scheduled, 5 tile(s) = 10240 frames per block" in plan
+    assert "block-scheduled, 5 tile(s) = 10240 frames per block, 3 step(s) per block" in plan
+    # the loop-breaking delay is read from its line by its consumer, the gain rides on an input edge of the delay's mix
+    assert "biquad_stream" in plan and "inside a block-scheduled loop" in plan and "gain node" in plan and "delayed:2ch" in plan
+    c.close()
+
+
+def test_plan_block_scheduled_loop_node_major_delay(hip, monkeypatch):
+    """the switches: every loop member a launch of its own (the round-1 form)"""
+    monkeypatch.setenv("WAA_NO_LOOP_FOLD", "1")
+    c = waa.OfflineAudioContext(2, 2048 * 8, 48000.0, n_instances=2, binding=hip, device=waa.PLAN_ONLY)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(white_noise(2, 2, 2048 * 8), 48000.0)
+    delay = c.create_delay(1.0, delay_time=0.25)
+    bq = c.create_biquad_filter(type_="lowpass", frequency=3000.0)
+    fb = c.create_gain(gain=0.5)
+    src.connect(delay)
+    delay.connect(bq).connect(fb).connect(delay)
+    bq.connect(c.destination())
+    src.start()
+    plan = c.plan_describe()
+    assert "block-scheduled, 5 tile(s) = 10240 frames per block, 4 step(s) per block" in plan
     assert "biquad_stream" in plan and "in a loop: clamped" in plan
     c.close()

@@ -192,6 +192,8 @@ def _plan_of_delay_graph(hip, a_rate=False, second_consumer=None):
     src.connect(c.create_gain(gain=0.5)).connect(d).connect(c.create_gain(gain=2.0)).connect(c.destination())
     if second_consumer == "delay":
         d.connect(c.create_delay(0.5, delay_time=0.02)).connect(c.destination())
+    if second_consumer == "conv":
+        d.connect(c.create_convolver(buffer=waa.AudioBuffer(np.ones((1, 300), np.float32), 48000.0))).connect(c.destination())
     src.start()
     plan = c.plan_describe()
     c.close()
@@ -208,9 +210,11 @@ def test_plan_delay_is_node_major(hip, monkeypatch):
     """per-frame delayTime, a node-major consumer, or the switch: the gather kernel (waa_delay.hip)"""
     plan = _plan_of_delay_graph(hip, a_rate=True)
     assert "delay node" in plan and "ring=189 quanta" in plan and "delayTime=a-rate" in plan
+    plan = _plan_of_delay_graph(hip, second_consumer="conv")
+    assert plan.count("ring=189 quanta") == 1 and "delayTime=const" in plan
+    # (a DelayNode behind a DelayNode: the second one's line is a mix of the first one's line, both folded)
     plan = _plan_of_delay_graph(hip, second_consumer="delay")
-    # (the first delay feeds another DelayNode: node-major; the second one only feeds the destination: folded)
-    assert plan.count("ring=189 quanta") == 1 and "delayTime=const" in plan and "delayed:2ch" in plan
+    assert "ring=" not in plan and plan.count("read by its consumers from the delay line") == 2
     monkeypatch.setenv("WAA_NO_DELAY_FOLD", "1")
     plan = _plan_of_delay_graph(hip)
     assert "delay node" in plan and "ring=189 quanta" in plan and "delayTime=const" in plan

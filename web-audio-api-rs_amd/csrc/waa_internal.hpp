@@ -85,7 +85,7 @@ struct InputRef {
   const int64_t* active;  // IN_CONSTANT: [n_inst][2] first/last+1 active frame
   double sample_rate;     // IN_DELAYED
   int32_t num_quanta;     // IN_DELAYED: ring capacity - 1 (delay.rs:300-302)
-  int32_t pad1;
+  int32_t feedback;       // IN_DELAYED (host side): the line is written later in the same block of a block-scheduled loop
   uint64_t valid;         // IN_DELAYED: frames of the delay line that may be read (zeros beyond: a source's buffer read in place)
   ParamRef gain;          // has_gain: a GainNode folded into this edge (applied before the mix to the receiver's count)
   int32_t has_gain;

@@ -172,6 +172,49 @@ int node_param(waa_batch* b, uint32_t id, size_t k, ParamRef* ref) {
   return 0;
 }
 
+// One input edge of a summing node as an InputRef: a materialised signal, a source fetched by the kernel itself, a
+// DelayNode read from its delay line (IN_DELAYED), each optionally through a GainNode folded into the edge.
+int build_edge_input(waa_batch* b, uint32_t head, int ie, InputRef* out) {
+  uint32_t pid = b->edges[ie].from;
+  InputRef in{};
+  if (!b->nodes[pid].materialized && b->nodes[pid].desc.kind == WAA_NODE_GAIN) {
+    // a GainNode folded into the edge (see the materialisation pass)
+    int e = node_param(b, pid, 0, &in.gain);
+    if (e) return e;
+    in.has_gain = 1;
+    plan_note(b, "gain node %u folded into an input edge of node %u", pid, head);
+    pid = b->edges[b->nodes[pid].in_edges[0]].from;
+  }
+  Node& pn = b->nodes[pid];
+  in.nch = pn.out_nch;
+  if (pn.materialized) {
+    in.kind = IN_SIGNAL;
+    in.sig = pn.sig;
+  } else if (pn.delay_folded) {
+    if (!pn.hist.base) return fail(WAA_ERR_INVALID_STATE, "internal: delay line of node %u not planned", pid);
+    in.kind = IN_DELAYED;
+    in.sig = pn.hist;
+    in.nch = pn.in_nch;
+    int e = node_param(b, pid, WAA_PARAM_DELAY_DELAY_TIME, &in.offset);
+    if (e) return e;
+    in.sample_rate = (double)b->sr;
+    in.num_quanta = (int32_t)std::ceil(pn.desc.d[0] * (double)b->sr / (double)RQ);
+    in.valid = pn.hist_valid;
+    // the delay line of a loop-breaking DelayNode is written by a LATER launch of the same block (the reads go to
+    // earlier blocks: the loop is block-scheduled with blocks shorter than the delay)
+    in.feedback = pid < b->cut.size() && b->cut[pid] ? 1 : 0;
+  } else if (pn.desc.kind == WAA_NODE_BUFFER_SOURCE || pn.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
+    in.kind = pn.desc.kind == WAA_NODE_BUFFER_SOURCE ? IN_SOURCE : IN_CONSTANT;
+    int e = prepare_source_input(b, pid, &in);
+    if (e) return e;
+  } else {
+    return fail(WAA_ERR_INVALID_STATE, "internal: unmaterialised fan-in input");
+  }
+  *out = in;
+  return 0;
+}
+
+
 // Upload host-computed per-instance (mode 0) or per-(instance, quantum) (mode 1) values.
 int upload_values(waa_batch* b, const std::vector<float>& host, int mode, ParamRef* ref) {
   float* d = nullptr;
@@ -513,6 +556,7 @@ int plan_delay_writer(waa_batch* b, uint32_t id);
 int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr);
 int plan_oscillator(waa_batch* b, uint32_t id);
 int plan_delay_reader(waa_batch* b, uint32_t id);
+int plan_folded_delay_line(waa_batch* b, uint32_t id);
 uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items);
 
 // Scheduled automation -> value blocks: every timeline is evaluated for all quanta of the render, in order
@@ -1104,12 +1148,24 @@ int build_plan(waa_batch* b) {
   // A DelayNode outside a feedback loop whose delayTime is one value per quantum and whose consumers are all input
   // stages of chain kernels is not rendered by a pass of its own: the consumers gather from the delay line (IN_DELAYED).
   // (Static plans only; an echo — source -> Delay -> Gain -> bus — then costs one pass instead of three.)
+  // Inside a feedback loop the same holds when the loop is block-scheduled (every loop-breaking delay longer than a block:
+  // the gather then only reaches into earlier blocks), and a GainNode of such a loop can ride on an input edge like
+  // outside: the classic echo loop Delay <-> Gain is ONE launch per block (line = source + gain * delayed(line)).
+  std::vector<uint32_t> scc_block((size_t)n_scc, 0);
+  if (!count_change_found && !b->force_dynamic && !getenv("WAA_NO_LOOP_FOLD"))
+    for (int sc = 0; sc < n_scc; sc++) {
+      std::vector<uint32_t> loop_items;
+      for (uint32_t v : items)
+        if (scc_of[v & ~VTX_READER] == sc) loop_items.push_back(v);
+      scc_block[(size_t)sc] = loop_block_tiles(b, loop_items);
+    }
+  auto block_loop = [&](uint32_t id) { return scc_of[id] >= 0 && scc_block[(size_t)scc_of[id]] > 0; };
   std::vector<uint8_t> folded_delay(N, 0);
   for (uint32_t id = 0; id < N; id++) {
     Node& n = b->nodes[id];
     n.delay_folded = false;
     if (!n.live || n.desc.kind != WAA_NODE_DELAY || count_change_found || b->force_dynamic || getenv("WAA_NO_DELAY_FOLD")) continue;
-    if (scc_of[id] >= 0 || (id < b->cut.size() && b->cut[id])) continue;
+    if ((scc_of[id] >= 0 || (id < b->cut.size() && b->cut[id])) && !block_loop(id)) continue;
     const ParamStore& dt = n.params[WAA_PARAM_DELAY_DELAY_TIME];
     bool ok = dt.mode() != 2 && n.in_edges.size() >= 1;
     if ((size_t)WAA_PARAM_DELAY_DELAY_TIME < n.pin_edges.size() && !n.pin_edges[WAA_PARAM_DELAY_DELAY_TIME].empty()) ok = false;
@@ -1119,8 +1175,9 @@ int build_plan(waa_batch* b) {
       consumers++;
       const Node& c = b->nodes[e.to];
       const uint32_t ck = c.desc.kind;
-      if ((e.to_input & 0x80000000u) || scc_of[e.to] >= 0 || (ck == WAA_NODE_CONVOLVER && c.has_ir) || ck == WAA_NODE_DELAY ||
-          is_frozen_node(c) || c.in_nch > 2 || n.out_nch > 2)
+      const bool other_loop = scc_of[e.to] >= 0 && !(scc_of[e.to] == scc_of[id] && block_loop(id));
+      if ((e.to_input & 0x80000000u) || other_loop || (ck == WAA_NODE_CONVOLVER && c.has_ir) || is_frozen_node(c) || c.in_nch > 2 ||
+          n.out_nch > 2)
         ok = false;
     }
     if (ok && consumers > 0) folded_delay[id] = 1;
@@ -1139,16 +1196,25 @@ int build_plan(waa_batch* b) {
     const uint32_t kind = n.desc.kind;
     if (kind == WAA_NODE_DESTINATION || kind == WAA_NODE_ANALYSER || kind == WAA_NODE_CONVOLVER || kind == WAA_NODE_DELAY) mat = true;
     if (is_frozen_node(n)) mat = true;  // rendered node-major (waa_frozen.hip)
-    if (scc_of[id] >= 0) mat = true;  // loop members publish their own signal
+    // (a GainNode of a block-scheduled loop may ride on an input edge of its consumer, see above)
+    const bool relaxed = kind == WAA_NODE_GAIN && block_loop(id);
+    if (scc_of[id] >= 0 && !relaxed) mat = true;  // loop members publish their own signal
     if (kind == WAA_NODE_OSCILLATOR) mat = true;  // rendered by its own (lane-per-instance) kernel
     int live_consumers = 0;
     for (auto& e : b->edges)
       if (e.from == id && b->nodes[e.to].live) {
         live_consumers++;
         const Node& c = b->nodes[e.to];
-        if ((c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir) || c.desc.kind == WAA_NODE_DELAY || is_frozen_node(c)) mat = true;
+        if ((c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir) || is_frozen_node(c)) mat = true;
+        if (c.desc.kind == WAA_NODE_DELAY) {
+          // a DelayNode mixes its inputs like a summing chain head (node_input_signal): materialised unless foldable
+          if (relaxed)
+            fan = true;
+          else
+            mat = true;
+        }
         if (e.to_input & 0x80000000u) mat = true;  // feeds an AudioParam: read back as a per-frame value signal
-        if (scc_of[e.to] >= 0) mat = true;         // feeds a feedback loop
+        if (scc_of[e.to] >= 0 && !(relaxed && scc_of[e.to] == scc_of[id])) mat = true;  // feeds a feedback loop
         int live_in = 0;
         for (int ie : c.in_edges)
           if (b->nodes[b->edges[ie].from].live) live_in++;
@@ -1195,23 +1261,17 @@ int build_plan(waa_batch* b) {
         n_live++;
         consumer = (e.to_input & 0x80000000u) ? -1 : (int)e.to;
       }
-    // ... or whose consumers are all input stages of chain kernels (which fetch a source themselves) and folded
-    // DelayNodes (whose delay line the source's buffer then IS): no copy either
+    // ... or whose consumers are all summing input stages (chain heads, DelayNode mixes: they fetch a source themselves)
+    // and folded single-input DelayNodes (whose delay line the source's buffer then IS): no copy either
     bool shared_ok = n_live >= 2;
-    int n_delay = 0;
     for (auto& e : b->edges) {
       if (e.from != id || !b->nodes[e.to].live || !shared_ok) continue;
       const Node& c = b->nodes[e.to];
       const uint32_t ck = c.desc.kind;
-      if (c.delay_folded) {
-        n_delay++;
-        shared_ok = c.in_edges.size() == 1 && c.in_nch == n.out_nch;
-      } else if ((e.to_input & 0x80000000u) || scc_of[e.to] >= 0 || (ck == WAA_NODE_CONVOLVER && c.has_ir) || ck == WAA_NODE_DELAY ||
-                 is_frozen_node(c) || ck == WAA_NODE_IIR_FILTER) {
+      if ((e.to_input & 0x80000000u) || (scc_of[e.to] >= 0 && !block_loop(e.to)) || (ck == WAA_NODE_CONVOLVER && c.has_ir) ||
+          is_frozen_node(c) || ck == WAA_NODE_IIR_FILTER)
         shared_ok = false;
-      }
     }
-    shared_ok = shared_ok && n_delay > 0;
     if (!shared_ok && (n_live != 1 || consumer < 0)) continue;
     const Node& c = b->nodes[(uint32_t)(shared_ok ? 0 : consumer)];
     const bool conv = !shared_ok && c.desc.kind == WAA_NODE_CONVOLVER && c.has_ir;
@@ -1386,38 +1446,9 @@ int build_plan(waa_batch* b) {
       cd.in_interp = hn.interp;
       std::vector<InputRef> ins;
       for (int ie : hn.in_edges) {
-        uint32_t pid = b->edges[ie].from;
         InputRef in{};
-        if (!b->nodes[pid].materialized && b->nodes[pid].desc.kind == WAA_NODE_GAIN) {
-          // a GainNode folded into the edge (see the materialisation pass)
-          int e = node_param(b, pid, 0, &in.gain);
-          if (e) return e;
-          in.has_gain = 1;
-          plan_note(b, "gain node %u folded into an input edge of node %u", pid, head);
-          pid = b->edges[b->nodes[pid].in_edges[0]].from;
-        }
-        Node& pn = b->nodes[pid];
-        in.nch = pn.out_nch;
-        if (pn.materialized) {
-          in.kind = IN_SIGNAL;
-          in.sig = pn.sig;
-        } else if (pn.delay_folded) {
-          if (!pn.hist.base) return fail(WAA_ERR_INVALID_STATE, "internal: delay line of node %u not planned", pid);
-          in.kind = IN_DELAYED;
-          in.sig = pn.hist;
-          in.nch = pn.in_nch;
-          int e = node_param(b, pid, WAA_PARAM_DELAY_DELAY_TIME, &in.offset);
-          if (e) return e;
-          in.sample_rate = (double)b->sr;
-          in.num_quanta = (int32_t)std::ceil(pn.desc.d[0] * (double)b->sr / (double)RQ);
-          in.valid = pn.hist_valid;
-        } else if (pn.desc.kind == WAA_NODE_BUFFER_SOURCE || pn.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
-          in.kind = pn.desc.kind == WAA_NODE_BUFFER_SOURCE ? IN_SOURCE : IN_CONSTANT;
-          int e = prepare_source_input(b, pid, &in);
-          if (e) return e;
-        } else {
-          return fail(WAA_ERR_INVALID_STATE, "internal: unmaterialised fan-in input");
-        }
+        int e = build_edge_input(b, head, ie, &in);
+        if (e) return e;
         ins.push_back(in);
       }
       int e = reduce_fan_in(b, ins, hn.in_nch, hn.interp);
@@ -1814,7 +1845,9 @@ int build_plan(waa_batch* b) {
       for (uint32_t v : loop_items) {
         const uint32_t mid = v & ~VTX_READER;
         int e = 0;
-        if (is_delay(b, mid))
+        if (is_delay(b, mid) && b->nodes[mid].delay_folded)
+          e = (v & VTX_READER) ? plan_folded_delay_line(b, mid) : plan_delay_writer(b, mid);
+        else if (is_delay(b, mid))
           e = (v & VTX_READER) ? plan_delay_reader(b, mid) : plan_delay_writer(b, mid);
         else
           e = plan_single(mid);
@@ -1859,7 +1892,7 @@ void io_param(const ParamRef& p, StepIo& io) {
   if (p.base && p.mode == 2) io.reads.push_back(p.base);  // per-frame values: possibly produced by a param chain
 }
 void io_input(const InputRef& in, StepIo& io) {
-  if (in.kind == IN_SIGNAL || in.kind == IN_DELAYED) io.reads.push_back(in.sig.base);
+  if (in.kind == IN_SIGNAL || (in.kind == IN_DELAYED && !in.feedback)) io.reads.push_back(in.sig.base);
   if (in.kind == IN_CONSTANT) io_param(in.offset, io);
   if (in.has_gain) io_param(in.gain, io);
 }
@@ -2178,12 +2211,8 @@ int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const Signa
     ins.push_back(in);
   } else {
     for (int ie : n.in_edges) {
-      Node& pn = b->nodes[b->edges[ie].from];
-      if (!pn.materialized) return fail(WAA_ERR_INVALID_STATE, "internal: unmaterialised input of a node-major step");
       InputRef in{};
-      in.kind = IN_SIGNAL;
-      in.nch = pn.out_nch;
-      in.sig = pn.sig;
+      if ((e = build_edge_input(b, id, ie, &in))) return e;
       ins.push_back(in);
     }
     if ((e = reduce_fan_in(b, ins, n.in_nch, n.interp))) return e;
@@ -2353,6 +2382,29 @@ int plan_delay_writer(waa_batch* b, uint32_t id) {
     return node_input_signal(b, id, &same, &n.hist);
   }
   return node_input_signal(b, id, &n.hist);
+}
+// A folded DelayNode inside a block-scheduled loop (reader half): no launch, only the choice of the delay line — the
+// producer's signal when there is exactly one materialised producer of the right layout, else a temporary the writer
+// half fills (as plan_delay_reader does for the node-major form).
+int plan_folded_delay_line(waa_batch* b, uint32_t id) {
+  Node& n = b->nodes[id];
+  if (!n.hist.base) {
+    bool direct = false;
+    if (n.in_edges.size() == 1) {
+      Node& p = b->nodes[b->edges[n.in_edges[0]].from];
+      direct = p.materialized && p.out_nch == n.in_nch && p.sig.base;
+      if (direct) n.hist = p.sig;
+    }
+    if (!direct) {
+      int e = temp_signal(b, n.in_nch, &n.hist);
+      if (e) return e;
+      n.hist_is_temp = true;
+    }
+  }
+  n.hist_valid = b->lp;
+  plan_note(b, "delay node %u: %dch, read by its consumers from the delay line (no pass of its own, inside a block-scheduled loop)", id,
+            n.in_nch);
+  return 0;
 }
 int plan_delay_reader(waa_batch* b, uint32_t id) {
   Node& n = b->nodes[id];
