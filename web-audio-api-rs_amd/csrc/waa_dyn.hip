@@ -57,12 +57,28 @@ __device__ __forceinline__ void mix12(float (&u)[2][2], int from, int to, int in
     }
   }
 }
+struct M2d {
+  double a, b, c, d;
+};
+__device__ __forceinline__ M2d mm2(const M2d& x, const M2d& y) {
+  M2d r;
+  r.a = __builtin_fma(x.a, y.a, x.b * y.c);
+  r.b = __builtin_fma(x.a, y.b, x.b * y.d);
+  r.c = __builtin_fma(x.c, y.a, x.d * y.c);
+  r.d = __builtin_fma(x.c, y.b, x.d * y.d);
+  return r;
+}
 __device__ __forceinline__ void stereo_gains(float x, float& gl, float& gr) {  // stereo_panner.rs:74-79
   const float PI_F = 3.14159265358979323846f;
   gl = sinf((1.f - x) * PI_F / 2.f);
   gr = sinf(x * PI_F / 2.f);
 }
 }  // namespace
+
+// One workgroup = one wavefront: LDS hand-offs between lanes need program order only (the DS operations of a wave execute
+// in order).  __syncthreads() would also drain every outstanding global store (its release fence waits for vmcnt(0)) —
+// with four to five of them per filter item and quantum the wave waited for its own output stores a dozen times per quantum.
+__device__ __forceinline__ void lds_sync() { __builtin_amdgcn_wave_barrier(); }
 
 __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -71,12 +87,24 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
   double* fst = reinterpret_cast<double*>(scratch + 2 * RQ);                  // [n_items][2][DYN_STATE] filter state
   int* ist = reinterpret_cast<int*>(fst + (size_t)d.n_items * 2 * DYN_STATE);  // [n_items][4] integer state
   int* codes = ist + (size_t)d.n_items * 4;                                   // [n_items] codes of this quantum
+  __shared__ double coef_s[2 * (DYN_STATE + 1)];                             // IIR coefficient block of the item at hand
+  // The item descriptors once into LDS: read through the pointer in the kernel argument they were ~80 dependent
+  // vector loads per quantum (uniform addresses, but not provably read-only: no scalar loads), each one an exposed L2
+  // round trip — with one wave per instance that WAS the kernel's time (23 k cycles per quantum for ~1100 instructions).
+  DynItem* items_s = reinterpret_cast<DynItem*>(codes + d.n_items + (d.n_items & 1));
   const uint32_t inst = blockIdx.x;
   const int lane = threadIdx.x;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(d.items);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(items_s);
+    const int words = d.n_items * (int)(sizeof(DynItem) / 4);
+    for (int i = lane; i < words; i += 64) dst[i] = load_global(src + i);
+  }
+  lds_sync();
   __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);  // f64 denormals flushed (FTZ/DAZ render scope, thread.rs:374-382)
   for (int i = lane; i < d.n_items * 2 * DYN_STATE; i += 64) fst[i] = 0.;
   for (int i = lane; i < d.n_items; i += 64) {
-    const DynItem& li = d.items[i];
+    const DynItem& li = items_s[i];
     // ist[0]: channels of the filter state (xy_len = 0, iir_filter.rs:303-306 "eagerly assume stereo" = 2) /
     //         delay writer: the line's channel count (ring of silent = mono quanta, delay.rs:386-397)
     ist[i * 4 + 0] = (li.kind == DI_NODE && li.dk == DK_IIR) ? 2 : (li.kind == DI_DELAY_W ? 1 : 0);
@@ -85,12 +113,12 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
     ist[i * 4 + 3] = 0;
     codes[i] = (int)(1u | CODE_SILENT);
   }
-  __syncthreads();
+  lds_sync();
 
   for (uint32_t q = 0; q < d.n_quanta; q++) {
     const uint64_t f0 = (uint64_t)q * RQ;
     for (int it = 0; it < d.n_items; it++) {
-      const DynItem& li = d.items[it];
+      const DynItem& li = items_s[it];
       float v[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
       int sn = 1;       // number_of_channels of the mixed input
       bool ss = true;   // is_silent
@@ -209,7 +237,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
               outn = nst;
             } else {
               if (sn != nst) {
-                __syncthreads();
+                lds_sync();
                 for (int j = lane; j < 2 * DYN_STATE; j += 64)
                   if (j / DYN_STATE >= nst && j / DYN_STATE < sn) st[j] = 0.;
                 if (lane == 0) ist[it * 4 + 0] = sn;
@@ -218,22 +246,110 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
               outn = sn;
             }
             outs = false;
-            __syncthreads();
+            lds_sync();
 #pragma unroll
             for (int c = 0; c < 2; c++) {
               // (a silent input reads its single zero channel for every state channel, :858-862)
               scratch[c * RQ + lane] = ss ? 0.f : v[c][0];
               scratch[c * RQ + 64 + lane] = ss ? 0.f : v[c][1];
             }
-            __syncthreads();
+            lds_sync();
+            if (iir) {  // the coefficient block (shared by all instances) once per quantum into LDS: b then a, zero padded
+              const double* cb = reinterpret_cast<const double*>(op.ptr0);
+              for (int j = lane; j < 2 * (ns + 1); j += 64) coef_s[j] = load_global(cb + j);
+              lds_sync();
+            }
+            // One coefficient set for the quantum (constant / k-rate params): the 128-frame recurrence spread over the
+            // wavefront like the streaming kernel does it (waa_biquad_stream.hip) — 32 lanes per channel, 4 frames per lane:
+            // zero-state response of the lane's frames, the lanes' true incoming states from a 5-step scan with the uniform
+            // powers of A = M^4 (M the one-frame transition), then the reference's evaluation order from that state.
+            // On two lanes the recurrence was a chain of ~640 dependent f64 operations per quantum (85 % of the kernel).
+            // Denormals: flushed by hardware mode like in the reference's render scope; inf / NaN: the quantum is redone
+            // serially below (the scan assumes linearity).
+            bool scan_done = false;
+            if (!iir && op.i0 != 2 && !d.no_scan) {
+              const int ch = lane >> 5, l = lane & 31;
+              const bool act = ch < outn;
+              const double* s = st + ch * DYN_STATE;
+              float* row = scratch + ch * RQ;
+              const double* cf = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0 + (op.i0 == 1 ? (uint64_t)q * 5 : 0);
+              const double b0 = load_global(cf), b1 = load_global(cf + 1), b2 = load_global(cf + 2), a1 = load_global(cf + 3),
+                           a2 = load_global(cf + 4);
+              const f4v xv = *reinterpret_cast<const f4v*>(row + 4 * l);
+              const double x0 = (double)xv.x, x1 = (double)xv.y, x2 = (double)xv.z, x3 = (double)xv.w;
+              double xm1 = __shfl_up(x3, 1, 32), xm2 = __shfl_up(x2, 1, 32);
+              const double cx1 = s[0], cx2 = s[1], cy1 = s[2], cy2 = s[3];
+              if (l == 0) {
+                xm1 = cx1;
+                xm2 = cx2;
+              }
+              // zero-state response of the lane's four frames (incoming y state 0, true x history)
+              const double w0 = b0 * x0 + b1 * xm1 + b2 * xm2, w1 = b0 * x1 + b1 * x0 + b2 * xm1, w2 = b0 * x2 + b1 * x1 + b2 * x0,
+                           w3 = b0 * x3 + b1 * x2 + b2 * x1;
+              const double z0 = w0, z1 = w1 - a1 * z0, z2 = w2 - a1 * z1 - a2 * z0, z3 = w3 - a1 * z2 - a2 * z1;
+              double r1 = z3, r2 = z2;
+              M2d P = {-a1, -a2, 1., 0.};
+              P = mm2(P, P);
+              P = mm2(P, P);  // A = M^4
+              if (l == 0) {
+                r1 = __builtin_fma(P.a, cy1, __builtin_fma(P.b, cy2, r1));
+                r2 = __builtin_fma(P.c, cy1, __builtin_fma(P.d, cy2, r2));
+              }
+#pragma unroll
+              for (int dd = 1; dd < 32; dd <<= 1) {
+                const double q1 = __shfl_up(r1, dd, 32), q2 = __shfl_up(r2, dd, 32);
+                if (l >= dd) {
+                  r1 = __builtin_fma(P.a, q1, __builtin_fma(P.b, q2, r1));
+                  r2 = __builtin_fma(P.c, q1, __builtin_fma(P.d, q2, r2));
+                }
+                P = mm2(P, P);
+              }
+              double y1 = __shfl_up(r1, 1, 32), y2 = __shfl_up(r2, 1, 32);
+              if (l == 0) {
+                y1 = cy1;
+                y2 = cy2;
+              }
+              // the reference's evaluation order from the true incoming state (biquad_filter.rs:877-883)
+              double p1 = xm1, p2 = xm2;
+              const double xs[4] = {x0, x1, x2, x3};
+              float yo[4];
+              bool bad = false;
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const double x = xs[e];
+                double y = b0 * x + b1 * p1 + b2 * p2 - a1 * y1 - a2 * y2;
+                bad |= !(__builtin_fabs(y) <= 1.7976931348623157e308);  // inf / NaN
+                if (!__builtin_isnormal(y)) y = 0.;
+                p2 = p1;
+                p1 = x;
+                y2 = y1;
+                y1 = y;
+                yo[e] = (float)y;
+              }
+              bad = act && bad;
+              if (!__any(bad)) {
+                scan_done = true;
+                if (act) {
+                  *reinterpret_cast<f4v*>(row + 4 * l) = f4v{yo[0], yo[1], yo[2], yo[3]};
+                  if (l == 31) {
+                    double* sw = st + ch * DYN_STATE;
+                    sw[0] = p1;
+                    sw[1] = p2;
+                    sw[2] = y1;
+                    sw[3] = y2;
+                  }
+                }
+              }
+            }
             if (lane < outn) {
               double* s = st + lane * DYN_STATE;
               float* row = scratch + lane * RQ;
-              if (!iir) {
+              if (!iir && op.i0 == 2) {
+                // per-frame coefficient sets (a-rate params)
                 double x1 = s[0], x2 = s[1], y1 = s[2], y2 = s[3];
                 const double* cbase = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0;
                 for (int i = 0; i < RQ; i++) {
-                  const double* cf = op.i0 == 0 ? cbase : op.i0 == 1 ? cbase + (uint64_t)q * 5 : cbase + (f0 + i) * 5;
+                  const double* cf = cbase + (f0 + i) * 5;
                   const double x = (double)row[i];
                   double y = load_global(cf) * x + load_global(cf + 1) * x1 + load_global(cf + 2) * x2 - load_global(cf + 3) * y1 -
                              load_global(cf + 4) * y2;
@@ -248,23 +364,54 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
                 s[1] = x2;
                 s[2] = y1;
                 s[3] = y2;
+              } else if (!iir && scan_done) {
+                // (rendered by all 64 lanes above)
+              } else if (!iir) {
+                // one coefficient set for the quantum: in registers, eight frames per LDS round trip (the loop used to load
+                // the five doubles from global memory in every frame: 128 exposed latencies per channel and quantum)
+                double x1 = s[0], x2 = s[1], y1 = s[2], y2 = s[3];
+                const double* cf = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0 + (op.i0 == 1 ? (uint64_t)q * 5 : 0);
+                const double b0 = load_global(cf), b1 = load_global(cf + 1), b2 = load_global(cf + 2), a1 = load_global(cf + 3),
+                             a2 = load_global(cf + 4);
+                for (int i = 0; i < RQ; i += 8) {
+                  const f4v p = *reinterpret_cast<const f4v*>(row + i), r = *reinterpret_cast<const f4v*>(row + i + 4);
+                  const float xin[8] = {p.x, p.y, p.z, p.w, r.x, r.y, r.z, r.w};
+                  float yo[8];
+#pragma unroll
+                  for (int e = 0; e < 8; e++) {
+                    const double x = (double)xin[e];
+                    double y = b0 * x + b1 * x1 + b2 * x2 - a1 * y1 - a2 * y2;
+                    if (!__builtin_isnormal(y)) y = 0.;
+                    x2 = x1;
+                    x1 = x;
+                    y2 = y1;
+                    y1 = y;
+                    yo[e] = (float)y;
+                  }
+                  *reinterpret_cast<f4v*>(row + i) = f4v{yo[0], yo[1], yo[2], yo[3]};
+                  *reinterpret_cast<f4v*>(row + i + 4) = f4v{yo[4], yo[5], yo[6], yo[7]};
+                }
+                s[0] = x1;
+                s[1] = x2;
+                s[2] = y1;
+                s[3] = y2;
               } else {
-                const double* cb = reinterpret_cast<const double*>(op.ptr0);  // [2][ns + 1]: b then a, zero padded
+                const double* cb = coef_s;  // [2][ns + 1]: b then a, zero padded
                 const double* ca = cb + (ns + 1);
-                const double b0 = load_global(cb);
+                const double b0 = cb[0];
                 for (int i = 0; i < RQ; i++) {
                   const double x = (double)row[i];
                   double y = __builtin_fma(b0, x, s[0]);
                   if (!__builtin_isnormal(y)) y = 0.;
                   for (int k = 1; k <= ns; k++) {
                     const double next = k < DYN_STATE ? s[k] : 0.;
-                    s[k - 1] = load_global(cb + k) * x - load_global(ca + k) * y + next;
+                    s[k - 1] = cb[k] * x - ca[k] * y + next;
                   }
                   row[i] = (float)y;
                 }
               }
             }
-            __syncthreads();
+            lds_sync();
 #pragma unroll
             for (int c = 0; c < 2; c++) {
               v[c][0] = c < outn ? scratch[c * RQ + lane] : 0.f;
@@ -377,7 +524,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
       } else {
         // ---- DelayReader::process, delay.rs:515-745, on the writer's line in absolute time
         __syncthreads();  // the writer's stores of this quantum (if it rendered first) have reached L2
-        const DynItem& wi = d.items[li.writer_item];
+        const DynItem& wi = items_s[li.writer_item];
         const SignalRef& hs = wi.out;
         const int nch = ist[li.writer_item * 4 + 0];         // ring[0].number_of_channels() right now
         const int last_mono = ist[li.writer_item * 4 + 1];   // entries written before it were collapsed to mono
@@ -487,17 +634,19 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
           if (li.kind == DI_DELAY_W) store_global(li.aux32 + (uint64_t)inst * li.code_stride + q, code);
         }
       }
-      __syncthreads();
+      lds_sync();
     }
   }
 }
 
 void launch_dyn(const DynDesc& d, void* stream) {
   const size_t lds = ((size_t)d.n_items * 2 * RQ + 2 * RQ) * sizeof(float) + (size_t)d.n_items * 2 * DYN_STATE * sizeof(double) +
-                     (size_t)d.n_items * 5 * sizeof(int);
+                     (size_t)(d.n_items * 5 + 2) * sizeof(int) + (size_t)d.n_items * sizeof(DynItem);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dyn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(dyn_kernel, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, d);
+  DynDesc dd = d;
+  dd.no_scan = getenv("WAA_DYN_NO_SCAN") ? 1u : 0u;
+  hipLaunchKernelGGL(dyn_kernel, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, dd);
 }
 
 // ConvolverRenderer::process on codes (convolver.rs:343-392): the tail counter cuts the output off once a silent input

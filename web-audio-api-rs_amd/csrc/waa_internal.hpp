@@ -366,7 +366,7 @@ struct DynDesc {
   int32_t n_items;
   uint32_t n_inst;
   uint32_t n_quanta;
-  uint32_t pad;
+  uint32_t no_scan;         // set by the launcher (WAA_DYN_NO_SCAN): biquad items on two lanes, serially (cross-check)
   double sample_rate;
   double quantum_duration;
 };
