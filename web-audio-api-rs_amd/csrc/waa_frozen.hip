@@ -666,7 +666,7 @@ __global__ __launch_bounds__(512, 4) void qgemm_bf16x6_w8_kernel(const QGemmDesc
       const int part = tid & 3;
       const int32_t sq = srow[i][second ? 1 : 0];
       // (unconditional load, row 0 instead of a skipped row, zeroed when staged: a load inside a branch is waited for at once)
-      x.s[i] = load_global_f4(src + (uint64_t)(sq < 0 ? 0 : sq) * d.src_q + (uint64_t)(koff + part * 4));
+      x.s[i] = load_global_f4(src + (uint64_t)(sq < 0 || DBG == 4 ? 0 : sq) * d.src_q + (uint64_t)(koff + part * 4));  // (DBG 4: one hot row)
     }
     // 768 matrix pieces for 512 threads: piece tid & 255 of plane tid >> 8, and of plane 2 (both halves of the workgroup:
     // the same load and the same LDS store twice, instead of a branch around a load)
@@ -779,6 +779,8 @@ void launch_qgemm(const QGemmDesc& d, void* stream) {
     if (xdbg[0] == 'd') hipLaunchKernelGGL(qgemm_bf16x6_w8_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, d);
     if (xdbg[0] == 'e') hipLaunchKernelGGL(qgemm_bf16x6_w8_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, d);
     if (xdbg[0] == 'f') hipLaunchKernelGGL(qgemm_bf16x6_w8_kernel<3>, grid, dim3(512), 0, (hipStream_t)stream, d);
+  } else if (d.A16 && xdbg && xdbg[0] == 'g') {
+    hipLaunchKernelGGL(qgemm_bf16x6_w8_kernel<4>, grid, dim3(512), 0, (hipStream_t)stream, d);
   } else if (d.A16 && !getenv("WAA_QGEMM_FMA") && !getenv("WAA_QGEMM_F32") && !xdbg && getenv("WAA_QGEMM_W4"))
     hipLaunchKernelGGL(qgemm_bf16x6_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d);
   else if (d.A16 && !getenv("WAA_QGEMM_FMA") && !getenv("WAA_QGEMM_F32") && !xdbg)
