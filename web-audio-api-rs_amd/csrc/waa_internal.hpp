@@ -306,7 +306,7 @@ struct LoopDesc {
   int32_t n_items;
   uint32_t n_inst;
   uint32_t n_quanta;
-  uint32_t pad;
+  uint32_t no_scan;       // set by the launcher (WAA_DYN_NO_SCAN): biquad members serially on one lane per channel
   double sample_rate;
   double quantum_duration;  // 128 * (1 / sample_rate), delay.rs:546-548
 };

@@ -8,9 +8,12 @@
 //   * a delay line is the writer's mixed input in absolute time; the reader gathers from it exactly like
 //     waa_delay.hip, with the in-cycle clamp of delay.rs:693-701; it reads through agent-scope loads because the
 //     same wave wrote those lines moments ago,
-//   * a BiquadFilter inside a loop runs its 128 frames serially on one lane per channel (exact arithmetic).
-// Latency-bound by construction (about 2-4 us per quantum and member); throughput comes from the batch.
+//   * a BiquadFilter inside a loop renders its 128 frames over the whole wavefront (zero-state + scan + exact-order pass,
+//     as in waa_dyn.hip); per-frame coefficient sets and quanta with inf / NaN: serially on one lane per channel.
+// Latency-bound by construction (about 1-2 us per quantum and member); throughput comes from the batch.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "waa_internal.hpp"
 
@@ -50,6 +53,19 @@ __device__ __forceinline__ void mix12(float (&u)[2][2], int from, int to, int in
     }
   }
 }
+struct M2d {
+  double a, b, c, d;
+};
+__device__ __forceinline__ M2d mm2(const M2d& x, const M2d& y) {
+  M2d r;
+  r.a = __builtin_fma(x.a, y.a, x.b * y.c);
+  r.b = __builtin_fma(x.a, y.b, x.b * y.d);
+  r.c = __builtin_fma(x.c, y.a, x.d * y.c);
+  r.d = __builtin_fma(x.c, y.b, x.d * y.d);
+  return r;
+}
+// One workgroup = one wavefront: LDS hand-offs between lanes need program order only (see waa_dyn.hip).
+__device__ __forceinline__ void lds_sync() { __builtin_amdgcn_wave_barrier(); }
 }  // namespace
 
 __global__ __launch_bounds__(64) void loop_kernel(const LoopDesc d) {
@@ -57,16 +73,24 @@ __global__ __launch_bounds__(64) void loop_kernel(const LoopDesc d) {
   float* cur = lds;                                        // [n_items][2][128] outputs of this quantum
   float* scratch = lds + (size_t)d.n_items * 2 * RQ;       // [2][128]
   double* bq_state = reinterpret_cast<double*>(scratch + 2 * RQ);  // [n_items][2][4]
+  // the item descriptors once into LDS (through the kernel argument they are dependent vector loads, see waa_dyn.hip)
+  LoopItem* items_s = reinterpret_cast<LoopItem*>(bq_state + (size_t)d.n_items * 8);
   const uint32_t inst = blockIdx.x;
   const int lane = threadIdx.x;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(d.items);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(items_s);
+    const int words = d.n_items * (int)(sizeof(LoopItem) / 4);
+    for (int i = lane; i < words; i += 64) dst[i] = load_global(src + i);
+  }
   __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);  // f64 denormals flushed (FTZ/DAZ render scope)
   for (int i = lane; i < d.n_items * 8; i += 64) bq_state[i] = 0.;
-  __syncthreads();
+  lds_sync();
 
   for (uint32_t q = 0; q < d.n_quanta; q++) {
     const uint64_t f0 = (uint64_t)q * RQ;
     for (int it = 0; it < d.n_items; it++) {
-      const LoopItem& li = d.items[it];
+      const LoopItem& li = items_s[it];
       float v[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
       if (li.kind != LI_DELAY_R) {
         // ---- inputs: every incoming edge mixed to the computed channel count, summed in edge order
@@ -152,14 +176,90 @@ __global__ __launch_bounds__(64) void loop_kernel(const LoopDesc d) {
             break;
           }
           case OP_BIQUAD: {  // biquad_filter.rs:857-897, 128 frames in order on one lane per channel
-            __syncthreads();
+            lds_sync();
 #pragma unroll
             for (int c = 0; c < 2; c++) {
               scratch[c * RQ + lane] = v[c][0];
               scratch[c * RQ + 64 + lane] = v[c][1];
             }
-            __syncthreads();
-            if (lane < op.nch_in) {
+            lds_sync();
+            // one coefficient set for the quantum: the recurrence over the whole wavefront (32 lanes per channel, 4 frames
+            // per lane: zero-state response, 5-step scan with the powers of M^4, the reference's order from the true
+            // incoming state) as in waa_dyn.hip / waa_biquad_stream.hip; per-frame sets and quanta with inf / NaN: serially
+            bool scan_done = false;
+            if (op.i0 != 2 && !d.no_scan) {
+              const int ch = lane >> 5, l = lane & 31;
+              const bool act = ch < op.nch_in;
+              const double* s = bq_state + ((size_t)it * 2 + ch) * 4;
+              float* row = scratch + ch * RQ;
+              const double* cf = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0 + (op.i0 == 1 ? (uint64_t)q * 5 : 0);
+              const double b0 = load_global(cf), b1 = load_global(cf + 1), b2 = load_global(cf + 2), a1 = load_global(cf + 3),
+                           a2 = load_global(cf + 4);
+              const f4v xv = *reinterpret_cast<const f4v*>(row + 4 * l);
+              const double x0 = (double)xv.x, x1 = (double)xv.y, x2 = (double)xv.z, x3 = (double)xv.w;
+              double xm1 = __shfl_up(x3, 1, 32), xm2 = __shfl_up(x2, 1, 32);
+              const double cy1 = s[2], cy2 = s[3];
+              if (l == 0) {
+                xm1 = s[0];
+                xm2 = s[1];
+              }
+              const double w0 = b0 * x0 + b1 * xm1 + b2 * xm2, w1 = b0 * x1 + b1 * x0 + b2 * xm1, w2 = b0 * x2 + b1 * x1 + b2 * x0,
+                           w3 = b0 * x3 + b1 * x2 + b2 * x1;
+              const double z0 = w0, z1 = w1 - a1 * z0, z2 = w2 - a1 * z1 - a2 * z0, z3 = w3 - a1 * z2 - a2 * z1;
+              double r1 = z3, r2 = z2;
+              M2d P = {-a1, -a2, 1., 0.};
+              P = mm2(P, P);
+              P = mm2(P, P);  // A = M^4
+              if (l == 0) {
+                r1 = __builtin_fma(P.a, cy1, __builtin_fma(P.b, cy2, r1));
+                r2 = __builtin_fma(P.c, cy1, __builtin_fma(P.d, cy2, r2));
+              }
+#pragma unroll
+              for (int dd = 1; dd < 32; dd <<= 1) {
+                const double q1 = __shfl_up(r1, dd, 32), q2 = __shfl_up(r2, dd, 32);
+                if (l >= dd) {
+                  r1 = __builtin_fma(P.a, q1, __builtin_fma(P.b, q2, r1));
+                  r2 = __builtin_fma(P.c, q1, __builtin_fma(P.d, q2, r2));
+                }
+                P = mm2(P, P);
+              }
+              double y1 = __shfl_up(r1, 1, 32), y2 = __shfl_up(r2, 1, 32);
+              if (l == 0) {
+                y1 = cy1;
+                y2 = cy2;
+              }
+              double p1 = xm1, p2 = xm2;
+              const double xs[4] = {x0, x1, x2, x3};
+              float yo[4];
+              bool bad = false;
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const double x = xs[e];
+                double y = b0 * x + b1 * p1 + b2 * p2 - a1 * y1 - a2 * y2;
+                bad |= !(__builtin_fabs(y) <= 1.7976931348623157e308);  // inf / NaN
+                if (!__builtin_isnormal(y)) y = 0.;
+                p2 = p1;
+                p1 = x;
+                y2 = y1;
+                y1 = y;
+                yo[e] = (float)y;
+              }
+              bad = act && bad;
+              if (!__any(bad)) {
+                scan_done = true;
+                if (act) {
+                  *reinterpret_cast<f4v*>(row + 4 * l) = f4v{yo[0], yo[1], yo[2], yo[3]};
+                  if (l == 31) {
+                    double* sw = bq_state + ((size_t)it * 2 + ch) * 4;
+                    sw[0] = p1;
+                    sw[1] = p2;
+                    sw[2] = y1;
+                    sw[3] = y2;
+                  }
+                }
+              }
+            }
+            if (!scan_done && lane < op.nch_in) {
               double* st = bq_state + ((size_t)it * 2 + lane) * 4;
               double x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
               const double* cbase = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0;
@@ -181,7 +281,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const LoopDesc d) {
               st[2] = y1;
               st[3] = y2;
             }
-            __syncthreads();
+            lds_sync();
 #pragma unroll
             for (int c = 0; c < 2; c++) {
               v[c][0] = scratch[c * RQ + lane];
@@ -194,7 +294,7 @@ __global__ __launch_bounds__(64) void loop_kernel(const LoopDesc d) {
       } else if (li.kind == LI_DELAY_R) {
         // delay.rs:515-745 in absolute time (see waa_delay.hip)
         __syncthreads();  // the writer's stores of this quantum (if it rendered first) have reached L2
-        const SignalRef& hs = d.items[li.writer_item].out;
+        const SignalRef& hs = items_s[li.writer_item].out;
         const OpDesc& op = li.op;
         int64_t pf0 = 0;
         float k0 = 0.f;
@@ -250,14 +350,19 @@ __global__ __launch_bounds__(64) void loop_kernel(const LoopDesc d) {
           store_global(gout + (uint64_t)c * li.out.ch_stride + lane, v[c][0]);
           store_global(gout + (uint64_t)c * li.out.ch_stride + 64 + lane, v[c][1]);
         }
-      __syncthreads();
+      lds_sync();
     }
   }
 }
 
 void launch_loop(const LoopDesc& d, void* stream) {
-  const size_t lds = ((size_t)d.n_items * 2 * RQ + 2 * RQ) * sizeof(float) + (size_t)d.n_items * 8 * sizeof(double);
-  hipLaunchKernelGGL(loop_kernel, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, d);
+  const size_t lds = ((size_t)d.n_items * 2 * RQ + 2 * RQ) * sizeof(float) + (size_t)d.n_items * 8 * sizeof(double) +
+                     (size_t)d.n_items * sizeof(LoopItem);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  LoopDesc dd = d;
+  dd.no_scan = getenv("WAA_DYN_NO_SCAN") ? 1u : 0u;
+  hipLaunchKernelGGL(loop_kernel, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, dd);
 }
 
 }  // namespace waa
