@@ -419,7 +419,7 @@ def main():
     extra = {}
     default_run = name == "c2" and args.instances is None and args.seconds == 10.0 and not args.no_extra
     if default_run:
-        for sub in ("t1", "c3", "c5", "c1a", "os2", "hrtf"):
+        for sub in ("t1", "c3", "c4", "c5", "c1a", "os2", "hrtf", "echo"):
             try:
                 extra[sub] = measure(torch, waa, hip, sub, DEFAULT_INSTANCES.get(sub, 1024), args.seconds, max(3, args.steps // 2),
                                      min(args.warmup, 2) or 1, rank, world, local_rank, dist, backend)

@@ -288,3 +288,68 @@ def test_delay_parity_mono_six_channel_inputs(hip, orc):
             outs.append(c.start_rendering_sync().data)
             c.close()
         assert np.array_equal(*outs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fold", [True, False])
+def test_folded_delay_forms_are_bit_identical(hip, orc, fold, monkeypatch):
+    """the gather inside the consumer's input stage (IN_DELAYED, source read in place) and the gather kernel behind a
+    materialised source: one arithmetic — identical to each other and to the oracle, including a buffer that ends before
+    the render does (zeros beyond the view), delays of 0 / sub-quantum / unaligned frames and a delay behind a delay"""
+    if not fold:
+        monkeypatch.setenv("WAA_NO_DELAY_FOLD", "1")
+        monkeypatch.setenv("WAA_NO_SOURCE_VIEW", "1")
+    n, frames, length = 6, RQ * 40, RQ * 64 + 57
+    noise = white_noise(n, 1, frames, seed0=17)  # (mono: the end of the source changes no channel count, the plan stays static)
+    delays = np.float32([0.0, 3.0 / 48000.0, 130.25 / 48000.0, 1001.0 / 48000.0, 0.0301, 0.0499])
+    outs = []
+    for be_ in (hip, orc):
+        c = waa.OfflineAudioContext(2, length, 48000.0, n_instances=n, binding=be_)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(noise, 48000.0)
+        d1 = c.create_delay(0.05)
+        d2 = c.create_delay(0.05, delay_time=0.0107)
+        for i in range(n):
+            d1.delay_time.set_value(float(delays[i]), instance=i)
+        src.connect(c.destination())
+        src.connect(d1).connect(c.create_gain(gain=0.5)).connect(c.destination())
+        d1.connect(d2).connect(c.create_gain(gain=0.25)).connect(c.destination())
+        src.start()
+        if be_ is hip:
+            plan = c.plan_describe()
+            assert ("delayed:1ch" in plan) == fold and "dynamic-count" not in plan
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_folded_delay_in_a_block_scheduled_loop(hip, orc, monkeypatch):
+    """echo loop Delay <-> Gain with a Biquad tap: one launch per block with the folds, three without — same samples"""
+    n, frames = 3, 2048 * 12
+    noise = white_noise(n, 2, frames, seed0=23)
+
+    def render(be_):
+        c = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n, binding=be_)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(noise, 48000.0)  # (as long as the render: no channel-count change, the plan stays static)
+        d = c.create_delay(1.0, delay_time=0.1)  # 4800 frames: blocks of 2 tiles
+        g = c.create_gain(gain=0.6)
+        src.connect(d)
+        d.connect(g).connect(d)
+        d.connect(c.create_biquad_filter(type_="highpass", frequency=300.0)).connect(c.destination())
+        src.connect(c.destination())
+        src.start()
+        plan = c.plan_describe() if be_ is hip else ""
+        out = c.start_rendering_sync().data
+        c.close()
+        return out, plan
+
+    folded, plan = render(hip)
+    assert "1 step(s) per block" in plan
+    monkeypatch.setenv("WAA_NO_LOOP_FOLD", "1")
+    plain, plan = render(hip)
+    assert "3 step(s) per block" in plan
+    ref, _ = render(orc)
+    assert np.array_equal(folded, plain)
+    assert rms_err(folded, ref).max() <= 1e-7
