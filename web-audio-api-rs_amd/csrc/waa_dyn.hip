@@ -309,16 +309,22 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
                 y1 = cy1;
                 y2 = cy2;
               }
+              // The scan is linear algebra; the reference flushes y to zero FRAME BY FRAME once it leaves the normal
+              // range (:881-883).  While a tail decays through the last decades above 2.2e-308 the two differ in WHEN
+              // the state reaches zero — by a quantum, and the quantum in which the tail ends is this item's silence
+              // flag (fuzz seed 6278: a DelayNode behind it re-mixed its line one quantum early).  Any state or output
+              // of this quantum that is non-zero but below 1e-280: the quantum is rendered serially.
+              auto tiny = [](double v) { return v != 0. && __builtin_fabs(v) < 1e-280; };
+              bool bad = tiny(y1) || tiny(y2);
               // the reference's evaluation order from the true incoming state (biquad_filter.rs:877-883)
               double p1 = xm1, p2 = xm2;
               const double xs[4] = {x0, x1, x2, x3};
               float yo[4];
-              bool bad = false;
 #pragma unroll
               for (int e = 0; e < 4; e++) {
                 const double x = xs[e];
                 double y = b0 * x + b1 * p1 + b2 * p2 - a1 * y1 - a2 * y2;
-                bad |= !(__builtin_fabs(y) <= 1.7976931348623157e308);  // inf / NaN
+                bad |= !(__builtin_fabs(y) <= 1.7976931348623157e308) || tiny(y);  // inf / NaN, or close to the flush
                 if (!__builtin_isnormal(y)) y = 0.;
                 p2 = p1;
                 p1 = x;
