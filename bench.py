@@ -256,7 +256,7 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
         # one streaming kernel: SURVEY section 8(d)'s algorithmic bytes of one launch / its mean duration (HIP events)
         roof["kernel"] = dom[0]
         roof["achieved"] = alg_bytes_step / (dom[2] / max(dom[1], 1) * 1e-3) / 1e9
-        roof["traffic"] = pmc["bytes_per_launch"] if pmc else None
+        roof["traffic"] = (pmc.get("bytes_per_launch") or pmc.get("bytes_per_step")) if pmc else None
         roof["algorithmic_bytes_per_launch"] = alg_bytes_step
     else:
         # several kernels (convolver pipelines, split chains, loops): the node-major design does not move the
