@@ -268,7 +268,9 @@ struct OscDesc {
   const struct OscQuantum* table_q;  // non-null: time-parallel kernel (host-known frequency), [n_inst][n_quanta]
   const int64_t* active;       // non-null: prefix-sum kernel (a-rate frequency): [n_inst][2] active frames [first, end)
   const double* start_ratio;   // [n_inst] sub-sample start offset in frames (oscillator.rs:516-528)
+  double* seg_phase;           // prefix-sum kernel: [n_inst][OSC_SEGMENTS] phase advance of each time segment (scratch)
 };
+constexpr int OSC_SEGMENTS = 8;  // time segments per instance of the prefix-sum oscillator (one wavefront each)
 // Per-(instance, quantum) record of the time-parallel oscillator: frames [first, end) of the quantum are active,
 // the phase of frame `first` is `phase`, every further frame advances by `incr` (oscillator.rs:395-440).
 struct OscQuantum {

@@ -193,16 +193,35 @@ __global__ __launch_bounds__(256) void osc_par_kernel(const OscDesc d) {
 // same ~1e-14 phase difference as the closed form above, far below one f32 ulp of the output; the per-frame
 // decisions (active range from the host replay of the reference's clock, Nyquist muting, sub-sample start phase)
 // and the waveform arithmetic are the reference's.
+// The a-rate oscillator in TIME SEGMENTS: one wavefront per (instance, segment) instead of one per instance — with 1024
+// instances that was one wave per SIMD walking 1875 groups of 256 frames one after the other, every exposed latency
+// (the frequency signal, the f64 arithmetic, the shuffles of the scan) paid in full.  PASS 0 computes the phase advance
+// of every segment (the same increments, no waveform), the render pass starts each segment at the running sum of the
+// segments before it.  The phase is a sum either way (the group scan was already a tree): rounding differences of the
+// order of 1e-16 in the phase, as between the group-serial form and the reference's frame-serial accumulation.
+template <int PASS>
 __global__ __launch_bounds__(64) void osc_scan_kernel(const OscDesc d) {
   const uint32_t inst = blockIdx.x;
+  const uint32_t seg = blockIdx.y;
   const int lane = threadIdx.x;
   __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);
   float* out = d.out.base + (uint64_t)inst * d.out.inst_stride;
   const int64_t first = d.active[(uint64_t)inst * 2], end = d.active[(uint64_t)inst * 2 + 1];
   const double ratio = d.start_ratio[inst];  // (time of frame `first` - start_time) / dt, 0 when it starts on a frame
   const double sample_rate = d.sample_rate, nyquist = sample_rate / 2.;
+  const uint64_t groups = (d.frames + 255) / 256, per_seg = (groups + OSC_SEGMENTS - 1) / OSC_SEGMENTS;
+  const uint64_t g_begin = (uint64_t)seg * per_seg * 256, g_end = g_begin + per_seg * 256 < d.frames ? g_begin + per_seg * 256 : d.frames;
   double carry = 0.;  // phase at the first frame of the group
-  for (uint64_t g0 = 0; g0 < d.frames; g0 += 256) {
+  if (PASS == 1) {
+    for (uint32_t sgm = 0; sgm < seg; sgm++) {
+      carry += d.seg_phase[(uint64_t)inst * OSC_SEGMENTS + sgm];
+      carry -= floor(carry);
+    }
+  }
+  // a constant detune: its factor once (the f64 exp2 per frame was most of the group's arithmetic)
+  const bool det_const = d.detune.mode == 0;
+  const double det_mul = det_const ? exp2((double)d.detune.base[inst] / 1200.) : 1.;
+  for (uint64_t g0 = g_begin; g0 < g_end; g0 += 256) {
     const uint64_t f0 = g0 + (uint64_t)lane * 4;
     double incr[4];
     bool outside[4];
@@ -214,10 +233,14 @@ __global__ __launch_bounds__(64) void osc_scan_kernel(const OscDesc d) {
       const float freq = d.frequency.mode == 0   ? d.frequency.base[inst]
                          : d.frequency.mode == 1 ? d.frequency.base[(uint64_t)inst * d.frequency.stride + q]
                                                  : d.frequency.base[(uint64_t)inst * d.frequency.stride + fc];
-      const float detune = d.detune.mode == 0   ? d.detune.base[inst]
-                           : d.detune.mode == 1 ? d.detune.base[(uint64_t)inst * d.detune.stride + q]
+      double computed_freq;
+      if (det_const) {
+        computed_freq = (double)freq * det_mul;
+      } else {
+        const float detune = d.detune.mode == 1 ? d.detune.base[(uint64_t)inst * d.detune.stride + q]
                                                 : d.detune.base[(uint64_t)inst * d.detune.stride + fc];
-      const double computed_freq = (double)freq * exp2((double)detune / 1200.);
+        computed_freq = (double)freq * exp2((double)detune / 1200.);
+      }
       incr[e] = computed_freq / sample_rate;
       outside[e] = fabs(computed_freq) >= nyquist;
     }
@@ -236,23 +259,26 @@ __global__ __launch_bounds__(64) void osc_scan_kernel(const OscDesc d) {
       const double t = __shfl_up(incl, sft, 64);
       if (lane >= sft) incl += t;
     }
-    double ph = carry + (incl - local);  // phase before this lane's first frame (may exceed 1: reduced per frame)
-    float r[4];
+    if (PASS == 1) {
+      double ph = carry + (incl - local);  // phase before this lane's first frame (may exceed 1: reduced per frame)
+      float r[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int64_t f = (int64_t)(f0 + e);
-      double p = ph;
-      if (f == first) p += incr[e] * ratio;
-      p -= floor(p);
-      if (p >= 1.) p -= 1.;
-      r[e] = (f >= first && f < end && !outside[e]) ? waveform_sample(d, p, incr[e]) : 0.f;
-      ph += adv[e];
+      for (int e = 0; e < 4; e++) {
+        const int64_t f = (int64_t)(f0 + e);
+        double p = ph;
+        if (f == first) p += incr[e] * ratio;
+        p -= floor(p);
+        if (p >= 1.) p -= 1.;
+        r[e] = (f >= first && f < end && !outside[e]) ? waveform_sample(d, p, incr[e]) : 0.f;
+        ph += adv[e];
+      }
+      *reinterpret_cast<float4*>(out + f0) = make_float4(r[0], r[1], r[2], r[3]);
     }
-    *reinterpret_cast<float4*>(out + f0) = make_float4(r[0], r[1], r[2], r[3]);
     double total = __shfl(incl, 63, 64) + carry;
     total -= floor(total);
     carry = total;
   }
+  if (PASS == 0 && lane == 0) d.seg_phase[(uint64_t)inst * OSC_SEGMENTS + seg] = carry;
 }
 
 void launch_osc(const OscDesc& d, void* stream) {
@@ -261,7 +287,8 @@ void launch_osc(const OscDesc& d, void* stream) {
     return;
   }
   if (d.active) {
-    hipLaunchKernelGGL(osc_scan_kernel, dim3(d.n_inst), dim3(64), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(osc_scan_kernel<0>, dim3(d.n_inst, OSC_SEGMENTS), dim3(64), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(osc_scan_kernel<1>, dim3(d.n_inst, OSC_SEGMENTS), dim3(64), 0, (hipStream_t)stream, d);
     return;
   }
   hipLaunchKernelGGL(osc_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);

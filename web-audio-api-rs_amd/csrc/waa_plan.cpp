@@ -2360,6 +2360,9 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
     if ((e = dev_upload(b, &d_act, act)) || (e = dev_upload(b, &d_ratio, ratio))) return e;
     d.active = d_act;
     d.start_ratio = d_ratio;
+    double* d_seg = nullptr;
+    if ((e = dev_alloc(b, &d_seg, (size_t)b->n_inst * OSC_SEGMENTS))) return e;
+    d.seg_phase = d_seg;
   }
   st.profile_slot = slot_for(b, parallel ? "osc_par_kernel" : scan ? "osc_scan_kernel" : "osc_kernel");
   b->steps.push_back(st);
