@@ -210,9 +210,12 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
   if (in.kind == IN_SOURCE) {
     const SrcInst si = in.src[inst];
     const SrcSchedule sc = si.sc;
-    if (si.aligned && load_global(sc.tile_fast + f_tile / TILE)) {
+    // (inside the linear prefix of the schedule the tile's start is arithmetic: no dependent table loads in front of
+    // the samples — the streaming kernels' shortcut, SrcInst::fast_prefix)
+    const bool in_prefix = si.aligned && f_tile / TILE < si.fast_prefix;
+    if (in_prefix || (si.aligned && load_global(sc.tile_fast + f_tile / TILE))) {
       // the enclosing 2048-frame tile is one contiguous, in-range, 16B-aligned run of the AudioBuffer
-      const int64_t start = load_global(&sc.qrec[(uint64_t)tile * QPT].start);
+      const int64_t start = in_prefix ? si.linear_start + (int64_t)f_tile : load_global(&sc.qrec[(uint64_t)tile * QPT].start);
 #pragma unroll
       for (int c = 0; c < C; c++) {
         if (c < in.nch) {
