@@ -169,13 +169,16 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
   constexpr int QPT = K / 2;
   const uint64_t f_tile = (uint64_t)tile * TILE_FR;
   if (in.kind == IN_SIGNAL) {
+    // (valid != 0: a BufferSource's AudioBuffer read in place — frames past its end are silence; whole float4 groups,
+    // the buffer length is a multiple of the render quantum)
 #pragma unroll
     for (int c = 0; c < C; c++) {
       if (c < in.nch) {
         const float* p = in.sig.base + (uint64_t)inst * in.sig.inst_stride + (uint64_t)c * in.sig.ch_stride + f_tile;
 #pragma unroll
         for (int j = 0; j < NV4; j++) {
-          const float4 t = *reinterpret_cast<const float4*>(p + j * 256 + lane * 4);
+          const bool inside = in.valid == 0 || f_tile + (uint64_t)(j * 256 + lane * 4) + 3 < in.valid;
+          const float4 t = inside ? *reinterpret_cast<const float4*>(p + j * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
           v[c][j * 4 + 0] = t.x;
           v[c][j * 4 + 1] = t.y;
           v[c][j * 4 + 2] = t.z;

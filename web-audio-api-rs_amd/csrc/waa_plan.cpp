@@ -203,6 +203,12 @@ int build_edge_input(waa_batch* b, uint32_t head, int ie, InputRef* out) {
     // the delay line of a loop-breaking DelayNode is written by a LATER launch of the same block (the reads go to
     // earlier blocks: the loop is block-scheduled with blocks shorter than the delay)
     in.feedback = pid < b->cut.size() && b->cut[pid] ? 1 : 0;
+  } else if (pn.is_view && !getenv("WAA_NO_VIEW_SIGNAL")) {
+    // a BufferSource that renders its AudioBuffer unchanged: a plain signal with an end (one layout for all instances:
+    // no per-instance source record in front of the samples); silence past the buffer
+    in.kind = IN_SIGNAL;
+    in.sig = pn.view_sig;
+    in.valid = pn.view_valid;
   } else if (pn.desc.kind == WAA_NODE_BUFFER_SOURCE || pn.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
     in.kind = pn.desc.kind == WAA_NODE_BUFFER_SOURCE ? IN_SOURCE : IN_CONSTANT;
     int e = prepare_source_input(b, pid, &in);
@@ -418,7 +424,8 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     // the streaming kernel wants ONE plain input (signal or source) of exactly the biquad's channel count
     const bool iir_exact = o.kind == OP_IIR && o.i0 < 0;  // the lane-per-stream kernel reads a materialised signal
     const bool plain = pending.empty() && inputs.size() == 1 && !inputs[0].has_gain &&
-                       ((inputs[0].kind == IN_SOURCE && !iir_exact) || inputs[0].kind == IN_SIGNAL) && inputs[0].nch == cur_nch;
+                       ((inputs[0].kind == IN_SOURCE && !iir_exact) || (inputs[0].kind == IN_SIGNAL && inputs[0].valid == 0)) &&
+                       inputs[0].nch == cur_nch;
     if (!plain) {
       SignalRef tmp;
       int e = temp_signal(b, cur_nch, &tmp);
