@@ -195,8 +195,9 @@ __device__ __forceinline__ void load_input(const InputRef& in, uint32_t inst, ui
       const uint64_t f = f_tile + (uint64_t)(j * 256 + lane * 4);
       const uint32_t q = (uint32_t)(f / RQ);
       const bool live = q < n_quanta;
-      const float dv = in.offset.mode == 0 ? load_global(in.offset.base + inst)
-                                           : load_global(in.offset.base + (uint64_t)inst * in.offset.stride + (live ? q : 0));
+      const float dv = in.offset.mode == 3   ? __uint_as_float((uint32_t)in.offset.stride)  // one value for the batch
+                       : in.offset.mode == 0 ? load_global(in.offset.base + inst)
+                                             : load_global(in.offset.base + (uint64_t)inst * in.offset.stride + (live ? q : 0));
 #pragma unroll
       for (int c = 0; c < C; c++) {
         if (c < in.nch) {

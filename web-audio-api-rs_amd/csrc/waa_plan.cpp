@@ -197,6 +197,20 @@ int build_edge_input(waa_batch* b, uint32_t head, int ie, InputRef* out) {
     in.nch = pn.in_nch;
     int e = node_param(b, pid, WAA_PARAM_DELAY_DELAY_TIME, &in.offset);
     if (e) return e;
+    if (in.offset.mode == 0) {
+      // one delayTime for the whole batch: an immediate (mode 3, the value in `stride`) instead of a load every wave has
+      // to wait for before it can form the addresses of its samples
+      const ParamStore& ps = pn.params[WAA_PARAM_DELAY_DELAY_TIME];
+      bool same = true;
+      for (uint32_t i = 1; i < b->n_inst && same; i++) same = ps.cst[i] == ps.cst[0];
+      if (same && !ps.dev_tl) {
+        const float v0 = ps.fix(ps.cst[0]);  // (the clamped value upload_param wrote)
+        uint32_t bits;
+        std::memcpy(&bits, &v0, 4);
+        in.offset.mode = 3;
+        in.offset.stride = bits;
+      }
+    }
     in.sample_rate = (double)b->sr;
     in.num_quanta = (int32_t)std::ceil(pn.desc.d[0] * (double)b->sr / (double)RQ);
     in.valid = pn.hist_valid;
