@@ -127,6 +127,7 @@ int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int inte
 // param.rs:309-311), adds the intrinsic value and clamps, written to a one-channel signal the consumer reads
 // as per-frame values.  Planned once, right before the first consumer (its producers are materialised and
 // precede the owner in processing order).
+int build_edge_input(waa_batch* b, uint32_t head, int ie, InputRef* out);
 int node_param(waa_batch* b, uint32_t id, size_t k, ParamRef* ref) {
   Node& n = b->nodes[id];
   if (k >= n.pin_edges.size() || n.pin_edges[k].empty()) return upload_param(b, n.params[k], ref);
@@ -136,13 +137,10 @@ int node_param(waa_batch* b, uint32_t id, size_t k, ParamRef* ref) {
   }
   std::vector<InputRef> ins;
   for (int ie : n.pin_edges[k]) {
-    Node& pn = b->nodes[b->edges[ie].from];
-    if (!pn.materialized || !pn.sig.base)
-      return fail(WAA_ERR_INVALID_STATE, "internal: AudioParam input of node %u is not materialised yet", id);
+    // (a GainNode between a modulator and the param — the LFO depth — rides on the edge, see the materialisation pass)
     InputRef in{};
-    in.kind = IN_SIGNAL;
-    in.nch = pn.out_nch;
-    in.sig = pn.sig;
+    int e = build_edge_input(b, id, ie, &in);
+    if (e) return e;
     ins.push_back(in);
   }
   int e = reduce_fan_in(b, ins, 1, WAA_INTERP_DISCRETE);
@@ -1234,7 +1232,14 @@ int build_plan(waa_batch* b) {
           else
             mat = true;
         }
-        if (e.to_input & 0x80000000u) mat = true;  // feeds an AudioParam: read back as a per-frame value signal
+        if (e.to_input & 0x80000000u) {
+          // feeds an AudioParam: read back as a per-frame value signal — except a plain GainNode (the depth of an LFO),
+          // which rides on the input edge of the param's summing chain like on any other summing input
+          if (kind == WAA_NODE_GAIN && scc_of[id] < 0 && !count_change_found && !b->force_dynamic && !getenv("WAA_NO_EDGE_FOLD"))
+            fan = true;
+          else
+            mat = true;
+        }
         if (scc_of[e.to] >= 0 && !(relaxed && scc_of[e.to] == scc_of[id])) mat = true;  // feeds a feedback loop
         int live_in = 0;
         for (int ie : c.in_edges)
