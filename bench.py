@@ -305,11 +305,11 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
     }
 
 
-def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, n_sub=4):
+def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, n_sub=8):
     """What the drop-in boundary costs when it is handed HOST buffers (never `value`): host noise ->
     waa_source_set_buffer_batch -> waa_render -> waa_download_all for the C2 graph, (a) as one batch, (b) as n_sub
-    sub-batches driven by n_sub host threads (ctypes releases the GIL; every batch has its own stream), so the
-    uploads / kernels / downloads of different sub-batches overlap.  Host buffers are pinned (torch)."""
+    sub-batches driven by n_sub host threads (ctypes releases the GIL; every batch has its own stream and its transfers run
+    on it), pipelined so that the upload of one sub-batch overlaps the download of another.  Host buffers are pinned (torch)."""
     import threading
     frames = int(round(seconds * SR))
     host_in = torch.empty((n_inst, 2, frames), dtype=torch.float32, pin_memory=True).uniform_(-1.0, 1.0)
@@ -317,17 +317,42 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, n_sub=4):
     import ctypes as C
     FP = C.POINTER(C.c_float)
 
-    def run(lo, hi):
+    # one upload and one download at a time: sub-batch i + 1 uploads while sub-batch i downloads (PCIe is full duplex:
+    # tools/pcie_probe.py, 57 GB/s each way, 97 GB/s both at once).  Without the two locks all uploads run side by side,
+    # finish together, and all downloads follow: a sum again, not a pipeline.
+    class Turn:  # sub-batches take the link in index order
+        def __init__(self):
+            self.cv, self.next = threading.Condition(), 0
+
+        def wait(self, k):
+            with self.cv:
+                self.cv.wait_for(lambda: self.next == k)
+
+        def done(self):
+            with self.cv:
+                self.next += 1
+                self.cv.notify_all()
+
+    turns = {}
+
+    def run(lo, hi, k=0):
+        up, down = turns["up"], turns["down"]
         ctx, src = build_workload(waa, hip, "c2", hi - lo, frames, local_rank, None)
         ctx.prepare()
         sl = host_in[lo:hi]
+        up.wait(k)
         hip.check(hip.source_set_buffer_batch(ctx._handle, src.id, C.cast(sl.data_ptr(), FP), 2, frames, SR))
+        up.done()
         hip.check(hip.render(ctx._handle))
+        hip.check(hip.sync(ctx._handle))
+        down.wait(k)
         hip.check(hip.download_all(ctx._handle, C.cast(host_out[lo:hi].data_ptr(), FP)))
+        down.done()
         ctx.close()
 
     def timed(parts):
-        bounds = [(k * n_inst // parts, (k + 1) * n_inst // parts) for k in range(parts)]
+        bounds = [(k * n_inst // parts, (k + 1) * n_inst // parts, k) for k in range(parts)]
+        turns["up"], turns["down"] = Turn(), Turn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ths = [threading.Thread(target=run, args=b) for b in bounds]
@@ -345,7 +370,8 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, n_sub=4):
            "host_bytes_moved": nbytes, "effective_GBps_single": nbytes / one / 1e6,
            "effective_GBps_split": nbytes / split / 1e6,
            "note": "host (pinned) -> set_buffer_batch -> render -> download_all, batch creation and planning included; "
-                   "PCIe-bound, reported for the boundary only"}
+                   "PCIe-bound, reported for the boundary only; the split run pipelines its sub-batches (upload of one "
+                   "while another downloads: the link is full duplex, tools/pcie_probe.py)"}
     # the same with the input handed over as decoded 16-bit PCM (waa_source_set_buffer_pcm16_batch: half the upload,
     # sample conversion on the device) — what a caller that holds WAV data would do
     try:

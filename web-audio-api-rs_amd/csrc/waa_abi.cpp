@@ -251,9 +251,19 @@ waa_status waa_source_set_buffer_batch(waa_batch* b, uint32_t node, const float*
   const uint64_t stride = (frames + 3) / 4 * 4;
   float* d = nullptr;
   if ((e = dev_alloc(b, &d, (size_t)b->n_inst * n_ch * std::max<uint64_t>(stride, 4), true))) return e;
-  if (frames && !b->dry)
-    HIP_TRY(hipMemcpy2D(d, stride * sizeof(float), data, frames * sizeof(float), frames * sizeof(float),
-                        (size_t)b->n_inst * n_ch, hipMemcpyHostToDevice));
+  if (frames && !b->dry) {
+    // on the batch's own stream (and waited for: the caller may free `data` on return): blocking copies on the null
+    // stream of several host threads serialise, and the upload of one sub-batch could not overlap the download of
+    // another (PCIe is full duplex) — SURVEY 8(e)
+    // (contiguous on both sides -> a plain 1-D copy: those go through the DMA engines, one per direction; pitched 2-D
+    // copies run as a copy kernel and did not overlap with a download on another stream)
+    if (stride == frames)
+      HIP_TRY(hipMemcpyAsync(d, data, (size_t)b->n_inst * n_ch * frames * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    else
+      HIP_TRY(hipMemcpy2DAsync(d, stride * sizeof(float), data, frames * sizeof(float), frames * sizeof(float),
+                               (size_t)b->n_inst * n_ch, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
   Node& n = b->nodes[node];
   for (uint32_t k = 0; k < b->n_inst; k++) {
     DeviceBuffer db;
@@ -841,8 +851,9 @@ waa_status waa_download_all(waa_batch* b, float* dst) {
   const SignalRef& s = b->nodes[0].sig;
   if (b->length == 0) return WAA_OK;
   if ((uint32_t)s.nch == b->n_out) {
-    HIP_TRY(hipMemcpy2D(dst, b->length * sizeof(float), s.base, s.ch_stride * sizeof(float), b->length * sizeof(float),
-                        (size_t)b->n_inst * b->n_out, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2DAsync(dst, b->length * sizeof(float), s.base, s.ch_stride * sizeof(float), b->length * sizeof(float),
+                             (size_t)b->n_inst * b->n_out, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
   } else {
     for (uint32_t i = 0; i < b->n_inst; i++)
       for (uint32_t c = 0; c < b->n_out; c++) {
