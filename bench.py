@@ -378,22 +378,36 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, n_sub=8):
         pcm = torch.empty((n_inst, frames, 2), dtype=torch.int16, pin_memory=True).random_(-32768, 32767)
         I16 = C.POINTER(C.c_int16)
 
-        def run_pcm(lo, hi):
+        def run_pcm(lo, hi, k=0):
+            up, down = turns["up"], turns["down"]
             ctx, src = build_workload(waa, hip, "c2", hi - lo, frames, local_rank, None)
             ctx.prepare()
+            up.wait(k)
             hip.check(hip.source_set_buffer_pcm16_batch(ctx._handle, src.id, C.cast(pcm[lo:hi].data_ptr(), I16), 2, frames, SR))
+            up.done()
             hip.check(hip.render(ctx._handle))
+            hip.check(hip.sync(ctx._handle))
+            down.wait(k)
             hip.check(hip.download_all(ctx._handle, C.cast(host_out[lo:hi].data_ptr(), FP)))
+            down.done()
             ctx.close()
 
-        def timed_pcm():
+        def timed_pcm(parts):
+            bounds = [(k * n_inst // parts, (k + 1) * n_inst // parts, k) for k in range(parts)]
+            turns["up"], turns["down"] = Turn(), Turn()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            run_pcm(0, n_inst)
+            ths = [threading.Thread(target=run_pcm, args=b_) for b_ in bounds]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
             return (time.perf_counter() - t0) * 1e3
 
-        timed_pcm()
-        rec["pcm16_single_batch_ms"] = min(timed_pcm() for _ in range(2))
+        timed_pcm(1)
+        rec["pcm16_single_batch_ms"] = min(timed_pcm(1) for _ in range(2))
+        timed_pcm(n_sub)
+        rec[f"pcm16_split_{n_sub}_batches_ms"] = min(timed_pcm(n_sub) for _ in range(2))
         rec["pcm16_host_bytes_moved"] = n_inst * 2 * frames * (2 + 4.0)
     except Exception as e:  # reporting only
         rec["pcm16_error"] = repr(e)
