@@ -975,9 +975,11 @@ __global__ __launch_bounds__(64) void hrtf8_kernel(const HrtfDesc d) {
     const float* xw = lds + (size_t)u * (size_t)per_unit;
     const float* hh = xw + O + RQ;
     const int b = O + n0;  // xw index of output frame n0 at tap 0
-    f4v c0 = *reinterpret_cast<const f4v*>(xw + b), c1 = *reinterpret_cast<const f4v*>(xw + b + 4);  // x[b .. b + 7]
-    for (int g = 0; g < O / 4; g++) {
-      const f4v nx = *reinterpret_cast<const f4v*>(xw + b - 4 * g - 4);  // x[b - 4g - 4 .. b - 4g - 1]
+    // window x[b - 4g - 4 .. b - 4g + 7] in three registers of four; the roles (new input, first four, next four) rotate
+    // over three steps instead of the registers being copied (12 % of the loop's issue slots were moves)
+    f4v r0, r1 = *reinterpret_cast<const f4v*>(xw + b), r2 = *reinterpret_cast<const f4v*>(xw + b + 4);  // x[b .. b + 7]
+    auto step = [&](int g, f4v& nx, const f4v& c0, const f4v& c1) __attribute__((always_inline)) {
+      nx = *reinterpret_cast<const f4v*>(xw + b - 4 * g - 4);  // x[b - 4g - 4 .. b - 4g - 1]
       const float w[12] = {nx.x, nx.y, nx.z, nx.w, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};  // x[b - 4g - 4 + i]
       f2v h[4];
       if (STATIC) {
@@ -998,9 +1000,16 @@ __global__ __launch_bounds__(64) void hrtf8_kernel(const HrtfDesc d) {
           const float x = w[4 - t + r];
           acc[r] = __builtin_elementwise_fma(h[t], f2v{x, x}, acc[r]);
         }
-      c1 = c0;
-      c0 = nx;
+    };
+    const int G = O / 4;
+    int g = 0;
+    for (; g + 2 < G; g += 3) {
+      step(g, r0, r1, r2);
+      step(g + 1, r2, r0, r1);
+      step(g + 2, r1, r2, r0);
     }
+    if (g < G) step(g, r0, r1, r2);
+    if (g + 1 < G) step(g + 1, r2, r0, r1);
   }
   float* out = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)q * RQ + n0;
   const float gc = gain * corr;
