@@ -273,3 +273,62 @@ def test_plan_validator_refuses_a_misordered_launch_list(hip, monkeypatch):
     with pytest.raises(waa.WaaError, match="reads a buffer that a later launch produces") as ei:
         build().plan_describe()
     assert ei.value.status == 3
+
+
+# --------------------------------------------------------------------------- round-2 folds (plan text only, no GPU)
+def _ctx(hip, n_ch=2, frames=2048 * 8, n=3):
+    c = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n, binding=hip, device=waa.PLAN_ONLY)
+    s = c.create_buffer_source()
+    s.set_buffer_batch(white_noise(n, n_ch, frames), 48000.0)
+    s.start()
+    return c, s
+
+
+def test_echo_is_one_launch(hip):
+    """source -> [dry] + [Delay -> Gain] -> destination: the buffer is read in place by both consumers, the delay from its
+    line, the gain on the edge — one chain launch"""
+    c, s = _ctx(hip)
+    s.connect(c.destination())
+    s.connect(c.create_delay(1.0, delay_time=0.05)).connect(c.create_gain(gain=0.5)).connect(c.destination())
+    lines = plan(c)
+    assert any("its 2 consumers read it in place" in l for l in lines)
+    assert any("read by its consumers from the delay line" in l for l in lines)
+    assert lines[-1] == "chain parallel C=2 in=[signal:2ch+gain*delayed:2ch]->2ch ops=[] out=2ch"
+    assert sum(l.startswith(("chain", "biquad_stream", "delay node 2: 2ch delayTime")) for l in lines) == 1
+
+
+def test_echo_keeps_the_gather_kernel_for_a_convolver_consumer(hip):
+    c, s = _ctx(hip)
+    d = c.create_delay(1.0, delay_time=0.05)
+    s.connect(d).connect(c.create_convolver(buffer=waa.AudioBuffer(np.ones((1, 300), np.float32), 48000.0))).connect(c.destination())
+    lines = plan(c)
+    assert any(l.startswith("delay node") and "ring=" in l for l in lines)
+    assert not any("delayed:" in l for l in lines)
+
+
+def test_lfo_depth_gain_rides_on_the_param_edge(hip):
+    """Oscillator -> Gain(depth) -> carrier.frequency: the depth is an edge gain of the param's summing chain"""
+    c = waa.OfflineAudioContext(2, 2048 * 4, 48000.0, n_instances=2, binding=hip, device=waa.PLAN_ONLY)
+    lfo = c.create_oscillator(frequency=5.0)
+    depth = c.create_gain(gain=30.0)
+    car = c.create_oscillator(frequency=440.0)
+    lfo.connect(depth).connect(car.frequency)
+    car.connect(c.destination())
+    lfo.start()
+    car.start()
+    lines = plan(c)
+    assert any("gain node" in l and "folded into an input edge" in l for l in lines)
+    assert any("in=[gain*signal:1ch]->1ch ops=[PARAM_ADD]" in l for l in lines)
+    assert sum("ops=[GAIN]" in l for l in lines) == 0
+
+
+def test_short_delay_loop_uses_the_quantum_serial_kernel(hip):
+    """a loop delay below one 2048-frame tile cannot be block-scheduled"""
+    c, s = _ctx(hip)
+    d = c.create_delay(1.0, delay_time=0.01)
+    s.connect(d)
+    d.connect(c.create_gain(gain=0.5)).connect(d)
+    d.connect(c.destination())
+    lines = plan(c)
+    assert any(l.startswith("feedback loop:") and "item(s) per quantum" in l for l in lines)
+    assert not any("block-scheduled" in l for l in lines)
