@@ -47,7 +47,9 @@ __device__ __forceinline__ M2 mm(const M2& x, const M2& y) {
 // its 32 coefficient sets twice (zero-state pass with the transition product P = M_31 ... M_0, then the exact-order
 // pass from the true incoming state) instead of holding 160 doubles in registers; the table is one per batch when the
 // automation is the same for every instance (then it lives in L2 / Infinity Cache and HBM only carries the samples).
-template <int DBG, int VARY, int NBUF = 2>
+// DUP: a mono stream whose result goes to both channels of a stereo signal (the speakers up-mix 1 -> 2 of the node behind it,
+// quantum.rs:330-340): the second store instead of a chain launch that reads the mono signal back and writes two copies.
+template <int DBG, int VARY, int NBUF = 2, bool DUP = false>
 __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStreamDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const uint32_t wid = blockIdx.x;
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
         asm volatile("" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
       } else {
         *reinterpret_cast<float4*>(op + j * 256 + lane * 4) = t;
+        if constexpr (DUP) *reinterpret_cast<float4*>(op + d.out.ch_stride + j * 256 + lane * 4) = t;
       }
     }
     lds_sync();
@@ -940,6 +943,10 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
   const dim3 grid(d.n_inst * (uint32_t)d.nch), block(64);
   const size_t lds = 2 * 64 * LDS_ROW * sizeof(float);
   const char* dbg = getenv("WAA_STREAM_DEBUG");  // measurement aid only, see profiles/r01_c2_memory_pattern.txt
+  if (d.dup_out && d.vary == 0) {
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 2, true>), grid, block, lds, (hipStream_t)stream, d);
+    return;
+  }
   if (d.vary == 3 && dbg && dbg[0] == '3')
     hipLaunchKernelGGL((biquad_stream_kernel_t<3, 3>), grid, block, lds, (hipStream_t)stream, d);
   else if (d.vary == 3 && dbg && dbg[0] == '4')

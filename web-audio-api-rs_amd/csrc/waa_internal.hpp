@@ -157,7 +157,7 @@ struct BiquadStreamDesc {
   uint32_t n_inst;
   uint32_t n_tiles;
   uint32_t n_quanta;
-  uint32_t pad;
+  uint32_t dup_out;      // mono stream whose only consumer is the speakers up-mix 1 -> 2 of the destination: both channels written here
   uint32_t tile0, tile1;
 };
 void launch_biquad_stream(const BiquadStreamDesc& d, void* stream);

@@ -454,8 +454,11 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     size_t j = i + 1;
     if (o.kind == OP_BIQUAD)  // the biquad kernel applies up to two constant gains on the way out
       while (j < ops.size() && j - i <= 2 && ops[j].kind == OP_GAIN && ops[j].p0.mode == 0 && ops[j].nch_in == cur_nch) j++;
+    // a mono biquad whose result only goes through the speakers up-mix 1 -> 2 into `out`: the kernel writes both channels
+    const bool dup = o.kind == OP_BIQUAD && o.i0 == 0 && cur_nch == 1 && out.nch == 2 && j + 1 == ops.size() && ops[j].kind == OP_MIX &&
+                     ops[j].nch_in == 1 && ops[j].nch_out == 2 && ops[j].i0 == WAA_INTERP_SPEAKERS && !getenv("WAA_NO_STREAM_DUP");
     SignalRef seg_out = out;
-    if (j < ops.size() || out.nch != cur_nch) {
+    if (!dup && (j < ops.size() || out.nch != cur_nch)) {
       int e = temp_signal(b, cur_nch, &seg_out);
       if (e) return e;
     }
@@ -531,6 +534,7 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     for (size_t k = i + 1; k < j; k++) q.gain[k - i - 1] = ops[k].p0;
     q.nch = cur_nch;
     q.out = seg_out;
+    q.dup_out = dup ? 1u : 0u;
     q.n_inst = b->n_inst;
     q.n_tiles = b->n_tiles;
     q.tile0 = 0;
@@ -538,6 +542,11 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     q.n_quanta = b->n_quanta;
     st.profile_slot = slot_for(b, "biquad_stream_kernel");
     b->steps.push_back(st);
+    if (dup) {
+      plan_note(b, "biquad_stream in=%s:1ch gains=%d out=final (both channels: the speakers up-mix 1 -> 2 behind it)",
+                input_kind_name(inputs[0].kind), q.n_gain);
+      return 0;
+    }
     plan_note(b, "biquad_stream%s in=%s:%dch gains=%d out=%s",
               q.vary == 3 ? "(a-rate, shared table)" : q.vary == 2 ? "(a-rate, per-instance table)" : q.vary ? "(k-rate)" : "",
               input_kind_name(inputs[0].kind),
