@@ -307,3 +307,38 @@ def test_reenters_the_audible_range_after_large_phase_increments(orc):
     out = c.start_rendering_sync().data[0, 0]
     assert np.max(np.abs(out[:RQ])) <= 1e-5
     assert np.all(np.isfinite(out[RQ:])) and np.any(out[RQ:] != 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("modulated", [False, True])
+def test_folded_post_ops_are_bit_identical(hip, orc, modulated, monkeypatch):
+    """Oscillator -> Gain -> Gain -> stereo destination: the gains and the up-mix 1 -> 2 are rendered by the oscillator's own
+    launch (time-parallel and prefix-sum kernels); same bits as the chain launch behind it, same samples as the oracle"""
+    def render(be_):
+        c = waa.OfflineAudioContext(2, RQ * 37 + 11, 48000.0, n_instances=3, binding=be_)
+        osc = c.create_oscillator(type_="sawtooth", frequency=220.0)
+        if modulated:
+            lfo = c.create_oscillator(frequency=6.0)
+            lfo.connect(c.create_gain(gain=40.0)).connect(osc.frequency)
+            lfo.start()
+        g1 = c.create_gain(gain=0.5)
+        for i in range(3):
+            g1.gain.set_value(0.25 * (i + 1), instance=i)
+        osc.connect(g1).connect(c.create_gain(gain=0.8)).connect(c.destination())
+        osc.start_at(0.0013)
+        osc.stop_at(0.09)
+        plan = c.plan_describe() if be_ is hip else ""
+        out = c.start_rendering_sync().data
+        c.close()
+        return out, plan
+
+    fused, plan = render(hip)
+    assert "renders 2 gain(s) and the up-mix 1 -> 2" in plan
+    monkeypatch.setenv("WAA_NO_OSC_POST", "1")
+    plain, plan = render(hip)
+    assert "renders 2 gain(s)" not in plan
+    ref, _ = render(orc)
+    assert np.array_equal(fused, plain)
+    assert np.array_equal(fused[:, 0], fused[:, 1]) and np.any(fused != 0)
+    err = np.sqrt(np.mean((fused.astype(np.float64) - ref) ** 2, axis=2))
+    assert err.max() <= 1e-6

@@ -175,6 +175,7 @@ struct Node {
   // DelayNode outside a loop, constant / k-rate delayTime, consumed by chain input stages only: no reader pass, the
   // consumers gather from the delay line themselves (IN_DELAYED)
   bool delay_folded = false;
+  int osc_step = -1;  // OscillatorNode: index of its launch in the plan (post ops may be folded into it later)
   uint64_t hist_valid = 0;  // frames of the delay line that may be read (zeros beyond): the padded length, or a source view's
   SignalRef view_sig{};
   uint64_t view_valid = 0;

@@ -269,6 +269,11 @@ struct OscDesc {
   const int64_t* active;       // non-null: prefix-sum kernel (a-rate frequency): [n_inst][2] active frames [first, end)
   const double* start_ratio;   // [n_inst] sub-sample start offset in frames (oscillator.rs:516-528)
   double* seg_phase;           // prefix-sum kernel: [n_inst][OSC_SEGMENTS] phase advance of each time segment (scratch)
+  // what stands between the oscillator and a consumer it alone feeds, folded into its store (time-parallel and prefix-sum
+  // kernels): up to two constant GainNodes (gain.rs:163-179 fast paths) and the speakers up-mix 1 -> 2 (`out` then has 2 channels)
+  ParamRef post_gain[2];
+  int32_t n_post;
+  int32_t post_dup;
 };
 constexpr int OSC_SEGMENTS = 8;  // time segments per instance of the prefix-sum oscillator (one wavefront each)
 // Per-(instance, quantum) record of the time-parallel oscillator: frames [first, end) of the quantum are active,

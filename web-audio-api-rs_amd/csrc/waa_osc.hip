@@ -67,6 +67,22 @@ __device__ __forceinline__ float waveform_sample(const OscDesc& d, double phase,
 }
 }  // namespace
 
+namespace {
+// four consecutive frames of the oscillator's output through the folded post ops (OscDesc::post_gain / post_dup)
+__device__ __forceinline__ void osc_store(const OscDesc& d, uint32_t inst, float* out, uint64_t f0, float (&r)[4]) {
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+    if (k < d.n_post) {
+      const float g = d.post_gain[k].base[inst];
+      const bool mute = fabsf(g) <= 1e-6f, pass = fabsf(1.f - g) <= 1e-6f;  // gain.rs:163-179
+#pragma unroll
+      for (int e = 0; e < 4; e++) r[e] = mute ? 0.f : (pass ? r[e] : r[e] * g);
+    }
+  *reinterpret_cast<float4*>(out + f0) = make_float4(r[0], r[1], r[2], r[3]);
+  if (d.post_dup) *reinterpret_cast<float4*>(out + d.out.ch_stride + f0) = make_float4(r[0], r[1], r[2], r[3]);
+}
+}  // namespace
+
 __global__ __launch_bounds__(64) void osc_kernel(const OscDesc d) {
   const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
   if (inst >= d.n_inst) return;
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(256) void osc_par_kernel(const OscDesc d) {
       }
     }
   }
-  *reinterpret_cast<float4*>(out + f0) = make_float4(r[0], r[1], r[2], r[3]);
+  osc_store(d, inst, out, f0, r);
 }
 
 // a-rate / graph-modulated frequency (FM): the phase is the running sum of per-frame increments.  One wavefront per
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(64) void osc_scan_kernel(const OscDesc d) {
         r[e] = (f >= first && f < end && !outside[e]) ? waveform_sample(d, p, incr[e]) : 0.f;
         ph += adv[e];
       }
-      *reinterpret_cast<float4*>(out + f0) = make_float4(r[0], r[1], r[2], r[3]);
+      osc_store(d, inst, out, f0, r);
     }
     double total = __shfl(incl, 63, 64) + carry;
     total -= floor(total);

@@ -1511,6 +1511,39 @@ int build_plan(waa_batch* b) {
       int e = prepare_source_input(b, head, &cd.in[0]);
       if (e) return e;
     }
+    // An oscillator that feeds nothing but this chain, and the chain nothing but constant gains and the speakers up-mix
+    // 1 -> 2 (Oscillator -> Gain -> stereo destination: the plain tone generator): the oscillator's own launch writes the
+    // result, no second pass over it.
+    if (cd.n_inputs == 1 && cd.in[0].kind == IN_SIGNAL && !cd.in[0].has_gain && cd.in[0].nch == 1 && cd.in_nch == 1 &&
+        scc_of[id] < 0 && !getenv("WAA_NO_OSC_POST")) {
+      int prod = -1;
+      for (uint32_t k = 0; k < N; k++)
+        if (b->nodes[k].live && b->nodes[k].desc.kind == WAA_NODE_OSCILLATOR && b->nodes[k].sig.base == cd.in[0].sig.base &&
+            b->nodes[k].osc_step >= 0)
+          prod = (int)k;
+      int consumers = 0;
+      if (prod >= 0)
+        for (auto& e2 : b->edges)
+          if (e2.from == (uint32_t)prod && b->nodes[e2.to].live) consumers++;
+      size_t n_gain = 0;
+      bool ok = prod >= 0 && consumers == 1 && b->steps[(size_t)b->nodes[(size_t)prod].osc_step].group < 0;
+      while (ok && n_gain < ops.size() && ops[n_gain].kind == OP_GAIN) {
+        ok = ops[n_gain].p0.mode == 0 && ops[n_gain].nch_in == 1 && n_gain < 2;
+        n_gain++;
+      }
+      const bool dup = ok && n_gain + 1 == ops.size() && ops[n_gain].kind == OP_MIX && ops[n_gain].nch_in == 1 &&
+                       ops[n_gain].nch_out == 2 && ops[n_gain].i0 == WAA_INTERP_SPEAKERS && term.sig.nch == 2;
+      if (ok && (dup || (n_gain == ops.size() && term.sig.nch == 1 && n_gain > 0))) {
+        OscDesc& od = b->steps[(size_t)b->nodes[(size_t)prod].osc_step].osc;
+        od.out = term.sig;
+        od.n_post = (int32_t)n_gain;
+        for (size_t k = 0; k < n_gain; k++) od.post_gain[k] = ops[k].p0;
+        od.post_dup = dup ? 1 : 0;
+        plan_note(b, "oscillator node %d renders %zu gain(s)%s of node %u's chain itself", prod, n_gain,
+                  dup ? " and the up-mix 1 -> 2" : "", id);
+        return 0;
+      }
+    }
     std::vector<InputRef> inputs(cd.in, cd.in + cd.n_inputs);
     int e = emit_segments(b, inputs, cd.in_nch, cd.in_interp, ops, term.sig);
     if (e) return e;
@@ -2400,6 +2433,7 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
     d.seg_phase = d_seg;
   }
   st.profile_slot = slot_for(b, parallel ? "osc_par_kernel" : scan ? "osc_scan_kernel" : "osc_kernel");
+  n.osc_step = (parallel || scan) ? (int)b->steps.size() : -1;  // (the serial cross-check kernel takes no post ops)
   b->steps.push_back(st);
   static const char* names[] = {"sine", "square", "sawtooth", "triangle", "custom"};
   plan_note(b, "oscillator node %u: %s (%s) frequency=%s detune=%s", id, names[d.type],
