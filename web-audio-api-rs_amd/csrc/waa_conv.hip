@@ -674,6 +674,18 @@ __global__ __launch_bounds__(256) void conv_mac_kernel(const ConvDesc d) {
 // spectra; conv_mac_kernel re-reads them (2.2x the X bytes from HBM, profiles/r02a_t1_fetch.txt), here they stay in
 // registers, the IR column h[0..PC) is loaded once per thread, and every X value is read exactly once.  One term per
 // output channel and P <= PC (every routing but the true-stereo 4-channel IR; the launcher picks).
+typedef float c2v __attribute__((ext_vector_type(2)));  // one complex value in a 64-bit register pair: (re, im)
+// acc += h * x as two packed FMAs (v_pk_fma_f32: two f32 FMAs per lane and issue slot).  The operand selects do what the
+// compiler cannot express from C: (re, im) += h.re * (x.re, x.im), then (re, im) += h.im * (-x.im, x.re) with x's halves
+// SWAPPED by op_sel and the sign on the low half by neg_lo — no moves.  Same four FMAs in the same order as
+//   re = fma(h.re, x.re, re); re = fma(-h.im, x.im, re); im = fma(h.re, x.im, im); im = fma(h.im, x.re, im)
+// hence bit-identical to the scalar form (conv_mac_kernel keeps it).  Same-box A/B against the four scalar FMAs on T1 / C3:
+// 3.12-3.35 ms against 3.19-3.32 ms — the kernel waits for memory (5 TB/s), not for the VALU; the packed form halves the
+// VALU instructions (704 instead of 1408 per k-tile) and a third of the registers (132 against 206) for the same time.
+__device__ __forceinline__ void cmac_pk(c2v& acc, const c2v h, const c2v x) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(h), "v"(x));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(h), "v"(x));
+}
 template <int KT, int PC>
 __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
   const int pos = blockIdx.x * 256 + threadIdx.x;
@@ -683,42 +695,40 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
   int term = 0;
   for (int t = 0; t < d.n_terms; t++)
     if (d.terms[t].out_ch == co) term = t;
-  Cplx* Yc = d.Y + ((uint64_t)pair * d.cout + co) * nb * n + pos;
-  const Cplx* Hc = d.H + (uint64_t)d.terms[term].ir_ch * P * n + pos;
-  const Cplx* Xc = d.X + ((uint64_t)pair * d.cin + d.terms[term].in_ch) * nb * n + pos;
+  c2v* Yc = reinterpret_cast<c2v*>(d.Y + ((uint64_t)pair * d.cout + co) * nb * n + pos);
+  const c2v* Hc = reinterpret_cast<const c2v*>(d.H + (uint64_t)d.terms[term].ir_ch * P * n + pos);
+  const c2v* Xc = reinterpret_cast<const c2v*>(d.X + ((uint64_t)pair * d.cin + d.terms[term].in_ch) * nb * n + pos);
+  const c2v zero = {0.f, 0.f};
   // Loads are unconditional (clamped index, the zero selected afterwards): behind `i < P ? load : 0` the compiler
   // branched around every load and waited for it on the spot — 22 memory latencies in a row before the first product
   // (about half of a workgroup's life), and again one full latency per k-tile before any of its arithmetic.
-  Cplx h[PC];
+  c2v h[PC];
 #pragma unroll
   for (int i = 0; i < PC; i++) h[i] = Hc[(uint64_t)(i < P ? i : 0) * n];
 #pragma unroll
   for (int i = 0; i < PC; i++)
-    if (i >= P) h[i] = Cplx{0.f, 0.f};
-  Cplx win[PC - 1];  // X_{k0 - (PC-1)} .. X_{k0 - 1}
+    if (i >= P) h[i] = zero;
+  c2v win[PC - 1];  // X_{k0 - (PC-1)} .. X_{k0 - 1}
 #pragma unroll
-  for (int i = 0; i < PC - 1; i++) win[i] = Cplx{0.f, 0.f};
+  for (int i = 0; i < PC - 1; i++) win[i] = zero;
   for (int k0 = 0; k0 < nb; k0 += KT) {
-    Cplx xn[KT];  // X_{k0} .. X_{k0 + KT - 1}
+    c2v xn[KT];  // X_{k0} .. X_{k0 + KT - 1}
 #pragma unroll
     for (int i = 0; i < KT; i++) xn[i] = Xc[(uint64_t)(k0 + i < nb ? k0 + i : nb - 1) * n];
 #pragma unroll
     for (int i = 0; i < KT; i++)
-      if (k0 + i >= nb) xn[i] = Cplx{0.f, 0.f};
-    Cplx acc[KT];
+      if (k0 + i >= nb) xn[i] = zero;
+    c2v acc[KT];
 #pragma unroll
-    for (int i = 0; i < KT; i++) acc[i] = Cplx{0.f, 0.f};
+    for (int i = 0; i < KT; i++) acc[i] = zero;
 #pragma clang loop unroll(full)
     for (int jj = 0; jj < KT + PC - 1; jj++) {
-      const Cplx x = jj < PC - 1 ? win[jj < PC - 1 ? jj : 0] : xn[jj >= PC - 1 ? jj - (PC - 1) : 0];
+      const c2v x = jj < PC - 1 ? win[jj < PC - 1 ? jj : 0] : xn[jj >= PC - 1 ? jj - (PC - 1) : 0];
 #pragma clang loop unroll(full)
       for (int i = 0; i < KT; i++) {
         const int pl = i + (PC - 1) - jj;  // partition index, compile-time after unrolling
         if (pl >= 0 && pl < PC) {
-          acc[i].re = __builtin_fmaf(h[pl].re, x.re, acc[i].re);
-          acc[i].re = __builtin_fmaf(-h[pl].im, x.im, acc[i].re);
-          acc[i].im = __builtin_fmaf(h[pl].re, x.im, acc[i].im);
-          acc[i].im = __builtin_fmaf(h[pl].im, x.re, acc[i].im);
+          cmac_pk(acc[i], h[pl], x);
         }
       }
     }
