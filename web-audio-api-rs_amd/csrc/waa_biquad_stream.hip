@@ -126,7 +126,10 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
                             : sig_base + (uint64_t)tile * TILE;
 #pragma unroll
     for (int j = 0; j < NV4; j++) {
-      const f4v t = load_global_f4(p + j * 256 + lane * 4);
+      // streamed once: non-temporal (same-box A/B on C2, tools/ab_env.py WAA_STREAM_DEBUG=5: 1.588 against 1.610 ms, ten
+      // alternations; stores alone make no difference)
+      const f4v t = DBG == 5 ? load_global_f4(p + j * 256 + lane * 4)
+                             : __builtin_nontemporal_load((const WAA_GLOBAL_AS f4v*)(p + j * 256 + lane * 4));
       dst[j * 4 + 0] = t.x;
       dst[j * 4 + 1] = t.y;
       dst[j * 4 + 2] = t.z;
@@ -170,9 +173,12 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
         }
       if constexpr (DBG == 2) {
         asm volatile("" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
-      } else {
+      } else if constexpr (DBG == 5) {  // (A/B: the plain loads and stores)
         *reinterpret_cast<float4*>(op + j * 256 + lane * 4) = t;
-        if constexpr (DUP) *reinterpret_cast<float4*>(op + d.out.ch_stride + j * 256 + lane * 4) = t;
+      } else {
+        __builtin_nontemporal_store(f4v{t.x, t.y, t.z, t.w}, (WAA_GLOBAL_AS f4v*)(op + j * 256 + lane * 4));
+        if constexpr (DUP)
+          __builtin_nontemporal_store(f4v{t.x, t.y, t.z, t.w}, (WAA_GLOBAL_AS f4v*)(op + d.out.ch_stride + j * 256 + lane * 4));
       }
     }
     lds_sync();
@@ -963,6 +969,8 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
     hipLaunchKernelGGL((biquad_stream_kernel_t<1, 0>), grid, block, lds, (hipStream_t)stream, d);
   else if (dbg && dbg[0] == '2')
     hipLaunchKernelGGL((biquad_stream_kernel_t<2, 0>), grid, block, lds, (hipStream_t)stream, d);
+  else if (dbg && dbg[0] == '5')
+    hipLaunchKernelGGL((biquad_stream_kernel_t<5, 0>), grid, block, lds, (hipStream_t)stream, d);
   else if (getenv("WAA_STREAM_PREFETCH2"))  // experiment (A/B with tools/ab_env.py)
     hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 4>), grid, block, lds, (hipStream_t)stream, d);
   else if (getenv("WAA_BIQUAD_DIGEST"))  // experiment, bit-identical output; same-box A/B (tools/ab_env.py): no gain — with 4

@@ -291,6 +291,27 @@ __global__ void conv_fft_kernel(const ConvDesc d) {
 //     loaded once per workgroup and lives in registers: no global loads inside the butterfly stages.
 // The arithmetic and its order are those of fft_dif_padded / fft_dit_inv_padded for n = 16384 (which butterfly a thread
 // executes does not change any value): results are bit-identical to the plain kernel (WAA_CONV_FFT_PLAIN=1 selects it; tests compare the two).
+// Cache policy of the streamed buffers (compile-time, -DWAA_CONV_POL=n for an A/B library, tools/ab_lib.py): bit 0 =
+// non-temporal loads, bit 1 = non-temporal stores.  Measured on T1 (three alternations of all four builds on one box): no
+// policy moves any of the three kernels outside the run-to-run spread (fwd 2.71-2.86, product 3.08-3.48, inv 3.09-3.26 ms),
+// so the plain forms stay.  (The streaming biquad does gain 1.4 % from non-temporal loads, waa_biquad_stream.hip.)
+#ifndef WAA_CONV_POL
+#define WAA_CONV_POL 0
+#endif
+template <class T>
+__device__ __forceinline__ T ld_pol(const T* p) {
+  if constexpr (WAA_CONV_POL & 1)
+    return __builtin_nontemporal_load(p);
+  else
+    return *p;
+}
+template <class T>
+__device__ __forceinline__ void st_pol(T* p, T v) {
+  if constexpr (WAA_CONV_POL & 2)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
 constexpr int PIPE_N = 16384, PIPE_NT = 512, PIPE_B = PIPE_N / 2;
 constexpr int PIPE_IT = PIPE_N / 4 / PIPE_NT;     // radix-4 butterflies per thread in the q = 16 stage (8)
 constexpr int PIPE_ROWS = PIPE_N / 16 / PIPE_NT;  // 16-element register rows per thread in the tail (2)
@@ -487,8 +508,8 @@ __device__ __forceinline__ void pipe_load_half(const float* pa, const float* pb,
     const int64_t f = f0 + 4 * (int64_t)(tid + r * PIPE_NT);
     const bool ok = f >= 0 && (uint64_t)f + 3 < frames;
     const int64_t fc = ok ? f : 0;
-    va[r] = *reinterpret_cast<const f4v*>(pa + fc);
-    vb[r] = *reinterpret_cast<const f4v*>(pb + fc);
+    va[r] = ld_pol(reinterpret_cast<const f4v*>(pa + fc));
+    vb[r] = ld_pol(reinterpret_cast<const f4v*>(pb + fc));
   }
 }
 __device__ __forceinline__ void pipe_stage_half(Cplx* a, int e0, int tid, const f4v (&va)[PIPE_H], const f4v (&vb)[PIPE_H], bool has_b,
@@ -572,7 +593,7 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
         if (DBG == 1)
           asm volatile("" ::"v"(v));
         else
-          dst[i] = v;
+          st_pol(dst + i, v);
       }
       pipe_barrier();  // LDS is rewritten by the next window
     }
@@ -583,7 +604,7 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
     const f4v* ybase = reinterpret_cast<const f4v*>(d.Y + ((uint64_t)pair * d.cout + c) * d.nb * PIPE_N);
     f4v y[PIPE_S];
 #pragma unroll
-    for (int r = 0; r < PIPE_S; r++) y[r] = ybase[(uint64_t)k0 * (PIPE_N / 2) + tid + r * PIPE_NT];
+    for (int r = 0; r < PIPE_S; r++) y[r] = ld_pol(ybase + (uint64_t)k0 * (PIPE_N / 2) + tid + r * PIPE_NT);
     pipe_settle(y);  // (as in the forward kernel)
     for (int k = k0; k < k1; k++) {
       int tid_k = tid;
@@ -595,7 +616,7 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
       const int kn = k + 1 < k1 ? k + 1 : k;
 #pragma unroll
       for (int r = 0; r < PIPE_S; r++)
-        if (DBG != 2) y[r] = ybase[(uint64_t)kn * (PIPE_N / 2) + tid_k + r * PIPE_NT];
+        if (DBG != 2) y[r] = ld_pol(ybase + (uint64_t)kn * (PIPE_N / 2) + tid_k + r * PIPE_NT);
       pipe_fft_dit_inv(a, w, d.tw, tid_k, tws);
       pipe_settle(y);
 #pragma unroll
@@ -611,8 +632,8 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
           if (DBG == 1) {
             asm volatile("" ::"v"(va), "v"(vb));
           } else {
-            *reinterpret_cast<f4v*>(pa + f) = va;
-            if (has_b) *reinterpret_cast<f4v*>(pb + f) = vb;
+            st_pol(reinterpret_cast<f4v*>(pa + f), va);
+            if (has_b) st_pol(reinterpret_cast<f4v*>(pb + f), vb);
           }
         }
       }
@@ -714,7 +735,7 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
   for (int k0 = 0; k0 < nb; k0 += KT) {
     c2v xn[KT];  // X_{k0} .. X_{k0 + KT - 1}
 #pragma unroll
-    for (int i = 0; i < KT; i++) xn[i] = Xc[(uint64_t)(k0 + i < nb ? k0 + i : nb - 1) * n];
+    for (int i = 0; i < KT; i++) xn[i] = ld_pol(Xc + (uint64_t)(k0 + i < nb ? k0 + i : nb - 1) * n);
 #pragma unroll
     for (int i = 0; i < KT; i++)
       if (k0 + i >= nb) xn[i] = zero;
@@ -734,7 +755,7 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
     }
 #pragma unroll
     for (int i = 0; i < KT; i++)
-      if (k0 + i < nb) Yc[(uint64_t)(k0 + i) * n] = acc[i];
+      if (k0 + i < nb) st_pol(Yc + (uint64_t)(k0 + i) * n, acc[i]);
     // slide the window by KT blocks
 #pragma unroll
     for (int w = 0; w < PC - 1; w++) {
