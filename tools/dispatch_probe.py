@@ -1,0 +1,89 @@
+"""tools/dispatch_probe.py — where and when the 2048 wavefronts of the C2 launch run (WAA_STREAM_DEBUG=7 records start / end
+time, HW_ID and XCC_ID per wavefront): batches are created until a fast and a slow one have been seen, and both traces are
+summarised (wavefronts per XCD / CU / SIMD, spread of start and end times, duration per wavefront).  (GPU box)"""
+import collections
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import web_audio_api_rs_amd as waa  # noqa: E402
+from placement_probe import timed  # noqa: E402
+
+n_inst, frames = 1024, 480000
+hip = waa.default_binding()
+lib = ctypes.CDLL(waa.LIB_PATH)
+noise = torch.empty((n_inst, 2, frames), dtype=torch.float32, device="cuda").uniform_(-1, 1)
+
+
+def trace(ctx, mode="7"):
+    os.environ["WAA_STREAM_DEBUG"] = mode
+    ctx.render_async()
+    ctx.sync()
+    os.environ.pop("WAA_STREAM_DEBUG")
+    buf = np.zeros(2048 * 4, dtype=np.uint64)
+    assert lib.waa_debug_stream_trace(buf.ctypes.data_as(ctypes.c_void_p), buf.size) == 0
+    return buf.reshape(2048, 4)
+
+
+def summarise(tag, ms, t):
+    t0, t1, hw, xcc = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2].astype(np.int64), t[:, 3].astype(np.int64) & 0xF
+    base = t0.min()
+    simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+    per_xcd = collections.Counter(xcc.tolist())
+    per_cu = collections.Counter(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))
+    per_simd = collections.Counter(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist(), simd.tolist()))
+    dur = (t1 - t0) / 100.0  # us (100 MHz counter)
+    print(f"{tag}: kernel {ms} ms; start spread {(t0.max() - base) / 100.0:.1f} us, end spread {(t1.max() - t1.min()) / 100.0:.1f} us, "
+          f"duration min/median/max {dur.min():.0f}/{np.median(dur):.0f}/{dur.max():.0f} us")
+    print(f"   per XCD {sorted(per_xcd.items())}")
+    print(f"   CUs used {len(per_cu)}, wavefronts per CU histogram {sorted(collections.Counter(per_cu.values()).items())}, "
+          f"per SIMD histogram {sorted(collections.Counter(per_simd.values()).items())}")
+    late = np.argsort(t0)[-8:]
+    print(f"   latest starters: {[(int(w), round((int(t0[w]) - int(base)) / 100.0, 1), round(float(dur[w]), 0)) for w in late]}")
+    def med_by(name, key):
+        g = collections.defaultdict(list)
+        for w in range(len(dur)):
+            g[int(key[w])].append(dur[w])
+        print(f"   median duration by {name}:", {k: int(np.median(v)) for k, v in sorted(g.items())})
+
+    wid = np.arange(len(dur))
+    med_by("XCD", xcc)
+    med_by("SE", se)
+    med_by("CU id", cu)
+    med_by("SIMD", simd)
+    med_by("channel (wid % 2)", wid % 2)
+    med_by("wid // 256", wid // 256)
+    med_by("wave slot", hw & 15)
+    slowest = np.argsort(dur)[-12:]
+    print("   slowest wavefronts (wid, xcd, se, cu, simd, us):",
+          [(int(w), int(xcc[w]), int(se[w]), int(cu[w]), int(simd[w]), int(dur[w])) for w in slowest])
+    fastest = np.argsort(dur)[:12]
+    print("   fastest wavefronts (wid, xcd, se, cu, simd, us):",
+          [(int(w), int(xcc[w]), int(se[w]), int(cu[w]), int(simd[w]), int(dur[w])) for w in fastest])
+    # duration against the number of wavefronts sharing the CU
+    by = collections.defaultdict(list)
+    for w in range(len(dur)):
+        by[per_cu[(int(xcc[w]), int(se[w]), int(sh[w]), int(cu[w]))]].append(dur[w])
+    print("   median duration by wavefronts on the same CU:", {k: round(float(np.median(v)), 0) for k, v in sorted(by.items())})
+
+
+seen = {}
+for trial in range(24):
+    ctx, _ = bench.build_workload(waa, hip, "c2", n_inst, frames, 0, noise.data_ptr())
+    ctx.prepare()
+    ctx.render_async()
+    ctx.sync()
+    ctx.profile(True)
+    ms = list(timed(ctx).values())[0]
+    kind = "fast" if ms < 1.42 else "slow" if ms > 1.52 else None
+    if kind and kind not in seen:
+        seen[kind] = True
+        summarise(kind, ms, trace(ctx))
+    ctx.close()
+    if len(seen) == 2:
+        break

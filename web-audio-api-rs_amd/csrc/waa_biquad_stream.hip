@@ -38,6 +38,9 @@ __device__ __forceinline__ M2 mm(const M2& x, const M2& y) {
 
 }  // namespace
 
+// (WAA_STREAM_DEBUG=7, tools/dispatch_probe.py: where and when every wavefront of the last launch ran)
+__device__ unsigned long long g_stream_trace[8192 * 4];
+
 // DBG is a measurement aid (WAA_STREAM_DEBUG): 0 = product kernel, 1 = same memory pattern without the recurrence,
 // 2 = recurrence without the stores (results are wrong by construction in modes 1 and 2)
 // VARY = 1: coefficients change per render quantum (k-rate automation; d.coefs holds n_quanta sets per instance):
@@ -61,6 +64,8 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
   // f64 (and f16) denormals: flush inputs and outputs, like the reference's FTZ/DAZ render scope.
   // hwreg(HW_REG_MODE = 1, offset 6, width 2)
   __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);
+  unsigned long long trace_t0 = 0;
+  if constexpr (DBG == 7) trace_t0 = wall_clock64();
 
   // coefficients: uniform per wave (constant params) or reloaded per tile and lane (VARY)
   const double* cp = d.coefs + (uint64_t)inst * d.coef_stride;
@@ -609,6 +614,14 @@ __global__ __launch_bounds__(64, 2) void biquad_stream_kernel_t(const BiquadStre
     st[2] = cy1;
     st[3] = cy2;
   }
+  if constexpr (DBG == 7) {
+    if (lane == 0 && wid < 8192) {
+      g_stream_trace[wid * 4 + 0] = trace_t0;
+      g_stream_trace[wid * 4 + 1] = wall_clock64();
+      g_stream_trace[wid * 4 + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+      g_stream_trace[wid * 4 + 3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -971,6 +984,8 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
     hipLaunchKernelGGL((biquad_stream_kernel_t<2, 0>), grid, block, lds, (hipStream_t)stream, d);
   else if (dbg && dbg[0] == '5')
     hipLaunchKernelGGL((biquad_stream_kernel_t<5, 0>), grid, block, lds, (hipStream_t)stream, d);
+  else if (dbg && dbg[0] == '7')
+    hipLaunchKernelGGL((biquad_stream_kernel_t<7, 0>), grid, block, lds, (hipStream_t)stream, d);
   else if (getenv("WAA_STREAM_PREFETCH2"))  // experiment (A/B with tools/ab_env.py)
     hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 4>), grid, block, lds, (hipStream_t)stream, d);
   else if (getenv("WAA_BIQUAD_DIGEST"))  // experiment, bit-identical output; same-box A/B (tools/ab_env.py): no gain — with 4
@@ -983,3 +998,8 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
 }
 
 }  // namespace waa
+
+// (measurement aid, not part of include/waa_hip.h: copies the trace of the last WAA_STREAM_DEBUG=7 launch)
+extern "C" int waa_debug_stream_trace(unsigned long long* dst, unsigned n_words) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(waa::g_stream_trace), (size_t)n_words * 8);
+}
