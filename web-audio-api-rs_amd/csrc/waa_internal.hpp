@@ -131,7 +131,7 @@ struct ChainDesc {
   uint32_t n_inst;
   uint32_t n_tiles;
   uint32_t n_quanta;
-  uint32_t pad;
+  uint32_t xcd_remap;      // set by the launcher: workgroup -> XCD-contiguous ranges of the (instance, sub-tile) order
   uint32_t tile0, tile1;   // tiles [tile0, tile1) of this launch (block-scheduled feedback loops); full range otherwise
   int32_t lds_curve_op;    // set by the launcher: op whose WaveShaper curve is staged in LDS (-1: none)
   int32_t tile_major;      // set by the launcher: wave index -> (sub-tile, instance) instead of (instance, sub-tile)

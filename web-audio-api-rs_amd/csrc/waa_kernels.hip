@@ -664,7 +664,15 @@ void chain_kernel(const ChainDesc d) {
     tile_last = d.tile1 * (TILE / TILE_FR);
   } else {
     // (readfirstlane: the wave index is uniform; telling the compiler keeps instance / tile addressing in SGPRs)
-    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Workgroup b runs on XCD b % 8.  In (instance, sub-tile) order the XCDs are dealt CONTIGUOUS ranges of it: what a
+    // workgroup re-reads of its predecessors' input — a folded delay line reads the same signal a few sub-tiles back —
+    // was then fetched by the same XCD a moment ago and is an L2 hit instead of a second trip to memory.
+    uint32_t blk = blockIdx.x;
+    if (d.xcd_remap) {
+      const uint32_t q = gridDim.x / 8, r = gridDim.x % 8, x = blk % 8, j = blk / 8;
+      blk = x * q + (x < r ? x : r) + j;
+    }
+    const uint64_t wid = (uint64_t)blk * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (d.tile_major) {
       // neighbouring waves render the SAME sub-tile of different instances: the per-frame playback table of a
       // resampling source (16 B per frame, shared by all instances of a schedule) is then reused out of L2 instead
@@ -1071,6 +1079,9 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
     dd.tile_major = 0;
     for (int k = 0; k < d.n_inputs; k++) dd.tile_major |= d.in[k].kind == IN_SOURCE;
     if (getenv("WAA_NO_TILE_MAJOR")) dd.tile_major = 0;  // measurement aid
+    // (same-batch A/B, tools/placement_probe.py with ALT=WAA_NO_XCD_REMAP=1: echo 2.01 against 2.06 ms, the pan stage of C4
+    // 1.39-1.44 against 1.44-1.46 ms)
+    dd.xcd_remap = !dd.tile_major && !getenv("WAA_NO_XCD_REMAP");
     for (int o = 0; o < d.n_ops; o++)
       if (d.ops[o].kind == OP_WAVESHAPER && d.ops[o].i0 > 0 && d.ops[o].i0 <= 8192) {
         dd.lds_curve_op = o;
