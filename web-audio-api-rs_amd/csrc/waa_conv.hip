@@ -880,6 +880,7 @@ static void allow_big_lds(size_t bytes) {
 }
 
 void launch_conv_ir_spectra(const ConvDesc& d, void* stream) {
+  if (d.fft3) return launch_conv3_ir_spectra(d, stream);
   allow_big_lds((size_t)d.n * sizeof(Cplx));
   hipLaunchKernelGGL(conv_fft_kernel<MODE_IR>, dim3(d.parts, d.ir_nch, 1), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
                      (hipStream_t)stream, d);
@@ -895,6 +896,7 @@ static int pipe_blocks_per_wg(const ConvDesc& d, int channels) {
 static bool use_pipe(const ConvDesc& d) { return d.n == PIPE_N && !getenv("WAA_CONV_FFT_PLAIN"); }
 
 void launch_conv_forward(const ConvDesc& d, void* stream) {
+  if (d.fft3) return launch_conv3_forward(d, stream);
   allow_big_lds((size_t)d.n * sizeof(Cplx));
   if (use_pipe(d)) {
     const int bpw = pipe_blocks_per_wg(d, d.cin);
@@ -913,6 +915,7 @@ void launch_conv_forward(const ConvDesc& d, void* stream) {
                      (hipStream_t)stream, d);
 }
 void launch_conv_inverse(const ConvDesc& d, void* stream) {
+  if (d.fft3) return launch_conv3_inverse(d, stream);
   allow_big_lds((size_t)d.n * sizeof(Cplx));
   if (use_pipe(d)) {
     const int bpw = pipe_blocks_per_wg(d, d.cout);

@@ -198,7 +198,8 @@ struct ConvDesc {
   int32_t block;    // partition size B
   int32_t parts;    // P = ceil(trimmed IR length / B)
   int32_t nb;       // number of output blocks = ceil(frames / B)
-  int32_t pad0;
+  int32_t fft3;     // n == 16384: the three-register-pass transforms (waa_conv3.hip); the spectra are then stored in THEIR
+                    // position order (decided when the impulse response's spectra are computed, i.e. at plan time)
   ConvTerm terms[4];
   const Cplx* H;    // [ir_nch][P][n] spectra of the IR partitions (bit-reversed order)
   Cplx* X;          // [n_pairs][cin][nb][n] input spectra of instance pairs (a + i b)
@@ -233,6 +234,10 @@ void launch_conv_ir_spectra(const ConvDesc& d, void* stream);
 void launch_conv_forward(const ConvDesc& d, void* stream);
 void launch_conv_mac(const ConvDesc& d, void* stream);
 void launch_conv_inverse(const ConvDesc& d, void* stream);
+// waa_conv3.hip (n == 16384 and d.fft3)
+void launch_conv3_ir_spectra(const ConvDesc& d, void* stream);
+void launch_conv3_forward(const ConvDesc& d, void* stream);
+void launch_conv3_inverse(const ConvDesc& d, void* stream);
 
 // ---- DelayNode outside a cycle (delay.rs:428-745) as a gather from its materialised input ---------
 struct DelayDesc {

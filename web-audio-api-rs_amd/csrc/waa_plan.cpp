@@ -2731,6 +2731,7 @@ int plan_convolver(waa_batch* b, uint32_t id) {
     }
   cv.block = B;
   cv.n = 2 * B;
+  cv.fft3 = cv.n == 16384 && !getenv("WAA_CONV_FFT_R4");  // (the round-2 radix-4-in-LDS kernels: same-box A/B only)
   cv.parts = (int)((len + B - 1) / B);
   cv.nb = (int)((b->lp + B - 1) / B);
   cv.cin = n.in_nch;
