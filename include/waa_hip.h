@@ -310,6 +310,16 @@ waa_status waa_analyser_get_float_time_domain_data(waa_batch* batch, uint32_t no
                                                    uint32_t n);
 waa_status waa_analyser_get_byte_time_domain_data(waa_batch* batch, uint32_t node, uint32_t instance, uint8_t* dst,
                                                   uint32_t n);
+/* The same pulls for EVERY instance of the batch at once: one launch (one workgroup per context), one transfer.  Replaces
+ * the loop "for ctx in contexts: analyser.get_float_frequency_data(&mut bins)" a caller of the reference runs after N
+ * start_rendering_sync calls (src/node/analyser.rs:228-258 -> src/analysis.rs:261-401; BASELINE config 4 pulls once per
+ * context).  dst is [n_instances][n]; row i receives what the per-instance call returns for instance i (min(n,
+ * frequencyBinCount) resp. min(n, fftSize) values, the rest of the row untouched).  The per-instance calls above are
+ * views into the same cached result. */
+waa_status waa_analyser_get_float_frequency_data_batch(waa_batch* batch, uint32_t node, float* dst, uint32_t n);
+waa_status waa_analyser_get_byte_frequency_data_batch(waa_batch* batch, uint32_t node, uint8_t* dst, uint32_t n);
+waa_status waa_analyser_get_float_time_domain_data_batch(waa_batch* batch, uint32_t node, float* dst, uint32_t n);
+waa_status waa_analyser_get_byte_time_domain_data_batch(waa_batch* batch, uint32_t node, uint8_t* dst, uint32_t n);
 
 /* ---- introspection --------------------------------------------------------------------- */
 

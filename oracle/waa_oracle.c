@@ -3903,6 +3903,41 @@ waa_status orc_analyser_get_byte_time_domain_data(orc_batch* b, uint32_t node, u
   return WAA_OK;
 }
 
+/* the batch forms of the boundary (include/waa_hip.h): here simply the per-context pulls a caller of the reference
+ * runs, one after the other (src/node/analyser.rs:228-258); dst rows of nn elements */
+waa_status orc_analyser_get_float_frequency_data_batch(orc_batch* b, uint32_t node, float* dst, uint32_t nn) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  for (uint32_t i = 0; i < b->n_inst; i++) {
+    int e = orc_analyser_get_float_frequency_data(b, node, i, dst + (size_t)i * nn, nn);
+    if (e) return e;
+  }
+  return WAA_OK;
+}
+waa_status orc_analyser_get_byte_frequency_data_batch(orc_batch* b, uint32_t node, uint8_t* dst, uint32_t nn) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  for (uint32_t i = 0; i < b->n_inst; i++) {
+    int e = orc_analyser_get_byte_frequency_data(b, node, i, dst + (size_t)i * nn, nn);
+    if (e) return e;
+  }
+  return WAA_OK;
+}
+waa_status orc_analyser_get_float_time_domain_data_batch(orc_batch* b, uint32_t node, float* dst, uint32_t nn) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  for (uint32_t i = 0; i < b->n_inst; i++) {
+    int e = orc_analyser_get_float_time_domain_data(b, node, i, dst + (size_t)i * nn, nn);
+    if (e) return e;
+  }
+  return WAA_OK;
+}
+waa_status orc_analyser_get_byte_time_domain_data_batch(orc_batch* b, uint32_t node, uint8_t* dst, uint32_t nn) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  for (uint32_t i = 0; i < b->n_inst; i++) {
+    int e = orc_analyser_get_byte_time_domain_data(b, node, i, dst + (size_t)i * nn, nn);
+    if (e) return e;
+  }
+  return WAA_OK;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* oracle-only helpers                                                                    */
 /* ------------------------------------------------------------------------------------ */

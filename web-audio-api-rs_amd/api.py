@@ -122,6 +122,10 @@ ABI = {
     "analyser_get_byte_frequency_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32]),
     "analyser_get_float_time_domain_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FP, C.c_uint32]),
     "analyser_get_byte_time_domain_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32]),
+    "analyser_get_float_frequency_data_batch": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32]),
+    "analyser_get_byte_frequency_data_batch": (C.c_int32, [_VP, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32]),
+    "analyser_get_float_time_domain_data_batch": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32]),
+    "analyser_get_byte_time_domain_data_batch": (C.c_int32, [_VP, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32]),
     "hrtf_load_sphere": (C.c_int32, [C.c_char_p, C.c_uint64]),
     "hrtf_hrir_length": (C.c_uint32, [C.c_float]),
     "hrtf_sample": (None, [C.c_float, _FP, _FP, _FP]),
@@ -725,6 +729,30 @@ class AnalyserNode(AudioNode):
         ptr = out.ctypes.data_as(_FP if dtype == np.float32 else C.POINTER(C.c_uint8))
         ctx._b.check(getattr(ctx._b, fn_name)(ctx._handle, self.id, instance, ptr, n))
         return out
+
+    def _pull_all(self, fn_name: str, n: int, dtype, out=None):
+        """[n_instances][n]: every context's pull in one call (one launch, one transfer on the device)."""
+        ctx = self.context
+        if ctx._handle is None:
+            raise WaaError(3, "InvalidStateError - analyser data is only available after start_rendering_sync")
+        if out is None:
+            out = np.zeros((ctx.n_instances, n), dtype=dtype)
+        assert out.shape == (ctx.n_instances, n) and out.dtype == dtype and out.flags.c_contiguous
+        ptr = out.ctypes.data_as(_FP if dtype == np.float32 else C.POINTER(C.c_uint8))
+        ctx._b.check(getattr(ctx._b, fn_name)(ctx._handle, self.id, ptr, n))
+        return out
+
+    def get_float_frequency_data_all(self, n: Optional[int] = None, out=None) -> np.ndarray:
+        return self._pull_all("analyser_get_float_frequency_data_batch", n or self.frequency_bin_count, np.float32, out)
+
+    def get_byte_frequency_data_all(self, n: Optional[int] = None, out=None) -> np.ndarray:
+        return self._pull_all("analyser_get_byte_frequency_data_batch", n or self.frequency_bin_count, np.uint8, out)
+
+    def get_float_time_domain_data_all(self, n: Optional[int] = None, out=None) -> np.ndarray:
+        return self._pull_all("analyser_get_float_time_domain_data_batch", n or self.fft_size, np.float32, out)
+
+    def get_byte_time_domain_data_all(self, n: Optional[int] = None, out=None) -> np.ndarray:
+        return self._pull_all("analyser_get_byte_time_domain_data_batch", n or self.fft_size, np.uint8, out)
 
     def get_float_frequency_data(self, n: Optional[int] = None, instance: int = 0) -> np.ndarray:
         return self._pull("analyser_get_float_frequency_data", n or self.frequency_bin_count, instance, np.float32)

@@ -679,7 +679,7 @@ waa_status waa_render(waa_batch* b) {
   // every render starts from the initial state (offline contexts render exactly once; re-rendering the
   // same batch is what the benchmark loop does)
   for (auto& sb : b->state_bufs) HIP_TRY(hipMemsetAsync(sb.first, 0, sb.second, b->stream));
-  for (auto& n : b->nodes) n.an_cache.clear();
+  for (auto& n : b->nodes) n.an = Node::AnBatch{};
   b->rendered = true;
   auto timed = [&](int slot, auto&& launch) -> int {
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -873,24 +873,29 @@ waa_status waa_output_device(waa_batch* b, const float** p, uint64_t* is, uint64
   return WAA_OK;
 }
 
-// AnalyserNode pulls (analysis.rs:261-401).  current_time after an offline render never changes, so the
-// spectrum is computed once per (node, instance) and repeated pulls return the same data (analysis.rs:354-357).
-static int analyser_compute(waa_batch* b, uint32_t node, uint32_t inst, Node::AnCache** out) {
+// AnalyserNode pulls (analysis.rs:261-401).  current_time after an offline render never changes, so the spectra of ALL
+// instances are computed once per render — one launch, one workgroup per context — and every pull, per instance or for
+// the whole batch, is a view into that result (repeated pulls return the same data, analysis.rs:354-357).
+enum { AN_DB = 0, AN_BYTES = 1, AN_TIME = 2 };
+static int analyser_compute(waa_batch* b, uint32_t node, int what) {
   int e;
   if ((e = check_node(b, node, WAA_NODE_ANALYSER))) return e;
-  if (inst >= b->n_inst) return fail(WAA_ERR_INVALID_ARGUMENT, "instance out of range");
   Node& n = b->nodes[node];
   const int N = n.desc.i[0], M = N / 2;
-  auto it = n.an_cache.find(inst);
-  if (it != n.an_cache.end()) {
-    *out = &it->second;
+  const size_t ni = b->n_inst;
+  const bool on_device = b->planned && b->rendered && n.live && !b->dry;
+  if (!on_device) {
+    // nothing rendered (or the node does not reach the destination): an all-zero ring buffer
+    if (!n.an.have_db) {
+      n.an.db.assign(ni * M, -INFINITY);   // 20 log10(0)
+      n.an.bytes.assign(ni * M, 0);        // (-inf - min) scaled and clamped
+      n.an.time.assign(ni * N, 0.f);
+      n.an.have_db = n.an.have_bytes = n.an.have_time = true;
+    }
     return 0;
   }
-  Node::AnCache cache;
-  cache.spec.assign(M, 0.f);
-  cache.time.assign(N, 0.f);
-  if (b->planned && b->rendered && n.live) {
-    HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipSetDevice(b->device));
+  if (!n.an.computed) {
     if (!n.d_window) {
       // generate_blackman (analysis.rs:14-24), f32 with the host libm the reference's f32::cos resolves to
       std::vector<float> win(N);
@@ -907,77 +912,135 @@ static int analyser_compute(waa_batch* b, uint32_t node, uint32_t inst, Node::An
       std::vector<float> zeros(M, 0.f);
       if ((e = dev_upload(b, &n.d_window, win)) || (e = dev_upload(b, &n.d_an_tw, tw)) ||
           (e = dev_upload(b, &n.d_an_twfull, twf)) || (e = dev_upload(b, &n.d_an_prev, zeros)) ||
-          (e = dev_alloc(b, &n.d_an_spec, (size_t)M)) || (e = dev_alloc(b, &n.d_an_time, (size_t)N)))
+          (e = dev_alloc(b, &n.d_an_db, ni * M)) || (e = dev_alloc(b, &n.d_an_bytes, ni * M)) ||
+          (e = dev_alloc(b, &n.d_an_time, ni * N)))
         return e;
     }
     AnalyserDesc ad{};
     ad.sig = n.sig;
-    ad.inst = inst;
+    ad.n_inst = b->n_inst;
     ad.fft_size = N;
     ad.frames_written = (uint64_t)b->n_quanta * RQ;
     ad.smoothing = (float)n.desc.d[0];
+    ad.min_db = (float)n.desc.d[1];
+    ad.max_db = (float)n.desc.d[2];
     ad.window = n.d_window;
     ad.tw = n.d_an_tw;
     ad.tw_full = n.d_an_twfull;
     ad.prev = n.d_an_prev;
-    ad.spec_out = n.d_an_spec;
+    ad.db_out = n.d_an_db;
+    ad.byte_out = n.d_an_bytes;
     ad.time_out = n.d_an_time;
+    int slot = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (b->profiling) {
+      slot = slot_for(b, "analyser_kernel");
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, b->stream));
+    }
     launch_analyser(ad, b->stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    HIP_TRY(hipMemcpy(cache.spec.data(), n.d_an_spec, (size_t)M * sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cache.time.data(), n.d_an_time, (size_t)N * sizeof(float), hipMemcpyDeviceToHost));
+    if (slot >= 0) {
+      HIP_TRY(hipEventRecord(e1, b->stream));
+      b->prof[slot].pending.push_back({e0, e1});
+    }
+    n.an.computed = true;
   }
-  auto ins = n.an_cache.emplace(inst, std::move(cache));
-  *out = &ins.first->second;
+  // one transfer per kind of result, on first use (asynchronous on the batch's stream, then waited for)
+  if (what == AN_DB && !n.an.have_db) {
+    n.an.db.resize(ni * M);
+    HIP_TRY(hipMemcpyAsync(n.an.db.data(), n.d_an_db, ni * M * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    n.an.have_db = true;
+  } else if (what == AN_BYTES && !n.an.have_bytes) {
+    n.an.bytes.resize(ni * M);
+    HIP_TRY(hipMemcpyAsync(n.an.bytes.data(), n.d_an_bytes, ni * M, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    n.an.have_bytes = true;
+  } else if (what == AN_TIME && !n.an.have_time) {
+    n.an.time.resize(ni * N);
+    HIP_TRY(hipMemcpyAsync(n.an.time.data(), n.d_an_time, ni * N * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    n.an.have_time = true;
+  }
+  return 0;
+}
+// rows [i0, i1) of one result kind -> dst rows of `nn` elements
+static int analyser_rows(waa_batch* b, uint32_t node, int what, uint32_t i0, uint32_t i1, void* dst, uint32_t nn) {
+  int e = analyser_compute(b, node, what);
+  if (e) return e;
+  const Node& n = b->nodes[node];
+  const uint32_t N = (uint32_t)n.desc.i[0], M = N / 2;
+  for (uint32_t i = i0; i < i1; i++) {
+    const size_t row = (size_t)(i - i0) * nn;
+    if (what == AN_DB) {
+      std::memcpy((float*)dst + row, &n.an.db[(size_t)i * M], std::min(nn, M) * sizeof(float));
+    } else if (what == AN_BYTES) {
+      std::memcpy((uint8_t*)dst + row, &n.an.bytes[(size_t)i * M], std::min(nn, M));
+    } else {
+      // ring_buffer.read: the most recent `len` frames (analysis.rs:114-127)
+      const uint32_t len = std::min(nn, N);
+      std::memcpy((float*)dst + row, &n.an.time[(size_t)i * N + (N - len)], len * sizeof(float));
+    }
+  }
+  return WAA_OK;
+}
+static int analyser_byte_time_rows(waa_batch* b, uint32_t node, uint32_t i0, uint32_t i1, uint8_t* dst, uint32_t nn) {
+  int e = analyser_compute(b, node, AN_TIME);
+  if (e) return e;
+  const Node& n = b->nodes[node];
+  const uint32_t N = (uint32_t)n.desc.i[0];
+  const uint32_t len = std::min(nn, N);
+  for (uint32_t i = i0; i < i1; i++) {
+    const float* t = &n.an.time[(size_t)i * N + (N - len)];
+    uint8_t* o = dst + (size_t)(i - i0) * nn;
+    for (uint32_t k = 0; k < nn; k++) {  // analysis.rs:268-276 (elements past fft_size read a zeroed tmp)
+      const float v = k < len ? t[k] : 0.f;
+      const float scaled = 128.f * (1.f + v);
+      const float clamped = scaled < 0.f ? 0.f : scaled > 255.f ? 255.f : scaled;
+      o[k] = (uint8_t)clamped;
+    }
+  }
+  return WAA_OK;
+}
+static int an_inst(waa_batch* b, uint32_t inst) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (inst >= b->n_inst) return fail(WAA_ERR_INVALID_ARGUMENT, "instance out of range");
   return 0;
 }
 
 waa_status waa_analyser_get_float_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t nn) {
-  Node::AnCache* c;
-  int e = analyser_compute(b, node, inst, &c);
-  if (e) return e;
-  const uint32_t len = std::min<uint32_t>(nn, (uint32_t)c->spec.size());
-  for (uint32_t k = 0; k < len; k++) dst[k] = 20.f * log10f(c->spec[k]);  // analysis.rs:365-368
-  return WAA_OK;
+  if (int e = an_inst(b, inst)) return e;
+  return analyser_rows(b, node, AN_DB, inst, inst + 1, dst, nn);
 }
 waa_status waa_analyser_get_byte_frequency_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t nn) {
-  Node::AnCache* c;
-  int e = analyser_compute(b, node, inst, &c);
-  if (e) return e;
-  const Node& n = b->nodes[node];
-  const float mind = (float)n.desc.d[1], maxd = (float)n.desc.d[2];
-  const uint32_t len = std::min<uint32_t>(nn, (uint32_t)c->spec.size());
-  for (uint32_t k = 0; k < len; k++) {  // analysis.rs:388-400
-    const float db = 20.f * log10f(c->spec[k]);
-    const float scaled = 255.f / (maxd - mind) * (db - mind);
-    const float clamped = scaled < 0.f ? 0.f : scaled > 255.f ? 255.f : scaled;
-    dst[k] = std::isnan(scaled) ? 0 : (uint8_t)clamped;
-  }
-  return WAA_OK;
+  if (int e = an_inst(b, inst)) return e;
+  return analyser_rows(b, node, AN_BYTES, inst, inst + 1, dst, nn);
 }
 waa_status waa_analyser_get_float_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, float* dst, uint32_t nn) {
-  Node::AnCache* c;
-  int e = analyser_compute(b, node, inst, &c);
-  if (e) return e;
-  const uint32_t N = (uint32_t)c->time.size();
-  const uint32_t len = std::min(nn, N);  // ring_buffer.read: the most recent `len` frames (analysis.rs:114-127)
-  for (uint32_t i = 0; i < len; i++) dst[i] = c->time[N - len + i];
-  return WAA_OK;
+  if (int e = an_inst(b, inst)) return e;
+  return analyser_rows(b, node, AN_TIME, inst, inst + 1, dst, nn);
 }
 waa_status waa_analyser_get_byte_time_domain_data(waa_batch* b, uint32_t node, uint32_t inst, uint8_t* dst, uint32_t nn) {
-  Node::AnCache* c;
-  int e = analyser_compute(b, node, inst, &c);
-  if (e) return e;
-  const uint32_t N = (uint32_t)c->time.size();
-  const uint32_t len = std::min(nn, N);
-  for (uint32_t i = 0; i < nn; i++) {  // analysis.rs:268-276 (elements past fft_size read a zeroed tmp)
-    const float v = i < len ? c->time[N - len + i] : 0.f;
-    const float scaled = 128.f * (1.f + v);
-    const float clamped = scaled < 0.f ? 0.f : scaled > 255.f ? 255.f : scaled;
-    dst[i] = (uint8_t)clamped;
-  }
-  return WAA_OK;
+  if (int e = an_inst(b, inst)) return e;
+  return analyser_byte_time_rows(b, node, inst, inst + 1, dst, nn);
+}
+waa_status waa_analyser_get_float_frequency_data_batch(waa_batch* b, uint32_t node, float* dst, uint32_t nn) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  return analyser_rows(b, node, AN_DB, 0, b->n_inst, dst, nn);
+}
+waa_status waa_analyser_get_byte_frequency_data_batch(waa_batch* b, uint32_t node, uint8_t* dst, uint32_t nn) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  return analyser_rows(b, node, AN_BYTES, 0, b->n_inst, dst, nn);
+}
+waa_status waa_analyser_get_float_time_domain_data_batch(waa_batch* b, uint32_t node, float* dst, uint32_t nn) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  return analyser_rows(b, node, AN_TIME, 0, b->n_inst, dst, nn);
+}
+waa_status waa_analyser_get_byte_time_domain_data_batch(waa_batch* b, uint32_t node, uint8_t* dst, uint32_t nn) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  return analyser_byte_time_rows(b, node, 0, b->n_inst, dst, nn);
 }
 
 // buffer.rs:311-363 (input prep, host side)

@@ -805,15 +805,18 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvDesc d) {
   }
 }
 
-// AnalyserNode control side (analysis.rs:261-345): most recent fft_size frames of the mono down-mix,
-// Blackman window, real FFT via a packed complex FFT of half the size, |X[k]| / N, smoothing against the
-// previous (zero) spectrum.  One workgroup per pull.
+// AnalyserNode control side (analysis.rs:261-401): most recent fft_size frames of the mono down-mix, Blackman window, real
+// FFT via a packed complex FFT of half the size, |X[k]| / N, smoothing against the previous (zero) spectrum, dB and byte
+// conversion.  One workgroup per INSTANCE: a pull for the whole batch is one launch (BASELINE config 4: one pull per
+// context; as 4096 single launches with a stream sync each the pulls cost more than the render).
 __global__ void analyser_kernel(const AnalyserDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   Cplx* a = reinterpret_cast<Cplx*>(lds_raw);
   const int tid = threadIdx.x, nt = blockDim.x;
   const int N = d.fft_size, M = N >> 1;
-  const float* p0 = d.sig.base + (uint64_t)d.inst * d.sig.inst_stride;
+  const uint32_t inst = blockIdx.x;
+  const float* p0 = d.sig.base + (uint64_t)inst * d.sig.inst_stride;
+  float* time_out = d.time_out + (uint64_t)inst * N;
   const int64_t first = (int64_t)d.frames_written - N;  // ring_buffer.read: the last N frames written
   for (int i = tid; i < N; i += nt) {
     const int64_t f = first + i;
@@ -832,7 +835,7 @@ __global__ void analyser_kernel(const AnalyserDesc d) {
         default: v = p0[f]; break;  // other layouts: truncate
       }
     }
-    d.time_out[i] = v;
+    time_out[i] = v;
     const float wv = v * d.window[i];
     reinterpret_cast<float*>(a)[i] = wv;  // z[n] = x[2n] + i x[2n+1]
   }
@@ -841,6 +844,7 @@ __global__ void analyser_kernel(const AnalyserDesc d) {
   const int lg = 31 - __builtin_clz(M);
   const float nf = 1.f / (float)N;
   const float tau = d.smoothing;
+  const float bscale = 255.f / (d.max_db - d.min_db);
   for (int k = tid; k < M; k += nt) {
     const int k2 = (M - k) & (M - 1);
     const Cplx z = a[__brev((unsigned)k) >> (32 - lg)];
@@ -850,8 +854,14 @@ __global__ void analyser_kernel(const AnalyserDesc d) {
     const Cplx w = d.tw_full[k];  // exp(-2 pi i k / N)
     const Cplx x = cadd(e, cmul(o, w));
     const float norm = hypotf(x.re, x.im) * nf;
-    const float value = tau * d.prev[k] + (1.f - tau) * norm;
-    d.spec_out[k] = isfinite(value) ? value : 0.f;
+    float value = tau * d.prev[k] + (1.f - tau) * norm;
+    value = isfinite(value) ? value : 0.f;
+    const float db = 20.f * log10f(value);  // analysis.rs:365-368
+    d.db_out[(uint64_t)inst * M + k] = db;
+    // analysis.rs:388-400
+    const float scaled = bscale * (db - d.min_db);
+    const float clamped = scaled < 0.f ? 0.f : scaled > 255.f ? 255.f : scaled;
+    d.byte_out[(uint64_t)inst * M + k] = isnan(scaled) ? (uint8_t)0 : (uint8_t)clamped;
   }
 }
 
@@ -944,7 +954,7 @@ void launch_analyser(const AnalyserDesc& d, void* stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(analyser_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     big = true;
   }
-  hipLaunchKernelGGL(analyser_kernel, dim3(1), dim3(fft_threads(M)), (size_t)M * sizeof(Cplx), (hipStream_t)stream, d);
+  hipLaunchKernelGGL(analyser_kernel, dim3(d.n_inst), dim3(fft_threads(M)), (size_t)M * sizeof(Cplx), (hipStream_t)stream, d);
 }
 void launch_conv_mac(const ConvDesc& d, void* stream) {
   dim3 grid(d.n / 256, d.n_pairs * (uint32_t)d.cout);

@@ -145,14 +145,18 @@ struct Node {
   std::vector<float> osc_wave;
   // iir filter: normalised coefficient pairs (iir_filter.rs:273-311)
   std::vector<double> iir_b, iir_a;
-  // analyser (control side state)
-  struct AnCache {
-    std::vector<float> spec, time;
-  };
-  std::map<uint32_t, AnCache> an_cache;
+  // analyser (control side state): the pulls of ALL instances are computed by one launch and cached until the next render
+  // (current_time after an offline render never changes: repeated pulls return the same data, analysis.rs:354-357)
+  struct AnBatch {
+    bool computed = false;              // device results are current
+    bool have_db = false, have_bytes = false, have_time = false;  // ... and downloaded
+    std::vector<float> db, time;        // [n_inst][fft_size / 2], [n_inst][fft_size]
+    std::vector<uint8_t> bytes;         // [n_inst][fft_size / 2]
+  } an;
   float* d_window = nullptr;
   Cplx *d_an_tw = nullptr, *d_an_twfull = nullptr;
-  float *d_an_prev = nullptr, *d_an_spec = nullptr, *d_an_time = nullptr;
+  float *d_an_prev = nullptr, *d_an_db = nullptr, *d_an_time = nullptr;
+  uint8_t* d_an_bytes = nullptr;
   // planning
   int in_nch = 1;      // computed input channel count
   int out_nch = 1;     // static output channel count

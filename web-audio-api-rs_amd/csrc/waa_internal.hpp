@@ -215,17 +215,19 @@ struct ConvDesc {
 };
 struct AnalyserDesc {
   SignalRef sig;         // the analyser's (passthrough) signal
-  uint32_t inst;
+  uint32_t n_inst;       // one workgroup per instance
   int32_t fft_size;
   uint64_t frames_written;  // n_quanta * 128
   float smoothing;
+  float min_db, max_db;  // byte variant (analysis.rs:371-401)
   int32_t pad;
   const float* window;   // [fft_size] Blackman
   const Cplx* tw;        // [fft_size/2] exp(-2 pi i t / (fft_size/2))
   const Cplx* tw_full;   // [fft_size/2] exp(-2 pi i k / fft_size)
-  const float* prev;     // [fft_size/2] previous smoothed spectrum
-  float* spec_out;       // [fft_size/2]
-  float* time_out;       // [fft_size]
+  const float* prev;     // [fft_size/2] previous smoothed spectrum (zeros: one pull per render)
+  float* db_out;         // [n_inst][fft_size/2]  20 log10 of the smoothed magnitudes (analysis.rs:365-368)
+  uint8_t* byte_out;     // [n_inst][fft_size/2]
+  float* time_out;       // [n_inst][fft_size]
 };
 void launch_analyser(const AnalyserDesc& d, void* stream);
 constexpr int DIRECT_MAX_TAPS = 128;  // trimmed IRs up to this length use the direct FIR kernel
