@@ -139,12 +139,34 @@ for _o in IIR_ORDERS:
     DESCR[f"iir{_o}"] = "IIR: {n} contexts x {s:g} s, BufferSource->IIRFilter(Butterworth order %d)->destination" % _o
 
 
-def cpu_baseline(waa, name, frames, target_wall=6.0):
+def usable_cpus():
+    """Host CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (v2 cpu.max, v1
+    cfs_quota) — os.cpu_count() reports the machine (256 on the GPU box) whatever the container is allowed."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    n = aff if quota is None else max(1, min(aff, int(quota + 0.999)))
+    return n, aff, quota
+
+
+def cpu_baseline(waa, name, frames, wall_per_point=1.5):
     """The oracle ("port": a C restatement of the reference algorithm, NOT the Rust reference itself — no cargo on
-    this box, probed) timed on this box's host cores, one context per thread on all threads, on a BOUNDED sample of
-    the same workload: one batch of `cores` contexts is rendered repeatedly until the timed region lasts at least
-    `target_wall` seconds (thread start-up and first-touch costs are amortised; the first, untimed render warms the
-    pages).  Also reports the single-thread figure (one context on one thread), BASELINE.md section 3."""
+    this box, probed) timed on this box's host cores, one context per thread, on a BOUNDED sample of the same workload:
+    a thread-SCALING table (1, 2, 4, ... usable CPUs; at every point one batch of 2 x threads contexts — 1 x for the
+    convolver graphs — is rendered repeatedly until >= wall_per_point seconds are timed; the batch is rewound, untimed,
+    between repetitions).  `value` / `cores` are the table's best point; `parallel_efficiency` = its speed-up / its
+    threads.  Every ratio in the bench line is reproducible from this record."""
     path = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(path):
         return None
@@ -153,7 +175,6 @@ def cpu_baseline(waa, name, frames, target_wall=6.0):
     lib.orc_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.orc_rewind.argtypes = [ctypes.c_void_p]
     lib.orc_rewind.restype = ctypes.c_int32
-    cores = os.cpu_count() or 1
     from graphs import white_noise
 
     def timed(n, fr, threads, wall_target):
@@ -163,7 +184,7 @@ def cpu_baseline(waa, name, frames, target_wall=6.0):
             src.set_buffer_batch(noise, SR)
         ctx.prepare()
         lib.orc_set_threads(ctx._handle, threads)
-        orc.check(orc.render(ctx._handle))  # untimed: the reference render; pages touched
+        orc.check(orc.render(ctx._handle))  # untimed: pages touched, threads' arenas warm
         reps, wall = 0, 0.0
         while wall < wall_target and reps < 10000:
             orc.check(lib.orc_rewind(ctx._handle))  # (timing aid of the oracle: pre-render state again, untimed)
@@ -174,38 +195,71 @@ def cpu_baseline(waa, name, frames, target_wall=6.0):
         ctx.close()
         return reps, wall
 
-    # sample length: the full render for cheap graphs, shortened for the convolver graphs (~0.2 s of CPU per
+    # sample length: the full render for cheap graphs, 2 s of audio for the convolver graphs (~0.2 s of CPU per
     # context-second) so that one repetition stays well under the target
     conv = name in ("t1", "c3", "c4")
-    sample_frames = min(frames, (RQ * 375 * 2) if conv else frames)  # 2 s of audio for convolver graphs
-    sample_frames = (sample_frames // RQ) * RQ
-    per_thread = 2 if not conv else 1
-    n = cores * per_thread
-    reps, wall = timed(n, sample_frames, cores, target_wall)
+    sample_frames = (min(frames, (RQ * 375 * 2) if conv else frames) // RQ) * RQ
+    per_thread = 1 if conv else 2
     nq = sample_frames // RQ
-    out = {"value": n * nq * reps / wall, "unit": "quanta/s", "cores": cores, "kind": "port",
-           "sample": f"{reps} x ({n} contexts x {sample_frames / SR:.2f} s of the same graph), one context per thread on "
-                     f"{cores} threads, {wall:.2f} s of timed renders (the batch is rewound, untimed, between repetitions)",
-           "rtf": n * (sample_frames / SR) * reps / wall,
-           "reference_toolchain": "cargo/rustc probed on the GPU box: absent (no network): the Rust crate cannot be timed"}
-    reps1, wall1 = timed(1, sample_frames, 1, min(2.0, target_wall))
-    out["single_thread_rtf"] = (sample_frames / SR) * reps1 / wall1
-    out["single_thread_quanta_per_s"] = nq * reps1 / wall1
+    n_cpu, aff, quota = usable_cpus()
+    points = sorted({1, n_cpu} | {1 << i for i in range(1, 12) if (1 << i) < n_cpu})
+    table, t1_rate = [], None
+    for th in points:
+        n = th * per_thread
+        reps, wall = timed(n, sample_frames, th, wall_per_point)
+        rate = n * nq * reps / wall
+        t1_rate = t1_rate or rate
+        table.append({"threads": th, "quanta_per_s": round(rate, 1), "rtf": round(n * (sample_frames / SR) * reps / wall, 3),
+                      "speedup": round(rate / t1_rate, 2)})
+    best = max(table, key=lambda r: r["quanta_per_s"])
+    return {"value": best["quanta_per_s"], "unit": "quanta/s", "cores": best["threads"], "kind": "port",
+            "rtf": best["rtf"], "parallel_efficiency": round(best["speedup"] / best["threads"], 2),
+            "single_thread_rtf": table[0]["rtf"], "single_thread_quanta_per_s": table[0]["quanta_per_s"],
+            "scaling": [[r["threads"], r["rtf"]] for r in table],
+            "usable_cpus": n_cpu, "affinity": aff, "cgroup_quota": quota, "os_cpu_count": os.cpu_count(),
+            "sample": f">={wall_per_point:g} s per point of repeated renders of ({per_thread} x threads) contexts x "
+                      f"{sample_frames / SR:.2f} s of the {name} graph, one context per thread; best point reported",
+            "reference_toolchain": "cargo/rustc: absent on this box (probed), no network: the Rust crate cannot be timed"}
+
+
+def source_hashes():
+    """sha256[:16] of every device-side source: a PMC traffic record is only replayed when the files its kernels live in
+    are byte-identical to the ones it was measured on (tools/pmc_merge.py stores the same hashes)."""
+    import hashlib
+    csrc = os.path.join(ROOT, "web-audio-api-rs_amd", "csrc")
+    out = {}
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            out[f] = hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16]
     return out
 
 
-def pmc_record(name, n_inst, frames):
+def pmc_record(name, n_inst, frames, launches_per_step=None):
     """rocprofv3 --pmc record of this workload (profiles/pmc_traffic.json; FETCH_SIZE and WRITE_SIZE are collected in
     separate passes of this same command and corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x 2 on gfx950;
-    the file records the numbers and their provenance).  None when no PMC data matches the configuration."""
+    the file records the numbers and their provenance).  Returns (record, why_not): the record is refused — the line then
+    carries traffic = null — when the configuration differs, when a source file one of its kernels lives in has changed
+    since the measurement, or when the live render launches a different number of kernels per step."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         rec = json.load(open(path)).get(name)
-        if rec and rec["contexts"] == n_inst and rec["frames"] == frames:
-            return rec
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    except (OSError, ValueError):
+        return None, "no profiles/pmc_traffic.json"
+    if not rec:
+        return None, "no PMC record for this workload"
+    if rec.get("contexts") != n_inst or rec.get("frames") != frames:
+        return None, "PMC record is for another configuration"
+    if "sources" not in rec:
+        return None, "PMC record predates the source stamps (round 2)"
+    live = source_hashes()
+    changed = [f for f, h in rec["sources"].items() if live.get(f) != h]
+    if changed:
+        return None, "stale: " + ",".join(changed) + " changed since the PMC passes"
+    if launches_per_step is not None and isinstance(rec.get("kernels"), dict):
+        want = sum(k.get("launches_per_step", 1) for k in rec["kernels"].values())
+        if abs(want - launches_per_step) > 0.5:
+            return None, f"stale: {launches_per_step:g} launches per step now, {want} when measured"
+    return rec, None
 
 
 DEFAULT_INSTANCES = {"c2": 1024, "c2k": 1024, "c1a": 1024, "t1": 1024, "c3": 512, "c4": 512, "c5": 2048}
@@ -213,9 +267,10 @@ F64_WORKLOADS = ("c2", "c2k", "c1a", "t1", "c4", "fbq", "osc")
 
 
 def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, local_rank, dist, backend):
-    """One workload on this rank's GPU: build (untimed), first render = plan (timed separately as plan_ms), then the
-    bench protocol (W untimed + K timed steps, barrier + sync on both sides, MAX over ranks).  Returns the record
-    fields that depend on the workload (rank 0 assembles the line)."""
+    """One workload on this rank's GPU: build (untimed), first render = plan + allocation + render (first_render_ms, what a
+    caller of an offline context really waits for; plan_ms = its host part), then the bench protocol (W untimed + K timed
+    steps, barrier + sync on both sides, MAX over ranks).  C4's step includes the batched analyser pull (one
+    get_float_frequency_data per context).  Returns the full record (rank 0 compacts it)."""
     frames = int(round(seconds * SR))
     nq = (frames + RQ - 1) // RQ
     gen = torch.Generator(device="cuda")
@@ -223,17 +278,26 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
     noise = torch.empty((n_inst, 2, frames), dtype=torch.float32, device="cuda").uniform_(-1.0, 1.0, generator=gen)
     ctx, _ = build_workload(waa, hip, name, n_inst, frames, local_rank, noise.data_ptr())
     ctx.prepare()
+    analyser = next((n for n in ctx._nodes if isinstance(n, waa.AnalyserNode)), None) if name == "c4" else None
+    bins = np.zeros((n_inst, analyser.frequency_bin_count), np.float32) if analyser else None
 
     from web_audio_api_rs_amd.sharding import timed_steps
 
+    def step():
+        ctx.render_async()
+        if analyser:
+            analyser.get_float_frequency_data_all(out=bins)  # (waits for the render: the pull is part of C4's step)
+
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ctx.render_async()  # the first launch builds the plan (graph planning, source scheduling replay, coefficient /
-    ctx.sync()          # automation evaluation and their uploads) — outside the timed steps, reported as plan_ms
+    step()      # the first launch builds the plan (graph planning, source scheduling replay, coefficient / automation
+    ctx.sync()  # evaluation, their uploads, every hipMalloc of the batch) and renders once
     first_ms = (time.perf_counter() - t0) * 1e3
+    head = ctx.plan_describe().splitlines()[0]
+    timing = head.split("| timing: ", 1)[1] if "| timing: " in head else None
     ctx.profile(True)
     ctx.profile_reset()
-    elapsed = timed_steps(ctx.render_async, torch.cuda.synchronize, steps, warmup, dist=dist,
+    elapsed = timed_steps(step, torch.cuda.synchronize, steps, warmup, dist=dist,
                           device_tensor=lambda v: torch.tensor([v], dtype=torch.float64,
                                                                device="cuda" if backend == "nccl" else "cpu"))
     ctx.sync()
@@ -249,9 +313,12 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
     kernel_ms_per_step = sum(ms for _, _, ms in prof) / total_launch_steps
     dom = prof[0] if prof else ("none", 1, float("nan"))
     alg_bytes_step = ALG_BYTES[name] * n_inst * nq
-    pmc = pmc_record(name, n_inst, frames)
+    pmc, pmc_why = pmc_record(name, n_inst, frames, sum(launches_per_step.values()))
     single = len(prof) == 1 and max(launches_per_step.values(), default=1) <= 1.5
-    roof = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "kernel_ms": kernel_ms, "launches_per_step": launches_per_step}
+    roof = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "kernel_ms": kernel_ms, "launches_per_step": launches_per_step,
+            "kernel_ms_per_step": kernel_ms_per_step}
+    if pmc_why:
+        roof["traffic_note"] = pmc_why
     if single:
         # one streaming kernel: SURVEY section 8(d)'s algorithmic bytes of one launch / its mean duration (HIP events)
         roof["kernel"] = dom[0]
@@ -262,14 +329,14 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
         # several kernels (convolver pipelines, split chains, loops): the node-major design does not move the
         # reference's frequency-domain-delay-line bytes, so dividing THAT figure by the time says nothing (it exceeds
         # the peak).  achieved = HBM bytes the kernels really moved (PMC, per step) / the sum of their durations;
-        # without a PMC record: the compulsory bytes (every input read once, every output written once).
+        # without a current PMC record: the compulsory bytes (every input read once, every output written once).
         compulsory = 2048.0 * n_inst * nq if name not in ("c5",) else ALG_BYTES[name] * n_inst * nq
         traffic = pmc["bytes_per_step"] if pmc and "bytes_per_step" in pmc else None
         roof["kernel"] = "render (all kernels)"
         roof["traffic"] = traffic
         roof["achieved"] = (traffic if traffic else compulsory) / (kernel_ms_per_step * 1e-3) / 1e9
         roof["achieved_basis"] = "measured HBM traffic (rocprofv3 PMC, profiles/pmc_traffic.json)" if traffic else \
-            "compulsory bytes (inputs read once + outputs written once): no PMC record for this configuration"
+            "compulsory bytes (inputs read once + outputs written once): no current PMC record"
         roof["compulsory_bytes_per_step"] = compulsory
         roof["compulsory_frac"] = compulsory / (kernel_ms_per_step * 1e-3) / 1e9 / 8000.0
         if name in ("t1", "c3", "c4"):
@@ -292,10 +359,12 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
             roof.update({"bound": "mfma", "peak": 2500.0 / 6.0, "peak_basis": "2.5 PFLOP/s dense bf16 MFMA / 6 products per f32 product",
                          "mfma_flops_per_step": 6.0 * flops, "vs_f32_vector_peak": roof["achieved"] / 157.3})
             roof["frac"] = roof["achieved"] / (2500.0 / 6.0)
-    return {
+    rec = {
         "value": world * n_inst * nq * steps / elapsed,
         "ms_per_step": ms_per_step,
+        "first_render_ms": first_ms,
         "plan_ms": max(first_ms - kernel_ms_per_step, 0.0),
+        "plan_timing": timing,
         "dtype": "f64" if name in F64_WORKLOADS or name.startswith("iir") else "f32",
         "config": {"workload": DESCR[name].format(n=n_inst, s=seconds), "contexts_per_gpu": n_inst,
                    "sample_rate": SR, "render_seconds": seconds, "quanta_per_context": nq,
@@ -303,114 +372,85 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
         "real_time_factor": world * n_inst * seconds * steps / elapsed,
         "roofline": roof,
     }
+    if analyser:
+        rec["analyser_pull"] = "one batched get_float_frequency_data for all contexts inside every step"
+        rec["analyser_kernel_ms"] = kernel_ms.get("analyser_kernel")
+    return rec
 
 
-def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, n_sub=8):
-    """What the drop-in boundary costs when it is handed HOST buffers (never `value`): host noise ->
-    waa_source_set_buffer_batch -> waa_render -> waa_download_all for the C2 graph, (a) as one batch, (b) as n_sub
-    sub-batches driven by n_sub host threads (ctypes releases the GIL; every batch has its own stream and its transfers run
-    on it), pipelined so that the upload of one sub-batch overlaps the download of another.  Host buffers are pinned (torch)."""
-    import threading
+def compact(rec, keep_traffic=True):
+    """The few numbers of a workload record that travel in the bench LINE (the driver keeps ~4 KB of it); the full
+    record goes to the detail file."""
+    if "error" in rec:
+        return {"error": rec["error"][:120]}
+    r = rec["roofline"]
+    out = {"ms": round(rec["ms_per_step"], 3), "quanta_per_s": round(rec["value"]), "rtf": round(rec["real_time_factor"], 1),
+           "first_render_ms": round(rec["first_render_ms"], 1), "kernel_ms": round(r["kernel_ms_per_step"], 3),
+           "frac": round(r["frac"], 3), "bound": r["bound"]}
+    if "compulsory_frac" in r:
+        out["compulsory_frac"] = round(r["compulsory_frac"], 3)
+    if keep_traffic:
+        out["traffic_GB"] = round(r["traffic"] / 1e9, 2) if r.get("traffic") else None
+    return out
+
+
+def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1, with_pcm=True, n_sub=8):
+    """What the drop-in boundary costs when it is handed HOST buffers (never `value`): pinned host buffers ->
+    sharding.render_sharded (set_buffer_batch -> render -> download_all, per sub-batch, pipelined: upload of one while
+    another renders and a third downloads) for the C2 graph and for C4 (512 contexts per GPU = BASELINE config 4's
+    4096 / 8, with the batched analyser pull per sub-batch).  Under torch.distributed EVERY rank does this at the same
+    time on its own GPU — the ranks share the host's PCIe root / memory system, which is SURVEY 8(e)'s scaling limiter —
+    and the slowest rank's time is reported."""
+    from web_audio_api_rs_amd.sharding import render_sharded
     frames = int(round(seconds * SR))
-    host_in = torch.empty((n_inst, 2, frames), dtype=torch.float32, pin_memory=True).uniform_(-1.0, 1.0)
-    host_out = torch.empty((n_inst, 2, frames), dtype=torch.float32, pin_memory=True)
-    import ctypes as C
-    FP = C.POINTER(C.c_float)
 
-    # one upload and one download at a time: sub-batch i + 1 uploads while sub-batch i downloads (PCIe is full duplex:
-    # tools/pcie_probe.py, 57 GB/s each way, 97 GB/s both at once).  Without the two locks all uploads run side by side,
-    # finish together, and all downloads follow: a sum again, not a pipeline.
-    class Turn:  # sub-batches take the link in index order
-        def __init__(self):
-            self.cv, self.next = threading.Condition(), 0
+    def run_graph(graph, n, parts, pcm=False):
+        if pcm:
+            host_in = torch.empty((n, frames, 2), dtype=torch.int16, pin_memory=True).random_(-32768, 32767)
+        else:
+            host_in = torch.empty((n, 2, frames), dtype=torch.float32, pin_memory=True).uniform_(-1.0, 1.0)
+        host_out = torch.empty((n, 2, frames), dtype=torch.float32, pin_memory=True)
+        bins = np.zeros((n, 1024), np.float32)
 
-        def wait(self, k):
-            with self.cv:
-                self.cv.wait_for(lambda: self.next == k)
+        def build(n_sub_inst, device):
+            return build_workload(waa, hip, graph, n_sub_inst, frames, device, None)
 
-        def done(self):
-            with self.cv:
-                self.next += 1
-                self.cv.notify_all()
+        def pull(ctx, lo, hi):
+            an = next(nd for nd in ctx._nodes if isinstance(nd, waa.AnalyserNode))
+            an.get_float_frequency_data_all(out=bins[lo:hi])
 
-    turns = {}
-
-    def run(lo, hi, k=0):
-        up, down = turns["up"], turns["down"]
-        ctx, src = build_workload(waa, hip, "c2", hi - lo, frames, local_rank, None)
-        ctx.prepare()
-        sl = host_in[lo:hi]
-        up.wait(k)
-        hip.check(hip.source_set_buffer_batch(ctx._handle, src.id, C.cast(sl.data_ptr(), FP), 2, frames, SR))
-        up.done()
-        hip.check(hip.render(ctx._handle))
-        hip.check(hip.sync(ctx._handle))
-        down.wait(k)
-        hip.check(hip.download_all(ctx._handle, C.cast(host_out[lo:hi].data_ptr(), FP)))
-        down.done()
-        ctx.close()
-
-    def timed(parts):
-        bounds = [(k * n_inst // parts, (k + 1) * n_inst // parts, k) for k in range(parts)]
-        turns["up"], turns["down"] = Turn(), Turn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ths = [threading.Thread(target=run, args=b) for b in bounds]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        return (time.perf_counter() - t0) * 1e3
-
-    timed(n_sub)  # warm-up: allocator, page registration
-    one = min(timed(1) for _ in range(2))
-    split = min(timed(n_sub) for _ in range(2))
-    nbytes = 2.0 * n_inst * 2 * frames * 4
-    rec = {"workload": "c2", "contexts": n_inst, "single_batch_ms": one, f"split_{n_sub}_batches_ms": split,
-           "host_bytes_moved": nbytes, "effective_GBps_single": nbytes / one / 1e6,
-           "effective_GBps_split": nbytes / split / 1e6,
-           "note": "host (pinned) -> set_buffer_batch -> render -> download_all, batch creation and planning included; "
-                   "PCIe-bound, reported for the boundary only; the split run pipelines its sub-batches (upload of one "
-                   "while another downloads: the link is full duplex, tools/pcie_probe.py)"}
-    # the same with the input handed over as decoded 16-bit PCM (waa_source_set_buffer_pcm16_batch: half the upload,
-    # sample conversion on the device) — what a caller that holds WAV data would do
-    try:
-        pcm = torch.empty((n_inst, frames, 2), dtype=torch.int16, pin_memory=True).random_(-32768, 32767)
-        I16 = C.POINTER(C.c_int16)
-
-        def run_pcm(lo, hi, k=0):
-            up, down = turns["up"], turns["down"]
-            ctx, src = build_workload(waa, hip, "c2", hi - lo, frames, local_rank, None)
-            ctx.prepare()
-            up.wait(k)
-            hip.check(hip.source_set_buffer_pcm16_batch(ctx._handle, src.id, C.cast(pcm[lo:hi].data_ptr(), I16), 2, frames, SR))
-            up.done()
-            hip.check(hip.render(ctx._handle))
-            hip.check(hip.sync(ctx._handle))
-            down.wait(k)
-            hip.check(hip.download_all(ctx._handle, C.cast(host_out[lo:hi].data_ptr(), FP)))
-            down.done()
-            ctx.close()
-
-        def timed_pcm(parts):
-            bounds = [(k * n_inst // parts, (k + 1) * n_inst // parts, k) for k in range(parts)]
-            turns["up"], turns["down"] = Turn(), Turn()
+        best = None
+        for rep in range(3):  # the first pass warms the allocator and registers the pages; best of the next two
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ths = [threading.Thread(target=run_pcm, args=b_) for b_ in bounds]
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
-            return (time.perf_counter() - t0) * 1e3
+            if dist is not None:
+                dist.barrier()
+            t = render_sharded(build, host_in, host_out, devices=(local_rank,), sub_batches=parts, sample_rate=SR, pcm16=pcm,
+                               pull=pull if graph == "c4" else None)["seconds"]
+            if dist is not None:
+                tt = torch.tensor([t], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t = float(tt.item())
+            if rep:
+                best = t if best is None else min(best, t)
+        nq = (frames + RQ - 1) // RQ
+        return best * 1e3, world * n * nq / best
 
-        timed_pcm(1)
-        rec["pcm16_single_batch_ms"] = min(timed_pcm(1) for _ in range(2))
-        timed_pcm(n_sub)
-        rec[f"pcm16_split_{n_sub}_batches_ms"] = min(timed_pcm(n_sub) for _ in range(2))
-        rec["pcm16_host_bytes_moved"] = n_inst * 2 * frames * (2 + 4.0)
-    except Exception as e:  # reporting only
-        rec["pcm16_error"] = repr(e)
+    rec = {"note": "host (pinned) -> set_buffer_batch -> render -> download_all, batch creation and planning included, "
+                   "PCIe-bound; every rank at once, slowest rank's time", "sub_batches": n_sub}
+    if world == 1:
+        ms1, _ = run_graph("c2", n_inst, 1)
+        rec["c2_single_batch_ms"] = ms1
+    ms, qps = run_graph("c2", n_inst, n_sub)
+    rec["c2_ms"], rec["c2_quanta_per_s"] = ms, round(qps)
+    rec["c2_GBps_per_gpu"] = 2.0 * n_inst * 2 * frames * 4 / ms / 1e6
+    if with_pcm:
+        try:
+            ms, _ = run_graph("c2", n_inst, n_sub, pcm=True)
+            rec["c2_pcm16_ms"] = ms
+        except Exception as e:  # reporting only
+            rec["c2_pcm16_error"] = repr(e)[:100]
+    ms, qps = run_graph("c4", 512, n_sub)
+    rec["c4_512_per_gpu_ms"], rec["c4_quanta_per_s"] = ms, round(qps)
     return rec
 
 
@@ -423,7 +463,8 @@ def main():
     ap.add_argument("--instances", type=int, default=None, help="contexts per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the nested T1/C3/C5/C1a records and the e2e record")
+    ap.add_argument("--no-extra", action="store_true", help="only the headline workload: no T1 / C3 / C4 / ... records, no e2e record")
+    ap.add_argument("--detail", default=None, help="file for the full per-workload records (default: gpurun_out/bench_detail.json)")
     args = ap.parse_args()
 
     import torch
@@ -454,20 +495,31 @@ def main():
     hip = waa.default_binding()
     rec = measure(torch, waa, hip, name, n_inst, args.seconds, args.steps, args.warmup, rank, world, local_rank, dist,
                   backend)
-    # The north-star target graph (T1) and the other BASELINE configs ride along in the same line, so that one driver
-    # run verifies them all: every rank renders them (same barrier protocol), rank 0 reports.  Fewer steps each.
+    # The north-star target graph (T1) and the other BASELINE configs ride along in the same line (compact: the driver
+    # keeps about 4 KB of it; the full records go to the detail file), so that one driver run verifies them all: every
+    # rank renders them (same barrier protocol), rank 0 reports.  Fewer steps each.  With N > 1 only T1 and C4 (the
+    # config BASELINE.json shards over 8 GPUs: 4096 contexts = 512 per GPU) ride along.
     extra = {}
     default_run = name == "c2" and args.instances is None and args.seconds == 10.0 and not args.no_extra
     if default_run:
-        for sub in ("t1", "c3", "c4", "c5", "c1a", "os2", "hrtf", "echo"):
+        subs = ("t1", "c3", "c4", "c5", "c1a", "os2", "hrtf", "echo") if world == 1 else ("t1", "c4")
+        for sub in subs:
             try:
                 extra[sub] = measure(torch, waa, hip, sub, DEFAULT_INSTANCES.get(sub, 1024), args.seconds, max(3, args.steps // 2),
                                      min(args.warmup, 2) or 1, rank, world, local_rank, dist, backend)
                 extra[sub]["steps"] = max(3, args.steps // 2)
             except Exception as e:  # a sub-record never takes the headline line down
                 extra[sub] = {"error": repr(e)}
+    e2e = None
+    if default_run:
+        try:  # host buffers -> device -> host on EVERY rank at once: the ranks share the host's PCIe / memory system
+            e2e = e2e_record(torch, waa, hip, n_inst, args.seconds, local_rank, dist=dist, world=world,
+                             with_pcm=(world == 1))
+        except Exception as e:
+            e2e = {"error": repr(e)}
 
     if rank == 0:
+        roof = rec["roofline"]
         out = {
             "metric": "render quanta/sec (48kHz, 128-frame)",
             "value": rec["value"],
@@ -483,31 +535,57 @@ def main():
             "data": "synthetic",
             "config": rec["config"],
             "real_time_factor": rec["real_time_factor"],
+            "first_render_ms": rec["first_render_ms"],
             "plan_ms": rec["plan_ms"],
-            "roofline": rec["roofline"],
+            "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic") if k in roof},
         }
-        if extra:
-            out["workloads"] = extra
-        if world > 1:
-            out["cpu_baseline"] = None  # timed at N = 1 only: the host cores are shared by the ranks
-        elif not args.no_cpu_baseline:
+        out["roofline"]["kernel_ms"] = round(roof["kernel_ms_per_step"], 4)
+        for k in ("algorithmic_bytes_per_launch", "compulsory_frac", "traffic_note", "achieved_basis"):
+            if k in roof:
+                out["roofline"][k] = roof[k]
+        detail = {"headline": rec, "workloads": extra, "e2e": e2e}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(waa, name, int(round(args.seconds * SR)))
-                if out["cpu_baseline"]:
-                    out["gpu_over_cpu_rtf"] = out["real_time_factor"] / out["cpu_baseline"]["rtf"]
-                if default_run and "t1" in extra and "error" not in extra["t1"]:
-                    cb = cpu_baseline(waa, "t1", int(round(args.seconds * SR)), target_wall=5.0)
-                    extra["t1"]["cpu_baseline"] = cb
-                    if cb:
-                        extra["t1"]["gpu_over_cpu_rtf"] = extra["t1"]["real_time_factor"] / cb["rtf"]
+                cpu = cpu_baseline(waa, name, int(round(args.seconds * SR)))
             except Exception as e:  # the baseline is reporting only; never fail the bench line on it
-                out["cpu_baseline"] = {"error": repr(e)}
-        if default_run and world == 1:
-            try:
-                out["e2e"] = e2e_record(torch, waa, hip, n_inst, args.seconds, local_rank)
-            except Exception as e:
-                out["e2e"] = {"error": repr(e)}
-        print(json.dumps(out))
+                cpu = {"error": repr(e)}
+        out["cpu_baseline"] = cpu  # (null with N > 1: timed at N = 1 only, the host cores are shared by the ranks)
+        if cpu and "rtf" in cpu:
+            out["gpu_over_cpu_rtf"] = round(out["real_time_factor"] / cpu["rtf"], 1)
+        # T1 = the graph the north star's targets are quoted on: top-level and complete enough to re-derive every ratio
+        if "t1" in extra and "error" not in extra["t1"]:
+            t1, r1 = extra["t1"], extra["t1"]["roofline"]
+            out["t1"] = compact(t1)
+            out["t1"]["workload"] = "1024 ctx x 10 s: BufferSource->Biquad->Convolver(garage IR 2x178899)->destination"
+            out["t1"]["kernels_ms"] = {k: round(v * r1["launches_per_step"].get(k, 1), 3) for k, v in r1["kernel_ms"].items()}
+            out["t1"]["frac_basis"] = "traffic/kernel_ms/8TB/s" if r1.get("traffic") else "compulsory bytes/kernel_ms/8TB/s"
+            if "traffic_note" in r1:
+                out["t1"]["traffic_note"] = r1["traffic_note"]
+            if world == 1 and not args.no_cpu_baseline:
+                try:
+                    cb = cpu_baseline(waa, "t1", int(round(args.seconds * SR)), wall_per_point=1.0)
+                    detail["t1_cpu_baseline"] = cb
+                    out["t1"]["cpu_baseline"] = {k: cb[k] for k in ("rtf", "cores", "kind", "parallel_efficiency", "single_thread_rtf")}
+                    out["t1"]["gpu_over_cpu_rtf"] = round(t1["real_time_factor"] / cb["rtf"], 1)
+                except Exception as e:
+                    out["t1"]["cpu_baseline"] = {"error": repr(e)[:100]}
+        if extra:
+            out["configs"] = {k: compact(v) for k, v in extra.items() if k != "t1"}
+            if "c4" in extra and "error" not in extra["c4"]:
+                out["configs"]["c4"]["analyser_pull_in_step"] = True
+                out["configs"]["c4"]["contexts_per_gpu"] = 512
+        if e2e is not None:
+            out["e2e"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in e2e.items() if k != "note"}
+        path = args.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(detail, f, indent=1)
+            out["detail_file"] = os.path.relpath(path, ROOT)
+        except OSError:
+            pass
+        print(json.dumps(out, separators=(",", ":")))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -37,3 +37,4 @@ def test_two_rank_gloo_shards_match_single_process(orc):
     ref = ctx.start_rendering_sync().data.astype(np.float64).sum(axis=(1, 2))
     ctx.close()
     assert np.allclose(got["sums"], ref, rtol=0, atol=1e-9)
+    assert np.allclose(got["sums_sharded"], ref, rtol=0, atol=1e-9)  # sharding.render_sharded on every rank's shard

@@ -60,6 +60,24 @@ if len(kernels) == 1:
     k = next(iter(kernels.values()))
     rec["kernel"] = next(iter(kernels))
     rec["bytes_per_launch"] = k["bytes_per_launch"]
+# provenance: the device-side source files the measured kernels live in (+ the shared headers), by content hash — bench.py
+# replays this record only while they are unchanged (and while the render still launches as many kernels per step)
+import hashlib  # noqa: E402
+import subprocess  # noqa: E402
+
+csrc = os.path.join(root, "web-audio-api-rs_amd", "csrc")
+files = {"waa_internal.hpp", "waa_stream_common.hpp", "waa_fft3.hpp"}
+for k in kernels:
+    fn = k.split("<")[0]
+    for f in os.listdir(csrc):
+        if f.endswith(".hip") and re.search(r"\b%s\s*\(" % re.escape(fn), open(os.path.join(csrc, f)).read()):
+            files.add(f)
+rec["sources"] = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16] for f in sorted(files)
+                  if os.path.exists(os.path.join(csrc, f))}
+try:
+    rec["git_head"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:  # (the GPU box's snapshot has no .git: merged here, in the authoring container)
+    rec["git_head"] = None
 data[name] = rec
 json.dump(data, open(path, "w"), indent=1)
 print(json.dumps(rec, indent=1))

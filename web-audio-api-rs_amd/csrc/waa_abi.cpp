@@ -646,17 +646,38 @@ waa_status waa_set_param_block(waa_batch* b, uint32_t node, uint32_t param, uint
   return WAA_OK;
 }
 
+// build_plan under a stopwatch; the split (hipMalloc / blocking uploads / the rest = host planning: ordering, scheduling
+// replay, coefficient and automation evaluation) goes into the plan description
+static int timed_build_plan(waa_batch* b) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const double a0 = b->t_alloc_ms, u0 = b->t_upload_ms;
+  const uint64_t n0 = b->n_alloc, by0 = b->alloc_bytes;
+  int e = build_plan(b);
+  b->t_plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  b->plan_alloc_ms = b->t_alloc_ms - a0;
+  b->plan_upload_ms = b->t_upload_ms - u0;
+  b->plan_n_alloc = b->n_alloc - n0;
+  b->plan_alloc_bytes = b->alloc_bytes - by0;
+  return e;
+}
+
 waa_status waa_plan_describe(waa_batch* b, char* buf, size_t cap, size_t* needed) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
   if (!b->planned) {
     if (!b->dry) HIP_TRY(hipSetDevice(b->device));
-    int e = build_plan(b);
+    int e = timed_build_plan(b);
     if (e) return e;
   }
   std::string text;
   char head[256];
   snprintf(head, sizeof head, "batch: %u instance(s) x %llu frames (%u quanta, %u tiles of %d) @ %g Hz, %u output channel(s)\n",
            b->n_inst, (unsigned long long)b->length, b->n_quanta, b->n_tiles, TILE, (double)b->sr, b->n_out);
+  text += head;
+  // (same line as the header: the plan lines below are positional in tests/test_plan.py)
+  text.pop_back();
+  snprintf(head, sizeof head, " | timing: build_plan %.2f ms = hipMalloc %.2f ms (%llu calls, %.3f GB) + uploads %.2f ms + host planning %.2f ms\n",
+           b->t_plan_ms, b->plan_alloc_ms, (unsigned long long)b->plan_n_alloc, (double)b->plan_alloc_bytes / 1e9, b->plan_upload_ms,
+           b->t_plan_ms - b->plan_alloc_ms - b->plan_upload_ms);
   text += head;
   for (auto& l : b->plan_log) text += l + "\n";
   if (needed) *needed = text.size();
@@ -673,7 +694,7 @@ waa_status waa_render(waa_batch* b) {
   if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch (WAA_DEVICE_PLAN_ONLY) cannot render: there is no CPU fallback");
   HIP_TRY(hipSetDevice(b->device));
   if (!b->planned) {
-    int e = build_plan(b);
+    int e = timed_build_plan(b);
     if (e) return e;
   }
   // every render starts from the initial state (offline contexts render exactly once; re-rendering the

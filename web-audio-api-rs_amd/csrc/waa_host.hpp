@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <complex>
@@ -258,6 +259,12 @@ struct waa_batch {
   std::vector<std::string> plan_log;  // waa_plan_describe
   bool profiling = false;
   std::vector<ProfileEntry> prof;
+  // where the first waa_render's host time goes (waa_plan_describe prints it: "timing: ..."): an offline context renders
+  // once, so planning + allocation IS part of what a caller waits for
+  double t_plan_ms = 0, t_alloc_ms = 0, t_upload_ms = 0;  // (alloc / upload: running totals of the batch)
+  uint64_t n_alloc = 0, alloc_bytes = 0;
+  double plan_alloc_ms = 0, plan_upload_ms = 0;          // ... and their part inside build_plan
+  uint64_t plan_n_alloc = 0, plan_alloc_bytes = 0;
 };
 
 namespace waa {
@@ -276,7 +283,11 @@ int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
     *out = reinterpret_cast<T*>(p);
     return 0;
   }
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&p, bytes);
+  b->t_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  b->n_alloc++;
+  b->alloc_bytes += bytes;
   if (e != hipSuccess) return fail(WAA_ERR_DEVICE, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
   (payload ? b->payload_allocs : b->allocs).push_back(p);
   *out = reinterpret_cast<T*>(p);
@@ -287,10 +298,13 @@ int dev_upload(waa_batch* b, T** out, const std::vector<T>& host) {
   int e = dev_alloc(b, out, host.size());
   if (e) return e;
   if (!host.empty()) {
-    if (b->dry)
+    if (b->dry) {
       std::memcpy(*out, host.data(), host.size() * sizeof(T));
-    else
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
       HIP_TRY(hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+      b->t_upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
   }
   return 0;
 }
