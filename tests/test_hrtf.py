@@ -243,6 +243,27 @@ def test_tail_then_silence(be):
     assert np.any(out[:, 6 * RQ:7 * RQ] != 0.0) and np.all(out[:, 7 * RQ:] == 0.0)
 
 
+@pytest.mark.parametrize("mode", ["explicit", "clamped-max"])
+def test_stereo_source_tail_gain_follows_the_quantum_count(be, mode):
+    """A stereo source stops after three quanta.  The tail quanta are silent; with channelCountMode explicit (count 2) they
+    are still TWO-channel quanta (quantum.rs:532-569), so the mix-down correction (x 2, panner.rs:800-810) applies to the
+    tail as well; with the default clamped-max they are mono and the tail comes out at 1 x.  (Round-2 advisor finding: the
+    device rendered the explicit case's tail at 1 x.)"""
+    nq = 12
+    rng = np.random.default_rng(31)
+    x = rng.uniform(-1, 1, (1, 2, 3 * RQ)).astype(np.float32)
+    opts = dict(channel_count=2, channel_count_mode="explicit") if mode == "explicit" else {}
+    ctx, _, _ = panner_graph(be, x, nq * RQ, **opts)
+    out = ctx.start_rendering_sync().data[0]
+    xin = np.zeros(nq * RQ)
+    xin[:3 * RQ] = (np.float32(0.5) * (x[0, 0] + x[0, 1])).astype(np.float32)
+    h = sample_bilinear(direction_of((1.0, 0.0, 0.0)))
+    corr = [2.0 if (q < 3 or mode == "explicit") else 1.0 for q in range(nq)]
+    ref = definition_render(xin, [h] * nq, corr, [q < 7 for q in range(nq)])
+    assert rms(out[0], ref[0]) <= 1e-6 and rms(out[1], ref[1]) <= 1e-6
+    assert np.any(out[:, 6 * RQ:7 * RQ] != 0.0) and np.all(out[:, 7 * RQ:] == 0.0)
+
+
 def _two_sources(be, a, b_, length, start_b, stop_b=None, position=(1.0, 0.0, 0.0)):
     ctx = waa.OfflineAudioContext(2, length, SR, n_instances=a.shape[0], binding=be)
     sa, sb = ctx.create_buffer_source(), ctx.create_buffer_source()

@@ -237,6 +237,52 @@ def test_channel_count_change_recreates_the_resamplers(be):
     assert rms(out[0], ref[0]) <= 1e-6 and rms(out[1], ref[1]) <= 1e-6
 
 
+def _stereo_shaper(be, x, curve, length, start, stop, **node_opts):
+    ctx = waa.OfflineAudioContext(2, length, SR, n_instances=x.shape[0], binding=be)
+    src = ctx.create_buffer_source()
+    src.set_buffer_batch(x, SR)
+    ws = ctx.create_wave_shaper(curve=curve, oversample="2x", **node_opts)
+    src.connect(ws).connect(ctx.destination())
+    src.start_at(start)
+    src.stop_at(stop)
+    return ctx
+
+
+def test_explicit_count_keeps_the_resamplers_over_silent_quanta(be):
+    """channelCountMode explicit, channelCount 2, a curve that does not map 0 to 0 (silent quanta are processed): the
+    silent input is MIXED to two channels like any other (quantum.rs:532-569 — it stays silent, its count is 2), so the
+    resamplers are never re-created at the active <-> silent transitions (waveshaper.rs:413-425) and their overlap carries
+    over.  (Round-2 advisor finding: the device treated every silent quantum as mono.)"""
+    curve = (TANH + np.float32(0.25)).astype(np.float32)
+    nq = 10
+    rng = np.random.default_rng(23)
+    x = rng.uniform(-1, 1, (1, 2, 4 * RQ)).astype(np.float32)
+    out = _stereo_shaper(be, x, curve, nq * RQ, 2 * RQ / SR, 6 * RQ / SR - 1e-9, channel_count=2,
+                         channel_count_mode="explicit").start_rendering_sync().data[0]
+    for c in range(2):
+        xin = np.zeros(nq * RQ)
+        xin[2 * RQ:6 * RQ] = x[0, c]
+        ref = definition_render(xin, curve, 2, active=[2 <= q < 6 for q in range(nq)], can_propagate=False)
+        assert rms(out[c], ref) <= 1e-6
+
+
+def test_max_mode_stereo_source_recreates_the_resamplers_at_silence(be):
+    """The same graph with the default channelCountMode max: the silent quanta are mono, so the count changes 1 -> 2 -> 1
+    and the resamplers start afresh at both transitions."""
+    curve = (TANH + np.float32(0.25)).astype(np.float32)
+    nq = 10
+    rng = np.random.default_rng(23)
+    x = rng.uniform(-1, 1, (1, 2, 4 * RQ)).astype(np.float32)
+    out = _stereo_shaper(be, x, curve, nq * RQ, 2 * RQ / SR, 6 * RQ / SR - 1e-9).start_rendering_sync().data[0]
+    for c in range(2):
+        ref = np.concatenate([definition_render(np.zeros(2 * RQ), curve, 2), definition_render(x[0, c].astype(np.float64), curve, 2),
+                              definition_render(np.zeros(4 * RQ), curve, 2)])
+        assert rms(out[c], ref) <= 1e-6
+    # (and the two differ where it matters: the first quantum after the source stopped)
+    keep = definition_render(np.concatenate([np.zeros(2 * RQ), x[0, 0], np.zeros(4 * RQ)]), curve, 2, can_propagate=False)
+    assert rms(out[0, 6 * RQ:7 * RQ], keep[6 * RQ:7 * RQ]) > 1e-3
+
+
 @pytest.mark.gpu
 def test_oversample_many_instances_sampled(hip, orc):
     """C5-shaped batch (256 contexts x 2 s, stereo, per-instance start times) on the device, sampled instances against

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(64) void link_kernel(const LinkDesc d) {
             link = LINK_SKIP;
             oc = (uint8_t)(1u | CODE_SILENT);
           } else {
-            const int nch = silent ? 1 : (int)(c & 7u);
+            // (a silent quantum keeps the count it was MIXED to — explicit mode: the node's channelCount, quantum.rs:532-569 —
+            // not 1: the code carries it)
+            const int nch = (int)(c & 7u);
             if (nch != cur_ch) {  // the resamplers are re-created for the new channel count: their overlap is gone
               cur_ch = nch;
               last = LINK_FRESH;
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(256) void hrtf_kernel(const HrtfDesc d) {
             m1 = 0.5f * (m1 + load_global(src + d.in.ch_stride + f + 64 + lane));
           }
         }
-        if (e == 0) corr = (!(c & CODE_SILENT) && (c & 7u) >= 2) ? 2.f : 1.f;
+        if (e == 0) corr = (c & 7u) >= 2 ? 2.f : 1.f;  // (panner.rs:800-810: by the quantum's count, silent or not)
       }
       const int p0 = O - e * RQ + lane, p1 = p0 + 64;
       if (p0 >= 0) xw[p0] = m0;
@@ -950,7 +952,7 @@ __global__ __launch_bounds__(64) void hrtf8_kernel(const HrtfDesc d) {
               m1 = 0.5f * (m1 + load_global(src + d.in.ch_stride + f + 64 + lane));
             }
           }
-          if (e == 0) corr = (!(c & CODE_SILENT) && (c & 7u) >= 2) ? 2.f : 1.f;
+          if (e == 0) corr = (c & 7u) >= 2 ? 2.f : 1.f;  // (panner.rs:800-810: by the quantum's count, silent or not)
         }
         const int p0 = O - e * RQ + lane, p1 = p0 + 64;
         if (p0 >= 0) xw[p0] = m0;

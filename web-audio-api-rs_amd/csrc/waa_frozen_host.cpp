@@ -125,6 +125,11 @@ static int plan_link(waa_batch* b, uint32_t id, int kind, int src_id, uint32_t t
   if (src_id >= 0) {
     int e = source_code_rows(b, (uint32_t)src_id, cs, &host_codes);
     if (e) return e;
+    // the node's MIXED input: a silent (mono) quantum of the source is mixed to the node's computed count like any other
+    // (quantum.rs:532-569) — with channelCountMode explicit that is the node's channelCount, and the quantum stays silent
+    const uint8_t silent_code = (uint8_t)((uint32_t)computed_in_nch(n, 1) | CODE_SILENT);
+    for (uint8_t& c : host_codes)
+      if (c & CODE_SILENT) c = silent_code;
     uint8_t* up = nullptr;
     if ((e = dev_upload(b, &up, host_codes))) return e;
     d_in = up;
@@ -148,7 +153,7 @@ static int plan_link(waa_batch* b, uint32_t id, int kind, int src_id, uint32_t t
           if (silent && can_propagate) {
             link = LINK_SKIP;
           } else {
-            const int nch = silent ? 1 : (int)(c & 7u);
+            const int nch = (int)(c & 7u);  // (the mixed count, also in silent quanta)
             if (nch != cur_ch) {
               cur_ch = nch;
               last = LINK_FRESH;
