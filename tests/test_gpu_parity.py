@@ -509,6 +509,34 @@ def test_c4_full_size_real_ir_sampled(hip, orc):
         assert np.abs(gl - ol).max() <= 1e-8 + 1e-3 * np.abs(ol).max()
 
 
+def test_t1_north_star_size_real_ir_sampled(hip, orc):
+    """The north-star target graph at ITS size: 1024 contexts x 10 s, BufferSource -> Biquad(lowpass 200 Hz, Q 1) ->
+    Convolver(the real parking-garage response, 2 x 178 899 frames, normalised) -> destination — the batch bench.py's `t1`
+    record times (512 instance pairs x 2 channels x 59 blocks through the N = 16384 transforms).  The oracle renders a
+    sample of the contexts: first and last, both members of a pair, and the two around the middle."""
+    n_inst, frames = 1024, 480000
+    noise = _noise_fast(n_inst, 2, frames, 34)
+    pick = [0, 1, 511, 512, 1022, 1023]
+    ctx, _ = t1(hip, noise, garage_ir(hip))
+    plan = ctx.plan_describe()
+    assert "P=22 blocks=59 pairs=512" in plan and "biquad_stream" in plan
+    out = ctx.render_instances(pick)
+    ctx.close()
+    octx, _ = t1(orc, noise[pick], garage_ir(orc))
+    ref = octx.start_rendering_sync().data
+    octx.close()
+    err = rms_err(out, ref)
+    assert err.max() <= TOL, err
+    assert float(np.abs(ref).max()) > 1e-3
+    # size-independent: the two members of a pair share one complex transform (a + i b) — their results must not leak into
+    # each other: instance 0 rendered again next to a DIFFERENT partner gives the same samples
+    swapped = noise[[0, 700]].copy()
+    ctx, _ = t1(hip, swapped, garage_ir(hip))
+    again = ctx.start_rendering_sync().data
+    ctx.close()
+    assert np.abs(again[0] - out[0]).max() <= 2e-6
+
+
 @pytest.mark.parametrize("rate,buf_sr,n_ch", [(1.5, None, 2), (1.0, 38000.0, 2), (1.5, None, 1)])
 def test_c5_full_size_sampled(hip, orc, rate, buf_sr, n_ch):
     """BASELINE config 5 at full size: 2048 contexts x 10 s, looping BufferSource with playbackRate 1.5 (or a 38 kHz

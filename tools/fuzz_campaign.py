@@ -1,0 +1,120 @@
+#!/usr/bin/env python
+"""tools/fuzz_campaign.py --first F --count N [--jobs J] [--out FILE] — the random-graph parity campaign as a tracked
+artefact (GPU box): seeds [F, F + N) of BOTH generators of tests/test_fuzz_graphs.py (the plain one and the one with
+oversampled WaveShapers / HRTF panners mixed in) are rendered by the HIP library and by the oracle; the JSON record holds
+the seed ranges, the counts (equal / refused with status 4 by reason / mismatching / errors), every mismatching seed with
+its error figures, and the library build it ran on.  J worker processes share the GPU (each has its own HIP context; the
+work is host-bound: planning + the oracle's render).  The suite itself runs 60 + 40 seeds of the same generators; this is
+the at-scale run DESIGN.md section 3.4 quotes."""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def worker(first, count, frozen, out_path):
+    import numpy as np
+
+    import web_audio_api_rs_amd as waa
+    from graphs import rms_err
+    from test_fuzz_graphs import build_random_graph
+
+    waa.set_hrtf_database(os.path.join(ROOT, "tests", "golden", "IRC_1003_C.bin"))
+    hip = waa.default_binding()
+    orc = waa.bind(ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_")
+    rec = {"equal": 0, "refused": {}, "mismatch": [], "errors": [], "worst_rms": 0.0, "worst_max": 0.0}
+    for seed in range(first, first + count):
+        try:
+            ch, descr = build_random_graph(hip, seed, frozen=frozen)
+            try:
+                g = ch.start_rendering_sync().data
+            except waa.WaaError as e:
+                if e.status == 4:
+                    msg = str(e)
+                    key = ("convolver in a feedback loop" if "ConvolverNode inside a feedback loop" in msg else
+                           "oversampled shaper / HRTF panner in a feedback loop" if "inside a feedback loop is out of scope" in msg else
+                           "param modulated from inside its loop" if "modulat" in msg else msg[:70])
+                    rec["refused"][key] = rec["refused"].get(key, 0) + 1
+                    ch.close()
+                    continue
+                raise
+            ch.close()
+            co, _ = build_random_graph(orc, seed, frozen=frozen)
+            o = co.start_rendering_sync().data
+            co.close()
+            scale = max(1.0, float(np.abs(o).max()))
+            rms, mx = float(rms_err(g, o).max()) / scale, float(np.abs(g - o).max()) / scale
+            if not np.isfinite(o).all() or not (rms <= 1e-6 and mx <= 2e-5):
+                rec["mismatch"].append({"seed": seed, "rms": rms, "max": mx, "graph": str(descr)[:300]})
+            else:
+                rec["equal"] += 1
+                rec["worst_rms"] = max(rec["worst_rms"], rms)
+                rec["worst_max"] = max(rec["worst_max"], mx)
+        except Exception as e:  # noqa: BLE001 — a crash of one seed is a finding, not the end of the run
+            rec["errors"].append({"seed": seed, "error": repr(e)[:300]})
+    json.dump(rec, open(out_path, "w"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--first", type=int, default=100000)
+    ap.add_argument("--count", type=int, default=5000)
+    ap.add_argument("--jobs", type=int, default=8)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_fuzz.json"))
+    ap.add_argument("--worker", nargs=4, default=None, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.worker:
+        worker(int(args.worker[0]), int(args.worker[1]), args.worker[2] == "1", args.worker[3])
+        return
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    t0 = time.time()
+    procs = []
+    for frozen in (0, 1):
+        per = (args.count + args.jobs - 1) // args.jobs
+        for j in range(args.jobs):
+            lo = args.first + j * per
+            n = min(per, args.first + args.count - lo)
+            if n <= 0:
+                continue
+            part = f"{args.out}.part{frozen}_{j}"
+            procs.append((frozen, lo, n, part, subprocess.Popen(
+                [sys.executable, os.path.abspath(__file__), "--worker", str(lo), str(n), str(frozen), part])))
+    total = {}
+    for frozen, lo, n, part, p in procs:
+        rc = p.wait()
+        gen = "frozen-state generator (oversampled WaveShapers, HRTF panners)" if frozen else "plain generator"
+        t = total.setdefault(gen, {"seeds": [args.first, args.first + args.count], "equal": 0, "refused": {}, "mismatch": [],
+                                   "errors": [], "worst_rms": 0.0, "worst_max": 0.0})
+        if rc != 0 or not os.path.exists(part):
+            t["errors"].append({"seed_range": [lo, lo + n], "error": f"worker exited with {rc}"})
+            continue
+        r = json.load(open(part))
+        os.remove(part)
+        t["equal"] += r["equal"]
+        for k, v in r["refused"].items():
+            t["refused"][k] = t["refused"].get(k, 0) + v
+        t["mismatch"] += r["mismatch"]
+        t["errors"] += r["errors"]
+        t["worst_rms"] = max(t["worst_rms"], r["worst_rms"])
+        t["worst_max"] = max(t["worst_max"], r["worst_max"])
+    for t in total.values():
+        t["refused_total"] = sum(t["refused"].values())
+    lib = os.path.join(ROOT, "web-audio-api-rs_amd", "csrc", "libwaa_hip.so")
+    out = {"what": "random Web Audio graphs (tests/test_fuzz_graphs.py::build_random_graph), HIP library vs oracle, 3 contexts x "
+                   "10440 frames each; equal = RMS <= 1e-6 and max |d| <= 2e-5 (relative to max(1, peak)) on every channel",
+           "generators": total, "wall_s": round(time.time() - t0, 1), "jobs": args.jobs,
+           "libwaa_hip_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]}
+    json.dump(out, open(args.out, "w"), indent=1)
+    print(json.dumps({g: {k: (v if k != "mismatch" else [m["seed"] for m in v]) for k, v in t.items()} for g, t in total.items()}))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,27 @@
+#!/bin/bash
+# tools/gpu_call.sh <tag> <section> [<section> ...] — one gpurun call's worth of GPU work (run from the repo root on the GPU
+# box); every section has its own time limit and writes under gpurun_out/<tag>_*.  Sections:
+#   tests      pytest -m gpu with durations
+#   abfft      same-process A/B of the N = 16384 convolver transforms (three register passes vs the round-2 radix-4-in-LDS form)
+#   bench      the default bench line (+ the detail file)
+#   pmc:<w>    rocprofv3 stats / FETCH_SIZE / WRITE_SIZE passes of bench workload <w>
+#   line:<w>   one bench line of workload <w>
+#   fuzz:<n>   tools/fuzz_campaign.py over n seeds per generator
+set -u
+TAG=$1; shift
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for S in "$@"; do
+  echo "=== $S"
+  case $S in
+    tests)  timeout 900 python -m pytest tests -m gpu -q -x --durations=15 > gpurun_out/${TAG}_gputests.log 2>&1; echo "rc=$?"; tail -5 gpurun_out/${TAG}_gputests.log ;;
+    testsall) timeout 900 python -m pytest tests -m gpu -q --durations=15 > gpurun_out/${TAG}_gputests.log 2>&1; echo "rc=$?"; tail -15 gpurun_out/${TAG}_gputests.log ;;
+    abfft)  AB_REPS=2 AB_ITERS=5 timeout 300 python tools/ab_env.py WAA_CONV_FFT_R4 t1 c3 > gpurun_out/${TAG}_ab_fft.txt 2>&1; cat gpurun_out/${TAG}_ab_fft.txt | tail -12 ;;
+    ab:*)   V=${S#ab:}; AB_REPS=2 AB_ITERS=5 timeout 300 python tools/ab_env.py ${V%%@*} ${V#*@} > gpurun_out/${TAG}_ab_${V%%[@=]*}.txt 2>&1; tail -12 gpurun_out/${TAG}_ab_${V%%[@=]*}.txt ;;
+    bench)  timeout 1200 python bench.py --detail gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "rc=$?"; wc -c gpurun_out/${TAG}_bench_default.json; cat gpurun_out/${TAG}_bench_default.json; tail -3 gpurun_out/${TAG}_bench_default.err ;;
+    pmc:*)  W=${S#pmc:}; timeout 600 bash tools/pmc_pass.sh $W ${TAG}_$W > /dev/null 2>&1; head -12 gpurun_out/${TAG}_${W}_stats.txt ;;
+    line:*) W=${S#line:}; timeout 300 python bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-extra > gpurun_out/${TAG}_bench_$W.json 2> gpurun_out/${TAG}_bench_$W.err; cat gpurun_out/${TAG}_bench_$W.json | cut -c1-1500 ;;
+    fuzz:*) N=${S#fuzz:}; timeout 1500 python tools/fuzz_campaign.py --first 100000 --count $N --jobs 8 --out gpurun_out/${TAG}_fuzz.json 2> gpurun_out/${TAG}_fuzz.err | cut -c1-3000; tail -3 gpurun_out/${TAG}_fuzz.err ;;
+    *) echo "unknown section $S" ;;
+  esac
+done
