@@ -31,8 +31,9 @@ def position_bins():
     return (r >> 5) + 32 * (r & 31) + 1024 * k3
 
 
+@pytest.mark.parametrize("half_tw", [False, True])
 @pytest.mark.parametrize("seed,kind", [(1, "noise"), (2, "noise"), (3, "impulse"), (4, "real-pair")])
-def test_three_pass_fft_matches_f64_dft(emulator, tmp_path, seed, kind):
+def test_three_pass_fft_matches_f64_dft(emulator, tmp_path, seed, kind, half_tw):
     rng = np.random.default_rng(seed)
     if kind == "noise":
         z = rng.uniform(-1, 1, 16384) + 1j * rng.uniform(-1, 1, 16384)
@@ -45,7 +46,10 @@ def test_three_pass_fft_matches_f64_dft(emulator, tmp_path, seed, kind):
     z = z.astype(np.complex64)
     fin, fspec, finv = (str(tmp_path / n) for n in ("in.bin", "spec.bin", "inv.bin"))
     z.tofile(fin)
-    subprocess.check_call([emulator, fin, fspec, finv])
+    env = dict(os.environ)
+    if half_tw:
+        env["F3_HALF_TW"] = "1"  # pass 1 with half the twiddle registers (the kernel with the Biquad folded in)
+    subprocess.check_call([emulator, fin, fspec, finv], env=env)
     spec = np.fromfile(fspec, dtype=np.complex64)
     inv = np.fromfile(finv, dtype=np.complex64)
     ref = np.fft.fft(z.astype(np.complex128))[position_bins()]

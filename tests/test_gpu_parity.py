@@ -509,6 +509,54 @@ def test_c4_full_size_real_ir_sampled(hip, orc):
         assert np.abs(gl - ol).max() <= 1e-8 + 1e-3 * np.abs(ol).max()
 
 
+def _t1_like(be, noise, ir, length, highpass=False, via_gain=False):
+    """source [-> Gain with a second consumer] -> Biquad -> Convolver -> destination"""
+    n_inst = noise.shape[0]
+    ctx = waa.OfflineAudioContext(2, length, 48000.0, n_instances=n_inst, binding=be)
+    src = ctx.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    node = src
+    if via_gain:  # the Biquad's input is a signal some other consumer materialises anyway (fan-out)
+        node = src.connect(ctx.create_gain(gain=0.7))
+        node.connect(ctx.create_gain(gain=0.1)).connect(ctx.destination())
+    bq = ctx.create_biquad_filter(type_="highpass" if highpass else "lowpass", frequency=900.0 if highpass else 200.0, q=1.3)
+    for i in range(n_inst):  # per-instance coefficients
+        bq.frequency.set_value(200.0 + 150.0 * i, instance=i)
+    node.connect(bq).connect(ctx.create_convolver(buffer=waa.AudioBuffer(ir, 48000.0))).connect(ctx.destination())
+    src.start()
+    return ctx
+
+
+@pytest.mark.parametrize("case", ["stereo-odd", "mono", "short-buffer", "via-gain", "highpass-one"])
+def test_biquad_folded_into_the_forward_transform(hip, orc, monkeypatch, case):
+    """source -> Biquad(constant coefficients) -> Convolver(long IR): the forward transform's input stage filters the
+    blocks (conv_fft3_fwd_bq_kernel, no Biquad launch, no filtered signal in HBM).  Checked against the oracle and against
+    the two-launch plan (WAA_NO_CONV_BIQUAD_FOLD=1): odd instance count (half-empty last pair), mono input, a buffer that
+    ends before the render does (the filter's tail rings into the convolver), a Biquad fed by a materialised signal, one
+    instance."""
+    ir = garage_ir(hip)
+    length = 8192 * 4 + 1000
+    n_inst, n_ch, buf = {"stereo-odd": (5, 2, length), "mono": (4, 1, length), "short-buffer": (3, 2, 128 * 150),
+                         "via-gain": (3, 2, length), "highpass-one": (1, 2, length)}[case]
+    noise = white_noise(n_inst, n_ch, buf)
+    kw = dict(highpass=case == "highpass-one", via_gain=case == "via-gain")
+    ctx = _t1_like(hip, noise, ir, length, **kw)
+    plan = ctx.plan_describe()
+    assert "filtered by the forward transform's input stage" in plan and "biquad_stream" not in plan
+    got = ctx.start_rendering_sync().data
+    ctx.close()
+    octx = _t1_like(orc, noise, garage_ir(orc), length, **kw)
+    ref = octx.start_rendering_sync().data
+    octx.close()
+    assert rms_err(got, ref).max() <= TOL
+    monkeypatch.setenv("WAA_NO_CONV_BIQUAD_FOLD", "1")
+    ctx = _t1_like(hip, noise, ir, length, **kw)
+    assert "biquad_stream" in ctx.plan_describe()
+    two = ctx.start_rendering_sync().data
+    ctx.close()
+    assert np.abs(got - two).max() <= 1e-7 * max(1.0, float(np.abs(two).max()))  # same arithmetic, same order
+
+
 def test_t1_north_star_size_real_ir_sampled(hip, orc):
     """The north-star target graph at ITS size: 1024 contexts x 10 s, BufferSource -> Biquad(lowpass 200 Hz, Q 1) ->
     Convolver(the real parking-garage response, 2 x 178 899 frames, normalised) -> destination — the batch bench.py's `t1`

@@ -38,14 +38,26 @@ def test_t1_and_c4_plans(hip):
     noise, ir = white_noise(5, 2, 480000), garage_like_ir()
     ctx, _ = t1(hip, noise, ir, device=waa.PLAN_ONLY)
     lines = plan(ctx)
-    assert "biquad_stream in=source:2ch gains=0 out=final" in lines
+    # the Biquad in front of the long convolver is rendered by the forward transform's input stage: no launch, no signal
+    assert not any(l.startswith("biquad_stream") for l in lines)
+    assert any("filtered by the forward transform's input stage (its source is read in place)" in l for l in lines)
     conv = [l for l in lines if l.startswith("convolver")]
     assert len(conv) == 1 and "fft B=8192 N=16384 P=22 blocks=59 pairs=3 cin=2 cout=2 terms=2" in conv[0]
+    assert "the Biquad in front, in the forward transform" in conv[0]
     assert lines[-1].startswith("alias node 0")  # the destination aliases the convolver output: no copy
     ctx, _ = c4(hip, noise, ir, device=waa.PLAN_ONLY)
     lines = plan(ctx)
     assert "chain parallel C=2 in=[signal:2ch]->2ch ops=[STEREO_PAN] out=2ch" in lines
     assert lines[-1].startswith("alias node 0")  # analyser output == destination
+
+
+def test_t1_unfolded_plan_switch(hip, monkeypatch):
+    """WAA_NO_CONV_BIQUAD_FOLD=1 keeps the Biquad a launch of its own (same-box A/B, and the parity tests' cross-check)."""
+    monkeypatch.setenv("WAA_NO_CONV_BIQUAD_FOLD", "1")
+    ctx, _ = t1(hip, white_noise(5, 2, 480000), garage_like_ir(), device=waa.PLAN_ONLY)
+    lines = plan(ctx)
+    assert "biquad_stream in=source:2ch gains=0 out=final" in lines
+    assert not any("in the forward transform" in l for l in lines)
 
 
 def test_c5_slow_track_goes_to_the_parallel_kernel(hip):

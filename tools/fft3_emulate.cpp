@@ -32,7 +32,13 @@ int main(int argc, char** argv) {
     c2v tws[32];
     load_tw1_slots(tw.data(), t, tws);
     for (int n1 = 0; n1 < 32; n1++) X(t)[n1] = z[n1 * 512 + t];
-    fwd_pass1_compute(X(t), tws);
+    if (getenv("F3_HALF_TW")) {  // (the filter-stage kernel's form of pass 1)
+      c2v twh[16], w16;
+      load_tw1_half(tw.data(), t, twh, w16);
+      fwd_pass1_compute_half(X(t), twh, w16);
+    } else {
+      fwd_pass1_compute(X(t), tws);
+    }
     fwd_pass1_write(X(t), lds.data(), t);
   }
   for (int t = 0; t < NT; t++) fwd_pass2_compute(X(t), lds.data(), t);

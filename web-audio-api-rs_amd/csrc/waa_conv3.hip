@@ -17,6 +17,7 @@
 
 #include "waa_fft3.hpp"
 #include "waa_internal.hpp"
+#include "waa_stream_common.hpp"
 
 namespace waa {
 
@@ -159,6 +160,348 @@ __global__ __launch_bounds__(NT) void conv_fft3_fwd_kernel(const ConvDesc d, int
   }
 }
 
+// ---- forward transform with the BiquadFilterNode in front of the convolver folded into its input stage ----------------
+// T1 / C4 (the north-star graph): source -> Biquad -> Convolver.  As two launches the filtered signal is written and read
+// back once (7.9 GB of the 49 GB a T1 render moved, and a 1.3-1.6 ms launch of its own); here the workgroup that transforms
+// block k of (pair, channel) first FILTERS the block's 8192 new frames of both instances:
+//   * the raw frames arrive coalesced (16 B per lane, prefetched one block ahead) and are transposed through LDS so that
+//     thread (half h, j) owns the 32 consecutive frames [32 j, 32 j + 32) of instance a (h = 0) or b (h = 1): four
+//     wavefronts per stream, in time order;
+//   * the recurrence is the scheme of waa_biquad_stream.hip, one level deeper: zero-state response per lane, DPP scan of
+//     the affine maps inside each wavefront (A = M^32, powers A .. A^8 within a row, A^16 across rows), the wavefronts' end
+//     states combined through LDS with A^64 — and then the reference's evaluation order, unfused, from every lane's true
+//     incoming state (biquad_filter.rs:877-883); the FIR part is recomputed in the second pass instead of kept (registers);
+//   * the results go back through LDS into pass 1's layout (thread m holds frames m, m + 512, ... of both instances).
+// The streams are serial in time, so a workgroup owns a whole (pair, channel): blocks_per_wg = nb.
+namespace bq {
+// LDS map of the filter stage.  Rows of 32 frames + 4 (conflict-free 16-byte row accesses), 256 rows per instance, in the
+// exchange buffer's space (free until pass 1 writes E1); the small f64 tables live behind the exchange buffer.
+constexpr int ROW = 36, HALF = 256 * ROW;            // floats
+constexpr int TAB = 160;                              // doubles per instance half
+constexpr int T_A1 = 0, T_A2 = 4, T_A4 = 8, T_A8 = 12, T_A16 = 16, T_A64 = 20, T_CO = 24, T_AJ = 32, T_W = 96, T_CY = 104, T_CX = 106;
+constexpr int TW3_OFF = LDS_BYTES + 2 * TAB * 8;    // bytes: pass 3's W_512 twiddles, [m2][k2] (they depend on k2 = t mod 32 only)
+constexpr int LDS_BYTES_BQ = TW3_OFF + 16 * 32 * 8;
+struct M2 {
+  double a, b, c, d;
+};
+__device__ __forceinline__ M2 mm(const M2& x, const M2& y) {
+  M2 r;
+  r.a = __builtin_fma(x.a, y.a, x.b * y.c);
+  r.b = __builtin_fma(x.a, y.b, x.b * y.d);
+  r.c = __builtin_fma(x.c, y.a, x.d * y.c);
+  r.d = __builtin_fma(x.c, y.b, x.d * y.d);
+  return r;
+}
+typedef __attribute__((address_space(3))) double* ldsd;
+__device__ __forceinline__ M2 ld_m2(const __attribute__((address_space(3))) double* p) { return M2{p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void mv(const M2& m, double x1, double x2, double e1, double e2, double& o1, double& o2) {
+  o1 = __builtin_fma(m.a, x1, __builtin_fma(m.b, x2, e1));
+  o2 = __builtin_fma(m.c, x1, __builtin_fma(m.d, x2, e2));
+}
+}  // namespace bq
+
+__global__ __launch_bounds__(NT) void conv_fft3_fwd_bq_kernel(const ConvDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  ldsp lds = (ldsp)lds_raw;
+  typedef __attribute__((address_space(3))) float* ldsf;
+  const ldsf ldf = (ldsf)lds_raw;
+  const int t = threadIdx.x;
+  const c2v* twg = reinterpret_cast<const c2v*>(d.tw);
+  c2v twh[16], w16;
+  load_tw1_half(twg, t, twh, w16);
+  // (pass 3's twiddles live in LDS here, not in registers: the filter stage needs them)
+  const ldsp tw3s = (ldsp)(lds_raw + bq::TW3_OFF / 4);
+  tw3s[t] = twg[((t >> 5) * (t & 31) * 32) & (N - 1)];  // entry [m2 = t >> 5][k2 = t & 31]
+  const int c = blockIdx.y;
+  const uint32_t pair = blockIdx.z;
+  const uint32_t ia = pair * 2, ib = pair * 2 + 1;
+  const bool has_b = ib < d.n_inst;
+  // f64 denormals: flush inputs and outputs, like the reference's FTZ/DAZ render scope (waa_biquad_stream.hip)
+  __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);
+  // filter-stage roles: half h filters instance a (0) or b (1); j = the thread's row, wv = its wavefront in time order
+  const int h = __builtin_amdgcn_readfirstlane(t >> 8);
+  const int j = t & 255, lane = t & 63, row = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane((t >> 6) & 3);
+  const uint32_t inst_h = h && has_b ? ib : ia;
+  const float* ph = d.in.base + (uint64_t)inst_h * d.in.inst_stride + (uint64_t)c * d.in.ch_stride;
+  c2v* xbase = reinterpret_cast<c2v*>(d.X) + ((uint64_t)pair * d.cin + c) * d.nb * N;
+  const bq::ldsd tab = (bq::ldsd)(lds_raw + LDS_BYTES / 4) + h * bq::TAB;
+  double* stp = d.pre_state + (uint64_t)inst_h * STATE_STRIDE + c * 4;
+  {
+    // coefficients and the powers of the 32-step transition A = M^32, M = [[-a1, -a2], [1, 0]]: once per workgroup, in LDS
+    const double* cp = d.pre_coefs + (uint64_t)inst_h * d.pre_coef_stride;
+    const double a1 = cp[3], a2 = cp[4];
+    bq::M2 m = {-a1, -a2, 1., 0.};
+#pragma unroll
+    for (int sq = 0; sq < 5; sq++) m = bq::mm(m, m);
+    const bq::M2 A1 = m, A2 = bq::mm(A1, A1), A4 = bq::mm(A2, A2), A8 = bq::mm(A4, A4), A16 = bq::mm(A8, A8);
+    const bq::M2 A32 = bq::mm(A16, A16), A64 = bq::mm(A32, A32);
+    if (j < 16) {  // A^(lane % 16)
+      bq::M2 Aj = {1., 0., 0., 1.};
+      if (j & 1) Aj = bq::mm(Aj, A1);
+      if (j & 2) Aj = bq::mm(Aj, A2);
+      if (j & 4) Aj = bq::mm(Aj, A4);
+      if (j & 8) Aj = bq::mm(Aj, A8);
+      tab[bq::T_AJ + j * 4 + 0] = Aj.a;
+      tab[bq::T_AJ + j * 4 + 1] = Aj.b;
+      tab[bq::T_AJ + j * 4 + 2] = Aj.c;
+      tab[bq::T_AJ + j * 4 + 3] = Aj.d;
+    }
+    if (j == 0) {
+      const bq::M2 ms[6] = {A1, A2, A4, A8, A16, A64};
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        tab[q * 4 + 0] = ms[q].a;
+        tab[q * 4 + 1] = ms[q].b;
+        tab[q * 4 + 2] = ms[q].c;
+        tab[q * 4 + 3] = ms[q].d;
+      }
+#pragma unroll
+      for (int q = 0; q < 5; q++) tab[bq::T_CO + q] = cp[q];
+      // carried state: x[n-1], x[n-2], y[n-1], y[n-2] (biquad_filter.rs:761)
+      tab[bq::T_CX + 0] = stp[0];
+      tab[bq::T_CX + 1] = stp[1];
+      tab[bq::T_CY + 0] = stp[2];
+      tab[bq::T_CY + 1] = stp[3];
+    }
+  }
+  // raw input of a block, coalesced: thread (h, j) asks for frames 4 (j + 256 r) .. + 3, r < 8, of its instance
+  f4v_ raw[8];
+  auto load_raw = [&](int64_t f0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int64_t f = f0 + 4 * (int64_t)(j + 256 * r);
+      const int64_t fc = (uint64_t)f + 3 < d.in_valid ? f : 0;  // (clamped; zeroed when staged)
+      raw[r] = *reinterpret_cast<const f4v_*>(ph + fc);
+    }
+  };
+  load_raw(0);
+  c2v hold[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) hold[q] = c2v{0.f, 0.f};  // block 0's first half: frames before the stream
+#pragma unroll
+  for (int r = 0; r < 8; r++) asm volatile("" : "+v"(raw[r])::"memory");
+  for (int k = 0; k < d.nb; k++) {
+    const int tk = f3_opaque(t);
+    const int jk = tk & 255;
+    f3_barrier();  // the previous block's pass 3 has read its rows; the filter tables are written
+    // ---- stage the raw block: row (frame >> 5), column (frame & 31) of the half's buffer
+    {
+      const ldsf rb = ldf + h * bq::HALF;
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int64_t f = (int64_t)k * B + 4 * (int64_t)(jk + 256 * r);
+        const bool ok = (uint64_t)f + 3 < d.in_valid;
+        const f4v_ z = {0.f, 0.f, 0.f, 0.f};
+        const int fl = 4 * (jk + 256 * r);
+        *(__attribute__((address_space(3))) f4v_*)(rb + (fl >> 5) * bq::ROW + (fl & 31)) = ok ? raw[r] : z;
+      }
+    }
+    load_raw(k + 1 < d.nb ? ((int64_t)k + 1) * B : (int64_t)d.in_valid);  // the next block: in flight during this one
+    f3_barrier();
+    // ---- this thread's 32 frames, the two before them, and the block's last two (next block's x history)
+    const ldsf myrow = ldf + h * bq::HALF + jk * bq::ROW;
+    float x[32];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const f4v_ v = *(const __attribute__((address_space(3))) f4v_*)(myrow + q * 4);
+      x[q * 4 + 0] = v.x;
+      x[q * 4 + 1] = v.y;
+      x[q * 4 + 2] = v.z;
+      x[q * 4 + 3] = v.w;
+    }
+    double xs1, xs2;  // x[n-1], x[n-2] in front of this thread's chunk
+    {
+      const ldsf prow = ldf + h * bq::HALF + (jk > 0 ? jk - 1 : 0) * bq::ROW;
+      const float p1 = prow[31], p2 = prow[30];
+      const double c1 = tab[bq::T_CX + 0], c2 = tab[bq::T_CX + 1];
+      xs1 = jk > 0 ? (double)p1 : c1;
+      xs2 = jk > 0 ? (double)p2 : c2;
+    }
+    const ldsf lrow = ldf + h * bq::HALF + 255 * bq::ROW;
+    const float nx1 = lrow[31], nx2 = lrow[30];
+    const double b0 = tab[bq::T_CO + 0], b1 = tab[bq::T_CO + 1], b2 = tab[bq::T_CO + 2], a1 = tab[bq::T_CO + 3], a2 = tab[bq::T_CO + 4];
+    // ---- sweep 1: zero-state response of the chunk
+    double z1 = 0., z2 = 0.;
+    {
+      double x1 = xs1, x2 = xs2;
+#pragma unroll
+      for (int i = 0; i < 32; i++) {
+        const double xd = (double)x[i];
+        const double w = (b0 * xd + b1 * x1) + b2 * x2;
+        x2 = x1;
+        x1 = xd;
+        const double u = __builtin_fma(-a2, z2, w);
+        const double y = __builtin_fma(-a1, z1, u);
+        z2 = z1;
+        z1 = y;
+      }
+    }
+    // in-row inclusive scan (rows of 16 lanes): R_l = sum_{i in row, i <= l} A^(l - i) z_i
+    double r1 = z1, r2 = z2;
+    {
+      bq::M2 P = bq::ld_m2(tab + bq::T_A1);
+      double q1 = row_shr<1>(r1), q2 = row_shr<1>(r2);
+      bq::mv(P, q1, q2, r1, r2, r1, r2);
+      P = bq::ld_m2(tab + bq::T_A2);
+      q1 = row_shr<2>(r1);
+      q2 = row_shr<2>(r2);
+      bq::mv(P, q1, q2, r1, r2, r1, r2);
+      P = bq::ld_m2(tab + bq::T_A4);
+      q1 = row_shr<4>(r1);
+      q2 = row_shr<4>(r2);
+      bq::mv(P, q1, q2, r1, r2, r1, r2);
+      P = bq::ld_m2(tab + bq::T_A8);
+      q1 = row_shr<8>(r1);
+      q2 = row_shr<8>(r2);
+      bq::mv(P, q1, q2, r1, r2, r1, r2);
+    }
+    const bq::M2 A16 = bq::ld_m2(tab + bq::T_A16);
+    const double e01 = read_lane(r1, 15), e02 = read_lane(r2, 15), e11 = read_lane(r1, 31), e12 = read_lane(r2, 31);
+    const double e21 = read_lane(r1, 47), e22 = read_lane(r2, 47), e31 = read_lane(r1, 63), e32 = read_lane(r2, 63);
+    {
+      // zero-state end state of this wavefront's 2048 frames
+      double u1 = e01, u2 = e02;
+      bq::mv(A16, u1, u2, e11, e12, u1, u2);
+      bq::mv(A16, u1, u2, e21, e22, u1, u2);
+      bq::mv(A16, u1, u2, e31, e32, u1, u2);
+      if (lane == 0) {
+        tab[bq::T_W + wv * 2 + 0] = u1;
+        tab[bq::T_W + wv * 2 + 1] = u2;
+      }
+    }
+    f3_barrier();
+    // ---- the state entering this wavefront, its rows, this lane
+    double t1 = tab[bq::T_CY + 0], t2 = tab[bq::T_CY + 1];
+    {
+      const bq::M2 A64 = bq::ld_m2(tab + bq::T_A64);
+      for (int w = 0; w < wv; w++) bq::mv(A64, t1, t2, tab[bq::T_W + w * 2], tab[bq::T_W + w * 2 + 1], t1, t2);
+    }
+    double T1 = t1, T2 = t2;
+    {
+      double v1 = t1, v2 = t2;
+      bq::mv(A16, v1, v2, e01, e02, v1, v2);
+      if (row == 1) {
+        T1 = v1;
+        T2 = v2;
+      }
+      bq::mv(A16, v1, v2, e11, e12, v1, v2);
+      if (row == 2) {
+        T1 = v1;
+        T2 = v2;
+      }
+      bq::mv(A16, v1, v2, e21, e22, v1, v2);
+      if (row == 3) {
+        T1 = v1;
+        T2 = v2;
+      }
+    }
+    double s1, s2;
+    {
+      const bq::M2 Aj = bq::ld_m2(tab + bq::T_AJ + (lane & 15) * 4);
+      const double ex1 = row_shr<1>(r1), ex2 = row_shr<1>(r2);
+      bq::mv(Aj, T1, T2, ex1, ex2, s1, s2);
+    }
+    // ---- sweep 2: the reference's evaluation order from the true incoming state (biquad_filter.rs:877-883); the results go
+    // into the thread's own row four at a time (the row's input values are in registers)
+    double y1 = s1, y2 = s2;
+    {
+      float badacc = 0.f;  // becomes NaN as soon as one output is inf / NaN, off the critical path
+      double x1 = xs1, x2 = xs2;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        float yo[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const double xd = (double)x[q * 4 + e];
+          const double w = (b0 * xd + b1 * x1) + b2 * x2;
+          x2 = x1;
+          x1 = xd;
+          const double y = (w - a1 * y1) - a2 * y2;
+          y2 = y1;
+          y1 = y;
+          yo[e] = (float)y;
+          badacc = __builtin_fmaf(yo[e], 0.f, badacc);
+        }
+        *(__attribute__((address_space(3))) f4v_*)(myrow + q * 4) = f4v_{yo[0], yo[1], yo[2], yo[3]};
+      }
+      if (__any(badacc != badacc)) {  // inf / NaN somewhere: redo with the explicit flush
+        y1 = __builtin_isfinite(s1) ? s1 : 0.;
+        y2 = __builtin_isfinite(s2) ? s2 : 0.;
+        x1 = xs1;
+        x2 = xs2;
+#pragma unroll 1
+        for (int q = 0; q < 8; q++) {
+          float yo[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const double xd = (double)x[q * 4 + e];
+            const double w = (b0 * xd + b1 * x1) + b2 * x2;
+            x2 = x1;
+            x1 = xd;
+            double y = (w - a1 * y1) - a2 * y2;
+            if (!__builtin_isnormal(y)) y = 0.;
+            y2 = y1;
+            y1 = y;
+            yo[e] = (float)y;
+          }
+          *(__attribute__((address_space(3))) f4v_*)(myrow + q * 4) = f4v_{yo[0], yo[1], yo[2], yo[3]};
+        }
+      }
+    }
+    // the last thread of the stream publishes the carried state
+    if (jk == 255) {
+      tab[bq::T_CY + 0] = y1;
+      tab[bq::T_CY + 1] = y2;
+      tab[bq::T_CX + 0] = (double)nx1;
+      tab[bq::T_CX + 1] = (double)nx2;
+    }
+    f3_barrier();
+    // ---- pass 1's layout: thread m holds frames m, m + 512, ... of both instances
+    c2v xx[32];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int f = q * 512 + tk;
+      const int o = (f >> 5) * bq::ROW + (f & 31);
+      const float va = ldf[o], vb = ldf[bq::HALF + o];
+      xx[q] = hold[q];
+      xx[q + 16] = c2v{va, has_b ? vb : 0.f};
+      hold[q] = xx[q + 16];
+    }
+    fwd_pass1_compute_half(xx, twh, w16);
+    f3_barrier();  // every thread has read its frames
+    fwd_pass1_write(xx, lds, tk);
+    f3_barrier();
+    fwd_pass2_compute(xx, lds, tk);
+    f3_barrier();
+    fwd_pass2_write(xx, lds, tk);
+    f3_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; r++) asm volatile("" : "+v"(raw[r])::"memory");  // (the prefetch settles in front of the stores)
+    c2v* dst = xbase + (uint64_t)k * N;
+    c2v tw3[16];
+#pragma unroll
+    for (int m2 = 1; m2 < 16; m2++) tw3[m2] = tw3s[m2 * 32 + (tk & 31)];
+    tw3[0] = c2v{1.f, 0.f};
+#pragma unroll
+    for (int set = 0; set < 2; set++) {
+      const int r = tk + set * NT;
+      c2v y[16];
+      fwd_pass3(y, tw3, lds, r);
+#pragma unroll
+      for (int sl = 0; sl < 16; sl++) dst[K16(sl) * 1024 + r] = y[sl];
+    }
+  }
+  // final filter state (the batch's state buffer; a later launch of a block-scheduled plan would continue from it)
+  f3_barrier();
+  if (j == 0 && (h == 0 || has_b)) {
+    stp[0] = tab[bq::T_CX + 0];
+    stp[1] = tab[bq::T_CX + 1];
+    stp[2] = tab[bq::T_CY + 0];
+    stp[3] = tab[bq::T_CY + 1];
+  }
+}
+
 __global__ __launch_bounds__(NT) void conv_fft3_inv_kernel(const ConvDesc d, int blocks_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   ldsp lds = (ldsp)lds_raw;
@@ -245,6 +588,7 @@ static void f3_allow_lds() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft3_fwd_kernel<F3_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft3_fwd_kernel<F3_IR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft3_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft3_fwd_bq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   done = true;
 }
 // blocks per persistent workgroup: whole (pair, channel) streams when there are enough of them to fill the chip, shorter
@@ -262,6 +606,10 @@ void launch_conv3_ir_spectra(const ConvDesc& d, void* stream) {
 }
 void launch_conv3_forward(const ConvDesc& d, void* stream) {
   f3_allow_lds();
+  if (d.pre_coefs) {  // the filter in front is serial in time: one workgroup per (pair, channel) stream
+    hipLaunchKernelGGL(conv_fft3_fwd_bq_kernel, dim3(1, d.cin, d.n_pairs), dim3(NT), (size_t)bq::LDS_BYTES_BQ, (hipStream_t)stream, d);
+    return;
+  }
   const int bpw = f3_blocks_per_wg(d, d.cin);
   hipLaunchKernelGGL(conv_fft3_fwd_kernel<F3_FWD>, dim3((d.nb + bpw - 1) / bpw, d.cin, d.n_pairs), dim3(NT), (size_t)LDS_BYTES,
                      (hipStream_t)stream, d, bpw);

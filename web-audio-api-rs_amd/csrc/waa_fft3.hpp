@@ -269,6 +269,27 @@ F3_FN void fwd_pass1_compute(c2v (&x)[32], const c2v (&tws)[32]) {
 #pragma unroll
   for (int s = 1; s < 32; s++) x[s] = cmul(x[s], tws[s]);
 }
+// The same with HALF the twiddle registers (the filter-stage kernel is short of them): W_N^(t k1) for k1 < 16 and
+// W_N^(16 t); the upper half is their product (one more complex multiply per element, ~1 ulp on those twiddles).
+F3_FN void load_tw1_half(const c2v* tw, int t, c2v (&twh)[16], c2v& w16) {
+#pragma unroll
+  for (int k = 1; k < 16; k++) twh[k] = tw[(t * k) & (N - 1)];
+  twh[0] = c2v{1.f, 0.f};
+  w16 = tw[(t * 16) & (N - 1)];
+}
+F3_FN void fwd_pass1_compute_half(c2v (&x)[32], const c2v (&twh)[16], const c2v w16) {
+  dft32<false>(x);
+#pragma unroll
+  for (int s = 1; s < 32; s++) {
+    const int k1 = K32(s);
+    if (k1 < 16)
+      x[s] = cmul(x[s], twh[k1]);
+    else if (k1 == 16)
+      x[s] = cmul(x[s], w16);
+    else
+      x[s] = cmul(x[s], cmul(twh[k1 - 16], w16));
+  }
+}
 F3_FN void fwd_pass1_write(const c2v (&x)[32], ldsp lds, int t) {
 #pragma unroll
   for (int s = 0; s < 32; s++) lds[e1(K32(s), 0) + t] = x[s];

@@ -177,6 +177,9 @@ struct Node {
   // every instance) and whose only consumer is a node-major step that takes a bounded view: it is not materialised,
   // the consumer reads the buffer in place (view_valid frames per channel, zeros beyond)
   bool is_view = false;
+  // BiquadFilterNode with constant coefficients whose only consumer is a long ConvolverNode (three-pass transforms): the
+  // forward transform's input stage renders it (fold_conv = the convolver; the convolver's pre_biquad = this node)
+  int fold_conv = -1, pre_biquad = -1;
   // DelayNode outside a loop, constant / k-rate delayTime, consumed by chain input stages only: no reader pass, the
   // consumers gather from the delay line themselves (IN_DELAYED)
   bool delay_folded = false;

@@ -212,6 +212,11 @@ struct ConvDesc {
                       // `in` is a view of a source's buffer (the source renders its buffer unchanged from frame 0)
   uint32_t n_inst, n_pairs;
   int32_t ir_nch, pad1;
+  // A BiquadFilterNode with constant coefficients directly in front of the convolver, rendered by the forward transform's
+  // input stage (fft3 only; waa_conv3.hip): `in` is then the BIQUAD's input and its filtered signal never crosses HBM.
+  const double* pre_coefs;   // [n_inst][pre_coef_stride]: b0 b1 b2 a1 a2 (null: no filter)
+  uint64_t pre_coef_stride;
+  double* pre_state;         // [n_inst][STATE_STRIDE]: x1 x2 y1 y2 per channel (initial state in, final state out)
 };
 struct AnalyserDesc {
   SignalRef sig;         // the analyser's (passthrough) signal

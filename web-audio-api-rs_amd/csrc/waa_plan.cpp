@@ -582,6 +582,8 @@ void vertex_targets(const waa_batch* b, uint32_t v, const std::vector<uint8_t>& 
 int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items);
 int plan_delay_writer(waa_batch* b, uint32_t id);
 int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr);
+int conv_block_size(const waa_batch* b, const Node& n);
+int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector<OpDesc>& ops, int* out_nch);
 int plan_oscillator(waa_batch* b, uint32_t id);
 int plan_delay_reader(waa_batch* b, uint32_t id);
 int plan_folded_delay_line(waa_batch* b, uint32_t id);
@@ -1348,6 +1350,62 @@ int build_plan(waa_batch* b) {
       plan_note(b, "source node %u renders its AudioBuffer unchanged: node %d reads it in place (%llu frames per channel)", id, consumer,
                 (unsigned long long)b0.frames);
   }
+  // A BiquadFilterNode with constant coefficients directly in front of a long ConvolverNode (source -> Biquad -> Convolver,
+  // the north-star graph): the forward transform's input stage filters its blocks itself (conv_fft3_fwd_bq_kernel) — the
+  // filtered signal never crosses HBM and the Biquad costs no launch.  Its own input must be a plain signal: a
+  // BufferSource that renders its AudioBuffer unchanged (read in place) or a signal some other node materialises anyway.
+  for (auto& n : b->nodes) n.fold_conv = n.pre_biquad = -1;
+  if (!count_change_found && !b->force_dynamic && !getenv("WAA_NO_CONV_BIQUAD_FOLD") && !getenv("WAA_CONV_FFT_R4"))
+    for (uint32_t cid = 0; cid < N; cid++) {
+      Node& c = b->nodes[cid];
+      if (!c.live || c.desc.kind != WAA_NODE_CONVOLVER || !c.has_ir || scc_of[cid] >= 0 || c.in_edges.size() != 1) continue;
+      if (conv_block_size(b, c) != 8192) continue;
+      const uint32_t qid = b->edges[c.in_edges[0]].from;
+      Node& q = b->nodes[qid];
+      if (!q.live || q.desc.kind != WAA_NODE_BIQUAD || scc_of[qid] >= 0 || q.in_nch != q.out_nch || q.out_nch != c.in_nch || q.in_nch > 2 ||
+          q.in_edges.size() != 1)
+        continue;
+      int q_consumers = 0;
+      for (auto& e : b->edges) q_consumers += e.from == qid && b->nodes[e.to].live;
+      bool plain = q_consumers == 1;
+      for (auto& pe : q.pin_edges) plain = plain && pe.empty();
+      for (auto& ps : q.params) plain = plain && ps.mode() == 0 && ps.timelines.empty() && !ps.dev_tl;
+      if (!plain) continue;
+      const uint32_t sid = b->edges[q.in_edges[0]].from;
+      Node& sn = b->nodes[sid];
+      if (!sn.live || sn.out_nch != q.in_nch) continue;
+      if (sn.desc.kind == WAA_NODE_BUFFER_SOURCE && !sn.materialized && !sn.is_view && !getenv("WAA_NO_SOURCE_VIEW")) {
+        int s_consumers = 0;
+        for (auto& e : b->edges) s_consumers += e.from == sid && b->nodes[e.to].live;
+        const ParamStore& pr = sn.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
+        const ParamStore& pd = sn.params[WAA_PARAM_SOURCE_DETUNE];
+        bool ok = s_consumers == 1 && pr.blocks.empty() && pd.blocks.empty() && pr.timelines.empty() && pd.timelines.empty() &&
+                  !pr.dev_tl && !pd.dev_tl;
+        for (auto& pe : sn.pin_edges) ok = ok && pe.empty();
+        const DeviceBuffer& b0 = sn.bufs[0];
+        ok = ok && b0.valid && b0.sr == b->sr && (uintptr_t)b0.base % 16 == 0 && b0.ch_stride % 4 == 0 && b0.frames % RQ == 0 && b0.frames > 0;
+        const int64_t inst_stride = b->n_inst > 1 && sn.bufs[1].valid ? sn.bufs[1].base - b0.base : (int64_t)b0.ch_stride * b0.nch;
+        ok = ok && inst_stride > 0 && inst_stride % 4 == 0;
+        for (uint32_t i = 0; i < b->n_inst && ok; i++) {
+          const DeviceBuffer& bf = sn.bufs[i];
+          const SourceSched& ss = sn.sched[i];
+          ok = bf.valid && bf.base == b0.base + (int64_t)i * inst_stride && bf.ch_stride == b0.ch_stride && bf.frames == b0.frames &&
+               bf.nch == b0.nch && bf.sr == b0.sr && pr.cst[i] == 1.f && pd.cst[i] == 0.f && ss.start == 0. && ss.stop == DBL_MAX &&
+               ss.offset == 0. && ss.duration == DBL_MAX && !ss.looping;
+        }
+        if (!ok) continue;
+        sn.is_view = true;
+        sn.view_sig = SignalRef{b0.base, (uint64_t)inst_stride, b0.ch_stride, (int32_t)b0.nch, 0};
+        sn.view_valid = b0.frames;
+      } else if (!(mat_hard[sid] && !sn.is_view && !sn.delay_folded)) {
+        continue;
+      }
+      q.fold_conv = (int)cid;
+      q.materialized = false;
+      c.pre_biquad = (int)qid;
+      plan_note(b, "biquad node %u has constant coefficients and only feeds convolver node %u: filtered by the forward transform's input stage%s",
+                qid, cid, sn.is_view ? " (its source is read in place)" : "");
+    }
   auto alloc_signal = [&](Node& n) -> int {
     float* p = nullptr;
     int e = dev_alloc(b, &p, (size_t)b->n_inst * n.out_nch * b->lp);
@@ -2683,12 +2741,35 @@ int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items) {
   return 0;
 }
 
+// the partition size the FFT path picks for a node's impulse response (0: none / all-zero / direct FIR)
+int conv_block_size(const waa_batch* b, const Node& n) {
+  if (!n.has_ir) return 0;
+  uint64_t len = 0;
+  for (int c = 0; c < n.ir_nch; c++) {
+    uint64_t l = n.ir_len;
+    while (l > 0 && std::fabs(n.ir[c][l - 1]) < 0.000001f) l--;
+    len = std::max(len, l);
+  }
+  if (len == 0) return 0;
+  if (len <= (uint64_t)DIRECT_MAX_TAPS && !b->dynamic && !getenv("WAA_NO_DIRECT_FIR")) return 0;
+  for (int cand : {128, 512, 2048, 8192})
+    if ((len + cand - 1) / cand <= 24) return cand;
+  return 8192;
+}
+
 int plan_convolver(waa_batch* b, uint32_t id) {
   Node& n = b->nodes[id];
   SignalRef in_sig{};
   uint64_t in_valid = b->lp;
   if (b->dynamic && n.hist.base) {
     in_sig = n.hist;  // dynamic plans: the mixed input was published by the DK_CONV_IN item (waa_dyn.hip)
+  } else if (n.pre_biquad >= 0) {
+    // the Biquad in front is rendered by the forward transform: the transform reads the BIQUAD's input
+    const Node& q = b->nodes[(uint32_t)n.pre_biquad];
+    const Node& sn = b->nodes[b->edges[q.in_edges[0]].from];
+    in_sig = sn.is_view ? sn.view_sig : sn.sig;
+    in_valid = sn.is_view ? sn.view_valid : b->lp;
+    if (!in_sig.base) return fail(WAA_ERR_INVALID_STATE, "internal: the input of folded biquad node %d is not planned yet", n.pre_biquad);
   } else {
     int e = node_input_signal(b, id, &in_sig, nullptr, &in_valid);
     if (e) return e;
@@ -2802,12 +2883,24 @@ int plan_convolver(waa_batch* b, uint32_t id) {
   cv.H = dH;
   cv.X = dX;
   cv.Y = dY;
+  if (n.pre_biquad >= 0) {
+    if (!cv.fft3) return fail(WAA_ERR_INVALID_STATE, "internal: biquad node %d folded into a convolver without the three-pass transforms", n.pre_biquad);
+    std::vector<OpDesc> qops;
+    int q_out = 0;
+    if ((e = emit_node_ops(b, (uint32_t)n.pre_biquad, cv.cin, true, qops, &q_out))) return e;
+    if (qops.size() != 1 || qops[0].kind != OP_BIQUAD || qops[0].i0 != 0)
+      return fail(WAA_ERR_INVALID_STATE, "internal: folded biquad node %d is not a constant-coefficient filter", n.pre_biquad);
+    cv.pre_coefs = reinterpret_cast<const double*>(qops[0].ptr0);
+    cv.pre_coef_stride = qops[0].u0;
+    cv.pre_state = reinterpret_cast<double*>(qops[0].ptr1);
+  }
   if (!b->dry) {
     launch_conv_ir_spectra(cv, b->stream);  // control-side work of ConvolverNode::set_buffer, once
     HIP_TRY(hipGetLastError());
   }
-  plan_note(b, "convolver node %u: fft B=%d N=%d P=%d blocks=%d pairs=%u cin=%d cout=%d terms=%d ir_len=%llu", id, cv.block,
-            cv.n, cv.parts, cv.nb, cv.n_pairs, cv.cin, cv.cout, cv.n_terms, (unsigned long long)len);
+  plan_note(b, "convolver node %u: fft B=%d N=%d P=%d blocks=%d pairs=%u cin=%d cout=%d terms=%d ir_len=%llu%s", id, cv.block,
+            cv.n, cv.parts, cv.nb, cv.n_pairs, cv.cin, cv.cout, cv.n_terms, (unsigned long long)len,
+            cv.pre_coefs ? " (+ the Biquad in front, in the forward transform)" : "");
   st.slot_fwd = slot_for(b, "conv_fft_kernel<fwd>");
   st.slot_mac = slot_for(b, "conv_mac_kernel");
   st.slot_inv = slot_for(b, "conv_fft_kernel<inv>");
