@@ -527,16 +527,16 @@ def _t1_like(be, noise, ir, length, highpass=False, via_gain=False):
     return ctx
 
 
-@pytest.mark.parametrize("case", ["stereo-odd", "mono", "short-buffer", "via-gain", "highpass-one"])
+@pytest.mark.parametrize("case", ["stereo-odd", "mono", "long-buffer", "via-gain", "highpass-one"])
 def test_biquad_folded_into_the_forward_transform(hip, orc, monkeypatch, case):
     """source -> Biquad(constant coefficients) -> Convolver(long IR): the forward transform's input stage filters the
     blocks (conv_fft3_fwd_bq_kernel, no Biquad launch, no filtered signal in HBM).  Checked against the oracle and against
-    the two-launch plan (WAA_NO_CONV_BIQUAD_FOLD=1): odd instance count (half-empty last pair), mono input, a buffer that
-    ends before the render does (the filter's tail rings into the convolver), a Biquad fed by a materialised signal, one
-    instance."""
+    the two-launch plan (WAA_NO_CONV_BIQUAD_FOLD=1): odd instance count (half-empty last pair), mono input, a buffer longer
+    than the render, a Biquad fed by a materialised signal, one instance.  (A buffer that ENDS mid-render changes the
+    reference's channel counts — the graph then takes the exact per-quantum path, which never folds.)"""
     ir = garage_ir(hip)
-    length = 8192 * 4 + 1000
-    n_inst, n_ch, buf = {"stereo-odd": (5, 2, length), "mono": (4, 1, length), "short-buffer": (3, 2, 128 * 150),
+    length = 8192 * 4 + 1024  # (a source is read in place when its buffer is a whole number of render quanta)
+    n_inst, n_ch, buf = {"stereo-odd": (5, 2, length), "mono": (4, 1, length), "long-buffer": (3, 2, length + 128 * 40),
                          "via-gain": (3, 2, length), "highpass-one": (1, 2, length)}[case]
     noise = white_noise(n_inst, n_ch, buf)
     kw = dict(highpass=case == "highpass-one", via_gain=case == "via-gain")

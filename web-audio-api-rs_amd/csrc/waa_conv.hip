@@ -707,7 +707,7 @@ __device__ __forceinline__ void cmac_pk(c2v& acc, const c2v h, const c2v x) {
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(h), "v"(x));
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(h), "v"(x));
 }
-template <int KT, int PC>
+template <int KT, int PC, bool PREFETCH = true>
 __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
   const int pos = blockIdx.x * 256 + threadIdx.x;
   const uint32_t pair = blockIdx.y / (uint32_t)d.cout;
@@ -732,13 +732,21 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
   c2v win[PC - 1];  // X_{k0 - (PC-1)} .. X_{k0 - 1}
 #pragma unroll
   for (int i = 0; i < PC - 1; i++) win[i] = zero;
+  // The k-tiles are software-pipelined: tile k + 1's sixteen spectra are requested before tile k's 352 complex
+  // multiply-adds start and are settled right in front of tile k's stores (loads and stores share one counter: a wait
+  // placed behind the stores would wait for them too) — the memory pipe no longer idles while a wave computes.
+  c2v xq[KT];
+#pragma unroll
+  for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(i < nb ? i : nb - 1) * n);
   for (int k0 = 0; k0 < nb; k0 += KT) {
     c2v xn[KT];  // X_{k0} .. X_{k0 + KT - 1}
 #pragma unroll
-    for (int i = 0; i < KT; i++) xn[i] = ld_pol(Xc + (uint64_t)(k0 + i < nb ? k0 + i : nb - 1) * n);
+    for (int i = 0; i < KT; i++) xn[i] = k0 + i >= nb ? zero : xq[i];
+    if (PREFETCH) {
+      const int kn = k0 + KT;  // (past the end: block nb - 1 again — an L2 hit nobody uses)
 #pragma unroll
-    for (int i = 0; i < KT; i++)
-      if (k0 + i >= nb) xn[i] = zero;
+      for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(kn + i < nb ? kn + i : nb - 1) * n);
+    }
     c2v acc[KT];
 #pragma unroll
     for (int i = 0; i < KT; i++) acc[i] = zero;
@@ -753,9 +761,20 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
         }
       }
     }
+    if (PREFETCH) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < KT; i++) asm volatile("" : "+v"(xq[i])::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < KT; i++)
       if (k0 + i < nb) st_pol(Yc + (uint64_t)(k0 + i) * n, acc[i]);
+    if (!PREFETCH) {
+      const int kn = k0 + KT;
+#pragma unroll
+      for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(kn + i < nb ? kn + i : nb - 1) * n);
+    }
     // slide the window by KT blocks
 #pragma unroll
     for (int w = 0; w < PC - 1; w++) {
@@ -969,10 +988,14 @@ void launch_conv_mac(const ConvDesc& d, void* stream) {
       hipLaunchKernelGGL((conv_mac_win_kernel<16, 12>), grid, dim3(256), 0, (hipStream_t)stream, d);
     else if (d.parts <= 16)
       hipLaunchKernelGGL((conv_mac_win_kernel<16, 16>), grid, dim3(256), 0, (hipStream_t)stream, d);
-    else if (d.parts <= 22)  // (8 output blocks per tile were measured: 220 registers all the same, 3.78 ms against 3.59)
-      hipLaunchKernelGGL((conv_mac_win_kernel<16, 22>), grid, dim3(256), 0, (hipStream_t)stream, d);
-    else
-      hipLaunchKernelGGL((conv_mac_win_kernel<16, 24>), grid, dim3(256), 0, (hipStream_t)stream, d);
+    else if (d.parts <= 22) {  // (8 output blocks per tile were measured: 220 registers all the same, 3.78 ms against 3.59)
+      if (getenv("WAA_CONV_MAC_NO_PREFETCH"))  // (switch: same-box A/B of the software pipeline)
+        hipLaunchKernelGGL((conv_mac_win_kernel<16, 22, false>), grid, dim3(256), 0, (hipStream_t)stream, d);
+      else
+        hipLaunchKernelGGL((conv_mac_win_kernel<16, 22>), grid, dim3(256), 0, (hipStream_t)stream, d);
+    }
+    else  // (with the prefetch buffer 24 partitions need 172 registers: two waves per SIMD instead of three)
+      hipLaunchKernelGGL((conv_mac_win_kernel<16, 24, false>), grid, dim3(256), 0, (hipStream_t)stream, d);
     return;
   }
   if (d.parts <= 8)
