@@ -554,7 +554,9 @@ def test_biquad_folded_into_the_forward_transform(hip, orc, monkeypatch, case):
     assert "biquad_stream" in ctx.plan_describe()
     two = ctx.start_rendering_sync().data
     ctx.close()
-    assert np.abs(got - two).max() <= 1e-7 * max(1.0, float(np.abs(two).max()))  # same arithmetic, same order
+    # same filter arithmetic in the same order; the transforms differ in rounding (pass 1 of the folded kernel multiplies
+    # half of its twiddles together, ~1 ulp): a few f32 ulps of the peak
+    assert np.abs(got - two).max() <= 1e-6 * max(1.0, float(np.abs(two).max()))
 
 
 def test_t1_north_star_size_real_ir_sampled(hip, orc):
@@ -567,7 +569,7 @@ def test_t1_north_star_size_real_ir_sampled(hip, orc):
     pick = [0, 1, 511, 512, 1022, 1023]
     ctx, _ = t1(hip, noise, garage_ir(hip))
     plan = ctx.plan_describe()
-    assert "P=22 blocks=59 pairs=512" in plan and "biquad_stream" in plan
+    assert "P=22 blocks=59 pairs=512" in plan and "the Biquad in front, in the forward transform" in plan
     out = ctx.render_instances(pick)
     ctx.close()
     octx, _ = t1(orc, noise[pick], garage_ir(orc))

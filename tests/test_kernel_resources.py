@@ -36,7 +36,9 @@ def test_convolver_transform_kernels_do_not_spill(tmp_path):
     assert len(hot) == 4, sorted(res)  # forward, forward + filter stage, IR spectra, inverse
     for name, r in hot.items():
         # (a couple of spilled SCALAR registers — the filter-stage kernel has two — cost a few scalar moves per block)
-        assert r["spill"] == 0 and r["sgpr_spill"] <= 4 and r["scratch"] <= 256, (name, r)
+        # ... and no scratch at all: a local array indexed by a rolled loop silently moves to scratch memory (the filter stage's
+        # redo path did: +3.96 GB of stores per T1 render, measured with WRITE_SIZE)
+        assert r["spill"] == 0 and r["sgpr_spill"] <= 4 and r["scratch"] == 0, (name, r)
         assert r["vgpr"] <= 256, (name, r)  # two wavefronts per SIMD
 
 

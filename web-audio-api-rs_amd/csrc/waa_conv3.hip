@@ -321,16 +321,18 @@ __global__ __launch_bounds__(NT) void conv_fft3_fwd_bq_kernel(const ConvDesc d) 
     const ldsf lrow = ldf + h * bq::HALF + 255 * bq::ROW;
     const float nx1 = lrow[31], nx2 = lrow[30];
     const double b0 = tab[bq::T_CO + 0], b1 = tab[bq::T_CO + 1], b2 = tab[bq::T_CO + 2], a1 = tab[bq::T_CO + 3], a2 = tab[bq::T_CO + 4];
-    // ---- sweep 1: zero-state response of the chunk
-    // (the FIR part in fused form — fma(b2, x2, fma(b1, x1, b0 x)), 64 fewer f64 operations — made the compiler hoist all 32
-    // conversions and spill 51 registers: 3.05 -> 4.8 ms.  tests/test_kernel_resources.py watches the spill count.)
+    // ---- sweep 1: zero-state response of the chunk (fused multiply-adds: this pass only feeds the scan, whose result is
+    // an incoming STATE accurate to f64 rounding; the samples come out of sweep 2 in the reference's own order)
     double z1 = 0., z2 = 0.;
     {
       double x1 = xs1, x2 = xs2;
 #pragma unroll
       for (int i = 0; i < 32; i++) {
-        const double xd = (double)x[i];
-        const double w = (b0 * xd + b1 * x1) + b2 * x2;
+        double xd = (double)x[i];
+        // (ties frame i's conversion to frame i - 2's result: without it the compiler hoists all 32 conversions and
+        // products — they do not depend on the recurrence — and spills 46 registers; same trick as waa_iir_stream.hip)
+        asm volatile("" : "+v"(xd) : "v"(z2));
+        const double w = __builtin_fma(b2, x2, __builtin_fma(b1, x1, b0 * xd));
         x2 = x1;
         x1 = xd;
         const double u = __builtin_fma(-a2, z2, w);
@@ -432,7 +434,8 @@ __global__ __launch_bounds__(NT) void conv_fft3_fwd_bq_kernel(const ConvDesc d) 
         y2 = __builtin_isfinite(s2) ? s2 : 0.;
         x1 = xs1;
         x2 = xs2;
-#pragma unroll 1
+#pragma unroll  // (fully: a rolled loop indexes x[] dynamically, which moves the whole array to scratch memory — 64 KB of
+                // extra stores per block, measured as +3.96 GB of WRITE_SIZE on T1)
         for (int q = 0; q < 8; q++) {
           float yo[4];
 #pragma unroll
