@@ -136,6 +136,40 @@ def test_source_scheduling_per_instance(hip, orc):
     assert np.abs(outs[0] - outs[1]).max() <= 1e-7
 
 
+@pytest.mark.parametrize("n_ch", [4, 6])
+@pytest.mark.parametrize("kind", ["const", "k-rate", "a-rate", "iir"])
+def test_filters_on_wide_signals(hip, orc, n_ch, kind):
+    """BiquadFilterNode / IIRFilterNode on quad and 5.1 signals: per-channel state of any width (biquad_filter.rs:797-812,
+    iir_filter.rs:323-405), one wavefront per (instance, channel) on the streaming kernels — constant, per-quantum and
+    per-frame coefficients — then the speakers down-mix to the stereo destination (quantum.rs:399-505)."""
+    n_inst, frames = 3, RQ * 50 + 9
+    noise = white_noise(n_inst, n_ch, frames)
+    outs = []
+    for b in (hip, orc):
+        ctx = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n_inst, binding=b)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(noise, 48000.0)
+        if kind == "iir":
+            from scipy import signal
+            bb, aa = signal.butter(4, 0.2)
+            flt = ctx.create_iir_filter(bb, aa)
+        else:
+            flt = ctx.create_biquad_filter(type_="peaking", frequency=900.0, q=2.0, gain=4.0)
+            if kind == "k-rate":
+                flt.frequency.set_block(0, np.geomspace(200.0, 6000.0, (frames + RQ - 1) // RQ).astype(np.float32))
+            elif kind == "a-rate":
+                flt.frequency.set_value_at_time(200.0, 0.0)
+                flt.frequency.exponential_ramp_to_value_at_time(6000.0, frames / 48000.0)
+        src.connect(flt).connect(ctx.create_gain(gain=0.5)).connect(ctx.destination())
+        src.start()
+        if b is hip:
+            assert ("iir_" if kind == "iir" else "biquad_stream") in ctx.plan_describe()
+        outs.append(ctx.start_rendering_sync().data)
+        ctx.close()
+    assert rms_err(*outs).max() <= TOL
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-6
+
+
 def test_panners_and_mixing(hip, orc):
     """mono/stereo StereoPanner, equal-power Panner, fan-in summing, mono -> stereo destination."""
     sr, n = 44100.0, 4

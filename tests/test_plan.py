@@ -148,16 +148,29 @@ def test_source_schedules_are_deduplicated_per_distinct_timing(hip):
     assert any("fast=0 fast_loop=0 slow=11 silent=19" in l for l in lines)
 
 
-def test_channel_limits_are_reported_loudly(hip):
+def test_wide_filters_plan_on_the_streaming_kernel_and_the_remaining_limit_is_loud(hip):
     sr = 48000.0
     ctx = waa.OfflineAudioContext(4, RQ * 4, sr, binding=hip, device=waa.PLAN_ONLY)
     src = ctx.create_buffer_source()
-    src.set_buffer(waa.AudioBuffer(np.ones((4, 64), np.float32), sr))
+    src.set_buffer(waa.AudioBuffer(np.ones((4, RQ * 4), np.float32), sr))
     src.connect(ctx.create_biquad_filter()).connect(ctx.destination())
     src.start()
+    assert "biquad_stream in=source:4ch gains=0 out=final" in ctx.plan_describe()  # (refused with status 4 until round 3)
+    ctx.close()
+    # what is still out of scope: a channel-count CHANGE above stereo (the exact per-quantum path renders mono / stereo)
+    ctx = waa.OfflineAudioContext(4, RQ * 8, sr, binding=hip, device=waa.PLAN_ONLY)
+    mono, quad = ctx.create_buffer_source(), ctx.create_buffer_source()
+    mono.set_buffer(waa.AudioBuffer(np.ones((1, RQ * 8), np.float32), sr))
+    quad.set_buffer(waa.AudioBuffer(np.ones((4, RQ * 4), np.float32), sr))
+    bq = ctx.create_biquad_filter()
+    mono.connect(bq)
+    quad.connect(bq)
+    bq.connect(ctx.destination())
+    mono.start()
+    quad.start_at(RQ * 2 / sr)
     with pytest.raises(waa.WaaError) as e:
         ctx.plan_describe()
-    assert e.value.status == 4 and "limited to 2 channels" in str(e.value)
+    assert e.value.status == 4 and "channel count changes mid-render" in str(e.value)
 
 
 # --------------------------------------------------------------------------- dynamic channel-count notes

@@ -356,7 +356,7 @@ int push_chain_step(waa_batch* b, const std::vector<InputRef>& inputs, int in_nc
   for (auto& o : ops)
     if (o.kind == OP_BIQUAD && cmax > 2)
       return fail(WAA_ERR_OUT_OF_SCOPE,
-                  "chains with a BiquadFilter are limited to 2 channels per signal on the device path of this round (needs %d)",
+                  "the serial chain interpreter renders a BiquadFilter on at most 2 channels (needs %d; only reached with the WAA_NO_*_STREAM debugging switches)",
                   cmax);
   cd.n_ops = (int)ops.size();
   for (size_t k = 0; k < ops.size(); k++) cd.ops[k] = ops[k];
@@ -419,7 +419,9 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
   bool any_stream = false;
   // debugging aids: force k-rate / a-rate biquads onto the serial interpreter
   const int max_mode = getenv("WAA_NO_KRATE_STREAM") ? 0 : (getenv("WAA_NO_ARATE_STREAM") ? 1 : 2);
-  auto streams = [&](const OpDesc& o) { return o.kind == OP_IIR || (o.kind == OP_BIQUAD && o.i0 <= max_mode && o.nch_in <= 2); };
+  // (any channel count: the streaming kernels run one wavefront per (instance, channel) with per-channel state, like the
+  // reference's per-channel state vector, biquad_filter.rs:797-812 — 4- and 6-channel signals included)
+  auto streams = [&](const OpDesc& o) { return o.kind == OP_IIR || (o.kind == OP_BIQUAD && o.i0 <= max_mode && o.nch_in <= MAX_CH); };
   for (auto& o : ops) any_stream |= streams(o);
   if (!any_stream) return push_chain_step(b, inputs, in_nch, in_interp, ops, out);
   std::vector<OpDesc> pending;
