@@ -163,11 +163,57 @@ def test_filters_on_wide_signals(hip, orc, n_ch, kind):
         src.connect(flt).connect(ctx.create_gain(gain=0.5)).connect(ctx.destination())
         src.start()
         if b is hip:
-            assert ("iir_" if kind == "iir" else "biquad_stream") in ctx.plan_describe()
+            assert ("iir_" if kind == "iir" else "biquad_lanes" if kind == "a-rate" else "biquad_stream") in ctx.plan_describe()
         outs.append(ctx.start_rendering_sync().data)
         ctx.close()
     assert rms_err(*outs).max() <= TOL
     assert np.abs(outs[0] - outs[1]).max() <= 2e-6
+
+
+def test_time_parallel_biquad_forms(hip, orc, monkeypatch):
+    """Two time-parallel forms of the streaming Biquad against the oracle and against the one-wavefront-per-stream kernel:
+    * waa_biquad_scan.hip (WAA_BIQUAD_SCAN=1, constant coefficients): one unit per tile and stream, the incoming state from a
+      chained scan over the stream's tiles (self-validating words, no fences) — odd stream counts (the eight unit shards are
+      uneven), a source that starts late and ends early (tiles the fast track does not cover, x history through the hand-off);
+    * waa_biquad_lanes.hip (default for a-rate params with one table for all instances): one LANE per stream, tile digests,
+      two passes — 67 streams (a ragged last group), constant gains behind the filter, a k-rate + a-rate param mix."""
+    n_inst, frames = 11, 2048 * 6 + 300
+    noise = white_noise(n_inst, 3, 2048 * 5)
+
+    def build(be, arate):
+        ctx = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n_inst, binding=be)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(noise, 48000.0)
+        bq = ctx.create_biquad_filter(type_="bandpass", frequency=700.0, q=3.0)
+        for i in range(n_inst):
+            bq.q.set_value(0.5 + i, instance=i)
+        if arate:
+            bq.frequency.set_value_at_time(90.0, 0.0)
+            bq.frequency.exponential_ramp_to_value_at_time(9000.0, frames / 48000.0)
+            bq.detune.set_value_at_time(300.0, 0.1)
+        src.connect(bq).connect(ctx.create_gain(gain=0.7)).connect(ctx.create_gain(gain=1.0)).connect(ctx.destination())
+        src.start_at(0.0 if arate else 77 / 48000.0)
+        return ctx
+
+    for arate in (False, True):
+        octx = build(orc, arate)
+        ref = octx.start_rendering_sync().data
+        octx.close()
+        outs = {}
+        for env in ({}, {"WAA_BIQUAD_SCAN": "1"}, {"WAA_ARATE_STREAM": "1"}):
+            for k in ("WAA_BIQUAD_SCAN", "WAA_ARATE_STREAM"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ctx = build(hip, arate)
+            plan = ctx.plan_describe()
+            outs[tuple(env)] = ctx.start_rendering_sync().data
+            ctx.close()
+            if arate:
+                assert ("biquad_lanes" in plan) == ("WAA_ARATE_STREAM" not in env), plan
+            assert rms_err(outs[tuple(env)], ref).max() <= TOL, (arate, env)
+            assert np.abs(outs[tuple(env)] - ref).max() <= 2e-6
+        assert np.abs(outs[()] - outs[("WAA_ARATE_STREAM",)]).max() <= 1e-6
 
 
 def test_panners_and_mixing(hip, orc):

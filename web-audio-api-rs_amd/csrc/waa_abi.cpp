@@ -700,7 +700,9 @@ waa_status waa_render(waa_batch* b) {
   // every render starts from the initial state (offline contexts render exactly once; re-rendering the
   // same batch is what the benchmark loop does)
   for (auto& sb : b->state_bufs) HIP_TRY(hipMemsetAsync(sb.first, 0, sb.second, b->stream));
+  for (auto& sb : b->ones_bufs) HIP_TRY(hipMemsetAsync(sb.first, 0xFF, sb.second, b->stream));
   for (auto& n : b->nodes) n.an = Node::AnBatch{};
+  for (auto& v : b->scan_issued) v = 0;
   b->rendered = true;
   auto timed = [&](int slot, auto&& launch) -> int {
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -725,7 +727,11 @@ waa_status waa_render(waa_batch* b) {
         BiquadStreamDesc d = st.bq;
         d.tile0 = t0;
         d.tile1 = t1;
-        e = timed(st.profile_slot, [&] { launch_biquad_stream(d, b->stream); });
+        if (st.scan.payload) {
+          e = timed(st.profile_slot, [&] { launch_biquad_scan(d, st.scan, b->scan_issued, b->stream); });
+        } else {
+          e = timed(st.profile_slot, [&] { launch_biquad_stream(d, b->stream); });
+        }
         break;
       }
       case 2:
@@ -762,6 +768,14 @@ waa_status waa_render(waa_batch* b) {
       case 12:
         if (st.hp.coefs) e = timed(st.profile_slot, [&] { launch_biquad_hp(st.hp, b->stream); });
         break;
+      case 18: e = timed(st.profile_slot, [&] { launch_biquad_tile_digest(st.lanes, b->stream); }); break;
+      case 19: {
+        BiquadLanesDesc d = st.lanes;
+        d.tile0 = t0;
+        d.tile1 = t1;
+        e = timed(st.profile_slot, [&] { launch_biquad_lanes(d, b->stream); });
+        break;
+      }
       default: {
         ChainDesc d = st.chain;
         d.tile0 = t0;
@@ -844,6 +858,11 @@ waa_status waa_sync(waa_batch* b) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
   if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch has no device");
   HIP_TRY(hipStreamSynchronize(b->stream));
+  if (b->scan_counter) {  // a bounded spin of the chained scan gave up: the render is not to be trusted
+    uint32_t words[1] = {0};
+    HIP_TRY(hipMemcpy(words, b->scan_counter + 8 * 16, sizeof words, hipMemcpyDeviceToHost));
+    if (words[0]) return fail(WAA_ERR_DEVICE, "internal: the time-parallel biquad gave up waiting for a predecessor tile");
+  }
   if (int e = dump_codes(b)) return e;
   return drain_profile(b);
 }

@@ -205,6 +205,8 @@ struct Step {
   int kind = 0;  // 15 link table of a frozen-state node, 16 one resampling stage of an oversampled WaveShaper (qgemm_kernel), 17 HRTF FIR; 0 chain (interpreter kernel), 1 streaming biquad kernel, 2 FFT convolver, 3 zero-fill, 4 direct FIR, 5 per-frame biquad coefficients, 6 streaming IIR kernel, 7 delay gather, 8 feedback loop, 9 oscillator, 10 dynamic-count group (dyn_kernel), 11 convolver codes, 12 digest of a shared per-frame coefficient table, 13 per-frame panner geometry, 14 automation timelines replayed on the device
   ChainDesc chain{};
   BiquadStreamDesc bq{};
+  BiquadScanCtl scan{};   // kind 1 with scan.payload: the time-parallel form (waa_biquad_scan.hip)
+  BiquadLanesDesc lanes{};  // kinds 18 (tile digests) and 19 (pass A + chain + pass B), waa_biquad_lanes.hip
   ConvDesc conv{};
   BiquadCoefDesc coef{};
   IirStreamDesc iir{};
@@ -252,6 +254,7 @@ struct waa_batch {
   std::vector<void*> allocs;        // plan-owned device allocations
   std::vector<void*> payload_allocs;  // buffers uploaded through the API
   std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render
+  std::vector<std::pair<void*, size_t>> ones_bufs;   // filled with 0xFF bytes at the start of every render
   std::vector<Step> steps;
   bool planned = false;
   bool force_dynamic = false;        // second planning pass: a loop member the static loop kernel cannot render
@@ -266,6 +269,8 @@ struct waa_batch {
   // once, so planning + allocation IS part of what a caller waits for
   double t_plan_ms = 0, t_alloc_ms = 0, t_upload_ms = 0;  // (alloc / upload: running totals of the batch)
   uint64_t n_alloc = 0, alloc_bytes = 0;
+  uint32_t* scan_counter = nullptr;   // 8 unit counters (16 words apart) + error flag of the time-parallel biquad launches
+  uint32_t scan_issued[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // host mirror of the counters during a render
   double plan_alloc_ms = 0, plan_upload_ms = 0;          // ... and their part inside build_plan
   uint64_t plan_n_alloc = 0, plan_alloc_bytes = 0;
 };

@@ -161,6 +161,34 @@ struct BiquadStreamDesc {
   uint32_t tile0, tile1;
 };
 void launch_biquad_stream(const BiquadStreamDesc& d, void* stream);
+// waa_biquad_scan.hip: the same shape parallel in time (one unit = one tile of one stream, chained scan over the tiles)
+constexpr int BIQUAD_SCAN_PW = 88;   // doubles per instance: A, A^2, A^4, A^8, A^16, A^64 (A = M^32), then A^0 .. A^15
+struct BiquadScanCtl {
+  uint32_t* counter;      // eight unit counters of the batch, 16 words apart (zeroed at the start of every render)
+  uint32_t counter_base[8];  // their values when this launch starts (host bookkeeping)
+  double* payload;        // [n_streams][n_tiles][8] self-validating words (filled with 0xFF bytes at the start of every render)
+  const double* pw;       // [n_inst][BIQUAD_SCAN_PW]
+  uint32_t* error;        // set when a bounded spin gave up
+};
+void launch_biquad_scan_powers(const double* coefs, uint64_t coef_stride, double* pw, uint32_t n_inst, void* stream);
+void launch_biquad_scan(const BiquadStreamDesc& d, const BiquadScanCtl& ctl, uint32_t* issued, void* stream);
+
+// ---- a-rate Biquad with one coefficient table for all instances, one LANE per stream (waa_biquad_lanes.hip) ----
+constexpr int BIQUAD_HT_WORDS = 2 * TILE + 8;  // doubles per tile digest: 2048 x (Hx, Hy), Hm1 (2), Hm2 (2), P (4)
+struct BiquadLanesDesc {
+  InputRef in;            // IN_SIGNAL (valid = 0: the padded length, else that many frames, zeros beyond) or IN_SOURCE
+  const double* coefs;    // frame-major [n_tiles * 2048][5], shared by all instances (biquad_coef_kernel, lane_major = 0)
+  double* ht;             // [n_tiles][BIQUAD_HT_WORDS] tile digests
+  double* z;              // [n_tiles][n_streams][2] zero-state end states of the tiles (pass A)
+  double* sin;            // [n_tiles][n_streams][2] y state in front of every tile (chain)
+  double* state;          // [n_inst][STATE_STRIDE]
+  ParamRef gain[2];       // mode 0 only
+  int32_t n_gain, nch;
+  SignalRef out;
+  uint32_t n_inst, n_tiles, n_quanta, tile0, tile1, pad;
+};
+void launch_biquad_tile_digest(const BiquadLanesDesc& d, void* stream);
+void launch_biquad_lanes(const BiquadLanesDesc& d, void* stream);
 
 // ---- streaming IIR kernel (IIRFilterNode, iir_filter.rs:323-405) -----------------------------
 // input (source or signal) -> transposed direct form II with ns state variables -> output; coefficients are
