@@ -639,6 +639,34 @@ def test_biquad_folded_into_the_forward_transform(hip, orc, monkeypatch, case):
     assert np.abs(got - two).max() <= 1e-6 * max(1.0, float(np.abs(two).max()))
 
 
+@pytest.mark.parametrize("with_biquad", [False, True])
+def test_shared_audio_buffer_in_front_of_the_convolver(hip, orc, with_biquad):
+    """One AudioBuffer shared by every context (set_buffer for all instances: instance stride 0), read in place by the
+    forward transform — with and without the Biquad folded in; per-instance filter coefficients keep the contexts apart."""
+    n_inst, length = 3, 8192 * 3 + 128
+    noise = white_noise(1, 2, length)[0]
+    outs = []
+    for be in (hip, orc):
+        ctx = waa.OfflineAudioContext(2, length, 48000.0, n_instances=n_inst, binding=be)
+        src = ctx.create_buffer_source()
+        src.set_buffer(waa.AudioBuffer(noise, 48000.0))
+        node = src
+        if with_biquad:
+            bq = ctx.create_biquad_filter(type_="lowpass", frequency=300.0, q=1.0)
+            for i in range(n_inst):
+                bq.frequency.set_value(300.0 + 400.0 * i, instance=i)
+            node = src.connect(bq)
+        node.connect(ctx.create_convolver(buffer=waa.AudioBuffer(garage_ir(be), 48000.0))).connect(ctx.destination())
+        src.start()
+        if be is hip:
+            assert "in place" in ctx.plan_describe()
+        outs.append(ctx.start_rendering_sync().data)
+        ctx.close()
+    assert rms_err(*outs).max() <= TOL
+    if with_biquad:
+        assert np.abs(outs[0][0] - outs[0][2]).max() > 1e-4  # (the contexts differ)
+
+
 def test_t1_north_star_size_real_ir_sampled(hip, orc):
     """The north-star target graph at ITS size: 1024 contexts x 10 s, BufferSource -> Biquad(lowpass 200 Hz, Q 1) ->
     Convolver(the real parking-garage response, 2 x 178 899 frames, normalised) -> destination — the batch bench.py's `t1`

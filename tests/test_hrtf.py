@@ -160,6 +160,26 @@ def test_needs_the_database():
         waa.api._HRTF_DATABASE = saved
 
 
+def test_malformed_sphere_headers_are_refused(hip):
+    """waa_hrtf_load_sphere validates the caller's header before it sizes anything (round-2 advisor finding): zero vertices /
+    faces, an impulse-response length beyond what the FIR kernels hold, sizes that do not add up."""
+    import ctypes
+    import struct
+
+    def load(blob):
+        return hip.hrtf_load_sphere(ctypes.c_char_p(blob), len(blob))
+
+    good = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "IRC_1003_C.bin"), "rb").read()
+    rate, length, nv, ni = struct.unpack_from("<4I", good, 4)
+    assert (rate, length) == (44100, 512) and nv > 0 and ni % 3 == 0
+    for hdr in [(rate, length, 0, 0), (rate, length, 0, ni), (rate, 0, nv, ni), (rate, 100000, nv, ni), (0, length, nv, ni),
+                (rate, length, nv, ni + 1), (rate, length, 0xFFFFFFFF, 0xFFFFFFFC)]:
+        blob = b"HRIR" + struct.pack("<4I", *hdr) + good[20:]
+        assert load(blob) == 1, hdr  # WAA_ERR_INVALID_ARGUMENT
+    assert load(good[:-4]) == 1 and load(b"HRIX" + good[4:]) == 1
+    assert load(good) == 0  # (and the real database loads again)
+
+
 # ---- HrirSphere::sample_bilinear ------------------------------------------------------------------------------------
 def test_sample_bilinear(be):
     sr, idx, pos, left, right = SPHERE

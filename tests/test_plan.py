@@ -60,6 +60,17 @@ def test_t1_unfolded_plan_switch(hip, monkeypatch):
     assert not any("in the forward transform" in l for l in lines)
 
 
+def test_one_shared_audio_buffer_is_read_in_place(hip):
+    """set_buffer for ALL instances = one AudioBuffer shared by every context (instance stride 0): read in place by a
+    convolver like a per-instance batch (round-2 advisor finding: the view needed a strictly positive stride)."""
+    ctx = waa.OfflineAudioContext(2, 480000, 48000.0, n_instances=4, binding=hip, device=waa.PLAN_ONLY)
+    src = ctx.create_buffer_source()
+    src.set_buffer(waa.AudioBuffer(white_noise(1, 2, 480000)[0], 48000.0))
+    src.connect(ctx.create_convolver(buffer=waa.AudioBuffer(garage_like_ir(), 48000.0))).connect(ctx.destination())
+    src.start()
+    assert any("renders its AudioBuffer unchanged" in l and "reads it in place" in l for l in plan(ctx))
+
+
 def test_c5_slow_track_goes_to_the_parallel_kernel(hip):
     ctx, _ = c5(hip, white_noise(2, 2, 5000), length=RQ * 50)
     ctx.device = waa.PLAN_ONLY

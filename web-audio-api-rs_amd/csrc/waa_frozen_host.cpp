@@ -541,8 +541,13 @@ extern "C" waa_status waa_hrtf_load_sphere(const void* data, uint64_t size) {
   uint32_t hdr[4];
   std::memcpy(hdr, d + 4, 16);
   const uint64_t len = hdr[1], nv = hdr[2], ni = hdr[3];
-  if (len == 0 || ni % 3 != 0 || size != 20 + 4 * ni + nv * (12 + 8 * len))
-    return fail(WAA_ERR_INVALID_ARGUMENT, "HRIR sphere: inconsistent sizes");
+  // (a caller-supplied header: every field is bounded before it sizes anything — no vertex / face counts of zero, which
+  // sphere_locate would index, no length beyond what the FIR kernels hold, and the three u32 fields cannot wrap the u64 size)
+  if (len == 0 || len > (uint64_t)waa::HRTF_MAX_TAPS || nv == 0 || nv > (1u << 20) || ni == 0 || ni % 3 != 0 || ni > (1u << 24) ||
+      hdr[0] == 0)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "HRIR sphere: header out of range (rate %u, %llu taps, %llu vertices, %llu indices)", hdr[0],
+                (unsigned long long)len, (unsigned long long)nv, (unsigned long long)ni);
+  if (size != 20 + 4 * ni + nv * (12 + 8 * len)) return fail(WAA_ERR_INVALID_ARGUMENT, "HRIR sphere: inconsistent sizes");
   auto s = std::make_shared<Sphere>();
   s->sr = hdr[0];
   s->taps = (int)len;

@@ -1406,7 +1406,7 @@ int build_plan(waa_batch* b) {
     const DeviceBuffer& b0 = n.bufs[0];
     ok = ok && b0.valid && b0.sr == b->sr && (uintptr_t)b0.base % 16 == 0 && b0.ch_stride % 4 == 0 && b0.frames % RQ == 0 && b0.frames > 0;
     const int64_t inst_stride = b->n_inst > 1 && n.bufs[1].valid ? n.bufs[1].base - b0.base : (int64_t)b0.ch_stride * b0.nch;
-    ok = ok && inst_stride > 0 && inst_stride % 4 == 0;
+    ok = ok && inst_stride >= 0 && inst_stride % 4 == 0;  // (0: one AudioBuffer shared by every instance, set_buffer(ALL))
     for (uint32_t i = 0; i < b->n_inst && ok; i++) {
       const DeviceBuffer& bf = n.bufs[i];
       const SourceSched& ss = n.sched[i];
@@ -1461,7 +1461,7 @@ int build_plan(waa_batch* b) {
         const DeviceBuffer& b0 = sn.bufs[0];
         ok = ok && b0.valid && b0.sr == b->sr && (uintptr_t)b0.base % 16 == 0 && b0.ch_stride % 4 == 0 && b0.frames % RQ == 0 && b0.frames > 0;
         const int64_t inst_stride = b->n_inst > 1 && sn.bufs[1].valid ? sn.bufs[1].base - b0.base : (int64_t)b0.ch_stride * b0.nch;
-        ok = ok && inst_stride > 0 && inst_stride % 4 == 0;
+        ok = ok && inst_stride >= 0 && inst_stride % 4 == 0;  // (0: one AudioBuffer shared by every instance, set_buffer(ALL))
         for (uint32_t i = 0; i < b->n_inst && ok; i++) {
           const DeviceBuffer& bf = sn.bufs[i];
           const SourceSched& ss = sn.sched[i];
