@@ -200,8 +200,9 @@ def test_parity_ping_pong_loop(hip, orc, modulated):
 @pytest.mark.gpu
 def test_node_kinds_outside_the_static_loop_kernel_go_to_the_dynamic_path(hip, orc):
     """An IIRFilter inside a short feedback loop: the static loop kernel does not cover it (status 4 in round 1); the
-    planner now renders the whole graph quantum by quantum with dyn_kernel.  A ConvolverNode inside a loop is still
-    refused (FFT convolvers are node-major launches)."""
+    planner now renders the whole graph quantum by quantum with dyn_kernel.  A ConvolverNode inside a loop whose delay is
+    shorter than one partition of its impulse response is still refused (FFT convolvers are node-major launches; the
+    block-scheduled form below needs a whole partition per block)."""
     outs = []
     for be in (hip, orc):
         c = waa.OfflineAudioContext(2, RQ * 40, 48000.0, n_instances=2, binding=be)
@@ -228,6 +229,92 @@ def test_node_kinds_outside_the_static_loop_kernel_go_to_the_dynamic_path(hip, o
     with pytest.raises(waa.WaaError) as ei:
         c.start_rendering_sync()
     assert ei.value.status == 4
+
+
+def _convolver_loop(binding, noise, ir, delay_s, fb_gain, frames, with_filter=False, device=-1):
+    """src -> Delay -> Convolver -> [Biquad] -> Gain -> back into the Delay; the destination hears the convolver and the
+    dry delay (a reverb inside an echo)"""
+    n, n_ch, _ = noise.shape
+    c = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n, binding=binding, device=device)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    d = c.create_delay(1.0, delay_time=delay_s)
+    conv = c.create_convolver(buffer=waa.AudioBuffer(ir, 48000.0), disable_normalization=True)
+    fb = c.create_gain(gain=fb_gain)
+    src.connect(d)
+    tail = d.connect(conv)
+    if with_filter:
+        tail = tail.connect(c.create_biquad_filter(type_="highpass", frequency=300.0))
+    tail.connect(fb).connect(d)
+    tail.connect(c.destination())
+    d.connect(c.destination())
+    src.start()
+    return c
+
+
+def _decaying_ir(n_ch, taps, seed, level):
+    rng = np.random.default_rng(seed)
+    env = np.exp(-4.0 * np.arange(taps) / taps)
+    return (rng.standard_normal((n_ch, taps)) * env * level).astype(np.float32)
+
+
+CONV_LOOPS = {
+    # name: (IR channels, IR taps, source channels, delay [s], feedback gain, with a Biquad in the loop)
+    "direct-fir-64": (1, 64, 2, 0.05, 0.6, False),            # 2400-frame delay: 1 tile per block, direct FIR pieces
+    "fft-128x24": (2, 3000, 2, 0.1, 0.5, True),               # B=128: 2 tiles per block = 32 partitions per launch
+    "fft-512-mono": (1, 9000, 1, 0.15, 0.5, False),           # B=512, mono all the way round (mono into a stereo IR would
+                                                              # change the loop's channel count after the first echo: dynamic)
+    "fft-2048": (2, 40000, 2, 0.2, 0.4, False),               # B=2048: 4 tiles per block
+    "fft3-8192-true-stereo": (4, 60000, 2, 0.5, 0.5, True),   # B=8192 (the three-pass transforms): 8 of 11 tiles per block
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CONV_LOOPS))
+def test_parity_convolver_inside_a_block_scheduled_loop(hip, orc, name):
+    """a ConvolverNode inside a feedback loop whose delay is longer than one partition: the forward transforms, the
+    partition sums and the inverse transforms run per block range of the loop (the spectra of earlier blocks stay in X)"""
+    ir_ch, taps, src_ch, delay_s, fb_gain, with_filter = CONV_LOOPS[name]
+    n, frames = 3, 2048 * 26 + 777
+    noise = white_noise(n, src_ch, frames, seed0=91)   # (a source that ends makes the channel counts dynamic: refused, below)
+    ir = _decaying_ir(ir_ch, taps, 5, 2.0 / np.sqrt(taps))
+    outs = []
+    for be in (hip, orc):
+        c = _convolver_loop(be, noise, ir, delay_s, fb_gain, frames, with_filter)
+        if be is hip:
+            plan = c.plan_describe()
+            assert "block-scheduled" in plan and "convolver node" in plan and "dynamic-count" not in plan, plan
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    g, o = outs
+    assert np.isfinite(o).all() and np.abs(o).max() > 0.1
+    scale = max(1.0, float(np.abs(o).max()))
+    assert rms_err(g, o).max() / scale <= 1e-6
+    assert np.abs(g - o).max() / scale <= 2e-5
+
+
+def test_plan_convolver_inside_a_loop(hip):
+    """plan only (CPU): the block is a whole number of partitions; a loop delay shorter than a partition is refused"""
+    noise = white_noise(2, 2, 2048 * 30)
+    c = _convolver_loop(hip, noise, _decaying_ir(2, 60000, 1, 0.01), 0.5, 0.5, 2048 * 30, device=waa.PLAN_ONLY)
+    plan = c.plan_describe()
+    assert "fft B=8192" in plan and "block-scheduled, 8 tile(s)" in plan, plan   # 24000-frame delay: 11 tiles, rounded to 2 partitions
+    c.close()
+    c = _convolver_loop(hip, noise, _decaying_ir(2, 3000, 1, 0.01), 0.1, 0.5, 2048 * 30, device=waa.PLAN_ONLY)
+    plan = c.plan_describe()
+    assert "fft B=128" in plan and "block-scheduled, 2 tile(s)" in plan, plan
+    c.close()
+    c = _convolver_loop(hip, noise, _decaying_ir(2, 60000, 1, 0.01), 0.1, 0.5, 2048 * 30, device=waa.PLAN_ONLY)   # 4800 < 8192
+    with pytest.raises(waa.WaaError) as ei:
+        c.plan_describe()
+    assert ei.value.status == 4 and "ConvolverNode inside a feedback loop" in str(ei.value)
+    c.close()
+    # channel counts that change during the render (the source ends) need the quantum-serial dynamic path: refused
+    c = _convolver_loop(hip, noise[:, :, :2048 * 8], _decaying_ir(2, 3000, 1, 0.01), 0.1, 0.5, 2048 * 30, device=waa.PLAN_ONLY)
+    with pytest.raises(waa.WaaError) as ei:
+        c.plan_describe()
+    assert ei.value.status == 4 and "ConvolverNode inside a feedback loop" in str(ei.value)
+    c.close()
 
 
 @pytest.mark.gpu

@@ -734,13 +734,27 @@ waa_status waa_render(waa_batch* b) {
         }
         break;
       }
-      case 2:
-        if ((e = timed(st.slot_fwd, [&] { launch_conv_forward(st.conv, b->stream); }))) break;
-        if ((e = timed(st.slot_mac, [&] { launch_conv_mac(st.conv, b->stream); }))) break;
-        e = timed(st.slot_inv, [&] { launch_conv_inverse(st.conv, b->stream); });
+      case 2: {
+        // (inside a block-scheduled feedback loop: the partitions of this tile range; loop_block_tiles made the range a
+        // whole number of them)
+        ConvDesc d = st.conv;
+        d.kb0 = (int)std::min<uint64_t>((uint64_t)t0 * TILE / (uint64_t)d.block, (uint64_t)d.nb);
+        d.kb1 = (int)std::min<uint64_t>(((uint64_t)t1 * TILE + (uint64_t)d.block - 1) / (uint64_t)d.block, (uint64_t)d.nb);
+        if (d.kb1 <= d.kb0) break;
+        if ((e = timed(st.slot_fwd, [&] { launch_conv_forward(d, b->stream); }))) break;
+        if ((e = timed(st.slot_mac, [&] { launch_conv_mac(d, b->stream); }))) break;
+        e = timed(st.slot_inv, [&] { launch_conv_inverse(d, b->stream); });
         break;
+      }
       case 3: HIP_TRY(hipMemsetAsync(st.zero_ptr, 0, st.zero_bytes, b->stream)); break;
-      case 4: e = timed(st.slot_mac, [&] { launch_conv_direct(st.conv, b->stream); }); break;
+      case 4: {
+        ConvDesc d = st.conv;
+        d.kb0 = (int)std::min<uint64_t>((uint64_t)t0 * (TILE / 1024), (uint64_t)st.conv.kb1);
+        d.kb1 = (int)std::min<uint64_t>((uint64_t)t1 * (TILE / 1024), (uint64_t)st.conv.kb1);
+        if (d.kb1 <= d.kb0) break;
+        e = timed(st.slot_mac, [&] { launch_conv_direct(d, b->stream); });
+        break;
+      }
       case 5: e = timed(st.profile_slot, [&] { launch_biquad_coefs(st.coef, b->stream); }); break;
       case 6: {
         IirStreamDesc d = st.iir;

@@ -220,7 +220,7 @@ __global__ void conv_fft_kernel(const ConvDesc d) {
   Cplx* a = reinterpret_cast<Cplx*>(lds_raw);
   const int tid = threadIdx.x, nt = blockDim.x;
   const int n = d.n, B = d.block;
-  const int k = blockIdx.x;  // output block (FWD/INV) or partition (IR)
+  const int k = blockIdx.x + (MODE == MODE_IR ? 0 : d.kb0);  // output block (FWD/INV) or partition (IR)
   const int c = blockIdx.y;  // channel
   const uint32_t pair = blockIdx.z;
   if (MODE == MODE_IR) {
@@ -545,8 +545,8 @@ __global__ __launch_bounds__(PIPE_NT) void conv_fft_pipe_kernel(const ConvDesc d
   const int tid = threadIdx.x;
   const int c = blockIdx.y;
   const uint32_t pair = blockIdx.z;
-  const int k0 = blockIdx.x * blocks_per_wg;
-  const int k1 = k0 + blocks_per_wg < d.nb ? k0 + blocks_per_wg : d.nb;
+  const int k0 = d.kb0 + blockIdx.x * blocks_per_wg;
+  const int k1 = k0 + blocks_per_wg < d.kb1 ? k0 + blocks_per_wg : d.kb1;
   if (k0 >= k1) return;
   const PipeTw w = pipe_twiddles<false>(d.tw, tid);
   Cplx* tws = a + (PIPE_N + PIPE_N / 8);  // behind the padded transform buffer
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void conv_mac_kernel(const ConvDesc d) {
   const int co = (int)(blockIdx.y % (uint32_t)d.cout);
   const int n = d.n, nb = d.nb, P = d.parts;
   Cplx* Yc = d.Y + ((uint64_t)pair * d.cout + co) * nb * n + pos;
-  for (int k0 = 0; k0 < nb; k0 += KT) {
+  for (int k0 = d.kb0; k0 < d.kb1; k0 += KT) {
     Cplx acc[KT];
 #pragma unroll
     for (int i = 0; i < KT; i++) acc[i] = Cplx{0.f, 0.f};
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256) void conv_mac_kernel(const ConvDesc d) {
     }
 #pragma unroll
     for (int i = 0; i < KT; i++)
-      if (k0 + i < nb) Yc[(uint64_t)(k0 + i) * n] = acc[i];
+      if (k0 + i < d.kb1) Yc[(uint64_t)(k0 + i) * n] = acc[i];
   }
 }
 
@@ -732,20 +732,29 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
   c2v win[PC - 1];  // X_{k0 - (PC-1)} .. X_{k0 - 1}
 #pragma unroll
   for (int i = 0; i < PC - 1; i++) win[i] = zero;
+  if (d.kb0 > 0) {  // a later block range of a block-scheduled loop: the window's history comes back from X
+#pragma unroll
+    for (int i = 0; i < PC - 1; i++) {
+      const int j = d.kb0 - (PC - 1) + i;
+      win[i] = Xc[(uint64_t)(j >= 0 ? j : 0) * n];
+      if (j < 0) win[i] = zero;
+    }
+  }
   // The k-tiles are software-pipelined: tile k + 1's sixteen spectra are requested before tile k's 352 complex
   // multiply-adds start and are settled right in front of tile k's stores (loads and stores share one counter: a wait
   // placed behind the stores would wait for them too) — the memory pipe no longer idles while a wave computes.
   c2v xq[KT];
+  const int kend = d.kb1;
 #pragma unroll
-  for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(i < nb ? i : nb - 1) * n);
-  for (int k0 = 0; k0 < nb; k0 += KT) {
+  for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(d.kb0 + i < kend ? d.kb0 + i : kend - 1) * n);
+  for (int k0 = d.kb0; k0 < kend; k0 += KT) {
     c2v xn[KT];  // X_{k0} .. X_{k0 + KT - 1}
 #pragma unroll
-    for (int i = 0; i < KT; i++) xn[i] = k0 + i >= nb ? zero : xq[i];
+    for (int i = 0; i < KT; i++) xn[i] = k0 + i >= kend ? zero : xq[i];
     if (PREFETCH) {
-      const int kn = k0 + KT;  // (past the end: block nb - 1 again — an L2 hit nobody uses)
+      const int kn = k0 + KT;  // (past the end: the last block again — an L2 hit nobody uses)
 #pragma unroll
-      for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(kn + i < nb ? kn + i : nb - 1) * n);
+      for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(kn + i < kend ? kn + i : kend - 1) * n);
     }
     c2v acc[KT];
 #pragma unroll
@@ -769,11 +778,11 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
     }
 #pragma unroll
     for (int i = 0; i < KT; i++)
-      if (k0 + i < nb) st_pol(Yc + (uint64_t)(k0 + i) * n, acc[i]);
+      if (k0 + i < kend) st_pol(Yc + (uint64_t)(k0 + i) * n, acc[i]);
     if (!PREFETCH) {
       const int kn = k0 + KT;
 #pragma unroll
-      for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(kn + i < nb ? kn + i : nb - 1) * n);
+      for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(kn + i < kend ? kn + i : kend - 1) * n);
     }
     // slide the window by KT blocks
 #pragma unroll
@@ -793,7 +802,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvDesc d) {
   __shared__ float xs[2][DIRECT_TILE + DIRECT_MAX_TAPS];
   __shared__ float hs[4][DIRECT_MAX_TAPS];
   const int tid = threadIdx.x;
-  const uint64_t f0 = (uint64_t)blockIdx.x * DIRECT_TILE;
+  const uint64_t f0 = ((uint64_t)blockIdx.x + (uint64_t)d.kb0) * DIRECT_TILE;  // (kb0 / kb1: 1024-frame pieces here)
   const int co = blockIdx.y;
   const uint32_t inst = blockIdx.z;
   const int taps = (int)d.ir_len;
@@ -917,10 +926,10 @@ void launch_conv_ir_spectra(const ConvDesc& d, void* stream) {
 // blocks per persistent workgroup: whole (pair, channel) streams when there are enough of them to fill the chip,
 // shorter runs otherwise
 static int pipe_blocks_per_wg(const ConvDesc& d, int channels) {
-  const int streams = (int)d.n_pairs * channels;
+  const int streams = (int)d.n_pairs * channels, nbl = d.kb1 - d.kb0;
   int segs = streams >= 512 ? 1 : (512 + streams - 1) / streams;
-  if (segs > d.nb) segs = d.nb;
-  return (d.nb + segs - 1) / segs;
+  if (segs > nbl) segs = nbl;
+  return (nbl + segs - 1) / segs;
 }
 static bool use_pipe(const ConvDesc& d) { return d.n == PIPE_N && !getenv("WAA_CONV_FFT_PLAIN"); }
 
@@ -929,7 +938,7 @@ void launch_conv_forward(const ConvDesc& d, void* stream) {
   allow_big_lds((size_t)d.n * sizeof(Cplx));
   if (use_pipe(d)) {
     const int bpw = pipe_blocks_per_wg(d, d.cin);
-    const dim3 grid((d.nb + bpw - 1) / bpw, d.cin, d.n_pairs);
+    const dim3 grid((d.kb1 - d.kb0 + bpw - 1) / bpw, d.cin, d.n_pairs);
     const size_t lds = (size_t)(d.n + d.n / 8) * sizeof(Cplx) + (size_t)PIPE_NT * 4 * sizeof(Cplx);
     const char* dbg = getenv("WAA_CONV_PIPE_DEBUG");
     if (dbg && dbg[0] == '1')
@@ -940,7 +949,7 @@ void launch_conv_forward(const ConvDesc& d, void* stream) {
       hipLaunchKernelGGL((conv_fft_pipe_kernel<MODE_FWD, 0>), grid, dim3(PIPE_NT), lds, (hipStream_t)stream, d, bpw);
     return;
   }
-  hipLaunchKernelGGL(conv_fft_kernel<MODE_FWD>, dim3(d.nb, d.cin, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
+  hipLaunchKernelGGL(conv_fft_kernel<MODE_FWD>, dim3(d.kb1 - d.kb0, d.cin, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
                      (hipStream_t)stream, d);
 }
 void launch_conv_inverse(const ConvDesc& d, void* stream) {
@@ -948,7 +957,7 @@ void launch_conv_inverse(const ConvDesc& d, void* stream) {
   allow_big_lds((size_t)d.n * sizeof(Cplx));
   if (use_pipe(d)) {
     const int bpw = pipe_blocks_per_wg(d, d.cout);
-    const dim3 grid((d.nb + bpw - 1) / bpw, d.cout, d.n_pairs);
+    const dim3 grid((d.kb1 - d.kb0 + bpw - 1) / bpw, d.cout, d.n_pairs);
     const size_t lds = (size_t)(d.n + d.n / 8) * sizeof(Cplx) + (size_t)PIPE_NT * 4 * sizeof(Cplx);
     const char* dbg = getenv("WAA_CONV_PIPE_DEBUG");
     if (dbg && dbg[0] == '1')
@@ -959,11 +968,11 @@ void launch_conv_inverse(const ConvDesc& d, void* stream) {
       hipLaunchKernelGGL((conv_fft_pipe_kernel<MODE_INV, 0>), grid, dim3(PIPE_NT), lds, (hipStream_t)stream, d, bpw);
     return;
   }
-  hipLaunchKernelGGL(conv_fft_kernel<MODE_INV>, dim3(d.nb, d.cout, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
+  hipLaunchKernelGGL(conv_fft_kernel<MODE_INV>, dim3(d.kb1 - d.kb0, d.cout, d.n_pairs), dim3(fft_threads(d.n)), (size_t)(d.n + d.n / 8) * sizeof(Cplx),
                      (hipStream_t)stream, d);
 }
 void launch_conv_direct(const ConvDesc& d, void* stream) {
-  dim3 grid((unsigned)((d.frames + DIRECT_TILE - 1) / DIRECT_TILE), d.cout, d.n_inst);
+  dim3 grid((unsigned)(d.kb1 - d.kb0), d.cout, d.n_inst);
   hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
 }
 void launch_analyser(const AnalyserDesc& d, void* stream) {

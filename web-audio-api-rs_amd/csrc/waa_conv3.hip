@@ -111,8 +111,8 @@ __global__ __launch_bounds__(NT) void conv_fft3_fwd_kernel(const ConvDesc d, int
   }
   const int c = blockIdx.y;
   const uint32_t pair = blockIdx.z;
-  const int k0 = blockIdx.x * blocks_per_wg;
-  const int k1 = k0 + blocks_per_wg < d.nb ? k0 + blocks_per_wg : d.nb;
+  const int k0 = d.kb0 + blockIdx.x * blocks_per_wg;
+  const int k1 = k0 + blocks_per_wg < d.kb1 ? k0 + blocks_per_wg : d.kb1;
   if (k0 >= k1) return;
   const uint32_t ia = pair * 2, ib = pair * 2 + 1;
   const bool has_b = ib < d.n_inst;
@@ -517,8 +517,8 @@ __global__ __launch_bounds__(NT) void conv_fft3_inv_kernel(const ConvDesc d, int
   load_tw3(twg, t, tw3);
   const int c = blockIdx.y;
   const uint32_t pair = blockIdx.z;
-  const int k0 = blockIdx.x * blocks_per_wg;
-  const int k1 = k0 + blocks_per_wg < d.nb ? k0 + blocks_per_wg : d.nb;
+  const int k0 = d.kb0 + blockIdx.x * blocks_per_wg;
+  const int k1 = k0 + blocks_per_wg < d.kb1 ? k0 + blocks_per_wg : d.kb1;
   if (k0 >= k1) return;
   const uint32_t ia = pair * 2, ib = pair * 2 + 1;
   const bool has_b = ib < d.n_inst;
@@ -599,10 +599,10 @@ static void f3_allow_lds() {
 // blocks per persistent workgroup: whole (pair, channel) streams when there are enough of them to fill the chip, shorter
 // runs otherwise
 static int f3_blocks_per_wg(const ConvDesc& d, int channels) {
-  const int streams = (int)d.n_pairs * channels;
+  const int streams = (int)d.n_pairs * channels, nbl = d.kb1 - d.kb0;
   int segs = streams >= 512 ? 1 : (512 + streams - 1) / streams;
-  if (segs > d.nb) segs = d.nb;
-  return (d.nb + segs - 1) / segs;
+  if (segs > nbl) segs = nbl;
+  return (nbl + segs - 1) / segs;
 }
 
 void launch_conv3_ir_spectra(const ConvDesc& d, void* stream) {
@@ -616,13 +616,13 @@ void launch_conv3_forward(const ConvDesc& d, void* stream) {
     return;
   }
   const int bpw = f3_blocks_per_wg(d, d.cin);
-  hipLaunchKernelGGL(conv_fft3_fwd_kernel<F3_FWD>, dim3((d.nb + bpw - 1) / bpw, d.cin, d.n_pairs), dim3(NT), (size_t)LDS_BYTES,
+  hipLaunchKernelGGL(conv_fft3_fwd_kernel<F3_FWD>, dim3((d.kb1 - d.kb0 + bpw - 1) / bpw, d.cin, d.n_pairs), dim3(NT), (size_t)LDS_BYTES,
                      (hipStream_t)stream, d, bpw);
 }
 void launch_conv3_inverse(const ConvDesc& d, void* stream) {
   f3_allow_lds();
   const int bpw = f3_blocks_per_wg(d, d.cout);
-  hipLaunchKernelGGL(conv_fft3_inv_kernel, dim3((d.nb + bpw - 1) / bpw, d.cout, d.n_pairs), dim3(NT), (size_t)LDS_BYTES,
+  hipLaunchKernelGGL(conv_fft3_inv_kernel, dim3((d.kb1 - d.kb0 + bpw - 1) / bpw, d.cout, d.n_pairs), dim3(NT), (size_t)LDS_BYTES,
                      (hipStream_t)stream, d, bpw);
 }
 

@@ -240,6 +240,9 @@ struct ConvDesc {
                       // `in` is a view of a source's buffer (the source renders its buffer unchanged from frame 0)
   uint32_t n_inst, n_pairs;
   int32_t ir_nch, pad1;
+  // blocks [kb0, kb1) of this launch: the full range, or the blocks of one tile range of a block-scheduled feedback loop
+  // (the spectra of earlier blocks stay in X between the launches)
+  int32_t kb0, kb1;
   // A BiquadFilterNode with constant coefficients directly in front of the convolver, rendered by the forward transform's
   // input stage (fft3 only; waa_conv3.hip): `in` is then the BIQUAD's input and its filtered signal never crosses HBM.
   const double* pre_coefs;   // [n_inst][pre_coef_stride]: b0 b1 b2 a1 a2 (null: no filter)

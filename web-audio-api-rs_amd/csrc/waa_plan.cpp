@@ -1530,7 +1530,8 @@ int build_plan(waa_batch* b) {
     }
     if (!term.live || !term.materialized) return 0;
     if (term.desc.kind == WAA_NODE_CONVOLVER && term.has_ir) {
-      if (scc_of[id] >= 0) return fail(WAA_ERR_OUT_OF_SCOPE, "a ConvolverNode inside a feedback loop is out of scope (node %u)", id);
+      if (scc_of[id] >= 0 && !block_loop(id))
+        return fail(WAA_ERR_OUT_OF_SCOPE, "a ConvolverNode inside a feedback loop is out of scope when the loop's delay is shorter than one partition of its impulse response (node %u)", id);
       int e = alloc_signal(term);
       if (e) return e;
       if ((e = plan_convolver(b, id))) return e;
@@ -2062,7 +2063,8 @@ int build_plan(waa_batch* b) {
         st.group = group;
         // steps that only depend on data from outside the loop run once, over the full range, before the blocks
         st.prologue = st.kind == 5 || st.kind == 12 || st.kind == 13 || st.kind == 14 || st.kind == 3 || (st.kind == 0 && st.chain.n_ops == 1 && st.chain.ops[0].kind == OP_PARAM_ADD);
-        if (st.kind == 2 || st.kind == 4 || st.kind == 15 || st.kind == 16 || st.kind == 17)
+        st.prologue |= st.kind == 18;
+        if (st.kind == 15 || st.kind == 16 || st.kind == 17)
           return fail(WAA_ERR_OUT_OF_SCOPE, "this node kind cannot be rendered inside a feedback loop");
       }
       plan_note(b, "feedback loop: block-scheduled, %u tile(s) = %u frames per block, %zu step(s) per block", bt, bt * TILE,
@@ -2677,11 +2679,13 @@ uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items)
   const double dt = 1. / (double)b->sr;
   const double quantum_duration = (double)RQ * dt;
   double dmin = 1e300;
+  uint32_t conv_tiles = 1;  // partition size of the largest convolver in the loop, in tiles (partitions <= 2048 frames divide a tile)
   for (uint32_t v : loop_items) {
     const uint32_t id = v & ~VTX_READER;
     Node& n = b->nodes[id];
     if (!(v & VTX_READER)) {
-      if (n.desc.kind == WAA_NODE_CONVOLVER && n.has_ir) return 0;
+      // a ConvolverNode renders whole partitions: the block must hold a whole number of them (below)
+      if (n.desc.kind == WAA_NODE_CONVOLVER && n.has_ir) conv_tiles = std::max(conv_tiles, (uint32_t)conv_block_size(b, n) / (uint32_t)TILE);
       continue;
     }
     if (!b->cut[id]) continue;  // keeps its writer->reader edge: reads the current block like any other node
@@ -2693,7 +2697,8 @@ uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items)
   if (!(dmin < 1e300)) return 0;
   const double tiles = std::ceil(dmin / (double)TILE) - 1.;  // block < delay, strictly
   if (tiles < 1.) return 0;
-  return (uint32_t)std::min(tiles, 64.);
+  const uint32_t bt = (uint32_t)std::min(tiles, 64.);
+  return bt / conv_tiles * conv_tiles;  // (0: the delay is shorter than the convolver's partition -> quantum-serial -> refused there)
 }
 
 // A feedback loop (strongly connected group around at least one DelayNode): one loop_kernel launch renders all
@@ -2911,6 +2916,8 @@ int plan_convolver(waa_batch* b, uint32_t id) {
   cv.n_pairs = (b->n_inst + 1) / 2;
   cv.ir_nch = ir_nch;
   cv.ir_len = len;
+  cv.kb0 = 0;
+  cv.kb1 = direct_fir ? (int)((b->lp + 1023) / 1024) : cv.nb;  // (the direct kernel works in 1024-frame pieces)
   // routing (convolver.rs:384-466)
   auto term = [&](int in_ch, int ir_ch, int out_ch) { cv.terms[cv.n_terms++] = ConvTerm{in_ch, ir_ch, out_ch, 0}; };
   if (n.in_nch == 1 && ir_nch == 1) {
