@@ -21,7 +21,9 @@
 // LDS transpose hands every lane its stream's 32 frames.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "waa_internal.hpp"
 #include "waa_stream_common.hpp"
@@ -168,13 +170,16 @@ __device__ float source_frame(const SrcInst& si, int ch, uint64_t frame, uint32_
 }  // namespace
 
 // PASS 0: the tiles' zero-state end states (pass A).  PASS 1: the exact render (pass B).
-template <int PASS>
-__global__ __launch_bounds__(64, PASS == 0 ? 4 : 3) void biquad_lanes_kernel(const BiquadLanesDesc d) {
+// FAST: every stream is one linear run over all tiles of the launch (the host knows: BiquadLanesDesc::fast_tiles) — that
+// instantiation carries no schedule record, no limits and no per-load pointer shuffles; the general one renders the rest
+// (tiles behind a source's fast prefix, bounded signals).
+template <int PASS, bool FAST>
+__global__ __launch_bounds__(64, 4) void biquad_lanes_kernel(const BiquadLanesDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [64][ROWF] chunk rows, then [2][TW] doubles of table
   const int lane = threadIdx.x;
   const uint32_t n_streams = d.n_inst * (uint32_t)d.nch;
   const uint32_t n_groups = (n_streams + 63u) / 64u;
-  const uint32_t tile = d.tile0 + blockIdx.x / n_groups, g = blockIdx.x % n_groups;
+  const uint32_t tile = d.lt0 + blockIdx.x / n_groups, g = blockIdx.x % n_groups;
   __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);  // f64 denormals flushed (FTZ/DAZ render scope, thread.rs:374-382)
   auto lds_sync = []() __attribute__((always_inline)) { __builtin_amdgcn_wave_barrier(); };
   // ---- this lane's stream: where its tile starts (null: not linear there), how many frames may be read
@@ -187,12 +192,24 @@ __global__ __launch_bounds__(64, PASS == 0 ? 4 : 3) void biquad_lanes_kernel(con
   uint64_t lin_frames = 0;        // frames [0, lin_frames) of the render are base[frame]; zeros beyond for a bounded signal
   bool generic_tail = false;      // (source) frames >= lin_frames follow the schedule tables
   SrcInst si{};
-  if (live) {
+  if (FAST) {
+    if (is_src) {
+      const SrcInst* sp = d.in.src + inst;
+      base = load_global(&sp->base) + (uint64_t)ch * load_global(&sp->ch_stride) + load_global(&sp->linear_start);
+    } else {
+      base = d.in.sig.base + (uint64_t)inst * d.in.sig.inst_stride + (uint64_t)ch * d.in.sig.ch_stride;
+    }
+    lin_frames = (uint64_t)d.n_tiles * TILE;
+  } else if (live) {
     if (is_src) {
       si = d.in.src[inst];
       base = si.base + (uint64_t)ch * si.ch_stride + si.linear_start;
       lin_frames = (uint64_t)si.fast_prefix * TILE;
       generic_tail = true;
+      if (si.linear_all) {  // the render's partial last tile continues the run: a bounded signal, nothing behind it is rendered
+        lin_frames = (uint64_t)d.n_quanta * RQ;
+        generic_tail = false;
+      }
     } else {
       base = d.in.sig.base + (uint64_t)inst * d.in.sig.inst_stride + (uint64_t)ch * d.in.sig.ch_stride;
       lin_frames = d.in.valid ? d.in.valid : (uint64_t)d.n_tiles * TILE;
@@ -200,8 +217,48 @@ __global__ __launch_bounds__(64, PASS == 0 ? 4 : 3) void biquad_lanes_kernel(con
   }
   const uint64_t f_tile = (uint64_t)tile * TILE;
   // does any stream of the group need the slow loader in this tile?  (uniform decision: the slow path is wave-cooperative)
-  const bool slow_tile = __any(live && generic_tail && f_tile + TILE > lin_frames);
-  // rows are fetched by OTHER lanes: lane l loads 16 B of row (l >> 3) + 8 j — pointers and limits by shuffle
+  const bool slow_tile = !FAST && __any(live && generic_tail && f_tile + TILE > lin_frames);
+  // rows are fetched by OTHER lanes: lane l loads 16 B of row (l >> 3) + 8 j — pointers and limits by shuffle.
+  // The common case — every stream of the group linear over the whole tile — keeps the eight row pointers in registers
+  // (advanced by one chunk per iteration) instead of shuffling pointer and limit for every load: the shuffles were 32
+  // LDS-pipe operations and eight dependent waits per chunk.  (A group's dead lanes alias its first stream.)
+  const float* prow[8];
+  if (FAST) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int r = j * 8 + (lane >> 3);
+      const bool r_live = g * 64u + (uint32_t)r < n_streams;
+      const uint64_t pb = (uint64_t)__shfl((unsigned long long)(uintptr_t)base, r_live ? r : 0, 64);
+      prow[j] = reinterpret_cast<const float*>(pb) + f_tile + (uint64_t)(lane & 7) * 4;
+      if (d.debug == 1)  // measurement aid: the 64 rows of a chunk as ONE contiguous 8 KB piece (what a transposed layout would give)
+        prow[j] = (is_src ? load_global(&d.in.src->base) : d.in.sig.base) + ((uint64_t)tile * n_groups + g) * 64 * TILE + r * CHUNK + (lane & 7) * 4;
+    }
+  }
+  const uint32_t row_step = FAST && d.debug == 1 ? 64u * CHUNK : (uint32_t)CHUNK;
+  // measurement aid (debug 4, pass A only — its sum does not care about the order): every workgroup starts at a different
+  // chunk of its tile, so that the wavefronts of the device do not walk addresses that are congruent modulo the stream stride
+  const int rot = (PASS == 0 && FAST && d.debug == 4) ? (int)((g * 5u + tile * 3u) & (NCHUNK - 1)) : 0;
+  int fetch_c = rot;
+  if (rot) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) prow[j] += (uint32_t)rot * row_step;
+  }
+  auto fetch_chunk_fast = [&](f4v (&raw)[8]) __attribute__((always_inline)) {
+    if (d.debug == 2) return;  // measurement aid: no sample loads (everything but the memory side)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      raw[j] = __builtin_nontemporal_load((const WAA_GLOBAL_AS f4v*)prow[j]);
+      prow[j] += row_step;
+    }
+    if (PASS == 0 && FAST && d.debug == 4) {
+      fetch_c++;
+      if (fetch_c == NCHUNK) {
+        fetch_c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) prow[j] -= (uint32_t)NCHUNK * row_step;
+      }
+    }
+  };
   auto fetch_chunk = [&](int c, f4v (&raw)[8]) __attribute__((always_inline)) {
     const uint64_t f0 = f_tile + (uint64_t)c * CHUNK + (uint64_t)(lane & 7) * 4;
 #pragma unroll
@@ -281,14 +338,13 @@ __global__ __launch_bounds__(64, PASS == 0 ? 4 : 3) void biquad_lanes_kernel(con
     if (fabsf(1.f - g0) <= 1e-6f) g0 = 1.f;
     if (fabsf(1.f - g1) <= 1e-6f) g1 = 1.f;
   }
-  float* out_base = PASS == 1 && live ? d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)ch * d.out.ch_stride : nullptr;
   // The per-frame table of a chunk — pass A: 32 x (Hx, Hy) = 512 B, pass B: 32 x 5 coefficients = 1280 B — is the same for
   // all 64 lanes.  It travels like the samples: one coalesced vector load a chunk ahead (registers), staged into LDS, read
   // back as BROADCAST reads (every lane the same address: one bank access).  As scalar loads (first build: s_load_dwordx16,
   // two or three in flight for lack of scalar registers, each an L2 round trip) the table was what every wave waited for:
   // 71 % of the wave-cycles parked, 620 cycles per frame.
   constexpr int TW = PASS == 0 ? CHUNK * 2 : CHUNK * 5;   // doubles per chunk
-  double* tabs = reinterpret_cast<double*>(lds + 64 * ROWF);   // [2][TW]
+  double* tabs = reinterpret_cast<double*>(lds + 64 * ROWF);   // [TW]: staged at the top of an iteration, when the previous chunk's sums are done
   const double* tsrc = PASS == 0 ? d.ht + (uint64_t)tile * BIQUAD_HT_WORDS : d.coefs + f_tile * 5;
   typedef double d2v __attribute__((ext_vector_type(2)));
   d2v traw[PASS == 0 ? 1 : 2];
@@ -308,82 +364,125 @@ __global__ __launch_bounds__(64, PASS == 0 ? 4 : 3) void biquad_lanes_kernel(con
   // ---- 64 chunks of 32 frames, software-pipelined: chunk c + 1 (samples and table) is in flight in registers while chunk c
   // is rendered; ONE row buffer in LDS (9 KB per wavefront: four wavefronts per SIMD)
   f4v raw[8];
-  if (!slow_tile) fetch_chunk(0, raw);
-  fetch_tab(0);
-  for (int c = 0; c < NCHUNK; c++) {
-    if (!slow_tile)
+  if (FAST)
+    fetch_chunk_fast(raw);
+  else if (!slow_tile)
+    fetch_chunk(0, raw);
+  fetch_tab(rot);
+  // output rows as 32-bit element offsets from the signal's base (the planner keeps signals below 2^32 elements on this path)
+  uint32_t orow[8];
+  if (PASS == 1) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int r = j * 8 + (lane >> 3);
+      const uint32_t sr = g * 64u + (uint32_t)r;
+      const bool r_live = sr < n_streams;
+      const uint32_t ri = sr / (uint32_t)d.nch, rc = sr % (uint32_t)d.nch;
+      orow[j] = r_live ? (uint32_t)((uint64_t)ri * d.out.inst_stride + (uint64_t)rc * d.out.ch_stride + f_tile + (uint64_t)(lane & 7) * 4)
+                       : 0xFFFFFFFFu;
+      if (FAST && d.debug == 1) orow[j] = (uint32_t)(((uint64_t)tile * n_groups + g) * 64 * TILE + r * CHUNK + (lane & 7) * 4);
+    }
+  }
+  // (the render's last tile may be partial: chunks behind the render's end are not read and written as zeros — a source whose
+  // whole render is one linear run, SrcInst::linear_all, then needs no general launch for that tile: a lone wavefront per CU
+  // there paid a full memory round trip per chunk, 0.5 ms per pass behind the other 234 tiles before it was bounded)
+  const uint64_t f_end = (uint64_t)d.n_quanta * RQ;
+  const int n_chunk = f_tile + TILE <= f_end ? NCHUNK : (int)((f_end - f_tile + CHUNK - 1) / CHUNK);  // (FAST: f_end is a multiple of CHUNK)
+  for (int c = 0; c < n_chunk; c++) {
+    if (FAST || !slow_tile)
       stage_chunk(0, raw);
     else
       stage_chunk_slow(0, c);
-    stage_tab(c & 1);
-    if (c + 1 < NCHUNK) {
-      if (!slow_tile) fetch_chunk(c + 1, raw);
-      fetch_tab(c + 1);
+    stage_tab(0);
+    if (c + 1 < n_chunk) {
+      if (FAST)
+        fetch_chunk_fast(raw);
+      else if (!slow_tile)
+        fetch_chunk(c + 1, raw);
+      fetch_tab((c + 1 + rot) & (NCHUNK - 1));
     }
     lds_sync();
     float* row = lds + lane * ROWF;
-    const double* tb = tabs + (c & 1) * TW;
-    float x[CHUNK];
+    const double* tb = tabs;
+    if (d.debug == 3) {
+      // measurement aid: no arithmetic (loads, staging and stores only)
+    } else if (PASS == 0) {
+      // (eight frames at a time: with all 32 table reads of the chunk hoisted in front of the sums the kernel spilled)
 #pragma unroll
-    for (int k = 0; k < CHUNK / 4; k++) {
-      const f4v v = *reinterpret_cast<const f4v*>(row + k * 4);
-      x[k * 4 + 0] = v.x;
-      x[k * 4 + 1] = v.y;
-      x[k * 4 + 2] = v.z;
-      x[k * 4 + 3] = v.w;
-    }
-    if (PASS == 0) {
+      for (int k8 = 0; k8 < CHUNK / 8; k8++) {
+        const f4v va = *reinterpret_cast<const f4v*>(row + k8 * 8), vb = *reinterpret_cast<const f4v*>(row + k8 * 8 + 4);
+        const float xs[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
-      for (int k = 0; k < CHUNK; k++) {
-        const d2v h = *reinterpret_cast<const d2v*>(tb + 2 * k);
-        const double xd = (double)x[k];
-        z1 = __builtin_fma(h.x, xd, z1);
-        z2 = __builtin_fma(h.y, xd, z2);
+        for (int e = 0; e < 8; e++) {
+          const d2v h = *reinterpret_cast<const d2v*>(tb + 2 * (k8 * 8 + e));
+          const double xd = (double)xs[e];
+          z1 = __builtin_fma(h.x, xd, z1);
+          z2 = __builtin_fma(h.y, xd, z2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
       for (int k4 = 0; k4 < CHUNK / 4; k4++) {
         float yo[4];
-        double cs[20];  // the four frames' coefficient sets: ten broadcast 16-byte reads
+        const f4v xv = *reinterpret_cast<const f4v*>(row + k4 * 4);  // (read per group: 32 samples held in registers cost a wave per SIMD)
+        const float x4[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-        for (int e = 0; e < 10; e++) {
-          const d2v v = *reinterpret_cast<const d2v*>(tb + k4 * 20 + 2 * e);
-          cs[2 * e] = v.x;
-          cs[2 * e + 1] = v.y;
-        }
+        for (int h = 0; h < 2; h++) {
+          double cs[10];  // two frames' coefficient sets: five broadcast 16-byte reads (four frames' worth cost 20 more registers)
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int k = k4 * 4 + e;
-          const double b0 = cs[e * 5 + 0], b1 = cs[e * 5 + 1], b2 = cs[e * 5 + 2], a1 = cs[e * 5 + 3], a2 = cs[e * 5 + 4];
-          const double xd = (double)x[k];
-          // biquad_filter.rs:877-883, the reference's order, unfused, with its flush (denormals: hardware mode)
-          double y = (b0 * xd + b1 * x1) + b2 * x2;
-          y = (y - a1 * y1) - a2 * y2;
-          if (!__builtin_isfinite(y)) y = 0.;
-          x2 = x1;
-          x1 = xd;
-          y2 = y1;
-          y1 = y;
-          float o = (float)y;
-          if (d.n_gain > 0 && g0 != 1.f) o *= g0;
-          if (d.n_gain > 1 && g1 != 1.f) o *= g1;
-          yo[e] = mute ? 0.f : o;
+          for (int e = 0; e < 5; e++) {
+            const d2v v = *reinterpret_cast<const d2v*>(tb + k4 * 20 + h * 10 + 2 * e);
+            cs[2 * e] = v.x;
+            cs[2 * e + 1] = v.y;
+          }
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            const double b0 = cs[e * 5 + 0], b1 = cs[e * 5 + 1], b2 = cs[e * 5 + 2], a1 = cs[e * 5 + 3], a2 = cs[e * 5 + 4];
+            const double xd = (double)x4[h * 2 + e];
+            // biquad_filter.rs:877-883, the reference's order, unfused, with its flush (denormals: hardware mode)
+            double y = (b0 * xd + b1 * x1) + b2 * x2;
+            y = (y - a1 * y1) - a2 * y2;
+            if (!__builtin_isfinite(y)) y = 0.;
+            x2 = x1;
+            x1 = xd;
+            y2 = y1;
+            y1 = y;
+            float o = (float)y;
+            if (d.n_gain > 0 && g0 != 1.f) o *= g0;
+            if (d.n_gain > 1 && g1 != 1.f) o *= g1;
+            yo[h * 2 + e] = mute ? 0.f : o;
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
         *reinterpret_cast<f4v*>(row + k4 * 4) = f4v{yo[0], yo[1], yo[2], yo[3]};
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     lds_sync();
     if (PASS == 1) {
       // rows -> full 128-byte lines of the streams' outputs
-      const uint64_t f0 = f_tile + (uint64_t)c * CHUNK + (uint64_t)(lane & 7) * 4;
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int r = j * 8 + (lane >> 3);
-        float* po = reinterpret_cast<float*>((uintptr_t)__shfl((unsigned long long)(uintptr_t)out_base, r, 64));
         const f4v v = *reinterpret_cast<const f4v*>(lds + r * ROWF + (lane & 7) * 4);
-        if (po) __builtin_nontemporal_store(v, (WAA_GLOBAL_AS f4v*)(po + f0));
+        if (orow[j] != 0xFFFFFFFFu) {  // (offsets are multiples of 4: never the marker)
+          __builtin_nontemporal_store(v, (WAA_GLOBAL_AS f4v*)(d.out.base + orow[j]));
+          orow[j] += FAST ? row_step : (uint32_t)CHUNK;
+        }
       }
       lds_sync();  // (the rows are restaged at the top of the next iteration)
+    }
+  }
+  if (PASS == 1) {
+    // the padding behind the render's end stays defined (whole-tile consumers read it): zeros, no round trips
+    for (int c = n_chunk; c < NCHUNK; c++) {
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (orow[j] != 0xFFFFFFFFu) {
+          __builtin_nontemporal_store(f4v{0.f, 0.f, 0.f, 0.f}, (WAA_GLOBAL_AS f4v*)(d.out.base + orow[j]));
+          orow[j] += FAST ? row_step : (uint32_t)CHUNK;
+        }
     }
   }
   if (!live) return;
@@ -436,12 +535,34 @@ __global__ __launch_bounds__(256) void biquad_lanes_chain_kernel(const BiquadLan
 void launch_biquad_tile_digest(const BiquadLanesDesc& d, void* stream) {
   hipLaunchKernelGGL(biquad_tile_digest_kernel, dim3(d.n_tiles), dim3(64), 0, (hipStream_t)stream, d);
 }
-void launch_biquad_lanes(const BiquadLanesDesc& d, void* stream) {
-  const uint32_t n_streams = d.n_inst * (uint32_t)d.nch, n_groups = (n_streams + 63u) / 64u, ntl = d.tile1 - d.tile0;
-  const size_t lds = 64 * ROWF * sizeof(float) + 2 * CHUNK * 5 * sizeof(double);
-  hipLaunchKernelGGL((biquad_lanes_kernel<0>), dim3(ntl * n_groups), dim3(64), lds, (hipStream_t)stream, d);
+void launch_biquad_lanes(const BiquadLanesDesc& d0, void* stream) {
+  BiquadLanesDesc d = d0;
+  d.debug = getenv("WAA_LANES_DEBUG") ? (uint32_t)atoi(getenv("WAA_LANES_DEBUG")) : 0u;
+  const uint32_t n_streams = d.n_inst * (uint32_t)d.nch, n_groups = (n_streams + 63u) / 64u;
+  // LDS per wavefront: the row buffer + ONE table buffer — 9.5 KB (pass A) / 10.25 KB (pass B): 16 / 15 wavefronts per CU.
+  // The 7520 units of C1a then take two rounds over the device; with 13 per CU (a second table buffer) they took three, the
+  // last a quarter full — that, not the access pattern, was a quarter of the two passes' time.
+  const size_t lds_a = 64 * ROWF * sizeof(float) + CHUNK * 2 * sizeof(double);
+  const size_t lds_b = 64 * ROWF * sizeof(float) + CHUNK * 5 * sizeof(double);
+  // tiles [tile0, tf): every stream linear (the instantiation without the general loader); [tf, tile1): the general one
+  const uint32_t tf = getenv("WAA_LANES_GENERAL") ? d.tile0 : std::min(std::max(d.fast_tiles, d.tile0), d.tile1);
+  auto pass = [&](auto pass_c) {
+    constexpr int PASS = decltype(pass_c)::value;
+    const size_t lds = (PASS == 0 ? lds_a : lds_b) + (getenv("WAA_LANES_LDS_PAD") ? (size_t)atoi(getenv("WAA_LANES_LDS_PAD")) : 0);  // (measurement aid: fewer wavefronts per CU)
+    if (tf > d.tile0) {
+      d.lt0 = d.tile0;
+      d.lt1 = tf;
+      hipLaunchKernelGGL((biquad_lanes_kernel<PASS, true>), dim3((tf - d.tile0) * n_groups), dim3(64), lds, (hipStream_t)stream, d);
+    }
+    if (tf < d.tile1) {
+      d.lt0 = tf;
+      d.lt1 = d.tile1;
+      hipLaunchKernelGGL((biquad_lanes_kernel<PASS, false>), dim3((d.tile1 - tf) * n_groups), dim3(64), lds, (hipStream_t)stream, d);
+    }
+  };
+  pass(std::integral_constant<int, 0>{});
   hipLaunchKernelGGL(biquad_lanes_chain_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, (hipStream_t)stream, d);
-  hipLaunchKernelGGL((biquad_lanes_kernel<1>), dim3(ntl * n_groups), dim3(64), lds, (hipStream_t)stream, d);
+  pass(std::integral_constant<int, 1>{});
 }
 
 }  // namespace waa

@@ -67,7 +67,7 @@ struct SrcInst {
   // them the kernel's copy floor was 4.9 TB/s)
   int64_t linear_start;
   uint32_t fast_prefix;
-  uint32_t pad;
+  uint32_t linear_all;   // 1: every quantum of the render (also those of a partial last tile) belongs to that run
 };
 
 // ---- chain kernel description ----------------------------------------------------------
@@ -89,7 +89,7 @@ struct InputRef {
   uint64_t valid;         // IN_DELAYED: frames of the delay line that may be read (zeros beyond: a source's buffer read in place)
   ParamRef gain;          // has_gain: a GainNode folded into this edge (applied before the mix to the receiver's count)
   int32_t has_gain;
-  int32_t pad;
+  uint32_t fast_tiles;    // IN_SOURCE (host side): tiles [0, fast_tiles) are fast and one linear run for every instance
 };
 
 enum : int32_t {
@@ -185,7 +185,10 @@ struct BiquadLanesDesc {
   ParamRef gain[2];       // mode 0 only
   int32_t n_gain, nch;
   SignalRef out;
-  uint32_t n_inst, n_tiles, n_quanta, tile0, tile1, pad;
+  uint32_t n_inst, n_tiles, n_quanta, tile0, tile1;
+  uint32_t fast_tiles;    // tiles [0, fast_tiles) are one linear run of the input for EVERY stream (host-known)
+  uint32_t lt0, lt1;      // (set by the launcher: the tiles of one kernel launch)
+  uint32_t debug, pad;    // WAA_LANES_DEBUG (measurement aid: 1 = the rows of a chunk contiguous in memory, results meaningless)
 };
 void launch_biquad_tile_digest(const BiquadLanesDesc& d, void* stream);
 void launch_biquad_lanes(const BiquadLanesDesc& d, void* stream);

@@ -507,7 +507,8 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
       continue;
     }
     if (o.kind == OP_BIQUAD && o.i0 == 2 && !dup && !b->dry && b->steps[(size_t)o.i1].coef.rows == 1 && !getenv("WAA_ARATE_STREAM") &&
-        (inputs[0].kind == IN_SIGNAL || inputs[0].kind == IN_SOURCE)) {
+        (inputs[0].kind == IN_SIGNAL || inputs[0].kind == IN_SOURCE) &&
+        (uint64_t)b->n_inst * seg_out.inst_stride < (1ull << 32)) {  // (its output rows are 32-bit element offsets)
       // per-frame coefficients, ONE table for all instances: a lane per stream, tiles in parallel (waa_biquad_lanes.hip)
       Step& cstep = b->steps[(size_t)o.i1];
       Step& dstep = b->steps[(size_t)o.i1 + 1];  // (reserved right behind the coefficient step by emit_node_ops)
@@ -535,6 +536,8 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
       L.n_quanta = b->n_quanta;
       L.tile0 = 0;
       L.tile1 = b->n_tiles;
+      L.fast_tiles = inputs[0].kind == IN_SOURCE ? inputs[0].fast_tiles
+                                                 : (inputs[0].valid ? (uint32_t)std::min<uint64_t>(inputs[0].valid / TILE, b->n_tiles) : b->n_tiles);
       dstep.kind = 18;
       dstep.lanes = L;
       dstep.profile_slot = slot_for(b, "biquad_tile_digest_kernel");
@@ -2267,6 +2270,7 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   std::vector<SrcInst> insts(b->n_inst);
   std::vector<SrcSchedule> scheds;
   std::vector<std::pair<int64_t, uint32_t>> linear;  // per schedule: (linear_start, fast_prefix)
+  std::vector<uint32_t> linear_all;                   // per schedule: the whole render is that linear run
   std::map<SchedKey, uint32_t> dedup;
   const ParamStore& p_rate = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
   const ParamStore& p_det = n.params[WAA_PARAM_SOURCE_DETUNE];
@@ -2314,8 +2318,17 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
           prefix++;
       }
       linear.push_back({start0, prefix});
-      plan_note(b, "source node %u schedule %zu: tiles [0, %u) are one linear run from buffer frame %lld", id, scheds.size(), prefix,
-                (long long)start0);
+      // ... and the render's last, partial tile continues that run as far as the render goes (quanta behind the render's end do
+      // not exist): the whole render is one linear run — consumers treat the source like a signal of n_quanta * 128 frames
+      bool all = prefix == b->n_tiles;
+      if (prefix + 1 == b->n_tiles && (size_t)prefix * QUANTA_PER_TILE < (size_t)b->n_quanta) {
+        all = true;
+        for (size_t q = (size_t)prefix * QUANTA_PER_TILE; q < (size_t)b->n_quanta && q < so.qrec.size(); q++)
+          all = all && so.qrec[q].mode == Q_FAST && so.qrec[q].start == start0 + (int64_t)q * RQ;
+      }
+      linear_all.push_back(all ? 1u : 0u);
+      plan_note(b, "source node %u schedule %zu: tiles [0, %u) are one linear run from buffer frame %lld%s", id, scheds.size(), prefix,
+                (long long)start0, all && prefix < b->n_tiles ? " (and so is the rest of the render)" : "");
     }
     SrcSchedule ds{};
     QRec* dq = nullptr;
@@ -2340,6 +2353,7 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
     si.sc = scheds[si.sched];
     si.linear_start = linear[si.sched].first;
     si.fast_prefix = si.aligned && !getenv("WAA_NO_LINEAR_PREFIX") ? linear[si.sched].second : 0;  // (switch: A/B aid)
+    si.linear_all = si.fast_prefix ? linear_all[si.sched] : 0;
   }
   SrcInst* d_insts = nullptr;
   int e = dev_upload(b, &d_insts, insts);
@@ -2349,6 +2363,8 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   if (e) return e;
   in->src = d_insts;
   in->sched = d_scheds;
+  in->fast_tiles = b->n_tiles;
+  for (auto& si : insts) in->fast_tiles = std::min(in->fast_tiles, !si.base ? 0u : (si.linear_all ? b->n_tiles : si.fast_prefix));
   plan_note(b, "source node %u: %zu distinct schedule(s) for %u instance(s)", id, scheds.size(), b->n_inst);
   return 0;
 }
