@@ -318,6 +318,22 @@ def test_plan_convolver_inside_a_loop(hip):
 
 
 @pytest.mark.gpu
+def test_parity_echo_loop_as_one_persistent_launch(hip, orc, monkeypatch):
+    """WAA_PERSISTENT_LOOP=1: the single-launch-per-block echo loop walks its blocks inside ONE launch (one workgroup per
+    instance, a barrier between blocks); bit-identical to the launch-per-block form"""
+    n, frames = 5, 2048 * 9 + 300
+    noise = white_noise(n, 2, frames, seed0=33)
+    delays = np.float32([0.0430, 0.05, 0.0861, 0.1, 0.0999])
+    gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6])
+    plain = _feedback_graph(hip, noise, delays, gains, False)
+    monkeypatch.setenv("WAA_PERSISTENT_LOOP", "1")
+    pers = _feedback_graph(hip, noise, delays, gains, False)
+    assert np.array_equal(plain, pers)
+    o = _feedback_graph(orc, noise, delays, gains, False)
+    assert np.abs(pers - o).max() == 0.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("forced_loop_kernel", [False, True])
 @pytest.mark.parametrize("with_filter", [False, True])
 def test_parity_long_feedback_delay_block_scheduled(hip, orc, with_filter, forced_loop_kernel, monkeypatch):

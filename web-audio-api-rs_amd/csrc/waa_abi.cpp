@@ -817,6 +817,34 @@ waa_status waa_render(waa_batch* b) {
         if (e) return e;
       }
     const uint32_t bt = b->group_tiles[st.group];
+    {
+      // a loop that is ONE element-wise launch per block (the echo loop): one persistent launch can walk the blocks itself
+      // (WAA_PERSISTENT_LOOP=1).  Measured on the fb workload (1024 contexts x 10 s, 47 blocks): 5.17-5.20 ms against
+      // 5.19-5.37 ms for the 47 launches — the loop is bound by its 3 x 3.9 GB per pass at 16 wavefronts per CU, not by the
+      // launches; opt-in, parity-tested (tests/test_cycles.py), not the default.
+      size_t n_body = 0, body = 0;
+      for (size_t k = i; k < j; k++)
+        if (!b->steps[k].prologue) {
+          n_body++;
+          body = k;
+        }
+      if (n_body == 1 && b->steps[body].kind == 0 && getenv("WAA_PERSISTENT_LOOP")) {
+        const Step& bs = b->steps[body];
+        bool element_wise = true;
+        for (int o = 0; o < bs.chain.n_ops; o++) element_wise &= bs.chain.ops[o].kind != OP_BIQUAD;
+        int curve_op = -1;
+        if (element_wise && !resample_shape(bs.chain, &curve_op)) {
+          ChainDesc d = bs.chain;
+          d.tile0 = 0;
+          d.tile1 = b->n_tiles;
+          d.persist_block = bt * (TILE / 256);
+          int e = timed(bs.profile_slot, [&] { launch_chain(d, bs.cmax, b->stream); });
+          if (e) return e;
+          i = j;
+          continue;
+        }
+      }
+    }
     for (uint32_t t0 = 0; t0 < b->n_tiles; t0 += bt) {
       const uint32_t t1 = std::min(b->n_tiles, t0 + bt);
       for (size_t k = i; k < j; k++)

@@ -135,6 +135,12 @@ struct ChainDesc {
   uint32_t tile0, tile1;   // tiles [tile0, tile1) of this launch (block-scheduled feedback loops); full range otherwise
   int32_t lds_curve_op;    // set by the launcher: op whose WaveShaper curve is staged in LDS (-1: none)
   int32_t tile_major;      // set by the launcher: wave index -> (sub-tile, instance) instead of (instance, sub-tile)
+  // Block-scheduled feedback loop made of this ONE launch (the echo loop  line = source + gain * delayed(line)): > 0 = the
+  // loop's block in 256-frame sub-tiles; the kernel is then PERSISTENT — one workgroup per instance walks the blocks of
+  // [tile0, tile1) in order, its four wavefronts share a block's sub-tiles, a workgroup barrier between blocks — instead of
+  // one launch per block (47 launches of 250 MB each for a 10 s render, at 2 TB/s).  0: a plain launch.
+  uint32_t persist_block;
+  uint32_t pad;
 };
 
 // ---- streaming biquad kernel (the C2 / T1 hot shape) --------------------------------------

@@ -658,10 +658,20 @@ void chain_kernel(const ChainDesc d) {
   const int lane = threadIdx.x & 63;
   const uint32_t n_tiles_k = (d.tile1 - d.tile0) * (TILE / TILE_FR);  // sub-tiles of this launch
   uint32_t inst, tile_first, tile_last;
+  uint32_t tile_step = 1, per_block = 0;  // (persistent form: sub-tiles a wavefront renders between two workgroup barriers)
   if (SERIAL) {
     inst = blockIdx.x;
     tile_first = d.tile0 * (TILE / TILE_FR);
     tile_last = d.tile1 * (TILE / TILE_FR);
+  } else if (d.persist_block) {
+    // one workgroup per instance, blocks in order: wavefront w renders sub-tiles w, w + 4, ... of every block (the block
+    // and the tile range are multiples of four sub-tiles, so the four wavefronts meet at every barrier).  What a block
+    // reads of the loop's history was written by THIS workgroup before an earlier barrier: same CU, same L1.
+    inst = blockIdx.x;
+    tile_first = d.tile0 * (TILE / TILE_FR) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    tile_last = d.tile1 * (TILE / TILE_FR);
+    tile_step = 4;
+    per_block = d.persist_block / 4;
   } else {
     // (readfirstlane: the wave index is uniform; telling the compiler keeps instance / tile addressing in SGPRs)
     // Workgroup b runs on XCD b % 8.  In (instance, sub-tile) order the XCDs are dealt CONTIGUOUS ranges of it: what a
@@ -712,7 +722,17 @@ void chain_kernel(const ChainDesc d) {
     __syncthreads();
   }
 
-  for (uint32_t tile = tile_first; tile < tile_last; tile++) {
+  uint32_t done_in_block = 0;
+  for (uint32_t tile = tile_first; tile < tile_last; tile += tile_step) {
+    if constexpr (!SERIAL) {
+      if (per_block) {
+        if (done_in_block == per_block) {
+          __syncthreads();  // (waits for this wavefront's stores, then for the other three: the block is in L2 / L1)
+          done_in_block = 0;
+        }
+        done_in_block++;
+      }
+    }
     float v[C][K];
     // ---- inputs: mix every incoming edge to the node's computed channel count and sum in edge order
     if constexpr (!FANIN) {
@@ -1091,6 +1111,11 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
     // (8 frames per lane instead of 4 was measured: fewer waves fit per SIMD and every workload got slower)
     const uint64_t waves = (uint64_t)d.n_inst * (d.tile1 - d.tile0) * (TILE / 256);
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (d.persist_block) {
+      grid = dim3(d.n_inst);
+      dd.tile_major = 0;
+      dd.xcd_remap = 0;
+    }
     if (d.n_inputs <= 1) {
       if (cmax <= 1)
         hipLaunchKernelGGL((chain_kernel<1, 4, false, false>), grid, block, lds, s, dd);
