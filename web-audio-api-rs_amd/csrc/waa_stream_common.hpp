@@ -37,6 +37,24 @@ __device__ __forceinline__ double read_lane(double v, int lane) {
 __device__ __noinline__ void load_channel_generic(const InputRef& in, const SrcInst& si, const SrcSchedule& sc, int ch,
                                                   uint32_t tile, int lane, uint32_t n_quanta, float* out32) {
   const float* chp = si.base + (uint64_t)ch * si.ch_stride;
+  if (si.linear_all) {
+    // the render's partial last tile of a source that is one linear run (SrcInst::linear_all; every tile in front of it is
+    // in the fast prefix): vector loads bounded by the render's end instead of eight dependent record / sample round trips
+    // at the end of EVERY wave
+    const float* p = chp + si.linear_start + (int64_t)tile * TILE;
+    const uint64_t f_end = (uint64_t)n_quanta * RQ;
+    for (int j = 0; j < NV4; j++) {
+      const uint64_t f = (uint64_t)tile * TILE + j * 256 + lane * 4;
+      const bool ok = f + 3 < f_end;
+      f4v t = load_global_f4(ok ? p + j * 256 + lane * 4 : chp + si.linear_start);
+      if (!ok) t = f4v{0.f, 0.f, 0.f, 0.f};
+      out32[j * 4 + 0] = t.x;
+      out32[j * 4 + 1] = t.y;
+      out32[j * 4 + 2] = t.z;
+      out32[j * 4 + 3] = t.w;
+    }
+    return;
+  }
   for (int j = 0; j < NV4; j++) {
     const uint32_t fq = j * 256 + lane * 4;
     const uint32_t q = tile * QUANTA_PER_TILE + fq / RQ;
