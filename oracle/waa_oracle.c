@@ -1606,7 +1606,8 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
     if ((int)pid >= dn->n_params) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - node %u has no param %u", to, pid);
     uint32_t kind = dn->desc.kind;
     if (!(kind == WAA_NODE_GAIN || kind == WAA_NODE_BIQUAD || kind == WAA_NODE_DELAY || kind == WAA_NODE_STEREO_PANNER ||
-          kind == WAA_NODE_CONSTANT_SOURCE || kind == WAA_NODE_OSCILLATOR))
+          kind == WAA_NODE_CONSTANT_SOURCE || kind == WAA_NODE_OSCILLATOR ||
+          (kind == WAA_NODE_BUFFER_SOURCE && (pid == WAA_PARAM_SOURCE_PLAYBACK_RATE || pid == WAA_PARAM_SOURCE_DETUNE))))
       return fail(WAA_ERR_OUT_OF_SCOPE, "audio-rate modulation of a host-evaluated param (node %u) is out of scope", to);
     for (uint32_t k = 0; k < n_inst; k++)
       if (!b->st[k][to].pin[pid]) {
@@ -2326,8 +2327,12 @@ static void process_buffer_source(orc_batch* b, NodeCfg* n, NodeState* s, uint32
 
   float tmp[RQ];
   int len;
-  double detune = (double)param_get(&n->params[WAA_PARAM_SOURCE_DETUNE], inst, sc->quantum, &len, tmp)[0];
-  double playback_rate = (double)param_get(&n->params[WAA_PARAM_SOURCE_PLAYBACK_RATE], inst, sc->quantum, &len, tmp)[0];
+  /* k-rate params (audio_buffer_source.rs:157,168): with an input from the graph the value of the quantum is the
+   * intrinsic value + the FIRST sample of the mixed input, NaN -> default, clamped (param.rs:739-760) - element 0 of what
+   * param_get_in forms in either of its branches */
+  double detune = (double)param_get_in(&n->params[WAA_PARAM_SOURCE_DETUNE], s->pin[WAA_PARAM_SOURCE_DETUNE], inst, sc->quantum, &len, tmp)[0];
+  double playback_rate =
+      (double)param_get_in(&n->params[WAA_PARAM_SOURCE_PLAYBACK_RATE], s->pin[WAA_PARAM_SOURCE_PLAYBACK_RATE], inst, sc->quantum, &len, tmp)[0];
   double computed_playback_rate = playback_rate * exp2(detune / 1200.);
 
   uint64_t buffer_length = buffer->frames;

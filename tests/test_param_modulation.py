@@ -66,12 +66,15 @@ def test_two_modulators_sum(be):
 
 
 def test_modulating_a_host_evaluated_param_is_out_of_scope(be):
-    c = ctx(be, 1, RQ)
+    """panner geometry is evaluated by the host per quantum: a graph input on it is refused (status 4); the source's
+    playbackRate / detune are host-evaluated too, but resolved at plan time (tests below)"""
+    c = ctx(be, 2, RQ)
     src = c.create_buffer_source()
     src.set_buffer(waa.AudioBuffer(np.ones((1, RQ), np.float32), 48000.0))
+    pan = c.create_panner()
     lfo = c.create_constant_source(offset=0.1)
-    lfo.connect(src.playback_rate)
-    src.connect(c.destination())
+    lfo.connect(pan.position_x)
+    src.connect(pan).connect(c.destination())
     src.start()
     lfo.start()
     with pytest.raises(waa.WaaError) as ei:
@@ -154,3 +157,113 @@ def test_parity_filter_sweep_and_flanger(hip, orc):
         c.close()
     assert rms_err(*outs).max() <= 1e-6
     assert np.abs(outs[0] - outs[1]).max() <= 2e-6
+
+
+# ---- playbackRate / detune of an AudioBufferSourceNode modulated from the graph (k-rate params: param.rs:739-760,
+# audio_buffer_source.rs:176-197).  The host replays the playhead, so the library renders the modulating subgraph at plan
+# time and reads one value per render quantum back (waa_abi.cpp::resolve_source_rate_modulation).
+def _ramp_buffer(frames, n_ch=1):
+    t = np.arange(frames, dtype=np.float32)
+    return np.stack([np.sin(t * (0.01 + 0.003 * c)) for c in range(n_ch)]).astype(np.float32)
+
+
+def _render_rate(be, frames, modulate, rate=1.0, extra=0.5, start_mod=0.0, device=-1):
+    c = ctx(be, 1, frames) if device == -1 else waa.OfflineAudioContext(1, frames, 48000.0, binding=be, device=device)
+    src = c.create_buffer_source()
+    src.set_buffer(waa.AudioBuffer(_ramp_buffer(frames * 3), 48000.0))
+    src.playback_rate.set_value(rate)
+    if modulate:
+        mod = c.create_constant_source(offset=extra)
+        mod.connect(src.playback_rate)
+        mod.start_at(start_mod)
+    src.connect(c.destination())
+    src.start()
+    return c
+
+
+def test_constant_modulator_on_playback_rate_equals_the_sum(be):
+    """rate 1.0 + a ConstantSource of 0.5 on the param = playbackRate 1.5 (the input is ADDED, once per quantum)"""
+    frames = RQ * 24
+    a = _render_rate(be, frames, True, 1.0, 0.5).start_rendering_sync().data
+    c = _render_rate(be, frames, False, 1.5)
+    b = c.start_rendering_sync().data
+    assert np.abs(a).max() > 0.5 and np.array_equal(a, b)
+
+
+def test_modulator_that_starts_later_changes_the_rate_at_a_quantum_boundary(be):
+    """k-rate: the FIRST sample of the quantum counts — a modulator that starts in the middle of quantum 3 (its first
+    frame still 0 there) moves the rate from quantum 4 on"""
+    frames = RQ * 16
+    start = (3 * RQ + 40) / 48000.0
+    out = _render_rate(be, frames, True, 1.0, 1.0, start_mod=start).start_rendering_sync().data[0, 0]
+    plain = _render_rate(be, frames, False, 1.0).start_rendering_sync().data[0, 0]
+    assert np.array_equal(out[:4 * RQ], plain[:4 * RQ])          # quanta 0..3 at rate 1
+    buf = _ramp_buffer(frames * 3)[0]
+    # from quantum 4 on the playhead advances 2 buffer frames per frame, starting where rate 1 left it
+    expect = buf[4 * RQ + 2 * np.arange(RQ)]
+    assert np.abs(out[4 * RQ:5 * RQ] - expect).max() <= 1e-6
+
+
+def test_plan_only_batch_names_the_reason(hip):
+    c = _render_rate(hip, RQ * 8, True, device=waa.PLAN_ONLY)
+    with pytest.raises(waa.WaaError) as ei:
+        c.plan_describe()
+    assert ei.value.status == 4 and "rendered at plan time" in str(ei.value)
+    c.close()
+
+
+def _vibrato(binding, noise, lfo_hz, depth, detune_cents, n_ch):
+    """the vibrato patch: Oscillator(LFO) -> Gain(depth) -> source.playbackRate, a second LFO on detune"""
+    n, _, frames = noise.shape
+    c = waa.OfflineAudioContext(n_ch, frames // 2, 48000.0, n_instances=n, binding=binding)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    src.set_loop(True)
+    lfo = c.create_oscillator(type_="sine", frequency=lfo_hz)
+    for i in range(n):
+        lfo.frequency.set_value(lfo_hz * (1.0 + 0.3 * i), instance=i)
+    d = c.create_gain(gain=depth)
+    lfo.connect(d).connect(src.playback_rate)
+    if detune_cents:
+        lfo2 = c.create_oscillator(type_="triangle", frequency=lfo_hz * 0.37)
+        d2 = c.create_gain(gain=detune_cents)
+        lfo2.connect(d2).connect(src.detune)
+        lfo2.start()
+    src.connect(c.create_gain(gain=0.5)).connect(c.destination())
+    lfo.start()
+    src.start()
+    return c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("detune_cents", [0.0, 300.0])
+def test_parity_vibrato_on_playback_rate(hip, orc, detune_cents):
+    """per-instance LFO rates: every instance gets its own playhead schedule (the slow, interpolating track)"""
+    noise = white_noise(3, 2, RQ * 160, seed0=77)
+    outs = []
+    for be in (hip, orc):
+        c = _vibrato(be, noise, 6.0, 0.2, detune_cents, 2)
+        if be is hip:
+            assert "modulated from the graph" in c.plan_describe()
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    g, o = outs
+    assert np.abs(o).max() > 0.1
+    assert rms_err(g, o).max() <= 1e-6 and np.abs(g - o).max() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_modulated_rate_source_next_to_a_plain_one(hip, orc):
+    """the rest of the graph plans as usual once the param edges are resolved: a filter behind the modulated source, a second
+    plain source, both into the destination"""
+    noise = white_noise(2, 1, RQ * 120, seed0=5)
+    outs = []
+    for be in (hip, orc):
+        c = _vibrato(be, noise, 4.0, 0.5, 0.0, 1)
+        plain = c.create_buffer_source()
+        plain.set_buffer_batch(noise[:, :, ::-1].copy(), 48000.0)
+        plain.connect(c.create_biquad_filter(type_="bandpass", frequency=1500.0)).connect(c.destination())
+        plain.start()
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    assert rms_err(outs[0], outs[1]).max() <= 1e-6

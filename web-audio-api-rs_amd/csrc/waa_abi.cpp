@@ -648,11 +648,101 @@ waa_status waa_set_param_block(waa_batch* b, uint32_t node, uint32_t param, uint
 
 // build_plan under a stopwatch; the split (hipMalloc / blocking uploads / the rest = host planning: ordering, scheduling
 // replay, coefficient and automation evaluation) goes into the plan description
+static int run_steps(waa_batch* b);
+
+// AudioBufferSourceNode::playback_rate / detune with an input from the graph (k-rate: value + the first sample of the
+// mixed input, NaN -> default, clamped, once per render quantum: param.rs:739-760; audio_buffer_source.rs:176-197).  The
+// playhead replay that turns those values into the source's per-quantum schedule runs on the host, so the modulating
+// subgraph is rendered FIRST, by the ordinary plan machinery (prepass), one value per quantum is read back and installed
+// as a k-rate value block per instance; the param edges are then removed and the real plan is built.
+static int resolve_source_rate_modulation(waa_batch* b) {
+  std::vector<std::pair<uint32_t, uint32_t>> mods;
+  for (auto& ed : b->edges) {
+    if (!(ed.to_input & 0x80000000u) || ed.to >= b->nodes.size()) continue;
+    const uint32_t pid = ed.to_input & 0x7fffffffu;
+    if (b->nodes[ed.to].desc.kind != WAA_NODE_BUFFER_SOURCE) continue;
+    if (pid != WAA_PARAM_SOURCE_PLAYBACK_RATE && pid != WAA_PARAM_SOURCE_DETUNE) continue;
+    const std::pair<uint32_t, uint32_t> key(ed.to, pid);
+    if (std::find(mods.begin(), mods.end(), key) == mods.end()) mods.push_back(key);
+  }
+  if (mods.empty() || b->dry) return 0;  // (plan-only batch: build_plan refuses the edges with the reason)
+  b->prepass = true;
+  b->prepass_params = mods;
+  b->prepass_refs.assign(mods.size(), ParamRef{});
+  int e = build_plan(b);
+  const size_t n_steps = b->steps.size();
+  if (!e) e = run_steps(b);
+  std::vector<std::vector<float>> heads(mods.size());
+  if (!e) {
+    float* d_heads = nullptr;
+    const size_t count = (size_t)b->n_inst * b->n_quanta;
+    HIP_TRY(hipMalloc(&d_heads, count * sizeof(float)));
+    for (size_t k = 0; k < mods.size() && !e; k++) {
+      const ParamRef& r = b->prepass_refs[k];
+      if (r.mode != 2 || !r.base) {
+        e = fail(WAA_ERR_INVALID_STATE, "internal: the modulated param %u of source node %u has no per-frame values", mods[k].second, mods[k].first);
+        break;
+      }
+      launch_quantum_heads(r.base, r.stride, b->n_inst, b->n_quanta, d_heads, b->stream);
+      heads[k].resize(count);
+      hipError_t he = hipMemcpyAsync(heads[k].data(), d_heads, count * sizeof(float), hipMemcpyDeviceToHost, b->stream);
+      if (he == hipSuccess) he = hipStreamSynchronize(b->stream);
+      if (he != hipSuccess) e = fail(WAA_ERR_DEVICE, "reading back the modulated playbackRate / detune values: %s", hipGetErrorString(he));
+    }
+    (void)hipFree(d_heads);
+  }
+  // back to an unplanned batch (what the second planning pass of a dynamic plan does, plus the prepass switch)
+  b->prepass = false;
+  b->steps.clear();
+  b->group_tiles.clear();
+  b->state_bufs.clear();
+  b->ones_bufs.clear();
+  b->plan_log.clear();
+  b->force_dynamic = false;
+  for (auto& nd : b->nodes) {
+    nd.sig = SignalRef{};
+    nd.hist = SignalRef{};
+    nd.hist_is_temp = false;
+  }
+  if (e) return e;
+  for (size_t k = 0; k < mods.size(); k++) {
+    ParamStore& p = b->nodes[mods[k].first].params[mods[k].second];
+    p.blocks.clear();  // (the chain added the intrinsic value — constants, value blocks, evaluated automation — already)
+    p.timelines.clear();
+    p.dev_tl = false;
+    for (uint32_t i = 0; i < b->n_inst; i++) {
+      ParamBlock blk;
+      blk.inst = i;
+      blk.q0 = 0;
+      blk.nq = b->n_quanta;
+      blk.vpq = 1;
+      blk.v.assign(heads[k].begin() + (size_t)i * b->n_quanta, heads[k].begin() + (size_t)(i + 1) * b->n_quanta);
+      p.blocks.push_back(std::move(blk));
+    }
+  }
+  b->edges.erase(std::remove_if(b->edges.begin(), b->edges.end(),
+                                [&](const waa_edge_desc& ed) {
+                                  if (!(ed.to_input & 0x80000000u)) return false;
+                                  const std::pair<uint32_t, uint32_t> key(ed.to, ed.to_input & 0x7fffffffu);
+                                  return std::find(mods.begin(), mods.end(), key) != mods.end();
+                                }),
+                 b->edges.end());
+  char note[256];
+  snprintf(note, sizeof note,
+           "playbackRate / detune modulated from the graph on %zu source param(s): the modulating subgraph was rendered at plan time "
+           "(%zu launch step(s)), one value per render quantum read back (k-rate, param.rs:739-760)",
+           mods.size(), n_steps);
+  b->prepass_note = note;
+  return 0;
+}
+
 static int timed_build_plan(waa_batch* b) {
   const auto t0 = std::chrono::steady_clock::now();
   const double a0 = b->t_alloc_ms, u0 = b->t_upload_ms;
   const uint64_t n0 = b->n_alloc, by0 = b->alloc_bytes;
-  int e = build_plan(b);
+  int e = resolve_source_rate_modulation(b);
+  if (!e) e = build_plan(b);
+  if (!e && !b->prepass_note.empty()) b->plan_log.push_back(b->prepass_note);
   b->t_plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   b->plan_alloc_ms = b->t_alloc_ms - a0;
   b->plan_upload_ms = b->t_upload_ms - u0;
@@ -697,13 +787,18 @@ waa_status waa_render(waa_batch* b) {
     int e = timed_build_plan(b);
     if (e) return e;
   }
+  b->rendered = true;
+  return run_steps(b);
+}
+
+// the launches of the current plan, from the initial state
+static int run_steps(waa_batch* b) {
   // every render starts from the initial state (offline contexts render exactly once; re-rendering the
   // same batch is what the benchmark loop does)
   for (auto& sb : b->state_bufs) HIP_TRY(hipMemsetAsync(sb.first, 0, sb.second, b->stream));
   for (auto& sb : b->ones_bufs) HIP_TRY(hipMemsetAsync(sb.first, 0xFF, sb.second, b->stream));
   for (auto& n : b->nodes) n.an = Node::AnBatch{};
   for (auto& v : b->scan_issued) v = 0;
-  b->rendered = true;
   auto timed = [&](int slot, auto&& launch) -> int {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->profiling && slot >= 0) {

@@ -709,9 +709,23 @@ __device__ __forceinline__ void cmac_pk(c2v& acc, const c2v h, const c2v x) {
 }
 template <int KT, int PC, bool PREFETCH = true>
 __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
-  const int pos = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t pair = blockIdx.y / (uint32_t)d.cout;
-  const int co = (int)(blockIdx.y % (uint32_t)d.cout);
+  // Workgroup order.  Every thread reads its position's IR column (P values) once; all (pair, channel) workgroups of one
+  // position block read the same 45 KB.  In grid order (position block fastest) a CU's neighbours in time are OTHER position
+  // blocks, and by the time the same block comes round again (one workgroup lifetime, ~100 us, 60 MB of spectra through the
+  // XCD's L2 later) the column is gone: half of the 2.95 GB of column reads were trips to memory (9.5 GB fetched for 7.9 GB
+  // of X, profiles/r03r_t1_fetch.txt).  Dispatch order id -> XCD id % 8; with  id = x_lo + 8 * (y + gridDim.y * x_hi)
+  // an XCD works through ALL (pair, channel) of one position block before the next: its IR columns stay in L2, and the
+  // eight XCDs still read eight adjacent position blocks (16 KB contiguous per spectrum) at a time.
+  uint32_t bx = blockIdx.x, by = blockIdx.y;
+  if (gridDim.x % 8 == 0 && !d.mac_grid_order) {
+    const uint32_t id = blockIdx.x + gridDim.x * blockIdx.y;
+    const uint32_t rest = id >> 3;
+    by = rest % gridDim.y;
+    bx = (rest / gridDim.y) * 8 + (id & 7);
+  }
+  const int pos = bx * 256 + threadIdx.x;
+  const uint32_t pair = by / (uint32_t)d.cout;
+  const int co = (int)(by % (uint32_t)d.cout);
   const int n = d.n, nb = d.nb, P = d.parts;
   int term = 0;
   for (int t = 0; t < d.n_terms; t++)
@@ -746,15 +760,18 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
   c2v xq[KT];
   const int kend = d.kb1;
 #pragma unroll
-  for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(d.kb0 + i < kend ? d.kb0 + i : kend - 1) * n);
+  // (a block past the end: the load stays unconditional, but it reads this thread's IR value again — resident in L2 — and
+  // not the last spectrum: with the streaming policy those 21 redundant reads per 59 blocks were real trips to memory,
+  // 9.5 GB fetched for the 7.9 GB of X, profiles/r03r_t1_fetch.txt)
+  for (int i = 0; i < KT; i++) xq[i] = ld_pol(d.kb0 + i < kend ? Xc + (uint64_t)(d.kb0 + i) * n : Hc);
   for (int k0 = d.kb0; k0 < kend; k0 += KT) {
     c2v xn[KT];  // X_{k0} .. X_{k0 + KT - 1}
 #pragma unroll
     for (int i = 0; i < KT; i++) xn[i] = k0 + i >= kend ? zero : xq[i];
     if (PREFETCH) {
-      const int kn = k0 + KT;  // (past the end: the last block again — an L2 hit nobody uses)
+      const int kn = k0 + KT;
 #pragma unroll
-      for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(kn + i < kend ? kn + i : kend - 1) * n);
+      for (int i = 0; i < KT; i++) xq[i] = ld_pol(kn + i < kend ? Xc + (uint64_t)(kn + i) * n : Hc);
     }
     c2v acc[KT];
 #pragma unroll
@@ -782,7 +799,7 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
     if (!PREFETCH) {
       const int kn = k0 + KT;
 #pragma unroll
-      for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(kn + i < kend ? kn + i : kend - 1) * n);
+      for (int i = 0; i < KT; i++) xq[i] = ld_pol(kn + i < kend ? Xc + (uint64_t)(kn + i) * n : Hc);
     }
     // slide the window by KT blocks
 #pragma unroll
@@ -984,8 +1001,11 @@ void launch_analyser(const AnalyserDesc& d, void* stream) {
   }
   hipLaunchKernelGGL(analyser_kernel, dim3(d.n_inst), dim3(fft_threads(M)), (size_t)M * sizeof(Cplx), (hipStream_t)stream, d);
 }
-void launch_conv_mac(const ConvDesc& d, void* stream) {
-  dim3 grid(d.n / 256, d.n_pairs * (uint32_t)d.cout);
+void launch_conv_mac(const ConvDesc& d0, void* stream) {
+  dim3 grid(d0.n / 256, d0.n_pairs * (uint32_t)d0.cout);
+  ConvDesc dm = d0;
+  dm.mac_grid_order = getenv("WAA_CONV_MAC_GRID_ORDER") ? 1 : 0;
+  const ConvDesc& d = dm;
   bool one_term = true;
   for (int co = 0; co < d.cout; co++) {
     int cnt = 0;

@@ -257,6 +257,14 @@ struct waa_batch {
   std::vector<std::pair<void*, size_t>> ones_bufs;   // filled with 0xFF bytes at the start of every render
   std::vector<Step> steps;
   bool planned = false;
+  // Graph-modulated playbackRate / detune of AudioBufferSourceNodes (k-rate params the HOST needs: the playhead replay).
+  // prepass = true: build_plan plans only what feeds those params (the modulators and the params' summing chains); the steps
+  // are run, one value per quantum is read back and installed as k-rate value blocks, the param edges are removed and the
+  // real plan is built (waa_abi.cpp::resolve_source_rate_modulation).
+  bool prepass = false;
+  std::vector<std::pair<uint32_t, uint32_t>> prepass_params;  // (source node, param)
+  std::vector<waa::ParamRef> prepass_refs;                          // per entry: the per-frame values the summing chain writes
+  std::string prepass_note;
   bool force_dynamic = false;        // second planning pass: a loop member the static loop kernel cannot render
   bool dynamic = false;              // the plan renders the reference's dynamic channel counts (dyn_kernel)
   uint64_t code_stride = 0;          // bytes per instance of a code table (n_quanta rounded up)

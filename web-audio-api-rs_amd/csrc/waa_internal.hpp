@@ -252,6 +252,7 @@ struct ConvDesc {
   // blocks [kb0, kb1) of this launch: the full range, or the blocks of one tile range of a block-scheduled feedback loop
   // (the spectra of earlier blocks stay in X between the launches)
   int32_t kb0, kb1;
+  int32_t mac_grid_order, pad2;  // (set by the launcher, WAA_CONV_MAC_GRID_ORDER: the product kernel's workgroups in grid order — A/B aid)
   // A BiquadFilterNode with constant coefficients directly in front of the convolver, rendered by the forward transform's
   // input stage (fft3 only; waa_conv3.hip): `in` is then the BIQUAD's input and its filtered signal never crosses HBM.
   const double* pre_coefs;   // [n_inst][pre_coef_stride]: b0 b1 b2 a1 a2 (null: no filter)
@@ -601,6 +602,8 @@ void launch_pcm16_resample(const DecodeDesc& d, void* stream);
 
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);
+// dst[inst][q] = src[inst * inst_stride + q * 128]: the first frame of every render quantum of a per-frame table
+void launch_quantum_heads(const float* src, uint64_t inst_stride, uint32_t n_inst, uint32_t n_quanta, float* dst, void* stream);
 // waa_resample.hip: AudioBufferSource [-> WaveShaper] -> signal without the op interpreter (the C5 shape)
 bool resample_shape(const ChainDesc& d, int* curve_op);
 void launch_resample(const ChainDesc& d, int curve_op, void* stream);

@@ -1078,6 +1078,18 @@ void launch_biquad_hp(const BiquadHpDesc& d, void* stream) {
   hipLaunchKernelGGL(biquad_hp_kernel, dim3(d.n_tiles), dim3(64), 0, (hipStream_t)stream, d);
 }
 
+__global__ void quantum_heads_kernel(const float* src, uint64_t inst_stride, uint32_t n_inst, uint32_t n_quanta, float* dst) {
+  const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (uint64_t)n_inst * n_quanta) return;
+  const uint64_t inst = idx / n_quanta, q = idx % n_quanta;
+  dst[idx] = src[inst * inst_stride + q * RQ];
+}
+void launch_quantum_heads(const float* src, uint64_t inst_stride, uint32_t n_inst, uint32_t n_quanta, float* dst, void* stream) {
+  const uint64_t count = (uint64_t)n_inst * n_quanta;
+  hipLaunchKernelGGL(quantum_heads_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, inst_stride,
+                     n_inst, n_quanta, dst);
+}
+
 void launch_chain(const ChainDesc& d, int cmax, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   bool serial = false;

@@ -898,8 +898,13 @@ int build_plan(waa_batch* b) {
       const uint32_t pid = ed.to_input & 0x7fffffffu;
       if (pid >= to.params.size()) return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - node %u has no param %u", ed.to, pid);
       const uint32_t k = to.desc.kind;
+      const bool source_rate = k == WAA_NODE_BUFFER_SOURCE && (pid == WAA_PARAM_SOURCE_PLAYBACK_RATE || pid == WAA_PARAM_SOURCE_DETUNE);
+      if (source_rate && !b->prepass)  // (with a device these edges are resolved before the plan is built, waa_abi.cpp)
+        return fail(WAA_ERR_OUT_OF_SCOPE,
+                    "playbackRate / detune of source node %u are modulated from the graph: the modulator is rendered at plan time, "
+                    "which needs the device (plan-only batch)", ed.to);
       if (!(k == WAA_NODE_GAIN || k == WAA_NODE_BIQUAD || k == WAA_NODE_DELAY || k == WAA_NODE_STEREO_PANNER ||
-            k == WAA_NODE_CONSTANT_SOURCE || k == WAA_NODE_OSCILLATOR))
+            k == WAA_NODE_CONSTANT_SOURCE || k == WAA_NODE_OSCILLATOR || source_rate))
         return fail(WAA_ERR_OUT_OF_SCOPE, "audio-rate modulation of a host-evaluated param (node %u) is out of scope", ed.to);
       to.pin_edges[pid].push_back((int)e);
     } else {
@@ -916,7 +921,10 @@ int build_plan(waa_batch* b) {
   {
     std::vector<uint32_t> stack;
     for (uint32_t i = 0; i < N; i++)
-      if (b->nodes[i].desc.kind == WAA_NODE_DESTINATION || b->nodes[i].desc.kind == WAA_NODE_ANALYSER) stack.push_back(i);
+      if (!b->prepass && (b->nodes[i].desc.kind == WAA_NODE_DESTINATION || b->nodes[i].desc.kind == WAA_NODE_ANALYSER)) stack.push_back(i);
+    // (prepass: only what feeds the graph-modulated playbackRate / detune params)
+    if (b->prepass)
+      for (auto& pp : b->prepass_params) stack.push_back(pp.first);
     while (!stack.empty()) {
       uint32_t id = stack.back();
       stack.pop_back();
@@ -1527,6 +1535,17 @@ int build_plan(waa_batch* b) {
   b->steps.clear();
   std::function<int(uint32_t)> plan_single = [&](uint32_t id) -> int {
     Node& term = b->nodes[id];
+    if (b->prepass) {
+      // a source whose playbackRate / detune the graph modulates: plan the params' summing chains (their producers are
+      // planned by now), not the source
+      bool mine = false;
+      for (size_t k = 0; k < b->prepass_params.size(); k++)
+        if (b->prepass_params[k].first == id) {
+          mine = true;
+          if (int e = node_param(b, id, b->prepass_params[k].second, &b->prepass_refs[k])) return e;
+        }
+      if (mine) return 0;
+    }
     if (term.live && term.delay_folded) {
       plan_note(b, "delay node %u: %dch, read by its consumers from the delay line (no pass of its own)", id, term.in_nch);
       return node_input_signal(b, id, &term.hist, nullptr, &term.hist_valid);  // the delay line = the node's mixed input
@@ -1693,6 +1712,8 @@ int build_plan(waa_batch* b) {
   // other live node becomes an item of a quantum-serial dyn_kernel launch that carries per-quantum codes
   // (count | silent) with every signal.  A convolver splits the items into groups (its input is produced by the
   // group in front of it, its output consumed by the group behind it).
+  if (b->prepass && (count_change_found || b->force_dynamic))
+    return fail(WAA_ERR_OUT_OF_SCOPE, "the graph that modulates a source's playbackRate / detune needs exact per-quantum channel counts: out of scope");
   if (count_change_found || b->force_dynamic) {
     if (!count_change_found)
       plan_note(b, "a feedback loop needs quantum-serial rendering with node kinds the loop kernel does not cover -> dyn_kernel");
