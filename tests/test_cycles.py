@@ -386,3 +386,47 @@ def test_plan_block_scheduled_loop_node_major_delay(hip, monkeypatch):
     assert "block-scheduled, 5 tile(s) = 10240 frames per block, 4 step(s) per block" in plan
     assert "biquad_stream" in plan and "in a loop: clamped" in plan
     c.close()
+
+
+def _self_modulated_loop(binding, noise, delay_s, device=-1):
+    """the loop's own signal modulates its feedback gain: src -> Delay -> Gain(g) -> back, Delay -> Gain(depth) -> g.gain"""
+    n, _, frames = noise.shape
+    c = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n, binding=binding, device=device)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    d = c.create_delay(1.0, delay_time=delay_s)
+    g = c.create_gain(gain=0.3)
+    depth = c.create_gain(gain=0.2)
+    src.connect(d)
+    d.connect(g).connect(d)
+    d.connect(depth).connect(g.gain)
+    d.connect(c.destination())
+    src.start()
+    return c
+
+
+@pytest.mark.gpu
+def test_parity_param_modulated_from_inside_a_block_scheduled_loop(hip, orc):
+    """the param's summing chain reads a signal of the loop: it is a launch of every block, in its place in the order (it was
+    classed with the loop's prologue — run once, before the blocks, on data not yet rendered — until round 3)"""
+    noise = white_noise(3, 2, 2048 * 9 + 500, seed0=12)
+    outs = []
+    for be in (hip, orc):
+        c = _self_modulated_loop(be, noise, 0.1)
+        if be is hip:
+            plan = c.plan_describe()
+            assert "block-scheduled" in plan and "PARAM_ADD" in plan, plan
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    g, o = outs
+    assert np.abs(o).max() > 0.1
+    assert rms_err(g, o).max() <= 1e-6 and np.abs(g - o).max() <= 2e-6
+
+
+def test_param_modulated_from_inside_a_short_loop_is_refused(hip):
+    noise = white_noise(2, 2, 2048 * 4)
+    c = _self_modulated_loop(hip, noise, 0.01, device=waa.PLAN_ONLY)   # 480 frames: quantum-serial loop
+    with pytest.raises(waa.WaaError) as ei:
+        c.plan_describe()
+    assert ei.value.status == 4 and "modulated from inside its own feedback loop" in str(ei.value)
+    c.close()

@@ -658,6 +658,14 @@ void vertex_targets(const waa_batch* b, uint32_t v, const std::vector<uint8_t>& 
   }
 }
 
+// what a launch reads and writes (plan validation, and the prologue decision of block-scheduled loops)
+struct StepIo {
+  std::vector<const void*> reads, writes;
+  bool feedback_reader = false;
+};
+namespace {
+StepIo step_io(const Step& st);
+}
 int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items);
 int plan_delay_writer(waa_batch* b, uint32_t id);
 int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr);
@@ -2087,6 +2095,17 @@ int build_plan(waa_batch* b) {
         st.group = group;
         // steps that only depend on data from outside the loop run once, over the full range, before the blocks
         st.prologue = st.kind == 5 || st.kind == 12 || st.kind == 13 || st.kind == 14 || st.kind == 3 || (st.kind == 0 && st.chain.n_ops == 1 && st.chain.ops[0].kind == OP_PARAM_ADD);
+        if (st.prologue && st.kind == 0) {
+          // ... unless the param is modulated from INSIDE the loop: its summing chain then reads what a launch of this
+          // group writes and belongs to the blocks, in its place in the order
+          const StepIo io = step_io(st);
+          for (size_t j = first_step; j < b->steps.size() && st.prologue; j++) {
+            if (j == k) continue;
+            const StepIo w = step_io(b->steps[j]);
+            for (const void* r : io.reads)
+              if (std::find(w.writes.begin(), w.writes.end(), r) != w.writes.end()) st.prologue = false;
+          }
+        }
         st.prologue |= st.kind == 18;
         if (st.kind == 15 || st.kind == 16 || st.kind == 17)
           return fail(WAA_ERR_OUT_OF_SCOPE, "this node kind cannot be rendered inside a feedback loop");
@@ -2112,10 +2131,6 @@ int build_plan(waa_batch* b) {
 // render stale or zero data silently.  The only legal read-before-write is a DelayNode reader inside a feedback
 // loop (it reads the PREVIOUS quanta of a line that is filled later in the same pass).
 namespace {
-struct StepIo {
-  std::vector<const void*> reads, writes;
-  bool feedback_reader = false;
-};
 void io_param(const ParamRef& p, StepIo& io) {
   if (p.base && p.mode == 2) io.reads.push_back(p.base);  // per-frame values: possibly produced by a param chain
 }
