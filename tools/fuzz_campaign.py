@@ -39,9 +39,11 @@ def worker(first, count, frozen, out_path):
             except waa.WaaError as e:
                 if e.status == 4:
                     msg = str(e)
-                    key = ("convolver in a feedback loop" if "ConvolverNode inside a feedback loop" in msg else
+                    import re
+                    key = ("convolver in a feedback loop (short delay or dynamic counts)" if "ConvolverNode inside a feedback loop" in msg else
                            "oversampled shaper / HRTF panner in a feedback loop" if "inside a feedback loop is out of scope" in msg else
-                           "param modulated from inside its loop" if "modulat" in msg else msg[:70])
+                           "param modulated from inside its (quantum-serial) loop" if "modulat" in msg else
+                           re.sub(r"\bnode \d+", "node N", msg)[:110])
                     rec["refused"][key] = rec["refused"].get(key, 0) + 1
                     ch.close()
                     continue

@@ -13,10 +13,13 @@ import numpy as np
 import web_audio_api_rs_amd as waa
 from test_fuzz_graphs import build_random_graph
 hip = waa.default_binding(); orc = waa.bind(ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_")
-for seed in map(int, sys.argv[1:]):
-    ch, descr = build_random_graph(hip, seed)
+FROZEN = "--frozen" in sys.argv   # the generator with oversampled WaveShapers / HRTF panners
+for seed in map(int, [a for a in sys.argv[1:] if not a.startswith("--")]):
+    ch, descr = build_random_graph(hip, seed, frozen=FROZEN)
+    if "--plan" in sys.argv:
+        print(ch.plan_describe())
     g = ch.start_rendering_sync().data
-    co, _ = build_random_graph(orc, seed)
+    co, _ = build_random_graph(orc, seed, frozen=FROZEN)
     o = co.start_rendering_sync().data
     d = np.abs(g - o)
     print("seed", seed, descr, "max", float(d.max()))

@@ -302,8 +302,10 @@ __global__ __launch_bounds__(64, 4) void biquad_lanes_kernel(const BiquadLanesDe
   double* st = d.state + (uint64_t)inst * STATE_STRIDE + ch * 4;
   if (live) {
     if (tile == d.tile0) {
-      x1 = st[0];
-      x2 = st[1];
+      if (PASS == 0) {  // (pass B: from the chain kernel's copy, below — `state` is being written by this launch)
+        x1 = st[0];
+        x2 = st[1];
+      }
     } else if (f_tile <= lin_frames) {
       x1 = (double)load_global(base + f_tile - 1);
       x2 = (double)load_global(base + f_tile - 2);
@@ -312,13 +314,13 @@ __global__ __launch_bounds__(64, 4) void biquad_lanes_kernel(const BiquadLanesDe
       x2 = (double)source_frame(si, ch, f_tile - 2, d.n_quanta);
     }
     if (PASS == 1) {
+      const double* sp = d.sin + ((uint64_t)tile * n_streams + sid) * 2;  // (also for the first tile: the chain kernel's copy)
+      y1 = load_global(sp);
+      y2 = load_global(sp + 1);
       if (tile == d.tile0) {
-        y1 = st[2];
-        y2 = st[3];
-      } else {
-        const double* sp = d.sin + ((uint64_t)tile * n_streams + sid) * 2;
-        y1 = load_global(sp);
-        y2 = load_global(sp + 1);
+        const double* xs = d.z + ((uint64_t)tile * n_streams + sid) * 2;
+        x1 = load_global(xs);
+        x2 = load_global(xs + 1);
       }
     }
   }
@@ -530,6 +532,14 @@ __global__ __launch_bounds__(256) void biquad_lanes_chain_kernel(const BiquadLan
       s2 = n2;
     }
   }
+  // Pass B takes the state in front of the launch's FIRST tile from here (y: sin[tile0], above; x: the slot z[tile0], consumed
+  // by now) and not from `state`: the workgroup of the launch's LAST tile writes the carried state there, and nothing orders
+  // it behind the first tile's read — with the last tile bounded by the render's end it is the shortest workgroup of the
+  // launch and, under load, finished before the first one started (found by the fuzz campaign with eight processes on one
+  // device: ~1 graph in 1000 rendered its first tile from the END state).
+  double* xs = d.z + ((uint64_t)d.tile0 * n_streams + sid) * 2;
+  xs[0] = st[0];
+  xs[1] = st[1];
 }
 
 void launch_biquad_tile_digest(const BiquadLanesDesc& d, void* stream) {
@@ -539,9 +549,8 @@ void launch_biquad_lanes(const BiquadLanesDesc& d0, void* stream) {
   BiquadLanesDesc d = d0;
   d.debug = getenv("WAA_LANES_DEBUG") ? (uint32_t)atoi(getenv("WAA_LANES_DEBUG")) : 0u;
   const uint32_t n_streams = d.n_inst * (uint32_t)d.nch, n_groups = (n_streams + 63u) / 64u;
-  // LDS per wavefront: the row buffer + ONE table buffer — 9.5 KB (pass A) / 10.25 KB (pass B): 16 / 15 wavefronts per CU.
-  // The 7520 units of C1a then take two rounds over the device; with 13 per CU (a second table buffer) they took three, the
-  // last a quarter full — that, not the access pattern, was a quarter of the two passes' time.
+  // LDS per wavefront: the row buffer + ONE table buffer — 9.5 KB (pass A) / 10.25 KB (pass B): 16 / 15 wavefronts per CU
+  // (a second table buffer is not needed: the table is staged at the top of an iteration, after the previous chunk's sums).
   const size_t lds_a = 64 * ROWF * sizeof(float) + CHUNK * 2 * sizeof(double);
   const size_t lds_b = 64 * ROWF * sizeof(float) + CHUNK * 5 * sizeof(double);
   // tiles [tile0, tf): every stream linear (the instantiation without the general loader); [tf, tile1): the general one
