@@ -336,7 +336,12 @@ waa_status waa_plan_describe(waa_batch* batch, char* buf, size_t cap, size_t* ne
  * here ONCE per process, before the first batch with an HRTF PannerNode is created (InvalidStateError otherwise).
  * Format (crate hrtf): "HRIR", then u32 LE sample rate, HRIR length, vertex count, index count; the triangle
  * indices (u32); per vertex x, y, z (f32) and the left and right HRIR (f32 each).  The bytes are copied.  HRIRs
- * for other context sample rates are derived on first use and cached per rate (panner.rs:39-60). */
+ * for other context sample rates are derived on first use and cached per rate (panner.rs:39-60).
+ * PARITY NOTE: the crate resamples the sphere with one chunk of rubato's SincFixedIn per impulse response; neither crate
+ * is available to this repository, so at every context rate other than the sphere's own (44.1 kHz for IRC_1003_C; 48 kHz
+ * is NOT it) the HRIRs — and through their length the panner's tail time — follow this library's written definition of that
+ * pass, shared with the oracle and not pinned against the crates.  Header fields are bounds-checked
+ * (HRIR length <= 1280 taps after resampling, non-zero counts). */
 waa_status waa_hrtf_load_sphere(const void* data, uint64_t size);
 /* HrirSphere::len() at a context sample rate (= PannerRenderer's HRTF tail in frames); 0 without a database */
 uint32_t waa_hrtf_hrir_length(float sample_rate);

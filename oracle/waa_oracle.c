@@ -37,7 +37,13 @@
  *     HRIRs of the triangle the direction pierces, linear convolution of the block with the
  *     previous input samples as history, distance gain) with an exact f64 direct
  *     convolution; the reference only asserts "differs from the input, non-zero tail"
- *     (panner.rs:1226-1269) => PARITY UNPINNED, definition in DESIGN.md section 3.6.
+ *     (panner.rs:1226-1269) => PARITY UNPINNED, definition in DESIGN.md section 3.6.  That covers
+ *     the resampling of the sphere to the context's rate as well (the crate runs one chunk of
+ *     rubato's SincFixedIn over every impulse response; here: the band-limited signal evaluated
+ *     directly with the same window and cutoff): only at the sphere's own rate (44.1 kHz for
+ *     the IRC_1003_C set) are the HRIRs the file's; at every other context rate - 48 kHz included -
+ *     they are this definition's, shared by the oracle and the device path, and unpinned against
+ *     the crates (include/waa_hip.h says so at waa_hrtf_load_sphere).
  *
  * Exports the same entry points as include/waa_hip.h with the prefix orc_.
  */
