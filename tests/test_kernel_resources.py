@@ -47,3 +47,16 @@ def test_convolver_product_kernel_keeps_three_waves_per_simd(tmp_path):
     res = kernel_resources("waa_conv.hip", tmp_path)
     k = [v for n, v in res.items() if "conv_mac_win_kernelILi16ELi22ELb1" in n]
     assert len(k) == 1 and k[0]["spill"] == 0 and k[0]["vgpr"] <= 168, k  # (176+ registers = two waves per SIMD)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_lane_per_stream_biquad_passes_keep_four_waves_per_simd(tmp_path):
+    """waa_biquad_lanes.hip: both passes of the fast instantiation fit 128 registers (four wavefronts per SIMD; the exact-order
+    pass without a spill — the zero-state pass spills outside its chunk loop only)"""
+    res = kernel_resources("waa_biquad_lanes.hip", tmp_path)
+    fast = {n: v for n, v in res.items() if "biquad_lanes_kernelILi" in n and "ELb1E" in n}
+    assert len(fast) == 2, sorted(res)
+    for name, r in fast.items():
+        assert r["vgpr"] <= 128, (name, r)
+        if "ILi1E" in name:
+            assert r["spill"] == 0 and r["scratch"] == 0, (name, r)

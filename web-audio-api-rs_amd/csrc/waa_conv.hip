@@ -760,18 +760,15 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
   c2v xq[KT];
   const int kend = d.kb1;
 #pragma unroll
-  // (a block past the end: the load stays unconditional, but it reads this thread's IR value again — resident in L2 — and
-  // not the last spectrum: with the streaming policy those 21 redundant reads per 59 blocks were real trips to memory,
-  // 9.5 GB fetched for the 7.9 GB of X, profiles/r03r_t1_fetch.txt)
-  for (int i = 0; i < KT; i++) xq[i] = ld_pol(d.kb0 + i < kend ? Xc + (uint64_t)(d.kb0 + i) * n : Hc);
+  for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(d.kb0 + i < kend ? d.kb0 + i : kend - 1) * n);
   for (int k0 = d.kb0; k0 < kend; k0 += KT) {
     c2v xn[KT];  // X_{k0} .. X_{k0 + KT - 1}
 #pragma unroll
     for (int i = 0; i < KT; i++) xn[i] = k0 + i >= kend ? zero : xq[i];
     if (PREFETCH) {
-      const int kn = k0 + KT;
+      const int kn = k0 + KT;  // (past the end: the last block again — an L2 hit nobody uses)
 #pragma unroll
-      for (int i = 0; i < KT; i++) xq[i] = ld_pol(kn + i < kend ? Xc + (uint64_t)(kn + i) * n : Hc);
+      for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(kn + i < kend ? kn + i : kend - 1) * n);
     }
     c2v acc[KT];
 #pragma unroll
@@ -799,7 +796,7 @@ __global__ __launch_bounds__(256) void conv_mac_win_kernel(const ConvDesc d) {
     if (!PREFETCH) {
       const int kn = k0 + KT;
 #pragma unroll
-      for (int i = 0; i < KT; i++) xq[i] = ld_pol(kn + i < kend ? Xc + (uint64_t)(kn + i) * n : Hc);
+      for (int i = 0; i < KT; i++) xq[i] = ld_pol(Xc + (uint64_t)(kn + i < kend ? kn + i : kend - 1) * n);
     }
     // slide the window by KT blocks
 #pragma unroll
