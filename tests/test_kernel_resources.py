@@ -60,3 +60,16 @@ def test_lane_per_stream_biquad_passes_keep_four_waves_per_simd(tmp_path):
         assert r["vgpr"] <= 128, (name, r)
         if "ILi1E" in name:
             assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_element_wise_chain_kernels_keep_their_occupancy(tmp_path):
+    """waa_kernels.hip: the tile-parallel chain kernel is latency-bound — waves per SIMD are its lever.  The stereo
+    single-input form stays at 64 registers (eight waves), the stereo summing form at 80 (six); round 3's persistent-loop
+    bookkeeping cost the former 17 registers until it got its own instantiation (C4's pan stage 0.84 -> 1.07 ms)."""
+    res = kernel_resources("waa_kernels.hip", tmp_path)
+    single = [v for n, v in res.items() if "chain_kernelILi2ELi4ELb0ELb0ELb0E" in n]
+    summing = [v for n, v in res.items() if "chain_kernelILi2ELi4ELb0ELb1ELb0E" in n]
+    assert len(single) == 1 and single[0]["vgpr"] <= 64 and single[0]["spill"] == 0, single
+    # (the summing form is held at six waves by its occupancy attribute and pays four spilled registers for it, since round 2)
+    assert len(summing) == 1 and summing[0]["vgpr"] <= 80 and summing[0]["spill"] <= 4, summing

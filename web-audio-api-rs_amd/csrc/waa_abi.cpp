@@ -923,7 +923,7 @@ static int run_steps(waa_batch* b) {
           n_body++;
           body = k;
         }
-      if (n_body == 1 && b->steps[body].kind == 0 && getenv("WAA_PERSISTENT_LOOP")) {
+      if (n_body == 1 && b->steps[body].kind == 0 && b->steps[body].cmax <= 2 && getenv("WAA_PERSISTENT_LOOP")) {
         const Step& bs = b->steps[body];
         bool element_wise = true;
         for (int o = 0; o < bs.chain.n_ops; o++) element_wise &= bs.chain.ops[o].kind != OP_BIQUAD;

@@ -648,7 +648,9 @@ __device__ __forceinline__ void stereo_gains_dev(float x, float& gl, float& gr) 
 // FANIN = false: single-input chains skip the summing loop; the second inlined copy of the input fetch is what
 // doubles the kernel's VGPR count (57 -> 110 for C = 2), i.e. halves the waves per SIMD of kernels that are bound
 // by the latency of their dependent loads.
-template <int C, int K, bool SERIAL, bool FANIN = true>
+// PERSIST = true: the persistent form of a block-scheduled loop (ChainDesc::persist_block) — its own instantiation: the
+// block bookkeeping cost the plain single-input kernels 12-17 registers, i.e. waves per SIMD, when it lived in them.
+template <int C, int K, bool SERIAL, bool FANIN = true, bool PERSIST = false>
 __global__ __launch_bounds__(SERIAL ? 64 : 256) __attribute__((amdgpu_waves_per_eu((!SERIAL && FANIN && C == 2) ? 6 : 1)))
 void chain_kernel(const ChainDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -663,7 +665,7 @@ void chain_kernel(const ChainDesc d) {
     inst = blockIdx.x;
     tile_first = d.tile0 * (TILE / TILE_FR);
     tile_last = d.tile1 * (TILE / TILE_FR);
-  } else if (d.persist_block) {
+  } else if (PERSIST) {
     // one workgroup per instance, blocks in order: wavefront w renders sub-tiles w, w + 4, ... of every block (the block
     // and the tile range are multiples of four sub-tiles, so the four wavefronts meet at every barrier).  What a block
     // reads of the loop's history was written by THIS workgroup before an earlier barrier: same CU, same L1.
@@ -723,8 +725,8 @@ void chain_kernel(const ChainDesc d) {
   }
 
   uint32_t done_in_block = 0;
-  for (uint32_t tile = tile_first; tile < tile_last; tile += tile_step) {
-    if constexpr (!SERIAL) {
+  for (uint32_t tile = tile_first; tile < tile_last; tile += (PERSIST ? tile_step : 1u)) {
+    if constexpr (PERSIST) {
       if (per_block) {
         if (done_in_block == per_block) {
           __syncthreads();  // (waits for this wavefront's stores, then for the other three: the block is in L2 / L1)
@@ -1123,10 +1125,21 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
     // (8 frames per lane instead of 4 was measured: fewer waves fit per SIMD and every workload got slower)
     const uint64_t waves = (uint64_t)d.n_inst * (d.tile1 - d.tile0) * (TILE / 256);
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    if (d.persist_block) {
+    if (d.persist_block) {  // (mono / stereo only: the caller checks)
       grid = dim3(d.n_inst);
       dd.tile_major = 0;
       dd.xcd_remap = 0;
+      if (d.n_inputs <= 1) {
+        if (cmax <= 1)
+          hipLaunchKernelGGL((chain_kernel<1, 4, false, false, true>), grid, block, lds, s, dd);
+        else
+          hipLaunchKernelGGL((chain_kernel<2, 4, false, false, true>), grid, block, lds, s, dd);
+      } else if (cmax <= 1) {
+        hipLaunchKernelGGL((chain_kernel<1, 4, false, true, true>), grid, block, lds, s, dd);
+      } else {
+        hipLaunchKernelGGL((chain_kernel<2, 4, false, true, true>), grid, block, lds, s, dd);
+      }
+      return;
     }
     if (d.n_inputs <= 1) {
       if (cmax <= 1)
