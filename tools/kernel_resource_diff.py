@@ -5,7 +5,7 @@ ROOT='/root/repo'; T='/tmp/lanes_tmp/cmp'
 os.makedirs(T, exist_ok=True)
 FLAGS=["--offload-arch=gfx950","-O3","-std=c++17","-fPIC","-ffp-contract=off","-fgpu-flush-denormals-to-zero","--cuda-device-only","-S"]
 def res(path, inc):
-    out=path+'.s'
+    out=T+'/'+os.path.basename(path)+'.s'   # (never next to the sources: make has a built-in rule  %: %.s)
     r=subprocess.run(['/opt/rocm/bin/hipcc']+FLAGS+['-I'+inc,'-I'+ROOT+'/include',path,'-o',out],stderr=subprocess.PIPE)
     if r.returncode: return None
     text=open(out).read(); d={}

@@ -305,6 +305,11 @@ int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
   b->n_alloc++;
   b->alloc_bytes += bytes;
   if (e != hipSuccess) return fail(WAA_ERR_DEVICE, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  // WAA_POISON_ALLOC=1 (testing aid): fresh device memory is filled with 0xFF bytes (NaNs as f32 / f64, huge indices) —
+  // a kernel whose OUTPUT depends on memory nobody wrote then fails loudly and every time, instead of once in 20 000
+  // graphs when the pages happen to hold something else (hipMalloc does not clear; found that way: see DESIGN.md section 5)
+  static const bool poison = getenv("WAA_POISON_ALLOC") != nullptr;
+  if (poison) (void)hipMemset(p, 0xFF, bytes);
   (payload ? b->payload_allocs : b->allocs).push_back(p);
   *out = reinterpret_cast<T*>(p);
   return 0;
