@@ -23,9 +23,10 @@ LATE_STARTS = True
 FRAMES = 2048 * 5 + 200
 
 
-def build_random_graph(be, seed, frozen=False):
+def build_random_graph(be, seed, frozen=False, tap=None):
     """frozen: WaveShapers may oversample (2x / 4x) and PannerNodes may use the HRTF model (extra draws: other graphs
-    than the same seed without it)."""
+    than the same seed without it).  tap = k (debugging aid, tools/fuzz_tap_probe.py): the SAME graph, but only node k of
+    its node list feeds the destination — where along the graph does a difference start?"""
     rng = np.random.default_rng(seed if not frozen else seed + 100000)
     c = waa.OfflineAudioContext(2, FRAMES, SR, n_instances=N_INST, binding=be)
     outputs = []      # nodes that can feed others
@@ -197,10 +198,16 @@ def build_random_graph(be, seed, frozen=False):
         descr.append("param-mod")
     # everything without a consumer goes to the destination, plus one random extra tap
     fed = {e[0] for e in c._edges}
+    extra = int(rng.integers(0, len(outputs)))
+    if tap is not None:
+        if tap >= len(outputs):
+            return None, "+".join(descr)
+        outputs[tap].connect(c.destination())
+        return c, "+".join(descr) + " | tap %d = %s" % (tap, type(outputs[tap]).__name__)
     for n in outputs:
         if n.id not in fed:
             n.connect(c.destination())
-    outputs[int(rng.integers(0, len(outputs)))].connect(c.destination())
+    outputs[extra].connect(c.destination())
     return c, "+".join(descr)
 
 

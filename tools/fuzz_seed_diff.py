@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import web_audio_api_rs_amd as waa
 from test_fuzz_graphs import build_random_graph
+waa.set_hrtf_database(os.path.join(ROOT, "tests", "golden", "IRC_1003_C.bin"))
 hip = waa.default_binding(); orc = waa.bind(ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_")
 FROZEN = "--frozen" in sys.argv   # the generator with oversampled WaveShapers / HRTF panners
 for seed in map(int, [a for a in sys.argv[1:] if not a.startswith("--")]):

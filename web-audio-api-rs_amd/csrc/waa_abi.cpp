@@ -218,6 +218,7 @@ static int upload_buffer(waa_batch* b, const float* const* channels, uint32_t n_
         std::memcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float));
       else
         HIP_TRY(hipMemcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipStreamSynchronize(nullptr));  // (null-stream copy vs the batch's own stream: see dev_upload)
     }
   out->base = d;
   out->ch_stride = stride;

@@ -662,24 +662,36 @@ __global__ void conv_code_kernel(const ConvCodeDesc d) {
   if (inst >= d.n_inst) return;
   const uint8_t* in = d.in_code + (uint64_t)inst * d.code_stride;
   uint8_t* out = d.out_code + (uint64_t)inst * d.code_stride;
+  uint8_t* clean = d.clean + (uint64_t)inst * d.code_stride;
   uint64_t tail = 0;
+  bool ever_active = false;  // (an input that has never been active: the convolver's output is exact zeros, see ConvCodeDesc)
   for (uint32_t q = 0; q < d.n_quanta; q++) {
     const uint32_t c = in[q];
+    clean[q] = 0;
     if (c & CODE_SILENT) {
       if (tail >= d.impulse_length) {
         out[q] = (uint8_t)(1u | CODE_SILENT);
         continue;
       }
       tail += RQ;
+      clean[q] = ever_active ? 0 : 1;
     } else {
       tail = 0;
+      ever_active = true;
     }
     const int ic = (int)(c & 7u);
     out[q] = (uint8_t)((ic == 1 && d.ir_nch == 1) ? 1u : 2u);
   }
 }
+__global__ __launch_bounds__(128) void conv_zero_kernel(const ConvCodeDesc d) {
+  const uint32_t q = blockIdx.x, inst = blockIdx.y;
+  if (!d.clean[(uint64_t)inst * d.code_stride + q]) return;
+  for (int c = 0; c < d.cout; c++)
+    d.out.base[(uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)q * RQ + threadIdx.x] = 0.f;
+}
 void launch_conv_codes(const ConvCodeDesc& d, void* stream) {
   hipLaunchKernelGGL(conv_code_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
+  hipLaunchKernelGGL(conv_zero_kernel, dim3(d.n_quanta, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
 }
 
 }  // namespace waa

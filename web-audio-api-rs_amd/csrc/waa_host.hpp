@@ -309,7 +309,10 @@ int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
   // a kernel whose OUTPUT depends on memory nobody wrote then fails loudly and every time, instead of once in 20 000
   // graphs when the pages happen to hold something else (hipMalloc does not clear; found that way: see DESIGN.md section 5)
   static const bool poison = getenv("WAA_POISON_ALLOC") != nullptr;
-  if (poison) (void)hipMemset(p, 0xFF, bytes);
+  if (poison) {  // (the fill must be over before anything else touches the buffer: it runs on the null stream, the batch on its own)
+    (void)hipMemset(p, 0xFF, bytes);
+    (void)hipDeviceSynchronize();
+  }
   (payload ? b->payload_allocs : b->allocs).push_back(p);
   *out = reinterpret_cast<T*>(p);
   return 0;
@@ -324,6 +327,12 @@ int dev_upload(waa_batch* b, T** out, const std::vector<T>& host) {
     } else {
       const auto t0 = std::chrono::steady_clock::now();
       HIP_TRY(hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+      // A synchronous hipMemcpy runs on the NULL stream; the batch's kernels — also the plan-time ones, e.g. the impulse-
+      // response spectra right after the IR's upload — run on a non-blocking stream of their own, which the null stream
+      // does not order.  hipMemcpy returns when the host buffer may be reused, not necessarily when the last bytes have
+      // landed in device memory: wait for the null stream, so that a table is THERE when dev_upload returns (a few us per
+      // table at plan time).  Suspected cause of two load-dependent mismatches in 40 000 random graphs.
+      HIP_TRY(hipStreamSynchronize(nullptr));
       b->t_upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
   }

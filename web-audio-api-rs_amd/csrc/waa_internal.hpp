@@ -439,7 +439,14 @@ struct ConvCodeDesc {
   uint64_t impulse_length;  // frames of the AudioBuffer (untrimmed), convolver.rs:357-366
   int32_t ir_nch;
   uint32_t n_inst, n_quanta;
-  int32_t pad;
+  int32_t cout;             // channels of `out`
+  // The FFT path packs two instances into one complex transform: an instance whose input has been silent since the start
+  // gets ~1e-9 of its partner's signal through the roundoff of the complex arithmetic — where the reference's convolver (one
+  // per context) puts out exact zeros.  Quanta the reference still processes there (tail counter < impulse length: coded
+  // active) must BE zeros, or every filter behind them starts a "tail" on that noise and the silence flags drift apart
+  // (fuzz seed 232847 of the frozen-state generator).  `clean` marks them, conv_zero_kernel clears them in `out`.
+  uint8_t* clean;           // [n_inst][code_stride]
+  SignalRef out;
 };
 void launch_conv_codes(const ConvCodeDesc& d, void* stream);
 

@@ -2023,6 +2023,11 @@ int build_plan(waa_batch* b) {
         cd.ir_nch = n.ir_nch;
         cd.n_inst = b->n_inst;
         cd.n_quanta = b->n_quanta;
+        // (a mono impulse response on a stereo input keeps channel 1 in compacted time: only channel 0 is cleared in place)
+        cd.cout = (n.ir_nch == 1 && n.in_nch == 2) ? 1 : n.out_nch;
+        cd.out = n.sig;
+        if ((e = dev_alloc(b, &cd.clean, (size_t)b->n_inst * cs))) return e;
+        cst.loop_writes.push_back(n.sig.base);
         cst.profile_slot = slot_for(b, "conv_code_kernel");
         b->steps.push_back(cst);
       }
