@@ -650,8 +650,11 @@ __device__ __forceinline__ void stereo_gains_dev(float x, float& gl, float& gr) 
 // by the latency of their dependent loads.
 // PERSIST = true: the persistent form of a block-scheduled loop (ChainDesc::persist_block) — its own instantiation: the
 // block bookkeeping cost the plain single-input kernels 12-17 registers, i.e. waves per SIMD, when it lived in them.
-template <int C, int K, bool SERIAL, bool FANIN = true, bool PERSIST = false>
-__global__ __launch_bounds__(SERIAL ? 64 : 256) __attribute__((amdgpu_waves_per_eu((!SERIAL && FANIN && C == 2) ? 6 : 1)))
+// NOSPILL = true (stereo summing form only): five wavefronts per SIMD and 96 registers instead of six and 80 — the six-wave
+// form pays for its last wave with four registers spilled to scratch memory.
+template <int C, int K, bool SERIAL, bool FANIN = true, bool PERSIST = false, bool NOSPILL = false>
+__global__ __launch_bounds__(SERIAL ? 64 : 256)
+    __attribute__((amdgpu_waves_per_eu((!SERIAL && FANIN && C == 2) ? (NOSPILL ? 5 : 6) : 1)))
 void chain_kernel(const ChainDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NV4 = K / 4;
@@ -1152,9 +1155,21 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
         hipLaunchKernelGGL((chain_kernel<6, 4, false, false>), grid, block, lds, s, dd);
     } else if (cmax <= 1)
       hipLaunchKernelGGL((chain_kernel<1, 4, false>), grid, block, lds, s, dd);
-    else if (cmax <= 2)
-      hipLaunchKernelGGL((chain_kernel<2, 4, false>), grid, block, lds, s, dd);
-    else if (cmax <= 4)
+    else if (cmax <= 2) {
+      // The six-wave form keeps four registers in scratch memory, on the per-frame panning path.  Twice in 120 000 random
+      // graphs rendered by eight processes on one device, 16 samples of the right channel behind an a-rate-automated
+      // StereoPanner — lanes 16..31, element 3: ONE 64-byte piece of one spilled register's scratch row — came out wrong in
+      // a first render and right in the next.  Unproven, but cheap to rule out: chains that pan with
+      // per-frame values take the five-wave instantiation, which has no scratch at all (plain sums keep six waves: the
+      // five-wave form costs them 9-10 %, same-box A/B on echo / fb).
+      bool frame_pan = false;
+      for (int o = 0; o < d.n_ops; o++)
+        frame_pan |= (d.ops[o].kind == OP_STEREO_PAN || d.ops[o].kind == OP_PANNER) && d.ops[o].p0.mode == 2;
+      if (frame_pan || getenv("WAA_CHAIN_NOSPILL"))
+        hipLaunchKernelGGL((chain_kernel<2, 4, false, true, false, true>), grid, block, lds, s, dd);
+      else
+        hipLaunchKernelGGL((chain_kernel<2, 4, false>), grid, block, lds, s, dd);
+    } else if (cmax <= 4)
       hipLaunchKernelGGL((chain_kernel<4, 4, false>), grid, block, lds, s, dd);
     else
       hipLaunchKernelGGL((chain_kernel<6, 4, false>), grid, block, lds, s, dd);
