@@ -198,3 +198,28 @@ def test_loop_members_outside_the_static_loop_kernel_use_the_dynamic_path(hip, o
         pan.connect(c.destination())
         return c
     _render(build, hip, orc)
+
+
+@pytest.mark.parametrize("wide,interp", [(4, "speakers"), (6, "speakers"), (4, "discrete")])
+def test_layouts_above_stereo_change_their_count_mid_render(hip, orc, wide, interp):
+    """round 3 (dyn_kernel<6>): a mono source from t = 0, a quad / 5.1 source that joins later and ends early, a stereo one on top —
+    through a Gain with an explicit wide channel count, a Biquad, an IIR filter and a WaveShaper (per-channel state for every
+    channel that appears, quantum.rs' up- and down-mix tables in both directions), down to the stereo destination"""
+    def build(be):
+        c = _ctx(be)
+        mono = _buf(c, 1, FRAMES, seed=21)
+        big = _buf(c, wide, RQ * 25, start=RQ * 7.25 / SR, seed=22, per_instance_start=True)
+        stereo = _buf(c, 2, RQ * 40, start=RQ * 20.0 / SR, seed=23)
+        bus = c.create_gain(gain=0.7, channel_count=wide, channel_count_mode="max", channel_interpretation=interp)
+        from scipy import signal
+        b, a = signal.butter(2, 0.3)
+        f1 = c.create_biquad_filter(type_="peaking", frequency=1500.0, q=2.0, gain=6.0)
+        f2 = c.create_iir_filter(b, a)
+        sh = c.create_wave_shaper(curve=np.tanh(np.linspace(-2.0, 2.0, 65)).astype(np.float32))
+        for s in (mono, big, stereo):
+            s.connect(bus)
+        bus.connect(f1).connect(f2).connect(sh).connect(c.destination())
+        f1.connect(c.destination())
+        return c
+    g, o = _render(build, hip, orc)
+    assert np.abs(o).max() > 0.1

@@ -168,20 +168,29 @@ def test_wide_filters_plan_on_the_streaming_kernel_and_the_remaining_limit_is_lo
     src.start()
     assert "biquad_stream in=source:4ch gains=0 out=final" in ctx.plan_describe()  # (refused with status 4 until round 3)
     ctx.close()
-    # what is still out of scope: a channel-count CHANGE above stereo (the exact per-quantum path renders mono / stereo)
-    ctx = waa.OfflineAudioContext(4, RQ * 8, sr, binding=hip, device=waa.PLAN_ONLY)
-    mono, quad = ctx.create_buffer_source(), ctx.create_buffer_source()
-    mono.set_buffer(waa.AudioBuffer(np.ones((1, RQ * 8), np.float32), sr))
-    quad.set_buffer(waa.AudioBuffer(np.ones((4, RQ * 4), np.float32), sr))
-    bq = ctx.create_biquad_filter()
-    mono.connect(bq)
-    quad.connect(bq)
-    bq.connect(ctx.destination())
-    mono.start()
-    quad.start_at(RQ * 2 / sr)
+    # a channel-count CHANGE above stereo: rendered by the six-channel instantiation of the exact per-quantum path (round 3) ...
+    def changing(with_delay):
+        ctx = waa.OfflineAudioContext(4, RQ * 8, sr, binding=hip, device=waa.PLAN_ONLY)
+        mono, quad = ctx.create_buffer_source(), ctx.create_buffer_source()
+        mono.set_buffer(waa.AudioBuffer(np.ones((1, RQ * 8), np.float32), sr))
+        quad.set_buffer(waa.AudioBuffer(np.ones((4, RQ * 4), np.float32), sr))
+        bq = ctx.create_biquad_filter()
+        mono.connect(bq)
+        quad.connect(bq)
+        tail = bq.connect(ctx.create_delay(0.1, delay_time=0.01)) if with_delay else bq
+        tail.connect(ctx.destination())
+        mono.start()
+        quad.start_at(RQ * 2 / sr)
+        return ctx
+    ctx = changing(False)
+    assert "dynamic-count group" in ctx.plan_describe()
+    ctx.close()
+    # ... except through a DelayNode (its line is re-mixed when the count changes: mono / stereo only)
+    ctx = changing(True)
     with pytest.raises(waa.WaaError) as e:
         ctx.plan_describe()
     assert e.value.status == 4 and "channel count changes mid-render" in str(e.value)
+    ctx.close()
 
 
 # --------------------------------------------------------------------------- dynamic channel-count notes

@@ -214,11 +214,12 @@ static int upload_buffer(waa_batch* b, const float* const* channels, uint32_t n_
   if (e) return e;
   for (uint32_t c = 0; c < n_ch; c++)
     if (frames) {
-      if (b->dry)
+      if (b->dry) {
         std::memcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float));
-      else
+      } else {
         HIP_TRY(hipMemcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipStreamSynchronize(nullptr));  // (null-stream copy vs the batch's own stream: see dev_upload)
+      }
     }
   out->base = d;
   out->ch_stride = stride;

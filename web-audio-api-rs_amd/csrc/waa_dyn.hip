@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "waa_internal.hpp"
+#include "waa_mix.hpp"
 
 namespace waa {
 
@@ -42,20 +43,13 @@ __device__ __forceinline__ float shape(const float* curve, int nn, float input) 
   const int ki = (int)k;
   return (1.f - f) * load_global(curve + ki) + f * load_global(curve + ki + 1);
 }
-// quantum.rs:285-505 mix_inner for mono / stereo; `sil` = every channel is the allocator's zero block.  A computed
-// down-mix goes through make_mut, so its result is no longer silent by pointer identity (quantum.rs:96-104).
-__device__ __forceinline__ void mix12(float (&u)[2][2], int from, int to, int interp, bool& sil) {
+// quantum.rs:285-505 mix_inner; `sil` = every channel is the allocator's zero block.  A computed down-mix goes through
+// make_mut, so its result is no longer silent by pointer identity (quantum.rs:96-104); up-mixes copy or pad.
+template <int CM>
+__device__ __forceinline__ void mixn(float (&u)[CM][2], int from, int to, int interp, bool& sil) {
   if (from == to) return;
-  if (from == 1 && to == 2) {
-#pragma unroll
-    for (int e = 0; e < 2; e++) u[1][e] = interp == 1 ? 0.f : u[0][e];
-  } else if (from == 2 && to == 1) {
-    if (interp != 1) {
-#pragma unroll
-      for (int e = 0; e < 2; e++) u[0][e] = 0.5f * (u[0][e] + u[1][e]);
-      sil = false;
-    }
-  }
+  mix_regs<CM, 2>(u, from, to, interp);
+  if (mix_is_computed(from, to, interp)) sil = false;
 }
 struct M2d {
   double a, b, c, d;
@@ -80,12 +74,14 @@ __device__ __forceinline__ void stereo_gains(float x, float& gl, float& gr) {  /
 // with four to five of them per filter item and quantum the wave waited for its own output stores a dozen times per quantum.
 __device__ __forceinline__ void lds_sync() { __builtin_amdgcn_wave_barrier(); }
 
+// CM = 2: mono / stereo graphs (the round-2 kernel); CM = 6: layouts up to 5.1 (DelayNodes stay mono / stereo: the planner checks)
+template <int CM>
 __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* cur = lds;                                                          // [n_items][2][128] outputs of this quantum
-  float* scratch = cur + (size_t)d.n_items * 2 * RQ;                          // [2][128]
-  double* fst = reinterpret_cast<double*>(scratch + 2 * RQ);                  // [n_items][2][DYN_STATE] filter state
-  int* ist = reinterpret_cast<int*>(fst + (size_t)d.n_items * 2 * DYN_STATE);  // [n_items][4] integer state
+  float* scratch = cur + (size_t)d.n_items * CM * RQ;                         // [CM][128]
+  double* fst = reinterpret_cast<double*>(scratch + CM * RQ);                 // [n_items][CM][DYN_STATE] filter state
+  int* ist = reinterpret_cast<int*>(fst + (size_t)d.n_items * CM * DYN_STATE);  // [n_items][4] integer state
   int* codes = ist + (size_t)d.n_items * 4;                                   // [n_items] codes of this quantum
   __shared__ double coef_s[2 * (DYN_STATE + 1)];                             // IIR coefficient block of the item at hand
   // The item descriptors once into LDS: read through the pointer in the kernel argument they were ~80 dependent
@@ -102,7 +98,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
   }
   lds_sync();
   __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);  // f64 denormals flushed (FTZ/DAZ render scope, thread.rs:374-382)
-  for (int i = lane; i < d.n_items * 2 * DYN_STATE; i += 64) fst[i] = 0.;
+  for (int i = lane; i < d.n_items * CM * DYN_STATE; i += 64) fst[i] = 0.;
   for (int i = lane; i < d.n_items; i += 64) {
     const DynItem& li = items_s[i];
     // ist[0]: channels of the filter state (xy_len = 0, iir_filter.rs:303-306 "eagerly assume stereo" = 2) /
@@ -119,20 +115,24 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
     const uint64_t f0 = (uint64_t)q * RQ;
     for (int it = 0; it < d.n_items; it++) {
       const DynItem& li = items_s[it];
-      float v[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+      float v[CM][2];
+#pragma unroll
+      for (int c = 0; c < CM; c++) v[c][0] = v[c][1] = 0.f;
       int sn = 1;       // number_of_channels of the mixed input
       bool ss = true;   // is_silent
       if (li.kind != DI_DELAY_R) {
         // ---- graph.rs:524-535: the input starts silent (mono); every incoming edge is `add`ed in order
         for (int k = 0; k < li.n_in; k++) {
           const DynInput& in = li.in[k];
-          float u[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+          float u[CM][2];
+#pragma unroll
+          for (int c = 0; c < CM; c++) u[c][0] = u[c][1] = 0.f;
           uint32_t oc;
           if (in.item >= 0) {
             oc = (uint32_t)codes[in.item];
-            const float* src = cur + (size_t)in.item * 2 * RQ;
+            const float* src = cur + (size_t)in.item * CM * RQ;
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < CM; c++)
               if (c < (int)(oc & 7u)) {
                 u[c][0] = src[c * RQ + lane];
                 u[c][1] = src[c * RQ + 64 + lane];
@@ -149,27 +149,33 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
                 u[1][0] = load_global(src + in.sig.ch_stride + f1 + lane);
                 u[1][1] = load_global(src + in.sig.ch_stride + f1 + 64 + lane);
               }
+#pragma unroll
+              for (int c = 2; c < CM; c++)
+                if (c < on) {
+                  u[c][0] = load_global(src + (uint64_t)c * in.sig.ch_stride + f0 + lane);
+                  u[c][1] = load_global(src + (uint64_t)c * in.sig.ch_stride + f0 + 64 + lane);
+                }
             }
           }
           int on = (int)(oc & 7u);
           bool os = (oc & CODE_SILENT) != 0;
-          if (on > 2) on = 2;  // (the planner refuses wider layouts in dynamic plans)
+          if (on > CM) on = CM;  // (the planner picks the instantiation by the widest signal)
           // quantum.rs:532-569
           const int maxc = sn > on ? sn : on;
           int newc = li.mode == 0 ? maxc : (li.mode == 2 ? li.cc : (maxc < li.cc ? maxc : li.cc));
-          if (newc > 2) newc = 2;
+          if (newc > CM) newc = CM;
           if (newc < 1) newc = 1;
-          mix12(v, sn, newc, li.interp, ss);
-          mix12(u, on, newc, li.interp, os);
+          mixn<CM>(v, sn, newc, li.interp, ss);
+          mixn<CM>(u, on, newc, li.interp, os);
           if (ss) {  // quantum.rs:114-120: a silent channel takes the other operand (and its flag)
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < CM; c++)
 #pragma unroll
               for (int e = 0; e < 2; e++) v[c][e] = u[c][e];
             ss = os;
           } else if (!os) {
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < CM; c++)
 #pragma unroll
               for (int e = 0; e < 2; e++) v[c][e] = v[c][e] + u[c][e];
           }
@@ -177,10 +183,10 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
         }
         if (ss) {  // silent data is the zero block
 #pragma unroll
-          for (int c = 0; c < 2; c++) v[c][0] = v[c][1] = 0.f;
+          for (int c = 0; c < CM; c++) v[c][0] = v[c][1] = 0.f;
         }
 #pragma unroll
-        for (int c = 0; c < 2; c++)
+        for (int c = 0; c < CM; c++)
           if (c >= sn) v[c][0] = v[c][1] = 0.f;
       }
       int outn = sn;
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
 #pragma unroll
               for (int e = 0; e < 2; e++) {
                 const float g = load_global(op.p0.base + (uint64_t)inst * op.p0.stride + f0 + e * 64 + lane);
-                v[0][e] *= g;
-                v[1][e] *= g;
+#pragma unroll
+                for (int c = 0; c < CM; c++) v[c][e] *= g;
               }
             } else {
               const float g = pval(op.p0, inst, q, 0);
@@ -206,10 +212,10 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
                 outs = true;
                 outn = 1;
 #pragma unroll
-                for (int c = 0; c < 2; c++) v[c][0] = v[c][1] = 0.f;
+                for (int c = 0; c < CM; c++) v[c][0] = v[c][1] = 0.f;
               } else if (!(fabsf(1.f - g) <= 1e-6f)) {
 #pragma unroll
-                for (int c = 0; c < 2; c++)
+                for (int c = 0; c < CM; c++)
 #pragma unroll
                   for (int e = 0; e < 2; e++) v[c][e] *= g;
               }
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
             // biquad_filter.rs:764-899 / iir_filter.rs:323-405: per-channel state, tail until the state is denormal
             const bool iir = li.dk == DK_IIR;
             const int ns = iir ? (op.i0 < 0 ? -op.i0 : op.i0) : 4;  // state doubles that decide the tail
-            double* st = fst + (size_t)it * 2 * DYN_STATE;
+            double* st = fst + (size_t)it * CM * DYN_STATE;
             int nst = ist[it * 4 + 0];
             if (ss) {
               bool normal = false;
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
             } else {
               if (sn != nst) {
                 lds_sync();
-                for (int j = lane; j < 2 * DYN_STATE; j += 64)
+                for (int j = lane; j < CM * DYN_STATE; j += 64)
                   if (j / DYN_STATE >= nst && j / DYN_STATE < sn) st[j] = 0.;
                 if (lane == 0) ist[it * 4 + 0] = sn;
                 nst = sn;
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
             outs = false;
             lds_sync();
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < CM; c++) {
               // (a silent input reads its single zero channel for every state channel, :858-862)
               scratch[c * RQ + lane] = ss ? 0.f : v[c][0];
               scratch[c * RQ + 64 + lane] = ss ? 0.f : v[c][1];
@@ -268,81 +274,99 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
             // serially below (the scan assumes linearity).
             bool scan_done = false;
             if (!iir && op.i0 != 2 && !d.no_scan) {
-              const int ch = lane >> 5, l = lane & 31;
-              const bool act = ch < outn;
-              const double* s = st + ch * DYN_STATE;
-              float* row = scratch + ch * RQ;
+              const int l = lane & 31;
               const double* cf = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0 + (op.i0 == 1 ? (uint64_t)q * 5 : 0);
               const double b0 = load_global(cf), b1 = load_global(cf + 1), b2 = load_global(cf + 2), a1 = load_global(cf + 3),
                            a2 = load_global(cf + 4);
-              const f4v xv = *reinterpret_cast<const f4v*>(row + 4 * l);
-              const double x0 = (double)xv.x, x1 = (double)xv.y, x2 = (double)xv.z, x3 = (double)xv.w;
-              double xm1 = __shfl_up(x3, 1, 32), xm2 = __shfl_up(x2, 1, 32);
-              const double cx1 = s[0], cx2 = s[1], cy1 = s[2], cy2 = s[3];
-              if (l == 0) {
-                xm1 = cx1;
-                xm2 = cx2;
-              }
-              // zero-state response of the lane's four frames (incoming y state 0, true x history)
-              const double w0 = b0 * x0 + b1 * xm1 + b2 * xm2, w1 = b0 * x1 + b1 * x0 + b2 * xm1, w2 = b0 * x2 + b1 * x1 + b2 * x0,
-                           w3 = b0 * x3 + b1 * x2 + b2 * x1;
-              const double z0 = w0, z1 = w1 - a1 * z0, z2 = w2 - a1 * z1 - a2 * z0, z3 = w3 - a1 * z2 - a2 * z1;
-              double r1 = z3, r2 = z2;
-              M2d P = {-a1, -a2, 1., 0.};
-              P = mm2(P, P);
-              P = mm2(P, P);  // A = M^4
-              if (l == 0) {
-                r1 = __builtin_fma(P.a, cy1, __builtin_fma(P.b, cy2, r1));
-                r2 = __builtin_fma(P.c, cy1, __builtin_fma(P.d, cy2, r2));
-              }
-#pragma unroll
-              for (int dd = 1; dd < 32; dd <<= 1) {
-                const double q1 = __shfl_up(r1, dd, 32), q2 = __shfl_up(r2, dd, 32);
-                if (l >= dd) {
-                  r1 = __builtin_fma(P.a, q1, __builtin_fma(P.b, q2, r1));
-                  r2 = __builtin_fma(P.c, q1, __builtin_fma(P.d, q2, r2));
-                }
-                P = mm2(P, P);
-              }
-              double y1 = __shfl_up(r1, 1, 32), y2 = __shfl_up(r2, 1, 32);
-              if (l == 0) {
-                y1 = cy1;
-                y2 = cy2;
-              }
-              // The scan is linear algebra; the reference flushes y to zero FRAME BY FRAME once it leaves the normal
-              // range (:881-883).  While a tail decays through the last decades above 2.2e-308 the two differ in WHEN
-              // the state reaches zero — by a quantum, and the quantum in which the tail ends is this item's silence
-              // flag (fuzz seed 6278: a DelayNode behind it re-mixed its line one quantum early).  Any state or output
-              // of this quantum that is non-zero but below 1e-280: the quantum is rendered serially.
+              // two channels per pass (32 lanes each); wider layouts take CM / 2 passes, and nothing is written back before
+              // every pass has found its quantum free of inf / NaN / near-flush values (the serial form below redoes ALL channels)
+              float yo_all[CM / 2][4];
+              double fin[CM / 2][4];
+              bool bad_any = false;
               auto tiny = [](double v) { return v != 0. && __builtin_fabs(v) < 1e-280; };
-              bool bad = tiny(y1) || tiny(y2);
-              // the reference's evaluation order from the true incoming state (biquad_filter.rs:877-883)
-              double p1 = xm1, p2 = xm2;
-              const double xs[4] = {x0, x1, x2, x3};
-              float yo[4];
 #pragma unroll
-              for (int e = 0; e < 4; e++) {
-                const double x = xs[e];
-                double y = b0 * x + b1 * p1 + b2 * p2 - a1 * y1 - a2 * y2;
-                bad |= !(__builtin_fabs(y) <= 1.7976931348623157e308) || tiny(y);  // inf / NaN, or close to the flush
-                if (!__builtin_isnormal(y)) y = 0.;
-                p2 = p1;
-                p1 = x;
-                y2 = y1;
-                y1 = y;
-                yo[e] = (float)y;
+              for (int pi = 0; pi < CM / 2; pi++) {
+                if (pi * 2 >= outn) continue;  // (uniform)
+                const int ch = pi * 2 + (lane >> 5);
+                const bool act = ch < outn;
+                const double* s = st + ch * DYN_STATE;
+                const float* row = scratch + ch * RQ;
+                const f4v xv = *reinterpret_cast<const f4v*>(row + 4 * l);
+                const double x0 = (double)xv.x, x1 = (double)xv.y, x2 = (double)xv.z, x3 = (double)xv.w;
+                double xm1 = __shfl_up(x3, 1, 32), xm2 = __shfl_up(x2, 1, 32);
+                const double cx1 = s[0], cx2 = s[1], cy1 = s[2], cy2 = s[3];
+                if (l == 0) {
+                  xm1 = cx1;
+                  xm2 = cx2;
+                }
+                // zero-state response of the lane's four frames (incoming y state 0, true x history)
+                const double w0 = b0 * x0 + b1 * xm1 + b2 * xm2, w1 = b0 * x1 + b1 * x0 + b2 * xm1, w2 = b0 * x2 + b1 * x1 + b2 * x0,
+                             w3 = b0 * x3 + b1 * x2 + b2 * x1;
+                const double z0 = w0, z1 = w1 - a1 * z0, z2 = w2 - a1 * z1 - a2 * z0, z3 = w3 - a1 * z2 - a2 * z1;
+                double r1 = z3, r2 = z2;
+                M2d P = {-a1, -a2, 1., 0.};
+                P = mm2(P, P);
+                P = mm2(P, P);  // A = M^4
+                if (l == 0) {
+                  r1 = __builtin_fma(P.a, cy1, __builtin_fma(P.b, cy2, r1));
+                  r2 = __builtin_fma(P.c, cy1, __builtin_fma(P.d, cy2, r2));
+                }
+#pragma unroll
+                for (int dd = 1; dd < 32; dd <<= 1) {
+                  const double q1 = __shfl_up(r1, dd, 32), q2 = __shfl_up(r2, dd, 32);
+                  if (l >= dd) {
+                    r1 = __builtin_fma(P.a, q1, __builtin_fma(P.b, q2, r1));
+                    r2 = __builtin_fma(P.c, q1, __builtin_fma(P.d, q2, r2));
+                  }
+                  P = mm2(P, P);
+                }
+                double y1 = __shfl_up(r1, 1, 32), y2 = __shfl_up(r2, 1, 32);
+                if (l == 0) {
+                  y1 = cy1;
+                  y2 = cy2;
+                }
+                // The scan is linear algebra; the reference flushes y to zero FRAME BY FRAME once it leaves the normal
+                // range (:881-883).  While a tail decays through the last decades above 2.2e-308 the two differ in WHEN
+                // the state reaches zero — by a quantum, and the quantum in which the tail ends is this item's silence
+                // flag (fuzz seed 6278: a DelayNode behind it re-mixed its line one quantum early).  Any state or output
+                // of this quantum that is non-zero but below 1e-280: the quantum is rendered serially.
+                bool bad = tiny(y1) || tiny(y2);
+                // the reference's evaluation order from the true incoming state (biquad_filter.rs:877-883)
+                double p1 = xm1, p2 = xm2;
+                const double xs[4] = {x0, x1, x2, x3};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  const double x = xs[e];
+                  double y = b0 * x + b1 * p1 + b2 * p2 - a1 * y1 - a2 * y2;
+                  bad |= !(__builtin_fabs(y) <= 1.7976931348623157e308) || tiny(y);  // inf / NaN, or close to the flush
+                  if (!__builtin_isnormal(y)) y = 0.;
+                  p2 = p1;
+                  p1 = x;
+                  y2 = y1;
+                  y1 = y;
+                  yo_all[pi][e] = (float)y;
+                }
+                fin[pi][0] = p1;
+                fin[pi][1] = p2;
+                fin[pi][2] = y1;
+                fin[pi][3] = y2;
+                bad_any |= act && bad;
               }
-              bad = act && bad;
-              if (!__any(bad)) {
+              if (!__any(bad_any)) {
                 scan_done = true;
-                if (act) {
-                  *reinterpret_cast<f4v*>(row + 4 * l) = f4v{yo[0], yo[1], yo[2], yo[3]};
-                  if (l == 31) {
-                    double* sw = st + ch * DYN_STATE;
-                    sw[0] = p1;
-                    sw[1] = p2;
-                    sw[2] = y1;
-                    sw[3] = y2;
+#pragma unroll
+                for (int pi = 0; pi < CM / 2; pi++) {
+                  if (pi * 2 >= outn) continue;
+                  const int ch = pi * 2 + (lane >> 5);
+                  if (ch < outn) {
+                    *reinterpret_cast<f4v*>(scratch + ch * RQ + 4 * l) = f4v{yo_all[pi][0], yo_all[pi][1], yo_all[pi][2], yo_all[pi][3]};
+                    if (l == 31) {
+                      double* sw = st + ch * DYN_STATE;
+                      sw[0] = fin[pi][0];
+                      sw[1] = fin[pi][1];
+                      sw[2] = fin[pi][2];
+                      sw[3] = fin[pi][3];
+                    }
                   }
                 }
               }
@@ -419,7 +443,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
             }
             lds_sync();
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < CM; c++) {
               v[c][0] = c < outn ? scratch[c * RQ + lane] : 0.f;
               v[c][1] = c < outn ? scratch[c * RQ + 64 + lane] : 0.f;
             }
@@ -433,7 +457,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
             if (op.ptr0) {
               const float* curve = reinterpret_cast<const float*>(op.ptr0);
 #pragma unroll
-              for (int c = 0; c < 2; c++)
+              for (int c = 0; c < CM; c++)
                 if (c < sn) {
 #pragma unroll
                   for (int e = 0; e < 2; e++) v[c][e] = shape(curve, op.i0, v[c][e]);
@@ -603,12 +627,12 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
       }
       if (outs) {
 #pragma unroll
-        for (int c = 0; c < 2; c++) v[c][0] = v[c][1] = 0.f;
+        for (int c = 0; c < CM; c++) v[c][0] = v[c][1] = 0.f;
       }
       // ---- hand over (LDS) and publish (HBM)
-      float* dst = cur + (size_t)it * 2 * RQ;
+      float* dst = cur + (size_t)it * CM * RQ;
 #pragma unroll
-      for (int c = 0; c < 2; c++) {
+      for (int c = 0; c < CM; c++) {
         dst[c * RQ + lane] = c < outn ? v[c][0] : 0.f;
         dst[c * RQ + 64 + lane] = c < outn ? v[c][1] : 0.f;
       }
@@ -626,7 +650,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
           }
         }
 #pragma unroll
-        for (int c = 0; c < 2; c++)
+        for (int c = 0; c < CM; c++)
           if (c < li.nch_pub) {
             const bool have = c < outn;
             const bool dup = !have && li.publish_upmix && !outs;
@@ -646,13 +670,25 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
 }
 
 void launch_dyn(const DynDesc& d, void* stream) {
-  const size_t lds = ((size_t)d.n_items * 2 * RQ + 2 * RQ) * sizeof(float) + (size_t)d.n_items * 2 * DYN_STATE * sizeof(double) +
+  const int cm = d.cmax > 2 ? 6 : 2;
+  const size_t lds = ((size_t)d.n_items * cm * RQ + cm * RQ) * sizeof(float) + (size_t)d.n_items * cm * DYN_STATE * sizeof(double) +
                      (size_t)(d.n_items * 5 + 2) * sizeof(int) + (size_t)d.n_items * sizeof(DynItem);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dyn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   DynDesc dd = d;
   dd.no_scan = getenv("WAA_DYN_NO_SCAN") ? 1u : 0u;
-  hipLaunchKernelGGL(dyn_kernel, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, dd);
+  if (cm == 2) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dyn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(dyn_kernel<2>, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, dd);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dyn_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(dyn_kernel<6>, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, dd);
+  }
+}
+size_t dyn_lds_bytes(int n_items, int cmax) {
+  const int cm = cmax > 2 ? 6 : 2;
+  return ((size_t)n_items * cm * RQ + cm * RQ) * sizeof(float) + (size_t)n_items * cm * DYN_STATE * sizeof(double) +
+         (size_t)(n_items * 5 + 2) * sizeof(int) + (size_t)n_items * sizeof(DynItem);
 }
 
 // ConvolverRenderer::process on codes (convolver.rs:343-392): the tail counter cuts the output off once a silent input

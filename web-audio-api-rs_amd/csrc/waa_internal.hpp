@@ -427,10 +427,13 @@ struct DynDesc {
   uint32_t n_inst;
   uint32_t n_quanta;
   uint32_t no_scan;         // set by the launcher (WAA_DYN_NO_SCAN): biquad items on two lanes, serially (cross-check)
+  int32_t cmax;             // widest signal of the group: <= 2 -> dyn_kernel<2>, else dyn_kernel<6> (layouts up to 5.1)
+  int32_t pad;
   double sample_rate;
   double quantum_duration;
 };
 void launch_dyn(const DynDesc& d, void* stream);
+size_t dyn_lds_bytes(int n_items, int cmax);  // dynamic LDS of the launch (<= 160 KB: the planner checks)
 // ConvolverNode tail / routing on codes (convolver.rs:343-392): input codes -> output codes
 struct ConvCodeDesc {
   const uint8_t* in_code;

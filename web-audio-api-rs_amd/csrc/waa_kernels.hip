@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "waa_internal.hpp"
+#include "waa_mix.hpp"
 
 namespace waa {
 
@@ -32,131 +33,7 @@ __device__ __forceinline__ float param_at(const ParamRef& p, uint32_t inst, uint
   return p.base[(uint64_t)inst * p.stride + frame];
 }
 
-// ---- channel mixing on register tiles (quantum.rs:285-505) ------------------------------
-template <int C, int K>
-__device__ __forceinline__ void mix_regs(float (&v)[C][K], int from, int to, int interp) {
-  constexpr int TILE_K = K;
-  if (from == to) return;
-  if (interp == 1 || from > 6 || to > 6) {  // discrete: pad with silence / truncate
-#pragma unroll
-    for (int c = 0; c < C; c++)
-      if (c >= from && c < to) {
-#pragma unroll
-        for (int i = 0; i < TILE_K; i++) v[c][i] = 0.f;
-      }
-    return;
-  }
-  if constexpr (C >= 2) {
-    if (from == 1 && to == 2) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) v[1][i] = v[0][i];
-      return;
-    }
-    if (from == 2 && to == 1) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) v[0][i] = 0.5f * (v[0][i] + v[1][i]);
-      return;
-    }
-  }
-  if constexpr (C >= 4) {
-    if (from == 1 && to == 4) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) {
-        v[1][i] = v[0][i];
-        v[2][i] = 0.f;
-        v[3][i] = 0.f;
-      }
-      return;
-    }
-    if (from == 2 && to == 4) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) {
-        v[2][i] = 0.f;
-        v[3][i] = 0.f;
-      }
-      return;
-    }
-    if (from == 4 && to == 1) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) v[0][i] = 0.25f * (v[0][i] + v[1][i] + v[2][i] + v[3][i]);
-      return;
-    }
-    if (from == 4 && to == 2) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) {
-        v[0][i] = 0.5f * (v[0][i] + v[2][i]);
-        v[1][i] = 0.5f * (v[1][i] + v[3][i]);
-      }
-      return;
-    }
-  }
-  if constexpr (C >= 6) {
-    const float sqrt05 = 0.70710678118654752440f;
-    if (from == 1 && to == 6) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) {
-        v[2][i] = v[0][i];
-        v[0][i] = v[1][i] = v[3][i] = v[4][i] = v[5][i] = 0.f;
-      }
-      return;
-    }
-    if (from == 2 && to == 6) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) v[2][i] = v[3][i] = v[4][i] = v[5][i] = 0.f;
-      return;
-    }
-    if (from == 4 && to == 5) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) {
-        v[4][i] = v[3][i];
-        v[3][i] = v[2][i];
-        v[2][i] = 0.f;
-      }
-      return;
-    }
-    if (from == 4 && to == 6) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) {
-        v[4][i] = v[2][i];
-        v[5][i] = v[3][i];
-        v[2][i] = v[3][i] = 0.f;
-      }
-      return;
-    }
-    if (from == 6 && to == 1) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++)
-        v[0][i] = __builtin_fmaf(sqrt05, v[0][i] + v[1][i], __builtin_fmaf(0.5f, v[4][i] + v[5][i], v[2][i]));
-      return;
-    }
-    if (from == 6 && to == 2) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) {
-        v[0][i] += sqrt05 * (v[2][i] + v[4][i]);
-        v[1][i] += sqrt05 * (v[2][i] + v[5][i]);
-      }
-      return;
-    }
-    if (from == 6 && to == 4) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) {
-        float c = v[2][i];
-        v[0][i] += sqrt05 * c;
-        v[1][i] += sqrt05 * c;
-        v[2][i] = v[4][i];
-        v[3][i] = v[5][i];
-      }
-      return;
-    }
-  }
-  // all other speaker layouts: pad with silence / truncate
-#pragma unroll
-  for (int c = 0; c < C; c++)
-    if (c >= from && c < to) {
-#pragma unroll
-      for (int i = 0; i < TILE_K; i++) v[c][i] = 0.f;
-    }
-}
+// (channel mixing on register tiles: waa_mix.hpp, shared with waa_dyn.hip)
 
 // ---- input fetch (layout A: lane holds float4 j at frame tile*TILE + j*256 + lane*4) ------
 // K = frames per lane: a tile is 64*K frames = K/2 render quanta (K = 32: the serial 2048-frame tiles of chains

@@ -1730,10 +1730,15 @@ int build_plan(waa_batch* b) {
     const uint64_t cs = b->code_stride;
     for (uint32_t id = 0; id < N; id++) {
       const Node& n = b->nodes[id];
-      if (n.live && (n.in_nch > 2 || n.out_nch > 2))
+      // layouts up to 5.1 are rendered by dyn_kernel<6> (round 3) for Gain / Biquad / IIR / WaveShaper / the panners / the
+      // destination; a DelayNode re-mixes its whole line when the count changes (the kernel keeps that history for mono <->
+      // stereo only) and the analyser reads a static stereo signal: those stay mono / stereo
+      const uint32_t k = n.desc.kind;
+      const bool narrow_only = k == WAA_NODE_DELAY || k == WAA_NODE_ANALYSER || (k == WAA_NODE_CONVOLVER && n.has_ir) || is_frozen_node(n);
+      if (n.live && narrow_only && (n.in_nch > 2 || n.out_nch > 2))
         return fail(WAA_ERR_OUT_OF_SCOPE,
                     "node %u: the reference's channel count changes mid-render and a signal is wider than stereo (%d channels): "
-                    "exact dynamic counts are rendered for mono / stereo graphs only",
+                    "exact dynamic counts above stereo are not rendered for this node kind",
                     id, std::max(n.in_nch, n.out_nch));
     }
     auto is_src = [&](uint32_t k) { return k == WAA_NODE_BUFFER_SOURCE || k == WAA_NODE_CONSTANT_SOURCE || k == WAA_NODE_OSCILLATOR; };
@@ -1931,6 +1936,15 @@ int build_plan(waa_batch* b) {
       d.n_quanta = b->n_quanta;
       d.sample_rate = (double)b->sr;
       d.quantum_duration = (double)RQ * (1. / (double)b->sr);  // delay.rs:546-548
+      d.cmax = 1;
+      for (uint32_t v : pending) {
+        const Node& pn = b->nodes[v & ~VTX_READER];
+        d.cmax = std::max(d.cmax, std::max(pn.in_nch, pn.out_nch));
+        for (int e : pn.in_edges) d.cmax = std::max(d.cmax, b->nodes[b->edges[e].from].out_nch);
+      }
+      if (dyn_lds_bytes(d.n_items, d.cmax) > 160 * 1024)
+        return fail(WAA_ERR_OUT_OF_SCOPE, "dynamic-count group of %d nodes with %d-channel signals does not fit the kernel's local memory",
+                    d.n_items, d.cmax);
       st.profile_slot = slot_for(b, "dyn_kernel");
       b->steps.push_back(st);
       plan_note(b, "dynamic-count group: %d item(s) per quantum [%s]", d.n_items, desc.c_str());
