@@ -68,8 +68,11 @@ def test_element_wise_chain_kernels_keep_their_occupancy(tmp_path):
     single-input form stays at 64 registers (eight waves), the stereo summing form at 80 (six); round 3's persistent-loop
     bookkeeping cost the former 17 registers until it got its own instantiation (C4's pan stage 0.84 -> 1.07 ms)."""
     res = kernel_resources("waa_kernels.hip", tmp_path)
-    single = [v for n, v in res.items() if "chain_kernelILi2ELi4ELb0ELb0ELb0E" in n]
-    summing = [v for n, v in res.items() if "chain_kernelILi2ELi4ELb0ELb1ELb0E" in n]
+    single = [v for n, v in res.items() if "chain_kernelILi2ELi4ELb0ELb0ELb0ELb0E" in n]
+    summing = [v for n, v in res.items() if "chain_kernelILi2ELi4ELb0ELb1ELb0ELb0E" in n]
+    nospill = [v for n, v in res.items() if "chain_kernelILi2ELi4ELb0ELb1ELb0ELb1E" in n]
     assert len(single) == 1 and single[0]["vgpr"] <= 64 and single[0]["spill"] == 0, single
     # (the summing form is held at six waves by its occupancy attribute and pays four spilled registers for it, since round 2)
     assert len(summing) == 1 and summing[0]["vgpr"] <= 80 and summing[0]["spill"] <= 4, summing
+    # (the five-wave form that chains with per-frame panning take: no scratch memory at all)
+    assert len(nospill) == 1 and nospill[0]["vgpr"] <= 96 and nospill[0]["spill"] == 0 and nospill[0]["scratch"] == 0, nospill
