@@ -223,3 +223,24 @@ def test_layouts_above_stereo_change_their_count_mid_render(hip, orc, wide, inte
         return c
     g, o = _render(build, hip, orc)
     assert np.abs(o).max() > 0.1
+
+
+@pytest.mark.parametrize("delay_time,feedback", [(0.0007, False), (0.02, False), (0.02, True)])
+def test_delay_line_above_stereo_is_remixed_in_place(hip, orc, delay_time, feedback):
+    """delay.rs:469-489 with layouts above stereo: mono -> quad -> stereo -> mono inputs; every stored quantum of the ring goes
+    through `mix(new count, Speakers)` at each change (4 -> 2 is a computed down-mix, 2 -> 4 pads: the chain has no closed
+    form, the kernel re-mixes the line in place); also with the delay inside a feedback loop"""
+    def build(be):
+        c = _ctx(be)
+        mono = _buf(c, 1, FRAMES, seed=31)
+        quad = _buf(c, 4, RQ * 18, start=RQ * 6.5 / SR, seed=32, per_instance_start=True)
+        stereo = _buf(c, 2, RQ * 50, start=RQ * 15.0 / SR, seed=33)
+        d = c.create_delay(0.1, delay_time=delay_time)
+        for s in (mono, quad, stereo):
+            s.connect(d)
+        tail = d.connect(c.create_biquad_filter(type_="lowpass", frequency=3000.0))
+        if feedback:
+            tail.connect(c.create_gain(gain=0.4)).connect(d)
+        tail.connect(c.destination())
+        return c
+    _render(build, hip, orc)

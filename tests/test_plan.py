@@ -169,7 +169,7 @@ def test_wide_filters_plan_on_the_streaming_kernel_and_the_remaining_limit_is_lo
     assert "biquad_stream in=source:4ch gains=0 out=final" in ctx.plan_describe()  # (refused with status 4 until round 3)
     ctx.close()
     # a channel-count CHANGE above stereo: rendered by the six-channel instantiation of the exact per-quantum path (round 3) ...
-    def changing(with_delay):
+    def changing(with_analyser):
         ctx = waa.OfflineAudioContext(4, RQ * 8, sr, binding=hip, device=waa.PLAN_ONLY)
         mono, quad = ctx.create_buffer_source(), ctx.create_buffer_source()
         mono.set_buffer(waa.AudioBuffer(np.ones((1, RQ * 8), np.float32), sr))
@@ -177,7 +177,9 @@ def test_wide_filters_plan_on_the_streaming_kernel_and_the_remaining_limit_is_lo
         bq = ctx.create_biquad_filter()
         mono.connect(bq)
         quad.connect(bq)
-        tail = bq.connect(ctx.create_delay(0.1, delay_time=0.01)) if with_delay else bq
+        tail = bq.connect(ctx.create_delay(0.1, delay_time=0.01))
+        if with_analyser:
+            tail = tail.connect(ctx.create_analyser(fft_size=256))
         tail.connect(ctx.destination())
         mono.start()
         quad.start_at(RQ * 2 / sr)
@@ -185,7 +187,7 @@ def test_wide_filters_plan_on_the_streaming_kernel_and_the_remaining_limit_is_lo
     ctx = changing(False)
     assert "dynamic-count group" in ctx.plan_describe()
     ctx.close()
-    # ... except through a DelayNode (its line is re-mixed when the count changes: mono / stereo only)
+    # ... DelayNodes included (the ring is re-mixed in place); an AnalyserNode reads a static stereo signal: still refused
     ctx = changing(True)
     with pytest.raises(waa.WaaError) as e:
         ctx.plan_describe()

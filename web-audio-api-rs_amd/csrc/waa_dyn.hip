@@ -547,6 +547,38 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
         }
       } else if (li.kind == DI_DELAY_W) {
         // delay.rs:428-489: the ring is re-mixed to the count of the current input, then the input is stored
+        if constexpr (CM > 2) {
+          // layouts above stereo: the ring entries are REALLY re-mixed, like DelayWriter::check_ring_buffer_up_down_mix does
+          // it (every stored quantum through `mix(new count, Speakers)`) — a chain of changes such as 4 -> 2 -> 4 has no
+          // closed form per entry the way mono <-> stereo has (below).  Count changes are rare; the ring is <= 376 quanta.
+          const int old = ist[it * 4 + 0];
+          if (sn != old && q > 0) {
+            __syncthreads();  // (this wave's earlier stores to the line have reached L2)
+            const uint32_t cap = (uint32_t)li.num_quanta + 1u;
+            uint32_t* wc = li.aux32 + (uint64_t)inst * li.code_stride;
+            float* hbw = li.out.base + (uint64_t)inst * li.out.inst_stride;
+            for (uint32_t p = q > cap ? q - cap : 0u; p < q; p++) {
+              const uint32_t pc = coherent_u(wc + p);
+              const int np = (int)(pc & 7u);
+              if (np == sn) continue;
+              float w[CM][2];
+#pragma unroll
+              for (int c = 0; c < CM; c++) {
+                w[c][0] = c < np ? coherent_f(hbw + (uint64_t)c * li.out.ch_stride + (uint64_t)p * RQ + lane) : 0.f;
+                w[c][1] = c < np ? coherent_f(hbw + (uint64_t)c * li.out.ch_stride + (uint64_t)p * RQ + 64 + lane) : 0.f;
+              }
+              mix_regs<CM, 2>(w, np, sn, 0);
+#pragma unroll
+              for (int c = 0; c < CM; c++)
+                if (c < sn && c < li.nch_pub) {
+                  store_global(hbw + (uint64_t)c * li.out.ch_stride + (uint64_t)p * RQ + lane, w[c][0]);
+                  store_global(hbw + (uint64_t)c * li.out.ch_stride + (uint64_t)p * RQ + 64 + lane, w[c][1]);
+                }
+              if (lane == 0) store_global(wc + p, (uint32_t)sn | (pc & CODE_SILENT));
+            }
+            __syncthreads();
+          }
+        }
         if (lane == 0) {
           ist[it * 4 + 0] = sn;
           if (sn == 1) ist[it * 4 + 1] = (int)q;
@@ -580,6 +612,8 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
           const uint32_t pc = coherent_u(wcode + p);
           if (pc & CODE_SILENT) return 0.f;
           const int np = (int)(pc & 7u);
+          if constexpr (CM > 2)  // (the writer re-mixed the ring in place: every entry carries the ring's count)
+            return c < np ? coherent_f(hb + (uint64_t)c * hs.ch_stride + idx) : 0.f;
           if (np <= 1) return coherent_f(hb + idx);
           if (last_mono > p) return 0.5f * (coherent_f(hb + idx) + coherent_f(hb + hs.ch_stride + idx));
           return coherent_f(hb + (uint64_t)c * hs.ch_stride + idx);
@@ -607,7 +641,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
           if (!li.in_cycle && pf == RQ - 1) next = ((int64_t)q - li.num_quanta) * RQ;
           if (li.in_cycle && next >= (int64_t)f0) next -= ((int64_t)li.num_quanta + 1) * RQ;
 #pragma unroll
-          for (int c = 0; c < 2; c++)
+          for (int c = 0; c < CM; c++)
             if (c < nch) {
               const float ps = sample(c, prev), nsv = sample(c, next);
               const float val = __builtin_fmaf(1.f - k, ps, k * nsv);
@@ -622,7 +656,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
           outn = 1;
           outs = true;
 #pragma unroll
-          for (int c = 0; c < 2; c++) v[c][0] = v[c][1] = 0.f;
+          for (int c = 0; c < CM; c++) v[c][0] = v[c][1] = 0.f;
         }
       }
       if (outs) {

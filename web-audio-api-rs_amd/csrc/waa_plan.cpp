@@ -1730,11 +1730,11 @@ int build_plan(waa_batch* b) {
     const uint64_t cs = b->code_stride;
     for (uint32_t id = 0; id < N; id++) {
       const Node& n = b->nodes[id];
-      // layouts up to 5.1 are rendered by dyn_kernel<6> (round 3) for Gain / Biquad / IIR / WaveShaper / the panners / the
-      // destination; a DelayNode re-mixes its whole line when the count changes (the kernel keeps that history for mono <->
-      // stereo only) and the analyser reads a static stereo signal: those stay mono / stereo
+      // layouts up to 5.1 are rendered by dyn_kernel<6> (round 3) for Gain / Biquad / IIR / WaveShaper / the panners / DelayNodes
+      // (whose line is then re-mixed in place when the count changes) / the destination; the analyser reads a static
+      // stereo signal, convolver and frozen-node inputs are stereo by their channel config: those stay mono / stereo
       const uint32_t k = n.desc.kind;
-      const bool narrow_only = k == WAA_NODE_DELAY || k == WAA_NODE_ANALYSER || (k == WAA_NODE_CONVOLVER && n.has_ir) || is_frozen_node(n);
+      const bool narrow_only = k == WAA_NODE_ANALYSER || (k == WAA_NODE_CONVOLVER && n.has_ir) || is_frozen_node(n);
       if (n.live && narrow_only && (n.in_nch > 2 || n.out_nch > 2))
         return fail(WAA_ERR_OUT_OF_SCOPE,
                     "node %u: the reference's channel count changes mid-render and a signal is wider than stereo (%d channels): "
@@ -1822,6 +1822,7 @@ int build_plan(waa_batch* b) {
         if (is_delay(b, id)) {
           if (!reader) {
             li.kind = DI_DELAY_W;
+            li.num_quanta = (int32_t)std::ceil(n.desc.d[0] * (double)b->sr / (double)RQ);  // (ring capacity - 1, as for the reader)
             int e = temp_signal(b, n.in_nch, &li.out);  // the delay line in absolute time, native layout
             if (e) return e;
             li.nch_pub = n.in_nch;
