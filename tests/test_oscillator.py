@@ -342,3 +342,41 @@ def test_folded_post_ops_are_bit_identical(hip, orc, modulated, monkeypatch):
     assert np.array_equal(fused[:, 0], fused[:, 1]) and np.any(fused != 0)
     err = np.sqrt(np.mean((fused.astype(np.float64) - ref) ** 2, axis=2))
     assert err.max() <= 1e-6
+
+
+def _osc_behind_an_analyser(be, device=-1):
+    """Oscillator -> Analyser -> two Gains -> destination: the analyser aliases the oscillator's signal, both Gains read it"""
+    kw = {"device": device} if device != -1 else {}
+    c = waa.OfflineAudioContext(2, 128 * 40, 48000.0, n_instances=3, binding=be, **kw)
+    osc = c.create_oscillator(type_="sawtooth", frequency=330.0)
+    an = c.create_analyser(fft_size=256)
+    a, b = c.create_gain(gain=0.5), c.create_gain(gain=0.25)
+    for i in range(3):
+        a.gain.set_value(0.2 + 0.3 * i, instance=i)
+    osc.connect(an)
+    an.connect(a).connect(c.destination())
+    an.connect(b).connect(c.destination())
+    osc.start()
+    return c, an
+
+
+def test_plan_oscillator_keeps_its_signal_when_an_alias_has_other_readers(hip):
+    """the oscillator may render a Gain chain itself only if NOTHING else reads its signal — also not through a node that
+    aliases it (fuzz seed 502310 of the frozen-state generator, found with WAA_POISON_ALLOC)"""
+    c, _ = _osc_behind_an_analyser(hip, device=waa.PLAN_ONLY)
+    plan = c.plan_describe()
+    assert "chain itself" not in plan, plan
+    c.close()
+
+
+@pytest.mark.gpu
+def test_parity_oscillator_behind_an_analyser_with_two_readers(hip, orc):
+    outs, bins = [], []
+    for be in (hip, orc):
+        c, an = _osc_behind_an_analyser(be)
+        outs.append(c.start_rendering_sync().data)
+        bins.append(an.get_float_frequency_data(instance=1))
+        c.close()
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-5 and np.abs(outs[1]).max() > 0.1
+    finite = np.isfinite(bins[1])
+    assert np.abs(bins[0][finite] - bins[1][finite]).max() <= 0.05

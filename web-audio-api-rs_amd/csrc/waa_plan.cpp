@@ -1686,10 +1686,22 @@ int build_plan(waa_batch* b) {
         if (b->nodes[k].live && b->nodes[k].desc.kind == WAA_NODE_OSCILLATOR && b->nodes[k].sig.base == cd.in[0].sig.base &&
             b->nodes[k].osc_step >= 0)
           prod = (int)k;
+      // every live reader of the oscillator's signal — also through nodes that ALIAS it (an AnalyserNode / pass-through right
+      // behind it shares the buffer, and the analyser's FFT reads it): with the fold the oscillator no longer writes that
+      // buffer at all (fuzz seed 502310: Oscillator -> Analyser -> two Gains; one Gain's chain was folded, the other read
+      // memory nobody had written — found with WAA_POISON_ALLOC)
       int consumers = 0;
-      if (prod >= 0)
-        for (auto& e2 : b->edges)
-          if (e2.from == (uint32_t)prod && b->nodes[e2.to].live) consumers++;
+      if (prod >= 0) {
+        const float* osc_sig = b->nodes[(size_t)prod].sig.base;
+        for (uint32_t k = 0; k < N; k++) {
+          const Node& an = b->nodes[k];
+          if (!an.live || an.sig.base != osc_sig) continue;
+          if (k != (uint32_t)prod && (an.desc.kind == WAA_NODE_ANALYSER || an.desc.kind == WAA_NODE_DESTINATION))
+            consumers += 2;  // (the analyser's FFT / the caller read that buffer)
+          for (auto& e2 : b->edges)
+            if (e2.from == k && b->nodes[e2.to].live && b->nodes[e2.to].sig.base != osc_sig) consumers++;
+        }
+      }
       size_t n_gain = 0;
       bool ok = prod >= 0 && consumers == 1 && b->steps[(size_t)b->nodes[(size_t)prod].osc_step].group < 0;
       while (ok && n_gain < ops.size() && ops[n_gain].kind == OP_GAIN) {
