@@ -319,3 +319,24 @@ def test_dynamic_channel_count_is_rendered(hip, orc, monkeypatch):
     with pytest.raises(waa.WaaError) as ei:
         c.start_rendering_sync()
     assert ei.value.status == 4
+
+
+@pytest.mark.gpu
+def test_random_graphs_on_poisoned_device_memory(tmp_path):
+    """WAA_POISON_ALLOC=1 fills every fresh device allocation with 0xFF bytes (NaN as f32 / f64): a kernel whose output depends
+    on memory nobody wrote fails every time instead of once in 20 000 graphs.  300 seeds of each generator in a subprocess
+    (tools/fuzz_campaign.py): no NaN output, no mismatch that a second render does not repeat.  (Found in round 3: the
+    oscillator fold behind an aliasing AnalyserNode.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "poison.json")
+    env = dict(os.environ, WAA_POISON_ALLOC="1")
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "fuzz_campaign.py"), "--first", "700000", "--count", "300",
+                           "--jobs", "2", "--out", out], env=env, stdout=subprocess.DEVNULL)
+    rec = json.load(open(out))
+    for gen, t in rec["generators"].items():
+        assert not t["errors"], (gen, t["errors"][:2])
+        for m in t["mismatch"]:
+            assert np.isfinite(m["max"]) and m["second_render_equals_first"], (gen, m)
