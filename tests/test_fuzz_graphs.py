@@ -16,11 +16,11 @@ from graphs import rms_err, white_noise
 
 RQ = 128
 SR = 48000.0
-N_INST = 3
+N_INST = int(os.environ.get("FUZZ_INST", 3))
 # Sources that start late change the reference's DYNAMIC channel counts mid-render (a silent input is mono); the
 # device plan uses static counts and says so in the plan; such graphs are skipped below.
 LATE_STARTS = True
-FRAMES = 2048 * 5 + 200
+FRAMES = int(os.environ.get("FUZZ_FRAMES", 2048 * 5 + 200))   # (FUZZ_FRAMES / FUZZ_INST: campaign variants, tools/fuzz_campaign.py)
 
 
 def build_random_graph(be, seed, frozen=False, tap=None):
