@@ -72,7 +72,7 @@ def build_random_graph(be, seed, frozen=False, tap=None):
             r = rng.random()
             if LATE_STARTS and r < 0.2:  # sub-quantum start, stop before the end
                 n.start_at(float(rng.integers(0, 700)) / SR)
-                n.stop_at(float(rng.integers(3000, FRAMES)) / SR)
+                n.stop_at(float(rng.integers(min(3000, FRAMES - 1), FRAMES)) / SR)   # (short FUZZ_FRAMES variants)
             else:
                 n.start()
             if rng.random() < 0.3:  # a glide: a-rate frequency (prefix-sum phase kernel)
