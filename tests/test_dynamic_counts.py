@@ -244,3 +244,33 @@ def test_delay_line_above_stereo_is_remixed_in_place(hip, orc, delay_time, feedb
         tail.connect(c.destination())
         return c
     _render(build, hip, orc)
+
+
+def test_analyser_behind_a_layout_above_stereo_follows_the_count_of_every_quantum(hip, orc):
+    """analyser.rs:277-280 down-mixes the quantum it is handed: mono quanta as they are, stereo as 0.5 (L + R), quad as
+    0.25 (L + R + SL + SR) — the analyser kernel reads the per-quantum codes in a dynamic-count plan"""
+    taps = {}
+    def build(be):
+        c = _ctx(be)
+        mono = _buf(c, 1, FRAMES, seed=41)
+        quad = _buf(c, 4, RQ * 30, start=RQ * 70.25 / SR, seed=42)          # plays into the analyser's last window
+        stereo = _buf(c, 2, RQ * 12, start=RQ * 80.0 / SR, seed=43)
+        bus = c.create_gain(gain=0.8, channel_count=4, channel_count_mode="max", channel_interpretation="speakers")
+        an = c.create_analyser(fft_size=2048, smoothing_time_constant=0.0)
+        for s in (mono, quad, stereo):
+            s.connect(bus)
+        bus.connect(an).connect(c.create_biquad_filter(type_="highpass", frequency=500.0)).connect(c.destination())
+        taps[id(be)] = an
+        return c
+    outs = {}
+    for be in (hip, orc):
+        c = build(be)
+        if be is hip:
+            assert "dynamic-count group" in c.plan_describe()
+        outs[id(be)] = (c.start_rendering_sync().data, taps[id(be)].get_float_time_domain_data(instance=1),
+                        taps[id(be)].get_float_frequency_data(instance=1))
+        c.close()
+    (g, gt, gf), (o, ot, of) = outs[id(hip)], outs[id(orc)]
+    assert rms_err(g, o).max() <= 1e-6 and np.abs(gt - ot).max() <= 1e-6 and np.abs(ot).max() > 0.05
+    fin = np.isfinite(of)
+    assert np.abs(gf[fin] - of[fin]).max() <= 0.05

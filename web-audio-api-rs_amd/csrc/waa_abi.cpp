@@ -1110,6 +1110,8 @@ static int analyser_compute(waa_batch* b, uint32_t node, int what) {
     ad.db_out = n.d_an_db;
     ad.byte_out = n.d_an_bytes;
     ad.time_out = n.d_an_time;
+    ad.code = b->dynamic ? n.code : nullptr;
+    ad.code_stride = b->code_stride;
     int slot = -1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->profiling) {

@@ -866,7 +866,13 @@ __global__ void analyser_kernel(const AnalyserDesc d) {
     if (f >= 0) {
       // mono down-mix of the analyser input (analyser.rs:277-280, quantum.rs:387-397)
       const uint64_t cs = d.sig.ch_stride;
-      switch (d.sig.nch) {  // quantum.rs:387-429 speaker down-mix to mono
+      int nch = d.sig.nch;
+      if (d.code) {  // (dynamic-count plans: the count of this frame's quantum)
+        const uint32_t c = d.code[(uint64_t)inst * d.code_stride + (uint64_t)(f >> 7)];
+        nch = (c & 0x80u) ? 0 : (int)(c & 7u);
+      }
+      switch (nch) {  // quantum.rs:387-429 speaker down-mix to mono
+        case 0: v = 0.f; break;  // (a silent quantum)
         case 1: v = p0[f]; break;
         case 2: v = 0.5f * (p0[f] + p0[cs + f]); break;
         case 4: v = 0.25f * (p0[f] + p0[cs + f] + p0[2 * cs + f] + p0[3 * cs + f]); break;

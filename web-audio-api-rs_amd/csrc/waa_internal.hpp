@@ -274,6 +274,10 @@ struct AnalyserDesc {
   float* db_out;         // [n_inst][fft_size/2]  20 log10 of the smoothed magnitudes (analysis.rs:365-368)
   uint8_t* byte_out;     // [n_inst][fft_size/2]
   float* time_out;       // [n_inst][fft_size]
+  // dynamic-count plans: the per-quantum codes of `sig` (count | silent) — the down-mix to mono follows the count of EVERY
+  // quantum (analyser.rs:277-280 mixes the quantum it is handed), not the signal's static width; null: static plans
+  const uint8_t* code;
+  uint64_t code_stride;
 };
 void launch_analyser(const AnalyserDesc& d, void* stream);
 constexpr int DIRECT_MAX_TAPS = 128;  // trimmed IRs up to this length use the direct FIR kernel

@@ -1743,10 +1743,10 @@ int build_plan(waa_batch* b) {
     for (uint32_t id = 0; id < N; id++) {
       const Node& n = b->nodes[id];
       // layouts up to 5.1 are rendered by dyn_kernel<6> (round 3) for Gain / Biquad / IIR / WaveShaper / the panners / DelayNodes
-      // (whose line is then re-mixed in place when the count changes) / the destination; the analyser reads a static
-      // stereo signal, convolver and frozen-node inputs are stereo by their channel config: those stay mono / stereo
+      // (whose line is then re-mixed in place when the count changes) / analysers (whose kernel follows the per-quantum codes)
+      // / the destination; convolver and frozen-node inputs are stereo by their channel config: those stay mono / stereo
       const uint32_t k = n.desc.kind;
-      const bool narrow_only = k == WAA_NODE_ANALYSER || (k == WAA_NODE_CONVOLVER && n.has_ir) || is_frozen_node(n);
+      const bool narrow_only = (k == WAA_NODE_CONVOLVER && n.has_ir) || is_frozen_node(n);
       if (n.live && narrow_only && (n.in_nch > 2 || n.out_nch > 2))
         return fail(WAA_ERR_OUT_OF_SCOPE,
                     "node %u: the reference's channel count changes mid-render and a signal is wider than stereo (%d channels): "
