@@ -111,12 +111,12 @@ def test_feedback_echo_matches_closed_form(be):
 
 
 # --------------------------------------------------------------------------- GPU parity on seeded inputs
-def _feedback_graph(binding, noise, delays, gains, with_filter):
+def _feedback_graph(binding, noise, delays, gains, with_filter, max_delay=0.05, want_plan=False):
     n = noise.shape[0]
     c = waa.OfflineAudioContext(2, noise.shape[2], 48000.0, n_instances=n, binding=binding)
     src = c.create_buffer_source()
     src.set_buffer_batch(noise, 48000.0)
-    delay = c.create_delay(0.05)
+    delay = c.create_delay(max_delay)
     fb = c.create_gain()
     for i in range(n):
         delay.delay_time.set_value(delays[i], instance=i)
@@ -129,9 +129,10 @@ def _feedback_graph(binding, noise, delays, gains, with_filter):
     src.connect(c.destination())
     tail.connect(c.destination())
     src.start()
+    plan = c.plan_describe() if want_plan else None
     out = c.start_rendering_sync().data
     c.close()
-    return out
+    return (out, plan) if want_plan else out
 
 
 @pytest.mark.gpu
@@ -331,6 +332,33 @@ def test_parity_echo_loop_as_one_persistent_launch(hip, orc, monkeypatch):
     assert np.array_equal(plain, pers)
     o = _feedback_graph(orc, noise, delays, gains, False)
     assert np.abs(pers - o).max() == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [1, 2])
+def test_parity_echo_loop_from_the_lds_ring(hip, orc, channels, monkeypatch):
+    """an echo loop whose body is ONE element-wise step and whose delays all fit the 16384-frame window is rendered by
+    waa_echo.hip in one launch, the delayed read served from LDS: bit-identical to the launch-per-block form and to the
+    oracle, at the window's limits (2064 frames = the shortest block-scheduled delay, 14328 = 16384-8*256-8 frames with
+    2048-frame chunks) and with a ragged tail; one frame past what the smallest chunk reaches, the launch-per-block form"""
+    n, frames = 6, 2048 * 11 + 77
+    noise = white_noise(n, channels, frames, seed0=35)
+    delays = (np.float64([2064, 2065.5, 3000.25, 4800, 9000.75, 14328]) / 48000.0).astype(np.float32)
+    gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
+    ring, plan = _feedback_graph(hip, noise, delays, gains, False, max_delay=0.4, want_plan=True)
+    assert "LDS-ring kernel" in plan and "chunks of 2048 frames" in plan
+    monkeypatch.setenv("WAA_NO_ECHO_RING", "1")
+    plain, plan = _feedback_graph(hip, noise, delays, gains, False, max_delay=0.4, want_plan=True)
+    assert "LDS-ring kernel" not in plan
+    assert np.array_equal(plain, ring)
+    o = _feedback_graph(orc, noise, delays, gains, False, max_delay=0.4)
+    assert np.abs(ring - o).max() == 0.0
+    monkeypatch.delenv("WAA_NO_ECHO_RING")
+    d2 = delays.copy()
+    d2[5] = np.float32(15354.0 / 48000.0)  # (16384 - 4*256 - 8 = 15352 is the last delay any chunk size reaches)
+    g2, plan = _feedback_graph(hip, noise, d2, gains, False, max_delay=0.4, want_plan=True)
+    assert "LDS-ring kernel" not in plan
+    assert np.abs(g2 - _feedback_graph(orc, noise, d2, gains, False, max_delay=0.4)).max() == 0.0
 
 
 @pytest.mark.gpu

@@ -925,6 +925,17 @@ static int run_steps(waa_batch* b) {
           n_body++;
           body = k;
         }
+      if (n_body == 1 && b->steps[body].kind == 0 && b->steps[body].echo_fb >= 0 && !getenv("WAA_NO_ECHO_RING")) {
+        // the echo loop with its delay line in LDS: the whole loop in one launch (waa_echo.hip)
+        const Step& bs = b->steps[body];
+        ChainDesc d = bs.chain;
+        d.tile0 = 0;
+        d.tile1 = b->n_tiles;
+        int e = timed(bs.profile_slot, [&] { launch_echo_ring(d, bs.echo_fb, bs.echo_chunk, b->stream); });
+        if (e) return e;
+        i = j;
+        continue;
+      }
       if (n_body == 1 && b->steps[body].kind == 0 && b->steps[body].cmax <= 2 && getenv("WAA_PERSISTENT_LOOP")) {
         const Step& bs = b->steps[body];
         bool element_wise = true;

@@ -1,0 +1,201 @@
+// waa_echo.hip — the echo loop  line = inputs + g * delayed(line)  with its delay line in LDS.
+//
+// A block-scheduled feedback loop whose body is ONE element-wise launch per block (DelayNode <-> GainNode, the delay read from
+// its line by the summing stage: DESIGN.md 3.1d) costs, per block, a read of the source, a read of the delayed line and a write
+// of the line — and 47 launches of 250 MB for a 10 s render.  Here one workgroup per instance walks the render in chunks and
+// keeps the last 16384 frames of the line in LDS: the delayed read never goes to memory, the line is written once (its
+// consumers outside the loop read it from HBM as before).  Same arithmetic in the same order as chain_kernel's input stage
+// (waa_kernels.hip: load -> edge gain with gain.rs' mute / pass-through cases -> up-mix -> sum in edge order; the delayed
+// sample is fma(1 - k, x[i], k * x[i + 1]), delay.rs:560-590): bit-identical, which tests/test_cycles.py asserts.
+// Qualification: echo_ring_applicable() below; everything else keeps the launch-per-block form.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "waa_internal.hpp"
+
+namespace waa {
+
+constexpr int ECHO_RING = 16384;  // frames per channel kept in LDS (two channels: 128 KB)
+
+namespace {
+__device__ __forceinline__ float echo_delay_value(const ParamRef& p, uint32_t inst) {
+  return p.mode == 3 ? __uint_as_float((uint32_t)p.stride) : load_global(p.base + inst);
+}
+
+template <int C>
+__global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int fb, int chunk_subtiles) {
+  extern __shared__ __attribute__((aligned(16))) float ring[];  // [C][ECHO_RING]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t inst = blockIdx.x;
+  for (int i = tid; i < C * ECHO_RING; i += blockDim.x) ring[i] = 0.f;
+  __syncthreads();
+  const InputRef& fbin = d.in[fb];
+  // DelayReader's position arithmetic (delay.rs:560-569), one delayTime per instance
+  const float dv = echo_delay_value(fbin.offset, inst);
+  const double position = 0. - (double)dv * fbin.sample_rate;
+  const double fl = floor(position);
+  const int64_t pf0 = (int64_t)fl;
+  const float kf = (float)(position - fl);
+  const uint32_t total_sub = (d.tile1 - d.tile0) * (TILE / 256);
+  const uint64_t f_first = (uint64_t)d.tile0 * TILE;
+  // the inputs from outside the loop do not depend on the ring: the next chunk's are requested before this chunk is rendered
+  // (one workgroup per CU: without it every chunk paid a full memory round trip between two barriers)
+  float nxt[MAX_INPUTS][C][4];
+  auto fetch_ext = [&](uint32_t sub_n) __attribute__((always_inline)) {
+    const uint64_t fn = f_first + (uint64_t)sub_n * 256 + (uint64_t)lane * 4;
+#pragma unroll
+    for (int k = 0; k < MAX_INPUTS; k++) {
+#pragma unroll
+      for (int c = 0; c < C; c++) nxt[k][c][0] = nxt[k][c][1] = nxt[k][c][2] = nxt[k][c][3] = 0.f;
+      if (k < d.n_inputs && k != fb && sub_n < total_sub) {
+        const InputRef& in = d.in[k];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+          if (c < in.nch) {
+            const float* p = in.sig.base + (uint64_t)inst * in.sig.inst_stride + (uint64_t)c * in.sig.ch_stride;
+            const bool inside = in.valid == 0 || fn + 3 < in.valid;
+            const f4v t = load_global_f4(inside ? p + fn : p);  // (unconditional load, the zero selected below)
+            nxt[k][c][0] = inside ? t.x : 0.f;
+            nxt[k][c][1] = inside ? t.y : 0.f;
+            nxt[k][c][2] = inside ? t.z : 0.f;
+            nxt[k][c][3] = inside ? t.w : 0.f;
+          }
+      }
+    }
+  };
+  if (wave < chunk_subtiles) fetch_ext((uint32_t)wave);
+  for (uint32_t s0 = 0; s0 < total_sub; s0 += (uint32_t)chunk_subtiles) {
+    const uint32_t sub = s0 + (uint32_t)wave;
+    float cur[MAX_INPUTS][C][4];
+#pragma unroll
+    for (int k = 0; k < MAX_INPUTS; k++)
+#pragma unroll
+      for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) cur[k][c][e] = nxt[k][c][e];
+    if (wave < chunk_subtiles) fetch_ext(sub + (uint32_t)chunk_subtiles);
+    if (wave < chunk_subtiles && sub < total_sub) {
+      const uint64_t f = f_first + (uint64_t)sub * 256 + (uint64_t)lane * 4;
+      const uint32_t q = (uint32_t)(f / RQ);
+      const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
+      float v[C][4];
+#pragma unroll
+      for (int c = 0; c < C; c++) v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAX_INPUTS; k++) {
+        if (k >= d.n_inputs) continue;
+        const InputRef& in = d.in[k];
+        float u[C][4];
+#pragma unroll
+        for (int c = 0; c < C; c++) u[c][0] = u[c][1] = u[c][2] = u[c][3] = 0.f;
+        if (k == fb) {
+          if (q < d.n_quanta) {
+#pragma unroll
+            for (int c = 0; c < C; c++)
+              if (c < in.nch) {
+                float x[5];
+#pragma unroll
+                for (int e = 0; e < 5; e++) {
+                  const int64_t idx = (int64_t)f + pf0 + e;
+                  x[e] = idx < 0 ? 0.f : ring[c * ECHO_RING + (int)(idx & (ECHO_RING - 1))];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) u[c][e] = __builtin_fmaf(1.f - kf, x[e], kf * x[e + 1]);
+              }
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (c < in.nch) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) u[c][e] = cur[k][c][e];
+            }
+        }
+        if (in.has_gain) {  // gain.rs:163-179 on the edge (mode 0 / 1: one value for the quantum)
+          const float g = in.gain.mode == 0 ? load_global(in.gain.base + inst) : load_global(in.gain.base + (uint64_t)inst * in.gain.stride + qc);
+          const bool mute = fabsf(g) <= 1e-6f, pass = fabsf(1.f - g) <= 1e-6f;
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (c < in.nch) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) u[c][e] = mute ? 0.f : (pass ? u[c][e] : u[c][e] * g);
+            }
+        }
+        if (C == 2 && in.nch == 1 && d.in_nch == 2) {  // quantum.rs up-mix 1 -> 2: copy (speakers) / silence (discrete)
+#pragma unroll
+          for (int e = 0; e < 4; e++) u[C - 1][e] = d.in_interp == 1 ? 0.f : u[0][e];
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++)
+          if (c < d.in_nch) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[c][e] = k == 0 ? u[c][e] : v[c][e] + u[c][e];
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < C; c++)
+        if (c < d.out.nch) {
+          float* po = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + f;
+          *reinterpret_cast<float4*>(po) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+          *reinterpret_cast<f4v*>(ring + c * ECHO_RING + (int)(f & (ECHO_RING - 1))) = f4v{v[c][0], v[c][1], v[c][2], v[c][3]};
+        }
+    }
+    __syncthreads();  // the chunk is in the ring before the next one reads behind it
+  }
+}
+}  // namespace
+
+// The loop step `d` (one element-wise launch per block, ChainDesc::tile0 / tile1 = the whole render) as the LDS-ring kernel?
+// Returns the index of the feedback input and the chunk size (sub-tiles of 256 frames), or -1.
+int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, int* chunk_subtiles) {
+  if (d.n_ops != 0 || d.in_nch < 1 || d.in_nch > 2 || d.out.nch != d.in_nch || d.n_inputs < 2 || d.n_inputs > MAX_INPUTS) return -1;
+  int fb = -1;
+  for (int k = 0; k < d.n_inputs; k++) {
+    const InputRef& in = d.in[k];
+    if (in.has_gain && !(in.gain.mode == 0 || in.gain.mode == 1)) return -1;
+    if (in.nch != d.in_nch && !(in.nch == 1 && d.in_nch == 2)) return -1;
+    if (in.kind == IN_DELAYED) {
+      // the line this launch writes, read back by itself; one delayTime per instance
+      if (fb >= 0 || !in.feedback || in.sig.base != d.out.base || in.sig.inst_stride != d.out.inst_stride ||
+          in.sig.ch_stride != d.out.ch_stride || !(in.offset.mode == 0 || in.offset.mode == 3))
+        return -1;
+      fb = k;
+    } else if (in.kind != IN_SIGNAL) {
+      return -1;
+    } else if (in.sig.base == d.out.base || ((uintptr_t)in.sig.base & 15) || (in.sig.ch_stride & 3) || (in.sig.inst_stride & 3)) {
+      return -1;
+    }
+  }
+  if (fb < 0 || ((uintptr_t)d.out.base & 15) || (d.out.ch_stride & 3) || (d.out.inst_stride & 3)) return -1;
+  // the frames a chunk reads must lie BEHIND the chunk (delay > chunk) and still be in the ring (delay + chunk < ring)
+  const float dmin = delay_min_max_frames[0], dmax = delay_min_max_frames[1];
+  int ch = 0;
+  for (int cand : {16, 8, 4})
+    if ((float)(cand * 256 + 8) <= dmin) {
+      ch = cand;
+      break;
+    }
+  if (!ch || dmax > (float)(ECHO_RING - ch * 256 - 8)) return -1;
+  *chunk_subtiles = ch;
+  return fb;
+}
+
+void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, void* stream) {
+  const size_t lds = (size_t)d.in_nch * ECHO_RING * sizeof(float);
+  static bool big = false;
+  if (!big) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(echo_ring_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(echo_ring_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    big = true;
+  }
+  const dim3 block((unsigned)chunk_subtiles * 64);
+  if (d.in_nch == 1)
+    hipLaunchKernelGGL(echo_ring_kernel<1>, dim3(d.n_inst), block, lds, (hipStream_t)stream, d, fb, chunk_subtiles);
+  else
+    hipLaunchKernelGGL(echo_ring_kernel<2>, dim3(d.n_inst), block, lds, (hipStream_t)stream, d, fb, chunk_subtiles);
+}
+
+}  // namespace waa

@@ -231,6 +231,9 @@ struct Step {
   std::vector<const void*> loop_reads, loop_writes;
   int group = -1;         // >= 0: member of a block-scheduled feedback loop (launched block by block)
   bool prologue = false;  // inside a group: runs once over the full range before the blocks
+  // the only body step of a block-scheduled loop, and the loop qualifies for the LDS-ring kernel (waa_echo.hip): index of
+  // the feedback input (-1: no) and the chunk size in 256-frame sub-tiles
+  int echo_fb = -1, echo_chunk = 0;
 };
 
 }  // namespace host

@@ -2144,6 +2144,41 @@ int build_plan(waa_batch* b) {
       }
       plan_note(b, "feedback loop: block-scheduled, %u tile(s) = %u frames per block, %zu step(s) per block", bt, bt * TILE,
                 b->steps.size() - first_step);
+      {
+        // one element-wise launch per block whose only loop-carried input is its own delay line (Delay <-> Gain): the
+        // LDS-ring kernel renders the whole loop in one launch (waa_echo.hip) when every instance's delay fits its window
+        size_t n_body = 0, body = 0;
+        for (size_t k = first_step; k < b->steps.size(); k++)
+          if (!b->steps[k].prologue) {
+            n_body++;
+            body = k;
+          }
+        if (n_body == 1 && b->steps[body].kind == 0 && !b->dry && !getenv("WAA_NO_ECHO_RING")) {
+          float range[2] = {1e30f, 0.f};
+          for (uint32_t v : loop_items) {
+            const uint32_t did = v & ~VTX_READER;
+            if (!(v & VTX_READER) || !b->cut[did]) continue;
+            Node& dn = b->nodes[did];
+            for (uint32_t i = 0; i < b->n_inst; i++)
+              for (float dvv : param_per_quantum(b, dn.params[WAA_PARAM_DELAY_DELAY_TIME], i, nullptr)) {
+                const float fr = std::max(dvv, (float)RQ / (float)b->sr) * (float)b->sr;
+                range[0] = std::min(range[0], fr);
+                range[1] = std::max(range[1], fr);
+              }
+          }
+          ChainDesc cd = b->steps[body].chain;
+          cd.tile0 = 0;
+          cd.tile1 = b->n_tiles;
+          int chunk = 0;
+          const int fb = echo_ring_applicable(cd, range, &chunk);
+          if (fb >= 0) {
+            b->steps[body].echo_fb = fb;
+            b->steps[body].echo_chunk = chunk;
+            plan_note(b, "  ... rendered by the LDS-ring kernel in ONE launch: delay %.0f .. %.0f frames, chunks of %d frames, the line's last %d frames stay in LDS",
+                      (double)range[0], (double)range[1], chunk * 256, 16384);
+          }
+        }
+      }
       continue;
     }
     int e = plan_single(id);
