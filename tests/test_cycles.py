@@ -334,31 +334,84 @@ def test_parity_echo_loop_as_one_persistent_launch(hip, orc, monkeypatch):
     assert np.abs(pers - o).max() == 0.0
 
 
+def _echo_graph(binding, noise, delays, gains, variant, out_channels=2):
+    """source -> Delay <-> Gain, the destination fed as `variant` says:
+    dry+wet      source and delay straight into the destination (the tail the ring kernel can render itself)
+    wet-gain     delay -> Gain(0.7) -> destination only (an edge gain on the tail's delayed input, no dry signal)
+    two-readers  delay -> destination and delay -> Biquad -> destination (the line has two readers: it must be stored)
+    other-dry    delay -> destination plus a SECOND source -> destination (a tail input the loop does not read)"""
+    n = noise.shape[0]
+    c = waa.OfflineAudioContext(out_channels, noise.shape[2], 48000.0, n_instances=n, binding=binding)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    delay = c.create_delay(0.4)
+    fb = c.create_gain()
+    for i in range(n):
+        delay.delay_time.set_value(delays[i], instance=i)
+        fb.gain.set_value(gains[i], instance=i)
+    src.connect(delay)
+    delay.connect(fb).connect(delay)
+    if variant == "dry+wet":
+        src.connect(c.destination())
+        delay.connect(c.destination())
+    elif variant == "wet-gain":
+        delay.connect(c.create_gain(gain=0.7)).connect(c.destination())
+    elif variant == "two-readers":
+        delay.connect(c.destination())
+        delay.connect(c.create_biquad_filter(type_="lowpass", frequency=3000.0)).connect(c.destination())
+    elif variant == "other-dry":
+        other = c.create_buffer_source()
+        other.set_buffer_batch(noise[:, :, ::-1].copy(), 48000.0)
+        other.connect(c.destination())
+        other.start()
+        delay.connect(c.destination())
+    src.start()
+    plan = c.plan_describe() if binding.prefix == "waa_" else ""
+    out = c.start_rendering_sync().data
+    c.close()
+    return out, plan
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("channels", [1, 2])
-def test_parity_echo_loop_from_the_lds_ring(hip, orc, channels, monkeypatch):
+@pytest.mark.parametrize("channels,out_channels", [(1, 1), (1, 2), (2, 2)])
+@pytest.mark.parametrize("variant", ["dry+wet", "wet-gain", "two-readers", "other-dry"])
+def test_parity_echo_loop_from_the_lds_ring(hip, orc, channels, out_channels, variant, monkeypatch):
     """an echo loop whose body is ONE element-wise step and whose delays all fit the 16384-frame window is rendered by
-    waa_echo.hip in one launch, the delayed read served from LDS: bit-identical to the launch-per-block form and to the
-    oracle, at the window's limits (2064 frames = the shortest block-scheduled delay, 14328 = 16384-8*256-8 frames with
-    2048-frame chunks) and with a ragged tail; one frame past what the smallest chunk reaches, the launch-per-block form"""
+    waa_echo.hip in one launch, the delayed read served from LDS; when the line's only other reader is a sum of the
+    delayed line and signals the loop reads (dry + wet into the destination) the same launch renders that too and the
+    line is never stored.  Bit-identical to the launch-per-block form and to the oracle, at the window's limits (2064
+    frames = the shortest block-scheduled delay, 14328 = 16384-8*256-8 frames with 2048-frame chunks), ragged tail"""
     n, frames = 6, 2048 * 11 + 77
     noise = white_noise(n, channels, frames, seed0=35)
     delays = (np.float64([2064, 2065.5, 3000.25, 4800, 9000.75, 14328]) / 48000.0).astype(np.float32)
     gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
-    ring, plan = _feedback_graph(hip, noise, delays, gains, False, max_delay=0.4, want_plan=True)
-    assert "LDS-ring kernel" in plan and "chunks of 2048 frames" in plan
+    ring, plan = _echo_graph(hip, noise, delays, gains, variant, out_channels)
+    assert "LDS-ring kernel in ONE launch" in plan and "chunks of 2048 frames" in plan
+    assert ("the line is not stored" in plan) == (variant in ("dry+wet", "wet-gain"))
+    o, _ = _echo_graph(orc, noise, delays, gains, variant, out_channels)
+    tol = 2e-6 if variant == "two-readers" else 0.0   # (the Biquad branch: f64 recurrence, other summation order)
+    assert np.abs(ring - o).max() <= tol
+    monkeypatch.setenv("WAA_NO_ECHO_TAIL", "1")
+    untailed, plan = _echo_graph(hip, noise, delays, gains, variant, out_channels)
+    assert "LDS-ring kernel in ONE launch" in plan and "the line is not stored" not in plan
+    assert np.array_equal(untailed, ring)
     monkeypatch.setenv("WAA_NO_ECHO_RING", "1")
-    plain, plan = _feedback_graph(hip, noise, delays, gains, False, max_delay=0.4, want_plan=True)
+    plain, plan = _echo_graph(hip, noise, delays, gains, variant, out_channels)
     assert "LDS-ring kernel" not in plan
     assert np.array_equal(plain, ring)
-    o = _feedback_graph(orc, noise, delays, gains, False, max_delay=0.4)
-    assert np.abs(ring - o).max() == 0.0
-    monkeypatch.delenv("WAA_NO_ECHO_RING")
-    d2 = delays.copy()
-    d2[5] = np.float32(15354.0 / 48000.0)  # (16384 - 4*256 - 8 = 15352 is the last delay any chunk size reaches)
-    g2, plan = _feedback_graph(hip, noise, d2, gains, False, max_delay=0.4, want_plan=True)
+
+
+@pytest.mark.gpu
+def test_echo_loop_past_the_lds_ring_window(hip, orc):
+    """one instance's delay is a frame past what the smallest chunk reaches (16384 - 4*256 - 8 = 15352 frames): the
+    launch-per-block form renders the loop"""
+    n, frames = 6, 2048 * 11 + 77
+    noise = white_noise(n, 2, frames, seed0=36)
+    delays = (np.float64([2064, 2065.5, 3000.25, 4800, 9000.75, 15354]) / 48000.0).astype(np.float32)
+    gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
+    g, plan = _echo_graph(hip, noise, delays, gains, "dry+wet")
     assert "LDS-ring kernel" not in plan
-    assert np.abs(g2 - _feedback_graph(orc, noise, d2, gains, False, max_delay=0.4)).max() == 0.0
+    assert np.abs(g - _echo_graph(orc, noise, delays, gains, "dry+wet")[0]).max() == 0.0
 
 
 @pytest.mark.gpu

@@ -900,8 +900,10 @@ static int run_steps(waa_batch* b) {
   for (size_t i = 0; i < b->steps.size();) {
     const Step& st = b->steps[i];
     if (st.group < 0) {
-      int e = run_step(st, 0, b->n_tiles);
-      if (e) return e;
+      if (!st.echo_fused) {  // (a fused tail was rendered by its loop's launch)
+        int e = run_step(st, 0, b->n_tiles);
+        if (e) return e;
+      }
       i++;
       continue;
     }
@@ -925,13 +927,13 @@ static int run_steps(waa_batch* b) {
           n_body++;
           body = k;
         }
-      if (n_body == 1 && b->steps[body].kind == 0 && b->steps[body].echo_fb >= 0 && !getenv("WAA_NO_ECHO_RING")) {
+      if (n_body == 1 && b->steps[body].kind == 0 && b->steps[body].echo_fb >= 0) {  // (decided by the planner)
         // the echo loop with its delay line in LDS: the whole loop in one launch (waa_echo.hip)
         const Step& bs = b->steps[body];
         ChainDesc d = bs.chain;
         d.tile0 = 0;
         d.tile1 = b->n_tiles;
-        int e = timed(bs.profile_slot, [&] { launch_echo_ring(d, bs.echo_fb, bs.echo_chunk, b->stream); });
+        int e = timed(bs.profile_slot, [&] { launch_echo_ring(d, bs.echo_fb, bs.echo_chunk, bs.echo_tail_step >= 0 ? &bs.echo_tail : nullptr, b->stream); });
         if (e) return e;
         i = j;
         continue;

@@ -8,6 +8,13 @@
 // (waa_kernels.hip: load -> edge gain with gain.rs' mute / pass-through cases -> up-mix -> sum in edge order; the delayed
 // sample is fma(1 - k, x[i], k * x[i + 1]), delay.rs:560-590): bit-identical, which tests/test_cycles.py asserts.
 // Qualification: echo_ring_applicable() below; everything else keeps the launch-per-block form.
+//
+// The tail.  The usual echo graph sends  dry + delayed(line)  to the destination: as a launch of its own that stage reads the
+// source and the line again and writes the output (3 x 3.9 GB of the fb workload's 19.7 GB).  When the line has exactly one
+// reader outside the loop and that reader is such a sum of the delayed line and signals the loop reads anyway
+// (echo_tail_applicable), this kernel renders it from the values it already holds — the delayed samples out of the ring, the
+// source out of registers — and the line itself is never written to memory: the loop costs its compulsory traffic, the source
+// read once and the output written once.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -25,8 +32,30 @@ __device__ __forceinline__ float echo_delay_value(const ParamRef& p, uint32_t in
   return p.mode == 3 ? __uint_as_float((uint32_t)p.stride) : load_global(p.base + inst);
 }
 
-template <int C>
-__global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int fb, int chunk_subtiles) {
+// gain.rs:163-179 on an input edge (mode 0 / 1: one value for the quantum), then quantum.rs' up-mix 1 -> 2: copy (speakers) /
+// silence (discrete)
+template <int CM>
+__device__ __forceinline__ void echo_edge(const InputRef& in, uint32_t inst, uint32_t qc, int to_nch, int interp, float (&u)[CM][4]) {
+  if (in.has_gain) {
+    const float g = in.gain.mode == 0 ? load_global(in.gain.base + inst) : load_global(in.gain.base + (uint64_t)inst * in.gain.stride + qc);
+    const bool mute = fabsf(g) <= 1e-6f, pass = fabsf(1.f - g) <= 1e-6f;
+#pragma unroll
+    for (int c = 0; c < CM; c++)
+      if (c < in.nch) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) u[c][e] = mute ? 0.f : (pass ? u[c][e] : u[c][e] * g);
+      }
+  }
+  if (CM == 2 && in.nch == 1 && to_nch == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) u[CM - 1][e] = interp == 1 ? 0.f : u[0][e];
+  }
+}
+
+// C: channels of the line (the ring); CT: channels of the fused tail stage (0: none)
+template <int C, int CT>
+__global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int fb, int chunk_subtiles, const EchoTail t) {
+  constexpr int CM = C > CT ? C : CT;
   extern __shared__ __attribute__((aligned(16))) float ring[];  // [C][ECHO_RING]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t inst = blockIdx.x;
@@ -81,53 +110,39 @@ __global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int 
       const uint64_t f = f_first + (uint64_t)sub * 256 + (uint64_t)lane * 4;
       const uint32_t q = (uint32_t)(f / RQ);
       const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
-      float v[C][4];
+      float v[C][4], xd[C][4];
 #pragma unroll
-      for (int c = 0; c < C; c++) v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+      for (int c = 0; c < C; c++) {
+        v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+        xd[c][0] = xd[c][1] = xd[c][2] = xd[c][3] = 0.f;
+      }
+      if (q < d.n_quanta) {  // the delayed samples of this group, out of the ring
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          float x[5];
+#pragma unroll
+          for (int e = 0; e < 5; e++) {
+            const int64_t idx = (int64_t)f + pf0 + e;
+            x[e] = idx < 0 ? 0.f : ring[c * ECHO_RING + (int)(idx & (ECHO_RING - 1))];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e++) xd[c][e] = __builtin_fmaf(1.f - kf, x[e], kf * x[e + 1]);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < MAX_INPUTS; k++) {
         if (k >= d.n_inputs) continue;
         const InputRef& in = d.in[k];
-        float u[C][4];
+        float u[CM][4];
 #pragma unroll
-        for (int c = 0; c < C; c++) u[c][0] = u[c][1] = u[c][2] = u[c][3] = 0.f;
-        if (k == fb) {
-          if (q < d.n_quanta) {
+        for (int c = 0; c < CM; c++) u[c][0] = u[c][1] = u[c][2] = u[c][3] = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; c++)
-              if (c < in.nch) {
-                float x[5];
+        for (int c = 0; c < C; c++)
+          if (c < in.nch) {
 #pragma unroll
-                for (int e = 0; e < 5; e++) {
-                  const int64_t idx = (int64_t)f + pf0 + e;
-                  x[e] = idx < 0 ? 0.f : ring[c * ECHO_RING + (int)(idx & (ECHO_RING - 1))];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; e++) u[c][e] = __builtin_fmaf(1.f - kf, x[e], kf * x[e + 1]);
-              }
+            for (int e = 0; e < 4; e++) u[c][e] = k == fb ? xd[c][e] : cur[k][c][e];
           }
-        } else {
-#pragma unroll
-          for (int c = 0; c < C; c++)
-            if (c < in.nch) {
-#pragma unroll
-              for (int e = 0; e < 4; e++) u[c][e] = cur[k][c][e];
-            }
-        }
-        if (in.has_gain) {  // gain.rs:163-179 on the edge (mode 0 / 1: one value for the quantum)
-          const float g = in.gain.mode == 0 ? load_global(in.gain.base + inst) : load_global(in.gain.base + (uint64_t)inst * in.gain.stride + qc);
-          const bool mute = fabsf(g) <= 1e-6f, pass = fabsf(1.f - g) <= 1e-6f;
-#pragma unroll
-          for (int c = 0; c < C; c++)
-            if (c < in.nch) {
-#pragma unroll
-              for (int e = 0; e < 4; e++) u[c][e] = mute ? 0.f : (pass ? u[c][e] : u[c][e] * g);
-            }
-        }
-        if (C == 2 && in.nch == 1 && d.in_nch == 2) {  // quantum.rs up-mix 1 -> 2: copy (speakers) / silence (discrete)
-#pragma unroll
-          for (int e = 0; e < 4; e++) u[C - 1][e] = d.in_interp == 1 ? 0.f : u[0][e];
-        }
+        echo_edge<CM>(in, inst, qc, d.in_nch, d.in_interp, u);
 #pragma unroll
         for (int c = 0; c < C; c++)
           if (c < d.in_nch) {
@@ -138,10 +153,50 @@ __global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int 
 #pragma unroll
       for (int c = 0; c < C; c++)
         if (c < d.out.nch) {
-          float* po = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + f;
-          *reinterpret_cast<float4*>(po) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+          if (CT == 0 || t.store_line) {
+            float* po = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + f;
+            *reinterpret_cast<float4*>(po) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+          }
           *reinterpret_cast<f4v*>(ring + c * ECHO_RING + (int)(f & (ECHO_RING - 1))) = f4v{v[c][0], v[c][1], v[c][2], v[c][3]};
         }
+      if (CT > 0) {  // the tail stage: same input arithmetic, its operands taken from xd / cur
+        float w[CM][4];
+#pragma unroll
+        for (int c = 0; c < CM; c++) w[c][0] = w[c][1] = w[c][2] = w[c][3] = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAX_INPUTS; k++) {
+          if (k >= t.n_inputs) continue;
+          const InputRef& in = t.in[k];
+          const int al = t.alias[k];
+          float u[CM][4];
+#pragma unroll
+          for (int c = 0; c < CM; c++) u[c][0] = u[c][1] = u[c][2] = u[c][3] = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; c++)
+            if (c < in.nch) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                float val = xd[c][e];  // (alias -2: the delayed line)
+#pragma unroll
+                for (int ka = 0; ka < MAX_INPUTS; ka++) val = al == ka ? cur[ka][c][e] : val;
+                u[c][e] = val;
+              }
+            }
+          echo_edge<CM>(in, inst, qc, t.in_nch, t.in_interp, u);
+#pragma unroll
+          for (int c = 0; c < CM; c++)
+            if (c < t.in_nch) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) w[c][e] = k == 0 ? u[c][e] : w[c][e] + u[c][e];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CM; c++)
+          if (c < t.out.nch) {
+            float* po = t.out.base + (uint64_t)inst * t.out.inst_stride + (uint64_t)c * t.out.ch_stride + f;
+            *reinterpret_cast<float4*>(po) = make_float4(w[c][0], w[c][1], w[c][2], w[c][3]);
+          }
+      }
     }
     __syncthreads();  // the chunk is in the ring before the next one reads behind it
   }
@@ -183,19 +238,70 @@ int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, 
   return fb;
 }
 
-void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, void* stream) {
-  const size_t lds = (size_t)d.in_nch * ECHO_RING * sizeof(float);
-  static bool big = false;
-  if (!big) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(echo_ring_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(echo_ring_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    big = true;
+// The chain step `tail` (outside the loop) as the tail stage of the ring kernel: a plain sum, to at least the line's channel
+// count, of delayed(line) — the loop's own delayTime — and of signals the loop step reads too.
+int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t) {
+  if (tail.n_ops != 0 || tail.in_nch < d.in_nch || tail.in_nch > 2 || tail.out.nch != tail.in_nch || tail.n_inputs < 1 ||
+      tail.n_inputs > MAX_INPUTS || tail.n_inst != d.n_inst || tail.n_quanta != d.n_quanta)
+    return 0;
+  if (((uintptr_t)tail.out.base & 15) || (tail.out.ch_stride & 3) || (tail.out.inst_stride & 3) || tail.out.base == d.out.base) return 0;
+  const InputRef& fbin = d.in[fb];
+  for (int j = 0; j < d.n_inputs; j++)
+    if (d.in[j].sig.base == tail.out.base) return 0;  // (rendered in place over something the loop still reads)
+  EchoTail r{};
+  r.n_inputs = tail.n_inputs;
+  r.in_nch = tail.in_nch;
+  r.in_interp = tail.in_interp;
+  r.out = tail.out;
+  bool reads_line = false;
+  for (int k = 0; k < tail.n_inputs; k++) {
+    const InputRef& in = tail.in[k];
+    if (in.has_gain && !(in.gain.mode == 0 || in.gain.mode == 1)) return 0;
+    if (in.nch != tail.in_nch && !(in.nch == 1 && tail.in_nch == 2)) return 0;
+    r.in[k] = in;
+    r.alias[k] = -1;
+    if (in.kind == IN_DELAYED) {
+      if (in.sig.base != d.out.base || in.sig.inst_stride != d.out.inst_stride || in.sig.ch_stride != d.out.ch_stride ||
+          in.nch != d.in_nch || in.offset.mode != fbin.offset.mode || in.offset.base != fbin.offset.base ||
+          in.offset.stride != fbin.offset.stride || in.sample_rate != fbin.sample_rate)
+        return 0;
+      r.alias[k] = -2;
+      reads_line = true;
+    } else if (in.kind == IN_SIGNAL) {
+      for (int j = 0; j < d.n_inputs; j++) {
+        const InputRef& lj = d.in[j];
+        if (j != fb && lj.kind == IN_SIGNAL && lj.sig.base == in.sig.base && lj.sig.inst_stride == in.sig.inst_stride &&
+            lj.sig.ch_stride == in.sig.ch_stride && lj.nch == in.nch && lj.valid == in.valid)
+          r.alias[k] = j;
+      }
+      if (r.alias[k] < 0) return 0;
+    } else {
+      return 0;
+    }
   }
-  const dim3 block((unsigned)chunk_subtiles * 64);
-  if (d.in_nch == 1)
-    hipLaunchKernelGGL(echo_ring_kernel<1>, dim3(d.n_inst), block, lds, (hipStream_t)stream, d, fb, chunk_subtiles);
-  else
-    hipLaunchKernelGGL(echo_ring_kernel<2>, dim3(d.n_inst), block, lds, (hipStream_t)stream, d, fb, chunk_subtiles);
+  if (!reads_line) return 0;
+  *t = r;
+  return 1;
+}
+
+void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const EchoTail* tail, void* stream) {
+  const size_t lds = (size_t)d.in_nch * ECHO_RING * sizeof(float);
+  const int ct = tail ? tail->in_nch : 0;
+  EchoTail t{};
+  if (tail) t = *tail;
+  const dim3 block((unsigned)chunk_subtiles * 64), grid(d.n_inst);
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, d, fb, chunk_subtiles, t);
+  };
+  if (d.in_nch == 1) {
+    if (ct == 0) go(echo_ring_kernel<1, 0>);
+    else if (ct == 1) go(echo_ring_kernel<1, 1>);
+    else go(echo_ring_kernel<1, 2>);
+  } else {
+    if (ct == 0) go(echo_ring_kernel<2, 0>);
+    else go(echo_ring_kernel<2, 2>);
+  }
 }
 
 }  // namespace waa

@@ -617,8 +617,17 @@ void launch_pcm16_resample(const DecodeDesc& d, void* stream);
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);
 // the echo loop with its delay line in LDS (waa_echo.hip): qualification (delay range in frames over all instances) and launch
+// EchoTail: the one reader of the line outside the loop (a sum of the delayed line and of signals the loop reads too),
+// rendered by the same launch; store_line == 0: nothing else reads the line, it stays in LDS
+struct EchoTail {
+  int32_t n_inputs, in_nch, in_interp, store_line;
+  InputRef in[MAX_INPUTS];
+  int32_t alias[MAX_INPUTS];  // -2: the delayed line; j >= 0: the same signal as input j of the loop step
+  SignalRef out;
+};
 int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, int* chunk_subtiles);
-void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, void* stream);
+int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t);
+void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const EchoTail* tail, void* stream);
 // dst[inst][q] = src[inst * inst_stride + q * 128]: the first frame of every render quantum of a per-frame table
 void launch_quantum_heads(const float* src, uint64_t inst_stride, uint32_t n_inst, uint32_t n_quanta, float* dst, void* stream);
 // waa_resample.hip: AudioBufferSource [-> WaveShaper] -> signal without the op interpreter (the C5 shape)

@@ -666,6 +666,7 @@ struct StepIo {
 namespace {
 StepIo step_io(const Step& st);
 }
+void fuse_echo_tails(waa_batch* b);
 int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items);
 int plan_delay_writer(waa_batch* b, uint32_t id);
 int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr);
@@ -2174,6 +2175,7 @@ int build_plan(waa_batch* b) {
           if (fb >= 0) {
             b->steps[body].echo_fb = fb;
             b->steps[body].echo_chunk = chunk;
+            b->steps[body].profile_slot = slot_for(b, "echo_ring_kernel");
             plan_note(b, "  ... rendered by the LDS-ring kernel in ONE launch: delay %.0f .. %.0f frames, chunks of %d frames, the line's last %d frames stay in LDS",
                       (double)range[0], (double)range[1], chunk * 256, 16384);
           }
@@ -2184,6 +2186,7 @@ int build_plan(waa_batch* b) {
     int e = plan_single(id);
     if (e) return e;
   }
+  fuse_echo_tails(b);
   // (self-test of the check below: a reversed launch list must not get past it, tests/test_plan.py)
   if (getenv("WAA_DEBUG_REVERSE_PLAN")) std::reverse(b->steps.begin(), b->steps.end());
   if (int e = validate_plan(b)) return e;
@@ -2302,6 +2305,45 @@ StepIo step_io(const Step& st) {
   return io;
 }
 }  // namespace
+
+// An echo loop rendered by the LDS-ring kernel (Step::echo_fb): when the line it writes has exactly ONE reader in the whole plan
+// and that reader is a plain sum of the delayed line and of signals the loop step reads too (the destination's  dry + wet),
+// the ring kernel renders that sum as well and the line is never stored (waa_echo.hip, "the tail").  Decided on the finished
+// launch list, buffer by buffer, with the same read / write sets the validation below uses; any launch kind those sets do
+// not describe keeps the plan as it is.
+void fuse_echo_tails(waa_batch* b) {
+  if (getenv("WAA_NO_ECHO_TAIL")) return;
+  for (const Step& st : b->steps)
+    if (st.kind == 11 || st.kind == 15 || st.kind > 19) return;
+  for (size_t l = 0; l < b->steps.size(); l++) {
+    Step& ls = b->steps[l];
+    if (ls.kind != 0 || ls.echo_fb < 0) continue;
+    const void* line = ls.chain.out.base;
+    size_t reader = 0;
+    int n_readers = 0;
+    bool other_writer = false;
+    for (size_t k = 0; k < b->steps.size(); k++) {
+      if (k == l) continue;
+      const StepIo io = step_io(b->steps[k]);
+      if (std::find(io.reads.begin(), io.reads.end(), line) != io.reads.end()) {
+        n_readers++;
+        reader = k;
+      }
+      other_writer |= std::find(io.writes.begin(), io.writes.end(), line) != io.writes.end();
+    }
+    if (n_readers != 1 || other_writer || reader < l) continue;
+    Step& ts = b->steps[reader];
+    if (ts.kind != 0 || ts.group >= 0) continue;
+    EchoTail t{};
+    if (!echo_tail_applicable(ls.chain, ls.echo_fb, ts.chain, &t)) continue;
+    t.store_line = 0;
+    ls.echo_tail = t;
+    ls.echo_tail_step = (int)reader;
+    ts.echo_fused = true;
+    plan_note(b, "echo loop: launch %zu (the only reader of the loop's delay line: %d input(s) -> %d channel(s)) is rendered by the LDS-ring kernel too; the line is not stored",
+              reader, t.n_inputs, t.in_nch);
+  }
+}
 
 int validate_plan(waa_batch* b) {
   std::vector<StepIo> ios;
