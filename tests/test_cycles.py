@@ -337,7 +337,8 @@ def test_parity_echo_loop_as_one_persistent_launch(hip, orc, monkeypatch):
 def _echo_graph(binding, noise, delays, gains, variant, out_channels=2):
     """source -> Delay <-> Gain, the destination fed as `variant` says:
     dry+wet      source and delay straight into the destination (the tail the ring kernel can render itself)
-    wet-gain     delay -> Gain(0.7) -> destination only (an edge gain on the tail's delayed input, no dry signal)
+    wet-only     delay -> destination only
+    wet-gain     delay -> Gain(0.7) -> destination (the reader has an op of its own: it stays a launch, the line is stored)
     two-readers  delay -> destination and delay -> Biquad -> destination (the line has two readers: it must be stored)
     other-dry    delay -> destination plus a SECOND source -> destination (a tail input the loop does not read)"""
     n = noise.shape[0]
@@ -353,6 +354,8 @@ def _echo_graph(binding, noise, delays, gains, variant, out_channels=2):
     delay.connect(fb).connect(delay)
     if variant == "dry+wet":
         src.connect(c.destination())
+        delay.connect(c.destination())
+    elif variant == "wet-only":
         delay.connect(c.destination())
     elif variant == "wet-gain":
         delay.connect(c.create_gain(gain=0.7)).connect(c.destination())
@@ -374,7 +377,7 @@ def _echo_graph(binding, noise, delays, gains, variant, out_channels=2):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("channels,out_channels", [(1, 1), (1, 2), (2, 2)])
-@pytest.mark.parametrize("variant", ["dry+wet", "wet-gain", "two-readers", "other-dry"])
+@pytest.mark.parametrize("variant", ["dry+wet", "wet-only", "wet-gain", "two-readers", "other-dry"])
 def test_parity_echo_loop_from_the_lds_ring(hip, orc, channels, out_channels, variant, monkeypatch):
     """an echo loop whose body is ONE element-wise step and whose delays all fit the 16384-frame window is rendered by
     waa_echo.hip in one launch, the delayed read served from LDS; when the line's only other reader is a sum of the
@@ -387,7 +390,7 @@ def test_parity_echo_loop_from_the_lds_ring(hip, orc, channels, out_channels, va
     gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
     ring, plan = _echo_graph(hip, noise, delays, gains, variant, out_channels)
     assert "LDS-ring kernel in ONE launch" in plan and "chunks of 2048 frames" in plan
-    assert ("the line is not stored" in plan) == (variant in ("dry+wet", "wet-gain"))
+    assert ("the line is not stored" in plan) == (variant in ("dry+wet", "wet-only"))
     o, _ = _echo_graph(orc, noise, delays, gains, variant, out_channels)
     tol = 2e-6 if variant == "two-readers" else 0.0   # (the Biquad branch: f64 recurrence, other summation order)
     assert np.abs(ring - o).max() <= tol
@@ -448,6 +451,49 @@ def test_plan_block_scheduled_loop(hip):
     # the loop-breaking delay is read from its line by its consumer, the gain rides on an input edge of the delay's mix
     assert "biquad_stream" in plan and "inside a block-scheduled loop" in plan and "gain node" in plan and "delayed:2ch" in plan
     c.close()
+
+
+@pytest.mark.parametrize("variant,fused", [("dry+wet", True), ("wet-only", True), ("wet-gain", False), ("two-readers", False),
+                                            ("other-dry", False)])
+def test_plan_echo_loop_ring_and_tail(hip, variant, fused, monkeypatch):
+    """which echo loops the planner hands to the LDS-ring kernel (waa_echo.hip), and which readers of the line it renders in
+    the same launch — decided on the launch list, so a plan-only context shows it"""
+    def plan_of(delay_frames):
+        c = waa.OfflineAudioContext(2, 2048 * 8, 48000.0, n_instances=2, binding=hip, device=waa.PLAN_ONLY)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(white_noise(2, 2, 2048 * 8), 48000.0)
+        delay = c.create_delay(1.0, delay_time=delay_frames / 48000.0)
+        src.connect(delay)
+        delay.connect(c.create_gain(gain=0.5)).connect(delay)
+        if variant == "dry+wet":
+            src.connect(c.destination())
+        if variant == "wet-gain":
+            delay.connect(c.create_gain(gain=0.7)).connect(c.destination())
+        else:
+            delay.connect(c.destination())
+        if variant == "two-readers":
+            delay.connect(c.create_biquad_filter(type_="lowpass", frequency=3000.0)).connect(c.destination())
+        if variant == "other-dry":
+            other = c.create_buffer_source()
+            other.set_buffer_batch(white_noise(2, 2, 2048 * 8, seed0=3), 48000.0)
+            other.connect(c.destination())
+            other.start()
+        src.start()
+        plan = c.plan_describe()
+        c.close()
+        return plan
+    plan = plan_of(12000)
+    assert "LDS-ring kernel in ONE launch: delay 12000 .. 12000 frames, chunks of 4096 frames" in plan
+    assert ("the line is not stored" in plan) == fused
+    if variant == "two-readers":
+        assert "the delay line has 2 reader(s) outside the loop" in plan
+    if variant in ("wet-gain", "other-dry"):
+        assert "is not a plain sum of the delayed line and of the loop's inputs" in plan
+    assert "chunks of 2048 frames" in plan_of(2064) and "LDS-ring" not in plan_of(15354)
+    monkeypatch.setenv("WAA_NO_ECHO_TAIL", "1")
+    assert "LDS-ring kernel in ONE launch" in plan_of(12000) and "the line is not stored" not in plan_of(12000)
+    monkeypatch.setenv("WAA_NO_ECHO_RING", "1")
+    assert "LDS-ring" not in plan_of(12000)
 
 
 def test_plan_block_scheduled_loop_node_major_delay(hip, monkeypatch):

@@ -262,9 +262,8 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
     r.alias[k] = -1;
     if (in.kind == IN_DELAYED) {
       if (in.sig.base != d.out.base || in.sig.inst_stride != d.out.inst_stride || in.sig.ch_stride != d.out.ch_stride ||
-          in.nch != d.in_nch || in.offset.mode != fbin.offset.mode || in.offset.base != fbin.offset.base ||
-          in.offset.stride != fbin.offset.stride || in.sample_rate != fbin.sample_rate)
-        return 0;
+          in.nch != d.in_nch || !(in.offset.mode == 0 || in.offset.mode == 3) || in.sample_rate != fbin.sample_rate)
+        return 0;  // (a line belongs to ONE DelayNode: every delayed read of it is by that node's delayTime, the loop's own)
       r.alias[k] = -2;
       reads_line = true;
     } else if (in.kind == IN_SIGNAL) {

@@ -2154,7 +2154,7 @@ int build_plan(waa_batch* b) {
             n_body++;
             body = k;
           }
-        if (n_body == 1 && b->steps[body].kind == 0 && !b->dry && !getenv("WAA_NO_ECHO_RING")) {
+        if (n_body == 1 && b->steps[body].kind == 0 && !getenv("WAA_NO_ECHO_RING")) {
           float range[2] = {1e30f, 0.f};
           for (uint32_t v : loop_items) {
             const uint32_t did = v & ~VTX_READER;
@@ -2324,18 +2324,31 @@ void fuse_echo_tails(waa_batch* b) {
     bool other_writer = false;
     for (size_t k = 0; k < b->steps.size(); k++) {
       if (k == l) continue;
-      const StepIo io = step_io(b->steps[k]);
-      if (std::find(io.reads.begin(), io.reads.end(), line) != io.reads.end()) {
+      const Step& sk = b->steps[k];
+      const StepIo io = step_io(sk);
+      // (a delayed read marked `feedback` is left out of the read sets: the validation's legal read-before-write)
+      auto delayed_from = [&](const InputRef& in) { return in.kind == IN_DELAYED && in.sig.base == line; };
+      bool reads = std::find(io.reads.begin(), io.reads.end(), line) != io.reads.end();
+      if (sk.kind == 0)
+        for (int q = 0; q < sk.chain.n_inputs; q++) reads |= delayed_from(sk.chain.in[q]);
+      reads |= (sk.kind == 1 && delayed_from(sk.bq.in)) || (sk.kind == 6 && delayed_from(sk.iir.in)) ||
+               (sk.kind == 19 && delayed_from(sk.lanes.in));
+      if (reads) {
         n_readers++;
         reader = k;
       }
       other_writer |= std::find(io.writes.begin(), io.writes.end(), line) != io.writes.end();
     }
-    if (n_readers != 1 || other_writer || reader < l) continue;
+    if (n_readers != 1 || other_writer || reader < l) {
+      plan_note(b, "echo loop: the delay line has %d reader(s) outside the loop: stored, read by them from memory", n_readers);
+      continue;
+    }
     Step& ts = b->steps[reader];
-    if (ts.kind != 0 || ts.group >= 0) continue;
     EchoTail t{};
-    if (!echo_tail_applicable(ls.chain, ls.echo_fb, ts.chain, &t)) continue;
+    if (ts.kind != 0 || ts.group >= 0 || !echo_tail_applicable(ls.chain, ls.echo_fb, ts.chain, &t)) {
+      plan_note(b, "echo loop: launch %zu, the only reader of the delay line, is not a plain sum of the delayed line and of the loop's inputs: the line is stored", reader);
+      continue;
+    }
     t.store_line = 0;
     ls.echo_tail = t;
     ls.echo_tail_step = (int)reader;
