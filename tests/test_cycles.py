@@ -340,7 +340,8 @@ def _echo_graph(binding, noise, delays, gains, variant, out_channels=2):
     wet-only     delay -> destination only
     wet-gain     delay -> Gain(0.7) -> destination (the reader has an op of its own: it stays a launch, the line is stored)
     two-readers  delay -> destination and delay -> Biquad -> destination (the line has two readers: it must be stored)
-    other-dry    delay -> destination plus a SECOND source -> destination (a tail input the loop does not read)"""
+    other-dry    delay -> destination plus a SECOND source -> destination (a tail input the loop does not read)
+    two-sources  a second source feeds the delay too; the destination gets that second source + delay"""
     n = noise.shape[0]
     c = waa.OfflineAudioContext(out_channels, noise.shape[2], 48000.0, n_instances=n, binding=binding)
     src = c.create_buffer_source()
@@ -368,6 +369,13 @@ def _echo_graph(binding, noise, delays, gains, variant, out_channels=2):
         other.connect(c.destination())
         other.start()
         delay.connect(c.destination())
+    elif variant == "two-sources":
+        other = c.create_buffer_source()
+        other.set_buffer_batch(noise[:, :, ::-1].copy(), 48000.0)
+        other.connect(delay)
+        other.connect(c.destination())
+        other.start()
+        delay.connect(c.destination())
     src.start()
     plan = c.plan_describe() if binding.prefix == "waa_" else ""
     out = c.start_rendering_sync().data
@@ -377,7 +385,7 @@ def _echo_graph(binding, noise, delays, gains, variant, out_channels=2):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("channels,out_channels", [(1, 1), (1, 2), (2, 2)])
-@pytest.mark.parametrize("variant", ["dry+wet", "wet-only", "wet-gain", "two-readers", "other-dry"])
+@pytest.mark.parametrize("variant", ["dry+wet", "wet-only", "wet-gain", "two-readers", "other-dry", "two-sources"])
 def test_parity_echo_loop_from_the_lds_ring(hip, orc, channels, out_channels, variant, monkeypatch):
     """an echo loop whose body is ONE element-wise step and whose delays all fit the 16384-frame window is rendered by
     waa_echo.hip in one launch, the delayed read served from LDS; when the line's only other reader is a sum of the
@@ -390,7 +398,7 @@ def test_parity_echo_loop_from_the_lds_ring(hip, orc, channels, out_channels, va
     gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
     ring, plan = _echo_graph(hip, noise, delays, gains, variant, out_channels)
     assert "LDS-ring kernel in ONE launch" in plan and "chunks of 2048 frames" in plan
-    assert ("the line is not stored" in plan) == (variant in ("dry+wet", "wet-only"))
+    assert ("the line is not stored" in plan) == (variant in ("dry+wet", "wet-only", "two-sources"))
     o, _ = _echo_graph(orc, noise, delays, gains, variant, out_channels)
     tol = 2e-6 if variant == "two-readers" else 0.0   # (the Biquad branch: f64 recurrence, other summation order)
     assert np.abs(ring - o).max() <= tol

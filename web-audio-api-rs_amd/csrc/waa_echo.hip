@@ -26,6 +26,7 @@
 namespace waa {
 
 constexpr int ECHO_RING = 16384;  // frames per channel kept in LDS (two channels: 128 KB)
+constexpr int ECHO_EXT = 2;        // inputs from outside the loop (held in registers two chunks ahead)
 
 namespace {
 __device__ __forceinline__ float echo_delay_value(const ParamRef& p, uint32_t inst) {
@@ -70,42 +71,48 @@ __global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int 
   const float kf = (float)(position - fl);
   const uint32_t total_sub = (d.tile1 - d.tile0) * (TILE / 256);
   const uint64_t f_first = (uint64_t)d.tile0 * TILE;
-  // the inputs from outside the loop do not depend on the ring: the next chunk's are requested before this chunk is rendered
-  // (one workgroup per CU: without it every chunk paid a full memory round trip between two barriers)
-  float nxt[MAX_INPUTS][C][4];
-  auto fetch_ext = [&](uint32_t sub_n) __attribute__((always_inline)) {
+  // The inputs from outside the loop (at most ECHO_EXT of them, slot = their order among the non-feedback inputs) do not
+  // depend on the ring: they are requested TWO chunks ahead.  One workgroup per CU and 16 KB per chunk and channel: with the
+  // loads of one chunk in flight the chip holds 8 MB of reads, 4 TB/s at the loaded latency; two chunks cover it.
+  float nx1[ECHO_EXT][C][4], nx2[ECHO_EXT][C][4];
+  auto fetch_ext = [&](uint32_t sub_n, float (&dst)[ECHO_EXT][C][4]) __attribute__((always_inline)) {
     const uint64_t fn = f_first + (uint64_t)sub_n * 256 + (uint64_t)lane * 4;
 #pragma unroll
-    for (int k = 0; k < MAX_INPUTS; k++) {
+    for (int sl = 0; sl < ECHO_EXT; sl++) {
 #pragma unroll
-      for (int c = 0; c < C; c++) nxt[k][c][0] = nxt[k][c][1] = nxt[k][c][2] = nxt[k][c][3] = 0.f;
-      if (k < d.n_inputs && k != fb && sub_n < total_sub) {
+      for (int c = 0; c < C; c++) dst[sl][c][0] = dst[sl][c][1] = dst[sl][c][2] = dst[sl][c][3] = 0.f;
+      const int k = sl + (sl >= fb ? 1 : 0);  // (input index of slot sl)
+      if (k < d.n_inputs && sub_n < total_sub) {
         const InputRef& in = d.in[k];
 #pragma unroll
         for (int c = 0; c < C; c++)
           if (c < in.nch) {
             const float* p = in.sig.base + (uint64_t)inst * in.sig.inst_stride + (uint64_t)c * in.sig.ch_stride;
             const bool inside = in.valid == 0 || fn + 3 < in.valid;
-            const f4v t = load_global_f4(inside ? p + fn : p);  // (unconditional load, the zero selected below)
-            nxt[k][c][0] = inside ? t.x : 0.f;
-            nxt[k][c][1] = inside ? t.y : 0.f;
-            nxt[k][c][2] = inside ? t.z : 0.f;
-            nxt[k][c][3] = inside ? t.w : 0.f;
+            const f4v t4 = load_global_f4(inside ? p + fn : p);  // (unconditional load, the zero selected below)
+            dst[sl][c][0] = inside ? t4.x : 0.f;
+            dst[sl][c][1] = inside ? t4.y : 0.f;
+            dst[sl][c][2] = inside ? t4.z : 0.f;
+            dst[sl][c][3] = inside ? t4.w : 0.f;
           }
       }
     }
   };
-  if (wave < chunk_subtiles) fetch_ext((uint32_t)wave);
+  fetch_ext((uint32_t)wave, nx1);
+  fetch_ext((uint32_t)(wave + chunk_subtiles), nx2);
   for (uint32_t s0 = 0; s0 < total_sub; s0 += (uint32_t)chunk_subtiles) {
     const uint32_t sub = s0 + (uint32_t)wave;
-    float cur[MAX_INPUTS][C][4];
+    float cur[ECHO_EXT][C][4];
 #pragma unroll
-    for (int k = 0; k < MAX_INPUTS; k++)
+    for (int sl = 0; sl < ECHO_EXT; sl++)
 #pragma unroll
       for (int c = 0; c < C; c++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) cur[k][c][e] = nxt[k][c][e];
-    if (wave < chunk_subtiles) fetch_ext(sub + (uint32_t)chunk_subtiles);
+        for (int e = 0; e < 4; e++) {
+          cur[sl][c][e] = nx1[sl][c][e];
+          nx1[sl][c][e] = nx2[sl][c][e];
+        }
+    fetch_ext(sub + 2u * (uint32_t)chunk_subtiles, nx2);
     if (wave < chunk_subtiles && sub < total_sub) {
       const uint64_t f = f_first + (uint64_t)sub * 256 + (uint64_t)lane * 4;
       const uint32_t q = (uint32_t)(f / RQ);
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int 
         for (int c = 0; c < C; c++)
           if (c < in.nch) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) u[c][e] = k == fb ? xd[c][e] : cur[k][c][e];
+            for (int e = 0; e < 4; e++) u[c][e] = k == fb ? xd[c][e] : (k - (k > fb ? 1 : 0) == 0 ? cur[0][c][e] : cur[1][c][e]);
           }
         echo_edge<CM>(in, inst, qc, d.in_nch, d.in_interp, u);
 #pragma unroll
@@ -176,10 +183,7 @@ __global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int 
             if (c < in.nch) {
 #pragma unroll
               for (int e = 0; e < 4; e++) {
-                float val = xd[c][e];  // (alias -2: the delayed line)
-#pragma unroll
-                for (int ka = 0; ka < MAX_INPUTS; ka++) val = al == ka ? cur[ka][c][e] : val;
-                u[c][e] = val;
+                u[c][e] = al == 0 ? cur[0][c][e] : (al == 1 ? cur[1][c][e] : xd[c][e]);  // (alias -2: the delayed line)
               }
             }
           echo_edge<CM>(in, inst, qc, t.in_nch, t.in_interp, u);
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int 
 // The loop step `d` (one element-wise launch per block, ChainDesc::tile0 / tile1 = the whole render) as the LDS-ring kernel?
 // Returns the index of the feedback input and the chunk size (sub-tiles of 256 frames), or -1.
 int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, int* chunk_subtiles) {
-  if (d.n_ops != 0 || d.in_nch < 1 || d.in_nch > 2 || d.out.nch != d.in_nch || d.n_inputs < 2 || d.n_inputs > MAX_INPUTS) return -1;
+  if (d.n_ops != 0 || d.in_nch < 1 || d.in_nch > 2 || d.out.nch != d.in_nch || d.n_inputs < 2 || d.n_inputs > 1 + ECHO_EXT) return -1;
   int fb = -1;
   for (int k = 0; k < d.n_inputs; k++) {
     const InputRef& in = d.in[k];
@@ -271,7 +275,7 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
         const InputRef& lj = d.in[j];
         if (j != fb && lj.kind == IN_SIGNAL && lj.sig.base == in.sig.base && lj.sig.inst_stride == in.sig.inst_stride &&
             lj.sig.ch_stride == in.sig.ch_stride && lj.nch == in.nch && lj.valid == in.valid)
-          r.alias[k] = j;
+          r.alias[k] = j - (j > fb ? 1 : 0);  // (its register slot)
       }
       if (r.alias[k] < 0) return 0;
     } else {

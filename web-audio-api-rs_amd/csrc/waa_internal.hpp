@@ -622,7 +622,7 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream);
 struct EchoTail {
   int32_t n_inputs, in_nch, in_interp, store_line;
   InputRef in[MAX_INPUTS];
-  int32_t alias[MAX_INPUTS];  // -2: the delayed line; j >= 0: the same signal as input j of the loop step
+  int32_t alias[MAX_INPUTS];  // -2: the delayed line; s >= 0: the same signal as the loop step's s-th input from outside the loop
   SignalRef out;
 };
 int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, int* chunk_subtiles);
