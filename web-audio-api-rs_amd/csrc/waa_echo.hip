@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "waa_internal.hpp"
 
@@ -27,183 +28,233 @@ namespace waa {
 
 constexpr int ECHO_RING = 16384;  // frames per channel kept in LDS (two channels: 128 KB)
 constexpr int ECHO_EXT = 2;        // inputs from outside the loop (held in registers two chunks ahead)
+constexpr int ECHO_TAIL_IN = 3;    // inputs of the fused tail stage: the delayed line and those
 
 namespace {
 __device__ __forceinline__ float echo_delay_value(const ParamRef& p, uint32_t inst) {
   return p.mode == 3 ? __uint_as_float((uint32_t)p.stride) : load_global(p.base + inst);
 }
 
-// gain.rs:163-179 on an input edge (mode 0 / 1: one value for the quantum), then quantum.rs' up-mix 1 -> 2: copy (speakers) /
-// silence (discrete)
-template <int CM>
-__device__ __forceinline__ void echo_edge(const InputRef& in, uint32_t inst, uint32_t qc, int to_nch, int interp, float (&u)[CM][4]) {
-  if (in.has_gain) {
-    const float g = in.gain.mode == 0 ? load_global(in.gain.base + inst) : load_global(in.gain.base + (uint64_t)inst * in.gain.stride + qc);
-    const bool mute = fabsf(g) <= 1e-6f, pass = fabsf(1.f - g) <= 1e-6f;
-#pragma unroll
-    for (int c = 0; c < CM; c++)
-      if (c < in.nch) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) u[c][e] = mute ? 0.f : (pass ? u[c][e] : u[c][e] * g);
-      }
-  }
-  if (CM == 2 && in.nch == 1 && to_nch == 2) {
-#pragma unroll
-    for (int e = 0; e < 4; e++) u[CM - 1][e] = interp == 1 ? 0.f : u[0][e];
-  }
-}
+// One chunk's operands from outside the loop, requested two chunks before they are used: the samples of the (at most
+// ECHO_EXT) inputs that are not the feedback input — slot = their order among those — and one edge gain per input of the
+// loop stage and of the tail stage.  RAW values: nothing may look at them before the chunk that uses them (a select on a
+// loaded value is a wait for the load, the prefetch would be none); every load is unconditional, so that the compiler can
+// count what is in flight behind it (vmcnt is in order: an unknown number of younger accesses turns every wait into "all").
+template <int C, int NG>
+struct EchoOperands {
+  float x[ECHO_EXT][C][4];
+  float g[NG];
+};
 
-// C: channels of the line (the ring); CT: channels of the fused tail stage (0: none)
-template <int C, int CT>
+// C: channels of the line (the ring); CT: channels of the fused tail stage (0: none); STORE: the line goes to memory too.
+// Everything that does not change from chunk to chunk — pointers, which operand an edge takes, whether it has a gain or
+// up-mixes — is worked out ONCE, into wave-uniform registers, before the walk: read from the descriptors inside the chunk it
+// was 1500 instructions per chunk and wave (a third of them scalar-register spills), as long as the chunk's memory time.
+template <int C, int CT, bool STORE>
 __global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int fb, int chunk_subtiles, const EchoTail t) {
   constexpr int CM = C > CT ? C : CT;
+  constexpr int NL = 1 + ECHO_EXT, NT = CT > 0 ? ECHO_TAIL_IN : 0, NG = NL + NT;
   extern __shared__ __attribute__((aligned(16))) float ring[];  // [C][ECHO_RING]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t inst = blockIdx.x;
   for (int i = tid; i < C * ECHO_RING; i += blockDim.x) ring[i] = 0.f;
   __syncthreads();
-  const InputRef& fbin = d.in[fb];
   // DelayReader's position arithmetic (delay.rs:560-569), one delayTime per instance
-  const float dv = echo_delay_value(fbin.offset, inst);
-  const double position = 0. - (double)dv * fbin.sample_rate;
+  const float dv = echo_delay_value(d.in[fb].offset, inst);
+  const double position = 0. - (double)dv * d.in[fb].sample_rate;
   const double fl = floor(position);
-  const int64_t pf0 = (int64_t)fl;
+  const int32_t pf0 = (int32_t)fl;  // (-ECHO_RING < pf0 < 0: echo_ring_applicable)
   const float kf = (float)(position - fl);
   const uint32_t total_sub = (d.tile1 - d.tile0) * (TILE / 256);
-  const uint64_t f_first = (uint64_t)d.tile0 * TILE;
-  // The inputs from outside the loop (at most ECHO_EXT of them, slot = their order among the non-feedback inputs) do not
-  // depend on the ring: they are requested TWO chunks ahead.  One workgroup per CU and 16 KB per chunk and channel: with the
-  // loads of one chunk in flight the chip holds 8 MB of reads, 4 TB/s at the loaded latency; two chunks cover it.
-  float nx1[ECHO_EXT][C][4], nx2[ECHO_EXT][C][4];
-  auto fetch_ext = [&](uint32_t sub_n, float (&dst)[ECHO_EXT][C][4]) __attribute__((always_inline)) {
-    const uint64_t fn = f_first + (uint64_t)sub_n * 256 + (uint64_t)lane * 4;
+  const uint32_t f_first = d.tile0 * TILE;  // (frames fit 31 bits: echo_ring_applicable)
+  const uint32_t cs = (uint32_t)chunk_subtiles;
+  const uint32_t last_q = d.n_quanta - 1;
+
+  // ---- the walk's constants
+  const float* px[ECHO_EXT][C];  // slot -> channel rows of this instance
+  uint32_t vlim[ECHO_EXT];       // ... and the frames that may be read (zeros beyond)
+#pragma unroll
+  for (int sl = 0; sl < ECHO_EXT; sl++) {
+    int k = sl + (sl >= fb ? 1 : 0);                 // (input index of slot sl)
+    if (k >= d.n_inputs) k = fb == 0 ? 1 : 0;        // (no such input: the slot re-reads another one, unused)
+    const InputRef& in = d.in[k];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+      px[sl][c] = in.sig.base + (uint64_t)inst * in.sig.inst_stride + (uint64_t)(c < in.nch ? c : 0) * in.sig.ch_stride;
+    vlim[sl] = in.valid == 0 || in.valid > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)in.valid;
+  }
+  const float* pg[NG];   // edge -> its gain values (an edge without a gain: a word of its signal, unused)
+  uint32_t gstep[NG];    // 1: one value per quantum, 0: one per instance
+  bool is_d[NG], is_a[NG];  // operand of the edge: the delayed line / slot 0 (neither: slot 1)
+  bool present[NG], has_gain[NG], up[NG];
+#pragma unroll
+  for (int k = 0; k < NG; k++) {
+    const bool tail = k >= NL;
+    const int kk = tail ? k - NL : k;
+    present[k] = kk < (tail ? t.n_inputs : d.n_inputs);
+    const InputRef& in = tail ? t.in[present[k] ? kk : 0] : d.in[present[k] ? kk : 0];
+    has_gain[k] = present[k] && in.has_gain;
+    pg[k] = !has_gain[k] ? in.sig.base : in.gain.mode == 0 ? in.gain.base + inst : in.gain.base + (uint64_t)inst * in.gain.stride;
+    gstep[k] = has_gain[k] && in.gain.mode != 0 ? 1u : 0u;
+    const int slot = tail ? t.alias[kk < MAX_INPUTS ? kk : 0] : (kk == fb ? -2 : kk - (kk > fb ? 1 : 0));
+    is_d[k] = slot < 0;
+    is_a[k] = slot == 0;
+    up[k] = in.nch == 1 && (tail ? t.in_nch : d.in_nch) == 2;
+  }
+  const bool l_discrete = d.in_interp == 1, t_discrete = t.in_interp == 1;
+  float* po[C];
+  float* pt[CT > 0 ? CT : 1];
+#pragma unroll
+  for (int c = 0; c < C; c++) po[c] = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride;
+#pragma unroll
+  for (int c = 0; c < CT; c++) pt[c] = t.out.base + (uint64_t)inst * t.out.inst_stride + (uint64_t)c * t.out.ch_stride;
+
+  auto fetch = [&](uint32_t sub_n, EchoOperands<C, NG>& o) __attribute__((always_inline)) {
+    const uint32_t fn = f_first + sub_n * 256u + (uint32_t)lane * 4u;
+    const uint32_t qn = fn / RQ;
+    const uint32_t qcn = qn < last_q ? qn : last_q;
 #pragma unroll
     for (int sl = 0; sl < ECHO_EXT; sl++) {
+      const bool ok = sub_n < total_sub && fn + 3u < vlim[sl];
+      const uint32_t off = ok ? fn : 0u;
 #pragma unroll
-      for (int c = 0; c < C; c++) dst[sl][c][0] = dst[sl][c][1] = dst[sl][c][2] = dst[sl][c][3] = 0.f;
-      const int k = sl + (sl >= fb ? 1 : 0);  // (input index of slot sl)
-      if (k < d.n_inputs && sub_n < total_sub) {
-        const InputRef& in = d.in[k];
+      for (int c = 0; c < C; c++) {
+        const f4v t4 = load_global_f4(px[sl][c] + off);
+        o.x[sl][c][0] = t4.x;
+        o.x[sl][c][1] = t4.y;
+        o.x[sl][c][2] = t4.z;
+        o.x[sl][c][3] = t4.w;
+      }
+    }
 #pragma unroll
-        for (int c = 0; c < C; c++)
-          if (c < in.nch) {
-            const float* p = in.sig.base + (uint64_t)inst * in.sig.inst_stride + (uint64_t)c * in.sig.ch_stride;
-            const bool inside = in.valid == 0 || fn + 3 < in.valid;
-            const f4v t4 = load_global_f4(inside ? p + fn : p);  // (unconditional load, the zero selected below)
-            dst[sl][c][0] = inside ? t4.x : 0.f;
-            dst[sl][c][1] = inside ? t4.y : 0.f;
-            dst[sl][c][2] = inside ? t4.z : 0.f;
-            dst[sl][c][3] = inside ? t4.w : 0.f;
-          }
+    for (int k = 0; k < NG; k++) o.g[k] = load_global(pg[k] + qcn * gstep[k]);
+  };
+
+  // gain.rs:163-179 on an input edge (one value for the quantum), then quantum.rs' up-mix 1 -> 2: copy (speakers) /
+  // silence (discrete); the edge's operand picked from the three the chunk has
+  // (three separate operand arrays and two flags per edge: ONE array indexed by the edge's selector is put in scratch memory)
+  auto edge = [&](int k, float g, bool discrete, const float (&xd)[C][4], const float (&xa)[C][4], const float (&xb)[C][4],
+                  float (&u)[CM][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CM; c++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) u[c][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; c++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) u[c][e] = is_d[k] ? xd[c][e] : (is_a[k] ? xa[c][e] : xb[c][e]);
+    if (has_gain[k]) {
+      const bool mute = fabsf(g) <= 1e-6f, pass = fabsf(1.f - g) <= 1e-6f;
+#pragma unroll
+      for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) u[c][e] = mute ? 0.f : (pass ? u[c][e] : u[c][e] * g);
+    }
+    if (CM == 2) {
+      if (up[k]) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) u[CM - 1][e] = discrete ? 0.f : u[0][e];
       }
     }
   };
-  fetch_ext((uint32_t)wave, nx1);
-  fetch_ext((uint32_t)(wave + chunk_subtiles), nx2);
-  for (uint32_t s0 = 0; s0 < total_sub; s0 += (uint32_t)chunk_subtiles) {
-    const uint32_t sub = s0 + (uint32_t)wave;
-    float cur[ECHO_EXT][C][4];
-#pragma unroll
-    for (int sl = 0; sl < ECHO_EXT; sl++)
-#pragma unroll
-      for (int c = 0; c < C; c++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          cur[sl][c][e] = nx1[sl][c][e];
-          nx1[sl][c][e] = nx2[sl][c][e];
-        }
-    fetch_ext(sub + 2u * (uint32_t)chunk_subtiles, nx2);
-    if (wave < chunk_subtiles && sub < total_sub) {
-      const uint64_t f = f_first + (uint64_t)sub * 256 + (uint64_t)lane * 4;
-      const uint32_t q = (uint32_t)(f / RQ);
-      const uint32_t qc = q < d.n_quanta ? q : d.n_quanta - 1;
-      float v[C][4], xd[C][4];
+
+  // One chunk: wave w renders sub-tile s0 + w (256 frames, 4 per lane).  GUARD: the last, partial chunk.
+  auto chunk = [&](const EchoOperands<C, NG>& o, uint32_t s0, auto guard) __attribute__((always_inline)) {
+    constexpr bool GUARD = decltype(guard)::value;
+    const uint32_t sub = s0 + wave;
+    if (!GUARD || sub < total_sub) {
+      const uint32_t f = f_first + sub * 256u + (uint32_t)lane * 4u;
+      const bool dead = f / RQ > last_q;
+      float xd[C][4], xa[C][4], xb[C][4];  // the delayed samples of this group, out of the ring; the inputs of slot 0 / 1
 #pragma unroll
       for (int c = 0; c < C; c++) {
-        v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
-        xd[c][0] = xd[c][1] = xd[c][2] = xd[c][3] = 0.f;
-      }
-      if (q < d.n_quanta) {  // the delayed samples of this group, out of the ring
+        float x[5];
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-          float x[5];
-#pragma unroll
-          for (int e = 0; e < 5; e++) {
-            const int64_t idx = (int64_t)f + pf0 + e;
-            x[e] = idx < 0 ? 0.f : ring[c * ECHO_RING + (int)(idx & (ECHO_RING - 1))];
-          }
-#pragma unroll
-          for (int e = 0; e < 4; e++) xd[c][e] = __builtin_fmaf(1.f - kf, x[e], kf * x[e + 1]);
+        for (int e = 0; e < 5; e++) {
+          const int32_t idx = (int32_t)f + pf0 + e;
+          const float r = ring[c * ECHO_RING + (idx & (ECHO_RING - 1))];
+          x[e] = idx < 0 || dead ? 0.f : r;
         }
-      }
 #pragma unroll
-      for (int k = 0; k < MAX_INPUTS; k++) {
-        if (k >= d.n_inputs) continue;
-        const InputRef& in = d.in[k];
+        for (int e = 0; e < 4; e++) xd[c][e] = __builtin_fmaf(1.f - kf, x[e], kf * x[e + 1]);
+      }
+      {
+        const bool in_a = f + 3u < vlim[0], in_b = f + 3u < vlim[1];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            xa[c][e] = in_a ? o.x[0][c][e] : 0.f;
+            xb[c][e] = in_b ? o.x[1][c][e] : 0.f;
+          }
+      }
+      float v[C][4];
+#pragma unroll
+      for (int k = 0; k < NL; k++) {
+        if (!present[k]) continue;
         float u[CM][4];
-#pragma unroll
-        for (int c = 0; c < CM; c++) u[c][0] = u[c][1] = u[c][2] = u[c][3] = 0.f;
-#pragma unroll
-        for (int c = 0; c < C; c++)
-          if (c < in.nch) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) u[c][e] = k == fb ? xd[c][e] : (k - (k > fb ? 1 : 0) == 0 ? cur[0][c][e] : cur[1][c][e]);
-          }
-        echo_edge<CM>(in, inst, qc, d.in_nch, d.in_interp, u);
+        edge(k, o.g[k], l_discrete, xd, xa, xb, u);
 #pragma unroll
         for (int c = 0; c < C; c++)
-          if (c < d.in_nch) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[c][e] = k == 0 ? u[c][e] : v[c][e] + u[c][e];
-          }
+          for (int e = 0; e < 4; e++) v[c][e] = k == 0 ? u[c][e] : v[c][e] + u[c][e];
       }
 #pragma unroll
-      for (int c = 0; c < C; c++)
-        if (c < d.out.nch) {
-          if (CT == 0 || t.store_line) {
-            float* po = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + f;
-            *reinterpret_cast<float4*>(po) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
-          }
-          *reinterpret_cast<f4v*>(ring + c * ECHO_RING + (int)(f & (ECHO_RING - 1))) = f4v{v[c][0], v[c][1], v[c][2], v[c][3]};
-        }
-      if (CT > 0) {  // the tail stage: same input arithmetic, its operands taken from xd / cur
+      for (int c = 0; c < C; c++) {  // (C == in_nch == out.nch: echo_ring_applicable)
+        if (STORE) *reinterpret_cast<float4*>(po[c] + f) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+        *reinterpret_cast<f4v*>(ring + c * ECHO_RING + (int)(f & (ECHO_RING - 1))) = f4v{v[c][0], v[c][1], v[c][2], v[c][3]};
+      }
+      if (CT > 0) {  // the tail stage: same input arithmetic, its operands the ones the loop stage had
         float w[CM][4];
 #pragma unroll
-        for (int c = 0; c < CM; c++) w[c][0] = w[c][1] = w[c][2] = w[c][3] = 0.f;
-#pragma unroll
-        for (int k = 0; k < MAX_INPUTS; k++) {
-          if (k >= t.n_inputs) continue;
-          const InputRef& in = t.in[k];
-          const int al = t.alias[k];
+        for (int k = 0; k < NT; k++) {
+          if (!present[NL + k]) continue;
           float u[CM][4];
-#pragma unroll
-          for (int c = 0; c < CM; c++) u[c][0] = u[c][1] = u[c][2] = u[c][3] = 0.f;
-#pragma unroll
-          for (int c = 0; c < C; c++)
-            if (c < in.nch) {
-#pragma unroll
-              for (int e = 0; e < 4; e++) {
-                u[c][e] = al == 0 ? cur[0][c][e] : (al == 1 ? cur[1][c][e] : xd[c][e]);  // (alias -2: the delayed line)
-              }
-            }
-          echo_edge<CM>(in, inst, qc, t.in_nch, t.in_interp, u);
+          edge(NL + k, o.g[NL + k], t_discrete, xd, xa, xb, u);
 #pragma unroll
           for (int c = 0; c < CM; c++)
-            if (c < t.in_nch) {
 #pragma unroll
-              for (int e = 0; e < 4; e++) w[c][e] = k == 0 ? u[c][e] : w[c][e] + u[c][e];
-            }
+            for (int e = 0; e < 4; e++) w[c][e] = k == 0 ? u[c][e] : w[c][e] + u[c][e];
         }
 #pragma unroll
-        for (int c = 0; c < CM; c++)
-          if (c < t.out.nch) {
-            float* po = t.out.base + (uint64_t)inst * t.out.inst_stride + (uint64_t)c * t.out.ch_stride + f;
-            *reinterpret_cast<float4*>(po) = make_float4(w[c][0], w[c][1], w[c][2], w[c][3]);
-          }
+        for (int c = 0; c < CT; c++)  // (CT == the tail's in_nch == out.nch: echo_tail_applicable)
+          *reinterpret_cast<float4*>(pt[c] + f) = make_float4(w[c][0], w[c][1], w[c][2], w[c][3]);
       }
     }
-    __syncthreads();  // the chunk is in the ring before the next one reads behind it
+    // the chunk is in the ring before the next one reads behind it.  (NOT __syncthreads(): its release fence waits for every
+    // outstanding global access, vmcnt(0) — the two chunks of loads in flight and this chunk's stores — at every chunk)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  // Three operand sets in rotation (chunk i uses set i % 3 and requests chunk i + 2 into the set chunk i - 1 used): the
+  // loop is unrolled by three so that no set is ever copied — a register copy of a pending load is a wait for it.
+  EchoOperands<C, NG> o0, o1, o2;
+  const uint32_t n_chunks = (total_sub + cs - 1) / cs, full_chunks = total_sub / cs;
+  fetch(wave, o0);
+  fetch(wave + cs, o1);
+  uint32_t i = 0;
+  const std::false_type plain{};
+  const std::true_type guarded{};
+  for (; i + 3 <= full_chunks; i += 3) {
+    fetch((i + 2) * cs + wave, o2);
+    chunk(o0, i * cs, plain);
+    fetch((i + 3) * cs + wave, o0);
+    chunk(o1, (i + 1) * cs, plain);
+    fetch((i + 4) * cs + wave, o1);
+    chunk(o2, (i + 2) * cs, plain);
   }
+  // (at most two full chunks and a partial one are left; what would be requested now lies past the end)
+  if (i < n_chunks) {
+    fetch((i + 2) * cs + wave, o2);
+    chunk(o0, i * cs, guarded);
+    i++;
+  }
+  if (i < n_chunks) {
+    chunk(o1, i * cs, guarded);
+    i++;
+  }
+  if (i < n_chunks) chunk(o2, i * cs, guarded);
 }
 }  // namespace
 
@@ -228,6 +279,7 @@ int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, 
       return -1;
     }
   }
+  if ((uint64_t)d.n_tiles * TILE >= (1ull << 31)) return -1;  // (32-bit frame arithmetic)
   if (fb < 0 || ((uintptr_t)d.out.base & 15) || (d.out.ch_stride & 3) || (d.out.inst_stride & 3)) return -1;
   // the frames a chunk reads must lie BEHIND the chunk (delay > chunk) and still be in the ring (delay + chunk < ring)
   const float dmin = delay_min_max_frames[0], dmax = delay_min_max_frames[1];
@@ -246,7 +298,7 @@ int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, 
 // count, of delayed(line) — the loop's own delayTime — and of signals the loop step reads too.
 int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t) {
   if (tail.n_ops != 0 || tail.in_nch < d.in_nch || tail.in_nch > 2 || tail.out.nch != tail.in_nch || tail.n_inputs < 1 ||
-      tail.n_inputs > MAX_INPUTS || tail.n_inst != d.n_inst || tail.n_quanta != d.n_quanta)
+      tail.n_inputs > ECHO_TAIL_IN || tail.n_inst != d.n_inst || tail.n_quanta != d.n_quanta)
     return 0;
   if (((uintptr_t)tail.out.base & 15) || (tail.out.ch_stride & 3) || (tail.out.inst_stride & 3) || tail.out.base == d.out.base) return 0;
   const InputRef& fbin = d.in[fb];
@@ -293,17 +345,18 @@ void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const Echo
   EchoTail t{};
   if (tail) t = *tail;
   const dim3 block((unsigned)chunk_subtiles * 64), grid(d.n_inst);
+  const bool store = !tail || tail->store_line;
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, d, fb, chunk_subtiles, t);
   };
   if (d.in_nch == 1) {
-    if (ct == 0) go(echo_ring_kernel<1, 0>);
-    else if (ct == 1) go(echo_ring_kernel<1, 1>);
-    else go(echo_ring_kernel<1, 2>);
+    if (ct == 0) go(echo_ring_kernel<1, 0, true>);
+    else if (ct == 1) store ? go(echo_ring_kernel<1, 1, true>) : go(echo_ring_kernel<1, 1, false>);
+    else store ? go(echo_ring_kernel<1, 2, true>) : go(echo_ring_kernel<1, 2, false>);
   } else {
-    if (ct == 0) go(echo_ring_kernel<2, 0>);
-    else go(echo_ring_kernel<2, 2>);
+    if (ct == 0) go(echo_ring_kernel<2, 0, true>);
+    else store ? go(echo_ring_kernel<2, 2, true>) : go(echo_ring_kernel<2, 2, false>);
   }
 }
 
