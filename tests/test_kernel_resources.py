@@ -76,3 +76,15 @@ def test_element_wise_chain_kernels_keep_their_occupancy(tmp_path):
     assert len(summing) == 1 and summing[0]["vgpr"] <= 80 and summing[0]["spill"] <= 4, summing
     # (the five-wave form that chains with per-frame panning take: no scratch memory at all)
     assert len(nospill) == 1 and nospill[0]["vgpr"] <= 96 and nospill[0]["spill"] == 0 and nospill[0]["scratch"] == 0, nospill
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_echo_ring_kernel_fits_one_workgroup_of_sixteen_waves(tmp_path):
+    """waa_echo.hip: the workgroup is 1024 threads (four wavefronts per SIMD) — more than 128 registers and it does not launch;
+    and nothing of the walk may live in scratch memory (one operand array indexed by an edge's selector did: 47 scratch loads
+    and a hundred waits per chunk)"""
+    res = kernel_resources("waa_echo.hip", tmp_path)
+    k = {n: v for n, v in res.items() if "echo_ring_kernel" in n}
+    assert len(k) == 8, sorted(res)
+    for name, r in k.items():
+        assert r["vgpr"] <= 128 and r["spill"] == 0 and r["scratch"] == 0, (name, r)
