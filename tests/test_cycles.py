@@ -412,6 +412,95 @@ def test_parity_echo_loop_from_the_lds_ring(hip, orc, channels, out_channels, va
     assert np.array_equal(plain, ring)
 
 
+def _random_echo_graph(binding, seed, plan_only=False):
+    """a random member of the echo-loop family: 1-2 sources (mono / stereo, optionally through a Gain that rides on the
+    delay's input edge) into Delay <-> Gain, connection order (= summation order) shuffled, feedback gain constant / per
+    instance / one value per quantum (one of them sometimes 0 or 1: gain.rs' mute and pass-through cases), speakers or
+    discrete up-mix, an explicit stereo line over a mono source, and one of several destinations"""
+    rng = np.random.default_rng(seed)
+    n = 3
+    frames = 2048 * int(rng.integers(6, 11)) + int(rng.integers(0, 300))
+    nq = (frames + RQ - 1) // RQ
+    out_ch = int(rng.integers(1, 3))
+    c = waa.OfflineAudioContext(out_ch, frames, 48000.0, n_instances=n, binding=binding, **({"device": waa.PLAN_ONLY} if plan_only else {}))
+    n_src = int(rng.integers(1, 3))
+    delay = c.create_delay(0.4)
+    if rng.random() < 0.3:
+        delay.set_channel_interpretation("discrete")
+    if rng.random() < 0.25:
+        delay.set_channel_count(2)
+        delay.set_channel_count_mode("explicit")
+    for i in range(n):
+        delay.delay_time.set_value(np.float32(rng.uniform(2057.0, 14000.0) / 48000.0), instance=i)
+    fb = c.create_gain()
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        fb.gain.set_value(float(rng.choice([0.5, -0.8, 0.0, 1.0])))
+    elif kind == 1:
+        for i in range(n):
+            fb.gain.set_value(np.float32(rng.uniform(-0.95, 0.95)), instance=i)
+    else:
+        g = rng.uniform(-0.9, 0.9, nq).astype(np.float32)
+        g[rng.integers(0, nq, 6)] = rng.choice([0.0, 1.0], 6)
+        fb.gain.set_block(0, g)
+    connects = []
+    srcs = []
+    for k in range(n_src):
+        ch = int(rng.integers(1, 3))
+        src = c.create_buffer_source()
+        src.set_buffer_batch(white_noise(n, ch, frames, seed0=seed * 7 + k), 48000.0)
+        src.start()
+        srcs.append(src)
+        head = src
+        if rng.random() < 0.4:
+            head = src.connect(c.create_gain(gain=float(rng.choice([0.7, -1.3, 1.0]))))
+        connects.append(lambda head=head: head.connect(delay))
+    connects.append(lambda: delay.connect(fb).connect(delay))
+    for k in rng.permutation(len(connects)):
+        connects[k]()
+    dest = int(rng.integers(0, 5))
+    if dest == 0:      # dry + wet
+        srcs[0].connect(c.destination())
+        delay.connect(c.destination())
+    elif dest == 1:    # wet + dry, the other order
+        delay.connect(c.destination())
+        srcs[-1].connect(c.destination())
+    elif dest == 2:    # wet only
+        delay.connect(c.destination())
+    elif dest == 3:    # a reader with an op of its own
+        delay.connect(c.create_gain(gain=0.6)).connect(c.destination())
+    else:              # two readers
+        delay.connect(c.destination())
+        delay.connect(c.create_wave_shaper(curve=np.float32([-0.5, 0.0, 0.8]))).connect(c.destination())
+    plan = c.plan_describe() if binding.prefix == "waa_" else ""
+    out = None if plan_only else c.start_rendering_sync().data
+    c.close()
+    return out, plan
+
+
+def test_random_echo_loops_mostly_qualify_for_the_ring(hip):
+    """(CPU) the family of the GPU test below is planned as intended: most members through the LDS-ring kernel, a good part
+    with the tail stage, nothing refused"""
+    plans = [_random_echo_graph(hip, 9000 + seed, plan_only=True)[1] for seed in range(40)]
+    ring = sum("LDS-ring kernel in ONE launch" in p for p in plans)
+    fused = sum("the line is not stored" in p for p in plans)
+    assert ring >= 25 and fused >= 8, (ring, fused)
+
+
+@pytest.mark.gpu
+def test_parity_random_echo_loops(hip, orc):
+    """40 random members of the echo-loop family, every one bit-identical to the oracle; most of them through the LDS-ring
+    kernel, a good part with the tail stage"""
+    ring = fused = 0
+    for seed in range(40):
+        g, plan = _random_echo_graph(hip, 9000 + seed)
+        o, _ = _random_echo_graph(orc, 9000 + seed)
+        assert np.array_equal(g, o), (seed, float(np.abs(g - o).max()), plan)
+        ring += "LDS-ring kernel in ONE launch" in plan
+        fused += "the line is not stored" in plan
+    assert ring >= 25 and fused >= 8, (ring, fused)
+
+
 @pytest.mark.gpu
 def test_echo_loop_past_the_lds_ring_window(hip, orc):
     """one instance's delay is a frame past what the smallest chunk reaches (16384 - 4*256 - 8 = 15352 frames): the

@@ -296,14 +296,20 @@ int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, 
 
 // The chain step `tail` (outside the loop) as the tail stage of the ring kernel: a plain sum, to at least the line's channel
 // count, of delayed(line) — the loop's own delayTime — and of signals the loop step reads too.
-int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t) {
-  if (tail.n_ops != 0 || tail.in_nch < d.in_nch || tail.in_nch > 2 || tail.out.nch != tail.in_nch || tail.n_inputs < 1 ||
-      tail.n_inputs > ECHO_TAIL_IN || tail.n_inst != d.n_inst || tail.n_quanta != d.n_quanta)
+int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t, const char** why) {
+  auto no = [&](const char* reason) {
+    *why = reason;
     return 0;
-  if (((uintptr_t)tail.out.base & 15) || (tail.out.ch_stride & 3) || (tail.out.inst_stride & 3) || tail.out.base == d.out.base) return 0;
+  };
+  if (tail.n_ops != 0) return no("it has ops of its own");
+  if (tail.in_nch < d.in_nch || tail.in_nch > 2 || tail.out.nch != tail.in_nch) return no("it mixes the line down, or to more than two channels");
+  if (tail.n_inputs < 1 || tail.n_inputs > ECHO_TAIL_IN) return no("it sums more than three inputs");
+  if (tail.n_inst != d.n_inst || tail.n_quanta != d.n_quanta) return no("it covers another range");
+  if (((uintptr_t)tail.out.base & 15) || (tail.out.ch_stride & 3) || (tail.out.inst_stride & 3) || tail.out.base == d.out.base)
+    return no("its output is not 16-byte aligned");
   const InputRef& fbin = d.in[fb];
   for (int j = 0; j < d.n_inputs; j++)
-    if (d.in[j].sig.base == tail.out.base) return 0;  // (rendered in place over something the loop still reads)
+    if (d.in[j].sig.base == tail.out.base) return no("it renders in place over a signal the loop reads");
   EchoTail r{};
   r.n_inputs = tail.n_inputs;
   r.in_nch = tail.in_nch;
@@ -312,14 +318,15 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
   bool reads_line = false;
   for (int k = 0; k < tail.n_inputs; k++) {
     const InputRef& in = tail.in[k];
-    if (in.has_gain && !(in.gain.mode == 0 || in.gain.mode == 1)) return 0;
-    if (in.nch != tail.in_nch && !(in.nch == 1 && tail.in_nch == 2)) return 0;
+    if (in.has_gain && !(in.gain.mode == 0 || in.gain.mode == 1)) return no("an edge gain of it has a value per frame");
+    if (in.nch != tail.in_nch && !(in.nch == 1 && tail.in_nch == 2)) return no("an input of it is mixed by a computed rule");
     r.in[k] = in;
     r.alias[k] = -1;
     if (in.kind == IN_DELAYED) {
+      // (a line belongs to ONE DelayNode: every delayed read of it is by that node's delayTime, the loop's own)
       if (in.sig.base != d.out.base || in.sig.inst_stride != d.out.inst_stride || in.sig.ch_stride != d.out.ch_stride ||
           in.nch != d.in_nch || !(in.offset.mode == 0 || in.offset.mode == 3) || in.sample_rate != fbin.sample_rate)
-        return 0;  // (a line belongs to ONE DelayNode: every delayed read of it is by that node's delayTime, the loop's own)
+        return no("it reads another delay line too");
       r.alias[k] = -2;
       reads_line = true;
     } else if (in.kind == IN_SIGNAL) {
@@ -329,12 +336,12 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
             lj.sig.ch_stride == in.sig.ch_stride && lj.nch == in.nch && lj.valid == in.valid)
           r.alias[k] = j - (j > fb ? 1 : 0);  // (its register slot)
       }
-      if (r.alias[k] < 0) return 0;
+      if (r.alias[k] < 0) return no("it sums a signal the loop does not read");
     } else {
-      return 0;
+      return no("it has a source or constant input");
     }
   }
-  if (!reads_line) return 0;
+  if (!reads_line) return no("it does not read the line");
   *t = r;
   return 1;
 }

@@ -626,7 +626,7 @@ struct EchoTail {
   SignalRef out;
 };
 int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, int* chunk_subtiles);
-int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t);
+int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t, const char** why);
 void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const EchoTail* tail, void* stream);
 // dst[inst][q] = src[inst * inst_stride + q * 128]: the first frame of every render quantum of a per-frame table
 void launch_quantum_heads(const float* src, uint64_t inst_stride, uint32_t n_inst, uint32_t n_quanta, float* dst, void* stream);

@@ -2345,8 +2345,9 @@ void fuse_echo_tails(waa_batch* b) {
     }
     Step& ts = b->steps[reader];
     EchoTail t{};
-    if (ts.kind != 0 || ts.group >= 0 || !echo_tail_applicable(ls.chain, ls.echo_fb, ts.chain, &t)) {
-      plan_note(b, "echo loop: launch %zu, the only reader of the delay line, is not a plain sum of the delayed line and of the loop's inputs: the line is stored", reader);
+    const char* why = "it is not an element-wise launch";
+    if (ts.kind != 0 || ts.group >= 0 || !echo_tail_applicable(ls.chain, ls.echo_fb, ts.chain, &t, &why)) {
+      plan_note(b, "echo loop: launch %zu, the only reader of the delay line, is not a plain sum of the delayed line and of the loop's inputs (%s): the line is stored", reader, why);
       continue;
     }
     t.store_line = 0;
