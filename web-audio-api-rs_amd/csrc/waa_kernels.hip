@@ -1002,7 +1002,9 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
         break;
       }
     const size_t lds = dd.lds_curve_op >= 0 ? (size_t)d.ops[dd.lds_curve_op].i0 * sizeof(float) : 0;
-    // (8 frames per lane instead of 4 was measured: fewer waves fit per SIMD and every workload got slower)
+    // (8 frames per lane instead of 4 was measured: fewer waves fit per SIMD and every workload got slower.  So were 2 / 4 / 8
+    // consecutive sub-tiles per wavefront, round 3: echo 2.06-2.14 -> 2.11-2.29 ms, C4's pan stage 1.40 -> 1.75 ms — it is
+    // not the number of waves launched; a wavefront that walks its stream needs the next sub-tile in flight, see waa_echo.hip)
     const uint64_t waves = (uint64_t)d.n_inst * (d.tile1 - d.tile0) * (TILE / 256);
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     if (d.persist_block) {  // (mono / stereo only: the caller checks)
