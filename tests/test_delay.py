@@ -353,3 +353,74 @@ def test_folded_delay_in_a_block_scheduled_loop(hip, orc, monkeypatch):
     ref, _ = render(orc)
     assert np.array_equal(folded, plain)
     assert rms_err(folded, ref).max() <= 1e-7
+
+
+def _ff_echo(binding, noise, delays, variant, length=None, plan_only=False):
+    """the feed-forward echo family the LDS-ring kernel renders with nothing fed back (waa_echo.hip, echo_feed_forward):
+    dry+wet  src -> destination, src -> Delay -> Gain(0.5) -> destination
+    wet+dry  the same, connected in the other order (the other summation order)
+    wet      src -> Delay -> destination only
+    other    the wet path plus ANOTHER source into the destination (stays on the tile-parallel kernel)"""
+    n_inst, n_ch, frames = noise.shape
+    c = waa.OfflineAudioContext(2, length or frames, 48000.0, n_instances=n_inst, binding=binding,
+                                **({"device": waa.PLAN_ONLY} if plan_only else {}))
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    d = c.create_delay(0.4)
+    for i in range(n_inst):
+        d.delay_time.set_value(delays[i], instance=i)
+    if variant == "dry+wet":
+        src.connect(c.destination())
+    if variant == "wet":
+        src.connect(d).connect(c.destination())
+    else:
+        src.connect(d).connect(c.create_gain(gain=0.5)).connect(c.destination())
+    if variant == "wet+dry":
+        src.connect(c.destination())
+    if variant == "other":
+        o2 = c.create_buffer_source()
+        o2.set_buffer_batch(noise[:, :, ::-1].copy(), 48000.0)
+        o2.connect(c.destination())
+        o2.start()
+    src.start()
+    plan = c.plan_describe() if binding.prefix == "waa_" else ""
+    out = None if plan_only else c.start_rendering_sync().data
+    c.close()
+    return out, plan
+
+
+FF_DELAYS = (np.float64([1032, 1033.5, 3000.25, 4800, 9000.75, 15352]) / 48000.0).astype(np.float32)
+
+
+@pytest.mark.parametrize("variant,ring", [("dry+wet", True), ("wet+dry", True), ("wet", True), ("other", False)])
+def test_plan_feed_forward_echo_out_of_the_ring(hip, variant, ring, monkeypatch):
+    noise = white_noise(6, 2, 2048 * 4, seed0=5)
+    assert "LDS-ring" not in _ff_echo(hip, noise, FF_DELAYS, variant, plan_only=True)[1]   # (6 instances: below one per CU)
+    monkeypatch.setenv("WAA_ECHO_FF_MIN_INST", "1")
+    plan = _ff_echo(hip, noise, FF_DELAYS, variant, plan_only=True)[1]
+    assert ("LDS-ring kernel with nothing fed back: delay 1032 .. 15352 frames, chunks of 1024 frames" in plan) == ring
+    if not ring:
+        assert "sums a delayed signal but keeps the tile-parallel kernel: it " in plan   # (... has an input that is not X)
+    late = FF_DELAYS.copy()
+    late[0] = np.float32(1031.0 / 48000.0)
+    assert "keeps the tile-parallel kernel: a delay outside the ring's window" in _ff_echo(hip, noise, late, "wet", plan_only=True)[1]
+    monkeypatch.setenv("WAA_NO_ECHO_FF", "1")
+    assert "LDS-ring" not in _ff_echo(hip, noise, FF_DELAYS, variant, plan_only=True)[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [1, 2])
+@pytest.mark.parametrize("variant", ["dry+wet", "wet+dry", "wet", "other"])
+def test_parity_feed_forward_echo_out_of_the_ring(hip, orc, variant, channels, monkeypatch):
+    """bit-identical to the tile-parallel launch and to the oracle: delays at both ends of the window, a ragged length,
+    a mono source up-mixed by the destination, and a source that ends before the render does (zeros beyond its view)"""
+    n, frames, length = 6, 2048 * 9 + 100, 2048 * 11 + 77
+    noise = white_noise(n, channels, frames if channels == 1 else length, seed0=41)
+    monkeypatch.setenv("WAA_ECHO_FF_MIN_INST", "1")
+    ring, plan = _ff_echo(hip, noise, FF_DELAYS, variant, length=length)
+    assert ("LDS-ring kernel with nothing fed back" in plan) == (variant != "other")
+    o, _ = _ff_echo(orc, noise, FF_DELAYS, variant, length=length)
+    assert np.array_equal(ring, o)
+    monkeypatch.setenv("WAA_NO_ECHO_FF", "1")
+    plain, plan = _ff_echo(hip, noise, FF_DELAYS, variant, length=length)
+    assert "LDS-ring" not in plan and np.array_equal(plain, ring)

@@ -888,6 +888,13 @@ static int run_steps(waa_batch* b) {
         break;
       }
       default: {
+        if (st.echo_ff && t0 == 0 && t1 == b->n_tiles) {  // the feed-forward echo out of the LDS ring (waa_echo.hip)
+          ChainDesc d = st.echo_line;
+          d.tile0 = t0;
+          d.tile1 = t1;
+          e = timed(st.profile_slot, [&] { launch_echo_ring(d, d.n_inputs, st.echo_chunk, &st.echo_tail, b->stream); });
+          break;
+        }
         ChainDesc d = st.chain;
         d.tile0 = t0;
         d.tile1 = t1;

@@ -61,8 +61,8 @@ __global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int 
   for (int i = tid; i < C * ECHO_RING; i += blockDim.x) ring[i] = 0.f;
   __syncthreads();
   // DelayReader's position arithmetic (delay.rs:560-569), one delayTime per instance
-  const float dv = echo_delay_value(d.in[fb].offset, inst);
-  const double position = 0. - (double)dv * d.in[fb].sample_rate;
+  const float dv = echo_delay_value(t.delay, inst);
+  const double position = 0. - (double)dv * t.sample_rate;
   const double fl = floor(position);
   const int32_t pf0 = (int32_t)fl;  // (-ECHO_RING < pf0 < 0: echo_ring_applicable)
   const float kf = (float)(position - fl);
@@ -258,6 +258,8 @@ __global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int 
 }
 }  // namespace
 
+static int echo_chunk_for(float dmin, float dmax);
+
 // The loop step `d` (one element-wise launch per block, ChainDesc::tile0 / tile1 = the whole render) as the LDS-ring kernel?
 // Returns the index of the feedback input and the chunk size (sub-tiles of 256 frames), or -1.
 int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, int* chunk_subtiles) {
@@ -281,15 +283,8 @@ int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, 
   }
   if ((uint64_t)d.n_tiles * TILE >= (1ull << 31)) return -1;  // (32-bit frame arithmetic)
   if (fb < 0 || ((uintptr_t)d.out.base & 15) || (d.out.ch_stride & 3) || (d.out.inst_stride & 3)) return -1;
-  // the frames a chunk reads must lie BEHIND the chunk (delay > chunk) and still be in the ring (delay + chunk < ring)
-  const float dmin = delay_min_max_frames[0], dmax = delay_min_max_frames[1];
-  int ch = 0;
-  for (int cand : {16, 8, 4})
-    if ((float)(cand * 256 + 8) <= dmin) {
-      ch = cand;
-      break;
-    }
-  if (!ch || dmax > (float)(ECHO_RING - ch * 256 - 8)) return -1;
+  const int ch = echo_chunk_for(delay_min_max_frames[0], delay_min_max_frames[1]);
+  if (!ch) return -1;
   *chunk_subtiles = ch;
   return fb;
 }
@@ -307,7 +302,7 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
   if (tail.n_inst != d.n_inst || tail.n_quanta != d.n_quanta) return no("it covers another range");
   if (((uintptr_t)tail.out.base & 15) || (tail.out.ch_stride & 3) || (tail.out.inst_stride & 3) || tail.out.base == d.out.base)
     return no("its output is not 16-byte aligned");
-  const InputRef& fbin = d.in[fb];
+  const double line_rate = fb < d.n_inputs ? d.in[fb].sample_rate : 0.;  // (0: nothing fed back, echo_feed_forward)
   for (int j = 0; j < d.n_inputs; j++)
     if (d.in[j].sig.base == tail.out.base) return no("it renders in place over a signal the loop reads");
   EchoTail r{};
@@ -325,7 +320,7 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
     if (in.kind == IN_DELAYED) {
       // (a line belongs to ONE DelayNode: every delayed read of it is by that node's delayTime, the loop's own)
       if (in.sig.base != d.out.base || in.sig.inst_stride != d.out.inst_stride || in.sig.ch_stride != d.out.ch_stride ||
-          in.nch != d.in_nch || !(in.offset.mode == 0 || in.offset.mode == 3) || in.sample_rate != fbin.sample_rate)
+          in.nch != d.in_nch || !(in.offset.mode == 0 || in.offset.mode == 3) || (line_rate != 0. && in.sample_rate != line_rate))
         return no("it reads another delay line too");
       r.alias[k] = -2;
       reads_line = true;
@@ -346,11 +341,67 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
   return 1;
 }
 
+static int echo_chunk_for(float dmin, float dmax) {
+  // the frames a chunk reads must lie BEHIND the chunk (delay > chunk) and still be in the ring (delay + chunk < ring)
+  for (int cand : {16, 8, 4})
+    if ((float)(cand * 256 + 8) <= dmin) return dmax > (float)(ECHO_RING - cand * 256 - 8) ? 0 : cand;
+  return 0;
+}
+
+int echo_feed_forward(const ChainDesc& st, ChainDesc* line, EchoTail* tail, const char** why) {
+  auto no = [&](const char* reason) {
+    *why = reason;
+    return 0;
+  };
+  int dk = -1;
+  for (int k = 0; k < st.n_inputs; k++)
+    if (st.in[k].kind == IN_DELAYED) {
+      if (dk >= 0) return no("two delayed inputs");
+      dk = k;
+    }
+  if (dk < 0) return no("no delayed input");
+  const InputRef& D = st.in[dk];
+  if (D.feedback) return no("the delay line is written inside a loop");
+  if (!(D.offset.mode == 0 || D.offset.mode == 3) || D.delay_hi < D.delay_lo) return no("the delay is not one host-known value per instance");
+  const int chunk = echo_chunk_for(D.delay_lo, D.delay_hi);
+  if (!chunk) return no("a delay outside the ring's window");
+  if ((uint64_t)st.n_tiles * TILE >= (1ull << 31)) return no("more than 2^31 frames");
+  if (D.nch < 1 || D.nch > 2 || ((uintptr_t)D.sig.base & 15) || (D.sig.ch_stride & 3) || (D.sig.inst_stride & 3))
+    return no("the delayed signal is wider than stereo or not 16-byte aligned");
+  // the stand-in loop stage: line = X, nothing fed back, never stored
+  ChainDesc l{};
+  l.n_inputs = 1;
+  l.in_nch = D.nch;
+  l.in[0].kind = IN_SIGNAL;
+  l.in[0].nch = D.nch;
+  l.in[0].sig = D.sig;
+  l.in[0].valid = D.valid;
+  l.out = D.sig;
+  l.out.nch = D.nch;
+  l.n_inst = st.n_inst;
+  l.n_tiles = st.n_tiles;
+  l.n_quanta = st.n_quanta;
+  l.tile0 = 0;
+  l.tile1 = st.n_tiles;
+  EchoTail t{};
+  if (!echo_tail_applicable(l, l.n_inputs, st, &t, why)) return 0;
+  t.store_line = 0;
+  t.delay = D.offset;
+  t.sample_rate = D.sample_rate;
+  *line = l;
+  *tail = t;
+  return chunk;
+}
+
 void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const EchoTail* tail, void* stream) {
   const size_t lds = (size_t)d.in_nch * ECHO_RING * sizeof(float);
   const int ct = tail ? tail->in_nch : 0;
   EchoTail t{};
   if (tail) t = *tail;
+  if (fb < d.n_inputs) {
+    t.delay = d.in[fb].offset;
+    t.sample_rate = d.in[fb].sample_rate;
+  }
   const dim3 block((unsigned)chunk_subtiles * 64), grid(d.n_inst);
   const bool store = !tail || tail->store_line;
   auto go = [&](auto kern) {

@@ -239,6 +239,10 @@ struct Step {
   int echo_tail_step = -1;
   EchoTail echo_tail{};
   bool echo_fused = false;
+  // a chain step outside any loop rendered by the ring kernel with nothing fed back (echo_feed_forward): the stand-in loop
+  // stage; echo_tail / echo_chunk as above
+  bool echo_ff = false;
+  ChainDesc echo_line{};
 };
 
 }  // namespace host

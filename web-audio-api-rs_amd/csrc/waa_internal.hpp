@@ -90,6 +90,8 @@ struct InputRef {
   ParamRef gain;          // has_gain: a GainNode folded into this edge (applied before the mix to the receiver's count)
   int32_t has_gain;
   uint32_t fast_tiles;    // IN_SOURCE (host side): tiles [0, fast_tiles) are fast and one linear run for every instance
+  float delay_lo, delay_hi;  // IN_DELAYED (host side): range of the delay over all instances, in frames (hi < lo: not one
+                             // host-known value per instance)
 };
 
 enum : int32_t {
@@ -624,8 +626,14 @@ struct EchoTail {
   InputRef in[MAX_INPUTS];
   int32_t alias[MAX_INPUTS];  // -2: the delayed line; s >= 0: the same signal as the loop step's s-th input from outside the loop
   SignalRef out;
+  ParamRef delay;             // the DelayNode's delayTime (mode 0 or 3) and rate: set by the launcher from the feedback
+  double sample_rate;         // input, or by echo_feed_forward for a line that is not fed back
 };
 int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, int* chunk_subtiles);
+// a chain step OUTSIDE any loop that sums delayed(X) with X itself and at most one other signal, no ops (the feed-forward
+// echo): the same kernel with nothing fed back — X goes through the ring instead of being read twice.  Fills the stand-in
+// loop stage (`line` = X) and the tail; returns the chunk size or 0.
+int echo_feed_forward(const ChainDesc& step, ChainDesc* line, EchoTail* tail, const char** why);
 int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t, const char** why);
 void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const EchoTail* tail, void* stream);
 // dst[inst][q] = src[inst * inst_stride + q * 128]: the first frame of every render quantum of a per-frame table

@@ -209,6 +209,21 @@ int build_edge_input(waa_batch* b, uint32_t head, int ie, InputRef* out) {
         in.offset.stride = bits;
       }
     }
+    in.delay_lo = 1.f;
+    in.delay_hi = 0.f;
+    {
+      const ParamStore& ps = pn.params[WAA_PARAM_DELAY_DELAY_TIME];
+      if ((in.offset.mode == 0 || in.offset.mode == 3) && !ps.dev_tl && ps.blocks.empty()) {
+        float lo = 1e30f, hi = 0.f;
+        for (uint32_t i = 0; i < b->n_inst; i++) {
+          const float fr = ps.fix(ps.cst[i]) * b->sr;
+          lo = std::min(lo, fr);
+          hi = std::max(hi, fr);
+        }
+        in.delay_lo = lo;
+        in.delay_hi = hi;
+      }
+    }
     in.sample_rate = (double)b->sr;
     in.num_quanta = (int32_t)std::ceil(pn.desc.d[0] * (double)b->sr / (double)RQ);
     in.valid = pn.hist_valid;
@@ -667,6 +682,7 @@ namespace {
 StepIo step_io(const Step& st);
 }
 void fuse_echo_tails(waa_batch* b);
+void ring_feed_forward_echoes(waa_batch* b);
 int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items);
 int plan_delay_writer(waa_batch* b, uint32_t id);
 int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr);
@@ -2187,6 +2203,7 @@ int build_plan(waa_batch* b) {
     if (e) return e;
   }
   fuse_echo_tails(b);
+  ring_feed_forward_echoes(b);
   // (self-test of the check below: a reversed launch list must not get past it, tests/test_plan.py)
   if (getenv("WAA_DEBUG_REVERSE_PLAN")) std::reverse(b->steps.begin(), b->steps.end());
   if (int e = validate_plan(b)) return e;
@@ -2356,6 +2373,44 @@ void fuse_echo_tails(waa_batch* b) {
     ts.echo_fused = true;
     plan_note(b, "echo loop: launch %zu (the only reader of the loop's delay line: %d input(s) -> %d channel(s)) is rendered by the LDS-ring kernel too; the line is not stored",
               reader, t.n_inputs, t.in_nch);
+  }
+}
+
+// The feed-forward echo  out = X + g * delayed(X)  as a chain launch reads X twice (the second time mostly out of L2) from
+// short-lived wavefronts, one per 256 frames: 3.8 TB/s on its compulsory bytes.  The ring kernel walks every instance's
+// stream with two chunks in flight and takes the delayed samples from LDS: 5 TB/s — when there is at least one instance
+// per CU to walk (WAA_ECHO_FF_MIN_INST, default 256: below that the tile-parallel launch fills the device better).
+void ring_feed_forward_echoes(waa_batch* b) {
+  if (getenv("WAA_NO_ECHO_RING") || getenv("WAA_NO_ECHO_FF")) return;
+  const char* mi = getenv("WAA_ECHO_FF_MIN_INST");
+  if (b->n_inst < (uint32_t)(mi ? atoi(mi) : 256)) return;
+  for (size_t k = 0; k < b->steps.size(); k++) {
+    Step& st = b->steps[k];
+    if (st.kind != 0 || st.group >= 0 || st.echo_fused || st.chain.n_ops != 0) continue;
+    bool any = false;
+    for (int q = 0; q < st.chain.n_inputs; q++) any |= st.chain.in[q].kind == IN_DELAYED;
+    if (!any) continue;
+    const char* why = "";
+    ChainDesc line{};
+    EchoTail t{};
+    const int chunk = echo_feed_forward(st.chain, &line, &t, &why);
+    if (!chunk) {
+      plan_note(b, "launch %zu sums a delayed signal but keeps the tile-parallel kernel: %s", k, why);
+      continue;
+    }
+    float delayed_lo = 0.f, delayed_hi = 0.f;
+    for (int q = 0; q < st.chain.n_inputs; q++)
+      if (st.chain.in[q].kind == IN_DELAYED) {
+        delayed_lo = st.chain.in[q].delay_lo;
+        delayed_hi = st.chain.in[q].delay_hi;
+      }
+    st.echo_ff = true;
+    st.echo_line = line;
+    st.echo_tail = t;
+    st.echo_chunk = chunk;
+    st.profile_slot = slot_for(b, "echo_ring_kernel");
+    plan_note(b, "launch %zu (delayed signal + %d more input(s), no ops) is rendered by the LDS-ring kernel with nothing fed back: delay %.0f .. %.0f frames, chunks of %d frames",
+              k, t.n_inputs - 1, (double)delayed_lo, (double)delayed_hi, chunk * 256);
   }
 }
 
