@@ -302,6 +302,8 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
   if (tail.n_inst != d.n_inst || tail.n_quanta != d.n_quanta) return no("it covers another range");
   if (((uintptr_t)tail.out.base & 15) || (tail.out.ch_stride & 3) || (tail.out.inst_stride & 3) || tail.out.base == d.out.base)
     return no("its output is not 16-byte aligned");
+  // (frames that may be read: 0 = no limit, and so is any limit past the rendered range)
+  auto limit = [&](uint64_t valid) { return valid >= (uint64_t)d.n_tiles * TILE ? (uint64_t)0 : valid; };
   const double line_rate = fb < d.n_inputs ? d.in[fb].sample_rate : 0.;  // (0: nothing fed back, echo_feed_forward)
   for (int j = 0; j < d.n_inputs; j++)
     if (d.in[j].sig.base == tail.out.base) return no("it renders in place over a signal the loop reads");
@@ -328,7 +330,7 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
       for (int j = 0; j < d.n_inputs; j++) {
         const InputRef& lj = d.in[j];
         if (j != fb && lj.kind == IN_SIGNAL && lj.sig.base == in.sig.base && lj.sig.inst_stride == in.sig.inst_stride &&
-            lj.sig.ch_stride == in.sig.ch_stride && lj.nch == in.nch && lj.valid == in.valid)
+            lj.sig.ch_stride == in.sig.ch_stride && lj.nch == in.nch && limit(lj.valid) == limit(in.valid))
           r.alias[k] = j - (j > fb ? 1 : 0);  // (its register slot)
       }
       if (r.alias[k] < 0) return no("it sums a signal the loop does not read");
