@@ -20,7 +20,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 #include "waa_internal.hpp"
 
@@ -407,7 +410,15 @@ void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const Echo
   const dim3 block((unsigned)chunk_subtiles * 64), grid(d.n_inst);
   const bool store = !tail || tail->store_line;
   auto go = [&](auto kern) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static std::mutex lock;
+    static std::set<std::pair<int, const void*>> raised;  // (the LDS limit of an instantiation is raised once per device)
+    {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      std::lock_guard<std::mutex> g(lock);
+      if (raised.insert({dev, reinterpret_cast<const void*>(kern)}).second)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, d, fb, chunk_subtiles, t);
   };
   if (d.in_nch == 1) {
