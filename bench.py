@@ -313,7 +313,9 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
     kernel_ms_per_step = sum(ms for _, _, ms in prof) / total_launch_steps
     dom = prof[0] if prof else ("none", 1, float("nan"))
     alg_bytes_step = ALG_BYTES[name] * n_inst * nq
-    pmc, pmc_why = pmc_record(name, n_inst, frames, sum(launches_per_step.values()))
+    # (one event-timed slot of the lane-per-stream Biquad covers its three kernels: pass A, tile-state chain, pass B)
+    kernels_per_slot = {"biquad_lanes_kernel": 3}
+    pmc, pmc_why = pmc_record(name, n_inst, frames, sum(l * kernels_per_slot.get(n_, 1) for n_, l in launches_per_step.items()))
     single = len(prof) == 1 and max(launches_per_step.values(), default=1) <= 1.5
     roof = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "kernel_ms": kernel_ms, "launches_per_step": launches_per_step,
             "kernel_ms_per_step": kernel_ms_per_step}
