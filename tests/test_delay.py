@@ -408,6 +408,16 @@ def test_plan_feed_forward_echo_out_of_the_ring(hip, variant, ring, monkeypatch)
     assert "LDS-ring" not in _ff_echo(hip, noise, FF_DELAYS, variant, plan_only=True)[1]
 
 
+def test_plan_feed_forward_echo_takes_the_ring_from_one_instance_per_cu(hip):
+    """the default threshold: 256 instances (one per CU of an MI355X) and the echo goes through the ring kernel, 255 and it
+    keeps the tile-parallel launch"""
+    for n, ring in ((255, False), (256, True)):
+        noise = np.zeros((n, 1, 2048 * 2), np.float32)
+        delays = np.full(n, 4800.0 / 48000.0, np.float32)
+        plan = _ff_echo(hip, noise, delays, "dry+wet", plan_only=True)[1]
+        assert ("LDS-ring kernel with nothing fed back" in plan) == ring, n
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("channels", [1, 2])
 @pytest.mark.parametrize("variant", ["dry+wet", "wet+dry", "wet", "other"])
