@@ -380,3 +380,36 @@ def test_parity_oscillator_behind_an_analyser_with_two_readers(hip, orc):
     assert np.abs(outs[0] - outs[1]).max() <= 2e-5 and np.abs(outs[1]).max() > 0.1
     finite = np.isfinite(bins[1])
     assert np.abs(bins[0][finite] - bins[1][finite]).max() <= 0.05
+
+
+def test_plan_replay_shortcut_agrees_with_the_frame_walk(hip, monkeypatch):
+    """plan_oscillator skips the 128-frame walk of a quantum that lies wholly inside [start, stop) (it was 2.4 s of a
+    1024-context plan); with WAA_OSC_PLAN_CHECK=1 every quantum is walked anyway and a shortcut that would have answered
+    differently fails the plan (status 3).  Random start / stop times — on quantum boundaries, a frame or a fraction of a
+    frame beside them, inside one quantum, never — for the constant-frequency (closed-form) and the a-rate (prefix-sum) plans."""
+    monkeypatch.setenv("WAA_OSC_PLAN_CHECK", "1")
+    rng = np.random.default_rng(77)
+    sr = 48000.0
+    for trial in range(60):
+        frames = int(rng.integers(1, 40)) * 128 + int(rng.integers(0, 128))
+        n = 8
+        c = waa.OfflineAudioContext(1, frames, sr, n_instances=n, binding=hip, device=waa.PLAN_ONLY)
+        osc = c.create_oscillator(type_="sawtooth", frequency=float(rng.uniform(20.0, 9000.0)))
+        if trial % 2:
+            osc.frequency.set_value_at_time(100.0, 0.0)
+            osc.frequency.linear_ramp_to_value_at_time(3000.0, frames / sr)
+        for i in range(n):
+            q0 = int(rng.integers(0, max(1, frames // 128)))
+            kind = int(rng.integers(0, 6))
+            start = [0.0, q0 * 128 / sr, (q0 * 128 + 1) / sr, (q0 * 128 - 0.25) / sr, (q0 * 128 + 64.5) / sr,
+                     float(np.nextafter(q0 * 128 / sr, 1.0))][kind]
+            osc.start_at(max(start, 0.0), instance=i)
+            if rng.random() < 0.7:
+                q1 = q0 + int(rng.integers(0, 12))
+                kind = int(rng.integers(0, 6))
+                stop = [(q1 + 1) * 128 / sr, ((q1 + 1) * 128 + 1) / sr, ((q1 + 1) * 128 - 1) / sr, (q1 * 128 + 77.3) / sr,
+                        float(np.nextafter((q1 + 1) * 128 / sr, 0.0)), float(np.nextafter((q1 + 1) * 128 / sr, 1.0))][kind]
+                osc.stop_at(max(stop, max(start, 0.0)), instance=i)
+        osc.connect(c.destination())
+        assert "oscillator node" in c.plan_describe()
+        c.close()

@@ -142,6 +142,10 @@ static int plan_link(waa_batch* b, uint32_t id, int kind, int src_id, uint32_t t
     std::vector<int32_t> hp((size_t)b->n_inst * b->n_quanta);
     for (uint32_t i = 0; i < b->n_inst; i++) {
       const uint8_t* row = host_codes.data() + (size_t)i * cs;
+      if (i > 0 && std::memcmp(row, row - cs, b->n_quanta) == 0) {  // the same codes as the previous instance: the same links
+        std::copy(hp.begin() + (size_t)(i - 1) * b->n_quanta, hp.begin() + (size_t)i * b->n_quanta, hp.begin() + (size_t)i * b->n_quanta);
+        continue;
+      }
       int32_t last = LINK_FRESH;
       int cur_ch = 1;             // kind 0: channels_x2 / channels_x4 start at 1 (waveshaper.rs:526-527)
       uint64_t tail_counter = 0;  // kind 1: only ever grows (panner.rs:697-711)

@@ -1,6 +1,7 @@
 // waa_plan.cpp — the planner: processing order with the reference's cycle breaker, liveness, static channel
 // counts, materialisation points, fusion of single-consumer paths into chain launches, node-major steps
 // (convolver, delay, oscillator, IIR), feedback loops (block-scheduled or quantum-serial), AudioParam chains.
+#include <array>
 #include <set>
 
 #include "waa_host.hpp"
@@ -1103,11 +1104,18 @@ int build_plan(waa_batch* b) {
           add_sig(shift_hi[id]);
         } else if (kind == WAA_NODE_GAIN && param_mode(n, 0) != 2) {
           const auto gv = param_per_quantum(b, n.params[0], inst, nullptr);
-          zero_gain[id].assign(nq, 0);
           bool any = false;
-          for (uint32_t q = 0; q < nq; q++) {
-            zero_gain[id][q] = std::fabs(gv[gv.size() == 1 ? 0 : q]) <= 1e-6f;
-            any |= zero_gain[id][q] != 0;
+          if (gv.size() == 1) {
+            // one value for the whole render (the usual case): no per-quantum table unless that value is a zero —
+            // filling and scanning n_quanta entries per instance and GainNode was 7.7 ms of a 1024-context plan
+            any = std::fabs(gv[0]) <= 1e-6f;
+            if (any) zero_gain[id].assign(nq, 1);
+          } else {
+            zero_gain[id].assign(nq, 0);
+            for (uint32_t q = 0; q < nq; q++) {
+              zero_gain[id][q] = std::fabs(gv[q]) <= 1e-6f;
+              any |= zero_gain[id][q] != 0;
+            }
           }
           if (!any) zero_gain[id].clear();
           for (uint8_t z : zero_gain[id]) sig.push_back((char)z);
@@ -2667,7 +2675,16 @@ int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const Signa
 }
 
 // OscillatorNode (oscillator.rs:323-660): one kernel, one lane per instance (the phase accumulator is serial)
+// Is every frame of the quantum [block_time, next_block_time) inside [start_time, stop_time) — also for the reference's
+// clock, which reaches frame k by k additions of dt (rounding: far below the one-frame margin asked of stop_time)?
+// Then OscillatorRenderer::process renders frames 0 .. 127 and the replay below need not walk them.
+static inline bool osc_quantum_fully_active(double block_time, double next_block_time, double start_time, double stop_time, double dt) {
+  return start_time <= block_time && stop_time >= next_block_time + dt;
+}
+
 int plan_oscillator(waa_batch* b, uint32_t id) {
+  // WAA_OSC_PLAN_CHECK=1 (tests): every quantum is walked frame by frame as before and the shortcut's answer is checked
+  const bool check_replay = getenv("WAA_OSC_PLAN_CHECK") != nullptr;
   Node& n = b->nodes[id];
   Step st;
   st.kind = 9;
@@ -2716,11 +2733,24 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
       long double r = x - floorl(x);
       return (double)(r >= 1.L ? r - 1.L : r);
     };
+    // instances with the same start / stop times and one frequency / detune value for the whole render replay alike: the
+    // row of the first such instance is copied (1024 contexts of one patch: one replay instead of 1024)
+    std::map<std::array<double, 4>, uint32_t> replayed;
     for (uint32_t i = 0; i < b->n_inst; i++) {
       const auto fq = param_per_quantum(b, n.params[WAA_PARAM_OSCILLATOR_FREQUENCY], i, nullptr);
       const auto dq = param_per_quantum(b, n.params[WAA_PARAM_OSCILLATOR_DETUNE], i, nullptr);
       double start_time = start[i];
       const double stop_time = stop[i];
+      if (fq.size() == 1 && dq.size() == 1) {
+        const std::array<double, 4> key = {start_time, stop_time, (double)fq[0], (double)dq[0]};
+        auto it = replayed.find(key);
+        if (it != replayed.end()) {
+          std::copy(tq.begin() + (size_t)it->second * b->n_quanta, tq.begin() + (size_t)(it->second + 1) * b->n_quanta,
+                    tq.begin() + (size_t)i * b->n_quanta);
+          continue;
+        }
+        replayed.emplace(key, i);
+      }
       long double phase = 0.L;
       bool started = false;
       for (uint32_t q = 0; q < b->n_quanta; q++) {
@@ -2736,22 +2766,35 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
         oq.incr = incr;
         oq.outside_nyquist = std::fabs(computed_freq) >= nyquist ? 1 : 0;
         // the reference advances current_time by repeated addition: replay it to find the active frame range
-        double current_time = block_time;
         int first = -1, end = RQ;
-        for (int k = 0; k < RQ; k++) {
-          const bool active = !(current_time < start_time || current_time >= stop_time);
-          if (active && first < 0) {
-            first = k;
-            if (!started) {
-              if (current_time > start_time) phase = frac((long double)incr * (long double)((current_time - start_time) / dt));
-              started = true;
+        if (osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt) && !check_replay) {
+          // (the usual quantum: 128 additions and comparisons per instance and quantum were 2.4 s of a 1024-context plan)
+          first = 0;
+          started = true;  // (start_time == block_time here when the node starts in this quantum: no sub-sample offset)
+        } else {
+          const bool expect_full = osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt);
+          const bool was_started = started;
+          double current_time = block_time;
+          for (int k = 0; k < RQ; k++) {
+            const bool active = !(current_time < start_time || current_time >= stop_time);
+            if (active && first < 0) {
+              first = k;
+              if (!started) {
+                if (current_time > start_time) {
+                  if (expect_full) return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (sub-sample start)");
+                  phase = frac((long double)incr * (long double)((current_time - start_time) / dt));
+                }
+                started = true;
+              }
             }
+            if (!active && first >= 0) {
+              end = k;
+              break;
+            }
+            current_time += dt;
           }
-          if (!active && first >= 0) {
-            end = k;
-            break;
-          }
-          current_time += dt;
+          (void)was_started;
+          if (expect_full && !(first == 0 && end == RQ)) return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (range)");
         }
         if (first < 0) continue;
         oq.first = (int16_t)first;
@@ -2782,19 +2825,35 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
         const double next_block_time = block_time + dt * (double)RQ;
         if (stop_time <= block_time || start_time >= next_block_time) continue;
         if (!started && start_time < block_time) start_time = block_time;
+        if (osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt) && !check_replay) {
+          if (first < 0) {
+            first = (int64_t)q * RQ;
+            started = true;
+          }
+          end = (int64_t)(q + 1) * RQ;
+          continue;
+        }
+        const bool expect_full = osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt);
+        const int64_t end_before = end;
         double current_time = block_time;
         for (int k = 0; k < RQ; k++) {
           const bool active = !(current_time < start_time || current_time >= stop_time);
           if (active) {
             if (first < 0) {
               first = (int64_t)q * RQ + k;
-              if (current_time > start_time) ratio[i] = (current_time - start_time) / dt;
+              if (current_time > start_time) {
+                if (expect_full) return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (sub-sample start)");
+                ratio[i] = (current_time - start_time) / dt;
+              }
               started = true;
             }
             end = (int64_t)q * RQ + k + 1;
           }
           current_time += dt;
         }
+        (void)end_before;
+        if (expect_full && !(end == (int64_t)(q + 1) * RQ && first <= (int64_t)q * RQ))
+          return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (range)");
       }
       act[(size_t)i * 2] = first < 0 ? 0 : first;
       act[(size_t)i * 2 + 1] = first < 0 ? 0 : end;
@@ -3323,11 +3382,21 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
       }
       const uint64_t per = varies ? (uint64_t)b->n_quanta * 5 : 5;
       std::vector<double> co((size_t)b->n_inst * per);
+      std::vector<float> pf, pd, pq, pg;  // the previous instance's values: the same values give the same coefficient row
       for (uint32_t i = 0; i < b->n_inst; i++) {
         auto f = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_FREQUENCY], i, nullptr);
         auto d = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_DETUNE], i, nullptr);
         auto q = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_Q], i, nullptr);
         auto g = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_GAIN], i, nullptr);
+        if (i > 0 && f == pf && d == pd && q == pq && g == pg) {
+          // (one k-rate sweep for all 1024 contexts: 3.8 M coefficient sets — sin, cos, pow each — were 0.7 s of the plan)
+          std::copy(co.begin() + (size_t)(i - 1) * per, co.begin() + (size_t)i * per, co.begin() + (size_t)i * per);
+          continue;
+        }
+        pf = f;
+        pd = d;
+        pq = q;
+        pg = g;
         const uint32_t cnt = varies ? b->n_quanta : 1;
         for (uint32_t k = 0; k < cnt; k++) {
           auto at = [&](const std::vector<float>& v) { return v[v.size() == 1 ? 0 : k]; };
