@@ -654,3 +654,65 @@ def test_param_modulated_from_inside_a_short_loop_is_refused(hip):
         c.plan_describe()
     assert ei.value.status == 4 and "modulated from inside its own feedback loop" in str(ei.value)
     c.close()
+
+
+def _echo_loop_with_an_analyser_on_the_line(binding, noise, device=-1):
+    """source -> WaveShaper(no curve: an identity member of the loop) -> Delay -> Gain -> back into the WaveShaper; an
+    AnalyserNode on the WaveShaper ALIASES the loop's delay line and is pulled by analyser_kernel, outside the launch
+    list; dry + wet into the destination is the line's only launch-side reader (fuse_echo_tails)"""
+    n, _, frames = noise.shape
+    c = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n, binding=binding, device=device)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    ws = c.create_wave_shaper()
+    delay = c.create_delay(1.0, delay_time=12000 / 48000.0)
+    an = c.create_analyser()
+    src.connect(ws).connect(delay)
+    delay.connect(c.create_gain(gain=0.5)).connect(ws)
+    ws.connect(an)
+    src.connect(c.destination())
+    delay.connect(c.destination())
+    src.start()
+    return c, an
+
+
+def test_plan_echo_line_stays_stored_for_an_analyser_that_aliases_it(hip):
+    c, _ = _echo_loop_with_an_analyser_on_the_line(hip, white_noise(2, 2, 2048 * 8), device=waa.PLAN_ONLY)
+    plan = c.plan_describe()
+    c.close()
+    assert "LDS-ring kernel in ONE launch" in plan and "alias node" in plan
+    assert "aliases the loop's delay line" in plan and "the line is not stored" not in plan, plan
+
+
+def _check_analyser_on_the_echo_line():
+    """body of the next test (run in a subprocess on poisoned device memory)"""
+    import ctypes
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    orc = waa.bind(ctypes.CDLL(os.path.join(root, "oracle", "liboracle.so")), "orc_")
+    noise = white_noise(3, 2, 2048 * 9 + 300, seed0=17)
+    outs, bins, times = [], [], []
+    for be in (waa.default_binding(), orc):
+        c, an = _echo_loop_with_an_analyser_on_the_line(be, noise)
+        outs.append(c.start_rendering_sync().data)
+        bins.append(an.get_float_frequency_data(instance=2))
+        times.append(an.get_float_time_domain_data(instance=2))
+        c.close()
+    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[1]).max() > 0.1
+    assert np.array_equal(times[0], times[1]) and np.abs(times[1]).max() > 0.1
+    assert np.abs(bins[0] - bins[1]).max() <= 1e-3
+    print("ok")
+
+
+@pytest.mark.gpu
+def test_parity_analyser_that_aliases_the_echo_line_on_poisoned_memory():
+    """the analyser's pull reads the line after the render: with WAA_POISON_ALLOC=1 (read once per process, hence the
+    subprocess) an unwritten line would be all NaN"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, WAA_POISON_ALLOC="1", PYTHONPATH=os.pathsep.join([os.path.dirname(here), here]))
+    out = subprocess.check_output([sys.executable, "-c", "import test_cycles as t; t._check_analyser_on_the_echo_line()"],
+                                  env=env, cwd=here)
+    assert out.strip().endswith(b"ok")

@@ -678,7 +678,9 @@ static int resolve_source_rate_modulation(waa_batch* b) {
   if (!e) {
     float* d_heads = nullptr;
     const size_t count = (size_t)b->n_inst * b->n_quanta;
-    HIP_TRY(hipMalloc(&d_heads, count * sizeof(float)));
+    // (no early return from here on: the prepass state installed above must be torn down on every path)
+    const hipError_t me = hipMalloc(&d_heads, count * sizeof(float));
+    if (me != hipSuccess) e = fail(WAA_ERR_DEVICE, "hipMalloc of the per-quantum param values: %s", hipGetErrorString(me));
     for (size_t k = 0; k < mods.size() && !e; k++) {
       const ParamRef& r = b->prepass_refs[k];
       if (r.mode != 2 || !r.base) {

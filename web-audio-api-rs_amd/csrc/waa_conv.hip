@@ -923,18 +923,16 @@ int fft_threads(int n) {
 }  // namespace
 
 static void allow_big_lds(size_t bytes) {
-  static bool done = false;
-  if (done || bytes <= 64 * 1024) return;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_IR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_kernel<MODE_INV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_FWD, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_INV, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_FWD, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_INV, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_FWD, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_INV, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  done = true;
+  if (bytes <= 64 * 1024) return;
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft_kernel<MODE_IR>));
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft_kernel<MODE_FWD>));
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft_kernel<MODE_INV>));
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_FWD, 0>));
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_INV, 0>));
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_FWD, 1>));
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_INV, 1>));
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_FWD, 2>));
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft_pipe_kernel<MODE_INV, 2>));
 }
 
 void launch_conv_ir_spectra(const ConvDesc& d, void* stream) {
@@ -997,11 +995,7 @@ void launch_conv_direct(const ConvDesc& d, void* stream) {
 }
 void launch_analyser(const AnalyserDesc& d, void* stream) {
   const int M = d.fft_size / 2;
-  static bool big = false;
-  if (!big) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(analyser_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    big = true;
-  }
+  if ((size_t)M * sizeof(Cplx) > 64 * 1024) raise_lds_limit(reinterpret_cast<const void*>(analyser_kernel));
   hipLaunchKernelGGL(analyser_kernel, dim3(d.n_inst), dim3(fft_threads(M)), (size_t)M * sizeof(Cplx), (hipStream_t)stream, d);
 }
 void launch_conv_mac(const ConvDesc& d0, void* stream) {

@@ -588,13 +588,10 @@ __global__ __launch_bounds__(NT) void conv_fft3_inv_kernel(const ConvDesc d, int
 }  // namespace
 
 static void f3_allow_lds() {
-  static bool done = false;
-  if (done) return;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft3_fwd_kernel<F3_FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft3_fwd_kernel<F3_IR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft3_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fft3_fwd_bq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  done = true;
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft3_fwd_kernel<F3_FWD>));
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft3_fwd_kernel<F3_IR>));
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft3_inv_kernel));
+  raise_lds_limit(reinterpret_cast<const void*>(conv_fft3_fwd_bq_kernel));
 }
 // blocks per persistent workgroup: whole (pair, channel) streams when there are enough of them to fill the chip, shorter
 // runs otherwise

@@ -711,11 +711,11 @@ void launch_dyn(const DynDesc& d, void* stream) {
   dd.no_scan = getenv("WAA_DYN_NO_SCAN") ? 1u : 0u;
   if (cm == 2) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dyn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      raise_lds_limit(reinterpret_cast<const void*>(dyn_kernel<2>));
     hipLaunchKernelGGL(dyn_kernel<2>, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, dd);
   } else {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dyn_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      raise_lds_limit(reinterpret_cast<const void*>(dyn_kernel<6>));
     hipLaunchKernelGGL(dyn_kernel<6>, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, dd);
   }
 }

@@ -33,6 +33,16 @@
 
 namespace waa {
 
+void raise_lds_limit(const void* kernel) {
+  static std::mutex lock;
+  static std::set<std::pair<int, const void*>> raised;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> g(lock);
+  if (raised.insert({dev, kernel}).second)
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 constexpr int ECHO_RING = 16384;  // frames per channel kept in LDS (two channels: 128 KB)
 constexpr int ECHO_EXT = 2;        // inputs from outside the loop (held in registers two chunks ahead)
 constexpr int ECHO_TAIL_IN = 3;    // inputs of the fused tail stage: the delayed line and those
@@ -414,15 +424,7 @@ void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const Echo
   const dim3 block((unsigned)chunk_subtiles * 64), grid(d.n_inst);
   const bool store = !tail || tail->store_line;
   auto go = [&](auto kern) {
-    static std::mutex lock;
-    static std::set<std::pair<int, const void*>> raised;  // (the LDS limit of an instantiation is raised once per device)
-    {
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      std::lock_guard<std::mutex> g(lock);
-      if (raised.insert({dev, reinterpret_cast<const void*>(kern)}).second)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
+    raise_lds_limit(reinterpret_cast<const void*>(kern));
     hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, d, fb, chunk_subtiles, t);
   };
   if (d.in_nch == 1) {

@@ -1040,7 +1040,7 @@ void launch_hrtf(const HrtfDesc& d, void* stream) {
     }
     if (getenv("WAA_HRTF_V8")) {  // (experiment: the eight-frame form with per-unit HRIR pairs in LDS — slower, see above)
       if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hrtf8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raise_lds_limit(reinterpret_cast<const void*>(hrtf8_kernel<false>));
       hipLaunchKernelGGL(hrtf8_kernel<false>, grid, dim3(64), lds, (hipStream_t)stream, d);
       return;
     }
@@ -1048,7 +1048,7 @@ void launch_hrtf(const HrtfDesc& d, void* stream) {
   const int O = (d.taps + 3) & ~3;
   const size_t lds = (size_t)4 * (size_t)(3 * O + RQ) * sizeof(float);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hrtf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raise_lds_limit(reinterpret_cast<const void*>(hrtf_kernel));
   dim3 grid((d.n_quanta + 3) / 4, d.n_inst);
   hipLaunchKernelGGL(hrtf_kernel, grid, dim3(256), lds, (hipStream_t)stream, d);
 }

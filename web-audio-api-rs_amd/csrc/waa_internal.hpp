@@ -5,6 +5,11 @@
 
 namespace waa {
 
+// Kernels that need more than 64 KB of dynamic LDS: the limit of a kernel function is a per-DEVICE attribute, and several
+// devices may be driven from threads of one process (waa_render_sharded): raised once per (device, function), under a lock.
+// Defined in waa_echo.hip (host code).
+void raise_lds_limit(const void* kernel);
+
 constexpr int RQ = 128;            // render quantum (reference src/lib.rs:18)
 constexpr int TILE_K = 32;         // frames per lane in the transposed (recurrence) layout
 constexpr int TILE = 64 * TILE_K;  // frames per wave-tile = 2048 = 16 render quanta

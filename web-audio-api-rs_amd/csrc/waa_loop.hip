@@ -359,7 +359,7 @@ void launch_loop(const LoopDesc& d, void* stream) {
   const size_t lds = ((size_t)d.n_items * 2 * RQ + 2 * RQ) * sizeof(float) + (size_t)d.n_items * 8 * sizeof(double) +
                      (size_t)d.n_items * sizeof(LoopItem);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raise_lds_limit(reinterpret_cast<const void*>(loop_kernel));
   LoopDesc dd = d;
   dd.no_scan = getenv("WAA_DYN_NO_SCAN") ? 1u : 0u;
   hipLaunchKernelGGL(loop_kernel, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, dd);

@@ -961,6 +961,16 @@ int build_plan(waa_batch* b) {
         for (int e : pe) stack.push_back(b->edges[e].from);
     }
   }
+  // (prepass) a modulated source that itself feeds the modulating subgraph of a modulated source: its own schedule is
+  // not known before ITS modulation has been resolved — a second prepass level nobody has asked for yet; refused loudly
+  // (it used to be skipped by plan_single and the outer param chain read an empty signal)
+  if (b->prepass)
+    for (auto& ed : b->edges) {
+      if (ed.from >= N || ed.to >= N || !b->nodes[ed.to].live) continue;
+      for (auto& pp : b->prepass_params)
+        if (pp.first == ed.from)
+          return fail(WAA_ERR_OUT_OF_SCOPE, "source node %u has a graph-modulated playbackRate / detune and feeds the modulation of source node %u: nested modulation of source rates is out of scope", ed.from, ed.to);
+    }
   // static channel counts (the reference's counts are dynamic: a silent quantum is mono; every case the
   // static count differs from the dynamic one carries zeros — see DESIGN.md "Silence and channel counts")
   // (inside a feedback loop a producer can come later in the order: iterate to the fixed point; counts only grow)
@@ -2366,6 +2376,20 @@ void fuse_echo_tails(waa_batch* b) {
     }
     if (n_readers != 1 || other_writer || reader < l) {
       plan_note(b, "echo loop: the delay line has %d reader(s) outside the loop: stored, read by them from memory", n_readers);
+      continue;
+    }
+    // Readers that are not launches: an AnalyserNode (pulled by analyser_kernel after the render) or the destination
+    // (downloaded) that ALIASES the line through an identity node of the loop never shows up in the read sets above.
+    // The line must then be stored for them (the same class as the oscillator post-op fold, fuzz seed 502310).
+    int alias_reader = -1;
+    for (size_t k = 0; k < b->nodes.size(); k++) {
+      const Node& an = b->nodes[k];
+      if (an.live && an.sig.base == line &&
+          (an.desc.kind == WAA_NODE_ANALYSER || an.desc.kind == WAA_NODE_DESTINATION))
+        alias_reader = (int)k;
+    }
+    if (alias_reader >= 0) {
+      plan_note(b, "echo loop: node %d (analyser / destination) aliases the loop's delay line and is read outside the launch list: the line is stored", alias_reader);
       continue;
     }
     Step& ts = b->steps[reader];
