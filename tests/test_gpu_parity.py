@@ -12,6 +12,10 @@ from graphs import c2, c5, rms_err, white_noise
 pytestmark = pytest.mark.gpu
 RQ = 128
 TOL = 1e-6
+# AnalyserNode spectra, device vs oracle: linear magnitude relative to the row's peak, and the dB bound that follows from it on
+# bins within 60 dB of the peak (derivation and the all-contexts measurement: tests/test_full_size_all_instances.py)
+ANALYSER_LIN_TOL = 4e-6
+ANALYSER_DB_TOL = 0.035
 
 
 def both(builder, hip, orc, *a, **kw):
@@ -388,9 +392,12 @@ def test_c4_small_with_analyser(hip, orc):
         # dB of a 2048-bin f32 FFT: bins at the f32 noise floor (-200 dB after the 200 Hz lowpass) are rounding
         # noise in both implementations, so compare linear magnitudes
         gl, ol = 10.0 ** (gf[i].astype(np.float64) / 20), 10.0 ** (of[i].astype(np.float64) / 20)
-        assert np.abs(gl - ol).max() <= 1e-8 + 1e-3 * np.abs(ol).max()
+        # two f32 transforms of 2048 points over the same samples: a few 1e-7 of the row's peak each (the tolerance and the
+        # dB bound derived from it: tests/test_full_size_all_instances.py, where all 512 contexts of C4 are compared)
+        print(f"analyser instance {i}: linear diff / peak {np.abs(gl - ol).max() / ol.max():.3e}")
+        assert np.abs(gl - ol).max() <= ANALYSER_LIN_TOL * np.abs(ol).max()
         big = ol > 1e-3 * ol.max()
-        assert np.abs(gf[i][big] - of[i][big]).max() <= 1e-2
+        assert np.abs(gf[i][big] - of[i][big]).max() <= ANALYSER_DB_TOL
         assert np.abs(gbf[i].astype(int) - obf[i].astype(int)).max() <= 1
         assert np.abs(gbt[i].astype(int) - obt[i].astype(int)).max() <= 1
 
@@ -586,7 +593,7 @@ def test_c4_full_size_real_ir_sampled(hip, orc):
     for k in range(len(pick)):
         assert np.abs(gt[k] - ot[k]).max() <= 2e-6
         gl, ol = 10.0 ** (gf[k].astype(np.float64) / 20), 10.0 ** (of[k].astype(np.float64) / 20)
-        assert np.abs(gl - ol).max() <= 1e-8 + 1e-3 * np.abs(ol).max()
+        assert np.abs(gl - ol).max() <= ANALYSER_LIN_TOL * np.abs(ol).max()
 
 
 def _t1_like(be, noise, ir, length, highpass=False, via_gain=False):

@@ -58,7 +58,8 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 }  // namespace
 
-template <int C>
+// RECLOAD = true: the round-2 form of the window pipeline (WAA_RESAMPLE_RECORD_LOAD=1, same-box A/B), see `fetch` below
+template <int C, bool RECLOAD = false>
 __global__ __launch_bounds__(WAVES * 64) void resample_kernel(const ChainDesc d, int curve_op) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nn = curve_op >= 0 ? d.ops[curve_op].i0 : 0;
@@ -190,27 +191,71 @@ __global__ __launch_bounds__(WAVES * 64) void resample_kernel(const ChainDesc d,
     // ---- pipelined window path: the window of instance g + 1 is in flight while instance g is interpolated
     constexpr int NV = WCAP / 256;
     f4v nx[C][NV];
+    if constexpr (RECLOAD) {
+      auto fetch = [&](uint32_t g) __attribute__((always_inline)) {
+        const SrcInst& sg = in.src[inst0 + g];
+        const float* base = sg.base + wlo;
+        const uint64_t cs = sg.ch_stride;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+          for (int j = 0; j < NV; j++) {
+            const int o = j * 256 + lane * 4;
+            f4v t = {0.f, 0.f, 0.f, 0.f};
+            if (o < span) {
+              const float* pch = base + (uint64_t)c * cs + o;
+              if ((uint64_t)(wlo + o + 3) < si0.frames) {
+                t = load_global_f4(pch);
+              } else {  // the buffer ends inside this vector
+                t.x = (uint64_t)(wlo + o) < si0.frames ? load_global(pch) : 0.f;
+                t.y = (uint64_t)(wlo + o + 1) < si0.frames ? load_global(pch + 1) : 0.f;
+                t.z = (uint64_t)(wlo + o + 2) < si0.frames ? load_global(pch + 2) : 0.f;
+              }
+            }
+            nx[c][j] = t;
+          }
+      };
+      fetch(0);
+#pragma unroll 1
+      for (uint32_t g = 0; g < n_here; g++) {
+        wave_sync();  // the previous instance's LDS reads are done
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+          for (int j = 0; j < NV; j++) {
+            const int o = j * 256 + lane * 4;
+            if (o < span) *reinterpret_cast<f4v*>(win + c * WCAP + o) = nx[c][j];
+          }
+        if (g + 1 < n_here) fetch(g + 1);
+        wave_sync();
+        finish(inst0 + g, [&](int c, int idx) __attribute__((always_inline)) { return win[c * WCAP + idx - wlo]; });
+      }
+      return;
+    }
+    // Round 3 (tools/isa_waits.py, profiles/r03z_c5_sq1.txt: 72 % of the kernel's wave-cycles were waits).  The form above
+    // (a) reads the next instance's buffer base / channel stride from its record inside the loop: a dependent load in front
+    // of every window request, (b) requests the window under conditions (inside the span? does the buffer end inside the
+    // vector?), so the compiler cannot count what is in flight and every wait is vmcnt(0) — which, vmcnt being ONE in-order
+    // counter, also waits for the stores of the instance just finished.  Here lane g fetches instance g's base and stride
+    // once (readlane picks them), every window vector is loaded unconditionally from a clamped offset (aligned rows: a
+    // vector that straddles the buffer's end stays inside the row's padding) and looked at only when it is written to LDS,
+    // where the frames past the end are zeroed.
+    const uint64_t* rec = reinterpret_cast<const uint64_t*>(in.src + inst0 + ((uint32_t)lane < n_here ? (uint32_t)lane : 0u));
+    const uint64_t my_base = load_global(rec);      // SrcInst::base
+    const uint64_t my_cs = load_global(rec + 1);    // SrcInst::ch_stride
     auto fetch = [&](uint32_t g) __attribute__((always_inline)) {
-      const SrcInst& sg = in.src[inst0 + g];
-      const float* base = sg.base + wlo;
-      const uint64_t cs = sg.ch_stride;
+      const int gl = (int)__builtin_amdgcn_readfirstlane((int)g);
+      const uint64_t b = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_base >> 32), gl) << 32) |
+                         (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_base, gl);
+      const uint64_t cs = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_cs >> 32), gl) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_cs, gl);
+      const float* base = reinterpret_cast<const float*>(b) + wlo;
 #pragma unroll
       for (int c = 0; c < C; c++)
 #pragma unroll
         for (int j = 0; j < NV; j++) {
           const int o = j * 256 + lane * 4;
-          f4v t = {0.f, 0.f, 0.f, 0.f};
-          if (o < span) {
-            const float* pch = base + (uint64_t)c * cs + o;
-            if ((uint64_t)(wlo + o + 3) < si0.frames) {
-              t = load_global_f4(pch);
-            } else {  // the buffer ends inside this vector
-              t.x = (uint64_t)(wlo + o) < si0.frames ? load_global(pch) : 0.f;
-              t.y = (uint64_t)(wlo + o + 1) < si0.frames ? load_global(pch + 1) : 0.f;
-              t.z = (uint64_t)(wlo + o + 2) < si0.frames ? load_global(pch + 2) : 0.f;
-            }
-          }
-          nx[c][j] = t;
+          nx[c][j] = load_global_f4(base + (uint64_t)c * cs + (o < span ? o : 0));
         }
     };
     fetch(0);
@@ -222,9 +267,16 @@ __global__ __launch_bounds__(WAVES * 64) void resample_kernel(const ChainDesc d,
 #pragma unroll
         for (int j = 0; j < NV; j++) {
           const int o = j * 256 + lane * 4;
-          if (o < span) *reinterpret_cast<f4v*>(win + c * WCAP + o) = nx[c][j];
+          if (o < span) {
+            const uint64_t a = (uint64_t)(wlo + o);  // (a < frames: the window ends at a frame some record names)
+            f4v t = nx[c][j];
+            t.y = a + 1 < si0.frames ? t.y : 0.f;
+            t.z = a + 2 < si0.frames ? t.z : 0.f;
+            t.w = a + 3 < si0.frames ? t.w : 0.f;
+            *reinterpret_cast<f4v*>(win + c * WCAP + o) = t;
+          }
         }
-      if (g + 1 < n_here) fetch(g + 1);
+      fetch(g + 1 < n_here ? g + 1 : g);  // (past the group: the same window again, never used — the count stays fixed)
       wave_sync();
       finish(inst0 + g, [&](int c, int idx) __attribute__((always_inline)) { return win[c * WCAP + idx - wlo]; });
     }
@@ -267,6 +319,13 @@ void launch_resample(const ChainDesc& d, int curve_op, void* stream) {
   const uint64_t n_sub = (uint64_t)(d.tile1 - d.tile0) * (TILE / 256);
   const uint64_t waves = n_sub * ((d.n_inst + GROUP - 1) / GROUP);
   const dim3 grid((unsigned)((waves + WAVES - 1) / WAVES)), block(WAVES * 64);
+  if (getenv("WAA_RESAMPLE_RECORD_LOAD")) {  // (measurement switch: the round-2 window pipeline)
+    if (C == 1)
+      hipLaunchKernelGGL((resample_kernel<1, true>), grid, block, lds, (hipStream_t)stream, d, curve_op);
+    else
+      hipLaunchKernelGGL((resample_kernel<2, true>), grid, block, lds, (hipStream_t)stream, d, curve_op);
+    return;
+  }
   if (C == 1)
     hipLaunchKernelGGL((resample_kernel<1>), grid, block, lds, (hipStream_t)stream, d, curve_op);
   else

@@ -30,11 +30,16 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def timed_steps(step: Callable[[], None], sync: Callable[[], None], steps: int, warmup: int, dist=None,
-                device_tensor: Optional[Callable[[float], object]] = None) -> float:
-    """bench.py's protocol: W untimed steps, barrier+sync, exactly K timed steps, sync+barrier, MAX over ranks."""
+                device_tensor: Optional[Callable[[float], object]] = None,
+                after_warmup: Optional[Callable[[], None]] = None) -> float:
+    """bench.py's protocol: W untimed steps, barrier+sync, exactly K timed steps, sync+barrier, MAX over ranks.
+    `after_warmup` runs between the warm-up and the timed region, device idle (bench.py resets the per-kernel event
+    totals there, so that kernel averages cover the timed steps only)."""
     for _ in range(warmup):
         step()
     sync()
+    if after_warmup is not None:
+        after_warmup()
     if dist is not None:
         dist.barrier()
     sync()
