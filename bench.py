@@ -114,6 +114,9 @@ ALG_BYTES["hrtf"] = 2048.0
 # the oversampled WaveShaper as matrix products (2 channels x (128R x 256 + 128 x 256R)), the HRTF FIR (128 frames x 2 ears
 # x 512 taps at 44.1 / 48 kHz -> 415 taps at 48 kHz)
 ALG_FLOPS = {"os2": 2 * 2.0 * (256 * 256 + 128 * 512), "os4": 2 * 2.0 * (512 * 256 + 128 * 1024), "hrtf": 2.0 * 128 * 2 * 415}
+# ... and as what the product path runs since round 4 (waa_osfft.hip): 2 + 2R complex 256-point transforms per STEREO quantum
+# (5 N log2 N = 10 240 flops each, the usual FFT convention) plus 2R spectral products of 256 complex multiplies (8 flops)
+OS_FFT_FLOPS = {"os2": 6 * 10240.0 + 4 * 256 * 8.0, "os4": 10 * 10240.0 + 8 * 256 * 8.0}
 IIR_ORDERS = (2, 4, 8, 12, 19)
 for _o in IIR_ORDERS:
     ALG_BYTES[f"iir{_o}"] = 2048.0
@@ -359,12 +362,19 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
     if name in ALG_FLOPS:
         # compute-bound rows (f32 FMA; no MFMA format with enough mantissa except the f32 one, same peak): flops of the
         # dominant kernels / their time against the 157.3 TFLOP/s f32 peak of MI355X_MICROARCH.md
-        flops = ALG_FLOPS[name] * n_inst * nq
-        comp_ms = sum(ms / max(l, 1) * (l / total_launch_steps) for n_, l, ms in prof if n_.startswith(("qgemm", "hrtf")))
+        matrix_form = bool(os.environ.get("WAA_OS_MATRIX"))
+        fft_form = name in OS_FFT_FLOPS and not matrix_form
+        flops = (OS_FFT_FLOPS[name] if fft_form else ALG_FLOPS[name]) * n_inst * nq
+        comp_ms = sum(ms / max(l, 1) * (l / total_launch_steps) for n_, l, ms in prof if n_.startswith(("qgemm", "hrtf", "osfft")))
         roof.update({"bound": "valu_f32", "peak": 157.3, "unit": "TFLOP/s", "achieved": flops / (comp_ms * 1e-3) / 1e12,
                      "algorithmic_flops_per_step": flops, "compute_kernel_ms_per_step": comp_ms})
         roof["frac"] = roof["achieved"] / 157.3
-        if name in ("os2", "os4") and not any(os.environ.get(k) for k in ("WAA_QGEMM_FMA", "WAA_QGEMM_F32")):
+        if fft_form:
+            # butterflies are adds and multiplies, not fused: against the FMA peak the transform form cannot exceed ~0.5; the
+            # figure to watch is the time itself next to the HBM floor (compulsory_frac) and to the matrix form it replaced
+            roof["flops_basis"] = "2+2R complex FFT256 per stereo quantum at 5 N log2 N + the spectral products"
+            roof["matrix_form_flops_per_step"] = ALG_FLOPS[name] * n_inst * nq
+        if name in ("os2", "os4") and matrix_form and not any(os.environ.get(k) for k in ("WAA_QGEMM_FMA", "WAA_QGEMM_F32")):
             # the resampling products run on the bf16 matrix cores as SIX bf16 products per f32 product (exact three-way
             # split of both operands, f32-grade result: DESIGN.md 3.5): the ceiling of that method is the dense bf16 MFMA
             # peak / 6, in f32-equivalent flops; `mfma_flops_per_step` is what the matrix cores really execute

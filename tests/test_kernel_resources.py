@@ -88,3 +88,19 @@ def test_echo_ring_kernel_fits_one_workgroup_of_sixteen_waves(tmp_path):
     assert len(k) == 8, sorted(res)
     for name, r in k.items():
         assert r["vgpr"] <= 128 and r["spill"] == 0 and r["scratch"] == 0, (name, r)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_oversampler_transform_kernel_keeps_two_waves_per_simd_at_2x(tmp_path):
+    """waa_osfft.hip: the 2x instantiation carries its whole state (two stages' overlaps, two spectra, the transform in flight)
+    in at most 256 registers — two wavefronts per SIMD hide each other's LDS exchanges; it was 304 with a divergent branch
+    around the state reset plus an early exit from the loop (copies of the carried state), which is how the kernel is written
+    the way it is.  The 4x instantiation holds twice the overlap and runs one wavefront per SIMD; neither touches scratch."""
+    res = kernel_resources("waa_osfft.hip", tmp_path)
+    x2 = {n: v for n, v in res.items() if "osfft_kernelILi2E" in n}
+    x4 = {n: v for n, v in res.items() if "osfft_kernelILi4E" in n}
+    assert len(x2) == 2 and len(x4) == 2, sorted(res)
+    for name, r in x2.items():
+        assert r["vgpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (name, r)
+    for name, r in x4.items():
+        assert r["vgpr"] <= 512 and r["spill"] == 0 and r["scratch"] == 0, (name, r)

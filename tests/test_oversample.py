@@ -4,7 +4,7 @@ The resamplers are rubato 0.16 `FftFixedInOut` (third party, not vendored): the 
 nodes (waveshaper.rs:608-670), so sample values are PARITY UNPINNED by the reference.  What pins them here:
 
 * the written definition restated a third time, independently, in numpy f64 (`RubatoStage`
-  below) — the oracle (f32 FFTs, like the crate) and the device (matrix products) both have to match it;
+  below) — the oracle (f32 FFTs, like the crate) and the device (256-point transforms in registers; round 2: matrix products) both have to match it;
 * the reference's control flow around the resamplers, which IS in the reference: a silent input with a curve that maps
   0 to 0 skips the block and freezes the overlap (:395-400), a change of the channel count re-creates the resamplers
   (:413-425), a curve that does not map 0 to 0 keeps processing silence (:498-509).
@@ -311,7 +311,7 @@ def test_oversample_many_instances_sampled(hip, orc):
 # ---- the three forms of the resampling products (waa_frozen.hip) -------------------------------------------------
 def _render_with_env(hip, x, oversample, env):
     import os
-    keys = ("WAA_QGEMM_FMA", "WAA_QGEMM_F32", "WAA_QGEMM_W4")
+    keys = ("WAA_OS_MATRIX", "WAA_QGEMM_FMA", "WAA_QGEMM_F32", "WAA_QGEMM_W4")
     saved = {k: os.environ.pop(k, None) for k in keys}
     try:
         os.environ.update(env)
@@ -326,19 +326,55 @@ def _render_with_env(hip, x, oversample, env):
 @pytest.mark.gpu
 @pytest.mark.parametrize("oversample,factor", [("2x", 2), ("4x", 4)])
 def test_product_forms_agree(hip, oversample, factor):
-    """vector FMA, f32 MFMA, six bf16 MFMA products per f32 product (eight and four wavefronts): one result, the written
+    """the product path (256-point transforms in one launch, waa_osfft.hip) and the four matrix forms of round 2 (WAA_OS_MATRIX=1:
+    vector FMA, f32 MFMA, six bf16 MFMA products per f32 product on eight and four wavefronts): one result, the written
     definition in f64 as the judge; the bf16 form is not allowed to be worse than the f32 forms"""
     nq = 140  # (two workgroup tiles of 128 quanta, the second one ragged)
     rng = np.random.default_rng(31)
     x = rng.uniform(-1, 1, (3, 2, nq * RQ)).astype(np.float32)
     ref = np.stack([[definition_render(x[i, c], TANH, factor) for c in range(2)] for i in range(3)])
     err = {}
-    for name, env in (("bf16x6", {}), ("bf16x6_w4", {"WAA_QGEMM_W4": "1"}), ("f32_mfma", {"WAA_QGEMM_F32": "1"}),
-                      ("f32_fma", {"WAA_QGEMM_FMA": "1"})):
+    m = {"WAA_OS_MATRIX": "1"}
+    for name, env in (("transforms", {}), ("bf16x6", m), ("bf16x6_w4", dict(m, WAA_QGEMM_W4="1")),
+                      ("f32_mfma", dict(m, WAA_QGEMM_F32="1")), ("f32_fma", dict(m, WAA_QGEMM_FMA="1"))):
         out = _render_with_env(hip, x, oversample, env)
         err[name] = max(rms(out[i, c], ref[i, c]) for i in range(3) for c in range(2))
         assert err[name] <= 1e-6, (name, err)
+    print(f"{oversample}: RMS error against the f64 definition by form: " + ", ".join(f"{k} {v:.2e}" for k, v in err.items()))
     assert err["bf16x6"] <= 2.0 * err["f32_fma"] + 1e-9, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("oversample,factor", [("2x", 2), ("4x", 4)])
+@pytest.mark.parametrize("seg", [1, 3, 7])
+def test_transform_form_run_heads(hip, monkeypatch, oversample, factor, seg):
+    """WAA_OSFFT_SEG: runs of 1 / 3 / 7 quanta — every run starts from overlaps recomputed out of the two processed quanta in
+    front of it; the result does not depend on where the runs are cut (bit for bit), a source that starts late and one that
+    ends early put skipped quanta in front of run heads"""
+    nq = 41
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (3, 2, nq * RQ)).astype(np.float32)
+
+    def render():
+        ctx = waa.OfflineAudioContext(2, nq * RQ, SR, n_instances=3, binding=hip)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(x[:, :, :RQ * 30], SR)
+        src.connect(ctx.create_wave_shaper(curve=TANH, oversample=oversample)).connect(ctx.destination())
+        for i in range(3):
+            src.start_at(i * 5 * RQ / SR, instance=i)   # instance 1 / 2: 5 / 10 silent quanta first; all end before the render does
+        plan = ctx.plan_describe()
+        return ctx.start_rendering_sync().data, plan
+
+    whole, plan = render()
+    assert "256-point transforms per quantum in one launch" in plan
+    monkeypatch.setenv("WAA_OSFFT_SEG", str(seg))
+    cut, plan = render()
+    assert f"runs of {seg} quanta" in plan
+    assert np.array_equal(whole, cut)
+    monkeypatch.setenv("WAA_OS_MATRIX", "1")
+    matrix, plan = render()
+    assert "matrix products" in plan
+    assert np.sqrt(np.mean((matrix.astype(np.float64) - whole) ** 2, axis=-1)).max() <= 1e-6
 
 
 @pytest.mark.gpu

@@ -20,7 +20,7 @@ for S in "$@"; do
     ab:*)   V=${S#ab:}; AB_REPS=2 AB_ITERS=5 timeout 300 python tools/ab_env.py ${V%%@*} ${V#*@} > gpurun_out/${TAG}_ab_${V%%[@=]*}.txt 2>&1; tail -12 gpurun_out/${TAG}_ab_${V%%[@=]*}.txt ;;
     bench)  timeout 1200 python bench.py --detail gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "rc=$?"; wc -c gpurun_out/${TAG}_bench_default.json; cat gpurun_out/${TAG}_bench_default.json; tail -3 gpurun_out/${TAG}_bench_default.err ;;
     pmc:*)  W=${S#pmc:}; timeout 600 bash tools/pmc_pass.sh $W ${TAG}_$W > /dev/null 2>&1; head -12 gpurun_out/${TAG}_${W}_stats.txt ;;
-    line:*) W=${S#line:}; timeout 300 python bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-extra > gpurun_out/${TAG}_bench_$W.json 2> gpurun_out/${TAG}_bench_$W.err; cat gpurun_out/${TAG}_bench_$W.json | cut -c1-1500 ;;
+    line:*) W=${S#line:}; timeout 300 python bench.py --workload $W --steps 5 --warmup 2 --sustain 0 --no-cpu-baseline --no-extra > gpurun_out/${TAG}_bench_$W.json 2> gpurun_out/${TAG}_bench_$W.err; cat gpurun_out/${TAG}_bench_$W.json | cut -c1-1500 ;;
     fuzz:*) N=${S#fuzz:}; timeout 1500 python tools/fuzz_campaign.py --first 100000 --count $N --jobs 8 --out gpurun_out/${TAG}_fuzz.json 2> gpurun_out/${TAG}_fuzz.err | cut -c1-3000; tail -3 gpurun_out/${TAG}_fuzz.err ;;
     *) echo "unknown section $S" ;;
   esac

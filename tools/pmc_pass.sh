@@ -9,7 +9,7 @@ set -u
 W=$1; TAG=$2; shift 2
 export TMPDIR=/tmp
 ROOT=$(pwd)
-CMD="python $ROOT/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-extra $*"
+CMD="python $ROOT/bench.py --workload $W --steps 3 --warmup 1 --sustain 0 --no-cpu-baseline --no-extra $*"
 mkdir -p gpurun_out
 for pass in stats fetch write; do
   OUT=/tmp/prof_${TAG}_${pass}

@@ -878,6 +878,7 @@ static int run_steps(waa_batch* b) {
       case 15: e = timed(st.profile_slot, [&] { launch_link(st.link, b->stream); }); break;
       case 16: e = timed(st.profile_slot, [&] { launch_qgemm(st.qgemm, b->stream); }); break;
       case 17: e = timed(st.profile_slot, [&] { launch_hrtf(st.hrtf, b->stream); }); break;
+      case 20: e = timed(st.profile_slot, [&] { launch_osfft(st.osfft, b->stream); }); break;
       case 12:
         if (st.hp.coefs) e = timed(st.profile_slot, [&] { launch_biquad_hp(st.hp, b->stream); });
         break;

@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "waa_host.hpp"
+#include "waa_osfft_tables.hpp"
 
 namespace waa {
 namespace host {
@@ -24,24 +25,7 @@ int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const Signa
 //   phi[p] = sum_{k < new_len} c_k Re(F[k] exp(2 pi i k p / (2 fm))),  c_0 = 1, c_k = 2,
 // which is what the device multiplies with: A[k][m] (k < fi) = the response of output frame m to input frame k of the
 // SAME block, A[fi + k][m] = the response of frame m to input frame k of the PREVIOUS processed block (its overlap).
-static std::vector<float> rubato_filter_taps(int fi, int fo) {
-  const float cutoff = fi > fo ? std::pow(0.4f, 16.0f / (float)fi) * (float)fo / (float)fi : std::pow(0.4f, 16.0f / (float)fi);
-  const float pi = 3.14159265358979323846f;
-  const float pi2 = 2.f * pi, pi4 = 4.f * pi, pi6 = 6.f * pi, np = (float)fi;
-  std::vector<float> y((size_t)fi);
-  float sum = 0.f;
-  for (int x = 0; x < fi; x++) {
-    const float xf = (float)x;
-    const float bh = 0.35875f - 0.48829f * std::cos(pi2 * xf / np) + 0.14128f * std::cos(pi4 * xf / np) - 0.01168f * std::cos(pi6 * xf / np);
-    const float arg = (xf - (float)(fi / 2)) * cutoff / 1.f;
-    const float sinc = arg == 0.f ? 1.f : std::sin(arg * pi) / (arg * pi);
-    const float val = bh * bh * sinc;
-    sum += val;
-    y[(size_t)x] = val;
-  }
-  for (int n = 0; n < fi; n++) y[(size_t)n] = (y[(size_t)n] / sum) / (float)(2 * fi);
-  return y;
-}
+using osfft::rubato_filter_taps;  // (waa_osfft_tables.hpp: shared with the transform form)
 static std::vector<float> resampler_matrix(int fi, int fo) {
   const std::vector<float> g = rubato_filter_taps(fi, fo);
   const int new_len = fi < fo ? fi + 1 : fo;
@@ -238,6 +222,46 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
   if (!n.d_curve && (e = dev_upload(b, &n.d_curve, n.curve))) return e;
   const int up_len = RQ * R;
   const int nch = n.in_nch;
+  const bool matrix_form = getenv("WAA_OS_MATRIX") != nullptr;  // (A/B: the round-2 dense products on the matrix cores)
+  if (!matrix_form && nch <= 2) {
+    // Transform form (waa_osfft.hip): one launch, the stages as 256-point transforms, nothing at the high rate in HBM.
+    float *d_tab = nullptr, *d_tw = nullptr;
+    if ((e = dev_upload(b, &d_tab, osfft::tables(R))) || (e = dev_upload(b, &d_tw, osfft::tw256()))) return e;
+    Step os;
+    os.kind = 20;
+    OsFftDesc& f = os.osfft;
+    std::memset(&f, 0, sizeof f);
+    f.src = in_sig.base;
+    f.src_inst = in_sig.inst_stride;
+    f.src_ch = in_sig.ch_stride;
+    f.dst = n.sig.base;
+    f.dst_inst = n.sig.inst_stride;
+    f.dst_ch = n.sig.ch_stride;
+    f.prev = prev;
+    f.prev_stride = b->n_quanta;
+    f.curve = n.d_curve;
+    f.curve_n = (int32_t)cn;
+    f.R = R;
+    f.tables = d_tab;
+    f.tw256 = d_tw;
+    f.nch = nch;
+    f.n_inst = b->n_inst;
+    f.n_quanta = b->n_quanta;
+    // runs: ~16 k groups of 16 lanes in the launch (4 waves per SIMD's worth), never shorter than 8 quanta (two more are
+    // rendered in front of every run for its overlaps)
+    const uint32_t want = std::max<uint32_t>(1, (16384 + b->n_inst - 1) / b->n_inst);
+    uint32_t seg = std::max<uint32_t>(8, (b->n_quanta + want - 1) / want);
+    if (const char* sv = getenv("WAA_OSFFT_SEG")) seg = std::max(1, atoi(sv));  // (tests: short runs exercise the run heads)
+    f.seg_len = seg;
+    f.n_seg = (b->n_quanta + seg - 1) / seg;
+    os.profile_slot = slot_for(b, "osfft_kernel");
+    os.loop_reads.push_back(in_sig.base);
+    os.loop_writes.push_back(n.sig.base);
+    b->steps.push_back(os);
+    plan_note(b, "waveshaper node %u: %dx oversampling as %d 256-point transforms per quantum in one launch (runs of %u quanta, %u per instance), %d channel(s)%s",
+              id, R, 2 + 2 * R, f.seg_len, f.n_seg, nch, can_propagate ? ", silent input skips the block" : "");
+    return 0;
+  }
   float *d_up = nullptr, *d_dn = nullptr, *sbuf = nullptr;
   uint16_t *d_up16 = nullptr, *d_dn16 = nullptr;
   const std::vector<float> m_up = resampler_matrix(RQ, up_len), m_dn = resampler_matrix(up_len, RQ);

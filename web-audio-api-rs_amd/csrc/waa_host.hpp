@@ -220,6 +220,7 @@ struct Step {
   TimelineDesc tl{};
   LinkDesc link{};
   QGemmDesc qgemm{};
+  OsFftDesc osfft{};      // kind 20: the oversampled WaveShaper in one launch (waa_osfft.hip)
   HrtfDesc hrtf{};
   int slot_fwd = -1, slot_mac = -1, slot_inv = -1;
   void* zero_ptr = nullptr;

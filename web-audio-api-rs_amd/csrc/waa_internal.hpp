@@ -582,6 +582,27 @@ struct QGemmDesc {
 };
 void launch_qgemm(const QGemmDesc& d, void* stream);
 
+// The same node in ONE launch as 256-point transforms (waa_osfft.hip / waa_osfft.hpp): both resampling stages and the
+// curve; groups of 16 lanes walk runs of `seg_len` quanta with the stages' overlaps in registers.
+struct OsFftDesc {
+  const float* src;         // the node's mixed input: frame f of (inst, ch) at src[inst * src_inst + ch * src_ch + f]
+  uint64_t src_inst, src_ch;
+  float* dst;
+  uint64_t dst_inst, dst_ch;
+  const int32_t* prev;      // [n_inst][prev_stride]: LINK_SKIP / LINK_FRESH / previous processed quantum
+  uint64_t prev_stride;
+  const float* curve;
+  int32_t curve_n;
+  int32_t R;                // 2 or 4
+  const float* tables;      // 2 R tables of osfft::TAB_SLOTS complex values (U_r, then V_r), lane-major rows
+  const float* tw256;       // exp(-2 pi i j / 256)
+  int32_t nch;              // 1 or 2
+  uint32_t n_inst, n_quanta;
+  uint32_t seg_len, n_seg;  // quanta per run, runs per instance (n_seg * seg_len >= n_quanta)
+};
+void launch_osfft(const OsFftDesc& d, void* stream);
+size_t osfft_lds_bytes(int R, int curve_n);
+
 // HRTF panner (panner.rs:781-829 + crate hrtf): per render quantum the HRIR pair of the direction
 // (barycentric mix of three measured HRIRs) is convolved with the mono input continued into the previously processed
 // quanta; direct-form FIR, one wavefront per (instance, quantum).

@@ -2174,7 +2174,7 @@ int build_plan(waa_batch* b) {
           }
         }
         st.prologue |= st.kind == 18;
-        if (st.kind == 15 || st.kind == 16 || st.kind == 17)
+        if (st.kind == 15 || st.kind == 16 || st.kind == 17 || st.kind == 20)
           return fail(WAA_ERR_OUT_OF_SCOPE, "this node kind cannot be rendered inside a feedback loop");
       }
       plan_note(b, "feedback loop: block-scheduled, %u tile(s) = %u frames per block, %zu step(s) per block", bt, bt * TILE,
@@ -2326,6 +2326,7 @@ StepIo step_io(const Step& st) {
     case 10:
     case 16:
     case 17:
+    case 20:
       io.reads = st.loop_reads;
       io.writes = st.loop_writes;
       break;
@@ -2349,7 +2350,7 @@ StepIo step_io(const Step& st) {
 void fuse_echo_tails(waa_batch* b) {
   if (getenv("WAA_NO_ECHO_TAIL")) return;
   for (const Step& st : b->steps)
-    if (st.kind == 11 || st.kind == 15 || st.kind > 19) return;
+    if (st.kind == 11 || st.kind == 15 || st.kind > 20) return;
   for (size_t l = 0; l < b->steps.size(); l++) {
     Step& ls = b->steps[l];
     if (ls.kind != 0 || ls.echo_fb < 0) continue;
