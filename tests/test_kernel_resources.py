@@ -91,16 +91,17 @@ def test_echo_ring_kernel_fits_one_workgroup_of_sixteen_waves(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
-def test_oversampler_transform_kernel_keeps_two_waves_per_simd_at_2x(tmp_path):
-    """waa_osfft.hip: the 2x instantiation carries its whole state (two stages' overlaps, two spectra, the transform in flight)
-    in at most 256 registers — two wavefronts per SIMD hide each other's LDS exchanges; it was 304 with a divergent branch
-    around the state reset plus an early exit from the loop (copies of the carried state), which is how the kernel is written
-    the way it is.  The 4x instantiation holds twice the overlap and runs one wavefront per SIMD; neither touches scratch."""
+def test_oversampler_transform_kernels_keep_two_waves_per_simd(tmp_path):
+    """waa_osfft.hip: a group's whole state (two stages' overlaps, two spectra, the transform in flight) stays within 256
+    registers — two wavefronts per SIMD hide each other's LDS exchanges.  It was 304 (2x) / 426 (4x) with a divergent branch
+    around the state reset, an early exit from the loop and branchy curve lookups (copies of the carried state), which is how
+    the kernel came to be written the way it is.  The 4x instantiations sit exactly at the limit and may park one pointer in
+    scratch (reloaded once per quantum); nothing else may spill."""
     res = kernel_resources("waa_osfft.hip", tmp_path)
     x2 = {n: v for n, v in res.items() if "osfft_kernelILi2E" in n}
     x4 = {n: v for n, v in res.items() if "osfft_kernelILi4E" in n}
-    assert len(x2) == 2 and len(x4) == 2, sorted(res)
+    assert len(x2) == 4 and len(x4) == 4, sorted(res)
     for name, r in x2.items():
         assert r["vgpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (name, r)
     for name, r in x4.items():
-        assert r["vgpr"] <= 512 and r["spill"] == 0 and r["scratch"] == 0, (name, r)
+        assert r["vgpr"] <= 256 and r["spill"] <= 2 and r["scratch"] <= 16, (name, r)

@@ -73,10 +73,7 @@ static void run(int nch, int nq, int seg_len, const std::vector<int32_t>& prev, 
         for (int t = 0; t < 16; t++) {
           c2v uu[8];
           ph_up_out(L[t], r, proc, uu);
-          for (int j = 0; j < 8; j++) {
-            uu[j].x = shape(curve.data(), cn, c_first, c_last, uu[j].x);
-            uu[j].y = shape(curve.data(), cn, c_first, c_last, uu[j].y);
-          }
+          for (int j = 0; j < 8; j++) uu[j] = shape2<false>(curve.data(), cn, c_first, c_last, uu[j]);
           ph_dn(L[t], uu);
         }
         exchange();

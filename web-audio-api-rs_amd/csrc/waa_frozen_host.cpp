@@ -226,7 +226,8 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
   if (!matrix_form && nch <= 2) {
     // Transform form (waa_osfft.hip): one launch, the stages as 256-point transforms, nothing at the high rate in HBM.
     float *d_tab = nullptr, *d_tw = nullptr;
-    if ((e = dev_upload(b, &d_tab, osfft::tables(R))) || (e = dev_upload(b, &d_tw, osfft::tw256()))) return e;
+    float* d_trash = nullptr;
+    if ((e = dev_upload(b, &d_tab, osfft::tables(R))) || (e = dev_upload(b, &d_tw, osfft::tw256())) || (e = dev_alloc(b, &d_trash, 64))) return e;
     Step os;
     os.kind = 20;
     OsFftDesc& f = os.osfft;
@@ -244,6 +245,7 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
     f.R = R;
     f.tables = d_tab;
     f.tw256 = d_tw;
+    f.trash = d_trash;
     f.nch = nch;
     f.n_inst = b->n_inst;
     f.n_quanta = b->n_quanta;

@@ -596,6 +596,7 @@ struct OsFftDesc {
   int32_t R;                // 2 or 4
   const float* tables;      // 2 R tables of osfft::TAB_SLOTS complex values (U_r, then V_r), lane-major rows
   const float* tw256;       // exp(-2 pi i j / 256)
+  float* trash;             // 64 floats nobody reads: where lanes that do not store a quantum put their values
   int32_t nch;              // 1 or 2
   uint32_t n_inst, n_quanta;
   uint32_t seg_len, n_seg;  // quanta per run, runs per instance (n_seg * seg_len >= n_quanta)

@@ -32,8 +32,8 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int R, bool CLDS>
-__global__ __launch_bounds__(WAVES * 64) void osfft_kernel(const OsFftDesc d) {
+template <int R, bool CLDS, bool STEREO>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void osfft_kernel(const OsFftDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   // LDS map (8-byte slots): 2 R tables | WAVES * 4 exchange buffers | curve (floats)
   const ldsp tab = (ldsp)lds_raw;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(WAVES * 64) void osfft_kernel(const OsFftDesc d) {
     for (int i = threadIdx.x; i < 2 * R * TAB_SLOTS / 2; i += WAVES * 64) dst[i] = load_global_f4(reinterpret_cast<const float*>(src + i));
     if (CLDS) {
       __attribute__((address_space(3))) float* cw = (__attribute__((address_space(3))) float*)cv;
-      for (int i = threadIdx.x; i < d.curve_n; i += WAVES * 64) cw[i] = load_global(d.curve + i);
+      for (int i = threadIdx.x; i <= d.curve_n; i += WAVES * 64) cw[i] = load_global(d.curve + (i < d.curve_n ? i : d.curve_n - 1));  // (+ the pad)
     }
   }
   __syncthreads();
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(WAVES * 64) void osfft_kernel(const OsFftDesc d) {
   lane_reset(L);
   const float* src = d.src + (uint64_t)(alive ? inst : 0) * d.src_inst;
   float* dst = d.dst + (uint64_t)(alive ? inst : 0) * d.dst_inst;
-  const bool stereo = d.nch == 2;
+  constexpr bool stereo = STEREO;
   const float c_first = d.curve_n > 0 ? load_global(d.curve) : 0.f, c_last = d.curve_n > 0 ? load_global(d.curve + d.curve_n - 1) : 0.f;
   const int n_it = (int)d.seg_len + 2;
   // step `it` of a group: its quantum (the two run heads first), whether the node processes it, whether it is stored
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(WAVES * 64) void osfft_kernel(const OsFftDesc d) {
     lane_reset_if(L, proc && link == LINK_FRESH);  // re-created resamplers (or the first processed quantum)
     // (the tables are loop-invariant LDS reads: the address is made opaque so that they are not hoisted out of the loop)
     int tofs = 0;
-    asm volatile("" : "+v"(tofs));
+    asm volatile("" : "+s"(tofs));
     const ldsp tabq = tab + tofs;
     {
       c2v x[8];
@@ -149,15 +149,9 @@ __global__ __launch_bounds__(WAVES * 64) void osfft_kernel(const OsFftDesc d) {
       c2v u[8];
       ph_up_out(L, r, proc, u);
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        if (CLDS) {
-          u[j].x = shape(cv, d.curve_n, c_first, c_last, u[j].x);
-          u[j].y = shape(cv, d.curve_n, c_first, c_last, u[j].y);
-        } else {
-          u[j].x = shape((const WAA_GLOBAL_AS float*)d.curve, d.curve_n, c_first, c_last, u[j].x);
-          u[j].y = shape((const WAA_GLOBAL_AS float*)d.curve, d.curve_n, c_first, c_last, u[j].y);
-        }
-      }
+      for (int j = 0; j < 8; j++)
+        u[j] = CLDS ? shape2<true>(cv, d.curve_n, c_first, c_last, u[j])
+                    : shape2<false>((const WAA_GLOBAL_AS float*)d.curve, d.curve_n, c_first, c_last, u[j]);
       ph_dn(L, u);
       xwrite(L.a, ex, t);
       wsync();
@@ -175,11 +169,14 @@ __global__ __launch_bounds__(WAVES * 64) void osfft_kernel(const OsFftDesc d) {
     wsync();
     c2v o[8];
     ph_out_end(L, proc, o);
-    if (store) {
+    {
+      // (lanes that do not store write their values to a scratch row instead of branching around sixteen stores)
+      float* p0 = store ? dst + (uint64_t)q * RQ + t : d.trash + lane;
+      float* p1c = store && stereo ? p0 + d.dst_ch : d.trash + lane;
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        store_global(dst + (uint64_t)q * RQ + 16 * j + t, proc ? o[j].x : 0.f);
-        if (stereo) store_global(dst + d.dst_ch + (uint64_t)q * RQ + 16 * j + t, proc ? o[j].y : 0.f);
+        store_global(p0 + (store ? 16 * j : 0), proc ? o[j].x : 0.f);
+        if (stereo) store_global(p1c + (store ? 16 * j : 0), proc ? o[j].y : 0.f);
       }
     }
   }
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(WAVES * 64) void osfft_kernel(const OsFftDesc d) {
 
 size_t osfft_lds_bytes(int R, int curve_n) {
   const bool clds = curve_n <= CURVE_LDS_MAX;
-  return ((size_t)2 * R * TAB_SLOTS + (size_t)WAVES * 4 * XSLOTS) * 8 + (clds ? (size_t)((curve_n + 3) & ~3) * 4 : 0);
+  return ((size_t)2 * R * TAB_SLOTS + (size_t)WAVES * 4 * XSLOTS) * 8 + (clds ? (size_t)((curve_n + 4) & ~3) * 4 : 0);
 }
 void launch_osfft(const OsFftDesc& d, void* stream) {
   const bool clds = d.curve_n <= CURVE_LDS_MAX;
@@ -199,10 +196,18 @@ void launch_osfft(const OsFftDesc& d, void* stream) {
     if (lds > 64 * 1024) raise_lds_limit(reinterpret_cast<const void*>(kern));
     hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, d);
   };
-  if (d.R == 2)
-    clds ? go(osfft_kernel<2, true>) : go(osfft_kernel<2, false>);
-  else
-    clds ? go(osfft_kernel<4, true>) : go(osfft_kernel<4, false>);
+  const bool st = d.nch == 2;
+  if (d.R == 2) {
+    if (st)
+      clds ? go(osfft_kernel<2, true, true>) : go(osfft_kernel<2, false, true>);
+    else
+      clds ? go(osfft_kernel<2, true, false>) : go(osfft_kernel<2, false, false>);
+  } else {
+    if (st)
+      clds ? go(osfft_kernel<4, true, true>) : go(osfft_kernel<4, false, true>);
+    else
+      clds ? go(osfft_kernel<4, true, false>) : go(osfft_kernel<4, false, false>);
+  }
 }
 
 }  // namespace waa

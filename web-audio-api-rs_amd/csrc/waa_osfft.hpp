@@ -39,7 +39,8 @@ using fft3::ldsp;
 using fft3::K16;
 
 constexpr int ROW = 18;              // pitch (8-byte slots) of a 16-slot row: 144 B lane stride, conflict-free 16-byte accesses
-constexpr int XSLOTS = 16 * ROW;     // one group's exchange buffer: E[k1][n2]
+constexpr int XSLOTS = 16 * ROW + 16;  // one group's exchange buffer E[k1][n2] (288 slots) + 128 B: the buffers of the four groups of a
+                                      // wavefront start in alternating halves of the banks (2304 B apart they collide pairwise)
 constexpr int TAB_SLOTS = 16 * ROW;  // one table (U_r or V_r) in lane-major rows: T[t][s] = table[t + 16 K16(s)]
 
 // The lane's pass-1 twiddles W_256^(t k1), k1 = 1..15, kept as six values instead of fifteen (the kernel is short of
@@ -57,25 +58,6 @@ F3_FN void load_tw(const c2v* tw256, int t, Tw& w) {
   }
   w.lo[0] = w.hi[0] = c2v{1.f, 0.f};
 }
-// x * W_256^(t k1) (INV: conjugated)
-template <bool INV, int K1>
-F3_FN c2v mul_tw(c2v x, const Tw& w) {
-  constexpr int a = K1 & 3, b = K1 >> 2;
-  if constexpr (K1 == 0) return x;
-  else if constexpr (b == 0) return INV ? fft3::cmulc(x, w.lo[a]) : fft3::cmul(x, w.lo[a]);
-  else if constexpr (a == 0) return INV ? fft3::cmulc(x, w.hi[b]) : fft3::cmul(x, w.hi[b]);
-  else {
-    const c2v ww = fft3::cmul(w.lo[a], w.hi[b]);
-    return INV ? fft3::cmulc(x, ww) : fft3::cmul(x, ww);
-  }
-}
-template <bool INV>
-F3_FN void apply_tw(c2v (&x)[16], const Tw& w) {
-#define OSF_T(S) x[S] = mul_tw<INV, K16(S)>(x[S], w);
-  OSF_T(1) OSF_T(2) OSF_T(3) OSF_T(4) OSF_T(5) OSF_T(6) OSF_T(7) OSF_T(8) OSF_T(9) OSF_T(10) OSF_T(11) OSF_T(12) OSF_T(13) OSF_T(14) OSF_T(15)
-#undef OSF_T
-}
-
 // acc + a * w as two packed FMAs: (acc.re + a.re w.re, acc.im + a.re w.im), then (.. - a.im w.im, .. + a.im w.re)
 F3_FN c2v cmac(c2v acc, c2v a, c2v w) {
 #if F3_DEV
@@ -87,6 +69,87 @@ F3_FN c2v cmac(c2v acc, c2v a, c2v w) {
   const c2v r = c2v{__builtin_fmaf(a.x, w.x, acc.x), __builtin_fmaf(a.x, w.y, acc.y)};
   return c2v{__builtin_fmaf(a.y, -w.y, r.x), __builtin_fmaf(a.y, w.x, r.y)};
 #endif
+}
+
+// Four independent complex multiplies in one block, the four products first and the four fused steps after them: a packed-f32
+// result cannot be forwarded to the very next instruction (the compiler puts an s_nop between a dependent pair — 250 of them
+// per quantum with one multiply at a time), so dependent halves are kept four instructions apart.  Same operations as
+// fft3::cmul / cmulc, element by element.
+template <bool CONJ>
+F3_FN void cmul4(c2v& r0, c2v& r1, c2v& r2, c2v& r3, c2v a0, c2v a1, c2v a2, c2v a3, c2v w0, c2v w1, c2v w2, c2v w3) {
+#if F3_DEV
+  c2v t0, t1, t2, t3;
+  if (!CONJ)
+    asm("v_pk_mul_f32 %0, %4, %8 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %5, %9 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %2, %6, %10 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %3, %7, %11 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+        "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+        "v_pk_fma_f32 %2, %6, %10, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+        "v_pk_fma_f32 %3, %7, %11, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+  else
+    asm("v_pk_mul_f32 %0, %4, %8 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %5, %9 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %2, %6, %10 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %3, %7, %11 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %2, %6, %10, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %3, %7, %11, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+  r0 = t0;
+  r1 = t1;
+  r2 = t2;
+  r3 = t3;
+#else
+  const c2v t0 = CONJ ? fft3::cmulc(a0, w0) : fft3::cmul(a0, w0), t1 = CONJ ? fft3::cmulc(a1, w1) : fft3::cmul(a1, w1);
+  const c2v t2 = CONJ ? fft3::cmulc(a2, w2) : fft3::cmul(a2, w2), t3 = CONJ ? fft3::cmulc(a3, w3) : fft3::cmul(a3, w3);
+  r0 = t0;
+  r1 = t1;
+  r2 = t2;
+  r3 = t3;
+#endif
+}
+// four accumulating ones (cmac), the two fused steps of an element four instructions apart
+F3_FN void cmac4(c2v& z0, c2v& z1, c2v& z2, c2v& z3, c2v a0, c2v a1, c2v a2, c2v a3, c2v w0, c2v w1, c2v w2, c2v w3) {
+#if F3_DEV
+  asm("v_pk_fma_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %2, %6, %10, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %3, %7, %11, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_fma_f32 %2, %6, %10, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_fma_f32 %3, %7, %11, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "+&v"(z0), "+&v"(z1), "+&v"(z2), "+&v"(z3)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+#else
+  z0 = cmac(z0, a0, w0);
+  z1 = cmac(z1, a1, w1);
+  z2 = cmac(z2, a2, w2);
+  z3 = cmac(z3, a3, w3);
+#endif
+}
+
+// x[s] *= W_256^(t K16(s)), s = 1..15 (INV: conjugated): the nine composite twiddles first, then the products, four at a time
+template <bool INV>
+F3_FN void apply_tw(c2v (&x)[16], const Tw& w) {
+  // tw[k1], k1 = 1..15: lo[a] (b == 0), hi[b] (a == 0), lo[a] * hi[b]
+  c2v tw[16];
+  tw[1] = w.lo[1]; tw[2] = w.lo[2]; tw[3] = w.lo[3];
+  tw[4] = w.hi[1]; tw[8] = w.hi[2]; tw[12] = w.hi[3];
+  cmul4<false>(tw[5], tw[6], tw[7], tw[9], w.lo[1], w.lo[2], w.lo[3], w.lo[1], w.hi[1], w.hi[1], w.hi[1], w.hi[2]);
+  cmul4<false>(tw[10], tw[11], tw[13], tw[14], w.lo[2], w.lo[3], w.lo[1], w.lo[2], w.hi[2], w.hi[2], w.hi[3], w.hi[3]);
+  tw[15] = fft3::cmul(w.lo[3], w.hi[3]);
+  // slot s holds k1 = K16(s)
+  cmul4<INV>(x[1], x[2], x[3], x[4], x[1], x[2], x[3], x[4], tw[K16(1)], tw[K16(2)], tw[K16(3)], tw[K16(4)]);
+  cmul4<INV>(x[5], x[6], x[7], x[8], x[5], x[6], x[7], x[8], tw[K16(5)], tw[K16(6)], tw[K16(7)], tw[K16(8)]);
+  cmul4<INV>(x[9], x[10], x[11], x[12], x[9], x[10], x[11], x[12], tw[K16(9)], tw[K16(10)], tw[K16(11)], tw[K16(12)]);
+  cmul4<INV>(x[13], x[14], x[15], tw[0], x[13], x[14], x[15], x[15], tw[K16(13)], tw[K16(14)], tw[K16(15)], tw[K16(15)]);
 }
 
 // pass 1 of a 256-point transform: x[n1] natural -> slot s holds (sum_n1 x[n1] W_16^(n1 K16(s))) W_256^(t K16(s))
@@ -164,6 +227,32 @@ F3_FN float shape(P curve, int nn, float c_first, float c_last, float input) {
   return nn == 0 ? 0.f : (v <= 0.f ? c_first : (v >= n - 1.f ? c_last : r));
 }
 
+// both channels of one frame: the arithmetic as packed operations (IEEE, element-wise: the same values as shape() per channel)
+// PADDED: the table holds one more element (a copy of the last one), so curve[k + 1] is always readable and the two reads
+// of a lookup are one ds_read2_b32
+template <bool PADDED, typename P>
+F3_FN c2v shape2(P curve, int nn, float c_first, float c_last, c2v in) {
+  const float n = (float)nn;
+  const float hn = (n - 1.f) / 2.0f;
+  const c2v v = c2v{hn, hn} * (in + c2v{1.f, 1.f});
+  const c2v k = c2v{__builtin_floorf(v.x), __builtin_floorf(v.y)};
+  const c2v f = v - k;
+  const int hi = nn >= 2 ? nn - 2 : 0, st = PADDED ? 1 : (nn >= 2 ? 1 : 0);
+  int k0 = (int)k.x, k1 = (int)k.y;
+  k0 = k0 < 0 ? 0 : (k0 > hi ? hi : k0);
+  k1 = k1 < 0 ? 0 : (k1 > hi ? hi : k1);
+  const c2v ca = c2v{curve[k0], curve[k1]}, cb = c2v{curve[k0 + st], curve[k1 + st]};
+  const c2v r = (c2v{1.f, 1.f} - f) * ca + f * cb;
+  // (sequential selects, innermost first: nested conditionals with the uniform nn == 0 test became 32 branches per quantum;
+  // an empty curve never gets here — a WaveShaperNode without a curve is an identity the planner aliases)
+  c2v o;
+  o.x = v.x >= n - 1.f ? c_last : r.x;
+  o.y = v.y >= n - 1.f ? c_last : r.y;
+  o.x = v.x <= 0.f ? c_first : o.x;
+  o.y = v.y <= 0.f ? c_first : o.y;
+  return o;
+}
+
 // ---- one lane's part of a quantum, phase by phase (an exchange through LDS sits between two phases: xwrite, wave
 // barrier, xread — the caller's; the emulator runs every phase for the 16 lanes of a group in turn) ------------------------
 template <int R>
@@ -221,7 +310,9 @@ F3_FN void ph_up(Lane<R>& L, cldsp tab_r, int t) {
     c2v w[8];
     tab_read8(w, tab_r, t, h);
 #pragma unroll
-    for (int s = 8 * h; s < 8 * h + 8; s++) L.a[K16(s)] = fft3::cmul(L.Z[s], w[s - 8 * h]);  // natural order: bin t + 16 K16(s)
+    for (int s = 8 * h; s < 8 * h + 8; s += 4)  // natural order: bin t + 16 K16(s)
+      cmul4<false>(L.a[K16(s)], L.a[K16(s + 1)], L.a[K16(s + 2)], L.a[K16(s + 3)], L.Z[s], L.Z[s + 1], L.Z[s + 2], L.Z[s + 3],
+                   w[s - 8 * h], w[s + 1 - 8 * h], w[s + 2 - 8 * h], w[s + 3 - 8 * h]);
   }
   pass1<true>(L.a, L.tws);
 }
@@ -253,8 +344,14 @@ F3_FN void ph_dn_acc(Lane<R>& L, int r, cldsp tab_r, int t) {
     c2v w[8];
     tab_read8(w, tab_r, t, h);
 #pragma unroll
-    for (int s = 8 * h; s < 8 * h + 8; s++)
-      L.Z3[s] = r == 0 ? fft3::cmul(L.a[s], w[s - 8 * h]) : cmac(L.Z3[s], L.a[s], w[s - 8 * h]);
+    for (int s = 8 * h; s < 8 * h + 8; s += 4) {
+      const int o = s - 8 * h;
+      if (r == 0)
+        cmul4<false>(L.Z3[s], L.Z3[s + 1], L.Z3[s + 2], L.Z3[s + 3], L.a[s], L.a[s + 1], L.a[s + 2], L.a[s + 3], w[o], w[o + 1], w[o + 2],
+                     w[o + 3]);
+      else
+        cmac4(L.Z3[s], L.Z3[s + 1], L.Z3[s + 2], L.Z3[s + 3], L.a[s], L.a[s + 1], L.a[s + 2], L.a[s + 3], w[o], w[o + 1], w[o + 2], w[o + 3]);
+    }
   }
 }
 // Z3 -> pass 1 of o
