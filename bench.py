@@ -428,12 +428,15 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
     from web_audio_api_rs_amd.sharding import render_sharded
     frames = int(round(seconds * SR))
 
-    def run_graph(graph, n, parts, pcm=False):
+    def run_graph(graph, n, parts, pcm=False, pcm_out=False):
         if pcm:
             host_in = torch.empty((n, frames, 2), dtype=torch.int16, pin_memory=True).random_(-32768, 32767)
         else:
             host_in = torch.empty((n, 2, frames), dtype=torch.float32, pin_memory=True).uniform_(-1.0, 1.0)
-        host_out = torch.empty((n, 2, frames), dtype=torch.float32, pin_memory=True)
+        if pcm_out:  # waa_download_all_pcm16: interleaved 16-bit PCM back over the link
+            host_out = torch.empty((n, frames, 2), dtype=torch.int16, pin_memory=True)
+        else:
+            host_out = torch.empty((n, 2, frames), dtype=torch.float32, pin_memory=True)
         bins = np.zeros((n, 1024), np.float32)
 
         def build(n_sub_inst, device):
@@ -449,7 +452,7 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
             if dist is not None:
                 dist.barrier()
             t = render_sharded(build, host_in, host_out, devices=(local_rank,), sub_batches=parts, sample_rate=SR, pcm16=pcm,
-                               pull=pull if graph == "c4" else None)["seconds"]
+                               pull=pull if graph == "c4" else None, out_pcm16=pcm_out)["seconds"]
             if dist is not None:
                 tt = torch.tensor([t], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -459,8 +462,8 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
         nq = (frames + RQ - 1) // RQ
         return best * 1e3, world * n * nq / best
 
-    rec = {"note": "host (pinned) -> set_buffer_batch -> render -> download_all, batch creation and planning included, "
-                   "PCIe-bound; every rank at once, slowest rank's time", "sub_batches": n_sub}
+    rec = {"note": "host (pinned) -> waa_render_sharded (C ABI: set_buffer_batch -> render -> download_all per sub-batch, pipelined), "
+                   "batch creation and planning included, PCIe-bound; every rank at once, slowest rank's time", "sub_batches": n_sub}
     if world == 1:
         ms1, _ = run_graph("c2", n_inst, 1)
         rec["c2_single_batch_ms"] = ms1
@@ -471,6 +474,8 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
         try:
             ms, _ = run_graph("c2", n_inst, n_sub, pcm=True)
             rec["c2_pcm16_ms"] = ms
+            ms, _ = run_graph("c2", n_inst, n_sub, pcm=True, pcm_out=True)
+            rec["c2_pcm16_in_and_out_ms"] = ms
         except Exception as e:  # reporting only
             rec["c2_pcm16_error"] = repr(e)[:100]
     ms, qps = run_graph("c4", 512, n_sub)

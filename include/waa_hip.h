@@ -297,6 +297,54 @@ waa_status waa_sync(waa_batch* batch);
 waa_status waa_download(waa_batch* batch, uint32_t instance, uint32_t channel, float* dst, uint64_t frames);
 /* all instances: dst laid out [instance][channel][length_frames] */
 waa_status waa_download_all(waa_batch* batch, float* dst);
+/* all instances as interleaved 16-bit PCM, dst laid out [instance][frame][channel] — the layout of the `_pcm16_batch`
+ * uploads: half the device-to-host bytes, which is what bounds the boundary when the caller holds host buffers (DESIGN.md
+ * section 6).  sample * 32768 rounded to nearest, saturated to [-32768, 32767], NaN -> 0: the inverse of the decoder's
+ * sample / 32768 (src/decoding.rs:15-54).  An extension: an OfflineAudioContext hands back f32 planes
+ * (src/context/offline.rs:157-185); use it where the next step is a 16-bit file anyway. */
+waa_status waa_download_all_pcm16(waa_batch* batch, int16_t* dst);
+
+/* ---- N devices --------------------------------------------------------------------------
+ * BASELINE config 4 (4096 contexts over the 8 GPUs of a node) as ONE call: what a host that holds every context's
+ * AudioBuffer does instead of N x start_rendering_sync (src/context/offline.rs:157-185) — the reference renders one context
+ * per thread on the CPU; here contexts are partitioned into contiguous ranges per device (no
+ * collective, nothing crosses devices), each range is cut into `sub_batches` batches and every batch runs on its own host
+ * thread: upload of one || render of another || download of a third on each device, one transfer per direction and device
+ * at a time.  The graph is the same for every batch; what differs per context is configured by `setup`.            */
+#define WAA_NO_NODE 0xFFFFFFFFu
+/* called on the sub-batch's thread with the batch just created for the job's contexts [first, first + count): payloads
+ * other than the streamed source buffer (impulse responses, curves), AudioParam values / automation, start / stop / loop.
+ * A non-zero return aborts that sub-batch and is what waa_render_sharded returns (first error wins). */
+typedef int32_t /* waa_status */ (*waa_shard_setup_fn)(waa_batch* batch, uint32_t first, uint32_t count, int32_t device, void* user);
+/* called after the sub-batch's render, before its download: control-side pulls (the batched AnalyserNode getters) */
+typedef int32_t /* waa_status */ (*waa_shard_pull_fn)(waa_batch* batch, uint32_t first, uint32_t count, int32_t device, void* user);
+typedef struct waa_sharded_job {
+  const waa_graph_desc* graph;
+  uint32_t n_instances;          /* contexts of the whole job */
+  uint32_t n_channels_out;
+  uint64_t length_frames;
+  float sample_rate;
+  uint32_t n_devices;
+  const int32_t* devices;        /* HIP device ordinals; device d renders the d-th contiguous range (waa_shard_range) */
+  uint32_t sub_batches;          /* per device (>= 1; 8 keeps both directions of the link busy) */
+  uint32_t source_node;          /* the AudioBufferSourceNode fed from host_in, or WAA_NO_NODE */
+  const void* host_in;           /* f32 [n_instances][in_channels][in_frames], or (in_pcm16) i16 [n_instances][in_frames][in_channels] */
+  uint32_t in_channels;
+  int32_t in_pcm16;
+  uint64_t in_frames;
+  float in_sample_rate;
+  int32_t out_pcm16;
+  void* host_out;                /* f32 [n_instances][n_channels_out][length_frames], or (out_pcm16) i16 [n_instances][length_frames][n_channels_out] */
+  waa_shard_setup_fn setup;      /* may be NULL */
+  waa_shard_pull_fn pull;        /* may be NULL */
+  void* user;
+} waa_sharded_job;
+/* Blocks until every context is rendered and downloaded; *seconds (may be NULL) = wall time.  Pinned host buffers let
+ * the transfers run at link speed.  Under one process per GPU (torch.distributed, MPI) every rank calls this with its own
+ * device and its own slice of the contexts. */
+waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds);
+/* the partition rule: contexts [*first, *end) of n_total belong to part `part` of `n_parts` (sizes differ by at most one) */
+waa_status waa_shard_range(uint32_t n_total, uint32_t part, uint32_t n_parts, uint32_t* first, uint32_t* end);
 /* device pointer + strides (in floats) of the rendered output, valid until destroy */
 waa_status waa_output_device(waa_batch* batch, const float** device_ptr, uint64_t* instance_stride,
                              uint64_t* channel_stride);

@@ -56,6 +56,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #if defined(__x86_64__)
 #include <xmmintrin.h>
 #include <pmmintrin.h>
@@ -3795,6 +3796,84 @@ waa_status orc_download(orc_batch* b, uint32_t inst, uint32_t ch, float* dst, ui
 waa_status orc_download_all(orc_batch* b, float* dst) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
   memcpy(dst, b->out, sizeof(float) * (size_t)b->n_inst * b->n_out * b->length);
+  return WAA_OK;
+}
+/* waa_download_all_pcm16: sample * 32768 rounded to nearest (ties to even, like the device's cvt), saturated, NaN -> 0 */
+waa_status orc_download_all_pcm16(orc_batch* b, int16_t* dst) {
+  if (!b || !dst) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch / destination");
+  for (uint32_t i = 0; i < b->n_inst; i++)
+    for (uint64_t f = 0; f < b->length; f++)
+      for (uint32_t c = 0; c < b->n_out; c++) {
+        float v = b->out[((size_t)i * b->n_out + c) * b->length + f] * 32768.f;
+        v = v < -32768.f ? -32768.f : (v > 32767.f ? 32767.f : v);
+        dst[((size_t)i * b->length + f) * b->n_out + c] = (int16_t)lrintf(v != v ? 0.f : v);
+      }
+  return WAA_OK;
+}
+/* waa_shard_range / waa_render_sharded: the same partition and the same callbacks, sub-batch after sub-batch on the
+ * calling thread (the `devices` are only passed through to the callbacks) — lets the tests exercise hosts written against
+ * the N-device entry point without a GPU. */
+static void orc_split(uint32_t n, uint32_t part, uint32_t parts, uint32_t* lo, uint32_t* hi) {
+  uint32_t base = n / parts, rem = n % parts;
+  *lo = part * base + (part < rem ? part : rem);
+  *hi = *lo + base + (part < rem ? 1u : 0u);
+}
+waa_status orc_shard_range(uint32_t n_total, uint32_t part, uint32_t n_parts, uint32_t* first, uint32_t* end) {
+  if (!first || !end || n_parts == 0 || part >= n_parts) return fail(WAA_ERR_INVALID_ARGUMENT, "bad shard index %u of %u", part, n_parts);
+  orc_split(n_total, part, n_parts, first, end);
+  return WAA_OK;
+}
+waa_status orc_render_sharded(const waa_sharded_job* job, double* seconds) {
+  if (!job || !job->graph) return fail(WAA_ERR_INVALID_ARGUMENT, "null job / graph");
+  if (job->n_instances == 0) return fail(WAA_ERR_INVALID_ARGUMENT, "a sharded job needs at least one context");
+  if (!job->devices || job->n_devices == 0) return fail(WAA_ERR_INVALID_ARGUMENT, "a sharded job needs at least one device");
+  if (!job->host_out) return fail(WAA_ERR_INVALID_ARGUMENT, "null output buffer");
+  int streamed = job->source_node != WAA_NO_NODE;
+  if (streamed && (!job->host_in || job->in_channels == 0 || job->in_channels > WAA_MAX_CHANNELS))
+    return fail(WAA_ERR_INVALID_ARGUMENT, "the streamed source needs host_in and 1..%d channels", WAA_MAX_CHANNELS);
+  size_t row_in = (size_t)job->in_channels * job->in_frames * (job->in_pcm16 ? sizeof(int16_t) : sizeof(float));
+  size_t row_out = (size_t)job->n_channels_out * job->length_frames * (job->out_pcm16 ? sizeof(int16_t) : sizeof(float));
+  uint32_t sub = job->sub_batches ? job->sub_batches : 1;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  waa_status first_error = WAA_OK;
+  char msg[512] = "";
+  for (uint32_t di = 0; di < job->n_devices; di++) {
+    uint32_t lo, hi;
+    orc_split(job->n_instances, di, job->n_devices, &lo, &hi);
+    uint32_t parts = hi - lo < sub ? hi - lo : sub;
+    if (parts == 0) parts = 1;
+    for (uint32_t p = 0; p < parts; p++) {
+      uint32_t a, e;
+      orc_split(hi - lo, p, parts, &a, &e);
+      if (e <= a) continue;
+      uint32_t first = lo + a, count = e - a;
+      orc_batch* b = NULL;
+      waa_status st = orc_batch_create(job->graph, count, job->n_channels_out, job->length_frames, job->sample_rate, job->devices[di], &b);
+      if (!st && job->setup) st = job->setup((waa_batch*)b, first, count, job->devices[di], job->user);
+      if (!st && streamed) {
+        const char* src = (const char*)job->host_in + (size_t)first * row_in;
+        st = job->in_pcm16 ? orc_source_set_buffer_pcm16_batch(b, job->source_node, (const int16_t*)src, job->in_channels, job->in_frames,
+                                                               job->in_sample_rate)
+                           : orc_source_set_buffer_batch(b, job->source_node, (const float*)src, job->in_channels, job->in_frames,
+                                                         job->in_sample_rate);
+      }
+      if (!st) st = orc_render(b);
+      if (!st && job->pull) st = job->pull((waa_batch*)b, first, count, job->devices[di], job->user);
+      if (!st) {
+        char* dst = (char*)job->host_out + (size_t)first * row_out;
+        st = job->out_pcm16 ? orc_download_all_pcm16(b, (int16_t*)dst) : orc_download_all(b, (float*)dst);
+      }
+      if (st && first_error == WAA_OK) {
+        first_error = st;
+        snprintf(msg, sizeof msg, "%s", orc_last_error());
+      }
+      if (b) orc_batch_destroy(b);
+    }
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  if (first_error != WAA_OK) return fail(first_error, "%s", msg);
   return WAA_OK;
 }
 waa_status orc_output_device(orc_batch* b, const float** p, uint64_t* is, uint64_t* cs) {

@@ -75,11 +75,13 @@ def test_sharded_render_pcm16_and_pull(orc):
 
 
 def test_a_failing_sub_batch_raises_and_does_not_hang(orc):
+    calls = []
+
     def build(n, device):
-        ctx, src = _build(orc)(n, device)
-        if n == 2:  # (the second of the two sub-batches: 5 contexts = 3 + 2)
-            ctx.create_stereo_panner(channel_count=2, channel_count_mode="max")  # NotSupportedError at batch creation
-        return ctx, src
+        calls.append(n)
+        if len(calls) == 3:  # (the template, the first sub-batch, then the second of the two: 5 contexts = 3 + 2)
+            raise waa.WaaError(2, "NotSupportedError - the second sub-batch refuses its configuration")
+        return _build(orc)(n, device)
     noise = white_noise(5, 2, RQ * 30 + 5)
     with pytest.raises(waa.WaaError, match="NotSupportedError"):
         render_sharded(build, noise, np.zeros_like(noise), devices=[-1], sub_batches=2)
@@ -120,3 +122,87 @@ def test_sharded_render_two_devices_hip(hip):
     whole = ctx.start_rendering_sync().data
     ctx.close()
     assert np.array_equal(out, whole)
+
+
+def test_sharded_render_pcm16_output(orc):
+    """out_pcm16: every context's AudioBuffer as interleaved 16-bit PCM (waa_download_all_pcm16): sample * 32768 rounded to
+    nearest and saturated — half the bytes back over the link"""
+    n, frames = 5, RQ * 30 + 5
+    noise = white_noise(n, 2, frames) * 1.9   # (some samples beyond +-1 after the gain of 0.5? no: keep a few that saturate)
+    noise[0, 0, :8] = [4.0, -4.0, 2.1, -2.1, 0.0, 1e-6, -1e-6, 1.999]
+    out16 = np.zeros((n, frames, 2), np.int16)
+    render_sharded(_build(orc), noise, out16, devices=[-1, -1], sub_batches=2, out_pcm16=True)
+    out = np.zeros((n, 2, frames), np.float32)
+    render_sharded(_build(orc), noise, out, devices=[-1], sub_batches=1)
+    want = np.clip(np.rint(out.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16).transpose(0, 2, 1)
+    assert np.array_equal(out16, want)
+
+
+def test_host_buffers_are_validated():
+    be = waa.default_binding()
+    build = _build(be)
+    good_in, good_out = np.zeros((3, 2, RQ * 30 + 5), np.float32), np.zeros((3, 2, RQ * 30 + 5), np.float32)
+    with pytest.raises(ValueError, match="host_in"):
+        render_sharded(build, good_in.astype(np.float64), good_out, devices=[waa.PLAN_ONLY])
+    with pytest.raises(ValueError, match="host_in"):
+        render_sharded(build, good_in[:, :, ::2], good_out, devices=[waa.PLAN_ONLY])
+    with pytest.raises(ValueError, match="host_out"):
+        render_sharded(build, good_in, np.zeros((3, 2, RQ * 30), np.float32), devices=[waa.PLAN_ONLY])
+    with pytest.raises(ValueError, match="contexts"):
+        render_sharded(build, good_in, np.zeros((4, 2, RQ * 30 + 5), np.float32), devices=[waa.PLAN_ONLY])
+
+
+@pytest.mark.gpu
+def test_sharded_render_pcm16_output_hip(hip, orc):
+    n, frames = 9, RQ * 30 + 5
+    noise = white_noise(n, 2, frames)
+    out16 = np.zeros((n, frames, 2), np.int16)
+    render_sharded(_build(hip), noise, out16, devices=[0], sub_batches=3, out_pcm16=True)
+    ref16 = np.zeros((n, frames, 2), np.int16)
+    render_sharded(_build(orc), noise, ref16, devices=[-1], sub_batches=1, out_pcm16=True)
+    assert np.abs(out16.astype(int) - ref16.astype(int)).max() <= 1   # (the f32 renders agree to 1e-7: at most one code apart)
+    assert np.abs(out16).max() > 1000
+
+
+def _build_heavy(be, ir):
+    """source -> Convolver(IR longer than 64 K frames: the 160 KB-LDS transforms) -> Analyser(32768: the 128 KB analyser
+    workgroup) -> destination: the kernels whose dynamic-LDS limit has to be raised on EVERY device they run on"""
+    def build(n, device):
+        ctx = waa.OfflineAudioContext(2, 8192 * 5 + 300, 48000.0, n_instances=n, binding=be, device=device)
+        src = ctx.create_buffer_source()
+        node = src.connect(ctx.create_convolver(buffer=waa.AudioBuffer(ir, 48000.0))).connect(ctx.create_analyser(fft_size=32768))
+        node.connect(ctx.destination())
+        src.start()
+        return ctx, src
+    return build
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("two_devices", [False, True])
+def test_sharded_render_with_the_big_lds_kernels(hip, orc, two_devices):
+    """the >64 KB dynamic-LDS limit of a kernel is a per-device attribute; it used to be raised once per
+    PROCESS (a static flag), so a second device driven from the same process would have failed its first long-IR convolver
+    or 32768-point analyser launch.  One device, two slots: runs everywhere; two devices: where the box has them."""
+    if two_devices and hip.device_count() < 2:
+        pytest.skip("needs a node with at least two GPUs")
+    from graphs import garage_like_ir
+    ir = garage_like_ir(frames=70000)
+    n, frames = 6, 8192 * 5 + 300
+    noise = white_noise(n, 2, frames)
+    out = np.zeros((n, 2, frames), np.float32)
+    bins = np.zeros((n, 16384), np.float32)
+
+    def pull(ctx, lo, hi):
+        an = next(nd for nd in ctx._nodes if isinstance(nd, waa.AnalyserNode))
+        an.get_float_frequency_data_all(out=bins[lo:hi])
+
+    render_sharded(_build_heavy(hip, ir), noise, out, devices=[0, 1] if two_devices else [0, 0], sub_batches=2, pull=pull)
+    ctx, src = _build_heavy(orc, ir)(n, -1)
+    src.set_buffer_batch(noise, 48000.0)
+    ref = ctx.start_rendering_sync().data
+    an = next(nd for nd in ctx._nodes if isinstance(nd, waa.AnalyserNode))
+    ref_bins = an.get_float_frequency_data_all()
+    ctx.close()
+    assert rms_err(out, ref).max() <= 1e-6 and np.abs(ref).max() > 1e-3
+    gl, ol = 10.0 ** (bins.astype(np.float64) / 20), 10.0 ** (ref_bins.astype(np.float64) / 20)
+    assert (np.abs(gl - ol).max(axis=1) / ol.max(axis=1)).max() <= 2e-5   # (a 32768-point f32 transform on each side)

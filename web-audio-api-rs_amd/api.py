@@ -76,10 +76,23 @@ class GraphDesc(C.Structure):
                 ("edges", C.POINTER(EdgeDesc))]
 
 
+
 _FP = C.POINTER(C.c_float)
 _DP = C.POINTER(C.c_double)
 _FPP = C.POINTER(_FP)
 _VP = C.c_void_p
+
+# waa_render_sharded (include/waa_hip.h): the callbacks run on the library's sub-batch threads (ctypes takes the GIL for them)
+SHARD_FN = C.CFUNCTYPE(C.c_int32, _VP, C.c_uint32, C.c_uint32, C.c_int32, _VP)
+
+
+class ShardedJob(C.Structure):
+    _fields_ = [("graph", C.POINTER(GraphDesc)), ("n_instances", C.c_uint32), ("n_channels_out", C.c_uint32),
+                ("length_frames", C.c_uint64), ("sample_rate", C.c_float), ("n_devices", C.c_uint32),
+                ("devices", C.POINTER(C.c_int32)), ("sub_batches", C.c_uint32), ("source_node", C.c_uint32),
+                ("host_in", _VP), ("in_channels", C.c_uint32), ("in_pcm16", C.c_int32), ("in_frames", C.c_uint64),
+                ("in_sample_rate", C.c_float), ("out_pcm16", C.c_int32), ("host_out", _VP), ("setup", SHARD_FN),
+                ("pull", SHARD_FN), ("user", _VP)]
 
 # name -> (restype, argtypes); every symbol include/waa_hip.h declares
 ABI = {
@@ -117,6 +130,9 @@ ABI = {
     "sync": (C.c_int32, [_VP]),
     "download": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FP, C.c_uint64]),
     "download_all": (C.c_int32, [_VP, _FP]),
+    "download_all_pcm16": (C.c_int32, [_VP, C.POINTER(C.c_int16)]),
+    "render_sharded": (C.c_int32, [_VP, C.POINTER(C.c_double)]),
+    "shard_range": (C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "output_device": (C.c_int32, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "analyser_get_float_frequency_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FP, C.c_uint32]),
     "analyser_get_byte_frequency_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32]),
@@ -952,7 +968,8 @@ class OfflineAudioContext:
         return IIRFilterNode(self, feedforward, feedback, **kw)
 
     # -- render -------------------------------------------------------------------------
-    def _build(self):
+    def graph_desc(self) -> "GraphDesc":
+        """The waa_graph_desc of this context's graph (the arrays it points at stay alive with the returned object)."""
         n = len(self._nodes)
         nodes = (NodeDesc * n)(*[nd._desc() for nd in self._nodes])
         m = len(self._edges)
@@ -960,14 +977,30 @@ class OfflineAudioContext:
         for k, (f, fo, t, ti) in enumerate(self._edges):
             edges[k].from_, edges[k].from_output, edges[k].to, edges[k].to_input = f, fo, t, ti
         g = GraphDesc(n, nodes, m, edges)
-        h = _VP()
+        g._keep = (nodes, edges)
         if any(getattr(nd, "panning_model", None) == "HRTF" for nd in self._nodes):
             ensure_hrtf_database(self._b)
+        return g
+
+    def _build(self):
+        g = self.graph_desc()
+        h = _VP()
         self._b.check(self._b.batch_create(C.byref(g), self.n_instances, self.number_of_channels, self.length,
                                            self.sample_rate, self.device, C.byref(h)))
         self._handle = h
         for nd in self._nodes:
             nd._apply(self)
+
+    def _adopt(self, handle):
+        """Configure a batch the LIBRARY created for this graph (waa_render_sharded's setup callback): node payloads, params,
+        schedules.  The batch stays the library's: _release() forgets it without destroying it."""
+        self._handle = _VP(handle) if not isinstance(handle, _VP) else handle
+        self._foreign = True
+        for nd in self._nodes:
+            nd._apply(self)
+
+    def _release(self):
+        self._handle = None
 
     def prepare(self):
         """Create the batch and upload every payload (outside any timed region)."""

@@ -201,6 +201,7 @@ void waa_batch_destroy(waa_batch* b) {
       }
     for (void* p : b->allocs) (void)hipFree(p);
     for (void* p : b->payload_allocs) (void)hipFree(p);
+    if (b->pcm_out) (void)hipFree(b->pcm_out);
     (void)hipStreamDestroy(b->stream);
   }
   delete b;
@@ -1384,6 +1385,13 @@ waa_status waa_profile_reset(waa_batch* b) {
   for (auto& p : b->prof) {
     p.launches = 0;
     p.total_ms = 0;
+    // ... and the event pairs of launches not yet folded into the totals (they are resolved lazily by waa_profile_get):
+    // a reset after warm-up launches must not leave them to be counted with the timed ones (bench.py, round 4)
+    for (auto& ev : p.pending) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    p.pending.clear();
   }
   return WAA_OK;
 }

@@ -43,4 +43,25 @@ void launch_pcm16_resample(const DecodeDesc& d, void* stream) {
   hipLaunchKernelGGL(pcm16_resample_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
 }
 
+// Rendered AudioBuffers -> interleaved 16-bit PCM on the device (waa_download_all_pcm16): the inverse of the decoder's
+// sample / 32768, rounded to nearest and saturated (what a WAV writer does with an AudioBuffer — the reference itself has no
+// such step: an OfflineAudioContext hands back f32 planes).  Channels the destination's signal does not carry are zero.
+__global__ __launch_bounds__(256) void pcm16_pack_kernel(const EncodeDesc d) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t item = blockIdx.y;
+  if (i >= d.frames) return;
+  int16_t* dst = d.pcm + ((uint64_t)item * d.frames + i) * d.nch_out;
+  for (uint32_t c = 0; c < d.nch_out; c++) {
+    float v = c < d.nch_in ? load_global(d.in + (uint64_t)item * d.in_item_stride + (uint64_t)c * d.in_ch_stride + i) : 0.f;
+    v = v * 32768.f;
+    v = v < -32768.f ? -32768.f : (v > 32767.f ? 32767.f : v);
+    dst[c] = (int16_t)__float2int_rn(v != v ? 0.f : v);
+  }
+}
+void launch_pcm16_pack(const EncodeDesc& d, void* stream) {
+  if (d.frames == 0 || d.n_items == 0) return;
+  dim3 grid((unsigned)((d.frames + 255) / 256), d.n_items);
+  hipLaunchKernelGGL(pcm16_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
+}
+
 }  // namespace waa

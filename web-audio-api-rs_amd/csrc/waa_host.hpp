@@ -282,6 +282,8 @@ struct waa_batch {
   bool dynamic = false;              // the plan renders the reference's dynamic channel counts (dyn_kernel)
   uint64_t code_stride = 0;          // bytes per instance of a code table (n_quanta rounded up)
   bool rendered = false;
+  int16_t* pcm_out = nullptr;     // staging of waa_download_all_pcm16 (allocated on first use, freed with the batch)
+  size_t pcm_out_count = 0;
   bool dry = false;                  // WAA_DEVICE_PLAN_ONLY: allocations are host memory, nothing is launched
   std::vector<std::string> plan_log;  // waa_plan_describe
   bool profiling = false;

@@ -642,6 +642,13 @@ struct DecodeDesc {
   float scale;               // 1 (kept for callers that fold a constant gain in)
 };
 void launch_pcm16_resample(const DecodeDesc& d, void* stream);
+struct EncodeDesc {
+  const float* in;           // planes: in[item * in_item_stride + ch * in_ch_stride + frame]
+  int16_t* pcm;              // [n_items][frames][nch_out] interleaved
+  uint64_t frames, in_item_stride, in_ch_stride;
+  uint32_t nch_in, nch_out, n_items, pad;
+};
+void launch_pcm16_pack(const EncodeDesc& d, void* stream);
 
 // launchers implemented in waa_kernels.hip
 void launch_chain(const ChainDesc& d, int cmax, void* stream);

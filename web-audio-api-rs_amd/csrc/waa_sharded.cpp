@@ -1,0 +1,178 @@
+// waa_sharded.cpp — the N-device render component behind the C ABI (include/waa_hip.h: waa_render_sharded,
+// waa_download_all_pcm16).  SURVEY.md section 8(e): the OfflineAudioContexts of a job are independent — contiguous instance
+// ranges per device, no collective — and a caller that holds every context's AudioBuffer on the HOST is bound by the link,
+// not by the render: each device's range is cut into sub-batches, one host thread per sub-batch,
+//     upload(k + 1)  ||  render(k)  ||  download(k - 1)
+// on each device, all devices in parallel; one transfer per direction and device at a time (the link is full duplex), handed
+// on in sub-batch order by two turn counters per device.  This is what web-audio-api-rs_amd/sharding.py did in Python in
+// round 3; that module is now a thin caller of this function, and a Rust or C host calls it directly.
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "waa_host.hpp"
+
+namespace {
+
+// sub-batches of one device take a direction of the link in index order
+struct Turn {
+  std::mutex m;
+  std::condition_variable cv;
+  uint32_t next = 0;
+  void wait(uint32_t k) {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return next == k; });
+  }
+  void done() {
+    {
+      std::lock_guard<std::mutex> l(m);
+      next++;
+    }
+    cv.notify_all();
+  }
+};
+
+struct Shard {
+  uint32_t slot, k, lo, hi;
+  int32_t device;
+};
+
+// items lo .. hi of n split into `parts` contiguous ranges that differ by at most one (tests/test_multi_rank.py pins the rule)
+void split_range(uint32_t n, uint32_t part, uint32_t parts, uint32_t* lo, uint32_t* hi) {
+  const uint32_t base = n / parts, rem = n % parts;
+  *lo = part * base + std::min(part, rem);
+  *hi = *lo + base + (part < rem ? 1u : 0u);
+}
+
+}  // namespace
+
+extern "C" {
+
+waa_status waa_shard_range(uint32_t n_total, uint32_t part, uint32_t n_parts, uint32_t* first, uint32_t* end) {
+  if (!first || !end || n_parts == 0 || part >= n_parts) return fail(WAA_ERR_INVALID_ARGUMENT, "bad shard index %u of %u", part, n_parts);
+  split_range(n_total, part, n_parts, first, end);
+  return WAA_OK;
+}
+
+waa_status waa_download_all_pcm16(waa_batch* b, int16_t* dst) {
+  if (!b || !dst) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch / destination");
+  if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch has no device");
+  if (!b->planned || !b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
+  if (b->length == 0) return WAA_OK;
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t count = (size_t)b->n_inst * b->length * b->n_out;
+  if (!b->pcm_out || b->pcm_out_count < count) {
+    if (b->pcm_out) (void)hipFree(b->pcm_out);
+    b->pcm_out = nullptr;
+    HIP_TRY(hipMalloc(&b->pcm_out, count * sizeof(int16_t)));
+    b->pcm_out_count = count;
+  }
+  const waa::SignalRef& s = b->nodes[0].sig;
+  waa::EncodeDesc d{};
+  d.in = s.base;
+  d.pcm = b->pcm_out;
+  d.frames = b->length;
+  d.in_item_stride = s.inst_stride;
+  d.in_ch_stride = s.ch_stride;
+  d.nch_in = (uint32_t)s.nch;
+  d.nch_out = b->n_out;
+  d.n_items = b->n_inst;
+  waa::launch_pcm16_pack(d, b->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(dst, b->pcm_out, count * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return WAA_OK;
+}
+
+waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds) {
+  if (!job || !job->graph) return fail(WAA_ERR_INVALID_ARGUMENT, "null job / graph");
+  if (job->n_instances == 0) return fail(WAA_ERR_INVALID_ARGUMENT, "a sharded job needs at least one context");
+  if (!job->devices || job->n_devices == 0) return fail(WAA_ERR_INVALID_ARGUMENT, "a sharded job needs at least one device");
+  if (!job->host_out) return fail(WAA_ERR_INVALID_ARGUMENT, "null output buffer");
+  const bool streamed = job->source_node != WAA_NO_NODE;
+  if (streamed && (!job->host_in || job->in_channels == 0 || job->in_channels > WAA_MAX_CHANNELS))
+    return fail(WAA_ERR_INVALID_ARGUMENT, "the streamed source needs host_in and 1..%d channels", WAA_MAX_CHANNELS);
+  // contiguous instance ranges per entry of `devices` (a device may be listed twice), each cut into sub-batches
+  std::vector<Shard> shards;
+  const uint32_t sub = std::max<uint32_t>(1, job->sub_batches);
+  for (uint32_t di = 0; di < job->n_devices; di++) {
+    uint32_t lo, hi;
+    split_range(job->n_instances, di, job->n_devices, &lo, &hi);
+    const uint32_t parts = std::max<uint32_t>(1, std::min(sub, hi - lo));
+    uint32_t k = 0;
+    for (uint32_t p = 0; p < parts; p++) {
+      uint32_t a, b2;
+      split_range(hi - lo, p, parts, &a, &b2);
+      if (b2 > a) shards.push_back(Shard{di, k++, lo + a, lo + b2, job->devices[di]});
+    }
+  }
+  std::vector<Turn> up(job->n_devices), down(job->n_devices);
+  const size_t row_in = (size_t)job->in_channels * job->in_frames * (job->in_pcm16 ? sizeof(int16_t) : sizeof(float));
+  const size_t row_out = (size_t)job->n_channels_out * job->length_frames * (job->out_pcm16 ? sizeof(int16_t) : sizeof(float));
+  std::mutex err_lock;
+  int first_status = WAA_OK;
+  std::string first_error;
+  auto report = [&](int st) {
+    std::lock_guard<std::mutex> l(err_lock);
+    if (first_status == WAA_OK) {
+      first_status = st;
+      first_error = waa_last_error();
+    }
+  };
+  auto run = [&](const Shard& sh) {
+    waa_batch* b = nullptr;
+    bool took_up = false, took_down = false;
+    int st = waa_batch_create(job->graph, sh.hi - sh.lo, job->n_channels_out, job->length_frames, job->sample_rate, sh.device, &b);
+    if (!st && job->setup) st = job->setup(b, sh.lo, sh.hi - sh.lo, sh.device, job->user);
+    if (!st) {
+      up[sh.slot].wait(sh.k);
+      took_up = true;
+      if (streamed) {
+        const char* src = static_cast<const char*>(job->host_in) + (size_t)sh.lo * row_in;
+        st = job->in_pcm16 ? waa_source_set_buffer_pcm16_batch(b, job->source_node, reinterpret_cast<const int16_t*>(src), job->in_channels,
+                                                               job->in_frames, job->in_sample_rate)
+                           : waa_source_set_buffer_batch(b, job->source_node, reinterpret_cast<const float*>(src), job->in_channels,
+                                                         job->in_frames, job->in_sample_rate);
+      }
+      up[sh.slot].done();
+    }
+    if (!st) st = waa_render(b);
+    if (!st) st = waa_sync(b);
+    if (!st && job->pull) st = job->pull(b, sh.lo, sh.hi - sh.lo, sh.device, job->user);
+    if (!st) {
+      down[sh.slot].wait(sh.k);
+      took_down = true;
+      char* dst = static_cast<char*>(job->host_out) + (size_t)sh.lo * row_out;
+      st = job->out_pcm16 ? waa_download_all_pcm16(b, reinterpret_cast<int16_t*>(dst)) : waa_download_all(b, reinterpret_cast<float*>(dst));
+      down[sh.slot].done();
+    }
+    if (st) {
+      report(st);
+      // a failed sub-batch still takes and passes on its turns: the ones behind it must not wait forever
+      if (!took_up) {
+        up[sh.slot].wait(sh.k);
+        up[sh.slot].done();
+      }
+      if (!took_down) {
+        down[sh.slot].wait(sh.k);
+        down[sh.slot].done();
+      }
+    }
+    if (b) waa_batch_destroy(b);
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> threads;
+  threads.reserve(shards.size());
+  for (const Shard& sh : shards) threads.emplace_back(run, std::cref(sh));
+  for (auto& t : threads) t.join();
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (first_status != WAA_OK) return fail(first_status, "%s", first_error.c_str());
+  return WAA_OK;
+}
+
+}  // extern "C"

@@ -58,22 +58,6 @@ def timed_steps(step: Callable[[], None], sync: Callable[[], None], steps: int, 
     return elapsed
 
 
-class _Turn:
-    """Sub-batches of one device take the link in index order (one direction each)."""
-
-    def __init__(self):
-        self.cv, self.next = threading.Condition(), 0
-
-    def wait(self, k: int):
-        with self.cv:
-            self.cv.wait_for(lambda: self.next == k)
-
-    def done(self):
-        with self.cv:
-            self.next += 1
-            self.cv.notify_all()
-
-
 def _addr(a) -> int:
     """Host address of a numpy array or a (pinned) torch tensor."""
     return a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data
@@ -96,76 +80,95 @@ def plan_shards(n_total: int, devices: Sequence[int], sub_batches: int):
     return out
 
 
+def _host_block(a, name, dtype, shape_tail=None):
+    """(address, shape) of a C-contiguous host array of `dtype` — numpy array or (pinned) torch tensor; anything else is an
+    error here rather than an out-of-bounds transfer inside the library."""
+    if hasattr(a, "data_ptr"):  # torch tensor
+        import torch
+        want = {np.float32: torch.float32, np.int16: torch.int16}[dtype]
+        if a.dtype != want or not a.is_contiguous() or a.device.type != "cpu":
+            raise ValueError(f"{name}: expected a contiguous CPU tensor of {want}, got {a.dtype} on {a.device}")
+    else:
+        if not isinstance(a, np.ndarray) or a.dtype != dtype or not a.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"{name}: expected a C-contiguous {np.dtype(dtype).name} array")
+    shape = tuple(int(x) for x in a.shape)
+    if len(shape) != 3 or (shape_tail is not None and shape[1:] != tuple(shape_tail)):
+        raise ValueError(f"{name}: shape {shape}, expected [N, {', '.join(map(str, shape_tail or ('*', '*')))}]")
+    return _addr(a), shape
+
+
 def render_sharded(build: Callable, host_in, host_out, devices: Sequence[int] = (0,), sub_batches: int = 8,
-                   sample_rate: float = 48000.0, pcm16: bool = False, pull: Optional[Callable] = None):
-    """Render N contexts whose source AudioBuffers live on the host, on one or several GPUs.
+                   sample_rate: float = 48000.0, pcm16: bool = False, pull: Optional[Callable] = None, out_pcm16: bool = False):
+    """Render N contexts whose source AudioBuffers live on the host, on one or several GPUs: a thin caller of the library's
+    waa_render_sharded (include/waa_hip.h; csrc/waa_sharded.cpp — contiguous ranges per device, sub-batches pipelined
+    upload || render || download, one host thread per sub-batch inside the library).
 
     build(n_instances, device) -> (ctx, src): builds the (identical) graph for a sub-batch of `n_instances` contexts on
-        `device`; `src` is the AudioBufferSourceNode that receives the contexts' buffers.  The ctx must not be rendered.
+        `device`; `src` is the AudioBufferSourceNode that receives the contexts' buffers.  Called once for the graph's shape
+        and once per sub-batch (on the library's thread) to configure that sub-batch: node payloads, params, schedules.
     host_in:  [N, channels, frames] float32 — or, with pcm16=True, [N, frames, channels] int16 (decoded WAV data: half
-        the upload, converted on the device) — numpy array or pinned torch tensor.
-    host_out: [N, n_out, length] float32, filled with every context's rendered AudioBuffer.
+        the upload, converted on the device) — C-contiguous numpy array or pinned torch tensor.
+    host_out: [N, n_out, length] float32 (out_pcm16=True: [N, length, n_out] int16), filled with every context's AudioBuffer.
     pull(ctx, lo, hi): optional control-side work per sub-batch after its render (e.g. the batched analyser pull).
     Returns {"seconds": wall time, "shards": [(device, lo, hi), ...]}.  Raises the first sub-batch error."""
-    n_total = int(host_in.shape[0])
-    assert int(host_out.shape[0]) == n_total
-    row_in = int(np.prod(host_in.shape[1:])) * (2 if pcm16 else 4)
-    row_out = int(np.prod(host_out.shape[1:])) * 4
-    frames = int(host_in.shape[1] if pcm16 else host_in.shape[2])
-    n_ch = int(host_in.shape[2] if pcm16 else host_in.shape[1])
-    shards = plan_shards(n_total, list(devices), sub_batches)
-    up = [_Turn() for _ in devices]
-    down = [_Turn() for _ in devices]
-    errors = []
-    FP, I16 = C.POINTER(C.c_float), C.POINTER(C.c_int16)
-    base_in, base_out = _addr(host_in), _addr(host_out)
+    from .api import SHARD_FN, ShardedJob, WaaError
+    devices = [int(d) for d in devices]
+    if not devices:
+        raise ValueError("render_sharded needs at least one device")
+    base_in, shape_in = _host_block(host_in, "host_in", np.int16 if pcm16 else np.float32)
+    n_total = shape_in[0]
+    frames, n_ch = (shape_in[1], shape_in[2]) if pcm16 else (shape_in[2], shape_in[1])
+    tmpl, tsrc = build(1, devices[0])
+    tail = (tmpl.length, tmpl.number_of_channels) if out_pcm16 else (tmpl.number_of_channels, tmpl.length)
+    base_out, shape_out = _host_block(host_out, "host_out", np.int16 if out_pcm16 else np.float32, tail)
+    if shape_out[0] != n_total:
+        raise ValueError(f"host_out holds {shape_out[0]} contexts, host_in {n_total}")
+    b = tmpl._b
+    graph = tmpl.graph_desc()
+    live, errors = {}, []
 
-    def run(slot, dev, k, lo, hi):
-        ctx = None
-        took_up = took_down = False
+    def setup(handle, first, count, device, _user):
         try:
-            ctx, src = build(hi - lo, dev)
-            ctx.prepare()
-            b = ctx._b
-            up[slot].wait(k)
-            took_up = True
-            try:
-                if pcm16:
-                    b.check(b.source_set_buffer_pcm16_batch(ctx._handle, src.id, C.cast(base_in + lo * row_in, I16), n_ch, frames,
-                                                           sample_rate))
-                else:
-                    b.check(b.source_set_buffer_batch(ctx._handle, src.id, C.cast(base_in + lo * row_in, FP), n_ch, frames,
-                                                     sample_rate))
-            finally:
-                up[slot].done()
-            b.check(b.render(ctx._handle))
-            b.check(b.sync(ctx._handle))
-            if pull is not None:
-                pull(ctx, lo, hi)
-            down[slot].wait(k)
-            took_down = True
-            try:
-                b.check(b.download_all(ctx._handle, C.cast(base_out + lo * row_out, FP)))
-            finally:
-                down[slot].done()
+            ctx, _ = build(int(count), int(device))
+            if len(ctx._nodes) != graph.n_nodes:
+                raise WaaError(1, "render_sharded: build() must return the same graph for every sub-batch")
+            ctx._adopt(handle)
+            live[int(first)] = ctx
+            return 0
+        except WaaError as e:
+            errors.append(e)
+            return e.status or 3
         except Exception as e:  # noqa: BLE001 — reported to the caller below
             errors.append(e)
-            if not took_up:
-                up[slot].wait(k)
-                up[slot].done()
-            if not took_down:
-                down[slot].wait(k)
-                down[slot].done()
-        finally:
-            if ctx is not None:
-                ctx.close()
+            return 3
 
-    t0 = time.perf_counter()
-    threads = [threading.Thread(target=run, args=s) for s in shards]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    def after(handle, first, count, device, _user):
+        try:
+            if pull is not None:
+                pull(live[int(first)], int(first), int(first) + int(count))
+            return 0
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            return 3
+
+    dev_arr = (C.c_int32 * len(devices))(*devices)
+    job = ShardedJob()
+    job.graph = C.pointer(graph)
+    job.n_instances, job.n_channels_out, job.length_frames = n_total, tmpl.number_of_channels, tmpl.length
+    job.sample_rate = tmpl.sample_rate
+    job.n_devices, job.devices, job.sub_batches = len(devices), dev_arr, max(1, int(sub_batches))
+    job.source_node = tsrc.id
+    job.host_in, job.in_channels, job.in_pcm16, job.in_frames, job.in_sample_rate = base_in, n_ch, int(pcm16), frames, sample_rate
+    job.out_pcm16, job.host_out = int(out_pcm16), base_out
+    job.setup, job.pull = SHARD_FN(setup), SHARD_FN(after)
+    seconds = C.c_double()
+    try:
+        status = b.render_sharded(C.cast(C.pointer(job), C.c_void_p), C.byref(seconds))
+    finally:
+        for ctx in live.values():
+            ctx._release()  # (the library created and destroyed these batches)
+        tmpl._release()
     if errors:
         raise errors[0]
-    return {"seconds": time.perf_counter() - t0, "shards": [(d, lo, hi) for _, d, _, lo, hi in shards]}
+    b.check(status)
+    return {"seconds": seconds.value, "shards": [(d, lo, hi) for _, d, _, lo, hi in plan_shards(n_total, devices, sub_batches)]}
