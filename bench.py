@@ -418,7 +418,7 @@ def compact(rec, keep_traffic=True):
     return out
 
 
-def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1, with_pcm=True, n_sub=8):
+def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1, with_pcm=True, n_sub=8, c4_inst=512):
     """What the drop-in boundary costs when it is handed HOST buffers (never `value`): pinned host buffers ->
     sharding.render_sharded (set_buffer_batch -> render -> download_all, per sub-batch, pipelined: upload of one while
     another renders and a third downloads) for the C2 graph and for C4 (512 contexts per GPU = BASELINE config 4's
@@ -478,7 +478,7 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
             rec["c2_pcm16_in_and_out_ms"] = ms
         except Exception as e:  # reporting only
             rec["c2_pcm16_error"] = repr(e)[:100]
-    ms, qps = run_graph("c4", 512, n_sub)
+    ms, qps = run_graph("c4", c4_inst, n_sub)
     rec["c4_512_per_gpu_ms"], rec["c4_quanta_per_s"] = ms, round(qps)
     return rec
 
@@ -522,7 +522,12 @@ def main():
             dist.init_process_group(backend=backend)
 
     name = args.workload
-    n_inst = args.instances or DEFAULT_INSTANCES.get(name, 1024)
+    # Rehearsal of the N > 1 line on a 1-GPU box (WAA_BENCH_SHARE_GPU=1 + WAA_BENCH_BACKEND=gloo): the N ranks share device 0,
+    # so every rank takes 1 / N of the contexts per GPU (the device and the host hold what ONE rank would) and the line says so;
+    # never a reported number.
+    share = os.environ.get("WAA_BENCH_SHARE_GPU") == "1" and world > 1
+    per_gpu = (lambda w: max(8, DEFAULT_INSTANCES.get(w, 1024) // world)) if share else (lambda w: DEFAULT_INSTANCES.get(w, 1024))
+    n_inst = args.instances or per_gpu(name)
     hip = waa.default_binding()
     rec = measure(torch, waa, hip, name, n_inst, args.seconds, args.steps, args.warmup, rank, world, local_rank, dist,
                   backend, sustain_s=args.sustain)
@@ -536,7 +541,7 @@ def main():
         subs = ("t1", "c3", "c4", "c5", "c1a", "os2", "hrtf", "echo") if world == 1 else ("t1", "c4")
         for sub in subs:
             try:
-                extra[sub] = measure(torch, waa, hip, sub, DEFAULT_INSTANCES.get(sub, 1024), args.seconds, max(3, args.steps // 2),
+                extra[sub] = measure(torch, waa, hip, sub, per_gpu(sub), args.seconds, max(3, args.steps // 2),
                                      min(args.warmup, 2) or 1, rank, world, local_rank, dist, backend,
                                      sustain_s=args.sustain if sub == "t1" else 0.0)
                 extra[sub]["steps"] = max(3, args.steps // 2)
@@ -545,7 +550,7 @@ def main():
     e2e = None
     if default_run:
         try:  # host buffers -> device -> host on EVERY rank at once: the ranks share the host's PCIe / memory system
-            e2e = e2e_record(torch, waa, hip, n_inst, args.seconds, local_rank, dist=dist, world=world,
+            e2e = e2e_record(torch, waa, hip, n_inst, args.seconds, local_rank, dist=dist, world=world, c4_inst=per_gpu("c4"),
                              with_pcm=(world == 1))
         except Exception as e:
             e2e = {"error": repr(e)}
@@ -571,6 +576,8 @@ def main():
             "plan_ms": rec["plan_ms"],
             "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic") if k in roof},
         }
+        if share:
+            out["rehearsal"] = f"{world} ranks SHARE one GPU (gloo): contexts per rank = the per-GPU count / {world}; format check only"
         out["roofline"]["kernel_ms"] = round(roof["kernel_ms_per_step"], 4)
         if "sustained" in rec:  # the same protocol over >= --sustain seconds of back-to-back steps (never `value`)
             out["sustained"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rec["sustained"].items()}
