@@ -598,7 +598,7 @@ def main():
         if "t1" in extra and "error" not in extra["t1"]:
             t1, r1 = extra["t1"], extra["t1"]["roofline"]
             out["t1"] = compact(t1)
-            out["t1"]["workload"] = "1024 ctx x 10 s: BufferSource->Biquad->Convolver(garage IR 2x178899)->destination"
+            out["t1"]["workload"] = f"{t1['config']['contexts_per_gpu']} ctx x 10 s: BufferSource->Biquad->Convolver(garage IR 2x178899)->destination"
             out["t1"]["kernels_ms"] = {k: round(v * r1["launches_per_step"].get(k, 1), 3) for k, v in r1["kernel_ms"].items()}
             if "sustained" in t1:
                 out["t1"]["sustained_ms"] = round(t1["sustained"]["ms_per_step"], 3)
@@ -617,7 +617,7 @@ def main():
             out["configs"] = {k: compact(v) for k, v in extra.items() if k != "t1"}
             if "c4" in extra and "error" not in extra["c4"]:
                 out["configs"]["c4"]["analyser_pull_in_step"] = True
-                out["configs"]["c4"]["contexts_per_gpu"] = 512
+                out["configs"]["c4"]["contexts_per_gpu"] = extra["c4"]["config"]["contexts_per_gpu"]
         if e2e is not None:
             out["e2e"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in e2e.items() if k != "note"}
         path = args.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
