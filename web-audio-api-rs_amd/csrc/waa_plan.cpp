@@ -5,6 +5,7 @@
 #include <set>
 
 #include "waa_host.hpp"
+#include "waa_plan_parts.hpp"
 
 namespace waa {
 namespace host {
@@ -273,7 +274,6 @@ int computed_in_nch(const Node& n, int maxc) {
 // writer, then reader, edge writer->reader); vertex `id` is the writer (or a plain node), `id | VTX_READER` the
 // reader.  Cycles are broken at the first DelayNode writer on the detected loop (its writer->reader edge is
 // cleared and the ordering restarts); nodes of a loop without one are dropped from the ordering (muted).
-constexpr uint32_t VTX_READER = 0x80000000u;
 struct OrderCtx {
   const waa_batch* b;
   std::vector<uint8_t> cut;
@@ -673,26 +673,6 @@ void vertex_targets(const waa_batch* b, uint32_t v, const std::vector<uint8_t>& 
     out.push_back(is_delay(b, e.to) && (e.to_input & 0x80000000u) ? (e.to | VTX_READER) : e.to);
   }
 }
-
-// what a launch reads and writes (plan validation, and the prologue decision of block-scheduled loops)
-struct StepIo {
-  std::vector<const void*> reads, writes;
-  bool feedback_reader = false;
-};
-namespace {
-StepIo step_io(const Step& st);
-}
-void fuse_echo_tails(waa_batch* b);
-void ring_feed_forward_echoes(waa_batch* b);
-int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items);
-int plan_delay_writer(waa_batch* b, uint32_t id);
-int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr);
-int conv_block_size(const waa_batch* b, const Node& n);
-int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector<OpDesc>& ops, int* out_nch);
-int plan_oscillator(waa_batch* b, uint32_t id);
-int plan_delay_reader(waa_batch* b, uint32_t id);
-int plan_folded_delay_line(waa_batch* b, uint32_t id);
-uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items);
 
 // Scheduled automation -> value blocks: every timeline is evaluated for all quanta of the render, in order
 // (AudioParamProcessor::process calls compute_intrinsic_values(current_time, 1 / sample_rate, 128) once per
@@ -2227,1496 +2207,6 @@ int build_plan(waa_batch* b) {
   if (int e = validate_plan(b)) return e;
   b->planned = true;
   return 0;
-}
-
-// ---- plan validation -----------------------------------------------------------------------------------------
-// The plan is a linear list of launches over shared device buffers; nothing but their order makes a consumer see
-// its producer's data.  This check walks the list once and refuses a plan in which a launch reads a buffer that
-// some launch of the plan writes, but none has written yet — an ordering bug of the planner would otherwise
-// render stale or zero data silently.  The only legal read-before-write is a DelayNode reader inside a feedback
-// loop (it reads the PREVIOUS quanta of a line that is filled later in the same pass).
-namespace {
-void io_param(const ParamRef& p, StepIo& io) {
-  if (p.base && p.mode == 2) io.reads.push_back(p.base);  // per-frame values: possibly produced by a param chain
-}
-void io_input(const InputRef& in, StepIo& io) {
-  if (in.kind == IN_SIGNAL || (in.kind == IN_DELAYED && !in.feedback)) io.reads.push_back(in.sig.base);
-  if (in.kind == IN_CONSTANT) io_param(in.offset, io);
-  if (in.has_gain) io_param(in.gain, io);
-}
-StepIo step_io(const Step& st) {
-  StepIo io;
-  switch (st.kind) {
-    case 0: {
-      const ChainDesc& c = st.chain;
-      for (int k = 0; k < c.n_inputs; k++) io_input(c.in[k], io);
-      for (int o = 0; o < c.n_ops; o++) {
-        const OpDesc& op = c.ops[o];
-        io_param(op.p0, io);
-        io_param(op.p1, io);
-        io_param(op.p2, io);
-        io_param(op.p3, io);
-        io_param(op.p4, io);
-        if (op.kind == OP_BIQUAD && op.i0 == 2) io.reads.push_back(op.ptr0);  // per-frame coefficient table
-      }
-      io.writes.push_back(c.out.base);
-      break;
-    }
-    case 1:
-      io_input(st.bq.in, io);
-      if (st.bq.vary >= 2) io.reads.push_back(st.bq.coefs);
-      if (st.bq.vary == 3) io.reads.push_back(st.bq.hp);
-      io.writes.push_back(st.bq.out.base);
-      break;
-    case 2:
-    case 4:
-      io.reads.push_back(st.conv.in.base);
-      io.writes.push_back(st.conv.out.base);
-      break;
-    case 3:
-      io.writes.push_back(st.zero_ptr);
-      break;
-    case 5:
-      io_param(st.coef.frequency, io);
-      io_param(st.coef.detune, io);
-      io_param(st.coef.q, io);
-      io_param(st.coef.gain, io);
-      io.writes.push_back(st.coef.coefs);
-      break;
-    case 14:
-      io.writes.push_back(st.tl.out);
-      break;
-    case 13:
-      for (int k = 0; k < 15; k++) io_param(st.geom.p[k], io);
-      io.writes.push_back(st.geom.az);
-      io.writes.push_back(st.geom.gl_mono);
-      io.writes.push_back(st.geom.gr_mono);
-      io.writes.push_back(st.geom.gl_stereo);
-      io.writes.push_back(st.geom.gr_stereo);
-      io.writes.push_back(st.geom.dg);
-      io.writes.push_back(st.geom.cg);
-      break;
-    case 12:
-      if (st.hp.coefs) {
-        io.reads.push_back(st.hp.coefs);
-        io.writes.push_back(st.hp.hp);
-      }
-      break;
-    case 18:
-      io.reads.push_back(st.lanes.coefs);
-      io.writes.push_back(st.lanes.ht);
-      break;
-    case 19:
-      io_input(st.lanes.in, io);
-      io.reads.push_back(st.lanes.coefs);
-      io.reads.push_back(st.lanes.ht);
-      io.writes.push_back(st.lanes.out.base);
-      break;
-    case 6:
-      io_input(st.iir.in, io);
-      io.writes.push_back(st.iir.out.base);
-      break;
-    case 7:
-      io.reads.push_back(st.delay.in.base);
-      io_param(st.delay.delay, io);
-      io.writes.push_back(st.delay.out.base);
-      io.feedback_reader = st.delay.in_cycle != 0;
-      break;
-    case 8:
-    case 10:
-    case 16:
-    case 17:
-    case 20:
-      io.reads = st.loop_reads;
-      io.writes = st.loop_writes;
-      break;
-    case 9:
-      io_param(st.osc.frequency, io);
-      io_param(st.osc.detune, io);
-      io.writes.push_back(st.osc.out.base);
-      break;
-    default:
-      break;
-  }
-  return io;
-}
-}  // namespace
-
-// An echo loop rendered by the LDS-ring kernel (Step::echo_fb): when the line it writes has exactly ONE reader in the whole plan
-// and that reader is a plain sum of the delayed line and of signals the loop step reads too (the destination's  dry + wet),
-// the ring kernel renders that sum as well and the line is never stored (waa_echo.hip, "the tail").  Decided on the finished
-// launch list, buffer by buffer, with the same read / write sets the validation below uses; any launch kind those sets do
-// not describe keeps the plan as it is.
-void fuse_echo_tails(waa_batch* b) {
-  if (getenv("WAA_NO_ECHO_TAIL")) return;
-  for (const Step& st : b->steps)
-    if (st.kind == 11 || st.kind == 15 || st.kind > 20) return;
-  for (size_t l = 0; l < b->steps.size(); l++) {
-    Step& ls = b->steps[l];
-    if (ls.kind != 0 || ls.echo_fb < 0) continue;
-    const void* line = ls.chain.out.base;
-    size_t reader = 0;
-    int n_readers = 0;
-    bool other_writer = false;
-    for (size_t k = 0; k < b->steps.size(); k++) {
-      if (k == l) continue;
-      const Step& sk = b->steps[k];
-      const StepIo io = step_io(sk);
-      // (a delayed read marked `feedback` is left out of the read sets: the validation's legal read-before-write)
-      auto delayed_from = [&](const InputRef& in) { return in.kind == IN_DELAYED && in.sig.base == line; };
-      bool reads = std::find(io.reads.begin(), io.reads.end(), line) != io.reads.end();
-      if (sk.kind == 0)
-        for (int q = 0; q < sk.chain.n_inputs; q++) reads |= delayed_from(sk.chain.in[q]);
-      reads |= (sk.kind == 1 && delayed_from(sk.bq.in)) || (sk.kind == 6 && delayed_from(sk.iir.in)) ||
-               (sk.kind == 19 && delayed_from(sk.lanes.in));
-      if (reads) {
-        n_readers++;
-        reader = k;
-      }
-      other_writer |= std::find(io.writes.begin(), io.writes.end(), line) != io.writes.end();
-    }
-    if (n_readers != 1 || other_writer || reader < l) {
-      plan_note(b, "echo loop: the delay line has %d reader(s) outside the loop: stored, read by them from memory", n_readers);
-      continue;
-    }
-    // Readers that are not launches: an AnalyserNode (pulled by analyser_kernel after the render) or the destination
-    // (downloaded) that ALIASES the line through an identity node of the loop never shows up in the read sets above.
-    // The line must then be stored for them (the same class as the oscillator post-op fold, fuzz seed 502310).
-    int alias_reader = -1;
-    for (size_t k = 0; k < b->nodes.size(); k++) {
-      const Node& an = b->nodes[k];
-      if (an.live && an.sig.base == line &&
-          (an.desc.kind == WAA_NODE_ANALYSER || an.desc.kind == WAA_NODE_DESTINATION))
-        alias_reader = (int)k;
-    }
-    if (alias_reader >= 0) {
-      plan_note(b, "echo loop: node %d (analyser / destination) aliases the loop's delay line and is read outside the launch list: the line is stored", alias_reader);
-      continue;
-    }
-    Step& ts = b->steps[reader];
-    EchoTail t{};
-    const char* why = "it is not an element-wise launch";
-    if (ts.kind != 0 || ts.group >= 0 || !echo_tail_applicable(ls.chain, ls.echo_fb, ts.chain, &t, &why)) {
-      plan_note(b, "echo loop: launch %zu, the only reader of the delay line, is not a plain sum of the delayed line and of the loop's inputs (%s): the line is stored", reader, why);
-      continue;
-    }
-    t.store_line = 0;
-    ls.echo_tail = t;
-    ls.echo_tail_step = (int)reader;
-    ts.echo_fused = true;
-    plan_note(b, "echo loop: launch %zu (the only reader of the loop's delay line: %d input(s) -> %d channel(s)) is rendered by the LDS-ring kernel too; the line is not stored",
-              reader, t.n_inputs, t.in_nch);
-  }
-}
-
-// The feed-forward echo  out = X + g * delayed(X)  as a chain launch reads X twice (the second time mostly out of L2) from
-// short-lived wavefronts, one per 256 frames: 3.8 TB/s on its compulsory bytes.  The ring kernel walks every instance's
-// stream with two chunks in flight and takes the delayed samples from LDS: 5 TB/s — when there is at least one instance
-// per CU to walk (WAA_ECHO_FF_MIN_INST, default 256: below that the tile-parallel launch fills the device better).
-void ring_feed_forward_echoes(waa_batch* b) {
-  if (getenv("WAA_NO_ECHO_RING") || getenv("WAA_NO_ECHO_FF")) return;
-  const char* mi = getenv("WAA_ECHO_FF_MIN_INST");
-  if (b->n_inst < (uint32_t)(mi ? atoi(mi) : 256)) return;
-  for (size_t k = 0; k < b->steps.size(); k++) {
-    Step& st = b->steps[k];
-    if (st.kind != 0 || st.group >= 0 || st.echo_fused || st.chain.n_ops != 0) continue;
-    bool any = false;
-    for (int q = 0; q < st.chain.n_inputs; q++) any |= st.chain.in[q].kind == IN_DELAYED;
-    if (!any) continue;
-    const char* why = "";
-    ChainDesc line{};
-    EchoTail t{};
-    const int chunk = echo_feed_forward(st.chain, &line, &t, &why);
-    if (!chunk) {
-      plan_note(b, "launch %zu sums a delayed signal but keeps the tile-parallel kernel: %s", k, why);
-      continue;
-    }
-    float delayed_lo = 0.f, delayed_hi = 0.f;
-    for (int q = 0; q < st.chain.n_inputs; q++)
-      if (st.chain.in[q].kind == IN_DELAYED) {
-        delayed_lo = st.chain.in[q].delay_lo;
-        delayed_hi = st.chain.in[q].delay_hi;
-      }
-    st.echo_ff = true;
-    st.echo_line = line;
-    st.echo_tail = t;
-    st.echo_chunk = chunk;
-    st.profile_slot = slot_for(b, "echo_ring_kernel");
-    plan_note(b, "launch %zu (delayed signal + %d more input(s), no ops) is rendered by the LDS-ring kernel with nothing fed back: delay %.0f .. %.0f frames, chunks of %d frames",
-              k, t.n_inputs - 1, (double)delayed_lo, (double)delayed_hi, chunk * 256);
-  }
-}
-
-int validate_plan(waa_batch* b) {
-  std::vector<StepIo> ios;
-  std::set<const void*> produced, written;
-  for (const Step& st : b->steps) {
-    ios.push_back(step_io(st));
-    for (const void* w : ios.back().writes)
-      if (w) produced.insert(w);
-  }
-  for (size_t k = 0; k < b->steps.size(); k++) {
-    const StepIo& io = ios[k];
-    if (b->steps[k].kind == 8 || b->steps[k].kind == 10) {  // the items of a quantum-serial launch hand over inside the kernel
-      for (const void* w : io.writes) written.insert(w);
-    }
-    for (const void* r : io.reads) {
-      if (!r || !produced.count(r) || written.count(r)) continue;
-      if (io.feedback_reader && r == b->steps[k].delay.in.base) continue;
-      return fail(WAA_ERR_INVALID_STATE, "internal: launch %zu of the plan (kind %d) reads a buffer that a later launch produces", k,
-                  b->steps[k].kind);
-    }
-    for (const void* w : io.writes)
-      if (w) written.insert(w);
-  }
-  return 0;
-}
-
-// Resolve a source node into an InputRef: schedules, per-instance buffer table, constant ranges.
-int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
-  Node& n = b->nodes[id];
-  if (n.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
-    int e = node_param(b, id, 0, &in->offset);
-    if (e) return e;
-    // active frame range per instance (constant_source.rs:203-258), found by replaying the quantum loop
-    std::vector<int64_t> act((size_t)b->n_inst * 2);
-    const double dt = 1. / (double)b->sr;
-    for (uint32_t i = 0; i < b->n_inst; i++) {
-      const double start = n.sched[i].start, stop = n.sched[i].stop;
-      int64_t a0 = -1, a1 = -1;
-      for (uint32_t q = 0; q < b->n_quanta; q++) {
-        const double ct = (double)((uint64_t)q * RQ) / (double)b->sr;
-        const double nbt = ct + dt * (double)RQ;
-        if (start >= nbt) continue;
-        if (start <= ct && stop >= nbt) {
-          if (a0 < 0) a0 = (int64_t)q * RQ;
-          a1 = (int64_t)(q + 1) * RQ;
-        } else {
-          double t = ct;
-          for (int s = 0; s < RQ; s++) {
-            if (!(t < start || t >= stop)) {
-              if (a0 < 0) a0 = (int64_t)q * RQ + s;
-              a1 = (int64_t)q * RQ + s + 1;
-            }
-            t += dt;
-          }
-        }
-        if (stop <= nbt) break;
-      }
-      act[(size_t)i * 2] = a0 < 0 ? 0 : a0;
-      act[(size_t)i * 2 + 1] = a0 < 0 ? 0 : a1;
-    }
-    int64_t* d = nullptr;
-    e = dev_upload(b, &d, act);
-    if (e) return e;
-    in->active = d;
-    plan_note(b, "constant source node %u: active frames [%lld, %lld) for instance 0", id, (long long)act[0], (long long)act[1]);
-    return 0;
-  }
-  // AudioBufferSourceNode
-  std::vector<SrcInst> insts(b->n_inst);
-  std::vector<SrcSchedule> scheds;
-  std::vector<std::pair<int64_t, uint32_t>> linear;  // per schedule: (linear_start, fast_prefix)
-  std::vector<uint32_t> linear_all;                   // per schedule: the whole render is that linear run
-  std::map<SchedKey, uint32_t> dedup;
-  const ParamStore& p_rate = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
-  const ParamStore& p_det = n.params[WAA_PARAM_SOURCE_DETUNE];
-  const bool automated = !p_rate.blocks.empty() || !p_det.blocks.empty();
-  for (uint32_t i = 0; i < b->n_inst; i++) {
-    const DeviceBuffer& bf = n.bufs[i];
-    SrcInst& si = insts[i];
-    si.base = bf.base;
-    si.ch_stride = bf.ch_stride;
-    si.frames = bf.frames;
-    si.aligned = (bf.valid && ((uintptr_t)bf.base % 16 == 0) && (bf.ch_stride % 4 == 0)) ? 1 : 0;
-    std::vector<float> rate_q = param_per_quantum(b, p_rate, i, nullptr);
-    std::vector<float> det_q = param_per_quantum(b, p_det, i, nullptr);
-    const SourceSched& ss = n.sched[i];
-    const SchedKey key(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end,
-                       bf.valid ? bf.frames : 0, bf.valid ? bf.sr : 0.f, rate_q[0], det_q[0]);
-    if (!automated) {
-      auto it = dedup.find(key);
-      if (it != dedup.end()) {
-        si.sched = it->second;
-        continue;
-      }
-    }
-    SchedOut so;
-    schedule_source(b, n.sched[i], bf.frames, bf.sr, bf.valid, rate_q, det_q, &so);
-    {
-      uint32_t nf = 0, nl = 0, ns = 0, nt = 0;
-      for (auto& r : so.qrec) {
-        nf += r.mode == Q_FAST;
-        nl += r.mode == Q_FAST_LOOP;
-        ns += r.mode == Q_SLOW;
-      }
-      for (auto t : so.tile_fast) nt += t;
-      plan_note(b, "source node %u schedule %zu: quanta fast=%u fast_loop=%u slow=%u silent=%u fast_tiles=%u/%u", id,
-                scheds.size(), nf, nl, ns, (uint32_t)so.qrec.size() - nf - nl - ns, nt, b->n_tiles);
-    }
-    {
-      // leading tiles that are fast and form one linear run of the buffer
-      int64_t start0 = 0;
-      uint32_t prefix = 0;
-      if (!so.tile_fast.empty() && so.tile_fast[0]) {
-        start0 = so.qrec[0].start;
-        while (prefix < b->n_tiles && so.tile_fast[prefix] &&
-               so.qrec[(size_t)prefix * QUANTA_PER_TILE].start == start0 + (int64_t)prefix * TILE)
-          prefix++;
-      }
-      linear.push_back({start0, prefix});
-      // ... and the render's last, partial tile continues that run as far as the render goes (quanta behind the render's end do
-      // not exist): the whole render is one linear run — consumers treat the source like a signal of n_quanta * 128 frames
-      bool all = prefix == b->n_tiles;
-      if (prefix + 1 == b->n_tiles && (size_t)prefix * QUANTA_PER_TILE < (size_t)b->n_quanta) {
-        all = true;
-        for (size_t q = (size_t)prefix * QUANTA_PER_TILE; q < (size_t)b->n_quanta && q < so.qrec.size(); q++)
-          all = all && so.qrec[q].mode == Q_FAST && so.qrec[q].start == start0 + (int64_t)q * RQ;
-      }
-      linear_all.push_back(all ? 1u : 0u);
-      plan_note(b, "source node %u schedule %zu: tiles [0, %u) are one linear run from buffer frame %lld%s", id, scheds.size(), prefix,
-                (long long)start0, all && prefix < b->n_tiles ? " (and so is the rest of the render)" : "");
-    }
-    SrcSchedule ds{};
-    QRec* dq = nullptr;
-    int e = dev_upload(b, &dq, so.qrec);
-    if (e) return e;
-    ds.qrec = dq;
-    if (so.any_slow) {
-      SlowRec* dsr = nullptr;
-      e = dev_upload(b, &dsr, so.slow);
-      if (e) return e;
-      ds.slow = dsr;
-    }
-    uint8_t* dtf = nullptr;
-    e = dev_upload(b, &dtf, so.tile_fast);
-    if (e) return e;
-    ds.tile_fast = dtf;
-    si.sched = (uint32_t)scheds.size();
-    scheds.push_back(ds);
-    if (!automated) dedup[key] = si.sched;
-  }
-  for (auto& si : insts) {
-    si.sc = scheds[si.sched];
-    si.linear_start = linear[si.sched].first;
-    si.fast_prefix = si.aligned && !getenv("WAA_NO_LINEAR_PREFIX") ? linear[si.sched].second : 0;  // (switch: A/B aid)
-    si.linear_all = si.fast_prefix ? linear_all[si.sched] : 0;
-  }
-  SrcInst* d_insts = nullptr;
-  int e = dev_upload(b, &d_insts, insts);
-  if (e) return e;
-  SrcSchedule* d_scheds = nullptr;
-  e = dev_upload(b, &d_scheds, scheds);
-  if (e) return e;
-  in->src = d_insts;
-  in->sched = d_scheds;
-  in->fast_tiles = b->n_tiles;
-  for (auto& si : insts) in->fast_tiles = std::min(in->fast_tiles, !si.base ? 0u : (si.linear_all ? b->n_tiles : si.fast_prefix));
-  plan_note(b, "source node %u: %zu distinct schedule(s) for %u instance(s)", id, scheds.size(), b->n_inst);
-  return 0;
-}
-
-// Fan-in above MAX_INPUTS: sum the first MAX_INPUTS inputs (mixed to the receiver's channel count) into a
-// temporary signal and continue; the left-to-right order of the f32 additions (graph.rs:524-535) is kept.
-int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int interp) {
-  while (ins.size() > (size_t)MAX_INPUTS) {
-    float* ptr = nullptr;
-    int e = dev_alloc(b, &ptr, (size_t)b->n_inst * in_nch * b->lp);
-    if (e) return e;
-    Step st;
-    ChainDesc& cd = st.chain;
-    std::memset(&cd, 0, sizeof cd);
-    cd.n_inputs = MAX_INPUTS;
-    for (int k = 0; k < MAX_INPUTS; k++) cd.in[k] = ins[k];
-    cd.in_nch = in_nch;
-    cd.in_interp = interp;
-    cd.out = SignalRef{ptr, (uint64_t)in_nch * b->lp, b->lp, in_nch, 0};
-    cd.n_inst = b->n_inst;
-    cd.n_tiles = b->n_tiles;
-    cd.tile0 = 0;
-    cd.tile1 = b->n_tiles;
-  cd.tile0 = 0;
-  cd.tile1 = b->n_tiles;
-    cd.n_quanta = b->n_quanta;
-    int cmax = in_nch;
-    for (int k = 0; k < MAX_INPUTS; k++) cmax = std::max(cmax, ins[k].nch);
-    st.cmax = cmax;
-    st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : "chain_kernel<2>");
-    b->steps.push_back(st);
-    InputRef partial{};
-    partial.kind = IN_SIGNAL;
-    partial.nch = in_nch;
-    partial.sig = cd.out;
-    ins.erase(ins.begin(), ins.begin() + MAX_INPUTS);
-    ins.insert(ins.begin(), partial);
-    plan_note(b, "fan-in partial sum of %d inputs -> %dch", MAX_INPUTS, in_nch);
-  }
-  return 0;
-}
-
-// ConvolverNode with an impulse response (convolver.rs:259-317, 343-490): input mix chain (if needed)
-// + forward FFT / spectral MAC / inverse FFT steps.
-// Input of a node-major step (convolver, delay): the single producer's signal if its channel count already
-// matches, else a mixing chain into a temporary.
-int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target, uint64_t* valid) {
-  Node& n = b->nodes[id];
-  if (valid) *valid = b->lp;
-  if (!target && n.in_edges.size() == 1) {
-    Node& p = b->nodes[b->edges[n.in_edges[0]].from];
-    if (p.is_view && valid) {  // a source read in place (see build_plan)
-      *out_sig = p.view_sig;
-      *valid = p.view_valid;
-      return 0;
-    }
-    if (p.materialized && p.out_nch == n.in_nch) {
-      *out_sig = p.sig;
-      return 0;
-    }
-  }
-  SignalRef in_sig;
-  int e = 0;
-  if (target)
-    in_sig = *target;  // mix into a signal somebody already reads from
-  else
-    e = temp_signal(b, n.in_nch, &in_sig);
-  if (e) return e;
-  std::vector<InputRef> ins;
-  if (n.in_edges.empty()) {
-    InputRef in{};
-    in.kind = IN_SILENT;
-    in.nch = 1;
-    ins.push_back(in);
-  } else {
-    for (int ie : n.in_edges) {
-      InputRef in{};
-      if ((e = build_edge_input(b, id, ie, &in))) return e;
-      ins.push_back(in);
-    }
-    if ((e = reduce_fan_in(b, ins, n.in_nch, n.interp))) return e;
-  }
-  if ((e = push_chain_step(b, ins, n.in_nch, n.interp, {}, in_sig))) return e;
-  *out_sig = in_sig;
-  return 0;
-}
-
-// OscillatorNode (oscillator.rs:323-660): one kernel, one lane per instance (the phase accumulator is serial)
-// Is every frame of the quantum [block_time, next_block_time) inside [start_time, stop_time) — also for the reference's
-// clock, which reaches frame k by k additions of dt (rounding: far below the one-frame margin asked of stop_time)?
-// Then OscillatorRenderer::process renders frames 0 .. 127 and the replay below need not walk them.
-static inline bool osc_quantum_fully_active(double block_time, double next_block_time, double start_time, double stop_time, double dt) {
-  return start_time <= block_time && stop_time >= next_block_time + dt;
-}
-
-int plan_oscillator(waa_batch* b, uint32_t id) {
-  // WAA_OSC_PLAN_CHECK=1 (tests): every quantum is walked frame by frame as before and the shortcut's answer is checked
-  const bool check_replay = getenv("WAA_OSC_PLAN_CHECK") != nullptr;
-  Node& n = b->nodes[id];
-  Step st;
-  st.kind = 9;
-  OscDesc& d = st.osc;
-  std::memset(&d, 0, sizeof d);
-  int e;
-  if ((e = node_param(b, id, WAA_PARAM_OSCILLATOR_FREQUENCY, &d.frequency)) ||
-      (e = node_param(b, id, WAA_PARAM_OSCILLATOR_DETUNE, &d.detune)))
-    return e;
-  std::vector<double> start(b->n_inst), stop(b->n_inst);
-  for (uint32_t i = 0; i < b->n_inst; i++) {
-    start[i] = n.sched[i].start;
-    stop[i] = n.sched[i].stop;
-  }
-  double *d_start = nullptr, *d_stop = nullptr;
-  if ((e = dev_upload(b, &d_start, start)) || (e = dev_upload(b, &d_stop, stop))) return e;
-  d.start = d_start;
-  d.stop = d_stop;
-  d.type = n.osc_wave.empty() ? n.desc.i[0] : WAA_OSC_CUSTOM;
-  if (d.type == WAA_OSC_CUSTOM && n.osc_wave.empty())
-    return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - custom oscillator %u has no PeriodicWave", id);
-  std::vector<float> table;
-  if (d.type == WAA_OSC_CUSTOM) {
-    table = n.osc_wave;
-  } else {  // oscillator.rs:16-28 (same libm sinf as the reference's f32::sin)
-    table.resize(2048);
-    const float pi = 3.14159265358979323846f;
-    for (int x = 0; x < 2048; x++) table[x] = std::sin(((float)x) * 2.0f * pi * (1.f / 2048.f));
-  }
-  float* d_table = nullptr;
-  if ((e = dev_upload(b, &d_table, table))) return e;
-  d.table = d_table;
-  d.table_len = (int32_t)table.size();
-  d.out = n.sig;
-  d.frames = b->lp;
-  d.n_inst = b->n_inst;
-  d.n_quanta = b->n_quanta;
-  d.sample_rate = (double)b->sr;
-  const bool parallel = d.frequency.mode != 2 && d.detune.mode != 2 && !getenv("WAA_OSC_EXACT");
-  if (parallel) {
-    // host-known frequency: replay the per-quantum decisions of OscillatorRenderer::process (oscillator.rs:336-452)
-    // and record the phase at the first active frame of every quantum
-    std::vector<OscQuantum> tq((size_t)b->n_inst * b->n_quanta);
-    const double sample_rate = (double)b->sr, dt = 1. / sample_rate, nyquist = sample_rate / 2.;
-    auto frac = [](long double x) {
-      long double r = x - floorl(x);
-      return (double)(r >= 1.L ? r - 1.L : r);
-    };
-    // instances with the same start / stop times and one frequency / detune value for the whole render replay alike: the
-    // row of the first such instance is copied (1024 contexts of one patch: one replay instead of 1024)
-    std::map<std::array<double, 4>, uint32_t> replayed;
-    for (uint32_t i = 0; i < b->n_inst; i++) {
-      const auto fq = param_per_quantum(b, n.params[WAA_PARAM_OSCILLATOR_FREQUENCY], i, nullptr);
-      const auto dq = param_per_quantum(b, n.params[WAA_PARAM_OSCILLATOR_DETUNE], i, nullptr);
-      double start_time = start[i];
-      const double stop_time = stop[i];
-      if (fq.size() == 1 && dq.size() == 1) {
-        const std::array<double, 4> key = {start_time, stop_time, (double)fq[0], (double)dq[0]};
-        auto it = replayed.find(key);
-        if (it != replayed.end()) {
-          std::copy(tq.begin() + (size_t)it->second * b->n_quanta, tq.begin() + (size_t)(it->second + 1) * b->n_quanta,
-                    tq.begin() + (size_t)i * b->n_quanta);
-          continue;
-        }
-        replayed.emplace(key, i);
-      }
-      long double phase = 0.L;
-      bool started = false;
-      for (uint32_t q = 0; q < b->n_quanta; q++) {
-        OscQuantum& oq = tq[(size_t)i * b->n_quanta + q];
-        oq = OscQuantum{0., 0., 0, 0, 0};
-        const double block_time = (double)((uint64_t)q * RQ) / sample_rate;
-        const double next_block_time = block_time + dt * (double)RQ;
-        if (stop_time <= block_time || start_time >= next_block_time) continue;
-        if (!started && start_time < block_time) start_time = block_time;
-        const float f = fq[fq.size() == 1 ? 0 : q], det = dq[dq.size() == 1 ? 0 : q];
-        const double computed_freq = (double)f * std::exp2((double)det / 1200.);
-        const double incr = computed_freq / sample_rate;
-        oq.incr = incr;
-        oq.outside_nyquist = std::fabs(computed_freq) >= nyquist ? 1 : 0;
-        // the reference advances current_time by repeated addition: replay it to find the active frame range
-        int first = -1, end = RQ;
-        if (osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt) && !check_replay) {
-          // (the usual quantum: 128 additions and comparisons per instance and quantum were 2.4 s of a 1024-context plan)
-          first = 0;
-          started = true;  // (start_time == block_time here when the node starts in this quantum: no sub-sample offset)
-        } else {
-          const bool expect_full = osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt);
-          const bool was_started = started;
-          double current_time = block_time;
-          for (int k = 0; k < RQ; k++) {
-            const bool active = !(current_time < start_time || current_time >= stop_time);
-            if (active && first < 0) {
-              first = k;
-              if (!started) {
-                if (current_time > start_time) {
-                  if (expect_full) return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (sub-sample start)");
-                  phase = frac((long double)incr * (long double)((current_time - start_time) / dt));
-                }
-                started = true;
-              }
-            }
-            if (!active && first >= 0) {
-              end = k;
-              break;
-            }
-            current_time += dt;
-          }
-          (void)was_started;
-          if (expect_full && !(first == 0 && end == RQ)) return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (range)");
-        }
-        if (first < 0) continue;
-        oq.first = (int16_t)first;
-        oq.end = (int16_t)end;
-        oq.phase = (double)phase;
-        phase = frac(phase + (long double)(end - first) * (long double)incr);
-      }
-    }
-    OscQuantum* d_tq = nullptr;
-    if ((e = dev_upload(b, &d_tq, tq))) return e;
-    d.table_q = d_tq;
-  }
-  const bool scan = !parallel && !getenv("WAA_OSC_EXACT");
-  if (scan) {
-    // a-rate / graph-modulated frequency: the device forms the phase as a prefix sum of per-frame increments; the
-    // host replays only the reference's clock (current_time += dt per frame, oscillator.rs:505-552) to find the
-    // active frame range and the sub-sample start offset of every instance
-    std::vector<int64_t> act((size_t)b->n_inst * 2, 0);
-    std::vector<double> ratio(b->n_inst, 0.);
-    const double sample_rate = (double)b->sr, dt = 1. / sample_rate;
-    for (uint32_t i = 0; i < b->n_inst; i++) {
-      double start_time = start[i];
-      const double stop_time = stop[i];
-      int64_t first = -1, end = -1;
-      bool started = false;
-      for (uint32_t q = 0; q < b->n_quanta; q++) {
-        const double block_time = (double)((uint64_t)q * RQ) / sample_rate;
-        const double next_block_time = block_time + dt * (double)RQ;
-        if (stop_time <= block_time || start_time >= next_block_time) continue;
-        if (!started && start_time < block_time) start_time = block_time;
-        if (osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt) && !check_replay) {
-          if (first < 0) {
-            first = (int64_t)q * RQ;
-            started = true;
-          }
-          end = (int64_t)(q + 1) * RQ;
-          continue;
-        }
-        const bool expect_full = osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt);
-        const int64_t end_before = end;
-        double current_time = block_time;
-        for (int k = 0; k < RQ; k++) {
-          const bool active = !(current_time < start_time || current_time >= stop_time);
-          if (active) {
-            if (first < 0) {
-              first = (int64_t)q * RQ + k;
-              if (current_time > start_time) {
-                if (expect_full) return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (sub-sample start)");
-                ratio[i] = (current_time - start_time) / dt;
-              }
-              started = true;
-            }
-            end = (int64_t)q * RQ + k + 1;
-          }
-          current_time += dt;
-        }
-        (void)end_before;
-        if (expect_full && !(end == (int64_t)(q + 1) * RQ && first <= (int64_t)q * RQ))
-          return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (range)");
-      }
-      act[(size_t)i * 2] = first < 0 ? 0 : first;
-      act[(size_t)i * 2 + 1] = first < 0 ? 0 : end;
-    }
-    int64_t* d_act = nullptr;
-    double* d_ratio = nullptr;
-    if ((e = dev_upload(b, &d_act, act)) || (e = dev_upload(b, &d_ratio, ratio))) return e;
-    d.active = d_act;
-    d.start_ratio = d_ratio;
-    double* d_seg = nullptr;
-    if ((e = dev_alloc(b, &d_seg, (size_t)b->n_inst * OSC_SEGMENTS))) return e;
-    d.seg_phase = d_seg;
-  }
-  st.profile_slot = slot_for(b, parallel ? "osc_par_kernel" : scan ? "osc_scan_kernel" : "osc_kernel");
-  n.osc_step = (parallel || scan) ? (int)b->steps.size() : -1;  // (the serial cross-check kernel takes no post ops)
-  b->steps.push_back(st);
-  static const char* names[] = {"sine", "square", "sawtooth", "triangle", "custom"};
-  plan_note(b, "oscillator node %u: %s (%s) frequency=%s detune=%s", id, names[d.type],
-            parallel ? "time-parallel, closed-form phase" : scan ? "prefix-sum phase" : "lane per instance, serial phase",
-            d.frequency.mode == 0 ? "const" : d.frequency.mode == 1 ? "k-rate" : "a-rate",
-            d.detune.mode == 0 ? "const" : d.detune.mode == 1 ? "k-rate" : "a-rate");
-  return 0;
-}
-
-// DelayNode (delay.rs:428-745).  Writer half: the node's mixed input becomes the delay line `hist` (an alias of the
-// producer's signal when nothing has to be mixed).  Reader half: one gather kernel from the delay line.  Outside a
-// loop the two are planned back to back; inside a block-scheduled loop each at its own place in the order.
-int plan_delay_writer(waa_batch* b, uint32_t id) {
-  Node& n = b->nodes[id];
-  if (n.hist.base) {  // the reader half was planned first (inside a loop) and chose the delay line
-    if (!n.hist_is_temp) return 0;
-    SignalRef same;
-    return node_input_signal(b, id, &same, &n.hist);
-  }
-  return node_input_signal(b, id, &n.hist);
-}
-// A folded DelayNode inside a block-scheduled loop (reader half): no launch, only the choice of the delay line — the
-// producer's signal when there is exactly one materialised producer of the right layout, else a temporary the writer
-// half fills (as plan_delay_reader does for the node-major form).
-int plan_folded_delay_line(waa_batch* b, uint32_t id) {
-  Node& n = b->nodes[id];
-  if (!n.hist.base) {
-    bool direct = false;
-    if (n.in_edges.size() == 1) {
-      Node& p = b->nodes[b->edges[n.in_edges[0]].from];
-      direct = p.materialized && p.out_nch == n.in_nch && p.sig.base;
-      if (direct) n.hist = p.sig;
-    }
-    if (!direct) {
-      int e = temp_signal(b, n.in_nch, &n.hist);
-      if (e) return e;
-      n.hist_is_temp = true;
-    }
-  }
-  n.hist_valid = b->lp;
-  plan_note(b, "delay node %u: %dch, read by its consumers from the delay line (no pass of its own, inside a block-scheduled loop)", id,
-            n.in_nch);
-  return 0;
-}
-int plan_delay_reader(waa_batch* b, uint32_t id) {
-  Node& n = b->nodes[id];
-  Step st;
-  st.kind = 7;
-  DelayDesc& d = st.delay;
-  std::memset(&d, 0, sizeof d);
-  const bool in_cycle = id < b->cut.size() && b->cut[id];
-  if (in_cycle && !n.hist.base) {
-    // the reader renders before its writer: the delay line is not planned yet.  It is the producer's signal when
-    // there is exactly one materialised producer of the right layout, else a temporary the writer half fills.
-    bool direct = false;
-    if (n.in_edges.size() == 1) {
-      Node& p = b->nodes[b->edges[n.in_edges[0]].from];
-      direct = p.materialized && p.out_nch == n.in_nch && p.sig.base;
-      if (direct) n.hist = p.sig;
-    }
-    if (!direct) {
-      int e = temp_signal(b, n.in_nch, &n.hist);
-      if (e) return e;
-      n.hist_is_temp = true;
-    }
-  }
-  if (!n.hist.base) return fail(WAA_ERR_INVALID_STATE, "internal: delay line of node %u not planned", id);
-  d.in = n.hist;
-  d.out = n.sig;
-  int e = node_param(b, id, WAA_PARAM_DELAY_DELAY_TIME, &d.delay);
-  if (e) return e;
-  d.sample_rate = (double)b->sr;
-  d.frames = b->lp;
-  d.num_quanta = (int32_t)std::ceil(n.desc.d[0] * (double)b->sr / (double)RQ);
-  d.nch = n.in_nch;
-  d.n_inst = b->n_inst;
-  d.n_quanta = b->n_quanta;
-  d.tile0 = 0;
-  d.tile1 = b->n_tiles;
-  d.in_cycle = in_cycle ? 1 : 0;
-  const double dt = 1. / (double)b->sr;
-  d.quantum_duration = (double)RQ * dt;  // delay.rs:546-548
-  st.profile_slot = slot_for(b, "delay_kernel");
-  b->steps.push_back(st);
-  plan_note(b, "delay node %u: %dch delayTime=%s ring=%d quanta%s", id, d.nch,
-            d.delay.mode == 0 ? "const" : d.delay.mode == 1 ? "k-rate" : "a-rate", d.num_quanta + 1,
-            in_cycle ? " (in a loop: clamped to one quantum)" : "");
-  return 0;
-}
-
-// Block size (in 2048-frame tiles) for a block-scheduled feedback loop, 0 if the loop needs the quantum-serial
-// kernel.  Every DelayNode whose writer->reader edge the cycle breaker removed must have a host-known delay
-// (constant or k-rate blocks, not modulated from the graph) strictly longer than the block: then no frame of a
-// block depends on loop history of the same block.
-uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items) {
-  if (getenv("WAA_LOOP_KERNEL")) return 0;  // debugging aid: force the quantum-serial kernel
-  const double dt = 1. / (double)b->sr;
-  const double quantum_duration = (double)RQ * dt;
-  double dmin = 1e300;
-  uint32_t conv_tiles = 1;  // partition size of the largest convolver in the loop, in tiles (partitions <= 2048 frames divide a tile)
-  for (uint32_t v : loop_items) {
-    const uint32_t id = v & ~VTX_READER;
-    Node& n = b->nodes[id];
-    if (!(v & VTX_READER)) {
-      // a ConvolverNode renders whole partitions: the block must hold a whole number of them (below)
-      if (n.desc.kind == WAA_NODE_CONVOLVER && n.has_ir) conv_tiles = std::max(conv_tiles, (uint32_t)conv_block_size(b, n) / (uint32_t)TILE);
-      continue;
-    }
-    if (!b->cut[id]) continue;  // keeps its writer->reader edge: reads the current block like any other node
-    if (param_mode(n, WAA_PARAM_DELAY_DELAY_TIME) == 2) return 0;
-    for (uint32_t i = 0; i < b->n_inst; i++)
-      for (float dv : param_per_quantum(b, n.params[WAA_PARAM_DELAY_DELAY_TIME], i, nullptr))
-        dmin = std::min(dmin, std::max((double)dv, quantum_duration) * (double)b->sr);
-  }
-  if (!(dmin < 1e300)) return 0;
-  const double tiles = std::ceil(dmin / (double)TILE) - 1.;  // block < delay, strictly
-  if (tiles < 1.) return 0;
-  const uint32_t bt = (uint32_t)std::min(tiles, 64.);
-  return bt / conv_tiles * conv_tiles;  // (0: the delay is shorter than the convolver's partition -> quantum-serial -> refused there)
-}
-
-// A feedback loop (strongly connected group around at least one DelayNode): one loop_kernel launch renders all
-// members quantum by quantum in the reference's processing order.  `loop_items` = that order, two entries per
-// DelayNode (writer / reader halves).
-int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items) {
-  if (loop_items.size() > (size_t)LOOP_MAX_ITEMS)
-    return fail(WAA_ERR_OUT_OF_SCOPE, "feedback loop with more than %d members", LOOP_MAX_ITEMS);
-  std::map<uint32_t, int> out_item;  // node id -> item that produces its output
-  std::map<uint32_t, int> writer_item;
-  for (size_t k = 0; k < loop_items.size(); k++) {
-    const uint32_t v = loop_items[k], id = v & ~VTX_READER;
-    if (is_delay(b, id)) {
-      if (v & VTX_READER)
-        out_item[id] = (int)k;
-      else
-        writer_item[id] = (int)k;
-    } else {
-      out_item[id] = (int)k;
-    }
-  }
-  std::vector<LoopItem> host(loop_items.size());
-  std::string desc;
-  for (size_t k = 0; k < loop_items.size(); k++) {
-    const uint32_t v = loop_items[k], id = v & ~VTX_READER;
-    Node& n = b->nodes[id];
-    LoopItem& li = host[k];
-    std::memset(&li, 0, sizeof li);
-    if (n.in_nch > 2 || n.out_nch > 2)
-      return fail(WAA_ERR_OUT_OF_SCOPE, "feedback loops render at most 2 channels per signal (node %u)", id);
-    if (is_frozen_node(n))
-      return fail(WAA_ERR_OUT_OF_SCOPE, "an oversampled WaveShaperNode / HRTF PannerNode inside a feedback loop is out of scope (node %u)", id);
-    for (auto& pe : n.pin_edges)
-      for (int e : pe)
-        if (out_item.count(b->edges[e].from))
-          return fail(WAA_ERR_OUT_OF_SCOPE, "an AudioParam of node %u is modulated from inside its own feedback loop", id);
-    const bool reader = is_delay(b, id) && (v & VTX_READER);
-    li.nch_in = n.in_nch;
-    li.nch_out = n.out_nch;
-    li.interp = n.interp;
-    if (!reader) {
-      // inputs of the node (of the writer half for a DelayNode), in summing order
-      if (n.in_edges.size() > (size_t)MAX_INPUTS)
-        return fail(WAA_ERR_OUT_OF_SCOPE, "more than %d inputs on node %u inside a feedback loop", MAX_INPUTS, id);
-      li.n_in = (int)n.in_edges.size();
-      for (int j = 0; j < li.n_in; j++) {
-        const uint32_t pid = b->edges[n.in_edges[j]].from;
-        Node& pn = b->nodes[pid];
-        if (pn.out_nch > 2)  // (the loop kernel loads and mixes mono / stereo inputs only)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "feedback loops render at most 2 channels per signal (input %u of node %u)", pid, id);
-        li.in_nch[j] = pn.out_nch;
-        auto it = out_item.find(pid);
-        if (it != out_item.end()) {
-          if (it->second >= (int)k) return fail(WAA_ERR_INVALID_STATE, "internal: loop member order");
-          li.in_item[j] = it->second;
-        } else {
-          if (!pn.materialized || !pn.sig.base) return fail(WAA_ERR_INVALID_STATE, "internal: loop input not planned");
-          li.in_item[j] = -1;
-          li.in_sig[j] = pn.sig;
-        }
-      }
-    }
-    char t[96];
-    if (is_delay(b, id)) {
-      if (!reader) {
-        li.kind = LI_DELAY_W;
-        int e = temp_signal(b, n.in_nch, &li.out);  // the delay line, in absolute time
-        if (e) return e;
-        snprintf(t, sizeof t, "delayW%u", id);
-      } else {
-        li.kind = LI_DELAY_R;
-        li.out = n.sig;
-        li.writer_item = writer_item.at(id);
-        li.in_cycle = li.writer_item > (int)k ? 1 : 0;  // delay.rs:535-541: the writer has not rendered yet
-        li.num_quanta = (int32_t)std::ceil(n.desc.d[0] * (double)b->sr / (double)RQ);
-        int e = node_param(b, id, WAA_PARAM_DELAY_DELAY_TIME, &li.op.p0);
-        if (e) return e;
-        snprintf(t, sizeof t, "delayR%u%s", id, li.in_cycle ? "(clamped)" : "");
-      }
-    } else {
-      li.kind = LI_NODE;
-      li.out = n.sig;
-      std::vector<OpDesc> ops;
-      int out_nch = 0;
-      int e = emit_node_ops(b, id, n.in_nch, true, ops, &out_nch);
-      if (e) return e;
-      if (ops.size() > 1) return fail(WAA_ERR_OUT_OF_SCOPE, "node %u cannot be rendered inside a feedback loop", id);
-      if (ops.empty()) {  // only true pass-through nodes may render nothing
-        const uint32_t k = n.desc.kind;
-        const bool pass = k == WAA_NODE_ANALYSER || (k == WAA_NODE_WAVESHAPER && !n.has_curve) ||
-                          (k == WAA_NODE_CONVOLVER && !n.has_ir);
-        if (!pass)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "node %u (kind %u) cannot be rendered inside a feedback loop on the device path", id, k);
-      }
-      if (!ops.empty()) {
-        const OpDesc& o = ops[0];
-        const bool ok = o.kind == OP_GAIN || o.kind == OP_BIQUAD || o.kind == OP_WAVESHAPER ||
-                        (o.kind == OP_STEREO_PAN && o.p0.mode != 2);
-        if (!ok)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "node %u (%s) cannot be rendered inside a feedback loop on the device path", id,
-                      op_name(o.kind));
-        li.op = o;
-      }
-      snprintf(t, sizeof t, "%s%u", ops.empty() ? "pass" : op_name(ops[0].kind), id);
-    }
-    desc += desc.empty() ? t : std::string(",") + t;
-  }
-  // fix up the reader items' writer outputs are read through host[writer_item].out on the device: same array
-  LoopItem* dev = nullptr;
-  int e = dev_upload(b, &dev, host);
-  if (e) return e;
-  Step st;
-  st.kind = 8;
-  LoopDesc& d = st.loop;
-  std::memset(&d, 0, sizeof d);
-  d.items = dev;
-  d.n_items = (int32_t)host.size();
-  d.n_inst = b->n_inst;
-  d.n_quanta = b->n_quanta;
-  d.sample_rate = (double)b->sr;
-  const double dt = 1. / (double)b->sr;
-  d.quantum_duration = (double)RQ * dt;  // delay.rs:546-548
-  st.profile_slot = slot_for(b, "loop_kernel");
-  for (const LoopItem& li : host) {
-    for (int j = 0; j < li.n_in; j++)
-      if (li.in_item[j] < 0) st.loop_reads.push_back(li.in_sig[j].base);
-    st.loop_writes.push_back(li.out.base);
-  }
-  b->steps.push_back(st);
-  plan_note(b, "feedback loop: %d item(s) per quantum [%s]", d.n_items, desc.c_str());
-  return 0;
-}
-
-// the partition size the FFT path picks for a node's impulse response (0: none / all-zero / direct FIR)
-int conv_block_size(const waa_batch* b, const Node& n) {
-  if (!n.has_ir) return 0;
-  uint64_t len = 0;
-  for (int c = 0; c < n.ir_nch; c++) {
-    uint64_t l = n.ir_len;
-    while (l > 0 && std::fabs(n.ir[c][l - 1]) < 0.000001f) l--;
-    len = std::max(len, l);
-  }
-  if (len == 0) return 0;
-  if (len <= (uint64_t)DIRECT_MAX_TAPS && !b->dynamic && !getenv("WAA_NO_DIRECT_FIR")) return 0;
-  for (int cand : {128, 512, 2048, 8192})
-    if ((len + cand - 1) / cand <= 24) return cand;
-  return 8192;
-}
-
-int plan_convolver(waa_batch* b, uint32_t id) {
-  Node& n = b->nodes[id];
-  SignalRef in_sig{};
-  uint64_t in_valid = b->lp;
-  if (b->dynamic && n.hist.base) {
-    in_sig = n.hist;  // dynamic plans: the mixed input was published by the DK_CONV_IN item (waa_dyn.hip)
-  } else if (n.pre_biquad >= 0) {
-    // the Biquad in front is rendered by the forward transform: the transform reads the BIQUAD's input
-    const Node& q = b->nodes[(uint32_t)n.pre_biquad];
-    const Node& sn = b->nodes[b->edges[q.in_edges[0]].from];
-    in_sig = sn.is_view ? sn.view_sig : sn.sig;
-    in_valid = sn.is_view ? sn.view_valid : b->lp;
-    if (!in_sig.base) return fail(WAA_ERR_INVALID_STATE, "internal: the input of folded biquad node %d is not planned yet", n.pre_biquad);
-  } else {
-    int e = node_input_signal(b, id, &in_sig, nullptr, &in_valid);
-    if (e) return e;
-  }
-  // one FFTConvolver per IR channel, at least two (convolver.rs:291-306); each trims its own trailing
-  // |h| < 1e-6 samples (fft-convolver init) — only the longest trimmed length matters here
-  const int ir_nch = n.ir_nch;
-  uint64_t len = 0;
-  for (int c = 0; c < ir_nch; c++) {
-    uint64_t l = n.ir_len;
-    while (l > 0 && std::fabs(n.ir[c][l - 1]) < 0.000001f) l--;
-    len = std::max(len, l);
-  }
-  Step st;
-  st.kind = 2;
-  ConvDesc& cv = st.conv;
-  std::memset(&cv, 0, sizeof cv);
-  if (len == 0) {
-    // all-zero impulse response: FFTConvolver::process outputs zeros
-    Step z;
-    z.kind = 3;
-    z.zero_ptr = n.sig.base;
-    z.zero_bytes = (size_t)b->n_inst * n.out_nch * b->lp * sizeof(float);
-    b->steps.push_back(z);
-    plan_note(b, "convolver node %u: all-zero impulse response -> zero fill", id);
-    return 0;
-  }
-  // Short impulse responses: the direct FIR is exact where the reference's FFT convolver leaves roundoff noise (its
-  // delta-IR tests ask for 1e-7).  In a dynamic-count plan that difference is audible further down: silence is DATA
-  // dependent there (a DelayNode reports silence when it read nothing but zeros, delay.rs:660-668; filter tails end
-  // when their state leaves the normal range), and exact zeros behind a convolver that has seen input turn "still
-  // ringing with noise, stereo" into "silent, mono" for every count-sensitive node behind it.  Dynamic plans therefore
-  // take the FFT form for every length, like the reference (fuzz seeds 1658, 1340 of the 1500-seed runs).
-  const bool direct_fir = len <= (uint64_t)DIRECT_MAX_TAPS && !b->dynamic && !getenv("WAA_NO_DIRECT_FIR");
-  int B = 8192;
-  for (int cand : {128, 512, 2048, 8192})
-    if ((len + cand - 1) / cand <= 24) {
-      B = cand;
-      break;
-    }
-  cv.block = B;
-  cv.n = 2 * B;
-  cv.fft3 = cv.n == 16384 && !getenv("WAA_CONV_FFT_R4");  // (the round-2 radix-4-in-LDS kernels: same-box A/B only)
-  cv.parts = (int)((len + B - 1) / B);
-  cv.nb = (int)((b->lp + B - 1) / B);
-  cv.cin = n.in_nch;
-  cv.cout = n.out_nch;
-  cv.in = in_sig;
-  cv.out = n.sig;
-  cv.frames = b->lp;
-  cv.in_valid = in_valid;
-  cv.n_inst = b->n_inst;
-  cv.n_pairs = (b->n_inst + 1) / 2;
-  cv.ir_nch = ir_nch;
-  cv.ir_len = len;
-  cv.kb0 = 0;
-  cv.kb1 = direct_fir ? (int)((b->lp + 1023) / 1024) : cv.nb;  // (the direct kernel works in 1024-frame pieces)
-  // routing (convolver.rs:384-466)
-  auto term = [&](int in_ch, int ir_ch, int out_ch) { cv.terms[cv.n_terms++] = ConvTerm{in_ch, ir_ch, out_ch, 0}; };
-  if (n.in_nch == 1 && ir_nch == 1) {
-    term(0, 0, 0);
-  } else if (n.in_nch == 1 && ir_nch == 2) {
-    term(0, 0, 0);
-    term(0, 1, 1);
-  } else if (n.in_nch == 2 && ir_nch == 1) {
-    term(0, 0, 0);
-    term(1, 0, 1);
-  } else if (n.in_nch == 2 && ir_nch == 2) {
-    term(0, 0, 0);
-    term(1, 1, 1);
-  } else if (n.in_nch == 2 && ir_nch == 4) {
-    term(0, 0, 0);
-    term(0, 1, 1);
-    term(1, 2, 0);
-    term(1, 3, 1);
-  } else {
-    term(0, 0, 0);
-    term(0, 1, 1);
-    term(0, 2, 0);
-    term(0, 3, 1);
-  }
-  // device resources
-  std::vector<float> irflat((size_t)ir_nch * len);
-  for (int c = 0; c < ir_nch; c++) {
-    uint64_t l = n.ir_len;
-    while (l > 0 && std::fabs(n.ir[c][l - 1]) < 0.000001f) l--;  // samples past a channel's own trim are dropped
-    for (uint64_t i = 0; i < len; i++) irflat[(size_t)c * len + i] = i < l ? n.ir[c][i] : 0.f;
-  }
-  float* d_ir = nullptr;
-  int e = dev_upload(b, &d_ir, irflat);
-  if (e) return e;
-  cv.ir = d_ir;
-  if (direct_fir) {
-    st.kind = 4;
-    st.slot_mac = slot_for(b, "conv_direct_kernel");
-    b->steps.push_back(st);
-    plan_note(b, "convolver node %u: direct FIR taps=%llu cin=%d cout=%d terms=%d", id, (unsigned long long)len, cv.cin,
-              cv.cout, cv.n_terms);
-    return 0;
-  }
-  std::vector<Cplx> tw(cv.n);
-  for (int t = 0; t < cv.n; t++) {
-    const double a = -2.0 * 3.14159265358979323846 * (double)t / (double)cv.n;
-    tw[t] = Cplx{(float)std::cos(a), (float)std::sin(a)};
-  }
-  Cplx* d_tw = nullptr;
-  if ((e = dev_upload(b, &d_tw, tw))) return e;
-  cv.tw = d_tw;
-  Cplx *dH = nullptr, *dX = nullptr, *dY = nullptr;
-  if ((e = dev_alloc(b, &dH, (size_t)ir_nch * cv.parts * cv.n))) return e;
-  if ((e = dev_alloc(b, &dX, (size_t)cv.n_pairs * cv.cin * cv.nb * cv.n))) return e;
-  if ((e = dev_alloc(b, &dY, (size_t)cv.n_pairs * cv.cout * cv.nb * cv.n))) return e;
-  cv.H = dH;
-  cv.X = dX;
-  cv.Y = dY;
-  if (n.pre_biquad >= 0) {
-    if (!cv.fft3) return fail(WAA_ERR_INVALID_STATE, "internal: biquad node %d folded into a convolver without the three-pass transforms", n.pre_biquad);
-    std::vector<OpDesc> qops;
-    int q_out = 0;
-    if ((e = emit_node_ops(b, (uint32_t)n.pre_biquad, cv.cin, true, qops, &q_out))) return e;
-    if (qops.size() != 1 || qops[0].kind != OP_BIQUAD || qops[0].i0 != 0)
-      return fail(WAA_ERR_INVALID_STATE, "internal: folded biquad node %d is not a constant-coefficient filter", n.pre_biquad);
-    cv.pre_coefs = reinterpret_cast<const double*>(qops[0].ptr0);
-    cv.pre_coef_stride = qops[0].u0;
-    cv.pre_state = reinterpret_cast<double*>(qops[0].ptr1);
-  }
-  if (!b->dry) {
-    launch_conv_ir_spectra(cv, b->stream);  // control-side work of ConvolverNode::set_buffer, once
-    HIP_TRY(hipGetLastError());
-  }
-  plan_note(b, "convolver node %u: fft B=%d N=%d P=%d blocks=%d pairs=%u cin=%d cout=%d terms=%d ir_len=%llu%s", id, cv.block,
-            cv.n, cv.parts, cv.nb, cv.n_pairs, cv.cin, cv.cout, cv.n_terms, (unsigned long long)len,
-            cv.pre_coefs ? " (+ the Biquad in front, in the forward transform)" : "");
-  st.slot_fwd = slot_for(b, "conv_fft_kernel<fwd>");
-  st.slot_mac = slot_for(b, "conv_mac_kernel");
-  st.slot_inv = slot_for(b, "conv_fft_kernel<inv>");
-  b->steps.push_back(st);
-  return 0;
-}
-
-// Emit the fused ops of node `id` given the running channel count.
-int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector<OpDesc>& ops, int* out_nch) {
-  Node& n = b->nodes[id];
-  const uint32_t kind = n.desc.kind;
-  if (kind == WAA_NODE_BUFFER_SOURCE || kind == WAA_NODE_CONSTANT_SOURCE) {
-    *out_nch = n.out_nch;
-    return 0;
-  }
-  // input mixing to the node's computed channel count (quantum.rs:532-569); the chain head's inputs are
-  // mixed by the input stage already
-  if (!head && cur_nch != n.in_nch) {
-    OpDesc m{};
-    m.kind = OP_MIX;
-    m.nch_in = cur_nch;
-    m.nch_out = n.in_nch;
-    m.i0 = n.interp;
-    ops.push_back(m);
-  }
-  const int nch = n.in_nch;
-  *out_nch = n.out_nch;
-  switch (kind) {
-    case WAA_NODE_GAIN: {
-      OpDesc o{};
-      o.kind = OP_GAIN;
-      o.nch_in = o.nch_out = nch;
-      int e = node_param(b, id, 0, &o.p0);
-      if (e) return e;
-      ops.push_back(o);
-      break;
-    }
-    case WAA_NODE_BIQUAD: {
-      OpDesc o{};
-      o.kind = OP_BIQUAD;
-      o.nch_in = o.nch_out = nch;
-      bool varies = false, a_rate = false;
-      for (size_t k = 0; k < n.params.size(); k++) {
-        if (param_mode(n, k) == 2) a_rate = true;
-        if (param_mode(n, k) == 1) varies = true;
-      }
-      if (a_rate) {
-        // a-rate params: coefficients per frame (biquad_filter.rs:837-855), computed on the device in f64 from
-        // the per-frame param values into a table the chain kernel streams
-        Step cs;
-        cs.kind = 5;
-        BiquadCoefDesc& cdsc = cs.coef;
-        std::memset(&cdsc, 0, sizeof cdsc);
-        int e;
-        if ((e = node_param(b, id, WAA_PARAM_BIQUAD_FREQUENCY, &cdsc.frequency)) ||
-            (e = node_param(b, id, WAA_PARAM_BIQUAD_DETUNE, &cdsc.detune)) ||
-            (e = node_param(b, id, WAA_PARAM_BIQUAD_Q, &cdsc.q)) ||
-            (e = node_param(b, id, WAA_PARAM_BIQUAD_GAIN, &cdsc.gain)))
-          return e;
-        cdsc.n_frames = (uint64_t)b->n_quanta * RQ;
-        cdsc.frames_padded = b->lp;
-        // one table for all instances when the four params do not depend on the instance (the usual automation:
-        // the same timeline scheduled on every context): 40 B per frame instead of 40 B per frame-instance
-        bool shared = true;
-        for (size_t k = 0; k < 4; k++) {
-          const bool modulated = k < n.pin_edges.size() && !n.pin_edges[k].empty();
-          const ParamStore& ps = n.params[k];
-          if (modulated || ps.dev_tl) shared = false;
-          for (uint32_t i = 1; i < b->n_inst && shared; i++) shared = ps.cst[i] == ps.cst[0];
-          for (auto& blk : ps.blocks) shared &= blk.inst == WAA_ALL_INSTANCES;
-        }
-        cdsc.rows = shared ? 1u : b->n_inst;
-        cdsc.type = n.desc.i[0];
-        cdsc.sample_rate = b->sr;
-        double* dco = nullptr;
-        if ((e = dev_alloc(b, &dco, (size_t)cdsc.rows * cdsc.frames_padded * 5))) return e;
-        cdsc.coefs = dco;
-        cs.profile_slot = slot_for(b, "biquad_coef_kernel");
-        b->steps.push_back(cs);
-        double* dst = nullptr;
-        if ((e = dev_alloc(b, &dst, (size_t)b->n_inst * STATE_STRIDE))) return e;
-        b->state_bufs.push_back({dst, (size_t)b->n_inst * STATE_STRIDE * sizeof(double)});
-        o.i0 = 2;
-        o.i1 = (int32_t)b->steps.size() - 1;  // the coefficient step: emit_segments may switch it to the lane-major layout
-        {
-          Step hs;  // placeholder for the digest of a shared table (a no-op unless emit_segments fills it in)
-          hs.kind = 12;
-          std::memset(&hs.hp, 0, sizeof hs.hp);
-          hs.profile_slot = slot_for(b, "biquad_hp_kernel");
-          b->steps.push_back(hs);
-        }
-        o.ptr0 = dco;
-        o.ptr1 = dst;
-        o.u0 = shared ? 0 : cdsc.frames_padded * 5;
-        ops.push_back(o);
-        break;
-      }
-      const uint64_t per = varies ? (uint64_t)b->n_quanta * 5 : 5;
-      std::vector<double> co((size_t)b->n_inst * per);
-      std::vector<float> pf, pd, pq, pg;  // the previous instance's values: the same values give the same coefficient row
-      for (uint32_t i = 0; i < b->n_inst; i++) {
-        auto f = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_FREQUENCY], i, nullptr);
-        auto d = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_DETUNE], i, nullptr);
-        auto q = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_Q], i, nullptr);
-        auto g = param_per_quantum(b, n.params[WAA_PARAM_BIQUAD_GAIN], i, nullptr);
-        if (i > 0 && f == pf && d == pd && q == pq && g == pg) {
-          // (one k-rate sweep for all 1024 contexts: 3.8 M coefficient sets — sin, cos, pow each — were 0.7 s of the plan)
-          std::copy(co.begin() + (size_t)(i - 1) * per, co.begin() + (size_t)i * per, co.begin() + (size_t)i * per);
-          continue;
-        }
-        pf = f;
-        pd = d;
-        pq = q;
-        pg = g;
-        const uint32_t cnt = varies ? b->n_quanta : 1;
-        for (uint32_t k = 0; k < cnt; k++) {
-          auto at = [&](const std::vector<float>& v) { return v[v.size() == 1 ? 0 : k]; };
-          Coefs c = biquad_coefs(n.desc.i[0], (double)b->sr, (double)computed_freq(at(f), at(d)), (double)at(g), (double)at(q));
-          double* dst = &co[(size_t)i * per + (size_t)k * 5];
-          dst[0] = c.b0;
-          dst[1] = c.b1;
-          dst[2] = c.b2;
-          dst[3] = c.a1;
-          dst[4] = c.a2;
-        }
-      }
-      double* dco = nullptr;
-      int e = dev_upload(b, &dco, co);
-      if (e) return e;
-      double* dst = nullptr;
-      e = dev_alloc(b, &dst, (size_t)b->n_inst * STATE_STRIDE);
-      if (e) return e;
-      b->state_bufs.push_back({dst, (size_t)b->n_inst * STATE_STRIDE * sizeof(double)});
-      o.i0 = varies ? 1 : 0;
-      o.ptr0 = dco;
-      o.ptr1 = dst;
-      o.u0 = per;
-      ops.push_back(o);
-      break;
-    }
-    case WAA_NODE_IIR_FILTER: {
-      // iir_filter.rs:323-405.  N = len - 1 state variables, padded with zero coefficients to a kernel size.
-      OpDesc o{};
-      o.kind = OP_IIR;
-      o.nch_in = o.nch_out = nch;
-      const int len = (int)n.iir_b.size();
-      const int ns = iir_padded_states(len - 1);
-      if (ns < 0) return fail(WAA_ERR_DEVICE, "internal: IIR order");
-      std::vector<double> co(2 * (size_t)(ns + 1), 0.);
-      for (int k = 0; k < len; k++) {
-        co[k] = n.iir_b[k];
-        co[ns + 1 + k] = n.iir_a[k];
-      }
-      // zero-input state transition M: s_i' = -a_{i+1} s_0 + s_{i+1}; powers M^(32 * 2^k), k = 0..5, for the
-      // lane scan of the kernel (double-double on the host, rounded once).  `growth` = largest entry of any power
-      // the scan can form (intermediate squarings and all A^j, j <= 64): the scan's rounding error relative to
-      // the state is about ns * growth * 2^-53, so ill-conditioned direct forms (clustered poles, high order)
-      // and unstable filters go to the exact lane-per-stream kernel instead.
-      // (double-double arithmetic, ~106 bits: repeated squaring of a matrix with large transient entries loses
-      // growth^2 * eps per step, which long double cannot absorb for the filters that are still worth scanning)
-      std::vector<DD> m((size_t)ns * ns), t((size_t)ns * ns);
-      for (int i = 0; i < ns; i++) {
-        m[(size_t)i * ns] = DD{-co[ns + 1 + i + 1], 0.};
-        if (i + 1 < ns) m[(size_t)i * ns + i + 1] = dd_add(m[(size_t)i * ns + i + 1], DD{1., 0.});
-      }
-      double growth = 0.;
-      auto note = [&](const std::vector<DD>& a) {
-        for (const DD& v : a) growth = std::isfinite(v.hi) ? std::max(growth, std::fabs(v.hi)) : INFINITY;
-      };
-      auto mul = [&](const std::vector<DD>& x, const std::vector<DD>& y, std::vector<DD>& out) {
-        for (int r = 0; r < ns; r++)
-          for (int c = 0; c < ns; c++) {
-            DD acc{0., 0.};
-            for (int k = 0; k < ns; k++) acc = dd_add(acc, dd_mul(x[(size_t)r * ns + k], y[(size_t)k * ns + c]));
-            out[(size_t)r * ns + c] = acc;
-          }
-      };
-      for (int k = 0; k < 5; k++) {  // M^32
-        mul(m, m, t);
-        m.swap(t);
-        note(m);
-      }
-      const std::vector<DD> A = m;
-      std::vector<double> pw(6 * (size_t)ns * ns);
-      for (int lvl = 0; lvl < 6; lvl++) {
-        for (size_t k = 0; k < (size_t)ns * ns; k++) pw[lvl * (size_t)ns * ns + k] = m[k].hi + m[k].lo;
-        mul(m, m, t);
-        m.swap(t);
-        note(m);
-      }
-      m = A;
-      for (int j = 2; j <= 64 && std::isfinite(growth); j++) {  // every A^j a lane can see
-        mul(m, A, t);
-        m.swap(t);
-        note(m);
-      }
-      const char* genv = getenv("WAA_IIR_GROWTH");  // experiments only
-      const double growth_limit = genv ? atof(genv) : 1e4;
-      const bool exact = !(growth <= growth_limit) || getenv("WAA_IIR_EXACT") != nullptr;  // env: debugging aid
-      if (exact)
-        for (auto& v : pw) v = 0.;  // unused
-      double *dco = nullptr, *dpw = nullptr, *dst = nullptr;
-      int e;
-      if ((e = dev_upload(b, &dco, co)) || (e = dev_upload(b, &dpw, pw))) return e;
-      const size_t n_state = (size_t)b->n_inst * nch * ns;
-      if ((e = dev_alloc(b, &dst, n_state))) return e;
-      b->state_bufs.push_back({dst, n_state * sizeof(double)});
-      o.i0 = exact ? -ns : ns;
-      o.ptr0 = dco;
-      o.ptr1 = dst;
-      o.ptr2 = dpw;
-      ops.push_back(o);
-      break;
-    }
-    case WAA_NODE_WAVESHAPER: {
-      if (n.has_curve) {
-        OpDesc o{};
-        o.kind = OP_WAVESHAPER;
-        o.nch_in = o.nch_out = nch;
-        if (!n.d_curve) {
-          int e = dev_upload(b, &n.d_curve, n.curve);
-          if (e) return e;
-        }
-        o.ptr0 = n.d_curve;
-        o.i0 = (int)n.curve.size();
-        ops.push_back(o);
-      }
-      break;
-    }
-    case WAA_NODE_STEREO_PANNER: {
-      OpDesc o{};
-      o.kind = OP_STEREO_PAN;
-      o.nch_in = nch;
-      o.nch_out = 2;
-      const ParamStore& p = n.params[0];
-      int e = node_param(b, id, 0, &o.p0);
-      if (e) return e;
-      if (param_mode(n, 0) != 2) {
-        // gains on the host with the same libm sinf the reference's f32::sin resolves to (stereo_panner.rs:74-79)
-        const uint32_t cnt = p.mode() == 1 ? b->n_quanta : 1;
-        std::vector<float> gl((size_t)b->n_inst * cnt), gr((size_t)b->n_inst * cnt);
-        for (uint32_t i = 0; i < b->n_inst; i++) {
-          auto pv = param_per_quantum(b, p, i, nullptr);
-          for (uint32_t k = 0; k < cnt; k++) {
-            float pan = pv[pv.size() == 1 ? 0 : k];
-            float x = nch == 1 ? (pan + 1.f) * 0.5f : (pan <= 0.f ? pan + 1.f : pan);
-            gl[(size_t)i * cnt + k] = sinf((1.f - x) * PI_F / 2.f);
-            gr[(size_t)i * cnt + k] = sinf(x * PI_F / 2.f);
-          }
-        }
-        if ((e = upload_values(b, gl, p.mode(), &o.p1))) return e;
-        if ((e = upload_values(b, gr, p.mode(), &o.p2))) return e;
-      }
-      ops.push_back(o);
-      break;
-    }
-    case WAA_NODE_PANNER: {
-      OpDesc o{};
-      o.kind = OP_PANNER;
-      o.nch_in = nch;
-      o.nch_out = 2;
-      int mode = 0;
-      for (auto& p : n.params) mode = std::max(mode, p.mode());
-      bool listener_a_rate = false;
-      for (int k = 6; k < 15; k++) listener_a_rate |= n.params[k].mode() == 2;
-      if (listener_a_rate) {
-        // audio-rate AudioListener automation (panner.rs:830-897, the `else` of `single_valued`): per-frame geometry on
-        // the device (waa_panner.hip).  Quanta in which all nine listener params happen to be single-valued keep the
-        // once-per-quantum rule (first value of every param), flagged per quantum from the value blocks.
-        Step gs;
-        gs.kind = 13;
-        PannerGeomDesc& g = gs.geom;
-        std::memset(&g, 0, sizeof g);
-        bool shared = true;
-        for (int k = 0; k < 15; k++) {
-          const ParamStore& ps = n.params[k];
-          if (ps.dev_tl) shared = false;
-          for (uint32_t i = 1; i < b->n_inst && shared; i++) shared = ps.cst[i] == ps.cst[0];
-          for (auto& blk : ps.blocks) shared &= blk.inst == WAA_ALL_INSTANCES;
-          int e = upload_param(b, ps, &g.p[k]);
-          if (e) return e;
-          if (k >= 6 && ps.dev_tl) g.dev_len[k - 6] = ps.dev_lens;  // slice lengths come from the device replay
-        }
-        g.rows = shared ? 1u : b->n_inst;
-        g.n_frames = (uint64_t)b->n_quanta * RQ;
-        std::vector<uint8_t> single((size_t)g.rows * b->n_quanta, 1);
-        for (uint32_t r = 0; r < g.rows; r++)
-          for (int k = 6; k < 15; k++) {
-            // length of the slice param k delivers in quantum q: the LAST block that covers (instance, q) decides
-            std::vector<uint8_t> len128(b->n_quanta, 0);
-            for (auto& blk : n.params[k].blocks) {
-              if (!(blk.inst == WAA_ALL_INSTANCES || blk.inst == r)) continue;
-              for (uint32_t j = 0; j < blk.nq; j++)
-                if (blk.q0 + j < b->n_quanta) len128[blk.q0 + j] = blk.vpq == 1 ? 0 : 1;
-            }
-            for (uint32_t q = 0; q < b->n_quanta; q++)
-              if (len128[q]) single[(size_t)r * b->n_quanta + q] = 0;
-          }
-        uint8_t* d_single = nullptr;
-        int e = dev_upload(b, &d_single, single);
-        if (e) return e;
-        g.single = d_single;
-        g.single_stride = b->n_quanta;
-        float* tabs[7];
-        for (auto& t : tabs)
-          if ((e = dev_alloc(b, &t, (size_t)g.rows * g.n_frames))) return e;
-        g.az = tabs[0];
-        g.gl_mono = tabs[1];
-        g.gr_mono = tabs[2];
-        g.gl_stereo = tabs[3];
-        g.gr_stereo = tabs[4];
-        g.dg = tabs[5];
-        g.cg = tabs[6];
-        g.distance_model = n.desc.i[1];
-        g.ref_distance = n.desc.d[0];
-        g.max_distance = n.desc.d[1];
-        g.rolloff = n.desc.d[2];
-        g.cone_inner = (float)n.desc.d[3];
-        g.cone_outer = (float)n.desc.d[4];
-        g.cone_outer_gain = (float)n.desc.d[5];
-        gs.profile_slot = slot_for(b, "panner_geom_kernel");
-        b->steps.push_back(gs);
-        auto ref = [&](float* base) {
-          ParamRef r{};
-          r.base = base;
-          r.stride = g.rows == 1 ? 0 : g.n_frames;
-          r.mode = 2;
-          return r;
-        };
-        o.p0 = ref(g.az);
-        o.p1 = ref(nch == 1 ? g.gl_mono : g.gl_stereo);
-        o.p2 = ref(nch == 1 ? g.gr_mono : g.gr_stereo);
-        o.p3 = ref(g.dg);
-        o.p4 = ref(g.cg);
-        plan_note(b, "panner node %u: audio-rate AudioListener automation -> per-frame geometry on the device (%u table row(s))", id,
-                  g.rows);
-        ops.push_back(o);
-        break;
-      }
-      // listener single-valued => the reference evaluates the geometry once per quantum from the first value of
-      // every param (panner.rs:833-846)
-      const uint32_t cnt = mode == 0 ? 1 : b->n_quanta;
-      const int vmode = mode == 0 ? 0 : 1;
-      std::vector<float> az((size_t)b->n_inst * cnt), gl(az.size()), gr(az.size()), dg(az.size()), cg(az.size());
-      for (uint32_t i = 0; i < b->n_inst; i++) {
-        std::vector<std::vector<float>> pv(15);
-        for (int k = 0; k < 15; k++) pv[k] = param_per_quantum(b, n.params[k], i, nullptr);
-        for (uint32_t k = 0; k < cnt; k++) {
-          auto at = [&](int p) { return pv[p][pv[p].size() == 1 ? 0 : k]; };
-          V3 sp{at(0), at(1), at(2)}, so{at(3), at(4), at(5)}, lp{at(6), at(7), at(8)}, lf{at(9), at(10), at(11)},
-              lu{at(12), at(13), at(14)};
-          float a, el;
-          azimuth_elevation(sp, lp, lf, lu, &a, &el);
-          // panner.rs:996-1004
-          a = a < -180.f ? -180.f : a > 180.f ? 180.f : a;
-          if (a < -90.f)
-            a = -180.f - a;
-          else if (a > 90.f)
-            a = 180.f - a;
-          float x = nch == 1 ? (a + 90.f) / 180.f : (a <= 0.f ? (a + 90.f) / 90.f : a / 90.f);
-          const size_t ix = (size_t)i * cnt + k;
-          az[ix] = a;
-          gl[ix] = cosf(x * PI_F / 2.f);
-          gr[ix] = sinf(x * PI_F / 2.f);
-          dg[ix] = dist_gain(n.desc, sp, lp);
-          cg[ix] = cone_gain(n.desc, sp, so, lp);
-        }
-      }
-      int e;
-      if ((e = upload_values(b, az, vmode, &o.p0)) || (e = upload_values(b, gl, vmode, &o.p1)) ||
-          (e = upload_values(b, gr, vmode, &o.p2)) || (e = upload_values(b, dg, vmode, &o.p3)) ||
-          (e = upload_values(b, cg, vmode, &o.p4)))
-        return e;
-      ops.push_back(o);
-      break;
-    }
-    case WAA_NODE_CONVOLVER:
-      // no buffer set: passthrough (convolver.rs:368-374)
-      break;
-    case WAA_NODE_ANALYSER:
-    case WAA_NODE_DESTINATION:
-    default:
-      break;
-  }
-  return 0;
-}
-
-void default_channel_config(Node& n, uint32_t n_out) {
-  int cc = 2, mode = WAA_COUNT_MODE_MAX, interp = WAA_INTERP_SPEAKERS;
-  switch (n.desc.kind) {
-    case WAA_NODE_DESTINATION:
-      cc = (int)n_out;
-      mode = WAA_COUNT_MODE_EXPLICIT;
-      break;
-    case WAA_NODE_CONVOLVER:
-    case WAA_NODE_STEREO_PANNER:
-    case WAA_NODE_PANNER:
-      mode = WAA_COUNT_MODE_CLAMPED_MAX;
-      break;
-    default: break;
-  }
-  if (n.desc.channel_count != 0) {
-    cc = (int)n.desc.channel_count;
-    mode = (int)n.desc.channel_count_mode;
-    interp = (int)n.desc.channel_interpretation;
-  }
-  n.cc = cc;
-  n.mode = mode;
-  n.interp = interp;
 }
 
 }  // namespace host

@@ -1,0 +1,444 @@
+// waa_plan_sources.cpp — inputs of chains: AudioBufferSource / ConstantSource schedules and buffer tables, fan-in reduction,
+// a node's mixed input as a signal, the OscillatorNode's plan (split out of waa_plan.cpp in round 4).
+#include <array>
+#include <set>
+
+#include "waa_host.hpp"
+#include "waa_plan_parts.hpp"
+
+namespace waa {
+namespace host {
+
+// Resolve a source node into an InputRef: schedules, per-instance buffer table, constant ranges.
+int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
+  Node& n = b->nodes[id];
+  if (n.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
+    int e = node_param(b, id, 0, &in->offset);
+    if (e) return e;
+    // active frame range per instance (constant_source.rs:203-258), found by replaying the quantum loop
+    std::vector<int64_t> act((size_t)b->n_inst * 2);
+    const double dt = 1. / (double)b->sr;
+    for (uint32_t i = 0; i < b->n_inst; i++) {
+      const double start = n.sched[i].start, stop = n.sched[i].stop;
+      int64_t a0 = -1, a1 = -1;
+      for (uint32_t q = 0; q < b->n_quanta; q++) {
+        const double ct = (double)((uint64_t)q * RQ) / (double)b->sr;
+        const double nbt = ct + dt * (double)RQ;
+        if (start >= nbt) continue;
+        if (start <= ct && stop >= nbt) {
+          if (a0 < 0) a0 = (int64_t)q * RQ;
+          a1 = (int64_t)(q + 1) * RQ;
+        } else {
+          double t = ct;
+          for (int s = 0; s < RQ; s++) {
+            if (!(t < start || t >= stop)) {
+              if (a0 < 0) a0 = (int64_t)q * RQ + s;
+              a1 = (int64_t)q * RQ + s + 1;
+            }
+            t += dt;
+          }
+        }
+        if (stop <= nbt) break;
+      }
+      act[(size_t)i * 2] = a0 < 0 ? 0 : a0;
+      act[(size_t)i * 2 + 1] = a0 < 0 ? 0 : a1;
+    }
+    int64_t* d = nullptr;
+    e = dev_upload(b, &d, act);
+    if (e) return e;
+    in->active = d;
+    plan_note(b, "constant source node %u: active frames [%lld, %lld) for instance 0", id, (long long)act[0], (long long)act[1]);
+    return 0;
+  }
+  // AudioBufferSourceNode
+  std::vector<SrcInst> insts(b->n_inst);
+  std::vector<SrcSchedule> scheds;
+  std::vector<std::pair<int64_t, uint32_t>> linear;  // per schedule: (linear_start, fast_prefix)
+  std::vector<uint32_t> linear_all;                   // per schedule: the whole render is that linear run
+  std::map<SchedKey, uint32_t> dedup;
+  const ParamStore& p_rate = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
+  const ParamStore& p_det = n.params[WAA_PARAM_SOURCE_DETUNE];
+  const bool automated = !p_rate.blocks.empty() || !p_det.blocks.empty();
+  for (uint32_t i = 0; i < b->n_inst; i++) {
+    const DeviceBuffer& bf = n.bufs[i];
+    SrcInst& si = insts[i];
+    si.base = bf.base;
+    si.ch_stride = bf.ch_stride;
+    si.frames = bf.frames;
+    si.aligned = (bf.valid && ((uintptr_t)bf.base % 16 == 0) && (bf.ch_stride % 4 == 0)) ? 1 : 0;
+    std::vector<float> rate_q = param_per_quantum(b, p_rate, i, nullptr);
+    std::vector<float> det_q = param_per_quantum(b, p_det, i, nullptr);
+    const SourceSched& ss = n.sched[i];
+    const SchedKey key(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end,
+                       bf.valid ? bf.frames : 0, bf.valid ? bf.sr : 0.f, rate_q[0], det_q[0]);
+    if (!automated) {
+      auto it = dedup.find(key);
+      if (it != dedup.end()) {
+        si.sched = it->second;
+        continue;
+      }
+    }
+    SchedOut so;
+    schedule_source(b, n.sched[i], bf.frames, bf.sr, bf.valid, rate_q, det_q, &so);
+    {
+      uint32_t nf = 0, nl = 0, ns = 0, nt = 0;
+      for (auto& r : so.qrec) {
+        nf += r.mode == Q_FAST;
+        nl += r.mode == Q_FAST_LOOP;
+        ns += r.mode == Q_SLOW;
+      }
+      for (auto t : so.tile_fast) nt += t;
+      plan_note(b, "source node %u schedule %zu: quanta fast=%u fast_loop=%u slow=%u silent=%u fast_tiles=%u/%u", id,
+                scheds.size(), nf, nl, ns, (uint32_t)so.qrec.size() - nf - nl - ns, nt, b->n_tiles);
+    }
+    {
+      // leading tiles that are fast and form one linear run of the buffer
+      int64_t start0 = 0;
+      uint32_t prefix = 0;
+      if (!so.tile_fast.empty() && so.tile_fast[0]) {
+        start0 = so.qrec[0].start;
+        while (prefix < b->n_tiles && so.tile_fast[prefix] &&
+               so.qrec[(size_t)prefix * QUANTA_PER_TILE].start == start0 + (int64_t)prefix * TILE)
+          prefix++;
+      }
+      linear.push_back({start0, prefix});
+      // ... and the render's last, partial tile continues that run as far as the render goes (quanta behind the render's end do
+      // not exist): the whole render is one linear run — consumers treat the source like a signal of n_quanta * 128 frames
+      bool all = prefix == b->n_tiles;
+      if (prefix + 1 == b->n_tiles && (size_t)prefix * QUANTA_PER_TILE < (size_t)b->n_quanta) {
+        all = true;
+        for (size_t q = (size_t)prefix * QUANTA_PER_TILE; q < (size_t)b->n_quanta && q < so.qrec.size(); q++)
+          all = all && so.qrec[q].mode == Q_FAST && so.qrec[q].start == start0 + (int64_t)q * RQ;
+      }
+      linear_all.push_back(all ? 1u : 0u);
+      plan_note(b, "source node %u schedule %zu: tiles [0, %u) are one linear run from buffer frame %lld%s", id, scheds.size(), prefix,
+                (long long)start0, all && prefix < b->n_tiles ? " (and so is the rest of the render)" : "");
+    }
+    SrcSchedule ds{};
+    QRec* dq = nullptr;
+    int e = dev_upload(b, &dq, so.qrec);
+    if (e) return e;
+    ds.qrec = dq;
+    if (so.any_slow) {
+      SlowRec* dsr = nullptr;
+      e = dev_upload(b, &dsr, so.slow);
+      if (e) return e;
+      ds.slow = dsr;
+    }
+    uint8_t* dtf = nullptr;
+    e = dev_upload(b, &dtf, so.tile_fast);
+    if (e) return e;
+    ds.tile_fast = dtf;
+    si.sched = (uint32_t)scheds.size();
+    scheds.push_back(ds);
+    if (!automated) dedup[key] = si.sched;
+  }
+  for (auto& si : insts) {
+    si.sc = scheds[si.sched];
+    si.linear_start = linear[si.sched].first;
+    si.fast_prefix = si.aligned && !getenv("WAA_NO_LINEAR_PREFIX") ? linear[si.sched].second : 0;  // (switch: A/B aid)
+    si.linear_all = si.fast_prefix ? linear_all[si.sched] : 0;
+  }
+  SrcInst* d_insts = nullptr;
+  int e = dev_upload(b, &d_insts, insts);
+  if (e) return e;
+  SrcSchedule* d_scheds = nullptr;
+  e = dev_upload(b, &d_scheds, scheds);
+  if (e) return e;
+  in->src = d_insts;
+  in->sched = d_scheds;
+  in->fast_tiles = b->n_tiles;
+  for (auto& si : insts) in->fast_tiles = std::min(in->fast_tiles, !si.base ? 0u : (si.linear_all ? b->n_tiles : si.fast_prefix));
+  plan_note(b, "source node %u: %zu distinct schedule(s) for %u instance(s)", id, scheds.size(), b->n_inst);
+  return 0;
+}
+
+// Fan-in above MAX_INPUTS: sum the first MAX_INPUTS inputs (mixed to the receiver's channel count) into a
+// temporary signal and continue; the left-to-right order of the f32 additions (graph.rs:524-535) is kept.
+int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int interp) {
+  while (ins.size() > (size_t)MAX_INPUTS) {
+    float* ptr = nullptr;
+    int e = dev_alloc(b, &ptr, (size_t)b->n_inst * in_nch * b->lp);
+    if (e) return e;
+    Step st;
+    ChainDesc& cd = st.chain;
+    std::memset(&cd, 0, sizeof cd);
+    cd.n_inputs = MAX_INPUTS;
+    for (int k = 0; k < MAX_INPUTS; k++) cd.in[k] = ins[k];
+    cd.in_nch = in_nch;
+    cd.in_interp = interp;
+    cd.out = SignalRef{ptr, (uint64_t)in_nch * b->lp, b->lp, in_nch, 0};
+    cd.n_inst = b->n_inst;
+    cd.n_tiles = b->n_tiles;
+    cd.tile0 = 0;
+    cd.tile1 = b->n_tiles;
+  cd.tile0 = 0;
+  cd.tile1 = b->n_tiles;
+    cd.n_quanta = b->n_quanta;
+    int cmax = in_nch;
+    for (int k = 0; k < MAX_INPUTS; k++) cmax = std::max(cmax, ins[k].nch);
+    st.cmax = cmax;
+    st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : "chain_kernel<2>");
+    b->steps.push_back(st);
+    InputRef partial{};
+    partial.kind = IN_SIGNAL;
+    partial.nch = in_nch;
+    partial.sig = cd.out;
+    ins.erase(ins.begin(), ins.begin() + MAX_INPUTS);
+    ins.insert(ins.begin(), partial);
+    plan_note(b, "fan-in partial sum of %d inputs -> %dch", MAX_INPUTS, in_nch);
+  }
+  return 0;
+}
+
+// ConvolverNode with an impulse response (convolver.rs:259-317, 343-490): input mix chain (if needed)
+// + forward FFT / spectral MAC / inverse FFT steps.
+// Input of a node-major step (convolver, delay): the single producer's signal if its channel count already
+// matches, else a mixing chain into a temporary.
+int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target, uint64_t* valid) {
+  Node& n = b->nodes[id];
+  if (valid) *valid = b->lp;
+  if (!target && n.in_edges.size() == 1) {
+    Node& p = b->nodes[b->edges[n.in_edges[0]].from];
+    if (p.is_view && valid) {  // a source read in place (see build_plan)
+      *out_sig = p.view_sig;
+      *valid = p.view_valid;
+      return 0;
+    }
+    if (p.materialized && p.out_nch == n.in_nch) {
+      *out_sig = p.sig;
+      return 0;
+    }
+  }
+  SignalRef in_sig;
+  int e = 0;
+  if (target)
+    in_sig = *target;  // mix into a signal somebody already reads from
+  else
+    e = temp_signal(b, n.in_nch, &in_sig);
+  if (e) return e;
+  std::vector<InputRef> ins;
+  if (n.in_edges.empty()) {
+    InputRef in{};
+    in.kind = IN_SILENT;
+    in.nch = 1;
+    ins.push_back(in);
+  } else {
+    for (int ie : n.in_edges) {
+      InputRef in{};
+      if ((e = build_edge_input(b, id, ie, &in))) return e;
+      ins.push_back(in);
+    }
+    if ((e = reduce_fan_in(b, ins, n.in_nch, n.interp))) return e;
+  }
+  if ((e = push_chain_step(b, ins, n.in_nch, n.interp, {}, in_sig))) return e;
+  *out_sig = in_sig;
+  return 0;
+}
+
+// OscillatorNode (oscillator.rs:323-660): one kernel, one lane per instance (the phase accumulator is serial)
+// Is every frame of the quantum [block_time, next_block_time) inside [start_time, stop_time) — also for the reference's
+// clock, which reaches frame k by k additions of dt (rounding: far below the one-frame margin asked of stop_time)?
+// Then OscillatorRenderer::process renders frames 0 .. 127 and the replay below need not walk them.
+static inline bool osc_quantum_fully_active(double block_time, double next_block_time, double start_time, double stop_time, double dt) {
+  return start_time <= block_time && stop_time >= next_block_time + dt;
+}
+
+int plan_oscillator(waa_batch* b, uint32_t id) {
+  // WAA_OSC_PLAN_CHECK=1 (tests): every quantum is walked frame by frame as before and the shortcut's answer is checked
+  const bool check_replay = getenv("WAA_OSC_PLAN_CHECK") != nullptr;
+  Node& n = b->nodes[id];
+  Step st;
+  st.kind = 9;
+  OscDesc& d = st.osc;
+  std::memset(&d, 0, sizeof d);
+  int e;
+  if ((e = node_param(b, id, WAA_PARAM_OSCILLATOR_FREQUENCY, &d.frequency)) ||
+      (e = node_param(b, id, WAA_PARAM_OSCILLATOR_DETUNE, &d.detune)))
+    return e;
+  std::vector<double> start(b->n_inst), stop(b->n_inst);
+  for (uint32_t i = 0; i < b->n_inst; i++) {
+    start[i] = n.sched[i].start;
+    stop[i] = n.sched[i].stop;
+  }
+  double *d_start = nullptr, *d_stop = nullptr;
+  if ((e = dev_upload(b, &d_start, start)) || (e = dev_upload(b, &d_stop, stop))) return e;
+  d.start = d_start;
+  d.stop = d_stop;
+  d.type = n.osc_wave.empty() ? n.desc.i[0] : WAA_OSC_CUSTOM;
+  if (d.type == WAA_OSC_CUSTOM && n.osc_wave.empty())
+    return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - custom oscillator %u has no PeriodicWave", id);
+  std::vector<float> table;
+  if (d.type == WAA_OSC_CUSTOM) {
+    table = n.osc_wave;
+  } else {  // oscillator.rs:16-28 (same libm sinf as the reference's f32::sin)
+    table.resize(2048);
+    const float pi = 3.14159265358979323846f;
+    for (int x = 0; x < 2048; x++) table[x] = std::sin(((float)x) * 2.0f * pi * (1.f / 2048.f));
+  }
+  float* d_table = nullptr;
+  if ((e = dev_upload(b, &d_table, table))) return e;
+  d.table = d_table;
+  d.table_len = (int32_t)table.size();
+  d.out = n.sig;
+  d.frames = b->lp;
+  d.n_inst = b->n_inst;
+  d.n_quanta = b->n_quanta;
+  d.sample_rate = (double)b->sr;
+  const bool parallel = d.frequency.mode != 2 && d.detune.mode != 2 && !getenv("WAA_OSC_EXACT");
+  if (parallel) {
+    // host-known frequency: replay the per-quantum decisions of OscillatorRenderer::process (oscillator.rs:336-452)
+    // and record the phase at the first active frame of every quantum
+    std::vector<OscQuantum> tq((size_t)b->n_inst * b->n_quanta);
+    const double sample_rate = (double)b->sr, dt = 1. / sample_rate, nyquist = sample_rate / 2.;
+    auto frac = [](long double x) {
+      long double r = x - floorl(x);
+      return (double)(r >= 1.L ? r - 1.L : r);
+    };
+    // instances with the same start / stop times and one frequency / detune value for the whole render replay alike: the
+    // row of the first such instance is copied (1024 contexts of one patch: one replay instead of 1024)
+    std::map<std::array<double, 4>, uint32_t> replayed;
+    for (uint32_t i = 0; i < b->n_inst; i++) {
+      const auto fq = param_per_quantum(b, n.params[WAA_PARAM_OSCILLATOR_FREQUENCY], i, nullptr);
+      const auto dq = param_per_quantum(b, n.params[WAA_PARAM_OSCILLATOR_DETUNE], i, nullptr);
+      double start_time = start[i];
+      const double stop_time = stop[i];
+      if (fq.size() == 1 && dq.size() == 1) {
+        const std::array<double, 4> key = {start_time, stop_time, (double)fq[0], (double)dq[0]};
+        auto it = replayed.find(key);
+        if (it != replayed.end()) {
+          std::copy(tq.begin() + (size_t)it->second * b->n_quanta, tq.begin() + (size_t)(it->second + 1) * b->n_quanta,
+                    tq.begin() + (size_t)i * b->n_quanta);
+          continue;
+        }
+        replayed.emplace(key, i);
+      }
+      long double phase = 0.L;
+      bool started = false;
+      for (uint32_t q = 0; q < b->n_quanta; q++) {
+        OscQuantum& oq = tq[(size_t)i * b->n_quanta + q];
+        oq = OscQuantum{0., 0., 0, 0, 0};
+        const double block_time = (double)((uint64_t)q * RQ) / sample_rate;
+        const double next_block_time = block_time + dt * (double)RQ;
+        if (stop_time <= block_time || start_time >= next_block_time) continue;
+        if (!started && start_time < block_time) start_time = block_time;
+        const float f = fq[fq.size() == 1 ? 0 : q], det = dq[dq.size() == 1 ? 0 : q];
+        const double computed_freq = (double)f * std::exp2((double)det / 1200.);
+        const double incr = computed_freq / sample_rate;
+        oq.incr = incr;
+        oq.outside_nyquist = std::fabs(computed_freq) >= nyquist ? 1 : 0;
+        // the reference advances current_time by repeated addition: replay it to find the active frame range
+        int first = -1, end = RQ;
+        if (osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt) && !check_replay) {
+          // (the usual quantum: 128 additions and comparisons per instance and quantum were 2.4 s of a 1024-context plan)
+          first = 0;
+          started = true;  // (start_time == block_time here when the node starts in this quantum: no sub-sample offset)
+        } else {
+          const bool expect_full = osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt);
+          const bool was_started = started;
+          double current_time = block_time;
+          for (int k = 0; k < RQ; k++) {
+            const bool active = !(current_time < start_time || current_time >= stop_time);
+            if (active && first < 0) {
+              first = k;
+              if (!started) {
+                if (current_time > start_time) {
+                  if (expect_full) return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (sub-sample start)");
+                  phase = frac((long double)incr * (long double)((current_time - start_time) / dt));
+                }
+                started = true;
+              }
+            }
+            if (!active && first >= 0) {
+              end = k;
+              break;
+            }
+            current_time += dt;
+          }
+          (void)was_started;
+          if (expect_full && !(first == 0 && end == RQ)) return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (range)");
+        }
+        if (first < 0) continue;
+        oq.first = (int16_t)first;
+        oq.end = (int16_t)end;
+        oq.phase = (double)phase;
+        phase = frac(phase + (long double)(end - first) * (long double)incr);
+      }
+    }
+    OscQuantum* d_tq = nullptr;
+    if ((e = dev_upload(b, &d_tq, tq))) return e;
+    d.table_q = d_tq;
+  }
+  const bool scan = !parallel && !getenv("WAA_OSC_EXACT");
+  if (scan) {
+    // a-rate / graph-modulated frequency: the device forms the phase as a prefix sum of per-frame increments; the
+    // host replays only the reference's clock (current_time += dt per frame, oscillator.rs:505-552) to find the
+    // active frame range and the sub-sample start offset of every instance
+    std::vector<int64_t> act((size_t)b->n_inst * 2, 0);
+    std::vector<double> ratio(b->n_inst, 0.);
+    const double sample_rate = (double)b->sr, dt = 1. / sample_rate;
+    for (uint32_t i = 0; i < b->n_inst; i++) {
+      double start_time = start[i];
+      const double stop_time = stop[i];
+      int64_t first = -1, end = -1;
+      bool started = false;
+      for (uint32_t q = 0; q < b->n_quanta; q++) {
+        const double block_time = (double)((uint64_t)q * RQ) / sample_rate;
+        const double next_block_time = block_time + dt * (double)RQ;
+        if (stop_time <= block_time || start_time >= next_block_time) continue;
+        if (!started && start_time < block_time) start_time = block_time;
+        if (osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt) && !check_replay) {
+          if (first < 0) {
+            first = (int64_t)q * RQ;
+            started = true;
+          }
+          end = (int64_t)(q + 1) * RQ;
+          continue;
+        }
+        const bool expect_full = osc_quantum_fully_active(block_time, next_block_time, start_time, stop_time, dt);
+        const int64_t end_before = end;
+        double current_time = block_time;
+        for (int k = 0; k < RQ; k++) {
+          const bool active = !(current_time < start_time || current_time >= stop_time);
+          if (active) {
+            if (first < 0) {
+              first = (int64_t)q * RQ + k;
+              if (current_time > start_time) {
+                if (expect_full) return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (sub-sample start)");
+                ratio[i] = (current_time - start_time) / dt;
+              }
+              started = true;
+            }
+            end = (int64_t)q * RQ + k + 1;
+          }
+          current_time += dt;
+        }
+        (void)end_before;
+        if (expect_full && !(end == (int64_t)(q + 1) * RQ && first <= (int64_t)q * RQ))
+          return fail(WAA_ERR_INVALID_STATE, "internal: oscillator replay shortcut (range)");
+      }
+      act[(size_t)i * 2] = first < 0 ? 0 : first;
+      act[(size_t)i * 2 + 1] = first < 0 ? 0 : end;
+    }
+    int64_t* d_act = nullptr;
+    double* d_ratio = nullptr;
+    if ((e = dev_upload(b, &d_act, act)) || (e = dev_upload(b, &d_ratio, ratio))) return e;
+    d.active = d_act;
+    d.start_ratio = d_ratio;
+    double* d_seg = nullptr;
+    if ((e = dev_alloc(b, &d_seg, (size_t)b->n_inst * OSC_SEGMENTS))) return e;
+    d.seg_phase = d_seg;
+  }
+  st.profile_slot = slot_for(b, parallel ? "osc_par_kernel" : scan ? "osc_scan_kernel" : "osc_kernel");
+  n.osc_step = (parallel || scan) ? (int)b->steps.size() : -1;  // (the serial cross-check kernel takes no post ops)
+  b->steps.push_back(st);
+  static const char* names[] = {"sine", "square", "sawtooth", "triangle", "custom"};
+  plan_note(b, "oscillator node %u: %s (%s) frequency=%s detune=%s", id, names[d.type],
+            parallel ? "time-parallel, closed-form phase" : scan ? "prefix-sum phase" : "lane per instance, serial phase",
+            d.frequency.mode == 0 ? "const" : d.frequency.mode == 1 ? "k-rate" : "a-rate",
+            d.detune.mode == 0 ? "const" : d.detune.mode == 1 ? "k-rate" : "a-rate");
+  return 0;
+}
+
+}  // namespace host
+}  // namespace waa
