@@ -232,7 +232,7 @@ def source_hashes():
     csrc = os.path.join(ROOT, "web-audio-api-rs_amd", "csrc")
     out = {}
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".hpp")):
+        if f.endswith((".hip", ".hpp", ".cpp")):  # (.cpp: the planner and the ABI choose the kernels and their launch shapes)
             out[f] = hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16]
     return out
 

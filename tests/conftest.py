@@ -12,6 +12,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "measure: flips a measurement switch: runs against libwaa_hip_measure.so (-DWAA_MEASURE)")
     # the HRIR database of the HRTF panning model: the reference embeds resources/IRC_1003_C.bin in the crate
     # (src/node/panner.rs:55); the copy under tests/golden/ is handed to whichever library a test binds
     import web_audio_api_rs_amd as waa
@@ -40,19 +41,46 @@ def orc_lib(orc):
     return orc.lib
 
 
-@pytest.fixture(scope="session")
-def hip():
-    """ctypes binding of the product library.  Built in-tree with hipcc (cross-compiles without a GPU) if the
-    shared object is missing or older than its sources; there is no fallback if that fails."""
+def _built_library(measure):
+    """in-tree build with hipcc (cross-compiles without a GPU) if a shared object is missing or older than its sources;
+    there is no fallback if that fails"""
     import web_audio_api_rs_amd as waa
 
     csrc = os.path.join(ROOT, "web-audio-api-rs_amd", "csrc")
-    lib = waa.LIB_PATH
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".hpp"))]
     srcs.append(os.path.join(ROOT, "include", "waa_hip.h"))
-    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
-        subprocess.check_call(["make", "-C", csrc, "-j4"])
-    return waa.default_binding()
+    newest = max(os.path.getmtime(f) for f in srcs)
+    for lib in (waa.LIB_PATH, waa.MEASURE_LIB_PATH):
+        if not os.path.exists(lib) or os.path.getmtime(lib) < newest:
+            subprocess.check_call(["make", "-C", csrc, "-j4"])
+            break
+    return waa.measure_binding() if measure else waa.default_binding()
+
+
+@pytest.fixture(scope="session")
+def hip_product():
+    return _built_library(False)
+
+
+@pytest.fixture(scope="session")
+def hip_measure():
+    return _built_library(True)
+
+
+@pytest.fixture(autouse=True)
+def _measure_tests_bind_the_measurement_build(request, monkeypatch):
+    """helpers that call waa.default_binding() themselves follow the test's marker too"""
+    if request.node.get_closest_marker("measure"):
+        monkeypatch.setenv("WAA_USE_MEASURE_LIB", "1")
+
+
+@pytest.fixture
+def hip(request):
+    """ctypes binding of the product library (libwaa_hip.so) — or, for tests marked `measure` (they flip A/B / debugging
+    switches that only exist in the measurement build), of libwaa_hip_measure.so: the same sources with -DWAA_MEASURE."""
+    if request.node.get_closest_marker("measure"):
+        return request.getfixturevalue("hip_measure")
+    return request.getfixturevalue("hip_product")
 
 
 @pytest.fixture(params=["orc", pytest.param("hip", marks=pytest.mark.gpu)])

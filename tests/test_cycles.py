@@ -318,6 +318,7 @@ def test_plan_convolver_inside_a_loop(hip):
     c.close()
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 def test_parity_echo_loop_as_one_persistent_launch(hip, orc, monkeypatch):
     """WAA_PERSISTENT_LOOP=1: the single-launch-per-block echo loop walks its blocks inside ONE launch (one workgroup per
@@ -383,6 +384,7 @@ def _echo_graph(binding, noise, delays, gains, variant, out_channels=2):
     return out, plan
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 @pytest.mark.parametrize("channels,out_channels", [(1, 1), (1, 2), (2, 2)])
 @pytest.mark.parametrize("variant", ["dry+wet", "wet-only", "wet-gain", "two-readers", "other-dry", "two-sources"])
@@ -514,6 +516,7 @@ def test_echo_loop_past_the_lds_ring_window(hip, orc):
     assert np.abs(g - _echo_graph(orc, noise, delays, gains, "dry+wet")[0]).max() == 0.0
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 @pytest.mark.parametrize("forced_loop_kernel", [False, True])
 @pytest.mark.parametrize("with_filter", [False, True])
@@ -550,6 +553,7 @@ def test_plan_block_scheduled_loop(hip):
     c.close()
 
 
+@pytest.mark.measure
 @pytest.mark.parametrize("variant,fused", [("dry+wet", True), ("wet-only", True), ("wet-gain", False), ("two-readers", False),
                                             ("other-dry", False)])
 def test_plan_echo_loop_ring_and_tail(hip, variant, fused, monkeypatch):
@@ -593,6 +597,7 @@ def test_plan_echo_loop_ring_and_tail(hip, variant, fused, monkeypatch):
     assert "LDS-ring" not in plan_of(12000)
 
 
+@pytest.mark.measure
 def test_plan_block_scheduled_loop_node_major_delay(hip, monkeypatch):
     """the switches: every loop member a launch of its own (the round-1 form)"""
     monkeypatch.setenv("WAA_NO_LOOP_FOLD", "1")

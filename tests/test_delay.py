@@ -206,6 +206,7 @@ def test_plan_constant_delay_is_folded_into_its_consumer(hip):
     assert "read by its consumers from the delay line" in plan and "delayed:2ch" in plan and "ring=" not in plan
 
 
+@pytest.mark.measure
 def test_plan_delay_is_node_major(hip, monkeypatch):
     """per-frame delayTime, a node-major consumer, or the switch: the gather kernel (waa_delay.hip)"""
     plan = _plan_of_delay_graph(hip, a_rate=True)
@@ -290,6 +291,7 @@ def test_delay_parity_mono_six_channel_inputs(hip, orc):
         assert np.array_equal(*outs)
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 @pytest.mark.parametrize("fold", [True, False])
 def test_folded_delay_forms_are_bit_identical(hip, orc, fold, monkeypatch):
@@ -323,6 +325,7 @@ def test_folded_delay_forms_are_bit_identical(hip, orc, fold, monkeypatch):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 def test_folded_delay_in_a_block_scheduled_loop(hip, orc, monkeypatch):
     """echo loop Delay <-> Gain with a Biquad tap: one launch per block with the folds, three without — same samples"""
@@ -392,6 +395,7 @@ def _ff_echo(binding, noise, delays, variant, length=None, plan_only=False):
 FF_DELAYS = (np.float64([1032, 1033.5, 3000.25, 4800, 9000.75, 15352]) / 48000.0).astype(np.float32)
 
 
+@pytest.mark.measure
 @pytest.mark.parametrize("variant,ring", [("dry+wet", True), ("wet+dry", True), ("wet", True), ("other", False)])
 def test_plan_feed_forward_echo_out_of_the_ring(hip, variant, ring, monkeypatch):
     noise = white_noise(6, 2, 2048 * 4, seed0=5)
@@ -418,6 +422,7 @@ def test_plan_feed_forward_echo_takes_the_ring_from_one_instance_per_cu(hip):
         assert ("LDS-ring kernel with nothing fed back" in plan) == ring, n
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 @pytest.mark.parametrize("channels", [1, 2])
 @pytest.mark.parametrize("variant", ["dry+wet", "wet+dry", "wet", "other"])

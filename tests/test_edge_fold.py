@@ -65,6 +65,7 @@ def test_mixer_plan_folds_sources_and_gains(hip):
     c.close()
 
 
+@pytest.mark.measure
 def test_fold_can_be_disabled(hip, monkeypatch):
     monkeypatch.setenv("WAA_NO_EDGE_FOLD", "1")
     c = mixer(hip, device=waa.PLAN_ONLY)
@@ -80,6 +81,7 @@ def test_mixer_parity(hip, orc):
     assert np.abs(g - o).max() <= 2e-6
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 def test_fold_matches_unfolded(hip, monkeypatch):
     """the folded plan and the node-per-launch plan are the same arithmetic in the same order: bit-identical"""

@@ -211,6 +211,7 @@ def build_random_graph(be, seed, frozen=False, tap=None):
     return c, "+".join(descr)
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_FIRST", "0")),
                                         int(os.environ.get("FUZZ_FIRST", "0")) + int(os.environ.get("FUZZ_SEEDS", "60"))))
@@ -280,6 +281,7 @@ def test_random_graphs_plan_on_cpu(hip):
     assert planned >= 40
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 def test_dynamic_channel_count_is_rendered(hip, orc, monkeypatch):
     """A mono oscillator from t = 0 plus a stereo buffer that starts later, into a BiquadFilter: the reference

@@ -174,6 +174,7 @@ def test_filters_on_wide_signals(hip, orc, n_ch, kind):
     assert np.abs(outs[0] - outs[1]).max() <= 2e-6
 
 
+@pytest.mark.measure
 def test_time_parallel_biquad_forms(hip, orc, monkeypatch):
     """Two time-parallel forms of the streaming Biquad against the oracle and against the one-wavefront-per-stream kernel:
     * waa_biquad_scan.hip (WAA_BIQUAD_SCAN=1, constant coefficients): one unit per tile and stream, the incoming state from a
@@ -614,6 +615,7 @@ def _t1_like(be, noise, ir, length, highpass=False, via_gain=False):
     return ctx
 
 
+@pytest.mark.measure
 @pytest.mark.parametrize("case", ["stereo-odd", "mono", "long-buffer", "via-gain", "highpass-one"])
 def test_biquad_folded_into_the_forward_transform(hip, orc, monkeypatch, case):
     """source -> Biquad(constant coefficients) -> Convolver(long IR): the forward transform's input stage filters the

@@ -400,6 +400,7 @@ def test_hrtf_many_instances_sampled(hip, orc):
             assert rms(outs[0][inst, c], outs[1][k, c]) <= 1e-6
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 @pytest.mark.parametrize("positions", ["batch", "instance"])
 def test_fir_forms_are_bit_identical(hip, positions):

@@ -309,6 +309,7 @@ def test_reenters_the_audible_range_after_large_phase_increments(orc):
     assert np.all(np.isfinite(out[RQ:])) and np.any(out[RQ:] != 0.0)
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 @pytest.mark.parametrize("modulated", [False, True])
 def test_folded_post_ops_are_bit_identical(hip, orc, modulated, monkeypatch):
@@ -382,6 +383,7 @@ def test_parity_oscillator_behind_an_analyser_with_two_readers(hip, orc):
     assert np.abs(bins[0][finite] - bins[1][finite]).max() <= 0.05
 
 
+@pytest.mark.measure
 def test_plan_replay_shortcut_agrees_with_the_frame_walk(hip, monkeypatch):
     """plan_oscillator skips the 128-frame walk of a quantum that lies wholly inside [start, stop) (it was 2.4 s of a
     1024-context plan); with WAA_OSC_PLAN_CHECK=1 every quantum is walked anyway and a shortcut that would have answered

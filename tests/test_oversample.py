@@ -323,6 +323,7 @@ def _render_with_env(hip, x, oversample, env):
                 os.environ[k] = saved[k]
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 @pytest.mark.parametrize("oversample,factor", [("2x", 2), ("4x", 4)])
 def test_product_forms_agree(hip, oversample, factor):
@@ -344,6 +345,7 @@ def test_product_forms_agree(hip, oversample, factor):
     assert err["bf16x6"] <= 2.0 * err["f32_fma"] + 1e-9, err
 
 
+@pytest.mark.measure
 @pytest.mark.gpu
 @pytest.mark.parametrize("oversample,factor", [("2x", 2), ("4x", 4)])
 @pytest.mark.parametrize("seg", [1, 3, 7])

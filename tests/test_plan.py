@@ -51,6 +51,7 @@ def test_t1_and_c4_plans(hip):
     assert lines[-1].startswith("alias node 0")  # analyser output == destination
 
 
+@pytest.mark.measure
 def test_t1_unfolded_plan_switch(hip, monkeypatch):
     """WAA_NO_CONV_BIQUAD_FOLD=1 keeps the Biquad a launch of its own (same-box A/B, and the parity tests' cross-check)."""
     monkeypatch.setenv("WAA_NO_CONV_BIQUAD_FOLD", "1")
@@ -217,6 +218,7 @@ def test_note_mono_first_then_stereo_into_a_filter():
     c.close()
 
 
+@pytest.mark.measure
 def test_static_plan_switch_keeps_the_round1_note(monkeypatch):
     """WAA_STATIC_CHANNEL_COUNTS=1 (A/B aid): the static plan of round 1 with its 'dynamic channel count' note"""
     monkeypatch.setenv("WAA_STATIC_CHANNEL_COUNTS", "1")
@@ -269,6 +271,7 @@ def test_note_delay_line_collapses_when_its_stereo_input_ends():
     c.close()
 
 
+@pytest.mark.measure
 def test_note_zero_gain_in_front_of_a_panner_and_strict_mode(monkeypatch):
     """gain.rs:163-170: |g| <= 1e-6 emits a silent (mono) quantum; the StereoPanner behind it then sees mono"""
     def build():
@@ -296,6 +299,7 @@ def test_note_zero_gain_in_front_of_a_panner_and_strict_mode(monkeypatch):
     c.close()
 
 
+@pytest.mark.measure
 def test_plan_validator_refuses_a_misordered_launch_list(hip, monkeypatch):
     """build_plan ends with a read-before-write check over the launch list (a consumer launched before its producer
     would render stale data silently).  WAA_DEBUG_REVERSE_PLAN reverses the list before the check: the dependent

@@ -2,6 +2,7 @@
 WAA_CONV_FFT_PLAIN=1 selects the one-FFT-per-workgroup kernel, otherwise N = 16384 uses the persistent pipelined
 kernel.  Prints per-kernel means (ms per render) for T1 and checks that both kernels give bit-identical output."""
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

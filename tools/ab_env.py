@@ -4,6 +4,7 @@ the batch is planned, launch-time ones at every launch), alternating twice (A B 
 the per-kernel HIP-event means.  Example — the linear-prefix fetch of the streaming kernels:
     python tools/ab_env.py WAA_NO_LINEAR_PREFIX c2 iir2 t1"""
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -4,6 +4,7 @@ compiled with -DWAA_CONV_POL=3), AB_REPS times over so that drift shows, and pri
 For compile-time choices that have no run-time switch (tools/ab_env.py covers those that do).  (GPU box)"""
 import ctypes
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

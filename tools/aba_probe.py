@@ -2,6 +2,7 @@
 are exactly the 2048 wavefronts the device holds at once (8 per CU), fewer leave slack.  Separates "the memory system is
 slower for this batch" from "a few workgroups did not get a slot in the first round".  (GPU box)"""
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -3,6 +3,7 @@
 (WAA_DUMP_CODES / ORC_DUMP_CODES) for one graph of tests/test_fuzz_graphs.py: prints the first quanta where they differ."""
 import ctypes
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

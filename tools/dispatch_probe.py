@@ -4,6 +4,7 @@ summarised (wavefronts per XCD / CU / SIMD, spread of start and end times, durat
 import collections
 import ctypes
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -2,6 +2,7 @@
 """tools/dyn_probe.py [contexts] [seconds] — time a graph the planner renders with exact per-quantum channel counts
 (dyn_kernel): a mono source from 0 s plus a stereo source from 1 s into Biquad -> StereoPanner (GPU box)."""
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 import time
 

@@ -1,5 +1,6 @@
 """debugging aid: where the feed-forward ring echo differs from the oracle (python tools/ff_probe.py)"""
-import os, sys, ctypes
+import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so, sys, ctypes
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["WAA_ECHO_FF_MIN_INST"] = "1"

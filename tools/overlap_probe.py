@@ -2,6 +2,7 @@
 (forward transform + Biquad: issue-bound, product: memory-bound, inverse: issue-bound.)  Prints sequential vs concurrent time of
 two 512-context T1 batches and the time of one 1024-context batch.  (GPU box)"""
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 import time
 

@@ -3,6 +3,7 @@ the batch's output buffer?  Per trial: the kernel's HIP-event time on a freshly 
 its 3.9 GB output.  If the two correlate, the library can pick its output allocation by probing candidates.  (GPU box)"""
 import ctypes
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 import time
 

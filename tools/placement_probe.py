@@ -3,6 +3,7 @@ from freshly created batches (spacer allocations of varying size in between) and
 per-kernel HIP-event means; with ALT="VAR=VALUE" every batch is also rendered with that launch-time switch set, so that
 a kernel variant is compared ON THE SAME physical pages.  (GPU box)"""
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -66,7 +66,10 @@ import hashlib  # noqa: E402
 import subprocess  # noqa: E402
 
 csrc = os.path.join(root, "web-audio-api-rs_amd", "csrc")
-files = {"waa_internal.hpp", "waa_stream_common.hpp", "waa_fft3.hpp"}
+# ... and the host files that CHOOSE the kernels and their launch shapes (round 4: a planner change can alter what a step
+# launches without touching a kernel file)
+files = {"waa_internal.hpp", "waa_stream_common.hpp", "waa_fft3.hpp", "waa_osfft.hpp", "waa_abi.cpp", "waa_frozen_host.cpp"}
+files |= {f for f in os.listdir(csrc) if f.startswith("waa_plan") and f.endswith((".cpp", ".hpp"))}
 for k in kernels:
     fn = k.split("<")[0]
     for f in os.listdir(csrc):

@@ -2,6 +2,7 @@
 (100 renders per block) against the time since the first render.  Shows whether the device changes its operating point
 (clocks / power state) under sustained load.  (GPU box)"""
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 import time
 

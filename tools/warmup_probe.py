@@ -2,6 +2,7 @@
 (HIP-event duration of every render in order; shows how many launches the GPU needs to reach its steady clocks —
 the reason bench.py's default warm-up is longer than two steps)."""
 import os
+os.environ.setdefault("WAA_USE_MEASURE_LIB", "1")  # A/B and probe tools flip measurement switches: libwaa_hip_measure.so
 import sys
 import time
 

@@ -13,17 +13,36 @@ from .api import Binding, bind
 
 _HERE = globals().get("_WAA_PKG_DIR") or os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libwaa_hip.so")
+# the same sources built with -DWAA_MEASURE: the only library in which the A/B / debugging / measurement switches
+# (measure_switch(), csrc/waa_internal.hpp) are read.  Tests marked `measure` and the tools under tools/ load it; nothing
+# that reports a number or ships does.
+MEASURE_LIB_PATH = os.path.join(_HERE, "csrc", "libwaa_hip_measure.so")
 _default = None
+_measure = None
+
+
+def _load(path) -> Binding:
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: the HIP extension is not built. Run __graft_entry__.build() "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    return bind(ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL), "waa_")
 
 
 def default_binding() -> Binding:
-    """ctypes binding of the HIP library.  Raises if it is missing — never falls back."""
+    """ctypes binding of the HIP library.  Raises if it is missing — never falls back.  (WAA_USE_MEASURE_LIB=1 in the
+    environment makes this the measurement build: how tools/ab_*.py flip switches under bench.py's workload builders.)"""
     global _default
+    if os.environ.get("WAA_USE_MEASURE_LIB") == "1":
+        return measure_binding()
     if _default is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(
-                f"{LIB_PATH} not found: the HIP extension is not built. Run __graft_entry__.build() "
-                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-        _default = bind(lib, "waa_")
+        _default = _load(LIB_PATH)
     return _default
+
+
+def measure_binding() -> Binding:
+    """the measurement build (libwaa_hip_measure.so): same code, measurement switches alive"""
+    global _measure
+    if _measure is None:
+        _measure = _load(MEASURE_LIB_PATH)
+    return _measure

@@ -949,7 +949,7 @@ static int run_steps(waa_batch* b) {
         i = j;
         continue;
       }
-      if (n_body == 1 && b->steps[body].kind == 0 && b->steps[body].cmax <= 2 && getenv("WAA_PERSISTENT_LOOP")) {
+      if (n_body == 1 && b->steps[body].kind == 0 && b->steps[body].cmax <= 2 && measure_switch("WAA_PERSISTENT_LOOP")) {
         const Step& bs = b->steps[body];
         bool element_wise = true;
         for (int o = 0; o < bs.chain.n_ops; o++) element_wise &= bs.chain.ops[o].kind != OP_BIQUAD;
@@ -998,7 +998,7 @@ static int drain_profile(waa_batch* b) {
 // Debugging aid of the dynamic-count path (WAA_DUMP_CODES=<file>): the per-quantum codes (count | 0x80 if silent) of every
 // node's published signal, [n_inst][n_nodes][n_quanta] behind a 3-word header; 0xFF where a node has no code table.
 static int dump_codes(waa_batch* b) {
-  const char* path = getenv("WAA_DUMP_CODES");
+  const char* path = measure_switch("WAA_DUMP_CODES");
   if (!path || !b->dynamic) return 0;
   const uint32_t N = (uint32_t)b->nodes.size(), nq = b->n_quanta;
   std::vector<uint8_t> all((size_t)b->n_inst * N * nq, 0xFF), tab((size_t)b->n_inst * b->code_stride);

@@ -547,17 +547,17 @@ void launch_biquad_tile_digest(const BiquadLanesDesc& d, void* stream) {
 }
 void launch_biquad_lanes(const BiquadLanesDesc& d0, void* stream) {
   BiquadLanesDesc d = d0;
-  d.debug = getenv("WAA_LANES_DEBUG") ? (uint32_t)atoi(getenv("WAA_LANES_DEBUG")) : 0u;
+  d.debug = measure_switch("WAA_LANES_DEBUG") ? (uint32_t)atoi(measure_switch("WAA_LANES_DEBUG")) : 0u;
   const uint32_t n_streams = d.n_inst * (uint32_t)d.nch, n_groups = (n_streams + 63u) / 64u;
   // LDS per wavefront: the row buffer + ONE table buffer — 9.5 KB (pass A) / 10.25 KB (pass B): 16 / 15 wavefronts per CU
   // (a second table buffer is not needed: the table is staged at the top of an iteration, after the previous chunk's sums).
   const size_t lds_a = 64 * ROWF * sizeof(float) + CHUNK * 2 * sizeof(double);
   const size_t lds_b = 64 * ROWF * sizeof(float) + CHUNK * 5 * sizeof(double);
   // tiles [tile0, tf): every stream linear (the instantiation without the general loader); [tf, tile1): the general one
-  const uint32_t tf = getenv("WAA_LANES_GENERAL") ? d.tile0 : std::min(std::max(d.fast_tiles, d.tile0), d.tile1);
+  const uint32_t tf = measure_switch("WAA_LANES_GENERAL") ? d.tile0 : std::min(std::max(d.fast_tiles, d.tile0), d.tile1);
   auto pass = [&](auto pass_c) {
     constexpr int PASS = decltype(pass_c)::value;
-    const size_t lds = (PASS == 0 ? lds_a : lds_b) + (getenv("WAA_LANES_LDS_PAD") ? (size_t)atoi(getenv("WAA_LANES_LDS_PAD")) : 0);  // (measurement aid: fewer wavefronts per CU)
+    const size_t lds = (PASS == 0 ? lds_a : lds_b) + (measure_switch("WAA_LANES_LDS_PAD") ? (size_t)atoi(measure_switch("WAA_LANES_LDS_PAD")) : 0);  // (measurement aid: fewer wavefronts per CU)
     if (tf > d.tile0) {
       d.lt0 = d.tile0;
       d.lt1 = tf;

@@ -497,7 +497,7 @@ void launch_biquad_scan(const BiquadStreamDesc& d, const BiquadScanCtl& ctl_in, 
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
-  const char* wpc = getenv("WAA_BIQUAD_SCAN_WAVES");  // resident wavefronts per CU (LDS: 9.2 KB each, registers: 4 per SIMD)
+  const char* wpc = measure_switch("WAA_BIQUAD_SCAN_WAVES");  // resident wavefronts per CU (LDS: 9.2 KB each, registers: 4 per SIMD)
   const uint64_t resident = (uint64_t)cus * (wpc ? (unsigned)atoi(wpc) : 16u);
   uint32_t waves = (uint32_t)(n_units < resident ? n_units : resident);
   waves = (waves + 7u) & ~7u;
@@ -507,7 +507,7 @@ void launch_biquad_scan(const BiquadStreamDesc& d, const BiquadScanCtl& ctl_in, 
     issued[sh] += ntl * ((n_streams + 7u - sh) / 8u) + waves / 8u;
   }
   const size_t lds = 64 * LDS_ROW * sizeof(float);
-  const char* dbg = getenv("WAA_SCAN_DEBUG");  // measurement aid (results wrong by construction): 1 no state hand-off,
+  const char* dbg = measure_switch("WAA_SCAN_DEBUG");  // measurement aid (results wrong by construction): 1 no state hand-off,
                                                // 2 static unit numbers, 3 both, 4 no output stores, 7 all three
   const int dm = dbg ? atoi(dbg) : 0;
   if (d.dup_out)

@@ -961,7 +961,7 @@ __global__ __launch_bounds__(64, 4) void biquad_stream_digest_kernel(const Biqua
 void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
   const dim3 grid(d.n_inst * (uint32_t)d.nch), block(64);
   const size_t lds = 2 * 64 * LDS_ROW * sizeof(float);
-  const char* dbg = getenv("WAA_STREAM_DEBUG");  // measurement aid only, see profiles/r01_c2_memory_pattern.txt
+  const char* dbg = measure_switch("WAA_STREAM_DEBUG");  // measurement aid only, see profiles/r01_c2_memory_pattern.txt
   if (d.dup_out && d.vary == 0) {
     hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 2, true>), grid, block, lds, (hipStream_t)stream, d);
     return;
@@ -970,7 +970,7 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
     hipLaunchKernelGGL((biquad_stream_kernel_t<3, 3>), grid, block, lds, (hipStream_t)stream, d);
   else if (d.vary == 3 && dbg && dbg[0] == '4')
     hipLaunchKernelGGL((biquad_stream_kernel_t<4, 3>), grid, block, lds, (hipStream_t)stream, d);
-  else if (d.vary == 3 && getenv("WAA_ARATE_BUFS3"))  // experiment: deeper coefficient prefetch (spills a few registers)
+  else if (d.vary == 3 && measure_switch("WAA_ARATE_BUFS3"))  // experiment: deeper coefficient prefetch (spills a few registers)
     hipLaunchKernelGGL((biquad_stream_kernel_t<0, 3, 3>), grid, block, lds, (hipStream_t)stream, d);
   else if (d.vary == 3)
     hipLaunchKernelGGL((biquad_stream_kernel_t<0, 3>), grid, block, lds, (hipStream_t)stream, d);
@@ -986,9 +986,9 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
     hipLaunchKernelGGL((biquad_stream_kernel_t<5, 0>), grid, block, lds, (hipStream_t)stream, d);
   else if (dbg && dbg[0] == '7')
     hipLaunchKernelGGL((biquad_stream_kernel_t<7, 0>), grid, block, lds, (hipStream_t)stream, d);
-  else if (getenv("WAA_STREAM_PREFETCH2"))  // experiment (A/B with tools/ab_env.py)
+  else if (measure_switch("WAA_STREAM_PREFETCH2"))  // experiment (A/B with tools/ab_env.py)
     hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 4>), grid, block, lds, (hipStream_t)stream, d);
-  else if (getenv("WAA_BIQUAD_DIGEST"))  // experiment, bit-identical output; same-box A/B (tools/ab_env.py): no gain — with 4
+  else if (measure_switch("WAA_BIQUAD_DIGEST"))  // experiment, bit-identical output; same-box A/B (tools/ab_env.py): no gain — with 4
                                          // instead of 2 waves per SIMD the kernel runs at the same 1.5-1.65 ms, i.e. what bounds
                                          // C2 is the memory side of 2048 concurrent streams, not the wave's latency hiding
     hipLaunchKernelGGL(biquad_stream_digest_kernel, grid, block, 64 * LDS_ROW * sizeof(float) + 34 * 2 * sizeof(double),

@@ -949,7 +949,7 @@ static int pipe_blocks_per_wg(const ConvDesc& d, int channels) {
   if (segs > nbl) segs = nbl;
   return (nbl + segs - 1) / segs;
 }
-static bool use_pipe(const ConvDesc& d) { return d.n == PIPE_N && !getenv("WAA_CONV_FFT_PLAIN"); }
+static bool use_pipe(const ConvDesc& d) { return d.n == PIPE_N && !measure_switch("WAA_CONV_FFT_PLAIN"); }
 
 void launch_conv_forward(const ConvDesc& d, void* stream) {
   if (d.fft3) return launch_conv3_forward(d, stream);
@@ -958,7 +958,7 @@ void launch_conv_forward(const ConvDesc& d, void* stream) {
     const int bpw = pipe_blocks_per_wg(d, d.cin);
     const dim3 grid((d.kb1 - d.kb0 + bpw - 1) / bpw, d.cin, d.n_pairs);
     const size_t lds = (size_t)(d.n + d.n / 8) * sizeof(Cplx) + (size_t)PIPE_NT * 4 * sizeof(Cplx);
-    const char* dbg = getenv("WAA_CONV_PIPE_DEBUG");
+    const char* dbg = measure_switch("WAA_CONV_PIPE_DEBUG");
     if (dbg && dbg[0] == '1')
       hipLaunchKernelGGL((conv_fft_pipe_kernel<MODE_FWD, 1>), grid, dim3(PIPE_NT), lds, (hipStream_t)stream, d, bpw);
     else if (dbg && dbg[0] == '2')
@@ -977,7 +977,7 @@ void launch_conv_inverse(const ConvDesc& d, void* stream) {
     const int bpw = pipe_blocks_per_wg(d, d.cout);
     const dim3 grid((d.kb1 - d.kb0 + bpw - 1) / bpw, d.cout, d.n_pairs);
     const size_t lds = (size_t)(d.n + d.n / 8) * sizeof(Cplx) + (size_t)PIPE_NT * 4 * sizeof(Cplx);
-    const char* dbg = getenv("WAA_CONV_PIPE_DEBUG");
+    const char* dbg = measure_switch("WAA_CONV_PIPE_DEBUG");
     if (dbg && dbg[0] == '1')
       hipLaunchKernelGGL((conv_fft_pipe_kernel<MODE_INV, 1>), grid, dim3(PIPE_NT), lds, (hipStream_t)stream, d, bpw);
     else if (dbg && dbg[0] == '2')
@@ -1001,7 +1001,7 @@ void launch_analyser(const AnalyserDesc& d, void* stream) {
 void launch_conv_mac(const ConvDesc& d0, void* stream) {
   dim3 grid(d0.n / 256, d0.n_pairs * (uint32_t)d0.cout);
   ConvDesc dm = d0;
-  dm.mac_grid_order = getenv("WAA_CONV_MAC_GRID_ORDER") ? 1 : 0;
+  dm.mac_grid_order = measure_switch("WAA_CONV_MAC_GRID_ORDER") ? 1 : 0;
   const ConvDesc& d = dm;
   bool one_term = true;
   for (int co = 0; co < d.cout; co++) {
@@ -1009,13 +1009,13 @@ void launch_conv_mac(const ConvDesc& d0, void* stream) {
     for (int t = 0; t < d.n_terms; t++) cnt += d.terms[t].out_ch == co;
     one_term &= cnt == 1;
   }
-  if (one_term && d.parts > 8 && d.parts <= 24 && !getenv("WAA_CONV_MAC_REREAD")) {  // (switch: A/B against conv_mac_kernel)
+  if (one_term && d.parts > 8 && d.parts <= 24 && !measure_switch("WAA_CONV_MAC_REREAD")) {  // (switch: A/B against conv_mac_kernel)
     if (d.parts <= 12)
       hipLaunchKernelGGL((conv_mac_win_kernel<16, 12>), grid, dim3(256), 0, (hipStream_t)stream, d);
     else if (d.parts <= 16)
       hipLaunchKernelGGL((conv_mac_win_kernel<16, 16>), grid, dim3(256), 0, (hipStream_t)stream, d);
     else if (d.parts <= 22) {  // (8 output blocks per tile were measured: 220 registers all the same, 3.78 ms against 3.59)
-      if (getenv("WAA_CONV_MAC_NO_PREFETCH"))  // (switch: same-box A/B of the software pipeline)
+      if (measure_switch("WAA_CONV_MAC_NO_PREFETCH"))  // (switch: same-box A/B of the software pipeline)
         hipLaunchKernelGGL((conv_mac_win_kernel<16, 22, false>), grid, dim3(256), 0, (hipStream_t)stream, d);
       else
         hipLaunchKernelGGL((conv_mac_win_kernel<16, 22>), grid, dim3(256), 0, (hipStream_t)stream, d);

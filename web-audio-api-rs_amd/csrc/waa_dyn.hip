@@ -708,7 +708,7 @@ void launch_dyn(const DynDesc& d, void* stream) {
   const size_t lds = ((size_t)d.n_items * cm * RQ + cm * RQ) * sizeof(float) + (size_t)d.n_items * cm * DYN_STATE * sizeof(double) +
                      (size_t)(d.n_items * 5 + 2) * sizeof(int) + (size_t)d.n_items * sizeof(DynItem);
   DynDesc dd = d;
-  dd.no_scan = getenv("WAA_DYN_NO_SCAN") ? 1u : 0u;
+  dd.no_scan = measure_switch("WAA_DYN_NO_SCAN") ? 1u : 0u;
   if (cm == 2) {
     if (lds > 64 * 1024)
       raise_lds_limit(reinterpret_cast<const void*>(dyn_kernel<2>));

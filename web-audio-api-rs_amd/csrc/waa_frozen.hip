@@ -772,7 +772,7 @@ __global__ __launch_bounds__(512, 4) void qgemm_bf16x6_w8_kernel(const QGemmDesc
 }
 void launch_qgemm(const QGemmDesc& d, void* stream) {
   dim3 grid((d.n_quanta + BN - 1) / BN, d.M / BM, d.n_inst * (uint32_t)d.nch);
-  const char* xdbg = getenv("WAA_QGEMM_DEBUG");
+  const char* xdbg = measure_switch("WAA_QGEMM_DEBUG");
   if (d.A16 && xdbg && xdbg[0] >= 'a' && xdbg[0] <= 'c') {
     if (xdbg[0] == 'a') hipLaunchKernelGGL(qgemm_bf16x6_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, d);
     if (xdbg[0] == 'b') hipLaunchKernelGGL(qgemm_bf16x6_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, d);
@@ -783,13 +783,13 @@ void launch_qgemm(const QGemmDesc& d, void* stream) {
     if (xdbg[0] == 'f') hipLaunchKernelGGL(qgemm_bf16x6_w8_kernel<3>, grid, dim3(512), 0, (hipStream_t)stream, d);
   } else if (d.A16 && xdbg && xdbg[0] == 'g') {
     hipLaunchKernelGGL(qgemm_bf16x6_w8_kernel<4>, grid, dim3(512), 0, (hipStream_t)stream, d);
-  } else if (d.A16 && !getenv("WAA_QGEMM_FMA") && !getenv("WAA_QGEMM_F32") && !xdbg && getenv("WAA_QGEMM_W4"))
+  } else if (d.A16 && !measure_switch("WAA_QGEMM_FMA") && !measure_switch("WAA_QGEMM_F32") && !xdbg && measure_switch("WAA_QGEMM_W4"))
     hipLaunchKernelGGL(qgemm_bf16x6_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d);
-  else if (d.A16 && !getenv("WAA_QGEMM_FMA") && !getenv("WAA_QGEMM_F32") && !xdbg)
+  else if (d.A16 && !measure_switch("WAA_QGEMM_FMA") && !measure_switch("WAA_QGEMM_F32") && !xdbg)
     hipLaunchKernelGGL(qgemm_bf16x6_w8_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, d);
-  else if (getenv("WAA_QGEMM_FMA"))  // (switch: the vector-FMA form, same-box A/B with tools/ab_env.py)
+  else if (measure_switch("WAA_QGEMM_FMA"))  // (switch: the vector-FMA form, same-box A/B with tools/ab_env.py)
     hipLaunchKernelGGL(qgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
-  else if (const char* dbg = getenv("WAA_QGEMM_DEBUG")) {
+  else if (const char* dbg = measure_switch("WAA_QGEMM_DEBUG")) {
     switch (dbg[0]) {
       case '1': hipLaunchKernelGGL(qgemm_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, d); break;
       case '2': hipLaunchKernelGGL(qgemm_mfma_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, d); break;
@@ -1029,16 +1029,16 @@ __global__ __launch_bounds__(64) void hrtf8_kernel(const HrtfDesc d) {
   *(WAA_GLOBAL_AS f4v*)(out + d.out.ch_stride + 4) = r1;
 }
 void launch_hrtf(const HrtfDesc& d, void* stream) {
-  if (!getenv("WAA_HRTF_V1")) {
+  if (!measure_switch("WAA_HRTF_V1")) {
     const int O = (d.taps + 3) & ~3;
-    const bool stat = d.hstatic != nullptr && !getenv("WAA_HRTF_DYNAMIC");
+    const bool stat = d.hstatic != nullptr && !measure_switch("WAA_HRTF_DYNAMIC");
     const size_t lds = (size_t)4 * (size_t)((stat ? O : 3 * O) + RQ) * sizeof(float);
     dim3 grid((d.n_quanta + 3) / 4, d.n_inst);
     if (stat) {
       hipLaunchKernelGGL(hrtf8_kernel<true>, grid, dim3(64), lds, (hipStream_t)stream, d);
       return;
     }
-    if (getenv("WAA_HRTF_V8")) {  // (experiment: the eight-frame form with per-unit HRIR pairs in LDS — slower, see above)
+    if (measure_switch("WAA_HRTF_V8")) {  // (experiment: the eight-frame form with per-unit HRIR pairs in LDS — slower, see above)
       if (lds > 64 * 1024)
         raise_lds_limit(reinterpret_cast<const void*>(hrtf8_kernel<false>));
       hipLaunchKernelGGL(hrtf8_kernel<false>, grid, dim3(64), lds, (hipStream_t)stream, d);

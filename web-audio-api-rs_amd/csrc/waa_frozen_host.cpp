@@ -120,7 +120,7 @@ static int plan_link(waa_batch* b, uint32_t id, int kind, int src_id, uint32_t t
   }
   if (!d_in) return fail(WAA_ERR_INVALID_STATE, "internal: node %u has no input codes", id);
   int32_t* d_prev = nullptr;
-  if (src_id >= 0 && !b->dynamic && !getenv("WAA_LINK_KERNEL")) {
+  if (src_id >= 0 && !b->dynamic && !measure_switch("WAA_LINK_KERNEL")) {
     // static plan: the codes are host-known, so is the replay (the automaton of link_kernel, once per plan instead of
     // one single-thread-per-instance launch per render: 0.7 ms of a 10-15 ms render)
     std::vector<int32_t> hp((size_t)b->n_inst * b->n_quanta);
@@ -222,7 +222,7 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
   if (!n.d_curve && (e = dev_upload(b, &n.d_curve, n.curve))) return e;
   const int up_len = RQ * R;
   const int nch = n.in_nch;
-  const bool matrix_form = getenv("WAA_OS_MATRIX") != nullptr;  // (A/B: the round-2 dense products on the matrix cores)
+  const bool matrix_form = measure_switch("WAA_OS_MATRIX") != nullptr;  // (A/B: the round-2 dense products on the matrix cores)
   if (!matrix_form && nch <= 2) {
     // Transform form (waa_osfft.hip): one launch, the stages as 256-point transforms, nothing at the high rate in HBM.
     float *d_tab = nullptr, *d_tw = nullptr;
@@ -253,7 +253,7 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
     // rendered in front of every run for its overlaps)
     const uint32_t want = std::max<uint32_t>(1, (16384 + b->n_inst - 1) / b->n_inst);
     uint32_t seg = std::max<uint32_t>(8, (b->n_quanta + want - 1) / want);
-    if (const char* sv = getenv("WAA_OSFFT_SEG")) seg = std::max(1, atoi(sv));  // (tests: short runs exercise the run heads)
+    if (const char* sv = measure_switch("WAA_OSFFT_SEG")) seg = std::max(1, atoi(sv));  // (tests: short runs exercise the run heads)
     f.seg_len = seg;
     f.n_seg = (b->n_quanta + seg - 1) / seg;
     os.profile_slot = slot_for(b, "osfft_kernel");

@@ -2,8 +2,23 @@
 // (waa_kernels.hip).  Not part of the public C ABI (include/waa_hip.h).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 
 namespace waa {
+
+// Switches read from the environment.  Four are part of the library's behaviour and documented:
+// WAA_POISON_ALLOC, WAA_STRICT_CHANNEL_COUNTS, WAA_OSC_EXACT, WAA_IIR_EXACT — plain getenv.  Everything else is an A/B,
+// debugging or measurement aid (several produce wrong results by construction): measure_switch() is getenv only in
+// libwaa_hip_measure.so (built from the same sources with -DWAA_MEASURE; the tests and tools that flip such switches load
+// it) and a constant null pointer in the product library, where the corresponding code folds away.
+inline const char* measure_switch(const char* name) {
+#ifdef WAA_MEASURE
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // Kernels that need more than 64 KB of dynamic LDS: the limit of a kernel function is a per-DEVICE attribute, and several
 // devices may be driven from threads of one process (waa_render_sharded): raised once per (device, function), under a lock.

@@ -992,10 +992,10 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
     dd.lds_curve_op = -1;
     dd.tile_major = 0;
     for (int k = 0; k < d.n_inputs; k++) dd.tile_major |= d.in[k].kind == IN_SOURCE;
-    if (getenv("WAA_NO_TILE_MAJOR")) dd.tile_major = 0;  // measurement aid
+    if (measure_switch("WAA_NO_TILE_MAJOR")) dd.tile_major = 0;  // measurement aid
     // (same-batch A/B, tools/placement_probe.py with ALT=WAA_NO_XCD_REMAP=1: echo 2.01 against 2.06 ms, the pan stage of C4
     // 1.39-1.44 against 1.44-1.46 ms)
-    dd.xcd_remap = !dd.tile_major && !getenv("WAA_NO_XCD_REMAP");
+    dd.xcd_remap = !dd.tile_major && !measure_switch("WAA_NO_XCD_REMAP");
     for (int o = 0; o < d.n_ops; o++)
       if (d.ops[o].kind == OP_WAVESHAPER && d.ops[o].i0 > 0 && d.ops[o].i0 <= 8192) {
         dd.lds_curve_op = o;
@@ -1044,7 +1044,7 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream) {
       bool frame_pan = false;
       for (int o = 0; o < d.n_ops; o++)
         frame_pan |= (d.ops[o].kind == OP_STEREO_PAN || d.ops[o].kind == OP_PANNER) && d.ops[o].p0.mode == 2;
-      if (frame_pan || getenv("WAA_CHAIN_NOSPILL"))
+      if (frame_pan || measure_switch("WAA_CHAIN_NOSPILL"))
         hipLaunchKernelGGL((chain_kernel<2, 4, false, true, false, true>), grid, block, lds, s, dd);
       else
         hipLaunchKernelGGL((chain_kernel<2, 4, false>), grid, block, lds, s, dd);

@@ -361,7 +361,7 @@ void launch_loop(const LoopDesc& d, void* stream) {
   if (lds > 64 * 1024)
     raise_lds_limit(reinterpret_cast<const void*>(loop_kernel));
   LoopDesc dd = d;
-  dd.no_scan = getenv("WAA_DYN_NO_SCAN") ? 1u : 0u;
+  dd.no_scan = measure_switch("WAA_DYN_NO_SCAN") ? 1u : 0u;
   hipLaunchKernelGGL(loop_kernel, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, dd);
 }
 

@@ -232,7 +232,7 @@ int build_edge_input(waa_batch* b, uint32_t head, int ie, InputRef* out) {
     // the delay line of a loop-breaking DelayNode is written by a LATER launch of the same block (the reads go to
     // earlier blocks: the loop is block-scheduled with blocks shorter than the delay)
     in.feedback = pid < b->cut.size() && b->cut[pid] ? 1 : 0;
-  } else if (pn.is_view && !getenv("WAA_NO_VIEW_SIGNAL")) {
+  } else if (pn.is_view && !measure_switch("WAA_NO_VIEW_SIGNAL")) {
     // a BufferSource that renders its AudioBuffer unchanged: a plain signal with an end (one layout for all instances:
     // no per-instance source record in front of the samples); silence past the buffer
     in.kind = IN_SIGNAL;
@@ -434,7 +434,7 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
                   const SignalRef& out) {
   bool any_stream = false;
   // debugging aids: force k-rate / a-rate biquads onto the serial interpreter
-  const int max_mode = getenv("WAA_NO_KRATE_STREAM") ? 0 : (getenv("WAA_NO_ARATE_STREAM") ? 1 : 2);
+  const int max_mode = measure_switch("WAA_NO_KRATE_STREAM") ? 0 : (measure_switch("WAA_NO_ARATE_STREAM") ? 1 : 2);
   // (any channel count: the streaming kernels run one wavefront per (instance, channel) with per-channel state, like the
   // reference's per-channel state vector, biquad_filter.rs:797-812 — 4- and 6-channel signals included)
   auto streams = [&](const OpDesc& o) { return o.kind == OP_IIR || (o.kind == OP_BIQUAD && o.i0 <= max_mode && o.nch_in <= MAX_CH); };
@@ -474,7 +474,7 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
       while (j < ops.size() && j - i <= 2 && ops[j].kind == OP_GAIN && ops[j].p0.mode == 0 && ops[j].nch_in == cur_nch) j++;
     // a mono biquad whose result only goes through the speakers up-mix 1 -> 2 into `out`: the kernel writes both channels
     const bool dup = o.kind == OP_BIQUAD && o.i0 == 0 && cur_nch == 1 && out.nch == 2 && j + 1 == ops.size() && ops[j].kind == OP_MIX &&
-                     ops[j].nch_in == 1 && ops[j].nch_out == 2 && ops[j].i0 == WAA_INTERP_SPEAKERS && !getenv("WAA_NO_STREAM_DUP");
+                     ops[j].nch_in == 1 && ops[j].nch_out == 2 && ops[j].i0 == WAA_INTERP_SPEAKERS && !measure_switch("WAA_NO_STREAM_DUP");
     SignalRef seg_out = out;
     if (!dup && (j < ops.size() || out.nch != cur_nch)) {
       int e = temp_signal(b, cur_nch, &seg_out);
@@ -497,7 +497,7 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
         const double streams = (double)b->n_inst * cur_nch;
         const double lane_cost = std::ceil(streams / 64. / 1024.) * (12. * q.ns + 32.);
         const double row_cost = std::ceil(streams / 4. / 1024.) * 64.;
-        q.exact = (row_cost < lane_cost && !getenv("WAA_IIR_LANE")) || getenv("WAA_IIR_ROW") ? 2u : 1u;
+        q.exact = (row_cost < lane_cost && !measure_switch("WAA_IIR_LANE")) || measure_switch("WAA_IIR_ROW") ? 2u : 1u;
       }
       q.nch = cur_nch;
       q.out = seg_out;
@@ -522,7 +522,7 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
       if (i == ops.size() && seg_out.base == out.base) return 0;
       continue;
     }
-    if (o.kind == OP_BIQUAD && o.i0 == 2 && !dup && !b->dry && b->steps[(size_t)o.i1].coef.rows == 1 && !getenv("WAA_ARATE_STREAM") &&
+    if (o.kind == OP_BIQUAD && o.i0 == 2 && !dup && !b->dry && b->steps[(size_t)o.i1].coef.rows == 1 && !measure_switch("WAA_ARATE_STREAM") &&
         (inputs[0].kind == IN_SIGNAL || inputs[0].kind == IN_SOURCE) &&
         (uint64_t)b->n_inst * seg_out.inst_stride < (1ull << 32)) {  // (its output rows are 32-bit element offsets)
       // per-frame coefficients, ONE table for all instances: a lane per stream, tiles in parallel (waa_biquad_lanes.hip)
@@ -585,7 +585,7 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     if (o.i0 == 2) {
       Step& cstep = b->steps[(size_t)o.i1];
       cstep.coef.lane_major = 1;  // the table is read lane by lane (waa_biquad_stream.hip)
-      if (cstep.coef.rows == 1 && !getenv("WAA_NO_ARATE_DIGEST")) {
+      if (cstep.coef.rows == 1 && !measure_switch("WAA_NO_ARATE_DIGEST")) {
         // one table for all instances: digest it once (zero-state end state as a dot product, BiquadHpDesc); the
         // digest step was reserved right behind the coefficient step by emit_node_ops
         Step& hstep = b->steps[(size_t)o.i1 + 1];
@@ -616,7 +616,7 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
     // wavefront per stream — 78 % of its wave-cycles are waits on the unit's dependent round trips (dequeue, source record,
     // predecessor state, coefficient powers); kept as the cross-check of the hand-off protocol and for very long renders of
     // few streams, where the per-stream kernel cannot fill the chip)
-    if (q.vary == 0 && !b->dry && getenv("WAA_BIQUAD_SCAN")) {
+    if (q.vary == 0 && !b->dry && measure_switch("WAA_BIQUAD_SCAN")) {
       const size_t n_streams = (size_t)b->n_inst * cur_nch;
       if (!b->scan_counter) {
         int e = dev_alloc(b, &b->scan_counter, 8 * 16 + 16);
@@ -698,8 +698,8 @@ int materialise_automation(waa_batch* b) {
                                 kind == WAA_NODE_STEREO_PANNER || kind == WAA_NODE_CONSTANT_SOURCE ||
                                 kind == WAA_NODE_OSCILLATOR ||
                                 (kind == WAA_NODE_PANNER && pk >= 6 && n.desc.i[0] != WAA_PANNING_HRTF);
-        const bool want = getenv("WAA_DEVICE_AUTOMATION") ? true : !shared;  // (switch: also replay shared timelines there)
-        if (consumable && !p.k_rate && want && !b->dry && !getenv("WAA_HOST_AUTOMATION")) {
+        const bool want = measure_switch("WAA_DEVICE_AUTOMATION") ? true : !shared;  // (switch: also replay shared timelines there)
+        if (consumable && !p.k_rate && want && !b->dry && !measure_switch("WAA_HOST_AUTOMATION")) {
           p.dev_tl = true;
           continue;  // (the timelines are consumed when the param is uploaded)
         }
@@ -1244,7 +1244,7 @@ int build_plan(waa_batch* b) {
               }
           }
         if (what) {
-          const bool keep_static = getenv("WAA_STATIC_CHANNEL_COUNTS") != nullptr;  // A/B aid: the round-1 behaviour
+          const bool keep_static = measure_switch("WAA_STATIC_CHANNEL_COUNTS") != nullptr;  // A/B aid: the round-1 behaviour
           if (keep_static)
             plan_note(b,
                       "note: the input of node %u %s at quantum %u (instance %u): the reference's dynamic channel count changes "
@@ -1272,7 +1272,7 @@ int build_plan(waa_batch* b) {
   for (uint32_t id = 0; id < N && !count_change_found && !b->force_dynamic; id++) {
     Node& n = b->nodes[id];
     if (!n.live || !is_frozen_node(n)) continue;
-    bool simple = n.in_edges.size() == 1 && scc_of[id] < 0 && !getenv("WAA_FROZEN_DYNAMIC");
+    bool simple = n.in_edges.size() == 1 && scc_of[id] < 0 && !measure_switch("WAA_FROZEN_DYNAMIC");
     if (simple) {
       const uint32_t p = b->edges[n.in_edges[0]].from;
       const uint32_t pk = b->nodes[p].desc.kind;
@@ -1280,7 +1280,7 @@ int build_plan(waa_batch* b) {
                b->nodes[p].out_nch == n.in_nch && n.in_nch <= 2;
       if (simple) frozen_src[id] = (int)p;
     }
-    if (!simple && !getenv("WAA_STATIC_CHANNEL_COUNTS")) {
+    if (!simple && !measure_switch("WAA_STATIC_CHANNEL_COUNTS")) {
       plan_note(b, "node %u keeps frozen state over silent quanta and is not fed by a single source -> exact per-quantum codes (dyn_kernel)", id);
       count_change_found = true;
     }
@@ -1292,7 +1292,7 @@ int build_plan(waa_batch* b) {
   // the gather then only reaches into earlier blocks), and a GainNode of such a loop can ride on an input edge like
   // outside: the classic echo loop Delay <-> Gain is ONE launch per block (line = source + gain * delayed(line)).
   std::vector<uint32_t> scc_block((size_t)n_scc, 0);
-  if (!count_change_found && !b->force_dynamic && !getenv("WAA_NO_LOOP_FOLD"))
+  if (!count_change_found && !b->force_dynamic && !measure_switch("WAA_NO_LOOP_FOLD"))
     for (int sc = 0; sc < n_scc; sc++) {
       std::vector<uint32_t> loop_items;
       for (uint32_t v : items)
@@ -1304,7 +1304,7 @@ int build_plan(waa_batch* b) {
   for (uint32_t id = 0; id < N; id++) {
     Node& n = b->nodes[id];
     n.delay_folded = false;
-    if (!n.live || n.desc.kind != WAA_NODE_DELAY || count_change_found || b->force_dynamic || getenv("WAA_NO_DELAY_FOLD")) continue;
+    if (!n.live || n.desc.kind != WAA_NODE_DELAY || count_change_found || b->force_dynamic || measure_switch("WAA_NO_DELAY_FOLD")) continue;
     if ((scc_of[id] >= 0 || (id < b->cut.size() && b->cut[id])) && !block_loop(id)) continue;
     const ParamStore& dt = n.params[WAA_PARAM_DELAY_DELAY_TIME];
     bool ok = dt.mode() != 2 && n.in_edges.size() >= 1;
@@ -1356,7 +1356,7 @@ int build_plan(waa_batch* b) {
         if (e.to_input & 0x80000000u) {
           // feeds an AudioParam: read back as a per-frame value signal — except a plain GainNode (the depth of an LFO),
           // which rides on the input edge of the param's summing chain like on any other summing input
-          if (kind == WAA_NODE_GAIN && scc_of[id] < 0 && !count_change_found && !b->force_dynamic && !getenv("WAA_NO_EDGE_FOLD"))
+          if (kind == WAA_NODE_GAIN && scc_of[id] < 0 && !count_change_found && !b->force_dynamic && !measure_switch("WAA_NO_EDGE_FOLD"))
             fan = true;
           else
             mat = true;
@@ -1377,7 +1377,7 @@ int build_plan(waa_batch* b) {
   // materialised signal (or on a source) becomes a per-edge gain — the mixer pattern source->Gain->bus costs no
   // pass through HBM of its own.
   auto is_source_kind = [&](uint32_t k) { return k == WAA_NODE_BUFFER_SOURCE || k == WAA_NODE_CONSTANT_SOURCE; };
-  if (!getenv("WAA_NO_EDGE_FOLD"))
+  if (!measure_switch("WAA_NO_EDGE_FOLD"))
     for (uint32_t id = 0; id < N; id++) {
       Node& n = b->nodes[id];
       if (!n.live || !fan_in_only[id]) continue;
@@ -1398,7 +1398,7 @@ int build_plan(waa_batch* b) {
   // A BufferSource whose output IS its AudioBuffer (fast track from frame 0: start 0, no offset / duration / stop /
   // loop, playbackRate 1, detune 0, buffer at the context's rate, one layout for all instances) and whose single
   // consumer is a node-major step that accepts a bounded view: read in place, no copy through HBM.
-  for (uint32_t id = 0; id < N && !getenv("WAA_NO_SOURCE_VIEW"); id++) {
+  for (uint32_t id = 0; id < N && !measure_switch("WAA_NO_SOURCE_VIEW"); id++) {
     Node& n = b->nodes[id];
     n.is_view = false;
     if (!n.live || n.desc.kind != WAA_NODE_BUFFER_SOURCE || !n.materialized || count_change_found || b->force_dynamic) continue;
@@ -1465,7 +1465,7 @@ int build_plan(waa_batch* b) {
   // filtered signal never crosses HBM and the Biquad costs no launch.  Its own input must be a plain signal: a
   // BufferSource that renders its AudioBuffer unchanged (read in place) or a signal some other node materialises anyway.
   for (auto& n : b->nodes) n.fold_conv = n.pre_biquad = -1;
-  if (!count_change_found && !b->force_dynamic && !getenv("WAA_NO_CONV_BIQUAD_FOLD") && !getenv("WAA_CONV_FFT_R4"))
+  if (!count_change_found && !b->force_dynamic && !measure_switch("WAA_NO_CONV_BIQUAD_FOLD") && !measure_switch("WAA_CONV_FFT_R4"))
     for (uint32_t cid = 0; cid < N; cid++) {
       Node& c = b->nodes[cid];
       if (!c.live || c.desc.kind != WAA_NODE_CONVOLVER || !c.has_ir || scc_of[cid] >= 0 || c.in_edges.size() != 1) continue;
@@ -1484,7 +1484,7 @@ int build_plan(waa_batch* b) {
       const uint32_t sid = b->edges[q.in_edges[0]].from;
       Node& sn = b->nodes[sid];
       if (!sn.live || sn.out_nch != q.in_nch) continue;
-      if (sn.desc.kind == WAA_NODE_BUFFER_SOURCE && !sn.materialized && !sn.is_view && !getenv("WAA_NO_SOURCE_VIEW")) {
+      if (sn.desc.kind == WAA_NODE_BUFFER_SOURCE && !sn.materialized && !sn.is_view && !measure_switch("WAA_NO_SOURCE_VIEW")) {
         int s_consumers = 0;
         for (auto& e : b->edges) s_consumers += e.from == sid && b->nodes[e.to].live;
         const ParamStore& pr = sn.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
@@ -1695,7 +1695,7 @@ int build_plan(waa_batch* b) {
     // 1 -> 2 (Oscillator -> Gain -> stereo destination: the plain tone generator): the oscillator's own launch writes the
     // result, no second pass over it.
     if (cd.n_inputs == 1 && cd.in[0].kind == IN_SIGNAL && !cd.in[0].has_gain && cd.in[0].nch == 1 && cd.in_nch == 1 &&
-        scc_of[id] < 0 && !getenv("WAA_NO_OSC_POST")) {
+        scc_of[id] < 0 && !measure_switch("WAA_NO_OSC_POST")) {
       int prod = -1;
       for (uint32_t k = 0; k < N; k++)
         if (b->nodes[k].live && b->nodes[k].desc.kind == WAA_NODE_OSCILLATOR && b->nodes[k].sig.base == cd.in[0].sig.base &&
@@ -2075,7 +2075,7 @@ int build_plan(waa_batch* b) {
       }
     }
     if (int e = flush()) return e;
-    if (getenv("WAA_DEBUG_REVERSE_PLAN")) std::reverse(b->steps.begin(), b->steps.end());
+    if (measure_switch("WAA_DEBUG_REVERSE_PLAN")) std::reverse(b->steps.begin(), b->steps.end());
     if (int e = validate_plan(b)) return e;
     b->planned = true;
     return 0;
@@ -2102,7 +2102,7 @@ int build_plan(waa_batch* b) {
       const uint32_t bt = loop_block_tiles(b, loop_items);
       if (bt == 0) {  // short or modulated loop delay: quantum-serial loop kernel
         int e = plan_loop(b, loop_items);
-        if (e == WAA_ERR_OUT_OF_SCOPE && !b->force_dynamic && !getenv("WAA_STATIC_CHANNEL_COUNTS")) {
+        if (e == WAA_ERR_OUT_OF_SCOPE && !b->force_dynamic && !measure_switch("WAA_STATIC_CHANNEL_COUNTS")) {
           // the static loop kernel covers Gain / Biquad / WaveShaper / k-rate StereoPanner / Delay members only; the
           // dynamic-count kernel renders every node kind quantum by quantum (waa_dyn.hip): plan the graph again with it
           b->force_dynamic = true;
@@ -2168,7 +2168,7 @@ int build_plan(waa_batch* b) {
             n_body++;
             body = k;
           }
-        if (n_body == 1 && b->steps[body].kind == 0 && !getenv("WAA_NO_ECHO_RING")) {
+        if (n_body == 1 && b->steps[body].kind == 0 && !measure_switch("WAA_NO_ECHO_RING")) {
           float range[2] = {1e30f, 0.f};
           for (uint32_t v : loop_items) {
             const uint32_t did = v & ~VTX_READER;
@@ -2203,7 +2203,7 @@ int build_plan(waa_batch* b) {
   fuse_echo_tails(b);
   ring_feed_forward_echoes(b);
   // (self-test of the check below: a reversed launch list must not get past it, tests/test_plan.py)
-  if (getenv("WAA_DEBUG_REVERSE_PLAN")) std::reverse(b->steps.begin(), b->steps.end());
+  if (measure_switch("WAA_DEBUG_REVERSE_PLAN")) std::reverse(b->steps.begin(), b->steps.end());
   if (int e = validate_plan(b)) return e;
   b->planned = true;
   return 0;

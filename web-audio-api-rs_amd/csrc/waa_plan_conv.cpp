@@ -19,7 +19,7 @@ int conv_block_size(const waa_batch* b, const Node& n) {
     len = std::max(len, l);
   }
   if (len == 0) return 0;
-  if (len <= (uint64_t)DIRECT_MAX_TAPS && !b->dynamic && !getenv("WAA_NO_DIRECT_FIR")) return 0;
+  if (len <= (uint64_t)DIRECT_MAX_TAPS && !b->dynamic && !measure_switch("WAA_NO_DIRECT_FIR")) return 0;
   for (int cand : {128, 512, 2048, 8192})
     if ((len + cand - 1) / cand <= 24) return cand;
   return 8192;
@@ -71,7 +71,7 @@ int plan_convolver(waa_batch* b, uint32_t id) {
   // when their state leaves the normal range), and exact zeros behind a convolver that has seen input turn "still
   // ringing with noise, stereo" into "silent, mono" for every count-sensitive node behind it.  Dynamic plans therefore
   // take the FFT form for every length, like the reference (fuzz seeds 1658, 1340 of the 1500-seed runs).
-  const bool direct_fir = len <= (uint64_t)DIRECT_MAX_TAPS && !b->dynamic && !getenv("WAA_NO_DIRECT_FIR");
+  const bool direct_fir = len <= (uint64_t)DIRECT_MAX_TAPS && !b->dynamic && !measure_switch("WAA_NO_DIRECT_FIR");
   int B = 8192;
   for (int cand : {128, 512, 2048, 8192})
     if ((len + cand - 1) / cand <= 24) {
@@ -80,7 +80,7 @@ int plan_convolver(waa_batch* b, uint32_t id) {
     }
   cv.block = B;
   cv.n = 2 * B;
-  cv.fft3 = cv.n == 16384 && !getenv("WAA_CONV_FFT_R4");  // (the round-2 radix-4-in-LDS kernels: same-box A/B only)
+  cv.fft3 = cv.n == 16384 && !measure_switch("WAA_CONV_FFT_R4");  // (the round-2 radix-4-in-LDS kernels: same-box A/B only)
   cv.parts = (int)((len + B - 1) / B);
   cv.nb = (int)((b->lp + B - 1) / B);
   cv.cin = n.in_nch;

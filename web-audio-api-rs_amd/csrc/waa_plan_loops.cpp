@@ -16,7 +16,7 @@ namespace host {
 // launch list, buffer by buffer, with the same read / write sets the validation below uses; any launch kind those sets do
 // not describe keeps the plan as it is.
 void fuse_echo_tails(waa_batch* b) {
-  if (getenv("WAA_NO_ECHO_TAIL")) return;
+  if (measure_switch("WAA_NO_ECHO_TAIL")) return;
   for (const Step& st : b->steps)
     if (st.kind == 11 || st.kind == 15 || st.kind > 20) return;
   for (size_t l = 0; l < b->steps.size(); l++) {
@@ -82,8 +82,8 @@ void fuse_echo_tails(waa_batch* b) {
 // stream with two chunks in flight and takes the delayed samples from LDS: 5 TB/s — when there is at least one instance
 // per CU to walk (WAA_ECHO_FF_MIN_INST, default 256: below that the tile-parallel launch fills the device better).
 void ring_feed_forward_echoes(waa_batch* b) {
-  if (getenv("WAA_NO_ECHO_RING") || getenv("WAA_NO_ECHO_FF")) return;
-  const char* mi = getenv("WAA_ECHO_FF_MIN_INST");
+  if (measure_switch("WAA_NO_ECHO_RING") || measure_switch("WAA_NO_ECHO_FF")) return;
+  const char* mi = measure_switch("WAA_ECHO_FF_MIN_INST");
   if (b->n_inst < (uint32_t)(mi ? atoi(mi) : 256)) return;
   for (size_t k = 0; k < b->steps.size(); k++) {
     Step& st = b->steps[k];
@@ -201,7 +201,7 @@ int plan_delay_reader(waa_batch* b, uint32_t id) {
 // (constant or k-rate blocks, not modulated from the graph) strictly longer than the block: then no frame of a
 // block depends on loop history of the same block.
 uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items) {
-  if (getenv("WAA_LOOP_KERNEL")) return 0;  // debugging aid: force the quantum-serial kernel
+  if (measure_switch("WAA_LOOP_KERNEL")) return 0;  // debugging aid: force the quantum-serial kernel
   const double dt = 1. / (double)b->sr;
   const double quantum_duration = (double)RQ * dt;
   double dmin = 1e300;

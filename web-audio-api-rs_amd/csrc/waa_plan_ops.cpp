@@ -198,7 +198,7 @@ int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector
         m.swap(t);
         note(m);
       }
-      const char* genv = getenv("WAA_IIR_GROWTH");  // experiments only
+      const char* genv = measure_switch("WAA_IIR_GROWTH");  // experiments only
       const double growth_limit = genv ? atof(genv) : 1e4;
       const bool exact = !(growth <= growth_limit) || getenv("WAA_IIR_EXACT") != nullptr;  // env: debugging aid
       if (exact)

@@ -136,7 +136,7 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   for (auto& si : insts) {
     si.sc = scheds[si.sched];
     si.linear_start = linear[si.sched].first;
-    si.fast_prefix = si.aligned && !getenv("WAA_NO_LINEAR_PREFIX") ? linear[si.sched].second : 0;  // (switch: A/B aid)
+    si.fast_prefix = si.aligned && !measure_switch("WAA_NO_LINEAR_PREFIX") ? linear[si.sched].second : 0;  // (switch: A/B aid)
     si.linear_all = si.fast_prefix ? linear_all[si.sched] : 0;
   }
   SrcInst* d_insts = nullptr;
@@ -246,7 +246,7 @@ static inline bool osc_quantum_fully_active(double block_time, double next_block
 
 int plan_oscillator(waa_batch* b, uint32_t id) {
   // WAA_OSC_PLAN_CHECK=1 (tests): every quantum is walked frame by frame as before and the shortcut's answer is checked
-  const bool check_replay = getenv("WAA_OSC_PLAN_CHECK") != nullptr;
+  const bool check_replay = measure_switch("WAA_OSC_PLAN_CHECK") != nullptr;
   Node& n = b->nodes[id];
   Step st;
   st.kind = 9;

@@ -310,7 +310,7 @@ bool resample_shape(const ChainDesc& d, int* curve_op) {
     if (o.kind != OP_WAVESHAPER || o.i0 <= 0 || o.i0 > 8192 || o.nch_in != d.in_nch) return false;
     *curve_op = 0;
   }
-  return getenv("WAA_NO_RESAMPLE_KERNEL") == nullptr;  // (switch: A/B against the interpreter)
+  return measure_switch("WAA_NO_RESAMPLE_KERNEL") == nullptr;  // (switch: A/B against the interpreter)
 }
 void launch_resample(const ChainDesc& d, int curve_op, void* stream) {
   const int nn = curve_op >= 0 ? d.ops[curve_op].i0 : 0;
@@ -319,7 +319,7 @@ void launch_resample(const ChainDesc& d, int curve_op, void* stream) {
   const uint64_t n_sub = (uint64_t)(d.tile1 - d.tile0) * (TILE / 256);
   const uint64_t waves = n_sub * ((d.n_inst + GROUP - 1) / GROUP);
   const dim3 grid((unsigned)((waves + WAVES - 1) / WAVES)), block(WAVES * 64);
-  if (getenv("WAA_RESAMPLE_RECORD_LOAD")) {  // (measurement switch: the round-2 window pipeline)
+  if (measure_switch("WAA_RESAMPLE_RECORD_LOAD")) {  // (measurement switch: the round-2 window pipeline)
     if (C == 1)
       hipLaunchKernelGGL((resample_kernel<1, true>), grid, block, lds, (hipStream_t)stream, d, curve_op);
     else
