@@ -180,6 +180,13 @@ typedef struct {
 waa_status waa_batch_create(const waa_graph_desc* graph, uint32_t n_instances, uint32_t n_channels_out,
                             uint64_t length_frames, float sample_rate, int32_t device, waa_batch** out);
 void waa_batch_destroy(waa_batch* batch);
+/* Optional: reserve ONE slab of device memory per device (device -1: the current one), once, ideally before anything else
+ * allocates on it; every batch created afterwards carves its large buffers (>= 1 MB) out of it in 2 MB-aligned pieces and
+ * falls back to hipMalloc for what does not fit.  Pieces return to the slab when the last batch holding one is destroyed.
+ * bytes = 0 releases the slab (InvalidStateError while batches still use it).  No counterpart in the reference (its buffers
+ * are Vec<f32>s): this exists because the same streaming kernel ran 15 % faster or slower depending on which hipMalloc
+ * served its output buffer. */
+waa_status waa_device_arena_reserve(int32_t device, uint64_t bytes);
 const char* waa_last_error(void);
 /* number of visible HIP devices (0 if none / runtime unavailable) */
 int32_t waa_device_count(void);

@@ -1638,6 +1638,12 @@ static void buf_release(Buf* bf) {
   memset(bf, 0, sizeof *bf);
 }
 
+/* waa_device_arena_reserve: a device-memory placement aid of the product library; nothing to do on the CPU */
+waa_status orc_device_arena_reserve(int32_t device, uint64_t bytes) {
+  (void)device;
+  (void)bytes;
+  return WAA_OK;
+}
 void orc_batch_destroy(orc_batch* b) {
   if (!b) return;
   for (uint32_t k = 0; k < b->n_inst; k++) {

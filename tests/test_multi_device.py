@@ -61,3 +61,38 @@ def test_concurrent_batches_on_one_device(hip, orc, world):
     ref = ctx.start_rendering_sync().data
     ctx.close()
     assert rms_err(got, ref).max() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_device_arena_serves_the_big_buffers_and_changes_nothing(hip, orc):
+    """waa_device_arena_reserve: batches created afterwards carve their large buffers out of one slab (2 MB-aligned pieces,
+    handed back when the last batch using the slab is destroyed); results are bit-identical to plain hipMalloc, a batch that
+    does not fit falls back to hipMalloc, releasing a slab in use is an InvalidStateError"""
+    from graphs import c2, white_noise
+    noise = white_noise(6, 2, 128 * 300)
+
+    def render():
+        ctx, _ = c2(hip, noise)
+        out = ctx.start_rendering_sync().data
+        ptr = ctx.output_device()[0]
+        return ctx, out, ptr
+
+    ctx, plain, _ = render()
+    ctx.close()
+    hip.check(hip.device_arena_reserve(0, 64 << 20))
+    try:
+        ctx, out, ptr = render()
+        assert np.array_equal(out, plain)
+        assert ptr % (2 << 20) == 0           # carved from the slab
+        ctx2, out2, ptr2 = render()           # a second batch next to the first
+        assert np.array_equal(out2, plain) and ptr2 != ptr and ptr2 % (2 << 20) == 0
+        with pytest.raises(waa.WaaError, match="InvalidStateError"):
+            hip.check(hip.device_arena_reserve(0, 0))
+        ctx.close()
+        ctx2.close()
+        hip.check(hip.device_arena_reserve(0, 1 << 20))   # too small for anything: everything falls back
+        ctx, out, _ = render()
+        assert np.array_equal(out, plain)
+        ctx.close()
+    finally:
+        hip.check(hip.device_arena_reserve(0, 0))

@@ -101,6 +101,7 @@ ABI = {
     "batch_destroy": (None, [_VP]),
     "last_error": (C.c_char_p, []),
     "device_count": (C.c_int32, []),
+    "device_arena_reserve": (C.c_int32, [C.c_int32, C.c_uint64]),
     "source_set_buffer": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FPP, C.c_uint32, C.c_uint64, C.c_float]),
     "source_set_buffer_batch": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32, C.c_uint64, C.c_float]),
     "source_set_buffer_pcm16": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_int16), C.c_uint32, C.c_uint64, C.c_float]),

@@ -2,6 +2,9 @@
 // panics become status codes with the same message text), payload uploads, render, download, analyser pulls,
 // control-side helpers, profiling.  All sample arithmetic happens in the HIP kernels; there is no CPU fallback:
 // without a HIP device every render call fails with WAA_ERR_DEVICE.
+#include <map>
+#include <mutex>
+
 #include "waa_host.hpp"
 
 namespace waa {
@@ -199,8 +202,10 @@ void waa_batch_destroy(waa_batch* b) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
       }
-    for (void* p : b->allocs) (void)hipFree(p);
-    for (void* p : b->payload_allocs) (void)hipFree(p);
+    for (void* p : b->allocs)
+      if (!arena_free(b->device, p)) (void)hipFree(p);
+    for (void* p : b->payload_allocs)
+      if (!arena_free(b->device, p)) (void)hipFree(p);
     if (b->pcm_out) (void)hipFree(b->pcm_out);
     (void)hipStreamDestroy(b->stream);
   }

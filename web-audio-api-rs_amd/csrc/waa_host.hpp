@@ -301,6 +301,14 @@ struct waa_batch {
 namespace waa {
 namespace host {
 
+// Device arena (waa_device_arena_reserve, include/waa_hip.h): one slab per device, reserved once — typically at process start,
+// before anything else fragments the device's memory — from which the big buffers of every batch are carved in 2 MB-aligned
+// pieces; the slab is one mapping with the largest page-table fragments the driver gives, so WHERE a batch's output lands no
+// longer changes from batch to batch (the same kernel ran at 1.33 or 1.55 ms depending on the
+// hipMalloc that happened to serve its output).  Defined in waa_abi.cpp.
+void* arena_alloc(int device, size_t bytes);
+bool arena_free(int device, void* p);
+
 template <typename T>
 int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
   void* p = nullptr;
@@ -315,7 +323,9 @@ int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
     return 0;
   }
   const auto t0 = std::chrono::steady_clock::now();
-  hipError_t e = hipMalloc(&p, bytes);
+  hipError_t e = hipSuccess;
+  if (bytes >= (1u << 20)) p = arena_alloc(b->device, bytes);  // (small tables stay with hipMalloc)
+  if (!p) e = hipMalloc(&p, bytes);
   b->t_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   b->n_alloc++;
   b->alloc_bytes += bytes;
