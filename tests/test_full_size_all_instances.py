@@ -198,3 +198,30 @@ def test_c4_every_instance_real_ir_and_every_analyser_pull(hip, orc):
 # follows from it: 20 log10(1 + 4e-6 * 10^(60/20)) = 0.035 dB on the bins within 60 dB of the peak.
 ANALYSER_LIN_TOL = 4e-6
 ANALYSER_DB_TOL = 0.035
+
+
+@pytest.mark.parametrize("oversample,n_inst", [("2x", 1024), ("4x", 512)])
+def test_oversampled_waveshaper_every_instance(hip, orc, oversample, n_inst):
+    """bench.py's os2 / os4 batches (BufferSource(stereo) -> WaveShaper(tanh 2049-pt, oversample) -> destination, 10 s): the
+    transform form of round 4 (waa_osfft.hip) walks every instance in runs of ~235 quanta whose overlaps are recomputed at
+    the run heads — every context and every run boundary against the oracle's stage-by-stage f32 FFT resamplers.  Sources
+    start at per-instance times (skipped quanta in front) and a third of them stop before the render ends."""
+    noise = _noise(n_inst, 2, FRAMES, 35)
+    curve = np.tanh(np.linspace(-3.0, 3.0, 2049)).astype(np.float32)
+
+    def build(be, lo, hi):
+        ctx = waa.OfflineAudioContext(2, FRAMES, 48000.0, n_instances=hi - lo, binding=be)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(noise[lo:hi], 48000.0)
+        src.connect(ctx.create_wave_shaper(curve=curve, oversample=oversample)).connect(ctx.destination())
+        for i in range(lo, hi):
+            src.start_at((i % 11) * 0.013, instance=i - lo)
+            if i % 3 == 0:
+                src.stop_at(6.0 + (i % 7) * 0.37, instance=i - lo)
+        return ctx, {}
+
+    ctx, _ = build(hip, 0, n_inst)
+    assert "256-point transforms per quantum in one launch" in ctx.plan_describe()
+    out = ctx.start_rendering_sync().data
+    ctx.close()
+    _compare_all(orc, out, build, chunk=128, max_abs=4e-6)

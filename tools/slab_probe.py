@@ -9,14 +9,16 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402  (imported first so that the library binds the HIP runtime torch ships — two runtimes in one process
+#                           see no devices; importing does not touch the device yet)
+
 import web_audio_api_rs_amd as waa  # noqa: E402
 
 arena_gb = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 hip = waa.default_binding()
 if arena_gb > 0:
-    hip.check(hip.device_arena_reserve(0, int(arena_gb * (1 << 30))))
-import torch  # noqa: E402  (after the reservation)
+    hip.check(hip.device_arena_reserve(0, int(arena_gb * (1 << 30))))  # the first device allocation of the process
 
 import bench  # noqa: E402
 
