@@ -342,3 +342,20 @@ def test_random_graphs_on_poisoned_device_memory(tmp_path):
         assert not t["errors"], (gen, t["errors"][:2])
         for m in t["mismatch"]:
             assert np.isfinite(m["max"]) and m["second_render_equals_first"], (gen, m)
+
+
+@pytest.mark.gpu
+def test_dynamic_group_that_needs_more_than_64k_of_lds(hip, orc):
+    """fuzz seed 903488 of the round-4 campaign (frozen-state generator): 13 items per quantum on 4-channel signals take
+    66.6 KB of dynamic LDS in dyn_kernel<6>, which also has 336 bytes of static LDS — raising the kernel's limit to the full
+    160 KB failed silently and the launch was refused ("invalid argument"); the limit is now raised to 160 KB minus the static
+    part"""
+    ch, descr = build_random_graph(hip, 903488, frozen=True)
+    assert "dynamic-count group: 13 item(s)" in ch.plan_describe()
+    g = ch.start_rendering_sync().data
+    ch.close()
+    co, _ = build_random_graph(orc, 903488, frozen=True)
+    o = co.start_rendering_sync().data
+    co.close()
+    scale = max(1.0, float(np.abs(o).max()))
+    assert rms_err(g, o).max() / scale <= 1e-6 and np.abs(g - o).max() / scale <= 2e-5

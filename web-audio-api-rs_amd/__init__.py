@@ -26,7 +26,10 @@ def _load(path) -> Binding:
         raise ImportError(
             f"{path} not found: the HIP extension is not built. Run __graft_entry__.build() "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    return bind(ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL), "waa_")
+    # RTLD_GLOBAL: the HIP runtime this library brings in must be the ONE runtime of the process — torch, imported later,
+    # otherwise initialises a second copy that sees no devices (measured: "no ROCm-capable device is detected").  The two
+    # builds of the library export the same symbols; they are linked -Bsymbolic, so each calls into itself.
+    return bind(ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL), "waa_")
 
 
 def default_binding() -> Binding:

@@ -817,7 +817,12 @@ static int run_steps(waa_batch* b) {
       HIP_TRY(hipEventRecord(e0, b->stream));
     }
     launch();
-    HIP_TRY(hipGetLastError());
+    {
+      const hipError_t le = hipGetLastError();
+      if (le != hipSuccess)
+        return fail(WAA_ERR_DEVICE, "launch of %s failed: %s", slot >= 0 ? b->prof[slot].name.c_str() : "a kernel without a profile slot",
+                    hipGetErrorString(le));
+    }
     if (b->profiling && slot >= 0) {
       HIP_TRY(hipEventRecord(e1, b->stream));
       b->prof[slot].pending.push_back({e0, e1});
