@@ -112,6 +112,49 @@ F3_FN c2v cmulc(c2v a, c2v w) {
   return c2v{__builtin_fmaf(a.x, w.x, a.y * w.y), __builtin_fmaf(a.x, -w.y, a.y * w.x)};
 #endif
 }
+// Four independent complex multiplies in one block, the four products first and the four fused steps after them: a packed-f32
+// result cannot be forwarded to the very next instruction (the compiler puts an s_nop between a dependent pair — 250 of them
+// per quantum with one multiply at a time), so dependent halves are kept four instructions apart.  Same operations as
+// cmul / cmulc, element by element.
+template <bool CONJ>
+F3_FN void cmul4(c2v& r0, c2v& r1, c2v& r2, c2v& r3, c2v a0, c2v a1, c2v a2, c2v a3, c2v w0, c2v w1, c2v w2, c2v w3) {
+#if F3_DEV
+  c2v t0, t1, t2, t3;
+  if (!CONJ)
+    asm("v_pk_mul_f32 %0, %4, %8 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %5, %9 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %2, %6, %10 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %3, %7, %11 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+        "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+        "v_pk_fma_f32 %2, %6, %10, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
+        "v_pk_fma_f32 %3, %7, %11, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+  else
+    asm("v_pk_mul_f32 %0, %4, %8 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %5, %9 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %2, %6, %10 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %3, %7, %11 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %2, %6, %10, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %3, %7, %11, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+  r0 = t0;
+  r1 = t1;
+  r2 = t2;
+  r3 = t3;
+#else
+  const c2v t0 = CONJ ? cmulc(a0, w0) : cmul(a0, w0), t1 = CONJ ? cmulc(a1, w1) : cmul(a1, w1);
+  const c2v t2 = CONJ ? cmulc(a2, w2) : cmul(a2, w2), t3 = CONJ ? cmulc(a3, w3) : cmul(a3, w3);
+  r0 = t0;
+  r1 = t1;
+  r2 = t2;
+  r3 = t3;
+#endif
+}
 // the same with a compile-time twiddle: a scalar register pair, no vector registers and no moves
 template <bool CONJ>
 F3_FN c2v cmul_k(c2v a, const c2v w) {
@@ -266,8 +309,12 @@ F3_FN void load_tw3(const c2v* tw, int t, c2v (&tw3)[16]) {
 // previous block's pass 3 reads)
 F3_FN void fwd_pass1_compute(c2v (&x)[32], const c2v (&tws)[32]) {
   dft32<false>(x);
+  // (four at a time: no hazard nop between a product and its fused step; slot 0's twiddle is 1)
+  x[1] = cmul(x[1], tws[1]);
+  x[2] = cmul(x[2], tws[2]);
+  x[3] = cmul(x[3], tws[3]);
 #pragma unroll
-  for (int s = 1; s < 32; s++) x[s] = cmul(x[s], tws[s]);
+  for (int s = 4; s < 32; s += 4) cmul4<false>(x[s], x[s + 1], x[s + 2], x[s + 3], x[s], x[s + 1], x[s + 2], x[s + 3], tws[s], tws[s + 1], tws[s + 2], tws[s + 3]);
 }
 // The same with HALF the twiddle registers (the filter-stage kernel is short of them): W_N^(t k1) for k1 < 16 and
 // W_N^(16 t); the upper half is their product (one more complex multiply per element, ~1 ulp on those twiddles).
@@ -317,16 +364,24 @@ F3_FN void fwd_pass3(c2v (&y)[16], const c2v (&tw3)[16], cldsp lds, int r) {
     y[2 * j] = c2v{v.x, v.y};
     y[2 * j + 1] = c2v{v.z, v.w};
   }
+  y[1] = cmul(y[1], tw3[1]);
+  y[2] = cmul(y[2], tw3[2]);
+  y[3] = cmul(y[3], tw3[3]);
 #pragma unroll
-  for (int m2 = 1; m2 < 16; m2++) y[m2] = cmul(y[m2], tw3[m2]);
+  for (int m2 = 4; m2 < 16; m2 += 4)
+    cmul4<false>(y[m2], y[m2 + 1], y[m2 + 2], y[m2 + 3], y[m2], y[m2 + 1], y[m2 + 2], y[m2 + 3], tw3[m2], tw3[m2 + 1], tw3[m2 + 2], tw3[m2 + 3]);
   dft16<false>(y);
 }
 
 // inverse pass 1 for row r: y[k3] = Y[k3 * 1024 + r] -> E2[r][m2]
 F3_FN void inv_pass1_compute(c2v (&y)[16], const c2v (&tw3)[16]) {
   dft16<true>(y);
+  y[1] = cmulc(y[1], tw3[K16(1)]);
+  y[2] = cmulc(y[2], tw3[K16(2)]);
+  y[3] = cmulc(y[3], tw3[K16(3)]);
 #pragma unroll
-  for (int s = 1; s < 16; s++) y[s] = cmulc(y[s], tw3[K16(s)]);
+  for (int s = 4; s < 16; s += 4)
+    cmul4<true>(y[s], y[s + 1], y[s + 2], y[s + 3], y[s], y[s + 1], y[s + 2], y[s + 3], tw3[K16(s)], tw3[K16(s + 1)], tw3[K16(s + 2)], tw3[K16(s + 3)]);
 }
 F3_FN void inv_pass1_write(const c2v (&y)[16], ldsp lds, int r) {
   F3_LDS f4v_* row = (F3_LDS f4v_*)(lds + e2(r, 0));
@@ -352,8 +407,12 @@ F3_FN void inv_pass2_write(const c2v (&x)[32], ldsp lds, int t) {
 F3_FN void inv_pass3(c2v (&x)[32], const c2v (&twn)[32], cldsp lds, int t) {
 #pragma unroll
   for (int k1 = 0; k1 < 32; k1++) x[k1] = lds_rd(lds + e1(k1, 0) + t);
+  x[1] = cmulc(x[1], twn[1]);
+  x[2] = cmulc(x[2], twn[2]);
+  x[3] = cmulc(x[3], twn[3]);
 #pragma unroll
-  for (int k1 = 1; k1 < 32; k1++) x[k1] = cmulc(x[k1], twn[k1]);
+  for (int k1 = 4; k1 < 32; k1 += 4)
+    cmul4<true>(x[k1], x[k1 + 1], x[k1 + 2], x[k1 + 3], x[k1], x[k1 + 1], x[k1 + 2], x[k1 + 3], twn[k1], twn[k1 + 1], twn[k1 + 2], twn[k1 + 3]);
   dft32<true, true>(x);
 }
 

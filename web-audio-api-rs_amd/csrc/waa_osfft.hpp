@@ -71,49 +71,8 @@ F3_FN c2v cmac(c2v acc, c2v a, c2v w) {
 #endif
 }
 
-// Four independent complex multiplies in one block, the four products first and the four fused steps after them: a packed-f32
-// result cannot be forwarded to the very next instruction (the compiler puts an s_nop between a dependent pair — 250 of them
-// per quantum with one multiply at a time), so dependent halves are kept four instructions apart.  Same operations as
-// fft3::cmul / cmulc, element by element.
-template <bool CONJ>
-F3_FN void cmul4(c2v& r0, c2v& r1, c2v& r2, c2v& r3, c2v a0, c2v a1, c2v a2, c2v a3, c2v w0, c2v w1, c2v w2, c2v w3) {
-#if F3_DEV
-  c2v t0, t1, t2, t3;
-  if (!CONJ)
-    asm("v_pk_mul_f32 %0, %4, %8 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-        "v_pk_mul_f32 %1, %5, %9 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-        "v_pk_mul_f32 %2, %6, %10 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-        "v_pk_mul_f32 %3, %7, %11 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-        "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
-        "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
-        "v_pk_fma_f32 %2, %6, %10, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]\n\t"
-        "v_pk_fma_f32 %3, %7, %11, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
-        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
-  else
-    asm("v_pk_mul_f32 %0, %4, %8 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-        "v_pk_mul_f32 %1, %5, %9 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-        "v_pk_mul_f32 %2, %6, %10 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-        "v_pk_mul_f32 %3, %7, %11 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-        "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
-        "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
-        "v_pk_fma_f32 %2, %6, %10, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
-        "v_pk_fma_f32 %3, %7, %11, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
-        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
-  r0 = t0;
-  r1 = t1;
-  r2 = t2;
-  r3 = t3;
-#else
-  const c2v t0 = CONJ ? fft3::cmulc(a0, w0) : fft3::cmul(a0, w0), t1 = CONJ ? fft3::cmulc(a1, w1) : fft3::cmul(a1, w1);
-  const c2v t2 = CONJ ? fft3::cmulc(a2, w2) : fft3::cmul(a2, w2), t3 = CONJ ? fft3::cmulc(a3, w3) : fft3::cmul(a3, w3);
-  r0 = t0;
-  r1 = t1;
-  r2 = t2;
-  r3 = t3;
-#endif
-}
+// (cmul4: four independent complex multiplies per asm block, fft3::cmul4 in waa_fft3.hpp)
+using fft3::cmul4;
 // four accumulating ones (cmac), the two fused steps of an element four instructions apart
 F3_FN void cmac4(c2v& z0, c2v& z1, c2v& z2, c2v& z3, c2v a0, c2v a1, c2v a2, c2v a3, c2v w0, c2v w1, c2v w2, c2v w3) {
 #if F3_DEV
