@@ -265,6 +265,58 @@ def pmc_record(name, n_inst, frames, launches_per_step=None):
     return rec, None
 
 
+def live_pmc(name, n_inst, seconds, timeout_s=240):
+    """HBM traffic of one workload measured IN THIS RUN: two child runs of this script under `rocprofv3 --kernel-trace --pmc
+    FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes for the TCC counters; FETCH_SIZE x 2 on
+    gfx950, both in KiB), steps 3 / warm-up 1 — the command tools/pmc_pass.sh runs by hand.  Returns {"bytes_per_step", "kernels":
+    {name: {"launches_per_step", "bytes_per_launch"}}} or raises.  The profiled children render the same batch the headline does; their
+    timings are not used."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        raise RuntimeError("no rocprofv3 on this box")
+    renders = 5.0  # (planning render + 1 warm-up + 3 timed: every per-step kernel is launched five times)
+    per = {}
+    for counter, factor in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
+        out = tempfile.mkdtemp(prefix="waa_pmc_", dir="/tmp")
+        try:
+            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "run", "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", name, "--instances", str(n_inst), "--seconds", str(seconds), "--steps", "3", "--warmup", "1",
+                   "--sustain", "0", "--no-cpu-baseline", "--no-extra", "--no-live-pmc"]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", WORLD_SIZE="1", RANK="0", LOCAL_RANK=os.environ.get("LOCAL_RANK", "0")),
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            dbs = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
+            if not dbs:
+                raise RuntimeError(f"rocprofv3 wrote no results database for {counter}")
+            cur = sqlite3.connect(dbs[0]).cursor()
+            cols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
+            ki, ci, vi = cols.index("kernel_name"), cols.index("counter_name"), cols.index("value")
+            for r in cur.execute("select * from counters_collection"):
+                if r[ci] != counter or "waa::" not in r[ki]:
+                    continue
+                k = per.setdefault(r[ki], {"n": {}, "sum": {}})
+                k["n"][counter] = k["n"].get(counter, 0) + 1
+                k["sum"][counter] = k["sum"].get(counter, 0.0) + float(r[vi]) * factor
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    kernels, total = {}, 0.0
+    for k, v in per.items():
+        n = max(v["n"].values())
+        per_step = round(n / renders)
+        if per_step < 1:
+            continue  # one-off kernels (impulse-response spectra, digests)
+        bpl = sum(v["sum"].get(c, 0.0) / max(v["n"].get(c, 1), 1) for c in ("FETCH_SIZE", "WRITE_SIZE"))
+        kernels[k] = {"launches_per_step": per_step, "bytes_per_launch": bpl}
+        total += bpl * per_step
+    if not kernels:
+        raise RuntimeError("no product kernel in the counter tables")
+    return {"bytes_per_step": total, "kernels": kernels}
+
+
 DEFAULT_INSTANCES = {"c2": 1024, "c2k": 1024, "c1a": 1024, "t1": 1024, "c3": 512, "c4": 512, "c5": 2048}
 F64_WORKLOADS = ("c2", "c2k", "c1a", "t1", "c4", "fbq", "osc")
 
@@ -503,6 +555,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--sustain", type=float, default=0.6,
                     help="seconds of back-to-back steps timed AFTER the K-step protocol for the `sustained` record (0 = off)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure the headline's HBM traffic in this run (two rocprofv3 --pmc child runs, ~30 s): replay the stamped record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="only the headline workload: no T1 / C3 / C4 / ... records, no e2e record")
     ap.add_argument("--detail", default=None, help="file for the full per-workload records (default: gpurun_out/bench_detail.json)")
@@ -589,6 +643,20 @@ def main():
         if share:
             out["rehearsal"] = f"{world} ranks SHARE one GPU (gloo): contexts per rank = the per-GPU count / {world}; format check only"
         out["roofline"]["kernel_ms"] = round(roof["kernel_ms_per_step"], 4)
+        # the headline's traffic measured by THIS run where rocprofv3 exists (the stamped record of profiles/pmc_traffic.json is what
+        # remains otherwise, and what the other workloads use)
+        if default_run and world == 1 and not args.no_live_pmc:
+            try:
+                lp = live_pmc(name, n_inst, args.seconds)
+                out["roofline"]["traffic"] = lp["bytes_per_step"]
+                out["roofline"]["traffic_source"] = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE (x2) / WRITE_SIZE, two child runs"
+                out["roofline"]["traffic_over_algorithmic"] = round(lp["bytes_per_step"] / (ALG_BYTES[name] * n_inst * rec["config"]["quanta_per_context"]), 4)
+                out["roofline"].pop("traffic_note", None)
+                roof["live_pmc"] = lp
+            except Exception as e:  # never fail the line on the profiler
+                out["roofline"]["traffic_source"] = "stamped record (live measurement failed: %s)" % repr(e)[:80]
+        elif "traffic" in out["roofline"] and out["roofline"]["traffic"]:
+            out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (stamped with the source hashes it was measured on)"
         if "sustained" in rec:  # the same protocol over >= --sustain seconds of back-to-back steps (never `value`)
             out["sustained"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rec["sustained"].items()}
         for k in ("algorithmic_bytes_per_launch", "compulsory_frac", "traffic_note", "achieved_basis"):
