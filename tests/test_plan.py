@@ -126,8 +126,12 @@ def test_automated_biquads(hip):
     assert "biquad_stream(k-rate) in=source:2ch gains=1 out=final" in plan(ctx)  # per-quantum coefficients: streaming too
     ctx, nodes = c2(hip, noise, device=waa.PLAN_ONLY)
     nodes["biquad"].frequency.set_value_at_time(10.0, 0.0).exponential_ramp_to_value_at_time(10000.0, 0.05)
-    # per-frame coefficients (a-rate automation, the same for every instance): one shared lane-major table + streaming
-    assert "biquad_stream(a-rate, shared table) in=source:2ch gains=1 out=final" in plan(ctx)
+    # per-frame coefficients (a-rate automation, the same for every instance): one shared table, a lane per stream, tiles in
+    # parallel (waa_biquad_lanes.hip) — what the device runs; a plan-only context describes the same launch list since round 4
+    # (it used to fall back to the round-2 streaming form there: ADVICE round 3)
+    p = plan(ctx)
+    assert "biquad_lanes(a-rate, shared table: one lane per stream, tiles in parallel) in=source:2ch gains=1 out=final" in p
+    assert "biquad_stream(a-rate" not in p
 
 
 def test_fan_in_above_four_inputs_is_reduced_in_order(hip):

@@ -522,7 +522,7 @@ int emit_segments(waa_batch* b, std::vector<InputRef> inputs, int in_nch, int in
       if (i == ops.size() && seg_out.base == out.base) return 0;
       continue;
     }
-    if (o.kind == OP_BIQUAD && o.i0 == 2 && !dup && !b->dry && b->steps[(size_t)o.i1].coef.rows == 1 && !measure_switch("WAA_ARATE_STREAM") &&
+    if (o.kind == OP_BIQUAD && o.i0 == 2 && !dup && b->steps[(size_t)o.i1].coef.rows == 1 && !measure_switch("WAA_ARATE_STREAM") &&
         (inputs[0].kind == IN_SIGNAL || inputs[0].kind == IN_SOURCE) &&
         (uint64_t)b->n_inst * seg_out.inst_stride < (1ull << 32)) {  // (its output rows are 32-bit element offsets)
       // per-frame coefficients, ONE table for all instances: a lane per stream, tiles in parallel (waa_biquad_lanes.hip)
