@@ -1307,7 +1307,7 @@ static void param_advance(Param* p, uint32_t inst, uint64_t q) {
   double block_time = (double)(q * RQ) / p->sample_rate;
   p->tl_vlen[inst] = (int)orc_timeline_compute(p->tl[inst], block_time, 1. / p->sample_rate, RQ, p->tl_vals + (size_t)inst * RQ);
 }
-static const float* param_get(const Param* p, uint32_t inst, uint64_t q, int* len, float* tmp) {
+static inline const float* param_get(const Param* p, uint32_t inst, uint64_t q, int* len, float* tmp) {
   return param_get_in(p, NULL, inst, q, len, tmp);
 }
 
@@ -1614,7 +1614,10 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
     uint32_t kind = dn->desc.kind;
     if (!(kind == WAA_NODE_GAIN || kind == WAA_NODE_BIQUAD || kind == WAA_NODE_DELAY || kind == WAA_NODE_STEREO_PANNER ||
           kind == WAA_NODE_CONSTANT_SOURCE || kind == WAA_NODE_OSCILLATOR ||
-          (kind == WAA_NODE_BUFFER_SOURCE && (pid == WAA_PARAM_SOURCE_PLAYBACK_RATE || pid == WAA_PARAM_SOURCE_DETUNE))))
+          (kind == WAA_NODE_BUFFER_SOURCE && (pid == WAA_PARAM_SOURCE_PLAYBACK_RATE || pid == WAA_PARAM_SOURCE_DETUNE)) ||
+          /* PannerNode position / orientation (panner.rs:430-449: a-rate AudioParams of the node; the AudioListener's nine
+           * params belong to the listener node and stay host values here) */
+          (kind == WAA_NODE_PANNER && pid <= WAA_PARAM_PANNER_ORIENTATION_Z)))
       return fail(WAA_ERR_OUT_OF_SCOPE, "audio-rate modulation of a host-evaluated param (node %u) is out of scope", to);
     for (uint32_t k = 0; k < n_inst; k++)
       if (!b->st[k][to].pin[pid]) {
@@ -3381,7 +3384,8 @@ static void process_panner(NodeCfg* n, NodeState* s, uint32_t inst, const Scope*
   float tmp[15][RQ];
   const float* pv[15];
   int len[15];
-  for (int p = 0; p < 15; p++) pv[p] = param_get(&n->params[p], inst, sc->quantum, &len[p], tmp[p]);
+  for (int p = 0; p < 15; p++) /* the six params of the node itself may carry an input from the graph (param.rs:739-795) */
+    pv[p] = param_get_in(&n->params[p], p < 6 ? s->pin[p] : NULL, inst, sc->quantum, &len[p], tmp[p]);
   int single_valued = 1;
   for (int p = 6; p < 15; p++)
     if (len[p] != 1) single_valued = 0;

@@ -65,21 +65,24 @@ def test_two_modulators_sum(be):
     assert np.allclose(out, 0.75, atol=0)
 
 
-def test_modulating_a_host_evaluated_param_is_out_of_scope(be):
-    """panner geometry is evaluated by the host per quantum: a graph input on it is refused (status 4); the source's
-    playbackRate / detune are host-evaluated too, but resolved at plan time (tests below)"""
-    c = ctx(be, 2, RQ)
-    src = c.create_buffer_source()
-    src.set_buffer(waa.AudioBuffer(np.ones((1, RQ), np.float32), 48000.0))
-    pan = c.create_panner()
-    lfo = c.create_constant_source(offset=0.1)
-    lfo.connect(pan.position_x)
-    src.connect(pan).connect(c.destination())
-    src.start()
-    lfo.start()
-    with pytest.raises(waa.WaaError) as ei:
-        c.start_rendering_sync()
-    assert ei.value.status == 4
+def test_a_constant_on_a_panner_position_equals_the_moved_position(be):
+    """a graph input on a PannerNode param is ADDED to its value (param.rs:739-795) — rendered since round 4 (the node's own six
+    params with a single-valued listener; the oracle everywhere): a ConstantSource of 2 on positionX of a panner at x = 1 is the
+    panner at x = 3"""
+    outs = []
+    for moved in (False, True):
+        c = ctx(be, 2, RQ * 6)
+        src = c.create_buffer_source()
+        src.set_buffer(waa.AudioBuffer(np.linspace(-1, 1, RQ * 6, dtype=np.float32)[None, :], 48000.0))
+        pan = c.create_panner(position=(3.0 if moved else 1.0, 0.0, -1.0))
+        if not moved:
+            k = c.create_constant_source(offset=2.0)
+            k.connect(pan.position_x)
+            k.start()
+        src.connect(pan).connect(c.destination())
+        src.start()
+        outs.append(c.start_rendering_sync().data)
+    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 0.1
 
 
 def test_plan_param_chain_precedes_consumer(hip):
@@ -267,3 +270,70 @@ def test_modulated_rate_source_next_to_a_plain_one(hip, orc):
         outs.append(c.start_rendering_sync().data)
         c.close()
     assert rms_err(outs[0], outs[1]).max() <= 1e-6
+
+
+# ---- PannerNode position / orientation driven by the graph (round 4) -------------------------------------------------
+def _orbiting_panner(binding, noise, lfo_hz, model, device=-1, a_rate_listener=False):
+    """a source that circles the listener: two LFOs (sine / cosine-ish: a triangle a quarter period late) -> Gain(radius) ->
+    panner.positionX / positionZ, a third one wobbles orientationX; per-instance LFO rates"""
+    n, n_ch, frames = noise.shape
+    c = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n, binding=binding, device=device)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    pan = c.create_panner(panning_model=model, distance_model="inverse", position=(0.0, 0.5, -1.0), ref_distance=1.0,
+                          cone_inner_angle=60.0, cone_outer_angle=200.0, cone_outer_gain=0.3)
+    lx = c.create_oscillator(type_="sine", frequency=lfo_hz)
+    lz = c.create_oscillator(type_="triangle", frequency=lfo_hz)
+    lo = c.create_oscillator(type_="sine", frequency=lfo_hz * 2.3)
+    for i in range(n):
+        lx.frequency.set_value(lfo_hz * (1.0 + 0.4 * i), instance=i)
+        lz.frequency.set_value(lfo_hz * (1.0 + 0.4 * i), instance=i)
+    lx.connect(c.create_gain(gain=3.0)).connect(pan.position_x)
+    lz.connect(c.create_gain(gain=2.0)).connect(pan.position_z)
+    lo.connect(c.create_gain(gain=0.8)).connect(pan.orientation_x)
+    pan.position_y.set_value_at_time(0.5, 0.0).linear_ramp_to_value_at_time(2.0, frames / 48000.0)  # automation next to it
+    if a_rate_listener:
+        c.listener().position_x.set_value_at_time(0.0, 0.0).linear_ramp_to_value_at_time(1.0, frames / 48000.0)
+    src.connect(pan).connect(c.destination())
+    lx.start()
+    lz.start_at(0.013)   # (starts mid-quantum: its first value is seen at the NEXT quantum boundary)
+    lo.start()
+    src.start()
+    return c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,n_ch", [("equalpower", 1), ("equalpower", 2), ("HRTF", 1)])
+def test_parity_panner_position_modulated_from_the_graph(hip, orc, model, n_ch):
+    """panner.rs:833-846 (HRTF: :781-829): with a single-valued AudioListener the node uses the FIRST value of every param per
+    render quantum — graph input included (param.rs:739-795).  The modulating subgraph is rendered at plan time, one value per
+    quantum read back (the mechanism of the graph-modulated playbackRate), then the ordinary plan."""
+    noise = white_noise(3, n_ch, RQ * 150, seed0=91)
+    outs = []
+    for be in (hip, orc):
+        c = _orbiting_panner(be, noise, 3.0, model)
+        if be is hip:
+            assert "modulated from the graph" in c.plan_describe() and "panner" in c.plan_describe()
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    g, o = outs
+    assert np.abs(o).max() > 0.05
+    assert rms_err(g, o).max() <= 1e-6 and np.abs(g - o).max() <= 2e-5
+
+
+def test_modulated_panner_geometry_needs_the_device_and_a_single_valued_listener(hip):
+    noise = white_noise(2, 1, RQ * 8)
+    c = _orbiting_panner(hip, noise, 3.0, "equalpower", device=waa.PLAN_ONLY)
+    with pytest.raises(waa.WaaError) as ei:
+        c.plan_describe()
+    assert ei.value.status == 4 and "resolved at plan time" in str(ei.value)
+    c.close()
+
+
+@pytest.mark.gpu
+def test_modulated_panner_geometry_next_to_an_audio_rate_listener_is_refused(hip):
+    c = _orbiting_panner(hip, white_noise(2, 1, RQ * 8), 3.0, "equalpower", a_rate_listener=True)
+    with pytest.raises(waa.WaaError) as ei:
+        c.start_rendering_sync()
+    assert ei.value.status == 4 and "single-valued AudioListener" in str(ei.value)
+    c.close()

@@ -668,8 +668,19 @@ static int resolve_source_rate_modulation(waa_batch* b) {
   for (auto& ed : b->edges) {
     if (!(ed.to_input & 0x80000000u) || ed.to >= b->nodes.size()) continue;
     const uint32_t pid = ed.to_input & 0x7fffffffu;
-    if (b->nodes[ed.to].desc.kind != WAA_NODE_BUFFER_SOURCE) continue;
-    if (pid != WAA_PARAM_SOURCE_PLAYBACK_RATE && pid != WAA_PARAM_SOURCE_DETUNE) continue;
+    const Node& tn = b->nodes[ed.to];
+    if (tn.desc.kind == WAA_NODE_BUFFER_SOURCE) {
+      if (pid != WAA_PARAM_SOURCE_PLAYBACK_RATE && pid != WAA_PARAM_SOURCE_DETUNE) continue;
+    } else if (tn.desc.kind == WAA_NODE_PANNER && pid <= WAA_PARAM_PANNER_ORIENTATION_Z && tn.params.size() >= 15) {
+      // PannerNode position / orientation: with a single-valued AudioListener the reference uses the first value of every
+      // param per quantum (panner.rs:833-846, HRTF :781-829): k-rate in effect, resolved like the source rates.  With
+      // audio-rate listener automation the params are consumed per frame: left to build_plan, which refuses the edge.
+      bool listener_a_rate = false;
+      for (int k = 6; k < 15; k++) listener_a_rate |= tn.params[(size_t)k].mode() == 2 || !tn.params[(size_t)k].timelines.empty();
+      if (listener_a_rate) continue;
+    } else {
+      continue;
+    }
     const std::pair<uint32_t, uint32_t> key(ed.to, pid);
     if (std::find(mods.begin(), mods.end(), key) == mods.end()) mods.push_back(key);
   }
@@ -739,7 +750,7 @@ static int resolve_source_rate_modulation(waa_batch* b) {
                  b->edges.end());
   char note[256];
   snprintf(note, sizeof note,
-           "playbackRate / detune modulated from the graph on %zu source param(s): the modulating subgraph was rendered at plan time "
+           "%zu host-evaluated k-rate param(s) (source playbackRate / detune, panner position / orientation) modulated from the graph: the modulating subgraph was rendered at plan time "
            "(%zu launch step(s)), one value per render quantum read back (k-rate, param.rs:739-760)",
            mods.size(), n_steps);
   b->prepass_note = note;

@@ -909,8 +909,16 @@ int build_plan(waa_batch* b) {
         return fail(WAA_ERR_OUT_OF_SCOPE,
                     "playbackRate / detune of source node %u are modulated from the graph: the modulator is rendered at plan time, "
                     "which needs the device (plan-only batch)", ed.to);
+      // PannerNode position / orientation with a single-valued AudioListener: the reference takes the FIRST value of every
+      // param per quantum (panner.rs:833-846; HRTF: :781-829) — the same plan-time resolution (round 4).  Edges that are still
+      // here outside the prepass were not resolved: an audio-rate listener next to them, or a plan-only batch.
+      const bool panner_geom = k == WAA_NODE_PANNER && pid <= WAA_PARAM_PANNER_ORIENTATION_Z;
+      if (panner_geom && !b->prepass)
+        return fail(WAA_ERR_OUT_OF_SCOPE,
+                    "position / orientation of panner node %u are modulated from the graph: resolved at plan time on the device for a "
+                    "single-valued AudioListener only (audio-rate listener automation next to it, or a plan-only batch)", ed.to);
       if (!(k == WAA_NODE_GAIN || k == WAA_NODE_BIQUAD || k == WAA_NODE_DELAY || k == WAA_NODE_STEREO_PANNER ||
-            k == WAA_NODE_CONSTANT_SOURCE || k == WAA_NODE_OSCILLATOR || source_rate))
+            k == WAA_NODE_CONSTANT_SOURCE || k == WAA_NODE_OSCILLATOR || source_rate || panner_geom))
         return fail(WAA_ERR_OUT_OF_SCOPE, "audio-rate modulation of a host-evaluated param (node %u) is out of scope", ed.to);
       to.pin_edges[pid].push_back((int)e);
     } else {
@@ -930,7 +938,11 @@ int build_plan(waa_batch* b) {
       if (!b->prepass && (b->nodes[i].desc.kind == WAA_NODE_DESTINATION || b->nodes[i].desc.kind == WAA_NODE_ANALYSER)) stack.push_back(i);
     // (prepass: only what feeds the graph-modulated playbackRate / detune params)
     if (b->prepass)
-      for (auto& pp : b->prepass_params) stack.push_back(pp.first);
+      for (auto& pp : b->prepass_params) {
+        // only what feeds the modulated PARAM: a PannerNode's audio input is not part of the prepass
+        b->nodes[pp.first].live = true;
+        for (int e : b->nodes[pp.first].pin_edges[pp.second]) stack.push_back(b->edges[e].from);
+      }
     while (!stack.empty()) {
       uint32_t id = stack.back();
       stack.pop_back();
