@@ -274,3 +274,73 @@ def test_analyser_behind_a_layout_above_stereo_follows_the_count_of_every_quantu
     assert rms_err(g, o).max() <= 1e-6 and np.abs(gt - ot).max() <= 1e-6 and np.abs(ot).max() > 0.05
     fin = np.isfinite(of)
     assert np.abs(gf[fin] - of[fin]).max() <= 0.05
+
+
+def _mixed_buffers(c, seed=70, rate=SR):
+    """instance 0 plays a mono AudioBuffer, instance 1 a stereo one, instance 2 a 4-channel one (trimmed by the consumers)"""
+    s = c.create_buffer_source()
+    for i, nch in enumerate((1, 2, 4)):
+        s.set_buffer(waa.AudioBuffer(white_noise(1, nch, FRAMES // 2 + 17 * i, seed0=seed + i)[0] * 0.5, rate), instance=i)
+    s.start_at(130.0 / SR)
+    return s
+
+
+@pytest.mark.parametrize("consumer", ["stereo_panner", "biquad", "panner", "plain", "delay"])
+def test_instances_play_buffers_of_different_channel_counts(hip, orc, consumer):
+    """audio_buffer_source.rs:560-600: the output quantum has the channel count of the instance's OWN buffer; the static plan has
+    one count per signal for the whole batch, so the planner answers with the dynamic-count plan whose codes are per instance
+    (the mono instance takes the StereoPanner's / PannerNode's mono law and the mono->stereo up-mix at the destination)."""
+    def build(be):
+        c = _ctx(be)
+        s = _mixed_buffers(c)
+        if consumer == "stereo_panner":
+            n = c.create_stereo_panner()
+            n.pan.set_value(0.4)
+        elif consumer == "biquad":
+            n = c.create_biquad_filter()
+        elif consumer == "panner":
+            n = c.create_panner()
+            n.position_x.set_value(1.5)
+            n.position_z.set_value(-0.5)
+        elif consumer == "delay":
+            n = c.create_delay(0.1)
+            n.delay_time.set_value(0.013)
+        else:
+            n = c.create_gain()
+        s.connect(n)
+        n.connect(c.destination())
+        return c
+    g, o = _render(build, hip, orc)
+    assert np.abs(o[0, 0]).max() > 0.05 and np.abs(o[1, 1]).max() > 0.05
+    if consumer == "plain":  # mono -> stereo copies (speakers), stereo stays
+        assert np.array_equal(g[0, 0], g[0, 1]) and not np.array_equal(g[1, 0], g[1, 1])
+
+
+def test_mixed_buffer_counts_with_a_resampled_buffer(hip, orc):
+    """the same through the resampling source path (buffer rate != context rate)"""
+    def build(be):
+        c = _ctx(be)
+        s = _mixed_buffers(c, seed=80, rate=44100.0)
+        g = c.create_gain()
+        g.gain.set_value(0.7)
+        s.connect(g)
+        g.connect(c.destination())
+        return c
+    _render(build, hip, orc)
+
+
+@pytest.mark.measure
+def test_mixed_buffer_counts_can_be_pinned_to_the_static_plan(hip):
+    """WAA_STATIC_CHANNEL_COUNTS (measurement switch): the static plan has one channel count per signal -> status 4"""
+    import os
+    os.environ["WAA_STATIC_CHANNEL_COUNTS"] = "1"
+    try:
+        c = _ctx(hip)
+        s = _mixed_buffers(c)
+        s.connect(c.destination())
+        with pytest.raises(waa.WaaError) as ei:
+            c.start_rendering_sync()
+        assert ei.value.status == 4 and "same channel count" in str(ei.value)
+        c.close()
+    finally:
+        del os.environ["WAA_STATIC_CHANNEL_COUNTS"]

@@ -222,6 +222,23 @@ def test_note_mono_first_then_stereo_into_a_filter():
     c.close()
 
 
+def test_buffers_of_different_channel_counts_across_instances_plan_dynamically():
+    """audio_buffer_source.rs:560-600: each instance's source has its own buffer's channel count -> per-instance codes"""
+    c = _plan_only()
+    s = c.create_buffer_source()
+    s.set_buffer(waa.AudioBuffer(np.zeros((1, RQ * 40), np.float32), 48000.0), instance=0)
+    s.set_buffer(waa.AudioBuffer(np.zeros((2, RQ * 30), np.float32), 48000.0), instance=1)
+    s.start_at(0.0)
+    p = c.create_stereo_panner()
+    s.connect(p)
+    p.connect(c.destination())
+    plan = c.plan_describe()
+    assert "AudioBuffers of different channel counts -> per-instance counts through dyn_kernel" in plan, plan
+    assert "dynamic-count group: 2 item(s) per quantum" in plan
+    assert c.plan_describe() == plan  # (planning again finds the widened copies in place)
+    c.close()
+
+
 @pytest.mark.measure
 def test_static_plan_switch_keeps_the_round1_note(monkeypatch):
     """WAA_STATIC_CHANNEL_COUNTS=1 (A/B aid): the static plan of round 1 with its 'dynamic channel count' note"""

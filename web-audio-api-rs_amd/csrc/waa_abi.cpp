@@ -748,7 +748,7 @@ static int resolve_source_rate_modulation(waa_batch* b) {
                                   return std::find(mods.begin(), mods.end(), key) != mods.end();
                                 }),
                  b->edges.end());
-  char note[256];
+  char note[512];
   snprintf(note, sizeof note,
            "%zu host-evaluated k-rate param(s) (source playbackRate / detune, panner position / orientation) modulated from the graph: the modulating subgraph was rendered at plan time "
            "(%zu launch step(s)), one value per render quantum read back (k-rate, param.rs:739-760)",

@@ -116,8 +116,10 @@ struct DeviceBuffer {  // an AudioBuffer resident in HBM
   uint64_t ch_stride = 0;
   uint64_t frames = 0;
   uint32_t nch = 0;
+  uint32_t nch_true = 0;  // != 0: the AudioBuffer's own channel count; `nch` is the widened copy's (widen_narrow_buffers)
   float sr = 0;
   bool valid = false;
+  uint32_t count() const { return nch_true ? nch_true : nch; }
 };
 
 struct SourceSched {  // per instance scheduling parameters

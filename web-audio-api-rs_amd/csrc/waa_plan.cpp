@@ -755,14 +755,15 @@ int source_code_rows(waa_batch* b, uint32_t id, uint64_t cs, std::vector<uint8_t
       std::vector<float> det_q = param_per_quantum(b, p_det, i, nullptr);
       const SchedKey key(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end,
                          bf.valid ? bf.frames : 0, bf.valid ? bf.sr : 0.f, rate_q[0], det_q[0]);
-      auto itc = automated ? cache.end() : cache.find(key);
+      // (rows differ by the buffer's own channel count too: one cache per count would do; mixed counts are rare -> no cache)
+      auto itc = automated || bf.nch_true ? cache.end() : cache.find(key);
       if (itc == cache.end()) {
         SchedOut so;
         schedule_source(b, ss, bf.frames, bf.sr, bf.valid, rate_q, det_q, &so);
         std::vector<uint8_t> r(b->n_quanta);
         for (uint32_t q = 0; q < b->n_quanta; q++)
-          r[q] = so.qrec[q].mode == Q_SILENT ? (uint8_t)(1u | CODE_SILENT) : (uint8_t)n.out_nch;
-        itc = cache.emplace(automated ? SchedKey(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end,
+          r[q] = so.qrec[q].mode == Q_SILENT ? (uint8_t)(1u | CODE_SILENT) : (uint8_t)(bf.valid ? bf.count() : (uint32_t)n.out_nch);
+        itc = cache.emplace(automated || bf.nch_true ? SchedKey(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end,
                                                  (uint64_t)i, -1.f, 0.f, 0.f)
                                       : key,
                             std::move(r)).first;
@@ -967,6 +968,7 @@ int build_plan(waa_batch* b) {
   // static count differs from the dynamic one carries zeros — see DESIGN.md "Silence and channel counts")
   // (inside a feedback loop a producer can come later in the order: iterate to the fixed point; counts only grow)
   for (auto& n : b->nodes) n.in_nch = n.out_nch = 1;
+  bool mixed_buffer_counts = false;
   for (int pass = 0; pass < 16; pass++) {
   bool changed = false;
   for (uint32_t id : b->order) {
@@ -978,12 +980,13 @@ int build_plan(waa_batch* b) {
     n.in_nch = computed_in_nch(n, maxc);
     switch (n.desc.kind) {
       case WAA_NODE_BUFFER_SOURCE: {
+        // instances may play AudioBuffers of different channel counts: the signal is laid out for the widest one, the
+        // per-quantum codes of the dynamic-count plan carry every instance's own count (below: widen_narrow_buffers)
         uint32_t nch = 0;
         for (auto& bf : n.bufs)
           if (bf.valid) {
-            if (nch && bf.nch != nch)
-              return fail(WAA_ERR_OUT_OF_SCOPE, "instances of one batch must use AudioBuffers with the same channel count");
-            nch = bf.nch;
+            if (nch && bf.count() != nch) mixed_buffer_counts = true;
+            nch = std::max(nch, bf.count());
           }
         n.out_nch = nch ? (int)nch : 1;
         break;
@@ -1006,6 +1009,18 @@ int build_plan(waa_batch* b) {
     changed |= n.in_nch != old_in || n.out_nch != old_out;
   }
   if (!changed || n_scc == 0) break;
+  }
+  if (mixed_buffer_counts) {
+    // buffer.rs / audio_buffer_source.rs:560-600: the source's output has the channel count of ITS buffer; with several
+    // counts in one batch no static count fits every instance -> the dynamic-count plan, whose codes are per instance
+    if (measure_switch("WAA_STATIC_CHANNEL_COUNTS"))
+      return fail(WAA_ERR_OUT_OF_SCOPE, "instances of one batch must use AudioBuffers with the same channel count (WAA_STATIC_CHANNEL_COUNTS)");
+    if (b->prepass)
+      return fail(WAA_ERR_OUT_OF_SCOPE, "the graph that modulates a host-evaluated param plays AudioBuffers of different channel counts across instances: out of scope");
+    for (auto& n : b->nodes)
+      if (n.live && n.desc.kind == WAA_NODE_BUFFER_SOURCE)
+        if (int e = widen_narrow_buffers(b, n, (uint32_t)n.out_nch)) return e;
+    b->force_dynamic = true;
   }
   // Static vs dynamic channel counts.  The reference counts a silent input as mono, so the channel count of a
   // signal changes mid-render when a narrow and a wide producer are not active over the same quanta, when a source
@@ -1762,7 +1777,9 @@ int build_plan(waa_batch* b) {
   if (b->prepass && (count_change_found || b->force_dynamic))
     return fail(WAA_ERR_OUT_OF_SCOPE, "the graph that modulates a source's playbackRate / detune needs exact per-quantum channel counts: out of scope");
   if (count_change_found || b->force_dynamic) {
-    if (!count_change_found)
+    if (!count_change_found && mixed_buffer_counts)
+      plan_note(b, "instances play AudioBuffers of different channel counts -> per-instance counts through dyn_kernel");
+    else if (!count_change_found)
       plan_note(b, "a feedback loop needs quantum-serial rendering with node kinds the loop kernel does not cover -> dyn_kernel");
     b->dynamic = true;
     b->code_stride = ((uint64_t)b->n_quanta + 15) & ~(uint64_t)15;

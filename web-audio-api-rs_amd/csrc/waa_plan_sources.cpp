@@ -9,6 +9,44 @@
 namespace waa {
 namespace host {
 
+// Instances of one batch may play AudioBuffers of different channel counts (audio_buffer_source.rs:560-600: the output of a
+// quantum has the count of the instance's buffer).  Every kernel that reads a source walks `out_nch` channels of every
+// instance's buffer, so a buffer narrower than the widest one is replaced by a copy with silent extra channels; the
+// per-quantum codes of the dynamic-count plan (source_code_rows) carry the buffer's OWN count, which is what the consumers
+// mix by — the extra channels are never looked at.  Copies are per distinct buffer, made once (they are payload: a re-plan
+// finds them in place).
+int widen_narrow_buffers(waa_batch* b, Node& n, uint32_t nch) {
+  std::map<const float*, DeviceBuffer> done;
+  for (auto& bf : n.bufs) {
+    if (!bf.valid || bf.nch >= nch) continue;
+    auto it = done.find(bf.base);
+    if (it == done.end()) {
+      const uint64_t stride = std::max<uint64_t>(bf.ch_stride, 4);
+      float* d = nullptr;
+      int e = dev_alloc(b, &d, (size_t)nch * stride, true);
+      if (e) return e;
+      const size_t all = (size_t)nch * stride * sizeof(float), plane = (size_t)bf.frames * sizeof(float);
+      if (b->dry) {
+        std::memset(d, 0, all);
+        for (uint32_t c = 0; c < bf.nch && plane; c++) std::memcpy(d + (size_t)c * stride, bf.base + (size_t)c * bf.ch_stride, plane);
+      } else {
+        HIP_TRY(hipMemsetAsync(d, 0, all, b->stream));
+        for (uint32_t c = 0; c < bf.nch && plane; c++)
+          HIP_TRY(hipMemcpyAsync(d + (size_t)c * stride, bf.base + (size_t)c * bf.ch_stride, plane, hipMemcpyDeviceToDevice, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+      }
+      DeviceBuffer w = bf;
+      w.base = d;
+      w.ch_stride = stride;
+      w.nch_true = bf.count();
+      w.nch = nch;
+      it = done.emplace(bf.base, w).first;
+    }
+    bf = it->second;
+  }
+  return 0;
+}
+
 // Resolve a source node into an InputRef: schedules, per-instance buffer table, constant ranges.
 int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   Node& n = b->nodes[id];
