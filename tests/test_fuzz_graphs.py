@@ -28,6 +28,9 @@ def build_random_graph(be, seed, frozen=False, tap=None):
     than the same seed without it).  tap = k (debugging aid, tools/fuzz_tap_probe.py): the SAME graph, but only node k of
     its node list feeds the destination — where along the graph does a difference start?"""
     rng = np.random.default_rng(seed if not frozen else seed + 100000)
+    # FUZZ_MIXED_COUNTS=1 (campaign variant): one instance of some buffer sources plays an AudioBuffer of another channel
+    # count (own generator: the graphs of a seed stay what they are without the switch)
+    mix_rng = np.random.default_rng(seed + 7000003) if os.environ.get("FUZZ_MIXED_COUNTS") else None
     c = waa.OfflineAudioContext(2, FRAMES, SR, n_instances=N_INST, binding=be)
     outputs = []      # nodes that can feed others
     descr = []
@@ -41,6 +44,10 @@ def build_random_graph(be, seed, frozen=False, tap=None):
             n = c.create_buffer_source()
             length = FRAMES if rng.random() < 0.7 else int(rng.integers(300, FRAMES // 2))  # some end early
             n.set_buffer_batch(white_noise(N_INST, nch, length, seed0=int(rng.integers(1, 1 << 20))) * 0.5, SR)
+            if mix_rng is not None and mix_rng.random() < 0.4:
+                other = int(mix_rng.choice([k for k in (1, 2, 4) if k != nch]))
+                n.set_buffer(waa.AudioBuffer(white_noise(1, other, length, seed0=int(mix_rng.integers(1, 1 << 20)))[0] * 0.5, SR),
+                             instance=int(mix_rng.integers(0, N_INST)))
             r = rng.random()
             if LATE_STARTS and r < 0.2:
                 n.start_at(float(rng.integers(0, 600)) / SR)
