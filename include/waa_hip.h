@@ -152,8 +152,10 @@ typedef struct {
  * channel count 1 / explicit / discrete whose summed input is added to the intrinsic value) is expressed as an
  * edge into the OWNING node with to_input = WAA_PARAM_INPUT(param id).  Supported on the device for a-rate
  * params rendered there (Gain gain, Biquad frequency/detune/Q/gain, Delay delayTime, StereoPanner pan,
- * ConstantSource offset); params evaluated by the host (source playbackRate/detune, panner geometry) report
- * WAA_ERR_OUT_OF_SCOPE when modulated. */
+ * ConstantSource offset); params evaluated by the host are resolved at plan time by rendering the modulating subgraph
+ * first (source playbackRate / detune: k-rate; PannerNode position / orientation next to a single-valued AudioListener:
+ * first value per quantum, panner.rs:833-846) — WAA_ERR_OUT_OF_SCOPE next to an audio-rate listener, for nested
+ * modulated sources and on plan-only batches. */
 #define WAA_PARAM_INPUT(param) (0x80000000u | (uint32_t)(param))
 typedef struct {
   uint32_t from;
