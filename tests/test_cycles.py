@@ -721,3 +721,99 @@ def test_parity_analyser_that_aliases_the_echo_line_on_poisoned_memory():
     out = subprocess.check_output([sys.executable, "-c", "import test_cycles as t; t._check_analyser_on_the_echo_line()"],
                                   env=env, cwd=here)
     assert out.strip().endswith(b"ok")
+
+
+def _filtered_echo_graph(binding, noise, delays, gains, variant, out_channels=2, plan_only=False):
+    """source -> Delay -> Biquad -> Gain -> back into the Delay (the classic filtered echo), the destination fed as `variant` says:
+    dry+wet       the filter's output and the source (the tail the ring kernel renders itself: nothing but the output is stored)
+    wet-only      the filter's output only
+    wet-gain      filter -> Gain(0.7) -> destination (a reader with an op of its own: the filter's output is stored for it)
+    line-reader   the DELAY's output reaches the destination too (read from the delay line, which is stored for that reader)
+    two-readers   the filter's output into the destination and into a WaveShaper -> destination (stored)
+    two-sources   a second source feeds the delay too (three inputs of the sum)
+    peaking       dry+wet with a peaking filter, per-instance frequency and Q"""
+    n = noise.shape[0]
+    kw = {"device": waa.PLAN_ONLY} if plan_only else {}
+    c = waa.OfflineAudioContext(out_channels, noise.shape[2], 48000.0, n_instances=n, binding=binding, **kw)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    delay = c.create_delay(0.4)
+    bq = c.create_biquad_filter(type_="peaking" if variant == "peaking" else "lowpass", frequency=2500.0)
+    fb = c.create_gain()
+    for i in range(n):
+        delay.delay_time.set_value(delays[i], instance=i)
+        fb.gain.set_value(gains[i], instance=i)
+        if variant == "peaking":
+            bq.frequency.set_value(700.0 + 900.0 * i, instance=i)
+            bq.q.set_value(0.7 + 0.4 * i, instance=i)
+            bq.gain.set_value(4.0 - 2.0 * i, instance=i)
+    src.connect(delay)
+    delay.connect(bq).connect(fb).connect(delay)
+    if variant in ("dry+wet", "peaking"):
+        bq.connect(c.destination())
+        src.connect(c.destination())
+    elif variant == "wet-only":
+        bq.connect(c.destination())
+    elif variant == "wet-gain":
+        bq.connect(c.create_gain(gain=0.7)).connect(c.destination())
+    elif variant == "line-reader":
+        bq.connect(c.destination())
+        delay.connect(c.destination())
+    elif variant == "two-readers":
+        bq.connect(c.destination())
+        bq.connect(c.create_wave_shaper(curve=np.float32([-0.5, 0.0, 0.8]))).connect(c.destination())
+    elif variant == "two-sources":
+        other = c.create_buffer_source()
+        other.set_buffer_batch(noise[:, :, ::-1].copy(), 48000.0)
+        other.connect(delay)
+        other.connect(c.destination())
+        other.start()
+        bq.connect(c.destination())
+    src.start()
+    plan = c.plan_describe() if binding.prefix == "waa_" else ""
+    out = None if plan_only else c.start_rendering_sync().data
+    c.close()
+    return out, plan
+
+
+FILTERED_ECHOES = ["dry+wet", "wet-only", "wet-gain", "line-reader", "two-readers", "two-sources", "peaking"]
+
+
+@pytest.mark.measure
+@pytest.mark.parametrize("variant", FILTERED_ECHOES)
+def test_plan_filtered_echo_loop(variant):
+    """which filtered echo loops become ONE launch of the ring kernel's BQ form, and what leaves that launch"""
+    n, frames = 6, 2048 * 11 + 77
+    noise = white_noise(n, 2, frames, seed0=37)
+    delays = (np.float64([2064, 2065.5, 3000.25, 4800, 9000.75, 14328]) / 48000.0).astype(np.float32)
+    gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
+    _, plan = _filtered_echo_graph(waa.measure_binding(), noise, delays, gains, variant, plan_only=True)
+    assert "with the Biquad between the delayed read and the sum" in plan, plan
+    assert ("the delay line is not stored" in plan) == (variant != "line-reader"), plan
+    # (wet-only: the destination IS the filter's output — stored, as the render's result)
+    fused = variant in ("dry+wet", "two-sources", "peaking")
+    assert ("the filter's output is not stored" in plan) == fused, plan
+
+
+@pytest.mark.measure
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,out_channels", [(1, 1), (1, 2), (2, 2)])
+@pytest.mark.parametrize("variant", FILTERED_ECHOES)
+def test_parity_filtered_echo_loop_from_the_lds_ring(hip, orc, channels, out_channels, variant, monkeypatch):
+    """waa_echo.hip's BQ form against the oracle and against the three launches per block it replaces (WAA_NO_ECHO_BQ): the
+    Biquad's f64 recurrence is evaluated in the reference's order from incoming states found by a scan, like the streaming
+    kernel — not bit-identical to the serial recurrence, hence the streaming kernel's tolerance"""
+    n, frames = 6, 2048 * 11 + 77
+    noise = white_noise(n, channels, frames, seed0=38)
+    delays = (np.float64([2064, 2065.5, 3000.25, 4800, 9000.75, 14328]) / 48000.0).astype(np.float32)
+    gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
+    ring, plan = _filtered_echo_graph(hip, noise, delays, gains, variant, out_channels)
+    assert "with the Biquad between the delayed read and the sum" in plan, plan
+    o, _ = _filtered_echo_graph(orc, noise, delays, gains, variant, out_channels)
+    scale = max(1.0, float(np.abs(o).max()))
+    assert rms_err(ring, o).max() <= 1e-6 * scale
+    assert np.abs(ring - o).max() <= 4e-6 * scale
+    monkeypatch.setenv("WAA_NO_ECHO_BQ", "1")
+    plain, plan = _filtered_echo_graph(hip, noise, delays, gains, variant, out_channels)
+    assert "with the Biquad between" not in plan
+    assert np.abs(plain - ring).max() <= 4e-6 * scale

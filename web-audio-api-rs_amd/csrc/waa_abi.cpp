@@ -955,7 +955,7 @@ static int run_steps(waa_batch* b) {
       // launches; opt-in, parity-tested (tests/test_cycles.py), not the default.
       size_t n_body = 0, body = 0;
       for (size_t k = i; k < j; k++)
-        if (!b->steps[k].prologue) {
+        if (!b->steps[k].prologue && !b->steps[k].echo_fused) {  // (fused: body launches the ring kernel's BQ form stands for)
           n_body++;
           body = k;
         }
@@ -965,7 +965,10 @@ static int run_steps(waa_batch* b) {
         ChainDesc d = bs.chain;
         d.tile0 = 0;
         d.tile1 = b->n_tiles;
-        int e = timed(bs.profile_slot, [&] { launch_echo_ring(d, bs.echo_fb, bs.echo_chunk, bs.echo_tail_step >= 0 ? &bs.echo_tail : nullptr, b->stream); });
+        int e = timed(bs.profile_slot, [&] {
+          launch_echo_ring(d, bs.echo_fb, bs.echo_chunk, bs.echo_tail_step >= 0 ? &bs.echo_tail : nullptr, b->stream,
+                           bs.echo_bq.coefs ? &bs.echo_bq : nullptr);
+        });
         if (e) return e;
         i = j;
         continue;
@@ -990,7 +993,7 @@ static int run_steps(waa_batch* b) {
     for (uint32_t t0 = 0; t0 < b->n_tiles; t0 += bt) {
       const uint32_t t1 = std::min(b->n_tiles, t0 + bt);
       for (size_t k = i; k < j; k++)
-        if (!b->steps[k].prologue) {
+        if (!b->steps[k].prologue && !b->steps[k].echo_fused) {
           int e = run_step(b->steps[k], t0, t1);
           if (e) return e;
         }

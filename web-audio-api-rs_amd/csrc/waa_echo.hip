@@ -19,6 +19,16 @@
 // Nothing fed back.  out = X + g * delayed(X) outside any loop (echo_feed_forward) is the same walk with the stand-in loop
 // stage line = X: X goes through the ring instead of being read twice by two million short-lived wavefronts of the
 // tile-parallel chain kernel (1.5 against 2.1 ms on the echo workload; taken when there is an instance per CU to walk).
+//
+// A Biquad in the loop (round 4).  The classic filtered echo  line = X + g * biquad(delayed(line))  was three launches per block
+// (the delayed read, the streaming biquad, the sum) with the delayed samples and the filter's output going through memory in
+// between.  The BQ form of the kernel filters the delayed samples on their way from the ring into the sum: per chunk every
+// lane has 4 consecutive frames of every channel; zero-state response of those frames (f64), the lanes' incoming y states
+// from a scan over the wavefront with the uniform powers of A = M^4 (M the one-frame transition), the waves' incoming states
+// from the chunk's starting state and the waves' zero-state end states (one LDS hand-over), then the reference's evaluation
+// order from the true incoming state (biquad_filter.rs:877-883) — the scheme of waa_biquad_stream.hip on the ring kernel's data
+// layout.  Constant coefficients only (one set per instance); anything else keeps the three launches.  The filter's output takes
+// the place of the delayed line as the operand of the loop stage and of the tail; it is stored only for other readers.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -76,8 +86,27 @@ struct EchoOperands {
 // Everything that does not change from chunk to chunk — pointers, which operand an edge takes, whether it has a gain or
 // up-mixes — is worked out ONCE, into wave-uniform registers, before the walk: read from the descriptors inside the chunk it
 // was 1500 instructions per chunk and wave (a third of them scalar-register spills), as long as the chunk's memory time.
-template <int C, int CT, bool STORE>
-__global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int fb, int chunk_subtiles, const EchoTail t) {
+struct M2e {
+  double a, b, c, d;
+};
+__device__ __forceinline__ M2e mme(const M2e& x, const M2e& y) {
+  M2e r;
+  r.a = __builtin_fma(x.a, y.a, x.b * y.c);
+  r.b = __builtin_fma(x.a, y.b, x.b * y.d);
+  r.c = __builtin_fma(x.c, y.a, x.d * y.c);
+  r.d = __builtin_fma(x.c, y.b, x.d * y.d);
+  return r;
+}
+__device__ __forceinline__ double uniform_d(double v) {  // a wave-uniform double into scalar registers
+  const uint64_t u = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+constexpr int ECHO_BQ_WAVES = 8;  // the BQ form: at most eight waves (256 registers each)
+
+template <int C, int CT, bool STORE, bool BQ = false>
+__global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kernel(const ChainDesc d, int fb, int chunk_subtiles, const EchoTail t,
+                                                                                 const EchoBq bq) {
   constexpr int CM = C > CT ? C : CT;
   constexpr int NL = 1 + ECHO_EXT, NT = CT > 0 ? ECHO_TAIL_IN : 0, NG = NL + NT;
   extern __shared__ __attribute__((aligned(16))) float ring[];  // [C][ECHO_RING]
@@ -86,6 +115,37 @@ __global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int 
   const uint32_t inst = blockIdx.x;
   for (int i = tid; i < C * ECHO_RING; i += blockDim.x) ring[i] = 0.f;
   __syncthreads();
+  // ---- BQ: the filter's constants (one coefficient set per instance) and what the scan needs of them
+  __shared__ double wz[BQ ? ECHO_BQ_WAVES : 1][C][2];  // zero-state end states (y1, y2) of the waves' sub-tiles of this chunk
+  [[maybe_unused]] double b0 = 0., b1 = 0., b2 = 0., a1 = 0., a2 = 0.;
+  [[maybe_unused]] M2e P[6], A64{}, PL{};   // A^(2^k), A^64 (A = M^4) — uniform; A^lane — per lane
+  [[maybe_unused]] double ys[C][2];         // y state (y1, y2) in front of the chunk at hand: the same value in every lane
+  [[maybe_unused]] float* py[C];
+  if constexpr (BQ) {
+    __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);  // f64 denormals flushed (FTZ/DAZ render scope, thread.rs:374-382)
+    const double* cf = bq.coefs + (uint64_t)inst * bq.coef_stride;
+    b0 = uniform_d(load_global(cf));
+    b1 = uniform_d(load_global(cf + 1));
+    b2 = uniform_d(load_global(cf + 2));
+    a1 = uniform_d(load_global(cf + 3));
+    a2 = uniform_d(load_global(cf + 4));
+    M2e m = {-a1, -a2, 1., 0.};
+    m = mme(m, m);
+    m = mme(m, m);  // A = M^4
+    PL = M2e{1., 0., 0., 1.};
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      P[k] = m;
+      if (lane & (1 << k)) PL = mme(m, PL);
+      m = mme(m, m);
+    }
+    A64 = m;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      ys[c][0] = ys[c][1] = 0.;
+      py[c] = bq.y.base + (uint64_t)inst * bq.y.inst_stride + (uint64_t)c * bq.y.ch_stride;
+    }
+  }
   // DelayReader's position arithmetic (delay.rs:560-569), one delayTime per instance
   const float dv = echo_delay_value(t.delay, inst);
   const double position = 0. - (double)dv * t.sample_rate;
@@ -185,67 +245,171 @@ __global__ __launch_bounds__(1024) void echo_ring_kernel(const ChainDesc d, int 
     }
   };
 
+  // The sum stage(s) of one group of 4 frames: `xd` = the operand the feedback edge takes (the delayed samples; BQ: the filter's
+  // output), the loop stage into the ring (and to memory), the tail stage to memory.
+  auto finish = [&](const EchoOperands<C, NG>& o, uint32_t f, const float (&xd)[C][4]) __attribute__((always_inline)) {
+    float xa[C][4], xb[C][4];  // the inputs of slot 0 / 1
+    {
+      const bool in_a = f + 3u < vlim[0], in_b = f + 3u < vlim[1];
+#pragma unroll
+      for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          xa[c][e] = in_a ? o.x[0][c][e] : 0.f;
+          xb[c][e] = in_b ? o.x[1][c][e] : 0.f;
+        }
+    }
+    float v[C][4];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+      if (!present[k]) continue;
+      float u[CM][4];
+      edge(k, o.g[k], l_discrete, xd, xa, xb, u);
+#pragma unroll
+      for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[c][e] = k == 0 ? u[c][e] : v[c][e] + u[c][e];
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++) {  // (C == in_nch == out.nch: echo_ring_applicable)
+      if (STORE) *reinterpret_cast<float4*>(po[c] + f) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+      *reinterpret_cast<f4v*>(ring + c * ECHO_RING + (int)(f & (ECHO_RING - 1))) = f4v{v[c][0], v[c][1], v[c][2], v[c][3]};
+    }
+    if (CT > 0) {  // the tail stage: same input arithmetic, its operands the ones the loop stage had
+      float w[CM][4];
+#pragma unroll
+      for (int k = 0; k < NT; k++) {
+        if (!present[NL + k]) continue;
+        float u[CM][4];
+        edge(NL + k, o.g[NL + k], t_discrete, xd, xa, xb, u);
+#pragma unroll
+        for (int c = 0; c < CM; c++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) w[c][e] = k == 0 ? u[c][e] : w[c][e] + u[c][e];
+      }
+#pragma unroll
+      for (int c = 0; c < CT; c++)  // (CT == the tail's in_nch == out.nch: echo_tail_applicable)
+        *reinterpret_cast<float4*>(pt[c] + f) = make_float4(w[c][0], w[c][1], w[c][2], w[c][3]);
+    }
+  };
+
   // One chunk: wave w renders sub-tile s0 + w (256 frames, 4 per lane).  GUARD: the last, partial chunk.
   auto chunk = [&](const EchoOperands<C, NG>& o, uint32_t s0, auto guard) __attribute__((always_inline)) {
     constexpr bool GUARD = decltype(guard)::value;
     const uint32_t sub = s0 + wave;
-    if (!GUARD || sub < total_sub) {
-      const uint32_t f = f_first + sub * 256u + (uint32_t)lane * 4u;
-      const bool dead = f / RQ > last_q;
-      float xd[C][4], xa[C][4], xb[C][4];  // the delayed samples of this group, out of the ring; the inputs of slot 0 / 1
+    const bool live = !GUARD || sub < total_sub;
+    const uint32_t f = f_first + sub * 256u + (uint32_t)lane * 4u;
+    const bool dead = f / RQ > last_q;
+    if constexpr (!BQ) {
+      if (live) {
+        float xd[C][4];  // the delayed samples of this group, out of the ring
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          float x[5];
+#pragma unroll
+          for (int e = 0; e < 5; e++) {
+            const int32_t idx = (int32_t)f + pf0 + e;
+            const float r = ring[c * ECHO_RING + (idx & (ECHO_RING - 1))];
+            x[e] = idx < 0 || dead ? 0.f : r;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e++) xd[c][e] = __builtin_fmaf(1.f - kf, x[e], kf * x[e + 1]);
+        }
+        finish(o, f, xd);
+      }
+    } else {
+      // ---- the delayed samples of the group AND of the two frames in front of it (the filter's x history: the same values
+      // the lane in front computed), the zero-state response of the four frames, the scan over the wavefront
+      double xq[C][6], r1[C], r2[C];
+      if (live) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          float x[7];
+#pragma unroll
+          for (int e = 0; e < 7; e++) {
+            const int32_t idx = (int32_t)f + pf0 + e - 2;
+            const float r = ring[c * ECHO_RING + (idx & (ECHO_RING - 1))];
+            x[e] = idx < 0 || dead ? 0.f : r;
+          }
+#pragma unroll
+          for (int e = 0; e < 6; e++) xq[c][e] = (double)__builtin_fmaf(1.f - kf, x[e], kf * x[e + 1]);
+          const double w0 = __builtin_fma(b2, xq[c][0], __builtin_fma(b1, xq[c][1], b0 * xq[c][2]));
+          const double w1 = __builtin_fma(b2, xq[c][1], __builtin_fma(b1, xq[c][2], b0 * xq[c][3]));
+          const double w2 = __builtin_fma(b2, xq[c][2], __builtin_fma(b1, xq[c][3], b0 * xq[c][4]));
+          const double w3 = __builtin_fma(b2, xq[c][3], __builtin_fma(b1, xq[c][4], b0 * xq[c][5]));
+          const double z0 = w0, z1 = __builtin_fma(-a1, z0, w1), z2 = __builtin_fma(-a2, z0, __builtin_fma(-a1, z1, w2)),
+                       z3 = __builtin_fma(-a2, z1, __builtin_fma(-a1, z2, w3));
+          r1[c] = z3;
+          r2[c] = z2;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const int dd = 1 << k;
+#pragma unroll
+          for (int c = 0; c < C; c++) {
+            const double q1 = __shfl_up(r1[c], dd, 64), q2 = __shfl_up(r2[c], dd, 64);
+            if (lane >= dd) {
+              r1[c] = __builtin_fma(P[k].a, q1, __builtin_fma(P[k].b, q2, r1[c]));
+              r2[c] = __builtin_fma(P[k].c, q1, __builtin_fma(P[k].d, q2, r2[c]));
+            }
+          }
+        }
+        if (lane == 63) {
+#pragma unroll
+          for (int c = 0; c < C; c++) {
+            wz[wave][c][0] = r1[c];
+            wz[wave][c][1] = r2[c];
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // ---- this wave's incoming state, and the state behind the chunk (every wave keeps its own copy)
+      double s1[C], s2[C];
 #pragma unroll
       for (int c = 0; c < C; c++) {
-        float x[5];
+        double t1 = ys[c][0], t2 = ys[c][1];
+        s1[c] = t1;
+        s2[c] = t2;
 #pragma unroll
-        for (int e = 0; e < 5; e++) {
-          const int32_t idx = (int32_t)f + pf0 + e;
-          const float r = ring[c * ECHO_RING + (idx & (ECHO_RING - 1))];
-          x[e] = idx < 0 || dead ? 0.f : r;
+        for (int j = 0; j < ECHO_BQ_WAVES; j++) {
+          if ((uint32_t)j < cs) {
+            if ((uint32_t)j == wave) {
+              s1[c] = t1;
+              s2[c] = t2;
+            }
+            const double n1 = __builtin_fma(A64.a, t1, __builtin_fma(A64.b, t2, wz[j][c][0]));
+            const double n2 = __builtin_fma(A64.c, t1, __builtin_fma(A64.d, t2, wz[j][c][1]));
+            t1 = n1;
+            t2 = n2;
+          }
         }
-#pragma unroll
-        for (int e = 0; e < 4; e++) xd[c][e] = __builtin_fmaf(1.f - kf, x[e], kf * x[e + 1]);
+        ys[c][0] = t1;
+        ys[c][1] = t2;
       }
-      {
-        const bool in_a = f + 3u < vlim[0], in_b = f + 3u < vlim[1];
+      if (live) {
+        float yo[C][4];
 #pragma unroll
-        for (int c = 0; c < C; c++)
+        for (int c = 0; c < C; c++) {
+          double y1 = __shfl_up(r1[c], 1, 64), y2 = __shfl_up(r2[c], 1, 64);
+          if (lane == 0) y1 = y2 = 0.;
+          y1 = __builtin_fma(PL.a, s1[c], __builtin_fma(PL.b, s2[c], y1));
+          y2 = __builtin_fma(PL.c, s1[c], __builtin_fma(PL.d, s2[c], y2));
+          // the reference's evaluation order from the true incoming state (biquad_filter.rs:877-883)
+          double p1 = xq[c][1], p2 = xq[c][0];
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            xa[c][e] = in_a ? o.x[0][c][e] : 0.f;
-            xb[c][e] = in_b ? o.x[1][c][e] : 0.f;
+            const double x = xq[c][e + 2];
+            double y = b0 * x + b1 * p1 + b2 * p2 - a1 * y1 - a2 * y2;
+            if (!__builtin_isnormal(y)) y = 0.;
+            p2 = p1;
+            p1 = x;
+            y2 = y1;
+            y1 = y;
+            yo[c][e] = (float)y;
           }
-      }
-      float v[C][4];
-#pragma unroll
-      for (int k = 0; k < NL; k++) {
-        if (!present[k]) continue;
-        float u[CM][4];
-        edge(k, o.g[k], l_discrete, xd, xa, xb, u);
-#pragma unroll
-        for (int c = 0; c < C; c++)
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[c][e] = k == 0 ? u[c][e] : v[c][e] + u[c][e];
-      }
-#pragma unroll
-      for (int c = 0; c < C; c++) {  // (C == in_nch == out.nch: echo_ring_applicable)
-        if (STORE) *reinterpret_cast<float4*>(po[c] + f) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
-        *reinterpret_cast<f4v*>(ring + c * ECHO_RING + (int)(f & (ECHO_RING - 1))) = f4v{v[c][0], v[c][1], v[c][2], v[c][3]};
-      }
-      if (CT > 0) {  // the tail stage: same input arithmetic, its operands the ones the loop stage had
-        float w[CM][4];
-#pragma unroll
-        for (int k = 0; k < NT; k++) {
-          if (!present[NL + k]) continue;
-          float u[CM][4];
-          edge(NL + k, o.g[NL + k], t_discrete, xd, xa, xb, u);
-#pragma unroll
-          for (int c = 0; c < CM; c++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) w[c][e] = k == 0 ? u[c][e] : w[c][e] + u[c][e];
+          if (bq.store_y) *reinterpret_cast<float4*>(py[c] + f) = make_float4(yo[c][0], yo[c][1], yo[c][2], yo[c][3]);
         }
-#pragma unroll
-        for (int c = 0; c < CT; c++)  // (CT == the tail's in_nch == out.nch: echo_tail_applicable)
-          *reinterpret_cast<float4*>(pt[c] + f) = make_float4(w[c][0], w[c][1], w[c][2], w[c][3]);
+        finish(o, f, yo);
       }
     }
     // the chunk is in the ring before the next one reads behind it.  (NOT __syncthreads(): its release fence waits for every
@@ -317,7 +481,7 @@ int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, 
 
 // The chain step `tail` (outside the loop) as the tail stage of the ring kernel: a plain sum, to at least the line's channel
 // count, of delayed(line) — the loop's own delayTime — and of signals the loop step reads too.
-int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t, const char** why) {
+int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t, const char** why, const EchoBq* bq) {
   auto no = [&](const char* reason) {
     *why = reason;
     return 0;
@@ -345,7 +509,15 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
     if (in.nch != tail.in_nch && !(in.nch == 1 && tail.in_nch == 2)) return no("an input of it is mixed by a computed rule");
     r.in[k] = in;
     r.alias[k] = -1;
-    if (in.kind == IN_DELAYED) {
+    if (bq && in.kind == IN_SIGNAL && in.sig.base == bq->y.base) {
+      // the BQ form: the filter's output is the operand the kernel holds in place of the delayed line
+      if (in.sig.inst_stride != bq->y.inst_stride || in.sig.ch_stride != bq->y.ch_stride || in.nch != d.in_nch || limit(in.valid) != 0)
+        return no("it reads the filter's output in another layout");
+      r.alias[k] = -2;
+      reads_line = true;
+    } else if (bq && in.kind == IN_DELAYED) {
+      return no("it reads the delay line itself, which the filtered loop does not hold as an operand");
+    } else if (in.kind == IN_DELAYED) {
       // (a line belongs to ONE DelayNode: every delayed read of it is by that node's delayTime, the loop's own)
       if (in.sig.base != d.out.base || in.sig.inst_stride != d.out.inst_stride || in.sig.ch_stride != d.out.ch_stride ||
           in.nch != d.in_nch || !(in.offset.mode == 0 || in.offset.mode == 3) || (line_rate != 0. && in.sample_rate != line_rate))
@@ -364,7 +536,7 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
       return no("it has a source or constant input");
     }
   }
-  if (!reads_line) return no("it does not read the line");
+  if (!reads_line) return no(bq ? "it does not read the filter's output" : "it does not read the line");
   *t = r;
   return 1;
 }
@@ -374,6 +546,54 @@ static int echo_chunk_for(float dmin, float dmax) {
   for (int cand : {16, 8, 4})
     if ((float)(cand * 256 + 8) <= dmin) return dmax > (float)(ECHO_RING - cand * 256 - 8) ? 0 : cand;
   return 0;
+}
+
+int echo_bq_applicable(const ChainDesc& rd, const BiquadStreamDesc& f, const ChainDesc& sum, const float* delay_min_max_frames,
+                       int* chunk_subtiles, EchoBq* bq) {
+  const int nch = sum.in_nch;
+  // the delayed read: the line the sum writes, by one delayTime per instance, nothing else
+  if (rd.n_ops != 0 || rd.n_inputs != 1 || rd.in_nch != nch || rd.out.nch != nch || nch < 1 || nch > 2) return -1;
+  const InputRef& D = rd.in[0];
+  if (D.kind != IN_DELAYED || !D.feedback || D.has_gain || D.nch != nch || D.sig.base != sum.out.base || D.sig.inst_stride != sum.out.inst_stride ||
+      D.sig.ch_stride != sum.out.ch_stride || !(D.offset.mode == 0 || D.offset.mode == 3))
+    return -1;
+  // the filter: constant coefficients, the delayed read in, no gains behind it
+  if (f.in.kind != IN_SIGNAL || f.in.has_gain || f.in.sig.base != rd.out.base || f.in.nch != nch || f.nch != nch || f.vary != 0 || f.n_gain != 0 ||
+      f.dup_out || f.out.nch != nch || !f.coefs || ((uintptr_t)f.out.base & 15) || (f.out.ch_stride & 3) || (f.out.inst_stride & 3))
+    return -1;
+  // the sum: the filter's output (once) plus signals from outside the loop
+  if (sum.n_ops != 0 || sum.out.nch != nch || sum.n_inputs < 2 || sum.n_inputs > 1 + ECHO_EXT) return -1;
+  int fb = -1;
+  for (int k = 0; k < sum.n_inputs; k++) {
+    const InputRef& in = sum.in[k];
+    if (in.kind != IN_SIGNAL) return -1;
+    if (in.has_gain && !(in.gain.mode == 0 || in.gain.mode == 1)) return -1;
+    if (in.nch != nch && !(in.nch == 1 && nch == 2)) return -1;
+    if (in.sig.base == f.out.base) {
+      if (fb >= 0 || in.nch != nch || in.sig.inst_stride != f.out.inst_stride || in.sig.ch_stride != f.out.ch_stride) return -1;
+      fb = k;
+    } else if (in.sig.base == sum.out.base || in.sig.base == rd.out.base || ((uintptr_t)in.sig.base & 15) || (in.sig.ch_stride & 3) ||
+               (in.sig.inst_stride & 3)) {
+      return -1;
+    }
+  }
+  if ((uint64_t)sum.n_tiles * TILE >= (1ull << 31)) return -1;
+  if (fb < 0 || ((uintptr_t)sum.out.base & 15) || (sum.out.ch_stride & 3) || (sum.out.inst_stride & 3)) return -1;
+  int ch = 0;
+  for (int cand : {ECHO_BQ_WAVES, 4})
+    if (!ch && (float)(cand * 256 + 8) <= delay_min_max_frames[0]) ch = delay_min_max_frames[1] > (float)(ECHO_RING - cand * 256 - 8) ? 0 : cand;
+  if (!ch) return -1;
+  *chunk_subtiles = ch;
+  EchoBq q{};
+  q.coefs = f.coefs;
+  q.coef_stride = f.coef_stride;
+  q.y = f.out;
+  q.store_y = 1;
+  q.store_line = 1;
+  q.delay = D.offset;
+  q.sample_rate = D.sample_rate;
+  *bq = q;
+  return fb;
 }
 
 int echo_feed_forward(const ChainDesc& st, ChainDesc* line, EchoTail* tail, const char** why) {
@@ -421,21 +641,37 @@ int echo_feed_forward(const ChainDesc& st, ChainDesc* line, EchoTail* tail, cons
   return chunk;
 }
 
-void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const EchoTail* tail, void* stream) {
+void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const EchoTail* tail, void* stream, const EchoBq* bq) {
   const size_t lds = (size_t)d.in_nch * ECHO_RING * sizeof(float);
   const int ct = tail ? tail->in_nch : 0;
   EchoTail t{};
   if (tail) t = *tail;
-  if (fb < d.n_inputs) {
+  if (bq) {
+    t.delay = bq->delay;
+    t.sample_rate = bq->sample_rate;
+  } else if (fb < d.n_inputs) {
     t.delay = d.in[fb].offset;
     t.sample_rate = d.in[fb].sample_rate;
   }
+  const EchoBq q = bq ? *bq : EchoBq{};
   const dim3 block((unsigned)chunk_subtiles * 64), grid(d.n_inst);
   const bool store = !tail || tail->store_line;
   auto go = [&](auto kern) {
     raise_lds_limit(reinterpret_cast<const void*>(kern));
-    hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, d, fb, chunk_subtiles, t);
+    hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, d, fb, chunk_subtiles, t, q);
   };
+  if (bq) {
+    const bool sl = bq->store_line != 0;
+    if (d.in_nch == 1) {
+      if (ct == 0) sl ? go(echo_ring_kernel<1, 0, true, true>) : go(echo_ring_kernel<1, 0, false, true>);
+      else if (ct == 1) sl ? go(echo_ring_kernel<1, 1, true, true>) : go(echo_ring_kernel<1, 1, false, true>);
+      else sl ? go(echo_ring_kernel<1, 2, true, true>) : go(echo_ring_kernel<1, 2, false, true>);
+    } else {
+      if (ct == 0) sl ? go(echo_ring_kernel<2, 0, true, true>) : go(echo_ring_kernel<2, 0, false, true>);
+      else sl ? go(echo_ring_kernel<2, 2, true, true>) : go(echo_ring_kernel<2, 2, false, true>);
+    }
+    return;
+  }
   if (d.in_nch == 1) {
     if (ct == 0) go(echo_ring_kernel<1, 0, true>);
     else if (ct == 1) store ? go(echo_ring_kernel<1, 1, true>) : go(echo_ring_kernel<1, 1, false>);

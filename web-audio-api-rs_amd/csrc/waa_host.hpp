@@ -237,6 +237,9 @@ struct Step {
   // the only body step of a block-scheduled loop, and the loop qualifies for the LDS-ring kernel (waa_echo.hip): index of
   // the feedback input (-1: no) and the chunk size in 256-frame sub-tiles
   int echo_fb = -1, echo_chunk = 0;
+  // ... or the LAST of three body steps (delayed read -> streaming biquad -> sum) rendered as the ring kernel's BQ form
+  // (echo_bq.coefs != nullptr); the first two are marked echo_fused
+  EchoBq echo_bq{};
   // ... and the line's only reader outside the loop rendered by the same launch (EchoTail): on the loop step, index of that
   // step and its descriptor; on that step itself, echo_fused = it is not launched
   int echo_tail_step = -1;

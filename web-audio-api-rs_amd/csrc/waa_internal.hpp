@@ -678,13 +678,28 @@ struct EchoTail {
   ParamRef delay;             // the DelayNode's delayTime (mode 0 or 3) and rate: set by the launcher from the feedback
   double sample_rate;         // input, or by echo_feed_forward for a line that is not fed back
 };
+// A Biquad (constant coefficients) between the delayed read and the loop's sum, rendered by the same launch (the BQ form):
+// `y` = the filter's output signal — the operand of the loop stage's feedback edge and of the tail; stored when store_y.
+struct EchoBq {
+  const double* coefs;        // [n_inst][coef_stride]: b0 b1 b2 a1 a2; nullptr: no filter in the loop
+  uint64_t coef_stride;
+  SignalRef y;
+  int32_t store_y, store_line;  // readers outside the launch (fuse_echo_tails decides)
+  ParamRef delay;             // the DelayNode's delayTime and rate (the delayed read is not an input of the sum here)
+  double sample_rate;
+};
 int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, int* chunk_subtiles);
+// the three body launches of a block-scheduled loop  delayed read -> streaming biquad -> sum into the line  as the BQ form?
+// Returns the index of the sum's input that reads the filter's output (and fills bq / the chunk size), or -1.
+struct BiquadStreamDesc;
+int echo_bq_applicable(const ChainDesc& read, const BiquadStreamDesc& filter, const ChainDesc& sum, const float* delay_min_max_frames,
+                       int* chunk_subtiles, EchoBq* bq);
 // a chain step OUTSIDE any loop that sums delayed(X) with X itself and at most one other signal, no ops (the feed-forward
 // echo): the same kernel with nothing fed back — X goes through the ring instead of being read twice.  Fills the stand-in
 // loop stage (`line` = X) and the tail; returns the chunk size or 0.
 int echo_feed_forward(const ChainDesc& step, ChainDesc* line, EchoTail* tail, const char** why);
-int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t, const char** why);
-void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const EchoTail* tail, void* stream);
+int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t, const char** why, const EchoBq* bq = nullptr);
+void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const EchoTail* tail, void* stream, const EchoBq* bq = nullptr);
 // dst[inst][q] = src[inst * inst_stride + q * 128]: the first frame of every render quantum of a per-frame table
 void launch_quantum_heads(const float* src, uint64_t inst_stride, uint32_t n_inst, uint32_t n_quanta, float* dst, void* stream);
 // waa_resample.hip: AudioBufferSource [-> WaveShaper] -> signal without the op interpreter (the C5 shape)

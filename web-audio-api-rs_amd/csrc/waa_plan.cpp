@@ -2192,13 +2192,15 @@ int build_plan(waa_batch* b) {
         // one element-wise launch per block whose only loop-carried input is its own delay line (Delay <-> Gain): the
         // LDS-ring kernel renders the whole loop in one launch (waa_echo.hip) when every instance's delay fits its window
         size_t n_body = 0, body = 0;
+        std::vector<size_t> bodies;
         for (size_t k = first_step; k < b->steps.size(); k++)
           if (!b->steps[k].prologue) {
             n_body++;
             body = k;
+            bodies.push_back(k);
           }
-        if (n_body == 1 && b->steps[body].kind == 0 && !measure_switch("WAA_NO_ECHO_RING")) {
-          float range[2] = {1e30f, 0.f};
+        float range[2] = {1e30f, 0.f};
+        auto delay_range = [&]() {
           for (uint32_t v : loop_items) {
             const uint32_t did = v & ~VTX_READER;
             if (!(v & VTX_READER) || !b->cut[did]) continue;
@@ -2210,6 +2212,9 @@ int build_plan(waa_batch* b) {
                 range[1] = std::max(range[1], fr);
               }
           }
+        };
+        if (n_body == 1 && b->steps[body].kind == 0 && !measure_switch("WAA_NO_ECHO_RING")) {
+          delay_range();
           ChainDesc cd = b->steps[body].chain;
           cd.tile0 = 0;
           cd.tile1 = b->n_tiles;
@@ -2221,6 +2226,36 @@ int build_plan(waa_batch* b) {
             b->steps[body].profile_slot = slot_for(b, "echo_ring_kernel");
             plan_note(b, "  ... rendered by the LDS-ring kernel in ONE launch: delay %.0f .. %.0f frames, chunks of %d frames, the line's last %d frames stay in LDS",
                       (double)range[0], (double)range[1], chunk * 256, 16384);
+          }
+        }
+        // delayed read -> streaming biquad (constant coefficients) -> sum into the line: the filtered echo, the ring kernel's BQ form
+        if (n_body == 3 && b->steps[bodies[0]].kind == 0 && b->steps[bodies[1]].kind == 1 && b->steps[bodies[2]].kind == 0 &&
+            !b->steps[bodies[1]].scan.payload && !measure_switch("WAA_NO_ECHO_RING") && !measure_switch("WAA_NO_ECHO_BQ")) {
+          delay_range();
+          Step &rd = b->steps[bodies[0]], &fl = b->steps[bodies[1]], &sm = b->steps[bodies[2]];
+          int chunk = 0;
+          EchoBq q{};
+          ChainDesc cd = sm.chain;
+          cd.tile0 = 0;
+          cd.tile1 = b->n_tiles;
+          int fb = echo_bq_applicable(rd.chain, fl.bq, cd, range, &chunk, &q);
+          // the delayed samples are not stored: nothing but the filter may read them
+          for (size_t k = 0; k < b->steps.size() && fb >= 0; k++) {
+            if (k == bodies[1]) continue;
+            const StepIo io = step_io(b->steps[k]);
+            if (std::find(io.reads.begin(), io.reads.end(), (const void*)rd.chain.out.base) != io.reads.end()) fb = -1;
+          }
+          for (const Node& an : b->nodes)
+            if (an.live && an.sig.base == rd.chain.out.base && (an.desc.kind == WAA_NODE_ANALYSER || an.desc.kind == WAA_NODE_DESTINATION)) fb = -1;
+          if (fb >= 0) {
+            rd.echo_fused = true;
+            fl.echo_fused = true;
+            sm.echo_fb = fb;
+            sm.echo_chunk = chunk;
+            sm.echo_bq = q;
+            sm.profile_slot = slot_for(b, "echo_ring_kernel");
+            plan_note(b, "  ... rendered by the LDS-ring kernel in ONE launch with the Biquad between the delayed read and the sum: delay %.0f .. %.0f frames, chunks of %d frames",
+                      (double)range[0], (double)range[1], chunk * 256);
           }
         }
       }

@@ -15,6 +15,63 @@ namespace host {
 // the ring kernel renders that sum as well and the line is never stored (waa_echo.hip, "the tail").  Decided on the finished
 // launch list, buffer by buffer, with the same read / write sets the validation below uses; any launch kind those sets do
 // not describe keeps the plan as it is.
+// The filtered echo (Step::echo_bq): two signals could leave the launch — the delay line (read inside the launch by the fused
+// delayed read) and the filter's output y (read by the loop's sum).  Each is stored only for readers outside the launch; when y
+// has exactly one, a later plain sum of y and of signals the loop reads anyway, that sum is rendered by the launch as well.
+static void fuse_filtered_echo_tail(waa_batch* b, size_t l) {
+  Step& ls = b->steps[l];
+  const void* line = ls.chain.out.base;
+  const void* y = ls.echo_bq.y.base;
+  int line_readers = 0, y_readers = 0;
+  size_t reader = 0;
+  bool other_writer = false;
+  for (size_t k = 0; k < b->steps.size(); k++) {
+    if (k == l) continue;
+    const Step& sk = b->steps[k];
+    if (sk.echo_fused && sk.group == ls.group) continue;  // (the delayed read and the filter: inside the launch)
+    const StepIo io = step_io(sk);
+    auto delayed_from = [&](const InputRef& in) { return in.kind == IN_DELAYED && in.sig.base == line; };
+    bool rl = std::find(io.reads.begin(), io.reads.end(), line) != io.reads.end();
+    if (sk.kind == 0)
+      for (int q = 0; q < sk.chain.n_inputs; q++) rl |= delayed_from(sk.chain.in[q]);
+    rl |= (sk.kind == 1 && delayed_from(sk.bq.in)) || (sk.kind == 6 && delayed_from(sk.iir.in)) || (sk.kind == 19 && delayed_from(sk.lanes.in));
+    line_readers += rl ? 1 : 0;
+    if (std::find(io.reads.begin(), io.reads.end(), y) != io.reads.end()) {
+      y_readers++;
+      reader = k;
+    }
+    other_writer |= std::find(io.writes.begin(), io.writes.end(), y) != io.writes.end() ||
+                    std::find(io.writes.begin(), io.writes.end(), line) != io.writes.end();
+  }
+  bool line_alias = false, y_alias = false;  // (analyser / destination nodes that alias a signal are read outside the launch list)
+  for (const Node& an : b->nodes)
+    if (an.live && (an.desc.kind == WAA_NODE_ANALYSER || an.desc.kind == WAA_NODE_DESTINATION)) {
+      line_alias |= an.sig.base == line;
+      y_alias |= an.sig.base == y;
+    }
+  if (other_writer) return;  // (everything stays stored)
+  ls.echo_bq.store_line = line_readers > 0 || line_alias ? 1 : 0;
+  ls.echo_bq.store_y = y_readers > 0 || y_alias ? 1 : 0;
+  if (y_readers == 1 && !y_alias && reader > l) {
+    Step& ts = b->steps[reader];
+    EchoTail t{};
+    const char* why = "it is not an element-wise launch";
+    if (ts.kind == 0 && ts.group < 0 && echo_tail_applicable(ls.chain, ls.echo_fb, ts.chain, &t, &why, &ls.echo_bq)) {
+      t.store_line = ls.echo_bq.store_line;
+      ls.echo_tail = t;
+      ls.echo_tail_step = (int)reader;
+      ts.echo_fused = true;
+      ls.echo_bq.store_y = 0;
+      plan_note(b, "filtered echo loop: launch %zu (the only reader of the filter's output: %d input(s) -> %d channel(s)) is rendered by the LDS-ring kernel too; the filter's output is not stored",
+                reader, t.n_inputs, t.in_nch);
+    } else {
+      plan_note(b, "filtered echo loop: launch %zu, the only reader of the filter's output, is not a plain sum of it and of the loop's inputs (%s): the output is stored", reader, why);
+    }
+  }
+  plan_note(b, "filtered echo loop: the delay line is %s, the filter's output is %s", ls.echo_bq.store_line ? "stored (read outside the launch)" : "not stored",
+            ls.echo_bq.store_y ? "stored" : "not stored");
+}
+
 void fuse_echo_tails(waa_batch* b) {
   if (measure_switch("WAA_NO_ECHO_TAIL")) return;
   for (const Step& st : b->steps)
@@ -22,6 +79,10 @@ void fuse_echo_tails(waa_batch* b) {
   for (size_t l = 0; l < b->steps.size(); l++) {
     Step& ls = b->steps[l];
     if (ls.kind != 0 || ls.echo_fb < 0) continue;
+    if (ls.echo_bq.coefs) {
+      fuse_filtered_echo_tail(b, l);
+      continue;
+    }
     const void* line = ls.chain.out.base;
     size_t reader = 0;
     int n_readers = 0;
