@@ -84,10 +84,15 @@ def test_echo_ring_kernel_fits_one_workgroup_of_sixteen_waves(tmp_path):
     and nothing of the walk may live in scratch memory (one operand array indexed by an edge's selector did: 47 scratch loads
     and a hundred waits per chunk)"""
     res = kernel_resources("waa_echo.hip", tmp_path)
-    k = {n: v for n, v in res.items() if "echo_ring_kernel" in n}
+    k = {n: v for n, v in res.items() if "echo_ring_kernel" in n and "Lb1EEEvN" not in n}   # (BQ = false)
     assert len(k) == 8, sorted(res)
     for name, r in k.items():
         assert r["vgpr"] <= 128 and r["spill"] == 0 and r["scratch"] == 0, (name, r)
+    # the BQ form (a Biquad between the ring and the sum, round 4): eight waves, 256 registers each, nothing in scratch
+    bq = {n: v for n, v in res.items() if "echo_ring_kernel" in n and "Lb1EEEvN" in n}
+    assert len(bq) == 10, sorted(res)
+    for name, r in bq.items():
+        assert r["vgpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (name, r)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")

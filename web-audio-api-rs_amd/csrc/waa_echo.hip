@@ -119,7 +119,8 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
   __shared__ double wz[BQ ? ECHO_BQ_WAVES : 1][C][2];  // zero-state end states (y1, y2) of the waves' sub-tiles of this chunk
   [[maybe_unused]] double b0 = 0., b1 = 0., b2 = 0., a1 = 0., a2 = 0.;
   [[maybe_unused]] M2e P[6], A64{}, PL{};   // A^(2^k), A^64 (A = M^4) — uniform; A^lane — per lane
-  [[maybe_unused]] double ys[C][2];         // y state (y1, y2) in front of the chunk at hand: the same value in every lane
+  __shared__ double ystate[2][C][2];        // y state (y1, y2) in front of the chunk at hand, by chunk parity (the last wave writes the next one's)
+  [[maybe_unused]] uint32_t parity = 0;
   [[maybe_unused]] float* py[C];
   if constexpr (BQ) {
     __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);  // f64 denormals flushed (FTZ/DAZ render scope, thread.rs:374-382)
@@ -141,10 +142,9 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
     }
     A64 = m;
 #pragma unroll
-    for (int c = 0; c < C; c++) {
-      ys[c][0] = ys[c][1] = 0.;
-      py[c] = bq.y.base + (uint64_t)inst * bq.y.inst_stride + (uint64_t)c * bq.y.ch_stride;
-    }
+    for (int c = 0; c < C; c++) py[c] = bq.y.base + (uint64_t)inst * bq.y.inst_stride + (uint64_t)c * bq.y.ch_stride;
+    if (tid < 2 * C * 2) (&ystate[0][0][0])[tid] = 0.;
+    __syncthreads();
   }
   // DelayReader's position arithmetic (delay.rs:560-569), one delayTime per instance
   const float dv = echo_delay_value(t.delay, inst);
@@ -158,6 +158,11 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
   const uint32_t last_q = d.n_quanta - 1;
 
   // ---- the walk's constants
+  // (BQ: the pointer tables are kept in VECTOR registers — an opaque per-lane zero is added to each: the 8-wave form has 256 of
+  // those and the same ~100 scalar registers, which the tables plus the filter's constants overflowed: 130 spill reloads per chunk)
+  uint32_t vz32 = 0;
+  if constexpr (BQ) asm volatile("v_mov_b32 %0, 0" : "=v"(vz32));
+  const uint64_t vz = vz32;
   const float* px[ECHO_EXT][C];  // slot -> channel rows of this instance
   uint32_t vlim[ECHO_EXT];       // ... and the frames that may be read (zeros beyond)
 #pragma unroll
@@ -167,34 +172,43 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
     const InputRef& in = d.in[k];
 #pragma unroll
     for (int c = 0; c < C; c++)
-      px[sl][c] = in.sig.base + (uint64_t)inst * in.sig.inst_stride + (uint64_t)(c < in.nch ? c : 0) * in.sig.ch_stride;
+      px[sl][c] = in.sig.base + (uint64_t)inst * in.sig.inst_stride + (uint64_t)(c < in.nch ? c : 0) * in.sig.ch_stride + vz;
     vlim[sl] = in.valid == 0 || in.valid > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)in.valid;
   }
   const float* pg[NG];   // edge -> its gain values (an edge without a gain: a word of its signal, unused)
   uint32_t gstep[NG];    // 1: one value per quantum, 0: one per instance
-  bool is_d[NG], is_a[NG];  // operand of the edge: the delayed line / slot 0 (neither: slot 1)
-  bool present[NG], has_gain[NG], up[NG];
+  // per-edge flags as bit masks (bit k = edge k): is_d / is_a = operand of the edge: the delayed line / slot 0 (neither: slot 1).
+  // (as bool arrays every flag was a 64-bit lane mask in two scalar registers: 60 of them, most of them spilled)
+  uint32_t m_is_d = 0, m_is_a = 0, m_present = 0, m_has_gain = 0, m_up = 0;
 #pragma unroll
   for (int k = 0; k < NG; k++) {
     const bool tail = k >= NL;
     const int kk = tail ? k - NL : k;
-    present[k] = kk < (tail ? t.n_inputs : d.n_inputs);
-    const InputRef& in = tail ? t.in[present[k] ? kk : 0] : d.in[present[k] ? kk : 0];
-    has_gain[k] = present[k] && in.has_gain;
-    pg[k] = !has_gain[k] ? in.sig.base : in.gain.mode == 0 ? in.gain.base + inst : in.gain.base + (uint64_t)inst * in.gain.stride;
-    gstep[k] = has_gain[k] && in.gain.mode != 0 ? 1u : 0u;
+    const bool pres = kk < (tail ? t.n_inputs : d.n_inputs);
+    const InputRef& in = tail ? t.in[pres ? kk : 0] : d.in[pres ? kk : 0];
+    const bool hg = pres && in.has_gain;
+    pg[k] = (!hg ? in.sig.base : in.gain.mode == 0 ? in.gain.base + inst : in.gain.base + (uint64_t)inst * in.gain.stride) + vz;
+    gstep[k] = (uint32_t)__builtin_amdgcn_readfirstlane(hg && in.gain.mode != 0 ? -1 : 0);  // (a 32-bit mask, not a lane mask)
+    m_present |= (pres ? 1u : 0u) << k;
+    m_has_gain |= (hg ? 1u : 0u) << k;
     const int slot = tail ? t.alias[kk < MAX_INPUTS ? kk : 0] : (kk == fb ? -2 : kk - (kk > fb ? 1 : 0));
-    is_d[k] = slot < 0;
-    is_a[k] = slot == 0;
-    up[k] = in.nch == 1 && (tail ? t.in_nch : d.in_nch) == 2;
+    m_is_d |= (slot < 0 ? 1u : 0u) << k;
+    m_is_a |= (slot == 0 ? 1u : 0u) << k;
+    m_up |= (in.nch == 1 && (tail ? t.in_nch : d.in_nch) == 2 ? 1u : 0u) << k;
   }
+  m_is_d = (uint32_t)__builtin_amdgcn_readfirstlane((int)m_is_d);
+  m_is_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)m_is_a);
+  m_present = (uint32_t)__builtin_amdgcn_readfirstlane((int)m_present);
+  m_has_gain = (uint32_t)__builtin_amdgcn_readfirstlane((int)m_has_gain);
+  m_up = (uint32_t)__builtin_amdgcn_readfirstlane((int)m_up);
+  auto bit = [](uint32_t m, int k) { return ((m >> k) & 1u) != 0; };
   const bool l_discrete = d.in_interp == 1, t_discrete = t.in_interp == 1;
   float* po[C];
   float* pt[CT > 0 ? CT : 1];
 #pragma unroll
   for (int c = 0; c < C; c++) po[c] = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride;
 #pragma unroll
-  for (int c = 0; c < CT; c++) pt[c] = t.out.base + (uint64_t)inst * t.out.inst_stride + (uint64_t)c * t.out.ch_stride;
+  for (int c = 0; c < CT; c++) pt[c] = t.out.base + (uint64_t)inst * t.out.inst_stride + (uint64_t)c * t.out.ch_stride + vz;
 
   auto fetch = [&](uint32_t sub_n, EchoOperands<C, NG>& o) __attribute__((always_inline)) {
     const uint32_t fn = f_first + sub_n * 256u + (uint32_t)lane * 4u;
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
       }
     }
 #pragma unroll
-    for (int k = 0; k < NG; k++) o.g[k] = load_global(pg[k] + qcn * gstep[k]);
+    for (int k = 0; k < NG; k++) o.g[k] = load_global(pg[k] + (qcn & gstep[k]));
   };
 
   // gain.rs:163-179 on an input edge (one value for the quantum), then quantum.rs' up-mix 1 -> 2: copy (speakers) /
@@ -229,8 +243,8 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
 #pragma unroll
     for (int c = 0; c < C; c++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) u[c][e] = is_d[k] ? xd[c][e] : (is_a[k] ? xa[c][e] : xb[c][e]);
-    if (has_gain[k]) {
+      for (int e = 0; e < 4; e++) u[c][e] = bit(m_is_d, k) ? xd[c][e] : (bit(m_is_a, k) ? xa[c][e] : xb[c][e]);
+    if (bit(m_has_gain, k)) {
       const bool mute = fabsf(g) <= 1e-6f, pass = fabsf(1.f - g) <= 1e-6f;
 #pragma unroll
       for (int c = 0; c < C; c++)
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
         for (int e = 0; e < 4; e++) u[c][e] = mute ? 0.f : (pass ? u[c][e] : u[c][e] * g);
     }
     if (CM == 2) {
-      if (up[k]) {
+      if (bit(m_up, k)) {
 #pragma unroll
         for (int e = 0; e < 4; e++) u[CM - 1][e] = discrete ? 0.f : u[0][e];
       }
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
     float v[C][4];
 #pragma unroll
     for (int k = 0; k < NL; k++) {
-      if (!present[k]) continue;
+      if (!bit(m_present, k)) continue;
       float u[CM][4];
       edge(k, o.g[k], l_discrete, xd, xa, xb, u);
 #pragma unroll
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
       float w[CM][4];
 #pragma unroll
       for (int k = 0; k < NT; k++) {
-        if (!present[NL + k]) continue;
+        if (!bit(m_present, NL + k)) continue;
         float u[CM][4];
         edge(NL + k, o.g[NL + k], t_discrete, xd, xa, xb, u);
 #pragma unroll
@@ -348,9 +362,10 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
 #pragma unroll
           for (int c = 0; c < C; c++) {
             const double q1 = __shfl_up(r1[c], dd, 64), q2 = __shfl_up(r2[c], dd, 64);
-            if (lane >= dd) {
+            if (lane >= dd) {  // (a real branch on the execution mask: as selects it was 8 more instructions per step and channel)
               r1[c] = __builtin_fma(P[k].a, q1, __builtin_fma(P[k].b, q2, r1[c]));
               r2[c] = __builtin_fma(P[k].c, q1, __builtin_fma(P[k].d, q2, r2[c]));
+              asm volatile("" : "+v"(r1[c]), "+v"(r2[c]));
             }
           }
         }
@@ -363,29 +378,36 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      // ---- this wave's incoming state, and the state behind the chunk (every wave keeps its own copy)
+      // ---- this wave's incoming state: the chunk's starting state pushed through the sub-tiles in front of this wave's (a uniform
+      // branch per step: wave w runs w of them); the last wave goes one further and leaves the next chunk's starting state
       double s1[C], s2[C];
 #pragma unroll
       for (int c = 0; c < C; c++) {
-        double t1 = ys[c][0], t2 = ys[c][1];
-        s1[c] = t1;
-        s2[c] = t2;
+        double t1 = ystate[parity][c][0], t2 = ystate[parity][c][1];
+        double z1[ECHO_BQ_WAVES], z2[ECHO_BQ_WAVES];
 #pragma unroll
         for (int j = 0; j < ECHO_BQ_WAVES; j++) {
-          if ((uint32_t)j < cs) {
-            if ((uint32_t)j == wave) {
-              s1[c] = t1;
-              s2[c] = t2;
-            }
-            const double n1 = __builtin_fma(A64.a, t1, __builtin_fma(A64.b, t2, wz[j][c][0]));
-            const double n2 = __builtin_fma(A64.c, t1, __builtin_fma(A64.d, t2, wz[j][c][1]));
+          z1[j] = wz[j][c][0];
+          z2[j] = wz[j][c][1];
+        }
+#pragma unroll
+        for (int j = 0; j < ECHO_BQ_WAVES - 1; j++) {
+          if ((uint32_t)j < wave) {
+            const double n1 = __builtin_fma(A64.a, t1, __builtin_fma(A64.b, t2, z1[j]));
+            const double n2 = __builtin_fma(A64.c, t1, __builtin_fma(A64.d, t2, z2[j]));
             t1 = n1;
             t2 = n2;
+            asm volatile("" : "+v"(t1), "+v"(t2));
           }
         }
-        ys[c][0] = t1;
-        ys[c][1] = t2;
+        s1[c] = t1;
+        s2[c] = t2;
+        if (wave + 1u == cs && lane == 63 && live) {  // (lane 63 holds the wave's own end state in r1 / r2)
+          ystate[parity ^ 1u][c][0] = __builtin_fma(A64.a, t1, __builtin_fma(A64.b, t2, r1[c]));
+          ystate[parity ^ 1u][c][1] = __builtin_fma(A64.c, t1, __builtin_fma(A64.d, t2, r2[c]));
+        }
       }
+      parity ^= 1u;
       if (live) {
         float yo[C][4];
 #pragma unroll
