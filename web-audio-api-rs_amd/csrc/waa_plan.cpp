@@ -1552,10 +1552,6 @@ int build_plan(waa_batch* b) {
   };
   // planning units: single nodes and whole feedback loops, producers first (the condensed graph is acyclic),
   // otherwise in processing order
-  struct Unit {
-    int scc;
-    uint32_t id;
-  };
   std::vector<Unit> units;
   {
     std::vector<uint8_t> node_done(N, 0), scc_done(n_scc, 0);
@@ -1777,337 +1773,8 @@ int build_plan(waa_batch* b) {
   if (b->prepass && (count_change_found || b->force_dynamic))
     return fail(WAA_ERR_OUT_OF_SCOPE, "the graph that modulates a source's playbackRate / detune needs exact per-quantum channel counts: out of scope");
   if (count_change_found || b->force_dynamic) {
-    if (!count_change_found && mixed_buffer_counts)
-      plan_note(b, "instances play AudioBuffers of different channel counts -> per-instance counts through dyn_kernel");
-    else if (!count_change_found)
-      plan_note(b, "a feedback loop needs quantum-serial rendering with node kinds the loop kernel does not cover -> dyn_kernel");
-    b->dynamic = true;
-    b->code_stride = ((uint64_t)b->n_quanta + 15) & ~(uint64_t)15;
-    const uint64_t cs = b->code_stride;
-    for (uint32_t id = 0; id < N; id++) {
-      const Node& n = b->nodes[id];
-      // layouts up to 5.1 are rendered by dyn_kernel<6> (round 3) for Gain / Biquad / IIR / WaveShaper / the panners / DelayNodes
-      // (whose line is then re-mixed in place when the count changes) / analysers (whose kernel follows the per-quantum codes)
-      // / the destination; convolver and frozen-node inputs are stereo by their channel config: those stay mono / stereo
-      const uint32_t k = n.desc.kind;
-      const bool narrow_only = (k == WAA_NODE_CONVOLVER && n.has_ir) || is_frozen_node(n);
-      if (n.live && narrow_only && (n.in_nch > 2 || n.out_nch > 2))
-        return fail(WAA_ERR_OUT_OF_SCOPE,
-                    "node %u: the reference's channel count changes mid-render and a signal is wider than stereo (%d channels): "
-                    "exact dynamic counts above stereo are not rendered for this node kind",
-                    id, std::max(n.in_nch, n.out_nch));
-    }
-    auto is_src = [&](uint32_t k) { return k == WAA_NODE_BUFFER_SOURCE || k == WAA_NODE_CONSTANT_SOURCE || k == WAA_NODE_OSCILLATOR; };
-    auto alloc_codes = [&](uint8_t** out) -> int { return dev_alloc(b, out, (size_t)b->n_inst * cs); };
-    for (auto& n : b->nodes) n.materialized = n.live;  // every signal is published
-    // position of every vertex in the processing order
-    std::map<uint32_t, size_t> vpos;
-    for (size_t k = 0; k < items.size(); k++) vpos[items[k]] = k;
-    std::vector<uint32_t> pending;        // vertices of the current group
-    std::set<uint32_t> pending_nodes;     // their node ids
-    std::vector<uint8_t> planned_node(N, 0);
-    auto in_pending = [&](uint32_t node) { return pending_nodes.count(node) != 0; };
-    // ---- host-known codes of a source: active quanta carry the source's channel count
-    auto source_codes = [&](uint32_t id) -> int {
-      std::vector<uint8_t> host;
-      int e = source_code_rows(b, id, cs, &host);
-      if (e) return e;
-      uint8_t* dcode = nullptr;
-      if ((e = dev_upload(b, &dcode, host))) return e;
-      b->nodes[id].code = dcode;
-      return 0;
-    };
-    // ---- one dyn_kernel launch for the pending vertices
-    auto flush = [&]() -> int {
-      if (pending.empty()) return 0;
-      std::sort(pending.begin(), pending.end(), [&](uint32_t x, uint32_t y) { return vpos[x] < vpos[y]; });
-      if (pending.size() > (size_t)DYN_MAX_ITEMS)
-        return fail(WAA_ERR_OUT_OF_SCOPE, "more than %d nodes in one dynamic-count group", DYN_MAX_ITEMS);
-      std::map<uint32_t, int> out_item, writer_item;  // node id -> item producing its output / its delay line
-      for (size_t k = 0; k < pending.size(); k++) {
-        const uint32_t v = pending[k], id = v & ~VTX_READER;
-        if (is_delay(b, id) && !(v & VTX_READER))
-          writer_item[id] = (int)k;
-        else
-          out_item[id] = (int)k;
-      }
-      std::vector<DynItem> host(pending.size());
-      Step st;
-      st.kind = 10;
-      std::string desc;
-      for (size_t k = 0; k < pending.size(); k++) {
-        const uint32_t v = pending[k], id = v & ~VTX_READER;
-        Node& n = b->nodes[id];
-        DynItem& li = host[k];
-        std::memset(&li, 0, sizeof li);
-        const bool reader = is_delay(b, id) && (v & VTX_READER);
-        li.cc = n.cc;
-        li.mode = n.mode;
-        li.interp = n.interp;
-        li.code_stride = cs;
-        li.writer_item = -1;
-        if (!reader) {
-          if (n.in_edges.size() > (size_t)DYN_MAX_IN)
-            return fail(WAA_ERR_OUT_OF_SCOPE, "more than %d inputs on node %u of a dynamic-count graph", DYN_MAX_IN, id);
-          li.n_in = (int)n.in_edges.size();
-          for (int j = 0; j < li.n_in; j++) {
-            const uint32_t pid = b->edges[n.in_edges[j]].from;
-            Node& pn = b->nodes[pid];
-            DynInput& in = li.in[j];
-            auto it = out_item.find(pid);
-            if (it != out_item.end()) {
-              // same quantum through LDS; a producer that renders LATER in the quantum is only legal for ... nothing:
-              // the cycle breaker guarantees producers first, except through a delay reader (which reads the line)
-              if (it->second >= (int)k) return fail(WAA_ERR_INVALID_STATE, "internal: dynamic group member order (node %u)", id);
-              in.item = it->second;
-            } else {
-              if (!pn.sig.base || !planned_node[pid])
-                return fail(WAA_ERR_INVALID_STATE, "internal: input %u of node %u is not planned yet", pid, id);
-              in.item = -1;
-              in.nch = pn.out_nch;
-              in.sig = pn.sig;
-              in.code = pn.code;
-              in.remap = pn.remap;
-              in.code_stride = cs;
-              st.loop_reads.push_back(pn.sig.base);
-            }
-          }
-        }
-        char t[64];
-        const uint32_t kind = n.desc.kind;
-        if (is_delay(b, id)) {
-          if (!reader) {
-            li.kind = DI_DELAY_W;
-            li.num_quanta = (int32_t)std::ceil(n.desc.d[0] * (double)b->sr / (double)RQ);  // (ring capacity - 1, as for the reader)
-            int e = temp_signal(b, n.in_nch, &li.out);  // the delay line in absolute time, native layout
-            if (e) return e;
-            li.nch_pub = n.in_nch;
-            if ((e = dev_alloc(b, &li.aux32, (size_t)b->n_inst * cs))) return e;
-            snprintf(t, sizeof t, "delayW%u", id);
-          } else {
-            li.kind = DI_DELAY_R;
-            li.out = n.sig;
-            li.nch_pub = n.out_nch;
-            li.writer_item = writer_item.at(id);
-            li.in_cycle = li.writer_item > (int)k ? 1 : 0;
-            li.num_quanta = (int32_t)std::ceil(n.desc.d[0] * (double)b->sr / (double)RQ);
-            int e = node_param(b, id, WAA_PARAM_DELAY_DELAY_TIME, &li.op.p0);
-            if (e) return e;
-            if ((e = alloc_codes(&n.code))) return e;
-            li.out_code = n.code;
-            snprintf(t, sizeof t, "delayR%u%s", id, li.in_cycle ? "(clamped)" : "");
-          }
-        } else {
-          li.kind = DI_NODE;
-          li.out = n.sig;
-          li.nch_pub = n.out_nch;
-          int e = alloc_codes(&n.code);
-          if (e) return e;
-          li.out_code = n.code;
-          std::vector<OpDesc> ops;
-          int out_nch = 0;
-          if ((kind == WAA_NODE_STEREO_PANNER || kind == WAA_NODE_PANNER) && !is_frozen_node(n)) {
-            // both laws: the gains for a mono input (alt) and for a stereo input (op)
-            const int keep = n.in_nch;
-            n.in_nch = 1;
-            e = emit_node_ops(b, id, 1, true, ops, &out_nch);
-            if (!e) {
-              li.alt1 = ops[0].p1;
-              li.alt2 = ops[0].p2;
-              ops.clear();
-              n.in_nch = 2;
-              e = emit_node_ops(b, id, 2, true, ops, &out_nch);
-            }
-            n.in_nch = keep;
-            if (e) return e;
-          } else if ((kind == WAA_NODE_CONVOLVER && n.has_ir) || is_frozen_node(n)) {
-            // (the mixed input of the node; its node-major steps follow the launch)
-          } else {
-            if ((e = emit_node_ops(b, id, n.in_nch, true, ops, &out_nch))) return e;
-          }
-          if (ops.size() > 1) return fail(WAA_ERR_DEVICE, "internal: node %u emitted %zu ops", id, ops.size());
-          li.dk = DK_PASS;
-          if (!ops.empty()) {
-            li.op = ops[0];
-            switch (ops[0].kind) {
-              case OP_GAIN: li.dk = DK_GAIN; break;
-              case OP_BIQUAD: li.dk = DK_BIQUAD; break;
-              case OP_IIR: li.dk = DK_IIR; break;
-              case OP_WAVESHAPER: li.dk = DK_WAVESHAPER; break;
-              case OP_STEREO_PAN: li.dk = DK_STEREO_PAN; break;
-              case OP_PANNER: li.dk = DK_PANNER; break;
-              default: return fail(WAA_ERR_DEVICE, "internal: op %d in a dynamic-count group", ops[0].kind);
-            }
-          }
-          if (kind == WAA_NODE_WAVESHAPER && !is_frozen_node(n)) {
-            li.dk = DK_WAVESHAPER;  // (without a curve: ptr0 == null, output = input)
-            const size_t cn = n.curve.size();
-            const float mid = cn == 0 ? 0.f : (cn % 2 ? n.curve[cn / 2] : (n.curve[cn / 2 - 1] + n.curve[cn / 2]) / 2.f);
-            li.flags = (!n.has_curve || cn == 0 || std::fabs(mid) < 1e-9f) ? 1 : 0;
-          }
-          if (kind == WAA_NODE_CONVOLVER && !n.has_ir) li.flags |= 2;
-          if (kind == WAA_NODE_ANALYSER) li.publish_upmix = 1;  // the analyser FFT reads a static stereo signal
-          if (is_frozen_node(n)) {
-            // the item publishes the node's INPUT (n.hist) and its codes; n.sig is written by the node-major steps
-            li.dk = DK_CONV_IN;
-            int e2 = temp_signal(b, n.in_nch, &n.hist);
-            if (e2) return e2;
-            li.out = n.hist;
-            li.nch_pub = n.in_nch;
-            if ((e2 = alloc_codes(&n.in_code))) return e2;
-            li.out_code = n.in_code;
-            li.publish_upmix = 1;
-          }
-          if (kind == WAA_NODE_CONVOLVER && n.has_ir) {
-            li.dk = DK_CONV_IN;
-            // the item publishes the convolver's INPUT (n.hist); its output signal n.sig is written by the FFT steps
-            int e2 = temp_signal(b, n.in_nch, &n.hist);
-            if (e2) return e2;
-            li.out = n.hist;
-            li.nch_pub = n.in_nch;
-            if ((e2 = alloc_codes(&n.in_code))) return e2;
-            li.out_code = n.in_code;
-            if (n.ir_nch == 1 && n.in_nch == 2) {
-              li.compact_ch1 = 1;
-              if ((e2 = dev_alloc(b, &n.remap, (size_t)b->n_inst * cs))) return e2;
-              li.aux32 = n.remap;
-              // channel 1 is written in compacted time: quanta it never reaches must read as zeros
-              b->state_bufs.push_back({n.hist.base, (size_t)b->n_inst * n.hist.inst_stride * sizeof(float)});
-            } else {
-              li.publish_upmix = 1;
-            }
-          }
-          snprintf(t, sizeof t, "%s%u", li.dk == DK_PASS ? "pass" : li.dk == DK_CONV_IN ? "convIn" : op_name(li.op.kind), id);
-        }
-        st.loop_writes.push_back(li.out.base);
-        desc += desc.empty() ? t : std::string(",") + t;
-      }
-      DynItem* dev = nullptr;
-      int e = dev_upload(b, &dev, host);
-      if (e) return e;
-      DynDesc& d = st.dyn;
-      std::memset(&d, 0, sizeof d);
-      d.items = dev;
-      d.n_items = (int32_t)host.size();
-      d.n_inst = b->n_inst;
-      d.n_quanta = b->n_quanta;
-      d.sample_rate = (double)b->sr;
-      d.quantum_duration = (double)RQ * (1. / (double)b->sr);  // delay.rs:546-548
-      d.cmax = 1;
-      for (uint32_t v : pending) {
-        const Node& pn = b->nodes[v & ~VTX_READER];
-        d.cmax = std::max(d.cmax, std::max(pn.in_nch, pn.out_nch));
-        for (int e : pn.in_edges) d.cmax = std::max(d.cmax, b->nodes[b->edges[e].from].out_nch);
-      }
-      if (dyn_lds_bytes(d.n_items, d.cmax) > 160 * 1024)
-        return fail(WAA_ERR_OUT_OF_SCOPE, "dynamic-count group of %d nodes with %d-channel signals does not fit the kernel's local memory",
-                    d.n_items, d.cmax);
-      st.profile_slot = slot_for(b, "dyn_kernel");
-      b->steps.push_back(st);
-      plan_note(b, "dynamic-count group: %d item(s) per quantum [%s]", d.n_items, desc.c_str());
-      for (uint32_t v : pending) planned_node[v & ~VTX_READER] = 1;
-      pending.clear();
-      pending_nodes.clear();
-      return 0;
-    };
-    for (const Unit& unit : units) {
-      std::vector<uint32_t> verts;
-      if (unit.scc >= 0) {
-        for (uint32_t v : items)
-          if (scc_of[v & ~VTX_READER] == unit.scc) verts.push_back(v);
-      } else {
-        if (is_delay(b, unit.id)) verts.push_back(unit.id);
-        verts.push_back(is_delay(b, unit.id) ? (unit.id | VTX_READER) : unit.id);
-      }
-      bool any_live = false;
-      for (uint32_t v : verts) any_live |= b->nodes[v & ~VTX_READER].live;
-      if (!any_live) continue;
-      if (unit.scc >= 0)
-        for (uint32_t v : verts) {
-          const Node& m = b->nodes[v & ~VTX_READER];
-          if (m.desc.kind == WAA_NODE_CONVOLVER && m.has_ir)
-            return fail(WAA_ERR_OUT_OF_SCOPE, "a ConvolverNode inside a feedback loop is out of scope (node %u)", v & ~VTX_READER);
-          if (is_frozen_node(m))
-            return fail(WAA_ERR_OUT_OF_SCOPE, "an oversampled WaveShaperNode / HRTF PannerNode inside a feedback loop is out of scope (node %u)",
-                        v & ~VTX_READER);
-        }
-      // AudioParam inputs are summed by a node-major chain in front of the group: their producers must be complete
-      bool param_dep = false;
-      for (uint32_t v : verts)
-        for (auto& pe : b->nodes[v & ~VTX_READER].pin_edges)
-          for (int e : pe) {
-            const uint32_t from = b->edges[e].from;
-            if (unit.scc >= 0 && scc_of[from] == unit.scc)
-              return fail(WAA_ERR_OUT_OF_SCOPE, "an AudioParam of node %u is modulated from inside its own feedback loop",
-                          v & ~VTX_READER);
-            param_dep |= in_pending(from);
-          }
-      if (param_dep)
-        if (int e = flush()) return e;
-      const uint32_t id = unit.id;
-      Node& n = b->nodes[id];
-      if (unit.scc < 0 && is_src(n.desc.kind)) {
-        int e = alloc_signal(n);
-        if (e) return e;
-        if (n.desc.kind == WAA_NODE_OSCILLATOR)
-          e = plan_oscillator(b, id);
-        else
-          e = plan_single(id);
-        if (e) return e;
-        if ((e = source_codes(id))) return e;
-        planned_node[id] = 1;
-        continue;
-      }
-      for (uint32_t v : verts) {
-        Node& m = b->nodes[v & ~VTX_READER];
-        if (!m.sig.base) {
-          int e = alloc_signal(m);
-          if (e) return e;
-        }
-        if (std::find(pending.begin(), pending.end(), v) == pending.end()) pending.push_back(v);
-        pending_nodes.insert(v & ~VTX_READER);
-      }
-      if (unit.scc < 0 && is_frozen_node(n)) {
-        // the group ends with the node's mixed input and its codes; then the link table (which also writes the node's
-        // output codes) and the node-major steps
-        if (int e = flush()) return e;
-        if (!n.in_code) return fail(WAA_ERR_INVALID_STATE, "internal: input codes of node %u", id);
-        int e = n.desc.kind == WAA_NODE_PANNER ? plan_hrtf(b, id, -1) : plan_oversampler(b, id, -1);
-        if (e) return e;
-      }
-      if (unit.scc < 0 && n.desc.kind == WAA_NODE_CONVOLVER && n.has_ir) {
-        // the group ends with the convolver's mixed input; then the node-major FFT steps and the code kernel
-        if (int e = flush()) return e;
-        uint8_t* in_code = n.in_code;  // published by the DK_CONV_IN item of the group just flushed
-        if (!in_code) return fail(WAA_ERR_INVALID_STATE, "internal: convolver input codes");
-        int e = plan_convolver(b, id);
-        if (e) return e;
-        if ((e = alloc_codes(&n.code))) return e;
-        Step cst;
-        cst.kind = 11;
-        ConvCodeDesc& cd = cst.ccode;
-        std::memset(&cd, 0, sizeof cd);
-        cd.in_code = in_code;
-        cd.out_code = n.code;
-        cd.code_stride = cs;
-        cd.impulse_length = n.ir_len;
-        cd.ir_nch = n.ir_nch;
-        cd.n_inst = b->n_inst;
-        cd.n_quanta = b->n_quanta;
-        // (a mono impulse response on a stereo input keeps channel 1 in compacted time: only channel 0 is cleared in place)
-        cd.cout = (n.ir_nch == 1 && n.in_nch == 2) ? 1 : n.out_nch;
-        cd.out = n.sig;
-        if ((e = dev_alloc(b, &cd.clean, (size_t)b->n_inst * cs))) return e;
-        cst.loop_writes.push_back(n.sig.base);
-        cst.profile_slot = slot_for(b, "conv_code_kernel");
-        b->steps.push_back(cst);
-      }
-    }
-    if (int e = flush()) return e;
-    if (measure_switch("WAA_DEBUG_REVERSE_PLAN")) std::reverse(b->steps.begin(), b->steps.end());
-    if (int e = validate_plan(b)) return e;
-    b->planned = true;
-    return 0;
+    DynPlanCtx dc{items, units, scc_of, alloc_signal, plan_single, count_change_found, mixed_buffer_counts};
+    return plan_dynamic_groups(b, dc);
   }
   // chains, in processing order of their terminal node
   for (const Unit& unit : units) {

@@ -1,6 +1,7 @@
 // waa_plan_parts.hpp — what the parts of the planner share (waa_plan.cpp: order, liveness, chains, dynamic groups;
 // waa_plan_sources.cpp, waa_plan_loops.cpp, waa_plan_conv.cpp, waa_plan_ops.cpp, waa_plan_check.cpp).  Host only.
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "waa_host.hpp"
@@ -14,6 +15,21 @@ struct StepIo {
   bool feedback_reader = false;
 };
 struct OrderCtx;
+// planning units: single nodes and whole feedback loops (scc >= 0), producers first
+struct Unit {
+  int scc;
+  uint32_t id;
+};
+// what build_plan hands to the dynamic-group builder (waa_plan_dyn.cpp)
+struct DynPlanCtx {
+  const std::vector<uint32_t>& items;   // vertices in processing order (two per DelayNode)
+  const std::vector<Unit>& units;
+  const std::vector<int>& scc_of;
+  std::function<int(Node&)> alloc_signal;
+  std::function<int(uint32_t)> plan_single;
+  bool count_change_found, mixed_buffer_counts;
+};
+int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c);
 // vertices of the expanded graph the cycle breaker works on: a DelayNode is two (writer `id`, reader `id | VTX_READER`)
 constexpr uint32_t VTX_READER = 0x80000000u;
 
