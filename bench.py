@@ -76,11 +76,12 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
     if name == "echo":
         node.connect(ctx.destination())
         node = node.connect(ctx.create_delay(1.0, delay_time=0.25)).connect(ctx.create_gain(gain=0.5))
-    if name in ("fb", "fbq"):  # feedback echo, DelayNode (0.25 s) <-> Gain(0.5) [-> Biquad]
-        delay = ctx.create_delay(1.0, delay_time=0.25)
+    if name in ("fb", "fbq", "comb", "pluck"):  # feedback echo, DelayNode (0.25 s) <-> Gain(0.5) [-> Biquad]
+        # comb / pluck: the same loops with a 10 ms delay (480 frames: a comb filter / a plucked string — shorter than a tile)
+        delay = ctx.create_delay(1.0, delay_time=0.01 if name in ("comb", "pluck") else 0.25)
         src.connect(delay)
         tail = delay
-        if name == "fbq":
+        if name in ("fbq", "pluck"):
             tail = delay.connect(ctx.create_biquad_filter(type_="lowpass", frequency=4000.0))
         tail.connect(ctx.create_gain(gain=0.5)).connect(delay)
         tail.connect(ctx.destination())
@@ -104,7 +105,7 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
 # algorithmic bytes per context-quantum
 ALG_BYTES = {"c2": 2048.0, "c2k": 2048.0, "c5": 2560.0, "c3": 362848.0, "t1": 362848.0 + 2048.0, "c4": 362848.0 + 2048.0 + 512.0}
 ALG_BYTES["c1a"] = 2048.0
-ALG_BYTES["fb"] = ALG_BYTES["fbq"] = 2048.0
+ALG_BYTES["fb"] = ALG_BYTES["fbq"] = ALG_BYTES["comb"] = ALG_BYTES["pluck"] = 2048.0
 ALG_BYTES["fm"] = 1024.0
 ALG_BYTES["osc"] = 1024.0   # no input; 2 output channels x 128 frames x 4 B
 ALG_BYTES["echo"] = 2048.0
@@ -137,6 +138,8 @@ DESCR["fm"] = "two-operator FM: {n} contexts x {s:g} s, Oscillator->Gain(300)->c
 DESCR["osc"] = "subtractive voice: {n} contexts x {s:g} s, Oscillator(sawtooth 110 Hz, detuned)->Biquad(lowpass)->Gain->destination"
 DESCR["echo"] = "feed-forward echo: {n} contexts x {s:g} s, BufferSource->destination + BufferSource->Delay(0.25s)->Gain(0.5)->destination"
 DESCR["fb"] = "feedback echo: {n} contexts x {s:g} s, BufferSource->[Delay(0.25s)<->Gain(0.5)]->destination (+dry)"
+DESCR["comb"] = "comb filter: {n} contexts x {s:g} s, BufferSource->[Delay(10 ms)->Gain(0.5)->back]->destination (+dry)"
+DESCR["pluck"] = "filtered comb (plucked string): {n} contexts x {s:g} s, BufferSource->[Delay(10 ms)->Biquad->Gain(0.5)->back]->destination (+dry)"
 DESCR["fbq"] = "filtered feedback echo: {n} contexts x {s:g} s, BufferSource->[Delay(0.25s)->Biquad->Gain(0.5)->back]->destination (+dry)"
 for _o in IIR_ORDERS:
     DESCR[f"iir{_o}"] = "IIR: {n} contexts x {s:g} s, BufferSource->IIRFilter(Butterworth order %d)->destination" % _o
@@ -318,7 +321,7 @@ def live_pmc(name, n_inst, seconds, timeout_s=240):
 
 
 DEFAULT_INSTANCES = {"c2": 1024, "c2k": 1024, "c1a": 1024, "t1": 1024, "c3": 512, "c4": 512, "c5": 2048}
-F64_WORKLOADS = ("c2", "c2k", "c1a", "t1", "c4", "fbq", "osc")
+F64_WORKLOADS = ("c2", "c2k", "c1a", "t1", "c4", "fbq", "pluck", "osc")
 
 
 def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, local_rank, dist, backend, sustain_s=0.0):

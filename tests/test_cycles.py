@@ -817,3 +817,75 @@ def test_parity_filtered_echo_loop_from_the_lds_ring(hip, orc, channels, out_cha
     plain, plan = _filtered_echo_graph(hip, noise, delays, gains, variant, out_channels)
     assert "with the Biquad between" not in plan
     assert np.abs(plain - ring).max() <= 4e-6 * scale
+
+
+SHORT_DELAYS = (np.float64([266, 300.5, 511.25, 777, 1031, 2040]) / 48000.0).astype(np.float32)   # all below one 2048-frame tile
+
+
+@pytest.mark.measure
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,out_channels", [(1, 2), (2, 2)])
+@pytest.mark.parametrize("variant", ["dry+wet", "wet-only", "wet-gain", "two-readers", "two-sources"])
+def test_parity_short_echo_loop_from_the_lds_ring(hip, orc, channels, out_channels, variant, monkeypatch):
+    """feedback delays of a few hundred frames (comb filters, plucked strings): shorter than a tile, so launches per block cannot
+    render them and they used to go to the quantum-serial loop kernel; the ring kernel walks them in chunks of 256 frames with a
+    ring as small as the delays need.  Bit-identical to the oracle and to the loop kernel (WAA_NO_SHORT_RING)"""
+    n, frames = 6, 2048 * 5 + 77
+    noise = white_noise(n, channels, frames, seed0=41)
+    gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
+    ring, plan = _echo_graph(hip, noise, SHORT_DELAYS, gains, variant, out_channels)
+    assert "LDS-ring kernel in ONE launch" in plan and "chunks of 256 frames" in plan and "shorter than a tile" in plan, plan
+    assert "the line's last 4096 frames stay in LDS" in plan   # (2040 + 256 + 8 frames -> 4096)
+    o, _ = _echo_graph(orc, noise, SHORT_DELAYS, gains, variant, out_channels)
+    tol = 2e-6 if variant == "two-readers" else 0.0
+    assert np.abs(ring - o).max() <= tol
+    monkeypatch.setenv("WAA_NO_SHORT_RING", "1")
+    serial, plan = _echo_graph(hip, noise, SHORT_DELAYS, gains, variant, out_channels)
+    assert "LDS-ring kernel" not in plan
+    assert np.abs(serial - ring).max() <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["dry+wet", "wet-gain", "line-reader", "peaking"])
+def test_parity_short_filtered_echo_loop_from_the_lds_ring(hip, orc, variant):
+    """the plucked string: Delay (a few hundred frames) -> Biquad -> Gain -> back, in the ring kernel's BQ form"""
+    n, frames = 6, 2048 * 5 + 77
+    noise = white_noise(n, 2, frames, seed0=42)
+    gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
+    ring, plan = _filtered_echo_graph(hip, noise, SHORT_DELAYS, gains, variant)
+    assert "with the Biquad between the delayed read and the sum" in plan and "chunks of 256 frames" in plan and "shorter than a tile" in plan, plan
+    o, _ = _filtered_echo_graph(orc, noise, SHORT_DELAYS, gains, variant)
+    scale = max(1.0, float(np.abs(o).max()))
+    assert rms_err(ring, o).max() <= 1e-6 * scale
+    assert np.abs(ring - o).max() <= 4e-6 * scale
+
+
+@pytest.mark.gpu
+def test_short_loops_the_ring_kernel_does_not_render_fall_back(hip, orc):
+    """one instance's delay below 264 frames (256-frame chunk + 8), or a member that is not Delay / Gain / constant Biquad: the second
+    planning pass hands the loop to the quantum-serial kernel"""
+    n, frames = 6, 2048 * 3 + 77
+    noise = white_noise(n, 2, frames, seed0=43)
+    gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
+    delays = SHORT_DELAYS.copy()
+    delays[2] = np.float32(200.0 / 48000.0)
+    g, plan = _echo_graph(hip, noise, delays, gains, "dry+wet")
+    assert "LDS-ring kernel" not in plan
+    assert np.abs(g - _echo_graph(orc, noise, delays, gains, "dry+wet")[0]).max() == 0.0
+
+    def shaped(binding):
+        c = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n, binding=binding)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(noise, 48000.0)
+        delay = c.create_delay(0.4, delay_time=0.01)
+        src.connect(delay)
+        delay.connect(c.create_wave_shaper(curve=np.float32([-0.8, 0.0, 0.8]))).connect(c.create_gain(gain=0.6)).connect(delay)
+        delay.connect(c.destination())
+        src.start()
+        plan = c.plan_describe() if binding.prefix == "waa_" else ""
+        out = c.start_rendering_sync().data
+        c.close()
+        return out, plan
+    g, plan = shaped(hip)
+    assert "LDS-ring kernel" not in plan
+    assert np.abs(g - shaped(orc)[0]).max() <= 1e-6

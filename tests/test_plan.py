@@ -390,12 +390,29 @@ def test_lfo_depth_gain_rides_on_the_param_edge(hip):
 
 
 def test_short_delay_loop_uses_the_quantum_serial_kernel(hip):
-    """a loop delay below one 2048-frame tile cannot be block-scheduled"""
+    """a loop delay below one 2048-frame tile cannot be block-scheduled: the quantum-serial kernel renders it — unless the loop has
+    the ring kernel's shape (Delay <-> Gain [-> constant Biquad], delay >= 264 frames), which walks it in 256-frame chunks (round 4)"""
     c, s = _ctx(hip)
-    d = c.create_delay(1.0, delay_time=0.01)
+    d = c.create_delay(1.0, delay_time=0.004)   # 192 frames: below the ring kernel's smallest chunk
     s.connect(d)
     d.connect(c.create_gain(gain=0.5)).connect(d)
     d.connect(c.destination())
     lines = plan(c)
     assert any(l.startswith("feedback loop:") and "item(s) per quantum" in l for l in lines)
     assert not any("block-scheduled" in l for l in lines)
+    c, s = _ctx(hip)
+    d = c.create_delay(1.0, delay_time=0.01)    # 480 frames: the ring kernel, a 1024-frame ring
+    s.connect(d)
+    d.connect(c.create_gain(gain=0.5)).connect(d)
+    d.connect(c.destination())
+    lines = plan(c)
+    assert any("LDS-ring kernel in ONE launch" in l and "chunks of 256 frames" in l and "last 1024 frames" in l for l in lines), lines
+    assert not any("item(s) per quantum" in l for l in lines)
+    c, s = _ctx(hip)
+    d = c.create_delay(1.0, delay_time=0.01)    # the same delay around a WaveShaper: not the ring kernel's shape
+    s.connect(d)
+    d.connect(c.create_wave_shaper(curve=np.float32([-1.0, 0.0, 1.0]))).connect(c.create_gain(gain=0.5)).connect(d)
+    d.connect(c.destination())
+    lines = plan(c)
+    assert any(l.startswith("feedback loop:") and "item(s) per quantum" in l for l in lines)
+    assert not any("LDS-ring" in l for l in lines)

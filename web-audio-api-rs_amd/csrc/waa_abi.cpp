@@ -917,7 +917,7 @@ static int run_steps(waa_batch* b) {
           ChainDesc d = st.echo_line;
           d.tile0 = t0;
           d.tile1 = t1;
-          e = timed(st.profile_slot, [&] { launch_echo_ring(d, d.n_inputs, st.echo_chunk, &st.echo_tail, b->stream); });
+          e = timed(st.profile_slot, [&] { launch_echo_ring(d, d.n_inputs, st.echo_chunk, st.echo_ring, &st.echo_tail, b->stream); });
           break;
         }
         ChainDesc d = st.chain;
@@ -966,7 +966,7 @@ static int run_steps(waa_batch* b) {
         d.tile0 = 0;
         d.tile1 = b->n_tiles;
         int e = timed(bs.profile_slot, [&] {
-          launch_echo_ring(d, bs.echo_fb, bs.echo_chunk, bs.echo_tail_step >= 0 ? &bs.echo_tail : nullptr, b->stream,
+          launch_echo_ring(d, bs.echo_fb, bs.echo_chunk, bs.echo_ring, bs.echo_tail_step >= 0 ? &bs.echo_tail : nullptr, b->stream,
                            bs.echo_bq.coefs ? &bs.echo_bq : nullptr);
         });
         if (e) return e;

@@ -62,7 +62,7 @@ void raise_lds_limit(const void* kernel) {
   }
 }
 
-constexpr int ECHO_RING = 16384;  // frames per channel kept in LDS (two channels: 128 KB)
+constexpr int ECHO_RING = 16384;  // frames per channel kept in LDS AT MOST (two channels: 128 KB); a launch takes the power of two its delays need
 constexpr int ECHO_EXT = 2;        // inputs from outside the loop (held in registers two chunks ahead)
 constexpr int ECHO_TAIL_IN = 3;    // inputs of the fused tail stage: the delayed line and those
 
@@ -109,11 +109,12 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
                                                                                  const EchoBq bq) {
   constexpr int CM = C > CT ? C : CT;
   constexpr int NL = 1 + ECHO_EXT, NT = CT > 0 ? ECHO_TAIL_IN : 0, NG = NL + NT;
-  extern __shared__ __attribute__((aligned(16))) float ring[];  // [C][ECHO_RING]
+  extern __shared__ __attribute__((aligned(16))) float ring[];  // [C][RF]
+  const int RF = __builtin_amdgcn_readfirstlane(t.ring_frames), RM = RF - 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t inst = blockIdx.x;
-  for (int i = tid; i < C * ECHO_RING; i += blockDim.x) ring[i] = 0.f;
+  for (int i = tid; i < C * RF; i += blockDim.x) ring[i] = 0.f;
   __syncthreads();
   // ---- BQ: the filter's constants (one coefficient set per instance) and what the scan needs of them
   __shared__ double wz[BQ ? ECHO_BQ_WAVES : 1][C][2];  // zero-state end states (y1, y2) of the waves' sub-tiles of this chunk
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
   const float dv = echo_delay_value(t.delay, inst);
   const double position = 0. - (double)dv * t.sample_rate;
   const double fl = floor(position);
-  const int32_t pf0 = (int32_t)fl;  // (-ECHO_RING < pf0 < 0: echo_ring_applicable)
+  const int32_t pf0 = (int32_t)fl;  // (-RF < pf0 < 0: echo_ring_applicable / echo_ring_frames)
   const float kf = (float)(position - fl);
   const uint32_t total_sub = (d.tile1 - d.tile0) * (TILE / 256);
   const uint32_t f_first = d.tile0 * TILE;  // (frames fit 31 bits: echo_ring_applicable)
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
 #pragma unroll
     for (int c = 0; c < C; c++) {  // (C == in_nch == out.nch: echo_ring_applicable)
       if (STORE) *reinterpret_cast<float4*>(po[c] + f) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
-      *reinterpret_cast<f4v*>(ring + c * ECHO_RING + (int)(f & (ECHO_RING - 1))) = f4v{v[c][0], v[c][1], v[c][2], v[c][3]};
+      *reinterpret_cast<f4v*>(ring + c * RF + (int)(f & (uint32_t)RM)) = f4v{v[c][0], v[c][1], v[c][2], v[c][3]};
     }
     if (CT > 0) {  // the tail stage: same input arithmetic, its operands the ones the loop stage had
       float w[CM][4];
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
 #pragma unroll
           for (int e = 0; e < 5; e++) {
             const int32_t idx = (int32_t)f + pf0 + e;
-            const float r = ring[c * ECHO_RING + (idx & (ECHO_RING - 1))];
+            const float r = ring[c * RF + (idx & RM)];
             x[e] = idx < 0 || dead ? 0.f : r;
           }
 #pragma unroll
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
 #pragma unroll
           for (int e = 0; e < 7; e++) {
             const int32_t idx = (int32_t)f + pf0 + e - 2;
-            const float r = ring[c * ECHO_RING + (idx & (ECHO_RING - 1))];
+            const float r = ring[c * RF + (idx & RM)];
             x[e] = idx < 0 || dead ? 0.f : r;
           }
 #pragma unroll
@@ -563,9 +564,17 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
   return 1;
 }
 
+int echo_ring_frames(float dmax_frames, int chunk_subtiles) {
+  int need = (int)std::ceil(dmax_frames) + chunk_subtiles * 256 + 8, rf = 1024;
+  while (rf < need && rf < ECHO_RING) rf <<= 1;
+  return rf;
+}
+
 static int echo_chunk_for(float dmin, float dmax) {
   // the frames a chunk reads must lie BEHIND the chunk (delay > chunk) and still be in the ring (delay + chunk < ring)
-  for (int cand : {16, 8, 4})
+  // (round 4: down to ONE sub-tile — a comb filter's / a plucked string's feedback delay of a few hundred frames walks in chunks
+  // of 256 frames, one wavefront per instance, with a ring as small as its delay needs: many instances per CU)
+  for (int cand : {16, 8, 4, 2, 1})
     if ((float)(cand * 256 + 8) <= dmin) return dmax > (float)(ECHO_RING - cand * 256 - 8) ? 0 : cand;
   return 0;
 }
@@ -602,7 +611,7 @@ int echo_bq_applicable(const ChainDesc& rd, const BiquadStreamDesc& f, const Cha
   if ((uint64_t)sum.n_tiles * TILE >= (1ull << 31)) return -1;
   if (fb < 0 || ((uintptr_t)sum.out.base & 15) || (sum.out.ch_stride & 3) || (sum.out.inst_stride & 3)) return -1;
   int ch = 0;
-  for (int cand : {ECHO_BQ_WAVES, 4})
+  for (int cand : {ECHO_BQ_WAVES, 4, 2, 1})
     if (!ch && (float)(cand * 256 + 8) <= delay_min_max_frames[0]) ch = delay_min_max_frames[1] > (float)(ECHO_RING - cand * 256 - 8) ? 0 : cand;
   if (!ch) return -1;
   *chunk_subtiles = ch;
@@ -634,7 +643,7 @@ int echo_feed_forward(const ChainDesc& st, ChainDesc* line, EchoTail* tail, cons
   if (D.feedback) return no("the delay line is written inside a loop");
   if (!(D.offset.mode == 0 || D.offset.mode == 3) || D.delay_hi < D.delay_lo) return no("the delay is not one host-known value per instance");
   const int chunk = echo_chunk_for(D.delay_lo, D.delay_hi);
-  if (!chunk) return no("a delay outside the ring's window");
+  if (chunk < 4) return no("a delay outside the ring's window");  // (chunks below 1024 frames: the tile-parallel launch is the better fit)
   if ((uint64_t)st.n_tiles * TILE >= (1ull << 31)) return no("more than 2^31 frames");
   if (D.nch < 1 || D.nch > 2 || ((uintptr_t)D.sig.base & 15) || (D.sig.ch_stride & 3) || (D.sig.inst_stride & 3))
     return no("the delayed signal is wider than stereo or not 16-byte aligned");
@@ -663,11 +672,13 @@ int echo_feed_forward(const ChainDesc& st, ChainDesc* line, EchoTail* tail, cons
   return chunk;
 }
 
-void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, const EchoTail* tail, void* stream, const EchoBq* bq) {
-  const size_t lds = (size_t)d.in_nch * ECHO_RING * sizeof(float);
+void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, int ring_frames, const EchoTail* tail, void* stream, const EchoBq* bq) {
+  if (ring_frames < 1024 || ring_frames > ECHO_RING || (ring_frames & (ring_frames - 1))) ring_frames = ECHO_RING;
+  const size_t lds = (size_t)d.in_nch * (size_t)ring_frames * sizeof(float);
   const int ct = tail ? tail->in_nch : 0;
   EchoTail t{};
   if (tail) t = *tail;
+  t.ring_frames = ring_frames;
   if (bq) {
     t.delay = bq->delay;
     t.sample_rate = bq->sample_rate;

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <tuple>
@@ -236,7 +237,7 @@ struct Step {
   bool prologue = false;  // inside a group: runs once over the full range before the blocks
   // the only body step of a block-scheduled loop, and the loop qualifies for the LDS-ring kernel (waa_echo.hip): index of
   // the feedback input (-1: no) and the chunk size in 256-frame sub-tiles
-  int echo_fb = -1, echo_chunk = 0;
+  int echo_fb = -1, echo_chunk = 0, echo_ring = 16384;  // (echo_ring: frames per channel of the LDS ring)
   // ... or the LAST of three body steps (delayed read -> streaming biquad -> sum) rendered as the ring kernel's BQ form
   // (echo_bq.coefs != nullptr); the first two are marked echo_fused
   EchoBq echo_bq{};
@@ -283,6 +284,8 @@ struct waa_batch {
   std::vector<std::pair<uint32_t, uint32_t>> prepass_params;  // (source node, param)
   std::vector<waa::ParamRef> prepass_refs;                          // per entry: the per-frame values the summing chain writes
   std::string prepass_note;
+  bool no_short_ring = false;        // second planning pass: a short feedback loop tried as the LDS-ring kernel did not qualify
+  std::set<uint32_t> short_ring_loops;  // DelayNodes of loops shorter than a tile planned for the ring kernel (loop_block_tiles)
   bool force_dynamic = false;        // second planning pass: a loop member the static loop kernel cannot render
   bool dynamic = false;              // the plan renders the reference's dynamic channel counts (dyn_kernel)
   uint64_t code_stride = 0;          // bytes per instance of a code table (n_quanta rounded up)

@@ -786,6 +786,7 @@ int source_code_rows(waa_batch* b, uint32_t id, uint64_t cs, std::vector<uint8_t
 
 int build_plan(waa_batch* b) {
   const uint32_t N = (uint32_t)b->nodes.size();
+  b->short_ring_loops.clear();
   if (int e = materialise_automation(b)) return e;
   for (uint32_t i = 0; i < N; i++)  // the reference takes the coefficients in the constructor
     if (b->nodes[i].desc.kind == WAA_NODE_IIR_FILTER && b->nodes[i].iir_b.empty())
@@ -1890,9 +1891,10 @@ int build_plan(waa_batch* b) {
           if (fb >= 0) {
             b->steps[body].echo_fb = fb;
             b->steps[body].echo_chunk = chunk;
+            b->steps[body].echo_ring = echo_ring_frames(range[1], chunk);
             b->steps[body].profile_slot = slot_for(b, "echo_ring_kernel");
             plan_note(b, "  ... rendered by the LDS-ring kernel in ONE launch: delay %.0f .. %.0f frames, chunks of %d frames, the line's last %d frames stay in LDS",
-                      (double)range[0], (double)range[1], chunk * 256, 16384);
+                      (double)range[0], (double)range[1], chunk * 256, b->steps[body].echo_ring);
           }
         }
         // delayed read -> streaming biquad (constant coefficients) -> sum into the line: the filtered echo, the ring kernel's BQ form
@@ -1919,12 +1921,32 @@ int build_plan(waa_batch* b) {
             fl.echo_fused = true;
             sm.echo_fb = fb;
             sm.echo_chunk = chunk;
+            sm.echo_ring = echo_ring_frames(range[1], chunk);
             sm.echo_bq = q;
             sm.profile_slot = slot_for(b, "echo_ring_kernel");
             plan_note(b, "  ... rendered by the LDS-ring kernel in ONE launch with the Biquad between the delayed read and the sum: delay %.0f .. %.0f frames, chunks of %d frames",
                       (double)range[0], (double)range[1], chunk * 256);
           }
         }
+        // a loop SHORTER than a tile was planned this way only for the ring kernel (loop_block_tiles): launches per block cannot
+        // render it — if it did not qualify, plan the graph again with the quantum-serial loop kernel for such loops
+        bool short_ring = false, qualified = false;
+        for (uint32_t v : loop_items) short_ring |= b->short_ring_loops.count(v & ~VTX_READER) != 0;
+        for (size_t k : bodies) qualified |= b->steps[k].echo_fb >= 0;
+        if (short_ring && !qualified) {
+          b->no_short_ring = true;
+          b->steps.clear();
+          b->group_tiles.clear();
+          b->state_bufs.clear();
+          b->plan_log.clear();
+          for (auto& nd : b->nodes) {
+            nd.sig = SignalRef{};
+            nd.hist = SignalRef{};
+            nd.hist_is_temp = false;
+          }
+          return build_plan(b);
+        }
+        if (short_ring) plan_note(b, "  (a feedback delay shorter than a tile: the ring kernel walks it in chunks shorter than the delay)");
       }
       continue;
     }

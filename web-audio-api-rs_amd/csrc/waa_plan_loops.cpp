@@ -170,6 +170,7 @@ void ring_feed_forward_echoes(waa_batch* b) {
     st.echo_line = line;
     st.echo_tail = t;
     st.echo_chunk = chunk;
+    st.echo_ring = echo_ring_frames(delayed_hi, chunk);
     st.profile_slot = slot_for(b, "echo_ring_kernel");
     plan_note(b, "launch %zu (delayed signal + %d more input(s), no ops) is rendered by the LDS-ring kernel with nothing fed back: delay %.0f .. %.0f frames, chunks of %d frames",
               k, t.n_inputs - 1, (double)delayed_lo, (double)delayed_hi, chunk * 256);
@@ -283,7 +284,41 @@ uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items)
   }
   if (!(dmin < 1e300)) return 0;
   const double tiles = std::ceil(dmin / (double)TILE) - 1.;  // block < delay, strictly
-  if (tiles < 1.) return 0;
+  if (tiles < 1.) {
+    // Shorter than a tile: launches per block cannot render it — but the LDS-ring kernel (waa_echo.hip) walks in chunks down to
+    // 256 frames.  A loop of the shapes it renders (ONE DelayNode with one delayTime per instance, GainNodes, at most one
+    // constant-coefficient Biquad, nothing modulated) is planned like a block-scheduled loop; build_plan checks that the
+    // ring kernel took it and plans again without this branch otherwise (no_short_ring).
+    if (b->no_short_ring || measure_switch("WAA_NO_ECHO_RING") || measure_switch("WAA_NO_SHORT_RING") || dmin < 264.) return 0;
+    int n_delay = 0, n_biquad = 0;
+    uint32_t delay_id = 0;
+    for (uint32_t v : loop_items) {
+      if (v & VTX_READER) continue;
+      const uint32_t id = v & ~VTX_READER;
+      const Node& n = b->nodes[id];
+      for (auto& pe : n.pin_edges)
+        if (!pe.empty()) return 0;
+      switch (n.desc.kind) {
+        case WAA_NODE_DELAY:
+          if (!b->cut[id] || param_mode(n, WAA_PARAM_DELAY_DELAY_TIME) == 1) return 0;  // (one value per quantum: not one per instance)
+          n_delay++;
+          delay_id = id;
+          break;
+        case WAA_NODE_GAIN:
+          if (param_mode(n, WAA_PARAM_GAIN_GAIN) == 2) return 0;
+          break;
+        case WAA_NODE_BIQUAD:
+          for (size_t k = 0; k < n.params.size(); k++)
+            if (param_mode(n, k) != 0) return 0;
+          n_biquad++;
+          break;
+        default: return 0;
+      }
+    }
+    if (n_delay != 1 || n_biquad > 1) return 0;
+    b->short_ring_loops.insert(delay_id);
+    return 1;
+  }
   const uint32_t bt = (uint32_t)std::min(tiles, 64.);
   return bt / conv_tiles * conv_tiles;  // (0: the delay is shorter than the convolver's partition -> quantum-serial -> refused there)
 }
