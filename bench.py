@@ -528,7 +528,15 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
         return best * 1e3, world * n * nq / best
 
     rec = {"note": "host (pinned) -> waa_render_sharded (C ABI: set_buffer_batch -> render -> download_all per sub-batch, pipelined), "
-                   "batch creation and planning included, PCIe-bound; every rank at once, slowest rank's time", "sub_batches": n_sub}
+                   "batch creation and planning included, PCIe-bound; every rank at once, slowest rank's time; the sub-batches' buffers come "
+                   "out of a device arena reserved for the record (waa_device_arena_reserve, what a serving process does once): "
+                   "hipMalloc / hipFree in the pipeline synchronise the device (c2_no_arena_ms: the same call without it)", "sub_batches": n_sub}
+    if world == 1:
+        ms0, _ = run_graph("c2", n_inst, n_sub)
+        rec["c2_no_arena_ms"] = ms0
+    arena_gb = int(os.environ.get("WAA_BENCH_E2E_ARENA_GB", "0" if os.environ.get("WAA_BENCH_SHARE_GPU") else "40"))
+    if arena_gb > 0:
+        hip.check(hip.device_arena_reserve(local_rank, arena_gb << 30))
     if world == 1:
         ms1, _ = run_graph("c2", n_inst, 1)
         rec["c2_single_batch_ms"] = ms1
@@ -545,6 +553,8 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
             rec["c2_pcm16_error"] = repr(e)[:100]
     ms, qps = run_graph("c4", c4_inst, n_sub)
     rec["c4_512_per_gpu_ms"], rec["c4_quanta_per_s"] = ms, round(qps)
+    if arena_gb > 0:
+        hip.check(hip.device_arena_reserve(local_rank, 0))
     return rec
 
 

@@ -206,7 +206,6 @@ void waa_batch_destroy(waa_batch* b) {
       if (!arena_free(b->device, p)) (void)hipFree(p);
     for (void* p : b->payload_allocs)
       if (!arena_free(b->device, p)) (void)hipFree(p);
-    if (b->pcm_out) (void)hipFree(b->pcm_out);
     (void)hipStreamDestroy(b->stream);
   }
   delete b;
@@ -236,6 +235,59 @@ static int upload_buffer(waa_batch* b, const float* const* channels, uint32_t n_
   return 0;
 }
 
+// The data movement of a batch-wide source buffer (waa_source_set_buffer_batch / _pcm16_batch), apart from its allocation:
+// waa_render_sharded registers the buffers first, plans, and fills them when the sub-batch has its turn on the link.
+static int fill_upload(waa_batch* b, const waa_batch::PendingFill& f) {
+  if (f.kind == 0) {
+    // on the batch's own stream (and waited for: the caller may free `data` on return): blocking copies on the null
+    // stream of several host threads serialise, and the upload of one sub-batch could not overlap the download of
+    // another (PCIe is full duplex) — SURVEY 8(e)
+    // (contiguous on both sides -> a plain 1-D copy: those go through the DMA engines, one per direction; pitched 2-D
+    // copies run as a copy kernel and did not overlap with a download on another stream)
+    if (f.stride == f.frames)
+      HIP_TRY(hipMemcpyAsync(f.planes, f.host, (size_t)f.n_items * f.n_ch * f.frames * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    else
+      HIP_TRY(hipMemcpy2DAsync(f.planes, f.stride * sizeof(float), f.host, f.frames * sizeof(float), f.frames * sizeof(float),
+                               (size_t)f.n_items * f.n_ch, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+  }
+  const size_t bytes = (size_t)f.n_items * f.frames * f.n_ch * sizeof(int16_t);
+  hipError_t he = hipMemcpyAsync(f.staging, f.host, bytes, hipMemcpyHostToDevice, b->stream);
+  if (he == hipSuccess) {
+    const bool same = std::fabs(f.src_sr - b->sr) <= 0.1f;
+    waa::DecodeDesc dd{};
+    dd.pcm = f.staging;
+    dd.out = f.planes;
+    dd.frames = f.frames;
+    dd.target_frames = f.target;
+    dd.out_item_stride = (uint64_t)f.n_ch * f.stride;
+    dd.out_ch_stride = f.stride;
+    dd.nch = f.n_ch;
+    dd.n_items = f.n_items;
+    dd.resample = same ? 0 : 1;
+    dd.scale = 1.f;
+    waa::launch_pcm16_resample(dd, b->stream);
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = hipStreamSynchronize(b->stream);
+  if (he != hipSuccess) return fail(WAA_ERR_DEVICE, "HIP error %s in the PCM decode path", hipGetErrorString(he));
+  return 0;
+}
+extern "C++" {
+namespace waa {
+namespace host {
+int fill_pending_uploads(waa_batch* b) {
+  HIP_TRY(hipSetDevice(b->device));
+  for (const auto& f : b->pending_fills)
+    if (int e = fill_upload(b, f)) return e;
+  b->pending_fills.clear();
+  return 0;
+}
+}  // namespace host
+}  // namespace waa
+}  // extern "C++"
+
 waa_status waa_source_set_buffer(waa_batch* b, uint32_t node, uint32_t inst, const float* const* channels,
                                  uint32_t n_ch, uint64_t frames, float sr) {
   int e;
@@ -260,17 +312,11 @@ waa_status waa_source_set_buffer_batch(waa_batch* b, uint32_t node, const float*
   float* d = nullptr;
   if ((e = dev_alloc(b, &d, (size_t)b->n_inst * n_ch * std::max<uint64_t>(stride, 4), true))) return e;
   if (frames && !b->dry) {
-    // on the batch's own stream (and waited for: the caller may free `data` on return): blocking copies on the null
-    // stream of several host threads serialise, and the upload of one sub-batch could not overlap the download of
-    // another (PCIe is full duplex) — SURVEY 8(e)
-    // (contiguous on both sides -> a plain 1-D copy: those go through the DMA engines, one per direction; pitched 2-D
-    // copies run as a copy kernel and did not overlap with a download on another stream)
-    if (stride == frames)
-      HIP_TRY(hipMemcpyAsync(d, data, (size_t)b->n_inst * n_ch * frames * sizeof(float), hipMemcpyHostToDevice, b->stream));
-    else
-      HIP_TRY(hipMemcpy2DAsync(d, stride * sizeof(float), data, frames * sizeof(float), frames * sizeof(float),
-                               (size_t)b->n_inst * n_ch, hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    waa_batch::PendingFill pf{0, data, d, nullptr, b->n_inst, n_ch, frames, stride, frames, sr};
+    if (b->defer_fill)
+      b->pending_fills.push_back(pf);
+    else if ((e = fill_upload(b, pf)))
+      return e;
   }
   Node& n = b->nodes[node];
   for (uint32_t k = 0; k < b->n_inst; k++) {
@@ -309,29 +355,17 @@ static int decode_pcm16(waa_batch* b, const int16_t* pcm, uint32_t n_items, uint
       }
     return 0;
   }
+  // the interleaved PCM's staging buffer belongs to the batch like every other buffer (freed with it; out of the device arena when
+  // one is reserved): a hipMalloc / hipFree pair per upload synchronised the whole device — in waa_render_sharded's pipeline the
+  // render of one sub-batch then waited for the upload of the next (WAA_SHARD_TRACE)
   int16_t* d_pcm = nullptr;
-  const size_t bytes = (size_t)n_items * frames * n_ch * sizeof(int16_t);
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_pcm), bytes));
-  hipError_t he = hipMemcpyAsync(d_pcm, pcm, bytes, hipMemcpyHostToDevice, b->stream);
-  if (he == hipSuccess) {
-    waa::DecodeDesc dd{};
-    dd.pcm = d_pcm;
-    dd.out = d;
-    dd.frames = frames;
-    dd.target_frames = target;
-    dd.out_item_stride = (uint64_t)n_ch * stride;
-    dd.out_ch_stride = stride;
-    dd.nch = n_ch;
-    dd.n_items = n_items;
-    dd.resample = same ? 0 : 1;
-    dd.scale = 1.f;
-    waa::launch_pcm16_resample(dd, b->stream);
-    he = hipGetLastError();
+  if (int ea = dev_alloc(b, &d_pcm, (size_t)n_items * frames * n_ch, true)) return ea;
+  waa_batch::PendingFill pf{1, pcm, d, d_pcm, n_items, n_ch, frames, stride, target, src_sr};
+  if (b->defer_fill && n_items == b->n_inst) {
+    b->pending_fills.push_back(pf);
+    return 0;
   }
-  if (he == hipSuccess) he = hipStreamSynchronize(b->stream);
-  (void)hipFree(d_pcm);
-  if (he != hipSuccess) return fail(WAA_ERR_DEVICE, "HIP error %s in the PCM decode path", hipGetErrorString(he));
-  return 0;
+  return fill_upload(b, pf);
 }
 
 waa_status waa_source_set_buffer_pcm16(waa_batch* b, uint32_t node, uint32_t inst, const int16_t* interleaved, uint32_t n_ch,

@@ -290,6 +290,19 @@ struct waa_batch {
   bool dynamic = false;              // the plan renders the reference's dynamic channel counts (dyn_kernel)
   uint64_t code_stride = 0;          // bytes per instance of a code table (n_quanta rounded up)
   bool rendered = false;
+  // waa_render_sharded: buffers of the streamed source are allocated and registered first (the plan only needs their shape), filled
+  // from the host when the sub-batch has its turn on the link (fill_pending_uploads, waa_abi.cpp)
+  bool defer_fill = false;
+  struct PendingFill {
+    int kind;  // 0: f32 planes, 1: interleaved 16-bit PCM through the decode kernel
+    const void* host;
+    float* planes;
+    int16_t* staging;
+    uint32_t n_items, n_ch;
+    uint64_t frames, stride, target;
+    float src_sr;
+  };
+  std::vector<PendingFill> pending_fills;
   int16_t* pcm_out = nullptr;     // staging of waa_download_all_pcm16 (allocated on first use, freed with the batch)
   size_t pcm_out_count = 0;
   bool dry = false;                  // WAA_DEVICE_PLAN_ONLY: allocations are host memory, nothing is launched

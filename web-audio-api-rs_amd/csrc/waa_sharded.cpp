@@ -17,6 +17,12 @@
 
 #include "waa_host.hpp"
 
+namespace waa {
+namespace host {
+int fill_pending_uploads(waa_batch* b);
+}
+}  // namespace waa
+
 namespace {
 
 // sub-batches of one device take a direction of the link in index order
@@ -66,10 +72,9 @@ waa_status waa_download_all_pcm16(waa_batch* b, int16_t* dst) {
   if (b->length == 0) return WAA_OK;
   HIP_TRY(hipSetDevice(b->device));
   const size_t count = (size_t)b->n_inst * b->length * b->n_out;
-  if (!b->pcm_out || b->pcm_out_count < count) {
-    if (b->pcm_out) (void)hipFree(b->pcm_out);
-    b->pcm_out = nullptr;
-    HIP_TRY(hipMalloc(&b->pcm_out, count * sizeof(int16_t)));
+  if (!b->pcm_out) {  // (the batch's size never changes; owned by the batch like every other buffer: the device arena serves it when reserved)
+    int e = dev_alloc(b, &b->pcm_out, count, true);
+    if (e) return e;
     b->pcm_out_count = count;
   }
   const waa::SignalRef& s = b->nodes[0].sig;
@@ -124,32 +129,64 @@ waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds) {
       first_error = waa_last_error();
     }
   };
+  // WAA_SHARD_TRACE=1 (runtime switch, stderr): when every phase of every sub-batch started and ended, in ms from the call
+  static const bool trace = getenv("WAA_SHARD_TRACE") != nullptr;
+  const auto t00 = std::chrono::steady_clock::now();
+  std::mutex trace_lock;
+  auto stamp = [&](const Shard& sh, const char* what) {
+    if (!trace) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t00).count();
+    std::lock_guard<std::mutex> l(trace_lock);
+    fprintf(stderr, "[shard %u.%u] %8.2f ms  %s\n", sh.slot, sh.k, ms, what);
+  };
   auto run = [&](const Shard& sh) {
     waa_batch* b = nullptr;
     bool took_up = false, took_down = false;
+    stamp(sh, "start");
     int st = waa_batch_create(job->graph, sh.hi - sh.lo, job->n_channels_out, job->length_frames, job->sample_rate, sh.device, &b);
     if (!st && job->setup) st = job->setup(b, sh.lo, sh.hi - sh.lo, sh.device, job->user);
+    stamp(sh, "created + set up");
+    // The source's buffers are allocated and registered BEFORE the sub-batch's turn on the link, and the batch is planned: the
+    // plan only needs their shape, and its small table uploads queue on the same DMA engine as the bulk upload of whichever
+    // sub-batch holds the turn — planned after the upload, every render waited ~5 ms for its neighbour's transfer (WAA_SHARD_TRACE).
+    // (Not when an AudioParam is modulated from the graph: that plan renders the modulating subgraph, which may read the source.)
+    bool preplanned = false;
+    if (!st && streamed) {
+      bool modulated = false;
+      for (uint32_t e = 0; e < job->graph->n_edges; e++) modulated |= (job->graph->edges[e].to_input & 0x80000000u) != 0;
+      b->defer_fill = true;
+      const char* src = static_cast<const char*>(job->host_in) + (size_t)sh.lo * row_in;
+      st = job->in_pcm16 ? waa_source_set_buffer_pcm16_batch(b, job->source_node, reinterpret_cast<const int16_t*>(src), job->in_channels,
+                                                             job->in_frames, job->in_sample_rate)
+                         : waa_source_set_buffer_batch(b, job->source_node, reinterpret_cast<const float*>(src), job->in_channels,
+                                                       job->in_frames, job->in_sample_rate);
+      b->defer_fill = false;
+      if (!st && !modulated) {
+        st = waa_plan_describe(b, nullptr, 0, nullptr);
+        preplanned = true;
+      }
+      stamp(sh, preplanned ? "buffers registered + planned" : "buffers registered");
+    }
     if (!st) {
       up[sh.slot].wait(sh.k);
       took_up = true;
-      if (streamed) {
-        const char* src = static_cast<const char*>(job->host_in) + (size_t)sh.lo * row_in;
-        st = job->in_pcm16 ? waa_source_set_buffer_pcm16_batch(b, job->source_node, reinterpret_cast<const int16_t*>(src), job->in_channels,
-                                                               job->in_frames, job->in_sample_rate)
-                           : waa_source_set_buffer_batch(b, job->source_node, reinterpret_cast<const float*>(src), job->in_channels,
-                                                         job->in_frames, job->in_sample_rate);
-      }
+      stamp(sh, "upload turn");
+      if (streamed) st = waa::host::fill_pending_uploads(b);
       up[sh.slot].done();
+      stamp(sh, "uploaded");
     }
     if (!st) st = waa_render(b);
     if (!st) st = waa_sync(b);
+    stamp(sh, "planned + rendered");
     if (!st && job->pull) st = job->pull(b, sh.lo, sh.hi - sh.lo, sh.device, job->user);
     if (!st) {
       down[sh.slot].wait(sh.k);
       took_down = true;
+      stamp(sh, "download turn");
       char* dst = static_cast<char*>(job->host_out) + (size_t)sh.lo * row_out;
       st = job->out_pcm16 ? waa_download_all_pcm16(b, reinterpret_cast<int16_t*>(dst)) : waa_download_all(b, reinterpret_cast<float*>(dst));
       down[sh.slot].done();
+      stamp(sh, "downloaded");
     }
     if (st) {
       report(st);
@@ -164,6 +201,7 @@ waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds) {
       }
     }
     if (b) waa_batch_destroy(b);
+    stamp(sh, "destroyed");
   };
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<std::thread> threads;
