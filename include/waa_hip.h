@@ -187,7 +187,9 @@ void waa_batch_destroy(waa_batch* batch);
  * falls back to hipMalloc for what does not fit.  Pieces return to the slab when the last batch holding one is destroyed.
  * bytes = 0 releases the slab (InvalidStateError while batches still use it).  No counterpart in the reference (its buffers
  * are Vec<f32>s): this exists because the same streaming kernel ran 15 % faster or slower depending on which hipMalloc
- * served its output buffer. */
+ * served its output buffer — and because hipMalloc / hipFree synchronise the device: a process that
+ * creates and destroys batches while others render (waa_render_sharded's pipeline, a server) should reserve one (DESIGN.md section 7:
+ * 112 -> 95 ms for 2 x 3.9 GB through one device). */
 waa_status waa_device_arena_reserve(int32_t device, uint64_t bytes);
 const char* waa_last_error(void);
 /* number of visible HIP devices (0 if none / runtime unavailable) */
@@ -349,7 +351,8 @@ typedef struct waa_sharded_job {
   void* user;
 } waa_sharded_job;
 /* Blocks until every context is rendered and downloaded; *seconds (may be NULL) = wall time.  Pinned host buffers let
- * the transfers run at link speed.  Under one process per GPU (torch.distributed, MPI) every rank calls this with its own
+ * the transfers run at link speed, and a device arena (waa_device_arena_reserve, once per process) keeps hipMalloc / hipFree —
+ * which synchronise the device — out of the pipeline.  WAA_SHARD_TRACE=1: the phase timeline of every sub-batch on stderr.  Under one process per GPU (torch.distributed, MPI) every rank calls this with its own
  * device and its own slice of the contexts. */
 waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds);
 /* the partition rule: contexts [*first, *end) of n_total belong to part `part` of `n_parts` (sizes differ by at most one) */
