@@ -414,7 +414,7 @@ def test_parity_echo_loop_from_the_lds_ring(hip, orc, channels, out_channels, va
     assert np.array_equal(plain, ring)
 
 
-def _random_echo_graph(binding, seed, plan_only=False):
+def _random_echo_graph(binding, seed, plan_only=False, short=False, filtered=False):
     """a random member of the echo-loop family: 1-2 sources (mono / stereo, optionally through a Gain that rides on the
     delay's input edge) into Delay <-> Gain, connection order (= summation order) shuffled, feedback gain constant / per
     instance / one value per quantum (one of them sometimes 0 or 1: gain.rs' mute and pass-through cases), speakers or
@@ -433,8 +433,15 @@ def _random_echo_graph(binding, seed, plan_only=False):
         delay.set_channel_count(2)
         delay.set_channel_count_mode("explicit")
     for i in range(n):
-        delay.delay_time.set_value(np.float32(rng.uniform(2057.0, 14000.0) / 48000.0), instance=i)
+        # (short: below one 2048-frame tile — comb filters, plucked strings: the ring kernel in 256- / 512-frame chunks)
+        delay.delay_time.set_value(np.float32((rng.uniform(266.0, 2040.0) if short else rng.uniform(2057.0, 14000.0)) / 48000.0), instance=i)
     fb = c.create_gain()
+    bq = None
+    if filtered:  # Delay -> Biquad -> Gain -> back (the ring kernel's BQ form)
+        bq = c.create_biquad_filter(type_=str(rng.choice(["lowpass", "highpass", "bandpass", "peaking", "allpass"])),
+                                    frequency=float(rng.uniform(300.0, 9000.0)))
+        bq.q.set_value(float(rng.uniform(0.3, 4.0)))
+        bq.gain.set_value(float(rng.uniform(-6.0, 6.0)))
     kind = rng.integers(0, 3)
     if kind == 0:
         fb.gain.set_value(float(rng.choice([0.5, -0.8, 0.0, 1.0])))
@@ -457,22 +464,23 @@ def _random_echo_graph(binding, seed, plan_only=False):
         if rng.random() < 0.4:
             head = src.connect(c.create_gain(gain=float(rng.choice([0.7, -1.3, 1.0]))))
         connects.append(lambda head=head: head.connect(delay))
-    connects.append(lambda: delay.connect(fb).connect(delay))
+    connects.append(lambda: (delay.connect(bq).connect(fb) if bq is not None else delay.connect(fb)).connect(delay))
+    wet = bq if bq is not None else delay   # what the destinations below listen to
     for k in rng.permutation(len(connects)):
         connects[k]()
     dest = int(rng.integers(0, 5))
     if dest == 0:      # dry + wet
         srcs[0].connect(c.destination())
-        delay.connect(c.destination())
+        wet.connect(c.destination())
     elif dest == 1:    # wet + dry, the other order
-        delay.connect(c.destination())
+        wet.connect(c.destination())
         srcs[-1].connect(c.destination())
     elif dest == 2:    # wet only
-        delay.connect(c.destination())
+        wet.connect(c.destination())
     elif dest == 3:    # a reader with an op of its own
-        delay.connect(c.create_gain(gain=0.6)).connect(c.destination())
+        wet.connect(c.create_gain(gain=0.6)).connect(c.destination())
     else:              # two readers
-        delay.connect(c.destination())
+        wet.connect(c.destination())
         delay.connect(c.create_wave_shaper(curve=np.float32([-0.5, 0.0, 0.8]))).connect(c.destination())
     plan = c.plan_describe() if binding.prefix == "waa_" else ""
     out = None if plan_only else c.start_rendering_sync().data
@@ -504,12 +512,31 @@ def test_parity_random_echo_loops(hip, orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("short,filtered", [(True, False), (False, True), (True, True)])
+def test_parity_random_echo_loops_short_and_filtered(hip, orc, short, filtered):
+    """the same family with delays below a tile (266 .. 2040 frames: chunks of 256 frames, rings of 1024 .. 4096) and / or a Biquad
+    in the loop (the BQ form): plain loops bit-identical to the oracle, filtered ones within the streaming Biquad's tolerance"""
+    ring = 0
+    for seed in range(40):
+        g, plan = _random_echo_graph(hip, 9500 + seed, short=short, filtered=filtered)
+        o, _ = _random_echo_graph(orc, 9500 + seed, short=short, filtered=filtered)
+        if filtered:
+            scale = max(1.0, float(np.abs(o).max()))
+            assert rms_err(g, o).max() <= 1e-6 * scale and np.abs(g - o).max() <= 4e-6 * scale, (seed, float(np.abs(g - o).max()), plan)
+        else:
+            assert np.array_equal(g, o), (seed, float(np.abs(g - o).max()), plan)
+        ring += "LDS-ring kernel in ONE launch" in plan
+        assert ("shorter than a tile" in plan) == (short and "LDS-ring kernel in ONE launch" in plan), plan
+    assert ring >= 15, ring
+
+
+@pytest.mark.gpu
 def test_echo_loop_past_the_lds_ring_window(hip, orc):
-    """one instance's delay is a frame past what the smallest chunk reaches (16384 - 4*256 - 8 = 15352 frames): the
+    """one instance's delay is past what the smallest chunk reaches (16384 - 256 - 8 = 16120 frames): the
     launch-per-block form renders the loop"""
     n, frames = 6, 2048 * 11 + 77
     noise = white_noise(n, 2, frames, seed0=36)
-    delays = (np.float64([2064, 2065.5, 3000.25, 4800, 9000.75, 15354]) / 48000.0).astype(np.float32)
+    delays = (np.float64([2064, 2065.5, 3000.25, 4800, 9000.75, 16122]) / 48000.0).astype(np.float32)
     gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
     g, plan = _echo_graph(hip, noise, delays, gains, "dry+wet")
     assert "LDS-ring kernel" not in plan
@@ -590,7 +617,7 @@ def test_plan_echo_loop_ring_and_tail(hip, variant, fused, monkeypatch):
         assert "the delay line has 2 reader(s) outside the loop" in plan
     if variant in ("wet-gain", "other-dry"):
         assert "is not a plain sum of the delayed line and of the loop's inputs" in plan
-    assert "chunks of 2048 frames" in plan_of(2064) and "LDS-ring" not in plan_of(15354)
+    assert "chunks of 2048 frames" in plan_of(2064) and "chunks of 512 frames" in plan_of(15354) and "LDS-ring" not in plan_of(16122)
     monkeypatch.setenv("WAA_NO_ECHO_TAIL", "1")
     assert "LDS-ring kernel in ONE launch" in plan_of(12000) and "the line is not stored" not in plan_of(12000)
     monkeypatch.setenv("WAA_NO_ECHO_RING", "1")

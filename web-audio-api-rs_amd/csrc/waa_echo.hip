@@ -574,8 +574,9 @@ static int echo_chunk_for(float dmin, float dmax) {
   // the frames a chunk reads must lie BEHIND the chunk (delay > chunk) and still be in the ring (delay + chunk < ring)
   // (round 4: down to ONE sub-tile — a comb filter's / a plucked string's feedback delay of a few hundred frames walks in chunks
   // of 256 frames, one wavefront per instance, with a ring as small as its delay needs: many instances per CU)
+  // (the largest chunk that fits BOTH ends: a batch whose delays span 4200 .. 13000 frames walks in chunks of 2048, not 4096)
   for (int cand : {16, 8, 4, 2, 1})
-    if ((float)(cand * 256 + 8) <= dmin) return dmax > (float)(ECHO_RING - cand * 256 - 8) ? 0 : cand;
+    if ((float)(cand * 256 + 8) <= dmin && dmax <= (float)(ECHO_RING - cand * 256 - 8)) return cand;
   return 0;
 }
 
@@ -612,7 +613,7 @@ int echo_bq_applicable(const ChainDesc& rd, const BiquadStreamDesc& f, const Cha
   if (fb < 0 || ((uintptr_t)sum.out.base & 15) || (sum.out.ch_stride & 3) || (sum.out.inst_stride & 3)) return -1;
   int ch = 0;
   for (int cand : {ECHO_BQ_WAVES, 4, 2, 1})
-    if (!ch && (float)(cand * 256 + 8) <= delay_min_max_frames[0]) ch = delay_min_max_frames[1] > (float)(ECHO_RING - cand * 256 - 8) ? 0 : cand;
+    if (!ch && (float)(cand * 256 + 8) <= delay_min_max_frames[0] && delay_min_max_frames[1] <= (float)(ECHO_RING - cand * 256 - 8)) ch = cand;
   if (!ch) return -1;
   *chunk_subtiles = ch;
   EchoBq q{};
