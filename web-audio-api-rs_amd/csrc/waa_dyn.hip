@@ -111,6 +111,18 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
   }
   lds_sync();
 
+#ifdef WAA_MEASURE
+  unsigned long long cyc[8][3] = {};
+#define DYN_STAMP(ph)                                                    \
+  if (d.cycles) {                                                        \
+    const unsigned long long now = __builtin_amdgcn_s_memtime();         \
+    if (it < 8) cyc[it][ph] += now - t_last;                             \
+    t_last = now;                                                        \
+  }
+  unsigned long long t_last = d.cycles ? __builtin_amdgcn_s_memtime() : 0ull;
+#else
+#define DYN_STAMP(ph)
+#endif
   for (uint32_t q = 0; q < d.n_quanta; q++) {
     const uint64_t f0 = (uint64_t)q * RQ;
     for (int it = 0; it < d.n_items; it++) {
@@ -191,6 +203,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
       }
       int outn = sn;
       bool outs = ss;
+      DYN_STAMP(0)
       if (li.kind == DI_NODE) {
         const OpDesc& op = li.op;
         switch (li.dk) {
@@ -663,6 +676,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
 #pragma unroll
         for (int c = 0; c < CM; c++) v[c][0] = v[c][1] = 0.f;
       }
+      DYN_STAMP(1)
       // ---- hand over (LDS) and publish (HBM)
       float* dst = cur + (size_t)it * CM * RQ;
 #pragma unroll
@@ -699,8 +713,14 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
         }
       }
       lds_sync();
+      DYN_STAMP(2)
     }
   }
+#ifdef WAA_MEASURE
+  if (d.cycles && inst == 0 && lane == 0)
+    for (int i = 0; i < 8; i++)
+      for (int p = 0; p < 3; p++) d.cycles[i * 3 + p] = cyc[i][p];
+#endif
 }
 
 void launch_dyn(const DynDesc& d, void* stream) {
@@ -709,6 +729,30 @@ void launch_dyn(const DynDesc& d, void* stream) {
                      (size_t)(d.n_items * 5 + 2) * sizeof(int) + (size_t)d.n_items * sizeof(DynItem);
   DynDesc dd = d;
   dd.no_scan = measure_switch("WAA_DYN_NO_SCAN") ? 1u : 0u;
+  dd.cycles = nullptr;
+#ifdef WAA_MEASURE
+  static unsigned long long* d_cycles = nullptr;
+  if (measure_switch("WAA_DYN_CYCLES")) {
+    if (!d_cycles) (void)hipMalloc(&d_cycles, 24 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(d_cycles, 0, 24 * sizeof(unsigned long long), (hipStream_t)stream);
+    dd.cycles = d_cycles;
+  }
+  struct Report {
+    unsigned long long* p;
+    hipStream_t st;
+    uint32_t nq;
+    int n_items;
+    ~Report() {
+      if (!p) return;
+      unsigned long long h[24];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h, p, sizeof h, hipMemcpyDeviceToHost);
+      for (int i = 0; i < n_items && i < 8; i++)
+        fprintf(stderr, "[dyn cycles] item %d: gather %.0f  node %.0f  hand-over %.0f  (shader-clock ticks per quantum, instance 0)\n", i,
+                (double)h[i * 3] / nq, (double)h[i * 3 + 1] / nq, (double)h[i * 3 + 2] / nq);
+    }
+  } report{dd.cycles, (hipStream_t)stream, d.n_quanta, d.n_items};
+#endif
   if (cm == 2) {
     if (lds > 64 * 1024)
       raise_lds_limit(reinterpret_cast<const void*>(dyn_kernel<2>));

@@ -457,6 +457,7 @@ struct DynDesc {
   int32_t pad;
   double sample_rate;
   double quantum_duration;
+  unsigned long long* cycles;  // measurement build, WAA_DYN_CYCLES: [items][3] shader-clock ticks of instance 0 (gather, node, hand-over)
 };
 void launch_dyn(const DynDesc& d, void* stream);
 size_t dyn_lds_bytes(int n_items, int cmax);  // dynamic LDS of the launch (<= 160 KB: the planner checks)
