@@ -14,6 +14,8 @@
 // comes from the batch (1024 instances = 1024 wavefronts).
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "waa_internal.hpp"
 #include "waa_mix.hpp"
 
@@ -75,6 +77,10 @@ __device__ __forceinline__ void stereo_gains(float x, float& gl, float& gr) {  /
 __device__ __forceinline__ void lds_sync() { __builtin_amdgcn_wave_barrier(); }
 
 // CM = 2: mono / stereo graphs (the round-2 kernel); CM = 6: layouts up to 5.1 (DelayNodes stay mono / stereo: the planner checks)
+static_assert(offsetof(DynItem, kind) == 0 && offsetof(DynItem, cc) == 8 && offsetof(DynItem, interp) == 16 && offsetof(DynItem, nch_pub) == 24 &&
+                  offsetof(DynItem, compact_ch1) == 32 && offsetof(DynItem, writer_item) == 40 && offsetof(DynItem, num_quanta) == 48 &&
+                  offsetof(DynItem, in) == 56 && sizeof(DynItem) % 8 == 0,
+              "dyn_kernel reads the item's scalar fields as seven 8-byte words");
 template <int CM>
 __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -127,14 +133,26 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
     const uint64_t f0 = (uint64_t)q * RQ;
     for (int it = 0; it < d.n_items; it++) {
       const DynItem& li = items_s[it];
+      // The item's scalar fields (the first 14 words of the descriptor) in ONE batch of LDS reads into scalar registers: read where
+      // they are used, every decision below (kind -> n_in -> input item -> ...) was a dependent LDS read -> readfirstlane -> branch,
+      // ~130 cycles each, eight to twelve in a row per phase (WAA_DYN_CYCLES: 1200-2000 cycles for a phase that computes nothing).
+      const int2* hp = reinterpret_cast<const int2*>(&li);
+      const int2 hw0 = hp[0], hw1 = hp[1], hw2 = hp[2], hw3 = hp[3], hw4 = hp[4], hw5 = hp[5], hw6 = hp[6];
+      const int h_kind = __builtin_amdgcn_readfirstlane(hw0.x), h_dk = __builtin_amdgcn_readfirstlane(hw0.y);
+      const int h_cc = __builtin_amdgcn_readfirstlane(hw1.x), h_mode = __builtin_amdgcn_readfirstlane(hw1.y);
+      const int h_interp = __builtin_amdgcn_readfirstlane(hw2.x), h_n_in = __builtin_amdgcn_readfirstlane(hw2.y);
+      const int h_nch_pub = __builtin_amdgcn_readfirstlane(hw3.x), h_publish_upmix = __builtin_amdgcn_readfirstlane(hw3.y);
+      const int h_compact_ch1 = __builtin_amdgcn_readfirstlane(hw4.x), h_flags = __builtin_amdgcn_readfirstlane(hw4.y);
+      const int h_writer_item = __builtin_amdgcn_readfirstlane(hw5.x), h_in_cycle = __builtin_amdgcn_readfirstlane(hw5.y);
+      const int h_num_quanta = __builtin_amdgcn_readfirstlane(hw6.x);
       float v[CM][2];
 #pragma unroll
       for (int c = 0; c < CM; c++) v[c][0] = v[c][1] = 0.f;
       int sn = 1;       // number_of_channels of the mixed input
       bool ss = true;   // is_silent
-      if (li.kind != DI_DELAY_R) {
+      if (h_kind != DI_DELAY_R) {
         // ---- graph.rs:524-535: the input starts silent (mono); every incoming edge is `add`ed in order
-        for (int k = 0; k < li.n_in; k++) {
+        for (int k = 0; k < h_n_in; k++) {
           const DynInput& in = li.in[k];
           float u[CM][2];
 #pragma unroll
@@ -174,11 +192,11 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
           if (on > CM) on = CM;  // (the planner picks the instantiation by the widest signal)
           // quantum.rs:532-569
           const int maxc = sn > on ? sn : on;
-          int newc = li.mode == 0 ? maxc : (li.mode == 2 ? li.cc : (maxc < li.cc ? maxc : li.cc));
+          int newc = h_mode == 0 ? maxc : (h_mode == 2 ? h_cc : (maxc < h_cc ? maxc : h_cc));
           if (newc > CM) newc = CM;
           if (newc < 1) newc = 1;
-          mixn<CM>(v, sn, newc, li.interp, ss);
-          mixn<CM>(u, on, newc, li.interp, os);
+          mixn<CM>(v, sn, newc, h_interp, ss);
+          mixn<CM>(u, on, newc, h_interp, os);
           if (ss) {  // quantum.rs:114-120: a silent channel takes the other operand (and its flag)
 #pragma unroll
             for (int c = 0; c < CM; c++)
@@ -204,9 +222,9 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
       int outn = sn;
       bool outs = ss;
       DYN_STAMP(0)
-      if (li.kind == DI_NODE) {
+      if (h_kind == DI_NODE) {
         const OpDesc& op = li.op;
-        switch (li.dk) {
+        switch (h_dk) {
           case DK_GAIN: {  // gain.rs:143-199
             if (ss) {
               outn = 1;
@@ -238,7 +256,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
           case DK_BIQUAD:
           case DK_IIR: {
             // biquad_filter.rs:764-899 / iir_filter.rs:323-405: per-channel state, tail until the state is denormal
-            const bool iir = li.dk == DK_IIR;
+            const bool iir = h_dk == DK_IIR;
             const int ns = iir ? (op.i0 < 0 ? -op.i0 : op.i0) : 4;  // state doubles that decide the tail
             double* st = fst + (size_t)it * CM * DYN_STATE;
             int nst = ist[it * 4 + 0];
@@ -463,7 +481,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
             break;
           }
           case DK_WAVESHAPER: {  // waveshaper.rs:383-487 (oversample none)
-            if (ss && (li.flags & 1)) {
+            if (ss && (h_flags & 1)) {
               outn = 1;
               break;
             }
@@ -552,13 +570,13 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
             break;
           }
           case DK_PASS:
-            if (li.flags & 2) {  // ConvolverNode without a buffer (convolver.rs:357-374): no tail, then passthrough
+            if (h_flags & 2) {  // ConvolverNode without a buffer (convolver.rs:357-374): no tail, then passthrough
               if (ss) outn = 1;
             }
             break;
           default: break;  // DK_CONV_IN: the mixed input as it is
         }
-      } else if (li.kind == DI_DELAY_W) {
+      } else if (h_kind == DI_DELAY_W) {
         // delay.rs:428-489: the ring is re-mixed to the count of the current input, then the input is stored
         if constexpr (CM > 2) {
           // layouts above stereo: the ring entries are REALLY re-mixed, like DelayWriter::check_ring_buffer_up_down_mix does
@@ -567,7 +585,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
           const int old = ist[it * 4 + 0];
           if (sn != old && q > 0) {
             __syncthreads();  // (this wave's earlier stores to the line have reached L2)
-            const uint32_t cap = (uint32_t)li.num_quanta + 1u;
+            const uint32_t cap = (uint32_t)h_num_quanta + 1u;
             uint32_t* wc = li.aux32 + (uint64_t)inst * li.code_stride;
             float* hbw = li.out.base + (uint64_t)inst * li.out.inst_stride;
             for (uint32_t p = q > cap ? q - cap : 0u; p < q; p++) {
@@ -583,7 +601,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
               mix_regs<CM, 2>(w, np, sn, 0);
 #pragma unroll
               for (int c = 0; c < CM; c++)
-                if (c < sn && c < li.nch_pub) {
+                if (c < sn && c < h_nch_pub) {
                   store_global(hbw + (uint64_t)c * li.out.ch_stride + (uint64_t)p * RQ + lane, w[c][0]);
                   store_global(hbw + (uint64_t)c * li.out.ch_stride + (uint64_t)p * RQ + 64 + lane, w[c][1]);
                 }
@@ -599,17 +617,17 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
       } else {
         // ---- DelayReader::process, delay.rs:515-745, on the writer's line in absolute time
         __syncthreads();  // the writer's stores of this quantum (if it rendered first) have reached L2
-        const DynItem& wi = items_s[li.writer_item];
+        const DynItem& wi = items_s[h_writer_item];
         const SignalRef& hs = wi.out;
-        const int nch = ist[li.writer_item * 4 + 0];         // ring[0].number_of_channels() right now
-        const int last_mono = ist[li.writer_item * 4 + 1];   // entries written before it were collapsed to mono
+        const int nch = ist[h_writer_item * 4 + 0];         // ring[0].number_of_channels() right now
+        const int last_mono = ist[h_writer_item * 4 + 1];   // entries written before it were collapsed to mono
         const uint32_t* wcode = wi.aux32 + (uint64_t)inst * wi.code_stride;
         const OpDesc& op = li.op;
         int64_t pf0 = 0;
         float k0 = 0.f;
         if (op.p0.mode != 2) {
           double dv = (double)pval(op.p0, inst, q, 0);
-          if (li.in_cycle) dv = fmax(dv, d.quantum_duration);
+          if (h_in_cycle) dv = fmax(dv, d.quantum_duration);
           const double position = 0. - dv * d.sample_rate;
           const double fl = floor(position);
           pf0 = (int64_t)fl;
@@ -641,7 +659,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
             k = k0;
           } else {
             double dv = (double)load_global(op.p0.base + (uint64_t)inst * op.p0.stride + f0 + i);
-            if (li.in_cycle) dv = fmax(dv, d.quantum_duration);
+            if (h_in_cycle) dv = fmax(dv, d.quantum_duration);
             const double position = (double)i - dv * d.sample_rate;
             const double fl = floor(position);
             pf = (int64_t)fl;
@@ -651,8 +669,8 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
           // frame 128 of the newest block wraps to the OLDEST ring block (delay.rs:622-626); a reader that renders
           // before its writer sees, in the slot of the current quantum, the block written ring-capacity quanta ago
           int64_t next = prev + 1;
-          if (!li.in_cycle && pf == RQ - 1) next = ((int64_t)q - li.num_quanta) * RQ;
-          if (li.in_cycle && next >= (int64_t)f0) next -= ((int64_t)li.num_quanta + 1) * RQ;
+          if (!h_in_cycle && pf == RQ - 1) next = ((int64_t)q - h_num_quanta) * RQ;
+          if (h_in_cycle && next >= (int64_t)f0) next -= ((int64_t)h_num_quanta + 1) * RQ;
 #pragma unroll
           for (int c = 0; c < CM; c++)
             if (c < nch) {
@@ -689,7 +707,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
       if (li.out.base) {
         float* gout = li.out.base + (uint64_t)inst * li.out.inst_stride;
         uint64_t f1 = f0;
-        if (li.compact_ch1) {  // mono impulse response: convolver 1 only runs (= its time only advances) on stereo quanta
+        if (h_compact_ch1) {  // mono impulse response: convolver 1 only runs (= its time only advances) on stereo quanta
           const int slot = ist[it * 4 + 2];
           f1 = (uint64_t)slot * RQ;
           if (lane == 0) {
@@ -699,17 +717,17 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
         }
 #pragma unroll
         for (int c = 0; c < CM; c++)
-          if (c < li.nch_pub) {
+          if (c < h_nch_pub) {
             const bool have = c < outn;
-            const bool dup = !have && li.publish_upmix && !outs;
-            if (c == 1 && li.compact_ch1 && !have) continue;  // nothing enters convolver 1 in this quantum
+            const bool dup = !have && h_publish_upmix && !outs;
+            if (c == 1 && h_compact_ch1 && !have) continue;  // nothing enters convolver 1 in this quantum
             const uint64_t fc = c == 1 ? f1 : f0;
             store_global(gout + (uint64_t)c * li.out.ch_stride + fc + lane, have ? v[c][0] : (dup ? v[0][0] : 0.f));
             store_global(gout + (uint64_t)c * li.out.ch_stride + fc + 64 + lane, have ? v[c][1] : (dup ? v[0][1] : 0.f));
           }
         if (lane == 0) {
           if (li.out_code) li.out_code[(uint64_t)inst * li.code_stride + q] = (uint8_t)code;
-          if (li.kind == DI_DELAY_W) store_global(li.aux32 + (uint64_t)inst * li.code_stride + q, code);
+          if (h_kind == DI_DELAY_W) store_global(li.aux32 + (uint64_t)inst * li.code_stride + q, code);
         }
       }
       lds_sync();
