@@ -532,11 +532,11 @@ def test_parity_random_echo_loops_short_and_filtered(hip, orc, short, filtered):
 
 @pytest.mark.gpu
 def test_echo_loop_past_the_lds_ring_window(hip, orc):
-    """one instance's delay is past what the smallest chunk reaches (16384 - 256 - 8 = 16120 frames): the
+    """one instance's delay is past what the smallest chunk reaches (16384 - 128 - 8 = 16248 frames): the
     launch-per-block form renders the loop"""
     n, frames = 6, 2048 * 11 + 77
     noise = white_noise(n, 2, frames, seed0=36)
-    delays = (np.float64([2064, 2065.5, 3000.25, 4800, 9000.75, 16122]) / 48000.0).astype(np.float32)
+    delays = (np.float64([2064, 2065.5, 3000.25, 4800, 9000.75, 16250]) / 48000.0).astype(np.float32)
     gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
     g, plan = _echo_graph(hip, noise, delays, gains, "dry+wet")
     assert "LDS-ring kernel" not in plan
@@ -617,7 +617,7 @@ def test_plan_echo_loop_ring_and_tail(hip, variant, fused, monkeypatch):
         assert "the delay line has 2 reader(s) outside the loop" in plan
     if variant in ("wet-gain", "other-dry"):
         assert "is not a plain sum of the delayed line and of the loop's inputs" in plan
-    assert "chunks of 2048 frames" in plan_of(2064) and "chunks of 512 frames" in plan_of(15354) and "LDS-ring" not in plan_of(16122)
+    assert "chunks of 2048 frames" in plan_of(2064) and "chunks of 512 frames" in plan_of(15354) and "LDS-ring" not in plan_of(16250)
     monkeypatch.setenv("WAA_NO_ECHO_TAIL", "1")
     assert "LDS-ring kernel in ONE launch" in plan_of(12000) and "the line is not stored" not in plan_of(12000)
     monkeypatch.setenv("WAA_NO_ECHO_RING", "1")
@@ -847,6 +847,7 @@ def test_parity_filtered_echo_loop_from_the_lds_ring(hip, orc, channels, out_cha
 
 
 SHORT_DELAYS = (np.float64([266, 300.5, 511.25, 777, 1031, 2040]) / 48000.0).astype(np.float32)   # all below one 2048-frame tile
+TINY_DELAYS = (np.float64([137, 150.5, 200.25, 240, 263, 1500]) / 48000.0).astype(np.float32)     # ... and below a 256-frame chunk + 8
 
 
 @pytest.mark.measure
@@ -873,6 +874,23 @@ def test_parity_short_echo_loop_from_the_lds_ring(hip, orc, channels, out_channe
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("filtered", [False, True])
+def test_parity_tiny_echo_loops_walk_in_half_wave_chunks(hip, orc, filtered):
+    """delays of 137 .. 263 frames (a plucked string above ~180 Hz): chunks of 128 frames, the upper half of the wavefront idle"""
+    n, frames = 6, 2048 * 3 + 77
+    noise = white_noise(n, 2, frames, seed0=44)
+    gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
+    graph = _filtered_echo_graph if filtered else _echo_graph
+    g, plan = graph(hip, noise, TINY_DELAYS, gains, "dry+wet")
+    assert "LDS-ring kernel in ONE launch" in plan and "chunks of 128 frames" in plan and "shorter than a tile" in plan, plan
+    o, _ = graph(orc, noise, TINY_DELAYS, gains, "dry+wet")
+    if filtered:
+        assert rms_err(g, o).max() <= 1e-6 and np.abs(g - o).max() <= 4e-6
+    else:
+        assert np.array_equal(g, o)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["dry+wet", "wet-gain", "line-reader", "peaking"])
 def test_parity_short_filtered_echo_loop_from_the_lds_ring(hip, orc, variant):
     """the plucked string: Delay (a few hundred frames) -> Biquad -> Gain -> back, in the ring kernel's BQ form"""
@@ -889,13 +907,13 @@ def test_parity_short_filtered_echo_loop_from_the_lds_ring(hip, orc, variant):
 
 @pytest.mark.gpu
 def test_short_loops_the_ring_kernel_does_not_render_fall_back(hip, orc):
-    """one instance's delay below 264 frames (256-frame chunk + 8), or a member that is not Delay / Gain / constant Biquad: the second
+    """one instance's delay below 136 frames (128-frame chunk + 8), or a member that is not Delay / Gain / constant Biquad: the second
     planning pass hands the loop to the quantum-serial kernel"""
     n, frames = 6, 2048 * 3 + 77
     noise = white_noise(n, 2, frames, seed0=43)
     gains = np.float32([0.5, -0.7, 0.9, 0.3, 0.6, -0.95])
     delays = SHORT_DELAYS.copy()
-    delays[2] = np.float32(200.0 / 48000.0)
+    delays[2] = np.float32(130.0 / 48000.0)
     g, plan = _echo_graph(hip, noise, delays, gains, "dry+wet")
     assert "LDS-ring kernel" not in plan
     assert np.abs(g - _echo_graph(orc, noise, delays, gains, "dry+wet")[0]).max() == 0.0

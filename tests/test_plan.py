@@ -391,9 +391,9 @@ def test_lfo_depth_gain_rides_on_the_param_edge(hip):
 
 def test_short_delay_loop_uses_the_quantum_serial_kernel(hip):
     """a loop delay below one 2048-frame tile cannot be block-scheduled: the quantum-serial kernel renders it — unless the loop has
-    the ring kernel's shape (Delay <-> Gain [-> constant Biquad], delay >= 264 frames), which walks it in 256-frame chunks (round 4)"""
+    the ring kernel's shape (Delay <-> Gain [-> constant Biquad], delay >= 136 frames), which walks it in chunks down to 128 frames (round 4)"""
     c, s = _ctx(hip)
-    d = c.create_delay(1.0, delay_time=0.004)   # 192 frames: below the ring kernel's smallest chunk
+    d = c.create_delay(1.0, delay_time=0.00275)   # 132 frames: below the ring kernel's smallest chunk (128 + 8)
     s.connect(d)
     d.connect(c.create_gain(gain=0.5)).connect(d)
     d.connect(c.destination())

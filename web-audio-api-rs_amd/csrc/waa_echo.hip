@@ -153,7 +153,11 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
   const double fl = floor(position);
   const int32_t pf0 = (int32_t)fl;  // (-RF < pf0 < 0: echo_ring_applicable / echo_ring_frames)
   const float kf = (float)(position - fl);
-  const uint32_t total_sub = (d.tile1 - d.tile0) * (TILE / 256);
+  // frames per wavefront and chunk: 256 (4 per lane), or 128 for delays below 264 frames (the upper half of the wavefront idles)
+  const uint32_t SUBF = (uint32_t)__builtin_amdgcn_readfirstlane(t.sub_frames);
+  const bool lane_on = (uint32_t)lane * 4u < SUBF;
+  const int last_lane = (int)(SUBF / 4u) - 1;
+  const uint32_t total_sub = (d.tile1 - d.tile0) * ((uint32_t)TILE / SUBF);
   const uint32_t f_first = d.tile0 * TILE;  // (frames fit 31 bits: echo_ring_applicable)
   const uint32_t cs = (uint32_t)chunk_subtiles;
   const uint32_t last_q = d.n_quanta - 1;
@@ -212,12 +216,12 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
   for (int c = 0; c < CT; c++) pt[c] = t.out.base + (uint64_t)inst * t.out.inst_stride + (uint64_t)c * t.out.ch_stride + vz;
 
   auto fetch = [&](uint32_t sub_n, EchoOperands<C, NG>& o) __attribute__((always_inline)) {
-    const uint32_t fn = f_first + sub_n * 256u + (uint32_t)lane * 4u;
+    const uint32_t fn = f_first + sub_n * SUBF + (uint32_t)lane * 4u;
     const uint32_t qn = fn / RQ;
     const uint32_t qcn = qn < last_q ? qn : last_q;
 #pragma unroll
     for (int sl = 0; sl < ECHO_EXT; sl++) {
-      const bool ok = sub_n < total_sub && fn + 3u < vlim[sl];
+      const bool ok = sub_n < total_sub && fn + 3u < vlim[sl] && lane_on;
       const uint32_t off = ok ? fn : 0u;
 #pragma unroll
       for (int c = 0; c < C; c++) {
@@ -312,8 +316,8 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
   auto chunk = [&](const EchoOperands<C, NG>& o, uint32_t s0, auto guard) __attribute__((always_inline)) {
     constexpr bool GUARD = decltype(guard)::value;
     const uint32_t sub = s0 + wave;
-    const bool live = !GUARD || sub < total_sub;
-    const uint32_t f = f_first + sub * 256u + (uint32_t)lane * 4u;
+    const bool live = (!GUARD || sub < total_sub) && lane_on;
+    const uint32_t f = f_first + sub * SUBF + (uint32_t)lane * 4u;
     const bool dead = f / RQ > last_q;
     if constexpr (!BQ) {
       if (live) {
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
             }
           }
         }
-        if (lane == 63) {
+        if (lane == last_lane) {
 #pragma unroll
           for (int c = 0; c < C; c++) {
             wz[wave][c][0] = r1[c];
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
         }
         s1[c] = t1;
         s2[c] = t2;
-        if (wave + 1u == cs && lane == 63 && live) {  // (lane 63 holds the wave's own end state in r1 / r2)
+        if (wave + 1u == cs && lane == last_lane && live) {  // (the last lane holds the wave's own end state in r1 / r2)
           ystate[parity ^ 1u][c][0] = __builtin_fma(A64.a, t1, __builtin_fma(A64.b, t2, r1[c]));
           ystate[parity ^ 1u][c][1] = __builtin_fma(A64.c, t1, __builtin_fma(A64.d, t2, r2[c]));
         }
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
 static int echo_chunk_for(float dmin, float dmax);
 
 // The loop step `d` (one element-wise launch per block, ChainDesc::tile0 / tile1 = the whole render) as the LDS-ring kernel?
-// Returns the index of the feedback input and the chunk size (sub-tiles of 256 frames), or -1.
+// Returns the index of the feedback input and the chunk size (frames), or -1.
 int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, int* chunk_subtiles) {
   if (d.n_ops != 0 || d.in_nch < 1 || d.in_nch > 2 || d.out.nch != d.in_nch || d.n_inputs < 2 || d.n_inputs > 1 + ECHO_EXT) return -1;
   int fb = -1;
@@ -564,8 +568,8 @@ int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, Echo
   return 1;
 }
 
-int echo_ring_frames(float dmax_frames, int chunk_subtiles) {
-  int need = (int)std::ceil(dmax_frames) + chunk_subtiles * 256 + 8, rf = 1024;
+int echo_ring_frames(float dmax_frames, int chunk_frames) {
+  int need = (int)std::ceil(dmax_frames) + chunk_frames + 8, rf = 1024;
   while (rf < need && rf < ECHO_RING) rf <<= 1;
   return rf;
 }
@@ -575,8 +579,9 @@ static int echo_chunk_for(float dmin, float dmax) {
   // (round 4: down to ONE sub-tile — a comb filter's / a plucked string's feedback delay of a few hundred frames walks in chunks
   // of 256 frames, one wavefront per instance, with a ring as small as its delay needs: many instances per CU)
   // (the largest chunk that fits BOTH ends: a batch whose delays span 4200 .. 13000 frames walks in chunks of 2048, not 4096)
-  for (int cand : {16, 8, 4, 2, 1})
-    if ((float)(cand * 256 + 8) <= dmin && dmax <= (float)(ECHO_RING - cand * 256 - 8)) return cand;
+  // (128: half a wavefront — the plucked string above ~180 Hz has a delay below 264 frames)
+  for (int cand : {4096, 2048, 1024, 512, 256, 128})
+    if ((float)(cand + 8) <= dmin && dmax <= (float)(ECHO_RING - cand - 8)) return cand;
   return 0;
 }
 
@@ -612,8 +617,8 @@ int echo_bq_applicable(const ChainDesc& rd, const BiquadStreamDesc& f, const Cha
   if ((uint64_t)sum.n_tiles * TILE >= (1ull << 31)) return -1;
   if (fb < 0 || ((uintptr_t)sum.out.base & 15) || (sum.out.ch_stride & 3) || (sum.out.inst_stride & 3)) return -1;
   int ch = 0;
-  for (int cand : {ECHO_BQ_WAVES, 4, 2, 1})
-    if (!ch && (float)(cand * 256 + 8) <= delay_min_max_frames[0] && delay_min_max_frames[1] <= (float)(ECHO_RING - cand * 256 - 8)) ch = cand;
+  for (int cand : {ECHO_BQ_WAVES * 256, 1024, 512, 256, 128})
+    if (!ch && (float)(cand + 8) <= delay_min_max_frames[0] && delay_min_max_frames[1] <= (float)(ECHO_RING - cand - 8)) ch = cand;
   if (!ch) return -1;
   *chunk_subtiles = ch;
   EchoBq q{};
@@ -644,7 +649,7 @@ int echo_feed_forward(const ChainDesc& st, ChainDesc* line, EchoTail* tail, cons
   if (D.feedback) return no("the delay line is written inside a loop");
   if (!(D.offset.mode == 0 || D.offset.mode == 3) || D.delay_hi < D.delay_lo) return no("the delay is not one host-known value per instance");
   const int chunk = echo_chunk_for(D.delay_lo, D.delay_hi);
-  if (chunk < 4) return no("a delay outside the ring's window");  // (chunks below 1024 frames: the tile-parallel launch is the better fit)
+  if (chunk < 1024) return no("a delay outside the ring's window");  // (chunks below 1024 frames: the tile-parallel launch is the better fit)
   if ((uint64_t)st.n_tiles * TILE >= (1ull << 31)) return no("more than 2^31 frames");
   if (D.nch < 1 || D.nch > 2 || ((uintptr_t)D.sig.base & 15) || (D.sig.ch_stride & 3) || (D.sig.inst_stride & 3))
     return no("the delayed signal is wider than stereo or not 16-byte aligned");
@@ -673,13 +678,15 @@ int echo_feed_forward(const ChainDesc& st, ChainDesc* line, EchoTail* tail, cons
   return chunk;
 }
 
-void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, int ring_frames, const EchoTail* tail, void* stream, const EchoBq* bq) {
+void launch_echo_ring(const ChainDesc& d, int fb, int chunk_frames, int ring_frames, const EchoTail* tail, void* stream, const EchoBq* bq) {
+  const int chunk_subtiles = std::max(1, chunk_frames / 256);
   if (ring_frames < 1024 || ring_frames > ECHO_RING || (ring_frames & (ring_frames - 1))) ring_frames = ECHO_RING;
   const size_t lds = (size_t)d.in_nch * (size_t)ring_frames * sizeof(float);
   const int ct = tail ? tail->in_nch : 0;
   EchoTail t{};
   if (tail) t = *tail;
   t.ring_frames = ring_frames;
+  t.sub_frames = chunk_frames >= 256 ? 256 : 128;
   if (bq) {
     t.delay = bq->delay;
     t.sample_rate = bq->sample_rate;

@@ -673,7 +673,7 @@ void launch_chain(const ChainDesc& d, int cmax, void* stream);
 // rendered by the same launch; store_line == 0: nothing else reads the line, it stays in LDS
 struct EchoTail {
   int32_t n_inputs, in_nch, in_interp, store_line;
-  int32_t ring_frames, pad_rf;  // frames per channel of the LDS ring (a power of two; set by the launcher)
+  int32_t ring_frames, sub_frames;  // frames per channel of the LDS ring (a power of two) / per wavefront and chunk (256 or 128): set by the launcher
   InputRef in[MAX_INPUTS];
   int32_t alias[MAX_INPUTS];  // -2: the delayed line; s >= 0: the same signal as the loop step's s-th input from outside the loop
   SignalRef out;
@@ -690,7 +690,7 @@ struct EchoBq {
   ParamRef delay;             // the DelayNode's delayTime and rate (the delayed read is not an input of the sum here)
   double sample_rate;
 };
-int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, int* chunk_subtiles);
+int echo_ring_applicable(const ChainDesc& d, const float* delay_min_max_frames, int* chunk_frames);
 // the three body launches of a block-scheduled loop  delayed read -> streaming biquad -> sum into the line  as the BQ form?
 // Returns the index of the sum's input that reads the filter's output (and fills bq / the chunk size), or -1.
 struct BiquadStreamDesc;
@@ -702,8 +702,8 @@ int echo_bq_applicable(const ChainDesc& read, const BiquadStreamDesc& filter, co
 int echo_feed_forward(const ChainDesc& step, ChainDesc* line, EchoTail* tail, const char** why);
 int echo_tail_applicable(const ChainDesc& d, int fb, const ChainDesc& tail, EchoTail* t, const char** why, const EchoBq* bq = nullptr);
 // frames per channel the ring needs for delays up to dmax with this chunk size: a power of two in [1024, 16384]
-int echo_ring_frames(float dmax_frames, int chunk_subtiles);
-void launch_echo_ring(const ChainDesc& d, int fb, int chunk_subtiles, int ring_frames, const EchoTail* tail, void* stream, const EchoBq* bq = nullptr);
+int echo_ring_frames(float dmax_frames, int chunk_frames);
+void launch_echo_ring(const ChainDesc& d, int fb, int chunk_frames, int ring_frames, const EchoTail* tail, void* stream, const EchoBq* bq = nullptr);
 // dst[inst][q] = src[inst * inst_stride + q * 128]: the first frame of every render quantum of a per-frame table
 void launch_quantum_heads(const float* src, uint64_t inst_stride, uint32_t n_inst, uint32_t n_quanta, float* dst, void* stream);
 // waa_resample.hip: AudioBufferSource [-> WaveShaper] -> signal without the op interpreter (the C5 shape)

@@ -1894,7 +1894,7 @@ int build_plan(waa_batch* b) {
             b->steps[body].echo_ring = echo_ring_frames(range[1], chunk);
             b->steps[body].profile_slot = slot_for(b, "echo_ring_kernel");
             plan_note(b, "  ... rendered by the LDS-ring kernel in ONE launch: delay %.0f .. %.0f frames, chunks of %d frames, the line's last %d frames stay in LDS",
-                      (double)range[0], (double)range[1], chunk * 256, b->steps[body].echo_ring);
+                      (double)range[0], (double)range[1], chunk, b->steps[body].echo_ring);
           }
         }
         // delayed read -> streaming biquad (constant coefficients) -> sum into the line: the filtered echo, the ring kernel's BQ form
@@ -1925,7 +1925,7 @@ int build_plan(waa_batch* b) {
             sm.echo_bq = q;
             sm.profile_slot = slot_for(b, "echo_ring_kernel");
             plan_note(b, "  ... rendered by the LDS-ring kernel in ONE launch with the Biquad between the delayed read and the sum: delay %.0f .. %.0f frames, chunks of %d frames",
-                      (double)range[0], (double)range[1], chunk * 256);
+                      (double)range[0], (double)range[1], chunk);
           }
         }
         // a loop SHORTER than a tile was planned this way only for the ring kernel (loop_block_tiles): launches per block cannot

@@ -173,7 +173,7 @@ void ring_feed_forward_echoes(waa_batch* b) {
     st.echo_ring = echo_ring_frames(delayed_hi, chunk);
     st.profile_slot = slot_for(b, "echo_ring_kernel");
     plan_note(b, "launch %zu (delayed signal + %d more input(s), no ops) is rendered by the LDS-ring kernel with nothing fed back: delay %.0f .. %.0f frames, chunks of %d frames",
-              k, t.n_inputs - 1, (double)delayed_lo, (double)delayed_hi, chunk * 256);
+              k, t.n_inputs - 1, (double)delayed_lo, (double)delayed_hi, chunk);
   }
 }
 
@@ -289,7 +289,7 @@ uint32_t loop_block_tiles(waa_batch* b, const std::vector<uint32_t>& loop_items)
     // 256 frames.  A loop of the shapes it renders (ONE DelayNode with one delayTime per instance, GainNodes, at most one
     // constant-coefficient Biquad, nothing modulated) is planned like a block-scheduled loop; build_plan checks that the
     // ring kernel took it and plans again without this branch otherwise (no_short_ring).
-    if (b->no_short_ring || measure_switch("WAA_NO_ECHO_RING") || measure_switch("WAA_NO_SHORT_RING") || dmin < 264.) return 0;
+    if (b->no_short_ring || measure_switch("WAA_NO_ECHO_RING") || measure_switch("WAA_NO_SHORT_RING") || dmin < 136.) return 0;
     int n_delay = 0, n_biquad = 0;
     uint32_t delay_id = 0;
     for (uint32_t v : loop_items) {
