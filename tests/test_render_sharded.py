@@ -206,3 +206,53 @@ def test_sharded_render_with_the_big_lds_kernels(hip, orc, two_devices):
     assert rms_err(out, ref).max() <= 1e-6 and np.abs(ref).max() > 1e-3
     gl, ol = 10.0 ** (bins.astype(np.float64) / 20), 10.0 ** (ref_bins.astype(np.float64) / 20)
     assert (np.abs(gl - ol).max(axis=1) / ol.max(axis=1)).max() <= 2e-5   # (a 32768-point f32 transform on each side)
+
+
+def _build_modulated(be):
+    """an LFO on the Biquad's frequency and a vibrato on the streamed source's playbackRate: the second makes the plan render the
+    modulating subgraph (waa_render_sharded must then plan AFTER the source's data is there, not before its turn on the link)"""
+    def build(n, device):
+        ctx = waa.OfflineAudioContext(2, RQ * 40 + 5, 48000.0, n_instances=n, binding=be, device=device)
+        src = ctx.create_buffer_source()
+        bq = ctx.create_biquad_filter(type_="lowpass", frequency=900.0, q=1.0)
+        lfo = ctx.create_oscillator(type_="sine", frequency=5.0)
+        lfo.connect(ctx.create_gain(gain=300.0)).connect(bq.frequency)
+        vib = ctx.create_oscillator(type_="sine", frequency=3.0)
+        vib.connect(ctx.create_gain(gain=0.02)).connect(src.playback_rate)
+        src.connect(bq).connect(ctx.destination())
+        lfo.start()
+        vib.start()
+        src.start()
+        return ctx, src
+    return build
+
+
+@pytest.mark.gpu
+def test_sharded_render_of_a_graph_with_modulated_params_hip(hip, orc):
+    n, frames = 7, RQ * 40 + 5
+    noise = white_noise(n, 2, frames)
+    out = np.zeros((n, 2, frames), np.float32)
+    render_sharded(_build_modulated(hip), noise, out, devices=[0], sub_batches=3)
+    ctx, src = _build_modulated(hip)(n, 0)
+    src.set_buffer_batch(noise, 48000.0)
+    whole = ctx.start_rendering_sync().data
+    ctx.close()
+    assert np.array_equal(out, whole)
+    ctx, src = _build_modulated(orc)(n, -1)
+    src.set_buffer_batch(noise, 48000.0)
+    ref = ctx.start_rendering_sync().data
+    ctx.close()
+    assert rms_err(out, ref).max() <= 1e-6 and np.abs(ref).max() > 0.05
+
+
+@pytest.mark.gpu
+def test_sharded_render_pcm16_input_at_another_rate_hip(hip, orc):
+    """16-bit PCM at 44.1 kHz into a 48 kHz context: the deferred fill goes through the device's decode + resample kernel"""
+    n, frames_in = 9, 3600
+    rng = np.random.default_rng(5)
+    pcm = rng.integers(-20000, 20000, (n, frames_in, 2)).astype(np.int16)
+    out = np.zeros((n, 2, RQ * 30 + 5), np.float32)
+    render_sharded(_build(hip), pcm, out, devices=[0], sub_batches=4, pcm16=True, sample_rate=44100.0)
+    ref = np.zeros_like(out)
+    render_sharded(_build(orc), pcm, ref, devices=[-1], sub_batches=1, pcm16=True, sample_rate=44100.0)
+    assert rms_err(out, ref).max() <= 1e-6 and np.abs(ref).max() > 0.01
