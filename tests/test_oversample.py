@@ -125,7 +125,7 @@ def test_curve_twice_is_an_error(be):
 
 # ---- the definition ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("oversample,factor", [("2x", 2), ("4x", 4)])
-@pytest.mark.parametrize("n_ch", [1, 2])
+@pytest.mark.parametrize("n_ch", [1, 2, 3, 4, 6])
 def test_matches_the_written_definition(be, oversample, factor, n_ch):
     nq = 12
     length = nq * RQ - 37  # (a truncated last quantum)
@@ -281,6 +281,43 @@ def test_max_mode_stereo_source_recreates_the_resamplers_at_silence(be):
     # (and the two differ where it matters: the first quantum after the source stopped)
     keep = definition_render(np.concatenate([np.zeros(2 * RQ), x[0, 0], np.zeros(4 * RQ)]), curve, 2, can_propagate=False)
     assert rms(out[0, 6 * RQ:7 * RQ], keep[6 * RQ:7 * RQ]) > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("oversample", ["2x", "4x"])
+def test_quad_source_joins_a_mono_one_in_front_of_an_oversampled_shaper(hip, orc, oversample):
+    """a mono source from t = 0 and a 4-channel source from quantum 7 (per instance) into ONE oversampled shaper: the count of its input
+    changes mid-render (1 -> 4 -> 1), the resamplers are re-created for every channel at each change (waveshaper.rs:409-425); the
+    dynamic-count plan publishes the shaper's 4-channel input, the transform kernel renders it as two channel pairs (round 4: such
+    graphs were refused)"""
+    n, nq = 3, 40
+    rng = np.random.default_rng(31)
+    mono = rng.uniform(-1, 1, (n, 1, nq * RQ)).astype(np.float32) * 0.6
+    quad = rng.uniform(-1, 1, (n, 4, 12 * RQ)).astype(np.float32) * 0.6
+    outs = []
+    for be in (hip, orc):
+        ctx = waa.OfflineAudioContext(4, nq * RQ - 9, 48000.0, n_instances=n, binding=be)
+        a = ctx.create_buffer_source()
+        a.set_buffer_batch(mono, 48000.0)
+        b_ = ctx.create_buffer_source()
+        b_.set_buffer_batch(quad, 48000.0)
+        ws = ctx.create_wave_shaper(curve=TANH, oversample=oversample)
+        a.connect(ws)
+        b_.connect(ws)
+        ws.connect(ctx.destination())
+        a.start()
+        for i in range(n):
+            b_.start_at((7 * RQ + 13 * i) / 48000.0, instance=i)
+        if be is hip:
+            plan = ctx.plan_describe()
+            assert "dynamic-count group" in plan and "4 channel(s)" in plan, plan
+        outs.append(ctx.start_rendering_sync().data)
+        ctx.close()
+    g, o = outs
+    assert np.abs(o[:, 3]).max() > 0.05
+    for i in range(n):
+        for c in range(4):
+            assert rms(g[i, c], o[i, c]) <= 1e-6, (i, c, rms(g[i, c], o[i, c]))
 
 
 @pytest.mark.gpu

@@ -223,45 +223,52 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
   const int up_len = RQ * R;
   const int nch = n.in_nch;
   const bool matrix_form = measure_switch("WAA_OS_MATRIX") != nullptr;  // (A/B: the round-2 dense products on the matrix cores)
-  if (!matrix_form && nch <= 2) {
-    // Transform form (waa_osfft.hip): one launch, the stages as 256-point transforms, nothing at the high rate in HBM.
+  if (!matrix_form) {
+    // Transform form (waa_osfft.hip): one launch per channel PAIR (a pair is one complex transform, L + iR; an odd last channel goes
+    // alone), the stages as 256-point transforms, nothing at the high rate in HBM.  Every pair follows the same link table: the
+    // node's state is reset for all channels when the input's count changes (waveshaper.rs:409-425).
     float *d_tab = nullptr, *d_tw = nullptr;
     float* d_trash = nullptr;
     if ((e = dev_upload(b, &d_tab, osfft::tables(R))) || (e = dev_upload(b, &d_tw, osfft::tw256())) || (e = dev_alloc(b, &d_trash, 64))) return e;
-    Step os;
-    os.kind = 20;
-    OsFftDesc& f = os.osfft;
-    std::memset(&f, 0, sizeof f);
-    f.src = in_sig.base;
-    f.src_inst = in_sig.inst_stride;
-    f.src_ch = in_sig.ch_stride;
-    f.dst = n.sig.base;
-    f.dst_inst = n.sig.inst_stride;
-    f.dst_ch = n.sig.ch_stride;
-    f.prev = prev;
-    f.prev_stride = b->n_quanta;
-    f.curve = n.d_curve;
-    f.curve_n = (int32_t)cn;
-    f.R = R;
-    f.tables = d_tab;
-    f.tw256 = d_tw;
-    f.trash = d_trash;
-    f.nch = nch;
-    f.n_inst = b->n_inst;
-    f.n_quanta = b->n_quanta;
-    // runs: ~16 k groups of 16 lanes in the launch (4 waves per SIMD's worth), never shorter than 8 quanta (two more are
-    // rendered in front of every run for its overlaps)
-    const uint32_t want = std::max<uint32_t>(1, (16384 + b->n_inst - 1) / b->n_inst);
-    uint32_t seg = std::max<uint32_t>(8, (b->n_quanta + want - 1) / want);
-    if (const char* sv = measure_switch("WAA_OSFFT_SEG")) seg = std::max(1, atoi(sv));  // (tests: short runs exercise the run heads)
-    f.seg_len = seg;
-    f.n_seg = (b->n_quanta + seg - 1) / seg;
-    os.profile_slot = slot_for(b, "osfft_kernel");
-    os.loop_reads.push_back(in_sig.base);
-    os.loop_writes.push_back(n.sig.base);
-    b->steps.push_back(os);
+    uint32_t seg_len = 0, n_seg = 0;
+    for (int c0 = 0; c0 < nch; c0 += 2) {
+      Step os;
+      os.kind = 20;
+      OsFftDesc& f = os.osfft;
+      std::memset(&f, 0, sizeof f);
+      f.src = in_sig.base + (uint64_t)c0 * in_sig.ch_stride;
+      f.src_inst = in_sig.inst_stride;
+      f.src_ch = in_sig.ch_stride;
+      f.dst = n.sig.base + (uint64_t)c0 * n.sig.ch_stride;
+      f.dst_inst = n.sig.inst_stride;
+      f.dst_ch = n.sig.ch_stride;
+      f.prev = prev;
+      f.prev_stride = b->n_quanta;
+      f.curve = n.d_curve;
+      f.curve_n = (int32_t)cn;
+      f.R = R;
+      f.tables = d_tab;
+      f.tw256 = d_tw;
+      f.trash = d_trash;
+      f.nch = std::min(2, nch - c0);
+      f.n_inst = b->n_inst;
+      f.n_quanta = b->n_quanta;
+      // runs: ~16 k groups of 16 lanes in the launch (4 waves per SIMD's worth), never shorter than 8 quanta (two more are
+      // rendered in front of every run for its overlaps)
+      const uint32_t want = std::max<uint32_t>(1, (16384 + b->n_inst - 1) / b->n_inst);
+      uint32_t seg = std::max<uint32_t>(8, (b->n_quanta + want - 1) / want);
+      if (const char* sv = measure_switch("WAA_OSFFT_SEG")) seg = std::max(1, atoi(sv));  // (tests: short runs exercise the run heads)
+      f.seg_len = seg;
+      f.n_seg = (b->n_quanta + seg - 1) / seg;
+      seg_len = f.seg_len;
+      n_seg = f.n_seg;
+      os.profile_slot = slot_for(b, "osfft_kernel");
+      os.loop_reads.push_back(in_sig.base);
+      os.loop_writes.push_back(n.sig.base);
+      b->steps.push_back(os);
+    }
     plan_note(b, "waveshaper node %u: %dx oversampling as %d 256-point transforms per quantum in one launch (runs of %u quanta, %u per instance), %d channel(s)%s",
-              id, R, 2 + 2 * R, f.seg_len, f.n_seg, nch, can_propagate ? ", silent input skips the block" : "");
+              id, R, 2 + 2 * R, seg_len, n_seg, nch, can_propagate ? ", silent input skips the block" : "");
     return 0;
   }
   float *d_up = nullptr, *d_dn = nullptr, *sbuf = nullptr;

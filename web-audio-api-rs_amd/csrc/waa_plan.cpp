@@ -1305,7 +1305,7 @@ int build_plan(waa_batch* b) {
       const uint32_t p = b->edges[n.in_edges[0]].from;
       const uint32_t pk = b->nodes[p].desc.kind;
       simple = (pk == WAA_NODE_BUFFER_SOURCE || pk == WAA_NODE_CONSTANT_SOURCE || pk == WAA_NODE_OSCILLATOR) &&
-               b->nodes[p].out_nch == n.in_nch && n.in_nch <= 2;
+               b->nodes[p].out_nch == n.in_nch && n.in_nch <= (n.desc.kind == WAA_NODE_WAVESHAPER ? 6 : 2);
       if (simple) frozen_src[id] = (int)p;
     }
     if (!simple && !measure_switch("WAA_STATIC_CHANNEL_COUNTS")) {
