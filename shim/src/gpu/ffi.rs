@@ -47,10 +47,12 @@ pub const WAA_NODE_BIQUAD: u32 = 2;
 pub const WAA_NODE_GAIN: u32 = 3;
 pub const WAA_NODE_CONVOLVER: u32 = 4;
 pub const WAA_NODE_STEREO_PANNER: u32 = 5;
+pub const WAA_NODE_PANNER: u32 = 6;
 pub const WAA_NODE_ANALYSER: u32 = 7;
 pub const WAA_NODE_WAVESHAPER: u32 = 8;
 pub const WAA_NODE_CONSTANT_SOURCE: u32 = 9;
 pub const WAA_NODE_IIR_FILTER: u32 = 10;
+pub const WAA_NODE_DELAY: u32 = 11;
 pub const WAA_NODE_OSCILLATOR: u32 = 12;
 
 pub const WAA_COUNT_MODE_MAX: u32 = 0;
@@ -107,6 +109,8 @@ extern "C" {
         sample_rate: f32,
     ) -> i32;
     pub fn waa_waveshaper_set_curve(batch: *mut waa_batch, node: u32, curve: *const f32, n: u32) -> i32;
+    /// load_hrtf_processor's database (panner.rs:39-68): once per process, before the first HRTF PannerNode renders
+    pub fn waa_hrtf_load_sphere(data: *const std::ffi::c_void, size: u64) -> i32;
     pub fn waa_iir_set_coefficients(
         batch: *mut waa_batch,
         node: u32,

@@ -96,6 +96,28 @@ pub(crate) enum GpuNode<'a> {
     Analyser {
         ring_buffer: &'a AnalyserRingBuffer,
     },
+    /// One half of a DelayNode (delay.rs:316-357 registers a writer and a reader processor that share a ring): the library has ONE
+    /// node per DelayNode and breaks cycles itself (graph.rs:323-487 restated in its planner), so the writer half becomes that node
+    /// and the reader half — the one with the delayTime param — is folded into it.  `ring` pairs the halves.
+    Delay {
+        ring: usize,
+        delay_time: Option<u64>,
+        /// capacity of the ring in render quanta = num_quanta + 1 (delay.rs:300-302)
+        capacity: usize,
+    },
+    /// PannerRenderer (panner.rs:667-683): six a-rate params, the distance / cone model, equal-power or HRTF
+    Panner {
+        position: [u64; 3],
+        orientation: [u64; 3],
+        distance_model: u32,
+        ref_distance: f64,
+        max_distance: f64,
+        rolloff_factor: f64,
+        cone_inner_angle: f64,
+        cone_outer_angle: f64,
+        cone_outer_gain: f64,
+        hrtf: bool,
+    },
 }
 
 impl GpuNode<'_> {
@@ -113,6 +135,9 @@ impl GpuNode<'_> {
             GpuNode::WaveShaper { .. } => ffi::WAA_NODE_WAVESHAPER,
             GpuNode::IirFilter { .. } => ffi::WAA_NODE_IIR_FILTER,
             GpuNode::Analyser { .. } => ffi::WAA_NODE_ANALYSER,
+            GpuNode::Delay { delay_time: None, .. } => ffi::WAA_NODE_DELAY,
+            GpuNode::Delay { delay_time: Some(_), .. } => return None, // (the reader half: GraphShape::from_graph folds it)
+            GpuNode::Panner { .. } => ffi::WAA_NODE_PANNER,
         })
     }
 
@@ -137,6 +162,17 @@ impl GpuNode<'_> {
             GpuNode::Oscillator {
                 frequency, detune, ..
             } => vec![(frequency, 0), (detune, 1)],
+            // WAA_PARAM_PANNER_POSITION_X .. ORIENTATION_Z = 0 .. 5 (the listener's nine follow at 6 .. 14, forward_payloads)
+            GpuNode::Panner {
+                position, orientation, ..
+            } => vec![
+                (position[0], 0),
+                (position[1], 1),
+                (position[2], 2),
+                (orientation[0], 3),
+                (orientation[1], 4),
+                (orientation[2], 5),
+            ],
             _ => vec![],
         }
     }
@@ -165,25 +201,45 @@ struct GraphShape {
     index_of: HashMap<u64, u32>,
     /// AudioParam node id -> (owner index, param index)
     param_owner: HashMap<u64, (u32, u32)>,
+    /// indices of the PannerNodes: the AudioListener's nine params (node ids 2..=10) are forwarded through each of them
+    panners: Vec<u32>,
 }
 
 const LISTENER_AND_ITS_PARAMS: std::ops::RangeInclusive<u64> = 1..=10; // LISTENER_NODE_ID = 1, LISTENER_PARAM_IDS = 2..=10 (context/mod.rs)
 
 impl GraphShape {
-    fn from_graph(graph: &Graph) -> Result<Self, Fallback> {
+    fn from_graph(graph: &Graph, sample_rate: f32) -> Result<Self, Fallback> {
         let views = graph.gpu_nodes();
         let mut nodes = Vec::new();
         let mut index_of = HashMap::new();
         let mut param_owner = HashMap::new();
+        let mut panners = Vec::new();
+        let mut delay_of_ring: HashMap<usize, u32> = HashMap::new(); // ring -> index of the writer half's node
+        let mut delay_halves: std::collections::HashSet<u64> = std::collections::HashSet::new();
         // pass 1: nodes that are not AudioParams, in id order (id 0 is the destination: the library wants it first)
         for v in &views {
             if LISTENER_AND_ITS_PARAMS.contains(&v.id.0) {
-                continue; // the AudioListener only matters to PannerNodes, which this version does not forward
+                continue; // the AudioListener is no node of the library: its params go through the PannerNodes (forward_payloads)
             }
             let desc = v
                 .processor()
                 .gpu_desc()
                 .ok_or_else(|| Fallback::UnsupportedNode(v.processor().name().to_string()))?;
+            if let GpuNode::Delay {
+                ring,
+                delay_time: Some(param_id),
+                ..
+            } = &desc
+            {
+                // the reader half: registered after its writer (delay.rs:316-317: the outer `register` takes its id first)
+                let &idx = delay_of_ring
+                    .get(ring)
+                    .ok_or_else(|| Fallback::UnsupportedNode("DelayReader without its DelayWriter".into()))?;
+                index_of.insert(v.id.0, idx);
+                param_owner.insert(*param_id, (idx, 0)); // WAA_PARAM_DELAY_DELAY_TIME
+                delay_halves.insert(v.id.0);
+                continue;
+            }
             let Some(kind) = desc.kind() else { continue };
             let (count, mode, interp) = v.channel_config();
             let mut d = ffi::waa_node_desc {
@@ -213,9 +269,47 @@ impl GraphShape {
                     d.d[1] = -100.;
                     d.d[2] = -30.;
                 }
+                // max_delay_time: the library derives num_quanta = ceil(max_delay * sample_rate / 128) like delay.rs:300-301; half a
+                // quantum below capacity - 1 quanta gives exactly the reference's ring
+                GpuNode::Delay { capacity, .. } => {
+                    d.d[0] = (capacity.saturating_sub(1) as f64 - 0.5).max(0.25) * RENDER_QUANTUM_SIZE as f64 / sample_rate as f64
+                }
+                GpuNode::Panner {
+                    distance_model,
+                    ref_distance,
+                    max_distance,
+                    rolloff_factor,
+                    cone_inner_angle,
+                    cone_outer_angle,
+                    cone_outer_gain,
+                    hrtf,
+                    ..
+                } => {
+                    d.i[0] = i32::from(*hrtf); // WAA_PANNING_EQUALPOWER / WAA_PANNING_HRTF
+                    d.i[1] = *distance_model as i32;
+                    d.d[0] = *ref_distance;
+                    d.d[1] = *max_distance;
+                    d.d[2] = *rolloff_factor;
+                    d.d[3] = *cone_inner_angle;
+                    d.d[4] = *cone_outer_angle;
+                    d.d[5] = *cone_outer_gain;
+                }
                 _ => {}
             }
             let idx = nodes.len() as u32;
+            match &desc {
+                GpuNode::Delay { ring, .. } => {
+                    delay_of_ring.insert(*ring, idx);
+                    delay_halves.insert(v.id.0);
+                }
+                GpuNode::Panner { hrtf, .. } => {
+                    if *hrtf {
+                        load_hrtf_sphere_once()?;
+                    }
+                    panners.push(idx);
+                }
+                _ => {}
+            }
             for (param_id, param_index) in desc.params() {
                 param_owner.insert(param_id, (idx, param_index));
             }
@@ -235,6 +329,9 @@ impl GraphShape {
                     continue;
                 }
                 if let Some(&to) = index_of.get(&other.0) {
+                    if to == from && v.id != other && delay_halves.contains(&v.id.0) && delay_halves.contains(&other.0) {
+                        continue; // the writer -> reader edge of one DelayNode (delay.rs:365): inside the library's node
+                    }
                     edges.push(ffi::waa_edge_desc {
                         from,
                         from_output: output as u32,
@@ -248,7 +345,13 @@ impl GraphShape {
                         to: owner,
                         to_input: ffi::waa_param_input(param),
                     });
-                } else if !LISTENER_AND_ITS_PARAMS.contains(&other.0) {
+                } else if LISTENER_AND_ITS_PARAMS.contains(&other.0) {
+                    // an AudioListener param driven from the graph only matters when a PannerNode listens
+                    // (panner.rs:735-760: the listener's params are read through the panner's inputs)
+                    if !panners.is_empty() && other.0 != 1 {
+                        return Err(Fallback::UnsupportedNode("AudioListener param with an audio-rate input".into()));
+                    }
+                } else {
                     return Err(Fallback::UnsupportedNode(format!("edge into unknown node {}", other.0)));
                 }
             }
@@ -259,12 +362,30 @@ impl GraphShape {
             edges,
             index_of,
             param_owner,
+            panners,
         })
     }
 
     fn same_shape(&self, other: &Self) -> bool {
         self.nodes == other.nodes && self.edges == other.edges
     }
+}
+
+/// The HRIR database the crate embeds (panner.rs:55) handed to the library once per process
+fn load_hrtf_sphere_once() -> Result<(), Fallback> {
+    static LOADED: std::sync::OnceLock<Result<(), String>> = std::sync::OnceLock::new();
+    LOADED
+        .get_or_init(|| {
+            let bytes: &[u8] = include_bytes!("../../resources/IRC_1003_C.bin");
+            let st = unsafe { ffi::waa_hrtf_load_sphere(bytes.as_ptr().cast(), bytes.len() as u64) };
+            if st == ffi::WAA_OK {
+                Ok(())
+            } else {
+                Err(ffi::last_error())
+            }
+        })
+        .clone()
+        .map_err(Fallback::Library)
 }
 
 fn check(status: i32) -> Result<(), Fallback> {
@@ -338,6 +459,12 @@ fn forward_payloads(
         if let GpuNode::Param(p) = &desc {
             if let Some(&(owner, param)) = shape.param_owner.get(&v.id.0) {
                 forward_param(batch, inst, owner, param, p, param_has_input.contains(&(owner, param)), n_quanta, sample_rate)?;
+            } else if (2..=10).contains(&v.id.0) {
+                // LISTENER_AUDIO_PARAM_IDS (context/mod.rs:30-40: position x y z, forward x y z, up x y z) =
+                // WAA_PARAM_LISTENER_POSITION_X .. UP_Z = 6 .. 14, addressed through every PannerNode
+                for &panner in &shape.panners {
+                    forward_param(batch, inst, panner, 6 + (v.id.0 - 2) as u32, p, false, n_quanta, sample_rate)?;
+                }
             }
             continue;
         }
@@ -444,7 +571,7 @@ fn render_on_device(
             .renderer
             .gpu_prepare()
             .ok_or_else(|| Fallback::UnsupportedNode("render thread without a graph".into()))?;
-        let shape = GraphShape::from_graph(graph)?;
+        let shape = GraphShape::from_graph(graph, sample_rate)?;
         if i > 0 && !shape.same_shape(&shapes[0]) {
             return Err(Fallback::DifferentShape(i));
         }
