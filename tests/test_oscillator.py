@@ -415,3 +415,80 @@ def test_plan_replay_shortcut_agrees_with_the_frame_walk(hip, monkeypatch):
         osc.connect(c.destination())
         assert "oscillator node" in c.plan_describe()
         c.close()
+
+
+def _two_operator(binding, n, frames, variant, plan_only=False):
+    """modulator -> [Gain (index)] -> carrier.frequency -> destination, in the variants the FM fold has to tell apart:
+    plain        sine modulator, constant index (folded into the carrier's kernel)
+    square-mod   a band-limited square as the modulator, per-instance index, modulator starting late and stopping early
+    ramped-index the index and the carrier's intrinsic frequency ramp (a-rate params: values per frame — not folded)
+    no-gain      the modulator connected straight to the param
+    clamped      an index large enough to drive the sum past the param's range (the clamp of mix_to_output) and below zero
+    shared       the modulator ALSO reaches the destination (it has a second reader: not folded)
+    two-mods     two modulators summed on the param (more than one input: not folded)"""
+    kw = {"device": waa.PLAN_ONLY} if plan_only else {}
+    c = waa.OfflineAudioContext(1, frames, 48000.0, n_instances=n, binding=binding, **kw)
+    mod = c.create_oscillator(type_="square" if variant == "square-mod" else "sine", frequency=110.0)
+    car = c.create_oscillator(type_="sine", frequency=440.0)
+    for i in range(n):
+        mod.frequency.set_value(90.0 + 13.0 * i, instance=i)
+        car.detune.set_value(30.0 * i, instance=i)
+    head = mod
+    if variant != "no-gain":
+        idx = c.create_gain(gain=300.0)
+        if variant == "square-mod":
+            for i in range(n):
+                idx.gain.set_value(100.0 + 150.0 * i, instance=i)
+        if variant == "ramped-index":
+            idx.gain.set_value_at_time(50.0, 0.0).linear_ramp_to_value_at_time(900.0, frames / 48000.0)
+            car.frequency.set_value_at_time(440.0, 0.0).linear_ramp_to_value_at_time(880.0, frames / 48000.0 * 0.7)
+        if variant == "clamped":
+            idx.gain.set_value(60000.0)
+        head = mod.connect(idx)
+    head.connect(car.frequency)
+    if variant == "two-mods":
+        m2 = c.create_oscillator(type_="triangle", frequency=3.0)
+        m2.connect(c.create_gain(gain=20.0)).connect(car.frequency)
+        m2.start()
+    if variant == "shared":
+        mod.connect(c.create_gain(gain=0.1)).connect(c.destination())
+    car.connect(c.destination())
+    if variant == "square-mod":
+        mod.start_at(700.3 / 48000.0)
+        mod.stop_at(frames / 48000.0 * 0.6)
+    else:
+        mod.start()
+    car.start_at(0.0005)
+    plan = c.plan_describe() if binding.prefix == "waa_" else ""
+    out = None if plan_only else c.start_rendering_sync().data
+    c.close()
+    return out, plan
+
+
+FM_VARIANTS = ["plain", "square-mod", "ramped-index", "no-gain", "clamped", "shared", "two-mods"]
+FM_NOT_FOLDED = ("ramped-index", "shared", "two-mods")
+
+
+@pytest.mark.measure
+@pytest.mark.parametrize("variant", FM_VARIANTS)
+def test_plan_fm_fold(variant):
+    _, plan = _two_operator(waa.measure_binding(), 3, 128 * 40, variant, plan_only=True)
+    assert ("folded into the carrier's prefix-sum kernel" in plan) == (variant not in FM_NOT_FOLDED), plan
+
+
+@pytest.mark.measure
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", FM_VARIANTS)
+def test_parity_fm_fold(hip, orc, variant, monkeypatch):
+    """the carrier evaluating modulator, index and mix_to_output itself (OscDesc::fm_*) is the same arithmetic as the three
+    launches it stands for: bit-identical to them (WAA_NO_FM_FOLD), and within the oscillator's tolerance of the oracle"""
+    n, frames = 3, 128 * 60 + 37
+    g, plan = _two_operator(hip, n, frames, variant)
+    assert ("folded into the carrier's prefix-sum kernel" in plan) == (variant not in FM_NOT_FOLDED), plan
+    o, _ = _two_operator(orc, n, frames, variant)
+    assert np.abs(o).max() > 0.5
+    assert np.abs(g - o).max() <= 2e-4 and rms_err(g, o).max() <= 2e-5, (float(np.abs(g - o).max()), rms_err(g, o))
+    monkeypatch.setenv("WAA_NO_FM_FOLD", "1")
+    u, plan = _two_operator(hip, n, frames, variant)
+    assert "folded into the carrier" not in plan
+    assert np.array_equal(g, u)

@@ -353,6 +353,16 @@ struct OscDesc {
   ParamRef post_gain[2];
   int32_t n_post;
   int32_t post_dup;
+  // Two-operator FM folded into the carrier (prefix-sum kernel, round 4): the `frequency` AudioParam's only input is ONE
+  // oscillator with a host-known frequency (its time-parallel table `fm_q`), through at most one edge gain — the carrier
+  // evaluates modulator, gain and AudioParamProcessor::mix_to_output (param.rs:737-795) per frame itself instead of reading a
+  // per-frame table three launches wrote and read back (fm_q == nullptr: not folded; `frequency` then is the intrinsic value).
+  const struct OscQuantum* fm_q;  // [n_inst][n_quanta] of the MODULATOR
+  const float* fm_table;
+  int32_t fm_table_len, fm_type;
+  ParamRef fm_gain;               // mode 0 / 1 (fm_has_gain)
+  int32_t fm_has_gain;
+  float fm_min, fm_max, fm_default;
 };
 constexpr int OSC_SEGMENTS = 8;  // time segments per instance of the prefix-sum oscillator (one wavefront each)
 // Per-(instance, quantum) record of the time-parallel oscillator: frames [first, end) of the quantum are active,

@@ -40,8 +40,8 @@ __device__ __forceinline__ float table_sample(const float* table, int len, doubl
   const float k = (float)(position - floored);
   return __builtin_fmaf(table[prev_index], 1.f - k, table[next_index] * k);
 }
-__device__ __forceinline__ float waveform_sample(const OscDesc& d, double phase, double phase_incr) {  // :561-602
-  switch (d.type) {
+__device__ __forceinline__ float waveform_sample(int type, const float* table, int table_len, double phase, double phase_incr) {  // :561-602
+  switch (type) {
     case 1: {  // square
       double sample = phase < 0.5 ? 1.0 : -1.0;
       sample += poly_blep(phase, phase_incr);
@@ -62,8 +62,11 @@ __device__ __forceinline__ float waveform_sample(const OscDesc& d, double phase,
         sample = -2. - sample;
       return (float)sample;
     }
-    default: return table_sample(d.table, d.table_len, phase);  // sine (2048) or custom (8192)
+    default: return table_sample(table, table_len, phase);  // sine (2048) or custom (8192)
   }
+}
+__device__ __forceinline__ float waveform_sample(const OscDesc& d, double phase, double phase_incr) {
+  return waveform_sample(d.type, d.table, d.table_len, phase, phase_incr);
 }
 }  // namespace
 
@@ -241,14 +244,37 @@ __global__ __launch_bounds__(64) void osc_scan_kernel(const OscDesc d) {
     const uint64_t f0 = g0 + (uint64_t)lane * 4;
     double incr[4];
     bool outside[4];
+    OscQuantum mq4{};
+    if (d.fm_q) {
+      const uint64_t fq = f0 < (uint64_t)d.n_quanta * RQ ? f0 : (uint64_t)d.n_quanta * RQ - 1;
+      mq4 = d.fm_q[(uint64_t)inst * d.n_quanta + fq / RQ];
+    }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const uint64_t f = f0 + e;
       const uint64_t fc = f < (uint64_t)d.n_quanta * RQ ? f : (uint64_t)d.n_quanta * RQ - 1;
       const uint32_t q = (uint32_t)(fc / RQ);
-      const float freq = d.frequency.mode == 0   ? d.frequency.base[inst]
-                         : d.frequency.mode == 1 ? d.frequency.base[(uint64_t)inst * d.frequency.stride + q]
-                                                 : d.frequency.base[(uint64_t)inst * d.frequency.stride + fc];
+      float freq = d.frequency.mode == 0   ? d.frequency.base[inst]
+                   : d.frequency.mode == 1 ? d.frequency.base[(uint64_t)inst * d.frequency.stride + q]
+                                           : d.frequency.base[(uint64_t)inst * d.frequency.stride + fc];
+      if (d.fm_q) {
+        // the folded modulator (osc_par_kernel's arithmetic for frame fc), the edge gain (gain.rs:163-179), then mix_to_output
+        const OscQuantum& mq = mq4;  // (the four frames of a lane lie in one render quantum)
+        const int i = (int)(fc % RQ);
+        float m = 0.f;
+        if (i >= mq.first && i < mq.end && !mq.outside_nyquist) {
+          const double x = __builtin_fma((double)(i - mq.first), mq.incr, mq.phase);
+          double ph = x - floor(x);
+          if (ph >= 1.) ph -= 1.;
+          m = waveform_sample(d.fm_type, d.fm_table, d.fm_table_len, ph, mq.incr);
+        }
+        if (d.fm_has_gain) {
+          const float g = d.fm_gain.mode == 0 ? d.fm_gain.base[inst] : d.fm_gain.base[(uint64_t)inst * d.fm_gain.stride + q];
+          m = fabsf(g) <= 1e-6f ? 0.f : (fabsf(1.f - g) <= 1e-6f ? m : m * g);
+        }
+        float o1 = m + freq;
+        freq = o1 != o1 ? d.fm_default : fminf(fmaxf(o1, d.fm_min), d.fm_max);
+      }
       double computed_freq;
       if (det_const) {
         computed_freq = (double)freq * det_mul;

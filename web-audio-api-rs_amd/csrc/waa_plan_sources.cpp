@@ -478,5 +478,70 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
   return 0;
 }
 
+// Two-operator FM (oscillator -> [Gain] -> carrier.frequency): three launches — the modulator's table-driven kernel, the
+// AudioParam's summing chain (PARAM_ADD), the carrier's prefix-sum kernel, which reads the per-frame frequency table in both of
+// its passes — moved 13.8 GB to produce 3.9 GB of output.  When the frequency param has ONE input, a materialised oscillator
+// with a host-known frequency that nothing else reads, the carrier evaluates modulator, edge gain and
+// AudioParamProcessor::mix_to_output per frame itself (OscDesc::fm_*: the same arithmetic as the two launches it stands for,
+// bit for bit) and those launches are not run.  Decided on the finished launch list like fuse_echo_tails.
+void fuse_fm_operators(waa_batch* b) {
+  if (measure_switch("WAA_NO_FM_FOLD")) return;
+  for (size_t c = 0; c < b->steps.size(); c++) {
+    Step& cs = b->steps[c];
+    if (cs.kind != 9 || !cs.osc.active || cs.osc.frequency.mode != 2 || cs.osc.fm_q || cs.group >= 0) continue;
+    const void* table = cs.osc.frequency.base;
+    int pi = -1, mi = -1;
+    for (size_t k = 0; k < c; k++) {
+      const Step& st = b->steps[k];
+      if (st.kind == 0 && st.group < 0 && !st.echo_fused && (const void*)st.chain.out.base == table) pi = (int)k;
+    }
+    if (pi < 0) continue;
+    Step& ps = b->steps[(size_t)pi];
+    const ChainDesc& ch = ps.chain;
+    if (ch.n_ops != 1 || ch.ops[0].kind != OP_PARAM_ADD || ch.n_inputs != 1 || ch.in_nch != 1 || ch.in[0].kind != IN_SIGNAL ||
+        ch.in[0].nch != 1 || ch.out.inst_stride != cs.osc.frequency.stride || ch.ops[0].p0.mode > 1 ||
+        (ch.in[0].has_gain && ch.in[0].gain.mode > 1) || (ch.in[0].valid != 0 && ch.in[0].valid < (uint64_t)b->n_quanta * RQ))
+      continue;
+    for (size_t k = 0; k < (size_t)pi; k++) {
+      const Step& st = b->steps[k];
+      if (st.kind == 9 && st.group < 0 && !st.echo_fused && st.osc.table_q && st.osc.out.base == ch.in[0].sig.base) mi = (int)k;
+    }
+    if (mi < 0) continue;
+    Step& ms = b->steps[(size_t)mi];
+    if (ms.osc.n_post != 0 || ms.osc.post_dup || ms.osc.out.nch != 1 || ms.osc.out.inst_stride != ch.in[0].sig.inst_stride) continue;
+    // nothing else may read the param's table or the modulator's signal (launches, analysers, the destination)
+    bool shared = false;
+    for (size_t k = 0; k < b->steps.size() && !shared; k++) {
+      if ((int)k == pi || k == c) continue;
+      const StepIo io = step_io(b->steps[k]);
+      for (const void* r : io.reads) shared |= r == table || ((int)k != pi && r == (const void*)ms.osc.out.base);
+    }
+    {
+      const StepIo io = step_io(cs);  // (the carrier itself: its detune could be modulated from the same oscillator)
+      for (const void* r : io.reads) shared |= r == (const void*)ms.osc.out.base;
+    }
+    for (const Node& an : b->nodes)
+      if (an.live && (an.desc.kind == WAA_NODE_ANALYSER || an.desc.kind == WAA_NODE_DESTINATION) &&
+          (an.sig.base == ms.osc.out.base || (const void*)an.sig.base == table))
+        shared = true;
+    if (shared) continue;
+    OscDesc& d = cs.osc;
+    d.fm_q = ms.osc.table_q;
+    d.fm_table = ms.osc.table;
+    d.fm_table_len = ms.osc.table_len;
+    d.fm_type = ms.osc.type;
+    d.fm_has_gain = ch.in[0].has_gain ? 1 : 0;
+    d.fm_gain = ch.in[0].gain;
+    std::memcpy(&d.fm_min, &ch.ops[0].i0, 4);
+    std::memcpy(&d.fm_max, &ch.ops[0].i1, 4);
+    std::memcpy(&d.fm_default, &ch.ops[0].i2, 4);
+    d.frequency = ch.ops[0].p0;  // the intrinsic value (constant or one per quantum)
+    ms.echo_fused = true;
+    ps.echo_fused = true;
+    plan_note(b, "FM: launches %d (the modulating oscillator) and %d (the frequency param's sum) are folded into the carrier's prefix-sum kernel (launch %zu): modulator, %sparam sum and clamp per frame in registers",
+              mi, pi, c, d.fm_has_gain ? "edge gain, " : "");
+  }
+}
+
 }  // namespace host
 }  // namespace waa
