@@ -4,6 +4,8 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "waa_osfft.hpp"
@@ -50,7 +52,7 @@ inline void filter_spectrum(const std::vector<float>& g, int fi, int n_bins, std
 }
 
 // 2 R tables of TAB_SLOTS complex f32: U_0 .. U_{R-1}, V_0 .. V_{R-1}; T[t * ROW + s] = table[t + 16 K16(s)]
-inline std::vector<float> tables(int R) {
+inline std::vector<float> make_tables(int R) {
   const int fo = 128 * R;
   const double two_pi = 6.283185307179586476925286766559, pi = 3.14159265358979323846264338327950288;
   std::vector<double> ur, ui, dr, di;
@@ -89,6 +91,16 @@ inline std::vector<float> tables(int R) {
       out[((size_t)(R + r) * TAB_SLOTS + slot) * 2 + 1] = (float)Vim;
     }
   return out;
+}
+
+// (the tables depend on R only: 5 ms of filter-tap and spectrum arithmetic per plan -> once per process)
+inline const std::vector<float>& tables(int R) {
+  static std::mutex lock;
+  static std::map<int, std::vector<float>> cache;
+  std::lock_guard<std::mutex> l(lock);
+  auto it = cache.find(R);
+  if (it == cache.end()) it = cache.emplace(R, make_tables(R)).first;
+  return it->second;
 }
 
 // exp(-2 pi i j / 256), j < 256
