@@ -93,7 +93,12 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
   // The item descriptors once into LDS: read through the pointer in the kernel argument they were ~80 dependent
   // vector loads per quantum (uniform addresses, but not provably read-only: no scalar loads), each one an exposed L2
   // round trip — with one wave per instance that WAS the kernel's time (23 k cycles per quantum for ~1100 instructions).
-  DynItem* items_s = reinterpret_cast<DynItem*>(codes + d.n_items + (d.n_items & 1));
+  // per-item caches of what never changes from quantum to quantum: the params with ONE value per instance (ParamRef mode 0: a global
+  // load per use, ~700 cycles each, three in a row in a panner item) and a Biquad's constant coefficient set (five doubles)
+  int* pmask_s = codes + d.n_items;                                                   // [n_items] bit s: slot s is cached; bit 8: the coefficients
+  float* pcs = reinterpret_cast<float*>(pmask_s + d.n_items);                         // [n_items][8]: op.p0 .. op.p4, alt1, alt2
+  double* cfs = reinterpret_cast<double*>(pcs + (size_t)d.n_items * 8);               // [n_items][5]  (8-byte aligned: 2 n_items ints + 8 n_items floats)
+  DynItem* items_s = reinterpret_cast<DynItem*>(cfs + (size_t)d.n_items * 5);
   const uint32_t inst = blockIdx.x;
   const int lane = threadIdx.x;
   {
@@ -114,6 +119,22 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
     ist[i * 4 + 2] = 0;   // DK_CONV_IN: compacted quantum slots used by channel 1
     ist[i * 4 + 3] = 0;
     codes[i] = (int)(1u | CODE_SILENT);
+    int mask = 0;
+    if (li.kind == DI_NODE) {
+      const ParamRef* slots[7] = {&li.op.p0, &li.op.p1, &li.op.p2, &li.op.p3, &li.op.p4, &li.alt1, &li.alt2};
+      const bool has_params = li.dk == DK_GAIN || li.dk == DK_STEREO_PAN || li.dk == DK_PANNER;
+      for (int sl = 0; sl < 7; sl++)
+        if (has_params && slots[sl]->mode == 0 && slots[sl]->base) {
+          pcs[i * 8 + sl] = load_global(slots[sl]->base + inst);
+          mask |= 1 << sl;
+        }
+      if (li.dk == DK_BIQUAD && li.op.i0 == 0 && li.op.ptr0) {
+        const double* cf = reinterpret_cast<const double*>(li.op.ptr0) + (uint64_t)inst * li.op.u0;
+        for (int j = 0; j < 5; j++) cfs[i * 5 + j] = load_global(cf + j);
+        mask |= 1 << 8;
+      }
+    }
+    pmask_s[i] = mask;
   }
   lds_sync();
 
@@ -145,6 +166,10 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
       const int h_compact_ch1 = __builtin_amdgcn_readfirstlane(hw4.x), h_flags = __builtin_amdgcn_readfirstlane(hw4.y);
       const int h_writer_item = __builtin_amdgcn_readfirstlane(hw5.x), h_in_cycle = __builtin_amdgcn_readfirstlane(hw5.y);
       const int h_num_quanta = __builtin_amdgcn_readfirstlane(hw6.x);
+      const int h_pmask = __builtin_amdgcn_readfirstlane(pmask_s[it]);
+      auto pvc = [&](int slot, const ParamRef& p, uint64_t frame) __attribute__((always_inline)) {
+        return (h_pmask >> slot) & 1 ? pcs[it * 8 + slot] : pval(p, inst, q, frame);
+      };
       float v[CM][2];
 #pragma unroll
       for (int c = 0; c < CM; c++) v[c][0] = v[c][1] = 0.f;
@@ -238,7 +263,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
                 for (int c = 0; c < CM; c++) v[c][e] *= g;
               }
             } else {
-              const float g = pval(op.p0, inst, q, 0);
+              const float g = pvc(0, op.p0, 0);
               if (fabsf(g) <= 1e-6f) {  // :163-171 silent output
                 outs = true;
                 outn = 1;
@@ -307,8 +332,10 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
             if (!iir && op.i0 != 2 && !d.no_scan) {
               const int l = lane & 31;
               const double* cf = reinterpret_cast<const double*>(op.ptr0) + (uint64_t)inst * op.u0 + (op.i0 == 1 ? (uint64_t)q * 5 : 0);
-              const double b0 = load_global(cf), b1 = load_global(cf + 1), b2 = load_global(cf + 2), a1 = load_global(cf + 3),
-                           a2 = load_global(cf + 4);
+              const bool cfc = ((h_pmask >> 8) & 1) != 0;  // (constant set: out of the LDS cache)
+              const double b0 = cfc ? cfs[it * 5] : load_global(cf), b1 = cfc ? cfs[it * 5 + 1] : load_global(cf + 1),
+                           b2 = cfc ? cfs[it * 5 + 2] : load_global(cf + 2), a1 = cfc ? cfs[it * 5 + 3] : load_global(cf + 3),
+                           a2 = cfc ? cfs[it * 5 + 4] : load_global(cf + 4);
               // two channels per pass (32 lanes each); wider layouts take CM / 2 passes, and nothing is written back before
               // every pass has found its quantum free of inf / NaN / near-flush values (the serial form below redoes ALL channels)
               float yo_all[CM / 2][4];
@@ -505,14 +532,14 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
 #pragma unroll
             for (int e = 0; e < 2; e++) {
               const uint64_t f = f0 + e * 64 + lane;
-              const float pan = pval(op.p0, inst, q, f);
+              const float pan = pvc(0, op.p0, f);
               float gl, gr;
               if (sn == 1) {
                 if (op.p0.mode == 2) {
                   stereo_gains((pan + 1.f) * 0.5f, gl, gr);
                 } else {
-                  gl = pval(li.alt1, inst, q, 0);
-                  gr = pval(li.alt2, inst, q, 0);
+                  gl = pvc(5, li.alt1, 0);
+                  gr = pvc(6, li.alt2, 0);
                 }
                 const float x = v[0][e];
                 v[0][e] = x * gl;
@@ -521,8 +548,8 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
                 if (op.p0.mode == 2) {
                   stereo_gains(pan <= 0.f ? pan + 1.f : pan, gl, gr);
                 } else {
-                  gl = pval(op.p1, inst, q, 0);
-                  gr = pval(op.p2, inst, q, 0);
+                  gl = pvc(1, op.p1, 0);
+                  gr = pvc(2, op.p2, 0);
                 }
                 const float il = v[0][e], ir = v[1][e];
                 if (pan <= 0.f) {
@@ -546,15 +573,15 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
 #pragma unroll
             for (int e = 0; e < 2; e++) {
               const uint64_t f = f0 + e * 64 + lane;  // (per-frame tables with an audio-rate AudioListener)
-              const float az = pval(op.p0, inst, q, f);
-              const float dg = pval(op.p3, inst, q, f), cg = pval(op.p4, inst, q, f);
+              const float az = pvc(0, op.p0, f);
+              const float dg = pvc(3, op.p3, f), cg = pvc(4, op.p4, f);
               if (sn == 1) {
-                const float gl = pval(li.alt1, inst, q, f), gr = pval(li.alt2, inst, q, f);
+                const float gl = pvc(5, li.alt1, f), gr = pvc(6, li.alt2, f);
                 const float x = v[0][e];
                 v[0][e] = x * (gl * dg * cg);
                 v[1][e] = x * (gr * dg * cg);
               } else {
-                const float gl = pval(op.p1, inst, q, f), gr = pval(op.p2, inst, q, f);
+                const float gl = pvc(1, op.p1, f), gr = pvc(2, op.p2, f);
                 const float il = v[0][e], ir = v[1][e];
                 if (az <= 0.f) {
                   v[0][e] = (il + ir * gl) * dg * cg;
@@ -743,8 +770,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
 
 void launch_dyn(const DynDesc& d, void* stream) {
   const int cm = d.cmax > 2 ? 6 : 2;
-  const size_t lds = ((size_t)d.n_items * cm * RQ + cm * RQ) * sizeof(float) + (size_t)d.n_items * cm * DYN_STATE * sizeof(double) +
-                     (size_t)(d.n_items * 5 + 2) * sizeof(int) + (size_t)d.n_items * sizeof(DynItem);
+  const size_t lds = dyn_lds_bytes(d.n_items, d.cmax);
   DynDesc dd = d;
   dd.no_scan = measure_switch("WAA_DYN_NO_SCAN") ? 1u : 0u;
   dd.cycles = nullptr;
@@ -783,8 +809,11 @@ void launch_dyn(const DynDesc& d, void* stream) {
 }
 size_t dyn_lds_bytes(int n_items, int cmax) {
   const int cm = cmax > 2 ? 6 : 2;
+  // signals + scratch, filter state, ist (4) + codes (1) + pmask (1) ints, the param cache (8 floats), the coefficient cache
+  // (5 doubles), the item descriptors
   return ((size_t)n_items * cm * RQ + cm * RQ) * sizeof(float) + (size_t)n_items * cm * DYN_STATE * sizeof(double) +
-         (size_t)(n_items * 5 + 2) * sizeof(int) + (size_t)n_items * sizeof(DynItem);
+         (size_t)(n_items * 6 + 2) * sizeof(int) + (size_t)n_items * 8 * sizeof(float) + (size_t)n_items * 5 * sizeof(double) +
+         (size_t)n_items * sizeof(DynItem);
 }
 
 // ConvolverRenderer::process on codes (convolver.rs:343-392): the tail counter cuts the output off once a silent input
