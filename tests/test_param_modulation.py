@@ -337,3 +337,69 @@ def test_modulated_panner_geometry_next_to_an_audio_rate_listener_is_refused(hip
         c.start_rendering_sync()
     assert ei.value.status == 4 and "single-valued AudioListener" in str(ei.value)
     c.close()
+
+
+# ---- an OSCILLATOR as the LFO (round 4: the param's summing chain is folded into the oscillator's store) -----------------------
+def _osc_lfo(binding, noise, variant, plan_only=False):
+    """tremolo       source -> Gain <- (sine LFO -> depth Gain) on gain.gain
+    sweep         the LFO (triangle, per-instance rate, starting late) -> depth -> Biquad.frequency
+    no-depth      the LFO straight on gain.gain (no depth gain), intrinsic value automated per... constant per instance
+    two-params    ONE LFO drives two params (its signal has two readers: not folded)
+    heard         the LFO also reaches the destination (not folded)"""
+    n, frames = noise.shape[0], noise.shape[2]
+    kw = {"device": waa.PLAN_ONLY} if plan_only else {}
+    c = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n, binding=binding, **kw)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    lfo = c.create_oscillator(type_="triangle" if variant == "sweep" else "sine", frequency=4.0)
+    for i in range(n):
+        lfo.frequency.set_value(3.0 + 1.5 * i, instance=i)
+    g = c.create_gain(gain=0.6)
+    for i in range(n):
+        g.gain.set_value(0.5 + 0.1 * i, instance=i)
+    bq = c.create_biquad_filter(type_="lowpass", frequency=1500.0, q=3.0)
+    if variant == "sweep":
+        lfo.connect(c.create_gain(gain=900.0)).connect(bq.frequency)
+        src.connect(bq).connect(c.destination())
+        lfo.start_at(300.5 / 48000.0)
+    else:
+        head = lfo if variant == "no-depth" else lfo.connect(c.create_gain(gain=0.4))
+        head.connect(g.gain)
+        if variant == "two-params":
+            head.connect(bq.detune)
+        if variant == "heard":
+            lfo.connect(c.create_gain(gain=0.05)).connect(c.destination())
+        src.connect(g).connect(bq).connect(c.destination())
+        lfo.start()
+    src.start()
+    plan = c.plan_describe() if binding.prefix == "waa_" else ""
+    out = None if plan_only else c.start_rendering_sync().data
+    c.close()
+    return out, plan
+
+
+LFO_VARIANTS = ["tremolo", "sweep", "no-depth", "two-params", "heard"]
+
+
+@pytest.mark.measure
+@pytest.mark.parametrize("variant", LFO_VARIANTS)
+def test_plan_lfo_fold(variant):
+    _, plan = _osc_lfo(waa.measure_binding(), white_noise(3, 2, 128 * 40), variant, plan_only=True)
+    assert ("is folded into the store of the oscillator that drives it" in plan) == (variant not in ("two-params", "heard")), plan
+
+
+@pytest.mark.measure
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", LFO_VARIANTS)
+def test_parity_lfo_fold(hip, orc, variant, monkeypatch):
+    """the oscillator's store applying depth gain, intrinsic value and clamp is the chain launch's arithmetic: bit-identical to the
+    unfolded plan (WAA_NO_LFO_FOLD), and the render matches the oracle"""
+    noise = white_noise(3, 2, 2048 * 3 + 77, seed0=9)
+    g, plan = _osc_lfo(hip, noise, variant)
+    assert ("is folded into the store of the oscillator that drives it" in plan) == (variant not in ("two-params", "heard")), plan
+    o, _ = _osc_lfo(orc, noise, variant)
+    assert rms_err(g, o).max() <= 1e-6 and np.abs(g - o).max() <= 4e-6
+    monkeypatch.setenv("WAA_NO_LFO_FOLD", "1")
+    u, plan = _osc_lfo(hip, noise, variant)
+    assert "is folded into the store" not in plan
+    assert np.array_equal(g, u)

@@ -363,6 +363,11 @@ struct OscDesc {
   ParamRef fm_gain;               // mode 0 / 1 (fm_has_gain)
   int32_t fm_has_gain;
   float fm_min, fm_max, fm_default;
+  // An LFO that only drives ONE AudioParam (time-parallel kernel, round 4): the param's summing chain — intrinsic value + input,
+  // NaN -> default, clamp (param.rs:737-795) — in the oscillator's store; `out` then IS the param's per-frame table
+  int32_t pa_on;
+  float pa_min, pa_max, pa_default;
+  ParamRef pa_intrinsic;          // mode 0 / 1
 };
 constexpr int OSC_SEGMENTS = 8;  // time segments per instance of the prefix-sum oscillator (one wavefront each)
 // Per-(instance, quantum) record of the time-parallel oscillator: frames [first, end) of the quantum are active,

@@ -81,6 +81,15 @@ __device__ __forceinline__ void osc_store(const OscDesc& d, uint32_t inst, float
 #pragma unroll
       for (int e = 0; e < 4; e++) r[e] = mute ? 0.f : (pass ? r[e] : r[e] * g);
     }
+  if (d.pa_on) {  // AudioParamProcessor::mix_to_output on the way out (OP_PARAM_ADD of the chain kernel, the same arithmetic)
+    const uint32_t q = (uint32_t)(f0 / RQ), qc = q < d.n_quanta ? q : d.n_quanta - 1;
+    const float iv = d.pa_intrinsic.mode == 0 ? d.pa_intrinsic.base[inst] : d.pa_intrinsic.base[(uint64_t)inst * d.pa_intrinsic.stride + qc];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float o1 = r[e] + iv;
+      r[e] = o1 != o1 ? d.pa_default : fminf(fmaxf(o1, d.pa_min), d.pa_max);
+    }
+  }
   *reinterpret_cast<float4*>(out + f0) = make_float4(r[0], r[1], r[2], r[3]);
   if (d.post_dup) *reinterpret_cast<float4*>(out + d.out.ch_stride + f0) = make_float4(r[0], r[1], r[2], r[3]);
 }

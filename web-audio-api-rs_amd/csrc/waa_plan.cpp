@@ -1956,6 +1956,7 @@ int build_plan(waa_batch* b) {
   fuse_echo_tails(b);
   ring_feed_forward_echoes(b);
   fuse_fm_operators(b);
+  fuse_lfo_params(b);
   // (self-test of the check below: a reversed launch list must not get past it, tests/test_plan.py)
   if (measure_switch("WAA_DEBUG_REVERSE_PLAN")) std::reverse(b->steps.begin(), b->steps.end());
   if (int e = validate_plan(b)) return e;

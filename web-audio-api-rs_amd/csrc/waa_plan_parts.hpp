@@ -61,6 +61,7 @@ int validate_plan(waa_batch* b);
 void fuse_echo_tails(waa_batch* b);
 void ring_feed_forward_echoes(waa_batch* b);
 void fuse_fm_operators(waa_batch* b);
+void fuse_lfo_params(waa_batch* b);
 int plan_delay_writer(waa_batch* b, uint32_t id);
 int plan_folded_delay_line(waa_batch* b, uint32_t id);
 int plan_delay_reader(waa_batch* b, uint32_t id);

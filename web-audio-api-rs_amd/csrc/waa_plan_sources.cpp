@@ -543,5 +543,53 @@ void fuse_fm_operators(waa_batch* b) {
   }
 }
 
+// An LFO (an oscillator with a host-known frequency, nothing else reading it) on ONE AudioParam — tremolo, a filter sweep, a
+// wobbling delay: the param's summing chain (edge gain + PARAM_ADD) was a launch of its own that read the oscillator's signal
+// and wrote the per-frame table.  The time-parallel oscillator kernel applies both in its store (OscDesc::post_gain / pa_*: the
+// chain kernel's arithmetic, bit for bit) and writes the table directly; the chain launch is not run.  After fuse_fm_operators
+// (an oscillator's frequency param takes the modulator all the way into the carrier).
+void fuse_lfo_params(waa_batch* b) {
+  if (measure_switch("WAA_NO_LFO_FOLD")) return;
+  for (size_t pi = 0; pi < b->steps.size(); pi++) {
+    Step& ps = b->steps[pi];
+    if (ps.kind != 0 || ps.group >= 0 || ps.echo_fused) continue;
+    const ChainDesc& ch = ps.chain;
+    if (ch.n_ops != 1 || ch.ops[0].kind != OP_PARAM_ADD || ch.n_inputs != 1 || ch.in_nch != 1 || ch.in[0].kind != IN_SIGNAL ||
+        ch.in[0].nch != 1 || ch.out.nch != 1 || ch.ops[0].p0.mode > 1 || (ch.in[0].has_gain && ch.in[0].gain.mode != 0) ||
+        (ch.in[0].valid != 0 && ch.in[0].valid < (uint64_t)b->n_quanta * RQ))
+      continue;
+    int mi = -1;
+    for (size_t k = 0; k < pi; k++) {
+      const Step& st = b->steps[k];
+      if (st.kind == 9 && st.group < 0 && !st.echo_fused && st.osc.table_q && !st.osc.pa_on && st.osc.out.base == ch.in[0].sig.base) mi = (int)k;
+    }
+    if (mi < 0) continue;
+    Step& ms = b->steps[(size_t)mi];
+    if (ms.osc.post_dup || ms.osc.out.nch != 1 || ms.osc.n_post + (ch.in[0].has_gain ? 1 : 0) > 2 ||
+        ms.osc.out.inst_stride != ch.in[0].sig.inst_stride || ch.out.inst_stride != ms.osc.out.inst_stride)
+      continue;
+    bool shared = false;
+    for (size_t k = 0; k < b->steps.size() && !shared; k++) {
+      if (k == pi) continue;
+      const StepIo io = step_io(b->steps[k]);
+      for (const void* r : io.reads) shared |= r == (const void*)ms.osc.out.base;
+    }
+    for (const Node& an : b->nodes)
+      if (an.live && (an.desc.kind == WAA_NODE_ANALYSER || an.desc.kind == WAA_NODE_DESTINATION) && an.sig.base == ms.osc.out.base) shared = true;
+    if (shared) continue;
+    OscDesc& d = ms.osc;
+    if (ch.in[0].has_gain) d.post_gain[d.n_post++] = ch.in[0].gain;
+    d.pa_on = 1;
+    d.pa_intrinsic = ch.ops[0].p0;
+    std::memcpy(&d.pa_min, &ch.ops[0].i0, 4);
+    std::memcpy(&d.pa_max, &ch.ops[0].i1, 4);
+    std::memcpy(&d.pa_default, &ch.ops[0].i2, 4);
+    d.out = ch.out;  // the oscillator writes the param's per-frame table itself
+    ps.echo_fused = true;
+    plan_note(b, "LFO: launch %zu (the param's sum: %sintrinsic value, clamp) is folded into the store of the oscillator that drives it (launch %d)", pi,
+              ch.in[0].has_gain ? "depth gain, " : "", mi);
+  }
+}
+
 }  // namespace host
 }  // namespace waa
