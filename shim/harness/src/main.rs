@@ -15,7 +15,7 @@ use web_audio_api::context::{BaseAudioContext, OfflineAudioContext};
 use web_audio_api::gpu::start_rendering_sync_batch_with_report;
 use web_audio_api::node::{
     AnalyserNode, AnalyserOptions, AudioNode, AudioScheduledSourceNode, BiquadFilterType, ConvolverNode, ConvolverOptions,
-    OverSampleType, WaveShaperNode, WaveShaperOptions,
+    OverSampleType, PanningModelType, WaveShaperNode, WaveShaperOptions,
 };
 use web_audio_api::AudioBuffer;
 
@@ -95,6 +95,30 @@ fn build(case: &str, i: usize, noise: &[f32], tanh_curve: &[f32], ir: &AudioBuff
             src.connect(&shaper);
             shaper.connect(&ctx.destination());
         }
+        "echo" => {
+            // Delay <-> Gain feedback loop + dry: the crate's writer / reader pair folded into ONE library node (round 4)
+            let delay = ctx.create_delay(1.);
+            delay.delay_time().set_value(0.05 + 0.01 * i as f32);
+            let feedback = ctx.create_gain();
+            feedback.gain().set_value(0.5);
+            src.connect(&delay);
+            delay.connect(&feedback);
+            feedback.connect(&delay);
+            delay.connect(&ctx.destination());
+            src.connect(&ctx.destination());
+        }
+        "panner" | "panner_hrtf" => {
+            // PannerNode with per-context position and a moved AudioListener (its nine params go through the panner)
+            let mut panner = ctx.create_panner();
+            if case == "panner_hrtf" {
+                panner.set_panning_model(PanningModelType::HRTF);
+            }
+            panner.position_x().set_value(1. + 0.3 * i as f32);
+            panner.position_z().set_value(-0.5);
+            ctx.listener().position_y().set_value(0.25);
+            src.connect(&panner);
+            panner.connect(&ctx.destination());
+        }
         "c5" => {
             src.playback_rate().set_value(1.5);
             src.set_loop(true);
@@ -128,7 +152,7 @@ fn main() {
         ctx.decode_audio_data_sync(File::open(reference.join("samples/parking-garage-response.wav")).unwrap()).unwrap()
     };
     let mut failures = 0;
-    for case in ["c1", "c1_arate", "c2", "t1", "c4", "os2", "os4", "c5"] {
+    for case in ["c1", "c1_arate", "c2", "t1", "c4", "os2", "os4", "c5", "echo", "panner", "panner_hrtf"] {
         let mut cpu: Vec<Built> = (0..N).map(|i| build(case, i, &noise, &tanh_curve, &ir)).collect();
         let mut gpu: Vec<Built> = (0..N).map(|i| build(case, i, &noise, &tanh_curve, &ir)).collect();
         let want: Vec<AudioBuffer> = cpu.iter_mut().map(|b| b.ctx.start_rendering_sync()).collect();
