@@ -85,6 +85,12 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
             tail = delay.connect(ctx.create_biquad_filter(type_="lowpass", frequency=4000.0))
         tail.connect(ctx.create_gain(gain=0.5)).connect(delay)
         tail.connect(ctx.destination())
+    if name == "trem":  # tremolo: an LFO oscillator on gain.gain through a depth gain (the LFO fold of waa_plan_sources.cpp)
+        g = ctx.create_gain(gain=0.6)
+        lfo = ctx.create_oscillator(type_="sine", frequency=5.0)
+        lfo.connect(ctx.create_gain(gain=0.4)).connect(g.gain)
+        lfo.start()
+        node = node.connect(g)
     if name in ("os2", "os4"):  # WaveShaper with 2x / 4x oversampling (waveshaper.rs:409-481)
         node = node.connect(ctx.create_wave_shaper(curve=np.tanh(np.linspace(-3.0, 3.0, 2049)).astype(np.float32),
                                                    oversample="2x" if name == "os2" else "4x"))
@@ -105,7 +111,7 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
 # algorithmic bytes per context-quantum
 ALG_BYTES = {"c2": 2048.0, "c2k": 2048.0, "c5": 2560.0, "c3": 362848.0, "t1": 362848.0 + 2048.0, "c4": 362848.0 + 2048.0 + 512.0}
 ALG_BYTES["c1a"] = 2048.0
-ALG_BYTES["fb"] = ALG_BYTES["fbq"] = ALG_BYTES["comb"] = ALG_BYTES["pluck"] = 2048.0
+ALG_BYTES["fb"] = ALG_BYTES["fbq"] = ALG_BYTES["comb"] = ALG_BYTES["pluck"] = ALG_BYTES["trem"] = 2048.0
 ALG_BYTES["fm"] = 1024.0
 ALG_BYTES["osc"] = 1024.0   # no input; 2 output channels x 128 frames x 4 B
 ALG_BYTES["echo"] = 2048.0
@@ -138,6 +144,7 @@ DESCR["fm"] = "two-operator FM: {n} contexts x {s:g} s, Oscillator->Gain(300)->c
 DESCR["osc"] = "subtractive voice: {n} contexts x {s:g} s, Oscillator(sawtooth 110 Hz, detuned)->Biquad(lowpass)->Gain->destination"
 DESCR["echo"] = "feed-forward echo: {n} contexts x {s:g} s, BufferSource->destination + BufferSource->Delay(0.25s)->Gain(0.5)->destination"
 DESCR["fb"] = "feedback echo: {n} contexts x {s:g} s, BufferSource->[Delay(0.25s)<->Gain(0.5)]->destination (+dry)"
+DESCR["trem"] = "tremolo: {n} contexts x {s:g} s, BufferSource->Gain<-[Oscillator(5 Hz)->Gain(0.4)]->destination"
 DESCR["comb"] = "comb filter: {n} contexts x {s:g} s, BufferSource->[Delay(10 ms)->Gain(0.5)->back]->destination (+dry)"
 DESCR["pluck"] = "filtered comb (plucked string): {n} contexts x {s:g} s, BufferSource->[Delay(10 ms)->Biquad->Gain(0.5)->back]->destination (+dry)"
 DESCR["fbq"] = "filtered feedback echo: {n} contexts x {s:g} s, BufferSource->[Delay(0.25s)->Biquad->Gain(0.5)->back]->destination (+dry)"
