@@ -344,7 +344,8 @@ struct OscDesc {
   uint32_t n_inst;
   uint32_t n_quanta;
   double sample_rate;
-  const struct OscQuantum* table_q;  // non-null: time-parallel kernel (host-known frequency), [n_inst][n_quanta]
+  const struct OscQuantum* table_q;  // non-null: time-parallel kernel (host-known frequency), [rows][n_quanta]
+  const uint32_t* tq_row;             // [n_inst] row of table_q an instance reads (instances that replay alike share a row)
   const int64_t* active;       // non-null: prefix-sum kernel (a-rate frequency): [n_inst][2] active frames [first, end)
   const double* start_ratio;   // [n_inst] sub-sample start offset in frames (oscillator.rs:516-528)
   double* seg_phase;           // prefix-sum kernel: [n_inst][OSC_SEGMENTS] phase advance of each time segment (scratch)
@@ -357,7 +358,8 @@ struct OscDesc {
   // oscillator with a host-known frequency (its time-parallel table `fm_q`), through at most one edge gain — the carrier
   // evaluates modulator, gain and AudioParamProcessor::mix_to_output (param.rs:737-795) per frame itself instead of reading a
   // per-frame table three launches wrote and read back (fm_q == nullptr: not folded; `frequency` then is the intrinsic value).
-  const struct OscQuantum* fm_q;  // [n_inst][n_quanta] of the MODULATOR
+  const struct OscQuantum* fm_q;  // [rows][n_quanta] of the MODULATOR
+  const uint32_t* fm_row;         // [n_inst] its row table
   const float* fm_table;
   int32_t fm_table_len, fm_type;
   ParamRef fm_gain;               // mode 0 / 1 (fm_has_gain)

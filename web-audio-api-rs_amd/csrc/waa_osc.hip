@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void osc_par_kernel(const OscDesc d) {
   const uint32_t q = (uint32_t)(f0 / RQ);
   float r[4] = {0.f, 0.f, 0.f, 0.f};
   if (q < d.n_quanta) {
-    const OscQuantum oq = d.table_q[(uint64_t)inst * d.n_quanta + q];
+    const OscQuantum oq = d.table_q[(uint64_t)d.tq_row[inst] * d.n_quanta + q];
     const int i0 = (int)(f0 % RQ);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64) void osc_scan_kernel(const OscDesc d) {
     OscQuantum mq4{};
     if (d.fm_q) {
       const uint64_t fq = f0 < (uint64_t)d.n_quanta * RQ ? f0 : (uint64_t)d.n_quanta * RQ - 1;
-      mq4 = d.fm_q[(uint64_t)inst * d.n_quanta + fq / RQ];
+      mq4 = d.fm_q[(uint64_t)d.fm_row[inst] * d.n_quanta + fq / RQ];
     }
 #pragma unroll
     for (int e = 0; e < 4; e++) {

@@ -327,7 +327,10 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
   if (parallel) {
     // host-known frequency: replay the per-quantum decisions of OscillatorRenderer::process (oscillator.rs:336-452)
     // and record the phase at the first active frame of every quantum
-    std::vector<OscQuantum> tq((size_t)b->n_inst * b->n_quanta);
+    // one row of n_quanta records per DISTINCT replay (tq grows row by row), a row index per instance: 1024 contexts of one patch
+    // used to get 1024 copies of the same 90 KB row (92 MB built, copied and uploaded per oscillator: most of a 45 ms plan)
+    std::vector<OscQuantum> tq;
+    std::vector<uint32_t> row_of(b->n_inst, 0);
     const double sample_rate = (double)b->sr, dt = 1. / sample_rate, nyquist = sample_rate / 2.;
     auto frac = [](long double x) {
       long double r = x - floorl(x);
@@ -345,16 +348,18 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
         const std::array<double, 4> key = {start_time, stop_time, (double)fq[0], (double)dq[0]};
         auto it = replayed.find(key);
         if (it != replayed.end()) {
-          std::copy(tq.begin() + (size_t)it->second * b->n_quanta, tq.begin() + (size_t)(it->second + 1) * b->n_quanta,
-                    tq.begin() + (size_t)i * b->n_quanta);
+          row_of[i] = it->second;
           continue;
         }
-        replayed.emplace(key, i);
+        replayed.emplace(key, (uint32_t)(tq.size() / b->n_quanta));
       }
+      const size_t row = tq.size() / b->n_quanta;
+      row_of[i] = (uint32_t)row;
+      tq.resize(tq.size() + b->n_quanta);
       long double phase = 0.L;
       bool started = false;
       for (uint32_t q = 0; q < b->n_quanta; q++) {
-        OscQuantum& oq = tq[(size_t)i * b->n_quanta + q];
+        OscQuantum& oq = tq[row * b->n_quanta + q];
         oq = OscQuantum{0., 0., 0, 0, 0};
         const double block_time = (double)((uint64_t)q * RQ) / sample_rate;
         const double next_block_time = block_time + dt * (double)RQ;
@@ -404,8 +409,10 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
       }
     }
     OscQuantum* d_tq = nullptr;
-    if ((e = dev_upload(b, &d_tq, tq))) return e;
+    uint32_t* d_row = nullptr;
+    if ((e = dev_upload(b, &d_tq, tq)) || (e = dev_upload(b, &d_row, row_of))) return e;
     d.table_q = d_tq;
+    d.tq_row = d_row;
   }
   const bool scan = !parallel && !getenv("WAA_OSC_EXACT");
   if (scan) {
@@ -415,9 +422,20 @@ int plan_oscillator(waa_batch* b, uint32_t id) {
     std::vector<int64_t> act((size_t)b->n_inst * 2, 0);
     std::vector<double> ratio(b->n_inst, 0.);
     const double sample_rate = (double)b->sr, dt = 1. / sample_rate;
+    std::map<std::pair<double, double>, uint32_t> clock_of;  // (start, stop) -> the first instance replayed with them
     for (uint32_t i = 0; i < b->n_inst; i++) {
       double start_time = start[i];
       const double stop_time = stop[i];
+      {
+        auto it = clock_of.find({start_time, stop_time});
+        if (it != clock_of.end()) {  // the clock replay depends on nothing else
+          act[(size_t)i * 2] = act[(size_t)it->second * 2];
+          act[(size_t)i * 2 + 1] = act[(size_t)it->second * 2 + 1];
+          ratio[i] = ratio[it->second];
+          continue;
+        }
+        clock_of.emplace(std::make_pair(start_time, stop_time), i);
+      }
       int64_t first = -1, end = -1;
       bool started = false;
       for (uint32_t q = 0; q < b->n_quanta; q++) {
@@ -527,6 +545,7 @@ void fuse_fm_operators(waa_batch* b) {
     if (shared) continue;
     OscDesc& d = cs.osc;
     d.fm_q = ms.osc.table_q;
+    d.fm_row = ms.osc.tq_row;
     d.fm_table = ms.osc.table;
     d.fm_table_len = ms.osc.table_len;
     d.fm_type = ms.osc.type;
