@@ -891,6 +891,37 @@ def test_parity_tiny_echo_loops_walk_in_half_wave_chunks(hip, orc, filtered):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("delay_frames", [144.0, 300.0])
+def test_parity_plucked_string_with_a_long_memory_filter(hip, orc, delay_frames):
+    """a 90 Hz lowpass (Q 3) in a short loop: the filter's state carries far across the ring kernel's chunks — with half-wave chunks
+    (128 frames) the power that carries it across one sub-tile is A^32, not A^64 (fuzz seed 661385: 4e-4); mono line, stored for a
+    reader outside the loop"""
+    n, frames = 3, 2048 * 4 + 77
+    noise = white_noise(n, 1, frames, seed0=45)
+    outs = []
+    for be in (hip, orc):
+        c = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=n, binding=be)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(noise, 48000.0)
+        delay = c.create_delay(0.1, delay_time=delay_frames / 48000.0)
+        bq = c.create_biquad_filter(type_="lowpass", frequency=90.0, q=3.0)
+        fb = c.create_gain(gain=0.8)
+        src.connect(delay)
+        delay.connect(bq).connect(fb).connect(delay)
+        delay.connect(c.create_gain(gain=0.5)).connect(c.destination())   # (the line has a reader outside the loop)
+        bq.connect(c.destination())
+        src.start()
+        if be is hip:
+            plan = c.plan_describe()
+            assert "with the Biquad between the delayed read and the sum" in plan and ("chunks of 128 frames" in plan) == (delay_frames < 264), plan
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    g, o = outs
+    scale = max(1.0, float(np.abs(o).max()))
+    assert rms_err(g, o).max() <= 1e-6 * scale and np.abs(g - o).max() <= 4e-6 * scale, (rms_err(g, o), float(np.abs(g - o).max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["dry+wet", "wet-gain", "line-reader", "peaking"])
 def test_parity_short_filtered_echo_loop_from_the_lds_ring(hip, orc, variant):
     """the plucked string: Delay (a few hundred frames) -> Biquad -> Gain -> back, in the ring kernel's BQ form"""

@@ -14,7 +14,7 @@ orc = waa.bind(ctypes.CDLL(glob.glob('/root/repo/oracle/*.so')[0]), "orc_")
 co, _ = build_random_graph(orc, seed, frozen=frozen)
 o = co.start_rendering_sync().data; co.close()
 hip = waa.default_binding()
-for env in [None, "WAA_NO_SHORT_RING", "WAA_NO_ECHO_RING", "WAA_NO_ECHO_FF", "WAA_NO_ECHO_TAIL", "WAA_NO_DELAY_FOLD", "WAA_NO_LOOP_FOLD", "WAA_STATIC_CHANNEL_COUNTS"]:
+for env in [None, "WAA_NO_SHORT_RING", "WAA_NO_ECHO_RING", "WAA_NO_ECHO_FF", "WAA_NO_ECHO_TAIL", "WAA_NO_DELAY_FOLD", "WAA_NO_LOOP_FOLD", "WAA_NO_FM_FOLD", "WAA_NO_LFO_FOLD", "WAA_NO_ECHO_BQ", "WAA_OSC_EXACT", "WAA_STATIC_CHANNEL_COUNTS"]:
     if env: os.environ[env] = "1"
     try:
         ch, d = build_random_graph(hip, seed, frozen=frozen)

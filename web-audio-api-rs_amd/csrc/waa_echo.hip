@@ -141,7 +141,9 @@ __global__ __launch_bounds__(BQ ? ECHO_BQ_WAVES * 64 : 1024) void echo_ring_kern
       if (lane & (1 << k)) PL = mme(m, PL);
       m = mme(m, m);
     }
-    A64 = m;
+    // (a wavefront's sub-tile is 64 lanes = 256 frames, or 32 lanes = 128 frames with half-wave chunks: the power that carries a
+    // state across ONE sub-tile — A^32 there; with A^64 a filter whose memory outlasts 128 frames was off by 4e-4, fuzz seed 661385)
+    A64 = t.sub_frames == 128 ? P[5] : m;
 #pragma unroll
     for (int c = 0; c < C; c++) py[c] = bq.y.base + (uint64_t)inst * bq.y.inst_stride + (uint64_t)c * bq.y.ch_stride;
     if (tid < 2 * C * 2) (&ystate[0][0][0])[tid] = 0.;
