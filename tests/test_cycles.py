@@ -434,12 +434,12 @@ def _random_echo_graph(binding, seed, plan_only=False, short=False, filtered=Fal
         delay.set_channel_count_mode("explicit")
     for i in range(n):
         # (short: below one 2048-frame tile — comb filters, plucked strings: the ring kernel in 256- / 512-frame chunks)
-        delay.delay_time.set_value(np.float32((rng.uniform(266.0, 2040.0) if short else rng.uniform(2057.0, 14000.0)) / 48000.0), instance=i)
+        delay.delay_time.set_value(np.float32((rng.uniform(137.0, 2040.0) if short else rng.uniform(2057.0, 14000.0)) / 48000.0), instance=i)
     fb = c.create_gain()
     bq = None
     if filtered:  # Delay -> Biquad -> Gain -> back (the ring kernel's BQ form)
         bq = c.create_biquad_filter(type_=str(rng.choice(["lowpass", "highpass", "bandpass", "peaking", "allpass"])),
-                                    frequency=float(rng.uniform(300.0, 9000.0)))
+                                    frequency=float(np.exp(rng.uniform(np.log(40.0), np.log(9000.0)))))   # (down to filters whose memory outlasts many chunks)
         bq.q.set_value(float(rng.uniform(0.3, 4.0)))
         bq.gain.set_value(float(rng.uniform(-6.0, 6.0)))
     kind = rng.integers(0, 3)
@@ -514,7 +514,7 @@ def test_parity_random_echo_loops(hip, orc):
 @pytest.mark.gpu
 @pytest.mark.parametrize("short,filtered", [(True, False), (False, True), (True, True)])
 def test_parity_random_echo_loops_short_and_filtered(hip, orc, short, filtered):
-    """the same family with delays below a tile (266 .. 2040 frames: chunks of 256 frames, rings of 1024 .. 4096) and / or a Biquad
+    """the same family with delays below a tile (137 .. 2040 frames: chunks of 128 / 256 / 512 frames, rings of 1024 .. 4096) and / or a Biquad
     in the loop (the BQ form): plain loops bit-identical to the oracle, filtered ones within the streaming Biquad's tolerance"""
     ring = 0
     for seed in range(40):
