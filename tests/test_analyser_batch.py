@@ -118,3 +118,20 @@ def test_c4_full_size_batch_pull_every_context(hip):
     lin = 10.0 ** (out.astype(np.float64) / 20)
     assert np.abs(lin - ref).max() <= 2e-6 * ref.max() + 1e-9   # f32 FFT of a 2048-frame window vs float64 (8.7e-7 measured)
     assert pull_ms < 5.0   # (measured: well under a millisecond; 512 single pulls took ~40 ms)
+
+
+def test_batched_pull_refuses_a_wrong_output_buffer(orc):
+    """the batched getters write through a raw pointer: shape / dtype / contiguity of a caller's buffer are checked (ValueError), not asserted"""
+    c = waa.OfflineAudioContext(1, 128 * 4, 48000.0, n_instances=3, binding=orc)
+    s = c.create_buffer_source()
+    s.set_buffer_batch(np.zeros((3, 1, 512), np.float32), 48000.0)
+    an = c.create_analyser(fft_size=256)
+    s.connect(an).connect(c.destination())
+    s.start()
+    c.start_rendering_sync()
+    good = np.zeros((3, 128), np.float32)
+    an.get_float_frequency_data_all(out=good)
+    for bad in (np.zeros((2, 128), np.float32), np.zeros((3, 128), np.float64), np.zeros((3, 256), np.float32)[:, ::2]):
+        with pytest.raises(ValueError):
+            an.get_float_frequency_data_all(out=bad)
+    c.close()

@@ -754,7 +754,9 @@ class AnalyserNode(AudioNode):
             raise WaaError(3, "InvalidStateError - analyser data is only available after start_rendering_sync")
         if out is None:
             out = np.zeros((ctx.n_instances, n), dtype=dtype)
-        assert out.shape == (ctx.n_instances, n) and out.dtype == dtype and out.flags.c_contiguous
+        if not isinstance(out, np.ndarray) or out.shape != (ctx.n_instances, n) or out.dtype != dtype or not out.flags.c_contiguous:
+            # (the library writes n values per context through the raw pointer: a wrong buffer is a silent out-of-bounds write)
+            raise ValueError(f"out: expected a C-contiguous {np.dtype(dtype).name} array of shape {(ctx.n_instances, n)}")
         ptr = out.ctypes.data_as(_FP if dtype == np.float32 else C.POINTER(C.c_uint8))
         ctx._b.check(getattr(ctx._b, fn_name)(ctx._handle, self.id, ptr, n))
         return out
