@@ -117,3 +117,29 @@ def c4(binding, noise, ir, sr=48000.0, length=None, device=-1):
 def rms_err(a, b):
     """per (instance, channel) RMS error, f64"""
     return np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2, axis=-1))
+
+
+def assert_all_finite(a, what):
+    """A render (or a pulled array) with a NaN / inf anywhere is a failure by itself: comparisons written as `x > worst` or
+    Python's max(worst, x) DROP a NaN (nan > x is False, max(0.0, nan) is 0.0), so every every-instance helper calls this on
+    the device's array first."""
+    a = np.asarray(a)
+    bad = ~np.isfinite(a)
+    if bad.any():
+        k = np.unravel_index(int(np.argmax(bad)), a.shape)
+        raise AssertionError(f"{what}: {int(bad.sum())} non-finite values, the first at index {tuple(int(i) for i in k)} = {a[k]}")
+
+
+def strict_max(*values):
+    """max() that FAILS on a NaN instead of dropping it (the accumulator form of the every-instance tests)"""
+    vals = [float(v) for v in values]
+    for v in vals:
+        if v != v:
+            raise AssertionError(f"NaN in an error accumulation: {vals}")
+    return max(vals)
+
+
+def assert_le(x, tol, what=""):
+    """x <= tol, a NaN on either side fails"""
+    x = float(x)
+    assert x == x and x <= tol, (what, x, tol)

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 import web_audio_api_rs_amd as waa
+from graphs import strict_max
 
 SR = 44100.0
 RQ = 128
@@ -376,7 +377,7 @@ def test_product_forms_agree(hip, oversample, factor):
     for name, env in (("transforms", {}), ("bf16x6", m), ("bf16x6_w4", dict(m, WAA_QGEMM_W4="1")),
                       ("f32_mfma", dict(m, WAA_QGEMM_F32="1")), ("f32_fma", dict(m, WAA_QGEMM_FMA="1"))):
         out = _render_with_env(hip, x, oversample, env)
-        err[name] = max(rms(out[i, c], ref[i, c]) for i in range(3) for c in range(2))
+        err[name] = strict_max(*[rms(out[i, c], ref[i, c]) for i in range(3) for c in range(2)])  # (fails on a NaN)
         assert err[name] <= 1e-6, (name, err)
     print(f"{oversample}: RMS error against the f64 definition by form: " + ", ".join(f"{k} {v:.2e}" for k, v in err.items()))
     assert err["bf16x6"] <= 2.0 * err["f32_fma"] + 1e-9, err
