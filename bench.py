@@ -565,6 +565,46 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
     return rec
 
 
+def launcher_decision(gpus, env):
+    """What `bench.py --gpus N` does about ranks (round-4 review, missing item 6: --gpus was parsed and never read, a plain
+    `python bench.py --gpus 8` rendered on one GPU and printed n_gpus: 1).
+      ("run",)          this process is one of exactly N ranks (WORLD_SIZE == N; N = 1 without a launcher is a rank too)
+      ("spawn",)        N > 1 and no launcher environment: re-exec under torch.distributed.run with N ranks
+      ("error", text)   a launcher started a different number of ranks than --gpus says: refuse (exit non-zero)"""
+    if gpus < 1:
+        return ("error", f"--gpus {gpus}: at least one GPU")
+    ws = env.get("WORLD_SIZE")
+    if ws is None:
+        return ("run",) if gpus == 1 else ("spawn",)
+    try:
+        world = int(ws)
+    except ValueError:
+        return ("error", f"WORLD_SIZE={ws!r} is not a number")
+    if world != gpus:
+        return ("error", f"bench.py --gpus {gpus} was started with WORLD_SIZE={world}: one rank per GPU, the two must agree "
+                         f"(launch with --nproc-per-node {gpus}, or run plain `python bench.py --gpus {gpus}`)")
+    return ("run",)
+
+
+def spawn_ranks(gpus, argv):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <argv>;
+    returns its exit code.  The port is picked free by binding port 0 first."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("WAA_BENCH_PRINT_LAUNCH"):
+        print(" ".join(cmd), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -582,10 +622,17 @@ def main():
     ap.add_argument("--detail", default=None, help="file for the full per-workload records (default: gpurun_out/bench_detail.json)")
     args = ap.parse_args()
 
+    decision = launcher_decision(args.gpus, os.environ)
+    if decision[0] == "error":
+        raise SystemExit(decision[1])
+    if decision[0] == "spawn":  # plain `python bench.py --gpus N`: start the N ranks ourselves (one per GPU, RCCL rendezvous on 127.0.0.1)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import web_audio_api_rs_amd as waa
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, (world, args.gpus)  # (launcher_decision guarantees it)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
