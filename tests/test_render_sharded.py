@@ -87,6 +87,49 @@ def test_a_failing_sub_batch_raises_and_does_not_hang(orc):
         render_sharded(build, noise, np.zeros_like(noise), devices=[-1], sub_batches=2)
 
 
+def test_a_node_that_fails_inside_setup_leaves_no_dangling_handle(orc):
+    """when a node's _apply raises INSIDE the setup callback (after the context adopted the
+    library's batch), the context must forget the handle — waa_render_sharded destroys the batch itself, and a context that
+    still held it destroyed it a second time from __del__ (double free).  The contexts are kept and closed explicitly here."""
+    import gc
+    made = []
+
+    def build(n, device):
+        ctx, src = _build(orc)(n, device)
+        made.append(ctx)
+        if len(made) == 3:  # (the template, the first sub-batch, then the second)
+            gain = next(nd for nd in ctx._nodes if isinstance(nd, waa.GainNode))
+            orig = gain._apply
+
+            def refuse(c):
+                orig(c)
+                raise waa.WaaError(2, "NotSupportedError - this node refuses its payload inside setup")
+            gain._apply = refuse
+        return ctx, src
+    noise = white_noise(5, 2, RQ * 30 + 5)
+    with pytest.raises(waa.WaaError, match="refuses its payload"):
+        render_sharded(build, noise, np.zeros_like(noise), devices=[-1], sub_batches=2)
+    assert len(made) == 3
+    for ctx in made:
+        assert ctx._handle is None  # nobody but the library owns a batch any more
+        ctx.close()
+    del made
+    gc.collect()
+    # the library is still healthy: the same job without the refusal renders
+    out = np.zeros_like(noise)
+    render_sharded(_build(orc), noise, out, devices=[-1], sub_batches=2)
+    assert np.abs(out).max() > 1e-3
+
+
+def test_close_never_destroys_an_adopted_batch(orc):
+    ctx, _ = _build(orc)(1, -1)
+    calls = []
+    ctx._b = type("B", (), {"batch_destroy": lambda self, h: calls.append(h)})()
+    ctx._handle, ctx._foreign = object(), True
+    ctx.close()
+    assert calls == [] and ctx._handle is None
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("slots,parts", [(1, 4), (2, 2), (3, 3)])
 def test_sharded_render_equals_single_batch_hip(hip, orc, slots, parts):

@@ -912,6 +912,7 @@ class OfflineAudioContext:
         self._edges = []
         self._handle = None
         self._rendered = False
+        self._foreign = False
         self._listener = AudioListener()
         self._destination = AudioDestinationNode(self)
 
@@ -999,8 +1000,12 @@ class OfflineAudioContext:
         schedules.  The batch stays the library's: _release() forgets it without destroying it."""
         self._handle = _VP(handle) if not isinstance(handle, _VP) else handle
         self._foreign = True
-        for nd in self._nodes:
-            nd._apply(self)
+        try:
+            for nd in self._nodes:
+                nd._apply(self)
+        except BaseException:
+            self._handle = None  # a node refused its payload: the batch is still the library's to destroy, never ours
+            raise
 
     def _release(self):
         self._handle = None
@@ -1071,7 +1076,8 @@ class OfflineAudioContext:
 
     def close(self):
         if self._handle is not None:
-            self._b.batch_destroy(self._handle)
+            if not getattr(self, "_foreign", False):  # an adopted batch belongs to the library (waa_render_sharded destroys it)
+                self._b.batch_destroy(self._handle)
             self._handle = None
 
     def __del__(self):

@@ -132,8 +132,8 @@ def render_sharded(build: Callable, host_in, host_out, devices: Sequence[int] = 
             ctx, _ = build(int(count), int(device))
             if len(ctx._nodes) != graph.n_nodes:
                 raise WaaError(1, "render_sharded: build() must return the same graph for every sub-batch")
+            live[int(first)] = ctx  # (before _adopt: whatever happens below, the finally clause forgets the library's handle)
             ctx._adopt(handle)
-            live[int(first)] = ctx
             return 0
         except WaaError as e:
             errors.append(e)
