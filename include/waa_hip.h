@@ -191,6 +191,14 @@ void waa_batch_destroy(waa_batch* batch);
  * creates and destroys batches while others render (waa_render_sharded's pipeline, a server) should reserve one (DESIGN.md section 7:
  * 112 -> 95 ms for 2 x 3.9 GB through one device). */
 waa_status waa_device_arena_reserve(int32_t device, uint64_t bytes);
+/* What the arena of `device` (-1: the current one) has done so far: a request of >= 1 MB the slab could not serve is a MISS
+ * (the batch fell back to hipMalloc, which synchronises the device) — a serving process watches `misses`.  All zero when no
+ * arena is reserved.  Pieces are handed back individually when their batch is destroyed (first-fit free list, neighbours merge). */
+typedef struct waa_arena_stats {
+  uint64_t reserved_bytes, in_use_bytes, peak_bytes, largest_free_bytes;
+  uint64_t served, misses, miss_bytes;
+} waa_arena_stats;
+waa_status waa_device_arena_stats(int32_t device, waa_arena_stats* out);
 const char* waa_last_error(void);
 /* number of visible HIP devices (0 if none / runtime unavailable) */
 int32_t waa_device_count(void);
@@ -355,6 +363,11 @@ typedef struct waa_sharded_job {
  * which synchronise the device — out of the pipeline.  WAA_SHARD_TRACE=1: the phase timeline of every sub-batch on stderr.  Under one process per GPU (torch.distributed, MPI) every rank calls this with its own
  * device and its own slice of the contexts. */
 waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds);
+/* Process-wide: how many sub-batches of ONE device may exist at a time inside waa_render_sharded (created, planned, uploading,
+ * rendering or downloading).  Default 4: the pipeline upload(k + 1) || render(k) || download(k - 1) plus one being prepared —
+ * device memory holds four sub-batches of a device's range, not all of them.  0 = no bound (everything resident at once, the
+ * behaviour before round 5). */
+waa_status waa_sharded_in_flight(uint32_t max_sub_batches_per_device);
 /* the partition rule: contexts [*first, *end) of n_total belong to part `part` of `n_parts` (sizes differ by at most one) */
 waa_status waa_shard_range(uint32_t n_total, uint32_t part, uint32_t n_parts, uint32_t* first, uint32_t* end);
 /* device pointer + strides (in floats) of the rendered output, valid until destroy */

@@ -1647,6 +1647,12 @@ waa_status orc_device_arena_reserve(int32_t device, uint64_t bytes) {
   (void)bytes;
   return WAA_OK;
 }
+waa_status orc_device_arena_stats(int32_t device, waa_arena_stats* out) {
+  (void)device;
+  if (!out) return WAA_ERR_INVALID_ARGUMENT;
+  memset(out, 0, sizeof *out);
+  return WAA_OK;
+}
 void orc_batch_destroy(orc_batch* b) {
   if (!b) return;
   for (uint32_t k = 0; k < b->n_inst; k++) {
@@ -3831,6 +3837,11 @@ static void orc_split(uint32_t n, uint32_t part, uint32_t parts, uint32_t* lo, u
 waa_status orc_shard_range(uint32_t n_total, uint32_t part, uint32_t n_parts, uint32_t* first, uint32_t* end) {
   if (!first || !end || n_parts == 0 || part >= n_parts) return fail(WAA_ERR_INVALID_ARGUMENT, "bad shard index %u of %u", part, n_parts);
   orc_split(n_total, part, n_parts, first, end);
+  return WAA_OK;
+}
+/* waa_sharded_in_flight bounds device memory inside the product's pipeline; the oracle renders one sub-batch at a time anyway */
+waa_status orc_sharded_in_flight(uint32_t max_sub_batches_per_device) {
+  (void)max_sub_batches_per_device;
   return WAA_OK;
 }
 waa_status orc_render_sharded(const waa_sharded_job* job, double* seconds) {

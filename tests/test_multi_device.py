@@ -96,3 +96,45 @@ def test_device_arena_serves_the_big_buffers_and_changes_nothing(hip, orc):
         ctx.close()
     finally:
         hip.check(hip.device_arena_reserve(0, 0))
+
+
+@pytest.mark.gpu
+def test_device_arena_hands_pieces_back_while_lifetimes_overlap(hip):
+    """the bump allocator rewound only when NO piece was live — a pipeline (the next batch created before the
+    previous one is destroyed) ran the slab dry and every later batch fell back to hipMalloc without a sign.  The free list
+    returns a batch's pieces when THAT batch is destroyed: 40 overlapping batches through a slab that holds about three,
+    zero misses (waa_device_arena_stats), and the caller's current device is left alone."""
+    import torch
+    from graphs import c2, white_noise
+    noise = white_noise(4, 2, 128 * 2000)  # 2 MB per plane set: source + output pieces of a few MB per batch
+    before = torch.cuda.current_device()
+    hip.check(hip.device_arena_reserve(0, 96 << 20))
+    assert torch.cuda.current_device() == before
+    try:
+        st = waa.arena_stats(hip, 0)
+        assert st["reserved_bytes"] == 96 << 20 and st["in_use_bytes"] == 0 and st["misses"] == 0
+        prev = None
+        first = None
+        for i in range(40):
+            ctx, _ = c2(hip, noise, device=0)
+            out = ctx.start_rendering_sync().data
+            first = out if first is None else first
+            assert np.array_equal(out, first)
+            if prev is not None:
+                prev.close()
+            prev = ctx
+        st = waa.arena_stats(hip, 0)
+        assert st["misses"] == 0 and st["served"] >= 80, st
+        assert 0 < st["in_use_bytes"] <= st["peak_bytes"] <= 96 << 20
+        prev.close()
+        st = waa.arena_stats(hip, 0)
+        assert st["in_use_bytes"] == 0 and st["largest_free_bytes"] == 96 << 20, st  # everything merged back into one block
+        # a request the slab cannot serve is counted
+        big = white_noise(4, 2, 128 * 40000)
+        ctx, _ = c2(hip, big, device=0)
+        ctx.prepare()
+        assert waa.arena_stats(hip, 0)["misses"] >= 1
+        ctx.close()
+    finally:
+        hip.check(hip.device_arena_reserve(0, 0))
+    assert waa.arena_stats(hip, 0)["reserved_bytes"] == 0

@@ -3,6 +3,8 @@ contiguous ranges per device -> pipelined sub-batches (upload || render || downl
 backend independent, so the partition / ordering / error paths are exercised here with the CPU oracle standing in for the
 device library; the GPU tests run it on the HIP library (several slots on one device on a 1-GPU box, two devices where
 there are two) and require the union of the shards to equal the unsharded render bit for bit."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -299,3 +301,71 @@ def test_sharded_render_pcm16_input_at_another_rate_hip(hip, orc):
     ref = np.zeros_like(out)
     render_sharded(_build(orc), pcm, ref, devices=[-1], sub_batches=1, pcm16=True, sample_rate=44100.0)
     assert rms_err(out, ref).max() <= 1e-6 and np.abs(ref).max() > 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", [1, 2, 0])
+def test_sharded_render_with_a_bounded_number_of_sub_batches_in_flight(hip, window):
+    """waa_sharded_in_flight: at most `window` sub-batches of a device exist at a time — 1 serialises them, 0 is
+    the unbounded behaviour of round 4; the result never changes and nothing deadlocks (8 sub-batches through every window)."""
+    n, frames = 24, RQ * 30 + 5
+    noise = white_noise(n, 2, frames)
+    ref = np.zeros((n, 2, frames), np.float32)
+    render_sharded(_build(hip), noise, ref, devices=[0], sub_batches=1)
+    out = np.zeros_like(ref)
+    hip.check(hip.sharded_in_flight(window))
+    try:
+        render_sharded(_build(hip), noise, out, devices=[0, 0], sub_batches=8)
+    finally:
+        hip.check(hip.sharded_in_flight(4))
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.gpu
+def test_in_flight_window_bounds_device_memory(hip):
+    """with window 1 the arena's peak holds ONE sub-batch's pieces, with no bound all eight"""
+    n, frames = 16, RQ * 4000
+    noise = white_noise(n, 2, frames)
+    out = np.zeros_like(noise)
+
+    def build(k, device):
+        ctx = waa.OfflineAudioContext(2, frames, 48000.0, n_instances=k, binding=hip, device=device)
+        src = ctx.create_buffer_source()
+        src.connect(ctx.create_biquad_filter(type_="lowpass", frequency=200.0, q=1.0)).connect(ctx.destination())
+        src.start()
+        return ctx, src
+    peaks = {}
+    for window in (1, 0):
+        hip.check(hip.device_arena_reserve(0, 512 << 20))
+        hip.check(hip.sharded_in_flight(window))
+        try:
+            render_sharded(build, noise, out, devices=[0], sub_batches=8)
+            st = waa.arena_stats(hip, 0)
+            assert st["misses"] == 0 and st["in_use_bytes"] == 0
+            peaks[window] = st["peak_bytes"]
+        finally:
+            hip.check(hip.sharded_in_flight(4))
+            hip.check(hip.device_arena_reserve(0, 0))
+    assert peaks[1] * 3 <= peaks[0], peaks
+
+
+@pytest.mark.gpu
+def test_pcm16_download_of_more_contexts_than_grid_rows(hip, orc):
+    """the PCM packer put the context index on gridDim.y (65535 rows at most) — a batch of 70 000 short contexts
+    failed at the launch; it now walks the rows in strides"""
+    n, frames = 70000, 64
+    rng = np.random.default_rng(3)
+    noise = rng.uniform(-1, 1, (n, 1, frames)).astype(np.float32)
+    outs = []
+    for be in (hip, orc):
+        ctx = waa.OfflineAudioContext(1, frames, 48000.0, n_instances=n, binding=be)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(noise, 48000.0)
+        src.connect(ctx.destination())
+        src.start()
+        ctx.render_async()
+        pcm = np.empty((n, frames, 1), np.int16)
+        be.check(be.download_all_pcm16(ctx._handle, pcm.ctypes.data_as(C.POINTER(C.c_int16))))
+        ctx.close()
+        outs.append(pcm)
+    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0][-1].astype(np.int32)).max() > 100

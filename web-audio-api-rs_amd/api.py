@@ -94,6 +94,19 @@ class ShardedJob(C.Structure):
                 ("in_sample_rate", C.c_float), ("out_pcm16", C.c_int32), ("host_out", _VP), ("setup", SHARD_FN),
                 ("pull", SHARD_FN), ("user", _VP)]
 
+class ArenaStats(C.Structure):
+    """waa_arena_stats (include/waa_hip.h)"""
+    _fields_ = [(n, C.c_uint64) for n in ("reserved_bytes", "in_use_bytes", "peak_bytes", "largest_free_bytes", "served", "misses",
+                                          "miss_bytes")]
+
+
+def arena_stats(binding, device=-1) -> dict:
+    """waa_device_arena_stats as a dict (all zero when no arena is reserved on the device)"""
+    st = ArenaStats()
+    binding.check(binding.device_arena_stats(int(device), C.cast(C.pointer(st), _VP)))
+    return {n: int(getattr(st, n)) for n, _ in ArenaStats._fields_}
+
+
 # name -> (restype, argtypes); every symbol include/waa_hip.h declares
 ABI = {
     "batch_create": (C.c_int32, [C.POINTER(GraphDesc), C.c_uint32, C.c_uint32, C.c_uint64, C.c_float, C.c_int32,
@@ -102,6 +115,7 @@ ABI = {
     "last_error": (C.c_char_p, []),
     "device_count": (C.c_int32, []),
     "device_arena_reserve": (C.c_int32, [C.c_int32, C.c_uint64]),
+    "device_arena_stats": (C.c_int32, [C.c_int32, _VP]),
     "source_set_buffer": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FPP, C.c_uint32, C.c_uint64, C.c_float]),
     "source_set_buffer_batch": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32, C.c_uint64, C.c_float]),
     "source_set_buffer_pcm16": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_int16), C.c_uint32, C.c_uint64, C.c_float]),
@@ -133,6 +147,7 @@ ABI = {
     "download_all": (C.c_int32, [_VP, _FP]),
     "download_all_pcm16": (C.c_int32, [_VP, C.POINTER(C.c_int16)]),
     "render_sharded": (C.c_int32, [_VP, C.POINTER(C.c_double)]),
+    "sharded_in_flight": (C.c_int32, [C.c_uint32]),
     "shard_range": (C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "output_device": (C.c_int32, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "analyser_get_float_frequency_data": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FP, C.c_uint32]),

@@ -10,10 +10,16 @@
 
 namespace waa {
 
+constexpr uint32_t MAX_GRID_ROWS = 65535;  // gridDim.y limit
+
+__device__ __forceinline__ void pcm16_resample_item(const DecodeDesc& d, uint32_t item, uint64_t i);
 __global__ __launch_bounds__(256) void pcm16_resample_kernel(const DecodeDesc d) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint32_t item = blockIdx.y;  // one AudioBuffer of the batch
   if (i >= d.target_frames) return;
+  // one AudioBuffer of the batch per blockIdx.y; batches above the grid's 65535 rows are walked in strides
+  for (uint32_t item = blockIdx.y; item < d.n_items; item += gridDim.y) pcm16_resample_item(d, item, i);
+}
+__device__ __forceinline__ void pcm16_resample_item(const DecodeDesc& d, uint32_t item, uint64_t i) {
   const int16_t* src = d.pcm + (uint64_t)item * d.frames * d.nch;
   float* dst = d.out + (uint64_t)item * d.out_item_stride;
   uint64_t prev = i, next = i;
@@ -39,7 +45,7 @@ __global__ __launch_bounds__(256) void pcm16_resample_kernel(const DecodeDesc d)
 }
 void launch_pcm16_resample(const DecodeDesc& d, void* stream) {
   if (d.target_frames == 0 || d.n_items == 0) return;
-  dim3 grid((unsigned)((d.target_frames + 255) / 256), d.n_items);
+  dim3 grid((unsigned)((d.target_frames + 255) / 256), d.n_items < MAX_GRID_ROWS ? d.n_items : MAX_GRID_ROWS);
   hipLaunchKernelGGL(pcm16_resample_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
 }
 
@@ -48,19 +54,20 @@ void launch_pcm16_resample(const DecodeDesc& d, void* stream) {
 // such step: an OfflineAudioContext hands back f32 planes).  Channels the destination's signal does not carry are zero.
 __global__ __launch_bounds__(256) void pcm16_pack_kernel(const EncodeDesc d) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint32_t item = blockIdx.y;
   if (i >= d.frames) return;
-  int16_t* dst = d.pcm + ((uint64_t)item * d.frames + i) * d.nch_out;
-  for (uint32_t c = 0; c < d.nch_out; c++) {
-    float v = c < d.nch_in ? load_global(d.in + (uint64_t)item * d.in_item_stride + (uint64_t)c * d.in_ch_stride + i) : 0.f;
-    v = v * 32768.f;
-    v = v < -32768.f ? -32768.f : (v > 32767.f ? 32767.f : v);
-    dst[c] = (int16_t)__float2int_rn(v != v ? 0.f : v);
+  for (uint32_t item = blockIdx.y; item < d.n_items; item += gridDim.y) {  // (more than 65535 contexts: strides of the grid's rows)
+    int16_t* dst = d.pcm + ((uint64_t)item * d.frames + i) * d.nch_out;
+    for (uint32_t c = 0; c < d.nch_out; c++) {
+      float v = c < d.nch_in ? load_global(d.in + (uint64_t)item * d.in_item_stride + (uint64_t)c * d.in_ch_stride + i) : 0.f;
+      v = v * 32768.f;
+      v = v < -32768.f ? -32768.f : (v > 32767.f ? 32767.f : v);
+      dst[c] = (int16_t)__float2int_rn(v != v ? 0.f : v);
+    }
   }
 }
 void launch_pcm16_pack(const EncodeDesc& d, void* stream) {
   if (d.frames == 0 || d.n_items == 0) return;
-  dim3 grid((unsigned)((d.frames + 255) / 256), d.n_items);
+  dim3 grid((unsigned)((d.frames + 255) / 256), d.n_items < MAX_GRID_ROWS ? d.n_items : MAX_GRID_ROWS);
   hipLaunchKernelGGL(pcm16_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
 }
 

@@ -7,6 +7,7 @@
 // on in sub-batch order by two turn counters per device.  This is what web-audio-api-rs_amd/sharding.py did in Python in
 // round 3; that module is now a thin caller of this function, and a Rust or C host calls it directly.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -48,6 +49,42 @@ struct Shard {
   int32_t device;
 };
 
+// At most `window` sub-batches of one device exist at a time (every sub-batch thread used to create, allocate and
+// plan its batch at once, so the whole device range plus its PCM staging was resident together and a job that only fits when
+// pipelined ran out of memory).  Sub-batch k is admitted once k - window + 1 of its predecessors are destroyed.
+struct Window {
+  std::mutex m;
+  std::condition_variable cv;
+  uint32_t finished = 0, limit = 4;
+  void enter(uint32_t k) {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return k < finished + limit; });
+  }
+  void leave() {
+    {
+      std::lock_guard<std::mutex> l(m);
+      finished++;
+    }
+    cv.notify_all();
+  }
+};
+
+// A callback reports through its return value only.  This thread's message is cleared before the call: if the callback failed
+// inside a library call, that call's text is kept (prefixed); otherwise a message is written here — report() reads it from this
+// thread, and a C or Rust host used to get a status with an empty (or stale) text.
+int call_back(waa_shard_setup_fn fn, const char* which, waa_batch* b, const Shard& sh, void* user) {
+  fail(0, "%s", "");
+  const int st = fn(b, sh.lo, sh.hi - sh.lo, sh.device, user);
+  if (!st) return 0;
+  const std::string inner = waa_last_error();
+  if (inner.empty()) return fail(st, "the %s callback of sub-batch [%u, %u) on device %d returned status %d", which, sh.lo, sh.hi, sh.device, st);
+  return fail(st, "%s (in the %s callback of sub-batch [%u, %u) on device %d)", inner.c_str(), which, sh.lo, sh.hi, sh.device);
+}
+
+// sub-batches in flight per device: upload(k + 1) || render(k) || download(k - 1) needs three; the fourth prepares (creates,
+// sets up, plans) while the third waits for its upload turn.  waa_sharded_in_flight changes it (0 = no bound).
+std::atomic<uint32_t> g_in_flight{4};
+
 // items lo .. hi of n split into `parts` contiguous ranges that differ by at most one (tests/test_multi_rank.py pins the rule)
 void split_range(uint32_t n, uint32_t part, uint32_t parts, uint32_t* lo, uint32_t* hi) {
   const uint32_t base = n / parts, rem = n % parts;
@@ -62,6 +99,11 @@ extern "C" {
 waa_status waa_shard_range(uint32_t n_total, uint32_t part, uint32_t n_parts, uint32_t* first, uint32_t* end) {
   if (!first || !end || n_parts == 0 || part >= n_parts) return fail(WAA_ERR_INVALID_ARGUMENT, "bad shard index %u of %u", part, n_parts);
   split_range(n_total, part, n_parts, first, end);
+  return WAA_OK;
+}
+
+waa_status waa_sharded_in_flight(uint32_t max_sub_batches_per_device) {
+  g_in_flight.store(max_sub_batches_per_device);
   return WAA_OK;
 }
 
@@ -117,6 +159,11 @@ waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds) {
     }
   }
   std::vector<Turn> up(job->n_devices), down(job->n_devices);
+  std::vector<Window> window(job->n_devices);
+  {
+    const uint32_t lim = g_in_flight.load();
+    for (auto& w : window) w.limit = lim ? lim : UINT32_MAX;
+  }
   const size_t row_in = (size_t)job->in_channels * job->in_frames * (job->in_pcm16 ? sizeof(int16_t) : sizeof(float));
   const size_t row_out = (size_t)job->n_channels_out * job->length_frames * (job->out_pcm16 ? sizeof(int16_t) : sizeof(float));
   std::mutex err_lock;
@@ -142,9 +189,12 @@ waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds) {
   auto run = [&](const Shard& sh) {
     waa_batch* b = nullptr;
     bool took_up = false, took_down = false;
+    window[sh.slot].enter(sh.k);
     stamp(sh, "start");
     int st = waa_batch_create(job->graph, sh.hi - sh.lo, job->n_channels_out, job->length_frames, job->sample_rate, sh.device, &b);
-    if (!st && job->setup) st = job->setup(b, sh.lo, sh.hi - sh.lo, sh.device, job->user);
+    if (!st && job->setup) {
+      st = call_back(job->setup, "setup", b, sh, job->user);
+    }
     stamp(sh, "created + set up");
     // The source's buffers are allocated and registered BEFORE the sub-batch's turn on the link, and the batch is planned: the
     // plan only needs their shape, and its small table uploads queue on the same DMA engine as the bulk upload of whichever
@@ -178,7 +228,9 @@ waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds) {
     if (!st) st = waa_render(b);
     if (!st) st = waa_sync(b);
     stamp(sh, "planned + rendered");
-    if (!st && job->pull) st = job->pull(b, sh.lo, sh.hi - sh.lo, sh.device, job->user);
+    if (!st && job->pull) {
+      st = call_back(job->pull, "pull", b, sh, job->user);
+    }
     if (!st) {
       down[sh.slot].wait(sh.k);
       took_down = true;
@@ -201,6 +253,7 @@ waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds) {
       }
     }
     if (b) waa_batch_destroy(b);
+    window[sh.slot].leave();
     stamp(sh, "destroyed");
   };
   const auto t0 = std::chrono::steady_clock::now();
