@@ -22,6 +22,7 @@
  *   waa_hrtf_hrir_length        HrirSphere::len (the HRTF panner's tail time)  src/node/panner.rs:56,270-272
  *   waa_hrtf_sample             hrtf::HrirSphere::sample_bilinear (test hook)  src/node/panner.rs:261 (process_samples)
  *   waa_oscillator_set_periodic_wave  OscillatorNode::set_periodic_wave     src/node/oscillator.rs:318-321
+ *   waa_oscillator_set_wavetable   OscillatorRenderer::onmessage(PeriodicWave)  src/node/oscillator.rs:487-493
  *   waa_iir_set_coefficients    IIRFilterNode::new(IIRFilterOptions)          src/node/iir_filter.rs:163-189
  *   waa_iir_frequency_response  IIRFilterNode::get_frequency_response         src/node/iir_filter.rs:218-262
  *   waa_set_param_const/block   AudioParamValues::get (len 1 / len 128)       src/render/processor.rs:186-229
@@ -247,6 +248,12 @@ waa_status waa_waveshaper_set_curve(waa_batch* batch, uint32_t node, const float
  * host; n >= 2 (IndexSizeError); real or imag may be NULL (zeros).  Switches the node to the custom type. */
 waa_status waa_oscillator_set_periodic_wave(waa_batch* batch, uint32_t node, const float* real, const float* imag,
                                             uint32_t n, int32_t disable_normalization);
+/* The same, for a caller that already holds the finished PeriodicWave (the reference's render side: the processor receives
+ * the 8192-point wavetable through onmessage, src/node/oscillator.rs:487-493, and PeriodicWave keeps no coefficients,
+ * src/periodic_wave.rs:72-74 — this is what the Rust shim forwards).  n must be 8192 (PERIODIC_WAVE_TABLE_LENGTH,
+ * periodic_wave.rs:76); the table is used as it is (already normalised or not).  Switches the node to the custom type. */
+#define WAA_PERIODIC_WAVE_TABLE_LENGTH 8192
+waa_status waa_oscillator_set_wavetable(waa_batch* batch, uint32_t node, const float* table, uint32_t n);
 /* IIRFilterOptions{feedforward, feedback} (src/node/iir_filter.rs:63-72), shared by all instances; required
  * before waa_render.  1..20 coefficients each (NotSupportedError otherwise), feedforward not all zero and
  * feedback[0] != 0 (InvalidStateError), iir_filter.rs:17-46. */

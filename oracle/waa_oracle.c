@@ -2016,6 +2016,20 @@ waa_status orc_oscillator_set_periodic_wave(orc_batch* b, uint32_t node, const f
   return WAA_OK;
 }
 
+/* the finished table (oscillator.rs:487-493) */
+waa_status orc_oscillator_set_wavetable(orc_batch* b, uint32_t node, const float* table, uint32_t n) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_OSCILLATOR))) return e;
+  if (!table || n != WAA_PERIODIC_WAVE_TABLE_LENGTH)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - a PeriodicWave table has %d points (got %u)", WAA_PERIODIC_WAVE_TABLE_LENGTH, n);
+  NodeCfg* nd = &b->nodes[node];
+  float* copy = (float*)malloc(sizeof(float) * n);
+  memcpy(copy, table, sizeof(float) * n);
+  free(nd->osc_wave);
+  nd->osc_wave = copy;
+  return WAA_OK;
+}
+
 /* AudioParam::set_value_at_time & co. (param.rs:428-596) on a param of the batch */
 waa_status orc_param_schedule_event(orc_batch* b, uint32_t node, uint32_t param, uint32_t inst, int32_t type, float value,
                                     double time, double aux, const float* curve, uint32_t n_curve) {

@@ -55,6 +55,9 @@ pub const WAA_NODE_IIR_FILTER: u32 = 10;
 pub const WAA_NODE_DELAY: u32 = 11;
 pub const WAA_NODE_OSCILLATOR: u32 = 12;
 
+/// `waa_node_desc.i[0]` of an oscillator (WAA_OSC_*); the reference's `OscillatorType as u32` has the same order
+pub const WAA_OSC_CUSTOM: u32 = 4;
+
 pub const WAA_COUNT_MODE_MAX: u32 = 0;
 pub const WAA_COUNT_MODE_CLAMPED_MAX: u32 = 1;
 pub const WAA_COUNT_MODE_EXPLICIT: u32 = 2;
@@ -109,6 +112,8 @@ extern "C" {
         sample_rate: f32,
     ) -> i32;
     pub fn waa_waveshaper_set_curve(batch: *mut waa_batch, node: u32, curve: *const f32, n: u32) -> i32;
+    /// OscillatorRenderer::onmessage(PeriodicWave) (oscillator.rs:487-493): the finished 8192-point table
+    pub fn waa_oscillator_set_wavetable(batch: *mut waa_batch, node: u32, table: *const f32, n: u32) -> i32;
     /// load_hrtf_processor's database (panner.rs:39-68): once per process, before the first HRTF PannerNode renders
     pub fn waa_hrtf_load_sphere(data: *const std::ffi::c_void, size: u64) -> i32;
     pub fn waa_iir_set_coefficients(

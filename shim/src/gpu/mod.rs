@@ -18,13 +18,20 @@
 //! 3. `waa_render`, download of every context's AudioBuffer, the analysers' ring buffers refilled from the device, `ended`
 //!    events dispatched in the order the reference would have, `complete` + state change (`gpu_complete`).
 //!
-//! Whatever the device path does not cover — a processor without `gpu_desc` (worklets, media nodes, PannerNode, DelayNode,
-//! custom PeriodicWaves: not forwarded by this first version of the shim although the library renders them), contexts with
-//! scheduled suspensions, graphs of different shape, or a graph the library refuses with status 4 — is rendered by the
-//! render threads taken in step 1 on the CPU, as if this module did not exist: they hold the fully applied graph.
+//! Forwarded node kinds: every renderer of SURVEY section 8 — Gain, Biquad, IIRFilter, StereoPanner, Panner (equal-power and
+//! HRTF, with the listener's params), Convolver, WaveShaper (all oversample types), Analyser, Delay (the writer / reader pair
+//! folded into one library node), AudioBufferSource, ConstantSource, Oscillator (built-in types and custom PeriodicWaves: the
+//! finished 8192-point table goes through `waa_oscillator_set_wavetable`), Destination, and every AudioParam.
 //!
-//! STATUS: written against web-audio-api 1.6.0 and include/waa_hip.h without a Rust toolchain at hand; it has never been
-//! compiled.  `sh oracle/build_ref.sh` of the engine's repository builds it where cargo exists and compares both paths.
+//! Whatever the device path does not cover — a processor without `gpu_desc` (worklets, media nodes, script processors),
+//! contexts with scheduled suspensions, graphs of different shape, or a graph the library refuses with status 4 — is rendered
+//! by the render threads taken in step 1 on the CPU, as if this module did not exist: they hold the fully applied graph.
+//!
+//! STATUS: UNCOMPILED SKETCH.  Written against web-audio-api 1.6.0 and include/waa_hip.h without a Rust toolchain at hand; it
+//! has never been through rustc, so borrow / lifetime errors are to be expected on the first build.  What IS checked without
+//! one (tests/test_shim_patch.py of the engine's repository): the patch applies, every `extern "C"` declaration of ffi.rs
+//! agrees with the header in parameter count AND type, the `#[repr(C)]` structs agree field by field, and every `ffi::waa_*`
+//! this file calls is declared.  `sh oracle/build_ref.sh` builds it where cargo exists and compares both paths.
 
 mod ffi;
 
@@ -81,6 +88,8 @@ pub(crate) enum GpuNode<'a> {
         detune: u64,
         start_time: f64,
         stop_time: f64,
+        /// `Some` = a custom PeriodicWave: the finished table the renderer received (oscillator.rs:487-493)
+        wavetable: Option<&'a [f32]>,
     },
     Convolver {
         impulse: Option<(&'a AudioBuffer, bool)>,
@@ -500,10 +509,24 @@ fn forward_payloads(
             }
             GpuNode::ConstantSource {
                 start_time, stop_time, ..
-            }
-            | GpuNode::Oscillator {
-                start_time, stop_time, ..
             } => {
+                if start_time != f64::MAX {
+                    check(unsafe { ffi::waa_source_start(batch, node, inst, start_time, 0., f64::MAX) })?;
+                }
+                if stop_time != f64::MAX {
+                    check(unsafe { ffi::waa_source_stop(batch, node, inst, stop_time) })?;
+                }
+            }
+            GpuNode::Oscillator {
+                start_time,
+                stop_time,
+                wavetable,
+                ..
+            } => {
+                // a custom PeriodicWave is kept once per batch like curves and impulse responses (instance 0's)
+                if let (Some(table), 0) = (wavetable, inst) {
+                    check(unsafe { ffi::waa_oscillator_set_wavetable(batch, node, table.as_ptr(), table.len() as u32) })?;
+                }
                 if start_time != f64::MAX {
                     check(unsafe { ffi::waa_source_start(batch, node, inst, start_time, 0., f64::MAX) })?;
                 }

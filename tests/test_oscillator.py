@@ -126,6 +126,43 @@ def test_periodic_wave(be, harmonics):
     assert np.max(np.abs(out - exp)) <= 1e-4  # 8192-point table, linear interpolation (reference: 1e-5 at lower freq)
 
 
+def test_finished_wavetable_equals_the_coefficient_form(be):
+    """waa_oscillator_set_wavetable (what the Rust shim forwards: the reference's processor only holds the finished table,
+    oscillator.rs:487-493): the table periodic_wave.rs:174-196 generates in f32, handed over as it is, renders bit for bit what
+    the coefficient form renders when the host's cos / sin agree with the library's — they need not to the last ulp, so the
+    bound here is the effect of one ulp of table error; the exact statement is the second half: a table is USED as given
+    (linear interpolation `prev.mul_add(1 - k, next * k)`, oscillator.rs:623-636)."""
+    sr, n, freq = 44100, 4096, 317.0
+    real, imag = [0.0, 0.3, 0.0, 0.1], [0.0, 1.0, 0.5, 0.0]
+    a = render_osc(be, sr, n, freq, wave=waa.PeriodicWave(real=real, imag=imag))
+    i = np.arange(8192, dtype=np.float32)
+    phase = np.float32(2.0 * np.float32(np.pi)) * i / np.float32(8192)
+    table = np.zeros(8192, np.float32)
+    for j in range(1, 4):
+        rad = phase * np.float32(j)
+        table += np.float32(real[j]) * np.cos(rad) + np.float32(imag[j]) * np.sin(rad)
+    table *= np.float32(1.0) / np.abs(table).max()
+    b = render_osc(be, sr, n, freq, wave=waa.PeriodicWave.from_wavetable(table))
+    assert np.max(np.abs(a - b)) <= 2e-6
+    # a random table: the lookup itself, restated
+    rng = np.random.default_rng(4)
+    table = rng.uniform(-1, 1, 8192).astype(np.float32)
+    out = render_osc(be, sr, n, freq, wave=waa.PeriodicWave.from_wavetable(table))
+    exp = np.zeros(n, np.float32)
+    ph, incr = 0.0, float(np.float32(freq)) / sr
+    for k in range(n):
+        pos = ph * 8192
+        lo = int(pos)
+        kk = np.float32(pos - lo)
+        exp[k] = np.float32(np.float64(table[lo % 8192]) * np.float64(np.float32(1.0) - kk) + np.float64(np.float32(table[(lo + 1) % 8192] * kk)))
+        ph += incr
+        if ph >= 1.0:
+            ph -= 1.0
+    assert np.max(np.abs(out - exp)) <= 2e-7
+    with pytest.raises(waa.WaaError, match="IndexSizeError"):
+        waa.PeriodicWave.from_wavetable(np.zeros(100, np.float32))
+
+
 def test_periodic_wave_validation(be):
     """periodic_wave.rs:104-139"""
     with pytest.raises(waa.WaaError, match="IndexSizeError"):

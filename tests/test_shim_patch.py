@@ -33,16 +33,169 @@ def test_patch_applies_and_carries_the_module_files(tmp_path):
         assert "fn gpu_desc(&self)" in body[:body.index("fn process(")], (node, proc)
 
 
-def test_rust_declarations_match_the_header():
-    ffi = open(os.path.join(ROOT, "shim", "src", "gpu", "ffi.rs")).read()
+# ---- declarations: count AND type of every parameter, return type, struct layouts, constants ------------------------------------
+_C_SCALARS = {"uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "int16_t": "i16", "float": "f32",
+              "double": "f64", "size_t": "usize", "char": "c_char", "void": "c_void", "waa_status": "i32", "int": "i32"}
+
+
+def _c_type(decl, named=True):
+    """'const float* const* channels' -> ('ptr_const', 'ptr_const', 'f32'); the parameter name (if any) is dropped"""
+    d = decl.strip()
+    d = re.sub(r"/\*.*?\*/", "", d, flags=re.S).strip()
+    toks = re.findall(r"[A-Za-z_]\w*|\*", d)
+    if named and toks and toks[-1] != "*" and toks[-1] not in _C_SCALARS and not toks[-1].startswith("waa_") and len(toks) > 1:
+        toks = toks[:-1]
+    elif named and len([t for t in toks if t not in ("const", "*")]) > 1:
+        toks = toks[:-1]
+    base, rest = None, []
+    pending_const = False
+    i = 0
+    # base type with its own const
+    base_const = False
+    while i < len(toks) and toks[i] != "*":
+        if toks[i] == "const":
+            base_const = True
+        else:
+            base = toks[i]
+        i += 1
+    out = []
+    const_of_pointee = base_const
+    while i < len(toks):
+        assert toks[i] == "*", decl
+        i += 1
+        out.append("ptr_const" if const_of_pointee else "ptr_mut")
+        const_of_pointee = False
+        if i < len(toks) and toks[i] == "const":
+            const_of_pointee = True
+            i += 1
+    out.reverse()
+    scalar = _C_SCALARS.get(base, base)
+    return tuple(out) + (scalar,)
+
+
+def _rust_type(t):
+    """'*const *const f32' -> ('ptr_const', 'ptr_const', 'f32')"""
+    t = t.strip()
+    out = []
+    while t.startswith("*"):
+        m = re.match(r"\*(const|mut)\s+", t)
+        assert m, t
+        out.append("ptr_" + m.group(1))
+        t = t[m.end():]
+    t = t.replace("std::ffi::", "").replace("std::os::raw::", "")
+    return tuple(out) + (t,)
+
+
+def _header():
     header = open(os.path.join(ROOT, "include", "waa_hip.h")).read()
-    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    decls = re.findall(r"pub fn (waa_\w+)\s*\((.*?)\)\s*(?:->\s*[\w:*\s]+)?;", ffi, flags=re.S)
-    assert len(decls) >= 18
-    for name, params in decls:
-        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, header, flags=re.S)
+    return re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+
+
+def _ffi():
+    return open(os.path.join(ROOT, "shim", "src", "gpu", "ffi.rs")).read()
+
+
+def _split_params(text):
+    return [p for p in (q.strip() for q in text.split(",")) if p and p != "void"]
+
+
+def test_type_translators():
+    assert _c_type("const float* const* channels") == ("ptr_const", "ptr_const", "f32")
+    assert _c_type("waa_batch** out") == ("ptr_mut", "ptr_mut", "waa_batch")
+    assert _c_type("const waa_graph_desc* graph") == ("ptr_const", "waa_graph_desc")
+    assert _c_type("uint32_t n") == ("u32",)
+    assert _c_type("float* dst") == ("ptr_mut", "f32")
+    assert _c_type("const void* data") == ("ptr_const", "c_void")
+    assert _rust_type("*const *const f32") == ("ptr_const", "ptr_const", "f32")
+    assert _rust_type("*mut *mut waa_batch") == ("ptr_mut", "ptr_mut", "waa_batch")
+    assert _rust_type("*const std::ffi::c_void") == ("ptr_const", "c_void")
+    assert _rust_type("u64") == ("u64",)
+
+
+def test_rust_declarations_match_the_header():
+    """every `pub fn waa_*` of ffi.rs against include/waa_hip.h: parameter count, every parameter's type (width, signedness,
+    float / integer, pointer depth and constness per level) and the return type"""
+    ffi, header = _ffi(), _header()
+    decls = re.findall(r"pub fn (waa_\w+)\s*\((.*?)\)\s*(?:->\s*([\w:*\s]+?))?;", ffi, flags=re.S)
+    assert len(decls) >= 19
+    for name, params, ret in decls:
+        m = re.search(r"([\w\s\*]+?)\b%s\s*\((.*?)\)\s*;" % name, header, flags=re.S)
         assert m, f"{name} is declared in shim/src/gpu/ffi.rs but not in include/waa_hip.h"
-        n_rust = len([p for p in params.split(",") if p.strip()])
-        c_params = m.group(1).strip()
-        n_c = 0 if c_params in ("", "void") else len([p for p in c_params.split(",") if p.strip()])
-        assert n_rust == n_c, (name, n_rust, n_c)
+        rust = [p.split(":", 1) for p in _split_params(params)]
+        c = _split_params(m.group(2))
+        assert len(rust) == len(c), (name, len(rust), len(c))
+        for (rname, rtype), cdecl in zip(rust, c):
+            assert _rust_type(rtype) == _c_type(cdecl), (name, rname.strip(), rtype.strip(), cdecl)
+        c_ret = m.group(1).strip().split("\n")[-1].strip()
+        c_ret_t = _c_type(c_ret, named=False)
+        rust_ret_t = _rust_type(ret) if ret else ("c_void",)
+        assert rust_ret_t == c_ret_t, (name, ret, c_ret)
+
+
+def test_repr_c_structs_match_the_header():
+    """waa_node_desc / waa_edge_desc / waa_graph_desc: same fields in the same order with the same types (arrays included)"""
+    ffi, header = _ffi(), _header()
+    for struct in ("waa_node_desc", "waa_edge_desc", "waa_graph_desc"):
+        mc = re.search(r"typedef struct\s*\{([^{}]*)\}\s*%s\s*;" % struct, header, flags=re.S)
+        mr = re.search(r"#\[repr\(C\)\][^{]*pub struct %s\s*\{(.*?)\}" % struct, ffi, flags=re.S)
+        assert mc and mr, struct
+        c_fields = []
+        for f in (x.strip() for x in mc.group(1).split(";")):
+            if not f:
+                continue
+            arr = re.search(r"\[(\d+)\]$", f)
+            f = re.sub(r"\[\d+\]$", "", f)
+            name = re.findall(r"[A-Za-z_]\w*", f)[-1]
+            c_fields.append((name, _c_type(f), int(arr.group(1)) if arr else None))
+        r_fields = []
+        for f in (x.strip() for x in mr.group(1).split(",")):
+            if not f:
+                continue
+            name, t = f.replace("pub ", "").split(":", 1)
+            arr = re.match(r"\s*\[(\w+);\s*(\d+)\]", t)
+            if arr:
+                r_fields.append((name.strip(), _rust_type(arr.group(1)), int(arr.group(2))))
+            else:
+                r_fields.append((name.strip(), _rust_type(t), None))
+        # (`from` is a keyword in neither language; the header and the Rust side use the same names)
+        assert c_fields == r_fields, (struct, c_fields, r_fields)
+
+
+def test_rust_constants_match_the_header():
+    ffi, header = _ffi(), open(os.path.join(ROOT, "include", "waa_hip.h")).read()
+    consts = dict(re.findall(r"pub const (WAA_\w+): [ui]\d+ = ([^;]+);", ffi))
+    assert len(consts) >= 20
+    enums = {}
+    for body in re.findall(r"enum\s*\{(.*?)\}", header, flags=re.S):
+        for k, v in re.findall(r"(WAA_\w+)\s*=\s*(-?\w+)", body):
+            enums[k] = int(v, 0)
+    for k, v in re.findall(r"#define (WAA_\w+) \(?(-?(?:0x)?[0-9A-Fa-f]+)u?\)?\s", header):
+        enums.setdefault(k, int(v, 0))
+    for k, v in consts.items():
+        rust_v = int(v.replace("_", ""), 0)
+        assert k in enums, f"{k} is not a constant of include/waa_hip.h"
+        assert enums[k] & 0xFFFFFFFFFFFFFFFF == rust_v & 0xFFFFFFFFFFFFFFFF, (k, v, enums[k])
+
+
+def test_every_library_call_of_the_shim_is_declared():
+    """every ffi::waa_* (function) and ffi::WAA_* (constant) that mod.rs uses exists in ffi.rs"""
+    ffi = _ffi()
+    mod = open(os.path.join(ROOT, "shim", "src", "gpu", "mod.rs")).read()
+    fns = set(re.findall(r"pub fn (\w+)", ffi))
+    consts = set(re.findall(r"pub const(?: fn)? (\w+)", ffi))
+    types = set(re.findall(r"pub struct (\w+)", ffi))
+    used = set(re.findall(r"ffi::(\w+)", mod)) - {"waa_", "WAA_"}  # (prose of the module header)
+    assert len(used) >= 30
+    missing = sorted(u for u in used if u not in fns | consts | types)
+    assert not missing, f"mod.rs uses ffi::{missing} which shim/src/gpu/ffi.rs does not declare"
+    # the custom PeriodicWave path of round 5
+    assert "waa_oscillator_set_wavetable" in used and "waa_oscillator_set_wavetable" in fns
+
+
+def test_module_header_is_not_stale():
+    mod = open(os.path.join(ROOT, "shim", "src", "gpu", "mod.rs")).read()
+    head = mod[:mod.index("mod ffi;")]
+    assert "UNCOMPILED SKETCH" in head
+    assert "not forwarded by this first version" not in head
+    for kind in ("Panner", "Delay", "Oscillator"):
+        assert f"GpuNode::{kind}" in mod and kind in head

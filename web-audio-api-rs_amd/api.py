@@ -129,6 +129,7 @@ ABI = {
     "convolver_set_buffer": (C.c_int32, [_VP, C.c_uint32, _FPP, C.c_uint32, C.c_uint64, C.c_float]),
     "waveshaper_set_curve": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32]),
     "oscillator_set_periodic_wave": (C.c_int32, [_VP, C.c_uint32, _FP, _FP, C.c_uint32, C.c_int32]),
+    "oscillator_set_wavetable": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32]),
     "iir_set_coefficients": (C.c_int32, [_VP, C.c_uint32, _DP, C.c_uint32, _DP, C.c_uint32]),
     "iir_frequency_response": (C.c_int32, [_DP, C.c_uint32, _DP, C.c_uint32, C.c_float, _FP, _FP, _FP, C.c_uint32]),
     "param_schedule_event": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_float, C.c_double, C.c_double,
@@ -530,6 +531,18 @@ class PeriodicWave:
         self.real = r if r is not None else np.zeros(n, np.float32)
         self.imag = i if i is not None else np.zeros(n, np.float32)
         self.disable_normalization = bool(disable_normalization)
+        self.table = None
+
+    @classmethod
+    def from_wavetable(cls, table):
+        """A PeriodicWave that already IS its 8192-point table — what the reference's render side holds (periodic_wave.rs:72-74,
+        oscillator.rs:487-493) and what the Rust shim forwards (waa_oscillator_set_wavetable)."""
+        t = _f32(table).reshape(-1)
+        if t.size != 8192:
+            raise WaaError(1, f"IndexSizeError - a PeriodicWave table has 8192 points (got {t.size})")
+        w = cls()
+        w.table = t
+        return w
 
 
 class OscillatorNode(_ScheduledSource):
@@ -568,8 +581,11 @@ class OscillatorNode(_ScheduledSource):
         if self.periodic_wave is not None:
             w = self.periodic_wave
             b, h = ctx._b, ctx._handle
-            b.check(b.oscillator_set_periodic_wave(h, self.id, _fp(w.real), _fp(w.imag), w.real.size,
-                                                   int(w.disable_normalization)))
+            if w.table is not None:
+                b.check(b.oscillator_set_wavetable(h, self.id, _fp(w.table), w.table.size))
+            else:
+                b.check(b.oscillator_set_periodic_wave(h, self.id, _fp(w.real), _fp(w.imag), w.real.size,
+                                                       int(w.disable_normalization)))
 
 
 class BiquadFilterNode(AudioNode):

@@ -597,6 +597,16 @@ waa_status waa_oscillator_set_periodic_wave(waa_batch* b, uint32_t node, const f
   return WAA_OK;
 }
 
+// the finished table (oscillator.rs:487-493: what the render side receives)
+waa_status waa_oscillator_set_wavetable(waa_batch* b, uint32_t node, const float* table, uint32_t n) {
+  int e;
+  if ((e = check_node(b, node, WAA_NODE_OSCILLATOR)) || (e = check_unplanned(b))) return e;
+  if (!table || n != WAA_PERIODIC_WAVE_TABLE_LENGTH)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - a PeriodicWave table has %d points (got %u)", WAA_PERIODIC_WAVE_TABLE_LENGTH, n);
+  b->nodes[node].osc_wave.assign(table, table + n);
+  return WAA_OK;
+}
+
 // iir_filter.rs:17-46 (validation) and :273-311 (pad to equal length, normalise by a0)
 static int check_iir_coefs(const double* ff, uint32_t nff, const double* fb, uint32_t nfb) {
   if (!ff || nff == 0 || nff > WAA_MAX_IIR_COEFFS)
