@@ -84,7 +84,7 @@ def c5(binding, noise, sr=48000.0, length=None, buf_sr=None, rate=1.5, loop=True
     return ctx, dict(src=src, shaper=sh)
 
 
-def t1(binding, noise, ir, sr=48000.0, length=None, with_biquad=True, device=-1):
+def t1(binding, noise, ir, sr=48000.0, length=None, with_biquad=True, device=-1, biquad_handle=False):
     """T1 / C3: src -> [Biquad] -> Convolver(IR, normalize) -> destination."""
     n_inst, n_ch, frames = noise.shape
     ctx = waa.OfflineAudioContext(2, length or frames, sr, n_instances=n_inst, binding=binding, device=device)
@@ -92,11 +92,13 @@ def t1(binding, noise, ir, sr=48000.0, length=None, with_biquad=True, device=-1)
     src.set_buffer_batch(noise, sr)
     conv = ctx.create_convolver(buffer=waa.AudioBuffer(ir, sr))
     node = src
+    nodes = dict(src=src, conv=conv)
     if with_biquad:
-        node = src.connect(ctx.create_biquad_filter(type_="lowpass", frequency=200.0, q=1.0))
+        nodes["biquad"] = ctx.create_biquad_filter(type_="lowpass", frequency=200.0, q=1.0)
+        node = src.connect(nodes["biquad"])
     node.connect(conv).connect(ctx.destination())
     src.start()
-    return ctx, dict(src=src, conv=conv)
+    return ctx, nodes
 
 
 def c4(binding, noise, ir, sr=48000.0, length=None, device=-1):

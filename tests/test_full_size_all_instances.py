@@ -98,11 +98,33 @@ def test_t1_every_instance_real_ir(hip, orc):
     noise = _noise(n_inst, 2, FRAMES, 34)
     ctx, _ = t1(hip, noise, garage_ir(hip))
     plan = ctx.plan_describe()
-    assert "P=22 blocks=59 pairs=512" in plan and "the Biquad in front, in the forward transform" in plan
+    assert "P=22 blocks=59 pairs=512" in plan and "the Biquad in front, in the impulse response" in plan
     out = ctx.start_rendering_sync().data
     ctx.close()
     ir = garage_ir(orc)
     _compare_all(orc, out, lambda be, lo, hi: t1(be, noise[lo:hi], ir), chunk=128, max_abs=2e-6)
+
+
+def test_t1_every_instance_with_its_own_filter(hip, orc):
+    """T1 with a cutoff per context (40 Hz .. 12 kHz): per-context coefficients cannot live in the shared impulse response, the
+    Biquad stays the exact-order filter stage of the forward transform (conv_fft3_fwd_bq_kernel, round 3's form) — every one of
+    the 1024 contexts against the oracle."""
+    n_inst = 1024
+    noise = _noise(n_inst, 2, FRAMES, 36)
+    f = np.geomspace(40.0, 12000.0, n_inst).astype(np.float32)
+
+    def build(be, lo, hi):
+        ctx, nodes = t1(be, noise[lo:hi], garage_ir(be))
+        for i in range(lo, hi):
+            nodes["biquad"].frequency.set_value(float(f[i]), instance=i - lo)
+        return ctx, nodes
+
+    ctx, _ = build(hip, 0, n_inst)
+    plan = ctx.plan_describe()
+    assert "P=22 blocks=59 pairs=512" in plan and "the Biquad in front, in the forward transform" in plan
+    out = ctx.start_rendering_sync().data
+    ctx.close()
+    _compare_all(orc, out, build, chunk=128, max_abs=2e-6)
 
 
 def test_c4_every_instance_real_ir_and_every_analyser_pull(hip, orc):

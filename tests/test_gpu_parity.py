@@ -623,6 +623,7 @@ def test_biquad_folded_into_the_forward_transform(hip, orc, monkeypatch, case):
     the two-launch plan (WAA_NO_CONV_BIQUAD_FOLD=1): odd instance count (half-empty last pair), mono input, a buffer longer
     than the render, a Biquad fed by a materialised signal, one instance.  (A buffer that ENDS mid-render changes the
     reference's channel counts — the graph then takes the exact per-quantum path, which never folds.)"""
+    monkeypatch.setenv("WAA_NO_CONV_BIQUAD_IR_FOLD", "1")  # (one context = "the same coefficients on every context": round 5's fold)
     ir = garage_ir(hip)
     length = 8192 * 4 + 1024  # (a source is read in place when its buffer is a whole number of render quanta)
     n_inst, n_ch, buf = {"stereo-odd": (5, 2, length), "mono": (4, 1, length), "long-buffer": (3, 2, length + 128 * 40),
@@ -646,6 +647,62 @@ def test_biquad_folded_into_the_forward_transform(hip, orc, monkeypatch, case):
     # same filter arithmetic in the same order; the transforms differ in rounding (pass 1 of the folded kernel multiplies
     # half of its twiddles together, ~1 ulp): a few f32 ulps of the peak
     assert np.abs(got - two).max() <= 1e-6 * max(1.0, float(np.abs(two).max()))
+
+
+@pytest.mark.measure
+@pytest.mark.parametrize("case", ["lowpass-odd", "mono-highpass", "peaking-long-buffer", "notch-via-gain", "allpass-one", "lowshelf-true-stereo"])
+def test_biquad_folded_into_the_impulse_response(hip, orc, monkeypatch, case):
+    """source -> Biquad(the same constant coefficients on every context) -> Convolver(long IR): Biquad and Convolver are LTI,
+    the filter's transfer function is folded into the impulse response at plan time (conv_fold_biquad_into_ir) and the render
+    is the plain forward transform.  Against the oracle's sample-by-sample cascade (f64 Biquad, then the restated
+    fft-convolver) at the north star's 1e-6 RMS per channel, and against the exact-order filter stage of round 3
+    (WAA_NO_CONV_BIQUAD_IR_FOLD=1): every filter type whose ringing dies inside the extension, odd instance count, mono input,
+    a buffer longer than the render, a Biquad fed by a materialised signal, a 4-channel (true stereo) response."""
+    length = 8192 * 4 + 1024
+    type_, freq, q, gain, n_inst, n_ch, buf, via_gain = {
+        "lowpass-odd": ("lowpass", 200.0, 1.0, 0.0, 5, 2, length, False),
+        "mono-highpass": ("highpass", 900.0, 1.3, 0.0, 4, 1, length, False),
+        "peaking-long-buffer": ("peaking", 1500.0, 2.0, 9.0, 3, 2, length + 128 * 40, False),
+        "notch-via-gain": ("notch", 3000.0, 4.0, 0.0, 3, 2, length, True),
+        "allpass-one": ("allpass", 700.0, 0.8, 0.0, 1, 2, length, False),
+        "lowshelf-true-stereo": ("lowshelf", 400.0, 1.0, -6.0, 2, 2, length, False)}[case]
+    noise = white_noise(n_inst, n_ch, buf)
+
+    def build(be):
+        ir = garage_ir(be)
+        if case == "lowshelf-true-stereo":  # four response channels (convolver.rs:419-485)
+            ir = np.ascontiguousarray(np.concatenate([ir, ir[::-1] * np.float32(0.5)]))
+        ctx = waa.OfflineAudioContext(2, length, 48000.0, n_instances=n_inst, binding=be)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(noise, 48000.0)
+        node = src
+        if via_gain:
+            node = src.connect(ctx.create_gain(gain=0.7))
+            node.connect(ctx.create_gain(gain=0.1)).connect(ctx.destination())
+        bq = ctx.create_biquad_filter(type_=type_, frequency=freq, q=q, gain=gain)
+        node.connect(bq).connect(ctx.create_convolver(buffer=waa.AudioBuffer(ir, 48000.0))).connect(ctx.destination())
+        src.start()
+        return ctx
+
+    ctx = build(hip)
+    plan = ctx.plan_describe()
+    assert "folded into the impulse response" in plan and "in the impulse response)" in plan and "biquad_stream" not in plan
+    assert "forward transform's input stage" not in plan
+    got = ctx.start_rendering_sync().data
+    ctx.close()
+    octx = build(orc)
+    ref = octx.start_rendering_sync().data
+    octx.close()
+    assert np.isfinite(got).all() and np.abs(ref).max() > 1e-3
+    err = rms_err(got, ref)
+    print(f"{case}: response fold vs the oracle's cascade: worst per-channel RMS {err.max():.3e} (signal RMS {np.sqrt(np.mean(ref.astype(np.float64) ** 2)):.3e})")
+    assert err.max() <= TOL
+    monkeypatch.setenv("WAA_NO_CONV_BIQUAD_IR_FOLD", "1")
+    ctx = build(hip)
+    assert "forward transform's input stage" in ctx.plan_describe()
+    kern = ctx.start_rendering_sync().data
+    ctx.close()
+    assert rms_err(got, kern).max() <= TOL and rms_err(kern, ref).max() <= TOL
 
 
 @pytest.mark.parametrize("with_biquad", [False, True])
@@ -686,7 +743,7 @@ def test_t1_north_star_size_real_ir_sampled(hip, orc):
     pick = [0, 1, 511, 512, 1022, 1023]
     ctx, _ = t1(hip, noise, garage_ir(hip))
     plan = ctx.plan_describe()
-    assert "P=22 blocks=59 pairs=512" in plan and "the Biquad in front, in the forward transform" in plan
+    assert "P=22 blocks=59 pairs=512" in plan and "the Biquad in front, in the impulse response" in plan
     out = ctx.render_instances(pick)
     ctx.close()
     octx, _ = t1(orc, noise[pick], garage_ir(orc))

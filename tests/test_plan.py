@@ -38,13 +38,22 @@ def test_t1_and_c4_plans(hip):
     noise, ir = white_noise(5, 2, 480000), garage_like_ir()
     ctx, _ = t1(hip, noise, ir, device=waa.PLAN_ONLY)
     lines = plan(ctx)
-    # the Biquad in front of the long convolver is rendered by the forward transform's input stage: no launch, no signal
+    # the Biquad in front of the long convolver has the same constant coefficients on every context: Biquad and Convolver are
+    # LTI, the filter's transfer function is folded into the impulse response (round 5) — no launch, no signal, no per-sample work.
+    # (garage_like_ir ends on a noise floor of 1e-3: the filter's ringing behind it needs a 23rd partition; the real response does not)
     assert not any(l.startswith("biquad_stream") for l in lines)
+    assert any("folded into the impulse response (178899 -> " in l and "(its source is read in place)" in l for l in lines)
+    conv = [l for l in lines if l.startswith("convolver")]
+    assert len(conv) == 1 and "fft B=8192 N=16384 P=23 blocks=59 pairs=3 cin=2 cout=2 terms=2" in conv[0]
+    assert "the Biquad in front, in the impulse response" in conv[0]
+    assert lines[-1].startswith("alias node 0")  # the destination aliases the convolver output: no copy
+    # per-context coefficients: per-context responses would be needed — the filter stays a stage of the forward transform
+    ctx, nodes = t1(hip, noise, ir, device=waa.PLAN_ONLY, biquad_handle=True)
+    nodes["biquad"].frequency.set_value(300.0, instance=2)
+    lines = plan(ctx)
     assert any("filtered by the forward transform's input stage (its source is read in place)" in l for l in lines)
     conv = [l for l in lines if l.startswith("convolver")]
-    assert len(conv) == 1 and "fft B=8192 N=16384 P=22 blocks=59 pairs=3 cin=2 cout=2 terms=2" in conv[0]
-    assert "the Biquad in front, in the forward transform" in conv[0]
-    assert lines[-1].startswith("alias node 0")  # the destination aliases the convolver output: no copy
+    assert "P=22 blocks=59" in conv[0] and "the Biquad in front, in the forward transform" in conv[0]
     ctx, _ = c4(hip, noise, ir, device=waa.PLAN_ONLY)
     lines = plan(ctx)
     assert "chain parallel C=2 in=[signal:2ch]->2ch ops=[STEREO_PAN] out=2ch" in lines
@@ -58,7 +67,34 @@ def test_t1_unfolded_plan_switch(hip, monkeypatch):
     ctx, _ = t1(hip, white_noise(5, 2, 480000), garage_like_ir(), device=waa.PLAN_ONLY)
     lines = plan(ctx)
     assert "biquad_stream in=source:2ch gains=0 out=final" in lines
-    assert not any("in the forward transform" in l for l in lines)
+    assert not any("in the forward transform" in l or "in the impulse response" in l for l in lines)
+
+
+@pytest.mark.measure
+def test_t1_kernel_fold_switch(hip, monkeypatch):
+    """WAA_NO_CONV_BIQUAD_IR_FOLD=1: the filter in front stays the exact-order stage of the forward transform (round 3's form;
+    the A/B partner of the impulse-response fold and the form long-memory / per-context filters take)."""
+    monkeypatch.setenv("WAA_NO_CONV_BIQUAD_IR_FOLD", "1")
+    ctx, _ = t1(hip, white_noise(5, 2, 480000), garage_like_ir(), device=waa.PLAN_ONLY)
+    lines = plan(ctx)
+    assert any("filtered by the forward transform's input stage" in l for l in lines)
+    assert any("P=22 blocks=59" in l and "in the forward transform" in l for l in lines)
+
+
+@pytest.mark.parametrize("freq,q,folded", [(200.0, 1.0, True), (2000.0, 0.7, True), (30.0, 30.0, False), (20.0, 40.0, False)])
+def test_impulse_response_fold_needs_a_short_filter_memory(hip, freq, q, folded):
+    """a resonant low filter rings for tens of thousands of frames: its ringing does not die inside the two-block extension,
+    the response fold is not taken (bandpass Q = 30 at 30 Hz: pole radius 0.99993)"""
+    noise, ir = white_noise(2, 2, 480000), garage_like_ir()
+    ctx = waa.OfflineAudioContext(2, 480000, 48000.0, n_instances=2, binding=hip, device=waa.PLAN_ONLY)
+    src = ctx.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    bq = ctx.create_biquad_filter(type_="bandpass", frequency=freq, q=q)
+    src.connect(bq).connect(ctx.create_convolver(buffer=waa.AudioBuffer(ir, 48000.0))).connect(ctx.destination())
+    src.start()
+    lines = plan(ctx)
+    assert any("folded into the impulse response" in l for l in lines) == folded
+    assert any("filtered by the forward transform's input stage" in l for l in lines) == (not folded)
 
 
 def test_one_shared_audio_buffer_is_read_in_place(hip):

@@ -7,6 +7,8 @@
 #   pmc:<w>    rocprofv3 stats / FETCH_SIZE / WRITE_SIZE passes of bench workload <w>
 #   line:<w>   one bench line of workload <w>
 #   fuzz:<n>   tools/fuzz_campaign.py over n seeds per generator
+#   box        copy floor of this box (tools/stream_probe) + rocm-smi clocks: C2 ran 1.35 ... 1.60 ms depending on the box
+#   plantrace:<w>  WAA_PLAN_TRACE of workload <w> (measurement build): where build_plan's host time goes
 set -u
 TAG=$1; shift
 mkdir -p gpurun_out
@@ -22,6 +24,10 @@ for S in "$@"; do
     pmc:*)  W=${S#pmc:}; timeout 600 bash tools/pmc_pass.sh $W ${TAG}_$W > /dev/null 2>&1; head -12 gpurun_out/${TAG}_${W}_stats.txt ;;
     line:*) W=${S#line:}; timeout 300 python bench.py --workload $W --steps 5 --warmup 2 --sustain 0 --no-cpu-baseline --no-extra > gpurun_out/${TAG}_bench_$W.json 2> gpurun_out/${TAG}_bench_$W.err; cat gpurun_out/${TAG}_bench_$W.json | cut -c1-1500 ;;
     fuzz:*) N=${S#fuzz:}; timeout 1500 python tools/fuzz_campaign.py --first 100000 --count $N --jobs 8 --out gpurun_out/${TAG}_fuzz.json 2> gpurun_out/${TAG}_fuzz.err | cut -c1-3000; tail -3 gpurun_out/${TAG}_fuzz.err ;;
+    box)    # which kind of box is this?  the copy floor of the C2 access pattern (tools/stream_probe, built in-tree) + clocks
+            { echo "# $(date -u) $(hostname)"; rocm-smi --showclocks --showpower --showmemuse 2>/dev/null | grep -v "^=\|^$" | head -30;
+              timeout 120 tools/stream_probe 2>&1 | head -20; } > gpurun_out/${TAG}_box.txt 2>&1; grep -E "linear 256x65536|stream tile 2048 |sclk|mclk|fclk" gpurun_out/${TAG}_box.txt | head -8 ;;
+    plantrace:*) W=${S#plantrace:}; WAA_USE_MEASURE_LIB=1 WAA_PLAN_TRACE=1 timeout 300 python bench.py --workload $W --steps 2 --warmup 1 --sustain 0 --no-cpu-baseline --no-extra 2> gpurun_out/${TAG}_plantrace_$W.txt | cut -c1-400; grep "\[plan\]" gpurun_out/${TAG}_plantrace_$W.txt | head -20 ;;
     *) echo "unknown section $S" ;;
   esac
 done

@@ -4,6 +4,8 @@
 #include <array>
 #include <mutex>
 
+#include <thread>
+
 #include "waa_host.hpp"
 #include "waa_osfft_tables.hpp"
 
@@ -101,13 +103,19 @@ int source_code_rows(waa_batch* b, uint32_t id, uint64_t cs, std::vector<uint8_t
 
 // codes of the node's mixed input and the prev table; `src_id` >= 0: static plan, the input is that source
 static int plan_link(waa_batch* b, uint32_t id, int kind, int src_id, uint32_t tail_frames, int can_propagate, const uint8_t** in_code,
-                     int32_t** prev_out) {
+                     int32_t** prev_out, uint64_t* prev_stride_out) {
+  PlanTrace trace("plan_link");
+  *prev_stride_out = b->n_quanta;
   Node& n = b->nodes[id];
   const uint64_t cs = b->code_stride ? b->code_stride : (((uint64_t)b->n_quanta + 15) & ~(uint64_t)15);
   const uint8_t* d_in = n.in_code;
   std::vector<uint8_t> host_codes;
   if (src_id >= 0) {
-    int e = source_code_rows(b, (uint32_t)src_id, cs, &host_codes);
+    int e;
+    {
+      PlanTrace t2("plan_link: source_code_rows");
+      e = source_code_rows(b, (uint32_t)src_id, cs, &host_codes);
+    }
     if (e) return e;
     // the node's MIXED input: a silent (mono) quantum of the source is mixed to the node's computed count like any other
     // (quantum.rs:532-569) — with channelCountMode explicit that is the node's channelCount, and the quantum stays silent
@@ -123,8 +131,15 @@ static int plan_link(waa_batch* b, uint32_t id, int kind, int src_id, uint32_t t
   if (src_id >= 0 && !b->dynamic && !measure_switch("WAA_LINK_KERNEL")) {
     // static plan: the codes are host-known, so is the replay (the automaton of link_kernel, once per plan instead of
     // one single-thread-per-instance launch per render: 0.7 ms of a 10-15 ms render)
-    std::vector<int32_t> hp((size_t)b->n_inst * b->n_quanta);
-    for (uint32_t i = 0; i < b->n_inst; i++) {
+    // every context with the same codes (the usual batch: one schedule): ONE row of links, instance stride 0 — the table of a
+    // 1024-context, 10 s batch was 15 MB built, copied and uploaded per plan (most of the 15 ms an HRTF plan took, round 5)
+    bool one_row = true;
+    for (uint32_t i = 1; i < b->n_inst && one_row; i++)
+      one_row = std::memcmp(host_codes.data() + (size_t)i * cs, host_codes.data(), b->n_quanta) == 0;
+    const uint32_t rows = one_row ? 1u : b->n_inst;
+    if (one_row) *prev_stride_out = 0;
+    std::vector<int32_t> hp((size_t)rows * b->n_quanta);
+    for (uint32_t i = 0; i < rows; i++) {
       const uint8_t* row = host_codes.data() + (size_t)i * cs;
       if (i > 0 && std::memcmp(row, row - cs, b->n_quanta) == 0) {  // the same codes as the previous instance: the same links
         std::copy(hp.begin() + (size_t)(i - 1) * b->n_quanta, hp.begin() + (size_t)i * b->n_quanta, hp.begin() + (size_t)i * b->n_quanta);
@@ -217,7 +232,8 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
   const int can_propagate = (cn == 0 || std::fabs(mid) < 1e-9f) ? 1 : 0;  // waveshaper.rs:498-509
   const uint8_t* in_code = nullptr;
   int32_t* prev = nullptr;
-  int e = plan_link(b, id, 0, src_id, 0, can_propagate, &in_code, &prev);
+  uint64_t prev_stride = 0;
+  int e = plan_link(b, id, 0, src_id, 0, can_propagate, &in_code, &prev, &prev_stride);
   if (e) return e;
   if (!n.d_curve && (e = dev_upload(b, &n.d_curve, n.curve))) return e;
   const int up_len = RQ * R;
@@ -243,7 +259,7 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
       f.dst_inst = n.sig.inst_stride;
       f.dst_ch = n.sig.ch_stride;
       f.prev = prev;
-      f.prev_stride = b->n_quanta;
+      f.prev_stride = prev_stride;
       f.curve = n.d_curve;
       f.curve_n = (int32_t)cn;
       f.R = R;
@@ -296,7 +312,7 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
   g.dst_inst = g.dst_ch * nch;
   g.dst_q = up_len;
   g.prev = prev;
-  g.prev_stride = b->n_quanta;
+  g.prev_stride = prev_stride;
   g.curve = n.d_curve;
   g.curve_n = (int32_t)cn;
   g.nch = nch;
@@ -323,7 +339,7 @@ int plan_oversampler(waa_batch* b, uint32_t id, int src_id) {
   h.dst_ch = n.sig.ch_stride;
   h.dst_q = RQ;
   h.prev = prev;
-  h.prev_stride = b->n_quanta;
+  h.prev_stride = prev_stride;
   h.nch = nch;
   h.n_inst = b->n_inst;
   h.n_quanta = b->n_quanta;
@@ -374,20 +390,33 @@ struct HrirResampler {
     m0.resize((size_t)n_out);
     m1.resize((size_t)n_out);
     w.assign((size_t)n_out * 257, 0.);
-    for (int n = 0; n < n_out; n++) {
-      const double t = (double)(n + 1) / ratio - 128.;
-      m0[(size_t)n] = std::max((int)std::ceil(t - 128.), 0);
-      m1[(size_t)n] = std::min((int)std::floor(t + 128.), len - 1);
-      for (int m = m0[(size_t)n]; m <= m1[(size_t)n]; m++) w[(size_t)n * 257 + (size_t)(m - m0[(size_t)n])] = resample_kernel_value(t - (double)m, fc);
-    }
+    // (140 000 kernel values, four trigonometric calls each: 8 ms on one core — rows are independent)
+    const int nt = std::max(1, std::min(8, std::min((int)std::thread::hardware_concurrency(), n_out / 16)));
+    auto rows = [&](int t0) {
+      for (int n = t0; n < n_out; n += nt) {
+        const double t = (double)(n + 1) / ratio - 128.;
+        m0[(size_t)n] = std::max((int)std::ceil(t - 128.), 0);
+        m1[(size_t)n] = std::min((int)std::floor(t + 128.), len - 1);
+        for (int m = m0[(size_t)n]; m <= m1[(size_t)n]; m++) w[(size_t)n * 257 + (size_t)(m - m0[(size_t)n])] = resample_kernel_value(t - (double)m, fc);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(rows, t);
+    rows(0);
+    for (auto& th : pool) th.join();
   }
-  void run(const float* in, std::vector<float>* out) const {
+  void run_into(const float* in, float* out) const {
     for (int n = 0; n < n_out; n++) {
       double acc = 0.;
       const double* wn = &w[(size_t)n * 257];
       for (int m = m0[(size_t)n]; m <= m1[(size_t)n]; m++) acc += (double)in[m] * wn[m - m0[(size_t)n]];
-      out->push_back((float)acc);
+      out[n] = (float)acc;
     }
+  }
+  void run(const float* in, std::vector<float>* out) const {
+    const size_t at = out->size();
+    out->resize(at + (size_t)n_out);
+    run_into(in, out->data() + at);
   }
 };
 static std::shared_ptr<Sphere> sphere_for_rate(uint32_t sample_rate) {
@@ -404,11 +433,26 @@ static std::shared_ptr<Sphere> sphere_for_rate(uint32_t sample_rate) {
   s->pos = f.pos;
   const double ratio = (double)sample_rate / (double)f.sr;
   const HrirResampler rs(f.taps, ratio);
-  for (int v = 0; v < f.nv(); v++) {
-    rs.run(f.left.data() + (size_t)v * f.taps, &s->left);
-    rs.run(f.right.data() + (size_t)v * f.taps, &s->right);
+  // 2 x 187 impulse responses x ~550 outputs x 257 taps: 20 ms on one core, and the first plan of a process at a rate other
+  // than the file's pays it — the responses are independent, a few threads share them (each output value is computed by
+  // exactly the same sequence of operations as before)
+  const int nv = f.nv();
+  s->left.assign((size_t)nv * rs.n_out, 0.f);
+  s->right.assign((size_t)nv * rs.n_out, 0.f);
+  {
+    const int nt = std::max(1, std::min(8, std::min((int)std::thread::hardware_concurrency(), nv / 8)));
+    std::vector<std::thread> pool;
+    auto work = [&](int t) {
+      for (int v = t; v < nv; v += nt) {
+        rs.run_into(f.left.data() + (size_t)v * f.taps, s->left.data() + (size_t)v * rs.n_out);
+        rs.run_into(f.right.data() + (size_t)v * f.taps, s->right.data() + (size_t)v * rs.n_out);
+      }
+    };
+    for (int t = 1; t < nt; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
   }
-  s->taps = f.nv() ? (int)(s->left.size() / (size_t)f.nv()) : 0;
+  s->taps = nv ? rs.n_out : 0;
   g_sphere_cache[sample_rate] = s;
   return s;
 }
@@ -450,6 +494,7 @@ static void sphere_locate(const Sphere& s, const float dir[3], int vtx[3], float
 }
 
 int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
+  PlanTrace trace("plan_hrtf");
   Node& n = b->nodes[id];
   std::shared_ptr<Sphere> sp = sphere_for_rate((uint32_t)b->sr);
   if (!sp) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - HRTF panning needs the HRIR sphere (waa_hrtf_load_sphere)");
@@ -466,9 +511,11 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
   }
   const uint8_t* in_code = nullptr;
   int32_t* prev = nullptr;
-  int e = plan_link(b, id, 1, src_id, (uint32_t)sp->taps, 0, &in_code, &prev);
+  uint64_t prev_stride = 0;
+  int e = plan_link(b, id, 1, src_id, (uint32_t)sp->taps, 0, &in_code, &prev, &prev_stride);
   if (e) return e;
   // geometry per (instance, quantum) on the host, always k-rate: the first value of every param (panner.rs:781-799)
+  PlanTrace t3("plan_hrtf: geometry + tables");
   bool shared = true, varies = false;
   for (int k = 0; k < 15; k++) {
     const ParamStore& ps = n.params[k];
@@ -548,7 +595,7 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
   d.in_code = in_code;
   d.code_stride = b->code_stride ? b->code_stride : (((uint64_t)b->n_quanta + 15) & ~(uint64_t)15);
   d.prev = prev;
-  d.prev_stride = b->n_quanta;
+  d.prev_stride = prev_stride;
   d.hrir = d_hr;
   d.hstatic = d_hstatic;
   d.table = d_table;

@@ -141,6 +141,9 @@ struct Node {
   uint64_t ir_len = 0;
   int ir_nch = 0;
   bool has_ir = false;
+  // the impulse response with the transfer function of the Biquad in front folded in (conv_fold_biquad_into_ir); empty = not folded
+  std::vector<std::vector<float>> ir_lti;
+  uint64_t ir_lti_len = 0;
   // waveshaper
   std::vector<float> curve;
   bool has_curve = false;
@@ -321,6 +324,17 @@ struct waa_batch {
 
 namespace waa {
 namespace host {
+
+// WAA_PLAN_TRACE=1 (measurement build only): how long the named sections of build_plan took, on stderr
+struct PlanTrace {
+  const char* what;
+  std::chrono::steady_clock::time_point t0;
+  bool on;
+  explicit PlanTrace(const char* w) : what(w), t0(std::chrono::steady_clock::now()), on(measure_switch("WAA_PLAN_TRACE") != nullptr) {}
+  ~PlanTrace() {
+    if (on) fprintf(stderr, "[plan] %-40s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
 
 // Device arena (waa_device_arena_reserve, include/waa_hip.h): one slab per device, reserved once — typically at process start,
 // before anything else fragments the device's memory — from which the big buffers of every batch are carved in 2 MB-aligned

@@ -1541,8 +1541,13 @@ int build_plan(waa_batch* b) {
       q.fold_conv = (int)cid;
       q.materialized = false;
       c.pre_biquad = (int)qid;
-      plan_note(b, "biquad node %u has constant coefficients and only feeds convolver node %u: filtered by the forward transform's input stage%s",
-                qid, cid, sn.is_view ? " (its source is read in place)" : "");
+      if (conv_fold_biquad_into_ir(b, c, q))
+        plan_note(b, "biquad node %u has the same constant coefficients on every context and only feeds convolver node %u: both are LTI, its "
+                     "transfer function is folded into the impulse response (%llu -> %llu taps)%s",
+                  qid, cid, (unsigned long long)c.ir_len, (unsigned long long)c.ir_lti_len, sn.is_view ? " (its source is read in place)" : "");
+      else
+        plan_note(b, "biquad node %u has constant coefficients and only feeds convolver node %u: filtered by the forward transform's input stage%s",
+                  qid, cid, sn.is_view ? " (its source is read in place)" : "");
     }
   auto alloc_signal = [&](Node& n) -> int {
     float* p = nullptr;

@@ -25,6 +25,87 @@ int conv_block_size(const waa_batch* b, const Node& n) {
   return 8192;
 }
 
+// The Biquad in front as part of the impulse response.  Both nodes are linear and time-invariant when the filter's four
+// AudioParams are constants, and every context of the batch convolves with the same response — so if they also share the
+// filter's coefficients, the cascade  source -> Biquad -> Convolver  IS one convolution with  h' = biquad(h):  the response the
+// reference hands to FFTConvolver::init (normalised, each channel's trailing |h| < 1e-6 samples dropped, convolver.rs:259-317)
+// run through the reference's own Direct Form I recurrence in f64 (biquad_filter.rs:877), followed by the filter's ringing.
+// The ringing is cut where what is left of it cannot matter: tail L1 norm <= 1e-12 of the response's L1 norm (an output error of
+// at most 1e-12 x the largest output the response can produce) — and the fold is only taken when that point lies inside the
+// simulated extension (two blocks) with the geometric remainder bounded the same way, i.e. never for a filter with a long
+// memory (poles within ~1e-3 of the unit circle): those keep conv_fft3_fwd_bq_kernel, the exact-order filter inside the
+// forward transform.  What changes numerically: the filter acts in the f32 frequency domain (like the convolver itself)
+// instead of as an f64 recurrence in front of it; the every-instance T1 / C4 tests hold the 1e-6 RMS bar against the oracle's
+// sample-by-sample cascade.  Not covered: non-finite source samples — the reference's Biquad turns a
+// NaN sample into a zero (biquad_filter.rs:881-883) before the convolver sees it, the folded form convolves it.
+bool conv_fold_biquad_into_ir(const waa_batch* b, Node& conv, const Node& q) {
+  conv.ir_lti.clear();
+  conv.ir_lti_len = 0;
+  if (measure_switch("WAA_NO_CONV_BIQUAD_IR_FOLD") || !conv.has_ir || q.params.size() < 4) return false;
+  float pv[4];
+  for (int k = 0; k < 4; k++) {
+    const ParamStore& ps = q.params[k];
+    if (ps.mode() != 0 || !ps.blocks.empty() || !ps.timelines.empty() || ps.dev_tl || ps.cst.empty()) return false;
+    for (uint32_t i = 1; i < b->n_inst; i++)
+      if (ps.cst[i] != ps.cst[0]) return false;  // (per-context coefficients: per-context responses — the kernel form keeps those)
+    pv[k] = ps.fix(ps.cst[0]);
+  }
+  const Coefs c = biquad_coefs(q.desc.i[0], (double)b->sr, (double)computed_freq(pv[WAA_PARAM_BIQUAD_FREQUENCY], pv[WAA_PARAM_BIQUAD_DETUNE]),
+                               (double)pv[WAA_PARAM_BIQUAD_GAIN], (double)pv[WAA_PARAM_BIQUAD_Q]);
+  for (double v : {c.b0, c.b1, c.b2, c.a1, c.a2})
+    if (!std::isfinite(v)) return false;
+  // spectral radius of z^2 + a1 z + a2
+  double rho;
+  {
+    const double disc = c.a1 * c.a1 - 4. * c.a2;
+    rho = disc < 0. ? std::sqrt(std::fabs(c.a2)) : std::max(std::fabs(-c.a1 + std::sqrt(disc)), std::fabs(-c.a1 - std::sqrt(disc))) * 0.5;
+  }
+  if (!(rho < 1.)) return false;
+  const int nch = conv.ir_nch;
+  uint64_t lmax = 0;
+  std::vector<uint64_t> trim(nch);
+  for (int ch = 0; ch < nch; ch++) {
+    uint64_t l = conv.ir_len;
+    while (l > 0 && std::fabs(conv.ir[ch][l - 1]) < 0.000001f) l--;
+    trim[ch] = l;
+    lmax = std::max(lmax, l);
+  }
+  if (lmax == 0) return false;
+  const uint64_t EXT = 2 * 8192, T = lmax + EXT;
+  std::vector<std::vector<double>> y(nch, std::vector<double>(T));
+  uint64_t len2 = 0;
+  for (int ch = 0; ch < nch; ch++) {
+    double x1 = 0., x2 = 0., y1 = 0., y2 = 0., l1 = 0.;
+    for (uint64_t i = 0; i < T; i++) {
+      const double x = i < trim[ch] ? (double)conv.ir[ch][i] : 0.;
+      const double v = (c.b0 * x + c.b1 * x1 + c.b2 * x2) - c.a1 * y1 - c.a2 * y2;  // biquad_filter.rs:877
+      x2 = x1;
+      x1 = x;
+      y2 = y1;
+      y1 = v;
+      y[ch][i] = v;
+      l1 += std::fabs(v);
+    }
+    if (!std::isfinite(l1)) return false;
+    if (l1 == 0.) continue;  // (a silent channel stays silent)
+    // what lies beyond the simulated extension: |state| / (1 - rho) bounds its L1 norm up to a small constant
+    if ((std::fabs(y1) + std::fabs(y2)) / (1. - rho) > 1e-13 * l1) return false;
+    double tail = 0.;
+    uint64_t n = T;
+    while (n > 0 && tail + std::fabs(y[ch][n - 1]) <= 1e-12 * l1) tail += std::fabs(y[ch][--n]);
+    if (n + 1024 > T) return false;  // not converged inside the extension
+    len2 = std::max(len2, n);
+  }
+  if (len2 == 0) return false;
+  // the block size must stay the one the three-pass transforms serve, and the partitions within the product kernel's range
+  if ((len2 + 2047) / 2048 <= 24 || (len2 + 8191) / 8192 > 24) return false;
+  conv.ir_lti.assign(nch, std::vector<float>(len2, 0.f));
+  for (int ch = 0; ch < nch; ch++)
+    for (uint64_t i = 0; i < len2; i++) conv.ir_lti[ch][i] = (float)y[ch][i];
+  conv.ir_lti_len = len2;
+  return true;
+}
+
 int plan_convolver(waa_batch* b, uint32_t id) {
   Node& n = b->nodes[id];
   SignalRef in_sig{};
@@ -45,11 +126,18 @@ int plan_convolver(waa_batch* b, uint32_t id) {
   // one FFTConvolver per IR channel, at least two (convolver.rs:291-306); each trims its own trailing
   // |h| < 1e-6 samples (fft-convolver init) — only the longest trimmed length matters here
   const int ir_nch = n.ir_nch;
+  const bool lti = n.pre_biquad >= 0 && n.ir_lti_len > 0;  // the Biquad in front lives in the impulse response
+  const std::vector<std::vector<float>>& ir_use = lti ? n.ir_lti : n.ir;
+  const uint64_t ir_use_len = lti ? n.ir_lti_len : n.ir_len;
   uint64_t len = 0;
-  for (int c = 0; c < ir_nch; c++) {
-    uint64_t l = n.ir_len;
-    while (l > 0 && std::fabs(n.ir[c][l - 1]) < 0.000001f) l--;
-    len = std::max(len, l);
+  if (lti) {
+    len = n.ir_lti_len;  // (already cut where the folded response ends)
+  } else {
+    for (int c = 0; c < ir_nch; c++) {
+      uint64_t l = n.ir_len;
+      while (l > 0 && std::fabs(n.ir[c][l - 1]) < 0.000001f) l--;
+      len = std::max(len, l);
+    }
   }
   Step st;
   st.kind = 2;
@@ -122,9 +210,10 @@ int plan_convolver(waa_batch* b, uint32_t id) {
   // device resources
   std::vector<float> irflat((size_t)ir_nch * len);
   for (int c = 0; c < ir_nch; c++) {
-    uint64_t l = n.ir_len;
-    while (l > 0 && std::fabs(n.ir[c][l - 1]) < 0.000001f) l--;  // samples past a channel's own trim are dropped
-    for (uint64_t i = 0; i < len; i++) irflat[(size_t)c * len + i] = i < l ? n.ir[c][i] : 0.f;
+    uint64_t l = ir_use_len;
+    if (!lti)
+      while (l > 0 && std::fabs(ir_use[c][l - 1]) < 0.000001f) l--;  // samples past a channel's own trim are dropped
+    for (uint64_t i = 0; i < len; i++) irflat[(size_t)c * len + i] = i < l ? ir_use[c][i] : 0.f;
   }
   float* d_ir = nullptr;
   int e = dev_upload(b, &d_ir, irflat);
@@ -153,7 +242,7 @@ int plan_convolver(waa_batch* b, uint32_t id) {
   cv.H = dH;
   cv.X = dX;
   cv.Y = dY;
-  if (n.pre_biquad >= 0) {
+  if (n.pre_biquad >= 0 && !lti) {
     if (!cv.fft3) return fail(WAA_ERR_INVALID_STATE, "internal: biquad node %d folded into a convolver without the three-pass transforms", n.pre_biquad);
     std::vector<OpDesc> qops;
     int q_out = 0;
@@ -170,7 +259,7 @@ int plan_convolver(waa_batch* b, uint32_t id) {
   }
   plan_note(b, "convolver node %u: fft B=%d N=%d P=%d blocks=%d pairs=%u cin=%d cout=%d terms=%d ir_len=%llu%s", id, cv.block,
             cv.n, cv.parts, cv.nb, cv.n_pairs, cv.cin, cv.cout, cv.n_terms, (unsigned long long)len,
-            cv.pre_coefs ? " (+ the Biquad in front, in the forward transform)" : "");
+            cv.pre_coefs ? " (+ the Biquad in front, in the forward transform)" : lti ? " (+ the Biquad in front, in the impulse response)" : "");
   st.slot_fwd = slot_for(b, "conv_fft_kernel<fwd>");
   st.slot_mac = slot_for(b, "conv_mac_kernel");
   st.slot_inv = slot_for(b, "conv_fft_kernel<inv>");

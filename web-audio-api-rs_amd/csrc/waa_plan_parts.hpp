@@ -73,6 +73,10 @@ int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int inte
 int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr);
 int plan_oscillator(waa_batch* b, uint32_t id);
 int conv_block_size(const waa_batch* b, const Node& n);
+// source -> Biquad(the same constant coefficients on every context) -> long Convolver: Biquad and Convolver are both LTI, so
+// (x * h_biquad) * h_ir = x * (h_biquad * h_ir): fills conv.ir_lti with the filtered impulse response when the filter's memory
+// dies out inside the partitions the response occupies anyway (true: folded; the Biquad then costs nothing per render)
+bool conv_fold_biquad_into_ir(const waa_batch* b, Node& conv, const Node& q);
 int plan_convolver(waa_batch* b, uint32_t id);
 int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector<OpDesc>& ops, int* out_nch);
 void default_channel_config(Node& n, uint32_t n_out);

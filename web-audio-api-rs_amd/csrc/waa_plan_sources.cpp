@@ -49,6 +49,7 @@ int widen_narrow_buffers(waa_batch* b, Node& n, uint32_t nch) {
 
 // Resolve a source node into an InputRef: schedules, per-instance buffer table, constant ranges.
 int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
+  PlanTrace trace_all("prepare_source_input");
   Node& n = b->nodes[id];
   if (n.desc.kind == WAA_NODE_CONSTANT_SOURCE) {
     int e = node_param(b, id, 0, &in->offset);
@@ -97,6 +98,9 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   const ParamStore& p_rate = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
   const ParamStore& p_det = n.params[WAA_PARAM_SOURCE_DETUNE];
   const bool automated = !p_rate.blocks.empty() || !p_det.blocks.empty();
+  SchedKey last_key(0., 0., 0., 0., 0, 0., 0., 0, 0.f, 0.f, 0.f);
+  uint32_t last_sched = 0;
+  bool last_key_valid = false;
   for (uint32_t i = 0; i < b->n_inst; i++) {
     const DeviceBuffer& bf = n.bufs[i];
     SrcInst& si = insts[i];
@@ -104,20 +108,30 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
     si.ch_stride = bf.ch_stride;
     si.frames = bf.frames;
     si.aligned = (bf.valid && ((uintptr_t)bf.base % 16 == 0) && (bf.ch_stride % 4 == 0)) ? 1 : 0;
-    std::vector<float> rate_q = param_per_quantum(b, p_rate, i, nullptr);
-    std::vector<float> det_q = param_per_quantum(b, p_det, i, nullptr);
     const SourceSched& ss = n.sched[i];
+    // (constant params: the key needs their one value — no per-quantum vectors for the 2047 contexts that share a schedule)
     const SchedKey key(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end,
-                       bf.valid ? bf.frames : 0, bf.valid ? bf.sr : 0.f, rate_q[0], det_q[0]);
+                       bf.valid ? bf.frames : 0, bf.valid ? bf.sr : 0.f, p_rate.fix(p_rate.cst[i]), p_det.fix(p_det.cst[i]));
     if (!automated) {
+      if (i > 0 && last_key_valid && key == last_key) {  // (the usual batch: every context like its neighbour — no tree walk)
+        si.sched = last_sched;
+        continue;
+      }
       auto it = dedup.find(key);
       if (it != dedup.end()) {
-        si.sched = it->second;
+        si.sched = last_sched = it->second;
+        last_key = key;
+        last_key_valid = true;
         continue;
       }
     }
+    std::vector<float> rate_q = param_per_quantum(b, p_rate, i, nullptr);
+    std::vector<float> det_q = param_per_quantum(b, p_det, i, nullptr);
     SchedOut so;
-    schedule_source(b, n.sched[i], bf.frames, bf.sr, bf.valid, rate_q, det_q, &so);
+    {
+      PlanTrace trace("source input: schedule_source");
+      schedule_source(b, n.sched[i], bf.frames, bf.sr, bf.valid, rate_q, det_q, &so);
+    }
     {
       uint32_t nf = 0, nl = 0, ns = 0, nt = 0;
       for (auto& r : so.qrec) {
@@ -169,7 +183,12 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
     ds.tile_fast = dtf;
     si.sched = (uint32_t)scheds.size();
     scheds.push_back(ds);
-    if (!automated) dedup[key] = si.sched;
+    if (!automated) {
+      dedup[key] = si.sched;
+      last_key = key;
+      last_sched = si.sched;
+      last_key_valid = true;
+    }
   }
   for (auto& si : insts) {
     si.sc = scheds[si.sched];

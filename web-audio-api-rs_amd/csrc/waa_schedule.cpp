@@ -2,6 +2,9 @@
 // on the host: biquad coefficient formulas, panner geometry, the AudioBufferSourceNode
 // playhead state machine (its output is a per-quantum record table, the interpolation arithmetic runs on the
 // device), per-quantum AudioParam values.
+#include <atomic>
+#include <cstring>
+
 #include "waa_host.hpp"
 
 namespace waa {
@@ -164,8 +167,37 @@ float dist_gain(const waa_node_desc& d, V3 sp, V3 lp) {
 
 // ---- AudioBufferSourceNode scheduler: port of audio_buffer_source.rs:422-845 -------------
 
+static void schedule_source_impl(const waa_batch* b, const SourceSched& cfg, uint64_t frames, float buf_sr, bool has_buffer,
+                                 const std::vector<float>& rate_q, const std::vector<float>& detune_q, SchedOut* out, bool allow_runs);
+
+// (measurement build, WAA_SCHED_VERIFY=1: every schedule is replayed twice — with the steady-state runs and frame by frame —
+// and the tables compared bit for bit; tests/test_schedule_runs.py reads the mismatch count)
+static std::atomic<uint64_t> g_sched_checked{0}, g_sched_mismatches{0};
+extern "C" uint64_t waa_debug_sched_verify(uint64_t* checked) {
+  if (checked) *checked = g_sched_checked.load();
+  return g_sched_mismatches.load();
+}
+
 void schedule_source(const waa_batch* b, const SourceSched& cfg, uint64_t frames, float buf_sr, bool has_buffer,
                      const std::vector<float>& rate_q, const std::vector<float>& detune_q, SchedOut* out) {
+  const bool no_runs = measure_switch("WAA_SCHED_NO_RUNS") != nullptr;
+  schedule_source_impl(b, cfg, frames, buf_sr, has_buffer, rate_q, detune_q, out, !no_runs);
+  if (measure_switch("WAA_SCHED_VERIFY")) {
+    SchedOut ref;
+    schedule_source_impl(b, cfg, frames, buf_sr, has_buffer, rate_q, detune_q, &ref, false);
+    bool same = ref.qrec.size() == out->qrec.size() && ref.slow.size() == out->slow.size() && ref.tile_fast == out->tile_fast &&
+                ref.any_slow == out->any_slow && ref.ended_quantum == out->ended_quantum && ref.ended_at_unload == out->ended_at_unload;
+    for (size_t i = 0; same && i < ref.qrec.size(); i++) same = ref.qrec[i].start == out->qrec[i].start && ref.qrec[i].mode == out->qrec[i].mode;
+    for (size_t i = 0; same && i < ref.slow.size(); i++)
+      same = ref.slow[i].prev == out->slow[i].prev && ref.slow[i].next == out->slow[i].next &&
+             std::memcmp(&ref.slow[i].k, &out->slow[i].k, sizeof(double)) == 0;
+    g_sched_checked++;
+    if (!same) g_sched_mismatches++;
+  }
+}
+
+static void schedule_source_impl(const waa_batch* b, const SourceSched& cfg, uint64_t frames, float buf_sr, bool has_buffer,
+                                 const std::vector<float>& rate_q, const std::vector<float>& detune_q, SchedOut* out, bool allow_runs) {
   const uint32_t nq = b->n_quanta;
   out->qrec.assign(nq, QRec{0, Q_SILENT, 0});
   out->slow.clear();
@@ -260,7 +292,55 @@ void schedule_source(const waa_batch* b, const SourceSched& cfg, uint64_t frames
       ensure_slow();
       out->qrec[q] = QRec{0, Q_SLOW, 0};
       SlowRec* rec = &out->slow[(size_t)q * RQ];
+      // The steady state of the playhead (round 5: one replay of a 10 s slow-track schedule was 9 ms of a plan, 20 ns per
+      // frame of tolerance tests that cannot fire): once the source has started (and entered its loop), while every frame of
+      // this block lies before stop_time, the played duration cannot reach `duration` inside the block, and buffer_time sits
+      // strictly inside (zone_lo, zone_hi) — farther than the `almost` tolerance from the loop points and from zero — every
+      // snapping test and both wrap loops below are no-ops by construction.  The frame then only computes its record and
+      // advances the clock with the SAME two additions in the same order (buffer_time += time_incr; elapsed += |time_incr|):
+      // the table is bit-identical to the frame-by-frame form (tests/test_reference_kat.py, C5 every-instance: bit-exact).
+      const double time_incr_blk = dt * cpr;
+      const bool blk_before_stop = block_time + (double)(RQ - 1) * dt < stop_time && std::isfinite(time_incr_blk);
+      const bool blk_duration_safe =
+          elapsed + (double)(RQ + 1) * std::fabs(time_incr_blk) < duration - 4. * ALMOST_TOL * std::fmax(std::fabs(duration), 1.) || duration == DBL_MAX;
+      const double zone_margin = 4. * ALMOST_TOL * std::fmax(1., std::fmax(std::fabs(actual_loop_end), std::fabs(buffer_duration)));
+      const double zone_lo = (is_looping ? actual_loop_start : 0.) + zone_margin;
+      const double zone_hi = is_looping ? actual_loop_end - zone_margin : DBL_MAX;
+      const bool blk_fast = allow_runs && blk_before_stop && blk_duration_safe && (!is_looping || actual_loop_start >= 0.);
       for (int i = 0; i < RQ; i++) {
+        if (blk_fast && started && (!is_looping || entered_loop) && buffer_time > zone_lo && buffer_time < zone_hi && buffer_time < buffer_duration) {
+          // a run of steady-state frames: first the clock (the only serial part: one dependent addition per frame), then
+          // the records of the run
+          double bts[RQ + 1], els[RQ + 1];
+          int n_run = 0;
+          {
+            double bt = buffer_time, el = elapsed;
+            const double ainc = std::fabs(time_incr_blk);
+            while (i + n_run < RQ && bt > zone_lo && bt < zone_hi && bt < buffer_duration) {
+              bts[n_run] = bt;
+              els[n_run] = el;
+              n_run++;
+              bt += time_incr_blk;
+              el += ainc;
+            }
+            bts[n_run] = bt;
+            els[n_run] = el;
+          }
+          int done = 0;
+          for (; done < n_run; done++) {
+            const double playhead = bts[done] * sampling_ratio * sample_rate;  // position = buffer_time * ratio; playhead = position * sr
+            const double pf = std::floor(playhead);
+            const uint64_t prev = (uint64_t)pf;
+            if (!(prev + 1 < frames)) break;  // (the buffer's last frame: the general form below knows the end rules)
+            rec[i + done] = SlowRec{(int32_t)prev, (int32_t)(prev + 1), playhead - pf};
+          }
+          if (done > 0) {
+            buffer_time = bts[done];
+            elapsed = els[done];
+            i += done - 1;
+            continue;
+          }
+        }
         rec[i] = SlowRec{-1, -1, 0.};
         const double current_time = block_time + (double)i * dt;
         if (!started && almost_equal(current_time, start_time)) start_time = current_time;
