@@ -255,6 +255,16 @@ struct Step {
   ChainDesc echo_line{};
 };
 
+struct SchedOut {
+  std::vector<QRec> qrec;
+  std::vector<SlowRec> slow;  // empty if no slow quantum
+  std::vector<uint8_t> tile_fast;
+  bool any_slow = false;
+  int64_t ended_quantum = -1;  // quantum in which the renderer sends `ended` (-1: not during the render)
+  bool ended_at_unload = false;  // ... or before_drop sends it after the last quantum
+};
+using SchedKey = std::tuple<double, double, double, double, int, double, double, uint64_t, float, float, float>;
+
 }  // namespace host
 }  // namespace waa
 
@@ -318,6 +328,9 @@ struct waa_batch {
   uint64_t n_alloc = 0, alloc_bytes = 0;
   uint32_t* scan_counter = nullptr;   // 8 unit counters (16 words apart) + error flag of the time-parallel biquad launches
   uint32_t scan_issued[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // host mirror of the counters during a render
+  // one playhead replay per distinct (source node, schedule) and plan: the silence / count replay, the code rows and the source's
+  // input tables all ask for it (a 10 s slow-track replay is milliseconds); cleared when build_plan returns
+  std::map<std::pair<uint32_t, SchedKey>, std::shared_ptr<SchedOut>> sched_cache;
   double plan_alloc_ms = 0, plan_upload_ms = 0;          // ... and their part inside build_plan
   uint64_t plan_n_alloc = 0, plan_alloc_bytes = 0;
 };
@@ -441,17 +454,12 @@ float spatial_angle(V3 sp, V3 so, V3 lp);
 float cone_gain(const waa_node_desc& d, V3 sp, V3 so, V3 lp);
 float dist_gain(const waa_node_desc& d, V3 sp, V3 lp);
 // AudioBufferSourceNode scheduler: port of audio_buffer_source.rs:422-845
-struct SchedOut {
-  std::vector<QRec> qrec;
-  std::vector<SlowRec> slow;  // empty if no slow quantum
-  std::vector<uint8_t> tile_fast;
-  bool any_slow = false;
-  int64_t ended_quantum = -1;  // quantum in which the renderer sends `ended` (-1: not during the render)
-  bool ended_at_unload = false;  // ... or before_drop sends it after the last quantum
-};
-using SchedKey = std::tuple<double, double, double, double, int, double, double, uint64_t, float, float, float>;
 void schedule_source(const waa_batch* b, const SourceSched& cfg, uint64_t frames, float buf_sr, bool has_buffer,
                      const std::vector<float>& rate_q, const std::vector<float>& detune_q, SchedOut* out);
+// the same through the batch's per-plan cache (params without per-quantum blocks only: the key holds their one value)
+std::shared_ptr<SchedOut> schedule_source_cached(waa_batch* b, uint32_t node, const SchedKey& key, const SourceSched& cfg, uint64_t frames,
+                                                 float buf_sr, bool has_buffer, const std::vector<float>& rate_q,
+                                                 const std::vector<float>& detune_q);
 // one value per quantum (or a single one) of a host-evaluated param, clamped like the reference
 std::vector<float> param_per_quantum(const waa_batch* b, const ParamStore& p, uint32_t inst, bool* varies);
 

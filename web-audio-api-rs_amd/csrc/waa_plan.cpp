@@ -4,6 +4,8 @@
 #include <array>
 #include <set>
 
+#include <memory>
+
 #include "waa_host.hpp"
 #include "waa_plan_parts.hpp"
 
@@ -758,8 +760,13 @@ int source_code_rows(waa_batch* b, uint32_t id, uint64_t cs, std::vector<uint8_t
       // (rows differ by the buffer's own channel count too: one cache per count would do; mixed counts are rare -> no cache)
       auto itc = automated || bf.nch_true ? cache.end() : cache.find(key);
       if (itc == cache.end()) {
-        SchedOut so;
-        schedule_source(b, ss, bf.frames, bf.sr, bf.valid, rate_q, det_q, &so);
+        SchedOut own;
+        std::shared_ptr<SchedOut> shared;
+        if (automated)
+          schedule_source(b, ss, bf.frames, bf.sr, bf.valid, rate_q, det_q, &own);
+        else
+          shared = schedule_source_cached(b, id, key, ss, bf.frames, bf.sr, bf.valid, rate_q, det_q);
+        const SchedOut& so = automated ? own : *shared;
         std::vector<uint8_t> r(b->n_quanta);
         for (uint32_t q = 0; q < b->n_quanta; q++)
           r[q] = so.qrec[q].mode == Q_SILENT ? (uint8_t)(1u | CODE_SILENT) : (uint8_t)(bf.valid ? bf.count() : (uint32_t)n.out_nch);
@@ -784,9 +791,19 @@ int source_code_rows(waa_batch* b, uint32_t id, uint64_t cs, std::vector<uint8_t
   return 0;
 }
 
+static int build_plan_impl(waa_batch* b);
 int build_plan(waa_batch* b) {
+  b->sched_cache.clear();
+  const int e = build_plan_impl(b);
+  b->sched_cache.clear();  // (the replays of one plan: a 10 s slow-track table is 7.7 MB)
+  return e;
+}
+
+static int build_plan_impl(waa_batch* b) {
   const uint32_t N = (uint32_t)b->nodes.size();
   b->short_ring_loops.clear();
+  PlanTrace trace_total("build_plan (host + device calls)");
+  std::unique_ptr<PlanTrace> ph(new PlanTrace("phase: automation + order + loops + counts"));
   if (int e = materialise_automation(b)) return e;
   for (uint32_t i = 0; i < N; i++)  // the reference takes the coefficients in the constructor
     if (b->nodes[i].desc.kind == WAA_NODE_IIR_FILTER && b->nodes[i].iir_b.empty())
@@ -1023,6 +1040,8 @@ int build_plan(waa_batch* b) {
         if (int e = widen_narrow_buffers(b, n, (uint32_t)n.out_nch)) return e;
     b->force_dynamic = true;
   }
+  ph.reset();
+  ph.reset(new PlanTrace("phase: silence / count replay"));
   // Static vs dynamic channel counts.  The reference counts a silent input as mono, so the channel count of a
   // signal changes mid-render when a narrow and a wide producer are not active over the same quanta, when a source
   // ends, when a Gain is (at times) zero.  Count-sensitive nodes then differ from this plan, which renders the
@@ -1067,20 +1086,25 @@ int build_plan(waa_batch* b) {
             const DeviceBuffer& bf = n.bufs[inst];
             const ParamStore& p_rate = n.params[WAA_PARAM_SOURCE_PLAYBACK_RATE];
             const ParamStore& p_det = n.params[WAA_PARAM_SOURCE_DETUNE];
-            std::vector<float> rate_q = param_per_quantum(b, p_rate, inst, nullptr);
-            std::vector<float> det_q = param_per_quantum(b, p_det, inst, nullptr);
             const bool automated = !p_rate.blocks.empty() || !p_det.blocks.empty();
+            // (constant params: the key needs their one value; the per-quantum vectors only for a replay)
             const SchedKey key(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end, bf.frames, bf.sr,
-                               rate_q[0], det_q[0]);
+                               p_rate.fix(p_rate.cst[inst]), p_det.fix(p_det.cst[inst]));
             int64_t endq;
             auto it = automated ? end_cache.end() : end_cache.find(std::make_pair(id, key));
             if (it != end_cache.end()) {
               endq = it->second;
             } else {
-              SchedOut so;
-              schedule_source(b, ss, bf.frames, bf.sr, true, rate_q, det_q, &so);
-              endq = so.ended_quantum;
-              if (!automated) end_cache[std::make_pair(id, key)] = endq;
+              std::vector<float> rate_q = param_per_quantum(b, p_rate, inst, nullptr);
+              std::vector<float> det_q = param_per_quantum(b, p_det, inst, nullptr);
+              if (automated) {
+                SchedOut so;
+                schedule_source(b, ss, bf.frames, bf.sr, true, rate_q, det_q, &so);
+                endq = so.ended_quantum;
+              } else {
+                endq = schedule_source_cached(b, id, key, ss, bf.frames, bf.sr, true, rate_q, det_q)->ended_quantum;
+                end_cache[std::make_pair(id, key)] = endq;
+              }
             }
             if (endq >= 0) hi[id] = std::min(hi[id], (double)endq + 1.);
           }
@@ -1293,6 +1317,8 @@ int build_plan(waa_batch* b) {
       }  // tail_mode
     }
   }
+  ph.reset();
+  ph.reset(new PlanTrace("phase: folds + materialisation + views"));
   // Nodes whose state freezes while they do not process (WaveShaper 2x / 4x, HRTF panner; waa_frozen.hip) follow the
   // per-quantum silence / count codes of their input EXACTLY.  Directly behind one source those codes are host-known
   // (the scheduling replay); behind anything else they come out of the dynamic-count rendering.
@@ -1556,6 +1582,8 @@ int build_plan(waa_batch* b) {
     n.sig = SignalRef{p, (uint64_t)n.out_nch * b->lp, b->lp, n.out_nch, 0};
     return 0;
   };
+  ph.reset();
+  ph.reset(new PlanTrace("phase: units + steps"));
   // planning units: single nodes and whole feedback loops, producers first (the condensed graph is acyclic),
   // otherwise in processing order
   std::vector<Unit> units;
@@ -1817,7 +1845,7 @@ int build_plan(waa_batch* b) {
             nd.hist = SignalRef{};
             nd.hist_is_temp = false;
           }
-          return build_plan(b);
+          return build_plan_impl(b);
         }
         if (e) return e;
         continue;
@@ -1949,7 +1977,7 @@ int build_plan(waa_batch* b) {
             nd.hist = SignalRef{};
             nd.hist_is_temp = false;
           }
-          return build_plan(b);
+          return build_plan_impl(b);
         }
         if (short_ring) plan_note(b, "  (a feedback delay shorter than a tile: the ring kernel walks it in chunks shorter than the delay)");
       }
@@ -1963,6 +1991,8 @@ int build_plan(waa_batch* b) {
   fuse_fm_operators(b);
   fuse_lfo_params(b);
   // (self-test of the check below: a reversed launch list must not get past it, tests/test_plan.py)
+  ph.reset();
+  ph.reset(new PlanTrace("phase: validate"));
   if (measure_switch("WAA_DEBUG_REVERSE_PLAN")) std::reverse(b->steps.begin(), b->steps.end());
   if (int e = validate_plan(b)) return e;
   b->planned = true;

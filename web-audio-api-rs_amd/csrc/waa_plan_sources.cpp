@@ -127,11 +127,16 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
     }
     std::vector<float> rate_q = param_per_quantum(b, p_rate, i, nullptr);
     std::vector<float> det_q = param_per_quantum(b, p_det, i, nullptr);
-    SchedOut so;
+    SchedOut own;
+    std::shared_ptr<SchedOut> shared;
     {
       PlanTrace trace("source input: schedule_source");
-      schedule_source(b, n.sched[i], bf.frames, bf.sr, bf.valid, rate_q, det_q, &so);
+      if (automated)
+        schedule_source(b, n.sched[i], bf.frames, bf.sr, bf.valid, rate_q, det_q, &own);
+      else
+        shared = schedule_source_cached(b, id, key, n.sched[i], bf.frames, bf.sr, bf.valid, rate_q, det_q);
     }
+    const SchedOut& so = automated ? own : *shared;
     {
       uint32_t nf = 0, nl = 0, ns = 0, nt = 0;
       for (auto& r : so.qrec) {

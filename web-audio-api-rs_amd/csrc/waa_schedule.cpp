@@ -196,6 +196,18 @@ void schedule_source(const waa_batch* b, const SourceSched& cfg, uint64_t frames
   }
 }
 
+std::shared_ptr<SchedOut> schedule_source_cached(waa_batch* b, uint32_t node, const SchedKey& key, const SourceSched& cfg, uint64_t frames,
+                                                 float buf_sr, bool has_buffer, const std::vector<float>& rate_q,
+                                                 const std::vector<float>& detune_q) {
+  auto k = std::make_pair(node, key);
+  auto it = b->sched_cache.find(k);
+  if (it != b->sched_cache.end()) return it->second;
+  auto so = std::make_shared<SchedOut>();
+  schedule_source(b, cfg, frames, buf_sr, has_buffer, rate_q, detune_q, so.get());
+  b->sched_cache.emplace(k, so);
+  return so;
+}
+
 static void schedule_source_impl(const waa_batch* b, const SourceSched& cfg, uint64_t frames, float buf_sr, bool has_buffer,
                                  const std::vector<float>& rate_q, const std::vector<float>& detune_q, SchedOut* out, bool allow_runs) {
   const uint32_t nq = b->n_quanta;
