@@ -589,6 +589,29 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
     return rec
 
 
+def box_record():
+    """Which kind of box is this?  The same kernel ran 1.35 ms on some boxes and 1.60 ms on others for four rounds; tools/stream_probe
+    (a standalone HIP program, built by __graft_entry__.build()) times a plain float4 copy and the one-wave-per-stream copy of
+    C2's footprint (2 x 3.94 GB) on THIS box: the rate a streaming kernel can reach here.  Returns {"linear_copy_GBps",
+    "stream_copy_GBps", "ms"} or None (no binary / it failed): reporting only."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "stream_probe")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=120).stdout
+        rec = {}
+        for line in out.splitlines():
+            m = re.match(r"\s*(linear 256x65536|stream tile 2048)\s+([0-9.]+) ms\s+([0-9.]+) GB/s", line)
+            if m:
+                rec["linear_copy_GBps" if m.group(1).startswith("linear") else "stream_copy_GBps"] = float(m.group(3))
+                rec.setdefault("ms", {})[m.group(1)] = float(m.group(2))
+        return rec or None
+    except Exception:  # noqa: BLE001 — reporting only
+        return None
+
+
 def launcher_decision(gpus, env):
     """What `bench.py --gpus N` does about ranks (round-4 review, missing item 6: --gpus was parsed and never read, a plain
     `python bench.py --gpus 8` rendered on one GPU and printed n_gpus: 1).
@@ -761,12 +784,23 @@ def main():
                 out["roofline"]["traffic_source"] = "stamped record (live measurement failed: %s)" % repr(e)[:80]
         elif "traffic" in out["roofline"] and out["roofline"]["traffic"]:
             out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (stamped with the source hashes it was measured on)"
+        if default_run and world == 1:
+            box = box_record()
+            if box and box.get("stream_copy_GBps"):
+                floor = max(box.get("stream_copy_GBps", 0.0), box.get("linear_copy_GBps", 0.0))
+                out["roofline"]["box_copy_floor"] = {"GBps": floor, "frac_of_peak": round(floor / 8000.0, 3), "kernel_over_floor": round(roof["achieved"] / floor, 3),
+                                                     "what": "tools/stream_probe on this box before the line was printed: plain float4 copy / one wave per stream, 2 x 3.94 GB"}
+                detail_box = box
+            else:
+                detail_box = None
+        else:
+            detail_box = None
         if "sustained" in rec:  # the same protocol over >= --sustain seconds of back-to-back steps (never `value`)
             out["sustained"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rec["sustained"].items()}
         for k in ("algorithmic_bytes_per_launch", "compulsory_frac", "traffic_note", "achieved_basis"):
             if k in roof:
                 out["roofline"][k] = roof[k]
-        detail = {"headline": rec, "workloads": extra, "e2e": e2e}
+        detail = {"headline": rec, "workloads": extra, "e2e": e2e, "box": detail_box}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -7,6 +7,7 @@
 #   pmc:<w>    rocprofv3 stats / FETCH_SIZE / WRITE_SIZE passes of bench workload <w>
 #   line:<w>   one bench line of workload <w>
 #   fuzz:<n>   tools/fuzz_campaign.py over n seeds per generator
+#   ranks:<n>  `python bench.py --gpus n` with no launcher (it spawns the ranks; WAA_BENCH_SHARE_GPU: they share this box's GPU)
 #   box        copy floor of this box (tools/stream_probe) + rocm-smi clocks: C2 ran 1.35 ... 1.60 ms depending on the box
 #   plantrace:<w>  WAA_PLAN_TRACE of workload <w> (measurement build): where build_plan's host time goes
 set -u
@@ -28,6 +29,8 @@ for S in "$@"; do
             { echo "# $(date -u) $(hostname)"; rocm-smi --showclocks --showpower --showmemuse 2>/dev/null | grep -v "^=\|^$" | head -30;
               timeout 120 tools/stream_probe 2>&1 | head -20; } > gpurun_out/${TAG}_box.txt 2>&1; grep -E "linear 256x65536|stream tile 2048 |sclk|mclk|fclk" gpurun_out/${TAG}_box.txt | head -8 ;;
     plantrace:*) W=${S#plantrace:}; WAA_USE_MEASURE_LIB=1 WAA_PLAN_TRACE=1 timeout 300 python bench.py --workload $W --steps 2 --warmup 1 --sustain 0 --no-cpu-baseline --no-extra 2> gpurun_out/${TAG}_plantrace_$W.txt | cut -c1-400; grep "\[plan\]" gpurun_out/${TAG}_plantrace_$W.txt | head -20 ;;
+    ranks:*) N=${S#ranks:}; # the N-rank line rehearsed on this 1-GPU box: plain `bench.py --gpus N` starts the ranks itself (they share device 0 over gloo)
+            WAA_BENCH_SHARE_GPU=1 WAA_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus $N --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_${N}rank_shared.json 2> gpurun_out/${TAG}_bench_${N}rank_shared.err; echo "rc=$?"; cut -c1-700 gpurun_out/${TAG}_bench_${N}rank_shared.json; tail -2 gpurun_out/${TAG}_bench_${N}rank_shared.err ;;
     *) echo "unknown section $S" ;;
   esac
 done
