@@ -344,3 +344,39 @@ def test_mixed_buffer_counts_can_be_pinned_to_the_static_plan(hip):
         c.close()
     finally:
         del os.environ["WAA_STATIC_CHANNEL_COUNTS"]
+
+
+@pytest.mark.measure
+def test_quantum_pipeline_is_bit_identical_to_the_one_wavefront_form(hip, monkeypatch):
+    """dyn_kernel<2, W>: the items cut into W stages, stage w rendering quantum t - w in step t (round 5) — every item runs the
+    code of the one-wavefront form on the same values, so the render must be BIT-identical (WAA_DYN_NO_PIPE=1 launches W = 1
+    on the same plan).  Random graphs of both fuzz generators: those whose plan has a pipelined group are compared."""
+    from test_fuzz_graphs import build_random_graph
+    compared = 0
+    staged = set()
+    for seed in range(300, 420):
+        for frozen in (False, True):
+            ch, descr = build_random_graph(hip, seed, frozen=frozen)
+            try:
+                plan = ch.plan_describe()
+            except waa.WaaError as e:
+                if e.status == 4:
+                    continue
+                raise
+            if "pipelined over the quanta" not in plan:
+                ch.close()
+                continue
+            for line in plan.splitlines():
+                if "pipelined over the quanta in" in line:
+                    staged.add(int(line.split("pipelined over the quanta in ")[1].split()[0]))
+            a = ch.start_rendering_sync().data
+            ch.close()
+            monkeypatch.setenv("WAA_DYN_NO_PIPE", "1")
+            ch, _ = build_random_graph(hip, seed, frozen=frozen)
+            b = ch.start_rendering_sync().data
+            ch.close()
+            monkeypatch.delenv("WAA_DYN_NO_PIPE")
+            assert np.array_equal(a, b), (seed, frozen, descr, float(np.abs(a - b).max()))
+            compared += 1
+    print(f"{compared} random graphs with a pipelined dynamic-count group, stage counts seen: {sorted(staged)}")
+    assert compared >= 20 and len(staged) >= 2

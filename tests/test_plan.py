@@ -452,3 +452,35 @@ def test_short_delay_loop_uses_the_quantum_serial_kernel(hip):
     lines = plan(c)
     assert any(l.startswith("feedback loop:") and "item(s) per quantum" in l for l in lines)
     assert not any("LDS-ring" in l for l in lines)
+
+
+def test_pipeline_stages_never_cut_a_delay_pair_or_a_loop(hip):
+    """plan-level: a DelayNode's writer and reader (and a feedback loop's members) share a stage"""
+    FRAMES, SR, N = 128 * 90 + 50, 48000.0, 3
+    c = waa.OfflineAudioContext(2, FRAMES, SR, n_instances=N, binding=hip, device=waa.PLAN_ONLY)
+    def _buf(c, nch, frames, start=0.0, seed=1):
+        s = c.create_buffer_source()
+        s.set_buffer_batch(white_noise(N, nch, frames, seed0=seed) * 0.5, SR)
+        s.start_at(start)
+        return s
+    mono = _buf(c, 1, FRAMES, seed=5)
+    st = _buf(c, 2, FRAMES // 2, start=0.3 * FRAMES / SR, seed=6)
+    g0 = c.create_gain(gain=0.9)
+    d = c.create_delay(0.1, delay_time=0.01)
+    fb = c.create_gain(gain=0.4)
+    pan = c.create_stereo_panner(pan=-0.2)
+    bq = c.create_biquad_filter(type_="lowpass", frequency=900.0)
+    mono.connect(g0)
+    st.connect(g0)
+    g0.connect(d)
+    d.connect(fb).connect(d)
+    d.connect(pan).connect(bq).connect(c.destination())
+    plan = c.plan_describe()
+    line = next(l for l in plan.splitlines() if l.startswith("dynamic-count group"))
+    assert "pipelined over the quanta" in line, plan
+    items = line.split("[")[1].split("]")[0].split(",")
+    cuts = [int(x) for x in line.rsplit("item(s) ", 1)[1].split(",")]
+    # the loop (delayR .. delayW and the gain between) is one contiguous run without a cut inside
+    loop_idx = [i for i, t in enumerate(items) if t.startswith("delay") or t.startswith("GAIN" + str(fb.id))]
+    lo, hi = min(loop_idx), max(loop_idx)
+    assert not any(lo < cpos <= hi for cpos in cuts), (items, cuts)

@@ -8,6 +8,8 @@
 #   line:<w>   one bench line of workload <w>
 #   fuzz:<n>   tools/fuzz_campaign.py over n seeds per generator
 #   ranks:<n>  `python bench.py --gpus n` with no launcher (it spawns the ranks; WAA_BENCH_SHARE_GPU: they share this box's GPU)
+#   dyn        tools/dyn_probe.py: dyn_kernel's quantum pipeline against the one-wavefront form
+#   t:<files>  pytest -m gpu -x on the '+'-separated test files
 #   box        copy floor of this box (tools/stream_probe) + rocm-smi clocks: C2 ran 1.35 ... 1.60 ms depending on the box
 #   plantrace:<w>  WAA_PLAN_TRACE of workload <w> (measurement build): where build_plan's host time goes
 set -u
@@ -31,6 +33,12 @@ for S in "$@"; do
     plantrace:*) W=${S#plantrace:}; WAA_USE_MEASURE_LIB=1 WAA_PLAN_TRACE=1 timeout 300 python bench.py --workload $W --steps 2 --warmup 1 --sustain 0 --no-cpu-baseline --no-extra 2> gpurun_out/${TAG}_plantrace_$W.txt | cut -c1-400; grep "\[plan\]" gpurun_out/${TAG}_plantrace_$W.txt | head -20 ;;
     ranks:*) N=${S#ranks:}; # the N-rank line rehearsed on this 1-GPU box: plain `bench.py --gpus N` starts the ranks itself (they share device 0 over gloo)
             WAA_BENCH_SHARE_GPU=1 WAA_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus $N --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_${N}rank_shared.json 2> gpurun_out/${TAG}_bench_${N}rank_shared.err; echo "rc=$?"; cut -c1-700 gpurun_out/${TAG}_bench_${N}rank_shared.json; tail -2 gpurun_out/${TAG}_bench_${N}rank_shared.err ;;
+    dyn)    # the quantum-serial probe graph: pipelined stages (default) against the one-wavefront form, twice each
+            for rep in 1 2; do for v in 0 1; do
+              if [ $v = 1 ]; then export WAA_DYN_NO_PIPE=1; else unset WAA_DYN_NO_PIPE; fi
+              echo "## WAA_DYN_NO_PIPE=${WAA_DYN_NO_PIPE:-unset}"; timeout 300 python tools/dyn_probe.py 2>&1 | grep -E "dynamic-count group|dyn_kernel|first render"
+            done; done > gpurun_out/${TAG}_dyn_probe.txt 2>&1; unset WAA_DYN_NO_PIPE; cat gpurun_out/${TAG}_dyn_probe.txt ;;
+    t:*)    F=${S#t:}; timeout 900 python -m pytest ${F//+/ } -m gpu -q -x > gpurun_out/${TAG}_tests_sel.log 2>&1; echo "rc=$?"; tail -6 gpurun_out/${TAG}_tests_sel.log ;;
     *) echo "unknown section $S" ;;
   esac
 done

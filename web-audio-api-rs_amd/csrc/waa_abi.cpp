@@ -193,11 +193,15 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
     static std::set<int> warm;
     std::lock_guard<std::mutex> l(warm_lock);
     if (!warm.count(b->device)) {
+      // (the very calls dev_upload makes: a synchronous copy of a table-sized block out of pageable memory + the null stream's
+      // synchronisation; a 4 KB asynchronous copy on the batch's stream did not take the same path — r05c: still 7.0 ms)
       void* d = nullptr;
-      if (hipMalloc(&d, 4096) == hipSuccess) {
-        std::vector<char> h(4096, 0);
-        (void)hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, b->stream);
-        (void)hipStreamSynchronize(b->stream);
+      if (hipMalloc(&d, 256 * 1024) == hipSuccess) {
+        std::vector<char> h(256 * 1024, 0);
+        for (size_t bytes : {(size_t)512, (size_t)64 * 1024, (size_t)256 * 1024}) {
+          (void)hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice);
+          (void)hipStreamSynchronize(nullptr);
+        }
         (void)hipFree(d);
       }
       warm.insert(b->device);

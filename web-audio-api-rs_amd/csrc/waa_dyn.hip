@@ -81,36 +81,54 @@ static_assert(offsetof(DynItem, kind) == 0 && offsetof(DynItem, cc) == 8 && offs
                   offsetof(DynItem, compact_ch1) == 32 && offsetof(DynItem, writer_item) == 40 && offsetof(DynItem, num_quanta) == 48 &&
                   offsetof(DynItem, in) == 56 && sizeof(DynItem) % 8 == 0,
               "dyn_kernel reads the item's scalar fields as seven 8-byte words");
-template <int CM>
-__global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
+// W = 1: one wavefront per instance walks items and quanta (the form of rounds 2-4).  W > 1 (round 5): the items are cut into W
+// contiguous STAGES (DynDesc::stage_begin, the planner's choice: a DelayNode's writer and reader and everything between them
+// share a stage, so do the members of a feedback loop) and stage w renders quantum t - w in step t: a software pipeline over
+// the render quanta, one wavefront per stage, the items' outputs and codes of the last W quanta in an LDS ring, one workgroup
+// barrier per step.  Every item runs exactly the code of the W = 1 form on exactly the same values: bit-identical
+// (tests/test_dynamic_counts.py, WAA_DYN_NO_PIPE), 1 / W of the dependent instruction chain per quantum and W wavefronts per
+// instance instead of one (the kernel is latency-bound: DESIGN.md section 8).
+template <int CM, int W>
+__global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* cur = lds;                                                          // [n_items][2][128] outputs of this quantum
-  float* scratch = cur + (size_t)d.n_items * CM * RQ;                         // [CM][128]
-  double* fst = reinterpret_cast<double*>(scratch + CM * RQ);                 // [n_items][CM][DYN_STATE] filter state
+  float* cur_ring = lds;                                                      // [W][n_items][CM][128] outputs of the last W quanta
+  float* scratch_all = cur_ring + (size_t)W * d.n_items * CM * RQ;            // [W][CM][128]
+  double* fst = reinterpret_cast<double*>(scratch_all + (size_t)W * CM * RQ); // [n_items][CM][DYN_STATE] filter state
   int* ist = reinterpret_cast<int*>(fst + (size_t)d.n_items * CM * DYN_STATE);  // [n_items][4] integer state
-  int* codes = ist + (size_t)d.n_items * 4;                                   // [n_items] codes of this quantum
-  __shared__ double coef_s[2 * (DYN_STATE + 1)];                             // IIR coefficient block of the item at hand
+  int* codes_ring = ist + (size_t)d.n_items * 4;                              // [W][n_items] codes of the last W quanta
+  __shared__ double coef_all[W][2 * (DYN_STATE + 1)];                        // IIR coefficient block of the item at hand, per stage
   // The item descriptors once into LDS: read through the pointer in the kernel argument they were ~80 dependent
   // vector loads per quantum (uniform addresses, but not provably read-only: no scalar loads), each one an exposed L2
   // round trip — with one wave per instance that WAS the kernel's time (23 k cycles per quantum for ~1100 instructions).
   // per-item caches of what never changes from quantum to quantum: the params with ONE value per instance (ParamRef mode 0: a global
   // load per use, ~700 cycles each, three in a row in a panner item) and a Biquad's constant coefficient set (five doubles)
-  int* pmask_s = codes + d.n_items;                                                   // [n_items] bit s: slot s is cached; bit 8: the coefficients
+  int* pmask_s = codes_ring + (size_t)W * d.n_items;                                  // [n_items] bit s: slot s is cached; bit 8: the coefficients
   float* pcs = reinterpret_cast<float*>(pmask_s + d.n_items);                         // [n_items][8]: op.p0 .. op.p4, alt1, alt2
-  double* cfs = reinterpret_cast<double*>(pcs + (size_t)d.n_items * 8);               // [n_items][5]  (8-byte aligned: 2 n_items ints + 8 n_items floats)
+  // [n_items][5], 8-byte aligned: (4 + W + 1) n_items ints + 8 n_items floats in front, one pad word when that count is odd
+  double* cfs = reinterpret_cast<double*>(pcs + (size_t)d.n_items * 8 + (((13 + W) * d.n_items) & 1));
   DynItem* items_s = reinterpret_cast<DynItem*>(cfs + (size_t)d.n_items * 5);
   const uint32_t inst = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = W > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;   // this wavefront's stage
+  float* scratch = scratch_all + (size_t)wv * CM * RQ;
+  double* coef_s = coef_all[wv];
+  auto all_sync = []() __attribute__((always_inline)) {
+    if constexpr (W > 1)
+      __syncthreads();
+    else
+      lds_sync();
+  };
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(d.items);
     uint32_t* dst = reinterpret_cast<uint32_t*>(items_s);
     const int words = d.n_items * (int)(sizeof(DynItem) / 4);
-    for (int i = lane; i < words; i += 64) dst[i] = load_global(src + i);
+    for (int i = tid; i < words; i += 64 * W) dst[i] = load_global(src + i);
   }
-  lds_sync();
+  all_sync();
   __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0);  // f64 denormals flushed (FTZ/DAZ render scope, thread.rs:374-382)
-  for (int i = lane; i < d.n_items * CM * DYN_STATE; i += 64) fst[i] = 0.;
-  for (int i = lane; i < d.n_items; i += 64) {
+  for (int i = tid; i < d.n_items * CM * DYN_STATE; i += 64 * W) fst[i] = 0.;
+  for (int i = tid; i < W * d.n_items; i += 64 * W) codes_ring[i] = (int)(1u | CODE_SILENT);
+  for (int i = tid; i < d.n_items; i += 64 * W) {
     const DynItem& li = items_s[i];
     // ist[0]: channels of the filter state (xy_len = 0, iir_filter.rs:303-306 "eagerly assume stereo" = 2) /
     //         delay writer: the line's channel count (ring of silent = mono quanta, delay.rs:386-397)
@@ -118,7 +136,6 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
     ist[i * 4 + 1] = -1;  // delay writer: last quantum in which the line was (re-)mixed to mono
     ist[i * 4 + 2] = 0;   // DK_CONV_IN: compacted quantum slots used by channel 1
     ist[i * 4 + 3] = 0;
-    codes[i] = (int)(1u | CODE_SILENT);
     int mask = 0;
     if (li.kind == DI_NODE) {
       const ParamRef* slots[7] = {&li.op.p0, &li.op.p1, &li.op.p2, &li.op.p3, &li.op.p4, &li.alt1, &li.alt2};
@@ -136,12 +153,12 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
     }
     pmask_s[i] = mask;
   }
-  lds_sync();
+  all_sync();
 
 #ifdef WAA_MEASURE
   unsigned long long cyc[8][3] = {};
 #define DYN_STAMP(ph)                                                    \
-  if (d.cycles) {                                                        \
+  if (W == 1 && d.cycles) {                                              \
     const unsigned long long now = __builtin_amdgcn_s_memtime();         \
     if (it < 8) cyc[it][ph] += now - t_last;                             \
     t_last = now;                                                        \
@@ -150,9 +167,24 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
 #else
 #define DYN_STAMP(ph)
 #endif
-  for (uint32_t q = 0; q < d.n_quanta; q++) {
+  // a delay reader sees its writer's stores of this quantum (same wavefront: they share a stage) once they have reached L2
+  auto vm_sync = []() __attribute__((always_inline)) {
+    if constexpr (W > 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (s_waitcnt vmcnt(0): the stores are out)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    } else {
+      __syncthreads();
+    }
+  };
+  const int it0 = W > 1 ? d.stage_begin[wv] : 0, it1 = W > 1 ? d.stage_begin[wv + 1] : d.n_items;
+  for (uint32_t t = 0; t < d.n_quanta + (uint32_t)(W - 1); t++) {
+    const uint32_t q = t - (uint32_t)wv;  // (wraps to a huge value while this stage has nothing to do yet)
+    if (q < d.n_quanta) {
     const uint64_t f0 = (uint64_t)q * RQ;
-    for (int it = 0; it < d.n_items; it++) {
+    const int slot = W > 1 ? (int)(q % (uint32_t)W) : 0;
+    float* cur = cur_ring + (size_t)slot * d.n_items * CM * RQ;
+    int* codes = codes_ring + (size_t)slot * d.n_items;
+    for (int it = it0; it < it1; it++) {
       const DynItem& li = items_s[it];
       // The item's scalar fields (the first 14 words of the descriptor) in ONE batch of LDS reads into scalar registers: read where
       // they are used, every decision below (kind -> n_in -> input item -> ...) was a dependent LDS read -> readfirstlane -> branch,
@@ -611,7 +643,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
           // closed form per entry the way mono <-> stereo has (below).  Count changes are rare; the ring is <= 376 quanta.
           const int old = ist[it * 4 + 0];
           if (sn != old && q > 0) {
-            __syncthreads();  // (this wave's earlier stores to the line have reached L2)
+            vm_sync();  // (this wave's earlier stores to the line have reached L2)
             const uint32_t cap = (uint32_t)h_num_quanta + 1u;
             uint32_t* wc = li.aux32 + (uint64_t)inst * li.code_stride;
             float* hbw = li.out.base + (uint64_t)inst * li.out.inst_stride;
@@ -634,7 +666,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
                 }
               if (lane == 0) store_global(wc + p, (uint32_t)sn | (pc & CODE_SILENT));
             }
-            __syncthreads();
+            vm_sync();
           }
         }
         if (lane == 0) {
@@ -643,7 +675,7 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
         }
       } else {
         // ---- DelayReader::process, delay.rs:515-745, on the writer's line in absolute time
-        __syncthreads();  // the writer's stores of this quantum (if it rendered first) have reached L2
+        vm_sync();  // the writer's stores of this quantum (if it rendered first) have reached L2
         const DynItem& wi = items_s[h_writer_item];
         const SignalRef& hs = wi.out;
         const int nch = ist[h_writer_item * 4 + 0];         // ring[0].number_of_channels() right now
@@ -760,9 +792,11 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
       lds_sync();
       DYN_STAMP(2)
     }
+    }
+    if constexpr (W > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the step's hand-over (LDS only)
   }
 #ifdef WAA_MEASURE
-  if (d.cycles && inst == 0 && lane == 0)
+  if (W == 1 && d.cycles && inst == 0 && lane == 0)
     for (int i = 0; i < 8; i++)
       for (int p = 0; p < 3; p++) d.cycles[i * 3 + p] = cyc[i][p];
 #endif
@@ -770,7 +804,9 @@ __global__ __launch_bounds__(64) void dyn_kernel(const DynDesc d) {
 
 void launch_dyn(const DynDesc& d, void* stream) {
   const int cm = d.cmax > 2 ? 6 : 2;
-  const size_t lds = dyn_lds_bytes(d.n_items, d.cmax);
+  // the pipelined form: mono / stereo groups the planner cut into stages (WAA_DYN_NO_PIPE=1: the one-wavefront form, A/B and cross-check)
+  const int stages = cm == 2 && d.n_stages > 1 && !measure_switch("WAA_DYN_NO_PIPE") && !measure_switch("WAA_DYN_CYCLES") ? d.n_stages : 1;
+  const size_t lds = dyn_lds_bytes(d.n_items, d.cmax, stages);
   DynDesc dd = d;
   dd.no_scan = measure_switch("WAA_DYN_NO_SCAN") ? 1u : 0u;
   dd.cycles = nullptr;
@@ -797,22 +833,28 @@ void launch_dyn(const DynDesc& d, void* stream) {
     }
   } report{dd.cycles, (hipStream_t)stream, d.n_quanta, d.n_items};
 #endif
-  if (cm == 2) {
-    if (lds > 64 * 1024)
-      raise_lds_limit(reinterpret_cast<const void*>(dyn_kernel<2>));
-    hipLaunchKernelGGL(dyn_kernel<2>, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, dd);
+  auto go = [&](auto kernel, int w) {
+    if (lds > 64 * 1024) raise_lds_limit(reinterpret_cast<const void*>(kernel));
+    hipLaunchKernelGGL(kernel, dim3(d.n_inst), dim3(64 * w), lds, (hipStream_t)stream, dd);
+  };
+  if (cm != 2) {
+    go(dyn_kernel<6, 1>, 1);
   } else {
-    if (lds > 64 * 1024)
-      raise_lds_limit(reinterpret_cast<const void*>(dyn_kernel<6>));
-    hipLaunchKernelGGL(dyn_kernel<6>, dim3(d.n_inst), dim3(64), lds, (hipStream_t)stream, dd);
+    switch (stages) {
+      case 4: go(dyn_kernel<2, 4>, 4); break;
+      case 3: go(dyn_kernel<2, 3>, 3); break;
+      case 2: go(dyn_kernel<2, 2>, 2); break;
+      default: go(dyn_kernel<2, 1>, 1); break;
+    }
   }
 }
-size_t dyn_lds_bytes(int n_items, int cmax) {
+size_t dyn_lds_bytes(int n_items, int cmax, int stages) {
   const int cm = cmax > 2 ? 6 : 2;
-  // signals + scratch, filter state, ist (4) + codes (1) + pmask (1) ints, the param cache (8 floats), the coefficient cache
-  // (5 doubles), the item descriptors
-  return ((size_t)n_items * cm * RQ + cm * RQ) * sizeof(float) + (size_t)n_items * cm * DYN_STATE * sizeof(double) +
-         (size_t)(n_items * 6 + 2) * sizeof(int) + (size_t)n_items * 8 * sizeof(float) + (size_t)n_items * 5 * sizeof(double) +
+  const int w = cm == 2 && stages > 1 ? stages : 1;
+  // signals (a ring of w quanta) + scratch (per stage), filter state, ist (4) + codes (w) + pmask (1) ints (+ the pad word in
+  // front of the doubles), the param cache (8 floats), the coefficient cache (5 doubles), the item descriptors
+  return ((size_t)w * n_items * cm * RQ + (size_t)w * cm * RQ) * sizeof(float) + (size_t)n_items * cm * DYN_STATE * sizeof(double) +
+         (size_t)(n_items * (5 + w) + 2) * sizeof(int) + (size_t)n_items * 8 * sizeof(float) + (size_t)n_items * 5 * sizeof(double) +
          (size_t)n_items * sizeof(DynItem);
 }
 

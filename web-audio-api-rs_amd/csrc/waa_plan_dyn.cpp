@@ -248,9 +248,92 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     if (dyn_lds_bytes(d.n_items, d.cmax) > 160 * 1024)
       return fail(WAA_ERR_OUT_OF_SCOPE, "dynamic-count group of %d nodes with %d-channel signals does not fit the kernel's local memory",
                   d.n_items, d.cmax);
+    // ---- the quantum pipeline (waa_dyn.hip, W > 1): cut the items into up to DYN_MAX_STAGES contiguous stages of about equal
+    // cost.  Never between a DelayNode's writer and reader (the reader looks at the writer's ring state of ITS quantum) nor
+    // inside a feedback loop (its members see each other's output of the same quantum through the delay line).
+    d.n_stages = 1;
+    d.stage_begin[0] = 0;
+    d.stage_begin[1] = d.n_items;
+    if (d.cmax <= 2 && d.n_items >= 2) {
+      const int n = d.n_items;
+      std::vector<uint8_t> nocut((size_t)n, 0);  // nocut[i]: items i and i + 1 stay together
+      auto keep = [&](int lo, int hi) {
+        for (int i = lo; i < hi; i++) nocut[(size_t)i] = 1;
+      };
+      std::map<int, std::pair<int, int>> scc_span;
+      for (int k = 0; k < n; k++) {
+        const uint32_t id = pending[(size_t)k] & ~VTX_READER;
+        if (host[(size_t)k].kind == DI_DELAY_R) keep(std::min(k, host[(size_t)k].writer_item), std::max(k, host[(size_t)k].writer_item));
+        if (scc_of[id] >= 0) {
+          auto it = scc_span.find(scc_of[id]);
+          if (it == scc_span.end())
+            scc_span[scc_of[id]] = {k, k};
+          else
+            it->second.second = k;
+        }
+      }
+      for (auto& sp : scc_span) keep(sp.second.first, sp.second.second);
+      // cost per item in thousands of cycles per quantum (every phase costs 1.2-2 k cycles whatever it computes)
+      std::vector<double> w((size_t)n), pre((size_t)n + 1, 0.);
+      for (int k = 0; k < n; k++) {
+        const DynItem& li = host[(size_t)k];
+        double c = 3.4;  // gather + hand-over of an item with one LDS input
+        for (int j = 0; j < li.n_in; j++) c += li.in[j].item < 0 ? 1.2 : 0.4;
+        if (li.kind == DI_DELAY_R) c += 3.0;
+        else if (li.kind == DI_DELAY_W) c += 0.5;
+        else if (li.dk == DK_BIQUAD) c += 3.0;
+        else if (li.dk == DK_IIR) c += 8.0;
+        else if (li.dk == DK_STEREO_PAN || li.dk == DK_PANNER) c += 1.6;
+        else if (li.dk == DK_WAVESHAPER) c += 1.5;
+        else c += 0.6;
+        w[(size_t)k] = c;
+        pre[(size_t)k + 1] = pre[(size_t)k] + c;
+      }
+      // best[s][i]: smallest possible largest-stage cost of the first i items in s stages; cut[s][i]: where the last stage starts
+      const double INF = 1e300;
+      std::vector<std::vector<double>> best(DYN_MAX_STAGES + 1, std::vector<double>((size_t)n + 1, INF));
+      std::vector<std::vector<int>> cut(DYN_MAX_STAGES + 1, std::vector<int>((size_t)n + 1, 0));
+      for (int i = 1; i <= n; i++) best[1][(size_t)i] = pre[(size_t)i];
+      for (int sN = 2; sN <= DYN_MAX_STAGES; sN++)
+        for (int i = sN; i <= n; i++)
+          for (int j = sN - 1; j < i; j++) {  // the last stage = items [j, i)
+            if (nocut[(size_t)j - 1] || best[sN - 1][(size_t)j] >= INF) continue;
+            const double v = std::max(best[sN - 1][(size_t)j], pre[(size_t)i] - pre[(size_t)j]);
+            if (v < best[sN][(size_t)i]) {
+              best[sN][(size_t)i] = v;
+              cut[sN][(size_t)i] = j;
+            }
+          }
+      int pick = 1;
+      double pick_cost = best[1][(size_t)n];
+      for (int sN = 2; sN <= DYN_MAX_STAGES; sN++) {
+        if (best[sN][(size_t)n] >= INF) continue;
+        if (dyn_lds_bytes(n, d.cmax, sN) > 156 * 1024) continue;
+        const double cst = best[sN][(size_t)n] + 0.4;  // (+ the step's barrier)
+        if (cst < 0.92 * pick_cost) {
+          pick = sN;
+          pick_cost = cst;
+        }
+      }
+      if (pick > 1 && !measure_switch("WAA_DYN_NO_STAGES")) {
+        d.n_stages = pick;
+        int i = n;
+        for (int sN = pick; sN >= 1; sN--) {
+          d.stage_begin[sN] = i;
+          i = sN > 1 ? cut[sN][(size_t)i] : 0;
+        }
+        d.stage_begin[0] = 0;
+      }
+    }
     st.profile_slot = slot_for(b, "dyn_kernel");
     b->steps.push_back(st);
-    plan_note(b, "dynamic-count group: %d item(s) per quantum [%s]", d.n_items, desc.c_str());
+    {
+      std::string cuts;
+      for (int sN = 1; sN < d.n_stages; sN++) cuts += (cuts.empty() ? "" : ",") + std::to_string(d.stage_begin[sN]);
+      plan_note(b, "dynamic-count group: %d item(s) per quantum [%s]%s%s", d.n_items, desc.c_str(),
+                d.n_stages > 1 ? (", pipelined over the quanta in " + std::to_string(d.n_stages) + " stages, cut in front of item(s) ").c_str() : "",
+                cuts.c_str());
+    }
     for (uint32_t v : pending) planned_node[v & ~VTX_READER] = 1;
     pending.clear();
     pending_nodes.clear();
