@@ -81,7 +81,8 @@ static_assert(offsetof(DynItem, kind) == 0 && offsetof(DynItem, cc) == 8 && offs
                   offsetof(DynItem, compact_ch1) == 32 && offsetof(DynItem, writer_item) == 40 && offsetof(DynItem, num_quanta) == 48 &&
                   offsetof(DynItem, in) == 56 && sizeof(DynItem) % 8 == 0,
               "dyn_kernel reads the item's scalar fields as seven 8-byte words");
-// W = 1: one wavefront per instance walks items and quanta (the form of rounds 2-4).  W > 1 (round 5): the items are cut into W
+// W = 1: one wavefront per instance walks items and quanta (the form of rounds 2-4).  W > 1 (round 5): the items — in HALVES: the
+// gather + mix of an item's inputs, and its node + hand-over — are cut into W
 // contiguous STAGES (DynDesc::stage_begin, the planner's choice: a DelayNode's writer and reader and everything between them
 // share a stage, so do the members of a feedback loop) and stage w renders quantum t - w in step t: a software pipeline over
 // the render quanta, one wavefront per stage, the items' outputs and codes of the last W quanta in an LDS ring, one workgroup
@@ -92,7 +93,10 @@ template <int CM, int W>
 __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* cur_ring = lds;                                                      // [W][n_items][CM][128] outputs of the last W quanta
-  float* scratch_all = cur_ring + (size_t)W * d.n_items * CM * RQ;            // [W][CM][128]
+  // (W > 1) the MIXED INPUTS of the last W quanta: an item's front half (gather + mix) and back half (node + hand-over) may
+  // belong to different stages
+  float* mix_ring = cur_ring + (size_t)W * d.n_items * CM * RQ;               // [W][n_items][CM][128] (W > 1 only)
+  float* scratch_all = mix_ring + (W > 1 ? (size_t)W * d.n_items * CM * RQ : 0);  // [W][CM][128]
   double* fst = reinterpret_cast<double*>(scratch_all + (size_t)W * CM * RQ); // [n_items][CM][DYN_STATE] filter state
   int* ist = reinterpret_cast<int*>(fst + (size_t)d.n_items * CM * DYN_STATE);  // [n_items][4] integer state
   int* codes_ring = ist + (size_t)d.n_items * 4;                              // [W][n_items] codes of the last W quanta
@@ -102,10 +106,11 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
   // round trip — with one wave per instance that WAS the kernel's time (23 k cycles per quantum for ~1100 instructions).
   // per-item caches of what never changes from quantum to quantum: the params with ONE value per instance (ParamRef mode 0: a global
   // load per use, ~700 cycles each, three in a row in a panner item) and a Biquad's constant coefficient set (five doubles)
-  int* pmask_s = codes_ring + (size_t)W * d.n_items;                                  // [n_items] bit s: slot s is cached; bit 8: the coefficients
+  int* meta_ring = codes_ring + (size_t)W * d.n_items;                                // [W][n_items] count | silent << 8 of the mixed inputs (W > 1 only)
+  int* pmask_s = meta_ring + (W > 1 ? (size_t)W * d.n_items : 0);                     // [n_items] bit s: slot s is cached; bit 8: the coefficients
   float* pcs = reinterpret_cast<float*>(pmask_s + d.n_items);                         // [n_items][8]: op.p0 .. op.p4, alt1, alt2
-  // [n_items][5], 8-byte aligned: (4 + W + 1) n_items ints + 8 n_items floats in front, one pad word when that count is odd
-  double* cfs = reinterpret_cast<double*>(pcs + (size_t)d.n_items * 8 + (((13 + W) * d.n_items) & 1));
+  // [n_items][5], 8-byte aligned: (4 + W (+ W) + 1) n_items ints + 8 n_items floats in front, one pad word when that count is odd
+  double* cfs = reinterpret_cast<double*>(pcs + (size_t)d.n_items * 8 + (((13 + (W > 1 ? 2 * W : W)) * d.n_items) & 1));
   DynItem* items_s = reinterpret_cast<DynItem*>(cfs + (size_t)d.n_items * 5);
   const uint32_t inst = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -176,7 +181,9 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
       __syncthreads();
     }
   };
-  const int it0 = W > 1 ? d.stage_begin[wv] : 0, it1 = W > 1 ? d.stage_begin[wv + 1] : d.n_items;
+  // stage_begin counts HALF items: unit 2 i = item i's front half (its inputs gathered and mixed), unit 2 i + 1 its back half
+  const int u0 = W > 1 ? d.stage_begin[wv] : 0, u1 = W > 1 ? d.stage_begin[wv + 1] : 2 * d.n_items;
+  const int it0 = u0 >> 1, it1 = (u1 + 1) >> 1;
   for (uint32_t t = 0; t < d.n_quanta + (uint32_t)(W - 1); t++) {
     const uint32_t q = t - (uint32_t)wv;  // (wraps to a huge value while this stage has nothing to do yet)
     if (q < d.n_quanta) {
@@ -184,6 +191,8 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
     const int slot = W > 1 ? (int)(q % (uint32_t)W) : 0;
     float* cur = cur_ring + (size_t)slot * d.n_items * CM * RQ;
     int* codes = codes_ring + (size_t)slot * d.n_items;
+    float* mixb = mix_ring + (size_t)slot * d.n_items * CM * RQ;
+    int* metab = meta_ring + (size_t)slot * d.n_items;
     for (int it = it0; it < it1; it++) {
       const DynItem& li = items_s[it];
       // The item's scalar fields (the first 14 words of the descriptor) in ONE batch of LDS reads into scalar registers: read where
@@ -202,12 +211,23 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
       auto pvc = [&](int slot, const ParamRef& p, uint64_t frame) __attribute__((always_inline)) {
         return (h_pmask >> slot) & 1 ? pcs[it * 8 + slot] : pval(p, inst, q, frame);
       };
+      const bool do_front = W == 1 || (2 * it >= u0 && 2 * it < u1), do_back = W == 1 || (2 * it + 1 >= u0 && 2 * it + 1 < u1);  // (uniform)
       float v[CM][2];
 #pragma unroll
       for (int c = 0; c < CM; c++) v[c][0] = v[c][1] = 0.f;
       int sn = 1;       // number_of_channels of the mixed input
       bool ss = true;   // is_silent
-      if (h_kind != DI_DELAY_R) {
+      if (!do_front) {
+        // the front half ran in an earlier stage: the mixed input of this quantum waits in the ring
+        const int m = __builtin_amdgcn_readfirstlane(metab[it]);
+        sn = m & 0xff;
+        ss = (m >> 8) != 0;
+#pragma unroll
+        for (int c = 0; c < CM; c++) {
+          v[c][0] = mixb[((size_t)it * CM + c) * RQ + lane];
+          v[c][1] = mixb[((size_t)it * CM + c) * RQ + 64 + lane];
+        }
+      } else if (h_kind != DI_DELAY_R) {
         // ---- graph.rs:524-535: the input starts silent (mono); every incoming edge is `add`ed in order
         for (int k = 0; k < h_n_in; k++) {
           const DynInput& in = li.in[k];
@@ -275,6 +295,16 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
 #pragma unroll
         for (int c = 0; c < CM; c++)
           if (c >= sn) v[c][0] = v[c][1] = 0.f;
+      }
+      if (!do_back) {  // this stage ends between the item's halves: hand the mixed input over
+#pragma unroll
+        for (int c = 0; c < CM; c++) {
+          mixb[((size_t)it * CM + c) * RQ + lane] = v[c][0];
+          mixb[((size_t)it * CM + c) * RQ + 64 + lane] = v[c][1];
+        }
+        if (lane == 0) metab[it] = sn | ((ss ? 1 : 0) << 8);
+        lds_sync();
+        continue;
       }
       int outn = sn;
       bool outs = ss;
@@ -841,6 +871,10 @@ void launch_dyn(const DynDesc& d, void* stream) {
     go(dyn_kernel<6, 1>, 1);
   } else {
     switch (stages) {
+      case 8: go(dyn_kernel<2, 8>, 8); break;
+      case 7: go(dyn_kernel<2, 7>, 7); break;
+      case 6: go(dyn_kernel<2, 6>, 6); break;
+      case 5: go(dyn_kernel<2, 5>, 5); break;
       case 4: go(dyn_kernel<2, 4>, 4); break;
       case 3: go(dyn_kernel<2, 3>, 3); break;
       case 2: go(dyn_kernel<2, 2>, 2); break;
@@ -851,10 +885,12 @@ void launch_dyn(const DynDesc& d, void* stream) {
 size_t dyn_lds_bytes(int n_items, int cmax, int stages) {
   const int cm = cmax > 2 ? 6 : 2;
   const int w = cm == 2 && stages > 1 ? stages : 1;
-  // signals (a ring of w quanta) + scratch (per stage), filter state, ist (4) + codes (w) + pmask (1) ints (+ the pad word in
-  // front of the doubles), the param cache (8 floats), the coefficient cache (5 doubles), the item descriptors
-  return ((size_t)w * n_items * cm * RQ + (size_t)w * cm * RQ) * sizeof(float) + (size_t)n_items * cm * DYN_STATE * sizeof(double) +
-         (size_t)(n_items * (5 + w) + 2) * sizeof(int) + (size_t)n_items * 8 * sizeof(float) + (size_t)n_items * 5 * sizeof(double) +
+  // signals (a ring of w quanta; w > 1: a second ring, the mixed inputs) + scratch (per stage), filter state, ist (4) + codes (w)
+  // (+ meta (w)) + pmask (1) ints (+ the pad word in front of the doubles), the param cache (8 floats), the coefficient cache
+  // (5 doubles), the item descriptors
+  const size_t rings = w > 1 ? 2 : 1;
+  return (rings * w * n_items * cm * RQ + (size_t)w * cm * RQ) * sizeof(float) + (size_t)n_items * cm * DYN_STATE * sizeof(double) +
+         (size_t)(n_items * (5 + rings * w) + 2) * sizeof(int) + (size_t)n_items * 8 * sizeof(float) + (size_t)n_items * 5 * sizeof(double) +
          (size_t)n_items * sizeof(DynItem);
 }
 

@@ -471,15 +471,15 @@ struct DynDesc {
   uint32_t n_quanta;
   uint32_t no_scan;         // set by the launcher (WAA_DYN_NO_SCAN): biquad items on two lanes, serially (cross-check)
   int32_t cmax;             // widest signal of the group: <= 2 -> dyn_kernel<2>, else dyn_kernel<6> (layouts up to 5.1)
-  int32_t n_stages;         // 1 .. DYN_MAX_STAGES: the items [stage_begin[w], stage_begin[w + 1]) are stage w of the quantum pipeline
-  int32_t stage_begin[5];
+  int32_t n_stages;         // 1 .. DYN_MAX_STAGES: the HALF items [stage_begin[w], stage_begin[w + 1]) are stage w of the quantum pipeline
+  int32_t stage_begin[9];   // (unit 2 i: item i's gather + mix, unit 2 i + 1: its node + hand-over)
   int32_t pad;
   double sample_rate;
   double quantum_duration;
   unsigned long long* cycles;  // measurement build, WAA_DYN_CYCLES: [items][3] shader-clock ticks of instance 0 (gather, node, hand-over)
 };
 void launch_dyn(const DynDesc& d, void* stream);
-constexpr int DYN_MAX_STAGES = 4;
+constexpr int DYN_MAX_STAGES = 8;
 size_t dyn_lds_bytes(int n_items, int cmax, int stages = 1);  // dynamic LDS of the launch (<= 160 KB: the planner checks)
 // ConvolverNode tail / routing on codes (convolver.rs:343-392): input codes -> output codes
 struct ConvCodeDesc {

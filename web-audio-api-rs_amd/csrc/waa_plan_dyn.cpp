@@ -248,22 +248,26 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     if (dyn_lds_bytes(d.n_items, d.cmax) > 160 * 1024)
       return fail(WAA_ERR_OUT_OF_SCOPE, "dynamic-count group of %d nodes with %d-channel signals does not fit the kernel's local memory",
                   d.n_items, d.cmax);
-    // ---- the quantum pipeline (waa_dyn.hip, W > 1): cut the items into up to DYN_MAX_STAGES contiguous stages of about equal
-    // cost.  Never between a DelayNode's writer and reader (the reader looks at the writer's ring state of ITS quantum) nor
-    // inside a feedback loop (its members see each other's output of the same quantum through the delay line).
+    // ---- the quantum pipeline (waa_dyn.hip, W > 1): cut the items — in halves: unit 2 i = item i's gather + mix of its inputs, unit
+    // 2 i + 1 = its node + hand-over — into up to DYN_MAX_STAGES contiguous stages of about equal cost.  Never between a DelayNode's
+    // writer and reader (the reader looks at the writer's ring state of ITS quantum) nor inside a feedback loop (its members see
+    // each other's output of the same quantum through the delay line).
     d.n_stages = 1;
     d.stage_begin[0] = 0;
-    d.stage_begin[1] = d.n_items;
-    if (d.cmax <= 2 && d.n_items >= 2) {
-      const int n = d.n_items;
-      std::vector<uint8_t> nocut((size_t)n, 0);  // nocut[i]: items i and i + 1 stay together
-      auto keep = [&](int lo, int hi) {
-        for (int i = lo; i < hi; i++) nocut[(size_t)i] = 1;
+    d.stage_begin[1] = 2 * d.n_items;
+    if (d.cmax <= 2 && d.n_items >= 1) {
+      const int n = d.n_items, nu = 2 * n;
+      std::vector<uint8_t> nocut((size_t)nu, 0);  // nocut[u]: units u and u + 1 stay together
+      auto keep = [&](int lo_item, int hi_item) {
+        for (int u = 2 * lo_item; u < 2 * hi_item + 1; u++) nocut[(size_t)u] = 1;
       };
       std::map<int, std::pair<int, int>> scc_span;
       for (int k = 0; k < n; k++) {
         const uint32_t id = pending[(size_t)k] & ~VTX_READER;
-        if (host[(size_t)k].kind == DI_DELAY_R) keep(std::min(k, host[(size_t)k].writer_item), std::max(k, host[(size_t)k].writer_item));
+        if (host[(size_t)k].kind == DI_DELAY_R) {
+          keep(std::min(k, host[(size_t)k].writer_item), std::max(k, host[(size_t)k].writer_item));
+          nocut[(size_t)(2 * k)] = 1;  // (a reader has no inputs to gather: its front half is empty)
+        }
         if (scc_of[id] >= 0) {
           auto it = scc_span.find(scc_of[id]);
           if (it == scc_span.end())
@@ -273,30 +277,33 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
         }
       }
       for (auto& sp : scc_span) keep(sp.second.first, sp.second.second);
-      // cost per item in thousands of cycles per quantum (every phase costs 1.2-2 k cycles whatever it computes)
-      std::vector<double> w((size_t)n), pre((size_t)n + 1, 0.);
+      // cost per unit in thousands of cycles per quantum (every phase costs 1.2-2 k cycles whatever it computes;
+      // WAA_DYN_CYCLES on the probe graph: Biquad gather 4.0 (two external inputs) / node 4.1 / hand-over 2.0, StereoPanner 1.6 /
+      // 3.1 / 1.9, pass 1.6 / 1.2 / 1.8)
+      std::vector<double> pre((size_t)nu + 1, 0.);
       for (int k = 0; k < n; k++) {
         const DynItem& li = host[(size_t)k];
-        double c = 3.4;  // gather + hand-over of an item with one LDS input
-        for (int j = 0; j < li.n_in; j++) c += li.in[j].item < 0 ? 1.2 : 0.4;
-        if (li.kind == DI_DELAY_R) c += 3.0;
-        else if (li.kind == DI_DELAY_W) c += 0.5;
-        else if (li.dk == DK_BIQUAD) c += 3.0;
-        else if (li.dk == DK_IIR) c += 8.0;
-        else if (li.dk == DK_STEREO_PAN || li.dk == DK_PANNER) c += 1.6;
-        else if (li.dk == DK_WAVESHAPER) c += 1.5;
-        else c += 0.6;
-        w[(size_t)k] = c;
-        pre[(size_t)k + 1] = pre[(size_t)k] + c;
+        double front = li.kind == DI_DELAY_R ? 0. : 1.1, back = 1.9;
+        for (int j = 0; j < li.n_in; j++) front += li.in[j].item < 0 ? 1.4 : 0.5;
+        if (li.kind == DI_DELAY_R) back += 4.0;
+        else if (li.kind == DI_DELAY_W) back += 1.0;
+        else if (li.dk == DK_BIQUAD) back += 4.1;
+        else if (li.dk == DK_IIR) back += 9.0;
+        else if (li.dk == DK_STEREO_PAN || li.dk == DK_PANNER) back += 3.1;
+        else if (li.dk == DK_WAVESHAPER) back += 2.5;
+        else if (li.dk == DK_GAIN) back += 1.5;
+        else back += 1.2;
+        pre[(size_t)(2 * k) + 1] = pre[(size_t)(2 * k)] + front;
+        pre[(size_t)(2 * k) + 2] = pre[(size_t)(2 * k) + 1] + back;
       }
-      // best[s][i]: smallest possible largest-stage cost of the first i items in s stages; cut[s][i]: where the last stage starts
+      // best[s][i]: smallest possible largest-stage cost of the first i units in s stages; cut[s][i]: where the last stage starts
       const double INF = 1e300;
-      std::vector<std::vector<double>> best(DYN_MAX_STAGES + 1, std::vector<double>((size_t)n + 1, INF));
-      std::vector<std::vector<int>> cut(DYN_MAX_STAGES + 1, std::vector<int>((size_t)n + 1, 0));
-      for (int i = 1; i <= n; i++) best[1][(size_t)i] = pre[(size_t)i];
+      std::vector<std::vector<double>> best(DYN_MAX_STAGES + 1, std::vector<double>((size_t)nu + 1, INF));
+      std::vector<std::vector<int>> cut(DYN_MAX_STAGES + 1, std::vector<int>((size_t)nu + 1, 0));
+      for (int i = 1; i <= nu; i++) best[1][(size_t)i] = pre[(size_t)i];
       for (int sN = 2; sN <= DYN_MAX_STAGES; sN++)
-        for (int i = sN; i <= n; i++)
-          for (int j = sN - 1; j < i; j++) {  // the last stage = items [j, i)
+        for (int i = sN; i <= nu; i++)
+          for (int j = sN - 1; j < i; j++) {  // the last stage = units [j, i)
             if (nocut[(size_t)j - 1] || best[sN - 1][(size_t)j] >= INF) continue;
             const double v = std::max(best[sN - 1][(size_t)j], pre[(size_t)i] - pre[(size_t)j]);
             if (v < best[sN][(size_t)i]) {
@@ -305,19 +312,23 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
             }
           }
       int pick = 1;
-      double pick_cost = best[1][(size_t)n];
+      double pick_cost = best[1][(size_t)nu];
       for (int sN = 2; sN <= DYN_MAX_STAGES; sN++) {
-        if (best[sN][(size_t)n] >= INF) continue;
-        if (dyn_lds_bytes(n, d.cmax, sN) > 156 * 1024) continue;
-        const double cst = best[sN][(size_t)n] + 0.4;  // (+ the step's barrier)
-        if (cst < 0.92 * pick_cost) {
+        if (best[sN][(size_t)nu] >= INF) continue;
+        if (dyn_lds_bytes(n, d.cmax, sN) > 100 * 1024) continue;  // (at least ... the ring must leave room for a second workgroup per CU)
+        const double cst = best[sN][(size_t)nu] + 0.3 + 0.05 * sN;  // (+ the step's barrier, which waits for the slowest of sN waves)
+        if (cst < 0.93 * pick_cost) {
           pick = sN;
           pick_cost = cst;
         }
       }
-      if (pick > 1 && !measure_switch("WAA_DYN_NO_STAGES")) {
+      if (const char* force = measure_switch("WAA_DYN_STAGES")) {  // (A/B aid: at most this many stages)
+        const int cap = std::max(1, atoi(force));
+        while (pick > cap || (pick > 1 && best[pick][(size_t)nu] >= INF)) pick--;
+      }
+      if (pick > 1) {
         d.n_stages = pick;
-        int i = n;
+        int i = nu;
         for (int sN = pick; sN >= 1; sN--) {
           d.stage_begin[sN] = i;
           i = sN > 1 ? cut[sN][(size_t)i] : 0;
@@ -329,7 +340,8 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     b->steps.push_back(st);
     {
       std::string cuts;
-      for (int sN = 1; sN < d.n_stages; sN++) cuts += (cuts.empty() ? "" : ",") + std::to_string(d.stage_begin[sN]);
+      for (int sN = 1; sN < d.n_stages; sN++)
+        cuts += (cuts.empty() ? "" : ",") + std::to_string(d.stage_begin[sN] / 2) + (d.stage_begin[sN] % 2 ? "b" : "");
       plan_note(b, "dynamic-count group: %d item(s) per quantum [%s]%s%s", d.n_items, desc.c_str(),
                 d.n_stages > 1 ? (", pipelined over the quanta in " + std::to_string(d.n_stages) + " stages, cut in front of item(s) ").c_str() : "",
                 cuts.c_str());
