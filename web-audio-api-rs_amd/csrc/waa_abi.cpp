@@ -185,6 +185,10 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
   }
   HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) == hipSuccess && cus > 0) b->n_cu = cus;
+  }
+  {
     // Once per process and device: the first host-to-device copy out of pageable memory makes the runtime set up its staging
     // buffers (6-7 ms on the GPU boxes: bench.py's first workload reported them as "uploads 6.9 ms" of a 10 ms first render).
     // A process pays that once whatever it does first; paid here, at context creation, it is not part of the first

@@ -277,6 +277,7 @@ struct waa_batch {
   uint32_t n_quanta = 0, n_tiles = 0;
   uint64_t lp = 0;  // padded frames per channel
   int device = 0;
+  int n_cu = 256;  // compute units of the device (plan-only batches: an MI355X)
   hipStream_t stream = nullptr;
   std::vector<Node> nodes;
   std::vector<waa_edge_desc> edges;

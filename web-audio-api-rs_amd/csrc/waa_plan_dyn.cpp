@@ -311,11 +311,17 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
               cut[sN][(size_t)i] = j;
             }
           }
+      // Every stage is a wavefront, and all of a launch's wavefronts must be resident at once or the launch takes a second round
+      // (r05e: five stages x 1024 contexts = 5120 wavefronts on a device that holds 4096 of this kernel — 107 registers: four per
+      // SIMD — ran SLOWER than one stage): at most (CUs x 4 SIMDs x 4) / contexts stages.
+      const int max_stages = std::max(1, std::min(DYN_MAX_STAGES, (int)((uint64_t)b->n_cu * 16 / std::max<uint32_t>(b->n_inst, 1))));
       int pick = 1;
       double pick_cost = best[1][(size_t)nu];
-      for (int sN = 2; sN <= DYN_MAX_STAGES; sN++) {
+      for (int sN = 2; sN <= max_stages; sN++) {
         if (best[sN][(size_t)nu] >= INF) continue;
-        if (dyn_lds_bytes(n, d.cmax, sN) > 100 * 1024) continue;  // (at least ... the ring must leave room for a second workgroup per CU)
+        // (... and so must their local memory: contexts / CUs workgroups share a CU's 160 KB)
+        const uint64_t wg_per_cu = ((uint64_t)b->n_inst + (uint64_t)b->n_cu - 1) / (uint64_t)b->n_cu;
+        if (dyn_lds_bytes(n, d.cmax, sN) * std::min<uint64_t>(wg_per_cu, 16) > 150 * 1024) continue;
         const double cst = best[sN][(size_t)nu] + 0.3 + 0.05 * sN;  // (+ the step's barrier, which waits for the slowest of sN waves)
         if (cst < 0.93 * pick_cost) {
           pick = sN;
