@@ -479,10 +479,10 @@ def test_pipeline_stages_never_cut_a_delay_pair_or_a_loop(hip):
     line = next(l for l in plan.splitlines() if l.startswith("dynamic-count group"))
     assert "pipelined over the quanta" in line, plan
     items = line.split("[")[1].split("]")[0].split(",")
-    # cuts are named by the half item they stand in front of: "2" = item 2's gather + mix, "2b" = its node + hand-over
-    cuts = [2 * int(x.rstrip("b")) + (1 if x.endswith("b") else 0) for x in line.rsplit("item(s) ", 1)[1].split(",")]
+    # cuts are named by the third of an item they stand in front of: "2" = item 2's gather + mix, "2b" = its node, "2c" = its publication
+    cuts = [3 * int(x.rstrip("bc")) + (1 if x.endswith("b") else 2 if x.endswith("c") else 0) for x in line.rsplit("item(s) ", 1)[1].split(",")]
     # the loop (delayR .. delayW and the gain between) is one contiguous run without a cut inside
     loop_idx = [i for i, t in enumerate(items) if t.startswith("delay") or t.startswith("GAIN" + str(fb.id))]
     lo, hi = min(loop_idx), max(loop_idx)
-    assert not any(2 * lo < u <= 2 * hi + 1 for u in cuts), (items, cuts)
+    assert not any(3 * lo < u <= 3 * hi + 2 for u in cuts), (items, cuts)
     assert len(cuts) >= 1

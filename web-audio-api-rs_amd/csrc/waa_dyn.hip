@@ -81,8 +81,8 @@ static_assert(offsetof(DynItem, kind) == 0 && offsetof(DynItem, cc) == 8 && offs
                   offsetof(DynItem, compact_ch1) == 32 && offsetof(DynItem, writer_item) == 40 && offsetof(DynItem, num_quanta) == 48 &&
                   offsetof(DynItem, in) == 56 && sizeof(DynItem) % 8 == 0,
               "dyn_kernel reads the item's scalar fields as seven 8-byte words");
-// W = 1: one wavefront per instance walks items and quanta (the form of rounds 2-4).  W > 1 (round 5): the items — in HALVES: the
-// gather + mix of an item's inputs, and its node + hand-over — are cut into W
+// W = 1: one wavefront per instance walks items and quanta (the form of rounds 2-4).  W > 1 (round 5): the items — in THIRDS: the
+// gather + mix of an item's inputs, its node (result into LDS), the result's publication to memory — are cut into W
 // contiguous STAGES (DynDesc::stage_begin, the planner's choice: a DelayNode's writer and reader and everything between them
 // share a stage, so do the members of a feedback loop) and stage w renders quantum t - w in step t: a software pipeline over
 // the render quanta, one wavefront per stage, the items' outputs and codes of the last W quanta in an LDS ring, one workgroup
@@ -90,7 +90,7 @@ static_assert(offsetof(DynItem, kind) == 0 && offsetof(DynItem, cc) == 8 && offs
 // (tests/test_dynamic_counts.py, WAA_DYN_NO_PIPE), 1 / W of the dependent instruction chain per quantum and W wavefronts per
 // instance instead of one (the kernel is latency-bound: DESIGN.md section 8).
 template <int CM, int W>
-__global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
+__device__ __forceinline__ void dyn_body(const DynDesc& d) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* cur_ring = lds;                                                      // [W][n_items][CM][128] outputs of the last W quanta
   // (W > 1) the MIXED INPUTS of the last W quanta: an item's front half (gather + mix) and back half (node + hand-over) may
@@ -181,9 +181,10 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
       __syncthreads();
     }
   };
-  // stage_begin counts HALF items: unit 2 i = item i's front half (its inputs gathered and mixed), unit 2 i + 1 its back half
-  const int u0 = W > 1 ? d.stage_begin[wv] : 0, u1 = W > 1 ? d.stage_begin[wv + 1] : 2 * d.n_items;
-  const int it0 = u0 >> 1, it1 = (u1 + 1) >> 1;
+  // stage_begin counts THIRDS of items: unit 3 i = item i's inputs gathered and mixed, 3 i + 1 = its node (result and code into the
+  // LDS ring), 3 i + 2 = the result published to memory
+  const int u0 = W > 1 ? d.stage_begin[wv] : 0, u1 = W > 1 ? d.stage_begin[wv + 1] : 3 * d.n_items;
+  const int it0 = u0 / 3, it1 = (u1 + 2) / 3;
   for (uint32_t t = 0; t < d.n_quanta + (uint32_t)(W - 1); t++) {
     const uint32_t q = t - (uint32_t)wv;  // (wraps to a huge value while this stage has nothing to do yet)
     if (q < d.n_quanta) {
@@ -211,14 +212,17 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
       auto pvc = [&](int slot, const ParamRef& p, uint64_t frame) __attribute__((always_inline)) {
         return (h_pmask >> slot) & 1 ? pcs[it * 8 + slot] : pval(p, inst, q, frame);
       };
-      const bool do_front = W == 1 || (2 * it >= u0 && 2 * it < u1), do_back = W == 1 || (2 * it + 1 >= u0 && 2 * it + 1 < u1);  // (uniform)
+      const bool do_front = W == 1 || (3 * it >= u0 && 3 * it < u1), do_node = W == 1 || (3 * it + 1 >= u0 && 3 * it + 1 < u1),
+                 do_pub = W == 1 || (3 * it + 2 >= u0 && 3 * it + 2 < u1);  // (uniform; a stage's units are contiguous)
       float v[CM][2];
 #pragma unroll
       for (int c = 0; c < CM; c++) v[c][0] = v[c][1] = 0.f;
       int sn = 1;       // number_of_channels of the mixed input
       bool ss = true;   // is_silent
-      if (!do_front) {
-        // the front half ran in an earlier stage: the mixed input of this quantum waits in the ring
+      if (!do_front && !do_node) {
+        // (only the publishing third of this item belongs to this stage: its result is recovered from the ring below)
+      } else if (!do_front) {
+        // the gather ran in an earlier stage: the mixed input of this quantum waits in the ring
         const int m = __builtin_amdgcn_readfirstlane(metab[it]);
         sn = m & 0xff;
         ss = (m >> 8) != 0;
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
         for (int c = 0; c < CM; c++)
           if (c >= sn) v[c][0] = v[c][1] = 0.f;
       }
-      if (!do_back) {  // this stage ends between the item's halves: hand the mixed input over
+      if (!do_node && !do_pub) {  // this stage ends behind the item's gather: hand the mixed input over
 #pragma unroll
         for (int c = 0; c < CM; c++) {
           mixb[((size_t)it * CM + c) * RQ + lane] = v[c][0];
@@ -309,7 +313,18 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
       int outn = sn;
       bool outs = ss;
       DYN_STAMP(0)
-      if (h_kind == DI_NODE) {
+      if (!do_node) {
+        // the node ran in an earlier stage: its result and code of this quantum wait in the ring
+        const uint32_t oc = (uint32_t)__builtin_amdgcn_readfirstlane(codes[it]);
+        outn = (int)(oc & 7u);
+        outs = (oc & CODE_SILENT) != 0;
+        const float* rs = cur + (size_t)it * CM * RQ;
+#pragma unroll
+        for (int c = 0; c < CM; c++) {
+          v[c][0] = rs[c * RQ + lane];
+          v[c][1] = rs[c * RQ + 64 + lane];
+        }
+      } else if (h_kind == DI_NODE) {
         const OpDesc& op = li.op;
         switch (h_dk) {
           case DK_GAIN: {  // gain.rs:143-199
@@ -785,14 +800,20 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
       }
       DYN_STAMP(1)
       // ---- hand over (LDS) and publish (HBM)
-      float* dst = cur + (size_t)it * CM * RQ;
-#pragma unroll
-      for (int c = 0; c < CM; c++) {
-        dst[c * RQ + lane] = c < outn ? v[c][0] : 0.f;
-        dst[c * RQ + 64 + lane] = c < outn ? v[c][1] : 0.f;
-      }
       const uint32_t code = (uint32_t)outn | (outs ? CODE_SILENT : 0u);
-      if (lane == 0) codes[it] = (int)code;
+      if (do_node) {
+        float* dst = cur + (size_t)it * CM * RQ;
+#pragma unroll
+        for (int c = 0; c < CM; c++) {
+          dst[c * RQ + lane] = c < outn ? v[c][0] : 0.f;
+          dst[c * RQ + 64 + lane] = c < outn ? v[c][1] : 0.f;
+        }
+        if (lane == 0) codes[it] = (int)code;
+      }
+      if (!do_pub) {  // (published by a later stage, out of the ring)
+        lds_sync();
+        continue;
+      }
       if (li.out.base) {
         float* gout = li.out.base + (uint64_t)inst * li.out.inst_stride;
         uint64_t f1 = f0;
@@ -830,6 +851,17 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
     for (int i = 0; i < 8; i++)
       for (int p = 0; p < 3; p++) d.cycles[i * 3 + p] = cyc[i][p];
 #endif
+}
+
+template <int CM, int W>
+__global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
+  dyn_body<CM, W>(d);
+}
+// The same body held to 96 registers (five wavefronts per SIMD instead of four; a handful of spilled registers): what a launch
+// of five or more stages per context needs for all its wavefronts to be resident at 1024 contexts (DynDesc::dense, the planner's choice)
+template <int CM, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8))) void dyn_kernel_dense(const DynDesc d) {
+  dyn_body<CM, W>(d);
 }
 
 void launch_dyn(const DynDesc& d, void* stream) {
@@ -870,11 +902,12 @@ void launch_dyn(const DynDesc& d, void* stream) {
   if (cm != 2) {
     go(dyn_kernel<6, 1>, 1);
   } else {
+    const bool dense = d.dense != 0 && !measure_switch("WAA_DYN_NO_DENSE");
     switch (stages) {
-      case 8: go(dyn_kernel<2, 8>, 8); break;
-      case 7: go(dyn_kernel<2, 7>, 7); break;
-      case 6: go(dyn_kernel<2, 6>, 6); break;
-      case 5: go(dyn_kernel<2, 5>, 5); break;
+      case 8: dense ? go(dyn_kernel_dense<2, 8>, 8) : go(dyn_kernel<2, 8>, 8); break;
+      case 7: dense ? go(dyn_kernel_dense<2, 7>, 7) : go(dyn_kernel<2, 7>, 7); break;
+      case 6: dense ? go(dyn_kernel_dense<2, 6>, 6) : go(dyn_kernel<2, 6>, 6); break;
+      case 5: dense ? go(dyn_kernel_dense<2, 5>, 5) : go(dyn_kernel<2, 5>, 5); break;
       case 4: go(dyn_kernel<2, 4>, 4); break;
       case 3: go(dyn_kernel<2, 3>, 3); break;
       case 2: go(dyn_kernel<2, 2>, 2); break;

@@ -248,25 +248,25 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     if (dyn_lds_bytes(d.n_items, d.cmax) > 160 * 1024)
       return fail(WAA_ERR_OUT_OF_SCOPE, "dynamic-count group of %d nodes with %d-channel signals does not fit the kernel's local memory",
                   d.n_items, d.cmax);
-    // ---- the quantum pipeline (waa_dyn.hip, W > 1): cut the items — in halves: unit 2 i = item i's gather + mix of its inputs, unit
-    // 2 i + 1 = its node + hand-over — into up to DYN_MAX_STAGES contiguous stages of about equal cost.  Never between a DelayNode's
+    // ---- the quantum pipeline (waa_dyn.hip, W > 1): cut the items — in thirds: unit 3 i = item i's gather + mix of its inputs, unit
+    // 3 i + 1 = its node, unit 3 i + 2 = the publication of its result — into up to DYN_MAX_STAGES contiguous stages of about equal cost.  Never between a DelayNode's
     // writer and reader (the reader looks at the writer's ring state of ITS quantum) nor inside a feedback loop (its members see
     // each other's output of the same quantum through the delay line).
     d.n_stages = 1;
     d.stage_begin[0] = 0;
-    d.stage_begin[1] = 2 * d.n_items;
+    d.stage_begin[1] = 3 * d.n_items;
     if (d.cmax <= 2 && d.n_items >= 1) {
-      const int n = d.n_items, nu = 2 * n;
+      const int n = d.n_items, nu = 3 * n;
       std::vector<uint8_t> nocut((size_t)nu, 0);  // nocut[u]: units u and u + 1 stay together
       auto keep = [&](int lo_item, int hi_item) {
-        for (int u = 2 * lo_item; u < 2 * hi_item + 1; u++) nocut[(size_t)u] = 1;
+        for (int u = 3 * lo_item; u < 3 * hi_item + 2; u++) nocut[(size_t)u] = 1;
       };
       std::map<int, std::pair<int, int>> scc_span;
       for (int k = 0; k < n; k++) {
         const uint32_t id = pending[(size_t)k] & ~VTX_READER;
         if (host[(size_t)k].kind == DI_DELAY_R) {
           keep(std::min(k, host[(size_t)k].writer_item), std::max(k, host[(size_t)k].writer_item));
-          nocut[(size_t)(2 * k)] = 1;  // (a reader has no inputs to gather: its front half is empty)
+          nocut[(size_t)(3 * k)] = 1;  // (a reader has no inputs to gather: its first third is empty)
         }
         if (scc_of[id] >= 0) {
           auto it = scc_span.find(scc_of[id]);
@@ -283,18 +283,19 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
       std::vector<double> pre((size_t)nu + 1, 0.);
       for (int k = 0; k < n; k++) {
         const DynItem& li = host[(size_t)k];
-        double front = li.kind == DI_DELAY_R ? 0. : 1.1, back = 1.9;
+        double front = li.kind == DI_DELAY_R ? 0. : 1.1, node = 0.6, pub = li.out.base ? 1.4 : 0.2;
         for (int j = 0; j < li.n_in; j++) front += li.in[j].item < 0 ? 1.4 : 0.5;
-        if (li.kind == DI_DELAY_R) back += 4.0;
-        else if (li.kind == DI_DELAY_W) back += 1.0;
-        else if (li.dk == DK_BIQUAD) back += 4.1;
-        else if (li.dk == DK_IIR) back += 9.0;
-        else if (li.dk == DK_STEREO_PAN || li.dk == DK_PANNER) back += 3.1;
-        else if (li.dk == DK_WAVESHAPER) back += 2.5;
-        else if (li.dk == DK_GAIN) back += 1.5;
-        else back += 1.2;
-        pre[(size_t)(2 * k) + 1] = pre[(size_t)(2 * k)] + front;
-        pre[(size_t)(2 * k) + 2] = pre[(size_t)(2 * k) + 1] + back;
+        if (li.kind == DI_DELAY_R) node += 4.0;
+        else if (li.kind == DI_DELAY_W) node += 1.0;
+        else if (li.dk == DK_BIQUAD) node += 4.1;
+        else if (li.dk == DK_IIR) node += 9.0;
+        else if (li.dk == DK_STEREO_PAN || li.dk == DK_PANNER) node += 3.1;
+        else if (li.dk == DK_WAVESHAPER) node += 2.5;
+        else if (li.dk == DK_GAIN) node += 1.5;
+        else node += 1.2;
+        pre[(size_t)(3 * k) + 1] = pre[(size_t)(3 * k)] + front;
+        pre[(size_t)(3 * k) + 2] = pre[(size_t)(3 * k) + 1] + node;
+        pre[(size_t)(3 * k) + 3] = pre[(size_t)(3 * k) + 2] + pub;
       }
       // best[s][i]: smallest possible largest-stage cost of the first i units in s stages; cut[s][i]: where the last stage starts
       const double INF = 1e300;
@@ -314,7 +315,10 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
       // Every stage is a wavefront, and all of a launch's wavefronts must be resident at once or the launch takes a second round
       // (r05e: five stages x 1024 contexts = 5120 wavefronts on a device that holds 4096 of this kernel — 107 registers: four per
       // SIMD — ran SLOWER than one stage): at most (CUs x 4 SIMDs x 4) / contexts stages.
-      const int max_stages = std::max(1, std::min(DYN_MAX_STAGES, (int)((uint64_t)b->n_cu * 16 / std::max<uint32_t>(b->n_inst, 1))));
+      // (five per SIMD with the 96-register build — a handful of spills — when that is what makes a fifth stage resident)
+      const int roomy = (int)((uint64_t)b->n_cu * 16 / std::max<uint32_t>(b->n_inst, 1));
+      const int dense_cap = (int)((uint64_t)b->n_cu * 20 / std::max<uint32_t>(b->n_inst, 1));
+      const int max_stages = std::max(1, std::min(DYN_MAX_STAGES, std::max(roomy, dense_cap >= 5 ? dense_cap : 0)));
       int pick = 1;
       double pick_cost = best[1][(size_t)nu];
       for (int sN = 2; sN <= max_stages; sN++) {
@@ -334,6 +338,7 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
       }
       if (pick > 1) {
         d.n_stages = pick;
+        d.dense = pick > roomy ? 1 : 0;
         int i = nu;
         for (int sN = pick; sN >= 1; sN--) {
           d.stage_begin[sN] = i;
@@ -347,7 +352,7 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     {
       std::string cuts;
       for (int sN = 1; sN < d.n_stages; sN++)
-        cuts += (cuts.empty() ? "" : ",") + std::to_string(d.stage_begin[sN] / 2) + (d.stage_begin[sN] % 2 ? "b" : "");
+        cuts += (cuts.empty() ? "" : ",") + std::to_string(d.stage_begin[sN] / 3) + (d.stage_begin[sN] % 3 == 1 ? "b" : d.stage_begin[sN] % 3 == 2 ? "c" : "");
       plan_note(b, "dynamic-count group: %d item(s) per quantum [%s]%s%s", d.n_items, desc.c_str(),
                 d.n_stages > 1 ? (", pipelined over the quanta in " + std::to_string(d.n_stages) + " stages, cut in front of item(s) ").c_str() : "",
                 cuts.c_str());
