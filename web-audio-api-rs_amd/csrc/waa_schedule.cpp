@@ -172,7 +172,8 @@ static void schedule_source_impl(const waa_batch* b, const SourceSched& cfg, uin
 
 // (measurement build, WAA_SCHED_VERIFY=1: every schedule is replayed twice — with the steady-state runs and frame by frame —
 // and the tables compared bit for bit; tests/test_schedule_runs.py reads the mismatch count)
-static std::atomic<uint64_t> g_sched_checked{0}, g_sched_mismatches{0};
+static std::atomic<uint64_t> g_sched_checked{0}, g_sched_mismatches{0}, g_sched_run_frames{0};
+extern "C" uint64_t waa_debug_sched_run_frames(void) { return g_sched_run_frames.load(); }  // frames rendered by steady-state runs so far
 extern "C" uint64_t waa_debug_sched_verify(uint64_t* checked) {
   if (checked) *checked = g_sched_checked.load();
   return g_sched_mismatches.load();
@@ -347,6 +348,7 @@ static void schedule_source_impl(const waa_batch* b, const SourceSched& cfg, uin
             rec[i + done] = SlowRec{(int32_t)prev, (int32_t)(prev + 1), playhead - pf};
           }
           if (done > 0) {
+            g_sched_run_frames.fetch_add((uint64_t)done, std::memory_order_relaxed);
             buffer_time = bts[done];
             elapsed = els[done];
             i += done - 1;
