@@ -788,6 +788,7 @@ static int resolve_source_rate_modulation(waa_batch* b) {
   b->prepass = false;
   b->steps.clear();
   b->group_tiles.clear();
+  b->qgroup_quanta.clear();
   b->state_bufs.clear();
   b->ones_bufs.clear();
   b->plan_log.clear();
@@ -1001,8 +1002,53 @@ static int run_steps(waa_batch* b) {
     }
     return e;
   };
+  // one ranged step of a quantum-blocked loop (dynamic-count plans): only the kinds the planner puts there
+  auto run_step_q = [&](const Step& st, uint32_t q0, uint32_t q1) -> int {
+    switch (st.kind) {
+      case 10: {
+        DynDesc d = st.dyn;
+        d.q0 = q0;
+        d.q1 = q1;
+        return timed(st.profile_slot, [&] { launch_dyn(d, b->stream); });
+      }
+      case 15: {
+        LinkDesc d = st.link;
+        d.q0 = q0;
+        d.q1 = q1;
+        return timed(st.profile_slot, [&] { launch_link(d, b->stream); });
+      }
+      case 17: {
+        HrtfDesc d = st.hrtf;
+        d.q0 = q0;
+        d.q1 = q1;
+        return timed(st.profile_slot, [&] { launch_hrtf(d, b->stream); });
+      }
+      case 20: {
+        OsFftDesc d = st.osfft;
+        d.q0 = q0;
+        d.q1 = q1;
+        return timed(st.profile_slot, [&] { launch_osfft(d, b->stream); });
+      }
+      default: return fail(WAA_ERR_INVALID_STATE, "internal: step kind %d inside a quantum-blocked loop", st.kind);
+    }
+  };
   for (size_t i = 0; i < b->steps.size();) {
     const Step& st = b->steps[i];
+    if (st.qgroup >= 0) {
+      // a feedback loop cut at frozen-state nodes: its launches in order, over the same few quanta each, block after block
+      size_t j = i;
+      while (j < b->steps.size() && b->steps[j].qgroup == st.qgroup) j++;
+      const uint32_t bq = std::max<uint32_t>(1, b->qgroup_quanta[(size_t)st.qgroup]);
+      for (uint32_t q0 = 0; q0 < b->n_quanta; q0 += bq) {
+        const uint32_t q1 = std::min<uint32_t>(b->n_quanta, q0 + bq);
+        for (size_t k = i; k < j; k++) {
+          int e = run_step_q(b->steps[k], q0, q1);
+          if (e) return e;
+        }
+      }
+      i = j;
+      continue;
+    }
     if (st.group < 0) {
       if (!st.echo_fused) {  // (a fused tail was rendered by its loop's launch)
         int e = run_step(st, 0, b->n_tiles);

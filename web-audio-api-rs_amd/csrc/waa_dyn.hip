@@ -159,6 +159,15 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
     pmask_s[i] = mask;
   }
   all_sync();
+  // a launch over a range of quanta that continues an earlier one (a loop rendered block by block): the items' state from memory
+  const uint32_t rq0 = d.q0, rq1 = d.q1 ? d.q1 : d.n_quanta;
+  if (d.save_f && rq0 > 0) {
+    const double* sf = d.save_f + (uint64_t)inst * (uint64_t)(d.n_items * CM * DYN_STATE);
+    const int32_t* si = d.save_i + (uint64_t)inst * (uint64_t)(d.n_items * 4);
+    for (int i = tid; i < d.n_items * CM * DYN_STATE; i += 64 * W) fst[i] = load_global(sf + i);
+    for (int i = tid; i < d.n_items * 4; i += 64 * W) ist[i] = load_global(si + i);
+    all_sync();
+  }
 
 #ifdef WAA_MEASURE
   unsigned long long cyc[8][3] = {};
@@ -185,9 +194,9 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
   // LDS ring), 3 i + 2 = the result published to memory
   const int u0 = W > 1 ? d.stage_begin[wv] : 0, u1 = W > 1 ? d.stage_begin[wv + 1] : 3 * d.n_items;
   const int it0 = u0 / 3, it1 = (u1 + 2) / 3;
-  for (uint32_t t = 0; t < d.n_quanta + (uint32_t)(W - 1); t++) {
-    const uint32_t q = t - (uint32_t)wv;  // (wraps to a huge value while this stage has nothing to do yet)
-    if (q < d.n_quanta) {
+  for (uint32_t t = rq0; t < rq1 + (uint32_t)(W - 1); t++) {
+    const uint32_t q = t - (uint32_t)wv;  // (wraps to a huge value / falls below the range while this stage has nothing to do yet)
+    if (q >= rq0 && q < rq1) {
     const uint64_t f0 = (uint64_t)q * RQ;
     const int slot = W > 1 ? (int)(q % (uint32_t)W) : 0;
     float* cur = cur_ring + (size_t)slot * d.n_items * CM * RQ;
@@ -717,15 +726,23 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
         if (lane == 0) {
           ist[it * 4 + 0] = sn;
           if (sn == 1) ist[it * 4 + 1] = (int)q;
+          if (li.xstate) {  // a reader in another launch follows the ring's state (round 5)
+            store_global(li.xstate + (uint64_t)inst * 2, sn - 1);
+            store_global(li.xstate + (uint64_t)inst * 2 + 1, (sn == 1 ? (int)q : ist[it * 4 + 1]) + 1);
+          }
         }
       } else {
         // ---- DelayReader::process, delay.rs:515-745, on the writer's line in absolute time
         vm_sync();  // the writer's stores of this quantum (if it rendered first) have reached L2
-        const DynItem& wi = items_s[h_writer_item];
-        const SignalRef& hs = wi.out;
-        const int nch = ist[h_writer_item * 4 + 0];         // ring[0].number_of_channels() right now
-        const int last_mono = ist[h_writer_item * 4 + 1];   // entries written before it were collapsed to mono
-        const uint32_t* wcode = wi.aux32 + (uint64_t)inst * wi.code_stride;
+        // (the writer: an item of this launch, or — a loop cut at a frozen-state node — of another one, seen through memory)
+        const bool xw = h_writer_item < 0;
+        const DynItem& wi = items_s[xw ? it : h_writer_item];
+        const SignalRef& hs = xw ? li.xline : wi.out;
+        const int nch = xw ? (int)coherent_u(reinterpret_cast<const uint32_t*>(li.xstate + (uint64_t)inst * 2)) + 1
+                           : ist[h_writer_item * 4 + 0];         // ring[0].number_of_channels() right now
+        const int last_mono = xw ? (int)coherent_u(reinterpret_cast<const uint32_t*>(li.xstate + (uint64_t)inst * 2 + 1)) - 1
+                                 : ist[h_writer_item * 4 + 1];   // entries written before it were collapsed to mono
+        const uint32_t* wcode = xw ? li.xaux32 + (uint64_t)inst * li.code_stride : wi.aux32 + (uint64_t)inst * wi.code_stride;
         const OpDesc& op = li.op;
         int64_t pf0 = 0;
         float k0 = 0.f;
@@ -845,6 +862,13 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
     }
     }
     if constexpr (W > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the step's hand-over (LDS only)
+  }
+  if (d.save_f) {  // ... and back, for the launch that renders the next block
+    all_sync();
+    double* sf = d.save_f + (uint64_t)inst * (uint64_t)(d.n_items * CM * DYN_STATE);
+    int32_t* si = d.save_i + (uint64_t)inst * (uint64_t)(d.n_items * 4);
+    for (int i = tid; i < d.n_items * CM * DYN_STATE; i += 64 * W) store_global(sf + i, fst[i]);
+    for (int i = tid; i < d.n_items * 4; i += 64 * W) store_global(si + i, ist[i]);
   }
 #ifdef WAA_MEASURE
   if (W == 1 && d.cycles && inst == 0 && lane == 0)

@@ -125,7 +125,69 @@ __global__ __launch_bounds__(64) void link_kernel(const LinkDesc d) {
     __syncthreads();
   }
 }
+// The same automaton over a RANGE of quanta with its state in memory between launches: the node sits inside a feedback loop that
+// is rendered block by block (round 5), so its input codes of quantum q only exist once the loop's items have rendered q.  One
+// thread per instance, a handful of quanta per launch.  State words: last + 2 (0 = LINK_SKIP never stored: the initial LINK_FRESH
+// = -1 is 1 ... so 0 means "never written" = LINK_FRESH), cur_ch - 1, the tail counter in two halves.
+__global__ __launch_bounds__(64) void link_range_kernel(const LinkDesc d) {
+  const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
+  if (inst >= d.n_inst) return;
+  int32_t* stw = d.state + (uint64_t)inst * 4;
+  int32_t last = stw[0] == 0 ? LINK_FRESH : stw[0] - 2;
+  int cur_ch = stw[1] + 1;
+  uint64_t tail_counter = (uint64_t)(uint32_t)stw[2] | ((uint64_t)(uint32_t)stw[3] << 32);
+  const uint8_t* cin = d.in_code + (uint64_t)inst * d.code_stride;
+  uint8_t* cout = d.out_code ? d.out_code + (uint64_t)inst * d.code_stride : nullptr;
+  int32_t* pv = d.prev + (uint64_t)inst * d.prev_stride;
+  for (uint32_t q = d.q0; q < d.q1; q++) {
+    const uint32_t c = cin[q];
+    const bool silent = (c & CODE_SILENT) != 0;
+    int32_t link;
+    uint8_t oc;
+    if (d.kind == 0) {  // (as in link_kernel: waveshaper.rs:395-400, 409-425)
+      if (silent && d.can_propagate_silence) {
+        link = LINK_SKIP;
+        oc = (uint8_t)(1u | CODE_SILENT);
+      } else {
+        const int nch = (int)(c & 7u);
+        if (nch != cur_ch) {
+          cur_ch = nch;
+          last = LINK_FRESH;
+        }
+        link = last;
+        last = (int32_t)q;
+        oc = (uint8_t)nch;
+      }
+    } else {  // (panner.rs:697-711)
+      bool skip = false;
+      if (silent) {
+        if (!((uint64_t)d.tail_frames > tail_counter))
+          skip = true;
+        else
+          tail_counter += RQ;
+      }
+      if (skip) {
+        link = LINK_SKIP;
+        oc = (uint8_t)(1u | CODE_SILENT);
+      } else {
+        link = last;
+        last = (int32_t)q;
+        oc = (uint8_t)2u;
+      }
+    }
+    pv[q] = link;
+    if (cout) cout[q] = oc;
+  }
+  stw[0] = last + 2;
+  stw[1] = cur_ch - 1;
+  stw[2] = (int32_t)(uint32_t)tail_counter;
+  stw[3] = (int32_t)(uint32_t)(tail_counter >> 32);
+}
 void launch_link(const LinkDesc& d, void* stream) {
+  if (d.state) {  // the ranged form
+    if (d.q1 > d.q0) hipLaunchKernelGGL(link_range_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
+    return;
+  }
   hipLaunchKernelGGL(link_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
 }
 
@@ -811,8 +873,8 @@ __global__ __launch_bounds__(256) void hrtf_kernel(const HrtfDesc d) {
   float* xw = lds + (size_t)wave * (size_t)(3 * O + RQ);
   float* hh = xw + O + RQ;  // [2][O]
   const uint32_t inst = blockIdx.y;
-  const uint32_t q = blockIdx.x * 4 + wave;
-  const bool in_range = q < d.n_quanta;
+  const uint32_t q = d.q0 + blockIdx.x * 4 + wave;
+  const bool in_range = q < d.q1;
   const int32_t* prev = d.prev + (uint64_t)inst * d.prev_stride;
   const uint8_t* code = d.in_code + (uint64_t)inst * d.code_stride;
   const int32_t link = in_range ? load_global(prev + q) : LINK_SKIP;
@@ -913,8 +975,8 @@ __global__ __launch_bounds__(64) void hrtf8_kernel(const HrtfDesc d) {
   for (int u = 0; u < 4; u++) {
     float* xw = lds + (size_t)u * (size_t)per_unit;
     float* hh = xw + O + RQ;  // [O][2]
-    const uint32_t q = blockIdx.x * 4 + u;
-    const int32_t link = q < d.n_quanta ? load_global(prev + q) : LINK_SKIP;
+    const uint32_t q = d.q0 + blockIdx.x * 4 + u;
+    const int32_t link = q < d.q1 ? load_global(prev + q) : LINK_SKIP;
     const bool process = link != LINK_SKIP;
     float gain = 0.f, corr = 1.f;
     if (process) {
@@ -967,8 +1029,8 @@ __global__ __launch_bounds__(64) void hrtf8_kernel(const HrtfDesc d) {
   }
   __syncthreads();
   const int u = lane >> 4, n0 = (lane & 15) * 8;
-  const uint32_t q = blockIdx.x * 4 + u;
-  if (q >= d.n_quanta) return;
+  const uint32_t q = d.q0 + blockIdx.x * 4 + u;
+  if (q >= d.q1) return;
   const float gain = meta[u][0], corr = meta[u][1];
   f2v acc[8];
 #pragma unroll
@@ -1028,12 +1090,16 @@ __global__ __launch_bounds__(64) void hrtf8_kernel(const HrtfDesc d) {
   *(WAA_GLOBAL_AS f4v*)(out + d.out.ch_stride) = r0;
   *(WAA_GLOBAL_AS f4v*)(out + d.out.ch_stride + 4) = r1;
 }
-void launch_hrtf(const HrtfDesc& d, void* stream) {
+void launch_hrtf(const HrtfDesc& d0, void* stream) {
+  HrtfDesc d = d0;
+  if (d.q1 == 0) d.q1 = d.n_quanta;  // (the whole render)
+  if (d.q1 <= d.q0) return;
+  const uint32_t nq_launch = d.q1 - d.q0;
   if (!measure_switch("WAA_HRTF_V1")) {
     const int O = (d.taps + 3) & ~3;
     const bool stat = d.hstatic != nullptr && !measure_switch("WAA_HRTF_DYNAMIC");
     const size_t lds = (size_t)4 * (size_t)((stat ? O : 3 * O) + RQ) * sizeof(float);
-    dim3 grid((d.n_quanta + 3) / 4, d.n_inst);
+    dim3 grid((nq_launch + 3) / 4, d.n_inst);
     if (stat) {
       hipLaunchKernelGGL(hrtf8_kernel<true>, grid, dim3(64), lds, (hipStream_t)stream, d);
       return;
@@ -1049,7 +1115,7 @@ void launch_hrtf(const HrtfDesc& d, void* stream) {
   const size_t lds = (size_t)4 * (size_t)(3 * O + RQ) * sizeof(float);
   if (lds > 64 * 1024)
     raise_lds_limit(reinterpret_cast<const void*>(hrtf_kernel));
-  dim3 grid((d.n_quanta + 3) / 4, d.n_inst);
+  dim3 grid((nq_launch + 3) / 4, d.n_inst);
   hipLaunchKernelGGL(hrtf_kernel, grid, dim3(256), lds, (hipStream_t)stream, d);
 }
 

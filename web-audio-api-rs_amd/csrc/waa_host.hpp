@@ -237,6 +237,8 @@ struct Step {
   // step lists the external signals its items read and the signals they publish
   std::vector<const void*> loop_reads, loop_writes;
   int group = -1;         // >= 0: member of a block-scheduled feedback loop (launched block by block)
+  int qgroup = -1;        // >= 0: member of a feedback loop that is cut at frozen-state nodes and launched QUANTUM BLOCK by quantum block
+                          // (dynamic-count plans, round 5: ranged dyn_kernel / link / oversampling / HRTF launches; waa_batch::qgroup_quanta)
   bool prologue = false;  // inside a group: runs once over the full range before the blocks
   // the only body step of a block-scheduled loop, and the loop qualifies for the LDS-ring kernel (waa_echo.hip): index of
   // the feedback input (-1: no) and the chunk size in 256-frame sub-tiles
@@ -284,6 +286,7 @@ struct waa_batch {
   std::vector<uint32_t> order;
   std::vector<uint8_t> cut;         // per DelayNode: writer->reader edge removed by the cycle breaker
   std::vector<uint32_t> group_tiles;  // block size (tiles) of every block-scheduled feedback loop
+  std::vector<uint32_t> qgroup_quanta;  // block size (render quanta) of every quantum-blocked loop of a dynamic-count plan
   std::vector<void*> allocs;        // plan-owned device allocations
   std::vector<void*> payload_allocs;  // buffers uploaded through the API
   std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render

@@ -463,6 +463,12 @@ struct DynItem {
   uint32_t* aux32;          // DI_DELAY_W: line codes as 32-bit words (read back by the reader of the same launch);
                             // DK_CONV_IN + compact_ch1: remap table [n_inst][code_stride]
   uint64_t code_stride;
+  // A DelayNode whose writer and reader sit in DIFFERENT launches (a feedback loop cut at a frozen-state node and rendered quantum
+  // by quantum, round 5): the reader (writer_item = -1) finds the writer's line, its codes and the ring's state here; the writer
+  // publishes that state per instance after every quantum as (count - 1, last mono quantum + 1), zero-initialised per render
+  SignalRef xline;          // DI_DELAY_R
+  const uint32_t* xaux32;   // DI_DELAY_R
+  int32_t* xstate;          // DI_DELAY_R: read; DI_DELAY_W: written (null: nobody outside the launch looks)
 };
 struct DynDesc {
   const DynItem* items;     // device memory
@@ -477,6 +483,11 @@ struct DynDesc {
   double sample_rate;
   double quantum_duration;
   unsigned long long* cycles;  // measurement build, WAA_DYN_CYCLES: [items][3] shader-clock ticks of instance 0 (gather, node, hand-over)
+  // launches over a RANGE of quanta (a loop rendered block by block, round 5): quanta [q0, q1) (q1 = 0: all), the items' filter
+  // and integer state kept in memory between launches ([n_inst][n_items * CM * DYN_STATE] doubles, [n_inst][n_items * 4] ints)
+  uint32_t q0, q1;
+  double* save_f;
+  int32_t* save_i;
 };
 void launch_dyn(const DynDesc& d, void* stream);
 constexpr int DYN_MAX_STAGES = 8;
@@ -594,6 +605,10 @@ struct LinkDesc {
   int32_t can_propagate_silence;  // kind 0 (waveshaper.rs:498-509)
   uint32_t tail_frames;     // kind 1: HRIR length (panner.rs:270-272)
   int32_t pad;
+  // ranged form (link_range_kernel: the node sits in a loop rendered block by block): quanta [q0, q1), the automaton's state
+  // per instance in memory between launches: {last, cur_ch, tail_counter lo, hi}, zero = the initial state shifted (see the kernel)
+  uint32_t q0, q1;
+  int32_t* state;
 };
 void launch_link(const LinkDesc& d, void* stream);
 
@@ -636,6 +651,7 @@ struct OsFftDesc {
   int32_t nch;              // 1 or 2
   uint32_t n_inst, n_quanta;
   uint32_t seg_len, n_seg;  // quanta per run, runs per instance (n_seg * seg_len >= n_quanta)
+  uint32_t q0, q1;          // the quanta this launch renders (q1 = 0: all); runs start at q0
 };
 void launch_osfft(const OsFftDesc& d, void* stream);
 size_t osfft_lds_bytes(int R, int curve_n);
@@ -662,6 +678,7 @@ struct HrtfDesc {
   uint32_t rows, per_row;   // rows: n_inst or 1 (nothing depends on the instance); per_row: n_quanta or 1 (static)
   int32_t taps;
   uint32_t n_inst, n_quanta;
+  uint32_t q0, q1;          // the quanta this launch renders (q1 = 0: all)
   int32_t pad;
 };
 void launch_hrtf(const HrtfDesc& d, void* stream);

@@ -56,13 +56,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
   const uint32_t inst = (uint32_t)(gid / d.n_seg), seg = (uint32_t)(gid % d.n_seg);
   const bool alive = inst < d.n_inst;
   const int32_t* prev = d.prev + (uint64_t)(alive ? inst : 0) * d.prev_stride;
-  const int q_lo = (int)(seg * d.seg_len);
-  const int q_hi = (int)((uint64_t)q_lo + d.seg_len < d.n_quanta ? q_lo + d.seg_len : d.n_quanta);
+  const int q_lo = (int)(d.q0 + seg * d.seg_len);
+  const int q_hi = (int)((uint64_t)q_lo + d.seg_len < d.q1 ? q_lo + d.seg_len : d.q1);
   // the two processed quanta in front of the run (-1: none).  The 16 lanes of the group look at 16 table entries per step.
   int p1 = -1, p2 = -1;
   if (q_lo > 0) {  // (q_lo depends on the group only through `seg`; groups past the end idle through the loop)
     int base = q_lo - 1;
-    bool searching = alive && q_lo < (int)d.n_quanta;
+    bool searching = alive && q_lo < (int)d.q1;
     while (__builtin_amdgcn_ballot_w64(searching) != 0) {
       const int qq = base - t;
       const int32_t l = (searching && qq >= 0) ? load_global(prev + qq) : LINK_SKIP;
@@ -187,7 +187,15 @@ size_t osfft_lds_bytes(int R, int curve_n) {
   const bool clds = curve_n <= CURVE_LDS_MAX;
   return ((size_t)2 * R * TAB_SLOTS + (size_t)WAVES * 4 * XSLOTS) * 8 + (clds ? (size_t)((curve_n + 4) & ~3) * 4 : 0);
 }
-void launch_osfft(const OsFftDesc& d, void* stream) {
+void launch_osfft(const OsFftDesc& d0, void* stream) {
+  OsFftDesc d = d0;
+  if (d.q1 == 0) d.q1 = d.n_quanta;  // (the whole render)
+  if (d.q0 != 0 || d.q1 != d.n_quanta) {  // a range: as many runs as it needs
+    const uint32_t nq = d.q1 > d.q0 ? d.q1 - d.q0 : 0;
+    if (nq == 0) return;
+    d.seg_len = d.seg_len < nq ? d.seg_len : nq;
+    d.n_seg = (nq + d.seg_len - 1) / d.seg_len;
+  }
   const bool clds = d.curve_n <= CURVE_LDS_MAX;
   const size_t lds = osfft_lds_bytes(d.R, d.curve_n);
   const uint64_t groups = (uint64_t)d.n_inst * d.n_seg;

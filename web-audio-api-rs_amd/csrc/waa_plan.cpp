@@ -1838,6 +1838,7 @@ static int build_plan_impl(waa_batch* b) {
           b->force_dynamic = true;
           b->steps.clear();
           b->group_tiles.clear();
+          b->qgroup_quanta.clear();
           b->state_bufs.clear();
           b->plan_log.clear();
           for (auto& nd : b->nodes) {
@@ -1970,6 +1971,7 @@ static int build_plan_impl(waa_batch* b) {
           b->no_short_ring = true;
           b->steps.clear();
           b->group_tiles.clear();
+          b->qgroup_quanta.clear();
           b->state_bufs.clear();
           b->plan_log.clear();
           for (auto& nd : b->nodes) {

@@ -63,6 +63,17 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     b->nodes[id].code = dcode;
     return 0;
   };
+  // ---- a feedback loop with frozen-state nodes inside (round 5): cut into segments at those nodes, every segment one RANGED
+  // dyn_kernel launch, the node's link / transform / FIR launches ranged too, all of them launched quantum block by quantum block
+  // (Step::qgroup).  A DelayNode whose writer and reader fall into different segments talks through memory (DynItem::xline ...).
+  struct XDelay {
+    SignalRef line{};
+    uint32_t* aux32 = nullptr;
+    int32_t* state = nullptr;
+    int writer_seg = -1, reader_seg = -1;
+  };
+  int cur_qgroup = -1;
+  std::map<uint32_t, XDelay> xdelay;  // delay node id -> cross-segment resources (only pairs that ARE split)
   // ---- one dyn_kernel launch for the pending vertices
   auto flush = [&]() -> int {
     if (pending.empty()) return 0;
@@ -122,20 +133,36 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
       char t[64];
       const uint32_t kind = n.desc.kind;
       if (is_delay(b, id)) {
+        const auto xd = cur_qgroup >= 0 ? xdelay.find(id) : xdelay.end();
         if (!reader) {
           li.kind = DI_DELAY_W;
           li.num_quanta = (int32_t)std::ceil(n.desc.d[0] * (double)b->sr / (double)RQ);  // (ring capacity - 1, as for the reader)
-          int e = temp_signal(b, n.in_nch, &li.out);  // the delay line in absolute time, native layout
-          if (e) return e;
+          int e = 0;
+          if (xd != xdelay.end()) {  // (the reader sits in another launch: line, codes and ring state were allocated for both)
+            li.out = xd->second.line;
+            li.aux32 = xd->second.aux32;
+            li.xstate = xd->second.state;
+          } else {
+            e = temp_signal(b, n.in_nch, &li.out);  // the delay line in absolute time, native layout
+            if (e) return e;
+            if ((e = dev_alloc(b, &li.aux32, (size_t)b->n_inst * cs))) return e;
+          }
           li.nch_pub = n.in_nch;
-          if ((e = dev_alloc(b, &li.aux32, (size_t)b->n_inst * cs))) return e;
           snprintf(t, sizeof t, "delayW%u", id);
         } else {
           li.kind = DI_DELAY_R;
           li.out = n.sig;
           li.nch_pub = n.out_nch;
-          li.writer_item = writer_item.at(id);
-          li.in_cycle = li.writer_item > (int)k ? 1 : 0;
+          if (xd != xdelay.end()) {
+            li.writer_item = -1;
+            li.xline = xd->second.line;
+            li.xaux32 = xd->second.aux32;
+            li.xstate = xd->second.state;
+            li.in_cycle = xd->second.writer_seg > xd->second.reader_seg ? 1 : 0;  // (the writer's launch of this quantum comes later)
+          } else {
+            li.writer_item = writer_item.at(id);
+            li.in_cycle = li.writer_item > (int)k ? 1 : 0;
+          }
           li.num_quanta = (int32_t)std::ceil(n.desc.d[0] * (double)b->sr / (double)RQ);
           int e = node_param(b, id, WAA_PARAM_DELAY_DELAY_TIME, &li.op.p0);
           if (e) return e;
@@ -255,7 +282,14 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     d.n_stages = 1;
     d.stage_begin[0] = 0;
     d.stage_begin[1] = 3 * d.n_items;
-    if (d.cmax <= 2 && d.n_items >= 1) {
+    if (cur_qgroup >= 0) {
+      // a segment of a quantum-blocked loop: ranged launches that carry the items' state through memory; no quantum pipeline
+      const int cm = d.cmax > 2 ? 6 : 2;
+      int e2 = dev_alloc(b, &d.save_f, (size_t)b->n_inst * (size_t)d.n_items * cm * DYN_STATE);
+      if (!e2) e2 = dev_alloc(b, &d.save_i, (size_t)b->n_inst * (size_t)d.n_items * 4);
+      if (e2) return e2;
+      st.qgroup = cur_qgroup;
+    } else if (d.cmax <= 2 && d.n_items >= 1) {
       const int n = d.n_items, nu = 3 * n;
       std::vector<uint8_t> nocut((size_t)nu, 0);  // nocut[u]: units u and u + 1 stay together
       auto keep = [&](int lo_item, int hi_item) {
@@ -374,14 +408,18 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     bool any_live = false;
     for (uint32_t v : verts) any_live |= b->nodes[v & ~VTX_READER].live;
     if (!any_live) continue;
+    bool frozen_loop = false;
     if (unit.scc >= 0)
       for (uint32_t v : verts) {
         const Node& m = b->nodes[v & ~VTX_READER];
         if (m.desc.kind == WAA_NODE_CONVOLVER && m.has_ir)
           return fail(WAA_ERR_OUT_OF_SCOPE, "a ConvolverNode inside a feedback loop is out of scope (node %u)", v & ~VTX_READER);
-        if (is_frozen_node(m))
-          return fail(WAA_ERR_OUT_OF_SCOPE, "an oversampled WaveShaperNode / HRTF PannerNode inside a feedback loop is out of scope (node %u)",
-                      v & ~VTX_READER);
+        if (is_frozen_node(m)) {
+          if (measure_switch("WAA_NO_FROZEN_LOOPS"))
+            return fail(WAA_ERR_OUT_OF_SCOPE, "an oversampled WaveShaperNode / HRTF PannerNode inside a feedback loop is out of scope (node %u)",
+                        v & ~VTX_READER);
+          frozen_loop = true;
+        }
       }
     // AudioParam inputs are summed by a node-major chain in front of the group: their producers must be complete
     bool param_dep = false;
@@ -396,6 +434,80 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
         }
     if (param_dep)
       if (int e = flush()) return e;
+    if (frozen_loop) {
+      // ---- the loop as a chain of ranged launches, one quantum per block: [items up to a frozen-state node -> its mixed input]
+      // [its link / transform / FIR launches] [the items behind it ...] — every launch over the same quantum, then the next quantum.
+      // (One quantum: the loop's delays are at least that long, delay.rs:693-701, and a split delay pair's reader must see the ring
+      // state of ITS quantum.)
+      for (uint32_t v : verts)
+        for (auto& pe : b->nodes[v & ~VTX_READER].pin_edges)
+          for (int e : pe)
+            if (scc_of[b->edges[e].from] == unit.scc)
+              return fail(WAA_ERR_OUT_OF_SCOPE, "an AudioParam of node %u is modulated from inside its own feedback loop", v & ~VTX_READER);
+      if (int e = flush()) return e;  // what was pending is complete before the loop starts
+      cur_qgroup = (int)b->qgroup_quanta.size();
+      b->qgroup_quanta.push_back(1);
+      // segment of every vertex; delay pairs that the cuts split
+      std::map<uint32_t, int> seg_of;
+      {
+        int sg = 0;
+        for (uint32_t v : verts) {
+          seg_of[v] = sg;
+          if (!(v & VTX_READER) && is_frozen_node(b->nodes[v])) sg++;
+        }
+      }
+      xdelay.clear();
+      for (uint32_t v : verts) {
+        const uint32_t did = v & ~VTX_READER;
+        if (!is_delay(b, did) || !(v & VTX_READER)) continue;
+        const int rs = seg_of.at(v), ws = seg_of.at(did);
+        if (rs == ws) continue;
+        XDelay xd;
+        xd.reader_seg = rs;
+        xd.writer_seg = ws;
+        int e = temp_signal(b, b->nodes[did].in_nch, &xd.line);
+        if (!e) e = dev_alloc(b, &xd.aux32, (size_t)b->n_inst * cs);
+        if (!e) e = dev_alloc(b, &xd.state, (size_t)b->n_inst * 2);
+        if (e) return e;
+        b->state_bufs.push_back({xd.state, (size_t)b->n_inst * 2 * sizeof(int32_t)});  // (count 1, never mixed to mono: zeros)
+        xdelay[did] = xd;
+      }
+      for (uint32_t v : verts) {
+        const uint32_t vid = v & ~VTX_READER;
+        Node& m = b->nodes[vid];
+        if (!m.sig.base) {
+          int e = alloc_signal(m);
+          if (e) return e;
+        }
+        pending.push_back(v);
+        pending_nodes.insert(vid);
+        if (!(v & VTX_READER) && is_frozen_node(m)) {
+          if (int e = flush()) return e;
+          if (!m.in_code) return fail(WAA_ERR_INVALID_STATE, "internal: input codes of node %u", vid);
+          const size_t first = b->steps.size();
+          int e = m.desc.kind == WAA_NODE_PANNER ? plan_hrtf(b, vid, -1) : plan_oversampler(b, vid, -1);
+          if (e) return e;
+          for (size_t k2 = first; k2 < b->steps.size(); k2++) {
+            Step& fs = b->steps[k2];
+            if (fs.kind != 15 && fs.kind != 17 && fs.kind != 20)
+              return fail(WAA_ERR_OUT_OF_SCOPE, "node %u inside a feedback loop: this form of the node has no ranged launch (step kind %d)", vid, fs.kind);
+            fs.qgroup = cur_qgroup;
+            if (fs.kind == 15) {
+              int32_t* lst = nullptr;
+              if ((e = dev_alloc(b, &lst, (size_t)b->n_inst * 4))) return e;
+              b->state_bufs.push_back({lst, (size_t)b->n_inst * 4 * sizeof(int32_t)});
+              fs.link.state = lst;
+            }
+          }
+        }
+      }
+      if (int e = flush()) return e;
+      plan_note(b, "feedback loop with a frozen-state node inside: cut at the node(s), %zu launch(es) per quantum, one quantum per block",
+                b->steps.size() ? (size_t)std::count_if(b->steps.begin(), b->steps.end(), [&](const Step& s2) { return s2.qgroup == cur_qgroup; }) : (size_t)0);
+      cur_qgroup = -1;
+      xdelay.clear();
+      continue;
+    }
     const uint32_t id = unit.id;
     Node& n = b->nodes[id];
     if (unit.scc < 0 && is_src(n.desc.kind)) {
