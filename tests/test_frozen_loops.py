@@ -122,3 +122,28 @@ def test_the_old_refusal_is_still_there_behind_its_switch(hip, monkeypatch):
         c.plan_describe()
     assert e.value.status == 4
     c.close()
+
+
+def test_automated_and_modulated_params_inside_such_a_loop(hip, orc):
+    """a chorus-like sweep of delayTime (a-rate), an automated Biquad, a gain modulated by an oscillator OUTSIDE the loop: their
+    tables and summing chains are launched once in front of the blocks (fuzz seeds 100961 / 101141 / 103054 / 103251 of r05h:
+    left between the loop's launches they cut the quantum-blocked loop in two)"""
+    def build(be):
+        c = waa.OfflineAudioContext(2, FRAMES, SR, n_instances=N, binding=be)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(white_noise(N, 2, RQ * 40, seed0=21) * 0.5, SR)
+        d = c.create_delay(0.05, delay_time=0.01)
+        d.delay_time.set_value_at_time(0.004, 0.0).linear_ramp_to_value_at_time(0.03, FRAMES / SR)
+        sh = c.create_wave_shaper(curve=CURVE, oversample="2x")
+        bq = c.create_biquad_filter(type_="bandpass", frequency=800.0, q=1.5)
+        bq.frequency.set_value_at_time(300.0, 0.0).exponential_ramp_to_value_at_time(4000.0, FRAMES / SR)
+        g = c.create_gain(gain=0.35)
+        lfo = c.create_oscillator(type_="sine", frequency=7.0)
+        lfo.connect(c.create_gain(gain=0.1)).connect(g.gain)
+        lfo.start()
+        src.connect(d)
+        d.connect(sh).connect(bq).connect(g).connect(d)
+        bq.connect(c.destination())
+        src.start()
+        return c
+    _compare(build, hip, orc)

@@ -360,20 +360,24 @@ def test_panner_equal_power_stereo_to_stereo(be):
     assert np.max(np.abs(o[0] - 0.2)) <= 1e-3 and np.max(np.abs(o[1])) <= 1e-3
 
 
-def test_panner_hrtf_in_a_feedback_loop_is_out_of_scope(be):
-    """HRTF panning itself is rendered (tests/test_hrtf.py); inside a feedback loop the product refuses it (status 4)."""
-    if be.prefix == "orc_":
-        pytest.skip("the oracle renders quantum by quantum and has no such limit")
-    c = ctx(be, 2, 8 * RQ, 44100.0)
-    s = c.create_constant_source()
-    s.start()
-    p = c.create_panner(panning_model="HRTF")
-    d = c.create_delay(1.0, delay_time=0.01)
-    s.connect(p).connect(d).connect(p)
-    d.connect(c.destination())
-    with pytest.raises(waa.WaaError) as e:
-        c.start_rendering_sync()
-    assert e.value.status == 4
+def test_panner_hrtf_in_a_feedback_loop(be, orc):
+    """HRTF panning inside a feedback loop: refused with status 4 until round 4; since round 5 the loop is rendered quantum block
+    by quantum block around the node (tests/test_frozen_loops.py) — here the smallest such graph, on both backends, the device
+    against the oracle"""
+    def render(b):
+        c = ctx(b, 2, 8 * RQ, 44100.0)
+        s = c.create_constant_source()
+        s.start()
+        p = c.create_panner(panning_model="HRTF")
+        d = c.create_delay(1.0, delay_time=0.01)
+        s.connect(p).connect(d).connect(p)
+        d.connect(c.destination())
+        return c.start_rendering_sync().data
+    out = render(be)
+    assert np.isfinite(out).all() and float(np.abs(out).max()) > 1e-3
+    if be.prefix != "orc_":
+        ref = render(orc)
+        assert np.sqrt(np.mean((out.astype(np.float64) - ref) ** 2, axis=-1)).max() <= 1e-6 * max(1.0, float(np.abs(ref).max()))
 
 
 # ----------------------------------------------------------------------------- buffer source

@@ -1038,10 +1038,16 @@ static int run_steps(waa_batch* b) {
       // a feedback loop cut at frozen-state nodes: its launches in order, over the same few quanta each, block after block
       size_t j = i;
       while (j < b->steps.size() && b->steps[j].qgroup == st.qgroup) j++;
+      for (size_t k = i; k < j; k++)
+        if (b->steps[k].prologue) {  // param tables and chains that only depend on data from outside the loop: once, whole render
+          int e = run_step(b->steps[k], 0, b->n_tiles);
+          if (e) return e;
+        }
       const uint32_t bq = std::max<uint32_t>(1, b->qgroup_quanta[(size_t)st.qgroup]);
       for (uint32_t q0 = 0; q0 < b->n_quanta; q0 += bq) {
         const uint32_t q1 = std::min<uint32_t>(b->n_quanta, q0 + bq);
         for (size_t k = i; k < j; k++) {
+          if (b->steps[k].prologue) continue;
           int e = run_step_q(b->steps[k], q0, q1);
           if (e) return e;
         }

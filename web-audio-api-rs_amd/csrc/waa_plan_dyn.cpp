@@ -445,6 +445,7 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
             if (scc_of[b->edges[e].from] == unit.scc)
               return fail(WAA_ERR_OUT_OF_SCOPE, "an AudioParam of node %u is modulated from inside its own feedback loop", v & ~VTX_READER);
       if (int e = flush()) return e;  // what was pending is complete before the loop starts
+      const size_t first_loop_step = b->steps.size();
       cur_qgroup = (int)b->qgroup_quanta.size();
       b->qgroup_quanta.push_back(1);
       // segment of every vertex; delay pairs that the cuts split
@@ -502,8 +503,26 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
         }
       }
       if (int e = flush()) return e;
-      plan_note(b, "feedback loop with a frozen-state node inside: cut at the node(s), %zu launch(es) per quantum, one quantum per block",
-                b->steps.size() ? (size_t)std::count_if(b->steps.begin(), b->steps.end(), [&](const Step& s2) { return s2.qgroup == cur_qgroup; }) : (size_t)0);
+      // Everything else the members' planning launched — AudioParam tables and summing chains (automation, modulation from OUTSIDE
+      // the loop: from inside is refused above), per-frame coefficient tables — depends on nothing inside the loop: once, over the
+      // whole render, in front of the blocks (r05h: left untagged they cut the loop's launches into two runs — garbage, and not
+      // even the same garbage twice).
+      size_t n_ranged = 0;
+      for (size_t k2 = first_loop_step; k2 < b->steps.size(); k2++) {
+        Step& ls = b->steps[k2];
+        const bool ranged = ls.kind == 10 || ls.kind == 15 || ls.kind == 17 || ls.kind == 20;
+        if (ranged && ls.qgroup != cur_qgroup) return fail(WAA_ERR_INVALID_STATE, "internal: ranged launch outside its loop");
+        if (!ranged) {
+          const bool once = ls.kind == 5 || ls.kind == 12 || ls.kind == 13 || ls.kind == 14 || ls.kind == 3 ||
+                            (ls.kind == 0 && ls.chain.n_ops == 1 && ls.chain.ops[0].kind == OP_PARAM_ADD);
+          if (!once)
+            return fail(WAA_ERR_OUT_OF_SCOPE, "a feedback loop with a frozen-state node inside needs a launch of kind %d per block: out of scope", ls.kind);
+          ls.qgroup = cur_qgroup;
+          ls.prologue = true;
+        }
+        n_ranged += ranged;
+      }
+      plan_note(b, "feedback loop with a frozen-state node inside: cut at the node(s), %zu launch(es) per quantum, one quantum per block", n_ranged);
       cur_qgroup = -1;
       xdelay.clear();
       continue;
