@@ -95,8 +95,10 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
   float* cur_ring = lds;                                                      // [W][n_items][CM][128] outputs of the last W quanta
   // (W > 1) the MIXED INPUTS of the last W quanta: an item's front half (gather + mix) and back half (node + hand-over) may
   // belong to different stages
-  float* mix_ring = cur_ring + (size_t)W * d.n_items * CM * RQ;               // [W][n_items][CM][128] (W > 1 only)
-  float* scratch_all = mix_ring + (W > 1 ? (size_t)W * d.n_items * CM * RQ : 0);  // [W][CM][128]
+  // (two slots: an item's gather and node are consecutive units, so their stages are the same or neighbours)
+  constexpr int MIXD = W > 1 ? 2 : 0;
+  float* mix_ring = cur_ring + (size_t)W * d.n_items * CM * RQ;               // [2][n_items][CM][128] (W > 1 only)
+  float* scratch_all = mix_ring + (size_t)MIXD * d.n_items * CM * RQ;         // [W][CM][128]
   double* fst = reinterpret_cast<double*>(scratch_all + (size_t)W * CM * RQ); // [n_items][CM][DYN_STATE] filter state
   int* ist = reinterpret_cast<int*>(fst + (size_t)d.n_items * CM * DYN_STATE);  // [n_items][4] integer state
   int* codes_ring = ist + (size_t)d.n_items * 4;                              // [W][n_items] codes of the last W quanta
@@ -106,11 +108,11 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
   // round trip — with one wave per instance that WAS the kernel's time (23 k cycles per quantum for ~1100 instructions).
   // per-item caches of what never changes from quantum to quantum: the params with ONE value per instance (ParamRef mode 0: a global
   // load per use, ~700 cycles each, three in a row in a panner item) and a Biquad's constant coefficient set (five doubles)
-  int* meta_ring = codes_ring + (size_t)W * d.n_items;                                // [W][n_items] count | silent << 8 of the mixed inputs (W > 1 only)
-  int* pmask_s = meta_ring + (W > 1 ? (size_t)W * d.n_items : 0);                     // [n_items] bit s: slot s is cached; bit 8: the coefficients
+  int* meta_ring = codes_ring + (size_t)W * d.n_items;                                // [2][n_items] count | silent << 8 of the mixed inputs (W > 1 only)
+  int* pmask_s = meta_ring + (size_t)MIXD * d.n_items;                                // [n_items] bit s: slot s is cached; bit 8: the coefficients
   float* pcs = reinterpret_cast<float*>(pmask_s + d.n_items);                         // [n_items][8]: op.p0 .. op.p4, alt1, alt2
   // [n_items][5], 8-byte aligned: (4 + W (+ W) + 1) n_items ints + 8 n_items floats in front, one pad word when that count is odd
-  double* cfs = reinterpret_cast<double*>(pcs + (size_t)d.n_items * 8 + (((13 + (W > 1 ? 2 * W : W)) * d.n_items) & 1));
+  double* cfs = reinterpret_cast<double*>(pcs + (size_t)d.n_items * 8 + (((13 + W + MIXD) * d.n_items) & 1));
   DynItem* items_s = reinterpret_cast<DynItem*>(cfs + (size_t)d.n_items * 5);
   const uint32_t inst = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -201,8 +203,8 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
     const int slot = W > 1 ? (int)(q % (uint32_t)W) : 0;
     float* cur = cur_ring + (size_t)slot * d.n_items * CM * RQ;
     int* codes = codes_ring + (size_t)slot * d.n_items;
-    float* mixb = mix_ring + (size_t)slot * d.n_items * CM * RQ;
-    int* metab = meta_ring + (size_t)slot * d.n_items;
+    float* mixb = mix_ring + (size_t)(q & 1u) * d.n_items * CM * RQ;
+    int* metab = meta_ring + (size_t)(q & 1u) * d.n_items;
     for (int it = it0; it < it1; it++) {
       const DynItem& li = items_s[it];
       // The item's scalar fields (the first 14 words of the descriptor) in ONE batch of LDS reads into scalar registers: read where
@@ -945,9 +947,9 @@ size_t dyn_lds_bytes(int n_items, int cmax, int stages) {
   // signals (a ring of w quanta; w > 1: a second ring, the mixed inputs) + scratch (per stage), filter state, ist (4) + codes (w)
   // (+ meta (w)) + pmask (1) ints (+ the pad word in front of the doubles), the param cache (8 floats), the coefficient cache
   // (5 doubles), the item descriptors
-  const size_t rings = w > 1 ? 2 : 1;
-  return (rings * w * n_items * cm * RQ + (size_t)w * cm * RQ) * sizeof(float) + (size_t)n_items * cm * DYN_STATE * sizeof(double) +
-         (size_t)(n_items * (5 + rings * w) + 2) * sizeof(int) + (size_t)n_items * 8 * sizeof(float) + (size_t)n_items * 5 * sizeof(double) +
+  const size_t mixd = w > 1 ? 2 : 0;  // (the mixed inputs: two slots, neighbours hand over)
+  return (((size_t)w + mixd) * n_items * cm * RQ + (size_t)w * cm * RQ) * sizeof(float) + (size_t)n_items * cm * DYN_STATE * sizeof(double) +
+         (size_t)(n_items * (5 + w + mixd) + 2) * sizeof(int) + (size_t)n_items * 8 * sizeof(float) + (size_t)n_items * 5 * sizeof(double) +
          (size_t)n_items * sizeof(DynItem);
 }
 
