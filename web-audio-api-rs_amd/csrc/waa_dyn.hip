@@ -883,13 +883,6 @@ template <int CM, int W>
 __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
   dyn_body<CM, W>(d);
 }
-// The same body held to 96 registers (five wavefronts per SIMD instead of four; a handful of spilled registers): what a launch
-// of five or more stages per context needs for all its wavefronts to be resident at 1024 contexts (DynDesc::dense, the planner's choice)
-template <int CM, int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(5, 8))) void dyn_kernel_dense(const DynDesc d) {
-  dyn_body<CM, W>(d);
-}
-
 void launch_dyn(const DynDesc& d, void* stream) {
   const int cm = d.cmax > 2 ? 6 : 2;
   // the pipelined form: mono / stereo groups the planner cut into stages (WAA_DYN_NO_PIPE=1: the one-wavefront form, A/B and cross-check)
@@ -928,12 +921,11 @@ void launch_dyn(const DynDesc& d, void* stream) {
   if (cm != 2) {
     go(dyn_kernel<6, 1>, 1);
   } else {
-    const bool dense = d.dense != 0 && !measure_switch("WAA_DYN_NO_DENSE");
     switch (stages) {
-      case 8: dense ? go(dyn_kernel_dense<2, 8>, 8) : go(dyn_kernel<2, 8>, 8); break;
-      case 7: dense ? go(dyn_kernel_dense<2, 7>, 7) : go(dyn_kernel<2, 7>, 7); break;
-      case 6: dense ? go(dyn_kernel_dense<2, 6>, 6) : go(dyn_kernel<2, 6>, 6); break;
-      case 5: dense ? go(dyn_kernel_dense<2, 5>, 5) : go(dyn_kernel<2, 5>, 5); break;
+      case 8: go(dyn_kernel<2, 8>, 8); break;
+      case 7: go(dyn_kernel<2, 7>, 7); break;
+      case 6: go(dyn_kernel<2, 6>, 6); break;
+      case 5: go(dyn_kernel<2, 5>, 5); break;
       case 4: go(dyn_kernel<2, 4>, 4); break;
       case 3: go(dyn_kernel<2, 3>, 3); break;
       case 2: go(dyn_kernel<2, 2>, 2); break;

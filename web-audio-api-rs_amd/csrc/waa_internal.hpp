@@ -479,7 +479,7 @@ struct DynDesc {
   int32_t cmax;             // widest signal of the group: <= 2 -> dyn_kernel<2>, else dyn_kernel<6> (layouts up to 5.1)
   int32_t n_stages;         // 1 .. DYN_MAX_STAGES: the item THIRDS [stage_begin[w], stage_begin[w + 1]) are stage w of the quantum pipeline
   int32_t stage_begin[9];   // (unit 3 i: item i's gather + mix, 3 i + 1: its node, 3 i + 2: the publication of its result)
-  int32_t dense;            // the launch only stays resident at five wavefronts per SIMD: the 96-register build of the kernel
+  int32_t pad;
   double sample_rate;
   double quantum_duration;
   unsigned long long* cycles;  // measurement build, WAA_DYN_CYCLES: [items][3] shader-clock ticks of instance 0 (gather, node, hand-over)

@@ -349,10 +349,9 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
       // Every stage is a wavefront, and all of a launch's wavefronts must be resident at once or the launch takes a second round
       // (r05e: five stages x 1024 contexts = 5120 wavefronts on a device that holds 4096 of this kernel — 107 registers: four per
       // SIMD — ran SLOWER than one stage): at most (CUs x 4 SIMDs x 4) / contexts stages.
-      // (five per SIMD with the 96-register build — a handful of spills — when that is what makes a fifth stage resident)
-      const int roomy = (int)((uint64_t)b->n_cu * 16 / std::max<uint32_t>(b->n_inst, 1));
-      const int dense_cap = (int)((uint64_t)b->n_cu * 20 / std::max<uint32_t>(b->n_inst, 1));
-      const int max_stages = std::max(1, std::min(DYN_MAX_STAGES, std::max(roomy, dense_cap >= 5 ? dense_cap : 0)));
+      // (A 96-register build — five wavefronts per SIMD, eight spilled registers — made a fifth stage resident at 1024 contexts and
+      // ran it at 20.8 ms against 13.1 ms for four stages, r05k: not kept.)
+      const int max_stages = std::max(1, std::min(DYN_MAX_STAGES, (int)((uint64_t)b->n_cu * 16 / std::max<uint32_t>(b->n_inst, 1))));
       int pick = 1;
       double pick_cost = best[1][(size_t)nu];
       for (int sN = 2; sN <= max_stages; sN++) {
@@ -372,7 +371,6 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
       }
       if (pick > 1) {
         d.n_stages = pick;
-        d.dense = pick > roomy ? 1 : 0;
         int i = nu;
         for (int sN = pick; sN >= 1; sN--) {
           d.stage_begin[sN] = i;
