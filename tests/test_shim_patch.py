@@ -199,3 +199,70 @@ def test_module_header_is_not_stale():
     assert "not forwarded by this first version" not in head
     for kind in ("Panner", "Delay", "Oscillator"):
         assert f"GpuNode::{kind}" in mod and kind in head
+
+
+def _strip_rust(src):
+    """comments, string / char literals and lifetimes out of Rust source (enough for a bracket check)"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            depth, i = 1, i + 2
+            while i < n and depth:
+                if src.startswith("/*", i):
+                    depth, i = depth + 1, i + 2
+                elif src.startswith("*/", i):
+                    depth, i = depth - 1, i + 2
+                else:
+                    i += 1
+        elif c == '"':
+            i += 1
+            while i < n and src[i] != '"':
+                i += 2 if src[i] == "\\" else 1
+            i += 1
+        elif c == "r" and re.match(r'r#*"', src[i:]):
+            m = re.match(r'r(#*)"', src[i:])
+            end = src.find('"' + m.group(1), i + len(m.group(0)))
+            i = n if end < 0 else end + 1 + len(m.group(1))
+        elif c == "'":
+            m = re.match(r"'(\\.|[^\\'])'", src[i:])      # a char literal ...
+            if m:
+                i += len(m.group(0))
+            else:                                           # ... or a lifetime
+                i += 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+@pytest.mark.parametrize("path", ["shim/src/gpu/mod.rs", "shim/src/gpu/ffi.rs", "shim/harness/src/main.rs", "oracle/ref_harness/src/main.rs"])
+def test_rust_sources_have_balanced_brackets(path):
+    """the cheapest thing rustc would say first: every (, [, { closes in the right order (outside comments, strings, chars)"""
+    full = os.path.join(ROOT, path)
+    if not os.path.exists(full):
+        pytest.skip(path)
+    code = _strip_rust(open(full).read())
+    stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+    line = 1
+    for ch in code:
+        if ch == "\n":
+            line += 1
+        elif ch in "([{":
+            stack.append((ch, line))
+        elif ch in ")]}":
+            assert stack and stack[-1][0] == pairs[ch], f"{path}:{line}: unmatched {ch!r} (open: {stack[-1] if stack else None})"
+            stack.pop()
+    assert not stack, f"{path}: unclosed {stack[-1]}"
+
+
+def test_patch_hunks_keep_brackets_balanced_per_added_function():
+    """every `fn gpu_desc` the patch adds is a complete item: its added lines balance their own brackets"""
+    patch = open(PATCH).read()
+    added = "\n".join(l[1:] for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++"))
+    code = _strip_rust(added)
+    assert code.count("{") == code.count("}") and code.count("(") == code.count(")") and code.count("[") == code.count("]")
+    assert code.count("fn gpu_desc") >= 14
