@@ -147,3 +147,69 @@ def test_automated_and_modulated_params_inside_such_a_loop(hip, orc):
         src.start()
         return c
     _compare(build, hip, orc)
+
+
+def _ir(n_ch, taps, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.uniform(-1, 1, (n_ch, taps)) * np.exp(-np.arange(taps) / (0.3 * taps))[None, :]).astype(np.float32)
+
+
+@pytest.mark.parametrize("delay_time", [0.0, 0.003, 0.01, 0.06])
+@pytest.mark.parametrize("ir_ch,src_ch,taps", [(2, 2, 700), (1, 1, 100), (2, 1, 16), (2, 2, 3000)])
+def test_echo_with_a_short_convolver_in_the_loop(hip, orc, ir_ch, src_ch, taps, delay_time):
+    """a ConvolverNode whose response has 128-frame partitions (at most 24 x 128 taps) inside a loop of any delay: its transforms
+    follow the loop quantum by quantum like the frozen-state nodes (status 4 until round 4 for delays below a partition / dynamic counts)"""
+    def build(be):
+        c = waa.OfflineAudioContext(2, FRAMES, SR, n_instances=N, binding=be)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(white_noise(N, src_ch, RQ * 22 + 5, seed0=31) * 0.5, SR)
+        d = c.create_delay(0.1, delay_time=delay_time)
+        cv = c.create_convolver(buffer=waa.AudioBuffer(_ir(ir_ch, taps, taps), SR))
+        g = c.create_gain(gain=0.3)
+        src.connect(d)
+        d.connect(cv).connect(g).connect(d)
+        cv.connect(c.destination())
+        for i in range(N):
+            src.start_at(i * 97.0 / SR, instance=i)
+        return c
+    if delay_time >= 0.06 and taps <= 700:
+        # a delay longer than a tile and static counts: may be the block-scheduled static loop of round 3 instead
+        _compare(build, hip, orc, what="convolver node")
+    else:
+        _compare(build, hip, orc)
+
+
+def test_convolver_and_oversampled_shaper_in_one_loop(hip, orc):
+    def build(be):
+        c = waa.OfflineAudioContext(2, FRAMES, SR, n_instances=N, binding=be)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(white_noise(N, 2, RQ * 30, seed0=33) * 0.4, SR)
+        d = c.create_delay(0.1, delay_time=0.005)
+        cv = c.create_convolver(buffer=waa.AudioBuffer(_ir(2, 300, 7), SR))
+        sh = c.create_wave_shaper(curve=CURVE, oversample="2x")
+        g = c.create_gain(gain=0.25)
+        src.connect(d)
+        d.connect(cv).connect(sh).connect(g).connect(d)
+        sh.connect(c.destination())
+        src.start()
+        return c
+    _compare(build, hip, orc)
+
+
+def test_what_stays_out_of_scope_in_a_loop(hip):
+    """a response longer than 24 x 128 taps in a short loop (its partitions span several quanta), and a mono response behind a
+    stereo input (channel 1 runs in compacted time): status 4"""
+    for ir, src_ch in ((_ir(2, 5000, 1), 2), (_ir(1, 100, 2), 2)):
+        c = waa.OfflineAudioContext(2, FRAMES, SR, n_instances=1, binding=hip)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(white_noise(1, src_ch, RQ * 9 + 3), SR)
+        d = c.create_delay(0.1, delay_time=0.003)
+        cv = c.create_convolver(buffer=waa.AudioBuffer(ir, SR))
+        src.connect(d)
+        d.connect(cv).connect(c.create_gain(gain=0.3)).connect(d)
+        cv.connect(c.destination())
+        src.start()
+        with pytest.raises(waa.WaaError) as e:
+            c.plan_describe()
+        assert e.value.status == 4, str(e.value)
+        c.close()

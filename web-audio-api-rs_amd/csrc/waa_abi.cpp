@@ -1029,6 +1029,22 @@ static int run_steps(waa_batch* b) {
         d.q1 = q1;
         return timed(st.profile_slot, [&] { launch_osfft(d, b->stream); });
       }
+      case 2: {  // a ConvolverNode with 128-frame partitions: block k of its transforms IS render quantum k
+        ConvDesc d = st.conv;
+        if (d.block != RQ) return fail(WAA_ERR_INVALID_STATE, "internal: a convolver with %d-frame partitions inside a quantum-blocked loop", d.block);
+        d.kb0 = (int)std::min<uint32_t>(q0, (uint32_t)d.nb);
+        d.kb1 = (int)std::min<uint32_t>(q1, (uint32_t)d.nb);
+        if (d.kb1 <= d.kb0) return 0;
+        if (int e = timed(st.slot_fwd, [&] { launch_conv_forward(d, b->stream); })) return e;
+        if (int e = timed(st.slot_mac, [&] { launch_conv_mac(d, b->stream); })) return e;
+        return timed(st.slot_inv, [&] { launch_conv_inverse(d, b->stream); });
+      }
+      case 11: {
+        ConvCodeDesc d = st.ccode;
+        d.q0 = q0;
+        d.q1 = q1;
+        return timed(st.profile_slot, [&] { launch_conv_codes(d, b->stream); });
+      }
       default: return fail(WAA_ERR_INVALID_STATE, "internal: step kind %d inside a quantum-blocked loop", st.kind);
     }
   };

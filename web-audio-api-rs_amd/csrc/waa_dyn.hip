@@ -973,13 +973,52 @@ __global__ void conv_code_kernel(const ConvCodeDesc d) {
     out[q] = (uint8_t)((ic == 1 && d.ir_nch == 1) ? 1u : 2u);
   }
 }
+// the same automaton over a range of quanta, its state in memory between launches (conv_code_kernel restated for one block)
+__global__ void conv_code_range_kernel(const ConvCodeDesc d) {
+  const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= d.n_inst) return;
+  const uint8_t* in = d.in_code + (uint64_t)inst * d.code_stride;
+  uint8_t* out = d.out_code + (uint64_t)inst * d.code_stride;
+  uint8_t* clean = d.clean + (uint64_t)inst * d.code_stride;
+  int32_t* stw = d.state + (uint64_t)inst * 4;
+  uint64_t tail = (uint64_t)(uint32_t)stw[0] | ((uint64_t)(uint32_t)stw[1] << 32);
+  bool ever_active = stw[2] != 0;
+  for (uint32_t q = d.q0; q < d.q1; q++) {
+    const uint32_t c = in[q];
+    clean[q] = 0;
+    if (c & CODE_SILENT) {
+      if (tail >= d.impulse_length) {
+        out[q] = (uint8_t)(1u | CODE_SILENT);
+        continue;
+      }
+      tail += RQ;
+      clean[q] = ever_active ? 0 : 1;
+    } else {
+      tail = 0;
+      ever_active = true;
+    }
+    const int ic = (int)(c & 7u);
+    out[q] = (uint8_t)((ic == 1 && d.ir_nch == 1) ? 1u : 2u);
+  }
+  stw[0] = (int32_t)(uint32_t)tail;
+  stw[1] = (int32_t)(uint32_t)(tail >> 32);
+  stw[2] = ever_active ? 1 : 0;
+}
 __global__ __launch_bounds__(128) void conv_zero_kernel(const ConvCodeDesc d) {
-  const uint32_t q = blockIdx.x, inst = blockIdx.y;
+  const uint32_t q = d.q0 + blockIdx.x, inst = blockIdx.y;
   if (!d.clean[(uint64_t)inst * d.code_stride + q]) return;
   for (int c = 0; c < d.cout; c++)
     d.out.base[(uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)q * RQ + threadIdx.x] = 0.f;
 }
-void launch_conv_codes(const ConvCodeDesc& d, void* stream) {
+void launch_conv_codes(const ConvCodeDesc& d0, void* stream) {
+  ConvCodeDesc d = d0;
+  if (d.state) {  // the ranged form
+    if (d.q1 <= d.q0) return;
+    hipLaunchKernelGGL(conv_code_range_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(conv_zero_kernel, dim3(d.q1 - d.q0, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
+    return;
+  }
+  d.q0 = 0;
   hipLaunchKernelGGL(conv_code_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
   hipLaunchKernelGGL(conv_zero_kernel, dim3(d.n_quanta, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
 }

@@ -508,6 +508,10 @@ struct ConvCodeDesc {
   // (fuzz seed 232847 of the frozen-state generator).  `clean` marks them, conv_zero_kernel clears them in `out`.
   uint8_t* clean;           // [n_inst][code_stride]
   SignalRef out;
+  // ranged form (the convolver sits in a loop rendered quantum by quantum, round 5): quanta [q0, q1), the tail counter and the
+  // "has ever been active" flag per instance in memory between launches ({tail lo, tail hi, ever_active, -}, zero-initialised)
+  uint32_t q0, q1;
+  int32_t* state;
 };
 void launch_conv_codes(const ConvCodeDesc& d, void* stream);
 

@@ -66,6 +66,7 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
   // ---- a feedback loop with frozen-state nodes inside (round 5): cut into segments at those nodes, every segment one RANGED
   // dyn_kernel launch, the node's link / transform / FIR launches ranged too, all of them launched quantum block by quantum block
   // (Step::qgroup).  A DelayNode whose writer and reader fall into different segments talks through memory (DynItem::xline ...).
+  auto is_cut_node = [&](const Node& m) { return is_frozen_node(m) || (m.desc.kind == WAA_NODE_CONVOLVER && m.has_ir); };
   struct XDelay {
     SignalRef line{};
     uint32_t* aux32 = nullptr;
@@ -394,6 +395,34 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     pending_nodes.clear();
     return 0;
   };
+  // ---- a ConvolverNode of a dynamic plan behind the group that published its mixed input: FFT steps + the code kernel
+  auto plan_dyn_convolver = [&](uint32_t id) -> int {
+    Node& n = b->nodes[id];
+    uint8_t* in_code = n.in_code;  // published by the DK_CONV_IN item of the group just flushed
+    if (!in_code) return fail(WAA_ERR_INVALID_STATE, "internal: convolver input codes");
+    int e = plan_convolver(b, id);
+    if (e) return e;
+    if ((e = alloc_codes(&n.code))) return e;
+    Step cst;
+    cst.kind = 11;
+    ConvCodeDesc& cd = cst.ccode;
+    std::memset(&cd, 0, sizeof cd);
+    cd.in_code = in_code;
+    cd.out_code = n.code;
+    cd.code_stride = cs;
+    cd.impulse_length = n.ir_len;
+    cd.ir_nch = n.ir_nch;
+    cd.n_inst = b->n_inst;
+    cd.n_quanta = b->n_quanta;
+    // (a mono impulse response on a stereo input keeps channel 1 in compacted time: only channel 0 is cleared in place)
+    cd.cout = (n.ir_nch == 1 && n.in_nch == 2) ? 1 : n.out_nch;
+    cd.out = n.sig;
+    if ((e = dev_alloc(b, &cd.clean, (size_t)b->n_inst * cs))) return e;
+    cst.loop_writes.push_back(n.sig.base);
+    cst.profile_slot = slot_for(b, "conv_code_kernel");
+    b->steps.push_back(cst);
+    return 0;
+  };
   for (const Unit& unit : units) {
     std::vector<uint32_t> verts;
     if (unit.scc >= 0) {
@@ -410,8 +439,15 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     if (unit.scc >= 0)
       for (uint32_t v : verts) {
         const Node& m = b->nodes[v & ~VTX_READER];
-        if (m.desc.kind == WAA_NODE_CONVOLVER && m.has_ir)
-          return fail(WAA_ERR_OUT_OF_SCOPE, "a ConvolverNode inside a feedback loop is out of scope (node %u)", v & ~VTX_READER);
+        if (m.desc.kind == WAA_NODE_CONVOLVER && m.has_ir) {
+          // (round 5) a response of at most 24 x 128 frames has 128-frame partitions: its transforms can follow the loop quantum by
+          // quantum like the frozen-state nodes.  Longer responses (a partition spans several quanta) and a mono response behind a
+          // stereo input (channel 1 runs in compacted time) stay out of scope.
+          const bool ok = !(v & VTX_READER) && conv_block_size(b, m) == RQ && !(m.ir_nch == 1 && m.in_nch == 2) && !measure_switch("WAA_NO_FROZEN_LOOPS");
+          if (!ok)
+            return fail(WAA_ERR_OUT_OF_SCOPE, "a ConvolverNode inside a feedback loop is out of scope (node %u)", v & ~VTX_READER);
+          frozen_loop = true;
+        }
         if (is_frozen_node(m)) {
           if (measure_switch("WAA_NO_FROZEN_LOOPS"))
             return fail(WAA_ERR_OUT_OF_SCOPE, "an oversampled WaveShaperNode / HRTF PannerNode inside a feedback loop is out of scope (node %u)",
@@ -452,7 +488,7 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
         int sg = 0;
         for (uint32_t v : verts) {
           seg_of[v] = sg;
-          if (!(v & VTX_READER) && is_frozen_node(b->nodes[v])) sg++;
+          if (!(v & VTX_READER) && is_cut_node(b->nodes[v])) sg++;
         }
       }
       xdelay.clear();
@@ -480,22 +516,26 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
         }
         pending.push_back(v);
         pending_nodes.insert(vid);
-        if (!(v & VTX_READER) && is_frozen_node(m)) {
+        if (!(v & VTX_READER) && is_cut_node(m)) {
           if (int e = flush()) return e;
           if (!m.in_code) return fail(WAA_ERR_INVALID_STATE, "internal: input codes of node %u", vid);
           const size_t first = b->steps.size();
-          int e = m.desc.kind == WAA_NODE_PANNER ? plan_hrtf(b, vid, -1) : plan_oversampler(b, vid, -1);
+          int e = m.desc.kind == WAA_NODE_CONVOLVER ? plan_dyn_convolver(vid)
+                  : m.desc.kind == WAA_NODE_PANNER  ? plan_hrtf(b, vid, -1)
+                                                    : plan_oversampler(b, vid, -1);
           if (e) return e;
           for (size_t k2 = first; k2 < b->steps.size(); k2++) {
             Step& fs = b->steps[k2];
-            if (fs.kind != 15 && fs.kind != 17 && fs.kind != 20)
+            if (fs.kind != 15 && fs.kind != 17 && fs.kind != 20 && fs.kind != 2 && fs.kind != 11)
               return fail(WAA_ERR_OUT_OF_SCOPE, "node %u inside a feedback loop: this form of the node has no ranged launch (step kind %d)", vid, fs.kind);
+            if (fs.kind == 2 && fs.conv.block != RQ)
+              return fail(WAA_ERR_OUT_OF_SCOPE, "a ConvolverNode inside a feedback loop is out of scope (node %u: %d-frame partitions)", vid, fs.conv.block);
             fs.qgroup = cur_qgroup;
-            if (fs.kind == 15) {
+            if (fs.kind == 15 || fs.kind == 11) {
               int32_t* lst = nullptr;
               if ((e = dev_alloc(b, &lst, (size_t)b->n_inst * 4))) return e;
               b->state_bufs.push_back({lst, (size_t)b->n_inst * 4 * sizeof(int32_t)});
-              fs.link.state = lst;
+              (fs.kind == 15 ? fs.link.state : fs.ccode.state) = lst;
             }
           }
         }
@@ -508,7 +548,7 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
       size_t n_ranged = 0;
       for (size_t k2 = first_loop_step; k2 < b->steps.size(); k2++) {
         Step& ls = b->steps[k2];
-        const bool ranged = ls.kind == 10 || ls.kind == 15 || ls.kind == 17 || ls.kind == 20;
+        const bool ranged = ls.kind == 10 || ls.kind == 15 || ls.kind == 17 || ls.kind == 20 || ls.kind == 2 || ls.kind == 11;
         if (ranged && ls.qgroup != cur_qgroup) return fail(WAA_ERR_INVALID_STATE, "internal: ranged launch outside its loop");
         if (!ranged) {
           const bool once = ls.kind == 5 || ls.kind == 12 || ls.kind == 13 || ls.kind == 14 || ls.kind == 3 ||
@@ -559,29 +599,7 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     if (unit.scc < 0 && n.desc.kind == WAA_NODE_CONVOLVER && n.has_ir) {
       // the group ends with the convolver's mixed input; then the node-major FFT steps and the code kernel
       if (int e = flush()) return e;
-      uint8_t* in_code = n.in_code;  // published by the DK_CONV_IN item of the group just flushed
-      if (!in_code) return fail(WAA_ERR_INVALID_STATE, "internal: convolver input codes");
-      int e = plan_convolver(b, id);
-      if (e) return e;
-      if ((e = alloc_codes(&n.code))) return e;
-      Step cst;
-      cst.kind = 11;
-      ConvCodeDesc& cd = cst.ccode;
-      std::memset(&cd, 0, sizeof cd);
-      cd.in_code = in_code;
-      cd.out_code = n.code;
-      cd.code_stride = cs;
-      cd.impulse_length = n.ir_len;
-      cd.ir_nch = n.ir_nch;
-      cd.n_inst = b->n_inst;
-      cd.n_quanta = b->n_quanta;
-      // (a mono impulse response on a stereo input keeps channel 1 in compacted time: only channel 0 is cleared in place)
-      cd.cout = (n.ir_nch == 1 && n.in_nch == 2) ? 1 : n.out_nch;
-      cd.out = n.sig;
-      if ((e = dev_alloc(b, &cd.clean, (size_t)b->n_inst * cs))) return e;
-      cst.loop_writes.push_back(n.sig.base);
-      cst.profile_slot = slot_for(b, "conv_code_kernel");
-      b->steps.push_back(cst);
+      if (int e = plan_dyn_convolver(id)) return e;
     }
   }
   if (int e = flush()) return e;
