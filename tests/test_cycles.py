@@ -202,8 +202,9 @@ def test_parity_ping_pong_loop(hip, orc, modulated):
 def test_node_kinds_outside_the_static_loop_kernel_go_to_the_dynamic_path(hip, orc):
     """An IIRFilter inside a short feedback loop: the static loop kernel does not cover it (status 4 in round 1); the
     planner now renders the whole graph quantum by quantum with dyn_kernel.  A ConvolverNode inside a loop whose delay is
-    shorter than one partition of its impulse response is still refused (FFT convolvers are node-major launches; the
-    block-scheduled form below needs a whole partition per block)."""
+    shorter than one partition of its impulse response was refused until round 4; since round 5 a response with 128-frame
+    partitions follows the loop quantum by quantum (tests/test_frozen_loops.py) — a LONGER response (partitions of several
+    quanta) in such a loop is still refused."""
     outs = []
     for be in (hip, orc):
         c = waa.OfflineAudioContext(2, RQ * 40, 48000.0, n_instances=2, binding=be)
@@ -222,7 +223,7 @@ def test_node_kinds_outside_the_static_loop_kernel_go_to_the_dynamic_path(hip, o
     c = waa.OfflineAudioContext(2, RQ * 4, 48000.0, n_instances=1, binding=hip)
     src = c.create_constant_source()
     d = c.create_delay(0.1, delay_time=0.01)
-    conv = c.create_convolver(buffer=waa.AudioBuffer(np.ones((1, 300), np.float32), 48000.0))
+    conv = c.create_convolver(buffer=waa.AudioBuffer(np.ones((1, 5000), np.float32), 48000.0))
     src.connect(d)
     d.connect(conv).connect(d)
     d.connect(c.destination())

@@ -560,7 +560,7 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
         }
         n_ranged += ranged;
       }
-      plan_note(b, "feedback loop with a frozen-state node inside: cut at the node(s), %zu launch(es) per quantum, one quantum per block", n_ranged);
+      plan_note(b, "feedback loop with a frozen-state node inside (oversampled WaveShaper / HRTF panner / short ConvolverNode): cut at the node(s), %zu launch step(s) per quantum, one quantum per block", n_ranged);
       cur_qgroup = -1;
       xdelay.clear();
       continue;
