@@ -296,7 +296,7 @@ def test_parity_convolver_inside_a_block_scheduled_loop(hip, orc, name):
 
 
 def test_plan_convolver_inside_a_loop(hip):
-    """plan only (CPU): the block is a whole number of partitions; a loop delay shorter than a partition is refused"""
+    """plan only (CPU): the block is a whole number of partitions; a loop delay shorter than a partition of a LONG response is refused"""
     noise = white_noise(2, 2, 2048 * 30)
     c = _convolver_loop(hip, noise, _decaying_ir(2, 60000, 1, 0.01), 0.5, 0.5, 2048 * 30, device=waa.PLAN_ONLY)
     plan = c.plan_describe()
@@ -311,8 +311,14 @@ def test_plan_convolver_inside_a_loop(hip):
         c.plan_describe()
     assert ei.value.status == 4 and "ConvolverNode inside a feedback loop" in str(ei.value)
     c.close()
-    # channel counts that change during the render (the source ends) need the quantum-serial dynamic path: refused
+    # channel counts that change during the render (the source ends) need the quantum-serial dynamic path: since round 5 a
+    # response with 128-frame partitions follows the loop quantum by quantum there (tests/test_frozen_loops.py) ...
     c = _convolver_loop(hip, noise[:, :, :2048 * 8], _decaying_ir(2, 3000, 1, 0.01), 0.1, 0.5, 2048 * 30, device=waa.PLAN_ONLY)
+    plan = c.plan_describe()
+    assert "fft B=128" in plan and "cut at the node(s)" in plan and "one quantum per block" in plan, plan
+    c.close()
+    # ... a longer response (partitions of several quanta) is still refused
+    c = _convolver_loop(hip, noise[:, :, :2048 * 8], _decaying_ir(2, 9000, 1, 0.01), 0.1, 0.5, 2048 * 30, device=waa.PLAN_ONLY)
     with pytest.raises(waa.WaaError) as ei:
         c.plan_describe()
     assert ei.value.status == 4 and "ConvolverNode inside a feedback loop" in str(ei.value)
