@@ -27,6 +27,11 @@ for S in "$@"; do
     pmc:*)  W=${S#pmc:}; timeout 600 bash tools/pmc_pass.sh $W ${TAG}_$W > /dev/null 2>&1; head -12 gpurun_out/${TAG}_${W}_stats.txt ;;
     line:*) W=${S#line:}; timeout 300 python bench.py --workload $W --steps 5 --warmup 2 --sustain 0 --no-cpu-baseline --no-extra > gpurun_out/${TAG}_bench_$W.json 2> gpurun_out/${TAG}_bench_$W.err; cat gpurun_out/${TAG}_bench_$W.json | cut -c1-1500 ;;
     fuzz:*) N=${S#fuzz:}; timeout 1500 python tools/fuzz_campaign.py --first 100000 --count $N --jobs 8 --out gpurun_out/${TAG}_fuzz.json 2> gpurun_out/${TAG}_fuzz.err | cut -c1-3000; tail -3 gpurun_out/${TAG}_fuzz.err ;;
+    determinism) # the same process, the same bits twice?  (tools/determinism_campaign.py, one process on the device, ~4 min)
+            timeout 600 python tools/determinism_campaign.py --first 800000 --count 25000 --repeats 6 --rebuild-every 8 --jobs 1 --hot-repeats 300 --seconds 240 --out gpurun_out/${TAG}_determinism.json 2> gpurun_out/${TAG}_determinism.err | cut -c1-1500 ;;
+    fuzzvariants) # the two campaign variants on fresh seeds: mixed channel counts, poisoned fresh device memory
+            FUZZ_MIXED_COUNTS=1 timeout 600 python tools/fuzz_campaign.py --first 300000 --count 4000 --jobs 8 --out gpurun_out/${TAG}_fuzz_mixed.json 2> /dev/null | cut -c1-1500
+            WAA_POISON_ALLOC=1 timeout 600 python tools/fuzz_campaign.py --first 400000 --count 4000 --jobs 8 --out gpurun_out/${TAG}_fuzz_poisoned.json 2> /dev/null | cut -c1-1500 ;;
     box)    # which kind of box is this?  the copy floor of the C2 access pattern (tools/stream_probe, built in-tree) + clocks
             { echo "# $(date -u) $(hostname)"; rocm-smi --showclocks --showpower --showmemuse 2>/dev/null | grep -v "^=\|^$" | head -30;
               timeout 120 tools/stream_probe 2>&1 | head -20; } > gpurun_out/${TAG}_box.txt 2>&1; grep -E "linear 256x65536|stream tile 2048 |sclk|mclk|fclk" gpurun_out/${TAG}_box.txt | head -8 ;;
