@@ -9,7 +9,7 @@
 #   fuzz:<n>   tools/fuzz_campaign.py over n seeds per generator
 #   ranks:<n>  `python bench.py --gpus n` with no launcher (it spawns the ranks; WAA_BENCH_SHARE_GPU: they share this box's GPU)
 #   dyn        tools/dyn_probe.py: dyn_kernel's quantum pipeline against the one-wavefront form
-#   t:<files>  pytest -m gpu -x on the '+'-separated test files
+#   t:<files>  pytest -m gpu -x on the '+'-separated test files (ta:<files>: without -x, every failure listed)
 #   box        copy floor of this box (tools/stream_probe) + rocm-smi clocks: C2 ran 1.35 ... 1.60 ms depending on the box
 #   plantrace:<w>  WAA_PLAN_TRACE of workload <w> (measurement build): where build_plan's host time goes
 set -u
@@ -44,6 +44,7 @@ for S in "$@"; do
               echo "## WAA_DYN_NO_PIPE=${WAA_DYN_NO_PIPE:-unset}"; timeout 300 python tools/dyn_probe.py 2>&1 | grep -E "dynamic-count group|dyn_kernel|first render"
             done; done > gpurun_out/${TAG}_dyn_probe.txt 2>&1; unset WAA_DYN_NO_PIPE; cat gpurun_out/${TAG}_dyn_probe.txt ;;
     t:*)    F=${S#t:}; timeout 900 python -m pytest ${F//+/ } -m gpu -q -x > gpurun_out/${TAG}_tests_sel.log 2>&1; echo "rc=$?"; tail -6 gpurun_out/${TAG}_tests_sel.log ;;
+    ta:*)   F=${S#ta:}; timeout 900 python -m pytest ${F//+/ } -m gpu -q > gpurun_out/${TAG}_tests_all.log 2>&1; echo "rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_tests_all.log | cut -c1-300 | tail -30 ;;
     *) echo "unknown section $S" ;;
   esac
 done

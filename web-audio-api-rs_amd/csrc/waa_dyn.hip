@@ -947,80 +947,140 @@ size_t dyn_lds_bytes(int n_items, int cmax, int stages) {
 
 // ConvolverRenderer::process on codes (convolver.rs:343-392): the tail counter cuts the output off once a silent input
 // has lasted for the length of the impulse response; the output count follows the routing table (:384-466).
+struct ConvCodeState {
+  uint64_t tail;
+  bool ever_active;  // (an input that has never been active: the convolver's output is exact zeros, see ConvCodeDesc)
+  ConvNoiseState cv[4];
+};
+// quanta [qa, qb) of one instance.  On entry clean[q] holds the non-zero flags of the input quantum (conv_nz_kernel; noise form).
+__device__ inline void conv_code_quanta(const ConvCodeDesc& d, uint32_t inst, uint32_t qa, uint32_t qb, ConvCodeState& s) {
+  const uint8_t* in = d.in_code + (uint64_t)inst * d.code_stride;
+  uint8_t* out = d.out_code + (uint64_t)inst * d.code_stride;
+  uint8_t* clean = d.clean + (uint64_t)inst * d.code_stride;
+  const uint32_t chmask = d.cout >= 2 ? 3u : 1u;  // (channels of `out` in absolute time)
+  for (uint32_t q = qa; q < qb; q++) {
+    const uint32_t c = in[q];
+    const uint32_t nz = d.noise ? clean[q] : 0u;
+    clean[q] = 0;
+    if (c & CODE_SILENT) {
+      if (s.tail >= d.impulse_length) {
+        out[q] = (uint8_t)(1u | CODE_SILENT);
+        continue;  // (the reference does not call its convolvers: their blocks stand still)
+      }
+      s.tail += RQ;
+      if (!d.noise) clean[q] = s.ever_active ? 0 : 1;
+    } else {
+      s.tail = 0;
+      s.ever_active = true;
+    }
+    const int ic = (int)(c & 7u);
+    const uint32_t outn = (ic == 1 && d.ir_nch == 1) ? 1u : 2u;
+    out[q] = (uint8_t)outn;
+    if (d.noise) {
+      // which FFTConvolver hears which input channel: convolver.rs:384-466 (a silent input is one channel of zeros)
+      const bool l = (nz & 1u) != 0, r = ic == 2 ? (nz & 2u) != 0 : l;
+      uint32_t noisy;
+      if (d.ir_nch == 4) {
+        const bool o0 = conv_noise_step(d.nir[0], s.cv[0], l), o1 = conv_noise_step(d.nir[1], s.cv[1], l);
+        const bool o2 = conv_noise_step(d.nir[2], s.cv[2], r), o3 = conv_noise_step(d.nir[3], s.cv[3], r);
+        noisy = ((o0 || o2) ? 1u : 0u) | ((o1 || o3) ? 2u : 0u);
+      } else if (outn == 1) {
+        noisy = conv_noise_step(d.nir[0], s.cv[0], l) ? 1u : 0u;
+      } else {
+        const bool o0 = conv_noise_step(d.nir[0], s.cv[0], l);
+        const bool o1 = conv_noise_step(d.nir[1], s.cv[1], ic == 2 ? r : l);
+        noisy = (o0 ? 1u : 0u) | (o1 ? 2u : 0u);
+      }
+      const uint32_t live = (outn == 2 ? 3u : 1u) & chmask;
+      clean[q] = (uint8_t)((~noisy & live) | ((noisy & live) << 2));
+    }
+  }
+}
 __global__ void conv_code_kernel(const ConvCodeDesc d) {
   const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
   if (inst >= d.n_inst) return;
-  const uint8_t* in = d.in_code + (uint64_t)inst * d.code_stride;
-  uint8_t* out = d.out_code + (uint64_t)inst * d.code_stride;
-  uint8_t* clean = d.clean + (uint64_t)inst * d.code_stride;
-  uint64_t tail = 0;
-  bool ever_active = false;  // (an input that has never been active: the convolver's output is exact zeros, see ConvCodeDesc)
-  for (uint32_t q = 0; q < d.n_quanta; q++) {
-    const uint32_t c = in[q];
-    clean[q] = 0;
-    if (c & CODE_SILENT) {
-      if (tail >= d.impulse_length) {
-        out[q] = (uint8_t)(1u | CODE_SILENT);
-        continue;
-      }
-      tail += RQ;
-      clean[q] = ever_active ? 0 : 1;
-    } else {
-      tail = 0;
-      ever_active = true;
-    }
-    const int ic = (int)(c & 7u);
-    out[q] = (uint8_t)((ic == 1 && d.ir_nch == 1) ? 1u : 2u);
-  }
+  ConvCodeState s;
+  s.tail = 0;
+  s.ever_active = false;
+  for (int k = 0; k < 4; k++) conv_noise_reset(s.cv[k]);
+  conv_code_quanta(d, inst, 0, d.n_quanta, s);
 }
-// the same automaton over a range of quanta, its state in memory between launches (conv_code_kernel restated for one block)
+// the same automaton over a range of quanta, its state in memory between launches
 __global__ void conv_code_range_kernel(const ConvCodeDesc d) {
   const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
   if (inst >= d.n_inst) return;
-  const uint8_t* in = d.in_code + (uint64_t)inst * d.code_stride;
-  uint8_t* out = d.out_code + (uint64_t)inst * d.code_stride;
-  uint8_t* clean = d.clean + (uint64_t)inst * d.code_stride;
-  int32_t* stw = d.state + (uint64_t)inst * 4;
-  uint64_t tail = (uint64_t)(uint32_t)stw[0] | ((uint64_t)(uint32_t)stw[1] << 32);
-  bool ever_active = stw[2] != 0;
-  for (uint32_t q = d.q0; q < d.q1; q++) {
-    const uint32_t c = in[q];
-    clean[q] = 0;
-    if (c & CODE_SILENT) {
-      if (tail >= d.impulse_length) {
-        out[q] = (uint8_t)(1u | CODE_SILENT);
-        continue;
-      }
-      tail += RQ;
-      clean[q] = ever_active ? 0 : 1;
+  int32_t* stw = d.state + (uint64_t)inst * CONV_CODE_STATE_INTS;
+  ConvCodeState s;
+  s.tail = (uint64_t)(uint32_t)stw[0] | ((uint64_t)(uint32_t)stw[1] << 32);
+  s.ever_active = stw[2] != 0;
+  for (int k = 0; k < 4; k++) {
+    if (stw[3]) {
+      s.cv[k].hist = (uint64_t)(uint32_t)stw[4 + 4 * k] | ((uint64_t)(uint32_t)stw[5 + 4 * k] << 32);
+      s.cv[k].age = (uint32_t)stw[6 + 4 * k];
+      s.cv[k].flags = (uint32_t)stw[7 + 4 * k];
     } else {
-      tail = 0;
-      ever_active = true;
+      conv_noise_reset(s.cv[k]);  // (the state arrives zero-filled)
     }
-    const int ic = (int)(c & 7u);
-    out[q] = (uint8_t)((ic == 1 && d.ir_nch == 1) ? 1u : 2u);
   }
-  stw[0] = (int32_t)(uint32_t)tail;
-  stw[1] = (int32_t)(uint32_t)(tail >> 32);
-  stw[2] = ever_active ? 1 : 0;
+  conv_code_quanta(d, inst, d.q0, d.q1, s);
+  stw[0] = (int32_t)(uint32_t)s.tail;
+  stw[1] = (int32_t)(uint32_t)(s.tail >> 32);
+  stw[2] = s.ever_active ? 1 : 0;
+  stw[3] = 1;
+  for (int k = 0; k < 4; k++) {
+    stw[4 + 4 * k] = (int32_t)(uint32_t)s.cv[k].hist;
+    stw[5 + 4 * k] = (int32_t)(uint32_t)(s.cv[k].hist >> 32);
+    stw[6 + 4 * k] = (int32_t)s.cv[k].age;
+    stw[7 + 4 * k] = (int32_t)s.cv[k].flags;
+  }
 }
-__global__ __launch_bounds__(128) void conv_zero_kernel(const ConvCodeDesc d) {
+// does channel c of input quantum q hold a non-zero sample?  (bit c of clean[q], read back by the code kernel; a quantum coded
+// silent is zeros in the reference whatever the buffer holds)
+__global__ __launch_bounds__(128) void conv_nz_kernel(const ConvCodeDesc d) {
   const uint32_t q = d.q0 + blockIdx.x, inst = blockIdx.y;
-  if (!d.clean[(uint64_t)inst * d.code_stride + q]) return;
-  for (int c = 0; c < d.cout; c++)
-    d.out.base[(uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)q * RQ + threadIdx.x] = 0.f;
+  const uint32_t code = d.in_code[(uint64_t)inst * d.code_stride + q];
+  uint32_t bits = 0;
+  if (!(code & CODE_SILENT)) {
+    const int ic = (int)(code & 7u);
+    for (int c = 0; c < ic && c < d.in_test_nch; c++) {
+      const float v = d.in.base[(uint64_t)inst * d.in.inst_stride + (uint64_t)c * d.in.ch_stride + (uint64_t)q * RQ + threadIdx.x];
+      if (__syncthreads_or(v != 0.f)) bits |= 1u << c;
+    }
+  }
+  if (threadIdx.x == 0) d.clean[(uint64_t)inst * d.code_stride + q] = (uint8_t)bits;
+}
+__global__ __launch_bounds__(128) void conv_floor_kernel(const ConvCodeDesc d) {
+  const uint32_t q = d.q0 + blockIdx.x, inst = blockIdx.y;
+  const uint32_t m = d.clean[(uint64_t)inst * d.code_stride + q];
+  if (!m) return;
+  if (!d.noise) {  // the round-3 form: the whole quantum is exact zeros
+    for (int c = 0; c < d.cout; c++)
+      d.out.base[(uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)q * RQ + threadIdx.x] = 0.f;
+    return;
+  }
+  for (int c = 0; c < 2 && c < d.cout; c++) {
+    float* p = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)q * RQ + threadIdx.x;
+    if (m & (1u << c)) {
+      *p = 0.f;
+    } else if (m & (4u << c)) {
+      const float v = *p;
+      if (__builtin_fabsf(v) < CONV_NOISE_FLOOR) *p = __builtin_copysignf(CONV_NOISE_FLOOR, v);
+    }
+  }
 }
 void launch_conv_codes(const ConvCodeDesc& d0, void* stream) {
   ConvCodeDesc d = d0;
   if (d.state) {  // the ranged form
     if (d.q1 <= d.q0) return;
+    if (d.noise) hipLaunchKernelGGL(conv_nz_kernel, dim3(d.q1 - d.q0, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
     hipLaunchKernelGGL(conv_code_range_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
-    hipLaunchKernelGGL(conv_zero_kernel, dim3(d.q1 - d.q0, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(conv_floor_kernel, dim3(d.q1 - d.q0, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
     return;
   }
   d.q0 = 0;
+  if (d.noise) hipLaunchKernelGGL(conv_nz_kernel, dim3(d.n_quanta, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
   hipLaunchKernelGGL(conv_code_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
-  hipLaunchKernelGGL(conv_zero_kernel, dim3(d.n_quanta, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
+  hipLaunchKernelGGL(conv_floor_kernel, dim3(d.n_quanta, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
 }
 
 }  // namespace waa

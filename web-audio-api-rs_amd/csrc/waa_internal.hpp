@@ -4,6 +4,8 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include "waa_conv_noise.hpp"
+
 namespace waa {
 
 // Switches read from the environment.  Four are part of the library's behaviour and documented:
@@ -505,14 +507,25 @@ struct ConvCodeDesc {
   // gets ~1e-9 of its partner's signal through the roundoff of the complex arithmetic — where the reference's convolver (one
   // per context) puts out exact zeros.  Quanta the reference still processes there (tail counter < impulse length: coded
   // active) must BE zeros, or every filter behind them starts a "tail" on that noise and the silence flags drift apart
-  // (fuzz seed 232847 of the frozen-state generator).  `clean` marks them, conv_zero_kernel clears them in `out`.
+  // (fuzz seed 232847 of the frozen-state generator).  `clean` marks them, conv_floor_kernel clears them in `out`.
   uint8_t* clean;           // [n_inst][code_stride]
   SignalRef out;
   // ranged form (the convolver sits in a loop rendered quantum by quantum, round 5): quanta [q0, q1), the tail counter and the
-  // "has ever been active" flag per instance in memory between launches ({tail lo, tail hi, ever_active, -}, zero-initialised)
+  // "has ever been active" flag per instance in memory between launches ({tail lo, tail hi, ever_active, initialised}, zero-initialised)
   uint32_t q0, q1;
   int32_t* state;
+  // Round 5: the reference's FFT convolver leaves roundoff noise — never exact zeros — for up to two 1024-frame
+  // blocks around anything non-zero in its input, and data-dependent silence behind it (a DelayNode that "read nothing but zeros")
+  // follows that noise.  With `noise` set the code kernel runs waa_conv_noise.hpp's automaton per FFTConvolver of the node over
+  // the non-zero flags of the input quanta (conv_nz_kernel: `in`, `in_test_nch` channels of it are in absolute time) and marks in
+  // `clean`, per output channel c, bit c = "exact zeros in the reference: clear" / bit 2 + c = "noise in the reference: raise
+  // |samples| below CONV_NOISE_FLOOR to it" (conv_floor_kernel).  The ranged form keeps the four automata behind the tail counter:
+  // CONV_CODE_STATE_INTS ints per instance.
+  int32_t noise, in_test_nch;
+  SignalRef in;
+  ConvNoiseIr nir[4];
 };
+constexpr int CONV_CODE_STATE_INTS = 4 + 4 * 4;
 void launch_conv_codes(const ConvCodeDesc& d, void* stream);
 
 // ---- per-frame biquad coefficients for a-rate params (biquad_filter.rs:837-855) -------------

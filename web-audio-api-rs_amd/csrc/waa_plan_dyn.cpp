@@ -4,6 +4,7 @@
 // a quantum-serial dyn_kernel launch that carries per-quantum codes (count | silent) with every signal.  A convolver / frozen-state
 // node splits the items into groups (its input is produced by the group in front of it, its output consumed by the group behind it).
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <set>
@@ -418,6 +419,32 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     cd.cout = (n.ir_nch == 1 && n.in_nch == 2) ? 1 : n.out_nch;
     cd.out = n.sig;
     if ((e = dev_alloc(b, &cd.clean, (size_t)b->n_inst * cs))) return e;
+    // (round 5) where the reference's FFT convolver leaves roundoff noise instead of exact zeros: one automaton per
+    // FFTConvolver of the node (convolver.rs:291-306: one per channel of the response, at least two), fed by the non-zero flags of
+    // the input quanta; waa_conv_noise.hpp
+    cd.noise = n.hist.base && !measure_switch("WAA_NO_CONV_NOISE_FLOOR") ? 1 : 0;
+    if (cd.noise) {
+      cd.in = n.hist;
+      cd.in_test_nch = (n.ir_nch == 1 && n.in_nch == 2) ? 1 : std::min(n.in_nch, 2);
+      const int ncv = std::max(n.ir_nch, 2);
+      for (int k = 0; k < 4; k++) {
+        ConvNoiseIr& ni = cd.nir[k];
+        ni = ConvNoiseIr{};
+        if (k >= ncv) continue;
+        const std::vector<float>& h = n.ir[std::min(k, n.ir_nch - 1)];
+        uint64_t l = n.ir_len;
+        while (l > 0 && std::fabs(h[l - 1]) < 0.000001f) l--;  // (fft-convolver's init drops the end of the response below 1e-6)
+        const uint64_t blk = (uint64_t)RQ * CONV_NOISE_BLOCK_QUANTA;
+        ni.seg_count = (uint32_t)((l + blk - 1) / blk);
+        ni.seg_mask = 0;
+        for (uint64_t sgm = 0; sgm < ni.seg_count && sgm < 64; sgm++)
+          for (uint64_t i = sgm * blk; i < std::min(l, (sgm + 1) * blk); i++)
+            if (h[i] != 0.f) {
+              ni.seg_mask |= (uint64_t)1 << sgm;
+              break;
+            }
+      }
+    }
     cst.loop_writes.push_back(n.sig.base);
     cst.profile_slot = slot_for(b, "conv_code_kernel");
     b->steps.push_back(cst);
@@ -533,8 +560,9 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
             fs.qgroup = cur_qgroup;
             if (fs.kind == 15 || fs.kind == 11) {
               int32_t* lst = nullptr;
-              if ((e = dev_alloc(b, &lst, (size_t)b->n_inst * 4))) return e;
-              b->state_bufs.push_back({lst, (size_t)b->n_inst * 4 * sizeof(int32_t)});
+              const size_t ints = fs.kind == 11 ? (size_t)CONV_CODE_STATE_INTS : 4;
+              if ((e = dev_alloc(b, &lst, (size_t)b->n_inst * ints))) return e;
+              b->state_bufs.push_back({lst, (size_t)b->n_inst * ints * sizeof(int32_t)});
               (fs.kind == 15 ? fs.link.state : fs.ccode.state) = lst;
             }
           }
