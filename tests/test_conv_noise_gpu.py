@@ -200,3 +200,32 @@ def test_fuzz_seeds_of_this_class(hip, orc, frozen, seed):
     scale = max(1.0, float(np.abs(o).max()))
     assert rms_err(g, o).max() <= 1e-6 * scale, f"{descr}: rms {rms_err(g, o).max():.3g}"
     assert np.abs(g - o).max() <= 2e-5 * scale, f"{descr}: max |d| {np.abs(g - o).max():.3g}"
+
+
+@pytest.mark.xfail(reason="DESIGN 5 (2b), last paragraph: a source that PLAYS digital silence counts as active in the planner's replay; "
+                          "the plan stays static and nothing tests the DelayNode's data", strict=False)
+def test_digital_silence_from_an_active_source_is_not_followed(hip, orc):
+    """the known gap next to this class, kept visible: the buffer goes on with zeros to the END of the render (no count change
+    anywhere: a static plan); in the reference D1 reads nothing but zeros from quantum 6 on and is silent, D2's ring collapses to
+    mono and the burst (R = -L) that leaves it 20 quanta later is averaged away — on the device it comes out in stereo"""
+    def build(be):
+        c = waa.OfflineAudioContext(2, RQ * 60, SR, n_instances=N, binding=be)
+        x = _padded(white_noise(N, 1, 2 * RQ, seed0=71) * 0.5, 60)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(np.concatenate([x, -x], axis=1), SR)
+        src.start_at(0.0)
+        d1 = c.create_delay(1.0, delay_time=3 * RQ / SR)
+        d2 = c.create_delay(1.0, delay_time=20 * RQ / SR)
+        src.connect(d1)
+        d1.connect(d2)
+        d2.connect(c.destination())
+        return c
+    c = build(hip)
+    assert "dynamic-count group" not in c.plan_describe()
+    g = c.start_rendering_sync().data
+    c.close()
+    c = build(orc)
+    o = c.start_rendering_sync().data
+    c.close()
+    assert np.abs(o).max() == 0.0  # (the reference: averaged away)
+    assert np.abs(g - o).max() <= 2e-5
