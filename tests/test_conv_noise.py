@@ -23,6 +23,8 @@ def cn(tmp_path_factory):
     lib.cn_describe.argtypes = [FP, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     lib.cn_predict.argtypes = [C.c_uint32, C.c_uint64, FP, C.c_uint32, C.POINTER(C.c_uint8)]
     lib.cn_floor.restype = C.c_float
+    lib.cn_node.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint8),
+                            C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
     return lib
 
 
@@ -115,3 +117,77 @@ def test_more_than_64_segments_fall_back_to_the_age_form(cn, ref):
 def test_the_floor_is_far_from_both_ends(cn):
     f = cn.cn_floor()
     assert 1e-30 < f < 1e-12  # normal after a long chain of small gains, nothing a parity tolerance (>= 1e-7) could see
+
+
+# ---- the whole node: tail counter + routing (waa_conv_noise.hpp::conv_noise_node_step) against the oracle's ConvolverNode -------------
+NODE_SR = 32768.0  # (a quantum is 1 / 256 s: start times on quantum boundaries are exact in binary, the sources start ON them)
+
+
+def _node_case(cn, orc, rng, ir_nch, taps, pad_to):
+    """a stereo and a mono BufferSource (quantum-aligned start, whole quanta long, runs of digital silence inside) into one
+    ConvolverNode; the response: `taps` taps, zero-padded to `pad_to` frames (the tail counter runs to the PADDED length)"""
+    import web_audio_api_rs_amd as waa
+    nq = 150
+    h = np.zeros((ir_nch, pad_to), np.float32)
+    h[:, :taps] = rng.standard_normal((ir_nch, taps)) * 0.1
+    srcs = []
+    for nch in (2, 1):
+        n_q = int(rng.integers(4, 40))
+        x = rng.standard_normal((nch, n_q * RQ)).astype(np.float32) * 0.3
+        for _ in range(int(rng.integers(1, 4))):   # digital silence inside the buffer: active quanta that hold zeros
+            a = int(rng.integers(0, n_q * RQ))
+            x[:, a:a + int(rng.integers(100, 1500))] = 0
+        srcs.append((int(rng.integers(0, 70)), x))
+    c = waa.OfflineAudioContext(2, nq * RQ, NODE_SR, n_instances=1, binding=orc)
+    conv = c.create_convolver(buffer=waa.AudioBuffer(h, NODE_SR), disable_normalization=True)
+    mixed = np.zeros((2, nq * RQ), np.float32)
+    count = np.zeros(nq, np.int32)
+    for start, x in srcs:
+        s = c.create_buffer_source()
+        s.set_buffer_batch(x[None], NODE_SR)
+        s.start_at(start * RQ / NODE_SR)
+        s.connect(conv)
+        n = min(x.shape[1], (nq - start) * RQ)
+        mixed[0, start * RQ:start * RQ + n] += x[0, :n]
+        mixed[1, start * RQ:start * RQ + n] += x[-1, :n]   # (a mono source is up-mixed to both channels when the input is stereo)
+        count[start:start + n // RQ] = np.maximum(count[start:start + n // RQ], x.shape[0])
+    conv.connect(c.destination())
+    o = c.start_rendering_sync().data[0]
+    c.close()
+    code = np.where(count == 0, 0x81, count).astype(np.uint8)
+    nzq = np.any(mixed.reshape(2, nq, RQ) != 0, axis=2)
+    nz = (nzq[0].astype(np.uint8) | (np.where(count == 2, nzq[1], False).astype(np.uint8) << 1)).astype(np.uint8)
+    segc = (C.c_uint32 * 4)()
+    mask = (C.c_uint64 * 4)()
+    for k in range(max(ir_nch, 2)):
+        hk = np.ascontiguousarray(h[min(k, ir_nch - 1)])
+        sc, mk = C.c_uint32(), C.c_uint64()
+        cn.cn_describe(hk.ctypes.data_as(FP), len(hk), C.byref(sc), C.byref(mk))
+        segc[k], mask[k] = sc.value, mk.value
+    out = np.zeros(nq, np.uint8)
+    U8 = C.POINTER(C.c_uint8)
+    cn.cn_node(ir_nch, segc, mask, pad_to, nq, code.ctypes.data_as(U8), nz.ctypes.data_as(U8), out.ctypes.data_as(U8))
+    got = np.any(o.reshape(2, nq, RQ) != 0, axis=2)
+    cut = out == 0x80
+    outn = out >> 4
+    want0 = ~cut & ((out & 1) != 0)
+    want1 = ~cut & np.where(outn == 1, (out & 1) != 0, (out & 2) != 0)   # (a mono output is up-mixed to both destination channels)
+    bad = np.nonzero((got[0] != want0) | (got[1] != want1))[0]
+    assert bad.size == 0, (f"ir {ir_nch}ch {taps}/{pad_to}: quanta {bad[:8]}: reference {got[:, bad[:8]].astype(int)}, "
+                           f"automaton {out[bad[:8]]}, codes {code[bad[:8]]}, nz {nz[bad[:8]]}; sources {[(s, x.shape) for s, x in srcs]}")
+    return cut.sum(), (~cut & (outn == 1)).sum()
+
+
+@pytest.mark.parametrize("ir_nch", [1, 2, 4])
+def test_node_routing_and_tail_counter_against_the_oracles_convolver_node(cn, orc, ir_nch):
+    """mono / stereo / silent input quanta in every order, the tail counter's standstill (the blocks of the FFTConvolvers do not
+    advance while the node puts out silence) and the second convolver of a mono response that only hears stereo quanta"""
+    rng = np.random.default_rng(77 + ir_nch)
+    cuts = monos = 0
+    for trial in range(40):
+        taps = int(rng.choice([8, 200, 1024, 1300, 2500]))
+        pad_to = taps + int(rng.choice([0, 0, 700, 3000]))
+        a, b = _node_case(cn, orc, rng, ir_nch, taps, pad_to)
+        cuts += a
+        monos += b
+    assert cuts > 100 and (ir_nch != 1 or monos > 50)  # (the cases did reach the standstill and the one-convolver route)

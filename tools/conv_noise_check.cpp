@@ -32,5 +32,16 @@ void cn_predict(uint32_t seg_count, uint64_t seg_mask, const float* x, uint32_t 
     noisy[q] = waa::conv_noise_step(ir, s, nz) ? 1 : 0;
   }
 }
+// a whole ConvolverNode (the tail counter and the routing around its FFTConvolvers): code[q] = input channels | 0x80 when the input
+// quantum is silent, nz[q] = bit c: channel c of it holds a non-zero sample -> out[q] = waa::conv_noise_node_step's answer
+void cn_node(int ir_nch, const uint32_t* seg_count, const uint64_t* seg_mask, uint64_t impulse_length, uint32_t n_quanta,
+             const uint8_t* code, const uint8_t* nz, uint8_t* out) {
+  waa::ConvNoiseIr ir[4];
+  for (int k = 0; k < 4; k++) ir[k] = waa::ConvNoiseIr{seg_count[k], 0, seg_mask[k]};
+  waa::ConvNoiseNode s;
+  waa::conv_noise_node_reset(s);
+  for (uint32_t q = 0; q < n_quanta; q++)
+    out[q] = (uint8_t)waa::conv_noise_node_step(ir, ir_nch, impulse_length, s, (code[q] & 0x80) != 0, code[q] & 7, nz[q]);
+}
 float cn_floor() { return waa::CONV_NOISE_FLOOR; }
 }

@@ -67,6 +67,41 @@ WAA_CN_FN bool conv_noise_step(const ConvNoiseIr& ir, ConvNoiseState& s, bool in
   return noisy;
 }
 
+// ---- one ConvolverNode: the tail counter and the routing of ConvolverRenderer::process (convolver.rs:343-392, :384-466) around
+// its FFTConvolvers — one per channel of the response, at least two
+struct ConvNoiseNode {
+  uint64_t tail;         // frames of silent input processed since the last active quantum (tail_count)
+  ConvNoiseState cv[4];
+};
+WAA_CN_FN void conv_noise_node_reset(ConvNoiseNode& s) {
+  s.tail = 0;
+  for (int k = 0; k < 4; k++) conv_noise_reset(s.cv[k]);
+}
+constexpr uint32_t CONV_NOISE_CUT = 0x80u;  // the tail has elapsed: silent output, the convolvers are not called (their blocks stand still)
+// one render quantum: the input is coded silent (= one channel of zeros) or carries in_count (1, 2) channels, bit c of nz = channel
+// c of it holds a non-zero sample.  Returns CONV_NOISE_CUT, or (output channels << 4) | bit c: output channel c is noise.
+WAA_CN_FN uint32_t conv_noise_node_step(const ConvNoiseIr* ir, int ir_nch, uint64_t impulse_length, ConvNoiseNode& s, bool in_silent,
+                                        int in_count, uint32_t nz) {
+  if (in_silent) {
+    if (s.tail >= impulse_length) return CONV_NOISE_CUT;
+    s.tail += 128;
+    in_count = 1;
+    nz = 0;
+  } else {
+    s.tail = 0;
+  }
+  const bool l = (nz & 1u) != 0, r = in_count == 2 ? (nz & 2u) != 0 : l;
+  if (ir_nch == 4) {  // true stereo: output c = convolver c of the left + convolver 2 + c of the right channel (a mono input: of itself)
+    const bool o0 = conv_noise_step(ir[0], s.cv[0], l), o1 = conv_noise_step(ir[1], s.cv[1], l);
+    const bool o2 = conv_noise_step(ir[2], s.cv[2], r), o3 = conv_noise_step(ir[3], s.cv[3], r);
+    return (2u << 4) | ((o0 || o2) ? 1u : 0u) | ((o1 || o3) ? 2u : 0u);
+  }
+  if (in_count == 1 && ir_nch == 1) return (1u << 4) | (conv_noise_step(ir[0], s.cv[0], l) ? 1u : 0u);  // the second convolver is not called
+  const bool o0 = conv_noise_step(ir[0], s.cv[0], l);
+  const bool o1 = conv_noise_step(ir[1], s.cv[1], r);  // (mono input: both convolvers hear it)
+  return (2u << 4) | (o0 ? 1u : 0u) | (o1 ? 2u : 0u);
+}
+
 // the floor a sample of a "noise" quantum is raised to: far below anything audible or testable (1e-20), far enough above the
 // denormal range (1e-38) that the gains and filters behind it keep it normal as long as they keep the reference's noise normal
 constexpr float CONV_NOISE_FLOOR = 1e-20f;

@@ -948,9 +948,8 @@ size_t dyn_lds_bytes(int n_items, int cmax, int stages) {
 // ConvolverRenderer::process on codes (convolver.rs:343-392): the tail counter cuts the output off once a silent input
 // has lasted for the length of the impulse response; the output count follows the routing table (:384-466).
 struct ConvCodeState {
-  uint64_t tail;
-  bool ever_active;  // (an input that has never been active: the convolver's output is exact zeros, see ConvCodeDesc)
-  ConvNoiseState cv[4];
+  ConvNoiseNode node;  // the tail counter and the node's FFTConvolvers (waa_conv_noise.hpp)
+  bool ever_active;    // (an input that has never been active: the convolver's output is exact zeros, see ConvCodeDesc)
 };
 // quanta [qa, qb) of one instance.  On entry clean[q] holds the non-zero flags of the input quantum (conv_nz_kernel; noise form).
 __device__ inline void conv_code_quanta(const ConvCodeDesc& d, uint32_t inst, uint32_t qa, uint32_t qb, ConvCodeState& s) {
@@ -961,48 +960,30 @@ __device__ inline void conv_code_quanta(const ConvCodeDesc& d, uint32_t inst, ui
   for (uint32_t q = qa; q < qb; q++) {
     const uint32_t c = in[q];
     const uint32_t nz = d.noise ? clean[q] : 0u;
+    const bool silent = (c & CODE_SILENT) != 0;
+    const uint32_t r = conv_noise_node_step(d.nir, d.ir_nch, d.impulse_length, s.node, silent, (int)(c & 7u), nz);
     clean[q] = 0;
-    if (c & CODE_SILENT) {
-      if (s.tail >= d.impulse_length) {
-        out[q] = (uint8_t)(1u | CODE_SILENT);
-        continue;  // (the reference does not call its convolvers: their blocks stand still)
-      }
-      s.tail += RQ;
-      if (!d.noise) clean[q] = s.ever_active ? 0 : 1;
-    } else {
-      s.tail = 0;
-      s.ever_active = true;
+    if (r == CONV_NOISE_CUT) {
+      out[q] = (uint8_t)(1u | CODE_SILENT);
+      continue;
     }
-    const int ic = (int)(c & 7u);
-    const uint32_t outn = (ic == 1 && d.ir_nch == 1) ? 1u : 2u;
+    const uint32_t outn = r >> 4, noisy = r & 3u;
     out[q] = (uint8_t)outn;
     if (d.noise) {
-      // which FFTConvolver hears which input channel: convolver.rs:384-466 (a silent input is one channel of zeros)
-      const bool l = (nz & 1u) != 0, r = ic == 2 ? (nz & 2u) != 0 : l;
-      uint32_t noisy;
-      if (d.ir_nch == 4) {
-        const bool o0 = conv_noise_step(d.nir[0], s.cv[0], l), o1 = conv_noise_step(d.nir[1], s.cv[1], l);
-        const bool o2 = conv_noise_step(d.nir[2], s.cv[2], r), o3 = conv_noise_step(d.nir[3], s.cv[3], r);
-        noisy = ((o0 || o2) ? 1u : 0u) | ((o1 || o3) ? 2u : 0u);
-      } else if (outn == 1) {
-        noisy = conv_noise_step(d.nir[0], s.cv[0], l) ? 1u : 0u;
-      } else {
-        const bool o0 = conv_noise_step(d.nir[0], s.cv[0], l);
-        const bool o1 = conv_noise_step(d.nir[1], s.cv[1], ic == 2 ? r : l);
-        noisy = (o0 ? 1u : 0u) | (o1 ? 2u : 0u);
-      }
       const uint32_t live = (outn == 2 ? 3u : 1u) & chmask;
       clean[q] = (uint8_t)((~noisy & live) | ((noisy & live) << 2));
+    } else if (silent) {
+      clean[q] = s.ever_active ? 0 : 1;
     }
+    if (!silent) s.ever_active = true;
   }
 }
 __global__ void conv_code_kernel(const ConvCodeDesc d) {
   const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
   if (inst >= d.n_inst) return;
   ConvCodeState s;
-  s.tail = 0;
+  conv_noise_node_reset(s.node);
   s.ever_active = false;
-  for (int k = 0; k < 4; k++) conv_noise_reset(s.cv[k]);
   conv_code_quanta(d, inst, 0, d.n_quanta, s);
 }
 // the same automaton over a range of quanta, its state in memory between launches
@@ -1011,27 +992,27 @@ __global__ void conv_code_range_kernel(const ConvCodeDesc d) {
   if (inst >= d.n_inst) return;
   int32_t* stw = d.state + (uint64_t)inst * CONV_CODE_STATE_INTS;
   ConvCodeState s;
-  s.tail = (uint64_t)(uint32_t)stw[0] | ((uint64_t)(uint32_t)stw[1] << 32);
+  s.node.tail = (uint64_t)(uint32_t)stw[0] | ((uint64_t)(uint32_t)stw[1] << 32);
   s.ever_active = stw[2] != 0;
   for (int k = 0; k < 4; k++) {
     if (stw[3]) {
-      s.cv[k].hist = (uint64_t)(uint32_t)stw[4 + 4 * k] | ((uint64_t)(uint32_t)stw[5 + 4 * k] << 32);
-      s.cv[k].age = (uint32_t)stw[6 + 4 * k];
-      s.cv[k].flags = (uint32_t)stw[7 + 4 * k];
+      s.node.cv[k].hist = (uint64_t)(uint32_t)stw[4 + 4 * k] | ((uint64_t)(uint32_t)stw[5 + 4 * k] << 32);
+      s.node.cv[k].age = (uint32_t)stw[6 + 4 * k];
+      s.node.cv[k].flags = (uint32_t)stw[7 + 4 * k];
     } else {
-      conv_noise_reset(s.cv[k]);  // (the state arrives zero-filled)
+      conv_noise_reset(s.node.cv[k]);  // (the state arrives zero-filled)
     }
   }
   conv_code_quanta(d, inst, d.q0, d.q1, s);
-  stw[0] = (int32_t)(uint32_t)s.tail;
-  stw[1] = (int32_t)(uint32_t)(s.tail >> 32);
+  stw[0] = (int32_t)(uint32_t)s.node.tail;
+  stw[1] = (int32_t)(uint32_t)(s.node.tail >> 32);
   stw[2] = s.ever_active ? 1 : 0;
   stw[3] = 1;
   for (int k = 0; k < 4; k++) {
-    stw[4 + 4 * k] = (int32_t)(uint32_t)s.cv[k].hist;
-    stw[5 + 4 * k] = (int32_t)(uint32_t)(s.cv[k].hist >> 32);
-    stw[6 + 4 * k] = (int32_t)s.cv[k].age;
-    stw[7 + 4 * k] = (int32_t)s.cv[k].flags;
+    stw[4 + 4 * k] = (int32_t)(uint32_t)s.node.cv[k].hist;
+    stw[5 + 4 * k] = (int32_t)(uint32_t)(s.node.cv[k].hist >> 32);
+    stw[6 + 4 * k] = (int32_t)s.node.cv[k].age;
+    stw[7 + 4 * k] = (int32_t)s.node.cv[k].flags;
   }
 }
 // does channel c of input quantum q hold a non-zero sample?  (bit c of clean[q], read back by the code kernel; a quantum coded
