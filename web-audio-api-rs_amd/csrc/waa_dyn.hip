@@ -14,6 +14,7 @@
 // comes from the batch (1024 instances = 1024 wavefronts).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
 
 #include "waa_internal.hpp"
@@ -1017,51 +1018,61 @@ __global__ void conv_code_range_kernel(const ConvCodeDesc d) {
 }
 // does channel c of input quantum q hold a non-zero sample?  (bit c of clean[q], read back by the code kernel; a quantum coded
 // silent is zeros in the reference whatever the buffer holds)
+// (one workgroup per (quantum, instance) pair, walked with a grid stride: neither count is bounded by a grid dimension)
 __global__ __launch_bounds__(128) void conv_nz_kernel(const ConvCodeDesc d) {
-  const uint32_t q = d.q0 + blockIdx.x, inst = blockIdx.y;
-  const uint32_t code = d.in_code[(uint64_t)inst * d.code_stride + q];
-  uint32_t bits = 0;
-  if (!(code & CODE_SILENT)) {
-    const int ic = (int)(code & 7u);
-    for (int c = 0; c < ic && c < d.in_test_nch; c++) {
-      const float v = d.in.base[(uint64_t)inst * d.in.inst_stride + (uint64_t)c * d.in.ch_stride + (uint64_t)q * RQ + threadIdx.x];
-      if (__syncthreads_or(v != 0.f)) bits |= 1u << c;
+  const uint64_t nq = d.q1 - d.q0, total = nq * d.n_inst;
+  for (uint64_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const uint32_t q = d.q0 + (uint32_t)(w % nq), inst = (uint32_t)(w / nq);
+    const uint32_t code = d.in_code[(uint64_t)inst * d.code_stride + q];
+    uint32_t bits = 0;
+    if (!(code & CODE_SILENT)) {
+      const int ic = (int)(code & 7u);
+      for (int c = 0; c < ic && c < d.in_test_nch; c++) {
+        const float v = d.in.base[(uint64_t)inst * d.in.inst_stride + (uint64_t)c * d.in.ch_stride + (uint64_t)q * RQ + threadIdx.x];
+        if (__syncthreads_or(v != 0.f)) bits |= 1u << c;
+      }
     }
+    if (threadIdx.x == 0) d.clean[(uint64_t)inst * d.code_stride + q] = (uint8_t)bits;
   }
-  if (threadIdx.x == 0) d.clean[(uint64_t)inst * d.code_stride + q] = (uint8_t)bits;
 }
 __global__ __launch_bounds__(128) void conv_floor_kernel(const ConvCodeDesc d) {
-  const uint32_t q = d.q0 + blockIdx.x, inst = blockIdx.y;
-  const uint32_t m = d.clean[(uint64_t)inst * d.code_stride + q];
-  if (!m) return;
-  if (!d.noise) {  // the round-3 form: the whole quantum is exact zeros
-    for (int c = 0; c < d.cout; c++)
-      d.out.base[(uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)q * RQ + threadIdx.x] = 0.f;
-    return;
-  }
-  for (int c = 0; c < 2 && c < d.cout; c++) {
-    float* p = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)q * RQ + threadIdx.x;
-    if (m & (1u << c)) {
-      *p = 0.f;
-    } else if (m & (4u << c)) {
-      const float v = *p;
-      if (__builtin_fabsf(v) < CONV_NOISE_FLOOR) *p = __builtin_copysignf(CONV_NOISE_FLOOR, v);
+  const uint64_t nq = d.q1 - d.q0, total = nq * d.n_inst;
+  for (uint64_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const uint32_t q = d.q0 + (uint32_t)(w % nq), inst = (uint32_t)(w / nq);
+    const uint32_t m = d.clean[(uint64_t)inst * d.code_stride + q];
+    if (!m) continue;
+    if (!d.noise) {  // the round-3 form: the whole quantum is exact zeros
+      for (int c = 0; c < d.cout; c++)
+        d.out.base[(uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)q * RQ + threadIdx.x] = 0.f;
+      continue;
+    }
+    for (int c = 0; c < 2 && c < d.cout; c++) {
+      float* p = d.out.base + (uint64_t)inst * d.out.inst_stride + (uint64_t)c * d.out.ch_stride + (uint64_t)q * RQ + threadIdx.x;
+      if (m & (1u << c)) {
+        *p = 0.f;
+      } else if (m & (4u << c)) {
+        const float v = *p;
+        if (__builtin_fabsf(v) < CONV_NOISE_FLOOR) *p = __builtin_copysignf(CONV_NOISE_FLOOR, v);
+      }
     }
   }
 }
 void launch_conv_codes(const ConvCodeDesc& d0, void* stream) {
   ConvCodeDesc d = d0;
-  if (d.state) {  // the ranged form
-    if (d.q1 <= d.q0) return;
-    if (d.noise) hipLaunchKernelGGL(conv_nz_kernel, dim3(d.q1 - d.q0, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
-    hipLaunchKernelGGL(conv_code_range_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
-    hipLaunchKernelGGL(conv_floor_kernel, dim3(d.q1 - d.q0, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
-    return;
+  const bool ranged = d.state != nullptr;
+  if (!ranged) {
+    d.q0 = 0;
+    d.q1 = d.n_quanta;
   }
-  d.q0 = 0;
-  if (d.noise) hipLaunchKernelGGL(conv_nz_kernel, dim3(d.n_quanta, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
-  hipLaunchKernelGGL(conv_code_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
-  hipLaunchKernelGGL(conv_floor_kernel, dim3(d.n_quanta, d.n_inst), dim3(128), 0, (hipStream_t)stream, d);
+  if (d.q1 <= d.q0 || d.n_inst == 0) return;
+  const uint64_t pairs = (uint64_t)(d.q1 - d.q0) * d.n_inst;
+  const dim3 grid((uint32_t)std::min<uint64_t>(pairs, 1u << 22));
+  if (d.noise) hipLaunchKernelGGL(conv_nz_kernel, grid, dim3(128), 0, (hipStream_t)stream, d);
+  if (ranged)
+    hipLaunchKernelGGL(conv_code_range_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
+  else
+    hipLaunchKernelGGL(conv_code_kernel, dim3((d.n_inst + 63) / 64), dim3(64), 0, (hipStream_t)stream, d);
+  hipLaunchKernelGGL(conv_floor_kernel, grid, dim3(128), 0, (hipStream_t)stream, d);
 }
 
 }  // namespace waa
