@@ -10,6 +10,8 @@
 #   ranks:<n>  `python bench.py --gpus n` with no launcher (it spawns the ranks; WAA_BENCH_SHARE_GPU: they share this box's GPU)
 #   dyn        tools/dyn_probe.py: dyn_kernel's quantum pipeline against the one-wavefront form
 #   t:<files>  pytest -m gpu -x on the '+'-separated test files (ta:<files>: without -x, every failure listed)
+#   determinism  tools/determinism_campaign.py, one process on the device (the same bits twice?)
+#   fuzzvariants the campaign's two variants on fresh seeds: FUZZ_MIXED_COUNTS=1, WAA_POISON_ALLOC=1
 #   box        copy floor of this box (tools/stream_probe) + rocm-smi clocks: C2 ran 1.35 ... 1.60 ms depending on the box
 #   plantrace:<w>  WAA_PLAN_TRACE of workload <w> (measurement build): where build_plan's host time goes
 set -u
