@@ -10,6 +10,7 @@
 #   ranks:<n>  `python bench.py --gpus n` with no launcher (it spawns the ranks; WAA_BENCH_SHARE_GPU: they share this box's GPU)
 #   dyn        tools/dyn_probe.py: dyn_kernel's quantum pipeline against the one-wavefront form
 #   t:<files>  pytest -m gpu -x on the '+'-separated test files (ta:<files>: without -x, every failure listed)
+#   convnoise  tools/conv_noise_probe.py: the cost of the convolver's noise floor in a dynamic plan, A/B
 #   determinism  tools/determinism_campaign.py, one process on the device (the same bits twice?)
 #   fuzzvariants the campaign's two variants on fresh seeds: FUZZ_MIXED_COUNTS=1, WAA_POISON_ALLOC=1
 #   box        copy floor of this box (tools/stream_probe) + rocm-smi clocks: C2 ran 1.35 ... 1.60 ms depending on the box
@@ -45,6 +46,10 @@ for S in "$@"; do
               if [ $v = 1 ]; then export WAA_DYN_NO_PIPE=1; else unset WAA_DYN_NO_PIPE; fi
               echo "## WAA_DYN_NO_PIPE=${WAA_DYN_NO_PIPE:-unset}"; timeout 300 python tools/dyn_probe.py 2>&1 | grep -E "dynamic-count group|dyn_kernel|first render"
             done; done > gpurun_out/${TAG}_dyn_probe.txt 2>&1; unset WAA_DYN_NO_PIPE; cat gpurun_out/${TAG}_dyn_probe.txt ;;
+    convnoise) # what the convolver's noise floor costs in a dynamic plan: with it, and with round 3's clearing only
+            for v in 0 1 0 1; do if [ $v = 1 ]; then export WAA_NO_CONV_NOISE_FLOOR=1; else unset WAA_NO_CONV_NOISE_FLOOR; fi
+              echo "## WAA_NO_CONV_NOISE_FLOOR=${WAA_NO_CONV_NOISE_FLOOR:-unset}"; timeout 300 python tools/conv_noise_probe.py 2>&1 | grep -vE "hostname|Warning"
+            done > gpurun_out/${TAG}_conv_noise_probe.txt 2>&1; unset WAA_NO_CONV_NOISE_FLOOR; cat gpurun_out/${TAG}_conv_noise_probe.txt ;;
     t:*)    F=${S#t:}; timeout 900 python -m pytest ${F//+/ } -m gpu -q -x > gpurun_out/${TAG}_tests_sel.log 2>&1; echo "rc=$?"; tail -6 gpurun_out/${TAG}_tests_sel.log ;;
     ta:*)   F=${S#ta:}; timeout 900 python -m pytest ${F//+/ } -m gpu -q > gpurun_out/${TAG}_tests_all.log 2>&1; echo "rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_tests_all.log | cut -c1-300 | tail -30 ;;
     *) echo "unknown section $S" ;;
