@@ -185,10 +185,14 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
 #define DYN_STAMP(ph)
 #endif
   // a delay reader sees its writer's stores of this quantum (same wavefront: they share a stage) once they have reached L2
+  // (Writer and reader share a wavefront, its stores go to the XCD's L2 and the reader's loads are L2-served — coherent_f /
+  // coherent_u, `sc1` — so all that is needed is that the stores have been acknowledged: workgroup scope = s_waitcnt vmcnt(0).
+  // The agent-scope pair used until the end of round 5 added `buffer_wbl2 sc1` + `buffer_inv sc1` — an L2 write-back per
+  // quantum and workgroup: 29 us per quantum on a 1024-context delay group, tools/conv_noise_probe.py, profiles/r05v_*.)
   auto vm_sync = []() __attribute__((always_inline)) {
     if constexpr (W > 1) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (s_waitcnt vmcnt(0): the stores are out)
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     } else {
       __syncthreads();
     }
