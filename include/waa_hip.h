@@ -192,6 +192,23 @@ void waa_batch_destroy(waa_batch* batch);
  * creates and destroys batches while others render (waa_render_sharded's pipeline, a server) should reserve one (DESIGN.md section 7:
  * 112 -> 95 ms for 2 x 3.9 GB through one device). */
 waa_status waa_device_arena_reserve(int32_t device, uint64_t bytes);
+/* The same slab, GRADED: which physical memory a buffer lies in decides how fast a streaming kernel writes it (MI355X: the copy of
+ * C2's footprint takes 1.30-1.37 ms into some regions, 1.49-1.52 ms into others; regions are tens of GB wide, stable, independent
+ * of the virtual address — profiles/r06a...r06f).  This call creates candidate_bytes (>= bytes; clamped to
+ * what is free) of physical memory in units (hipMemCreate), times the one-wave-per-stream copy INTO every unit, maps the `bytes`
+ * fastest-to-write units side by side — fastest first — and releases the rest.  Batches then take what they WRITE (signals,
+ * spectra, outputs) from the bottom of the slab and what they only read (source AudioBuffers) from the top.  About 4 ms per
+ * GiB of candidates, once per process: what a serving process does at start-up; an offline context that renders once does not
+ * win the time back.  Everything else as waa_device_arena_reserve (bytes = 0 releases; InvalidStateError while in use). */
+waa_status waa_device_arena_reserve_graded(int32_t device, uint64_t bytes, uint64_t candidate_bytes);
+/* The grades of the units of the graded arena of `device`, in address order (ms per copy into the unit: ascending), and what
+ * the candidates looked like.  All zero when the device has no graded arena.  unit_ms may be NULL. */
+typedef struct waa_arena_grades {
+  uint64_t unit_bytes;
+  uint32_t n_units, n_candidates;
+  float best_ms, worst_kept_ms, worst_candidate_ms, grading_ms;
+} waa_arena_grades;
+waa_status waa_device_arena_grades(int32_t device, waa_arena_grades* out, float* unit_ms, uint32_t capacity);
 /* What the arena of `device` (-1: the current one) has done so far: a request of >= 1 MB the slab could not serve is a MISS
  * (the batch fell back to hipMalloc, which synchronises the device) — a serving process watches `misses`.  All zero when no
  * arena is reserved.  Pieces are handed back individually when their batch is destroyed (first-fit free list, neighbours merge). */

@@ -1647,6 +1647,15 @@ waa_status orc_device_arena_reserve(int32_t device, uint64_t bytes) {
   (void)bytes;
   return WAA_OK;
 }
+waa_status orc_device_arena_reserve_graded(int32_t device, uint64_t bytes, uint64_t candidate_bytes) {
+  (void)device; (void)bytes; (void)candidate_bytes;
+  return WAA_OK;
+}
+waa_status orc_device_arena_grades(int32_t device, waa_arena_grades* out, float* unit_ms, uint32_t capacity) {
+  (void)device; (void)unit_ms; (void)capacity;
+  if (out) memset(out, 0, sizeof *out);
+  return WAA_OK;
+}
 waa_status orc_device_arena_stats(int32_t device, waa_arena_stats* out) {
   (void)device;
   if (!out) return WAA_ERR_INVALID_ARGUMENT;

@@ -138,3 +138,57 @@ def test_device_arena_hands_pieces_back_while_lifetimes_overlap(hip):
     finally:
         hip.check(hip.device_arena_reserve(0, 0))
     assert waa.arena_stats(hip, 0)["reserved_bytes"] == 0
+
+
+@pytest.mark.gpu
+def test_graded_arena_sorts_its_units_and_serves_reads_from_the_top(hip, orc):
+    """waa_device_arena_reserve_graded (round 6): candidate physical units are timed as the destination of C2's copy shape, the
+    fastest are mapped side by side in ascending order of that time, the rest released; a batch's written buffers come from the
+    bottom of the slab, its source AudioBuffers (only read) from the top; the render is bit-identical to plain hipMalloc."""
+    from graphs import c2, white_noise
+    noise = white_noise(6, 2, 128 * 300)
+
+    def render():
+        ctx, _ = c2(hip, noise)
+        out = ctx.start_rendering_sync().data
+        return ctx, out, ctx.output_device()[0]
+
+    ctx, plain, _ = render()
+    ctx.close()
+    free0 = __import__("torch").cuda.mem_get_info()[0]
+    hip.check(hip.device_arena_reserve_graded(0, 256 << 20, 1024 << 20))
+    try:
+        g = waa.arena_grades(hip, 0)
+        assert g["unit_bytes"] == 64 << 20 and g["n_units"] == 4 and g["n_candidates"] == 16, g
+        assert g["unit_ms"] == sorted(g["unit_ms"]) and 0 < g["best_ms"] == g["unit_ms"][0] <= g["worst_kept_ms"] <= g["worst_candidate_ms"]
+        st = waa.arena_stats(hip, 0)
+        assert st["reserved_bytes"] == 256 << 20 and st["in_use_bytes"] == 0
+        # the surplus candidates went back to the device
+        assert free0 - __import__("torch").cuda.mem_get_info()[0] < (256 + 64) << 20
+        ctx, out, ptr = render()
+        assert np.array_equal(out, plain)
+        ctx2, out2, ptr2 = render()
+        assert np.array_equal(out2, plain) and ptr2 != ptr
+        with pytest.raises(waa.WaaError, match="InvalidStateError"):
+            hip.check(hip.device_arena_reserve_graded(0, 0, 0))
+        ctx.close()
+        ctx2.close()
+        assert waa.arena_stats(hip, 0)["in_use_bytes"] == 0
+    finally:
+        hip.check(hip.device_arena_reserve(0, 0))
+    assert waa.arena_grades(hip, 0)["n_units"] == 0 and waa.arena_stats(hip, 0)["reserved_bytes"] == 0
+    # big buffers: the output below the source (white_noise 2 MB+ planes are carved from the slab: >= 1 MB)
+    big = white_noise(8, 2, 128 * 4000)
+    hip.check(hip.device_arena_reserve_graded(0, 512 << 20, 512 << 20))
+    try:
+        ctx, _ = c2(hip, big)
+        out = ctx.start_rendering_sync().data
+        st = waa.arena_stats(hip, 0)
+        assert st["served"] >= 2 and st["misses"] == 0
+        ctx.close()
+    finally:
+        hip.check(hip.device_arena_reserve(0, 0))
+    ctx, _ = c2(orc, big)
+    ref = ctx.start_rendering_sync().data
+    ctx.close()
+    assert rms_err(out, ref).max() <= 1e-6

@@ -20,6 +20,9 @@ def main(argv):
     n_inst, frames = 1024, 480000
     hip = waa.default_binding()
     noise = torch.empty((n_inst, 2, frames), dtype=torch.float32, device="cuda").uniform_(-1, 1)
+    if os.environ.get("ARENA_GB"):  # the batches' buffers out of a graded arena (waa_device_arena_reserve_graded): placement out of the picture
+        hip.check(hip.device_arena_reserve_graded(0, int(os.environ["ARENA_GB"]) << 30, int(os.environ.get("CAND_GB", "100")) << 30))
+        print({k: v for k, v in waa.arena_grades(hip, 0).items() if k != "unit_ms"}, flush=True)
     for name in argv[1:]:
         for rep in range(int(os.environ.get("AB_REPS", "2"))):
             for on in (False, True):

@@ -27,7 +27,8 @@ int main(int argc, char** argv) {
     if (do_alloc) {
       const size_t bytes = 1 + rng() % (align * 40);
       const size_t units = (bytes + align - 1) / align;
-      const size_t off = fl.alloc(bytes);
+      const bool top = (rng() % 3) == 0;  // (a third of the requests from the top end, as payloads of a graded arena)
+      const size_t off = top ? fl.alloc_top(bytes) : fl.alloc(bytes);
       ops++;
       if (off == FreeList::npos) {
         // a miss is only legal when no run of `units` free units exists (first fit finds any)

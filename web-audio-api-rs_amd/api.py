@@ -100,6 +100,23 @@ class ArenaStats(C.Structure):
                                           "miss_bytes")]
 
 
+class ArenaGrades(C.Structure):
+    """waa_arena_grades (include/waa_hip.h)"""
+    _fields_ = [("unit_bytes", C.c_uint64), ("n_units", C.c_uint32), ("n_candidates", C.c_uint32), ("best_ms", C.c_float),
+                ("worst_kept_ms", C.c_float), ("worst_candidate_ms", C.c_float), ("grading_ms", C.c_float)]
+
+
+def arena_grades(binding, device=-1) -> dict:
+    """waa_device_arena_grades as a dict (+ "unit_ms": the kept units' grades in address order); all zero without a graded arena"""
+    g = ArenaGrades()
+    binding.check(binding.device_arena_grades(int(device), C.cast(C.pointer(g), _VP), None, 0))
+    out = {n: (int if n in ("unit_bytes", "n_units", "n_candidates") else float)(getattr(g, n)) for n, _ in ArenaGrades._fields_}
+    ms = (C.c_float * max(int(g.n_units), 1))()
+    binding.check(binding.device_arena_grades(int(device), C.cast(C.pointer(g), _VP), ms, int(g.n_units)))
+    out["unit_ms"] = [float(ms[k]) for k in range(int(g.n_units))]
+    return out
+
+
 def arena_stats(binding, device=-1) -> dict:
     """waa_device_arena_stats as a dict (all zero when no arena is reserved on the device)"""
     st = ArenaStats()
@@ -116,6 +133,8 @@ ABI = {
     "device_count": (C.c_int32, []),
     "device_arena_reserve": (C.c_int32, [C.c_int32, C.c_uint64]),
     "device_arena_stats": (C.c_int32, [C.c_int32, _VP]),
+    "device_arena_reserve_graded": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64]),
+    "device_arena_grades": (C.c_int32, [C.c_int32, _VP, _FP, C.c_uint32]),
     "source_set_buffer": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FPP, C.c_uint32, C.c_uint64, C.c_float]),
     "source_set_buffer_batch": (C.c_int32, [_VP, C.c_uint32, _FP, C.c_uint32, C.c_uint64, C.c_float]),
     "source_set_buffer_pcm16": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_int16), C.c_uint32, C.c_uint64, C.c_float]),

@@ -275,8 +275,8 @@ static int fill_upload(waa_batch* b, const waa_batch::PendingFill& f) {
     if (f.stride == f.frames)
       HIP_TRY(hipMemcpyAsync(f.planes, f.host, (size_t)f.n_items * f.n_ch * f.frames * sizeof(float), hipMemcpyHostToDevice, b->stream));
     else
-      HIP_TRY(hipMemcpy2DAsync(f.planes, f.stride * sizeof(float), f.host, f.frames * sizeof(float), f.frames * sizeof(float),
-                               (size_t)f.n_items * f.n_ch, hipMemcpyHostToDevice, b->stream));
+      HIP_TRY(copy2d_async(b->device, f.planes, f.stride * sizeof(float), f.host, f.frames * sizeof(float), f.frames * sizeof(float),
+                           (size_t)f.n_items * f.n_ch, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
   }
@@ -1218,8 +1218,8 @@ waa_status waa_download_all(waa_batch* b, float* dst) {
   const SignalRef& s = b->nodes[0].sig;
   if (b->length == 0) return WAA_OK;
   if ((uint32_t)s.nch == b->n_out) {
-    HIP_TRY(hipMemcpy2DAsync(dst, b->length * sizeof(float), s.base, s.ch_stride * sizeof(float), b->length * sizeof(float),
-                             (size_t)b->n_inst * b->n_out, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(copy2d_async(b->device, dst, b->length * sizeof(float), s.base, s.ch_stride * sizeof(float), b->length * sizeof(float),
+                         (size_t)b->n_inst * b->n_out, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
   } else {
     for (uint32_t i = 0; i < b->n_inst; i++)

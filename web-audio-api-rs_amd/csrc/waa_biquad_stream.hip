@@ -963,7 +963,7 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
   const size_t lds = 2 * 64 * LDS_ROW * sizeof(float);
   const char* dbg = measure_switch("WAA_STREAM_DEBUG");  // measurement aid only, see profiles/r01_c2_memory_pattern.txt
   if (d.dup_out && d.vary == 0) {
-    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 2, true>), grid, block, lds, (hipStream_t)stream, d);
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 4, true>), grid, block, lds, (hipStream_t)stream, d);
     return;
   }
   if (d.vary == 3 && dbg && dbg[0] == '3')
@@ -986,15 +986,19 @@ void launch_biquad_stream(const BiquadStreamDesc& d, void* stream) {
     hipLaunchKernelGGL((biquad_stream_kernel_t<5, 0>), grid, block, lds, (hipStream_t)stream, d);
   else if (dbg && dbg[0] == '7')
     hipLaunchKernelGGL((biquad_stream_kernel_t<7, 0>), grid, block, lds, (hipStream_t)stream, d);
-  else if (measure_switch("WAA_STREAM_PREFETCH2"))  // experiment (A/B with tools/ab_env.py)
-    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 4>), grid, block, lds, (hipStream_t)stream, d);
+  else if (measure_switch("WAA_STREAM_PREFETCH1"))  // the form of rounds 1-5: one tile in flight (A/B with tools/ab_env.py)
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 2>), grid, block, lds, (hipStream_t)stream, d);
   else if (measure_switch("WAA_BIQUAD_DIGEST"))  // experiment, bit-identical output; same-box A/B (tools/ab_env.py): no gain — with 4
                                          // instead of 2 waves per SIMD the kernel runs at the same 1.5-1.65 ms, i.e. what bounds
                                          // C2 is the memory side of 2048 concurrent streams, not the wave's latency hiding
     hipLaunchKernelGGL(biquad_stream_digest_kernel, grid, block, 64 * LDS_ROW * sizeof(float) + 34 * 2 * sizeof(double),
                        (hipStream_t)stream, d);
   else
-    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0>), grid, block, lds, (hipStream_t)stream, d);
+    // Two tiles in flight per wavefront (round 6).  Rounds 2-5 measured this form "identical" — on batches whose OUTPUT lay in
+    // slow-to-write memory (1.58 against 1.58 ms: the memory system was the bound either way).  In fast-to-write memory
+    // (waa_device_arena_reserve_graded) the kernel sits 3.5 % above its own copy-only form with one tile in flight and 1.5 % with
+    // two: 1.345 -> 1.320 ms on six batches out of six (profiles/r06k_c2_variants.txt).  256 registers, no spill.
+    hipLaunchKernelGGL((biquad_stream_kernel_t<0, 0, 4>), grid, block, lds, (hipStream_t)stream, d);
 }
 
 }  // namespace waa

@@ -1,5 +1,7 @@
 // waa_freelist.hpp — first-fit free list with coalescing over one slab, offsets only (no HIP): the bookkeeping of the device
-// arena (waa_arena.cpp).  Plain C++ so that tools/freelist_check.cpp exercises it on a box without a GPU
+// arena (waa_arena.cpp).  Two directions: alloc() takes the LOWEST block that fits and carves from its start, alloc_top() the
+// HIGHEST and carves from its end — a graded arena (waa_device_arena_reserve_graded) is sorted best-for-writing first, so what a
+// batch writes comes from the bottom and what it only reads (source AudioBuffers) from the top.  Plain C++ so that tools/freelist_check.cpp exercises it on a box without a GPU
 // (tests/test_arena_freelist.py).
 #pragma once
 #include <algorithm>
@@ -32,6 +34,26 @@ class FreeList {
       const size_t off = fb->first, rest = fb->second - need;
       free_.erase(fb);
       if (rest) free_[off + need] = rest;
+      used_[off] = need;
+      in_use_ += need;
+      peak_ = std::max(peak_, in_use_);
+      served_++;
+      return off;
+    }
+    misses_++;
+    miss_bytes_ += need;
+    return npos;
+  }
+  // the same from the other end: the highest free block that fits, its LAST round(bytes)
+  size_t alloc_top(size_t bytes) {
+    const size_t need = std::max(round(bytes), align_);
+    for (auto fb = free_.rbegin(); fb != free_.rend(); ++fb) {
+      if (fb->second < need) continue;
+      const size_t start = fb->first, rest = fb->second - need, off = start + rest;
+      if (rest)
+        fb->second = rest;
+      else
+        free_.erase(std::next(fb).base());
       used_[off] = need;
       in_use_ += need;
       peak_ = std::max(peak_, in_use_);

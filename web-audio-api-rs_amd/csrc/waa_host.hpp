@@ -358,8 +358,26 @@ struct PlanTrace {
 // pieces; the slab is one mapping with the largest page-table fragments the driver gives, so WHERE a batch's output lands no
 // longer changes from batch to batch (the same kernel ran at 1.33 or 1.55 ms depending on the
 // hipMalloc that happened to serve its output).  Defined in waa_abi.cpp.
-void* arena_alloc(int device, size_t bytes);
+void* arena_alloc(int device, size_t bytes, bool read_only = false);  // (read_only: the top end of a graded arena)
 bool arena_free(int device, void* p);
+// bytes of one physical unit when `p` lies in a GRADED arena of `device` (units mapped side by side), else 0
+size_t arena_unit_of(int device, const void* p);
+// hipMemcpy2DAsync whose device side may lie in a graded arena: the runtime refuses a pitched copy whose extent exceeds ONE mapped
+// physical unit ("invalid argument"; 1-D copies, memsets and kernels are not affected — tools/vmm_copy_check.hip,
+// profiles/r06h_vmm_copy_check*.txt), so such a copy is issued in row groups of at most half a unit.
+inline hipError_t copy2d_async(int device, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                               hipMemcpyKind kind, hipStream_t stream) {
+  const bool dev_is_dst = kind == hipMemcpyHostToDevice;
+  const size_t unit = arena_unit_of(device, dev_is_dst ? dst : src), pitch = dev_is_dst ? dpitch : spitch;
+  if (!unit || pitch * height <= unit / 2) return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, stream);
+  const size_t per = std::max<size_t>((unit / 2) / pitch, 1);
+  for (size_t r = 0; r < height; r += per) {
+    const hipError_t e = hipMemcpy2DAsync(static_cast<char*>(dst) + r * dpitch, dpitch, static_cast<const char*>(src) + r * spitch, spitch, width,
+                                          std::min(per, height - r), kind, stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
 
 template <typename T>
 int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
@@ -376,7 +394,7 @@ int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
   }
   const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipSuccess;
-  if (bytes >= (1u << 20)) p = arena_alloc(b->device, bytes);  // (small tables stay with hipMalloc)
+  if (bytes >= (1u << 20)) p = arena_alloc(b->device, bytes, payload);  // (small tables stay with hipMalloc; payloads are only read)
   if (!p) e = hipMalloc(&p, bytes);
   b->t_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   b->n_alloc++;
