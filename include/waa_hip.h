@@ -77,7 +77,7 @@ enum {
   WAA_NODE_GAIN = 3,            /* src/node/gain.rs:143-199          */
   WAA_NODE_CONVOLVER = 4,       /* src/node/convolver.rs:343-490     */
   WAA_NODE_STEREO_PANNER = 5,   /* src/node/stereo_panner.rs:218-317 */
-  WAA_NODE_PANNER = 6,          /* src/node/panner.rs:685-904 (equal-power only) */
+  WAA_NODE_PANNER = 6,          /* src/node/panner.rs:685-904 (equal-power and HRTF panning models, all distance models, cone) */
   WAA_NODE_ANALYSER = 7,        /* src/node/analyser.rs:265-290      */
   WAA_NODE_WAVESHAPER = 8,      /* src/node/waveshaper.rs:383-487 (oversample None, 2x, 4x) */
   WAA_NODE_CONSTANT_SOURCE = 9, /* src/node/constant_source.rs:190-275 */

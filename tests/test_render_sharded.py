@@ -130,6 +130,15 @@ def test_close_never_destroys_an_adopted_batch(orc):
     ctx._handle, ctx._foreign = object(), True
     ctx.close()
     assert calls == [] and ctx._handle is None
+    # ... and a batch the context creates for ITSELF afterwards is its own again (it leaked: _foreign stayed set)
+    assert ctx._foreign is False
+    own = object()
+    ctx._handle = own
+    ctx.close()
+    assert calls == [own]
+    ctx._handle, ctx._foreign = object(), True
+    ctx._release()
+    assert ctx._foreign is False and ctx._handle is None
 
 
 @pytest.mark.gpu

@@ -1059,6 +1059,7 @@ class OfflineAudioContext:
 
     def _release(self):
         self._handle = None
+        self._foreign = False  # (the adopted batch is forgotten: whatever this context creates next is its own)
 
     def prepare(self):
         """Create the batch and upload every payload (outside any timed region)."""
@@ -1129,6 +1130,7 @@ class OfflineAudioContext:
             if not getattr(self, "_foreign", False):  # an adopted batch belongs to the library (waa_render_sharded destroys it)
                 self._b.batch_destroy(self._handle)
             self._handle = None
+            self._foreign = False  # (a context that is prepared on its own afterwards owns THAT batch)
 
     def __del__(self):
         try:

@@ -35,6 +35,7 @@
 #include "waa_stream_common.hpp"
 
 namespace waa {
+#ifdef WAA_MEASURE
 
 namespace {
 struct M2 {
@@ -526,4 +527,10 @@ void launch_biquad_scan(const BiquadStreamDesc& d, const BiquadScanCtl& ctl_in, 
     hipLaunchKernelGGL((biquad_scan_kernel<false>), dim3(waves), dim3(64), lds, (hipStream_t)stream, d, ctl);
 }
 
+#else
+// (product build: the chained scan is a measured negative result, opt-in through WAA_BIQUAD_SCAN in the measurement build only —
+// DESIGN.md 3.1g; its kernels are not part of libwaa_hip.so)
+void launch_biquad_scan_powers(const double*, uint64_t, double*, uint32_t, void*) {}
+void launch_biquad_scan(const BiquadStreamDesc&, const BiquadScanCtl&, uint32_t*, void*) {}
+#endif  // WAA_MEASURE
 }  // namespace waa

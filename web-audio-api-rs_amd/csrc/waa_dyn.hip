@@ -193,6 +193,9 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
     if constexpr (W > 1) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      // (whether a workgroup-scope fence lowers to a wait for the outstanding stores is the compiler's memory-model
+      // choice for the target, not a promise; the wait the hand-over NEEDS is stated)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       __syncthreads();
     }

@@ -192,6 +192,7 @@ void launch_link(const LinkDesc& d, void* stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef WAA_MEASURE  // the matrix (qgemm) form of the oversampling stages: measurement build only
 namespace {
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LDA = BM + 4, LDB = BN + 4;  // padded LDS rows (bank spread of the transposing stores)
@@ -861,6 +862,11 @@ void launch_qgemm(const QGemmDesc& d, void* stream) {
   } else
     hipLaunchKernelGGL(qgemm_mfma_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d);
 }
+#else
+// (product build: the matrix form of the resampling stages is a measured alternative, WAA_OS_MATRIX — DESIGN.md 3.5 — that only the
+// measurement build plans; its kernels are not part of libwaa_hip.so)
+void launch_qgemm(const QGemmDesc&, void*) {}
+#endif  // WAA_MEASURE
 
 // ---------------------------------------------------------------------------------------------------------------
 // HRTF FIR.  Workgroup = 4 wavefronts, each renders one (instance, quantum): lanes 0..31 the left ear, 32..63 the
