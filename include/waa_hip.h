@@ -31,6 +31,9 @@
  *                               -> RenderThread::render_audiobuffer_sync      src/render/thread.rs:260-302
  *                               -> Graph::render                              src/render/graph.rs:490-591
  *                               -> every AudioProcessor::process              src/render/processor.rs:113-139
+ *   waa_render_range            OfflineAudioContext::suspend_sync             src/context/offline.rs:359-397
+ *                               + the suspend points of the quantum loop      src/render/thread.rs:277-294
+ *   waa_connect / waa_disconnect  AudioNode::connect / disconnect_*           src/node/audio_node.rs:247-289, 341-420
  *   waa_download*               AudioBuffer returned by start_rendering_sync  src/render/thread.rs:384-395
  *   waa_analyser_*              AnalyserNode::get_*_data                      src/node/analyser.rs:228-258, src/analysis.rs:261-401
  *
@@ -335,6 +338,26 @@ waa_status waa_timeline_render_device(const waa_timeline* timeline, uint32_t n_q
 /* start_rendering_sync for every instance: renders all ceil(length/128) quanta. Asynchronous on the
  * batch's stream; waa_download / waa_download_all / waa_sync wait for it. */
 waa_status waa_render(waa_batch* batch);
+/* The same render with SUSPEND POINTS: OfflineAudioContext::suspend_sync (src/context/offline.rs:359-397) and the quantum loop
+ * that honours it (RenderThread::render_audiobuffer_sync, src/render/thread.rs:277-294: "callback -> handle_control_messages ->
+ * render the quantum").  Ranges are consecutive and start at quantum 0; after waa_render_range(b, q0, n) the render is suspended
+ * in front of quantum q0 + n, and every control call made until the next range — waa_connect / waa_disconnect,
+ * waa_set_param_const (AudioParam::set_value), waa_param_schedule_event, waa_source_start / stop — takes effect FROM THAT
+ * QUANTUM, exactly where the reference's render thread would have handled the control message: a start time that has passed
+ * becomes the block's time (audio_buffer_source.rs:516-518), an automation event enters the param's queue as it is then
+ * (param.rs:796-1047).  The range that reaches the last quantum renders (asynchronously, like waa_render); the engine renders
+ * node-major, so the earlier ranges only move the control clock — reading rendered audio in between (waa_download, the
+ * analyser getters) is an InvalidStateError: a host that needs it renders a shorter batch of the graph so far.  Payload
+ * setters (buffers, curves, coefficients) called at a suspend point apply to the whole render. */
+waa_status waa_render_range(waa_batch* batch, uint64_t quantum0, uint32_t n_quanta);
+/* AudioNode::connect_from_output_to_input / disconnect_dest_from_output_to_input (src/node/audio_node.rs:247-289, 341-420,
+ * ControlMessage::ConnectNode / DisconnectNode -> Graph::add_edge / remove_edge, src/render/graph.rs:203-262) on a batch that
+ * exists: before the first range they edit the graph, at a suspend point the connection lives from resp. until that quantum.
+ * to_input as in waa_edge_desc (WAA_PARAM_INPUT(param) for an AudioParam).  Connecting twice is a no-op; disconnecting what is
+ * not connected an InvalidAccessError.  Nodes cannot be added to a batch: a node a callback creates is declared in the graph
+ * description and left unconnected (an unconnected node renders nothing anybody hears) until the callback's connect. */
+waa_status waa_connect(waa_batch* batch, uint32_t from, uint32_t from_output, uint32_t to, uint32_t to_input);
+waa_status waa_disconnect(waa_batch* batch, uint32_t from, uint32_t from_output, uint32_t to, uint32_t to_input);
 waa_status waa_sync(waa_batch* batch);
 /* rendered AudioBuffer channel of one instance -> dst[frames] (frames <= length) */
 waa_status waa_download(waa_batch* batch, uint32_t instance, uint32_t channel, float* dst, uint64_t frames);

@@ -1155,6 +1155,7 @@ typedef struct {
   /* buffer source (per instance arrays) */
   Buf* bufs;           /* [n_inst] */
   double *start_time, *stop_time, *offset, *duration; /* [n_inst] */
+  unsigned char* msg_started;                          /* [n_inst] start() called at a suspend point (a control message) */
   int* is_looping;
   double *loop_start, *loop_end;
   /* convolver (shared) */
@@ -1233,12 +1234,44 @@ typedef struct {
 
 static const struct HrirSphere* hrir_for_rate(uint32_t sample_rate); /* HRTF panner, below */
 
+/* A control message submitted while the render is suspended in front of quantum q (OfflineAudioContext::suspend_sync,
+ * offline.rs:359-397): the render thread handles it right before that quantum (thread.rs:277-294).  Unlike the product
+ * library — which renders node-major and therefore COMPILES the history into the plan (gated connections, clamped start
+ * times, events that enter the automation queue late) — this interpreter really is a quantum loop and applies the message
+ * when its quantum comes: an independent statement of the same semantics. */
+enum { CTL_EVENT = 1, CTL_START = 2, CTL_STOP = 3 };
+typedef struct {
+  uint32_t q;
+  int kind;
+  uint32_t node, param, inst;
+  int32_t type;
+  float value;
+  double t, aux, offset, duration;
+  float* curve;
+  uint32_t n_curve;
+} CtlMsg;
+typedef struct {
+  uint32_t q0;            /* first quantum of the epoch */
+  unsigned char* active;  /* [n_edges] the connections that exist during it */
+  uint32_t* order;
+  uint32_t n_order;
+} Epoch;
+#define ORC_EDGE_NEVER 0xFFFFFFFFu
 struct orc_batch {
   uint32_t n_nodes, n_edges, n_inst, n_out;
   uint64_t length;
   float sr;
   NodeCfg* nodes;
   waa_edge_desc* edges;
+  uint32_t *edge_on, *edge_off; /* [n_edges] live for quanta [on, off) */
+  uint32_t edge_cap;
+  const unsigned char* edge_active; /* the epoch order_nodes is asked about (NULL: every edge) */
+  uint32_t ctl_q;               /* the control clock: orc_render_range */
+  int ranged;
+  CtlMsg* msgs;
+  uint32_t n_msgs, msg_cap;
+  Epoch* epochs;
+  uint32_t n_epochs;
   uint32_t* order;
   uint32_t n_order;
   NodeState** st; /* [n_inst][n_nodes] */
@@ -1249,6 +1282,15 @@ struct orc_batch {
   unsigned char* dbg_codes; /* [n_inst][n_nodes][n_quanta], ORC_DUMP_CODES only */
 };
 typedef struct orc_batch orc_batch;
+
+static void ctl_push(orc_batch* b, CtlMsg m) {
+  if (b->n_msgs == b->msg_cap) {
+    b->msg_cap = b->msg_cap ? 2 * b->msg_cap : 16;
+    b->msgs = (CtlMsg*)realloc(b->msgs, sizeof(CtlMsg) * b->msg_cap);
+  }
+  m.q = b->ctl_q;
+  b->msgs[b->n_msgs++] = m;
+}
 
 static void param_init(Param* p, uint32_t n_inst, float defv, float minv, float maxv) {
   p->cst = (float*)malloc(sizeof(float) * n_inst);
@@ -1351,7 +1393,7 @@ static int order_visit(OrderCtx* c, uint32_t v) {
     if (!c->cut[id] && order_visit(c, id | ORC_READER)) return 1;
   } else {
     for (uint32_t e = 0; e < b->n_edges; e++) {
-      if (b->edges[e].from != id) continue;
+      if (b->edges[e].from != id || (b->edge_active && !b->edge_active[e])) continue;
       uint32_t to = b->edges[e].to;
       /* inputs go to the writer; a param edge goes to the param's owner: delayTime belongs to the reader */
       if (b->nodes[to].desc.kind == WAA_NODE_DELAY && (b->edges[e].to_input & 0x80000000u)) to |= ORC_READER;
@@ -1451,8 +1493,12 @@ waa_status orc_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
   b->sr = sr;
   b->n_threads = 1;
   b->nodes = (NodeCfg*)calloc(g->n_nodes, sizeof(NodeCfg));
-  b->edges = (waa_edge_desc*)malloc(sizeof(waa_edge_desc) * (g->n_edges ? g->n_edges : 1));
+  b->edge_cap = g->n_edges + 16;
+  b->edges = (waa_edge_desc*)malloc(sizeof(waa_edge_desc) * b->edge_cap);
   memcpy(b->edges, g->edges, sizeof(waa_edge_desc) * g->n_edges);
+  b->edge_on = (uint32_t*)calloc(b->edge_cap, sizeof(uint32_t));
+  b->edge_off = (uint32_t*)malloc(sizeof(uint32_t) * b->edge_cap);
+  for (uint32_t e = 0; e < b->edge_cap; e++) b->edge_off[e] = ORC_EDGE_NEVER;
   for (uint32_t e = 0; e < g->n_edges; e++) {
     if (g->edges[e].from >= g->n_nodes || g->edges[e].to >= g->n_nodes || g->edges[e].from_output != 0 ||
         (g->edges[e].to_input != 0 && !(g->edges[e].to_input & 0x80000000u)))
@@ -1698,6 +1744,7 @@ void orc_batch_destroy(orc_batch* b) {
       free(n->bufs);
     }
     free(n->start_time);
+    free(n->msg_started);
     free(n->stop_time);
     free(n->offset);
     free(n->duration);
@@ -1713,6 +1760,15 @@ void orc_batch_destroy(orc_batch* b) {
   free(b->nodes);
   free(b->edges);
   free(b->order);
+  free(b->edge_on);
+  free(b->edge_off);
+  for (uint32_t k = 0; k < b->n_msgs; k++) free(b->msgs[k].curve);
+  free(b->msgs);
+  for (uint32_t k = 0; k < b->n_epochs; k++) {
+    free(b->epochs[k].active);
+    free(b->epochs[k].order);
+  }
+  free(b->epochs);
   free(b->out);
   free(b->dbg_codes);
   free(b);
@@ -1785,6 +1841,23 @@ waa_status orc_source_start(orc_batch* b, uint32_t node, uint32_t inst, double w
     return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - timing value should be finite and positive");
   NodeCfg* n = &b->nodes[node];
   uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  if (b->ctl_q > 0) { /* at a suspend point: a control message (the renderer's times change when it is handled) */
+    if (!n->msg_started) n->msg_started = (unsigned char*)calloc(b->n_inst, 1);
+    for (uint32_t k = lo; k < hi; k++) {
+      if (n->start_time[k] != DBL_MAX || n->msg_started[k]) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot call `start` twice");
+      n->msg_started[k] = 1;
+    }
+    CtlMsg m;
+    memset(&m, 0, sizeof m);
+    m.kind = CTL_START;
+    m.node = node;
+    m.inst = inst;
+    m.t = when;
+    m.offset = offset;
+    m.duration = duration;
+    ctl_push(b, m);
+    return WAA_OK;
+  }
   for (uint32_t k = lo; k < hi; k++) {
     if (n->start_time[k] != DBL_MAX) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot call `start` twice");
     n->start_time[k] = when;
@@ -1805,6 +1878,19 @@ waa_status orc_source_stop(orc_batch* b, uint32_t node, uint32_t inst, double wh
   if (!(when >= 0.)) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - timing value should be finite and positive");
   NodeCfg* n = &b->nodes[node];
   uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  if (b->ctl_q > 0) {
+    for (uint32_t k = lo; k < hi; k++)
+      if (n->start_time[k] == DBL_MAX && !(n->msg_started && n->msg_started[k]))
+        return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot stop before start");
+    CtlMsg m;
+    memset(&m, 0, sizeof m);
+    m.kind = CTL_STOP;
+    m.node = node;
+    m.inst = inst;
+    m.t = when;
+    ctl_push(b, m);
+    return WAA_OK;
+  }
   for (uint32_t k = lo; k < hi; k++) {
     if (n->start_time[k] == DBL_MAX)
       return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot stop before start");
@@ -2060,7 +2146,32 @@ waa_status orc_param_schedule_event(orc_batch* b, uint32_t node, uint32_t param,
       /* the node constructor's `param.set_value(options.x)` (e.g. gain.rs:117) */
       if ((e = orc_timeline_event(p->tl[k], WAA_EVENT_SET_VALUE, p->cst[k], 0., 0., NULL, 0))) return e;
     }
+    if (b->ctl_q > 0) continue; /* (a control message, below) */
     if ((e = orc_timeline_event(p->tl[k], type, value, time, aux, curve, n_curve))) return e;
+  }
+  if (b->ctl_q > 0) {
+    { /* the control-side assertions now, on a scratch timeline (only argument checks can fire) */
+      orc_timeline* probe = orc_timeline_create(p->defv, p->minv, p->maxv, !p->k_rate);
+      e = orc_timeline_event(probe, type, value, time, aux, curve, n_curve);
+      orc_timeline_destroy(probe);
+      if (e) return e;
+    }
+    CtlMsg m;
+    memset(&m, 0, sizeof m);
+    m.kind = CTL_EVENT;
+    m.node = node;
+    m.param = param;
+    m.inst = inst;
+    m.type = type;
+    m.value = value;
+    m.t = time;
+    m.aux = aux;
+    if (curve && n_curve) {
+      m.curve = (float*)malloc(sizeof(float) * n_curve);
+      memcpy(m.curve, curve, sizeof(float) * n_curve);
+      m.n_curve = n_curve;
+    }
+    ctl_push(b, m);
   }
   return WAA_OK;
 }
@@ -2072,6 +2183,8 @@ waa_status orc_set_param_const(orc_batch* b, uint32_t node, uint32_t param, uint
   if ((e = check_inst(b, inst))) return e;
   Param* p = &b->nodes[node].params[param];
   uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  if (b->ctl_q > 0) /* AudioParam::set_value from a suspend callback: a SetValue event handled in front of that quantum */
+    return orc_param_schedule_event(b, node, param, inst, WAA_EVENT_SET_VALUE, value, 0., 0., NULL, 0);
   for (uint32_t k = lo; k < hi; k++) {
     p->cst[k] = value;
     /* AudioParam::set_value after automation methods is one more SetValue event (param.rs:392-415) */
@@ -3649,16 +3762,39 @@ static void render_instance(orc_batch* b, uint32_t inst) {
   uint64_t num_quanta = (b->length + RQ - 1) / RQ;
   float* out = b->out + (size_t)inst * b->n_out * b->length;
   uint64_t written = 0;
+  uint32_t epoch = 0, next_msg = 0;
   for (uint64_t q = 0; q < num_quanta; q++) {
     Scope sc;
     sc.current_frame = q * RQ;
     sc.current_time = (double)sc.current_frame / (double)b->sr;
     sc.sample_rate = b->sr;
     sc.quantum = q;
+    /* the suspend point in front of this quantum: control messages first (thread.rs:281-287) */
+    for (; next_msg < b->n_msgs && b->msgs[next_msg].q <= q; next_msg++) {
+      const CtlMsg* m = &b->msgs[next_msg];
+      if (m->inst != WAA_ALL_INSTANCES && m->inst != inst) continue;
+      NodeState* ms = &st[m->node];
+      if (m->kind == CTL_EVENT) {
+        Param* mp = &b->nodes[m->node].params[m->param];
+        if (mp->tl && mp->tl[inst]) (void)orc_timeline_event(mp->tl[inst], m->type, m->value, m->t, m->aux, m->curve, m->n_curve);
+      } else if (m->kind == CTL_START) { /* AudioScheduledSourceNode::start_at...: onmessage sets the renderer's times */
+        ms->start_time = m->t;
+        if (b->nodes[m->node].desc.kind == WAA_NODE_BUFFER_SOURCE) {
+          ms->offset = m->offset;
+          ms->duration = m->duration;
+        }
+      } else if (m->kind == CTL_STOP) {
+        ms->stop_time = m->t;
+      }
+    }
+    while (epoch + 1 < b->n_epochs && b->epochs[epoch + 1].q0 <= q) epoch++;
+    const uint32_t* order = b->n_epochs ? b->epochs[epoch].order : b->order;
+    const uint32_t n_order = b->n_epochs ? b->epochs[epoch].n_order : b->n_order;
+    const unsigned char* active = b->n_epochs ? b->epochs[epoch].active : NULL;
     for (uint32_t i = 0; i < b->n_nodes; i++)
       for (int p = 0; p < b->nodes[i].n_params; p++) param_advance(&b->nodes[i].params[p], inst, q);
-    for (uint32_t oi = 0; oi < b->n_order; oi++) {
-      uint32_t item = b->order[oi], id = item & ~ORC_READER;
+    for (uint32_t oi = 0; oi < n_order; oi++) {
+      uint32_t item = order[oi], id = item & ~ORC_READER;
       NodeState* s = &st[id];
       if (b->nodes[id].desc.kind == WAA_NODE_DELAY) {
         if (!(item & ORC_READER)) { /* writer half: consumes the input, produces nothing */
@@ -3673,7 +3809,7 @@ static void render_instance(orc_batch* b, uint32_t inst) {
       if (b->dbg_codes) /* debugging aid (ORC_DUMP_CODES): number_of_channels | 0x80 if silent, per node and quantum */
         b->dbg_codes[((size_t)inst * b->n_nodes + id) * num_quanta + q] = (unsigned char)(s->out.n | (q_is_silent(&s->out) ? 0x80 : 0));
       for (uint32_t e = 0; e < b->n_edges; e++) {
-        if (b->edges[e].from != id) continue;
+        if (b->edges[e].from != id || (active && !active[e])) continue;
         NodeCfg* dn = &b->nodes[b->edges[e].to];
         NodeState* ds = &st[b->edges[e].to];
         uint32_t ti = b->edges[e].to_input;
@@ -3731,6 +3867,87 @@ waa_status orc_set_threads(orc_batch* b, int32_t n) {
   return WAA_OK;
 }
 
+waa_status orc_render(orc_batch* b);
+/* waa_render_range: the quantum loop with its suspend points (thread.rs:277-294).  The interpreter renders when the last range
+ * arrives, like the product library, and applies every control message in front of the quantum it was submitted at. */
+waa_status orc_render_range(orc_batch* b, uint64_t quantum0, uint32_t n_quanta) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - the batch is frozen once rendering has started");
+  uint32_t nq = (uint32_t)((b->length + RQ - 1) / RQ);
+  if (quantum0 != b->ctl_q)
+    return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - ranges are consecutive: the next one starts at quantum %u, not %llu", b->ctl_q,
+                (unsigned long long)quantum0);
+  if (n_quanta == 0 || quantum0 + n_quanta > nq)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - quanta [%llu, %llu) of a render of %u", (unsigned long long)quantum0,
+                (unsigned long long)(quantum0 + n_quanta), nq);
+  b->ranged = 1;
+  b->ctl_q = (uint32_t)(quantum0 + n_quanta);
+  if (b->ctl_q < nq) return WAA_OK;
+  return orc_render(b);
+}
+static int orc_check_edge(orc_batch* b, uint32_t from, uint32_t from_output, uint32_t to, uint32_t to_input) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (from >= b->n_nodes || to >= b->n_nodes || from_output != 0 || (to_input != 0 && !(to_input & 0x80000000u)))
+    return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - invalid edge %u:%u -> %u:%u", from, from_output, to, to_input);
+  if ((to_input & 0x80000000u) && (int)(to_input & 0x7fffffffu) >= b->nodes[to].n_params)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "no such param %u on node %u", to_input & 0x7fffffffu, to);
+  if (b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - the batch is frozen once rendering has started");
+  return 0;
+}
+waa_status orc_connect(orc_batch* b, uint32_t from, uint32_t from_output, uint32_t to, uint32_t to_input) {
+  int e;
+  if ((e = orc_check_edge(b, from, from_output, to, to_input))) return e;
+  for (uint32_t k = 0; k < b->n_edges; k++) {
+    const waa_edge_desc* ed = &b->edges[k];
+    if (ed->from == from && ed->from_output == from_output && ed->to == to && ed->to_input == to_input && b->edge_off[k] == ORC_EDGE_NEVER) return WAA_OK;
+  }
+  if (b->n_edges == b->edge_cap) {
+    uint32_t cap = 2 * b->edge_cap;
+    b->edges = (waa_edge_desc*)realloc(b->edges, sizeof(waa_edge_desc) * cap);
+    b->edge_on = (uint32_t*)realloc(b->edge_on, sizeof(uint32_t) * cap);
+    b->edge_off = (uint32_t*)realloc(b->edge_off, sizeof(uint32_t) * cap);
+    b->edge_cap = cap;
+  }
+  waa_edge_desc ed = {from, from_output, to, to_input};
+  b->edges[b->n_edges] = ed;
+  b->edge_on[b->n_edges] = b->ctl_q;
+  b->edge_off[b->n_edges] = ORC_EDGE_NEVER;
+  b->n_edges++;
+  if (to_input & 0x80000000u) { /* node.connect(&param): the param's audio-rate input (param.rs:300-320) */
+    uint32_t pid = to_input & 0x7fffffffu;
+    for (uint32_t k = 0; k < b->n_inst; k++)
+      if (!b->st[k][to].pin[pid]) {
+        b->st[k][to].pin[pid] = (Quantum*)malloc(sizeof(Quantum));
+        q_make_silent(b->st[k][to].pin[pid]);
+      }
+  }
+  if (b->ctl_q == 0) order_nodes(b);
+  return WAA_OK;
+}
+waa_status orc_disconnect(orc_batch* b, uint32_t from, uint32_t from_output, uint32_t to, uint32_t to_input) {
+  int e;
+  if ((e = orc_check_edge(b, from, from_output, to, to_input))) return e;
+  for (uint32_t k = b->n_edges; k-- > 0;) {
+    const waa_edge_desc* ed = &b->edges[k];
+    if (!(ed->from == from && ed->from_output == from_output && ed->to == to && ed->to_input == to_input) || b->edge_off[k] != ORC_EDGE_NEVER) continue;
+    if (b->edge_on[k] >= b->ctl_q) { /* made and cut at the same point */
+      for (uint32_t j = k; j + 1 < b->n_edges; j++) {
+        b->edges[j] = b->edges[j + 1];
+        b->edge_on[j] = b->edge_on[j + 1];
+        b->edge_off[j] = b->edge_off[j + 1];
+      }
+      b->n_edges--;
+      b->edge_off[b->n_edges] = ORC_EDGE_NEVER;
+      b->edge_on[b->n_edges] = 0;
+    } else {
+      b->edge_off[k] = b->ctl_q;
+    }
+    if (b->ctl_q == 0) order_nodes(b);
+    return WAA_OK;
+  }
+  return fail(WAA_ERR_INVALID_ARGUMENT, "InvalidAccessError - attempting to disconnect unconnected nodes");
+}
+
 waa_status orc_render(orc_batch* b) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
   if (b->rendered) /* offline.rs:163 */
@@ -3738,7 +3955,49 @@ waa_status orc_render(orc_batch* b) {
   for (uint32_t i = 0; i < b->n_nodes; i++) /* the reference takes the coefficients in the constructor */
     if (b->nodes[i].desc.kind == WAA_NODE_IIR_FILTER && b->nodes[i].iir_len == 0)
       return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - IIRFilterNode %u has no coefficients", i);
+  if (b->ranged && b->ctl_q < (uint32_t)((b->length + RQ - 1) / RQ))
+    return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - a ranged render is in progress (suspended in front of quantum %u)", b->ctl_q);
   b->rendered = 1;
+  { /* the graph's epochs: the connections change at the suspend points, and with them the render order (graph.rs:490-500:
+     * the graph is re-ordered whenever an edge was added or removed) */
+    uint32_t nq = (uint32_t)((b->length + RQ - 1) / RQ), n_pts = 0;
+    uint32_t* pts = (uint32_t*)malloc(sizeof(uint32_t) * (2 * b->n_edges + 2));
+    pts[n_pts++] = 0;
+    for (uint32_t e = 0; e < b->n_edges; e++) {
+      if (b->edge_on[e] > 0 && b->edge_on[e] < nq) pts[n_pts++] = b->edge_on[e];
+      if (b->edge_off[e] != ORC_EDGE_NEVER && b->edge_off[e] < nq) pts[n_pts++] = b->edge_off[e];
+    }
+    for (uint32_t i = 1; i < n_pts; i++) /* insertion sort, then unique */
+      for (uint32_t j = i; j > 0 && pts[j - 1] > pts[j]; j--) {
+        uint32_t t = pts[j];
+        pts[j] = pts[j - 1];
+        pts[j - 1] = t;
+      }
+    uint32_t nu = 0;
+    for (uint32_t i = 0; i < n_pts; i++)
+      if (nu == 0 || pts[nu - 1] != pts[i]) pts[nu++] = pts[i];
+    if (nu > 1 || b->n_msgs) {
+      b->epochs = (Epoch*)calloc(nu, sizeof(Epoch));
+      b->n_epochs = nu;
+      uint32_t* keep_order = b->order;
+      uint32_t keep_n = b->n_order;
+      for (uint32_t k = 0; k < nu; k++) {
+        Epoch* ep = &b->epochs[k];
+        ep->q0 = pts[k];
+        ep->active = (unsigned char*)calloc(b->n_edges ? b->n_edges : 1, 1);
+        for (uint32_t e = 0; e < b->n_edges; e++) ep->active[e] = b->edge_on[e] <= ep->q0 && ep->q0 < b->edge_off[e];
+        ep->order = (uint32_t*)malloc(sizeof(uint32_t) * (2 * b->n_nodes + 2));
+        b->order = ep->order;
+        b->edge_active = ep->active;
+        order_nodes(b);
+        ep->n_order = b->n_order;
+      }
+      b->order = keep_order;
+      b->n_order = keep_n;
+      b->edge_active = NULL;
+    }
+    free(pts);
+  }
   const char* dump = getenv("ORC_DUMP_CODES");
   uint64_t dbg_nq = (b->length + RQ - 1) / RQ;
   if (dump) {
@@ -3829,11 +4088,13 @@ waa_status orc_sync(orc_batch* b) {
 waa_status orc_download(orc_batch* b, uint32_t inst, uint32_t ch, float* dst, uint64_t frames) {
   if (!b || inst >= b->n_inst || ch >= b->n_out || frames > b->length)
     return fail(WAA_ERR_INVALID_ARGUMENT, "download out of range");
+  if (!b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
   memcpy(dst, b->out + ((size_t)inst * b->n_out + ch) * b->length, sizeof(float) * frames);
   return WAA_OK;
 }
 waa_status orc_download_all(orc_batch* b, float* dst) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (!b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
   memcpy(dst, b->out, sizeof(float) * (size_t)b->n_inst * b->n_out * b->length);
   return WAA_OK;
 }

@@ -136,6 +136,10 @@ extern "C" {
         values: *const f32,
     ) -> i32;
     pub fn waa_render(batch: *mut waa_batch) -> i32;
+    /// round 6: the quantum loop's suspend points (thread.rs:277-294); see `mod.rs::render_with_suspends`
+    pub fn waa_render_range(batch: *mut waa_batch, quantum0: u64, n_quanta: u32) -> i32;
+    pub fn waa_connect(batch: *mut waa_batch, from: u32, from_output: u32, to: u32, to_input: u32) -> i32;
+    pub fn waa_disconnect(batch: *mut waa_batch, from: u32, from_output: u32, to: u32, to_input: u32) -> i32;
     pub fn waa_sync(batch: *mut waa_batch) -> i32;
     pub fn waa_source_ended(batch: *mut waa_batch, node: u32, instance: u32, quantum: *mut i64) -> i32;
     pub fn waa_download(batch: *mut waa_batch, instance: u32, channel: u32, dst: *mut f32, frames: u64) -> i32;

@@ -579,6 +579,41 @@ impl Drop for BatchGuard {
 
 /// The device render of a batch whose render threads have applied their control messages; `Err` = nothing was consumed,
 /// the caller renders on the CPU.
+/// Round 6 — contexts WITH suspensions on the device (UNCOMPILED SKETCH like the rest of this module; until it is wired in,
+/// `start_rendering_sync_batch_with_report` keeps returning `Fallback::Suspended` for them).
+///
+/// `render_audiobuffer_sync` (thread.rs:277-294) runs, in front of quantum q: the callback registered for q, then
+/// `handle_control_messages`, then the quantum.  The library's `waa_render_range` is that loop's skeleton without the quanta: it
+/// moves a control clock, and whatever the shim forwards between two ranges takes effect from the suspended quantum on.  So per
+/// suspend point q (the union over the batch's contexts — they must agree, like their graphs):
+///   1. `ffi::waa_render_range(batch, prev, q - prev)`;
+///   2. every context's callback runs (`OfflineAudioContext` is `&mut`, state Suspended / Running around it, offline.rs:383-388);
+///   3. every render thread handles the messages it produced (`RenderThread::gpu_prepare`), and the `Graph` is READ again
+///      (`GraphShape::from_graph`): edges that appeared -> `waa_connect`, edges that vanished -> `waa_disconnect`; nodes that
+///      appeared must have been declared up front — the shim builds the `waa_graph_desc` from the graph AFTER the last callback
+///      of a dry pass over the callbacks' node creations (a callback that creates nodes depending on rendered audio is the one
+///      case that stays on the CPU: `Fallback::Suspended`);
+///   4. the params' values for the quanta up to the next suspend point come from the crate's own processor
+///      (`AudioParamProcessor::gpu_values`, which now holds the events the callback scheduled) -> `waa_set_param_block(q, n)`:
+///      no automation semantics restated, as in the unsuspended path;
+///   5. scheduled sources whose renderer state changed (start / stop times, loop points) -> `waa_source_start` / `_stop`
+///      with the times the renderer holds; the library clamps a time that has passed to the block (audio_buffer_source.rs:516-518).
+/// The last range renders.  A callback that pulls an AnalyserNode is served by a second, shorter batch of the graph so far
+/// (`web-audio-api-rs_amd/api.py::OfflineAudioContext::_prefix_render` does exactly that for the Python mirror).
+#[allow(dead_code)]
+fn render_with_suspends(batch: *mut ffi::waa_batch, suspend_quanta: &[usize], n_quanta: usize, mut at_suspend: impl FnMut(usize) -> Result<(), Fallback>) -> Result<(), Fallback> {
+    let mut prev = 0usize;
+    for &q in suspend_quanta {
+        if q == 0 || q >= n_quanta {
+            continue; // (a suspend in front of quantum 0 edits the graph before the batch exists)
+        }
+        check(unsafe { ffi::waa_render_range(batch, prev as u64, (q - prev) as u32) })?;
+        at_suspend(q)?; // steps 2-5 above
+        prev = q;
+    }
+    check(unsafe { ffi::waa_render_range(batch, prev as u64, (n_quanta - prev) as u32) })
+}
+
 fn render_on_device(
     contexts: &[OfflineAudioContext],
     taken: &mut [Taken],

@@ -133,6 +133,9 @@ ABI = {
     "device_count": (C.c_int32, []),
     "device_arena_reserve": (C.c_int32, [C.c_int32, C.c_uint64]),
     "device_arena_stats": (C.c_int32, [C.c_int32, _VP]),
+    "render_range": (C.c_int32, [_VP, C.c_uint64, C.c_uint32]),
+    "connect": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "disconnect": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "device_arena_reserve_graded": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64]),
     "device_arena_grades": (C.c_int32, [C.c_int32, _VP, _FP, C.c_uint32]),
     "source_set_buffer": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, _FPP, C.c_uint32, C.c_uint64, C.c_float]),
@@ -276,6 +279,11 @@ class AudioParam:
         self.set_value(v)
 
     def set_value(self, v: float, instance: int = ALL):
+        ctx = self._node.context
+        if ctx._now_q > 0:  # inside a suspend_sync callback: a SetValue event the render thread handles at that quantum
+            nid, pid, v = self._node.id, self._pid, float(v)
+            ctx._log(lambda b, h: b.check(b.set_param_const(h, nid, pid, instance, v)))
+            return self
         self._const[instance] = float(v)
         if instance == ALL:
             self._const = {ALL: float(v)}
@@ -294,7 +302,14 @@ class AudioParam:
     #    evaluated by the library's restatement of AudioParamProcessor; nothing is computed in this mirror.
     #    `instance`: the context of the batch the call is made on (ALL = the same call on every context).
     def _event(self, kind: int, value: float, time: float, aux: float = 0.0, curve=None, instance: int = ALL):
-        self._events.append((kind, float(value), float(time), float(aux), None if curve is None else _f32(curve), instance))
+        ev = (kind, float(value), float(time), float(aux), None if curve is None else _f32(curve), instance)
+        ctx = self._node.context
+        if ctx._now_q > 0:  # inside a suspend_sync callback
+            nid, pid = self._node.id, self._pid
+            ctx._log(lambda b, h: b.check(b.param_schedule_event(h, nid, pid, ev[5], ev[0], ev[1], ev[2], ev[3],
+                                                                 None if ev[4] is None else _fp(ev[4]), 0 if ev[4] is None else ev[4].size)))
+            return self
+        self._events.append(ev)
         return self
 
     def set_value_at_time(self, value: float, start_time: float, instance: int = ALL):
@@ -366,12 +381,38 @@ class AudioNode:
         if isinstance(dest, AudioParam):
             if dest._node.context is not self.context:
                 raise WaaError(1, "InvalidAccessError - Attempting to connect nodes from different contexts")
-            self.context._edges.append((self.id, output, dest._node.id, PARAM_INPUT | dest._pid))
+            self.context._connect((self.id, output, dest._node.id, PARAM_INPUT | dest._pid))
             return dest
         if dest.context is not self.context:
             raise WaaError(1, "InvalidAccessError - Attempting to connect nodes from different contexts")
-        self.context._edges.append((self.id, output, dest.id, input))
+        self.context._connect((self.id, output, dest.id, input))
         return dest
+
+    # AudioNode::disconnect and its four narrower forms (audio_node.rs:291-420); `dest` may be an AudioParam
+    def disconnect(self, dest=None, output: Optional[int] = None, input: Optional[int] = None):
+        if dest is not None:
+            dctx = dest._node.context if isinstance(dest, AudioParam) else dest.context
+            if dctx is not self.context:
+                raise WaaError(1, "InvalidAccessError - Attempting to disconnect nodes from different contexts")
+        if output is not None and output != 0:
+            raise WaaError(1, f"IndexSizeError - output port {output} is out of bounds")
+        to = None if dest is None else (dest._node.id if isinstance(dest, AudioParam) else dest.id)
+        ti = None if dest is None else (PARAM_INPUT | dest._pid if isinstance(dest, AudioParam) else input)
+        self.context._disconnect(self.id, output, to, ti)
+
+    def disconnect_dest(self, dest):
+        self.disconnect(dest)
+
+    def disconnect_output(self, output: int):
+        self.disconnect(None, output)
+
+    def disconnect_dest_from_output(self, dest, output: int):
+        self.disconnect(dest, output)
+
+    def disconnect_dest_from_output_to_input(self, dest, output: int, input: int):
+        if input != 0:
+            raise WaaError(1, f"IndexSizeError - input port {input} is out of bounds")
+        self.disconnect(dest, output, input)
 
     def _desc(self) -> NodeDesc:
         d = NodeDesc()
@@ -405,6 +446,7 @@ class _ScheduledSource(AudioNode):
         super().__init__(ctx, **kw)
         self._starts = {}
         self._stops = {}
+        self._late = set()
 
     def start(self):
         return self.start_at(0.0)
@@ -419,6 +461,11 @@ class _ScheduledSource(AudioNode):
         if instance in self._starts or ALL in self._starts:
             raise WaaError(3, "InvalidStateError - Cannot call `start` twice")
         self._starts[instance] = (float(when), float(offset), float(duration))
+        ctx = self.context
+        if ctx._now_q > 0:  # inside a suspend_sync callback: the start message is handled in front of that quantum
+            nid, args = self.id, self._starts[instance]
+            self._late.add(("start", instance))
+            ctx._log(lambda b, h: b.check(b.source_start(h, nid, instance, *args)))
         return self
 
     def stop(self):
@@ -428,6 +475,11 @@ class _ScheduledSource(AudioNode):
         if instance not in self._starts and ALL not in self._starts:
             raise WaaError(3, "InvalidStateError - cannot stop before start")
         self._stops[instance] = float(when)
+        ctx = self.context
+        if ctx._now_q > 0:
+            nid, w = self.id, float(when)
+            self._late.add(("stop", instance))
+            ctx._log(lambda b, h: b.check(b.source_stop(h, nid, instance, w)))
         return self
 
     def ended_quantum(self, instance: int = 0) -> int:
@@ -443,9 +495,11 @@ class _ScheduledSource(AudioNode):
         super()._apply(ctx)
         b, h = ctx._b, ctx._handle
         for inst, (w, o, d) in self._starts.items():
-            b.check(b.source_start(h, self.id, inst, w, o, d))
+            if ("start", inst) not in self._late:  # (calls made at a suspend point are replayed from the control log)
+                b.check(b.source_start(h, self.id, inst, w, o, d))
         for inst, w in self._stops.items():
-            b.check(b.source_stop(h, self.id, inst, w))
+            if ("stop", inst) not in self._late:
+                b.check(b.source_stop(h, self.id, inst, w))
 
 
 class AudioBufferSourceNode(_ScheduledSource):
@@ -790,6 +844,9 @@ class AnalyserNode(AudioNode):
 
     def _pull(self, fn_name: str, n: int, instance: int, dtype):
         ctx = self.context
+        if ctx._now_q > 0 and ctx._handle is None:  # inside a suspend_sync callback: what has been rendered up to here
+            with ctx._prefix_render(ctx._now_q):
+                return self._pull(fn_name, n, instance, dtype)
         if ctx._handle is None:
             raise WaaError(3, "InvalidStateError - analyser data is only available after start_rendering_sync")
         out = np.zeros(n, dtype=dtype)
@@ -800,6 +857,9 @@ class AnalyserNode(AudioNode):
     def _pull_all(self, fn_name: str, n: int, dtype, out=None):
         """[n_instances][n]: every context's pull in one call (one launch, one transfer on the device)."""
         ctx = self.context
+        if ctx._now_q > 0 and ctx._handle is None:
+            with ctx._prefix_render(ctx._now_q):
+                return self._pull_all(fn_name, n, dtype, out)
         if ctx._handle is None:
             raise WaaError(3, "InvalidStateError - analyser data is only available after start_rendering_sync")
         if out is None:
@@ -963,8 +1023,70 @@ class OfflineAudioContext:
         self._handle = None
         self._rendered = False
         self._foreign = False
+        # OfflineAudioContext::suspend_sync (offline.rs:359-397): callbacks by render quantum; while one runs, _now_q is its quantum
+        # and every control call (connect / disconnect, AudioParam methods, start / stop) goes to _ctl[q] instead of the node's
+        # static description — replayed between the ranges of waa_render_range, where the reference's render thread handles them
+        self._suspends = {}
+        self._ctl = {}
+        self._now_q = 0
+        self._replayed = 0  # the control log has been replayed up to this quantum on the current batch
+        self._live = []   # the connections that exist "now" (disconnect's InvalidAccessError, disconnect() of everything)
+        self._state = "suspended"  # AudioContextState of a context that has not started rendering (offline.rs:451)
         self._listener = AudioListener()
         self._destination = AudioDestinationNode(self)
+
+    def state(self) -> str:
+        return self._state
+
+    def _log(self, action):
+        self._ctl.setdefault(self._now_q, []).append(action)
+
+    def _connect(self, edge):
+        if edge in self._live:
+            return  # (connecting twice is a no-op: the reference keeps a set of connections)
+        self._live.append(edge)
+        if self._now_q > 0:
+            self._log(lambda b, h: b.check(b.connect(h, *edge)))
+        else:
+            self._edges.append(edge)
+
+    def _disconnect(self, frm, output, to, to_input):
+        hit = [e for e in self._live if e[0] == frm and (output is None or e[1] == output) and (to is None or e[2] == to) and
+               (to_input is None or e[3] == to_input)]
+        if to is not None and not hit:
+            raise WaaError(1, "InvalidAccessError - attempting to disconnect unconnected nodes")
+        for e in hit:
+            self._live.remove(e)
+            if self._now_q > 0:
+                self._log(lambda b, h, e=e: b.check(b.disconnect(h, *e)))
+            else:
+                self._edges.remove(e)
+
+    def suspend_sync(self, suspend_time: float, callback):
+        """OfflineAudioContext::suspend_sync (offline.rs:359-397): run `callback(context)` when the render reaches `suspend_time`
+        (quantised UP to a render quantum, calculate_suspend_frame offline.rs:241-251); the render resumes when it returns."""
+        if self._rendered:
+            raise WaaError(3, "InvalidStateError - cannot suspend when rendering has already started")
+        if not suspend_time >= 0.0:
+            raise WaaError(3, "InvalidStateError: suspendTime cannot be negative")
+        if not suspend_time < self.length / float(self.sample_rate):
+            raise WaaError(3, "InvalidStateError: suspendTime cannot be greater than or equal to the total render duration")
+        q = int(np.ceil(suspend_time * float(self.sample_rate) / RENDER_QUANTUM_SIZE))
+        if q in self._suspends:
+            raise WaaError(3, "InvalidStateError - cannot suspend multiple times at the same render quantum")
+        self._suspends[q] = callback
+
+    def _run_suspend_callbacks(self):
+        """The callbacks in render order, each with the control clock at its quantum (thread.rs:281-287)."""
+        for q in sorted(self._suspends):
+            cb = self._suspends.pop(q)
+            self._now_q = q if q > 0 else 0  # (a suspend at time 0 runs in front of the first quantum: plain graph edits)
+            self._state = "suspended"
+            try:
+                cb(self)
+            finally:
+                self._state = "running"
+                self._now_q = 0
 
     def _register(self, node: AudioNode) -> int:
         if self._handle is not None:
@@ -1036,14 +1158,61 @@ class OfflineAudioContext:
             ensure_hrtf_database(self._b)
         return g
 
-    def _build(self):
+    def _prefix_render(self, q):
+        """What a suspend callback sees when it READS rendered audio (an analyser pull at quantum q): the engine renders node-major,
+        so the quanta in front of the suspend point are rendered by a batch of their own — the graph as it is so far, `q` quanta
+        long, the control log of the earlier suspend points replayed (a render is causal: its first q quanta do not depend on what
+        happens later).  The batch lives for the duration of the `with` block."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            now, replayed, rendered = self._now_q, self._replayed, self._rendered
+            self._now_q = 0
+            try:
+                self._build(length=q * RENDER_QUANTUM_SIZE, run_callbacks=False)
+                self._replayed = 0
+                self._render_ranges(q)
+                yield
+            finally:
+                if self._handle is not None:
+                    self._b.batch_destroy(self._handle)
+                self._handle = None
+                self._now_q, self._replayed, self._rendered = now, replayed, rendered
+        return scope()
+
+    def _build(self, length=None, run_callbacks=True):
+        if run_callbacks:
+            self._run_suspend_callbacks()  # (every node a callback creates must be in the graph description)
         g = self.graph_desc()
         h = _VP()
-        self._b.check(self._b.batch_create(C.byref(g), self.n_instances, self.number_of_channels, self.length,
+        self._b.check(self._b.batch_create(C.byref(g), self.n_instances, self.number_of_channels, self.length if length is None else length,
                                            self.sample_rate, self.device, C.byref(h)))
         self._handle = h
         for nd in self._nodes:
             nd._apply(self)
+
+    def _render_ranges(self, n_quanta, final=True):
+        """waa_render_range between the suspend points, the control log of each point replayed in front of its quantum; the last
+        range renders (final=False: everything but that last range — what a plan description needs).  Without suspend points:
+        waa_render."""
+        points = [q for q in sorted(self._ctl) if 0 < q < n_quanta]
+        if self._replayed:
+            points = []
+        if not points:
+            if final:
+                self._b.check(self._b.render(self._handle) if not self._replayed else
+                              self._b.render_range(self._handle, self._replayed, n_quanta - self._replayed))
+            return
+        prev = 0
+        for q in points:
+            self._b.check(self._b.render_range(self._handle, prev, q - prev))
+            for action in self._ctl[q]:
+                action(self._b, self._handle)
+            prev = q
+        self._replayed = prev
+        if final:
+            self._b.check(self._b.render_range(self._handle, prev, n_quanta - prev))
 
     def _adopt(self, handle):
         """Configure a batch the LIBRARY created for this graph (waa_render_sharded's setup callback): node payloads, params,
@@ -1070,7 +1239,11 @@ class OfflineAudioContext:
     def render_async(self):
         """Launch the render on the batch's stream without waiting (bench inner loop)."""
         self.prepare()
-        self._b.check(self._b.render(self._handle))
+        self._state = "running"
+        if self._rendered or not self._ctl:
+            self._b.check(self._b.render(self._handle))  # (a second render of the same batch: the bench loop)
+        else:
+            self._render_ranges((self.length + RENDER_QUANTUM_SIZE - 1) // RENDER_QUANTUM_SIZE)
         self._rendered = True
 
     def sync(self):
@@ -1082,6 +1255,7 @@ class OfflineAudioContext:
         self.render_async()
         out = np.empty((self.n_instances, self.number_of_channels, self.length), np.float32)
         self._b.check(self._b.download_all(self._handle, _fp(out)))
+        self._state = "closed"  # offline.rs:176
         return RenderedBatch(out, self.sample_rate)
 
     def render_instances(self, instances) -> np.ndarray:
@@ -1099,6 +1273,8 @@ class OfflineAudioContext:
     def plan_describe(self) -> str:
         """The launch plan derived from the graph (works on a plan-only context: device=PLAN_ONLY)."""
         self.prepare()
+        if self._ctl and not self._rendered:
+            self._render_ranges((self.length + RENDER_QUANTUM_SIZE - 1) // RENDER_QUANTUM_SIZE, final=False)
         need = C.c_size_t()
         self._b.check(self._b.plan_describe(self._handle, None, 0, C.byref(need)))
         buf = C.create_string_buffer(need.value + 1)

@@ -63,6 +63,9 @@ waa_status waa_batch_create(const waa_graph_desc* g, uint32_t n_inst, uint32_t n
       return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - invalid edge %u", e);
     b->edges.push_back(ed);
   }
+  b->edge_on.assign(b->edges.size(), 0u);
+  b->edge_off.assign(b->edges.size(), EDGE_NEVER);
+  b->n_user_nodes = g->n_nodes;
   b->nodes.resize(g->n_nodes);
   for (uint32_t i = 0; i < g->n_nodes; i++) {
     Node& n = b->nodes[i];
@@ -475,6 +478,11 @@ waa_status waa_source_start(waa_batch* b, uint32_t node, uint32_t inst, double w
     return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - The provided time value cannot be negative");
   Node& n = b->nodes[node];
   uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  // A start message handled in front of quantum ctl_q (a suspend point): the node is unscheduled — silent — before, and a start
+  // time that has passed by then becomes that block's time (audio_buffer_source.rs:516-518 `if !started && start_time <
+  // block_time { start_time = block_time }`, constant_source.rs:225-231 / oscillator.rs:400-406: start_index 0): the schedule
+  // replay sees the time the reference's renderer ends up with.  (block time as thread.rs:366: frames as f64 / rate as f64)
+  if (b->ctl_q > 0) when = std::max(when, (double)((uint64_t)b->ctl_q * RQ) / (double)b->sr);
   for (uint32_t k = lo; k < hi; k++) {
     if (n.sched[k].start != DBL_MAX) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot call `start` twice");
     n.sched[k].start = when;
@@ -497,6 +505,7 @@ waa_status waa_source_stop(waa_batch* b, uint32_t node, uint32_t inst, double wh
   if (when < 0.) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - The provided time value cannot be negative");
   Node& n = b->nodes[node];
   uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  if (b->ctl_q > 0) when = std::max(when, (double)((uint64_t)b->ctl_q * RQ) / (double)b->sr);  // (a stop in the past stops at this block)
   for (uint32_t k = lo; k < hi; k++) {
     if (n.sched[k].start == DBL_MAX) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot stop before start");
     n.sched[k].stop = when;
@@ -684,7 +693,7 @@ waa_status waa_param_schedule_event(waa_batch* b, uint32_t node, uint32_t param,
       // the node constructor's `param.set_value(options.x)` (e.g. gain.rs:117)
       if ((e = p.timelines[k]->schedule(WAA_EVENT_SET_VALUE, p.cst[k], 0., 0., nullptr, 0))) return e;
     }
-    if ((e = p.timelines[k]->schedule(type, value, time, aux, curve, n_curve))) return e;
+    if ((e = p.timelines[k]->schedule_at(b->ctl_q, type, value, time, aux, curve, n_curve))) return e;
   }
   return WAA_OK;
 }
@@ -696,6 +705,21 @@ waa_status waa_set_param_const(waa_batch* b, uint32_t node, uint32_t param, uint
   if ((e = check_inst(b, inst)) || (e = check_unplanned(b))) return e;
   ParamStore& p = b->nodes[node].params[param];
   uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
+  if (b->ctl_q > 0) {
+    // AudioParam::set_value from a suspend callback: a SetValue event the render thread handles in front of quantum ctl_q
+    // (param.rs:386-400, thread.rs:277-294) — through the timeline, which is created (seeded with the constant so far) if the
+    // param had none
+    if (p.timelines.empty()) p.timelines.resize(b->n_inst);
+    if (inst != WAA_ALL_INSTANCES) p.timelines_shared = false;
+    for (uint32_t k = lo; k < hi; k++) {
+      if (!p.timelines[k]) {
+        p.timelines[k] = std::make_shared<Timeline>(p.defv, p.minv, p.maxv, !p.k_rate);
+        if ((e = p.timelines[k]->schedule(WAA_EVENT_SET_VALUE, p.cst[k], 0., 0., nullptr, 0))) return e;
+      }
+      if ((e = p.timelines[k]->schedule_at(b->ctl_q, WAA_EVENT_SET_VALUE, value, 0., 0., nullptr, 0))) return e;
+    }
+    return WAA_OK;
+  }
   for (uint32_t k = lo; k < hi; k++) {
     p.cst[k] = value;
     // AudioParam::set_value after automation methods enqueues a SetValue event (param.rs:386-400): a timeline that
@@ -830,13 +854,67 @@ static int resolve_source_rate_modulation(waa_batch* b) {
   return 0;
 }
 
+// An edge that is live for quanta [on, off) only (waa_connect / waa_disconnect at a suspend point) becomes
+//   from -> GainNode(gain = 1 inside the window, 0 outside, one value per quantum, every instance) -> to
+// before the graph is planned.  gain.rs:163-179: a gain of exactly 1 passes the input through (clone: same channels, same
+// samples), a gain of exactly 0 makes the output silent (one silent channel) — what the destination's input sees of a connection
+// that exists resp. does not (quantum.rs mixing: a silent mono input changes neither the sum nor the computed channel count).
+// The gate inherits nothing else: count mode max / speakers (a GainNode's defaults) forwards whatever count arrives.
+// A window that is empty drops the edge; the summation ORDER at the destination follows the processing order of the gates
+// instead of the sources' (three or more summands may differ in the last bit from the reference).
+static int desugar_timed_edges(waa_batch* b) {
+  if (b->timed_edges_done) return 0;
+  b->timed_edges_done = true;
+  std::vector<waa_edge_desc> edges;
+  size_t n_gates = 0;
+  for (size_t k = 0; k < b->edges.size(); k++) {
+    const uint32_t on = b->edge_on[k], off = std::min(b->edge_off[k], b->n_quanta);
+    if (on == 0 && off >= b->n_quanta) {
+      edges.push_back(b->edges[k]);
+      continue;
+    }
+    if (on >= off) continue;  // never live
+    const uint32_t gid = (uint32_t)b->nodes.size();
+    b->nodes.emplace_back();
+    Node& g = b->nodes.back();
+    g.desc = waa_node_desc{};
+    g.desc.kind = WAA_NODE_GAIN;
+    default_channel_config(g, b->n_out);
+    g.params.resize(1);
+    g.params[0].init(b->n_inst, on == 0 ? 1.f : 0.f, -FLT_MAX, FLT_MAX);
+    ParamBlock blk;
+    blk.inst = WAA_ALL_INSTANCES;
+    blk.q0 = 0;
+    blk.nq = b->n_quanta;
+    blk.vpq = 1;
+    blk.v.assign(b->n_quanta, 0.f);
+    for (uint32_t q = on; q < off; q++) blk.v[q] = 1.f;
+    g.params[0].blocks.push_back(std::move(blk));
+    edges.push_back(waa_edge_desc{b->edges[k].from, b->edges[k].from_output, gid, 0});
+    edges.push_back(waa_edge_desc{gid, 0, b->edges[k].to, b->edges[k].to_input});
+    n_gates++;
+  }
+  if (n_gates) {
+    char note[200];
+    snprintf(note, sizeof note, "%zu connection(s) made or cut at suspend points (waa_connect / waa_disconnect after waa_render_range): gated by GainNodes %u..%u",
+             n_gates, b->n_user_nodes, (uint32_t)b->nodes.size() - 1);
+    b->timed_note = note;
+  }
+  b->edges = std::move(edges);
+  b->edge_on.assign(b->edges.size(), 0u);
+  b->edge_off.assign(b->edges.size(), EDGE_NEVER);
+  return 0;
+}
+
 static int timed_build_plan(waa_batch* b) {
+  if (int et = desugar_timed_edges(b)) return et;
   const auto t0 = std::chrono::steady_clock::now();
   const double a0 = b->t_alloc_ms, u0 = b->t_upload_ms;
   const uint64_t n0 = b->n_alloc, by0 = b->alloc_bytes;
   int e = resolve_source_rate_modulation(b);
   if (!e) e = build_plan(b);
   if (!e && !b->prepass_note.empty()) b->plan_log.push_back(b->prepass_note);
+  if (!e && !b->timed_note.empty()) b->plan_log.push_back(b->timed_note);
   b->t_plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   b->plan_alloc_ms = b->t_alloc_ms - a0;
   b->plan_upload_ms = b->t_upload_ms - u0;
@@ -873,8 +951,74 @@ waa_status waa_plan_describe(waa_batch* b, char* buf, size_t cap, size_t* needed
   return WAA_OK;
 }
 
+// The quantum loop of render_audiobuffer_sync with its suspend points (thread.rs:277-294; OfflineAudioContext::suspend_sync,
+// offline.rs:359-397).  The engine renders node-major, not quantum-major, so a range is not rendered when it is asked for: the
+// call moves the CONTROL CLOCK to quantum0 + n_quanta, every control call made before the next one (waa_connect /
+// waa_disconnect, param values and automation, start / stop) is recorded with the quantum in front of which the reference's
+// render thread would have handled it, and the call that reaches the last quantum plans the graph WITH its history and renders
+// all of it.  What a suspend callback cannot do through this ABI is read rendered audio (an analyser pull before the last range
+// is an InvalidStateError): a host that needs that renders a shorter batch of the graph as it is so far
+// (api.py::OfflineAudioContext does).
+waa_status waa_render_range(waa_batch* b, uint64_t quantum0, uint32_t n_quanta) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - the batch is frozen once rendering has started");
+  if (quantum0 != b->ctl_q)
+    return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - ranges are consecutive: the next one starts at quantum %u, not %llu", b->ctl_q,
+                (unsigned long long)quantum0);
+  if (n_quanta == 0 || quantum0 + n_quanta > b->n_quanta)
+    return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - quanta [%llu, %llu) of a render of %u", (unsigned long long)quantum0,
+                (unsigned long long)(quantum0 + n_quanta), b->n_quanta);
+  b->ranged = true;
+  b->ctl_q = (uint32_t)(quantum0 + n_quanta);
+  if (b->ctl_q < b->n_quanta) return WAA_OK;
+  return waa_render(b);
+}
+
+static int check_edge(waa_batch* b, uint32_t from, uint32_t from_output, uint32_t to, uint32_t to_input) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (from >= b->n_user_nodes || to >= b->n_user_nodes || from_output != 0 || (to_input != 0 && !(to_input & 0x80000000u)))
+    return fail(WAA_ERR_INVALID_ARGUMENT, "IndexSizeError - invalid edge %u:%u -> %u:%u", from, from_output, to, to_input);
+  if ((to_input & 0x80000000u) && (to_input & 0x7fffffffu) >= b->nodes[to].params.size())
+    return fail(WAA_ERR_INVALID_ARGUMENT, "no such param %u on node %u", to_input & 0x7fffffffu, to);
+  return check_unplanned(b);
+}
+
+// AudioNode::connect_from_output_to_input (audio_node.rs:247-289) after the batch was created — at a suspend point when the
+// control clock has moved.  Connecting what is connected already is a no-op, as in the reference (graph.rs add_edge on a set).
+waa_status waa_connect(waa_batch* b, uint32_t from, uint32_t from_output, uint32_t to, uint32_t to_input) {
+  if (int e = check_edge(b, from, from_output, to, to_input)) return e;
+  for (size_t k = 0; k < b->edges.size(); k++) {
+    const waa_edge_desc& ed = b->edges[k];
+    if (ed.from == from && ed.from_output == from_output && ed.to == to && ed.to_input == to_input && b->edge_off[k] == EDGE_NEVER) return WAA_OK;
+  }
+  b->edges.push_back(waa_edge_desc{from, from_output, to, to_input});
+  b->edge_on.push_back(b->ctl_q);
+  b->edge_off.push_back(EDGE_NEVER);
+  return WAA_OK;
+}
+
+// AudioNode::disconnect_dest_from_output_to_input (audio_node.rs:341-420): the connection must exist
+waa_status waa_disconnect(waa_batch* b, uint32_t from, uint32_t from_output, uint32_t to, uint32_t to_input) {
+  if (int e = check_edge(b, from, from_output, to, to_input)) return e;
+  for (size_t k = b->edges.size(); k-- > 0;) {
+    const waa_edge_desc& ed = b->edges[k];
+    if (!(ed.from == from && ed.from_output == from_output && ed.to == to && ed.to_input == to_input) || b->edge_off[k] != EDGE_NEVER) continue;
+    if (b->edge_on[k] >= b->ctl_q) {  // made and cut at the same point: it never carried a quantum
+      b->edges.erase(b->edges.begin() + (long)k);
+      b->edge_on.erase(b->edge_on.begin() + (long)k);
+      b->edge_off.erase(b->edge_off.begin() + (long)k);
+    } else {
+      b->edge_off[k] = b->ctl_q;
+    }
+    return WAA_OK;
+  }
+  return fail(WAA_ERR_INVALID_ARGUMENT, "InvalidAccessError - attempting to disconnect unconnected nodes");
+}
+
 waa_status waa_render(waa_batch* b) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (b->ranged && b->ctl_q < b->n_quanta)
+    return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - a ranged render is in progress (suspended in front of quantum %u): waa_render_range renders the rest", b->ctl_q);
   if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch (WAA_DEVICE_PLAN_ONLY) cannot render: there is no CPU fallback");
   HIP_TRY(hipSetDevice(b->device));
   if (!b->planned) {

@@ -124,6 +124,32 @@ int Timeline::schedule(int type, float value, double time, double aux, const flo
   return insert(std::move(ev));
 }
 
+int Timeline::schedule_at(uint32_t arrival_q, int type, float value, double time, double aux, const float* curve, uint32_t n_curve) {
+  if (arrival_q == 0 && arrivals_.empty()) return schedule(type, value, time, aux, curve, n_curve);
+  {
+    // the control-side assertions now (a scratch timeline without a queue: only the argument checks can fire)
+    Timeline probe(intrinsic_, min_, max_, a_rate_);
+    if (int e = probe.schedule(type, value, time, aux, curve, n_curve)) return e;
+  }
+  Arrival a;
+  a.q = arrival_q;
+  a.type = type;
+  a.value = value;
+  a.time = time;
+  a.aux = aux;
+  if (curve && n_curve) a.curve.assign(curve, curve + n_curve);
+  arrivals_.push_back(std::move(a));
+  return 0;
+}
+
+int Timeline::apply_arrivals(uint32_t q) {
+  while (next_arrival_ < arrivals_.size() && arrivals_[next_arrival_].q <= q) {
+    const Arrival& a = arrivals_[next_arrival_++];
+    if (int e = schedule(a.type, a.value, a.time, a.aux, a.curve.empty() ? nullptr : a.curve.data(), (uint32_t)a.curve.size())) return e;
+  }
+  return 0;
+}
+
 // handle_incoming_event, param.rs:796-1047
 int Timeline::insert(Event ev) {
   auto sort_queue = [&] {

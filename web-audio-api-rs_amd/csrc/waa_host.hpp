@@ -44,6 +44,13 @@ class Timeline {
   ~Timeline();
   // one automation method call (WAA_EVENT_*); returns a waa_status (the reference's panics)
   int schedule(int type, float value, double time, double aux, const float* curve, uint32_t n_curve);
+  // the same call made while the render is suspended in front of quantum `arrival_q` (OfflineAudioContext::suspend_sync,
+  // offline.rs:359-397): the render thread handles the control message right before it renders that quantum
+  // (handle_control_messages, thread.rs:277-294) — the event enters the queue THEN, with the queue as it is then.  Argument
+  // errors are reported at once, queue-dependent ones (an event inside a value curve) by apply_arrivals.
+  int schedule_at(uint32_t arrival_q, int type, float value, double time, double aux, const float* curve, uint32_t n_curve);
+  int apply_arrivals(uint32_t q);  // before compute() of quantum q
+  bool has_arrivals() const { return !arrivals_.empty(); }
   // one block: 1 or `count` values into out (capacity >= count); returns how many
   uint32_t compute(double block_time, double dt, uint32_t count, float* out);
   float value() const;  // AudioParam::value()
@@ -58,6 +65,15 @@ class Timeline {
   bool a_rate_;
   std::vector<Event> queue_;     // sorted by time (stable)
   std::unique_ptr<Event> last_;  // the last event that was consumed (start point of ramps and targets)
+  struct Arrival {
+    uint32_t q;
+    int type;
+    float value;
+    double time, aux;
+    std::vector<float> curve;
+  };
+  std::vector<Arrival> arrivals_;  // in call order (arrival quanta never decrease: the control clock only moves forward)
+  size_t next_arrival_ = 0;
 };
 
 struct ParamBlock {
@@ -272,6 +288,7 @@ using SchedKey = std::tuple<double, double, double, double, int, double, double,
 
 using namespace waa::host;  // (the opaque C handle lives in the global namespace)
 
+constexpr uint32_t EDGE_NEVER = 0xFFFFFFFFu;
 struct waa_batch {
   uint32_t n_inst = 0, n_out = 0;
   uint64_t length = 0;
@@ -283,6 +300,17 @@ struct waa_batch {
   hipStream_t stream = nullptr;
   std::vector<Node> nodes;
   std::vector<waa_edge_desc> edges;
+  // OfflineAudioContext::suspend_sync (offline.rs:359-397): the control clock — the render quantum in front of which the render
+  // is "suspended" (waa_render_range moves it); control calls made at ctl_q > 0 take effect from that quantum on.  An edge is
+  // live for quanta [edge_on, edge_off): waa_connect / waa_disconnect at ctl_q > 0 (EDGE_NEVER: no end).  At plan time an edge
+  // that is not live for the whole render becomes a GainNode whose gain is 1 inside the window and 0 outside
+  // (desugar_timed_edges, waa_abi.cpp): gain.rs' two fast paths — pass-through and silence — are exactly "connected" and "not".
+  uint32_t ctl_q = 0;
+  std::vector<uint32_t> edge_on, edge_off;
+  bool ranged = false;              // waa_render_range has been called: waa_render would render from the start again
+  uint32_t n_user_nodes = 0;        // nodes of the caller's graph (the gates of timed edges are appended behind them)
+  bool timed_edges_done = false;
+  std::string timed_note;
   std::vector<uint32_t> order;
   std::vector<uint8_t> cut;         // per DelayNode: writer->reader edge removed by the cycle breaker
   std::vector<uint32_t> group_tiles;  // block size (tiles) of every block-scheduled feedback loop

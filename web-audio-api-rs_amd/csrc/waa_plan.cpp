@@ -701,7 +701,9 @@ int materialise_automation(waa_batch* b) {
                                 kind == WAA_NODE_OSCILLATOR ||
                                 (kind == WAA_NODE_PANNER && pk >= 6 && n.desc.i[0] != WAA_PANNING_HRTF);
         const bool want = measure_switch("WAA_DEVICE_AUTOMATION") ? true : !shared;  // (switch: also replay shared timelines there)
-        if (consumable && !p.k_rate && want && !b->dry && !measure_switch("WAA_HOST_AUTOMATION")) {
+        bool arrivals = false;  // (events that arrive at a suspend point: the host's replay applies them in front of their quantum)
+        for (const auto& tl : p.timelines) arrivals |= tl && tl->has_arrivals();
+        if (consumable && !p.k_rate && want && !arrivals && !b->dry && !measure_switch("WAA_HOST_AUTOMATION")) {
           p.dev_tl = true;
           continue;  // (the timelines are consumed when the param is uploaded)
         }
@@ -721,6 +723,7 @@ int materialise_automation(waa_batch* b) {
         };
         for (uint32_t q = 0; q < b->n_quanta; q++) {
           const double block_time = (double)((uint64_t)q * RQ) / sample_rate;
+          if (int ea = tl->apply_arrivals(q)) return ea;  // (control messages of a suspend point in front of this quantum)
           const uint32_t len = tl->compute(block_time, dt, RQ, buf);
           if (run.nq && run.vpq != len) flush();
           if (!run.nq) {
