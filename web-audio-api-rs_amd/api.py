@@ -270,6 +270,16 @@ class AudioParam:
         self._blocks = []
         self._events = []
 
+    def _ctx(self):
+        """the context whose control clock this param follows (an AudioListener's params: the listener's context)"""
+        return self._node.context if self._node is not None else getattr(self, "_listener_ctx", None)
+
+    def _owner_ids(self, ctx):
+        """the node ids the param is addressed through (the listener's nine params: every PannerNode, like AudioListener::_apply)"""
+        if self._node is not None:
+            return [self._node.id]
+        return [nd.id for nd in ctx._nodes if nd.kind == NODE_PANNER]
+
     @property
     def value(self) -> float:
         return self._const[ALL]
@@ -279,10 +289,11 @@ class AudioParam:
         self.set_value(v)
 
     def set_value(self, v: float, instance: int = ALL):
-        ctx = self._node.context
-        if ctx._now_q > 0:  # inside a suspend_sync callback: a SetValue event the render thread handles at that quantum
-            nid, pid, v = self._node.id, self._pid, float(v)
-            ctx._log(lambda b, h: b.check(b.set_param_const(h, nid, pid, instance, v)))
+        ctx = self._ctx()
+        if ctx is not None and ctx._now_q > 0:  # inside a suspend_sync callback: a SetValue event the render thread handles at that quantum
+            pid, v = self._pid, float(v)
+            for nid in self._owner_ids(ctx):
+                ctx._log(lambda b, h, nid=nid: b.check(b.set_param_const(h, nid, pid, instance, v)))
             return self
         self._const[instance] = float(v)
         if instance == ALL:
@@ -303,11 +314,12 @@ class AudioParam:
     #    `instance`: the context of the batch the call is made on (ALL = the same call on every context).
     def _event(self, kind: int, value: float, time: float, aux: float = 0.0, curve=None, instance: int = ALL):
         ev = (kind, float(value), float(time), float(aux), None if curve is None else _f32(curve), instance)
-        ctx = self._node.context
-        if ctx._now_q > 0:  # inside a suspend_sync callback
-            nid, pid = self._node.id, self._pid
-            ctx._log(lambda b, h: b.check(b.param_schedule_event(h, nid, pid, ev[5], ev[0], ev[1], ev[2], ev[3],
-                                                                 None if ev[4] is None else _fp(ev[4]), 0 if ev[4] is None else ev[4].size)))
+        ctx = self._ctx()
+        if ctx is not None and ctx._now_q > 0:  # inside a suspend_sync callback
+            pid = self._pid
+            for nid in self._owner_ids(ctx):
+                ctx._log(lambda b, h, nid=nid: b.check(b.param_schedule_event(h, nid, pid, ev[5], ev[0], ev[1], ev[2], ev[3],
+                                                                              None if ev[4] is None else _fp(ev[4]), 0 if ev[4] is None else ev[4].size)))
             return self
         self._events.append(ev)
         return self
@@ -1033,6 +1045,8 @@ class OfflineAudioContext:
         self._live = []   # the connections that exist "now" (disconnect's InvalidAccessError, disconnect() of everything)
         self._state = "suspended"  # AudioContextState of a context that has not started rendering (offline.rs:451)
         self._listener = AudioListener()
+        for prm in self._listener.params:
+            prm._listener_ctx = self
         self._destination = AudioDestinationNode(self)
 
     def state(self) -> str:
