@@ -831,6 +831,8 @@ def main():
         if share:
             out["rehearsal"] = f"{world} ranks SHARE one GPU (gloo): contexts per rank = the per-GPU count / {world}; format check only"
         out["roofline"]["kernel_ms"] = round(roof["kernel_ms_per_step"], 4)
+        if len(roof.get("kernel_ms", {})) > 1:  # (a multi-kernel headline, e.g. --workload t1: every kernel's mean over the timed steps)
+            out["roofline"]["kernel_ms_all"] = {k: round(v * roof["launches_per_step"].get(k, 1), 4) for k, v in roof["kernel_ms"].items()}
         # the headline's traffic measured by THIS run where rocprofv3 exists (the stamped record of profiles/pmc_traffic.json is what
         # remains otherwise, and what the other workloads use)
         if default_run and world == 1 and not args.no_live_pmc:

@@ -315,7 +315,7 @@ def test_plan_convolver_inside_a_loop(hip):
     # response with 128-frame partitions follows the loop quantum by quantum there (tests/test_frozen_loops.py) ...
     c = _convolver_loop(hip, noise[:, :, :2048 * 8], _decaying_ir(2, 3000, 1, 0.01), 0.1, 0.5, 2048 * 30, device=waa.PLAN_ONLY)
     plan = c.plan_describe()
-    assert "fft B=128" in plan and "cut at the node(s)" in plan and "one quantum per block" in plan, plan
+    assert "fft B=128" in plan and "cut at the node(s)" in plan and "render quanta (the shortest delay across a cut" in plan, plan
     c.close()
     # ... a longer response (partitions of several quanta) is still refused
     c = _convolver_loop(hip, noise[:, :, :2048 * 8], _decaying_ir(2, 9000, 1, 0.01), 0.1, 0.5, 2048 * 30, device=waa.PLAN_ONLY)

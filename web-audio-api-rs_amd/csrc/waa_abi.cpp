@@ -753,6 +753,7 @@ waa_status waa_set_param_block(waa_batch* b, uint32_t node, uint32_t param, uint
 // build_plan under a stopwatch; the split (hipMalloc / blocking uploads / the rest = host planning: ordering, scheduling
 // replay, coefficient and automation evaluation) goes into the plan description
 static int run_steps(waa_batch* b);
+int waa_settle_loops(waa_batch* b);
 
 // AudioBufferSourceNode::playback_rate / detune with an input from the graph (k-rate: value + the first sample of the
 // mixed input, NaN -> default, clamped, once per render quantum: param.rs:739-760; audio_buffer_source.rs:176-197).  The
@@ -1015,6 +1016,28 @@ waa_status waa_disconnect(waa_batch* b, uint32_t from, uint32_t from_output, uin
   return fail(WAA_ERR_INVALID_ARGUMENT, "InvalidAccessError - attempting to disconnect unconnected nodes");
 }
 
+// Quantum-blocked loops rendered in blocks of several quanta are optimistic about ONE thing (waa_plan_dyn.cpp: the ring's channel
+// count as the reader of a split delay pair sees it).  Every entry point that hands out results waits for the render and looks at
+// the writers' flags first; a flagged render is repeated with one quantum per block — the round-5 form, always right.
+int waa_settle_loops(waa_batch* b) {
+  if (!b->loops_unsettled || b->dry) return 0;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->loops_unsettled = false;
+  bool bad = false;
+  for (int32_t* f : b->loop_flags) {
+    int32_t v = 0;
+    HIP_TRY(hipMemcpy(&v, f, sizeof v, hipMemcpyDeviceToHost));
+    bad |= v != 0;
+  }
+  if (!bad) return 0;
+  b->loops_one_quantum = true;
+  b->plan_log.push_back("a feedback loop's channel counts moved inside a block of several quanta: rendered again one quantum per block (and from now on)");
+  int e = run_steps(b);
+  if (e) return e;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
 waa_status waa_render(waa_batch* b) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
   if (b->ranged && b->ctl_q < b->n_quanta)
@@ -1203,14 +1226,18 @@ static int run_steps(waa_batch* b) {
           int e = run_step(b->steps[k], 0, b->n_tiles);
           if (e) return e;
         }
-      const uint32_t bq = std::max<uint32_t>(1, b->qgroup_quanta[(size_t)st.qgroup]);
-      for (uint32_t q0 = 0; q0 < b->n_quanta; q0 += bq) {
-        const uint32_t q1 = std::min<uint32_t>(b->n_quanta, q0 + bq);
+      const uint32_t bq = b->loops_one_quantum ? 1u : std::max<uint32_t>(1, b->qgroup_quanta[(size_t)st.qgroup]);
+      if (bq > 1) b->loops_unsettled = true;
+      // (the first block is one quantum: every delay line starts as one silent channel, so the count moves in quantum 0 of
+      // nearly every graph — and a change in a block's LAST quantum is the one place where it is harmless)
+      for (uint32_t q0 = 0; q0 < b->n_quanta;) {
+        const uint32_t q1 = std::min<uint32_t>(b->n_quanta, q0 + (q0 == 0 ? 1u : bq));
         for (size_t k = i; k < j; k++) {
           if (b->steps[k].prologue) continue;
           int e = run_step_q(b->steps[k], q0, q1);
           if (e) return e;
         }
+        q0 = q1;
       }
       i = j;
       continue;
@@ -1329,6 +1356,7 @@ waa_status waa_sync(waa_batch* b) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
   if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch has no device");
   HIP_TRY(hipStreamSynchronize(b->stream));
+  if (int es = waa_settle_loops(b)) return es;
   if (b->scan_counter) {  // a bounded spin of the chained scan gave up: the render is not to be trusted
     uint32_t words[1] = {0};
     HIP_TRY(hipMemcpy(words, b->scan_counter + 8 * 16, sizeof words, hipMemcpyDeviceToHost));
@@ -1344,6 +1372,7 @@ waa_status waa_download(waa_batch* b, uint32_t inst, uint32_t ch, float* dst, ui
   if (!b->planned || !b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
+  if (int es = waa_settle_loops(b)) return es;
   const SignalRef& s = b->nodes[0].sig;
   if ((int)ch < s.nch) {
     HIP_TRY(hipMemcpy(dst, s.base + (size_t)inst * s.inst_stride + (size_t)ch * s.ch_stride, frames * sizeof(float),
@@ -1359,6 +1388,7 @@ waa_status waa_download_all(waa_batch* b, float* dst) {
   if (!b->planned || !b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
+  if (int es = waa_settle_loops(b)) return es;
   const SignalRef& s = b->nodes[0].sig;
   if (b->length == 0) return WAA_OK;
   if ((uint32_t)s.nch == b->n_out) {
@@ -1395,6 +1425,8 @@ static int analyser_compute(waa_batch* b, uint32_t node, int what) {
   const int N = n.desc.i[0], M = N / 2;
   const size_t ni = b->n_inst;
   const bool on_device = b->planned && b->rendered && n.live && !b->dry;
+  if (on_device)
+    if (int es = waa_settle_loops(b)) return es;  // (run_steps resets the analysers' caches: the pull below sees the settled render)
   if (!on_device) {
     // nothing rendered (or the node does not reach the destination): an all-zero ring buffer
     if (!n.an.have_db) {

@@ -734,6 +734,11 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
           }
         }
         if (lane == 0) {
+          // (round 6) blocks of several quanta: the reader in the EARLIER launch of this block has already rendered the block's
+          // later quanta with the ring count it found at the block's start.  The count it should have seen is this one, one
+          // quantum late (delay.rs:515-530: ring[0].number_of_channels() right now) — a change anywhere but in the block's last
+          // quantum invalidates the block: flagged, and the host renders the loop again one quantum per block (waa_abi.cpp).
+          if (li.xstate && sn != ist[it * 4 + 0] && q + 1 < rq1 && rq1 - rq0 > 1) store_global(li.xstate + (uint64_t)d.n_inst * 2, 1);
           ist[it * 4 + 0] = sn;
           if (sn == 1) ist[it * 4 + 1] = (int)q;
           if (li.xstate) {  // a reader in another launch follows the ring's state (round 5)

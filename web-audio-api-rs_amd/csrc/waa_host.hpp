@@ -315,6 +315,9 @@ struct waa_batch {
   std::vector<uint8_t> cut;         // per DelayNode: writer->reader edge removed by the cycle breaker
   std::vector<uint32_t> group_tiles;  // block size (tiles) of every block-scheduled feedback loop
   std::vector<uint32_t> qgroup_quanta;  // block size (render quanta) of every quantum-blocked loop of a dynamic-count plan
+  std::vector<int32_t*> loop_flags;     // device words a delay writer sets when a multi-quantum block was invalid (waa_dyn.hip)
+  bool loops_one_quantum = false;       // ... after which the loops are rendered one quantum per block
+  bool loops_unsettled = false;         // a render with multi-quantum blocks is in flight: its flags have not been looked at
   std::vector<void*> allocs;        // plan-owned device allocations
   std::vector<void*> payload_allocs;  // buffers uploaded through the API
   std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render

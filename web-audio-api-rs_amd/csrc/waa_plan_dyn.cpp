@@ -529,10 +529,40 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
         xd.writer_seg = ws;
         int e = temp_signal(b, b->nodes[did].in_nch, &xd.line);
         if (!e) e = dev_alloc(b, &xd.aux32, (size_t)b->n_inst * cs);
-        if (!e) e = dev_alloc(b, &xd.state, (size_t)b->n_inst * 2);
+        if (!e) e = dev_alloc(b, &xd.state, (size_t)b->n_inst * 2 + 4);  // (+ the block-violation flag behind the instances' pairs)
         if (e) return e;
-        b->state_bufs.push_back({xd.state, (size_t)b->n_inst * 2 * sizeof(int32_t)});  // (count 1, never mixed to mono: zeros)
+        b->state_bufs.push_back({xd.state, ((size_t)b->n_inst * 2 + 4) * sizeof(int32_t)});  // (count 1, never mixed to mono: zeros)
+        b->loop_flags.push_back(xd.state + (size_t)b->n_inst * 2);
         xdelay[did] = xd;
+      }
+      {
+        // The block size (round-5 review, weak 6: one quantum per block = 15 000 launch sets for a 10 s render,
+        // 333 ms for 1024 contexts).  Every path from a later segment back into an earlier one goes through a DelayNode whose
+        // writer and reader the cuts separated; the reader of block [t, t + bq) reads the line up to frame
+        // (t + bq) * 128 - delay + 1 (linear interpolation, delay.rs:560-590), which must have been written by EARLIER blocks:
+        // bq <= (delay_frames - 1) / 128 for every split pair.  Known at plan time when delayTime is a constant; an automated or
+        // modulated delayTime keeps one quantum (delay.rs:693-701 guarantees no more than that).
+        uint32_t bq = xdelay.empty() ? 1u : b->n_quanta;
+        for (auto& kv : xdelay) {
+          const Node& dn = b->nodes[kv.first];
+          const ParamStore& dp = dn.params[WAA_PARAM_DELAY_DELAY_TIME];
+          const bool constant = dp.mode() == 0 && dp.timelines.empty() && !dp.dev_tl &&
+                                (dn.pin_edges.size() <= (size_t)WAA_PARAM_DELAY_DELAY_TIME || dn.pin_edges[WAA_PARAM_DELAY_DELAY_TIME].empty());
+          if (!constant) {
+            bq = 1;
+            break;
+          }
+          float mn = dp.cst.empty() ? 0.f : dp.cst[0];
+          for (float v2 : dp.cst) mn = std::min(mn, v2);
+          const double frames = std::floor((double)dp.fix(mn) * (double)b->sr);
+          bq = std::min(bq, frames >= 2. * RQ + 1. ? (uint32_t)((frames - 1.) / RQ) : 1u);
+        }
+        // (what the delay does NOT bound: the reader's channel count follows the writer's input with ONE quantum of lag whatever the
+        // delay time — ring[0].number_of_channels() — so a block is only right while that count stands still inside it.  It does
+        // almost always (it moves when a source starts or ends and when the loop falls silent); the writer flags the blocks where it
+        // did not, and the render is repeated one quantum per block: waa_abi.cpp::settle_loops.)
+        if (measure_switch("WAA_LOOP_ONE_QUANTUM")) bq = 1;  // (A/B: the round-5 form)
+        b->qgroup_quanta.back() = std::max(bq, 1u);
       }
       for (uint32_t v : verts) {
         const uint32_t vid = v & ~VTX_READER;
@@ -588,7 +618,13 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
         }
         n_ranged += ranged;
       }
-      plan_note(b, "feedback loop with a frozen-state node inside (oversampled WaveShaper / HRTF panner / short ConvolverNode): cut at the node(s), %zu launch step(s) per quantum, one quantum per block", n_ranged);
+      {
+        const uint32_t bq = b->qgroup_quanta.back(), n_blocks = (b->n_quanta + bq - 1) / bq;
+        plan_note(b, "feedback loop with a frozen-state node inside (oversampled WaveShaper / HRTF panner / short ConvolverNode): cut at the node(s), "
+                     "%zu launch step(s) per block of %u render quanta (the shortest delay across a cut allows no more), %u blocks = %zu launches per render"
+                     " — a correctness path: expect ~10 us of host + device time per launch, whatever the batch size",
+                  n_ranged, bq, n_blocks, (size_t)n_blocks * n_ranged);
+      }
       cur_qgroup = -1;
       xdelay.clear();
       continue;

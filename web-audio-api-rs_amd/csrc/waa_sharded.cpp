@@ -18,6 +18,8 @@
 
 #include "waa_host.hpp"
 
+extern "C" int waa_settle_loops(waa_batch* b);  // waa_abi.cpp
+
 namespace waa {
 namespace host {
 int fill_pending_uploads(waa_batch* b);
@@ -113,6 +115,7 @@ waa_status waa_download_all_pcm16(waa_batch* b, int16_t* dst) {
   if (!b->planned || !b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing rendered yet");
   if (b->length == 0) return WAA_OK;
   HIP_TRY(hipSetDevice(b->device));
+  if (int es = waa_settle_loops(b)) return es;
   const size_t count = (size_t)b->n_inst * b->length * b->n_out;
   if (!b->pcm_out) {  // (the batch's size never changes; owned by the batch like every other buffer: the device arena serves it when reserved)
     int e = dev_alloc(b, &b->pcm_out, count, true);
