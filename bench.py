@@ -544,7 +544,7 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
     from web_audio_api_rs_amd.sharding import render_sharded
     frames = int(round(seconds * SR))
 
-    def run_graph(graph, n, parts, pcm=False, pcm_out=False):
+    def run_graph(graph, n, parts, pcm=False, pcm_out=False, reuse=True):
         if pcm:
             host_in = torch.empty((n, frames, 2), dtype=torch.int16, pin_memory=True).random_(-32768, 32767)
         else:
@@ -568,7 +568,7 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
             if dist is not None:
                 dist.barrier()
             t = render_sharded(build, host_in, host_out, devices=(local_rank,), sub_batches=parts, sample_rate=SR, pcm16=pcm,
-                               pull=pull if graph == "c4" else None, out_pcm16=pcm_out)["seconds"]
+                               pull=pull if graph == "c4" else None, out_pcm16=pcm_out, reuse=reuse)["seconds"]
             if dist is not None:
                 tt = torch.tensor([t], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -581,7 +581,8 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
     rec = {"note": "host (pinned) -> waa_render_sharded (C ABI: set_buffer_batch -> render -> download_all per sub-batch, pipelined), "
                    "batch creation and planning included, PCIe-bound; every rank at once, slowest rank's time; the sub-batches' buffers come "
                    "out of a device arena reserved for the record (waa_device_arena_reserve, what a serving process does once): "
-                   "hipMalloc / hipFree in the pipeline synchronise the device (c2_no_arena_ms: the same call without it)", "sub_batches": n_sub}
+                   "hipMalloc / hipFree in the pipeline synchronise the device (c2_no_arena_ms: the same call without it); sub-batches of equal "
+                   "size are re-armed instead of re-created (waa_sharded_job.reuse_batches; c4_512_no_reuse_ms: without)", "sub_batches": n_sub}
     if world == 1:
         ms0, _ = run_graph("c2", n_inst, n_sub)
         rec["c2_no_arena_ms"] = ms0
@@ -604,6 +605,16 @@ def e2e_record(torch, waa, hip, n_inst, seconds, local_rank, dist=None, world=1,
             rec["c2_pcm16_error"] = repr(e)[:100]
     ms, qps = run_graph("c4", c4_inst, n_sub)
     rec["c4_512_per_gpu_ms"], rec["c4_quanta_per_s"] = ms, round(qps)
+    if world == 1:
+        try:  # (what re-arming buys: the same call with every sub-batch created, set up and planned anew — rounds 3-5's pipeline)
+            rec["c4_512_no_reuse_ms"] = run_graph("c4", c4_inst, n_sub, reuse=False)[0]
+        except Exception as e:  # reporting only
+            rec["c4_no_reuse_error"] = repr(e)[:100]
+        try:  # the north-star graph through the same boundary (round-5 review, weak 3)
+            ms, qps = run_graph("t1", n_inst, n_sub)
+            rec["t1_ms"], rec["t1_quanta_per_s"] = ms, round(qps)
+        except Exception as e:
+            rec["t1_error"] = repr(e)[:100]
     if arena_gb > 0:
         hip.check(hip.device_arena_reserve(local_rank, 0))
     return rec

@@ -358,6 +358,14 @@ waa_status waa_render_range(waa_batch* batch, uint64_t quantum0, uint32_t n_quan
  * description and left unconnected (an unconnected node renders nothing anybody hears) until the callback's connect. */
 waa_status waa_connect(waa_batch* batch, uint32_t from, uint32_t from_output, uint32_t to, uint32_t to_input);
 waa_status waa_disconnect(waa_batch* batch, uint32_t from, uint32_t from_output, uint32_t to, uint32_t to_input);
+/* "Same graph, new audio": put a planned (usually rendered) batch back in front of its render WITHOUT planning or allocating
+ * again.  An OfflineAudioContext renders once (src/context/offline.rs:157-185: the renderer is taken); a host that renders the
+ * same graph for one set of AudioBuffers after the other creates context after context — here it keeps the batch: after
+ * waa_batch_rearm, waa_source_set_buffer_batch / waa_source_set_buffer_pcm16_batch upload INTO the device buffers the batch was
+ * planned with (same channels, frames and rate: anything else is an InvalidStateError), waa_source_adopt_device accepts the
+ * pointer it already reads, and waa_render renders from the initial state.  Everything else of the batch is frozen as before.
+ * waa_render_sharded does this for the sub-batches of a job when waa_sharded_job.reuse_batches is set. */
+waa_status waa_batch_rearm(waa_batch* batch);
 waa_status waa_sync(waa_batch* batch);
 /* rendered AudioBuffer channel of one instance -> dst[frames] (frames <= length) */
 waa_status waa_download(waa_batch* batch, uint32_t instance, uint32_t channel, float* dst, uint64_t frames);
@@ -404,6 +412,9 @@ typedef struct waa_sharded_job {
   waa_shard_setup_fn setup;      /* may be NULL */
   waa_shard_pull_fn pull;        /* may be NULL */
   void* user;
+  uint32_t reuse_batches;        /* 1: `setup` configures every sub-batch the same way (nothing depends on `first`): a sub-batch that
+                                  * has been downloaded is re-armed (waa_batch_rearm) for a later sub-batch of the same size instead
+                                  * of being destroyed — the later one skips creation, setup and planning */
 } waa_sharded_job;
 /* Blocks until every context is rendered and downloaded; *seconds (may be NULL) = wall time.  Pinned host buffers let
  * the transfers run at link speed, and a device arena (waa_device_arena_reserve, once per process) keeps hipMalloc / hipFree —

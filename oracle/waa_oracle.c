@@ -3867,6 +3867,17 @@ waa_status orc_set_threads(orc_batch* b, int32_t n) {
   return WAA_OK;
 }
 
+/* waa_batch_rearm: the product library's "same graph, new audio" entry point.  The interpreter has no plan to keep: a batch is put
+ * back in front of its render (orc_rewind's state reset) and then takes new source buffers like a fresh one. */
+waa_status orc_rewind(orc_batch* b);
+waa_status orc_batch_rearm(orc_batch* b) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (!b->rendered) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing to re-arm: the batch has not been rendered");
+  int e = orc_rewind(b);
+  if (e) return e;
+  b->rendered = 0;
+  return WAA_OK;
+}
 waa_status orc_render(orc_batch* b);
 /* waa_render_range: the quantum loop with its suspend points (thread.rs:277-294).  The interpreter renders when the last range
  * arrives, like the product library, and applies every control message in front of the quantum it was submitted at. */

@@ -378,3 +378,54 @@ def test_pcm16_download_of_more_contexts_than_grid_rows(hip, orc):
         ctx.close()
         outs.append(pcm)
     assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0][-1].astype(np.int32)).max() > 100
+
+
+@pytest.mark.gpu
+def test_rearmed_batch_renders_new_audio_without_a_new_plan(hip, orc):
+    """waa_batch_rearm (round 6): a planned batch takes the next AudioBuffers of the same shape into the device buffers it was
+    planned with; the render is the one a fresh batch gives, bit for bit; another shape is an InvalidStateError"""
+    n, frames = 6, RQ * 30 + 5
+    a, b2 = white_noise(n, 2, frames), white_noise(n, 2, frames, seed0=77)
+    ctx, src = _build(hip)(n, 0)
+    src.set_buffer_batch(a, 48000.0)
+    first = ctx.start_rendering_sync().data
+    hb, h = ctx._b, ctx._handle
+    hb.check(hb.batch_rearm(h))
+    with pytest.raises(waa.WaaError, match="InvalidStateError"):   # nothing rendered (yet) after a re-arm
+        hb.check(hb.download_all(h, waa.api._fp(np.empty_like(first))))
+    with pytest.raises(waa.WaaError, match="the shape it was planned with"):
+        hb.check(hb.source_set_buffer_batch(h, src.id, waa.api._fp(b2[:, :, :-1].copy()), 2, frames - 1, 48000.0))
+    hb.check(hb.source_set_buffer_batch(h, src.id, waa.api._fp(b2), 2, frames, 48000.0))
+    hb.check(hb.render(h))
+    second = np.empty_like(first)
+    hb.check(hb.download_all(h, waa.api._fp(second)))
+    ctx.close()
+    fresh, fsrc = _build(hip)(n, 0)
+    fsrc.set_buffer_batch(b2, 48000.0)
+    want = fresh.start_rendering_sync().data
+    fresh.close()
+    assert np.array_equal(second, want) and not np.array_equal(second, first)
+
+
+@pytest.mark.gpu
+def test_sharded_render_with_reused_batches_equals_the_plain_pipeline(hip):
+    """waa_sharded_job.reuse_batches: later sub-batches of the same size re-arm a downloaded one — same bits"""
+    n, frames = 32, RQ * 30 + 5
+    noise = white_noise(n, 2, frames)
+    outs = []
+    for reuse in (False, True):
+        out = np.zeros((n, 2, frames), np.float32)
+        render_sharded(_build(hip), noise, out, devices=[0], sub_batches=8, reuse=reuse)
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 1e-3
+
+
+def test_sharded_render_reuse_flag_on_the_oracle(orc):
+    n, frames = 9, RQ * 30 + 5
+    noise = white_noise(n, 2, frames)
+    outs = []
+    for reuse in (False, True):
+        out = np.zeros((n, 2, frames), np.float32)
+        render_sharded(_build(orc), noise, out, devices=[-1], sub_batches=3, reuse=reuse)
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1])

@@ -92,7 +92,7 @@ class ShardedJob(C.Structure):
                 ("devices", C.POINTER(C.c_int32)), ("sub_batches", C.c_uint32), ("source_node", C.c_uint32),
                 ("host_in", _VP), ("in_channels", C.c_uint32), ("in_pcm16", C.c_int32), ("in_frames", C.c_uint64),
                 ("in_sample_rate", C.c_float), ("out_pcm16", C.c_int32), ("host_out", _VP), ("setup", SHARD_FN),
-                ("pull", SHARD_FN), ("user", _VP)]
+                ("pull", SHARD_FN), ("user", _VP), ("reuse_batches", C.c_uint32)]
 
 class ArenaStats(C.Structure):
     """waa_arena_stats (include/waa_hip.h)"""
@@ -133,6 +133,7 @@ ABI = {
     "device_count": (C.c_int32, []),
     "device_arena_reserve": (C.c_int32, [C.c_int32, C.c_uint64]),
     "device_arena_stats": (C.c_int32, [C.c_int32, _VP]),
+    "batch_rearm": (C.c_int32, [_VP]),
     "render_range": (C.c_int32, [_VP, C.c_uint64, C.c_uint32]),
     "connect": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "disconnect": (C.c_int32, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -333,10 +333,27 @@ waa_status waa_source_set_buffer(waa_batch* b, uint32_t node, uint32_t inst, con
   return WAA_OK;
 }
 
+// A re-armed batch (waa_batch_rearm) takes the next AudioBuffers of a source into the device buffers it was planned with
+static int refill_source(waa_batch* b, uint32_t node, int kind, const void* data, uint32_t n_ch, uint64_t frames, float sr) {
+  auto it = b->batch_fills.find(node);
+  if (it == b->batch_fills.end() || it->second.kind != kind || it->second.n_ch != n_ch || it->second.frames != frames || it->second.src_sr != sr)
+    return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - a re-armed batch takes source buffers of the shape it was planned with (node %u)", node);
+  HIP_TRY(hipSetDevice(b->device));
+  waa_batch::PendingFill pf = it->second;
+  pf.host = data;
+  if (b->defer_fill) {
+    b->pending_fills.push_back(pf);
+    return 0;
+  }
+  return fill_upload(b, pf);
+}
+
 waa_status waa_source_set_buffer_batch(waa_batch* b, uint32_t node, const float* data, uint32_t n_ch, uint64_t frames,
                                        float sr) {
   int e;
-  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_unplanned(b))) return e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE))) return e;
+  if (b->planned && b->rearmed) return refill_source(b, node, 0, data, n_ch, frames, sr);
+  if ((e = check_unplanned(b))) return e;
   if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
   if (!b->dry) HIP_TRY(hipSetDevice(b->device));
   const uint64_t stride = (frames + 3) / 4 * 4;
@@ -344,6 +361,7 @@ waa_status waa_source_set_buffer_batch(waa_batch* b, uint32_t node, const float*
   if ((e = dev_alloc(b, &d, (size_t)b->n_inst * n_ch * std::max<uint64_t>(stride, 4), true))) return e;
   if (frames && !b->dry) {
     waa_batch::PendingFill pf{0, data, d, nullptr, b->n_inst, n_ch, frames, stride, frames, sr};
+    b->batch_fills[node] = pf;
     if (b->defer_fill)
       b->pending_fills.push_back(pf);
     else if ((e = fill_upload(b, pf)))
@@ -392,6 +410,7 @@ static int decode_pcm16(waa_batch* b, const int16_t* pcm, uint32_t n_items, uint
   int16_t* d_pcm = nullptr;
   if (int ea = dev_alloc(b, &d_pcm, (size_t)n_items * frames * n_ch, true)) return ea;
   waa_batch::PendingFill pf{1, pcm, d, d_pcm, n_items, n_ch, frames, stride, target, src_sr};
+  if (b->batch_fill_node >= 0 && n_items == b->n_inst) b->batch_fills[(uint32_t)b->batch_fill_node] = pf;
   if (b->defer_fill && n_items == b->n_inst) {
     b->pending_fills.push_back(pf);
     return 0;
@@ -425,13 +444,18 @@ waa_status waa_source_set_buffer_pcm16(waa_batch* b, uint32_t node, uint32_t ins
 waa_status waa_source_set_buffer_pcm16_batch(waa_batch* b, uint32_t node, const int16_t* data, uint32_t n_ch, uint64_t frames,
                                              float sr) {
   int e;
-  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_unplanned(b))) return e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE))) return e;
+  if (b->planned && b->rearmed) return refill_source(b, node, 1, data, n_ch, frames, sr);
+  if ((e = check_unplanned(b))) return e;
   if (n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid number of channels");
   if (!(sr >= 3000.f && sr <= 768000.f)) return fail(WAA_ERR_NOT_SUPPORTED, "NotSupportedError - Invalid sample rate: %f", sr);
   if (!b->dry) HIP_TRY(hipSetDevice(b->device));
   float* d = nullptr;
   uint64_t stride = 0, target = 0;
-  if ((e = decode_pcm16(b, data, b->n_inst, n_ch, frames, sr, &d, &stride, &target))) return e;
+  b->batch_fill_node = (int64_t)node;  // (decode_pcm16 records the fill for waa_batch_rearm)
+  e = decode_pcm16(b, data, b->n_inst, n_ch, frames, sr, &d, &stride, &target);
+  b->batch_fill_node = -1;
+  if (e) return e;
   Node& n = b->nodes[node];
   for (uint32_t k = 0; k < b->n_inst; k++) {
     DeviceBuffer db;
@@ -449,7 +473,13 @@ waa_status waa_source_set_buffer_pcm16_batch(waa_batch* b, uint32_t node, const 
 waa_status waa_source_adopt_device(waa_batch* b, uint32_t node, const float* device_data, uint32_t n_ch, uint64_t frames,
                                    float sr) {
   int e;
-  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE)) || (e = check_unplanned(b))) return e;
+  if ((e = check_node(b, node, WAA_NODE_BUFFER_SOURCE))) return e;
+  if (b->planned && b->rearmed) {  // (the plan's tables hold the address: the caller refilled the SAME device buffer)
+    const DeviceBuffer& cur = b->nodes[node].bufs[0];
+    if (cur.base == device_data && cur.nch == n_ch && cur.frames == frames && cur.sr == sr) return WAA_OK;
+    return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - a re-armed batch reads the device buffer it was planned with (node %u)", node);
+  }
+  if ((e = check_unplanned(b))) return e;
   if (!device_data || n_ch == 0 || n_ch > WAA_MAX_CHANNELS) return fail(WAA_ERR_INVALID_ARGUMENT, "bad device buffer");
   Node& n = b->nodes[node];
   for (uint32_t k = 0; k < b->n_inst; k++) {
@@ -949,6 +979,21 @@ waa_status waa_plan_describe(waa_batch* b, char* buf, size_t cap, size_t* needed
     std::memcpy(buf, text.data(), n);
     buf[n] = 0;
   }
+  return WAA_OK;
+}
+
+// A serving loop renders the same graph over and over with new audio: the batch keeps its plan, its device buffers and its tables;
+// waa_source_set_buffer_batch / _pcm16_batch / waa_source_adopt_device then REFILL the source buffers of the shape the batch was
+// planned with (anything else is an InvalidStateError), and waa_render renders from the initial state as every render does.
+waa_status waa_batch_rearm(waa_batch* b) {
+  if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
+  if (b->dry) return fail(WAA_ERR_DEVICE, "plan-only batch has no device");
+  if (!b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - nothing to re-arm: the batch has not been planned (waa_render / waa_plan_describe)");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));  // (the previous render and its downloads are over before its inputs are overwritten)
+  b->rearmed = true;
+  b->rendered = false;
+  b->pending_fills.clear();
   return WAA_OK;
 }
 

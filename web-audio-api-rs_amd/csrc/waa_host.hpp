@@ -351,6 +351,11 @@ struct waa_batch {
     float src_sr;
   };
   std::vector<PendingFill> pending_fills;
+  // waa_batch_rearm: the whole-batch source uploads by node, so that a planned batch can take the NEXT set of AudioBuffers of the
+  // same shape into the same device buffers (a serving loop: same graph, new audio — no plan, no allocation)
+  std::map<uint32_t, PendingFill> batch_fills;
+  bool rearmed = false;
+  int64_t batch_fill_node = -1;
   int16_t* pcm_out = nullptr;     // staging of waa_download_all_pcm16 (allocated on first use, freed with the batch)
   size_t pcm_out_count = 0;
   bool dry = false;                  // WAA_DEVICE_PLAN_ONLY: allocations are host memory, nothing is launched

@@ -16,6 +16,8 @@
 #include <thread>
 #include <vector>
 
+#include <map>
+
 #include "waa_host.hpp"
 
 extern "C" int waa_settle_loops(waa_batch* b);  // waa_abi.cpp
@@ -189,16 +191,35 @@ waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds) {
     std::lock_guard<std::mutex> l(trace_lock);
     fprintf(stderr, "[shard %u.%u] %8.2f ms  %s\n", sh.slot, sh.k, ms, what);
   };
+  // reuse_batches: downloaded sub-batches wait here, by (slot, contexts), for a later sub-batch of the same size (waa_batch_rearm)
+  std::mutex pool_lock;
+  std::map<std::pair<uint32_t, uint32_t>, std::vector<waa_batch*>> pool;
   auto run = [&](const Shard& sh) {
     waa_batch* b = nullptr;
     bool took_up = false, took_down = false;
     window[sh.slot].enter(sh.k);
     stamp(sh, "start");
-    int st = waa_batch_create(job->graph, sh.hi - sh.lo, job->n_channels_out, job->length_frames, job->sample_rate, sh.device, &b);
-    if (!st && job->setup) {
-      st = call_back(job->setup, "setup", b, sh, job->user);
+    int st = WAA_OK;
+    bool reused = false;
+    if (job->reuse_batches) {
+      std::lock_guard<std::mutex> l(pool_lock);
+      auto& v = pool[{sh.slot, sh.hi - sh.lo}];
+      if (!v.empty()) {
+        b = v.back();
+        v.pop_back();
+        reused = true;
+      }
     }
-    stamp(sh, "created + set up");
+    if (reused) {
+      st = waa_batch_rearm(b);
+      stamp(sh, "re-armed");
+    } else {
+      st = waa_batch_create(job->graph, sh.hi - sh.lo, job->n_channels_out, job->length_frames, job->sample_rate, sh.device, &b);
+      if (!st && job->setup) {
+        st = call_back(job->setup, "setup", b, sh, job->user);
+      }
+      stamp(sh, "created + set up");
+    }
     // The source's buffers are allocated and registered BEFORE the sub-batch's turn on the link, and the batch is planned: the
     // plan only needs their shape, and its small table uploads queue on the same DMA engine as the bulk upload of whichever
     // sub-batch holds the turn — planned after the upload, every render waited ~5 ms for its neighbour's transfer (WAA_SHARD_TRACE).
@@ -214,7 +235,7 @@ waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds) {
                          : waa_source_set_buffer_batch(b, job->source_node, reinterpret_cast<const float*>(src), job->in_channels,
                                                        job->in_frames, job->in_sample_rate);
       b->defer_fill = false;
-      if (!st && !modulated) {
+      if (!st && !modulated && !reused) {
         st = waa_plan_describe(b, nullptr, 0, nullptr);
         preplanned = true;
       }
@@ -255,15 +276,22 @@ waa_status waa_render_sharded(const waa_sharded_job* job, double* seconds) {
         down[sh.slot].done();
       }
     }
+    if (b && job->reuse_batches && !st) {
+      std::lock_guard<std::mutex> l(pool_lock);
+      pool[{sh.slot, sh.hi - sh.lo}].push_back(b);
+      b = nullptr;
+    }
     if (b) waa_batch_destroy(b);
     window[sh.slot].leave();
-    stamp(sh, "destroyed");
+    stamp(sh, job->reuse_batches && !st ? "kept for re-use" : "destroyed");
   };
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<std::thread> threads;
   threads.reserve(shards.size());
   for (const Shard& sh : shards) threads.emplace_back(run, std::cref(sh));
   for (auto& t : threads) t.join();
+  for (auto& kv : pool)
+    for (waa_batch* pb : kv.second) waa_batch_destroy(pb);
   if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (first_status != WAA_OK) return fail(first_status, "%s", first_error.c_str());
   return WAA_OK;

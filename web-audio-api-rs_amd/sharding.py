@@ -98,7 +98,8 @@ def _host_block(a, name, dtype, shape_tail=None):
 
 
 def render_sharded(build: Callable, host_in, host_out, devices: Sequence[int] = (0,), sub_batches: int = 8,
-                   sample_rate: float = 48000.0, pcm16: bool = False, pull: Optional[Callable] = None, out_pcm16: bool = False):
+                   sample_rate: float = 48000.0, pcm16: bool = False, pull: Optional[Callable] = None, out_pcm16: bool = False,
+                   reuse: bool = False):
     """Render N contexts whose source AudioBuffers live on the host, on one or several GPUs: a thin caller of the library's
     waa_render_sharded (include/waa_hip.h; csrc/waa_sharded.cpp — contiguous ranges per device, sub-batches pipelined
     upload || render || download, one host thread per sub-batch inside the library).
@@ -110,6 +111,8 @@ def render_sharded(build: Callable, host_in, host_out, devices: Sequence[int] = 
         the upload, converted on the device) — C-contiguous numpy array or pinned torch tensor.
     host_out: [N, n_out, length] float32 (out_pcm16=True: [N, length, n_out] int16), filled with every context's AudioBuffer.
     pull(ctx, lo, hi): optional control-side work per sub-batch after its render (e.g. the batched analyser pull).
+    reuse: build() configures every sub-batch identically (waa_sharded_job.reuse_batches): a downloaded sub-batch is re-armed for a
+        later one of the same size instead of being destroyed — no second creation, setup or plan.
     Returns {"seconds": wall time, "shards": [(device, lo, hi), ...]}.  Raises the first sub-batch error."""
     from .api import SHARD_FN, ShardedJob, WaaError
     devices = [int(d) for d in devices]
@@ -125,7 +128,7 @@ def render_sharded(build: Callable, host_in, host_out, devices: Sequence[int] = 
         raise ValueError(f"host_out holds {shape_out[0]} contexts, host_in {n_total}")
     b = tmpl._b
     graph = tmpl.graph_desc()
-    live, errors = {}, []
+    live, errors, by_handle = {}, [], {}
 
     def setup(handle, first, count, device, _user):
         try:
@@ -133,6 +136,7 @@ def render_sharded(build: Callable, host_in, host_out, devices: Sequence[int] = 
             if len(ctx._nodes) != graph.n_nodes:
                 raise WaaError(1, "render_sharded: build() must return the same graph for every sub-batch")
             live[int(first)] = ctx  # (before _adopt: whatever happens below, the finally clause forgets the library's handle)
+            by_handle[int(handle)] = ctx
             ctx._adopt(handle)
             return 0
         except WaaError as e:
@@ -144,8 +148,8 @@ def render_sharded(build: Callable, host_in, host_out, devices: Sequence[int] = 
 
     def after(handle, first, count, device, _user):
         try:
-            if pull is not None:
-                pull(live[int(first)], int(first), int(first) + int(count))
+            if pull is not None:  # (a re-used batch was set up for an earlier sub-batch: found by its handle)
+                pull(by_handle[int(handle)], int(first), int(first) + int(count))
             return 0
         except Exception as e:  # noqa: BLE001
             errors.append(e)
@@ -161,6 +165,7 @@ def render_sharded(build: Callable, host_in, host_out, devices: Sequence[int] = 
     job.host_in, job.in_channels, job.in_pcm16, job.in_frames, job.in_sample_rate = base_in, n_ch, int(pcm16), frames, sample_rate
     job.out_pcm16, job.host_out = int(out_pcm16), base_out
     job.setup, job.pull = SHARD_FN(setup), SHARD_FN(after)
+    job.reuse_batches = int(bool(reuse))
     seconds = C.c_double()
     try:
         status = b.render_sharded(C.cast(C.pointer(job), C.c_void_p), C.byref(seconds))
