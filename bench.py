@@ -385,7 +385,7 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < PREROLL_S:
             step()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()  # (per step: 0.15 s of DEVICE time, not 0.15 s worth of queued launches)
     ctx.profile(True)
     # (the per-kernel HIP-event totals are reset after the warm-up: kernel averages cover the K timed steps only)
     elapsed = timed_steps(step, torch.cuda.synchronize, steps, warmup, dist=dist, device_tensor=dev_t,
@@ -673,6 +673,9 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not measure the headline's HBM traffic in this run (two rocprofv3 --pmc child runs, ~30 s): replay the stamped record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold", action="store_true",
+                    help="skip the `cold` record (the headline once more on plain hipMalloc before the arena is reserved): profiled runs, "
+                         "where every launch of the kernel should be of one kind")
     ap.add_argument("--no-preroll", action="store_true",
                     help="no untimed back-to-back steps in front of the W + K protocol (the profiled child runs: every kernel exactly 5 times)")
     ap.add_argument("--no-extra", action="store_true", help="only the headline workload: no T1 / C3 / C4 / ... records, no e2e record")
@@ -733,7 +736,7 @@ def main():
     arena = None
     share_gpu = os.environ.get("WAA_BENCH_SHARE_GPU") == "1"
     if args.arena_gb > 0 and not share_gpu:
-        if name == "c2" and args.instances is None and args.seconds == 10.0:
+        if name == "c2" and args.instances is None and args.seconds == 10.0 and not args.no_cold:
             try:
                 c = measure(torch, waa, hip, name, n_inst, args.seconds, max(3, args.steps // 2), 1, rank, world, local_rank, dist, backend)
                 cold = {"ms_per_step": round(c["ms_per_step"], 4), "kernel_ms": round(c["roofline"]["kernel_ms_per_step"], 4),

@@ -44,7 +44,7 @@ for k, (n_calls, avg_us) in stats.items():
         continue
     rd = fetch[k][2] * 1024.0 * 2.0
     wr = write[k][2] * 1024.0
-    per_step = round(n_calls / 5.0)
+    per_step = round(fetch[k][1] / 5.0)  # (the counter passes launch every per-step kernel five times; the stats pass runs the driver's protocol)
     if per_step < 1:
         continue  # one-off kernels (IR spectra)
     kernels[short(k)] = {"launches_per_step": per_step, "avg_us": avg_us, "read_bytes": rd, "write_bytes": wr,
@@ -54,7 +54,7 @@ path = os.path.join(root, "profiles", "pmc_traffic.json")
 data = json.load(open(path))
 rec = {"contexts": contexts, "frames": frames, "kernels": kernels, "bytes_per_step": total,
        "note": f"tools/pmc_pass.sh {name} {tag}: rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE in "
-               "separate passes of `python bench.py --workload %s --steps 3 --warmup 1 --no-cpu-baseline --no-extra`; "
+               "separate passes of `python bench.py --workload %s ...` (stats: --steps 20 --warmup 5 out of the graded arena; counters: --steps 3 --warmup 1 --arena-gb 0 --no-preroll); "
                "gfx950 correction FETCH_SIZE x 2; summaries: profiles/%s_*.txt" % (name, tag)}
 if len(kernels) == 1:
     k = next(iter(kernels.values()))
