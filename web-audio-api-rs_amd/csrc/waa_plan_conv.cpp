@@ -44,8 +44,7 @@ bool conv_fold_biquad_into_ir(const waa_batch* b, Node& conv, const Node& q) {
   // (a RUNTIME switch of the product library, not a measurement switch — ADVICE round 5: a caller whose sources may hold NaN / Inf
   // samples and who needs the reference's recovery from them sets WAA_NO_CONV_BIQUAD_IR_FOLD=1 and gets the exact-order filter
   // stage of conv_fft3_fwd_bq_kernel back; DESIGN.md section 5.9, INTEGRATION.md "runtime switches")
-  static const bool no_fold = getenv("WAA_NO_CONV_BIQUAD_IR_FOLD") != nullptr;
-  if (no_fold || measure_switch("WAA_NO_CONV_BIQUAD_IR_FOLD") || !conv.has_ir || q.params.size() < 4) return false;
+  if (getenv("WAA_NO_CONV_BIQUAD_IR_FOLD") || !conv.has_ir || q.params.size() < 4) return false;  // (read per plan: tests toggle it)
   float pv[4];
   for (int k = 0; k < 4; k++) {
     const ParamStore& ps = q.params[k];
