@@ -123,7 +123,9 @@ ALG_BYTES["hrtf"] = 2048.0
 ALG_FLOPS = {"os2": 2 * 2.0 * (256 * 256 + 128 * 512), "os4": 2 * 2.0 * (512 * 256 + 128 * 1024), "hrtf": 2.0 * 128 * 2 * 415}
 # ... and as what the product path runs since round 4 (waa_osfft.hip): 2 + 2R complex 256-point transforms per STEREO quantum
 # (5 N log2 N = 10 240 flops each, the usual FFT convention) plus 2R spectral products of 256 complex multiplies (8 flops)
-OS_FFT_FLOPS = {"os2": 6 * 10240.0 + 4 * 256 * 8.0, "os4": 10 * 10240.0 + 8 * 256 * 8.0}
+OS_FFT_FLOPS = {"os2": 6 * 10240.0 + 4 * 256 * 8.0, "os4": 10 * 10240.0 + 8 * 256 * 8.0,
+                # round 6 (waa_hrtf_fft.hip): the static-direction HRTF FIR as partitioned overlap-add: 2 transforms + 4 spectral products
+                "hrtf": 2 * 10240.0 + 4 * 256 * 8.0}
 IIR_ORDERS = (2, 4, 8, 12, 19)
 for _o in IIR_ORDERS:
     ALG_BYTES[f"iir{_o}"] = 2048.0
@@ -459,8 +461,9 @@ def measure(torch, waa, hip, name, n_inst, seconds, steps, warmup, rank, world, 
         if fft_form:
             # butterflies are adds and multiplies, not fused: against the FMA peak the transform form cannot exceed ~0.5; the
             # figure to watch is the time itself next to the HBM floor (compulsory_frac) and to the matrix form it replaced
-            roof["flops_basis"] = "2+2R complex FFT256 per stereo quantum at 5 N log2 N + the spectral products"
-            roof["matrix_form_flops_per_step"] = ALG_FLOPS[name] * n_inst * nq
+            roof["flops_basis"] = ("2 complex FFT256 per quantum at 5 N log2 N + 4 spectral products (both ears in one transform)" if name == "hrtf"
+                                   else "2+2R complex FFT256 per stereo quantum at 5 N log2 N + the spectral products")
+            roof["matrix_form_flops_per_step" if name != "hrtf" else "direct_form_flops_per_step"] = ALG_FLOPS[name] * n_inst * nq
         if name in ("os2", "os4") and matrix_form and not any(os.environ.get(k) for k in ("WAA_QGEMM_FMA", "WAA_QGEMM_F32")):
             # the resampling products run on the bf16 matrix cores as SIX bf16 products per f32 product (exact three-way
             # split of both operands, f32-grade result: DESIGN.md 3.5): the ceiling of that method is the dense bf16 MFMA

@@ -425,9 +425,11 @@ def test_fir_forms_are_bit_identical(hip, positions):
                 pan.position_y.set_value(0.2 * k - 0.4, instance=k)
         return ctx.start_rendering_sync().data
 
-    saved = {k: os.environ.pop(k, None) for k in ("WAA_HRTF_V1", "WAA_HRTF_V8", "WAA_HRTF_DYNAMIC")}
+    saved = {k: os.environ.pop(k, None) for k in ("WAA_HRTF_V1", "WAA_HRTF_V8", "WAA_HRTF_DYNAMIC", "WAA_HRTF_DIRECT")}
     try:
+        os.environ["WAA_HRTF_DIRECT"] = "1"  # (one direction for the batch takes the transform form since round 6: not this test's subject)
         new = render()
+        os.environ.pop("WAA_HRTF_DIRECT")
         os.environ["WAA_HRTF_V1"] = "1"
         old = render()
         os.environ.pop("WAA_HRTF_V1")
@@ -442,3 +444,66 @@ def test_fir_forms_are_bit_identical(hip, positions):
     assert np.any(new != 0)
     assert np.array_equal(new, old)
     assert np.array_equal(lds, old)
+
+
+@pytest.mark.measure
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr", [44100.0, 48000.0, 32000.0])
+def test_transform_form_against_the_direct_form_and_the_oracle(hip, orc, sr):
+    """round 6, waa_hrtf_fft.hip: PannerNode and AudioListener at rest = one HRIR pair for the whole batch -> partitioned
+    overlap-add on 256-point transforms (2 per quantum, both ears in one) instead of taps x 128 x 2 multiply-adds.  Stereo and mono
+    inputs, per-instance start times (gaps: skipped quanta, the frozen history), sources that end (the tail), a ragged end, runs
+    shorter than the render (the four unstored quanta in front of every run); against hrtf8_kernel on the same device and against
+    the oracle's f64-accumulated direct form"""
+    import os
+    n_inst, nq = 7, 300
+    rng = np.random.default_rng(51)
+    x = rng.uniform(-1, 1, (n_inst, 2, 90 * RQ + 17)).astype(np.float32)
+    y = rng.uniform(-1, 1, (n_inst, 1, 40 * RQ)).astype(np.float32)
+
+    def render(be):
+        ctx = waa.OfflineAudioContext(2, nq * RQ - 5, sr, n_instances=n_inst, binding=be)
+        a = ctx.create_buffer_source()
+        a.set_buffer_batch(x, sr)
+        b2 = ctx.create_buffer_source()
+        b2.set_buffer_batch(y, sr)
+        pan = ctx.create_panner(panning_model="HRTF", position=(-1.5, 0.4, 0.7), ref_distance=0.5)
+        a.connect(pan)
+        b2.connect(pan)
+        pan.connect(ctx.destination())
+        for k in range(n_inst):
+            a.start_at(0.003 * k, instance=k)
+            b2.start_at(0.9 + 0.11 * k, instance=k)   # well after `a` has ended and the tail has run out: a second stretch
+        if be is hip:
+            plan = ctx.plan_describe()
+            assert "partitions of 128 taps as 256-point transforms" in plan, plan  # (WAA_HRTF_DIRECT is a launch-time switch)
+        out = ctx.start_rendering_sync().data
+        ctx.close()
+        return out
+
+    saved = os.environ.pop("WAA_HRTF_DIRECT", None)
+    try:
+        fft = render(hip)
+        os.environ["WAA_HRTF_DIRECT"] = "1"
+        direct = render(hip)
+    finally:
+        os.environ.pop("WAA_HRTF_DIRECT", None)
+        if saved is not None:
+            os.environ["WAA_HRTF_DIRECT"] = saved
+    ref = render(orc)
+    assert np.abs(ref).max() > 0.05
+    for k in range(n_inst):
+        for c in range(2):
+            assert rms(fft[k, c], ref[k, c]) <= 1e-6 and rms(direct[k, c], ref[k, c]) <= 1e-6
+            assert rms(fft[k, c], direct[k, c]) <= 5e-7
+    # Where the direct form's products are exact zeros INSIDE a processed quantum (the HRIR's leading zeros, the input's gaps) the
+    # transform form leaves its roundoff (1e-10 ... 2e-8 of full scale; the crate renders with an FFT too).  Quanta the node SKIPS are zeros in
+    # both forms: a quantum that is all zero in the direct form, like the four in front of it, is all zero in the transform form.
+    assert np.abs(fft[direct == 0]).max() <= 1e-7  # (measured: 2e-8)
+    nqq = direct.shape[2] // RQ
+    zq = (direct[:, :, :nqq * RQ].reshape(n_inst, 2, nqq, RQ) == 0).all(axis=(1, 3))
+    fq = (fft[:, :, :nqq * RQ].reshape(n_inst, 2, nqq, RQ) == 0).all(axis=(1, 3))
+    for k in range(n_inst):
+        for q in range(4, nqq):
+            if zq[k, q - 4:q + 1].all():
+                assert fq[k, q], (k, q)

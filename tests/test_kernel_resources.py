@@ -111,3 +111,12 @@ def test_oversampler_transform_kernels_keep_two_waves_per_simd(tmp_path):
         assert r["vgpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (name, r)
     for name, r in x4.items():
         assert r["vgpr"] <= 256 and r["spill"] <= 2 and r["scratch"] <= 16, (name, r)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_hrtf_transform_kernel_holds_its_state_in_registers(tmp_path):
+    """waa_hrtf_fft.hip: three spectra of history, the carry and two transforms in flight per lane = one wavefront per SIMD on the
+    unified register file (arch + accumulation registers); nothing in scratch memory"""
+    res = kernel_resources("waa_hrtf_fft.hip", tmp_path)
+    k = [v for n, v in res.items() if "hrtf_fft_kernel" in n]
+    assert len(k) == 1 and k[0]["spill"] == 0 and k[0]["scratch"] == 0, k

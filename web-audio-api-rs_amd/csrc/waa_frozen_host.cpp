@@ -7,6 +7,7 @@
 #include <thread>
 
 #include "waa_host.hpp"
+#include "waa_hrtf_fft_tables.hpp"
 #include "waa_osfft_tables.hpp"
 
 namespace waa {
@@ -604,12 +605,46 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
   d.taps = sp->taps;
   d.n_inst = b->n_inst;
   d.n_quanta = b->n_quanta;
+  bool fft_form = false;
+  if (per_row == 1 && rows == 1 && sp->taps <= 128 * hrtffft::PARTS && !b->dry) {
+    // PannerNode and AudioListener at rest, the same for every context: the HRIR pair's partition spectra (both ears in one
+    // complex table), the transform form of waa_hrtf_fft.hip.  Runs as for the oversampled WaveShaper: ~16 k groups per launch.
+    const int O = (sp->taps + 3) & ~3;
+    std::vector<float> pair((size_t)O * 2, 0.f);
+    {
+      const HrtfQ& r = table[0];
+      for (int ear = 0; ear < 2; ear++)
+        for (int t = 0; t < sp->taps; t++) {
+          const size_t o = (size_t)ear * sp->taps + t;
+          const float a = hr[(size_t)r.v[0] * 2 * sp->taps + o], bb = hr[(size_t)r.v[1] * 2 * sp->taps + o], c = hr[(size_t)r.v[2] * 2 * sp->taps + o];
+          volatile float p0 = a * r.w[0], p1 = bb * r.w[1], p2 = c * r.w[2];
+          volatile float s01 = p0 + p1;
+          pair[(size_t)t * 2 + ear] = s01 + p2;
+        }
+    }
+    float *d_tab = nullptr, *d_tw = nullptr, *d_trash = nullptr;
+    if ((e = dev_upload(b, &d_tab, hrtffft::make_tables(pair.data(), sp->taps))) || (e = dev_upload(b, &d_tw, osfft::tw256())) ||
+        (e = dev_alloc(b, &d_trash, 64)))
+      return e;
+    d.fft_tables = d_tab;
+    d.tw256 = d_tw;
+    d.trash = d_trash;
+    uint32_t seg = std::max<uint32_t>(8, (uint32_t)(((uint64_t)b->n_inst * b->n_quanta + 16383) / 16384));
+    seg = std::min(seg, b->n_quanta);
+    d.seg_len = seg;
+    d.n_seg = (b->n_quanta + seg - 1) / seg;
+    fft_form = true;
+  }
   st.profile_slot = slot_for(b, "hrtf_kernel");
   st.loop_reads.push_back(in_sig.base);
   st.loop_writes.push_back(n.sig.base);
   b->steps.push_back(st);
-  plan_note(b, "panner node %u: HRTF, %d-tap impulse responses at %u Hz, geometry table %u row(s) x %u, direct FIR per render quantum", id,
-            sp->taps, sp->sr, rows, per_row);
+  if (fft_form)
+    plan_note(b, "panner node %u: HRTF, %d-tap impulse responses at %u Hz, one direction for the whole batch: %d partitions of 128 taps as 256-point "
+                 "transforms (2 per quantum, runs of %u quanta, %u per instance)", id, sp->taps, sp->sr, hrtffft::PARTS, d.seg_len, d.n_seg);
+  else
+    plan_note(b, "panner node %u: HRTF, %d-tap impulse responses at %u Hz, geometry table %u row(s) x %u, direct FIR per render quantum", id,
+              sp->taps, sp->sr, rows, per_row);
   return 0;
 }
 

@@ -1,0 +1,179 @@
+// waa_hrtf_fft.hip — the HRTF panner for a direction that does not change during the render, as uniform partitioned overlap-add on
+// 256-point transforms in registers (waa_hrtf_fft.hpp has the algebra; the oversampled WaveShaper's kernel, waa_osfft.hip, the
+// machinery).  Replaces hrtf8_kernel's direct form (415 taps x 128 frames x 2 ears of fused multiply-adds per quantum: 8.5-9 ms for
+// 1024 contexts x 10 s at 0.6 of the packed-f32 peak) for batches in which PannerNode and AudioListener are at rest; moving
+// sources keep the direct kernels (their HRIR pair changes per quantum, panner.rs:781-829).
+//
+// Work decomposition as in waa_osfft.hip: a GROUP of 16 lanes renders a run of `seg_len` render quanta of one instance, quantum
+// after quantum, with the node's state — the spectra of the last three processed quanta and the overlap-add carry — in registers;
+// the state a run starts with is recomputed from the FOUR processed quanta in front of it (found through the node's `prev` table,
+// which is also how skipped quanta and the frozen history of panner.rs:697-711 are followed).  Four groups per wavefront, four
+// wavefronts per workgroup share the spectral tables in LDS.
+#include <hip/hip_runtime.h>
+
+#include "waa_hrtf_fft.hpp"
+#include "waa_internal.hpp"
+
+namespace waa {
+namespace {
+using namespace hrtffft;
+constexpr int WAVES = 4;
+
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void hrtf_fft_kernel(const HrtfDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  // LDS map (8-byte slots): PARTS tables | WAVES * 4 exchange buffers
+  const ldsp tab = (ldsp)lds_raw;
+  const int lane = threadIdx.x & 63, wv = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, t = lane & 15;
+  const ldsp ex = tab + PARTS * TAB_SLOTS + (wv * 4 + g) * XSLOTS;
+  {
+    const f4v* src = reinterpret_cast<const f4v*>(d.fft_tables);
+    __attribute__((address_space(3))) f4v* dst = (__attribute__((address_space(3))) f4v*)tab;
+    for (int i = threadIdx.x; i < PARTS * TAB_SLOTS / 2; i += WAVES * 64) dst[i] = load_global_f4(reinterpret_cast<const float*>(src + i));
+  }
+  __syncthreads();
+  const uint64_t gid = ((uint64_t)blockIdx.x * WAVES + wv) * 4 + g;
+  const uint32_t inst = (uint32_t)(gid / d.n_seg), seg = (uint32_t)(gid % d.n_seg);
+  const bool alive = inst < d.n_inst;
+  const int32_t* prev = d.prev + (uint64_t)(alive ? inst : 0) * d.prev_stride;
+  const uint8_t* code = d.in_code + (uint64_t)(alive ? inst : 0) * d.code_stride;
+  const int q_lo = (int)(d.q0 + seg * d.seg_len);
+  const int q_hi = (int)((uint64_t)q_lo + d.seg_len < d.q1 ? q_lo + d.seg_len : d.q1);
+  // the four processed quanta in front of the run, ph[3] the nearest (-1: none)
+  int ph[HEADS];
+#pragma unroll
+  for (int k = 0; k < HEADS; k++) ph[k] = -1;
+  if (q_lo > 0) {
+    int base = q_lo - 1, p1 = -1;
+    bool searching = alive && q_lo < (int)d.q1;
+    while (__builtin_amdgcn_ballot_w64(searching) != 0) {
+      const int qq = base - t;
+      const int32_t l = (searching && qq >= 0) ? load_global(prev + qq) : LINK_SKIP;
+      const uint64_t hit = __builtin_amdgcn_ballot_w64(l != LINK_SKIP) >> (g * 16) & 0xffffull;
+      if (searching) {
+        if (hit) {
+          p1 = base - __builtin_ctzll(hit);
+          searching = false;
+        } else {
+          base -= 16;
+          if (base < 0) searching = false;
+        }
+      }
+    }
+    int p = p1;
+#pragma unroll
+    for (int k = HEADS - 1; k >= 0; k--) {
+      ph[k] = p;
+      if (p >= 0) {
+        const int32_t l = load_global(prev + p);
+        p = l >= 0 ? l : -1;
+      }
+    }
+  }
+  HLane L;
+  load_tw(reinterpret_cast<const c2v*>(d.tw256), t, L.tws);
+  lane_reset_if(L, true);
+  const float* src = d.in.base + (uint64_t)(alive ? inst : 0) * d.in.inst_stride;
+  float* dst = d.out.base + (uint64_t)(alive ? inst : 0) * d.out.inst_stride;
+  const float gain = load_global(&d.table->gain);  // (one direction, one gain: rows == per_row == 1)
+  const int n_it = (int)d.seg_len + HEADS;
+  auto quantum_of = [&](int it) { return it < HEADS ? (it == 0 ? ph[0] : it == 1 ? ph[1] : it == 2 ? ph[2] : ph[3]) : q_lo + it - HEADS; };
+  auto valid_at = [&](int it, int q) { return alive && it < n_it && q >= 0 && (it < HEADS || q < q_hi); };
+  const float* safe = d.tw256;  // (any 128 readable floats: what a lane that does not process loads and throws away)
+  float xn0[8], xn1[8];         // the next step's input frames (channel 0 / channel 1), requested one step ahead
+  int32_t link_n;
+  uint32_t code_n;
+  auto request = [&](int q, bool procn, uint32_t c) __attribute__((always_inline)) {
+    const bool live = procn && !(c & CODE_SILENT);
+    const float* p0 = live ? src + (uint64_t)q * RQ + t : safe + t;
+    const float* p1c = live && (c & 7u) >= 2 ? p0 + d.in.ch_stride : safe + t;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      xn0[j] = load_global(p0 + 16 * j);
+      xn1[j] = load_global(p1c + 16 * j);
+    }
+  };
+  {
+    const int q0 = quantum_of(0);
+    const bool v = valid_at(0, q0);
+    link_n = v ? load_global(prev + q0) : LINK_SKIP;
+    code_n = v ? (uint32_t)load_global(code + q0) : (uint32_t)CODE_SILENT;
+    request(q0, link_n != LINK_SKIP, code_n);
+  }
+#pragma unroll 1
+  for (int it = 0; it < n_it; it++) {
+    const int q = quantum_of(it);
+    const int32_t link = link_n;
+    const uint32_t c = code_n;
+    const bool proc = link != LINK_SKIP;  // (LINK_SKIP also stands for "no quantum in this step")
+    const bool store = alive && it >= HEADS && q < q_hi;
+    const int qn = quantum_of(it + 1);
+    {
+      const bool v = valid_at(it + 1, qn);
+      link_n = v ? load_global(prev + qn) : LINK_SKIP;
+      code_n = v ? (uint32_t)load_global(code + qn) : (uint32_t)CODE_SILENT;
+    }
+    lane_reset_if(L, proc && link == LINK_FRESH);
+    int tofs = 0;
+    asm volatile("" : "+s"(tofs));
+    const ldsp tabq = tab + tofs;  // (loop-invariant LDS reads: the address is opaque so that they are not hoisted out of the loop)
+    {
+      // the quantum's mono mix (panner.rs:800-810; quantum.rs:387-397): a silent input is zeros, a stereo one 0.5 (L + R)
+      const bool live = proc && !(c & CODE_SILENT), st2 = (c & 7u) >= 2;
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float m = st2 ? 0.5f * (xn0[j] + xn1[j]) : xn0[j];
+        x[j] = live ? m : 0.f;
+      }
+      ph_in(L, x);
+    }
+    xwrite(L.a, ex, t);
+    wsync();
+    xread(L.a, ex, t);
+    wsync();
+    ph_spec(L, tabq, t, proc);
+    request(qn, link_n != LINK_SKIP, code_n);
+    xwrite(L.Y, ex, t);
+    wsync();
+    xread(L.Y, ex, t);
+    wsync();
+    c2v o[8];
+    ph_out(L, proc, o);
+    {
+      // acc * gain * corr in hrtf8_kernel's order; corr = 2 behind a stereo input (by the quantum's count, silent or not)
+      const float corr = (c & 7u) >= 2 ? 2.f : 1.f;
+      float* p0 = store ? dst + (uint64_t)q * RQ + t : d.trash + lane;
+      float* p1c = store ? p0 + d.out.ch_stride : d.trash + lane;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        store_global(p0 + (store ? 16 * j : 0), proc ? o[j].x * gain * corr : 0.f);
+        store_global(p1c + (store ? 16 * j : 0), proc ? o[j].y * gain * corr : 0.f);
+      }
+    }
+  }
+}
+}  // namespace
+
+void launch_hrtf_fft(const HrtfDesc& d0, void* stream) {
+  HrtfDesc d = d0;
+  if (d.q1 == 0) d.q1 = d.n_quanta;
+  if (d.q1 <= d.q0) return;
+  const uint32_t nq = d.q1 - d.q0;
+  if (d.q0 != 0 || d.q1 != d.n_quanta || d.seg_len == 0) {  // a range: as many runs as it needs
+    d.seg_len = d.seg_len && d.seg_len < nq ? d.seg_len : nq;
+  }
+  d.n_seg = (nq + d.seg_len - 1) / d.seg_len;
+  const size_t lds = ((size_t)PARTS * TAB_SLOTS + (size_t)WAVES * 4 * XSLOTS) * 8;
+  const uint64_t groups = (uint64_t)d.n_inst * d.n_seg;
+  const dim3 grid((unsigned)((groups + WAVES * 4 - 1) / (WAVES * 4))), block(WAVES * 64);
+  hipLaunchKernelGGL(hrtf_fft_kernel, grid, block, lds, (hipStream_t)stream, d);
+}
+
+}  // namespace waa

@@ -697,8 +697,14 @@ struct HrtfDesc {
   uint32_t n_inst, n_quanta;
   uint32_t q0, q1;          // the quanta this launch renders (q1 = 0: all)
   int32_t pad;
+  // the transform form (waa_hrtf_fft.hip; round 6): one direction for the whole batch (rows == per_row == 1), taps <= 512
+  const float* fft_tables;  // hrtffft::PARTS tables of osfft::TAB_SLOTS complex values, lane-major rows; null: direct form only
+  const float* tw256;       // exp(-2 pi i j / 256)
+  float* trash;             // 64 floats nobody reads
+  uint32_t seg_len, n_seg;  // quanta per run, runs per instance
 };
 void launch_hrtf(const HrtfDesc& d, void* stream);
+void launch_hrtf_fft(const HrtfDesc& d, void* stream);
 
 // ---- input preparation on the device (waa_decode.hip): decoded 16-bit PCM -> f32 planes at the context rate ----
 struct DecodeDesc {
