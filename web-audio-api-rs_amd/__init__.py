@@ -10,6 +10,7 @@ import os
 
 from .api import *  # noqa: F401,F403
 from .api import Binding, bind
+from .mixed import bucket_report, render_contexts, shape_key  # noqa: F401  (contexts of different shapes -> batches)
 
 _HERE = globals().get("_WAA_PKG_DIR") or os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libwaa_hip.so")
