@@ -87,3 +87,25 @@ def hip(request):
 def be(request):
     """Backend under test: the CPU oracle (pins the oracle) or the HIP library (-m gpu)."""
     return request.getfixturevalue(request.param)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _optional_test_arena():
+    """WAA_TEST_ARENA_MB=<n> (GPU box): every batch of the session carves its big buffers from one device arena — together with
+    WAA_POISON_ALLOC=1 (the slab starts as 0xFF bytes) a read BEHIND a buffer returns NaNs instead of whatever the neighbour holds"""
+    mb = int(os.environ.get("WAA_TEST_ARENA_MB", "0"))
+    if mb <= 0:
+        yield
+        return
+    import web_audio_api_rs_amd as waa
+    libs = [waa.default_binding()]
+    if os.path.exists(waa.MEASURE_LIB_PATH):
+        libs.append(waa.measure_binding())
+    for b in libs:
+        b.check(b.device_arena_reserve(0, mb << 20))
+    yield
+    for b in libs:
+        try:
+            b.check(b.device_arena_reserve(0, 0))
+        except Exception:  # noqa: BLE001 (batches still alive at teardown: the process ends anyway)
+            pass

@@ -507,3 +507,25 @@ def test_transform_form_against_the_direct_form_and_the_oracle(hip, orc, sr):
         for q in range(4, nqq):
             if zq[k, q - 4:q + 1].all():
                 assert fq[k, q], (k, q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [502, 630])
+def test_transform_form_is_not_used_where_a_node_behind_the_panner_decides_on_exact_zeros(hip, orc, seed):
+    """round 6, found by the frozen-state fuzz generator on the first build with waa_hrtf_fft.hip: behind the end of the panner's
+    tail the direct form puts out exact zeros, the transforms 1e-10 of roundoff — and a DelayNode / BiquadFilterNode behind the
+    panner goes silent (= mono) on exactly that (delay.rs:640-668, biquad_filter.rs:775-790): the channel count behind it flipped
+    33 quanta into the render (seed 502: 1.5e-3 of full scale; seed 630, a feedback loop: 6e-2).  A dynamic plan keeps the
+    transform form only when nothing but GainNodes and the destination hears the panner"""
+    from test_fuzz_graphs import build_random_graph
+    ch, descr = build_random_graph(hip, seed, frozen=True)
+    plan = ch.plan_describe()
+    assert "HRTF" in plan and "direct FIR per render quantum" in plan and "256-point transforms (2 per quantum" not in plan, plan
+    g = ch.start_rendering_sync().data
+    ch.close()
+    co, _ = build_random_graph(orc, seed, frozen=True)
+    o = co.start_rendering_sync().data
+    co.close()
+    scale = max(1.0, float(np.abs(o).max()))
+    assert max(rms(g[i, c], o[i, c]) for i in range(g.shape[0]) for c in range(g.shape[1])) <= 1e-6 * scale, descr
+    assert np.abs(g - o).max() <= 2e-5 * scale, descr

@@ -535,7 +535,15 @@ waa_status waa_source_stop(waa_batch* b, uint32_t node, uint32_t inst, double wh
   if (when < 0.) return fail(WAA_ERR_INVALID_ARGUMENT, "RangeError - The provided time value cannot be negative");
   Node& n = b->nodes[node];
   uint32_t lo = inst == WAA_ALL_INSTANCES ? 0 : inst, hi = inst == WAA_ALL_INSTANCES ? b->n_inst : inst + 1;
-  if (b->ctl_q > 0) when = std::max(when, (double)((uint64_t)b->ctl_q * RQ) / (double)b->sr);  // (a stop in the past stops at this block)
+  if (b->ctl_q > 0) {
+    when = std::max(when, (double)((uint64_t)b->ctl_q * RQ) / (double)b->sr);  // (a stop in the past stops at this block)
+    // ONE stop time is what the schedule replay knows.  The reference accepts any number of stop messages and its renderer follows
+    // the stop time as it changes from suspend point to suspend point (a source that fell silent may even come back): a second
+    // stop message at a suspend point is legal there and out of scope here
+    for (uint32_t k = lo; k < hi; k++)
+      if (n.sched[k].stop != DBL_MAX)
+        return fail(WAA_ERR_OUT_OF_SCOPE, "a second stop() of source node %u arriving at a suspend point is out of scope (one stop time per source)", node);
+  }
   for (uint32_t k = lo; k < hi; k++) {
     if (n.sched[k].start == DBL_MAX) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - Cannot stop before start");
     n.sched[k].stop = when;
@@ -896,6 +904,104 @@ static int resolve_source_rate_modulation(waa_batch* b) {
 static int desugar_timed_edges(waa_batch* b) {
   if (b->timed_edges_done) return 0;
   b->timed_edges_done = true;
+  {
+    // A connection INSIDE a feedback loop made or cut at a suspend point changes what the reference's graph ordering does from then
+    // on (graph.rs:323-487: the cycle is gone, the DelayNode's writer renders before its reader again while the reader's in_cycle
+    // flag stays set, delay.rs:535-541) — the gate keeps the loop a loop for the whole render.  Found by the suspend fuzz
+    // (tests/test_fuzz_suspend.py, seeds 71 / 365 / 525: 3 of 600).  Strongly connected components of the union of all connections;
+    // a timed edge whose ends share one is out of scope.
+    bool any_timed = false;
+    for (size_t k = 0; k < b->edges.size(); k++) any_timed |= b->edge_on[k] != 0 || b->edge_off[k] < b->n_quanta;
+    if (any_timed) {
+      const uint32_t n = (uint32_t)b->nodes.size();
+      std::vector<std::vector<uint32_t>> adj(n);
+      for (const waa_edge_desc& ed : b->edges) adj[ed.from].push_back(ed.to);
+      std::vector<int> index(n, -1), low(n, 0), comp(n, -1);
+      std::vector<uint8_t> on_stack(n, 0);
+      std::vector<uint32_t> stack;
+      int next_index = 0, n_comp = 0;
+      struct Frame {
+        uint32_t v;
+        size_t child;
+      };
+      for (uint32_t root = 0; root < n; root++) {
+        if (index[root] >= 0) continue;
+        std::vector<Frame> call{{root, 0}};
+        index[root] = low[root] = next_index++;
+        stack.push_back(root);
+        on_stack[root] = 1;
+        while (!call.empty()) {
+          Frame& f = call.back();
+          if (f.child < adj[f.v].size()) {
+            const uint32_t w = adj[f.v][f.child++];
+            if (index[w] < 0) {
+              index[w] = low[w] = next_index++;
+              stack.push_back(w);
+              on_stack[w] = 1;
+              call.push_back({w, 0});
+            } else if (on_stack[w]) {
+              low[f.v] = std::min(low[f.v], index[w]);
+            }
+          } else {
+            const uint32_t v = f.v;
+            if (low[v] == index[v]) {
+              for (;;) {
+                const uint32_t w = stack.back();
+                stack.pop_back();
+                on_stack[w] = 0;
+                comp[w] = n_comp;
+                if (w == v) break;
+              }
+              n_comp++;
+            }
+            call.pop_back();
+            if (!call.empty()) low[call.back().v] = std::min(low[call.back().v], low[v]);
+          }
+        }
+      }
+      for (size_t k = 0; k < b->edges.size(); k++) {
+        if (b->edge_on[k] == 0 && b->edge_off[k] >= b->n_quanta) continue;
+        const waa_edge_desc& ed = b->edges[k];
+        if (comp[ed.from] == comp[ed.to])
+          return fail(WAA_ERR_OUT_OF_SCOPE, "the connection %u -> %u lies inside a feedback loop and is made or cut at a suspend point: out of scope",
+                      ed.from, ed.to);
+      }
+      // ... and a connection OUTSIDE every loop can still move the place where the reference breaks one: order_nodes walks the
+      // edges in insertion order, and which DelayNode of a loop with several of them meets the walk first — and loses its
+      // writer -> reader edge, i.e. renders one quantum late — depends on every edge the walk passes (suspend fuzz seed 10216: the
+      // source -> delay connection cut at quantum 15 moved the breaker to the loop's other DelayNode, 2.7 of full scale).  The plan
+      // has ONE order: the reference's ordering is computed for the connections of every epoch, and the epochs must agree on the
+      // cut DelayNodes and on the muted nodes.
+      std::vector<uint32_t> pts{0};
+      for (size_t k = 0; k < b->edges.size(); k++) {
+        if (b->edge_on[k] > 0 && b->edge_on[k] < b->n_quanta) pts.push_back(b->edge_on[k]);
+        if (b->edge_off[k] < b->n_quanta) pts.push_back(b->edge_off[k]);
+      }
+      std::sort(pts.begin(), pts.end());
+      pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+      const std::vector<waa_edge_desc> all = b->edges;
+      std::vector<uint8_t> cut0, muted0;
+      int bad = 0;
+      for (size_t e = 0; e < pts.size() && !bad; e++) {
+        b->edges.clear();
+        for (size_t k = 0; k < all.size(); k++)
+          if (b->edge_on[k] <= pts[e] && pts[e] < b->edge_off[k]) b->edges.push_back(all[k]);
+        std::vector<uint8_t> cut, muted;
+        std::vector<uint32_t> items;
+        compute_order(b, &cut, &muted, &items);
+        if (e == 0) {
+          cut0 = cut;
+          muted0 = muted;
+        } else if (cut != cut0 || muted != muted0) {
+          bad = (int)pts[e];
+        }
+      }
+      b->edges = all;
+      if (bad)
+        return fail(WAA_ERR_OUT_OF_SCOPE, "the connections made or cut at the suspend point in front of quantum %d change where the reference breaks a "
+                                          "feedback loop (or which nodes it mutes): out of scope", bad);
+    }
+  }
   std::vector<waa_edge_desc> edges;
   size_t n_gates = 0;
   for (size_t k = 0; k < b->edges.size(); k++) {
@@ -1007,7 +1113,9 @@ waa_status waa_batch_rearm(waa_batch* b) {
 // (api.py::OfflineAudioContext does).
 waa_status waa_render_range(waa_batch* b, uint64_t quantum0, uint32_t n_quanta) {
   if (!b) return fail(WAA_ERR_INVALID_ARGUMENT, "null batch");
-  if (b->planned) return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - the batch is frozen once rendering has started");
+  // (a batch that has been PLANNED in front of its last range — waa_plan_describe at the last suspend point — may still render it)
+  if (b->planned && !(quantum0 == b->ctl_q && quantum0 + n_quanta == b->n_quanta && !b->rendered))
+    return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - the batch is frozen once rendering has started");
   if (quantum0 != b->ctl_q)
     return fail(WAA_ERR_INVALID_STATE, "InvalidStateError - ranges are consecutive: the next one starts at quantum %u, not %llu", b->ctl_q,
                 (unsigned long long)quantum0);

@@ -149,6 +149,13 @@ extern "C" waa_status waa_device_arena_reserve(int32_t device, uint64_t bytes) {
   a.base = static_cast<char*>(p);
   a.size = bytes;
   a.list.reset(bytes, waa::host::ARENA_ALIGN);
+  // WAA_POISON_ALLOC=1 (testing aid, see dev_alloc): the WHOLE slab starts as 0xFF bytes — what lies BEHIND a piece is then poison
+  // as well, so that a kernel reading past the end of its buffer shows (round 6: a source read 56 frames behind its AudioBuffer for
+  // three rounds; only stale memory behind the LAST plane of a batch, transformed by a convolver, ever made it visible)
+  if (getenv("WAA_POISON_ALLOC")) {
+    (void)hipMemset(a.base, 0xFF, bytes);
+    (void)hipDeviceSynchronize();
+  }
   return WAA_OK;
 }
 

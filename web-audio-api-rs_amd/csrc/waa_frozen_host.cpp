@@ -606,7 +606,28 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
   d.n_inst = b->n_inst;
   d.n_quanta = b->n_quanta;
   bool fft_form = false;
-  if (per_row == 1 && rows == 1 && sp->taps <= 128 * hrtffft::PARTS && !b->dry) {
+  // Where the direct form puts out EXACT zeros (frames more than `taps` behind the last non-zero input frame: the end of the node's
+  // tail) the transforms leave roundoff of 1e-10, and in a dynamic plan a node behind the panner may decide on exactly that (a
+  // DelayNode that read nothing but zeros, a BiquadFilterNode whose state is no longer normal: biquad_filter.rs:775-790) — fuzz seeds
+  // 502 and 630 of the frozen-state generator, DESIGN.md section 5.  A dynamic plan keeps the transform form when nothing but
+  // GainNodes and the destination hears the panner.
+  auto plain_listeners_only = [&]() {
+    std::vector<uint32_t> todo{id};
+    std::vector<char> seen(b->nodes.size(), 0);
+    while (!todo.empty()) {
+      const uint32_t u = todo.back();
+      todo.pop_back();
+      for (const waa_edge_desc& ed : b->edges) {
+        if (ed.from != u) continue;
+        if (ed.to_input >= WAA_PARAM_INPUT(0)) return false;  // (into an AudioParam)
+        const int k = b->nodes[ed.to].desc.kind;
+        if (k != WAA_NODE_DESTINATION && k != WAA_NODE_GAIN) return false;
+        if (!seen[ed.to]) seen[ed.to] = 1, todo.push_back(ed.to);
+      }
+    }
+    return true;
+  };
+  if (per_row == 1 && rows == 1 && sp->taps <= 128 * hrtffft::PARTS && !b->dry && (!b->dynamic || plain_listeners_only())) {
     // PannerNode and AudioListener at rest, the same for every context: the HRIR pair's partition spectra (both ears in one
     // complex table), the transform form of waa_hrtf_fft.hip.  Runs as for the oversampled WaveShaper: ~16 k groups per launch.
     const int O = (sp->taps + 3) & ~3;

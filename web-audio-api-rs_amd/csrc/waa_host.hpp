@@ -531,6 +531,7 @@ bool hrtf_sphere_loaded();
 void plan_note(waa_batch* b, const char* fmt, ...);
 int slot_for(waa_batch* b, const char* name);
 void default_channel_config(Node& n, uint32_t n_out);
+void compute_order(const waa_batch* b, std::vector<uint8_t>* cut, std::vector<uint8_t>* muted, std::vector<uint32_t>* items);
 int computed_in_nch(const Node& n, int maxc);  // quantum.rs:543-547
 
 }  // namespace host

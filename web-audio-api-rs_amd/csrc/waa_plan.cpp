@@ -795,6 +795,7 @@ int source_code_rows(waa_batch* b, uint32_t id, uint64_t cs, std::vector<uint8_t
 }
 
 static int build_plan_impl(waa_batch* b);
+static int build_plan_rest(waa_batch* b, std::vector<uint32_t>& items, std::vector<uint8_t>& muted);
 int build_plan(waa_batch* b) {
   b->sched_cache.clear();
   const int e = build_plan_impl(b);
@@ -815,6 +816,24 @@ static int build_plan_impl(waa_batch* b) {
   // (graph.rs:323-487); `items` has two entries per DelayNode (writer, reader), none for muted nodes
   std::vector<uint32_t> items;
   std::vector<uint8_t> muted(N, 0);
+  compute_order(b, &b->cut, &muted, &items);
+  // one entry per node, at the position where its OUTPUT is produced (the reader half of a DelayNode)
+  b->order.clear();
+  for (uint32_t v : items)
+    if (!is_delay(b, v & ~VTX_READER) || (v & VTX_READER)) b->order.push_back(v & ~VTX_READER);
+  for (uint32_t i = 0; i < N; i++)
+    if (muted[i]) plan_note(b, "node %u is part of a cycle without a DelayNode: muted (graph.rs:362-368)", i);
+  return build_plan_rest(b, items, muted);
+}
+
+// graph.rs:323-487 for the batch's current nodes and edges: which DelayNodes lose their writer->reader edge (`cut`), which nodes
+// sit in a cycle without one (`muted`), and the render order (two entries per DelayNode: writer, reader; none for muted nodes)
+void compute_order(const waa_batch* b, std::vector<uint8_t>* cut_out, std::vector<uint8_t>* muted_out, std::vector<uint32_t>* items_out) {
+  const uint32_t N = (uint32_t)b->nodes.size();
+  std::vector<uint32_t>& items = *items_out;
+  std::vector<uint8_t>& muted = *muted_out;
+  items.clear();
+  muted.assign(N, 0);
   {
     OrderCtx c;
     c.b = b;
@@ -842,14 +861,13 @@ static int build_plan_impl(waa_batch* b) {
     for (uint32_t v : c.in_cycle) muted[v & ~VTX_READER] = 1;
     for (auto it = c.ordered.rbegin(); it != c.ordered.rend(); ++it)
       if (!muted[*it & ~VTX_READER]) items.push_back(*it);
-    b->cut = c.cut;
+    *cut_out = c.cut;
   }
-  // one entry per node, at the position where its OUTPUT is produced (the reader half of a DelayNode)
-  b->order.clear();
-  for (uint32_t v : items)
-    if (!is_delay(b, v & ~VTX_READER) || (v & VTX_READER)) b->order.push_back(v & ~VTX_READER);
-  for (uint32_t i = 0; i < N; i++)
-    if (muted[i]) plan_note(b, "node %u is part of a cycle without a DelayNode: muted (graph.rs:362-368)", i);
+}
+
+static int build_plan_rest(waa_batch* b, std::vector<uint32_t>& items, std::vector<uint8_t>& muted) {
+  const uint32_t N = (uint32_t)b->nodes.size();
+  std::unique_ptr<PlanTrace> ph(new PlanTrace("phase: loops + counts"));
   // feedback loops: strongly connected components of the graph with the writer->reader edges in place
   // (Tarjan); their members are rendered quantum by quantum by the loop kernel
   std::vector<int> scc_of(N, -1);

@@ -166,6 +166,13 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
         all = true;
         for (size_t q = (size_t)prefix * QUANTA_PER_TILE; q < (size_t)b->n_quanta && q < so.qrec.size(); q++)
           all = all && so.qrec[q].mode == Q_FAST && so.qrec[q].start == start0 + (int64_t)q * RQ;
+        // ... and the AudioBuffer reaches the END of the last render quantum: the consumers of a linear_all source load whole
+        // quanta without looking at the buffer's length, and a buffer that ends inside the last quantum (a render length that is
+        // no multiple of 128, the buffer as long as the render) made them read up to 127 frames behind it — the next plane's
+        // samples, or, for the last plane, whatever lies behind the allocation: harmless to a causal consumer, but a CONVOLVER
+        // behind it transforms the whole block, and 1e22 of stale memory in the block's unused tail is 1e15 of roundoff in its
+        // valid part (suspend fuzz seed 16381 run behind other graphs, round 6; the generic loader zero-fills).
+        all = all && start0 + (int64_t)b->n_quanta * RQ <= (int64_t)bf.frames;
       }
       linear_all.push_back(all ? 1u : 0u);
       plan_note(b, "source node %u schedule %zu: tiles [0, %u) are one linear run from buffer frame %lld%s", id, scheds.size(), prefix,
