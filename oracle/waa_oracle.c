@@ -65,7 +65,7 @@
 #include "../include/waa_hip.h"
 
 #define RQ 128
-#define ORC_MAXC 8 /* oracle supports up to 8 channels per quantum (mix rules are defined up to 6) */
+#define ORC_MAXC 32 /* MAX_CHANNELS, src/lib.rs:21 (the speakers mix rules are defined up to 6: everything wider mixes discretely, quantum.rs:296-306) */
 #define ORC_MAX_INPUTS 1
 
 static __thread char g_err[512];

@@ -321,6 +321,9 @@ struct waa_batch {
   std::vector<void*> allocs;        // plan-owned device allocations
   std::vector<void*> payload_allocs;  // buffers uploaded through the API
   std::vector<std::pair<void*, size_t>> state_bufs;  // zeroed at the start of every render
+  // host copies of the per-instance source tables handed to the kernels (key: the device table): a signal wider than six channels is
+  // rendered in channel slices (push_chain_step), and a slice of a SOURCE is the same table with its base pointers moved on
+  std::map<const waa::SrcInst*, std::vector<waa::SrcInst>> src_tables;
   std::vector<std::pair<void*, size_t>> ones_bufs;   // filled with 0xFF bytes at the start of every render
   std::vector<Step> steps;
   bool planned = false;

@@ -33,7 +33,7 @@ constexpr int TILE = 64 * TILE_K;  // frames per wave-tile = 2048 = 16 render qu
 constexpr int QUANTA_PER_TILE = TILE / RQ;
 constexpr int MAX_OPS = 12;
 constexpr int MAX_INPUTS = 4;
-constexpr int MAX_CH = 8;          // channels per signal the device path supports
+constexpr int MAX_CH = 32;         // channels per signal (MAX_CHANNELS, src/lib.rs:21): per-channel filter state is laid out for it
 constexpr int STATE_STRIDE = MAX_CH * 4;  // doubles of biquad state per instance per op
 
 // An AudioParam's values as seen by a kernel (AudioParamValues::get, processor.rs:186-229).

@@ -272,6 +272,133 @@ int computed_in_nch(const Node& n, int maxc) {
   }
 }
 
+// ---- the ORDER of a node's inputs (graph.rs:524-535 + AudioRenderQuantum::add, quantum.rs:425-470) ----------------------------
+// The reference sums a node's inputs one after the other into a bus that starts as one silent channel: for every input the bus is
+// mixed to f(max(bus, input)) channels FIRST (f = the node's count mode), then the input is mixed to that count and added.  An input
+// therefore reaches the final count through every width the bus takes behind it, and the speakers table is not transitive:
+// mono -> stereo -> 5.1 leaves the mono signal in L and R, mono -> 5.1 puts it in C; quad -> 5.1 -> 8 leaves the surrounds in
+// channels 4 and 5, quad -> 8 (discrete above six channels) in 2 and 3.  mix_matrix is mix_regs (waa_mix.hpp) as a matrix
+// [to][from]; an input whose path differs from its direct mix is pre-mixed along the path (premix_ordered_inputs).
+static std::vector<double> mix_matrix(int from, int to, int interp) {
+  std::vector<double> m((size_t)to * from, 0.);
+  auto at = [&](int r, int c) -> double& { return m[(size_t)r * from + c]; };
+  const double s = 0.70710678118654752440;
+  bool done = true;
+  if (from == to || interp == WAA_INTERP_DISCRETE || from > 6 || to > 6) {
+    done = false;
+  } else if (from == 1 && to == 2) {
+    at(0, 0) = at(1, 0) = 1;
+  } else if (from == 2 && to == 1) {
+    at(0, 0) = at(0, 1) = 0.5;
+  } else if (from == 1 && to == 4) {
+    at(0, 0) = at(1, 0) = 1;
+  } else if (from == 2 && to == 4) {
+    at(0, 0) = at(1, 1) = 1;
+  } else if (from == 4 && to == 1) {
+    for (int c = 0; c < 4; c++) at(0, c) = 0.25;
+  } else if (from == 4 && to == 2) {
+    at(0, 0) = at(0, 2) = at(1, 1) = at(1, 3) = 0.5;
+  } else if (from == 1 && to == 6) {
+    at(2, 0) = 1;
+  } else if (from == 2 && to == 6) {
+    at(0, 0) = at(1, 1) = 1;
+  } else if (from == 4 && to == 5) {
+    at(0, 0) = at(1, 1) = at(3, 2) = at(4, 3) = 1;
+  } else if (from == 4 && to == 6) {
+    at(0, 0) = at(1, 1) = at(4, 2) = at(5, 3) = 1;
+  } else if (from == 6 && to == 1) {
+    at(0, 0) = at(0, 1) = s;
+    at(0, 2) = 1;
+    at(0, 4) = at(0, 5) = 0.5;
+  } else if (from == 6 && to == 2) {
+    at(0, 0) = at(1, 1) = 1;
+    at(0, 2) = at(1, 2) = at(0, 4) = at(1, 5) = s;
+  } else if (from == 6 && to == 4) {
+    at(0, 0) = at(1, 1) = at(2, 4) = at(3, 5) = 1;
+    at(0, 2) = at(1, 2) = s;
+  } else {
+    done = false;
+  }
+  if (!done)  // pad with silence / truncate
+    for (int c = 0; c < std::min(from, to); c++) at(c, c) = 1;
+  return m;
+}
+// widths the bus takes: w[k] = the count input k is mixed to when it is added (static widths)
+static std::vector<int> bus_widths(const Node& n, const std::vector<int>& in_w) {
+  std::vector<int> w(in_w.size());
+  int bus = 1;
+  for (size_t k = 0; k < in_w.size(); k++) {
+    bus = computed_in_nch(n, std::max(bus, in_w[k]));
+    w[k] = bus;
+  }
+  return w;
+}
+// does input k reach the final count by another matrix than its direct mix?
+static bool path_differs(const Node& n, const std::vector<int>& in_w, const std::vector<int>& w, size_t k) {
+  const int last = w.back();
+  std::vector<double> pm = mix_matrix(in_w[k], w[k], n.interp);
+  int cur = w[k];
+  for (size_t j = k + 1; j < w.size(); j++) {
+    if (w[j] == cur) continue;
+    const std::vector<double> step = mix_matrix(cur, w[j], n.interp);
+    std::vector<double> nm((size_t)w[j] * in_w[k], 0.);
+    for (int r = 0; r < w[j]; r++)
+      for (int c = 0; c < in_w[k]; c++) {
+        double acc = 0;
+        for (int t = 0; t < cur; t++) acc += step[(size_t)r * cur + t] * pm[(size_t)t * in_w[k] + c];
+        nm[(size_t)r * in_w[k] + c] = acc;
+      }
+    pm.swap(nm);
+    cur = w[j];
+  }
+  return pm != mix_matrix(in_w[k], last, n.interp);
+}
+bool inputs_mix_in_order(const waa_batch* b, const Node& n) {
+  if (n.mode == WAA_COUNT_MODE_EXPLICIT || n.in_edges.size() < 2) return false;  // (explicit: every input is mixed to `count` directly)
+  std::vector<int> in_w;
+  for (int e : n.in_edges) in_w.push_back(b->nodes[b->edges[e].from].out_nch);
+  const std::vector<int> w = bus_widths(n, in_w);
+  for (size_t k = 0; k < in_w.size(); k++)
+    if (path_differs(n, in_w, w, k)) return true;
+  return false;
+}
+// `ins` = the node's inputs in edge order (before any fan-in reduction): every input whose path differs is replaced by a
+// temporary signal of the final count that holds it mixed along its path
+int premix_ordered_inputs(waa_batch* b, uint32_t id, std::vector<InputRef>& ins) {
+  const Node& n = b->nodes[id];
+  if (n.mode == WAA_COUNT_MODE_EXPLICIT || ins.size() < 2) return 0;
+  std::vector<int> in_w;
+  for (auto& in : ins) in_w.push_back(in.nch);
+  const std::vector<int> w = bus_widths(n, in_w);
+  if (w.back() != n.in_nch) return 0;  // (static counts that are not the plain maximum: a fold upstream — nothing to order)
+  for (size_t k = 0; k < ins.size(); k++) {
+    if (!path_differs(n, in_w, w, k)) continue;
+    std::vector<OpDesc> ops;
+    int cur = w[k];
+    for (size_t j = k + 1; j < w.size(); j++) {
+      if (w[j] == cur) continue;
+      OpDesc o{};
+      o.kind = OP_MIX;
+      o.nch_in = cur;
+      o.nch_out = w[j];
+      o.i0 = n.interp;
+      ops.push_back(o);
+      cur = w[j];
+    }
+    SignalRef tmp;
+    if (int e = temp_signal(b, cur, &tmp)) return e;
+    plan_note(b, "node %u: input %zu (%d channels) is mixed along the widths the reference's input bus takes behind it (%d -> ... -> %d): not its direct mix",
+              id, k, in_w[k], w[k], cur);
+    if (int e = push_chain_step(b, {ins[k]}, w[k], n.interp, ops, tmp)) return e;
+    InputRef in{};
+    in.kind = IN_SIGNAL;
+    in.nch = cur;
+    in.sig = tmp;
+    ins[k] = in;
+  }
+  return 0;
+}
+
 // graph.rs:323-487 order_nodes / visit.  A DelayNode is two graph nodes in the reference (delay.rs:283-366:
 // writer, then reader, edge writer->reader); vertex `id` is the writer (or a plain node), `id | VTX_READER` the
 // reader.  Cycles are broken at the first DelayNode writer on the detected loop (its writer->reader edge is
@@ -353,9 +480,108 @@ int slot_for(waa_batch* b, const char* name) {
 // ---------------------------------------------------------------------------------------
 int emit_node_ops(waa_batch* b, uint32_t id, int cur_nch, bool head, std::vector<OpDesc>& ops, int* out_nch);
 
-// One interpreter-kernel step: input(s) -> [mix to in_nch] -> ops -> out
-int push_chain_step(waa_batch* b, const std::vector<InputRef>& inputs, int in_nch, int in_interp,
-                    const std::vector<OpDesc>& ops, const SignalRef& out) {
+// ---- signals wider than six channels (MAX_CHANNELS = 32, src/lib.rs:21) ----------------------------------------------
+// AudioRenderQuantum::mix (quantum.rs:285-306): as soon as either side of a mix has more than six channels the interpretation is
+// "discrete" whatever the node says — channel c of the result is channel c of the input or silence.  Everything the chain kernel
+// does to a signal is then independent per channel (sums, gains, curves; the panners and the speakers table only ever see <= 6),
+// so a wide chain is rendered as SLICES of at most six channels: slice s is the same chain on channels [6 s, 6 s + 6) of every
+// input, op and output, with every count n replaced by clamp(n - 6 s, 0, 6).  Counts <= 6 live in slice 0 unchanged (with the
+// node's own interpretation); in the other slices they are "no channel at all", modelled as one channel of zeros that no op
+// touches (a discrete up-mix of it pads with those zeros).
+constexpr int SLICE_CH = 6;
+static int slice_count(int n, int c0) { return std::max(0, std::min(n - c0, SLICE_CH)); }
+static SignalRef slice_signal(const SignalRef& sg, int c0) {
+  SignalRef r = sg;
+  r.base = sg.base + (uint64_t)c0 * sg.ch_stride;
+  r.nch = slice_count(sg.nch, c0);
+  return r;
+}
+int push_chain_step_narrow(waa_batch* b, const std::vector<InputRef>& inputs, int in_nch, int in_interp, const std::vector<OpDesc>& ops,
+                           const SignalRef& out);
+int push_chain_step(waa_batch* b, const std::vector<InputRef>& inputs, int in_nch, int in_interp, const std::vector<OpDesc>& ops,
+                    const SignalRef& out) {
+  int cmax = std::max(in_nch, out.nch);
+  for (auto& in : inputs) cmax = std::max(cmax, in.nch);
+  for (auto& o : ops) cmax = std::max({cmax, o.nch_in, o.nch_out});
+  if (cmax <= SLICE_CH) return push_chain_step_narrow(b, inputs, in_nch, in_interp, ops, out);
+  plan_note(b, "chain on up to %d channels: rendered as %d slices of at most %d channels (discrete mixing above six channels is per channel)", cmax,
+            (cmax + SLICE_CH - 1) / SLICE_CH, SLICE_CH);
+  auto wide_mix = [](int from, int to, int interp) { return interp == WAA_INTERP_DISCRETE || from > 6 || to > 6; };
+  for (int c0 = 0; c0 < out.nch; c0 += SLICE_CH) {
+    std::vector<InputRef> ins;
+    for (const InputRef& in0 : inputs) {
+      InputRef in = in0;
+      // (an input narrower than the receiver is padded discretely when the receiver is wide: nothing of it in the later slices;
+      // when both are narrow the speakers rules apply — in slice 0, where all their channels are)
+      in.nch = slice_count(in0.nch, c0);
+      if (in0.nch > 6 && in_nch <= 6) in.nch = std::min(in.nch, slice_count(in_nch, c0));  // (a wide input into a narrow receiver: truncated)
+      if (in.nch == 0) continue;
+      if (c0 > 0) switch (in0.kind) {
+          case IN_SIGNAL:
+          case IN_DELAYED: in.sig = slice_signal(in0.sig, c0); break;
+          case IN_SOURCE: {
+            auto it = b->src_tables.find(in0.src);
+            if (it == b->src_tables.end()) return fail(WAA_ERR_DEVICE, "internal: a source table without its host copy");
+            std::vector<SrcInst> t = it->second;
+            for (auto& si : t)
+              if (si.base) si.base += (uint64_t)c0 * si.ch_stride;
+            SrcInst* dt = nullptr;
+            if (int e = dev_upload(b, &dt, t)) return e;
+            in.src = dt;
+            break;
+          }
+          default: return fail(WAA_ERR_DEVICE, "internal: input kind %d with more than %d channels", in0.kind, SLICE_CH);
+        }
+      ins.push_back(in);
+    }
+    // the chain's counts in this slice; 0 = "nothing here" (see above)
+    int cur = slice_count(in_nch, c0);
+    int s_in_nch = cur, s_in_interp = in_interp;
+    if (in_nch > 6) s_in_interp = WAA_INTERP_DISCRETE;
+    bool nothing = cur == 0;  // the data so far are zeros that stand for no channel
+    if (nothing) {
+      // (inputs narrower than a wide in_nch were dropped above; a narrow in_nch leaves every input of this slice without channels)
+      ins.clear();
+      s_in_nch = 1;
+    }
+    if (ins.empty()) {
+      InputRef z{};
+      z.kind = IN_SILENT;
+      z.nch = 1;
+      ins.push_back(z);
+    }
+    std::vector<OpDesc> sops;
+    for (const OpDesc& o0 : ops) {
+      const int ni = slice_count(o0.nch_in, c0), no = slice_count(o0.nch_out, c0);
+      if (ni == 0 && no == 0) continue;  // the op works on channels that are not in this slice
+      if (no == 0)  // the slice's channels end here; anything behind would have to start from silence again
+        return fail(WAA_ERR_OUT_OF_SCOPE, "a signal of more than six channels that narrows and widens again within one fused chain is out of scope");
+      OpDesc o = o0;
+      if (o0.kind == OP_MIX) {
+        if (ni == 0 && !nothing) return fail(WAA_ERR_DEVICE, "internal: slice bookkeeping");
+        o.nch_in = ni == 0 ? 1 : ni;  // (from nothing: from the one channel of zeros)
+        o.nch_out = no;
+        if (wide_mix(o0.nch_in, o0.nch_out, o0.i0)) o.i0 = WAA_INTERP_DISCRETE;
+        nothing = false;
+      } else if (o0.nch_in > 6 || o0.nch_out > 6) {
+        // an op on a wide signal: per channel or not at all
+        if (o0.nch_in != o0.nch_out || (o0.kind != OP_GAIN && o0.kind != OP_WAVESHAPER))
+          return fail(WAA_ERR_OUT_OF_SCOPE, "a %s op on a signal of more than six channels is out of scope", op_name(o0.kind));
+        o.nch_in = o.nch_out = ni;
+      }  // (else: an op on a narrow signal, all of it in slice 0 — the later slices skipped it above)
+      sops.push_back(o);
+      cur = no;
+    }
+    const SignalRef so = slice_signal(out, c0);
+    if (nothing) {  // the chain never reaches this slice's channels: they are silence
+      if (cur == 0 && so.nch > 0) cur = 1;
+    }
+    if (int e = push_chain_step_narrow(b, ins, s_in_nch, s_in_interp, sops, so)) return e;
+  }
+  return 0;
+}
+int push_chain_step_narrow(waa_batch* b, const std::vector<InputRef>& inputs, int in_nch, int in_interp,
+                           const std::vector<OpDesc>& ops, const SignalRef& out) {
   if (ops.size() > (size_t)MAX_OPS) return fail(WAA_ERR_OUT_OF_SCOPE, "more than %d fused ops in one chain", MAX_OPS);
   Step st;
   ChainDesc& cd = st.chain;
@@ -1042,9 +1268,8 @@ static int build_plan_rest(waa_batch* b, std::vector<uint32_t>& items, std::vect
         break;
       default: n.out_nch = n.in_nch; break;
     }
-    if (n.in_nch > 6 || n.out_nch > 6)
-      return fail(WAA_ERR_OUT_OF_SCOPE, "the device path renders at most 6 channels per signal (node %u needs %d)", id,
-                  std::max(n.in_nch, n.out_nch));
+    if (n.in_nch > WAA_MAX_CHANNELS || n.out_nch > WAA_MAX_CHANNELS)
+      return fail(WAA_ERR_OUT_OF_SCOPE, "at most %d channels per signal (node %u needs %d)", WAA_MAX_CHANNELS, id, std::max(n.in_nch, n.out_nch));
     changed |= n.in_nch != old_in || n.out_nch != old_out;
   }
   if (!changed || n_scc == 0) break;
@@ -1315,6 +1540,21 @@ static int build_plan_rest(waa_batch* b, std::vector<uint32_t>& items, std::vect
                        "speakers up-mix made upstream (discrete interpretation or more than two channels);";
                 at = q;
               }
+          }
+        // the order of the inputs matters to the mix (inputs_mix_in_order) and not all of them are active over the same quanta: the
+        // widths the bus takes — and with them an earlier input's path — change with the activity of the later ones
+        if (!what && inputs_mix_in_order(b, n))
+          for (uint32_t q = 0; q < nq && !what; q++) {
+            bool any = false, all = true;
+            for (int e : n.in_edges) {
+              const bool a = act[b->edges[e].from][q];
+              any |= a;
+              all &= a;
+            }
+            if (any && !all) {
+              what = "sums signals of different widths whose up-mixes depend on the order and on which of them are active (the reference's input bus grows input by input);";
+              at = q;
+            }
           }
         if (what) {
           const bool keep_static = measure_switch("WAA_STATIC_CHANNEL_COUNTS") != nullptr;  // A/B aid: the round-1 behaviour
@@ -1744,7 +1984,9 @@ static int build_plan_rest(waa_batch* b, std::vector<uint32_t>& items, std::vect
         if (e) return e;
         ins.push_back(in);
       }
-      int e = reduce_fan_in(b, ins, hn.in_nch, hn.interp);
+      int e = premix_ordered_inputs(b, head, ins);
+      if (e) return e;
+      e = reduce_fan_in(b, ins, hn.in_nch, hn.interp);
       if (e) return e;
       cd.n_inputs = (int)ins.size();
       for (int k = 0; k < cd.n_inputs; k++) {

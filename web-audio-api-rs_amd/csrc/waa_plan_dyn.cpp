@@ -37,6 +37,11 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     // (whose line is then re-mixed in place when the count changes) / analysers (whose kernel follows the per-quantum codes)
     // / the destination; convolver and frozen-node inputs are stereo by their channel config: those stay mono / stereo
     const uint32_t k = n.desc.kind;
+    if (n.live && (n.in_nch > 6 || n.out_nch > 6))
+      return fail(WAA_ERR_OUT_OF_SCOPE,
+                  "node %u: the reference's channel count changes mid-render and a signal is wider than six channels (%d): exact dynamic "
+                  "counts are rendered up to 5.1 (signals of 7 ... 32 channels render where the counts are static)",
+                  id, std::max(n.in_nch, n.out_nch));
     const bool narrow_only = (k == WAA_NODE_CONVOLVER && n.has_ir) || (is_frozen_node(n) && k == WAA_NODE_PANNER);  // (an oversampled WaveShaper renders channel pairs, round 4)
     if (n.live && narrow_only && (n.in_nch > 2 || n.out_nch > 2))
       return fail(WAA_ERR_OUT_OF_SCOPE,

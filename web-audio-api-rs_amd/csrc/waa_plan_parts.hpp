@@ -70,6 +70,7 @@ int plan_loop(waa_batch* b, const std::vector<uint32_t>& loop_items);
 int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in);
 int widen_narrow_buffers(waa_batch* b, Node& n, uint32_t nch);
 int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int interp);
+int premix_ordered_inputs(waa_batch* b, uint32_t id, std::vector<InputRef>& ins);
 int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const SignalRef* target = nullptr, uint64_t* valid = nullptr);
 int plan_oscillator(waa_batch* b, uint32_t id);
 int conv_block_size(const waa_batch* b, const Node& n);

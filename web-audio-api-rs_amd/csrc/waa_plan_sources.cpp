@@ -216,6 +216,7 @@ int prepare_source_input(waa_batch* b, uint32_t id, InputRef* in) {
   if (e) return e;
   in->src = d_insts;
   in->sched = d_scheds;
+  b->src_tables[d_insts] = insts;
   in->fast_tiles = b->n_tiles;
   for (auto& si : insts) in->fast_tiles = std::min(in->fast_tiles, !si.base ? 0u : (si.linear_all ? b->n_tiles : si.fast_prefix));
   plan_note(b, "source node %u: %zu distinct schedule(s) for %u instance(s)", id, scheds.size(), b->n_inst);
@@ -229,30 +230,12 @@ int reduce_fan_in(waa_batch* b, std::vector<InputRef>& ins, int in_nch, int inte
     float* ptr = nullptr;
     int e = dev_alloc(b, &ptr, (size_t)b->n_inst * in_nch * b->lp);
     if (e) return e;
-    Step st;
-    ChainDesc& cd = st.chain;
-    std::memset(&cd, 0, sizeof cd);
-    cd.n_inputs = MAX_INPUTS;
-    for (int k = 0; k < MAX_INPUTS; k++) cd.in[k] = ins[k];
-    cd.in_nch = in_nch;
-    cd.in_interp = interp;
-    cd.out = SignalRef{ptr, (uint64_t)in_nch * b->lp, b->lp, in_nch, 0};
-    cd.n_inst = b->n_inst;
-    cd.n_tiles = b->n_tiles;
-    cd.tile0 = 0;
-    cd.tile1 = b->n_tiles;
-  cd.tile0 = 0;
-  cd.tile1 = b->n_tiles;
-    cd.n_quanta = b->n_quanta;
-    int cmax = in_nch;
-    for (int k = 0; k < MAX_INPUTS; k++) cmax = std::max(cmax, ins[k].nch);
-    st.cmax = cmax;
-    st.profile_slot = slot_for(b, cmax <= 1 ? "chain_kernel<1>" : "chain_kernel<2>");
-    b->steps.push_back(st);
+    const SignalRef part{ptr, (uint64_t)in_nch * b->lp, b->lp, in_nch, 0};
+    if ((e = push_chain_step(b, std::vector<InputRef>(ins.begin(), ins.begin() + MAX_INPUTS), in_nch, interp, {}, part))) return e;
     InputRef partial{};
     partial.kind = IN_SIGNAL;
     partial.nch = in_nch;
-    partial.sig = cd.out;
+    partial.sig = part;
     ins.erase(ins.begin(), ins.begin() + MAX_INPUTS);
     ins.insert(ins.begin(), partial);
     plan_note(b, "fan-in partial sum of %d inputs -> %dch", MAX_INPUTS, in_nch);
@@ -298,6 +281,7 @@ int node_input_signal(waa_batch* b, uint32_t id, SignalRef* out_sig, const Signa
       if ((e = build_edge_input(b, id, ie, &in))) return e;
       ins.push_back(in);
     }
+    if ((e = premix_ordered_inputs(b, id, ins))) return e;
     if ((e = reduce_fan_in(b, ins, n.in_nch, n.interp))) return e;
   }
   if ((e = push_chain_step(b, ins, n.in_nch, n.interp, {}, in_sig))) return e;
