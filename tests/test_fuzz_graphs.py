@@ -31,7 +31,14 @@ def build_random_graph(be, seed, frozen=False, tap=None):
     # FUZZ_MIXED_COUNTS=1 (campaign variant): one instance of some buffer sources plays an AudioBuffer of another channel
     # count (own generator: the graphs of a seed stay what they are without the switch)
     mix_rng = np.random.default_rng(seed + 7000003) if os.environ.get("FUZZ_MIXED_COUNTS") else None
-    c = waa.OfflineAudioContext(2, FRAMES, SR, n_instances=N_INST, binding=be)
+    # FUZZ_WIDE=1 (campaign variant, round 6): AudioBuffers of 1 / 2 / 4 / 6 / 8 channels, destinations of 2 ... 8 channels with either
+    # interpretation, GainNodes with wide explicit counts — the speakers table, discrete mixing above six channels and the ORDER in
+    # which a node's inputs are summed (own generator: the graphs of a seed stay what they are without the switch)
+    wide_rng = np.random.default_rng(seed + 9000011) if os.environ.get("FUZZ_WIDE") else None
+    n_out = int(wide_rng.choice([2, 2, 4, 6, 8])) if wide_rng is not None else 2
+    c = waa.OfflineAudioContext(n_out, FRAMES, SR, n_instances=N_INST, binding=be)
+    if wide_rng is not None and wide_rng.random() < 0.3:
+        c.destination().set_channel_interpretation("discrete")
     outputs = []      # nodes that can feed others
     descr = []
 
@@ -41,6 +48,8 @@ def build_random_graph(be, seed, frozen=False, tap=None):
             kind = "buffer2"
         if kind.startswith("buffer"):
             nch = int(kind[-1])
+            if wide_rng is not None and wide_rng.random() < 0.6:
+                nch = int(wide_rng.choice([1, 2, 4, 6, 8]))
             n = c.create_buffer_source()
             length = FRAMES if rng.random() < 0.7 else int(rng.integers(300, FRAMES // 2))  # some end early
             n.set_buffer_batch(white_noise(N_INST, nch, length, seed0=int(rng.integers(1, 1 << 20))) * 0.5, SR)
@@ -103,6 +112,9 @@ def build_random_graph(be, seed, frozen=False, tap=None):
         elif kind == "cfg-gain":  # explicit / clamped-max channel configs, discrete interpretation
             cc, mode, interp = [(1, "explicit", "speakers"), (2, "explicit", "speakers"), (1, "clamped-max", "speakers"),
                                 (2, "explicit", "discrete"), (4, "explicit", "discrete")][int(rng.integers(0, 5))]
+            if wide_rng is not None and wide_rng.random() < 0.6:
+                cc, mode, interp = [(6, "explicit", "speakers"), (8, "explicit", "speakers"), (4, "clamped-max", "speakers"),
+                                    (6, "clamped-max", "discrete"), (4, "explicit", "speakers"), (7, "explicit", "discrete")][int(wide_rng.integers(0, 6))]
             n = c.create_gain(gain=float(rng.uniform(0.2, 1.0)), channel_count=cc, channel_count_mode=mode,
                               channel_interpretation=interp)
         elif kind == "krate-gain":  # one value per render quantum (includes exact 0 and 1: gain.rs fast paths)

@@ -110,6 +110,25 @@ def g_shaper(ctx, src, n):
     src.connect(sh).connect(ctx.destination())
 
 
+def g_shaper_2x(ctx, src, n):
+    sh = ctx.create_wave_shaper()
+    sh.set_curve(np.tanh(np.linspace(-2, 2, 257)).astype(np.float32))
+    sh.set_oversample("2x")
+    src.connect(sh).connect(ctx.destination())
+
+
+def g_shaper_4x(ctx, src, n):
+    sh = ctx.create_wave_shaper()
+    sh.set_curve((np.tanh(np.linspace(-2, 2, 65)) + 0.1).astype(np.float32))
+    sh.set_oversample("4x")
+    src.connect(sh).connect(ctx.destination())
+
+
+def g_hrtf(ctx, src, n):
+    p = ctx.create_panner(panning_model="HRTF", position=(1.0, 0.5, -0.3))
+    src.connect(p).connect(ctx.destination())
+
+
 def g_delay(ctx, src, n):
     d = ctx.create_delay(0.1)
     d.delay_time.set_value(0.0123)
@@ -152,8 +171,8 @@ def g_five_inputs(ctx, src, n):
         src.connect(g).connect(ctx.destination())
 
 
-GRAPHS = [g_gain, g_gain_ramp, g_biquad, g_biquad_gain, g_biquad_arate, g_iir, g_shaper, g_delay, g_mixed_widths, g_explicit_wider, g_stereo_nodes,
-          g_five_inputs]
+GRAPHS = [g_gain, g_gain_ramp, g_biquad, g_biquad_gain, g_biquad_arate, g_iir, g_shaper, g_shaper_2x, g_shaper_4x, g_hrtf, g_delay, g_mixed_widths,
+          g_explicit_wider, g_stereo_nodes, g_five_inputs]
 
 
 def _render(be, graph, n, n_out, n_inst=3, length=20 * RQ + 37, start=0.0):
@@ -185,7 +204,13 @@ def test_wide_graphs_run_on_the_oracle(orc, graph, n):
 @pytest.mark.parametrize("n", WIDTHS)
 @pytest.mark.parametrize("graph", GRAPHS, ids=lambda g: g.__name__)
 def test_wide_graphs_against_the_oracle(hip, orc, graph, n):
-    g = _render(hip, graph, n, n)
+    try:
+        g = _render(hip, graph, n, n)
+    except waa.WaaError as e:
+        # nodes whose state freezes over silent quanta (oversampled WaveShapers, HRTF panners) are rendered on the exact per-quantum counts
+        # of the dynamic plan unless they sit directly behind a mono / stereo source: above 5.1 that is status 4
+        assert e.status == 4 and graph in (g_shaper_2x, g_shaper_4x, g_hrtf), e
+        pytest.skip(f"refused: {e}")
     o = _render(orc, graph, n, n)
     assert g.shape == o.shape and np.isfinite(g).all()
     assert np.abs(o).max() > 0.05
@@ -415,3 +440,30 @@ def test_feedback_loops_on_wide_signals(hip, orc, n, burst, delay_s, with_filter
     for i in range(g.shape[0]):
         for c in range(n):
             assert rms(g[i, c], o[i, c]) <= 1e-6, (i, c, plan)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,n_out", [(6, 2), (4, 2), (6, 1), (4, 1)])
+def test_a_wide_signal_that_is_in_fact_mono_in_front_of_a_narrower_node(hip, orc, n, n_out):
+    """wide fuzz seed 293 (round 6): a WaveShaper whose curve does not map 0 to 0 renders silence — ONE channel in the reference — into
+    a signal, so behind a 5.1 source that starts late its output is mono at first: a stereo destination hears it on L and R as it is
+    (mono -> stereo), not through the 5.1 -> stereo matrix the static plan applied to its six static channels (2.41 x).  A DOWN-mix of
+    a producer wider than stereo is count-sensitive like every mix above stereo: the exact per-quantum counts of the dynamic plan"""
+    outs = []
+    for be in (hip, orc):
+        ctx = waa.OfflineAudioContext(n_out, 16 * RQ, SR, n_instances=2, binding=be)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(_noise(2, n, 16 * RQ, 61) * 0.3, SR)
+        src.start_at(5.5 * RQ / SR)
+        sh = ctx.create_wave_shaper()
+        sh.set_curve((np.tanh(np.linspace(-2, 2, 65)) + 0.2).astype(np.float32))
+        src.connect(sh).connect(ctx.destination())
+        if be is hip:
+            assert "dyn_kernel" in ctx.plan_describe()
+        outs.append(ctx.start_rendering_sync().data)
+        ctx.close()
+    g, o = outs
+    assert np.allclose(o[0, :, :5 * RQ], 0.2, atol=1e-6)  # curve(0), on every output channel, as it is
+    for i in range(2):
+        for c in range(n_out):
+            assert rms(g[i, c], o[i, c]) <= 1e-6

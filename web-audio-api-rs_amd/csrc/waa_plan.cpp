@@ -334,7 +334,7 @@ static std::vector<int> bus_widths(const Node& n, const std::vector<int>& in_w) 
   return w;
 }
 // does input k reach the final count by another matrix than its direct mix?
-static bool path_differs(const Node& n, const std::vector<int>& in_w, const std::vector<int>& w, size_t k) {
+static bool path_differs(const Node& n, const std::vector<int>& in_w, const std::vector<int>& w, size_t k) {  // (all inputs active)
   const int last = w.back();
   std::vector<double> pm = mix_matrix(in_w[k], w[k], n.interp);
   int cur = w[k];
@@ -353,13 +353,41 @@ static bool path_differs(const Node& n, const std::vector<int>& in_w, const std:
   }
   return pm != mix_matrix(in_w[k], last, n.interp);
 }
-bool inputs_mix_in_order(const waa_batch* b, const Node& n) {
-  if (n.mode == WAA_COUNT_MODE_EXPLICIT || n.in_edges.size() < 2) return false;  // (explicit: every input is mixed to `count` directly)
-  std::vector<int> in_w;
-  for (int e : n.in_edges) in_w.push_back(b->nodes[b->edges[e].from].out_nch);
-  const std::vector<int> w = bus_widths(n, in_w);
-  for (size_t k = 0; k < in_w.size(); k++)
-    if (path_differs(n, in_w, w, k)) return true;
+// Does the reference's sum differ from what the static plan renders (every input mixed along the path premix_ordered_inputs derives from
+// the STATIC widths) in a quantum in which exactly the inputs of `active` (bit k = input k) are active?  A silent input is one channel
+// of zeros: it adds nothing and does not widen the bus, so the inputs behind it see another sequence of widths.
+bool inputs_mix_in_order_differs(const waa_batch* b, const Node& n, uint64_t active) {
+  if (n.mode == WAA_COUNT_MODE_EXPLICIT || n.in_edges.size() < 2 || n.in_edges.size() > 64) return false;  // (explicit: every input is mixed to `count` directly)
+  std::vector<int> in_w, dyn_w;
+  for (size_t k = 0; k < n.in_edges.size(); k++) {
+    in_w.push_back(b->nodes[b->edges[n.in_edges[k]].from].out_nch);
+    dyn_w.push_back((active >> k) & 1 ? in_w.back() : 1);
+  }
+  const std::vector<int> ws = bus_widths(n, in_w), wd = bus_widths(n, dyn_w);
+  if (wd.back() != ws.back()) return false;  // (narrower than the static count altogether: the finding above)
+  for (size_t k = 0; k < in_w.size(); k++) {
+    if (!((active >> k) & 1)) continue;
+    // the matrix the static plan applies to input k  vs  the one the reference applies in this quantum
+    auto path = [&](const std::vector<int>& w) {
+      std::vector<double> pm = mix_matrix(in_w[k], w[k], n.interp);
+      int cur = w[k];
+      for (size_t j = k + 1; j < w.size(); j++) {
+        if (w[j] == cur) continue;
+        const std::vector<double> step = mix_matrix(cur, w[j], n.interp);
+        std::vector<double> nm((size_t)w[j] * in_w[k], 0.);
+        for (int r = 0; r < w[j]; r++)
+          for (int c = 0; c < in_w[k]; c++) {
+            double acc = 0;
+            for (int t = 0; t < cur; t++) acc += step[(size_t)r * cur + t] * pm[(size_t)t * in_w[k] + c];
+            nm[(size_t)r * in_w[k] + c] = acc;
+          }
+        pm.swap(nm);
+        cur = w[j];
+      }
+      return pm;
+    };
+    if (path(ws) != path(wd)) return true;
+  }
   return false;
 }
 // `ins` = the node's inputs in edge order (before any fan-in reduction): every input whose path differs is replaced by a
@@ -1499,11 +1527,20 @@ static int build_plan_rest(waa_batch* b, std::vector<uint32_t>& items, std::vect
       // findings
       for (uint32_t id : b->order) {
         Node& n = b->nodes[id];
-        if (!n.live || n.in_nch <= 1 || n.in_edges.empty()) continue;
+        if (!n.live || n.in_edges.empty()) continue;
+        {
+          bool wide_producer = false;
+          for (int e : n.in_edges) wide_producer |= b->nodes[b->edges[e].from].out_nch > 2;
+          if (n.in_nch <= 1 && !wide_producer) continue;
+        }
         const uint32_t kind = n.desc.kind;
         const bool line = kind == WAA_NODE_DELAY || (kind == WAA_NODE_CONVOLVER && n.has_ir);
-        const bool sensitive = kind == WAA_NODE_BIQUAD || kind == WAA_NODE_IIR_FILTER || kind == WAA_NODE_STEREO_PANNER ||
-                               kind == WAA_NODE_PANNER || line || n.in_nch > 2 || n.interp == WAA_INTERP_DISCRETE;
+        bool sensitive = kind == WAA_NODE_BIQUAD || kind == WAA_NODE_IIR_FILTER || kind == WAA_NODE_STEREO_PANNER ||
+                         kind == WAA_NODE_PANNER || line || n.in_nch > 2 || n.interp == WAA_INTERP_DISCRETE;
+        // (a producer wider than stereo into a mono / stereo node: its DOWN-mix does not commute with the up-mix the static plan made
+        // upstream either — a 5.1 signal that is in fact mono goes to L and R as it is, its static 5.1 form through the 5.1 -> stereo
+        // matrix; round 6, wide fuzz seed 293: a WaveShaper with curve(0) != 0 on a silent 5.1 input in front of a stereo destination)
+        for (int e : n.in_edges) sensitive |= b->nodes[b->edges[e].from].out_nch > 2;
         if (!sensitive) continue;
         // a DelayNode up-mixes its line by copying when the wide signal arrives (= the static plan) but collapses it
         // when the input narrows or falls silent while the line still holds wide material
@@ -1543,19 +1580,21 @@ static int build_plan_rest(waa_batch* b, std::vector<uint32_t>& items, std::vect
           }
         // the order of the inputs matters to the mix (inputs_mix_in_order) and not all of them are active over the same quanta: the
         // widths the bus takes — and with them an earlier input's path — change with the activity of the later ones
-        if (!what && inputs_mix_in_order(b, n))
+        if (!what && n.mode != WAA_COUNT_MODE_EXPLICIT && n.in_edges.size() >= 2 && n.in_edges.size() <= 64) {
+          std::map<uint64_t, bool> seen;  // (few distinct activity patterns per node)
           for (uint32_t q = 0; q < nq && !what; q++) {
-            bool any = false, all = true;
-            for (int e : n.in_edges) {
-              const bool a = act[b->edges[e].from][q];
-              any |= a;
-              all &= a;
-            }
-            if (any && !all) {
+            uint64_t mask = 0;
+            for (size_t k = 0; k < n.in_edges.size(); k++)
+              if (act[b->edges[n.in_edges[k]].from][q]) mask |= (uint64_t)1 << k;
+            if (!mask) continue;
+            auto it = seen.find(mask);
+            if (it == seen.end()) it = seen.emplace(mask, inputs_mix_in_order_differs(b, n, mask)).first;
+            if (it->second) {
               what = "sums signals of different widths whose up-mixes depend on the order and on which of them are active (the reference's input bus grows input by input);";
               at = q;
             }
           }
+        }
         if (what) {
           const bool keep_static = measure_switch("WAA_STATIC_CHANNEL_COUNTS") != nullptr;  // A/B aid: the round-1 behaviour
           if (keep_static)
