@@ -62,7 +62,64 @@ size_t arena_unit_of(int device, const void* p) {
   const char* c = static_cast<const char*>(p);
   return c >= a.base && c < a.base + a.size ? a.unit_bytes : 0;
 }
+// ---- WAA_GUARD_ALLOC=1 (testing aid, round 6): every device buffer of a batch gets physical memory of its own, mapped so that the
+// buffer ENDS where the mapping ends — the address behind it is reserved but unmapped, and a kernel that reads or writes one element
+// past a buffer faults on the spot instead of reading its neighbour (hipMalloc sub-allocates: out-of-bounds reads are silent, and a
+// fault only ever happened with several processes on the device, never twice in the same place).  tools/fuzz_crash_probe.py then names
+// the graph.  16-byte placement granularity (what the kernels' vector loads need); 2 MiB of memory per buffer: small batches only.
+namespace {
+struct GuardPiece {
+  void* va;
+  size_t va_size, mapped;
+  hipMemGenericAllocationHandle_t handle;
+};
+std::map<void*, GuardPiece> g_guard;
+}  // namespace
+void* guard_alloc(int device, size_t bytes) {
+  std::lock_guard<std::mutex> l(g_arena_lock);
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || !gran) return nullptr;
+  const size_t mapped = (bytes + gran - 1) / gran * gran;
+  GuardPiece g{};
+  g.mapped = mapped;
+  g.va_size = mapped + gran;  // (one granule behind the mapping stays unmapped)
+  if (hipMemAddressReserve(&g.va, g.va_size, gran, nullptr, 0) != hipSuccess) return nullptr;
+  if (hipMemCreate(&g.handle, mapped, &prop, 0) != hipSuccess) {
+    (void)hipMemAddressFree(g.va, g.va_size);
+    return nullptr;
+  }
+  hipMemAccessDesc acc{};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  if (hipMemMap(g.va, mapped, 0, g.handle, 0) != hipSuccess || hipMemSetAccess(g.va, mapped, &acc, 1) != hipSuccess) {
+    (void)hipMemRelease(g.handle);
+    (void)hipMemAddressFree(g.va, g.va_size);
+    return nullptr;
+  }
+  char* p = static_cast<char*>(g.va) + mapped - (bytes + 15) / 16 * 16;
+  (void)hipMemset(g.va, 0xFF, mapped);  // (what lies in FRONT of the buffer is poison)
+  (void)hipDeviceSynchronize();
+  g_guard[p] = g;
+  if (getenv("WAA_ARENA_TRACE")) fprintf(stderr, "[waa guard] %zu bytes at %p, mapping ends at %p\n", bytes, (void*)p, (void*)(static_cast<char*>(g.va) + mapped));
+  return p;
+}
+bool guard_free(void* p) {
+  std::lock_guard<std::mutex> l(g_arena_lock);
+  auto it = g_guard.find(p);
+  if (it == g_guard.end()) return false;
+  (void)hipDeviceSynchronize();
+  (void)hipMemUnmap(it->second.va, it->second.mapped);
+  (void)hipMemRelease(it->second.handle);
+  (void)hipMemAddressFree(it->second.va, it->second.va_size);
+  g_guard.erase(it);
+  return true;
+}
 bool arena_free(int device, void* p) {
+  if (guard_free(p)) return true;
   std::lock_guard<std::mutex> l(g_arena_lock);
   auto it = g_arenas.find(device);
   if (it == g_arenas.end()) return false;

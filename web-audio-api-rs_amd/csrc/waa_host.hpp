@@ -399,6 +399,7 @@ struct PlanTrace {
 // hipMalloc that happened to serve its output).  Defined in waa_abi.cpp.
 void* arena_alloc(int device, size_t bytes, bool read_only = false);  // (read_only: the top end of a graded arena)
 bool arena_free(int device, void* p);
+void* guard_alloc(int device, size_t bytes);  // WAA_GUARD_ALLOC=1 (testing aid, waa_arena.cpp)
 // bytes of one physical unit when `p` lies in a GRADED arena of `device` (units mapped side by side), else 0
 size_t arena_unit_of(int device, const void* p);
 // hipMemcpy2DAsync whose device side may lie in a graded arena: the runtime refuses a pitched copy whose extent exceeds ONE mapped
@@ -433,7 +434,9 @@ int dev_alloc(waa_batch* b, T** out, size_t count, bool payload = false) {
   }
   const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipSuccess;
-  if (bytes >= (1u << 20)) p = arena_alloc(b->device, bytes, payload);  // (small tables stay with hipMalloc; payloads are only read)
+  static const bool guard = getenv("WAA_GUARD_ALLOC") != nullptr;
+  if (guard) p = guard_alloc(b->device, bytes);
+  if (!p && bytes >= (1u << 20)) p = arena_alloc(b->device, bytes, payload);  // (small tables stay with hipMalloc; payloads are only read)
   if (!p) e = hipMalloc(&p, bytes);
   b->t_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   b->n_alloc++;
