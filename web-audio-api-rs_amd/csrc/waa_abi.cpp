@@ -237,10 +237,14 @@ void waa_batch_destroy(waa_batch* b) {
       if (!arena_free(b->device, p)) (void)hipFree(p);
     for (void* p : b->payload_allocs)
       if (!arena_free(b->device, p)) (void)hipFree(p);
+    if (b->stage) (void)hipHostFree(b->stage);
     (void)hipStreamDestroy(b->stream);
   }
   delete b;
 }
+
+int waa_internal_xfer_h2d(waa_batch* b, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height);
+int waa_internal_xfer_d2h(waa_batch* b, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height);
 
 static int upload_buffer(waa_batch* b, const float* const* channels, uint32_t n_ch, uint64_t frames, float sr,
                          DeviceBuffer* out) {
@@ -253,8 +257,8 @@ static int upload_buffer(waa_batch* b, const float* const* channels, uint32_t n_
       if (b->dry) {
         std::memcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float));
       } else {
-        HIP_TRY(hipMemcpy(d + (size_t)c * stride, channels[c], frames * sizeof(float), hipMemcpyHostToDevice));
-        HIP_TRY(hipStreamSynchronize(nullptr));  // (null-stream copy vs the batch's own stream: see dev_upload)
+        if (int e2 = waa_internal_xfer_h2d(b, d + (size_t)c * stride, frames * sizeof(float), channels[c], frames * sizeof(float), frames * sizeof(float), 1)) return e2;
+        HIP_TRY(hipStreamSynchronize(b->stream));
       }
     }
   out->base = d;
@@ -263,6 +267,97 @@ static int upload_buffer(waa_batch* b, const float* const* channels, uint32_t n_
   out->nch = n_ch;
   out->sr = sr;
   out->valid = true;
+  return 0;
+}
+
+// ---- transfers between CALLER memory and the device --------------------------------------------------------------------------
+// Pinned caller memory (hipHostMalloc / hipHostRegister: what a host that cares about the link hands over — bench.py, the sharded
+// path) is copied directly.  PAGEABLE caller memory (a numpy array, a Rust Vec) goes through a pinned block of the batch: the runtime
+// would otherwise lock the caller's pages on the fly and let its copy kernels read / write them in place — and a destination that
+// has just been mapped and never touched (numpy's np.empty, a fresh Vec) is exactly what the round-6 campaigns saw go wrong under
+// several processes (one download that never arrived: a render "of zeros"; "Memory access fault by GPU ... Write access to a
+// read-only page").  Through the staging block the GPU only ever touches memory this library pinned.
+namespace {
+constexpr size_t STAGE_BYTES = 8u << 20;
+bool caller_memory_is_pinned(const void* p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+int stage_of(waa_batch* b, char** out) {
+  if (!b->stage) HIP_TRY(hipHostMalloc(&b->stage, STAGE_BYTES, hipHostMallocDefault));
+  *out = static_cast<char*>(b->stage);
+  return 0;
+}
+}  // namespace
+// `height` rows of `width` bytes, pitches in bytes; asynchronous on the batch's stream for pinned memory, complete on return otherwise
+int waa_internal_xfer_h2d(waa_batch* b, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+  if (!width || !height) return 0;
+  if (caller_memory_is_pinned(src)) {
+    if (dpitch == width && spitch == width)
+      HIP_TRY(hipMemcpyAsync(dst, src, width * height, hipMemcpyHostToDevice, b->stream));
+    else
+      HIP_TRY(copy2d_async(b->device, dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, b->stream));
+    return 0;
+  }
+  char* st = nullptr;
+  if (int e = stage_of(b, &st)) return e;
+  for (size_t r = 0; r < height;) {
+    if (width > STAGE_BYTES) {  // a row longer than the block: in pieces
+      for (size_t o = 0; o < width; o += STAGE_BYTES) {
+        const size_t n = std::min(STAGE_BYTES, width - o);
+        std::memcpy(st, static_cast<const char*>(src) + r * spitch + o, n);
+        HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst) + r * dpitch + o, st, n, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+      }
+      r++;
+      continue;
+    }
+    const size_t rows = std::min(height - r, STAGE_BYTES / width);
+    for (size_t k = 0; k < rows; k++) std::memcpy(st + k * width, static_cast<const char*>(src) + (r + k) * spitch, width);
+    if (dpitch == width)
+      HIP_TRY(hipMemcpyAsync(static_cast<char*>(dst) + r * dpitch, st, rows * width, hipMemcpyHostToDevice, b->stream));
+    else
+      HIP_TRY(copy2d_async(b->device, static_cast<char*>(dst) + r * dpitch, dpitch, st, width, width, rows, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    r += rows;
+  }
+  return 0;
+}
+int waa_internal_xfer_d2h(waa_batch* b, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+  if (!width || !height) return 0;
+  if (caller_memory_is_pinned(dst)) {
+    if (dpitch == width && spitch == width)
+      HIP_TRY(hipMemcpyAsync(dst, src, width * height, hipMemcpyDeviceToHost, b->stream));
+    else
+      HIP_TRY(copy2d_async(b->device, dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, b->stream));
+    return 0;
+  }
+  char* st = nullptr;
+  if (int e = stage_of(b, &st)) return e;
+  for (size_t r = 0; r < height;) {
+    if (width > STAGE_BYTES) {
+      for (size_t o = 0; o < width; o += STAGE_BYTES) {
+        const size_t n = std::min(STAGE_BYTES, width - o);
+        HIP_TRY(hipMemcpyAsync(st, static_cast<const char*>(src) + r * spitch + o, n, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        std::memcpy(static_cast<char*>(dst) + r * dpitch + o, st, n);
+      }
+      r++;
+      continue;
+    }
+    const size_t rows = std::min(height - r, STAGE_BYTES / width);
+    if (spitch == width)
+      HIP_TRY(hipMemcpyAsync(st, static_cast<const char*>(src) + r * spitch, rows * width, hipMemcpyDeviceToHost, b->stream));
+    else
+      HIP_TRY(copy2d_async(b->device, st, width, static_cast<const char*>(src) + r * spitch, spitch, width, rows, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    for (size_t k = 0; k < rows; k++) std::memcpy(static_cast<char*>(dst) + (r + k) * dpitch, st + k * width, width);
+    r += rows;
+  }
   return 0;
 }
 
@@ -275,17 +370,15 @@ static int fill_upload(waa_batch* b, const waa_batch::PendingFill& f) {
     // another (PCIe is full duplex) — SURVEY 8(e)
     // (contiguous on both sides -> a plain 1-D copy: those go through the DMA engines, one per direction; pitched 2-D
     // copies run as a copy kernel and did not overlap with a download on another stream)
-    if (f.stride == f.frames)
-      HIP_TRY(hipMemcpyAsync(f.planes, f.host, (size_t)f.n_items * f.n_ch * f.frames * sizeof(float), hipMemcpyHostToDevice, b->stream));
-    else
-      HIP_TRY(copy2d_async(b->device, f.planes, f.stride * sizeof(float), f.host, f.frames * sizeof(float), f.frames * sizeof(float),
-                           (size_t)f.n_items * f.n_ch, hipMemcpyHostToDevice, b->stream));
+    if (int e = waa_internal_xfer_h2d(b, f.planes, f.stride * sizeof(float), f.host, f.frames * sizeof(float), f.frames * sizeof(float), (size_t)f.n_items * f.n_ch))
+      return e;
     HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
   }
   const size_t bytes = (size_t)f.n_items * f.frames * f.n_ch * sizeof(int16_t);
-  hipError_t he = hipMemcpyAsync(f.staging, f.host, bytes, hipMemcpyHostToDevice, b->stream);
-  if (he == hipSuccess) {
+  if (int e = waa_internal_xfer_h2d(b, f.staging, bytes, f.host, bytes, bytes, 1)) return e;
+  hipError_t he = hipSuccess;
+  {
     const bool same = std::fabs(f.src_sr - b->sr) <= 0.1f;
     waa::DecodeDesc dd{};
     dd.pcm = f.staging;
@@ -1528,8 +1621,10 @@ waa_status waa_download(waa_batch* b, uint32_t inst, uint32_t ch, float* dst, ui
   if (int es = waa_settle_loops(b)) return es;
   const SignalRef& s = b->nodes[0].sig;
   if ((int)ch < s.nch) {
-    HIP_TRY(hipMemcpy(dst, s.base + (size_t)inst * s.inst_stride + (size_t)ch * s.ch_stride, frames * sizeof(float),
-                      hipMemcpyDeviceToHost));
+    if (int e = waa_internal_xfer_d2h(b, dst, frames * sizeof(float), s.base + (size_t)inst * s.inst_stride + (size_t)ch * s.ch_stride, frames * sizeof(float),
+                         frames * sizeof(float), 1))
+      return e;
+    HIP_TRY(hipStreamSynchronize(b->stream));
   } else {
     std::memset(dst, 0, frames * sizeof(float));
   }
@@ -1545,8 +1640,8 @@ waa_status waa_download_all(waa_batch* b, float* dst) {
   const SignalRef& s = b->nodes[0].sig;
   if (b->length == 0) return WAA_OK;
   if ((uint32_t)s.nch == b->n_out) {
-    HIP_TRY(copy2d_async(b->device, dst, b->length * sizeof(float), s.base, s.ch_stride * sizeof(float), b->length * sizeof(float),
-                         (size_t)b->n_inst * b->n_out, hipMemcpyDeviceToHost, b->stream));
+    if (int e = waa_internal_xfer_d2h(b, dst, b->length * sizeof(float), s.base, s.ch_stride * sizeof(float), b->length * sizeof(float), (size_t)b->n_inst * b->n_out))
+      return e;
     HIP_TRY(hipStreamSynchronize(b->stream));
   } else {
     for (uint32_t i = 0; i < b->n_inst; i++)

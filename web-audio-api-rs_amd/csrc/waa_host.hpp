@@ -298,6 +298,7 @@ struct waa_batch {
   int device = 0;
   int n_cu = 256;  // compute units of the device (plan-only batches: an MI355X)
   hipStream_t stream = nullptr;
+  void* stage = nullptr;  // pinned staging block for transfers from / to PAGEABLE caller memory (waa_internal_xfer_h2d / waa_internal_xfer_d2h, waa_abi.cpp)
   std::vector<Node> nodes;
   std::vector<waa_edge_desc> edges;
   // OfflineAudioContext::suspend_sync (offline.rs:359-397): the control clock — the render quantum in front of which the render

@@ -19,6 +19,7 @@
 #include <map>
 
 #include "waa_host.hpp"
+extern "C" int waa_internal_xfer_d2h(waa_batch* b, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height);  // waa_abi.cpp
 
 extern "C" int waa_settle_loops(waa_batch* b);  // waa_abi.cpp
 
@@ -136,7 +137,7 @@ waa_status waa_download_all_pcm16(waa_batch* b, int16_t* dst) {
   d.n_items = b->n_inst;
   waa::launch_pcm16_pack(d, b->stream);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(dst, b->pcm_out, count * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
+  if (int e = waa_internal_xfer_d2h(b, dst, count * sizeof(int16_t), b->pcm_out, count * sizeof(int16_t), count * sizeof(int16_t), 1)) return e;
   HIP_TRY(hipStreamSynchronize(b->stream));
   return WAA_OK;
 }
