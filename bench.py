@@ -96,7 +96,12 @@ def build_workload(waa, binding, name, n_inst, frames, device, noise_ptr):
                                                    oversample="2x" if name == "os2" else "4x"))
     if name == "hrtf":  # PannerNode, HRTF panning model (panner.rs:781-829), static geometry
         waa.set_hrtf_database(os.path.join(ROOT, "tests", "golden", "IRC_1003_C.bin"))
-        node = node.connect(ctx.create_panner(panning_model="HRTF", position=(1.0, 0.5, -0.5)))
+        pan = ctx.create_panner(panning_model="HRTF", position=(1.0, 0.5, -0.5))
+        if os.environ.get("WAA_BENCH_HRTF_PER_CONTEXT"):  # every context its own source position, at rest (one table per context)
+            for i in range(ctx.n_instances):
+                pan.position_x.set_value(float(np.cos(0.37 * i) * 2.0), instance=i)
+                pan.position_z.set_value(float(np.sin(0.37 * i) * 2.0), instance=i)
+        node = node.connect(pan)
     if name == "c5":
         src.playback_rate.set_value(1.5)
         src.set_loop(True)

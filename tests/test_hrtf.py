@@ -449,7 +449,8 @@ def test_fir_forms_are_bit_identical(hip, positions):
 @pytest.mark.measure
 @pytest.mark.gpu
 @pytest.mark.parametrize("sr", [44100.0, 48000.0, 32000.0])
-def test_transform_form_against_the_direct_form_and_the_oracle(hip, orc, sr):
+@pytest.mark.parametrize("per_context", [False, True], ids=["one-direction", "a-direction-per-context"])
+def test_transform_form_against_the_direct_form_and_the_oracle(hip, orc, sr, per_context):
     """round 6, waa_hrtf_fft.hip: PannerNode and AudioListener at rest = one HRIR pair for the whole batch -> partitioned
     overlap-add on 256-point transforms (2 per quantum, both ears in one) instead of taps x 128 x 2 multiply-adds.  Stereo and mono
     inputs, per-instance start times (gaps: skipped quanta, the frozen history), sources that end (the tail), a ragged end, runs
@@ -468,6 +469,10 @@ def test_transform_form_against_the_direct_form_and_the_oracle(hip, orc, sr):
         b2 = ctx.create_buffer_source()
         b2.set_buffer_batch(y, sr)
         pan = ctx.create_panner(panning_model="HRTF", position=(-1.5, 0.4, 0.7), ref_distance=0.5)
+        if per_context:  # every context its own source position (at rest): one table per context, built on the device
+            for k in range(n_inst):
+                pan.position_x.set_value(-2.0 + 0.7 * k, instance=k)
+                pan.position_z.set_value(1.5 - 0.4 * k, instance=k)
         a.connect(pan)
         b2.connect(pan)
         pan.connect(ctx.destination())
@@ -477,6 +482,7 @@ def test_transform_form_against_the_direct_form_and_the_oracle(hip, orc, sr):
         if be is hip:
             plan = ctx.plan_describe()
             assert "partitions of 128 taps as 256-point transforms" in plan, plan  # (WAA_HRTF_DIRECT is a launch-time switch)
+            assert ("one direction per context" if per_context else "one direction for the whole batch") in plan, plan
         out = ctx.start_rendering_sync().data
         ctx.close()
         return out

@@ -1103,7 +1103,7 @@ void launch_hrtf(const HrtfDesc& d0, void* stream) {
   const uint32_t nq_launch = d.q1 - d.q0;
   // one direction for the whole batch: the FIR as partitioned overlap-add on 256-point transforms (waa_hrtf_fft.hip) — unless the
   // launch is a short range of a loop rendered block by block (a run pays four unstored quanta up front)
-  if (d.fft_tables && d.rows == 1 && d.per_row == 1 && nq_launch >= 16 && !measure_switch("WAA_HRTF_DIRECT") && !measure_switch("WAA_HRTF_V1") &&
+  if (d.fft_tables && d.per_row == 1 && nq_launch >= 16 && !measure_switch("WAA_HRTF_DIRECT") && !measure_switch("WAA_HRTF_V1") &&
       !measure_switch("WAA_HRTF_V8") && !measure_switch("WAA_HRTF_DYNAMIC")) {
     launch_hrtf_fft(d, stream);
     return;

@@ -571,9 +571,11 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
   if ((e = dev_upload(b, &d_hr, hr)) || (e = dev_upload(b, &d_table, table))) return e;
   // one direction for the whole batch: the HRIR pair once, in the device kernel's arithmetic (a * u + b * v + c * w, f32)
   float* d_hstatic = nullptr;
+  std::vector<float> hs_host;
   if (per_row == 1) {  // (one direction per instance, or one for the batch)
     const int O = (sp->taps + 3) & ~3;
-    std::vector<float> hs((size_t)rows * 2 * O, 0.f);
+    std::vector<float>& hs = hs_host;
+    hs.assign((size_t)rows * 2 * O, 0.f);
     for (uint32_t i = 0; i < rows; i++) {
       const HrtfQ& r = table[i];
       for (int ear = 0; ear < 2; ear++)
@@ -627,30 +629,36 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
     }
     return true;
   };
-  if (per_row == 1 && rows == 1 && sp->taps <= 128 * hrtffft::PARTS && !b->dry && (!b->dynamic || plain_listeners_only())) {
+  if (per_row == 1 && sp->taps <= 128 * hrtffft::PARTS && !b->dry && (!b->dynamic || plain_listeners_only())) {
     // PannerNode and AudioListener at rest, the same for every context: the HRIR pair's partition spectra (both ears in one
     // complex table), the transform form of waa_hrtf_fft.hip.  Runs as for the oversampled WaveShaper: ~16 k groups per launch.
     const int O = (sp->taps + 3) & ~3;
-    std::vector<float> pair((size_t)O * 2, 0.f);
-    {
-      const HrtfQ& r = table[0];
-      for (int ear = 0; ear < 2; ear++)
-        for (int t = 0; t < sp->taps; t++) {
-          const size_t o = (size_t)ear * sp->taps + t;
-          const float a = hr[(size_t)r.v[0] * 2 * sp->taps + o], bb = hr[(size_t)r.v[1] * 2 * sp->taps + o], c = hr[(size_t)r.v[2] * 2 * sp->taps + o];
-          volatile float p0 = a * r.w[0], p1 = bb * r.w[1], p2 = c * r.w[2];
-          volatile float s01 = p0 + p1;
-          pair[(size_t)t * 2 + ear] = s01 + p2;
-        }
-    }
     float *d_tab = nullptr, *d_tw = nullptr, *d_trash = nullptr;
-    if ((e = dev_upload(b, &d_tab, hrtffft::make_tables(pair.data(), sp->taps))) || (e = dev_upload(b, &d_tw, osfft::tw256())) ||
-        (e = dev_alloc(b, &d_trash, 64)))
-      return e;
+    if (rows == 1) {
+      // (the pair plan_hrtf built above for hrtf8_kernel, in the device kernel's f32 arithmetic: hs = [tap][ear])
+      if ((e = dev_upload(b, &d_tab, hrtffft::make_tables(hs_host.data(), sp->taps)))) return e;
+    } else {
+      // one direction per context: the tables of all rows on the device, from the pairs already uploaded (same sums, same order)
+      std::vector<double> cs_sn(512);
+      for (int j = 0; j < 256; j++) {
+        cs_sn[(size_t)j] = std::cos(-6.283185307179586476925286766559 * (double)j / 256.);
+        cs_sn[(size_t)256 + j] = std::sin(-6.283185307179586476925286766559 * (double)j / 256.);
+      }
+      double* d_cs = nullptr;
+      if ((e = dev_upload(b, &d_cs, cs_sn)) || (e = dev_alloc(b, &d_tab, (size_t)rows * hrtffft::PARTS * osfft::TAB_SLOTS * 2))) return e;
+      launch_hrtf_fft_tables(d_hstatic, (uint32_t)(2 * O), sp->taps, rows, d_cs, d_tab, b->stream);
+      HIP_TRY(hipGetLastError());
+    }
+    if ((e = dev_upload(b, &d_tw, osfft::tw256())) || (e = dev_alloc(b, &d_trash, 64))) return e;
     d.fft_tables = d_tab;
     d.tw256 = d_tw;
     d.trash = d_trash;
+    // runs of ~16 k groups per launch; with one table per context the runs of a context come in sixteens (one workgroup = one table)
     uint32_t seg = std::max<uint32_t>(8, (uint32_t)(((uint64_t)b->n_inst * b->n_quanta + 16383) / 16384));
+    if (rows > 1) {
+      const uint32_t sixteens = std::max<uint32_t>(1, (uint32_t)((16384 + 8 * (uint64_t)b->n_inst) / (16 * (uint64_t)b->n_inst)));
+      seg = std::max<uint32_t>(8, (b->n_quanta + 16 * sixteens - 1) / (16 * sixteens));
+    }
     seg = std::min(seg, b->n_quanta);
     d.seg_len = seg;
     d.n_seg = (b->n_quanta + seg - 1) / seg;
@@ -661,8 +669,9 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
   st.loop_writes.push_back(n.sig.base);
   b->steps.push_back(st);
   if (fft_form)
-    plan_note(b, "panner node %u: HRTF, %d-tap impulse responses at %u Hz, one direction for the whole batch: %d partitions of 128 taps as 256-point "
-                 "transforms (2 per quantum, runs of %u quanta, %u per instance)", id, sp->taps, sp->sr, hrtffft::PARTS, d.seg_len, d.n_seg);
+    plan_note(b, "panner node %u: HRTF, %d-tap impulse responses at %u Hz, %s: %d partitions of 128 taps as 256-point "
+                 "transforms (2 per quantum, runs of %u quanta, %u per instance)", id, sp->taps, sp->sr,
+              rows == 1 ? "one direction for the whole batch" : "one direction per context", hrtffft::PARTS, d.seg_len, d.n_seg);
   else
     plan_note(b, "panner node %u: HRTF, %d-tap impulse responses at %u Hz, geometry table %u row(s) x %u, direct FIR per render quantum", id,
               sp->taps, sp->sr, rows, per_row);

@@ -1,4 +1,4 @@
-// waa_hrtf_fft.hip — the HRTF panner for a direction that does not change during the render, as uniform partitioned overlap-add on
+// waa_hrtf_fft.hip — the HRTF panner for directions that do not change during the render (one for the batch or one per context), as uniform partitioned overlap-add on
 // 256-point transforms in registers (waa_hrtf_fft.hpp has the algebra; the oversampled WaveShaper's kernel, waa_osfft.hip, the
 // machinery).  Replaces hrtf8_kernel's direct form (415 taps x 128 frames x 2 ears of fused multiply-adds per quantum: 8.5-9 ms for
 // 1024 contexts x 10 s at 0.6 of the packed-f32 peak) for batches in which PannerNode and AudioListener are at rest; moving
@@ -32,15 +32,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1
   const int lane = threadIdx.x & 63, wv = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, t = lane & 15;
   const ldsp ex = tab + PARTS * TAB_SLOTS + (wv * 4 + g) * XSLOTS;
+  // One direction for the whole batch (rows == 1): any group renders any (instance, run).  One direction PER instance (rows == n_inst):
+  // the sixteen groups of a workgroup render sixteen runs of ONE instance and share its table — the runs of an instance are padded to
+  // a multiple of sixteen (n_seg_pad, idle groups at the end of an instance's last workgroup).
+  const uint64_t gid = ((uint64_t)blockIdx.x * WAVES + wv) * 4 + g;
+  const uint32_t inst = (uint32_t)(gid / d.n_seg_pad), seg = (uint32_t)(gid % d.n_seg_pad);
+  const bool alive = inst < d.n_inst && seg < d.n_seg;
+  const uint32_t row = d.rows > 1 && inst < d.n_inst ? inst : 0u;  // (uniform over the workgroup when rows > 1)
   {
-    const f4v* src = reinterpret_cast<const f4v*>(d.fft_tables);
+    const f4v* src = reinterpret_cast<const f4v*>(d.fft_tables + (uint64_t)row * (PARTS * TAB_SLOTS * 2));
     __attribute__((address_space(3))) f4v* dst = (__attribute__((address_space(3))) f4v*)tab;
     for (int i = threadIdx.x; i < PARTS * TAB_SLOTS / 2; i += WAVES * 64) dst[i] = load_global_f4(reinterpret_cast<const float*>(src + i));
   }
   __syncthreads();
-  const uint64_t gid = ((uint64_t)blockIdx.x * WAVES + wv) * 4 + g;
-  const uint32_t inst = (uint32_t)(gid / d.n_seg), seg = (uint32_t)(gid % d.n_seg);
-  const bool alive = inst < d.n_inst;
   const int32_t* prev = d.prev + (uint64_t)(alive ? inst : 0) * d.prev_stride;
   const uint8_t* code = d.in_code + (uint64_t)(alive ? inst : 0) * d.code_stride;
   const int q_lo = (int)(d.q0 + seg * d.seg_len);
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1
   lane_reset_if(L, true);
   const float* src = d.in.base + (uint64_t)(alive ? inst : 0) * d.in.inst_stride;
   float* dst = d.out.base + (uint64_t)(alive ? inst : 0) * d.out.inst_stride;
-  const float gain = load_global(&d.table->gain);  // (one direction, one gain: rows == per_row == 1)
+  const float gain = load_global(&d.table[row].gain);  // (per_row == 1: one geometry row per instance, or one for the batch)
   const int n_it = (int)d.seg_len + HEADS;
   auto quantum_of = [&](int it) { return it < HEADS ? (it == 0 ? ph[0] : it == 1 ? ph[1] : it == 2 ? ph[2] : ph[3]) : q_lo + it - HEADS; };
   auto valid_at = [&](int it, int q) { return alive && it < n_it && q >= 0 && (it < HEADS || q < q_hi); };
@@ -159,7 +163,34 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1
     }
   }
 }
+// The partition spectra of MANY HRIR pairs (one direction per context), hrtffft::make_tables on the device: one thread per (row,
+// partition, bin), the 128-tap sum in f64 in the host function's order (no contraction), cos / sin from the host's table.
+__global__ __launch_bounds__(256) void hrtf_fft_tables_kernel(const float* pairs, uint32_t pair_stride, int taps, const double* cs_sn, float* out) {
+  const uint32_t row = blockIdx.x / PARTS, p = blockIdx.x % PARTS;
+  const int kp = (int)threadIdx.x;
+  const float* pair = pairs + (uint64_t)row * pair_stride;
+  double re = 0., im = 0.;
+  for (int n = 0; n < 128; n++) {
+    const int tap = 128 * (int)p + n;
+    if (tap >= taps) break;
+    const double hl = (double)pair[(size_t)tap * 2], hr = (double)pair[(size_t)tap * 2 + 1];
+    const int e = (kp * n) & 255;
+    const double c = cs_sn[e], sn = cs_sn[256 + e];
+    re += hl * c - hr * sn;
+    im += hl * sn + hr * c;
+  }
+  const int t = kp & 15, j = kp >> 4;
+  const size_t slot = (size_t)t * ROW + (size_t)K16(j);
+  float* o = out + (((uint64_t)row * PARTS + p) * TAB_SLOTS + slot) * 2;
+  o[0] = (float)(re / 256.);
+  o[1] = (float)(im / 256.);
+}
 }  // namespace
+
+void launch_hrtf_fft_tables(const float* pairs, uint32_t pair_stride, int taps, uint32_t rows, const double* cs_sn, float* out, void* stream) {
+  (void)hipMemsetAsync(out, 0, (size_t)rows * PARTS * TAB_SLOTS * 2 * sizeof(float), (hipStream_t)stream);  // (the rows' padding slots)
+  hipLaunchKernelGGL(hrtf_fft_tables_kernel, dim3(rows * PARTS), dim3(256), 0, (hipStream_t)stream, pairs, pair_stride, taps, cs_sn, out);
+}
 
 void launch_hrtf_fft(const HrtfDesc& d0, void* stream) {
   HrtfDesc d = d0;
@@ -170,8 +201,9 @@ void launch_hrtf_fft(const HrtfDesc& d0, void* stream) {
     d.seg_len = d.seg_len && d.seg_len < nq ? d.seg_len : nq;
   }
   d.n_seg = (nq + d.seg_len - 1) / d.seg_len;
+  d.n_seg_pad = d.rows > 1 ? (d.n_seg + WAVES * 4 - 1) / (WAVES * 4) * (WAVES * 4) : d.n_seg;
   const size_t lds = ((size_t)PARTS * TAB_SLOTS + (size_t)WAVES * 4 * XSLOTS) * 8;
-  const uint64_t groups = (uint64_t)d.n_inst * d.n_seg;
+  const uint64_t groups = (uint64_t)d.n_inst * d.n_seg_pad;
   const dim3 grid((unsigned)((groups + WAVES * 4 - 1) / (WAVES * 4))), block(WAVES * 64);
   hipLaunchKernelGGL(hrtf_fft_kernel, grid, block, lds, (hipStream_t)stream, d);
 }

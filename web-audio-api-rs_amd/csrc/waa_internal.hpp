@@ -697,14 +697,17 @@ struct HrtfDesc {
   uint32_t n_inst, n_quanta;
   uint32_t q0, q1;          // the quanta this launch renders (q1 = 0: all)
   int32_t pad;
-  // the transform form (waa_hrtf_fft.hip; round 6): one direction for the whole batch (rows == per_row == 1), taps <= 512
-  const float* fft_tables;  // hrtffft::PARTS tables of osfft::TAB_SLOTS complex values, lane-major rows; null: direct form only
+  // the transform form (waa_hrtf_fft.hip; round 6): directions that do not change during the render (per_row == 1) — one for the
+  // whole batch (rows == 1) or one per context (rows == n_inst) —, taps <= 512
+  const float* fft_tables;  // per row: hrtffft::PARTS tables of osfft::TAB_SLOTS complex values, lane-major rows; null: direct form only
   const float* tw256;       // exp(-2 pi i j / 256)
   float* trash;             // 64 floats nobody reads
   uint32_t seg_len, n_seg;  // quanta per run, runs per instance
+  uint32_t n_seg_pad, pad2; // set by the launcher: runs per instance in the workgroup mapping (rows > 1: a multiple of 16)
 };
 void launch_hrtf(const HrtfDesc& d, void* stream);
 void launch_hrtf_fft(const HrtfDesc& d, void* stream);
+void launch_hrtf_fft_tables(const float* pairs, uint32_t pair_stride, int taps, uint32_t rows, const double* cs_sn, float* out, void* stream);
 
 // ---- input preparation on the device (waa_decode.hip): decoded 16-bit PCM -> f32 planes at the context rate ----
 struct DecodeDesc {
