@@ -535,3 +535,33 @@ def test_transform_form_is_not_used_where_a_node_behind_the_panner_decides_on_ex
     scale = max(1.0, float(np.abs(o).max()))
     assert max(rms(g[i, c], o[i, c]) for i in range(g.shape[0]) for c in range(g.shape[1])) <= 1e-6 * scale, descr
     assert np.abs(g - o).max() <= 2e-5 * scale, descr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("consumer", ["hrtf", "convolver"])
+def test_buffer_that_ends_on_a_quantum_boundary_read_in_place(hip, orc, consumer):
+    """frozen-state fuzz seed 38723 (round 6).  An AudioBuffer of exactly 18 quanta in front of an HRTF panner (or a ConvolverNode) is
+    read in place by the node's kernel.  The reference renders ONE more quantum behind such a buffer as active — zeros, not the silent
+    block: the source's clock reaches the duration by additions of dt and may still compare below it — and in place that quantum was
+    the next context's first one: 0.2 of full scale in the panner's tail for every context but the last.  Such a source is copied now"""
+    frames, n_inst = 18 * 128, 3
+    x = np.random.default_rng(38723).uniform(-1, 1, (n_inst, 1, frames)).astype(np.float32)
+    outs = []
+    for be in (hip, orc):
+        ctx = waa.OfflineAudioContext(2, 40 * 128, 48000.0, n_instances=n_inst, binding=be)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(x, 48000.0)
+        if consumer == "hrtf":
+            node = ctx.create_panner(panning_model="HRTF", position=(1.0, 0.2, -0.4))
+        else:
+            node = ctx.create_convolver(buffer=waa.AudioBuffer(np.random.default_rng(1).uniform(-1, 1, (1, 700)).astype(np.float32) * 0.05, 48000.0),
+                                        disable_normalization=True)
+        src.connect(node).connect(ctx.destination())
+        src.start()
+        outs.append(ctx.start_rendering_sync().data)
+        ctx.close()
+    g, o = outs
+    assert np.abs(o[:, :, 18 * 128:22 * 128]).max() > 1e-3  # (the tail)
+    for k in range(n_inst):
+        for c in range(2):
+            assert rms(g[k, c], o[k, c]) <= 1e-6, (k, c)

@@ -115,7 +115,17 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
   // [n_items][5], 8-byte aligned: (4 + W (+ W) + 1) n_items ints + 8 n_items floats in front, one pad word when that count is odd
   double* cfs = reinterpret_cast<double*>(pcs + (size_t)d.n_items * 8 + (((13 + W + MIXD) * d.n_items) & 1));
   DynItem* items_s = reinterpret_cast<DynItem*>(cfs + (size_t)d.n_items * 5);
-  const uint32_t inst = blockIdx.x;
+  // (round 6) q_split > 1: the quanta of this ranged launch spread over q_split workgroups per instance (stateless items only)
+  const uint32_t split = W == 1 && d.q_split > 1 ? d.q_split : 1u;
+  const uint32_t inst = blockIdx.x / split;
+  const uint32_t bq0 = d.q0, bq1 = d.q1 ? d.q1 : d.n_quanta;  // the launch's range (a block of a quantum-blocked loop, or the whole render)
+  uint32_t sub_q0 = bq0, sub_q1 = bq1;
+  if (split > 1) {
+    const uint32_t per = (bq1 - bq0 + split - 1) / split;
+    sub_q0 = bq0 + (blockIdx.x % split) * per;
+    sub_q1 = sub_q0 + per < bq1 ? sub_q0 + per : bq1;
+    if (sub_q0 >= sub_q1) return;  // (the whole workgroup: nothing has been synchronised yet)
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = W > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;   // this wavefront's stage
   float* scratch = scratch_all + (size_t)wv * CM * RQ;
@@ -163,8 +173,8 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
   }
   all_sync();
   // a launch over a range of quanta that continues an earlier one (a loop rendered block by block): the items' state from memory
-  const uint32_t rq0 = d.q0, rq1 = d.q1 ? d.q1 : d.n_quanta;
-  if (d.save_f && rq0 > 0) {
+  const uint32_t rq0 = sub_q0, rq1 = sub_q1;
+  if (d.save_f && bq0 > 0) {
     const double* sf = d.save_f + (uint64_t)inst * (uint64_t)(d.n_items * CM * DYN_STATE);
     const int32_t* si = d.save_i + (uint64_t)inst * (uint64_t)(d.n_items * 4);
     for (int i = tid; i < d.n_items * CM * DYN_STATE; i += 64 * W) fst[i] = load_global(sf + i);
@@ -738,10 +748,12 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
           // later quanta with the ring count it found at the block's start.  The count it should have seen is this one, one
           // quantum late (delay.rs:515-530: ring[0].number_of_channels() right now) — a change anywhere but in the block's last
           // quantum invalidates the block: flagged, and the host renders the loop again one quantum per block (waa_abi.cpp).
-          if (li.xstate && sn != ist[it * 4 + 0] && q + 1 < rq1 && rq1 - rq0 > 1) store_global(li.xstate + (uint64_t)d.n_inst * 2, 1);
+          if (li.xstate && sn != ist[it * 4 + 0] && q + 1 < bq1 && bq1 - bq0 > 1) store_global(li.xstate + (uint64_t)d.n_inst * 2, 1);
           ist[it * 4 + 0] = sn;
           if (sn == 1) ist[it * 4 + 1] = (int)q;
-          if (li.xstate) {  // a reader in another launch follows the ring's state (round 5)
+          // (a split launch: the state the next block's reader finds is the one behind the block's LAST quantum; the workgroups of
+          // the earlier quanta keep out of it — they run concurrently)
+          if (li.xstate && (split == 1 || q + 1 == bq1)) {  // a reader in another launch follows the ring's state (round 5)
             store_global(li.xstate + (uint64_t)inst * 2, sn - 1);
             store_global(li.xstate + (uint64_t)inst * 2 + 1, (sn == 1 ? (int)q : ist[it * 4 + 1]) + 1);
           }
@@ -878,7 +890,7 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
     }
     if constexpr (W > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the step's hand-over (LDS only)
   }
-  if (d.save_f) {  // ... and back, for the launch that renders the next block
+  if (d.save_f && (split == 1 || rq1 == bq1)) {  // ... and back, for the launch that renders the next block (split: the last quanta's workgroup)
     all_sync();
     double* sf = d.save_f + (uint64_t)inst * (uint64_t)(d.n_items * CM * DYN_STATE);
     int32_t* si = d.save_i + (uint64_t)inst * (uint64_t)(d.n_items * 4);
@@ -899,7 +911,8 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
 void launch_dyn(const DynDesc& d, void* stream) {
   const int cm = d.cmax > 2 ? 6 : 2;
   // the pipelined form: mono / stereo groups the planner cut into stages (WAA_DYN_NO_PIPE=1: the one-wavefront form, A/B and cross-check)
-  const int stages = cm == 2 && d.n_stages > 1 && !measure_switch("WAA_DYN_NO_PIPE") && !measure_switch("WAA_DYN_CYCLES") ? d.n_stages : 1;
+  const bool split = d.split_ok && cm == 2 && !measure_switch("WAA_DYN_NO_SPLIT") && !measure_switch("WAA_DYN_CYCLES");
+  const int stages = cm == 2 && d.n_stages > 1 && !split && !measure_switch("WAA_DYN_NO_PIPE") && !measure_switch("WAA_DYN_CYCLES") ? d.n_stages : 1;
   const size_t lds = dyn_lds_bytes(d.n_items, d.cmax, stages);
   DynDesc dd = d;
   dd.no_scan = measure_switch("WAA_DYN_NO_SCAN") ? 1u : 0u;
@@ -927,9 +940,16 @@ void launch_dyn(const DynDesc& d, void* stream) {
     }
   } report{dd.cycles, (hipStream_t)stream, d.n_quanta, d.n_items};
 #endif
+  dd.q_split = 1;
+  if (split) {
+    // (at least six quanta per workgroup: each one loads the descriptors and the state; ~16 k workgroups fill the device)
+    const uint32_t nq = (dd.q1 ? dd.q1 : dd.n_quanta) - dd.q0;
+    const uint32_t want = (uint32_t)std::max<uint64_t>(1, 16384 / std::max<uint32_t>(d.n_inst, 1));
+    dd.q_split = std::max<uint32_t>(1, std::min<uint32_t>(std::max<uint32_t>(want, 16), nq / 6));
+  }
   auto go = [&](auto kernel, int w) {
     if (lds > 64 * 1024) raise_lds_limit(reinterpret_cast<const void*>(kernel));
-    hipLaunchKernelGGL(kernel, dim3(d.n_inst), dim3(64 * w), lds, (hipStream_t)stream, dd);
+    hipLaunchKernelGGL(kernel, dim3(d.n_inst * (w == 1 ? dd.q_split : 1u)), dim3(64 * w), lds, (hipStream_t)stream, dd);
   };
   if (cm != 2) {
     go(dyn_kernel<6, 1>, 1);

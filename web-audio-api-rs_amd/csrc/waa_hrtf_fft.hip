@@ -198,7 +198,9 @@ void launch_hrtf_fft(const HrtfDesc& d0, void* stream) {
   if (d.q1 <= d.q0) return;
   const uint32_t nq = d.q1 - d.q0;
   if (d.q0 != 0 || d.q1 != d.n_quanta || d.seg_len == 0) {  // a range: as many runs as it needs
-    d.seg_len = d.seg_len && d.seg_len < nq ? d.seg_len : nq;
+    // (a block of a quantum-blocked loop: runs short enough for ~16 k groups, at least 8 quanta — four unstored heads per run)
+    const uint32_t fill = (uint32_t)(((uint64_t)d.n_inst * nq + 16383) / 16384);
+    d.seg_len = nq < 8 ? nq : (fill > 8 ? (fill < nq ? fill : nq) : 8);
   }
   d.n_seg = (nq + d.seg_len - 1) / d.seg_len;
   d.n_seg_pad = d.rows > 1 ? (d.n_seg + WAVES * 4 - 1) / (WAVES * 4) * (WAVES * 4) : d.n_seg;

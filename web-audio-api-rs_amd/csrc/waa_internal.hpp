@@ -490,6 +490,11 @@ struct DynDesc {
   uint32_t q0, q1;
   double* save_f;
   int32_t* save_i;
+  // (round 6) a ranged launch whose items carry NO state from quantum to quantum — DelayNode readers / writers whose partner sits
+  // in another launch (the ring's channel count is the block's optimistic constant), gains, mixes, curves: nothing of a block's
+  // quantum depends on an earlier one of the same launch, so the block's quanta are spread over `q_split` workgroups per instance
+  // (set by the launcher from split_ok and the range's length) instead of walked by one wavefront at ~6 us per quantum
+  uint32_t split_ok, q_split;
 };
 void launch_dyn(const DynDesc& d, void* stream);
 constexpr int DYN_MAX_STAGES = 8;

@@ -15,6 +15,8 @@
 // curve in LDS; the exchange buffers are per group.  seg_len is chosen on the host so that the launch has ~16 k groups.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "waa_internal.hpp"
 #include "waa_osfft.hpp"
 
@@ -193,7 +195,10 @@ void launch_osfft(const OsFftDesc& d0, void* stream) {
   if (d.q0 != 0 || d.q1 != d.n_quanta) {  // a range: as many runs as it needs
     const uint32_t nq = d.q1 > d.q0 ? d.q1 - d.q0 : 0;
     if (nq == 0) return;
-    d.seg_len = d.seg_len < nq ? d.seg_len : nq;
+    // (the plan's run length fills the device with the WHOLE render's quanta; a block of a quantum-blocked loop is a few dozen quanta
+    // per instance: runs as short as it takes to have ~16 k groups again, at least 8 quanta — two unstored heads per run)
+    const uint32_t fill = (uint32_t)(((uint64_t)d.n_inst * nq + 16383) / 16384);
+    d.seg_len = std::min(nq, std::max<uint32_t>(8, fill));
     d.n_seg = (nq + d.seg_len - 1) / d.seg_len;
   }
   const bool clds = d.curve_n <= CURVE_LDS_MAX;

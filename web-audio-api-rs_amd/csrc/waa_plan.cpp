@@ -1802,6 +1802,21 @@ static int build_plan_rest(waa_batch* b, std::vector<uint32_t>& items, std::vect
            bf.nch == b0.nch && bf.sr == b0.sr && pr.cst[i] == 1.f && pd.cst[i] == 0.f && ss.start == 0. && ss.stop == DBL_MAX &&
            ss.offset == 0. && ss.duration == DBL_MAX && !ss.looping;
     }
+    // ... and every quantum the reference renders as ACTIVE lies inside the buffer.  The quantum right behind a buffer that ends on
+    // a quantum boundary can be one: the source's clock reaches the duration by additions of dt, and where it still compares below it
+    // the renderer produces one more quantum — of zeros, but not the silent block — before it ends (audio_buffer_source.rs:560-600).
+    // Read in place that quantum is the next context's first one (frozen-state fuzz seed 38723, round 6: a 2304-frame buffer in
+    // front of an HRTF panner; 0.2 of full scale for two of three contexts in the panner's tail).
+    for (uint32_t i = 0; i < b->n_inst && ok; i++) {
+      const DeviceBuffer& bf = n.bufs[i];
+      const SourceSched& ss = n.sched[i];
+      const SchedKey key(ss.start, ss.stop, ss.offset, ss.duration, ss.looping, ss.loop_start, ss.loop_end, bf.frames, bf.sr, pr.fix(pr.cst[i]),
+                         pd.fix(pd.cst[i]));
+      const auto so = schedule_source_cached(b, id, key, ss, bf.frames, bf.sr, true, param_per_quantum(b, pr, i, nullptr), param_per_quantum(b, pd, i, nullptr));
+      for (size_t q = 0; q < so->qrec.size() && ok; q++)
+        if (so->qrec[q].mode != Q_SILENT)
+          ok = so->qrec[q].mode == Q_FAST && so->qrec[q].start == (int64_t)q * RQ && (uint64_t)(q + 1) * RQ <= bf.frames;
+    }
     if (!ok) continue;
     n.is_view = true;
     n.materialized = false;

@@ -289,6 +289,23 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     d.n_stages = 1;
     d.stage_begin[0] = 0;
     d.stage_begin[1] = 3 * d.n_items;
+    {
+      // (round 6) items without state from quantum to quantum — gains, mixes, curves, the destination's pass, DelayNode halves whose
+      // partner sits in another launch: no quantum of the launch depends on an earlier one, the launcher spreads the quanta over
+      // workgroups (a block of a quantum-blocked loop, or the whole render of such a group) instead of walking them one by one
+      d.split_ok = d.cmax <= 2 ? 1 : 0;
+      for (int k = 0; k < d.n_items; k++) {
+        const DynItem& li = host[(size_t)k];
+        bool ok = false;
+        if (li.kind == DI_DELAY_R)
+          ok = li.writer_item < 0 && li.xstate;
+        else if (li.kind == DI_DELAY_W)
+          ok = li.xstate != nullptr;
+        else
+          ok = li.dk == DK_PASS || li.dk == DK_GAIN || li.dk == DK_WAVESHAPER || (li.dk == DK_CONV_IN && !li.compact_ch1);
+        if (!ok) d.split_ok = 0;
+      }
+    }
     if (cur_qgroup >= 0) {
       // a segment of a quantum-blocked loop: ranged launches that carry the items' state through memory; no quantum pipeline
       const int cm = d.cmax > 2 ? 6 : 2;
@@ -296,7 +313,8 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
       if (!e2) e2 = dev_alloc(b, &d.save_i, (size_t)b->n_inst * (size_t)d.n_items * 4);
       if (e2) return e2;
       st.qgroup = cur_qgroup;
-    } else if (d.cmax <= 2 && d.n_items >= 1) {
+
+    } else if (d.cmax <= 2 && d.n_items >= 1 && !d.split_ok) {
       const int n = d.n_items, nu = 3 * n;
       std::vector<uint8_t> nocut((size_t)nu, 0);  // nocut[u]: units u and u + 1 stay together
       auto keep = [&](int lo_item, int hi_item) {
@@ -392,9 +410,9 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
       std::string cuts;
       for (int sN = 1; sN < d.n_stages; sN++)
         cuts += (cuts.empty() ? "" : ",") + std::to_string(d.stage_begin[sN] / 3) + (d.stage_begin[sN] % 3 == 1 ? "b" : d.stage_begin[sN] % 3 == 2 ? "c" : "");
-      plan_note(b, "dynamic-count group: %d item(s) per quantum [%s]%s%s", d.n_items, desc.c_str(),
+      plan_note(b, "dynamic-count group: %d item(s) per quantum [%s]%s%s%s", d.n_items, desc.c_str(),
                 d.n_stages > 1 ? (", pipelined over the quanta in " + std::to_string(d.n_stages) + " stages, cut in front of item(s) ").c_str() : "",
-                cuts.c_str());
+                cuts.c_str(), d.split_ok ? ", no item keeps state from quantum to quantum: the quanta are spread over workgroups" : "");
     }
     for (uint32_t v : pending) planned_node[v & ~VTX_READER] = 1;
     pending.clear();
