@@ -517,16 +517,16 @@ def test_transform_form_against_the_direct_form_and_the_oracle(hip, orc, sr, per
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [502, 630])
-def test_transform_form_is_not_used_where_a_node_behind_the_panner_decides_on_exact_zeros(hip, orc, seed):
+def test_transform_form_where_a_node_behind_the_panner_decides_on_exact_zeros(hip, orc, seed):
     """round 6, found by the frozen-state fuzz generator on the first build with waa_hrtf_fft.hip: behind the end of the panner's
     tail the direct form puts out exact zeros, the transforms 1e-10 of roundoff — and a DelayNode / BiquadFilterNode behind the
     panner goes silent (= mono) on exactly that (delay.rs:640-668, biquad_filter.rs:775-790): the channel count behind it flipped
-    33 quanta into the render (seed 502: 1.5e-3 of full scale; seed 630, a feedback loop: 6e-2).  A dynamic plan keeps the
-    transform form only when nothing but GainNodes and the destination hears the panner"""
+    33 quanta into the render (seed 502: 1.5e-3 of full scale; seed 630, a feedback loop: 6e-2).  In such plans the kernel runs its
+    exact-zeros form: it follows the last non-zero input frame and puts out 0 behind the response's reach, like the direct sum"""
     from test_fuzz_graphs import build_random_graph
     ch, descr = build_random_graph(hip, seed, frozen=True)
     plan = ch.plan_describe()
-    assert "HRTF" in plan and "direct FIR per render quantum" in plan and "256-point transforms (2 per quantum" not in plan, plan
+    assert "HRTF" in plan and "exact zeros behind the response's reach" in plan, plan
     g = ch.start_rendering_sync().data
     ch.close()
     co, _ = build_random_graph(orc, seed, frozen=True)
@@ -565,3 +565,55 @@ def test_buffer_that_ends_on_a_quantum_boundary_read_in_place(hip, orc, consumer
     for k in range(n_inst):
         for c in range(2):
             assert rms(g[k, c], o[k, c]) <= 1e-6, (k, c)
+
+
+@pytest.mark.measure
+@pytest.mark.gpu
+def test_exact_zeros_form_has_the_direct_forms_zeros(hip, orc):
+    """the exact-zeros form of the transform kernel (a DelayNode behind the panner: a dynamic plan) against the direct form on the same
+    device: bursts with gaps longer and shorter than the response, a per-context start; wherever the direct sum is exactly zero
+    the transform form is — except on the handful of frames right at an onset (the response's leading zero taps are not modelled)"""
+    import os
+    n_inst, nq, sr = 5, 120, 48000.0
+    rng = np.random.default_rng(77)
+    x = np.zeros((n_inst, 2, 80 * RQ), np.float32)  # (the source ENDS inside the render: the DelayNode behind the panner makes the plan dynamic)
+    for k in range(n_inst):
+        for (a, b2) in ((3, 9), (11, 12), (20, 31), (40, 41), (60, 75)):
+            lo, hi = a * RQ + 17 * k, b2 * RQ + 40 + 9 * k
+            x[k, :, lo:hi] = rng.uniform(-1, 1, (2, hi - lo))
+
+    def render(be):
+        ctx = waa.OfflineAudioContext(2, nq * RQ, sr, n_instances=n_inst, binding=be)
+        a = ctx.create_buffer_source()
+        a.set_buffer_batch(x, sr)
+        a.start()
+        pan = ctx.create_panner(panning_model="HRTF", position=(0.8, -0.3, 1.1))
+        dl = ctx.create_delay(0.1)
+        dl.delay_time.set_value(0.01)
+        a.connect(pan).connect(dl).connect(ctx.destination())
+        pan.connect(ctx.destination())
+        plan = ctx.plan_describe() if be is not orc else ""
+        out = ctx.start_rendering_sync().data
+        ctx.close()
+        return out, plan
+
+    saved = os.environ.pop("WAA_HRTF_DIRECT", None)
+    try:
+        fft, plan = render(hip)
+        assert "exact zeros behind the response's reach" in plan, plan
+        os.environ["WAA_HRTF_DIRECT"] = "1"
+        direct, _ = render(hip)
+    finally:
+        os.environ.pop("WAA_HRTF_DIRECT", None)
+        if saved is not None:
+            os.environ["WAA_HRTF_DIRECT"] = saved
+    ref, _ = render(orc)
+    for k in range(n_inst):
+        for c in range(2):
+            assert rms(fft[k, c], ref[k, c]) <= 1e-6 and rms(direct[k, c], ref[k, c]) <= 1e-6
+    stray = (direct == 0) & (fft != 0)
+    assert np.abs(fft[stray]).max(initial=0.0) <= 1e-7
+    assert stray.sum() <= 40 * n_inst * 2 * 5, stray.sum()   # (onsets only: five bursts per context)
+    zq_d = (direct.reshape(n_inst, 2, nq, RQ) == 0).all(axis=3)
+    zq_f = (fft.reshape(n_inst, 2, nq, RQ) == 0).all(axis=3)
+    assert np.array_equal(zq_d, zq_f)   # quanta of exact zeros: the same ones

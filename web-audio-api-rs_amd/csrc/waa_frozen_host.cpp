@@ -611,8 +611,9 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
   // Where the direct form puts out EXACT zeros (frames more than `taps` behind the last non-zero input frame: the end of the node's
   // tail) the transforms leave roundoff of 1e-10, and in a dynamic plan a node behind the panner may decide on exactly that (a
   // DelayNode that read nothing but zeros, a BiquadFilterNode whose state is no longer normal: biquad_filter.rs:775-790) — fuzz seeds
-  // 502 and 630 of the frozen-state generator, DESIGN.md section 5.  A dynamic plan keeps the transform form when nothing but
-  // GainNodes and the destination hears the panner.
+  // 502 and 630 of the frozen-state generator, DESIGN.md section 5.  When anything but GainNodes and the destination hears the panner
+  // of a dynamic plan, the kernel runs its exact-zeros form (HrtfDesc::jmax: 0 wherever no non-zero input frame lies within the
+  // response's reach, like the direct sum).
   auto plain_listeners_only = [&]() {
     std::vector<uint32_t> todo{id};
     std::vector<char> seen(b->nodes.size(), 0);
@@ -629,7 +630,7 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
     }
     return true;
   };
-  if (per_row == 1 && sp->taps <= 128 * hrtffft::PARTS && !b->dry && (!b->dynamic || plain_listeners_only())) {
+  if (per_row == 1 && sp->taps <= 128 * hrtffft::PARTS && !b->dry) {
     // PannerNode and AudioListener at rest, the same for every context: the HRIR pair's partition spectra (both ears in one
     // complex table), the transform form of waa_hrtf_fft.hip.  Runs as for the oversampled WaveShaper: ~16 k groups per launch.
     const int O = (sp->taps + 3) & ~3;
@@ -650,6 +651,20 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
       HIP_TRY(hipGetLastError());
     }
     if ((e = dev_upload(b, &d_tw, osfft::tw256())) || (e = dev_alloc(b, &d_trash, 64))) return e;
+    if (b->dynamic && !plain_listeners_only()) {
+      // a node behind the panner may decide on exact zeros: the kernel's exact-zeros form needs the last non-zero tap per ear and row
+      std::vector<int32_t> jm((size_t)rows * 2, 0);
+      for (uint32_t i = 0; i < rows; i++)
+        for (int ear = 0; ear < 2; ear++)
+          for (int t = sp->taps - 1; t >= 0; t--)
+            if (hs_host[((size_t)i * O + t) * 2 + ear] != 0.f) {
+              jm[(size_t)i * 2 + ear] = t;
+              break;
+            }
+      int32_t* d_jm = nullptr;
+      if ((e = dev_upload(b, &d_jm, jm))) return e;
+      d.jmax = d_jm;
+    }
     d.fft_tables = d_tab;
     d.tw256 = d_tw;
     d.trash = d_trash;
@@ -671,7 +686,9 @@ int plan_hrtf(waa_batch* b, uint32_t id, int src_id) {
   if (fft_form)
     plan_note(b, "panner node %u: HRTF, %d-tap impulse responses at %u Hz, %s: %d partitions of 128 taps as 256-point "
                  "transforms (2 per quantum, runs of %u quanta, %u per instance)", id, sp->taps, sp->sr,
-              rows == 1 ? "one direction for the whole batch" : "one direction per context", hrtffft::PARTS, d.seg_len, d.n_seg);
+              rows == 1 ? (d.jmax ? "one direction for the whole batch (exact zeros behind the response's reach)" : "one direction for the whole batch")
+                        : (d.jmax ? "one direction per context (exact zeros behind the response's reach)" : "one direction per context"),
+              hrtffft::PARTS, d.seg_len, d.n_seg);
   else
     plan_note(b, "panner node %u: HRTF, %d-tap impulse responses at %u Hz, geometry table %u row(s) x %u, direct FIR per render quantum", id,
               sp->taps, sp->sr, rows, per_row);

@@ -25,6 +25,14 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// EXACTZ (dynamic plans in which a node behind the panner may DECIDE on exact zeros — a DelayNode that read nothing normal, a Biquad whose
+// state is no longer normal): the direct form's sum is exactly zero where no non-zero input frame lies within the response's reach
+// (every product is +-0), the transforms leave 1e-10 of roundoff there.  The kernel follows the position of the last non-zero input frame
+// through the processed quanta (per row of 16 frames: a ballot of the group's lanes, the highest set bit at or below the lane's frame)
+// and puts out 0 where that frame is further back than the ear's last non-zero tap (jmax).  The quanta in front of a run are 4 x 128 =
+// 512 frames >= taps: enough history.  (Leading zero taps are not modelled: the few frames right at an onset keep their roundoff — the
+// quantum is not silent there anyway.)
+template <bool EXACTZ>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void hrtf_fft_kernel(const HrtfDesc d) {
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   // LDS map (8-byte slots): PARTS tables | WAVES * 4 exchange buffers
@@ -86,11 +94,17 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1
   const float* src = d.in.base + (uint64_t)(alive ? inst : 0) * d.in.inst_stride;
   float* dst = d.out.base + (uint64_t)(alive ? inst : 0) * d.out.inst_stride;
   const float gain = load_global(&d.table[row].gain);  // (per_row == 1: one geometry row per instance, or one for the batch)
+  int jmax_l = 0, jmax_r = 0, lastnz = -8192;  // EXACTZ: last non-zero tap per ear; last non-zero input frame relative to the quantum's start
+  if constexpr (EXACTZ) {
+    jmax_l = load_global(d.jmax + 2 * row);
+    jmax_r = load_global(d.jmax + 2 * row + 1);
+  }
   const int n_it = (int)d.seg_len + HEADS;
   auto quantum_of = [&](int it) { return it < HEADS ? (it == 0 ? ph[0] : it == 1 ? ph[1] : it == 2 ? ph[2] : ph[3]) : q_lo + it - HEADS; };
   auto valid_at = [&](int it, int q) { return alive && it < n_it && q >= 0 && (it < HEADS || q < q_hi); };
   const float* safe = d.tw256;  // (any 128 readable floats: what a lane that does not process loads and throws away)
   float xn0[8], xn1[8];         // the next step's input frames (channel 0 / channel 1), requested one step ahead
+  int zpos[8];                  // EXACTZ: per frame t + 16 j of the quantum at hand, the last non-zero input frame at or in front of it
   int32_t link_n;
   uint32_t code_n;
   auto request = [&](int q, bool procn, uint32_t c) __attribute__((always_inline)) {
@@ -124,6 +138,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1
       code_n = v ? (uint32_t)load_global(code + qn) : (uint32_t)CODE_SILENT;
     }
     lane_reset_if(L, proc && link == LINK_FRESH);
+    if constexpr (EXACTZ) lastnz = proc && link == LINK_FRESH ? -8192 : lastnz;
     int tofs = 0;
     asm volatile("" : "+s"(tofs));
     const ldsp tabq = tab + tofs;  // (loop-invariant LDS reads: the address is opaque so that they are not hoisted out of the loop)
@@ -135,6 +150,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1
       for (int j = 0; j < 8; j++) {
         const float m = st2 ? 0.5f * (xn0[j] + xn1[j]) : xn0[j];
         x[j] = live ? m : 0.f;
+      }
+      if constexpr (EXACTZ) {
+        int run_last = lastnz;  // last non-zero frame in front of row j (relative to this quantum's first frame; < 0: an earlier quantum)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint64_t bal = __builtin_amdgcn_ballot_w64(x[j] != 0.f);
+          const uint32_t rm = (uint32_t)(bal >> (g * 16)) & 0xffffu;   // the group's sixteen frames 16 j + t
+          const uint32_t below = rm & ((2u << t) - 1u);                 // ... at or below this lane's
+          zpos[j] = below ? 16 * j + (31 - __builtin_clz(below)) : run_last;
+          run_last = rm ? 16 * j + (31 - __builtin_clz(rm)) : run_last;
+        }
+        const int nxt = run_last - 128 < -8192 ? -8192 : run_last - 128;
+        lastnz = proc ? nxt : lastnz;
       }
       ph_in(L, x);
     }
@@ -157,8 +185,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1
       float* p1c = store ? p0 + d.out.ch_stride : d.trash + lane;
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        store_global(p0 + (store ? 16 * j : 0), proc ? o[j].x * gain * corr : 0.f);
-        store_global(p1c + (store ? 16 * j : 0), proc ? o[j].y * gain * corr : 0.f);
+        float ol = proc ? o[j].x * gain * corr : 0.f, orr = proc ? o[j].y * gain * corr : 0.f;
+        if constexpr (EXACTZ) {
+          const int back = 16 * j + t - zpos[j];  // frames between this one and the last non-zero input frame
+          ol = back > jmax_l ? 0.f : ol;
+          orr = back > jmax_r ? 0.f : orr;
+        }
+        store_global(p0 + (store ? 16 * j : 0), ol);
+        store_global(p1c + (store ? 16 * j : 0), orr);
       }
     }
   }
@@ -207,7 +241,10 @@ void launch_hrtf_fft(const HrtfDesc& d0, void* stream) {
   const size_t lds = ((size_t)PARTS * TAB_SLOTS + (size_t)WAVES * 4 * XSLOTS) * 8;
   const uint64_t groups = (uint64_t)d.n_inst * d.n_seg_pad;
   const dim3 grid((unsigned)((groups + WAVES * 4 - 1) / (WAVES * 4))), block(WAVES * 64);
-  hipLaunchKernelGGL(hrtf_fft_kernel, grid, block, lds, (hipStream_t)stream, d);
+  if (d.jmax)
+    hipLaunchKernelGGL(hrtf_fft_kernel<true>, grid, block, lds, (hipStream_t)stream, d);
+  else
+    hipLaunchKernelGGL(hrtf_fft_kernel<false>, grid, block, lds, (hipStream_t)stream, d);
 }
 
 }  // namespace waa

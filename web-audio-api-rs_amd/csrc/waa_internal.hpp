@@ -709,6 +709,7 @@ struct HrtfDesc {
   float* trash;             // 64 floats nobody reads
   uint32_t seg_len, n_seg;  // quanta per run, runs per instance
   uint32_t n_seg_pad, pad2; // set by the launcher: runs per instance in the workgroup mapping (rows > 1: a multiple of 16)
+  const int32_t* jmax;      // [rows][2] last non-zero tap per ear: the exact-zeros form (dynamic plans); null: plain
 };
 void launch_hrtf(const HrtfDesc& d, void* stream);
 void launch_hrtf_fft(const HrtfDesc& d, void* stream);
