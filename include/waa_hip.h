@@ -68,7 +68,7 @@ enum {
   WAA_ERR_INVALID_ARGUMENT = 1, /* reference: assert!/panic with "…Error - …" message */
   WAA_ERR_NOT_SUPPORTED = 2,    /* reference: "NotSupportedError - …"                 */
   WAA_ERR_INVALID_STATE = 3,    /* reference: "InvalidStateError - …"                 */
-  WAA_ERR_OUT_OF_SCOPE = 4,     /* legal in the reference, not on this hot path (worklets, dynamic channel counts above 5.1, …) */
+  WAA_ERR_OUT_OF_SCOPE = 4,     /* legal in the reference, not on this hot path (worklets, a long ConvolverNode in a short feedback loop, …) */
   WAA_ERR_DEVICE = 5            /* HIP runtime failure                                 */
 };
 

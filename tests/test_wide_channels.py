@@ -230,10 +230,10 @@ def test_destination_narrower_or_wider_than_the_signal(hip, orc, n, n_out):
 
 
 @pytest.mark.gpu
-def test_a_wide_source_that_ends_mid_render_is_refused_where_counts_matter(hip, orc):
+def test_a_wide_source_that_starts_late_in_front_of_a_count_sensitive_node(hip, orc):
     """a wide source that starts late or ends early changes the reference's channel count mid-render (silence is mono); where nothing
-    downstream is count-sensitive the static plan renders it, where something is (a DelayNode: its line is re-mixed) the library
-    says so (status 4) instead of rendering the static counts"""
+    downstream is count-sensitive the static plan renders it, where something is (a DelayNode: its line is re-mixed — and loses
+    channels 1 ... 7 of what it holds when the input falls silent) the exact per-quantum counts of the dynamic plan do (dyn_kernel<32>)"""
     g = _render(hip, g_gain, 8, 8, start=0.01)
     o = _render(orc, g_gain, 8, 8, start=0.01)
     assert np.array_equal(g, o)
@@ -331,7 +331,7 @@ def test_the_order_of_the_inputs_static(hip, orc, wide):
 @pytest.mark.gpu
 def test_the_order_of_the_inputs_when_the_stereo_source_ends_early(hip, orc):
     """... and while the stereo source is silent the bus goes mono -> 5.1 directly: the constant moves to the centre channel.  That is a
-    channel-count change mid-render: the exact per-quantum counts of the dynamic plan (5.1), status 4 above six channels"""
+    channel-count change mid-render: the exact per-quantum counts of the dynamic plan"""
     g, plan = _ordered_sum(hip, ["mono", "stereo", "wide"], 6, 6, stereo_frames=5 * RQ)
     o, _ = _ordered_sum(orc, ["mono", "stereo", "wide"], 6, 6, stereo_frames=5 * RQ)
     assert "dyn_kernel" in plan
@@ -340,9 +340,17 @@ def test_the_order_of_the_inputs_when_the_stereo_source_ends_early(hip, orc):
     for i in range(g.shape[0]):
         for c in range(6):
             assert rms(g[i, c], o[i, c]) <= 1e-6, (i, c)
-    with pytest.raises(waa.WaaError) as ei:
-        _ordered_sum(hip, ["mono", "stereo", "wide"], 8, 8, stereo_frames=5 * RQ)
-    assert ei.value.status == 4
+    # ... and the same above six channels (dyn_kernel<32>, round 6): while the stereo source plays the constant is on channels 0 and 1,
+    # afterwards on channel 0 alone (mono -> 8 is a padding)
+    for wide in (8, 32):
+        g, plan = _ordered_sum(hip, ["mono", "stereo", "wide"], wide, wide, stereo_frames=5 * RQ)
+        o, _ = _ordered_sum(orc, ["mono", "stereo", "wide"], wide, wide, stereo_frames=5 * RQ)
+        assert "dyn_kernel" in plan
+        x_w = _noise(2, wide, 12 * RQ, 22) * 0.1
+        assert np.abs((o[0] - x_w[0])[0, 6 * RQ:]).max() > 0.2 and np.abs((o[0] - x_w[0])[1, 6 * RQ:]).max() < 1e-6
+        for i in range(g.shape[0]):
+            for c in range(wide):
+                assert rms(g[i, c], o[i, c]) <= 1e-6, (wide, i, c)
 
 
 @pytest.mark.gpu
@@ -467,3 +475,33 @@ def test_a_wide_signal_that_is_in_fact_mono_in_front_of_a_narrower_node(hip, orc
     for i in range(2):
         for c in range(n_out):
             assert rms(g[i, c], o[i, c]) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [8, 16, 32])
+def test_a_wide_source_that_ends_early_in_front_of_a_delay_and_a_filter(hip, orc, n):
+    """the usual multi-channel case: a file shorter than the render in front of a DelayNode and a BiquadFilterNode.  When the source
+    ends the DelayNode's input is silent = ONE channel: the reference re-mixes the line to mono (channels 1 ... n-1 of the delayed
+    audio are gone, delay.rs:428-489), the filter keeps its n states and rings out.  Exact per-quantum counts: dyn_kernel<32>"""
+    length = 40 * RQ
+    outs = []
+    for be in (hip, orc):
+        ctx = waa.OfflineAudioContext(n, length, SR, n_instances=2, binding=be)
+        src = ctx.create_buffer_source()
+        src.set_buffer_batch(_noise(2, n, 12 * RQ + 50, 71), SR)
+        src.start_at(3.3 * RQ / SR)
+        d = ctx.create_delay(0.1)
+        d.delay_time.set_value(0.02)
+        bq = ctx.create_biquad_filter(type_="lowpass", frequency=1200.0, q=3.0)
+        src.connect(d).connect(bq).connect(ctx.destination())
+        src.connect(ctx.destination())
+        if be is hip:
+            assert "dyn_kernel" in ctx.plan_describe()
+        outs.append(ctx.start_rendering_sync().data)
+        ctx.close()
+    g, o = outs
+    assert np.abs(o[:, 0, 18 * RQ:24 * RQ]).max() > 1e-3 and np.all(o[:, 1:, 24 * RQ:] == 0)  # (channel 0 rings on; the others are gone)
+    assert np.abs(o[:, 1:, 5 * RQ:14 * RQ]).max() > 0.1
+    for i in range(2):
+        for c in range(n):
+            assert rms(g[i, c], o[i, c]) <= 1e-6, (i, c)

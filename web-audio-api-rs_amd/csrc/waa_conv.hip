@@ -869,7 +869,7 @@ __global__ void analyser_kernel(const AnalyserDesc d) {
       int nch = d.sig.nch;
       if (d.code) {  // (dynamic-count plans: the count of this frame's quantum)
         const uint32_t c = d.code[(uint64_t)inst * d.code_stride + (uint64_t)(f >> 7)];
-        nch = (c & 0x80u) ? 0 : (int)(c & 7u);
+        nch = (c & 0x80u) ? 0 : (int)(c & 63u);
       }
       switch (nch) {  // quantum.rs:387-429 speaker down-mix to mono
         case 0: v = 0.f; break;  // (a silent quantum)

@@ -273,14 +273,14 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
             const float* src = cur + (size_t)in.item * CM * RQ;
 #pragma unroll
             for (int c = 0; c < CM; c++)
-              if (c < (int)(oc & 7u)) {
+              if (c < (int)(oc & 63u)) {
                 u[c][0] = src[c * RQ + lane];
                 u[c][1] = src[c * RQ + 64 + lane];
               }
           } else {
             oc = in.code ? (uint32_t)load_global(in.code + (uint64_t)inst * in.code_stride + q) : (uint32_t)in.nch;
             const float* src = in.sig.base + (uint64_t)inst * in.sig.inst_stride;
-            const int on = (int)(oc & 7u);
+            const int on = (int)(oc & 63u);
             if (!(oc & CODE_SILENT)) {
               u[0][0] = load_global(src + f0 + lane);
               u[0][1] = load_global(src + f0 + 64 + lane);
@@ -297,7 +297,7 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
                 }
             }
           }
-          int on = (int)(oc & 7u);
+          int on = (int)(oc & 63u);
           bool os = (oc & CODE_SILENT) != 0;
           if (on > CM) on = CM;  // (the planner picks the instantiation by the widest signal)
           // quantum.rs:532-569
@@ -345,7 +345,7 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
       if (!do_node) {
         // the node ran in an earlier stage: its result and code of this quantum wait in the ring
         const uint32_t oc = (uint32_t)__builtin_amdgcn_readfirstlane(codes[it]);
-        outn = (int)(oc & 7u);
+        outn = (int)(oc & 63u);
         outs = (oc & CODE_SILENT) != 0;
         const float* rs = cur + (size_t)it * CM * RQ;
 #pragma unroll
@@ -723,7 +723,7 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
             float* hbw = li.out.base + (uint64_t)inst * li.out.inst_stride;
             for (uint32_t p = q > cap ? q - cap : 0u; p < q; p++) {
               const uint32_t pc = coherent_u(wc + p);
-              const int np = (int)(pc & 7u);
+              const int np = (int)(pc & 63u);
               if (np == sn) continue;
               float w[CM][2];
 #pragma unroll
@@ -790,7 +790,7 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
           const int p = (int)(idx >> 7);
           const uint32_t pc = coherent_u(wcode + p);
           if (pc & CODE_SILENT) return 0.f;
-          const int np = (int)(pc & 7u);
+          const int np = (int)(pc & 63u);
           if constexpr (CM > 2)  // (the writer re-mixed the ring in place: every entry carries the ring's count)
             return c < np ? coherent_f(hb + (uint64_t)c * hs.ch_stride + idx) : 0.f;
           if (np <= 1) return coherent_f(hb + idx);
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(64 * W) void dyn_kernel(const DynDesc d) {
   dyn_body<CM, W>(d);
 }
 void launch_dyn(const DynDesc& d, void* stream) {
-  const int cm = d.cmax > 2 ? 6 : 2;
+  const int cm = dyn_planes(d.cmax);
   // the pipelined form: mono / stereo groups the planner cut into stages (WAA_DYN_NO_PIPE=1: the one-wavefront form, A/B and cross-check)
   const bool split = d.split_ok && cm == 2 && !measure_switch("WAA_DYN_NO_SPLIT") && !measure_switch("WAA_DYN_CYCLES");
   const int stages = cm == 2 && d.n_stages > 1 && !split && !measure_switch("WAA_DYN_NO_PIPE") && !measure_switch("WAA_DYN_CYCLES") ? d.n_stages : 1;
@@ -951,7 +951,13 @@ void launch_dyn(const DynDesc& d, void* stream) {
     if (lds > 64 * 1024) raise_lds_limit(reinterpret_cast<const void*>(kernel));
     hipLaunchKernelGGL(kernel, dim3(d.n_inst * (w == 1 ? dd.q_split : 1u)), dim3(64 * w), lds, (hipStream_t)stream, dd);
   };
-  if (cm != 2) {
+  if (cm == 32) {
+    go(dyn_kernel<32, 1>, 1);  // (round 6) signals of 7 ... 32 channels: every mix is discrete there, the count rules are the same
+  } else if (cm == 16) {
+    go(dyn_kernel<16, 1>, 1);
+  } else if (cm == 8) {
+    go(dyn_kernel<8, 1>, 1);
+  } else if (cm != 2) {
     go(dyn_kernel<6, 1>, 1);
   } else {
     switch (stages) {
@@ -967,7 +973,7 @@ void launch_dyn(const DynDesc& d, void* stream) {
   }
 }
 size_t dyn_lds_bytes(int n_items, int cmax, int stages) {
-  const int cm = cmax > 2 ? 6 : 2;
+  const int cm = dyn_planes(cmax);
   const int w = cm == 2 && stages > 1 ? stages : 1;
   // signals (a ring of w quanta; w > 1: a second ring, the mixed inputs) + scratch (per stage), filter state, ist (4) + codes (w)
   // (+ meta (w)) + pmask (1) ints (+ the pad word in front of the doubles), the param cache (8 floats), the coefficient cache
@@ -994,7 +1000,7 @@ __device__ inline void conv_code_quanta(const ConvCodeDesc& d, uint32_t inst, ui
     const uint32_t c = in[q];
     const uint32_t nz = d.noise ? clean[q] : 0u;
     const bool silent = (c & CODE_SILENT) != 0;
-    const uint32_t r = conv_noise_node_step(d.nir, d.ir_nch, d.impulse_length, s.node, silent, (int)(c & 7u), nz);
+    const uint32_t r = conv_noise_node_step(d.nir, d.ir_nch, d.impulse_length, s.node, silent, (int)(c & 63u), nz);
     clean[q] = 0;
     if (r == CONV_NOISE_CUT) {
       out[q] = (uint8_t)(1u | CODE_SILENT);
@@ -1058,7 +1064,7 @@ __global__ __launch_bounds__(128) void conv_nz_kernel(const ConvCodeDesc d) {
     const uint32_t code = d.in_code[(uint64_t)inst * d.code_stride + q];
     uint32_t bits = 0;
     if (!(code & CODE_SILENT)) {
-      const int ic = (int)(code & 7u);
+      const int ic = (int)(code & 63u);
       for (int c = 0; c < ic && c < d.in_test_nch; c++) {
         const float v = d.in.base[(uint64_t)inst * d.in.inst_stride + (uint64_t)c * d.in.ch_stride + (uint64_t)q * RQ + threadIdx.x];
         if (__syncthreads_or(v != 0.f)) bits |= 1u << c;

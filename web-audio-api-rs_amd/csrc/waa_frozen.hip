@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void link_kernel(const LinkDesc d) {
           } else {
             // (a silent quantum keeps the count it was MIXED to — explicit mode: the node's channelCount, quantum.rs:532-569 —
             // not 1: the code carries it)
-            const int nch = (int)(c & 7u);
+            const int nch = (int)(c & 63u);
             if (nch != cur_ch) {  // the resamplers are re-created for the new channel count: their overlap is gone
               cur_ch = nch;
               last = LINK_FRESH;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64) void link_range_kernel(const LinkDesc d) {
         link = LINK_SKIP;
         oc = (uint8_t)(1u | CODE_SILENT);
       } else {
-        const int nch = (int)(c & 7u);
+        const int nch = (int)(c & 63u);
         if (nch != cur_ch) {
           cur_ch = nch;
           last = LINK_FRESH;
@@ -915,12 +915,12 @@ __global__ __launch_bounds__(256) void hrtf_kernel(const HrtfDesc d) {
           const uint64_t f = (uint64_t)qe * RQ;
           m0 = load_global(src + f + lane);
           m1 = load_global(src + f + 64 + lane);
-          if ((c & 7u) >= 2) {  // stereo input: mixed down (quantum.rs:387-397), doubled after the convolution
+          if ((c & 63u) >= 2) {  // stereo input: mixed down (quantum.rs:387-397), doubled after the convolution
             m0 = 0.5f * (m0 + load_global(src + d.in.ch_stride + f + lane));
             m1 = 0.5f * (m1 + load_global(src + d.in.ch_stride + f + 64 + lane));
           }
         }
-        if (e == 0) corr = (c & 7u) >= 2 ? 2.f : 1.f;  // (panner.rs:800-810: by the quantum's count, silent or not)
+        if (e == 0) corr = (c & 63u) >= 2 ? 2.f : 1.f;  // (panner.rs:800-810: by the quantum's count, silent or not)
       }
       const int p0 = O - e * RQ + lane, p1 = p0 + 64;
       if (p0 >= 0) xw[p0] = m0;
@@ -1015,12 +1015,12 @@ __global__ __launch_bounds__(64) void hrtf8_kernel(const HrtfDesc d) {
             const uint64_t f = (uint64_t)qe * RQ;
             m0 = load_global(src + f + lane);
             m1 = load_global(src + f + 64 + lane);
-            if ((c & 7u) >= 2) {  // stereo input: mixed down (quantum.rs:387-397), doubled after the convolution
+            if ((c & 63u) >= 2) {  // stereo input: mixed down (quantum.rs:387-397), doubled after the convolution
               m0 = 0.5f * (m0 + load_global(src + d.in.ch_stride + f + lane));
               m1 = 0.5f * (m1 + load_global(src + d.in.ch_stride + f + 64 + lane));
             }
           }
-          if (e == 0) corr = (c & 7u) >= 2 ? 2.f : 1.f;  // (panner.rs:800-810: by the quantum's count, silent or not)
+          if (e == 0) corr = (c & 63u) >= 2 ? 2.f : 1.f;  // (panner.rs:800-810: by the quantum's count, silent or not)
         }
         const int p0 = O - e * RQ + lane, p1 = p0 + 64;
         if (p0 >= 0) xw[p0] = m0;

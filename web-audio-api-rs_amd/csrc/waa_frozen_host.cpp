@@ -157,7 +157,7 @@ static int plan_link(waa_batch* b, uint32_t id, int kind, int src_id, uint32_t t
           if (silent && can_propagate) {
             link = LINK_SKIP;
           } else {
-            const int nch = (int)(c & 7u);  // (the mixed count, also in silent quanta)
+            const int nch = (int)(c & 63u);  // (the mixed count, also in silent quanta)
             if (nch != cur_ch) {
               cur_ch = nch;
               last = LINK_FRESH;

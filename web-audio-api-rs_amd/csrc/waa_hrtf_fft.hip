@@ -110,7 +110,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1
   auto request = [&](int q, bool procn, uint32_t c) __attribute__((always_inline)) {
     const bool live = procn && !(c & CODE_SILENT);
     const float* p0 = live ? src + (uint64_t)q * RQ + t : safe + t;
-    const float* p1c = live && (c & 7u) >= 2 ? p0 + d.in.ch_stride : safe + t;
+    const float* p1c = live && (c & 63u) >= 2 ? p0 + d.in.ch_stride : safe + t;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       xn0[j] = load_global(p0 + 16 * j);
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1
     const ldsp tabq = tab + tofs;  // (loop-invariant LDS reads: the address is opaque so that they are not hoisted out of the loop)
     {
       // the quantum's mono mix (panner.rs:800-810; quantum.rs:387-397): a silent input is zeros, a stereo one 0.5 (L + R)
-      const bool live = proc && !(c & CODE_SILENT), st2 = (c & 7u) >= 2;
+      const bool live = proc && !(c & CODE_SILENT), st2 = (c & 63u) >= 2;
       float x[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1
     ph_out(L, proc, o);
     {
       // acc * gain * corr in hrtf8_kernel's order; corr = 2 behind a stereo input (by the quantum's count, silent or not)
-      const float corr = (c & 7u) >= 2 ? 2.f : 1.f;
+      const float corr = (c & 63u) >= 2 ? 2.f : 1.f;
       float* p0 = store ? dst + (uint64_t)q * RQ + t : d.trash + lane;
       float* p1c = store ? p0 + d.out.ch_stride : d.trash + lane;
 #pragma unroll

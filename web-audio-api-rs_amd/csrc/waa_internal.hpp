@@ -497,6 +497,8 @@ struct DynDesc {
   uint32_t split_ok, q_split;
 };
 void launch_dyn(const DynDesc& d, void* stream);
+// register planes of the kernel instantiation that renders signals of up to `cmax` channels (mono / stereo, 5.1, 7.1, 16, 32)
+inline int dyn_planes(int cmax) { return cmax > 16 ? 32 : cmax > 8 ? 16 : cmax > 6 ? 8 : cmax > 2 ? 6 : 2; }
 constexpr int DYN_MAX_STAGES = 8;
 size_t dyn_lds_bytes(int n_items, int cmax, int stages = 1);  // dynamic LDS of the launch (<= 160 KB: the planner checks)
 // ConvolverNode tail / routing on codes (convolver.rs:343-392): input codes -> output codes

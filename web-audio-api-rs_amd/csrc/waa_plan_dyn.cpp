@@ -37,10 +37,12 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     // (whose line is then re-mixed in place when the count changes) / analysers (whose kernel follows the per-quantum codes)
     // / the destination; convolver and frozen-node inputs are stereo by their channel config: those stay mono / stereo
     const uint32_t k = n.desc.kind;
-    if (n.live && (n.in_nch > 6 || n.out_nch > 6))
+    // (round 6) signals of 7 ... 32 channels in a dynamic plan: dyn_kernel<32> — the same count rules, every mix above six channels
+    // discrete; what stays out are the nodes rendered node-major on channel pairs
+    if (n.live && (n.in_nch > 6 || n.out_nch > 6) && is_frozen_node(n))
       return fail(WAA_ERR_OUT_OF_SCOPE,
-                  "node %u: the reference's channel count changes mid-render and a signal is wider than six channels (%d): exact dynamic "
-                  "counts are rendered up to 5.1 (signals of 7 ... 32 channels render where the counts are static)",
+                  "node %u: the reference's channel count changes mid-render and an oversampled WaveShaperNode / HRTF PannerNode sits on a signal "
+                  "wider than six channels (%d): out of scope",
                   id, std::max(n.in_nch, n.out_nch));
     const bool narrow_only = (k == WAA_NODE_CONVOLVER && n.has_ir) || (is_frozen_node(n) && k == WAA_NODE_PANNER);  // (an oversampled WaveShaper renders channel pairs, round 4)
     if (n.live && narrow_only && (n.in_nch > 2 || n.out_nch > 2))
@@ -308,7 +310,7 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     }
     if (cur_qgroup >= 0) {
       // a segment of a quantum-blocked loop: ranged launches that carry the items' state through memory; no quantum pipeline
-      const int cm = d.cmax > 2 ? 6 : 2;
+      const int cm = dyn_planes(d.cmax);
       int e2 = dev_alloc(b, &d.save_f, (size_t)b->n_inst * (size_t)d.n_items * cm * DYN_STATE);
       if (!e2) e2 = dev_alloc(b, &d.save_i, (size_t)b->n_inst * (size_t)d.n_items * 4);
       if (e2) return e2;
