@@ -37,13 +37,8 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
     // (whose line is then re-mixed in place when the count changes) / analysers (whose kernel follows the per-quantum codes)
     // / the destination; convolver and frozen-node inputs are stereo by their channel config: those stay mono / stereo
     const uint32_t k = n.desc.kind;
-    // (round 6) signals of 7 ... 32 channels in a dynamic plan: dyn_kernel<32> — the same count rules, every mix above six channels
-    // discrete; what stays out are the nodes rendered node-major on channel pairs
-    if (n.live && (n.in_nch > 6 || n.out_nch > 6) && is_frozen_node(n))
-      return fail(WAA_ERR_OUT_OF_SCOPE,
-                  "node %u: the reference's channel count changes mid-render and an oversampled WaveShaperNode / HRTF PannerNode sits on a signal "
-                  "wider than six channels (%d): out of scope",
-                  id, std::max(n.in_nch, n.out_nch));
+    // (round 6) signals of 7 ... 32 channels in a dynamic plan: dyn_kernel<8 / 16 / 32> — the same count rules, every mix above six
+    // channels discrete; an oversampled WaveShaper renders its channel pairs whatever their number (one launch per pair, one link table)
     const bool narrow_only = (k == WAA_NODE_CONVOLVER && n.has_ir) || (is_frozen_node(n) && k == WAA_NODE_PANNER);  // (an oversampled WaveShaper renders channel pairs, round 4)
     if (n.live && narrow_only && (n.in_nch > 2 || n.out_nch > 2))
       return fail(WAA_ERR_OUT_OF_SCOPE,
