@@ -403,3 +403,53 @@ def test_parity_lfo_fold(hip, orc, variant, monkeypatch):
     u, plan = _osc_lfo(hip, noise, variant)
     assert "is folded into the store" not in plan
     assert np.array_equal(g, u)
+
+
+def _feedback_gain_loop(be, noise, delay_s, variant, gain0=0.2, depth=0.3):
+    """src -> Delay -> Gain(g) -> back into the Delay, and g.gain is driven by the loop's own signal:
+    direct     Delay -> g.gain                       (the reader's output of this quantum)
+    depth      Delay -> Gain(depth) -> g.gain        (through a member of the loop)
+    two        Delay -> g.gain  and  Delay -> Gain(depth) -> g.gain   (two inputs, summed in edge order)"""
+    n = noise.shape[0]
+    c = waa.OfflineAudioContext(2, noise.shape[2], 48000.0, n_instances=n, binding=be)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    d = c.create_delay(1.0, delay_time=delay_s)
+    g = c.create_gain(gain=gain0)
+    for i in range(n):
+        g.gain.set_value(gain0 + 0.05 * i, instance=i)
+    src.connect(d)
+    d.connect(g).connect(d)
+    if variant in ("direct", "two"):
+        d.connect(g.gain)
+    if variant in ("depth", "two"):
+        dp = c.create_gain(gain=depth)
+        d.connect(dp)
+        dp.connect(g.gain)
+    g.connect(c.destination())
+    src.connect(c.destination())
+    src.start()
+    return c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["direct", "depth", "two"])
+@pytest.mark.parametrize("delay_s", [0.0, 0.004, 0.031])
+def test_parity_gain_modulated_from_inside_its_own_loop(hip, orc, delay_s, variant):
+    """round 6: an AudioParam driven by a member of the node's own feedback loop (legal: graph.rs:340-361 orders param edges like any
+    other, param.rs:762-795 sums them per quantum) was status 4 for quantum-serial loops.  A GainNode's gain is now rendered by the
+    dynamic-count kernel itself: the param's inputs are the loop members' outputs of the same quantum (channel 0: count 1, explicit,
+    discrete), plus the intrinsic value, clamped.  (Loops with block-long delays rendered it before: node-major param chains.)"""
+    noise = white_noise(3, 2, 60 * RQ) * 0.1  # (small: the loop gain follows the signal, |g| stays well below 1)
+    outs = []
+    for be in (hip, orc):
+        c = _feedback_gain_loop(be, noise, delay_s, variant)
+        if be is hip:
+            assert "GAIN" in c.plan_describe()
+        outs.append(c.start_rendering_sync().data)
+        c.close()
+    g, o = outs
+    assert np.isfinite(o).all() and np.abs(o).max() < 50.0
+    x = white_noise(3, 2, 60 * RQ) * 0.1
+    assert np.abs(o - x).max() > 0.01  # (the loop contributes)
+    assert rms_err(g, o).max() <= 1e-6 * max(1.0, float(np.abs(o).max()))

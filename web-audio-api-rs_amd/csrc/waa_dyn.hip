@@ -361,7 +361,26 @@ __device__ __forceinline__ void dyn_body(const DynDesc& d) {
               outn = 1;
               break;
             }
-            if (op.p0.mode == 2) {
+            const int pm = __builtin_amdgcn_readfirstlane(li.pmod_n);
+            if (pm > 0) {
+              // the gain param's inputs are members of this loop (round 6): their outputs of THIS quantum, out of the ring
+              float m[2] = {0.f, 0.f};
+              for (int j = 0; j < pm; j++) {
+                const int it2 = __builtin_amdgcn_readfirstlane(li.pmod_item[j]);
+                const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane(codes[it2]);
+                if (c2 & CODE_SILENT) continue;
+                const float* rs = cur + (size_t)it2 * CM * RQ;
+                m[0] = j == 0 ? rs[lane] : m[0] + rs[lane];
+                m[1] = j == 0 ? rs[64 + lane] : m[1] + rs[64 + lane];
+              }
+#pragma unroll
+              for (int e = 0; e < 2; e++) {
+                float g = m[e] + pval(op.p0, inst, q, f0 + e * 64 + lane);
+                g = g != g ? li.pmod_def : fminf(fmaxf(g, li.pmod_min), li.pmod_max);
+#pragma unroll
+                for (int c = 0; c < CM; c++) v[c][e] *= g;
+              }
+            } else if (op.p0.mode == 2) {
 #pragma unroll
               for (int e = 0; e < 2; e++) {
                 const float g = load_global(op.p0.base + (uint64_t)inst * op.p0.stride + f0 + e * 64 + lane);

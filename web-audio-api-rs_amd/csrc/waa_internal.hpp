@@ -471,6 +471,12 @@ struct DynItem {
   SignalRef xline;          // DI_DELAY_R
   const uint32_t* xaux32;   // DI_DELAY_R
   int32_t* xstate;          // DI_DELAY_R: read; DI_DELAY_W: written (null: nobody outside the launch looks)
+  // (round 6) DK_GAIN whose `gain` AudioParam is modulated from INSIDE the node's own feedback loop (param.rs:686-795): the param's
+  // inputs are items of this launch — their channel 0 of this quantum (count 1, explicit, discrete), summed in edge order, plus the
+  // intrinsic value op.p0, NaN -> default, clamped to [min, max]; pmod_n = 0: not modulated this way
+  int32_t pmod_n;
+  int32_t pmod_item[4];
+  float pmod_min, pmod_max, pmod_def;
 };
 struct DynDesc {
   const DynItem* items;     // device memory

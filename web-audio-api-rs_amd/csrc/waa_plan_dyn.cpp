@@ -199,6 +199,31 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
           if (e) return e;
         } else if ((kind == WAA_NODE_CONVOLVER && n.has_ir) || is_frozen_node(n)) {
           // (the mixed input of the node; its node-major steps follow the launch)
+        } else if (kind == WAA_NODE_GAIN && scc_of[id] >= 0 && !n.pin_edges.empty() && !n.pin_edges[0].empty() &&
+                   scc_of[b->edges[n.pin_edges[0][0]].from] == scc_of[id]) {
+          // (round 6) the gain param is modulated from inside the node's own loop: its inputs are items of this launch (same quantum,
+          // out of the ring) instead of a node-major param chain in front of the group
+          if (cur_qgroup >= 0) return fail(WAA_ERR_OUT_OF_SCOPE, "an AudioParam of node %u is modulated from inside its own feedback loop", id);
+          std::vector<int> saved = n.pin_edges[0];
+          if (saved.size() > 4) return fail(WAA_ERR_OUT_OF_SCOPE, "more than 4 inputs on the gain param of node %u inside a feedback loop", id);
+          for (size_t j = 0; j < saved.size(); j++) {
+            const uint32_t from = b->edges[saved[j]].from;
+            const uint32_t want = is_delay(b, from) ? (from | VTX_READER) : from;
+            int found = -1;
+            for (size_t k2 = 0; k2 < k; k2++)
+              if (pending[k2] == want) found = (int)k2;
+            if (found < 0 || scc_of[from] != scc_of[id])
+              return fail(WAA_ERR_OUT_OF_SCOPE, "an AudioParam of node %u is modulated from inside its own feedback loop (producer %u is not rendered in front of it)", id, from);
+            li.pmod_item[j] = found;
+          }
+          li.pmod_n = (int32_t)saved.size();
+          li.pmod_min = n.params[0].minv;
+          li.pmod_max = n.params[0].maxv;
+          li.pmod_def = n.params[0].defv;
+          n.pin_edges[0].clear();  // (the intrinsic value alone: constants / value blocks / automation)
+          e = emit_node_ops(b, id, n.in_nch, true, ops, &out_nch);
+          n.pin_edges[0] = saved;
+          if (e) return e;
         } else {
           if ((e = emit_node_ops(b, id, n.in_nch, true, ops, &out_nch))) return e;
         }
@@ -508,9 +533,15 @@ int plan_dynamic_groups(waa_batch* b, const DynPlanCtx& c) {
       for (auto& pe : b->nodes[v & ~VTX_READER].pin_edges)
         for (int e : pe) {
           const uint32_t from = b->edges[e].from;
-          if (unit.scc >= 0 && scc_of[from] == unit.scc)
-            return fail(WAA_ERR_OUT_OF_SCOPE, "an AudioParam of node %u is modulated from inside its own feedback loop",
-                        v & ~VTX_READER);
+          if (unit.scc >= 0 && scc_of[from] == unit.scc) {
+            // (round 6) a GainNode's gain from inside its own loop is rendered by the group itself (DynItem::pmod_*)
+            const Node& owner = b->nodes[v & ~VTX_READER];
+            const bool gain_param = owner.desc.kind == WAA_NODE_GAIN && &pe == &owner.pin_edges[0] && !frozen_loop;
+            if (!gain_param)
+              return fail(WAA_ERR_OUT_OF_SCOPE, "an AudioParam of node %u is modulated from inside its own feedback loop",
+                          v & ~VTX_READER);
+            continue;
+          }
           param_dep |= in_pending(from);
         }
     if (param_dep)
