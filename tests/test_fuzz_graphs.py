@@ -207,6 +207,18 @@ def build_random_graph(be, seed, frozen=False, tap=None):
         fb = c.create_gain(gain=float(rng.uniform(-0.5, 0.5)))
         tail.connect(fb).connect(d)
         descr.append("feedback")
+        # FUZZ_LOOP_PARAM=1 (campaign variant, round 6): the feedback gain is driven by the loop's own signal — an AudioParam modulated
+        # from inside its feedback loop (own generator: the graphs of a seed stay what they are without the switch)
+        if os.environ.get("FUZZ_LOOP_PARAM"):
+            lp_rng = np.random.default_rng(seed + 5000011)
+            if lp_rng.random() < 0.7:
+                # (through a limiter: a gain that follows the loop's signal without bound makes the loop quadratic — random graphs of that
+                # kind blow up to 1e37 within the render, on both back-ends at the same frame, and compare nothing)
+                lim = c.create_wave_shaper(curve=np.tanh(np.linspace(-3.0, 3.0, 65)).astype(np.float32))
+                depth = c.create_gain(gain=float(lp_rng.uniform(-0.1, 0.1)))
+                (d if lp_rng.random() < 0.5 else tail).connect(lim).connect(depth)
+                depth.connect(fb.gain)
+                descr.append("loop-param")
     # audio-rate modulation of a param from a source
     gains = [p for p in procs if isinstance(p, waa.GainNode)]
     if gains and rng.random() < 0.5:

@@ -127,7 +127,7 @@ def main():
     lib = os.path.join(ROOT, "web-audio-api-rs_amd", "csrc", "libwaa_hip.so")
     out = {"what": "random Web Audio graphs (tests/test_fuzz_graphs.py::build_random_graph), HIP library vs oracle, 3 contexts x "
                    "10440 frames each; equal = RMS <= 1e-6 and max |d| <= 2e-5 (relative to max(1, peak)) on every channel",
-           "variant": {k: os.environ[k] for k in ("FUZZ_FRAMES", "FUZZ_INST", "FUZZ_MIXED_COUNTS", "FUZZ_WIDE", "WAA_POISON_ALLOC", "WAA_ECHO_FF_MIN_INST") if k in os.environ},
+           "variant": {k: os.environ[k] for k in ("FUZZ_FRAMES", "FUZZ_INST", "FUZZ_MIXED_COUNTS", "FUZZ_WIDE", "FUZZ_LOOP_PARAM", "WAA_POISON_ALLOC", "WAA_ECHO_FF_MIN_INST") if k in os.environ},
            "generators": total, "wall_s": round(time.time() - t0, 1), "jobs": args.jobs,
            "libwaa_hip_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]}
     json.dump(out, open(args.out, "w"), indent=1)
