@@ -686,9 +686,24 @@ def test_parity_param_modulated_from_inside_a_block_scheduled_loop(hip, orc):
     assert rms_err(g, o).max() <= 1e-6 and np.abs(g - o).max() <= 2e-6
 
 
-def test_param_modulated_from_inside_a_short_loop_is_refused(hip):
+def test_param_modulated_from_inside_a_short_loop(hip):
+    """a GainNode's gain driven from inside its own quantum-serial loop is rendered by the dynamic-count kernel since round 6 (parity:
+    tests/test_param_modulation.py); a filter's or a DelayNode's param driven that way stays status 4"""
     noise = white_noise(2, 2, 2048 * 4)
     c = _self_modulated_loop(hip, noise, 0.01, device=waa.PLAN_ONLY)   # 480 frames: quantum-serial loop
+    plan = c.plan_describe()
+    assert "dyn_kernel" in plan and "GAIN" in plan
+    c.close()
+    c = waa.OfflineAudioContext(2, 2048 * 4, 48000.0, n_instances=2, binding=hip, device=waa.PLAN_ONLY)
+    src = c.create_buffer_source()
+    src.set_buffer_batch(noise, 48000.0)
+    d = c.create_delay(1.0, delay_time=0.01)
+    bq = c.create_biquad_filter(type_="lowpass", frequency=800.0)
+    src.connect(d)
+    d.connect(bq).connect(c.create_gain(gain=0.3)).connect(d)
+    d.connect(c.create_gain(gain=200.0)).connect(bq.frequency)
+    d.connect(c.destination())
+    src.start()
     with pytest.raises(waa.WaaError) as ei:
         c.plan_describe()
     assert ei.value.status == 4 and "modulated from inside its own feedback loop" in str(ei.value)
