@@ -453,3 +453,37 @@ def test_parity_gain_modulated_from_inside_its_own_loop(hip, orc, delay_s, varia
     x = white_noise(3, 2, 60 * RQ) * 0.1
     assert np.abs(o - x).max() > 0.01  # (the loop contributes)
     assert rms_err(g, o).max() <= 1e-6 * max(1.0, float(np.abs(o).max()))
+
+
+def test_a_modulated_gain_that_is_zero_while_its_modulator_is_silent_is_refused(hip):
+    """suspend fuzz seed 90491 (round 6).  While the audio-rate input of a GainNode's gain is silent the param is ONE value per quantum
+    (param.rs:737-760) and the node's fast paths apply: a gain of 0 emits the silent block — one channel —, the modulated kernels
+    multiply by a per-frame table of zeros and keep the static layout.  Not rendered differently: status 4 with the quantum"""
+    def build(zero_at, stop):
+        c = waa.OfflineAudioContext(2, 40 * RQ, 48000.0, n_instances=2, binding=hip, device=waa.PLAN_ONLY)
+        src = c.create_buffer_source()
+        src.set_buffer_batch(white_noise(2, 2, 40 * RQ), 48000.0)
+        src.start()
+        g = c.create_gain(gain=0.5)
+        vals = np.full(40, 0.5, np.float32)
+        if zero_at is not None:
+            vals[zero_at] = 0.0
+        g.gain.set_block(0, vals)
+        lfo = c.create_oscillator(type_="sine", frequency=7.0)
+        depth = c.create_gain(gain=0.2)
+        lfo.connect(depth)
+        depth.connect(g.gain)
+        lfo.start()
+        if stop is not None:
+            lfo.stop_at(stop * RQ / 48000.0)
+        src.connect(g).connect(c.create_stereo_panner(pan=0.3)).connect(c.destination())
+        return c
+    for zero_at, stop in ((None, 20), (30, None), (10, 20)):  # no zero / the modulator never stops / the zero falls while it still runs
+        c = build(zero_at, stop)
+        assert "PARAM_ADD" in c.plan_describe()
+        c.close()
+    c = build(30, 20)
+    with pytest.raises(waa.WaaError) as ei:
+        c.plan_describe()
+    assert ei.value.status == 4 and "gain is 0 in quantum 30" in str(ei.value)
+    c.close()

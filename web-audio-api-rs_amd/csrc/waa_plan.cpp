@@ -1524,6 +1524,26 @@ static int build_plan_rest(waa_batch* b, std::vector<uint32_t>& items, std::vect
             cnt[id][q] = a ? c : 1;
           }
         }
+      // A GainNode whose `gain` has an audio-rate input that is SILENT in some quantum: the param is then one value for that quantum
+      // (param.rs:737-760) and gain.rs:163-179's fast paths apply — a value of 0 emits the silent block (ONE channel), where the
+      // modulated form of the kernels multiplies by a per-frame table of zeros and keeps the static layout.  Only the zero matters (a
+      // value of 1 is the same samples either way); rendering it differently from the reference is not on offer: status 4 (suspend
+      // fuzz seed 90491, round 6: an LFO stopped at a suspend point in front of a k-rate gain that visits 0).
+      for (uint32_t id : b->order) {
+        const Node& n = b->nodes[id];
+        if (!n.live || n.desc.kind != WAA_NODE_GAIN || n.pin_edges.empty() || n.pin_edges[0].empty() || in_act[id].empty()) continue;
+        const auto gv = param_per_quantum(b, n.params[0], inst, nullptr);
+        for (uint32_t q = 0; q < nq; q++) {
+          if (!(std::fabs(gv[gv.size() == 1 ? 0 : q]) <= 1e-6f) || !in_act[id][q]) continue;
+          bool mod_active = false;
+          for (int e : n.pin_edges[0]) mod_active |= act[b->edges[e].from][q] != 0;
+          if (!mod_active)
+            return fail(WAA_ERR_OUT_OF_SCOPE,
+                        "gain node %u: its gain is 0 in quantum %u (instance %u) while the audio-rate input of the param is silent — the reference emits "
+                        "a silent (one-channel) quantum there (gain.rs:163-171), the modulated gain kernels do not: out of scope",
+                        id, q, inst);
+        }
+      }
       // findings
       for (uint32_t id : b->order) {
         Node& n = b->nodes[id];
