@@ -1074,6 +1074,35 @@ static int desugar_timed_edges(waa_batch* b) {
       pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
       const std::vector<waa_edge_desc> all = b->edges;
       std::vector<uint8_t> cut0, muted0;
+      // (... and on the ORDER in which the members of every loop are rendered: inside a loop the order decides who hears this quantum's
+      // and who last quantum's output of whom — suspend fuzz seed 122641 of the wide generator, round 6: cutting an oscillator's
+      // connection into a loop's second DelayNode left the breaker where it was and still moved that DelayNode's reader in front of
+      // the loop's first members, 1.0 of full scale)
+      std::vector<uint32_t> comp_size(n_comp, 0);
+      for (uint32_t v = 0; v < b->nodes.size(); v++) comp_size[comp[v]]++;
+      std::vector<uint32_t> loop_order0;
+      // (... and, where a signal can be wider than stereo, on the order in which every summing node hears its producers: the reference
+      // adds a producer's output to its consumers' input buses WHEN IT RENDERS (graph.rs:524-535), so the order of the sum is the render
+      // order, and above stereo the sum is not commutative — the bus is up-mixed input by input, mono -> stereo -> 5.1 is not
+      // mono -> 5.1 (DESIGN.md section 5 "Channels").  Same seed: the cut also moved the oscillator behind the loop in the order, and
+      // the analyser behind both heard it on the centre channel instead of L and R.)
+      int widest = (int)b->n_out;
+      for (const Node& nd : b->nodes) {
+        widest = std::max(widest, nd.cc);
+        for (const DeviceBuffer& bf : nd.bufs)
+          if (bf.valid) widest = std::max(widest, (int)bf.nch);
+      }
+      // (the plan renders the UNION of the connections, gated: its order is the reference for every epoch)
+      std::vector<int64_t> pos0(b->nodes.size(), -1);
+      {
+        std::vector<uint8_t> cutu, mutedu;
+        std::vector<uint32_t> itemsu;
+        compute_order(b, &cutu, &mutedu, &itemsu);
+        for (size_t k = 0; k < itemsu.size(); k++) {
+          const uint32_t v = itemsu[k], id = v & 0x7fffffffu;
+          if ((v & 0x80000000u) || b->nodes[id].desc.kind != WAA_NODE_DELAY) pos0[id] = (int64_t)k;
+        }
+      }
       int bad = 0;
       for (size_t e = 0; e < pts.size() && !bad; e++) {
         b->edges.clear();
@@ -1082,17 +1111,35 @@ static int desugar_timed_edges(waa_batch* b) {
         std::vector<uint8_t> cut, muted;
         std::vector<uint32_t> items;
         compute_order(b, &cut, &muted, &items);
+        std::vector<uint32_t> loop_order;
+        for (uint32_t v : items)
+          if (comp_size[comp[v & 0x7fffffffu]] > 1) loop_order.push_back(v);  // (bit 31: a DelayNode's reader vertex, waa_plan_parts.hpp)
+        std::vector<int64_t> pos(b->nodes.size(), -1);  // render position of every node's OUTPUT (a DelayNode: its reader's)
+        for (size_t k = 0; k < items.size(); k++) {
+          const uint32_t v = items[k], id = v & 0x7fffffffu;
+          if ((v & 0x80000000u) || b->nodes[id].desc.kind != WAA_NODE_DELAY) pos[id] = (int64_t)k;
+        }
         if (e == 0) {
           cut0 = cut;
           muted0 = muted;
-        } else if (cut != cut0 || muted != muted0) {
+          loop_order0 = loop_order;
+        } else if (cut != cut0 || muted != muted0 || loop_order != loop_order0) {
           bad = (int)pts[e];
+        }
+        if (!bad && widest > 2) {
+          for (size_t k1 = 0; k1 < b->edges.size() && !bad; k1++)
+            for (size_t k2 = k1 + 1; k2 < b->edges.size() && !bad; k2++) {
+              const waa_edge_desc &a = b->edges[k1], &c = b->edges[k2];
+              if (a.to != c.to || a.to_input != c.to_input || a.from == c.from) continue;
+              if (pos[a.from] < 0 || pos[c.from] < 0 || pos0[a.from] < 0 || pos0[c.from] < 0) continue;
+              if ((pos[a.from] < pos[c.from]) != (pos0[a.from] < pos0[c.from])) bad = (int)pts[e];
+            }
         }
       }
       b->edges = all;
       if (bad)
         return fail(WAA_ERR_OUT_OF_SCOPE, "the connections made or cut at the suspend point in front of quantum %d change where the reference breaks a "
-                                          "feedback loop (or which nodes it mutes): out of scope", bad);
+                                          "feedback loop, which nodes it mutes, the order in which it renders a loop's members or (with signals wider than stereo) the order in which a node sums its inputs: out of scope", bad);
     }
   }
   std::vector<waa_edge_desc> edges;
